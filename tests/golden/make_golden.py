@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REAL reference Python on CPU.
+
+Run in the build container (where /root/reference is mounted):  python tests/golden/make_golden.py
+The GPU box has no /root/reference; it only reads the committed fixtures.
+
+How the reference is imported without mmcv/mmdet (absent, no network): the reference files are
+loaded BY PATH (importlib) after registering inert stand-ins for the third-party names they
+import at module scope (mmcv.runner.BaseModule -> nn.Module, force_fp32 -> identity, registries
+-> pass-through decorators).  The arithmetic that produces the fixtures -- create_frustum,
+get_lidar_coor, voxel_pooling_prepare_v2 (view_transformer.py:389-411,458-498,547-605),
+get_reference_points / point_sampling (bevformer_encoder.py:52-120) and QuickCumsumCuda's
+wrapper logic (bev_pool.py:14-89) -- is the reference's own code, executed unmodified.
+The only non-reference arithmetic is the native kernel behind bev_pool_v2_ext (CUDA-only in
+the reference): it is served by the C oracle, so `bev_feat` fixtures pin the wrapper + index
+semantics, while the kernel itself is pinned by the known-answer fixture and by oracle/_ref.
+"""
+import importlib.util
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+REF = os.environ.get('FBBEV_REFERENCE', '/root/reference')
+sys.path.insert(0, REPO)
+OUT = os.path.join(REPO, 'tests', 'golden')
+
+
+def _mod(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def _identity_decorator(*a, **k):
+    if len(a) == 1 and callable(a[0]) and not k:
+        return a[0]
+    return lambda f: f
+
+
+class _Registry:
+    def register_module(self, *a, **k):
+        return _identity_decorator(*a, **k)
+
+
+def install_stubs():
+    from oracle import oracle as O
+
+    _mod('mmcv')
+    _mod('mmcv.cnn', build_conv_layer=None, xavier_init=None, constant_init=None)
+    _mod('mmcv.cnn.bricks')
+    _mod('mmcv.cnn.bricks.registry', ATTENTION=_Registry(), TRANSFORMER_LAYER=_Registry(),
+         TRANSFORMER_LAYER_SEQUENCE=_Registry())
+
+    class TransformerLayerSequence(nn.Module):
+        def __init__(self, *a, **k):
+            super().__init__()
+    _mod('mmcv.cnn.bricks.transformer', TransformerLayerSequence=TransformerLayerSequence,
+         build_attention=None)
+    _mod('mmcv.runner', BaseModule=nn.Module, force_fp32=_identity_decorator,
+         auto_fp16=_identity_decorator)
+    _mod('mmcv.utils', TORCH_VERSION=torch.__version__, digit_version=lambda v: v,
+         ext_loader=types.SimpleNamespace(load_ext=lambda *a, **k: None))
+    _mod('cv2')
+    _mod('mmdet'); _mod('mmdet.models'); _mod('mmdet.models.backbones')
+    _mod('mmdet.models.backbones.resnet', BasicBlock=None)
+    _mod('mmdet3d'); _mod('mmdet3d.models'); _mod('mmdet3d.models.builder', NECKS=_Registry())
+    _mod('mmdet3d.models.fbbev'); _mod('mmdet3d.models.fbbev.custom_ops')
+    _mod('mmdet3d.models.fbbev.custom_ops.bev_pool_v2', bev_pool_v2=None)
+    _mod('mmdet3d.ops')
+
+    # native ext stand-in: same signature as bev_pool.cpp:28-37,72-83, computed by the C oracle
+    def fwd(depth, feat, out, rd, rf, rb, lengths, starts):
+        out.copy_(O.bev_pool_v2_fwd(depth, feat, rd, rf, rb, out.shape, starts, lengths))
+
+    def bwd(out_grad, depth_grad, feat_grad, depth, feat, rd, rf, rb, lengths, starts):
+        c = out_grad.shape[-1]
+        O.lib().oracle_bev_pool_v2_bwd(c, starts.numel(), O._p(out_grad), O._p(depth), O._p(feat),
+                                       O._p(rd), O._p(rf), O._p(rb), O._p(starts), O._p(lengths),
+                                       O._p(depth_grad), O._p(feat_grad), 1)
+    pkg = _mod('mmdet3d.ops.bev_pool_v2')
+    pkg.__path__ = [os.path.join(REF, 'mmdet3d/ops/bev_pool_v2')]
+    pkg.bev_pool_v2_ext = _mod('mmdet3d.ops.bev_pool_v2.bev_pool_v2_ext',
+                               bev_pool_v2_forward=fwd, bev_pool_v2_backward=bwd)
+
+
+def load_ref(modname, relpath):
+    spec = importlib.util.spec_from_file_location(modname, os.path.join(REF, relpath))
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[modname] = m
+    spec.loader.exec_module(m)
+    return m
+
+
+def main():
+    from fb_bev_amd import synthetic as S
+    install_stubs()
+    bp = load_ref('mmdet3d.ops.bev_pool_v2.bev_pool', 'mmdet3d/ops/bev_pool_v2/bev_pool.py')
+    vt = load_ref('ref_view_transformer',
+                  'mmdet3d/models/fbbev/view_transformation/forward_projection/view_transformer.py')
+    _mod('refbp').__path__ = []
+    _mod('refbp.custom_base_transformer_layer', MyCustomBaseTransformerLayer=nn.Module)
+    enc = load_ref('refbp.bevformer_encoder',
+                   'mmdet3d/models/fbbev/view_transformation/backward_projection/bevformer_utils/'
+                   'bevformer_encoder.py')
+
+    meta = {}
+    # ---- full index tensors for small configs, stats + digests for the big ones
+    cases = [('TINY', 2, True), ('SMALL', 2, True), ('REF', 1, False), ('BL1', 1, False),
+             ('BL2', 1, False), ('BL2', 2, True), ('BL5', 1, False)]
+    for name, B, aug in cases:
+        cfg = S.CONFIGS[name]
+        mod = vt.LSSViewTransformerFunction3D(cfg.grid_config, cfg.input_size, cfg.downsample)
+        cam = S.camera_rig(cfg, B, seed=0, bda_aug=aug)
+        coor = mod.get_lidar_coor(*cam)
+        rb, rd, rf, st, ln = mod.voxel_pooling_prepare_v2(coor)
+        # canonical (stable) order inside each voxel -- the reference argsort is unstable
+        key = rb.long() * (int(rd.max()) + 1) + rd.long()
+        order = torch.argsort(key, stable=True)
+        rbc, rdc, rfc = rb[order], rd[order], rf[order]
+        tag = f'{name}_B{B}' + ('_aug' if aug else '')
+        entry = dict(config=name, B=B, bda_aug=aug, P=int(rb.numel()), I=int(st.numel()),
+                     len_max=int(ln.max()), len_mean=float(ln.float().mean()),
+                     sum_ranks_bev=int(rbc.long().sum()), sum_ranks_depth=int(rdc.long().sum()),
+                     sum_ranks_feat=int(rfc.long().sum()), sum_starts=int(st.long().sum()),
+                     wsum=int((rbc.long() * (torch.arange(rbc.numel()) % 9973 + 1)).sum()),
+                     wsum_depth=int((rdc.long() * (torch.arange(rdc.numel()) % 9973 + 1)).sum()),
+                     coor_sum=float(coor.double().sum()))
+        if name in ('TINY', 'SMALL'):
+            depth, ctx = S.depth_and_context(cfg, B, seed=0)
+            bev = mod.view_transform(cam, depth, ctx)  # reference wrapper + oracle kernel
+            np.savez_compressed(os.path.join(OUT, f'index_{tag}.npz'),
+                                coor=coor.numpy(), ranks_bev=rbc.numpy(), ranks_depth=rdc.numpy(),
+                                ranks_feat=rfc.numpy(), interval_starts=st.numpy(),
+                                interval_lengths=ln.numpy(),
+                                bev_feat=bev.contiguous().numpy())
+        meta[tag] = entry
+        print(tag, entry['P'], entry['I'], entry['len_max'])
+
+    # ---- backward-projection geometry (bevformer_encoder.py:52-120) on the shipped grid
+    gcb = {'x': [-40, 40, 0.8], 'y': [-40, 40, 0.8], 'z': [-1, 5.4, 1.6]}  # cfg :87-91
+    e = enc.bevformer_encoder.__new__(enc.bevformer_encoder)
+    nn.Module.__init__(e)
+    e.x_bound, e.y_bound, e.z_bound = gcb['x'], gcb['y'], gcb['z']
+    e.final_dim = (256, 704)
+    cfg = S.CONFIGS['REF']
+    cam = S.camera_rig(cfg, 2, seed=0, bda_aug=True)
+    ref3d = e.get_reference_points(100, 100, 6.4, dim='3d', bs=2, device='cpu', dtype=torch.float)
+    _, ref_cam, mask, qdepth = e.point_sampling(ref3d, None, None, cam_params=cam)
+    sub = slice(0, 10000, 37)  # keep the fixture small: every 37th BEV query
+    np.savez_compressed(os.path.join(OUT, 'point_sampling_REF_B2_aug.npz'),
+                        ref3d_corner=ref3d[:2, :2].numpy(), ref_cam=ref_cam[:, :, sub].numpy(),
+                        mask=mask[:, :, sub].numpy(), qdepth=qdepth[:, :, sub].numpy(),
+                        mask_count=np.int64(mask.sum().item()),
+                        ref_cam_sum=np.float64(ref_cam.double().sum().item()))
+    meta['point_sampling_REF_B2_aug'] = dict(mask_count=int(mask.sum()),
+                                             per_cam_hits=[int(m.any(-1).sum()) for m in mask])
+
+    # ---- the reference's own known-answer test (bev_pool.py:144-175), numbers restated verbatim
+    known = dict(depth=[0.3, 0.4, 0.2, 0.1, 0.7, 0.6, 0.8, 0.9], depth_shape=[1, 1, 2, 2, 2],
+                 feat_ones_shape=[1, 1, 2, 2, 2], ranks_depth=[0, 4, 1, 6], ranks_feat=[0, 0, 1, 2],
+                 ranks_bev=[0, 0, 1, 1], bev_feat_shape=[1, 1, 2, 2, 2], loss=4.4,
+                 grad_depth=[2., 2., 0., 0., 2., 0., 2., 0.],
+                 grad_feat=[1.0, 1.0, 0.4, 0.4, 0.8, 0.8, 0., 0.])
+    # run it through the reference's autograd wrapper on CPU (kernel = oracle) as a self-check
+    depth = torch.tensor(known['depth']).view(1, 1, 2, 2, 2).requires_grad_()
+    feat = torch.ones(1, 1, 2, 2, 2, requires_grad=True)
+    rd = torch.tensor(known['ranks_depth']).int(); rf = torch.tensor(known['ranks_feat']).int()
+    rb = torch.tensor(known['ranks_bev']).int()
+    st = torch.tensor([0, 2]).int(); ln = torch.tensor([2, 2]).int()
+    out = bp.bev_pool_v2(depth, feat, rd, rf, rb, (1, 1, 2, 2, 2), st, ln)
+    out.sum().backward()
+    assert abs(out.sum().item() - 4.4) < 1e-6
+    assert torch.allclose(depth.grad.view(-1), torch.tensor(known['grad_depth']))
+    assert torch.allclose(feat.grad.view(-1), torch.tensor(known['grad_feat']))
+    with open(os.path.join(OUT, 'bev_pool_v2_known_answer.json'), 'w') as f:
+        json.dump(known, f, indent=1)
+    with open(os.path.join(OUT, 'index_stats.json'), 'w') as f:
+        json.dump(meta, f, indent=1)
+    print('golden fixtures written to', OUT)
+
+
+if __name__ == '__main__':
+    main()
