@@ -1,0 +1,169 @@
+"""ctypes binding of libfbbev_hip.so (include/fbbev.h).
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; the kernels are reached only
+through the C ABI with raw pointers.  There is NO CPU fallback: if the library is missing or a
+tensor is not on a GPU the call raises.
+"""
+import ctypes
+import os
+from ctypes import c_int, c_int32, c_int64, c_size_t, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libfbbev_hip.so')
+
+# name -> (restype, argtypes); mirrors include/fbbev.h one to one
+SIGNATURES = {
+    'fbbev_version': (c_int, []),
+    'fbbev_bev_pool_v2_fwd': (c_int, [c_int, c_int] + [c_void_p] * 8 + [c_void_p]),
+    'fbbev_bev_pool_v2_bwd': (c_int, [c_int, c_int] + [c_void_p] * 10 + [c_void_p]),
+    'fbbev_rank_workspace_bytes': (c_size_t, [c_int64]),
+    'fbbev_rank_build': (c_int, [c_void_p] + [c_int] * 5 + [c_void_p] * 3 + [c_void_p] * 7 +
+                         [c_void_p, c_size_t, c_void_p]),
+    'fbbev_pool_dense_workspace_bytes': (c_size_t, [c_int] * 4),
+    'fbbev_bev_pool_v2_dense_fwd': (c_int, [c_void_p] * 8 + [c_int] * 6 + [c_void_p, c_void_p, c_size_t,
+                                            c_int, c_void_p]),
+    'fbbev_msda_fwd': (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_void_p, c_void_p]),
+    'fbbev_msda_bwd': (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p] * 3 + [c_void_p]),
+}
+
+_lib = None
+
+
+class FbbevError(RuntimeError):
+    pass
+
+
+def declare(cdll):
+    """Attach restype/argtypes for every symbol of the ABI (raises if one is missing)."""
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(cdll, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    return cdll
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FbbevError(
+                f'{LIB_PATH} not found: build it with `python -m fb_bev_amd.build` '
+                '(hipcc --offload-arch=gfx950). There is no CPU fallback.')
+        _lib = declare(ctypes.CDLL(LIB_PATH))
+    return _lib
+
+
+def _check(code, what):
+    if code != 0:
+        kind = 'invalid argument' if code < 0 else 'hipError_t'
+        raise FbbevError(f'{what} failed: {kind} {code}')
+
+
+def _dev(t, dtype, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise FbbevError(f'{name} must be a GPU tensor (no CPU fallback in fb_bev_amd)')
+    if t.dtype != dtype:
+        raise FbbevError(f'{name} must be {dtype}, got {t.dtype}')
+    if not t.is_contiguous():
+        raise FbbevError(f'{name} must be contiguous')
+    return c_void_p(t.data_ptr())
+
+
+def _stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+F32, I32, I64 = torch.float32, torch.int32, torch.int64
+
+
+def bev_pool_v2_fwd(depth, feat, out, ranks_depth, ranks_feat, ranks_bev, interval_starts,
+                    interval_lengths):
+    c = feat.shape[-1]
+    n = interval_starts.numel()
+    with torch.cuda.device(depth.device):
+        _check(lib().fbbev_bev_pool_v2_fwd(
+            c, n, _dev(depth, F32, 'depth'), _dev(feat, F32, 'feat'),
+            _dev(ranks_depth, I32, 'ranks_depth'), _dev(ranks_feat, I32, 'ranks_feat'),
+            _dev(ranks_bev, I32, 'ranks_bev'), _dev(interval_starts, I32, 'interval_starts'),
+            _dev(interval_lengths, I32, 'interval_lengths'), _dev(out, F32, 'out'), _stream()),
+            'fbbev_bev_pool_v2_fwd')
+
+
+def bev_pool_v2_bwd(out_grad, depth_grad, feat_grad, depth, feat, ranks_depth, ranks_feat,
+                    ranks_bev, interval_starts, interval_lengths):
+    c = out_grad.shape[-1]
+    n = interval_starts.numel()
+    with torch.cuda.device(out_grad.device):
+        _check(lib().fbbev_bev_pool_v2_bwd(
+            c, n, _dev(out_grad, F32, 'out_grad'), _dev(depth, F32, 'depth'), _dev(feat, F32, 'feat'),
+            _dev(ranks_depth, I32, 'ranks_depth'), _dev(ranks_feat, I32, 'ranks_feat'),
+            _dev(ranks_bev, I32, 'ranks_bev'), _dev(interval_starts, I32, 'interval_starts'),
+            _dev(interval_lengths, I32, 'interval_lengths'), _dev(depth_grad, F32, 'depth_grad'),
+            _dev(feat_grad, F32, 'feat_grad'), _stream()), 'fbbev_bev_pool_v2_bwd')
+
+
+def rank_workspace_bytes(n_points):
+    return int(lib().fbbev_rank_workspace_bytes(int(n_points)))
+
+
+def rank_build(coor, lower3, interval3, grid_size3, ranks_bev, ranks_depth, ranks_feat,
+               interval_starts, interval_lengths, interval_rank, counts, workspace):
+    """coor (B,N,D,H,W,3) f32 GPU; lower3/interval3/grid_size3: 3 python floats each (fp32 values)."""
+    B, N, D, H, W, three = coor.shape
+    assert three == 3
+    arr = ctypes.c_float * 3
+    lo, it, gs = arr(*lower3), arr(*interval3), arr(*grid_size3)
+    with torch.cuda.device(coor.device):
+        _check(lib().fbbev_rank_build(
+            _dev(coor, F32, 'coor'), B, N, D, H, W, ctypes.cast(lo, c_void_p), ctypes.cast(it, c_void_p),
+            ctypes.cast(gs, c_void_p), _dev(ranks_bev, I32, 'ranks_bev'),
+            _dev(ranks_depth, I32, 'ranks_depth'), _dev(ranks_feat, I32, 'ranks_feat'),
+            _dev(interval_starts, I32, 'interval_starts'), _dev(interval_lengths, I32, 'interval_lengths'),
+            _dev(interval_rank, I32, 'interval_rank') if interval_rank is not None else c_void_p(0),
+            _dev(counts, I32, 'counts'), c_void_p(workspace.data_ptr()),
+            workspace.numel() * workspace.element_size(), _stream()), 'fbbev_rank_build')
+
+
+def pool_dense_workspace_bytes(B, Z, Y, X):
+    return int(lib().fbbev_pool_dense_workspace_bytes(B, Z, Y, X))
+
+
+def bev_pool_v2_dense_fwd(depth, feat, ranks_depth, ranks_feat, ranks_bev, interval_starts,
+                          interval_lengths, n_intervals_dev, n_intervals_max, B, C, Z, Y, X, out,
+                          tile_ws, tile_voxels=128):
+    with torch.cuda.device(depth.device):
+        _check(lib().fbbev_bev_pool_v2_dense_fwd(
+            _dev(depth, F32, 'depth'), _dev(feat, F32, 'feat'), _dev(ranks_depth, I32, 'ranks_depth'),
+            _dev(ranks_feat, I32, 'ranks_feat'), _dev(ranks_bev, I32, 'ranks_bev'),
+            _dev(interval_starts, I32, 'interval_starts'), _dev(interval_lengths, I32, 'interval_lengths'),
+            _dev(n_intervals_dev, I32, 'n_intervals_dev'), int(n_intervals_max), B, C, Z, Y, X,
+            _dev(out, F32, 'out'), c_void_p(tile_ws.data_ptr()),
+            tile_ws.numel() * tile_ws.element_size(), int(tile_voxels), _stream()),
+            'fbbev_bev_pool_v2_dense_fwd')
+
+
+def msda_fwd(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, out):
+    B, S, M, Dh = value.shape
+    _, Q, _, L, P, _ = sampling_loc.shape
+    with torch.cuda.device(value.device):
+        _check(lib().fbbev_msda_fwd(
+            _dev(value, F32, 'value'), _dev(spatial_shapes, I64, 'spatial_shapes'),
+            _dev(level_start_index, I64, 'level_start_index'), _dev(sampling_loc, F32, 'sampling_loc'),
+            _dev(attn_weight, F32, 'attn_weight'), B, S, M, Dh, L, Q, P, _dev(out, F32, 'out'),
+            _stream()), 'fbbev_msda_fwd')
+
+
+def msda_bwd(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output,
+             grad_value, grad_sampling_loc, grad_attn_weight):
+    B, S, M, Dh = value.shape
+    _, Q, _, L, P, _ = sampling_loc.shape
+    with torch.cuda.device(value.device):
+        _check(lib().fbbev_msda_bwd(
+            _dev(value, F32, 'value'), _dev(spatial_shapes, I64, 'spatial_shapes'),
+            _dev(level_start_index, I64, 'level_start_index'), _dev(sampling_loc, F32, 'sampling_loc'),
+            _dev(attn_weight, F32, 'attn_weight'), _dev(grad_output, F32, 'grad_output'),
+            B, S, M, Dh, L, Q, P, _dev(grad_value, F32, 'grad_value'),
+            _dev(grad_sampling_loc, F32, 'grad_sampling_loc'),
+            _dev(grad_attn_weight, F32, 'grad_attn_weight'), _stream()), 'fbbev_msda_bwd')

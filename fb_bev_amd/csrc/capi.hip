@@ -1,0 +1,261 @@
+// capi.hip -- extern "C" entry points of libfbbev_hip.so (include/fbbev.h): argument checks,
+// launch geometry, workspace carving.  No torch, no host synchronisation, caller's stream.
+#include "rt.h"
+#include "pool_kernels.h"
+#include "rank_kernels.h"
+#include "msda_kernels.h"
+#include "../../include/fbbev.h"
+
+#define FBBEV_CHECK_LAUNCH()                      \
+    do {                                          \
+        int e_ = fbbev_rt_last_error();           \
+        if (e_ != 0) return e_;                   \
+    } while (0)
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+extern "C" int fbbev_version(void) { return 100; }
+
+// ------------------------------------------------------------------------------ bev_pool_v2 fwd
+extern "C" int fbbev_bev_pool_v2_fwd(int c, int n_intervals, const float* depth, const float* feat,
+                                     const int32_t* ranks_depth, const int32_t* ranks_feat,
+                                     const int32_t* ranks_bev, const int32_t* interval_starts,
+                                     const int32_t* interval_lengths, float* out,
+                                     fbbev_stream_t stream_) {
+    if (c <= 0 || n_intervals < 0) return FBBEV_E_BADARG;
+    if (n_intervals == 0) return 0;
+    if (!depth || !feat || !ranks_depth || !ranks_feat || !ranks_bev || !interval_starts ||
+        !interval_lengths || !out) return FBBEV_E_BADARG;
+    fbbev_rt_stream stream = (fbbev_rt_stream)stream_;
+    if (c % 4 == 0 && aligned16(feat) && aligned16(out)) {
+        const long long threads = (long long)n_intervals * (c / 4);
+        FBBEV_LAUNCH(k_pool_fwd_rows<4>, (threads + 255) / 256, 256, 0, stream, c, n_intervals, depth,
+                     feat, ranks_depth, ranks_feat, ranks_bev, interval_starts, interval_lengths, out);
+    } else {
+        const long long threads = (long long)n_intervals * c;
+        FBBEV_LAUNCH(k_pool_fwd_rows<1>, (threads + 255) / 256, 256, 0, stream, c, n_intervals, depth,
+                     feat, ranks_depth, ranks_feat, ranks_bev, interval_starts, interval_lengths, out);
+    }
+    FBBEV_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------ bev_pool_v2 bwd
+extern "C" int fbbev_bev_pool_v2_bwd(int c, int n_intervals, const float* out_grad,
+                                     const float* depth, const float* feat,
+                                     const int32_t* ranks_depth, const int32_t* ranks_feat,
+                                     const int32_t* ranks_bev, const int32_t* interval_starts,
+                                     const int32_t* interval_lengths, float* depth_grad,
+                                     float* feat_grad, fbbev_stream_t stream_) {
+    if (c <= 0 || n_intervals < 0) return FBBEV_E_BADARG;
+    if (c > 256) return FBBEV_E_UNSUPPORTED;
+    if (n_intervals == 0) return 0;
+    if (!out_grad || !depth || !feat || !ranks_depth || !ranks_feat || !ranks_bev ||
+        !interval_starts || !interval_lengths || !depth_grad || !feat_grad) return FBBEV_E_BADARG;
+    fbbev_rt_stream stream = (fbbev_rt_stream)stream_;
+    const long long blocks = ((long long)n_intervals * 64 + 255) / 256;  // one wave64 per interval
+    const int nch = (c + 63) / 64;
+#define FBBEV_BWD(NCH)                                                                             \
+    FBBEV_LAUNCH(k_pool_bwd<NCH>, blocks, 256, 0, stream, c, n_intervals, out_grad, depth, feat,   \
+                 ranks_depth, ranks_feat, ranks_bev, interval_starts, interval_lengths, depth_grad, \
+                 feat_grad)
+    switch (nch) {
+        case 1: FBBEV_BWD(1); break;
+        case 2: FBBEV_BWD(2); break;
+        case 3: FBBEV_BWD(3); break;
+        default: FBBEV_BWD(4); break;
+    }
+#undef FBBEV_BWD
+    FBBEV_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------ voxel ranking
+static inline int key_bits(long long total_voxels) {
+    int bits = 1;
+    while ((1ll << bits) <= total_voxels) ++bits;  // total_voxels < 2^bits
+    return bits;
+}
+
+struct rank_ws_layout {
+    size_t keys_in, vals_in, block_counts, sort_temp, total;
+    size_t sort_temp_bytes;
+    int n_blocks;
+};
+
+static rank_ws_layout rank_layout(long long n) {
+    rank_ws_layout L;
+    L.n_blocks = (int)((n + FBBEV_RANK_CHUNK - 1) / FBBEV_RANK_CHUNK);
+    size_t off = 0;
+    L.keys_in = off; off = align_up(off + (size_t)n * 4, 256);
+    L.vals_in = off; off = align_up(off + (size_t)n * 4, 256);
+    L.block_counts = off; off = align_up(off + (size_t)(L.n_blocks + 1) * 4, 256);
+    L.sort_temp_bytes = fbbev_rt_sort_pairs_temp_bytes((size_t)n, 32);
+    L.sort_temp = off; off = align_up(off + L.sort_temp_bytes, 256);
+    L.total = off;
+    return L;
+}
+
+extern "C" size_t fbbev_rank_workspace_bytes(int64_t n_points) {
+    if (n_points <= 0) return 256;
+    return rank_layout(n_points).total;
+}
+
+extern "C" int fbbev_rank_build(const float* coor, int B, int N, int D, int H, int W,
+                                const float* lower3, const float* interval3,
+                                const float* grid_size3, int32_t* ranks_bev, int32_t* ranks_depth,
+                                int32_t* ranks_feat, int32_t* interval_starts,
+                                int32_t* interval_lengths, int32_t* interval_rank, int32_t* counts,
+                                void* workspace, size_t workspace_bytes, fbbev_stream_t stream_) {
+    if (B <= 0 || N <= 0 || D <= 0 || H <= 0 || W <= 0) return FBBEV_E_BADARG;
+    if (!coor || !lower3 || !interval3 || !grid_size3 || !ranks_bev || !ranks_depth || !ranks_feat ||
+        !interval_starts || !interval_lengths || !counts || !workspace) return FBBEV_E_BADARG;
+    const long long n = (long long)B * N * D * H * W;
+    if (n >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
+    fbbev_rt_stream stream = (fbbev_rt_stream)stream_;
+    const rank_ws_layout L = rank_layout(n);
+    if (workspace_bytes < L.total) return FBBEV_E_WORKSPACE;
+    unsigned char* ws = static_cast<unsigned char*>(workspace);
+    unsigned int* keys_in = reinterpret_cast<unsigned int*>(ws + L.keys_in);
+    unsigned int* vals_in = reinterpret_cast<unsigned int*>(ws + L.vals_in);
+    int* block_counts = reinterpret_cast<int*>(ws + L.block_counts);
+
+    fbbev_grid_params gp;
+    gp.lx = lower3[0]; gp.ly = lower3[1]; gp.lz = lower3[2];
+    gp.ix = interval3[0]; gp.iy = interval3[1]; gp.iz = interval3[2];
+    gp.gx = grid_size3[0]; gp.gy = grid_size3[1]; gp.gz = grid_size3[2];
+    // the 0-dim fp32 products of view_transformer.py:586-588, rounded step by step like torch
+    volatile float zy = gp.gz * gp.gy;
+    volatile float zyx = zy * gp.gx;
+    volatile float yx = gp.gy * gp.gx;
+    gp.f_zyx = zyx; gp.f_yx = yx;
+    const long long total_voxels = (long long)B * (long long)gp.gz * (long long)gp.gy * (long long)gp.gx;
+    if (total_voxels <= 0 || total_voxels >= (1ll << 30)) return FBBEV_E_UNSUPPORTED;
+    const int bits = key_bits(total_voxels) + 1;               // room for the sentinel above every rank
+    const unsigned int sentinel = (1u << bits) - 1u;
+
+    int e = fbbev_rt_memset_async(counts, 0, 2 * sizeof(int32_t), stream);
+    if (e) return e;
+    long long kb = (n + 255) / 256;
+    if (kb > 8192) kb = 8192;
+    FBBEV_LAUNCH(k_rank_keys, kb, 256, 0, stream, coor, n, n / B, gp, sentinel, keys_in, vals_in);
+    FBBEV_CHECK_LAUNCH();
+    e = fbbev_rt_sort_pairs(ws + L.sort_temp, L.sort_temp_bytes, keys_in,
+                            reinterpret_cast<unsigned int*>(ranks_bev), vals_in,
+                            reinterpret_cast<unsigned int*>(ranks_depth), (size_t)n, bits, stream);
+    if (e) return e;
+    const unsigned int* keys = reinterpret_cast<const unsigned int*>(ranks_bev);
+    const unsigned int* vals = reinterpret_cast<const unsigned int*>(ranks_depth);
+    FBBEV_LAUNCH(k_flag_count, L.n_blocks, FBBEV_RANK_BLOCK, 0, stream, keys, n, sentinel, block_counts, counts);
+    FBBEV_CHECK_LAUNCH();
+    FBBEV_LAUNCH(k_scan_blocks, 1, FBBEV_RANK_BLOCK, 0, stream, block_counts, L.n_blocks, counts);
+    FBBEV_CHECK_LAUNCH();
+    FBBEV_LAUNCH(k_write_intervals, L.n_blocks, FBBEV_RANK_BLOCK, 0, stream, keys, vals, n, sentinel,
+                 (const int*)block_counts, D, H * W, ranks_feat, interval_starts, interval_rank);
+    FBBEV_CHECK_LAUNCH();
+    long long lb = (n + 255) / 256;
+    if (lb > 4096) lb = 4096;
+    FBBEV_LAUNCH(k_interval_lengths, lb, 256, 0, stream, (const int*)interval_starts, (const int*)counts, n,
+                 interval_lengths);
+    FBBEV_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------ fused dense fwd
+static inline int pick_tile(int tile_voxels) {
+    return (tile_voxels == 64 || tile_voxels == 128 || tile_voxels == 256) ? tile_voxels : 128;
+}
+
+extern "C" size_t fbbev_pool_dense_workspace_bytes(int B, int Z, int Y, int X) {
+    if (B <= 0 || Z <= 0 || Y <= 0 || X <= 0) return 256;
+    const long long yx = (long long)Y * X;
+    const long long tiles = (long long)B * Z * ((yx + 63) / 64);  // smallest tile = most tiles
+    return align_up((size_t)(tiles + 2) * 4, 256);
+}
+
+extern "C" int fbbev_bev_pool_v2_dense_fwd(const float* depth, const float* feat,
+                                           const int32_t* ranks_depth, const int32_t* ranks_feat,
+                                           const int32_t* ranks_bev, const int32_t* interval_starts,
+                                           const int32_t* interval_lengths,
+                                           const int32_t* n_intervals_dev, int n_intervals_max, int B,
+                                           int C, int Z, int Y, int X, float* out, void* tile_ws,
+                                           size_t tile_ws_bytes, int tile_voxels,
+                                           fbbev_stream_t stream_) {
+    if (B <= 0 || C <= 0 || Z <= 0 || Y <= 0 || X <= 0 || n_intervals_max < 0) return FBBEV_E_BADARG;
+    if (!depth || !feat || !ranks_depth || !ranks_feat || !ranks_bev || !interval_starts ||
+        !interval_lengths || !n_intervals_dev || !out || !tile_ws) return FBBEV_E_BADARG;
+    const long long yx = (long long)Y * X;
+    if (C % 4 != 0 || C > 256 || yx % 4 != 0 || !aligned16(out) || !aligned16(feat)) return FBBEV_E_UNSUPPORTED;
+    if ((long long)B * Z * yx >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
+    fbbev_rt_stream stream = (fbbev_rt_stream)stream_;
+    const int TV = pick_tile(tile_voxels);
+    const int tiles_per_plane = (int)((yx + TV - 1) / TV);
+    const long long n_tiles = (long long)B * Z * tiles_per_plane;
+    if (tile_ws_bytes < (size_t)(n_tiles + 1) * 4) return FBBEV_E_WORKSPACE;
+    int* tile_istart = static_cast<int*>(tile_ws);
+    FBBEV_LAUNCH(k_tile_lower_bound, (n_tiles + 1 + 255) / 256, 256, 0, stream, (int)n_tiles,
+                 tiles_per_plane, (int)yx, TV, ranks_bev, interval_starts, n_intervals_dev,
+                 n_intervals_max, tile_istart);
+    FBBEV_CHECK_LAUNCH();
+    const size_t lds = (size_t)C * (TV + 4) * sizeof(float);
+#define FBBEV_DENSE(TVV)                                                                              \
+    FBBEV_LAUNCH(k_pool_fwd_dense<TVV>, n_tiles, 256, lds, stream, C, Z, (int)yx, tiles_per_plane,    \
+                 depth, feat, ranks_depth, ranks_feat, ranks_bev, interval_starts, interval_lengths, \
+                 (const int*)tile_istart, out)
+    if (TV == 64) FBBEV_DENSE(64);
+    else if (TV == 128) FBBEV_DENSE(128);
+    else FBBEV_DENSE(256);
+#undef FBBEV_DENSE
+    FBBEV_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------ MSDeformAttn
+extern "C" int fbbev_msda_fwd(const float* value, const int64_t* spatial_shapes,
+                              const int64_t* level_start_index, const float* sampling_loc,
+                              const float* attn_weight, int batch, int spatial_size, int num_heads,
+                              int channels, int num_levels, int num_query, int num_point, float* out,
+                              fbbev_stream_t stream_) {
+    if (batch < 0 || spatial_size <= 0 || num_heads <= 0 || channels <= 0 || num_levels <= 0 ||
+        num_query < 0 || num_point <= 0) return FBBEV_E_BADARG;
+    const long long n = (long long)batch * num_query * num_heads * channels;
+    if (n == 0) return 0;
+    if (!value || !spatial_shapes || !level_start_index || !sampling_loc || !attn_weight || !out)
+        return FBBEV_E_BADARG;
+    fbbev_rt_stream stream = (fbbev_rt_stream)stream_;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    FBBEV_LAUNCH(k_msda_fwd, blocks, 256, 0, stream, n, value, spatial_shapes, level_start_index,
+                 sampling_loc, attn_weight, spatial_size, num_heads, channels, num_levels, num_query,
+                 num_point, out);
+    FBBEV_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int fbbev_msda_bwd(const float* value, const int64_t* spatial_shapes,
+                              const int64_t* level_start_index, const float* sampling_loc,
+                              const float* attn_weight, const float* grad_output, int batch,
+                              int spatial_size, int num_heads, int channels, int num_levels,
+                              int num_query, int num_point, float* grad_value,
+                              float* grad_sampling_loc, float* grad_attn_weight,
+                              fbbev_stream_t stream_) {
+    if (batch < 0 || spatial_size <= 0 || num_heads <= 0 || channels <= 0 || num_levels <= 0 ||
+        num_query < 0 || num_point <= 0) return FBBEV_E_BADARG;
+    const long long n_units = (long long)batch * num_query * num_heads;
+    if (n_units == 0) return 0;
+    if (!value || !spatial_shapes || !level_start_index || !sampling_loc || !attn_weight ||
+        !grad_output || !grad_value || !grad_sampling_loc || !grad_attn_weight) return FBBEV_E_BADARG;
+    fbbev_rt_stream stream = (fbbev_rt_stream)stream_;
+#define FBBEV_MSDA_BWD(GW)                                                                          \
+    FBBEV_LAUNCH(k_msda_bwd<GW>, (n_units * GW + 255) / 256, 256, 0, stream, n_units, value,       \
+                 spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output,         \
+                 spatial_size, num_heads, channels, num_levels, num_query, num_point, grad_value,   \
+                 grad_sampling_loc, grad_attn_weight)
+    if (channels <= 16) FBBEV_MSDA_BWD(16);
+    else if (channels <= 32) FBBEV_MSDA_BWD(32);
+    else FBBEV_MSDA_BWD(64);
+#undef FBBEV_MSDA_BWD
+    FBBEV_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,31 @@
+// rt.h -- device runtime glue for the gfx950 build (HIP).  The kernels and the C-ABI launchers
+// include "rt.h" and nothing else from HIP; tests/emu/rt.h offers the same names for the
+// CPU kernel-logic emulator used by the `not gpu` tests (test infrastructure, never shipped).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+typedef hipStream_t fbbev_rt_stream;
+
+#define FBBEV_LAUNCH(kern, grid, block, lds_bytes, stream, ...) \
+    hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), (size_t)(lds_bytes), stream, __VA_ARGS__)
+
+static inline int fbbev_rt_last_error() { return (int)hipGetLastError(); }
+
+static inline int fbbev_rt_memset_async(void* p, int byte, size_t n, fbbev_rt_stream s) {
+    return (int)hipMemsetAsync(p, byte, n, s);
+}
+
+// dynamic LDS carve-out; base is 16-byte aligned (no static __shared__ precedes it in any kernel
+// that uses it -- cdna_hip_programming.md Guideline 17)
+extern __shared__ __attribute__((aligned(16))) unsigned char fbbev_dyn_lds_raw[];
+__device__ __forceinline__ float* fbbev_dyn_lds_f32() { return reinterpret_cast<float*>(fbbev_dyn_lds_raw); }
+
+// stable LSD radix sort of (key, value) pairs on `bits` low key bits (sort_rocprim.hip)
+size_t fbbev_rt_sort_pairs_temp_bytes(size_t n, int bits);
+int fbbev_rt_sort_pairs(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out,
+                        const uint32_t* vals_in, uint32_t* vals_out, size_t n, int bits,
+                        fbbev_rt_stream stream);
+
+__device__ __forceinline__ void fbbev_atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }

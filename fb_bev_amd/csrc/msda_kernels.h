@@ -1,0 +1,134 @@
+// msda_kernels.h -- multi-scale deformable attention sampling (forward / backward) for gfx950.
+//
+// Replaces mmcv._ext.ms_deform_attn_forward / ms_deform_attn_backward (mmcv-full 1.5.2; the
+// source is NOT in the FB-BEV tree).  Call sites in the reference:
+//   backward_projection/bevformer_utils/multi_scale_deformable_attn_function.py:127-133,159-169
+//   backward_projection/bevformer_utils/spatial_cross_attention_depth.py:586-588 (depth map sampled
+//     as a 1-head x D-channel value), :593-595 (value sampling, 8 heads x 10 channels).
+// Semantics: out[b,q,m,c] = sum_{l,p} w[b,q,m,l,p] * bilinear(value_l[b,:,m,c],
+//   x = loc_x*W_l - 0.5, y = loc_y*H_l - 0.5), sample counted only if -1 < x < W_l and -1 < y < H_l,
+//   the 4 corners individually zero-padded  (== F.grid_sample bilinear / zeros / align_corners=False).
+//
+// Mapping: forward = one lane per output scalar, channel fastest, so the Dh lanes of one
+// (b,q,m) read Dh contiguous floats per corner and share (broadcast) the loc/weight loads.
+// Backward = a group of GW lanes (16/32/64) per (b,q,m); channels strided over the group;
+// d/dloc and d/dweight are reduced over channels with wave shuffles (no LDS), d/dvalue goes out
+// through hardware fp32 atomics.
+#pragma once
+#include "rt.h"
+
+struct fbbev_bilinear {
+    int o1, o2, o3, o4;        // corner offsets (floats) relative to value_l + m*Dh + c; -1 = padded
+    float w1, w2, w3, w4;      // corner weights
+    float lh, lw, hh, hw;
+};
+
+__device__ __forceinline__ fbbev_bilinear fbbev_bilinear_setup(float h, float w, int height, int width,
+                                                              int row_stride /* M*Dh */) {
+    fbbev_bilinear s;
+    const int h_low = (int)floorf(h), w_low = (int)floorf(w);
+    const int h_high = h_low + 1, w_high = w_low + 1;
+    s.lh = h - (float)h_low; s.lw = w - (float)w_low; s.hh = 1.f - s.lh; s.hw = 1.f - s.lw;
+    const int hs = width * row_stride;
+    s.o1 = (h_low >= 0 && w_low >= 0) ? h_low * hs + w_low * row_stride : -1;
+    s.o2 = (h_low >= 0 && w_high <= width - 1) ? h_low * hs + w_high * row_stride : -1;
+    s.o3 = (h_high <= height - 1 && w_low >= 0) ? h_high * hs + w_low * row_stride : -1;
+    s.o4 = (h_high <= height - 1 && w_high <= width - 1) ? h_high * hs + w_high * row_stride : -1;
+    s.w1 = s.hh * s.hw; s.w2 = s.hh * s.lw; s.w3 = s.lh * s.hw; s.w4 = s.lh * s.lw;
+    return s;
+}
+
+__global__ void __launch_bounds__(256)
+k_msda_fwd(long long n, const float* __restrict__ value, const int64_t* __restrict__ spatial_shapes,
+           const int64_t* __restrict__ level_start, const float* __restrict__ loc,
+           const float* __restrict__ attn, int spatial_size, int M, int Dh, int L, int Q, int P,
+           float* __restrict__ out) {
+    const int row_stride = M * Dh;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < n;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % Dh);
+        const long long unit = idx / Dh;          // (b*Q + q)*M + m
+        const int m = (int)(unit % M);
+        const long long b = unit / M / Q;
+        long long wp = unit * L * P, lp = wp * 2;
+        float col = 0.f;
+        for (int l = 0; l < L; ++l) {
+            const int sh = (int)spatial_shapes[2 * l], sw = (int)spatial_shapes[2 * l + 1];
+            const float* vp = value + (b * spatial_size + level_start[l]) * row_stride + m * Dh + c;
+            for (int p = 0; p < P; ++p, wp += 1, lp += 2) {
+                const float loc_w = loc[lp], loc_h = loc[lp + 1], weight = attn[wp];
+                const float h_im = loc_h * sh - 0.5f, w_im = loc_w * sw - 0.5f;
+                if (h_im > -1.f && w_im > -1.f && h_im < (float)sh && w_im < (float)sw) {
+                    const fbbev_bilinear s = fbbev_bilinear_setup(h_im, w_im, sh, sw, row_stride);
+                    const float v1 = s.o1 >= 0 ? vp[s.o1] : 0.f;
+                    const float v2 = s.o2 >= 0 ? vp[s.o2] : 0.f;
+                    const float v3 = s.o3 >= 0 ? vp[s.o3] : 0.f;
+                    const float v4 = s.o4 >= 0 ? vp[s.o4] : 0.f;
+                    col += (s.w1 * v1 + s.w2 * v2 + s.w3 * v3 + s.w4 * v4) * weight;
+                }
+            }
+        }
+        out[idx] = col;
+    }
+}
+
+template <int GW>
+__device__ __forceinline__ float fbbev_group_sum(float v) {
+#pragma unroll
+    for (int o = GW / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int GW>
+__global__ void __launch_bounds__(256)
+k_msda_bwd(long long n_units, const float* __restrict__ value,
+           const int64_t* __restrict__ spatial_shapes, const int64_t* __restrict__ level_start,
+           const float* __restrict__ loc, const float* __restrict__ attn,
+           const float* __restrict__ grad_out, int spatial_size, int M, int Dh, int L, int Q, int P,
+           float* __restrict__ grad_value, float* __restrict__ grad_loc, float* __restrict__ grad_attn) {
+    const int slot = threadIdx.x % GW;
+    const long long unit = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / GW;
+    const bool active = unit < n_units;
+    const long long u = active ? unit : 0;
+    const int m = (int)(u % M);
+    const long long b = u / M / Q;
+    const int row_stride = M * Dh;
+    long long wp = u * L * P, lp = wp * 2;
+    for (int l = 0; l < L; ++l) {
+        const int height = (int)spatial_shapes[2 * l], width = (int)spatial_shapes[2 * l + 1];
+        const long long voff = (b * spatial_size + level_start[l]) * row_stride + m * Dh;
+        for (int p = 0; p < P; ++p, wp += 1, lp += 2) {
+            const float loc_w = loc[lp], loc_h = loc[lp + 1], weight = attn[wp];
+            const float h_im = loc_h * height - 0.5f, w_im = loc_w * width - 0.5f;
+            const bool inr = active && h_im > -1.f && w_im > -1.f && h_im < (float)height &&
+                             w_im < (float)width;
+            float g_w = 0.f, g_x = 0.f, g_y = 0.f;
+            if (inr) {
+                const fbbev_bilinear s = fbbev_bilinear_setup(h_im, w_im, height, width, row_stride);
+                for (int c = slot; c < Dh; c += GW) {
+                    const float top = grad_out[u * Dh + c];
+                    const float tgv = top * weight;
+                    const float* vp = value + voff + c;
+                    float* gp = grad_value + voff + c;
+                    float ghw = 0.f, gww = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;
+                    if (s.o1 >= 0) { v1 = vp[s.o1]; ghw -= s.hw * v1; gww -= s.hh * v1; fbbev_atomic_add_f32(gp + s.o1, s.w1 * tgv); }
+                    if (s.o2 >= 0) { v2 = vp[s.o2]; ghw -= s.lw * v2; gww += s.hh * v2; fbbev_atomic_add_f32(gp + s.o2, s.w2 * tgv); }
+                    if (s.o3 >= 0) { v3 = vp[s.o3]; ghw += s.hw * v3; gww -= s.lh * v3; fbbev_atomic_add_f32(gp + s.o3, s.w3 * tgv); }
+                    if (s.o4 >= 0) { v4 = vp[s.o4]; ghw += s.lw * v4; gww += s.lh * v4; fbbev_atomic_add_f32(gp + s.o4, s.w4 * tgv); }
+                    const float val = s.w1 * v1 + s.w2 * v2 + s.w3 * v3 + s.w4 * v4;
+                    g_w += top * val;
+                    g_x += (float)width * gww * tgv;
+                    g_y += (float)height * ghw * tgv;
+                }
+            }
+            g_w = fbbev_group_sum<GW>(g_w);
+            g_x = fbbev_group_sum<GW>(g_x);
+            g_y = fbbev_group_sum<GW>(g_y);
+            if (active && slot == 0) {
+                grad_attn[wp] += g_w;
+                grad_loc[lp] += g_x;
+                grad_loc[lp + 1] += g_y;
+            }
+        }
+    }
+}

@@ -1,0 +1,178 @@
+// rank_kernels.h -- voxel ranking: frustum point -> voxel key -> sorted runs (intervals).
+//
+// Replaces LSSViewTransformerFunction3D.voxel_pooling_prepare_v2
+// (fbbev/view_transformation/forward_projection/view_transformer.py:547-605): in the reference
+// ~17 torch launches, an unstable argsort over B*N*D*H*W keys, three boolean-mask gathers and a
+// torch.where -- at least four host syncs.  Here everything stays on the device:
+//   k_rank_keys        : point -> key (fp32 rank evaluation + truncation, bit-for-bit the
+//                        reference arithmetic); points outside the grid get a sentinel key that
+//                        sorts behind every real voxel.
+//   (stable radix sort of (key, point id) pairs, rt.h)
+//   k_flag_count       : per-block count of run heads + P (number of kept points)
+//   k_scan_blocks      : exclusive scan of the block counts + I (number of intervals)
+//   k_write_intervals  : run heads -> interval_starts (block scan = wave prefix sums), ranks_feat
+//   k_interval_lengths : starts -> lengths
+#pragma once
+#include "rt.h"
+
+#define FBBEV_RANK_ITEMS 4          // items per thread in the run-detection kernels
+#define FBBEV_RANK_BLOCK 256
+#define FBBEV_RANK_CHUNK (FBBEV_RANK_ITEMS * FBBEV_RANK_BLOCK)
+
+struct fbbev_grid_params {
+    float lx, ly, lz;     // grid_lower_bound        (view_transformer.py:384)
+    float ix, iy, iz;     // grid_interval           (:385)
+    float gx, gy, gz;     // grid_size as fp32       (:386-387)
+    float f_yx, f_zyx;    // fl(gy*gx), fl(fl(gz*gy)*gx): the 0-dim fp32 products of :586-588
+};
+
+// view_transformer.py:570-589.  Every operation is a single correctly-rounded fp32 op (no fma
+// contraction, IEEE divide): the rank must be the SAME float the reference computes, because it
+// is the sort key and, above 2^24, decides which voxels collide.
+__global__ void __launch_bounds__(256)
+k_rank_keys(const float* __restrict__ coor, long long npts, long long pts_per_batch,
+            fbbev_grid_params gp, unsigned int sentinel, unsigned int* __restrict__ keys,
+            unsigned int* __restrict__ vals) {
+    for (long long pid = (long long)blockIdx.x * blockDim.x + threadIdx.x; pid < npts;
+         pid += (long long)gridDim.x * blockDim.x) {
+        const float cx = coor[3 * pid], cy = coor[3 * pid + 1], cz = coor[3 * pid + 2];
+        const float fx = __fdiv_rn(__fsub_rn(cx, gp.lx), gp.ix);
+        const float fy = __fdiv_rn(__fsub_rn(cy, gp.ly), gp.iy);
+        const float fz = __fdiv_rn(__fsub_rn(cz, gp.lz), gp.iz);
+        // .long(): truncation toward zero.  |f| >= 2^31 or NaN can never be inside the grid.
+        const bool finite = (fx == fx) && (fy == fy) && (fz == fz) && fabsf(fx) < 2.0e9f &&
+                            fabsf(fy) < 2.0e9f && fabsf(fz) < 2.0e9f;
+        const int vx = finite ? (int)fx : -1;
+        const int vy = finite ? (int)fy : -1;
+        const int vz = finite ? (int)fz : -1;
+        // kept: integer >= 0 and (float)v < grid_size (long vs 0-dim fp32 tensor compares in fp32)
+        const bool kept = finite && vx >= 0 && vy >= 0 && vz >= 0 && (float)vx < gp.gx &&
+                          (float)vy < gp.gy && (float)vz < gp.gz;
+        const float bf = (float)(pid / pts_per_batch);
+        float r = __fmul_rn(bf, gp.f_zyx);
+        r = __fadd_rn(r, __fmul_rn((float)vz, gp.f_yx));
+        const float t = __fadd_rn(__fmul_rn((float)vy, gp.gx), (float)vx);
+        r = __fadd_rn(r, t);
+        keys[pid] = kept ? (unsigned int)(int)r : sentinel;
+        vals[pid] = (unsigned int)pid;
+    }
+}
+
+__device__ __forceinline__ int fbbev_wave_incl_scan(int v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int n = __shfl_up(v, o, 64);
+        if (lane >= o) v += n;
+    }
+    return v;
+}
+
+// exclusive scan of one int per thread over a 256-thread block; *total gets the block sum.
+// lds4: 4 ints of static LDS owned by the caller.
+__device__ __forceinline__ int fbbev_block_excl_scan(int v, int* lds4, int* total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int inc = fbbev_wave_incl_scan(v, lane);
+    if (lane == 63) lds4[w] = inc;
+    __syncthreads();
+    int woff = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int x = lds4[i];
+        if (i < w) woff += x;
+        tot += x;
+    }
+    __syncthreads();
+    *total = tot;
+    return woff + inc - v;
+}
+
+// keys sorted ascending, sentinels last. counts[0] = P.
+__global__ void __launch_bounds__(FBBEV_RANK_BLOCK)
+k_flag_count(const unsigned int* __restrict__ keys, long long n, unsigned int sentinel,
+             int* __restrict__ block_counts, int* __restrict__ counts) {
+    __shared__ int lds4[4];
+    const long long base = (long long)blockIdx.x * FBBEV_RANK_CHUNK + threadIdx.x * FBBEV_RANK_ITEMS;
+    int local = 0;
+#pragma unroll
+    for (int j = 0; j < FBBEV_RANK_ITEMS; ++j) {
+        const long long i = base + j;
+        if (i < n) {
+            const unsigned int k = keys[i];
+            const bool valid = k != sentinel;
+            const bool head = valid && (i == 0 || keys[i - 1] != k);
+            local += head ? 1 : 0;
+            if (valid && (i + 1 == n || keys[i + 1] == sentinel)) counts[0] = (int)(i + 1);
+        }
+    }
+    int total;
+    (void)fbbev_block_excl_scan(local, lds4, &total);
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = total;
+}
+
+// single block: exclusive scan of block_counts[0..nblocks) in place; counts[1] = I.
+__global__ void __launch_bounds__(FBBEV_RANK_BLOCK)
+k_scan_blocks(int* __restrict__ block_counts, int nblocks, int* __restrict__ counts) {
+    __shared__ int lds4[4];
+    int running = 0;
+    for (int base = 0; base < nblocks; base += FBBEV_RANK_BLOCK) {
+        const int i = base + threadIdx.x;
+        const int v = (i < nblocks) ? block_counts[i] : 0;
+        int total;
+        const int ex = fbbev_block_excl_scan(v, lds4, &total);
+        if (i < nblocks) block_counts[i] = running + ex;
+        running += total;
+    }
+    if (threadIdx.x == 0) counts[1] = running;
+}
+
+__global__ void __launch_bounds__(FBBEV_RANK_BLOCK)
+k_write_intervals(const unsigned int* __restrict__ keys, const unsigned int* __restrict__ vals,
+                  long long n, unsigned int sentinel, const int* __restrict__ block_offsets,
+                  int D, int HW, int* __restrict__ ranks_feat, int* __restrict__ interval_starts,
+                  int* __restrict__ interval_rank) {
+    __shared__ int lds4[4];
+    const long long base = (long long)blockIdx.x * FBBEV_RANK_CHUNK + threadIdx.x * FBBEV_RANK_ITEMS;
+    bool head[FBBEV_RANK_ITEMS];
+    unsigned int key[FBBEV_RANK_ITEMS];
+    int local = 0;
+    const unsigned int dhw = (unsigned int)D * (unsigned int)HW;
+#pragma unroll
+    for (int j = 0; j < FBBEV_RANK_ITEMS; ++j) {
+        const long long i = base + j;
+        head[j] = false;
+        key[j] = sentinel;
+        if (i < n) {
+            const unsigned int k = keys[i];
+            key[j] = k;
+            const bool valid = k != sentinel;
+            head[j] = valid && (i == 0 || keys[i - 1] != k);
+            local += head[j] ? 1 : 0;
+            if (valid) {  // view_transformer.py:563-568: feature pixel of point ((b*N+n)*D+d)*HW + hw
+                const unsigned int pid = vals[i];
+                ranks_feat[i] = (int)((pid / dhw) * (unsigned int)HW + pid % (unsigned int)HW);
+            }
+        }
+    }
+    int total;
+    int j0 = block_offsets[blockIdx.x] + fbbev_block_excl_scan(local, lds4, &total);
+#pragma unroll
+    for (int j = 0; j < FBBEV_RANK_ITEMS; ++j) {
+        if (head[j]) {
+            interval_starts[j0] = (int)(base + j);
+            if (interval_rank) interval_rank[j0] = (int)key[j];
+            ++j0;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_interval_lengths(const int* __restrict__ interval_starts, const int* __restrict__ counts,
+                   long long n_max, int* __restrict__ interval_lengths) {
+    const int P = counts[0], I = counts[1];
+    for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < I && j < n_max;
+         j += (long long)gridDim.x * blockDim.x) {
+        const int s = interval_starts[j];
+        const int e = (j + 1 < I) ? interval_starts[j + 1] : P;
+        interval_lengths[j] = e - s;
+    }
+}

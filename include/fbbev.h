@@ -1,0 +1,128 @@
+/*
+ * fbbev.h -- C ABI of libfbbev_hip.so: the MI355X (gfx950) native view-transformation hot path
+ * of FB-OCC (forward lift-splat + backward-projection sampling).
+ *
+ * Drop-in boundary.  Every entry point takes plain device pointers, sizes and a HIP stream;
+ * nothing here knows about torch.  Each function names the reference interface it replaces
+ * (paths relative to the NVlabs/FB-BEV tree).  All functions are re-entrant, hold no global
+ * mutable state, never synchronise the host and enqueue on the caller's stream (the reference
+ * launches on the legacy default stream, bev_pool_cuda.cu:124,133).
+ *
+ * Return value: 0 = ok, <0 = invalid argument (FBBEV_E_*), >0 = hipError_t of the failed launch.
+ * Nothing throws across this ABI.
+ */
+#ifndef FBBEV_H_
+#define FBBEV_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* fbbev_stream_t; /* hipStream_t */
+
+#define FBBEV_E_BADARG (-1)
+#define FBBEV_E_UNSUPPORTED (-2)
+#define FBBEV_E_WORKSPACE (-3)
+
+/* flags for the pooling entry points */
+#define FBBEV_POOL_DEFAULT 0
+
+int fbbev_version(void);
+
+/* ----------------------------------------------------------------------------------------------
+ * Boundary 1: mmdet3d.ops.bev_pool_v2.bev_pool_v2_ext
+ * -------------------------------------------------------------------------------------------- */
+
+/* Replaces  void bev_pool_v2(int c, int n_intervals, const float* depth, const float* feat,
+ *   const int* ranks_depth, const int* ranks_feat, const int* ranks_bev,
+ *   const int* interval_starts, const int* interval_lengths, float* out)
+ *   -- mmdet3d/ops/bev_pool_v2/src/bev_pool_cuda.cu:122-128 (kernel :18-45), reached from
+ *   bev_pool_v2_forward, src/bev_pool.cpp:28-55.
+ * depth (B,N,D,H,W) f32, feat (B,N,H,W,C) f32, out (B,Z,Y,X,C) f32 PRE-ZEROED by the caller
+ * (bev_pool.py:24); only rows ranks_bev[interval_starts[i]] are written.  Each output element is
+ * an fmaf chain over the interval in the given order == the reference kernel's arithmetic. */
+int fbbev_bev_pool_v2_fwd(int c, int n_intervals, const float* depth, const float* feat,
+                          const int32_t* ranks_depth, const int32_t* ranks_feat,
+                          const int32_t* ranks_bev, const int32_t* interval_starts,
+                          const int32_t* interval_lengths, float* out, fbbev_stream_t stream);
+
+/* Replaces  void bev_pool_v2_grad(int c, int n_intervals, const float* out_grad, ...)
+ *   -- src/bev_pool_cuda.cu:130-137 (kernel :64-118), reached from bev_pool_v2_backward,
+ *   src/bev_pool.cpp:72-102.  Rank arrays are sorted by ranks_feat and the intervals are over
+ *   ranks_feat (bev_pool.py:44-54).  depth_grad / feat_grad are pre-zeroed by the caller. */
+int fbbev_bev_pool_v2_bwd(int c, int n_intervals, const float* out_grad, const float* depth,
+                          const float* feat, const int32_t* ranks_depth, const int32_t* ranks_feat,
+                          const int32_t* ranks_bev, const int32_t* interval_starts,
+                          const int32_t* interval_lengths, float* depth_grad, float* feat_grad,
+                          fbbev_stream_t stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * Fused forward-projection entry points (additive; same arithmetic, no host sync)
+ * -------------------------------------------------------------------------------------------- */
+
+/* Replaces LSSViewTransformerFunction3D.voxel_pooling_prepare_v2
+ *   -- fbbev/view_transformation/forward_projection/view_transformer.py:547-605
+ *   (~17 torch launches, an argsort and >=4 host syncs in the reference).
+ * coor (B,N,D,H,W,3) f32 ego-frame frustum points.  lower/interval/grid_size are the three fp32
+ * values of grid_lower_bound / grid_interval / grid_size (view_transformer.py:384-387).
+ * Outputs are sized to the upper bound n = B*N*D*H*W; the valid prefix lengths are written to
+ * counts[0] = P (points kept) and counts[1] = I (non-empty voxels) ON THE DEVICE.
+ * Bit-exact with the reference for ranks_bev / interval_starts / interval_lengths, including the
+ * fp32 rank evaluation and the truncation toward zero; (ranks_depth, ranks_feat) come out in the
+ * canonical STABLE order (ascending point id inside a voxel).
+ * interval_rank (optional, may be NULL) receives ranks_bev[interval_starts[i]]. */
+size_t fbbev_rank_workspace_bytes(int64_t n_points);
+int fbbev_rank_build(const float* coor, int B, int N, int D, int H, int W, const float* lower3,
+                     const float* interval3, const float* grid_size3, int32_t* ranks_bev,
+                     int32_t* ranks_depth, int32_t* ranks_feat, int32_t* interval_starts,
+                     int32_t* interval_lengths, int32_t* interval_rank, int32_t* counts,
+                     void* workspace, size_t workspace_bytes, fbbev_stream_t stream);
+
+/* Fused replacement of  feat.new_zeros + bev_pool_v2_forward + permute(0,4,1,2,3).contiguous()
+ *   -- bev_pool.py:24-35,88.
+ * Writes EVERY element of out (B,C,Z,Y,X) exactly once (zeros for empty voxels) in the final
+ * layout, so `out` need not be pre-zeroed.  n_intervals_dev points at the device-side interval
+ * count (counts+1 of fbbev_rank_build) so no host sync is needed; n_intervals_max bounds it.
+ * tile_ws: workspace of fbbev_pool_dense_workspace_bytes(B,Z,Y,X) bytes. */
+size_t fbbev_pool_dense_workspace_bytes(int B, int Z, int Y, int X);
+int fbbev_bev_pool_v2_dense_fwd(const float* depth, const float* feat, const int32_t* ranks_depth,
+                                const int32_t* ranks_feat, const int32_t* ranks_bev,
+                                const int32_t* interval_starts, const int32_t* interval_lengths,
+                                const int32_t* n_intervals_dev, int n_intervals_max, int B, int C,
+                                int Z, int Y, int X, float* out_bczyx, void* tile_ws,
+                                size_t tile_ws_bytes, int tile_voxels, fbbev_stream_t stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * Boundary 2: mmcv._ext.ms_deform_attn_{forward,backward} (mmcv-full 1.5.2, external to the tree)
+ * -------------------------------------------------------------------------------------------- */
+
+/* Replaces ext_module.ms_deform_attn_forward(value, spatial_shapes, level_start_index,
+ *   sampling_locations, attention_weights, im2col_step=...)
+ *   -- call sites bevformer_utils/multi_scale_deformable_attn_function.py:127-133,
+ *   spatial_cross_attention_depth.py:586-588,593-595.
+ * value (B,S,M,Dh) f32; spatial_shapes (L,2) int64 (h,w); level_start_index (L) int64;
+ * sampling_loc (B,Q,M,L,P,2) f32 (x,y) normalised; attn_weight (B,Q,M,L,P) f32; out (B,Q,M*Dh).
+ * im2col_step is accepted and ignored (any batch size works). */
+int fbbev_msda_fwd(const float* value, const int64_t* spatial_shapes,
+                   const int64_t* level_start_index, const float* sampling_loc,
+                   const float* attn_weight, int batch, int spatial_size, int num_heads,
+                   int channels, int num_levels, int num_query, int num_point, float* out,
+                   fbbev_stream_t stream);
+
+/* Replaces ext_module.ms_deform_attn_backward(..., grad_output, grad_value, grad_sampling_loc,
+ *   grad_attn_weight, im2col_step=...) -- multi_scale_deformable_attn_function.py:159-169.
+ * The three grad outputs are pre-zeroed by the caller (:155-157) and accumulated into. */
+int fbbev_msda_bwd(const float* value, const int64_t* spatial_shapes,
+                   const int64_t* level_start_index, const float* sampling_loc,
+                   const float* attn_weight, const float* grad_output, int batch, int spatial_size,
+                   int num_heads, int channels, int num_levels, int num_query, int num_point,
+                   float* grad_value, float* grad_sampling_loc, float* grad_attn_weight,
+                   fbbev_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FBBEV_H_ */

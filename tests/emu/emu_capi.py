@@ -1,0 +1,85 @@
+"""Test-only adapter: drive the C ABI of the CPU-emulated kernel library with CPU tensors.
+
+The emulated library is the SAME capi.hip + kernel headers as the product, compiled against
+tests/emu/rt.h.  This module lives under tests/ and is not importable from fb_bev_amd.
+"""
+import ctypes
+import os
+import sys
+from ctypes import c_void_p
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import build_emu  # noqa: E402
+from fb_bev_amd import _capi  # noqa: E402  (signature table only)
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = _capi.declare(ctypes.CDLL(build_emu.build()))
+    return _lib
+
+
+def p(t):
+    assert t.is_contiguous() and not t.is_cuda
+    return c_void_p(t.data_ptr())
+
+
+def ok(code):
+    assert code == 0, f'C ABI returned {code}'
+
+
+def rank_build(coor, lower3, interval3, grid_size3, with_rank=True):
+    B, N, D, H, W, _ = coor.shape
+    n = B * N * D * H * W
+    rb, rd, rf = (torch.full((n,), -7, dtype=torch.int32) for _ in range(3))
+    st, ln, ir = (torch.full((n,), -7, dtype=torch.int32) for _ in range(3))
+    counts = torch.full((2,), -1, dtype=torch.int32)
+    ws = torch.zeros(lib().fbbev_rank_workspace_bytes(n), dtype=torch.uint8)
+    arr = ctypes.c_float * 3
+    lo, it, gs = arr(*lower3), arr(*interval3), arr(*grid_size3)
+    ok(lib().fbbev_rank_build(p(coor), B, N, D, H, W, ctypes.cast(lo, c_void_p), ctypes.cast(it, c_void_p),
+                              ctypes.cast(gs, c_void_p), p(rb), p(rd), p(rf), p(st), p(ln),
+                              p(ir) if with_rank else c_void_p(0), p(counts), p(ws), ws.numel(), None))
+    return rb, rd, rf, st, ln, ir, counts
+
+
+def pool_fwd(depth, feat, out, rd, rf, rb, st, ln, n=None):
+    ok(lib().fbbev_bev_pool_v2_fwd(feat.shape[-1], st.numel() if n is None else n, p(depth), p(feat), p(rd),
+                                   p(rf), p(rb), p(st), p(ln), p(out), None))
+
+
+def pool_bwd(out_grad, depth_grad, feat_grad, depth, feat, rd, rf, rb, st, ln):
+    ok(lib().fbbev_bev_pool_v2_bwd(out_grad.shape[-1], st.numel(), p(out_grad), p(depth), p(feat), p(rd),
+                                   p(rf), p(rb), p(st), p(ln), p(depth_grad), p(feat_grad), None))
+
+
+def pool_dense(depth, feat, rd, rf, rb, st, ln, counts, n_max, B, C, Z, Y, X, tile_voxels):
+    out = torch.full((B, C, Z, Y, X), float('nan'))
+    ws = torch.zeros(lib().fbbev_pool_dense_workspace_bytes(B, Z, Y, X), dtype=torch.uint8)
+    code = lib().fbbev_bev_pool_v2_dense_fwd(p(depth), p(feat), p(rd), p(rf), p(rb), p(st), p(ln),
+                                             c_void_p(counts.data_ptr() + 4), n_max, B, C, Z, Y, X,
+                                             p(out), p(ws), ws.numel(), tile_voxels, None)
+    return code, out
+
+
+def msda_fwd(value, ss, ls, loc, w):
+    B, S, M, Dh = value.shape
+    _, Q, _, L, P, _ = loc.shape
+    out = torch.full((B, Q, M * Dh), float('nan'))
+    ok(lib().fbbev_msda_fwd(p(value), p(ss), p(ls), p(loc), p(w), B, S, M, Dh, L, Q, P, p(out), None))
+    return out
+
+
+def msda_bwd(value, ss, ls, loc, w, go):
+    B, S, M, Dh = value.shape
+    _, Q, _, L, P, _ = loc.shape
+    gv, gl, gw = torch.zeros_like(value), torch.zeros_like(loc), torch.zeros_like(w)
+    ok(lib().fbbev_msda_bwd(p(value), p(ss), p(ls), p(loc), p(w), p(go), B, S, M, Dh, L, Q, P, p(gv), p(gl),
+                            p(gw), None))
+    return gv, gl, gw

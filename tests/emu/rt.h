@@ -1,0 +1,158 @@
+// tests/emu/rt.h -- CPU emulation of the device runtime names used by fb_bev_amd/csrc/*.h.
+//
+// TEST INFRASTRUCTURE ONLY.  It lets the `not gpu` test-suite execute the *same kernel source and
+// the same C-ABI launch code* (capi.hip) on the CPU at tiny sizes, to catch indexing / scan /
+// tiling logic errors without a GPU.  It is never built into, nor loadable by, the product
+// package (fb_bev_amd/_capi.py only ever opens libfbbev_hip.so and rejects CPU tensors).
+//
+// Model: blocks run one after another; the threads of a block are ucontext fibers scheduled
+// round-robin on ONE OS thread, so __syncthreads() and the wave64 shuffles are exact rendezvous
+// points and execution is deterministic.  Wave intrinsics must be called wave-uniformly.
+#pragma once
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <ucontext.h>
+
+#include <algorithm>
+#include <functional>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __shared__ static
+
+struct dim3 { unsigned x, y, z; };
+struct float4 { float x, y, z, w; } __attribute__((aligned(16)));
+
+namespace emu {
+struct Fiber { ucontext_t ctx; bool done; };
+struct State {
+    dim3 tid{0, 0, 0}, bid{0, 0, 0}, bdim{1, 1, 1}, gdim{1, 1, 1};
+    std::vector<Fiber> fibers;
+    std::vector<char> stacks;
+    ucontext_t sched;
+    int cur = 0;
+    int live = 0, arrived = 0; unsigned gen = 0;                 // block barrier
+    int wlive[16], warrived[16]; unsigned wgen[16];              // wave rendezvous (<=1024 threads)
+    uint64_t wslot[16][64];
+    std::function<void()> body;
+    std::vector<unsigned char> lds;
+    int last_error = 0;
+};
+inline State& S() { static State s; return s; }
+inline void yield() { State& s = S(); swapcontext(&s.fibers[s.cur].ctx, &s.sched); }
+inline void trampoline() {
+    State& s = S();
+    s.body();
+    const int me = s.cur, w = me >> 6;
+    s.fibers[me].done = true;
+    s.live--; s.wlive[w]--;
+    if (s.live > 0 && s.arrived == s.live) { s.arrived = 0; s.gen++; }
+    if (s.wlive[w] > 0 && s.warrived[w] == s.wlive[w]) { s.warrived[w] = 0; s.wgen[w]++; }
+    swapcontext(&s.fibers[me].ctx, &s.sched);
+}
+inline void block_barrier() {
+    State& s = S();
+    const unsigned g = s.gen;
+    if (++s.arrived == s.live) { s.arrived = 0; s.gen++; return; }
+    while (s.gen == g) yield();
+}
+inline void wave_barrier() {
+    State& s = S();
+    const int w = s.cur >> 6;
+    const unsigned g = s.wgen[w];
+    if (++s.warrived[w] == s.wlive[w]) { s.warrived[w] = 0; s.wgen[w]++; return; }
+    while (s.wgen[w] == g) yield();
+}
+inline void launch(unsigned grid, unsigned block, size_t lds_bytes, std::function<void()> body) {
+    State& s = S();
+    const size_t STK = 256 * 1024;
+    if (s.fibers.size() < block) { s.fibers.resize(block); s.stacks.resize((size_t)block * STK); }
+    if (s.lds.size() < lds_bytes + 16) s.lds.resize(lds_bytes + 16);
+    s.body = body;
+    s.bdim = dim3{block, 1, 1};
+    s.gdim = dim3{grid, 1, 1};
+    for (unsigned b = 0; b < grid; ++b) {
+        s.bid = dim3{b, 0, 0};
+        s.live = (int)block; s.arrived = 0;
+        for (int w = 0; w < 16; ++w) { s.wlive[w] = 0; s.warrived[w] = 0; }
+        for (unsigned t = 0; t < block; ++t) {
+            s.wlive[t >> 6]++;
+            Fiber& f = s.fibers[t];
+            f.done = false;
+            getcontext(&f.ctx);
+            f.ctx.uc_stack.ss_sp = s.stacks.data() + (size_t)t * STK;
+            f.ctx.uc_stack.ss_size = STK;
+            f.ctx.uc_link = &s.sched;
+            makecontext(&f.ctx, (void (*)())trampoline, 0);
+        }
+        int remaining = (int)block;
+        while (remaining > 0) {
+            remaining = 0;
+            for (unsigned t = 0; t < block; ++t) {
+                if (s.fibers[t].done) continue;
+                s.cur = (int)t;
+                s.tid = dim3{t, 0, 0};
+                swapcontext(&s.sched, &s.fibers[t].ctx);
+                if (!s.fibers[t].done) remaining++;
+            }
+        }
+    }
+}
+template <class T> inline uint64_t to_bits(T v) { uint64_t b = 0; memcpy(&b, &v, sizeof(T)); return b; }
+template <class T> inline T from_bits(uint64_t b) { T v; memcpy(&v, &b, sizeof(T)); return v; }
+template <class T> inline T shfl_src(T v, int src_lane_or_neg) {
+    State& s = S();
+    const int w = s.cur >> 6, lane = s.cur & 63;
+    s.wslot[w][lane] = to_bits(v);
+    wave_barrier();
+    T r = (src_lane_or_neg < 0 || src_lane_or_neg > 63) ? v : from_bits<T>(s.wslot[w][src_lane_or_neg]);
+    wave_barrier();
+    return r;
+}
+}  // namespace emu
+
+#define threadIdx (emu::S().tid)
+#define blockIdx (emu::S().bid)
+#define blockDim (emu::S().bdim)
+#define gridDim (emu::S().gdim)
+
+inline void __syncthreads() { emu::block_barrier(); }
+template <class T> inline T __shfl_xor(T v, int mask, int = 64) { return emu::shfl_src(v, (emu::S().cur & 63) ^ mask); }
+template <class T> inline T __shfl_up(T v, int d, int = 64) { return emu::shfl_src(v, (emu::S().cur & 63) - d); }
+template <class T> inline T __shfl(T v, int src, int = 64) { return emu::shfl_src(v, src & 63); }
+
+// single correctly-rounded fp32 ops (volatile defeats re-association / contraction)
+inline float __fsub_rn(float a, float b) { volatile float r = a - b; return r; }
+inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
+inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
+inline float __fdiv_rn(float a, float b) { volatile float r = a / b; return r; }
+
+typedef void* fbbev_rt_stream;
+#define FBBEV_LAUNCH(kern, grid, block, lds_bytes, stream, ...) \
+    emu::launch((unsigned)(grid), (unsigned)(block), (size_t)(lds_bytes), [=]() { kern(__VA_ARGS__); })
+static inline int fbbev_rt_last_error() { return 0; }
+static inline int fbbev_rt_memset_async(void* p, int byte, size_t n, fbbev_rt_stream) { memset(p, byte, n); return 0; }
+inline float* fbbev_dyn_lds_f32() {
+    uintptr_t p = reinterpret_cast<uintptr_t>(emu::S().lds.data());
+    return reinterpret_cast<float*>((p + 15) & ~uintptr_t(15));
+}
+inline void fbbev_atomic_add_f32(float* p, float v) { *p += v; }
+
+inline size_t fbbev_rt_sort_pairs_temp_bytes(size_t n, int) { return n * 8 + 16; }
+inline int fbbev_rt_sort_pairs(void*, size_t, const uint32_t* keys_in, uint32_t* keys_out,
+                               const uint32_t* vals_in, uint32_t* vals_out, size_t n, int bits,
+                               fbbev_rt_stream) {
+    std::vector<std::pair<uint32_t, uint32_t>> v(n);
+    const uint32_t mask = bits >= 32 ? 0xFFFFFFFFu : ((1u << bits) - 1u);
+    for (size_t i = 0; i < n; ++i) v[i] = {keys_in[i], vals_in[i]};
+    std::stable_sort(v.begin(), v.end(), [mask](const auto& a, const auto& b) { return (a.first & mask) < (b.first & mask); });
+    for (size_t i = 0; i < n; ++i) { keys_out[i] = v[i].first; vals_out[i] = v[i].second; }
+    return 0;
+}

@@ -1,0 +1,140 @@
+"""Kernel-logic tests on the CPU fiber emulator (tests/emu): the same kernel source and C-ABI
+launch code as the product, executed at tiny sizes and compared with the oracle.  These do NOT
+replace the `-m gpu` parity tests (memory model, wave64 hardware behaviour and performance are only
+visible on the MI355X); they catch indexing / scan / tiling mistakes before a GPU call is spent."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from fb_bev_amd import synthetic as S
+from oracle import oracle as O
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), 'emu'))
+import emu_capi as E  # noqa: E402
+
+
+def _grid3(vt):
+    return vt.grid_lower_bound.tolist(), vt.grid_interval.tolist(), vt.grid_size.tolist()
+
+
+def _case(name, B, aug=True):
+    cfg = S.CONFIGS[name]
+    vt = O.ViewTransformerOracle(cfg.grid_config, cfg.input_size, cfg.downsample)
+    cam = S.camera_rig(cfg, B, seed=0, bda_aug=aug)
+    coor = vt.get_lidar_coor(*cam).contiguous()
+    depth, ctx = S.depth_and_context(cfg, B, seed=0)
+    feat = ctx.permute(0, 1, 3, 4, 2).contiguous()
+    return cfg, vt, coor, depth, feat
+
+
+@pytest.mark.parametrize('name,B', [('TINY', 2), ('TINY', 1)])
+def test_rank_build_bit_exact(name, B):
+    cfg, vt, coor, _, _ = _case(name, B)
+    rb, rd, rf, st, ln, ir, counts = E.rank_build(coor, *_grid3(vt))
+    erb, erd, erf, est, eln = vt.voxel_pooling_prepare_v2(coor)
+    P, I = counts.tolist()
+    assert (P, I) == (erb.numel(), est.numel())
+    assert torch.equal(rb[:P], erb) and torch.equal(rd[:P], erd) and torch.equal(rf[:P], erf)
+    assert torch.equal(st[:I], est) and torch.equal(ln[:I], eln)
+    assert torch.equal(ir[:I], erb[est.long()])
+
+
+def test_rank_build_golden_coor():
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'index_TINY_B2_aug.npz'))
+    cfg = S.CONFIGS['TINY']
+    vt = O.ViewTransformerOracle(cfg.grid_config, cfg.input_size, cfg.downsample)
+    rb, rd, rf, st, ln, ir, counts = E.rank_build(torch.from_numpy(z['coor']), *_grid3(vt))
+    P, I = counts.tolist()
+    assert np.array_equal(rb[:P].numpy(), z['ranks_bev']) and np.array_equal(rd[:P].numpy(), z['ranks_depth'])
+    assert np.array_equal(rf[:P].numpy(), z['ranks_feat'])
+    assert np.array_equal(st[:I].numpy(), z['interval_starts']) and np.array_equal(ln[:I].numpy(), z['interval_lengths'])
+
+
+def test_rank_build_empty_and_edges():
+    cfg = S.CONFIGS['TINY']
+    vt = O.ViewTransformerOracle(cfg.grid_config, cfg.input_size, cfg.downsample)
+    coor = torch.full((1, 1, 2, 2, 3, 3), 1000.0)                # everything outside
+    *_, counts = E.rank_build(coor, *_grid3(vt))
+    assert counts.tolist() == [0, 0]
+    coor[0, 0, 1, 1, 2] = torch.tensor([-8.5, -8.0, -1.0])      # (-1,0) voxel coord truncates to 0
+    coor[0, 0, 0, 0, 0] = torch.tensor([float('nan'), 0.0, 0.0])
+    coor[0, 0, 0, 0, 1] = torch.tensor([7.999, 7.999, 2.999])   # last voxel
+    rb, rd, rf, st, ln, ir, counts = E.rank_build(coor, *_grid3(vt))
+    erb, erd, erf, est, eln = vt.voxel_pooling_prepare_v2(coor)
+    assert counts.tolist() == [2, 2]
+    assert torch.equal(rb[:2], erb) and torch.equal(rd[:2], erd) and torch.equal(rf[:2], erf)
+
+
+@pytest.mark.parametrize('name,B', [('TINY', 2)])
+def test_pool_fwd_rows_and_bwd(name, B):
+    cfg, vt, coor, depth, feat = _case(name, B)
+    rb, rd, rf, st, ln = vt.voxel_pooling_prepare_v2(coor)
+    shape = vt.bev_feat_shape(B, cfg.channels)
+    out = torch.zeros(shape)
+    E.pool_fwd(depth, feat, out, rd, rf, rb, st, ln)
+    exp = O.bev_pool_v2_fwd(depth, feat, rd, rf, rb, shape, st, ln, use_fma=True)
+    assert torch.equal(out, exp)                                  # same fmaf chain -> bit-exact
+    # backward: intervals over ranks_feat
+    order = torch.argsort(rf, stable=True)
+    rf2, rd2, rb2 = rf[order].contiguous(), rd[order].contiguous(), rb[order].contiguous()
+    st2, ln2 = O.intervals_from_sorted(rf2)
+    og = torch.randn(shape, generator=torch.Generator().manual_seed(3))
+    dg, fg = torch.zeros_like(depth), torch.zeros_like(feat)
+    E.pool_bwd(og, dg, fg, depth, feat, rd2, rf2, rb2, st2.contiguous(), ln2.contiguous())
+    edg, efg = O.bev_pool_v2_bwd(og, depth, feat, rd, rf, rb)
+    assert torch.equal(fg, efg)                                   # in-order fmaf chain
+    assert torch.allclose(dg, edg, atol=1e-5, rtol=1e-5)          # wave-tree vs serial channel sum
+
+
+@pytest.mark.parametrize('tv', [64, 128, 256])
+def test_pool_dense_matches_oracle(tv):
+    cfg, vt, coor, depth, feat = _case('TINY', 2)
+    rb, rd, rf, st, ln, ir, counts = E.rank_build(coor, *_grid3(vt))
+    B, Z, Y, X, C = vt.bev_feat_shape(2, cfg.channels)
+    code, out = E.pool_dense(depth, feat, rd, rf, rb, st, ln, counts, st.numel(), B, C, Z, Y, X, tv)
+    assert code == 0
+    erb, erd, erf, est, eln = vt.voxel_pooling_prepare_v2(coor)
+    exp = O.bev_pool_v2(depth, feat, erd, erf, erb, (B, Z, Y, X, C), est, eln, use_fma=True)
+    assert not torch.isnan(out).any()                             # every element written exactly once
+    assert torch.equal(out, exp)
+
+
+def test_pool_dense_rejects_unsupported():
+    cfg, vt, coor, depth, feat = _case('TINY', 1)
+    rb, rd, rf, st, ln, ir, counts = E.rank_build(coor, *_grid3(vt))
+    code, _ = E.pool_dense(depth, feat[..., :6].contiguous(), rd, rf, rb, st, ln, counts, st.numel(),
+                           1, 6, 4, 16, 16, 128)
+    assert code == -2                                             # FBBEV_E_UNSUPPORTED (C % 4 != 0)
+
+
+def test_msda_fwd_bwd_emulated():
+    from test_oracle_msda import CASES, make_case
+    for case in CASES[:3]:
+        value, ss, ls, loc, w = make_case(**case)
+        out = E.msda_fwd(value, ss, ls, loc, w)
+        assert torch.allclose(out, O.msda_fwd(value, ss, ls, loc, w), atol=1e-6, rtol=1e-6)
+        go = torch.randn(out.shape, generator=torch.Generator().manual_seed(1))
+        gv, gl, gw = E.msda_bwd(value, ss, ls, loc, w, go)
+        egv, egl, egw = O.msda_bwd(value, ss, ls, loc, w, go)
+        assert torch.allclose(gv, egv, atol=1e-5, rtol=1e-5)
+        assert torch.allclose(gl, egl, atol=1e-4, rtol=1e-4)
+        assert torch.allclose(gw, egw, atol=1e-5, rtol=1e-5)
+
+
+def test_pool_dense_partial_tiles_small_config():
+    """SMALL: 50x50x8 grid (YX=2500 is not a multiple of 64/128), C=20 (5 lanes per interval)."""
+    cfg, vt, coor, depth, feat = _case('SMALL', 1)
+    rb, rd, rf, st, ln, ir, counts = E.rank_build(coor, *_grid3(vt))
+    B, Z, Y, X, C = vt.bev_feat_shape(1, cfg.channels)
+    erb, erd, erf, est, eln = vt.voxel_pooling_prepare_v2(coor)
+    P, I = counts.tolist()
+    assert (P, I) == (erb.numel(), est.numel())
+    assert torch.equal(rb[:P], erb) and torch.equal(rd[:P], erd) and torch.equal(st[:I], est)
+    exp = O.bev_pool_v2(depth, feat, erd, erf, erb, (B, Z, Y, X, C), est, eln, use_fma=True)
+    for tv in (64, 128):
+        code, out = E.pool_dense(depth, feat, rd, rf, rb, st, ln, counts, st.numel(), B, C, Z, Y, X, tv)
+        assert code == 0 and not torch.isnan(out).any()
+        assert torch.equal(out, exp)
