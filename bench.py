@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py -- samples/s of the FB-OCC forward view-transformation hot path on MI355X.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W
+  N>1 is launched as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`
+  (one rank per GPU, RCCL via backend "nccl"); rank 0 prints ONE JSON line.
+
+Step   = one pass of the hot path (scope S2 of SURVEY 8d: get_lidar_coor -> voxel ranking ->
+         bev_pool_v2 into the dense (B,C,Z,Y,X) volume) over one batch of synthetic 6-camera samples,
+         BASELINE.json configs[1] shapes (6x256x704 in, 16x44 feature map, D=59, C=80, 200x200x16 grid).
+         Nothing is cached across steps: the index tensors are rebuilt every step, as the reference
+         does (view_transformer.py:628 disables its acceleration path).  Inputs are resident in HBM.
+Shard  = independent samples: each rank owns `--batch` samples (weak scaling), no data-path collective.
+value  = total samples all ranks processed / max-over-ranks wall time of the K timed steps.
+roofline = algorithmic HBM bytes of ONE bev_pool_v2 dense-forward launch (BASELINE.md section 4 /
+         SURVEY 8d: depth + feat + 4*(3P+2I) + dense output, each once) / its mean launch duration
+         from HIP events recorded on the launch stream inside the timed region, vs 8 TB/s.
+cpu_baseline = the same scope in pure CPU PyTorch (oracle restatement of the reference ops), rank 0,
+         N=1 only, on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--batch', type=int, default=16, help='samples per GPU per step (weak scaling)')
+    ap.add_argument('--config', default='BL2')
+    ap.add_argument('--tile-voxels', type=int, default=128)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=15.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, seconds):
+    """Pure-CPU PyTorch restatement of the same scope (oracle.ViewTransformerOracle + index_add
+    pooling), timed on this host's cores on a bounded sample (1 sample per iteration)."""
+    import torch
+    from fb_bev_amd import synthetic as S
+    from oracle import oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    ovt = O.ViewTransformerOracle(cfg.grid_config, cfg.input_size, cfg.downsample)
+    cam = S.camera_rig(cfg, 1, seed=0, bda_aug=True)
+    depth, ctx = S.depth_and_context(cfg, 1, seed=0)
+    shape = ovt.bev_feat_shape(1, cfg.channels)
+
+    def one():
+        coor = ovt.get_lidar_coor(*cam)
+        rb, rd, rf, st, ln = ovt.voxel_pooling_prepare_v2(coor)
+        feat = ctx.permute(0, 1, 3, 4, 2).contiguous()
+        return O.bev_pool_v2_torch(depth, feat, rd, rf, rb, shape)
+    one()
+    one()
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        one()
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds or n >= 200:
+            break
+    return {'value': n / dt, 'unit': 'samples/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'{n} x 1-sample {cfg.name} passes in {dt:.1f}s (torch {torch.__version__} CPU ops: '
+                      'inverse/matmul geometry, argsort ranking, index_add pooling, permute)'}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from fb_bev_amd import _capi
+    from fb_bev_amd import synthetic as S
+    from fb_bev_amd.view_transformer import LSSViewTransformerFunction3D, _IndexSet
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    dev = torch.device('cuda', local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    cfg = S.CONFIGS[args.config]
+    B = args.batch
+    # every rank gets its own samples (different seeds => different rigs/augmentations)
+    cam = [t.to(dev) for t in S.camera_rig(cfg, B, seed=1000 * rank, bda_aug=True)]
+    depth, ctx = S.depth_and_context(cfg, B, seed=1000 * rank)
+    depth, ctx = depth.to(dev), ctx.to(dev)
+    vt = LSSViewTransformerFunction3D(cfg.grid_config, cfg.input_size, cfg.downsample,
+                                      tile_voxels=args.tile_voxels).to(dev)
+    Z, Y, X = vt.grid_zyx
+    C = cfg.channels
+    tile_ws = vt._tile_ws(dev, B)
+    out = torch.empty((B, C, Z, Y, X), dtype=torch.float32, device=dev)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(args.steps)]
+
+    def step(i=None):
+        coor = vt.get_lidar_coor(*cam)                              # fbbev_lidar_coor
+        idx = vt.build_index(coor)                                  # fbbev_rank_build (device counts)
+        feat = ctx.permute(0, 1, 3, 4, 2).contiguous()              # (B,N,H,W,C), as bev_pool.py:18
+        _capi.pool_tile_index(idx.ranks_bev, idx.interval_starts, idx.counts[1:2], idx.n, B, Z, Y, X,
+                              tile_ws, args.tile_voxels)
+        if i is not None:
+            ev[i][0].record()
+        _capi.bev_pool_v2_dense_fwd(depth, feat, idx.ranks_depth, idx.ranks_feat, idx.ranks_bev,
+                                    idx.interval_starts, idx.interval_lengths, B, C, Z, Y, X, out, tile_ws,
+                                    args.tile_voxels)
+        if i is not None:
+            ev[i][1].record()
+        return idx
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        idx = step()
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        idx = step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)
+    P, I = idx.counts.tolist()
+    D = cfg.D
+    H, W = cfg.feat_hw
+    algo_bytes = 4 * B * cfg.n_cams * D * H * W + 4 * B * cfg.n_cams * H * W * C + 4 * (3 * P + 2 * I) + \
+        4 * B * Z * Y * X * C
+    achieved = algo_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    traffic = None
+    tj = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    if os.path.exists(tj):
+        try:
+            rec = json.load(open(tj))
+            key = f'{cfg.name}_B{B}_tv{args.tile_voxels}'
+            traffic = rec.get(key, {}).get('hbm_bytes_per_launch')
+        except Exception:
+            traffic = None
+
+    if rank == 0:
+        total = B * world * args.steps
+        res = {
+            'metric': 'multi-cam samples/sec (forward view transformation: lift + voxel ranking + bev_pool_v2)',
+            'value': total / elapsed, 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'FB-OCC forward projection, BASELINE configs[1] ({cfg.name}): 6x256x704 in, '
+                                   f'feat {H}x{W}, D={D}, C={C}, grid {X}x{Y}x{Z}; index tensors rebuilt every step',
+                       'samples_per_gpu': B, 'global_batch': B * world, 'points_kept': P, 'intervals': I,
+                       'tile_voxels': args.tile_voxels, 'parallelism': f'dp{world} (independent samples, no collective)'},
+            'roofline': {'kernel': 'k_pool_fwd_dense', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
+                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         'algorithmic_bytes_per_launch': algo_bytes, 'kernel_ms': kern_ms},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline(cfg, args.cpu_seconds)
+            res['gpu_over_cpu'] = res['value'] / res['cpu_baseline']['value']
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -18,11 +18,13 @@ SIGNATURES = {
     'fbbev_version': (c_int, []),
     'fbbev_bev_pool_v2_fwd': (c_int, [c_int, c_int] + [c_void_p] * 8 + [c_void_p]),
     'fbbev_bev_pool_v2_bwd': (c_int, [c_int, c_int] + [c_void_p] * 10 + [c_void_p]),
+    'fbbev_lidar_coor': (c_int, [c_void_p] * 9 + [c_int] * 5 + [c_void_p, c_void_p]),
     'fbbev_rank_workspace_bytes': (c_size_t, [c_int64]),
     'fbbev_rank_build': (c_int, [c_void_p] + [c_int] * 5 + [c_void_p] * 3 + [c_void_p] * 7 +
                          [c_void_p, c_size_t, c_void_p]),
     'fbbev_pool_dense_workspace_bytes': (c_size_t, [c_int] * 4),
-    'fbbev_bev_pool_v2_dense_fwd': (c_int, [c_void_p] * 8 + [c_int] * 6 + [c_void_p, c_void_p, c_size_t,
+    'fbbev_pool_tile_index': (c_int, [c_void_p] * 3 + [c_int] * 6 + [c_void_p, c_size_t, c_void_p]),
+    'fbbev_bev_pool_v2_dense_fwd': (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t,
                                             c_int, c_void_p]),
     'fbbev_msda_fwd': (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_void_p, c_void_p]),
     'fbbev_msda_bwd': (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p] * 3 + [c_void_p]),
@@ -71,6 +73,13 @@ def _dev(t, dtype, name):
     return c_void_p(t.data_ptr())
 
 
+def _on(t):
+    """Device guard for the tensor's GPU (the OptionalCUDAGuard of bev_pool.cpp:40,86)."""
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise FbbevError('expected a GPU tensor (no CPU fallback in fb_bev_amd)')
+    return torch.cuda.device(t.device)
+
+
 def _stream():
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -82,7 +91,7 @@ def bev_pool_v2_fwd(depth, feat, out, ranks_depth, ranks_feat, ranks_bev, interv
                     interval_lengths):
     c = feat.shape[-1]
     n = interval_starts.numel()
-    with torch.cuda.device(depth.device):
+    with _on(depth):
         _check(lib().fbbev_bev_pool_v2_fwd(
             c, n, _dev(depth, F32, 'depth'), _dev(feat, F32, 'feat'),
             _dev(ranks_depth, I32, 'ranks_depth'), _dev(ranks_feat, I32, 'ranks_feat'),
@@ -95,13 +104,24 @@ def bev_pool_v2_bwd(out_grad, depth_grad, feat_grad, depth, feat, ranks_depth, r
                     ranks_bev, interval_starts, interval_lengths):
     c = out_grad.shape[-1]
     n = interval_starts.numel()
-    with torch.cuda.device(out_grad.device):
+    with _on(out_grad):
         _check(lib().fbbev_bev_pool_v2_bwd(
             c, n, _dev(out_grad, F32, 'out_grad'), _dev(depth, F32, 'depth'), _dev(feat, F32, 'feat'),
             _dev(ranks_depth, I32, 'ranks_depth'), _dev(ranks_feat, I32, 'ranks_feat'),
             _dev(ranks_bev, I32, 'ranks_bev'), _dev(interval_starts, I32, 'interval_starts'),
             _dev(interval_lengths, I32, 'interval_lengths'), _dev(depth_grad, F32, 'depth_grad'),
             _dev(feat_grad, F32, 'feat_grad'), _stream()), 'fbbev_bev_pool_v2_bwd')
+
+
+def lidar_coor(xs, ys, ds, rots, trans, intrins, post_rots, post_trans, bda, coor):
+    B, N = trans.shape[:2]
+    D, H, W = ds.numel(), ys.numel(), xs.numel()
+    with _on(coor):
+        _check(lib().fbbev_lidar_coor(
+            _dev(xs, F32, 'xs'), _dev(ys, F32, 'ys'), _dev(ds, F32, 'ds'), _dev(rots, F32, 'rots'),
+            _dev(trans, F32, 'trans'), _dev(intrins, F32, 'intrins'), _dev(post_rots, F32, 'post_rots'),
+            _dev(post_trans, F32, 'post_trans'), _dev(bda, F32, 'bda'), B, N, D, H, W,
+            _dev(coor, F32, 'coor'), _stream()), 'fbbev_lidar_coor')
 
 
 def rank_workspace_bytes(n_points):
@@ -115,7 +135,7 @@ def rank_build(coor, lower3, interval3, grid_size3, ranks_bev, ranks_depth, rank
     assert three == 3
     arr = ctypes.c_float * 3
     lo, it, gs = arr(*lower3), arr(*interval3), arr(*grid_size3)
-    with torch.cuda.device(coor.device):
+    with _on(coor):
         _check(lib().fbbev_rank_build(
             _dev(coor, F32, 'coor'), B, N, D, H, W, ctypes.cast(lo, c_void_p), ctypes.cast(it, c_void_p),
             ctypes.cast(gs, c_void_p), _dev(ranks_bev, I32, 'ranks_bev'),
@@ -130,16 +150,24 @@ def pool_dense_workspace_bytes(B, Z, Y, X):
     return int(lib().fbbev_pool_dense_workspace_bytes(B, Z, Y, X))
 
 
+def pool_tile_index(ranks_bev, interval_starts, n_intervals_dev, n_intervals_max, B, Z, Y, X, tile_ws,
+                    tile_voxels=128):
+    with _on(ranks_bev):
+        _check(lib().fbbev_pool_tile_index(
+            _dev(ranks_bev, I32, 'ranks_bev'), _dev(interval_starts, I32, 'interval_starts'),
+            _dev(n_intervals_dev, I32, 'n_intervals_dev'), int(n_intervals_max), B, Z, Y, X,
+            int(tile_voxels), c_void_p(tile_ws.data_ptr()), tile_ws.numel() * tile_ws.element_size(),
+            _stream()), 'fbbev_pool_tile_index')
+
+
 def bev_pool_v2_dense_fwd(depth, feat, ranks_depth, ranks_feat, ranks_bev, interval_starts,
-                          interval_lengths, n_intervals_dev, n_intervals_max, B, C, Z, Y, X, out,
-                          tile_ws, tile_voxels=128):
-    with torch.cuda.device(depth.device):
+                          interval_lengths, B, C, Z, Y, X, out, tile_ws, tile_voxels=128):
+    with _on(depth):
         _check(lib().fbbev_bev_pool_v2_dense_fwd(
             _dev(depth, F32, 'depth'), _dev(feat, F32, 'feat'), _dev(ranks_depth, I32, 'ranks_depth'),
             _dev(ranks_feat, I32, 'ranks_feat'), _dev(ranks_bev, I32, 'ranks_bev'),
             _dev(interval_starts, I32, 'interval_starts'), _dev(interval_lengths, I32, 'interval_lengths'),
-            _dev(n_intervals_dev, I32, 'n_intervals_dev'), int(n_intervals_max), B, C, Z, Y, X,
-            _dev(out, F32, 'out'), c_void_p(tile_ws.data_ptr()),
+            B, C, Z, Y, X, _dev(out, F32, 'out'), c_void_p(tile_ws.data_ptr()),
             tile_ws.numel() * tile_ws.element_size(), int(tile_voxels), _stream()),
             'fbbev_bev_pool_v2_dense_fwd')
 
@@ -147,7 +175,7 @@ def bev_pool_v2_dense_fwd(depth, feat, ranks_depth, ranks_feat, ranks_bev, inter
 def msda_fwd(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, out):
     B, S, M, Dh = value.shape
     _, Q, _, L, P, _ = sampling_loc.shape
-    with torch.cuda.device(value.device):
+    with _on(value):
         _check(lib().fbbev_msda_fwd(
             _dev(value, F32, 'value'), _dev(spatial_shapes, I64, 'spatial_shapes'),
             _dev(level_start_index, I64, 'level_start_index'), _dev(sampling_loc, F32, 'sampling_loc'),
@@ -159,7 +187,7 @@ def msda_bwd(value, spatial_shapes, level_start_index, sampling_loc, attn_weight
              grad_value, grad_sampling_loc, grad_attn_weight):
     B, S, M, Dh = value.shape
     _, Q, _, L, P, _ = sampling_loc.shape
-    with torch.cuda.device(value.device):
+    with _on(value):
         _check(lib().fbbev_msda_bwd(
             _dev(value, F32, 'value'), _dev(spatial_shapes, I64, 'spatial_shapes'),
             _dev(level_start_index, I64, 'level_start_index'), _dev(sampling_loc, F32, 'sampling_loc'),

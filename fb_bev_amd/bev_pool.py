@@ -1,0 +1,68 @@
+"""Host-side mirror of mmdet3d/ops/bev_pool_v2/bev_pool.py (QuickCumsumCuda :11-80,
+bev_pool_v2 :83-89): same names, argument meaning and autograd contract (gradients for `depth`
+and `feat` only), running on the HIP kernels of libfbbev_hip.so.
+"""
+import torch
+
+from . import bev_pool_v2_ext
+
+__all__ = ['bev_pool_v2', 'QuickCumsumCuda', 'intervals_over']
+
+
+def intervals_over(sorted_keys):
+    """Run starts / lengths over a sorted 1-D key tensor (the construction of bev_pool.py:47-54
+    and view_transformer.py:593-602).  Needs one host sync (nonzero) -- the fused path in
+    view_transformer.LiftSplat avoids it; this exists for the reference-compatible entry."""
+    n = sorted_keys.shape[0]
+    head = torch.ones(n, dtype=torch.bool, device=sorted_keys.device)
+    head[1:] = sorted_keys[1:] != sorted_keys[:-1]
+    starts = head.nonzero().squeeze(1).int()
+    lengths = torch.empty_like(starts)
+    if starts.numel():
+        lengths[:-1] = starts[1:] - starts[:-1]
+        lengths[-1] = n - starts[-1]
+    return starts, lengths
+
+
+class QuickCumsumCuda(torch.autograd.Function):
+    """bev_pool.py:11-80.  forward -> (B,Z,Y,X,C) with only non-empty voxels written."""
+
+    @staticmethod
+    def forward(ctx, depth, feat, ranks_depth, ranks_feat, ranks_bev, bev_feat_shape,
+                interval_starts, interval_lengths):
+        depth = depth.contiguous().float()
+        feat = feat.contiguous().float()
+        ranks_bev = ranks_bev.contiguous().int()
+        ranks_depth = ranks_depth.contiguous().int()
+        ranks_feat = ranks_feat.contiguous().int()
+        interval_lengths = interval_lengths.contiguous().int()
+        interval_starts = interval_starts.contiguous().int()
+        out = feat.new_zeros(bev_feat_shape)
+        bev_pool_v2_ext.bev_pool_v2_forward(depth, feat, out, ranks_depth, ranks_feat, ranks_bev,
+                                            interval_lengths, interval_starts)
+        ctx.save_for_backward(ranks_bev, depth, feat, ranks_feat, ranks_depth)
+        return out
+
+    @staticmethod
+    def backward(ctx, out_grad):
+        ranks_bev, depth, feat, ranks_feat, ranks_depth = ctx.saved_tensors
+        # bev_pool.py:44-54: regroup the points by feature pixel.  Stable sort => deterministic
+        # summation order (the reference's argsort is unstable).
+        ranks_feat, order = torch.sort(ranks_feat, stable=True)
+        ranks_depth = ranks_depth[order].contiguous()
+        ranks_bev = ranks_bev[order].contiguous()
+        ranks_feat = ranks_feat.contiguous()
+        starts_bp, lengths_bp = intervals_over(ranks_feat)
+        depth_grad = depth.new_zeros(depth.shape)
+        feat_grad = feat.new_zeros(feat.shape)
+        bev_pool_v2_ext.bev_pool_v2_backward(out_grad.contiguous(), depth_grad, feat_grad, depth, feat,
+                                             ranks_depth, ranks_feat, ranks_bev, lengths_bp, starts_bp)
+        return depth_grad, feat_grad, None, None, None, None, None, None
+
+
+def bev_pool_v2(depth, feat, ranks_depth, ranks_feat, ranks_bev, bev_feat_shape, interval_starts,
+                interval_lengths):
+    """bev_pool.py:83-89 -> (B,C,Z,Y,X) contiguous."""
+    x = QuickCumsumCuda.apply(depth, feat, ranks_depth, ranks_feat, ranks_bev, bev_feat_shape,
+                              interval_starts, interval_lengths)
+    return x.permute(0, 4, 1, 2, 3).contiguous()

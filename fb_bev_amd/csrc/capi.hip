@@ -4,6 +4,7 @@
 #include "pool_kernels.h"
 #include "rank_kernels.h"
 #include "msda_kernels.h"
+#include "geom_kernels.h"
 #include "../../include/fbbev.h"
 
 #define FBBEV_CHECK_LAUNCH()                      \
@@ -71,6 +72,23 @@ extern "C" int fbbev_bev_pool_v2_bwd(int c, int n_intervals, const float* out_gr
     return 0;
 }
 
+// ------------------------------------------------------------------------------ frustum geometry
+extern "C" int fbbev_lidar_coor(const float* xs, const float* ys, const float* ds, const float* rots,
+                                const float* trans, const float* intrins, const float* post_rots,
+                                const float* post_trans, const float* bda, int B, int N, int D, int H,
+                                int W, float* coor, fbbev_stream_t stream_) {
+    if (B <= 0 || N <= 0 || D <= 0 || H <= 0 || W <= 0) return FBBEV_E_BADARG;
+    if (!xs || !ys || !ds || !rots || !trans || !intrins || !post_rots || !post_trans || !bda || !coor)
+        return FBBEV_E_BADARG;
+    const long long dhw = (long long)D * H * W;
+    const long long chunks = (dhw + 255) / 256;
+    if (chunks * B * N >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
+    FBBEV_LAUNCH(k_lidar_coor, chunks * B * N, 256, 0, (fbbev_rt_stream)stream_, xs, ys, ds, rots, trans,
+                 intrins, post_rots, post_trans, bda, N, D, H, W, (int)chunks, coor);
+    FBBEV_CHECK_LAUNCH();
+    return 0;
+}
+
 // ------------------------------------------------------------------------------ voxel ranking
 static inline int key_bits(long long total_voxels) {
     int bits = 1;
@@ -84,14 +102,16 @@ struct rank_ws_layout {
     int n_blocks;
 };
 
-static rank_ws_layout rank_layout(long long n) {
+static rank_ws_layout rank_layout(long long n, bool query_sort_temp) {
     rank_ws_layout L;
     L.n_blocks = (int)((n + FBBEV_RANK_CHUNK - 1) / FBBEV_RANK_CHUNK);
     size_t off = 0;
     L.keys_in = off; off = align_up(off + (size_t)n * 4, 256);
     L.vals_in = off; off = align_up(off + (size_t)n * 4, 256);
     L.block_counts = off; off = align_up(off + (size_t)(L.n_blocks + 1) * 4, 256);
-    L.sort_temp_bytes = fbbev_rt_sort_pairs_temp_bytes((size_t)n, 32);
+    // the size query runs only in fbbev_rank_workspace_bytes; the launch path hands the sort whatever
+    // is left of the caller's workspace
+    L.sort_temp_bytes = query_sort_temp ? fbbev_rt_sort_pairs_temp_bytes((size_t)n, 32) : 0;
     L.sort_temp = off; off = align_up(off + L.sort_temp_bytes, 256);
     L.total = off;
     return L;
@@ -99,7 +119,7 @@ static rank_ws_layout rank_layout(long long n) {
 
 extern "C" size_t fbbev_rank_workspace_bytes(int64_t n_points) {
     if (n_points <= 0) return 256;
-    return rank_layout(n_points).total;
+    return rank_layout(n_points, true).total;
 }
 
 extern "C" int fbbev_rank_build(const float* coor, int B, int N, int D, int H, int W,
@@ -114,8 +134,8 @@ extern "C" int fbbev_rank_build(const float* coor, int B, int N, int D, int H, i
     const long long n = (long long)B * N * D * H * W;
     if (n >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
     fbbev_rt_stream stream = (fbbev_rt_stream)stream_;
-    const rank_ws_layout L = rank_layout(n);
-    if (workspace_bytes < L.total) return FBBEV_E_WORKSPACE;
+    const rank_ws_layout L = rank_layout(n, false);
+    if (workspace_bytes < L.total + 256) return FBBEV_E_WORKSPACE;
     unsigned char* ws = static_cast<unsigned char*>(workspace);
     unsigned int* keys_in = reinterpret_cast<unsigned int*>(ws + L.keys_in);
     unsigned int* vals_in = reinterpret_cast<unsigned int*>(ws + L.vals_in);
@@ -141,7 +161,7 @@ extern "C" int fbbev_rank_build(const float* coor, int B, int N, int D, int H, i
     if (kb > 8192) kb = 8192;
     FBBEV_LAUNCH(k_rank_keys, kb, 256, 0, stream, coor, n, n / B, gp, sentinel, keys_in, vals_in);
     FBBEV_CHECK_LAUNCH();
-    e = fbbev_rt_sort_pairs(ws + L.sort_temp, L.sort_temp_bytes, keys_in,
+    e = fbbev_rt_sort_pairs(ws + L.sort_temp, workspace_bytes - L.sort_temp, keys_in,
                             reinterpret_cast<unsigned int*>(ranks_bev), vals_in,
                             reinterpret_cast<unsigned int*>(ranks_depth), (size_t)n, bits, stream);
     if (e) return e;
@@ -174,17 +194,34 @@ extern "C" size_t fbbev_pool_dense_workspace_bytes(int B, int Z, int Y, int X) {
     return align_up((size_t)(tiles + 2) * 4, 256);
 }
 
+extern "C" int fbbev_pool_tile_index(const int32_t* ranks_bev, const int32_t* interval_starts,
+                                     const int32_t* n_intervals_dev, int n_intervals_max, int B, int Z,
+                                     int Y, int X, int tile_voxels, void* tile_ws, size_t tile_ws_bytes,
+                                     fbbev_stream_t stream_) {
+    if (B <= 0 || Z <= 0 || Y <= 0 || X <= 0 || n_intervals_max < 0) return FBBEV_E_BADARG;
+    if (!ranks_bev || !interval_starts || !n_intervals_dev || !tile_ws) return FBBEV_E_BADARG;
+    const long long yx = (long long)Y * X;
+    if ((long long)B * Z * yx >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
+    const int TV = pick_tile(tile_voxels);
+    const int tiles_per_plane = (int)((yx + TV - 1) / TV);
+    const long long n_tiles = (long long)B * Z * tiles_per_plane;
+    if (tile_ws_bytes < (size_t)(n_tiles + 1) * 4) return FBBEV_E_WORKSPACE;
+    FBBEV_LAUNCH(k_tile_lower_bound, (n_tiles + 1 + 255) / 256, 256, 0, (fbbev_rt_stream)stream_,
+                 (int)n_tiles, tiles_per_plane, (int)yx, TV, ranks_bev, interval_starts, n_intervals_dev,
+                 n_intervals_max, static_cast<int*>(tile_ws));
+    FBBEV_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int fbbev_bev_pool_v2_dense_fwd(const float* depth, const float* feat,
                                            const int32_t* ranks_depth, const int32_t* ranks_feat,
                                            const int32_t* ranks_bev, const int32_t* interval_starts,
-                                           const int32_t* interval_lengths,
-                                           const int32_t* n_intervals_dev, int n_intervals_max, int B,
-                                           int C, int Z, int Y, int X, float* out, void* tile_ws,
-                                           size_t tile_ws_bytes, int tile_voxels,
-                                           fbbev_stream_t stream_) {
-    if (B <= 0 || C <= 0 || Z <= 0 || Y <= 0 || X <= 0 || n_intervals_max < 0) return FBBEV_E_BADARG;
+                                           const int32_t* interval_lengths, int B, int C, int Z, int Y,
+                                           int X, float* out, const void* tile_ws, size_t tile_ws_bytes,
+                                           int tile_voxels, fbbev_stream_t stream_) {
+    if (B <= 0 || C <= 0 || Z <= 0 || Y <= 0 || X <= 0) return FBBEV_E_BADARG;
     if (!depth || !feat || !ranks_depth || !ranks_feat || !ranks_bev || !interval_starts ||
-        !interval_lengths || !n_intervals_dev || !out || !tile_ws) return FBBEV_E_BADARG;
+        !interval_lengths || !out || !tile_ws) return FBBEV_E_BADARG;
     const long long yx = (long long)Y * X;
     if (C % 4 != 0 || C > 256 || yx % 4 != 0 || !aligned16(out) || !aligned16(feat)) return FBBEV_E_UNSUPPORTED;
     if ((long long)B * Z * yx >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
@@ -193,19 +230,21 @@ extern "C" int fbbev_bev_pool_v2_dense_fwd(const float* depth, const float* feat
     const int tiles_per_plane = (int)((yx + TV - 1) / TV);
     const long long n_tiles = (long long)B * Z * tiles_per_plane;
     if (tile_ws_bytes < (size_t)(n_tiles + 1) * 4) return FBBEV_E_WORKSPACE;
-    int* tile_istart = static_cast<int*>(tile_ws);
-    FBBEV_LAUNCH(k_tile_lower_bound, (n_tiles + 1 + 255) / 256, 256, 0, stream, (int)n_tiles,
-                 tiles_per_plane, (int)yx, TV, ranks_bev, interval_starts, n_intervals_dev,
-                 n_intervals_max, tile_istart);
-    FBBEV_CHECK_LAUNCH();
+    const int* tile_istart = static_cast<const int*>(tile_ws);
     const size_t lds = (size_t)C * (TV + 4) * sizeof(float);
 #define FBBEV_DENSE(TVV)                                                                              \
     FBBEV_LAUNCH(k_pool_fwd_dense<TVV>, n_tiles, 256, lds, stream, C, Z, (int)yx, tiles_per_plane,    \
                  depth, feat, ranks_depth, ranks_feat, ranks_bev, interval_starts, interval_lengths, \
-                 (const int*)tile_istart, out)
+                 tile_istart, out)
     if (TV == 64) FBBEV_DENSE(64);
     else if (TV == 128) FBBEV_DENSE(128);
-    else FBBEV_DENSE(256);
+    else {
+        if (lds > 64 * 1024) {  // > 64 KiB of dynamic LDS must be opted into (160 KiB per CU on gfx950)
+            int e = fbbev_rt_allow_dyn_lds((const void*)k_pool_fwd_dense<256>, lds);
+            if (e) return e;
+        }
+        FBBEV_DENSE(256);
+    }
 #undef FBBEV_DENSE
     FBBEV_CHECK_LAUNCH();
     return 0;

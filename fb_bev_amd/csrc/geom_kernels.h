@@ -1,0 +1,67 @@
+// geom_kernels.h -- frustum lift geometry: image-plane frustum -> ego-frame points.
+//
+// Replaces LSSViewTransformerFunction3D.get_lidar_coor
+// (fbbev/view_transformation/forward_projection/view_transformer.py:458-498): in the reference two
+// batched 3x3 torch.inverse calls, three broadcast matmuls and a cat, ~8 launches that materialise
+// three (B,N,D,H,W,3) temporaries.  Here one kernel: the per-camera 3x3 algebra is done once per
+// workgroup in LDS, then every lane transforms points with the same operation order as the
+// reference (subtract post_trans, inv(post_rots)*p, scale xy by depth, (rots*inv(K))*p + trans,
+// bda*p).  The 3x3 inverses are closed-form (adjugate / determinant) instead of LU, so `coor` can
+// differ from the torch result in the last ulps: the bit-exactness contract of the path is pinned
+// at voxel_pooling_prepare_v2's INPUT.
+#pragma once
+#include "rt.h"
+
+__device__ __forceinline__ void fbbev_inv3(const float* m, float* o) {
+    const float a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
+    const float A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g;
+    const float det = a * A + b * B + c * C;
+    const float r = 1.0f / det;
+    o[0] = A * r; o[1] = -(b * i - c * h) * r; o[2] = (b * f - c * e) * r;
+    o[3] = B * r; o[4] = (a * i - c * g) * r;  o[5] = -(a * f - c * d) * r;
+    o[6] = C * r; o[7] = -(a * h - b * g) * r; o[8] = (a * e - b * d) * r;
+}
+
+__device__ __forceinline__ void fbbev_mat3(const float* a, const float* b, float* o) {
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c)
+            o[r * 3 + c] = a[r * 3] * b[c] + a[r * 3 + 1] * b[3 + c] + a[r * 3 + 2] * b[6 + c];
+}
+
+// grid: (ceil(D*H*W / 256), B*N) flattened into blockIdx.x = cam * chunks + chunk
+__global__ void __launch_bounds__(256)
+k_lidar_coor(const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ ds,
+             const float* __restrict__ rots, const float* __restrict__ trans,
+             const float* __restrict__ intrins, const float* __restrict__ post_rots,
+             const float* __restrict__ post_trans, const float* __restrict__ bda, int N, int D, int H,
+             int W, int chunks, float* __restrict__ coor) {
+    __shared__ float m[9 + 9 + 9 + 3 + 3];  // inv(post_rots), rots*inv(K), bda, post_trans, trans
+    const int cam = blockIdx.x / chunks, chunk = blockIdx.x - cam * chunks;
+    const int b = cam / N;
+    if (threadIdx.x == 0) {
+        float ik[9];
+        fbbev_inv3(post_rots + cam * 9, m);
+        fbbev_inv3(intrins + cam * 9, ik);
+        fbbev_mat3(rots + cam * 9, ik, m + 9);
+        for (int j = 0; j < 9; ++j) m[18 + j] = bda[b * 9 + j];
+        for (int j = 0; j < 3; ++j) { m[27 + j] = post_trans[cam * 3 + j]; m[30 + j] = trans[cam * 3 + j]; }
+    }
+    __syncthreads();
+    const int dhw = D * H * W;
+    const int i = chunk * 256 + threadIdx.x;
+    if (i < dhw) {
+        const int w = i % W, h = (i / W) % H, d = i / (W * H);
+        float px = xs[w] - m[27], py = ys[h] - m[28], pz = ds[d] - m[29];
+        float qx = m[0] * px + m[1] * py + m[2] * pz;
+        float qy = m[3] * px + m[4] * py + m[5] * pz;
+        float qz = m[6] * px + m[7] * py + m[8] * pz;
+        qx *= qz; qy *= qz;
+        px = m[9] * qx + m[10] * qy + m[11] * qz + m[30];
+        py = m[12] * qx + m[13] * qy + m[14] * qz + m[31];
+        pz = m[15] * qx + m[16] * qy + m[17] * qz + m[32];
+        float* o = coor + ((long long)cam * dhw + i) * 3;
+        o[0] = m[18] * px + m[19] * py + m[20] * pz;
+        o[1] = m[21] * px + m[22] * py + m[23] * pz;
+        o[2] = m[24] * px + m[25] * py + m[26] * pz;
+    }
+}

@@ -17,6 +17,10 @@ static inline int fbbev_rt_memset_async(void* p, int byte, size_t n, fbbev_rt_st
     return (int)hipMemsetAsync(p, byte, n, s);
 }
 
+static inline int fbbev_rt_allow_dyn_lds(const void* kern, size_t bytes) {
+    return (int)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
 // dynamic LDS carve-out; base is 16-byte aligned (no static __shared__ precedes it in any kernel
 // that uses it -- cdna_hip_programming.md Guideline 17)
 extern __shared__ __attribute__((aligned(16))) unsigned char fbbev_dyn_lds_raw[];

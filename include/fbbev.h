@@ -63,6 +63,17 @@ int fbbev_bev_pool_v2_bwd(int c, int n_intervals, const float* out_grad, const f
  * Fused forward-projection entry points (additive; same arithmetic, no host sync)
  * -------------------------------------------------------------------------------------------- */
 
+/* Replaces LSSViewTransformerFunction3D.get_lidar_coor
+ *   -- fbbev/view_transformation/forward_projection/view_transformer.py:458-498.
+ * xs (W), ys (H), ds (D): the three axes of the frustum template (create_frustum, :389-411);
+ * rots/intrins/post_rots (B,N,3,3), trans/post_trans (B,N,3), bda (B,3,3); coor (B,N,D,H,W,3).
+ * Closed-form 3x3 inverses: coor may differ from torch.inverse-based results in the last ulps
+ * (the bit-exact contract starts at fbbev_rank_build's input). */
+int fbbev_lidar_coor(const float* xs, const float* ys, const float* ds, const float* rots,
+                     const float* trans, const float* intrins, const float* post_rots,
+                     const float* post_trans, const float* bda, int B, int N, int D, int H, int W,
+                     float* coor, fbbev_stream_t stream);
+
 /* Replaces LSSViewTransformerFunction3D.voxel_pooling_prepare_v2
  *   -- fbbev/view_transformation/forward_projection/view_transformer.py:547-605
  *   (~17 torch launches, an argsort and >=4 host syncs in the reference).
@@ -82,17 +93,24 @@ int fbbev_rank_build(const float* coor, int B, int N, int D, int H, int W, const
                      void* workspace, size_t workspace_bytes, fbbev_stream_t stream);
 
 /* Fused replacement of  feat.new_zeros + bev_pool_v2_forward + permute(0,4,1,2,3).contiguous()
- *   -- bev_pool.py:24-35,88.
- * Writes EVERY element of out (B,C,Z,Y,X) exactly once (zeros for empty voxels) in the final
- * layout, so `out` need not be pre-zeroed.  n_intervals_dev points at the device-side interval
- * count (counts+1 of fbbev_rank_build) so no host sync is needed; n_intervals_max bounds it.
- * tile_ws: workspace of fbbev_pool_dense_workspace_bytes(B,Z,Y,X) bytes. */
+ *   -- bev_pool.py:24-35,88.  Two launches:
+ * fbbev_pool_tile_index: for every tile of `tile_voxels` (64/128/256) consecutive voxels of a (b,z)
+ *   plane, the first interval whose rank falls in it (parallel lower bound).  n_intervals_dev points
+ *   at the device-side interval count (counts+1 of fbbev_rank_build): no host sync.
+ * fbbev_bev_pool_v2_dense_fwd: writes EVERY element of out (B,C,Z,Y,X) exactly once (zeros for empty
+ *   voxels) in the final layout, so `out` need not be pre-zeroed.  Same in-order fmaf chains as
+ *   fbbev_bev_pool_v2_fwd => identical bits.  Requires C % 4 == 0, (Y*X) % 4 == 0, 16-byte aligned
+ *   feat/out (else FBBEV_E_UNSUPPORTED; callers fall back to fbbev_bev_pool_v2_fwd).
+ * tile_ws: fbbev_pool_dense_workspace_bytes(B,Z,Y,X) bytes, shared by the two calls. */
 size_t fbbev_pool_dense_workspace_bytes(int B, int Z, int Y, int X);
+int fbbev_pool_tile_index(const int32_t* ranks_bev, const int32_t* interval_starts,
+                          const int32_t* n_intervals_dev, int n_intervals_max, int B, int Z, int Y,
+                          int X, int tile_voxels, void* tile_ws, size_t tile_ws_bytes,
+                          fbbev_stream_t stream);
 int fbbev_bev_pool_v2_dense_fwd(const float* depth, const float* feat, const int32_t* ranks_depth,
                                 const int32_t* ranks_feat, const int32_t* ranks_bev,
-                                const int32_t* interval_starts, const int32_t* interval_lengths,
-                                const int32_t* n_intervals_dev, int n_intervals_max, int B, int C,
-                                int Z, int Y, int X, float* out_bczyx, void* tile_ws,
+                                const int32_t* interval_starts, const int32_t* interval_lengths, int B,
+                                int C, int Z, int Y, int X, float* out_bczyx, const void* tile_ws,
                                 size_t tile_ws_bytes, int tile_voxels, fbbev_stream_t stream);
 
 /* ----------------------------------------------------------------------------------------------

@@ -62,9 +62,10 @@ def pool_bwd(out_grad, depth_grad, feat_grad, depth, feat, rd, rf, rb, st, ln):
 def pool_dense(depth, feat, rd, rf, rb, st, ln, counts, n_max, B, C, Z, Y, X, tile_voxels):
     out = torch.full((B, C, Z, Y, X), float('nan'))
     ws = torch.zeros(lib().fbbev_pool_dense_workspace_bytes(B, Z, Y, X), dtype=torch.uint8)
+    ok(lib().fbbev_pool_tile_index(p(rb), p(st), c_void_p(counts.data_ptr() + 4), n_max, B, Z, Y, X,
+                                   tile_voxels, p(ws), ws.numel(), None))
     code = lib().fbbev_bev_pool_v2_dense_fwd(p(depth), p(feat), p(rd), p(rf), p(rb), p(st), p(ln),
-                                             c_void_p(counts.data_ptr() + 4), n_max, B, C, Z, Y, X,
-                                             p(out), p(ws), ws.numel(), tile_voxels, None)
+                                             B, C, Z, Y, X, p(out), p(ws), ws.numel(), tile_voxels, None)
     return code, out
 
 
@@ -83,3 +84,12 @@ def msda_bwd(value, ss, ls, loc, w, go):
     ok(lib().fbbev_msda_bwd(p(value), p(ss), p(ls), p(loc), p(w), p(go), B, S, M, Dh, L, Q, P, p(gv), p(gl),
                             p(gw), None))
     return gv, gl, gw
+
+
+def lidar_coor(xs, ys, ds, cam):
+    rots, trans, intrins, post_rots, post_trans, bda = cam
+    B, N = trans.shape[:2]
+    coor = torch.full((B, N, ds.numel(), ys.numel(), xs.numel(), 3), float('nan'))
+    ok(lib().fbbev_lidar_coor(p(xs), p(ys), p(ds), p(rots), p(trans), p(intrins), p(post_rots), p(post_trans),
+                              p(bda), B, N, ds.numel(), ys.numel(), xs.numel(), p(coor), None))
+    return coor

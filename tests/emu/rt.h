@@ -138,6 +138,7 @@ typedef void* fbbev_rt_stream;
 #define FBBEV_LAUNCH(kern, grid, block, lds_bytes, stream, ...) \
     emu::launch((unsigned)(grid), (unsigned)(block), (size_t)(lds_bytes), [=]() { kern(__VA_ARGS__); })
 static inline int fbbev_rt_last_error() { return 0; }
+static inline int fbbev_rt_allow_dyn_lds(const void*, size_t) { return 0; }
 static inline int fbbev_rt_memset_async(void* p, int byte, size_t n, fbbev_rt_stream) { memset(p, byte, n); return 0; }
 inline float* fbbev_dyn_lds_f32() {
     uintptr_t p = reinterpret_cast<uintptr_t>(emu::S().lds.data());

@@ -138,3 +138,16 @@ def test_pool_dense_partial_tiles_small_config():
         code, out = E.pool_dense(depth, feat, rd, rf, rb, st, ln, counts, st.numel(), B, C, Z, Y, X, tv)
         assert code == 0 and not torch.isnan(out).any()
         assert torch.equal(out, exp)
+
+
+def test_lidar_coor_emulated():
+    for name in ('TINY', 'SMALL'):
+        cfg = S.CONFIGS[name]
+        vt = O.ViewTransformerOracle(cfg.grid_config, cfg.input_size, cfg.downsample)
+        cam = S.camera_rig(cfg, 2, seed=0, bda_aug=True)
+        exp = vt.get_lidar_coor(*cam)
+        xs = vt.frustum[0, 0, :, 0].contiguous(); ys = vt.frustum[0, :, 0, 1].contiguous()
+        ds = vt.frustum[:, 0, 0, 2].contiguous()
+        got = E.lidar_coor(xs, ys, ds, cam)
+        assert not torch.isnan(got).any()
+        assert (got - exp).abs().max().item() < 2e-4   # metres; closed-form vs LU inverse
