@@ -25,7 +25,7 @@ SIGNATURES = {
     'fbbev_pool_dense_workspace_bytes': (c_size_t, [c_int] * 4),
     'fbbev_pool_tile_index': (c_int, [c_void_p] * 3 + [c_int] * 6 + [c_void_p, c_size_t, c_void_p]),
     'fbbev_bev_pool_v2_dense_fwd': (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t,
-                                            c_int, c_void_p]),
+                                            c_int, c_int, c_void_p]),
     'fbbev_msda_fwd': (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_void_p, c_void_p]),
     'fbbev_msda_bwd': (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p] * 3 + [c_void_p]),
 }
@@ -150,25 +150,34 @@ def pool_dense_workspace_bytes(B, Z, Y, X):
     return int(lib().fbbev_pool_dense_workspace_bytes(B, Z, Y, X))
 
 
-def pool_tile_index(ranks_bev, interval_starts, n_intervals_dev, n_intervals_max, B, Z, Y, X, tile_ws,
-                    tile_voxels=128):
-    with _on(ranks_bev):
+POOL_STORE_PLAIN, POOL_STORE_NT, POOL_STORE_SC1, POOL_CPL8 = 0, 1, 2, 4
+DEFAULT_POOL_FLAGS = POOL_CPL8
+
+
+def pool_flags(store=0, cpl8=True, csplit=1):
+    return (store & 3) | (POOL_CPL8 if cpl8 else 0) | ((csplit & 0xF) << 4)
+
+
+def pool_tile_index(interval_rank, interval_starts, counts, n_intervals_max, B, Z, Y, X, tile_ws,
+                    tile_voxels=64):
+    with _on(interval_rank):
         _check(lib().fbbev_pool_tile_index(
-            _dev(ranks_bev, I32, 'ranks_bev'), _dev(interval_starts, I32, 'interval_starts'),
-            _dev(n_intervals_dev, I32, 'n_intervals_dev'), int(n_intervals_max), B, Z, Y, X,
-            int(tile_voxels), c_void_p(tile_ws.data_ptr()), tile_ws.numel() * tile_ws.element_size(),
-            _stream()), 'fbbev_pool_tile_index')
+            _dev(interval_rank, I32, 'interval_rank'), _dev(interval_starts, I32, 'interval_starts'),
+            _dev(counts, I32, 'counts'), int(n_intervals_max), B, Z, Y, X, int(tile_voxels),
+            c_void_p(tile_ws.data_ptr()), tile_ws.numel() * tile_ws.element_size(), _stream()),
+            'fbbev_pool_tile_index')
 
 
-def bev_pool_v2_dense_fwd(depth, feat, ranks_depth, ranks_feat, ranks_bev, interval_starts,
-                          interval_lengths, B, C, Z, Y, X, out, tile_ws, tile_voxels=128):
+def bev_pool_v2_dense_fwd(depth, feat, ranks_depth, ranks_feat, interval_rank, interval_starts,
+                          interval_lengths, B, C, Z, Y, X, out, tile_ws, tile_voxels=64,
+                          flags=DEFAULT_POOL_FLAGS):
     with _on(depth):
         _check(lib().fbbev_bev_pool_v2_dense_fwd(
             _dev(depth, F32, 'depth'), _dev(feat, F32, 'feat'), _dev(ranks_depth, I32, 'ranks_depth'),
-            _dev(ranks_feat, I32, 'ranks_feat'), _dev(ranks_bev, I32, 'ranks_bev'),
+            _dev(ranks_feat, I32, 'ranks_feat'), _dev(interval_rank, I32, 'interval_rank'),
             _dev(interval_starts, I32, 'interval_starts'), _dev(interval_lengths, I32, 'interval_lengths'),
             B, C, Z, Y, X, _dev(out, F32, 'out'), c_void_p(tile_ws.data_ptr()),
-            tile_ws.numel() * tile_ws.element_size(), int(tile_voxels), _stream()),
+            tile_ws.numel() * tile_ws.element_size(), int(tile_voxels), int(flags), _stream()),
             'fbbev_bev_pool_v2_dense_fwd')
 
 

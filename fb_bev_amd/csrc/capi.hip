@@ -184,43 +184,70 @@ extern "C" int fbbev_rank_build(const float* coor, int B, int N, int D, int H, i
 
 // ------------------------------------------------------------------------------ fused dense fwd
 static inline int pick_tile(int tile_voxels) {
-    return (tile_voxels == 64 || tile_voxels == 128 || tile_voxels == 256) ? tile_voxels : 128;
+    return (tile_voxels == 64 || tile_voxels == 128 || tile_voxels == 256) ? tile_voxels : 64;
 }
 
 extern "C" size_t fbbev_pool_dense_workspace_bytes(int B, int Z, int Y, int X) {
     if (B <= 0 || Z <= 0 || Y <= 0 || X <= 0) return 256;
     const long long yx = (long long)Y * X;
     const long long tiles = (long long)B * Z * ((yx + 63) / 64);  // smallest tile = most tiles
-    return align_up((size_t)(tiles + 2) * 4, 256);
+    return align_up((size_t)(tiles + 2) * 8, 256);                // (first interval, first point) per tile
 }
 
-extern "C" int fbbev_pool_tile_index(const int32_t* ranks_bev, const int32_t* interval_starts,
-                                     const int32_t* n_intervals_dev, int n_intervals_max, int B, int Z,
-                                     int Y, int X, int tile_voxels, void* tile_ws, size_t tile_ws_bytes,
+extern "C" int fbbev_pool_tile_index(const int32_t* interval_rank, const int32_t* interval_starts,
+                                     const int32_t* counts, int n_intervals_max, int B, int Z, int Y,
+                                     int X, int tile_voxels, void* tile_ws, size_t tile_ws_bytes,
                                      fbbev_stream_t stream_) {
     if (B <= 0 || Z <= 0 || Y <= 0 || X <= 0 || n_intervals_max < 0) return FBBEV_E_BADARG;
-    if (!ranks_bev || !interval_starts || !n_intervals_dev || !tile_ws) return FBBEV_E_BADARG;
+    if (!interval_rank || !interval_starts || !counts || !tile_ws) return FBBEV_E_BADARG;
     const long long yx = (long long)Y * X;
     if ((long long)B * Z * yx >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
     const int TV = pick_tile(tile_voxels);
     const int tiles_per_plane = (int)((yx + TV - 1) / TV);
     const long long n_tiles = (long long)B * Z * tiles_per_plane;
-    if (tile_ws_bytes < (size_t)(n_tiles + 1) * 4) return FBBEV_E_WORKSPACE;
-    FBBEV_LAUNCH(k_tile_lower_bound, (n_tiles + 1 + 255) / 256, 256, 0, (fbbev_rt_stream)stream_,
-                 (int)n_tiles, tiles_per_plane, (int)yx, TV, ranks_bev, interval_starts, n_intervals_dev,
+    if (tile_ws_bytes < (size_t)(n_tiles + 1) * 8) return FBBEV_E_WORKSPACE;
+    FBBEV_LAUNCH(k_tile_lower_bound2, (n_tiles + 1 + 255) / 256, 256, 0, (fbbev_rt_stream)stream_,
+                 (int)n_tiles, tiles_per_plane, (int)yx, TV, interval_rank, interval_starts, counts,
                  n_intervals_max, static_cast<int*>(tile_ws));
     FBBEV_CHECK_LAUNCH();
     return 0;
 }
 
+template <int TV, int CPL, int ST>
+static int launch_dense2(long long n_blocks, size_t lds, fbbev_rt_stream stream, int C, int Z, int yx,
+                         int tiles_per_plane, int csplit, const float* depth, const float* feat,
+                         const int32_t* rd, const int32_t* rf, const int32_t* irank, const int32_t* starts,
+                         const int32_t* lengths, const int* tile_meta, float* out) {
+    if (lds > 64 * 1024) {  // > 64 KiB of dynamic LDS must be opted into (160 KiB per CU on gfx950)
+        int e = fbbev_rt_allow_dyn_lds((const void*)k_pool_fwd_dense2<TV, CPL, ST>, lds);
+        if (e) return e;
+    }
+    FBBEV_LAUNCH((k_pool_fwd_dense2<TV, CPL, ST>), n_blocks, 256, lds, stream, C, Z, yx, tiles_per_plane,
+                 csplit, depth, feat, rd, rf, irank, starts, lengths, tile_meta, out);
+    return fbbev_rt_last_error();
+}
+
+template <int TV, int CPL>
+static int launch_dense2_st(int st, long long n_blocks, size_t lds, fbbev_rt_stream stream, int C, int Z,
+                            int yx, int tpp, int csplit, const float* depth, const float* feat,
+                            const int32_t* rd, const int32_t* rf, const int32_t* irank,
+                            const int32_t* starts, const int32_t* lengths, const int* tile_meta,
+                            float* out) {
+    switch (st) {
+        case 1: return launch_dense2<TV, CPL, 1>(n_blocks, lds, stream, C, Z, yx, tpp, csplit, depth, feat, rd, rf, irank, starts, lengths, tile_meta, out);
+        case 2: return launch_dense2<TV, CPL, 2>(n_blocks, lds, stream, C, Z, yx, tpp, csplit, depth, feat, rd, rf, irank, starts, lengths, tile_meta, out);
+        default: return launch_dense2<TV, CPL, 0>(n_blocks, lds, stream, C, Z, yx, tpp, csplit, depth, feat, rd, rf, irank, starts, lengths, tile_meta, out);
+    }
+}
+
 extern "C" int fbbev_bev_pool_v2_dense_fwd(const float* depth, const float* feat,
                                            const int32_t* ranks_depth, const int32_t* ranks_feat,
-                                           const int32_t* ranks_bev, const int32_t* interval_starts,
+                                           const int32_t* interval_rank, const int32_t* interval_starts,
                                            const int32_t* interval_lengths, int B, int C, int Z, int Y,
                                            int X, float* out, const void* tile_ws, size_t tile_ws_bytes,
-                                           int tile_voxels, fbbev_stream_t stream_) {
+                                           int tile_voxels, int flags, fbbev_stream_t stream_) {
     if (B <= 0 || C <= 0 || Z <= 0 || Y <= 0 || X <= 0) return FBBEV_E_BADARG;
-    if (!depth || !feat || !ranks_depth || !ranks_feat || !ranks_bev || !interval_starts ||
+    if (!depth || !feat || !ranks_depth || !ranks_feat || !interval_rank || !interval_starts ||
         !interval_lengths || !out || !tile_ws) return FBBEV_E_BADARG;
     const long long yx = (long long)Y * X;
     if (C % 4 != 0 || C > 256 || yx % 4 != 0 || !aligned16(out) || !aligned16(feat)) return FBBEV_E_UNSUPPORTED;
@@ -229,25 +256,30 @@ extern "C" int fbbev_bev_pool_v2_dense_fwd(const float* depth, const float* feat
     const int TV = pick_tile(tile_voxels);
     const int tiles_per_plane = (int)((yx + TV - 1) / TV);
     const long long n_tiles = (long long)B * Z * tiles_per_plane;
-    if (tile_ws_bytes < (size_t)(n_tiles + 1) * 4) return FBBEV_E_WORKSPACE;
-    const int* tile_istart = static_cast<const int*>(tile_ws);
-    const size_t lds = (size_t)C * (TV + 4) * sizeof(float);
-#define FBBEV_DENSE(TVV)                                                                              \
-    FBBEV_LAUNCH(k_pool_fwd_dense<TVV>, n_tiles, 256, lds, stream, C, Z, (int)yx, tiles_per_plane,    \
-                 depth, feat, ranks_depth, ranks_feat, ranks_bev, interval_starts, interval_lengths, \
-                 tile_istart, out)
-    if (TV == 64) FBBEV_DENSE(64);
-    else if (TV == 128) FBBEV_DENSE(128);
-    else {
-        if (lds > 64 * 1024) {  // > 64 KiB of dynamic LDS must be opted into (160 KiB per CU on gfx950)
-            int e = fbbev_rt_allow_dyn_lds((const void*)k_pool_fwd_dense<256>, lds);
-            if (e) return e;
-        }
-        FBBEV_DENSE(256);
-    }
-#undef FBBEV_DENSE
-    FBBEV_CHECK_LAUNCH();
-    return 0;
+    if (tile_ws_bytes < (size_t)(n_tiles + 1) * 8) return FBBEV_E_WORKSPACE;
+    const int st = flags & FBBEV_POOL_STORE_MASK;
+    int csplit = (flags >> FBBEV_POOL_CSPLIT_SHIFT) & 0xF;
+    if (csplit < 1) csplit = 1;
+    if (C % (4 * csplit) != 0) csplit = 1;
+    const int CC = C / csplit;
+    const bool cpl8 = (flags & FBBEV_POOL_CPL8) && (CC % 8 == 0);
+    if (256 / (CC / (cpl8 ? 8 : 4)) < 1) return FBBEV_E_UNSUPPORTED;
+    const int* tile_meta = static_cast<const int*>(tile_ws);
+    const size_t lds = ((size_t)CC * (TV + 4) + 3 * (size_t)TV + 2 * FBBEV_NP_STAGE) * sizeof(float);
+    const long long n_blocks = n_tiles * csplit;
+    int e;
+#define FBBEV_DENSE2(TVV)                                                                            \
+    e = cpl8 ? launch_dense2_st<TVV, 8>(st, n_blocks, lds, stream, C, Z, (int)yx, tiles_per_plane,    \
+                                        csplit, depth, feat, ranks_depth, ranks_feat, interval_rank,  \
+                                        interval_starts, interval_lengths, tile_meta, out)           \
+             : launch_dense2_st<TVV, 4>(st, n_blocks, lds, stream, C, Z, (int)yx, tiles_per_plane,    \
+                                        csplit, depth, feat, ranks_depth, ranks_feat, interval_rank,  \
+                                        interval_starts, interval_lengths, tile_meta, out)
+    if (TV == 64) { FBBEV_DENSE2(64); }
+    else if (TV == 128) { FBBEV_DENSE2(128); }
+    else { FBBEV_DENSE2(256); }
+#undef FBBEV_DENSE2
+    return e;
 }
 
 // ------------------------------------------------------------------------------ MSDeformAttn

@@ -7,8 +7,8 @@
 //   * forward "rows"  : a group of C/4 lanes owns one interval; each lane carries 4 channels as a
 //     float4, so a feature row is one fully coalesced 256-320 B read, and the interval is an
 //     fmaf chain in the given sorted order (bit-identical arithmetic to the reference kernel).
-//   * forward "dense" : a 256-thread workgroup owns a tile of TV consecutive voxels of one (b,z)
-//     plane for all C channels.  Sparse per-voxel sums are staged in an LDS tile [C][TV] (the
+//   * forward "dense" (k_pool_fwd_dense2, end of file): a 256-thread workgroup owns a tile of TV
+//     consecutive voxels of one (b,z) plane for all (or half of the) C channels.  Sparse per-voxel sums are staged in an LDS tile [C][TV] (the
 //     per-pillar accumulation), then the whole tile -- zeros included -- is streamed to HBM once,
 //     in the final (B,C,Z,Y,X) layout, as 16-byte stores forming 4*TV-byte contiguous runs per
 //     channel.  This removes the reference's new_zeros + kernel write + permute().contiguous()
@@ -97,96 +97,6 @@ k_pool_fwd_rows(int c, int n_intervals, const float* __restrict__ depth,
     fbbev_stv<VEC>(out + (long long)rb[s] * c + slot * VEC, acc);
 }
 
-// ---------------------------------------------------------------- tile index for the dense kernel
-// tile t = (plane p = b*Z+z, k) covers ranks [p*YX + k*TV, p*YX + min((k+1)*TV, YX)).
-// tile_istart[t] = first interval whose rank >= the tile's first rank (lower bound), t in [0,n_tiles];
-// tile_istart[n_tiles] = number of intervals with rank < total voxels.
-__global__ void __launch_bounds__(256)
-k_tile_lower_bound(int n_tiles, int tiles_per_plane, int YX, int TV, const int* __restrict__ rb,
-                   const int* __restrict__ starts, const int* __restrict__ n_intervals_dev,
-                   int n_intervals_max, int* __restrict__ tile_istart) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t > n_tiles) return;
-    int n = *n_intervals_dev;
-    if (n > n_intervals_max) n = n_intervals_max;
-    const int plane = t / tiles_per_plane, k = t - plane * tiles_per_plane;
-    const long long target = (long long)plane * YX + (long long)k * TV;  // t==n_tiles -> total voxels
-    int lo = 0, hi = n;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        const long long r = rb[starts[mid]];
-        if (r < target) lo = mid + 1; else hi = mid;
-    }
-    tile_istart[t] = lo;
-}
-
-// ---------------------------------------------------------------- forward, fused dense (B,C,Z,Y,X)
-// LDS tile layout: row c at c*(TV+4) floats (16-byte aligned rows for ds_read_b128 in phase 2).
-// Requires C % 4 == 0, YX % 4 == 0, out 16-byte aligned.
-template <int TV>
-__global__ void __launch_bounds__(256)
-k_pool_fwd_dense(int C, int Z, int YX, int tiles_per_plane, const float* __restrict__ depth,
-                 const float* __restrict__ feat, const int* __restrict__ rd,
-                 const int* __restrict__ rf, const int* __restrict__ rb,
-                 const int* __restrict__ starts, const int* __restrict__ lengths,
-                 const int* __restrict__ tile_istart, float* __restrict__ out) {
-    constexpr int LD = TV + 4;       // LDS row stride in floats
-    constexpr int Q4 = TV / 4;       // float4 per row
-    float* tile = fbbev_dyn_lds_f32();
-    const int tid = threadIdx.x;
-    const int t = blockIdx.x;
-    const int plane = t / tiles_per_plane, k = t - plane * tiles_per_plane;
-    const int b = plane / Z, z = plane - b * Z;
-    const int v0 = k * TV;
-    const int nv = (YX - v0 < TV) ? (YX - v0) : TV;
-    const int i0 = tile_istart[t], i1 = tile_istart[t + 1];
-    const long long cstride = (long long)Z * YX;  // floats between channels
-    float* __restrict__ obase = out + ((long long)b * C * Z + z) * YX + v0;
-    const int n4 = C * Q4;
-
-    if (i0 == i1) {  // empty tile: stream zeros straight from registers, no LDS round trip
-        float4 zero; zero.x = zero.y = zero.z = zero.w = 0.f;
-        for (int idx = tid; idx < n4; idx += 256) {
-            const int c = idx / Q4, j = (idx - c * Q4) * 4;
-            if (j < nv) *reinterpret_cast<float4*>(obase + c * cstride + j) = zero;
-        }
-        return;
-    }
-
-    for (int idx = tid; idx < C * LD; idx += 256) tile[idx] = 0.f;
-    __syncthreads();
-
-    // phase 1: per-voxel (per-pillar) sums into the LDS tile; C/4 lanes per interval
-    {
-        const int lpi = C >> 2;
-        const int gpb = 256 / lpi;
-        const int g = tid / lpi, slot = tid - g * lpi;
-        if (g < gpb) {
-            const int rank0 = plane * YX + v0;
-            for (int i = i0 + g; i < i1; i += gpb) {
-                const int s = starts[i], len = lengths[i];
-                const int v = rb[s] - rank0;
-                float acc[4];
-                fbbev_interval_sum<4>(C, s, len, depth, feat + slot * 4, rd, rf, acc);
-                if (v >= 0 && v < nv) {
-                    float* dst = tile + (slot * 4) * LD + v;
-                    dst[0] = acc[0]; dst[LD] = acc[1]; dst[2 * LD] = acc[2]; dst[3 * LD] = acc[3];
-                }
-            }
-        }
-    }
-    __syncthreads();
-
-    // phase 2: stream the tile out, 16 B per lane, 4*TV-byte contiguous run per channel row
-    for (int idx = tid; idx < n4; idx += 256) {
-        const int c = idx / Q4, j = (idx - c * Q4) * 4;
-        if (j < nv) {
-            const float4 val = *reinterpret_cast<const float4*>(tile + c * LD + j);
-            *reinterpret_cast<float4*>(obase + c * cstride + j) = val;
-        }
-    }
-}
-
 // ---------------------------------------------------------------- backward
 // One wave64 per interval over ranks_feat (= one feature pixel); lane handles channels
 // lane, lane+64, ... (NCH = ceil(c/64)).  Per point: depth_grad = <out_grad row, feat row>
@@ -259,5 +169,179 @@ k_pool_bwd(int c, int n_intervals, const float* __restrict__ out_grad,
     for (int r = 0; r < NCH; ++r) {
         const int ch = lane + 64 * r;
         if (ch < c) feat_grad[pf * c + ch] = g[r];
+    }
+}
+
+// ================================================================ fused dense forward, v2
+// Same contract and same bits as k_pool_fwd_dense, restructured for memory latency:
+//   * level 1: tile_istart / tile_pstart (two broadcast loads) give the tile's interval range
+//     [i0,i1) AND its point range [p0,p1) -- the points of a tile are contiguous in the sorted
+//     arrays -- so
+//   * level 2: interval metadata (start, length, voxel) and the first NP point indices
+//     (ranks_depth, ranks_feat) are staged into LDS with coalesced loads by the whole block,
+//     overlapping the zero-fill of the LDS tile;
+//   * level 3: lane groups gather depth scalars and feature rows (the only remaining
+//     latency-exposed dependent loads) and run the in-order fmaf chains.
+// CPL channels per lane (4 or 8): with 8, C=80 needs 10 lanes per interval -> 25 intervals per
+// block in flight instead of 12.  `csplit` splits the channel range over blockIdx.y-like halves
+// (tile LDS shrinks -> more resident blocks per CU).  ST selects the store cache policy.
+#define FBBEV_NP_STAGE 512
+
+template <int CPL>
+__device__ __forceinline__ void fbbev_interval_sum_staged(int c, int s, int len, int p0,
+                                                          const int* __restrict__ prd_lds,
+                                                          const int* __restrict__ prf_lds,
+                                                          const float* __restrict__ depth,
+                                                          const float* __restrict__ fbase,
+                                                          const int* __restrict__ rd,
+                                                          const int* __restrict__ rf,
+                                                          float (&acc)[CPL]) {
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) acc[j] = 0.f;
+    int k = 0;
+    for (; k + 4 <= len; k += 4) {
+        int pd[4], pf[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = s + k + u;
+            if (idx < FBBEV_NP_STAGE) { pd[u] = prd_lds[idx]; pf[u] = prf_lds[idx]; }
+            else { pd[u] = rd[p0 + idx]; pf[u] = rf[p0 + idx]; }
+        }
+        float d[4];
+        float f[4][CPL];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            d[u] = depth[pd[u]];
+            const float* fp = fbase + (long long)pf[u] * c;
+#pragma unroll
+            for (int q = 0; q < CPL / 4; ++q) {
+                const fbbev_v4f t = *reinterpret_cast<const fbbev_v4f*>(fp + 4 * q);
+                f[u][4 * q] = t[0]; f[u][4 * q + 1] = t[1]; f[u][4 * q + 2] = t[2]; f[u][4 * q + 3] = t[3];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+            acc[j] = fmaf(f[0][j], d[0], acc[j]);
+            acc[j] = fmaf(f[1][j], d[1], acc[j]);
+            acc[j] = fmaf(f[2][j], d[2], acc[j]);
+            acc[j] = fmaf(f[3][j], d[3], acc[j]);
+        }
+    }
+    for (; k < len; ++k) {
+        const int idx = s + k;
+        int pd, pf;
+        if (idx < FBBEV_NP_STAGE) { pd = prd_lds[idx]; pf = prf_lds[idx]; }
+        else { pd = rd[p0 + idx]; pf = rf[p0 + idx]; }
+        const float d0 = depth[pd];
+        const float* fp = fbase + (long long)pf * c;
+#pragma unroll
+        for (int q = 0; q < CPL / 4; ++q) {
+            const fbbev_v4f t = *reinterpret_cast<const fbbev_v4f*>(fp + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[4 * q + e] = fmaf(t[e], d0, acc[4 * q + e]);
+        }
+    }
+}
+
+// tile_meta[2*t] = first interval of tile t, tile_meta[2*t+1] = first point of tile t (t in [0,n_tiles])
+__global__ void __launch_bounds__(256)
+k_tile_lower_bound2(int n_tiles, int tiles_per_plane, int YX, int TV,
+                    const int* __restrict__ interval_rank, const int* __restrict__ starts,
+                    const int* __restrict__ counts /* [P, I] */, int n_intervals_max,
+                    int* __restrict__ tile_meta) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > n_tiles) return;
+    const int P = counts[0];
+    int n = counts[1];
+    if (n > n_intervals_max) n = n_intervals_max;
+    const int plane = t / tiles_per_plane, k = t - plane * tiles_per_plane;
+    const long long target = (long long)plane * YX + (long long)k * TV;
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if ((long long)interval_rank[mid] < target) lo = mid + 1; else hi = mid;
+    }
+    tile_meta[2 * t] = lo;
+    tile_meta[2 * t + 1] = (lo < n) ? starts[lo] : P;
+}
+
+template <int TV, int CPL, int ST>
+__global__ void __launch_bounds__(256)
+k_pool_fwd_dense2(int C, int Z, int YX, int tiles_per_plane, int csplit,
+                  const float* __restrict__ depth, const float* __restrict__ feat,
+                  const int* __restrict__ rd, const int* __restrict__ rf,
+                  const int* __restrict__ interval_rank, const int* __restrict__ starts,
+                  const int* __restrict__ lengths, const int* __restrict__ tile_meta,
+                  float* __restrict__ out) {
+    constexpr int LD = TV + 4;
+    constexpr int Q4 = TV / 4;
+    const int CC = C / csplit;                 // channels handled by this block
+    float* tile = fbbev_dyn_lds_f32();         // [CC][LD]
+    int* ist = reinterpret_cast<int*>(tile + CC * LD);   // [TV] interval start relative to p0
+    int* iln = ist + TV;                       // [TV]
+    int* ivx = iln + TV;                       // [TV] voxel offset inside the tile
+    int* prd = ivx + TV;                       // [NP_STAGE]
+    int* prf = prd + FBBEV_NP_STAGE;           // [NP_STAGE]
+    const int tid = threadIdx.x;
+    const int t = blockIdx.x / csplit, half = blockIdx.x - t * csplit;
+    const int c0 = half * CC;
+    const int plane = t / tiles_per_plane, k = t - plane * tiles_per_plane;
+    const int b = plane / Z, z = plane - b * Z;
+    const int v0 = k * TV;
+    const int nv = (YX - v0 < TV) ? (YX - v0) : TV;
+    const int i0 = tile_meta[2 * t], p0 = tile_meta[2 * t + 1];
+    const int i1 = tile_meta[2 * t + 2], p1 = tile_meta[2 * t + 3];
+    const long long cstride = (long long)Z * YX;
+    float* __restrict__ obase = out + ((long long)b * C * Z + z) * YX + v0 + (long long)c0 * cstride;
+    const int n4 = CC * Q4;
+
+    if (i0 == i1) {
+        fbbev_v4f zero; zero[0] = zero[1] = zero[2] = zero[3] = 0.f;
+        for (int idx = tid; idx < n4; idx += 256) {
+            const int c = idx / Q4, j = (idx - c * Q4) * 4;
+            if (j < nv) fbbev_store4<ST>(obase + c * cstride + j, zero);
+        }
+        return;
+    }
+
+    const int ni = i1 - i0;
+    const int np = p1 - p0;
+    const int rank0 = plane * YX + v0;
+    for (int j = tid; j < ni; j += 256) {
+        ist[j] = starts[i0 + j] - p0;
+        iln[j] = lengths[i0 + j];
+        ivx[j] = interval_rank[i0 + j] - rank0;
+    }
+    const int nps = np < FBBEV_NP_STAGE ? np : FBBEV_NP_STAGE;
+    for (int j = tid; j < nps; j += 256) { prd[j] = rd[p0 + j]; prf[j] = rf[p0 + j]; }
+    for (int idx = tid; idx < CC * LD; idx += 256) tile[idx] = 0.f;
+    __syncthreads();
+
+    {
+        const int lpi = CC / CPL;
+        const int gpb = 256 / lpi;
+        const int g = tid / lpi, slot = tid - g * lpi;
+        if (g < gpb) {
+            const float* fbase = feat + c0 + slot * CPL;
+            for (int i = g; i < ni; i += gpb) {
+                const int v = ivx[i];
+                float acc[CPL];
+                fbbev_interval_sum_staged<CPL>(C, ist[i], iln[i], p0, prd, prf, depth, fbase, rd, rf, acc);
+                if (v >= 0 && v < nv) {
+                    float* dst = tile + (slot * CPL) * LD + v;
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) dst[j * LD] = acc[j];
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    for (int idx = tid; idx < n4; idx += 256) {
+        const int c = idx / Q4, j = (idx - c * Q4) * 4;
+        if (j < nv) {
+            const fbbev_v4f val = *reinterpret_cast<const fbbev_v4f*>(tile + c * LD + j);
+            fbbev_store4<ST>(obase + c * cstride + j, val);
+        }
     }
 }

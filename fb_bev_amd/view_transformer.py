@@ -56,17 +56,17 @@ class LiftSplat(torch.autograd.Function):
     once.  Backward regroups by feature pixel and runs the wave-per-pixel grad kernel."""
 
     @staticmethod
-    def forward(ctx, depth, feat, idx, grid_zyx, tile_ws, tile_voxels):
+    def forward(ctx, depth, feat, idx, grid_zyx, tile_ws, tile_voxels, pool_flags):
         depth = depth.contiguous().float()
         feat = feat.contiguous().float()
         B, C = depth.shape[0], feat.shape[-1]
         Z, Y, X = grid_zyx
         out = torch.empty((B, C, Z, Y, X), dtype=torch.float32, device=depth.device)
-        _capi.pool_tile_index(idx.ranks_bev, idx.interval_starts, idx.counts[1:2], idx.n, B, Z, Y, X,
+        _capi.pool_tile_index(idx.interval_rank, idx.interval_starts, idx.counts, idx.n, B, Z, Y, X,
                               tile_ws, tile_voxels)
-        _capi.bev_pool_v2_dense_fwd(depth, feat, idx.ranks_depth, idx.ranks_feat, idx.ranks_bev,
+        _capi.bev_pool_v2_dense_fwd(depth, feat, idx.ranks_depth, idx.ranks_feat, idx.interval_rank,
                                     idx.interval_starts, idx.interval_lengths, B, C, Z, Y, X, out,
-                                    tile_ws, tile_voxels)
+                                    tile_ws, tile_voxels, pool_flags)
         ctx.idx = idx
         ctx.save_for_backward(depth, feat)
         return out
@@ -84,7 +84,7 @@ class LiftSplat(torch.autograd.Function):
         depth_grad, feat_grad = torch.zeros_like(depth), torch.zeros_like(feat)
         bev_pool_v2_ext.bev_pool_v2_backward(og, depth_grad, feat_grad, depth, feat, rd, rf.contiguous(), rb,
                                              lengths_bp, starts_bp)
-        return depth_grad, feat_grad, None, None, None, None
+        return depth_grad, feat_grad, None, None, None, None, None
 
 
 class LSSViewTransformerFunction3D(nn.Module):
@@ -97,7 +97,8 @@ class LSSViewTransformerFunction3D(nn.Module):
     """
 
     def __init__(self, grid_config, input_size, downsample=16, accelerate=False, uniform=False,
-                 with_cp=False, extra_relu=False, fused=True, tile_voxels=128):
+                 with_cp=False, extra_relu=False, fused=True, tile_voxels=64,
+                 pool_flags=_capi.DEFAULT_POOL_FLAGS):
         super().__init__()
         self.uniform = uniform
         self.with_cp = with_cp
@@ -115,6 +116,7 @@ class LSSViewTransformerFunction3D(nn.Module):
         self.initial_flag = True
         self.fused = fused
         self.tile_voxels = tile_voxels
+        self.pool_flags = pool_flags
         self._cache = {}
         self._index_cache = None
 
@@ -224,7 +226,7 @@ class LSSViewTransformerFunction3D(nn.Module):
         """Fused dense pooling on a prepared index set -> (B,C,Y,X,Z) view of (B,C,Z,Y,X)."""
         feat = tran_feat.permute(0, 1, 3, 4, 2)
         out = LiftSplat.apply(depth, feat, idx, self.grid_zyx, self._tile_ws(depth.device, depth.shape[0]),
-                              self.tile_voxels)
+                              self.tile_voxels, self.pool_flags)
         return out.permute(0, 1, 3, 4, 2)
 
     def view_transform_core(self, cam_params, depth, tran_feat):

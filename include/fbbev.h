@@ -27,8 +27,10 @@ typedef void* fbbev_stream_t; /* hipStream_t */
 #define FBBEV_E_UNSUPPORTED (-2)
 #define FBBEV_E_WORKSPACE (-3)
 
-/* flags for the pooling entry points */
-#define FBBEV_POOL_DEFAULT 0
+/* flags of fbbev_bev_pool_v2_dense_fwd (tuning knobs; none changes the result bits) */
+#define FBBEV_POOL_STORE_MASK 0x3   /* output store cache policy: 0 plain, 1 nontemporal, 2 sc1 */
+#define FBBEV_POOL_CPL8 0x4         /* 8 channels per lane instead of 4 */
+#define FBBEV_POOL_CSPLIT_SHIFT 4   /* bits 4-7: split the channel range over this many workgroups */
 
 int fbbev_version(void);
 
@@ -95,23 +97,23 @@ int fbbev_rank_build(const float* coor, int B, int N, int D, int H, int W, const
 /* Fused replacement of  feat.new_zeros + bev_pool_v2_forward + permute(0,4,1,2,3).contiguous()
  *   -- bev_pool.py:24-35,88.  Two launches:
  * fbbev_pool_tile_index: for every tile of `tile_voxels` (64/128/256) consecutive voxels of a (b,z)
- *   plane, the first interval whose rank falls in it (parallel lower bound).  n_intervals_dev points
- *   at the device-side interval count (counts+1 of fbbev_rank_build): no host sync.
+ *   plane, the first interval whose rank falls in it (parallel lower bound over interval_rank) and
+ *   that interval's first point.  counts = device-side [P, I] of fbbev_rank_build: no host sync.
  * fbbev_bev_pool_v2_dense_fwd: writes EVERY element of out (B,C,Z,Y,X) exactly once (zeros for empty
  *   voxels) in the final layout, so `out` need not be pre-zeroed.  Same in-order fmaf chains as
- *   fbbev_bev_pool_v2_fwd => identical bits.  Requires C % 4 == 0, (Y*X) % 4 == 0, 16-byte aligned
- *   feat/out (else FBBEV_E_UNSUPPORTED; callers fall back to fbbev_bev_pool_v2_fwd).
+ *   fbbev_bev_pool_v2_fwd => identical bits.  interval_rank[i] = ranks_bev[interval_starts[i]].
+ *   Requires C % 4 == 0, (Y*X) % 4 == 0, 16-byte aligned feat/out (else FBBEV_E_UNSUPPORTED; callers
+ *   fall back to fbbev_bev_pool_v2_fwd).
  * tile_ws: fbbev_pool_dense_workspace_bytes(B,Z,Y,X) bytes, shared by the two calls. */
 size_t fbbev_pool_dense_workspace_bytes(int B, int Z, int Y, int X);
-int fbbev_pool_tile_index(const int32_t* ranks_bev, const int32_t* interval_starts,
-                          const int32_t* n_intervals_dev, int n_intervals_max, int B, int Z, int Y,
-                          int X, int tile_voxels, void* tile_ws, size_t tile_ws_bytes,
-                          fbbev_stream_t stream);
+int fbbev_pool_tile_index(const int32_t* interval_rank, const int32_t* interval_starts,
+                          const int32_t* counts, int n_intervals_max, int B, int Z, int Y, int X,
+                          int tile_voxels, void* tile_ws, size_t tile_ws_bytes, fbbev_stream_t stream);
 int fbbev_bev_pool_v2_dense_fwd(const float* depth, const float* feat, const int32_t* ranks_depth,
-                                const int32_t* ranks_feat, const int32_t* ranks_bev,
+                                const int32_t* ranks_feat, const int32_t* interval_rank,
                                 const int32_t* interval_starts, const int32_t* interval_lengths, int B,
                                 int C, int Z, int Y, int X, float* out_bczyx, const void* tile_ws,
-                                size_t tile_ws_bytes, int tile_voxels, fbbev_stream_t stream);
+                                size_t tile_ws_bytes, int tile_voxels, int flags, fbbev_stream_t stream);
 
 /* ----------------------------------------------------------------------------------------------
  * Boundary 2: mmcv._ext.ms_deform_attn_{forward,backward} (mmcv-full 1.5.2, external to the tree)

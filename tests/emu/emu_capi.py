@@ -59,13 +59,12 @@ def pool_bwd(out_grad, depth_grad, feat_grad, depth, feat, rd, rf, rb, st, ln):
                                    p(rf), p(rb), p(st), p(ln), p(depth_grad), p(feat_grad), None))
 
 
-def pool_dense(depth, feat, rd, rf, rb, st, ln, counts, n_max, B, C, Z, Y, X, tile_voxels):
+def pool_dense(depth, feat, rd, rf, ir, st, ln, counts, n_max, B, C, Z, Y, X, tile_voxels, flags=0):
     out = torch.full((B, C, Z, Y, X), float('nan'))
     ws = torch.zeros(lib().fbbev_pool_dense_workspace_bytes(B, Z, Y, X), dtype=torch.uint8)
-    ok(lib().fbbev_pool_tile_index(p(rb), p(st), c_void_p(counts.data_ptr() + 4), n_max, B, Z, Y, X,
-                                   tile_voxels, p(ws), ws.numel(), None))
-    code = lib().fbbev_bev_pool_v2_dense_fwd(p(depth), p(feat), p(rd), p(rf), p(rb), p(st), p(ln),
-                                             B, C, Z, Y, X, p(out), p(ws), ws.numel(), tile_voxels, None)
+    ok(lib().fbbev_pool_tile_index(p(ir), p(st), p(counts), n_max, B, Z, Y, X, tile_voxels, p(ws), ws.numel(), None))
+    code = lib().fbbev_bev_pool_v2_dense_fwd(p(depth), p(feat), p(rd), p(rf), p(ir), p(st), p(ln),
+                                             B, C, Z, Y, X, p(out), p(ws), ws.numel(), tile_voxels, flags, None)
     return code, out
 
 

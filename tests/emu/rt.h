@@ -144,6 +144,8 @@ inline float* fbbev_dyn_lds_f32() {
     uintptr_t p = reinterpret_cast<uintptr_t>(emu::S().lds.data());
     return reinterpret_cast<float*>((p + 15) & ~uintptr_t(15));
 }
+typedef float fbbev_v4f __attribute__((vector_size(16)));
+template <int ST> inline void fbbev_store4(float* p, fbbev_v4f v) { memcpy(p, &v, 16); }
 inline void fbbev_atomic_add_f32(float* p, float v) { *p += v; }
 
 inline size_t fbbev_rt_sort_pairs_temp_bytes(size_t n, int) { return n * 8 + 16; }

@@ -89,12 +89,12 @@ def test_pool_fwd_rows_and_bwd(name, B):
     assert torch.allclose(dg, edg, atol=1e-5, rtol=1e-5)          # wave-tree vs serial channel sum
 
 
-@pytest.mark.parametrize('tv', [64, 128, 256])
-def test_pool_dense_matches_oracle(tv):
+@pytest.mark.parametrize('tv,flags', [(64, 0), (128, 4), (256, 0x24), (64, 0x22), (128, 0x21)])
+def test_pool_dense_matches_oracle(tv, flags):
     cfg, vt, coor, depth, feat = _case('TINY', 2)
     rb, rd, rf, st, ln, ir, counts = E.rank_build(coor, *_grid3(vt))
     B, Z, Y, X, C = vt.bev_feat_shape(2, cfg.channels)
-    code, out = E.pool_dense(depth, feat, rd, rf, rb, st, ln, counts, st.numel(), B, C, Z, Y, X, tv)
+    code, out = E.pool_dense(depth, feat, rd, rf, ir, st, ln, counts, st.numel(), B, C, Z, Y, X, tv, flags)
     assert code == 0
     erb, erd, erf, est, eln = vt.voxel_pooling_prepare_v2(coor)
     exp = O.bev_pool_v2(depth, feat, erd, erf, erb, (B, Z, Y, X, C), est, eln, use_fma=True)
@@ -105,7 +105,7 @@ def test_pool_dense_matches_oracle(tv):
 def test_pool_dense_rejects_unsupported():
     cfg, vt, coor, depth, feat = _case('TINY', 1)
     rb, rd, rf, st, ln, ir, counts = E.rank_build(coor, *_grid3(vt))
-    code, _ = E.pool_dense(depth, feat[..., :6].contiguous(), rd, rf, rb, st, ln, counts, st.numel(),
+    code, _ = E.pool_dense(depth, feat[..., :6].contiguous(), rd, rf, ir, st, ln, counts, st.numel(),
                            1, 6, 4, 16, 16, 128)
     assert code == -2                                             # FBBEV_E_UNSUPPORTED (C % 4 != 0)
 
@@ -134,8 +134,8 @@ def test_pool_dense_partial_tiles_small_config():
     assert (P, I) == (erb.numel(), est.numel())
     assert torch.equal(rb[:P], erb) and torch.equal(rd[:P], erd) and torch.equal(st[:I], est)
     exp = O.bev_pool_v2(depth, feat, erd, erf, erb, (B, Z, Y, X, C), est, eln, use_fma=True)
-    for tv in (64, 128):
-        code, out = E.pool_dense(depth, feat, rd, rf, rb, st, ln, counts, st.numel(), B, C, Z, Y, X, tv)
+    for tv, flags in ((64, 0), (128, 0x24), (64, 0x14)):   # C=20: cpl8 falls back to 4; csplit 2 -> 10 ch
+        code, out = E.pool_dense(depth, feat, rd, rf, ir, st, ln, counts, st.numel(), B, C, Z, Y, X, tv, flags)
         assert code == 0 and not torch.isnan(out).any()
         assert torch.equal(out, exp)
 

@@ -151,8 +151,8 @@ def test_pool_forward_bit_exact_vs_oracle_and_reference_kernel(dev, name, B, aug
 
 
 @pytest.mark.parametrize('name,B,aug', CASES)
-@pytest.mark.parametrize('tv', [64, 128, 256])
-def test_dense_forward_equals_rows_path(dev, name, B, aug, tv):
+@pytest.mark.parametrize('tv,flags', [(64, 0), (64, 4), (128, 4), (256, 0x24), (64, 0x26), (128, 0x25), (64, 1)])
+def test_dense_forward_equals_rows_path(dev, name, B, aug, tv, flags):
     """Fused (B,C,Z,Y,X) kernel == zero-init + rows kernel + permute, bit for bit, and writes every element."""
     from fb_bev_amd import _capi
     from fb_bev_amd.bev_pool import bev_pool_v2
@@ -163,9 +163,10 @@ def test_dense_forward_equals_rows_path(dev, name, B, aug, tv):
     Z, Y, X = vt.grid_zyx
     out = torch.full((B, cfg.channels, Z, Y, X), float('nan'), device=dev)
     ws = vt._tile_ws(dev, B)
-    _capi.pool_tile_index(idx.ranks_bev, idx.interval_starts, idx.counts[1:2], idx.n, B, Z, Y, X, ws, tv)
-    _capi.bev_pool_v2_dense_fwd(depth.to(dev), feat, idx.ranks_depth, idx.ranks_feat, idx.ranks_bev,
-                                idx.interval_starts, idx.interval_lengths, B, cfg.channels, Z, Y, X, out, ws, tv)
+    _capi.pool_tile_index(idx.interval_rank, idx.interval_starts, idx.counts, idx.n, B, Z, Y, X, ws, tv)
+    _capi.bev_pool_v2_dense_fwd(depth.to(dev), feat, idx.ranks_depth, idx.ranks_feat, idx.interval_rank,
+                                idx.interval_starts, idx.interval_lengths, B, cfg.channels, Z, Y, X, out, ws, tv,
+                                flags)
     assert not torch.isnan(out).any()
     rb, rd, rf, st, ln = idx.exact()
     exp = bev_pool_v2(depth.to(dev), feat, rd, rf, rb, (B, Z, Y, X, cfg.channels), st, ln)
