@@ -150,12 +150,20 @@ def pool_dense_workspace_bytes(B, Z, Y, X):
     return int(lib().fbbev_pool_dense_workspace_bytes(B, Z, Y, X))
 
 
-POOL_STORE_PLAIN, POOL_STORE_NT, POOL_STORE_SC1, POOL_CPL8 = 0, 1, 2, 4
-DEFAULT_POOL_FLAGS = POOL_CPL8
+POOL_STORE_PLAIN, POOL_STORE_NT, POOL_CPL8 = 0, 1, 4
 
 
-def pool_flags(store=0, cpl8=True, csplit=1):
-    return (store & 3) | (POOL_CPL8 if cpl8 else 0) | ((csplit & 0xF) << 4)
+def pool_flags(store=POOL_STORE_NT, cpl8=True, csplit=1, wg=256, swizzle=True):
+    """Tuning flags of fbbev_bev_pool_v2_dense_fwd (include/fbbev.h); none changes the result bits."""
+    cs = 0xF if csplit == 20 else (csplit & 0xF)
+    return (store & 3) | (POOL_CPL8 if cpl8 else 0) | (cs << 4) | ({256: 0, 128: 1}[wg] << 8) | \
+        (0x400 if swizzle else 0)
+
+
+# measured best on MI355X at BASELINE configs[1] (profiles/r01_pool_variants.md): 64-voxel tiles,
+# 8 channels/lane, nontemporal stores, XCD-contiguous tile order -> 0.87 of the 8 TB/s HBM peak
+DEFAULT_POOL_FLAGS = pool_flags()
+DEFAULT_TILE_VOXELS = 64
 
 
 def pool_tile_index(interval_rank, interval_starts, counts, n_intervals_max, B, Z, Y, X, tile_ws,

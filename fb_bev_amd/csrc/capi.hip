@@ -184,7 +184,7 @@ extern "C" int fbbev_rank_build(const float* coor, int B, int N, int D, int H, i
 
 // ------------------------------------------------------------------------------ fused dense fwd
 static inline int pick_tile(int tile_voxels) {
-    return (tile_voxels == 64 || tile_voxels == 128 || tile_voxels == 256) ? tile_voxels : 64;
+    switch (tile_voxels) { case 64: case 128: case 256: case 512: case 1024: return tile_voxels; default: return 64; }
 }
 
 extern "C" size_t fbbev_pool_dense_workspace_bytes(int B, int Z, int Y, int X) {
@@ -213,31 +213,33 @@ extern "C" int fbbev_pool_tile_index(const int32_t* interval_rank, const int32_t
     return 0;
 }
 
-template <int TV, int CPL, int ST>
-static int launch_dense2(long long n_blocks, size_t lds, fbbev_rt_stream stream, int C, int Z, int yx,
-                         int tiles_per_plane, int csplit, const float* depth, const float* feat,
-                         const int32_t* rd, const int32_t* rf, const int32_t* irank, const int32_t* starts,
-                         const int32_t* lengths, const int* tile_meta, float* out) {
-    if (lds > 64 * 1024) {  // > 64 KiB of dynamic LDS must be opted into (160 KiB per CU on gfx950)
-        int e = fbbev_rt_allow_dyn_lds((const void*)k_pool_fwd_dense2<TV, CPL, ST>, lds);
+struct dense2_args {
+    long long n_blocks; size_t lds; fbbev_rt_stream stream; int C, Z, yx, tpp, csplit, swizzle;
+    const float *depth, *feat; const int32_t *rd, *rf, *irank, *starts, *lengths; const int* tile_meta;
+    float* out;
+};
+
+template <int TV, int CPL, int ST, int NT>
+static int launch_dense2(const dense2_args& a) {
+    if (a.lds > 64 * 1024) {  // > 64 KiB of dynamic LDS must be opted into (160 KiB per CU on gfx950)
+        int e = fbbev_rt_allow_dyn_lds((const void*)k_pool_fwd_dense2<TV, CPL, ST, NT>, a.lds);
         if (e) return e;
     }
-    FBBEV_LAUNCH((k_pool_fwd_dense2<TV, CPL, ST>), n_blocks, 256, lds, stream, C, Z, yx, tiles_per_plane,
-                 csplit, depth, feat, rd, rf, irank, starts, lengths, tile_meta, out);
+    const long long grid = (a.n_blocks + 7) / 8 * 8;
+    FBBEV_LAUNCH((k_pool_fwd_dense2<TV, CPL, ST, NT>), grid, NT, a.lds, a.stream, a.C, a.Z, a.yx, a.tpp,
+                 a.csplit, (int)a.n_blocks, a.swizzle, a.depth, a.feat, a.rd, a.rf, a.irank, a.starts, a.lengths, a.tile_meta, a.out);
     return fbbev_rt_last_error();
 }
 
+template <int TV, int CPL, int ST>
+static int launch_dense2_nt(int nt, const dense2_args& a) {
+    return nt == 128 ? launch_dense2<TV, CPL, ST, 128>(a) : launch_dense2<TV, CPL, ST, 256>(a);
+}
+
 template <int TV, int CPL>
-static int launch_dense2_st(int st, long long n_blocks, size_t lds, fbbev_rt_stream stream, int C, int Z,
-                            int yx, int tpp, int csplit, const float* depth, const float* feat,
-                            const int32_t* rd, const int32_t* rf, const int32_t* irank,
-                            const int32_t* starts, const int32_t* lengths, const int* tile_meta,
-                            float* out) {
-    switch (st) {
-        case 1: return launch_dense2<TV, CPL, 1>(n_blocks, lds, stream, C, Z, yx, tpp, csplit, depth, feat, rd, rf, irank, starts, lengths, tile_meta, out);
-        case 2: return launch_dense2<TV, CPL, 2>(n_blocks, lds, stream, C, Z, yx, tpp, csplit, depth, feat, rd, rf, irank, starts, lengths, tile_meta, out);
-        default: return launch_dense2<TV, CPL, 0>(n_blocks, lds, stream, C, Z, yx, tpp, csplit, depth, feat, rd, rf, irank, starts, lengths, tile_meta, out);
-    }
+static int launch_dense2_st(int st, int nt, const dense2_args& a) {
+    // plain and nontemporal stores only: the sc1 policy measured no better than plain (profiles/)
+    return st == 0 ? launch_dense2_nt<TV, CPL, 0>(nt, a) : launch_dense2_nt<TV, CPL, 1>(nt, a);
 }
 
 extern "C" int fbbev_bev_pool_v2_dense_fwd(const float* depth, const float* feat,
@@ -259,27 +261,28 @@ extern "C" int fbbev_bev_pool_v2_dense_fwd(const float* depth, const float* feat
     if (tile_ws_bytes < (size_t)(n_tiles + 1) * 8) return FBBEV_E_WORKSPACE;
     const int st = flags & FBBEV_POOL_STORE_MASK;
     int csplit = (flags >> FBBEV_POOL_CSPLIT_SHIFT) & 0xF;
+    if (csplit == 0xF) csplit = 20;
     if (csplit < 1) csplit = 1;
     if (C % (4 * csplit) != 0) csplit = 1;
     const int CC = C / csplit;
     const bool cpl8 = (flags & FBBEV_POOL_CPL8) && (CC % 8 == 0);
-    if (256 / (CC / (cpl8 ? 8 : 4)) < 1) return FBBEV_E_UNSUPPORTED;
-    const int* tile_meta = static_cast<const int*>(tile_ws);
-    const size_t lds = ((size_t)CC * (TV + 4) + 3 * (size_t)TV + 2 * FBBEV_NP_STAGE) * sizeof(float);
-    const long long n_blocks = n_tiles * csplit;
-    int e;
-#define FBBEV_DENSE2(TVV)                                                                            \
-    e = cpl8 ? launch_dense2_st<TVV, 8>(st, n_blocks, lds, stream, C, Z, (int)yx, tiles_per_plane,    \
-                                        csplit, depth, feat, ranks_depth, ranks_feat, interval_rank,  \
-                                        interval_starts, interval_lengths, tile_meta, out)           \
-             : launch_dense2_st<TVV, 4>(st, n_blocks, lds, stream, C, Z, (int)yx, tiles_per_plane,    \
-                                        csplit, depth, feat, ranks_depth, ranks_feat, interval_rank,  \
-                                        interval_starts, interval_lengths, tile_meta, out)
-    if (TV == 64) { FBBEV_DENSE2(64); }
-    else if (TV == 128) { FBBEV_DENSE2(128); }
-    else { FBBEV_DENSE2(256); }
-#undef FBBEV_DENSE2
-    return e;
+    int nt = 256;
+    if (((flags >> FBBEV_POOL_WG_SHIFT) & 0x3) == 1) nt = 128;
+    if (nt / (CC / (cpl8 ? 8 : 4)) < 1) return FBBEV_E_UNSUPPORTED;
+    dense2_args a;
+    a.n_blocks = n_tiles * csplit;
+    a.lds = ((size_t)CC * (TV + 4) + 3 * (size_t)TV + 2 * FBBEV_NP_STAGE) * sizeof(float);
+    a.stream = stream; a.C = C; a.Z = Z; a.yx = (int)yx; a.tpp = tiles_per_plane; a.csplit = csplit;
+    a.swizzle = (flags & FBBEV_POOL_XCD_SWIZZLE) ? 1 : 0;
+    if (a.n_blocks + 8 >= (1ll << 31) || a.lds > 160 * 1024) return FBBEV_E_UNSUPPORTED;
+    a.depth = depth; a.feat = feat; a.rd = ranks_depth; a.rf = ranks_feat; a.irank = interval_rank;
+    a.starts = interval_starts; a.lengths = interval_lengths; a.tile_meta = static_cast<const int*>(tile_ws);
+    a.out = out;
+    if (TV == 64) return cpl8 ? launch_dense2_st<64, 8>(st, nt, a) : launch_dense2_st<64, 4>(st, nt, a);
+    if (TV == 128) return cpl8 ? launch_dense2_st<128, 8>(st, nt, a) : launch_dense2_st<128, 4>(st, nt, a);
+    if (TV == 256) return cpl8 ? launch_dense2_st<256, 8>(st, nt, a) : launch_dense2_st<256, 4>(st, nt, a);
+    if (TV == 512) return cpl8 ? launch_dense2_st<512, 8>(st, nt, a) : launch_dense2_st<512, 4>(st, nt, a);
+    return cpl8 ? launch_dense2_st<1024, 8>(st, nt, a) : launch_dense2_st<1024, 4>(st, nt, a);
 }
 
 // ------------------------------------------------------------------------------ MSDeformAttn

@@ -182,6 +182,7 @@ k_pool_bwd(int c, int n_intervals, const float* __restrict__ out_grad,
 //     overlapping the zero-fill of the LDS tile;
 //   * level 3: lane groups gather depth scalars and feature rows (the only remaining
 //     latency-exposed dependent loads) and run the in-order fmaf chains.
+// NT threads per workgroup (64 = one wave per tile: no cross-wave barrier, tiles fully decoupled).
 // CPL channels per lane (4 or 8): with 8, C=80 needs 10 lanes per interval -> 25 intervals per
 // block in flight instead of 12.  `csplit` splits the channel range over blockIdx.y-like halves
 // (tile LDS shrinks -> more resident blocks per CU).  ST selects the store cache policy.
@@ -265,9 +266,9 @@ k_tile_lower_bound2(int n_tiles, int tiles_per_plane, int YX, int TV,
     tile_meta[2 * t + 1] = (lo < n) ? starts[lo] : P;
 }
 
-template <int TV, int CPL, int ST>
-__global__ void __launch_bounds__(256)
-k_pool_fwd_dense2(int C, int Z, int YX, int tiles_per_plane, int csplit,
+template <int TV, int CPL, int ST, int NT>
+__global__ void __launch_bounds__(NT)
+k_pool_fwd_dense2(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_blocks, int swizzle,
                   const float* __restrict__ depth, const float* __restrict__ feat,
                   const int* __restrict__ rd, const int* __restrict__ rf,
                   const int* __restrict__ interval_rank, const int* __restrict__ starts,
@@ -283,7 +284,15 @@ k_pool_fwd_dense2(int C, int Z, int YX, int tiles_per_plane, int csplit,
     int* prd = ivx + TV;                       // [NP_STAGE]
     int* prf = prd + FBBEV_NP_STAGE;           // [NP_STAGE]
     const int tid = threadIdx.x;
-    const int t = blockIdx.x / csplit, half = blockIdx.x - t * csplit;
+    int bid = blockIdx.x;
+    if (swizzle) {  // XCD-aware: dispatch places block b on XCD b%8; give each XCD a contiguous tile range
+        const int per = (n_blocks + 7) >> 3;
+        bid = (bid & 7) * per + (bid >> 3);
+        if (bid >= n_blocks) return;
+    } else if (bid >= n_blocks) {
+        return;
+    }
+    const int t = bid / csplit, half = bid - t * csplit;
     const int c0 = half * CC;
     const int plane = t / tiles_per_plane, k = t - plane * tiles_per_plane;
     const int b = plane / Z, z = plane - b * Z;
@@ -297,7 +306,7 @@ k_pool_fwd_dense2(int C, int Z, int YX, int tiles_per_plane, int csplit,
 
     if (i0 == i1) {
         fbbev_v4f zero; zero[0] = zero[1] = zero[2] = zero[3] = 0.f;
-        for (int idx = tid; idx < n4; idx += 256) {
+        for (int idx = tid; idx < n4; idx += NT) {
             const int c = idx / Q4, j = (idx - c * Q4) * 4;
             if (j < nv) fbbev_store4<ST>(obase + c * cstride + j, zero);
         }
@@ -307,19 +316,19 @@ k_pool_fwd_dense2(int C, int Z, int YX, int tiles_per_plane, int csplit,
     const int ni = i1 - i0;
     const int np = p1 - p0;
     const int rank0 = plane * YX + v0;
-    for (int j = tid; j < ni; j += 256) {
+    for (int j = tid; j < ni; j += NT) {
         ist[j] = starts[i0 + j] - p0;
         iln[j] = lengths[i0 + j];
         ivx[j] = interval_rank[i0 + j] - rank0;
     }
     const int nps = np < FBBEV_NP_STAGE ? np : FBBEV_NP_STAGE;
-    for (int j = tid; j < nps; j += 256) { prd[j] = rd[p0 + j]; prf[j] = rf[p0 + j]; }
-    for (int idx = tid; idx < CC * LD; idx += 256) tile[idx] = 0.f;
+    for (int j = tid; j < nps; j += NT) { prd[j] = rd[p0 + j]; prf[j] = rf[p0 + j]; }
+    for (int idx = tid; idx < CC * LD; idx += NT) tile[idx] = 0.f;
     __syncthreads();
 
     {
         const int lpi = CC / CPL;
-        const int gpb = 256 / lpi;
+        const int gpb = NT / lpi;
         const int g = tid / lpi, slot = tid - g * lpi;
         if (g < gpb) {
             const float* fbase = feat + c0 + slot * CPL;
@@ -337,7 +346,7 @@ k_pool_fwd_dense2(int C, int Z, int YX, int tiles_per_plane, int csplit,
     }
     __syncthreads();
 
-    for (int idx = tid; idx < n4; idx += 256) {
+    for (int idx = tid; idx < n4; idx += NT) {
         const int c = idx / Q4, j = (idx - c * Q4) * 4;
         if (j < nv) {
             const fbbev_v4f val = *reinterpret_cast<const fbbev_v4f*>(tile + c * LD + j);

@@ -97,7 +97,7 @@ class LSSViewTransformerFunction3D(nn.Module):
     """
 
     def __init__(self, grid_config, input_size, downsample=16, accelerate=False, uniform=False,
-                 with_cp=False, extra_relu=False, fused=True, tile_voxels=64,
+                 with_cp=False, extra_relu=False, fused=True, tile_voxels=_capi.DEFAULT_TILE_VOXELS,
                  pool_flags=_capi.DEFAULT_POOL_FLAGS):
         super().__init__()
         self.uniform = uniform

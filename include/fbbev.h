@@ -28,9 +28,11 @@ typedef void* fbbev_stream_t; /* hipStream_t */
 #define FBBEV_E_WORKSPACE (-3)
 
 /* flags of fbbev_bev_pool_v2_dense_fwd (tuning knobs; none changes the result bits) */
-#define FBBEV_POOL_STORE_MASK 0x3   /* output store cache policy: 0 plain, 1 nontemporal, 2 sc1 */
+#define FBBEV_POOL_STORE_MASK 0x3   /* output store cache policy: 0 plain, 1 nontemporal */
 #define FBBEV_POOL_CPL8 0x4         /* 8 channels per lane instead of 4 */
 #define FBBEV_POOL_CSPLIT_SHIFT 4   /* bits 4-7: split the channel range over this many workgroups */
+#define FBBEV_POOL_WG_SHIFT 8       /* bits 8-9: workgroup size 0 -> 256, 1 -> 128 threads */
+#define FBBEV_POOL_XCD_SWIZZLE 0x400 /* give each XCD (block % 8) a contiguous range of tiles */
 
 int fbbev_version(void);
 
@@ -96,7 +98,7 @@ int fbbev_rank_build(const float* coor, int B, int N, int D, int H, int W, const
 
 /* Fused replacement of  feat.new_zeros + bev_pool_v2_forward + permute(0,4,1,2,3).contiguous()
  *   -- bev_pool.py:24-35,88.  Two launches:
- * fbbev_pool_tile_index: for every tile of `tile_voxels` (64/128/256) consecutive voxels of a (b,z)
+ * fbbev_pool_tile_index: for every tile of `tile_voxels` (64..1024) consecutive voxels of a (b,z)
  *   plane, the first interval whose rank falls in it (parallel lower bound over interval_rank) and
  *   that interval's first point.  counts = device-side [P, I] of fbbev_rank_build: no host sync.
  * fbbev_bev_pool_v2_dense_fwd: writes EVERY element of out (B,C,Z,Y,X) exactly once (zeros for empty

@@ -89,7 +89,7 @@ def test_pool_fwd_rows_and_bwd(name, B):
     assert torch.allclose(dg, edg, atol=1e-5, rtol=1e-5)          # wave-tree vs serial channel sum
 
 
-@pytest.mark.parametrize('tv,flags', [(64, 0), (128, 4), (256, 0x24), (64, 0x22), (128, 0x21)])
+@pytest.mark.parametrize('tv,flags', [(64, 0), (128, 4), (256, 0x24), (64, 0x421), (128, 0x125), (512, 0x405), (1024, 0x24)])
 def test_pool_dense_matches_oracle(tv, flags):
     cfg, vt, coor, depth, feat = _case('TINY', 2)
     rb, rd, rf, st, ln, ir, counts = E.rank_build(coor, *_grid3(vt))

@@ -50,25 +50,43 @@ def main():
     print(json.dumps({'variant': 'torch_zero_', 'ms': ms, 'GBps': out.numel() * 4 / ms / 1e6}))
     zero_counts = torch.zeros(2, dtype=torch.int32, device=dev)
     ref = None
-    for tv, cpl8, csplit, st in itertools.product((64, 128, 256), (0, 1), (1, 2), (0, 1, 2)):
-        flags = _capi.pool_flags(store=st, cpl8=bool(cpl8), csplit=csplit)
+    combos = []
+    for tv in (64, 128, 256, 512, 1024):
+        for csplit in (1, 2, 4, 5, 10, 20):
+            if C % (4 * csplit):
+                continue
+            cc = C // csplit
+            lds = (cc * (tv + 4) + 3 * tv + 1024) * 4
+            if lds > 60 * 1024:
+                continue
+            cpl8 = cc % 8 == 0
+            if 128 // (cc // (8 if cpl8 else 4)) < 1:
+                continue
+            for swz in (False, True):
+                for wg in (128, 256):
+                    combos.append((tv, csplit, cpl8, swz, wg))
+    mode = sys.argv[3] if len(sys.argv) > 3 else 'both'
+    for tv, csplit, cpl8, swz, wg in combos:
+        name_v = f'tv{tv}_cs{csplit}_cpl{8 if cpl8 else 4}_wg{wg}' + ('_swz' if swz else '')
+        rec = {'variant': name_v}
         try:
-            _capi.pool_tile_index(idx.interval_rank, idx.interval_starts, idx.counts, idx.n, B, Z, Y, X, ws, tv)
-            f = lambda: _capi.bev_pool_v2_dense_fwd(depth, feat, idx.ranks_depth, idx.ranks_feat, idx.interval_rank,  # noqa
-                                                    idx.interval_starts, idx.interval_lengths, B, C, Z, Y, X, out, ws, tv, flags)
-            ms = timeit(f)
-            if ref is None:
-                ref = out.clone()
-            same = bool(torch.equal(out, ref))
-            rec = {'variant': f'tv{tv}_cpl{8 if cpl8 else 4}_cs{csplit}_st{st}', 'ms': ms, 'GBps_algo': algo / ms / 1e6,
-                   'frac_8TBs': algo / ms / 1e6 / 8000, 'bits_equal_ref': same}
-            if st == 0 and cpl8 == 1 and csplit == 1:   # pure pattern write with the same tiling
+            for st, tag in ((1, 'nt'), (0, 'plain')):
+                flags = _capi.pool_flags(store=st, cpl8=cpl8, csplit=csplit, wg=wg, swizzle=swz)
+                f = lambda: _capi.bev_pool_v2_dense_fwd(depth, feat, idx.ranks_depth, idx.ranks_feat, idx.interval_rank,  # noqa
+                                                        idx.interval_starts, idx.interval_lengths, B, C, Z, Y, X, out, ws, tv, flags)
                 _capi.pool_tile_index(idx.interval_rank, idx.interval_starts, zero_counts, idx.n, B, Z, Y, X, ws, tv)
-                rec['empty_index_ms'] = timeit(f)
-                rec['empty_index_GBps'] = out.numel() * 4 / rec['empty_index_ms'] / 1e6
+                ms = timeit(f, iters=10, warm=2)
+                rec[f'empty_{tag}_GBps'] = round(out.numel() * 4 / ms / 1e6)
+                if st == 1 and mode == 'both':
+                    _capi.pool_tile_index(idx.interval_rank, idx.interval_starts, idx.counts, idx.n, B, Z, Y, X, ws, tv)
+                    ms = timeit(f, iters=10, warm=2)
+                    if ref is None:
+                        ref = out.clone()
+                    rec.update(ms=round(ms, 4), frac_8TBs=round(algo / ms / 1e6 / 8000, 4), bits_equal_ref=bool(torch.equal(out, ref)))
             print(json.dumps(rec), flush=True)
         except Exception as e:  # noqa
-            print(json.dumps({'variant': f'tv{tv}_cpl{cpl8}_cs{csplit}_st{st}', 'error': str(e)}), flush=True)
+            rec['error'] = str(e)
+            print(json.dumps(rec), flush=True)
 
 
 if __name__ == '__main__':
