@@ -38,7 +38,7 @@ def parse():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=16, help='samples per GPU per step (weak scaling)')
     ap.add_argument('--config', default='BL2')
-    ap.add_argument('--tile-voxels', type=int, default=64)
+    ap.add_argument('--tile-voxels', type=int, default=128)
     ap.add_argument('--pool-flags', type=lambda x: int(x, 0), default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)

@@ -150,20 +150,22 @@ def pool_dense_workspace_bytes(B, Z, Y, X):
     return int(lib().fbbev_pool_dense_workspace_bytes(B, Z, Y, X))
 
 
-POOL_STORE_PLAIN, POOL_STORE_NT, POOL_CPL8 = 0, 1, 4
+POOL_STORE_PLAIN, POOL_STORE_NT, POOL_STORE_SC1_NT, POOL_CPL8 = 0, 1, 4, 4
 
 
-def pool_flags(store=POOL_STORE_NT, cpl8=True, csplit=1, wg=256, swizzle=True):
+def pool_flags(store=4, cpl8=True, csplit=2, wg=256, swizzle=True, swz_log2=4):
     """Tuning flags of fbbev_bev_pool_v2_dense_fwd (include/fbbev.h); none changes the result bits."""
     cs = 0xF if csplit == 20 else (csplit & 0xF)
-    return (store & 3) | (POOL_CPL8 if cpl8 else 0) | (cs << 4) | ({256: 0, 128: 1}[wg] << 8) | \
-        (0x400 if swizzle else 0)
+    return (store & 3) | (((store >> 2) & 1) << 17) | (POOL_CPL8 if cpl8 else 0) | (cs << 4) | ({256: 0, 128: 1}[wg] << 8) | \
+        (0x400 if swizzle else 0) | ((swz_log2 & 0x1F) << 12)
 
 
-# measured best on MI355X at BASELINE configs[1] (profiles/r01_pool_variants.md): 64-voxel tiles,
-# 8 channels/lane, nontemporal stores, XCD-contiguous tile order -> 0.87 of the 8 TB/s HBM peak
+# measured best PER LAUNCH on MI355X at BASELINE configs[1], B=16 (profiles/r01_pool_*.jsonl): 128-voxel
+# tiles, channel range split over 2 workgroups, 8 channels/lane, `sc1 nt` stores (do not evict the
+# gathered inputs from L2), chunks of 16 tiles dealt round-robin to the XCDs -> 0.56 ms = 0.745 of 8 TB/s
+# (a linear torch.zero_ of the same buffer: 0.47 ms = 0.86).
 DEFAULT_POOL_FLAGS = pool_flags()
-DEFAULT_TILE_VOXELS = 64
+DEFAULT_TILE_VOXELS = 128
 
 
 def pool_tile_index(interval_rank, interval_starts, counts, n_intervals_max, B, Z, Y, X, tile_ws,

@@ -225,7 +225,11 @@ static int launch_dense2(const dense2_args& a) {
         int e = fbbev_rt_allow_dyn_lds((const void*)k_pool_fwd_dense2<TV, CPL, ST, NT>, a.lds);
         if (e) return e;
     }
-    const long long grid = (a.n_blocks + 7) / 8 * 8;
+    long long grid = a.n_blocks;
+    if (a.swizzle) {  // round up to whole groups of 8 chunks
+        const long long g = 8ll << (a.swizzle - 1);
+        grid = (a.n_blocks + g - 1) / g * g;
+    }
     FBBEV_LAUNCH((k_pool_fwd_dense2<TV, CPL, ST, NT>), grid, NT, a.lds, a.stream, a.C, a.Z, a.yx, a.tpp,
                  a.csplit, (int)a.n_blocks, a.swizzle, a.depth, a.feat, a.rd, a.rf, a.irank, a.starts, a.lengths, a.tile_meta, a.out);
     return fbbev_rt_last_error();
@@ -238,8 +242,16 @@ static int launch_dense2_nt(int nt, const dense2_args& a) {
 
 template <int TV, int CPL>
 static int launch_dense2_st(int st, int nt, const dense2_args& a) {
-    // plain and nontemporal stores only: the sc1 policy measured no better than plain (profiles/)
-    return st == 0 ? launch_dense2_nt<TV, CPL, 0>(nt, a) : launch_dense2_nt<TV, CPL, 1>(nt, a);
+    switch (st) {
+        case 0: return launch_dense2_nt<TV, CPL, 0>(nt, a);
+        case 2: return launch_dense2_nt<TV, CPL, 2>(nt, a);
+        case 3: return launch_dense2_nt<TV, CPL, 3>(nt, a);
+        case 4: return launch_dense2_nt<TV, CPL, 4>(nt, a);
+        case 5: return launch_dense2_nt<TV, CPL, 5>(nt, a);
+        case 6: return launch_dense2_nt<TV, CPL, 6>(nt, a);
+        case 7: return launch_dense2_nt<TV, CPL, 7>(nt, a);
+        default: return launch_dense2_nt<TV, CPL, 1>(nt, a);
+    }
 }
 
 extern "C" int fbbev_bev_pool_v2_dense_fwd(const float* depth, const float* feat,
@@ -259,7 +271,7 @@ extern "C" int fbbev_bev_pool_v2_dense_fwd(const float* depth, const float* feat
     const int tiles_per_plane = (int)((yx + TV - 1) / TV);
     const long long n_tiles = (long long)B * Z * tiles_per_plane;
     if (tile_ws_bytes < (size_t)(n_tiles + 1) * 8) return FBBEV_E_WORKSPACE;
-    const int st = flags & FBBEV_POOL_STORE_MASK;
+    const int st = (flags & FBBEV_POOL_STORE_MASK) | ((flags >> FBBEV_POOL_STORE_HI_SHIFT) & 1) << 2;
     int csplit = (flags >> FBBEV_POOL_CSPLIT_SHIFT) & 0xF;
     if (csplit == 0xF) csplit = 20;
     if (csplit < 1) csplit = 1;
@@ -273,7 +285,12 @@ extern "C" int fbbev_bev_pool_v2_dense_fwd(const float* depth, const float* feat
     a.n_blocks = n_tiles * csplit;
     a.lds = ((size_t)CC * (TV + 4) + 3 * (size_t)TV + 2 * FBBEV_NP_STAGE) * sizeof(float);
     a.stream = stream; a.C = C; a.Z = Z; a.yx = (int)yx; a.tpp = tiles_per_plane; a.csplit = csplit;
-    a.swizzle = (flags & FBBEV_POOL_XCD_SWIZZLE) ? 1 : 0;
+    a.swizzle = 0;
+    if (flags & FBBEV_POOL_XCD_SWIZZLE) {
+        int lg = (flags >> FBBEV_POOL_SWZ_CHUNK_SHIFT) & 0x1F;   // log2(tiles per chunk); 0 -> default
+        if (lg == 0) lg = 6;
+        a.swizzle = lg + 1;
+    }
     if (a.n_blocks + 8 >= (1ll << 31) || a.lds > 160 * 1024) return FBBEV_E_UNSUPPORTED;
     a.depth = depth; a.feat = feat; a.rd = ranks_depth; a.rf = ranks_feat; a.irank = interval_rank;
     a.starts = interval_starts; a.lengths = interval_lengths; a.tile_meta = static_cast<const int*>(tile_ws);

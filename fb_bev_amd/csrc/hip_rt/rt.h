@@ -32,10 +32,10 @@ int fbbev_rt_sort_pairs(void* temp, size_t temp_bytes, const uint32_t* keys_in, 
                         const uint32_t* vals_in, uint32_t* vals_out, size_t n, int bits,
                         fbbev_rt_stream stream);
 
-// 16-byte store with a selectable cache policy for write-once streaming output:
-//   0 = plain, 1 = nontemporal hint, 2 = sc1 (line is not kept in the XCD's L2 --
-//   MI355X_MICROARCH.md "stores of each flavour"), so the output stream does not evict the
-//   depth/feat/index working set that phase 1 gathers from.
+// 16-byte store with a selectable cache policy for the write-once streaming output.
+//   0 plain | 1 nt (clang nontemporal builtin) | 2 sc1 | 3 sc0 sc1 | 4 sc1 nt | 5 sc0 nt | 6 sc0 sc1 nt | 7 sc0
+// (gfx950 cache-control bits; MI355X_MICROARCH.md "stores of each flavour").  Stores have no
+// return value, so the hand-written forms need no extra s_waitcnt bookkeeping.
 typedef float fbbev_v4f __attribute__((ext_vector_type(4)));
 template <int ST>
 __device__ __forceinline__ void fbbev_store4(float* p, fbbev_v4f v) {
@@ -43,6 +43,16 @@ __device__ __forceinline__ void fbbev_store4(float* p, fbbev_v4f v) {
         __builtin_nontemporal_store(v, reinterpret_cast<fbbev_v4f*>(p));
     } else if constexpr (ST == 2) {
         asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+    } else if constexpr (ST == 3) {
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+    } else if constexpr (ST == 4) {
+        asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" : : "v"(p), "v"(v) : "memory");
+    } else if constexpr (ST == 5) {
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 nt" : : "v"(p), "v"(v) : "memory");
+    } else if constexpr (ST == 6) {
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" : : "v"(p), "v"(v) : "memory");
+    } else if constexpr (ST == 7) {
+        asm volatile("global_store_dwordx4 %0, %1, off sc0" : : "v"(p), "v"(v) : "memory");
     } else {
         *reinterpret_cast<fbbev_v4f*>(p) = v;
     }

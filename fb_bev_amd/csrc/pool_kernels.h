@@ -285,13 +285,16 @@ k_pool_fwd_dense2(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_b
     int* prf = prd + FBBEV_NP_STAGE;           // [NP_STAGE]
     const int tid = threadIdx.x;
     int bid = blockIdx.x;
-    if (swizzle) {  // XCD-aware: dispatch places block b on XCD b%8; give each XCD a contiguous tile range
-        const int per = (n_blocks + 7) >> 3;
-        bid = (bid & 7) * per + (bid >> 3);
-        if (bid >= n_blocks) return;
-    } else if (bid >= n_blocks) {
-        return;
+    if (swizzle) {
+        // XCD-aware order: the dispatcher places block b on XCD b%8.  Chunks of S = 2^(swizzle-1)
+        // consecutive tiles are dealt round-robin to the 8 XCDs, so each XCD's L2 sees runs of S
+        // adjacent tiles (contiguous S*TV*4-byte spans per channel row) while the 8 XCDs stay
+        // de-phased by S tiles instead of marching in lock-step 1/8 of the tensor apart.
+        const int sh = swizzle - 1;
+        const int xcd = bid & 7, j = bid >> 3;
+        bid = ((((j >> sh) << 3) + xcd) << sh) + (j & ((1 << sh) - 1));
     }
+    if (bid >= n_blocks) return;
     const int t = bid / csplit, half = bid - t * csplit;
     const int c0 = half * CC;
     const int plane = t / tiles_per_plane, k = t - plane * tiles_per_plane;

@@ -32,7 +32,9 @@ typedef void* fbbev_stream_t; /* hipStream_t */
 #define FBBEV_POOL_CPL8 0x4         /* 8 channels per lane instead of 4 */
 #define FBBEV_POOL_CSPLIT_SHIFT 4   /* bits 4-7: split the channel range over this many workgroups */
 #define FBBEV_POOL_WG_SHIFT 8       /* bits 8-9: workgroup size 0 -> 256, 1 -> 128 threads */
-#define FBBEV_POOL_XCD_SWIZZLE 0x400 /* give each XCD (block % 8) a contiguous range of tiles */
+#define FBBEV_POOL_XCD_SWIZZLE 0x400 /* deal chunks of consecutive tiles round-robin to the 8 XCDs */
+#define FBBEV_POOL_STORE_HI_SHIFT 17 /* bit 17: third bit of the store policy (experimental policies 4-7) */
+#define FBBEV_POOL_SWZ_CHUNK_SHIFT 12 /* bits 12-16: log2(tiles per chunk) for the swizzle, 0 = default */
 
 int fbbev_version(void);
 

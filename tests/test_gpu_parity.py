@@ -151,7 +151,7 @@ def test_pool_forward_bit_exact_vs_oracle_and_reference_kernel(dev, name, B, aug
 
 
 @pytest.mark.parametrize('name,B,aug', CASES)
-@pytest.mark.parametrize('tv,flags', [(64, 0), (64, 5), (128, 5), (256, 0x25), (64, 0x425), (128, 0x125), (512, 0x455), (1024, 0x4a1), (256, 0x4f1)])
+@pytest.mark.parametrize('tv,flags', [(64, 0), (64, 5), (128, 5), (256, 0x25), (64, 0x425), (128, 0x125), (512, 0x455), (1024, 0x4a1), (256, 0x4f1), (128, 0x24424), (64, 0x22416)])
 def test_dense_forward_equals_rows_path(dev, name, B, aug, tv, flags):
     """Fused (B,C,Z,Y,X) kernel == zero-init + rows kernel + permute, bit for bit, and writes every element."""
     from fb_bev_amd import _capi

@@ -23,15 +23,12 @@ timeout 600 python bench.py --steps 30 --warmup 5 > $OUT/bench.json 2> $OUT/benc
 cat $OUT/bench.json; tail -5 $OUT/bench.err
 
 if [ "$MODE" != "quick" ]; then
-  for tv in 64 256; do
-    timeout 300 python bench.py --steps 20 --warmup 5 --tile-voxels $tv --no-cpu-baseline > $OUT/bench_tv$tv.json 2>> $OUT/bench.err
-    cat $OUT/bench_tv$tv.json
-  done
   for b in 1 4 32; do
     timeout 300 python bench.py --steps 20 --warmup 5 --batch $b --no-cpu-baseline > $OUT/bench_b$b.json 2>> $OUT/bench.err
     cat $OUT/bench_b$b.json
   done
   cd /tmp
+  rm -rf $OUT/prof_stats $OUT/prof_fetch $OUT/prof_write
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -- python $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/prof_stats.log 2>&1
   echo "rocprof stats rc=$?" | tee -a $OUT/box.txt
   timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/prof_fetch -- python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/prof_fetch.log 2>&1
@@ -39,8 +36,11 @@ if [ "$MODE" != "quick" ]; then
   timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/prof_write -- python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/prof_write.log 2>&1
   echo "rocprof write rc=$?" | tee -a $OUT/box.txt
   cd $REPO
-  find $OUT -name "*.csv" | head -30
-  # keep the merged-back payload small: drop per-dispatch traces > 20 MB
+  python tools/pmc_to_json.py $OUT BL2_B16_tv128
   find $OUT -name "*.csv" -size +20M -delete
+  if [ "$MODE" == "sweep" ]; then
+    timeout 400 python tools/exp_pool.py REF 16 > $OUT/exp_pool3_REF.jsonl 2>> $OUT/exp_pool.err
+    timeout 400 python tools/exp_pool.py BL5 4 > $OUT/exp_pool3_BL5.jsonl 2>> $OUT/exp_pool.err
+  fi
 fi
 echo "== done $(date)" >> $OUT/box.txt
