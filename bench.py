@@ -98,23 +98,19 @@ def main():
     from fb_bev_amd import synthetic as S
     from fb_bev_amd.view_transformer import LSSViewTransformerFunction3D, _IndexSet
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    from fb_bev_amd import shard
+    world, rank, local_rank = shard.world()
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     dev = torch.device('cuda', local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
+    shard.init('nccl', dev)     # backend "nccl" is RCCL on ROCm; used for the fence + max-reduce only
 
     cfg = S.CONFIGS[args.config]
     B = args.batch
     # every rank gets its own samples (different seeds => different rigs/augmentations)
-    cam = [t.to(dev) for t in S.camera_rig(cfg, B, seed=1000 * rank, bda_aug=True)]
-    depth, ctx = S.depth_and_context(cfg, B, seed=1000 * rank)
+    cam = [t.to(dev) for t in S.camera_rig(cfg, B, seed=shard.shard_seed(rank), bda_aug=True)]
+    depth, ctx = S.depth_and_context(cfg, B, seed=shard.shard_seed(rank))
     depth, ctx = depth.to(dev), ctx.to(dev)
     vt = LSSViewTransformerFunction3D(cfg.grid_config, cfg.input_size, cfg.downsample,
                                       tile_voxels=args.tile_voxels).to(dev)
@@ -142,10 +138,7 @@ def main():
         return idx
 
     def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        shard.fence(dev)
 
     for _ in range(args.warmup):
         idx = step()
@@ -155,10 +148,7 @@ def main():
         idx = step(i)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = shard.max_over_ranks(elapsed, dev)
 
     kern_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)
     P, I = idx.counts.tolist()
@@ -181,7 +171,7 @@ def main():
         total = B * world * args.steps
         res = {
             'metric': 'multi-cam samples/sec (forward view transformation: lift + voxel ranking + bev_pool_v2)',
-            'value': total / elapsed, 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps,
+            'value': shard.whole_job_rate(B, args.steps, elapsed, world), 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'FB-OCC forward projection, BASELINE configs[1] ({cfg.name}): 6x256x704 in, '

@@ -1,0 +1,60 @@
+"""Sample sharding + timing helpers of the multi-GPU bench.
+
+The path shards by independent samples: rank r owns `samples_per_gpu` samples with their own
+camera parameters; there is NO data-path collective.  torch.distributed (RCCL on GPUs, gloo in the
+CPU tests) is used only to fence the timed region and to take the max elapsed time over ranks.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def world():
+    return int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0')), \
+        int(os.environ.get('LOCAL_RANK', '0'))
+
+
+def init(backend, device=None):
+    ws, rank, _ = world()
+    if ws > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        kw = {'device_id': device} if (device is not None and backend == 'nccl') else {}
+        dist.init_process_group(backend, **kw)
+    return ws, rank
+
+
+def shard_seed(rank, base=0):
+    """Seed of rank r's synthetic samples: different rigs / augmentations / features per rank."""
+    return base + 1000 * rank
+
+
+def fence(device=None):
+    """barrier + device sync on both sides of the timed region (bench contract)."""
+    if device is not None and device.type == 'cuda':
+        torch.cuda.synchronize(device)
+    if dist.is_initialized():
+        dist.barrier()
+    if device is not None and device.type == 'cuda':
+        torch.cuda.synchronize(device)
+
+
+def max_over_ranks(seconds, device=None):
+    if not dist.is_initialized():
+        return float(seconds)
+    t = torch.tensor([seconds], dtype=torch.float64, device=device if device is not None else 'cpu')
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value, device=None):
+    if not dist.is_initialized():
+        return int(value)
+    t = torch.tensor([value], dtype=torch.int64, device=device if device is not None else 'cpu')
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(t.item())
+
+
+def whole_job_rate(samples_per_gpu, steps, elapsed_max, world_size):
+    """value = samples ALL ranks processed / max-over-ranks time."""
+    return samples_per_gpu * world_size * steps / elapsed_max
