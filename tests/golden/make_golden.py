@@ -44,6 +44,13 @@ def _identity_decorator(*a, **k):
     return lambda f: f
 
 
+class _BaseModule(nn.Module):
+    """mmcv.runner.BaseModule stand-in: nn.Module that accepts (and ignores) init_cfg."""
+    def __init__(self, init_cfg=None):
+        super().__init__()
+        self.init_cfg = init_cfg
+
+
 class _Registry:
     def register_module(self, *a, **k):
         return _identity_decorator(*a, **k)
@@ -63,7 +70,7 @@ def install_stubs():
             super().__init__()
     _mod('mmcv.cnn.bricks.transformer', TransformerLayerSequence=TransformerLayerSequence,
          build_attention=None)
-    _mod('mmcv.runner', BaseModule=nn.Module, force_fp32=_identity_decorator,
+    _mod('mmcv.runner', BaseModule=_BaseModule, force_fp32=_identity_decorator,
          auto_fp16=_identity_decorator)
     _mod('mmcv.utils', TORCH_VERSION=torch.__version__, digit_version=lambda v: v,
          ext_loader=types.SimpleNamespace(load_ext=lambda *a, **k: None))
@@ -96,6 +103,96 @@ def load_ref(modname, relpath):
     sys.modules[modname] = m
     spec.loader.exec_module(m)
     return m
+
+
+def _inner_stub(query, value, reference_points, spatial_shapes, level_start_index, bev_query_depth,
+                pred_img_depth):
+    """Deterministic stand-in for the inner deformable attention: touches every input, so the
+    reference's rebatch / pad / scatter / normalise logic around it is fully exercised."""
+    return (query * 0.5 + reference_points.sum((-1, -2))[..., None] +
+            bev_query_depth.float().argmax(-1).sum(-1)[..., None] * 0.01 + value.mean(1, keepdim=True) +
+            pred_img_depth.mean((1, 2))[:, None, None])
+
+
+def make_backward_projection_fixtures():
+    from oracle import oracle as O
+    T = sys.modules['mmcv.cnn.bricks.transformer']
+
+    def xavier_init(m, gain=1, bias=0, distribution='normal'):
+        if m is not None and hasattr(m, 'weight') and m.weight is not None:
+            (nn.init.xavier_uniform_ if distribution == 'uniform' else nn.init.xavier_normal_)(m.weight, gain=gain)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, bias)
+
+    def constant_init(m, val, bias=0):
+        if m is not None and hasattr(m, 'weight') and m.weight is not None:
+            nn.init.constant_(m.weight, val)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, bias)
+    sys.modules['mmcv.cnn'].xavier_init, sys.modules['mmcv.cnn'].constant_init = xavier_init, constant_init
+
+    class Inner(nn.Module):
+        def forward(self, query=None, key=None, value=None, reference_points=None, spatial_shapes=None,
+                    level_start_index=None, bev_query_depth=None, pred_img_depth=None):
+            return _inner_stub(query, value, reference_points, spatial_shapes, level_start_index,
+                               bev_query_depth, pred_img_depth)
+    T.build_attention = lambda cfg: Inner()
+    _mod('mmcv.ops'); _mod('mmcv.ops.multi_scale_deform_attn',
+                           multi_scale_deformable_attn_pytorch=lambda v, ss, loc, w: O.msda_grid_sample(v, ss, loc, w))
+    _mod('mmcv.runner.base_module', BaseModule=_BaseModule, ModuleList=nn.ModuleList, Sequential=nn.Sequential)
+    from torch.autograd import Function
+    _mod('refbp.multi_scale_deformable_attn_function', MultiScaleDeformableAttnFunction_fp32=Function,
+         MultiScaleDeformableAttnFunction_fp16=Function)
+    _mod('mmdet3d.models.fbbev.custom_ops.multi_scale_deformable_attn', multi_scale_deformable_attn=None)
+    sca = load_ref('refbp.spatial_cross_attention_depth',
+                   'mmdet3d/models/fbbev/view_transformation/backward_projection/bevformer_utils/'
+                   'spatial_cross_attention_depth.py')
+    sca.xavier_init, sca.constant_init = xavier_init, constant_init
+    sca.build_attention = T.build_attention
+
+    g = torch.Generator().manual_seed(123)
+    B, N, Q, Za, E, DC, H, W = 2, 6, 90, 4, 16, 12, 5, 7
+    dbound = [2.0, 14.0, 1.0]
+    torch.manual_seed(7)
+    mod = sca.DA_SpatialCrossAttention(embed_dims=E, num_cams=N, dropout=0.0, dbound=dbound,
+                                       deformable_attention=dict(type='x'), batch_first=True)
+    query = torch.randn(B, Q, E, generator=g)
+    query_pos = torch.randn(B, Q, E, generator=g)
+    key = torch.randn(N, H * W, B, E, generator=g)
+    ref_cam = torch.rand(N, B, Q, Za, 2, generator=g)
+    mask = torch.rand(N, B, Q, Za, generator=g) < 0.15
+    mask[3] = False                                     # one camera sees nothing (len 0 branch)
+    qdepth = torch.rand(N, B, Q, Za, 1, generator=g) * 16.0
+    pred = torch.rand(B, N, DC, H, W, generator=g).softmax(2)
+    ss = torch.tensor([[H, W]]); ls = torch.tensor([0])
+    with torch.no_grad():
+        out = mod(query, key, key, query_pos=query_pos, reference_points_cam=ref_cam, spatial_shapes=ss,
+                  level_start_index=ls, bev_query_depth=qdepth, pred_img_depth=pred, per_cam_mask_list=mask)
+    np.savez_compressed(os.path.join(OUT, 'da_sca_stub_inner.npz'), query=query.numpy(), query_pos=query_pos.numpy(),
+                        key=key.numpy(), ref_cam=ref_cam.numpy(), mask=mask.numpy(), qdepth=qdepth.numpy(),
+                        pred=pred.numpy(), out=out.numpy(), w=mod.output_proj.weight.detach().numpy(),
+                        b=mod.output_proj.bias.detach().numpy(), dbound=np.array(dbound))
+
+    # DA_MSDeformableAttention.forward on the reference's CPU branch (:596-598; no depth weighting):
+    # pins value_proj / offsets / softmax / the (point, Z-anchor) interleave of the sampling locations.
+    torch.manual_seed(11)
+    M, L, P = 4, 2, 8
+    att = sca.DA_MSDeformableAttention(embed_dims=E, num_heads=M, num_levels=L, num_points=P, num_Z_anchors=Za,
+                                       dropout=0.0, batch_first=True)
+    with torch.no_grad():
+        att.sampling_offsets.weight.normal_(0, 0.3, generator=g)
+        att.attention_weights.weight.normal_(0, 0.5, generator=g)
+    ss2 = torch.tensor([[5, 7], [3, 4]]); ls2 = torch.tensor([0, 35])
+    q2 = torch.randn(3, 20, E, generator=g)
+    v2 = torch.randn(3, 47, E, generator=g)
+    ref2 = torch.rand(3, 20, Za, 2, generator=g)
+    with torch.no_grad():
+        out2 = att(q2, value=v2, reference_points=ref2, spatial_shapes=ss2, level_start_index=ls2,
+                   bev_query_depth=None, pred_img_depth=None)
+    sd = {k: v.numpy() for k, v in att.state_dict().items()}
+    np.savez_compressed(os.path.join(OUT, 'da_msda_cpu_branch.npz'), q=q2.numpy(), v=v2.numpy(), ref=ref2.numpy(),
+                        out=out2.numpy(), **{'sd_' + k: v for k, v in sd.items()})
+    print('backward-projection fixtures written')
 
 
 def main():
@@ -161,6 +258,9 @@ def main():
                         ref_cam_sum=np.float64(ref_cam.double().sum().item()))
     meta['point_sampling_REF_B2_aug'] = dict(mask_count=int(mask.sum()),
                                              per_cam_hits=[int(m.any(-1).sum()) for m in mask])
+
+    # ---- backward projection: real DA_SpatialCrossAttention / DA_MSDeformableAttention code on CPU
+    make_backward_projection_fixtures()
 
     # ---- the reference's own known-answer test (bev_pool.py:144-175), numbers restated verbatim
     known = dict(depth=[0.3, 0.4, 0.2, 0.1, 0.7, 0.6, 0.8, 0.9], depth_shape=[1, 1, 2, 2, 2],
