@@ -6,7 +6,7 @@ tensor is not on a GPU the call raises.
 """
 import ctypes
 import os
-from ctypes import c_int, c_int32, c_int64, c_size_t, c_void_p
+from ctypes import c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 import torch
 
@@ -27,6 +27,7 @@ SIGNATURES = {
     'fbbev_bev_pool_v2_dense_fwd': (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t,
                                             c_int, c_int, c_void_p]),
     'fbbev_msda_fwd': (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_void_p, c_void_p]),
+    'fbbev_da_cross_attn_fwd': (c_int, [c_void_p] * 9 + [c_int] * 10 + [c_float, c_float, c_void_p, c_void_p]),
     'fbbev_msda_bwd': (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p] * 3 + [c_void_p]),
 }
 
@@ -214,3 +215,22 @@ def msda_bwd(value, spatial_shapes, level_start_index, sampling_loc, attn_weight
             B, S, M, Dh, L, Q, P, _dev(grad_value, F32, 'grad_value'),
             _dev(grad_sampling_loc, F32, 'grad_sampling_loc'),
             _dev(grad_attn_weight, F32, 'grad_attn_weight'), _stream()), 'fbbev_msda_bwd')
+
+
+def da_cross_attn_fwd(value, spatial_shapes, level_start_index, pred_depth, ref_cam, mask, qdepth, offsets,
+                      attn, d0, dstep, slots):
+    """value (B*Ncam,S,M,Dh); pred_depth (B*Ncam,DC,H0,W0); ref_cam (Ncam,B,Q,Za,2); mask (Ncam,B,Q,Za) bool;
+    qdepth (Ncam,B,Q,Za); offsets (B,Q,M,L,P,2); attn (B,Q,M,L,P); slots (B,Q,M*Dh)."""
+    Ncam, B, Q, Za = mask.shape
+    _, S, M, Dh = value.shape
+    L, P = attn.shape[3], attn.shape[4]
+    DC = pred_depth.shape[1]
+    if mask.dtype == torch.bool:
+        mask = mask.view(torch.uint8)
+    with _on(value):
+        _check(lib().fbbev_da_cross_attn_fwd(
+            _dev(value, F32, 'value'), _dev(spatial_shapes, I64, 'spatial_shapes'),
+            _dev(level_start_index, I64, 'level_start_index'), _dev(pred_depth, F32, 'pred_depth'),
+            _dev(ref_cam, F32, 'ref_cam'), _dev(mask, torch.uint8, 'mask'), _dev(qdepth, F32, 'qdepth'),
+            _dev(offsets, F32, 'offsets'), _dev(attn, F32, 'attn'), B, Ncam, S, M, Dh, L, Q, P, Za, DC,
+            float(d0), float(dstep), _dev(slots, F32, 'slots'), _stream()), 'fbbev_da_cross_attn_fwd')

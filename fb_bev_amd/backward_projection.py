@@ -1,0 +1,558 @@
+"""Backward projection (BEV -> image refinement with depth-aware deformable cross-attention) --
+host-side mirror of mmdet3d/models/fbbev/view_transformation/backward_projection/:
+  BackwardProjection ................. backward_projection.py:34-133
+  BEVFormer .......................... bevformer_utils/bevformer.py:22-132
+  bevformer_encoder .................. bevformer_utils/bevformer_encoder.py:27-203
+  BEVFormerEncoderLayer .............. bevformer_utils/bevformer_encoder.py:206-377
+  DA_SpatialCrossAttention ........... bevformer_utils/spatial_cross_attention_depth.py:31-223
+  DA_MSDeformableAttention ........... bevformer_utils/spatial_cross_attention_depth.py:361-601
+  CustormLearnedPositionalEncoding ... bevformer_utils/positional_encoding.py:11-68
+  MultiScaleDeformableAttention, FFN . mmcv-full 1.5.2 classes the config names (cfg :176-198)
+Class names, constructor arguments and state_dict keys follow the reference so the
+`backward_projection=dict(type='BackwardProjection', ...)` block of
+occupancy_configs/fb_occ/fbocc-r50-cbgs_depth_16f_16x4_20e.py:154-211 builds unchanged via `build()`
+and reference checkpoints load.  All deformable sampling runs on the HIP kernels of libfbbev_hip.so:
+  * training / autograd: composite path over ms_deform_attn_forward/backward (vectorised rebatch,
+    one host sync for max_len -- the reference needs 6*B);
+  * inference (no grad): fbbev_da_cross_attn_fwd, one fused launch, no sync, no padding.
+"""
+import copy
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _capi
+from .ms_deform_attn import MultiScaleDeformableAttnFunction_fp32
+
+REGISTRY = {}
+
+
+def register(cls):
+    REGISTRY[cls.__name__] = cls
+    return cls
+
+
+def build(cfg, **extra):
+    """mmcv-style build_from_cfg over one flat registry (the reference spreads these names over
+    HEADS / TRANSFORMER / TRANSFORMER_LAYER_SEQUENCE / TRANSFORMER_LAYER / ATTENTION /
+    POSITIONAL_ENCODING / FEEDFORWARD_NETWORK)."""
+    cfg = dict(cfg)
+    typ = cfg.pop('type')
+    cfg.update(extra)
+    return REGISTRY[typ](**cfg)
+
+
+def inv3x3(m):
+    """Closed-form inverse of (...,3,3) matrices (adjugate / determinant): no solver dependency."""
+    a, b, c = m[..., 0, 0], m[..., 0, 1], m[..., 0, 2]
+    d, e, f = m[..., 1, 0], m[..., 1, 1], m[..., 1, 2]
+    g, h, i = m[..., 2, 0], m[..., 2, 1], m[..., 2, 2]
+    A, Bc, C = e * i - f * h, -(d * i - f * g), d * h - e * g
+    det = a * A + b * Bc + c * C
+    adj = torch.stack([torch.stack([A, -(b * i - c * h), b * f - c * e], -1),
+                       torch.stack([Bc, a * i - c * g, -(a * f - c * d)], -1),
+                       torch.stack([C, -(a * h - b * g), a * e - b * d], -1)], -2)
+    return adj / det[..., None, None]
+
+
+def _xavier(m, bias=0.):
+    if m is not None:
+        nn.init.xavier_uniform_(m.weight)
+        nn.init.constant_(m.bias, bias)
+
+
+@register
+class CustormLearnedPositionalEncoding(nn.Module):
+    """positional_encoding.py:11-68."""
+
+    def __init__(self, num_feats, row_num_embed=50, col_num_embed=50, init_cfg=None):
+        super().__init__()
+        self.row_embed = nn.Embedding(row_num_embed, num_feats)
+        self.col_embed = nn.Embedding(col_num_embed, num_feats)
+        nn.init.uniform_(self.row_embed.weight)
+        nn.init.uniform_(self.col_embed.weight)
+        self.num_feats = num_feats
+
+    def forward(self, bs, h, w, device):
+        x_embed = self.col_embed(torch.arange(w, device=device))
+        y_embed = self.row_embed(torch.arange(h, device=device))
+        pos = torch.cat((x_embed.unsqueeze(0).repeat(h, 1, 1), y_embed.unsqueeze(1).repeat(1, w, 1)), dim=-1)
+        return pos.permute(2, 0, 1).unsqueeze(0).repeat(bs, 1, 1, 1)
+
+
+@register
+class FFN(nn.Module):
+    """mmcv.cnn.bricks.transformer.FFN (state_dict: layers.0.0.*, layers.1.*)."""
+
+    def __init__(self, embed_dims=256, feedforward_channels=1024, num_fcs=2, act_cfg=None, ffn_drop=0.,
+                 dropout_layer=None, add_identity=True, init_cfg=None, **kwargs):
+        super().__init__()
+        layers, in_ch = [], embed_dims
+        for _ in range(num_fcs - 1):
+            layers.append(nn.Sequential(nn.Linear(in_ch, feedforward_channels), nn.ReLU(inplace=True),
+                                        nn.Dropout(ffn_drop)))
+            in_ch = feedforward_channels
+        layers.append(nn.Linear(feedforward_channels, embed_dims))
+        layers.append(nn.Dropout(ffn_drop))
+        self.layers = nn.Sequential(*layers)
+        self.add_identity = add_identity
+        self.embed_dims = embed_dims
+
+    def forward(self, x, identity=None):
+        out = self.layers(x)
+        if not self.add_identity:
+            return out
+        return (x if identity is None else identity) + out
+
+
+def _ring_offsets(num_heads):
+    thetas = torch.arange(num_heads, dtype=torch.float32) * (2.0 * math.pi / num_heads)
+    g = torch.stack([thetas.cos(), thetas.sin()], -1)
+    return g / g.abs().max(-1, keepdim=True)[0]
+
+
+@register
+class MultiScaleDeformableAttention(nn.Module):
+    """mmcv.ops.MultiScaleDeformableAttention (BEV self-attention of the encoder layer, cfg :176-180)."""
+
+    def __init__(self, embed_dims=256, num_heads=8, num_levels=4, num_points=4, im2col_step=64, dropout=0.1,
+                 batch_first=False, norm_cfg=None, init_cfg=None):
+        super().__init__()
+        assert embed_dims % num_heads == 0
+        self.embed_dims, self.num_heads, self.num_levels, self.num_points = embed_dims, num_heads, num_levels, num_points
+        self.im2col_step, self.batch_first = im2col_step, batch_first
+        self.dropout = nn.Dropout(dropout)
+        self.sampling_offsets = nn.Linear(embed_dims, num_heads * num_levels * num_points * 2)
+        self.attention_weights = nn.Linear(embed_dims, num_heads * num_levels * num_points)
+        self.value_proj = nn.Linear(embed_dims, embed_dims)
+        self.output_proj = nn.Linear(embed_dims, embed_dims)
+        self.init_weights()
+
+    def init_weights(self):
+        nn.init.constant_(self.sampling_offsets.weight, 0.)
+        g = _ring_offsets(self.num_heads).view(self.num_heads, 1, 1, 2).repeat(1, self.num_levels, self.num_points, 1)
+        for i in range(self.num_points):
+            g[:, :, i, :] *= i + 1
+        self.sampling_offsets.bias.data = g.view(-1)
+        nn.init.constant_(self.attention_weights.weight, 0.)
+        nn.init.constant_(self.attention_weights.bias, 0.)
+        _xavier(self.value_proj)
+        _xavier(self.output_proj)
+
+    def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_padding_mask=None,
+                reference_points=None, spatial_shapes=None, level_start_index=None, **kwargs):
+        if value is None:
+            value = query
+        if identity is None:
+            identity = query
+        if query_pos is not None:
+            query = query + query_pos
+        if not self.batch_first:
+            query, value = query.permute(1, 0, 2), value.permute(1, 0, 2)
+        bs, num_query, _ = query.shape
+        num_value = value.shape[1]
+        value = self.value_proj(value)
+        if key_padding_mask is not None:
+            value = value.masked_fill(key_padding_mask[..., None], 0.0)
+        value = value.view(bs, num_value, self.num_heads, -1)
+        so = self.sampling_offsets(query).view(bs, num_query, self.num_heads, self.num_levels, self.num_points, 2)
+        aw = self.attention_weights(query).view(bs, num_query, self.num_heads, self.num_levels * self.num_points)
+        aw = aw.softmax(-1).view(bs, num_query, self.num_heads, self.num_levels, self.num_points)
+        assert reference_points.shape[-1] == 2
+        norm = torch.stack([spatial_shapes[..., 1], spatial_shapes[..., 0]], -1)
+        loc = reference_points[:, :, None, :, None, :] + so / norm[None, None, None, :, None, :]
+        out = MultiScaleDeformableAttnFunction_fp32.apply(value, spatial_shapes, level_start_index, loc, aw,
+                                                          self.im2col_step)
+        out = self.output_proj(out)
+        if not self.batch_first:
+            out = out.permute(1, 0, 2)
+        return self.dropout(out) + identity
+
+
+@register
+class DA_MSDeformableAttention(nn.Module):
+    """spatial_cross_attention_depth.py:361-601 (no output_proj, :406)."""
+
+    def __init__(self, embed_dims=256, num_heads=8, num_levels=4, num_points=8, num_Z_anchors=4, im2col_step=64,
+                 dropout=0.1, batch_first=True, disable_deformable=False, norm_cfg=None, init_cfg=None):
+        super().__init__()
+        assert embed_dims % num_heads == 0
+        self.embed_dims, self.num_heads, self.num_levels, self.num_points = embed_dims, num_heads, num_levels, num_points
+        self.num_Z_anchors, self.im2col_step, self.batch_first = num_Z_anchors, im2col_step, batch_first
+        self.disable_deformable = disable_deformable
+        self.output_proj = None
+        self.sampling_offsets = nn.Linear(embed_dims, num_heads * num_levels * num_points * 2)
+        self.attention_weights = nn.Linear(embed_dims, num_heads * num_levels * num_points)
+        self.value_proj = nn.Linear(embed_dims, embed_dims)
+        self.init_weights()
+
+    def init_weights(self):
+        """:440-462 -- ring pattern, scaled by (point index within anchor + 1)."""
+        nn.init.constant_(self.sampling_offsets.weight, 0.)
+        self.each_anchor_points = self.num_points // self.num_Z_anchors
+        g = _ring_offsets(self.num_heads).view(self.num_heads, 1, 1, 1, 2).repeat(
+            1, self.num_levels, self.each_anchor_points, self.num_Z_anchors, 1)
+        for i in range(self.each_anchor_points):
+            g[:, :, i, :, :] *= i + 1
+        self.sampling_offsets.bias.data = g.view(-1)
+        nn.init.constant_(self.attention_weights.weight, 0.)
+        nn.init.constant_(self.attention_weights.bias, 0.)
+        _xavier(self.value_proj)
+
+    def project(self, query):
+        """Per-query projections (camera independent): raw offsets (B,Q,M,L,P,2), softmaxed weights."""
+        bs, nq, _ = query.shape
+        so = self.sampling_offsets(query).view(bs, nq, self.num_heads, self.num_levels, self.num_points, 2)
+        aw = self.attention_weights(query).view(bs, nq, self.num_heads, self.num_levels * self.num_points)
+        if self.disable_deformable:
+            so, aw = so * 0, aw * 0
+        aw = aw.softmax(-1).view(bs, nq, self.num_heads, self.num_levels, self.num_points)
+        return so, aw
+
+    def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_padding_mask=None,
+                reference_points=None, spatial_shapes=None, level_start_index=None, bev_query_depth=None,
+                pred_img_depth=None, **kwargs):
+        """Composite (autograd) path == the reference's CUDA branch (:513-595)."""
+        if value is None:
+            value = query
+        if query_pos is not None:
+            query = query + query_pos
+        if not self.batch_first:
+            query, value = query.permute(1, 0, 2), value.permute(1, 0, 2)
+        bs, nq, _ = query.shape
+        num_value = value.shape[1]
+        value = self.value_proj(value)
+        if key_padding_mask is not None:
+            value = value.masked_fill(key_padding_mask[..., None], 0.0)
+        value = value.view(bs, num_value, self.num_heads, -1)
+        so, aw = self.project(query)
+        norm = torch.stack([spatial_shapes[..., 1], spatial_shapes[..., 0]], -1)
+        Za = reference_points.shape[2]
+        P = self.num_points
+        so = (so / norm[None, None, None, :, None, :]).view(bs, nq, self.num_heads, self.num_levels, P // Za, Za, 2)
+        loc = (reference_points[:, :, None, None, None, :, :] + so).view(bs, nq, self.num_heads, self.num_levels, P, 2)
+        Fn = MultiScaleDeformableAttnFunction_fp32
+        dref = reference_points.reshape(bs, nq * Za, 1, 1, 1, 2).contiguous()
+        dsamp = Fn.apply(pred_img_depth.unsqueeze(2).contiguous(), spatial_shapes[0:1], level_start_index[0:1], dref,
+                         torch.ones_like(dref[..., 0]).contiguous(), self.im2col_step).reshape(bs, nq, Za, -1)
+        dw = (dsamp * bev_query_depth).sum(-1)
+        dw = dw.unsqueeze(2).repeat(1, 1, P // Za, 1).reshape(bs, nq, P)
+        aw = aw * dw[:, :, None, None, :]
+        out = Fn.apply(value, spatial_shapes, level_start_index, loc.contiguous(), aw.contiguous(), self.im2col_step)
+        if not self.batch_first:
+            out = out.permute(1, 0, 2)
+        return out
+
+
+@register
+class DA_SpatialCrossAttention(nn.Module):
+    """spatial_cross_attention_depth.py:31-223."""
+
+    def __init__(self, embed_dims=256, num_cams=6, pc_range=None, dropout=0.1, init_cfg=None, batch_first=False,
+                 deformable_attention=dict(type='DA_MSDeformableAttention', embed_dims=256, num_levels=4),
+                 layer_scale=None, dbound=None, fused=True, **kwargs):
+        super().__init__()
+        self.dropout = nn.Dropout(dropout)
+        self.pc_range = pc_range
+        self.deformable_attention = build(deformable_attention)
+        self.embed_dims, self.num_cams, self.dbound, self.batch_first = embed_dims, num_cams, dbound, batch_first
+        self.output_proj = nn.Linear(embed_dims, embed_dims)
+        self.layer_scale = nn.Parameter(layer_scale * torch.ones(embed_dims)) if layer_scale is not None else None
+        self.fused = fused
+        _xavier(self.output_proj)
+
+    # ---- inference: one fused HIP launch (fbbev_da_cross_attn_fwd), no host sync
+    def _slots_fused(self, query, value, reference_points_cam, mask, bev_query_depth, pred_img_depth,
+                     spatial_shapes, level_start_index):
+        da = self.deformable_attention
+        B, Q, E = query.shape
+        ncam, S, _, _ = value.shape
+        v = da.value_proj(value.permute(2, 0, 1, 3).reshape(B * ncam, S, E)).view(B * ncam, S, da.num_heads, -1)
+        so, aw = da.project(query)
+        DC, H0, W0 = pred_img_depth.shape[2:]
+        slots = torch.empty((B, Q, E), dtype=torch.float32, device=query.device)
+        _capi.da_cross_attn_fwd(v.contiguous().float(), spatial_shapes.to(torch.int64).contiguous(),
+                                level_start_index.to(torch.int64).contiguous(),
+                                pred_img_depth.reshape(B * ncam, DC, H0, W0).contiguous().float(),
+                                reference_points_cam.contiguous().float(), mask.contiguous(),
+                                bev_query_depth.squeeze(-1).contiguous().float(), so.contiguous().float(),
+                                aw.contiguous().float(), self.dbound[0], self.dbound[2], slots)
+        return slots
+
+    # ---- training: vectorised rebatch + composite deformable attention (autograd through the MSDA op)
+    def _slots_composite(self, query, value, reference_points_cam, mask, bev_query_depth, pred_img_depth,
+                         spatial_shapes, level_start_index):
+        B, Q, E = query.shape
+        ncam, S, _, _ = value.shape
+        DC = pred_img_depth.shape[2]
+        hit = mask.any(-1).permute(1, 0, 2)                                    # (B,N,Q)
+        lens = hit.sum(-1)
+        max_len = max(int(lens.max()), 1)                                      # the ONE host sync
+        order = torch.argsort((~hit).to(torch.uint8), dim=-1, stable=True)[..., :max_len]   # hit queries first, ascending
+        valid = torch.arange(max_len, device=query.device)[None, None] < lens[..., None]
+        gi = order[..., None]
+        q_re = torch.gather(query[:, None].expand(B, ncam, Q, E), 2, gi.expand(-1, -1, -1, E)) * valid[..., None]
+        ref = reference_points_cam.permute(1, 0, 2, 3, 4)                      # (B,N,Q,Za,2)
+        Za = ref.shape[3]
+        r_re = torch.gather(ref, 2, gi[..., None].expand(-1, -1, -1, Za, 2)) * valid[..., None, None]
+        d = bev_query_depth.permute(1, 0, 2, 3, 4).squeeze(-1)                 # (B,N,Q,Za)
+        d_re = torch.gather(d, 2, gi.expand(-1, -1, -1, Za)) * valid[..., None]
+        bins = torch.clip(torch.floor((d_re - self.dbound[0]) / self.dbound[2]), 0, DC - 1).to(torch.long)
+        onehot = F.one_hot(bins, num_classes=DC)
+        pred = pred_img_depth.reshape(B * ncam, DC, -1).permute(0, 2, 1)
+        val = value.permute(2, 0, 1, 3).reshape(B * ncam, S, E)
+        out = self.deformable_attention(query=q_re.reshape(B * ncam, max_len, E), key=val, value=val,
+                                        reference_points=r_re.reshape(B * ncam, max_len, Za, 2),
+                                        spatial_shapes=spatial_shapes, level_start_index=level_start_index,
+                                        bev_query_depth=onehot.reshape(B * ncam, max_len, Za, DC),
+                                        pred_img_depth=pred).view(B, ncam, max_len, E)
+        out = out * valid[..., None]
+        slots = torch.zeros_like(query)
+        for i in range(ncam):                                                  # camera order == reference (:208-211)
+            slots = slots.scatter_add(1, order[:, i, :, None].expand(-1, -1, E), out[:, i])
+        count = torch.clamp(hit.sum(1), min=1.0)
+        return slots / count[..., None]
+
+    def forward(self, query, key, value, residual=None, query_pos=None, key_padding_mask=None, reference_points=None,
+                spatial_shapes=None, reference_points_cam=None, level_start_index=None, flag='encoder',
+                bev_query_depth=None, pred_img_depth=None, bev_mask=None, per_cam_mask_list=None, **kwargs):
+        if key is None:
+            key = query
+        if value is None:
+            value = key
+        inp_residual = query if residual is None else residual
+        if query_pos is not None:
+            query = query + query_pos
+        mask = per_cam_mask_list
+        if bev_mask is not None:
+            mask = mask & bev_mask[None, :, :, None]
+        needs_grad = torch.is_grad_enabled() and any(
+            t is not None and t.requires_grad for t in (query, value, pred_img_depth)) or \
+            (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()))
+        fn = self._slots_composite if (needs_grad or not self.fused) else self._slots_fused
+        slots = fn(query, value, reference_points_cam, mask, bev_query_depth, pred_img_depth, spatial_shapes,
+                   level_start_index)
+        slots = self.output_proj(slots)
+        if self.layer_scale is not None:
+            slots = self.layer_scale * slots
+        return self.dropout(slots) + inp_residual
+
+
+@register
+class BEVFormerEncoderLayer(nn.Module):
+    """bevformer_encoder.py:206-377 (+ custom_base_transformer_layer.py:38-175)."""
+
+    def __init__(self, attn_cfgs, feedforward_channels=512, ffn_dropout=0.0, operation_order=None,
+                 act_cfg=dict(type='ReLU', inplace=True), norm_cfg=dict(type='LN'), ffn_num_fcs=2, ffn_cfgs=None,
+                 batch_first=True, **kwargs):
+        super().__init__()
+        assert len(operation_order) in {2, 4, 6}
+        self.operation_order = tuple(operation_order)
+        self.batch_first = batch_first
+        self.pre_norm = operation_order[0] == 'norm'
+        num_attn = operation_order.count('self_attn') + operation_order.count('cross_attn')
+        if isinstance(attn_cfgs, dict):
+            attn_cfgs = [copy.deepcopy(attn_cfgs) for _ in range(num_attn)]
+        assert len(attn_cfgs) == num_attn
+        self.attentions = nn.ModuleList()
+        for cfg in attn_cfgs:
+            cfg = dict(cfg)
+            cfg.setdefault('batch_first', batch_first)
+            self.attentions.append(build(cfg))
+        self.embed_dims = self.attentions[0].embed_dims
+        ffn = dict(type='FFN', embed_dims=self.embed_dims, feedforward_channels=feedforward_channels,
+                   num_fcs=ffn_num_fcs, ffn_drop=ffn_dropout, act_cfg=act_cfg)
+        if ffn_cfgs:
+            ffn.update(ffn_cfgs)
+            ffn['feedforward_channels'] = feedforward_channels     # deprecated-arg override (:88-99)
+            ffn['ffn_drop'] = ffn_dropout
+        self.ffns = nn.ModuleList([build(ffn) for _ in range(operation_order.count('ffn'))])
+        self.norms = nn.ModuleList([nn.LayerNorm(self.embed_dims) for _ in range(operation_order.count('norm'))])
+
+    def forward(self, query, key=None, value=None, bev_pos=None, ref_2d=None, ref_3d=None, bev_h=None, bev_w=None,
+                reference_points_cam=None, spatial_shapes=None, level_start_index=None, bev_mask=None,
+                bev_query_depth=None, per_cam_mask_list=None, pred_img_depth=None, key_pos=None, **kwargs):
+        ni = ai = fi = 0
+        identity = query
+        for layer in self.operation_order:
+            if layer == 'self_attn':
+                query = self.attentions[ai](
+                    query, None, None, identity if self.pre_norm else None, query_pos=bev_pos, key_pos=bev_pos,
+                    key_padding_mask=bev_mask, reference_points=ref_2d,
+                    spatial_shapes=torch.tensor([[bev_h, bev_w]], device=query.device),
+                    level_start_index=torch.tensor([0], device=query.device))
+                ai += 1
+                identity = query
+            elif layer == 'norm':
+                query = self.norms[ni](query)
+                ni += 1
+            elif layer == 'cross_attn':
+                query = self.attentions[ai](
+                    query, key, value, identity if self.pre_norm else None, query_pos=bev_pos, key_pos=key_pos,
+                    reference_points=ref_3d, reference_points_cam=reference_points_cam, spatial_shapes=spatial_shapes,
+                    level_start_index=level_start_index, bev_query_depth=bev_query_depth,
+                    pred_img_depth=pred_img_depth, bev_mask=bev_mask, per_cam_mask_list=per_cam_mask_list)
+                ai += 1
+                identity = query
+            elif layer == 'ffn':
+                query = self.ffns[fi](query, identity if self.pre_norm else None)
+                fi += 1
+        return query
+
+
+@register
+class bevformer_encoder(nn.Module):
+    """bevformer_encoder.py:27-203."""
+
+    def __init__(self, transformerlayers=None, num_layers=None, pc_range=None, grid_config=None, data_config=None,
+                 return_intermediate=False, dataset_type='nuscenes', fix_bug=False, init_cfg=None, **kwargs):
+        super().__init__()
+        layers = transformerlayers if isinstance(transformerlayers, list) else \
+            [copy.deepcopy(transformerlayers) for _ in range(num_layers)]
+        self.layers = nn.ModuleList([build(c) for c in layers])
+        self.num_layers = num_layers
+        self.embed_dims = self.layers[0].embed_dims
+        self.return_intermediate = return_intermediate
+        self.x_bound, self.y_bound, self.z_bound = grid_config['x'], grid_config['y'], grid_config['z']
+        self.final_dim = data_config['input_size']
+        self.pc_range = pc_range
+
+    def get_reference_points(self, H, W, Z=8, dim='3d', bs=1, device='cuda', dtype=torch.float):
+        """:52-89."""
+        if dim == '3d':
+            X = torch.arange(*self.x_bound, dtype=torch.float) + self.x_bound[-1] / 2
+            Y = torch.arange(*self.y_bound, dtype=torch.float) + self.y_bound[-1] / 2
+            Zs = torch.arange(*self.z_bound, dtype=torch.float) + self.z_bound[-1] / 2
+            Y, X, Zs = torch.meshgrid([Y, X, Zs], indexing='ij')
+            return torch.stack([X, Y, Zs], dim=-1).to(dtype).to(device)
+        ref_y, ref_x = torch.meshgrid(torch.linspace(0.5, H - 0.5, H, dtype=dtype, device=device),
+                                      torch.linspace(0.5, W - 0.5, W, dtype=dtype, device=device), indexing='ij')
+        ref_y = ref_y.reshape(-1)[None] / H
+        ref_x = ref_x.reshape(-1)[None] / W
+        return torch.stack((ref_x, ref_y), -1).repeat(bs, 1, 1).unsqueeze(2)
+
+    def point_sampling(self, reference_points, pc_range, img_metas, cam_params=None, gt_bboxes_3d=None):
+        """:91-120 -- ego voxel centres -> per-camera normalised pixel coords, mask, camera depth."""
+        rots, trans, intrins, post_rots, post_trans, bda = [t.float() for t in cam_params]
+        B, N, _ = trans.shape
+        eps = 1e-5
+        ogfH, ogfW = self.final_dim
+        rp = reference_points[None, None].repeat(B, N, 1, 1, 1, 1)
+        rp = inv3x3(bda).view(B, 1, 1, 1, 1, 3, 3).matmul(rp.unsqueeze(-1)).squeeze(-1)
+        rp = rp - trans.view(B, N, 1, 1, 1, 3)
+        combine = inv3x3(rots.matmul(inv3x3(intrins)))
+        cam = combine.view(B, N, 1, 1, 1, 3, 3).matmul(rp.unsqueeze(-1)).squeeze(-1)
+        cam = torch.cat([cam[..., 0:2] / torch.maximum(cam[..., 2:3], torch.ones_like(cam[..., 2:3]) * eps),
+                         cam[..., 2:3]], 5)
+        cam = post_rots.view(B, N, 1, 1, 1, 3, 3).matmul(cam.unsqueeze(-1)).squeeze(-1)
+        cam = cam + post_trans.view(B, N, 1, 1, 1, 3)
+        cam = torch.cat([cam[..., 0:1] / ogfW, cam[..., 1:2] / ogfH, cam[..., 2:3]], -1)
+        mask = (cam[..., 2:3] > eps) & (cam[..., 0:1] > eps) & (cam[..., 0:1] < (1.0 - eps)) & \
+               (cam[..., 1:2] > eps) & (cam[..., 1:2] < (1.0 - eps))
+        _, _, H, W, D, _ = cam.shape
+        cam = cam.permute(1, 0, 2, 3, 4, 5).reshape(N, B, H * W, D, 3)
+        mask = mask.permute(1, 0, 2, 3, 4, 5).reshape(N, B, H * W, D, 1).squeeze(-1)
+        return rp, cam[..., :2], mask, cam[..., 2:3]
+
+    def forward(self, bev_query, key, value, *args, bev_h=None, bev_w=None, bev_pos=None, spatial_shapes=None,
+                level_start_index=None, cam_params=None, gt_bboxes_3d=None, pred_img_depth=None, bev_mask=None,
+                prev_bev=None, **kwargs):
+        """:123-203."""
+        ref_3d = self.get_reference_points(bev_h, bev_w, self.pc_range[5] - self.pc_range[2], dim='3d',
+                                           bs=bev_query.size(1), device=bev_query.device, dtype=bev_query.dtype)
+        ref_2d = self.get_reference_points(bev_h, bev_w, dim='2d', bs=bev_query.size(1), device=bev_query.device,
+                                           dtype=bev_query.dtype)
+        ref_3d, ref_cam, per_cam_mask_list, bev_query_depth = self.point_sampling(
+            ref_3d, self.pc_range, kwargs.get('img_metas'), cam_params=cam_params, gt_bboxes_3d=gt_bboxes_3d)
+        bev_query = bev_query.permute(1, 0, 2)
+        bev_pos = bev_pos.permute(1, 0, 2)
+        output, inter = bev_query, []
+        for layer in self.layers:
+            output = layer(bev_query, key, value, bev_pos=bev_pos, ref_2d=ref_2d, ref_3d=ref_3d, bev_h=bev_h,
+                           bev_w=bev_w, spatial_shapes=spatial_shapes, level_start_index=level_start_index,
+                           reference_points_cam=ref_cam, per_cam_mask_list=per_cam_mask_list, bev_mask=bev_mask,
+                           bev_query_depth=bev_query_depth, pred_img_depth=pred_img_depth)
+            bev_query = output
+            if self.return_intermediate:
+                inter.append(output)
+        return torch.stack(inter) if self.return_intermediate else output
+
+
+@register
+class BEVFormer(nn.Module):
+    """bevformer.py:22-132."""
+
+    def __init__(self, num_cams=6, encoder=None, embed_dims=256, output_dims=256, use_cams_embeds=True, **kwargs):
+        super().__init__()
+        self.encoder = build(encoder)
+        self.embed_dims, self.num_cams, self.output_dims = embed_dims, num_cams, output_dims
+        self.use_cams_embeds = use_cams_embeds
+        self.cams_embeds = nn.Parameter(torch.Tensor(num_cams, embed_dims))
+        self.init_weights()
+
+    def init_weights(self):
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        for m in self.modules():
+            if isinstance(m, (DA_MSDeformableAttention, MultiScaleDeformableAttention)):
+                m.init_weights()
+        nn.init.normal_(self.cams_embeds)
+
+    def forward(self, mlvl_feats, bev_queries, bev_h, bev_w, bev_pos=None, cam_params=None, gt_bboxes_3d=None,
+                pred_img_depth=None, prev_bev=None, bev_mask=None, **kwargs):
+        bev_pos = bev_pos.flatten(2).permute(2, 0, 1)
+        feats, shapes = [], []
+        for feat in mlvl_feats:
+            _, _, c, h, w = feat.shape
+            f = feat.flatten(3).permute(1, 0, 3, 2)
+            ce = self.cams_embeds[:, None, None, :].to(f.dtype)
+            f = f + (ce if self.use_cams_embeds else ce * 0)
+            shapes.append((h, w))
+            feats.append(f)
+        feat_flatten = torch.cat(feats, 2)
+        spatial_shapes = torch.as_tensor(shapes, dtype=torch.long, device=bev_pos.device)
+        level_start_index = torch.cat((spatial_shapes.new_zeros((1,)), spatial_shapes.prod(1).cumsum(0)[:-1]))
+        feat_flatten = feat_flatten.permute(0, 2, 1, 3)                        # (num_cam, sum HW, bs, C)
+        return self.encoder(bev_queries, feat_flatten, feat_flatten, bev_h=bev_h, bev_w=bev_w, bev_pos=bev_pos,
+                            spatial_shapes=spatial_shapes, level_start_index=level_start_index, cam_params=cam_params,
+                            gt_bboxes_3d=gt_bboxes_3d, pred_img_depth=pred_img_depth, prev_bev=prev_bev,
+                            bev_mask=bev_mask, **kwargs)
+
+
+@register
+class BackwardProjection(nn.Module):
+    """backward_projection.py:34-133."""
+
+    def __init__(self, *args, transformer=None, positional_encoding=None, pc_range=None, in_channels=64,
+                 out_channels=64, use_zero_embedding=False, bev_h=30, bev_w=30, **kwargs):
+        super().__init__()
+        self.bev_h, self.bev_w, self.pc_range = bev_h, bev_w, pc_range
+        self.use_zero_embedding = use_zero_embedding
+        self.real_w = pc_range[3] - pc_range[0]
+        self.real_h = pc_range[4] - pc_range[1]
+        self.positional_encoding = build(positional_encoding)
+        self.transformer = build(transformer)
+        self.embed_dims = self.transformer.embed_dims
+        self.bev_embedding = nn.Embedding(bev_h * bev_w, self.embed_dims)
+
+    def init_weights(self):
+        self.transformer.init_weights()
+
+    def forward(self, mlvl_feats, img_metas, lss_bev=None, gt_bboxes_3d=None, cam_params=None, pred_img_depth=None,
+                bev_mask=None):
+        bs = mlvl_feats[0].shape[0]
+        dtype = mlvl_feats[0].dtype
+        bev_queries = self.bev_embedding.weight.to(dtype).unsqueeze(1).repeat(1, bs, 1)
+        if lss_bev is not None:
+            bev_queries = bev_queries + lss_bev.flatten(2).permute(2, 0, 1)
+        if bev_mask is not None:
+            bev_mask = bev_mask.reshape(bs, -1)
+        bev_pos = self.positional_encoding(bs, self.bev_h, self.bev_w, bev_queries.device).to(dtype)
+        bev = self.transformer(mlvl_feats, bev_queries, self.bev_h, self.bev_w,
+                               grid_length=(self.real_h / self.bev_h, self.real_w / self.bev_w), bev_pos=bev_pos,
+                               img_metas=img_metas, cam_params=cam_params, gt_bboxes_3d=gt_bboxes_3d,
+                               pred_img_depth=pred_img_depth, prev_bev=None, bev_mask=bev_mask)
+        return bev.permute(0, 2, 1).view(bs, -1, self.bev_h, self.bev_w).contiguous()

@@ -5,6 +5,7 @@
 #include "rank_kernels.h"
 #include "msda_kernels.h"
 #include "geom_kernels.h"
+#include "da_kernels.h"
 #include "../../include/fbbev.h"
 
 #define FBBEV_CHECK_LAUNCH()                      \
@@ -347,6 +348,30 @@ extern "C" int fbbev_msda_bwd(const float* value, const int64_t* spatial_shapes,
     else if (channels <= 32) FBBEV_MSDA_BWD(32);
     else FBBEV_MSDA_BWD(64);
 #undef FBBEV_MSDA_BWD
+    FBBEV_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------ fused DA cross-attention
+extern "C" int fbbev_da_cross_attn_fwd(const float* value, const int64_t* spatial_shapes,
+                                       const int64_t* level_start_index, const float* pred_depth,
+                                       const float* ref_cam, const uint8_t* mask, const float* qdepth,
+                                       const float* offsets, const float* attn, int B, int Ncam, int S, int M,
+                                       int Dh, int L, int Q, int P, int Za, int DC, float d0, float dstep,
+                                       float* slots, fbbev_stream_t stream_) {
+    if (B <= 0 || Ncam <= 0 || S <= 0 || M <= 0 || Dh <= 0 || L <= 0 || Q < 0 || P <= 0 || Za <= 0 || DC <= 0)
+        return FBBEV_E_BADARG;
+    if (Za > FBBEV_DA_MAX_ZA || P % Za != 0) return FBBEV_E_UNSUPPORTED;
+    if (dstep == 0.f) return FBBEV_E_BADARG;
+    const long long n = (long long)B * Q * M * Dh;
+    if (n == 0) return 0;
+    if (!value || !spatial_shapes || !level_start_index || !pred_depth || !ref_cam || !mask || !qdepth ||
+        !offsets || !attn || !slots) return FBBEV_E_BADARG;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    FBBEV_LAUNCH(k_da_cross_attn_fwd, blocks, 256, 0, (fbbev_rt_stream)stream_, n, value, spatial_shapes,
+                 level_start_index, pred_depth, ref_cam, mask, qdepth, offsets, attn, B, Ncam, S, M, Dh, L, Q, P,
+                 Za, DC, d0, dstep, slots);
     FBBEV_CHECK_LAUNCH();
     return 0;
 }

@@ -1,0 +1,103 @@
+// da_kernels.h -- fused depth-aware spatial cross-attention sampling (backward projection).
+//
+// Replaces, in ONE launch, the sampling core of DA_SpatialCrossAttention + DA_MSDeformableAttention
+// (fbbev/view_transformation/backward_projection/bevformer_utils/spatial_cross_attention_depth.py):
+//   :163-169  6*B nonzero() host syncs building per-camera query lists, padded to max_len
+//   :173-186  rebatch of queries / reference points / depths in Python loops (18*B index-puts)
+//   :196-199  one-hot of the query depth bin  -> (B*6, L, Za, DC) int64
+//   :584-590  MSDA #2: the whole DC-channel depth distribution sampled at every reference point,
+//             then dotted with the one-hot                     -> here: ONE bilinear sample of the
+//             query's own bin plane (identical value: the dot product with a one-hot selects it)
+//   :592-595  attention_weights *= depth weight (no renormalisation); MSDA #3 value sampling
+//   :208-216  scatter-add back per camera in camera order, divide by the number of cameras hit
+// The per-query Linear layers (sampling_offsets, attention_weights) do not depend on the camera, so
+// the host computes them ONCE per BEV query (the reference recomputes them per (camera, query) pair
+// after rebatching) and hands them in.
+//
+// Semantics kept exactly: a query "hits" a camera if ANY of its Za anchors projects inside the image
+// (per_cam_mask.sum(-1) > 0); for a hit camera ALL Za anchors are sampled, including the ones whose
+// own mask bit is false; point index p = i*Za + z uses anchor z = p % Za (:560-570); cameras are
+// accumulated in index order; empty hit set -> count clamped to 1.
+#pragma once
+#include "rt.h"
+#include "msda_kernels.h"
+
+#define FBBEV_DA_MAX_ZA 8
+
+// bilinear sample of ONE plane (H,W) row-major at normalised (x,y), MSDA validity/padding rules
+__device__ __forceinline__ float fbbev_plane_sample(const float* __restrict__ plane, int H, int W, float x,
+                                                    float y) {
+    const float h_im = y * H - 0.5f, w_im = x * W - 0.5f;
+    if (!(h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W)) return 0.f;
+    const fbbev_bilinear s = fbbev_bilinear_setup(h_im, w_im, H, W, 1);
+    const float v1 = s.o1 >= 0 ? plane[s.o1] : 0.f;
+    const float v2 = s.o2 >= 0 ? plane[s.o2] : 0.f;
+    const float v3 = s.o3 >= 0 ? plane[s.o3] : 0.f;
+    const float v4 = s.o4 >= 0 ? plane[s.o4] : 0.f;
+    return s.w1 * v1 + s.w2 * v2 + s.w3 * v3 + s.w4 * v4;
+}
+
+// value (B*Ncam,S,M,Dh); pred_depth (B*Ncam,DC,H0,W0); ref_cam (Ncam,B,Q,Za,2); mask (Ncam,B,Q,Za) u8;
+// qdepth (Ncam,B,Q,Za); offsets (B,Q,M,L,P,2) raw; attn (B,Q,M,L,P) softmaxed; slots (B,Q,M*Dh)
+__global__ void __launch_bounds__(256)
+k_da_cross_attn_fwd(long long n, const float* __restrict__ value, const int64_t* __restrict__ spatial_shapes,
+                    const int64_t* __restrict__ level_start, const float* __restrict__ pred_depth,
+                    const float* __restrict__ ref_cam, const unsigned char* __restrict__ mask,
+                    const float* __restrict__ qdepth, const float* __restrict__ offsets,
+                    const float* __restrict__ attn, int B, int Ncam, int S, int M, int Dh, int L, int Q, int P,
+                    int Za, int DC, float d0, float dstep, float* __restrict__ slots) {
+    const int row_stride = M * Dh;
+    const int H0 = (int)spatial_shapes[0], W0 = (int)spatial_shapes[1];
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < n;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % Dh);
+        const long long unit = idx / Dh;               // (b*Q + q)*M + m
+        const int m = (int)(unit % M);
+        const long long bq = unit / M;
+        const int q = (int)(bq % Q);
+        const int b = (int)(bq / Q);
+        float acc = 0.f;
+        int count = 0;
+        for (int cam = 0; cam < Ncam; ++cam) {
+            const long long base = (((long long)cam * B + b) * Q + q) * Za;
+            bool hit = false;
+            for (int z = 0; z < Za; ++z) hit = hit || (mask[base + z] != 0);
+            if (!hit) continue;
+            ++count;
+            const long long bn = (long long)b * Ncam + cam;
+            float rx[FBBEV_DA_MAX_ZA], ry[FBBEV_DA_MAX_ZA], dw[FBBEV_DA_MAX_ZA];
+            for (int z = 0; z < Za; ++z) {
+                rx[z] = ref_cam[(base + z) * 2];
+                ry[z] = ref_cam[(base + z) * 2 + 1];
+                // :196-197  bin = clip(floor((d - dbound[0]) / dbound[2]), 0, DC-1)
+                float fb = floorf(__fdiv_rn(__fsub_rn(qdepth[base + z], d0), dstep));
+                fb = fminf(fmaxf(fb, 0.f), (float)(DC - 1));
+                const int bin = (int)fb;
+                dw[z] = fbbev_plane_sample(pred_depth + (bn * DC + bin) * (long long)(H0 * W0), H0, W0, rx[z], ry[z]);
+            }
+            float col = 0.f;
+            long long wp = unit * L * P;
+            for (int l = 0; l < L; ++l) {
+                const int sh = (int)spatial_shapes[2 * l], sw = (int)spatial_shapes[2 * l + 1];
+                const float* vp = value + (bn * S + level_start[l]) * row_stride + m * Dh + c;
+                for (int p = 0; p < P; ++p, ++wp) {
+                    const int z = p % Za;
+                    const float loc_w = rx[z] + __fdiv_rn(offsets[wp * 2], (float)sw);
+                    const float loc_h = ry[z] + __fdiv_rn(offsets[wp * 2 + 1], (float)sh);
+                    const float weight = attn[wp] * dw[z];
+                    const float h_im = loc_h * sh - 0.5f, w_im = loc_w * sw - 0.5f;
+                    if (h_im > -1.f && w_im > -1.f && h_im < (float)sh && w_im < (float)sw) {
+                        const fbbev_bilinear s = fbbev_bilinear_setup(h_im, w_im, sh, sw, row_stride);
+                        const float v1 = s.o1 >= 0 ? vp[s.o1] : 0.f;
+                        const float v2 = s.o2 >= 0 ? vp[s.o2] : 0.f;
+                        const float v3 = s.o3 >= 0 ? vp[s.o3] : 0.f;
+                        const float v4 = s.o4 >= 0 ? vp[s.o4] : 0.f;
+                        col += (s.w1 * v1 + s.w2 * v2 + s.w3 * v3 + s.w4 * v4) * weight;
+                    }
+                }
+            }
+            acc += col;
+        }
+        slots[idx] = acc / (float)(count > 1 ? count : 1);
+    }
+}

@@ -146,6 +146,27 @@ int fbbev_msda_bwd(const float* value, const int64_t* spatial_shapes,
                    float* grad_value, float* grad_sampling_loc, float* grad_attn_weight,
                    fbbev_stream_t stream);
 
+/* ----------------------------------------------------------------------------------------------
+ * Fused backward-projection sampling (additive)
+ * -------------------------------------------------------------------------------------------- */
+
+/* Replaces the sampling core of DA_SpatialCrossAttention.forward + DA_MSDeformableAttention.forward
+ *   -- bevformer_utils/spatial_cross_attention_depth.py:163-216 and :554-595 (6*B nonzero() syncs,
+ *   rebatch/pad/scatter Python loops, the (B*6,L,Za,DC) one-hot, two ms_deform_attn_forward launches).
+ * value (B*Ncam,S,M,Dh) = value_proj(camera tokens); pred_depth (B*Ncam,DC,H0,W0) = the depth
+ * distribution in its native layout (level-0 shape); ref_cam (Ncam,B,Q,Za,2), mask (Ncam,B,Q,Za) bool,
+ * qdepth (Ncam,B,Q,Za) from point_sampling (bevformer_encoder.py:91-120); offsets (B,Q,M,L,P,2) =
+ * sampling_offsets(query) raw, attn (B,Q,M,L,P) = softmax(attention_weights(query)), both computed once
+ * per BEV query; d0/dstep = dbound[0]/dbound[2].
+ * slots (B,Q,M*Dh) = sum over hit cameras of the depth-weighted deformable sample / max(#hit,1)
+ * (the tensor the reference feeds to output_proj, :216-219). */
+int fbbev_da_cross_attn_fwd(const float* value, const int64_t* spatial_shapes,
+                            const int64_t* level_start_index, const float* pred_depth,
+                            const float* ref_cam, const uint8_t* mask, const float* qdepth,
+                            const float* offsets, const float* attn, int B, int Ncam, int S, int M, int Dh,
+                            int L, int Q, int P, int Za, int DC, float d0, float dstep, float* slots,
+                            fbbev_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -81,7 +81,7 @@ def da_msda(P, pre, query, value, reference_points, spatial_shapes, level_start_
 
 def da_spatial_cross_attention(P, pre, query, key, value, query_pos, reference_points_cam, per_cam_mask,
                                bev_query_depth, pred_img_depth, spatial_shapes, level_start_index, dbound,
-                               num_cams=6, inner=None, **attn_kw):
+                               num_cams=6, inner=None, return_slots=False, **attn_kw):
     """DA_SpatialCrossAttention.forward (:85-223), loops and all."""
     N, B, len_query, Z, _ = bev_query_depth.shape
     B, N, DC, H, W = pred_img_depth.shape
@@ -126,6 +126,8 @@ def da_spatial_cross_attention(P, pre, query, key, value, query_pos, reference_p
             slots[j, idx] += out[j, i, :len(idx)]
     count = (per_cam_mask.sum(-1) > 0).permute(1, 2, 0).sum(-1)
     slots = slots / torch.clamp(count, min=1.0)[..., None]
+    if return_slots:
+        return slots
     slots = _lin(P, pre + 'output_proj', slots)
     return slots + inp_residual
 
@@ -150,7 +152,7 @@ def reference_points_2d(H, W, bs):
 
 def backward_projection(P, mlvl_feats, lss_bev, cam_params, pred_img_depth, bev_h, bev_w, grid_config_bevformer,
                         final_dim, dbound, num_layers=1, num_heads=8, self_points=4, cross_points=8,
-                        use_cams_embeds=False):
+                        use_cams_embeds=False, inverse=torch.inverse):
     """BackwardProjection.forward -> (B, C, bev_h, bev_w). Weight keys follow the module tree."""
     bs, num_cam = mlvl_feats[0].shape[:2]
     bev_queries = P['bev_embedding.weight'].unsqueeze(1).repeat(1, bs, 1)
@@ -172,7 +174,7 @@ def backward_projection(P, mlvl_feats, lss_bev, cam_params, pred_img_depth, bev_
     # bevformer_encoder.forward
     ref_3d = O.reference_points_3d(grid_config_bevformer)
     ref_2d = reference_points_2d(bev_h, bev_w, bs)
-    ref_cam, mask, qdepth = O.point_sampling(ref_3d, cam_params, final_dim)
+    ref_cam, mask, qdepth = O.point_sampling(ref_3d, cam_params, final_dim, inverse=inverse)
     query = bev_queries.permute(1, 0, 2)
     pos = bev_pos.permute(1, 0, 2)
     ss_bev = torch.tensor([[bev_h, bev_w]])

@@ -237,13 +237,13 @@ def msda_grid_sample(value, spatial_shapes, sampling_locations, attention_weight
     _, Q, _, L, P, _ = sampling_locations.shape
     sizes = [int(h) * int(w) for h, w in spatial_shapes.tolist()]
     value_list = value.split(sizes, dim=1)
-    grids = 2 * sampling_locations - 1
+    grids = (2 * sampling_locations - 1).to(value.dtype)
     sampled = []
     for lvl, (h, w) in enumerate(spatial_shapes.tolist()):
         v = value_list[lvl].flatten(2).transpose(1, 2).reshape(B * M, Dh, int(h), int(w))
         g = grids[:, :, :, lvl].transpose(1, 2).flatten(0, 1)  # (B*M, Q, P, 2)
         sampled.append(F.grid_sample(v, g, mode='bilinear', padding_mode='zeros', align_corners=False))
-    aw = attention_weights.transpose(1, 2).reshape(B * M, 1, Q, L * P)
+    aw = attention_weights.to(value.dtype).transpose(1, 2).reshape(B * M, 1, Q, L * P)
     out = (torch.stack(sampled, dim=-2).flatten(-2) * aw).sum(-1).view(B, M * Dh, Q)
     return out.transpose(1, 2).contiguous()
 
@@ -259,17 +259,31 @@ def reference_points_3d(grid_config_bevformer):
     return torch.stack([X, Y, Z], dim=-1)
 
 
-def point_sampling(reference_points, cam_params, final_dim):
+def inv3x3_closed_form(m):
+    """Adjugate/determinant inverse (what the product's point_sampling uses instead of LU)."""
+    a, b, c = m[..., 0, 0], m[..., 0, 1], m[..., 0, 2]
+    d, e, f = m[..., 1, 0], m[..., 1, 1], m[..., 1, 2]
+    g, h, i = m[..., 2, 0], m[..., 2, 1], m[..., 2, 2]
+    A, Bc, C = e * i - f * h, -(d * i - f * g), d * h - e * g
+    det = a * A + b * Bc + c * C
+    adj = torch.stack([torch.stack([A, -(b * i - c * h), b * f - c * e], -1),
+                       torch.stack([Bc, a * i - c * g, -(a * f - c * d)], -1),
+                       torch.stack([C, -(a * h - b * g), a * e - b * d], -1)], -2)
+    return adj / det[..., None, None]
+
+
+def point_sampling(reference_points, cam_params, final_dim, inverse=torch.inverse):
     """bevformer_encoder.py:91-120: ego voxel centres -> per-camera normalised pixel coords,
-    in-image mask and camera-frame depth."""
+    in-image mask and camera-frame depth.  `inverse` = torch.inverse reproduces the reference; tests
+    that compare against the GPU module pass the closed-form inverse so both sides see the same mask."""
     rots, trans, intrins, post_rots, post_trans, bda = cam_params
     B, N, _ = trans.shape
     eps = 1e-5
     ogfH, ogfW = final_dim
-    rp = reference_points[None, None].repeat(B, N, 1, 1, 1, 1)
-    rp = torch.inverse(bda).view(B, 1, 1, 1, 1, 3, 3).matmul(rp.unsqueeze(-1)).squeeze(-1)
+    rp = reference_points.to(trans)[None, None].repeat(B, N, 1, 1, 1, 1)
+    rp = inverse(bda).view(B, 1, 1, 1, 1, 3, 3).matmul(rp.unsqueeze(-1)).squeeze(-1)
     rp = rp - trans.view(B, N, 1, 1, 1, 3)
-    combine = rots.matmul(torch.inverse(intrins)).inverse()
+    combine = inverse(rots.matmul(inverse(intrins)))
     cam = combine.view(B, N, 1, 1, 1, 3, 3).matmul(rp.unsqueeze(-1)).squeeze(-1)
     cam = torch.cat([cam[..., 0:2] / torch.maximum(cam[..., 2:3], torch.ones_like(cam[..., 2:3]) * eps),
                      cam[..., 2:3]], 5)

@@ -92,3 +92,15 @@ def lidar_coor(xs, ys, ds, cam):
     ok(lib().fbbev_lidar_coor(p(xs), p(ys), p(ds), p(rots), p(trans), p(intrins), p(post_rots), p(post_trans),
                               p(bda), B, N, ds.numel(), ys.numel(), xs.numel(), p(coor), None))
     return coor
+
+
+def da_cross_attn_fwd(value, ss, ls, pred_depth, ref_cam, mask, qdepth, offsets, attn, d0, dstep):
+    Ncam, B, Q, Za = mask.shape
+    _, S, M, Dh = value.shape
+    L, P = attn.shape[3], attn.shape[4]
+    slots = torch.full((B, Q, M * Dh), float('nan'))
+    m8 = mask.to(torch.uint8).contiguous()
+    ok(lib().fbbev_da_cross_attn_fwd(p(value), p(ss), p(ls), p(pred_depth), p(ref_cam), p(m8), p(qdepth), p(offsets),
+                                     p(attn), B, Ncam, S, M, Dh, L, Q, P, Za, pred_depth.shape[1], d0, dstep,
+                                     p(slots), None))
+    return slots

@@ -1,0 +1,42 @@
+"""CPU: the backward-projection module tree builds from the reference config block and exposes the
+reference's parameter names (so reference checkpoints load); forward needs the GPU (no fallback)."""
+import pytest
+import torch
+
+from fb_bev_amd import _capi, backward_projection as BP, configs
+
+
+def test_builds_from_config_with_reference_state_dict_keys():
+    cfg = configs.fbocc_r50()
+    m = BP.build(cfg['backward_projection'])
+    keys = set(m.state_dict().keys())
+    pre = 'transformer.encoder.layers.0.'
+    expect = {'bev_embedding.weight', 'positional_encoding.row_embed.weight', 'positional_encoding.col_embed.weight',
+              'transformer.cams_embeds'}
+    for n in ('sampling_offsets', 'attention_weights', 'value_proj', 'output_proj'):
+        expect |= {f'{pre}attentions.0.{n}.weight', f'{pre}attentions.0.{n}.bias'}
+    for n in ('sampling_offsets', 'attention_weights', 'value_proj'):
+        expect |= {f'{pre}attentions.1.deformable_attention.{n}.weight', f'{pre}attentions.1.deformable_attention.{n}.bias'}
+    expect |= {f'{pre}attentions.1.output_proj.weight', f'{pre}attentions.1.output_proj.bias'}
+    expect |= {f'{pre}ffns.0.layers.0.0.weight', f'{pre}ffns.0.layers.0.0.bias', f'{pre}ffns.0.layers.1.weight',
+               f'{pre}ffns.0.layers.1.bias'}
+    for i in range(3):
+        expect |= {f'{pre}norms.{i}.weight', f'{pre}norms.{i}.bias'}
+    assert keys == expect
+    sd = m.state_dict()
+    assert sd[f'{pre}attentions.0.sampling_offsets.weight'].shape == (8 * 1 * 4 * 2, 80)      # mmcv defaults: 8 heads, 4 pts
+    assert sd[f'{pre}attentions.1.deformable_attention.sampling_offsets.weight'].shape == (8 * 1 * 8 * 2, 80)
+    assert sd[f'{pre}ffns.0.layers.0.0.weight'].shape == (320, 80)
+    assert sd['bev_embedding.weight'].shape == (10000, 80)
+    # ring-pattern initial offsets (spatial_cross_attention_depth.py:442-458): point i of an anchor scaled by i+1
+    b = sd[f'{pre}attentions.1.deformable_attention.sampling_offsets.bias'].view(8, 1, 2, 4, 2)
+    assert torch.allclose(b[:, :, 1], 2 * b[:, :, 0])
+
+
+def test_forward_refuses_cpu_tensors():
+    cfg = configs.fbocc_r50(bev_h=4, bev_w=4)
+    att = BP.build(dict(type='MultiScaleDeformableAttention', embed_dims=80, num_levels=1, batch_first=True))
+    q = torch.zeros(1, 16, 80)
+    with pytest.raises(_capi.FbbevError):
+        att(q, query_pos=q, reference_points=torch.zeros(1, 16, 1, 2), spatial_shapes=torch.tensor([[4, 4]]),
+            level_start_index=torch.tensor([0]))

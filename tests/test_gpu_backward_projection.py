@@ -1,0 +1,120 @@
+"""GPU parity of the backward projection against the CPU oracle
+(oracle/backward_projection_oracle.py, pinned on fixtures from the real reference Python).
+fp32 tolerance 1e-4 on O(1) features (the path is floating point; MSDA itself is 'parity unpinned'
+vs mmcv)."""
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.dirname(__file__))
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device('cuda:0')
+
+
+def test_fused_da_kernel_vs_oracle_composite(dev):
+    from test_emu_kernels import _da_case
+    from fb_bev_amd import _capi
+    for seed, kw in ((0, {}), (1, dict(B=1, Q=33, shapes=((4, 6),), P=4, M=2, E=8)),
+                     (2, dict(B=2, Q=2000, E=80, M=8, shapes=((16, 44),), P=8, DC=80)),          # shipped shapes
+                     (3, dict(B=1, Q=500, E=80, M=8, shapes=((32, 88), (16, 44), (8, 22), (4, 11)), P=8, DC=59))):  # BL3
+        args, exp = _da_case(seed, **kw)
+        value, ss, ls, pred, ref_cam, mask, qdepth, offsets, attn, d0, dstep = args
+        g = lambda t: t.to(dev).contiguous()  # noqa: E731
+        slots = torch.full(exp.shape, float('nan'), device=dev)
+        _capi.da_cross_attn_fwd(g(value), g(ss), g(ls), g(pred), g(ref_cam), g(mask), g(qdepth), g(offsets), g(attn),
+                                d0, dstep, slots)
+        assert not torch.isnan(slots).any()
+        assert torch.allclose(slots.cpu(), exp, atol=1e-4, rtol=1e-4), (seed, (slots.cpu() - exp).abs().max())
+
+
+def _setup(dev, B=2, num_levels=1, bev=20, seed=0):
+    from fb_bev_amd import backward_projection as BP, configs, synthetic as S
+    gcb = {'x': [-40, 40, 80.0 / bev], 'y': [-40, 40, 80.0 / bev], 'z': [-1, 5.4, 1.6]}
+    cfg = configs.fbocc_r50(num_levels=num_levels, bev_h=bev, bev_w=bev, grid_config_bevformer=gcb)
+    torch.manual_seed(seed)
+    m = BP.build(cfg['backward_projection'])
+    # non-trivial weights so offsets / attention depend on the query (the reference init zeroes them)
+    with torch.no_grad():
+        for name, p in m.named_parameters():
+            if 'sampling_offsets.weight' in name or 'attention_weights.weight' in name:
+                p.normal_(0, 0.05)
+    m = m.to(dev).eval()
+    pcfg = S.CONFIGS['REF']
+    cam = S.camera_rig(pcfg, B, seed=seed, bda_aug=True)
+    g = torch.Generator().manual_seed(seed + 5)
+    C, DC = 80, 80
+    shapes = [(16, 44), (8, 22), (4, 11), (2, 6)][:num_levels]
+    feats = [torch.randn(B, 6, C, h, w, generator=g) for h, w in shapes]
+    depth = (torch.randn(B, 6, DC, 16, 44, generator=g) * 3).softmax(2)
+    lss = torch.randn(B, C, bev, bev, generator=g)
+    return m, cfg, cam, feats, depth, lss, gcb
+
+
+def _oracle_out(m, cfg, cam, feats, depth, lss, gcb, bev, num_levels):
+    from oracle import backward_projection_oracle as BO, oracle as O
+    P = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    return BO.backward_projection(P, feats, lss, cam, depth, bev, bev, gcb, (256, 704), cfg['depth_bound'],
+                                  inverse=O.inv3x3_closed_form)
+
+
+@pytest.mark.parametrize('num_levels', [1, 4])
+def test_backward_projection_module_vs_oracle(dev, num_levels):
+    bev = 20
+    m, cfg, cam, feats, depth, lss, gcb = _setup(dev, num_levels=num_levels, bev=bev)
+    with torch.no_grad():                                        # -> fused kernel path
+        out = m([f.to(dev) for f in feats], None, lss_bev=lss.to(dev), cam_params=[t.to(dev) for t in cam],
+                pred_img_depth=depth.to(dev))
+    exp = _oracle_out(m, cfg, cam, feats, depth, lss, gcb, bev, num_levels)
+    assert out.shape == exp.shape == (2, 80, bev, bev)
+    err = (out.cpu() - exp).abs()
+    # point_sampling masks are compared through the output: a borderline projected point may flip its mask bit
+    # between CPU and GPU fp32 op orders, which changes that single query -> allow a handful of such queries
+    bad = (err > 1e-3).any(dim=1).sum().item()
+    assert bad <= 3, bad
+    assert err.median().item() < 1e-5
+
+
+def test_composite_path_equals_fused_and_backprops(dev):
+    from oracle import backward_projection_oracle as BO, oracle as O
+    bev = 12
+    m, cfg, cam, feats, depth, lss, gcb = _setup(dev, B=1, num_levels=1, bev=bev, seed=3)
+    cam_g = [t.to(dev) for t in cam]
+    with torch.no_grad():
+        fused = m([f.to(dev) for f in feats], None, lss_bev=lss.to(dev), cam_params=cam_g, pred_img_depth=depth.to(dev))
+    f_g = [f.to(dev).requires_grad_() for f in feats]
+    d_g = depth.to(dev).requires_grad_()
+    l_g = lss.to(dev).requires_grad_()
+    comp = m(f_g, None, lss_bev=l_g, cam_params=cam_g, pred_img_depth=d_g)       # grad enabled -> composite path
+    assert torch.allclose(comp, fused, atol=1e-4, rtol=1e-4)
+    w = torch.randn(comp.shape, generator=torch.Generator().manual_seed(9))
+    (comp * w.to(dev)).sum().backward()
+    # oracle autograd (grid_sample formulation) on CPU, double precision
+    P = {k: v.detach().cpu().double().requires_grad_() for k, v in m.state_dict().items()}
+    f_c = [f.double().requires_grad_() for f in feats]
+    d_c = depth.double().requires_grad_()
+    l_c = lss.double().requires_grad_()
+    out_c = BO.backward_projection(P, f_c, l_c, cam, d_c,   # fp32 cameras: same in-image masks as the GPU
+                                   bev, bev, gcb, (256, 704),
+                                   cfg['depth_bound'], inverse=O.inv3x3_closed_form)
+    (out_c * w.double()).sum().backward()
+    def close(a, b, tol):
+        # fp32 GPU vs fp64 oracle: elementwise within tol of the tensor scale for >= 98 % of the entries and
+        # never wildly off.  Isolated kinks are legitimate: a ReLU pre-activation or a bilinear cell boundary
+        # within fp32 rounding of zero flips for ONE BEV query (1/144 of the entries here; diagnosed with
+        # tools/diag_bp_grad.py: every other entry agrees to ~1e-3).
+        scale = b.abs().max().item() + 1e-12
+        err = (a.double().cpu() - b).abs() / scale
+        return (err > tol).double().mean().item() <= 0.02 and err.max().item() <= 0.05
+    assert close(l_g.grad, l_c.grad, 2e-3)
+    assert close(f_g[0].grad, f_c[0].grad, 2e-3)
+    assert close(d_g.grad, d_c.grad, 5e-3)
+    for name, p in m.named_parameters():
+        if p.grad is not None and P[name].grad is not None and P[name].grad.abs().max() > 0:
+            assert close(p.grad, P[name].grad, 5e-3), name
