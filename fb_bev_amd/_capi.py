@@ -27,6 +27,7 @@ SIGNATURES = {
     'fbbev_bev_pool_v2_dense_fwd': (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t,
                                             c_int, c_int, c_void_p]),
     'fbbev_msda_fwd': (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_void_p, c_void_p]),
+    'fbbev_point_sampling': (c_int, [c_void_p] * 9 + [c_int] * 5 + [c_float, c_float] + [c_void_p] * 4),
     'fbbev_da_cross_attn_fwd': (c_int, [c_void_p] * 9 + [c_int] * 10 + [c_float, c_float, c_void_p, c_void_p]),
     'fbbev_msda_bwd': (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p] * 3 + [c_void_p]),
 }
@@ -234,3 +235,17 @@ def da_cross_attn_fwd(value, spatial_shapes, level_start_index, pred_depth, ref_
             _dev(ref_cam, F32, 'ref_cam'), _dev(mask, torch.uint8, 'mask'), _dev(qdepth, F32, 'qdepth'),
             _dev(offsets, F32, 'offsets'), _dev(attn, F32, 'attn'), B, Ncam, S, M, Dh, L, Q, P, Za, DC,
             float(d0), float(dstep), _dev(slots, F32, 'slots'), _stream()), 'fbbev_da_cross_attn_fwd')
+
+
+def point_sampling(xs, ys, zs, rots, trans, intrins, post_rots, post_trans, bda, ogfH, ogfW, ref_cam, mask, qdepth):
+    """ref_cam (N,B,Y*X,Za,2) f32, mask (N,B,Y*X,Za) uint8/bool, qdepth (N,B,Y*X,Za) f32, all preallocated."""
+    B, N = trans.shape[:2]
+    if mask.dtype == torch.bool:
+        mask = mask.view(torch.uint8)
+    with _on(ref_cam):
+        _check(lib().fbbev_point_sampling(
+            _dev(xs, F32, 'xs'), _dev(ys, F32, 'ys'), _dev(zs, F32, 'zs'), _dev(rots, F32, 'rots'),
+            _dev(trans, F32, 'trans'), _dev(intrins, F32, 'intrins'), _dev(post_rots, F32, 'post_rots'),
+            _dev(post_trans, F32, 'post_trans'), _dev(bda, F32, 'bda'), B, N, ys.numel(), xs.numel(), zs.numel(),
+            float(ogfH), float(ogfW), _dev(ref_cam, F32, 'ref_cam'), _dev(mask, torch.uint8, 'mask'),
+            _dev(qdepth, F32, 'qdepth'), _stream()), 'fbbev_point_sampling')

@@ -433,37 +433,43 @@ class bevformer_encoder(nn.Module):
         ref_x = ref_x.reshape(-1)[None] / W
         return torch.stack((ref_x, ref_y), -1).repeat(bs, 1, 1).unsqueeze(2)
 
+    def _axes(self, device):
+        """Voxel-centre axes of get_reference_points('3d'), cached per device."""
+        if not hasattr(self, '_axes_cache'):
+            self._axes_cache = {}
+        if device not in self._axes_cache:
+            ax = [torch.arange(*b, dtype=torch.float) + b[-1] / 2 for b in (self.x_bound, self.y_bound, self.z_bound)]
+            self._axes_cache[device] = tuple(t.to(device).contiguous() for t in ax)
+        return self._axes_cache[device]
+
     def point_sampling(self, reference_points, pc_range, img_metas, cam_params=None, gt_bboxes_3d=None):
-        """:91-120 -- ego voxel centres -> per-camera normalised pixel coords, mask, camera depth."""
-        rots, trans, intrins, post_rots, post_trans, bda = [t.float() for t in cam_params]
+        """:91-120 -- ego voxel centres -> per-camera normalised pixel coords, in-image mask, camera depth;
+        one HIP kernel (fbbev_point_sampling).  `reference_points` must be the '3d' grid of this encoder."""
+        rots, trans, intrins, post_rots, post_trans, bda = [t.float().contiguous() for t in cam_params]
         B, N, _ = trans.shape
-        eps = 1e-5
+        xs, ys, zs = self._axes(trans.device)
+        Q, Za = ys.numel() * xs.numel(), zs.numel()
+        ref_cam = torch.empty((N, B, Q, Za, 2), dtype=torch.float32, device=trans.device)
+        mask = torch.empty((N, B, Q, Za), dtype=torch.bool, device=trans.device)
+        qdepth = torch.empty((N, B, Q, Za), dtype=torch.float32, device=trans.device)
         ogfH, ogfW = self.final_dim
-        rp = reference_points[None, None].repeat(B, N, 1, 1, 1, 1)
-        rp = inv3x3(bda).view(B, 1, 1, 1, 1, 3, 3).matmul(rp.unsqueeze(-1)).squeeze(-1)
-        rp = rp - trans.view(B, N, 1, 1, 1, 3)
-        combine = inv3x3(rots.matmul(inv3x3(intrins)))
-        cam = combine.view(B, N, 1, 1, 1, 3, 3).matmul(rp.unsqueeze(-1)).squeeze(-1)
-        cam = torch.cat([cam[..., 0:2] / torch.maximum(cam[..., 2:3], torch.ones_like(cam[..., 2:3]) * eps),
-                         cam[..., 2:3]], 5)
-        cam = post_rots.view(B, N, 1, 1, 1, 3, 3).matmul(cam.unsqueeze(-1)).squeeze(-1)
-        cam = cam + post_trans.view(B, N, 1, 1, 1, 3)
-        cam = torch.cat([cam[..., 0:1] / ogfW, cam[..., 1:2] / ogfH, cam[..., 2:3]], -1)
-        mask = (cam[..., 2:3] > eps) & (cam[..., 0:1] > eps) & (cam[..., 0:1] < (1.0 - eps)) & \
-               (cam[..., 1:2] > eps) & (cam[..., 1:2] < (1.0 - eps))
-        _, _, H, W, D, _ = cam.shape
-        cam = cam.permute(1, 0, 2, 3, 4, 5).reshape(N, B, H * W, D, 3)
-        mask = mask.permute(1, 0, 2, 3, 4, 5).reshape(N, B, H * W, D, 1).squeeze(-1)
-        return rp, cam[..., :2], mask, cam[..., 2:3]
+        _capi.point_sampling(xs, ys, zs, rots, trans, intrins, post_rots, post_trans, bda, ogfH, ogfW, ref_cam, mask,
+                             qdepth)
+        return reference_points, ref_cam, mask, qdepth.unsqueeze(-1)
 
     def forward(self, bev_query, key, value, *args, bev_h=None, bev_w=None, bev_pos=None, spatial_shapes=None,
                 level_start_index=None, cam_params=None, gt_bboxes_3d=None, pred_img_depth=None, bev_mask=None,
                 prev_bev=None, **kwargs):
         """:123-203."""
-        ref_3d = self.get_reference_points(bev_h, bev_w, self.pc_range[5] - self.pc_range[2], dim='3d',
-                                           bs=bev_query.size(1), device=bev_query.device, dtype=bev_query.dtype)
-        ref_2d = self.get_reference_points(bev_h, bev_w, dim='2d', bs=bev_query.size(1), device=bev_query.device,
-                                           dtype=bev_query.dtype)
+        ck = (bev_h, bev_w, bev_query.size(1), bev_query.device, bev_query.dtype)
+        if getattr(self, '_ref_cache_key', None) != ck:        # config-only tensors: build once
+            self._ref_cache = (
+                self.get_reference_points(bev_h, bev_w, self.pc_range[5] - self.pc_range[2], dim='3d',
+                                          bs=bev_query.size(1), device=bev_query.device, dtype=bev_query.dtype),
+                self.get_reference_points(bev_h, bev_w, dim='2d', bs=bev_query.size(1), device=bev_query.device,
+                                          dtype=bev_query.dtype))
+            self._ref_cache_key = ck
+        ref_3d, ref_2d = self._ref_cache
         ref_3d, ref_cam, per_cam_mask_list, bev_query_depth = self.point_sampling(
             ref_3d, self.pc_range, kwargs.get('img_metas'), cam_params=cam_params, gt_bboxes_3d=gt_bboxes_3d)
         bev_query = bev_query.permute(1, 0, 2)

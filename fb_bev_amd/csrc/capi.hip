@@ -90,6 +90,24 @@ extern "C" int fbbev_lidar_coor(const float* xs, const float* ys, const float* d
     return 0;
 }
 
+extern "C" int fbbev_point_sampling(const float* xs, const float* ys, const float* zs, const float* rots,
+                                    const float* trans, const float* intrins, const float* post_rots,
+                                    const float* post_trans, const float* bda, int B, int N, int Y, int X,
+                                    int Za, float ogfH, float ogfW, float* ref_cam, uint8_t* mask,
+                                    float* qdepth, fbbev_stream_t stream_) {
+    if (B <= 0 || N <= 0 || Y <= 0 || X <= 0 || Za <= 0 || !(ogfH > 0.f) || !(ogfW > 0.f)) return FBBEV_E_BADARG;
+    if (!xs || !ys || !zs || !rots || !trans || !intrins || !post_rots || !post_trans || !bda || !ref_cam ||
+        !mask || !qdepth) return FBBEV_E_BADARG;
+    const long long npts = (long long)Y * X * Za;
+    const long long chunks = (npts + 255) / 256;
+    if (chunks * B * N >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
+    FBBEV_LAUNCH(k_point_sampling, chunks * B * N, 256, 0, (fbbev_rt_stream)stream_, xs, ys, zs, rots, trans,
+                 intrins, post_rots, post_trans, bda, B, N, Y, X, Za, ogfH, ogfW, (int)chunks, ref_cam, mask,
+                 qdepth);
+    FBBEV_CHECK_LAUNCH();
+    return 0;
+}
+
 // ------------------------------------------------------------------------------ voxel ranking
 static inline int key_bits(long long total_voxels) {
     int bits = 1;

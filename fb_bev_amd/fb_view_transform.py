@@ -1,0 +1,26 @@
+"""Forward-backward view transformation: the hot-path slice of FBOCC.extract_img_bev_feat
+(mmdet3d/models/fbbev/detectors/fbocc.py:344-366): forward projection (lift-splat) -> backward
+projection refinement of the Z-mean BEV -> re-add broadcast over Z.  Inputs are what the depth net
+produces (`context`, `depth`) plus `cam_params = img_inputs[1:7]`."""
+import torch.nn as nn
+
+from . import backward_projection as BP
+from .view_transformer import LSSViewTransformerFunction3D
+
+
+class FBViewTransform(nn.Module):
+    def __init__(self, forward_projection, backward_projection=None, readd=True):
+        super().__init__()
+        fp = dict(forward_projection)
+        assert fp.pop('type') == 'LSSViewTransformerFunction3D'
+        self.forward_projection = LSSViewTransformerFunction3D(**fp)
+        self.backward_projection = BP.build(backward_projection) if backward_projection is not None else None
+        self.readd = readd
+
+    def forward(self, cam_params, context, depth, img_metas=None, bev_mask=None):
+        bev_feat = self.forward_projection(cam_params, context, depth)            # (B,C,Y,X,Z)   fbocc.py:344-345
+        if self.backward_projection is None:
+            return bev_feat
+        refined = self.backward_projection([context], img_metas, lss_bev=bev_feat.mean(-1), cam_params=cam_params,
+                                           bev_mask=bev_mask, gt_bboxes_3d=None, pred_img_depth=depth)   # :357-363
+        return refined[..., None] + bev_feat if self.readd else refined           # :365-368

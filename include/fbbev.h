@@ -150,6 +150,17 @@ int fbbev_msda_bwd(const float* value, const int64_t* spatial_shapes,
  * Fused backward-projection sampling (additive)
  * -------------------------------------------------------------------------------------------- */
 
+/* Replaces bevformer_encoder.point_sampling
+ *   -- bevformer_utils/bevformer_encoder.py:91-120 (3 batched inverses + 3 broadcast matmuls).
+ * xs (X), ys (Y), zs (Za): voxel-centre axes of get_reference_points '3d' (:66-75); camera tensors as in
+ * fbbev_lidar_coor; ogfH/ogfW = data_config['input_size'].  Outputs: ref_cam (N,B,Y*X,Za,2) normalised
+ * pixel coordinates, mask (N,B,Y*X,Za) bool, qdepth (N,B,Y*X,Za) camera-frame depth. */
+int fbbev_point_sampling(const float* xs, const float* ys, const float* zs, const float* rots,
+                         const float* trans, const float* intrins, const float* post_rots,
+                         const float* post_trans, const float* bda, int B, int N, int Y, int X, int Za,
+                         float ogfH, float ogfW, float* ref_cam, uint8_t* mask, float* qdepth,
+                         fbbev_stream_t stream);
+
 /* Replaces the sampling core of DA_SpatialCrossAttention.forward + DA_MSDeformableAttention.forward
  *   -- bevformer_utils/spatial_cross_attention_depth.py:163-216 and :554-595 (6*B nonzero() syncs,
  *   rebatch/pad/scatter Python loops, the (B*6,L,Za,DC) one-hot, two ms_deform_attn_forward launches).

@@ -104,3 +104,16 @@ def da_cross_attn_fwd(value, ss, ls, pred_depth, ref_cam, mask, qdepth, offsets,
                                      p(attn), B, Ncam, S, M, Dh, L, Q, P, Za, pred_depth.shape[1], d0, dstep,
                                      p(slots), None))
     return slots
+
+
+def point_sampling(xs, ys, zs, cam, ogfH, ogfW):
+    rots, trans, intrins, post_rots, post_trans, bda = cam
+    B, N = trans.shape[:2]
+    Q, Za = ys.numel() * xs.numel(), zs.numel()
+    ref_cam = torch.full((N, B, Q, Za, 2), float('nan'))
+    mask = torch.full((N, B, Q, Za), 7, dtype=torch.uint8)
+    qd = torch.full((N, B, Q, Za), float('nan'))
+    ok(lib().fbbev_point_sampling(p(xs), p(ys), p(zs), p(rots), p(trans), p(intrins), p(post_rots), p(post_trans),
+                                  p(bda), B, N, ys.numel(), xs.numel(), Za, float(ogfH), float(ogfW), p(ref_cam), p(mask),
+                                  p(qd), None))
+    return ref_cam, mask.bool(), qd

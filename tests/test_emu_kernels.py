@@ -197,3 +197,19 @@ def test_fused_da_cross_attention_emulated():
         got = E.da_cross_attn_fwd(*args)
         assert not torch.isnan(got).any()
         assert torch.allclose(got, exp, atol=2e-5, rtol=1e-5)
+
+
+def test_point_sampling_emulated():
+    cfg = S.CONFIGS['REF']
+    cam = S.camera_rig(cfg, 2, seed=0, bda_aug=True)
+    gcb = {'x': [-40, 40, 4.0], 'y': [-40, 40, 4.0], 'z': [-1, 5.4, 1.6]}          # 20x20x4 voxel centres
+    ref3d = O.reference_points_3d(gcb)
+    exp_ref, exp_mask, exp_d = O.point_sampling(ref3d, cam, (256, 704), inverse=O.inv3x3_closed_form)
+    xs = ref3d[0, :, 0, 0].contiguous(); ys = ref3d[:, 0, 0, 1].contiguous(); zs = ref3d[0, 0, :, 2].contiguous()
+    ref, mask, qd = E.point_sampling(xs, ys, zs, cam, 256, 704)
+    assert not torch.isnan(ref).any() and not torch.isnan(qd).any()
+    assert (mask != exp_mask).sum().item() <= 2            # borderline points may flip (different fp32 op order)
+    same = (mask == exp_mask)
+    vis = exp_mask & same
+    assert torch.allclose(ref[vis], exp_ref[vis], atol=2e-5)
+    assert torch.allclose(qd[vis], exp_d.squeeze(-1)[vis], atol=2e-4, rtol=1e-5)

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Time the forward+backward view transformation (BASELINE configs[2] scope) on one GPU."""
+import json, os, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from fb_bev_amd import configs, synthetic as S
+from fb_bev_amd.fb_view_transform import FBViewTransform
+
+def main():
+    name = sys.argv[1] if len(sys.argv) > 1 else 'REF'
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    steps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+    dev = torch.device('cuda:0')
+    pc = S.CONFIGS[name]
+    X, Y, Z = pc.grid_xyz
+    gcb = {'x': pc.grid_config['x'], 'y': pc.grid_config['y'], 'z': [-1, 5.4, 1.6]}
+    cfg = configs.fbocc_r50(bev_h=Y, bev_w=X, numC_Trans=pc.channels, input_size=pc.input_size, grid_config=pc.grid_config,
+                            grid_config_bevformer=gcb, depth_bound=tuple(pc.grid_config['depth']), downsample=pc.downsample)
+    m = FBViewTransform(cfg['forward_projection'], cfg['backward_projection']).to(dev).eval()
+    cam = [t.to(dev) for t in S.camera_rig(pc, B, seed=0, bda_aug=True)]
+    depth, ctx = S.depth_and_context(pc, B, seed=0)
+    depth, ctx = depth.to(dev), ctx.to(dev)
+    with torch.no_grad():
+        for _ in range(3):
+            out = m(cam, ctx, depth)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = m(cam, ctx, depth)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        fp = m.forward_projection
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            b = fp(cam, ctx, depth)
+        torch.cuda.synchronize()
+        dt_f = (time.perf_counter() - t0) / steps
+    print(json.dumps({'config': name, 'B': B, 'bev': [Y, X], 'out': list(out.shape), 'ms_fb': dt * 1e3, 'ms_forward_only': dt_f * 1e3,
+                      'samples_per_s_fb': B / dt}))
+
+if __name__ == '__main__':
+    main()
