@@ -11,8 +11,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libfbbev_hip.so')
-SOURCES = ['capi.hip', 'sort_rocprim.hip']
-HEADERS = ['hip_rt/rt.h', 'pool_kernels.h', 'rank_kernels.h', 'msda_kernels.h', 'geom_kernels.h', 'da_kernels.h', '../../include/fbbev.h']
+SOURCES = ['capi.hip']
+HEADERS = ['hip_rt/rt.h', 'pool_kernels.h', 'rank_kernels.h', 'sort_kernels.h', 'msda_kernels.h', 'geom_kernels.h', 'da_kernels.h', '../../include/fbbev.h']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics',
          '-fno-gpu-rdc', '-Wall', '-Wno-unused-function',
          '-I' + os.path.join(CSRC, 'hip_rt')]

@@ -3,6 +3,7 @@
 #include "rt.h"
 #include "pool_kernels.h"
 #include "rank_kernels.h"
+#include "sort_kernels.h"
 #include "msda_kernels.h"
 #include "geom_kernels.h"
 #include "da_kernels.h"
@@ -116,29 +117,66 @@ static inline int key_bits(long long total_voxels) {
 }
 
 struct rank_ws_layout {
-    size_t keys_in, vals_in, block_counts, sort_temp, total;
-    size_t sort_temp_bytes;
-    int n_blocks;
+    size_t keys_in, vals_in, keys_tmp, vals_tmp, block_counts, hist, totals, total;
+    int n_blocks, sort_blocks;
 };
 
-static rank_ws_layout rank_layout(long long n, bool query_sort_temp) {
+static rank_ws_layout rank_layout(long long n) {
     rank_ws_layout L;
     L.n_blocks = (int)((n + FBBEV_RANK_CHUNK - 1) / FBBEV_RANK_CHUNK);
+    L.sort_blocks = (int)((n + FBBEV_SORT_TILE - 1) / FBBEV_SORT_TILE);
     size_t off = 0;
     L.keys_in = off; off = align_up(off + (size_t)n * 4, 256);
     L.vals_in = off; off = align_up(off + (size_t)n * 4, 256);
+    L.keys_tmp = off; off = align_up(off + (size_t)n * 4, 256);
+    L.vals_tmp = off; off = align_up(off + (size_t)n * 4, 256);
     L.block_counts = off; off = align_up(off + (size_t)(L.n_blocks + 1) * 4, 256);
-    // the size query runs only in fbbev_rank_workspace_bytes; the launch path hands the sort whatever
-    // is left of the caller's workspace
-    L.sort_temp_bytes = query_sort_temp ? fbbev_rt_sort_pairs_temp_bytes((size_t)n, 32) : 0;
-    L.sort_temp = off; off = align_up(off + L.sort_temp_bytes, 256);
+    L.hist = off; off = align_up(off + ((size_t)L.sort_blocks << FBBEV_SORT_MAX_RB) * 4, 256);
+    L.totals = off; off = align_up(off + ((size_t)4 << FBBEV_SORT_MAX_RB) * 4, 256);   // one row per pass
     L.total = off;
     return L;
 }
 
+// stable LSD radix sort of the low `bits` key bits; result lands in (keys_out, vals_out)
+template <int RB>
+static int sort_pass(const unsigned int* kin, const unsigned int* vin, unsigned int* kout, unsigned int* vout,
+                     long long n, int shift, int nblocks, int* hist, int* totals, fbbev_rt_stream stream) {
+    FBBEV_LAUNCH(k_sort_hist<RB>, nblocks, 256, 0, stream, kin, n, shift, nblocks, hist, totals);
+    FBBEV_LAUNCH(k_sort_scan, 1 << RB, 256, 0, stream, hist, (const int*)totals, nblocks);
+    FBBEV_LAUNCH(k_sort_scatter<RB>, nblocks, 256, 0, stream, kin, vin, n, shift, nblocks, (const int*)hist, kout, vout);
+    return fbbev_rt_last_error();
+}
+
+static int radix_sort_pairs(unsigned int* keys_a, unsigned int* vals_a, unsigned int* keys_t, unsigned int* vals_t,
+                            unsigned int* keys_out, unsigned int* vals_out, long long n, int bits, int nblocks,
+                            int* hist, int* totals, fbbev_rt_stream stream) {
+    const int passes = (bits + FBBEV_SORT_MAX_RB - 1) / FBBEV_SORT_MAX_RB;
+    const int rb = (bits + passes - 1) / passes;      // digits as even as possible, <= 9 bits
+    int e = fbbev_rt_memset_async(totals, 0, ((size_t)passes << FBBEV_SORT_MAX_RB) * sizeof(int), stream);
+    if (e) return e;
+    const unsigned int* kin = keys_a; const unsigned int* vin = vals_a;
+    for (int p = 0; p < passes; ++p) {
+        const bool to_out = ((passes - 1 - p) % 2) == 0;   // last pass always writes the outputs
+        unsigned int* ko = to_out ? keys_out : keys_t;
+        unsigned int* vo = to_out ? vals_out : vals_t;
+        int* tot = totals + ((size_t)p << FBBEV_SORT_MAX_RB);
+        const int shift = p * rb;
+        switch (rb) {
+            case 9: e = sort_pass<9>(kin, vin, ko, vo, n, shift, nblocks, hist, tot, stream); break;
+            case 8: e = sort_pass<8>(kin, vin, ko, vo, n, shift, nblocks, hist, tot, stream); break;
+            case 7: e = sort_pass<7>(kin, vin, ko, vo, n, shift, nblocks, hist, tot, stream); break;
+            case 6: e = sort_pass<6>(kin, vin, ko, vo, n, shift, nblocks, hist, tot, stream); break;
+            default: e = sort_pass<5>(kin, vin, ko, vo, n, shift, nblocks, hist, tot, stream); break;
+        }
+        if (e) return e;
+        kin = ko; vin = vo;
+    }
+    return 0;
+}
+
 extern "C" size_t fbbev_rank_workspace_bytes(int64_t n_points) {
     if (n_points <= 0) return 256;
-    return rank_layout(n_points, true).total;
+    return rank_layout(n_points).total;
 }
 
 extern "C" int fbbev_rank_build(const float* coor, int B, int N, int D, int H, int W,
@@ -153,8 +191,8 @@ extern "C" int fbbev_rank_build(const float* coor, int B, int N, int D, int H, i
     const long long n = (long long)B * N * D * H * W;
     if (n >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
     fbbev_rt_stream stream = (fbbev_rt_stream)stream_;
-    const rank_ws_layout L = rank_layout(n, false);
-    if (workspace_bytes < L.total + 256) return FBBEV_E_WORKSPACE;
+    const rank_ws_layout L = rank_layout(n);
+    if (workspace_bytes < L.total) return FBBEV_E_WORKSPACE;
     unsigned char* ws = static_cast<unsigned char*>(workspace);
     unsigned int* keys_in = reinterpret_cast<unsigned int*>(ws + L.keys_in);
     unsigned int* vals_in = reinterpret_cast<unsigned int*>(ws + L.vals_in);
@@ -180,9 +218,10 @@ extern "C" int fbbev_rank_build(const float* coor, int B, int N, int D, int H, i
     if (kb > 8192) kb = 8192;
     FBBEV_LAUNCH(k_rank_keys, kb, 256, 0, stream, coor, n, n / B, gp, sentinel, keys_in, vals_in);
     FBBEV_CHECK_LAUNCH();
-    e = fbbev_rt_sort_pairs(ws + L.sort_temp, workspace_bytes - L.sort_temp, keys_in,
-                            reinterpret_cast<unsigned int*>(ranks_bev), vals_in,
-                            reinterpret_cast<unsigned int*>(ranks_depth), (size_t)n, bits, stream);
+    e = radix_sort_pairs(keys_in, vals_in, reinterpret_cast<unsigned int*>(ws + L.keys_tmp),
+                         reinterpret_cast<unsigned int*>(ws + L.vals_tmp), reinterpret_cast<unsigned int*>(ranks_bev),
+                         reinterpret_cast<unsigned int*>(ranks_depth), n, bits, L.sort_blocks,
+                         reinterpret_cast<int*>(ws + L.hist), reinterpret_cast<int*>(ws + L.totals), stream);
     if (e) return e;
     const unsigned int* keys = reinterpret_cast<const unsigned int*>(ranks_bev);
     const unsigned int* vals = reinterpret_cast<const unsigned int*>(ranks_depth);

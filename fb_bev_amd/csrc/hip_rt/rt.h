@@ -26,12 +26,6 @@ static inline int fbbev_rt_allow_dyn_lds(const void* kern, size_t bytes) {
 extern __shared__ __attribute__((aligned(16))) unsigned char fbbev_dyn_lds_raw[];
 __device__ __forceinline__ float* fbbev_dyn_lds_f32() { return reinterpret_cast<float*>(fbbev_dyn_lds_raw); }
 
-// stable LSD radix sort of (key, value) pairs on `bits` low key bits (sort_rocprim.hip)
-size_t fbbev_rt_sort_pairs_temp_bytes(size_t n, int bits);
-int fbbev_rt_sort_pairs(void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out,
-                        const uint32_t* vals_in, uint32_t* vals_out, size_t n, int bits,
-                        fbbev_rt_stream stream);
-
 // 16-byte store with a selectable cache policy for the write-once streaming output.
 //   0 plain | 1 nt (clang nontemporal builtin) | 2 sc1 | 3 sc0 sc1 | 4 sc1 nt | 5 sc0 nt | 6 sc0 sc1 nt | 7 sc0
 // (gfx950 cache-control bits; MI355X_MICROARCH.md "stores of each flavour").  Stores have no

@@ -1,0 +1,118 @@
+// sort_kernels.h -- stable LSD radix sort of (key, value) pairs for the voxel ranking.
+//
+// The reference sorts with torch.argsort (view_transformer.py:590, unstable).  Here a hand-written
+// stable radix sort on exactly the key bits that can be set (log2(B*X*Y*Z)+1), RB bits per pass:
+//   k_sort_hist    : per-workgroup digit histogram (LDS atomics) -> hist[digit][workgroup], totals[digit]
+//   k_sort_scan    : one workgroup per digit: base = sum of lower digits' totals, then an exclusive scan of
+//                    the digit's row over workgroups (wave-prefix-sum block scan)
+//   k_sort_scatter : each wave owns a contiguous 1024-key chunk; per round of 64 keys the lanes holding the
+//                    same digit find each other with RB ballots (a wave-level match), rank = popcount of the
+//                    lower matching lanes + the wave's running digit counter (LDS, wave-private, no
+//                    workgroup barrier inside the loop); after one barrier the per-digit wave prefix is
+//                    added and the pairs go to their final positions.  Order = (workgroup, wave, round, lane)
+//                    = input order, so the sort is stable and the voxel order canonical.
+#pragma once
+#include "rt.h"
+
+#define FBBEV_SORT_WAVES 4
+#define FBBEV_SORT_ROUNDS 16
+#define FBBEV_SORT_TILE (FBBEV_SORT_WAVES * 64 * FBBEV_SORT_ROUNDS)   // 4096 keys per workgroup
+#define FBBEV_SORT_MAX_RB 9
+
+template <int RB>
+__global__ void __launch_bounds__(256)
+k_sort_hist(const unsigned int* __restrict__ keys, long long n, int shift, int nblocks,
+            int* __restrict__ hist, int* __restrict__ totals) {
+    constexpr int NB = 1 << RB;
+    __shared__ int cnt[NB];
+    for (int d = threadIdx.x; d < NB; d += 256) cnt[d] = 0;
+    __syncthreads();
+    const long long base = (long long)blockIdx.x * FBBEV_SORT_TILE;
+    for (int i = threadIdx.x; i < FBBEV_SORT_TILE; i += 256) {
+        const long long idx = base + i;
+        if (idx < n) atomicAdd(&cnt[(keys[idx] >> shift) & (NB - 1)], 1);
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < NB; d += 256) {
+        const int c = cnt[d];
+        hist[(long long)d * nblocks + blockIdx.x] = c;
+        if (c) atomicAdd(&totals[d], c);
+    }
+}
+
+// grid = number of digits; exclusive scan of hist[d][0..nblocks) offset by the totals of all lower digits
+__global__ void __launch_bounds__(256)
+k_sort_scan(int* __restrict__ hist, const int* __restrict__ totals, int nblocks) {
+    __shared__ int lds4[4];
+    const int d = blockIdx.x;
+    int part = 0;
+    for (int j = threadIdx.x; j < d; j += 256) part += totals[j];
+    int base;
+    (void)fbbev_block_excl_scan(part, lds4, &base);
+    int running = base;
+    int* row = hist + (long long)d * nblocks;
+    for (int b0 = 0; b0 < nblocks; b0 += 256) {
+        const int i = b0 + threadIdx.x;
+        const int v = (i < nblocks) ? row[i] : 0;
+        int total;
+        const int ex = fbbev_block_excl_scan(v, lds4, &total);
+        if (i < nblocks) row[i] = running + ex;
+        running += total;
+    }
+}
+
+template <int RB>
+__global__ void __launch_bounds__(256)
+k_sort_scatter(const unsigned int* __restrict__ keys_in, const unsigned int* __restrict__ vals_in, long long n,
+               int shift, int nblocks, const int* __restrict__ hist, unsigned int* __restrict__ keys_out,
+               unsigned int* __restrict__ vals_out) {
+    constexpr int NB = 1 << RB;
+    __shared__ int cnt[FBBEV_SORT_WAVES][NB];    // per-wave running digit counters -> per-wave totals
+    __shared__ int woff[FBBEV_SORT_WAVES][NB];   // global position of each wave's first key of a digit
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int i = tid; i < FBBEV_SORT_WAVES * NB; i += 256) (&cnt[0][0])[i] = 0;
+    __syncthreads();
+    const long long chunk = (long long)blockIdx.x * FBBEV_SORT_TILE + (long long)wave * (64 * FBBEV_SORT_ROUNDS);
+    unsigned int k[FBBEV_SORT_ROUNDS], v[FBBEV_SORT_ROUNDS];
+    int lr[FBBEV_SORT_ROUNDS];
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int r = 0; r < FBBEV_SORT_ROUNDS; ++r) {
+        const long long idx = chunk + r * 64 + lane;
+        const bool valid = idx < n;
+        k[r] = valid ? keys_in[idx] : 0u;
+        v[r] = valid ? vals_in[idx] : 0u;
+        const unsigned int d = (k[r] >> shift) & (NB - 1);
+        unsigned long long m = __ballot(valid ? 1 : 0);          // wave-level match on the digit
+#pragma unroll
+        for (int bit = 0; bit < RB; ++bit) {
+            const unsigned long long b = __ballot((int)((d >> bit) & 1u));
+            m &= ((d >> bit) & 1u) ? b : ~b;
+        }
+        const int leader = valid ? (__ffsll((long long)m) - 1) : lane;
+        int prev = 0;
+        if (valid && lane == leader) {
+            prev = cnt[wave][d];
+            cnt[wave][d] = prev + __popcll(m);
+        }
+        prev = __shfl(prev, leader, 64);
+        lr[r] = prev + __popcll(m & lt);
+    }
+    __syncthreads();
+    for (int d = tid; d < NB; d += 256) {
+        int run = hist[(long long)d * nblocks + blockIdx.x];
+#pragma unroll
+        for (int w = 0; w < FBBEV_SORT_WAVES; ++w) { woff[w][d] = run; run += cnt[w][d]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < FBBEV_SORT_ROUNDS; ++r) {
+        const long long idx = chunk + r * 64 + lane;
+        if (idx < n) {
+            const unsigned int d = (k[r] >> shift) & (NB - 1);
+            const int pos = woff[wave][d] + lr[r];
+            keys_out[pos] = k[r];
+            vals_out[pos] = v[r];
+        }
+    }
+}

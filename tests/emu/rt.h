@@ -127,6 +127,21 @@ inline void __syncthreads() { emu::block_barrier(); }
 template <class T> inline T __shfl_xor(T v, int mask, int = 64) { return emu::shfl_src(v, (emu::S().cur & 63) ^ mask); }
 template <class T> inline T __shfl_up(T v, int d, int = 64) { return emu::shfl_src(v, (emu::S().cur & 63) - d); }
 template <class T> inline T __shfl(T v, int src, int = 64) { return emu::shfl_src(v, src & 63); }
+inline unsigned long long __ballot(int pred) {
+    emu::State& s = emu::S();
+    const int w = s.cur >> 6, lane = s.cur & 63;
+    s.wslot[w][lane] = pred ? 1 : 0;
+    emu::wave_barrier();
+    unsigned long long m = 0;
+    const int base = w << 6;
+    for (int l = 0; l < 64; ++l)
+        if (base + l < (int)s.bdim.x && !s.fibers[base + l].done && s.wslot[w][l]) m |= (1ull << l);
+    emu::wave_barrier();
+    return m;
+}
+inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+inline int __ffsll(long long x) { return __builtin_ffsll(x); }
+inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 
 // single correctly-rounded fp32 ops (volatile defeats re-association / contraction)
 inline float __fsub_rn(float a, float b) { volatile float r = a - b; return r; }
@@ -147,15 +162,3 @@ inline float* fbbev_dyn_lds_f32() {
 typedef float fbbev_v4f __attribute__((vector_size(16)));
 template <int ST> inline void fbbev_store4(float* p, fbbev_v4f v) { memcpy(p, &v, 16); }
 inline void fbbev_atomic_add_f32(float* p, float v) { *p += v; }
-
-inline size_t fbbev_rt_sort_pairs_temp_bytes(size_t n, int) { return n * 8 + 16; }
-inline int fbbev_rt_sort_pairs(void*, size_t, const uint32_t* keys_in, uint32_t* keys_out,
-                               const uint32_t* vals_in, uint32_t* vals_out, size_t n, int bits,
-                               fbbev_rt_stream) {
-    std::vector<std::pair<uint32_t, uint32_t>> v(n);
-    const uint32_t mask = bits >= 32 ? 0xFFFFFFFFu : ((1u << bits) - 1u);
-    for (size_t i = 0; i < n; ++i) v[i] = {keys_in[i], vals_in[i]};
-    std::stable_sort(v.begin(), v.end(), [mask](const auto& a, const auto& b) { return (a.first & mask) < (b.first & mask); });
-    for (size_t i = 0; i < n; ++i) { keys_out[i] = v[i].first; vals_out[i] = v[i].second; }
-    return 0;
-}
