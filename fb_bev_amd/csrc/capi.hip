@@ -132,7 +132,7 @@ static rank_ws_layout rank_layout(long long n) {
     L.vals_tmp = off; off = align_up(off + (size_t)n * 4, 256);
     L.block_counts = off; off = align_up(off + (size_t)(L.n_blocks + 1) * 4, 256);
     L.hist = off; off = align_up(off + ((size_t)L.sort_blocks << FBBEV_SORT_MAX_RB) * 4, 256);
-    L.totals = off; off = align_up(off + ((size_t)4 << FBBEV_SORT_MAX_RB) * 4, 256);   // one row per pass
+    L.totals = off; off = align_up(off + ((size_t)4 * FBBEV_SORT_SHARDS << FBBEV_SORT_MAX_RB) * 4, 256);   // [pass][shard][digit]
     L.total = off;
     return L;
 }
@@ -140,33 +140,41 @@ static rank_ws_layout rank_layout(long long n) {
 // stable LSD radix sort of the low `bits` key bits; result lands in (keys_out, vals_out)
 template <int RB>
 static int sort_pass(const unsigned int* kin, const unsigned int* vin, unsigned int* kout, unsigned int* vout,
-                     long long n, int shift, int nblocks, int* hist, int* totals, fbbev_rt_stream stream) {
-    FBBEV_LAUNCH(k_sort_hist<RB>, nblocks, 256, 0, stream, kin, n, shift, nblocks, hist, totals);
-    FBBEV_LAUNCH(k_sort_scan, 1 << RB, 256, 0, stream, hist, (const int*)totals, nblocks);
-    FBBEV_LAUNCH(k_sort_scatter<RB>, nblocks, 256, 0, stream, kin, vin, n, shift, nblocks, (const int*)hist, kout, vout);
+                     long long n_host, const int* n_dev, int shift, int nblocks, unsigned int drop_key, int drop,
+                     int* hist, int* totals, int* n_out, fbbev_rt_stream stream) {
+    FBBEV_LAUNCH(k_sort_hist<RB>, nblocks, 256, 0, stream, kin, n_host, n_dev, shift, nblocks, drop_key, drop, hist, totals);
+    FBBEV_LAUNCH(k_sort_scan, 1 << RB, 256, 0, stream, hist, (const int*)totals, nblocks, n_out);
+    FBBEV_LAUNCH(k_sort_scatter<RB>, nblocks, 256, 0, stream, kin, vin, n_host, n_dev, shift, nblocks, drop_key, drop,
+                 (const int*)hist, kout, vout);
     return fbbev_rt_last_error();
 }
 
+// Stable LSD radix sort of the low `bits` key bits.  Pass 0 drops keys == drop_key and writes the number
+// of kept pairs to *n_kept_dev; later passes read that device counter.  Result in (keys_out, vals_out).
 static int radix_sort_pairs(unsigned int* keys_a, unsigned int* vals_a, unsigned int* keys_t, unsigned int* vals_t,
-                            unsigned int* keys_out, unsigned int* vals_out, long long n, int bits, int nblocks,
-                            int* hist, int* totals, fbbev_rt_stream stream) {
+                            unsigned int* keys_out, unsigned int* vals_out, long long n, int bits,
+                            unsigned int drop_key, int* n_kept_dev, int nblocks, int* hist, int* totals,
+                            fbbev_rt_stream stream) {
     const int passes = (bits + FBBEV_SORT_MAX_RB - 1) / FBBEV_SORT_MAX_RB;
     const int rb = (bits + passes - 1) / passes;      // digits as even as possible, <= 9 bits
-    int e = fbbev_rt_memset_async(totals, 0, ((size_t)passes << FBBEV_SORT_MAX_RB) * sizeof(int), stream);
+    int e = fbbev_rt_memset_async(totals, 0, ((size_t)passes * FBBEV_SORT_SHARDS << FBBEV_SORT_MAX_RB) * sizeof(int), stream);
     if (e) return e;
     const unsigned int* kin = keys_a; const unsigned int* vin = vals_a;
     for (int p = 0; p < passes; ++p) {
         const bool to_out = ((passes - 1 - p) % 2) == 0;   // last pass always writes the outputs
         unsigned int* ko = to_out ? keys_out : keys_t;
         unsigned int* vo = to_out ? vals_out : vals_t;
-        int* tot = totals + ((size_t)p << FBBEV_SORT_MAX_RB);
+        int* tot = totals + ((size_t)p * FBBEV_SORT_SHARDS << FBBEV_SORT_MAX_RB);
         const int shift = p * rb;
+        const int* n_dev = (p == 0) ? nullptr : n_kept_dev;
+        int* n_out = (p == 0) ? n_kept_dev : nullptr;
+        const int drop = (p == 0) ? 1 : 0;
         switch (rb) {
-            case 9: e = sort_pass<9>(kin, vin, ko, vo, n, shift, nblocks, hist, tot, stream); break;
-            case 8: e = sort_pass<8>(kin, vin, ko, vo, n, shift, nblocks, hist, tot, stream); break;
-            case 7: e = sort_pass<7>(kin, vin, ko, vo, n, shift, nblocks, hist, tot, stream); break;
-            case 6: e = sort_pass<6>(kin, vin, ko, vo, n, shift, nblocks, hist, tot, stream); break;
-            default: e = sort_pass<5>(kin, vin, ko, vo, n, shift, nblocks, hist, tot, stream); break;
+            case 9: e = sort_pass<9>(kin, vin, ko, vo, n, n_dev, shift, nblocks, drop_key, drop, hist, tot, n_out, stream); break;
+            case 8: e = sort_pass<8>(kin, vin, ko, vo, n, n_dev, shift, nblocks, drop_key, drop, hist, tot, n_out, stream); break;
+            case 7: e = sort_pass<7>(kin, vin, ko, vo, n, n_dev, shift, nblocks, drop_key, drop, hist, tot, n_out, stream); break;
+            case 6: e = sort_pass<6>(kin, vin, ko, vo, n, n_dev, shift, nblocks, drop_key, drop, hist, tot, n_out, stream); break;
+            default: e = sort_pass<5>(kin, vin, ko, vo, n, n_dev, shift, nblocks, drop_key, drop, hist, tot, n_out, stream); break;
         }
         if (e) return e;
         kin = ko; vin = vo;
@@ -220,16 +228,16 @@ extern "C" int fbbev_rank_build(const float* coor, int B, int N, int D, int H, i
     FBBEV_CHECK_LAUNCH();
     e = radix_sort_pairs(keys_in, vals_in, reinterpret_cast<unsigned int*>(ws + L.keys_tmp),
                          reinterpret_cast<unsigned int*>(ws + L.vals_tmp), reinterpret_cast<unsigned int*>(ranks_bev),
-                         reinterpret_cast<unsigned int*>(ranks_depth), n, bits, L.sort_blocks,
+                         reinterpret_cast<unsigned int*>(ranks_depth), n, bits, sentinel, counts, L.sort_blocks,
                          reinterpret_cast<int*>(ws + L.hist), reinterpret_cast<int*>(ws + L.totals), stream);
     if (e) return e;
     const unsigned int* keys = reinterpret_cast<const unsigned int*>(ranks_bev);
     const unsigned int* vals = reinterpret_cast<const unsigned int*>(ranks_depth);
-    FBBEV_LAUNCH(k_flag_count, L.n_blocks, FBBEV_RANK_BLOCK, 0, stream, keys, n, sentinel, block_counts, counts);
+    FBBEV_LAUNCH(k_flag_count, L.n_blocks, FBBEV_RANK_BLOCK, 0, stream, keys, (const int*)counts, block_counts);
     FBBEV_CHECK_LAUNCH();
     FBBEV_LAUNCH(k_scan_blocks, 1, FBBEV_RANK_BLOCK, 0, stream, block_counts, L.n_blocks, counts);
     FBBEV_CHECK_LAUNCH();
-    FBBEV_LAUNCH(k_write_intervals, L.n_blocks, FBBEV_RANK_BLOCK, 0, stream, keys, vals, n, sentinel,
+    FBBEV_LAUNCH(k_write_intervals, L.n_blocks, FBBEV_RANK_BLOCK, 0, stream, keys, vals, (const int*)counts,
                  (const int*)block_counts, D, H * W, ranks_feat, interval_starts, interval_rank);
     FBBEV_CHECK_LAUNCH();
     long long lb = (n + 255) / 256;

@@ -5,10 +5,10 @@
 // ~17 torch launches, an unstable argsort over B*N*D*H*W keys, three boolean-mask gathers and a
 // torch.where -- at least four host syncs.  Here everything stays on the device:
 //   k_rank_keys        : point -> key (fp32 rank evaluation + truncation, bit-for-bit the
-//                        reference arithmetic); points outside the grid get a sentinel key that
-//                        sorts behind every real voxel.
-//   (stable radix sort of (key, point id) pairs, rt.h)
-//   k_flag_count       : per-block count of run heads + P (number of kept points)
+//                        reference arithmetic); points outside the grid get a sentinel key.
+//   (stable radix sort of (key, point id) pairs, sort_kernels.h; its first pass drops the
+//    sentinel keys and publishes P, the number of kept points, on the device)
+//   k_flag_count       : per-block count of run heads
 //   k_scan_blocks      : exclusive scan of the block counts + I (number of intervals)
 //   k_write_intervals  : run heads -> interval_starts (block scan = wave prefix sums), ranks_feat
 //   k_interval_lengths : starts -> lengths
@@ -86,11 +86,12 @@ __device__ __forceinline__ int fbbev_block_excl_scan(int v, int* lds4, int* tota
     return woff + inc - v;
 }
 
-// keys sorted ascending, sentinels last. counts[0] = P.
+// keys[0..P) sorted ascending (P = counts[0], published by the sort's compaction pass)
 __global__ void __launch_bounds__(FBBEV_RANK_BLOCK)
-k_flag_count(const unsigned int* __restrict__ keys, long long n, unsigned int sentinel,
-             int* __restrict__ block_counts, int* __restrict__ counts) {
+k_flag_count(const unsigned int* __restrict__ keys, const int* __restrict__ counts,
+             int* __restrict__ block_counts) {
     __shared__ int lds4[4];
+    const long long n = counts[0];
     const long long base = (long long)blockIdx.x * FBBEV_RANK_CHUNK + threadIdx.x * FBBEV_RANK_ITEMS;
     int local = 0;
 #pragma unroll
@@ -98,10 +99,7 @@ k_flag_count(const unsigned int* __restrict__ keys, long long n, unsigned int se
         const long long i = base + j;
         if (i < n) {
             const unsigned int k = keys[i];
-            const bool valid = k != sentinel;
-            const bool head = valid && (i == 0 || keys[i - 1] != k);
-            local += head ? 1 : 0;
-            if (valid && (i + 1 == n || keys[i + 1] == sentinel)) counts[0] = (int)(i + 1);
+            local += (i == 0 || keys[i - 1] != k) ? 1 : 0;
         }
     }
     int total;
@@ -127,10 +125,11 @@ k_scan_blocks(int* __restrict__ block_counts, int nblocks, int* __restrict__ cou
 
 __global__ void __launch_bounds__(FBBEV_RANK_BLOCK)
 k_write_intervals(const unsigned int* __restrict__ keys, const unsigned int* __restrict__ vals,
-                  long long n, unsigned int sentinel, const int* __restrict__ block_offsets,
+                  const int* __restrict__ counts, const int* __restrict__ block_offsets,
                   int D, int HW, int* __restrict__ ranks_feat, int* __restrict__ interval_starts,
                   int* __restrict__ interval_rank) {
     __shared__ int lds4[4];
+    const long long n = counts[0];
     const long long base = (long long)blockIdx.x * FBBEV_RANK_CHUNK + threadIdx.x * FBBEV_RANK_ITEMS;
     bool head[FBBEV_RANK_ITEMS];
     unsigned int key[FBBEV_RANK_ITEMS];
@@ -140,17 +139,15 @@ k_write_intervals(const unsigned int* __restrict__ keys, const unsigned int* __r
     for (int j = 0; j < FBBEV_RANK_ITEMS; ++j) {
         const long long i = base + j;
         head[j] = false;
-        key[j] = sentinel;
+        key[j] = 0u;
         if (i < n) {
             const unsigned int k = keys[i];
             key[j] = k;
-            const bool valid = k != sentinel;
-            head[j] = valid && (i == 0 || keys[i - 1] != k);
+            head[j] = (i == 0 || keys[i - 1] != k);
             local += head[j] ? 1 : 0;
-            if (valid) {  // view_transformer.py:563-568: feature pixel of point ((b*N+n)*D+d)*HW + hw
-                const unsigned int pid = vals[i];
-                ranks_feat[i] = (int)((pid / dhw) * (unsigned int)HW + pid % (unsigned int)HW);
-            }
+            // view_transformer.py:563-568: feature pixel of point ((b*N+n)*D+d)*HW + hw
+            const unsigned int pid = vals[i];
+            ranks_feat[i] = (int)((pid / dhw) * (unsigned int)HW + pid % (unsigned int)HW);
         }
     }
     int total;

@@ -2,6 +2,9 @@
 //
 // The reference sorts with torch.argsort (view_transformer.py:590, unstable).  Here a hand-written
 // stable radix sort on exactly the key bits that can be set (log2(B*X*Y*Z)+1), RB bits per pass:
+// Pass 1 also COMPACTS: keys equal to `drop_key` (the out-of-grid sentinel, ~55 % of a frustum) are
+// neither counted nor written, and the number of kept keys P is published on the device; later passes
+// read their length from that device counter (no host sync) and move only P pairs.
 //   k_sort_hist    : per-workgroup digit histogram (LDS atomics) -> hist[digit][workgroup], totals[digit]
 //   k_sort_scan    : one workgroup per digit: base = sum of lower digits' totals, then an exclusive scan of
 //                    the digit's row over workgroups (wave-prefix-sum block scan)
@@ -18,35 +21,48 @@
 #define FBBEV_SORT_ROUNDS 16
 #define FBBEV_SORT_TILE (FBBEV_SORT_WAVES * 64 * FBBEV_SORT_ROUNDS)   // 4096 keys per workgroup
 #define FBBEV_SORT_MAX_RB 9
+#define FBBEV_SORT_SHARDS 16    // totals[] is sharded by workgroup index to spread the global atomics
 
 template <int RB>
 __global__ void __launch_bounds__(256)
-k_sort_hist(const unsigned int* __restrict__ keys, long long n, int shift, int nblocks,
-            int* __restrict__ hist, int* __restrict__ totals) {
+k_sort_hist(const unsigned int* __restrict__ keys, long long n_host, const int* __restrict__ n_dev, int shift,
+            int nblocks, unsigned int drop_key, int drop, int* __restrict__ hist, int* __restrict__ totals) {
     constexpr int NB = 1 << RB;
+    const long long n = n_dev ? (long long)*n_dev : n_host;
     __shared__ int cnt[NB];
     for (int d = threadIdx.x; d < NB; d += 256) cnt[d] = 0;
     __syncthreads();
     const long long base = (long long)blockIdx.x * FBBEV_SORT_TILE;
     for (int i = threadIdx.x; i < FBBEV_SORT_TILE; i += 256) {
         const long long idx = base + i;
-        if (idx < n) atomicAdd(&cnt[(keys[idx] >> shift) & (NB - 1)], 1);
+        if (idx < n) {
+            const unsigned int key = keys[idx];
+            if (!(drop && key == drop_key)) atomicAdd(&cnt[(key >> shift) & (NB - 1)], 1);
+        }
     }
     __syncthreads();
     for (int d = threadIdx.x; d < NB; d += 256) {
         const int c = cnt[d];
         hist[(long long)d * nblocks + blockIdx.x] = c;
-        if (c) atomicAdd(&totals[d], c);
+        if (c) atomicAdd(&totals[((blockIdx.x & (FBBEV_SORT_SHARDS - 1)) << RB) + d], c);
     }
 }
 
 // grid = number of digits; exclusive scan of hist[d][0..nblocks) offset by the totals of all lower digits
 __global__ void __launch_bounds__(256)
-k_sort_scan(int* __restrict__ hist, const int* __restrict__ totals, int nblocks) {
+k_sort_scan(int* __restrict__ hist, const int* __restrict__ totals, int nblocks, int* __restrict__ n_out) {
     __shared__ int lds4[4];
     const int d = blockIdx.x;
+    const int NBs = (int)gridDim.x;             // digits; totals is [SHARDS][NBs]
+    if (n_out && d == NBs - 1) {                // publish the number of keys this pass keeps
+        int all = 0;
+        for (int j = threadIdx.x; j < NBs * FBBEV_SORT_SHARDS; j += 256) all += totals[j];
+        int tot;
+        (void)fbbev_block_excl_scan(all, lds4, &tot);
+        if (threadIdx.x == 0) *n_out = tot;
+    }
     int part = 0;
-    for (int j = threadIdx.x; j < d; j += 256) part += totals[j];
+    for (int j = threadIdx.x; j < d * FBBEV_SORT_SHARDS; j += 256) part += totals[(j / d) * NBs + (j % d)];
     int base;
     (void)fbbev_block_excl_scan(part, lds4, &base);
     int running = base;
@@ -63,10 +79,12 @@ k_sort_scan(int* __restrict__ hist, const int* __restrict__ totals, int nblocks)
 
 template <int RB>
 __global__ void __launch_bounds__(256)
-k_sort_scatter(const unsigned int* __restrict__ keys_in, const unsigned int* __restrict__ vals_in, long long n,
-               int shift, int nblocks, const int* __restrict__ hist, unsigned int* __restrict__ keys_out,
+k_sort_scatter(const unsigned int* __restrict__ keys_in, const unsigned int* __restrict__ vals_in,
+               long long n_host, const int* __restrict__ n_dev, int shift, int nblocks, unsigned int drop_key,
+               int drop, const int* __restrict__ hist, unsigned int* __restrict__ keys_out,
                unsigned int* __restrict__ vals_out) {
     constexpr int NB = 1 << RB;
+    const long long n = n_dev ? (long long)*n_dev : n_host;
     __shared__ int cnt[FBBEV_SORT_WAVES][NB];    // per-wave running digit counters -> per-wave totals
     __shared__ int woff[FBBEV_SORT_WAVES][NB];   // global position of each wave's first key of a digit
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -79,9 +97,11 @@ k_sort_scatter(const unsigned int* __restrict__ keys_in, const unsigned int* __r
 #pragma unroll
     for (int r = 0; r < FBBEV_SORT_ROUNDS; ++r) {
         const long long idx = chunk + r * 64 + lane;
-        const bool valid = idx < n;
+        bool valid = idx < n;
         k[r] = valid ? keys_in[idx] : 0u;
         v[r] = valid ? vals_in[idx] : 0u;
+        valid = valid && !(drop && k[r] == drop_key);
+        lr[r] = -1;
         const unsigned int d = (k[r] >> shift) & (NB - 1);
         unsigned long long m = __ballot(valid ? 1 : 0);          // wave-level match on the digit
 #pragma unroll
@@ -96,7 +116,7 @@ k_sort_scatter(const unsigned int* __restrict__ keys_in, const unsigned int* __r
             cnt[wave][d] = prev + __popcll(m);
         }
         prev = __shfl(prev, leader, 64);
-        lr[r] = prev + __popcll(m & lt);
+        if (valid) lr[r] = prev + __popcll(m & lt);
     }
     __syncthreads();
     for (int d = tid; d < NB; d += 256) {
@@ -107,8 +127,7 @@ k_sort_scatter(const unsigned int* __restrict__ keys_in, const unsigned int* __r
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < FBBEV_SORT_ROUNDS; ++r) {
-        const long long idx = chunk + r * 64 + lane;
-        if (idx < n) {
+        if (lr[r] >= 0) {
             const unsigned int d = (k[r] >> shift) & (NB - 1);
             const int pos = woff[wave][d] + lr[r];
             keys_out[pos] = k[r];
