@@ -5,7 +5,7 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W
   N>1 is launched as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`
   (one rank per GPU, RCCL via backend "nccl"); rank 0 prints ONE JSON line.
 
-Step   = one pass of the hot path (scope S2 of SURVEY 8d: get_lidar_coor -> voxel ranking ->
+Step   = one pass of the hot path (scope S2 of SURVEY 8d: get_lidar_coor + voxel ranking (fused) ->
          bev_pool_v2 into the dense (B,C,Z,Y,X) volume) over one batch of synthetic 6-camera samples,
          BASELINE.json configs[1] shapes (6x256x704 in, 16x44 feature map, D=59, C=80, 200x200x16 grid).
          Nothing is cached across steps: the index tensors are rebuilt every step, as the reference
@@ -123,8 +123,7 @@ def main():
           for _ in range(args.steps)]
 
     def step(i=None):
-        coor = vt.get_lidar_coor(*cam)                              # fbbev_lidar_coor
-        idx = vt.build_index(coor)                                  # fbbev_rank_build (device counts)
+        idx = vt.build_index_from_cams(*cam)                        # fbbev_lift_rank_build: geometry + ranking, device counts
         feat = ctx.permute(0, 1, 3, 4, 2).contiguous()              # (B,N,H,W,C), as bev_pool.py:18
         _capi.pool_tile_index(idx.interval_rank, idx.interval_starts, idx.counts, idx.n, B, Z, Y, X,
                               tile_ws, args.tile_voxels)

@@ -22,10 +22,12 @@ SIGNATURES = {
     'fbbev_rank_workspace_bytes': (c_size_t, [c_int64]),
     'fbbev_rank_build': (c_int, [c_void_p] + [c_int] * 5 + [c_void_p] * 3 + [c_void_p] * 7 +
                          [c_void_p, c_size_t, c_void_p]),
+    'fbbev_lift_rank_build': (c_int, [c_void_p] * 9 + [c_int] * 5 + [c_void_p] * 3 + [c_void_p] * 7 +
+                              [c_void_p, c_size_t, c_void_p]),
     'fbbev_pool_dense_workspace_bytes': (c_size_t, [c_int] * 4),
-    'fbbev_pool_tile_index': (c_int, [c_void_p] * 3 + [c_int] * 6 + [c_void_p, c_size_t, c_void_p]),
-    'fbbev_bev_pool_v2_dense_fwd': (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t,
-                                            c_int, c_int, c_void_p]),
+    'fbbev_pool_tile_index': (c_int, [c_void_p] * 3 + [c_int] * 7 + [c_void_p, c_size_t, c_void_p]),
+    'fbbev_bev_pool_v2_dense_fwd': (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_void_p, c_int64, c_int64, c_void_p,
+                                            c_size_t, c_int, c_int, c_void_p]),
     'fbbev_msda_fwd': (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_void_p, c_void_p]),
     'fbbev_point_sampling': (c_int, [c_void_p] * 9 + [c_int] * 5 + [c_float, c_float] + [c_void_p] * 4),
     'fbbev_da_cross_attn_fwd': (c_int, [c_void_p] * 9 + [c_int] * 10 + [c_float, c_float, c_void_p, c_void_p]),
@@ -148,6 +150,28 @@ def rank_build(coor, lower3, interval3, grid_size3, ranks_bev, ranks_depth, rank
             workspace.numel() * workspace.element_size(), _stream()), 'fbbev_rank_build')
 
 
+def lift_rank_build(xs, ys, ds, rots, trans, intrins, post_rots, post_trans, bda, lower3, interval3, grid_size3,
+                    ranks_bev, ranks_depth, ranks_feat, interval_starts, interval_lengths, interval_rank, counts,
+                    workspace):
+    """Geometry + ranking in one call (no coor tensor); arguments as lidar_coor + rank_build."""
+    B, N = trans.shape[:2]
+    D, H, W = ds.numel(), ys.numel(), xs.numel()
+    arr = ctypes.c_float * 3
+    lo, it, gs = arr(*lower3), arr(*interval3), arr(*grid_size3)
+    with _on(ranks_bev):
+        _check(lib().fbbev_lift_rank_build(
+            _dev(xs, F32, 'xs'), _dev(ys, F32, 'ys'), _dev(ds, F32, 'ds'), _dev(rots, F32, 'rots'),
+            _dev(trans, F32, 'trans'), _dev(intrins, F32, 'intrins'), _dev(post_rots, F32, 'post_rots'),
+            _dev(post_trans, F32, 'post_trans'), _dev(bda, F32, 'bda'), B, N, D, H, W,
+            ctypes.cast(lo, c_void_p), ctypes.cast(it, c_void_p), ctypes.cast(gs, c_void_p),
+            _dev(ranks_bev, I32, 'ranks_bev'), _dev(ranks_depth, I32, 'ranks_depth'),
+            _dev(ranks_feat, I32, 'ranks_feat'), _dev(interval_starts, I32, 'interval_starts'),
+            _dev(interval_lengths, I32, 'interval_lengths'),
+            _dev(interval_rank, I32, 'interval_rank') if interval_rank is not None else c_void_p(0),
+            _dev(counts, I32, 'counts'), c_void_p(workspace.data_ptr()),
+            workspace.numel() * workspace.element_size(), _stream()), 'fbbev_lift_rank_build')
+
+
 def pool_dense_workspace_bytes(B, Z, Y, X):
     return int(lib().fbbev_pool_dense_workspace_bytes(B, Z, Y, X))
 
@@ -170,12 +194,15 @@ DEFAULT_POOL_FLAGS = pool_flags()
 DEFAULT_TILE_VOXELS = 128
 
 
+POOL_CHANNELS_LAST = 0x100000
+
+
 def pool_tile_index(interval_rank, interval_starts, counts, n_intervals_max, B, Z, Y, X, tile_ws,
-                    tile_voxels=64):
+                    tile_voxels=64, flags=0):
     with _on(interval_rank):
         _check(lib().fbbev_pool_tile_index(
             _dev(interval_rank, I32, 'interval_rank'), _dev(interval_starts, I32, 'interval_starts'),
-            _dev(counts, I32, 'counts'), int(n_intervals_max), B, Z, Y, X, int(tile_voxels),
+            _dev(counts, I32, 'counts'), int(n_intervals_max), B, Z, Y, X, int(tile_voxels), int(flags),
             c_void_p(tile_ws.data_ptr()), tile_ws.numel() * tile_ws.element_size(), _stream()),
             'fbbev_pool_tile_index')
 
@@ -183,12 +210,24 @@ def pool_tile_index(interval_rank, interval_starts, counts, n_intervals_max, B, 
 def bev_pool_v2_dense_fwd(depth, feat, ranks_depth, ranks_feat, interval_rank, interval_starts,
                           interval_lengths, B, C, Z, Y, X, out, tile_ws, tile_voxels=64,
                           flags=DEFAULT_POOL_FLAGS):
+    """`out` is (B,C,Z,Y,X) f32 whose (Z,Y,X) block is contiguous (batch/channel strides may be padded), or,
+    with POOL_CHANNELS_LAST in `flags`, a contiguous (B,Z,Y,X,C) tensor (the reference op's own layout)."""
+    if out.dtype != F32 or not out.is_cuda:
+        raise FbbevError('out must be a GPU float32 tensor')
+    if flags & POOL_CHANNELS_LAST:
+        if tuple(out.shape) != (B, Z, Y, X, C) or not out.is_contiguous():
+            raise FbbevError('channels-last out must be a contiguous (B,Z,Y,X,C) tensor')
+        sb, sc = C * Z * Y * X, Z * Y * X
+    else:
+        if tuple(out.shape) != (B, C, Z, Y, X) or out.stride()[2:] != (Y * X, X, 1):
+            raise FbbevError('out must be a (B,C,Z,Y,X) tensor with a contiguous (Z,Y,X) block')
+        sb, sc = out.stride(0), out.stride(1)
     with _on(depth):
         _check(lib().fbbev_bev_pool_v2_dense_fwd(
             _dev(depth, F32, 'depth'), _dev(feat, F32, 'feat'), _dev(ranks_depth, I32, 'ranks_depth'),
             _dev(ranks_feat, I32, 'ranks_feat'), _dev(interval_rank, I32, 'interval_rank'),
             _dev(interval_starts, I32, 'interval_starts'), _dev(interval_lengths, I32, 'interval_lengths'),
-            B, C, Z, Y, X, _dev(out, F32, 'out'), c_void_p(tile_ws.data_ptr()),
+            B, C, Z, Y, X, c_void_p(out.data_ptr()), sb, sc, c_void_p(tile_ws.data_ptr()),
             tile_ws.numel() * tile_ws.element_size(), int(tile_voxels), int(flags), _stream()),
             'fbbev_bev_pool_v2_dense_fwd')
 

@@ -85,8 +85,10 @@ extern "C" int fbbev_lidar_coor(const float* xs, const float* ys, const float* d
     const long long dhw = (long long)D * H * W;
     const long long chunks = (dhw + 255) / 256;
     if (chunks * B * N >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
-    FBBEV_LAUNCH(k_lidar_coor, chunks * B * N, 256, 0, (fbbev_rt_stream)stream_, xs, ys, ds, rots, trans,
-                 intrins, post_rots, post_trans, bda, N, D, H, W, (int)chunks, coor);
+    fbbev_cam_ptrs g;
+    g.xs = xs; g.ys = ys; g.ds = ds; g.rots = rots; g.trans = trans; g.intrins = intrins; g.post_rots = post_rots;
+    g.post_trans = post_trans; g.bda = bda; g.N = N; g.D = D; g.H = H; g.W = W;
+    FBBEV_LAUNCH(k_lidar_coor, chunks * B * N, 256, 0, (fbbev_rt_stream)stream_, g, (int)chunks, coor);
     FBBEV_CHECK_LAUNCH();
     return 0;
 }
@@ -131,7 +133,7 @@ static rank_ws_layout rank_layout(long long n) {
     L.keys_tmp = off; off = align_up(off + (size_t)n * 4, 256);
     L.vals_tmp = off; off = align_up(off + (size_t)n * 4, 256);
     L.block_counts = off; off = align_up(off + (size_t)(L.n_blocks + 1) * 4, 256);
-    L.hist = off; off = align_up(off + ((size_t)L.sort_blocks << FBBEV_SORT_MAX_RB) * 4, 256);
+    L.hist = off; off = align_up(off + ((size_t)(L.sort_blocks + 64) * 2 << FBBEV_SORT_MAX_RB) * 4, 256);  // also covers the per-camera tiling
     L.totals = off; off = align_up(off + ((size_t)4 * FBBEV_SORT_SHARDS << FBBEV_SORT_MAX_RB) * 4, 256);   // [pass][shard][digit]
     L.total = off;
     return L;
@@ -151,10 +153,20 @@ static int sort_pass(const unsigned int* kin, const unsigned int* vin, unsigned 
 
 // Stable LSD radix sort of the low `bits` key bits.  Pass 0 drops keys == drop_key and writes the number
 // of kept pairs to *n_kept_dev; later passes read that device counter.  Result in (keys_out, vals_out).
+template <int RB>
+static int sort_pass_geom(const fbbev_geom_src& g, unsigned int* kout, unsigned int* vout, int nblocks, int* hist,
+                          int* totals, int* n_out, fbbev_rt_stream stream) {
+    FBBEV_LAUNCH(k_sort_hist_geom<RB>, nblocks, 256, 0, stream, g, 0, nblocks, hist, totals);
+    FBBEV_LAUNCH(k_sort_scan, 1 << RB, 256, 0, stream, hist, (const int*)totals, nblocks, n_out);
+    FBBEV_LAUNCH(k_sort_scatter_geom<RB>, nblocks, 256, 0, stream, g, 0, nblocks, (const int*)hist, kout, vout);
+    return fbbev_rt_last_error();
+}
+
+// geom != nullptr: pass 0 evaluates the keys from the camera geometry (no keys_a/vals_a input).
 static int radix_sort_pairs(unsigned int* keys_a, unsigned int* vals_a, unsigned int* keys_t, unsigned int* vals_t,
                             unsigned int* keys_out, unsigned int* vals_out, long long n, int bits,
                             unsigned int drop_key, int* n_kept_dev, int nblocks, int* hist, int* totals,
-                            fbbev_rt_stream stream) {
+                            fbbev_rt_stream stream, const fbbev_geom_src* geom = nullptr, int geom_blocks = 0) {
     const int passes = (bits + FBBEV_SORT_MAX_RB - 1) / FBBEV_SORT_MAX_RB;
     const int rb = (bits + passes - 1) / passes;      // digits as even as possible, <= 9 bits
     int e = fbbev_rt_memset_async(totals, 0, ((size_t)passes * FBBEV_SORT_SHARDS << FBBEV_SORT_MAX_RB) * sizeof(int), stream);
@@ -169,6 +181,18 @@ static int radix_sort_pairs(unsigned int* keys_a, unsigned int* vals_a, unsigned
         const int* n_dev = (p == 0) ? nullptr : n_kept_dev;
         int* n_out = (p == 0) ? n_kept_dev : nullptr;
         const int drop = (p == 0) ? 1 : 0;
+        if (p == 0 && geom) {
+            switch (rb) {
+                case 9: e = sort_pass_geom<9>(*geom, ko, vo, geom_blocks, hist, tot, n_out, stream); break;
+                case 8: e = sort_pass_geom<8>(*geom, ko, vo, geom_blocks, hist, tot, n_out, stream); break;
+                case 7: e = sort_pass_geom<7>(*geom, ko, vo, geom_blocks, hist, tot, n_out, stream); break;
+                case 6: e = sort_pass_geom<6>(*geom, ko, vo, geom_blocks, hist, tot, n_out, stream); break;
+                default: e = sort_pass_geom<5>(*geom, ko, vo, geom_blocks, hist, tot, n_out, stream); break;
+            }
+            if (e) return e;
+            kin = ko; vin = vo;
+            continue;
+        }
         switch (rb) {
             case 9: e = sort_pass<9>(kin, vin, ko, vo, n, n_dev, shift, nblocks, drop_key, drop, hist, tot, n_out, stream); break;
             case 8: e = sort_pass<8>(kin, vin, ko, vo, n, n_dev, shift, nblocks, drop_key, drop, hist, tot, n_out, stream); break;
@@ -187,18 +211,16 @@ extern "C" size_t fbbev_rank_workspace_bytes(int64_t n_points) {
     return rank_layout(n_points).total;
 }
 
-extern "C" int fbbev_rank_build(const float* coor, int B, int N, int D, int H, int W,
-                                const float* lower3, const float* interval3,
-                                const float* grid_size3, int32_t* ranks_bev, int32_t* ranks_depth,
-                                int32_t* ranks_feat, int32_t* interval_starts,
-                                int32_t* interval_lengths, int32_t* interval_rank, int32_t* counts,
-                                void* workspace, size_t workspace_bytes, fbbev_stream_t stream_) {
+static int rank_build_impl(const float* coor, const fbbev_cam_ptrs* cams, int B, int N, int D, int H, int W,
+                           const float* lower3, const float* interval3, const float* grid_size3,
+                           int32_t* ranks_bev, int32_t* ranks_depth, int32_t* ranks_feat,
+                           int32_t* interval_starts, int32_t* interval_lengths, int32_t* interval_rank,
+                           int32_t* counts, void* workspace, size_t workspace_bytes, fbbev_rt_stream stream) {
     if (B <= 0 || N <= 0 || D <= 0 || H <= 0 || W <= 0) return FBBEV_E_BADARG;
-    if (!coor || !lower3 || !interval3 || !grid_size3 || !ranks_bev || !ranks_depth || !ranks_feat ||
+    if ((!coor && !cams) || !lower3 || !interval3 || !grid_size3 || !ranks_bev || !ranks_depth || !ranks_feat ||
         !interval_starts || !interval_lengths || !counts || !workspace) return FBBEV_E_BADARG;
     const long long n = (long long)B * N * D * H * W;
     if (n >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
-    fbbev_rt_stream stream = (fbbev_rt_stream)stream_;
     const rank_ws_layout L = rank_layout(n);
     if (workspace_bytes < L.total) return FBBEV_E_WORKSPACE;
     unsigned char* ws = static_cast<unsigned char*>(workspace);
@@ -222,23 +244,33 @@ extern "C" int fbbev_rank_build(const float* coor, int B, int N, int D, int H, i
 
     int e = fbbev_rt_memset_async(counts, 0, 2 * sizeof(int32_t), stream);
     if (e) return e;
-    long long kb = (n + 255) / 256;
-    if (kb > 8192) kb = 8192;
-    FBBEV_LAUNCH(k_rank_keys, kb, 256, 0, stream, coor, n, n / B, gp, sentinel, keys_in, vals_in);
-    FBBEV_CHECK_LAUNCH();
+    fbbev_geom_src gs;
+    int geom_blocks = 0;
+    if (cams) {
+        gs.cam = *cams; gs.gp = gp; gs.sentinel = sentinel;
+        const long long dhw = (long long)D * H * W;
+        gs.chunks_per_cam = (int)((dhw + FBBEV_SORT_TILE - 1) / FBBEV_SORT_TILE);
+        const long long gb = (long long)B * N * gs.chunks_per_cam;
+        if (gb > (long long)(L.sort_blocks + 64) * 2) return FBBEV_E_UNSUPPORTED;   // hist capacity (tiny frusta, huge B*N)
+        geom_blocks = (int)gb;
+    } else {
+        long long kb = (n + 255) / 256;
+        if (kb > 8192) kb = 8192;
+        FBBEV_LAUNCH(k_rank_keys, kb, 256, 0, stream, coor, n, n / B, gp, sentinel, keys_in, vals_in);
+        FBBEV_CHECK_LAUNCH();
+    }
     e = radix_sort_pairs(keys_in, vals_in, reinterpret_cast<unsigned int*>(ws + L.keys_tmp),
                          reinterpret_cast<unsigned int*>(ws + L.vals_tmp), reinterpret_cast<unsigned int*>(ranks_bev),
                          reinterpret_cast<unsigned int*>(ranks_depth), n, bits, sentinel, counts, L.sort_blocks,
-                         reinterpret_cast<int*>(ws + L.hist), reinterpret_cast<int*>(ws + L.totals), stream);
+                         reinterpret_cast<int*>(ws + L.hist), reinterpret_cast<int*>(ws + L.totals), stream,
+                         cams ? &gs : nullptr, geom_blocks);
     if (e) return e;
     const unsigned int* keys = reinterpret_cast<const unsigned int*>(ranks_bev);
     const unsigned int* vals = reinterpret_cast<const unsigned int*>(ranks_depth);
     FBBEV_LAUNCH(k_flag_count, L.n_blocks, FBBEV_RANK_BLOCK, 0, stream, keys, (const int*)counts, block_counts);
     FBBEV_CHECK_LAUNCH();
-    FBBEV_LAUNCH(k_scan_blocks, 1, FBBEV_RANK_BLOCK, 0, stream, block_counts, L.n_blocks, counts);
-    FBBEV_CHECK_LAUNCH();
-    FBBEV_LAUNCH(k_write_intervals, L.n_blocks, FBBEV_RANK_BLOCK, 0, stream, keys, vals, (const int*)counts,
-                 (const int*)block_counts, D, H * W, ranks_feat, interval_starts, interval_rank);
+    FBBEV_LAUNCH(k_write_intervals, L.n_blocks, FBBEV_RANK_BLOCK, 0, stream, keys, vals, counts,
+                 (const int*)block_counts, L.n_blocks, D, H * W, ranks_feat, interval_starts, interval_rank);
     FBBEV_CHECK_LAUNCH();
     long long lb = (n + 255) / 256;
     if (lb > 4096) lb = 4096;
@@ -248,32 +280,88 @@ extern "C" int fbbev_rank_build(const float* coor, int B, int N, int D, int H, i
     return 0;
 }
 
+extern "C" int fbbev_rank_build(const float* coor, int B, int N, int D, int H, int W,
+                                const float* lower3, const float* interval3,
+                                const float* grid_size3, int32_t* ranks_bev, int32_t* ranks_depth,
+                                int32_t* ranks_feat, int32_t* interval_starts,
+                                int32_t* interval_lengths, int32_t* interval_rank, int32_t* counts,
+                                void* workspace, size_t workspace_bytes, fbbev_stream_t stream_) {
+    if (!coor) return FBBEV_E_BADARG;
+    return rank_build_impl(coor, nullptr, B, N, D, H, W, lower3, interval3, grid_size3, ranks_bev, ranks_depth,
+                           ranks_feat, interval_starts, interval_lengths, interval_rank, counts, workspace,
+                           workspace_bytes, (fbbev_rt_stream)stream_);
+}
+
+extern "C" int fbbev_lift_rank_build(const float* xs, const float* ys, const float* ds, const float* rots,
+                                     const float* trans, const float* intrins, const float* post_rots,
+                                     const float* post_trans, const float* bda, int B, int N, int D, int H,
+                                     int W, const float* lower3, const float* interval3,
+                                     const float* grid_size3, int32_t* ranks_bev, int32_t* ranks_depth,
+                                     int32_t* ranks_feat, int32_t* interval_starts, int32_t* interval_lengths,
+                                     int32_t* interval_rank, int32_t* counts, void* workspace,
+                                     size_t workspace_bytes, fbbev_stream_t stream_) {
+    if (!xs || !ys || !ds || !rots || !trans || !intrins || !post_rots || !post_trans || !bda) return FBBEV_E_BADARG;
+    fbbev_cam_ptrs g;
+    g.xs = xs; g.ys = ys; g.ds = ds; g.rots = rots; g.trans = trans; g.intrins = intrins; g.post_rots = post_rots;
+    g.post_trans = post_trans; g.bda = bda; g.N = N; g.D = D; g.H = H; g.W = W;
+    return rank_build_impl(nullptr, &g, B, N, D, H, W, lower3, interval3, grid_size3, ranks_bev, ranks_depth,
+                           ranks_feat, interval_starts, interval_lengths, interval_rank, counts, workspace,
+                           workspace_bytes, (fbbev_rt_stream)stream_);
+}
+
 // ------------------------------------------------------------------------------ fused dense fwd
 static inline int pick_tile(int tile_voxels) {
     switch (tile_voxels) { case 64: case 128: case 256: case 512: case 1024: return tile_voxels; default: return 64; }
+}
+// channels-last small tiles: 8 / 16 / 32 voxels per workgroup (one 16-byte store per thread)
+static inline int small_tile_shift(int tile_voxels) {
+    switch (tile_voxels) { case 8: return 3; case 16: return 4; case 32: return 5; default: return 0; }
 }
 
 extern "C" size_t fbbev_pool_dense_workspace_bytes(int B, int Z, int Y, int X) {
     if (B <= 0 || Z <= 0 || Y <= 0 || X <= 0) return 256;
     const long long yx = (long long)Y * X;
-    const long long tiles = (long long)B * Z * ((yx + 63) / 64);  // smallest tile = most tiles
-    return align_up((size_t)(tiles + 2) * 8, 256);                // (first interval, first point) per tile
+    const long long tiles = ((long long)B * Z * yx + 7) / 8 + (long long)B * Z;   // smallest tile (8 voxels) = most tiles
+    return align_up((size_t)(tiles + 2) * 8, 256);                // two ints per tile
 }
 
 extern "C" int fbbev_pool_tile_index(const int32_t* interval_rank, const int32_t* interval_starts,
                                      const int32_t* counts, int n_intervals_max, int B, int Z, int Y,
-                                     int X, int tile_voxels, void* tile_ws, size_t tile_ws_bytes,
+                                     int X, int tile_voxels, int flags, void* tile_ws, size_t tile_ws_bytes,
                                      fbbev_stream_t stream_) {
     if (B <= 0 || Z <= 0 || Y <= 0 || X <= 0 || n_intervals_max < 0) return FBBEV_E_BADARG;
     if (!interval_rank || !interval_starts || !counts || !tile_ws) return FBBEV_E_BADARG;
     const long long yx = (long long)Y * X;
     if ((long long)B * Z * yx >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
+    if ((flags & FBBEV_POOL_CHANNELS_LAST) && small_tile_shift(tile_voxels)) {
+        // small tiles: scatter-built table (first/last interval per tile), -1 = empty
+        const int sh = small_tile_shift(tile_voxels);
+        const long long nvox = (long long)B * Z * yx;
+        const long long nt = (nvox + (1 << sh) - 1) >> sh;
+        if (tile_ws_bytes < (size_t)nt * 8) return FBBEV_E_WORKSPACE;
+        int* first = static_cast<int*>(tile_ws);
+        int e = fbbev_rt_memset_async(first, 0xFF, (size_t)nt * 8, (fbbev_rt_stream)stream_);
+        if (e) return e;
+        long long blocks = ((long long)n_intervals_max + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        if (blocks < 1) blocks = 1;
+        FBBEV_LAUNCH(k_tile_scatter, blocks, 256, 0, (fbbev_rt_stream)stream_, interval_rank, counts,
+                     n_intervals_max, sh, nvox, first, first + nt);
+        FBBEV_CHECK_LAUNCH();
+        return 0;
+    }
     const int TV = pick_tile(tile_voxels);
-    const int tiles_per_plane = (int)((yx + TV - 1) / TV);
-    const long long n_tiles = (long long)B * Z * tiles_per_plane;
+    int tiles_per_plane = (int)((yx + TV - 1) / TV);
+    long long n_tiles = (long long)B * Z * tiles_per_plane;
+    long long plane = yx;
+    if (flags & FBBEV_POOL_CHANNELS_LAST) {   // flat tiling of the whole (B*Z*Y*X) rank space
+        plane = (long long)B * Z * yx;
+        n_tiles = (plane + TV - 1) / TV;
+        tiles_per_plane = (int)n_tiles + 1;   // every tile index t (incl. t == n_tiles) stays in "plane" 0
+    }
     if (tile_ws_bytes < (size_t)(n_tiles + 1) * 8) return FBBEV_E_WORKSPACE;
     FBBEV_LAUNCH(k_tile_lower_bound2, (n_tiles + 1 + 255) / 256, 256, 0, (fbbev_rt_stream)stream_,
-                 (int)n_tiles, tiles_per_plane, (int)yx, TV, interval_rank, interval_starts, counts,
+                 (int)n_tiles, tiles_per_plane, (int)plane, TV, interval_rank, interval_starts, counts,
                  n_intervals_max, static_cast<int*>(tile_ws));
     FBBEV_CHECK_LAUNCH();
     return 0;
@@ -281,6 +369,7 @@ extern "C" int fbbev_pool_tile_index(const int32_t* interval_rank, const int32_t
 
 struct dense2_args {
     long long n_blocks; size_t lds; fbbev_rt_stream stream; int C, Z, yx, tpp, csplit, swizzle;
+    long long stride_b, stride_c;
     const float *depth, *feat; const int32_t *rd, *rf, *irank, *starts, *lengths; const int* tile_meta;
     float* out;
 };
@@ -297,13 +386,34 @@ static int launch_dense2(const dense2_args& a) {
         grid = (a.n_blocks + g - 1) / g * g;
     }
     FBBEV_LAUNCH((k_pool_fwd_dense2<TV, CPL, ST, NT>), grid, NT, a.lds, a.stream, a.C, a.Z, a.yx, a.tpp,
-                 a.csplit, (int)a.n_blocks, a.swizzle, a.depth, a.feat, a.rd, a.rf, a.irank, a.starts, a.lengths, a.tile_meta, a.out);
+                 a.csplit, (int)a.n_blocks, a.swizzle, a.stride_b, a.stride_c, a.depth, a.feat, a.rd, a.rf, a.irank, a.starts, a.lengths, a.tile_meta, a.out);
     return fbbev_rt_last_error();
 }
 
 template <int TV, int CPL, int ST>
 static int launch_dense2_nt(int nt, const dense2_args& a) {
     return nt == 128 ? launch_dense2<TV, CPL, ST, 128>(a) : launch_dense2<TV, CPL, ST, 256>(a);
+}
+
+template <int TV, int CPL, int ST, int NT>
+static int launch_dense_cl(const dense2_args& a) {
+    long long grid = a.n_blocks;
+    if (a.swizzle) {
+        const long long g = 8ll << (a.swizzle - 1);
+        grid = (a.n_blocks + g - 1) / g * g;
+    }
+    FBBEV_LAUNCH((k_pool_fwd_dense_cl<TV, CPL, ST, NT>), grid, NT, a.lds, a.stream, a.C, a.yx, (int)a.n_blocks,
+                 a.swizzle, a.depth, a.feat, a.rd, a.rf, a.irank, a.starts, a.lengths, a.tile_meta, a.out);
+    return fbbev_rt_last_error();
+}
+
+template <int TV, int CPL>
+static int launch_dense_cl_st(int st, const dense2_args& a) {
+    switch (st) {
+        case 0: return launch_dense_cl<TV, CPL, 0, 256>(a);
+        case 1: return launch_dense_cl<TV, CPL, 1, 256>(a);
+        default: return launch_dense_cl<TV, CPL, 4, 256>(a);
+    }
 }
 
 template <int TV, int CPL>
@@ -324,20 +434,72 @@ extern "C" int fbbev_bev_pool_v2_dense_fwd(const float* depth, const float* feat
                                            const int32_t* ranks_depth, const int32_t* ranks_feat,
                                            const int32_t* interval_rank, const int32_t* interval_starts,
                                            const int32_t* interval_lengths, int B, int C, int Z, int Y,
-                                           int X, float* out, const void* tile_ws, size_t tile_ws_bytes,
-                                           int tile_voxels, int flags, fbbev_stream_t stream_) {
+                                           int X, float* out, long long out_stride_b, long long out_stride_c,
+                                           const void* tile_ws, size_t tile_ws_bytes, int tile_voxels,
+                                           int flags, fbbev_stream_t stream_) {
     if (B <= 0 || C <= 0 || Z <= 0 || Y <= 0 || X <= 0) return FBBEV_E_BADARG;
     if (!depth || !feat || !ranks_depth || !ranks_feat || !interval_rank || !interval_starts ||
         !interval_lengths || !out || !tile_ws) return FBBEV_E_BADARG;
     const long long yx = (long long)Y * X;
     if (C % 4 != 0 || C > 256 || yx % 4 != 0 || !aligned16(out) || !aligned16(feat)) return FBBEV_E_UNSUPPORTED;
     if ((long long)B * Z * yx >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
+    if (out_stride_c == 0) out_stride_c = (long long)Z * yx;            // contiguous (B,C,Z,Y,X)
+    if (out_stride_b == 0) out_stride_b = (long long)C * out_stride_c;
+    if (out_stride_c < (long long)Z * yx || out_stride_b < (long long)C * out_stride_c || out_stride_c % 4 != 0 ||
+        out_stride_b % 4 != 0) return FBBEV_E_BADARG;
     fbbev_rt_stream stream = (fbbev_rt_stream)stream_;
     const int TV = pick_tile(tile_voxels);
     const int tiles_per_plane = (int)((yx + TV - 1) / TV);
     const long long n_tiles = (long long)B * Z * tiles_per_plane;
     if (tile_ws_bytes < (size_t)(n_tiles + 1) * 8) return FBBEV_E_WORKSPACE;
     const int st = (flags & FBBEV_POOL_STORE_MASK) | ((flags >> FBBEV_POOL_STORE_HI_SHIFT) & 1) << 2;
+    if (flags & FBBEV_POOL_CHANNELS_LAST) {
+        // out is (B,Z,Y,X,C) contiguous: flat tiles, linear store stream, no LDS value tile
+        if (out_stride_b != (long long)C * Z * yx || out_stride_c != (long long)Z * yx) return FBBEV_E_BADARG;
+        const long long nvox = (long long)B * Z * yx;
+        if (const int sh = small_tile_shift(tile_voxels)) {
+            const long long nt = (nvox + (1 << sh) - 1) >> sh;
+            if (tile_ws_bytes < (size_t)nt * 8) return FBBEV_E_WORKSPACE;
+            int threads = (C / 4) << sh;
+            if (threads > 1024) return FBBEV_E_UNSUPPORTED;
+            threads = (threads + 63) / 64 * 64;
+            int swz = 0;
+            if (flags & FBBEV_POOL_XCD_SWIZZLE) {
+                int lg = (flags >> FBBEV_POOL_SWZ_CHUNK_SHIFT) & 0x1F;
+                swz = lg + 1;            // lg == 0 -> chunks of one tile (== plain round-robin)
+            }
+            long long grid = nt;
+            if (swz) { const long long g = 8ll << (swz - 1); grid = (nt + g - 1) / g * g; }
+            const int* first = static_cast<const int*>(tile_ws);
+#define FBBEV_CLS(STV)                                                                                          \
+    FBBEV_LAUNCH(k_pool_fwd_cl_small<STV>, grid, threads, 0, stream, C, sh, nvox, (int)nt, swz, depth, feat,    \
+                 ranks_depth, ranks_feat, interval_rank, interval_starts, interval_lengths, first, first + nt, out)
+            if (st == 0) { FBBEV_CLS(0); } else if (st == 1) { FBBEV_CLS(1); } else { FBBEV_CLS(4); }
+#undef FBBEV_CLS
+            return fbbev_rt_last_error();
+        }
+        const bool cpl8cl = (flags & FBBEV_POOL_CPL8) && (C % 8 == 0);
+        if (256 / (C / (cpl8cl ? 8 : 4)) < 1) return FBBEV_E_UNSUPPORTED;
+        dense2_args a;
+        a.n_blocks = (nvox + TV - 1) / TV;
+        if (tile_ws_bytes < (size_t)(a.n_blocks + 1) * 8) return FBBEV_E_WORKSPACE;
+        a.lds = (3 * (size_t)TV + 2 * FBBEV_NP_STAGE) * sizeof(int);
+        a.stream = stream; a.C = C; a.Z = Z; a.yx = (int)nvox; a.tpp = 0; a.csplit = 1;
+        a.swizzle = 0;
+        if (flags & FBBEV_POOL_XCD_SWIZZLE) {
+            int lg = (flags >> FBBEV_POOL_SWZ_CHUNK_SHIFT) & 0x1F;
+            if (lg == 0) lg = 4;
+            a.swizzle = lg + 1;
+        }
+        a.depth = depth; a.feat = feat; a.rd = ranks_depth; a.rf = ranks_feat; a.irank = interval_rank;
+        a.starts = interval_starts; a.lengths = interval_lengths; a.tile_meta = static_cast<const int*>(tile_ws);
+        a.out = out; a.stride_b = 0; a.stride_c = 0;
+        if (TV == 64) return cpl8cl ? launch_dense_cl_st<64, 8>(st, a) : launch_dense_cl_st<64, 4>(st, a);
+        if (TV == 128) return cpl8cl ? launch_dense_cl_st<128, 8>(st, a) : launch_dense_cl_st<128, 4>(st, a);
+        if (TV == 256) return cpl8cl ? launch_dense_cl_st<256, 8>(st, a) : launch_dense_cl_st<256, 4>(st, a);
+        if (TV == 512) return cpl8cl ? launch_dense_cl_st<512, 8>(st, a) : launch_dense_cl_st<512, 4>(st, a);
+        return cpl8cl ? launch_dense_cl_st<1024, 8>(st, a) : launch_dense_cl_st<1024, 4>(st, a);
+    }
     int csplit = (flags >> FBBEV_POOL_CSPLIT_SHIFT) & 0xF;
     if (csplit == 0xF) csplit = 20;
     if (csplit < 1) csplit = 1;
@@ -351,6 +513,8 @@ extern "C" int fbbev_bev_pool_v2_dense_fwd(const float* depth, const float* feat
     a.n_blocks = n_tiles * csplit;
     a.lds = ((size_t)CC * (TV + 4) + 3 * (size_t)TV + 2 * FBBEV_NP_STAGE) * sizeof(float);
     a.stream = stream; a.C = C; a.Z = Z; a.yx = (int)yx; a.tpp = tiles_per_plane; a.csplit = csplit;
+    if (flags & FBBEV_POOL_DIAG_NO_META) a.csplit |= 0x40000000;   // diagnostic only (wrong output)
+    if (flags & FBBEV_POOL_CHANNEL_MAJOR) a.csplit |= 0x20000000;
     a.swizzle = 0;
     if (flags & FBBEV_POOL_XCD_SWIZZLE) {
         int lg = (flags >> FBBEV_POOL_SWZ_CHUNK_SHIFT) & 0x1F;   // log2(tiles per chunk); 0 -> default
@@ -360,7 +524,7 @@ extern "C" int fbbev_bev_pool_v2_dense_fwd(const float* depth, const float* feat
     if (a.n_blocks + 8 >= (1ll << 31) || a.lds > 160 * 1024) return FBBEV_E_UNSUPPORTED;
     a.depth = depth; a.feat = feat; a.rd = ranks_depth; a.rf = ranks_feat; a.irank = interval_rank;
     a.starts = interval_starts; a.lengths = interval_lengths; a.tile_meta = static_cast<const int*>(tile_ws);
-    a.out = out;
+    a.out = out; a.stride_b = out_stride_b; a.stride_c = out_stride_c;
     if (TV == 64) return cpl8 ? launch_dense2_st<64, 8>(st, nt, a) : launch_dense2_st<64, 4>(st, nt, a);
     if (TV == 128) return cpl8 ? launch_dense2_st<128, 8>(st, nt, a) : launch_dense2_st<128, 4>(st, nt, a);
     if (TV == 256) return cpl8 ? launch_dense2_st<256, 8>(st, nt, a) : launch_dense2_st<256, 4>(st, nt, a);

@@ -28,41 +28,57 @@ __device__ __forceinline__ void fbbev_mat3(const float* a, const float* b, float
             o[r * 3 + c] = a[r * 3] * b[c] + a[r * 3 + 1] * b[3 + c] + a[r * 3 + 2] * b[6 + c];
 }
 
+struct fbbev_cam_ptrs {
+    const float *xs, *ys, *ds;                               // frustum axes (W), (H), (D)
+    const float *rots, *trans, *intrins, *post_rots, *post_trans, *bda;
+    int N, D, H, W;
+};
+
+// per-camera algebra, done once per workgroup by one thread into m[33]:
+//   m[0:9] inv(post_rots), m[9:18] rots*inv(K), m[18:27] bda, m[27:30] post_trans, m[30:33] trans
+__device__ __forceinline__ void fbbev_cam_setup(const fbbev_cam_ptrs& g, int cam, float* m) {
+    const int b = cam / g.N;
+    float ik[9];
+    fbbev_inv3(g.post_rots + cam * 9, m);
+    fbbev_inv3(g.intrins + cam * 9, ik);
+    fbbev_mat3(g.rots + cam * 9, ik, m + 9);
+    for (int j = 0; j < 9; ++j) m[18 + j] = g.bda[b * 9 + j];
+    for (int j = 0; j < 3; ++j) { m[27 + j] = g.post_trans[cam * 3 + j]; m[30 + j] = g.trans[cam * 3 + j]; }
+}
+
+// one frustum point (u, v, depth) -> ego frame; the SAME expression sequence serves the materialising
+// kernel (k_lidar_coor) and the fused geometry->key source of the sort's first pass, so both produce the
+// same bits.
+__device__ __forceinline__ void fbbev_point_coor(const float* m, float u, float v, float d, float& ox, float& oy,
+                                                 float& oz) {
+    float px = u - m[27], py = v - m[28], pz = d - m[29];
+    float qx = m[0] * px + m[1] * py + m[2] * pz;
+    float qy = m[3] * px + m[4] * py + m[5] * pz;
+    float qz = m[6] * px + m[7] * py + m[8] * pz;
+    qx *= qz; qy *= qz;
+    px = m[9] * qx + m[10] * qy + m[11] * qz + m[30];
+    py = m[12] * qx + m[13] * qy + m[14] * qz + m[31];
+    pz = m[15] * qx + m[16] * qy + m[17] * qz + m[32];
+    ox = m[18] * px + m[19] * py + m[20] * pz;
+    oy = m[21] * px + m[22] * py + m[23] * pz;
+    oz = m[24] * px + m[25] * py + m[26] * pz;
+}
+
 // grid: (ceil(D*H*W / 256), B*N) flattened into blockIdx.x = cam * chunks + chunk
 __global__ void __launch_bounds__(256)
-k_lidar_coor(const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ ds,
-             const float* __restrict__ rots, const float* __restrict__ trans,
-             const float* __restrict__ intrins, const float* __restrict__ post_rots,
-             const float* __restrict__ post_trans, const float* __restrict__ bda, int N, int D, int H,
-             int W, int chunks, float* __restrict__ coor) {
-    __shared__ float m[9 + 9 + 9 + 3 + 3];  // inv(post_rots), rots*inv(K), bda, post_trans, trans
+k_lidar_coor(fbbev_cam_ptrs g, int chunks, float* __restrict__ coor) {
+    __shared__ float m[33];
     const int cam = blockIdx.x / chunks, chunk = blockIdx.x - cam * chunks;
-    const int b = cam / N;
-    if (threadIdx.x == 0) {
-        float ik[9];
-        fbbev_inv3(post_rots + cam * 9, m);
-        fbbev_inv3(intrins + cam * 9, ik);
-        fbbev_mat3(rots + cam * 9, ik, m + 9);
-        for (int j = 0; j < 9; ++j) m[18 + j] = bda[b * 9 + j];
-        for (int j = 0; j < 3; ++j) { m[27 + j] = post_trans[cam * 3 + j]; m[30 + j] = trans[cam * 3 + j]; }
-    }
+    if (threadIdx.x == 0) fbbev_cam_setup(g, cam, m);
     __syncthreads();
-    const int dhw = D * H * W;
+    const int dhw = g.D * g.H * g.W;
     const int i = chunk * 256 + threadIdx.x;
     if (i < dhw) {
-        const int w = i % W, h = (i / W) % H, d = i / (W * H);
-        float px = xs[w] - m[27], py = ys[h] - m[28], pz = ds[d] - m[29];
-        float qx = m[0] * px + m[1] * py + m[2] * pz;
-        float qy = m[3] * px + m[4] * py + m[5] * pz;
-        float qz = m[6] * px + m[7] * py + m[8] * pz;
-        qx *= qz; qy *= qz;
-        px = m[9] * qx + m[10] * qy + m[11] * qz + m[30];
-        py = m[12] * qx + m[13] * qy + m[14] * qz + m[31];
-        pz = m[15] * qx + m[16] * qy + m[17] * qz + m[32];
+        const int w = i % g.W, h = (i / g.W) % g.H, d = i / (g.W * g.H);
+        float ox, oy, oz;
+        fbbev_point_coor(m, g.xs[w], g.ys[h], g.ds[d], ox, oy, oz);
         float* o = coor + ((long long)cam * dhw + i) * 3;
-        o[0] = m[18] * px + m[19] * py + m[20] * pz;
-        o[1] = m[21] * px + m[22] * py + m[23] * pz;
-        o[2] = m[24] * px + m[25] * py + m[26] * pz;
+        o[0] = ox; o[1] = oy; o[2] = oz;
     }
 }
 

@@ -269,6 +269,7 @@ k_tile_lower_bound2(int n_tiles, int tiles_per_plane, int YX, int TV,
 template <int TV, int CPL, int ST, int NT>
 __global__ void __launch_bounds__(NT)
 k_pool_fwd_dense2(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_blocks, int swizzle,
+                  long long out_stride_b, long long out_stride_c,
                   const float* __restrict__ depth, const float* __restrict__ feat,
                   const int* __restrict__ rd, const int* __restrict__ rf,
                   const int* __restrict__ interval_rank, const int* __restrict__ starts,
@@ -276,6 +277,8 @@ k_pool_fwd_dense2(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_b
                   float* __restrict__ out) {
     constexpr int LD = TV + 4;
     constexpr int Q4 = TV / 4;
+    const int csplit_raw = csplit;
+    csplit &= 0x1FFFFFFF;
     const int CC = C / csplit;                 // channels handled by this block
     float* tile = fbbev_dyn_lds_f32();         // [CC][LD]
     int* ist = reinterpret_cast<int*>(tile + CC * LD);   // [TV] interval start relative to p0
@@ -295,16 +298,25 @@ k_pool_fwd_dense2(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_b
         bid = ((((j >> sh) << 3) + xcd) << sh) + (j & ((1 << sh) - 1));
     }
     if (bid >= n_blocks) return;
-    const int t = bid / csplit, half = bid - t * csplit;
+    // tile-major: the csplit channel groups of a tile are adjacent workgroups (index/feat reads shared through
+    // L2); channel-major (csplit_raw bit 29): the whole grid sweeps channel group 0 over all tiles, then
+    // group 1, ... -> few output planes are written at any one time (near-linear DRAM streams).
+    const int n_tiles_k = n_blocks / csplit;
+    const bool chan_major = (csplit_raw & 0x20000000) != 0;
+    const int t = chan_major ? (bid % n_tiles_k) : (bid / csplit);
+    const int half = chan_major ? (bid / n_tiles_k) : (bid - t * csplit);
     const int c0 = half * CC;
     const int plane = t / tiles_per_plane, k = t - plane * tiles_per_plane;
     const int b = plane / Z, z = plane - b * Z;
     const int v0 = k * TV;
     const int nv = (YX - v0 < TV) ? (YX - v0) : TV;
-    const int i0 = tile_meta[2 * t], p0 = tile_meta[2 * t + 1];
-    const int i1 = tile_meta[2 * t + 2], p1 = tile_meta[2 * t + 3];
-    const long long cstride = (long long)Z * YX;
-    float* __restrict__ obase = out + ((long long)b * C * Z + z) * YX + v0 + (long long)c0 * cstride;
+    // swizzle bit 30 = diagnostic: treat every tile as empty WITHOUT touching the metadata (measures the
+    // pure store pattern; profiles/r01_exp_pool_floor.jsonl)
+    const bool diag_no_meta = (csplit_raw & 0x40000000) != 0;
+    const int i0 = diag_no_meta ? 0 : tile_meta[2 * t], p0 = diag_no_meta ? 0 : tile_meta[2 * t + 1];
+    const int i1 = diag_no_meta ? 0 : tile_meta[2 * t + 2], p1 = diag_no_meta ? 0 : tile_meta[2 * t + 3];
+    const long long cstride = out_stride_c;      // elements between channels (Z*YX when contiguous)
+    float* __restrict__ obase = out + (long long)b * out_stride_b + (long long)z * YX + v0 + (long long)c0 * cstride;
     const int n4 = CC * Q4;
 
     if (i0 == i1) {
@@ -356,4 +368,153 @@ k_pool_fwd_dense2(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_b
             fbbev_store4<ST>(obase + c * cstride + j, val);
         }
     }
+}
+
+// ================================================================ fused dense forward, channels-last
+// out (B,Z,Y,X,C) -- the reference op's own output layout (QuickCumsumCuda.forward, bev_pool.py:24-38) --
+// but with EVERY voxel row written exactly once (zeros for empty voxels): replaces new_zeros + kernel.
+// A tile is TV consecutive voxels of the flat (B*Z*Y*X) rank space = ONE contiguous TV*C*4-byte span, so
+// the store stream of the whole grid is linear like a memset (the (B,C,Z,Y,X) variant above writes C
+// separate planes per tile and floors ~15 % below memset speed, profiles/r01_exp_pool_chanmajor.jsonl).
+// No LDS value tile: a lane group of C/CPL lanes owns a voxel row and stores its CPL channels directly;
+// LDS only holds the staged interval metadata, the voxel->interval slot map and the staged point indices.
+template <int TV, int CPL, int ST, int NT>
+__global__ void __launch_bounds__(NT)
+k_pool_fwd_dense_cl(int C, int n_voxels, int n_blocks, int swizzle, const float* __restrict__ depth,
+                    const float* __restrict__ feat, const int* __restrict__ rd, const int* __restrict__ rf,
+                    const int* __restrict__ interval_rank, const int* __restrict__ starts,
+                    const int* __restrict__ lengths, const int* __restrict__ tile_meta,
+                    float* __restrict__ out) {
+    int* ist = reinterpret_cast<int*>(fbbev_dyn_lds_f32());   // [TV]
+    int* iln = ist + TV;                                      // [TV]
+    int* slot = iln + TV;                                     // [TV] interval (tile-local) of each voxel, -1 = empty
+    int* prd = slot + TV;                                     // [NP_STAGE]
+    int* prf = prd + FBBEV_NP_STAGE;                          // [NP_STAGE]
+    const int tid = threadIdx.x;
+    int t = blockIdx.x;
+    if (swizzle) {
+        const int sh = swizzle - 1;
+        const int xcd = t & 7, j = t >> 3;
+        t = ((((j >> sh) << 3) + xcd) << sh) + (j & ((1 << sh) - 1));
+    }
+    if (t >= n_blocks) return;
+    const int v0 = t * TV;
+    const int nv = (n_voxels - v0 < TV) ? (n_voxels - v0) : TV;
+    const int i0 = tile_meta[2 * t], p0 = tile_meta[2 * t + 1];
+    const int i1 = tile_meta[2 * t + 2], p1 = tile_meta[2 * t + 3];
+    float* __restrict__ obase = out + (long long)v0 * C;
+    fbbev_v4f zero; zero[0] = zero[1] = zero[2] = zero[3] = 0.f;
+
+    if (i0 == i1) {  // empty tile: one linear run of zeros
+        const int n4 = nv * (C >> 2);
+        for (int idx = tid; idx < n4; idx += NT) fbbev_store4<ST>(obase + 4 * idx, zero);
+        return;
+    }
+
+    const int ni = i1 - i0;
+    const int np = p1 - p0;
+    for (int j = tid; j < TV; j += NT) slot[j] = -1;
+    for (int j = tid; j < ni; j += NT) { ist[j] = starts[i0 + j] - p0; iln[j] = lengths[i0 + j]; }
+    const int nps = np < FBBEV_NP_STAGE ? np : FBBEV_NP_STAGE;
+    for (int j = tid; j < nps; j += NT) { prd[j] = rd[p0 + j]; prf[j] = rf[p0 + j]; }
+    __syncthreads();
+    for (int j = tid; j < ni; j += NT) {
+        const int v = interval_rank[i0 + j] - v0;
+        if (v >= 0 && v < nv) slot[v] = j;
+    }
+    __syncthreads();
+
+    const int lpi = C / CPL;
+    const int gpb = NT / lpi;
+    const int g = tid / lpi, lane_slot = tid - g * lpi;
+    if (g < gpb) {
+        const float* fbase = feat + lane_slot * CPL;
+        for (int v = g; v < nv; v += gpb) {
+            const int s = slot[v];
+            float acc[CPL];
+            if (s >= 0) {
+                fbbev_interval_sum_staged<CPL>(C, ist[s], iln[s], p0, prd, prf, depth, fbase, rd, rf, acc);
+            } else {
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) acc[j] = 0.f;
+            }
+            float* dst = obase + (long long)v * C + lane_slot * CPL;
+#pragma unroll
+            for (int q = 0; q < CPL / 4; ++q) {
+                fbbev_v4f val; val[0] = acc[4 * q]; val[1] = acc[4 * q + 1]; val[2] = acc[4 * q + 2]; val[3] = acc[4 * q + 3];
+                fbbev_store4<ST>(dst + 4 * q, val);
+            }
+        }
+    }
+}
+
+// ================================================================ channels-last, small tiles ("one store per thread")
+// Measured on MI355X (tools/micro/fill_bench.hip, profiles/r01_fill_bench*.jsonl): the HBM write stream peaks
+// (7.0-7.6 TB/s) when every workgroup writes ~4 KiB with ONE 16-byte `sc1 nt` store per thread; 4+ stores per
+// thread or persistent grid-stride loops lose 15-80 %.  With the (B,Z,Y,X,C) layout a tile of TV voxels is one
+// contiguous TV*C*4-byte span, so TV=16, C=80 gives 5 KiB per workgroup of 320 threads: thread -> (voxel, channel
+// quad), exactly one store.  Non-empty voxels run the same in-order fmaf chain first (C/4 lanes per voxel).
+//
+// Tile table built by scatter instead of a binary search per tile (there are B*Z*Y*X/TV tiles):
+// tile_first[T] / tile_last[T] = first / last interval whose voxel falls in tile T, -1 for empty tiles.
+__global__ void __launch_bounds__(256)
+k_tile_scatter(const int* __restrict__ interval_rank, const int* __restrict__ counts, int n_intervals_max,
+               int tile_shift, long long n_voxels, int* __restrict__ tile_first, int* __restrict__ tile_last) {
+    int n = counts[1];
+    if (n > n_intervals_max) n = n_intervals_max;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int r = interval_rank[i];
+        if (r < 0 || r >= n_voxels) continue;          // fp32-rank overflow garbage is never pooled
+        const int T = r >> tile_shift;
+        const int rp = (i > 0) ? interval_rank[i - 1] : -1;
+        const int rn = (i + 1 < n) ? interval_rank[i + 1] : -1;
+        if (rp < 0 || (rp >> tile_shift) != T) tile_first[T] = i;
+        if (rn < 0 || rn >= n_voxels || (rn >> tile_shift) != T) tile_last[T] = i;
+    }
+}
+
+template <int ST>
+__global__ void __launch_bounds__(1024)
+k_pool_fwd_cl_small(int C, int tile_shift, long long n_voxels, int n_tiles, int swizzle,
+                    const float* __restrict__ depth, const float* __restrict__ feat,
+                    const int* __restrict__ rd, const int* __restrict__ rf,
+                    const int* __restrict__ interval_rank, const int* __restrict__ starts,
+                    const int* __restrict__ lengths, const int* __restrict__ tile_first,
+                    const int* __restrict__ tile_last, float* __restrict__ out) {
+    // Waves are independent: no LDS, no workgroup barrier.  A wave whose voxels are all empty issues its
+    // single store and retires at once, so only waves that really gather hold a wave slot.
+    const int TV = 1 << tile_shift;
+    const int q4 = C >> 2;                            // channel quads per voxel row
+    const int tid = threadIdx.x, lane = tid & 63;
+    int t = blockIdx.x;
+    if (swizzle) {
+        const int sh = swizzle - 1;
+        const int xcd = t & 7, j = t >> 3;
+        t = ((((j >> sh) << 3) + xcd) << sh) + (j & ((1 << sh) - 1));
+    }
+    if (t >= n_tiles) return;
+    const long long v0 = (long long)t << tile_shift;
+    const int nv = (n_voxels - v0 < TV) ? (int)(n_voxels - v0) : TV;
+    const int v = tid / q4, quad = tid - v * q4;
+    const bool active = v < nv;
+    const int i0 = tile_first[t];
+    float* dst = out + (v0 + v) * C + quad * 4;
+    fbbev_v4f val; val[0] = val[1] = val[2] = val[3] = 0.f;
+    if (i0 < 0) {                                     // empty tile: the store is all there is
+        if (active) fbbev_store4<ST>(dst, val);
+        return;
+    }
+    const int ni = tile_last[t] - i0 + 1;             // <= TV <= 64 intervals, one per lane
+    const int myrank = (lane < ni) ? (interval_rank[i0 + lane] - (int)v0) : -1;
+    int s = -1;
+    for (int k = 0; k < ni; ++k) {                    // wave-uniform trip count
+        const int r = __shfl(myrank, k, 64);
+        if (r == v) s = i0 + k;
+    }
+    if (active && s >= 0) {
+        float acc[4];
+        fbbev_interval_sum<4>(C, starts[s], lengths[s], depth, feat + quad * 4, rd, rf, acc);
+        val[0] = acc[0]; val[1] = acc[1]; val[2] = acc[2]; val[3] = acc[3];
+    }
+    if (active) fbbev_store4<ST>(dst, val);
 }

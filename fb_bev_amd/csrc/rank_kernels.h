@@ -9,8 +9,8 @@
 //   (stable radix sort of (key, point id) pairs, sort_kernels.h; its first pass drops the
 //    sentinel keys and publishes P, the number of kept points, on the device)
 //   k_flag_count       : per-block count of run heads
-//   k_scan_blocks      : exclusive scan of the block counts + I (number of intervals)
-//   k_write_intervals  : run heads -> interval_starts (block scan = wave prefix sums), ranks_feat
+//   k_write_intervals  : prefix of the block counts + run heads -> interval_starts (wave prefix sums),
+//                        ranks_feat, I (number of intervals)
 //   k_interval_lengths : starts -> lengths
 #pragma once
 #include "rt.h"
@@ -29,31 +29,35 @@ struct fbbev_grid_params {
 // view_transformer.py:570-589.  Every operation is a single correctly-rounded fp32 op (no fma
 // contraction, IEEE divide): the rank must be the SAME float the reference computes, because it
 // is the sort key and, above 2^24, decides which voxels collide.
+__device__ __forceinline__ unsigned int fbbev_rank_key(float cx, float cy, float cz, const fbbev_grid_params& gp,
+                                                       float bf, unsigned int sentinel) {
+    const float fx = __fdiv_rn(__fsub_rn(cx, gp.lx), gp.ix);
+    const float fy = __fdiv_rn(__fsub_rn(cy, gp.ly), gp.iy);
+    const float fz = __fdiv_rn(__fsub_rn(cz, gp.lz), gp.iz);
+    // .long(): truncation toward zero.  |f| >= 2^31 or NaN can never be inside the grid.
+    const bool finite = (fx == fx) && (fy == fy) && (fz == fz) && fabsf(fx) < 2.0e9f &&
+                        fabsf(fy) < 2.0e9f && fabsf(fz) < 2.0e9f;
+    const int vx = finite ? (int)fx : -1;
+    const int vy = finite ? (int)fy : -1;
+    const int vz = finite ? (int)fz : -1;
+    // kept: integer >= 0 and (float)v < grid_size (long vs 0-dim fp32 tensor compares in fp32)
+    const bool kept = finite && vx >= 0 && vy >= 0 && vz >= 0 && (float)vx < gp.gx &&
+                      (float)vy < gp.gy && (float)vz < gp.gz;
+    float r = __fmul_rn(bf, gp.f_zyx);
+    r = __fadd_rn(r, __fmul_rn((float)vz, gp.f_yx));
+    const float t = __fadd_rn(__fmul_rn((float)vy, gp.gx), (float)vx);
+    r = __fadd_rn(r, t);
+    return kept ? (unsigned int)(int)r : sentinel;
+}
+
 __global__ void __launch_bounds__(256)
 k_rank_keys(const float* __restrict__ coor, long long npts, long long pts_per_batch,
             fbbev_grid_params gp, unsigned int sentinel, unsigned int* __restrict__ keys,
             unsigned int* __restrict__ vals) {
     for (long long pid = (long long)blockIdx.x * blockDim.x + threadIdx.x; pid < npts;
          pid += (long long)gridDim.x * blockDim.x) {
-        const float cx = coor[3 * pid], cy = coor[3 * pid + 1], cz = coor[3 * pid + 2];
-        const float fx = __fdiv_rn(__fsub_rn(cx, gp.lx), gp.ix);
-        const float fy = __fdiv_rn(__fsub_rn(cy, gp.ly), gp.iy);
-        const float fz = __fdiv_rn(__fsub_rn(cz, gp.lz), gp.iz);
-        // .long(): truncation toward zero.  |f| >= 2^31 or NaN can never be inside the grid.
-        const bool finite = (fx == fx) && (fy == fy) && (fz == fz) && fabsf(fx) < 2.0e9f &&
-                            fabsf(fy) < 2.0e9f && fabsf(fz) < 2.0e9f;
-        const int vx = finite ? (int)fx : -1;
-        const int vy = finite ? (int)fy : -1;
-        const int vz = finite ? (int)fz : -1;
-        // kept: integer >= 0 and (float)v < grid_size (long vs 0-dim fp32 tensor compares in fp32)
-        const bool kept = finite && vx >= 0 && vy >= 0 && vz >= 0 && (float)vx < gp.gx &&
-                          (float)vy < gp.gy && (float)vz < gp.gz;
-        const float bf = (float)(pid / pts_per_batch);
-        float r = __fmul_rn(bf, gp.f_zyx);
-        r = __fadd_rn(r, __fmul_rn((float)vz, gp.f_yx));
-        const float t = __fadd_rn(__fmul_rn((float)vy, gp.gx), (float)vx);
-        r = __fadd_rn(r, t);
-        keys[pid] = kept ? (unsigned int)(int)r : sentinel;
+        keys[pid] = fbbev_rank_key(coor[3 * pid], coor[3 * pid + 1], coor[3 * pid + 2], gp,
+                                   (float)(pid / pts_per_batch), sentinel);
         vals[pid] = (unsigned int)pid;
     }
 }
@@ -107,29 +111,19 @@ k_flag_count(const unsigned int* __restrict__ keys, const int* __restrict__ coun
     if (threadIdx.x == 0) block_counts[blockIdx.x] = total;
 }
 
-// single block: exclusive scan of block_counts[0..nblocks) in place; counts[1] = I.
-__global__ void __launch_bounds__(FBBEV_RANK_BLOCK)
-k_scan_blocks(int* __restrict__ block_counts, int nblocks, int* __restrict__ counts) {
-    __shared__ int lds4[4];
-    int running = 0;
-    for (int base = 0; base < nblocks; base += FBBEV_RANK_BLOCK) {
-        const int i = base + threadIdx.x;
-        const int v = (i < nblocks) ? block_counts[i] : 0;
-        int total;
-        const int ex = fbbev_block_excl_scan(v, lds4, &total);
-        if (i < nblocks) block_counts[i] = running + ex;
-        running += total;
-    }
-    if (threadIdx.x == 0) counts[1] = running;
-}
-
 __global__ void __launch_bounds__(FBBEV_RANK_BLOCK)
 k_write_intervals(const unsigned int* __restrict__ keys, const unsigned int* __restrict__ vals,
-                  const int* __restrict__ counts, const int* __restrict__ block_offsets,
+                  int* __restrict__ counts, const int* __restrict__ block_counts, int nblocks,
                   int D, int HW, int* __restrict__ ranks_feat, int* __restrict__ interval_starts,
                   int* __restrict__ interval_rank) {
     __shared__ int lds4[4];
     const long long n = counts[0];
+    // exclusive prefix of the per-block head counts: every block sums the counts of the blocks before it
+    // (<= 16 KiB of L2-resident ints) -- cheaper than a separate single-block scan launch on the critical path
+    int part = 0;
+    for (int j = threadIdx.x; j < (int)blockIdx.x; j += FBBEV_RANK_BLOCK) part += block_counts[j];
+    int block_offset;
+    (void)fbbev_block_excl_scan(part, lds4, &block_offset);
     const long long base = (long long)blockIdx.x * FBBEV_RANK_CHUNK + threadIdx.x * FBBEV_RANK_ITEMS;
     bool head[FBBEV_RANK_ITEMS];
     unsigned int key[FBBEV_RANK_ITEMS];
@@ -151,7 +145,8 @@ k_write_intervals(const unsigned int* __restrict__ keys, const unsigned int* __r
         }
     }
     int total;
-    int j0 = block_offsets[blockIdx.x] + fbbev_block_excl_scan(local, lds4, &total);
+    int j0 = block_offset + fbbev_block_excl_scan(local, lds4, &total);
+    if (blockIdx.x == (unsigned)(nblocks - 1) && threadIdx.x == 0) counts[1] = block_offset + total;   // I
 #pragma unroll
     for (int j = 0; j < FBBEV_RANK_ITEMS; ++j) {
         if (head[j]) {

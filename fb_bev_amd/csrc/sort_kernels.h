@@ -16,6 +16,8 @@
 //                    = input order, so the sort is stable and the voxel order canonical.
 #pragma once
 #include "rt.h"
+#include "geom_kernels.h"
+#include "rank_kernels.h"
 
 #define FBBEV_SORT_WAVES 4
 #define FBBEV_SORT_ROUNDS 16
@@ -132,6 +134,110 @@ k_sort_scatter(const unsigned int* __restrict__ keys_in, const unsigned int* __r
             const int pos = woff[wave][d] + lr[r];
             keys_out[pos] = k[r];
             vals_out[pos] = v[r];
+        }
+    }
+}
+
+// ---------------------------------------------------------------- pass 1 with a fused geometry -> key source
+// Workgroup = (camera, 4096-point chunk of that camera's D*H*W frustum).  The keys are evaluated in registers
+// from the camera parameters (fbbev_point_coor + fbbev_rank_key: the same code the two-step contract path
+// runs), so `coor`, `keys` and `vals` are never materialised; out-of-grid points are dropped right here.
+struct fbbev_geom_src {
+    fbbev_cam_ptrs cam;
+    fbbev_grid_params gp;
+    unsigned int sentinel;
+    int chunks_per_cam;      // ceil(D*H*W / FBBEV_SORT_TILE)
+};
+
+__device__ __forceinline__ unsigned int fbbev_geom_key(const fbbev_geom_src& g, const float* m, int cam, int i) {
+    const int w = i % g.cam.W, h = (i / g.cam.W) % g.cam.H, d = i / (g.cam.W * g.cam.H);
+    float cx, cy, cz;
+    fbbev_point_coor(m, g.cam.xs[w], g.cam.ys[h], g.cam.ds[d], cx, cy, cz);
+    return fbbev_rank_key(cx, cy, cz, g.gp, (float)(cam / g.cam.N), g.sentinel);
+}
+
+template <int RB>
+__global__ void __launch_bounds__(256)
+k_sort_hist_geom(fbbev_geom_src g, int shift, int nblocks, int* __restrict__ hist, int* __restrict__ totals) {
+    constexpr int NB = 1 << RB;
+    __shared__ int cnt[NB];
+    __shared__ float m[33];
+    const int cam = blockIdx.x / g.chunks_per_cam, chunk = blockIdx.x - cam * g.chunks_per_cam;
+    if (threadIdx.x == 0) fbbev_cam_setup(g.cam, cam, m);
+    for (int d = threadIdx.x; d < NB; d += 256) cnt[d] = 0;
+    __syncthreads();
+    const int dhw = g.cam.D * g.cam.H * g.cam.W;
+    const int base = chunk * FBBEV_SORT_TILE;
+    for (int i = threadIdx.x; i < FBBEV_SORT_TILE; i += 256) {
+        const int idx = base + i;
+        if (idx < dhw) {
+            const unsigned int key = fbbev_geom_key(g, m, cam, idx);
+            if (key != g.sentinel) atomicAdd(&cnt[(key >> shift) & (NB - 1)], 1);
+        }
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < NB; d += 256) {
+        const int c = cnt[d];
+        hist[(long long)d * nblocks + blockIdx.x] = c;
+        if (c) atomicAdd(&totals[((blockIdx.x & (FBBEV_SORT_SHARDS - 1)) << RB) + d], c);
+    }
+}
+
+template <int RB>
+__global__ void __launch_bounds__(256)
+k_sort_scatter_geom(fbbev_geom_src g, int shift, int nblocks, const int* __restrict__ hist,
+                    unsigned int* __restrict__ keys_out, unsigned int* __restrict__ vals_out) {
+    constexpr int NB = 1 << RB;
+    __shared__ int cnt[FBBEV_SORT_WAVES][NB];
+    __shared__ int woff[FBBEV_SORT_WAVES][NB];
+    __shared__ float m[33];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int cam = blockIdx.x / g.chunks_per_cam, chunk = blockIdx.x - cam * g.chunks_per_cam;
+    if (tid == 0) fbbev_cam_setup(g.cam, cam, m);
+    for (int i = tid; i < FBBEV_SORT_WAVES * NB; i += 256) (&cnt[0][0])[i] = 0;
+    __syncthreads();
+    const int dhw = g.cam.D * g.cam.H * g.cam.W;
+    const int wbase = chunk * FBBEV_SORT_TILE + wave * (64 * FBBEV_SORT_ROUNDS);
+    unsigned int k[FBBEV_SORT_ROUNDS];
+    int lr[FBBEV_SORT_ROUNDS];
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int r = 0; r < FBBEV_SORT_ROUNDS; ++r) {
+        const int idx = wbase + r * 64 + lane;
+        k[r] = (idx < dhw) ? fbbev_geom_key(g, m, cam, idx) : g.sentinel;
+        const bool valid = k[r] != g.sentinel;
+        lr[r] = -1;
+        const unsigned int d = (k[r] >> shift) & (NB - 1);
+        unsigned long long mm = __ballot(valid ? 1 : 0);
+#pragma unroll
+        for (int bit = 0; bit < RB; ++bit) {
+            const unsigned long long b = __ballot((int)((d >> bit) & 1u));
+            mm &= ((d >> bit) & 1u) ? b : ~b;
+        }
+        const int leader = valid ? (__ffsll((long long)mm) - 1) : lane;
+        int prev = 0;
+        if (valid && lane == leader) {
+            prev = cnt[wave][d];
+            cnt[wave][d] = prev + __popcll(mm);
+        }
+        prev = __shfl(prev, leader, 64);
+        if (valid) lr[r] = prev + __popcll(mm & lt);
+    }
+    __syncthreads();
+    for (int d = tid; d < NB; d += 256) {
+        int run = hist[(long long)d * nblocks + blockIdx.x];
+#pragma unroll
+        for (int w = 0; w < FBBEV_SORT_WAVES; ++w) { woff[w][d] = run; run += cnt[w][d]; }
+    }
+    __syncthreads();
+    const long long pid0 = (long long)cam * dhw;
+#pragma unroll
+    for (int r = 0; r < FBBEV_SORT_ROUNDS; ++r) {
+        if (lr[r] >= 0) {
+            const unsigned int d = (k[r] >> shift) & (NB - 1);
+            const int pos = woff[wave][d] + lr[r];
+            keys_out[pos] = k[r];
+            vals_out[pos] = (unsigned int)(pid0 + wbase + r * 64 + lane);   // point id ((b*N+n)*D+d)*HW+hw
         }
     }
 }

@@ -7,9 +7,9 @@ entry builds this class unchanged.
 Two execution paths over the same HIP kernels:
   * reference-shaped : get_lidar_coor -> voxel_pooling_prepare_v2 (exact-size index tensors, one
     host sync to read the two counts) -> bev_pool_v2 (autograd op)           [parity surface]
-  * fused (default)  : fbbev_lidar_coor -> fbbev_rank_build -> fbbev_bev_pool_v2_dense_fwd, all
-    enqueued on the current stream with device-side counts: no host sync, no new_zeros, no
-    permute().contiguous()                                                    [bench surface]
+  * fused (default)  : fbbev_lift_rank_build (geometry evaluated inside the sort's first pass, no coor
+    tensor) -> fbbev_pool_tile_index -> fbbev_bev_pool_v2_dense_fwd, all enqueued on the current stream
+    with device-side counts: no host sync, no new_zeros, no permute().contiguous()   [bench surface]
 Both produce the same bits: the pooled sums are the same in-order fmaf chains.
 """
 import torch
@@ -178,6 +178,23 @@ class LSSViewTransformerFunction3D(nn.Module):
                          self._cache[key])
         return idx
 
+    def build_index_from_cams(self, rots, trans, cam2imgs, post_rots, post_trans, bda):
+        """get_lidar_coor + voxel_pooling_prepare_v2 fused (fbbev_lift_rank_build): the keys are evaluated from
+        the camera parameters inside the sort's first pass; same index tensors as build_index(get_lidar_coor())."""
+        B, N, _ = trans.shape
+        xs, ys, ds = self._axes(trans.device)
+        n = B * N * ds.numel() * ys.numel() * xs.numel()
+        key = ('rank_ws', trans.device, n)
+        if key not in self._cache:
+            self._cache[key] = torch.empty(_capi.rank_workspace_bytes(n), dtype=torch.uint8, device=trans.device)
+        idx = _IndexSet(n, trans.device)
+        lo, it, gs = self._grid3()
+        f = lambda t: t.contiguous().float()  # noqa: E731
+        _capi.lift_rank_build(xs, ys, ds, f(rots), f(trans), f(cam2imgs), f(post_rots), f(post_trans), f(bda), lo, it,
+                              gs, idx.ranks_bev, idx.ranks_depth, idx.ranks_feat, idx.interval_starts,
+                              idx.interval_lengths, idx.interval_rank, idx.counts, self._cache[key])
+        return idx
+
     def voxel_pooling_prepare_v2(self, coor):
         """view_transformer.py:547-605 -> (ranks_bev, ranks_depth, ranks_feat, interval_starts,
         interval_lengths), exact sizes, int32; None x5 when no point falls inside the grid."""
@@ -236,7 +253,7 @@ class LSSViewTransformerFunction3D(nn.Module):
         if self.accelerate and self._index_cache is not None:
             idx = self._index_cache
         else:
-            idx = self.build_index(self.get_lidar_coor(*cam_params))
+            idx = self.build_index_from_cams(*cam_params)
         return self.lift_splat(idx, depth, tran_feat)
 
     def view_transform(self, cam_params, depth, tran_feat):

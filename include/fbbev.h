@@ -34,6 +34,9 @@ typedef void* fbbev_stream_t; /* hipStream_t */
 #define FBBEV_POOL_WG_SHIFT 8       /* bits 8-9: workgroup size 0 -> 256, 1 -> 128 threads */
 #define FBBEV_POOL_XCD_SWIZZLE 0x400 /* deal chunks of consecutive tiles round-robin to the 8 XCDs */
 #define FBBEV_POOL_STORE_HI_SHIFT 17 /* bit 17: third bit of the store policy (experimental policies 4-7) */
+#define FBBEV_POOL_DIAG_NO_META 0x40000 /* DIAGNOSTIC: write zeros without reading tile metadata (wrong output) */
+#define FBBEV_POOL_CHANNEL_MAJOR 0x80000 /* workgroup order: channel group outermost (fewer planes written at once) */
+#define FBBEV_POOL_CHANNELS_LAST 0x100000 /* out is (B,Z,Y,X,C) -- the reference op's own layout -- written densely */
 #define FBBEV_POOL_SWZ_CHUNK_SHIFT 12 /* bits 12-16: log2(tiles per chunk) for the swizzle, 0 = default */
 
 int fbbev_version(void);
@@ -98,6 +101,18 @@ int fbbev_rank_build(const float* coor, int B, int N, int D, int H, int W, const
                      int32_t* interval_lengths, int32_t* interval_rank, int32_t* counts,
                      void* workspace, size_t workspace_bytes, fbbev_stream_t stream);
 
+/* get_lidar_coor + voxel_pooling_prepare_v2 in one call (view_transformer.py:458-498 + :547-605): the
+ * keys are evaluated from the camera parameters inside the sort's first pass -- the same per-point
+ * arithmetic as fbbev_lidar_coor followed by fbbev_rank_build, hence the same index tensors -- and
+ * `coor` is never materialised.  Arguments as in those two functions. */
+int fbbev_lift_rank_build(const float* xs, const float* ys, const float* ds, const float* rots,
+                          const float* trans, const float* intrins, const float* post_rots,
+                          const float* post_trans, const float* bda, int B, int N, int D, int H, int W,
+                          const float* lower3, const float* interval3, const float* grid_size3,
+                          int32_t* ranks_bev, int32_t* ranks_depth, int32_t* ranks_feat,
+                          int32_t* interval_starts, int32_t* interval_lengths, int32_t* interval_rank,
+                          int32_t* counts, void* workspace, size_t workspace_bytes, fbbev_stream_t stream);
+
 /* Fused replacement of  feat.new_zeros + bev_pool_v2_forward + permute(0,4,1,2,3).contiguous()
  *   -- bev_pool.py:24-35,88.  Two launches:
  * fbbev_pool_tile_index: for every tile of `tile_voxels` (64..1024) consecutive voxels of a (b,z)
@@ -108,16 +123,26 @@ int fbbev_rank_build(const float* coor, int B, int N, int D, int H, int W, const
  *   fbbev_bev_pool_v2_fwd => identical bits.  interval_rank[i] = ranks_bev[interval_starts[i]].
  *   Requires C % 4 == 0, (Y*X) % 4 == 0, 16-byte aligned feat/out (else FBBEV_E_UNSUPPORTED; callers
  *   fall back to fbbev_bev_pool_v2_fwd).
+ *   out_stride_b / out_stride_c: element strides of the batch and channel dimensions of `out`
+ *   (0 = contiguous); the (Z,Y,X) block of one channel is always contiguous.
+ *   With FBBEV_POOL_CHANNELS_LAST (pass the same flag to fbbev_pool_tile_index) `out` is instead the
+ *   reference op's own (B,Z,Y,X,C) layout (bev_pool.py:24), every row written once: the whole launch is
+ *   one linear store stream; callers take out.permute(0,4,1,2,3) as a view instead of copying (:88).
+ *   Channels-last tile_voxels of 8/16/32 select the "one 16-byte store per thread" kernel (a workgroup
+ *   writes tile_voxels*C*4 contiguous bytes, e.g. 5 KiB at C=80) -- the shape that reaches the HBM write
+ *   ceiling on MI355X.
  * tile_ws: fbbev_pool_dense_workspace_bytes(B,Z,Y,X) bytes, shared by the two calls. */
 size_t fbbev_pool_dense_workspace_bytes(int B, int Z, int Y, int X);
 int fbbev_pool_tile_index(const int32_t* interval_rank, const int32_t* interval_starts,
                           const int32_t* counts, int n_intervals_max, int B, int Z, int Y, int X,
-                          int tile_voxels, void* tile_ws, size_t tile_ws_bytes, fbbev_stream_t stream);
+                          int tile_voxels, int flags, void* tile_ws, size_t tile_ws_bytes,
+                          fbbev_stream_t stream);
 int fbbev_bev_pool_v2_dense_fwd(const float* depth, const float* feat, const int32_t* ranks_depth,
                                 const int32_t* ranks_feat, const int32_t* interval_rank,
                                 const int32_t* interval_starts, const int32_t* interval_lengths, int B,
-                                int C, int Z, int Y, int X, float* out_bczyx, const void* tile_ws,
-                                size_t tile_ws_bytes, int tile_voxels, int flags, fbbev_stream_t stream);
+                                int C, int Z, int Y, int X, float* out_bczyx, long long out_stride_b,
+                                long long out_stride_c, const void* tile_ws, size_t tile_ws_bytes,
+                                int tile_voxels, int flags, fbbev_stream_t stream);
 
 /* ----------------------------------------------------------------------------------------------
  * Boundary 2: mmcv._ext.ms_deform_attn_{forward,backward} (mmcv-full 1.5.2, external to the tree)

@@ -60,11 +60,12 @@ def pool_bwd(out_grad, depth_grad, feat_grad, depth, feat, rd, rf, rb, st, ln):
 
 
 def pool_dense(depth, feat, rd, rf, ir, st, ln, counts, n_max, B, C, Z, Y, X, tile_voxels, flags=0):
-    out = torch.full((B, C, Z, Y, X), float('nan'))
+    cl = bool(flags & 0x100000)
+    out = torch.full((B, Z, Y, X, C) if cl else (B, C, Z, Y, X), float('nan'))
     ws = torch.zeros(lib().fbbev_pool_dense_workspace_bytes(B, Z, Y, X), dtype=torch.uint8)
-    ok(lib().fbbev_pool_tile_index(p(ir), p(st), p(counts), n_max, B, Z, Y, X, tile_voxels, p(ws), ws.numel(), None))
+    ok(lib().fbbev_pool_tile_index(p(ir), p(st), p(counts), n_max, B, Z, Y, X, tile_voxels, flags, p(ws), ws.numel(), None))
     code = lib().fbbev_bev_pool_v2_dense_fwd(p(depth), p(feat), p(rd), p(rf), p(ir), p(st), p(ln),
-                                             B, C, Z, Y, X, p(out), p(ws), ws.numel(), tile_voxels, flags, None)
+                                             B, C, Z, Y, X, p(out), 0, 0, p(ws), ws.numel(), tile_voxels, flags, None)
     return code, out
 
 
@@ -117,3 +118,21 @@ def point_sampling(xs, ys, zs, cam, ogfH, ogfW):
                                   p(bda), B, N, ys.numel(), xs.numel(), Za, float(ogfH), float(ogfW), p(ref_cam), p(mask),
                                   p(qd), None))
     return ref_cam, mask.bool(), qd
+
+
+def lift_rank_build(xs, ys, ds, cam, lower3, interval3, grid_size3):
+    rots, trans, intrins, post_rots, post_trans, bda = cam
+    B, N = trans.shape[:2]
+    D, H, W = ds.numel(), ys.numel(), xs.numel()
+    n = B * N * D * H * W
+    rb, rd, rf = (torch.full((n,), -7, dtype=torch.int32) for _ in range(3))
+    st, ln, ir = (torch.full((n,), -7, dtype=torch.int32) for _ in range(3))
+    counts = torch.full((2,), -1, dtype=torch.int32)
+    ws = torch.zeros(lib().fbbev_rank_workspace_bytes(n), dtype=torch.uint8)
+    arr = ctypes.c_float * 3
+    lo, it, gs = arr(*lower3), arr(*interval3), arr(*grid_size3)
+    ok(lib().fbbev_lift_rank_build(p(xs), p(ys), p(ds), p(rots), p(trans), p(intrins), p(post_rots), p(post_trans), p(bda),
+                                   B, N, D, H, W, ctypes.cast(lo, c_void_p), ctypes.cast(it, c_void_p),
+                                   ctypes.cast(gs, c_void_p), p(rb), p(rd), p(rf), p(st), p(ln), p(ir), p(counts), p(ws),
+                                   ws.numel(), None))
+    return rb, rd, rf, st, ln, ir, counts

@@ -213,3 +213,34 @@ def test_point_sampling_emulated():
     vis = exp_mask & same
     assert torch.allclose(ref[vis], exp_ref[vis], atol=2e-5)
     assert torch.allclose(qd[vis], exp_d.squeeze(-1)[vis], atol=2e-4, rtol=1e-5)
+
+
+@pytest.mark.parametrize('tv,flags', [(64, 0x100000), (128, 0x100004), (256, 0x104405), (1024, 0x100001), (16, 0x120000),
+                                      (8, 0x100400), (32, 0x102401)])
+def test_pool_dense_channels_last_matches_oracle(tv, flags):
+    """(B,Z,Y,X,C) dense output == the reference op's layout with every row written once."""
+    for name, B in (('TINY', 2), ('SMALL', 1)):
+        cfg, vt, coor, depth, feat = _case(name, B)
+        rb, rd, rf, st, ln, ir, counts = E.rank_build(coor, *_grid3(vt))
+        Bz, Z, Y, X, C = vt.bev_feat_shape(B, cfg.channels)
+        code, out = E.pool_dense(depth, feat, rd, rf, ir, st, ln, counts, st.numel(), B, C, Z, Y, X, tv, flags)
+        assert code == 0 and not torch.isnan(out).any()
+        erb, erd, erf, est, eln = vt.voxel_pooling_prepare_v2(coor)
+        exp = O.bev_pool_v2_fwd(depth, feat, erd, erf, erb, (B, Z, Y, X, C), est, eln, use_fma=True)
+        assert torch.equal(out, exp)
+
+
+@pytest.mark.parametrize('name,B', [('TINY', 2), ('SMALL', 1)])
+def test_fused_geometry_rank_build_equals_two_step(name, B):
+    """fbbev_lift_rank_build (keys evaluated inside the sort's first pass) == fbbev_lidar_coor + fbbev_rank_build."""
+    cfg = S.CONFIGS[name]
+    vt = O.ViewTransformerOracle(cfg.grid_config, cfg.input_size, cfg.downsample)
+    cam = S.camera_rig(cfg, B, seed=0, bda_aug=True)
+    xs = vt.frustum[0, 0, :, 0].contiguous(); ys = vt.frustum[0, :, 0, 1].contiguous(); ds = vt.frustum[:, 0, 0, 2].contiguous()
+    coor = E.lidar_coor(xs, ys, ds, cam)
+    two = E.rank_build(coor, *_grid3(vt))
+    one = E.lift_rank_build(xs, ys, ds, cam, *_grid3(vt))
+    P, I = two[6].tolist()
+    assert one[6].tolist() == [P, I] and P > 0
+    for a, b, n in zip(one[:6], two[:6], (P, P, P, I, I, I)):
+        assert torch.equal(a[:n], b[:n])

@@ -93,6 +93,22 @@ def test_rank_build_full_size_bit_exact(dev, name, B, aug):
                                                                        stats[tag]['len_max'])
 
 
+@pytest.mark.parametrize('name,B', [('SMALL', 2), ('REF', 2), ('BL2', 3), ('BL5', 1)])
+def test_fused_geometry_rank_build_equals_two_step(dev, name, B):
+    """fbbev_lift_rank_build == fbbev_lidar_coor + fbbev_rank_build, bit for bit, and == the oracle on the same coor."""
+    cfg, ovt, cam, _, _, _ = _inputs(name, B, True, dev)
+    vt = _vt(cfg, dev)
+    cam_g = [t.to(dev) for t in cam]
+    coor = vt.get_lidar_coor(*cam_g)
+    two = vt.build_index(coor).exact()
+    one = vt.build_index_from_cams(*cam_g).exact()
+    for a, b in zip(one, two):
+        assert torch.equal(a, b)
+    exp = ovt.voxel_pooling_prepare_v2(coor.cpu())
+    for a, e in zip(one, exp):
+        assert torch.equal(a.cpu(), e)
+
+
 def test_rank_build_edge_cases(dev):
     cfg = S.CONFIGS['TINY']
     O = _oracle()
