@@ -124,7 +124,7 @@ def main():
 
     def step(i=None):
         idx = vt.build_index_from_cams(*cam)                        # fbbev_lift_rank_build: geometry + ranking, device counts
-        feat = ctx.permute(0, 1, 3, 4, 2).contiguous()              # (B,N,H,W,C), as bev_pool.py:18
+        feat = _capi.nchw_to_nhwc(ctx)                              # (B,N,H,W,C), the copy of bev_pool.py:18
         _capi.pool_tile_index(idx.interval_rank, idx.interval_starts, idx.counts, idx.n, B, Z, Y, X,
                               tile_ws, args.tile_voxels)
         if i is not None:

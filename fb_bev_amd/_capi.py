@@ -19,10 +19,11 @@ SIGNATURES = {
     'fbbev_bev_pool_v2_fwd': (c_int, [c_int, c_int] + [c_void_p] * 8 + [c_void_p]),
     'fbbev_bev_pool_v2_bwd': (c_int, [c_int, c_int] + [c_void_p] * 10 + [c_void_p]),
     'fbbev_lidar_coor': (c_int, [c_void_p] * 9 + [c_int] * 5 + [c_void_p, c_void_p]),
+    'fbbev_nchw_to_nhwc': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'fbbev_rank_workspace_bytes': (c_size_t, [c_int64]),
     'fbbev_rank_build': (c_int, [c_void_p] + [c_int] * 5 + [c_void_p] * 3 + [c_void_p] * 7 +
                          [c_void_p, c_size_t, c_void_p]),
-    'fbbev_lift_rank_build': (c_int, [c_void_p] * 9 + [c_int] * 5 + [c_void_p] * 3 + [c_void_p] * 7 +
+    'fbbev_lift_rank_build': (c_int, [c_void_p] * 10 + [c_int] * 5 + [c_void_p] * 3 + [c_void_p] * 7 +
                               [c_void_p, c_size_t, c_void_p]),
     'fbbev_pool_dense_workspace_bytes': (c_size_t, [c_int] * 4),
     'fbbev_pool_tile_index': (c_int, [c_void_p] * 3 + [c_int] * 7 + [c_void_p, c_size_t, c_void_p]),
@@ -152,7 +153,7 @@ def rank_build(coor, lower3, interval3, grid_size3, ranks_bev, ranks_depth, rank
 
 def lift_rank_build(xs, ys, ds, rots, trans, intrins, post_rots, post_trans, bda, lower3, interval3, grid_size3,
                     ranks_bev, ranks_depth, ranks_feat, interval_starts, interval_lengths, interval_rank, counts,
-                    workspace):
+                    workspace, frustum=None):
     """Geometry + ranking in one call (no coor tensor); arguments as lidar_coor + rank_build."""
     B, N = trans.shape[:2]
     D, H, W = ds.numel(), ys.numel(), xs.numel()
@@ -160,7 +161,7 @@ def lift_rank_build(xs, ys, ds, rots, trans, intrins, post_rots, post_trans, bda
     lo, it, gs = arr(*lower3), arr(*interval3), arr(*grid_size3)
     with _on(ranks_bev):
         _check(lib().fbbev_lift_rank_build(
-            _dev(xs, F32, 'xs'), _dev(ys, F32, 'ys'), _dev(ds, F32, 'ds'), _dev(rots, F32, 'rots'),
+            _dev(frustum, F32, 'frustum') if frustum is not None else c_void_p(0), _dev(xs, F32, 'xs'), _dev(ys, F32, 'ys'), _dev(ds, F32, 'ds'), _dev(rots, F32, 'rots'),
             _dev(trans, F32, 'trans'), _dev(intrins, F32, 'intrins'), _dev(post_rots, F32, 'post_rots'),
             _dev(post_trans, F32, 'post_trans'), _dev(bda, F32, 'bda'), B, N, D, H, W,
             ctypes.cast(lo, c_void_p), ctypes.cast(it, c_void_p), ctypes.cast(gs, c_void_p),
@@ -288,3 +289,13 @@ def point_sampling(xs, ys, zs, rots, trans, intrins, post_rots, post_trans, bda,
             _dev(post_trans, F32, 'post_trans'), _dev(bda, F32, 'bda'), B, N, ys.numel(), xs.numel(), zs.numel(),
             float(ogfH), float(ogfW), _dev(ref_cam, F32, 'ref_cam'), _dev(mask, torch.uint8, 'mask'),
             _dev(qdepth, F32, 'qdepth'), _stream()), 'fbbev_point_sampling')
+
+
+def nchw_to_nhwc(context):
+    """context (B,N,C,H,W) f32 contiguous -> feat (B,N,H,W,C) contiguous (LDS-tiled transpose kernel)."""
+    B, N, C, H, W = context.shape
+    feat = torch.empty((B, N, H, W, C), dtype=torch.float32, device=context.device)
+    with _on(context):
+        _check(lib().fbbev_nchw_to_nhwc(_dev(context, F32, 'context'), _dev(feat, F32, 'feat'), B * N, C, H * W,
+                                        _stream()), 'fbbev_nchw_to_nhwc')
+    return feat

@@ -93,6 +93,18 @@ extern "C" int fbbev_lidar_coor(const float* xs, const float* ys, const float* d
     return 0;
 }
 
+extern "C" int fbbev_nchw_to_nhwc(const float* in, float* out, int n_images, int C, int HW, fbbev_stream_t stream_) {
+    if (n_images < 0 || C <= 0 || HW <= 0) return FBBEV_E_BADARG;
+    if (n_images == 0) return 0;
+    if (!in || !out) return FBBEV_E_BADARG;
+    const int tc = (C + 31) / 32, th = (HW + 31) / 32;
+    const long long blocks = (long long)n_images * tc * th;
+    if (blocks >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
+    FBBEV_LAUNCH(k_nchw_to_nhwc, blocks, 256, 0, (fbbev_rt_stream)stream_, in, out, C, HW, tc, th);
+    FBBEV_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int fbbev_point_sampling(const float* xs, const float* ys, const float* zs, const float* rots,
                                     const float* trans, const float* intrins, const float* post_rots,
                                     const float* post_trans, const float* bda, int B, int N, int Y, int X,
@@ -134,7 +146,7 @@ static rank_ws_layout rank_layout(long long n) {
     L.vals_tmp = off; off = align_up(off + (size_t)n * 4, 256);
     L.block_counts = off; off = align_up(off + (size_t)(L.n_blocks + 1) * 4, 256);
     L.hist = off; off = align_up(off + ((size_t)(L.sort_blocks + 64) * 2 << FBBEV_SORT_MAX_RB) * 4, 256);  // also covers the per-camera tiling
-    L.totals = off; off = align_up(off + ((size_t)4 * FBBEV_SORT_SHARDS << FBBEV_SORT_MAX_RB) * 4, 256);   // [pass][shard][digit]
+    L.totals = off; off = align_up(off + ((size_t)4 << FBBEV_SORT_MAX_RB) * 4, 256);   // [pass][digit]
     L.total = off;
     return L;
 }
@@ -144,21 +156,28 @@ template <int RB>
 static int sort_pass(const unsigned int* kin, const unsigned int* vin, unsigned int* kout, unsigned int* vout,
                      long long n_host, const int* n_dev, int shift, int nblocks, unsigned int drop_key, int drop,
                      int* hist, int* totals, int* n_out, fbbev_rt_stream stream) {
-    FBBEV_LAUNCH(k_sort_hist<RB>, nblocks, 256, 0, stream, kin, n_host, n_dev, shift, nblocks, drop_key, drop, hist, totals);
+    FBBEV_LAUNCH(k_sort_hist<RB>, nblocks, 256, 0, stream, kin, n_host, n_dev, shift, nblocks, drop_key, drop, hist);
+    FBBEV_LAUNCH(k_sort_rowsum, 1 << RB, 256, 0, stream, (const int*)hist, nblocks, totals);
     FBBEV_LAUNCH(k_sort_scan, 1 << RB, 256, 0, stream, hist, (const int*)totals, nblocks, n_out);
-    FBBEV_LAUNCH(k_sort_scatter<RB>, nblocks, 256, 0, stream, kin, vin, n_host, n_dev, shift, nblocks, drop_key, drop,
-                 (const int*)hist, kout, vout);
+    FBBEV_LAUNCH(k_sort_scatter<RB>, nblocks, 256, 0, stream, kin, vin, n_host, n_dev, n_host, nblocks, shift, nblocks,
+                 drop_key, drop, (const int*)hist, kout, vout);
     return fbbev_rt_last_error();
 }
 
 // Stable LSD radix sort of the low `bits` key bits.  Pass 0 drops keys == drop_key and writes the number
 // of kept pairs to *n_kept_dev; later passes read that device counter.  Result in (keys_out, vals_out).
 template <int RB>
-static int sort_pass_geom(const fbbev_geom_src& g, unsigned int* kout, unsigned int* vout, int nblocks, int* hist,
-                          int* totals, int* n_out, fbbev_rt_stream stream) {
-    FBBEV_LAUNCH(k_sort_hist_geom<RB>, nblocks, 256, 0, stream, g, 0, nblocks, hist, totals);
+static int sort_pass_geom(const fbbev_geom_src& g, unsigned int* keys_scratch, long long n, unsigned int* kout,
+                          unsigned int* vout, int nblocks, int* hist, int* totals, int* n_out,
+                          fbbev_rt_stream stream) {
+    const long long dhw = (long long)g.cam.D * g.cam.H * g.cam.W;
+    FBBEV_LAUNCH(k_sort_hist_geom<RB>, nblocks, 256, 0, stream, g, 0, nblocks, hist, keys_scratch);
+    FBBEV_LAUNCH(k_sort_rowsum, 1 << RB, 256, 0, stream, (const int*)hist, nblocks, totals);
     FBBEV_LAUNCH(k_sort_scan, 1 << RB, 256, 0, stream, hist, (const int*)totals, nblocks, n_out);
-    FBBEV_LAUNCH(k_sort_scatter_geom<RB>, nblocks, 256, 0, stream, g, 0, nblocks, (const int*)hist, kout, vout);
+    // same per-camera tiling; values are the key positions = point ids ((b*N+n)*D+d)*HW+hw
+    FBBEV_LAUNCH(k_sort_scatter<RB>, nblocks, 256, 0, stream, (const unsigned int*)keys_scratch,
+                 (const unsigned int*)nullptr, n, (const int*)nullptr, dhw, g.chunks_per_cam, 0, nblocks, g.sentinel, 1,
+                 (const int*)hist, kout, vout);
     return fbbev_rt_last_error();
 }
 
@@ -169,25 +188,24 @@ static int radix_sort_pairs(unsigned int* keys_a, unsigned int* vals_a, unsigned
                             fbbev_rt_stream stream, const fbbev_geom_src* geom = nullptr, int geom_blocks = 0) {
     const int passes = (bits + FBBEV_SORT_MAX_RB - 1) / FBBEV_SORT_MAX_RB;
     const int rb = (bits + passes - 1) / passes;      // digits as even as possible, <= 9 bits
-    int e = fbbev_rt_memset_async(totals, 0, ((size_t)passes * FBBEV_SORT_SHARDS << FBBEV_SORT_MAX_RB) * sizeof(int), stream);
-    if (e) return e;
+    int e = 0;
     const unsigned int* kin = keys_a; const unsigned int* vin = vals_a;
     for (int p = 0; p < passes; ++p) {
         const bool to_out = ((passes - 1 - p) % 2) == 0;   // last pass always writes the outputs
         unsigned int* ko = to_out ? keys_out : keys_t;
         unsigned int* vo = to_out ? vals_out : vals_t;
-        int* tot = totals + ((size_t)p * FBBEV_SORT_SHARDS << FBBEV_SORT_MAX_RB);
+        int* tot = totals + ((size_t)p << FBBEV_SORT_MAX_RB);
         const int shift = p * rb;
         const int* n_dev = (p == 0) ? nullptr : n_kept_dev;
         int* n_out = (p == 0) ? n_kept_dev : nullptr;
         const int drop = (p == 0) ? 1 : 0;
         if (p == 0 && geom) {
             switch (rb) {
-                case 9: e = sort_pass_geom<9>(*geom, ko, vo, geom_blocks, hist, tot, n_out, stream); break;
-                case 8: e = sort_pass_geom<8>(*geom, ko, vo, geom_blocks, hist, tot, n_out, stream); break;
-                case 7: e = sort_pass_geom<7>(*geom, ko, vo, geom_blocks, hist, tot, n_out, stream); break;
-                case 6: e = sort_pass_geom<6>(*geom, ko, vo, geom_blocks, hist, tot, n_out, stream); break;
-                default: e = sort_pass_geom<5>(*geom, ko, vo, geom_blocks, hist, tot, n_out, stream); break;
+                case 9: e = sort_pass_geom<9>(*geom, keys_a, n, ko, vo, geom_blocks, hist, tot, n_out, stream); break;
+                case 8: e = sort_pass_geom<8>(*geom, keys_a, n, ko, vo, geom_blocks, hist, tot, n_out, stream); break;
+                case 7: e = sort_pass_geom<7>(*geom, keys_a, n, ko, vo, geom_blocks, hist, tot, n_out, stream); break;
+                case 6: e = sort_pass_geom<6>(*geom, keys_a, n, ko, vo, geom_blocks, hist, tot, n_out, stream); break;
+                default: e = sort_pass_geom<5>(*geom, keys_a, n, ko, vo, geom_blocks, hist, tot, n_out, stream); break;
             }
             if (e) return e;
             kin = ko; vin = vo;
@@ -211,7 +229,8 @@ extern "C" size_t fbbev_rank_workspace_bytes(int64_t n_points) {
     return rank_layout(n_points).total;
 }
 
-static int rank_build_impl(const float* coor, const fbbev_cam_ptrs* cams, int B, int N, int D, int H, int W,
+static int rank_build_impl(const float* coor, const fbbev_cam_ptrs* cams, const float* frustum, int B, int N, int D,
+                           int H, int W,
                            const float* lower3, const float* interval3, const float* grid_size3,
                            int32_t* ranks_bev, int32_t* ranks_depth, int32_t* ranks_feat,
                            int32_t* interval_starts, int32_t* interval_lengths, int32_t* interval_rank,
@@ -247,7 +266,7 @@ static int rank_build_impl(const float* coor, const fbbev_cam_ptrs* cams, int B,
     fbbev_geom_src gs;
     int geom_blocks = 0;
     if (cams) {
-        gs.cam = *cams; gs.gp = gp; gs.sentinel = sentinel;
+        gs.cam = *cams; gs.frustum = frustum; gs.gp = gp; gs.sentinel = sentinel;
         const long long dhw = (long long)D * H * W;
         gs.chunks_per_cam = (int)((dhw + FBBEV_SORT_TILE - 1) / FBBEV_SORT_TILE);
         const long long gb = (long long)B * N * gs.chunks_per_cam;
@@ -287,12 +306,13 @@ extern "C" int fbbev_rank_build(const float* coor, int B, int N, int D, int H, i
                                 int32_t* interval_lengths, int32_t* interval_rank, int32_t* counts,
                                 void* workspace, size_t workspace_bytes, fbbev_stream_t stream_) {
     if (!coor) return FBBEV_E_BADARG;
-    return rank_build_impl(coor, nullptr, B, N, D, H, W, lower3, interval3, grid_size3, ranks_bev, ranks_depth,
+    return rank_build_impl(coor, nullptr, nullptr, B, N, D, H, W, lower3, interval3, grid_size3, ranks_bev, ranks_depth,
                            ranks_feat, interval_starts, interval_lengths, interval_rank, counts, workspace,
                            workspace_bytes, (fbbev_rt_stream)stream_);
 }
 
-extern "C" int fbbev_lift_rank_build(const float* xs, const float* ys, const float* ds, const float* rots,
+extern "C" int fbbev_lift_rank_build(const float* frustum, const float* xs, const float* ys, const float* ds,
+                                     const float* rots,
                                      const float* trans, const float* intrins, const float* post_rots,
                                      const float* post_trans, const float* bda, int B, int N, int D, int H,
                                      int W, const float* lower3, const float* interval3,
@@ -304,7 +324,7 @@ extern "C" int fbbev_lift_rank_build(const float* xs, const float* ys, const flo
     fbbev_cam_ptrs g;
     g.xs = xs; g.ys = ys; g.ds = ds; g.rots = rots; g.trans = trans; g.intrins = intrins; g.post_rots = post_rots;
     g.post_trans = post_trans; g.bda = bda; g.N = N; g.D = D; g.H = H; g.W = W;
-    return rank_build_impl(nullptr, &g, B, N, D, H, W, lower3, interval3, grid_size3, ranks_bev, ranks_depth,
+    return rank_build_impl(nullptr, &g, frustum, B, N, D, H, W, lower3, interval3, grid_size3, ranks_bev, ranks_depth,
                            ranks_feat, interval_starts, interval_lengths, interval_rank, counts, workspace,
                            workspace_bytes, (fbbev_rt_stream)stream_);
 }

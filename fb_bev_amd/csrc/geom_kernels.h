@@ -137,3 +137,29 @@ k_point_sampling(const float* __restrict__ xs, const float* __restrict__ ys, con
         qdepth[o] = uz;
     }
 }
+
+// ---------------------------------------------------------------- context (B*N,C,H*W) -> feat (B*N,H*W,C)
+// The depth net emits NCHW; bev_pool_v2 gathers channel rows, so the reference makes feat.permute(0,1,3,4,2)
+// contiguous inside the op (bev_pool.py:18, view_transformer.py:536).  LDS-tiled 32x32 transpose: both the
+// read (along H*W) and the write (along C) are coalesced.
+__global__ void __launch_bounds__(256)
+k_nchw_to_nhwc(const float* __restrict__ in, float* __restrict__ out, int C, int HW, int tiles_c, int tiles_hw) {
+    __shared__ float tile[32][33];
+    const int t = blockIdx.x;
+    const int img = t / (tiles_c * tiles_hw), r = t - img * (tiles_c * tiles_hw);
+    const int tc = r / tiles_hw, th = r - tc * tiles_hw;
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;           // 32 x 8
+    const float* src = in + (long long)img * C * HW;
+    float* dst = out + (long long)img * C * HW;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = tc * 32 + ly + 8 * k, p = th * 32 + lx;
+        tile[ly + 8 * k][lx] = (c < C && p < HW) ? src[(long long)c * HW + p] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int p = th * 32 + ly + 8 * k, c = tc * 32 + lx;
+        if (c < C && p < HW) dst[(long long)p * C + c] = tile[lx][ly + 8 * k];
+    }
+}

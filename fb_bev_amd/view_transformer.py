@@ -42,7 +42,7 @@ class _IndexSet:
         self.n = n
         self.ranks_bev, self.ranks_depth, self.ranks_feat = buf(), buf(), buf()
         self.interval_starts, self.interval_lengths, self.interval_rank = buf(), buf(), buf()
-        self.counts = torch.zeros(2, dtype=torch.int32, device=device)
+        self.counts = torch.empty(2, dtype=torch.int32, device=device)   # zeroed by the rank build itself
 
     def exact(self):
         """Trim to exact sizes (ONE host sync: reads the two counts)."""
@@ -58,7 +58,13 @@ class LiftSplat(torch.autograd.Function):
     @staticmethod
     def forward(ctx, depth, feat, idx, grid_zyx, tile_ws, tile_voxels, pool_flags):
         depth = depth.contiguous().float()
-        feat = feat.contiguous().float()
+        # `feat` arrives as the (B,N,H,W,C) permuted view of the NCHW context (view_transformer.py:536); when
+        # the underlying tensor is contiguous NCHW the copy is done by the LDS-tiled transpose kernel
+        base = feat.permute(0, 1, 4, 2, 3)
+        if base.is_contiguous() and base.dtype == torch.float32:
+            feat = _capi.nchw_to_nhwc(base)
+        else:
+            feat = feat.contiguous().float()
         B, C = depth.shape[0], feat.shape[-1]
         Z, Y, X = grid_zyx
         out = torch.empty((B, C, Z, Y, X), dtype=torch.float32, device=depth.device)
@@ -150,6 +156,12 @@ class LSSViewTransformerFunction3D(nn.Module):
             self._cache[key] = tuple(t.to(device).contiguous() for t in (self._xs, self._ys, self._ds))
         return self._cache[key]
 
+    def _frustum_dev(self, device):
+        key = ('frustum', device)
+        if key not in self._cache:
+            self._cache[key] = self.frustum.to(device).contiguous()
+        return self._cache[key]
+
     # ------------------------------------------------------------------ per-forward geometry
     def get_lidar_coor(self, rots, trans, cam2imgs, post_rots, post_trans, bda):
         """view_transformer.py:458-498 -> coor (B,N,D,H,W,3), one HIP kernel (fbbev_lidar_coor)."""
@@ -192,7 +204,8 @@ class LSSViewTransformerFunction3D(nn.Module):
         f = lambda t: t.contiguous().float()  # noqa: E731
         _capi.lift_rank_build(xs, ys, ds, f(rots), f(trans), f(cam2imgs), f(post_rots), f(post_trans), f(bda), lo, it,
                               gs, idx.ranks_bev, idx.ranks_depth, idx.ranks_feat, idx.interval_starts,
-                              idx.interval_lengths, idx.interval_rank, idx.counts, self._cache[key])
+                              idx.interval_lengths, idx.interval_rank, idx.counts, self._cache[key],
+                              frustum=self._frustum_dev(trans.device))
         return idx
 
     def voxel_pooling_prepare_v2(self, coor):

@@ -83,6 +83,10 @@ int fbbev_lidar_coor(const float* xs, const float* ys, const float* ds, const fl
                      const float* post_trans, const float* bda, int B, int N, int D, int H, int W,
                      float* coor, fbbev_stream_t stream);
 
+/* Replaces feat.permute(0,1,3,4,2) + .contiguous() (view_transformer.py:536, bev_pool.py:18):
+ * in (n_images, C, HW) -> out (n_images, HW, C), f32, LDS-tiled transpose. */
+int fbbev_nchw_to_nhwc(const float* in, float* out, int n_images, int C, int HW, fbbev_stream_t stream);
+
 /* Replaces LSSViewTransformerFunction3D.voxel_pooling_prepare_v2
  *   -- fbbev/view_transformation/forward_projection/view_transformer.py:547-605
  *   (~17 torch launches, an argsort and >=4 host syncs in the reference).
@@ -104,8 +108,11 @@ int fbbev_rank_build(const float* coor, int B, int N, int D, int H, int W, const
 /* get_lidar_coor + voxel_pooling_prepare_v2 in one call (view_transformer.py:458-498 + :547-605): the
  * keys are evaluated from the camera parameters inside the sort's first pass -- the same per-point
  * arithmetic as fbbev_lidar_coor followed by fbbev_rank_build, hence the same index tensors -- and
- * `coor` is never materialised.  Arguments as in those two functions. */
-int fbbev_lift_rank_build(const float* xs, const float* ys, const float* ds, const float* rots,
+ * `coor` is never materialised.  Arguments as in those two functions; `frustum` is the optional
+ * (D,H,W,3) template of create_frustum (view_transformer.py:389-411) -- when given, points are looked up
+ * in it instead of being decomposed with integer divisions (same values, it is stacked from xs/ys/ds). */
+int fbbev_lift_rank_build(const float* frustum, const float* xs, const float* ys, const float* ds,
+                          const float* rots,
                           const float* trans, const float* intrins, const float* post_rots,
                           const float* post_trans, const float* bda, int B, int N, int D, int H, int W,
                           const float* lower3, const float* interval3, const float* grid_size3,

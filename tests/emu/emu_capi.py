@@ -120,7 +120,7 @@ def point_sampling(xs, ys, zs, cam, ogfH, ogfW):
     return ref_cam, mask.bool(), qd
 
 
-def lift_rank_build(xs, ys, ds, cam, lower3, interval3, grid_size3):
+def lift_rank_build(xs, ys, ds, cam, lower3, interval3, grid_size3, frustum=None):
     rots, trans, intrins, post_rots, post_trans, bda = cam
     B, N = trans.shape[:2]
     D, H, W = ds.numel(), ys.numel(), xs.numel()
@@ -131,8 +131,15 @@ def lift_rank_build(xs, ys, ds, cam, lower3, interval3, grid_size3):
     ws = torch.zeros(lib().fbbev_rank_workspace_bytes(n), dtype=torch.uint8)
     arr = ctypes.c_float * 3
     lo, it, gs = arr(*lower3), arr(*interval3), arr(*grid_size3)
-    ok(lib().fbbev_lift_rank_build(p(xs), p(ys), p(ds), p(rots), p(trans), p(intrins), p(post_rots), p(post_trans), p(bda),
+    ok(lib().fbbev_lift_rank_build(p(frustum) if frustum is not None else c_void_p(0), p(xs), p(ys), p(ds), p(rots), p(trans), p(intrins), p(post_rots), p(post_trans), p(bda),
                                    B, N, D, H, W, ctypes.cast(lo, c_void_p), ctypes.cast(it, c_void_p),
                                    ctypes.cast(gs, c_void_p), p(rb), p(rd), p(rf), p(st), p(ln), p(ir), p(counts), p(ws),
                                    ws.numel(), None))
     return rb, rd, rf, st, ln, ir, counts
+
+
+def nchw_to_nhwc(x):
+    B, N, C, H, W = x.shape
+    out = torch.full((B, N, H, W, C), float('nan'))
+    ok(lib().fbbev_nchw_to_nhwc(p(x), p(out), B * N, C, H * W, None))
+    return out

@@ -239,8 +239,15 @@ def test_fused_geometry_rank_build_equals_two_step(name, B):
     xs = vt.frustum[0, 0, :, 0].contiguous(); ys = vt.frustum[0, :, 0, 1].contiguous(); ds = vt.frustum[:, 0, 0, 2].contiguous()
     coor = E.lidar_coor(xs, ys, ds, cam)
     two = E.rank_build(coor, *_grid3(vt))
-    one = E.lift_rank_build(xs, ys, ds, cam, *_grid3(vt))
     P, I = two[6].tolist()
-    assert one[6].tolist() == [P, I] and P > 0
-    for a, b, n in zip(one[:6], two[:6], (P, P, P, I, I, I)):
-        assert torch.equal(a[:n], b[:n])
+    for frustum in (None, vt.frustum.contiguous()):
+        one = E.lift_rank_build(xs, ys, ds, cam, *_grid3(vt), frustum=frustum)
+        assert one[6].tolist() == [P, I] and P > 0
+        for a, b, n in zip(one[:6], two[:6], (P, P, P, I, I, I)):
+            assert torch.equal(a[:n], b[:n])
+
+
+def test_nchw_to_nhwc_emulated():
+    for shape in ((2, 3, 8, 4, 6), (1, 2, 80, 5, 7), (1, 1, 33, 3, 11)):
+        x = torch.randn(shape, generator=torch.Generator().manual_seed(0))
+        assert torch.equal(E.nchw_to_nhwc(x), x.permute(0, 1, 3, 4, 2).contiguous())

@@ -140,6 +140,13 @@ def test_lidar_coor_close_to_oracle(dev):
         assert (got - coor).abs().max().item() < 5e-4   # metres (closed-form vs LU 3x3 inverse)
 
 
+def test_nchw_to_nhwc_kernel(dev):
+    from fb_bev_amd import _capi
+    for shape in ((2, 6, 80, 16, 44), (1, 6, 64, 64, 176), (3, 2, 33, 5, 7)):
+        x = torch.randn(shape, device=dev)
+        assert torch.equal(_capi.nchw_to_nhwc(x), x.permute(0, 1, 3, 4, 2).contiguous())
+
+
 # ------------------------------------------------------------------ pooling forward
 CASES = [('TINY', 2, True), ('SMALL', 2, True), ('REF', 1, False), ('BL2', 2, True), ('BL1', 1, False)]
 
