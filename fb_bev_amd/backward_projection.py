@@ -44,6 +44,18 @@ def build(cfg, **extra):
     return REGISTRY[typ](**cfg)
 
 
+_CONST = {}
+
+
+def const_tensor(values, device, dtype=torch.long):
+    """Small constant device tensors (spatial shapes, level starts) built once per (value, device): creating
+    them from Python lists on every forward is a pageable H2D copy, which also breaks hipGraph capture."""
+    key = (repr(values), str(device), dtype)
+    if key not in _CONST:
+        _CONST[key] = torch.as_tensor(values, dtype=dtype, device=device)
+    return _CONST[key]
+
+
 def inv3x3(m):
     """Closed-form inverse of (...,3,3) matrices (adjugate / determinant): no solver dependency."""
     a, b, c = m[..., 0, 0], m[..., 0, 1], m[..., 0, 2]
@@ -381,8 +393,8 @@ class BEVFormerEncoderLayer(nn.Module):
                 query = self.attentions[ai](
                     query, None, None, identity if self.pre_norm else None, query_pos=bev_pos, key_pos=bev_pos,
                     key_padding_mask=bev_mask, reference_points=ref_2d,
-                    spatial_shapes=torch.tensor([[bev_h, bev_w]], device=query.device),
-                    level_start_index=torch.tensor([0], device=query.device))
+                    spatial_shapes=const_tensor([[bev_h, bev_w]], query.device),
+                    level_start_index=const_tensor([0], query.device))
                 ai += 1
                 identity = query
             elif layer == 'norm':
@@ -519,8 +531,11 @@ class BEVFormer(nn.Module):
             shapes.append((h, w))
             feats.append(f)
         feat_flatten = torch.cat(feats, 2)
-        spatial_shapes = torch.as_tensor(shapes, dtype=torch.long, device=bev_pos.device)
-        level_start_index = torch.cat((spatial_shapes.new_zeros((1,)), spatial_shapes.prod(1).cumsum(0)[:-1]))
+        spatial_shapes = const_tensor(shapes, bev_pos.device)
+        starts = [0]
+        for h, w in shapes[:-1]:
+            starts.append(starts[-1] + h * w)
+        level_start_index = const_tensor(starts, bev_pos.device)
         feat_flatten = feat_flatten.permute(0, 2, 1, 3)                        # (num_cam, sum HW, bs, C)
         return self.encoder(bev_queries, feat_flatten, feat_flatten, bev_h=bev_h, bev_w=bev_w, bev_pos=bev_pos,
                             spatial_shapes=spatial_shapes, level_start_index=level_start_index, cam_params=cam_params,

@@ -36,8 +36,24 @@ def main():
             b = fp(cam, ctx, depth)
         torch.cuda.synchronize()
         dt_f = (time.perf_counter() - t0) / steps
+        # the same two scopes replayed from captured hipGraphs (no host launch overhead)
+        res = {}
+        for tag, fn in (('fb', lambda: m(cam, ctx, depth)), ('forward_only', lambda: fp(cam, ctx, depth))):
+            g = torch.cuda.CUDAGraph()
+            st = torch.cuda.Stream(); st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                fn()
+            torch.cuda.current_stream().wait_stream(st)
+            with torch.cuda.graph(g):
+                o = fn()
+            g.replay(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                g.replay()
+            torch.cuda.synchronize()
+            res['ms_' + tag + '_graph'] = (time.perf_counter() - t0) / steps * 1e3
     print(json.dumps({'config': name, 'B': B, 'bev': [Y, X], 'out': list(out.shape), 'ms_fb': dt * 1e3, 'ms_forward_only': dt_f * 1e3,
-                      'samples_per_s_fb': B / dt}))
+                      'samples_per_s_fb': B / dt, **res, 'samples_per_s_fb_graph': B / (res['ms_fb_graph'] * 1e-3)}))
 
 if __name__ == '__main__':
     main()
