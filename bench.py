@@ -38,7 +38,7 @@ def parse():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=16, help='samples per GPU per step (weak scaling)')
     ap.add_argument('--config', default='BL2')
-    ap.add_argument('--tile-voxels', type=int, default=128)
+    ap.add_argument('--tile-voxels', type=int, default=None, help='default: chosen by grid density')
     ap.add_argument('--pool-flags', type=lambda x: int(x, 0), default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
@@ -113,11 +113,12 @@ def main():
     depth, ctx = S.depth_and_context(cfg, B, seed=shard.shard_seed(rank))
     depth, ctx = depth.to(dev), ctx.to(dev)
     vt = LSSViewTransformerFunction3D(cfg.grid_config, cfg.input_size, cfg.downsample,
-                                      tile_voxels=args.tile_voxels).to(dev)
+                                      tile_voxels=args.tile_voxels, pool_flags=args.pool_flags).to(dev)
+    args.tile_voxels = vt.tile_voxels
     Z, Y, X = vt.grid_zyx
     C = cfg.channels
     tile_ws = vt._tile_ws(dev, B)
-    flags = _capi.DEFAULT_POOL_FLAGS if args.pool_flags is None else args.pool_flags
+    flags = vt.pool_flags
     out = torch.empty((B, C, Z, Y, X), dtype=torch.float32, device=dev)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(args.steps)]
@@ -173,7 +174,8 @@ def main():
             'value': shard.whole_job_rate(B, args.steps, elapsed, world), 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'FB-OCC forward projection, BASELINE configs[1] ({cfg.name}): 6x256x704 in, '
+            'config': {'workload': f'FB-OCC forward projection, ' + ('BASELINE configs[1] ' if cfg.name == 'BL2' else '') +
+                                   f'({cfg.name}): 6x{cfg.input_size[0]}x{cfg.input_size[1]} in, '
                                    f'feat {H}x{W}, D={D}, C={C}, grid {X}x{Y}x{Z}; index tensors rebuilt every step',
                        'samples_per_gpu': B, 'global_batch': B * world, 'points_kept': P, 'intervals': I,
                        'tile_voxels': args.tile_voxels, 'pool_flags': hex(flags), 'parallelism': f'dp{world} (independent samples, no collective)'},

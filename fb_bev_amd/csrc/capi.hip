@@ -390,14 +390,15 @@ extern "C" int fbbev_pool_tile_index(const int32_t* interval_rank, const int32_t
 struct dense2_args {
     long long n_blocks; size_t lds; fbbev_rt_stream stream; int C, Z, yx, tpp, csplit, swizzle;
     long long stride_b, stride_c;
+    int deep;   // 8 points per load batch instead of 4
     const float *depth, *feat; const int32_t *rd, *rf, *irank, *starts, *lengths; const int* tile_meta;
     float* out;
 };
 
-template <int TV, int CPL, int ST, int NT>
-static int launch_dense2(const dense2_args& a) {
+template <int TV, int CPL, int ST, int NT, int UB>
+static int launch_dense2u(const dense2_args& a) {
     if (a.lds > 64 * 1024) {  // > 64 KiB of dynamic LDS must be opted into (160 KiB per CU on gfx950)
-        int e = fbbev_rt_allow_dyn_lds((const void*)k_pool_fwd_dense2<TV, CPL, ST, NT>, a.lds);
+        int e = fbbev_rt_allow_dyn_lds((const void*)k_pool_fwd_dense2<TV, CPL, ST, NT, UB>, a.lds);
         if (e) return e;
     }
     long long grid = a.n_blocks;
@@ -405,9 +406,14 @@ static int launch_dense2(const dense2_args& a) {
         const long long g = 8ll << (a.swizzle - 1);
         grid = (a.n_blocks + g - 1) / g * g;
     }
-    FBBEV_LAUNCH((k_pool_fwd_dense2<TV, CPL, ST, NT>), grid, NT, a.lds, a.stream, a.C, a.Z, a.yx, a.tpp,
+    FBBEV_LAUNCH((k_pool_fwd_dense2<TV, CPL, ST, NT, UB>), grid, NT, a.lds, a.stream, a.C, a.Z, a.yx, a.tpp,
                  a.csplit, (int)a.n_blocks, a.swizzle, a.stride_b, a.stride_c, a.depth, a.feat, a.rd, a.rf, a.irank, a.starts, a.lengths, a.tile_meta, a.out);
     return fbbev_rt_last_error();
+}
+
+template <int TV, int CPL, int ST, int NT>
+static int launch_dense2(const dense2_args& a) {
+    return a.deep ? launch_dense2u<TV, CPL, ST, NT, 8>(a) : launch_dense2u<TV, CPL, ST, NT, 4>(a);
 }
 
 template <int TV, int CPL, int ST>
@@ -513,7 +519,7 @@ extern "C" int fbbev_bev_pool_v2_dense_fwd(const float* depth, const float* feat
         }
         a.depth = depth; a.feat = feat; a.rd = ranks_depth; a.rf = ranks_feat; a.irank = interval_rank;
         a.starts = interval_starts; a.lengths = interval_lengths; a.tile_meta = static_cast<const int*>(tile_ws);
-        a.out = out; a.stride_b = 0; a.stride_c = 0;
+        a.out = out; a.stride_b = 0; a.stride_c = 0; a.deep = 0;
         if (TV == 64) return cpl8cl ? launch_dense_cl_st<64, 8>(st, a) : launch_dense_cl_st<64, 4>(st, a);
         if (TV == 128) return cpl8cl ? launch_dense_cl_st<128, 8>(st, a) : launch_dense_cl_st<128, 4>(st, a);
         if (TV == 256) return cpl8cl ? launch_dense_cl_st<256, 8>(st, a) : launch_dense_cl_st<256, 4>(st, a);
@@ -544,7 +550,7 @@ extern "C" int fbbev_bev_pool_v2_dense_fwd(const float* depth, const float* feat
     if (a.n_blocks + 8 >= (1ll << 31) || a.lds > 160 * 1024) return FBBEV_E_UNSUPPORTED;
     a.depth = depth; a.feat = feat; a.rd = ranks_depth; a.rf = ranks_feat; a.irank = interval_rank;
     a.starts = interval_starts; a.lengths = interval_lengths; a.tile_meta = static_cast<const int*>(tile_ws);
-    a.out = out; a.stride_b = out_stride_b; a.stride_c = out_stride_c;
+    a.out = out; a.stride_b = out_stride_b; a.stride_c = out_stride_c; a.deep = (flags & FBBEV_POOL_DEEP_BATCH) ? 1 : 0;
     if (TV == 64) return cpl8 ? launch_dense2_st<64, 8>(st, nt, a) : launch_dense2_st<64, 4>(st, nt, a);
     if (TV == 128) return cpl8 ? launch_dense2_st<128, 8>(st, nt, a) : launch_dense2_st<128, 4>(st, nt, a);
     if (TV == 256) return cpl8 ? launch_dense2_st<256, 8>(st, nt, a) : launch_dense2_st<256, 4>(st, nt, a);

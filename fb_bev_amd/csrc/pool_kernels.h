@@ -188,7 +188,7 @@ k_pool_bwd(int c, int n_intervals, const float* __restrict__ out_grad,
 // (tile LDS shrinks -> more resident blocks per CU).  ST selects the store cache policy.
 #define FBBEV_NP_STAGE 512
 
-template <int CPL>
+template <int CPL, int U>
 __device__ __forceinline__ void fbbev_interval_sum_staged(int c, int s, int len, int p0,
                                                           const int* __restrict__ prd_lds,
                                                           const int* __restrict__ prf_lds,
@@ -197,21 +197,23 @@ __device__ __forceinline__ void fbbev_interval_sum_staged(int c, int s, int len,
                                                           const int* __restrict__ rd,
                                                           const int* __restrict__ rf,
                                                           float (&acc)[CPL]) {
+    // U points per batch: their index / depth / feature-row loads are all issued before the first fmaf,
+    // so an interval of len points costs ceil(len/U) memory round trips; the fmaf order stays k = 0,1,2,...
 #pragma unroll
     for (int j = 0; j < CPL; ++j) acc[j] = 0.f;
     int k = 0;
-    for (; k + 4 <= len; k += 4) {
-        int pd[4], pf[4];
+    for (; k + U <= len; k += U) {
+        int pd[U], pf[U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
             const int idx = s + k + u;
             if (idx < FBBEV_NP_STAGE) { pd[u] = prd_lds[idx]; pf[u] = prf_lds[idx]; }
             else { pd[u] = rd[p0 + idx]; pf[u] = rf[p0 + idx]; }
         }
-        float d[4];
-        float f[4][CPL];
+        float d[U];
+        float f[U][CPL];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
             d[u] = depth[pd[u]];
             const float* fp = fbase + (long long)pf[u] * c;
 #pragma unroll
@@ -222,10 +224,8 @@ __device__ __forceinline__ void fbbev_interval_sum_staged(int c, int s, int len,
         }
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
-            acc[j] = fmaf(f[0][j], d[0], acc[j]);
-            acc[j] = fmaf(f[1][j], d[1], acc[j]);
-            acc[j] = fmaf(f[2][j], d[2], acc[j]);
-            acc[j] = fmaf(f[3][j], d[3], acc[j]);
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc[j] = fmaf(f[u][j], d[u], acc[j]);
         }
     }
     for (; k < len; ++k) {
@@ -266,7 +266,7 @@ k_tile_lower_bound2(int n_tiles, int tiles_per_plane, int YX, int TV,
     tile_meta[2 * t + 1] = (lo < n) ? starts[lo] : P;
 }
 
-template <int TV, int CPL, int ST, int NT>
+template <int TV, int CPL, int ST, int NT, int UB>
 __global__ void __launch_bounds__(NT)
 k_pool_fwd_dense2(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_blocks, int swizzle,
                   long long out_stride_b, long long out_stride_c,
@@ -350,7 +350,7 @@ k_pool_fwd_dense2(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_b
             for (int i = g; i < ni; i += gpb) {
                 const int v = ivx[i];
                 float acc[CPL];
-                fbbev_interval_sum_staged<CPL>(C, ist[i], iln[i], p0, prd, prf, depth, fbase, rd, rf, acc);
+                fbbev_interval_sum_staged<CPL, UB>(C, ist[i], iln[i], p0, prd, prf, depth, fbase, rd, rf, acc);
                 if (v >= 0 && v < nv) {
                     float* dst = tile + (slot * CPL) * LD + v;
 #pragma unroll
@@ -433,7 +433,7 @@ k_pool_fwd_dense_cl(int C, int n_voxels, int n_blocks, int swizzle, const float*
             const int s = slot[v];
             float acc[CPL];
             if (s >= 0) {
-                fbbev_interval_sum_staged<CPL>(C, ist[s], iln[s], p0, prd, prf, depth, fbase, rd, rf, acc);
+                fbbev_interval_sum_staged<CPL, 4>(C, ist[s], iln[s], p0, prd, prf, depth, fbase, rd, rf, acc);
             } else {
 #pragma unroll
                 for (int j = 0; j < CPL; ++j) acc[j] = 0.f;

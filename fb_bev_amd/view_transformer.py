@@ -103,8 +103,7 @@ class LSSViewTransformerFunction3D(nn.Module):
     """
 
     def __init__(self, grid_config, input_size, downsample=16, accelerate=False, uniform=False,
-                 with_cp=False, extra_relu=False, fused=True, tile_voxels=_capi.DEFAULT_TILE_VOXELS,
-                 pool_flags=_capi.DEFAULT_POOL_FLAGS):
+                 with_cp=False, extra_relu=False, fused=True, tile_voxels=None, pool_flags=None):
         super().__init__()
         self.uniform = uniform
         self.with_cp = with_cp
@@ -121,8 +120,17 @@ class LSSViewTransformerFunction3D(nn.Module):
         self.accelerate = accelerate
         self.initial_flag = True
         self.fused = fused
-        self.tile_voxels = tile_voxels
-        self.pool_flags = pool_flags
+        # dense-kernel tiling: measured per launch on MI355X (profiles/r01_sweep_*.jsonl).  Sparse grids (BL2:
+        # 0.4 frustum points per voxel) are store-bound -> 128-voxel tiles, channel range split over 2
+        # workgroups; dense grids (shipped config: 4.2 points per voxel) are bound by the per-voxel gather
+        # chains -> 64-voxel tiles, no channel split (the gathers are not repeated).
+        n_cam = 6
+        Z, Y, X = self.grid_zyx
+        density = n_cam * self.frustum.shape[0] * self.frustum.shape[1] * self.frustum.shape[2] / float(X * Y * Z)
+        dense = density >= 1.0
+        self.tile_voxels = tile_voxels if tile_voxels is not None else (64 if dense else _capi.DEFAULT_TILE_VOXELS)
+        self.pool_flags = pool_flags if pool_flags is not None else (
+            _capi.pool_flags(csplit=1) if dense else _capi.DEFAULT_POOL_FLAGS)
         self._cache = {}
         self._index_cache = None
 

@@ -37,6 +37,7 @@ typedef void* fbbev_stream_t; /* hipStream_t */
 #define FBBEV_POOL_DIAG_NO_META 0x40000 /* DIAGNOSTIC: write zeros without reading tile metadata (wrong output) */
 #define FBBEV_POOL_CHANNEL_MAJOR 0x80000 /* workgroup order: channel group outermost (fewer planes written at once) */
 #define FBBEV_POOL_CHANNELS_LAST 0x100000 /* out is (B,Z,Y,X,C) -- the reference op's own layout -- written densely */
+#define FBBEV_POOL_DEEP_BATCH 0x200000 /* 8 instead of 4 points per load batch in the per-voxel fmaf chain */
 #define FBBEV_POOL_SWZ_CHUNK_SHIFT 12 /* bits 12-16: log2(tiles per chunk) for the swizzle, 0 = default */
 
 int fbbev_version(void);
