@@ -55,3 +55,27 @@ def test_compat_install_binds_reference_names():
     assert sys.modules['mmdet3d.ops.bev_pool_v2.bev_pool_v2_ext'].bev_pool_v2_forward
     assert callable(ext.ms_deform_attn_forward) and callable(ext.ms_deform_attn_backward)
     del sys.modules['mmdet3d.ops.bev_pool_v2.bev_pool_v2_ext']
+
+
+def test_invalid_arguments_return_error_codes_without_touching_the_gpu():
+    """Error convention of include/fbbev.h: <0 for invalid arguments, never an exception across the ABI.
+    Every call below is rejected by the argument checks BEFORE any launch, so this runs without a GPU."""
+    lib = _capi.declare(ctypes.CDLL(_capi.LIB_PATH))
+    NULL = ctypes.c_void_p(0)
+    P = ctypes.c_void_p(0x1000)          # non-null dummy; never dereferenced on these paths
+    assert lib.fbbev_bev_pool_v2_fwd(0, 4, P, P, P, P, P, P, P, P, NULL) == -1          # c <= 0
+    assert lib.fbbev_bev_pool_v2_fwd(80, -1, P, P, P, P, P, P, P, P, NULL) == -1        # n_intervals < 0
+    assert lib.fbbev_bev_pool_v2_fwd(80, 0, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL) == 0   # empty: no-op
+    assert lib.fbbev_bev_pool_v2_fwd(80, 4, NULL, P, P, P, P, P, P, P, NULL) == -1      # null depth
+    assert lib.fbbev_bev_pool_v2_bwd(300, 4, P, P, P, P, P, P, P, P, P, P, NULL) == -2  # c > 256 unsupported
+    assert lib.fbbev_lidar_coor(P, P, P, P, P, P, P, P, P, 0, 6, 8, 4, 6, P, NULL) == -1
+    assert lib.fbbev_rank_build(NULL, 1, 6, 8, 4, 6, P, P, P, P, P, P, P, P, P, P, P, 1 << 30, NULL) == -1
+    assert lib.fbbev_rank_build(P, 1, 6, 8, 4, 6, P, P, P, P, P, P, P, P, P, P, P, 16, NULL) == -3      # workspace too small
+    assert lib.fbbev_pool_tile_index(P, P, P, 10, 1, 16, 200, 200, 128, 0, P, 8, NULL) == -3
+    assert lib.fbbev_bev_pool_v2_dense_fwd(P, P, P, P, P, P, P, 1, 6, 4, 16, 16, P, 0, 0, P, 1 << 20, 128, 0, NULL) == -2  # C % 4
+    assert lib.fbbev_bev_pool_v2_dense_fwd(P, P, P, P, P, P, P, 1, 8, 4, 16, 16, P, 0, 17, P, 1 << 20, 128, 0, NULL) == -1  # bad stride
+    assert lib.fbbev_msda_fwd(P, P, P, P, P, 1, 0, 8, 10, 1, 5, 4, P, NULL) == -1       # spatial_size <= 0
+    assert lib.fbbev_msda_fwd(P, P, P, P, P, 0, 704, 8, 10, 1, 5, 4, P, NULL) == 0      # empty batch: no-op
+    assert lib.fbbev_da_cross_attn_fwd(P, P, P, P, P, P, P, P, P, 1, 6, 704, 8, 10, 1, 100, 8, 16, 80, 2.0, 0.5, P, NULL) == -2  # Za > 8
+    assert lib.fbbev_da_cross_attn_fwd(P, P, P, P, P, P, P, P, P, 1, 6, 704, 8, 10, 1, 100, 8, 4, 80, 2.0, 0.0, P, NULL) == -1   # dstep == 0
+    assert lib.fbbev_rank_workspace_bytes(0) == 256 and lib.fbbev_pool_dense_workspace_bytes(0, 1, 1, 1) == 256
