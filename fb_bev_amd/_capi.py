@@ -29,6 +29,9 @@ SIGNATURES = {
     'fbbev_pool_tile_index': (c_int, [c_void_p] * 3 + [c_int] * 7 + [c_void_p, c_size_t, c_void_p]),
     'fbbev_bev_pool_v2_dense_fwd': (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_void_p, c_int64, c_int64, c_void_p,
                                             c_size_t, c_int, c_int, c_void_p]),
+    'fbbev_pool_dense_bwd_workspace_bytes': (c_size_t, [c_int] * 9),
+    'fbbev_bev_pool_v2_dense_bwd': (c_int, [c_void_p, c_int64, c_int64] + [c_void_p] * 6 + [c_int] * 10 +
+                                    [c_void_p] * 3 + [c_size_t, c_void_p]),
     'fbbev_msda_fwd': (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_void_p, c_void_p]),
     'fbbev_point_sampling': (c_int, [c_void_p] * 9 + [c_int] * 5 + [c_float, c_float] + [c_void_p] * 4),
     'fbbev_da_cross_attn_fwd': (c_int, [c_void_p] * 9 + [c_int] * 10 + [c_float, c_float, c_void_p, c_void_p]),
@@ -68,12 +71,12 @@ def _check(code, what):
         raise FbbevError(f'{what} failed: {kind} {code}')
 
 
-def _dev(t, dtype, name):
+def _dev(t, dtype, name, contiguous=True):
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise FbbevError(f'{name} must be a GPU tensor (no CPU fallback in fb_bev_amd)')
     if t.dtype != dtype:
         raise FbbevError(f'{name} must be {dtype}, got {t.dtype}')
-    if not t.is_contiguous():
+    if contiguous and not t.is_contiguous():
         raise FbbevError(f'{name} must be contiguous')
     return c_void_p(t.data_ptr())
 
@@ -231,6 +234,32 @@ def bev_pool_v2_dense_fwd(depth, feat, ranks_depth, ranks_feat, interval_rank, i
             B, C, Z, Y, X, c_void_p(out.data_ptr()), sb, sc, c_void_p(tile_ws.data_ptr()),
             tile_ws.numel() * tile_ws.element_size(), int(tile_voxels), int(flags), _stream()),
             'fbbev_bev_pool_v2_dense_fwd')
+
+
+def pool_dense_bwd_workspace_bytes(B, N, D, H, W, C, Z, Y, X):
+    return int(lib().fbbev_pool_dense_bwd_workspace_bytes(B, N, D, H, W, C, Z, Y, X))
+
+
+def bev_pool_v2_dense_bwd(out_grad, depth, feat, ranks_depth, interval_rank, interval_starts, counts,
+                          n_intervals_max, grid_zyx, depth_grad, feat_grad, workspace):
+    """Sync-free backward of the fused lift-splat.  out_grad: (B,C,Z,Y,X) f32 with a contiguous (Z,Y,X)
+    block; depth (B,N,D,H,W); feat (B,N,H,W,C); depth_grad / feat_grad: same shapes, written completely."""
+    B, N, D, H, W = depth.shape
+    C = feat.shape[-1]
+    Z, Y, X = grid_zyx
+    if tuple(out_grad.shape) != (B, C, Z, Y, X) or out_grad.stride()[2:] != (Y * X, X, 1):
+        raise FbbevError('out_grad must be a (B,C,Z,Y,X) tensor with a contiguous (Z,Y,X) block')
+    if tuple(feat.shape) != (B, N, H, W, C) or depth_grad.shape != depth.shape or feat_grad.shape != feat.shape:
+        raise FbbevError('depth/feat/grad shapes do not match')
+    with _on(depth):
+        _check(lib().fbbev_bev_pool_v2_dense_bwd(
+            _dev(out_grad, F32, 'out_grad', contiguous=False), out_grad.stride(0), out_grad.stride(1),
+            _dev(depth, F32, 'depth'), _dev(feat, F32, 'feat'),
+            _dev(ranks_depth, I32, 'ranks_depth'), _dev(interval_rank, I32, 'interval_rank'),
+            _dev(interval_starts, I32, 'interval_starts'), _dev(counts, I32, 'counts'), int(n_intervals_max),
+            B, N, D, H, W, C, Z, Y, X, _dev(depth_grad, F32, 'depth_grad'), _dev(feat_grad, F32, 'feat_grad'),
+            c_void_p(workspace.data_ptr()), workspace.numel() * workspace.element_size(), _stream()),
+            'fbbev_bev_pool_v2_dense_bwd')
 
 
 def msda_fwd(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, out):

@@ -2,6 +2,7 @@
 // launch geometry, workspace carving.  No torch, no host synchronisation, caller's stream.
 #include "rt.h"
 #include "pool_kernels.h"
+#include "pool_bwd_kernels.h"
 #include "rank_kernels.h"
 #include "sort_kernels.h"
 #include "msda_kernels.h"
@@ -627,6 +628,88 @@ extern "C" int fbbev_da_cross_attn_fwd(const float* value, const int64_t* spatia
     FBBEV_LAUNCH(k_da_cross_attn_fwd, blocks, 256, 0, (fbbev_rt_stream)stream_, n, value, spatial_shapes,
                  level_start_index, pred_depth, ref_cam, mask, qdepth, offsets, attn, B, Ncam, S, M, Dh, L, Q, P,
                  Za, DC, d0, dstep, slots);
+    FBBEV_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---------------------------------------------------------------- fused lift-splat backward (training)
+struct bwd_layout { size_t table, meta, rows, total; long long n_tiles; int tpp; long long max_rows; };
+
+static bwd_layout pool_bwd_layout(int B, int N, int D, int H, int W, int C, int Z, int Y, int X) {
+    bwd_layout l;
+    const long long n = (long long)B * N * D * H * W, yx = (long long)Y * X, nvox = (long long)B * Z * yx;
+    l.tpp = (int)((yx + 127) / 128);
+    l.n_tiles = (long long)B * Z * l.tpp;
+    l.max_rows = n < nvox ? n : nvox;                 // I <= min(points, voxels)
+    l.table = 0;
+    l.meta = align_up((size_t)n * 4, 256);
+    l.rows = l.meta + align_up((size_t)(l.n_tiles + 1) * 8, 256);
+    l.total = l.rows + align_up((size_t)l.max_rows * C * 4, 256);
+    return l;
+}
+
+extern "C" size_t fbbev_pool_dense_bwd_workspace_bytes(int B, int N, int D, int H, int W, int C, int Z, int Y, int X) {
+    if (B <= 0 || N <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0 || Z <= 0 || Y <= 0 || X <= 0) return 256;
+    return pool_bwd_layout(B, N, D, H, W, C, Z, Y, X).total;
+}
+
+extern "C" int fbbev_bev_pool_v2_dense_bwd(const float* out_grad, long long og_stride_b, long long og_stride_c,
+                                           const float* depth, const float* feat, const int32_t* ranks_depth,
+                                           const int32_t* interval_rank, const int32_t* interval_starts,
+                                           const int32_t* counts, int n_intervals_max, int B, int N, int D,
+                                           int H, int W, int C, int Z, int Y, int X, float* depth_grad,
+                                           float* feat_grad, void* workspace, size_t workspace_bytes,
+                                           fbbev_stream_t stream_) {
+    if (B <= 0 || N <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0 || Z <= 0 || Y <= 0 || X <= 0 || n_intervals_max < 0)
+        return FBBEV_E_BADARG;
+    if (!out_grad || !depth || !feat || !ranks_depth || !interval_rank || !interval_starts || !counts ||
+        !depth_grad || !feat_grad || !workspace) return FBBEV_E_BADARG;
+    const long long yx = (long long)Y * X, n = (long long)B * N * D * H * W;
+    if (C % 4 != 0 || C > 256 || yx % 4 != 0 || !aligned16(out_grad) || !aligned16(feat) || !aligned16(feat_grad) ||
+        !aligned16(workspace)) return FBBEV_E_UNSUPPORTED;
+    if ((long long)B * Z * yx >= (1ll << 31) || n >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
+    if (og_stride_c == 0) og_stride_c = (long long)Z * yx;
+    if (og_stride_b == 0) og_stride_b = (long long)C * og_stride_c;
+    if (og_stride_c < (long long)Z * yx || og_stride_b < (long long)C * og_stride_c || og_stride_c % 4 != 0 ||
+        og_stride_b % 4 != 0) return FBBEV_E_BADARG;
+    const bwd_layout l = pool_bwd_layout(B, N, D, H, W, C, Z, Y, X);
+    if (workspace_bytes < l.total) return FBBEV_E_WORKSPACE;
+    const size_t lds = (size_t)C * (128 + 4) * 4;
+    if (lds > 160 * 1024) return FBBEV_E_UNSUPPORTED;
+    fbbev_rt_stream stream = (fbbev_rt_stream)stream_;
+    char* ws = static_cast<char*>(workspace);
+    int* table = reinterpret_cast<int*>(ws + l.table);
+    int* meta = reinterpret_cast<int*>(ws + l.meta);
+    float* rows = reinterpret_cast<float*>(ws + l.rows);
+    int e = fbbev_rt_memset_async(table, 0xFF, (size_t)n * 4, stream);      // -1 = point dropped
+    if (e) return e;
+    {
+        long long blocks = (n + 255) / 256;      // P <= n, grid-stride over the device-side P
+        if (blocks > 8192) blocks = 8192;
+        FBBEV_LAUNCH(k_point_row_table, blocks, 256, 0, stream, ranks_depth, interval_starts, counts,
+                     n_intervals_max, table);
+        FBBEV_CHECK_LAUNCH();
+    }
+    FBBEV_LAUNCH(k_tile_lower_bound2, (l.n_tiles + 1 + 255) / 256, 256, 0, stream, (int)l.n_tiles, l.tpp, (int)yx,
+                 128, interval_rank, interval_starts, counts, n_intervals_max, meta);
+    FBBEV_CHECK_LAUNCH();
+    if (lds > 64 * 1024) {
+        e = fbbev_rt_allow_dyn_lds((const void*)k_pool_bwd_rows<128>, lds);
+        if (e) return e;
+    }
+    FBBEV_LAUNCH(k_pool_bwd_rows<128>, l.n_tiles, 256, lds, stream, C, Z, (int)yx, l.tpp, og_stride_b, og_stride_c,
+                 out_grad, interval_rank, meta, rows);
+    FBBEV_CHECK_LAUNCH();
+    const long long n_pixels = (long long)B * N * H * W;
+    const long long blocks = (n_pixels + 7) / 8;      // 8 half-waves per 256-thread workgroup
+    if (C <= 128)
+        FBBEV_LAUNCH(k_pool_bwd_pixel<4>, blocks, 256, 0, stream, C, D, H * W, n_pixels, (long long)C, rows, depth,
+                     feat, table, depth_grad, feat_grad);
+    else if (C % 8 == 0)
+        FBBEV_LAUNCH(k_pool_bwd_pixel<8>, blocks, 256, 0, stream, C, D, H * W, n_pixels, (long long)C, rows, depth,
+                     feat, table, depth_grad, feat_grad);
+    else
+        return FBBEV_E_UNSUPPORTED;
     FBBEV_CHECK_LAUNCH();
     return 0;
 }

@@ -74,23 +74,35 @@ class LiftSplat(torch.autograd.Function):
                                     idx.interval_starts, idx.interval_lengths, B, C, Z, Y, X, out,
                                     tile_ws, tile_voxels, pool_flags)
         ctx.idx = idx
+        ctx.grid_zyx = (Z, Y, X)
         ctx.save_for_backward(depth, feat)
         return out
 
     @staticmethod
     def backward(ctx, out_grad):
-        from .bev_pool import intervals_over
-        from . import bev_pool_v2_ext
+        """Sync-free: the frustum structure is the feature-pixel index (no argsort of ranks_feat, no mask-built
+        intervals, no permuted copy of the gradient) -- fbbev_bev_pool_v2_dense_bwd."""
         depth, feat = ctx.saved_tensors
-        rb, rd, rf, _, _ = ctx.idx.exact()
-        rf, order = torch.sort(rf, stable=True)
-        rd, rb = rd[order].contiguous(), rb[order].contiguous()
-        starts_bp, lengths_bp = intervals_over(rf)
-        og = out_grad.permute(0, 2, 3, 4, 1).contiguous()  # (B,Z,Y,X,C), the op's gradient layout
-        depth_grad, feat_grad = torch.zeros_like(depth), torch.zeros_like(feat)
-        bev_pool_v2_ext.bev_pool_v2_backward(og, depth_grad, feat_grad, depth, feat, rd, rf.contiguous(), rb,
-                                             lengths_bp, starts_bp)
+        idx = ctx.idx
+        Z, Y, X = ctx.grid_zyx
+        B, N, D, H, W = depth.shape
+        C = feat.shape[-1]
+        og = out_grad
+        sb, sc = og.stride(0), og.stride(1)
+        if (og.dtype != torch.float32 or og.stride()[2:] != (Y * X, X, 1) or sc < Z * Y * X or sb < C * sc or sc % 4
+                or sb % 4 or og.data_ptr() % 16):
+            og = og.contiguous().float()
+        key = (depth.device, _capi.pool_dense_bwd_workspace_bytes(B, N, D, H, W, C, Z, Y, X))
+        if key not in _BWD_WS:
+            _BWD_WS.clear()      # one live workspace per process: it is sized for the largest rows buffer
+            _BWD_WS[key] = torch.empty(key[1], dtype=torch.uint8, device=depth.device)
+        depth_grad, feat_grad = torch.empty_like(depth), torch.empty_like(feat)
+        _capi.bev_pool_v2_dense_bwd(og, depth, feat, idx.ranks_depth, idx.interval_rank, idx.interval_starts,
+                                    idx.counts, idx.n, (Z, Y, X), depth_grad, feat_grad, _BWD_WS[key])
         return depth_grad, feat_grad, None, None, None, None, None
+
+
+_BWD_WS = {}
 
 
 class LSSViewTransformerFunction3D(nn.Module):

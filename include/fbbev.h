@@ -211,6 +211,26 @@ int fbbev_da_cross_attn_fwd(const float* value, const int64_t* spatial_shapes,
                             int L, int Q, int P, int Za, int DC, float d0, float dstep, float* slots,
                             fbbev_stream_t stream);
 
+/* Training backward of the fused lift-splat:  replaces QuickCumsumCuda.backward (bev_pool.py:39-78 --
+ * argsort of ranks_feat, mask-built intervals [2 host syncs], the permute().contiguous() of the gradient)
+ * and bev_pool_v2_backward / bev_pool_v2_grad_kernel (src/bev_pool_cuda.cu:52-100,128-135).
+ * No host sync: the index tensors and counts are the device-side outputs of fbbev_rank_build /
+ * fbbev_lift_rank_build of the forward pass (padded arrays, valid prefixes counts[0]=P, counts[1]=I).
+ * out_grad is the gradient of the (B,C,Z,Y,X) output in THAT layout (element strides og_stride_b /
+ * og_stride_c, 0 = contiguous; the (Z,Y,X) block of a channel contiguous) -- no channels-last copy.
+ * depth (B,N,D,H,W), feat (B,N,H,W,C) as in the forward; depth_grad / feat_grad have the same shapes and
+ * are written completely (zeros for dropped points / untouched pixels): they need not be pre-zeroed.
+ * feat_grad: in-order fmaf chain over the kept depth bins of each pixel in ascending d (the reference's
+ * order is that of its unstable argsort); depth_grad: C-long dot product reduced across lanes.
+ * Requires C % 4 == 0, C <= 256 (C % 8 == 0 above 128), (Y*X) % 4 == 0, 16-byte aligned pointers. */
+size_t fbbev_pool_dense_bwd_workspace_bytes(int B, int N, int D, int H, int W, int C, int Z, int Y, int X);
+int fbbev_bev_pool_v2_dense_bwd(const float* out_grad, long long og_stride_b, long long og_stride_c,
+                                const float* depth, const float* feat, const int32_t* ranks_depth,
+                                const int32_t* interval_rank, const int32_t* interval_starts,
+                                const int32_t* counts, int n_intervals_max, int B, int N, int D, int H, int W,
+                                int C, int Z, int Y, int X, float* depth_grad, float* feat_grad,
+                                void* workspace, size_t workspace_bytes, fbbev_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

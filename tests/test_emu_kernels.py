@@ -21,7 +21,7 @@ def _grid3(vt):
 
 
 def _case(name, B, aug=True):
-    cfg = S.CONFIGS[name]
+    cfg = name if isinstance(name, S.PathConfig) else S.CONFIGS[name]
     vt = O.ViewTransformerOracle(cfg.grid_config, cfg.input_size, cfg.downsample)
     cam = S.camera_rig(cfg, B, seed=0, bda_aug=aug)
     coor = vt.get_lidar_coor(*cam).contiguous()
@@ -251,3 +251,49 @@ def test_nchw_to_nhwc_emulated():
     for shape in ((2, 3, 8, 4, 6), (1, 2, 80, 5, 7), (1, 1, 33, 3, 11)):
         x = torch.randn(shape, generator=torch.Generator().manual_seed(0))
         assert torch.equal(E.nchw_to_nhwc(x), x.permute(0, 1, 3, 4, 2).contiguous())
+
+
+def _bwd_expected(og_ncdhw, depth, feat, rb, rd, rf):
+    """Oracle backward with the points of a pixel taken in ascending point id (= ascending depth bin)."""
+    o = torch.argsort(rd.long())
+    return O.bev_pool_v2_bwd(og_ncdhw.permute(0, 2, 3, 4, 1).contiguous(), depth, feat, rd[o].contiguous(),
+                             rf[o].contiguous(), rb[o].contiguous())
+
+
+# D=40 (two 32-bin chunks per pixel) and C=136 (> 128: the 8-channels-per-lane instantiation)
+DEEP = S.PathConfig('DEEP', (32, 48), 8, {'x': [-8, 8, 1.0], 'y': [-8, 8, 1.0], 'z': [-1, 3, 1.0],
+                                           'depth': [1.0, 9.0, 0.2]}, 136, n_cams=2)
+
+
+@pytest.mark.parametrize('name,B,padded', [('TINY', 2, False), ('TINY', 1, True), ('SMALL', 1, False),
+                                           (DEEP, 1, False)])
+def test_pool_dense_bwd_emulated(name, B, padded):
+    cfg, vt, coor, depth, feat = _case(name, B)
+    rb, rd, rf, st, ln, ir, counts = E.rank_build(coor, *_grid3(vt))
+    _, Z, Y, X, C = vt.bev_feat_shape(B, cfg.channels)
+    g = torch.Generator().manual_seed(5)
+    if padded:      # gradient living inside a wider (B, C+4, Z, Y, X) buffer: strides are honoured
+        og = torch.randn((B, C + 4, Z, Y, X), generator=g)[:, 2:2 + C]
+    else:
+        og = torch.randn((B, C, Z, Y, X), generator=g)
+    code, dg, fg = E.pool_dense_bwd(og, depth, feat, rd, ir, st, counts, st.numel(), (Z, Y, X))
+    assert code == 0
+    assert not torch.isnan(dg).any() and not torch.isnan(fg).any()     # both written completely, zeros included
+    erb, erd, erf, est, eln = vt.voxel_pooling_prepare_v2(coor)
+    edg, efg = _bwd_expected(og, depth, feat, erb, erd, erf)
+    assert torch.equal(fg, efg)                                        # in-order fmaf chain, ascending depth bin
+    assert torch.allclose(dg, edg, atol=1e-5, rtol=1e-5)               # lane-tree vs serial channel sum
+    kept = torch.zeros(depth.numel(), dtype=torch.bool)
+    kept[erd.long()] = True
+    assert torch.equal(dg.flatten()[~kept], torch.zeros((~kept).sum()))
+
+
+def test_pool_dense_bwd_empty_index_writes_zeros():
+    cfg, vt, coor, depth, feat = _case('TINY', 1)
+    coor = coor + 1.0e4                                                # every point leaves the grid
+    rb, rd, rf, st, ln, ir, counts = E.rank_build(coor, *_grid3(vt))
+    assert counts.tolist() == [0, 0]
+    _, Z, Y, X, C = vt.bev_feat_shape(1, cfg.channels)
+    og = torch.randn((1, C, Z, Y, X), generator=torch.Generator().manual_seed(1))
+    code, dg, fg = E.pool_dense_bwd(og, depth, feat, rd, ir, st, counts, st.numel(), (Z, Y, X))
+    assert code == 0 and not dg.any() and not fg.any()
