@@ -151,6 +151,17 @@ def main():
     elapsed = shard.max_over_ranks(elapsed, dev)
 
     kern_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)
+    # context for the roofline fraction (outside the timed region): what a plain device fill of the same output
+    # buffer reaches on this box -- the practical write ceiling (report vs peak AND vs measured bandwidth)
+    fill_ms = []
+    for _ in range(7):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        out.zero_()
+        b.record()
+        torch.cuda.synchronize(dev)
+        fill_ms.append(a.elapsed_time(b))
+    fill_gbs = out.numel() * 4 / (sorted(fill_ms)[len(fill_ms) // 2] * 1e-3) / 1e9
     P, I = idx.counts.tolist()
     D = cfg.D
     H, W = cfg.feat_hw
@@ -181,7 +192,8 @@ def main():
                        'tile_voxels': args.tile_voxels, 'pool_flags': hex(flags), 'parallelism': f'dp{world} (independent samples, no collective)'},
             'roofline': {'kernel': 'k_pool_fwd_dense2', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'algorithmic_bytes_per_launch': algo_bytes, 'kernel_ms': kern_ms},
+                         'algorithmic_bytes_per_launch': algo_bytes, 'kernel_ms': kern_ms,
+                         'device_fill_GBps': fill_gbs, 'frac_of_device_fill': achieved / fill_gbs if fill_gbs > 0 else None},
         }
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(cfg, args.cpu_seconds)

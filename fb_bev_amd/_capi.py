@@ -11,7 +11,8 @@ from ctypes import c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libfbbev_hip.so')
+# FBBEV_LIB: alternate build of the same C ABI (debug / tuning variants); there is still no non-HIP path
+LIB_PATH = os.environ.get('FBBEV_LIB') or os.path.join(_HERE, 'libfbbev_hip.so')
 
 # name -> (restype, argtypes); mirrors include/fbbev.h one to one
 SIGNATURES = {

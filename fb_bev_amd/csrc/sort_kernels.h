@@ -21,7 +21,9 @@
 #include "rank_kernels.h"
 
 #define FBBEV_SORT_WAVES 4
-#define FBBEV_SORT_ROUNDS 16
+#ifndef FBBEV_SORT_ROUNDS
+#define FBBEV_SORT_ROUNDS 16   // keys per lane; tile = 4 waves x 64 lanes x ROUNDS
+#endif
 #define FBBEV_SORT_TILE (FBBEV_SORT_WAVES * 64 * FBBEV_SORT_ROUNDS)   // 4096 keys per workgroup
 #define FBBEV_SORT_MAX_RB 9
 
