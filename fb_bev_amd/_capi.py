@@ -33,6 +33,8 @@ SIGNATURES = {
     'fbbev_pool_dense_bwd_workspace_bytes': (c_size_t, [c_int] * 9),
     'fbbev_bev_pool_v2_dense_bwd': (c_int, [c_void_p, c_int64, c_int64] + [c_void_p] * 6 + [c_int] * 10 +
                                     [c_void_p] * 3 + [c_size_t, c_void_p]),
+    'fbbev_history_flow': (c_int, [c_void_p] * 5 + [c_int, c_void_p, c_void_p]),
+    'fbbev_history_warp': (c_int, [c_void_p, c_int64, c_void_p] + [c_int] * 5 + [c_void_p, c_int64, c_void_p]),
     'fbbev_msda_fwd': (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_void_p, c_void_p]),
     'fbbev_point_sampling': (c_int, [c_void_p] * 9 + [c_int] * 5 + [c_float, c_float] + [c_void_p] * 4),
     'fbbev_da_cross_attn_fwd': (c_int, [c_void_p] * 9 + [c_int] * 10 + [c_float, c_float, c_void_p, c_void_p]),
@@ -80,6 +82,11 @@ def _dev(t, dtype, name, contiguous=True):
     if contiguous and not t.is_contiguous():
         raise FbbevError(f'{name} must be contiguous')
     return c_void_p(t.data_ptr())
+
+
+def require_gpu(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise FbbevError(f'{name} must be a GPU tensor (no CPU fallback in fb_bev_amd)')
 
 
 def _on(t):
@@ -329,3 +336,33 @@ def nchw_to_nhwc(context):
         _check(lib().fbbev_nchw_to_nhwc(_dev(context, F32, 'context'), _dev(feat, F32, 'feat'), B * N, C, H * W,
                                         _stream()), 'fbbev_nchw_to_nhwc')
     return feat
+
+
+def history_flow(history_forward_augs, curr_to_prev_ego_rt, bda, dx3, lower3):
+    """(B,4,4), (B,4,4), (B,3,3) f32 GPU tensors + host (x,y,z) voxel size / grid lower bound -> rt_flow (B,4,4)."""
+    B = bda.shape[0]
+    flow = torch.empty((B, 4, 4), dtype=torch.float32, device=bda.device)
+    arr = ctypes.c_float * 3
+    d, lo = arr(*[float(v) for v in dx3]), arr(*[float(v) for v in lower3])
+    with _on(bda):
+        _check(lib().fbbev_history_flow(_dev(history_forward_augs, F32, 'history_forward_augs'),
+                                        _dev(curr_to_prev_ego_rt, F32, 'curr_to_prev_ego_rt'), _dev(bda, F32, 'bda'),
+                                        ctypes.cast(d, c_void_p), ctypes.cast(lo, c_void_p), B, _dev(flow, F32, 'flow'),
+                                        _stream()), 'fbbev_history_flow')
+    return flow
+
+
+def history_warp(history, rt_flow, out):
+    """history, out: (B,CH,Z,Y,X) f32 whose per-sample (CH,Z,Y,X) block is contiguous (batch stride free)."""
+    B, CH, Z, Y, X = history.shape
+    if tuple(out.shape) != (B, CH, Z, Y, X):
+        raise FbbevError('out must have the shape of history')
+    for t, n in ((history, 'history'), (out, 'out')):
+        if t.stride()[1:] != (Z * Y * X, Y * X, X, 1):
+            raise FbbevError(f'{n}: the (CH,Z,Y,X) block of a sample must be contiguous')
+    with _on(history):
+        _check(lib().fbbev_history_warp(_dev(history, F32, 'history', contiguous=False), history.stride(0),
+                                        _dev(rt_flow, F32, 'rt_flow'), B, CH, Z, Y, X,
+                                        _dev(out, F32, 'out', contiguous=False), out.stride(0), _stream()),
+               'fbbev_history_warp')
+    return out

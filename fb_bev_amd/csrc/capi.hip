@@ -8,6 +8,7 @@
 #include "msda_kernels.h"
 #include "geom_kernels.h"
 #include "da_kernels.h"
+#include "history_kernels.h"
 #include "../../include/fbbev.h"
 
 #define FBBEV_CHECK_LAUNCH()                      \
@@ -710,6 +711,42 @@ extern "C" int fbbev_bev_pool_v2_dense_bwd(const float* out_grad, long long og_s
                      feat, table, depth_grad, feat_grad);
     else
         return FBBEV_E_UNSUPPORTED;
+    FBBEV_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------ temporal history alignment
+extern "C" int fbbev_history_flow(const float* history_forward_augs, const float* curr_to_prev_ego_rt, const float* bda,
+                                  const float* dx3, const float* lower3, int B, float* rt_flow, fbbev_stream_t stream_) {
+    if (B < 0) return FBBEV_E_BADARG;
+    if (B == 0) return 0;
+    if (!history_forward_augs || !curr_to_prev_ego_rt || !bda || !dx3 || !lower3 || !rt_flow) return FBBEV_E_BADARG;
+    if (!(dx3[0] > 0.f) || !(dx3[1] > 0.f) || !(dx3[2] > 0.f)) return FBBEV_E_BADARG;
+    FBBEV_LAUNCH(k_history_flow, (B + 63) / 64, 64, 0, (fbbev_rt_stream)stream_, history_forward_augs, curr_to_prev_ego_rt,
+                 bda, dx3[0], dx3[1], dx3[2], lower3[0], lower3[1], lower3[2], B, rt_flow);
+    FBBEV_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int fbbev_history_warp(const float* history, long long history_stride_b, const float* rt_flow, int B, int CH,
+                                  int Z, int Y, int X, float* out, long long out_stride_b, fbbev_stream_t stream_) {
+    if (B < 0 || CH < 0 || Z < 2 || Y < 2 || X < 2) return FBBEV_E_BADARG;      // size-1 axes divide by zero in :208
+    if (B == 0 || CH == 0) return 0;
+    if (!history || !rt_flow || !out) return FBBEV_E_BADARG;
+    const long long zyx = (long long)Z * Y * X;
+    if (zyx >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
+    if (history_stride_b == 0) history_stride_b = (long long)CH * zyx;
+    if (out_stride_b == 0) out_stride_b = (long long)CH * zyx;
+    if (history_stride_b < (long long)CH * zyx || out_stride_b < (long long)CH * zyx) return FBBEV_E_BADARG;
+    const int n_chunks = (int)((zyx + 255) / 256);
+    // enough workgroups to fill 256 CUs several times over, at least 8 channels each to amortise the tap setup
+    int cpb = 64;
+    while (cpb > 8 && (long long)B * n_chunks * ((CH + cpb - 1) / cpb) < 4096) cpb >>= 1;
+    const int n_groups = (CH + cpb - 1) / cpb;
+    const long long blocks = (long long)B * n_groups * n_chunks;
+    if (blocks >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
+    FBBEV_LAUNCH(k_history_warp, blocks, 256, 0, (fbbev_rt_stream)stream_, history, history_stride_b, rt_flow, CH, Z, Y, X,
+                 cpb, n_groups, n_chunks, out, out_stride_b);
     FBBEV_CHECK_LAUNCH();
     return 0;
 }

@@ -1,0 +1,180 @@
+"""Temporal history fusion of FB-OCC as a standalone module.
+
+Mirror of the history part of `FBOCC` -- mmdet3d/models/fbbev/detectors/fbocc.py:
+layers and state :101-131, `generate_grid` :169-205, `fuse_history` :207-319 -- with the same constructor
+argument names, the same sub-module names (`history_keyframe_time_conv`, `history_keyframe_cat_conv`: a detector
+state_dict loads unchanged) and the same state semantics (`history_bev`, `history_seq_ids`,
+`history_forward_augs`, `history_sweep_time`, sequence restarts, `do_history`).
+
+What runs where:
+  * rt_flow and the trilinear warp of the T-frame history: HIP (`fbbev_history_flow`, `fbbev_history_warp`) -- the
+    sampling grid is never materialised;
+  * inference: the warp writes straight into the frame slots 1..T of the next (T+1)-frame buffer, the current frame
+    is copied into slot 0, and `history_bev` becomes a VIEW of slots 0..T-1 (the reference cats, clones and re-cats
+    the 16x80-channel volume: ~6 full passes); the time channel of the 81->80 conv is folded into a per-(sample,
+    frame) bias and the eval-mode batch norms into the 1x1x1 conv weights, so each conv is one batched library GEMM
+    with a bias epilogue (`baddbmm`) + ReLU;
+  * training (grad enabled): the reference's own op sequence on the module's layers (batch-norm statistics intact),
+    only the warp is the HIP kernel -- `history_bev` is detached (:241), so the warp needs no backward.
+No CPU fallback: the HIP extension must be present and the tensors on the GPU.
+"""
+import torch
+import torch.nn as nn
+
+from . import _capi
+
+
+class TemporalHistoryFusion(nn.Module):
+    def __init__(self, dx, bx, single_bev_num_channels=80, history_cat_num=16, history_cat_conv_out_channels=None,
+                 do_history=True, interpolation_mode='bilinear', history_cam_sweep_freq=0.5):
+        super().__init__()
+        if interpolation_mode != 'bilinear':
+            raise NotImplementedError("only interpolation_mode='bilinear' (trilinear on the voxel grid) is built")
+        self.dx = [float(v) for v in dx]                               # forward_projection.dx  (fbocc.py:186-188)
+        self.lower = [float(b) - float(d) / 2.0 for b, d in zip(bx, dx)]   # bx - dx/2           (fbocc.py:189-191)
+        self.single_bev_num_channels = C = single_bev_num_channels
+        self.do_history = do_history
+        self.interpolation_mode = interpolation_mode
+        self.history_cat_num = T = history_cat_num
+        self.history_cam_sweep_freq = history_cam_sweep_freq           # seconds between frames (fbocc.py:105)
+        out_c = history_cat_conv_out_channels if history_cat_conv_out_channels is not None else C
+        self.history_keyframe_time_conv = nn.Sequential(               # fbocc.py:111-118
+            nn.Conv3d(C + 1, C, kernel_size=1, padding=0, stride=1), nn.SyncBatchNorm(C), nn.ReLU(inplace=True))
+        self.history_keyframe_cat_conv = nn.Sequential(                # fbocc.py:120-127
+            nn.Conv3d(C * (T + 1), out_c, kernel_size=1, padding=0, stride=1), nn.SyncBatchNorm(out_c),
+            nn.ReLU(inplace=True))
+        self.reset()
+
+    def reset(self):
+        self.history_sweep_time = None        # (B,T) CPU float tensor
+        self.history_bev = None               # (B,T*C,Z,Y,X) GPU
+        self.history_seq_ids = None           # (B,) CPU long
+        self.history_forward_augs = None      # (B,4,4) GPU
+        self._bufs = None
+
+    # ------------------------------------------------------------------ pieces
+    @staticmethod
+    def forward_augs(bda):
+        """generate_forward_transformation_matrix (fbocc.py:36-41), no per-sample Python loop."""
+        m = torch.zeros((bda.shape[0], 4, 4), dtype=torch.float32, device=bda.device)
+        m[:, :3, :3] = bda
+        m[:, 3, 3] = 1.0
+        return m
+
+    def rt_flow(self, curr_to_prev_ego_rt, bda):
+        return _capi.history_flow(self.history_forward_augs, curr_to_prev_ego_rt.contiguous().float(),
+                                  bda.contiguous().float(), self.dx, self.lower)
+
+    def _folded(self, seq):
+        """1x1x1 conv + eval batch norm -> (weight (Cout,Cin), bias (Cout)) of the equivalent affine map."""
+        conv, bn = seq[0], seq[1]
+        scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+        w = conv.weight.flatten(1) * scale[:, None]
+        b = (conv.bias - bn.running_mean) * scale + bn.bias
+        return w, b
+
+    # ------------------------------------------------------------------ fuse_history (fbocc.py:207-319)
+    def fuse_history(self, curr_bev, img_metas, bda):
+        if curr_bev.dim() != 5:
+            raise NotImplementedError('2-D BEV history (nx[-1] == 1) is outside the built path: FB-OCC fuses a voxel grid')
+        _capi.require_gpu(curr_bev, 'curr_bev')
+        T, C = self.history_cat_num, self.single_bev_num_channels
+        dev = curr_bev.device
+        curr = curr_bev.permute(0, 1, 4, 2, 3).float()                 # n, c, z, h, w   (:212)
+        B, _, Z, Y, X = curr.shape
+        seq_ids = torch.LongTensor([m['sequence_group_idx'] for m in img_metas])
+        start = torch.BoolTensor([bool(m['start_of_sequence']) for m in img_metas])
+        fwd = self.forward_augs(bda.float())                           # :220
+        ego = torch.stack([torch.as_tensor(m['curr_to_prev_ego_rt'], dtype=torch.float32) for m in img_metas]).to(
+            dev, non_blocking=True)                                    # :222-224
+        train_path = torch.is_grad_enabled() and (curr.requires_grad or self.training)
+
+        if self.history_bev is None:                                   # first batch (:227-238)
+            self.history_bev = self._new_history(curr, train_path)
+            self.history_seq_ids = seq_ids.clone()
+            self.history_forward_augs = fwd.clone()
+            self.history_sweep_time = torch.zeros(B, T)
+        self.history_bev = self.history_bev.detach()                   # :241
+        bad = (self.history_seq_ids != seq_ids)[~start]
+        assert int(bad.sum()) == 0, '{}, {}, {}'.format(self.history_seq_ids, seq_ids, start)   # :248-249
+        self.history_sweep_time = self.history_sweep_time + 1          # :252
+        if bool(start.any()):                                          # :253-261 (indices known on the host: no sync)
+            for b in torch.nonzero(start).flatten().tolist():
+                self.history_bev[b].view(T, C, Z, Y, X).copy_(curr[b].detach().unsqueeze(0).expand(T, C, Z, Y, X))
+                self.history_forward_augs[b] = fwd[b]
+            self.history_sweep_time[start] = 0
+            self.history_seq_ids[start] = seq_ids[start]
+
+        flow = self.rt_flow(ego, bda)                                  # generate_grid :197-203
+        sweep = torch.cat([torch.zeros(B, 1), self.history_sweep_time], dim=1)    # :279-281, B x (1+T)
+        if train_path:
+            out, feats_cat = self._fuse_train(curr, flow, sweep.to(dev, non_blocking=True))
+            self.history_bev = feats_cat[:, :-C].detach().clone()      # :312
+        else:
+            with torch.no_grad():
+                out, nxt = self._fuse_infer(curr.detach(), flow, sweep.to(dev, non_blocking=True))
+            self.history_bev = nxt[:, :T * C]                          # view of the buffer just written: no clone
+        self.history_sweep_time = sweep[:, :-1]                        # :313
+        self.history_forward_augs = fwd.clone()                        # :314
+        if not self.do_history:                                        # :317-318
+            self.history_bev = None
+        return out.permute(0, 1, 3, 4, 2)                              # (B,Cout,Y,X,Z) view, as :315-319
+
+    forward = fuse_history
+
+    # ------------------------------------------------------------------ internals
+    def _frame_buffers(self, like, B, Z, Y, X):
+        T, C = self.history_cat_num, self.single_bev_num_channels
+        shape = (B, (T + 1) * C, Z, Y, X)
+        if self._bufs is None or tuple(self._bufs[0].shape) != shape or self._bufs[0].device != like.device:
+            self._bufs = [torch.empty(shape, dtype=torch.float32, device=like.device) for _ in range(2)]
+        return self._bufs
+
+    def _new_history(self, curr, train_path):
+        T = self.history_cat_num
+        if train_path:
+            return curr.detach().repeat(1, T, 1, 1, 1)                 # :234
+        B, C, Z, Y, X = curr.shape
+        a, _ = self._frame_buffers(curr, B, Z, Y, X)
+        hist = a[:, :T * C]
+        hist.view(B, T, C, Z, Y, X).copy_(curr.detach().unsqueeze(1).expand(B, T, C, Z, Y, X))
+        return hist
+
+    def _fuse_train(self, curr, flow, sweep):
+        """The reference's op sequence (:264-310) on this module's layers; the warp is the HIP kernel."""
+        T, C = self.history_cat_num, self.single_bev_num_channels
+        B, _, Z, Y, X = curr.shape
+        hist = self.history_bev
+        if hist.stride()[1:] != (Z * Y * X, Y * X, X, 1):
+            hist = hist.contiguous()
+        sampled = _capi.history_warp(hist, flow, torch.empty((B, T * C, Z, Y, X), dtype=torch.float32, device=curr.device))
+        feats_cat = torch.cat([curr, sampled], dim=1)                  # :286
+        f = feats_cat.reshape(B, T + 1, C, Z, Y, X)
+        tchan = (sweep * self.history_cam_sweep_freq)[:, :, None, None, None, None].expand(B, T + 1, 1, Z, Y, X)
+        f = torch.cat([f, tchan], dim=2)                               # :292-295
+        f = self.history_keyframe_time_conv(f.reshape(-1, C + 1, Z, Y, X)).reshape(B, T + 1, -1, Z, Y, X)   # :303-305
+        out = self.history_keyframe_cat_conv(f.reshape(B, -1, Z, Y, X))                                      # :308-310
+        return out, feats_cat
+
+    def _fuse_infer(self, curr, flow, sweep):
+        T, C = self.history_cat_num, self.single_bev_num_channels
+        B, _, Z, Y, X = curr.shape
+        n = Z * Y * X
+        a, b = self._frame_buffers(curr, B, Z, Y, X)
+        hist = self.history_bev
+        nxt = b if hist.data_ptr() == a.data_ptr() else a              # the buffer the history does NOT live in
+        if hist.data_ptr() not in (a.data_ptr(), b.data_ptr()):        # history came from the training path
+            a[:, :T * C].copy_(hist)
+            hist, nxt = a[:, :T * C], b
+        nxt[:, :C].copy_(curr)                                         # slot 0 = current frame (:286)
+        _capi.history_warp(hist, flow, nxt[:, C:])                     # slots 1..T = aligned history (:275)
+        w1, b1 = self._folded(self.history_keyframe_time_conv)
+        w2, b2 = self._folded(self.history_keyframe_cat_conv)
+        tau = (sweep * self.history_cam_sweep_freq).reshape(B * (T + 1), 1)
+        # folded bias already contains scale * conv.bias; the time channel adds scale * W[:, C] * tau = w1[:, C] * tau
+        bias1 = (b1[None, :] + tau * w1[None, :, C]).unsqueeze(-1)    # (B*(T+1), C, 1)
+        y = torch.baddbmm(bias1, w1[:, :C].unsqueeze(0).expand(B * (T + 1), C, C), nxt.view(B * (T + 1), C, n))
+        y.relu_()
+        out = torch.baddbmm(b2.view(1, -1, 1), w2.unsqueeze(0).expand(B, *w2.shape), y.view(B, (T + 1) * C, n))
+        out.relu_()
+        return out.view(B, -1, Z, Y, X), nxt

@@ -231,6 +231,20 @@ int fbbev_bev_pool_v2_dense_bwd(const float* out_grad, long long og_stride_b, lo
                                 int C, int Z, int Y, int X, float* depth_grad, float* feat_grad,
                                 void* workspace, size_t workspace_bytes, fbbev_stream_t stream);
 
+/* Temporal history alignment -- replaces FBOCC.generate_grid + the 5-D F.grid_sample of FBOCC.fuse_history
+ *   -- mmdet3d/models/fbbev/detectors/fbocc.py:169-205 and :264-275.
+ * fbbev_history_flow: rt_flow[b] (4x4, row-major) = inv(feat2bev) . history_forward_augs[b] . curr_to_prev_ego_rt[b]
+ *   . inv(forward_augs[b]) . feat2bev (:184-203), forward_augs = the homogeneous embedding of bda[b] (:36-41),
+ *   feat2bev = diag(dx3) with translation lower3 = bx - dx/2 (:184-195).  dx3 / lower3 are HOST pointers (x,y,z).
+ * fbbev_history_warp: out[b,ch,z,y,x] = trilinear sample (align_corners=True, zero padding) of history[b,ch] at
+ *   rt_flow[b] . (x,y,z,1) -- the sampling grid is never materialised.  history / out: (B,CH,Z,Y,X) f32 with batch
+ *   strides in elements (0 = contiguous), so `out` may be a channel slice of the next history buffer.
+ *   Z, Y, X >= 2 (the reference normalises by size-1). */
+int fbbev_history_flow(const float* history_forward_augs, const float* curr_to_prev_ego_rt, const float* bda,
+                       const float* dx3, const float* lower3, int B, float* rt_flow, fbbev_stream_t stream);
+int fbbev_history_warp(const float* history, long long history_stride_b, const float* rt_flow, int B, int CH, int Z,
+                       int Y, int X, float* out, long long out_stride_b, fbbev_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

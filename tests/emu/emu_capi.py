@@ -158,3 +158,22 @@ def nchw_to_nhwc(x):
     out = torch.full((B, N, H, W, C), float('nan'))
     ok(lib().fbbev_nchw_to_nhwc(p(x), p(out), B * N, C, H * W, None))
     return out
+
+
+def history_flow(hist_augs, ego, bda, dx3, lower3):
+    B = bda.shape[0]
+    flow = torch.full((B, 4, 4), float('nan'))
+    arr = ctypes.c_float * 3
+    d, lo = arr(*[float(v) for v in dx3]), arr(*[float(v) for v in lower3])
+    ok(lib().fbbev_history_flow(p(hist_augs), p(ego), p(bda), ctypes.cast(d, c_void_p), ctypes.cast(lo, c_void_p), B,
+                                p(flow), None))
+    return flow
+
+
+def history_warp(history, flow, out=None):
+    B, CH, Z, Y, X = history.shape
+    if out is None:
+        out = torch.full((B, CH, Z, Y, X), float('nan'))
+    ok(lib().fbbev_history_warp(c_void_p(history.data_ptr()), history.stride(0), p(flow), B, CH, Z, Y, X,
+                                c_void_p(out.data_ptr()), out.stride(0), None))
+    return out

@@ -40,3 +40,21 @@ def test_forward_refuses_cpu_tensors():
     with pytest.raises(_capi.FbbevError):
         att(q, query_pos=q, reference_points=torch.zeros(1, 16, 1, 2), spatial_shapes=torch.tensor([[4, 4]]),
             level_start_index=torch.tensor([0]))
+
+
+def test_history_fusion_module_builds_with_detector_key_names():
+    """fbocc.py:111-127: the two Sequentials keep their names so a detector checkpoint loads unchanged."""
+    import pytest
+    import torch
+    from fb_bev_amd import _capi
+    from fb_bev_amd.history_fusion import TemporalHistoryFusion
+    m = TemporalHistoryFusion([0.8, 0.8, 0.8], [-39.6, -39.6, -0.6], single_bev_num_channels=80, history_cat_num=16)
+    keys = set(m.state_dict().keys())
+    assert {'history_keyframe_time_conv.0.weight', 'history_keyframe_time_conv.1.running_mean',
+            'history_keyframe_cat_conv.0.weight', 'history_keyframe_cat_conv.1.running_var'} <= keys
+    assert tuple(m.history_keyframe_time_conv[0].weight.shape) == (80, 81, 1, 1, 1)
+    assert tuple(m.history_keyframe_cat_conv[0].weight.shape) == (80, 80 * 17, 1, 1, 1)
+    assert m.lower == pytest.approx([-40.0, -40.0, -1.0])
+    with pytest.raises(_capi.FbbevError):      # no CPU fallback
+        m.fuse_history(torch.zeros(1, 80, 4, 4, 2), [dict(sequence_group_idx=0, start_of_sequence=True,
+                                                          curr_to_prev_ego_rt=torch.eye(4))], torch.eye(3)[None])

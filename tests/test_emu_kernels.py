@@ -297,3 +297,62 @@ def test_pool_dense_bwd_empty_index_writes_zeros():
     og = torch.randn((1, C, Z, Y, X), generator=torch.Generator().manual_seed(1))
     code, dg, fg = E.pool_dense_bwd(og, depth, feat, rd, ir, st, counts, st.numel(), (Z, Y, X))
     assert code == 0 and not dg.any() and not fg.any()
+
+
+# ------------------------------------------------------------------ temporal history alignment
+def _history_fixture():
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'history_fusion_seq4.npz'))
+    return z, [int(v) for v in z['dims']]
+
+
+def test_history_flow_and_warp_emulated_vs_reference_fixture():
+    """k_history_flow + k_history_warp against the grid / sampled volume recorded from the real
+    FBOCC.generate_grid + F.grid_sample (fbocc.py:169-205,264-275)."""
+    from oracle import history_oracle as H
+    z, (B, C, T, Z, Y, X) = _history_fixture()
+    dx, bx = z['dx'], z['bx']
+    lower = bx - dx / 2
+    hist_augs = None
+    for i in range(4):
+        f = {k: torch.from_numpy(z[f'f{i}.{k}']) for k in ('curr', 'bda', 'ego', 'start', 'grid', 'sampled', 'history_after')}
+        fwd = H.forward_aug_matrix(f['bda'])
+        if hist_augs is None:
+            hist_augs = fwd.clone()
+        hist_augs[f['start'].bool()] = fwd[f['start'].bool()]
+        flow = E.history_flow(hist_augs.contiguous(), f['ego'].contiguous(), f['bda'].contiguous(), dx, lower)
+        eflow = H.rt_flow(hist_augs, fwd, f['ego'], torch.from_numpy(dx), torch.from_numpy(bx))
+        assert torch.allclose(flow, eflow, atol=2e-5, rtol=1e-5), i
+        grid = H.generate_grid(flow, (Z, Y, X)).permute(0, 3, 1, 2, 4)
+        assert torch.allclose(grid, f['grid'], atol=3e-5), i
+        # history entering frame i = history_after of frame i-1 with restarted samples overwritten (fbocc.py:253-257)
+        if i == 0:
+            hist = f['curr'].permute(0, 1, 4, 2, 3).repeat(1, T, 1, 1, 1).contiguous()
+        else:
+            hist = torch.from_numpy(z[f'f{i - 1}.history_after']).clone()
+            st = f['start'].bool()
+            hist[st] = f['curr'].permute(0, 1, 4, 2, 3)[st].repeat(1, T, 1, 1, 1)
+        out = E.history_warp(hist, flow)
+        assert not torch.isnan(out).any()
+        assert torch.allclose(out, f['sampled'], atol=2e-4), i                # vs the reference's own kernel
+        assert torch.allclose(out, H.warp_history(hist, flow), atol=1e-5), i  # vs the oracle on the same rt_flow
+        hist_augs = fwd.clone()
+
+
+def test_history_warp_strided_output_and_padding_emulated():
+    from oracle import history_oracle as H
+    g = torch.Generator().manual_seed(4)
+    B, CH, Z, Y, X = 2, 11, 3, 9, 21                                         # odd channel count: tail path
+    hist = torch.randn(B, CH, Z, Y, X, generator=g)
+    flow = torch.eye(4)[None].repeat(B, 1, 1)
+    flow[0, :3, 3] = torch.tensor([2.5, -1.25, 0.5])                         # translation: part of the volume leaves the grid
+    flow[1, :3, :3] = torch.tensor([[0.9, -0.4, 0.0], [0.4, 0.9, 0.0], [0.0, 0.0, 1.0]])
+    big = torch.full((B, CH + 5, Z, Y, X), float('nan'))
+    E.history_warp(hist, flow, big[:, 5:])                                   # write into a channel slice (batch stride)
+    exp = H.warp_history(hist, flow)
+    assert torch.allclose(big[:, 5:], exp, atol=1e-5)
+    assert torch.isnan(big[:, :5]).all()
+    assert (exp[0, :, :, :, -2:] == 0).all()                                 # x + 2.5 > X-1: zero padding
+    ident = E.history_warp(hist, torch.eye(4)[None].repeat(B, 1, 1).contiguous())
+    assert torch.allclose(ident, hist, atol=1e-6)
+    nanflow = flow.clone(); nanflow[0, 0, 0] = float('nan')
+    assert (E.history_warp(hist, nanflow)[0] == 0).all()                     # NaN coordinates sample nothing

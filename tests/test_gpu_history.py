@@ -1,0 +1,116 @@
+"""GPU parity of the temporal history fusion against fixtures recorded from the REAL
+FBOCC.fuse_history (tests/golden/make_golden_history.py) and against the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), 'golden', 'history_fusion_seq4.npz')
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device('cuda:0')
+
+
+def _module(z, dev, **kw):
+    from fb_bev_amd.history_fusion import TemporalHistoryFusion
+    B, C, T, Z, Y, X = (int(v) for v in z['dims'])
+    m = TemporalHistoryFusion(z['dx'], z['bx'], single_bev_num_channels=C, history_cat_num=T, **kw).to(dev).eval()
+    sd = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('w.')}
+    m.load_state_dict(sd)                      # the detector's own key names (fbocc.py:111-127)
+    return m, (B, C, T, Z, Y, X)
+
+
+def _metas(z, i):
+    return [dict(sequence_group_idx=int(z[f'f{i}.seq'][b]), start_of_sequence=bool(z[f'f{i}.start'][b]),
+                 curr_to_prev_ego_rt=torch.from_numpy(z[f'f{i}.ego'][b])) for b in range(len(z[f'f{i}.seq']))]
+
+
+@pytest.mark.parametrize('grad', [False, True])
+def test_sequence_matches_reference_fixture(dev, grad):
+    z = np.load(G)
+    m, (B, C, T, Z, Y, X) = _module(z, dev)
+    for i in range(4):
+        curr = torch.from_numpy(z[f'f{i}.curr']).to(dev).requires_grad_(grad)
+        bda = torch.from_numpy(z[f'f{i}.bda']).to(dev)
+        with torch.set_grad_enabled(grad):
+            out = m.fuse_history(curr, _metas(z, i), bda)
+        assert out.shape == (B, C, Y, X, Z)
+        assert (out.detach().cpu() - torch.from_numpy(z[f'f{i}.out'])).abs().max().item() < 3e-4, i
+        assert (m.history_bev.cpu() - torch.from_numpy(z[f'f{i}.history_after'])).abs().max().item() < 3e-4, i
+        assert torch.equal(m.history_sweep_time, torch.from_numpy(z[f'f{i}.sweep_time_after'])), i
+        if grad:
+            out.sum().backward()
+            assert curr.grad is not None and torch.isfinite(curr.grad).all()
+
+
+def test_warp_kernel_vs_reference_grid_sample_and_oracle(dev):
+    from fb_bev_amd import _capi
+    from oracle import history_oracle as H
+    g = torch.Generator().manual_seed(2)
+    B, CH, Z, Y, X = 2, 37, 8, 50, 60
+    hist = torch.randn(B, CH, Z, Y, X, generator=g)
+    flow = torch.eye(4)[None].repeat(B, 1, 1)
+    flow[0, :3, 3] = torch.tensor([3.25, -1.5, 0.3])
+    c, s = np.cos(0.2), np.sin(0.2)
+    flow[1, :3, :3] = torch.tensor([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]], dtype=torch.float32)
+    flow[1, :3, 3] = torch.tensor([4.0, -6.0, -0.2])
+    big = torch.full((B, CH + 3, Z, Y, X), float('nan'), device=dev)
+    _capi.history_warp(hist.to(dev), flow.to(dev), big[:, 3:])
+    grid = H.generate_grid(flow, (Z, Y, X)).permute(0, 3, 1, 2, 4)
+    ref = H.grid_sample_reference(hist, grid)                   # torch's CPU grid_sample on the reference's grid
+    assert (big[:, 3:].cpu() - ref).abs().max().item() < 2e-4
+    assert (big[:, 3:].cpu() - H.grid_sample_3d(hist, grid)).abs().max().item() < 2e-4
+    assert torch.isnan(big[:, :3]).all()
+
+
+def test_history_flow_kernel(dev):
+    from fb_bev_amd import _capi
+    from oracle import history_oracle as H
+    g = torch.Generator().manual_seed(3)
+    B = 5
+    def rigid():
+        a = (torch.rand(1, generator=g).item() - 0.5) * 0.6
+        m = torch.eye(4)
+        m[:2, :2] = torch.tensor([[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]], dtype=torch.float32)
+        m[:3, 3] = torch.randn(3, generator=g)
+        return m
+    hist_augs = torch.stack([rigid() for _ in range(B)]); hist_augs[:, :3, 3] = 0
+    ego = torch.stack([rigid() for _ in range(B)])
+    bda = torch.stack([rigid()[:3, :3] for _ in range(B)]) * torch.tensor([1., -1., 1.])
+    dx, bx = torch.tensor([0.4, 0.4, 0.4]), torch.tensor([-39.8, -39.8, -0.8])
+    flow = _capi.history_flow(hist_augs.to(dev), ego.to(dev), bda.contiguous().to(dev), dx.tolist(), (bx - dx / 2).tolist())
+    exp = H.rt_flow(hist_augs.double(), H.forward_aug_matrix(bda.double()), ego.double(), dx.double(), bx.double())
+    assert (flow.cpu().double() - exp).abs().max().item() < 2e-4        # entries up to ~200 voxels, fp32
+
+
+def test_inference_path_keeps_history_as_a_view_and_is_sync_free(dev):
+    z = np.load(G)
+    m, (B, C, T, Z, Y, X) = _module(z, dev)
+    for i in range(2):
+        m.fuse_history(torch.from_numpy(z[f'f{i}.curr']).to(dev), _metas(z, i), torch.from_numpy(z[f'f{i}.bda']).to(dev))
+    assert m.history_bev.data_ptr() in (m._bufs[0].data_ptr(), m._bufs[1].data_ptr())
+    curr = torch.from_numpy(z['f2.curr']).to(dev)
+    bda = torch.from_numpy(z['f2.bda']).to(dev)
+    metas = _metas(z, 2)
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode('error')
+    try:
+        out = m.fuse_history(curr, metas, bda)
+    finally:
+        torch.cuda.set_sync_debug_mode('default')
+    assert (out.cpu() - torch.from_numpy(z['f2.out'])).abs().max().item() < 3e-4
+
+
+def test_do_history_false_uses_only_the_current_frame(dev):
+    z = np.load(G)
+    m, (B, C, T, Z, Y, X) = _module(z, dev, do_history=False)
+    outs = []
+    for i in (0, 1):       # identity ego motion, different bda: rt_flow = inv(f2b).fwd.I.inv(fwd).f2b = I
+        outs.append(m.fuse_history(torch.from_numpy(z['f0.curr']).to(dev), _metas(z, 0), torch.from_numpy(z[f'f{i}.bda']).to(dev)))
+        assert m.history_bev is None
+    assert torch.allclose(outs[0], outs[1], atol=1e-4)      # no state carried over

@@ -60,3 +60,36 @@ def test_sequence_restart_resets_history():
         assert torch.allclose(hist[t], curr, atol=1e-5)
     assert fr[2]['sweep_time_after'][1].tolist() == [0.0] * T
     assert fr[2]['sweep_time_after'][0].tolist() == [0.0, 1.0, 2.0]
+
+
+def test_module_state_logic_on_cpu_with_oracle_standing_in_for_the_hip_calls(monkeypatch):
+    """Host logic of fb_bev_amd.history_fusion (buffers, restarts, folded convs, both paths) exercised on CPU: the two
+    HIP entry points are replaced by the oracle FOR THIS TEST ONLY (the product has no such fallback; the real
+    kernels are checked by tests/test_gpu_history.py and the emulator tests)."""
+    from fb_bev_amd import _capi
+    from fb_bev_amd.history_fusion import TemporalHistoryFusion
+    z, (B, C, T, Z, Y, X), sd = load()
+    dx, bx = torch.from_numpy(z['dx']), torch.from_numpy(z['bx'])
+
+    def flow_stub(hist_augs, ego, bda, dx3, lower3):
+        return H.rt_flow(hist_augs, H.forward_aug_matrix(bda), ego, dx, bx)
+
+    def warp_stub(history, flow, out):
+        out.copy_(H.warp_history(history, flow))
+        return out
+    monkeypatch.setattr(_capi, 'history_flow', flow_stub)
+    monkeypatch.setattr(_capi, 'history_warp', warp_stub)
+    monkeypatch.setattr(_capi, 'require_gpu', lambda t, name: None)
+    for grad in (False, True):
+        m = TemporalHistoryFusion(z['dx'], z['bx'], single_bev_num_channels=C, history_cat_num=T).eval()
+        m.load_state_dict(sd)
+        for i, f in frames(z):
+            metas = [dict(sequence_group_idx=int(f['seq'][b]), start_of_sequence=bool(f['start'][b]),
+                          curr_to_prev_ego_rt=f['ego'][b]) for b in range(B)]
+            with torch.set_grad_enabled(grad):
+                out = m.fuse_history(f['curr'].clone().requires_grad_(grad), metas, f['bda'])
+            assert torch.allclose(out.detach(), f['out'], atol=2e-4), (grad, i)
+            assert torch.allclose(m.history_bev, f['history_after'], atol=2e-4), (grad, i)
+            assert torch.equal(m.history_sweep_time, f['sweep_time_after']), (grad, i)
+        if not grad:
+            assert m.history_bev.data_ptr() in (m._bufs[0].data_ptr(), m._bufs[1].data_ptr())   # a view, not a clone
