@@ -40,6 +40,8 @@ def parse():
     ap.add_argument('--config', default='BL2')
     ap.add_argument('--tile-voxels', type=int, default=None, help='default: chosen by grid density')
     ap.add_argument('--pool-flags', type=lambda x: int(x, 0), default=None)
+    ap.add_argument('--storage', choices=['f32', 'bf16', 'f16'], default='f32',
+                    help='element type the BEV volume is STORED in (sums are always fp32); the reference is f32')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     return ap.parse_args()
@@ -119,7 +121,9 @@ def main():
     C = cfg.channels
     tile_ws = vt._tile_ws(dev, B)
     flags = vt.pool_flags
-    out = torch.empty((B, C, Z, Y, X), dtype=torch.float32, device=dev)
+    store_dt = {'f32': torch.float32, 'bf16': torch.bfloat16, 'f16': torch.float16}[args.storage]
+    esz = 4 if args.storage == 'f32' else 2
+    out = torch.empty((B, C, Z, Y, X), dtype=store_dt, device=dev)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(args.steps)]
 
@@ -161,19 +165,19 @@ def main():
         b.record()
         torch.cuda.synchronize(dev)
         fill_ms.append(a.elapsed_time(b))
-    fill_gbs = out.numel() * 4 / (sorted(fill_ms)[len(fill_ms) // 2] * 1e-3) / 1e9
+    fill_gbs = out.numel() * esz / (sorted(fill_ms)[len(fill_ms) // 2] * 1e-3) / 1e9
     P, I = idx.counts.tolist()
     D = cfg.D
     H, W = cfg.feat_hw
     algo_bytes = 4 * B * cfg.n_cams * D * H * W + 4 * B * cfg.n_cams * H * W * C + 4 * (3 * P + 2 * I) + \
-        4 * B * Z * Y * X * C
+        esz * B * Z * Y * X * C
     achieved = algo_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
     traffic = None
     tj = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     if os.path.exists(tj):
         try:
             rec = json.load(open(tj))
-            key = f'{cfg.name}_B{B}_tv{args.tile_voxels}'
+            key = f'{cfg.name}_B{B}_tv{args.tile_voxels}' + ('' if args.storage == 'f32' else '_' + args.storage)
             traffic = rec.get(key, {}).get('hbm_bytes_per_launch')
         except Exception:
             traffic = None
@@ -189,7 +193,7 @@ def main():
                                    f'({cfg.name}): 6x{cfg.input_size[0]}x{cfg.input_size[1]} in, '
                                    f'feat {H}x{W}, D={D}, C={C}, grid {X}x{Y}x{Z}; index tensors rebuilt every step',
                        'samples_per_gpu': B, 'global_batch': B * world, 'points_kept': P, 'intervals': I,
-                       'tile_voxels': args.tile_voxels, 'pool_flags': hex(flags), 'parallelism': f'dp{world} (independent samples, no collective)'},
+                       'tile_voxels': args.tile_voxels, 'pool_flags': hex(flags), 'volume_storage': args.storage, 'parallelism': f'dp{world} (independent samples, no collective)'},
             'roofline': {'kernel': 'k_pool_fwd_dense2', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'algorithmic_bytes_per_launch': algo_bytes, 'kernel_ms': kern_ms,

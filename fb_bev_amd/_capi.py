@@ -207,6 +207,7 @@ DEFAULT_TILE_VOXELS = 128
 
 
 POOL_CHANNELS_LAST = 0x100000
+POOL_OUT_BF16, POOL_OUT_F16 = 0x800000, 0x1000000
 
 
 def pool_tile_index(interval_rank, interval_starts, counts, n_intervals_max, B, Z, Y, X, tile_ws,
@@ -224,8 +225,10 @@ def bev_pool_v2_dense_fwd(depth, feat, ranks_depth, ranks_feat, interval_rank, i
                           flags=DEFAULT_POOL_FLAGS):
     """`out` is (B,C,Z,Y,X) f32 whose (Z,Y,X) block is contiguous (batch/channel strides may be padded), or,
     with POOL_CHANNELS_LAST in `flags`, a contiguous (B,Z,Y,X,C) tensor (the reference op's own layout)."""
-    if out.dtype != F32 or not out.is_cuda:
-        raise FbbevError('out must be a GPU float32 tensor')
+    if not out.is_cuda or out.dtype not in (F32, torch.bfloat16, torch.float16):
+        raise FbbevError('out must be a GPU float32 / bfloat16 / float16 tensor')
+    flags = int(flags) & ~(POOL_OUT_BF16 | POOL_OUT_F16)
+    flags |= {F32: 0, torch.bfloat16: POOL_OUT_BF16, torch.float16: POOL_OUT_F16}[out.dtype]   # storage type follows `out`
     if flags & POOL_CHANNELS_LAST:
         if tuple(out.shape) != (B, Z, Y, X, C) or not out.is_contiguous():
             raise FbbevError('channels-last out must be a contiguous (B,Z,Y,X,C) tensor')

@@ -392,15 +392,14 @@ extern "C" int fbbev_pool_tile_index(const int32_t* interval_rank, const int32_t
 struct dense2_args {
     long long n_blocks; size_t lds; fbbev_rt_stream stream; int C, Z, yx, tpp, csplit, swizzle;
     long long stride_b, stride_c;
-    int deep;   // 8 points per load batch instead of 4
     const float *depth, *feat; const int32_t *rd, *rf, *irank, *starts, *lengths; const int* tile_meta;
     float* out;
 };
 
-template <int TV, int CPL, int ST, int NT, int UB>
-static int launch_dense2u(const dense2_args& a) {
+template <int TV, int CPL, int ST, int NT, int OT>
+static int launch_dense2(const dense2_args& a) {
     if (a.lds > 64 * 1024) {  // > 64 KiB of dynamic LDS must be opted into (160 KiB per CU on gfx950)
-        int e = fbbev_rt_allow_dyn_lds((const void*)k_pool_fwd_dense2<TV, CPL, ST, NT, UB>, a.lds);
+        int e = fbbev_rt_allow_dyn_lds((const void*)k_pool_fwd_dense2<TV, CPL, ST, NT, OT>, a.lds);
         if (e) return e;
     }
     long long grid = a.n_blocks;
@@ -408,19 +407,18 @@ static int launch_dense2u(const dense2_args& a) {
         const long long g = 8ll << (a.swizzle - 1);
         grid = (a.n_blocks + g - 1) / g * g;
     }
-    FBBEV_LAUNCH((k_pool_fwd_dense2<TV, CPL, ST, NT, UB>), grid, NT, a.lds, a.stream, a.C, a.Z, a.yx, a.tpp,
+    FBBEV_LAUNCH((k_pool_fwd_dense2<TV, CPL, ST, NT, OT>), grid, NT, a.lds, a.stream, a.C, a.Z, a.yx, a.tpp,
                  a.csplit, (int)a.n_blocks, a.swizzle, a.stride_b, a.stride_c, a.depth, a.feat, a.rd, a.rf, a.irank, a.starts, a.lengths, a.tile_meta, a.out);
     return fbbev_rt_last_error();
 }
 
-template <int TV, int CPL, int ST, int NT>
-static int launch_dense2(const dense2_args& a) {
-    return a.deep ? launch_dense2u<TV, CPL, ST, NT, 8>(a) : launch_dense2u<TV, CPL, ST, NT, 4>(a);
-}
-
 template <int TV, int CPL, int ST>
-static int launch_dense2_nt(int nt, const dense2_args& a) {
-    return nt == 128 ? launch_dense2<TV, CPL, ST, 128>(a) : launch_dense2<TV, CPL, ST, 256>(a);
+static int launch_dense2_nt(int nt, int ot, const dense2_args& a) {
+    if constexpr (ST == 4) {      // 16-bit output storage is built for the default store policy only
+        if (ot == 1) return nt == 128 ? launch_dense2<TV, CPL, 4, 128, 1>(a) : launch_dense2<TV, CPL, 4, 256, 1>(a);
+        if (ot == 2) return nt == 128 ? launch_dense2<TV, CPL, 4, 128, 2>(a) : launch_dense2<TV, CPL, 4, 256, 2>(a);
+    }
+    return nt == 128 ? launch_dense2<TV, CPL, ST, 128, 0>(a) : launch_dense2<TV, CPL, ST, 256, 0>(a);
 }
 
 template <int TV, int CPL, int ST, int NT>
@@ -444,17 +442,14 @@ static int launch_dense_cl_st(int st, const dense2_args& a) {
     }
 }
 
+// store cache policy: 0 plain, 1 nontemporal, anything else -> `sc1 nt` (4), the measured best
 template <int TV, int CPL>
-static int launch_dense2_st(int st, int nt, const dense2_args& a) {
+static int launch_dense2_st(int st, int nt, int ot, const dense2_args& a) {
+    if (ot != 0) return launch_dense2_nt<TV, CPL, 4>(nt, ot, a);
     switch (st) {
-        case 0: return launch_dense2_nt<TV, CPL, 0>(nt, a);
-        case 2: return launch_dense2_nt<TV, CPL, 2>(nt, a);
-        case 3: return launch_dense2_nt<TV, CPL, 3>(nt, a);
-        case 4: return launch_dense2_nt<TV, CPL, 4>(nt, a);
-        case 5: return launch_dense2_nt<TV, CPL, 5>(nt, a);
-        case 6: return launch_dense2_nt<TV, CPL, 6>(nt, a);
-        case 7: return launch_dense2_nt<TV, CPL, 7>(nt, a);
-        default: return launch_dense2_nt<TV, CPL, 1>(nt, a);
+        case 0: return launch_dense2_nt<TV, CPL, 0>(nt, 0, a);
+        case 1: return launch_dense2_nt<TV, CPL, 1>(nt, 0, a);
+        default: return launch_dense2_nt<TV, CPL, 4>(nt, 0, a);
     }
 }
 
@@ -481,6 +476,12 @@ extern "C" int fbbev_bev_pool_v2_dense_fwd(const float* depth, const float* feat
     const long long n_tiles = (long long)B * Z * tiles_per_plane;
     if (tile_ws_bytes < (size_t)(n_tiles + 1) * 8) return FBBEV_E_WORKSPACE;
     const int st = (flags & FBBEV_POOL_STORE_MASK) | ((flags >> FBBEV_POOL_STORE_HI_SHIFT) & 1) << 2;
+    const int ot = (flags & FBBEV_POOL_OUT_BF16) ? 1 : ((flags & FBBEV_POOL_OUT_F16) ? 2 : 0);
+    if (ot != 0) {   // 16-bit storage: 8 elements per 16-byte store
+        if ((flags & FBBEV_POOL_OUT_BF16) && (flags & FBBEV_POOL_OUT_F16)) return FBBEV_E_BADARG;
+        if (flags & FBBEV_POOL_CHANNELS_LAST) return FBBEV_E_UNSUPPORTED;
+        if (yx % 8 != 0 || out_stride_c % 8 != 0 || out_stride_b % 8 != 0) return FBBEV_E_UNSUPPORTED;
+    }
     if (flags & FBBEV_POOL_CHANNELS_LAST) {
         // out is (B,Z,Y,X,C) contiguous: flat tiles, linear store stream, no LDS value tile
         if (out_stride_b != (long long)C * Z * yx || out_stride_c != (long long)Z * yx) return FBBEV_E_BADARG;
@@ -521,7 +522,7 @@ extern "C" int fbbev_bev_pool_v2_dense_fwd(const float* depth, const float* feat
         }
         a.depth = depth; a.feat = feat; a.rd = ranks_depth; a.rf = ranks_feat; a.irank = interval_rank;
         a.starts = interval_starts; a.lengths = interval_lengths; a.tile_meta = static_cast<const int*>(tile_ws);
-        a.out = out; a.stride_b = 0; a.stride_c = 0; a.deep = 0;
+        a.out = out; a.stride_b = 0; a.stride_c = 0;
         if (TV == 64) return cpl8cl ? launch_dense_cl_st<64, 8>(st, a) : launch_dense_cl_st<64, 4>(st, a);
         if (TV == 128) return cpl8cl ? launch_dense_cl_st<128, 8>(st, a) : launch_dense_cl_st<128, 4>(st, a);
         if (TV == 256) return cpl8cl ? launch_dense_cl_st<256, 8>(st, a) : launch_dense_cl_st<256, 4>(st, a);
@@ -541,8 +542,6 @@ extern "C" int fbbev_bev_pool_v2_dense_fwd(const float* depth, const float* feat
     a.n_blocks = n_tiles * csplit;
     a.lds = ((size_t)CC * (TV + 4) + 3 * (size_t)TV + 2 * FBBEV_NP_STAGE) * sizeof(float);
     a.stream = stream; a.C = C; a.Z = Z; a.yx = (int)yx; a.tpp = tiles_per_plane; a.csplit = csplit;
-    if (flags & FBBEV_POOL_DIAG_NO_META) a.csplit |= 0x40000000;   // diagnostic only (wrong output)
-    if (flags & FBBEV_POOL_CHANNEL_MAJOR) a.csplit |= 0x20000000;
     a.swizzle = 0;
     if (flags & FBBEV_POOL_XCD_SWIZZLE) {
         int lg = (flags >> FBBEV_POOL_SWZ_CHUNK_SHIFT) & 0x1F;   // log2(tiles per chunk); 0 -> default
@@ -552,12 +551,12 @@ extern "C" int fbbev_bev_pool_v2_dense_fwd(const float* depth, const float* feat
     if (a.n_blocks + 8 >= (1ll << 31) || a.lds > 160 * 1024) return FBBEV_E_UNSUPPORTED;
     a.depth = depth; a.feat = feat; a.rd = ranks_depth; a.rf = ranks_feat; a.irank = interval_rank;
     a.starts = interval_starts; a.lengths = interval_lengths; a.tile_meta = static_cast<const int*>(tile_ws);
-    a.out = out; a.stride_b = out_stride_b; a.stride_c = out_stride_c; a.deep = (flags & FBBEV_POOL_DEEP_BATCH) ? 1 : 0;
-    if (TV == 64) return cpl8 ? launch_dense2_st<64, 8>(st, nt, a) : launch_dense2_st<64, 4>(st, nt, a);
-    if (TV == 128) return cpl8 ? launch_dense2_st<128, 8>(st, nt, a) : launch_dense2_st<128, 4>(st, nt, a);
-    if (TV == 256) return cpl8 ? launch_dense2_st<256, 8>(st, nt, a) : launch_dense2_st<256, 4>(st, nt, a);
-    if (TV == 512) return cpl8 ? launch_dense2_st<512, 8>(st, nt, a) : launch_dense2_st<512, 4>(st, nt, a);
-    return cpl8 ? launch_dense2_st<1024, 8>(st, nt, a) : launch_dense2_st<1024, 4>(st, nt, a);
+    a.out = out; a.stride_b = out_stride_b; a.stride_c = out_stride_c;
+    if (TV == 64) return cpl8 ? launch_dense2_st<64, 8>(st, nt, ot, a) : launch_dense2_st<64, 4>(st, nt, ot, a);
+    if (TV == 128) return cpl8 ? launch_dense2_st<128, 8>(st, nt, ot, a) : launch_dense2_st<128, 4>(st, nt, ot, a);
+    if (TV == 256) return cpl8 ? launch_dense2_st<256, 8>(st, nt, ot, a) : launch_dense2_st<256, 4>(st, nt, ot, a);
+    if (TV == 512) return cpl8 ? launch_dense2_st<512, 8>(st, nt, ot, a) : launch_dense2_st<512, 4>(st, nt, ot, a);
+    return cpl8 ? launch_dense2_st<1024, 8>(st, nt, ot, a) : launch_dense2_st<1024, 4>(st, nt, ot, a);
 }
 
 // ------------------------------------------------------------------------------ MSDeformAttn
@@ -745,8 +744,9 @@ extern "C" int fbbev_history_warp(const float* history, long long history_stride
     const int n_groups = (CH + cpb - 1) / cpb;
     const long long blocks = (long long)B * n_groups * n_chunks;
     if (blocks >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
-    FBBEV_LAUNCH(k_history_warp, blocks, 256, 0, (fbbev_rt_stream)stream_, history, history_stride_b, rt_flow, CH, Z, Y, X,
-                 cpb, n_groups, n_chunks, out, out_stride_b);
+    const int per_xcd = (int)((blocks + 7) / 8);
+    FBBEV_LAUNCH(k_history_warp, (long long)per_xcd * 8, 256, 0, (fbbev_rt_stream)stream_, history, history_stride_b, rt_flow,
+                 CH, Z, Y, X, cpb, n_groups, n_chunks, per_xcd, (int)blocks, out, out_stride_b);
     FBBEV_CHECK_LAUNCH();
     return 0;
 }

@@ -49,13 +49,17 @@ k_history_flow(const float* __restrict__ hist_augs, const float* __restrict__ eg
     for (int k = 0; k < 16; ++k) flow[b * 16 + k] = c[k];
 }
 
-// blockIdx.x = ((b * n_groups) + group) * n_chunks + chunk
+// work item = ((b * n_groups) + group) * n_chunks + chunk
 __global__ void __launch_bounds__(256)
 k_history_warp(const float* __restrict__ hist, long long hist_stride_b, const float* __restrict__ flow, int CH,
-               int Z, int Y, int X, int ch_per_block, int n_groups, int n_chunks, float* __restrict__ out,
-               long long out_stride_b) {
-    const int chunk = blockIdx.x % n_chunks;
-    const int bg = blockIdx.x / n_chunks;
+               int Z, int Y, int X, int ch_per_block, int n_groups, int n_chunks, int per_xcd, int n_work,
+               float* __restrict__ out, long long out_stride_b) {
+    // workgroup b runs on XCD b%8: give each XCD one contiguous eighth of the (sample, channel group, chunk) space so
+    // that the y-neighbour taps of adjacent chunks are re-used from that XCD's own L2
+    const int work = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per_xcd || work >= n_work) return;
+    const int chunk = work % n_chunks;
+    const int bg = work / n_chunks;
     const int grp = bg % n_groups, b = bg / n_groups;
     const int YX = Y * X, ZYX = Z * YX;
     const int v = chunk * 256 + threadIdx.x;

@@ -266,7 +266,51 @@ k_tile_lower_bound2(int n_tiles, int tiles_per_plane, int YX, int TV,
     tile_meta[2 * t + 1] = (lo < n) ? starts[lo] : P;
 }
 
-template <int TV, int CPL, int ST, int NT, int UB>
+// OT: element type of `out` -- 0 f32, 1 bf16, 2 f16.  The per-voxel sums are ALWAYS the fp32 in-order fmaf chains;
+// 16-bit storage rounds them once (nearest-even) at the store: BASELINE configs[1] (bf16) / configs[4] (fp16).
+// IEEE binary32 -> binary16 bits, round to nearest even, overflow -> inf, NaN -> quiet NaN (integer arithmetic only,
+// so the CPU emulator and the GPU produce the same bits)
+__device__ __forceinline__ unsigned int fbbev_f32_to_f16(float f) {
+    unsigned int u;
+    __builtin_memcpy(&u, &f, 4);
+    const unsigned int sign = (u >> 16) & 0x8000u;
+    u &= 0x7fffffffu;
+    unsigned int o;
+    if (u >= ((127u + 16u) << 23)) {
+        o = (u > 0x7f800000u) ? 0x7e00u : 0x7c00u;
+    } else if (u < (113u << 23)) {                       // result is a half subnormal (or zero)
+        const unsigned int magic = ((127u - 15u) + (23u - 10u) + 1u) << 23;
+        float t, m;
+        __builtin_memcpy(&t, &u, 4);
+        __builtin_memcpy(&m, &magic, 4);
+        t += m;                                          // the fp32 add performs the nearest-even rounding
+        unsigned int r;
+        __builtin_memcpy(&r, &t, 4);
+        o = r - magic;
+    } else {
+        const unsigned int odd = (u >> 13) & 1u;
+        u += ((unsigned int)(15 - 127) << 23) + 0xfffu;
+        u += odd;
+        o = u >> 13;
+    }
+    return sign | o;
+}
+
+template <int OT>
+__device__ __forceinline__ unsigned int fbbev_pack2(float lo, float hi) {
+    if constexpr (OT == 1) {
+        unsigned int a, b;
+        __builtin_memcpy(&a, &lo, 4);
+        __builtin_memcpy(&b, &hi, 4);
+        a = ((a & 0x7fffffffu) > 0x7f800000u) ? ((a >> 16) | 0x40u) : ((a + 0x7fffu + ((a >> 16) & 1u)) >> 16);
+        b = ((b & 0x7fffffffu) > 0x7f800000u) ? ((b >> 16) | 0x40u) : ((b + 0x7fffu + ((b >> 16) & 1u)) >> 16);
+        return (a & 0xffffu) | (b << 16);
+    } else {
+        return fbbev_f32_to_f16(lo) | (fbbev_f32_to_f16(hi) << 16);
+    }
+}
+
+template <int TV, int CPL, int ST, int NT, int OT>
 __global__ void __launch_bounds__(NT)
 k_pool_fwd_dense2(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_blocks, int swizzle,
                   long long out_stride_b, long long out_stride_c,
@@ -277,8 +321,6 @@ k_pool_fwd_dense2(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_b
                   float* __restrict__ out) {
     constexpr int LD = TV + 4;
     constexpr int Q4 = TV / 4;
-    const int csplit_raw = csplit;
-    csplit &= 0x1FFFFFFF;
     const int CC = C / csplit;                 // channels handled by this block
     float* tile = fbbev_dyn_lds_f32();         // [CC][LD]
     int* ist = reinterpret_cast<int*>(tile + CC * LD);   // [TV] interval start relative to p0
@@ -298,32 +340,35 @@ k_pool_fwd_dense2(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_b
         bid = ((((j >> sh) << 3) + xcd) << sh) + (j & ((1 << sh) - 1));
     }
     if (bid >= n_blocks) return;
-    // tile-major: the csplit channel groups of a tile are adjacent workgroups (index/feat reads shared through
-    // L2); channel-major (csplit_raw bit 29): the whole grid sweeps channel group 0 over all tiles, then
-    // group 1, ... -> few output planes are written at any one time (near-linear DRAM streams).
-    const int n_tiles_k = n_blocks / csplit;
-    const bool chan_major = (csplit_raw & 0x20000000) != 0;
-    const int t = chan_major ? (bid % n_tiles_k) : (bid / csplit);
-    const int half = chan_major ? (bid / n_tiles_k) : (bid - t * csplit);
+    // tile-major: the csplit channel groups of a tile are adjacent workgroups (index / feat reads shared through L2)
+    const int t = bid / csplit;
+    const int half = bid - t * csplit;
     const int c0 = half * CC;
     const int plane = t / tiles_per_plane, k = t - plane * tiles_per_plane;
     const int b = plane / Z, z = plane - b * Z;
     const int v0 = k * TV;
     const int nv = (YX - v0 < TV) ? (YX - v0) : TV;
-    // swizzle bit 30 = diagnostic: treat every tile as empty WITHOUT touching the metadata (measures the
-    // pure store pattern; profiles/r01_exp_pool_floor.jsonl)
-    const bool diag_no_meta = (csplit_raw & 0x40000000) != 0;
-    const int i0 = diag_no_meta ? 0 : tile_meta[2 * t], p0 = diag_no_meta ? 0 : tile_meta[2 * t + 1];
-    const int i1 = diag_no_meta ? 0 : tile_meta[2 * t + 2], p1 = diag_no_meta ? 0 : tile_meta[2 * t + 3];
+    const int i0 = tile_meta[2 * t], p0 = tile_meta[2 * t + 1];
+    const int i1 = tile_meta[2 * t + 2], p1 = tile_meta[2 * t + 3];
     const long long cstride = out_stride_c;      // elements between channels (Z*YX when contiguous)
-    float* __restrict__ obase = out + (long long)b * out_stride_b + (long long)z * YX + v0 + (long long)c0 * cstride;
+    const long long oofs = (long long)b * out_stride_b + (long long)z * YX + v0 + (long long)c0 * cstride;
+    float* __restrict__ obase = out + oofs;                                         // OT == 0
+    unsigned short* __restrict__ obase16 = reinterpret_cast<unsigned short*>(out) + oofs;   // OT != 0
     const int n4 = CC * Q4;
+    constexpr int Q8 = TV / 8;
 
     if (i0 == i1) {
         fbbev_v4f zero; zero[0] = zero[1] = zero[2] = zero[3] = 0.f;
-        for (int idx = tid; idx < n4; idx += NT) {
-            const int c = idx / Q4, j = (idx - c * Q4) * 4;
-            if (j < nv) fbbev_store4<ST>(obase + c * cstride + j, zero);
+        if constexpr (OT == 0) {
+            for (int idx = tid; idx < n4; idx += NT) {
+                const int c = idx / Q4, j = (idx - c * Q4) * 4;
+                if (j < nv) fbbev_store4<ST>(obase + c * cstride + j, zero);
+            }
+        } else {
+            for (int idx = tid; idx < CC * Q8; idx += NT) {
+                const int c = idx / Q8, j = (idx - c * Q8) * 8;
+                if (j < nv) fbbev_store4<ST>(reinterpret_cast<float*>(obase16 + c * cstride + j), zero);
+            }
         }
         return;
     }
@@ -350,7 +395,7 @@ k_pool_fwd_dense2(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_b
             for (int i = g; i < ni; i += gpb) {
                 const int v = ivx[i];
                 float acc[CPL];
-                fbbev_interval_sum_staged<CPL, UB>(C, ist[i], iln[i], p0, prd, prf, depth, fbase, rd, rf, acc);
+                fbbev_interval_sum_staged<CPL, 4>(C, ist[i], iln[i], p0, prd, prf, depth, fbase, rd, rf, acc);
                 if (v >= 0 && v < nv) {
                     float* dst = tile + (slot * CPL) * LD + v;
 #pragma unroll
@@ -361,11 +406,26 @@ k_pool_fwd_dense2(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_b
     }
     __syncthreads();
 
-    for (int idx = tid; idx < n4; idx += NT) {
-        const int c = idx / Q4, j = (idx - c * Q4) * 4;
-        if (j < nv) {
-            const fbbev_v4f val = *reinterpret_cast<const fbbev_v4f*>(tile + c * LD + j);
-            fbbev_store4<ST>(obase + c * cstride + j, val);
+    if constexpr (OT == 0) {
+        for (int idx = tid; idx < n4; idx += NT) {
+            const int c = idx / Q4, j = (idx - c * Q4) * 4;
+            if (j < nv) {
+                const fbbev_v4f val = *reinterpret_cast<const fbbev_v4f*>(tile + c * LD + j);
+                fbbev_store4<ST>(obase + c * cstride + j, val);
+            }
+        }
+    } else {
+        for (int idx = tid; idx < CC * Q8; idx += NT) {
+            const int c = idx / Q8, j = (idx - c * Q8) * 8;
+            if (j < nv) {
+                const fbbev_v4f lo = *reinterpret_cast<const fbbev_v4f*>(tile + c * LD + j);
+                const fbbev_v4f hi = *reinterpret_cast<const fbbev_v4f*>(tile + c * LD + j + 4);
+                unsigned int pk[4] = {fbbev_pack2<OT>(lo[0], lo[1]), fbbev_pack2<OT>(lo[2], lo[3]),
+                                      fbbev_pack2<OT>(hi[0], hi[1]), fbbev_pack2<OT>(hi[2], hi[3])};
+                fbbev_v4f val;
+                __builtin_memcpy(&val, pk, 16);
+                fbbev_store4<ST>(reinterpret_cast<float*>(obase16 + c * cstride + j), val);
+            }
         }
     }
 }

@@ -56,7 +56,7 @@ class LiftSplat(torch.autograd.Function):
     once.  Backward regroups by feature pixel and runs the wave-per-pixel grad kernel."""
 
     @staticmethod
-    def forward(ctx, depth, feat, idx, grid_zyx, tile_ws, tile_voxels, pool_flags):
+    def forward(ctx, depth, feat, idx, grid_zyx, tile_ws, tile_voxels, pool_flags, out_dtype=torch.float32):
         depth = depth.contiguous().float()
         # `feat` arrives as the (B,N,H,W,C) permuted view of the NCHW context (view_transformer.py:536); when
         # the underlying tensor is contiguous NCHW the copy is done by the LDS-tiled transpose kernel
@@ -67,7 +67,7 @@ class LiftSplat(torch.autograd.Function):
             feat = feat.contiguous().float()
         B, C = depth.shape[0], feat.shape[-1]
         Z, Y, X = grid_zyx
-        out = torch.empty((B, C, Z, Y, X), dtype=torch.float32, device=depth.device)
+        out = torch.empty((B, C, Z, Y, X), dtype=out_dtype, device=depth.device)   # 16-bit: fp32 sums rounded at the store
         _capi.pool_tile_index(idx.interval_rank, idx.interval_starts, idx.counts, idx.n, B, Z, Y, X,
                               tile_ws, tile_voxels)
         _capi.bev_pool_v2_dense_fwd(depth, feat, idx.ranks_depth, idx.ranks_feat, idx.interval_rank,
@@ -99,7 +99,7 @@ class LiftSplat(torch.autograd.Function):
         depth_grad, feat_grad = torch.empty_like(depth), torch.empty_like(feat)
         _capi.bev_pool_v2_dense_bwd(og, depth, feat, idx.ranks_depth, idx.interval_rank, idx.interval_starts,
                                     idx.counts, idx.n, (Z, Y, X), depth_grad, feat_grad, _BWD_WS[key])
-        return depth_grad, feat_grad, None, None, None, None, None
+        return depth_grad, feat_grad, None, None, None, None, None, None
 
 
 _BWD_WS = {}
@@ -115,7 +115,8 @@ class LSSViewTransformerFunction3D(nn.Module):
     """
 
     def __init__(self, grid_config, input_size, downsample=16, accelerate=False, uniform=False,
-                 with_cp=False, extra_relu=False, fused=True, tile_voxels=None, pool_flags=None):
+                 with_cp=False, extra_relu=False, fused=True, tile_voxels=None, pool_flags=None,
+                 out_dtype=torch.float32):
         super().__init__()
         self.uniform = uniform
         self.with_cp = with_cp
@@ -132,6 +133,9 @@ class LSSViewTransformerFunction3D(nn.Module):
         self.accelerate = accelerate
         self.initial_flag = True
         self.fused = fused
+        # storage type of the fused path's BEV volume (fp32 sums, rounded once at the store); BASELINE configs[1]
+        # names bf16, configs[4] fp16; the reference itself is fp32 (bev_pool.py:16-22)
+        self.out_dtype = out_dtype
         # dense-kernel tiling: measured per launch on MI355X (profiles/r01_sweep_*.jsonl).  Sparse grids (BL2:
         # 0.4 frustum points per voxel) are store-bound -> 128-voxel tiles, channel range split over 2
         # workgroups; dense grids (shipped config: 4.2 points per voxel) are bound by the per-voxel gather
@@ -276,7 +280,7 @@ class LSSViewTransformerFunction3D(nn.Module):
         """Fused dense pooling on a prepared index set -> (B,C,Y,X,Z) view of (B,C,Z,Y,X)."""
         feat = tran_feat.permute(0, 1, 3, 4, 2)
         out = LiftSplat.apply(depth, feat, idx, self.grid_zyx, self._tile_ws(depth.device, depth.shape[0]),
-                              self.tile_voxels, self.pool_flags)
+                              self.tile_voxels, self.pool_flags, self.out_dtype)
         return out.permute(0, 1, 3, 4, 2)
 
     def view_transform_core(self, cam_params, depth, tran_feat):

@@ -27,17 +27,17 @@ typedef void* fbbev_stream_t; /* hipStream_t */
 #define FBBEV_E_UNSUPPORTED (-2)
 #define FBBEV_E_WORKSPACE (-3)
 
-/* flags of fbbev_bev_pool_v2_dense_fwd (tuning knobs; none changes the result bits) */
-#define FBBEV_POOL_STORE_MASK 0x3   /* output store cache policy: 0 plain, 1 nontemporal */
+/* flags of fbbev_bev_pool_v2_dense_fwd (tuning knobs: none changes the result bits; OUT_BF16 / OUT_F16 select the
+ * storage type of `out` -- the sums stay fp32 in-order fmaf chains and are rounded once at the store) */
+#define FBBEV_POOL_STORE_MASK 0x3   /* output store cache policy: 0 plain, 1 nontemporal; with bit 17 set: sc1 nt */
 #define FBBEV_POOL_CPL8 0x4         /* 8 channels per lane instead of 4 */
 #define FBBEV_POOL_CSPLIT_SHIFT 4   /* bits 4-7: split the channel range over this many workgroups */
 #define FBBEV_POOL_WG_SHIFT 8       /* bits 8-9: workgroup size 0 -> 256, 1 -> 128 threads */
 #define FBBEV_POOL_XCD_SWIZZLE 0x400 /* deal chunks of consecutive tiles round-robin to the 8 XCDs */
-#define FBBEV_POOL_STORE_HI_SHIFT 17 /* bit 17: third bit of the store policy (experimental policies 4-7) */
-#define FBBEV_POOL_DIAG_NO_META 0x40000 /* DIAGNOSTIC: write zeros without reading tile metadata (wrong output) */
-#define FBBEV_POOL_CHANNEL_MAJOR 0x80000 /* workgroup order: channel group outermost (fewer planes written at once) */
+#define FBBEV_POOL_STORE_HI_SHIFT 17 /* bit 17: `sc1 nt` stores (the default; do not evict the gathered inputs from L2) */
 #define FBBEV_POOL_CHANNELS_LAST 0x100000 /* out is (B,Z,Y,X,C) -- the reference op's own layout -- written densely */
-#define FBBEV_POOL_DEEP_BATCH 0x200000 /* 8 instead of 4 points per load batch in the per-voxel fmaf chain */
+#define FBBEV_POOL_OUT_BF16 0x800000  /* `out` holds bfloat16: fp32 sums rounded once (nearest-even) at the store */
+#define FBBEV_POOL_OUT_F16 0x1000000  /* `out` holds IEEE half; both: (B,C,Z,Y,X) layout only, (Y*X) % 8 == 0 */
 #define FBBEV_POOL_SWZ_CHUNK_SHIFT 12 /* bits 12-16: log2(tiles per chunk) for the swizzle, 0 = default */
 
 int fbbev_version(void);
@@ -133,6 +133,8 @@ int fbbev_lift_rank_build(const float* frustum, const float* xs, const float* ys
  *   fall back to fbbev_bev_pool_v2_fwd).
  *   out_stride_b / out_stride_c: element strides of the batch and channel dimensions of `out`
  *   (0 = contiguous); the (Z,Y,X) block of one channel is always contiguous.
+ *   With FBBEV_POOL_OUT_BF16 / FBBEV_POOL_OUT_F16 `out` points to 16-bit elements (strides in those elements,
+ *   multiples of 8; (Y*X) % 8 == 0): the storage formats BASELINE configs[1] (bf16) and configs[4] (fp16) name.
  *   With FBBEV_POOL_CHANNELS_LAST (pass the same flag to fbbev_pool_tile_index) `out` is instead the
  *   reference op's own (B,Z,Y,X,C) layout (bev_pool.py:24), every row written once: the whole launch is
  *   one linear store stream; callers take out.permute(0,4,1,2,3) as a view instead of copying (:88).

@@ -356,3 +356,40 @@ def test_history_warp_strided_output_and_padding_emulated():
     assert torch.allclose(ident, hist, atol=1e-6)
     nanflow = flow.clone(); nanflow[0, 0, 0] = float('nan')
     assert (E.history_warp(hist, nanflow)[0] == 0).all()                     # NaN coordinates sample nothing
+
+
+@pytest.mark.parametrize('tv,flags,dt', [(64, 0x800000, torch.bfloat16), (128, 0x824424, torch.bfloat16),
+                                         (64, 0x1000000, torch.float16), (256, 0x1020024, torch.float16)])
+def test_pool_dense_16bit_storage_is_the_rounded_fp32_result(tv, flags, dt):
+    """BASELINE configs[1] (bf16) / configs[4] (fp16) storage: the fp32 in-order sums, rounded once to nearest-even
+    at the store -- bit-identical to torch's own fp32 -> bf16 / fp16 conversion of the fp32 output."""
+    cfg, vt, coor, depth, feat = _case('TINY', 2)                    # Y*X = 256: a multiple of 8
+    depth = depth * 37.0                                             # spread the sums over more binades
+    rb, rd, rf, st, ln, ir, counts = E.rank_build(coor, *_grid3(vt))
+    B, Z, Y, X, C = vt.bev_feat_shape(2, cfg.channels)
+    code, out = E.pool_dense(depth, feat, rd, rf, ir, st, ln, counts, st.numel(), B, C, Z, Y, X, tv, flags)
+    assert code == 0 and out.dtype == dt
+    erb, erd, erf, est, eln = vt.voxel_pooling_prepare_v2(coor)
+    exp = O.bev_pool_v2(depth, feat, erd, erf, erb, (B, Z, Y, X, C), est, eln, use_fma=True)
+    assert torch.equal(out.view(torch.int16), exp.to(dt).view(torch.int16))
+
+
+def test_f16_conversion_edge_cases_emulated():
+    """fbbev_f32_to_f16 through the kernel: subnormals, ties, overflow, NaN."""
+    cfg, vt, coor, depth, feat = _case('TINY', 1)
+    rb, rd, rf, st, ln, ir, counts = E.rank_build(coor, *_grid3(vt))
+    B, Z, Y, X, C = vt.bev_feat_shape(1, cfg.channels)
+    vals = torch.tensor([6.0e-8, 5.9604645e-8 * 1.5, 6.1035e-5, 65504.0, 65520.0, 1.0e6, 1.0009765625, 1.00048828125],
+                        dtype=torch.float32)
+    feat = vals.view(1, 1, 1, 1, C).expand_as(feat).contiguous()     # C == 8 channels carry the probe values
+    depth = torch.zeros_like(depth)
+    P = int(counts[0])
+    first = rd[:P].long()[st[:int(counts[1])].long()]                # first point of every interval: depth 1, rest 0
+    depth.view(-1)[first] = 1.0
+    for flags, dt in ((0x1000000, torch.float16), (0x800000, torch.bfloat16)):
+        code, out = E.pool_dense(depth, feat, rd, rf, ir, st, ln, counts, st.numel(), B, C, Z, Y, X, 64, flags)
+        assert code == 0
+        got = out.permute(0, 2, 3, 4, 1).reshape(-1, C)
+        hit = got.float().abs().sum(1) > 0
+        assert hit.any()
+        assert torch.equal(got[hit].view(torch.int16), vals.to(dt).view(torch.int16).expand(int(hit.sum()), C))

@@ -475,3 +475,21 @@ def test_dense_forward_stress_grid_bl5(dev):
     assert torch.equal(out.permute(0, 1, 4, 2, 3), exp)
     stats = json.load(open(os.path.join(G, 'index_stats.json')))['BL5_B1']
     assert abs(rb.numel() - stats['P']) < 0.2 * stats['P']             # augmented rig: same order of magnitude
+
+
+@pytest.mark.parametrize('name,B,dt', [('BL2', 2, torch.bfloat16), ('BL2', 1, torch.float16), ('REF', 2, torch.bfloat16)])
+def test_16bit_storage_equals_rounded_fp32_volume(dev, name, B, dt):
+    """FBBEV_POOL_OUT_BF16 / OUT_F16: the same fp32 in-order sums, rounded once (nearest-even) at the store."""
+    cfg, ovt, cam, _, depth, ctx = _inputs(name, B, True, dev)
+    cam_g = [t.to(dev) for t in cam]
+    d, c = depth.to(dev), ctx.to(dev)
+    full = _vt(cfg, dev)(cam_g, c, d)
+    half = _vt(cfg, dev, out_dtype=dt)(cam_g, c, d)
+    assert half.dtype == dt and half.shape == full.shape
+    assert torch.equal(half.contiguous().view(torch.int16), full.to(dt).contiguous().view(torch.int16))
+    # autograd still works through the 16-bit volume (gradient converted to fp32 for the backward kernels)
+    d2, c2 = d.clone().requires_grad_(), c.clone().requires_grad_()
+    _vt(cfg, dev, out_dtype=dt)(cam_g, c2, d2).float().sum().backward()
+    d3, c3 = d.clone().requires_grad_(), c.clone().requires_grad_()
+    _vt(cfg, dev)(cam_g, c3, d3).sum().backward()
+    assert torch.allclose(d2.grad, d3.grad, atol=1e-4) and torch.allclose(c2.grad, c3.grad, atol=1e-4)

@@ -39,8 +39,8 @@ if [ "$MODE" != "quick" ]; then
   python tools/pmc_to_json.py $OUT BL2_B16_tv128
   find $OUT -name "*.csv" -size +20M -delete
   if [ "$MODE" == "sweep" ]; then
-    timeout 400 python tools/exp_pool.py REF 16 > $OUT/exp_pool3_REF.jsonl 2>> $OUT/exp_pool.err
-    timeout 400 python tools/exp_pool.py BL5 4 > $OUT/exp_pool3_BL5.jsonl 2>> $OUT/exp_pool.err
+    timeout 400 python tools/sweep_pool.py REF 16 > $OUT/sweep_REF_16.jsonl 2>> $OUT/sweep.err
+    timeout 400 python tools/sweep_pool.py BL5 4 > $OUT/sweep_BL5_4.jsonl 2>> $OUT/sweep.err
   fi
 fi
 echo "== done $(date)" >> $OUT/box.txt

@@ -37,7 +37,7 @@ def main():
         cc = C // cs
         if (cc * (tv + 4) + 3 * tv + 1024) * 4 > 64 * 1024:
             continue
-        for cpl8, deep in itertools.product((True, False), (0, 0x200000)):
+        for cpl8, deep in itertools.product((True, False), (0,)):
             if cpl8 and cc % 8:
                 continue
             if wg // (cc // (8 if cpl8 else 4)) < 1:
