@@ -41,6 +41,11 @@ def build(cfg, **extra):
     cfg = dict(cfg)
     typ = cfg.pop('type')
     cfg.update(extra)
+    if typ not in REGISTRY and typ.endswith('TRT') and typ[:-3] in REGISTRY:
+        # the *TRT classes of the deployment config (fbocc-..._trt.py; backward_projection.py:137,
+        # spatial_cross_attention_depth.py:227,604, multi_scale_deformable_attn_function.py:175) are the same modules
+        # with the same constructor arguments and parameters, re-worded for TensorRT export: built as the native class
+        typ = typ[:-3]
     return REGISTRY[typ](**cfg)
 
 
