@@ -37,7 +37,7 @@ SIGNATURES = {
     'fbbev_history_warp': (c_int, [c_void_p, c_int64, c_void_p] + [c_int] * 5 + [c_void_p, c_int64, c_void_p]),
     'fbbev_msda_fwd': (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_void_p, c_void_p]),
     'fbbev_point_sampling': (c_int, [c_void_p] * 9 + [c_int] * 5 + [c_float, c_float] + [c_void_p] * 4),
-    'fbbev_da_cross_attn_fwd': (c_int, [c_void_p] * 9 + [c_int] * 10 + [c_float, c_float, c_void_p, c_void_p]),
+    'fbbev_da_cross_attn_fwd': (c_int, [c_void_p] * 9 + [c_int] * 10 + [c_float, c_float, c_int, c_void_p, c_void_p]),
     'fbbev_msda_bwd': (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p] * 3 + [c_void_p]),
 }
 
@@ -299,12 +299,16 @@ def msda_bwd(value, spatial_shapes, level_start_index, sampling_loc, attn_weight
 
 
 def da_cross_attn_fwd(value, spatial_shapes, level_start_index, pred_depth, ref_cam, mask, qdepth, offsets,
-                      attn, d0, dstep, slots):
+                      attn, d0, dstep, slots, head_minor=0):
     """value (B*Ncam,S,M,Dh); pred_depth (B*Ncam,DC,H0,W0); ref_cam (Ncam,B,Q,Za,2); mask (Ncam,B,Q,Za) bool;
-    qdepth (Ncam,B,Q,Za); offsets (B,Q,M,L,P,2); attn (B,Q,M,L,P); slots (B,Q,M*Dh)."""
+    qdepth (Ncam,B,Q,Za); offsets (B,Q,M,L,P,2); attn (B,Q,M,L,P); head_minor bit 0: offsets is (B,Q,L,P,M,2),
+    bit 1: attn is (B,Q,L,P,M); slots (B,Q,M*Dh)."""
     Ncam, B, Q, Za = mask.shape
     _, S, M, Dh = value.shape
-    L, P = attn.shape[3], attn.shape[4]
+    head_minor = int(head_minor)
+    L, P = (attn.shape[2], attn.shape[3]) if head_minor & 2 else (attn.shape[3], attn.shape[4])
+    if attn.shape[-1 if head_minor & 2 else 2] != M or offsets.shape[-2 if head_minor & 1 else 2] != M:
+        raise FbbevError('offsets / attn layout does not match head_minor')
     DC = pred_depth.shape[1]
     if mask.dtype == torch.bool:
         mask = mask.view(torch.uint8)
@@ -314,7 +318,7 @@ def da_cross_attn_fwd(value, spatial_shapes, level_start_index, pred_depth, ref_
             _dev(level_start_index, I64, 'level_start_index'), _dev(pred_depth, F32, 'pred_depth'),
             _dev(ref_cam, F32, 'ref_cam'), _dev(mask, torch.uint8, 'mask'), _dev(qdepth, F32, 'qdepth'),
             _dev(offsets, F32, 'offsets'), _dev(attn, F32, 'attn'), B, Ncam, S, M, Dh, L, Q, P, Za, DC,
-            float(d0), float(dstep), _dev(slots, F32, 'slots'), _stream()), 'fbbev_da_cross_attn_fwd')
+            float(d0), float(dstep), head_minor, _dev(slots, F32, 'slots'), _stream()), 'fbbev_da_cross_attn_fwd')
 
 
 def point_sampling(xs, ys, zs, rots, trans, intrins, post_rots, post_trans, bda, ogfH, ogfW, ref_cam, mask, qdepth):

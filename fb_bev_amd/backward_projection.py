@@ -228,6 +228,24 @@ class DA_MSDeformableAttention(nn.Module):
         aw = aw.softmax(-1).view(bs, nq, self.num_heads, self.num_levels, self.num_points)
         return so, aw
 
+    def project_head_minor(self, query):
+        """`project` with the sampling_offsets rows permuted so that the offsets come out head-minor, (B,Q,L,P,M,2):
+        the layout the fused kernel reads with contiguous lanes (same dot product per element, only the row order of
+        the weight matrix changes).  The attention weights keep (B,Q,M,L,P): their softmax runs over the last dim."""
+        bs, nq, _ = query.shape
+        M, L, P = self.num_heads, self.num_levels, self.num_points
+        key = (M, L, P, str(query.device))
+        if getattr(self, '_perm_key', None) != key:
+            o = torch.arange(M * L * P).view(M, L, P).permute(1, 2, 0).reshape(-1)        # new (l,p,m) -> old (m,l,p)
+            self._perm_so = (o[:, None] * 2 + torch.arange(2)[None]).reshape(-1).to(query.device)
+            self._perm_key = key
+        so = F.linear(query, self.sampling_offsets.weight[self._perm_so], self.sampling_offsets.bias[self._perm_so])
+        so = so.view(bs, nq, L, P, M, 2)
+        aw = self.attention_weights(query).view(bs, nq, M, L * P)
+        if self.disable_deformable:
+            so, aw = so * 0, aw * 0
+        return so, aw.softmax(-1).view(bs, nq, M, L, P)
+
     def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_padding_mask=None,
                 reference_points=None, spatial_shapes=None, level_start_index=None, bev_query_depth=None,
                 pred_img_depth=None, **kwargs):
@@ -287,7 +305,7 @@ class DA_SpatialCrossAttention(nn.Module):
         B, Q, E = query.shape
         ncam, S, _, _ = value.shape
         v = da.value_proj(value.permute(2, 0, 1, 3).reshape(B * ncam, S, E)).view(B * ncam, S, da.num_heads, -1)
-        so, aw = da.project(query)
+        so, aw = da.project_head_minor(query)
         DC, H0, W0 = pred_img_depth.shape[2:]
         slots = torch.empty((B, Q, E), dtype=torch.float32, device=query.device)
         _capi.da_cross_attn_fwd(v.contiguous().float(), spatial_shapes.to(torch.int64).contiguous(),
@@ -295,7 +313,7 @@ class DA_SpatialCrossAttention(nn.Module):
                                 pred_img_depth.reshape(B * ncam, DC, H0, W0).contiguous().float(),
                                 reference_points_cam.contiguous().float(), mask.contiguous(),
                                 bev_query_depth.squeeze(-1).contiguous().float(), so.contiguous().float(),
-                                aw.contiguous().float(), self.dbound[0], self.dbound[2], slots)
+                                aw.contiguous().float(), self.dbound[0], self.dbound[2], slots, head_minor=1)
         return slots
 
     # ---- training: vectorised rebatch + composite deformable attention (autograd through the MSDA op)
@@ -536,6 +554,10 @@ class BEVFormer(nn.Module):
             shapes.append((h, w))
             feats.append(f)
         feat_flatten = torch.cat(feats, 2)
+        if pred_img_depth is not None and tuple(pred_img_depth.shape[-2:]) != tuple(shapes[0]):
+            # the depth distribution is sampled on spatial_shapes[0:1] (spatial_cross_attention_depth.py:586):
+            # level 0 must be the level the depth net ran on, or the sampling would index past the depth map
+            raise ValueError(f'pred_img_depth is {tuple(pred_img_depth.shape[-2:])} but feature level 0 is {tuple(shapes[0])}')
         spatial_shapes = const_tensor(shapes, bev_pos.device)
         starts = [0]
         for h, w in shapes[:-1]:

@@ -614,7 +614,7 @@ extern "C" int fbbev_da_cross_attn_fwd(const float* value, const int64_t* spatia
                                        const float* ref_cam, const uint8_t* mask, const float* qdepth,
                                        const float* offsets, const float* attn, int B, int Ncam, int S, int M,
                                        int Dh, int L, int Q, int P, int Za, int DC, float d0, float dstep,
-                                       float* slots, fbbev_stream_t stream_) {
+                                       int head_minor, float* slots, fbbev_stream_t stream_) {
     if (B <= 0 || Ncam <= 0 || S <= 0 || M <= 0 || Dh <= 0 || L <= 0 || Q < 0 || P <= 0 || Za <= 0 || DC <= 0)
         return FBBEV_E_BADARG;
     if (Za > FBBEV_DA_MAX_ZA || P % Za != 0) return FBBEV_E_UNSUPPORTED;
@@ -623,11 +623,28 @@ extern "C" int fbbev_da_cross_attn_fwd(const float* value, const int64_t* spatia
     if (n == 0) return 0;
     if (!value || !spatial_shapes || !level_start_index || !pred_depth || !ref_cam || !mask || !qdepth ||
         !offsets || !attn || !slots) return FBBEV_E_BADARG;
+    const bool al8 = (((uintptr_t)value | (uintptr_t)offsets | (uintptr_t)slots) & 7) == 0;
+    if (al8 && (Dh == 10 || Dh == 8 || Dh == 16 || Dh == 32)) {   // a lane owns all Dh channels of a (b,q,head) unit
+        const long long units = (long long)B * Q * M;
+        long long ub = (units + 255) / 256;
+        if (ub > 65536) ub = 65536;
+#define FBBEV_DA_UNIT(DH_)                                                                                          \
+    FBBEV_LAUNCH(k_da_cross_attn_fwd_unit<DH_>, ub, 256, 0, (fbbev_rt_stream)stream_, units, value, spatial_shapes, \
+                 level_start_index, pred_depth, ref_cam, mask, qdepth, offsets, attn, B, Ncam, S, M, L, Q, P, Za,   \
+                 DC, d0, dstep, head_minor & 3, slots)
+        if (Dh == 10) FBBEV_DA_UNIT(10);
+        else if (Dh == 8) FBBEV_DA_UNIT(8);
+        else if (Dh == 16) FBBEV_DA_UNIT(16);
+        else FBBEV_DA_UNIT(32);
+#undef FBBEV_DA_UNIT
+        FBBEV_CHECK_LAUNCH();
+        return 0;
+    }
     long long blocks = (n + 255) / 256;
     if (blocks > 65536) blocks = 65536;
     FBBEV_LAUNCH(k_da_cross_attn_fwd, blocks, 256, 0, (fbbev_rt_stream)stream_, n, value, spatial_shapes,
                  level_start_index, pred_depth, ref_cam, mask, qdepth, offsets, attn, B, Ncam, S, M, Dh, L, Q, P,
-                 Za, DC, d0, dstep, slots);
+                 Za, DC, d0, dstep, head_minor & 3, slots);
     FBBEV_CHECK_LAUNCH();
     return 0;
 }

@@ -38,14 +38,15 @@ __device__ __forceinline__ float fbbev_plane_sample(const float* __restrict__ pl
 }
 
 // value (B*Ncam,S,M,Dh); pred_depth (B*Ncam,DC,H0,W0); ref_cam (Ncam,B,Q,Za,2); mask (Ncam,B,Q,Za) u8;
-// qdepth (Ncam,B,Q,Za); offsets (B,Q,M,L,P,2) raw; attn (B,Q,M,L,P) softmaxed; slots (B,Q,M*Dh)
+// qdepth (Ncam,B,Q,Za); offsets (B,Q,M,L,P,2) raw; attn (B,Q,M,L,P) softmaxed [head_minor: (B,Q,L,P,M,2) / (B,Q,L,P,M)];
+// slots (B,Q,M*Dh)
 __global__ void __launch_bounds__(256)
 k_da_cross_attn_fwd(long long n, const float* __restrict__ value, const int64_t* __restrict__ spatial_shapes,
                     const int64_t* __restrict__ level_start, const float* __restrict__ pred_depth,
                     const float* __restrict__ ref_cam, const unsigned char* __restrict__ mask,
                     const float* __restrict__ qdepth, const float* __restrict__ offsets,
                     const float* __restrict__ attn, int B, int Ncam, int S, int M, int Dh, int L, int Q, int P,
-                    int Za, int DC, float d0, float dstep, float* __restrict__ slots) {
+                    int Za, int DC, float d0, float dstep, int head_minor, float* __restrict__ slots) {
     const int row_stride = M * Dh;
     const int H0 = (int)spatial_shapes[0], W0 = (int)spatial_shapes[1];
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < n;
@@ -76,15 +77,18 @@ k_da_cross_attn_fwd(long long n, const float* __restrict__ value, const int64_t*
                 dw[z] = fbbev_plane_sample(pred_depth + (bn * DC + bin) * (long long)(H0 * W0), H0, W0, rx[z], ry[z]);
             }
             float col = 0.f;
-            long long wp = unit * L * P;
             for (int l = 0; l < L; ++l) {
                 const int sh = (int)spatial_shapes[2 * l], sw = (int)spatial_shapes[2 * l + 1];
                 const float* vp = value + (bn * S + level_start[l]) * row_stride + m * Dh + c;
-                for (int p = 0; p < P; ++p, ++wp) {
+                for (int p = 0; p < P; ++p) {
+                    // offsets / attn: (B,Q,M,L,P[,2]) as the Linear layers emit them, or head-minor (B,Q,L,P,M[,2]):
+                    // head_minor bit 0 -> offsets, bit 1 -> attn
+                    const long long wm = (unit * L + l) * P + p, wh = ((bq * L + l) * P + p) * M + m;
+                    const long long wo = (head_minor & 1) ? wh : wm, wa = (head_minor & 2) ? wh : wm;
                     const int z = p % Za;
-                    const float loc_w = rx[z] + __fdiv_rn(offsets[wp * 2], (float)sw);
-                    const float loc_h = ry[z] + __fdiv_rn(offsets[wp * 2 + 1], (float)sh);
-                    const float weight = attn[wp] * dw[z];
+                    const float loc_w = rx[z] + __fdiv_rn(offsets[wo * 2], (float)sw);
+                    const float loc_h = ry[z] + __fdiv_rn(offsets[wo * 2 + 1], (float)sh);
+                    const float weight = attn[wa] * dw[z];
                     const float h_im = loc_h * sh - 0.5f, w_im = loc_w * sw - 0.5f;
                     if (h_im > -1.f && w_im > -1.f && h_im < (float)sh && w_im < (float)sw) {
                         const fbbev_bilinear s = fbbev_bilinear_setup(h_im, w_im, sh, sw, row_stride);
@@ -99,5 +103,103 @@ k_da_cross_attn_fwd(long long n, const float* __restrict__ value, const int64_t*
             acc += col;
         }
         slots[idx] = acc / (float)(count > 1 ? count : 1);
+    }
+}
+
+
+// ---------------------------------------------------------------- unit-per-lane variant (the one FB-OCC shapes take)
+// Same arithmetic, expression for expression, as k_da_cross_attn_fwd above (=> identical bits), different ownership: a
+// lane owns a whole (b, q, head) unit -- all DH channels.  The camera hit test, the Za depth weights, the sampling
+// offsets / attention weights and the bilinear setup are evaluated ONCE per unit instead of once per channel lane, and
+// each corner is read as DH/2 eight-byte loads (a head's DH floats are contiguous; neighbouring lanes = neighbouring
+// heads read one contiguous M*DH*4-byte row).  The channel-per-lane kernel spends its time in the vector L1's per-lane
+// dword rate (7 loads per sample per lane, 10 lanes per unit at Dh = 10); this one issues 23 loads per sample per unit.
+template <int DH>
+__global__ void __launch_bounds__(256)
+k_da_cross_attn_fwd_unit(long long n_units, const float* __restrict__ value, const int64_t* __restrict__ spatial_shapes,
+                         const int64_t* __restrict__ level_start, const float* __restrict__ pred_depth,
+                         const float* __restrict__ ref_cam, const unsigned char* __restrict__ mask,
+                         const float* __restrict__ qdepth, const float* __restrict__ offsets,
+                         const float* __restrict__ attn, int B, int Ncam, int S, int M, int L, int Q, int P, int Za,
+                         int DC, float d0, float dstep, int head_minor, float* __restrict__ slots) {
+    static_assert(DH % 2 == 0, "eight-byte loads");
+    constexpr int row_stride_unit = DH;
+    const int row_stride = M * DH;
+    const int H0 = (int)spatial_shapes[0], W0 = (int)spatial_shapes[1];
+    for (long long unit = (long long)blockIdx.x * blockDim.x + threadIdx.x; unit < n_units;
+         unit += (long long)gridDim.x * blockDim.x) {
+        const int m = (int)(unit % M);
+        const long long bq = unit / M;
+        const int q = (int)(bq % Q);
+        const int b = (int)(bq / Q);
+        float acc[DH];
+#pragma unroll
+        for (int c = 0; c < DH; ++c) acc[c] = 0.f;
+        int count = 0;
+        for (int cam = 0; cam < Ncam; ++cam) {
+            const long long base = (((long long)cam * B + b) * Q + q) * Za;
+            bool hit = false;
+            for (int z = 0; z < Za; ++z) hit = hit || (mask[base + z] != 0);
+            if (!hit) continue;
+            ++count;
+            const long long bn = (long long)b * Ncam + cam;
+            float rx[FBBEV_DA_MAX_ZA], ry[FBBEV_DA_MAX_ZA], dw[FBBEV_DA_MAX_ZA];
+            for (int z = 0; z < Za; ++z) {
+                rx[z] = ref_cam[(base + z) * 2];
+                ry[z] = ref_cam[(base + z) * 2 + 1];
+                float fb = floorf(__fdiv_rn(__fsub_rn(qdepth[base + z], d0), dstep));
+                fb = fminf(fmaxf(fb, 0.f), (float)(DC - 1));
+                const int bin = (int)fb;
+                dw[z] = fbbev_plane_sample(pred_depth + (bn * DC + bin) * (long long)(H0 * W0), H0, W0, rx[z], ry[z]);
+            }
+            float col[DH];
+#pragma unroll
+            for (int c = 0; c < DH; ++c) col[c] = 0.f;
+            for (int l = 0; l < L; ++l) {
+                const int sh = (int)spatial_shapes[2 * l], sw = (int)spatial_shapes[2 * l + 1];
+                const float* vp = value + (bn * S + level_start[l]) * row_stride + m * row_stride_unit;
+                for (int p = 0; p < P; ++p) {
+                    // head-minor (B,Q,L,P,M[,2]): the 8 heads of a query read 64 contiguous bytes per sample; the
+                    // (B,Q,M,L,P[,2]) layout strides lanes by L*P*8 bytes and thrashes the vector L1
+                    // (head_minor bit 0 -> offsets, bit 1 -> attn; a unit's 32 attention weights are one 128-byte line,
+                    // so attn may stay in the layout the fast last-dim softmax produces)
+                    const long long wm = (unit * L + l) * P + p, wh = ((bq * L + l) * P + p) * M + m;
+                    const long long wo = (head_minor & 1) ? wh : wm, wa = (head_minor & 2) ? wh : wm;
+                    const int z = p % Za;
+                    const fbbev_v2f o = *reinterpret_cast<const fbbev_v2f*>(offsets + wo * 2);
+                    const float loc_w = rx[z] + __fdiv_rn(o[0], (float)sw);
+                    const float loc_h = ry[z] + __fdiv_rn(o[1], (float)sh);
+                    const float weight = attn[wa] * dw[z];
+                    const float h_im = loc_h * sh - 0.5f, w_im = loc_w * sw - 0.5f;
+                    if (h_im > -1.f && w_im > -1.f && h_im < (float)sh && w_im < (float)sw) {
+                        const fbbev_bilinear s = fbbev_bilinear_setup(h_im, w_im, sh, sw, row_stride);
+                        float v1[DH], v2[DH], v3[DH], v4[DH];
+#pragma unroll
+                        for (int c = 0; c < DH; c += 2) {
+                            const fbbev_v2f zero = {0.f, 0.f};
+                            const fbbev_v2f a1 = s.o1 >= 0 ? *reinterpret_cast<const fbbev_v2f*>(vp + s.o1 + c) : zero;
+                            const fbbev_v2f a2 = s.o2 >= 0 ? *reinterpret_cast<const fbbev_v2f*>(vp + s.o2 + c) : zero;
+                            const fbbev_v2f a3 = s.o3 >= 0 ? *reinterpret_cast<const fbbev_v2f*>(vp + s.o3 + c) : zero;
+                            const fbbev_v2f a4 = s.o4 >= 0 ? *reinterpret_cast<const fbbev_v2f*>(vp + s.o4 + c) : zero;
+                            v1[c] = a1[0]; v1[c + 1] = a1[1]; v2[c] = a2[0]; v2[c + 1] = a2[1];
+                            v3[c] = a3[0]; v3[c + 1] = a3[1]; v4[c] = a4[0]; v4[c + 1] = a4[1];
+                        }
+#pragma unroll
+                        for (int c = 0; c < DH; ++c)
+                            col[c] += (s.w1 * v1[c] + s.w2 * v2[c] + s.w3 * v3[c] + s.w4 * v4[c]) * weight;
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < DH; ++c) acc[c] += col[c];
+        }
+        const float inv = (float)(count > 1 ? count : 1);
+        float* dst = slots + unit * DH;
+#pragma unroll
+        for (int c = 0; c < DH; c += 2) {
+            fbbev_v2f r;
+            r[0] = acc[c] / inv; r[1] = acc[c + 1] / inv;
+            *reinterpret_cast<fbbev_v2f*>(dst + c) = r;
+        }
     }
 }

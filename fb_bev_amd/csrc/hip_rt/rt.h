@@ -31,6 +31,7 @@ __device__ __forceinline__ float* fbbev_dyn_lds_f32() { return reinterpret_cast<
 // (gfx950 cache-control bits; MI355X_MICROARCH.md "stores of each flavour").  Stores have no
 // return value, so the hand-written forms need no extra s_waitcnt bookkeeping.
 typedef float fbbev_v4f __attribute__((ext_vector_type(4)));
+typedef float fbbev_v2f __attribute__((ext_vector_type(2)));
 template <int ST>
 __device__ __forceinline__ void fbbev_store4(float* p, fbbev_v4f v) {
     if constexpr (ST == 1) {

@@ -17,10 +17,12 @@ class FBViewTransform(nn.Module):
         self.backward_projection = BP.build(backward_projection) if backward_projection is not None else None
         self.readd = readd
 
-    def forward(self, cam_params, context, depth, img_metas=None, bev_mask=None):
+    def forward(self, cam_params, context, depth, img_metas=None, bev_mask=None, mlvl_feats=None):
+        """mlvl_feats: optional list of (B,N,C,H_l,W_l) image features for the backward projection (default
+        [context], as fbocc.py:357 passes); BASELINE configs[2] uses 4 levels."""
         bev_feat = self.forward_projection(cam_params, context, depth)            # (B,C,Y,X,Z)   fbocc.py:344-345
         if self.backward_projection is None:
             return bev_feat
-        refined = self.backward_projection([context], img_metas, lss_bev=bev_feat.mean(-1), cam_params=cam_params,
+        refined = self.backward_projection(mlvl_feats if mlvl_feats is not None else [context], img_metas, lss_bev=bev_feat.mean(-1), cam_params=cam_params,
                                            bev_mask=bev_mask, gt_bboxes_3d=None, pred_img_depth=depth)   # :357-363
         return refined[..., None] + bev_feat if self.readd else refined           # :365-368

@@ -203,15 +203,17 @@ int fbbev_point_sampling(const float* xs, const float* ys, const float* zs, cons
  * distribution in its native layout (level-0 shape); ref_cam (Ncam,B,Q,Za,2), mask (Ncam,B,Q,Za) bool,
  * qdepth (Ncam,B,Q,Za) from point_sampling (bevformer_encoder.py:91-120); offsets (B,Q,M,L,P,2) =
  * sampling_offsets(query) raw, attn (B,Q,M,L,P) = softmax(attention_weights(query)), both computed once
- * per BEV query; d0/dstep = dbound[0]/dbound[2].
+ * per BEV query; d0/dstep = dbound[0]/dbound[2].  head_minor: bit 0 -> offsets is laid out (B,Q,L,P,M,2), bit 1 -> attn
+ * is (B,Q,L,P,M) -- what the Linear layers emit when their output rows are permuted; the heads of a query then
+ * read contiguous bytes per sample (offsets head-minor is the fast path of the FB-OCC shapes).
  * slots (B,Q,M*Dh) = sum over hit cameras of the depth-weighted deformable sample / max(#hit,1)
  * (the tensor the reference feeds to output_proj, :216-219). */
 int fbbev_da_cross_attn_fwd(const float* value, const int64_t* spatial_shapes,
                             const int64_t* level_start_index, const float* pred_depth,
                             const float* ref_cam, const uint8_t* mask, const float* qdepth,
                             const float* offsets, const float* attn, int B, int Ncam, int S, int M, int Dh,
-                            int L, int Q, int P, int Za, int DC, float d0, float dstep, float* slots,
-                            fbbev_stream_t stream);
+                            int L, int Q, int P, int Za, int DC, float d0, float dstep, int head_minor,
+                            float* slots, fbbev_stream_t stream);
 
 /* Training backward of the fused lift-splat:  replaces QuickCumsumCuda.backward (bev_pool.py:39-78 --
  * argsort of ranks_feat, mask-built intervals [2 host syncs], the permute().contiguous() of the gradient)

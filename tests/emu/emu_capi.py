@@ -111,16 +111,23 @@ def lidar_coor(xs, ys, ds, cam):
     return coor
 
 
-def da_cross_attn_fwd(value, ss, ls, pred_depth, ref_cam, mask, qdepth, offsets, attn, d0, dstep):
+def da_cross_attn_fwd(value, ss, ls, pred_depth, ref_cam, mask, qdepth, offsets, attn, d0, dstep, misalign=False,
+                      head_minor=0):
+    """misalign=True: output buffer at a 4-byte (not 8-byte) aligned address => the channel-per-lane kernel runs"""
     Ncam, B, Q, Za = mask.shape
     _, S, M, Dh = value.shape
-    L, P = attn.shape[3], attn.shape[4]
-    slots = torch.full((B, Q, M * Dh), float('nan'))
+    L, P = (attn.shape[2], attn.shape[3]) if head_minor & 2 else (attn.shape[3], attn.shape[4])
+    buf = torch.full((B * Q * M * Dh + 3,), float('nan'))
+    off = 1 if (buf.data_ptr() % 8 == 0) == misalign else 0
+    if not misalign and (buf.data_ptr() + 4 * off) % 8:
+        off += 1
+    slots = buf[off:off + B * Q * M * Dh].view(B, Q, M * Dh)
+    assert (slots.data_ptr() % 8 != 0) == misalign
     m8 = mask.to(torch.uint8).contiguous()
     ok(lib().fbbev_da_cross_attn_fwd(p(value), p(ss), p(ls), p(pred_depth), p(ref_cam), p(m8), p(qdepth), p(offsets),
                                      p(attn), B, Ncam, S, M, Dh, L, Q, P, Za, pred_depth.shape[1], d0, dstep,
-                                     p(slots), None))
-    return slots
+                                     int(head_minor), c_void_p(slots.data_ptr()), None))
+    return slots.clone()
 
 
 def point_sampling(xs, ys, zs, cam, ogfH, ogfW):

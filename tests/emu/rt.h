@@ -160,5 +160,6 @@ inline float* fbbev_dyn_lds_f32() {
     return reinterpret_cast<float*>((p + 15) & ~uintptr_t(15));
 }
 typedef float fbbev_v4f __attribute__((vector_size(16)));
+typedef float fbbev_v2f __attribute__((vector_size(8)));
 template <int ST> inline void fbbev_store4(float* p, fbbev_v4f v) { memcpy(p, &v, 16); }
 inline void fbbev_atomic_add_f32(float* p, float v) { *p += v; }

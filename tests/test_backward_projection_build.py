@@ -58,3 +58,19 @@ def test_history_fusion_module_builds_with_detector_key_names():
     with pytest.raises(_capi.FbbevError):      # no CPU fallback
         m.fuse_history(torch.zeros(1, 80, 4, 4, 2), [dict(sequence_group_idx=0, start_of_sequence=True,
                                                           curr_to_prev_ego_rt=torch.eye(4))], torch.eye(3)[None])
+
+
+def test_head_minor_projection_is_a_row_permutation_of_the_reference_projection():
+    """DA_MSDeformableAttention.project_head_minor == project with (M,L,P) -> (L,P,M) transposed outputs."""
+    import torch
+    torch.manual_seed(0)
+    da = BP.build(dict(type='DA_MSDeformableAttention', embed_dims=80, num_points=8, num_levels=4))
+    with torch.no_grad():
+        da.sampling_offsets.weight.normal_(0, 0.1)
+        da.attention_weights.weight.normal_(0, 0.1); da.attention_weights.bias.normal_(0, 0.1)
+    q = torch.randn(2, 37, 80)
+    so, aw = da.project(q)
+    so2, aw2 = da.project_head_minor(q)
+    assert so2.shape == (2, 37, 4, 8, 8, 2) and aw2.shape == aw.shape
+    assert torch.allclose(so2, so.permute(0, 1, 3, 4, 2, 5), atol=1e-6)
+    assert torch.allclose(aw2, aw, atol=1e-6)

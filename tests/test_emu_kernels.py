@@ -192,11 +192,24 @@ def _da_case(seed=0, B=2, N=6, Q=70, Za=4, E=16, M=4, shapes=((5, 7), (3, 4)), P
 
 
 def test_fused_da_cross_attention_emulated():
-    for seed, kw in ((0, {}), (1, dict(B=1, Q=33, shapes=((4, 6),), P=4, M=2, E=8))):
+    for seed, kw in ((0, {}), (1, dict(B=1, Q=33, shapes=((4, 6),), P=4, M=2, E=8)),
+                     (2, dict(B=1, Q=41, E=40, M=4)),                      # Dh = 10: unit-per-lane kernel (FB-OCC)
+                     (3, dict(B=2, Q=19, E=16, M=2, shapes=((6, 5), (3, 3), (2, 2)), P=4))):   # Dh = 8, 3 levels
         args, exp = _da_case(seed, **kw)
         got = E.da_cross_attn_fwd(*args)
         assert not torch.isnan(got).any()
         assert torch.allclose(got, exp, atol=2e-5, rtol=1e-5)
+        if args[0].shape[-1] in (8, 10, 16, 32):
+            # both kernels evaluate the same expressions in the same order: identical bits
+            assert torch.equal(got, E.da_cross_attn_fwd(*args, misalign=True))
+        # head-minor layout of the two per-query tensors: (B,Q,M,L,P[,2]) -> (B,Q,L,P,M[,2]), same values => same bits
+        a = list(args)
+        a[7] = args[7].permute(0, 1, 3, 4, 2, 5).contiguous()
+        a[8] = args[8].permute(0, 1, 3, 4, 2).contiguous()
+        assert torch.equal(got, E.da_cross_attn_fwd(*a, head_minor=3))
+        assert torch.equal(got, E.da_cross_attn_fwd(*a, head_minor=3, misalign=True))
+        a[8] = args[8]                                                    # offsets head-minor only (the module's choice)
+        assert torch.equal(got, E.da_cross_attn_fwd(*a, head_minor=1))
 
 
 def test_point_sampling_emulated():
