@@ -35,6 +35,7 @@ SIGNATURES = {
                                     [c_void_p] * 3 + [c_size_t, c_void_p]),
     'fbbev_history_flow': (c_int, [c_void_p] * 5 + [c_int, c_void_p, c_void_p]),
     'fbbev_history_warp': (c_int, [c_void_p, c_int64, c_void_p] + [c_int] * 5 + [c_void_p, c_int64, c_void_p]),
+    'fbbev_layernorm': (c_int, [c_void_p] * 4 + [c_float, c_int64, c_int, c_void_p, c_void_p]),
     'fbbev_msda_fwd': (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_void_p, c_void_p]),
     'fbbev_point_sampling': (c_int, [c_void_p] * 9 + [c_int] * 5 + [c_float, c_float] + [c_void_p] * 4),
     'fbbev_da_cross_attn_fwd': (c_int, [c_void_p] * 9 + [c_int] * 10 + [c_float, c_float, c_int, c_void_p, c_void_p]),
@@ -372,4 +373,17 @@ def history_warp(history, rt_flow, out):
                                         _dev(rt_flow, F32, 'rt_flow'), B, CH, Z, Y, X,
                                         _dev(out, F32, 'out', contiguous=False), out.stride(0), _stream()),
                'fbbev_history_warp')
+    return out
+
+
+def layernorm(x, weight, bias, eps, residual=None, out=None):
+    """LayerNorm over the last dim of a contiguous f32 GPU tensor (C % 4 == 0, C <= 128); out = LN(x [+ residual])."""
+    C = x.shape[-1]
+    rows = x.numel() // C
+    if out is None:
+        out = torch.empty_like(x)
+    with _on(x):
+        _check(lib().fbbev_layernorm(_dev(x, F32, 'x'), _dev(residual, F32, 'residual') if residual is not None else None,
+                                     _dev(weight, F32, 'weight'), _dev(bias, F32, 'bias'), float(eps), rows, C,
+                                     _dev(out, F32, 'out'), _stream()), 'fbbev_layernorm')
     return out

@@ -375,6 +375,20 @@ class DA_SpatialCrossAttention(nn.Module):
         return self.dropout(slots) + inp_residual
 
 
+class LayerNorm(nn.LayerNorm):
+    """torch.nn.LayerNorm (= mmcv build_norm_layer('LN')) whose inference forward runs fbbev_layernorm: half a wave64
+    per 80-float row instead of torch's generic kernel (150 us -> ~25 us on 160k rows).  Same parameters / state_dict;
+    with autograd enabled, or for shapes the kernel does not take, it is exactly nn.LayerNorm."""
+
+    def forward(self, x):
+        C = x.shape[-1]
+        if (x.is_cuda and x.dtype == torch.float32 and self.elementwise_affine and self.bias is not None and
+                len(self.normalized_shape) == 1 and C % 4 == 0 and C <= 128 and x.is_contiguous() and
+                not (torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad))):
+            return _capi.layernorm(x, self.weight, self.bias, self.eps)
+        return super().forward(x)
+
+
 @register
 class BEVFormerEncoderLayer(nn.Module):
     """bevformer_encoder.py:206-377 (+ custom_base_transformer_layer.py:38-175)."""
@@ -404,7 +418,7 @@ class BEVFormerEncoderLayer(nn.Module):
             ffn['feedforward_channels'] = feedforward_channels     # deprecated-arg override (:88-99)
             ffn['ffn_drop'] = ffn_dropout
         self.ffns = nn.ModuleList([build(ffn) for _ in range(operation_order.count('ffn'))])
-        self.norms = nn.ModuleList([nn.LayerNorm(self.embed_dims) for _ in range(operation_order.count('norm'))])
+        self.norms = nn.ModuleList([LayerNorm(self.embed_dims) for _ in range(operation_order.count('norm'))])
 
     def forward(self, query, key=None, value=None, bev_pos=None, ref_2d=None, ref_3d=None, bev_h=None, bev_w=None,
                 reference_points_cam=None, spatial_shapes=None, level_start_index=None, bev_mask=None,

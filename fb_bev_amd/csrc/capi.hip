@@ -9,6 +9,7 @@
 #include "geom_kernels.h"
 #include "da_kernels.h"
 #include "history_kernels.h"
+#include "norm_kernels.h"
 #include "../../include/fbbev.h"
 
 #define FBBEV_CHECK_LAUNCH()                      \
@@ -764,6 +765,21 @@ extern "C" int fbbev_history_warp(const float* history, long long history_stride
     const int per_xcd = (int)((blocks + 7) / 8);
     FBBEV_LAUNCH(k_history_warp, (long long)per_xcd * 8, 256, 0, (fbbev_rt_stream)stream_, history, history_stride_b, rt_flow,
                  CH, Z, Y, X, cpb, n_groups, n_chunks, per_xcd, (int)blocks, out, out_stride_b);
+    FBBEV_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------ LayerNorm over short rows
+extern "C" int fbbev_layernorm(const float* x, const float* residual, const float* weight, const float* bias, float eps,
+                               long long rows, int C, float* out, fbbev_stream_t stream_) {
+    if (rows < 0 || C <= 0 || !(eps >= 0.f)) return FBBEV_E_BADARG;
+    if (rows == 0) return 0;
+    if (!x || !weight || !bias || !out) return FBBEV_E_BADARG;
+    if (C % 4 != 0 || C > 128 || !aligned16(x) || !aligned16(out) || !aligned16(weight) || !aligned16(bias) ||
+        (residual && !aligned16(residual))) return FBBEV_E_UNSUPPORTED;
+    const long long blocks = (rows + 7) / 8;          // 8 half-waves per 256-thread workgroup
+    if (blocks >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
+    FBBEV_LAUNCH(k_layernorm_rows, blocks, 256, 0, (fbbev_rt_stream)stream_, x, residual, weight, bias, eps, rows, C, out);
     FBBEV_CHECK_LAUNCH();
     return 0;
 }

@@ -249,6 +249,13 @@ int fbbev_history_flow(const float* history_forward_augs, const float* curr_to_p
 int fbbev_history_warp(const float* history, long long history_stride_b, const float* rt_flow, int B, int CH, int Z,
                        int Y, int X, float* out, long long out_stride_b, fbbev_stream_t stream);
 
+/* LayerNorm over the last dimension of (rows, C) f32, optional residual:  out = LN(x + residual) * weight + bias
+ * (biased variance, eps inside the square root: torch.nn.LayerNorm = mmcv build_norm_layer('LN'), the `norm` steps of
+ * BEVFormerEncoderLayer, bevformer_encoder.py:250-377).  C % 4 == 0, C <= 128, 16-byte aligned pointers, else
+ * FBBEV_E_UNSUPPORTED (callers keep torch's kernel).  residual may be NULL; out may alias x. */
+int fbbev_layernorm(const float* x, const float* residual, const float* weight, const float* bias, float eps,
+                    long long rows, int C, float* out, fbbev_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

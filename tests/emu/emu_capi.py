@@ -185,3 +185,11 @@ def history_warp(history, flow, out=None):
     ok(lib().fbbev_history_warp(c_void_p(history.data_ptr()), history.stride(0), p(flow), B, CH, Z, Y, X,
                                 c_void_p(out.data_ptr()), out.stride(0), None))
     return out
+
+
+def layernorm(x, weight, bias, eps, residual=None):
+    C = x.shape[-1]
+    out = torch.full_like(x, float('nan'))
+    ok(lib().fbbev_layernorm(p(x), p(residual) if residual is not None else None, p(weight), p(bias), eps,
+                             x.numel() // C, C, p(out), None))
+    return out

@@ -406,3 +406,15 @@ def test_f16_conversion_edge_cases_emulated():
         hit = got.float().abs().sum(1) > 0
         assert hit.any()
         assert torch.equal(got[hit].view(torch.int16), vals.to(dt).view(torch.int16).expand(int(hit.sum()), C))
+
+
+@pytest.mark.parametrize('rows,C', [(37, 80), (8, 128), (5, 4), (64, 64)])
+def test_layernorm_rows_emulated(rows, C):
+    g = torch.Generator().manual_seed(rows)
+    x = torch.randn(rows, C, generator=g) * 3 + 1.5
+    r = torch.randn(rows, C, generator=g)
+    w, b = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    exp = torch.nn.functional.layer_norm(x, (C,), w, b, 1e-5)
+    assert torch.allclose(E.layernorm(x, w, b, 1e-5), exp, atol=2e-6, rtol=1e-5)
+    exp2 = torch.nn.functional.layer_norm(x + r, (C,), w, b, 1e-5)
+    assert torch.allclose(E.layernorm(x, w, b, 1e-5, residual=r), exp2, atol=2e-6, rtol=1e-5)

@@ -138,3 +138,16 @@ def test_point_sampling_kernel_vs_reference_python_fixture(dev):
     vis = m_r & m_g
     assert np.allclose(ref_cam[:, :, sub].cpu().numpy()[vis], z['ref_cam'][vis], atol=5e-5)
     assert np.allclose(qd[:, :, sub].cpu().numpy()[vis], z['qdepth'][vis], atol=5e-4, rtol=1e-5)
+
+
+def test_layernorm_kernel_vs_torch(dev):
+    from fb_bev_amd import _capi
+    g = torch.Generator().manual_seed(0)
+    for rows, C in ((160000, 80), (1000, 128), (7, 4)):
+        x = (torch.randn(rows, C, generator=g) * 2 + 0.5).to(dev)
+        r = torch.randn(rows, C, generator=g).to(dev)
+        w, b = torch.randn(C, generator=g).to(dev), torch.randn(C, generator=g).to(dev)
+        exp = torch.nn.functional.layer_norm(x, (C,), w, b, 1e-5)
+        assert (_capi.layernorm(x, w, b, 1e-5) - exp).abs().max().item() < 1e-5
+        exp2 = torch.nn.functional.layer_norm(x + r, (C,), w, b, 1e-5)
+        assert (_capi.layernorm(x, w, b, 1e-5, residual=r) - exp2).abs().max().item() < 1e-5
