@@ -39,6 +39,7 @@ SIGNATURES = {
     'fbbev_msda_fwd': (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_void_p, c_void_p]),
     'fbbev_point_sampling': (c_int, [c_void_p] * 9 + [c_int] * 5 + [c_float, c_float] + [c_void_p] * 4),
     'fbbev_da_cross_attn_fwd': (c_int, [c_void_p] * 9 + [c_int] * 10 + [c_float, c_float, c_int, c_void_p, c_void_p]),
+    'fbbev_da_cross_attn_bwd': (c_int, [c_void_p] * 10 + [c_int] * 10 + [c_float, c_float, c_int] + [c_void_p] * 5),
     'fbbev_msda_bwd': (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p] * 3 + [c_void_p]),
 }
 
@@ -320,6 +321,28 @@ def da_cross_attn_fwd(value, spatial_shapes, level_start_index, pred_depth, ref_
             _dev(ref_cam, F32, 'ref_cam'), _dev(mask, torch.uint8, 'mask'), _dev(qdepth, F32, 'qdepth'),
             _dev(offsets, F32, 'offsets'), _dev(attn, F32, 'attn'), B, Ncam, S, M, Dh, L, Q, P, Za, DC,
             float(d0), float(dstep), head_minor, _dev(slots, F32, 'slots'), _stream()), 'fbbev_da_cross_attn_fwd')
+
+
+def da_cross_attn_bwd(value, spatial_shapes, level_start_index, pred_depth, ref_cam, mask, qdepth, offsets, attn,
+                      grad_slots, d0, dstep, head_minor, grad_value, grad_pred_depth, grad_offsets, grad_attn):
+    """Backward of da_cross_attn_fwd; the four grad tensors must be pre-zeroed (accumulated into)."""
+    Ncam, B, Q, Za = mask.shape
+    _, S, M, Dh = value.shape
+    head_minor = int(head_minor)
+    L, P = (attn.shape[2], attn.shape[3]) if head_minor & 2 else (attn.shape[3], attn.shape[4])
+    DC = pred_depth.shape[1]
+    if mask.dtype == torch.bool:
+        mask = mask.view(torch.uint8)
+    with _on(value):
+        _check(lib().fbbev_da_cross_attn_bwd(
+            _dev(value, F32, 'value'), _dev(spatial_shapes, I64, 'spatial_shapes'),
+            _dev(level_start_index, I64, 'level_start_index'), _dev(pred_depth, F32, 'pred_depth'),
+            _dev(ref_cam, F32, 'ref_cam'), _dev(mask, torch.uint8, 'mask'), _dev(qdepth, F32, 'qdepth'),
+            _dev(offsets, F32, 'offsets'), _dev(attn, F32, 'attn'), _dev(grad_slots, F32, 'grad_slots'),
+            B, Ncam, S, M, Dh, L, Q, P, Za, DC, float(d0), float(dstep), head_minor,
+            _dev(grad_value, F32, 'grad_value'), _dev(grad_pred_depth, F32, 'grad_pred_depth'),
+            _dev(grad_offsets, F32, 'grad_offsets'), _dev(grad_attn, F32, 'grad_attn'), _stream()),
+            'fbbev_da_cross_attn_bwd')
 
 
 def point_sampling(xs, ys, zs, rots, trans, intrins, post_rots, post_trans, bda, ogfH, ogfW, ref_cam, mask, qdepth):

@@ -281,6 +281,37 @@ class DA_MSDeformableAttention(nn.Module):
         return out
 
 
+class FusedDACrossAttention(torch.autograd.Function):
+    """fbbev_da_cross_attn_fwd / fbbev_da_cross_attn_bwd as one differentiable op: gradients for the projected
+    camera tokens (`value`), the depth distribution, the raw sampling offsets and the softmaxed attention weights; the
+    geometry inputs (reference points, masks, query depths) carry none, as in the reference (they come from
+    point_sampling on camera parameters).  No host sync in either direction."""
+
+    @staticmethod
+    def forward(ctx, value, pred_depth, offsets, attn, spatial_shapes, level_start_index, ref_cam, mask, qdepth,
+                d0, dstep, head_minor):
+        B, Q = offsets.shape[0], offsets.shape[1]
+        M, Dh = value.shape[2], value.shape[3]
+        slots = torch.empty((B, Q, M * Dh), dtype=torch.float32, device=value.device)
+        _capi.da_cross_attn_fwd(value, spatial_shapes, level_start_index, pred_depth, ref_cam, mask, qdepth, offsets,
+                                attn, d0, dstep, slots, head_minor=head_minor)
+        ctx.save_for_backward(value, pred_depth, offsets, attn, spatial_shapes, level_start_index, ref_cam, mask, qdepth)
+        ctx.consts = (d0, dstep, head_minor)
+        return slots
+
+    @staticmethod
+    def backward(ctx, grad_slots):
+        value, pred_depth, offsets, attn, spatial_shapes, level_start_index, ref_cam, mask, qdepth = ctx.saved_tensors
+        d0, dstep, head_minor = ctx.consts
+        gv, gd, go, ga = (torch.zeros_like(t) for t in (value, pred_depth, offsets, attn))
+        _capi.da_cross_attn_bwd(value, spatial_shapes, level_start_index, pred_depth, ref_cam, mask, qdepth, offsets,
+                                attn, grad_slots.contiguous().float(), d0, dstep, head_minor, gv, gd, go, ga)
+        return gv, gd, go, ga, None, None, None, None, None, None, None, None
+
+
+FUSED_BWD_MAX_HEAD_DIM = 32                 # k_da_cross_attn_bwd: one lane per channel, groups of 16 / 32 lanes
+
+
 @register
 class DA_SpatialCrossAttention(nn.Module):
     """spatial_cross_attention_depth.py:31-223."""
@@ -307,14 +338,11 @@ class DA_SpatialCrossAttention(nn.Module):
         v = da.value_proj(value.permute(2, 0, 1, 3).reshape(B * ncam, S, E)).view(B * ncam, S, da.num_heads, -1)
         so, aw = da.project_head_minor(query)
         DC, H0, W0 = pred_img_depth.shape[2:]
-        slots = torch.empty((B, Q, E), dtype=torch.float32, device=query.device)
-        _capi.da_cross_attn_fwd(v.contiguous().float(), spatial_shapes.to(torch.int64).contiguous(),
-                                level_start_index.to(torch.int64).contiguous(),
-                                pred_img_depth.reshape(B * ncam, DC, H0, W0).contiguous().float(),
-                                reference_points_cam.contiguous().float(), mask.contiguous(),
-                                bev_query_depth.squeeze(-1).contiguous().float(), so.contiguous().float(),
-                                aw.contiguous().float(), self.dbound[0], self.dbound[2], slots, head_minor=1)
-        return slots
+        return FusedDACrossAttention.apply(
+            v.contiguous().float(), pred_img_depth.reshape(B * ncam, DC, H0, W0).contiguous().float(),
+            so.contiguous().float(), aw.contiguous().float(), spatial_shapes.to(torch.int64).contiguous(),
+            level_start_index.to(torch.int64).contiguous(), reference_points_cam.contiguous().float(), mask.contiguous(),
+            bev_query_depth.squeeze(-1).contiguous().float(), self.dbound[0], self.dbound[2], 1)
 
     # ---- training: vectorised rebatch + composite deformable attention (autograd through the MSDA op)
     def _slots_composite(self, query, value, reference_points_cam, mask, bev_query_depth, pred_img_depth,
@@ -366,7 +394,9 @@ class DA_SpatialCrossAttention(nn.Module):
         needs_grad = torch.is_grad_enabled() and any(
             t is not None and t.requires_grad for t in (query, value, pred_img_depth)) or \
             (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()))
-        fn = self._slots_composite if (needs_grad or not self.fused) else self._slots_fused
+        head_dim = self.embed_dims // self.deformable_attention.num_heads
+        fused_ok = self.fused and (not needs_grad or head_dim <= FUSED_BWD_MAX_HEAD_DIM)
+        fn = self._slots_fused if fused_ok else self._slots_composite
         slots = fn(query, value, reference_points_cam, mask, bev_query_depth, pred_img_depth, spatial_shapes,
                    level_start_index)
         slots = self.output_proj(slots)

@@ -650,6 +650,35 @@ extern "C" int fbbev_da_cross_attn_fwd(const float* value, const int64_t* spatia
     return 0;
 }
 
+extern "C" int fbbev_da_cross_attn_bwd(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                       const float* pred_depth, const float* ref_cam, const uint8_t* mask,
+                                       const float* qdepth, const float* offsets, const float* attn,
+                                       const float* grad_slots, int B, int Ncam, int S, int M, int Dh, int L, int Q,
+                                       int P, int Za, int DC, float d0, float dstep, int head_minor, float* grad_value,
+                                       float* grad_pred_depth, float* grad_offsets, float* grad_attn,
+                                       fbbev_stream_t stream_) {
+    if (B <= 0 || Ncam <= 0 || S <= 0 || M <= 0 || Dh <= 0 || L <= 0 || Q < 0 || P <= 0 || Za <= 0 || DC <= 0)
+        return FBBEV_E_BADARG;
+    if (Za > FBBEV_DA_MAX_ZA || P % Za != 0) return FBBEV_E_UNSUPPORTED;
+    if (dstep == 0.f) return FBBEV_E_BADARG;
+    const long long units = (long long)B * Q * M;
+    if (units == 0) return 0;
+    if (!value || !spatial_shapes || !level_start_index || !pred_depth || !ref_cam || !mask || !qdepth || !offsets ||
+        !attn || !grad_slots || !grad_value || !grad_pred_depth || !grad_offsets || !grad_attn) return FBBEV_E_BADARG;
+    if (Dh > 32) return FBBEV_E_UNSUPPORTED;
+#define FBBEV_DA_BWD(GW_)                                                                                             \
+    FBBEV_LAUNCH(k_da_cross_attn_bwd<GW_>, (units * GW_ + 255) / 256, 256, 0, (fbbev_rt_stream)stream_, units, value,  \
+                 spatial_shapes, level_start_index, pred_depth, ref_cam, mask, qdepth, offsets, attn, grad_slots, B,  \
+                 Ncam, S, M, Dh, L, Q, P, Za, DC, d0, dstep, head_minor & 3, grad_value, grad_pred_depth,            \
+                 grad_offsets, grad_attn)
+    if ((units * 32 + 255) / 256 >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
+    if (Dh <= 16) FBBEV_DA_BWD(16);
+    else FBBEV_DA_BWD(32);
+#undef FBBEV_DA_BWD
+    FBBEV_CHECK_LAUNCH();
+    return 0;
+}
+
 // ---------------------------------------------------------------- fused lift-splat backward (training)
 struct bwd_layout { size_t table, meta, rows, total; long long n_tiles; int tpp; long long max_rows; };
 

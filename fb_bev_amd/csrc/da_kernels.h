@@ -203,3 +203,129 @@ k_da_cross_attn_fwd_unit(long long n_units, const float* __restrict__ value, con
         }
     }
 }
+
+
+// ---------------------------------------------------------------- backward of the fused sampling (training path)
+// Replaces the autograd chain of the reference's training step through DA_SpatialCrossAttention /
+// DA_MSDeformableAttention (spatial_cross_attention_depth.py:163-216,513-595 -> two MultiScaleDeformableAttnFunction
+// backward launches, multi_scale_deformable_attn_function.py:137-172, the one-hot / rebatch / scatter index ops and
+// their 6*B host syncs) with one launch.  A group of GW lanes owns a (b,q,head) unit, lane = channel (as k_msda_bwd):
+// the value-gradient atomics of a corner then hit Dh CONSECUTIVE floats from consecutive lanes (one coalesced atomic
+// request per corner instead of Dh scattered ones -- the unit-per-lane form of this kernel was 3x slower for it).
+//   grad_attn, grad_offsets : owned by the unit -> lane 0 of the group accumulates them over the hit cameras with plain
+//                             read-modify-writes (buffers pre-zeroed by the caller; layouts = the forward's)
+//   grad_value              : fp32 hardware atomics (corners shared between units), as mmcv's col2im
+//   grad_pred_depth         : the depth weight dw[z] is ONE bilinear sample of the query's bin plane; its gradient
+//                             ddw[z] = sum over the samples of anchor z of attn * <grad, sampled value> goes back
+//                             to the four corners of that plane by atomics
+// Bilinear-gradient terms follow mmcv's ms_deform_attn_col2im_bilinear (grad_h_weight / grad_w_weight); since
+// loc = ref + offset / size and im = loc * size - 0.5, d im / d offset = 1.
+// Control flow is wave-uniform (cameras nobody in the wave hits are skipped by a ballot) because the group
+// reductions are cross-lane shuffles.
+template <int GW>
+__global__ void __launch_bounds__(256)
+k_da_cross_attn_bwd(long long n_units, const float* __restrict__ value, const int64_t* __restrict__ spatial_shapes,
+                    const int64_t* __restrict__ level_start, const float* __restrict__ pred_depth,
+                    const float* __restrict__ ref_cam, const unsigned char* __restrict__ mask,
+                    const float* __restrict__ qdepth, const float* __restrict__ offsets,
+                    const float* __restrict__ attn, const float* __restrict__ grad_slots, int B, int Ncam, int S,
+                    int M, int Dh, int L, int Q, int P, int Za, int DC, float d0, float dstep, int head_minor,
+                    float* __restrict__ grad_value, float* __restrict__ grad_pred_depth,
+                    float* __restrict__ grad_offsets, float* __restrict__ grad_attn) {
+    const int slot = threadIdx.x % GW;
+    const long long unit = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / GW;
+    const bool active = unit < n_units;
+    const long long u = active ? unit : 0;
+    const int row_stride = M * Dh;
+    const int H0 = (int)spatial_shapes[0], W0 = (int)spatial_shapes[1];
+    const int m = (int)(u % M);
+    const long long bq = u / M;
+    const int q = (int)(bq % Q);
+    const int b = (int)(bq / Q);
+    const bool chan = active && slot < Dh;
+    int count = 0;
+    for (int cam = 0; cam < Ncam; ++cam) {
+        const long long base = (((long long)cam * B + b) * Q + q) * Za;
+        bool hit = false;
+        for (int z = 0; z < Za; ++z) hit = hit || (mask[base + z] != 0);
+        count += hit ? 1 : 0;
+    }
+    const float g = chan ? grad_slots[u * Dh + slot] / (float)(count > 1 ? count : 1) : 0.f;
+    for (int cam = 0; cam < Ncam; ++cam) {
+        const long long base = (((long long)cam * B + b) * Q + q) * Za;
+        bool hit = false;
+        for (int z = 0; z < Za; ++z) hit = hit || (mask[base + z] != 0);
+        hit = hit && active;
+        if (__ballot(hit ? 1 : 0) == 0ull) continue;                      // wave-uniform skip
+        const long long bn = (long long)b * Ncam + cam;
+        float rx[FBBEV_DA_MAX_ZA], ry[FBBEV_DA_MAX_ZA], dw[FBBEV_DA_MAX_ZA], ddw[FBBEV_DA_MAX_ZA];
+        int bin[FBBEV_DA_MAX_ZA];
+        for (int z = 0; z < Za; ++z) {
+            rx[z] = ry[z] = dw[z] = ddw[z] = 0.f;
+            bin[z] = 0;
+            if (hit) {
+                rx[z] = ref_cam[(base + z) * 2];
+                ry[z] = ref_cam[(base + z) * 2 + 1];
+                float fb = floorf(__fdiv_rn(__fsub_rn(qdepth[base + z], d0), dstep));
+                fb = fminf(fmaxf(fb, 0.f), (float)(DC - 1));
+                bin[z] = (int)fb;
+                dw[z] = fbbev_plane_sample(pred_depth + (bn * DC + bin[z]) * (long long)(H0 * W0), H0, W0, rx[z], ry[z]);
+            }
+        }
+        for (int l = 0; l < L; ++l) {
+            const int sh = (int)spatial_shapes[2 * l], sw = (int)spatial_shapes[2 * l + 1];
+            const long long voff = (bn * S + level_start[l]) * row_stride + m * Dh + slot;
+            for (int p = 0; p < P; ++p) {
+                const long long wm = (u * L + l) * P + p, wh = ((bq * L + l) * P + p) * M + m;
+                const long long wo = (head_minor & 1) ? wh : wm, wa = (head_minor & 2) ? wh : wm;
+                const int z = p % Za;
+                float a = 0.f, h_im = -2.f, w_im = -2.f;
+                if (hit) {
+                    const float loc_w = rx[z] + __fdiv_rn(offsets[wo * 2], (float)sw);
+                    const float loc_h = ry[z] + __fdiv_rn(offsets[wo * 2 + 1], (float)sh);
+                    a = attn[wa];
+                    h_im = loc_h * sh - 0.5f;
+                    w_im = loc_w * sw - 0.5f;
+                }
+                const bool inr = hit && h_im > -1.f && w_im > -1.f && h_im < (float)sh && w_im < (float)sw;
+                const float weight = a * dw[z];
+                float dot = 0.f, gx = 0.f, gy = 0.f;     // <g, sample>, d/d w_im, d/d h_im of <g, sample>
+                if (inr && chan) {
+                    const fbbev_bilinear s = fbbev_bilinear_setup(h_im, w_im, sh, sw, row_stride);
+                    const float* vp = value + voff;
+                    float* gp = grad_value + voff;
+                    const float tgv = g * weight;
+                    float v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;
+                    if (s.o1 >= 0) { v1 = vp[s.o1]; fbbev_atomic_add_f32(gp + s.o1, s.w1 * tgv); }
+                    if (s.o2 >= 0) { v2 = vp[s.o2]; fbbev_atomic_add_f32(gp + s.o2, s.w2 * tgv); }
+                    if (s.o3 >= 0) { v3 = vp[s.o3]; fbbev_atomic_add_f32(gp + s.o3, s.w3 * tgv); }
+                    if (s.o4 >= 0) { v4 = vp[s.o4]; fbbev_atomic_add_f32(gp + s.o4, s.w4 * tgv); }
+                    dot = g * (s.w1 * v1 + s.w2 * v2 + s.w3 * v3 + s.w4 * v4);
+                    gy = g * (-s.hw * v1 - s.lw * v2 + s.hw * v3 + s.lw * v4);
+                    gx = g * (-s.hh * v1 + s.hh * v2 - s.lh * v3 + s.lh * v4);
+                }
+                dot = fbbev_group_sum<GW>(dot);
+                gx = fbbev_group_sum<GW>(gx);
+                gy = fbbev_group_sum<GW>(gy);
+                if (inr && slot == 0) {
+                    grad_attn[wa] += dw[z] * dot;
+                    grad_offsets[wo * 2] += weight * gx;
+                    grad_offsets[wo * 2 + 1] += weight * gy;
+                    ddw[z] += a * dot;
+                }
+            }
+        }
+        if (hit && slot == 0) {
+            for (int z = 0; z < Za; ++z) {       // dw[z] -> the four corners of the query's bin plane (fbbev_plane_sample)
+                const float h_im = ry[z] * H0 - 0.5f, w_im = rx[z] * W0 - 0.5f;
+                if (!(h_im > -1.f && w_im > -1.f && h_im < (float)H0 && w_im < (float)W0) || ddw[z] == 0.f) continue;
+                const fbbev_bilinear s = fbbev_bilinear_setup(h_im, w_im, H0, W0, 1);
+                float* gd = grad_pred_depth + (bn * DC + bin[z]) * (long long)(H0 * W0);
+                if (s.o1 >= 0) fbbev_atomic_add_f32(gd + s.o1, s.w1 * ddw[z]);
+                if (s.o2 >= 0) fbbev_atomic_add_f32(gd + s.o2, s.w2 * ddw[z]);
+                if (s.o3 >= 0) fbbev_atomic_add_f32(gd + s.o3, s.w3 * ddw[z]);
+                if (s.o4 >= 0) fbbev_atomic_add_f32(gd + s.o4, s.w4 * ddw[z]);
+            }
+        }
+    }
+}

@@ -215,6 +215,19 @@ int fbbev_da_cross_attn_fwd(const float* value, const int64_t* spatial_shapes,
                             int L, int Q, int P, int Za, int DC, float d0, float dstep, int head_minor,
                             float* slots, fbbev_stream_t stream);
 
+/* Backward of fbbev_da_cross_attn_fwd in one launch -- replaces the autograd chain of the reference's training step
+ * through DA_SpatialCrossAttention / DA_MSDeformableAttention (two MultiScaleDeformableAttnFunction backward launches,
+ * multi_scale_deformable_attn_function.py:137-172, plus the rebatch / one-hot / scatter index ops and their host syncs).
+ * Inputs as the forward + grad_slots (B,Q,M*Dh).  Outputs, all PRE-ZEROED by the caller (the mmcv convention,
+ * :159-169): grad_value like value and grad_pred_depth like pred_depth (accumulated with fp32 atomics), grad_offsets /
+ * grad_attn in the layouts of offsets / attn (head_minor bits).  Dh <= 32, else FBBEV_E_UNSUPPORTED. */
+int fbbev_da_cross_attn_bwd(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                            const float* pred_depth, const float* ref_cam, const uint8_t* mask, const float* qdepth,
+                            const float* offsets, const float* attn, const float* grad_slots, int B, int Ncam, int S,
+                            int M, int Dh, int L, int Q, int P, int Za, int DC, float d0, float dstep, int head_minor,
+                            float* grad_value, float* grad_pred_depth, float* grad_offsets, float* grad_attn,
+                            fbbev_stream_t stream);
+
 /* Training backward of the fused lift-splat:  replaces QuickCumsumCuda.backward (bev_pool.py:39-78 --
  * argsort of ranks_feat, mask-built intervals [2 host syncs], the permute().contiguous() of the gradient)
  * and bev_pool_v2_backward / bev_pool_v2_grad_kernel (src/bev_pool_cuda.cu:52-100,128-135).

@@ -193,3 +193,15 @@ def layernorm(x, weight, bias, eps, residual=None):
     ok(lib().fbbev_layernorm(p(x), p(residual) if residual is not None else None, p(weight), p(bias), eps,
                              x.numel() // C, C, p(out), None))
     return out
+
+
+def da_cross_attn_bwd(value, ss, ls, pred_depth, ref_cam, mask, qdepth, offsets, attn, d0, dstep, grad_slots, head_minor=0):
+    Ncam, B, Q, Za = mask.shape
+    _, S, M, Dh = value.shape
+    L, P = (attn.shape[2], attn.shape[3]) if head_minor & 2 else (attn.shape[3], attn.shape[4])
+    gv, gd, go, ga = (torch.zeros_like(t) for t in (value, pred_depth, offsets, attn))
+    m8 = mask.to(torch.uint8).contiguous()
+    ok(lib().fbbev_da_cross_attn_bwd(p(value), p(ss), p(ls), p(pred_depth), p(ref_cam), p(m8), p(qdepth), p(offsets),
+                                     p(attn), p(grad_slots), B, Ncam, S, M, Dh, L, Q, P, Za, pred_depth.shape[1], d0,
+                                     dstep, int(head_minor), p(gv), p(gd), p(go), p(ga), None))
+    return gv, gd, go, ga

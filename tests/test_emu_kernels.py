@@ -153,7 +153,7 @@ def test_lidar_coor_emulated():
         assert (got - exp).abs().max().item() < 2e-4   # metres; closed-form vs LU inverse
 
 
-def _da_case(seed=0, B=2, N=6, Q=70, Za=4, E=16, M=4, shapes=((5, 7), (3, 4)), P=8, DC=12):
+def _da_case(seed=0, B=2, N=6, Q=70, Za=4, E=16, M=4, shapes=((5, 7), (3, 4)), P=8, DC=12, grad=False):
     """Random DA cross-attention case + the oracle's composite result (slots before output_proj)."""
     from oracle import backward_projection_oracle as BO
     g = torch.Generator().manual_seed(seed)
@@ -174,6 +174,11 @@ def _da_case(seed=0, B=2, N=6, Q=70, Za=4, E=16, M=4, shapes=((5, 7), (3, 4)), P
     mask[2] = False
     qdepth = torch.rand(N, B, Q, Za, 1, generator=g) * (DC + 4.0)
     pred = torch.rand(B, N, DC, H0, W0, generator=g).softmax(2).contiguous()
+    if grad:      # double-precision leaves for the autograd cross-check of the fused backward
+        Pm = {k: v.double().requires_grad_() for k, v in Pm.items()}
+        query, qpos, key, ref_cam, qdepth = (t.double() for t in (query, qpos, key, ref_cam, qdepth))
+        pred = pred.double().requires_grad_()
+        key.requires_grad_()
     exp = BO.da_spatial_cross_attention(Pm, 'a.', query, key, key, qpos, ref_cam, mask, qdepth, pred, ss, ls, dbound,
                                         num_cams=N, return_slots=True, num_heads=M, num_levels=L, num_points=P)
     # what the host hands to the fused kernel: camera-independent per-query projections
@@ -188,6 +193,8 @@ def _da_case(seed=0, B=2, N=6, Q=70, Za=4, E=16, M=4, shapes=((5, 7), (3, 4)), P
                      Pm['a.deformable_attention.value_proj.bias']).view(B * N, S_, M, E // M).contiguous()
     args = (value, ss, ls, pred.view(B * N, DC, H0, W0), ref_cam.contiguous(), mask.contiguous(),
             qdepth.squeeze(-1).contiguous(), offsets, attn, dbound[0], dbound[2])
+    if grad:
+        return args, exp, dict(Pm=Pm, key=key, pred=pred)
     return args, exp
 
 
@@ -418,3 +425,36 @@ def test_layernorm_rows_emulated(rows, C):
     assert torch.allclose(E.layernorm(x, w, b, 1e-5), exp, atol=2e-6, rtol=1e-5)
     exp2 = torch.nn.functional.layer_norm(x + r, (C,), w, b, 1e-5)
     assert torch.allclose(E.layernorm(x, w, b, 1e-5, residual=r), exp2, atol=2e-6, rtol=1e-5)
+
+
+def test_fused_da_cross_attention_backward_emulated():
+    """fbbev_da_cross_attn_bwd: the four gradients, pushed back to the leaves with torch autograd, against the
+    double-precision autograd of the oracle's loop-for-loop restatement of the reference's training path."""
+    for seed, kw in ((5, dict(B=1, Q=29, E=16, M=4)),                       # Dh = 4
+                     (6, dict(B=2, Q=17, E=40, M=4, shapes=((4, 6), (2, 3))))):   # Dh = 10
+        args, exp, leaves = _da_case(seed, grad=True, **kw)
+        g = torch.randn(exp.shape, generator=torch.Generator().manual_seed(seed), dtype=torch.float64)
+        wrt = [leaves['key'], leaves['pred']] + [leaves['Pm'][k] for k in sorted(leaves['Pm']) if 'output_proj' not in k]
+        ref = torch.autograd.grad(exp, wrt, grad_outputs=g, retain_graph=True, allow_unused=True)
+        value, ss, ls, pred4, ref_cam, mask, qdepth, offsets, attn, d0, dstep = args
+        f32 = lambda t: t.detach().float().contiguous()  # noqa: E731
+        got = E.da_cross_attn_fwd(f32(value), ss, ls, f32(pred4), f32(ref_cam), mask, f32(qdepth), f32(offsets), f32(attn),
+                                  d0, dstep)
+        assert torch.allclose(got.double(), exp.detach(), atol=2e-5, rtol=1e-5)
+        for hm in (0, 1, 3):
+            o_in = f32(offsets).permute(0, 1, 3, 4, 2, 5).contiguous() if hm & 1 else f32(offsets)
+            a_in = f32(attn).permute(0, 1, 3, 4, 2).contiguous() if hm & 2 else f32(attn)
+            gv, gd, go, ga = E.da_cross_attn_bwd(f32(value), ss, ls, f32(pred4), f32(ref_cam), mask, f32(qdepth), o_in, a_in,
+                                                 d0, dstep, f32(g), head_minor=hm)
+            if hm & 1:
+                go = go.permute(0, 1, 4, 2, 3, 5)
+            if hm & 2:
+                ga = ga.permute(0, 1, 4, 2, 3)
+            mine = torch.autograd.grad([value, pred4, offsets, attn], wrt,
+                                       grad_outputs=[gv.double(), gd.double(), go.double(), ga.double()],
+                                       retain_graph=True, allow_unused=True)
+            for a, b in zip(mine, ref):
+                if b is None:
+                    assert a is None or not a.any()
+                    continue
+                assert torch.allclose(a, b, atol=5e-5 * max(1.0, b.abs().max().item()), rtol=1e-4), hm

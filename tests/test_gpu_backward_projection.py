@@ -81,17 +81,24 @@ def test_backward_projection_module_vs_oracle(dev, num_levels):
     assert err.median().item() < 1e-5
 
 
-def test_composite_path_equals_fused_and_backprops(dev):
+@pytest.mark.parametrize('train_fused', [True, False])
+def test_training_paths_equal_inference_and_backprop(dev, train_fused):
+    """train_fused=True: FusedDACrossAttention (fbbev_da_cross_attn_fwd + _bwd, no host sync);
+    False: the composite rebatch + MSDA-op path.  Both against the fused inference output and the oracle's autograd."""
     from oracle import backward_projection_oracle as BO, oracle as O
+    from fb_bev_amd.backward_projection import DA_SpatialCrossAttention
     bev = 12
     m, cfg, cam, feats, depth, lss, gcb = _setup(dev, B=1, num_levels=1, bev=bev, seed=3)
     cam_g = [t.to(dev) for t in cam]
     with torch.no_grad():
         fused = m([f.to(dev) for f in feats], None, lss_bev=lss.to(dev), cam_params=cam_g, pred_img_depth=depth.to(dev))
+    for mod in m.modules():
+        if isinstance(mod, DA_SpatialCrossAttention):
+            mod.fused = train_fused
     f_g = [f.to(dev).requires_grad_() for f in feats]
     d_g = depth.to(dev).requires_grad_()
     l_g = lss.to(dev).requires_grad_()
-    comp = m(f_g, None, lss_bev=l_g, cam_params=cam_g, pred_img_depth=d_g)       # grad enabled -> composite path
+    comp = m(f_g, None, lss_bev=l_g, cam_params=cam_g, pred_img_depth=d_g)       # grad enabled -> training path
     assert torch.allclose(comp, fused, atol=1e-4, rtol=1e-4)
     w = torch.randn(comp.shape, generator=torch.Generator().manual_seed(9))
     (comp * w.to(dev)).sum().backward()
@@ -151,3 +158,22 @@ def test_layernorm_kernel_vs_torch(dev):
         assert (_capi.layernorm(x, w, b, 1e-5) - exp).abs().max().item() < 1e-5
         exp2 = torch.nn.functional.layer_norm(x + r, (C,), w, b, 1e-5)
         assert (_capi.layernorm(x, w, b, 1e-5, residual=r) - exp2).abs().max().item() < 1e-5
+
+
+def test_fused_training_step_has_no_host_sync(dev):
+    """forward + backward of the backward projection with autograd enabled: FusedDACrossAttention, no nonzero()/max()."""
+    m, cfg, cam, feats, depth, lss, gcb = _setup(dev, B=2, num_levels=1, bev=16, seed=1)
+    cam_g = [t.to(dev) for t in cam]
+    f_g = [f.to(dev).requires_grad_() for f in feats]
+    d_g, l_g = depth.to(dev).requires_grad_(), lss.to(dev).requires_grad_()
+    m(f_g, None, lss_bev=l_g, cam_params=cam_g, pred_img_depth=d_g).sum().backward()      # warm-up (allocations, caches)
+    for t in f_g + [d_g, l_g]:
+        t.grad = None
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode('error')
+    try:
+        m(f_g, None, lss_bev=l_g, cam_params=cam_g, pred_img_depth=d_g).sum().backward()
+    finally:
+        torch.cuda.set_sync_debug_mode('default')
+    torch.cuda.synchronize()
+    assert all(t.grad is not None and torch.isfinite(t.grad).all() for t in f_g + [d_g, l_g])

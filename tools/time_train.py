@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Forward + backward (training) step of the view-transformation path on one GPU:
+python tools/time_train.py CONFIG BATCH [levels]   -> JSON (ms per step, fwd/bwd split, top autograd-free check)"""
+import json, os, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+from fb_bev_amd import configs, synthetic as S
+from fb_bev_amd.fb_view_transform import FBViewTransform
+
+
+def main():
+    name = sys.argv[1] if len(sys.argv) > 1 else 'REF'
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    dev = torch.device('cuda:0')
+    pc = S.CONFIGS[name]
+    X, Y, Z = pc.grid_xyz
+    gcb = {'x': pc.grid_config['x'], 'y': pc.grid_config['y'], 'z': [-1, 5.4, 1.6]}
+    cfg = configs.fbocc_r50(bev_h=Y, bev_w=X, numC_Trans=pc.channels, input_size=pc.input_size, grid_config=pc.grid_config,
+                            grid_config_bevformer=gcb, depth_bound=tuple(pc.grid_config['depth']), downsample=pc.downsample)
+    m = FBViewTransform(cfg['forward_projection'], cfg['backward_projection']).to(dev).train()
+    cam = [t.to(dev) for t in S.camera_rig(pc, B, seed=0, bda_aug=True)]
+    depth, ctx = S.depth_and_context(pc, B, seed=0)
+    depth, ctx = depth.to(dev).requires_grad_(), ctx.to(dev).requires_grad_()
+    w = torch.randn(B, pc.channels, Y, X, Z, device=dev)
+
+    def step():
+        for p in m.parameters():
+            p.grad = None
+        depth.grad = ctx.grad = None
+        out = m(cam, ctx, depth)
+        loss = (out * w).sum()
+        return out, loss
+
+    for _ in range(3):
+        out, loss = step(); loss.backward()
+    torch.cuda.synchronize()
+    n = 10
+    t0 = time.perf_counter()
+    for _ in range(n):
+        out, loss = step()
+    torch.cuda.synchronize()
+    t_f = (time.perf_counter() - t0) / n
+    t0 = time.perf_counter()
+    for _ in range(n):
+        out, loss = step(); loss.backward()
+    torch.cuda.synchronize()
+    t_fb = (time.perf_counter() - t0) / n
+    print(json.dumps({'config': name, 'B': B, 'ms_forward_train_mode': t_f * 1e3, 'ms_forward_backward': t_fb * 1e3,
+                      'samples_per_s_train_step': B / t_fb}))
+
+
+if __name__ == '__main__':
+    main()
