@@ -58,3 +58,47 @@ def sum_over_ranks(value, device=None):
 def whole_job_rate(samples_per_gpu, steps, elapsed_max, world_size):
     """value = samples ALL ranks processed / max-over-ranks time."""
     return samples_per_gpu * world_size * steps / elapsed_max
+
+
+# ------------------------------------------------------------------ training step: the one collective of the path
+def allreduce_gradients(params, bucket_bytes=64 << 20, async_op=False):
+    """Average the gradients of `params` over all ranks: the single collective of the training step (SURVEY 8e --
+    the data path itself stays collective-free).  Gradients are packed into flat fp32 buckets of <= bucket_bytes and
+    each bucket is ONE all-reduce: over xGMI a ring all-reduce is bound by a single ~153 GB/s link whatever the
+    message count, so few large messages beat DDP's default 25 MB buckets; the path's own parameters (BEV queries,
+    encoder layer, history convs: ~4 MB) fit one bucket.  Returns the list of work handles when async_op=True (call
+    `finish_allreduce` before the optimizer step) so the reduction overlaps the rest of the backward pass."""
+    grads = [p.grad for p in params if p.grad is not None]
+    if not dist.is_initialized() or dist.get_world_size() == 1 or not grads:
+        return []
+    world = dist.get_world_size()
+    buckets, cur, size = [], [], 0
+    for g in grads:
+        n = g.numel() * g.element_size()
+        if cur and size + n > bucket_bytes:
+            buckets.append(cur)
+            cur, size = [], 0
+        cur.append(g)
+        size += n
+    if cur:
+        buckets.append(cur)
+    pending = []
+    for b in buckets:
+        flat = torch.cat([g.reshape(-1) for g in b])
+        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+        pending.append((work, flat, b, world))
+    if async_op:
+        return pending
+    finish_allreduce(pending)
+    return []
+
+
+def finish_allreduce(pending):
+    for work, flat, bucket, world in pending:
+        work.wait()
+        flat.div_(world)
+        off = 0
+        for g in bucket:
+            n = g.numel()
+            g.copy_(flat[off:off + n].view_as(g))
+            off += n
