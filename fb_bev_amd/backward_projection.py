@@ -96,7 +96,10 @@ class CustormLearnedPositionalEncoding(nn.Module):
         x_embed = self.col_embed(torch.arange(w, device=device))
         y_embed = self.row_embed(torch.arange(h, device=device))
         pos = torch.cat((x_embed.unsqueeze(0).repeat(h, 1, 1), y_embed.unsqueeze(1).repeat(1, w, 1)), dim=-1)
-        return pos.permute(2, 0, 1).unsqueeze(0).repeat(bs, 1, 1, 1)
+        # (bs,C,h,w) like the reference (positional_encoding.py:57-60) but as a broadcast VIEW of the token-major
+        # (h,w,C) table instead of `.repeat`: flattened and permuted back to (bs,Q,C) by the encoder it is again
+        # contiguous rows, so `query + query_pos` runs vectorised and nothing is copied
+        return pos.permute(2, 0, 1).unsqueeze(0).expand(bs, -1, -1, -1)
 
 
 @register
@@ -637,9 +640,13 @@ class BackwardProjection(nn.Module):
                 bev_mask=None):
         bs = mlvl_feats[0].shape[0]
         dtype = mlvl_feats[0].dtype
-        bev_queries = self.bev_embedding.weight.to(dtype).unsqueeze(1).repeat(1, bs, 1)
+        # (Q,bs,C) as backward_projection.py:96-99 -- built batch-major so that the encoder's permute(1,0,2) yields
+        # contiguous (bs,Q,C) tokens (the Linear layers then take them without a copy); same sums element for element
         if lss_bev is not None:
-            bev_queries = bev_queries + lss_bev.flatten(2).permute(2, 0, 1)
+            tok = lss_bev.flatten(2).transpose(1, 2).contiguous()                       # (bs,Q,C): the one transposition
+            bev_queries = (tok + self.bev_embedding.weight.to(dtype).unsqueeze(0)).permute(1, 0, 2)
+        else:
+            bev_queries = self.bev_embedding.weight.to(dtype).unsqueeze(0).repeat(bs, 1, 1).permute(1, 0, 2)
         if bev_mask is not None:
             bev_mask = bev_mask.reshape(bs, -1)
         bev_pos = self.positional_encoding(bs, self.bev_h, self.bev_w, bev_queries.device).to(dtype)

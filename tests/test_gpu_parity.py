@@ -109,6 +109,31 @@ def test_fused_geometry_rank_build_equals_two_step(dev, name, B):
         assert torch.equal(a.cpu(), e)
 
 
+def test_fp32_rank_collisions_above_2_24_are_reproduced(dev):
+    """the reference evaluates rank = b*ZYX + z*YX + y*X + x in fp32 (view_transformer.py:586-589), so once
+    B*X*Y*Z exceeds 2^24 neighbouring voxels of the late samples share a rank.  That merge is part of the reference's
+    output; the device-side key evaluation must reproduce it bit for bit (BL2 grid, B=28: 17.9 M voxels)."""
+    cfg, ovt, cam, _, _, _ = _inputs('BL2', 28, True, dev)
+    vt = _vt(cfg, dev)
+    cam_g = [t.to(dev) for t in cam]
+    coor_g = vt.get_lidar_coor(*cam_g)                     # the bit-exact contract starts at coor (SURVEY H2)
+    coor = coor_g.cpu()
+    exp = ovt.voxel_pooling_prepare_v2(coor)
+    got = vt.build_index_from_cams(*cam_g).exact()
+    two = vt.voxel_pooling_prepare_v2(coor_g)
+    for g, t, e, key in zip(got, two, exp, ('ranks_bev', 'ranks_depth', 'ranks_feat', 'starts', 'lengths')):
+        assert torch.equal(g.cpu(), e), key
+        assert torch.equal(t.cpu(), e), key
+    # the quirk is really exercised: exact integer ranks of the kept points differ from the fp32 ones
+    Z, Y, X = vt.grid_zyx
+    c = coor.view(-1, 3)[exp[1].long()]
+    lo, it = ovt.grid_lower_bound, ovt.grid_interval
+    v = ((c - lo) / it).long()
+    b = exp[1].long() // (coor[0].numel() // 3)
+    exact = ((b * Z + v[:, 2]) * Y + v[:, 1]) * X + v[:, 0]
+    assert int((exact != exp[0].long()).sum()) > 0
+
+
 def test_rank_build_edge_cases(dev):
     cfg = S.CONFIGS['TINY']
     O = _oracle()
