@@ -36,6 +36,7 @@ SIGNATURES = {
     'fbbev_history_flow': (c_int, [c_void_p] * 5 + [c_int, c_void_p, c_void_p]),
     'fbbev_history_warp': (c_int, [c_void_p, c_int64, c_void_p] + [c_int] * 5 + [c_void_p, c_int64, c_void_p]),
     'fbbev_layernorm': (c_int, [c_void_p] * 4 + [c_float, c_int64, c_int, c_void_p, c_void_p]),
+    'fbbev_history_conv': (c_int, [c_void_p, c_int64] + [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t, c_void_p]),
     'fbbev_msda_fwd': (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_void_p, c_void_p]),
     'fbbev_point_sampling': (c_int, [c_void_p] * 9 + [c_int] * 5 + [c_float, c_float] + [c_void_p] * 4),
     'fbbev_da_cross_attn_fwd': (c_int, [c_void_p] * 9 + [c_int] * 10 + [c_float, c_float, c_int, c_void_p, c_void_p]),
@@ -409,4 +410,22 @@ def layernorm(x, weight, bias, eps, residual=None, out=None):
         _check(lib().fbbev_layernorm(_dev(x, F32, 'x'), _dev(residual, F32, 'residual') if residual is not None else None,
                                      _dev(weight, F32, 'weight'), _dev(bias, F32, 'bias'), float(eps), rows, C,
                                      _dev(out, F32, 'out'), _stream()), 'fbbev_layernorm')
+    return out
+
+
+def history_conv(feats, w1, bias1, w2, bias2, out):
+    """feats (B, T1*C, N) f32 whose per-sample block is contiguous; w1 (C,C); bias1 (B*T1, C); w2 (Cout, T1*C);
+    bias2 (Cout); out (B, Cout, N) contiguous -> out = relu(bias2 + sum_t w2_t . relu(w1 . x_t + bias1_t))."""
+    B, TC, N = feats.shape
+    C = w1.shape[0]
+    T1 = TC // C
+    Cout = w2.shape[0]
+    if feats.stride()[1:] != (N, 1) or tuple(out.shape) != (B, Cout, N):
+        raise FbbevError('history_conv: bad feats / out layout')
+    ws = torch.empty((1 + T1) * C * max(C, Cout), dtype=torch.float32, device=feats.device)   # fragment-ordered weights
+    with _on(feats):
+        _check(lib().fbbev_history_conv(_dev(feats, F32, 'feats', contiguous=False), feats.stride(0), _dev(w1, F32, 'w1'),
+                                        _dev(bias1, F32, 'bias1'), _dev(w2, F32, 'w2'), _dev(bias2, F32, 'bias2'),
+                                        B, T1, C, Cout, N, _dev(out, F32, 'out'), c_void_p(ws.data_ptr()),
+                                        ws.numel() * 4, _stream()), 'fbbev_history_conv')
     return out

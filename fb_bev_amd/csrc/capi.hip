@@ -10,6 +10,7 @@
 #include "da_kernels.h"
 #include "history_kernels.h"
 #include "norm_kernels.h"
+#include "history_conv_kernels.h"
 #include "../../include/fbbev.h"
 
 #define FBBEV_CHECK_LAUNCH()                      \
@@ -809,6 +810,43 @@ extern "C" int fbbev_layernorm(const float* x, const float* residual, const floa
     const long long blocks = (rows + 7) / 8;          // 8 half-waves per 256-thread workgroup
     if (blocks >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
     FBBEV_LAUNCH(k_layernorm_rows, blocks, 256, 0, (fbbev_rt_stream)stream_, x, residual, weight, bias, eps, rows, C, out);
+    FBBEV_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int fbbev_history_conv(const float* feats, long long feats_stride_b, const float* w1, const float* bias1,
+                                  const float* w2, const float* bias2, int B, int T1, int C, int Cout, int N,
+                                  float* out, void* workspace, size_t workspace_bytes, fbbev_stream_t stream_) {
+    if (B < 0 || T1 <= 0 || C <= 0 || Cout <= 0 || N < 0) return FBBEV_E_BADARG;
+    if (B == 0 || N == 0) return 0;
+    if (!feats || !w1 || !bias1 || !w2 || !bias2 || !out) return FBBEV_E_BADARG;
+    if (C % 16 != 0 || Cout % 16 != 0 || C > 16 * FBBEV_HC_MAX_TILES || Cout > 16 * FBBEV_HC_MAX_TILES)
+        return FBBEV_E_UNSUPPORTED;
+    if (feats_stride_b == 0) feats_stride_b = (long long)T1 * C * N;
+    if (feats_stride_b < (long long)T1 * C * N) return FBBEV_E_BADARG;
+    const int tiles_per_b = (N + 63) / 64;
+    const long long blocks = (long long)B * tiles_per_b;
+    if (blocks >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
+    const size_t lds = (size_t)4 * C * 16 * sizeof(float);
+    if (workspace && ((C == 80 && Cout == 80) || (C == 16 && Cout == 16))) {
+        // fragment-ordered copies of the two weight matrices (tiny: (1 + T1) * C * C floats), then the register-resident kernel
+        const int MT1 = C / 16, MT2 = Cout / 16, KS = C / 4;
+        const size_t need = ((size_t)MT1 * KS + (size_t)T1 * MT2 * KS) * 64 * sizeof(float);
+        if (workspace_bytes < need) return FBBEV_E_WORKSPACE;
+        float* w1f = static_cast<float*>(workspace);
+        float* w2f = w1f + (size_t)MT1 * KS * 64;
+        const int nfrag = (MT1 * KS + T1 * MT2 * KS) * 64;
+        FBBEV_LAUNCH(k_history_weight_fragments, (nfrag + 255) / 256, 256, 0, (fbbev_rt_stream)stream_, w1, w2, MT1, MT2, KS,
+                     T1, w1f);
+        if (C == 80)
+            FBBEV_LAUNCH((k_history_conv_t<5, 5>), blocks, 256, lds, (fbbev_rt_stream)stream_, feats, feats_stride_b,
+                         (const float*)w1f, bias1, (const float*)w2f, bias2, T1, N, tiles_per_b, out);
+        else
+            FBBEV_LAUNCH((k_history_conv_t<1, 1>), blocks, 256, lds, (fbbev_rt_stream)stream_, feats, feats_stride_b,
+                         (const float*)w1f, bias1, (const float*)w2f, bias2, T1, N, tiles_per_b, out);
+    } else
+        FBBEV_LAUNCH(k_history_conv, blocks, 256, lds, (fbbev_rt_stream)stream_, feats, feats_stride_b, w1, bias1, w2, bias2,
+                     T1, C, Cout, N, tiles_per_b, out);
     FBBEV_CHECK_LAUNCH();
     return 0;
 }

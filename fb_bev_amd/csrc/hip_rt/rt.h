@@ -54,3 +54,9 @@ __device__ __forceinline__ void fbbev_store4(float* p, fbbev_v4f v) {
 }
 
 __device__ __forceinline__ void fbbev_atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }
+
+// v_mfma_f32_16x16x4_f32: D(16x16) = A(16x4) . B(4x16) + C, exact fp32 (a k-ordered fmaf chain per element).
+// A: lane holds A[lane%16][lane/16]; B: lane holds B[lane/16][lane%16]; register r of C/D: row 4*(lane/16)+r, col lane%16.
+__device__ __forceinline__ fbbev_v4f fbbev_mfma_f32_16x16x4(float a, float b, fbbev_v4f c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}

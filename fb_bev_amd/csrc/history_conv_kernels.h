@@ -1,0 +1,183 @@
+// history_conv_kernels.h -- the two 1x1x1 convolutions of FB-OCC's temporal fusion as ONE fp32-MFMA kernel.
+//
+// Replaces, for inference, history_keyframe_time_conv + history_keyframe_cat_conv of FBOCC.fuse_history
+// (mmdet3d/models/fbbev/detectors/fbocc.py:111-127, 289-310): the reference concatenates a time channel (81 channels),
+// runs Conv3d(81->80)+BN+ReLU on each of the T+1 frames, concatenates the results (1360 channels) and runs
+// Conv3d(1360->80)+BN+ReLU -- the (T+1)*C-channel intermediate is written and read back (435 MB per sample at
+// 100x100x8).  With the eval-mode batch norms folded into the weights and the time channel into a per-frame bias
+// (history_fusion.py) the math per voxel n is
+//     out[:, n] = relu( b2 + sum_t  W2_t . relu( W1 . x_t[:, n] + b1_t ) ),      W1: CxC, W2_t: Cout x C
+// which is GEMM-shaped (2 * 2 * C * C * (T+1) flops per voxel = 35 GFLOP per 100x100x8 sample) and therefore belongs
+// on the matrix cores.  The path stays fp32 (the reference pins fuse_history to fp32, fbocc.py:207 @force_fp32), so
+// this uses v_mfma_f32_16x16x4_f32: exact f32, bit-for-bit a k-ordered fmaf chain (MI355X guide: 157 TF peak).
+//
+// Tiling (wave64): a workgroup of 4 waves owns 64 consecutive voxels, wave w the 16-voxel N-tile n0+16w.  Per frame t
+// the wave computes Y_t = relu(W1 . X_t + b1_t) for ALL C output channels (C/16 M-tiles x C/4 k-steps; the B fragment
+// of k-step kk is X_t[4kk + lane/16][n0 + lane%16], read straight from HBM: 4 rows x 64 contiguous bytes), parks Y_t in a
+// wave-private LDS slab in the MFMA C layout, reads it back in the B layout and accumulates Out += W2_t . Y_t.
+// The intermediate never leaves the CU.  Fragment layouts of v_mfma_f32_16x16x4_f32 (A 16x4, B 4x16, C/D 16x16):
+//     A: lane holds A[i = lane%16][k = lane/16]      B: lane holds B[k = lane/16][j = lane%16]
+//     D: register r of a lane holds D[i = 4*(lane/16) + r][j = lane%16]
+// Bound: fp32 MFMA (64 FLOP/clk/SIMD); HBM traffic = the (T+1)*C-channel volume read once + the output written once.
+#pragma once
+#include "rt.h"
+
+#define FBBEV_HC_MAX_TILES 8      // C, Cout <= 128 (M-tiles of 16)
+
+// feats (B, T1*C, N) with batch stride fstride_b; w1 (C,C); bias1 (B*T1, C); w2 (Cout, T1*C); bias2 (Cout); out (B,Cout,N)
+__global__ void __launch_bounds__(256)
+k_history_conv(const float* __restrict__ feats, long long fstride_b, const float* __restrict__ w1,
+               const float* __restrict__ bias1, const float* __restrict__ w2, const float* __restrict__ bias2,
+               int T1, int C, int Cout, int N, int tiles_per_b, float* __restrict__ out) {
+    float* lds = fbbev_dyn_lds_f32();                      // [4 waves][C][16]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = lane >> 4, j = lane & 15;
+    const int b = blockIdx.x / tiles_per_b, tile = blockIdx.x - b * tiles_per_b;
+    const int n = tile * 64 + wave * 16 + j;
+    const bool inb = n < N;
+    const int MT1 = C >> 4, MT2 = Cout >> 4, KS = C >> 2;
+    float* ylds = lds + wave * C * 16;
+    const float* xb = feats + (long long)b * fstride_b;
+    fbbev_v4f acc2[FBBEV_HC_MAX_TILES];
+#pragma unroll
+    for (int mt = 0; mt < FBBEV_HC_MAX_TILES; ++mt) {
+        acc2[mt] = fbbev_v4f{0.f, 0.f, 0.f, 0.f};
+        if (mt < MT2)
+            for (int r = 0; r < 4; ++r) acc2[mt][r] = bias2[16 * mt + 4 * g + r];
+    }
+    for (int t = 0; t < T1; ++t) {
+        const float* xt = xb + (long long)t * C * N;
+        const float* b1 = bias1 + ((long long)b * T1 + t) * C;
+        fbbev_v4f acc1[FBBEV_HC_MAX_TILES];
+#pragma unroll
+        for (int mt = 0; mt < FBBEV_HC_MAX_TILES; ++mt) {
+            acc1[mt] = fbbev_v4f{0.f, 0.f, 0.f, 0.f};
+            if (mt < MT1)
+                for (int r = 0; r < 4; ++r) acc1[mt][r] = b1[16 * mt + 4 * g + r];
+        }
+        for (int kk = 0; kk < KS; ++kk) {
+            const float bf = inb ? xt[(long long)(4 * kk + g) * N + n] : 0.f;
+#pragma unroll
+            for (int mt = 0; mt < FBBEV_HC_MAX_TILES; ++mt)
+                if (mt < MT1) acc1[mt] = fbbev_mfma_f32_16x16x4(w1[(16 * mt + j) * C + 4 * kk + g], bf, acc1[mt]);
+        }
+        __syncthreads();                                    // the previous frame's reads of ylds are done
+#pragma unroll
+        for (int mt = 0; mt < FBBEV_HC_MAX_TILES; ++mt)
+            if (mt < MT1)
+                for (int r = 0; r < 4; ++r) ylds[(16 * mt + 4 * g + r) * 16 + j] = fmaxf(acc1[mt][r], 0.f);
+        __syncthreads();
+        const float* w2t = w2 + (long long)t * C;
+        const long long w2ld = (long long)T1 * C;
+        for (int kk = 0; kk < KS; ++kk) {
+            const float bf = ylds[(4 * kk + g) * 16 + j];
+#pragma unroll
+            for (int mt = 0; mt < FBBEV_HC_MAX_TILES; ++mt)
+                if (mt < MT2) acc2[mt] = fbbev_mfma_f32_16x16x4(w2t[(16 * mt + j) * w2ld + 4 * kk + g], bf, acc2[mt]);
+        }
+    }
+    if (inb) {
+        float* ob = out + (long long)b * Cout * N + n;
+#pragma unroll
+        for (int mt = 0; mt < FBBEV_HC_MAX_TILES; ++mt)
+            if (mt < MT2)
+                for (int r = 0; r < 4; ++r) ob[(long long)(16 * mt + 4 * g + r) * N] = fmaxf(acc2[mt][r], 0.f);
+    }
+}
+
+
+// Register-resident variant for compile-time channel counts (C = 16*MT1, Cout = 16*MT2).  In the generic kernel above
+// every MFMA waits for its own scattered dword load of a weight fragment (measured 12x off the MFMA bound).  Here
+//   * the weights arrive PRE-ARRANGED in fragment order (w1f[mt][kk][lane], w2f[t][mt][kk][lane]: the host permutes the
+//     folded weight matrices once), so a fragment load is one coalesced 256-byte wave load;
+//   * the W1 fragments live in registers for the whole kernel, the W2_t fragments of a frame are loaded in one burst;
+//   * the X fragments of frame t+1 are fetched while frame t's second GEMM runs (register double buffer).
+template <int MT1, int MT2>
+__global__ void __launch_bounds__(256)
+k_history_conv_t(const float* __restrict__ feats, long long fstride_b, const float* __restrict__ w1f,
+                 const float* __restrict__ bias1, const float* __restrict__ w2f, const float* __restrict__ bias2,
+                 int T1, int N, int tiles_per_b, float* __restrict__ out) {
+    constexpr int C = 16 * MT1, Cout = 16 * MT2, KS = C / 4;
+    float* lds = fbbev_dyn_lds_f32();                      // [4 waves][C][16]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = lane >> 4, j = lane & 15;
+    const int b = blockIdx.x / tiles_per_b, tile = blockIdx.x - b * tiles_per_b;
+    const int n = tile * 64 + wave * 16 + j;
+    const bool inb = n < N;
+    float* ylds = lds + wave * C * 16;
+    const float* xb = feats + (long long)b * fstride_b;
+    float a1[MT1][KS];
+#pragma unroll
+    for (int mt = 0; mt < MT1; ++mt)
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) a1[mt][kk] = w1f[(mt * KS + kk) * 64 + lane];
+    fbbev_v4f acc2[MT2];
+#pragma unroll
+    for (int mt = 0; mt < MT2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc2[mt][r] = bias2[16 * mt + 4 * g + r];
+    float bx[KS];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) bx[kk] = inb ? xb[(long long)(4 * kk + g) * N + n] : 0.f;
+    for (int t = 0; t < T1; ++t) {
+        const float* b1 = bias1 + ((long long)b * T1 + t) * C;
+        const float* w2t = w2f + (long long)t * MT2 * KS * 64;
+        float a2[MT2][KS];
+#pragma unroll
+        for (int mt = 0; mt < MT2; ++mt)
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) a2[mt][kk] = w2t[(mt * KS + kk) * 64 + lane];
+        fbbev_v4f acc1[MT1];
+#pragma unroll
+        for (int mt = 0; mt < MT1; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc1[mt][r] = b1[16 * mt + 4 * g + r];
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+            for (int mt = 0; mt < MT1; ++mt) acc1[mt] = fbbev_mfma_f32_16x16x4(a1[mt][kk], bx[kk], acc1[mt]);
+        if (t + 1 < T1) {                                   // next frame's X fragments: in flight during GEMM 2
+            const float* xn = xb + (long long)(t + 1) * C * N;
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) bx[kk] = inb ? xn[(long long)(4 * kk + g) * N + n] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < MT1; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ylds[(16 * mt + 4 * g + r) * 16 + j] = fmaxf(acc1[mt][r], 0.f);
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            const float by = ylds[(4 * kk + g) * 16 + j];
+#pragma unroll
+            for (int mt = 0; mt < MT2; ++mt) acc2[mt] = fbbev_mfma_f32_16x16x4(a2[mt][kk], by, acc2[mt]);
+        }
+    }
+    if (inb) {
+        float* ob = out + (long long)b * Cout * N + n;
+#pragma unroll
+        for (int mt = 0; mt < MT2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ob[(long long)(16 * mt + 4 * g + r) * N] = fmaxf(acc2[mt][r], 0.f);
+    }
+}
+
+// Weight matrices -> MFMA A-fragment order, one launch: dst = [ w1f[mt][kk][lane] | w2f[t][mt][kk][lane] ] with
+// fragment element A[16mt + lane%16][4kk + lane/16]; w1 is (16*MT1, C), w2 is (16*MT2, T1*C) and frame t uses columns t*C..
+__global__ void __launch_bounds__(256)
+k_history_weight_fragments(const float* __restrict__ w1, const float* __restrict__ w2, int MT1, int MT2, int KS, int T1,
+                           float* __restrict__ dst) {
+    const int n1 = MT1 * KS * 64, n2 = MT2 * KS * 64;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n1 + T1 * n2) return;
+    const int C = 4 * KS;
+    if (i < n1) {
+        const int lane = i & 63, kk = (i >> 6) % KS, mt = (i >> 6) / KS;
+        dst[i] = w1[(long long)(16 * mt + (lane & 15)) * C + 4 * kk + (lane >> 4)];
+    } else {
+        const int r = i - n1, t = r / n2, e = r - t * n2;
+        const int lane = e & 63, kk = (e >> 6) % KS, mt = (e >> 6) / KS;
+        dst[i] = w2[(long long)(16 * mt + (lane & 15)) * ((long long)T1 * C) + t * C + 4 * kk + (lane >> 4)];
+    }
+}

@@ -12,8 +12,10 @@ What runs where:
   * inference: the warp writes straight into the frame slots 1..T of the next (T+1)-frame buffer, the current frame
     is copied into slot 0, and `history_bev` becomes a VIEW of slots 0..T-1 (the reference cats, clones and re-cats
     the 16x80-channel volume: ~6 full passes); the time channel of the 81->80 conv is folded into a per-(sample,
-    frame) bias and the eval-mode batch norms into the 1x1x1 conv weights, so each conv is one batched library GEMM
-    with a bias epilogue (`baddbmm`) + ReLU;
+    frame) bias and the eval-mode batch norms into the 1x1x1 conv weights; both convs then run as ONE fp32-MFMA kernel
+    (`fbbev_history_conv`: per 64-voxel tile, relu(W1 x_t + b_t) is parked in LDS and immediately consumed by the
+    W2_t accumulation -- the 1360-channel intermediate never reaches HBM); channel counts that are not multiples of
+    16 fall back to two batched library GEMMs with a bias epilogue;
   * training (grad enabled): the reference's own op sequence on the module's layers (batch-norm statistics intact),
     only the warp is the HIP kernel -- `history_bev` is detached (:241), so the warp needs no backward.
 No CPU fallback: the HIP extension must be present and the tensors on the GPU.
@@ -43,6 +45,7 @@ class TemporalHistoryFusion(nn.Module):
         self.history_keyframe_cat_conv = nn.Sequential(                # fbocc.py:120-127
             nn.Conv3d(C * (T + 1), out_c, kernel_size=1, padding=0, stride=1), nn.SyncBatchNorm(out_c),
             nn.ReLU(inplace=True))
+        self.use_mfma_convs = True          # inference: both 1x1x1 convs in one fp32-MFMA kernel when the channels allow
         self.reset()
 
     def reset(self):
@@ -172,9 +175,15 @@ class TemporalHistoryFusion(nn.Module):
         w2, b2 = self._folded(self.history_keyframe_cat_conv)
         tau = (sweep * self.history_cam_sweep_freq).reshape(B * (T + 1), 1)
         # folded bias already contains scale * conv.bias; the time channel adds scale * W[:, C] * tau = w1[:, C] * tau
-        bias1 = (b1[None, :] + tau * w1[None, :, C]).unsqueeze(-1)    # (B*(T+1), C, 1)
-        y = torch.baddbmm(bias1, w1[:, :C].unsqueeze(0).expand(B * (T + 1), C, C), nxt.view(B * (T + 1), C, n))
-        y.relu_()
-        out = torch.baddbmm(b2.view(1, -1, 1), w2.unsqueeze(0).expand(B, *w2.shape), y.view(B, (T + 1) * C, n))
-        out.relu_()
+        bias1 = b1[None, :] + tau * w1[None, :, C]                     # (B*(T+1), C)
+        cout = w2.shape[0]
+        if self.use_mfma_convs and C % 16 == 0 and cout % 16 == 0 and max(C, cout) <= 128:
+            # both convs in one fp32-MFMA kernel: the (T+1)*C-channel intermediate never leaves the CU
+            out = _capi.history_conv(nxt.view(B, (T + 1) * C, n), w1[:, :C].contiguous(), bias1.contiguous(), w2.contiguous(),
+                                     b2.contiguous(), torch.empty((B, cout, n), dtype=torch.float32, device=curr.device))
+        else:
+            y = torch.baddbmm(bias1.unsqueeze(-1), w1[:, :C].unsqueeze(0).expand(B * (T + 1), C, C), nxt.view(B * (T + 1), C, n))
+            y.relu_()
+            out = torch.baddbmm(b2.view(1, -1, 1), w2.unsqueeze(0).expand(B, *w2.shape), y.view(B, (T + 1) * C, n))
+            out.relu_()
         return out.view(B, -1, Z, Y, X), nxt

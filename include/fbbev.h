@@ -269,6 +269,19 @@ int fbbev_history_warp(const float* history, long long history_stride_b, const f
 int fbbev_layernorm(const float* x, const float* residual, const float* weight, const float* bias, float eps,
                     long long rows, int C, float* out, fbbev_stream_t stream);
 
+/* The two 1x1x1 convolutions of the temporal fusion in one fp32-MFMA kernel (inference): replaces
+ * history_keyframe_time_conv + history_keyframe_cat_conv of FBOCC.fuse_history (fbocc.py:111-127, 289-310) once the
+ * eval-mode batch norms are folded into the weights and the time channel into a per-frame bias:
+ *   out[b,:,n] = relu( bias2 + sum_t w2[:, t*C:(t+1)*C] . relu( w1 . feats[b, t*C:(t+1)*C, n] + bias1[b*T1+t] ) )
+ * feats (B, T1*C, N) f32 with batch stride feats_stride_b (elements, 0 = contiguous), w1 (C,C), bias1 (B*T1,C),
+ * w2 (Cout, T1*C), bias2 (Cout), out (B,Cout,N).  C, Cout multiples of 16 and <= 128, else FBBEV_E_UNSUPPORTED.
+ * workspace (optional, may be NULL): (1 + T1) * C * max(C, Cout) * 4 bytes of device scratch for fragment-ordered
+ * weight copies; with it the C = Cout = 80 shape of FB-OCC takes the register-resident kernel.
+ * Exact fp32 arithmetic (v_mfma_f32_16x16x4_f32: k-ordered fmaf chains). */
+int fbbev_history_conv(const float* feats, long long feats_stride_b, const float* w1, const float* bias1,
+                       const float* w2, const float* bias2, int B, int T1, int C, int Cout, int N, float* out,
+                       void* workspace, size_t workspace_bytes, fbbev_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

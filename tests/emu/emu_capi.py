@@ -205,3 +205,13 @@ def da_cross_attn_bwd(value, ss, ls, pred_depth, ref_cam, mask, qdepth, offsets,
                                      p(attn), p(grad_slots), B, Ncam, S, M, Dh, L, Q, P, Za, pred_depth.shape[1], d0,
                                      dstep, int(head_minor), p(gv), p(gd), p(go), p(ga), None))
     return gv, gd, go, ga
+
+
+def history_conv(feats, w1, bias1, w2, bias2):
+    B, TC, N = feats.shape
+    C, Cout = w1.shape[0], w2.shape[0]
+    out = torch.full((B, Cout, N), float('nan'))
+    ws = torch.zeros((1 + TC // C) * C * max(C, Cout))
+    ok(lib().fbbev_history_conv(c_void_p(feats.data_ptr()), feats.stride(0), p(w1), p(bias1), p(w2), p(bias2), B, TC // C, C,
+                                Cout, N, p(out), p(ws), ws.numel() * 4, None))
+    return out

@@ -163,3 +163,22 @@ typedef float fbbev_v4f __attribute__((vector_size(16)));
 typedef float fbbev_v2f __attribute__((vector_size(8)));
 template <int ST> inline void fbbev_store4(float* p, fbbev_v4f v) { memcpy(p, &v, 16); }
 inline void fbbev_atomic_add_f32(float* p, float v) { *p += v; }
+
+// emulation of v_mfma_f32_16x16x4_f32 with the documented fragment layouts (see csrc/hip_rt/rt.h); every lane of the
+// wave must call it (wave-uniform control flow, as on the hardware)
+inline fbbev_v4f fbbev_mfma_f32_16x16x4(float a, float b, fbbev_v4f c) {
+    emu::State& s = emu::S();
+    const int w = s.cur >> 6, lane = s.cur & 63;
+    static thread_local float A[16][64], B[16][64];
+    A[w][lane] = a; B[w][lane] = b;
+    emu::wave_barrier();
+    const int g = lane >> 4, j = lane & 15;
+    fbbev_v4f d = c;
+    for (int r = 0; r < 4; ++r) {
+        float acc = c[r];
+        for (int k = 0; k < 4; ++k) acc = fmaf(A[w][k * 16 + 4 * g + r], B[w][k * 16 + j], acc);
+        d[r] = acc;
+    }
+    emu::wave_barrier();
+    return d;
+}

@@ -458,3 +458,19 @@ def test_fused_da_cross_attention_backward_emulated():
                     assert a is None or not a.any()
                     continue
                 assert torch.allclose(a, b, atol=5e-5 * max(1.0, b.abs().max().item()), rtol=1e-4), hm
+
+
+@pytest.mark.parametrize('B,T1,C,Cout,N', [(1, 3, 16, 16, 64), (2, 2, 32, 16, 100), (1, 4, 16, 32, 17)])
+def test_history_conv_mfma_emulated(B, T1, C, Cout, N):
+    """k_history_conv on the emulated v_mfma_f32_16x16x4_f32: out = relu(b2 + sum_t W2_t relu(W1 x_t + b1_t))."""
+    g = torch.Generator().manual_seed(N)
+    big = torch.randn(B, T1 * C + 8, N, generator=g)
+    feats = big[:, 8:]                                       # per-sample block contiguous, batch stride padded
+    w1, w2 = torch.randn(C, C, generator=g) * 0.3, torch.randn(Cout, T1 * C, generator=g) * 0.2
+    b1, b2 = torch.randn(B * T1, C, generator=g), torch.randn(Cout, generator=g)
+    got = E.history_conv(feats, w1, b1, w2, b2)
+    x = feats.reshape(B, T1, C, N).double()
+    y = torch.relu(torch.einsum('oc,btcn->bton', w1.double(), x) + b1.view(B, T1, C, 1).double())
+    exp = torch.relu(torch.einsum('oc,bcn->bon', w2.double(), y.reshape(B, T1 * C, N)) + b2.view(1, Cout, 1).double())
+    assert not torch.isnan(got).any()
+    assert torch.allclose(got.double(), exp, atol=2e-5, rtol=1e-5)

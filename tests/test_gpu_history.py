@@ -114,3 +114,48 @@ def test_do_history_false_uses_only_the_current_frame(dev):
         outs.append(m.fuse_history(torch.from_numpy(z['f0.curr']).to(dev), _metas(z, 0), torch.from_numpy(z[f'f{i}.bda']).to(dev)))
         assert m.history_bev is None
     assert torch.allclose(outs[0], outs[1], atol=1e-4)      # no state carried over
+
+
+@pytest.mark.parametrize('B,T1,C,Cout,N', [(1, 17, 80, 80, 8000), (2, 3, 16, 32, 1000), (1, 2, 128, 128, 77)])
+def test_history_conv_mfma_kernel(dev, B, T1, C, Cout, N):
+    """fbbev_history_conv (v_mfma_f32_16x16x4_f32) vs a float64 evaluation of the same two folded convolutions."""
+    from fb_bev_amd import _capi
+    g = torch.Generator().manual_seed(C + N)
+    feats = torch.randn(B, T1 * C, N, generator=g)
+    w1, w2 = torch.randn(C, C, generator=g) * 0.1, torch.randn(Cout, T1 * C, generator=g) * 0.05
+    b1, b2 = torch.randn(B * T1, C, generator=g) * 0.2, torch.randn(Cout, generator=g) * 0.2
+    out = torch.full((B, Cout, N), float('nan'), device=dev)
+    _capi.history_conv(feats.to(dev), w1.to(dev), b1.to(dev), w2.to(dev), b2.to(dev), out)
+    x = feats.view(B, T1, C, N).double()
+    y = torch.relu(torch.einsum('oc,btcn->bton', w1.double(), x) + b1.view(B, T1, C, 1).double())
+    exp = torch.relu(torch.einsum('oc,bcn->bon', w2.double(), y.reshape(B, T1 * C, N)) + b2.view(1, Cout, 1).double())
+    assert not torch.isnan(out).any()
+    assert (out.cpu().double() - exp).abs().max().item() < 2e-5 * max(1.0, exp.abs().max().item())
+
+
+def test_fusion_with_mfma_convs_matches_library_gemm_path(dev):
+    """C = Cout = 16: the module takes fbbev_history_conv; with use_mfma_convs=False it runs the two batched library
+    GEMMs -- same folded weights, same sequence, same result."""
+    from fb_bev_amd.history_fusion import TemporalHistoryFusion
+    torch.manual_seed(1)
+    C, T, Z, Y, X, B = 16, 3, 4, 10, 12, 2
+    m = TemporalHistoryFusion([0.8, 0.8, 0.8], [-4.4, -3.6, -0.6], single_bev_num_channels=C, history_cat_num=T).to(dev).eval()
+    for seq in (m.history_keyframe_time_conv, m.history_keyframe_cat_conv):
+        seq[1].running_mean.uniform_(-0.2, 0.2)
+        seq[1].running_var.uniform_(0.6, 1.4)
+    frames = [torch.randn(B, C, Y, X, Z, device=dev) for _ in range(3)]
+    bda = torch.eye(3, device=dev)[None].repeat(B, 1, 1)
+    ego = torch.eye(4)
+    ego[0, 3] = 0.7
+
+    def run(use_mfma):
+        m.reset()
+        m.use_mfma_convs = use_mfma
+        outs = []
+        for i, f in enumerate(frames):
+            metas = [dict(sequence_group_idx=b, start_of_sequence=(i == 0), curr_to_prev_ego_rt=ego) for b in range(B)]
+            outs.append(m.fuse_history(f, metas, bda).clone())
+        return outs
+    a, b = run(True), run(False)
+    for x, y in zip(a, b):
+        assert (x - y).abs().max().item() < 1e-4
