@@ -37,12 +37,17 @@ k_sort_hist(const unsigned int* __restrict__ keys, long long n_host, const int* 
     for (int d = threadIdx.x; d < NB; d += 256) cnt[d] = 0;
     __syncthreads();
     const long long base = (long long)blockIdx.x * FBBEV_SORT_TILE;
-    for (int i = threadIdx.x; i < FBBEV_SORT_TILE; i += 256) {
-        const long long idx = base + i;
-        if (idx < n) {
-            const unsigned int key = keys[idx];
-            if (!(drop && key == drop_key)) atomicAdd(&cnt[(key >> shift) & (NB - 1)], 1);
-        }
+    constexpr int PER = FBBEV_SORT_TILE / 256;
+    unsigned int key[PER];
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {                 // all loads first: one memory round trip, not PER of them
+        const long long idx = base + threadIdx.x + r * 256;
+        key[r] = (idx < n) ? keys[idx] : drop_key;
+    }
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {
+        const long long idx = base + threadIdx.x + r * 256;
+        if (idx < n && !(drop && key[r] == drop_key)) atomicAdd(&cnt[(key[r] >> shift) & (NB - 1)], 1);
     }
     __syncthreads();
     for (int d = threadIdx.x; d < NB; d += 256) {
@@ -117,11 +122,16 @@ k_sort_scatter(const unsigned int* __restrict__ keys_in, const unsigned int* __r
     int lr[FBBEV_SORT_ROUNDS];
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
+    for (int r = 0; r < FBBEV_SORT_ROUNDS; ++r) {     // all loads of the wave's chunk first (one memory round trip)
+        const long long idx = chunk + r * 64 + lane;
+        const bool valid = idx < n;
+        k[r] = valid ? keys_in[idx] : 0u;
+        v[r] = valid ? (vals_in ? vals_in[idx] : (unsigned int)idx) : 0u;
+    }
+#pragma unroll
     for (int r = 0; r < FBBEV_SORT_ROUNDS; ++r) {
         const long long idx = chunk + r * 64 + lane;
         bool valid = idx < n;
-        k[r] = valid ? keys_in[idx] : 0u;
-        v[r] = valid ? (vals_in ? vals_in[idx] : (unsigned int)idx) : 0u;
         valid = valid && !(drop && k[r] == drop_key);
         lr[r] = -1;
         const unsigned int d = (k[r] >> shift) & (NB - 1);
@@ -198,12 +208,19 @@ k_sort_hist_geom(fbbev_geom_src g, int shift, int nblocks, int* __restrict__ his
     __syncthreads();
     const int dhw = g.cam.D * g.cam.H * g.cam.W;
     const int base = chunk * FBBEV_SORT_TILE;
-    for (int i = threadIdx.x; i < FBBEV_SORT_TILE; i += 256) {
-        const int idx = base + i;
+    constexpr int PER = FBBEV_SORT_TILE / 256;
+    unsigned int key[PER];
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {                 // keys of all PER points first (their table loads overlap) ...
+        const int idx = base + threadIdx.x + r * 256;
+        key[r] = (idx < dhw) ? fbbev_geom_key(g, m, cam, idx) : g.sentinel;
+    }
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {                 // ... then the stores and the LDS histogram
+        const int idx = base + threadIdx.x + r * 256;
         if (idx < dhw) {
-            const unsigned int key = fbbev_geom_key(g, m, cam, idx);
-            keys_out[(long long)cam * dhw + idx] = key;
-            if (key != g.sentinel) atomicAdd(&cnt[(key >> shift) & (NB - 1)], 1);
+            keys_out[(long long)cam * dhw + idx] = key[r];
+            if (key[r] != g.sentinel) atomicAdd(&cnt[(key[r] >> shift) & (NB - 1)], 1);
         }
     }
     __syncthreads();

@@ -159,3 +159,31 @@ def test_fusion_with_mfma_convs_matches_library_gemm_path(dev):
     a, b = run(True), run(False)
     for x, y in zip(a, b):
         assert (x - y).abs().max().item() < 1e-4
+
+
+def test_config_built_path_end_to_end_at_shipped_size(dev):
+    """The shipped detector config (committed extraction) -> FBViewTransform + TemporalHistoryFusion, two frames of
+    synthetic 6-camera input at the shipped sizes: forward projection -> backward projection -> re-add -> history."""
+    import json
+    from fb_bev_amd import config as C, synthetic as S
+    blocks = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'fbocc_config_path_blocks.json')))
+    info = blocks['fbocc-r50-cbgs_depth_16f_16x4_20e.py']
+    fvt, hist = C.build_view_transformation(info['path_blocks'])
+    fvt, hist = fvt.to(dev).eval(), hist.to(dev).eval()
+    cfg = S.CONFIGS['REF']
+    B = 1
+    cam = [t.to(dev) for t in S.camera_rig(cfg, B, seed=0, bda_aug=False)]
+    outs = []
+    with torch.no_grad():
+        for i in range(2):
+            depth, ctx = S.depth_and_context(cfg, B, seed=i)
+            bev = fvt(cam, ctx.to(dev), depth.to(dev))
+            assert bev.shape == (B, 80, 100, 100, 8)
+            ego = torch.eye(4)
+            ego[0, 3] = 0.8 * i
+            metas = [dict(sequence_group_idx=0, start_of_sequence=(i == 0), curr_to_prev_ego_rt=ego)]
+            out = hist.fuse_history(bev, metas, cam[5])
+            assert out.shape == (B, 80, 100, 100, 8) and torch.isfinite(out).all()
+            outs.append(out)
+    assert hist.history_bev.shape == (B, 16 * 80, 8, 100, 100)
+    assert (outs[0] - outs[1]).abs().max().item() > 0
