@@ -170,6 +170,8 @@ def test_config_built_path_end_to_end_at_shipped_size(dev):
     info = blocks['fbocc-r50-cbgs_depth_16f_16x4_20e.py']
     fvt, hist = C.build_view_transformation(info['path_blocks'])
     fvt, hist = fvt.to(dev).eval(), hist.to(dev).eval()
+    assert hist.do_history is False          # the shipped config trains without history ...
+    hist.do_history = True                   # ... and FBOCC.forward_test switches it on (fbocc.py:481)
     cfg = S.CONFIGS['REF']
     B = 1
     cam = [t.to(dev) for t in S.camera_rig(cfg, B, seed=0, bda_aug=False)]
