@@ -30,6 +30,9 @@ SIGNATURES = {
     'fbbev_pool_tile_index': (c_int, [c_void_p] * 3 + [c_int] * 7 + [c_void_p, c_size_t, c_void_p]),
     'fbbev_bev_pool_v2_dense_fwd': (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_void_p, c_int64, c_int64, c_void_p,
                                             c_size_t, c_int, c_int, c_void_p]),
+    'fbbev_bev_pool_v2_dense_fwd_add': (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_void_p, c_int64, c_int64, c_void_p,
+                                                c_size_t, c_int, c_int, c_void_p, c_void_p]),
+    'fbbev_pool_zmean': (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
     'fbbev_pool_dense_bwd_workspace_bytes': (c_size_t, [c_int] * 9),
     'fbbev_bev_pool_v2_dense_bwd': (c_int, [c_void_p, c_int64, c_int64] + [c_void_p] * 6 + [c_int] * 10 +
                                     [c_void_p] * 3 + [c_size_t, c_void_p]),
@@ -223,9 +226,25 @@ def pool_tile_index(interval_rank, interval_starts, counts, n_intervals_max, B, 
             'fbbev_pool_tile_index')
 
 
+def pool_zmean(depth, feat, ranks_depth, ranks_feat, interval_rank, interval_starts, interval_lengths, B, C, Z, Y, X,
+               out_mean, tile_ws, tile_voxels=64, flags=DEFAULT_POOL_FLAGS):
+    """out_mean (B,C,Y,X) f32 contiguous = mean over z of the pooled sums (tile index of the same tile_voxels in tile_ws)."""
+    if tuple(out_mean.shape) != (B, C, Y, X):
+        raise FbbevError('out_mean must be (B,C,Y,X)')
+    with _on(depth):
+        _check(lib().fbbev_pool_zmean(
+            _dev(depth, F32, 'depth'), _dev(feat, F32, 'feat'), _dev(ranks_depth, I32, 'ranks_depth'),
+            _dev(ranks_feat, I32, 'ranks_feat'), _dev(interval_rank, I32, 'interval_rank'),
+            _dev(interval_starts, I32, 'interval_starts'), _dev(interval_lengths, I32, 'interval_lengths'),
+            B, C, Z, Y, X, _dev(out_mean, F32, 'out_mean'), c_void_p(tile_ws.data_ptr()),
+            tile_ws.numel() * tile_ws.element_size(), int(tile_voxels), int(flags) & ~(POOL_OUT_BF16 | POOL_OUT_F16),
+            _stream()), 'fbbev_pool_zmean')
+    return out_mean
+
+
 def bev_pool_v2_dense_fwd(depth, feat, ranks_depth, ranks_feat, interval_rank, interval_starts,
                           interval_lengths, B, C, Z, Y, X, out, tile_ws, tile_voxels=64,
-                          flags=DEFAULT_POOL_FLAGS):
+                          flags=DEFAULT_POOL_FLAGS, addend=None):
     """`out` is (B,C,Z,Y,X) f32 whose (Z,Y,X) block is contiguous (batch/channel strides may be padded), or,
     with POOL_CHANNELS_LAST in `flags`, a contiguous (B,Z,Y,X,C) tensor (the reference op's own layout)."""
     if not out.is_cuda or out.dtype not in (F32, torch.bfloat16, torch.float16):
@@ -240,14 +259,19 @@ def bev_pool_v2_dense_fwd(depth, feat, ranks_depth, ranks_feat, interval_rank, i
         if tuple(out.shape) != (B, C, Z, Y, X) or out.stride()[2:] != (Y * X, X, 1):
             raise FbbevError('out must be a (B,C,Z,Y,X) tensor with a contiguous (Z,Y,X) block')
         sb, sc = out.stride(0), out.stride(1)
-    with _on(depth):
-        _check(lib().fbbev_bev_pool_v2_dense_fwd(
-            _dev(depth, F32, 'depth'), _dev(feat, F32, 'feat'), _dev(ranks_depth, I32, 'ranks_depth'),
+    args = (_dev(depth, F32, 'depth'), _dev(feat, F32, 'feat'), _dev(ranks_depth, I32, 'ranks_depth'),
             _dev(ranks_feat, I32, 'ranks_feat'), _dev(interval_rank, I32, 'interval_rank'),
             _dev(interval_starts, I32, 'interval_starts'), _dev(interval_lengths, I32, 'interval_lengths'),
             B, C, Z, Y, X, c_void_p(out.data_ptr()), sb, sc, c_void_p(tile_ws.data_ptr()),
-            tile_ws.numel() * tile_ws.element_size(), int(tile_voxels), int(flags), _stream()),
-            'fbbev_bev_pool_v2_dense_fwd')
+            tile_ws.numel() * tile_ws.element_size(), int(tile_voxels), int(flags))
+    with _on(depth):
+        if addend is None:
+            _check(lib().fbbev_bev_pool_v2_dense_fwd(*args, _stream()), 'fbbev_bev_pool_v2_dense_fwd')
+        else:       # out = pooled + addend[b,c,y,x] broadcast over z (the re-add of fbocc.py:365-366)
+            if tuple(addend.shape) != (B, C, Y, X):
+                raise FbbevError('addend must be (B,C,Y,X)')
+            _check(lib().fbbev_bev_pool_v2_dense_fwd_add(*args, _dev(addend, F32, 'addend'), _stream()),
+                   'fbbev_bev_pool_v2_dense_fwd_add')
 
 
 def pool_dense_bwd_workspace_bytes(B, N, D, H, W, C, Z, Y, X):

@@ -395,6 +395,7 @@ struct dense2_args {
     long long n_blocks; size_t lds; fbbev_rt_stream stream; int C, Z, yx, tpp, csplit, swizzle;
     long long stride_b, stride_c;
     const float *depth, *feat; const int32_t *rd, *rf, *irank, *starts, *lengths; const int* tile_meta;
+    const float* addend = nullptr;   // optional (B,C,Y,X) broadcast-over-z add in the dense2 epilogue
     float* out;
 };
 
@@ -410,7 +411,7 @@ static int launch_dense2(const dense2_args& a) {
         grid = (a.n_blocks + g - 1) / g * g;
     }
     FBBEV_LAUNCH((k_pool_fwd_dense2<TV, CPL, ST, NT, OT>), grid, NT, a.lds, a.stream, a.C, a.Z, a.yx, a.tpp,
-                 a.csplit, (int)a.n_blocks, a.swizzle, a.stride_b, a.stride_c, a.depth, a.feat, a.rd, a.rf, a.irank, a.starts, a.lengths, a.tile_meta, a.out);
+                 a.csplit, (int)a.n_blocks, a.swizzle, a.stride_b, a.stride_c, a.depth, a.feat, a.rd, a.rf, a.irank, a.starts, a.lengths, a.tile_meta, a.addend, a.out);
     return fbbev_rt_last_error();
 }
 
@@ -455,13 +456,13 @@ static int launch_dense2_st(int st, int nt, int ot, const dense2_args& a) {
     }
 }
 
-extern "C" int fbbev_bev_pool_v2_dense_fwd(const float* depth, const float* feat,
-                                           const int32_t* ranks_depth, const int32_t* ranks_feat,
-                                           const int32_t* interval_rank, const int32_t* interval_starts,
-                                           const int32_t* interval_lengths, int B, int C, int Z, int Y,
-                                           int X, float* out, long long out_stride_b, long long out_stride_c,
-                                           const void* tile_ws, size_t tile_ws_bytes, int tile_voxels,
-                                           int flags, fbbev_stream_t stream_) {
+static int pool_dense_fwd_impl(const float* depth, const float* feat,
+                               const int32_t* ranks_depth, const int32_t* ranks_feat,
+                               const int32_t* interval_rank, const int32_t* interval_starts,
+                               const int32_t* interval_lengths, int B, int C, int Z, int Y,
+                               int X, float* out, long long out_stride_b, long long out_stride_c,
+                               const void* tile_ws, size_t tile_ws_bytes, int tile_voxels,
+                               int flags, const float* addend, fbbev_stream_t stream_) {
     if (B <= 0 || C <= 0 || Z <= 0 || Y <= 0 || X <= 0) return FBBEV_E_BADARG;
     if (!depth || !feat || !ranks_depth || !ranks_feat || !interval_rank || !interval_starts ||
         !interval_lengths || !out || !tile_ws) return FBBEV_E_BADARG;
@@ -484,6 +485,7 @@ extern "C" int fbbev_bev_pool_v2_dense_fwd(const float* depth, const float* feat
         if (flags & FBBEV_POOL_CHANNELS_LAST) return FBBEV_E_UNSUPPORTED;
         if (yx % 8 != 0 || out_stride_c % 8 != 0 || out_stride_b % 8 != 0) return FBBEV_E_UNSUPPORTED;
     }
+    if (addend && ((flags & FBBEV_POOL_CHANNELS_LAST) || !aligned16(addend))) return FBBEV_E_UNSUPPORTED;
     if (flags & FBBEV_POOL_CHANNELS_LAST) {
         // out is (B,Z,Y,X,C) contiguous: flat tiles, linear store stream, no LDS value tile
         if (out_stride_b != (long long)C * Z * yx || out_stride_c != (long long)Z * yx) return FBBEV_E_BADARG;
@@ -553,12 +555,76 @@ extern "C" int fbbev_bev_pool_v2_dense_fwd(const float* depth, const float* feat
     if (a.n_blocks + 8 >= (1ll << 31) || a.lds > 160 * 1024) return FBBEV_E_UNSUPPORTED;
     a.depth = depth; a.feat = feat; a.rd = ranks_depth; a.rf = ranks_feat; a.irank = interval_rank;
     a.starts = interval_starts; a.lengths = interval_lengths; a.tile_meta = static_cast<const int*>(tile_ws);
-    a.out = out; a.stride_b = out_stride_b; a.stride_c = out_stride_c;
+    a.out = out; a.stride_b = out_stride_b; a.stride_c = out_stride_c; a.addend = addend;
     if (TV == 64) return cpl8 ? launch_dense2_st<64, 8>(st, nt, ot, a) : launch_dense2_st<64, 4>(st, nt, ot, a);
     if (TV == 128) return cpl8 ? launch_dense2_st<128, 8>(st, nt, ot, a) : launch_dense2_st<128, 4>(st, nt, ot, a);
     if (TV == 256) return cpl8 ? launch_dense2_st<256, 8>(st, nt, ot, a) : launch_dense2_st<256, 4>(st, nt, ot, a);
     if (TV == 512) return cpl8 ? launch_dense2_st<512, 8>(st, nt, ot, a) : launch_dense2_st<512, 4>(st, nt, ot, a);
     return cpl8 ? launch_dense2_st<1024, 8>(st, nt, ot, a) : launch_dense2_st<1024, 4>(st, nt, ot, a);
+}
+
+extern "C" int fbbev_bev_pool_v2_dense_fwd(const float* depth, const float* feat,
+                                           const int32_t* ranks_depth, const int32_t* ranks_feat,
+                                           const int32_t* interval_rank, const int32_t* interval_starts,
+                                           const int32_t* interval_lengths, int B, int C, int Z, int Y,
+                                           int X, float* out, long long out_stride_b, long long out_stride_c,
+                                           const void* tile_ws, size_t tile_ws_bytes, int tile_voxels,
+                                           int flags, fbbev_stream_t stream_) {
+    return pool_dense_fwd_impl(depth, feat, ranks_depth, ranks_feat, interval_rank, interval_starts, interval_lengths, B, C,
+                               Z, Y, X, out, out_stride_b, out_stride_c, tile_ws, tile_ws_bytes, tile_voxels, flags, nullptr,
+                               stream_);
+}
+
+extern "C" int fbbev_bev_pool_v2_dense_fwd_add(const float* depth, const float* feat,
+                                               const int32_t* ranks_depth, const int32_t* ranks_feat,
+                                               const int32_t* interval_rank, const int32_t* interval_starts,
+                                               const int32_t* interval_lengths, int B, int C, int Z, int Y,
+                                               int X, float* out, long long out_stride_b, long long out_stride_c,
+                                               const void* tile_ws, size_t tile_ws_bytes, int tile_voxels,
+                                               int flags, const float* addend, fbbev_stream_t stream_) {
+    if (!addend) return FBBEV_E_BADARG;
+    return pool_dense_fwd_impl(depth, feat, ranks_depth, ranks_feat, interval_rank, interval_starts, interval_lengths, B, C,
+                               Z, Y, X, out, out_stride_b, out_stride_c, tile_ws, tile_ws_bytes, tile_voxels, flags, addend,
+                               stream_);
+}
+
+extern "C" int fbbev_pool_zmean(const float* depth, const float* feat, const int32_t* ranks_depth,
+                                const int32_t* ranks_feat, const int32_t* interval_rank,
+                                const int32_t* interval_starts, const int32_t* interval_lengths, int B, int C, int Z,
+                                int Y, int X, float* out_mean, const void* tile_ws, size_t tile_ws_bytes,
+                                int tile_voxels, int flags, fbbev_stream_t stream_) {
+    if (B <= 0 || C <= 0 || Z <= 0 || Y <= 0 || X <= 0) return FBBEV_E_BADARG;
+    if (!depth || !feat || !ranks_depth || !ranks_feat || !interval_rank || !interval_starts || !interval_lengths ||
+        !out_mean || !tile_ws) return FBBEV_E_BADARG;
+    const long long yx = (long long)Y * X;
+    if (C % 4 != 0 || C > 256 || yx % 4 != 0 || !aligned16(out_mean) || !aligned16(feat)) return FBBEV_E_UNSUPPORTED;
+    if ((long long)B * Z * yx >= (1ll << 31) || (flags & FBBEV_POOL_CHANNELS_LAST)) return FBBEV_E_UNSUPPORTED;
+    const int TV = pick_tile(tile_voxels);
+    if (TV > 256) return FBBEV_E_UNSUPPORTED;
+    const int tiles_per_plane = (int)((yx + TV - 1) / TV);
+    const long long n_tiles = (long long)B * Z * tiles_per_plane;
+    if (tile_ws_bytes < (size_t)(n_tiles + 1) * 8) return FBBEV_E_WORKSPACE;
+    int csplit = (flags >> FBBEV_POOL_CSPLIT_SHIFT) & 0xF;
+    if (csplit == 0xF) csplit = 20;
+    if (csplit < 1) csplit = 1;
+    if (C % (4 * csplit) != 0) csplit = 1;
+    const int CC = C / csplit;
+    const bool cpl8 = (flags & FBBEV_POOL_CPL8) && (CC % 8 == 0);
+    if (256 / (CC / (cpl8 ? 8 : 4)) < 1) return FBBEV_E_UNSUPPORTED;
+    const size_t lds = ((size_t)CC * (TV + 4) + 3 * (size_t)TV + 2 * FBBEV_NP_STAGE) * sizeof(float);
+    if (lds > 64 * 1024) return FBBEV_E_UNSUPPORTED;
+    const long long blocks = (long long)B * tiles_per_plane * csplit;
+    const int* meta = static_cast<const int*>(tile_ws);
+#define FBBEV_ZMEAN(TV_, CPL_)                                                                                       \
+    FBBEV_LAUNCH((k_pool_zmean<TV_, CPL_, 256>), blocks, 256, lds, (fbbev_rt_stream)stream_, C, Z, (int)yx,           \
+                 tiles_per_plane, csplit, (int)blocks, depth, feat, ranks_depth, ranks_feat, interval_rank,          \
+                 interval_starts, interval_lengths, meta, out_mean)
+    if (TV == 64) { if (cpl8) FBBEV_ZMEAN(64, 8); else FBBEV_ZMEAN(64, 4); }
+    else if (TV == 128) { if (cpl8) FBBEV_ZMEAN(128, 8); else FBBEV_ZMEAN(128, 4); }
+    else { if (cpl8) FBBEV_ZMEAN(256, 8); else FBBEV_ZMEAN(256, 4); }
+#undef FBBEV_ZMEAN
+    FBBEV_CHECK_LAUNCH();
+    return 0;
 }
 
 // ------------------------------------------------------------------------------ MSDeformAttn

@@ -318,7 +318,7 @@ k_pool_fwd_dense2(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_b
                   const int* __restrict__ rd, const int* __restrict__ rf,
                   const int* __restrict__ interval_rank, const int* __restrict__ starts,
                   const int* __restrict__ lengths, const int* __restrict__ tile_meta,
-                  float* __restrict__ out) {
+                  const float* __restrict__ addend, float* __restrict__ out) {
     constexpr int LD = TV + 4;
     constexpr int Q4 = TV / 4;
     const int CC = C / csplit;                 // channels handled by this block
@@ -356,18 +356,32 @@ k_pool_fwd_dense2(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_b
     unsigned short* __restrict__ obase16 = reinterpret_cast<unsigned short*>(out) + oofs;   // OT != 0
     const int n4 = CC * Q4;
     constexpr int Q8 = TV / 8;
+    // optional epilogue: out[b,c,z,y,x] = pooled + addend[b,c,y,x] (the re-add of the refined BEV, fbocc.py:365-366,
+    // fused into the one pass that writes the volume); addend is (B,C,Y,X) contiguous, broadcast over z
+    const float* __restrict__ ab = addend ? addend + ((long long)b * C + c0) * YX + v0 : nullptr;
 
     if (i0 == i1) {
         fbbev_v4f zero; zero[0] = zero[1] = zero[2] = zero[3] = 0.f;
         if constexpr (OT == 0) {
             for (int idx = tid; idx < n4; idx += NT) {
                 const int c = idx / Q4, j = (idx - c * Q4) * 4;
-                if (j < nv) fbbev_store4<ST>(obase + c * cstride + j, zero);
+                if (j < nv) fbbev_store4<ST>(obase + c * cstride + j,
+                                             ab ? *reinterpret_cast<const fbbev_v4f*>(ab + (long long)c * YX + j) : zero);
             }
         } else {
             for (int idx = tid; idx < CC * Q8; idx += NT) {
                 const int c = idx / Q8, j = (idx - c * Q8) * 8;
-                if (j < nv) fbbev_store4<ST>(reinterpret_cast<float*>(obase16 + c * cstride + j), zero);
+                if (j < nv) {
+                    fbbev_v4f val = zero;
+                    if (ab) {
+                        const fbbev_v4f lo = *reinterpret_cast<const fbbev_v4f*>(ab + (long long)c * YX + j);
+                        const fbbev_v4f hi = *reinterpret_cast<const fbbev_v4f*>(ab + (long long)c * YX + j + 4);
+                        unsigned int pk[4] = {fbbev_pack2<OT>(lo[0], lo[1]), fbbev_pack2<OT>(lo[2], lo[3]),
+                                              fbbev_pack2<OT>(hi[0], hi[1]), fbbev_pack2<OT>(hi[2], hi[3])};
+                        __builtin_memcpy(&val, pk, 16);
+                    }
+                    fbbev_store4<ST>(reinterpret_cast<float*>(obase16 + c * cstride + j), val);
+                }
             }
         }
         return;
@@ -410,7 +424,8 @@ k_pool_fwd_dense2(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_b
         for (int idx = tid; idx < n4; idx += NT) {
             const int c = idx / Q4, j = (idx - c * Q4) * 4;
             if (j < nv) {
-                const fbbev_v4f val = *reinterpret_cast<const fbbev_v4f*>(tile + c * LD + j);
+                fbbev_v4f val = *reinterpret_cast<const fbbev_v4f*>(tile + c * LD + j);
+                if (ab) val += *reinterpret_cast<const fbbev_v4f*>(ab + (long long)c * YX + j);
                 fbbev_store4<ST>(obase + c * cstride + j, val);
             }
         }
@@ -418,14 +433,97 @@ k_pool_fwd_dense2(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_b
         for (int idx = tid; idx < CC * Q8; idx += NT) {
             const int c = idx / Q8, j = (idx - c * Q8) * 8;
             if (j < nv) {
-                const fbbev_v4f lo = *reinterpret_cast<const fbbev_v4f*>(tile + c * LD + j);
-                const fbbev_v4f hi = *reinterpret_cast<const fbbev_v4f*>(tile + c * LD + j + 4);
+                fbbev_v4f lo = *reinterpret_cast<const fbbev_v4f*>(tile + c * LD + j);
+                fbbev_v4f hi = *reinterpret_cast<const fbbev_v4f*>(tile + c * LD + j + 4);
+                if (ab) {
+                    lo += *reinterpret_cast<const fbbev_v4f*>(ab + (long long)c * YX + j);
+                    hi += *reinterpret_cast<const fbbev_v4f*>(ab + (long long)c * YX + j + 4);
+                }
                 unsigned int pk[4] = {fbbev_pack2<OT>(lo[0], lo[1]), fbbev_pack2<OT>(lo[2], lo[3]),
                                       fbbev_pack2<OT>(hi[0], hi[1]), fbbev_pack2<OT>(hi[2], hi[3])};
                 fbbev_v4f val;
                 __builtin_memcpy(&val, pk, 16);
                 fbbev_store4<ST>(reinterpret_cast<float*>(obase16 + c * cstride + j), val);
             }
+        }
+    }
+}
+
+// ================================================================ Z-mean of the pooled volume without the volume
+// lss_bev = bev_feat.mean(-1) (fbocc.py:359: the backward projection's input) computed straight from the index
+// tensors: a workgroup owns TV consecutive (y,x) voxels x CC channels and walks the Z planes in ascending order,
+// accumulating each plane's per-voxel sums (the same in-order fmaf chains) into one LDS tile; out (B,C,Y,X) =
+// tile / Z.  The reference writes the (B,C,Z,Y,X) volume, permutes it and reads it back for this mean; with this
+// kernel before and the `addend` epilogue of k_pool_fwd_dense2 after the backward projection the volume is written
+// exactly once and never re-read.  Uses the same tile index as the dense kernel (same tile_voxels).
+template <int TV, int CPL, int NT>
+__global__ void __launch_bounds__(NT)
+k_pool_zmean(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_blocks,
+             const float* __restrict__ depth, const float* __restrict__ feat,
+             const int* __restrict__ rd, const int* __restrict__ rf,
+             const int* __restrict__ interval_rank, const int* __restrict__ starts,
+             const int* __restrict__ lengths, const int* __restrict__ tile_meta, float* __restrict__ out) {
+    constexpr int LD = TV + 4;
+    constexpr int Q4 = TV / 4;
+    const int CC = C / csplit;
+    float* tile = fbbev_dyn_lds_f32();         // [CC][LD]
+    int* ist = reinterpret_cast<int*>(tile + CC * LD);
+    int* iln = ist + TV;
+    int* ivx = iln + TV;
+    int* prd = ivx + TV;
+    int* prf = prd + FBBEV_NP_STAGE;
+    const int tid = threadIdx.x;
+    const int bid = blockIdx.x;
+    if (bid >= n_blocks) return;
+    const int tk = bid / csplit, half = bid - tk * csplit;      // tk = b * tiles_per_plane + k
+    const int c0 = half * CC;
+    const int b = tk / tiles_per_plane, k = tk - b * tiles_per_plane;
+    const int v0 = k * TV;
+    const int nv = (YX - v0 < TV) ? (YX - v0) : TV;
+    for (int idx = tid; idx < CC * LD; idx += NT) tile[idx] = 0.f;
+    for (int z = 0; z < Z; ++z) {
+        const int plane = b * Z + z;
+        const int t = plane * tiles_per_plane + k;
+        const int i0 = tile_meta[2 * t], p0 = tile_meta[2 * t + 1];
+        const int i1 = tile_meta[2 * t + 2], p1 = tile_meta[2 * t + 3];
+        if (i0 == i1) continue;                 // block-uniform
+        const int ni = i1 - i0, np = p1 - p0;
+        const int rank0 = plane * YX + v0;
+        __syncthreads();                        // previous plane's gathers are done with the staging buffers / tile init
+        for (int j = tid; j < ni; j += NT) {
+            ist[j] = starts[i0 + j] - p0;
+            iln[j] = lengths[i0 + j];
+            ivx[j] = interval_rank[i0 + j] - rank0;
+        }
+        const int nps = np < FBBEV_NP_STAGE ? np : FBBEV_NP_STAGE;
+        for (int j = tid; j < nps; j += NT) { prd[j] = rd[p0 + j]; prf[j] = rf[p0 + j]; }
+        __syncthreads();
+        const int lpi = CC / CPL;
+        const int gpb = NT / lpi;
+        const int g = tid / lpi, slot = tid - g * lpi;
+        if (g < gpb) {
+            const float* fbase = feat + c0 + slot * CPL;
+            for (int i = g; i < ni; i += gpb) {          // a voxel appears in at most one interval of a plane:
+                const int v = ivx[i];                    // its LDS cell is owned by one lane group per plane
+                float acc[CPL];
+                fbbev_interval_sum_staged<CPL, 4>(C, ist[i], iln[i], p0, prd, prf, depth, fbase, rd, rf, acc);
+                if (v >= 0 && v < nv) {
+                    float* dst = tile + (slot * CPL) * LD + v;
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) dst[j * LD] += acc[j];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const float zf = (float)Z;
+    float* __restrict__ ob = out + ((long long)b * C + c0) * YX + v0;
+    for (int idx = tid; idx < CC * Q4; idx += NT) {
+        const int c = idx / Q4, j = (idx - c * Q4) * 4;
+        if (j < nv) {
+            fbbev_v4f val = *reinterpret_cast<const fbbev_v4f*>(tile + c * LD + j);
+            val[0] /= zf; val[1] /= zf; val[2] /= zf; val[3] /= zf;
+            *reinterpret_cast<fbbev_v4f*>(ob + (long long)c * YX + j) = val;
         }
     }
 }

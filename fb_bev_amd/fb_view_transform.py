@@ -2,6 +2,7 @@
 (mmdet3d/models/fbbev/detectors/fbocc.py:344-366): forward projection (lift-splat) -> backward
 projection refinement of the Z-mean BEV -> re-add broadcast over Z.  Inputs are what the depth net
 produces (`context`, `depth`) plus `cam_params = img_inputs[1:7]`."""
+import torch
 import torch.nn as nn
 
 from . import backward_projection as BP
@@ -16,13 +17,28 @@ class FBViewTransform(nn.Module):
         self.forward_projection = LSSViewTransformerFunction3D(**fp)
         self.backward_projection = BP.build(backward_projection) if backward_projection is not None else None
         self.readd = readd
+        self.write_once = True      # inference: Z-mean from the index tensors + re-add in the pooling store (volume written once)
 
     def forward(self, cam_params, context, depth, img_metas=None, bev_mask=None, mlvl_feats=None):
         """mlvl_feats: optional list of (B,N,C,H_l,W_l) image features for the backward projection (default
         [context], as fbocc.py:357 passes); BASELINE configs[2] uses 4 levels."""
-        bev_feat = self.forward_projection(cam_params, context, depth)            # (B,C,Y,X,Z)   fbocc.py:344-345
+        fp = self.forward_projection
+        feats = mlvl_feats if mlvl_feats is not None else [context]
+        needs_grad = torch.is_grad_enabled() and (context.requires_grad or depth.requires_grad or
+                                                  any(p.requires_grad for p in self.parameters()))
+        if (self.write_once and self.backward_projection is not None and self.readd and fp.fused and not fp.extra_relu and not needs_grad
+                and context.is_cuda):
+            # inference: the volume is written ONCE.  The reference writes it (bev_pool_v2), reads it for the Z-mean
+            # (fbocc.py:359) and reads + re-writes it for the re-add (:365-366); here the Z-mean comes straight from the
+            # index tensors and the refined BEV is added in the store epilogue of the one dense pooling pass.
+            parts = fp.pooling_inputs(cam_params, context, depth)
+            lss_mean = fp.pooled_zmean(parts)
+            refined = self.backward_projection(feats, img_metas, lss_bev=lss_mean, cam_params=cam_params, bev_mask=bev_mask,
+                                               gt_bboxes_3d=None, pred_img_depth=depth)
+            return fp.pooled_volume(parts, addend=refined)
+        bev_feat = fp(cam_params, context, depth)                                 # (B,C,Y,X,Z)   fbocc.py:344-345
         if self.backward_projection is None:
             return bev_feat
-        refined = self.backward_projection(mlvl_feats if mlvl_feats is not None else [context], img_metas, lss_bev=bev_feat.mean(-1), cam_params=cam_params,
+        refined = self.backward_projection(feats, img_metas, lss_bev=bev_feat.mean(-1), cam_params=cam_params,
                                            bev_mask=bev_mask, gt_bboxes_3d=None, pred_img_depth=depth)   # :357-363
         return refined[..., None] + bev_feat if self.readd else refined           # :365-368

@@ -305,5 +305,45 @@ class LSSViewTransformerFunction3D(nn.Module):
         bev = self.view_transform(cam_params, depth, context)
         return bev.relu() if self.extra_relu else bev
 
+    # ------------------------------------------------------------------ write-once volume (inference, FBViewTransform)
+    def pooling_inputs(self, cam_params, context, depth):
+        """Index set (cached when accelerate=True) + the two gather sources of the fused kernels."""
+        if self.accelerate:
+            self.pre_compute(cam_params)
+        idx = self._index_cache if (self.accelerate and self._index_cache is not None) else \
+            self.build_index_from_cams(*cam_params)
+        depth = depth.contiguous().float()
+        feat = _capi.nchw_to_nhwc(context.contiguous().float())
+        B = depth.shape[0]
+        Z, Y, X = self.grid_zyx
+        tile_ws = self._tile_ws(depth.device, B)
+        _capi.pool_tile_index(idx.interval_rank, idx.interval_starts, idx.counts, idx.n, B, Z, Y, X, tile_ws,
+                              self._wo_tile)
+        return idx, depth, feat, tile_ws
+
+    @property
+    def _wo_tile(self):
+        return min(self.tile_voxels, 256)       # fbbev_pool_zmean takes tiles of 64..256 voxels
+
+    def pooled_zmean(self, parts):
+        """bev_feat.mean(-1) of the lift-splat output, (B,C,Y,X), without materialising the volume (fbbev_pool_zmean)."""
+        idx, depth, feat, tile_ws = parts
+        B, C = depth.shape[0], feat.shape[-1]
+        Z, Y, X = self.grid_zyx
+        out = torch.empty((B, C, Y, X), dtype=torch.float32, device=depth.device)
+        return _capi.pool_zmean(depth, feat, idx.ranks_depth, idx.ranks_feat, idx.interval_rank, idx.interval_starts,
+                                idx.interval_lengths, B, C, Z, Y, X, out, tile_ws, self._wo_tile, self.pool_flags)
+
+    def pooled_volume(self, parts, addend=None):
+        """The (B,C,Y,X,Z) view of the volume, written once; addend (B,C,Y,X) is added broadcast over z in the store."""
+        idx, depth, feat, tile_ws = parts
+        B, C = depth.shape[0], feat.shape[-1]
+        Z, Y, X = self.grid_zyx
+        out = torch.empty((B, C, Z, Y, X), dtype=self.out_dtype, device=depth.device)
+        _capi.bev_pool_v2_dense_fwd(depth, feat, idx.ranks_depth, idx.ranks_feat, idx.interval_rank, idx.interval_starts,
+                                    idx.interval_lengths, B, C, Z, Y, X, out, tile_ws, self._wo_tile, self.pool_flags,
+                                    addend=None if addend is None else addend.contiguous().float())
+        return out.permute(0, 1, 3, 4, 2)
+
     def get_mlp_input(self, rot, tran, intrin, post_rot, post_tran, bda):
         return None

@@ -154,6 +154,26 @@ int fbbev_bev_pool_v2_dense_fwd(const float* depth, const float* feat, const int
                                 long long out_stride_c, const void* tile_ws, size_t tile_ws_bytes,
                                 int tile_voxels, int flags, fbbev_stream_t stream);
 
+/* The forward + backward projection of FB-OCC needs the pooled volume twice -- its Z-mean as the backward projection's
+ * input (fbocc.py:359 `lss_bev=bev_feat.mean(-1)`) and, after the refinement, re-added to it (:365-366
+ * `bev_feat_refined[..., None] + bev_feat`): the reference writes the volume, reads it for the mean, and reads +
+ * re-writes it for the add.  With these two entry points the volume is written once and never re-read:
+ * fbbev_pool_zmean: out_mean (B,C,Y,X) = mean over z of the pooled sums, straight from the index tensors (planes
+ *   accumulated in ascending z, same in-order fmaf chains per voxel); same tile index / tile_voxels (64..256) / csplit
+ *   and CPL8 flags as the dense kernel.
+ * fbbev_bev_pool_v2_dense_fwd_add: fbbev_bev_pool_v2_dense_fwd with out[b,c,z,y,x] = pooled + addend[b,c,y,x]
+ *   (addend (B,C,Y,X) f32 contiguous, 16-byte aligned; (B,C,Z,Y,X) layout only). */
+int fbbev_pool_zmean(const float* depth, const float* feat, const int32_t* ranks_depth, const int32_t* ranks_feat,
+                     const int32_t* interval_rank, const int32_t* interval_starts, const int32_t* interval_lengths,
+                     int B, int C, int Z, int Y, int X, float* out_mean, const void* tile_ws, size_t tile_ws_bytes,
+                     int tile_voxels, int flags, fbbev_stream_t stream);
+int fbbev_bev_pool_v2_dense_fwd_add(const float* depth, const float* feat, const int32_t* ranks_depth,
+                                    const int32_t* ranks_feat, const int32_t* interval_rank,
+                                    const int32_t* interval_starts, const int32_t* interval_lengths, int B, int C,
+                                    int Z, int Y, int X, float* out, long long out_stride_b, long long out_stride_c,
+                                    const void* tile_ws, size_t tile_ws_bytes, int tile_voxels, int flags,
+                                    const float* addend, fbbev_stream_t stream);
+
 /* ----------------------------------------------------------------------------------------------
  * Boundary 2: mmcv._ext.ms_deform_attn_{forward,backward} (mmcv-full 1.5.2, external to the tree)
  * -------------------------------------------------------------------------------------------- */

@@ -59,12 +59,25 @@ def pool_bwd(out_grad, depth_grad, feat_grad, depth, feat, rd, rf, rb, st, ln):
                                    p(rf), p(rb), p(st), p(ln), p(depth_grad), p(feat_grad), None))
 
 
-def pool_dense(depth, feat, rd, rf, ir, st, ln, counts, n_max, B, C, Z, Y, X, tile_voxels, flags=0):
+def pool_zmean(depth, feat, rd, rf, ir, st, ln, counts, n_max, B, C, Z, Y, X, tile_voxels, flags=0):
+    out = torch.full((B, C, Y, X), float('nan'))
+    ws = torch.zeros(lib().fbbev_pool_dense_workspace_bytes(B, Z, Y, X), dtype=torch.uint8)
+    ok(lib().fbbev_pool_tile_index(p(ir), p(st), p(counts), n_max, B, Z, Y, X, tile_voxels, flags, p(ws), ws.numel(), None))
+    code = lib().fbbev_pool_zmean(p(depth), p(feat), p(rd), p(rf), p(ir), p(st), p(ln), B, C, Z, Y, X, p(out), p(ws),
+                                  ws.numel(), tile_voxels, flags, None)
+    return code, out
+
+
+def pool_dense(depth, feat, rd, rf, ir, st, ln, counts, n_max, B, C, Z, Y, X, tile_voxels, flags=0, addend=None):
     cl = bool(flags & 0x100000)
     dt = torch.bfloat16 if flags & 0x800000 else (torch.float16 if flags & 0x1000000 else torch.float32)
     out = torch.full((B, Z, Y, X, C) if cl else (B, C, Z, Y, X), float('nan'), dtype=dt)
     ws = torch.zeros(lib().fbbev_pool_dense_workspace_bytes(B, Z, Y, X), dtype=torch.uint8)
     ok(lib().fbbev_pool_tile_index(p(ir), p(st), p(counts), n_max, B, Z, Y, X, tile_voxels, flags, p(ws), ws.numel(), None))
+    if addend is not None:
+        code = lib().fbbev_bev_pool_v2_dense_fwd_add(p(depth), p(feat), p(rd), p(rf), p(ir), p(st), p(ln), B, C, Z, Y, X,
+                                                     p(out), 0, 0, p(ws), ws.numel(), tile_voxels, flags, p(addend), None)
+        return code, out
     code = lib().fbbev_bev_pool_v2_dense_fwd(p(depth), p(feat), p(rd), p(rf), p(ir), p(st), p(ln),
                                              B, C, Z, Y, X, p(out), 0, 0, p(ws), ws.numel(), tile_voxels, flags, None)
     return code, out

@@ -474,3 +474,27 @@ def test_history_conv_mfma_emulated(B, T1, C, Cout, N):
     exp = torch.relu(torch.einsum('oc,bcn->bon', w2.double(), y.reshape(B, T1 * C, N)) + b2.view(1, Cout, 1).double())
     assert not torch.isnan(got).any()
     assert torch.allclose(got.double(), exp, atol=2e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize('name,tv,flags', [('TINY', 64, 0), ('TINY', 128, 0x24), ('SMALL', 128, 0x24424), ('SMALL', 256, 0x4)])
+def test_pool_zmean_and_add_epilogue_emulated(name, tv, flags):
+    """fbbev_pool_zmean == mean over z of the pooled volume; fbbev_bev_pool_v2_dense_fwd_add == volume + addend[...,None]
+    (fbocc.py:359,365-366): the volume is written once and never re-read."""
+    B = 2 if name == 'TINY' else 1
+    cfg, vt, coor, depth, feat = _case(name, B)
+    rb, rd, rf, st, ln, ir, counts = E.rank_build(coor, *_grid3(vt))
+    _, Z, Y, X, C = vt.bev_feat_shape(B, cfg.channels)
+    erb, erd, erf, est, eln = vt.voxel_pooling_prepare_v2(coor)
+    vol = O.bev_pool_v2(depth, feat, erd, erf, erb, (B, Z, Y, X, C), est, eln, use_fma=True)      # (B,C,Z,Y,X)
+    code, mean = E.pool_zmean(depth, feat, rd, rf, ir, st, ln, counts, st.numel(), B, C, Z, Y, X, tv, flags)
+    assert code == 0 and not torch.isnan(mean).any()
+    assert torch.allclose(mean, vol.mean(2), atol=1e-6, rtol=1e-5)
+    assert torch.allclose(mean, vol.double().sum(2).float() / Z, atol=1e-6, rtol=1e-5)
+    addend = torch.randn(B, C, Y, X, generator=torch.Generator().manual_seed(3))
+    code, out = E.pool_dense(depth, feat, rd, rf, ir, st, ln, counts, st.numel(), B, C, Z, Y, X, tv, flags, addend=addend)
+    assert code == 0
+    assert torch.equal(out, vol + addend[:, :, None])                # one fp32 add per element: identical bits
+    if (Y * X) % 8 == 0:
+        code, o16 = E.pool_dense(depth, feat, rd, rf, ir, st, ln, counts, st.numel(), B, C, Z, Y, X, tv, flags | 0x800000,
+                                 addend=addend)
+        assert code == 0 and torch.equal(o16.view(torch.int16), (vol + addend[:, :, None]).to(torch.bfloat16).view(torch.int16))

@@ -177,3 +177,35 @@ def test_fused_training_step_has_no_host_sync(dev):
         torch.cuda.set_sync_debug_mode('default')
     torch.cuda.synchronize()
     assert all(t.grad is not None and torch.isfinite(t.grad).all() for t in f_g + [d_g, l_g])
+
+
+@pytest.mark.parametrize('name,B', [('REF', 2), ('BL2', 1), ('REF', 1)])
+def test_write_once_volume_path_equals_reference_composition(dev, name, B):
+    """FBViewTransform inference: Z-mean from the index tensors (fbbev_pool_zmean) + re-add in the pooling store
+    (fbbev_bev_pool_v2_dense_fwd_add) == pool -> mean(-1) -> backward projection -> refined[...,None] + volume."""
+    from fb_bev_amd import configs, synthetic as S
+    from fb_bev_amd.fb_view_transform import FBViewTransform
+    pc = S.CONFIGS[name]
+    X, Y, Z = pc.grid_xyz
+    gcb = {'x': pc.grid_config['x'], 'y': pc.grid_config['y'], 'z': [-1, 5.4, 1.6]}
+    cfg = configs.fbocc_r50(bev_h=Y, bev_w=X, numC_Trans=pc.channels, input_size=pc.input_size, grid_config=pc.grid_config,
+                            grid_config_bevformer=gcb, depth_bound=tuple(pc.grid_config['depth']), downsample=pc.downsample)
+    torch.manual_seed(0)
+    m = FBViewTransform(cfg['forward_projection'], cfg['backward_projection']).to(dev).eval()
+    cam = [t.to(dev) for t in S.camera_rig(pc, B, seed=0, bda_aug=True)]
+    depth, ctx = S.depth_and_context(pc, B, seed=0)
+    depth, ctx = depth.to(dev), ctx.to(dev)
+    with torch.no_grad():
+        m.write_once = True
+        a = m(cam, ctx, depth)
+        m.write_once = False
+        b = m(cam, ctx, depth)
+        # the pieces: Z-mean and add epilogue against the materialised volume
+        fp = m.forward_projection
+        vol = fp(cam, ctx, depth)
+        parts = fp.pooling_inputs(cam, ctx, depth)
+        assert (fp.pooled_zmean(parts) - vol.mean(-1)).abs().max().item() < 1e-5
+        addend = torch.randn(B, pc.channels, Y, X, device=dev)
+        assert torch.equal(fp.pooled_volume(parts, addend=addend), vol + addend[..., None])
+    assert a.shape == b.shape == (B, pc.channels, Y, X, Z)
+    assert (a - b).abs().max().item() < 1e-4
