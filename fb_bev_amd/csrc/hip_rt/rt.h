@@ -60,3 +60,11 @@ __device__ __forceinline__ void fbbev_atomic_add_f32(float* p, float v) { unsafe
 __device__ __forceinline__ fbbev_v4f fbbev_mfma_f32_16x16x4(float a, float b, fbbev_v4f c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
+
+// wave-level ordering point for a wave-PRIVATE LDS region: the 64 lanes run in lockstep and the LDS queue of a wave is
+// in order, so only the compiler has to be kept from moving LDS accesses across it (no s_barrier, no other wave waits)
+__device__ __forceinline__ void fbbev_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}

@@ -141,12 +141,12 @@ k_history_conv_t(const float* __restrict__ feats, long long fstride_b, const flo
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk) bx[kk] = inb ? xn[(long long)(4 * kk + g) * N + n] : 0.f;
         }
-        __syncthreads();
+        fbbev_wave_sync();                                  // ylds is wave-private: no workgroup barrier
 #pragma unroll
         for (int mt = 0; mt < MT1; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) ylds[(16 * mt + 4 * g + r) * 16 + j] = fmaxf(acc1[mt][r], 0.f);
-        __syncthreads();
+        fbbev_wave_sync();
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) {
             const float by = ylds[(4 * kk + g) * 16 + j];

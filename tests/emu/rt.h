@@ -182,3 +182,5 @@ inline fbbev_v4f fbbev_mfma_f32_16x16x4(float a, float b, fbbev_v4f c) {
     emu::wave_barrier();
     return d;
 }
+
+inline void fbbev_wave_sync() { emu::wave_barrier(); }
