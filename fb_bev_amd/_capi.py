@@ -42,8 +42,8 @@ SIGNATURES = {
     'fbbev_history_conv': (c_int, [c_void_p, c_int64] + [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t, c_void_p]),
     'fbbev_msda_fwd': (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_void_p, c_void_p]),
     'fbbev_point_sampling': (c_int, [c_void_p] * 9 + [c_int] * 5 + [c_float, c_float] + [c_void_p] * 4),
-    'fbbev_da_cross_attn_fwd': (c_int, [c_void_p] * 9 + [c_int] * 10 + [c_float, c_float, c_int, c_void_p, c_void_p]),
-    'fbbev_da_cross_attn_bwd': (c_int, [c_void_p] * 10 + [c_int] * 10 + [c_float, c_float, c_int] + [c_void_p] * 5),
+    'fbbev_da_cross_attn_fwd': (c_int, [c_void_p] * 9 + [c_int] * 10 + [c_float, c_float, c_int, c_int, c_void_p, c_void_p]),
+    'fbbev_da_cross_attn_bwd': (c_int, [c_void_p] * 10 + [c_int] * 10 + [c_float, c_float, c_int, c_int] + [c_void_p] * 5),
     'fbbev_msda_bwd': (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p] * 3 + [c_void_p]),
 }
 
@@ -326,16 +326,19 @@ def msda_bwd(value, spatial_shapes, level_start_index, sampling_loc, attn_weight
 
 
 def da_cross_attn_fwd(value, spatial_shapes, level_start_index, pred_depth, ref_cam, mask, qdepth, offsets,
-                      attn, d0, dstep, slots, head_minor=0):
+                      attn, d0, dstep, slots, head_minor=0, head_dim=None):
     """value (B*Ncam,S,M,Dh); pred_depth (B*Ncam,DC,H0,W0); ref_cam (Ncam,B,Q,Za,2); mask (Ncam,B,Q,Za) bool;
     qdepth (Ncam,B,Q,Za); offsets (B,Q,M,L,P,2); attn (B,Q,M,L,P); head_minor bit 0: offsets is (B,Q,L,P,M,2),
     bit 1: attn is (B,Q,L,P,M); slots (B,Q,M*Dh)."""
     Ncam, B, Q, Za = mask.shape
-    _, S, M, Dh = value.shape
+    _, S, M, HS = value.shape                 # HS = head stride; head_dim (<= HS) of them are channels, the rest padding
+    Dh = HS if head_dim is None else int(head_dim)
     head_minor = int(head_minor)
     L, P = (attn.shape[2], attn.shape[3]) if head_minor & 2 else (attn.shape[3], attn.shape[4])
     if attn.shape[-1 if head_minor & 2 else 2] != M or offsets.shape[-2 if head_minor & 1 else 2] != M:
         raise FbbevError('offsets / attn layout does not match head_minor')
+    if tuple(slots.shape[-1:]) != (M * Dh,):
+        raise FbbevError('slots must be (B,Q,M*head_dim)')
     DC = pred_depth.shape[1]
     if mask.dtype == torch.bool:
         mask = mask.view(torch.uint8)
@@ -345,14 +348,15 @@ def da_cross_attn_fwd(value, spatial_shapes, level_start_index, pred_depth, ref_
             _dev(level_start_index, I64, 'level_start_index'), _dev(pred_depth, F32, 'pred_depth'),
             _dev(ref_cam, F32, 'ref_cam'), _dev(mask, torch.uint8, 'mask'), _dev(qdepth, F32, 'qdepth'),
             _dev(offsets, F32, 'offsets'), _dev(attn, F32, 'attn'), B, Ncam, S, M, Dh, L, Q, P, Za, DC,
-            float(d0), float(dstep), head_minor, _dev(slots, F32, 'slots'), _stream()), 'fbbev_da_cross_attn_fwd')
+            float(d0), float(dstep), head_minor, HS, _dev(slots, F32, 'slots'), _stream()), 'fbbev_da_cross_attn_fwd')
 
 
 def da_cross_attn_bwd(value, spatial_shapes, level_start_index, pred_depth, ref_cam, mask, qdepth, offsets, attn,
-                      grad_slots, d0, dstep, head_minor, grad_value, grad_pred_depth, grad_offsets, grad_attn):
+                      grad_slots, d0, dstep, head_minor, grad_value, grad_pred_depth, grad_offsets, grad_attn, head_dim=None):
     """Backward of da_cross_attn_fwd; the four grad tensors must be pre-zeroed (accumulated into)."""
     Ncam, B, Q, Za = mask.shape
-    _, S, M, Dh = value.shape
+    _, S, M, HS = value.shape
+    Dh = HS if head_dim is None else int(head_dim)
     head_minor = int(head_minor)
     L, P = (attn.shape[2], attn.shape[3]) if head_minor & 2 else (attn.shape[3], attn.shape[4])
     DC = pred_depth.shape[1]
@@ -364,7 +368,7 @@ def da_cross_attn_bwd(value, spatial_shapes, level_start_index, pred_depth, ref_
             _dev(level_start_index, I64, 'level_start_index'), _dev(pred_depth, F32, 'pred_depth'),
             _dev(ref_cam, F32, 'ref_cam'), _dev(mask, torch.uint8, 'mask'), _dev(qdepth, F32, 'qdepth'),
             _dev(offsets, F32, 'offsets'), _dev(attn, F32, 'attn'), _dev(grad_slots, F32, 'grad_slots'),
-            B, Ncam, S, M, Dh, L, Q, P, Za, DC, float(d0), float(dstep), head_minor,
+            B, Ncam, S, M, Dh, L, Q, P, Za, DC, float(d0), float(dstep), head_minor, HS,
             _dev(grad_value, F32, 'grad_value'), _dev(grad_pred_depth, F32, 'grad_pred_depth'),
             _dev(grad_offsets, F32, 'grad_offsets'), _dev(grad_attn, F32, 'grad_attn'), _stream()),
             'fbbev_da_cross_attn_bwd')

@@ -292,24 +292,25 @@ class FusedDACrossAttention(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, value, pred_depth, offsets, attn, spatial_shapes, level_start_index, ref_cam, mask, qdepth,
-                d0, dstep, head_minor):
+                d0, dstep, head_minor, head_dim=None):
         B, Q = offsets.shape[0], offsets.shape[1]
-        M, Dh = value.shape[2], value.shape[3]
+        M = value.shape[2]
+        Dh = value.shape[3] if head_dim is None else head_dim          # value rows may be head-padded (stride value.shape[3])
         slots = torch.empty((B, Q, M * Dh), dtype=torch.float32, device=value.device)
         _capi.da_cross_attn_fwd(value, spatial_shapes, level_start_index, pred_depth, ref_cam, mask, qdepth, offsets,
-                                attn, d0, dstep, slots, head_minor=head_minor)
+                                attn, d0, dstep, slots, head_minor=head_minor, head_dim=Dh)
         ctx.save_for_backward(value, pred_depth, offsets, attn, spatial_shapes, level_start_index, ref_cam, mask, qdepth)
-        ctx.consts = (d0, dstep, head_minor)
+        ctx.consts = (d0, dstep, head_minor, Dh)
         return slots
 
     @staticmethod
     def backward(ctx, grad_slots):
         value, pred_depth, offsets, attn, spatial_shapes, level_start_index, ref_cam, mask, qdepth = ctx.saved_tensors
-        d0, dstep, head_minor = ctx.consts
+        d0, dstep, head_minor, Dh = ctx.consts
         gv, gd, go, ga = (torch.zeros_like(t) for t in (value, pred_depth, offsets, attn))
         _capi.da_cross_attn_bwd(value, spatial_shapes, level_start_index, pred_depth, ref_cam, mask, qdepth, offsets,
-                                attn, grad_slots.contiguous().float(), d0, dstep, head_minor, gv, gd, go, ga)
-        return gv, gd, go, ga, None, None, None, None, None, None, None, None
+                                attn, grad_slots.contiguous().float(), d0, dstep, head_minor, gv, gd, go, ga, head_dim=Dh)
+        return gv, gd, go, ga, None, None, None, None, None, None, None, None, None
 
 
 FUSED_BWD_MAX_HEAD_DIM = 32                 # k_da_cross_attn_bwd: one lane per channel, groups of 16 / 32 lanes
@@ -338,14 +339,36 @@ class DA_SpatialCrossAttention(nn.Module):
         da = self.deformable_attention
         B, Q, E = query.shape
         ncam, S, _, _ = value.shape
-        v = da.value_proj(value.permute(2, 0, 1, 3).reshape(B * ncam, S, E)).view(B * ncam, S, da.num_heads, -1)
+        M = da.num_heads
+        Dh = E // M
+        HS = (Dh + 3) // 4 * 4
+        x = value.permute(2, 0, 1, 3).reshape(B * ncam, S, E)
+        if HS != Dh:
+            # value_proj with its output rows padded per head (Dh = 10 -> 12 floats): every head chunk of a camera token is
+            # then 16-byte aligned and the kernel reads a bilinear corner with 3 dwordx4 loads instead of 5 eight-byte
+            # ones.  Same dot products for the real rows; the padding rows are zero and ignored by the kernel.
+            wt, bs = da.value_proj.weight, da.value_proj.bias
+            key = (wt.data_ptr(), wt._version, bs._version, str(wt.device))
+            if torch.is_grad_enabled() and (wt.requires_grad or bs.requires_grad):
+                w = F.pad(wt.view(M, Dh, E), (0, 0, 0, HS - Dh)).reshape(M * HS, E)
+                bb = F.pad(bs.view(M, Dh), (0, HS - Dh)).reshape(M * HS)
+            else:                           # inference: pad once per weight version
+                if getattr(self, '_vpad_key', None) != key:
+                    with torch.no_grad():
+                        self._vpad = (F.pad(wt.view(M, Dh, E), (0, 0, 0, HS - Dh)).reshape(M * HS, E).contiguous(),
+                                      F.pad(bs.view(M, Dh), (0, HS - Dh)).reshape(M * HS).contiguous())
+                    self._vpad_key = key
+                w, bb = self._vpad
+            v = F.linear(x, w, bb).view(B * ncam, S, M, HS)
+        else:
+            v = da.value_proj(x).view(B * ncam, S, M, Dh)
         so, aw = da.project_head_minor(query)
         DC, H0, W0 = pred_img_depth.shape[2:]
         return FusedDACrossAttention.apply(
             v.contiguous().float(), pred_img_depth.reshape(B * ncam, DC, H0, W0).contiguous().float(),
             so.contiguous().float(), aw.contiguous().float(), spatial_shapes.to(torch.int64).contiguous(),
             level_start_index.to(torch.int64).contiguous(), reference_points_cam.contiguous().float(), mask.contiguous(),
-            bev_query_depth.squeeze(-1).contiguous().float(), self.dbound[0], self.dbound[2], 1)
+            bev_query_depth.squeeze(-1).contiguous().float(), self.dbound[0], self.dbound[2], 1, Dh)
 
     # ---- training: vectorised rebatch + composite deformable attention (autograd through the MSDA op)
     def _slots_composite(self, query, value, reference_points_cam, mask, bev_query_depth, pred_img_depth,

@@ -682,7 +682,7 @@ extern "C" int fbbev_da_cross_attn_fwd(const float* value, const int64_t* spatia
                                        const float* ref_cam, const uint8_t* mask, const float* qdepth,
                                        const float* offsets, const float* attn, int B, int Ncam, int S, int M,
                                        int Dh, int L, int Q, int P, int Za, int DC, float d0, float dstep,
-                                       int head_minor, float* slots, fbbev_stream_t stream_) {
+                                       int head_minor, int head_stride, float* slots, fbbev_stream_t stream_) {
     if (B <= 0 || Ncam <= 0 || S <= 0 || M <= 0 || Dh <= 0 || L <= 0 || Q < 0 || P <= 0 || Za <= 0 || DC <= 0)
         return FBBEV_E_BADARG;
     if (Za > FBBEV_DA_MAX_ZA || P % Za != 0) return FBBEV_E_UNSUPPORTED;
@@ -691,19 +691,24 @@ extern "C" int fbbev_da_cross_attn_fwd(const float* value, const int64_t* spatia
     if (n == 0) return 0;
     if (!value || !spatial_shapes || !level_start_index || !pred_depth || !ref_cam || !mask || !qdepth ||
         !offsets || !attn || !slots) return FBBEV_E_BADARG;
+    const int HS = head_stride == 0 ? Dh : head_stride;
+    if (HS < Dh) return FBBEV_E_BADARG;
+    const bool wide = HS % 4 == 0 && HS >= (Dh + 3) / 4 * 4 && aligned16(value);
     const bool al8 = (((uintptr_t)value | (uintptr_t)offsets | (uintptr_t)slots) & 7) == 0;
-    if (al8 && (Dh == 10 || Dh == 8 || Dh == 16 || Dh == 32)) {   // a lane owns all Dh channels of a (b,q,head) unit
+    if (al8 && HS % 2 == 0 && (Dh == 10 || Dh == 8 || Dh == 16 || Dh == 32)) {   // a lane owns all Dh channels of a (b,q,head) unit
         const long long units = (long long)B * Q * M;
         long long ub = (units + 255) / 256;
         if (ub > 65536) ub = 65536;
-#define FBBEV_DA_UNIT(DH_)                                                                                          \
-    FBBEV_LAUNCH(k_da_cross_attn_fwd_unit<DH_>, ub, 256, 0, (fbbev_rt_stream)stream_, units, value, spatial_shapes, \
-                 level_start_index, pred_depth, ref_cam, mask, qdepth, offsets, attn, B, Ncam, S, M, L, Q, P, Za,   \
-                 DC, d0, dstep, head_minor & 3, slots)
+#define FBBEV_DA_UNIT_W(DH_, W_)                                                                                    \
+    FBBEV_LAUNCH((k_da_cross_attn_fwd_unit<DH_, W_>), ub, 256, 0, (fbbev_rt_stream)stream_, units, value,             \
+                 spatial_shapes, level_start_index, pred_depth, ref_cam, mask, qdepth, offsets, attn, B, Ncam, S, M, \
+                 L, Q, P, Za, DC, d0, dstep, head_minor & 3, HS, slots)
+#define FBBEV_DA_UNIT(DH_) do { if (wide) FBBEV_DA_UNIT_W(DH_, true); else FBBEV_DA_UNIT_W(DH_, false); } while (0)
         if (Dh == 10) FBBEV_DA_UNIT(10);
         else if (Dh == 8) FBBEV_DA_UNIT(8);
         else if (Dh == 16) FBBEV_DA_UNIT(16);
         else FBBEV_DA_UNIT(32);
+#undef FBBEV_DA_UNIT_W
 #undef FBBEV_DA_UNIT
         FBBEV_CHECK_LAUNCH();
         return 0;
@@ -712,7 +717,7 @@ extern "C" int fbbev_da_cross_attn_fwd(const float* value, const int64_t* spatia
     if (blocks > 65536) blocks = 65536;
     FBBEV_LAUNCH(k_da_cross_attn_fwd, blocks, 256, 0, (fbbev_rt_stream)stream_, n, value, spatial_shapes,
                  level_start_index, pred_depth, ref_cam, mask, qdepth, offsets, attn, B, Ncam, S, M, Dh, L, Q, P,
-                 Za, DC, d0, dstep, head_minor & 3, slots);
+                 Za, DC, d0, dstep, head_minor & 3, HS, slots);
     FBBEV_CHECK_LAUNCH();
     return 0;
 }
@@ -721,9 +726,9 @@ extern "C" int fbbev_da_cross_attn_bwd(const float* value, const int64_t* spatia
                                        const float* pred_depth, const float* ref_cam, const uint8_t* mask,
                                        const float* qdepth, const float* offsets, const float* attn,
                                        const float* grad_slots, int B, int Ncam, int S, int M, int Dh, int L, int Q,
-                                       int P, int Za, int DC, float d0, float dstep, int head_minor, float* grad_value,
-                                       float* grad_pred_depth, float* grad_offsets, float* grad_attn,
-                                       fbbev_stream_t stream_) {
+                                       int P, int Za, int DC, float d0, float dstep, int head_minor, int head_stride,
+                                       float* grad_value, float* grad_pred_depth, float* grad_offsets,
+                                       float* grad_attn, fbbev_stream_t stream_) {
     if (B <= 0 || Ncam <= 0 || S <= 0 || M <= 0 || Dh <= 0 || L <= 0 || Q < 0 || P <= 0 || Za <= 0 || DC <= 0)
         return FBBEV_E_BADARG;
     if (Za > FBBEV_DA_MAX_ZA || P % Za != 0) return FBBEV_E_UNSUPPORTED;
@@ -733,10 +738,12 @@ extern "C" int fbbev_da_cross_attn_bwd(const float* value, const int64_t* spatia
     if (!value || !spatial_shapes || !level_start_index || !pred_depth || !ref_cam || !mask || !qdepth || !offsets ||
         !attn || !grad_slots || !grad_value || !grad_pred_depth || !grad_offsets || !grad_attn) return FBBEV_E_BADARG;
     if (Dh > 32) return FBBEV_E_UNSUPPORTED;
+    const int HS = head_stride == 0 ? Dh : head_stride;
+    if (HS < Dh) return FBBEV_E_BADARG;
 #define FBBEV_DA_BWD(GW_)                                                                                             \
     FBBEV_LAUNCH(k_da_cross_attn_bwd<GW_>, (units * GW_ + 255) / 256, 256, 0, (fbbev_rt_stream)stream_, units, value,  \
                  spatial_shapes, level_start_index, pred_depth, ref_cam, mask, qdepth, offsets, attn, grad_slots, B,  \
-                 Ncam, S, M, Dh, L, Q, P, Za, DC, d0, dstep, head_minor & 3, grad_value, grad_pred_depth,            \
+                 Ncam, S, M, Dh, L, Q, P, Za, DC, d0, dstep, head_minor & 3, HS, grad_value, grad_pred_depth,        \
                  grad_offsets, grad_attn)
     if ((units * 32 + 255) / 256 >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
     if (Dh <= 16) FBBEV_DA_BWD(16);

@@ -46,8 +46,8 @@ k_da_cross_attn_fwd(long long n, const float* __restrict__ value, const int64_t*
                     const float* __restrict__ ref_cam, const unsigned char* __restrict__ mask,
                     const float* __restrict__ qdepth, const float* __restrict__ offsets,
                     const float* __restrict__ attn, int B, int Ncam, int S, int M, int Dh, int L, int Q, int P,
-                    int Za, int DC, float d0, float dstep, int head_minor, float* __restrict__ slots) {
-    const int row_stride = M * Dh;
+                    int Za, int DC, float d0, float dstep, int head_minor, int HS, float* __restrict__ slots) {
+    const int row_stride = M * HS;               // HS = floats between two heads of a value row (>= Dh; padding ignored)
     const int H0 = (int)spatial_shapes[0], W0 = (int)spatial_shapes[1];
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < n;
          idx += (long long)gridDim.x * blockDim.x) {
@@ -79,7 +79,7 @@ k_da_cross_attn_fwd(long long n, const float* __restrict__ value, const int64_t*
             float col = 0.f;
             for (int l = 0; l < L; ++l) {
                 const int sh = (int)spatial_shapes[2 * l], sw = (int)spatial_shapes[2 * l + 1];
-                const float* vp = value + (bn * S + level_start[l]) * row_stride + m * Dh + c;
+                const float* vp = value + (bn * S + level_start[l]) * row_stride + m * HS + c;
                 for (int p = 0; p < P; ++p) {
                     // offsets / attn: (B,Q,M,L,P[,2]) as the Linear layers emit them, or head-minor (B,Q,L,P,M[,2]):
                     // head_minor bit 0 -> offsets, bit 1 -> attn
@@ -114,17 +114,21 @@ k_da_cross_attn_fwd(long long n, const float* __restrict__ value, const int64_t*
 // each corner is read as DH/2 eight-byte loads (a head's DH floats are contiguous; neighbouring lanes = neighbouring
 // heads read one contiguous M*DH*4-byte row).  The channel-per-lane kernel spends its time in the vector L1's per-lane
 // dword rate (7 loads per sample per lane, 10 lanes per unit at Dh = 10); this one issues 23 loads per sample per unit.
-template <int DH>
+// WIDE: the head stride HS is a multiple of 4 floats and covers DH rounded up to 4 (the host pads value_proj's output
+// rows, e.g. Dh = 10 -> HS = 12): every head chunk is 16-byte aligned and a corner is read as DHP/4 dwordx4 loads
+// (3 L1 accesses instead of 5 eight-byte ones; the padding floats are loaded and ignored).
+template <int DH, bool WIDE>
 __global__ void __launch_bounds__(256)
 k_da_cross_attn_fwd_unit(long long n_units, const float* __restrict__ value, const int64_t* __restrict__ spatial_shapes,
                          const int64_t* __restrict__ level_start, const float* __restrict__ pred_depth,
                          const float* __restrict__ ref_cam, const unsigned char* __restrict__ mask,
                          const float* __restrict__ qdepth, const float* __restrict__ offsets,
                          const float* __restrict__ attn, int B, int Ncam, int S, int M, int L, int Q, int P, int Za,
-                         int DC, float d0, float dstep, int head_minor, float* __restrict__ slots) {
+                         int DC, float d0, float dstep, int head_minor, int HS, float* __restrict__ slots) {
     static_assert(DH % 2 == 0, "eight-byte loads");
-    constexpr int row_stride_unit = DH;
-    const int row_stride = M * DH;
+    constexpr int DHP = (DH + 3) / 4 * 4;
+    const int row_stride_unit = HS;
+    const int row_stride = M * HS;
     const int H0 = (int)spatial_shapes[0], W0 = (int)spatial_shapes[1];
     for (long long unit = (long long)blockIdx.x * blockDim.x + threadIdx.x; unit < n_units;
          unit += (long long)gridDim.x * blockDim.x) {
@@ -173,16 +177,29 @@ k_da_cross_attn_fwd_unit(long long n_units, const float* __restrict__ value, con
                     const float h_im = loc_h * sh - 0.5f, w_im = loc_w * sw - 0.5f;
                     if (h_im > -1.f && w_im > -1.f && h_im < (float)sh && w_im < (float)sw) {
                         const fbbev_bilinear s = fbbev_bilinear_setup(h_im, w_im, sh, sw, row_stride);
-                        float v1[DH], v2[DH], v3[DH], v4[DH];
+                        float v1[DHP], v2[DHP], v3[DHP], v4[DHP];
+                        if constexpr (WIDE) {
 #pragma unroll
-                        for (int c = 0; c < DH; c += 2) {
-                            const fbbev_v2f zero = {0.f, 0.f};
-                            const fbbev_v2f a1 = s.o1 >= 0 ? *reinterpret_cast<const fbbev_v2f*>(vp + s.o1 + c) : zero;
-                            const fbbev_v2f a2 = s.o2 >= 0 ? *reinterpret_cast<const fbbev_v2f*>(vp + s.o2 + c) : zero;
-                            const fbbev_v2f a3 = s.o3 >= 0 ? *reinterpret_cast<const fbbev_v2f*>(vp + s.o3 + c) : zero;
-                            const fbbev_v2f a4 = s.o4 >= 0 ? *reinterpret_cast<const fbbev_v2f*>(vp + s.o4 + c) : zero;
-                            v1[c] = a1[0]; v1[c + 1] = a1[1]; v2[c] = a2[0]; v2[c + 1] = a2[1];
-                            v3[c] = a3[0]; v3[c + 1] = a3[1]; v4[c] = a4[0]; v4[c + 1] = a4[1];
+                            for (int c = 0; c < DHP; c += 4) {
+                                const fbbev_v4f zero = {0.f, 0.f, 0.f, 0.f};
+                                const fbbev_v4f a1 = s.o1 >= 0 ? *reinterpret_cast<const fbbev_v4f*>(vp + s.o1 + c) : zero;
+                                const fbbev_v4f a2 = s.o2 >= 0 ? *reinterpret_cast<const fbbev_v4f*>(vp + s.o2 + c) : zero;
+                                const fbbev_v4f a3 = s.o3 >= 0 ? *reinterpret_cast<const fbbev_v4f*>(vp + s.o3 + c) : zero;
+                                const fbbev_v4f a4 = s.o4 >= 0 ? *reinterpret_cast<const fbbev_v4f*>(vp + s.o4 + c) : zero;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) { v1[c + e] = a1[e]; v2[c + e] = a2[e]; v3[c + e] = a3[e]; v4[c + e] = a4[e]; }
+                            }
+                        } else {
+#pragma unroll
+                            for (int c = 0; c < DH; c += 2) {
+                                const fbbev_v2f zero = {0.f, 0.f};
+                                const fbbev_v2f a1 = s.o1 >= 0 ? *reinterpret_cast<const fbbev_v2f*>(vp + s.o1 + c) : zero;
+                                const fbbev_v2f a2 = s.o2 >= 0 ? *reinterpret_cast<const fbbev_v2f*>(vp + s.o2 + c) : zero;
+                                const fbbev_v2f a3 = s.o3 >= 0 ? *reinterpret_cast<const fbbev_v2f*>(vp + s.o3 + c) : zero;
+                                const fbbev_v2f a4 = s.o4 >= 0 ? *reinterpret_cast<const fbbev_v2f*>(vp + s.o4 + c) : zero;
+                                v1[c] = a1[0]; v1[c + 1] = a1[1]; v2[c] = a2[0]; v2[c + 1] = a2[1];
+                                v3[c] = a3[0]; v3[c + 1] = a3[1]; v4[c] = a4[0]; v4[c + 1] = a4[1];
+                            }
                         }
 #pragma unroll
                         for (int c = 0; c < DH; ++c)
@@ -229,14 +246,14 @@ k_da_cross_attn_bwd(long long n_units, const float* __restrict__ value, const in
                     const float* __restrict__ ref_cam, const unsigned char* __restrict__ mask,
                     const float* __restrict__ qdepth, const float* __restrict__ offsets,
                     const float* __restrict__ attn, const float* __restrict__ grad_slots, int B, int Ncam, int S,
-                    int M, int Dh, int L, int Q, int P, int Za, int DC, float d0, float dstep, int head_minor,
+                    int M, int Dh, int L, int Q, int P, int Za, int DC, float d0, float dstep, int head_minor, int HS,
                     float* __restrict__ grad_value, float* __restrict__ grad_pred_depth,
                     float* __restrict__ grad_offsets, float* __restrict__ grad_attn) {
     const int slot = threadIdx.x % GW;
     const long long unit = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / GW;
     const bool active = unit < n_units;
     const long long u = active ? unit : 0;
-    const int row_stride = M * Dh;
+    const int row_stride = M * HS;               // value / grad_value rows: M heads of HS floats (Dh used)
     const int H0 = (int)spatial_shapes[0], W0 = (int)spatial_shapes[1];
     const int m = (int)(u % M);
     const long long bq = u / M;
@@ -274,7 +291,7 @@ k_da_cross_attn_bwd(long long n_units, const float* __restrict__ value, const in
         }
         for (int l = 0; l < L; ++l) {
             const int sh = (int)spatial_shapes[2 * l], sw = (int)spatial_shapes[2 * l + 1];
-            const long long voff = (bn * S + level_start[l]) * row_stride + m * Dh + slot;
+            const long long voff = (bn * S + level_start[l]) * row_stride + m * HS + slot;
             for (int p = 0; p < P; ++p) {
                 const long long wm = (u * L + l) * P + p, wh = ((bq * L + l) * P + p) * M + m;
                 const long long wo = (head_minor & 1) ? wh : wm, wa = (head_minor & 2) ? wh : wm;

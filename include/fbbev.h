@@ -226,6 +226,9 @@ int fbbev_point_sampling(const float* xs, const float* ys, const float* zs, cons
  * per BEV query; d0/dstep = dbound[0]/dbound[2].  head_minor: bit 0 -> offsets is laid out (B,Q,L,P,M,2), bit 1 -> attn
  * is (B,Q,L,P,M) -- what the Linear layers emit when their output rows are permuted; the heads of a query then
  * read contiguous bytes per sample (offsets head-minor is the fast path of the FB-OCC shapes).
+ * head_stride: floats between two heads inside a value row (0 = Dh, i.e. value is (B*Ncam,S,M,Dh) dense); a value_proj
+ * output padded to a multiple of 4 floats per head (Dh = 10 -> 12) makes every head chunk 16-byte aligned and lets the
+ * kernel read a corner with 3 dwordx4 loads; the padding floats are ignored (grad_value of the padding stays 0).
  * slots (B,Q,M*Dh) = sum over hit cameras of the depth-weighted deformable sample / max(#hit,1)
  * (the tensor the reference feeds to output_proj, :216-219). */
 int fbbev_da_cross_attn_fwd(const float* value, const int64_t* spatial_shapes,
@@ -233,7 +236,7 @@ int fbbev_da_cross_attn_fwd(const float* value, const int64_t* spatial_shapes,
                             const float* ref_cam, const uint8_t* mask, const float* qdepth,
                             const float* offsets, const float* attn, int B, int Ncam, int S, int M, int Dh,
                             int L, int Q, int P, int Za, int DC, float d0, float dstep, int head_minor,
-                            float* slots, fbbev_stream_t stream);
+                            int head_stride, float* slots, fbbev_stream_t stream);
 
 /* Backward of fbbev_da_cross_attn_fwd in one launch -- replaces the autograd chain of the reference's training step
  * through DA_SpatialCrossAttention / DA_MSDeformableAttention (two MultiScaleDeformableAttnFunction backward launches,
@@ -245,8 +248,8 @@ int fbbev_da_cross_attn_bwd(const float* value, const int64_t* spatial_shapes, c
                             const float* pred_depth, const float* ref_cam, const uint8_t* mask, const float* qdepth,
                             const float* offsets, const float* attn, const float* grad_slots, int B, int Ncam, int S,
                             int M, int Dh, int L, int Q, int P, int Za, int DC, float d0, float dstep, int head_minor,
-                            float* grad_value, float* grad_pred_depth, float* grad_offsets, float* grad_attn,
-                            fbbev_stream_t stream);
+                            int head_stride, float* grad_value, float* grad_pred_depth, float* grad_offsets,
+                            float* grad_attn, fbbev_stream_t stream);
 
 /* Training backward of the fused lift-splat:  replaces QuickCumsumCuda.backward (bev_pool.py:39-78 --
  * argsort of ranks_feat, mask-built intervals [2 host syncs], the permute().contiguous() of the gradient)

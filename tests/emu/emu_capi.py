@@ -125,10 +125,11 @@ def lidar_coor(xs, ys, ds, cam):
 
 
 def da_cross_attn_fwd(value, ss, ls, pred_depth, ref_cam, mask, qdepth, offsets, attn, d0, dstep, misalign=False,
-                      head_minor=0):
+                      head_minor=0, head_dim=None):
     """misalign=True: output buffer at a 4-byte (not 8-byte) aligned address => the channel-per-lane kernel runs"""
     Ncam, B, Q, Za = mask.shape
-    _, S, M, Dh = value.shape
+    _, S, M, HS = value.shape
+    Dh = HS if head_dim is None else head_dim
     L, P = (attn.shape[2], attn.shape[3]) if head_minor & 2 else (attn.shape[3], attn.shape[4])
     buf = torch.full((B * Q * M * Dh + 3,), float('nan'))
     off = 1 if (buf.data_ptr() % 8 == 0) == misalign else 0
@@ -139,7 +140,7 @@ def da_cross_attn_fwd(value, ss, ls, pred_depth, ref_cam, mask, qdepth, offsets,
     m8 = mask.to(torch.uint8).contiguous()
     ok(lib().fbbev_da_cross_attn_fwd(p(value), p(ss), p(ls), p(pred_depth), p(ref_cam), p(m8), p(qdepth), p(offsets),
                                      p(attn), B, Ncam, S, M, Dh, L, Q, P, Za, pred_depth.shape[1], d0, dstep,
-                                     int(head_minor), c_void_p(slots.data_ptr()), None))
+                                     int(head_minor), HS, c_void_p(slots.data_ptr()), None))
     return slots.clone()
 
 
@@ -208,15 +209,17 @@ def layernorm(x, weight, bias, eps, residual=None):
     return out
 
 
-def da_cross_attn_bwd(value, ss, ls, pred_depth, ref_cam, mask, qdepth, offsets, attn, d0, dstep, grad_slots, head_minor=0):
+def da_cross_attn_bwd(value, ss, ls, pred_depth, ref_cam, mask, qdepth, offsets, attn, d0, dstep, grad_slots, head_minor=0,
+                      head_dim=None):
     Ncam, B, Q, Za = mask.shape
-    _, S, M, Dh = value.shape
+    _, S, M, HS = value.shape
+    Dh = HS if head_dim is None else head_dim
     L, P = (attn.shape[2], attn.shape[3]) if head_minor & 2 else (attn.shape[3], attn.shape[4])
     gv, gd, go, ga = (torch.zeros_like(t) for t in (value, pred_depth, offsets, attn))
     m8 = mask.to(torch.uint8).contiguous()
     ok(lib().fbbev_da_cross_attn_bwd(p(value), p(ss), p(ls), p(pred_depth), p(ref_cam), p(m8), p(qdepth), p(offsets),
                                      p(attn), p(grad_slots), B, Ncam, S, M, Dh, L, Q, P, Za, pred_depth.shape[1], d0,
-                                     dstep, int(head_minor), p(gv), p(gd), p(go), p(ga), None))
+                                     dstep, int(head_minor), HS, p(gv), p(gd), p(go), p(ga), None))
     return gv, gd, go, ga
 
 

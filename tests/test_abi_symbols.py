@@ -76,6 +76,6 @@ def test_invalid_arguments_return_error_codes_without_touching_the_gpu():
     assert lib.fbbev_bev_pool_v2_dense_fwd(P, P, P, P, P, P, P, 1, 8, 4, 16, 16, P, 0, 17, P, 1 << 20, 128, 0, NULL) == -1  # bad stride
     assert lib.fbbev_msda_fwd(P, P, P, P, P, 1, 0, 8, 10, 1, 5, 4, P, NULL) == -1       # spatial_size <= 0
     assert lib.fbbev_msda_fwd(P, P, P, P, P, 0, 704, 8, 10, 1, 5, 4, P, NULL) == 0      # empty batch: no-op
-    assert lib.fbbev_da_cross_attn_fwd(P, P, P, P, P, P, P, P, P, 1, 6, 704, 8, 10, 1, 100, 8, 16, 80, 2.0, 0.5, 0, P, NULL) == -2  # Za > 8
-    assert lib.fbbev_da_cross_attn_fwd(P, P, P, P, P, P, P, P, P, 1, 6, 704, 8, 10, 1, 100, 8, 4, 80, 2.0, 0.0, 0, P, NULL) == -1   # dstep == 0
+    assert lib.fbbev_da_cross_attn_fwd(P, P, P, P, P, P, P, P, P, 1, 6, 704, 8, 10, 1, 100, 8, 16, 80, 2.0, 0.5, 0, 0, P, NULL) == -2  # Za > 8
+    assert lib.fbbev_da_cross_attn_fwd(P, P, P, P, P, P, P, P, P, 1, 6, 704, 8, 10, 1, 100, 8, 4, 80, 2.0, 0.0, 0, 0, P, NULL) == -1   # dstep == 0
     assert lib.fbbev_rank_workspace_bytes(0) == 256 and lib.fbbev_pool_dense_workspace_bytes(0, 1, 1, 1) == 256

@@ -217,6 +217,14 @@ def test_fused_da_cross_attention_emulated():
         assert torch.equal(got, E.da_cross_attn_fwd(*a, head_minor=3, misalign=True))
         a[8] = args[8]                                                    # offsets head-minor only (the module's choice)
         assert torch.equal(got, E.da_cross_attn_fwd(*a, head_minor=1))
+        # head-padded value rows (Dh -> multiple of 4, 16-byte aligned head chunks): same bits, padding ignored
+        Dh = args[0].shape[-1]
+        HS = (Dh + 3) // 4 * 4 + (4 if Dh % 4 == 0 else 0)
+        vp = torch.full(args[0].shape[:-1] + (HS,), 7.0e5)              # garbage in the padding must not matter
+        vp[..., :Dh] = args[0]
+        a[0] = vp
+        assert torch.equal(got, E.da_cross_attn_fwd(*a, head_minor=1, head_dim=Dh))
+        assert torch.equal(got, E.da_cross_attn_fwd(*a, head_minor=1, head_dim=Dh, misalign=True))
 
 
 def test_point_sampling_emulated():
@@ -458,6 +466,18 @@ def test_fused_da_cross_attention_backward_emulated():
                     assert a is None or not a.any()
                     continue
                 assert torch.allclose(a, b, atol=5e-5 * max(1.0, b.abs().max().item()), rtol=1e-4), hm
+        # head-padded value: gradients land in the first Dh floats of every head chunk, the padding stays zero
+        Dh = value.shape[-1]
+        HS = (Dh + 3) // 4 * 4
+        if HS != Dh:
+            vp = torch.zeros(value.shape[:-1] + (HS,))
+            vp[..., :Dh] = f32(value)
+            gv2, gd2, go2, ga2 = E.da_cross_attn_bwd(vp, ss, ls, f32(pred4), f32(ref_cam), mask, f32(qdepth), f32(offsets), f32(attn),
+                                                     d0, dstep, f32(g), head_minor=0, head_dim=Dh)
+            gv0, gd0, go0, ga0 = E.da_cross_attn_bwd(f32(value), ss, ls, f32(pred4), f32(ref_cam), mask, f32(qdepth), f32(offsets),
+                                                     f32(attn), d0, dstep, f32(g), head_minor=0)
+            assert torch.equal(gv2[..., :Dh], gv0) and not gv2[..., Dh:].any()
+            assert torch.equal(gd2, gd0) and torch.equal(go2, go0) and torch.equal(ga2, ga0)
 
 
 @pytest.mark.parametrize('B,T1,C,Cout,N', [(1, 3, 16, 16, 64), (2, 2, 32, 16, 100), (1, 4, 16, 32, 17)])
