@@ -24,6 +24,8 @@ SIGNATURES = {
     'fbbev_rank_workspace_bytes': (c_size_t, [c_int64]),
     'fbbev_rank_build': (c_int, [c_void_p] + [c_int] * 5 + [c_void_p] * 3 + [c_void_p] * 7 +
                          [c_void_p, c_size_t, c_void_p]),
+    'fbbev_rank_build_depth': (c_int, [c_void_p, c_void_p, c_float] + [c_int] * 5 + [c_void_p] * 3 + [c_void_p] * 7 +
+                               [c_void_p, c_size_t, c_void_p]),
     'fbbev_lift_rank_build': (c_int, [c_void_p] * 10 + [c_int] * 5 + [c_void_p] * 3 + [c_void_p] * 7 +
                               [c_void_p, c_size_t, c_void_p]),
     'fbbev_pool_dense_workspace_bytes': (c_size_t, [c_int] * 4),
@@ -151,21 +153,28 @@ def rank_workspace_bytes(n_points):
 
 
 def rank_build(coor, lower3, interval3, grid_size3, ranks_bev, ranks_depth, ranks_feat,
-               interval_starts, interval_lengths, interval_rank, counts, workspace):
-    """coor (B,N,D,H,W,3) f32 GPU; lower3/interval3/grid_size3: 3 python floats each (fp32 values)."""
+               interval_starts, interval_lengths, interval_rank, counts, workspace, depth=None, depth_threshold=0.01):
+    """coor (B,N,D,H,W,3) f32 GPU; lower3/interval3/grid_size3: 3 python floats each (fp32 values).
+    depth (B,N,D,H,W): optional BEVDet-era filter, points with depth <= depth_threshold are dropped."""
     B, N, D, H, W, three = coor.shape
     assert three == 3
     arr = ctypes.c_float * 3
     lo, it, gs = arr(*lower3), arr(*interval3), arr(*grid_size3)
-    with _on(coor):
-        _check(lib().fbbev_rank_build(
-            _dev(coor, F32, 'coor'), B, N, D, H, W, ctypes.cast(lo, c_void_p), ctypes.cast(it, c_void_p),
+    tail = (B, N, D, H, W, ctypes.cast(lo, c_void_p), ctypes.cast(it, c_void_p),
             ctypes.cast(gs, c_void_p), _dev(ranks_bev, I32, 'ranks_bev'),
             _dev(ranks_depth, I32, 'ranks_depth'), _dev(ranks_feat, I32, 'ranks_feat'),
             _dev(interval_starts, I32, 'interval_starts'), _dev(interval_lengths, I32, 'interval_lengths'),
             _dev(interval_rank, I32, 'interval_rank') if interval_rank is not None else c_void_p(0),
             _dev(counts, I32, 'counts'), c_void_p(workspace.data_ptr()),
-            workspace.numel() * workspace.element_size(), _stream()), 'fbbev_rank_build')
+            workspace.numel() * workspace.element_size())
+    with _on(coor):
+        if depth is None:
+            _check(lib().fbbev_rank_build(_dev(coor, F32, 'coor'), *tail, _stream()), 'fbbev_rank_build')
+        else:
+            if depth.numel() != B * N * D * H * W:
+                raise FbbevError('depth must have one element per frustum point')
+            _check(lib().fbbev_rank_build_depth(_dev(coor, F32, 'coor'), _dev(depth, F32, 'depth'), float(depth_threshold),
+                                                *tail, _stream()), 'fbbev_rank_build_depth')
 
 
 def lift_rank_build(xs, ys, ds, rots, trans, intrins, post_rots, post_trans, bda, lower3, interval3, grid_size3,

@@ -238,8 +238,10 @@ static int rank_build_impl(const float* coor, const fbbev_cam_ptrs* cams, const 
                            const float* lower3, const float* interval3, const float* grid_size3,
                            int32_t* ranks_bev, int32_t* ranks_depth, int32_t* ranks_feat,
                            int32_t* interval_starts, int32_t* interval_lengths, int32_t* interval_rank,
-                           int32_t* counts, void* workspace, size_t workspace_bytes, fbbev_rt_stream stream) {
+                           int32_t* counts, void* workspace, size_t workspace_bytes, fbbev_rt_stream stream,
+                           const float* point_depth = nullptr, float depth_thr = 0.f) {
     if (B <= 0 || N <= 0 || D <= 0 || H <= 0 || W <= 0) return FBBEV_E_BADARG;
+    if (point_depth && cams) return FBBEV_E_UNSUPPORTED;      // the depth filter belongs to the coor-based (two-step) contract
     if ((!coor && !cams) || !lower3 || !interval3 || !grid_size3 || !ranks_bev || !ranks_depth || !ranks_feat ||
         !interval_starts || !interval_lengths || !counts || !workspace) return FBBEV_E_BADARG;
     const long long n = (long long)B * N * D * H * W;
@@ -279,7 +281,7 @@ static int rank_build_impl(const float* coor, const fbbev_cam_ptrs* cams, const 
     } else {
         long long kb = (n + 255) / 256;
         if (kb > 8192) kb = 8192;
-        FBBEV_LAUNCH(k_rank_keys, kb, 256, 0, stream, coor, n, n / B, gp, sentinel, keys_in, vals_in);
+        FBBEV_LAUNCH(k_rank_keys, kb, 256, 0, stream, coor, n, n / B, gp, sentinel, point_depth, depth_thr, keys_in, vals_in);
         FBBEV_CHECK_LAUNCH();
     }
     e = radix_sort_pairs(keys_in, vals_in, reinterpret_cast<unsigned int*>(ws + L.keys_tmp),
@@ -313,6 +315,18 @@ extern "C" int fbbev_rank_build(const float* coor, int B, int N, int D, int H, i
     return rank_build_impl(coor, nullptr, nullptr, B, N, D, H, W, lower3, interval3, grid_size3, ranks_bev, ranks_depth,
                            ranks_feat, interval_starts, interval_lengths, interval_rank, counts, workspace,
                            workspace_bytes, (fbbev_rt_stream)stream_);
+}
+
+extern "C" int fbbev_rank_build_depth(const float* coor, const float* depth, float depth_threshold, int B, int N, int D,
+                                      int H, int W, const float* lower3, const float* interval3,
+                                      const float* grid_size3, int32_t* ranks_bev, int32_t* ranks_depth,
+                                      int32_t* ranks_feat, int32_t* interval_starts, int32_t* interval_lengths,
+                                      int32_t* interval_rank, int32_t* counts, void* workspace, size_t workspace_bytes,
+                                      fbbev_stream_t stream_) {
+    if (!coor || !depth) return FBBEV_E_BADARG;
+    return rank_build_impl(coor, nullptr, nullptr, B, N, D, H, W, lower3, interval3, grid_size3, ranks_bev, ranks_depth,
+                           ranks_feat, interval_starts, interval_lengths, interval_rank, counts, workspace,
+                           workspace_bytes, (fbbev_rt_stream)stream_, depth, depth_threshold);
 }
 
 extern "C" int fbbev_lift_rank_build(const float* frustum, const float* xs, const float* ys, const float* ds,

@@ -52,12 +52,16 @@ __device__ __forceinline__ unsigned int fbbev_rank_key(float cx, float cy, float
 
 __global__ void __launch_bounds__(256)
 k_rank_keys(const float* __restrict__ coor, long long npts, long long pts_per_batch,
-            fbbev_grid_params gp, unsigned int sentinel, unsigned int* __restrict__ keys,
-            unsigned int* __restrict__ vals) {
+            fbbev_grid_params gp, unsigned int sentinel, const float* __restrict__ depth, float depth_thr,
+            unsigned int* __restrict__ keys, unsigned int* __restrict__ vals) {
     for (long long pid = (long long)blockIdx.x * blockDim.x + threadIdx.x; pid < npts;
          pid += (long long)gridDim.x * blockDim.x) {
-        keys[pid] = fbbev_rank_key(coor[3 * pid], coor[3 * pid + 1], coor[3 * pid + 2], gp,
-                                   (float)(pid / pts_per_batch), sentinel);
+        unsigned int key = fbbev_rank_key(coor[3 * pid], coor[3 * pid + 1], coor[3 * pid + 2], gp,
+                                          (float)(pid / pts_per_batch), sentinel);
+        // BEVDet-era variant (mmdet3d/models/necks/view_transformer.py:556-557): kept &= depth.view(-1) > 0.01 --
+        // the number of kept points becomes data dependent, which the device-side counts absorb
+        if (depth && !(depth[pid] > depth_thr)) key = sentinel;
+        keys[pid] = key;
         vals[pid] = (unsigned int)pid;
     }
 }

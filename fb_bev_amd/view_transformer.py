@@ -200,8 +200,10 @@ class LSSViewTransformerFunction3D(nn.Module):
     def _grid3(self):
         return self.grid_lower_bound.tolist(), self.grid_interval.tolist(), self.grid_size.tolist()
 
-    def build_index(self, coor):
-        """Device-side rank build (fbbev_rank_build); no host sync. -> _IndexSet"""
+    def build_index(self, coor, depth=None, depth_threshold=0.01):
+        """Device-side rank build (fbbev_rank_build); no host sync. -> _IndexSet
+        depth: optional (B,N,D,H,W) distribution for the BEVDet-era filter `kept &= depth > 0.01`
+        (mmdet3d/models/necks/view_transformer.py:556-557); P is then data dependent, still without a host sync."""
         B, N, D, H, W, _ = coor.shape
         n = B * N * D * H * W
         key = ('rank_ws', coor.device, n)
@@ -211,7 +213,8 @@ class LSSViewTransformerFunction3D(nn.Module):
         lo, it, gs = self._grid3()
         _capi.rank_build(coor.contiguous(), lo, it, gs, idx.ranks_bev, idx.ranks_depth, idx.ranks_feat,
                          idx.interval_starts, idx.interval_lengths, idx.interval_rank, idx.counts,
-                         self._cache[key])
+                         self._cache[key], depth=None if depth is None else depth.contiguous().float(),
+                         depth_threshold=depth_threshold)
         return idx
 
     def build_index_from_cams(self, rots, trans, cam2imgs, post_rots, post_trans, bda):

@@ -106,6 +106,16 @@ int fbbev_rank_build(const float* coor, int B, int N, int D, int H, int W, const
                      int32_t* interval_lengths, int32_t* interval_rank, int32_t* counts,
                      void* workspace, size_t workspace_bytes, fbbev_stream_t stream);
 
+/* fbbev_rank_build with the BEVDet-era point filter  kept &= depth.view(-1) > depth_threshold
+ *   -- mmdet3d/models/necks/view_transformer.py:552-557 (0.01 there): `depth` is the (B,N,D,H,W) depth distribution the
+ * pooling will read; points whose own depth probability does not exceed the threshold are dropped before ranking, so
+ * P becomes data dependent -- the device-side counts absorb that without a host sync. */
+int fbbev_rank_build_depth(const float* coor, const float* depth, float depth_threshold, int B, int N, int D, int H,
+                           int W, const float* lower3, const float* interval3, const float* grid_size3,
+                           int32_t* ranks_bev, int32_t* ranks_depth, int32_t* ranks_feat, int32_t* interval_starts,
+                           int32_t* interval_lengths, int32_t* interval_rank, int32_t* counts, void* workspace,
+                           size_t workspace_bytes, fbbev_stream_t stream);
+
 /* get_lidar_coor + voxel_pooling_prepare_v2 in one call (view_transformer.py:458-498 + :547-605): the
  * keys are evaluated from the camera parameters inside the sort's first pass -- the same per-point
  * arithmetic as fbbev_lidar_coor followed by fbbev_rank_build, hence the same index tensors -- and

@@ -34,7 +34,7 @@ def ok(code):
     assert code == 0, f'C ABI returned {code}'
 
 
-def rank_build(coor, lower3, interval3, grid_size3, with_rank=True):
+def rank_build(coor, lower3, interval3, grid_size3, with_rank=True, depth=None, depth_threshold=0.01):
     B, N, D, H, W, _ = coor.shape
     n = B * N * D * H * W
     rb, rd, rf = (torch.full((n,), -7, dtype=torch.int32) for _ in range(3))
@@ -43,9 +43,12 @@ def rank_build(coor, lower3, interval3, grid_size3, with_rank=True):
     ws = torch.zeros(lib().fbbev_rank_workspace_bytes(n), dtype=torch.uint8)
     arr = ctypes.c_float * 3
     lo, it, gs = arr(*lower3), arr(*interval3), arr(*grid_size3)
-    ok(lib().fbbev_rank_build(p(coor), B, N, D, H, W, ctypes.cast(lo, c_void_p), ctypes.cast(it, c_void_p),
-                              ctypes.cast(gs, c_void_p), p(rb), p(rd), p(rf), p(st), p(ln),
-                              p(ir) if with_rank else c_void_p(0), p(counts), p(ws), ws.numel(), None))
+    tail = (B, N, D, H, W, ctypes.cast(lo, c_void_p), ctypes.cast(it, c_void_p), ctypes.cast(gs, c_void_p), p(rb), p(rd),
+            p(rf), p(st), p(ln), p(ir) if with_rank else c_void_p(0), p(counts), p(ws), ws.numel(), None)
+    if depth is None:
+        ok(lib().fbbev_rank_build(p(coor), *tail))
+    else:
+        ok(lib().fbbev_rank_build_depth(p(coor), p(depth), depth_threshold, *tail))
     return rb, rd, rf, st, ln, ir, counts
 
 

@@ -518,3 +518,21 @@ def test_pool_zmean_and_add_epilogue_emulated(name, tv, flags):
         code, o16 = E.pool_dense(depth, feat, rd, rf, ir, st, ln, counts, st.numel(), B, C, Z, Y, X, tv, flags | 0x800000,
                                  addend=addend)
         assert code == 0 and torch.equal(o16.view(torch.int16), (vol + addend[:, :, None]).to(torch.bfloat16).view(torch.int16))
+
+
+def test_rank_build_with_depth_threshold_emulated():
+    """BEVDet-era filter kept &= depth > 0.01 (mmdet3d/models/necks/view_transformer.py:552-557): data-dependent P."""
+    cfg, vt, coor, depth, feat = _case('TINY', 2)
+    g = torch.Generator().manual_seed(9)
+    depth = depth.clone()
+    depth[torch.rand(depth.shape, generator=g) < 0.4] = 0.005                  # 40 % of the points fall under the threshold
+    depth.view(-1)[0] = 0.01                                                   # exactly the threshold: dropped (strict >)
+    rb, rd, rf, st, ln, ir, counts = E.rank_build(coor, *_grid3(vt), depth=depth.contiguous(), depth_threshold=0.01)
+    # oracle: the reference prepare on the coordinates with the under-threshold points pushed out of the grid
+    c2 = coor.clone()
+    c2.view(-1, 3)[~(depth.reshape(-1) > 0.01)] = 1.0e6
+    erb, erd, erf, est, eln = vt.voxel_pooling_prepare_v2(c2)
+    P, I = counts.tolist()
+    assert (P, I) == (erb.numel(), est.numel()) and P < E.rank_build(coor, *_grid3(vt))[6][0]
+    assert torch.equal(rb[:P], erb) and torch.equal(rd[:P], erd) and torch.equal(rf[:P], erf)
+    assert torch.equal(st[:I], est) and torch.equal(ln[:I], eln)

@@ -134,6 +134,20 @@ def test_fp32_rank_collisions_above_2_24_are_reproduced(dev):
     assert int((exact != exp[0].long()).sum()) > 0
 
 
+def test_rank_build_with_depth_threshold(dev):
+    """BEVDet-era filter kept &= depth > 0.01 (necks/view_transformer.py:552-557) at BL2 size: data-dependent P, no sync."""
+    cfg, ovt, cam, coor, depth, _ = _inputs('BL2', 2, True, dev)
+    depth = depth.clone()
+    depth[torch.rand(depth.shape, generator=torch.Generator().manual_seed(9)) < 0.5] = 0.0
+    vt = _vt(cfg, dev)
+    idx = vt.build_index(coor.to(dev), depth=depth.to(dev), depth_threshold=0.01)
+    c2 = coor.clone()
+    c2.view(-1, 3)[~(depth.reshape(-1) > 0.01)] = 1.0e6
+    exp = ovt.voxel_pooling_prepare_v2(c2)
+    for g, e, key in zip(idx.exact(), exp, ('ranks_bev', 'ranks_depth', 'ranks_feat', 'starts', 'lengths')):
+        assert torch.equal(g.cpu(), e), key
+
+
 def test_rank_build_edge_cases(dev):
     cfg = S.CONFIGS['TINY']
     O = _oracle()
