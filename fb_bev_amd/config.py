@@ -8,8 +8,9 @@ loaded first; dict values of the child are merged key-by-key into the parent's d
 
 `build_view_transformation(model_cfg)` consumes exactly the keys `FBOCC.__init__` consumes for the path
 (mmdet3d/models/fbbev/detectors/fbocc.py:47-131): forward_projection, backward_projection, readd, do_history,
-history_cat_num, history_cat_conv_out_channels, single_bev_num_channels, interpolation_mode.  The other blocks
-(img_backbone, depth_net, bev encoder, occupancy head ...) stay with stock PyTorch-ROCm / MIOpen and are ignored here.
+history_cat_num, history_cat_conv_out_channels, single_bev_num_channels, interpolation_mode; `build_depth_net` consumes
+the `depth_net` block (CM_DepthNet: vendor-library convolutions with the path's execution setup).  The other blocks
+(img_backbone, bev encoder, occupancy head ...) stay with stock PyTorch-ROCm / MIOpen and are ignored here.
 """
 import os
 import types
@@ -43,7 +44,7 @@ def load_config(path):
     return _merge(merged, own)
 
 
-PATH_KEYS = ('forward_projection', 'backward_projection', 'readd', 'do_history', 'history_cat_num',
+PATH_KEYS = ('depth_net', 'forward_projection', 'backward_projection', 'readd', 'do_history', 'history_cat_num',
              'history_cat_conv_out_channels', 'single_bev_num_channels', 'interpolation_mode')
 
 
@@ -68,3 +69,15 @@ def build_view_transformation(model_cfg, with_history=True):
                                      do_history=model_cfg.get('do_history', True),
                                      interpolation_mode=model_cfg.get('interpolation_mode', 'bilinear'))
     return fvt, hist
+
+
+def build_depth_net(model_cfg, **execution_knobs):
+    """-> CM_DepthNet from the detector's `depth_net` block (fbocc.py:79-80 builds it as a neck); execution_knobs:
+    channels_last / compute_dtype of fb_bev_amd.depth_net.CM_DepthNet."""
+    from .depth_net import CM_DepthNet
+    cfg = dict(model_cfg['depth_net'])
+    typ = cfg.pop('type')
+    if typ != 'CM_DepthNet':
+        raise KeyError(f'depth_net type {typ!r} is not part of the built path')
+    cfg.update(execution_knobs)
+    return CM_DepthNet(**cfg)

@@ -38,6 +38,9 @@ def test_committed_extraction_builds():
     for name, info in blocks.items():
         fvt, hist = C.build_view_transformation(info['path_blocks'])
         _check_built(fvt, hist, info)
+        dn = C.build_depth_net(info['path_blocks'])
+        assert dn.depth_conv[-1].out_channels == fvt.forward_projection.frustum.shape[0]      # D depth bins
+        assert dn.context_conv.out_channels == info['numC_Trans']
 
 
 @pytest.mark.skipif(not LIVE, reason='reference tree not mounted (GPU box)')
