@@ -126,8 +126,12 @@ def main():
     out = torch.empty((B, C, Z, Y, X), dtype=store_dt, device=dev)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(args.steps)]
+    sev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+           for _ in range(args.steps)]       # whole-step GPU time, for the p10 / p50 / p90 spread
 
     def step(i=None):
+        if i is not None:
+            sev[i][0].record()
         idx = vt.build_index_from_cams(*cam)                        # fbbev_lift_rank_build: geometry + ranking, device counts
         feat = _capi.nchw_to_nhwc(ctx)                              # (B,N,H,W,C), the copy of bev_pool.py:18
         _capi.pool_tile_index(idx.interval_rank, idx.interval_starts, idx.counts, idx.n, B, Z, Y, X,
@@ -139,6 +143,7 @@ def main():
                                     args.tile_voxels, flags)
         if i is not None:
             ev[i][1].record()
+            sev[i][1].record()
         return idx
 
     def fence():
@@ -155,6 +160,8 @@ def main():
     elapsed = shard.max_over_ranks(elapsed, dev)
 
     kern_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)
+    step_ms = sorted(a.elapsed_time(b) for a, b in sev)
+    pct = lambda q: step_ms[min(len(step_ms) - 1, int(q * len(step_ms)))] if step_ms else None  # noqa: E731
     # context for the roofline fraction (outside the timed region): what a plain device fill of the same output
     # buffer reaches on this box -- the practical write ceiling (report vs peak AND vs measured bandwidth)
     fill_ms = []
@@ -188,6 +195,7 @@ def main():
             'metric': 'multi-cam samples/sec (forward view transformation: lift + voxel ranking + bev_pool_v2)',
             'value': shard.whole_job_rate(B, args.steps, elapsed, world), 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
+            'step_gpu_ms_p10_p50_p90': [pct(0.1), pct(0.5), pct(0.9)],
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'FB-OCC forward projection, ' + ('BASELINE configs[1] ' if cfg.name == 'BL2' else '') +
                                    f'({cfg.name}): 6x{cfg.input_size[0]}x{cfg.input_size[1]} in, '
