@@ -12,7 +12,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libfbbev_hip.so')
 SOURCES = ['capi.hip']
-HEADERS = ['hip_rt/rt.h', 'pool_kernels.h', 'rank_kernels.h', 'sort_kernels.h', 'msda_kernels.h', 'geom_kernels.h', 'da_kernels.h', '../../include/fbbev.h']
+def _headers():
+    """every header the translation unit can include: a header-only edit must trigger a rebuild (a hard-coded list
+    here once went stale and a measurement was taken on an old binary)"""
+    import glob
+    return sorted(glob.glob(os.path.join(CSRC, '*.h'))) + [os.path.join(CSRC, 'hip_rt', 'rt.h'),
+                                                          os.path.join(HERE, '..', 'include', 'fbbev.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics',
          '-fno-gpu-rdc', '-Wall', '-Wno-unused-function',
          '-I' + os.path.join(CSRC, 'hip_rt')]
@@ -34,7 +39,7 @@ def _stale(target, deps):
 
 def build(force=False, verbose=False):
     """Compile every HIP translation unit for gfx950 and link the shared library."""
-    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    hdrs = _headers()
     objdir = os.path.join(HERE, 'csrc', '_obj')
     os.makedirs(objdir, exist_ok=True)
     objs = []

@@ -92,8 +92,10 @@ k_history_conv(const float* __restrict__ feats, long long fstride_b, const float
 //     folded weight matrices once), so a fragment load is one coalesced 256-byte wave load;
 //   * the W1 fragments live in registers for the whole kernel, the W2_t fragments of a frame are loaded in one burst;
 //   * the X fragments of frame t+1 are fetched while frame t's second GEMM runs (register double buffer).
+// (Streaming the W2 fragments instead of the per-frame burst, to fit two waves per SIMD, measured 1.9x SLOWER on the
+// same box -- 1.77 vs 0.94 ms for the whole fusion step -- and was dropped.)
 template <int MT1, int MT2>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256)
 k_history_conv_t(const float* __restrict__ feats, long long fstride_b, const float* __restrict__ w1f,
                  const float* __restrict__ bias1, const float* __restrict__ w2f, const float* __restrict__ bias2,
                  int T1, int N, int tiles_per_b, float* __restrict__ out) {
@@ -122,6 +124,11 @@ k_history_conv_t(const float* __restrict__ feats, long long fstride_b, const flo
     for (int t = 0; t < T1; ++t) {
         const float* b1 = bias1 + ((long long)b * T1 + t) * C;
         const float* w2t = w2f + (long long)t * MT2 * KS * 64;
+        float a2[MT2][KS];
+#pragma unroll
+        for (int mt = 0; mt < MT2; ++mt)
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) a2[mt][kk] = w2t[(mt * KS + kk) * 64 + lane];
         fbbev_v4f acc1[MT1];
 #pragma unroll
         for (int mt = 0; mt < MT1; ++mt)
@@ -146,8 +153,7 @@ k_history_conv_t(const float* __restrict__ feats, long long fstride_b, const flo
         for (int kk = 0; kk < KS; ++kk) {
             const float by = ylds[(4 * kk + g) * 16 + j];
 #pragma unroll
-            for (int mt = 0; mt < MT2; ++mt)      // W2_t fragments streamed (coalesced, L1/L2-resident): 2 waves per SIMD fit
-                acc2[mt] = fbbev_mfma_f32_16x16x4(w2t[(mt * KS + kk) * 64 + lane], by, acc2[mt]);
+            for (int mt = 0; mt < MT2; ++mt) acc2[mt] = fbbev_mfma_f32_16x16x4(a2[mt][kk], by, acc2[mt]);
         }
     }
     if (inb) {

@@ -40,8 +40,11 @@ def main():
 
     with torch.no_grad():
         frame(0, first=True)
-        for i in range(1, 4):
-            out = frame(i)
+        t0 = time.perf_counter()
+        i = 1
+        while time.perf_counter() - t0 < 2.0:          # sustained load first: the engine clock needs ~1 s to ramp up,
+            out = frame(i)                              # and the MFMA-bound kernels scale with it (3x between cold and warm)
+            i += 1
         torch.cuda.synchronize()
         t_all = ev_time(lambda i: frame(i))
         mlp = depth_net.get_mlp_input(*cam)
