@@ -46,6 +46,7 @@ SIGNATURES = {
     'fbbev_point_sampling': (c_int, [c_void_p] * 9 + [c_int] * 5 + [c_float, c_float] + [c_void_p] * 4),
     'fbbev_da_cross_attn_fwd': (c_int, [c_void_p] * 9 + [c_int] * 10 + [c_float, c_float, c_int, c_int, c_void_p, c_void_p]),
     'fbbev_da_cross_attn_bwd': (c_int, [c_void_p] * 10 + [c_int] * 10 + [c_float, c_float, c_int, c_int] + [c_void_p] * 5),
+    'fbbev_msda_fwd_fused': (c_int, [c_void_p] * 6 + [c_int] * 9 + [c_void_p, c_void_p]),
     'fbbev_msda_bwd': (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p] * 3 + [c_void_p]),
 }
 
@@ -318,6 +319,21 @@ def msda_fwd(value, spatial_shapes, level_start_index, sampling_loc, attn_weight
             _dev(level_start_index, I64, 'level_start_index'), _dev(sampling_loc, F32, 'sampling_loc'),
             _dev(attn_weight, F32, 'attn_weight'), B, S, M, Dh, L, Q, P, _dev(out, F32, 'out'),
             _stream()), 'fbbev_msda_fwd')
+
+
+def msda_fwd_fused(value, spatial_shapes, level_start_index, ref_points, offsets, attn_weight, out, head_dim=None,
+                   offsets_head_minor=False):
+    """value (B,S,M,HS); ref_points (B,Q,L,2); offsets (B,Q,M,L,P,2) or head-minor (B,Q,L,P,M,2); attn (B,Q,M,L,P)."""
+    B, S, M, HS = value.shape
+    Dh = HS if head_dim is None else int(head_dim)
+    _, Q, _, L, P = attn_weight.shape
+    with _on(value):
+        _check(lib().fbbev_msda_fwd_fused(
+            _dev(value, F32, 'value'), _dev(spatial_shapes, I64, 'spatial_shapes'),
+            _dev(level_start_index, I64, 'level_start_index'), _dev(ref_points, F32, 'ref_points'),
+            _dev(offsets, F32, 'offsets'), _dev(attn_weight, F32, 'attn_weight'), B, S, M, Dh, L, Q, P, HS,
+            1 if offsets_head_minor else 0, _dev(out, F32, 'out'), _stream()), 'fbbev_msda_fwd_fused')
+    return out
 
 
 def msda_bwd(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output,

@@ -148,6 +148,7 @@ class MultiScaleDeformableAttention(nn.Module):
         self.attention_weights = nn.Linear(embed_dims, num_heads * num_levels * num_points)
         self.value_proj = nn.Linear(embed_dims, embed_dims)
         self.output_proj = nn.Linear(embed_dims, embed_dims)
+        self.fused_inference = True
         self.init_weights()
 
     def init_weights(self):
@@ -173,6 +174,39 @@ class MultiScaleDeformableAttention(nn.Module):
             query, value = query.permute(1, 0, 2), value.permute(1, 0, 2)
         bs, num_query, _ = query.shape
         num_value = value.shape[1]
+        Dh = self.embed_dims // self.num_heads
+        needs_grad = torch.is_grad_enabled() and (query.requires_grad or value.requires_grad or
+                                                  any(p.requires_grad for p in self.parameters()))
+        if (self.fused_inference and not needs_grad and query.is_cuda and key_padding_mask is None
+                and Dh in (4, 8, 10, 16, 32) and query.dtype == torch.float32
+                and not (self.training and self.dropout.p > 0) and reference_points.shape[-1] == 2):
+            # inference: fbbev_msda_fwd_fused builds `reference_points + offsets / (W,H)` per sample inside the kernel
+            # (the reference spends two elementwise passes on that tensor) and reads head-padded value rows with
+            # aligned 16-byte loads (value_proj rows padded once, like DA_MSDeformableAttention)
+            HS = (Dh + 3) // 4 * 4
+            w, b = self.value_proj.weight, self.value_proj.bias
+            if HS != Dh:
+                key = (w._version, b._version, w.device)
+                if getattr(self, '_vpad_key', None) != key:
+                    M, E = self.num_heads, w.shape[1]
+                    with torch.no_grad():
+                        self._vpad = (F.pad(w.view(M, Dh, E), (0, 0, 0, HS - Dh)).reshape(M * HS, E).contiguous(),
+                                      F.pad(b.view(M, Dh), (0, HS - Dh)).reshape(-1).contiguous())
+                    self._vpad_key = key
+                w, b = self._vpad
+            value = F.linear(value, w, b).view(bs, num_value, self.num_heads, HS)
+            so = self.sampling_offsets(query)
+            aw = self.attention_weights(query).view(bs, num_query, self.num_heads, -1).softmax(-1)
+            aw = aw.view(bs, num_query, self.num_heads, self.num_levels, self.num_points)
+            out = torch.empty(bs, num_query, self.embed_dims, dtype=torch.float32, device=query.device)
+            ref = reference_points.expand(bs, num_query, self.num_levels, 2).contiguous()
+            _capi.msda_fwd_fused(value, spatial_shapes.to(torch.int64).contiguous(),
+                                 level_start_index.to(torch.int64).contiguous(), ref, so.contiguous(), aw.contiguous(),
+                                 out, head_dim=Dh)
+            out = self.output_proj(out)
+            if not self.batch_first:
+                out = out.permute(1, 0, 2)
+            return out + identity
         value = self.value_proj(value)
         if key_padding_mask is not None:
             value = value.masked_fill(key_padding_mask[..., None], 0.0)

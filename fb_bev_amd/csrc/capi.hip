@@ -663,6 +663,40 @@ extern "C" int fbbev_msda_fwd(const float* value, const int64_t* spatial_shapes,
     return 0;
 }
 
+extern "C" int fbbev_msda_fwd_fused(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                    const float* ref_points, const float* offsets, const float* attn_weight, int batch,
+                                    int spatial_size, int num_heads, int channels, int num_levels, int num_query,
+                                    int num_point, int head_stride, int offsets_head_minor, float* out,
+                                    fbbev_stream_t stream_) {
+    if (batch < 0 || spatial_size <= 0 || num_heads <= 0 || channels <= 0 || num_levels <= 0 || num_query < 0 ||
+        num_point <= 0) return FBBEV_E_BADARG;
+    const long long units = (long long)batch * num_query * num_heads;
+    if (units == 0) return 0;
+    if (!value || !spatial_shapes || !level_start_index || !ref_points || !offsets || !attn_weight || !out)
+        return FBBEV_E_BADARG;
+    const int HS = head_stride == 0 ? channels : head_stride;
+    if (HS < channels) return FBBEV_E_BADARG;
+    if ((((uintptr_t)offsets) & 7) != 0) return FBBEV_E_UNSUPPORTED;
+    const bool wide = HS % 4 == 0 && HS >= (channels + 3) / 4 * 4 && aligned16(value);
+    long long ub = (units + 255) / 256;
+    if (ub > 65536) ub = 65536;
+#define FBBEV_MSDA_UNIT_W(DH_, W_)                                                                                  \
+    FBBEV_LAUNCH((k_msda_fwd_unit<DH_, W_>), ub, 256, 0, (fbbev_rt_stream)stream_, units, value, spatial_shapes,     \
+                 level_start_index, ref_points, offsets, attn_weight, spatial_size, num_heads, num_levels, num_query, \
+                 num_point, HS, offsets_head_minor ? 1 : 0, out)
+#define FBBEV_MSDA_UNIT(DH_) do { if (wide) FBBEV_MSDA_UNIT_W(DH_, true); else FBBEV_MSDA_UNIT_W(DH_, false); } while (0)
+    if (channels == 10) FBBEV_MSDA_UNIT(10);
+    else if (channels == 8) FBBEV_MSDA_UNIT(8);
+    else if (channels == 16) FBBEV_MSDA_UNIT(16);
+    else if (channels == 32) FBBEV_MSDA_UNIT(32);
+    else if (channels == 4) FBBEV_MSDA_UNIT(4);
+    else return FBBEV_E_UNSUPPORTED;
+#undef FBBEV_MSDA_UNIT
+#undef FBBEV_MSDA_UNIT_W
+    FBBEV_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int fbbev_msda_bwd(const float* value, const int64_t* spatial_shapes,
                               const int64_t* level_start_index, const float* sampling_loc,
                               const float* attn_weight, const float* grad_output, int batch,

@@ -72,6 +72,74 @@ k_msda_fwd(long long n, const float* __restrict__ value, const int64_t* __restri
     }
 }
 
+// ---------------------------------------------------------------- BEV self-attention sampling, fused (inference)
+// mmcv MultiScaleDeformableAttention.forward (external, mmcv/ops/multi_scale_deform_attn.py) builds
+//   sampling_locations = reference_points[:, :, None, :, None, :] + sampling_offsets / offset_normalizer
+// with two elementwise passes over the (B,Q,M,L,P,2) tensor and then calls ms_deform_attn_forward.  Here a lane owns a
+// (b,q,head) unit (all DH channels, as k_da_cross_attn_fwd_unit): loc = ref + __fdiv_rn(offset, size) is evaluated in
+// the kernel -- the same two correctly rounded fp32 operations -- the bilinear setup happens once per sample instead of
+// once per channel lane, and with head-padded value rows (WIDE) a corner is DHP/4 aligned dwordx4 loads.
+// ref (B,Q,L,2); offsets (B,Q,M,L,P,2) raw, or head-minor (B,Q,L,P,M,2) when off_head_minor; attn (B,Q,M,L,P) softmaxed.
+template <int DH, bool WIDE>
+__global__ void __launch_bounds__(256)
+k_msda_fwd_unit(long long n_units, const float* __restrict__ value, const int64_t* __restrict__ spatial_shapes,
+                const int64_t* __restrict__ level_start, const float* __restrict__ ref,
+                const float* __restrict__ offsets, const float* __restrict__ attn, int spatial_size, int M, int L,
+                int Q, int P, int HS, int off_head_minor, float* __restrict__ out) {
+    constexpr int DHP = (DH + 3) / 4 * 4;
+    const int row_stride = M * HS;
+    for (long long unit = (long long)blockIdx.x * blockDim.x + threadIdx.x; unit < n_units;
+         unit += (long long)gridDim.x * blockDim.x) {
+        const int m = (int)(unit % M);
+        const long long bq = unit / M;
+        const long long b = bq / Q;
+        float col[DH];
+#pragma unroll
+        for (int c = 0; c < DH; ++c) col[c] = 0.f;
+        for (int l = 0; l < L; ++l) {
+            const int sh = (int)spatial_shapes[2 * l], sw = (int)spatial_shapes[2 * l + 1];
+            const float rx = ref[(bq * L + l) * 2], ry = ref[(bq * L + l) * 2 + 1];
+            const float* vp = value + (b * spatial_size + level_start[l]) * row_stride + m * HS;
+            for (int p = 0; p < P; ++p) {
+                const long long wm = (unit * L + l) * P + p, wh = ((bq * L + l) * P + p) * M + m;
+                const long long wo = off_head_minor ? wh : wm;
+                const fbbev_v2f o = *reinterpret_cast<const fbbev_v2f*>(offsets + wo * 2);
+                const float loc_w = rx + __fdiv_rn(o[0], (float)sw), loc_h = ry + __fdiv_rn(o[1], (float)sh);
+                const float weight = attn[wm];
+                const float h_im = loc_h * sh - 0.5f, w_im = loc_w * sw - 0.5f;
+                if (!(h_im > -1.f && w_im > -1.f && h_im < (float)sh && w_im < (float)sw)) continue;
+                const fbbev_bilinear s = fbbev_bilinear_setup(h_im, w_im, sh, sw, row_stride);
+                float v1[DHP], v2[DHP], v3[DHP], v4[DHP];
+                if constexpr (WIDE) {
+#pragma unroll
+                    for (int c = 0; c < DHP; c += 4) {
+                        const fbbev_v4f zero = {0.f, 0.f, 0.f, 0.f};
+                        const fbbev_v4f a1 = s.o1 >= 0 ? *reinterpret_cast<const fbbev_v4f*>(vp + s.o1 + c) : zero;
+                        const fbbev_v4f a2 = s.o2 >= 0 ? *reinterpret_cast<const fbbev_v4f*>(vp + s.o2 + c) : zero;
+                        const fbbev_v4f a3 = s.o3 >= 0 ? *reinterpret_cast<const fbbev_v4f*>(vp + s.o3 + c) : zero;
+                        const fbbev_v4f a4 = s.o4 >= 0 ? *reinterpret_cast<const fbbev_v4f*>(vp + s.o4 + c) : zero;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v1[c + e] = a1[e]; v2[c + e] = a2[e]; v3[c + e] = a3[e]; v4[c + e] = a4[e]; }
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < DH; ++c) {
+                        v1[c] = s.o1 >= 0 ? vp[s.o1 + c] : 0.f;
+                        v2[c] = s.o2 >= 0 ? vp[s.o2 + c] : 0.f;
+                        v3[c] = s.o3 >= 0 ? vp[s.o3 + c] : 0.f;
+                        v4[c] = s.o4 >= 0 ? vp[s.o4 + c] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < DH; ++c) col[c] += (s.w1 * v1[c] + s.w2 * v2[c] + s.w3 * v3[c] + s.w4 * v4[c]) * weight;
+            }
+        }
+        float* dst = out + unit * DH;
+#pragma unroll
+        for (int c = 0; c < DH; ++c) dst[c] = col[c];
+    }
+}
+
 template <int GW>
 __device__ __forceinline__ float fbbev_group_sum(float v) {
 #pragma unroll

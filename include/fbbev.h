@@ -201,6 +201,16 @@ int fbbev_msda_fwd(const float* value, const int64_t* spatial_shapes,
                    int channels, int num_levels, int num_query, int num_point, float* out,
                    fbbev_stream_t stream);
 
+/* BEV self-attention sampling with the location arithmetic folded in (inference): replaces, inside mmcv's
+ * MultiScaleDeformableAttention.forward, `reference_points[:, :, None, :, None, :] + sampling_offsets /
+ * offset_normalizer` (two elementwise passes over (B,Q,M,L,P,2)) + ms_deform_attn_forward.  ref_points (B,Q,L,2);
+ * offsets (B,Q,M,L,P,2) raw [offsets_head_minor: (B,Q,L,P,M,2)]; attn_weight (B,Q,M,L,P) softmaxed; value
+ * (B,S,M,head_stride) with `channels` used floats per head (0 = dense).  channels in {4,8,10,16,32}. */
+int fbbev_msda_fwd_fused(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                         const float* ref_points, const float* offsets, const float* attn_weight, int batch,
+                         int spatial_size, int num_heads, int channels, int num_levels, int num_query, int num_point,
+                         int head_stride, int offsets_head_minor, float* out, fbbev_stream_t stream);
+
 /* Replaces ext_module.ms_deform_attn_backward(..., grad_output, grad_value, grad_sampling_loc,
  *   grad_attn_weight, im2col_step=...) -- multi_scale_deformable_attn_function.py:159-169.
  * The three grad outputs are pre-zeroed by the caller (:155-157) and accumulated into. */

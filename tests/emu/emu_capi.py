@@ -234,3 +234,13 @@ def history_conv(feats, w1, bias1, w2, bias2):
     ok(lib().fbbev_history_conv(c_void_p(feats.data_ptr()), feats.stride(0), p(w1), p(bias1), p(w2), p(bias2), B, TC // C, C,
                                 Cout, N, p(out), p(ws), ws.numel() * 4, None))
     return out
+
+
+def msda_fwd_fused(value, ss, ls, ref, offsets, w, head_dim=None, offsets_head_minor=False):
+    B, S, M, HS = value.shape
+    Dh = HS if head_dim is None else head_dim
+    _, Q, _, L, P = w.shape
+    out = torch.full((B, Q, M * Dh), float('nan'))
+    ok(lib().fbbev_msda_fwd_fused(p(value), p(ss), p(ls), p(ref), p(offsets), p(w), B, S, M, Dh, L, Q, P, HS,
+                                  1 if offsets_head_minor else 0, p(out), None))
+    return out

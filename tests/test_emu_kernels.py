@@ -536,3 +536,27 @@ def test_rank_build_with_depth_threshold_emulated():
     assert (P, I) == (erb.numel(), est.numel()) and P < E.rank_build(coor, *_grid3(vt))[6][0]
     assert torch.equal(rb[:P], erb) and torch.equal(rd[:P], erd) and torch.equal(rf[:P], erf)
     assert torch.equal(st[:I], est) and torch.equal(ln[:I], eln)
+
+
+@pytest.mark.parametrize('B,Q,M,Dh,shapes,P', [(2, 31, 4, 10, [[6, 5]], 4), (1, 17, 2, 8, [[5, 4], [3, 2]], 3), (1, 9, 2, 4, [[4, 4]], 2)])
+def test_msda_fwd_fused_equals_unfused_emulated(B, Q, M, Dh, shapes, P):
+    """fbbev_msda_fwd_fused (loc = ref + offset / size inside the kernel, unit-per-lane, head-padded rows) produces the
+    bits of fbbev_msda_fwd on the location tensor torch builds the way mmcv does."""
+    g = torch.Generator().manual_seed(Q)
+    ss = torch.tensor(shapes)
+    ls = torch.cat([ss.new_zeros(1), (ss[:, 0] * ss[:, 1]).cumsum(0)[:-1]])
+    S_, L = int((ss[:, 0] * ss[:, 1]).sum()), len(shapes)
+    value = torch.randn(B, S_, M, Dh, generator=g)
+    ref = torch.rand(B, Q, L, 2, generator=g)
+    so = torch.randn(B, Q, M, L, P, 2, generator=g) * 2.0
+    w = torch.rand(B, Q, M, L * P, generator=g).softmax(-1).view(B, Q, M, L, P).contiguous()
+    norm = torch.stack([ss[..., 1], ss[..., 0]], -1)
+    loc = (ref[:, :, None, :, None, :] + so / norm[None, None, None, :, None, :]).contiguous()      # mmcv's two passes
+    base = E.msda_fwd(value, ss, ls, loc, w)
+    assert torch.equal(E.msda_fwd_fused(value, ss, ls, ref, so, w), base)
+    assert torch.equal(E.msda_fwd_fused(value, ss, ls, ref, so.permute(0, 1, 3, 4, 2, 5).contiguous(), w,
+                                        offsets_head_minor=True), base)
+    HS = (Dh + 3) // 4 * 4 + (4 if Dh % 4 == 0 else 0)
+    vp = torch.full((B, S_, M, HS), -3.0e4)
+    vp[..., :Dh] = value
+    assert torch.equal(E.msda_fwd_fused(vp, ss, ls, ref, so, w, head_dim=Dh), base)

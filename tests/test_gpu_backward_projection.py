@@ -127,6 +127,32 @@ def test_training_paths_equal_inference_and_backprop(dev, train_fused):
             assert close(p.grad, P[name].grad, 5e-3), name
 
 
+@pytest.mark.parametrize('E,M,L', [(80, 8, 1), (64, 8, 2)])
+def test_self_attention_fused_inference_equals_composed(dev, E, M, L):
+    """MultiScaleDeformableAttention inference (fbbev_msda_fwd_fused: locations built in the kernel, padded value rows)
+    against the composed path (torch location tensor + fbbev_msda_fwd)."""
+    from fb_bev_amd.backward_projection import MultiScaleDeformableAttention
+    torch.manual_seed(E)
+    m = MultiScaleDeformableAttention(embed_dims=E, num_heads=M, num_levels=L, num_points=4, batch_first=True)
+    with torch.no_grad():
+        m.sampling_offsets.weight.normal_(0, 0.05)
+        m.attention_weights.weight.normal_(0, 0.05)
+    m = m.to(dev).eval()
+    shapes = [(20, 18), (10, 9)][:L]
+    ss = torch.tensor(shapes, device=dev)
+    ls = torch.cat([ss.new_zeros(1), (ss[:, 0] * ss[:, 1]).cumsum(0)[:-1]])
+    S_ = int((ss[:, 0] * ss[:, 1]).sum())
+    B, Q = 2, 360
+    q = torch.randn(B, Q, E, device=dev)
+    v = torch.randn(B, S_, E, device=dev)
+    ref = torch.rand(B, Q, L, 2, device=dev)
+    with torch.no_grad():
+        fused = m(q, value=v, reference_points=ref, spatial_shapes=ss, level_start_index=ls)
+        m.fused_inference = False
+        comp = m(q, value=v, reference_points=ref, spatial_shapes=ss, level_start_index=ls)
+    assert torch.allclose(fused, comp, atol=2e-6, rtol=1e-6), (fused - comp).abs().max()
+
+
 def test_point_sampling_kernel_vs_reference_python_fixture(dev):
     """fbbev_point_sampling against the fixture produced by the REAL bevformer_encoder.point_sampling."""
     import numpy as np
