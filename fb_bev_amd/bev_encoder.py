@@ -161,7 +161,7 @@ class CustomResNet3D(nn.Module):
     def forward(self, x):
         if self.plane2voxel is not None:
             x = x.unsqueeze(-1).repeat(1, 1, 1, 1, self.plane2voxel)
-        if self.channels_last:
+        if self.channels_last and x.is_cuda:        # MIOpen layout; ATen's CPU NDHWC backward is not relied on
             x = x.contiguous(memory_format=torch.channels_last_3d)
         if self.compute_dtype != torch.float32 and x.is_cuda:
             with torch.autocast('cuda', dtype=self.compute_dtype):

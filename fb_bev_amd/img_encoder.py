@@ -131,7 +131,7 @@ class ResNet(nn.Module):
         return tuple(outs)
 
     def forward(self, x):
-        if self.channels_last:
+        if self.channels_last and x.is_cuda:        # MIOpen layout; ATen's CPU NHWC backward is not relied on
             x = x.contiguous(memory_format=torch.channels_last)
         if self.compute_dtype != torch.float32 and x.is_cuda:
             with torch.autocast('cuda', dtype=self.compute_dtype):

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Extract the view-transformation blocks of every shipped FB-OCC config with fb_bev_amd.config.load_config and
+"""Extract the `model` block (and its view-transformation sub-blocks) of every shipped FB-OCC config with fb_bev_amd.config.load_config and
 store them as JSON, so the GPU box (no /root/reference) can still check that those blocks build unchanged.
 Run in the build container:  python tests/golden/make_golden_configs.py"""
 import glob
@@ -17,7 +17,7 @@ def main():
     out = {}
     for path in sorted(glob.glob(os.path.join(REF, 'occupancy_configs', 'fb_occ', '*.py'))):
         cfg = C.load_config(path)
-        out[os.path.basename(path)] = {'model_type': cfg['model']['type'], 'path_blocks': C.path_blocks(cfg['model']),
+        out[os.path.basename(path)] = {'model_type': cfg['model']['type'], 'path_blocks': C.path_blocks(cfg['model']), 'model': cfg['model'],
                                        'grid_config': cfg['grid_config'], 'data_config_input_size': list(cfg['data_config']['input_size']),
                                        'numC_Trans': cfg['numC_Trans'], 'bev_h_': cfg.get('bev_h_'), 'bev_w_': cfg.get('bev_w_')}
     dst = os.path.join(REPO, 'tests', 'golden', 'fbocc_config_path_blocks.json')

@@ -33,6 +33,8 @@ def _norm(cfg, n, dims=3):
     cfg.pop('requires_grad', None)
     if typ == 'GN':
         return 'gn', nn.GroupNorm(num_channels=n, **cfg)
+    if typ == 'SyncBN':                      # mmcv builds nn.SyncBatchNorm: same parameters / state names as BatchNorm
+        return 'bn', {2: nn.BatchNorm2d, 3: nn.BatchNorm3d}[dims](n, **cfg)
     return 'bn', {'BN3d': nn.BatchNorm3d, 'BN': nn.BatchNorm2d, 'BN2d': nn.BatchNorm2d}[typ](n, **cfg)
 
 
@@ -208,6 +210,18 @@ def main():
     out['fpn.c4'], out['fpn.c5'], out['fpn.out'] = c4.numpy(), c5.numpy(), y.numpy()
     for k, v in cf.state_dict().items():
         out['w.fpn.' + k] = v.numpy()
+
+    # ---- parameter names / shapes of the in-tree blocks at the SHIPPED config (what a reference checkpoint contains)
+    import json
+    model = json.load(open(os.path.join(MG.OUT, 'fbocc_config_path_blocks.json')))['fbocc-r50-cbgs_depth_16f_16x4_20e.py']['model']
+    strip = lambda d: {k: v for k, v in d.items() if k != 'type'}  # noqa: E731
+    blocks = {'img_neck': fpn.CustomFPN(**strip(model['img_neck'])),
+              'img_bev_encoder_backbone': r3d.CustomResNet3D(**strip(model['img_bev_encoder_backbone'])),
+              'img_bev_encoder_neck': fpn3d.FPN3D(**strip(model['img_bev_encoder_neck'])),
+              'occupancy_head': head.OccHead(**strip(model['occupancy_head']))}
+    keys = {name: {k: list(v.shape) for k, v in m.state_dict().items()} for name, m in blocks.items()}
+    json.dump(keys, open(os.path.join(MG.OUT, 'fbocc_reference_state_keys.json'), 'w'), indent=0, sort_keys=True)
+    print('state keys:', {k: len(v) for k, v in keys.items()})
 
     path = os.path.join(MG.OUT, 'occ_encoder_head_small.npz')
     np.savez_compressed(path, **{k: (v.astype(np.float32) if v.dtype == np.float64 and v.ndim > 0 else v) for k, v in out.items()})
