@@ -105,6 +105,13 @@ class BasicBlock3D(nn.Module):
         return F.relu(out + residual)
 
 
+def _low_precision_ok(dtype, x):
+    """bf16 for the voxel encoder is an INFERENCE setting: the backward pass of the bf16 3-D convolutions of this stack
+    segfaults inside the vendor library on the ROCm 7.2 image (profiles/r01_full_model_bf16_voxel_backward_crash.log;
+    the 2-D stacks and the occupancy head train in bf16), so under autograd the stack computes in fp32."""
+    return dtype != torch.float32 and x.is_cuda and not (torch.is_grad_enabled() and x.requires_grad)
+
+
 class CustomResNet3D(nn.Module):
     """resnet3d.py:143-274.  `depth` picks the block type and the per-stage block counts (:159-172); only the first
     len(block_inplanes) stages are built (:198-200)."""
@@ -163,7 +170,7 @@ class CustomResNet3D(nn.Module):
             x = x.unsqueeze(-1).repeat(1, 1, 1, 1, self.plane2voxel)
         if self.channels_last and x.is_cuda:        # MIOpen layout; ATen's CPU NDHWC backward is not relied on
             x = x.contiguous(memory_format=torch.channels_last_3d)
-        if self.compute_dtype != torch.float32 and x.is_cuda:
+        if _low_precision_ok(self.compute_dtype, x):
             with torch.autocast('cuda', dtype=self.compute_dtype):
                 return self._stages(x)
         return self._stages(x.float())
@@ -198,7 +205,7 @@ class FPN3D(nn.Module):
 
     def forward(self, inputs):
         assert len(inputs) == len(self.in_channels)
-        if self.compute_dtype != torch.float32 and inputs[0].is_cuda:
+        if _low_precision_ok(self.compute_dtype, inputs[0]):
             with torch.autocast('cuda', dtype=self.compute_dtype):
                 return self._forward(inputs)
         return self._forward([x.float() for x in inputs])

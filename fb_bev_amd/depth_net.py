@@ -203,5 +203,8 @@ class CM_DepthNet(nn.Module):
         preds = depth_preds.permute(0, 1, 3, 4, 2).contiguous().view(-1, self.depth_channels)
         fg = labels.max(dim=1).values > 0.0
         with torch.autocast('cuda', enabled=False):
-            loss = F.binary_cross_entropy(preds[fg].float(), labels[fg], reduction='none').sum() / fg.sum().clamp(min=1.0)
+            # the reference compacts the foreground rows first (`preds[fg_mask]`, depth_net.py:441-448: a nonzero() + host
+            # sync per step); multiplying by the mask sums the same terms without leaving the stream
+            bce = F.binary_cross_entropy(preds.float(), labels, reduction='none')
+            loss = (bce * fg[:, None].float()).sum() / fg.sum().clamp(min=1.0)
         return dict(loss_depth=self.loss_depth_weight * loss)

@@ -58,18 +58,21 @@ class FBOCC(nn.Module):
                  img_neck=None, pts_bbox_head=None, train_cfg=None, test_cfg=None, pretrained=None, init_cfg=None,
                  execution=None, **kwargs):
         """execution (not part of the reference config): dict(img_dtype=, depth_dtype=, voxel_dtype=, head_dtype=) with
-        values 'f32' | 'bf16' -- compute dtype of the four convolution stacks (default fp32 everywhere = reference)."""
+        values 'f32' | 'bf16' -- compute dtype of the four convolution stacks (default fp32 everywhere; the shipped
+        config trains them under mmcv's fp16 hook, cfg :394) -- and with_cp=True|False to override the blocks'
+        activation checkpointing (the configs turn it on to fit 16-32 GB parts; 288 GB of HBM does not need it)."""
         super().__init__()
         if frpn is not None or pts_bbox_head is not None:
             raise NotImplementedError('frpn / pts_bbox_head are None in every fb_occ config (fbocc.py:86-88 "not used in FB-OCC")')
         if forward_projection is None:
             raise ValueError('FBOCC needs a forward_projection block')
         ex = dict(execution or {})
+        cp = {} if ex.get('with_cp') is None else {'with_cp': bool(ex['with_cp'])}
         self.fix_void, self.readd, self.use_depth_supervision = fix_void, readd, use_depth_supervision
         self.occupancy_save_path = occupancy_save_path
-        self.img_backbone = _build(img_backbone, compute_dtype=_dtype(ex.get('img_dtype')))
-        self.img_neck = _build(img_neck, compute_dtype=_dtype(ex.get('img_dtype')))
-        self.depth_net = _build(depth_net, compute_dtype=_dtype(ex.get('depth_dtype')))
+        self.img_backbone = _build(img_backbone, **cp, compute_dtype=_dtype(ex.get('img_dtype')))
+        self.img_neck = _build(img_neck, **cp, compute_dtype=_dtype(ex.get('img_dtype')))
+        self.depth_net = _build(depth_net, **cp, compute_dtype=_dtype(ex.get('depth_dtype')))
         fvt = FBViewTransform(forward_projection, backward_projection, readd=readd)
         self.forward_projection = fvt.forward_projection
         self.backward_projection = fvt.backward_projection
@@ -82,9 +85,9 @@ class FBOCC(nn.Module):
         self.history_keyframe_time_conv = hist.history_keyframe_time_conv
         self.history_keyframe_cat_conv = hist.history_keyframe_cat_conv
         self._path = [fvt, hist]                  # plain list: holders stay out of the parameter tree (names above)
-        self.img_bev_encoder_backbone = _build(img_bev_encoder_backbone, compute_dtype=_dtype(ex.get('voxel_dtype')))
-        self.img_bev_encoder_neck = _build(img_bev_encoder_neck, compute_dtype=_dtype(ex.get('voxel_dtype')))
-        self.occupancy_head = _build(occupancy_head, compute_dtype=_dtype(ex.get('head_dtype')))
+        self.img_bev_encoder_backbone = _build(img_bev_encoder_backbone, **cp, compute_dtype=_dtype(ex.get('voxel_dtype')))
+        self.img_bev_encoder_neck = _build(img_bev_encoder_neck, **cp, compute_dtype=_dtype(ex.get('voxel_dtype')))
+        self.occupancy_head = _build(occupancy_head, **cp, compute_dtype=_dtype(ex.get('head_dtype')))
 
     # ------------------------------------------------------------------ plumbing
     @property
