@@ -42,6 +42,7 @@ SIGNATURES = {
     'fbbev_history_warp': (c_int, [c_void_p, c_int64, c_void_p] + [c_int] * 5 + [c_void_p, c_int64, c_void_p]),
     'fbbev_layernorm': (c_int, [c_void_p] * 4 + [c_float, c_int64, c_int, c_void_p, c_void_p]),
     'fbbev_history_conv': (c_int, [c_void_p, c_int64] + [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t, c_void_p]),
+    'fbbev_conv3d_ndhwc': (c_int, [c_void_p] * 4 + [c_int] * 14 + [c_void_p, c_void_p]),
     'fbbev_msda_fwd': (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_void_p, c_void_p]),
     'fbbev_point_sampling': (c_int, [c_void_p] * 9 + [c_int] * 5 + [c_float, c_float] + [c_void_p] * 4),
     'fbbev_da_cross_attn_fwd': (c_int, [c_void_p] * 9 + [c_int] * 10 + [c_float, c_float, c_int, c_int, c_void_p, c_void_p]),
@@ -463,6 +464,27 @@ def layernorm(x, weight, bias, eps, residual=None, out=None):
         _check(lib().fbbev_layernorm(_dev(x, F32, 'x'), _dev(residual, F32, 'residual') if residual is not None else None,
                                      _dev(weight, F32, 'weight'), _dev(bias, F32, 'bias'), float(eps), rows, C,
                                      _dev(out, F32, 'out'), _stream()), 'fbbev_layernorm')
+    return out
+
+
+def conv3d_ndhwc(x, weight_fragments, bias, out, Cout, ksize=3, stride=1, pad=1, relu=False, residual=None, transposed=False):
+    """x (B,Di,Hi,Wi,Cin) f32 contiguous (NDHWC); out (B,Do,Ho,Wo,Cout) [transposed: (B,2Di,2Hi,2Wi,Cout)] contiguous;
+    weight_fragments / bias as built by fb_bev_amd.mfma_conv3d (batch norm folded, MFMA A-fragment order)."""
+    B, Di, Hi, Wi, Cin = x.shape
+    if transposed:
+        Do, Ho, Wo = Di, Hi, Wi
+        want = (B, 2 * Di, 2 * Hi, 2 * Wi, Cout)
+    else:
+        Do, Ho, Wo = [(n + 2 * pad - ksize) // stride + 1 for n in (Di, Hi, Wi)]
+        want = (B, Do, Ho, Wo, Cout)
+    if tuple(out.shape) != want or (residual is not None and tuple(residual.shape) != want):
+        raise FbbevError(f'conv3d_ndhwc: out / residual must be {want}')
+    with _on(x):
+        _check(lib().fbbev_conv3d_ndhwc(
+            _dev(x, F32, 'x'), _dev(weight_fragments, F32, 'weight_fragments'), _dev(bias, F32, 'bias'),
+            None if residual is None else _dev(residual, F32, 'residual'), B, Di, Hi, Wi, Cin, Do, Ho, Wo, int(Cout), int(ksize),
+            int(stride), int(pad), 1 if relu else 0, 1 if transposed else 0, _dev(out, F32, 'out'), _stream()),
+            'fbbev_conv3d_ndhwc')
     return out
 
 

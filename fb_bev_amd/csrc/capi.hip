@@ -11,6 +11,7 @@
 #include "history_kernels.h"
 #include "norm_kernels.h"
 #include "history_conv_kernels.h"
+#include "conv3d_kernels.h"
 #include "../../include/fbbev.h"
 
 #define FBBEV_CHECK_LAUNCH()                      \
@@ -968,6 +969,44 @@ extern "C" int fbbev_history_conv(const float* feats, long long feats_stride_b, 
     } else
         FBBEV_LAUNCH(k_history_conv, blocks, 256, lds, (fbbev_rt_stream)stream_, feats, feats_stride_b, w1, bias1, w2, bias2,
                      T1, C, Cout, N, tiles_per_b, out);
+    FBBEV_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int fbbev_conv3d_ndhwc(const float* x, const float* weight_fragments, const float* bias, const float* residual,
+                                  int B, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout, int ksize,
+                                  int stride, int pad, int relu, int transposed, float* out, fbbev_stream_t stream_) {
+    if (B < 0 || Di <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Do <= 0 || Ho <= 0 || Wo <= 0 || Cout <= 0) return FBBEV_E_BADARG;
+    if (transposed) {
+        if (Do != Di || Ho != Hi || Wo != Wi) return FBBEV_E_BADARG;
+        ksize = 1; stride = 1; pad = 0;
+    } else {
+        if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2) || pad < 0 || pad > 1) return FBBEV_E_UNSUPPORTED;
+        if (Do != (Di + 2 * pad - ksize) / stride + 1 || Ho != (Hi + 2 * pad - ksize) / stride + 1 ||
+            Wo != (Wi + 2 * pad - ksize) / stride + 1) return FBBEV_E_BADARG;
+    }
+    if (B == 0) return 0;
+    if (!x || !weight_fragments || !bias || !out) return FBBEV_E_BADARG;
+    if (Cin % 16 != 0 || !aligned16(x) || !aligned16(weight_fragments) || !aligned16(bias) || !aligned16(out) ||
+        (residual && !aligned16(residual))) return FBBEV_E_UNSUPPORTED;
+    const long long nvox = (long long)B * Do * Ho * Wo;
+    const long long gx = (nvox + 255) / 256;
+    const int mt_total = (Cout + 15) / 16;
+    const int MT = mt_total % 4 == 0 ? 4 : (mt_total % 2 == 0 ? 2 : 1);
+    const long long pstride = (long long)(Cin / 16) * mt_total * 256;
+    const int gy = mt_total / MT;
+    const long long grid = gx * gy * (transposed ? 8 : 1);
+    if (grid >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
+#define FBBEV_CONV3D(KS_, MT_)                                                                                       \
+    FBBEV_LAUNCH((k_conv3d_ndhwc<KS_, MT_>), grid, 256, 0, (fbbev_rt_stream)stream_, x, weight_fragments, bias,       \
+                 residual, out, B, Di, Hi, Wi, Cin, Do, Ho, Wo, Cout, mt_total, stride, pad, relu ? 1 : 0,            \
+                 transposed ? 1 : 0, pstride, (int)gx, gy)
+    if (ksize == 3) {
+        if (MT == 4) FBBEV_CONV3D(3, 4); else if (MT == 2) FBBEV_CONV3D(3, 2); else FBBEV_CONV3D(3, 1);
+    } else {
+        if (MT == 4) FBBEV_CONV3D(1, 4); else if (MT == 2) FBBEV_CONV3D(1, 2); else FBBEV_CONV3D(1, 1);
+    }
+#undef FBBEV_CONV3D
     FBBEV_CHECK_LAUNCH();
     return 0;
 }

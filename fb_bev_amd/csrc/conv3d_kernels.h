@@ -1,0 +1,150 @@
+// conv3d_kernels.h -- dense 3-D convolutions of FB-OCC's voxel encoder / occupancy head as fp32-MFMA implicit GEMMs
+// (inference).
+//
+// Replaces, for eval-mode modules, the Conv3d(+BatchNorm)(+residual)(+ReLU) groups of
+//   CustomResNet3D   mmdet3d/models/fbbev/modules/resnet3d.py:19-43 (conv3x3x3 / conv1x1x1), :78-102 (BasicBlock)
+//   FPN3D            mmdet3d/models/fbbev/modules/fpn3d.py:50-70 (ConvModule 1x1x1 / 3x3x3)
+//   OccHead          mmdet3d/models/fbbev/heads/occupancy_head.py:82-141 (3x3x3, 1x1x1, deconv3d k=2 s=2)
+// which the reference runs in fp32 (@force_fp32) through the vendor library.  Measured on MI355X
+// (profiles/r01_time_full.jsonl): those stacks are 33 of the 41.7 ms of a frame -- 670 GFLOP at ~20 TFLOP/s.
+//
+// Layout: activations NDHWC (torch channels_last_3d), so the Cin floats of a voxel are contiguous.  Batch norm is folded
+// into the weights / bias on the host; bias, residual add and ReLU run in the store epilogue.
+//
+// GEMM view: D[cout][voxel] = sum over (tap, cin) of W[cout][tap][cin] * X[voxel + tap][cin], on
+// v_mfma_f32_16x16x4_f32 (exact fp32; fragment layouts as in history_conv_kernels.h, validated on the hardware there).
+// A wave owns NT=4 voxel tiles (64 consecutive output voxels, flat (b,d,h,w) order) x MT cout tiles; a workgroup is 4
+// waves with the same cout tiles (their weight fragments hit the same L1 lines) and 256 consecutive voxels.
+// K is walked tap by tap, 16 input channels at a time: lane (voxel i = lane%16, kk = lane/16) loads ONE float4
+//   X[voxel_i + tap][16j + 4kk .. 4kk+3]        (a voxel's 4 lanes read 64 contiguous bytes)
+// and uses element e of it as the B operand of k-step (j, e): the K order inside a 16-channel group is permuted
+// (k-step (j,e) covers channels 16j + {e, 4+e, 8+e, 12+e}), which a dot product does not care about as long as the
+// weights follow: the host stores them in fragment order
+//   wf[tap][j][mt][lane][e] = W[cout = 16mt + lane%16][cin = 16j + 4(lane/16) + e][tap]
+// so a lane's four A operands of a (tap, j, mt) are one aligned float4 and a wave's load is 1 KB contiguous.
+// Per (tap, j): NT + MT float4 loads feed 4 * MT * NT MFMAs (64 at MT=4).  Zero padding = B operand 0.
+// Transposed convolution k=2 s=2 (the head's `deblock`): every output voxel (2d+a, 2h+b, 2w+c) sees exactly one tap,
+// i.e. 8 independent 1x1x1 convolutions with a strided store; the slowest grid index is the parity (a,b,c).
+// Bound: fp32 MFMA (157 TFLOP/s peak).
+#pragma once
+#include "rt.h"
+
+template <int KS, int MT>
+__global__ void __launch_bounds__(256)
+k_conv3d_ndhwc(const float* __restrict__ x, const float* __restrict__ wf, const float* __restrict__ bias,
+               const float* __restrict__ residual, float* __restrict__ out, int B, int Di, int Hi, int Wi, int Cin,
+               int Do, int Ho, int Wo, int Cout, int mt_total, int stride, int pad, int relu, int ups,
+               long long wf_parity_stride, int gx, int gy) {
+    constexpr int NT = 4;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = lane >> 4, i = lane & 15;
+    const long long nvox = (long long)B * Do * Ho * Wo;
+    // 1-D grid: voxel block fastest, then cout block, then (transposed only) output parity
+    const int bx = blockIdx.x % gx, by = (blockIdx.x / gx) % gy, parity = blockIdx.x / (gx * gy);
+    const long long base = ((long long)bx * 4 + wave) * (16 * NT);
+    if (base >= nvox) return;                                // whole wave: there is no workgroup barrier below
+    const int mt0 = by * MT;
+    int bq[NT], dq[NT], hq[NT], wq[NT];
+    bool vq[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const long long n = base + 16 * t + i;
+        vq[t] = n < nvox;
+        long long r = vq[t] ? n : 0;
+        wq[t] = (int)(r % Wo); r /= Wo;
+        hq[t] = (int)(r % Ho); r /= Ho;
+        dq[t] = (int)(r % Do);
+        bq[t] = (int)(r / Do);
+    }
+    fbbev_v4f acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[mt][t] = fbbev_v4f{0.f, 0.f, 0.f, 0.f};
+    const int J = Cin >> 4;
+    const float* __restrict__ wfp = wf + (long long)parity * wf_parity_stride + (long long)mt0 * 256 + lane * 4;
+    for (int tap = 0; tap < KS * KS * KS; ++tap) {
+        const int kd = tap / (KS * KS), kh = (tap / KS) % KS, kw = tap % KS;
+        long long off[NT];
+        bool ok[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int di = dq[t] * stride + kd - pad, hi = hq[t] * stride + kh - pad, wi = wq[t] * stride + kw - pad;
+            ok[t] = vq[t] && di >= 0 && di < Di && hi >= 0 && hi < Hi && wi >= 0 && wi < Wi;
+            off[t] = (ok[t] ? ((((long long)bq[t] * Di + di) * Hi + hi) * Wi + wi) * Cin : 0) + 4 * g;
+        }
+        const float* __restrict__ wt = wfp + (long long)tap * J * mt_total * 256;
+        // ping-pong register buffers over the 16-channel groups of this tap: group j+1 is in flight during the MFMAs
+        // of group j (two named buffers, no copies: a copy would make the compiler wait for the load right away)
+        auto load = [&](fbbev_v4f (&bfr)[NT], fbbev_v4f (&afr)[MT], int j) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                // unconditional load (a padded tap reads voxel 0, always mapped); the zero select happens at the point of
+                // use: no divergent branch and no early consumer, so the loads of the next group overlap the MFMAs
+                bfr[t] = *reinterpret_cast<const fbbev_v4f*>(x + off[t] + 16 * j);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                afr[mt] = *reinterpret_cast<const fbbev_v4f*>(wt + ((long long)j * mt_total + mt) * 256);
+        };
+        auto mma = [&](const fbbev_v4f (&braw)[NT], const fbbev_v4f (&afr)[MT], bool live) {
+            fbbev_v4f bfr[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) bfr[t] = (ok[t] && live) ? braw[t] : fbbev_v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[mt][t] = fbbev_mfma_f32_16x16x4(afr[mt][e], bfr[t][e], acc[mt][t]);
+        };
+        fbbev_v4f b0[NT], a0[MT], b1[NT], a1[MT];
+        load(b0, a0, 0);
+        for (int j = 0; j < J; j += 2) {
+            // straight-line body: both prefetches are unconditional (index clamped to the last group: a redundant, cached
+            // re-read at the end of a tap) and for an odd group count the second MFMA block runs on a zero B operand
+            // instead of being skipped.  Any branch here merges control-flow paths with different numbers of loads in
+            // flight (the compiler then waits for all of them) or lets it sink a prefetch next to its consumer.
+            // The scheduling fences pin the prefetch in front of the MFMA block it overlaps (the scheduler otherwise sinks
+            // the loads behind the block to save registers and then waits for them at once).
+            load(b1, a1, j + 1 < J ? j + 1 : J - 1);
+            fbbev_sched_fence();
+            mma(b0, a0, true);
+            fbbev_sched_fence();
+            load(b0, a0, j + 2 < J ? j + 2 : J - 1);
+            fbbev_sched_fence();
+            mma(b1, a1, j + 1 < J);
+            fbbev_sched_fence();
+        }
+    }
+    // epilogue: lane holds couts 16(mt0+mt) + 4g + {0..3} of voxel i of every tile
+    const int pa = parity >> 2, pb = (parity >> 1) & 1, pc = parity & 1;
+    const bool vec = (Cout & 3) == 0;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (!vq[t]) continue;
+        long long ovox;
+        if (ups)
+            ovox = (((long long)bq[t] * (2 * Do) + 2 * dq[t] + pa) * (2 * Ho) + 2 * hq[t] + pb) * (2 * Wo) + 2 * wq[t] + pc;
+        else
+            ovox = (((long long)bq[t] * Do + dq[t]) * Ho + hq[t]) * Wo + wq[t];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int c0 = 16 * (mt0 + mt) + 4 * g;
+            if (c0 >= Cout) continue;
+            fbbev_v4f v = acc[mt][t] + *reinterpret_cast<const fbbev_v4f*>(bias + c0);     // bias is padded to 16*mt_total
+            const long long o = ovox * Cout + c0;
+            if (vec) {
+                if (residual) v = v + *reinterpret_cast<const fbbev_v4f*>(residual + o);
+                if (relu) v = fbbev_v4f{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+                *reinterpret_cast<fbbev_v4f*>(out + o) = v;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (c0 + r >= Cout) break;
+                    float s = v[r] + (residual ? residual[o + r] : 0.f);
+                    out[o + r] = relu ? fmaxf(s, 0.f) : s;
+                }
+            }
+        }
+    }
+}

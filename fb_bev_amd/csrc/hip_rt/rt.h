@@ -63,6 +63,9 @@ __device__ __forceinline__ fbbev_v4f fbbev_mfma_f32_16x16x4(float a, float b, fb
 
 // wave-level ordering point for a wave-PRIVATE LDS region: the 64 lanes run in lockstep and the LDS queue of a wave is
 // in order, so only the compiler has to be kept from moving LDS accesses across it (no s_barrier, no other wave waits)
+// instruction-scheduling fence: nothing is moved across it (keeps prefetch loads ahead of the MFMA block they overlap)
+__device__ __forceinline__ void fbbev_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+
 __device__ __forceinline__ void fbbev_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();

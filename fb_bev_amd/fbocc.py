@@ -88,6 +88,10 @@ class FBOCC(nn.Module):
         self.img_bev_encoder_backbone = _build(img_bev_encoder_backbone, **cp, compute_dtype=_dtype(ex.get('voxel_dtype')))
         self.img_bev_encoder_neck = _build(img_bev_encoder_neck, **cp, compute_dtype=_dtype(ex.get('voxel_dtype')))
         self.occupancy_head = _build(occupancy_head, **cp, compute_dtype=_dtype(ex.get('head_dtype')))
+        # opt-in: eval-mode voxel encoder + head on the fp32-MFMA implicit-GEMM kernel (mfma_conv3d.py; validated on the
+        # CPU emulator only so far, hence off by default)
+        self.mfma_conv3d = bool(ex.get('mfma_conv3d', False))
+        self._runners = None
 
     # ------------------------------------------------------------------ plumbing
     @property
@@ -110,7 +114,18 @@ class FBOCC(nn.Module):
         super().train(mode)
         for m in self._path:
             m.training = mode
+        self._runners = None                      # folded weights are rebuilt from the current parameters on next use
         return self
+
+    def _mfma_stacks(self):
+        if self._runners is None:
+            from . import mfma_conv3d as M
+            self._runners = (M.ResNet3DRunner(self.img_bev_encoder_backbone), M.FPN3DRunner(self.img_bev_encoder_neck),
+                             M.OccHeadRunner(self.occupancy_head))
+        return self._runners
+
+    def _use_mfma(self, x):
+        return self.mfma_conv3d and x.is_cuda and not self.training and not torch.is_grad_enabled()
 
     def reset_history(self):
         self.history.reset()
@@ -145,6 +160,11 @@ class FBOCC(nn.Module):
         bev_feat = self.view_transform(cam_params, context.float(), depth.float(), img_metas=img_metas)   # :344-368
         ret['cam_params'] = cam_params
         bev_feat = self.history.fuse_history(bev_feat, img_metas, img[6])                                # :371
+        if self._use_mfma(bev_feat):
+            from .mfma_conv3d import to_ndhwc
+            backbone, neck, _ = self._mfma_stacks()
+            ret['img_bev_feat_ndhwc'] = neck(backbone(to_ndhwc(bev_feat)))       # NDHWC maps, consumed by the head runner
+            return ret
         ret['img_bev_feat'] = self.bev_encoder(bev_feat)
         return ret
 
@@ -186,7 +206,10 @@ class FBOCC(nn.Module):
         """simple_test's device-side part for a whole batch: -> (B, X', Y', Z) class ids (or (B, X', Y', Z, classes)
         probabilities) in the CVPR-2023 axis convention of :547-552, still on the GPU."""
         results = self.extract_feat(None, img=img_inputs, img_metas=img_metas, **kwargs)
-        occ = self.occupancy_head(results['img_bev_feat'], results=results)['output_voxels'][0]   # (B,cls,H,W,D)
+        if 'img_bev_feat_ndhwc' in results:
+            occ = self._mfma_stacks()[2](results['img_bev_feat_ndhwc'])                           # (B,cls,H,W,D) view
+        else:
+            occ = self.occupancy_head(results['img_bev_feat'], results=results)['output_voxels'][0]   # (B,cls,H,W,D)
         if self.fix_void:
             occ = occ[:, 1:]                                                            # :542-543
         occ = occ.softmax(1)

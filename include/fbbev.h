@@ -325,6 +325,24 @@ int fbbev_history_conv(const float* feats, long long feats_stride_b, const float
                        const float* w2, const float* bias2, int B, int T1, int C, int Cout, int N, float* out,
                        void* workspace, size_t workspace_bytes, fbbev_stream_t stream);
 
+/* Dense 3-D convolution on NDHWC (torch channels_last_3d) f32 activations as an fp32-MFMA implicit GEMM, inference:
+ * replaces the eval-mode Conv3d (+ folded BatchNorm) (+ residual) (+ ReLU) groups of CustomResNet3D (resnet3d.py:19-43,
+ * 78-102), FPN3D (fpn3d.py:50-70) and OccHead (occupancy_head.py:82-141), which the reference runs in fp32 through the
+ * vendor library.
+ *   x (B,Di,Hi,Wi,Cin), out (B,Do,Ho,Wo,Cout) [transposed: (B,2Di,2Hi,2Wi,Cout)], residual like out or NULL.
+ *   ksize 1 or 3, one stride (1|2) and padding for the three axes, Do = (Di + 2 pad - ksize) / stride + 1 (checked).
+ *   transposed != 0: ConvTranspose3d kernel 2 stride 2 padding 0 (the head's deblock); ksize/stride/pad are ignored,
+ *   Do,Ho,Wo must equal Di,Hi,Wi.
+ *   weight_fragments: the weights in MFMA A-fragment order with the batch norm folded in,
+ *     wf[parity][tap][j][mt][lane][e] = W[cout = 16mt + lane%16][cin = 16j + 4(lane/16) + e][tap],  zero for cout >= Cout,
+ *     tap = (kd*k + kh)*k + kw, j < Cin/16, mt < ceil(Cout/16); parity = (a*2+b)*2+c of the output voxel for the transposed
+ *     case (8 blocks, W[cin][cout][a][b][c]), one block otherwise.
+ *   bias: ceil(Cout/16)*16 floats (zero padded).  Cin % 16 == 0, 16-byte aligned pointers, else FBBEV_E_UNSUPPORTED.
+ * Exact fp32 arithmetic (v_mfma_f32_16x16x4_f32). */
+int fbbev_conv3d_ndhwc(const float* x, const float* weight_fragments, const float* bias, const float* residual, int B,
+                       int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout, int ksize, int stride, int pad,
+                       int relu, int transposed, float* out, fbbev_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -244,3 +244,22 @@ def msda_fwd_fused(value, ss, ls, ref, offsets, w, head_dim=None, offsets_head_m
     ok(lib().fbbev_msda_fwd_fused(p(value), p(ss), p(ls), p(ref), p(offsets), p(w), B, S, M, Dh, L, Q, P, HS,
                                   1 if offsets_head_minor else 0, p(out), None))
     return out
+
+
+def conv3d_fragments(w, transposed=False):
+    """Host-side weight layout of fbbev_conv3d_ndhwc (same arithmetic as fb_bev_amd.mfma_conv3d.weight_fragments)."""
+    from fb_bev_amd.mfma_conv3d import weight_fragments
+    return weight_fragments(w, transposed)
+
+
+def conv3d_ndhwc(x, wf, bias, Cout, ksize=3, stride=1, pad=1, relu=False, residual=None, transposed=False):
+    B, Di, Hi, Wi, Cin = x.shape
+    if transposed:
+        Do, Ho, Wo = Di, Hi, Wi
+        out = torch.full((B, 2 * Di, 2 * Hi, 2 * Wi, Cout), float('nan'))
+    else:
+        Do, Ho, Wo = [(n + 2 * pad - ksize) // stride + 1 for n in (Di, Hi, Wi)]
+        out = torch.full((B, Do, Ho, Wo, Cout), float('nan'))
+    code = lib().fbbev_conv3d_ndhwc(p(x), p(wf), p(bias), p(residual) if residual is not None else None, B, Di, Hi, Wi, Cin,
+                                    Do, Ho, Wo, Cout, ksize, stride, pad, 1 if relu else 0, 1 if transposed else 0, p(out), None)
+    return code, out

@@ -184,3 +184,4 @@ inline fbbev_v4f fbbev_mfma_f32_16x16x4(float a, float b, fbbev_v4f c) {
 }
 
 inline void fbbev_wave_sync() { emu::wave_barrier(); }
+inline void fbbev_sched_fence() {}

@@ -1,0 +1,160 @@
+"""fbbev_conv3d_ndhwc (fp32-MFMA implicit-GEMM 3-D convolution, csrc/conv3d_kernels.h) on the CPU device emulator
+against torch's fp32 convolutions, and the eval-mode mapping of CustomResNet3D / FPN3D / OccHead onto it
+(fb_bev_amd/mfma_conv3d.py) against the modules' own forward.  Tolerance 1e-4 abs on O(1) activations: both sides are
+fp32, only the summation order over (tap, cin) differs."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), 'emu'))
+import emu_capi as E  # noqa: E402
+from fb_bev_amd import mfma_conv3d as M  # noqa: E402
+
+
+def emu_backend(x, wf, bias, out, Cout, ksize=3, stride=1, pad=1, relu=False, residual=None, transposed=False):
+    code, y = E.conv3d_ndhwc(x.contiguous(), wf, bias, Cout, ksize=ksize, stride=stride, pad=pad, relu=relu,
+                             residual=None if residual is None else residual.contiguous(), transposed=transposed)
+    assert code == 0
+    assert tuple(y.shape) == tuple(out.shape) and not torch.isnan(y).any()          # every element written
+    return y
+
+
+@pytest.mark.parametrize('B,dims,Cin,Cout,k,s,p,relu,res', [
+    (1, (5, 6, 3), 16, 16, 3, 1, 1, False, False),         # MT=1
+    (2, (5, 6, 3), 32, 64, 3, 2, 1, True, False),          # MT=4, stride 2, two samples, odd extents
+    (1, (4, 9, 8), 16, 32, 3, 1, 1, True, True),           # MT=2, 288 voxels: two workgroups, partial last wave; residual
+    (1, (3, 5, 2), 48, 19, 1, 1, 0, False, False),         # 1x1x1 to 19 classes: scalar store path, padded cout tile
+    (1, (6, 6, 4), 16, 80, 1, 2, 0, False, False),         # strided 1x1x1 (downsample branch), 5 cout tiles
+    (1, (3, 4, 2), 32, 4, 1, 1, 0, False, True),           # 4 soft-weight channels
+])
+def test_conv3d_kernel_vs_torch(B, dims, Cin, Cout, k, s, p, relu, res):
+    g = torch.Generator().manual_seed(Cin * 100 + Cout)
+    x = torch.randn(B, Cin, *dims, generator=g)
+    w = torch.randn(Cout, Cin, k, k, k, generator=g) / (Cin * k ** 3) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    exp = F.conv3d(x, w, b, stride=s, padding=p)
+    r = torch.randn(exp.shape, generator=g) if res else None
+    if res:
+        exp = exp + r
+    if relu:
+        exp = exp.relu()
+    wf = M.weight_fragments(w)
+    bias = F.pad(b, (0, (Cout + 15) // 16 * 16 - Cout))
+    code, y = E.conv3d_ndhwc(M.to_ndhwc(x), wf, bias, Cout, ksize=k, stride=s, pad=p, relu=relu,
+                             residual=None if r is None else M.to_ndhwc(r))
+    assert code == 0 and not torch.isnan(y).any()
+    assert torch.allclose(M.to_ncdhw(y), exp, atol=1e-4, rtol=1e-4), (M.to_ncdhw(y) - exp).abs().max()
+
+
+def test_transposed_conv_k2s2_vs_torch():
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 32, 3, 4, 2, generator=g)
+    w = torch.randn(32, 24, 2, 2, 2, generator=g) / 32 ** 0.5
+    exp = F.conv_transpose3d(x, w, None, stride=2).relu()
+    wf = M.weight_fragments(w, transposed=True)
+    code, y = E.conv3d_ndhwc(M.to_ndhwc(x), wf, torch.zeros(32), 24, relu=True, transposed=True)
+    assert code == 0 and not torch.isnan(y).any()
+    assert torch.allclose(M.to_ncdhw(y), exp, atol=1e-4, rtol=1e-4)
+
+
+def test_conv3d_argument_checks():
+    x = torch.zeros(1, 2, 2, 2, 16)
+    wf = torch.zeros(27 * 256)
+    bias = torch.zeros(16)
+    assert E.conv3d_ndhwc(torch.zeros(1, 2, 2, 2, 8), wf, bias, 16)[0] == -2                # Cin % 16
+    assert E.conv3d_ndhwc(x, wf, bias, 16, ksize=5, pad=2)[0] == -2
+    out = torch.zeros(1, 3, 2, 2, 16)                                                        # wrong Do
+    code = E.lib().fbbev_conv3d_ndhwc(E.p(x), E.p(wf), E.p(bias), None, 1, 2, 2, 2, 16, 3, 2, 2, 16, 3, 1, 1, 0, 0, E.p(out), None)
+    assert code == -1
+
+
+def _randomise(net, seed):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, nn.BatchNorm3d):
+                m.running_mean.copy_(torch.rand(m.running_mean.shape, generator=g) * 0.6 - 0.3)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+                m.weight.copy_(torch.rand(m.weight.shape, generator=g) * 0.6 + 0.7)
+                m.bias.copy_(torch.rand(m.bias.shape, generator=g) * 0.4 - 0.2)
+    return net.eval()
+
+
+def test_voxel_encoder_and_head_runners_equal_the_modules():
+    """Eval-mode CustomResNet3D -> FPN3D -> OccHead through the folded single-launch groups == the torch modules."""
+    from fb_bev_amd.bev_encoder import CustomResNet3D, FPN3D
+    from fb_bev_amd.occ_head import OccHead
+    torch.manual_seed(0)
+    chans = [16, 32, 48]
+    bb = _randomise(CustomResNet3D(depth=10, block_strides=[1, 2, 2], n_input_channels=16, block_inplanes=chans,
+                                   out_indices=(0, 1, 2), norm_cfg=dict(type='SyncBN')), 1)
+    neck = _randomise(FPN3D(in_channels=chans, out_channels=64, norm_cfg=dict(type='SyncBN')), 2)
+    head = _randomise(OccHead(in_channels=[64] * 3, out_channel=19, num_level=3, soft_weights=True, use_focal_loss=False,
+                              norm_cfg=dict(type='SyncBN'), final_occ_size=[16, 16, 8], empty_idx=18), 3)
+    x = torch.randn(1, 16, 8, 8, 4)
+    with torch.no_grad():
+        f_ref = bb(x)
+        n_ref = neck(f_ref)
+        o_ref = head(n_ref)['output_voxels'][0]
+        f = M.ResNet3DRunner(bb)(M.to_ndhwc(x), backend=emu_backend)
+        n = M.FPN3DRunner(neck)(f, backend=emu_backend)
+        o = M.OccHeadRunner(head)(n, backend=emu_backend)
+    for a, b in zip(f, f_ref):
+        assert torch.allclose(M.to_ncdhw(a), b, atol=1e-4, rtol=1e-4)
+    for a, b in zip(n, n_ref):
+        assert torch.allclose(M.to_ncdhw(a), b, atol=1e-4, rtol=1e-4)
+    assert o.shape == o_ref.shape == (1, 19, 16, 16, 8)
+    assert torch.allclose(o, o_ref, atol=2e-4, rtol=1e-4), (o - o_ref).abs().max()
+
+
+def test_groupnorm_stacks_are_rejected():
+    from fb_bev_amd.bev_encoder import FPN3D
+    with pytest.raises(NotImplementedError):
+        M.FPN3DRunner(FPN3D(in_channels=[32], out_channels=32, norm_cfg=dict(type='GN', num_groups=4)))
+
+
+def test_detector_opt_in_route_equals_module_route(monkeypatch):
+    """FBOCC(execution=dict(mfma_conv3d=True)).predict_occupancy through the folded MFMA stacks (emulated) == the torch
+    modules; the two GPU-only stages in front are replaced by CPU stand-ins as in tests/test_fbocc_model.py."""
+    from fb_bev_amd import _capi, synthetic as S
+    from fb_bev_amd.fbocc import FBOCC
+    grid = {'x': [-8, 8, 2.0], 'y': [-8, 8, 2.0], 'z': [-1, 2.2, 0.8], 'depth': [2.0, 10.0, 1.0]}     # 8x8x4, D=8
+    C = 16
+    cfg = dict(
+        fix_void=True, do_history=True, history_cat_num=2, single_bev_num_channels=C, readd=True,
+        img_backbone=dict(type='ResNet', depth=18, num_stages=4, out_indices=(2, 3), norm_eval=False, base_channels=8),
+        img_neck=dict(type='CustomFPN', in_channels=[32, 64], out_channels=24, num_outs=1, start_level=0, out_ids=[0]),
+        depth_net=dict(type='CM_DepthNet', in_channels=24, context_channels=C, downsample=16, grid_config=grid,
+                       depth_channels=8, mid_channels=32, use_dcn=False),
+        forward_projection=dict(type='LSSViewTransformerFunction3D', grid_config=grid, input_size=(64, 96), downsample=16),
+        img_bev_encoder_backbone=dict(type='CustomResNet3D', depth=10, block_strides=[1, 2, 2], n_input_channels=C,
+                                      block_inplanes=[16, 32, 32], out_indices=(0, 1, 2), norm_cfg=dict(type='SyncBN')),
+        img_bev_encoder_neck=dict(type='FPN3D', in_channels=[16, 32, 32], out_channels=64, norm_cfg=dict(type='SyncBN')),
+        occupancy_head=dict(type='OccHead', norm_cfg=dict(type='SyncBN'), soft_weights=True, final_occ_size=[16, 16, 8],
+                            empty_idx=18, num_level=3, in_channels=[64] * 3, out_channel=19))
+    torch.manual_seed(0)
+    m = FBOCC(**cfg, execution=dict(mfma_conv3d=True))
+    _randomise(m, 4)
+    B = 1
+    g = torch.Generator().manual_seed(2)
+    bev = torch.randn(B, C, 8, 8, 4, generator=g)
+    monkeypatch.setattr(m._path[0], 'forward', lambda cam, ctx, dep, img_metas=None, **kw: bev)
+    monkeypatch.setattr(m._path[1], 'fuse_history', lambda x, metas, bda: x)
+    pc = S.PathConfig(name='t', input_size=(64, 96), downsample=16, grid_config=grid, channels=C)
+    inputs = [torch.randn(B, 6, 3, 64, 96, generator=g)] + list(S.camera_rig(pc, B, seed=0))
+    metas = [dict(sequence_group_idx=0, start_of_sequence=True, curr_to_prev_ego_rt=torch.eye(4), index=0)]
+    with torch.no_grad():
+        ref_raw = m.predict_occupancy(inputs, metas, return_raw_occ=True)         # CPU tensors: module route
+        monkeypatch.setattr(_capi, 'conv3d_ndhwc', emu_backend)
+        monkeypatch.setattr(m, '_use_mfma', lambda x: True)
+        got_raw = m.predict_occupancy(inputs, metas, return_raw_occ=True)
+        got_ids = m.predict_occupancy(inputs, metas)
+    assert got_raw.shape == ref_raw.shape == (1, 16, 16, 8, 18)
+    assert torch.allclose(got_raw, ref_raw, atol=1e-5, rtol=1e-4), (got_raw - ref_raw).abs().max()
+    assert (got_ids == ref_raw.argmax(-1)).float().mean() > 0.999
+    m.train()
+    assert m._runners is None                                                     # folded weights dropped with the mode
