@@ -1,0 +1,75 @@
+"""GPU parity of fbbev_conv3d_ndhwc and of the opt-in MFMA route of the detector against torch's fp32 convolutions.
+
+The kernel has only run on the CPU emulator so far (tests/test_emu_conv3d.py): these tests are the first thing to run on
+an MI355X next (`FBBEV_EXPERIMENTAL=1 python -m pytest tests/test_gpu_conv3d.py -m gpu`), and stay out of the default
+GPU suite until they have passed there once."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(__file__))
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(os.environ.get('FBBEV_EXPERIMENTAL') != '1', reason='not yet validated on the GPU')]
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device('cuda:0')
+
+
+@pytest.mark.parametrize('B,dims,Cin,Cout,k,s,p,relu,res', [
+    (1, (100, 100, 8), 64, 64, 3, 1, 1, True, True),       # stage-1 block conv of the shipped voxel backbone
+    (2, (50, 50, 4), 64, 128, 3, 2, 1, True, False),
+    (1, (25, 25, 2), 256, 256, 3, 1, 1, True, False),
+    (1, (100, 100, 8), 80, 64, 1, 1, 0, True, False),      # input_proj: odd number of 16-channel groups
+    (1, (40, 40, 16), 64, 19, 1, 1, 0, False, False),
+    (1, (7, 5, 3), 16, 80, 1, 2, 0, False, True),
+])
+def test_conv3d_kernel_vs_torch(dev, B, dims, Cin, Cout, k, s, p, relu, res):
+    from fb_bev_amd import _capi, mfma_conv3d as M
+    g = torch.Generator().manual_seed(Cin + Cout)
+    x = torch.randn(B, Cin, *dims, generator=g).to(dev)
+    w = (torch.randn(Cout, Cin, k, k, k, generator=g) / (Cin * k ** 3) ** 0.5).to(dev)
+    b = torch.randn(Cout, generator=g).to(dev)
+    torch.backends.cudnn.allow_tf32 = False
+    exp = F.conv3d(x.double(), w.double(), b.double(), stride=s, padding=p)
+    r = torch.randn(exp.shape, generator=g).to(dev) if res else None
+    if res:
+        exp = exp + r.double()
+    if relu:
+        exp = exp.relu()
+    xn = M.to_ndhwc(x)
+    out = torch.full((B, *exp.shape[2:], Cout), float('nan'), device=dev)
+    _capi.conv3d_ndhwc(xn, M.weight_fragments(w), F.pad(b, (0, (Cout + 15) // 16 * 16 - Cout)), out, Cout, ksize=k, stride=s,
+                       pad=p, relu=relu, residual=None if r is None else M.to_ndhwc(r))
+    assert not torch.isnan(out).any()
+    assert torch.allclose(M.to_ncdhw(out).double(), exp, atol=1e-4, rtol=1e-4), (M.to_ncdhw(out).double() - exp).abs().max()
+
+
+def test_transposed_conv_vs_torch(dev):
+    from fb_bev_amd import _capi, mfma_conv3d as M
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 256, 20, 20, 8, generator=g).to(dev)
+    w = (torch.randn(256, 128, 2, 2, 2, generator=g) / 16).to(dev)
+    exp = F.conv_transpose3d(x.double(), w.double(), None, stride=2).relu()
+    out = torch.full((1, 40, 40, 16, 128), float('nan'), device=dev)
+    _capi.conv3d_ndhwc(M.to_ndhwc(x), M.weight_fragments(w, transposed=True), torch.zeros(128, device=dev), out, 128, relu=True,
+                       transposed=True)
+    assert not torch.isnan(out).any()
+    assert torch.allclose(M.to_ncdhw(out).double(), exp, atol=1e-4, rtol=1e-4)
+
+
+def test_detector_mfma_route_equals_vendor_route(dev):
+    import test_gpu_full_model as T
+    m = T._small_model(dev, neck_channels=64).eval()          # 64 -> 32 -> 16 channels in the head: multiples of 16
+    img_inputs, metas, _, _ = T._inputs(dev, 1)
+    with torch.no_grad():
+        ref = m.predict_occupancy(img_inputs, metas(True), return_raw_occ=True)
+        m.reset_history()
+        m.mfma_conv3d = True
+        got = m.predict_occupancy(img_inputs, metas(True), return_raw_occ=True)
+    assert torch.allclose(got, ref, atol=1e-4, rtol=1e-3), (got - ref).abs().max()

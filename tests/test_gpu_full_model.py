@@ -14,7 +14,7 @@ def dev():
     return torch.device('cuda:0')
 
 
-def _small_model(dev, execution=None):
+def _small_model(dev, execution=None, neck_channels=32):
     from fb_bev_amd import configs
     from fb_bev_amd.fbocc import FBOCC
     bev, C = 20, 80
@@ -31,9 +31,9 @@ def _small_model(dev, execution=None):
         forward_projection=blocks['forward_projection'], backward_projection=blocks['backward_projection'],
         img_bev_encoder_backbone=dict(type='CustomResNet3D', depth=18, block_strides=[1, 2, 2], n_input_channels=C,
                                       block_inplanes=[16, 32, 64], out_indices=(0, 1, 2), norm_cfg=dict(type='SyncBN')),
-        img_bev_encoder_neck=dict(type='FPN3D', in_channels=[16, 32, 64], out_channels=32, norm_cfg=dict(type='SyncBN')),
+        img_bev_encoder_neck=dict(type='FPN3D', in_channels=[16, 32, 64], out_channels=neck_channels, norm_cfg=dict(type='SyncBN')),
         occupancy_head=dict(type='OccHead', use_focal_loss=True, norm_cfg=dict(type='SyncBN'), soft_weights=True,
-                            final_occ_size=[40, 40, 16], empty_idx=18, num_level=3, in_channels=[32] * 3, out_channel=19,
+                            final_occ_size=[40, 40, 16], empty_idx=18, num_level=3, in_channels=[neck_channels] * 3, out_channel=19,
                             point_cloud_range=pcr))
     torch.manual_seed(0)
     m = FBOCC(**cfg, execution=execution)

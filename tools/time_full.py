@@ -3,7 +3,8 @@
 (tests/golden/fbocc_config_path_blocks.json, extracted from occupancy_configs/fb_occ/fbocc-r50-cbgs_depth_16f_16x4_20e.py)
 with random-init weights and synthetic inputs of SURVEY Appendix B.
 
-    python tools/time_full.py infer B [f32|bf16]      S4: images -> occupancy class ids (device), per-stage split
+    python tools/time_full.py infer B [f32|bf16] [mfma]   S4: images -> occupancy class ids (device), per-stage split;
+                                                          mfma = voxel encoder + head on fbbev_conv3d_ndhwc (fp32 MFMA)
     python tools/time_full.py train B [f32|bf16]      S5: forward_train + backward + grad all-reduce + clip + AdamW step
 
 bf16 = convolution stacks (image encoder, depth net, voxel encoder, head) under bf16 autocast; the view transformation,
@@ -22,11 +23,11 @@ from fb_bev_amd import shard, synthetic as S  # noqa: E402
 from fb_bev_amd.fbocc import FBOCC  # noqa: E402
 
 
-def build(dtype, with_cp=False):
+def build(dtype, with_cp=False, mfma=False):
     cfg = dict(json.load(open(os.path.join(ROOT, 'tests', 'golden', 'fbocc_config_path_blocks.json')))
                ['fbocc-r50-cbgs_depth_16f_16x4_20e.py']['model'])
     cfg.pop('type')
-    ex = dict(with_cp=with_cp)
+    ex = dict(with_cp=with_cp, mfma_conv3d=mfma)
     if dtype == 'bf16':
         ex.update(img_dtype='bf16', depth_dtype='bf16', voxel_dtype='bf16', head_dtype='bf16')
     torch.manual_seed(0)
@@ -60,9 +61,9 @@ def ev_ms(fn, n):
     return ts[len(ts) // 2], ts[max(0, len(ts) // 10)], ts[min(len(ts) - 1, len(ts) * 9 // 10)]
 
 
-def infer(B, dtype):
+def infer(B, dtype, mfma=False):
     dev = torch.device('cuda:0')
-    m = build(dtype).to(dev).eval()
+    m = build(dtype, mfma=mfma).to(dev).eval()
     m.do_history = True
     img_inputs, metas, _, _ = inputs(B, dev)
     out = {}
@@ -84,13 +85,20 @@ def infer(B, dtype):
         bev = m.view_transform(cam, ctx.float(), dep.float())
         t_h = ev_ms(lambda i: m.history.fuse_history(bev, metas(False), img_inputs[6]), 5)[0]
         fused = m.history.fuse_history(bev, metas(False), img_inputs[6])
-        t_enc = ev_ms(lambda i: m.bev_encoder(fused), 5)[0]
-        feats = m.bev_encoder(fused)
-        t_head = ev_ms(lambda i: m.occupancy_head(feats)['output_voxels'][0].softmax(1).argmax(1), 5)[0]
+        if mfma:
+            from fb_bev_amd.mfma_conv3d import to_ndhwc
+            bb, neck, head = m._mfma_stacks()
+            t_enc = ev_ms(lambda i: neck(bb(to_ndhwc(fused))), 5)[0]
+            feats = neck(bb(to_ndhwc(fused)))
+            t_head = ev_ms(lambda i: head(feats).softmax(1).argmax(1), 5)[0]
+        else:
+            t_enc = ev_ms(lambda i: m.bev_encoder(fused), 5)[0]
+            feats = m.bev_encoder(fused)
+            t_head = ev_ms(lambda i: m.occupancy_head(feats)['output_voxels'][0].softmax(1).argmax(1), 5)[0]
         if B == 1:
             t_host = ev_ms(lambda i: m.simple_test(None, metas(False), img_inputs)[0]['pred_occupancy'], 5)[0]
             out['ms_simple_test_incl_d2h'] = round(t_host, 3)
-    out.update(scope='S4 full forward', B=B, conv_dtype=dtype, pred=list(ids.shape), ms_frame=round(med, 3),
+    out.update(scope='S4 full forward', B=B, conv_dtype=dtype, mfma_conv3d=mfma, pred=list(ids.shape), ms_frame=round(med, 3),
                ms_p10_p90=[round(p10, 3), round(p90, 3)], samples_per_s=round(1e3 * B / med, 2),
                ms_image_encoder=round(t_img, 3), ms_depth_net=round(t_dn, 3), ms_view_transform=round(t_vt, 3),
                ms_history_fusion=round(t_h, 3), ms_voxel_encoder=round(t_enc, 3), ms_head_argmax=round(t_head, 3),
@@ -143,4 +151,7 @@ if __name__ == '__main__':
     mode = sys.argv[1] if len(sys.argv) > 1 else 'infer'
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     dtype = sys.argv[3] if len(sys.argv) > 3 else 'f32'
-    (infer if mode == 'infer' else train)(B, dtype)
+    if mode == 'infer':
+        infer(B, dtype, mfma=len(sys.argv) > 4 and sys.argv[4] == 'mfma')
+    else:
+        train(B, dtype)
