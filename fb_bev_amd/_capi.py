@@ -43,6 +43,7 @@ SIGNATURES = {
     'fbbev_layernorm': (c_int, [c_void_p] * 4 + [c_float, c_int64, c_int, c_void_p, c_void_p]),
     'fbbev_history_conv': (c_int, [c_void_p, c_int64] + [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t, c_void_p]),
     'fbbev_conv3d_ndhwc': (c_int, [c_void_p] * 4 + [c_int] * 14 + [c_void_p, c_void_p]),
+    'fbbev_blend_levels_ndhwc': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p] + [c_int] * 6 + [c_void_p, c_void_p]),
     'fbbev_msda_fwd': (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_void_p, c_void_p]),
     'fbbev_point_sampling': (c_int, [c_void_p] * 9 + [c_int] * 5 + [c_float, c_float] + [c_void_p] * 4),
     'fbbev_da_cross_attn_fwd': (c_int, [c_void_p] * 9 + [c_int] * 10 + [c_float, c_float, c_int, c_int, c_void_p, c_void_p]),
@@ -485,6 +486,26 @@ def conv3d_ndhwc(x, weight_fragments, bias, out, Cout, ksize=3, stride=1, pad=1,
             None if residual is None else _dev(residual, F32, 'residual'), B, Di, Hi, Wi, Cin, Do, Ho, Wo, int(Cout), int(ksize),
             int(stride), int(pad), 1 if relu else 0, 1 if transposed else 0, _dev(out, F32, 'out'), _stream()),
             'fbbev_conv3d_ndhwc')
+    return out
+
+
+def blend_levels_ndhwc(level0, coarse, wsoft, out):
+    """out = wsoft[...,0] * level0 + sum_k wsoft[...,k] * trilinear_upsample(coarse[k-1]); all NDHWC f32 contiguous."""
+    import ctypes
+    B, D, H, W, C = level0.shape
+    n = len(coarse)
+    ptrs = (c_void_p * max(n, 1))(*[_dev(t, F32, 'coarse').value for t in coarse]) if n else None
+    dims = (c_int * max(3 * n, 1))(*[int(v) for t in coarse for v in t.shape[1:4]]) if n else None
+    for t in coarse:
+        if t.shape[0] != B or t.shape[4] != C:
+            raise FbbevError('blend_levels_ndhwc: coarse level batch / channels differ')
+    if tuple(out.shape) != tuple(level0.shape) or tuple(wsoft.shape[:4]) != (B, D, H, W):
+        raise FbbevError('blend_levels_ndhwc: bad out / wsoft shape')
+    with _on(level0):
+        _check(lib().fbbev_blend_levels_ndhwc(
+            _dev(level0, F32, 'level0'), ctypes.cast(ptrs, c_void_p) if n else None, ctypes.cast(dims, c_void_p) if n else None,
+            n, _dev(wsoft, F32, 'wsoft'), int(wsoft.shape[4]), B, D, H, W, C, _dev(out, F32, 'out'), _stream()),
+            'fbbev_blend_levels_ndhwc')
     return out
 
 

@@ -1010,3 +1010,25 @@ extern "C" int fbbev_conv3d_ndhwc(const float* x, const float* weight_fragments,
     FBBEV_CHECK_LAUNCH();
     return 0;
 }
+
+extern "C" int fbbev_blend_levels_ndhwc(const float* level0, const float* const* coarse, const int* coarse_dims,
+                                        int n_coarse, const float* wsoft, int K, int B, int D, int H, int W, int C,
+                                        float* out, fbbev_stream_t stream_) {
+    if (B < 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0 || n_coarse < 0 || n_coarse > 3 || K < n_coarse + 1) return FBBEV_E_BADARG;
+    if (B == 0) return 0;
+    if (!level0 || !wsoft || !out || (n_coarse > 0 && (!coarse || !coarse_dims))) return FBBEV_E_BADARG;
+    if (C % 4 != 0 || !aligned16(level0) || !aligned16(out)) return FBBEV_E_UNSUPPORTED;
+    fbbev_blend_level lv[3] = {{nullptr, 1, 1, 1}, {nullptr, 1, 1, 1}, {nullptr, 1, 1, 1}};
+    for (int k = 0; k < n_coarse; ++k) {
+        if (!coarse[k] || coarse_dims[3 * k] <= 0 || coarse_dims[3 * k + 1] <= 0 || coarse_dims[3 * k + 2] <= 0) return FBBEV_E_BADARG;
+        if (!aligned16(coarse[k])) return FBBEV_E_UNSUPPORTED;
+        lv[k] = fbbev_blend_level{coarse[k], coarse_dims[3 * k], coarse_dims[3 * k + 1], coarse_dims[3 * k + 2]};
+    }
+    const long long total = (long long)B * D * H * W * (C / 4);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 262144) blocks = 262144;
+    FBBEV_LAUNCH(k_blend_levels_ndhwc, blocks, 256, 0, (fbbev_rt_stream)stream_, level0, lv[0], lv[1], lv[2], n_coarse, wsoft, K,
+                 B, D, H, W, C, out);
+    FBBEV_CHECK_LAUNCH();
+    return 0;
+}

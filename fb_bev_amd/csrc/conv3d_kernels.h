@@ -148,3 +148,63 @@ k_conv3d_ndhwc(const float* __restrict__ x, const float* __restrict__ wf, const 
         }
     }
 }
+
+// ---------------------------------------------------------------- soft-weighted multi-level blend of the head
+// OccHead.forward_coarse_voxel (occupancy_head.py:159-170): every level is brought to the finest resolution with
+// F.interpolate(trilinear, align_corners=False) and summed with per-voxel softmax weights -- three full-resolution
+// 128-channel temporaries (328 MB each at 200x200x16) plus four multiply-add passes over them.  Here a lane owns 4
+// channels of one fine voxel, takes level 0 directly, samples the (up to 3) coarse NDHWC maps itself (source index
+// max(scale * (dst + 0.5) - 0.5, 0), scale = in / out, as ATen's area_pixel_compute_source_index; corners combined
+// in ATen's nesting order) and writes the blended voxel once.  Bound: HBM (level 0 read + output written).
+struct fbbev_blend_level {
+    const float* f;          // (B, d, h, w, C)
+    int d, h, w;
+};
+
+__device__ __forceinline__ void fbbev_lin_index(int dst, int in_size, int out_size, int& i0, int& i1, float& l0, float& l1) {
+    const float scale = (float)in_size / (float)out_size;
+    float real = scale * ((float)dst + 0.5f) - 0.5f;
+    real = real < 0.f ? 0.f : real;
+    i0 = (int)real;
+    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    l1 = real - (float)i0;
+    l0 = 1.f - l1;
+}
+
+__global__ void __launch_bounds__(256)
+k_blend_levels_ndhwc(const float* __restrict__ x0, fbbev_blend_level lv1, fbbev_blend_level lv2, fbbev_blend_level lv3,
+                     int n_coarse, const float* __restrict__ wsoft, int K, int B, int D, int H, int W, int C,
+                     float* __restrict__ out) {
+    const int quads = C >> 2;
+    const long long total = (long long)B * D * H * W * quads;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int q = (int)(idx % quads);
+        long long v = idx / quads;
+        const long long vox = v;
+        const int wz = (int)(v % W); v /= W;
+        const int hy = (int)(v % H); v /= H;
+        const int dz = (int)(v % D);
+        const int b = (int)(v / D);
+        const float* ws = wsoft + vox * K;
+        fbbev_v4f acc = *reinterpret_cast<const fbbev_v4f*>(x0 + vox * C + 4 * q) * ws[0];
+        const fbbev_blend_level lv[3] = {lv1, lv2, lv3};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (k >= n_coarse) break;
+            int d0, d1, h0, h1, w0, w1;
+            float ld0, ld1, lh0, lh1, lw0, lw1;
+            fbbev_lin_index(dz, lv[k].d, D, d0, d1, ld0, ld1);
+            fbbev_lin_index(hy, lv[k].h, H, h0, h1, lh0, lh1);
+            fbbev_lin_index(wz, lv[k].w, W, w0, w1, lw0, lw1);
+            const float* fb = lv[k].f + (long long)b * lv[k].d * lv[k].h * lv[k].w * C + 4 * q;
+            auto at = [&](int d, int h, int w) {
+                return *reinterpret_cast<const fbbev_v4f*>(fb + (((long long)d * lv[k].h + h) * lv[k].w + w) * C);
+            };
+            const fbbev_v4f t0 = (at(d0, h0, w0) * lw0 + at(d0, h0, w1) * lw1) * lh0 + (at(d0, h1, w0) * lw0 + at(d0, h1, w1) * lw1) * lh1;
+            const fbbev_v4f t1 = (at(d1, h0, w0) * lw0 + at(d1, h0, w1) * lw1) * lh0 + (at(d1, h1, w0) * lw0 + at(d1, h1, w1) * lw1) * lh1;
+            acc = acc + (t0 * ld0 + t1 * ld1) * ws[k + 1];
+        }
+        *reinterpret_cast<fbbev_v4f*>(out + vox * C + 4 * q) = acc;
+    }
+}

@@ -159,7 +159,7 @@ class OccHeadRunner:
                          FoldedConv3d(head.voxel_soft_weights[3], None, relu=False))
         self.n_feat = head.num_point_sampling_feat
 
-    def __call__(self, feats, backend=None):
+    def __call__(self, feats, backend=None, blend_backend=None):
         occs = []
         if self.deblock is not None:
             occs.append(self.deblock(feats[0], backend=backend))
@@ -169,10 +169,15 @@ class OccHeadRunner:
             w = torch.softmax(self.soft[1](self.soft[0](occs[0], backend=backend), backend=backend), dim=-1)   # (B,D,H,W,n)
         else:
             w = occs[0].new_full((*occs[0].shape[:4], self.n_feat), 1.0 / self.n_feat)
-        out = 0
-        for k, f in enumerate(occs):
-            if tuple(f.shape[1:4]) != tuple(size):
-                f = F.interpolate(to_ncdhw(f), size=list(size), mode='trilinear', align_corners=False).permute(0, 2, 3, 4, 1)
-            out = out + f * w[..., k:k + 1]
+        if len(occs) <= 4 and occs[0].shape[-1] % 4 == 0:
+            # one pass: level 0 read once, the coarse levels sampled in the kernel, the blended map written once
+            blend = blend_backend or _capi.blend_levels_ndhwc
+            out = blend(occs[0], [f.contiguous() for f in occs[1:]], w.contiguous(), torch.empty_like(occs[0]))
+        else:
+            out = 0
+            for k, f in enumerate(occs):
+                if tuple(f.shape[1:4]) != tuple(size):
+                    f = F.interpolate(to_ncdhw(f), size=list(size), mode='trilinear', align_corners=False).permute(0, 2, 3, 4, 1)
+                out = out + f * w[..., k:k + 1]
         logits = self.pred[1](self.pred[0](out.contiguous(), backend=backend), backend=backend)
         return to_ncdhw(logits)

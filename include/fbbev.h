@@ -343,6 +343,16 @@ int fbbev_conv3d_ndhwc(const float* x, const float* weight_fragments, const floa
                        int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout, int ksize, int stride, int pad,
                        int relu, int transposed, float* out, fbbev_stream_t stream);
 
+/* Soft-weighted multi-level blend of the occupancy head on NDHWC f32 (inference): replaces the F.interpolate(trilinear,
+ * align_corners=False) + `out += feats * weights` loop of OccHead.forward_coarse_voxel (occupancy_head.py:159-170).
+ *   out[b,v,:] = wsoft[b,v,0] * level0[b,v,:] + sum_k wsoft[b,v,k] * trilinear(coarse_k)[b,v,:],  k = 1..n_coarse (<= 3)
+ *   level0, out (B,D,H,W,C); coarse_k (B, dims[3k], dims[3k+1], dims[3k+2], C); wsoft (B,D,H,W,K), K >= n_coarse + 1.
+ *   `coarse` (n_coarse device pointers) and `coarse_dims` (3 * n_coarse ints) are HOST arrays, read before the launch.
+ * C % 4 == 0 and 16-byte aligned pointers, else FBBEV_E_UNSUPPORTED. */
+int fbbev_blend_levels_ndhwc(const float* level0, const float* const* coarse, const int* coarse_dims, int n_coarse,
+                             const float* wsoft, int K, int B, int D, int H, int W, int C, float* out,
+                             fbbev_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -263,3 +263,15 @@ def conv3d_ndhwc(x, wf, bias, Cout, ksize=3, stride=1, pad=1, relu=False, residu
     code = lib().fbbev_conv3d_ndhwc(p(x), p(wf), p(bias), p(residual) if residual is not None else None, B, Di, Hi, Wi, Cin,
                                     Do, Ho, Wo, Cout, ksize, stride, pad, 1 if relu else 0, 1 if transposed else 0, p(out), None)
     return code, out
+
+
+def blend_levels_ndhwc(level0, coarse, wsoft):
+    import ctypes
+    B, D, H, W, C = level0.shape
+    n = len(coarse)
+    ptrs = (c_void_p * max(n, 1))(*[t.data_ptr() for t in coarse])
+    dims = (ctypes.c_int * max(3 * n, 1))(*[int(v) for t in coarse for v in t.shape[1:4]])
+    out = torch.full(level0.shape, float('nan'))
+    code = lib().fbbev_blend_levels_ndhwc(p(level0), ctypes.cast(ptrs, c_void_p), ctypes.cast(dims, c_void_p), n, p(wsoft),
+                                          int(wsoft.shape[4]), B, D, H, W, C, p(out), None)
+    return code, out

@@ -72,6 +72,29 @@ def test_conv3d_argument_checks():
     assert code == -1
 
 
+def emu_blend(level0, coarse, wsoft, out):
+    code, y = E.blend_levels_ndhwc(level0.contiguous(), coarse, wsoft)
+    assert code == 0 and not torch.isnan(y).any()
+    return y
+
+
+@pytest.mark.parametrize('dims,coarse_dims,C,K', [((8, 6, 4), [(4, 3, 2), (2, 2, 1)], 8, 3), ((10, 10, 4), [(5, 5, 2), (3, 3, 1), (1, 2, 1)], 16, 4),
+                                               ((4, 4, 2), [], 4, 1)])
+def test_blend_levels_kernel_vs_torch_interpolate(dims, coarse_dims, C, K):
+    g = torch.Generator().manual_seed(C)
+    B = 2
+    level0 = torch.randn(B, *dims, C, generator=g)
+    coarse = [torch.randn(B, *cd, C, generator=g) for cd in coarse_dims]
+    w = torch.rand(B, *dims, K, generator=g).softmax(-1)
+    exp = level0 * w[..., :1]
+    for k, f in enumerate(coarse):
+        up = F.interpolate(M.to_ncdhw(f), size=list(dims), mode='trilinear', align_corners=False).permute(0, 2, 3, 4, 1)
+        exp = exp + up * w[..., k + 1:k + 2]
+    code, got = E.blend_levels_ndhwc(level0, coarse, w)
+    assert code == 0 and not torch.isnan(got).any()
+    assert torch.allclose(got, exp, atol=2e-6, rtol=1e-5), (got - exp).abs().max()
+
+
 def _randomise(net, seed):
     g = torch.Generator().manual_seed(seed)
     with torch.no_grad():
@@ -102,7 +125,7 @@ def test_voxel_encoder_and_head_runners_equal_the_modules():
         o_ref = head(n_ref)['output_voxels'][0]
         f = M.ResNet3DRunner(bb)(M.to_ndhwc(x), backend=emu_backend)
         n = M.FPN3DRunner(neck)(f, backend=emu_backend)
-        o = M.OccHeadRunner(head)(n, backend=emu_backend)
+        o = M.OccHeadRunner(head)(n, backend=emu_backend, blend_backend=emu_blend)
     for a, b in zip(f, f_ref):
         assert torch.allclose(M.to_ncdhw(a), b, atol=1e-4, rtol=1e-4)
     for a, b in zip(n, n_ref):
@@ -150,6 +173,7 @@ def test_detector_opt_in_route_equals_module_route(monkeypatch):
     with torch.no_grad():
         ref_raw = m.predict_occupancy(inputs, metas, return_raw_occ=True)         # CPU tensors: module route
         monkeypatch.setattr(_capi, 'conv3d_ndhwc', emu_backend)
+        monkeypatch.setattr(_capi, 'blend_levels_ndhwc', emu_blend)
         monkeypatch.setattr(m, '_use_mfma', lambda x: True)
         got_raw = m.predict_occupancy(inputs, metas, return_raw_occ=True)
         got_ids = m.predict_occupancy(inputs, metas)

@@ -73,3 +73,20 @@ def test_detector_mfma_route_equals_vendor_route(dev):
         m.mfma_conv3d = True
         got = m.predict_occupancy(img_inputs, metas(True), return_raw_occ=True)
     assert torch.allclose(got, ref, atol=1e-4, rtol=1e-3), (got - ref).abs().max()
+
+
+def test_blend_levels_vs_torch_interpolate(dev):
+    from fb_bev_amd import _capi, mfma_conv3d as M
+    g = torch.Generator().manual_seed(1)
+    B, dims, C = 1, (40, 40, 16), 128
+    level0 = torch.randn(B, *dims, C, generator=g).to(dev)
+    coarse = [torch.randn(B, *cd, C, generator=g).to(dev) for cd in ((20, 20, 8), (10, 10, 4), (5, 5, 2))]
+    w = torch.rand(B, *dims, 4, generator=g).softmax(-1).to(dev)
+    exp = level0 * w[..., :1]
+    for k, f in enumerate(coarse):
+        exp = exp + F.interpolate(M.to_ncdhw(f), size=list(dims), mode='trilinear', align_corners=False).permute(0, 2, 3, 4, 1) \
+            * w[..., k + 1:k + 2]
+    out = torch.full(level0.shape, float('nan'), device=dev)
+    _capi.blend_levels_ndhwc(level0, coarse, w, out)
+    assert not torch.isnan(out).any()
+    assert torch.allclose(out, exp, atol=5e-6, rtol=1e-5), (out - exp).abs().max()
