@@ -43,6 +43,8 @@ SIGNATURES = {
     'fbbev_layernorm': (c_int, [c_void_p] * 4 + [c_float, c_int64, c_int, c_void_p, c_void_p]),
     'fbbev_history_conv': (c_int, [c_void_p, c_int64] + [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t, c_void_p]),
     'fbbev_conv3d_ndhwc': (c_int, [c_void_p] * 4 + [c_int] * 14 + [c_void_p, c_void_p]),
+    'fbbev_conv3d_dgrad_ndhwc': (c_int, [c_void_p] * 3 + [c_int] * 12 + [c_void_p, c_void_p]),
+    'fbbev_conv3d_wgrad_ndhwc': (c_int, [c_void_p] * 2 + [c_int] * 12 + [c_void_p, c_void_p]),
     'fbbev_blend_levels_ndhwc': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p] + [c_int] * 6 + [c_void_p, c_void_p]),
     'fbbev_msda_fwd': (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_void_p, c_void_p]),
     'fbbev_point_sampling': (c_int, [c_void_p] * 9 + [c_int] * 5 + [c_float, c_float] + [c_void_p] * 4),
@@ -487,6 +489,32 @@ def conv3d_ndhwc(x, weight_fragments, bias, out, Cout, ksize=3, stride=1, pad=1,
             int(stride), int(pad), 1 if relu else 0, 1 if transposed else 0, _dev(out, F32, 'out'), _stream()),
             'fbbev_conv3d_ndhwc')
     return out
+
+
+def conv3d_dgrad_ndhwc(dy, weight_fragments_t, dx, ksize=3, stride=1, pad=1):
+    """dx (B,Di,Hi,Wi,Cin) <- data gradient of the convolution whose output gradient is dy (B,Do,Ho,Wo,Cout);
+    weight_fragments_t = mfma_conv3d.weight_fragments(weight.transpose(0, 1))."""
+    B, Do, Ho, Wo, Cout = dy.shape
+    _, Di, Hi, Wi, Cin = dx.shape
+    zero = torch.zeros((Cin + 15) // 16 * 16, dtype=F32, device=dy.device)
+    with _on(dy):
+        _check(lib().fbbev_conv3d_dgrad_ndhwc(_dev(dy, F32, 'dy'), _dev(weight_fragments_t, F32, 'weight_fragments_t'),
+                                              _dev(zero, F32, 'zero'), B, Do, Ho, Wo, Cout, Di, Hi, Wi, Cin, int(ksize), int(stride),
+                                              int(pad), _dev(dx, F32, 'dx'), _stream()), 'fbbev_conv3d_dgrad_ndhwc')
+    return dx
+
+
+def conv3d_wgrad_ndhwc(x, dy, dw, ksize=3, stride=1, pad=1):
+    """dw (ksize^3, Cout, Cin) f32, zero on entry, += sum_v dy[v] (x) x[v*stride + tap - pad]."""
+    B, Di, Hi, Wi, Cin = x.shape
+    _, Do, Ho, Wo, Cout = dy.shape
+    if tuple(dw.shape) != (ksize ** 3, Cout, Cin):
+        raise FbbevError('conv3d_wgrad_ndhwc: dw must be (ksize^3, Cout, Cin)')
+    with _on(x):
+        _check(lib().fbbev_conv3d_wgrad_ndhwc(_dev(x, F32, 'x'), _dev(dy, F32, 'dy'), B, Di, Hi, Wi, Cin, Do, Ho, Wo, Cout,
+                                              int(ksize), int(stride), int(pad), _dev(dw, F32, 'dw'), _stream()),
+               'fbbev_conv3d_wgrad_ndhwc')
+    return dw
 
 
 def blend_levels_ndhwc(level0, coarse, wsoft, out):

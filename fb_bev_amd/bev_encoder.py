@@ -17,6 +17,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.utils.checkpoint import checkpoint
 
+from .mfma_conv3d import MConv3d
+
 
 def build_norm(norm_cfg, channels, dims=3):
     """mmcv.cnn.build_norm_layer (external) for the types the FB-OCC configs use -> (state-dict abbreviation, layer).
@@ -53,7 +55,7 @@ class ConvModule(nn.Module):
                  act_cfg=dict(type='ReLU'), bias='auto', inplace=True):
         super().__init__()
         ctype = (conv_cfg or dict(type='Conv2d'))['type']
-        conv = {'Conv2d': nn.Conv2d, 'Conv3d': nn.Conv3d, 'Conv': nn.Conv2d}[ctype]
+        conv = {'Conv2d': nn.Conv2d, 'Conv3d': MConv3d, 'Conv': nn.Conv2d}[ctype]
         dims = 3 if ctype == 'Conv3d' else 2
         if bias == 'auto':
             bias = norm_cfg is None
@@ -80,11 +82,11 @@ class ConvModule(nn.Module):
 
 
 def _conv3(cin, cout, stride=1):
-    return nn.Conv3d(cin, cout, kernel_size=3, stride=stride, padding=1, bias=True)     # resnet3d.py:19-30 (BIAS = True)
+    return MConv3d(cin, cout, kernel_size=3, stride=stride, padding=1, bias=True)     # resnet3d.py:19-30 (BIAS = True)
 
 
 def _conv1(cin, cout, stride=1):
-    return nn.Conv3d(cin, cout, kernel_size=1, stride=stride, bias=True)                # :33-43
+    return MConv3d(cin, cout, kernel_size=1, stride=stride, bias=True)                # :33-43
 
 
 class BasicBlock3D(nn.Module):
@@ -135,7 +137,7 @@ class CustomResNet3D(nn.Module):
         self.channels_last, self.compute_dtype = channels_last, compute_dtype
         planes = [int(p * widen_factor) for p in block_inplanes]
         self.in_planes = planes[0]
-        self.input_proj = nn.Sequential(nn.Conv3d(n_input_channels, self.in_planes, kernel_size=1, bias=False),
+        self.input_proj = nn.Sequential(MConv3d(n_input_channels, self.in_planes, kernel_size=1, bias=False),
                                         build_norm(norm_cfg, self.in_planes)[1], nn.ReLU(inplace=True))
         self.layers = nn.ModuleList(
             self._make_layer(block, planes[i], counts[i], block_strides[i], norm_cfg) for i in range(len(planes)))

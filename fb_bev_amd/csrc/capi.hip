@@ -973,18 +973,9 @@ extern "C" int fbbev_history_conv(const float* feats, long long feats_stride_b, 
     return 0;
 }
 
-extern "C" int fbbev_conv3d_ndhwc(const float* x, const float* weight_fragments, const float* bias, const float* residual,
-                                  int B, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout, int ksize,
-                                  int stride, int pad, int relu, int transposed, float* out, fbbev_stream_t stream_) {
-    if (B < 0 || Di <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Do <= 0 || Ho <= 0 || Wo <= 0 || Cout <= 0) return FBBEV_E_BADARG;
-    if (transposed) {
-        if (Do != Di || Ho != Hi || Wo != Wi) return FBBEV_E_BADARG;
-        ksize = 1; stride = 1; pad = 0;
-    } else {
-        if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2) || pad < 0 || pad > 1) return FBBEV_E_UNSUPPORTED;
-        if (Do != (Di + 2 * pad - ksize) / stride + 1 || Ho != (Hi + 2 * pad - ksize) / stride + 1 ||
-            Wo != (Wi + 2 * pad - ksize) / stride + 1) return FBBEV_E_BADARG;
-    }
+static int conv3d_launch(const float* x, const float* weight_fragments, const float* bias, const float* residual, int B,
+                         int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout, int ksize, int stride, int pad,
+                         int relu, int mode, float* out, fbbev_stream_t stream_) {
     if (B == 0) return 0;
     if (!x || !weight_fragments || !bias || !out) return FBBEV_E_BADARG;
     if (Cin % 16 != 0 || !aligned16(x) || !aligned16(weight_fragments) || !aligned16(bias) || !aligned16(out) ||
@@ -995,18 +986,76 @@ extern "C" int fbbev_conv3d_ndhwc(const float* x, const float* weight_fragments,
     const int MT = mt_total % 4 == 0 ? 4 : (mt_total % 2 == 0 ? 2 : 1);
     const long long pstride = (long long)(Cin / 16) * mt_total * 256;
     const int gy = mt_total / MT;
-    const long long grid = gx * gy * (transposed ? 8 : 1);
+    const long long grid = gx * gy * (mode == 1 ? 8 : 1);
     if (grid >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
 #define FBBEV_CONV3D(KS_, MT_)                                                                                       \
     FBBEV_LAUNCH((k_conv3d_ndhwc<KS_, MT_>), grid, 256, 0, (fbbev_rt_stream)stream_, x, weight_fragments, bias,       \
-                 residual, out, B, Di, Hi, Wi, Cin, Do, Ho, Wo, Cout, mt_total, stride, pad, relu ? 1 : 0,            \
-                 transposed ? 1 : 0, pstride, (int)gx, gy)
-    if (ksize == 3) {
-        if (MT == 4) FBBEV_CONV3D(3, 4); else if (MT == 2) FBBEV_CONV3D(3, 2); else FBBEV_CONV3D(3, 1);
-    } else {
-        if (MT == 4) FBBEV_CONV3D(1, 4); else if (MT == 2) FBBEV_CONV3D(1, 2); else FBBEV_CONV3D(1, 1);
-    }
+                 residual, out, B, Di, Hi, Wi, Cin, Do, Ho, Wo, Cout, mt_total, stride, pad, relu ? 1 : 0, mode, pstride, \
+                 (int)gx, gy)
+#define FBBEV_CONV3D_K(KS_) do { if (MT == 4) FBBEV_CONV3D(KS_, 4); else if (MT == 2) FBBEV_CONV3D(KS_, 2); else FBBEV_CONV3D(KS_, 1); } while (0)
+    if (ksize == 3) FBBEV_CONV3D_K(3); else if (ksize == 2) FBBEV_CONV3D_K(2); else FBBEV_CONV3D_K(1);
+#undef FBBEV_CONV3D_K
 #undef FBBEV_CONV3D
+    FBBEV_CHECK_LAUNCH();
+    return 0;
+}
+
+static bool conv3d_geometry_ok(int in, int out, int ksize, int stride, int pad) { return out == (in + 2 * pad - ksize) / stride + 1; }
+
+extern "C" int fbbev_conv3d_ndhwc(const float* x, const float* weight_fragments, const float* bias, const float* residual,
+                                  int B, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout, int ksize,
+                                  int stride, int pad, int relu, int transposed, float* out, fbbev_stream_t stream_) {
+    if (B < 0 || Di <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Do <= 0 || Ho <= 0 || Wo <= 0 || Cout <= 0) return FBBEV_E_BADARG;
+    if (transposed) {
+        if (Do != Di || Ho != Hi || Wo != Wi) return FBBEV_E_BADARG;
+        ksize = 1; stride = 1; pad = 0;
+    } else {
+        if (ksize < 1 || ksize > 3 || (stride != 1 && stride != 2) || pad < 0 || pad > 1) return FBBEV_E_UNSUPPORTED;
+        if (!conv3d_geometry_ok(Di, Do, ksize, stride, pad) || !conv3d_geometry_ok(Hi, Ho, ksize, stride, pad) ||
+            !conv3d_geometry_ok(Wi, Wo, ksize, stride, pad)) return FBBEV_E_BADARG;
+    }
+    return conv3d_launch(x, weight_fragments, bias, residual, B, Di, Hi, Wi, Cin, Do, Ho, Wo, Cout, ksize, stride, pad, relu,
+                         transposed ? 1 : 0, out, stream_);
+}
+
+extern "C" int fbbev_conv3d_dgrad_ndhwc(const float* dy, const float* weight_fragments_t, const float* zero_bias, int B,
+                                        int Do, int Ho, int Wo, int Cout, int Di, int Hi, int Wi, int Cin, int ksize,
+                                        int stride, int pad, float* dx, fbbev_stream_t stream_) {
+    if (B < 0 || Di <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Do <= 0 || Ho <= 0 || Wo <= 0 || Cout <= 0) return FBBEV_E_BADARG;
+    if (ksize < 1 || ksize > 3 || (stride != 1 && stride != 2) || pad < 0 || pad > 1) return FBBEV_E_UNSUPPORTED;
+    if (!conv3d_geometry_ok(Di, Do, ksize, stride, pad) || !conv3d_geometry_ok(Hi, Ho, ksize, stride, pad) ||
+        !conv3d_geometry_ok(Wi, Wo, ksize, stride, pad)) return FBBEV_E_BADARG;
+    // gather form: the kernel's "input" is dy (Cout channels), its "output" voxels are those of dx (Cin channels)
+    return conv3d_launch(dy, weight_fragments_t, zero_bias, nullptr, B, Do, Ho, Wo, Cout, Di, Hi, Wi, Cin, ksize, stride, pad, 0,
+                         2, dx, stream_);
+}
+
+extern "C" int fbbev_conv3d_wgrad_ndhwc(const float* x, const float* dy, int B, int Di, int Hi, int Wi, int Cin, int Do,
+                                        int Ho, int Wo, int Cout, int ksize, int stride, int pad, float* dw,
+                                        fbbev_stream_t stream_) {
+    if (B < 0 || Di <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Do <= 0 || Ho <= 0 || Wo <= 0 || Cout <= 0) return FBBEV_E_BADARG;
+    if (ksize < 1 || ksize > 3 || (stride != 1 && stride != 2) || pad < 0 || pad > 1) return FBBEV_E_UNSUPPORTED;
+    if (!conv3d_geometry_ok(Di, Do, ksize, stride, pad) || !conv3d_geometry_ok(Hi, Ho, ksize, stride, pad) ||
+        !conv3d_geometry_ok(Wi, Wo, ksize, stride, pad)) return FBBEV_E_BADARG;
+    if (B == 0) return 0;
+    if (!x || !dy || !dw) return FBBEV_E_BADARG;
+    if (Cin % 4 != 0 || Cout % 4 != 0 || !aligned16(x) || !aligned16(dy)) return FBBEV_E_UNSUPPORTED;
+    const long long nvox = (long long)B * Do * Ho * Wo;
+    // voxel chunk per wave: enough chunks to fill the chip a few times over, at least 256 voxels (16 loop iterations)
+    const int cout_blocks = (Cout + 63) / 64, cin_blocks = (Cin + 63) / 64, T = ksize * ksize * ksize;
+    long long chunk = nvox / 64;
+    if (chunk < 256) chunk = 256;
+    if (chunk > 4096) chunk = 4096;
+    chunk = (chunk + 15) / 16 * 16;
+    const long long n_chunks = (nvox + chunk - 1) / chunk;
+    const long long tasks = n_chunks * cout_blocks * cin_blocks * T;
+    const long long blocks = (tasks + 3) / 4;
+    if (blocks >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
+#define FBBEV_WGRAD(KS_)                                                                                             \
+    FBBEV_LAUNCH((k_conv3d_wgrad_ndhwc<KS_>), blocks, 256, 0, (fbbev_rt_stream)stream_, x, dy, dw, B, Di, Hi, Wi, Cin, Do, \
+                 Ho, Wo, Cout, stride, pad, (int)chunk, (int)n_chunks, cout_blocks, cin_blocks)
+    if (ksize == 3) FBBEV_WGRAD(3); else if (ksize == 2) FBBEV_WGRAD(2); else FBBEV_WGRAD(1);
+#undef FBBEV_WGRAD
     FBBEV_CHECK_LAUNCH();
     return 0;
 }

@@ -33,7 +33,7 @@ template <int KS, int MT>
 __global__ void __launch_bounds__(256)
 k_conv3d_ndhwc(const float* __restrict__ x, const float* __restrict__ wf, const float* __restrict__ bias,
                const float* __restrict__ residual, float* __restrict__ out, int B, int Di, int Hi, int Wi, int Cin,
-               int Do, int Ho, int Wo, int Cout, int mt_total, int stride, int pad, int relu, int ups,
+               int Do, int Ho, int Wo, int Cout, int mt_total, int stride, int pad, int relu, int mode,
                long long wf_parity_stride, int gx, int gy) {
     constexpr int NT = 4;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -69,8 +69,18 @@ k_conv3d_ndhwc(const float* __restrict__ x, const float* __restrict__ wf, const 
         bool ok[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const int di = dq[t] * stride + kd - pad, hi = hq[t] * stride + kh - pad, wi = wq[t] * stride + kw - pad;
-            ok[t] = vq[t] && di >= 0 && di < Di && hi >= 0 && hi < Hi && wi >= 0 && wi < Wi;
+            int di, hi, wi;
+            if (mode == 2) {
+                // data gradient of a stride-s convolution: dx[i] = sum_k W_k^T dy[(i + pad - k) / s] over the taps for which
+                // the division is exact -- `x` is dy here, (Di,Hi,Wi) its extent and the "output" voxel is the dx voxel
+                const int nd = dq[t] + pad - kd, nh = hq[t] + pad - kh, nw = wq[t] + pad - kw;
+                di = nd / stride; hi = nh / stride; wi = nw / stride;
+                ok[t] = vq[t] && nd >= 0 && nh >= 0 && nw >= 0 && di * stride == nd && hi * stride == nh && wi * stride == nw &&
+                        di < Di && hi < Hi && wi < Wi;
+            } else {
+                di = dq[t] * stride + kd - pad; hi = hq[t] * stride + kh - pad; wi = wq[t] * stride + kw - pad;
+                ok[t] = vq[t] && di >= 0 && di < Di && hi >= 0 && hi < Hi && wi >= 0 && wi < Wi;
+            }
             off[t] = (ok[t] ? ((((long long)bq[t] * Di + di) * Hi + hi) * Wi + wi) * Cin : 0) + 4 * g;
         }
         const float* __restrict__ wt = wfp + (long long)tap * J * mt_total * 256;
@@ -123,7 +133,7 @@ k_conv3d_ndhwc(const float* __restrict__ x, const float* __restrict__ wf, const 
     for (int t = 0; t < NT; ++t) {
         if (!vq[t]) continue;
         long long ovox;
-        if (ups)
+        if (mode == 1)
             ovox = (((long long)bq[t] * (2 * Do) + 2 * dq[t] + pa) * (2 * Ho) + 2 * hq[t] + pb) * (2 * Wo) + 2 * wq[t] + pc;
         else
             ovox = (((long long)bq[t] * Do + dq[t]) * Ho + hq[t]) * Wo + wq[t];
@@ -207,4 +217,111 @@ k_blend_levels_ndhwc(const float* __restrict__ x0, fbbev_blend_level lv1, fbbev_
         }
         *reinterpret_cast<fbbev_v4f*>(out + vox * C + 4 * q) = acc;
     }
+}
+
+// ---------------------------------------------------------------- weight gradient (training)
+// dW[tap][cout][cin] = sum over output voxels v of dY[v][cout] * X[src(v, tap)][cin]: per tap a GEMM with M = Cout,
+// N = Cin and K = all output voxels.  A wave owns one (voxel chunk, 64 couts, 64 cins, tap) task: 16 accumulator tiles.
+// K runs over voxels, whose rows are contiguous in channels, so here the M / N labelling is permuted instead of K:
+// tile mt of the A operand holds couts {64mb + 4i + mt}, tile nt of the B operand cins {64nb + 4i + nt} (i = lane%16)
+// -- a lane's ONE float4 of dY[v][64mb + 4i ..] is its A operand for the four M tiles and ONE float4 of
+// X[src][64nb + 4i ..] its B operand for the four N tiles: 2 float4 loads (a voxel's 16 lanes read 256 contiguous bytes)
+// feed 16 MFMAs, four k-steps (16 voxels) are batched per loop iteration with the next batch in flight (ping-pong).
+// The voxel -> (b,d,h,w) decomposition is carried incrementally (v advances by 4 per k-step).  Partial sums of the
+// chunks meet in dW through fp32 atomic adds (dW is small; it must be zero on entry).  Requires Cout % 4 == Cin % 4 == 0.
+template <int KS>
+__global__ void __launch_bounds__(256)
+k_conv3d_wgrad_ndhwc(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw, int B, int Di,
+                     int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout, int stride, int pad, int chunk,
+                     int n_chunks, int cout_blocks, int cin_blocks) {
+    constexpr int T = KS * KS * KS, U = 4;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int kk = lane >> 4, i = lane & 15;
+    long long task = (long long)blockIdx.x * 4 + wave;
+    const long long n_tasks = (long long)n_chunks * cout_blocks * cin_blocks * T;
+    if (task >= n_tasks) return;
+    const int tap = (int)(task % T); task /= T;
+    const int nb = (int)(task % cin_blocks); task /= cin_blocks;
+    const int mb = (int)(task % cout_blocks);
+    const int ch = (int)(task / cout_blocks);
+    const int kd = tap / (KS * KS), kh = (tap / KS) % KS, kw = tap % KS;
+    const long long nvox = (long long)B * Do * Ho * Wo;
+    const long long v_begin = (long long)ch * chunk;
+    const long long v_end = v_begin + chunk < nvox ? v_begin + chunk : nvox;
+    const int ca = 64 * mb + 4 * i, cb = 64 * nb + 4 * i;
+    const bool a_ok = ca < Cout, b_ok = cb < Cin;
+    // this lane's voxel of k-step 0 and its coordinates
+    long long v = v_begin + kk;
+    int wq, hq, dq, bq;
+    {
+        long long r = v < nvox ? v : 0;
+        wq = (int)(r % Wo); r /= Wo;
+        hq = (int)(r % Ho); r /= Ho;
+        dq = (int)(r % Do);
+        bq = (int)(r / Do);
+    }
+    fbbev_v4f acc[4][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = fbbev_v4f{0.f, 0.f, 0.f, 0.f};
+    auto load = [&](fbbev_v4f (&af)[U], fbbev_v4f (&bf)[U], bool (&ok)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int di = dq * stride + kd - pad, hi = hq * stride + kh - pad, wi = wq * stride + kw - pad;
+            const bool vin = v < v_end;
+            const bool sin = vin && di >= 0 && di < Di && hi >= 0 && hi < Hi && wi >= 0 && wi < Wi;
+            ok[u] = sin;
+            const long long ao = (vin && a_ok) ? v * Cout + ca : 0;
+            const long long bo = (sin && b_ok) ? ((((long long)bq * Di + di) * Hi + hi) * Wi + wi) * Cin + cb : 0;
+            const fbbev_v4f ar = *reinterpret_cast<const fbbev_v4f*>(dy + ao);
+            af[u] = (vin && a_ok) ? ar : fbbev_v4f{0.f, 0.f, 0.f, 0.f};      // masked here: `vin` changes with the step
+            bf[u] = *reinterpret_cast<const fbbev_v4f*>(x + bo);
+            ok[u] = sin && b_ok;
+            v += 4;
+            wq += 4;
+            while (wq >= Wo) {
+                wq -= Wo;
+                if (++hq == Ho) { hq = 0; if (++dq == Do) { dq = 0; ++bq; } }
+            }
+        }
+    };
+    auto mma = [&](const fbbev_v4f (&af)[U], const fbbev_v4f (&braw)[U], const bool (&ok)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const fbbev_v4f bf = ok[u] ? braw[u] : fbbev_v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = fbbev_mfma_f32_16x16x4(af[u][mt], bf[nt], acc[mt][nt]);
+        }
+    };
+    const int steps = (int)((v_end - v_begin + 4 * U - 1) / (4 * U));      // iterations of U k-steps (16 voxels)
+    fbbev_v4f a0[U], b0[U], a1[U], b1[U];
+    bool k0[U], k1[U];
+    load(a0, b0, k0);
+    for (int s = 0; s < steps; s += 2) {
+        load(a1, b1, k1);                        // beyond the chunk every lane is masked: harmless, no branch
+        fbbev_sched_fence();
+        mma(a0, b0, k0);
+        fbbev_sched_fence();
+        load(a0, b0, k0);
+        fbbev_sched_fence();
+        mma(a1, b1, k1);
+        fbbev_sched_fence();
+    }
+    // D register r of a lane: row 4*kk + r -> cout 64mb + 4(4kk + r) + mt ; column i -> cin 64nb + 4i + nt
+    float* dwt = dw + (long long)tap * Cout * Cin;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = 64 * mb + 4 * (4 * kk + r) + mt;
+            if (co >= Cout) continue;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int ci = cb + nt;
+                if (ci < Cin) fbbev_atomic_add_f32(dwt + (long long)co * Cin + ci, acc[mt][nt][r]);
+            }
+        }
 }

@@ -60,7 +60,8 @@ class FBOCC(nn.Module):
         """execution (not part of the reference config): dict(img_dtype=, depth_dtype=, voxel_dtype=, head_dtype=) with
         values 'f32' | 'bf16' -- compute dtype of the four convolution stacks (default fp32 everywhere; the shipped
         config trains them under mmcv's fp16 hook, cfg :394) -- and with_cp=True|False to override the blocks'
-        activation checkpointing (the configs turn it on to fit 16-32 GB parts; 288 GB of HBM does not need it)."""
+        activation checkpointing (the configs turn it on to fit 16-32 GB parts; 288 GB of HBM does not need it);
+        mfma_conv3d / mfma_conv3d_train=True route the voxel encoder + head through fbbev_conv3d_* (mfma_conv3d.py)."""
         super().__init__()
         if frpn is not None or pts_bbox_head is not None:
             raise NotImplementedError('frpn / pts_bbox_head are None in every fb_occ config (fbocc.py:86-88 "not used in FB-OCC")')
@@ -92,6 +93,11 @@ class FBOCC(nn.Module):
         # CPU emulator only so far, hence off by default)
         self.mfma_conv3d = bool(ex.get('mfma_conv3d', False))
         self._runners = None
+        if ex.get('mfma_conv3d_train'):           # same status: the autograd route (forward + dgrad + wgrad kernels)
+            from .mfma_conv3d import enable_training_route
+            for blk in (self.img_bev_encoder_backbone, self.img_bev_encoder_neck, self.occupancy_head):
+                if blk is not None:
+                    enable_training_route(blk, True)
 
     # ------------------------------------------------------------------ plumbing
     @property

@@ -88,6 +88,130 @@ class FoldedConv3d:
                    residual=residual, transposed=self.transposed)
 
 
+# ------------------------------------------------------------------ training route (autograd)
+def _supported_train(conv, x):
+    if isinstance(conv, nn.ConvTranspose3d):
+        cin, cout = conv.in_channels, conv.out_channels
+        ok = (conv.kernel_size, conv.stride, conv.padding, conv.output_padding) == ((2, 2, 2), (2, 2, 2), (0, 0, 0), (0, 0, 0))
+    else:
+        cin, cout = conv.in_channels, conv.out_channels
+        k, s, p = conv.kernel_size, conv.stride, conv.padding
+        ok = len(set(k)) == len(set(s)) == len(set(p)) == 1 and k[0] in (1, 3) and s[0] in (1, 2) and p[0] in (0, 1) \
+            and set(conv.dilation) == {1} and conv.padding_mode == 'zeros'
+    return ok and conv.groups == 1 and cin % 16 == 0 and cout % 16 == 0 and x.dtype == torch.float32
+
+
+class _Conv3dFn(torch.autograd.Function):
+    """Conv3d on NDHWC f32: forward fbbev_conv3d_ndhwc, backward fbbev_conv3d_dgrad_ndhwc + fbbev_conv3d_wgrad_ndhwc."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, ksize, stride, pad, backends):
+        fwd = backends[0] if backends else _capi.conv3d_ndhwc
+        cout = weight.shape[0]
+        b = torch.zeros((cout + 15) // 16 * 16, dtype=torch.float32, device=x.device)
+        if bias is not None:
+            b[:cout] = bias.detach()
+        B, D, H, W, _ = x.shape
+        f = lambda n: (n + 2 * pad - ksize) // stride + 1  # noqa: E731
+        out = torch.empty((B, f(D), f(H), f(W), cout), dtype=torch.float32, device=x.device)
+        out = fwd(x, weight_fragments(weight.detach()), b, out, cout, ksize=ksize, stride=stride, pad=pad)
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (ksize, stride, pad, bias is not None, backends)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        ksize, stride, pad, has_bias, backends = ctx.cfg
+        dgrad = backends[1] if backends else _capi.conv3d_dgrad_ndhwc
+        wgrad = backends[2] if backends else _capi.conv3d_wgrad_ndhwc
+        dy = dy.contiguous().float()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = dgrad(dy, weight_fragments(weight.detach().transpose(0, 1)), torch.empty_like(x), ksize=ksize, stride=stride, pad=pad)
+        if ctx.needs_input_grad[1]:
+            cout, cin = weight.shape[:2]
+            dwt = wgrad(x, dy, torch.zeros((ksize ** 3, cout, cin), dtype=torch.float32, device=x.device), ksize=ksize,
+                        stride=stride, pad=pad)
+            dw = dwt.view(ksize, ksize, ksize, cout, cin).permute(3, 4, 0, 1, 2).contiguous()
+        if has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum((0, 1, 2, 3))
+        return dx, dw, db, None, None, None, None
+
+
+class _ConvTranspose3dFn(torch.autograd.Function):
+    """ConvTranspose3d(k=2, s=2, p=0) on NDHWC f32.  Its data gradient is a kernel-2 stride-2 convolution of dy with the
+    same weight read as (out=Cin, in=Cout, 2,2,2); its weight gradient the wgrad of that convolution (x := dy fine,
+    dy := x coarse)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, backends):
+        fwd = backends[0] if backends else _capi.conv3d_ndhwc
+        cout = weight.shape[1]
+        b = torch.zeros((cout + 15) // 16 * 16, dtype=torch.float32, device=x.device)
+        if bias is not None:
+            b[:cout] = bias.detach()
+        B, D, H, W, _ = x.shape
+        out = torch.empty((B, 2 * D, 2 * H, 2 * W, cout), dtype=torch.float32, device=x.device)
+        out = fwd(x, weight_fragments(weight.detach(), transposed=True), b, out, cout, transposed=True)
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (bias is not None, backends)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        has_bias, backends = ctx.cfg
+        fwd = backends[0] if backends else _capi.conv3d_ndhwc
+        wgrad = backends[2] if backends else _capi.conv3d_wgrad_ndhwc
+        dy = dy.contiguous().float()
+        cin, cout = weight.shape[:2]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            zero = torch.zeros((cin + 15) // 16 * 16, dtype=torch.float32, device=x.device)
+            dx = fwd(dy, weight_fragments(weight.detach()), zero, torch.empty_like(x), cin, ksize=2, stride=2, pad=0)
+        if ctx.needs_input_grad[1]:
+            dwt = wgrad(dy, x, torch.zeros((8, cin, cout), dtype=torch.float32, device=x.device), ksize=2, stride=2, pad=0)
+            dw = dwt.view(2, 2, 2, cin, cout).permute(3, 4, 0, 1, 2).contiguous()
+        if has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum((0, 1, 2, 3))
+        return dx, dw, db, None
+
+
+class MConv3d(nn.Conv3d):
+    """nn.Conv3d whose forward can take the fp32-MFMA route under autograd (`mfma = True`, set by
+    enable_training_route); parameters, state-dict names and the default behaviour are nn.Conv3d's."""
+    mfma = False
+    backends = None            # tests: (forward, dgrad, wgrad) callables standing in for the HIP entry points
+
+    def forward(self, x):
+        if self.mfma and (x.is_cuda or self.backends) and not torch.is_autocast_enabled() and _supported_train(self, x):
+            y = _Conv3dFn.apply(to_ndhwc(x), self.weight, self.bias, self.kernel_size[0], self.stride[0], self.padding[0],
+                                self.backends)
+            return to_ncdhw(y)
+        return super().forward(x)
+
+
+class MConvTranspose3d(nn.ConvTranspose3d):
+    mfma = False
+    backends = None
+
+    def forward(self, x, output_size=None):
+        if self.mfma and (x.is_cuda or self.backends) and not torch.is_autocast_enabled() and _supported_train(self, x):
+            return to_ncdhw(_ConvTranspose3dFn.apply(to_ndhwc(x), self.weight, self.bias, self.backends))
+        return super().forward(x, output_size)
+
+
+def enable_training_route(module, on=True, backends=None):
+    """Switch every supported 3-D convolution below `module` to the MFMA autograd route (or back)."""
+    n = 0
+    for m in module.modules():
+        if isinstance(m, (MConv3d, MConvTranspose3d)):
+            m.mfma, m.backends = bool(on), backends
+            n += 1
+    return n
+
+
 def to_ndhwc(x):
     """(B,C,D,H,W) logical -> (B,D,H,W,C) contiguous (free when x is channels_last_3d)."""
     return x.permute(0, 2, 3, 4, 1).contiguous().float()

@@ -15,15 +15,16 @@ from torch.utils.checkpoint import checkpoint
 
 from . import occ_loss as L
 from .bev_encoder import build_norm
+from .mfma_conv3d import MConv3d, MConvTranspose3d
 
 
 def _conv(conv_cfg, cin, cout, k, stride=1, padding=0):
     cfg = dict(conv_cfg)
     typ = cfg.pop('type')
     if typ == 'Conv3d':
-        return nn.Conv3d(cin, cout, k, stride=stride, padding=padding, **cfg)
+        return MConv3d(cin, cout, k, stride=stride, padding=padding, **cfg)
     if typ == 'deconv3d':
-        return nn.ConvTranspose3d(cin, cout, k, stride=stride, padding=padding, **cfg)
+        return MConvTranspose3d(cin, cout, k, stride=stride, padding=padding, **cfg)
     raise KeyError(typ)
 
 

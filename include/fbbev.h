@@ -330,7 +330,7 @@ int fbbev_history_conv(const float* feats, long long feats_stride_b, const float
  * 78-102), FPN3D (fpn3d.py:50-70) and OccHead (occupancy_head.py:82-141), which the reference runs in fp32 through the
  * vendor library.
  *   x (B,Di,Hi,Wi,Cin), out (B,Do,Ho,Wo,Cout) [transposed: (B,2Di,2Hi,2Wi,Cout)], residual like out or NULL.
- *   ksize 1 or 3, one stride (1|2) and padding for the three axes, Do = (Di + 2 pad - ksize) / stride + 1 (checked).
+ *   ksize 1, 2 or 3, one stride (1|2) and padding (0|1) for the three axes, Do = (Di + 2 pad - ksize) / stride + 1 (checked).
  *   transposed != 0: ConvTranspose3d kernel 2 stride 2 padding 0 (the head's deblock); ksize/stride/pad are ignored,
  *   Do,Ho,Wo must equal Di,Hi,Wi.
  *   weight_fragments: the weights in MFMA A-fragment order with the batch norm folded in,
@@ -342,6 +342,24 @@ int fbbev_history_conv(const float* feats, long long feats_stride_b, const float
 int fbbev_conv3d_ndhwc(const float* x, const float* weight_fragments, const float* bias, const float* residual, int B,
                        int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout, int ksize, int stride, int pad,
                        int relu, int transposed, float* out, fbbev_stream_t stream);
+
+/* Data gradient of fbbev_conv3d_ndhwc's convolution (training): dx[i] = sum_k W_k^T dy[(i + pad - k) / stride] over the
+ * taps for which the division is exact.  dy (B,Do,Ho,Wo,Cout), dx (B,Di,Hi,Wi,Cin) with the forward geometry (checked);
+ * weight_fragments_t = the fragment layout of the TRANSPOSED weight (Cin, Cout, k, k, k) -- same tap index;
+ * zero_bias: ceil(Cin/16)*16 zeros.  Cout % 16 == 0.  (The data gradient of the head's ConvTranspose3d(k=2,s=2) is the
+ * forward entry point itself with ksize 2, stride 2, pad 0 on the deconvolution weight read as (out=Cin, in=Cout,2,2,2).) */
+int fbbev_conv3d_dgrad_ndhwc(const float* dy, const float* weight_fragments_t, const float* zero_bias, int B, int Do,
+                             int Ho, int Wo, int Cout, int Di, int Hi, int Wi, int Cin, int ksize, int stride, int pad,
+                             float* dx, fbbev_stream_t stream);
+
+/* Weight gradient of fbbev_conv3d_ndhwc's convolution (training):
+ *   dw[tap][cout][cin] += sum over output voxels v of dy[v][cout] * x[v * stride + tap - pad][cin]
+ * x (B,Di,Hi,Wi,Cin), dy (B,Do,Ho,Wo,Cout) NDHWC f32 with the forward geometry (checked); dw (ksize^3, Cout, Cin) f32,
+ * ZERO on entry (voxel chunks meet through fp32 atomic adds; tap = (kd*k + kh)*k + kw).  Cin % 4 == Cout % 4 == 0.
+ * (For the head's ConvTranspose3d(k=2,s=2) call it with x := the fine output gradient, dy := the coarse input,
+ *  ksize 2, stride 2, pad 0: dw[tap][cin_deconv][cout_deconv].) */
+int fbbev_conv3d_wgrad_ndhwc(const float* x, const float* dy, int B, int Di, int Hi, int Wi, int Cin, int Do, int Ho,
+                             int Wo, int Cout, int ksize, int stride, int pad, float* dw, fbbev_stream_t stream);
 
 /* Soft-weighted multi-level blend of the occupancy head on NDHWC f32 (inference): replaces the F.interpolate(trilinear,
  * align_corners=False) + `out += feats * weights` loop of OccHead.forward_coarse_voxel (occupancy_head.py:159-170).

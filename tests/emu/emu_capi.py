@@ -275,3 +275,19 @@ def blend_levels_ndhwc(level0, coarse, wsoft):
     code = lib().fbbev_blend_levels_ndhwc(p(level0), ctypes.cast(ptrs, c_void_p), ctypes.cast(dims, c_void_p), n, p(wsoft),
                                           int(wsoft.shape[4]), B, D, H, W, C, p(out), None)
     return code, out
+
+
+def conv3d_dgrad_ndhwc(dy, wft, in_dims, Cin, ksize=3, stride=1, pad=1):
+    B, Do, Ho, Wo, Cout = dy.shape
+    dx = torch.full((B, *in_dims, Cin), float('nan'))
+    zero = torch.zeros((Cin + 15) // 16 * 16)
+    code = lib().fbbev_conv3d_dgrad_ndhwc(p(dy), p(wft), p(zero), B, Do, Ho, Wo, Cout, *in_dims, Cin, ksize, stride, pad, p(dx), None)
+    return code, dx
+
+
+def conv3d_wgrad_ndhwc(x, dy, ksize=3, stride=1, pad=1):
+    B, Di, Hi, Wi, Cin = x.shape
+    _, Do, Ho, Wo, Cout = dy.shape
+    dw = torch.zeros(ksize ** 3, Cout, Cin)
+    code = lib().fbbev_conv3d_wgrad_ndhwc(p(x), p(dy), B, Di, Hi, Wi, Cin, Do, Ho, Wo, Cout, ksize, stride, pad, p(dw), None)
+    return code, dw

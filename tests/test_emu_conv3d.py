@@ -72,6 +72,48 @@ def test_conv3d_argument_checks():
     assert code == -1
 
 
+@pytest.mark.parametrize('B,dims,Cin,Cout,k,s,p', [
+    (1, (5, 6, 3), 16, 16, 3, 1, 1),
+    (2, (6, 6, 4), 16, 32, 3, 2, 1),          # stride 2: taps selected by parity
+    (1, (5, 7, 3), 32, 16, 3, 2, 1),          # odd extents: the last input plane gets no gradient from some taps
+    (1, (4, 4, 2), 48, 16, 1, 1, 0),
+    (1, (6, 4, 4), 16, 80, 1, 2, 0),          # strided 1x1x1: 7/8 of the dx voxels are exactly zero
+    (2, (3, 4, 2), 16, 32, 2, 2, 0),          # kernel 2 stride 2 (the data gradient of the head's deconvolution, see below)
+])
+def test_conv3d_dgrad_and_wgrad_vs_torch_autograd(B, dims, Cin, Cout, k, s, p):
+    g = torch.Generator().manual_seed(Cin + 7 * Cout + k)
+    dims = tuple(d if (d + 2 * p - k) // s + 1 > 0 else k for d in dims)
+    if k == 2:
+        dims = tuple(2 * ((d + 1) // 2) for d in dims)                  # kernel 2 stride 2 tiles the input exactly
+    x = torch.randn(B, Cin, *dims, generator=g, requires_grad=True)
+    w = (torch.randn(Cout, Cin, k, k, k, generator=g) / (Cin * k ** 3) ** 0.5).requires_grad_()
+    y = F.conv3d(x, w, None, stride=s, padding=p)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    code, dx = E.conv3d_dgrad_ndhwc(M.to_ndhwc(dy), M.weight_fragments(w.detach().transpose(0, 1)), dims, Cin, ksize=k, stride=s, pad=p)
+    assert code == 0 and not torch.isnan(dx).any()
+    assert torch.allclose(M.to_ncdhw(dx), x.grad, atol=1e-4, rtol=1e-4), (M.to_ncdhw(dx) - x.grad).abs().max()
+    code, dw = E.conv3d_wgrad_ndhwc(M.to_ndhwc(x.detach()), M.to_ndhwc(dy), ksize=k, stride=s, pad=p)
+    assert code == 0
+    got = dw.view(k, k, k, Cout, Cin).permute(3, 4, 0, 1, 2)
+    assert torch.allclose(got, w.grad, atol=2e-4, rtol=1e-4), (got - w.grad).abs().max()
+
+
+def test_wgrad_many_chunks_and_channel_tails():
+    """> 256 voxels per chunk boundary, Cout / Cin not multiples of 64 (80 and 20), two samples."""
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 20, 12, 10, 6, generator=g, requires_grad=False)
+    w = torch.randn(80, 20, 3, 3, 3, generator=g, requires_grad=True)
+    y = F.conv3d(x, w, None, stride=1, padding=1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    code, dw = E.conv3d_wgrad_ndhwc(M.to_ndhwc(x), M.to_ndhwc(dy))
+    assert code == 0
+    got = dw.view(3, 3, 3, 80, 20).permute(3, 4, 0, 1, 2)
+    assert torch.allclose(got, w.grad, atol=1e-3, rtol=1e-4), (got - w.grad).abs().max()
+    assert E.conv3d_wgrad_ndhwc(torch.zeros(1, 2, 2, 2, 6), torch.zeros(1, 2, 2, 2, 8))[0] == -2      # Cin % 4
+
+
 def emu_blend(level0, coarse, wsoft, out):
     code, y = E.blend_levels_ndhwc(level0.contiguous(), coarse, wsoft)
     assert code == 0 and not torch.isnan(y).any()
@@ -182,3 +224,55 @@ def test_detector_opt_in_route_equals_module_route(monkeypatch):
     assert (got_ids == ref_raw.argmax(-1)).float().mean() > 0.999
     m.train()
     assert m._runners is None                                                     # folded weights dropped with the mode
+
+
+def emu_dgrad(dy, wft, dx, ksize=3, stride=1, pad=1):
+    code, y = E.conv3d_dgrad_ndhwc(dy.contiguous(), wft, tuple(dx.shape[1:4]), dx.shape[4], ksize=ksize, stride=stride, pad=pad)
+    assert code == 0 and not torch.isnan(y).any()
+    return y
+
+
+def emu_wgrad(x, dy, dw, ksize=3, stride=1, pad=1):
+    code, y = E.conv3d_wgrad_ndhwc(x.contiguous(), dy.contiguous(), ksize=ksize, stride=stride, pad=pad)
+    assert code == 0 and tuple(y.shape) == tuple(dw.shape)
+    return y
+
+
+def test_training_route_gradients_equal_torch_autograd():
+    """CustomResNet3D -> FPN3D -> OccHead in TRAIN mode (batch-statistics BN between the convolutions stays torch):
+    forward, input gradient and every parameter gradient through the MFMA autograd route == the nn.Conv3d route."""
+    import copy
+    from fb_bev_amd.bev_encoder import CustomResNet3D, FPN3D
+    from fb_bev_amd.occ_head import OccHead
+    torch.manual_seed(0)
+    chans = [16, 32, 32]
+    net = nn.ModuleDict(dict(
+        bb=CustomResNet3D(depth=10, block_strides=[1, 2, 2], n_input_channels=16, block_inplanes=chans, out_indices=(0, 1, 2),
+                          norm_cfg=dict(type='SyncBN')),
+        neck=FPN3D(in_channels=chans, out_channels=64, norm_cfg=dict(type='SyncBN')),
+        head=OccHead(in_channels=[64] * 3, out_channel=19, num_level=3, soft_weights=True, use_focal_loss=False,
+                     norm_cfg=dict(type='SyncBN'), final_occ_size=[16, 16, 8], empty_idx=18))).train()
+    ref = copy.deepcopy(net)
+    n = M.enable_training_route(net, True, backends=(emu_backend, emu_dgrad, emu_wgrad))
+    assert n == sum(isinstance(m, (nn.Conv3d, nn.ConvTranspose3d)) for m in net.modules())
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 16, 8, 8, 4, generator=g)
+    wgt = torch.randn(2, 19, 16, 16, 8, generator=g)
+    outs = []
+    for mod in (net, ref):
+        xi = x.clone().requires_grad_()
+        o = mod['head'](mod['neck'](mod['bb'](xi)))['output_voxels'][0]
+        (o * wgt).sum().backward()
+        outs.append((o.detach(), xi.grad))
+    assert torch.allclose(outs[0][0], outs[1][0], atol=2e-4, rtol=1e-4)
+    scale = outs[1][1].abs().max()
+    assert (outs[0][1] - outs[1][1]).abs().max() <= 2e-4 * scale
+    for (name, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        assert p.grad is not None and q.grad is not None, name
+        # absolute floor: a conv bias in front of a batch-statistics BN has an analytically zero gradient (rounding noise)
+        tol = 3e-4 * q.grad.abs().max() + 2e-4
+        assert (p.grad - q.grad).abs().max() <= tol, (name, float((p.grad - q.grad).abs().max()), float(tol))
+    # the two tiny output convolutions (19 / 4 channels) are not multiples of 16 and stay on the library route
+    assert not M._supported_train(net['head'].occ_pred_conv[3], x) and M._supported_train(net['head'].occ_pred_conv[0], x)
+    M.enable_training_route(net, False)
+    assert not any(getattr(m, 'mfma', False) for m in net.modules())

@@ -90,3 +90,40 @@ def test_blend_levels_vs_torch_interpolate(dev):
     _capi.blend_levels_ndhwc(level0, coarse, w, out)
     assert not torch.isnan(out).any()
     assert torch.allclose(out, exp, atol=5e-6, rtol=1e-5), (out - exp).abs().max()
+
+
+@pytest.mark.parametrize('B,dims,Cin,Cout,k,s,p', [(1, (50, 50, 4), 64, 64, 3, 1, 1), (2, (20, 20, 8), 64, 128, 3, 2, 1),
+                                                   (1, (21, 9, 5), 32, 80, 1, 2, 0), (1, (10, 10, 4), 128, 64, 2, 2, 0)])
+def test_dgrad_wgrad_vs_torch_autograd(dev, B, dims, Cin, Cout, k, s, p):
+    from fb_bev_amd import _capi, mfma_conv3d as M
+    g = torch.Generator().manual_seed(Cin + Cout)
+    x = torch.randn(B, Cin, *dims, generator=g).to(dev).double().requires_grad_()
+    w = (torch.randn(Cout, Cin, k, k, k, generator=g) / (Cin * k ** 3) ** 0.5).to(dev).double().requires_grad_()
+    y = F.conv3d(x, w, None, stride=s, padding=p)
+    dy = torch.randn(y.shape, generator=g).to(dev)
+    y.backward(dy.double())
+    dx = torch.full((B, *dims, Cin), float('nan'), device=dev)
+    _capi.conv3d_dgrad_ndhwc(M.to_ndhwc(dy), M.weight_fragments(w.detach().float().transpose(0, 1)), dx, ksize=k, stride=s, pad=p)
+    assert torch.allclose(M.to_ncdhw(dx).double(), x.grad, atol=1e-4, rtol=1e-4)
+    dw = torch.zeros(k ** 3, Cout, Cin, device=dev)
+    _capi.conv3d_wgrad_ndhwc(M.to_ndhwc(x.detach().float()), M.to_ndhwc(dy), dw, ksize=k, stride=s, pad=p)
+    got = dw.view(k, k, k, Cout, Cin).permute(3, 4, 0, 1, 2).double()
+    assert (got - w.grad).abs().max() <= 2e-4 * w.grad.abs().max() + 1e-4
+
+
+def test_training_route_equals_vendor_route(dev):
+    import copy
+    import test_gpu_full_model as T
+    from fb_bev_amd import mfma_conv3d as M
+    m = T._small_model(dev, neck_channels=64).train()
+    ref = copy.deepcopy(m)
+    for blk in (m.img_bev_encoder_backbone, m.img_bev_encoder_neck, m.occupancy_head):
+        M.enable_training_route(blk, True)
+    img_inputs, metas, gt_occ, gt_depth = T._inputs(dev, 2, seed=3)
+    grads = []
+    for mod in (m, ref):
+        losses = mod(return_loss=True, img_inputs=img_inputs, img_metas=metas(True), gt_occupancy=gt_occ, gt_depth=gt_depth)
+        mod.parse_losses(losses).backward()
+        grads.append({n: p.grad for n, p in mod.named_parameters() if p.grad is not None})
+    for n, gref in grads[1].items():
+        assert (grads[0][n] - gref).abs().max() <= 2e-3 * gref.abs().max() + 1e-4, n

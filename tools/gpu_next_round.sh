@@ -13,7 +13,7 @@ echo "conv3d tests rc=$?"; grep -E "passed|failed|Error|crashed" $OUT/conv3d_tes
 for mode in "1 f32" "1 bf16" "1 f32 mfma" "4 bf16" "4 f32 mfma"; do
   timeout -k 5 120 python tools/time_full.py infer $mode 2>> $OUT/time_full.err | tail -1 | tee -a $OUT/time_full.jsonl
 done
-for mode in "2 f32" "4 bf16"; do
+for mode in "2 f32" "2 f32 mfma" "4 bf16"; do
   timeout -k 5 240 python tools/time_full.py train $mode 2>> $OUT/time_full.err | tail -1 | tee -a $OUT/time_full.jsonl
 done
 cd /tmp

@@ -5,7 +5,7 @@ with random-init weights and synthetic inputs of SURVEY Appendix B.
 
     python tools/time_full.py infer B [f32|bf16] [mfma]   S4: images -> occupancy class ids (device), per-stage split;
                                                           mfma = voxel encoder + head on fbbev_conv3d_ndhwc (fp32 MFMA)
-    python tools/time_full.py train B [f32|bf16]      S5: forward_train + backward + grad all-reduce + clip + AdamW step
+    python tools/time_full.py train B [f32|bf16] [mfma]   S5: forward_train + backward + grad all-reduce + clip + AdamW step
 
 bf16 = convolution stacks (image encoder, depth net, voxel encoder, head) under bf16 autocast; the view transformation,
 history fusion and losses stay fp32.  Prints one JSON line.
@@ -23,11 +23,11 @@ from fb_bev_amd import shard, synthetic as S  # noqa: E402
 from fb_bev_amd.fbocc import FBOCC  # noqa: E402
 
 
-def build(dtype, with_cp=False, mfma=False):
+def build(dtype, with_cp=False, mfma=False, mfma_train=False):
     cfg = dict(json.load(open(os.path.join(ROOT, 'tests', 'golden', 'fbocc_config_path_blocks.json')))
                ['fbocc-r50-cbgs_depth_16f_16x4_20e.py']['model'])
     cfg.pop('type')
-    ex = dict(with_cp=with_cp, mfma_conv3d=mfma)
+    ex = dict(with_cp=with_cp, mfma_conv3d=mfma, mfma_conv3d_train=mfma_train)
     if dtype == 'bf16':
         ex.update(img_dtype='bf16', depth_dtype='bf16', voxel_dtype='bf16', head_dtype='bf16')
     torch.manual_seed(0)
@@ -106,9 +106,9 @@ def infer(B, dtype, mfma=False):
     print(json.dumps(out))
 
 
-def train(B, dtype):
+def train(B, dtype, mfma=False):
     dev = torch.device('cuda:0')
-    m = build(dtype).to(dev).train()
+    m = build(dtype, mfma_train=mfma).to(dev).train()
     img_inputs, metas, gt_occ, gt_depth = inputs(B, dev)
     params = [p for p in m.parameters() if p.requires_grad]
     opt = torch.optim.AdamW(params, lr=2e-4, weight_decay=1e-2)                  # cfg :360-362
@@ -140,7 +140,7 @@ def train(B, dtype):
     finally:
         torch.cuda.set_sync_debug_mode('default')
     torch.cuda.synchronize()
-    print(json.dumps(dict(scope='S5 training step', B=B, conv_dtype=dtype, ms_step=round(med, 3),
+    print(json.dumps(dict(scope='S5 training step', B=B, conv_dtype=dtype, mfma_conv3d_train=mfma, ms_step=round(med, 3),
                           ms_p10_p90=[round(p10, 3), round(p90, 3)], samples_per_s=round(1e3 * B / med, 2),
                           loss=round(float(total), 4), losses={k: round(float(v), 4) for k, v in losses.items()},
                           step_without_host_sync=sync_free, first_sync=why, n_params=sum(p.numel() for p in params),
@@ -154,4 +154,4 @@ if __name__ == '__main__':
     if mode == 'infer':
         infer(B, dtype, mfma=len(sys.argv) > 4 and sys.argv[4] == 'mfma')
     else:
-        train(B, dtype)
+        train(B, dtype, mfma=len(sys.argv) > 4 and sys.argv[4] == 'mfma')
