@@ -43,6 +43,7 @@ SIGNATURES = {
     'fbbev_layernorm': (c_int, [c_void_p] * 4 + [c_float, c_int64, c_int, c_void_p, c_void_p]),
     'fbbev_history_conv': (c_int, [c_void_p, c_int64] + [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t, c_void_p]),
     'fbbev_conv3d_ndhwc': (c_int, [c_void_p] * 4 + [c_int] * 14 + [c_void_p, c_void_p]),
+    'fbbev_conv2d_nhwc': (c_int, [c_void_p] * 4 + [c_int] * 11 + [c_void_p, c_void_p]),
     'fbbev_conv3d_dgrad_ndhwc': (c_int, [c_void_p] * 3 + [c_int] * 12 + [c_void_p, c_void_p]),
     'fbbev_conv3d_wgrad_ndhwc': (c_int, [c_void_p] * 2 + [c_int] * 12 + [c_void_p, c_void_p]),
     'fbbev_blend_levels_ndhwc': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p] + [c_int] * 6 + [c_void_p, c_void_p]),
@@ -488,6 +489,20 @@ def conv3d_ndhwc(x, weight_fragments, bias, out, Cout, ksize=3, stride=1, pad=1,
             None if residual is None else _dev(residual, F32, 'residual'), B, Di, Hi, Wi, Cin, Do, Ho, Wo, int(Cout), int(ksize),
             int(stride), int(pad), 1 if relu else 0, 1 if transposed else 0, _dev(out, F32, 'out'), _stream()),
             'fbbev_conv3d_ndhwc')
+    return out
+
+
+def conv2d_nhwc(x, weight_fragments, bias, out, Cout, ksize=3, stride=1, pad=1, relu=False, residual=None):
+    """x (B,H,W,Cin) f32 contiguous (NHWC); out (B,Ho,Wo,Cout); weights as mfma_conv3d.weight_fragments(w[:, :, None])."""
+    B, Hi, Wi, Cin = x.shape
+    Ho, Wo = [(n + 2 * pad - ksize) // stride + 1 for n in (Hi, Wi)]
+    if tuple(out.shape) != (B, Ho, Wo, Cout) or (residual is not None and tuple(residual.shape) != (B, Ho, Wo, Cout)):
+        raise FbbevError(f'conv2d_nhwc: out / residual must be {(B, Ho, Wo, Cout)}')
+    with _on(x):
+        _check(lib().fbbev_conv2d_nhwc(
+            _dev(x, F32, 'x'), _dev(weight_fragments, F32, 'weight_fragments'), _dev(bias, F32, 'bias'),
+            None if residual is None else _dev(residual, F32, 'residual'), B, Hi, Wi, Cin, Ho, Wo, int(Cout), int(ksize), int(stride),
+            int(pad), 1 if relu else 0, _dev(out, F32, 'out'), _stream()), 'fbbev_conv2d_nhwc')
     return out
 
 

@@ -975,7 +975,7 @@ extern "C" int fbbev_history_conv(const float* feats, long long feats_stride_b, 
 
 static int conv3d_launch(const float* x, const float* weight_fragments, const float* bias, const float* residual, int B,
                          int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout, int ksize, int stride, int pad,
-                         int relu, int mode, float* out, fbbev_stream_t stream_) {
+                         int relu, int mode, float* out, fbbev_stream_t stream_, bool planar = false) {
     if (B == 0) return 0;
     if (!x || !weight_fragments || !bias || !out) return FBBEV_E_BADARG;
     if (Cin % 16 != 0 || !aligned16(x) || !aligned16(weight_fragments) || !aligned16(bias) || !aligned16(out) ||
@@ -988,12 +988,13 @@ static int conv3d_launch(const float* x, const float* weight_fragments, const fl
     const int gy = mt_total / MT;
     const long long grid = gx * gy * (mode == 1 ? 8 : 1);
     if (grid >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
-#define FBBEV_CONV3D(KS_, MT_)                                                                                       \
-    FBBEV_LAUNCH((k_conv3d_ndhwc<KS_, MT_>), grid, 256, 0, (fbbev_rt_stream)stream_, x, weight_fragments, bias,       \
+#define FBBEV_CONV3D(KD_, KS_, MT_)                                                                                      \
+    FBBEV_LAUNCH((k_conv3d_ndhwc<KD_, KS_, MT_>), grid, 256, 0, (fbbev_rt_stream)stream_, x, weight_fragments, bias,  \
                  residual, out, B, Di, Hi, Wi, Cin, Do, Ho, Wo, Cout, mt_total, stride, pad, relu ? 1 : 0, mode, pstride, \
                  (int)gx, gy)
-#define FBBEV_CONV3D_K(KS_) do { if (MT == 4) FBBEV_CONV3D(KS_, 4); else if (MT == 2) FBBEV_CONV3D(KS_, 2); else FBBEV_CONV3D(KS_, 1); } while (0)
-    if (ksize == 3) FBBEV_CONV3D_K(3); else if (ksize == 2) FBBEV_CONV3D_K(2); else FBBEV_CONV3D_K(1);
+#define FBBEV_CONV3D_K(KD_, KS_) do { if (MT == 4) FBBEV_CONV3D(KD_, KS_, 4); else if (MT == 2) FBBEV_CONV3D(KD_, KS_, 2); else FBBEV_CONV3D(KD_, KS_, 1); } while (0)
+    if (ksize == 3 && planar) FBBEV_CONV3D_K(1, 3); else if (ksize == 3) FBBEV_CONV3D_K(3, 3); else if (ksize == 2) FBBEV_CONV3D_K(2, 2);
+    else FBBEV_CONV3D_K(1, 1);
 #undef FBBEV_CONV3D_K
 #undef FBBEV_CONV3D
     FBBEV_CHECK_LAUNCH();
@@ -1016,6 +1017,17 @@ extern "C" int fbbev_conv3d_ndhwc(const float* x, const float* weight_fragments,
     }
     return conv3d_launch(x, weight_fragments, bias, residual, B, Di, Hi, Wi, Cin, Do, Ho, Wo, Cout, ksize, stride, pad, relu,
                          transposed ? 1 : 0, out, stream_);
+}
+
+extern "C" int fbbev_conv2d_nhwc(const float* x, const float* weight_fragments, const float* bias, const float* residual,
+                                 int B, int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int ksize, int stride, int pad,
+                                 int relu, float* out, fbbev_stream_t stream_) {
+    if (B < 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Ho <= 0 || Wo <= 0 || Cout <= 0) return FBBEV_E_BADARG;
+    if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2) || pad < 0 || pad > 1) return FBBEV_E_UNSUPPORTED;
+    if (!conv3d_geometry_ok(Hi, Ho, ksize, stride, pad) || !conv3d_geometry_ok(Wi, Wo, ksize, stride, pad)) return FBBEV_E_BADARG;
+    // an NHWC image is an NDHWC volume with one plane; the planar instantiation has a single tap along that axis
+    return conv3d_launch(x, weight_fragments, bias, residual, B, 1, Hi, Wi, Cin, 1, Ho, Wo, Cout, ksize, stride, pad, relu, 0, out,
+                         stream_, true);
 }
 
 extern "C" int fbbev_conv3d_dgrad_ndhwc(const float* dy, const float* weight_fragments_t, const float* zero_bias, int B,

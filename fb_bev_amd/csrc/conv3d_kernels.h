@@ -29,7 +29,9 @@
 #pragma once
 #include "rt.h"
 
-template <int KS, int MT>
+// KD = taps along the slowest spatial axis: KS for a 3-D convolution, 1 for a 2-D convolution on an NHWC image (= NDHWC
+// with D = 1; no padding along that axis)
+template <int KD, int KS, int MT>
 __global__ void __launch_bounds__(256)
 k_conv3d_ndhwc(const float* __restrict__ x, const float* __restrict__ wf, const float* __restrict__ bias,
                const float* __restrict__ residual, float* __restrict__ out, int B, int Di, int Hi, int Wi, int Cin,
@@ -63,7 +65,8 @@ k_conv3d_ndhwc(const float* __restrict__ x, const float* __restrict__ wf, const 
         for (int t = 0; t < NT; ++t) acc[mt][t] = fbbev_v4f{0.f, 0.f, 0.f, 0.f};
     const int J = Cin >> 4;
     const float* __restrict__ wfp = wf + (long long)parity * wf_parity_stride + (long long)mt0 * 256 + lane * 4;
-    for (int tap = 0; tap < KS * KS * KS; ++tap) {
+    const int pad_d = KD == 1 ? 0 : pad;
+    for (int tap = 0; tap < KD * KS * KS; ++tap) {
         const int kd = tap / (KS * KS), kh = (tap / KS) % KS, kw = tap % KS;
         long long off[NT];
         bool ok[NT];
@@ -73,12 +76,12 @@ k_conv3d_ndhwc(const float* __restrict__ x, const float* __restrict__ wf, const 
             if (mode == 2) {
                 // data gradient of a stride-s convolution: dx[i] = sum_k W_k^T dy[(i + pad - k) / s] over the taps for which
                 // the division is exact -- `x` is dy here, (Di,Hi,Wi) its extent and the "output" voxel is the dx voxel
-                const int nd = dq[t] + pad - kd, nh = hq[t] + pad - kh, nw = wq[t] + pad - kw;
+                const int nd = dq[t] + pad_d - kd, nh = hq[t] + pad - kh, nw = wq[t] + pad - kw;
                 di = nd / stride; hi = nh / stride; wi = nw / stride;
                 ok[t] = vq[t] && nd >= 0 && nh >= 0 && nw >= 0 && di * stride == nd && hi * stride == nh && wi * stride == nw &&
                         di < Di && hi < Hi && wi < Wi;
             } else {
-                di = dq[t] * stride + kd - pad; hi = hq[t] * stride + kh - pad; wi = wq[t] * stride + kw - pad;
+                di = dq[t] * stride + kd - pad_d; hi = hq[t] * stride + kh - pad; wi = wq[t] * stride + kw - pad;
                 ok[t] = vq[t] && di >= 0 && di < Di && hi >= 0 && hi < Hi && wi >= 0 && wi < Wi;
             }
             off[t] = (ok[t] ? ((((long long)bq[t] * Di + di) * Hi + hi) * Wi + wi) * Cin : 0) + 4 * g;

@@ -126,8 +126,14 @@ class FBOCC(nn.Module):
     def _mfma_stacks(self):
         if self._runners is None:
             from . import mfma_conv3d as M
+            img = None
+            if self.img_backbone is not None and self.img_neck is not None:
+                try:
+                    img = (M.ResNetRunner(self.img_backbone), M.CustomFPNRunner(self.img_neck))
+                except (ValueError, NotImplementedError):      # channel counts / layers outside the kernel: vendor route
+                    img = None
             self._runners = (M.ResNet3DRunner(self.img_bev_encoder_backbone), M.FPN3DRunner(self.img_bev_encoder_neck),
-                             M.OccHeadRunner(self.occupancy_head))
+                             M.OccHeadRunner(self.occupancy_head), img)
         return self._runners
 
     def _use_mfma(self, x):
@@ -139,6 +145,10 @@ class FBOCC(nn.Module):
     # ------------------------------------------------------------------ fbocc.py:135-162
     def image_encoder(self, img):
         B, N, C, H, W = img.shape
+        if self._use_mfma(img) and self._mfma_stacks()[3] is not None:
+            backbone, neck = self._mfma_stacks()[3]
+            x = neck(backbone(img.view(B * N, C, H, W)))
+            return x.reshape(B, N, *x.shape[1:])
         x = self.img_backbone(img.view(B * N, C, H, W))
         if self.img_neck is not None:
             x = self.img_neck(x)
@@ -168,7 +178,7 @@ class FBOCC(nn.Module):
         bev_feat = self.history.fuse_history(bev_feat, img_metas, img[6])                                # :371
         if self._use_mfma(bev_feat):
             from .mfma_conv3d import to_ndhwc
-            backbone, neck, _ = self._mfma_stacks()
+            backbone, neck = self._mfma_stacks()[:2]
             ret['img_bev_feat_ndhwc'] = neck(backbone(to_ndhwc(bev_feat)))       # NDHWC maps, consumed by the head runner
             return ret
         ret['img_bev_feat'] = self.bev_encoder(bev_feat)

@@ -305,3 +305,89 @@ class OccHeadRunner:
                 out = out + f * w[..., k:k + 1]
         logits = self.pred[1](self.pred[0](out.contiguous(), backend=backend), backend=backend)
         return to_ncdhw(logits)
+
+
+# ------------------------------------------------------------------ 2-D stacks (image encoder), inference
+class FoldedConv2d:
+    """One launch of fbbev_conv2d_nhwc: Conv2d (+ folded BN) (+ residual) (+ ReLU) on NHWC activations."""
+
+    def __init__(self, conv, bn=None, relu=False):
+        k, s, p = conv.kernel_size, conv.stride, conv.padding
+        if len(set(k)) != 1 or len(set(s)) != 1 or len(set(p)) != 1 or k[0] not in (1, 3) or s[0] not in (1, 2) \
+                or p[0] not in (0, 1) or conv.groups != 1 or set(conv.dilation) != {1}:
+            raise NotImplementedError(f'conv2d {k} stride {s} pad {p}')
+        self.ksize, self.stride, self.pad, self.relu = k[0], s[0], p[0], relu
+        w = conv.weight.detach().float()
+        b = conv.bias.detach().float() if conv.bias is not None else torch.zeros(w.shape[0], device=w.device)
+        if bn is not None:
+            scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.float() + bn.eps)
+            w = w * scale.view(-1, 1, 1, 1)
+            b = (b - bn.running_mean.float()) * scale + bn.bias.detach().float()
+        self.cout = w.shape[0]
+        self.wf = weight_fragments(w[:, :, None])
+        self.bias = F.pad(b, (0, (self.cout + 15) // 16 * 16 - self.cout)).contiguous()
+
+    def __call__(self, x, residual=None, backend=None):
+        B, H, W, _ = x.shape
+        f = lambda n: (n + 2 * self.pad - self.ksize) // self.stride + 1  # noqa: E731
+        out = torch.empty((B, f(H), f(W), self.cout), dtype=torch.float32, device=x.device)
+        run = backend or _capi.conv2d_nhwc
+        return run(x, self.wf, self.bias, out, self.cout, ksize=self.ksize, stride=self.stride, pad=self.pad, relu=self.relu,
+                   residual=residual)
+
+
+class ResNetRunner:
+    """img_encoder.ResNet.forward in eval mode: the 7x7 stem (3 input channels) and the max-pool stay torch; every
+    residual block is 2-3 launches (conv+BN+ReLU ..., the last one with the identity added before the ReLU)."""
+
+    def __init__(self, net):
+        self.net = net
+        self.out_indices = net.out_indices
+        self.stages = []
+        for name in net.res_layers:
+            blocks = []
+            for blk in getattr(net, name):
+                down = None if blk.downsample is None else FoldedConv2d(blk.downsample[0], blk.downsample[1], relu=False)
+                if hasattr(blk, 'conv3'):
+                    convs = [FoldedConv2d(blk.conv1, blk.bn1, relu=True), FoldedConv2d(blk.conv2, blk.bn2, relu=True),
+                             FoldedConv2d(blk.conv3, blk.bn3, relu=True)]
+                else:
+                    convs = [FoldedConv2d(blk.conv1, blk.bn1, relu=True), FoldedConv2d(blk.conv2, blk.bn2, relu=True)]
+                blocks.append((convs, down))
+            self.stages.append(blocks)
+
+    def __call__(self, img, backend=None):
+        """img (B,3,H,W) -> tuple of NHWC feature maps of the out_indices stages."""
+        net = self.net
+        x = net.maxpool(F.relu(net.bn1(net.conv1(img.float()))))
+        x = x.permute(0, 2, 3, 1).contiguous()
+        outs = []
+        for i, blocks in enumerate(self.stages):
+            for convs, down in blocks:
+                identity = x if down is None else down(x, backend=backend)
+                y = x
+                for c in convs[:-1]:
+                    y = c(y, backend=backend)
+                x = convs[-1](y, residual=identity, backend=backend)
+            if i in self.out_indices:
+                outs.append(x)
+        return tuple(outs)
+
+
+class CustomFPNRunner:
+    """img_encoder.CustomFPN.forward (necks/fpn.py:160-206) on NHWC maps -> (B,C,H,W) logical view of outs[0]."""
+
+    def __init__(self, neck):
+        if len(neck.fpn_convs) != len(neck.out_ids) or neck.num_outs != len(neck.out_ids):
+            raise NotImplementedError('extra output levels')
+        mk = lambda m: FoldedConv2d(m.conv, getattr(m, m.norm_name) if m.norm_name else None, relu=m.activate is not None)  # noqa: E731
+        self.laterals = [mk(m) for m in neck.lateral_convs]
+        self.outs = [mk(m) for m in neck.fpn_convs]
+        self.out_ids, self.start_level, self.upsample_cfg = list(neck.out_ids), neck.start_level, dict(neck.upsample_cfg)
+
+    def __call__(self, feats, backend=None):
+        lat = [conv(feats[i + self.start_level], backend=backend) for i, conv in enumerate(self.laterals)]
+        for i in range(len(lat) - 1, 0, -1):
+            up = F.interpolate(lat[i].permute(0, 3, 1, 2), size=lat[i - 1].shape[1:3], **self.upsample_cfg)
+            lat[i - 1] = lat[i - 1] + up.permute(0, 2, 3, 1)
+        return self.outs[0](lat[self.out_ids[0]].contiguous(), backend=backend).permute(0, 3, 1, 2)

@@ -343,6 +343,14 @@ int fbbev_conv3d_ndhwc(const float* x, const float* weight_fragments, const floa
                        int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout, int ksize, int stride, int pad,
                        int relu, int transposed, float* out, fbbev_stream_t stream);
 
+/* 2-D convolution on NHWC (torch channels_last) f32 activations, inference: the same kernel on a one-plane volume with a
+ * single tap along the plane axis; for the eval-mode Conv2d + folded BatchNorm (+ residual) (+ ReLU) groups of the image
+ * backbone (mmdet ResNet bottlenecks, cfg fbocc-r50-cbgs_depth_16f_16x4_20e.py:119-129) and CustomFPN (necks/fpn.py:108-134).
+ * weight_fragments: the 3-D layout of the weight viewed as (Cout, Cin, 1, k, k).  ksize 1 or 3, Cin % 16 == 0. */
+int fbbev_conv2d_nhwc(const float* x, const float* weight_fragments, const float* bias, const float* residual, int B,
+                      int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int ksize, int stride, int pad, int relu,
+                      float* out, fbbev_stream_t stream);
+
 /* Data gradient of fbbev_conv3d_ndhwc's convolution (training): dx[i] = sum_k W_k^T dy[(i + pad - k) / stride] over the
  * taps for which the division is exact.  dy (B,Do,Ho,Wo,Cout), dx (B,Di,Hi,Wi,Cin) with the forward geometry (checked);
  * weight_fragments_t = the fragment layout of the TRANSPOSED weight (Cin, Cout, k, k, k) -- same tap index;

@@ -291,3 +291,12 @@ def conv3d_wgrad_ndhwc(x, dy, ksize=3, stride=1, pad=1):
     dw = torch.zeros(ksize ** 3, Cout, Cin)
     code = lib().fbbev_conv3d_wgrad_ndhwc(p(x), p(dy), B, Di, Hi, Wi, Cin, Do, Ho, Wo, Cout, ksize, stride, pad, p(dw), None)
     return code, dw
+
+
+def conv2d_nhwc(x, wf, bias, Cout, ksize=3, stride=1, pad=1, relu=False, residual=None):
+    B, Hi, Wi, Cin = x.shape
+    Ho, Wo = [(n + 2 * pad - ksize) // stride + 1 for n in (Hi, Wi)]
+    out = torch.full((B, Ho, Wo, Cout), float('nan'))
+    code = lib().fbbev_conv2d_nhwc(p(x), p(wf), p(bias), p(residual) if residual is not None else None, B, Hi, Wi, Cin, Ho, Wo, Cout,
+                                   ksize, stride, pad, 1 if relu else 0, p(out), None)
+    return code, out

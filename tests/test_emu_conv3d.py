@@ -276,3 +276,55 @@ def test_training_route_gradients_equal_torch_autograd():
     assert not M._supported_train(net['head'].occ_pred_conv[3], x) and M._supported_train(net['head'].occ_pred_conv[0], x)
     M.enable_training_route(net, False)
     assert not any(getattr(m, 'mfma', False) for m in net.modules())
+
+
+@pytest.mark.parametrize('B,hw,Cin,Cout,k,s,p,relu,res', [(2, (9, 7), 16, 32, 3, 1, 1, True, True), (1, (8, 11), 32, 64, 3, 2, 1, True, False),
+                                                          (1, (5, 6), 64, 16, 1, 1, 0, False, True), (2, (6, 6), 16, 48, 1, 2, 0, False, False)])
+def test_conv2d_nhwc_vs_torch(B, hw, Cin, Cout, k, s, p, relu, res):
+    g = torch.Generator().manual_seed(Cin + Cout + k)
+    x = torch.randn(B, Cin, *hw, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    exp = F.conv2d(x, w, b, stride=s, padding=p)
+    r = torch.randn(exp.shape, generator=g) if res else None
+    exp = exp + r if res else exp
+    exp = exp.relu() if relu else exp
+    code, y = E.conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous(), M.weight_fragments(w[:, :, None]),
+                            F.pad(b, (0, (Cout + 15) // 16 * 16 - Cout)), Cout, ksize=k, stride=s, pad=p, relu=relu,
+                            residual=None if r is None else r.permute(0, 2, 3, 1).contiguous())
+    assert code == 0 and not torch.isnan(y).any()
+    assert torch.allclose(y.permute(0, 3, 1, 2), exp, atol=1e-4, rtol=1e-4), (y.permute(0, 3, 1, 2) - exp).abs().max()
+
+
+def emu_conv2d(x, wf, bias, out, Cout, ksize=3, stride=1, pad=1, relu=False, residual=None):
+    code, y = E.conv2d_nhwc(x.contiguous(), wf, bias, Cout, ksize=ksize, stride=stride, pad=pad, relu=relu,
+                            residual=None if residual is None else residual.contiguous())
+    assert code == 0 and tuple(y.shape) == tuple(out.shape) and not torch.isnan(y).any()
+    return y
+
+
+@pytest.mark.parametrize('depth', [18, 50])
+def test_image_encoder_runners_equal_the_modules(depth):
+    from fb_bev_amd.img_encoder import CustomFPN, ResNet
+    torch.manual_seed(depth)
+    net = ResNet(depth=depth, base_channels=16, num_stages=4, out_indices=(2, 3), norm_eval=False)
+    exp = 1 if depth == 18 else 4
+    neck = CustomFPN(in_channels=[64 * exp, 128 * exp], out_channels=32, num_outs=1, start_level=0, out_ids=[0])
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for m in list(net.modules()) + list(neck.modules()):
+            if isinstance(m, nn.BatchNorm2d):
+                m.running_mean.copy_(torch.rand(m.running_mean.shape, generator=g) * 0.4 - 0.2)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+                m.weight.copy_(torch.rand(m.weight.shape, generator=g) * 0.4 + 0.3)      # < 1: keeps 16 blocks well scaled
+                m.bias.copy_(torch.rand(m.bias.shape, generator=g) * 0.2 - 0.1)
+    net.eval(); neck.eval()
+    img = torch.randn(2, 3, 64, 96, generator=g)
+    with torch.no_grad():
+        ref_feats = net(img)
+        ref = neck(ref_feats)
+        feats = M.ResNetRunner(net)(img, backend=emu_conv2d)
+        got = M.CustomFPNRunner(neck)(feats, backend=emu_conv2d)
+    for a, b in zip(feats, ref_feats):
+        assert torch.allclose(a.permute(0, 3, 1, 2), b, atol=1e-4, rtol=1e-4), (a.permute(0, 3, 1, 2) - b).abs().max()
+    assert got.shape == ref.shape and torch.allclose(got, ref, atol=1e-4, rtol=1e-4)

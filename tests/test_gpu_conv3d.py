@@ -127,3 +127,16 @@ def test_training_route_equals_vendor_route(dev):
         grads.append({n: p.grad for n, p in mod.named_parameters() if p.grad is not None})
     for n, gref in grads[1].items():
         assert (grads[0][n] - gref).abs().max() <= 2e-3 * gref.abs().max() + 1e-4, n
+
+
+def test_image_encoder_mfma_route_equals_vendor_route(dev):
+    from fb_bev_amd import mfma_conv3d as M
+    from fb_bev_amd.img_encoder import CustomFPN, ResNet
+    torch.manual_seed(0)
+    net = ResNet(depth=50, num_stages=4, out_indices=(2, 3), norm_eval=False).to(dev).eval()
+    neck = CustomFPN(in_channels=[1024, 2048], out_channels=256, num_outs=1, start_level=0, out_ids=[0]).to(dev).eval()
+    img = torch.randn(2, 3, 256, 704, device=dev)
+    with torch.no_grad():
+        ref = neck(net(img))
+        got = M.CustomFPNRunner(neck)(M.ResNetRunner(net)(img))
+    assert (got - ref).abs().max() <= 1e-3 * ref.abs().max()

@@ -87,7 +87,7 @@ def infer(B, dtype, mfma=False):
         fused = m.history.fuse_history(bev, metas(False), img_inputs[6])
         if mfma:
             from fb_bev_amd.mfma_conv3d import to_ndhwc
-            bb, neck, head = m._mfma_stacks()
+            bb, neck, head = m._mfma_stacks()[:3]
             t_enc = ev_ms(lambda i: neck(bb(to_ndhwc(fused))), 5)[0]
             feats = neck(bb(to_ndhwc(fused)))
             t_head = ev_ms(lambda i: head(feats).softmax(1).argmax(1), 5)[0]
