@@ -1,0 +1,34 @@
+"""GPU run of the BEVDet-era view transformers against the real-reference fixture.  The CPU suite checks the same chain
+on the emulated kernels (tests/test_bevdet_view_transformer.py); this file joins the default GPU suite after its first
+pass on an MI355X (`FBBEV_EXPERIMENTAL=1 python -m pytest tests/test_gpu_bevdet.py -m gpu`)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(os.environ.get('FBBEV_EXPERIMENTAL') != '1', reason='not yet validated on the GPU')]
+G = os.path.join(os.path.dirname(__file__), 'golden', 'bevdet_view_transformer_small.npz')
+GRID = {'x': [-8, 8, 1.0], 'y': [-8, 8, 1.0], 'z': [-1, 3, 2.0], 'depth': [1.0, 9.0, 1.0]}
+
+
+@pytest.mark.parametrize('name', ['v1', 'v2'])
+def test_module_equals_reference_fixture_and_backpropagates(name):
+    from fb_bev_amd.bevdet_view_transformer import LSSViewTransformer, LSSViewTransformer2
+    dev = torch.device('cuda:0')
+    gold = np.load(G)
+    B, N, Cin, C, H, W = gold['dims'].tolist()
+    m = (LSSViewTransformer if name == 'v1' else LSSViewTransformer2)(grid_config=GRID, input_size=(64, 96), downsample=16,
+                                                                       in_channels=Cin, out_channels=C).to(dev)
+    with torch.no_grad():
+        m.depth_net.weight.copy_(torch.from_numpy(gold[f'{name}.w']))
+        m.depth_net.bias.copy_(torch.from_numpy(gold[f'{name}.b']))
+    inp = [torch.from_numpy(gold['x']).to(dev)] + [torch.from_numpy(gold[f'cam{i}']).to(dev) for i in range(6)]
+    with torch.no_grad():
+        bev, depth = m(inp)
+    assert torch.allclose(bev.cpu(), torch.from_numpy(gold[f'{name}.bev']), atol=1e-5, rtol=1e-5)
+    inp[0].requires_grad_()
+    bev, _ = m(inp)
+    bev.square().sum().backward()
+    assert inp[0].grad is not None and torch.isfinite(inp[0].grad).all() and m.depth_net.weight.grad.abs().sum() > 0
