@@ -66,3 +66,26 @@ def bev_pool_v2(depth, feat, ranks_depth, ranks_feat, ranks_bev, bev_feat_shape,
     x = QuickCumsumCuda.apply(depth, feat, ranks_depth, ranks_feat, ranks_bev, bev_feat_shape,
                               interval_starts, interval_lengths)
     return x.permute(0, 4, 1, 2, 3).contiguous()
+
+
+class TRTBEVPoolv2(torch.autograd.Function):
+    """ONNX export stand-in of the op (ops/bev_pool_v2/bev_pool.py:92-141): `symbolic` emits the custom node
+    `mmdeploy::bev_pool_v2` with the reference's attribute names; `forward` is the eager equivalent on the HIP op for a
+    single-sample, Z = 1 grid -> (1, out_height, out_width, C)."""
+
+    @staticmethod
+    def symbolic(g, depth, feat, ranks_depth, ranks_feat, ranks_bev, interval_starts, interval_lengths, out_height=128,
+                 out_width=128):
+        return g.op('mmdeploy::bev_pool_v2', depth, feat, ranks_depth, ranks_feat, ranks_bev, interval_starts,
+                    interval_lengths, out_height_i=out_height, out_width_i=out_width)
+
+    @staticmethod
+    def forward(g, depth, feat, ranks_depth, ranks_feat, ranks_bev, interval_starts, interval_lengths, out_height=128,
+                out_width=128):
+        n, d, h, w = depth.shape
+        feat = feat.view(1, n, feat.shape[3], h, w).permute(0, 1, 3, 4, 2)
+        depth = depth.view(1, n, d, h, w)
+        bev_feat_shape = (1, 1, out_height, out_width, feat.shape[-1])                   # (B, Z, Y, X, C)
+        bev_feat = bev_pool_v2(depth, feat, ranks_depth, ranks_feat, ranks_bev, bev_feat_shape, interval_starts,
+                               interval_lengths)
+        return bev_feat.squeeze(2).permute(0, 2, 3, 1)

@@ -64,3 +64,16 @@ def test_module_equals_reference_fixture(name):
     assert torch.equal(bev, bev2) and digit.shape == (B * N, 8, H, W)
     if name == 'v2':        # the threshold matters on this input: the two fixtures differ
         assert not np.allclose(gold['v1.bev'], gold['v2.bev'], atol=1e-4)
+
+
+def test_onnx_symbolic_emits_the_reference_node():
+    """TRTBEVPoolv2.symbolic (ops/bev_pool_v2/bev_pool.py:94-116): node name, input order and attribute names."""
+    from fb_bev_amd.bev_pool import TRTBEVPoolv2
+
+    class FakeGraph:
+        def op(self, name, *inputs, **attrs):
+            return name, inputs, attrs
+    name, inputs, attrs = TRTBEVPoolv2.symbolic(FakeGraph(), 'depth', 'feat', 'rd', 'rf', 'rb', 'starts', 'lengths', 200, 100)
+    assert name == 'mmdeploy::bev_pool_v2'
+    assert inputs == ('depth', 'feat', 'rd', 'rf', 'rb', 'starts', 'lengths')
+    assert attrs == {'out_height_i': 200, 'out_width_i': 100}
