@@ -8,7 +8,8 @@ with random-init weights and synthetic inputs of SURVEY Appendix B.
     python tools/time_full.py train B [f32|bf16] [mfma]   S5: forward_train + backward + grad all-reduce + clip + AdamW step
 
 bf16 = convolution stacks (image encoder, depth net, voxel encoder, head) under bf16 autocast; the view transformation,
-history fusion and losses stay fp32.  Prints one JSON line.
+history fusion and losses stay fp32.  A trailing `tune` turns on the vendor library's algorithm search
+(torch.backends.cudnn.benchmark).  Prints one JSON line.
 """
 import json
 import os
@@ -148,6 +149,9 @@ def train(B, dtype, mfma=False):
 
 
 if __name__ == '__main__':
+    if 'tune' in sys.argv:          # let the vendor library search its convolution algorithms during the warm-up
+        torch.backends.cudnn.benchmark = True
+        sys.argv.remove('tune')
     mode = sys.argv[1] if len(sys.argv) > 1 else 'infer'
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     dtype = sys.argv[3] if len(sys.argv) > 3 else 'f32'
