@@ -9,8 +9,8 @@ loaded first; dict values of the child are merged key-by-key into the parent's d
 `build_view_transformation(model_cfg)` consumes exactly the keys `FBOCC.__init__` consumes for the path
 (mmdet3d/models/fbbev/detectors/fbocc.py:47-131): forward_projection, backward_projection, readd, do_history,
 history_cat_num, history_cat_conv_out_channels, single_bev_num_channels, interpolation_mode; `build_depth_net` consumes
-the `depth_net` block (CM_DepthNet: vendor-library convolutions with the path's execution setup).  The other blocks
-(img_backbone, bev encoder, occupancy head ...) stay with stock PyTorch-ROCm / MIOpen and are ignored here.
+the `depth_net` block (CM_DepthNet: vendor-library convolutions with the path's execution setup); `build_detector`
+assembles the whole FBOCC (fb_bev_amd/fbocc.py) from the unchanged `model` block.
 """
 import os
 import types
@@ -81,3 +81,14 @@ def build_depth_net(model_cfg, **execution_knobs):
         raise KeyError(f'depth_net type {typ!r} is not part of the built path')
     cfg.update(execution_knobs)
     return CM_DepthNet(**cfg)
+
+
+def build_detector(model_cfg, execution=None):
+    """The whole detector from a config's `model` block (type FBOCC; the deployment config's FBOCCTRT subclass takes the same
+    blocks, fbocc_trt.py) -> fb_bev_amd.fbocc.FBOCC with the reference's parameter names.  `execution`: see FBOCC."""
+    from .fbocc import FBOCC
+    cfg = dict(model_cfg)
+    typ = cfg.pop('type', 'FBOCC')
+    if typ not in ('FBOCC', 'FBOCCTRT', 'FBOCC_TRT'):
+        raise KeyError(f'detector type {typ!r} is not an FB-OCC occupancy detector')
+    return FBOCC(**cfg, execution=execution)

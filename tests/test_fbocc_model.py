@@ -163,3 +163,13 @@ def test_forward_train_and_simple_test_plumbing_on_cpu(monkeypatch):
         m(return_loss=False, img_inputs=tuple(one), img_metas=[metas[:1]])
     with pytest.raises(ValueError):
         m(return_loss=False, img_inputs=one, img_metas=[metas[:1]])
+
+
+@pytest.mark.parametrize('name', ['fbocc-r50-cbgs_depth_16f_16x4_20e.py', 'fbocc-r50-cbgs_depth_16f_16x4_20e_trt.py'])
+def test_build_detector_from_config_block(name):
+    from fb_bev_amd import config as C
+    block = json.load(open(os.path.join(GOLD, 'fbocc_config_path_blocks.json')))[name]['model']
+    m = C.build_detector(block, execution=dict(with_cp=False))
+    assert type(m).__name__ == 'FBOCC' and m.img_backbone.with_cp is False and m.occupancy_head.with_cp is False
+    with pytest.raises(KeyError):
+        C.build_detector({**block, 'type': 'BEVDet'})
