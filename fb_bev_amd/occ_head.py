@@ -84,11 +84,13 @@ class OccHead(nn.Module):
             w = output_occs[0].new_ones(output_occs[0].shape[0], self.num_point_sampling_feat, 1, 1, 1) \
                 / self.num_point_sampling_feat
         size = output_occs[0].shape[2:]
-        out = 0
+        out = None
         for feats, wk in zip(output_occs, torch.unbind(w, dim=1)):
             if tuple(feats.shape[2:]) != tuple(size):          # trilinear resize to the same size is the identity
                 feats = F.interpolate(feats, size=list(size), mode='trilinear', align_corners=False)
-            out = out + feats * wk.unsqueeze(1)
+            # out += feats * weights (:169) as one multiply-add pass per level instead of a multiply and an add pass over
+            # the full-resolution 128-channel maps
+            out = feats * wk.unsqueeze(1) if out is None else torch.addcmul(out, feats, wk.unsqueeze(1))
         return {'out_voxel_feats': [out], 'occ': [self._run(self.occ_pred_conv, out)]}
 
     def forward(self, voxel_feats, img_feats=None, pts_feats=None, transform=None, **kwargs):
