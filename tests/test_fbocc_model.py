@@ -173,3 +173,17 @@ def test_build_detector_from_config_block(name):
     assert type(m).__name__ == 'FBOCC' and m.img_backbone.with_cp is False and m.occupancy_head.with_cp is False
     with pytest.raises(KeyError):
         C.build_detector({**block, 'type': 'BEVDet'})
+
+
+def test_detector_fails_loudly_without_a_gpu(shipped):
+    """No CPU fallback: the assembled detector refuses CPU tensors at the first HIP stage instead of computing elsewhere."""
+    from fb_bev_amd import _capi, synthetic as S
+    model, _ = shipped
+    model.eval()
+    pc = S.CONFIGS['REF']
+    cam = S.camera_rig(pc, 1, seed=0)
+    feats = torch.zeros(1, 6, 256, 16, 44)
+    with torch.no_grad(), pytest.raises(_capi.FbbevError):
+        mlp = model.depth_net.get_mlp_input(*cam)
+        context, depth = model.depth_net(feats, mlp)
+        model.view_transform(list(cam), context, depth)
