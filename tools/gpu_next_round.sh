@@ -18,5 +18,7 @@ for mode in "2 f32" "2 f32 mfma" "4 bf16"; do
 done
 cd /tmp
 timeout -k 5 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_full -- python $REPO/tools/time_full.py infer 1 f32 mfma > $OUT/prof_full.log 2>&1
-echo "rocprof rc=$?"
+echo "rocprof mfma rc=$?"
+timeout -k 5 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_full_vendor -- python $REPO/tools/time_full.py infer 1 bf16 > $OUT/prof_full_vendor.log 2>&1
+echo "rocprof vendor rc=$?"
 find $OUT -name "*.csv" -size +20M -delete
