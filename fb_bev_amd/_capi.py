@@ -44,6 +44,7 @@ SIGNATURES = {
     'fbbev_history_conv': (c_int, [c_void_p, c_int64] + [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t, c_void_p]),
     'fbbev_conv3d_ndhwc': (c_int, [c_void_p] * 4 + [c_int] * 14 + [c_void_p, c_void_p]),
     'fbbev_conv2d_nhwc': (c_int, [c_void_p] * 4 + [c_int] * 11 + [c_void_p, c_void_p]),
+    'fbbev_conv3d_ndhwc_bf16': (c_int, [c_void_p] * 4 + [c_int] * 15 + [c_void_p, c_void_p]),
     'fbbev_conv3d_dgrad_ndhwc': (c_int, [c_void_p] * 3 + [c_int] * 12 + [c_void_p, c_void_p]),
     'fbbev_conv3d_wgrad_ndhwc': (c_int, [c_void_p] * 2 + [c_int] * 12 + [c_void_p, c_void_p]),
     'fbbev_blend_levels_ndhwc': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p] + [c_int] * 6 + [c_void_p, c_void_p]),
@@ -503,6 +504,25 @@ def conv2d_nhwc(x, weight_fragments, bias, out, Cout, ksize=3, stride=1, pad=1, 
             _dev(x, F32, 'x'), _dev(weight_fragments, F32, 'weight_fragments'), _dev(bias, F32, 'bias'),
             None if residual is None else _dev(residual, F32, 'residual'), B, Hi, Wi, Cin, Ho, Wo, int(Cout), int(ksize), int(stride),
             int(pad), 1 if relu else 0, _dev(out, F32, 'out'), _stream()), 'fbbev_conv2d_nhwc')
+    return out
+
+
+def conv3d_ndhwc_bf16(x, weight_fragments_bf16, bias, out, Cout, ksize=3, stride=1, pad=1, relu=False, residual=None,
+                      transposed=False, planar=False):
+    """bf16-MFMA variant of conv3d_ndhwc (planar=True: x (B,1,H,W,Cin), the 2-D case); weights from
+    mfma_conv3d.weight_fragments_bf16 (torch.bfloat16 tensor)."""
+    B, Di, Hi, Wi, Cin = x.shape
+    Do, Ho, Wo = out.shape[1:4]
+    if transposed:
+        Do, Ho, Wo = Di, Hi, Wi
+    if weight_fragments_bf16.dtype != torch.bfloat16:
+        raise FbbevError('weight_fragments_bf16 must be a bfloat16 tensor')
+    with _on(x):
+        _check(lib().fbbev_conv3d_ndhwc_bf16(
+            _dev(x, F32, 'x'), _dev(weight_fragments_bf16, torch.bfloat16, 'weight_fragments_bf16'), _dev(bias, F32, 'bias'),
+            None if residual is None else _dev(residual, F32, 'residual'), B, Di, Hi, Wi, Cin, int(Do), int(Ho), int(Wo), int(Cout),
+            int(ksize), int(stride), int(pad), 1 if relu else 0, 1 if transposed else 0, 1 if planar else 0,
+            _dev(out, F32, 'out'), _stream()), 'fbbev_conv3d_ndhwc_bf16')
     return out
 
 

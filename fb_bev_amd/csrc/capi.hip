@@ -1030,6 +1030,44 @@ extern "C" int fbbev_conv2d_nhwc(const float* x, const float* weight_fragments, 
                          stream_, true);
 }
 
+extern "C" int fbbev_conv3d_ndhwc_bf16(const float* x, const void* weight_fragments_bf16, const float* bias,
+                                       const float* residual, int B, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo,
+                                       int Cout, int ksize, int stride, int pad, int relu, int transposed, int planar,
+                                       float* out, fbbev_stream_t stream_) {
+    if (B < 0 || Di <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Do <= 0 || Ho <= 0 || Wo <= 0 || Cout <= 0) return FBBEV_E_BADARG;
+    if (transposed) {
+        if (Do != Di || Ho != Hi || Wo != Wi || planar) return FBBEV_E_BADARG;
+        ksize = 1; stride = 1; pad = 0;
+    } else {
+        if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2) || pad < 0 || pad > 1) return FBBEV_E_UNSUPPORTED;
+        if (planar ? (Di != 1 || Do != 1) : !conv3d_geometry_ok(Di, Do, ksize, stride, pad)) return FBBEV_E_BADARG;
+        if (!conv3d_geometry_ok(Hi, Ho, ksize, stride, pad) || !conv3d_geometry_ok(Wi, Wo, ksize, stride, pad)) return FBBEV_E_BADARG;
+    }
+    if (B == 0) return 0;
+    if (!x || !weight_fragments_bf16 || !bias || !out) return FBBEV_E_BADARG;
+    if (Cin % 32 != 0 || !aligned16(x) || !aligned16(weight_fragments_bf16) || !aligned16(bias) || !aligned16(out) ||
+        (residual && !aligned16(residual))) return FBBEV_E_UNSUPPORTED;
+    const long long nvox = (long long)B * Do * Ho * Wo;
+    const long long gx = (nvox + 255) / 256;
+    const int mt_total = (Cout + 15) / 16;
+    const int MT = mt_total % 4 == 0 ? 4 : (mt_total % 2 == 0 ? 2 : 1);
+    const long long pstride = (long long)(Cin / 32) * mt_total * 512;
+    const int gy = mt_total / MT;
+    const long long grid = gx * gy * (transposed ? 8 : 1);
+    if (grid >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
+    const unsigned short* wfb = static_cast<const unsigned short*>(weight_fragments_bf16);
+#define FBBEV_CONV3DB(KD_, KS_, MT_)                                                                                 \
+    FBBEV_LAUNCH((k_conv3d_ndhwc_bf16<KD_, KS_, MT_>), grid, 256, 0, (fbbev_rt_stream)stream_, x, wfb, bias, residual, out, \
+                 B, Di, Hi, Wi, Cin, Do, Ho, Wo, Cout, mt_total, stride, pad, relu ? 1 : 0, transposed ? 1 : 0, pstride,  \
+                 (int)gx, gy)
+#define FBBEV_CONV3DB_K(KD_, KS_) do { if (MT == 4) FBBEV_CONV3DB(KD_, KS_, 4); else if (MT == 2) FBBEV_CONV3DB(KD_, KS_, 2); else FBBEV_CONV3DB(KD_, KS_, 1); } while (0)
+    if (ksize == 3 && planar) FBBEV_CONV3DB_K(1, 3); else if (ksize == 3) FBBEV_CONV3DB_K(3, 3); else FBBEV_CONV3DB_K(1, 1);
+#undef FBBEV_CONV3DB_K
+#undef FBBEV_CONV3DB
+    FBBEV_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int fbbev_conv3d_dgrad_ndhwc(const float* dy, const float* weight_fragments_t, const float* zero_bias, int B,
                                         int Do, int Ho, int Wo, int Cout, int Di, int Hi, int Wi, int Cin, int ksize,
                                         int stride, int pad, float* dx, fbbev_stream_t stream_) {

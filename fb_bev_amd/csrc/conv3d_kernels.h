@@ -328,3 +328,125 @@ k_conv3d_wgrad_ndhwc(const float* __restrict__ x, const float* __restrict__ dy, 
             }
         }
 }
+
+// ---------------------------------------------------------------- bf16-MFMA variant of the forward convolution (inference)
+// Same decomposition as k_conv3d_ndhwc -- a wave owns 64 voxels x 16*MT couts, activations and outputs stay fp32 NDHWC --
+// but K is walked in 32-channel groups on v_mfma_f32_16x16x32_bf16 (16x the fp32 MFMA rate): a lane's B operand is the 8
+// consecutive channels 32j + 8(lane/16) .. +7 of its voxel (two float4 loads, rounded to bf16 in registers), its A operand
+// 8 bf16 of host-prepared fragment-ordered weights (one 16-byte load)
+//   wfb[parity][tap][j][mt][lane][e] = bf16( W[cout = 16mt + lane%16][cin = 32j + 8(lane/16) + e][tap] ).
+// Both operands use the same slot -> channel rule, which is all the instruction needs (see rt.h).  Accumulation is fp32;
+// results equal an fp32 convolution of the bf16-rounded inputs and weights up to summation order.  Cin % 32 == 0.
+template <int KD, int KS, int MT>
+__global__ void __launch_bounds__(256)
+k_conv3d_ndhwc_bf16(const float* __restrict__ x, const unsigned short* __restrict__ wfb, const float* __restrict__ bias,
+                    const float* __restrict__ residual, float* __restrict__ out, int B, int Di, int Hi, int Wi, int Cin,
+                    int Do, int Ho, int Wo, int Cout, int mt_total, int stride, int pad, int relu, int mode,
+                    long long wf_parity_stride, int gx, int gy) {
+    constexpr int NT = 4;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = lane >> 4, i = lane & 15;
+    const long long nvox = (long long)B * Do * Ho * Wo;
+    const int bx = blockIdx.x % gx, by = (blockIdx.x / gx) % gy, parity = blockIdx.x / (gx * gy);
+    const long long base = ((long long)bx * 4 + wave) * (16 * NT);
+    if (base >= nvox) return;
+    const int mt0 = by * MT;
+    int bq[NT], dq[NT], hq[NT], wq[NT];
+    bool vq[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const long long n = base + 16 * t + i;
+        vq[t] = n < nvox;
+        long long r = vq[t] ? n : 0;
+        wq[t] = (int)(r % Wo); r /= Wo;
+        hq[t] = (int)(r % Ho); r /= Ho;
+        dq[t] = (int)(r % Do);
+        bq[t] = (int)(r / Do);
+    }
+    fbbev_v4f acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[mt][t] = fbbev_v4f{0.f, 0.f, 0.f, 0.f};
+    const int J = Cin >> 5;
+    // fragment element = 8 bf16 = 16 bytes per lane: 64 lanes * 8 = 512 shorts per (tap, j, mt)
+    const unsigned short* __restrict__ wfp = wfb + (long long)parity * wf_parity_stride + (long long)mt0 * 512 + lane * 8;
+    const int pad_d = KD == 1 ? 0 : pad;
+    for (int tap = 0; tap < KD * KS * KS; ++tap) {
+        const int kd = tap / (KS * KS), kh = (tap / KS) % KS, kw = tap % KS;
+        long long off[NT];
+        bool ok[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int di = dq[t] * stride + kd - pad_d, hi = hq[t] * stride + kh - pad, wi = wq[t] * stride + kw - pad;
+            ok[t] = vq[t] && di >= 0 && di < Di && hi >= 0 && hi < Hi && wi >= 0 && wi < Wi;
+            off[t] = (ok[t] ? ((((long long)bq[t] * Di + di) * Hi + hi) * Wi + wi) * Cin : 0) + 8 * g;
+        }
+        const unsigned short* __restrict__ wt = wfp + (long long)tap * J * mt_total * 512;
+        auto load = [&](fbbev_v4f (&blo)[NT], fbbev_v4f (&bhi)[NT], fbbev_bf16x8 (&afr)[MT], int j) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                blo[t] = *reinterpret_cast<const fbbev_v4f*>(x + off[t] + 32 * j);
+                bhi[t] = *reinterpret_cast<const fbbev_v4f*>(x + off[t] + 32 * j + 4);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) afr[mt] = fbbev_ld_bf16x8(wt + ((long long)j * mt_total + mt) * 512);
+        };
+        auto mma = [&](const fbbev_v4f (&blo)[NT], const fbbev_v4f (&bhi)[NT], const fbbev_bf16x8 (&afr)[MT], bool live) {
+            fbbev_bf16x8 bfr[NT];
+            const fbbev_v4f zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const bool use = ok[t] && live;
+                bfr[t] = fbbev_cvt_bf16x8(use ? blo[t] : zero, use ? bhi[t] : zero);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[mt][t] = fbbev_mfma_f32_16x16x32_bf16(afr[mt], bfr[t], acc[mt][t]);
+        };
+        fbbev_v4f l0[NT], h0[NT], l1[NT], h1[NT];
+        fbbev_bf16x8 a0[MT], a1[MT];
+        load(l0, h0, a0, 0);
+        for (int j = 0; j < J; j += 2) {          // straight-line ping-pong body, as in k_conv3d_ndhwc
+            load(l1, h1, a1, j + 1 < J ? j + 1 : J - 1);
+            fbbev_sched_fence();
+            mma(l0, h0, a0, true);
+            fbbev_sched_fence();
+            load(l0, h0, a0, j + 2 < J ? j + 2 : J - 1);
+            fbbev_sched_fence();
+            mma(l1, h1, a1, j + 1 < J);
+            fbbev_sched_fence();
+        }
+    }
+    const int pa = parity >> 2, pb = (parity >> 1) & 1, pc = parity & 1;
+    const bool vec = (Cout & 3) == 0;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (!vq[t]) continue;
+        long long ovox;
+        if (mode == 1)
+            ovox = (((long long)bq[t] * (2 * Do) + 2 * dq[t] + pa) * (2 * Ho) + 2 * hq[t] + pb) * (2 * Wo) + 2 * wq[t] + pc;
+        else
+            ovox = (((long long)bq[t] * Do + dq[t]) * Ho + hq[t]) * Wo + wq[t];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int c0 = 16 * (mt0 + mt) + 4 * g;
+            if (c0 >= Cout) continue;
+            fbbev_v4f v = acc[mt][t] + *reinterpret_cast<const fbbev_v4f*>(bias + c0);
+            const long long o = ovox * Cout + c0;
+            if (vec) {
+                if (residual) v = v + *reinterpret_cast<const fbbev_v4f*>(residual + o);
+                if (relu) v = fbbev_v4f{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+                *reinterpret_cast<fbbev_v4f*>(out + o) = v;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (c0 + r >= Cout) break;
+                    float s = v[r] + (residual ? residual[o + r] : 0.f);
+                    out[o + r] = relu ? fmaxf(s, 0.f) : s;
+                }
+            }
+        }
+    }
+}

@@ -61,6 +61,22 @@ __device__ __forceinline__ fbbev_v4f fbbev_mfma_f32_16x16x4(float a, float b, fb
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// v_mfma_f32_16x16x32_bf16: D(16x16) = A(16x32) . B(32x16) + C with bf16 operands and fp32 accumulation.  A lane passes 8
+// bf16 of row lane%16 of A and 8 bf16 of column lane%16 of B; which k each (lane/16, element) slot stands for is the SAME
+// function for A and B, so a kernel that fills both operands with the same slot -> channel rule needs no further
+// knowledge of it.  C/D layout as the f32 form (dtype independent on gfx950): register r = row 4*(lane/16)+r, col lane%16.
+typedef __bf16 fbbev_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ fbbev_bf16x8 fbbev_cvt_bf16x8(fbbev_v4f lo, fbbev_v4f hi) {     // round to nearest even
+    fbbev_bf16x8 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { r[e] = (__bf16)lo[e]; r[4 + e] = (__bf16)hi[e]; }
+    return r;
+}
+__device__ __forceinline__ fbbev_bf16x8 fbbev_ld_bf16x8(const void* p) { return *reinterpret_cast<const fbbev_bf16x8*>(p); }
+__device__ __forceinline__ fbbev_v4f fbbev_mfma_f32_16x16x32_bf16(fbbev_bf16x8 a, fbbev_bf16x8 b, fbbev_v4f c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
 // wave-level ordering point for a wave-PRIVATE LDS region: the 64 lanes run in lockstep and the LDS queue of a wave is
 // in order, so only the compiler has to be kept from moving LDS accesses across it (no s_barrier, no other wave waits)
 // instruction-scheduling fence: nothing is moved across it (keeps prefetch loads ahead of the MFMA block they overlap)

@@ -91,7 +91,7 @@ class FBOCC(nn.Module):
         self.occupancy_head = _build(occupancy_head, **cp, compute_dtype=_dtype(ex.get('head_dtype')))
         # opt-in: eval-mode voxel encoder + head on the fp32-MFMA implicit-GEMM kernel (mfma_conv3d.py; validated on the
         # CPU emulator only so far, hence off by default)
-        self.mfma_conv3d = bool(ex.get('mfma_conv3d', False))
+        self.mfma_conv3d = ex.get('mfma_conv3d', False)          # False | True (fp32 MFMA) | 'bf16' (bf16 MFMA where Cin % 32 == 0)
         self._runners = None
         if ex.get('mfma_conv3d_train'):           # same status: the autograd route (forward + dgrad + wgrad kernels)
             from .mfma_conv3d import enable_training_route
@@ -126,18 +126,19 @@ class FBOCC(nn.Module):
     def _mfma_stacks(self):
         if self._runners is None:
             from . import mfma_conv3d as M
+            prec = 'bf16' if self.mfma_conv3d == 'bf16' else 'f32'
             img = None
             if self.img_backbone is not None and self.img_neck is not None:
                 try:
-                    img = (M.ResNetRunner(self.img_backbone), M.CustomFPNRunner(self.img_neck))
+                    img = (M.ResNetRunner(self.img_backbone, prec), M.CustomFPNRunner(self.img_neck, prec))
                 except (ValueError, NotImplementedError):      # channel counts / layers outside the kernel: vendor route
                     img = None
-            self._runners = (M.ResNet3DRunner(self.img_bev_encoder_backbone), M.FPN3DRunner(self.img_bev_encoder_neck),
-                             M.OccHeadRunner(self.occupancy_head), img)
+            self._runners = (M.ResNet3DRunner(self.img_bev_encoder_backbone, prec), M.FPN3DRunner(self.img_bev_encoder_neck, prec),
+                             M.OccHeadRunner(self.occupancy_head, prec), img)
         return self._runners
 
     def _use_mfma(self, x):
-        return self.mfma_conv3d and x.is_cuda and not self.training and not torch.is_grad_enabled()
+        return bool(self.mfma_conv3d) and x.is_cuda and not self.training and not torch.is_grad_enabled()
 
     def reset_history(self):
         self.history.reset()

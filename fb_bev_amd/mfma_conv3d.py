@@ -39,6 +39,23 @@ def weight_fragments(w, transposed=False):
     return wp.permute(5, 2, 0, 3, 1, 4).contiguous().view(-1)                               # tap, j, mt, kk, i, e
 
 
+def weight_fragments_bf16(w, transposed=False):
+    """bf16 fragment layout of fbbev_conv3d_ndhwc_bf16: wfb[parity][tap][j][mt][lane = 16 g + i][e] =
+    bf16(W[cout = 16 mt + i][cin = 32 j + 8 g + e][tap]) -> flat torch.bfloat16 tensor."""
+    if transposed:
+        blocks = [weight_fragments_bf16(w[:, :, a, b, c].transpose(0, 1).reshape(w.shape[1], w.shape[0], 1, 1, 1))
+                  for a in range(2) for b in range(2) for c in range(2)]
+        return torch.cat(blocks)
+    Cout, Cin = w.shape[:2]
+    T = w[0, 0].numel()
+    if Cin % 32:
+        raise ValueError('fbbev_conv3d_ndhwc_bf16 needs Cin % 32 == 0')
+    MT = (Cout + 15) // 16
+    wp = F.pad(w.reshape(Cout, Cin, T).float(), (0, 0, 0, 0, 0, 16 * MT - Cout))            # (16 MT, Cin, T)
+    wp = wp.view(MT, 16, Cin // 32, 4, 8, T)                                                # mt, i, j, g, e, tap
+    return wp.permute(5, 2, 0, 3, 1, 4).contiguous().view(-1).to(torch.bfloat16)            # tap, j, mt, g, i, e
+
+
 def fold(conv, bn=None):
     """(weight, bias) of conv followed by eval-mode batch norm as one affine convolution."""
     w = conv.weight.detach().float()
@@ -55,10 +72,26 @@ def fold(conv, bn=None):
     return w, b
 
 
-class FoldedConv3d:
-    """One launch of fbbev_conv3d_ndhwc: conv (+ folded BN) (+ residual) (+ ReLU) on NDHWC activations."""
+def _launch(x, wf, bias, out, cout, backend=None, planar=False, **kw):
+    """One convolution launch.  The kernel follows the weight layout: bf16 fragments -> fbbev_conv3d_ndhwc_bf16, fp32
+    fragments -> fbbev_conv3d_ndhwc / fbbev_conv2d_nhwc.  `backend` (tests) stands in for the HIP entry points."""
+    if backend is not None:
+        return backend(x, wf, bias, out, cout, planar=planar, **kw)
+    if wf.dtype == torch.bfloat16:
+        if planar:
+            _capi.conv3d_ndhwc_bf16(x.unsqueeze(1), wf, bias, out.unsqueeze(1), cout, planar=True, **kw)
+            return out
+        return _capi.conv3d_ndhwc_bf16(x, wf, bias, out, cout, **kw)
+    if planar:
+        return _capi.conv2d_nhwc(x, wf, bias, out, cout, **kw)
+    return _capi.conv3d_ndhwc(x, wf, bias, out, cout, **kw)
 
-    def __init__(self, conv, bn=None, relu=False):
+
+class FoldedConv3d:
+    """One launch of fbbev_conv3d_ndhwc[_bf16]: conv (+ folded BN) (+ residual) (+ ReLU) on NDHWC activations.
+    precision='bf16' takes the bf16-MFMA kernel where the input channels allow it (Cin % 32 == 0), fp32 otherwise."""
+
+    def __init__(self, conv, bn=None, relu=False, precision='f32'):
         self.transposed = isinstance(conv, nn.ConvTranspose3d)
         k, s, p = conv.kernel_size, conv.stride, conv.padding
         if len(set(k)) != 1 or len(set(s)) != 1 or len(set(p)) != 1:
@@ -71,7 +104,9 @@ class FoldedConv3d:
         self.ksize, self.stride, self.pad, self.relu = k[0], s[0], p[0], relu
         w, b = fold(conv, bn)
         self.cout = w.shape[1] if self.transposed else w.shape[0]
-        self.wf = weight_fragments(w, self.transposed)
+        cin = w.shape[0] if self.transposed else w.shape[1]
+        self.wf = weight_fragments_bf16(w, self.transposed) if (precision == 'bf16' and cin % 32 == 0) \
+            else weight_fragments(w, self.transposed)
         self.bias = F.pad(b, (0, (self.cout + 15) // 16 * 16 - self.cout)).contiguous()
 
     def out_shape(self, x):
@@ -83,9 +118,8 @@ class FoldedConv3d:
 
     def __call__(self, x, residual=None, backend=None):
         out = torch.empty(self.out_shape(x), dtype=torch.float32, device=x.device)
-        run = backend or _capi.conv3d_ndhwc
-        return run(x, self.wf, self.bias, out, self.cout, ksize=self.ksize, stride=self.stride, pad=self.pad, relu=self.relu,
-                   residual=residual, transposed=self.transposed)
+        return _launch(x, self.wf, self.bias, out, self.cout, backend=backend, ksize=self.ksize, stride=self.stride, pad=self.pad,
+                       relu=self.relu, residual=residual, transposed=self.transposed)
 
 
 # ------------------------------------------------------------------ training route (autograd)
@@ -226,17 +260,18 @@ def to_ncdhw(x):
 class ResNet3DRunner:
     """CustomResNet3D.forward (resnet3d.py:248-274) with every conv+BN(+residual)+ReLU group as one launch."""
 
-    def __init__(self, net):
+    def __init__(self, net, precision='f32'):
         if net.plane2voxel is not None:
             raise NotImplementedError('plane2voxel')
         self.out_indices = net.out_indices
-        self.input_proj = FoldedConv3d(net.input_proj[0], net.input_proj[1], relu=True)
+        FC = lambda *a, **k: FoldedConv3d(*a, precision=precision, **k)  # noqa: E731
+        self.input_proj = FC(net.input_proj[0], net.input_proj[1], relu=True)
         self.stages = []
         for layer in net.layers:
             blocks = []
             for blk in layer:
-                down = None if blk.downsample is None else FoldedConv3d(blk.downsample[0], blk.downsample[1], relu=False)
-                blocks.append((FoldedConv3d(blk.conv1, blk.bn1, relu=True), FoldedConv3d(blk.conv2, blk.bn2, relu=True), down))
+                down = None if blk.downsample is None else FC(blk.downsample[0], blk.downsample[1], relu=False)
+                blocks.append((FC(blk.conv1, blk.bn1, relu=True), FC(blk.conv2, blk.bn2, relu=True), down))
             self.stages.append(blocks)
 
     def __call__(self, x, backend=None):
@@ -255,8 +290,9 @@ class ResNet3DRunner:
 class FPN3DRunner:
     """FPN3D.forward (fpn3d.py:72-110)."""
 
-    def __init__(self, neck):
-        mk = lambda seq: FoldedConv3d(seq[0].conv, getattr(seq[0], seq[0].norm_name), relu=seq[0].activate is not None)  # noqa: E731
+    def __init__(self, neck, precision='f32'):
+        mk = lambda seq: FoldedConv3d(seq[0].conv, getattr(seq[0], seq[0].norm_name), relu=seq[0].activate is not None,  # noqa: E731
+                                      precision=precision)
         self.laterals = [mk(s) for s in neck.lateral_convs]
         self.outs = [mk(s) for s in neck.fpn_convs]
         self.upsample_cfg = dict(neck.upsample_cfg)
@@ -272,15 +308,15 @@ class FPN3DRunner:
 class OccHeadRunner:
     """OccHead.forward_coarse_voxel (occupancy_head.py:143-181) -> class logits (B, classes, H, W, D) like the module."""
 
-    def __init__(self, head):
-        self.deblock = FoldedConv3d(head.deblock[0], head.deblock[1], relu=True) if head.use_deblock else None
-        self.occ_convs = [FoldedConv3d(s[0], s[1], relu=True) for s in head.occ_convs]
-        self.pred = (FoldedConv3d(head.occ_pred_conv[0], head.occ_pred_conv[1], relu=True),
-                     FoldedConv3d(head.occ_pred_conv[3], None, relu=False))
+    def __init__(self, head, precision='f32'):
+        FC = lambda *a, **k: FoldedConv3d(*a, precision=precision, **k)  # noqa: E731
+        self.deblock = FC(head.deblock[0], head.deblock[1], relu=True) if head.use_deblock else None
+        self.occ_convs = [FC(s[0], s[1], relu=True) for s in head.occ_convs]
+        self.pred = (FC(head.occ_pred_conv[0], head.occ_pred_conv[1], relu=True), FC(head.occ_pred_conv[3], None, relu=False))
         self.soft = None
         if head.soft_weights:
-            self.soft = (FoldedConv3d(head.voxel_soft_weights[0], head.voxel_soft_weights[1], relu=True),
-                         FoldedConv3d(head.voxel_soft_weights[3], None, relu=False))
+            self.soft = (FC(head.voxel_soft_weights[0], head.voxel_soft_weights[1], relu=True),
+                         FC(head.voxel_soft_weights[3], None, relu=False))
         self.n_feat = head.num_point_sampling_feat
 
     def __call__(self, feats, backend=None, blend_backend=None):
@@ -311,7 +347,7 @@ class OccHeadRunner:
 class FoldedConv2d:
     """One launch of fbbev_conv2d_nhwc: Conv2d (+ folded BN) (+ residual) (+ ReLU) on NHWC activations."""
 
-    def __init__(self, conv, bn=None, relu=False):
+    def __init__(self, conv, bn=None, relu=False, precision='f32'):
         k, s, p = conv.kernel_size, conv.stride, conv.padding
         if len(set(k)) != 1 or len(set(s)) != 1 or len(set(p)) != 1 or k[0] not in (1, 3) or s[0] not in (1, 2) \
                 or p[0] not in (0, 1) or conv.groups != 1 or set(conv.dilation) != {1}:
@@ -324,35 +360,34 @@ class FoldedConv2d:
             w = w * scale.view(-1, 1, 1, 1)
             b = (b - bn.running_mean.float()) * scale + bn.bias.detach().float()
         self.cout = w.shape[0]
-        self.wf = weight_fragments(w[:, :, None])
+        self.wf = weight_fragments_bf16(w[:, :, None]) if (precision == 'bf16' and w.shape[1] % 32 == 0) else weight_fragments(w[:, :, None])
         self.bias = F.pad(b, (0, (self.cout + 15) // 16 * 16 - self.cout)).contiguous()
 
     def __call__(self, x, residual=None, backend=None):
         B, H, W, _ = x.shape
         f = lambda n: (n + 2 * self.pad - self.ksize) // self.stride + 1  # noqa: E731
         out = torch.empty((B, f(H), f(W), self.cout), dtype=torch.float32, device=x.device)
-        run = backend or _capi.conv2d_nhwc
-        return run(x, self.wf, self.bias, out, self.cout, ksize=self.ksize, stride=self.stride, pad=self.pad, relu=self.relu,
-                   residual=residual)
+        return _launch(x, self.wf, self.bias, out, self.cout, backend=backend, planar=True, ksize=self.ksize, stride=self.stride,
+                       pad=self.pad, relu=self.relu, residual=residual)
 
 
 class ResNetRunner:
     """img_encoder.ResNet.forward in eval mode: the 7x7 stem (3 input channels) and the max-pool stay torch; every
     residual block is 2-3 launches (conv+BN+ReLU ..., the last one with the identity added before the ReLU)."""
 
-    def __init__(self, net):
+    def __init__(self, net, precision='f32'):
         self.net = net
+        FC2 = lambda *a, **k: FoldedConv2d(*a, precision=precision, **k)  # noqa: E731
         self.out_indices = net.out_indices
         self.stages = []
         for name in net.res_layers:
             blocks = []
             for blk in getattr(net, name):
-                down = None if blk.downsample is None else FoldedConv2d(blk.downsample[0], blk.downsample[1], relu=False)
+                down = None if blk.downsample is None else FC2(blk.downsample[0], blk.downsample[1], relu=False)
                 if hasattr(blk, 'conv3'):
-                    convs = [FoldedConv2d(blk.conv1, blk.bn1, relu=True), FoldedConv2d(blk.conv2, blk.bn2, relu=True),
-                             FoldedConv2d(blk.conv3, blk.bn3, relu=True)]
+                    convs = [FC2(blk.conv1, blk.bn1, relu=True), FC2(blk.conv2, blk.bn2, relu=True), FC2(blk.conv3, blk.bn3, relu=True)]
                 else:
-                    convs = [FoldedConv2d(blk.conv1, blk.bn1, relu=True), FoldedConv2d(blk.conv2, blk.bn2, relu=True)]
+                    convs = [FC2(blk.conv1, blk.bn1, relu=True), FC2(blk.conv2, blk.bn2, relu=True)]
                 blocks.append((convs, down))
             self.stages.append(blocks)
 
@@ -377,10 +412,11 @@ class ResNetRunner:
 class CustomFPNRunner:
     """img_encoder.CustomFPN.forward (necks/fpn.py:160-206) on NHWC maps -> (B,C,H,W) logical view of outs[0]."""
 
-    def __init__(self, neck):
+    def __init__(self, neck, precision='f32'):
         if len(neck.fpn_convs) != len(neck.out_ids) or neck.num_outs != len(neck.out_ids):
             raise NotImplementedError('extra output levels')
-        mk = lambda m: FoldedConv2d(m.conv, getattr(m, m.norm_name) if m.norm_name else None, relu=m.activate is not None)  # noqa: E731
+        mk = lambda m: FoldedConv2d(m.conv, getattr(m, m.norm_name) if m.norm_name else None, relu=m.activate is not None,  # noqa: E731
+                                    precision=precision)
         self.laterals = [mk(m) for m in neck.lateral_convs]
         self.outs = [mk(m) for m in neck.fpn_convs]
         self.out_ids, self.start_level, self.upsample_cfg = list(neck.out_ids), neck.start_level, dict(neck.upsample_cfg)

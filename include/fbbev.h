@@ -351,6 +351,16 @@ int fbbev_conv2d_nhwc(const float* x, const float* weight_fragments, const float
                       int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int ksize, int stride, int pad, int relu,
                       float* out, fbbev_stream_t stream);
 
+/* bf16-MFMA variant of fbbev_conv3d_ndhwc / fbbev_conv2d_nhwc (inference): same fp32 NDHWC activations, bias, residual and
+ * output; inputs and weights are rounded to bf16 (nearest even) in front of v_mfma_f32_16x16x32_bf16, accumulation is
+ * fp32 -- the execution option the detector's `*_dtype='bf16'` knobs select on the vendor route, here on the hand-written one.
+ *   weight_fragments_bf16[parity][tap][j][mt][lane][e] = bf16(W[cout = 16mt + lane%16][cin = 32j + 8(lane/16) + e][tap]);
+ *   planar != 0: x is one plane (Di = Do = 1) and the kernel has a single tap along that axis (the 2-D case).
+ * ksize 1 or 3 (transposed: kernel 2 stride 2), Cin % 32 == 0, else FBBEV_E_UNSUPPORTED. */
+int fbbev_conv3d_ndhwc_bf16(const float* x, const void* weight_fragments_bf16, const float* bias, const float* residual,
+                            int B, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout, int ksize, int stride,
+                            int pad, int relu, int transposed, int planar, float* out, fbbev_stream_t stream);
+
 /* Data gradient of fbbev_conv3d_ndhwc's convolution (training): dx[i] = sum_k W_k^T dy[(i + pad - k) / stride] over the
  * taps for which the division is exact.  dy (B,Do,Ho,Wo,Cout), dx (B,Di,Hi,Wi,Cin) with the forward geometry (checked);
  * weight_fragments_t = the fragment layout of the TRANSPOSED weight (Cin, Cout, k, k, k) -- same tap index;

@@ -300,3 +300,19 @@ def conv2d_nhwc(x, wf, bias, Cout, ksize=3, stride=1, pad=1, relu=False, residua
     code = lib().fbbev_conv2d_nhwc(p(x), p(wf), p(bias), p(residual) if residual is not None else None, B, Hi, Wi, Cin, Ho, Wo, Cout,
                                    ksize, stride, pad, 1 if relu else 0, p(out), None)
     return code, out
+
+
+def conv3d_ndhwc_bf16(x, wfb, bias, Cout, ksize=3, stride=1, pad=1, relu=False, residual=None, transposed=False, planar=False):
+    B, Di, Hi, Wi, Cin = x.shape
+    if transposed:
+        Do, Ho, Wo = Di, Hi, Wi
+        out = torch.full((B, 2 * Di, 2 * Hi, 2 * Wi, Cout), float('nan'))
+    else:
+        Do = 1 if planar else (Di + 2 * pad - ksize) // stride + 1
+        Ho, Wo = [(n + 2 * pad - ksize) // stride + 1 for n in (Hi, Wi)]
+        out = torch.full((B, Do, Ho, Wo, Cout), float('nan'))
+    assert wfb.dtype == torch.bfloat16 and wfb.is_contiguous()
+    code = lib().fbbev_conv3d_ndhwc_bf16(p(x), c_void_p(wfb.data_ptr()), p(bias), p(residual) if residual is not None else None, B,
+                                         Di, Hi, Wi, Cin, Do, Ho, Wo, Cout, ksize, stride, pad, 1 if relu else 0,
+                                         1 if transposed else 0, 1 if planar else 0, p(out), None)
+    return code, out

@@ -183,5 +183,41 @@ inline fbbev_v4f fbbev_mfma_f32_16x16x4(float a, float b, fbbev_v4f c) {
     return d;
 }
 
+// bf16 (round to nearest even, NaN kept quiet) and the emulation of v_mfma_f32_16x16x32_bf16: slot (lane/16, e) of A and B
+// stands for k = 8*(lane/16) + e; products are exact in fp32, accumulation is a k-ordered fp32 chain (the hardware's
+// internal order is unspecified: tests compare with a tolerance)
+struct fbbev_bf16x8 { uint16_t v[8]; };
+inline uint16_t fbbev_emu_bf16(float f) {
+    uint32_t u; memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+inline float fbbev_emu_bf16_to_f32(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+inline fbbev_bf16x8 fbbev_cvt_bf16x8(fbbev_v4f lo, fbbev_v4f hi) {
+    fbbev_bf16x8 r;
+    for (int e = 0; e < 4; ++e) { r.v[e] = fbbev_emu_bf16(lo[e]); r.v[4 + e] = fbbev_emu_bf16(hi[e]); }
+    return r;
+}
+inline fbbev_bf16x8 fbbev_ld_bf16x8(const void* p) { fbbev_bf16x8 r; memcpy(&r, p, 16); return r; }
+inline fbbev_v4f fbbev_mfma_f32_16x16x32_bf16(fbbev_bf16x8 a, fbbev_bf16x8 b, fbbev_v4f c) {
+    emu::State& s = emu::S();
+    const int w = s.cur >> 6, lane = s.cur & 63;
+    static thread_local fbbev_bf16x8 A[16][64], B[16][64];
+    A[w][lane] = a; B[w][lane] = b;
+    emu::wave_barrier();
+    const int g = lane >> 4, j = lane & 15;
+    fbbev_v4f d = c;
+    for (int r = 0; r < 4; ++r) {
+        float acc = c[r];
+        for (int gg = 0; gg < 4; ++gg)
+            for (int e = 0; e < 8; ++e)
+                acc += fbbev_emu_bf16_to_f32(A[w][gg * 16 + 4 * g + r].v[e]) * fbbev_emu_bf16_to_f32(B[w][gg * 16 + j].v[e]);
+        d[r] = acc;
+    }
+    emu::wave_barrier();
+    return d;
+}
+
 inline void fbbev_wave_sync() { emu::wave_barrier(); }
 inline void fbbev_sched_fence() {}

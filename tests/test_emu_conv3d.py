@@ -15,9 +15,20 @@ import emu_capi as E  # noqa: E402
 from fb_bev_amd import mfma_conv3d as M  # noqa: E402
 
 
-def emu_backend(x, wf, bias, out, Cout, ksize=3, stride=1, pad=1, relu=False, residual=None, transposed=False):
-    code, y = E.conv3d_ndhwc(x.contiguous(), wf, bias, Cout, ksize=ksize, stride=stride, pad=pad, relu=relu,
-                             residual=None if residual is None else residual.contiguous(), transposed=transposed)
+def emu_backend(x, wf, bias, out, Cout, planar=False, ksize=3, stride=1, pad=1, relu=False, residual=None, transposed=False):
+    """The HIP entry points on the emulator, chosen like mfma_conv3d._launch: by the weight layout and `planar`."""
+    res = None if residual is None else residual.contiguous()
+    if wf.dtype == torch.bfloat16:
+        x5 = x.unsqueeze(1) if planar else x
+        code, y = E.conv3d_ndhwc_bf16(x5.contiguous(), wf, bias, Cout, ksize=ksize, stride=stride, pad=pad, relu=relu,
+                                      residual=None if res is None else (res.unsqueeze(1) if planar else res), transposed=transposed,
+                                      planar=planar)
+        y = y.squeeze(1) if planar else y
+    elif planar:
+        code, y = E.conv2d_nhwc(x.contiguous(), wf, bias, Cout, ksize=ksize, stride=stride, pad=pad, relu=relu, residual=res)
+    else:
+        code, y = E.conv3d_ndhwc(x.contiguous(), wf, bias, Cout, ksize=ksize, stride=stride, pad=pad, relu=relu, residual=res,
+                                 transposed=transposed)
     assert code == 0
     assert tuple(y.shape) == tuple(out.shape) and not torch.isnan(y).any()          # every element written
     return y
@@ -296,13 +307,6 @@ def test_conv2d_nhwc_vs_torch(B, hw, Cin, Cout, k, s, p, relu, res):
     assert torch.allclose(y.permute(0, 3, 1, 2), exp, atol=1e-4, rtol=1e-4), (y.permute(0, 3, 1, 2) - exp).abs().max()
 
 
-def emu_conv2d(x, wf, bias, out, Cout, ksize=3, stride=1, pad=1, relu=False, residual=None):
-    code, y = E.conv2d_nhwc(x.contiguous(), wf, bias, Cout, ksize=ksize, stride=stride, pad=pad, relu=relu,
-                            residual=None if residual is None else residual.contiguous())
-    assert code == 0 and tuple(y.shape) == tuple(out.shape) and not torch.isnan(y).any()
-    return y
-
-
 @pytest.mark.parametrize('depth', [18, 50])
 def test_image_encoder_runners_equal_the_modules(depth):
     from fb_bev_amd.img_encoder import CustomFPN, ResNet
@@ -323,8 +327,77 @@ def test_image_encoder_runners_equal_the_modules(depth):
     with torch.no_grad():
         ref_feats = net(img)
         ref = neck(ref_feats)
-        feats = M.ResNetRunner(net)(img, backend=emu_conv2d)
-        got = M.CustomFPNRunner(neck)(feats, backend=emu_conv2d)
+        feats = M.ResNetRunner(net)(img, backend=emu_backend)
+        got = M.CustomFPNRunner(neck)(feats, backend=emu_backend)
     for a, b in zip(feats, ref_feats):
         assert torch.allclose(a.permute(0, 3, 1, 2), b, atol=1e-4, rtol=1e-4), (a.permute(0, 3, 1, 2) - b).abs().max()
     assert got.shape == ref.shape and torch.allclose(got, ref, atol=1e-4, rtol=1e-4)
+
+
+def _bf(t):
+    return t.to(torch.bfloat16).float()
+
+
+@pytest.mark.parametrize('B,dims,Cin,Cout,k,s,p,relu,res,planar', [
+    (1, (5, 6, 3), 32, 16, 3, 1, 1, False, False, False),
+    (2, (5, 6, 3), 64, 64, 3, 2, 1, True, True, False),
+    (1, (3, 5, 2), 96, 19, 1, 1, 0, False, False, False),          # odd number of 32-channel groups; scalar stores
+    (1, (1, 9, 7), 32, 32, 3, 1, 1, True, False, True),            # planar: the 2-D case
+    (1, (1, 8, 6), 64, 48, 1, 2, 0, False, True, True),
+])
+def test_conv3d_bf16_kernel_vs_torch_on_rounded_operands(B, dims, Cin, Cout, k, s, p, relu, res, planar):
+    """fbbev_conv3d_ndhwc_bf16 == an fp32 convolution of the bf16-rounded input and weight (fp32 accumulation)."""
+    g = torch.Generator().manual_seed(Cin + Cout + k)
+    x = torch.randn(B, Cin, *dims, generator=g)
+    w = torch.randn(Cout, Cin, k, k, k, generator=g) / (Cin * k ** 3) ** 0.5
+    if planar:
+        w = w[:, :, :1].contiguous()
+    b = torch.randn(Cout, generator=g)
+    pad = (0, p, p) if planar else p
+    exp = F.conv3d(_bf(x), _bf(w), b, stride=(1, s, s) if planar else s, padding=pad)
+    r = torch.randn(exp.shape, generator=g) if res else None
+    exp = exp + r if res else exp
+    exp = exp.relu() if relu else exp
+    code, y = E.conv3d_ndhwc_bf16(M.to_ndhwc(x), M.weight_fragments_bf16(w), F.pad(b, (0, (Cout + 15) // 16 * 16 - Cout)), Cout, ksize=k,
+                                  stride=s, pad=p, relu=relu, residual=None if r is None else M.to_ndhwc(r), planar=planar)
+    assert code == 0 and not torch.isnan(y).any()
+    assert torch.allclose(M.to_ncdhw(y), exp, atol=1e-4, rtol=1e-4), (M.to_ncdhw(y) - exp).abs().max()
+    # and it is a bf16-precision approximation of the fp32 convolution
+    full = F.conv3d(x, w, b, stride=(1, s, s) if planar else s, padding=pad)
+    full = (full + r if res else full)
+    full = full.relu() if relu else full
+    assert (M.to_ncdhw(y) - full).abs().max() < 3e-2
+
+
+def test_transposed_conv_bf16_vs_torch():
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 64, 3, 4, 2, generator=g)
+    w = torch.randn(64, 24, 2, 2, 2, generator=g) / 8
+    exp = F.conv_transpose3d(_bf(x), _bf(w), None, stride=2)
+    code, y = E.conv3d_ndhwc_bf16(M.to_ndhwc(x), M.weight_fragments_bf16(w, transposed=True), torch.zeros(32), 24, transposed=True)
+    assert code == 0 and torch.allclose(M.to_ncdhw(y), exp, atol=1e-4, rtol=1e-4)
+    assert E.conv3d_ndhwc_bf16(torch.zeros(1, 2, 2, 2, 16), torch.zeros(27 * 512, dtype=torch.bfloat16), torch.zeros(16), 16)[0] == -2
+
+
+def test_bf16_runners_track_the_fp32_modules():
+    """precision='bf16': layers with Cin % 32 == 0 take the bf16-MFMA kernel (fp32 activations in and out), the others the fp32
+    one; the stack output stays within bf16 accuracy of the fp32 modules."""
+    from fb_bev_amd.bev_encoder import CustomResNet3D, FPN3D
+    from fb_bev_amd.occ_head import OccHead
+    torch.manual_seed(0)
+    chans = [32, 32, 64]
+    bb = _randomise(CustomResNet3D(depth=10, block_strides=[1, 2, 2], n_input_channels=16, block_inplanes=chans,
+                                   out_indices=(0, 1, 2), norm_cfg=dict(type='SyncBN')), 1)
+    neck = _randomise(FPN3D(in_channels=chans, out_channels=64, norm_cfg=dict(type='SyncBN')), 2)
+    head = _randomise(OccHead(in_channels=[64] * 3, out_channel=19, num_level=3, soft_weights=True, use_focal_loss=False,
+                              norm_cfg=dict(type='SyncBN'), final_occ_size=[16, 16, 8], empty_idx=18), 3)
+    rb, rn, rh = M.ResNet3DRunner(bb, 'bf16'), M.FPN3DRunner(neck, 'bf16'), M.OccHeadRunner(head, 'bf16')
+    assert rb.input_proj.wf.dtype == torch.float32                          # 16 input channels: fp32 kernel
+    assert rb.stages[0][0][1].wf.dtype == torch.bfloat16 and rn.outs[0].wf.dtype == torch.bfloat16
+    assert rh.deblock.wf.dtype == torch.bfloat16 and rh.pred[1].wf.dtype == torch.float32      # 16 -> 19: fp32
+    x = torch.randn(1, 16, 8, 8, 4)
+    with torch.no_grad():
+        ref = head(neck(bb(x)))['output_voxels'][0]
+        got = rh(rn(rb(M.to_ndhwc(x), backend=emu_backend), backend=emu_backend), backend=emu_backend, blend_backend=emu_blend)
+    err = (got - ref).abs().max() / ref.abs().max()
+    assert 0 < err < 3e-2, err

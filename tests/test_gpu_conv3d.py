@@ -140,3 +140,22 @@ def test_image_encoder_mfma_route_equals_vendor_route(dev):
         ref = neck(net(img))
         got = M.CustomFPNRunner(neck)(M.ResNetRunner(net)(img))
     assert (got - ref).abs().max() <= 1e-3 * ref.abs().max()
+
+
+@pytest.mark.parametrize('B,dims,Cin,Cout,k,s,p,planar', [(1, (100, 100, 8), 64, 64, 3, 1, 1, False), (1, (25, 25, 2), 256, 256, 3, 1, 1, False),
+                                                          (2, (1, 16, 44), 256, 512, 3, 1, 1, True), (1, (40, 40, 16), 128, 64, 1, 1, 0, False)])
+def test_conv3d_bf16_kernel_vs_torch_on_rounded_operands(dev, B, dims, Cin, Cout, k, s, p, planar):
+    """First check of the bf16 MFMA route on the hardware (the slot -> k rule of v_mfma_f32_16x16x32_bf16 cancels between the
+    two operands; the row / column lane rule is what this verifies)."""
+    from fb_bev_amd import _capi, mfma_conv3d as M
+    g = torch.Generator().manual_seed(Cin + Cout)
+    x = torch.randn(B, Cin, *dims, generator=g).to(dev)
+    w = (torch.randn(Cout, Cin, 1 if planar else k, k, k, generator=g) / (Cin * k ** 3) ** 0.5).to(dev)
+    b = torch.randn(Cout, generator=g).to(dev)
+    bf = lambda t: t.to(torch.bfloat16).double()  # noqa: E731
+    exp = F.conv3d(bf(x), bf(w), b.double(), stride=(1, s, s) if planar else s, padding=(0, p, p) if planar else p).relu()
+    out = torch.full((B, *exp.shape[2:], Cout), float('nan'), device=dev)
+    _capi.conv3d_ndhwc_bf16(M.to_ndhwc(x), M.weight_fragments_bf16(w), F.pad(b, (0, (Cout + 15) // 16 * 16 - Cout)), out, Cout, ksize=k,
+                            stride=s, pad=p, relu=True, planar=planar)
+    assert not torch.isnan(out).any()
+    assert torch.allclose(M.to_ncdhw(out).double(), exp, atol=1e-4, rtol=1e-4), (M.to_ncdhw(out).double() - exp).abs().max()

@@ -4,7 +4,7 @@
 with random-init weights and synthetic inputs of SURVEY Appendix B.
 
     python tools/time_full.py infer B [f32|bf16] [mfma]   S4: images -> occupancy class ids (device), per-stage split;
-                                                          mfma = voxel encoder + head on fbbev_conv3d_ndhwc (fp32 MFMA)
+                                                          mfma | mfma_bf16 = conv stacks on fbbev_conv3d_ndhwc (fp32 MFMA) / _bf16
     python tools/time_full.py train B [f32|bf16] [mfma]   S5: forward_train + backward + grad all-reduce + clip + AdamW step
 
 bf16 = convolution stacks (image encoder, depth net, voxel encoder, head) under bf16 autocast; the view transformation,
@@ -28,7 +28,7 @@ def build(dtype, with_cp=False, mfma=False, mfma_train=False):
     cfg = dict(json.load(open(os.path.join(ROOT, 'tests', 'golden', 'fbocc_config_path_blocks.json')))
                ['fbocc-r50-cbgs_depth_16f_16x4_20e.py']['model'])
     cfg.pop('type')
-    ex = dict(with_cp=with_cp, mfma_conv3d=mfma, mfma_conv3d_train=mfma_train)
+    ex = dict(with_cp=with_cp, mfma_conv3d=mfma, mfma_conv3d_train=mfma_train)     # mfma: False | True | 'bf16'
     if dtype == 'bf16':
         ex.update(img_dtype='bf16', depth_dtype='bf16', voxel_dtype='bf16', head_dtype='bf16')
     torch.manual_seed(0)
@@ -156,6 +156,6 @@ if __name__ == '__main__':
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     dtype = sys.argv[3] if len(sys.argv) > 3 else 'f32'
     if mode == 'infer':
-        infer(B, dtype, mfma=len(sys.argv) > 4 and sys.argv[4] == 'mfma')
+        infer(B, dtype, mfma={'mfma': True, 'mfma_bf16': 'bf16'}.get(sys.argv[4] if len(sys.argv) > 4 else '', False))
     else:
         train(B, dtype, mfma=len(sys.argv) > 4 and sys.argv[4] == 'mfma')
