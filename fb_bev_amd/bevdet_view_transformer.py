@@ -13,7 +13,6 @@ for the splat.  P stays on the device in both variants: no host synchronisation 
 gather, an argsort and a `where`.  Not referenced by any fb_occ config (lowest rank of SURVEY 8f); kept to the module
 interface: `forward(input) -> (bev_feat, depth)`.
 """
-import torch
 import torch.nn as nn
 from torch.utils.checkpoint import checkpoint
 
