@@ -45,6 +45,7 @@ SIGNATURES = {
     'fbbev_conv3d_ndhwc': (c_int, [c_void_p] * 4 + [c_int] * 14 + [c_void_p, c_void_p]),
     'fbbev_conv2d_nhwc': (c_int, [c_void_p] * 4 + [c_int] * 11 + [c_void_p, c_void_p]),
     'fbbev_conv3d_ndhwc_bf16': (c_int, [c_void_p] * 4 + [c_int] * 15 + [c_void_p, c_void_p]),
+    'fbbev_conv3d_k3s1_tiled_bf16': (c_int, [c_void_p] * 4 + [c_int] * 7 + [c_void_p, c_void_p]),
     'fbbev_conv3d_dgrad_ndhwc': (c_int, [c_void_p] * 3 + [c_int] * 12 + [c_void_p, c_void_p]),
     'fbbev_conv3d_wgrad_ndhwc': (c_int, [c_void_p] * 2 + [c_int] * 12 + [c_void_p, c_void_p]),
     'fbbev_blend_levels_ndhwc': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p] + [c_int] * 6 + [c_void_p, c_void_p]),
@@ -523,6 +524,19 @@ def conv3d_ndhwc_bf16(x, weight_fragments_bf16, bias, out, Cout, ksize=3, stride
             None if residual is None else _dev(residual, F32, 'residual'), B, Di, Hi, Wi, Cin, int(Do), int(Ho), int(Wo), int(Cout),
             int(ksize), int(stride), int(pad), 1 if relu else 0, 1 if transposed else 0, 1 if planar else 0,
             _dev(out, F32, 'out'), _stream()), 'fbbev_conv3d_ndhwc_bf16')
+    return out
+
+
+def conv3d_k3s1_tiled_bf16(x, weight_fragments_bf16, bias, out, Cout, relu=False, residual=None):
+    """3x3x3 / stride 1 / padding 1 on (B,D,H,W,Cin) f32 with the LDS-staged halo tile (bf16 MFMA)."""
+    B, D, H, W, Cin = x.shape
+    if tuple(out.shape) != (B, D, H, W, Cout) or weight_fragments_bf16.dtype != torch.bfloat16:
+        raise FbbevError('conv3d_k3s1_tiled_bf16: bad out shape / weight dtype')
+    with _on(x):
+        _check(lib().fbbev_conv3d_k3s1_tiled_bf16(
+            _dev(x, F32, 'x'), _dev(weight_fragments_bf16, torch.bfloat16, 'weight_fragments_bf16'), _dev(bias, F32, 'bias'),
+            None if residual is None else _dev(residual, F32, 'residual'), B, D, H, W, Cin, int(Cout), 1 if relu else 0,
+            _dev(out, F32, 'out'), _stream()), 'fbbev_conv3d_k3s1_tiled_bf16')
     return out
 
 

@@ -1068,6 +1068,35 @@ extern "C" int fbbev_conv3d_ndhwc_bf16(const float* x, const void* weight_fragme
     return 0;
 }
 
+extern "C" int fbbev_conv3d_k3s1_tiled_bf16(const float* x, const void* weight_fragments_bf16, const float* bias,
+                                            const float* residual, int B, int D, int H, int W, int Cin, int Cout, int relu,
+                                            float* out, fbbev_stream_t stream_) {
+    if (B < 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return FBBEV_E_BADARG;
+    if (B == 0) return 0;
+    if (!x || !weight_fragments_bf16 || !bias || !out) return FBBEV_E_BADARG;
+    if (Cin % 32 != 0 || !aligned16(x) || !aligned16(weight_fragments_bf16) || !aligned16(bias) || !aligned16(out) ||
+        (residual && !aligned16(residual))) return FBBEV_E_UNSUPPORTED;
+    const int tiles_d = (D + 3) / 4, tiles_h = (H + 7) / 8, tiles_w = (W + 7) / 8;
+    const int mt_total = (Cout + 15) / 16;
+    const int MT = mt_total % 4 == 0 ? 4 : (mt_total % 2 == 0 ? 2 : 1);
+    const int gy = mt_total / MT;
+    const long long grid = (long long)B * tiles_d * tiles_h * tiles_w * gy;
+    if (grid >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
+    const size_t lds = (size_t)2 * 600 * 32 * sizeof(unsigned short);
+    const unsigned short* wfb = static_cast<const unsigned short*>(weight_fragments_bf16);
+#define FBBEV_CONV3DT(MT_)                                                                                           \
+    do {                                                                                                             \
+        int e = fbbev_rt_allow_dyn_lds((const void*)k_conv3d_k3_tile_bf16<MT_>, lds);                                \
+        if (e) return e;                                                                                             \
+        FBBEV_LAUNCH((k_conv3d_k3_tile_bf16<MT_>), grid, 512, lds, (fbbev_rt_stream)stream_, x, wfb, bias, residual, out, B, \
+                     D, H, W, Cin, Cout, mt_total, relu ? 1 : 0, tiles_d, tiles_h, tiles_w, gy);                      \
+    } while (0)
+    if (MT == 4) FBBEV_CONV3DT(4); else if (MT == 2) FBBEV_CONV3DT(2); else FBBEV_CONV3DT(1);
+#undef FBBEV_CONV3DT
+    FBBEV_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int fbbev_conv3d_dgrad_ndhwc(const float* dy, const float* weight_fragments_t, const float* zero_bias, int B,
                                         int Do, int Ho, int Wo, int Cout, int Di, int Hi, int Wi, int Cin, int ksize,
                                         int stride, int pad, float* dx, fbbev_stream_t stream_) {

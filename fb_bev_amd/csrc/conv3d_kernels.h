@@ -450,3 +450,146 @@ k_conv3d_ndhwc_bf16(const float* __restrict__ x, const unsigned short* __restric
         }
     }
 }
+
+// ---------------------------------------------------------------- 3x3x3 stride-1 convolution, LDS-staged halo tile (bf16 MFMA)
+// The direct kernels above re-read every input row 27 x (Cout/64) times from L2 / MALL; for the bf16 instruction that
+// traffic, not the matrix pipe, is the bound.  Here a workgroup owns a compact 4 x 8 x 8 voxel tile (wave w = depth slice
+// w, MFMA tile t = rows 2t, 2t+1 of that slice) and stages the tile's (4+2) x (8+2) x (8+2) = 600 halo rows ONCE per
+// 32-channel group into LDS, already rounded to bf16 (64 bytes per row, 38.4 KB per buffer, two buffers): the 27 taps then
+// read their B operands from LDS (16 bytes per lane: a voxel's 4 lanes read the row's 64 bytes; rows 4 apart share banks,
+// i.e. the 4-way pattern a 1 KB wave read needs anyway) and only the A operands (weights, shared by all workgroups) come
+// from L1 / L2.  Input rows are read 600 / 256 = 2.3 times per 64-channel output block instead of 27 times.
+// Producer / consumer split: the workgroup is 8 waves -- waves 0..3 run the MFMAs, waves 4..7 only stage the next channel
+// group into the other LDS buffer (one barrier per group).  The split is what makes the overlap real: a wave's memory
+// counter retires loads in issue order, so a wave that both prefetched 20 row chunks and then needed its next weight
+// fragment would have to wait for all of them; the loader waves have their own counters.  Zero padding and partial tiles
+// are zero rows / skipped stores.
+// Weights: the wfb layout of k_conv3d_ndhwc_bf16.  Requires Cin % 32 == 0; kernel 3, stride 1, padding 1 only.
+template <int MT>
+__global__ void __launch_bounds__(512)
+k_conv3d_k3_tile_bf16(const float* __restrict__ x, const unsigned short* __restrict__ wfb, const float* __restrict__ bias,
+                      const float* __restrict__ residual, float* __restrict__ out, int B, int D, int H, int W, int Cin,
+                      int Cout, int mt_total, int relu, int tiles_d, int tiles_h, int tiles_w, int gy) {
+    constexpr int TD = 4, TH = 8, TW = 8, HD = TD + 2, HH = TH + 2, HW = TW + 2, ROWS = HD * HH * HW;      // 600 halo rows
+    constexpr int ITEMS = (ROWS * 4 + 255) / 256;                  // (row, 8-channel chunk) items per loader thread: 10
+    unsigned short* lds = reinterpret_cast<unsigned short*>(fbbev_dyn_lds_f32());    // [2][ROWS][32] bf16
+    const int tid = threadIdx.x, wave = (tid >> 6) & 3, lane = tid & 63;
+    const bool loader = tid >= 256;
+    const int g = lane >> 4, i = lane & 15;
+    long long id = blockIdx.x;
+    const int by = (int)(id % gy); id /= gy;
+    const int tw = (int)(id % tiles_w); id /= tiles_w;
+    const int th = (int)(id % tiles_h); id /= tiles_h;
+    const int td = (int)(id % tiles_d);
+    const int b = (int)(id / tiles_d);
+    const int d0 = td * TD, h0 = th * TH, w0 = tw * TW;
+    const int mt0 = by * MT;
+    const int J = Cin >> 5;
+    auto stage = [&](int j, int buf) {                               // loader waves: group j's halo rows -> LDS buffer `buf`
+        const fbbev_v4f zero = {0.f, 0.f, 0.f, 0.f};
+        fbbev_v4f slo[ITEMS], shi[ITEMS];
+        bool in[ITEMS];
+#pragma unroll
+        for (int q = 0; q < ITEMS; ++q) {
+            const int item = (tid - 256) + 256 * q;
+            const int row = item >> 2, chunk = item & 3;
+            const int rd = row / (HH * HW), rh = (row / HW) % HH, rw = row % HW;
+            const int vd = d0 - 1 + rd, vh = h0 - 1 + rh, vw = w0 - 1 + rw;
+            in[q] = item < ROWS * 4 && vd >= 0 && vd < D && vh >= 0 && vh < H && vw >= 0 && vw < W;
+            const float* p = x + (in[q] ? ((((long long)b * D + vd) * H + vh) * W + vw) * Cin + 8 * chunk + 32 * j : 0);
+            slo[q] = *reinterpret_cast<const fbbev_v4f*>(p);         // all loads first, then the conversions and LDS stores
+            shi[q] = *reinterpret_cast<const fbbev_v4f*>(p + 4);
+        }
+#pragma unroll
+        for (int q = 0; q < ITEMS; ++q) {
+            const int item = (tid - 256) + 256 * q;
+            if (item >= ROWS * 4) continue;
+            *reinterpret_cast<fbbev_bf16x8*>(lds + buf * (ROWS * 32) + (item >> 2) * 32 + 8 * (item & 3)) =
+                fbbev_cvt_bf16x8(in[q] ? slo[q] : zero, in[q] ? shi[q] : zero);
+        }
+    };
+    // compute waves: this lane's voxel of each MFMA tile -- depth slice = wave, rows 2t + i/8, column i%8 -> halo row of tap (0,0,0)
+    int hrow[4];
+    bool vq[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int lh = 2 * t + (i >> 3), lw = i & 7;
+        hrow[t] = (wave * HH + lh) * HW + lw;
+        vq[t] = !loader && d0 + wave < D && h0 + lh < H && w0 + lw < W;
+    }
+    fbbev_v4f acc[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[mt][t] = fbbev_v4f{0.f, 0.f, 0.f, 0.f};
+    const unsigned short* __restrict__ wfp = wfb + (long long)mt0 * 512 + lane * 8;
+    if (loader) stage(0, 0);
+    __syncthreads();
+    for (int j = 0; j < J; ++j) {
+        const int buf = j & 1;
+        if (loader) {
+            if (j + 1 < J) stage(j + 1, buf ^ 1);                    // nobody reads that buffer during this iteration
+        } else {
+            const unsigned short* lb = lds + buf * (ROWS * 32) + 8 * g;
+            fbbev_bf16x8 a0[MT], a1[MT];
+            auto loadA = [&](fbbev_bf16x8 (&afr)[MT], int tap) {
+                const unsigned short* wt = wfp + ((long long)tap * J + j) * mt_total * 512;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) afr[mt] = fbbev_ld_bf16x8(wt + (long long)mt * 512);
+            };
+            auto mma = [&](const fbbev_bf16x8 (&afr)[MT], int tap, bool live) {
+                const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+                const int shift = (kd * HH + kh) * HW + kw;
+                const fbbev_bf16x8 zero = fbbev_cvt_bf16x8(fbbev_v4f{0.f, 0.f, 0.f, 0.f}, fbbev_v4f{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const fbbev_bf16x8 raw = fbbev_ld_bf16x8(lb + (hrow[t] + shift) * 32);
+                    const fbbev_bf16x8 bfr = live ? raw : zero;
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc[mt][t] = fbbev_mfma_f32_16x16x32_bf16(afr[mt], bfr, acc[mt][t]);
+                }
+            };
+            // weights ping-pong across the 27 taps: straight-line body with clamped prefetch indices and scheduling fences
+            // (see k_conv3d_ndhwc); the 28th slot runs on a zero B operand
+            loadA(a0, 0);
+            for (int tap = 0; tap < 27; tap += 2) {
+                loadA(a1, tap + 1 < 27 ? tap + 1 : 26);
+                fbbev_sched_fence();
+                mma(a0, tap, true);
+                fbbev_sched_fence();
+                loadA(a0, tap + 2 < 27 ? tap + 2 : 26);
+                fbbev_sched_fence();
+                mma(a1, tap + 1 < 27 ? tap + 1 : 26, tap + 1 < 27);
+                fbbev_sched_fence();
+            }
+        }
+        __syncthreads();
+    }
+    // epilogue (as k_conv3d_ndhwc): lane holds couts 16(mt0+mt) + 4g + {0..3} of voxel i of every tile
+    const bool vec = (Cout & 3) == 0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        if (!vq[t]) continue;
+        const int lh = 2 * t + (i >> 3), lw = i & 7;
+        const long long ovox = (((long long)b * D + d0 + wave) * H + h0 + lh) * W + w0 + lw;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int c0 = 16 * (mt0 + mt) + 4 * g;
+            if (c0 >= Cout) continue;
+            fbbev_v4f v = acc[mt][t] + *reinterpret_cast<const fbbev_v4f*>(bias + c0);
+            const long long o = ovox * Cout + c0;
+            if (vec) {
+                if (residual) v = v + *reinterpret_cast<const fbbev_v4f*>(residual + o);
+                if (relu) v = fbbev_v4f{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+                *reinterpret_cast<fbbev_v4f*>(out + o) = v;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (c0 + r >= Cout) break;
+                    float s = v[r] + (residual ? residual[o + r] : 0.f);
+                    out[o + r] = relu ? fmaxf(s, 0.f) : s;
+                }
+            }
+        }
+    }
+}

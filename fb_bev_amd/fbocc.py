@@ -91,7 +91,7 @@ class FBOCC(nn.Module):
         self.occupancy_head = _build(occupancy_head, **cp, compute_dtype=_dtype(ex.get('head_dtype')))
         # opt-in: eval-mode voxel encoder + head on the fp32-MFMA implicit-GEMM kernel (mfma_conv3d.py; validated on the
         # CPU emulator only so far, hence off by default)
-        self.mfma_conv3d = ex.get('mfma_conv3d', False)          # False | True (fp32 MFMA) | 'bf16' (bf16 MFMA where Cin % 32 == 0)
+        self.mfma_conv3d = ex.get('mfma_conv3d', False)          # False | True (fp32 MFMA) | 'bf16' | 'bf16_tiled' (bf16 MFMA where Cin % 32 == 0)
         self._runners = None
         if ex.get('mfma_conv3d_train'):           # same status: the autograd route (forward + dgrad + wgrad kernels)
             from .mfma_conv3d import enable_training_route
@@ -126,7 +126,7 @@ class FBOCC(nn.Module):
     def _mfma_stacks(self):
         if self._runners is None:
             from . import mfma_conv3d as M
-            prec = 'bf16' if self.mfma_conv3d == 'bf16' else 'f32'
+            prec = self.mfma_conv3d if self.mfma_conv3d in ('bf16', 'bf16_tiled') else 'f32'
             img = None
             if self.img_backbone is not None and self.img_neck is not None:
                 try:

@@ -72,12 +72,14 @@ def fold(conv, bn=None):
     return w, b
 
 
-def _launch(x, wf, bias, out, cout, backend=None, planar=False, **kw):
+def _launch(x, wf, bias, out, cout, backend=None, planar=False, tiled=False, **kw):
     """One convolution launch.  The kernel follows the weight layout: bf16 fragments -> fbbev_conv3d_ndhwc_bf16, fp32
     fragments -> fbbev_conv3d_ndhwc / fbbev_conv2d_nhwc.  `backend` (tests) stands in for the HIP entry points."""
     if backend is not None:
-        return backend(x, wf, bias, out, cout, planar=planar, **kw)
+        return backend(x, wf, bias, out, cout, planar=planar, tiled=tiled, **kw)
     if wf.dtype == torch.bfloat16:
+        if tiled:                                   # 3x3x3 / stride 1 / padding 1: LDS-staged halo tile
+            return _capi.conv3d_k3s1_tiled_bf16(x, wf, bias, out, cout, relu=kw.get('relu', False), residual=kw.get('residual'))
         if planar:
             _capi.conv3d_ndhwc_bf16(x.unsqueeze(1), wf, bias, out.unsqueeze(1), cout, planar=True, **kw)
             return out
@@ -89,7 +91,8 @@ def _launch(x, wf, bias, out, cout, backend=None, planar=False, **kw):
 
 class FoldedConv3d:
     """One launch of fbbev_conv3d_ndhwc[_bf16]: conv (+ folded BN) (+ residual) (+ ReLU) on NDHWC activations.
-    precision='bf16' takes the bf16-MFMA kernel where the input channels allow it (Cin % 32 == 0), fp32 otherwise."""
+    precision='bf16' takes the bf16-MFMA kernel where the input channels allow it (Cin % 32 == 0), fp32 otherwise;
+    'bf16_tiled' additionally routes 3x3x3 / stride 1 / padding 1 layers to the LDS-halo kernel."""
 
     def __init__(self, conv, bn=None, relu=False, precision='f32'):
         self.transposed = isinstance(conv, nn.ConvTranspose3d)
@@ -105,8 +108,9 @@ class FoldedConv3d:
         w, b = fold(conv, bn)
         self.cout = w.shape[1] if self.transposed else w.shape[0]
         cin = w.shape[0] if self.transposed else w.shape[1]
-        self.wf = weight_fragments_bf16(w, self.transposed) if (precision == 'bf16' and cin % 32 == 0) \
-            else weight_fragments(w, self.transposed)
+        bf16 = precision in ('bf16', 'bf16_tiled') and cin % 32 == 0
+        self.wf = weight_fragments_bf16(w, self.transposed) if bf16 else weight_fragments(w, self.transposed)
+        self.tiled = bf16 and precision == 'bf16_tiled' and not self.transposed and (self.ksize, self.stride, self.pad) == (3, 1, 1)
         self.bias = F.pad(b, (0, (self.cout + 15) // 16 * 16 - self.cout)).contiguous()
 
     def out_shape(self, x):
@@ -118,8 +122,8 @@ class FoldedConv3d:
 
     def __call__(self, x, residual=None, backend=None):
         out = torch.empty(self.out_shape(x), dtype=torch.float32, device=x.device)
-        return _launch(x, self.wf, self.bias, out, self.cout, backend=backend, ksize=self.ksize, stride=self.stride, pad=self.pad,
-                       relu=self.relu, residual=residual, transposed=self.transposed)
+        return _launch(x, self.wf, self.bias, out, self.cout, backend=backend, tiled=self.tiled, ksize=self.ksize,
+                       stride=self.stride, pad=self.pad, relu=self.relu, residual=residual, transposed=self.transposed)
 
 
 # ------------------------------------------------------------------ training route (autograd)
@@ -360,7 +364,8 @@ class FoldedConv2d:
             w = w * scale.view(-1, 1, 1, 1)
             b = (b - bn.running_mean.float()) * scale + bn.bias.detach().float()
         self.cout = w.shape[0]
-        self.wf = weight_fragments_bf16(w[:, :, None]) if (precision == 'bf16' and w.shape[1] % 32 == 0) else weight_fragments(w[:, :, None])
+        self.wf = weight_fragments_bf16(w[:, :, None]) if (precision in ('bf16', 'bf16_tiled') and w.shape[1] % 32 == 0) \
+            else weight_fragments(w[:, :, None])
         self.bias = F.pad(b, (0, (self.cout + 15) // 16 * 16 - self.cout)).contiguous()
 
     def __call__(self, x, residual=None, backend=None):

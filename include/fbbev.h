@@ -361,6 +361,13 @@ int fbbev_conv3d_ndhwc_bf16(const float* x, const void* weight_fragments_bf16, c
                             int B, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout, int ksize, int stride,
                             int pad, int relu, int transposed, int planar, float* out, fbbev_stream_t stream);
 
+/* The 3x3x3, stride 1, padding 1 case of fbbev_conv3d_ndhwc_bf16 with the input halo staged in LDS: a workgroup owns a
+ * 4x8x8 voxel tile and reads its 600 halo rows once per 32-channel group (2.3 reads of the input per 64-channel output
+ * block instead of 27).  Same arguments / weight layout / results (up to fp32 summation order) as that entry point.
+ * x, out, residual (B,D,H,W,C) f32; Cin % 32 == 0. */
+int fbbev_conv3d_k3s1_tiled_bf16(const float* x, const void* weight_fragments_bf16, const float* bias, const float* residual,
+                                 int B, int D, int H, int W, int Cin, int Cout, int relu, float* out, fbbev_stream_t stream);
+
 /* Data gradient of fbbev_conv3d_ndhwc's convolution (training): dx[i] = sum_k W_k^T dy[(i + pad - k) / stride] over the
  * taps for which the division is exact.  dy (B,Do,Ho,Wo,Cout), dx (B,Di,Hi,Wi,Cin) with the forward geometry (checked);
  * weight_fragments_t = the fragment layout of the TRANSPOSED weight (Cin, Cout, k, k, k) -- same tap index;

@@ -316,3 +316,11 @@ def conv3d_ndhwc_bf16(x, wfb, bias, Cout, ksize=3, stride=1, pad=1, relu=False, 
                                          Di, Hi, Wi, Cin, Do, Ho, Wo, Cout, ksize, stride, pad, 1 if relu else 0,
                                          1 if transposed else 0, 1 if planar else 0, p(out), None)
     return code, out
+
+
+def conv3d_k3s1_tiled_bf16(x, wfb, bias, Cout, relu=False, residual=None):
+    B, D, H, W, Cin = x.shape
+    out = torch.full((B, D, H, W, Cout), float('nan'))
+    code = lib().fbbev_conv3d_k3s1_tiled_bf16(p(x), c_void_p(wfb.data_ptr()), p(bias), p(residual) if residual is not None else None,
+                                              B, D, H, W, Cin, Cout, 1 if relu else 0, p(out), None)
+    return code, out

@@ -15,10 +15,14 @@ import emu_capi as E  # noqa: E402
 from fb_bev_amd import mfma_conv3d as M  # noqa: E402
 
 
-def emu_backend(x, wf, bias, out, Cout, planar=False, ksize=3, stride=1, pad=1, relu=False, residual=None, transposed=False):
-    """The HIP entry points on the emulator, chosen like mfma_conv3d._launch: by the weight layout and `planar`."""
+def emu_backend(x, wf, bias, out, Cout, planar=False, tiled=False, ksize=3, stride=1, pad=1, relu=False, residual=None,
+                transposed=False):
+    """The HIP entry points on the emulator, chosen like mfma_conv3d._launch: by the weight layout, `planar` and `tiled`."""
     res = None if residual is None else residual.contiguous()
-    if wf.dtype == torch.bfloat16:
+    if tiled:
+        assert wf.dtype == torch.bfloat16 and (ksize, stride, pad, transposed, planar) == (3, 1, 1, False, False)
+        code, y = E.conv3d_k3s1_tiled_bf16(x.contiguous(), wf, bias, Cout, relu=relu, residual=res)
+    elif wf.dtype == torch.bfloat16:
         x5 = x.unsqueeze(1) if planar else x
         code, y = E.conv3d_ndhwc_bf16(x5.contiguous(), wf, bias, Cout, ksize=ksize, stride=stride, pad=pad, relu=relu,
                                       residual=None if res is None else (res.unsqueeze(1) if planar else res), transposed=transposed,
@@ -391,7 +395,8 @@ def test_bf16_runners_track_the_fp32_modules():
     neck = _randomise(FPN3D(in_channels=chans, out_channels=64, norm_cfg=dict(type='SyncBN')), 2)
     head = _randomise(OccHead(in_channels=[64] * 3, out_channel=19, num_level=3, soft_weights=True, use_focal_loss=False,
                               norm_cfg=dict(type='SyncBN'), final_occ_size=[16, 16, 8], empty_idx=18), 3)
-    rb, rn, rh = M.ResNet3DRunner(bb, 'bf16'), M.FPN3DRunner(neck, 'bf16'), M.OccHeadRunner(head, 'bf16')
+    rb, rn, rh = M.ResNet3DRunner(bb, 'bf16_tiled'), M.FPN3DRunner(neck, 'bf16_tiled'), M.OccHeadRunner(head, 'bf16_tiled')
+    assert rb.stages[0][0][1].tiled and rn.outs[0].tiled and not rh.deblock.tiled and not rb.stages[1][0][0].tiled   # stride 2: direct
     assert rb.input_proj.wf.dtype == torch.float32                          # 16 input channels: fp32 kernel
     assert rb.stages[0][0][1].wf.dtype == torch.bfloat16 and rn.outs[0].wf.dtype == torch.bfloat16
     assert rh.deblock.wf.dtype == torch.bfloat16 and rh.pred[1].wf.dtype == torch.float32      # 16 -> 19: fp32
@@ -401,3 +406,27 @@ def test_bf16_runners_track_the_fp32_modules():
         got = rh(rn(rb(M.to_ndhwc(x), backend=emu_backend), backend=emu_backend), backend=emu_backend, blend_backend=emu_blend)
     err = (got - ref).abs().max() / ref.abs().max()
     assert 0 < err < 3e-2, err
+
+
+@pytest.mark.parametrize('B,dims,Cin,Cout,relu,res', [
+    (1, (4, 8, 8), 32, 16, False, False),           # exactly one tile
+    (2, (5, 11, 9), 64, 64, True, True),            # partial tiles along all three axes, two samples, MT=4
+    (1, (8, 3, 8), 32, 19, False, False),           # scalar stores, a tile thinner than its height
+])
+def test_conv3d_tiled_bf16_kernel_equals_direct_bf16_kernel_and_torch(B, dims, Cin, Cout, relu, res):
+    g = torch.Generator().manual_seed(Cin + Cout)
+    x = torch.randn(B, Cin, *dims, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, 3, generator=g) / (Cin * 27) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    exp = F.conv3d(_bf(x), _bf(w), b, padding=1)
+    r = torch.randn(exp.shape, generator=g) if res else None
+    exp = exp + r if res else exp
+    exp = exp.relu() if relu else exp
+    wfb = M.weight_fragments_bf16(w)
+    bias = F.pad(b, (0, (Cout + 15) // 16 * 16 - Cout))
+    rn = None if r is None else M.to_ndhwc(r)
+    code, y = E.conv3d_k3s1_tiled_bf16(M.to_ndhwc(x), wfb, bias, Cout, relu=relu, residual=rn)
+    assert code == 0 and not torch.isnan(y).any()
+    assert torch.allclose(M.to_ncdhw(y), exp, atol=1e-4, rtol=1e-4), (M.to_ncdhw(y) - exp).abs().max()
+    code, y2 = E.conv3d_ndhwc_bf16(M.to_ndhwc(x), wfb, bias, Cout, relu=relu, residual=rn)
+    assert code == 0 and torch.allclose(y, y2, atol=2e-5, rtol=1e-5)

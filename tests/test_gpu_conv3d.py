@@ -159,3 +159,18 @@ def test_conv3d_bf16_kernel_vs_torch_on_rounded_operands(dev, B, dims, Cin, Cout
                             stride=s, pad=p, relu=True, planar=planar)
     assert not torch.isnan(out).any()
     assert torch.allclose(M.to_ncdhw(out).double(), exp, atol=1e-4, rtol=1e-4), (M.to_ncdhw(out).double() - exp).abs().max()
+
+
+@pytest.mark.parametrize('B,dims,Cin,Cout', [(1, (100, 100, 8), 64, 64), (1, (100, 100, 8), 256, 256), (2, (25, 25, 2), 256, 128)])
+def test_conv3d_tiled_bf16_kernel_vs_torch_on_rounded_operands(dev, B, dims, Cin, Cout):
+    from fb_bev_amd import _capi, mfma_conv3d as M
+    g = torch.Generator().manual_seed(Cin + Cout)
+    x = torch.randn(B, Cin, *dims, generator=g).to(dev)
+    w = (torch.randn(Cout, Cin, 3, 3, 3, generator=g) / (Cin * 27) ** 0.5).to(dev)
+    b = torch.randn(Cout, generator=g).to(dev)
+    bf = lambda t: t.to(torch.bfloat16).float()  # noqa: E731
+    exp = F.conv3d(bf(x).double(), bf(w).double(), b.double(), padding=1).relu()
+    out = torch.full((B, *dims, Cout), float('nan'), device=dev)
+    _capi.conv3d_k3s1_tiled_bf16(M.to_ndhwc(x), M.weight_fragments_bf16(w), b.contiguous(), out, Cout, relu=True)
+    assert not torch.isnan(out).any()
+    assert torch.allclose(M.to_ncdhw(out).double(), exp, atol=1e-4, rtol=1e-4), (M.to_ncdhw(out).double() - exp).abs().max()

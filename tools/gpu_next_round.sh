@@ -10,7 +10,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 FBBEV_EXPERIMENTAL=1 PYTHONFAULTHANDLER=1 timeout -k 5 200 python -m pytest tests/test_gpu_conv3d.py tests/test_gpu_bevdet.py -m gpu -q -p no:cacheprovider > $OUT/conv3d_tests.log 2>&1
 echo "conv3d tests rc=$?"; grep -E "passed|failed|Error|crashed" $OUT/conv3d_tests.log | tail -5
-for mode in "1 f32" "1 bf16" "1 bf16 tune" "1 f32 mfma" "1 f32 mfma_bf16" "4 bf16" "4 f32 mfma" "4 f32 mfma_bf16"; do
+for mode in "1 f32" "1 bf16" "1 bf16 tune" "1 f32 mfma" "1 f32 mfma_bf16" "1 f32 mfma_bf16_tiled" "4 bf16" "4 f32 mfma" "4 f32 mfma_bf16"; do
   timeout -k 5 120 python tools/time_full.py infer $mode 2>> $OUT/time_full.err | tail -1 | tee -a $OUT/time_full.jsonl
 done
 for mode in "2 f32" "2 f32 mfma" "4 bf16"; do

@@ -156,6 +156,6 @@ if __name__ == '__main__':
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     dtype = sys.argv[3] if len(sys.argv) > 3 else 'f32'
     if mode == 'infer':
-        infer(B, dtype, mfma={'mfma': True, 'mfma_bf16': 'bf16'}.get(sys.argv[4] if len(sys.argv) > 4 else '', False))
+        infer(B, dtype, mfma={'mfma': True, 'mfma_bf16': 'bf16', 'mfma_bf16_tiled': 'bf16_tiled'}.get(sys.argv[4] if len(sys.argv) > 4 else '', False))
     else:
         train(B, dtype, mfma=len(sys.argv) > 4 and sys.argv[4] == 'mfma')
