@@ -49,6 +49,7 @@ BUDGETS = {
     r'k_history_conv_tILi5ELi5E': 384,         # register-resident weights: one wave per SIMD by design
     r'k_conv3d_ndhwc': 256,                    # two waves / SIMD: the ping-pong buffers need a partner wave
     r'k_conv3d_wgrad_ndhwc': 256,
+    r'k_conv3d_k3_tile_bf16': 256,             # 8 waves per workgroup (4 MFMA + 4 loader): two per SIMD
     r'k_msda_fwd_unitILi10E': 136,
 }
 
