@@ -1080,7 +1080,8 @@ extern "C" int fbbev_conv3d_k3s1_tiled_bf16(const float* x, const void* weight_f
     const int mt_total = (Cout + 15) / 16;
     const int MT = mt_total % 4 == 0 ? 4 : (mt_total % 2 == 0 ? 2 : 1);
     const int gy = mt_total / MT;
-    const long long grid = (long long)B * tiles_d * tiles_h * tiles_w * gy;
+    const long long n_tiles = (long long)B * tiles_d * tiles_h * tiles_w;
+    const long long grid = (n_tiles + 7) / 8 * 8 * gy;          // whole groups of 8 tiles (one per XCD), see the kernel
     if (grid >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
     const size_t lds = (size_t)2 * 600 * 32 * sizeof(unsigned short);
     const unsigned short* wfb = static_cast<const unsigned short*>(weight_fragments_bf16);

@@ -476,8 +476,14 @@ k_conv3d_k3_tile_bf16(const float* __restrict__ x, const unsigned short* __restr
     const int tid = threadIdx.x, wave = (tid >> 6) & 3, lane = tid & 63;
     const bool loader = tid >= 256;
     const int g = lane >> 4, i = lane & 15;
-    long long id = blockIdx.x;
-    const int by = (int)(id % gy); id /= gy;
+    // XCD-aware order: workgroup n runs on XCD n % 8 (each XCD has its own L2).  The gy output-channel blocks of one voxel
+    // tile are given consecutive slots of the SAME XCD, so the tile's input rows are fetched into that L2 once and its
+    // other gy - 1 workgroups hit it; neighbouring tiles (shared halo) follow on the same XCD.
+    const long long n_tiles = (long long)B * tiles_d * tiles_h * tiles_w;
+    const long long slot = blockIdx.x >> 3;
+    const int by = (int)(slot % gy);
+    long long id = (slot / gy) * 8 + (blockIdx.x & 7);
+    if (id >= n_tiles) return;                                       // whole workgroup, before any barrier
     const int tw = (int)(id % tiles_w); id /= tiles_w;
     const int th = (int)(id % tiles_h); id /= tiles_h;
     const int td = (int)(id % tiles_d);
