@@ -10,6 +10,8 @@ OUT = os.path.join(HERE, '_build', 'libfbbev_emu.so')
 
 
 def build():
+    if os.environ.get('FBBEV_EMU_LIB'):             # e.g. an AddressSanitizer build (tools/emu_asan.sh)
+        return os.environ['FBBEV_EMU_LIB']
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.h', '.hip'))]
     deps += [os.path.join(HERE, 'rt.h'), os.path.join(ROOT, 'include', 'fbbev.h')]
     if os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in deps):
