@@ -230,7 +230,7 @@ k_blend_levels_ndhwc(const float* __restrict__ x0, fbbev_blend_level lv1, fbbev_
 // -- a lane's ONE float4 of dY[v][64mb + 4i ..] is its A operand for the four M tiles and ONE float4 of
 // X[src][64nb + 4i ..] its B operand for the four N tiles: 2 float4 loads (a voxel's 16 lanes read 256 contiguous bytes)
 // feed 16 MFMAs, four k-steps (16 voxels) are batched per loop iteration with the next batch in flight (ping-pong).
-// The voxel -> (b,d,h,w) decomposition is carried incrementally (v advances by 4 per k-step).  Partial sums of the
+// The voxel -> (b,d,h,w) decomposition is carried incrementally and branch-free (v advances by 4 per k-step).  Partial sums of the
 // chunks meet in dW through fp32 atomic adds (dW is small; it must be zero on entry).  Requires Cout % 4 == Cin % 4 == 0.
 template <int KS>
 __global__ void __launch_bounds__(256)
@@ -253,6 +253,8 @@ k_conv3d_wgrad_ndhwc(const float* __restrict__ x, const float* __restrict__ dy, 
     const long long v_end = v_begin + chunk < nvox ? v_begin + chunk : nvox;
     const int ca = 64 * mb + 4 * i, cb = 64 * nb + 4 * i;
     const bool a_ok = ca < Cout, b_ok = cb < Cin;
+    const int q4 = 4 / Wo, r4 = 4 % Wo;
+    const int cac = a_ok ? ca : 0, cbc = b_ok ? cb : 0;
     // this lane's voxel of k-step 0 and its coordinates
     long long v = v_begin + kk;
     int wq, hq, dq, bq;
@@ -268,49 +270,61 @@ k_conv3d_wgrad_ndhwc(const float* __restrict__ x, const float* __restrict__ dy, 
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = fbbev_v4f{0.f, 0.f, 0.f, 0.f};
-    auto load = [&](fbbev_v4f (&af)[U], fbbev_v4f (&bf)[U], bool (&ok)[U]) {
+    auto load = [&](fbbev_v4f (&af)[U], fbbev_v4f (&bf)[U], bool (&aok)[U], bool (&ok)[U]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int di = dq * stride + kd - pad, hi = hq * stride + kh - pad, wi = wq * stride + kw - pad;
             const bool vin = v < v_end;
-            const bool sin = vin && di >= 0 && di < Di && hi >= 0 && hi < Hi && wi >= 0 && wi < Wi;
-            ok[u] = sin;
-            const long long ao = (vin && a_ok) ? v * Cout + ca : 0;
-            const long long bo = (sin && b_ok) ? ((((long long)bq * Di + di) * Hi + hi) * Wi + wi) * Cin + cb : 0;
-            const fbbev_v4f ar = *reinterpret_cast<const fbbev_v4f*>(dy + ao);
-            af[u] = (vin && a_ok) ? ar : fbbev_v4f{0.f, 0.f, 0.f, 0.f};      // masked here: `vin` changes with the step
+            const bool sin = vin & (di >= 0) & (di < Di) & (hi >= 0) & (hi < Hi) & (wi >= 0) & (wi < Wi);   // no short circuit: no branch
+            // addresses from CLAMPED coordinates (always inside the tensors), validity applied by the selects below: a
+            // conditional address computation would come out as a branch between the loads
+            const long long vc = v < nvox ? v : nvox - 1;
+            const int bqc = bq < B ? bq : B - 1;
+            const int dic = di < 0 ? 0 : (di < Di ? di : Di - 1), hic = hi < 0 ? 0 : (hi < Hi ? hi : Hi - 1),
+                      wic = wi < 0 ? 0 : (wi < Wi ? wi : Wi - 1);
+            const long long ao = vc * Cout + cac;
+            const long long bo = ((((long long)bqc * Di + dic) * Hi + hic) * Wi + wic) * Cin + cbc;
+            af[u] = *reinterpret_cast<const fbbev_v4f*>(dy + ao);           // raw loads; the zero selects happen in mma()
             bf[u] = *reinterpret_cast<const fbbev_v4f*>(x + bo);
-            ok[u] = sin && b_ok;
+            aok[u] = vin & a_ok;
+            ok[u] = sin & b_ok;
+            // v += 4 in (b,d,h,w) digits without a data-dependent branch (a branch between the loads would also make the
+            // compiler count them conservatively): w takes 4 % Wo with at most one wrap, the carries are at most 5
             v += 4;
-            wq += 4;
-            while (wq >= Wo) {
-                wq -= Wo;
-                if (++hq == Ho) { hq = 0; if (++dq == Do) { dq = 0; ++bq; } }
-            }
+            wq += r4;
+            int c = wq >= Wo ? 1 : 0;
+            wq -= c ? Wo : 0;
+            hq += q4 + c;
+#pragma unroll
+            for (int rep = 0; rep < 5; ++rep) { c = hq >= Ho ? 1 : 0; hq -= c ? Ho : 0; dq += c; }
+#pragma unroll
+            for (int rep = 0; rep < 5; ++rep) { c = dq >= Do ? 1 : 0; dq -= c ? Do : 0; bq += c; }
         }
     };
-    auto mma = [&](const fbbev_v4f (&af)[U], const fbbev_v4f (&braw)[U], const bool (&ok)[U]) {
+    auto mma = [&](const fbbev_v4f (&araw)[U], const fbbev_v4f (&braw)[U], const bool (&aok)[U], const bool (&ok)[U]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const fbbev_v4f bf = ok[u] ? braw[u] : fbbev_v4f{0.f, 0.f, 0.f, 0.f};
+            fbbev_v4f af[1];
+            af[0] = aok[u] ? araw[u] : fbbev_v4f{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = fbbev_mfma_f32_16x16x4(af[u][mt], bf[nt], acc[mt][nt]);
+                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = fbbev_mfma_f32_16x16x4(af[0][mt], bf[nt], acc[mt][nt]);
         }
     };
     const int steps = (int)((v_end - v_begin + 4 * U - 1) / (4 * U));      // iterations of U k-steps (16 voxels)
     fbbev_v4f a0[U], b0[U], a1[U], b1[U];
-    bool k0[U], k1[U];
-    load(a0, b0, k0);
+    bool k0[U], k1[U], m0[U], m1[U];
+    load(a0, b0, m0, k0);
     for (int s = 0; s < steps; s += 2) {
-        load(a1, b1, k1);                        // beyond the chunk every lane is masked: harmless, no branch
+        load(a1, b1, m1, k1);                    // beyond the chunk every lane is masked: harmless, no branch
         fbbev_sched_fence();
-        mma(a0, b0, k0);
+        mma(a0, b0, m0, k0);
         fbbev_sched_fence();
-        load(a0, b0, k0);
+        load(a0, b0, m0, k0);
         fbbev_sched_fence();
-        mma(a1, b1, k1);
+        mma(a1, b1, m1, k1);
         fbbev_sched_fence();
     }
     // D register r of a lane: row 4*kk + r -> cout 64mb + 4(4kk + r) + mt ; column i -> cin 64nb + 4i + nt
