@@ -3,7 +3,12 @@
 
 Contract (driver):  python bench.py --gpus N --steps K --warmup W
   N>1 is launched as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`
-  (one rank per GPU, RCCL via backend "nccl"); rank 0 prints ONE JSON line.
+  (one rank per GPU, RCCL via backend "nccl"); rank 0 prints ONE JSON line.  Started WITHOUT a launcher
+  (`python bench.py --gpus N`, WORLD_SIZE unset) it re-executes itself under torch.distributed.run with N ranks.
+
+--mode forward (default, the headline metric) | train (BASELINE configs[3]: forward_train + backward of the whole
+  FB-OCC detector, 4 samples per GPU, gradients of ALL parameters averaged over ranks by bucketed RCCL all-reduces
+  launched from autograd hooks, clip + AdamW step; the one collective of the path).
 
 Step   = one pass of the hot path (scope S2 of SURVEY 8d: get_lidar_coor + voxel ranking (fused) ->
          bev_pool_v2 into the dense (B,C,Z,Y,X) volume) over one batch of synthetic 6-camera samples,
@@ -44,7 +49,34 @@ def parse():
                     help='element type the BEV volume is STORED in (sums are always fp32); the reference is f32')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
+    ap.add_argument('--mode', choices=['forward', 'train'], default='forward')
+    ap.add_argument('--sync-bn', action='store_true', help="train mode: cross-rank statistics for the config's SyncBN layers "
+                    '(SURVEY 8e: off for the headline, the delta is reported separately)')
+    ap.add_argument('--bucket-mb', type=int, default=64, help='train mode: gradient bucket size')
+    ap.add_argument('--conv', choices=['vendor', 'mfma'], default='mfma',
+                    help='train mode: 3-D convolution stacks on the vendor library or on fbbev_conv3d_* (fwd + dgrad + wgrad)')
+    ap.add_argument('--conv-dtype', choices=['f32', 'bf16'], default='f32', help='train mode: compute dtype of the 2-D stacks')
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: become `torch.distributed.run --nproc-per-node N bench.py ...`
+    (one rank per GPU, rank -> GPU binding through LOCAL_RANK, rendezvous on 127.0.0.1)."""
+    if args.gpus <= 1 or 'WORLD_SIZE' in os.environ:
+        return
+    import socket
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        raise SystemExit(f'bench.py --gpus {args.gpus}: only {have} GPU(s) visible on this node')
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
 
 
 def cpu_baseline(cfg, seconds):
@@ -94,6 +126,43 @@ def cpu_baseline(cfg, seconds):
 
 def main():
     args = parse()
+    self_launch(args)                       # no-op under a launcher / for --gpus 1
+    if 'WORLD_SIZE' in os.environ and int(os.environ['WORLD_SIZE']) != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks")
+    if args.mode == 'train':
+        return run_train(args)
+    return run_forward(args)
+
+
+def cpu_baseline_c(cfg, seconds):
+    """Second CPU baseline of SURVEY 8d: same scope, the pooling done by the loop-exact C oracle (OpenMP over
+    intervals, oracle/fbbev_oracle.c) instead of torch index_add; geometry + ranking are the same torch CPU ops."""
+    import torch
+    from fb_bev_amd import synthetic as S
+    from oracle import oracle as O
+    ovt = O.ViewTransformerOracle(cfg.grid_config, cfg.input_size, cfg.downsample)
+    cam = S.camera_rig(cfg, 1, seed=0, bda_aug=True)
+    depth, ctx = S.depth_and_context(cfg, 1, seed=0)
+    shape = ovt.bev_feat_shape(1, cfg.channels)
+
+    def one():
+        rb, rd, rf, st, ln = ovt.voxel_pooling_prepare_v2(ovt.get_lidar_coor(*cam))
+        return O.bev_pool_v2(depth, ctx.permute(0, 1, 3, 4, 2).contiguous(), rd, rf, rb, shape, st, ln)
+    one()
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        one()
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds or n >= 200:
+            break
+    return {'value': n / dt, 'unit': 'samples/s', 'cores': int(os.environ.get('OMP_NUM_THREADS', os.cpu_count() or 1)),
+            'kind': 'port', 'sample': f'{n} x 1-sample {cfg.name} passes in {dt:.1f}s; pooling = loop-exact C oracle with OpenMP over '
+                                      f'intervals, geometry + ranking = torch CPU ops on {torch.get_num_threads()} threads'}
+
+
+def run_forward(args):
     import torch
     import torch.distributed as dist
     from fb_bev_amd import _capi
@@ -179,7 +248,7 @@ def main():
     algo_bytes = 4 * B * cfg.n_cams * D * H * W + 4 * B * cfg.n_cams * H * W * C + 4 * (3 * P + 2 * I) + \
         esz * B * Z * Y * X * C
     achieved = algo_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-    traffic = None
+    traffic, key = None, None
     tj = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     if os.path.exists(tj):
         try:
@@ -196,7 +265,7 @@ def main():
             'value': shard.whole_job_rate(B, args.steps, elapsed, world), 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
             'step_gpu_ms_p10_p50_p90': [pct(0.1), pct(0.5), pct(0.9)],
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': args.storage, 'accumulate_dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'FB-OCC forward projection, ' + ('BASELINE configs[1] ' if cfg.name == 'BL2' else '') +
                                    f'({cfg.name}): 6x{cfg.input_size[0]}x{cfg.input_size[1]} in, '
                                    f'feat {H}x{W}, D={D}, C={C}, grid {X}x{Y}x{Z}; index tensors rebuilt every step',
@@ -204,13 +273,109 @@ def main():
                        'tile_voxels': args.tile_voxels, 'pool_flags': hex(flags), 'volume_storage': args.storage, 'parallelism': f'dp{world} (independent samples, no collective)'},
             'roofline': {'kernel': 'k_pool_fwd_dense2', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         'traffic_source': None if traffic is None else f'profiles/pmc_traffic.json[{key}] (rocprofv3 --pmc FETCH_SIZE / '
+                                                                       'WRITE_SIZE passes of this command, recorded earlier -- not measured in this run)',
                          'algorithmic_bytes_per_launch': algo_bytes, 'kernel_ms': kern_ms,
                          'device_fill_GBps': fill_gbs, 'frac_of_device_fill': achieved / fill_gbs if fill_gbs > 0 else None},
         }
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(cfg, args.cpu_seconds)
             res['gpu_over_cpu'] = res['value'] / res['cpu_baseline']['value']
+            try:
+                res['cpu_baseline_c_openmp'] = cpu_baseline_c(cfg, max(3.0, args.cpu_seconds / 3))
+            except OSError as e:                  # oracle/_build not built on this box
+                res['cpu_baseline_c_openmp'] = {'error': str(e)}
         print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def run_train(args):
+    """BASELINE configs[3]: one DDP training step of the whole FB-OCC detector per rank-batch of `--batch` samples
+    (default 4 per GPU; 8 GPUs = global batch 32).  Reference: tools/dist_train.sh:10-20 -> mmdet3d/apis/train.py:229-233
+    (MMDistributedDataParallel + AdamW lr 2e-4 wd 1e-2, grad clip 5: cfg :360-364), FBOCC.forward_train fbocc.py:400-461.
+    Timed step = zero grads -> forward_train -> backward (bucket all-reduces launched from autograd hooks, overlapping
+    it) -> wait -> clip -> AdamW.  Nothing is skipped or cached; history fusion runs with its 16-frame state."""
+    import torch
+    import torch.distributed as dist
+    from fb_bev_amd import shard, synthetic as S
+    from fb_bev_amd.fbocc import FBOCC
+    world, rank, local_rank = shard.world()
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
+    dev = torch.device('cuda', local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+    shard.init('nccl', dev)
+    B = args.batch if args.batch != 16 else 4          # 16 is the forward mode's default; configs[3] is 4 per GPU
+    name = 'fbocc-r50-cbgs_depth_16f_16x4_20e.py'
+    cfg = dict(json.load(open(os.path.join(ROOT, 'tests', 'golden', 'fbocc_config_path_blocks.json')))[name]['model'])
+    cfg.pop('type')
+    ex = dict(with_cp=False, mfma_conv3d_train=(args.conv == 'mfma'))
+    if args.conv_dtype == 'bf16':
+        ex.update(img_dtype='bf16', depth_dtype='bf16')
+    torch.manual_seed(0)                               # identical initial parameters on every rank
+    model = FBOCC(**cfg, execution=ex).to(dev).train()
+    model, buckets = shard.prepare_ddp(model, sync_bn=args.sync_bn, bucket_bytes=args.bucket_mb << 20)
+    params = buckets.params
+    opt = torch.optim.AdamW(params, lr=2e-4, weight_decay=1e-2)
+    pc = S.CONFIGS['REF']
+    seed = shard.shard_seed(rank)
+    g = torch.Generator().manual_seed(seed)
+    cam = [t.to(dev) for t in S.camera_rig(pc, B, seed=seed, bda_aug=True)]
+    img = torch.randn(B, 6, 3, 256, 704, generator=g).to(dev)
+    gt_depth = torch.rand(B, 6, 256, 704, generator=g) * 40 + 2
+    gt_depth[torch.rand(gt_depth.shape, generator=g) > 0.03] = 0          # ~3 % LiDAR returns (SURVEY App. B)
+    gt_occ = torch.randint(1, 19, (B, 200, 200, 16), generator=g)
+    gt_occ[torch.rand(gt_occ.shape, generator=g) < 0.6] = 18
+    gt_occ[torch.rand(gt_occ.shape, generator=g) < 0.4] = 255
+    gt_occ, gt_depth = gt_occ.to(dev), gt_depth.to(dev)
+    ego = torch.eye(4)
+    ego[0, 3] = 0.5
+    img_inputs = [img] + cam
+
+    def metas(first):
+        return [dict(sequence_group_idx=rank * B + b, start_of_sequence=first, curr_to_prev_ego_rt=ego, index=b) for b in range(B)]
+    ar_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def step(i=None, first=False):
+        buckets.zero_grad()
+        losses = model(return_loss=True, img_inputs=img_inputs, img_metas=metas(first), gt_occupancy=gt_occ, gt_depth=gt_depth)
+        total = model.parse_losses(losses)
+        total.backward()                              # hooks launch each bucket's all-reduce as soon as it is complete
+        if i is not None:
+            ar_ev[i][0].record()
+        buckets.finish()                              # exposed (non-overlapped) tail of the gradient all-reduce
+        if i is not None:
+            ar_ev[i][1].record()
+        torch.nn.utils.clip_grad_norm_(params, max_norm=5, norm_type=2)
+        opt.step()
+        return total
+
+    total = step(first=True)
+    for _ in range(max(0, args.warmup - 1)):
+        total = step()
+    shard.fence(dev)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        total = step(i)
+    shard.fence(dev)
+    elapsed = shard.max_over_ranks(time.perf_counter() - t0, dev)
+    ar_tail_ms = sum(a.elapsed_time(b) for a, b in ar_ev) / max(1, args.steps)
+    if rank == 0:
+        print(json.dumps({
+            'metric': 'multi-cam samples/sec (FB-OCC R50 training step: forward_train + backward + gradient all-reduce + AdamW)',
+            'value': shard.whole_job_rate(B, args.steps, elapsed, world), 'unit': 'samples/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if args.conv_dtype == 'f32' else 'bf16 2-D conv stacks, f32 elsewhere',
+            'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[3]: FB-OCC R50 (fbocc-r50-cbgs_depth_16f_16x4_20e) training step, 6x256x704 in, '
+                                   'D=80, 100x100x8 grid, 16-frame history, occupancy + depth losses',
+                       'samples_per_gpu': B, 'global_batch': B * world, 'parallelism': f'dp{world}',
+                       'parameters': sum(p.numel() for p in params), 'gradient_bytes': buckets.nbytes,
+                       'gradient_buckets': len(buckets.buckets), 'bucket_mb': args.bucket_mb, 'sync_bn': bool(args.sync_bn and world > 1),
+                       'conv3d_route': args.conv, 'optimizer': 'AdamW lr 2e-4 wd 1e-2, clip 5'},
+            'allreduce_exposed_ms': ar_tail_ms, 'loss': float(total.detach()),
+        }))
     if world > 1:
         dist.destroy_process_group()
 

@@ -22,8 +22,9 @@ from .mfma_conv3d import MConv3d
 
 def build_norm(norm_cfg, channels, dims=3):
     """mmcv.cnn.build_norm_layer (external) for the types the FB-OCC configs use -> (state-dict abbreviation, layer).
-    SyncBN is built as plain BatchNorm (identical parameters / state names / eval arithmetic); wrap the model with
-    torch.nn.SyncBatchNorm.convert_sync_batchnorm for multi-GPU training when cross-rank statistics are wanted."""
+    SyncBN is built as plain BatchNorm (identical parameters / state names / eval arithmetic) and MARKED
+    (`_fbbev_sync_bn`): `shard.convert_sync_batchnorm(model)` -- called by `shard.prepare_ddp` for every multi-rank
+    training job -- swaps the marked layers for the cross-rank implementation, as the reference's SyncBN does."""
     cfg = dict(norm_cfg or dict(type='BN'))
     typ = cfg.pop('type')
     requires_grad = cfg.pop('requires_grad', True)
@@ -37,6 +38,7 @@ def build_norm(norm_cfg, channels, dims=3):
             cls = nn.BatchNorm3d
         cfg.setdefault('eps', 1e-5)
         layer, abbr = cls(channels, **cfg), 'bn'
+        layer._fbbev_sync_bn = (typ == 'SyncBN')
     elif typ == 'GN':
         cfg.setdefault('eps', 1e-5)
         layer, abbr = nn.GroupNorm(num_channels=channels, **cfg), 'gn'

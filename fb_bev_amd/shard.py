@@ -61,30 +61,116 @@ def whole_job_rate(samples_per_gpu, steps, elapsed_max, world_size):
 
 
 # ------------------------------------------------------------------ training step: the one collective of the path
+class GradBuckets:
+    """Bucketed gradient averaging launched from autograd hooks (the DDP step of tools/dist_train.sh:10-20 /
+    mmdet3d/apis/train.py:229-233, rebuilt for xGMI): the single collective of the training step.
+
+    * every `requires_grad` parameter, in REVERSE registration order (~ the order autograd produces gradients), is
+      assigned a slice of a flat, pre-allocated fp32 bucket; `p.grad` IS that slice (a view), so there is no
+      pack (`cat`) and no copy-back pass;
+    * a post-accumulate-grad hook counts the bucket's parameters; when the last one has its gradient the bucket's
+      all-reduce is launched asynchronously on the collective library's own stream, overlapping the rest of backward;
+    * `finish()` launches whatever is still pending (a parameter that received no gradient on this rank contributes
+      its zeros, so every rank always reduces the SAME bucket layout -- no hang when a block is unused on one rank),
+      waits, and scales by 1/world;
+    * bucket size: a ring all-reduce over xGMI is bound by one ~153 GB/s link whatever the message count, so the
+      buckets are few and large (default 64 MB; the 270 MB detector = 5 messages) instead of DDP's 25 MB.
+    """
+
+    def __init__(self, params, bucket_bytes=64 << 20, group=None):
+        self.group = group
+        self.params = [p for p in params if p.requires_grad]
+        order = list(reversed(self.params))
+        self.buckets = []                                   # [flat, [params], pending count, work]
+        cur, size = [], 0
+        for p in order:
+            n = p.numel() * 4
+            if cur and size + n > bucket_bytes:
+                self.buckets.append(cur)
+                cur, size = [], 0
+            cur.append(p)
+            size += n
+        if cur:
+            self.buckets.append(cur)
+        self._flat, self._of, self._ready, self._work = [], {}, [], []
+        for bi, ps in enumerate(self.buckets):
+            dev = ps[0].device
+            if any(p.device != dev or p.dtype != torch.float32 for p in ps):
+                raise ValueError('GradBuckets: a bucket must hold fp32 parameters of one device')
+            flat = torch.zeros(sum(p.numel() for p in ps), dtype=torch.float32, device=dev)
+            off = 0
+            for p in ps:
+                p.grad = flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+                self._of[p] = bi
+            self._flat.append(flat)
+            self._ready.append(0)
+            self._work.append(None)
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.nbytes = sum(f.numel() * 4 for f in self._flat)
+
+    def _launch(self, bi):
+        if self.world > 1 and self._work[bi] is None:
+            self._work[bi] = dist.all_reduce(self._flat[bi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _on_grad(self, p):
+        bi = self._of[p]
+        if p.grad.data_ptr() < self._flat[bi].data_ptr() or \
+                p.grad.data_ptr() >= self._flat[bi].data_ptr() + self._flat[bi].numel() * 4:
+            raise RuntimeError('GradBuckets: a .grad was replaced (zero_grad(set_to_none=True)?); use buckets.zero_grad()')
+        self._ready[bi] += 1
+        if self._ready[bi] == len(self.buckets[bi]):
+            self._launch(bi)
+
+    def zero_grad(self):
+        """Zero the flat buckets in place (the .grad views stay attached)."""
+        for f in self._flat:
+            f.zero_()
+
+    def finish(self):
+        """Call after backward(), before clipping / the optimizer step: every gradient is the mean over ranks."""
+        for bi in range(len(self._flat)):
+            self._launch(bi)
+        for bi, w in enumerate(self._work):
+            if w is not None:
+                w.wait()
+                self._flat[bi].div_(self.world)
+            self._work[bi] = None
+            self._ready[bi] = 0
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+
 def allreduce_gradients(params, bucket_bytes=64 << 20, async_op=False):
-    """Average the gradients of `params` over all ranks: the single collective of the training step (SURVEY 8e --
-    the data path itself stays collective-free).  Gradients are packed into flat fp32 buckets of <= bucket_bytes and
-    each bucket is ONE all-reduce: over xGMI a ring all-reduce is bound by a single ~153 GB/s link whatever the
-    message count, so few large messages beat DDP's default 25 MB buckets; the path's own parameters (BEV queries,
-    encoder layer, history convs: ~4 MB) fit one bucket.  Returns the list of work handles when async_op=True (call
-    `finish_allreduce` before the optimizer step) so the reduction overlaps the rest of the backward pass."""
-    grads = [p.grad for p in params if p.grad is not None]
-    if not dist.is_initialized() or dist.get_world_size() == 1 or not grads:
+    """One-shot form of the same collective for code without hooks: averages the gradients of EVERY requires_grad
+    parameter in a fixed order (a parameter without a gradient on this rank contributes zeros, so the bucket layout
+    is identical on all ranks).  Returns pending handles when async_op=True (`finish_allreduce`)."""
+    params = [p for p in params if p.requires_grad]
+    if not dist.is_initialized() or dist.get_world_size() == 1 or not params:
         return []
     world = dist.get_world_size()
     buckets, cur, size = [], [], 0
-    for g in grads:
-        n = g.numel() * g.element_size()
+    for p in params:
+        n = p.numel() * 4
         if cur and size + n > bucket_bytes:
             buckets.append(cur)
             cur, size = [], 0
-        cur.append(g)
+        cur.append(p)
         size += n
     if cur:
         buckets.append(cur)
     pending = []
     for b in buckets:
-        flat = torch.cat([g.reshape(-1) for g in b])
+        flat = torch.zeros(sum(p.numel() for p in b), dtype=torch.float32, device=b[0].device)
+        off = 0
+        for p in b:
+            if p.grad is not None:
+                flat[off:off + p.numel()].copy_(p.grad.reshape(-1))
+            off += p.numel()
         work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
         pending.append((work, flat, b, world))
     if async_op:
@@ -98,7 +184,119 @@ def finish_allreduce(pending):
         work.wait()
         flat.div_(world)
         off = 0
-        for g in bucket:
-            n = g.numel()
-            g.copy_(flat[off:off + n].view_as(g))
+        for p in bucket:
+            n = p.numel()
+            if p.grad is not None:
+                p.grad.copy_(flat[off:off + n].view_as(p))
             off += n
+
+
+# ------------------------------------------------------------------ cross-rank batch norm (the configs' `SyncBN`)
+class _SyncBNFunction(torch.autograd.Function):
+    """Batch-norm over the samples of ALL ranks: forward all-reduces (count, sum, sum of squares) per channel, backward
+    all-reduces (sum dy, sum dy*xhat).  Plain torch ops + dist.all_reduce, so it runs on RCCL and on gloo (the CPU
+    tests); torch.nn.SyncBatchNorm refuses CPU tensors."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, group):
+        C = x.shape[1]
+        dims = [0] + list(range(2, x.dim()))
+        xf = x.float()
+        stat = torch.empty(2 * C + 1, dtype=torch.float32, device=x.device)
+        stat[:C] = xf.sum(dims)
+        stat[C:2 * C] = (xf * xf).sum(dims)
+        stat[2 * C] = x.numel() // C
+        dist.all_reduce(stat, group=group)
+        n = stat[2 * C]
+        mean = stat[:C] / n
+        var = (stat[C:2 * C] / n - mean * mean).clamp_(min=0)
+        invstd = torch.rsqrt(var + eps)
+        shape = [1, C] + [1] * (x.dim() - 2)
+        xhat = (xf - mean.view(shape)) * invstd.view(shape)
+        out = xhat
+        if weight is not None:
+            out = out * weight.float().view(shape) + bias.float().view(shape)
+        ctx.save_for_backward(xhat, invstd, weight)
+        ctx.group, ctx.n = group, n
+        ctx.mark_non_differentiable(mean, var, n)
+        return out.to(x.dtype), mean, var, n
+
+    @staticmethod
+    def backward(ctx, dy, _m, _v, _n):
+        xhat, invstd, weight = ctx.saved_tensors
+        C = xhat.shape[1]
+        dims = [0] + list(range(2, xhat.dim()))
+        shape = [1, C] + [1] * (xhat.dim() - 2)
+        dyf = dy.float()
+        red = torch.empty(2 * C, dtype=torch.float32, device=dy.device)
+        red[:C] = dyf.sum(dims)
+        red[C:] = (dyf * xhat).sum(dims)
+        dw = red[C:].clone() if weight is not None else None     # parameter gradients stay per-rank (averaged later)
+        db = red[:C].clone() if weight is not None else None
+        dist.all_reduce(red, group=ctx.group)
+        g = dyf if weight is None else dyf * weight.float().view(shape)
+        w = 1.0 if weight is None else weight.float()
+        mean_dy = (red[:C] * w / ctx.n).view(shape)
+        mean_dyx = (red[C:] * w / ctx.n).view(shape)
+        dx = (g - mean_dy - xhat * mean_dyx) * invstd.view(shape)
+        return dx.to(dy.dtype), dw, db, None, None
+
+
+class SyncBatchNorm(torch.nn.modules.batchnorm._BatchNorm):
+    """`norm_cfg=dict(type='SyncBN')` of the FB-OCC configs (CustomResNet3D / FPN3D / OccHead): statistics over the
+    global batch while training in a multi-rank job; identical to BatchNorm otherwise (same parameters and buffers)."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True, process_group=None):
+        super().__init__(num_features, eps, momentum, affine, track_running_stats)
+        self.process_group = process_group
+        self.sync = True                         # False: per-rank statistics (plain BatchNorm), no collective
+
+    def _check_input_dim(self, x):
+        if x.dim() < 2:
+            raise ValueError(f'expected at least 2D input (got {x.dim()}D input)')
+
+    def forward(self, x):
+        sync = self.sync and self.training and dist.is_initialized() and dist.get_world_size(self.process_group) > 1
+        if not sync:
+            return super().forward(x)
+        out, mean, var, n = _SyncBNFunction.apply(x, self.weight, self.bias, self.eps, self.process_group)
+        if self.track_running_stats:
+            with torch.no_grad():
+                self.num_batches_tracked += 1
+                m = self.momentum if self.momentum is not None else 1.0 / float(self.num_batches_tracked)
+                self.running_mean.mul_(1 - m).add_(mean.to(self.running_mean.dtype), alpha=m)
+                self.running_var.mul_(1 - m).add_((var * (n / (n - 1).clamp(min=1))).to(self.running_var.dtype), alpha=m)
+        return out
+
+
+def convert_sync_batchnorm(module, process_group=None, sync=True):
+    """Replace every norm layer the config declared as `SyncBN` (marked `_fbbev_sync_bn` by build_norm) -- and every
+    torch.nn.SyncBatchNorm -- by `SyncBatchNorm` above; parameters / buffers are shared, names unchanged.
+    sync=False keeps the same layers on per-rank statistics (the bench's `sync_bn` off setting)."""
+    def conv(m):
+        if isinstance(m, torch.nn.SyncBatchNorm) or getattr(m, '_fbbev_sync_bn', False):
+            if isinstance(m, SyncBatchNorm):
+                m.sync = bool(sync)
+                return m
+            new = SyncBatchNorm(m.num_features, m.eps, m.momentum, m.affine, m.track_running_stats, process_group)
+            if m.affine:
+                new.weight, new.bias = m.weight, m.bias
+            if m.track_running_stats:
+                new.running_mean, new.running_var, new.num_batches_tracked = m.running_mean, m.running_var, m.num_batches_tracked
+            new.training = m.training
+            new._fbbev_sync_bn = True
+            new.sync = bool(sync)
+            return new
+        for name, child in list(m.named_children()):
+            setattr(m, name, conv(child))
+        return m
+    return conv(module)
+
+
+def prepare_ddp(model, sync_bn=True, bucket_bytes=64 << 20, process_group=None):
+    """What MMDistributedDataParallel + the config's SyncBN do for the reference (apis/train.py:229-233), for one model
+    replica per rank: cross-rank batch-norm statistics for the layers the config declares `SyncBN`, and gradient
+    buckets reduced from autograd hooks.  -> (model, GradBuckets); call buckets.zero_grad() / buckets.finish() around
+    backward().  Parameters must already be identical on all ranks (same seed or a broadcast checkpoint)."""
+    model = convert_sync_batchnorm(model, process_group, sync=sync_bn)
+    return model, GradBuckets([p for p in model.parameters() if p.requires_grad], bucket_bytes, process_group)

@@ -1,14 +1,13 @@
 """GPU run of the BEVDet-era view transformers against the real-reference fixture.  The CPU suite checks the same chain
-on the emulated kernels (tests/test_bevdet_view_transformer.py); this file joins the default GPU suite after its first
-pass on an MI355X (`FBBEV_EXPERIMENTAL=1 python -m pytest tests/test_gpu_bevdet.py -m gpu`)."""
+on the emulated kernels (tests/test_bevdet_view_transformer.py); first passed on an MI355X in round 2
+(gpurun_out/s1_gated_tests.log) and part of the default GPU suite since."""
 import os
 
 import numpy as np
 import pytest
 import torch
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get('FBBEV_EXPERIMENTAL') != '1', reason='not yet validated on the GPU')]
+pytestmark = [pytest.mark.gpu]
 G = os.path.join(os.path.dirname(__file__), 'golden', 'bevdet_view_transformer_small.npz')
 GRID = {'x': [-8, 8, 1.0], 'y': [-8, 8, 1.0], 'z': [-1, 3, 2.0], 'depth': [1.0, 9.0, 1.0]}
 

@@ -1,8 +1,7 @@
-"""GPU parity of fbbev_conv3d_ndhwc and of the opt-in MFMA route of the detector against torch's fp32 convolutions.
+"""GPU parity of fbbev_conv3d_ndhwc and of the MFMA route of the detector against torch's fp32 convolutions.
 
-The kernel has only run on the CPU emulator so far (tests/test_emu_conv3d.py): these tests are the first thing to run on
-an MI355X next (`FBBEV_EXPERIMENTAL=1 python -m pytest tests/test_gpu_conv3d.py -m gpu`), and stay out of the default
-GPU suite until they have passed there once."""
+First run on an MI355X in round 2 (gpurun_out/s1_gated_tests.log: kernels, transposed conv, blend, dgrad / wgrad, bf16 and
+tiled bf16 variants, detector + image-encoder inference routes all pass); part of the default GPU suite since."""
 import os
 import sys
 
@@ -11,8 +10,7 @@ import torch
 import torch.nn.functional as F
 
 sys.path.insert(0, os.path.dirname(__file__))
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get('FBBEV_EXPERIMENTAL') != '1', reason='not yet validated on the GPU')]
+pytestmark = [pytest.mark.gpu]
 
 
 @pytest.fixture(scope='module')
@@ -111,6 +109,50 @@ def test_dgrad_wgrad_vs_torch_autograd(dev, B, dims, Cin, Cout, k, s, p):
     assert (got - w.grad).abs().max() <= 2e-4 * w.grad.abs().max() + 1e-4
 
 
+def test_training_route_stacks_vs_vendor_route_and_cpu(dev):
+    """CustomResNet3D -> FPN3D -> OccHead in TRAIN mode with a LINEAR loss (no sort / argmax in the way): output, input
+    gradient and every parameter gradient of (a) the MFMA autograd route and (b) the vendor route on the GPU against
+    (c) the same modules evaluated on the CPU (fp32; the stacks cast their input to float) -- the arbiter when (a) and
+    (b) disagree."""
+    import copy
+    import torch.nn as nn
+    from fb_bev_amd import mfma_conv3d as M
+    from fb_bev_amd.bev_encoder import CustomResNet3D, FPN3D
+    from fb_bev_amd.occ_head import OccHead
+    torch.manual_seed(0)
+    chans = [16, 32, 64]
+    net = nn.ModuleDict(dict(
+        bb=CustomResNet3D(depth=18, block_strides=[1, 2, 2], n_input_channels=80, block_inplanes=chans, out_indices=(0, 1, 2),
+                          norm_cfg=dict(type='SyncBN')),
+        neck=FPN3D(in_channels=chans, out_channels=64, norm_cfg=dict(type='SyncBN')),
+        head=OccHead(in_channels=[64] * 3, out_channel=19, num_level=3, soft_weights=True, use_focal_loss=False,
+                     norm_cfg=dict(type='SyncBN'), final_occ_size=[40, 40, 16], empty_idx=18))).train()
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 80, 20, 20, 8, generator=g)
+    wgt = torch.randn(2, 19, 40, 40, 16, generator=g)
+    gold = copy.deepcopy(net)
+    xg = x.clone().requires_grad_()
+    og = gold['head'](gold['neck'](gold['bb'](xg)))['output_voxels'][0]
+    (og * wgt).sum().backward()
+    res = {}
+    for tag in ('mfma', 'vendor'):
+        mod = copy.deepcopy(net).to(dev)
+        if tag == 'mfma':
+            assert M.enable_training_route(mod, True) > 0
+        xi = x.to(dev).requires_grad_()
+        o = mod['head'](mod['neck'](mod['bb'](xi)))['output_voxels'][0]
+        (o * wgt.to(dev)).sum().backward()
+        err = {'out': float((o.detach().cpu().double() - og.detach()).abs().max() / og.detach().abs().max()),
+               'dx': float((xi.grad.cpu().double() - xg.grad).abs().max() / xg.grad.abs().max())}
+        for (name, p), (_, q) in zip(mod.named_parameters(), gold.named_parameters()):
+            err[name] = float((p.grad.cpu().double() - q.grad).abs().max() / (q.grad.abs().max() + 1e-3))
+        res[tag] = err
+    worst = {t: sorted(e.items(), key=lambda kv: -kv[1])[:4] for t, e in res.items()}
+    print('stack training routes vs the CPU evaluation (max rel err):', worst)
+    assert worst['vendor'][0][1] <= 2e-3, worst['vendor']
+    assert worst['mfma'][0][1] <= 2e-3, worst['mfma']
+
+
 def test_training_route_equals_vendor_route(dev):
     import copy
     import test_gpu_full_model as T
@@ -125,8 +167,14 @@ def test_training_route_equals_vendor_route(dev):
         losses = mod(return_loss=True, img_inputs=img_inputs, img_metas=metas(True), gt_occupancy=gt_occ, gt_depth=gt_depth)
         mod.parse_losses(losses).backward()
         grads.append({n: p.grad for n, p in mod.named_parameters() if p.grad is not None})
-    for n, gref in grads[1].items():
-        assert (grads[0][n] - gref).abs().max() <= 2e-3 * gref.abs().max() + 1e-4, n
+    rel = {n: float((grads[0][n] - gref).abs().max() / (gref.abs().max() + 1e-12)) for n, gref in grads[1].items()}
+    worst = {}
+    for n, r in rel.items():
+        blk = n.split('.')[0]
+        worst[blk] = max(worst.get(blk, (0.0, '')), (r, n))
+    print('training-route gradient error per block (max rel):', {k: (round(v[0], 5), v[1]) for k, v in worst.items()})
+    bad = {n: round(r, 5) for n, r in rel.items() if r > 2e-3 and float(grads[1][n].abs().max()) > 1e-4}
+    assert not bad, (len(bad), len(rel), dict(list(bad.items())[:12]))
 
 
 def test_image_encoder_mfma_route_equals_vendor_route(dev):

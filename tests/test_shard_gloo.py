@@ -56,9 +56,28 @@ def test_single_process_helpers_are_noops():
     shard.fence(None)
 
 
-def _grad_worker(rank, world, port, q):
+def _run(world, target, *args):
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=target, args=(r, world, port, q) + args) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+def _env(rank, world, port):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank),
-                      LOCAL_RANK=str(rank))
+                      LOCAL_RANK=str(rank), OMP_NUM_THREADS='2')
+    torch.set_num_threads(2)
+
+
+def _grad_worker(rank, world, port, q):
+    _env(rank, world, port)
     from fb_bev_amd import shard
     from fb_bev_amd.history_fusion import TemporalHistoryFusion
     shard.init('gloo')
@@ -67,25 +86,169 @@ def _grad_worker(rank, world, port, q):
     params = list(m.parameters())
     for i, p in enumerate(params):                          # rank-dependent gradients with a known mean
         p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
-    params[1].grad = None                                   # a parameter without gradient is skipped
+    if rank == 1:
+        params[1].grad = None                               # missing on ONE rank only: contributes zeros, no hang
     pending = shard.allreduce_gradients(params, bucket_bytes=256, async_op=True)   # tiny buckets: several messages
     assert len(pending) > 1
     shard.finish_allreduce(pending)
-    ok = all(torch.allclose(p.grad, torch.full_like(p, 1.5 * (i + 1))) for i, p in enumerate(params) if p.grad is not None)
+    ok = all(torch.allclose(p.grad, torch.full_like(p, (1.5 if i != 1 else 0.5) * (i + 1))) for i, p in enumerate(params)
+             if p.grad is not None)
     q.put((rank, ok, params[1].grad is None))
     torch.distributed.destroy_process_group()
 
 
 def test_two_rank_gradient_allreduce_of_path_parameters():
-    """The training step's only collective: bucketed average of the path's parameter gradients."""
-    world, port = 2, _free_port()
-    ctx = mp.get_context('spawn')
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = sorted(q.get(timeout=120) for _ in range(world))
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    assert all(ok and none_kept for _, ok, none_kept in res)
+    """One-shot form of the training step's only collective; a parameter without gradient on one rank keeps
+    the bucket layout identical on all ranks (no hang, no wrong slices)."""
+    res = _run(2, _grad_worker)
+    assert all(ok for _, ok, _ in res)
+    assert [none for _, _, none in res] == [False, True]
+
+
+# ---------------------------------------------------------------- DDP step of the detector (BASELINE configs[3]) on CPU shapes
+def _small_detector():
+    """tests/test_fbocc_model.py's CPU-sized detector: the two GPU-only stages are replaced by shape-correct stand-ins."""
+    from fb_bev_amd.fbocc import FBOCC
+    grid = {'x': [-8, 8, 0.8], 'y': [-8, 8, 0.8], 'z': [-1, 2.2, 0.8], 'depth': [2.0, 10.0, 1.0]}
+    C = 16
+    cfg = dict(
+        use_depth_supervision=True, fix_void=True, do_history=True, history_cat_num=2, single_bev_num_channels=C, readd=True,
+        img_backbone=dict(type='ResNet', depth=18, num_stages=4, out_indices=(2, 3), norm_eval=False, base_channels=8),
+        img_neck=dict(type='CustomFPN', in_channels=[32, 64], out_channels=24, num_outs=1, start_level=0, out_ids=[0]),
+        depth_net=dict(type='CM_DepthNet', in_channels=24, context_channels=C, downsample=16, grid_config=grid,
+                       depth_channels=8, mid_channels=32, loss_depth_weight=1., use_dcn=False),
+        forward_projection=dict(type='LSSViewTransformerFunction3D', grid_config=grid, input_size=(64, 96), downsample=16),
+        backward_projection=None,
+        img_bev_encoder_backbone=dict(type='CustomResNet3D', depth=18, block_strides=[1, 2, 2], n_input_channels=C,
+                                      block_inplanes=[8, 16, 32], out_indices=(0, 1, 2), norm_cfg=dict(type='SyncBN')),
+        img_bev_encoder_neck=dict(type='FPN3D', in_channels=[8, 16, 32], out_channels=16, norm_cfg=dict(type='SyncBN')),
+        occupancy_head=dict(type='OccHead', use_focal_loss=True, norm_cfg=dict(type='SyncBN'), soft_weights=True,
+                            final_occ_size=[40, 40, 8], empty_idx=18, num_level=3, in_channels=[16] * 3, out_channel=19,
+                            point_cloud_range=[-8, -8, -1, 8, 8, 2.2]))
+    torch.manual_seed(0)
+    m = FBOCC(**cfg)
+
+    def vt_stub(cam_params, context, depth, img_metas=None, **kw):
+        pooled = (context.mean((1, 3, 4))[:, :, None, None, None] + depth.mean((1, 2, 3, 4)).view(-1, 1, 1, 1, 1))
+        return pooled.expand(context.shape[0], C, 20, 20, 4) + torch.linspace(0, 1, 20).view(1, 1, 20, 1, 1)
+    m._path[0].forward = vt_stub
+    m._path[1].fuse_history = lambda bev, img_metas, bda: bev
+    return m.train(), grid, C
+
+
+def _detector_batch(grid, C, seed, B=1):
+    from fb_bev_amd import synthetic as S
+    pc = S.PathConfig(name='t', input_size=(64, 96), downsample=16, grid_config=grid, channels=C)
+    cam = S.camera_rig(pc, B, seed=seed, bda_aug=True)
+    g = torch.Generator().manual_seed(seed + 1)
+    img = torch.randn(B, 6, 3, 64, 96, generator=g)
+    metas = [dict(sequence_group_idx=b, start_of_sequence=True, curr_to_prev_ego_rt=torch.eye(4), index=b) for b in range(B)]
+    gt_occ = torch.randint(1, 19, (B, 40, 40, 8), generator=g)
+    gt_occ[torch.rand(gt_occ.shape, generator=g) < 0.3] = 255
+    gt_depth = torch.rand(B, 6, 64, 96, generator=g) * 9 + 2
+    gt_depth[torch.rand(gt_depth.shape, generator=g) < 0.9] = 0
+    return dict(img_inputs=[img] + list(cam), img_metas=metas, gt_occupancy=gt_occ, gt_depth=gt_depth)
+
+
+def _ddp_step_worker(rank, world, port, q):
+    _env(rank, world, port)
+    from fb_bev_amd import shard
+    shard.init('gloo')
+    # expected: every rank's sample through an identical un-hooked replica, gradients averaged over the ranks
+    expect = None
+    for r in range(world):
+        ref, grid, C = _small_detector()
+        ref.parse_losses(ref(return_loss=True, **_detector_batch(grid, C, shard.shard_seed(r)))).backward()
+        gs = {n: (p.grad.clone() if p.grad is not None else torch.zeros_like(p)) for n, p in ref.named_parameters() if p.requires_grad}
+        expect = gs if expect is None else {n: expect[n] + g for n, g in gs.items()}
+    expect = {n: g / world for n, g in expect.items()}
+    # the DDP step: hooks launch the bucket all-reduces during backward
+    model, grid, C = _small_detector()
+    model, buckets = shard.prepare_ddp(model, sync_bn=False, bucket_bytes=64 << 10)     # 64 KB buckets: several messages
+    assert len(buckets.buckets) > 3 and buckets.nbytes == 4 * sum(p.numel() for p in buckets.params)
+    early = []
+    launch = buckets._launch
+    buckets._launch = lambda bi: (early.append(bi), launch(bi))[1]
+    buckets.zero_grad()
+    model.parse_losses(model(return_loss=True, **_detector_batch(grid, C, shard.shard_seed(rank)))).backward()
+    launched_in_backward = len(set(early))
+    buckets.finish()
+    err = max(float((p.grad - expect[n]).abs().max() / (expect[n].abs().max() + 1e-6))
+              for n, p in model.named_parameters() if p.requires_grad)
+    views = all(p.grad.data_ptr() >= buckets._flat[buckets._of[p]].data_ptr() for p in buckets.params)
+    # second step with zeroed buckets gives the same gradients (hook / counter state is reset by finish)
+    buckets.zero_grad()
+    model.parse_losses(model(return_loss=True, **_detector_batch(grid, C, shard.shard_seed(rank)))).backward()
+    buckets.finish()
+    q.put((rank, err, launched_in_backward, len(buckets.buckets), views, float(sum(p.grad.abs().sum() for p in buckets.params))))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_ddp_training_step_equals_single_process_average():
+    """bench.py --mode train on CPU-sized shapes: forward_train + backward of the detector on 2 gloo ranks with the
+    hook-launched flat buckets == the average of the two ranks' single-process gradients, for EVERY parameter."""
+    res = _run(2, _ddp_step_worker)
+    for rank, err, early, nb, views, _ in res:
+        assert err < 1e-4, (rank, err)
+        assert early >= nb - 1, (early, nb)          # all but (at most) the last bucket went out before backward returned
+        assert views
+    assert abs(res[0][5] - res[1][5]) <= 1e-4 * res[0][5]      # both ranks end with the same gradients
+
+
+def _syncbn_worker(rank, world, port, q):
+    _env(rank, world, port)
+    import torch.nn as nn
+    from fb_bev_amd import shard
+    from fb_bev_amd.bev_encoder import build_norm
+    shard.init('gloo')
+
+    def net():
+        torch.manual_seed(0)
+        bn = build_norm(dict(type='SyncBN'), 6)[1]
+        plain = build_norm(dict(type='BN3d'), 6)[1]
+        return nn.Sequential(nn.Conv3d(3, 6, 3, padding=1), bn, nn.ReLU(), nn.Conv3d(6, 6, 1), plain, nn.SyncBatchNorm(6)).train()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(4, 3, 5, 6, 4, generator=g)
+    w = torch.randn(4, 6, 5, 6, 4, generator=g)
+    # single process over the whole batch (plain BatchNorm everywhere except the per-rank layer, evaluated per half)
+    ref = net()
+    ref[5] = nn.BatchNorm3d(6)
+    ref[5].load_state_dict(net()[5].state_dict())
+
+    class HalfBN(nn.Module):                                  # the config's plain `BN3d` stays per-rank in the DDP job
+        def __init__(self, bn):
+            super().__init__()
+            self.bn = bn
+
+        def forward(self, t):
+            return torch.cat([self.bn(t[:2]), self.bn(t[2:])])
+    ref[4] = HalfBN(ref[4])
+    xr = x.clone().requires_grad_()
+    (ref(xr) * w).sum().backward()
+    # 2 ranks, half the batch each
+    m = shard.convert_sync_batchnorm(net())
+    kinds = [type(l).__name__ for l in m]
+    xi = x[2 * rank:2 * rank + 2].clone().requires_grad_()
+    out = m(xi)
+    (out * w[2 * rank:2 * rank + 2]).sum().backward()
+    e_dx = float((xi.grad - xr.grad[2 * rank:2 * rank + 2]).abs().max() / xr.grad.abs().max())
+    pend = shard.allreduce_gradients(list(m.parameters()), async_op=True)
+    shard.finish_allreduce(pend)
+    refp = [p for p in ref.parameters()]
+    # absolute floor: a conv bias in front of a batch-statistics BN has an analytically zero gradient (rounding noise)
+    e_dw = max(float((p.grad * world - rp.grad).abs().max() / (rp.grad.abs().max() + 1.0)) for p, rp in zip(m.parameters(), refp))
+    e_rm = float((m[1].running_mean - ref[1].running_mean).abs().max())
+    e_rv = float((m[1].running_var - ref[1].running_var).abs().max())
+    q.put((rank, kinds, e_dx, e_dw, e_rm, e_rv, int(m[1].num_batches_tracked)))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_sync_batchnorm_equals_full_batch_statistics():
+    """the config's `SyncBN` layers normalise with the statistics of the GLOBAL batch in a multi-rank
+    job -- output, input gradient, parameter gradients and running statistics equal one process over the whole batch;
+    a layer the config declares plain `BN3d` stays per-rank."""
+    res = _run(2, _syncbn_worker)
+    for rank, kinds, e_dx, e_dw, e_rm, e_rv, nbt in res:
+        assert kinds == ['Conv3d', 'SyncBatchNorm', 'ReLU', 'Conv3d', 'BatchNorm3d', 'SyncBatchNorm'], kinds
+        assert e_dx < 2e-4 and e_dw < 2e-4, (rank, e_dx, e_dw)
+        assert e_rm < 1e-5 and e_rv < 1e-5 and nbt == 1
