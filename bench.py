@@ -185,11 +185,10 @@ def run_forward(args):
     depth, ctx = depth.to(dev), ctx.to(dev)
     vt = LSSViewTransformerFunction3D(cfg.grid_config, cfg.input_size, cfg.downsample,
                                       tile_voxels=args.tile_voxels, pool_flags=args.pool_flags).to(dev)
-    args.tile_voxels = vt.tile_voxels
+    args.tile_voxels, flags = vt.tiling(cfg.n_cams)            # density-aware tiling of this rig (6 cameras here)
     Z, Y, X = vt.grid_zyx
     C = cfg.channels
-    tile_ws = vt._tile_ws(dev, B)
-    flags = vt.pool_flags
+    tile_ws = vt._tile_ws(dev, B, args.tile_voxels)
     store_dt = {'f32': torch.float32, 'bf16': torch.bfloat16, 'f16': torch.float16}[args.storage]
     esz = 4 if args.storage == 'f32' else 2
     out = torch.empty((B, C, Z, Y, X), dtype=store_dt, device=dev)

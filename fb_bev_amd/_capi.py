@@ -28,6 +28,10 @@ SIGNATURES = {
                                [c_void_p, c_size_t, c_void_p]),
     'fbbev_lift_rank_build': (c_int, [c_void_p] * 10 + [c_int] * 5 + [c_void_p] * 3 + [c_void_p] * 7 +
                               [c_void_p, c_size_t, c_void_p]),
+    'fbbev_cam_key_words': (c_size_t, [c_int] * 2),
+    'fbbev_lift_rank_build_cached': (c_int, [c_void_p] * 10 + [c_int] * 5 + [c_void_p] * 3 + [c_void_p] * 7 +
+                                     [c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    'fbbev_pool_tile_index_cached': (c_int, [c_void_p] * 3 + [c_int] * 7 + [c_void_p, c_size_t, c_void_p, c_void_p]),
     'fbbev_pool_dense_workspace_bytes': (c_size_t, [c_int] * 4),
     'fbbev_pool_tile_index': (c_int, [c_void_p] * 3 + [c_int] * 7 + [c_void_p, c_size_t, c_void_p]),
     'fbbev_bev_pool_v2_dense_fwd': (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_void_p, c_int64, c_int64, c_void_p,
@@ -187,14 +191,16 @@ def rank_build(coor, lower3, interval3, grid_size3, ranks_bev, ranks_depth, rank
 
 def lift_rank_build(xs, ys, ds, rots, trans, intrins, post_rots, post_trans, bda, lower3, interval3, grid_size3,
                     ranks_bev, ranks_depth, ranks_feat, interval_starts, interval_lengths, interval_rank, counts,
-                    workspace, frustum=None):
-    """Geometry + ranking in one call (no coor tensor); arguments as lidar_coor + rank_build."""
+                    workspace, frustum=None, cam_key=None, cache_state=None):
+    """Geometry + ranking in one call (no coor tensor); arguments as lidar_coor + rank_build.
+    cam_key (int32[cam_key_words(B,N)], initialised to -1) + cache_state (int32[2]): the camera-keyed cache -- the build
+    is skipped on the device when the six camera tensors equal the cached key (fbbev_lift_rank_build_cached)."""
     B, N = trans.shape[:2]
     D, H, W = ds.numel(), ys.numel(), xs.numel()
     arr = ctypes.c_float * 3
     lo, it, gs = arr(*lower3), arr(*interval3), arr(*grid_size3)
     with _on(ranks_bev):
-        _check(lib().fbbev_lift_rank_build(
+        args = [
             _dev(frustum, F32, 'frustum') if frustum is not None else c_void_p(0), _dev(xs, F32, 'xs'), _dev(ys, F32, 'ys'), _dev(ds, F32, 'ds'), _dev(rots, F32, 'rots'),
             _dev(trans, F32, 'trans'), _dev(intrins, F32, 'intrins'), _dev(post_rots, F32, 'post_rots'),
             _dev(post_trans, F32, 'post_trans'), _dev(bda, F32, 'bda'), B, N, D, H, W,
@@ -204,7 +210,18 @@ def lift_rank_build(xs, ys, ds, rots, trans, intrins, post_rots, post_trans, bda
             _dev(interval_lengths, I32, 'interval_lengths'),
             _dev(interval_rank, I32, 'interval_rank') if interval_rank is not None else c_void_p(0),
             _dev(counts, I32, 'counts'), c_void_p(workspace.data_ptr()),
-            workspace.numel() * workspace.element_size(), _stream()), 'fbbev_lift_rank_build')
+            workspace.numel() * workspace.element_size()]
+        if cam_key is None:
+            _check(lib().fbbev_lift_rank_build(*args, _stream()), 'fbbev_lift_rank_build')
+        else:      # camera-keyed cache: device-side compare, early-out of the whole build when nothing changed
+            if cam_key.numel() < cam_key_words(B, N) or cache_state.numel() < 2:
+                raise FbbevError('cam_key / cache_state too small')
+            _check(lib().fbbev_lift_rank_build_cached(*args, _dev(cam_key, I32, 'cam_key'), _dev(cache_state, I32, 'cache_state'),
+                                                      _stream()), 'fbbev_lift_rank_build_cached')
+
+
+def cam_key_words(B, N):
+    return int(lib().fbbev_cam_key_words(int(B), int(N)))
 
 
 def pool_dense_workspace_bytes(B, Z, Y, X):
@@ -234,13 +251,16 @@ POOL_OUT_BF16, POOL_OUT_F16 = 0x800000, 0x1000000
 
 
 def pool_tile_index(interval_rank, interval_starts, counts, n_intervals_max, B, Z, Y, X, tile_ws,
-                    tile_voxels=64, flags=0):
+                    tile_voxels=64, flags=0, cache_state=None):
     with _on(interval_rank):
-        _check(lib().fbbev_pool_tile_index(
-            _dev(interval_rank, I32, 'interval_rank'), _dev(interval_starts, I32, 'interval_starts'),
-            _dev(counts, I32, 'counts'), int(n_intervals_max), B, Z, Y, X, int(tile_voxels), int(flags),
-            c_void_p(tile_ws.data_ptr()), tile_ws.numel() * tile_ws.element_size(), _stream()),
-            'fbbev_pool_tile_index')
+        args = [_dev(interval_rank, I32, 'interval_rank'), _dev(interval_starts, I32, 'interval_starts'),
+                _dev(counts, I32, 'counts'), int(n_intervals_max), B, Z, Y, X, int(tile_voxels), int(flags),
+                c_void_p(tile_ws.data_ptr()), tile_ws.numel() * tile_ws.element_size()]
+        if cache_state is None:
+            _check(lib().fbbev_pool_tile_index(*args, _stream()), 'fbbev_pool_tile_index')
+        else:
+            _check(lib().fbbev_pool_tile_index_cached(*args, _dev(cache_state, I32, 'cache_state'), _stream()),
+                   'fbbev_pool_tile_index_cached')
 
 
 def pool_zmean(depth, feat, ranks_depth, ranks_feat, interval_rank, interval_starts, interval_lengths, B, C, Z, Y, X,

@@ -186,7 +186,8 @@ class MultiScaleDeformableAttention(nn.Module):
             HS = (Dh + 3) // 4 * 4
             w, b = self.value_proj.weight, self.value_proj.bias
             if HS != Dh:
-                key = (w._version, b._version, w.device)
+                # data_ptr: a storage swap (param.data = ..., load_state_dict(assign=True), EMA) does not bump _version
+                key = (w._version, b._version, w.data_ptr(), b.data_ptr(), w.device)
                 if getattr(self, '_vpad_key', None) != key:
                     M, E = self.num_heads, w.shape[1]
                     with torch.no_grad():

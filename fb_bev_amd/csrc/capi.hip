@@ -1,5 +1,7 @@
 // capi.hip -- extern "C" entry points of libfbbev_hip.so (include/fbbev.h): argument checks,
 // launch geometry, workspace carving.  No torch, no host synchronisation, caller's stream.
+#include <stdio.h>
+#include <stdlib.h>
 #include "rt.h"
 #include "pool_kernels.h"
 #include "pool_bwd_kernels.h"
@@ -131,103 +133,74 @@ extern "C" int fbbev_point_sampling(const float* xs, const float* ys, const floa
 // ------------------------------------------------------------------------------ voxel ranking
 static inline int key_bits(long long total_voxels) {
     int bits = 1;
-    while ((1ll << bits) <= total_voxels) ++bits;  // total_voxels < 2^bits
+    while ((1ll << bits) < total_voxels) ++bits;   // every rank < total_voxels <= 2^bits
     return bits;
 }
 
+// Chunk shapes of the ranking chain.  A workgroup owns one chunk; fat chunks keep the count matrix (chunks x digits)
+// small enough to be summed directly by every scatter workgroup, and the chunk is the smallest one whose workgroup count
+// still fits ONE round on the 256 CUs (a 1024-thread workgroup is alone on its CU: a second, partly filled round doubles
+// the kernel's time -- measured: 325 workgroups 56 us, the same work in 146 workgroups 29 us).
+//   variant: 0 = 4 waves x 8 (2048), 1 = 16 x 4 (4096), 2 = 16 x 8 (8192), 3 = 16 x 12 (12288), 4 = 16 x 16 (16384)
+static const int kSortTile[5] = {2048, 4096, 8192, 12288, 16384};
+static int sort_variant_for(long long items) {
+    for (int v = 0; v < 5; ++v)
+        if ((items + kSortTile[v] - 1) / kSortTile[v] <= 256) return v;
+    return 4;
+}
+//   interval kernels: 0 = 4 waves x 4 (1024), 1 = 16 x 4 (4096), 2 = 16 x 8 (8192)
+static const int kIvTile[3] = {1024, 4096, 8192};
+static int iv_variant_for(long long items) {
+    for (int v = 0; v < 3; ++v)
+        if ((items + kIvTile[v] - 1) / kIvTile[v] <= 256) return v;
+    return 2;
+}
+
 struct rank_ws_layout {
-    size_t keys_in, vals_in, keys_tmp, vals_tmp, block_counts, hist, totals, total;
-    int n_blocks, sort_blocks;
+    size_t keys_a, keys_t, vals_t, matrix, chunk_info, total;
+    int v0, wgs0;          // pass 0 (keys + scatter over all n points)
+    int v1, wgs1;          // later passes (over the P kept pairs; P is only known on the device: sized for about n/2,
+                           // the grid covers the worst case P = n and surplus workgroups leave at once)
+    int vi, wgsi;          // interval kernels
 };
 
 static rank_ws_layout rank_layout(long long n) {
     rank_ws_layout L;
-    L.n_blocks = (int)((n + FBBEV_RANK_CHUNK - 1) / FBBEV_RANK_CHUNK);
-    L.sort_blocks = (int)((n + FBBEV_SORT_TILE - 1) / FBBEV_SORT_TILE);
+    L.v0 = sort_variant_for(n);
+    L.v1 = sort_variant_for((n + 1) / 2);
+    L.vi = iv_variant_for((n + 1) / 2);
+    // tuning / test knob: FBBEV_RANK_SHAPE="v0,v1,vi" forces the chunk variants (results do not depend on them)
+    if (const char* env = getenv("FBBEV_RANK_SHAPE")) {
+        int a = -1, b = -1, c = -1;
+        if (sscanf(env, "%d,%d,%d", &a, &b, &c) == 3 && a >= 0 && a < 5 && b >= 0 && b < 5 && c >= 0 && c < 3) {
+            L.v0 = a; L.v1 = b; L.vi = c;
+        }
+    }
+    L.wgs0 = (int)((n + kSortTile[L.v0] - 1) / kSortTile[L.v0]);
+    L.wgs1 = (int)((n + kSortTile[L.v1] - 1) / kSortTile[L.v1]);
+    L.wgsi = (int)((n + kIvTile[L.vi] - 1) / kIvTile[L.vi]);
     size_t off = 0;
-    L.keys_in = off; off = align_up(off + (size_t)n * 4, 256);
-    L.vals_in = off; off = align_up(off + (size_t)n * 4, 256);
-    L.keys_tmp = off; off = align_up(off + (size_t)n * 4, 256);
-    L.vals_tmp = off; off = align_up(off + (size_t)n * 4, 256);
-    L.block_counts = off; off = align_up(off + (size_t)(L.n_blocks + 1) * 4, 256);
-    L.hist = off; off = align_up(off + ((size_t)(L.sort_blocks + 64) * 2 << FBBEV_SORT_MAX_RB) * 4, 256);  // also covers the per-camera tiling
-    L.totals = off; off = align_up(off + ((size_t)4 << FBBEV_SORT_MAX_RB) * 4, 256);   // [pass][digit]
-    L.total = off;
+    L.keys_a = off; off = align_up(off + (size_t)n * 4, 256);
+    L.keys_t = off; off = align_up(off + (size_t)n * 4, 256);
+    L.vals_t = off; off = align_up(off + (size_t)n * 4, 256);
+    const int rows = L.wgs0 > L.wgs1 ? L.wgs0 : L.wgs1;
+    L.matrix = off; off = align_up(off + (size_t)rows * FBBEV_SORT_MAX_NB * 4, 256);
+    L.chunk_info = off; off = align_up(off + (size_t)L.wgsi * 8, 256);
+    L.total = off;                                         // no per-build state: nothing to clear, no kernel waits for another
     return L;
 }
 
-// stable LSD radix sort of the low `bits` key bits; result lands in (keys_out, vals_out)
-template <int RB>
-static int sort_pass(const unsigned int* kin, const unsigned int* vin, unsigned int* kout, unsigned int* vout,
-                     long long n_host, const int* n_dev, int shift, int nblocks, unsigned int drop_key, int drop,
-                     int* hist, int* totals, int* n_out, fbbev_rt_stream stream) {
-    FBBEV_LAUNCH(k_sort_hist<RB>, nblocks, 256, 0, stream, kin, n_host, n_dev, shift, nblocks, drop_key, drop, hist);
-    FBBEV_LAUNCH(k_sort_rowsum, 1 << RB, 256, 0, stream, (const int*)hist, nblocks, totals);
-    FBBEV_LAUNCH(k_sort_scan, 1 << RB, 256, 0, stream, hist, (const int*)totals, nblocks, n_out);
-    FBBEV_LAUNCH(k_sort_scatter<RB>, nblocks, 256, 0, stream, kin, vin, n_host, n_dev, n_host, nblocks, shift, nblocks,
-                 drop_key, drop, (const int*)hist, kout, vout);
-    return fbbev_rt_last_error();
-}
-
-// Stable LSD radix sort of the low `bits` key bits.  Pass 0 drops keys == drop_key and writes the number
-// of kept pairs to *n_kept_dev; later passes read that device counter.  Result in (keys_out, vals_out).
-template <int RB>
-static int sort_pass_geom(const fbbev_geom_src& g, unsigned int* keys_scratch, long long n, unsigned int* kout,
-                          unsigned int* vout, int nblocks, int* hist, int* totals, int* n_out,
-                          fbbev_rt_stream stream) {
-    const long long dhw = (long long)g.cam.D * g.cam.H * g.cam.W;
-    FBBEV_LAUNCH(k_sort_hist_geom<RB>, nblocks, 256, 0, stream, g, 0, nblocks, hist, keys_scratch);
-    FBBEV_LAUNCH(k_sort_rowsum, 1 << RB, 256, 0, stream, (const int*)hist, nblocks, totals);
-    FBBEV_LAUNCH(k_sort_scan, 1 << RB, 256, 0, stream, hist, (const int*)totals, nblocks, n_out);
-    // same per-camera tiling; values are the key positions = point ids ((b*N+n)*D+d)*HW+hw
-    FBBEV_LAUNCH(k_sort_scatter<RB>, nblocks, 256, 0, stream, (const unsigned int*)keys_scratch,
-                 (const unsigned int*)nullptr, n, (const int*)nullptr, dhw, g.chunks_per_cam, 0, nblocks, g.sentinel, 1,
-                 (const int*)hist, kout, vout);
-    return fbbev_rt_last_error();
-}
-
-// geom != nullptr: pass 0 evaluates the keys from the camera geometry (no keys_a/vals_a input).
-static int radix_sort_pairs(unsigned int* keys_a, unsigned int* vals_a, unsigned int* keys_t, unsigned int* vals_t,
-                            unsigned int* keys_out, unsigned int* vals_out, long long n, int bits,
-                            unsigned int drop_key, int* n_kept_dev, int nblocks, int* hist, int* totals,
-                            fbbev_rt_stream stream, const fbbev_geom_src* geom = nullptr, int geom_blocks = 0) {
-    const int passes = (bits + FBBEV_SORT_MAX_RB - 1) / FBBEV_SORT_MAX_RB;
-    const int rb = (bits + passes - 1) / passes;      // digits as even as possible, <= 9 bits
-    int e = 0;
-    const unsigned int* kin = keys_a; const unsigned int* vin = vals_a;
-    for (int p = 0; p < passes; ++p) {
-        const bool to_out = ((passes - 1 - p) % 2) == 0;   // last pass always writes the outputs
-        unsigned int* ko = to_out ? keys_out : keys_t;
-        unsigned int* vo = to_out ? vals_out : vals_t;
-        int* tot = totals + ((size_t)p << FBBEV_SORT_MAX_RB);
-        const int shift = p * rb;
-        const int* n_dev = (p == 0) ? nullptr : n_kept_dev;
-        int* n_out = (p == 0) ? n_kept_dev : nullptr;
-        const int drop = (p == 0) ? 1 : 0;
-        if (p == 0 && geom) {
-            switch (rb) {
-                case 9: e = sort_pass_geom<9>(*geom, keys_a, n, ko, vo, geom_blocks, hist, tot, n_out, stream); break;
-                case 8: e = sort_pass_geom<8>(*geom, keys_a, n, ko, vo, geom_blocks, hist, tot, n_out, stream); break;
-                case 7: e = sort_pass_geom<7>(*geom, keys_a, n, ko, vo, geom_blocks, hist, tot, n_out, stream); break;
-                case 6: e = sort_pass_geom<6>(*geom, keys_a, n, ko, vo, geom_blocks, hist, tot, n_out, stream); break;
-                default: e = sort_pass_geom<5>(*geom, keys_a, n, ko, vo, geom_blocks, hist, tot, n_out, stream); break;
-            }
-            if (e) return e;
-            kin = ko; vin = vo;
-            continue;
-        }
-        switch (rb) {
-            case 9: e = sort_pass<9>(kin, vin, ko, vo, n, n_dev, shift, nblocks, drop_key, drop, hist, tot, n_out, stream); break;
-            case 8: e = sort_pass<8>(kin, vin, ko, vo, n, n_dev, shift, nblocks, drop_key, drop, hist, tot, n_out, stream); break;
-            case 7: e = sort_pass<7>(kin, vin, ko, vo, n, n_dev, shift, nblocks, drop_key, drop, hist, tot, n_out, stream); break;
-            case 6: e = sort_pass<6>(kin, vin, ko, vo, n, n_dev, shift, nblocks, drop_key, drop, hist, tot, n_out, stream); break;
-            default: e = sort_pass<5>(kin, vin, ko, vo, n, n_dev, shift, nblocks, drop_key, drop, hist, tot, n_out, stream); break;
-        }
-        if (e) return e;
-        kin = ko; vin = vo;
-    }
-    return 0;
-}
+// one launch of KERNEL<threads or waves, per-thread items> for chunk variant v
+#define FBBEV_SORT_DISPATCH(KERNEL, v, by_waves, grid, stream, ...)                                             \
+    do {                                                                                                        \
+        switch (v) {                                                                                            \
+            case 0: FBBEV_LAUNCH((KERNEL<(by_waves) ? 4 : 256, 8>), grid, 256, 0, stream, __VA_ARGS__); break;   \
+            case 1: FBBEV_LAUNCH((KERNEL<(by_waves) ? 16 : 1024, 4>), grid, 1024, 0, stream, __VA_ARGS__); break; \
+            case 2: FBBEV_LAUNCH((KERNEL<(by_waves) ? 16 : 1024, 8>), grid, 1024, 0, stream, __VA_ARGS__); break; \
+            case 3: FBBEV_LAUNCH((KERNEL<(by_waves) ? 16 : 1024, 12>), grid, 1024, 0, stream, __VA_ARGS__); break; \
+            default: FBBEV_LAUNCH((KERNEL<(by_waves) ? 16 : 1024, 16>), grid, 1024, 0, stream, __VA_ARGS__); break; \
+        }                                                                                                       \
+    } while (0)
 
 extern "C" size_t fbbev_rank_workspace_bytes(int64_t n_points) {
     if (n_points <= 0) return 256;
@@ -240,19 +213,21 @@ static int rank_build_impl(const float* coor, const fbbev_cam_ptrs* cams, const 
                            int32_t* ranks_bev, int32_t* ranks_depth, int32_t* ranks_feat,
                            int32_t* interval_starts, int32_t* interval_lengths, int32_t* interval_rank,
                            int32_t* counts, void* workspace, size_t workspace_bytes, fbbev_rt_stream stream,
-                           const float* point_depth = nullptr, float depth_thr = 0.f) {
+                           const float* point_depth = nullptr, float depth_thr = 0.f, const int* skip = nullptr) {
     if (B <= 0 || N <= 0 || D <= 0 || H <= 0 || W <= 0) return FBBEV_E_BADARG;
     if (point_depth && cams) return FBBEV_E_UNSUPPORTED;      // the depth filter belongs to the coor-based (two-step) contract
     if ((!coor && !cams) || !lower3 || !interval3 || !grid_size3 || !ranks_bev || !ranks_depth || !ranks_feat ||
         !interval_starts || !interval_lengths || !counts || !workspace) return FBBEV_E_BADARG;
     const long long n = (long long)B * N * D * H * W;
-    if (n >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
+    if (n >= (1ll << 30)) return FBBEV_E_UNSUPPORTED;          // 30-bit counts in the look-back words
     const rank_ws_layout L = rank_layout(n);
     if (workspace_bytes < L.total) return FBBEV_E_WORKSPACE;
     unsigned char* ws = static_cast<unsigned char*>(workspace);
-    unsigned int* keys_in = reinterpret_cast<unsigned int*>(ws + L.keys_in);
-    unsigned int* vals_in = reinterpret_cast<unsigned int*>(ws + L.vals_in);
-    int* block_counts = reinterpret_cast<int*>(ws + L.block_counts);
+    unsigned int* keys_a = reinterpret_cast<unsigned int*>(ws + L.keys_a);
+    unsigned int* keys_t = reinterpret_cast<unsigned int*>(ws + L.keys_t);
+    unsigned int* vals_t = reinterpret_cast<unsigned int*>(ws + L.vals_t);
+    int* matrix = reinterpret_cast<int*>(ws + L.matrix);
+    int2* chunk_info = reinterpret_cast<int2*>(ws + L.chunk_info);
 
     fbbev_grid_params gp;
     gp.lx = lower3[0]; gp.ly = lower3[1]; gp.lz = lower3[2];
@@ -265,43 +240,55 @@ static int rank_build_impl(const float* coor, const fbbev_cam_ptrs* cams, const 
     gp.f_zyx = zyx; gp.f_yx = yx;
     const long long total_voxels = (long long)B * (long long)gp.gz * (long long)gp.gy * (long long)gp.gx;
     if (total_voxels <= 0 || total_voxels >= (1ll << 30)) return FBBEV_E_UNSUPPORTED;
-    const int bits = key_bits(total_voxels) + 1;               // room for the sentinel above every rank
-    const unsigned int sentinel = (1u << bits) - 1u;
-
-    int e = fbbev_rt_memset_async(counts, 0, 2 * sizeof(int32_t), stream);
-    if (e) return e;
-    fbbev_geom_src gs;
-    int geom_blocks = 0;
+    // fp32 rank evaluation can round UP above 2^24 voxels: one spare bit covers total_voxels itself
+    const int bits = key_bits(total_voxels + 128);
+    struct { int passes, rb; } plan;
+    plan.passes = (bits + FBBEV_SORT_MAX_RB - 1) / FBBEV_SORT_MAX_RB;
+    plan.rb = (bits + plan.passes - 1) / plan.passes;          // digits as even as possible, <= 8 bits
+    if (plan.rb < 4) plan.rb = 4;
+    const int rb = plan.rb;
     if (cams) {
-        gs.cam = *cams; gs.frustum = frustum; gs.gp = gp; gs.sentinel = sentinel;
-        const long long dhw = (long long)D * H * W;
-        gs.chunks_per_cam = (int)((dhw + FBBEV_SORT_TILE - 1) / FBBEV_SORT_TILE);
-        const long long gb = (long long)B * N * gs.chunks_per_cam;
-        if (gb > (long long)(L.sort_blocks + 64) * 2) return FBBEV_E_UNSUPPORTED;   // hist capacity (tiny frusta, huge B*N)
-        geom_blocks = (int)gb;
+        fbbev_geom_src gs;
+        gs.cam = *cams; gs.frustum = frustum; gs.gp = gp;
+        FBBEV_SORT_DISPATCH(k_keys_hist_geom, L.v0, false, L.wgs0, stream, gs, n, rb, skip, keys_a, matrix);
     } else {
-        long long kb = (n + 255) / 256;
-        if (kb > 8192) kb = 8192;
-        FBBEV_LAUNCH(k_rank_keys, kb, 256, 0, stream, coor, n, n / B, gp, sentinel, point_depth, depth_thr, keys_in, vals_in);
-        FBBEV_CHECK_LAUNCH();
+        FBBEV_SORT_DISPATCH(k_keys_hist_coor, L.v0, false, L.wgs0, stream, coor, n, n / B, gp, point_depth, depth_thr, rb, keys_a, matrix);
     }
-    e = radix_sort_pairs(keys_in, vals_in, reinterpret_cast<unsigned int*>(ws + L.keys_tmp),
-                         reinterpret_cast<unsigned int*>(ws + L.vals_tmp), reinterpret_cast<unsigned int*>(ranks_bev),
-                         reinterpret_cast<unsigned int*>(ranks_depth), n, bits, sentinel, counts, L.sort_blocks,
-                         reinterpret_cast<int*>(ws + L.hist), reinterpret_cast<int*>(ws + L.totals), stream,
-                         cams ? &gs : nullptr, geom_blocks);
-    if (e) return e;
+    FBBEV_CHECK_LAUNCH();
+    const unsigned int* kin = keys_a;
+    const unsigned int* vin = nullptr;                         // pass 0: value = position = point id
+    for (int p = 0; p < plan.passes; ++p) {
+        const bool to_out = ((plan.passes - 1 - p) % 2) == 0;  // the last pass always writes the outputs
+        unsigned int* ko = to_out ? reinterpret_cast<unsigned int*>(ranks_bev) : keys_t;
+        unsigned int* vo = to_out ? reinterpret_cast<unsigned int*>(ranks_depth) : vals_t;
+        const int v = p == 0 ? L.v0 : L.v1, wgs = p == 0 ? L.wgs0 : L.wgs1;
+        if (p > 0) {                                           // count matrix of this pass (pass 0: written with the keys)
+            FBBEV_SORT_DISPATCH(k_sort_hist, v, false, wgs, stream, kin, (const int*)counts, p * rb, rb, skip, matrix);
+            FBBEV_CHECK_LAUNCH();
+        }
+        FBBEV_SORT_DISPATCH(k_sort_scatter, v, true, wgs, stream, kin, vin, n, (const int*)matrix, p, rb, skip, ko, vo, counts);
+        FBBEV_CHECK_LAUNCH();
+        kin = ko; vin = vo;
+    }
     const unsigned int* keys = reinterpret_cast<const unsigned int*>(ranks_bev);
     const unsigned int* vals = reinterpret_cast<const unsigned int*>(ranks_depth);
-    FBBEV_LAUNCH(k_flag_count, L.n_blocks, FBBEV_RANK_BLOCK, 0, stream, keys, (const int*)counts, block_counts);
-    FBBEV_CHECK_LAUNCH();
-    FBBEV_LAUNCH(k_write_intervals, L.n_blocks, FBBEV_RANK_BLOCK, 0, stream, keys, vals, counts,
-                 (const int*)block_counts, L.n_blocks, D, H * W, ranks_feat, interval_starts, interval_rank);
-    FBBEV_CHECK_LAUNCH();
-    long long lb = (n + 255) / 256;
-    if (lb > 4096) lb = 4096;
-    FBBEV_LAUNCH(k_interval_lengths, lb, 256, 0, stream, (const int*)interval_starts, (const int*)counts, n,
-                 interval_lengths);
+    switch (L.vi) {
+        case 0:
+            FBBEV_LAUNCH((k_interval_count<4, 4>), L.wgsi, 256, 0, stream, keys, (const int*)counts, skip, chunk_info);
+            FBBEV_LAUNCH((k_interval_write<4, 4>), L.wgsi, 256, 0, stream, keys, vals, D, H * W, (const int2*)chunk_info, skip,
+                         ranks_feat, interval_starts, interval_lengths, interval_rank, counts);
+            break;
+        case 1:
+            FBBEV_LAUNCH((k_interval_count<16, 4>), L.wgsi, 1024, 0, stream, keys, (const int*)counts, skip, chunk_info);
+            FBBEV_LAUNCH((k_interval_write<16, 4>), L.wgsi, 1024, 0, stream, keys, vals, D, H * W, (const int2*)chunk_info, skip,
+                         ranks_feat, interval_starts, interval_lengths, interval_rank, counts);
+            break;
+        default:
+            FBBEV_LAUNCH((k_interval_count<16, 8>), L.wgsi, 1024, 0, stream, keys, (const int*)counts, skip, chunk_info);
+            FBBEV_LAUNCH((k_interval_write<16, 8>), L.wgsi, 1024, 0, stream, keys, vals, D, H * W, (const int2*)chunk_info, skip,
+                         ranks_feat, interval_starts, interval_lengths, interval_rank, counts);
+            break;
+    }
     FBBEV_CHECK_LAUNCH();
     return 0;
 }
@@ -330,6 +317,30 @@ extern "C" int fbbev_rank_build_depth(const float* coor, const float* depth, flo
                            workspace_bytes, (fbbev_rt_stream)stream_, depth, depth_threshold);
 }
 
+static int lift_rank_build_impl(const float* frustum, const float* xs, const float* ys, const float* ds,
+                                const float* rots, const float* trans, const float* intrins, const float* post_rots,
+                                const float* post_trans, const float* bda, int B, int N, int D, int H, int W,
+                                const float* lower3, const float* interval3, const float* grid_size3,
+                                int32_t* ranks_bev, int32_t* ranks_depth, int32_t* ranks_feat, int32_t* interval_starts,
+                                int32_t* interval_lengths, int32_t* interval_rank, int32_t* counts, void* workspace,
+                                size_t workspace_bytes, fbbev_rt_stream stream, uint32_t* cam_key, int32_t* cache_state) {
+    if (!xs || !ys || !ds || !rots || !trans || !intrins || !post_rots || !post_trans || !bda) return FBBEV_E_BADARG;
+    if (B <= 0 || N <= 0) return FBBEV_E_BADARG;
+    fbbev_cam_ptrs g;
+    g.xs = xs; g.ys = ys; g.ds = ds; g.rots = rots; g.trans = trans; g.intrins = intrins; g.post_rots = post_rots;
+    g.post_trans = post_trans; g.bda = bda; g.N = N; g.D = D; g.H = H; g.W = W;
+    const int* skip = nullptr;
+    if (cam_key) {
+        if (!cache_state) return FBBEV_E_BADARG;
+        FBBEV_LAUNCH(k_cam_key, 1, 256, 0, stream, g, B, cam_key, cache_state);
+        FBBEV_CHECK_LAUNCH();
+        skip = cache_state;
+    }
+    return rank_build_impl(nullptr, &g, frustum, B, N, D, H, W, lower3, interval3, grid_size3, ranks_bev, ranks_depth,
+                           ranks_feat, interval_starts, interval_lengths, interval_rank, counts, workspace,
+                           workspace_bytes, stream, nullptr, 0.f, skip);
+}
+
 extern "C" int fbbev_lift_rank_build(const float* frustum, const float* xs, const float* ys, const float* ds,
                                      const float* rots,
                                      const float* trans, const float* intrins, const float* post_rots,
@@ -339,13 +350,30 @@ extern "C" int fbbev_lift_rank_build(const float* frustum, const float* xs, cons
                                      int32_t* ranks_feat, int32_t* interval_starts, int32_t* interval_lengths,
                                      int32_t* interval_rank, int32_t* counts, void* workspace,
                                      size_t workspace_bytes, fbbev_stream_t stream_) {
-    if (!xs || !ys || !ds || !rots || !trans || !intrins || !post_rots || !post_trans || !bda) return FBBEV_E_BADARG;
-    fbbev_cam_ptrs g;
-    g.xs = xs; g.ys = ys; g.ds = ds; g.rots = rots; g.trans = trans; g.intrins = intrins; g.post_rots = post_rots;
-    g.post_trans = post_trans; g.bda = bda; g.N = N; g.D = D; g.H = H; g.W = W;
-    return rank_build_impl(nullptr, &g, frustum, B, N, D, H, W, lower3, interval3, grid_size3, ranks_bev, ranks_depth,
-                           ranks_feat, interval_starts, interval_lengths, interval_rank, counts, workspace,
-                           workspace_bytes, (fbbev_rt_stream)stream_);
+    return lift_rank_build_impl(frustum, xs, ys, ds, rots, trans, intrins, post_rots, post_trans, bda, B, N, D, H, W, lower3,
+                                interval3, grid_size3, ranks_bev, ranks_depth, ranks_feat, interval_starts,
+                                interval_lengths, interval_rank, counts, workspace, workspace_bytes,
+                                (fbbev_rt_stream)stream_, nullptr, nullptr);
+}
+
+extern "C" size_t fbbev_cam_key_words(int B, int N) {
+    return (B <= 0 || N <= 0) ? 0 : (size_t)B * N * 33 + (size_t)B * 9;
+}
+
+extern "C" int fbbev_lift_rank_build_cached(const float* frustum, const float* xs, const float* ys, const float* ds,
+                                            const float* rots, const float* trans, const float* intrins,
+                                            const float* post_rots, const float* post_trans, const float* bda, int B,
+                                            int N, int D, int H, int W, const float* lower3, const float* interval3,
+                                            const float* grid_size3, int32_t* ranks_bev, int32_t* ranks_depth,
+                                            int32_t* ranks_feat, int32_t* interval_starts, int32_t* interval_lengths,
+                                            int32_t* interval_rank, int32_t* counts, void* workspace,
+                                            size_t workspace_bytes, uint32_t* cam_key, int32_t* cache_state,
+                                            fbbev_stream_t stream_) {
+    if (!cam_key || !cache_state) return FBBEV_E_BADARG;
+    return lift_rank_build_impl(frustum, xs, ys, ds, rots, trans, intrins, post_rots, post_trans, bda, B, N, D, H, W, lower3,
+                                interval3, grid_size3, ranks_bev, ranks_depth, ranks_feat, interval_starts,
+                                interval_lengths, interval_rank, counts, workspace, workspace_bytes,
+                                (fbbev_rt_stream)stream_, cam_key, cache_state);
 }
 
 // ------------------------------------------------------------------------------ fused dense fwd
@@ -364,10 +392,33 @@ extern "C" size_t fbbev_pool_dense_workspace_bytes(int B, int Z, int Y, int X) {
     return align_up((size_t)(tiles + 2) * 8, 256);                // two ints per tile
 }
 
+static int pool_tile_index_impl(const int32_t* interval_rank, const int32_t* interval_starts,
+                                const int32_t* counts, int n_intervals_max, int B, int Z, int Y,
+                                int X, int tile_voxels, int flags, void* tile_ws, size_t tile_ws_bytes,
+                                fbbev_stream_t stream_, const int32_t* skip);
+
 extern "C" int fbbev_pool_tile_index(const int32_t* interval_rank, const int32_t* interval_starts,
                                      const int32_t* counts, int n_intervals_max, int B, int Z, int Y,
                                      int X, int tile_voxels, int flags, void* tile_ws, size_t tile_ws_bytes,
                                      fbbev_stream_t stream_) {
+    return pool_tile_index_impl(interval_rank, interval_starts, counts, n_intervals_max, B, Z, Y, X, tile_voxels, flags,
+                                tile_ws, tile_ws_bytes, stream_, nullptr);
+}
+
+extern "C" int fbbev_pool_tile_index_cached(const int32_t* interval_rank, const int32_t* interval_starts,
+                                            const int32_t* counts, int n_intervals_max, int B, int Z, int Y,
+                                            int X, int tile_voxels, int flags, void* tile_ws, size_t tile_ws_bytes,
+                                            const int32_t* cache_state, fbbev_stream_t stream_) {
+    if (!cache_state) return FBBEV_E_BADARG;
+    if ((flags & FBBEV_POOL_CHANNELS_LAST) && small_tile_shift(tile_voxels)) return FBBEV_E_UNSUPPORTED;
+    return pool_tile_index_impl(interval_rank, interval_starts, counts, n_intervals_max, B, Z, Y, X, tile_voxels, flags,
+                                tile_ws, tile_ws_bytes, stream_, cache_state);
+}
+
+static int pool_tile_index_impl(const int32_t* interval_rank, const int32_t* interval_starts,
+                                const int32_t* counts, int n_intervals_max, int B, int Z, int Y,
+                                int X, int tile_voxels, int flags, void* tile_ws, size_t tile_ws_bytes,
+                                fbbev_stream_t stream_, const int32_t* skip) {
     if (B <= 0 || Z <= 0 || Y <= 0 || X <= 0 || n_intervals_max < 0) return FBBEV_E_BADARG;
     if (!interval_rank || !interval_starts || !counts || !tile_ws) return FBBEV_E_BADARG;
     const long long yx = (long long)Y * X;
@@ -401,7 +452,7 @@ extern "C" int fbbev_pool_tile_index(const int32_t* interval_rank, const int32_t
     if (tile_ws_bytes < (size_t)(n_tiles + 1) * 8) return FBBEV_E_WORKSPACE;
     FBBEV_LAUNCH(k_tile_lower_bound2, (n_tiles + 1 + 255) / 256, 256, 0, (fbbev_rt_stream)stream_,
                  (int)n_tiles, tiles_per_plane, (int)plane, TV, interval_rank, interval_starts, counts,
-                 n_intervals_max, static_cast<int*>(tile_ws));
+                 n_intervals_max, skip, static_cast<int*>(tile_ws));
     FBBEV_CHECK_LAUNCH();
     return 0;
 }
@@ -861,7 +912,7 @@ extern "C" int fbbev_bev_pool_v2_dense_bwd(const float* out_grad, long long og_s
         FBBEV_CHECK_LAUNCH();
     }
     FBBEV_LAUNCH(k_tile_lower_bound2, (l.n_tiles + 1 + 255) / 256, 256, 0, stream, (int)l.n_tiles, l.tpp, (int)yx,
-                 128, interval_rank, interval_starts, counts, n_intervals_max, meta);
+                 128, interval_rank, interval_starts, counts, n_intervals_max, (const int*)nullptr, meta);
     FBBEV_CHECK_LAUNCH();
     if (lds > 64 * 1024) {
         e = fbbev_rt_allow_dyn_lds((const void*)k_pool_bwd_rows<128>, lds);

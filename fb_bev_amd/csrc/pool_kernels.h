@@ -249,12 +249,15 @@ __global__ void __launch_bounds__(256)
 k_tile_lower_bound2(int n_tiles, int tiles_per_plane, int YX, int TV,
                     const int* __restrict__ interval_rank, const int* __restrict__ starts,
                     const int* __restrict__ counts /* [P, I] */, int n_intervals_max,
+                    const int* __restrict__ skip /* cached index set unchanged: keep the table */,
                     int* __restrict__ tile_meta) {
+    if (skip != nullptr && *skip != 0) return;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t > n_tiles) return;
-    const int P = counts[0];
+    int P = counts[0];
     int n = counts[1];
     if (n > n_intervals_max) n = n_intervals_max;
+    if (n < 0 || P < 0) { n = 0; P = 0; }          // a failed rank build reports P = I = -1: pool nothing
     const int plane = t / tiles_per_plane, k = t - plane * tiles_per_plane;
     const long long target = (long long)plane * YX + (long long)k * TV;
     int lo = 0, hi = n;

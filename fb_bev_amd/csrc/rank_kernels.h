@@ -4,20 +4,15 @@
 // (fbbev/view_transformation/forward_projection/view_transformer.py:547-605): in the reference
 // ~17 torch launches, an unstable argsort over B*N*D*H*W keys, three boolean-mask gathers and a
 // torch.where -- at least four host syncs.  Here everything stays on the device:
-//   k_rank_keys        : point -> key (fp32 rank evaluation + truncation, bit-for-bit the
-//                        reference arithmetic); points outside the grid get a sentinel key.
-//   (stable radix sort of (key, point id) pairs, sort_kernels.h; its first pass drops the
-//    sentinel keys and publishes P, the number of kept points, on the device)
-//   k_flag_count       : per-block count of run heads
-//   k_write_intervals  : prefix of the block counts + run heads -> interval_starts (wave prefix sums),
-//                        ranks_feat, I (number of intervals)
-//   k_interval_lengths : starts -> lengths
+//   k_keys_hist_*     : point -> key (fp32 rank evaluation + truncation, bit-for-bit the
+//                        reference arithmetic); points outside the grid get a sentinel key  (sort_kernels.h)
+//   (stable radix sort of (key, point id) pairs, sort_kernels.h: count matrix + scatter per pass; its first
+//    pass drops the sentinel keys and publishes P, the number of kept points, on the device)
+//   k_interval_count / k_interval_write : run heads of the sorted keys -> interval_starts / interval_lengths /
+//                        interval_rank, ranks_feat, I (number of intervals); see the kernels below
 #pragma once
 #include "rt.h"
 
-#define FBBEV_RANK_ITEMS 4          // items per thread in the run-detection kernels
-#define FBBEV_RANK_BLOCK 256
-#define FBBEV_RANK_CHUNK (FBBEV_RANK_ITEMS * FBBEV_RANK_BLOCK)
 
 struct fbbev_grid_params {
     float lx, ly, lz;     // grid_lower_bound        (view_transformer.py:384)
@@ -50,22 +45,6 @@ __device__ __forceinline__ unsigned int fbbev_rank_key(float cx, float cy, float
     return kept ? (unsigned int)(int)r : sentinel;
 }
 
-__global__ void __launch_bounds__(256)
-k_rank_keys(const float* __restrict__ coor, long long npts, long long pts_per_batch,
-            fbbev_grid_params gp, unsigned int sentinel, const float* __restrict__ depth, float depth_thr,
-            unsigned int* __restrict__ keys, unsigned int* __restrict__ vals) {
-    for (long long pid = (long long)blockIdx.x * blockDim.x + threadIdx.x; pid < npts;
-         pid += (long long)gridDim.x * blockDim.x) {
-        unsigned int key = fbbev_rank_key(coor[3 * pid], coor[3 * pid + 1], coor[3 * pid + 2], gp,
-                                          (float)(pid / pts_per_batch), sentinel);
-        // BEVDet-era variant (mmdet3d/models/necks/view_transformer.py:556-557): kept &= depth.view(-1) > 0.01 --
-        // the number of kept points becomes data dependent, which the device-side counts absorb
-        if (depth && !(depth[pid] > depth_thr)) key = sentinel;
-        keys[pid] = key;
-        vals[pid] = (unsigned int)pid;
-    }
-}
-
 __device__ __forceinline__ int fbbev_wave_incl_scan(int v, int lane) {
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -94,81 +73,142 @@ __device__ __forceinline__ int fbbev_block_excl_scan(int v, int* lds4, int* tota
     return woff + inc - v;
 }
 
-// keys[0..P) sorted ascending (P = counts[0], published by the sort's compaction pass)
-__global__ void __launch_bounds__(FBBEV_RANK_BLOCK)
-k_flag_count(const unsigned int* __restrict__ keys, const int* __restrict__ counts,
-             int* __restrict__ block_counts) {
-    __shared__ int lds4[4];
-    const long long n = counts[0];
-    const long long base = (long long)blockIdx.x * FBBEV_RANK_CHUNK + threadIdx.x * FBBEV_RANK_ITEMS;
-    int local = 0;
+// exclusive sum / max scans of one int per thread over a block of WAVES wave64s; *total = block result.
+// ldsw: WAVES ints of LDS owned by the caller.  (max: values >= 0, identity 0)
+template <int WAVES, bool MAX>
+__device__ __forceinline__ int fbbev_block_excl_scan_w(int v, int* ldsw, int* total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int inc = v;
 #pragma unroll
-    for (int j = 0; j < FBBEV_RANK_ITEMS; ++j) {
-        const long long i = base + j;
-        if (i < n) {
-            const unsigned int k = keys[i];
-            local += (i == 0 || keys[i - 1] != k) ? 1 : 0;
-        }
+    for (int o = 1; o < 64; o <<= 1) {
+        const int nbr = __shfl_up(inc, o, 64);
+        if (lane >= o) inc = MAX ? (nbr > inc ? nbr : inc) : inc + nbr;
     }
-    int total;
-    (void)fbbev_block_excl_scan(local, lds4, &total);
-    if (threadIdx.x == 0) block_counts[blockIdx.x] = total;
+    int excl = __shfl_up(inc, 1, 64);
+    if (lane == 0) excl = 0;
+    if (lane == 63) ldsw[w] = inc;
+    __syncthreads();
+    int carry = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < WAVES; ++i) {
+        const int x = ldsw[i];
+        if (i < w) carry = MAX ? (x > carry ? x : carry) : carry + x;
+        tot = MAX ? (x > tot ? x : tot) : tot + x;
+    }
+    __syncthreads();
+    *total = tot;
+    return MAX ? (excl > carry ? excl : carry) : carry + excl;
 }
 
-__global__ void __launch_bounds__(FBBEV_RANK_BLOCK)
-k_write_intervals(const unsigned int* __restrict__ keys, const unsigned int* __restrict__ vals,
-                  int* __restrict__ counts, const int* __restrict__ block_counts, int nblocks,
-                  int D, int HW, int* __restrict__ ranks_feat, int* __restrict__ interval_starts,
-                  int* __restrict__ interval_rank) {
-    __shared__ int lds4[4];
-    const long long n = counts[0];
-    // exclusive prefix of the per-block head counts: every block sums the counts of the blocks before it
-    // (<= 16 KiB of L2-resident ints) -- cheaper than a separate single-block scan launch on the critical path
-    int part = 0;
-    for (int j = threadIdx.x; j < (int)blockIdx.x; j += FBBEV_RANK_BLOCK) part += block_counts[j];
-    int block_offset;
-    (void)fbbev_block_excl_scan(part, lds4, &block_offset);
-    const long long base = (long long)blockIdx.x * FBBEV_RANK_CHUNK + threadIdx.x * FBBEV_RANK_ITEMS;
-    bool head[FBBEV_RANK_ITEMS];
-    unsigned int key[FBBEV_RANK_ITEMS];
-    int local = 0;
-    const unsigned int dhw = (unsigned int)D * (unsigned int)HW;
+// ---------------------------------------------------------------- run detection: two launches, no inter-workgroup waiting
+// keys[0..P) sorted ascending, vals = point ids; P = counts[0] (published by the sort's first pass).  Chunk w of both
+// kernels = keys[w*TILE, (w+1)*TILE), TILE = WAVES*64*ITEMS, thread t owns ITEMS consecutive keys.
+//   k_interval_count : per chunk (number of run heads, position + 1 of its last head or 0) -> chunk_info[w]
+//   k_interval_write : the interval index of a head is a prefix sum over the whole array and its length needs the position of
+//                      the head before it: both come from a plain read of chunk_info[0..w) (a few hundred pairs, one
+//                      coalesced load + two block reductions) -- no scan launch, no look-back chain (measured on MI355X:
+//                      a decoupled look-back over device-scope status words cost 33 us here, profiles/r02_*).
+//                      Writes interval_starts / interval_lengths / interval_rank, ranks_feat and I.
+template <int WAVES, int ITEMS>
+__global__ void __launch_bounds__(WAVES * 64)
+k_interval_count(const unsigned int* __restrict__ keys, const int* __restrict__ counts, const int* __restrict__ skip,
+                 int2* __restrict__ chunk_info) {
+    if (skip != nullptr && *skip != 0) return;
+    constexpr int NT = WAVES * 64;
+    constexpr int TILE = NT * ITEMS;
+    __shared__ int ldsw[WAVES];
+    const int tid = threadIdx.x;
+    const int P = counts[0];
+    const long long wg0 = (long long)blockIdx.x * TILE;
+    if (wg0 >= P) return;
+    const long long base = wg0 + (long long)tid * ITEMS;
+    int local = 0, last1 = 0;
+    unsigned int prevk = (base > 0 && base <= P) ? keys[base - 1] : 0u;
 #pragma unroll
-    for (int j = 0; j < FBBEV_RANK_ITEMS; ++j) {
+    for (int j = 0; j < ITEMS; ++j) {
+        const long long i = base + j;
+        if (i < P) {
+            const unsigned int k = keys[i];
+            if (i == 0 || prevk != k) { ++local; last1 = (int)i + 1; }
+            prevk = k;
+        }
+    }
+    int tot, wg_last1;
+    (void)fbbev_block_excl_scan_w<WAVES, false>(local, ldsw, &tot);
+    (void)fbbev_block_excl_scan_w<WAVES, true>(last1, ldsw, &wg_last1);
+    if (tid == 0) chunk_info[blockIdx.x] = make_int2(tot, wg_last1);
+}
+
+template <int WAVES, int ITEMS>
+__global__ void __launch_bounds__(WAVES * 64)
+k_interval_write(const unsigned int* __restrict__ keys, const unsigned int* __restrict__ vals, int D, int HW,
+                 const int2* __restrict__ chunk_info, const int* __restrict__ skip, int* __restrict__ ranks_feat,
+                 int* __restrict__ interval_starts, int* __restrict__ interval_lengths, int* __restrict__ interval_rank,
+                 int* __restrict__ counts) {
+    if (skip != nullptr && *skip != 0) return;
+    constexpr int NT = WAVES * 64;
+    constexpr int TILE = NT * ITEMS;
+    __shared__ int ldsw[WAVES];
+    const int tid = threadIdx.x;
+    const int wg = blockIdx.x;
+    const int P = counts[0];
+    const long long wg0 = (long long)wg * TILE;
+    if (wg0 >= P) {
+        if (wg == 0 && tid == 0) counts[1] = 0;          // no point inside the grid: P = I = 0
+        return;
+    }
+    // heads / last head of all earlier chunks: one strided pass over chunk_info[0..wg) + two block reductions
+    int h = 0, l1 = 0;
+    for (int r = tid; r < wg; r += NT) {
+        const int2 ci = chunk_info[r];
+        h += ci.x;
+        l1 = ci.y > l1 ? ci.y : l1;                       // positions grow with the chunk index: max = nearest
+    }
+    int before_heads, before_last1;
+    (void)fbbev_block_excl_scan_w<WAVES, false>(h, ldsw, &before_heads);
+    (void)fbbev_block_excl_scan_w<WAVES, true>(l1, ldsw, &before_last1);
+    const long long base = wg0 + (long long)tid * ITEMS;
+    bool head[ITEMS];
+    unsigned int key[ITEMS];
+    int local = 0, last1 = 0;
+    const unsigned int dhw = (unsigned int)D * (unsigned int)HW;
+    unsigned int prevk = (base > 0 && base <= P) ? keys[base - 1] : 0u;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
         const long long i = base + j;
         head[j] = false;
         key[j] = 0u;
-        if (i < n) {
+        if (i < P) {
             const unsigned int k = keys[i];
             key[j] = k;
-            head[j] = (i == 0 || keys[i - 1] != k);
-            local += head[j] ? 1 : 0;
+            head[j] = (i == 0 || prevk != k);
+            prevk = k;
+            if (head[j]) { ++local; last1 = (int)i + 1; }
             // view_transformer.py:563-568: feature pixel of point ((b*N+n)*D+d)*HW + hw
             const unsigned int pid = vals[i];
             ranks_feat[i] = (int)((pid / dhw) * (unsigned int)HW + pid % (unsigned int)HW);
         }
     }
-    int total;
-    int j0 = block_offset + fbbev_block_excl_scan(local, lds4, &total);
-    if (blockIdx.x == (unsigned)(nblocks - 1) && threadIdx.x == 0) counts[1] = block_offset + total;   // I
+    int tot, wg_last1;
+    const int off = fbbev_block_excl_scan_w<WAVES, false>(local, ldsw, &tot);
+    const int prev1 = fbbev_block_excl_scan_w<WAVES, true>(last1, ldsw, &wg_last1);   // last head before this thread, +1
+    int j0 = before_heads + off;
+    int prevhead1 = prev1 ? prev1 : before_last1;        // position + 1 of the head before this thread's first head
 #pragma unroll
-    for (int j = 0; j < FBBEV_RANK_ITEMS; ++j) {
+    for (int j = 0; j < ITEMS; ++j) {
         if (head[j]) {
-            interval_starts[j0] = (int)(base + j);
+            const int pos = (int)(base + j);
+            interval_starts[j0] = pos;
             if (interval_rank) interval_rank[j0] = (int)key[j];
+            if (j0 > 0) interval_lengths[j0 - 1] = pos - (prevhead1 - 1);
+            prevhead1 = pos + 1;
             ++j0;
         }
     }
-}
-
-__global__ void __launch_bounds__(256)
-k_interval_lengths(const int* __restrict__ interval_starts, const int* __restrict__ counts,
-                   long long n_max, int* __restrict__ interval_lengths) {
-    const int P = counts[0], I = counts[1];
-    for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < I && j < n_max;
-         j += (long long)gridDim.x * blockDim.x) {
-        const int s = interval_starts[j];
-        const int e = (j + 1 < I) ? interval_starts[j + 1] : P;
-        interval_lengths[j] = e - s;
+    if (tid == 0 && wg0 + TILE >= P) {                    // the chunk that holds the last point closes the chain
+        const int I = before_heads + tot;
+        const int lasthead1 = wg_last1 ? wg_last1 : before_last1;
+        interval_lengths[I - 1] = P - (lasthead1 - 1);
+        counts[1] = I;
     }
 }

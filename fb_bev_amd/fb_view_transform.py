@@ -27,7 +27,7 @@ class FBViewTransform(nn.Module):
         needs_grad = torch.is_grad_enabled() and (context.requires_grad or depth.requires_grad or
                                                   any(p.requires_grad for p in self.parameters()))
         if (self.write_once and self.backward_projection is not None and self.readd and fp.fused and not fp.extra_relu and not needs_grad
-                and context.is_cuda):
+                and context.is_cuda and fp._fused_supported(context.shape[2])):
             # inference: the volume is written ONCE.  The reference writes it (bev_pool_v2), reads it for the Z-mean
             # (fbocc.py:359) and reads + re-writes it for the re-add (:365-366); here the Z-mean comes straight from the
             # index tensors and the refined BEV is added in the store epilogue of the one dense pooling pass.

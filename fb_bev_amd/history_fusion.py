@@ -90,7 +90,10 @@ class TemporalHistoryFusion(nn.Module):
         fwd = self.forward_augs(bda.float())                           # :220
         ego = torch.stack([torch.as_tensor(m['curr_to_prev_ego_rt'], dtype=torch.float32) for m in img_metas]).to(
             dev, non_blocking=True)                                    # :222-224
-        train_path = torch.is_grad_enabled() and (curr.requires_grad or self.training)
+        # Like BatchNorm itself, the route is decided by the module's MODE: a module in training mode normalises with batch
+        # statistics and updates the running ones even under no_grad (a validation loss computed without .eval());
+        # only eval mode without gradients takes the folded-statistics MFMA kernel
+        train_path = self.training or (torch.is_grad_enabled() and curr.requires_grad)
 
         if self.history_bev is None:                                   # first batch (:227-238)
             self.history_bev = self._new_history(curr, train_path)

@@ -34,7 +34,7 @@ class _IndexSet:
     """Device-resident index tensors of one rank build, padded to the frustum size n; the valid
     prefixes are counts[0]=P points and counts[1]=I intervals (device-side)."""
     __slots__ = ('ranks_bev', 'ranks_depth', 'ranks_feat', 'interval_starts', 'interval_lengths',
-                 'interval_rank', 'counts', 'n')
+                 'interval_rank', 'counts', 'n', 'cache_state')
 
     def __init__(self, n, device):
         def buf():
@@ -42,7 +42,8 @@ class _IndexSet:
         self.n = n
         self.ranks_bev, self.ranks_depth, self.ranks_feat = buf(), buf(), buf()
         self.interval_starts, self.interval_lengths, self.interval_rank = buf(), buf(), buf()
-        self.counts = torch.empty(2, dtype=torch.int32, device=device)   # zeroed by the rank build itself
+        self.counts = torch.empty(2, dtype=torch.int32, device=device)   # written by the rank build itself
+        self.cache_state = None             # device flag of the camera-keyed cache (None: built unconditionally)
 
     def exact(self):
         """Trim to exact sizes (ONE host sync: reads the two counts)."""
@@ -51,12 +52,28 @@ class _IndexSet:
                 self.interval_starts[:I], self.interval_lengths[:I])
 
 
+class _WorkspaceCache:
+    """Per-module, per-device scratch of the fused backward (one live buffer per device, grown on demand).  Held by the
+    module -- not by the process: two view transformers, or two devices, never share or free each other's workspace."""
+
+    def __init__(self):
+        self._bwd = {}
+
+    def bwd_workspace(self, device, nbytes):
+        buf = self._bwd.get(device)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(nbytes, dtype=torch.uint8, device=device)   # the old one is released by the caching
+            self._bwd[device] = buf                                        # allocator in stream order
+        return buf
+
+
 class LiftSplat(torch.autograd.Function):
     """Fused dense pooling: depth (B,N,D,H,W), feat (B,N,H,W,C) -> (B,C,Z,Y,X), every voxel written
     once.  Backward regroups by feature pixel and runs the wave-per-pixel grad kernel."""
 
     @staticmethod
-    def forward(ctx, depth, feat, idx, grid_zyx, tile_ws, tile_voxels, pool_flags, out_dtype=torch.float32):
+    def forward(ctx, depth, feat, idx, grid_zyx, tile_ws, tile_voxels, pool_flags, out_dtype=torch.float32,
+                ws_cache=None, cache_state=None):
         depth = depth.contiguous().float()
         # `feat` arrives as the (B,N,H,W,C) permuted view of the NCHW context (view_transformer.py:536); when
         # the underlying tensor is contiguous NCHW the copy is done by the LDS-tiled transpose kernel
@@ -69,11 +86,12 @@ class LiftSplat(torch.autograd.Function):
         Z, Y, X = grid_zyx
         out = torch.empty((B, C, Z, Y, X), dtype=out_dtype, device=depth.device)   # 16-bit: fp32 sums rounded at the store
         _capi.pool_tile_index(idx.interval_rank, idx.interval_starts, idx.counts, idx.n, B, Z, Y, X,
-                              tile_ws, tile_voxels)
+                              tile_ws, tile_voxels, cache_state=cache_state)
         _capi.bev_pool_v2_dense_fwd(depth, feat, idx.ranks_depth, idx.ranks_feat, idx.interval_rank,
                                     idx.interval_starts, idx.interval_lengths, B, C, Z, Y, X, out,
                                     tile_ws, tile_voxels, pool_flags)
         ctx.idx = idx
+        ctx.ws_cache = ws_cache if ws_cache is not None else _WorkspaceCache()
         ctx.grid_zyx = (Z, Y, X)
         ctx.save_for_backward(depth, feat)
         return out
@@ -92,26 +110,22 @@ class LiftSplat(torch.autograd.Function):
         if (og.dtype != torch.float32 or og.stride()[2:] != (Y * X, X, 1) or sc < Z * Y * X or sb < C * sc or sc % 4
                 or sb % 4 or og.data_ptr() % 16):
             og = og.contiguous().float()
-        key = (depth.device, _capi.pool_dense_bwd_workspace_bytes(B, N, D, H, W, C, Z, Y, X))
-        if key not in _BWD_WS:
-            _BWD_WS.clear()      # one live workspace per process: it is sized for the largest rows buffer
-            _BWD_WS[key] = torch.empty(key[1], dtype=torch.uint8, device=depth.device)
+        ws = ctx.ws_cache.bwd_workspace(depth.device, _capi.pool_dense_bwd_workspace_bytes(B, N, D, H, W, C, Z, Y, X))
         depth_grad, feat_grad = torch.empty_like(depth), torch.empty_like(feat)
         _capi.bev_pool_v2_dense_bwd(og, depth, feat, idx.ranks_depth, idx.interval_rank, idx.interval_starts,
-                                    idx.counts, idx.n, (Z, Y, X), depth_grad, feat_grad, _BWD_WS[key])
-        return depth_grad, feat_grad, None, None, None, None, None, None
+                                    idx.counts, idx.n, (Z, Y, X), depth_grad, feat_grad, ws)
+        return depth_grad, feat_grad, None, None, None, None, None, None, None, None
 
-
-_BWD_WS = {}
 
 
 class LSSViewTransformerFunction3D(nn.Module):
     """Lift-Splat view transformer with a 3-D (X,Y,Z) voxel grid -- view_transformer.py:315-663.
 
     Args mirror the reference (grid_config, input_size, downsample, accelerate, uniform, with_cp,
-    extra_relu).  `accelerate=True` caches the index tensors after the first call (valid when the
-    camera rig and augmentation are constant), which the reference's 3-D class intends but disables
-    with `assert False` (:628).  Extra knobs: `fused` (default True) and `tile_voxels`.
+    extra_relu).  `accelerate=True` keeps ONE index set per (device, B, N) keyed on the camera tensors: every call
+    compares them with the cached key on the device (no host sync) and skips the rank build when nothing changed,
+    rebuilds when anything did -- the `pre_compute` the reference's 3-D class intends (:607-611) but disables with
+    `assert False` (:628) because nothing invalidates it.  Extra knobs: `fused` (default True) and `tile_voxels`.
     """
 
     def __init__(self, grid_config, input_size, downsample=16, accelerate=False, uniform=False,
@@ -136,19 +150,12 @@ class LSSViewTransformerFunction3D(nn.Module):
         # storage type of the fused path's BEV volume (fp32 sums, rounded once at the store); BASELINE configs[1]
         # names bf16, configs[4] fp16; the reference itself is fp32 (bev_pool.py:16-22)
         self.out_dtype = out_dtype
-        # dense-kernel tiling: measured per launch on MI355X (profiles/r01_sweep_*.jsonl).  Sparse grids (BL2:
-        # 0.4 frustum points per voxel) are store-bound -> 128-voxel tiles, channel range split over 2
-        # workgroups; dense grids (shipped config: 4.2 points per voxel) are bound by the per-voxel gather
-        # chains -> 64-voxel tiles, no channel split (the gathers are not repeated).
-        n_cam = 6
-        Z, Y, X = self.grid_zyx
-        density = n_cam * self.frustum.shape[0] * self.frustum.shape[1] * self.frustum.shape[2] / float(X * Y * Z)
-        dense = density >= 1.0
-        self.tile_voxels = tile_voxels if tile_voxels is not None else (64 if dense else _capi.DEFAULT_TILE_VOXELS)
-        self.pool_flags = pool_flags if pool_flags is not None else (
-            _capi.pool_flags(csplit=1) if dense else _capi.DEFAULT_POOL_FLAGS)
+        self._tile_voxels_arg, self._pool_flags_arg = tile_voxels, pool_flags
+        self._tiling = {}                   # number of cameras -> (tile_voxels, pool_flags)
+        self.n_cams = None                  # set by the first call (the camera tensors carry it)
+        self._ws = _WorkspaceCache()
         self._cache = {}
-        self._index_cache = None
+        self._index_cache = {}              # (device, B, N) -> (_IndexSet, cam_key, cache_state): accelerate=True
 
     # ------------------------------------------------------------------ static geometry (init time)
     def create_grid_infos(self, x, y, z, **kwargs):
@@ -169,6 +176,32 @@ class LSSViewTransformerFunction3D(nn.Module):
         x = self._xs.view(1, 1, W_feat).expand(self.D, H_feat, W_feat)
         y = self._ys.view(1, H_feat, 1).expand(self.D, H_feat, W_feat)
         self.frustum = torch.stack((x, y, d), -1)
+
+    def tiling(self, n_cams=None):
+        """(tile_voxels, pool_flags) of the dense kernel, chosen by the frustum-points-per-voxel density of THIS rig:
+        measured per launch on MI355X (profiles/r01_sweep_*.jsonl).  Sparse grids (BL2: 0.4 frustum points per voxel) are
+        store-bound -> 128-voxel tiles, channel range split over 2 workgroups; dense grids (shipped config: 4.2 points
+        per voxel) are bound by the per-voxel gather chains -> 64-voxel tiles, no channel split."""
+        n_cams = n_cams if n_cams is not None else self.n_cams
+        if n_cams is None:
+            raise RuntimeError('tiling() needs the number of cameras (known after the first call, or pass n_cams)')
+        if n_cams not in self._tiling:
+            Z, Y, X = self.grid_zyx
+            density = n_cams * self.frustum.shape[0] * self.frustum.shape[1] * self.frustum.shape[2] / float(X * Y * Z)
+            dense = density >= 1.0
+            tv = self._tile_voxels_arg if self._tile_voxels_arg is not None else (64 if dense else _capi.DEFAULT_TILE_VOXELS)
+            fl = self._pool_flags_arg if self._pool_flags_arg is not None else (
+                _capi.pool_flags(csplit=1) if dense else _capi.DEFAULT_POOL_FLAGS)
+            self._tiling[n_cams] = (tv, fl)
+        return self._tiling[n_cams]
+
+    @property
+    def tile_voxels(self):
+        return self.tiling()[0]
+
+    @property
+    def pool_flags(self):
+        return self.tiling()[1]
 
     @property
     def grid_zyx(self):
@@ -205,6 +238,7 @@ class LSSViewTransformerFunction3D(nn.Module):
         depth: optional (B,N,D,H,W) distribution for the BEVDet-era filter `kept &= depth > 0.01`
         (mmdet3d/models/necks/view_transformer.py:556-557); P is then data dependent, still without a host sync."""
         B, N, D, H, W, _ = coor.shape
+        self.n_cams = N
         n = B * N * D * H * W
         key = ('rank_ws', coor.device, n)
         if key not in self._cache:
@@ -217,23 +251,41 @@ class LSSViewTransformerFunction3D(nn.Module):
                          depth_threshold=depth_threshold)
         return idx
 
-    def build_index_from_cams(self, rots, trans, cam2imgs, post_rots, post_trans, bda):
+    def build_index_from_cams(self, rots, trans, cam2imgs, post_rots, post_trans, bda, cached=False):
         """get_lidar_coor + voxel_pooling_prepare_v2 fused (fbbev_lift_rank_build): the keys are evaluated from
-        the camera parameters inside the sort's first pass; same index tensors as build_index(get_lidar_coor())."""
+        the camera parameters inside the sort's first pass; same index tensors as build_index(get_lidar_coor()).
+        cached=True (accelerate): ONE persistent index set per (device, B, N) keyed on the camera tensors -- the device
+        compares them with the cached key and skips the whole build when nothing changed (no host sync), rebuilds
+        when anything did (view_transformer.py:607-611 `pre_compute`, with the invalidation upstream lacks)."""
         B, N, _ = trans.shape
+        self.n_cams = N
         xs, ys, ds = self._axes(trans.device)
         n = B * N * ds.numel() * ys.numel() * xs.numel()
         key = ('rank_ws', trans.device, n)
         if key not in self._cache:
             self._cache[key] = torch.empty(_capi.rank_workspace_bytes(n), dtype=torch.uint8, device=trans.device)
-        idx = _IndexSet(n, trans.device)
+        cam_key = cache_state = None
+        if cached:
+            ck = (trans.device, B, N)
+            if ck not in self._index_cache:
+                self._index_cache[ck] = (_IndexSet(n, trans.device),
+                                         torch.full((_capi.cam_key_words(B, N),), -1, dtype=torch.int32, device=trans.device),
+                                         torch.zeros(2, dtype=torch.int32, device=trans.device))
+            idx, cam_key, cache_state = self._index_cache[ck]
+        else:
+            idx = _IndexSet(n, trans.device)
         lo, it, gs = self._grid3()
         f = lambda t: t.contiguous().float()  # noqa: E731
         _capi.lift_rank_build(xs, ys, ds, f(rots), f(trans), f(cam2imgs), f(post_rots), f(post_trans), f(bda), lo, it,
                               gs, idx.ranks_bev, idx.ranks_depth, idx.ranks_feat, idx.interval_starts,
                               idx.interval_lengths, idx.interval_rank, idx.counts, self._cache[key],
-                              frustum=self._frustum_dev(trans.device))
+                              frustum=self._frustum_dev(trans.device), cam_key=cam_key, cache_state=cache_state)
+        idx.cache_state = cache_state
         return idx
+
+    def index_builds(self, device=None):
+        """Number of real builds of the camera-keyed cache so far (ONE host sync; diagnostics / tests)."""
+        return sum(int(st[1]) for (dev, _, _), (_, _, st) in self._index_cache.items() if device is None or dev == device)
 
     def voxel_pooling_prepare_v2(self, coor):
         """view_transformer.py:547-605 -> (ranks_bev, ranks_depth, ranks_feat, interval_starts,
@@ -245,9 +297,9 @@ class LSSViewTransformerFunction3D(nn.Module):
         return rb.contiguous(), rd.contiguous(), rf.contiguous(), st.contiguous(), ln.contiguous()
 
     def init_acceleration_v2(self, coor):
-        """view_transformer.py:500-519."""
-        self._index_cache = self.build_index(coor)
-        rb, rd, rf, st, ln = self._index_cache.exact()
+        """view_transformer.py:500-519: exact-size index tensors as attributes (reference API; the fused path keeps its
+        own camera-keyed device cache instead, see build_index_from_cams)."""
+        rb, rd, rf, st, ln = self.build_index(coor).exact()
         self.ranks_bev, self.ranks_depth, self.ranks_feat = rb, rd, rf
         self.interval_starts, self.interval_lengths = st, ln
 
@@ -256,6 +308,12 @@ class LSSViewTransformerFunction3D(nn.Module):
         if self.initial_flag:
             self.init_acceleration_v2(self.get_lidar_coor(*cam_params))
             self.initial_flag = False
+
+    def _index_for(self, cam_params, *tensors):
+        """The index set of this call.  accelerate=True: the camera-keyed device cache -- but only when no autograd graph
+        will hold on to the index buffers (a later rebuild would overwrite what an earlier graph's backward reads)."""
+        cached = self.accelerate and not (torch.is_grad_enabled() and any(t.requires_grad for t in tensors))
+        return self.build_index_from_cams(*cam_params, cached=cached)
 
     # ------------------------------------------------------------------ pooling
     def voxel_pooling_v2(self, coor, depth, feat):
@@ -271,9 +329,9 @@ class LSSViewTransformerFunction3D(nn.Module):
         bev_feat = bev_pool_v2(depth, feat, rd, rf, rb, bev_feat_shape, st, ln)
         return bev_feat.permute(0, 1, 3, 4, 2)
 
-    def _tile_ws(self, device, B):
+    def _tile_ws(self, device, B, tile_voxels=None):
         Z, Y, X = self.grid_zyx
-        key = ('tile_ws', device, B)
+        key = ('tile_ws', device, B, tile_voxels)     # one table per tile size: a cached (skipped) build keeps it valid
         if key not in self._cache:
             self._cache[key] = torch.empty(_capi.pool_dense_workspace_bytes(B, Z, Y, X), dtype=torch.uint8,
                                            device=device)
@@ -282,24 +340,26 @@ class LSSViewTransformerFunction3D(nn.Module):
     def lift_splat(self, idx, depth, tran_feat):
         """Fused dense pooling on a prepared index set -> (B,C,Y,X,Z) view of (B,C,Z,Y,X)."""
         feat = tran_feat.permute(0, 1, 3, 4, 2)
-        out = LiftSplat.apply(depth, feat, idx, self.grid_zyx, self._tile_ws(depth.device, depth.shape[0]),
-                              self.tile_voxels, self.pool_flags, self.out_dtype)
+        out = LiftSplat.apply(depth, feat, idx, self.grid_zyx, self._tile_ws(depth.device, depth.shape[0], self.tile_voxels),
+                              self.tile_voxels, self.pool_flags, self.out_dtype, self._ws, idx.cache_state)
         return out.permute(0, 1, 3, 4, 2)
 
     def view_transform_core(self, cam_params, depth, tran_feat):
         """view_transformer.py:613-635."""
-        if not self.fused:
-            return self.voxel_pooling_v2(self.get_lidar_coor(*cam_params), depth, tran_feat)
-        if self.accelerate and self._index_cache is not None:
-            idx = self._index_cache
-        else:
-            idx = self.build_index_from_cams(*cam_params)
-        return self.lift_splat(idx, depth, tran_feat)
+        if not self.fused or not self._fused_supported(tran_feat.shape[2]):
+            # reference-shaped path; also the fallback for shapes outside the fused kernels' preconditions
+            # (fbbev_bev_pool_v2_dense_fwd: C % 4 == 0, C <= 256, (Y*X) % 4 == 0 -- % 8 for 16-bit storage)
+            out = self.voxel_pooling_v2(self.get_lidar_coor(*cam_params), depth, tran_feat)
+            return out if self.out_dtype == torch.float32 else out.to(self.out_dtype)
+        return self.lift_splat(self._index_for(cam_params, depth, tran_feat), depth, tran_feat)
+
+    def _fused_supported(self, C):
+        Z, Y, X = self.grid_zyx
+        q = 4 if self.out_dtype == torch.float32 else 8
+        return C % 4 == 0 and C <= 256 and (Y * X) % q == 0
 
     def view_transform(self, cam_params, depth, tran_feat):
-        """view_transformer.py:639-643."""
-        if self.accelerate:
-            self.pre_compute(cam_params)
+        """view_transformer.py:639-643 (the `pre_compute` of :641 is the camera-keyed cache inside _index_for)."""
         return self.view_transform_core(cam_params, depth, tran_feat)
 
     def forward(self, cam_params, context, depth, **kwargs):
@@ -310,18 +370,15 @@ class LSSViewTransformerFunction3D(nn.Module):
 
     # ------------------------------------------------------------------ write-once volume (inference, FBViewTransform)
     def pooling_inputs(self, cam_params, context, depth):
-        """Index set (cached when accelerate=True) + the two gather sources of the fused kernels."""
-        if self.accelerate:
-            self.pre_compute(cam_params)
-        idx = self._index_cache if (self.accelerate and self._index_cache is not None) else \
-            self.build_index_from_cams(*cam_params)
+        """Index set (camera-keyed cache when accelerate=True) + the two gather sources of the fused kernels."""
+        idx = self._index_for(cam_params, depth, context)
         depth = depth.contiguous().float()
         feat = _capi.nchw_to_nhwc(context.contiguous().float())
         B = depth.shape[0]
         Z, Y, X = self.grid_zyx
-        tile_ws = self._tile_ws(depth.device, B)
+        tile_ws = self._tile_ws(depth.device, B, self._wo_tile)
         _capi.pool_tile_index(idx.interval_rank, idx.interval_starts, idx.counts, idx.n, B, Z, Y, X, tile_ws,
-                              self._wo_tile)
+                              self._wo_tile, cache_state=idx.cache_state)
         return idx, depth, feat, tile_ws
 
     @property

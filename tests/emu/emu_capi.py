@@ -160,21 +160,32 @@ def point_sampling(xs, ys, zs, cam, ogfH, ogfW):
     return ref_cam, mask.bool(), qd
 
 
-def lift_rank_build(xs, ys, ds, cam, lower3, interval3, grid_size3, frustum=None):
+def lift_rank_build(xs, ys, ds, cam, lower3, interval3, grid_size3, frustum=None, cache=None):
+    """cache: dict kept by the caller across calls -> the camera-keyed entry point (same buffers every call)."""
     rots, trans, intrins, post_rots, post_trans, bda = cam
     B, N = trans.shape[:2]
     D, H, W = ds.numel(), ys.numel(), xs.numel()
     n = B * N * D * H * W
-    rb, rd, rf = (torch.full((n,), -7, dtype=torch.int32) for _ in range(3))
-    st, ln, ir = (torch.full((n,), -7, dtype=torch.int32) for _ in range(3))
-    counts = torch.full((2,), -1, dtype=torch.int32)
-    ws = torch.zeros(lib().fbbev_rank_workspace_bytes(n), dtype=torch.uint8)
+    if cache is not None and 'bufs' in cache:
+        rb, rd, rf, st, ln, ir, counts, ws = cache['bufs']
+    else:
+        rb, rd, rf = (torch.full((n,), -7, dtype=torch.int32) for _ in range(3))
+        st, ln, ir = (torch.full((n,), -7, dtype=torch.int32) for _ in range(3))
+        counts = torch.full((2,), -1, dtype=torch.int32)
+        ws = torch.full((lib().fbbev_rank_workspace_bytes(n),), 0xA5, dtype=torch.uint8)   # garbage: the build clears its own state
     arr = ctypes.c_float * 3
     lo, it, gs = arr(*lower3), arr(*interval3), arr(*grid_size3)
-    ok(lib().fbbev_lift_rank_build(p(frustum) if frustum is not None else c_void_p(0), p(xs), p(ys), p(ds), p(rots), p(trans), p(intrins), p(post_rots), p(post_trans), p(bda),
-                                   B, N, D, H, W, ctypes.cast(lo, c_void_p), ctypes.cast(it, c_void_p),
-                                   ctypes.cast(gs, c_void_p), p(rb), p(rd), p(rf), p(st), p(ln), p(ir), p(counts), p(ws),
-                                   ws.numel(), None))
+    args = [p(frustum) if frustum is not None else c_void_p(0), p(xs), p(ys), p(ds), p(rots), p(trans), p(intrins), p(post_rots), p(post_trans), p(bda),
+            B, N, D, H, W, ctypes.cast(lo, c_void_p), ctypes.cast(it, c_void_p),
+            ctypes.cast(gs, c_void_p), p(rb), p(rd), p(rf), p(st), p(ln), p(ir), p(counts), p(ws), ws.numel()]
+    if cache is None:
+        ok(lib().fbbev_lift_rank_build(*args, None))
+    else:
+        if 'bufs' not in cache:
+            cache['bufs'] = (rb, rd, rf, st, ln, ir, counts, ws)
+            cache['key'] = torch.full((lib().fbbev_cam_key_words(B, N),), -1, dtype=torch.int32)
+            cache['state'] = torch.zeros(2, dtype=torch.int32)
+        ok(lib().fbbev_lift_rank_build_cached(*args, p(cache['key']), p(cache['state']), None))
     return rb, rd, rf, st, ln, ir, counts
 
 

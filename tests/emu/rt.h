@@ -29,6 +29,8 @@
 
 struct dim3 { unsigned x, y, z; };
 struct float4 { float x, y, z, w; } __attribute__((aligned(16)));
+struct int2 { int x, y; } __attribute__((aligned(8)));
+inline int2 make_int2(int x, int y) { int2 r; r.x = x; r.y = y; return r; }
 
 namespace emu {
 struct Fiber { ucontext_t ctx; bool done; };
@@ -142,6 +144,7 @@ inline unsigned long long __ballot(int pred) {
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __ffsll(long long x) { return __builtin_ffsll(x); }
 inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
+inline unsigned int atomicOr(unsigned int* p, unsigned int v) { unsigned int o = *p; *p = o | v; return o; }
 
 // single correctly-rounded fp32 ops (volatile defeats re-association / contraction)
 inline float __fsub_rn(float a, float b) { volatile float r = a - b; return r; }
@@ -163,7 +166,6 @@ typedef float fbbev_v4f __attribute__((vector_size(16)));
 typedef float fbbev_v2f __attribute__((vector_size(8)));
 template <int ST> inline void fbbev_store4(float* p, fbbev_v4f v) { memcpy(p, &v, 16); }
 inline void fbbev_atomic_add_f32(float* p, float v) { *p += v; }
-
 // emulation of v_mfma_f32_16x16x4_f32 with the documented fragment layouts (see csrc/hip_rt/rt.h); every lane of the
 // wave must call it (wave-uniform control flow, as on the hardware)
 inline fbbev_v4f fbbev_mfma_f32_16x16x4(float a, float b, fbbev_v4f c) {

@@ -560,3 +560,67 @@ def test_msda_fwd_fused_equals_unfused_emulated(B, Q, M, Dh, shapes, P):
     vp = torch.full((B, S_, M, HS), -3.0e4)
     vp[..., :Dh] = value
     assert torch.equal(E.msda_fwd_fused(vp, ss, ls, ref, so, w, head_dim=Dh), base)
+
+
+# ---------------------------------------------------------------- one-launch-per-pass sort: chunk shapes + look-back
+def _lift_vs_oracle(name, B, cache=None, cam=None):
+    cfg = S.CONFIGS[name]
+    vt = O.ViewTransformerOracle(cfg.grid_config, cfg.input_size, cfg.downsample)
+    cam = cam if cam is not None else S.camera_rig(cfg, B, seed=0, bda_aug=True)
+    xs = vt.frustum[0, 0, :, 0].contiguous(); ys = vt.frustum[0, :, 0, 1].contiguous(); ds = vt.frustum[:, 0, 0, 2].contiguous()
+    got = E.lift_rank_build(xs, ys, ds, cam, *_grid3(vt), frustum=vt.frustum.contiguous(), cache=cache)
+    coor = E.lidar_coor(xs, ys, ds, cam)                     # the contract pins bit-exactness at coor
+    erb, erd, erf, est, eln = vt.voxel_pooling_prepare_v2(coor)
+    return got, (erb, erd, erf, est, eln)
+
+
+def _assert_index_equal(got, exp):
+    rb, rd, rf, st, ln, ir, counts = got
+    erb, erd, erf, est, eln = exp
+    P, I = counts.tolist()
+    assert (P, I) == (erb.numel(), est.numel())
+    assert torch.equal(rb[:P], erb) and torch.equal(rd[:P], erd) and torch.equal(rf[:P], erf)
+    assert torch.equal(st[:I], est) and torch.equal(ln[:I], eln) and torch.equal(ir[:I], erb[est.long()])
+
+
+@pytest.mark.parametrize('shape', ['0,0,0', '1,0,1', '2,1,2', '3,2,1', '4,3,2', '0,4,0'])
+def test_rank_build_every_chunk_variant_emulated(shape, monkeypatch):
+    """Every chunk shape of the sort / interval kernels (thin 256-thread chunks up to 16 waves x 16 rounds) on the SAME
+    input: the index tensors do not depend on the shape (FBBEV_RANK_SHAPE = the launcher's tuning knob) and equal the
+    oracle.  SMALL B=2 (61 k points): several chunks per pass for the thin shapes, partial chunks for the fat ones."""
+    monkeypatch.setenv('FBBEV_RANK_SHAPE', shape)
+    got, exp = _lift_vs_oracle('SMALL', 2)
+    _assert_index_equal(got, exp)
+
+
+def test_rank_build_fat_chunks_at_bench_scale_emulated():
+    """n = 0.75 M points (BL2, 3 samples): the launcher itself picks 16-wave chunks for pass 0 and the 1024-thread interval
+    kernels -- many full chunks per pass, bit-exact against the oracle on the emulator."""
+    got, exp = _lift_vs_oracle('BL2', 3)
+    _assert_index_equal(got, exp)
+
+
+def test_camera_keyed_cache_skips_and_rebuilds_emulated():
+    """same rig -> the build is skipped on the device (state[1] counts builds), a changed bda -> rebuild,
+    bit-exact with a fresh build; the skip leaves the previous index set untouched."""
+    cfg = S.CONFIGS['TINY']
+    cache = {}
+    cam = S.camera_rig(cfg, 2, seed=0, bda_aug=True)
+    got, exp = _lift_vs_oracle('TINY', 2, cache=cache, cam=cam)
+    _assert_index_equal(got, exp)
+    assert cache['state'].tolist() == [0, 1]
+    snap = [t.clone() for t in got]
+    got2, _ = _lift_vs_oracle('TINY', 2, cache=cache, cam=[t.clone() for t in cam])
+    assert cache['state'].tolist() == [1, 1]                 # skipped: nothing ran
+    assert all(torch.equal(a, b) for a, b in zip(got2, snap))
+    cam2 = [t.clone() for t in cam]
+    cam2[5][1] = cam2[5][1] @ torch.tensor([[0., -1., 0.], [1., 0., 0.], [0., 0., 1.]])     # rotate sample 1's bda
+    got3, exp3 = _lift_vs_oracle('TINY', 2, cache=cache, cam=cam2)
+    assert cache['state'].tolist() == [0, 2]
+    _assert_index_equal(got3, exp3)
+    assert not torch.equal(got3[0][:got3[6][0]], snap[0][:got3[6][0]]) or got3[6].tolist() != snap[6].tolist()
+    cam3 = [t.clone() for t in cam2]
+    cam3[4][0, 3, 1] += 1.0                                   # one post_trans element of one camera
+    got4, exp4 = _lift_vs_oracle('TINY', 2, cache=cache, cam=cam3)
+    assert cache['state'].tolist() == [0, 3]
+    _assert_index_equal(got4, exp4)

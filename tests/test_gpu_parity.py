@@ -228,7 +228,7 @@ def test_dense_forward_equals_rows_path(dev, name, B, aug, tv, flags):
     cc = cfg.channels // cs if cfg.channels % (4 * cs) == 0 else cfg.channels
     if (cc * (tv + 4) + 3 * tv + 1024) * 4 > 160 * 1024:
         pytest.skip('tile does not fit the 160 KiB LDS for this channel count (FBBEV_E_UNSUPPORTED by contract)')
-    ws = vt._tile_ws(dev, B)
+    ws = vt._tile_ws(dev, B, tv)
     _capi.pool_tile_index(idx.interval_rank, idx.interval_starts, idx.counts, idx.n, B, Z, Y, X, ws, tv)
     _capi.bev_pool_v2_dense_fwd(depth.to(dev), feat, idx.ranks_depth, idx.ranks_feat, idx.interval_rank,
                                 idx.interval_starts, idx.interval_lengths, B, cfg.channels, Z, Y, X, out, ws, tv,
@@ -483,20 +483,81 @@ def test_fused_forward_is_hip_graph_capturable(dev):
         assert not torch.equal(eager0, eager1)
 
 
-def test_accelerate_caches_indices(dev):
-    """accelerate=True (view_transformer.py:607-643, disabled by `assert False` at :628 in the reference):
-    the index tensors are built once for a constant rig and reused; results equal the per-call rebuild."""
+def test_accelerate_is_a_camera_keyed_cache(dev):
+    """accelerate=True (view_transformer.py:607-643, disabled by `assert False` at :628 in the reference because nothing
+    invalidates it): the index set is keyed on the camera tensors ON THE DEVICE.  Same rig -> the rank build is skipped
+    (no rebuild, no host sync); a changed bda / post_rots -> rebuilt, bit-exact with a per-call build."""
     cfg, ovt, cam, _, depth, ctx = _inputs('SMALL', 2, True, dev)
     cam_g = [t.to(dev) for t in cam]
     d, c = depth.to(dev), ctx.to(dev)
-    ref = _vt(cfg, dev)(cam_g, c, d)
+    plain = _vt(cfg, dev)
+    ref = plain(cam_g, c, d)
     vt = _vt(cfg, dev, accelerate=True)
-    a = vt(cam_g, c, d)
-    idx_first = vt._index_cache
-    b = vt(cam_g, 2.0 * c, d)
-    assert vt._index_cache is idx_first and not vt.initial_flag          # no rebuild on the second call
-    assert torch.equal(a, ref) and torch.equal(b, 2.0 * ref)
-    assert vt.ranks_bev.dtype == torch.int32 and vt.interval_starts.numel() == int(idx_first.counts[1])
+    with torch.no_grad():
+        a = vt(cam_g, c, d)
+        assert vt.index_builds() == 1
+        torch.cuda.set_sync_debug_mode('error')                 # the cached call path has no host sync
+        try:
+            b = vt([t.clone() for t in cam_g], 2.0 * c, d)      # equal VALUES in other buffers: still a hit
+        finally:
+            torch.cuda.set_sync_debug_mode('default')
+        assert vt.index_builds() == 1                           # no rebuild on the second call
+        assert torch.equal(a, ref) and torch.equal(b, 2.0 * ref)
+        cam2 = [t.clone() for t in cam_g]
+        rz = torch.tensor([[0., -1., 0.], [1., 0., 0.], [0., 0., 1.]], device=dev)
+        cam2[5][1] = cam2[5][1] @ rz                            # another BEV augmentation for sample 1
+        e = vt(cam2, c, d)
+        assert vt.index_builds() == 2
+        assert torch.equal(e, plain(cam2, c, d)) and not torch.equal(e, a)
+        cam3 = [t.clone() for t in cam2]
+        cam3[3][0, 2] = cam3[3][0, 2] * 1.1                     # image-space augmentation of one camera (post_rots)
+        f = vt(cam3, c, d)
+        assert vt.index_builds() == 3 and torch.equal(f, plain(cam3, c, d))
+        g = vt(cam3, c, d)
+        assert vt.index_builds() == 3 and torch.equal(g, f)
+        # write-once route (FBViewTransform) shares the cache
+        parts = vt.pooling_inputs(cam3, c, d)
+        assert vt.index_builds() == 3
+        assert torch.equal(vt.pooled_volume(parts), f)
+    # under autograd the persistent buffers are not used (an earlier graph must keep its own index set)
+    dg = d.clone().requires_grad_()
+    h = vt(cam_g, c, dg)
+    assert vt.index_builds() == 3 and torch.equal(h.detach(), ref)
+    h.sum().backward()
+    assert dg.grad is not None
+    # reference-API attributes
+    vt.pre_compute(cam_g)
+    assert vt.ranks_bev.dtype == torch.int32 and vt.interval_starts.numel() > 0 and not vt.initial_flag
+
+
+def test_cached_index_build_is_graph_capturable(dev):
+    """The camera-key compare + early-out chain contains no host decision: captured once, replayed with the same rig
+    (skip) and with a new rig written into the captured input buffers (rebuild)."""
+    cfg, ovt, cam, _, depth, ctx = _inputs('SMALL', 1, True, dev)
+    vt = _vt(cfg, dev, accelerate=True)
+    plain = _vt(cfg, dev)
+    cam_g = [t.to(dev).clone() for t in cam]
+    d, c = depth.to(dev), ctx.to(dev)
+    with torch.no_grad():
+        vt(cam_g, c, d)                                         # warm-up: allocations + first build
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            vt(cam_g, c, d)
+        torch.cuda.current_stream().wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = vt(cam_g, c, d)
+        g.replay()
+        assert torch.equal(out, plain(cam_g, c, d))
+        builds = vt.index_builds()
+        new = [t.clone() for t in cam_g]
+        new[5][0] = new[5][0] @ torch.tensor([[0., -1., 0.], [1., 0., 0.], [0., 0., 1.]], device=dev)
+        for dst, src in zip(cam_g, new):
+            dst.copy_(src)
+        g.replay()
+        assert vt.index_builds() == builds + 1
+        assert torch.equal(out, plain(cam_g, c, d))
 
 
 def test_dense_forward_stress_grid_bl5(dev):

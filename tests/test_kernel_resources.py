@@ -41,8 +41,11 @@ BUDGETS = {
     r'k_pool_zmean': 72,
     r'k_pool_bwd_pixel': 96,
     r'k_pool_bwd_rows': 32,
-    r'k_sort_scatter|k_sort_hist(?!_geom)|k_rank_keys': 64,
-    r'k_sort_hist_geom': 80,
+    r'k_sort_scatterILi4E': 64,           # thin chunks: 8 waves / SIMD
+    r'k_sort_scatterILi16E': 128,         # 1024-thread workgroups (4 waves / SIMD is one workgroup: 128 registers each)
+    r'k_sort_hist': 64,
+    r'k_interval_write': 80,
+    r'k_keys_hist_geom': 128,
     r'k_da_cross_attn_fwd_unitILi10E': 136,    # the shipped head dim: 3 waves / SIMD
     r'k_da_cross_attn_bwd': 128,
     r'k_history_warp': 168,
