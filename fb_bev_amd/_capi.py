@@ -44,8 +44,10 @@ SIGNATURES = {
                                     [c_void_p] * 3 + [c_size_t, c_void_p]),
     'fbbev_history_flow': (c_int, [c_void_p] * 5 + [c_int, c_void_p, c_void_p]),
     'fbbev_history_warp': (c_int, [c_void_p, c_int64, c_void_p] + [c_int] * 5 + [c_void_p, c_int64, c_void_p]),
+    'fbbev_history_warp_e': (c_int, [c_void_p, c_int64, c_void_p] + [c_int] * 5 + [c_void_p, c_int64, c_int, c_void_p]),
     'fbbev_layernorm': (c_int, [c_void_p] * 4 + [c_float, c_int64, c_int, c_void_p, c_void_p]),
     'fbbev_history_conv': (c_int, [c_void_p, c_int64] + [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t, c_void_p]),
+    'fbbev_history_conv_e': (c_int, [c_void_p, c_int64] + [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     'fbbev_conv3d_ndhwc': (c_int, [c_void_p] * 4 + [c_int] * 14 + [c_void_p, c_void_p]),
     'fbbev_conv2d_nhwc': (c_int, [c_void_p] * 4 + [c_int] * 11 + [c_void_p, c_void_p]),
     'fbbev_conv3d_ndhwc_bf16': (c_int, [c_void_p] * 4 + [c_int] * 15 + [c_void_p, c_void_p]),
@@ -464,19 +466,25 @@ def history_flow(history_forward_augs, curr_to_prev_ego_rt, bda, dx3, lower3):
     return flow
 
 
+ELEM_TYPE = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}       # FBBEV_ELEM_*: storage element of the history ring
+
+
 def history_warp(history, rt_flow, out):
-    """history, out: (B,CH,Z,Y,X) f32 whose per-sample (CH,Z,Y,X) block is contiguous (batch stride free)."""
+    """history, out: (B,CH,Z,Y,X) f32 / bf16 / f16 (the same type) whose per-sample (CH,Z,Y,X) block is contiguous (batch
+    stride free).  16-bit storage: fp32 taps math, rounded once at the store."""
     B, CH, Z, Y, X = history.shape
     if tuple(out.shape) != (B, CH, Z, Y, X):
         raise FbbevError('out must have the shape of history')
+    if history.dtype not in ELEM_TYPE or out.dtype != history.dtype:
+        raise FbbevError('history / out must both be f32, bf16 or f16')
     for t, n in ((history, 'history'), (out, 'out')):
         if t.stride()[1:] != (Z * Y * X, Y * X, X, 1):
             raise FbbevError(f'{n}: the (CH,Z,Y,X) block of a sample must be contiguous')
     with _on(history):
-        _check(lib().fbbev_history_warp(_dev(history, F32, 'history', contiguous=False), history.stride(0),
-                                        _dev(rt_flow, F32, 'rt_flow'), B, CH, Z, Y, X,
-                                        _dev(out, F32, 'out', contiguous=False), out.stride(0), _stream()),
-               'fbbev_history_warp')
+        _check(lib().fbbev_history_warp_e(_dev(history, history.dtype, 'history', contiguous=False), history.stride(0),
+                                          _dev(rt_flow, F32, 'rt_flow'), B, CH, Z, Y, X,
+                                          _dev(out, out.dtype, 'out', contiguous=False), out.stride(0),
+                                          ELEM_TYPE[history.dtype], _stream()), 'fbbev_history_warp_e')
     return out
 
 
@@ -607,18 +615,18 @@ def blend_levels_ndhwc(level0, coarse, wsoft, out):
 
 
 def history_conv(feats, w1, bias1, w2, bias2, out):
-    """feats (B, T1*C, N) f32 whose per-sample block is contiguous; w1 (C,C); bias1 (B*T1, C); w2 (Cout, T1*C);
-    bias2 (Cout); out (B, Cout, N) contiguous -> out = relu(bias2 + sum_t w2_t . relu(w1 . x_t + bias1_t))."""
+    """feats (B, T1*C, N) f32 / bf16 / f16 whose per-sample block is contiguous; w1 (C,C); bias1 (B*T1, C); w2 (Cout, T1*C);
+    bias2 (Cout); out (B, Cout, N) f32 contiguous -> out = relu(bias2 + sum_t w2_t . relu(w1 . x_t + bias1_t))."""
     B, TC, N = feats.shape
     C = w1.shape[0]
     T1 = TC // C
     Cout = w2.shape[0]
-    if feats.stride()[1:] != (N, 1) or tuple(out.shape) != (B, Cout, N):
+    if feats.stride()[1:] != (N, 1) or tuple(out.shape) != (B, Cout, N) or feats.dtype not in ELEM_TYPE:
         raise FbbevError('history_conv: bad feats / out layout')
     ws = torch.empty((1 + T1) * C * max(C, Cout), dtype=torch.float32, device=feats.device)   # fragment-ordered weights
     with _on(feats):
-        _check(lib().fbbev_history_conv(_dev(feats, F32, 'feats', contiguous=False), feats.stride(0), _dev(w1, F32, 'w1'),
-                                        _dev(bias1, F32, 'bias1'), _dev(w2, F32, 'w2'), _dev(bias2, F32, 'bias2'),
-                                        B, T1, C, Cout, N, _dev(out, F32, 'out'), c_void_p(ws.data_ptr()),
-                                        ws.numel() * 4, _stream()), 'fbbev_history_conv')
+        _check(lib().fbbev_history_conv_e(_dev(feats, feats.dtype, 'feats', contiguous=False), feats.stride(0), _dev(w1, F32, 'w1'),
+                                          _dev(bias1, F32, 'bias1'), _dev(w2, F32, 'w2'), _dev(bias2, F32, 'bias2'),
+                                          B, T1, C, Cout, N, _dev(out, F32, 'out'), c_void_p(ws.data_ptr()),
+                                          ws.numel() * 4, ELEM_TYPE[feats.dtype], _stream()), 'fbbev_history_conv_e')
     return out

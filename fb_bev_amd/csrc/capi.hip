@@ -948,9 +948,11 @@ extern "C" int fbbev_history_flow(const float* history_forward_augs, const float
     return 0;
 }
 
-extern "C" int fbbev_history_warp(const float* history, long long history_stride_b, const float* rt_flow, int B, int CH,
-                                  int Z, int Y, int X, float* out, long long out_stride_b, fbbev_stream_t stream_) {
+extern "C" int fbbev_history_warp_e(const void* history, long long history_stride_b, const float* rt_flow, int B, int CH,
+                                    int Z, int Y, int X, void* out, long long out_stride_b, int elem_type,
+                                    fbbev_stream_t stream_) {
     if (B < 0 || CH < 0 || Z < 2 || Y < 2 || X < 2) return FBBEV_E_BADARG;      // size-1 axes divide by zero in :208
+    if (elem_type < 0 || elem_type > 2) return FBBEV_E_BADARG;
     if (B == 0 || CH == 0) return 0;
     if (!history || !rt_flow || !out) return FBBEV_E_BADARG;
     const long long zyx = (long long)Z * Y * X;
@@ -966,10 +968,23 @@ extern "C" int fbbev_history_warp(const float* history, long long history_stride
     const long long blocks = (long long)B * n_groups * n_chunks;
     if (blocks >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
     const int per_xcd = (int)((blocks + 7) / 8);
-    FBBEV_LAUNCH(k_history_warp, (long long)per_xcd * 8, 256, 0, (fbbev_rt_stream)stream_, history, history_stride_b, rt_flow,
-                 CH, Z, Y, X, cpb, n_groups, n_chunks, per_xcd, (int)blocks, out, out_stride_b);
+    fbbev_rt_stream stream = (fbbev_rt_stream)stream_;
+    if (elem_type == 0)
+        FBBEV_LAUNCH(k_history_warp<0>, (long long)per_xcd * 8, 256, 0, stream, history, history_stride_b, rt_flow,
+                     CH, Z, Y, X, cpb, n_groups, n_chunks, per_xcd, (int)blocks, out, out_stride_b);
+    else if (elem_type == 1)
+        FBBEV_LAUNCH(k_history_warp<1>, (long long)per_xcd * 8, 256, 0, stream, history, history_stride_b, rt_flow,
+                     CH, Z, Y, X, cpb, n_groups, n_chunks, per_xcd, (int)blocks, out, out_stride_b);
+    else
+        FBBEV_LAUNCH(k_history_warp<2>, (long long)per_xcd * 8, 256, 0, stream, history, history_stride_b, rt_flow,
+                     CH, Z, Y, X, cpb, n_groups, n_chunks, per_xcd, (int)blocks, out, out_stride_b);
     FBBEV_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int fbbev_history_warp(const float* history, long long history_stride_b, const float* rt_flow, int B, int CH,
+                                  int Z, int Y, int X, float* out, long long out_stride_b, fbbev_stream_t stream_) {
+    return fbbev_history_warp_e(history, history_stride_b, rt_flow, B, CH, Z, Y, X, out, out_stride_b, 0, stream_);
 }
 
 // ------------------------------------------------------------------------------ LayerNorm over short rows
@@ -987,16 +1002,10 @@ extern "C" int fbbev_layernorm(const float* x, const float* residual, const floa
     return 0;
 }
 
-extern "C" int fbbev_history_conv(const float* feats, long long feats_stride_b, const float* w1, const float* bias1,
-                                  const float* w2, const float* bias2, int B, int T1, int C, int Cout, int N,
-                                  float* out, void* workspace, size_t workspace_bytes, fbbev_stream_t stream_) {
-    if (B < 0 || T1 <= 0 || C <= 0 || Cout <= 0 || N < 0) return FBBEV_E_BADARG;
-    if (B == 0 || N == 0) return 0;
-    if (!feats || !w1 || !bias1 || !w2 || !bias2 || !out) return FBBEV_E_BADARG;
-    if (C % 16 != 0 || Cout % 16 != 0 || C > 16 * FBBEV_HC_MAX_TILES || Cout > 16 * FBBEV_HC_MAX_TILES)
-        return FBBEV_E_UNSUPPORTED;
-    if (feats_stride_b == 0) feats_stride_b = (long long)T1 * C * N;
-    if (feats_stride_b < (long long)T1 * C * N) return FBBEV_E_BADARG;
+template <int ET>
+static int history_conv_launch(const void* feats, long long feats_stride_b, const float* w1, const float* bias1,
+                               const float* w2, const float* bias2, int B, int T1, int C, int Cout, int N,
+                               float* out, void* workspace, size_t workspace_bytes, fbbev_rt_stream stream) {
     const int tiles_per_b = (N + 63) / 64;
     const long long blocks = (long long)B * tiles_per_b;
     if (blocks >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
@@ -1009,19 +1018,42 @@ extern "C" int fbbev_history_conv(const float* feats, long long feats_stride_b, 
         float* w1f = static_cast<float*>(workspace);
         float* w2f = w1f + (size_t)MT1 * KS * 64;
         const int nfrag = (MT1 * KS + T1 * MT2 * KS) * 64;
-        FBBEV_LAUNCH(k_history_weight_fragments, (nfrag + 255) / 256, 256, 0, (fbbev_rt_stream)stream_, w1, w2, MT1, MT2, KS,
-                     T1, w1f);
+        FBBEV_LAUNCH(k_history_weight_fragments, (nfrag + 255) / 256, 256, 0, stream, w1, w2, MT1, MT2, KS, T1, w1f);
         if (C == 80)
-            FBBEV_LAUNCH((k_history_conv_t<5, 5>), blocks, 256, lds, (fbbev_rt_stream)stream_, feats, feats_stride_b,
+            FBBEV_LAUNCH((k_history_conv_t<5, 5, ET>), blocks, 256, lds, stream, feats, feats_stride_b,
                          (const float*)w1f, bias1, (const float*)w2f, bias2, T1, N, tiles_per_b, out);
         else
-            FBBEV_LAUNCH((k_history_conv_t<1, 1>), blocks, 256, lds, (fbbev_rt_stream)stream_, feats, feats_stride_b,
+            FBBEV_LAUNCH((k_history_conv_t<1, 1, ET>), blocks, 256, lds, stream, feats, feats_stride_b,
                          (const float*)w1f, bias1, (const float*)w2f, bias2, T1, N, tiles_per_b, out);
     } else
-        FBBEV_LAUNCH(k_history_conv, blocks, 256, lds, (fbbev_rt_stream)stream_, feats, feats_stride_b, w1, bias1, w2, bias2,
+        FBBEV_LAUNCH(k_history_conv<ET>, blocks, 256, lds, stream, feats, feats_stride_b, w1, bias1, w2, bias2,
                      T1, C, Cout, N, tiles_per_b, out);
     FBBEV_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int fbbev_history_conv_e(const void* feats, long long feats_stride_b, const float* w1, const float* bias1,
+                                    const float* w2, const float* bias2, int B, int T1, int C, int Cout, int N,
+                                    float* out, void* workspace, size_t workspace_bytes, int elem_type,
+                                    fbbev_stream_t stream_) {
+    if (B < 0 || T1 <= 0 || C <= 0 || Cout <= 0 || N < 0 || elem_type < 0 || elem_type > 2) return FBBEV_E_BADARG;
+    if (B == 0 || N == 0) return 0;
+    if (!feats || !w1 || !bias1 || !w2 || !bias2 || !out) return FBBEV_E_BADARG;
+    if (C % 16 != 0 || Cout % 16 != 0 || C > 16 * FBBEV_HC_MAX_TILES || Cout > 16 * FBBEV_HC_MAX_TILES)
+        return FBBEV_E_UNSUPPORTED;
+    if (feats_stride_b == 0) feats_stride_b = (long long)T1 * C * N;
+    if (feats_stride_b < (long long)T1 * C * N) return FBBEV_E_BADARG;
+    fbbev_rt_stream stream = (fbbev_rt_stream)stream_;
+    if (elem_type == 0) return history_conv_launch<0>(feats, feats_stride_b, w1, bias1, w2, bias2, B, T1, C, Cout, N, out, workspace, workspace_bytes, stream);
+    if (elem_type == 1) return history_conv_launch<1>(feats, feats_stride_b, w1, bias1, w2, bias2, B, T1, C, Cout, N, out, workspace, workspace_bytes, stream);
+    return history_conv_launch<2>(feats, feats_stride_b, w1, bias1, w2, bias2, B, T1, C, Cout, N, out, workspace, workspace_bytes, stream);
+}
+
+extern "C" int fbbev_history_conv(const float* feats, long long feats_stride_b, const float* w1, const float* bias1,
+                                  const float* w2, const float* bias2, int B, int T1, int C, int Cout, int N,
+                                  float* out, void* workspace, size_t workspace_bytes, fbbev_stream_t stream_) {
+    return fbbev_history_conv_e(feats, feats_stride_b, w1, bias1, w2, bias2, B, T1, C, Cout, N, out, workspace,
+                                workspace_bytes, 0, stream_);
 }
 
 static int conv3d_launch(const float* x, const float* weight_fragments, const float* bias, const float* residual, int B,

@@ -21,12 +21,14 @@
 // Bound: fp32 MFMA (64 FLOP/clk/SIMD); HBM traffic = the (T+1)*C-channel volume read once + the output written once.
 #pragma once
 #include "rt.h"
+#include "history_kernels.h"    // fbbev_ld_elem: 16-bit storage of the frame buffer (widened exactly, fp32 MFMA as before)
 
 #define FBBEV_HC_MAX_TILES 8      // C, Cout <= 128 (M-tiles of 16)
 
 // feats (B, T1*C, N) with batch stride fstride_b; w1 (C,C); bias1 (B*T1, C); w2 (Cout, T1*C); bias2 (Cout); out (B,Cout,N)
+template <int ET>
 __global__ void __launch_bounds__(256)
-k_history_conv(const float* __restrict__ feats, long long fstride_b, const float* __restrict__ w1,
+k_history_conv(const void* __restrict__ feats, long long fstride_b, const float* __restrict__ w1,
                const float* __restrict__ bias1, const float* __restrict__ w2, const float* __restrict__ bias2,
                int T1, int C, int Cout, int N, int tiles_per_b, float* __restrict__ out) {
     float* lds = fbbev_dyn_lds_f32();                      // [4 waves][C][16]
@@ -37,7 +39,7 @@ k_history_conv(const float* __restrict__ feats, long long fstride_b, const float
     const bool inb = n < N;
     const int MT1 = C >> 4, MT2 = Cout >> 4, KS = C >> 2;
     float* ylds = lds + wave * C * 16;
-    const float* xb = feats + (long long)b * fstride_b;
+    const long long xb = (long long)b * fstride_b;        // element offset of this sample's frames
     fbbev_v4f acc2[FBBEV_HC_MAX_TILES];
 #pragma unroll
     for (int mt = 0; mt < FBBEV_HC_MAX_TILES; ++mt) {
@@ -46,7 +48,7 @@ k_history_conv(const float* __restrict__ feats, long long fstride_b, const float
             for (int r = 0; r < 4; ++r) acc2[mt][r] = bias2[16 * mt + 4 * g + r];
     }
     for (int t = 0; t < T1; ++t) {
-        const float* xt = xb + (long long)t * C * N;
+        const long long xt = xb + (long long)t * C * N;
         const float* b1 = bias1 + ((long long)b * T1 + t) * C;
         fbbev_v4f acc1[FBBEV_HC_MAX_TILES];
 #pragma unroll
@@ -56,7 +58,7 @@ k_history_conv(const float* __restrict__ feats, long long fstride_b, const float
                 for (int r = 0; r < 4; ++r) acc1[mt][r] = b1[16 * mt + 4 * g + r];
         }
         for (int kk = 0; kk < KS; ++kk) {
-            const float bf = inb ? xt[(long long)(4 * kk + g) * N + n] : 0.f;
+            const float bf = inb ? fbbev_ld_elem<ET>(feats, xt + (long long)(4 * kk + g) * N + n) : 0.f;
 #pragma unroll
             for (int mt = 0; mt < FBBEV_HC_MAX_TILES; ++mt)
                 if (mt < MT1) acc1[mt] = fbbev_mfma_f32_16x16x4(w1[(16 * mt + j) * C + 4 * kk + g], bf, acc1[mt]);
@@ -94,9 +96,9 @@ k_history_conv(const float* __restrict__ feats, long long fstride_b, const float
 //   * the X fragments of frame t+1 are fetched while frame t's second GEMM runs (register double buffer).
 // (Streaming the W2 fragments instead of the per-frame burst, to fit two waves per SIMD, measured 1.9x SLOWER on the
 // same box -- 1.77 vs 0.94 ms for the whole fusion step -- and was dropped.)
-template <int MT1, int MT2>
+template <int MT1, int MT2, int ET>
 __global__ void __launch_bounds__(256)
-k_history_conv_t(const float* __restrict__ feats, long long fstride_b, const float* __restrict__ w1f,
+k_history_conv_t(const void* __restrict__ feats, long long fstride_b, const float* __restrict__ w1f,
                  const float* __restrict__ bias1, const float* __restrict__ w2f, const float* __restrict__ bias2,
                  int T1, int N, int tiles_per_b, float* __restrict__ out) {
     constexpr int C = 16 * MT1, Cout = 16 * MT2, KS = C / 4;
@@ -107,7 +109,7 @@ k_history_conv_t(const float* __restrict__ feats, long long fstride_b, const flo
     const int n = tile * 64 + wave * 16 + j;
     const bool inb = n < N;
     float* ylds = lds + wave * C * 16;
-    const float* xb = feats + (long long)b * fstride_b;
+    const long long xb = (long long)b * fstride_b;        // element offset of this sample's frames
     float a1[MT1][KS];
 #pragma unroll
     for (int mt = 0; mt < MT1; ++mt)
@@ -120,7 +122,7 @@ k_history_conv_t(const float* __restrict__ feats, long long fstride_b, const flo
         for (int r = 0; r < 4; ++r) acc2[mt][r] = bias2[16 * mt + 4 * g + r];
     float bx[KS];
 #pragma unroll
-    for (int kk = 0; kk < KS; ++kk) bx[kk] = inb ? xb[(long long)(4 * kk + g) * N + n] : 0.f;
+    for (int kk = 0; kk < KS; ++kk) bx[kk] = inb ? fbbev_ld_elem<ET>(feats, xb + (long long)(4 * kk + g) * N + n) : 0.f;
     for (int t = 0; t < T1; ++t) {
         const float* b1 = bias1 + ((long long)b * T1 + t) * C;
         const float* w2t = w2f + (long long)t * MT2 * KS * 64;
@@ -139,9 +141,9 @@ k_history_conv_t(const float* __restrict__ feats, long long fstride_b, const flo
 #pragma unroll
             for (int mt = 0; mt < MT1; ++mt) acc1[mt] = fbbev_mfma_f32_16x16x4(a1[mt][kk], bx[kk], acc1[mt]);
         if (t + 1 < T1) {                                   // next frame's X fragments: in flight during GEMM 2
-            const float* xn = xb + (long long)(t + 1) * C * N;
+            const long long xn = xb + (long long)(t + 1) * C * N;
 #pragma unroll
-            for (int kk = 0; kk < KS; ++kk) bx[kk] = inb ? xn[(long long)(4 * kk + g) * N + n] : 0.f;
+            for (int kk = 0; kk < KS; ++kk) bx[kk] = inb ? fbbev_ld_elem<ET>(feats, xn + (long long)(4 * kk + g) * N + n) : 0.f;
         }
         fbbev_wave_sync();                                  // ylds is wave-private: no workgroup barrier
 #pragma unroll

@@ -19,6 +19,40 @@
 #pragma once
 #include "rt.h"
 #include "geom_kernels.h"
+#include "pool_kernels.h"      // fbbev_f32_to_f16: the integer-only binary32 -> binary16 rounding (same bits on the emulator)
+
+// Storage element of the history ring: ET 0 = f32, 1 = bf16, 2 = f16 (BASELINE configs[4] names fp16).  All arithmetic is
+// fp32: elements are widened exactly at the load and rounded ONCE (nearest-even) at the store.
+__device__ __forceinline__ float fbbev_f16_bits_to_f32(unsigned int h) {
+    const unsigned int sign = (h & 0x8000u) << 16;
+    unsigned int e = (h >> 10) & 0x1fu, m = h & 0x3ffu, u;
+    if (e == 0) {
+        if (m == 0) u = sign;
+        else {                                              // subnormal half: normalise
+            int sh = 0;
+            while (!(m & 0x400u)) { m <<= 1; ++sh; }
+            u = sign | ((unsigned int)(113 - sh) << 23) | ((m & 0x3ffu) << 13);
+        }
+    } else if (e == 31) u = sign | 0x7f800000u | (m << 13);
+    else u = sign | ((e + 112u) << 23) | (m << 13);
+    float f;
+    __builtin_memcpy(&f, &u, 4);
+    return f;
+}
+template <int ET>
+__device__ __forceinline__ float fbbev_ld_elem(const void* base, long long i) {
+    if constexpr (ET == 0) return static_cast<const float*>(base)[i];
+    else {
+        const unsigned int h = static_cast<const unsigned short*>(base)[i];
+        if constexpr (ET == 1) { const unsigned int u = h << 16; float f; __builtin_memcpy(&f, &u, 4); return f; }
+        else return fbbev_f16_bits_to_f32(h);
+    }
+}
+template <int ET>
+__device__ __forceinline__ void fbbev_st_elem(void* base, long long i, float v) {
+    if constexpr (ET == 0) static_cast<float*>(base)[i] = v;
+    else static_cast<unsigned short*>(base)[i] = (unsigned short)(fbbev_pack2<ET>(v, 0.f) & 0xffffu);
+}
 
 __device__ __forceinline__ void fbbev_mat4(const float* a, const float* b, float* o) {
     for (int r = 0; r < 4; ++r)
@@ -50,10 +84,11 @@ k_history_flow(const float* __restrict__ hist_augs, const float* __restrict__ eg
 }
 
 // work item = ((b * n_groups) + group) * n_chunks + chunk
+template <int ET>
 __global__ void __launch_bounds__(256)
-k_history_warp(const float* __restrict__ hist, long long hist_stride_b, const float* __restrict__ flow, int CH,
+k_history_warp(const void* __restrict__ hist, long long hist_stride_b, const float* __restrict__ flow, int CH,
                int Z, int Y, int X, int ch_per_block, int n_groups, int n_chunks, int per_xcd, int n_work,
-               float* __restrict__ out, long long out_stride_b) {
+               void* __restrict__ out, long long out_stride_b) {
     // workgroup b runs on XCD b%8: give each XCD one contiguous eighth of the (sample, channel group, chunk) space so
     // that the y-neighbour taps of adjacent chunks are re-used from that XCD's own L2
     const int work = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
@@ -95,8 +130,9 @@ k_history_warp(const float* __restrict__ hist, long long hist_stride_b, const fl
     }
     const int c0 = grp * ch_per_block;
     const int c1 = (c0 + ch_per_block < CH) ? c0 + ch_per_block : CH;
-    const float* __restrict__ src = hist + (long long)b * hist_stride_b + (long long)c0 * ZYX;
-    float* __restrict__ dst = out + (long long)b * out_stride_b + (long long)c0 * ZYX + v;
+    // element offsets of this workgroup's first channel (16-bit storage: the same offsets, half the bytes)
+    long long so = (long long)b * hist_stride_b + (long long)c0 * ZYX;
+    long long dof = (long long)b * out_stride_b + (long long)c0 * ZYX + v;
     int c = c0;
     constexpr int U = 4;                           // channels in flight per thread: 8*U independent gathers
     for (; c + U <= c1; c += U) {
@@ -104,29 +140,23 @@ k_history_warp(const float* __restrict__ hist, long long hist_stride_b, const fl
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int k = 0; k < 8; ++k) a[u][k] = src[(long long)u * ZYX + off[k]];
+            for (int k = 0; k < 8; ++k) a[u][k] = fbbev_ld_elem<ET>(hist, so + (long long)u * ZYX + off[k]);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             float s0 = 0.f;
 #pragma unroll
             for (int k = 0; k < 8; ++k) s0 = fmaf(a[u][k], w[k], s0);
-            dst[(long long)u * ZYX] = s0;
+            fbbev_st_elem<ET>(out, dof + (long long)u * ZYX, s0);
         }
-        src += U * (long long)ZYX;
-        dst += U * (long long)ZYX;
+        so += U * (long long)ZYX;
+        dof += U * (long long)ZYX;
     }
-    for (; c + 1 < c1; ++c) {
+    for (; c < c1; ++c) {
         float s0 = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) s0 = fmaf(src[off[k]], w[k], s0);
-        dst[0] = s0;
-        src += ZYX;
-        dst += ZYX;
-    }
-    if (c < c1) {
-        float s0 = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) s0 = fmaf(src[off[k]], w[k], s0);
-        dst[0] = s0;
+        for (int k = 0; k < 8; ++k) s0 = fmaf(fbbev_ld_elem<ET>(hist, so + off[k]), w[k], s0);
+        fbbev_st_elem<ET>(out, dof, s0);
+        so += ZYX;
+        dof += ZYX;
     }
 }

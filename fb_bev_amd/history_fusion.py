@@ -28,7 +28,7 @@ from . import _capi
 
 class TemporalHistoryFusion(nn.Module):
     def __init__(self, dx, bx, single_bev_num_channels=80, history_cat_num=16, history_cat_conv_out_channels=None,
-                 do_history=True, interpolation_mode='bilinear', history_cam_sweep_freq=0.5):
+                 do_history=True, interpolation_mode='bilinear', history_cam_sweep_freq=0.5, history_dtype=torch.float32):
         super().__init__()
         if interpolation_mode != 'bilinear':
             raise NotImplementedError("only interpolation_mode='bilinear' (trilinear on the voxel grid) is built")
@@ -46,6 +46,11 @@ class TemporalHistoryFusion(nn.Module):
             nn.Conv3d(C * (T + 1), out_c, kernel_size=1, padding=0, stride=1), nn.SyncBatchNorm(out_c),
             nn.ReLU(inplace=True))
         self.use_mfma_convs = True          # inference: both 1x1x1 convs in one fp32-MFMA kernel when the channels allow
+        # Storage type of the inference history ring (T+1 frames per sample): float32 (the reference), or float16 / bfloat16
+        # -- BASELINE configs[4] names fp16; at 400x400x16 the ring is 13 GB per sample in fp32.  Sampling and the two
+        # convolutions stay fp32 (taps widened exactly, one nearest-even rounding when a frame is stored); the autograd
+        # path always keeps fp32.
+        self.history_dtype = history_dtype
         self.reset()
 
     def reset(self):
@@ -132,8 +137,9 @@ class TemporalHistoryFusion(nn.Module):
     def _frame_buffers(self, like, B, Z, Y, X):
         T, C = self.history_cat_num, self.single_bev_num_channels
         shape = (B, (T + 1) * C, Z, Y, X)
-        if self._bufs is None or tuple(self._bufs[0].shape) != shape or self._bufs[0].device != like.device:
-            self._bufs = [torch.empty(shape, dtype=torch.float32, device=like.device) for _ in range(2)]
+        if (self._bufs is None or tuple(self._bufs[0].shape) != shape or self._bufs[0].device != like.device
+                or self._bufs[0].dtype != self.history_dtype):
+            self._bufs = [torch.empty(shape, dtype=self.history_dtype, device=like.device) for _ in range(2)]
         return self._bufs
 
     def _new_history(self, curr, train_path):
@@ -150,7 +156,7 @@ class TemporalHistoryFusion(nn.Module):
         """The reference's op sequence (:264-310) on this module's layers; the warp is the HIP kernel."""
         T, C = self.history_cat_num, self.single_bev_num_channels
         B, _, Z, Y, X = curr.shape
-        hist = self.history_bev
+        hist = self.history_bev.float()                                # the autograd path is fp32 (the ring may be 16-bit)
         if hist.stride()[1:] != (Z * Y * X, Y * X, X, 1):
             hist = hist.contiguous()
         sampled = _capi.history_warp(hist, flow, torch.empty((B, T * C, Z, Y, X), dtype=torch.float32, device=curr.device))
@@ -185,7 +191,8 @@ class TemporalHistoryFusion(nn.Module):
             out = _capi.history_conv(nxt.view(B, (T + 1) * C, n), w1[:, :C].contiguous(), bias1.contiguous(), w2.contiguous(),
                                      b2.contiguous(), torch.empty((B, cout, n), dtype=torch.float32, device=curr.device))
         else:
-            y = torch.baddbmm(bias1.unsqueeze(-1), w1[:, :C].unsqueeze(0).expand(B * (T + 1), C, C), nxt.view(B * (T + 1), C, n))
+            y = torch.baddbmm(bias1.unsqueeze(-1), w1[:, :C].unsqueeze(0).expand(B * (T + 1), C, C),
+                              nxt.view(B * (T + 1), C, n).float())
             y.relu_()
             out = torch.baddbmm(b2.view(1, -1, 1), w2.unsqueeze(0).expand(B, *w2.shape), y.view(B, (T + 1) * C, n))
             out.relu_()

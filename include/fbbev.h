@@ -326,6 +326,15 @@ int fbbev_history_flow(const float* history_forward_augs, const float* curr_to_p
                        const float* dx3, const float* lower3, int B, float* rt_flow, fbbev_stream_t stream);
 int fbbev_history_warp(const float* history, long long history_stride_b, const float* rt_flow, int B, int CH, int Z,
                        int Y, int X, float* out, long long out_stride_b, fbbev_stream_t stream);
+/* The same with a storage element type for history AND out: elem_type 0 = f32, 1 = bf16, 2 = f16 (BASELINE configs[4]
+ * names fp16: the 16-frame history of a 400x400x16 grid is 13 GB per sample in fp32).  The taps are widened exactly,
+ * the trilinear sum is the same fp32 fmaf chain, the result is rounded ONCE (nearest-even) at the store; strides are in
+ * elements.  fbbev_history_conv_e reads a frame buffer of that element type (fp32 MFMA, fp32 output, as before). */
+#define FBBEV_ELEM_F32 0
+#define FBBEV_ELEM_BF16 1
+#define FBBEV_ELEM_F16 2
+int fbbev_history_warp_e(const void* history, long long history_stride_b, const float* rt_flow, int B, int CH, int Z,
+                         int Y, int X, void* out, long long out_stride_b, int elem_type, fbbev_stream_t stream);
 
 /* LayerNorm over the last dimension of (rows, C) f32, optional residual:  out = LN(x + residual) * weight + bias
  * (biased variance, eps inside the square root: torch.nn.LayerNorm = mmcv build_norm_layer('LN'), the `norm` steps of
@@ -346,6 +355,9 @@ int fbbev_layernorm(const float* x, const float* residual, const float* weight, 
 int fbbev_history_conv(const float* feats, long long feats_stride_b, const float* w1, const float* bias1,
                        const float* w2, const float* bias2, int B, int T1, int C, int Cout, int N, float* out,
                        void* workspace, size_t workspace_bytes, fbbev_stream_t stream);
+int fbbev_history_conv_e(const void* feats, long long feats_stride_b, const float* w1, const float* bias1,
+                         const float* w2, const float* bias2, int B, int T1, int C, int Cout, int N, float* out,
+                         void* workspace, size_t workspace_bytes, int elem_type, fbbev_stream_t stream);
 
 /* Dense 3-D convolution on NDHWC (torch channels_last_3d) f32 activations as an fp32-MFMA implicit GEMM, inference:
  * replaces the eval-mode Conv3d (+ folded BatchNorm) (+ residual) (+ ReLU) groups of CustomResNet3D (resnet3d.py:19-43,

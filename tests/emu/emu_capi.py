@@ -209,9 +209,11 @@ def history_flow(hist_augs, ego, bda, dx3, lower3):
 def history_warp(history, flow, out=None):
     B, CH, Z, Y, X = history.shape
     if out is None:
-        out = torch.full((B, CH, Z, Y, X), float('nan'))
-    ok(lib().fbbev_history_warp(c_void_p(history.data_ptr()), history.stride(0), p(flow), B, CH, Z, Y, X,
-                                c_void_p(out.data_ptr()), out.stride(0), None))
+        out = torch.full((B, CH, Z, Y, X), float('nan'), dtype=history.dtype)
+    et = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[history.dtype]
+    assert out.dtype == history.dtype
+    ok(lib().fbbev_history_warp_e(c_void_p(history.data_ptr()), history.stride(0), p(flow), B, CH, Z, Y, X,
+                                  c_void_p(out.data_ptr()), out.stride(0), et, None))
     return out
 
 
@@ -242,8 +244,9 @@ def history_conv(feats, w1, bias1, w2, bias2):
     C, Cout = w1.shape[0], w2.shape[0]
     out = torch.full((B, Cout, N), float('nan'))
     ws = torch.zeros((1 + TC // C) * C * max(C, Cout))
-    ok(lib().fbbev_history_conv(c_void_p(feats.data_ptr()), feats.stride(0), p(w1), p(bias1), p(w2), p(bias2), B, TC // C, C,
-                                Cout, N, p(out), p(ws), ws.numel() * 4, None))
+    et = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[feats.dtype]
+    ok(lib().fbbev_history_conv_e(c_void_p(feats.data_ptr()), feats.stride(0), p(w1), p(bias1), p(w2), p(bias2), B, TC // C, C,
+                                  Cout, N, p(out), p(ws), ws.numel() * 4, et, None))
     return out
 
 

@@ -624,3 +624,37 @@ def test_camera_keyed_cache_skips_and_rebuilds_emulated():
     got4, exp4 = _lift_vs_oracle('TINY', 2, cache=cache, cam=cam3)
     assert cache['state'].tolist() == [0, 3]
     _assert_index_equal(got4, exp4)
+
+
+# ---------------------------------------------------------------- 16-bit storage of the history ring (BASELINE configs[4])
+@pytest.mark.parametrize('dt', [torch.float16, torch.bfloat16])
+def test_history_warp_and_conv_16bit_storage_emulated(dt):
+    """fbbev_history_warp_e / fbbev_history_conv_e: the stored elements are widened exactly, the arithmetic is the fp32
+    kernel's, the warp result is rounded once (nearest-even) at the store -- i.e. bit-identical to the fp32 kernel run on
+    the widened input followed by torch's own fp32 -> 16-bit conversion."""
+    g = torch.Generator().manual_seed(9)
+    B, CH, Z, Y, X = 2, 10, 3, 8, 12
+    hist = (torch.randn(B, CH, Z, Y, X, generator=g) * 3).to(dt)
+    hist[0, 0, 0, 0, :4] = torch.tensor([0.0, -0.0, 6.0e-5, 65000.0]).to(dt)     # zero, signed zero, subnormal half, near max
+    flow = torch.eye(4)[None].repeat(B, 1, 1)
+    flow[0, :3, 3] = torch.tensor([1.25, -0.5, 0.25])
+    flow[1, :3, :3] = torch.tensor([[0.9, -0.4, 0.0], [0.4, 0.9, 0.0], [0.0, 0.0, 1.0]])
+    got = E.history_warp(hist, flow)
+    assert got.dtype == dt
+    exp32 = E.history_warp(hist.float(), flow)                                   # same kernel arithmetic on the widened taps
+    assert torch.equal(got.view(torch.int16), exp32.to(dt).view(torch.int16))
+    ident = E.history_warp(hist, torch.eye(4)[None].repeat(B, 1, 1).contiguous())
+    # identity flow: the stored bits survive (sample 1; sample 0 holds the 65000 next to small values, where the 1e-7
+    # residual tap weight of the reference's normalise / un-normalise round trip is visible in half precision)
+    assert torch.equal(ident[1].view(torch.int16), hist[1].view(torch.int16))
+    # convolution reading a 16-bit frame buffer == the fp32 kernel on the widened buffer, bit for bit
+    T1, C, Cout, N = 3, 16, 16, 70
+    feats = (torch.randn(B, T1 * C, N, generator=g)).to(dt)
+    w1, w2 = torch.randn(C, C, generator=g) * 0.3, torch.randn(Cout, T1 * C, generator=g) * 0.2
+    b1, b2 = torch.randn(B * T1, C, generator=g), torch.randn(Cout, generator=g)
+    assert torch.equal(E.history_conv(feats, w1, b1, w2, b2), E.history_conv(feats.float(), w1, b1, w2, b2))
+    T1, C, Cout = 2, 32, 16                                                      # the generic (non register-resident) kernel
+    feats = (torch.randn(B, T1 * C, N, generator=g)).to(dt)
+    w1, w2 = torch.randn(C, C, generator=g) * 0.3, torch.randn(Cout, T1 * C, generator=g) * 0.2
+    b1 = torch.randn(B * T1, C, generator=g)
+    assert torch.equal(E.history_conv(feats, w1, b1, w2, b2), E.history_conv(feats.float(), w1, b1, w2, b2))
