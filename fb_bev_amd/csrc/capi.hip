@@ -156,6 +156,19 @@ static int iv_variant_for(long long items) {
     return 2;
 }
 
+// (m, sh) of fbbev_div for an invariant divisor d (Granlund & Montgomery, N = 32): l = ceil(log2 d),
+// m = floor(2^32 (2^l - d) / d) + 1, sh = l - 1
+static fbbev_fastdiv make_fastdiv(unsigned int d) {
+    fbbev_fastdiv f;
+    f.d = d; f.m = 0; f.sh = 0;
+    if (d <= 1) { f.d = 1; return f; }
+    unsigned int l = 0;
+    while ((1ull << l) < d) ++l;
+    f.m = (unsigned int)((((1ull << l) - d) << 32) / d + 1);
+    f.sh = l - 1;
+    return f;
+}
+
 struct rank_ws_layout {
     size_t keys_a, keys_t, vals_t, matrix, chunk_info, total;
     int v0, wgs0;          // pass 0 (keys + scatter over all n points)
@@ -272,20 +285,21 @@ static int rank_build_impl(const float* coor, const fbbev_cam_ptrs* cams, const 
     }
     const unsigned int* keys = reinterpret_cast<const unsigned int*>(ranks_bev);
     const unsigned int* vals = reinterpret_cast<const unsigned int*>(ranks_depth);
+    const fbbev_fastdiv div_dhw = make_fastdiv((unsigned int)((long long)D * H * W)), div_hw = make_fastdiv((unsigned int)(H * W));
     switch (L.vi) {
         case 0:
             FBBEV_LAUNCH((k_interval_count<4, 4>), L.wgsi, 256, 0, stream, keys, (const int*)counts, skip, chunk_info);
-            FBBEV_LAUNCH((k_interval_write<4, 4>), L.wgsi, 256, 0, stream, keys, vals, D, H * W, (const int2*)chunk_info, skip,
+            FBBEV_LAUNCH((k_interval_write<4, 4>), L.wgsi, 256, 0, stream, keys, vals, div_dhw, div_hw, (const int2*)chunk_info, skip,
                          ranks_feat, interval_starts, interval_lengths, interval_rank, counts);
             break;
         case 1:
             FBBEV_LAUNCH((k_interval_count<16, 4>), L.wgsi, 1024, 0, stream, keys, (const int*)counts, skip, chunk_info);
-            FBBEV_LAUNCH((k_interval_write<16, 4>), L.wgsi, 1024, 0, stream, keys, vals, D, H * W, (const int2*)chunk_info, skip,
+            FBBEV_LAUNCH((k_interval_write<16, 4>), L.wgsi, 1024, 0, stream, keys, vals, div_dhw, div_hw, (const int2*)chunk_info, skip,
                          ranks_feat, interval_starts, interval_lengths, interval_rank, counts);
             break;
         default:
             FBBEV_LAUNCH((k_interval_count<16, 8>), L.wgsi, 1024, 0, stream, keys, (const int*)counts, skip, chunk_info);
-            FBBEV_LAUNCH((k_interval_write<16, 8>), L.wgsi, 1024, 0, stream, keys, vals, D, H * W, (const int2*)chunk_info, skip,
+            FBBEV_LAUNCH((k_interval_write<16, 8>), L.wgsi, 1024, 0, stream, keys, vals, div_dhw, div_hw, (const int2*)chunk_info, skip,
                          ranks_feat, interval_starts, interval_lengths, interval_rank, counts);
             break;
     }

@@ -139,10 +139,20 @@ k_interval_count(const unsigned int* __restrict__ keys, const int* __restrict__ 
     if (tid == 0) chunk_info[blockIdx.x] = make_int2(tot, wg_last1);
 }
 
+// division of a 32-bit unsigned by an invariant divisor d (1 <= d < 2^31): q = (t + ((n - t) >> 1)) >> sh with
+// t = mulhi(n, m) -- Granlund & Montgomery; the launcher computes (m, sh) once.  Replaces two hardware-less integer
+// divisions per point (~40 dependent instructions each, a third of k_interval_write's issue stalls in the round-2 PMC run).
+struct fbbev_fastdiv { unsigned int d, m, sh; };
+__device__ __forceinline__ unsigned int fbbev_div(unsigned int n, const fbbev_fastdiv& f) {
+    if (f.d == 1u) return n;
+    const unsigned int t = (unsigned int)(((unsigned long long)n * f.m) >> 32);
+    return (t + ((n - t) >> 1)) >> f.sh;
+}
+
 template <int WAVES, int ITEMS>
 __global__ void __launch_bounds__(WAVES * 64)
-k_interval_write(const unsigned int* __restrict__ keys, const unsigned int* __restrict__ vals, int D, int HW,
-                 const int2* __restrict__ chunk_info, const int* __restrict__ skip, int* __restrict__ ranks_feat,
+k_interval_write(const unsigned int* __restrict__ keys, const unsigned int* __restrict__ vals, fbbev_fastdiv div_dhw,
+                 fbbev_fastdiv div_hw, const int2* __restrict__ chunk_info, const int* __restrict__ skip, int* __restrict__ ranks_feat,
                  int* __restrict__ interval_starts, int* __restrict__ interval_lengths, int* __restrict__ interval_rank,
                  int* __restrict__ counts) {
     if (skip != nullptr && *skip != 0) return;
@@ -171,7 +181,6 @@ k_interval_write(const unsigned int* __restrict__ keys, const unsigned int* __re
     bool head[ITEMS];
     unsigned int key[ITEMS];
     int local = 0, last1 = 0;
-    const unsigned int dhw = (unsigned int)D * (unsigned int)HW;
     unsigned int prevk = (base > 0 && base <= P) ? keys[base - 1] : 0u;
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
@@ -186,7 +195,8 @@ k_interval_write(const unsigned int* __restrict__ keys, const unsigned int* __re
             if (head[j]) { ++local; last1 = (int)i + 1; }
             // view_transformer.py:563-568: feature pixel of point ((b*N+n)*D+d)*HW + hw
             const unsigned int pid = vals[i];
-            ranks_feat[i] = (int)((pid / dhw) * (unsigned int)HW + pid % (unsigned int)HW);
+            const unsigned int cam = fbbev_div(pid, div_dhw), hw = pid - fbbev_div(pid, div_hw) * div_hw.d;
+            ranks_feat[i] = (int)(cam * div_hw.d + hw);
         }
     }
     int tot, wg_last1;

@@ -98,7 +98,8 @@ class FBOCC(nn.Module):
         self._runners = None
         if ex.get('mfma_conv3d_train'):           # opt-in: the autograd route (forward + dgrad + wgrad kernels)
             from .mfma_conv3d import enable_training_route
-            for blk in (self.img_bev_encoder_backbone, self.img_bev_encoder_neck, self.occupancy_head):
+            for blk in (self.img_bev_encoder_backbone, self.img_bev_encoder_neck, self.occupancy_head,
+                        self.history_keyframe_time_conv, self.history_keyframe_cat_conv):
                 if blk is not None:
                     enable_training_route(blk, True)
 

@@ -24,6 +24,7 @@ import torch
 import torch.nn as nn
 
 from . import _capi
+from .mfma_conv3d import MConv3d      # nn.Conv3d (same parameters / state dict) that can take the fbbev_conv3d_* autograd route
 
 
 class TemporalHistoryFusion(nn.Module):
@@ -41,9 +42,9 @@ class TemporalHistoryFusion(nn.Module):
         self.history_cam_sweep_freq = history_cam_sweep_freq           # seconds between frames (fbocc.py:105)
         out_c = history_cat_conv_out_channels if history_cat_conv_out_channels is not None else C
         self.history_keyframe_time_conv = nn.Sequential(               # fbocc.py:111-118
-            nn.Conv3d(C + 1, C, kernel_size=1, padding=0, stride=1), nn.SyncBatchNorm(C), nn.ReLU(inplace=True))
+            MConv3d(C + 1, C, kernel_size=1, padding=0, stride=1), nn.SyncBatchNorm(C), nn.ReLU(inplace=True))
         self.history_keyframe_cat_conv = nn.Sequential(                # fbocc.py:120-127
-            nn.Conv3d(C * (T + 1), out_c, kernel_size=1, padding=0, stride=1), nn.SyncBatchNorm(out_c),
+            MConv3d(C * (T + 1), out_c, kernel_size=1, padding=0, stride=1), nn.SyncBatchNorm(out_c),
             nn.ReLU(inplace=True))
         self.use_mfma_convs = True          # inference: both 1x1x1 convs in one fp32-MFMA kernel when the channels allow
         # Storage type of the inference history ring (T+1 frames per sample): float32 (the reference), or float16 / bfloat16

@@ -136,7 +136,10 @@ def _supported_train(conv, x):
         k, s, p = conv.kernel_size, conv.stride, conv.padding
         ok = len(set(k)) == len(set(s)) == len(set(p)) == 1 and k[0] in (1, 3) and s[0] in (1, 2) and p[0] in (0, 1) \
             and set(conv.dilation) == {1} and conv.padding_mode == 'zeros'
-    return ok and conv.groups == 1 and cin % 16 == 0 and cout % 16 == 0 and x.dtype == torch.float32
+    if isinstance(conv, nn.ConvTranspose3d):
+        return ok and conv.groups == 1 and cin % 16 == 0 and cout % 16 == 0 and x.dtype == torch.float32
+    # plain convolutions take any channel count: MConv3d pads Cin / Cout to the kernels' multiple of 16 with zeros
+    return ok and conv.groups == 1 and x.dtype == torch.float32
 
 
 class _Conv3dFn(torch.autograd.Function):
@@ -224,9 +227,19 @@ class MConv3d(nn.Conv3d):
 
     def forward(self, x):
         if self.mfma and (x.is_cuda or self.backends) and not torch.is_autocast_enabled() and _supported_train(self, x):
-            y = _Conv3dFn.apply(to_ndhwc(x), self.weight, self.bias, self.kernel_size[0], self.stride[0], self.padding[0],
-                                self.backends)
-            return to_ncdhw(y)
+            # Channel counts off the kernels' multiple of 16 (the head's 19-class / 4-weight outputs, the history fusion's
+            # 81 inputs) are zero-padded here: on this ROCm image the vendor library runs exactly those layers with its
+            # naive fallback kernels (0.3-0.5 s EACH per training step at 200x200x16, profiles/r02_rocprofv3_train_step.csv).
+            cin, cout = self.in_channels, self.out_channels
+            pi, po = (-cin) % 16, (-cout) % 16
+            xn, w, b = to_ndhwc(x), self.weight, self.bias
+            if pi:
+                xn, w = F.pad(xn, (0, pi)), F.pad(w, (0, 0, 0, 0, 0, 0, 0, pi))
+            if po:
+                w = F.pad(w, (0, 0, 0, 0, 0, 0, 0, 0, 0, po))
+                b = F.pad(b, (0, po)) if b is not None else None
+            y = _Conv3dFn.apply(xn, w, b, self.kernel_size[0], self.stride[0], self.padding[0], self.backends)
+            return to_ncdhw(y[..., :cout] if po else y)
         return super().forward(x)
 
 

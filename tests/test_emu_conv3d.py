@@ -287,8 +287,8 @@ def test_training_route_gradients_equal_torch_autograd():
         # absolute floor: a conv bias in front of a batch-statistics BN has an analytically zero gradient (rounding noise)
         tol = 3e-4 * q.grad.abs().max() + 2e-4
         assert (p.grad - q.grad).abs().max() <= tol, (name, float((p.grad - q.grad).abs().max()), float(tol))
-    # the two tiny output convolutions (19 / 4 channels) are not multiples of 16 and stay on the library route
-    assert not M._supported_train(net['head'].occ_pred_conv[3], x) and M._supported_train(net['head'].occ_pred_conv[0], x)
+    # the two tiny output convolutions (19 / 4 channels) are not multiples of 16: MConv3d zero-pads them onto the same route
+    assert M._supported_train(net['head'].occ_pred_conv[3], x) and M._supported_train(net['head'].occ_pred_conv[0], x)
     M.enable_training_route(net, False)
     assert not any(getattr(m, 'mfma', False) for m in net.modules())
 

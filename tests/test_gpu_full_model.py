@@ -145,3 +145,79 @@ def test_training_step_backpropagates_everywhere_without_host_sync(dev, executio
     finally:
         torch.cuda.set_sync_debug_mode('default')
     assert torch.isfinite(total2)
+
+
+def test_baseline_config3_training_step_at_shipped_size(dev):
+    """BASELINE configs[3]: ONE forward_train + backward of the WHOLE shipped FB-OCC R50 config (6x256x704 in, 100x100x8
+    grid, 16-frame history) at the per-GPU batch of the 8x4 = 32 global batch, on the route bench.py --mode train times
+    (3-D stacks on fbbev_conv3d_*).  Checks: the five losses are finite and equal their CPU re-evaluation from the
+    GPU logits / depth distribution (the loss functions are pinned on the reference fixture, tests/test_occ_modules.py);
+    every parameter of every block receives a finite gradient; the flat gradient buckets (shard.GradBuckets: what
+    the DDP step all-reduces) hold exactly those gradients; no host synchronisation in the second step."""
+    import json
+    import os
+    from fb_bev_amd import shard, synthetic as S
+    from fb_bev_amd.fbocc import FBOCC
+    cfg = dict(json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'fbocc_config_path_blocks.json')))
+               ['fbocc-r50-cbgs_depth_16f_16x4_20e.py']['model'])
+    cfg.pop('type')
+    torch.manual_seed(0)
+    m = FBOCC(**cfg, execution=dict(with_cp=False, mfma_conv3d_train=True)).to(dev).train()
+    B = 4
+    pc = S.CONFIGS['REF']
+    g = torch.Generator().manual_seed(11)
+    cam = [t.to(dev) for t in S.camera_rig(pc, B, seed=11, bda_aug=True)]
+    img = torch.randn(B, 6, 3, 256, 704, generator=g).to(dev)
+    gt_depth = torch.rand(B, 6, 256, 704, generator=g) * 40 + 2
+    gt_depth[torch.rand(gt_depth.shape, generator=g) > 0.03] = 0
+    gt_occ = torch.randint(1, 19, (B, 200, 200, 16), generator=g)
+    gt_occ[torch.rand(gt_occ.shape, generator=g) < 0.6] = 18
+    gt_occ[torch.rand(gt_occ.shape, generator=g) < 0.4] = 255
+    gt_occ, gt_depth = gt_occ.to(dev), gt_depth.to(dev)
+
+    def metas(first):
+        return [dict(sequence_group_idx=b, start_of_sequence=first, curr_to_prev_ego_rt=torch.eye(4), index=b) for b in range(B)]
+    model, buckets = shard.prepare_ddp(m, sync_bn=False)
+    captured = {}
+    h1 = m.occupancy_head.register_forward_hook(lambda mod, i, o: captured.__setitem__('occ', o))
+    h2 = m.depth_net.register_forward_hook(lambda mod, i, o: captured.__setitem__('depth', o))
+    buckets.zero_grad()
+    losses = m(return_loss=True, img_inputs=[img] + cam, img_metas=metas(True), gt_occupancy=gt_occ, gt_depth=gt_depth)
+    h1.remove(); h2.remove()
+    total = m.parse_losses(losses)
+    total.backward()
+    buckets.finish()
+    assert set(losses) == {'loss_voxel_ce_c_0', 'loss_voxel_sem_scal_c_0', 'loss_voxel_geo_scal_c_0', 'loss_voxel_lovasz_c_0',
+                           'loss_depth'}
+    assert all(torch.isfinite(v).all() for v in losses.values()) and torch.isfinite(total)
+    # losses re-evaluated on the CPU from the GPU's own logits / depth distribution
+    head_cpu = type(m.occupancy_head)(**{k: v for k, v in cfg['occupancy_head'].items() if k != 'type'})
+    logits = [captured['occ']['output_voxels'][0].detach().float().cpu()]
+    cpu_losses = head_cpu.loss(output_voxels=logits, target_voxels=gt_occ.cpu())
+    for k, v in cpu_losses.items():
+        assert abs(float(losses[k]) - float(v)) <= 2e-4 * abs(float(v)) + 1e-5, (k, float(losses[k]), float(v))
+    import copy
+    depth_cpu = copy.deepcopy(m.depth_net).cpu().get_depth_loss(gt_depth.cpu(), captured['depth'][1].detach().float().cpu())
+    assert abs(float(losses['loss_depth']) - float(depth_cpu['loss_depth'])) <= 2e-4 * abs(float(depth_cpu['loss_depth'])) + 1e-5
+    # every parameter has a finite gradient living in the flat buckets, every block a non-zero gradient norm
+    norms = {}
+    for n, p in m.named_parameters():
+        if p.requires_grad:
+            assert p.grad is not None and torch.isfinite(p.grad).all(), n
+            norms[n.split('.')[0]] = norms.get(n.split('.')[0], 0.0) + float(p.grad.double().pow(2).sum())
+    assert set(norms) == {'img_backbone', 'img_neck', 'depth_net', 'backward_projection', 'history_keyframe_time_conv',
+                          'history_keyframe_cat_conv', 'img_bev_encoder_backbone', 'img_bev_encoder_neck', 'occupancy_head'}
+    assert all(v > 0 for v in norms.values()), norms
+    flat = sum(float(f.double().pow(2).sum()) for f in buckets._flat)
+    assert abs(flat - sum(norms.values())) <= 1e-6 * flat          # the buckets ARE the gradients (views, no copies)
+    assert buckets.nbytes == 4 * sum(p.numel() for p in buckets.params) and len(buckets.buckets) >= 4
+    print('configs[3] B=4 step: loss', float(total), 'grad norm per block', {k: round(v ** 0.5, 4) for k, v in norms.items()})
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode('error')
+    try:
+        buckets.zero_grad()
+        m.parse_losses(m(return_loss=True, img_inputs=[img] + cam, img_metas=metas(False), gt_occupancy=gt_occ,
+                         gt_depth=gt_depth)).backward()
+        buckets.finish()
+    finally:
+        torch.cuda.set_sync_debug_mode('default')
