@@ -20,6 +20,39 @@ from torch.utils.checkpoint import checkpoint
 from .mfma_conv3d import MConv3d
 
 
+def _linear_resize_matrix(n_in, n_out, device):
+    """(n_out, n_in) matrix of ATen's 1-D linear resize, align_corners=False: src = (dst + 0.5) * n_in / n_out - 0.5,
+    clamped at 0; taps floor(src) and the next index (clamped at n_in - 1) with weights 1 - frac, frac."""
+    dst = torch.arange(n_out, dtype=torch.float32, device=device)
+    src = ((dst + 0.5) * (float(n_in) / float(n_out)) - 0.5).clamp_(min=0)
+    i0 = src.floor().clamp_(max=n_in - 1)
+    lam = src - i0
+    i0 = i0.long()
+    i1 = (i0 + 1).clamp_(max=n_in - 1)
+    w = torch.zeros(n_out, n_in, dtype=torch.float32, device=device)
+    rows = torch.arange(n_out, device=device)
+    w.index_put_((rows, i0), 1.0 - lam, accumulate=True)
+    w.index_put_((rows, i1), lam, accumulate=True)
+    return w
+
+
+def upsample_trilinear(x, size):
+    """F.interpolate(x, size, mode='trilinear', align_corners=False) (occupancy_head.py:163-166, fpn3d.py:92-96).  Under autograd on the
+    GPU the resize is applied as its three 1-D factors (trilinear interpolation is separable), each a small dense
+    matrix product: the same linear map (to fp32 summation order), but its backward is three transposed GEMMs instead
+    of ATen's atomic scatter (upsample_trilinear3d_backward: 63 % of the training step at 200x200x16 before this,
+    profiles/r02_rocprofv3_train_step_before_separable_upsample.csv)."""
+    if not (x.is_cuda and x.requires_grad and torch.is_grad_enabled()):
+        return F.interpolate(x, size=list(size), mode='trilinear', align_corners=False)
+    out = x.float()
+    for axis, n_out in zip((2, 3, 4), size):                   # z, y, x in turn: smallest tensors first
+        n_in = out.shape[axis]
+        if n_in != n_out:
+            w = _linear_resize_matrix(n_in, n_out, x.device)
+            out = torch.movedim(torch.matmul(torch.movedim(out, axis, -1), w.t()), -1, axis)
+    return out.to(x.dtype)
+
+
 def build_norm(norm_cfg, channels, dims=3):
     """mmcv.cnn.build_norm_layer (external) for the types the FB-OCC configs use -> (state-dict abbreviation, layer).
     SyncBN is built as plain BatchNorm (identical parameters / state names / eval arithmetic) and MARKED
@@ -203,8 +236,11 @@ class FPN3D(nn.Module):
     def _forward(self, inputs):
         laterals = [self._run(conv, x) for conv, x in zip(self.lateral_convs, inputs)]
         for i in range(self.num_out - 1, 0, -1):                                       # :92-96
-            laterals[i - 1] = laterals[i - 1] + F.interpolate(laterals[i], size=laterals[i - 1].shape[2:],
-                                                              align_corners=False, **self.upsample_cfg)
+            if self.upsample_cfg.get('mode') == 'trilinear' and len(self.upsample_cfg) == 1:
+                up = upsample_trilinear(laterals[i], laterals[i - 1].shape[2:])       # separable form under autograd
+            else:
+                up = F.interpolate(laterals[i], size=laterals[i - 1].shape[2:], align_corners=False, **self.upsample_cfg)
+            laterals[i - 1] = laterals[i - 1] + up
         return [self._run(conv, x) for conv, x in zip(self.fpn_convs, laterals)]
 
     def forward(self, inputs):

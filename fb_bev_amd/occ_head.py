@@ -14,7 +14,7 @@ import torch.nn.functional as F
 from torch.utils.checkpoint import checkpoint
 
 from . import occ_loss as L
-from .bev_encoder import build_norm
+from .bev_encoder import build_norm, upsample_trilinear
 from .mfma_conv3d import MConv3d, MConvTranspose3d
 
 
@@ -87,7 +87,7 @@ class OccHead(nn.Module):
         out = None
         for feats, wk in zip(output_occs, torch.unbind(w, dim=1)):
             if tuple(feats.shape[2:]) != tuple(size):          # trilinear resize to the same size is the identity
-                feats = F.interpolate(feats, size=list(size), mode='trilinear', align_corners=False)
+                feats = upsample_trilinear(feats, size)
             # out += feats * weights (:169) as one multiply-add pass per level instead of a multiply and an add pass over
             # the full-resolution 128-channel maps
             out = feats * wk.unsqueeze(1) if out is None else torch.addcmul(out, feats, wk.unsqueeze(1))

@@ -179,11 +179,17 @@ def test_baseline_config3_training_step_at_shipped_size(dev):
         return [dict(sequence_group_idx=b, start_of_sequence=first, curr_to_prev_ego_rt=torch.eye(4), index=b) for b in range(B)]
     model, buckets = shard.prepare_ddp(m, sync_bn=False)
     captured = {}
-    h1 = m.occupancy_head.register_forward_hook(lambda mod, i, o: captured.__setitem__('occ', o))
+    head_loss = m.occupancy_head.loss                       # forward_train calls forward() / loss() directly: wrap loss()
+
+    def capture_loss(**kw):
+        captured['occ'] = [v.detach().float().cpu() for v in kw['output_voxels']]
+        return head_loss(**kw)
+    m.occupancy_head.loss = capture_loss
     h2 = m.depth_net.register_forward_hook(lambda mod, i, o: captured.__setitem__('depth', o))
     buckets.zero_grad()
     losses = m(return_loss=True, img_inputs=[img] + cam, img_metas=metas(True), gt_occupancy=gt_occ, gt_depth=gt_depth)
-    h1.remove(); h2.remove()
+    h2.remove()
+    m.occupancy_head.loss = head_loss
     total = m.parse_losses(losses)
     total.backward()
     buckets.finish()
@@ -192,8 +198,7 @@ def test_baseline_config3_training_step_at_shipped_size(dev):
     assert all(torch.isfinite(v).all() for v in losses.values()) and torch.isfinite(total)
     # losses re-evaluated on the CPU from the GPU's own logits / depth distribution
     head_cpu = type(m.occupancy_head)(**{k: v for k, v in cfg['occupancy_head'].items() if k != 'type'})
-    logits = [captured['occ']['output_voxels'][0].detach().float().cpu()]
-    cpu_losses = head_cpu.loss(output_voxels=logits, target_voxels=gt_occ.cpu())
+    cpu_losses = head_cpu.loss(output_voxels=captured['occ'], target_voxels=gt_occ.cpu())
     for k, v in cpu_losses.items():
         assert abs(float(losses[k]) - float(v)) <= 2e-4 * abs(float(v)) + 1e-5, (k, float(losses[k]), float(v))
     import copy
