@@ -183,13 +183,13 @@ def run_forward(args):
     cam = [t.to(dev) for t in S.camera_rig(cfg, B, seed=shard.shard_seed(rank), bda_aug=True)]
     depth, ctx = S.depth_and_context(cfg, B, seed=shard.shard_seed(rank))
     depth, ctx = depth.to(dev), ctx.to(dev)
-    vt = LSSViewTransformerFunction3D(cfg.grid_config, cfg.input_size, cfg.downsample,
-                                      tile_voxels=args.tile_voxels, pool_flags=args.pool_flags).to(dev)
+    store_dt = {'f32': torch.float32, 'bf16': torch.bfloat16, 'f16': torch.float16}[args.storage]
+    vt = LSSViewTransformerFunction3D(cfg.grid_config, cfg.input_size, cfg.downsample, tile_voxels=args.tile_voxels,
+                                      pool_flags=args.pool_flags, out_dtype=store_dt).to(dev)
     args.tile_voxels, flags = vt.tiling(cfg.n_cams)            # density-aware tiling of this rig (6 cameras here)
     Z, Y, X = vt.grid_zyx
     C = cfg.channels
     tile_ws = vt._tile_ws(dev, B, args.tile_voxels)
-    store_dt = {'f32': torch.float32, 'bf16': torch.bfloat16, 'f16': torch.float16}[args.storage]
     esz = 4 if args.storage == 'f32' else 2
     out = torch.empty((B, C, Z, Y, X), dtype=store_dt, device=dev)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))

@@ -479,10 +479,13 @@ struct dense2_args {
     float* out;
 };
 
-template <int TV, int CPL, int ST, int NT, int OT>
+template <int TV, int CPL, int ST, int NT, int OT, bool T16 = false>
 static int launch_dense2(const dense2_args& a) {
-    if (a.lds > 64 * 1024) {  // > 64 KiB of dynamic LDS must be opted into (160 KiB per CU on gfx950)
-        int e = fbbev_rt_allow_dyn_lds((const void*)k_pool_fwd_dense2<TV, CPL, ST, NT, OT>, a.lds);
+    size_t lds = a.lds;
+    if (T16)                                   // 16-bit tile [CC][TV + 8] instead of fp32 [CC][TV + 4]
+        lds = (size_t)(a.C / a.csplit) * (TV + 8) * 2 + ((size_t)3 * TV + 2 * FBBEV_NP_STAGE) * sizeof(int);
+    if (lds > 64 * 1024) {  // > 64 KiB of dynamic LDS must be opted into (160 KiB per CU on gfx950)
+        int e = fbbev_rt_allow_dyn_lds((const void*)k_pool_fwd_dense2<TV, CPL, ST, NT, OT, T16>, lds);
         if (e) return e;
     }
     long long grid = a.n_blocks;
@@ -490,7 +493,7 @@ static int launch_dense2(const dense2_args& a) {
         const long long g = 8ll << (a.swizzle - 1);
         grid = (a.n_blocks + g - 1) / g * g;
     }
-    FBBEV_LAUNCH((k_pool_fwd_dense2<TV, CPL, ST, NT, OT>), grid, NT, a.lds, a.stream, a.C, a.Z, a.yx, a.tpp,
+    FBBEV_LAUNCH((k_pool_fwd_dense2<TV, CPL, ST, NT, OT, T16>), grid, NT, lds, a.stream, a.C, a.Z, a.yx, a.tpp,
                  a.csplit, (int)a.n_blocks, a.swizzle, a.stride_b, a.stride_c, a.depth, a.feat, a.rd, a.rf, a.irank, a.starts, a.lengths, a.tile_meta, a.addend, a.out);
     return fbbev_rt_last_error();
 }
@@ -498,6 +501,8 @@ static int launch_dense2(const dense2_args& a) {
 template <int TV, int CPL, int ST>
 static int launch_dense2_nt(int nt, int ot, const dense2_args& a) {
     if constexpr (ST == 4) {      // 16-bit output storage is built for the default store policy only
+        if (ot != 0 && !a.addend && nt == 256)        // no epilogue add: the LDS tile itself is 16-bit (see the kernel)
+            return ot == 1 ? launch_dense2<TV, CPL, 4, 256, 1, true>(a) : launch_dense2<TV, CPL, 4, 256, 2, true>(a);
         if (ot == 1) return nt == 128 ? launch_dense2<TV, CPL, 4, 128, 1>(a) : launch_dense2<TV, CPL, 4, 256, 1>(a);
         if (ot == 2) return nt == 128 ? launch_dense2<TV, CPL, 4, 128, 2>(a) : launch_dense2<TV, CPL, 4, 256, 2>(a);
     }
@@ -974,6 +979,36 @@ extern "C" int fbbev_history_warp_e(const void* history, long long history_strid
     if (history_stride_b == 0) history_stride_b = (long long)CH * zyx;
     if (out_stride_b == 0) out_stride_b = (long long)CH * zyx;
     if (history_stride_b < (long long)CH * zyx || out_stride_b < (long long)CH * zyx) return FBBEV_E_BADARG;
+    fbbev_rt_stream stream = (fbbev_rt_stream)stream_;
+    // LDS-staged bricks (the default when the grid is big enough for a 4096-voxel brick); FBBEV_HISTORY_WARP=direct keeps
+    // the gather kernel (A/B timing, tests)
+    const char* mode = getenv("FBBEV_HISTORY_WARP");
+    const bool direct = mode && mode[0] == 'd';
+    if (!direct && zyx >= 4096 && X >= 16) {
+        int TX = 64;
+        while (TX / 2 >= X) TX /= 2;
+        const int BZ = Z < 8 ? Z : 8;
+        int TY = 4096 / (BZ * TX);
+        if (TY > Y) TY = Y;
+        if (TY < 1) TY = 1;
+        const int ntx = (X + TX - 1) / TX, nty = (Y + TY - 1) / TY, ntz = (Z + BZ - 1) / BZ;
+        int cpb = 64;                                  // channels per workgroup: the brick's tap setup is amortised over them
+        while (cpb > 8 && (long long)B * ntz * nty * ntx * ((CH + cpb - 1) / cpb) < 2048) cpb >>= 1;
+        const int n_groups = (CH + cpb - 1) / cpb;
+        const long long blocks = (long long)B * n_groups * ntz * nty * ntx;
+        if (blocks >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
+        if (elem_type == 0)
+            FBBEV_LAUNCH(k_history_warp_lds<0>, blocks, 1024, 0, stream, history, history_stride_b, rt_flow, CH, Z, Y, X, BZ, TY,
+                         TX, ntz, nty, ntx, cpb, n_groups, out, out_stride_b);
+        else if (elem_type == 1)
+            FBBEV_LAUNCH(k_history_warp_lds<1>, blocks, 1024, 0, stream, history, history_stride_b, rt_flow, CH, Z, Y, X, BZ, TY,
+                         TX, ntz, nty, ntx, cpb, n_groups, out, out_stride_b);
+        else
+            FBBEV_LAUNCH(k_history_warp_lds<2>, blocks, 1024, 0, stream, history, history_stride_b, rt_flow, CH, Z, Y, X, BZ, TY,
+                         TX, ntz, nty, ntx, cpb, n_groups, out, out_stride_b);
+        FBBEV_CHECK_LAUNCH();
+        return 0;
+    }
     const int n_chunks = (int)((zyx + 255) / 256);
     // enough workgroups to fill 256 CUs several times over, at least 8 channels each to amortise the tap setup
     int cpb = 64;
@@ -982,7 +1017,6 @@ extern "C" int fbbev_history_warp_e(const void* history, long long history_strid
     const long long blocks = (long long)B * n_groups * n_chunks;
     if (blocks >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
     const int per_xcd = (int)((blocks + 7) / 8);
-    fbbev_rt_stream stream = (fbbev_rt_stream)stream_;
     if (elem_type == 0)
         FBBEV_LAUNCH(k_history_warp<0>, (long long)per_xcd * 8, 256, 0, stream, history, history_stride_b, rt_flow,
                      CH, Z, Y, X, cpb, n_groups, n_chunks, per_xcd, (int)blocks, out, out_stride_b);

@@ -55,6 +55,14 @@ __device__ __forceinline__ void fbbev_store4(float* p, fbbev_v4f v) {
 
 __device__ __forceinline__ void fbbev_atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }
 
+// IEEE binary16 bits -> binary32: v_cvt_f32_f16, exact for every half (subnormals included)
+__device__ __forceinline__ float fbbev_f16_bits_to_f32(unsigned int h) {
+    const unsigned short b = (unsigned short)h;
+    _Float16 x;
+    __builtin_memcpy(&x, &b, 2);
+    return (float)x;
+}
+
 // v_mfma_f32_16x16x4_f32: D(16x16) = A(16x4) . B(4x16) + C, exact fp32 (a k-ordered fmaf chain per element).
 // A: lane holds A[lane%16][lane/16]; B: lane holds B[lane/16][lane%16]; register r of C/D: row 4*(lane/16)+r, col lane%16.
 __device__ __forceinline__ fbbev_v4f fbbev_mfma_f32_16x16x4(float a, float b, fbbev_v4f c) {

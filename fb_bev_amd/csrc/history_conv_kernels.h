@@ -120,9 +120,11 @@ k_history_conv_t(const void* __restrict__ feats, long long fstride_b, const floa
     for (int mt = 0; mt < MT2; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc2[mt][r] = bias2[16 * mt + 4 * g + r];
-    float bx[KS];
+    // X fragments stay RAW (unconverted) in registers: the prefetch of frame t+1 is issued before GEMM 2 of frame t and
+    // must not be followed by a conversion that waits for it; the exact widening happens when the MFMA consumes them
+    unsigned int bx[KS];
 #pragma unroll
-    for (int kk = 0; kk < KS; ++kk) bx[kk] = inb ? fbbev_ld_elem<ET>(feats, xb + (long long)(4 * kk + g) * N + n) : 0.f;
+    for (int kk = 0; kk < KS; ++kk) bx[kk] = inb ? fbbev_ld_raw<ET>(feats, xb + (long long)(4 * kk + g) * N + n) : 0u;
     for (int t = 0; t < T1; ++t) {
         const float* b1 = bias1 + ((long long)b * T1 + t) * C;
         const float* w2t = w2f + (long long)t * MT2 * KS * 64;
@@ -139,11 +141,11 @@ k_history_conv_t(const void* __restrict__ feats, long long fstride_b, const floa
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
-            for (int mt = 0; mt < MT1; ++mt) acc1[mt] = fbbev_mfma_f32_16x16x4(a1[mt][kk], bx[kk], acc1[mt]);
+            for (int mt = 0; mt < MT1; ++mt) acc1[mt] = fbbev_mfma_f32_16x16x4(a1[mt][kk], fbbev_widen<ET>(bx[kk]), acc1[mt]);
         if (t + 1 < T1) {                                   // next frame's X fragments: in flight during GEMM 2
             const long long xn = xb + (long long)(t + 1) * C * N;
 #pragma unroll
-            for (int kk = 0; kk < KS; ++kk) bx[kk] = inb ? fbbev_ld_elem<ET>(feats, xn + (long long)(4 * kk + g) * N + n) : 0.f;
+            for (int kk = 0; kk < KS; ++kk) bx[kk] = inb ? fbbev_ld_raw<ET>(feats, xn + (long long)(4 * kk + g) * N + n) : 0u;
         }
         fbbev_wave_sync();                                  // ylds is wave-private: no workgroup barrier
 #pragma unroll

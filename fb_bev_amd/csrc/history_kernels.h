@@ -23,29 +23,29 @@
 
 // Storage element of the history ring: ET 0 = f32, 1 = bf16, 2 = f16 (BASELINE configs[4] names fp16).  All arithmetic is
 // fp32: elements are widened exactly at the load and rounded ONCE (nearest-even) at the store.
-__device__ __forceinline__ float fbbev_f16_bits_to_f32(unsigned int h) {
-    const unsigned int sign = (h & 0x8000u) << 16;
-    unsigned int e = (h >> 10) & 0x1fu, m = h & 0x3ffu, u;
-    if (e == 0) {
-        if (m == 0) u = sign;
-        else {                                              // subnormal half: normalise
-            int sh = 0;
-            while (!(m & 0x400u)) { m <<= 1; ++sh; }
-            u = sign | ((unsigned int)(113 - sh) << 23) | ((m & 0x3ffu) << 13);
-        }
-    } else if (e == 31) u = sign | 0x7f800000u | (m << 13);
-    else u = sign | ((e + 112u) << 23) | (m << 13);
-    float f;
-    __builtin_memcpy(&f, &u, 4);
-    return f;
-}
 template <int ET>
 __device__ __forceinline__ float fbbev_ld_elem(const void* base, long long i) {
     if constexpr (ET == 0) return static_cast<const float*>(base)[i];
     else {
         const unsigned int h = static_cast<const unsigned short*>(base)[i];
         if constexpr (ET == 1) { const unsigned int u = h << 16; float f; __builtin_memcpy(&f, &u, 4); return f; }
-        else return fbbev_f16_bits_to_f32(h);
+        else return fbbev_f16_bits_to_f32(h);        // rt.h: v_cvt_f32_f16 on the GPU (exact for every half, subnormals included)
+    }
+}
+// raw element (no conversion: a prefetch must not wait for its own load) and its exact widening at the point of use
+template <int ET>
+__device__ __forceinline__ unsigned int fbbev_ld_raw(const void* base, long long i) {
+    if constexpr (ET == 0) return static_cast<const unsigned int*>(base)[i];
+    else return static_cast<const unsigned short*>(base)[i];
+}
+template <int ET>
+__device__ __forceinline__ float fbbev_widen(unsigned int r) {
+    if constexpr (ET == 2) return fbbev_f16_bits_to_f32(r);
+    else {
+        const unsigned int u = (ET == 1) ? (r << 16) : r;
+        float f;
+        __builtin_memcpy(&f, &u, 4);
+        return f;
     }
 }
 template <int ET>
@@ -158,5 +158,175 @@ k_history_warp(const void* __restrict__ hist, long long hist_stride_b, const flo
         fbbev_st_elem<ET>(out, dof, s0);
         so += ZYX;
         dof += ZYX;
+    }
+}
+
+// ---------------------------------------------------------------- LDS-staged variant
+// k_history_warp above is bound by the vector L1's access rate (8 dword gathers per output: 0.30 of the HBM peak; with a
+// 16-bit ring the same gathers move half the bytes: 0.20): for the near-rigid flows of ego motion the 8 taps of
+// neighbouring voxels overlap 8-fold.  Here a 1024-thread workgroup owns an output brick of BZ x TY x TX <= 4096 voxels
+// (x fastest: a wave stores 64 consecutive x), computes the bounding box of the brick's source coordinates once (the flow
+// is affine: the extremes are at the 8 corners; +-1 voxel of slack covers the second tap and the fp32 rounding of the
+// chain), and per channel stages that box into LDS with coalesced row loads -- every source element is fetched once per
+// brick instead of ~8 times -- then takes the 8 taps from LDS.  Tap order, weights and the fmaf chain are those of
+// k_history_warp: the two kernels produce the same bits (tested).  A brick whose box does not fit (large rotations)
+// gathers from global memory as before.
+#define FBBEV_HW_BOX_FLOATS 12288                 // 48 KiB of LDS per workgroup: two workgroups per CU
+#define FBBEV_HW_VPT 4                            // voxels per thread (brick <= 4096 voxels, 1024 threads)
+#define FBBEV_HW_PITCH 80                         // LDS row pitch of the staged box (x extent <= 80: TX = 64 + halo)
+
+template <int ET>
+__global__ void __launch_bounds__(1024)
+k_history_warp_lds(const void* __restrict__ hist, long long hist_stride_b, const float* __restrict__ flow, int CH,
+                   int Z, int Y, int X, int BZ, int TY, int TX, int ntz, int nty, int ntx, int ch_per_block,
+                   int n_groups, void* __restrict__ out, long long out_stride_b) {
+    __shared__ float box[FBBEV_HW_BOX_FLOATS];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    int work = blockIdx.x;
+    const int tx = work % ntx; work /= ntx;
+    const int ty = work % nty; work /= nty;
+    const int tz = work % ntz; work /= ntz;
+    const int grp = work % n_groups, b = work / n_groups;
+    const int X0 = tx * TX, Y0 = ty * TY, Z0 = tz * BZ;
+    const int YX = Y * X, ZYX = Z * YX;
+    const float* m = flow + b * 16;
+    // source coordinate of an output voxel: EXACTLY the expression sequence of k_history_warp
+    auto src = [&](float fx, float fy, float fz, float& ix, float& iy, float& iz) {
+        float gx = m[0] * fx + m[1] * fy + m[2] * fz + m[3];
+        float gy = m[4] * fx + m[5] * fy + m[6] * fz + m[7];
+        float gz = m[8] * fx + m[9] * fy + m[10] * fz + m[11];
+        gx = gx / (float)(X - 1) * 2.0f - 1.0f;
+        gy = gy / (float)(Y - 1) * 2.0f - 1.0f;
+        gz = gz / (float)(Z - 1) * 2.0f - 1.0f;
+        ix = ((gx + 1.f) / 2.f) * (float)(X - 1);
+        iy = ((gy + 1.f) / 2.f) * (float)(Y - 1);
+        iz = ((gz + 1.f) / 2.f) * (float)(Z - 1);
+    };
+    // bounding box of the brick's sources (uniform: every thread evaluates the 8 corners)
+    const int X1 = (X0 + TX < X ? X0 + TX : X) - 1, Y1 = (Y0 + TY < Y ? Y0 + TY : Y) - 1, Z1 = (Z0 + BZ < Z ? Z0 + BZ : Z) - 1;
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    bool finite = true;
+    for (int k = 0; k < 8; ++k) {
+        float c[3];
+        src((float)((k & 1) ? X1 : X0), (float)((k & 2) ? Y1 : Y0), (float)((k & 4) ? Z1 : Z0), c[0], c[1], c[2]);
+        for (int a = 0; a < 3; ++a) {
+            finite = finite && (fabsf(c[a]) < 1.0e9f);
+            lo[a] = fminf(lo[a], c[a]);
+            hi[a] = fmaxf(hi[a], c[a]);
+        }
+    }
+    int b0[3] = {0, 0, 0}, bs[3] = {0, 0, 0};
+    const int dim[3] = {X, Y, Z};
+    bool use_lds = finite;
+    if (finite) {
+        for (int a = 0; a < 3; ++a) {
+            int l = (int)floorf(lo[a]) - 1, h = (int)floorf(hi[a]) + 2;      // taps floor and floor + 1, one voxel of slack
+            l = l < 0 ? 0 : l;
+            h = h > dim[a] - 1 ? dim[a] - 1 : h;
+            b0[a] = l;
+            bs[a] = h >= l ? h - l + 1 : 0;                                  // 0: the whole brick samples outside the grid
+        }
+        use_lds = bs[0] <= FBBEV_HW_PITCH && (long long)FBBEV_HW_PITCH * bs[1] * bs[2] <= FBBEV_HW_BOX_FLOATS;
+    }
+    const int bxs = bs[0], bys = bs[1], bzs = bs[2];
+    const bool empty = use_lds && (bxs == 0 || bys == 0 || bzs == 0);
+    // this thread's voxels: brick-local id j = tid + v * 1024, x fastest.  Per tap: weight (0 for a tap outside the grid)
+    // and its LDS offset packed 2 x 16 bit (0 for an invalid tap: "0 x a staged element", like the gather kernel's
+    // offset 0) -- no per-tap predicate survives into the channel loop (the compiler would keep 64 lane masks alive).
+    int vox[FBBEV_HW_VPT];
+    float w[FBBEV_HW_VPT][8];
+    unsigned int loff[FBBEV_HW_VPT][4];
+    bool miss = false;                               // a valid tap outside the staged box (slack exceeded)
+    const int nbrick = BZ * TY * TX;
+#pragma unroll
+    for (int v = 0; v < FBBEV_HW_VPT; ++v) {
+        const int j = tid + v * 1024;
+        vox[v] = -1;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) w[v][k] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) loff[v][k] = 0u;
+        if (j >= nbrick) continue;
+        const int lx = j % TX, ly = (j / TX) % TY, lz = j / (TX * TY);
+        const int x = X0 + lx, y = Y0 + ly, z = Z0 + lz;
+        if (x >= X || y >= Y || z >= Z) continue;
+        vox[v] = (z * Y + y) * X + x;
+        float ix, iy, iz;
+        src((float)x, (float)y, (float)z, ix, iy, iz);
+        const float x0f = floorf(ix), y0f = floorf(iy), z0f = floorf(iz);
+        const float wx1 = ix - x0f, wy1 = iy - y0f, wz1 = iz - z0f;
+        const float wx0 = (x0f + 1.f) - ix, wy0 = (y0f + 1.f) - iy, wz0 = (z0f + 1.f) - iz;
+        const bool fin = (fabsf(ix) < 1.0e9f) && (fabsf(iy) < 1.0e9f) && (fabsf(iz) < 1.0e9f);
+        const int x0 = fin ? (int)x0f : -2, y0 = fin ? (int)y0f : -2, z0 = fin ? (int)z0f : -2;
+        const int base = ((z0 - b0[2]) * bys + (y0 - b0[1])) * FBBEV_HW_PITCH + (x0 - b0[0]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {                 // order tnw,tne,tsw,tse,bnw,bne,bsw,bse: x fastest, then y, then z
+            const int cx = x0 + (k & 1), cy = y0 + ((k >> 1) & 1), cz = z0 + (k >> 2);
+            const bool ok = cx >= 0 && cx < X && cy >= 0 && cy < Y && cz >= 0 && cz < Z;
+            const float wk = ((k & 1) ? wx1 : wx0) * (((k >> 1) & 1) ? wy1 : wy0) * ((k >> 2) ? wz1 : wz0);
+            w[v][k] = ok ? wk : 0.f;
+            // inside the staged box?  (always, for a valid tap, unless the slack was exceeded)
+            const bool inbox = ok && cx >= b0[0] && cx < b0[0] + bxs && cy >= b0[1] && cy < b0[1] + bys &&
+                               cz >= b0[2] && cz < b0[2] + bzs;
+            miss = miss || (ok && !inbox);
+            const unsigned int lo16 = inbox ? (unsigned int)(base + (k >> 2) * bys * FBBEV_HW_PITCH + ((k >> 1) & 1) * FBBEV_HW_PITCH + (k & 1)) : 0u;
+            loff[v][k >> 1] |= lo16 << (16 * (k & 1));
+        }
+    }
+    // one valid tap outside its box anywhere in the workgroup -> the whole brick gathers from global memory
+    __shared__ int any_miss;
+    if (tid == 0) any_miss = 0;
+    __syncthreads();
+    if (miss) any_miss = 1;
+    __syncthreads();
+    use_lds = use_lds && any_miss == 0;
+    const int c0 = grp * ch_per_block;
+    const int c1 = (c0 + ch_per_block < CH) ? c0 + ch_per_block : CH;
+    const int rows = bzs * bys;
+    for (int c = c0; c < c1; ++c) {
+        const long long so = (long long)b * hist_stride_b + (long long)c * ZYX;
+        const long long dof = (long long)b * out_stride_b + (long long)c * ZYX;
+        if (use_lds && !empty) {
+            __syncthreads();                                       // the previous channel's taps are done
+            for (int r = wave; r < rows; r += 16) {                // a wave stages whole rows: coalesced along x
+                const int bz = r / bys, by = r - bz * bys;
+                const long long g = so + ((long long)(b0[2] + bz) * Y + (b0[1] + by)) * X + b0[0];
+                for (int xx = lane; xx < bxs; xx += 64) box[r * FBBEV_HW_PITCH + xx] = fbbev_ld_elem<ET>(hist, g + xx);
+            }
+            __syncthreads();
+        }
+        if (use_lds) {
+#pragma unroll
+            for (int v = 0; v < FBBEV_HW_VPT; ++v) {
+                fbbev_sched_fence();                      // one voxel's 8 LDS taps at a time: 16 waves per CU hide the latency
+                if (vox[v] < 0) continue;
+                float s0 = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float a = empty ? 0.f : box[(loff[v][k >> 1] >> (16 * (k & 1))) & 0xffffu];
+                    s0 = fmaf(a, w[v][k], s0);
+                }
+                fbbev_st_elem<ET>(out, dof + vox[v], s0);
+            }
+        } else {
+#pragma unroll
+            for (int v = 0; v < FBBEV_HW_VPT; ++v) {     // rare path (large rotations): the tap positions are re-derived here
+                fbbev_sched_fence();                      // so that the common path carries no state for it
+                if (vox[v] < 0) continue;
+                const int x = vox[v] % X, y = (vox[v] / X) % Y, z = vox[v] / YX;
+                float ix, iy, iz;
+                src((float)x, (float)y, (float)z, ix, iy, iz);
+                const bool fin = (fabsf(ix) < 1.0e9f) && (fabsf(iy) < 1.0e9f) && (fabsf(iz) < 1.0e9f);
+                const int x0 = fin ? (int)floorf(ix) : -2, y0 = fin ? (int)floorf(iy) : -2, z0 = fin ? (int)floorf(iz) : -2;
+                float s0 = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int cx = x0 + (k & 1), cy = y0 + ((k >> 1) & 1), cz = z0 + (k >> 2);
+                    const bool ok = cx >= 0 && cx < X && cy >= 0 && cy < Y && cz >= 0 && cz < Z;
+                    s0 = fmaf(fbbev_ld_elem<ET>(hist, so + (ok ? (cz * Y + cy) * X + cx : 0)), w[v][k], s0);
+                }
+                fbbev_st_elem<ET>(out, dof + vox[v], s0);
+            }
+        }
     }
 }

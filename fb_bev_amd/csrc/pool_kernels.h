@@ -313,7 +313,13 @@ __device__ __forceinline__ unsigned int fbbev_pack2(float lo, float hi) {
     }
 }
 
-template <int TV, int CPL, int ST, int NT, int OT>
+// T16 (16-bit output, no addend): the LDS tile itself holds 16-bit elements.  A voxel's sum is complete when it is
+// written to the tile (one lane group accumulates the whole interval in registers), so rounding it there is the same
+// single rounding as rounding at the store -- but the tile is half the size: a workgroup can own twice the voxels at the
+// same LDS footprint and keeps the same number of OUTPUT bytes in flight per CU as the fp32 kernel (with an fp32 tile the
+// 16-bit variants were bound by the latency of the dependent-load chain at half the bytes per workgroup: 0.42 of the HBM
+// peak at BASELINE configs[1], profiles/r01_bench_storage_variants.jsonl).
+template <int TV, int CPL, int ST, int NT, int OT, bool T16 = false>
 __global__ void __launch_bounds__(NT)
 k_pool_fwd_dense2(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_blocks, int swizzle,
                   long long out_stride_b, long long out_stride_c,
@@ -322,11 +328,14 @@ k_pool_fwd_dense2(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_b
                   const int* __restrict__ interval_rank, const int* __restrict__ starts,
                   const int* __restrict__ lengths, const int* __restrict__ tile_meta,
                   const float* __restrict__ addend, float* __restrict__ out) {
-    constexpr int LD = TV + 4;
+    static_assert(!T16 || OT != 0, "a 16-bit tile only for 16-bit output");
+    constexpr int LD = T16 ? TV + 8 : TV + 4;  // tile row pitch in ELEMENTS (16-byte aligned rows either way)
     constexpr int Q4 = TV / 4;
     const int CC = C / csplit;                 // channels handled by this block
-    float* tile = fbbev_dyn_lds_f32();         // [CC][LD]
-    int* ist = reinterpret_cast<int*>(tile + CC * LD);   // [TV] interval start relative to p0
+    float* tile = fbbev_dyn_lds_f32();         // [CC][LD] f32, or [CC][LD] 16-bit when T16
+    unsigned short* tile16 = reinterpret_cast<unsigned short*>(tile);
+    int* ist = T16 ? reinterpret_cast<int*>(tile16 + CC * LD)
+                   : reinterpret_cast<int*>(tile + CC * LD);   // [TV] interval start relative to p0
     int* iln = ist + TV;                       // [TV]
     int* ivx = iln + TV;                       // [TV] voxel offset inside the tile
     int* prd = ivx + TV;                       // [NP_STAGE]
@@ -400,7 +409,11 @@ k_pool_fwd_dense2(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_b
     }
     const int nps = np < FBBEV_NP_STAGE ? np : FBBEV_NP_STAGE;
     for (int j = tid; j < nps; j += NT) { prd[j] = rd[p0 + j]; prf[j] = rf[p0 + j]; }
-    for (int idx = tid; idx < CC * LD; idx += NT) tile[idx] = 0.f;
+    if constexpr (T16) {
+        for (int idx = tid; idx < CC * LD / 2; idx += NT) reinterpret_cast<unsigned int*>(tile16)[idx] = 0u;
+    } else {
+        for (int idx = tid; idx < CC * LD; idx += NT) tile[idx] = 0.f;
+    }
     __syncthreads();
 
     {
@@ -414,9 +427,15 @@ k_pool_fwd_dense2(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_b
                 float acc[CPL];
                 fbbev_interval_sum_staged<CPL, 4>(C, ist[i], iln[i], p0, prd, prf, depth, fbase, rd, rf, acc);
                 if (v >= 0 && v < nv) {
-                    float* dst = tile + (slot * CPL) * LD + v;
+                    if constexpr (T16) {
+                        unsigned short* dst = tile16 + (slot * CPL) * LD + v;
 #pragma unroll
-                    for (int j = 0; j < CPL; ++j) dst[j * LD] = acc[j];
+                        for (int j = 0; j < CPL; ++j) dst[j * LD] = (unsigned short)(fbbev_pack2<OT>(acc[j], 0.f) & 0xffffu);
+                    } else {
+                        float* dst = tile + (slot * CPL) * LD + v;
+#pragma unroll
+                        for (int j = 0; j < CPL; ++j) dst[j * LD] = acc[j];
+                    }
                 }
             }
         }
@@ -431,6 +450,13 @@ k_pool_fwd_dense2(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_b
                 if (ab) val += *reinterpret_cast<const fbbev_v4f*>(ab + (long long)c * YX + j);
                 fbbev_store4<ST>(obase + c * cstride + j, val);
             }
+        }
+    } else if constexpr (T16) {
+        for (int idx = tid; idx < CC * Q8; idx += NT) {
+            const int c = idx / Q8, j = (idx - c * Q8) * 8;
+            if (j < nv)
+                fbbev_store4<ST>(reinterpret_cast<float*>(obase16 + c * cstride + j),
+                                 *reinterpret_cast<const fbbev_v4f*>(tile16 + c * LD + j));
         }
     } else {
         for (int idx = tid; idx < CC * Q8; idx += NT) {

@@ -190,6 +190,8 @@ class LSSViewTransformerFunction3D(nn.Module):
             density = n_cams * self.frustum.shape[0] * self.frustum.shape[1] * self.frustum.shape[2] / float(X * Y * Z)
             dense = density >= 1.0
             tv = self._tile_voxels_arg if self._tile_voxels_arg is not None else (64 if dense else _capi.DEFAULT_TILE_VOXELS)
+            if self._tile_voxels_arg is None and self.out_dtype != torch.float32:
+                tv *= 2     # 16-bit storage: the kernel's LDS tile is 16-bit too -> twice the voxels per workgroup at the same footprint
             fl = self._pool_flags_arg if self._pool_flags_arg is not None else (
                 _capi.pool_flags(csplit=1) if dense else _capi.DEFAULT_POOL_FLAGS)
             self._tiling[n_cams] = (tv, fl)
@@ -383,7 +385,10 @@ class LSSViewTransformerFunction3D(nn.Module):
 
     @property
     def _wo_tile(self):
-        return min(self.tile_voxels, 256)       # fbbev_pool_zmean takes tiles of 64..256 voxels
+        # fbbev_pool_zmean takes tiles of 64..256 voxels; the write-once route adds the refined BEV in the store epilogue,
+        # which keeps an fp32 LDS tile: no doubling for 16-bit storage there
+        tv = self.tile_voxels if self.out_dtype == torch.float32 else self.tile_voxels // 2
+        return min(tv, 256)
 
     def pooled_zmean(self, parts):
         """bev_feat.mean(-1) of the lift-splat output, (B,C,Y,X), without materialising the volume (fbbev_pool_zmean)."""

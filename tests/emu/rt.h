@@ -221,5 +221,22 @@ inline fbbev_v4f fbbev_mfma_f32_16x16x32_bf16(fbbev_bf16x8 a, fbbev_bf16x8 b, fb
     return d;
 }
 
+// IEEE binary16 bits -> binary32, exact (the GPU build uses v_cvt_f32_f16)
+inline float fbbev_f16_bits_to_f32(unsigned int h) {
+    const unsigned int sign = (h & 0x8000u) << 16;
+    unsigned int e = (h >> 10) & 0x1fu, m = h & 0x3ffu, u;
+    if (e == 0) {
+        if (m == 0) u = sign;
+        else {                                              // subnormal half: normalise
+            int sh = 0;
+            while (!(m & 0x400u)) { m <<= 1; ++sh; }
+            u = sign | ((unsigned int)(113 - sh) << 23) | ((m & 0x3ffu) << 13);
+        }
+    } else if (e == 31) u = sign | 0x7f800000u | (m << 13);
+    else u = sign | ((e + 112u) << 23) | (m << 13);
+    float f;
+    __builtin_memcpy(&f, &u, 4);
+    return f;
+}
 inline void fbbev_wave_sync() { emu::wave_barrier(); }
 inline void fbbev_sched_fence() {}

@@ -27,7 +27,7 @@ def _on_emulator(m):
     m.get_lidar_coor = lambda *cam: E.lidar_coor(*m._axes(dev), [c.contiguous().float() for c in cam])
     m.build_index = lambda coor, depth=None, depth_threshold=0.01: pack(E.rank_build(
         coor.contiguous(), *m._grid3(), depth=None if depth is None else depth.contiguous().float(), depth_threshold=depth_threshold))
-    m.build_index_from_cams = lambda *cam: pack(E.lift_rank_build(*m._axes(dev), [c.contiguous().float() for c in cam], *m._grid3())[:7])
+    m.build_index_from_cams = lambda *cam, cached=False: pack(E.lift_rank_build(*m._axes(dev), [c.contiguous().float() for c in cam], *m._grid3())[:7])
 
     def lift_splat(idx, depth, feat):
         Z, Y, X = m.grid_zyx

@@ -658,3 +658,35 @@ def test_history_warp_and_conv_16bit_storage_emulated(dt):
     w1, w2 = torch.randn(C, C, generator=g) * 0.3, torch.randn(Cout, T1 * C, generator=g) * 0.2
     b1 = torch.randn(B * T1, C, generator=g)
     assert torch.equal(E.history_conv(feats, w1, b1, w2, b2), E.history_conv(feats.float(), w1, b1, w2, b2))
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.float16])
+def test_history_warp_lds_staged_equals_gather_kernel_emulated(dt, monkeypatch):
+    """k_history_warp_lds (a brick's source box staged in LDS) == k_history_warp (8 global gathers per output), bit for bit:
+    translation, yaw rotation + translation, a flip (mirrored box), a flow that leaves the grid (empty box, zero padding),
+    a large rotation (box does not fit: per-tap global reads), NaN flow; partial bricks at every border."""
+    g = torch.Generator().manual_seed(7)
+    B, CH, Z, Y, X = 6, 5, 9, 37, 70                                        # 9 planes: two z-bricks; 70: a partial x-brick
+    hist = torch.randn(B, CH, Z, Y, X, generator=g).to(dt)
+    flow = torch.eye(4)[None].repeat(B, 1, 1)
+    flow[0, :3, 3] = torch.tensor([2.5, -1.25, 0.5])
+    c, s = np.cos(0.03), np.sin(0.03)
+    flow[1, :3, :3] = torch.tensor([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]], dtype=torch.float32)
+    flow[1, :3, 3] = torch.tensor([1.7, -0.6, -0.2])
+    flow[2, 0, 0] = -1.0; flow[2, 0, 3] = X - 1.0                           # flip x (bda flip)
+    flow[3, :3, 3] = torch.tensor([500.0, 0.0, 0.0])                        # everything outside
+    c, s = np.cos(0.9), np.sin(0.9)
+    flow[4, :3, :3] = torch.tensor([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]], dtype=torch.float32)
+    flow[4, :3, 3] = torch.tensor([20.0, -10.0, 0.0])                       # 52 degrees: the box of a brick does not fit
+    flow[5, 1, 1] = float('nan')
+    monkeypatch.setenv('FBBEV_HISTORY_WARP', 'direct')
+    ref = E.history_warp(hist, flow)
+    monkeypatch.setenv('FBBEV_HISTORY_WARP', 'lds')
+    got = E.history_warp(hist, flow)
+    assert not torch.isnan(got.float()).any()
+    assert torch.equal(got.view(torch.int16 if dt == torch.float16 else torch.int32), ref.view(torch.int16 if dt == torch.float16 else torch.int32))
+    assert (got[3] == 0).all() and (got[5] == 0).all() and got[0].abs().sum() > 0 and got[4].abs().sum() > 0
+    big = torch.full((B, CH + 3, Z, Y, X), float('nan')).to(dt)             # strided output (channel slice of a ring)
+    E.history_warp(hist, flow, big[:, 3:])
+    assert torch.equal(big[:, 3:].contiguous().view(torch.int16 if dt == torch.float16 else torch.int32),
+                       ref.view(torch.int16 if dt == torch.float16 else torch.int32)) and torch.isnan(big[:, :3].float()).all()

@@ -269,3 +269,34 @@ def test_baseline_config4_grid_16_frame_fp16_history(dev):
     assert (edge == 0).all()                                                     # zero padding outside the grid
     torch.cuda.synchronize()
     print('configs[4] history ring: %.1f GB fp16 per sample' % (m.history_bev.numel() * 2 / 2 ** 30))
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.float16])
+def test_warp_lds_staged_kernel_equals_gather_kernel(dev, dt, monkeypatch):
+    """k_history_warp_lds (source box of a 4096-voxel brick staged in LDS, the default) against k_history_warp (8 global
+    gathers per output): the same taps, weights and fmaf chain -> bit-identical, for a translation, ego yaw + translation,
+    a bda flip, a flow that leaves the grid, a rotation too large for the box (in-kernel gather path) and a NaN flow."""
+    from fb_bev_amd import _capi
+    g = torch.Generator().manual_seed(7)
+    B, CH, Z, Y, X = 6, 24, 8, 100, 100
+    hist = torch.randn(B, CH, Z, Y, X, generator=g).to(dt).to(dev)
+    flow = torch.eye(4)[None].repeat(B, 1, 1)
+    flow[0, :3, 3] = torch.tensor([2.5, -1.25, 0.5])
+    c, s = np.cos(0.03), np.sin(0.03)
+    flow[1, :3, :3] = torch.tensor([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]], dtype=torch.float32)
+    flow[1, :3, 3] = torch.tensor([1.7, -0.6, -0.2])
+    flow[2, 0, 0] = -1.0; flow[2, 0, 3] = X - 1.0
+    flow[3, :3, 3] = torch.tensor([500.0, 0.0, 0.0])
+    c, s = np.cos(0.9), np.sin(0.9)
+    flow[4, :3, :3] = torch.tensor([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]], dtype=torch.float32)
+    flow[4, :3, 3] = torch.tensor([60.0, -20.0, 0.0])
+    flow[5, 1, 1] = float('nan')
+    flow = flow.to(dev)
+    monkeypatch.setenv('FBBEV_HISTORY_WARP', 'direct')
+    ref = _capi.history_warp(hist, flow, torch.empty_like(hist))
+    monkeypatch.setenv('FBBEV_HISTORY_WARP', 'lds')
+    got = _capi.history_warp(hist, flow, torch.full_like(hist, float('nan')))
+    torch.cuda.synchronize()
+    it = torch.int16 if dt == torch.float16 else torch.int32
+    assert torch.equal(got.view(it), ref.view(it))
+    assert (got[3] == 0).all() and (got[5] == 0).all() and got[4].abs().sum() > 0

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Temporal history fusion at FB-OCC sizes: fb_bev_amd.TemporalHistoryFusion (HIP warp + folded GEMMs) vs the
 reference's op sequence (fbocc.py:264-319: generate_grid, F.grid_sample, cats, Conv3d+BN+ReLU x2, clone) written in
-plain torch on the same GPU.   python tools/time_history.py [Y X Z] [B]"""
+plain torch on the same GPU.   python tools/time_history.py [Y X Z] [B] [f32|f16|bf16] [noref]
+(f16 / bf16: the 16-bit history ring of BASELINE configs[4]; noref: skip the torch reference sequence)"""
 import json, os, sys
 import torch
 import torch.nn.functional as F
@@ -65,10 +66,13 @@ def main():
     Y, X, Z = (int(v) for v in sys.argv[1:4]) if len(sys.argv) >= 4 else (100, 100, 8)
     B = int(sys.argv[4]) if len(sys.argv) >= 5 else 1
     C, T = 80, 16
+    dt = {'f32': torch.float32, 'f16': torch.float16, 'bf16': torch.bfloat16}[sys.argv[5] if len(sys.argv) >= 6 else 'f32']
+    noref = 'noref' in sys.argv
+    esz = 4 if dt == torch.float32 else 2
     dev = torch.device('cuda:0')
     torch.manual_seed(0)
     dxv = 80.0 / X
-    m = TemporalHistoryFusion([dxv, dxv, 6.4 / Z], [-40 + dxv / 2, -40 + dxv / 2, -1 + 3.2 / Z], C, T).to(dev).eval()
+    m = TemporalHistoryFusion([dxv, dxv, 6.4 / Z], [-40 + dxv / 2, -40 + dxv / 2, -1 + 3.2 / Z], C, T, history_dtype=dt).to(dev).eval()
     for seq in (m.history_keyframe_time_conv, m.history_keyframe_cat_conv):
         seq[1].running_var.uniform_(0.5, 1.5); seq[1].running_mean.uniform_(-0.2, 0.2)
     ref = TorchReference(m)
@@ -90,19 +94,23 @@ def main():
 
     with torch.no_grad():
         o1 = m.fuse_history(frames[0], metas(True), bda); o1 = m.fuse_history(frames[1], metas(False), bda)
-        r1 = ref.fuse(frames[0], ego_cpu.to(dev), bda, first=True); r1 = ref.fuse(frames[1], ego_cpu.to(dev), bda)
-        err = (o1 - r1).abs().max().item()
-        herr = (m.history_bev - ref.hist).abs().max().item()
+        err = herr = t_ref = None
         t_hip = timed(lambda i: m.fuse_history(frames[i % 3], metas(False), bda))
         ego_dev = ego_cpu.to(dev)
-        t_ref = timed(lambda i: ref.fuse(frames[i % 3], ego_dev, bda))
+        if not noref:
+            r1 = ref.fuse(frames[0], ego_dev, bda, first=True); r1 = ref.fuse(frames[1], ego_dev, bda)
+            m.reset(); o1 = m.fuse_history(frames[0], metas(True), bda); o1 = m.fuse_history(frames[1], metas(False), bda)
+            err = (o1 - r1).abs().max().item()
+            herr = (m.history_bev.float() - ref.hist).abs().max().item()
+            t_ref = timed(lambda i: ref.fuse(frames[i % 3], ego_dev, bda))
         # the warp alone
         from fb_bev_amd import _capi
-        hist = m.history_bev; flow = m.rt_flow(ego_dev, bda); dst = torch.empty_like(ref.hist)
+        hist = m.history_bev; flow = m.rt_flow(ego_dev, bda); dst = torch.empty_like(hist)
         t_warp = timed(lambda i: _capi.history_warp(hist, flow, dst))
-    hist_bytes = B * T * C * Z * Y * X * 4
+    hist_bytes = B * T * C * Z * Y * X * esz
     print(json.dumps({'grid': [Y, X, Z], 'B': B, 'C': C, 'T': T, 'history_MB': round(hist_bytes / 1e6, 1),
-                      'fused_ms': round(t_hip, 4), 'torch_reference_sequence_ms': round(t_ref, 4), 'speedup': round(t_ref / t_hip, 2),
+                      'history_dtype': str(dt).split('.')[-1], 'fused_ms': round(t_hip, 4),
+                      'torch_reference_sequence_ms': None if t_ref is None else round(t_ref, 4), 'speedup': None if t_ref is None else round(t_ref / t_hip, 2),
                       'warp_ms': round(t_warp, 4), 'warp_GBps_read_plus_write': round(2 * hist_bytes / t_warp / 1e6, 1),
                       'max_abs_diff_out': err, 'max_abs_diff_history': herr}))
 
