@@ -980,11 +980,12 @@ extern "C" int fbbev_history_warp_e(const void* history, long long history_strid
     if (out_stride_b == 0) out_stride_b = (long long)CH * zyx;
     if (history_stride_b < (long long)CH * zyx || out_stride_b < (long long)CH * zyx) return FBBEV_E_BADARG;
     fbbev_rt_stream stream = (fbbev_rt_stream)stream_;
-    // LDS-staged bricks (the default when the grid is big enough for a 4096-voxel brick); FBBEV_HISTORY_WARP=direct keeps
-    // the gather kernel (A/B timing, tests)
+    // FBBEV_HISTORY_WARP=lds selects the LDS-staged brick kernel (k_history_warp_lds: bit-identical, but as built --
+    // one 1024-thread workgroup per CU, staging and taps of a channel serialised by two barriers -- 3x SLOWER than the
+    // gather kernel on MI355X, profiles/r02_time_history_lds_vs_gather.jsonl; kept for the next iteration, not the default)
     const char* mode = getenv("FBBEV_HISTORY_WARP");
-    const bool direct = mode && mode[0] == 'd';
-    if (!direct && zyx >= 4096 && X >= 16) {
+    const bool lds = mode && mode[0] == 'l';
+    if (lds && zyx >= 4096 && X >= 16) {
         int TX = 64;
         while (TX / 2 >= X) TX /= 2;
         const int BZ = Z < 8 ? Z : 8;

@@ -161,7 +161,11 @@ k_history_warp(const void* __restrict__ hist, long long hist_stride_b, const flo
     }
 }
 
-// ---------------------------------------------------------------- LDS-staged variant
+// ---------------------------------------------------------------- LDS-staged variant (opt-in: FBBEV_HISTORY_WARP=lds)
+// STATUS (round 2, measured): bit-identical to k_history_warp on the GPU, but 3x slower as built (REF 1.05 vs 0.36 ms,
+// 400x400x16 25.6 vs 10.7 ms): with one 1024-thread workgroup per CU the staging loads, the barrier and the taps of a
+// channel run back to back with nothing to overlap them.  What it needs next: 256-thread bricks (4 workgroups per CU) or a
+// register-prefetched double buffer, and several channels per staging round.  Not the default.
 // k_history_warp above is bound by the vector L1's access rate (8 dword gathers per output: 0.30 of the HBM peak; with a
 // 16-bit ring the same gathers move half the bytes: 0.20): for the near-rigid flows of ego motion the 8 taps of
 // neighbouring voxels overlap 8-fold.  Here a 1024-thread workgroup owns an output brick of BZ x TY x TX <= 4096 voxels
