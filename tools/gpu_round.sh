@@ -1,46 +1,21 @@
 #!/bin/bash
-# One GPU-box session: smoke, GPU parity tests, bench, rocprofv3 (kernel trace + PMC passes).
-# Usage (from the build container):  gpurun --timeout 1500 -- 'bash tools/gpu_round.sh [quick]'
-REPO=$(pwd)
-OUT=$REPO/gpurun_out
-mkdir -p $OUT
-export TMPDIR=/tmp
+# One GPU-box validation session: smoke, the whole GPU suite, bench (f32 + bf16 storage), rocprofv3 kernel stats and the
+# FETCH_SIZE / WRITE_SIZE passes behind roofline.traffic.       gpurun --timeout 1500 -- 'bash tools/gpu_round.sh [quick]'
+REPO=$(pwd); OUT=$REPO/gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
 MODE=${1:-full}
-{
-echo "== $(date) mode=$MODE"
-rocminfo 2>/dev/null | grep -E "Marketing Name|gfx9|Compute Unit" | sort | uniq -c | head -8
-nproc; grep -m1 "model name" /proc/cpuinfo
-} > $OUT/box.txt 2>&1
-
-timeout 600 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?" | tee -a $OUT/box.txt
-tail -3 $OUT/smoke.log
-
-timeout 1200 python -m pytest tests -m gpu -q --timeout 300 -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1
-echo "pytest rc=$?" | tee -a $OUT/box.txt
-tail -25 $OUT/pytest_gpu.log
-
-timeout 600 python bench.py --steps 30 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?" | tee -a $OUT/box.txt
-cat $OUT/bench.json; tail -5 $OUT/bench.err
-
+{ echo "== $(date) mode=$MODE"; rocminfo 2>/dev/null | grep -E "Marketing Name|gfx9|Compute Unit" | sort | uniq -c | head -8; nproc; grep -m1 "model name" /proc/cpuinfo; } > $OUT/box.txt 2>&1
+timeout 600 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?" | tee -a $OUT/box.txt; tail -2 $OUT/smoke.log
+timeout 1200 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/box.txt; tail -4 $OUT/pytest_gpu.log | cut -c1-300
+timeout 600 python bench.py --steps 30 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?" | tee -a $OUT/box.txt; cut -c1-2200 $OUT/bench.json; tail -3 $OUT/bench.err
 if [ "$MODE" != "quick" ]; then
-  for b in 1 4 32; do
-    timeout 300 python bench.py --steps 20 --warmup 5 --batch $b --no-cpu-baseline > $OUT/bench_b$b.json 2>> $OUT/bench.err
-    cat $OUT/bench_b$b.json
-  done
+  timeout 300 python bench.py --steps 30 --warmup 5 --storage bf16 --no-cpu-baseline > $OUT/bench_bf16.json 2>> $OUT/bench.err; cut -c1-300 $OUT/bench_bf16.json
   cd /tmp
   rm -rf $OUT/prof_stats $OUT/prof_fetch $OUT/prof_write
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -- python $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/prof_stats.log 2>&1
-  echo "rocprof stats rc=$?" | tee -a $OUT/box.txt
-  timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/prof_fetch -- python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/prof_fetch.log 2>&1
-  echo "rocprof fetch rc=$?" | tee -a $OUT/box.txt
-  timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/prof_write -- python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/prof_write.log 2>&1
-  echo "rocprof write rc=$?" | tee -a $OUT/box.txt
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -- python $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/prof_stats.log 2>&1; echo "rocprof stats rc=$?" | tee -a $OUT/box.txt
+  timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/prof_fetch -- python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/prof_fetch.log 2>&1; echo "rocprof fetch rc=$?" | tee -a $OUT/box.txt
+  timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/prof_write -- python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/prof_write.log 2>&1; echo "rocprof write rc=$?" | tee -a $OUT/box.txt
   cd $REPO
   python tools/pmc_to_json.py $OUT BL2_B16_tv128
   find $OUT -name "*.csv" -size +20M -delete
-  if [ "$MODE" == "sweep" ]; then
-    timeout 400 python tools/sweep_pool.py REF 16 > $OUT/sweep_REF_16.jsonl 2>> $OUT/sweep.err
-    timeout 400 python tools/sweep_pool.py BL5 4 > $OUT/sweep_BL5_4.jsonl 2>> $OUT/sweep.err
-  fi
 fi
 echo "== done $(date)" >> $OUT/box.txt
