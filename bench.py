@@ -48,6 +48,13 @@ def parse():
     ap.add_argument('--storage', choices=['f32', 'bf16', 'f16'], default='f32',
                     help='element type the BEV volume is STORED in (sums are always fp32); the reference is f32')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--pipeline', choices=['alternate', 'graphs'], default='alternate',
+                    help='--streams > 1: launch the steps eagerly on alternating streams, or replay one captured hipGraph per stream')
+    ap.add_argument('--streams', type=int, default=1,
+                    help='forward mode, N=1, experiment: after the timed loop, time the same steps once more with consecutive '
+                         'batches on this many HIP streams (the rank build of batch i+1 may overlap the pooling of batch i); '
+                         'reported as the extra "pipelined" object, never as `value`.  Measured gain on MI355X: 4-12 %, not '
+                         'stable (profiles/r02_exp_stream_overlap.jsonl), so off by default')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--mode', choices=['forward', 'train'], default='forward')
     ap.add_argument('--sync-bn', action='store_true', help="train mode: cross-rank statistics for the config's SyncBN layers "
@@ -227,6 +234,68 @@ def run_forward(args):
     elapsed = time.perf_counter() - t0
     elapsed = shard.max_over_ranks(elapsed, dev)
 
+    # Extra leg (reported beside `value`, not as it): consecutive batches on alternating HIP streams, each with its own index
+    # workspace and output volume.  The ranking kernels are short latency-bound launches (<= 256 workgroups) that leave
+    # most of the chip idle; on a second stream they run under the HBM-bound pooling kernel of the previous batch.
+    piped = None
+    if world == 1 and args.streams > 1:
+        ns = args.streams
+        ctxs = [(vt, tile_ws, out)]
+        for _ in range(ns - 1):
+            v2 = LSSViewTransformerFunction3D(cfg.grid_config, cfg.input_size, cfg.downsample, tile_voxels=args.tile_voxels,
+                                              pool_flags=args.pool_flags, out_dtype=store_dt).to(dev)
+            v2.tiling(cfg.n_cams)
+            ctxs.append((v2, v2._tile_ws(dev, B, args.tile_voxels), torch.empty_like(out)))
+        streams = [torch.cuda.Stream(dev) for _ in range(ns)]
+
+        def pstep(i):
+            v, tws, o = ctxs[i % ns]
+            with torch.cuda.stream(streams[i % ns]):
+                ix = v.build_index_from_cams(*cam)
+                ft = _capi.nchw_to_nhwc(ctx)
+                _capi.pool_tile_index(ix.interval_rank, ix.interval_starts, ix.counts, ix.n, B, Z, Y, X, tws, args.tile_voxels)
+                _capi.bev_pool_v2_dense_fwd(depth, ft, ix.ranks_depth, ix.ranks_feat, ix.interval_rank, ix.interval_starts,
+                                            ix.interval_lengths, B, C, Z, Y, X, o, tws, args.tile_voxels, flags)
+
+        if args.pipeline == 'graphs':
+            # every stream's step captured once into a hipGraph (the whole step is capturable: no host sync, device-side
+            # counts), replayed alternately: no per-kernel host launch cost left in the loop
+            graphs = []
+            for k in range(ns):
+                fence()
+                pstep(k)
+                fence()
+                gk = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gk, stream=streams[k]):
+                    v, tws, o = ctxs[k]
+                    ix = v.build_index_from_cams(*cam)
+                    ft = _capi.nchw_to_nhwc(ctx)
+                    _capi.pool_tile_index(ix.interval_rank, ix.interval_starts, ix.counts, ix.n, B, Z, Y, X, tws, args.tile_voxels)
+                    _capi.bev_pool_v2_dense_fwd(depth, ft, ix.ranks_depth, ix.ranks_feat, ix.interval_rank, ix.interval_starts,
+                                                ix.interval_lengths, B, C, Z, Y, X, o, tws, args.tile_voxels, flags)
+                graphs.append(gk)
+
+            def pstep(i):  # noqa: F811
+                with torch.cuda.stream(streams[i % ns]):
+                    graphs[i % ns].replay()
+
+        fence()
+        for i in range(max(args.warmup, 2 * ns)):
+            pstep(i)
+        fence()
+        tp = time.perf_counter()
+        for i in range(args.steps):
+            pstep(i)
+        fence()
+        tp = time.perf_counter() - tp
+        same = all(torch.equal(o, out) for _, _, o in ctxs[1:])     # every stream's volume == the single-stream one
+        piped = {'streams': ns, 'scheme': args.pipeline, 'value': B * args.steps / tp, 'unit': 'samples/s', 'ms_per_step': 1e3 * tp / args.steps,
+                 'volumes_identical_to_single_stream': bool(same),
+                 'what': 'the same K steps, batch i on stream i % streams with its own index workspace and output volume: the '
+                         'rank build of batch i+1 runs under the pooling kernel of batch i'}
+        del ctxs, streams
+
+
     kern_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)
     step_ms = sorted(a.elapsed_time(b) for a, b in sev)
     pct = lambda q: step_ms[min(len(step_ms) - 1, int(q * len(step_ms)))] if step_ms else None  # noqa: E731
@@ -277,6 +346,8 @@ def run_forward(args):
                          'algorithmic_bytes_per_launch': algo_bytes, 'kernel_ms': kern_ms,
                          'device_fill_GBps': fill_gbs, 'frac_of_device_fill': achieved / fill_gbs if fill_gbs > 0 else None},
         }
+        if piped is not None:
+            res['pipelined'] = piped
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(cfg, args.cpu_seconds)
             res['gpu_over_cpu'] = res['value'] / res['cpu_baseline']['value']

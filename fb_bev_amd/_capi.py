@@ -21,6 +21,7 @@ SIGNATURES = {
     'fbbev_bev_pool_v2_bwd': (c_int, [c_int, c_int] + [c_void_p] * 10 + [c_void_p]),
     'fbbev_lidar_coor': (c_int, [c_void_p] * 9 + [c_int] * 5 + [c_void_p, c_void_p]),
     'fbbev_nchw_to_nhwc': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'fbbev_tokens_from_nchw': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_void_p, c_int, c_void_p]),
     'fbbev_rank_workspace_bytes': (c_size_t, [c_int64]),
     'fbbev_rank_build': (c_int, [c_void_p] + [c_int] * 5 + [c_void_p] * 3 + [c_void_p] * 7 +
                          [c_void_p, c_size_t, c_void_p]),
@@ -351,8 +352,9 @@ def msda_fwd(value, spatial_shapes, level_start_index, sampling_loc, attn_weight
 
 
 def msda_fwd_fused(value, spatial_shapes, level_start_index, ref_points, offsets, attn_weight, out, head_dim=None,
-                   offsets_head_minor=False):
-    """value (B,S,M,HS); ref_points (B,Q,L,2); offsets (B,Q,M,L,P,2) or head-minor (B,Q,L,P,M,2); attn (B,Q,M,L,P)."""
+                   offsets_head_minor=False, value_interleaved=False):
+    """value (B,S,M,HS); ref_points (B,Q,L,2); offsets (B,Q,M,L,P,2) or head-minor (B,Q,L,P,M,2); attn (B,Q,M,L,P).
+    value_interleaved: a token's M*HS floats are stored (HS/4, M, 4) -- chunk-major -- instead of (M, HS)."""
     B, S, M, HS = value.shape
     Dh = HS if head_dim is None else int(head_dim)
     _, Q, _, L, P = attn_weight.shape
@@ -361,7 +363,8 @@ def msda_fwd_fused(value, spatial_shapes, level_start_index, ref_points, offsets
             _dev(value, F32, 'value'), _dev(spatial_shapes, I64, 'spatial_shapes'),
             _dev(level_start_index, I64, 'level_start_index'), _dev(ref_points, F32, 'ref_points'),
             _dev(offsets, F32, 'offsets'), _dev(attn_weight, F32, 'attn_weight'), B, S, M, Dh, L, Q, P, HS,
-            1 if offsets_head_minor else 0, _dev(out, F32, 'out'), _stream()), 'fbbev_msda_fwd_fused')
+            (1 if offsets_head_minor else 0) | (4 if value_interleaved else 0), _dev(out, F32, 'out'), _stream()),
+            'fbbev_msda_fwd_fused')
     return out
 
 
@@ -383,7 +386,7 @@ def da_cross_attn_fwd(value, spatial_shapes, level_start_index, pred_depth, ref_
                       attn, d0, dstep, slots, head_minor=0, head_dim=None):
     """value (B*Ncam,S,M,Dh); pred_depth (B*Ncam,DC,H0,W0); ref_cam (Ncam,B,Q,Za,2); mask (Ncam,B,Q,Za) bool;
     qdepth (Ncam,B,Q,Za); offsets (B,Q,M,L,P,2); attn (B,Q,M,L,P); head_minor bit 0: offsets is (B,Q,L,P,M,2),
-    bit 1: attn is (B,Q,L,P,M); slots (B,Q,M*Dh)."""
+    bit 1: attn is (B,Q,L,P,M), bit 2: a value token's M*HS floats are stored (HS/4, M, 4); slots (B,Q,M*Dh)."""
     Ncam, B, Q, Za = mask.shape
     _, S, M, HS = value.shape                 # HS = head stride; head_dim (<= HS) of them are channels, the rest padding
     Dh = HS if head_dim is None else int(head_dim)
@@ -450,6 +453,31 @@ def nchw_to_nhwc(context):
         _check(lib().fbbev_nchw_to_nhwc(_dev(context, F32, 'context'), _dev(feat, F32, 'feat'), B * N, C, H * W,
                                         _stream()), 'fbbev_nchw_to_nhwc')
     return feat
+
+
+def tokens_from_nchw(x, out, out_offset=0, bias=None):
+    """x (n_images, C, HW) f32 contiguous -> out[img, out_offset/C + p, c] = x[img, c, p] (+ bias[img % rows, c]);
+    out (n_images, S, C) contiguous with S >= HW rows per image; out_offset in floats."""
+    n, C, HW = x.shape
+    if out.shape[0] != n or out.shape[-1] != C or not out.is_contiguous():
+        raise FbbevError('tokens_from_nchw: out must be (n_images, S, C) contiguous')
+    stride = out.stride(0)
+    if out_offset + C * HW > stride:
+        raise FbbevError('tokens_from_nchw: level does not fit the token rows')
+    with _on(x):
+        _check(lib().fbbev_tokens_from_nchw(
+            _dev(x, F32, 'x'), _dev(out, F32, 'out'), n, C, HW, stride, int(out_offset),
+            None if bias is None else _dev(bias, F32, 'bias'), 0 if bias is None else bias.shape[0], _stream()),
+            'fbbev_tokens_from_nchw')
+    return out
+
+
+def transpose_last2(x):
+    """(B, R, S) f32 contiguous -> (B, S, R) contiguous, LDS-tiled (torch's .transpose().contiguous() runs its
+    generic strided copy at ~0.7 TB/s on these shapes)."""
+    B, R, S = x.shape
+    out = torch.empty((B, S, R), dtype=torch.float32, device=x.device)
+    return tokens_from_nchw(x, out)
 
 
 def history_flow(history_forward_augs, curr_to_prev_ego_rt, bda, dx3, lower3):

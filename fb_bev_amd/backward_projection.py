@@ -185,17 +185,14 @@ class MultiScaleDeformableAttention(nn.Module):
             # aligned 16-byte loads (value_proj rows padded once, like DA_MSDeformableAttention)
             HS = (Dh + 3) // 4 * 4
             w, b = self.value_proj.weight, self.value_proj.bias
-            if HS != Dh:
-                # data_ptr: a storage swap (param.data = ..., load_state_dict(assign=True), EMA) does not bump _version
-                key = (w._version, b._version, w.data_ptr(), b.data_ptr(), w.device)
-                if getattr(self, '_vpad_key', None) != key:
-                    M, E = self.num_heads, w.shape[1]
-                    with torch.no_grad():
-                        self._vpad = (F.pad(w.view(M, Dh, E), (0, 0, 0, HS - Dh)).reshape(M * HS, E).contiguous(),
-                                      F.pad(b.view(M, Dh), (0, HS - Dh)).reshape(-1).contiguous())
-                    self._vpad_key = key
-                w, b = self._vpad
-            value = F.linear(value, w, b).view(bs, num_value, self.num_heads, HS)
+            # data_ptr: a storage swap (param.data = ..., load_state_dict(assign=True), EMA) does not bump _version
+            key = (w._version, b._version, w.data_ptr(), b.data_ptr(), w.device)
+            if getattr(self, '_vpad_key', None) != key:
+                with torch.no_grad():
+                    self._vpad = _pad_interleave_rows(w, b, self.num_heads, Dh, HS)
+                self._vpad_key = key
+            w, b = self._vpad
+            value = F.linear(value, w, b).view(bs, num_value, self.num_heads, HS)   # stored (HS/4, M, 4) per token
             so = self.sampling_offsets(query)
             aw = self.attention_weights(query).view(bs, num_query, self.num_heads, -1).softmax(-1)
             aw = aw.view(bs, num_query, self.num_heads, self.num_levels, self.num_points)
@@ -203,7 +200,7 @@ class MultiScaleDeformableAttention(nn.Module):
             ref = reference_points.expand(bs, num_query, self.num_levels, 2).contiguous()
             _capi.msda_fwd_fused(value, spatial_shapes.to(torch.int64).contiguous(),
                                  level_start_index.to(torch.int64).contiguous(), ref, so.contiguous(), aw.contiguous(),
-                                 out, head_dim=Dh)
+                                 out, head_dim=Dh, value_interleaved=True)
             out = self.output_proj(out)
             if not self.batch_first:
                 out = out.permute(1, 0, 2)
@@ -348,6 +345,17 @@ class FusedDACrossAttention(torch.autograd.Function):
         return gv, gd, go, ga, None, None, None, None, None, None, None, None, None
 
 
+def _pad_interleave_rows(w, b, M, Dh, HS):
+    """value_proj rows for the fused kernels: each head padded Dh -> HS (multiple of 4) output rows, then the rows of a
+    token reordered (head m, chunk k, e) -> (chunk k, head m, e): the 8 head lanes of a query read one contiguous
+    M*16-byte piece per load instruction (k_da_cross_attn_fwd_unit, QI).  Same dot products, only the row order of the
+    weight matrix changes; differentiable (pad + permute of the parameter)."""
+    E = w.shape[1]
+    w = F.pad(w.view(M, Dh, E), (0, 0, 0, HS - Dh)).view(M, HS // 4, 4, E).permute(1, 0, 2, 3).reshape(M * HS, E)
+    b = F.pad(b.view(M, Dh), (0, HS - Dh)).view(M, HS // 4, 4).permute(1, 0, 2).reshape(M * HS)
+    return w.contiguous(), b.contiguous()
+
+
 FUSED_BWD_MAX_HEAD_DIM = 32                 # k_da_cross_attn_bwd: one lane per channel, groups of 16 / 32 lanes
 
 
@@ -378,32 +386,27 @@ class DA_SpatialCrossAttention(nn.Module):
         Dh = E // M
         HS = (Dh + 3) // 4 * 4
         x = value.permute(2, 0, 1, 3).reshape(B * ncam, S, E)
-        if HS != Dh:
-            # value_proj with its output rows padded per head (Dh = 10 -> 12 floats): every head chunk of a camera token is
-            # then 16-byte aligned and the kernel reads a bilinear corner with 3 dwordx4 loads instead of 5 eight-byte
-            # ones.  Same dot products for the real rows; the padding rows are zero and ignored by the kernel.
-            wt, bs = da.value_proj.weight, da.value_proj.bias
+        # value_proj with its output rows padded per head (Dh = 10 -> 12 floats) and stored chunk-major per token
+        # (_pad_interleave_rows): every 4-channel chunk of a head is 16-byte aligned and the 8 heads' chunks are adjacent.
+        # Same dot products for the real rows; the padding rows are zero and ignored by the kernel.
+        wt, bs = da.value_proj.weight, da.value_proj.bias
+        if torch.is_grad_enabled() and (wt.requires_grad or bs.requires_grad):
+            w, bb = _pad_interleave_rows(wt, bs, M, Dh, HS)
+        else:                               # inference: once per weight version
             key = (wt.data_ptr(), wt._version, bs._version, str(wt.device))
-            if torch.is_grad_enabled() and (wt.requires_grad or bs.requires_grad):
-                w = F.pad(wt.view(M, Dh, E), (0, 0, 0, HS - Dh)).reshape(M * HS, E)
-                bb = F.pad(bs.view(M, Dh), (0, HS - Dh)).reshape(M * HS)
-            else:                           # inference: pad once per weight version
-                if getattr(self, '_vpad_key', None) != key:
-                    with torch.no_grad():
-                        self._vpad = (F.pad(wt.view(M, Dh, E), (0, 0, 0, HS - Dh)).reshape(M * HS, E).contiguous(),
-                                      F.pad(bs.view(M, Dh), (0, HS - Dh)).reshape(M * HS).contiguous())
-                    self._vpad_key = key
-                w, bb = self._vpad
-            v = F.linear(x, w, bb).view(B * ncam, S, M, HS)
-        else:
-            v = da.value_proj(x).view(B * ncam, S, M, Dh)
+            if getattr(self, '_vpad_key', None) != key:
+                with torch.no_grad():
+                    self._vpad = _pad_interleave_rows(wt, bs, M, Dh, HS)
+                self._vpad_key = key
+            w, bb = self._vpad
+        v = F.linear(x, w, bb).view(B * ncam, S, M, HS)           # a token's M*HS floats are (HS/4, M, 4)
         so, aw = da.project_head_minor(query)
         DC, H0, W0 = pred_img_depth.shape[2:]
         return FusedDACrossAttention.apply(
             v.contiguous().float(), pred_img_depth.reshape(B * ncam, DC, H0, W0).contiguous().float(),
             so.contiguous().float(), aw.contiguous().float(), spatial_shapes.to(torch.int64).contiguous(),
             level_start_index.to(torch.int64).contiguous(), reference_points_cam.contiguous().float(), mask.contiguous(),
-            bev_query_depth.squeeze(-1).contiguous().float(), self.dbound[0], self.dbound[2], 1, Dh)
+            bev_query_depth.squeeze(-1).contiguous().float(), self.dbound[0], self.dbound[2], 1 | 4, Dh)
 
     # ---- training: vectorised rebatch + composite deformable attention (autograd through the MSDA op)
     def _slots_composite(self, query, value, reference_points_cam, mask, bev_query_depth, pred_img_depth,
@@ -635,6 +638,7 @@ class BEVFormer(nn.Module):
         self.encoder = build(encoder)
         self.embed_dims, self.num_cams, self.output_dims = embed_dims, num_cams, output_dims
         self.use_cams_embeds = use_cams_embeds
+        self.fused_tokens = True
         self.cams_embeds = nn.Parameter(torch.Tensor(num_cams, embed_dims))
         self.init_weights()
 
@@ -650,15 +654,32 @@ class BEVFormer(nn.Module):
     def forward(self, mlvl_feats, bev_queries, bev_h, bev_w, bev_pos=None, cam_params=None, gt_bboxes_3d=None,
                 pred_img_depth=None, prev_bev=None, bev_mask=None, **kwargs):
         bev_pos = bev_pos.flatten(2).permute(2, 0, 1)
-        feats, shapes = [], []
-        for feat in mlvl_feats:
-            _, _, c, h, w = feat.shape
-            f = feat.flatten(3).permute(1, 0, 3, 2)
-            ce = self.cams_embeds[:, None, None, :].to(f.dtype)
-            f = f + (ce if self.use_cams_embeds else ce * 0)
-            shapes.append((h, w))
-            feats.append(f)
-        feat_flatten = torch.cat(feats, 2)
+        shapes = [tuple(feat.shape[-2:]) for feat in mlvl_feats]
+        f0 = mlvl_feats[0]
+        needs_grad = torch.is_grad_enabled() and (self.cams_embeds.requires_grad or any(f.requires_grad for f in mlvl_feats))
+        if (self.fused_tokens and f0.is_cuda and f0.dtype == torch.float32 and not needs_grad and f0.shape[1] == self.num_cams
+                and all(f.shape[:3] == f0.shape[:3] for f in mlvl_feats)):
+            # inference: one transposing pass per level (fbbev_tokens_from_nchw) writes feat + cams_embeds straight into the
+            # (bs*num_cam, sum HW, C) token rows the cross-attention's value projection reads -- the flatten/permute/add,
+            # the cat and the rebatch permute of the reference (three copies of the camera features) in one.  What the
+            # encoder receives is the reference's (num_cam, sum HW, bs, C) tensor as a VIEW of those rows.
+            bs, ncam, c = f0.shape[:3]
+            S = sum(h * w for h, w in shapes)
+            rows = torch.empty((bs * ncam, S, c), dtype=torch.float32, device=f0.device)
+            ce = self.cams_embeds.detach().to(torch.float32)
+            ce = (ce if self.use_cams_embeds else ce * 0).contiguous()
+            start = 0
+            for feat, (h, w) in zip(mlvl_feats, shapes):
+                _capi.tokens_from_nchw(feat.reshape(bs * ncam, c, h * w).contiguous(), rows, start * c, ce)
+                start += h * w
+            feat_flatten = rows.view(bs, ncam, S, c).permute(1, 0, 2, 3)            # (num_cam, bs, sum HW, C)
+        else:
+            feats = []
+            for feat in mlvl_feats:
+                f = feat.flatten(3).permute(1, 0, 3, 2)
+                ce = self.cams_embeds[:, None, None, :].to(f.dtype)
+                feats.append(f + (ce if self.use_cams_embeds else ce * 0))
+            feat_flatten = torch.cat(feats, 2)
         if pred_img_depth is not None and tuple(pred_img_depth.shape[-2:]) != tuple(shapes[0]):
             # the depth distribution is sampled on spatial_shapes[0:1] (spatial_cross_attention_depth.py:586):
             # level 0 must be the level the depth net ran on, or the sampling would index past the depth map
@@ -700,9 +721,20 @@ class BackwardProjection(nn.Module):
         dtype = mlvl_feats[0].dtype
         # (Q,bs,C) as backward_projection.py:96-99 -- built batch-major so that the encoder's permute(1,0,2) yields
         # contiguous (bs,Q,C) tokens (the Linear layers then take them without a copy); same sums element for element
+        fast = (lss_bev is not None and lss_bev.is_cuda and lss_bev.dtype == torch.float32 and
+                not (torch.is_grad_enabled() and (lss_bev.requires_grad or self.bev_embedding.weight.requires_grad)))
         if lss_bev is not None:
-            tok = lss_bev.flatten(2).transpose(1, 2).contiguous()                       # (bs,Q,C): the one transposition
-            bev_queries = (tok + self.bev_embedding.weight.to(dtype).unsqueeze(0)).permute(1, 0, 2)
+            if fast:                                                                    # LDS-tiled transposition kernel
+                tok = _capi.tokens_from_nchw(lss_bev.reshape(bs, lss_bev.shape[1], -1).contiguous(),
+                                             torch.empty((bs, self.bev_h * self.bev_w, lss_bev.shape[1]),
+                                                         dtype=torch.float32, device=lss_bev.device),
+                                             0, None)
+                # + bev_embedding: the same single fp32 add per element as below
+                tok.add_(self.bev_embedding.weight.detach().unsqueeze(0))
+                bev_queries = tok.permute(1, 0, 2)
+            else:
+                tok = lss_bev.flatten(2).transpose(1, 2).contiguous()                   # (bs,Q,C): the one transposition
+                bev_queries = (tok + self.bev_embedding.weight.to(dtype).unsqueeze(0)).permute(1, 0, 2)
         else:
             bev_queries = self.bev_embedding.weight.to(dtype).unsqueeze(0).repeat(bs, 1, 1).permute(1, 0, 2)
         if bev_mask is not None:
@@ -712,4 +744,6 @@ class BackwardProjection(nn.Module):
                                grid_length=(self.real_h / self.bev_h, self.real_w / self.bev_w), bev_pos=bev_pos,
                                img_metas=img_metas, cam_params=cam_params, gt_bboxes_3d=gt_bboxes_3d,
                                pred_img_depth=pred_img_depth, prev_bev=None, bev_mask=bev_mask)
+        if fast and bev.is_contiguous() and not bev.requires_grad:
+            return _capi.transpose_last2(bev).view(bs, -1, self.bev_h, self.bev_w)
         return bev.permute(0, 2, 1).view(bs, -1, self.bev_h, self.bev_w).contiguous()

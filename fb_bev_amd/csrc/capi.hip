@@ -101,13 +101,21 @@ extern "C" int fbbev_lidar_coor(const float* xs, const float* ys, const float* d
 }
 
 extern "C" int fbbev_nchw_to_nhwc(const float* in, float* out, int n_images, int C, int HW, fbbev_stream_t stream_) {
-    if (n_images < 0 || C <= 0 || HW <= 0) return FBBEV_E_BADARG;
+    return fbbev_tokens_from_nchw(in, out, n_images, C, HW, (long long)C * HW, 0, nullptr, 0, stream_);
+}
+
+extern "C" int fbbev_tokens_from_nchw(const float* in, float* out, int n_images, int C, int HW,
+                                      long long out_image_stride, long long out_offset, const float* bias,
+                                      int bias_rows, fbbev_stream_t stream_) {
+    if (n_images < 0 || C <= 0 || HW <= 0 || out_offset < 0 || out_image_stride < (long long)C * HW) return FBBEV_E_BADARG;
+    if (bias && bias_rows <= 0) return FBBEV_E_BADARG;
     if (n_images == 0) return 0;
     if (!in || !out) return FBBEV_E_BADARG;
     const int tc = (C + 31) / 32, th = (HW + 31) / 32;
     const long long blocks = (long long)n_images * tc * th;
     if (blocks >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
-    FBBEV_LAUNCH(k_nchw_to_nhwc, blocks, 256, 0, (fbbev_rt_stream)stream_, in, out, C, HW, tc, th);
+    FBBEV_LAUNCH(k_nchw_to_nhwc, blocks, 256, 0, (fbbev_rt_stream)stream_, in, out, C, HW, tc, th, out_image_stride,
+                 out_offset, bias, bias ? bias_rows : 1);
     FBBEV_CHECK_LAUNCH();
     return 0;
 }
@@ -749,13 +757,21 @@ extern "C" int fbbev_msda_fwd_fused(const float* value, const int64_t* spatial_s
     if (HS < channels) return FBBEV_E_BADARG;
     if ((((uintptr_t)offsets) & 7) != 0) return FBBEV_E_UNSUPPORTED;
     const bool wide = HS % 4 == 0 && HS >= (channels + 3) / 4 * 4 && aligned16(value);
-    long long ub = (units + 255) / 256;
+    const bool qi = (offsets_head_minor & 4) != 0;                 // value rows stored [chunk][head][4 floats]
+    if (qi && !wide) return FBBEV_E_UNSUPPORTED;
+    if ((long long)batch * spatial_size * num_heads * HS * 4 >= (1ll << 32)) return FBBEV_E_UNSUPPORTED;   // 32-bit byte offsets
+    long long ub = ((units + 255) / 256 + 7) / 8 * 8;             // XCD-contiguous order: a multiple of 8 workgroups
     if (ub > 65536) ub = 65536;
-#define FBBEV_MSDA_UNIT_W(DH_, W_)                                                                                  \
-    FBBEV_LAUNCH((k_msda_fwd_unit<DH_, W_>), ub, 256, 0, (fbbev_rt_stream)stream_, units, value, spatial_shapes,     \
-                 level_start_index, ref_points, offsets, attn_weight, spatial_size, num_heads, num_levels, num_query, \
-                 num_point, HS, offsets_head_minor ? 1 : 0, out)
-#define FBBEV_MSDA_UNIT(DH_) do { if (wide) FBBEV_MSDA_UNIT_W(DH_, true); else FBBEV_MSDA_UNIT_W(DH_, false); } while (0)
+    // attention weights staged through LDS ([256][L*P+1] floats) when they fit beside 4 workgroups per CU
+    const int LP = num_levels * num_point;
+    const bool stage = LP % 4 == 0 && LP <= 36 && aligned16(attn_weight);
+    const size_t lds = stage ? (size_t)256 * (LP + 1) * sizeof(float) : 0;
+#define FBBEV_MSDA_UNIT_W(DH_, W_, Q_)                                                                               \
+    FBBEV_LAUNCH((k_msda_fwd_unit<DH_, W_, Q_>), ub, 256, lds, (fbbev_rt_stream)stream_, units, value,                \
+                 spatial_shapes, level_start_index, ref_points, offsets, attn_weight, spatial_size, num_heads,        \
+                 num_levels, num_query, num_point, HS, (offsets_head_minor & 1) ? 1 : 0, stage ? 1 : 0, out)
+#define FBBEV_MSDA_UNIT(DH_) do { if (qi) FBBEV_MSDA_UNIT_W(DH_, true, true); else if (wide) FBBEV_MSDA_UNIT_W(DH_, true, false); \
+                                  else FBBEV_MSDA_UNIT_W(DH_, false, false); } while (0)
     if (channels == 10) FBBEV_MSDA_UNIT(10);
     else if (channels == 8) FBBEV_MSDA_UNIT(8);
     else if (channels == 16) FBBEV_MSDA_UNIT(16);
@@ -813,16 +829,25 @@ extern "C" int fbbev_da_cross_attn_fwd(const float* value, const int64_t* spatia
     const int HS = head_stride == 0 ? Dh : head_stride;
     if (HS < Dh) return FBBEV_E_BADARG;
     const bool wide = HS % 4 == 0 && HS >= (Dh + 3) / 4 * 4 && aligned16(value);
+    const bool qi = (head_minor & 4) != 0;                         // value rows stored [chunk][head][4 floats]
+    if (qi && !wide) return FBBEV_E_UNSUPPORTED;
     const bool al8 = (((uintptr_t)value | (uintptr_t)offsets | (uintptr_t)slots) & 7) == 0;
-    if (al8 && HS % 2 == 0 && (Dh == 10 || Dh == 8 || Dh == 16 || Dh == 32)) {   // a lane owns all Dh channels of a (b,q,head) unit
+    const bool fits32 = (long long)B * Ncam * S * M * HS * 4 < (1ll << 32);        // unit kernels: 32-bit byte offsets into value
+    if (qi && !fits32) return FBBEV_E_UNSUPPORTED;
+    if (al8 && fits32 && HS % 2 == 0 && (Dh == 10 || Dh == 8 || Dh == 16 || Dh == 32)) {   // a lane owns all Dh channels of a (b,q,head) unit
         const long long units = (long long)B * Q * M;
-        long long ub = (units + 255) / 256;
+        long long ub = ((units + 255) / 256 + 7) / 8 * 8;         // XCD-contiguous order: a multiple of 8 workgroups
         if (ub > 65536) ub = 65536;
-#define FBBEV_DA_UNIT_W(DH_, W_)                                                                                    \
-    FBBEV_LAUNCH((k_da_cross_attn_fwd_unit<DH_, W_>), ub, 256, 0, (fbbev_rt_stream)stream_, units, value,             \
+        // attention weights in (B,Q,M,L,P) staged through LDS ([256][L*P+1] floats) when 4 workgroups per CU still fit
+        const int LP = L * P;
+        const bool stage = !(head_minor & 2) && LP % 4 == 0 && LP <= 36 && aligned16(attn);
+        const size_t lds = stage ? (size_t)256 * (LP + 1) * sizeof(float) : 0;
+#define FBBEV_DA_UNIT_W(DH_, W_, Q_)                                                                                \
+    FBBEV_LAUNCH((k_da_cross_attn_fwd_unit<DH_, W_, Q_>), ub, 256, lds, (fbbev_rt_stream)stream_, units, value,      \
                  spatial_shapes, level_start_index, pred_depth, ref_cam, mask, qdepth, offsets, attn, B, Ncam, S, M, \
-                 L, Q, P, Za, DC, d0, dstep, head_minor & 3, HS, slots)
-#define FBBEV_DA_UNIT(DH_) do { if (wide) FBBEV_DA_UNIT_W(DH_, true); else FBBEV_DA_UNIT_W(DH_, false); } while (0)
+                 L, Q, P, Za, DC, d0, dstep, head_minor & 3, HS, stage ? 1 : 0, slots)
+#define FBBEV_DA_UNIT(DH_) do { if (qi) FBBEV_DA_UNIT_W(DH_, true, true); else if (wide) FBBEV_DA_UNIT_W(DH_, true, false); \
+                                else FBBEV_DA_UNIT_W(DH_, false, false); } while (0)
         if (Dh == 10) FBBEV_DA_UNIT(10);
         else if (Dh == 8) FBBEV_DA_UNIT(8);
         else if (Dh == 16) FBBEV_DA_UNIT(16);
@@ -836,7 +861,7 @@ extern "C" int fbbev_da_cross_attn_fwd(const float* value, const int64_t* spatia
     if (blocks > 65536) blocks = 65536;
     FBBEV_LAUNCH(k_da_cross_attn_fwd, blocks, 256, 0, (fbbev_rt_stream)stream_, n, value, spatial_shapes,
                  level_start_index, pred_depth, ref_cam, mask, qdepth, offsets, attn, B, Ncam, S, M, Dh, L, Q, P,
-                 Za, DC, d0, dstep, head_minor & 3, HS, slots);
+                 Za, DC, d0, dstep, head_minor & 7, HS, slots);
     FBBEV_CHECK_LAUNCH();
     return 0;
 }
@@ -859,10 +884,11 @@ extern "C" int fbbev_da_cross_attn_bwd(const float* value, const int64_t* spatia
     if (Dh > 32) return FBBEV_E_UNSUPPORTED;
     const int HS = head_stride == 0 ? Dh : head_stride;
     if (HS < Dh) return FBBEV_E_BADARG;
+    if ((head_minor & 4) && HS % 4 != 0) return FBBEV_E_UNSUPPORTED;
 #define FBBEV_DA_BWD(GW_)                                                                                             \
     FBBEV_LAUNCH(k_da_cross_attn_bwd<GW_>, (units * GW_ + 255) / 256, 256, 0, (fbbev_rt_stream)stream_, units, value,  \
                  spatial_shapes, level_start_index, pred_depth, ref_cam, mask, qdepth, offsets, attn, grad_slots, B,  \
-                 Ncam, S, M, Dh, L, Q, P, Za, DC, d0, dstep, head_minor & 3, HS, grad_value, grad_pred_depth,        \
+                 Ncam, S, M, Dh, L, Q, P, Za, DC, d0, dstep, head_minor & 7, HS, grad_value, grad_pred_depth,        \
                  grad_offsets, grad_attn)
     if ((units * 32 + 255) / 256 >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
     if (Dh <= 16) FBBEV_DA_BWD(16);

@@ -79,10 +79,11 @@ k_da_cross_attn_fwd(long long n, const float* __restrict__ value, const int64_t*
             float col = 0.f;
             for (int l = 0; l < L; ++l) {
                 const int sh = (int)spatial_shapes[2 * l], sw = (int)spatial_shapes[2 * l + 1];
-                const float* vp = value + (bn * S + level_start[l]) * row_stride + m * HS + c;
+                const float* vp = value + (bn * S + level_start[l]) * row_stride +
+                                  ((head_minor & 4) ? (c >> 2) * (M * 4) + m * 4 + (c & 3) : m * HS + c);
                 for (int p = 0; p < P; ++p) {
                     // offsets / attn: (B,Q,M,L,P[,2]) as the Linear layers emit them, or head-minor (B,Q,L,P,M[,2]):
-                    // head_minor bit 0 -> offsets, bit 1 -> attn
+                    // head_minor bit 0 -> offsets, bit 1 -> attn; bit 2 -> quad-interleaved value rows (see the unit kernel)
                     const long long wm = (unit * L + l) * P + p, wh = ((bq * L + l) * P + p) * M + m;
                     const long long wo = (head_minor & 1) ? wh : wm, wa = (head_minor & 2) ? wh : wm;
                     const int z = p % Za;
@@ -117,21 +118,49 @@ k_da_cross_attn_fwd(long long n, const float* __restrict__ value, const int64_t*
 // WIDE: the head stride HS is a multiple of 4 floats and covers DH rounded up to 4 (the host pads value_proj's output
 // rows, e.g. Dh = 10 -> HS = 12): every head chunk is 16-byte aligned and a corner is read as DHP/4 dwordx4 loads
 // (3 L1 accesses instead of 5 eight-byte ones; the padding floats are loaded and ignored).
-template <int DH, bool WIDE>
+template <int DH, bool WIDE, bool QI>
 __global__ void __launch_bounds__(256)
 k_da_cross_attn_fwd_unit(long long n_units, const float* __restrict__ value, const int64_t* __restrict__ spatial_shapes,
                          const int64_t* __restrict__ level_start, const float* __restrict__ pred_depth,
                          const float* __restrict__ ref_cam, const unsigned char* __restrict__ mask,
                          const float* __restrict__ qdepth, const float* __restrict__ offsets,
                          const float* __restrict__ attn, int B, int Ncam, int S, int M, int L, int Q, int P, int Za,
-                         int DC, float d0, float dstep, int head_minor, int HS, float* __restrict__ slots) {
+                         int DC, float d0, float dstep, int head_minor, int HS, int stage_attn,
+                         float* __restrict__ slots) {
     static_assert(DH % 2 == 0, "eight-byte loads");
-    constexpr int DHP = (DH + 3) / 4 * 4;
-    const int row_stride_unit = HS;
+    static_assert(!QI || WIDE, "quad-interleaved rows are read with 16-byte loads");
+    // QI: a camera token's row is stored [chunk k][head m][4 floats] instead of [head m][HS floats]: the 8 head lanes
+    // of a query then read ONE contiguous M*16-byte piece per load instruction (one 128-byte line at M = 8) where the
+    // head-major row makes every one of the DHP/4 loads touch all of the row's lines.  Same floats, same arithmetic.
+    const int head_off_m = QI ? 4 : HS, chunk_stride = QI ? M * 4 : 4;
     const int row_stride = M * HS;
     const int H0 = (int)spatial_shapes[0], W0 = (int)spatial_shapes[1];
-    for (long long unit = (long long)blockIdx.x * blockDim.x + threadIdx.x; unit < n_units;
-         unit += (long long)gridDim.x * blockDim.x) {
+    const int LP = L * P, LDW = LP + 1;
+    float* staged = fbbev_dyn_lds_f32();          // [256][LP+1] when stage_attn: the workgroup's attention weights
+    // XCD-contiguous order: workgroup w runs on XCD w % 8 (each with its own L2); XCD x takes the x-th eighth of the
+    // unit range -- a contiguous piece of the BEV plane, whose queries project into the same few camera regions -- instead
+    // of every eighth workgroup of the whole plane (gridDim.x is a multiple of 8)
+    const long long n_wg = (n_units + blockDim.x - 1) / blockDim.x, per_xcd = (n_wg + 7) / 8;
+    for (long long w = blockIdx.x; (w >> 3) < per_xcd; w += gridDim.x) {
+        const long long ubase = ((w & 7) * per_xcd + (w >> 3)) * blockDim.x;
+        const long long unit = ubase + threadIdx.x;
+        if (stage_attn) {
+            // attn (B,Q,M,L,P): the workgroup's 256 units own 256*LP CONTIGUOUS floats; read them with coalesced
+            // 16-byte loads once (a lane reading its own weights sample by sample touches a different 128-byte line
+            // than each of its 63 neighbours, 32 times per camera) and hand them out from LDS, row pitch LP+1.
+            __syncthreads();
+            const long long rem = n_units - ubase;       // <= 0 for the padding workgroups of the last XCD
+            const int nfl = rem <= 0 ? 0 : (int)(rem < (long long)blockDim.x ? rem : (long long)blockDim.x) * LP;
+            const float* src = attn + ubase * LP;
+            for (int i = threadIdx.x * 4; i < nfl; i += blockDim.x * 4) {
+                const fbbev_v4f a = *reinterpret_cast<const fbbev_v4f*>(src + i);
+                float* d = staged + (i / LP) * LDW + (i % LP);
+                d[0] = a[0]; d[1] = a[1]; d[2] = a[2]; d[3] = a[3];
+            }
+            __syncthreads();
+        }
+        if (unit >= n_units) continue;
+        const float* my_attn = staged + threadIdx.x * LDW;
         const int m = (int)(unit % M);
         const long long bq = unit / M;
         const int q = (int)(bq % Q);
@@ -139,6 +168,9 @@ k_da_cross_attn_fwd_unit(long long n_units, const float* __restrict__ value, con
         float acc[DH];
 #pragma unroll
         for (int c = 0; c < DH; ++c) acc[c] = 0.f;
+        // offsets of sample lp: (B,Q,M,L,P,2) -> unit*LP + lp, head-minor (B,Q,L,P,M,2) -> (bq*LP + lp)*M + m
+        const fbbev_v2f* op = reinterpret_cast<const fbbev_v2f*>(offsets) + ((head_minor & 1) ? bq * LP * M + m : unit * LP);
+        const int wo_step = (head_minor & 1) ? M : 1;
         int count = 0;
         for (int cam = 0; cam < Ncam; ++cam) {
             const long long base = (((long long)cam * B + b) * Q + q) * Za;
@@ -159,51 +191,28 @@ k_da_cross_attn_fwd_unit(long long n_units, const float* __restrict__ value, con
             float col[DH];
 #pragma unroll
             for (int c = 0; c < DH; ++c) col[c] = 0.f;
+            fbbev_v2f o_next = op[0];
+            int lp = 0;
             for (int l = 0; l < L; ++l) {
                 const int sh = (int)spatial_shapes[2 * l], sw = (int)spatial_shapes[2 * l + 1];
-                const float* vp = value + (bn * S + level_start[l]) * row_stride + m * row_stride_unit;
-                for (int p = 0; p < P; ++p) {
+                const unsigned lane_off = (unsigned)(((bn * S + level_start[l]) * row_stride + m * head_off_m) * 4);
+                for (int p = 0; p < P; ++p, ++lp) {
                     // head-minor (B,Q,L,P,M[,2]): the 8 heads of a query read 64 contiguous bytes per sample; the
                     // (B,Q,M,L,P[,2]) layout strides lanes by L*P*8 bytes and thrashes the vector L1
-                    // (head_minor bit 0 -> offsets, bit 1 -> attn; a unit's 32 attention weights are one 128-byte line,
-                    // so attn may stay in the layout the fast last-dim softmax produces)
-                    const long long wm = (unit * L + l) * P + p, wh = ((bq * L + l) * P + p) * M + m;
-                    const long long wo = (head_minor & 1) ? wh : wm, wa = (head_minor & 2) ? wh : wm;
+                    // (head_minor bit 0 -> offsets, bit 1 -> attn; attn may stay in the layout the fast last-dim
+                    // softmax produces: it is then staged through LDS above).  The next sample's offsets are requested
+                    // before this sample's value loads: one exposed memory latency per sample instead of two.
+                    const fbbev_v2f o = o_next;
+                    o_next = op[(long long)(lp + 1 < LP ? lp + 1 : lp) * wo_step];
                     const int z = p % Za;
-                    const fbbev_v2f o = *reinterpret_cast<const fbbev_v2f*>(offsets + wo * 2);
                     const float loc_w = rx[z] + __fdiv_rn(o[0], (float)sw);
                     const float loc_h = ry[z] + __fdiv_rn(o[1], (float)sh);
-                    const float weight = attn[wa] * dw[z];
+                    const float a = stage_attn ? my_attn[lp] : attn[(head_minor & 2) ? (bq * LP + lp) * M + m : unit * LP + lp];
+                    const float weight = a * dw[z];
                     const float h_im = loc_h * sh - 0.5f, w_im = loc_w * sw - 0.5f;
                     if (h_im > -1.f && w_im > -1.f && h_im < (float)sh && w_im < (float)sw) {
                         const fbbev_bilinear s = fbbev_bilinear_setup(h_im, w_im, sh, sw, row_stride);
-                        float v1[DHP], v2[DHP], v3[DHP], v4[DHP];
-                        if constexpr (WIDE) {
-#pragma unroll
-                            for (int c = 0; c < DHP; c += 4) {
-                                const fbbev_v4f zero = {0.f, 0.f, 0.f, 0.f};
-                                const fbbev_v4f a1 = s.o1 >= 0 ? *reinterpret_cast<const fbbev_v4f*>(vp + s.o1 + c) : zero;
-                                const fbbev_v4f a2 = s.o2 >= 0 ? *reinterpret_cast<const fbbev_v4f*>(vp + s.o2 + c) : zero;
-                                const fbbev_v4f a3 = s.o3 >= 0 ? *reinterpret_cast<const fbbev_v4f*>(vp + s.o3 + c) : zero;
-                                const fbbev_v4f a4 = s.o4 >= 0 ? *reinterpret_cast<const fbbev_v4f*>(vp + s.o4 + c) : zero;
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) { v1[c + e] = a1[e]; v2[c + e] = a2[e]; v3[c + e] = a3[e]; v4[c + e] = a4[e]; }
-                            }
-                        } else {
-#pragma unroll
-                            for (int c = 0; c < DH; c += 2) {
-                                const fbbev_v2f zero = {0.f, 0.f};
-                                const fbbev_v2f a1 = s.o1 >= 0 ? *reinterpret_cast<const fbbev_v2f*>(vp + s.o1 + c) : zero;
-                                const fbbev_v2f a2 = s.o2 >= 0 ? *reinterpret_cast<const fbbev_v2f*>(vp + s.o2 + c) : zero;
-                                const fbbev_v2f a3 = s.o3 >= 0 ? *reinterpret_cast<const fbbev_v2f*>(vp + s.o3 + c) : zero;
-                                const fbbev_v2f a4 = s.o4 >= 0 ? *reinterpret_cast<const fbbev_v2f*>(vp + s.o4 + c) : zero;
-                                v1[c] = a1[0]; v1[c + 1] = a1[1]; v2[c] = a2[0]; v2[c + 1] = a2[1];
-                                v3[c] = a3[0]; v3[c + 1] = a3[1]; v4[c] = a4[0]; v4[c + 1] = a4[1];
-                            }
-                        }
-#pragma unroll
-                        for (int c = 0; c < DH; ++c)
-                            col[c] += (s.w1 * v1[c] + s.w2 * v2[c] + s.w3 * v3[c] + s.w4 * v4[c]) * weight;
+                        fbbev_unit_sample<DH, WIDE ? 4 : 2>(value, lane_off, s, chunk_stride, weight, col);
                     }
                 }
             }
@@ -291,7 +300,8 @@ k_da_cross_attn_bwd(long long n_units, const float* __restrict__ value, const in
         }
         for (int l = 0; l < L; ++l) {
             const int sh = (int)spatial_shapes[2 * l], sw = (int)spatial_shapes[2 * l + 1];
-            const long long voff = (bn * S + level_start[l]) * row_stride + m * HS + slot;
+            const long long voff = (bn * S + level_start[l]) * row_stride +
+                                   ((head_minor & 4) ? (slot >> 2) * (M * 4) + m * 4 + (slot & 3) : m * HS + slot);
             for (int p = 0; p < P; ++p) {
                 const long long wm = (u * L + l) * P + p, wh = ((bq * L + l) * P + p) * M + m;
                 const long long wo = (head_minor & 1) ? wh : wm, wa = (head_minor & 2) ? wh : wm;

@@ -142,24 +142,30 @@ k_point_sampling(const float* __restrict__ xs, const float* __restrict__ ys, con
 // The depth net emits NCHW; bev_pool_v2 gathers channel rows, so the reference makes feat.permute(0,1,3,4,2)
 // contiguous inside the op (bev_pool.py:18, view_transformer.py:536).  LDS-tiled 32x32 transpose: both the
 // read (along H*W) and the write (along C) are coalesced.
+// Generalised for the backward projection's camera tokens (bevformer.py:95-117: flatten(3).permute(1,0,3,2) + cams_embeds,
+// cat over levels, and the per-camera rebatch permute of spatial_cross_attention_depth.py:151): image `img` is written at
+// out + img*out_image_stride + out_offset, with bias[(img % bias_rows)*C + c] added when bias != nullptr.
 __global__ void __launch_bounds__(256)
-k_nchw_to_nhwc(const float* __restrict__ in, float* __restrict__ out, int C, int HW, int tiles_c, int tiles_hw) {
+k_nchw_to_nhwc(const float* __restrict__ in, float* __restrict__ out, int C, int HW, int tiles_c, int tiles_hw,
+               long long out_image_stride, long long out_offset, const float* __restrict__ bias, int bias_rows) {
     __shared__ float tile[32][33];
     const int t = blockIdx.x;
     const int img = t / (tiles_c * tiles_hw), r = t - img * (tiles_c * tiles_hw);
     const int tc = r / tiles_hw, th = r - tc * tiles_hw;
     const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;           // 32 x 8
     const float* src = in + (long long)img * C * HW;
-    float* dst = out + (long long)img * C * HW;
+    float* dst = out + (long long)img * out_image_stride + out_offset;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int c = tc * 32 + ly + 8 * k, p = th * 32 + lx;
         tile[ly + 8 * k][lx] = (c < C && p < HW) ? src[(long long)c * HW + p] : 0.f;
     }
     __syncthreads();
+    const int cb = tc * 32 + lx;
+    const float add = (bias != nullptr && cb < C) ? bias[(long long)(img % bias_rows) * C + cb] : 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int p = th * 32 + ly + 8 * k, c = tc * 32 + lx;
-        if (c < C && p < HW) dst[(long long)p * C + c] = tile[lx][ly + 8 * k];
+        const int p = th * 32 + ly + 8 * k;
+        if (cb < C && p < HW) dst[(long long)p * C + cb] = bias != nullptr ? tile[lx][ly + 8 * k] + add : tile[lx][ly + 8 * k];
     }
 }

@@ -38,6 +38,65 @@ __device__ __forceinline__ fbbev_bilinear fbbev_bilinear_setup(float h, float w,
     return s;
 }
 
+// One bilinear sample of a (b,q,head) unit's DH channels, accumulated into col[]: the body shared by the unit-per-lane
+// kernels.  WIDE: corners are read as DHP/4 16-byte loads, `chunk_stride` floats apart (4 for head-major rows, M*4 for
+// quad-interleaved ones).  The loads are unconditional -- a padded corner reads the level's first token instead and its
+// floats are replaced by zeros afterwards -- so the 4*DHP/4 loads of a sample issue back to back instead of each
+// sitting in its own exec-masked branch (what `valid ? *p : 0` compiles to); the arithmetic is unchanged.
+template <int DH, int VEC>        // VEC = floats per load: 4 (WIDE), 2 (rows 8-byte aligned) or 1
+__device__ __forceinline__ void fbbev_unit_sample(const float* __restrict__ value, unsigned lane_off,
+                                                  const fbbev_bilinear& s, int chunk_stride, float weight,
+                                                  float (&col)[DH]) {
+    // value: the tensor's base (wave-uniform); lane_off: BYTE offset of this lane's head chunk in the level's first token
+    // (the host guarantees the tensor is < 4 GiB: a uniform base + 32-bit lane offset is one address VGPR per load)
+    constexpr int DHP = (DH + 3) / 4 * 4;
+    const char* vb = reinterpret_cast<const char*>(value);
+    const float* vp = reinterpret_cast<const float*>(vb + lane_off);
+    float v1[DHP], v2[DHP], v3[DHP], v4[DHP];
+    if constexpr (VEC == 4) {
+        const bool k1 = s.o1 >= 0, k2 = s.o2 >= 0, k3 = s.o3 >= 0, k4 = s.o4 >= 0;
+        const unsigned b1 = lane_off + (k1 ? (unsigned)s.o1 * 4u : 0u), b2 = lane_off + (k2 ? (unsigned)s.o2 * 4u : 0u);
+        const unsigned b3 = lane_off + (k3 ? (unsigned)s.o3 * 4u : 0u), b4 = lane_off + (k4 ? (unsigned)s.o4 * 4u : 0u);
+        const unsigned cs = (unsigned)chunk_stride * 4u;
+        fbbev_v4f a1[DHP / 4], a2[DHP / 4], a3[DHP / 4], a4[DHP / 4];
+#pragma unroll
+        for (int k = 0; k < DHP / 4; ++k) {
+            a1[k] = *reinterpret_cast<const fbbev_v4f*>(vb + (b1 + k * cs));
+            a2[k] = *reinterpret_cast<const fbbev_v4f*>(vb + (b2 + k * cs));
+            a3[k] = *reinterpret_cast<const fbbev_v4f*>(vb + (b3 + k * cs));
+            a4[k] = *reinterpret_cast<const fbbev_v4f*>(vb + (b4 + k * cs));
+        }
+#pragma unroll
+        for (int k = 0; k < DHP / 4; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v1[4 * k + e] = k1 ? a1[k][e] : 0.f; v2[4 * k + e] = k2 ? a2[k][e] : 0.f;
+                v3[4 * k + e] = k3 ? a3[k][e] : 0.f; v4[4 * k + e] = k4 ? a4[k][e] : 0.f;
+            }
+    } else if constexpr (VEC == 2) {
+#pragma unroll
+        for (int c = 0; c < DH; c += 2) {
+            const fbbev_v2f zero = {0.f, 0.f};
+            const fbbev_v2f a1 = s.o1 >= 0 ? *reinterpret_cast<const fbbev_v2f*>(vp + s.o1 + c) : zero;
+            const fbbev_v2f a2 = s.o2 >= 0 ? *reinterpret_cast<const fbbev_v2f*>(vp + s.o2 + c) : zero;
+            const fbbev_v2f a3 = s.o3 >= 0 ? *reinterpret_cast<const fbbev_v2f*>(vp + s.o3 + c) : zero;
+            const fbbev_v2f a4 = s.o4 >= 0 ? *reinterpret_cast<const fbbev_v2f*>(vp + s.o4 + c) : zero;
+            v1[c] = a1[0]; v1[c + 1] = a1[1]; v2[c] = a2[0]; v2[c + 1] = a2[1];
+            v3[c] = a3[0]; v3[c + 1] = a3[1]; v4[c] = a4[0]; v4[c + 1] = a4[1];
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < DH; ++c) {
+            v1[c] = s.o1 >= 0 ? vp[s.o1 + c] : 0.f;
+            v2[c] = s.o2 >= 0 ? vp[s.o2 + c] : 0.f;
+            v3[c] = s.o3 >= 0 ? vp[s.o3 + c] : 0.f;
+            v4[c] = s.o4 >= 0 ? vp[s.o4 + c] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < DH; ++c) col[c] += (s.w1 * v1[c] + s.w2 * v2[c] + s.w3 * v3[c] + s.w4 * v4[c]) * weight;
+}
+
 __global__ void __launch_bounds__(256)
 k_msda_fwd(long long n, const float* __restrict__ value, const int64_t* __restrict__ spatial_shapes,
            const int64_t* __restrict__ level_start, const float* __restrict__ loc,
@@ -80,58 +139,65 @@ k_msda_fwd(long long n, const float* __restrict__ value, const int64_t* __restri
 // the kernel -- the same two correctly rounded fp32 operations -- the bilinear setup happens once per sample instead of
 // once per channel lane, and with head-padded value rows (WIDE) a corner is DHP/4 aligned dwordx4 loads.
 // ref (B,Q,L,2); offsets (B,Q,M,L,P,2) raw, or head-minor (B,Q,L,P,M,2) when off_head_minor; attn (B,Q,M,L,P) softmaxed.
-template <int DH, bool WIDE>
+template <int DH, bool WIDE, bool QI>
 __global__ void __launch_bounds__(256)
 k_msda_fwd_unit(long long n_units, const float* __restrict__ value, const int64_t* __restrict__ spatial_shapes,
                 const int64_t* __restrict__ level_start, const float* __restrict__ ref,
                 const float* __restrict__ offsets, const float* __restrict__ attn, int spatial_size, int M, int L,
-                int Q, int P, int HS, int off_head_minor, float* __restrict__ out) {
-    constexpr int DHP = (DH + 3) / 4 * 4;
+                int Q, int P, int HS, int off_head_minor, int stage_attn, float* __restrict__ out) {
+    static_assert(!QI || WIDE, "quad-interleaved rows are read with 16-byte loads");
+    // QI (value rows stored [chunk][head][4 floats]) and the LDS-staged attention weights: see k_da_cross_attn_fwd_unit
+    const int head_off_m = QI ? 4 : HS, chunk_stride = QI ? M * 4 : 4;
     const int row_stride = M * HS;
-    for (long long unit = (long long)blockIdx.x * blockDim.x + threadIdx.x; unit < n_units;
-         unit += (long long)gridDim.x * blockDim.x) {
+    const int LP = L * P, LDW = LP + 1;
+    float* staged = fbbev_dyn_lds_f32();          // [256][LP+1] when stage_attn
+    // XCD-contiguous order: workgroup w runs on XCD w % 8 (each with its own L2); XCD x takes the x-th eighth of the
+    // unit range -- a contiguous piece of the BEV plane, whose queries project into the same few camera regions -- instead
+    // of every eighth workgroup of the whole plane (gridDim.x is a multiple of 8)
+    const long long n_wg = (n_units + blockDim.x - 1) / blockDim.x, per_xcd = (n_wg + 7) / 8;
+    for (long long w = blockIdx.x; (w >> 3) < per_xcd; w += gridDim.x) {
+        const long long ubase = ((w & 7) * per_xcd + (w >> 3)) * blockDim.x;
+        const long long unit = ubase + threadIdx.x;
+        if (stage_attn) {
+            __syncthreads();
+            const long long rem = n_units - ubase;       // <= 0 for the padding workgroups of the last XCD
+            const int nfl = rem <= 0 ? 0 : (int)(rem < (long long)blockDim.x ? rem : (long long)blockDim.x) * LP;
+            const float* src = attn + ubase * LP;
+            for (int i = threadIdx.x * 4; i < nfl; i += blockDim.x * 4) {
+                const fbbev_v4f a = *reinterpret_cast<const fbbev_v4f*>(src + i);
+                float* d = staged + (i / LP) * LDW + (i % LP);
+                d[0] = a[0]; d[1] = a[1]; d[2] = a[2]; d[3] = a[3];
+            }
+            __syncthreads();
+        }
+        if (unit >= n_units) continue;
+        const float* my_attn = staged + threadIdx.x * LDW;
         const int m = (int)(unit % M);
         const long long bq = unit / M;
         const long long b = bq / Q;
         float col[DH];
 #pragma unroll
         for (int c = 0; c < DH; ++c) col[c] = 0.f;
+        // offsets of sample lp: (B,Q,M,L,P,2) -> unit*LP + lp, head-minor (B,Q,L,P,M,2) -> (bq*LP + lp)*M + m
+        const fbbev_v2f* op = reinterpret_cast<const fbbev_v2f*>(offsets) + (off_head_minor ? bq * LP * M + m : unit * LP);
+        const int wo_step = off_head_minor ? M : 1;
+        fbbev_v2f o_next = op[0];
+        int lp = 0;
         for (int l = 0; l < L; ++l) {
             const int sh = (int)spatial_shapes[2 * l], sw = (int)spatial_shapes[2 * l + 1];
             const float rx = ref[(bq * L + l) * 2], ry = ref[(bq * L + l) * 2 + 1];
-            const float* vp = value + (b * spatial_size + level_start[l]) * row_stride + m * HS;
-            for (int p = 0; p < P; ++p) {
-                const long long wm = (unit * L + l) * P + p, wh = ((bq * L + l) * P + p) * M + m;
-                const long long wo = off_head_minor ? wh : wm;
-                const fbbev_v2f o = *reinterpret_cast<const fbbev_v2f*>(offsets + wo * 2);
+            const unsigned lane_off = (unsigned)(((b * spatial_size + level_start[l]) * row_stride + m * head_off_m) * 4);
+            for (int p = 0; p < P; ++p, ++lp) {
+                // the next sample's offsets are requested before this sample's value loads: one exposed memory latency
+                // per sample instead of two dependent ones
+                const fbbev_v2f o = o_next;
+                o_next = op[(long long)(lp + 1 < LP ? lp + 1 : lp) * wo_step];
                 const float loc_w = rx + __fdiv_rn(o[0], (float)sw), loc_h = ry + __fdiv_rn(o[1], (float)sh);
-                const float weight = attn[wm];
+                const float weight = stage_attn ? my_attn[lp] : attn[unit * LP + lp];
                 const float h_im = loc_h * sh - 0.5f, w_im = loc_w * sw - 0.5f;
                 if (!(h_im > -1.f && w_im > -1.f && h_im < (float)sh && w_im < (float)sw)) continue;
                 const fbbev_bilinear s = fbbev_bilinear_setup(h_im, w_im, sh, sw, row_stride);
-                float v1[DHP], v2[DHP], v3[DHP], v4[DHP];
-                if constexpr (WIDE) {
-#pragma unroll
-                    for (int c = 0; c < DHP; c += 4) {
-                        const fbbev_v4f zero = {0.f, 0.f, 0.f, 0.f};
-                        const fbbev_v4f a1 = s.o1 >= 0 ? *reinterpret_cast<const fbbev_v4f*>(vp + s.o1 + c) : zero;
-                        const fbbev_v4f a2 = s.o2 >= 0 ? *reinterpret_cast<const fbbev_v4f*>(vp + s.o2 + c) : zero;
-                        const fbbev_v4f a3 = s.o3 >= 0 ? *reinterpret_cast<const fbbev_v4f*>(vp + s.o3 + c) : zero;
-                        const fbbev_v4f a4 = s.o4 >= 0 ? *reinterpret_cast<const fbbev_v4f*>(vp + s.o4 + c) : zero;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { v1[c + e] = a1[e]; v2[c + e] = a2[e]; v3[c + e] = a3[e]; v4[c + e] = a4[e]; }
-                    }
-                } else {
-#pragma unroll
-                    for (int c = 0; c < DH; ++c) {
-                        v1[c] = s.o1 >= 0 ? vp[s.o1 + c] : 0.f;
-                        v2[c] = s.o2 >= 0 ? vp[s.o2 + c] : 0.f;
-                        v3[c] = s.o3 >= 0 ? vp[s.o3 + c] : 0.f;
-                        v4[c] = s.o4 >= 0 ? vp[s.o4 + c] : 0.f;
-                    }
-                }
-#pragma unroll
-                for (int c = 0; c < DH; ++c) col[c] += (s.w1 * v1[c] + s.w2 * v2[c] + s.w3 * v3[c] + s.w4 * v4[c]) * weight;
+                fbbev_unit_sample<DH, WIDE ? 4 : 1>(value, lane_off, s, chunk_stride, weight, col);
             }
         }
         float* dst = out + unit * DH;

@@ -88,6 +88,19 @@ int fbbev_lidar_coor(const float* xs, const float* ys, const float* ds, const fl
  * in (n_images, C, HW) -> out (n_images, HW, C), f32, LDS-tiled transpose. */
 int fbbev_nchw_to_nhwc(const float* in, float* out, int n_images, int C, int HW, fbbev_stream_t stream);
 
+/* Camera tokens of the backward projection in one pass per feature level.  Replaces, in
+ *   fbbev/view_transformation/backward_projection/bevformer_utils/bevformer.py:95-117
+ * feat.flatten(3).permute(1,0,3,2) + cams_embeds[:,None,None,:], torch.cat over the levels and the
+ * (num_cam, sum HW, bs, C) permute, and in spatial_cross_attention_depth.py:151,188-191 the rebatch
+ * value.permute(2,0,1,3).reshape(bs*num_cams, sum HW, C):
+ *   out[img*out_image_stride + out_offset + p*C + c] = in[img, c, p] (+ bias[(img % bias_rows)*C + c])
+ * in (n_images, C, HW) f32; bias (bias_rows, C) or NULL (then exactly fbbev_nchw_to_nhwc with strides);
+ * strides / offset in floats, out_image_stride >= C*HW.  The same call with the roles of C and HW
+ * swapped is the inverse transposition (tokens -> channel planes). */
+int fbbev_tokens_from_nchw(const float* in, float* out, int n_images, int C, int HW,
+                           long long out_image_stride, long long out_offset, const float* bias,
+                           int bias_rows, fbbev_stream_t stream);
+
 /* Replaces LSSViewTransformerFunction3D.voxel_pooling_prepare_v2
  *   -- fbbev/view_transformation/forward_projection/view_transformer.py:547-605
  *   (~17 torch launches, an argsort and >=4 host syncs in the reference).

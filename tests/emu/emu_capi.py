@@ -250,13 +250,20 @@ def history_conv(feats, w1, bias1, w2, bias2):
     return out
 
 
-def msda_fwd_fused(value, ss, ls, ref, offsets, w, head_dim=None, offsets_head_minor=False):
+def tokens_from_nchw(x, out, out_offset=0, bias=None):
+    n, C, HW = x.shape
+    ok(lib().fbbev_tokens_from_nchw(p(x), p(out), n, C, HW, out.stride(0), out_offset, None if bias is None else p(bias),
+                                    0 if bias is None else bias.shape[0], None))
+    return out
+
+
+def msda_fwd_fused(value, ss, ls, ref, offsets, w, head_dim=None, offsets_head_minor=False, value_interleaved=False):
     B, S, M, HS = value.shape
     Dh = HS if head_dim is None else head_dim
     _, Q, _, L, P = w.shape
     out = torch.full((B, Q, M * Dh), float('nan'))
     ok(lib().fbbev_msda_fwd_fused(p(value), p(ss), p(ls), p(ref), p(offsets), p(w), B, S, M, Dh, L, Q, P, HS,
-                                  1 if offsets_head_minor else 0, p(out), None))
+                                  (1 if offsets_head_minor else 0) | (4 if value_interleaved else 0), p(out), None))
     return out
 
 

@@ -198,6 +198,17 @@ def _da_case(seed=0, B=2, N=6, Q=70, Za=4, E=16, M=4, shapes=((5, 7), (3, 4)), P
     return args, exp
 
 
+def _interleave(v):
+    """(..., M, HS) head-major token rows -> the same floats stored (HS/4, M, 4), shape label kept"""
+    M, HS = v.shape[-2:]
+    return v.reshape(v.shape[:-2] + (M, HS // 4, 4)).transpose(-3, -2).contiguous().view(v.shape)
+
+
+def _deinterleave(v):
+    M, HS = v.shape[-2:]
+    return v.reshape(v.shape[:-2] + (HS // 4, M, 4)).transpose(-3, -2).contiguous().view(v.shape)
+
+
 def test_fused_da_cross_attention_emulated():
     for seed, kw in ((0, {}), (1, dict(B=1, Q=33, shapes=((4, 6),), P=4, M=2, E=8)),
                      (2, dict(B=1, Q=41, E=40, M=4)),                      # Dh = 10: unit-per-lane kernel (FB-OCC)
@@ -225,6 +236,34 @@ def test_fused_da_cross_attention_emulated():
         a[0] = vp
         assert torch.equal(got, E.da_cross_attn_fwd(*a, head_minor=1, head_dim=Dh))
         assert torch.equal(got, E.da_cross_attn_fwd(*a, head_minor=1, head_dim=Dh, misalign=True))
+        # chunk-major token rows (HS/4, M, 4) -- head_minor bit 2: same floats at other addresses => same bits
+        a[0] = _interleave(vp)
+        for hm in (4, 5):
+            a[7] = args[7].permute(0, 1, 3, 4, 2, 5).contiguous() if hm & 1 else args[7]
+            assert torch.equal(got, E.da_cross_attn_fwd(*a, head_minor=hm, head_dim=Dh))
+            assert torch.equal(got, E.da_cross_attn_fwd(*a, head_minor=hm, head_dim=Dh, misalign=True))
+
+
+def test_tokens_from_nchw_emulated():
+    """fbbev_tokens_from_nchw: per-level transposition + cams_embeds into the (bs*num_cam, sum HW, C) token rows ==
+    bevformer.py:95-117 (flatten/permute/add, cat) followed by the rebatch permute; and the plain inverse transposition."""
+    g = torch.Generator().manual_seed(3)
+    bs, ncam, C = 2, 3, 40
+    shapes = [(5, 7), (10, 13), (2, 3)]
+    feats = [torch.randn(bs, ncam, C, h, w, generator=g) for h, w in shapes]
+    ce = torch.randn(ncam, C, generator=g)
+    S_ = sum(h * w for h, w in shapes)
+    rows = torch.full((bs * ncam, S_, C), float('nan'))
+    start = 0
+    for f, (h, w) in zip(feats, shapes):
+        E.tokens_from_nchw(f.reshape(bs * ncam, C, h * w).contiguous(), rows, start * C, ce)
+        start += h * w
+    ref = torch.cat([f.flatten(3).permute(1, 0, 3, 2) + ce[:, None, None, :] for f in feats], 2)     # (ncam, bs, S, C)
+    ref = ref.permute(0, 2, 1, 3).permute(2, 0, 1, 3).reshape(bs * ncam, S_, C)
+    assert torch.equal(rows, ref)
+    x = torch.randn(2, 37, 50, generator=g)
+    out = E.tokens_from_nchw(x, torch.full((2, 50, 37), float('nan')))
+    assert torch.equal(out, x.transpose(1, 2).contiguous())
 
 
 def test_point_sampling_emulated():
@@ -478,6 +517,16 @@ def test_fused_da_cross_attention_backward_emulated():
                                                      f32(attn), d0, dstep, f32(g), head_minor=0)
             assert torch.equal(gv2[..., :Dh], gv0) and not gv2[..., Dh:].any()
             assert torch.equal(gd2, gd0) and torch.equal(go2, go0) and torch.equal(ga2, ga0)
+        # chunk-major token rows (head_minor bit 2): the value gradient comes back in the same storage order
+        vp = torch.zeros(value.shape[:-1] + (HS,))
+        vp[..., :Dh] = f32(value)
+        gv0, gd0, go0, ga0 = E.da_cross_attn_bwd(vp, ss, ls, f32(pred4), f32(ref_cam), mask, f32(qdepth), f32(offsets), f32(attn),
+                                                 d0, dstep, f32(g), head_minor=0, head_dim=Dh)
+        gv3, gd3, go3, ga3 = E.da_cross_attn_bwd(_interleave(vp), ss, ls, f32(pred4), f32(ref_cam), mask, f32(qdepth),
+                                                 f32(offsets), f32(attn), d0, dstep, f32(g), head_minor=4, head_dim=Dh)
+        # (atomics: the emulator runs lanes in a fixed order, so even the value gradient is reproducible)
+        assert torch.allclose(_deinterleave(gv3), gv0, rtol=1e-5, atol=1e-6)
+        assert torch.equal(gd3, gd0) and torch.equal(go3, go0) and torch.equal(ga3, ga0)
 
 
 @pytest.mark.parametrize('B,T1,C,Cout,N', [(1, 3, 16, 16, 64), (2, 2, 32, 16, 100), (1, 4, 16, 32, 17)])
@@ -560,6 +609,7 @@ def test_msda_fwd_fused_equals_unfused_emulated(B, Q, M, Dh, shapes, P):
     vp = torch.full((B, S_, M, HS), -3.0e4)
     vp[..., :Dh] = value
     assert torch.equal(E.msda_fwd_fused(vp, ss, ls, ref, so, w, head_dim=Dh), base)
+    assert torch.equal(E.msda_fwd_fused(_interleave(vp), ss, ls, ref, so, w, head_dim=Dh, value_interleaved=True), base)
 
 
 # ---------------------------------------------------------------- one-launch-per-pass sort: chunk shapes + look-back
