@@ -60,6 +60,9 @@ SIGNATURES = {
     'fbbev_point_sampling': (c_int, [c_void_p] * 9 + [c_int] * 5 + [c_float, c_float] + [c_void_p] * 4),
     'fbbev_da_cross_attn_fwd': (c_int, [c_void_p] * 9 + [c_int] * 10 + [c_float, c_float, c_int, c_int, c_void_p, c_void_p]),
     'fbbev_da_cross_attn_bwd': (c_int, [c_void_p] * 10 + [c_int] * 10 + [c_float, c_float, c_int, c_int] + [c_void_p] * 5),
+    'fbbev_da_cross_attn_bwd_ws_bytes': (c_size_t, [c_int] * 7),
+    'fbbev_da_cross_attn_bwd_ws': (c_int, [c_void_p] * 10 + [c_int] * 10 + [c_float, c_float, c_int, c_int] + [c_void_p] * 4 +
+                                   [c_void_p, c_size_t, c_void_p]),
     'fbbev_msda_fwd_fused': (c_int, [c_void_p] * 6 + [c_int] * 9 + [c_void_p, c_void_p]),
     'fbbev_msda_bwd': (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p] * 3 + [c_void_p]),
 }
@@ -409,7 +412,8 @@ def da_cross_attn_fwd(value, spatial_shapes, level_start_index, pred_depth, ref_
 
 
 def da_cross_attn_bwd(value, spatial_shapes, level_start_index, pred_depth, ref_cam, mask, qdepth, offsets, attn,
-                      grad_slots, d0, dstep, head_minor, grad_value, grad_pred_depth, grad_offsets, grad_attn, head_dim=None):
+                      grad_slots, d0, dstep, head_minor, grad_value, grad_pred_depth, grad_offsets, grad_attn, head_dim=None,
+                      lds_planes=True):
     """Backward of da_cross_attn_fwd; the four grad tensors must be pre-zeroed (accumulated into)."""
     Ncam, B, Q, Za = mask.shape
     _, S, M, HS = value.shape
@@ -419,16 +423,22 @@ def da_cross_attn_bwd(value, spatial_shapes, level_start_index, pred_depth, ref_
     DC = pred_depth.shape[1]
     if mask.dtype == torch.bool:
         mask = mask.view(torch.uint8)
-    with _on(value):
-        _check(lib().fbbev_da_cross_attn_bwd(
-            _dev(value, F32, 'value'), _dev(spatial_shapes, I64, 'spatial_shapes'),
+    args = (_dev(value, F32, 'value'), _dev(spatial_shapes, I64, 'spatial_shapes'),
             _dev(level_start_index, I64, 'level_start_index'), _dev(pred_depth, F32, 'pred_depth'),
             _dev(ref_cam, F32, 'ref_cam'), _dev(mask, torch.uint8, 'mask'), _dev(qdepth, F32, 'qdepth'),
             _dev(offsets, F32, 'offsets'), _dev(attn, F32, 'attn'), _dev(grad_slots, F32, 'grad_slots'),
             B, Ncam, S, M, Dh, L, Q, P, Za, DC, float(d0), float(dstep), head_minor, HS,
             _dev(grad_value, F32, 'grad_value'), _dev(grad_pred_depth, F32, 'grad_pred_depth'),
-            _dev(grad_offsets, F32, 'grad_offsets'), _dev(grad_attn, F32, 'grad_attn'), _stream()),
-            'fbbev_da_cross_attn_bwd')
+            _dev(grad_offsets, F32, 'grad_offsets'), _dev(grad_attn, F32, 'grad_attn'))
+    with _on(value):
+        # value gradient through LDS planes + a partial buffer when the shape fits (fbbev_da_cross_attn_bwd_ws), else
+        # the global-atomic kernel
+        need = lib().fbbev_da_cross_attn_bwd_ws_bytes(B, Ncam, S, M, Dh, Q, HS) if lds_planes else 0
+        if need:
+            ws = torch.empty(need // 4, dtype=torch.float32, device=value.device)
+            _check(lib().fbbev_da_cross_attn_bwd_ws(*args, ws.data_ptr(), need, _stream()), 'fbbev_da_cross_attn_bwd_ws')
+        else:
+            _check(lib().fbbev_da_cross_attn_bwd(*args, _stream()), 'fbbev_da_cross_attn_bwd')
 
 
 def point_sampling(xs, ys, zs, rots, trans, intrins, post_rots, post_trans, bda, ogfH, ogfW, ref_cam, mask, qdepth):

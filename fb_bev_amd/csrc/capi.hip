@@ -297,17 +297,17 @@ static int rank_build_impl(const float* coor, const fbbev_cam_ptrs* cams, const 
     switch (L.vi) {
         case 0:
             FBBEV_LAUNCH((k_interval_count<4, 4>), L.wgsi, 256, 0, stream, keys, (const int*)counts, skip, chunk_info);
-            FBBEV_LAUNCH((k_interval_write<4, 4>), L.wgsi, 256, 0, stream, keys, vals, div_dhw, div_hw, (const int2*)chunk_info, skip,
+            FBBEV_LAUNCH((k_interval_write<4, 4>), L.wgsi, 256, (size_t)2 * 4 * 256 * 4, stream, keys, vals, div_dhw, div_hw, (const int2*)chunk_info, skip,
                          ranks_feat, interval_starts, interval_lengths, interval_rank, counts);
             break;
         case 1:
             FBBEV_LAUNCH((k_interval_count<16, 4>), L.wgsi, 1024, 0, stream, keys, (const int*)counts, skip, chunk_info);
-            FBBEV_LAUNCH((k_interval_write<16, 4>), L.wgsi, 1024, 0, stream, keys, vals, div_dhw, div_hw, (const int2*)chunk_info, skip,
+            FBBEV_LAUNCH((k_interval_write<16, 4>), L.wgsi, 1024, (size_t)2 * 4 * 1024 * 4, stream, keys, vals, div_dhw, div_hw, (const int2*)chunk_info, skip,
                          ranks_feat, interval_starts, interval_lengths, interval_rank, counts);
             break;
         default:
             FBBEV_LAUNCH((k_interval_count<16, 8>), L.wgsi, 1024, 0, stream, keys, (const int*)counts, skip, chunk_info);
-            FBBEV_LAUNCH((k_interval_write<16, 8>), L.wgsi, 1024, 0, stream, keys, vals, div_dhw, div_hw, (const int2*)chunk_info, skip,
+            FBBEV_LAUNCH((k_interval_write<16, 8>), L.wgsi, 1024, (size_t)2 * 8 * 1024 * 4, stream, keys, vals, div_dhw, div_hw, (const int2*)chunk_info, skip,
                          ranks_feat, interval_starts, interval_lengths, interval_rank, counts);
             break;
     }
@@ -894,6 +894,69 @@ extern "C" int fbbev_da_cross_attn_bwd(const float* value, const int64_t* spatia
     if (Dh <= 16) FBBEV_DA_BWD(16);
     else FBBEV_DA_BWD(32);
 #undef FBBEV_DA_BWD
+    FBBEV_CHECK_LAUNCH();
+    return 0;
+}
+
+// LDS-plane backward (k_da_cross_attn_bwd_tile + k_da_bwd_reduce): needs a caller-owned partial buffer
+struct da_bwd_plan { int chunks, q_per_chunk; size_t lds, ws; };
+static bool da_bwd_tile_plan(int B, int Ncam, int S, int M, int Dh, int Q, int HS, da_bwd_plan* pl) {
+    const size_t plane = (size_t)S * HS * sizeof(float);
+    // four lanes per unit, lane k = channels 4k..4k+3: head dims up to 16 (FB-OCC: 10); >= 2 workgroups per CU
+    if (plane > 64 * 1024 || Dh > 16 || HS % 4 != 0 || HS > 16 || Q <= 0) return false;
+    const int ng = 64;                                                            // queries per workgroup iteration
+    long long want = (1024 + (long long)B * M - 1) / ((long long)B * M);          // ~1024 workgroups (4 per CU)
+    if (const char* e = getenv("FBBEV_DA_BWD_CHUNKS")) { const int v = atoi(e); if (v > 0) want = v; }
+    if (want < 1) want = 1;
+    if (want > 256) want = 256;
+    int qpc = (int)((Q + want - 1) / want);
+    qpc = (qpc + ng - 1) / ng * ng;
+    pl->q_per_chunk = qpc;
+    pl->chunks = (Q + qpc - 1) / qpc;
+    pl->lds = plane + ((size_t)qpc + 4) * sizeof(int);                            // + the camera's hit list and its counter
+    pl->ws = (size_t)B * M * pl->chunks * Ncam * S * HS * sizeof(float);
+    return true;
+}
+
+extern "C" size_t fbbev_da_cross_attn_bwd_ws_bytes(int B, int Ncam, int S, int M, int Dh, int Q, int head_stride) {
+    if (B <= 0 || Ncam <= 0 || S <= 0 || M <= 0 || Dh <= 0) return 0;
+    da_bwd_plan pl;
+    const int HS = head_stride == 0 ? Dh : head_stride;
+    if (HS < Dh || !da_bwd_tile_plan(B, Ncam, S, M, Dh, Q, HS, &pl)) return 0;
+    return pl.ws;
+}
+
+extern "C" int fbbev_da_cross_attn_bwd_ws(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                          const float* pred_depth, const float* ref_cam, const uint8_t* mask,
+                                          const float* qdepth, const float* offsets, const float* attn,
+                                          const float* grad_slots, int B, int Ncam, int S, int M, int Dh, int L, int Q,
+                                          int P, int Za, int DC, float d0, float dstep, int head_minor, int head_stride,
+                                          float* grad_value, float* grad_pred_depth, float* grad_offsets,
+                                          float* grad_attn, void* ws, size_t ws_bytes, fbbev_stream_t stream_) {
+    if (B <= 0 || Ncam <= 0 || S <= 0 || M <= 0 || Dh <= 0 || L <= 0 || Q < 0 || P <= 0 || Za <= 0 || DC <= 0)
+        return FBBEV_E_BADARG;
+    const int HS = head_stride == 0 ? Dh : head_stride;
+    da_bwd_plan pl;
+    if (HS < Dh || Q == 0 || !ws || !aligned16(ws) || !aligned16(grad_value) || !da_bwd_tile_plan(B, Ncam, S, M, Dh, Q, HS, &pl) ||
+        ws_bytes < pl.ws || (long long)B * M * pl.chunks >= (1ll << 31))
+        return fbbev_da_cross_attn_bwd(value, spatial_shapes, level_start_index, pred_depth, ref_cam, mask, qdepth, offsets,
+                                       attn, grad_slots, B, Ncam, S, M, Dh, L, Q, P, Za, DC, d0, dstep, head_minor,
+                                       head_stride, grad_value, grad_pred_depth, grad_offsets, grad_attn, stream_);
+    if (Za > FBBEV_DA_MAX_ZA || P % Za != 0) return FBBEV_E_UNSUPPORTED;
+    if (dstep == 0.f) return FBBEV_E_BADARG;
+    if (!value || !spatial_shapes || !level_start_index || !pred_depth || !ref_cam || !mask || !qdepth || !offsets ||
+        !attn || !grad_slots || !grad_value || !grad_pred_depth || !grad_offsets || !grad_attn) return FBBEV_E_BADARG;
+    fbbev_rt_stream stream = (fbbev_rt_stream)stream_;
+    float* part = static_cast<float*>(ws);
+    const long long wgs = (long long)B * M * pl.chunks;
+    FBBEV_LAUNCH(k_da_cross_attn_bwd_tile, wgs, 256, pl.lds, stream, value, spatial_shapes, level_start_index,
+                 pred_depth, ref_cam, mask, qdepth, offsets, attn, grad_slots, B, Ncam, S, M, Dh, L, Q, P, Za, DC, d0,
+                 dstep, head_minor & 7, HS, pl.chunks, pl.q_per_chunk, part, grad_pred_depth, grad_offsets, grad_attn);
+    const long long n = (long long)B * Ncam * S * M * HS;
+    long long rb = (n + 255) / 256;
+    if (rb > 65536) rb = 65536;
+    FBBEV_LAUNCH(k_da_bwd_reduce, rb, 256, 0, stream, (const float*)part, B, Ncam, S, M, HS, pl.chunks, (head_minor & 4) ? 1 : 0,
+                 grad_value);
     FBBEV_CHECK_LAUNCH();
     return 0;
 }

@@ -356,3 +356,226 @@ k_da_cross_attn_bwd(long long n_units, const float* __restrict__ value, const in
         }
     }
 }
+
+
+// ---------------------------------------------------------------- backward with an LDS-resident value-gradient plane
+// k_da_cross_attn_bwd sends every corner of every sample to the value gradient with a global fp32 atomic: at the shipped
+// shapes (Q = 10^4, one 16x44 level) ~110 adds land on each of the 1.6 M gradient floats, across all 8 XCDs -- 1.5 ms at
+// B = 4, bound by the atomic rate.  Here a workgroup owns (sample b, head m, a chunk of consecutive BEV queries) and
+// walks the cameras in order; for each camera the head's gradient plane (S tokens x HS floats, 34 KB at the shipped
+// shape) lives in LDS, the corner adds are LDS atomics, and the finished plane is written with plain 16-byte stores to
+// this workgroup's slice of a partial buffer  part[b][m][chunk][cam][S*HS].  k_da_bwd_reduce then sums the chunks into
+// grad_value in the layout of `value` -- no global atomic touches the value gradient (its sum order over the chunks is
+// fixed; only the LDS adds inside a plane keep the hardware's order).  grad_attn / grad_offsets / grad_pred_depth as in
+// k_da_cross_attn_bwd: a group of GW lanes owns a (b,q,m) unit for every camera (same wave, program order), lane = channel.
+// Lane mapping: FOUR lanes own a (b,q,m) unit -- lane k its channels 4k..4k+3 (one 16-byte load per corner; with the
+// chunk-major token rows the three chunk lanes of a head read three 16-byte pieces) and its depth anchor z = k (k+4) --
+// so a wave works on 16 queries at once; the queries a camera sees (~28 % of a chunk) are first compacted into an LDS
+// list, so every group of every wave is busy.  (One lane per channel and one query per 16 lanes, the layout of the
+// atomic kernel, left 62 % of the lanes and a third of the groups active: 0.99 ms at the shipped shape, B = 4.)
+__global__ void __launch_bounds__(256)
+k_da_cross_attn_bwd_tile(const float* __restrict__ value, const int64_t* __restrict__ spatial_shapes,
+                         const int64_t* __restrict__ level_start, const float* __restrict__ pred_depth,
+                         const float* __restrict__ ref_cam, const unsigned char* __restrict__ mask,
+                         const float* __restrict__ qdepth, const float* __restrict__ offsets,
+                         const float* __restrict__ attn, const float* __restrict__ grad_slots, int B, int Ncam, int S,
+                         int M, int Dh, int L, int Q, int P, int Za, int DC, float d0, float dstep, int head_minor,
+                         int HS, int n_chunks, int q_per_chunk, float* __restrict__ part,
+                         float* __restrict__ grad_pred_depth, float* __restrict__ grad_offsets,
+                         float* __restrict__ grad_attn) {
+    float* plane = fbbev_dyn_lds_f32();                        // [S][HS]
+    const int plane_n = S * HS;
+    int* hits = reinterpret_cast<int*>(plane + plane_n);       // [q_per_chunk] queries of the chunk the camera sees
+    int* n_hits = hits + q_per_chunk;                          // [1]
+    const int lane = threadIdx.x & 63;
+    const int k = threadIdx.x & 3;                             // channel chunk / anchor lane of the group
+    const int gidx = threadIdx.x >> 2;                         // group in the workgroup: 0..63
+    const int gbase = lane & ~3;                               // first lane of the group in its wave
+    const int chunk = blockIdx.x % n_chunks;
+    const int m = (blockIdx.x / n_chunks) % M;
+    const int b = blockIdx.x / (n_chunks * M);
+    const int q0 = chunk * q_per_chunk, q1 = (q0 + q_per_chunk < Q) ? q0 + q_per_chunk : Q;
+    const int nq = q1 - q0;
+    const int row_stride = M * HS;
+    const int H0 = (int)spatial_shapes[0], W0 = (int)spatial_shapes[1];
+    const int lane_off = (head_minor & 4) ? k * (M * 4) + m * 4 : m * HS + 4 * k;   // this lane's 4 channels in a token row
+    const bool chunk_live = 4 * k < Dh;                        // HS may hold a chunk of pure padding (Dh = 8, HS = 12)
+    for (int i = threadIdx.x; i < plane_n; i += 256) plane[i] = 0.f;
+    for (int cam = 0; cam < Ncam; ++cam) {
+        const long long bn = (long long)b * Ncam + cam;
+        if (threadIdx.x == 0) *n_hits = 0;
+        __syncthreads();
+        for (int i0 = 0; i0 < nq; i0 += 256) {                 // ascending query order inside a wave's 64, waves in any order
+            const int qi = i0 + threadIdx.x;
+            bool hit = false;
+            if (qi < nq) {
+                const long long base = (((long long)cam * B + b) * Q + (q0 + qi)) * Za;
+                for (int z = 0; z < Za; ++z) hit = hit || (mask[base + z] != 0);
+            }
+            const unsigned long long bal = __ballot(hit ? 1 : 0);
+            int wbase = 0;
+            if (lane == 0 && bal) wbase = atomicAdd(n_hits, __popcll(bal));
+            wbase = __shfl(wbase, 0, 64);
+            if (hit) hits[wbase + __popcll(bal & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))))] = q0 + qi;
+        }
+        __syncthreads();
+        const int nh = *n_hits;
+        for (int it = 0; it < nh; it += 64) {
+            const bool active = it + gidx < nh;
+            if (__ballot(active ? 1 : 0) == 0ull) continue;
+            const int q = active ? hits[it + gidx] : q0;
+            const long long bq = (long long)b * Q + q;
+            const long long u = bq * M + m;
+            const long long base = (((long long)cam * B + b) * Q + q) * Za;
+            // number of cameras that see the query: lane k tests cameras k, k+4, ...
+            int count = 0;
+            for (int c2 = k; c2 < Ncam; c2 += 4) {
+                const long long b2 = (((long long)c2 * B + b) * Q + q) * Za;
+                bool h2 = false;
+                for (int z = 0; z < Za; ++z) h2 = h2 || (mask[b2 + z] != 0);
+                count += h2 ? 1 : 0;
+            }
+            count += __shfl_xor(count, 1, 64);
+            count += __shfl_xor(count, 2, 64);
+            const float inv = (float)(count > 1 ? count : 1);
+            float g[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = (active && 4 * k + e < Dh) ? grad_slots[u * Dh + 4 * k + e] / inv : 0.f;
+            // this lane's anchors: z = k and z = k + 4
+            float rxo[2], ryo[2], dwo[2], ddwo[2];
+            int bino[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int z = k + 4 * h;
+                rxo[h] = ryo[h] = dwo[h] = ddwo[h] = 0.f;
+                bino[h] = 0;
+                if (active && z < Za) {
+                    rxo[h] = ref_cam[(base + z) * 2];
+                    ryo[h] = ref_cam[(base + z) * 2 + 1];
+                    float fb = floorf(__fdiv_rn(__fsub_rn(qdepth[base + z], d0), dstep));
+                    fb = fminf(fmaxf(fb, 0.f), (float)(DC - 1));
+                    bino[h] = (int)fb;
+                    dwo[h] = fbbev_plane_sample(pred_depth + (bn * DC + bino[h]) * (long long)(H0 * W0), H0, W0, rxo[h], ryo[h]);
+                }
+            }
+            // sample lp of the unit: (B,Q,M,L,P[,2]) -> u*LP + lp, head-minor (B,Q,L,P,M[,2]) -> (bq*LP + lp)*M + m.  The next
+            // sample's offsets / weight are requested before this sample's value loads (one exposed latency per sample).
+            const int LP = L * P;
+            const long long wo0 = (head_minor & 1) ? bq * LP * M + m : u * LP, wa0 = (head_minor & 2) ? bq * LP * M + m : u * LP;
+            const int wo_step = (head_minor & 1) ? M : 1, wa_step = (head_minor & 2) ? M : 1;
+            fbbev_v2f o_next = *reinterpret_cast<const fbbev_v2f*>(offsets + wo0 * 2);
+            float a_next = attn[wa0];
+            int lp = 0;
+            for (int l = 0; l < L; ++l) {
+                const int sh = (int)spatial_shapes[2 * l], sw = (int)spatial_shapes[2 * l + 1];
+                const int ls = (int)level_start[l];
+                const float* vp = value + (bn * S + ls) * row_stride + lane_off;
+                float* pl = plane + ls * HS + 4 * k;
+                for (int p = 0; p < P; ++p, ++lp) {
+                    const long long wo = wo0 + (long long)lp * wo_step, wa = wa0 + (long long)lp * wa_step;
+                    const int nlp = lp + 1 < LP ? lp + 1 : lp;
+                    const fbbev_v2f o = o_next;
+                    const float a = active ? a_next : 0.f;
+                    o_next = *reinterpret_cast<const fbbev_v2f*>(offsets + (wo0 + (long long)nlp * wo_step) * 2);
+                    a_next = attn[wa0 + (long long)nlp * wa_step];
+                    const int z = p % Za;
+                    const int src = gbase | (z & 3);
+                    const float rxz = __shfl(z < 4 ? rxo[0] : rxo[1], src, 64);
+                    const float ryz = __shfl(z < 4 ? ryo[0] : ryo[1], src, 64);
+                    const float dwz = __shfl(z < 4 ? dwo[0] : dwo[1], src, 64);
+                    float h_im = -2.f, w_im = -2.f;
+                    if (active) {
+                        const float loc_w = rxz + __fdiv_rn(o[0], (float)sw);
+                        const float loc_h = ryz + __fdiv_rn(o[1], (float)sh);
+                        h_im = loc_h * sh - 0.5f;
+                        w_im = loc_w * sw - 0.5f;
+                    }
+                    const bool inr = active && h_im > -1.f && w_im > -1.f && h_im < (float)sh && w_im < (float)sw;
+                    const float weight = a * dwz;
+                    float dot = 0.f, gx = 0.f, gy = 0.f;
+                    if (inr && chunk_live) {
+                        const fbbev_bilinear s = fbbev_bilinear_setup(h_im, w_im, sh, sw, 1);      // o1..o4 = token indices
+                        const fbbev_v4f zero = {0.f, 0.f, 0.f, 0.f};
+                        const bool k1 = s.o1 >= 0, k2 = s.o2 >= 0, k3 = s.o3 >= 0, k4 = s.o4 >= 0;
+                        fbbev_v4f v1 = *reinterpret_cast<const fbbev_v4f*>(vp + (long long)(k1 ? s.o1 : 0) * row_stride);
+                        fbbev_v4f v2 = *reinterpret_cast<const fbbev_v4f*>(vp + (long long)(k2 ? s.o2 : 0) * row_stride);
+                        fbbev_v4f v3 = *reinterpret_cast<const fbbev_v4f*>(vp + (long long)(k3 ? s.o3 : 0) * row_stride);
+                        fbbev_v4f v4 = *reinterpret_cast<const fbbev_v4f*>(vp + (long long)(k4 ? s.o4 : 0) * row_stride);
+                        v1 = k1 ? v1 : zero; v2 = k2 ? v2 : zero; v3 = k3 ? v3 : zero; v4 = k4 ? v4 : zero;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float tgv = g[e] * weight;
+                            // LDS fp32 atomics retire about one LANE per cycle and CU (SQ_WAIT_INST_LDS = 39 % of the wave
+                            // cycles, profiles/r02_pmc_da_bwd_tile.json): padding channels stay out of them
+                            const bool ce = 4 * k + e < Dh;
+                            if (k1 && ce) fbbev_lds_atomic_add_f32(pl + s.o1 * HS + e, s.w1 * tgv);
+                            if (k2 && ce) fbbev_lds_atomic_add_f32(pl + s.o2 * HS + e, s.w2 * tgv);
+                            if (k3 && ce) fbbev_lds_atomic_add_f32(pl + s.o3 * HS + e, s.w3 * tgv);
+                            if (k4 && ce) fbbev_lds_atomic_add_f32(pl + s.o4 * HS + e, s.w4 * tgv);
+                            dot += g[e] * (s.w1 * v1[e] + s.w2 * v2[e] + s.w3 * v3[e] + s.w4 * v4[e]);
+                            gy += g[e] * (-s.hw * v1[e] - s.lw * v2[e] + s.hw * v3[e] + s.lw * v4[e]);
+                            gx += g[e] * (-s.hh * v1[e] + s.hh * v2[e] - s.lh * v3[e] + s.lh * v4[e]);
+                        }
+                    }
+                    dot += __shfl_xor(dot, 1, 64); dot += __shfl_xor(dot, 2, 64);
+                    gx += __shfl_xor(gx, 1, 64);   gx += __shfl_xor(gx, 2, 64);
+                    gy += __shfl_xor(gy, 1, 64);   gy += __shfl_xor(gy, 2, 64);
+                    // the unit's weight / offset gradients: one add per camera that sees the query (<= Ncam per element).
+                    // Fire-and-forget atomics: a read-modify-write would put a global round trip into every sample of the
+                    // chain (the workgroups of the other cameras' phases are this same workgroup, so there is no race --
+                    // only the latency); the order of the <= Ncam adds is the hardware's.
+                    if (inr && k == 0) fbbev_atomic_add_f32(grad_attn + wa, dwz * dot);
+                    if (inr && k == 1) fbbev_atomic_add_f32(grad_offsets + wo * 2, weight * gx);
+                    if (inr && k == 2) fbbev_atomic_add_f32(grad_offsets + wo * 2 + 1, weight * gy);
+                    if (inr && k == (z & 3)) ddwo[z >> 2] += a * dot;
+                }
+            }
+            // dw[z] -> the four corners of the query's bin plane (fbbev_plane_sample), each anchor by its own lane
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int z = k + 4 * h;
+                if (!active || z >= Za || ddwo[h] == 0.f) continue;
+                const float h_im = ryo[h] * H0 - 0.5f, w_im = rxo[h] * W0 - 0.5f;
+                if (!(h_im > -1.f && w_im > -1.f && h_im < (float)H0 && w_im < (float)W0)) continue;
+                const fbbev_bilinear s = fbbev_bilinear_setup(h_im, w_im, H0, W0, 1);
+                float* gd = grad_pred_depth + (bn * DC + bino[h]) * (long long)(H0 * W0);
+                if (s.o1 >= 0) fbbev_atomic_add_f32(gd + s.o1, s.w1 * ddwo[h]);
+                if (s.o2 >= 0) fbbev_atomic_add_f32(gd + s.o2, s.w2 * ddwo[h]);
+                if (s.o3 >= 0) fbbev_atomic_add_f32(gd + s.o3, s.w3 * ddwo[h]);
+                if (s.o4 >= 0) fbbev_atomic_add_f32(gd + s.o4, s.w4 * ddwo[h]);
+            }
+        }
+        __syncthreads();
+        // the camera's plane -> this workgroup's slice of the partial buffer; cleared for the next camera on the way
+        float* dst = part + ((((long long)b * M + m) * n_chunks + chunk) * Ncam + cam) * (long long)plane_n;
+        for (int i = threadIdx.x * 4; i < plane_n; i += 256 * 4) {
+            const fbbev_v4f t = *reinterpret_cast<const fbbev_v4f*>(plane + i);
+            *reinterpret_cast<fbbev_v4f*>(dst + i) = t;
+            const fbbev_v4f zero = {0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<fbbev_v4f*>(plane + i) = zero;
+        }
+        __syncthreads();
+    }
+}
+
+// grad_value[(b*Ncam+cam), s, (m,c) in the layout of value] = sum over the query chunks of part[b][m][chunk][cam][s*HS+c]
+__global__ void __launch_bounds__(256)
+k_da_bwd_reduce(const float* __restrict__ part, int B, int Ncam, int S, int M, int HS, int n_chunks, int interleaved,
+                float* __restrict__ grad_value) {
+    const long long n = (long long)B * Ncam * S * M * HS;
+    const long long plane_n = (long long)S * HS;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x) {
+        // idx enumerates (b, cam, m, s, c) with c fastest: reads of consecutive lanes are consecutive floats of a plane
+        const int c = (int)(idx % HS);
+        long long r = idx / HS;
+        const int sidx = (int)(r % S); r /= S;
+        const int m = (int)(r % M); r /= M;
+        const int cam = (int)(r % Ncam);
+        const int b = (int)(r / Ncam);
+        const float* src = part + (((long long)b * M + m) * n_chunks * Ncam + cam) * plane_n + (long long)sidx * HS + c;
+        float acc = 0.f;
+        for (int k = 0; k < n_chunks; ++k) acc += src[(long long)k * Ncam * plane_n];
+        const long long row = (((long long)b * Ncam + cam) * S + sidx) * (long long)(M * HS);
+        grad_value[row + (interleaved ? (c >> 2) * (M * 4) + m * 4 + (c & 3) : m * HS + c)] = acc;
+    }
+}

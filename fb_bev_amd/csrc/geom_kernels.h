@@ -162,10 +162,18 @@ k_nchw_to_nhwc(const float* __restrict__ in, float* __restrict__ out, int C, int
     }
     __syncthreads();
     const int cb = tc * 32 + lx;
-    const float add = (bias != nullptr && cb < C) ? bias[(long long)(img % bias_rows) * C + cb] : 0.f;
+    if (bias == nullptr) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int p = th * 32 + ly + 8 * k;
+            if (cb < C && p < HW) dst[(long long)p * C + cb] = tile[lx][ly + 8 * k];
+        }
+        return;
+    }
+    const float add = cb < C ? bias[(long long)(img % bias_rows) * C + cb] : 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int p = th * 32 + ly + 8 * k;
-        if (cb < C && p < HW) dst[(long long)p * C + cb] = bias != nullptr ? tile[lx][ly + 8 * k] + add : tile[lx][ly + 8 * k];
+        if (cb < C && p < HW) dst[(long long)p * C + cb] = tile[lx][ly + 8 * k] + add;
     }
 }

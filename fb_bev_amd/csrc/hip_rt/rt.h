@@ -32,6 +32,8 @@ __device__ __forceinline__ float* fbbev_dyn_lds_f32() { return reinterpret_cast<
 // return value, so the hand-written forms need no extra s_waitcnt bookkeeping.
 typedef float fbbev_v4f __attribute__((ext_vector_type(4)));
 typedef float fbbev_v2f __attribute__((ext_vector_type(2)));
+typedef unsigned int fbbev_v4u __attribute__((ext_vector_type(4)));
+typedef int fbbev_v4i __attribute__((ext_vector_type(4)));
 template <int ST>
 __device__ __forceinline__ void fbbev_store4(float* p, fbbev_v4f v) {
     if constexpr (ST == 1) {
@@ -54,6 +56,10 @@ __device__ __forceinline__ void fbbev_store4(float* p, fbbev_v4f v) {
 }
 
 __device__ __forceinline__ void fbbev_atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }
+// fp32 add on an LDS word (ds_add_f32, no return value)
+__device__ __forceinline__ void fbbev_lds_atomic_add_f32(float* p, float v) {
+    __builtin_amdgcn_ds_faddf((__attribute__((address_space(3))) float*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP, false);
+}
 
 // IEEE binary16 bits -> binary32: v_cvt_f32_f16, exact for every half (subnormals included)
 __device__ __forceinline__ float fbbev_f16_bits_to_f32(unsigned int h) {

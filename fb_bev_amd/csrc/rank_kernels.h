@@ -109,6 +109,25 @@ __device__ __forceinline__ int fbbev_block_excl_scan_w(int v, int* ldsw, int* to
 //                      coalesced load + two block reductions) -- no scan launch, no look-back chain (measured on MI355X:
 //                      a decoupled look-back over device-scope status words cost 33 us here, profiles/r02_*).
 //                      Writes interval_starts / interval_lengths / interval_rank, ranks_feat and I.
+// ITEMS consecutive 32-bit words starting at p[base] into r[]: 16-byte loads when the whole run is inside [0, P) and
+// the address is 16-byte aligned (a thread owning 8 consecutive keys otherwise issues 8 dword loads whose 64 lanes are
+// 32 bytes apart -- every instruction touches 16 cache lines for 256 useful bytes); words at or beyond P read as `fill`.
+template <int ITEMS>
+__device__ __forceinline__ void fbbev_ld_run(const unsigned int* __restrict__ p, long long base, long long P, unsigned int fill,
+                                             unsigned int (&r)[ITEMS]) {
+    static_assert(ITEMS % 4 == 0, "runs of whole 16-byte groups");
+    if (base + ITEMS <= P && ((reinterpret_cast<uintptr_t>(p + base) & 15u) == 0)) {
+#pragma unroll
+        for (int q = 0; q < ITEMS / 4; ++q) {
+            const fbbev_v4u t = *reinterpret_cast<const fbbev_v4u*>(p + base + 4 * q);
+            r[4 * q] = t[0]; r[4 * q + 1] = t[1]; r[4 * q + 2] = t[2]; r[4 * q + 3] = t[3];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) r[j] = (base + j < P) ? p[base + j] : fill;
+    }
+}
+
 template <int WAVES, int ITEMS>
 __global__ void __launch_bounds__(WAVES * 64)
 k_interval_count(const unsigned int* __restrict__ keys, const int* __restrict__ counts, const int* __restrict__ skip,
@@ -124,11 +143,13 @@ k_interval_count(const unsigned int* __restrict__ keys, const int* __restrict__ 
     const long long base = wg0 + (long long)tid * ITEMS;
     int local = 0, last1 = 0;
     unsigned int prevk = (base > 0 && base <= P) ? keys[base - 1] : 0u;
+    unsigned int kk[ITEMS];
+    fbbev_ld_run<ITEMS>(keys, base, P, 0u, kk);
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const long long i = base + j;
         if (i < P) {
-            const unsigned int k = keys[i];
+            const unsigned int k = kk[j];
             if (i == 0 || prevk != k) { ++local; last1 = (int)i + 1; }
             prevk = k;
         }
@@ -182,38 +203,56 @@ k_interval_write(const unsigned int* __restrict__ keys, const unsigned int* __re
     unsigned int key[ITEMS];
     int local = 0, last1 = 0;
     unsigned int prevk = (base > 0 && base <= P) ? keys[base - 1] : 0u;
+    unsigned int pid[ITEMS];
+    fbbev_ld_run<ITEMS>(keys, base, P, 0u, key);
+    fbbev_ld_run<ITEMS>(vals, base, P, 0u, pid);
+    int rf[ITEMS];
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const long long i = base + j;
         head[j] = false;
-        key[j] = 0u;
+        rf[j] = 0;
         if (i < P) {
-            const unsigned int k = keys[i];
-            key[j] = k;
+            const unsigned int k = key[j];
             head[j] = (i == 0 || prevk != k);
             prevk = k;
             if (head[j]) { ++local; last1 = (int)i + 1; }
             // view_transformer.py:563-568: feature pixel of point ((b*N+n)*D+d)*HW + hw
-            const unsigned int pid = vals[i];
-            const unsigned int cam = fbbev_div(pid, div_dhw), hw = pid - fbbev_div(pid, div_hw) * div_hw.d;
-            ranks_feat[i] = (int)(cam * div_hw.d + hw);
+            const unsigned int cam = fbbev_div(pid[j], div_dhw), hw = pid[j] - fbbev_div(pid[j], div_hw) * div_hw.d;
+            rf[j] = (int)(cam * div_hw.d + hw);
         }
+    }
+    if (base + ITEMS <= P && ((reinterpret_cast<uintptr_t>(ranks_feat + base) & 15u) == 0)) {
+#pragma unroll
+        for (int q = 0; q < ITEMS / 4; ++q) {
+            fbbev_v4i t;
+            t[0] = rf[4 * q]; t[1] = rf[4 * q + 1]; t[2] = rf[4 * q + 2]; t[3] = rf[4 * q + 3];
+            *reinterpret_cast<fbbev_v4i*>(ranks_feat + base + 4 * q) = t;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j)
+            if (base + j < P) ranks_feat[base + j] = rf[j];
     }
     int tot, wg_last1;
     const int off = fbbev_block_excl_scan_w<WAVES, false>(local, ldsw, &tot);
-    const int prev1 = fbbev_block_excl_scan_w<WAVES, true>(last1, ldsw, &wg_last1);   // last head before this thread, +1
-    int j0 = before_heads + off;
-    int prevhead1 = prev1 ? prev1 : before_last1;        // position + 1 of the head before this thread's first head
+    (void)fbbev_block_excl_scan_w<WAVES, true>(last1, ldsw, &wg_last1);
+    // the chunk's heads, compacted in LDS (position, voxel), then written with consecutive lanes on consecutive interval
+    // slots: a thread storing its own ~5 heads one by one scatters every store instruction over 64 x 20-byte strides
+    int* hpos = reinterpret_cast<int*>(fbbev_dyn_lds_f32());        // [TILE] positions, then [TILE] voxel ranks
+    int* hkey = hpos + TILE;
+    {
+        int o = off;
 #pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        if (head[j]) {
-            const int pos = (int)(base + j);
-            interval_starts[j0] = pos;
-            if (interval_rank) interval_rank[j0] = (int)key[j];
-            if (j0 > 0) interval_lengths[j0 - 1] = pos - (prevhead1 - 1);
-            prevhead1 = pos + 1;
-            ++j0;
-        }
+        for (int j = 0; j < ITEMS; ++j)
+            if (head[j]) { hpos[o] = (int)(base + j); hkey[o] = (int)key[j]; ++o; }
+    }
+    __syncthreads();
+    for (int o = tid; o < tot; o += NT) {
+        const int pos = hpos[o], j0 = before_heads + o;
+        interval_starts[j0] = pos;
+        if (interval_rank) interval_rank[j0] = hkey[o];
+        if (j0 > 0) interval_lengths[j0 - 1] = pos - (o > 0 ? hpos[o - 1] : before_last1 - 1);
     }
     if (tid == 0 && wg0 + TILE >= P) {                    // the chunk that holds the last point closes the chain
         const int I = before_heads + tot;

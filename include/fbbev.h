@@ -306,6 +306,22 @@ int fbbev_da_cross_attn_bwd(const float* value, const int64_t* spatial_shapes, c
                             int head_stride, float* grad_value, float* grad_pred_depth, float* grad_offsets,
                             float* grad_attn, fbbev_stream_t stream);
 
+/* fbbev_da_cross_attn_bwd with the value gradient accumulated in LDS planes instead of global atomics: a workgroup
+ * owns (sample, head, chunk of BEV queries), keeps the head's (S x head_stride) gradient plane of one camera at a
+ * time in LDS and writes it to its slice of `ws`; a second launch sums the slices into grad_value (written, not
+ * accumulated -- no pre-zeroing needed for it; grad_pred_depth / grad_offsets / grad_attn are accumulated as in
+ * fbbev_da_cross_attn_bwd and must be pre-zeroed).  ws: fbbev_da_cross_attn_bwd_ws_bytes(...) bytes, 16-byte
+ * aligned; returns 0 bytes when the shape does not fit (plane > 64 KiB).  With ws == NULL, too small, or an
+ * unsupported shape the call IS fbbev_da_cross_attn_bwd (same results up to the order of the fp32 adds). */
+size_t fbbev_da_cross_attn_bwd_ws_bytes(int B, int Ncam, int S, int M, int Dh, int Q, int head_stride);
+int fbbev_da_cross_attn_bwd_ws(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                               const float* pred_depth, const float* ref_cam, const uint8_t* mask,
+                               const float* qdepth, const float* offsets, const float* attn,
+                               const float* grad_slots, int B, int Ncam, int S, int M, int Dh, int L, int Q,
+                               int P, int Za, int DC, float d0, float dstep, int head_minor, int head_stride,
+                               float* grad_value, float* grad_pred_depth, float* grad_offsets,
+                               float* grad_attn, void* ws, size_t ws_bytes, fbbev_stream_t stream);
+
 /* Training backward of the fused lift-splat:  replaces QuickCumsumCuda.backward (bev_pool.py:39-78 --
  * argsort of ranks_feat, mask-built intervals [2 host syncs], the permute().contiguous() of the gradient)
  * and bev_pool_v2_backward / bev_pool_v2_grad_kernel (src/bev_pool_cuda.cu:52-100,128-135).

@@ -226,16 +226,23 @@ def layernorm(x, weight, bias, eps, residual=None):
 
 
 def da_cross_attn_bwd(value, ss, ls, pred_depth, ref_cam, mask, qdepth, offsets, attn, d0, dstep, grad_slots, head_minor=0,
-                      head_dim=None):
+                      head_dim=None, lds_planes=False):
     Ncam, B, Q, Za = mask.shape
     _, S, M, HS = value.shape
     Dh = HS if head_dim is None else head_dim
     L, P = (attn.shape[2], attn.shape[3]) if head_minor & 2 else (attn.shape[3], attn.shape[4])
     gv, gd, go, ga = (torch.zeros_like(t) for t in (value, pred_depth, offsets, attn))
     m8 = mask.to(torch.uint8).contiguous()
-    ok(lib().fbbev_da_cross_attn_bwd(p(value), p(ss), p(ls), p(pred_depth), p(ref_cam), p(m8), p(qdepth), p(offsets),
-                                     p(attn), p(grad_slots), B, Ncam, S, M, Dh, L, Q, P, Za, pred_depth.shape[1], d0,
-                                     dstep, int(head_minor), HS, p(gv), p(gd), p(go), p(ga), None))
+    args = (p(value), p(ss), p(ls), p(pred_depth), p(ref_cam), p(m8), p(qdepth), p(offsets), p(attn), p(grad_slots), B, Ncam,
+            S, M, Dh, L, Q, P, Za, pred_depth.shape[1], d0, dstep, int(head_minor), HS, p(gv), p(gd), p(go), p(ga))
+    if lds_planes:
+        need = lib().fbbev_da_cross_attn_bwd_ws_bytes(B, Ncam, S, M, Dh, Q, HS)
+        assert need > 0
+        ws = torch.full((need // 4,), float('nan'))
+        gv.fill_(float('nan'))                       # written, not accumulated
+        ok(lib().fbbev_da_cross_attn_bwd_ws(*args, p(ws), need, None))
+    else:
+        ok(lib().fbbev_da_cross_attn_bwd(*args, None))
     return gv, gd, go, ga
 
 

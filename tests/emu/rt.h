@@ -164,8 +164,11 @@ inline float* fbbev_dyn_lds_f32() {
 }
 typedef float fbbev_v4f __attribute__((vector_size(16)));
 typedef float fbbev_v2f __attribute__((vector_size(8)));
+typedef unsigned int fbbev_v4u __attribute__((vector_size(16)));
+typedef int fbbev_v4i __attribute__((vector_size(16)));
 template <int ST> inline void fbbev_store4(float* p, fbbev_v4f v) { memcpy(p, &v, 16); }
 inline void fbbev_atomic_add_f32(float* p, float v) { *p += v; }
+inline void fbbev_lds_atomic_add_f32(float* p, float v) { *p += v; }
 // emulation of v_mfma_f32_16x16x4_f32 with the documented fragment layouts (see csrc/hip_rt/rt.h); every lane of the
 // wave must call it (wave-uniform control flow, as on the hardware)
 inline fbbev_v4f fbbev_mfma_f32_16x16x4(float a, float b, fbbev_v4f c) {

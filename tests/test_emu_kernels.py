@@ -527,6 +527,26 @@ def test_fused_da_cross_attention_backward_emulated():
         # (atomics: the emulator runs lanes in a fixed order, so even the value gradient is reproducible)
         assert torch.allclose(_deinterleave(gv3), gv0, rtol=1e-5, atol=1e-6)
         assert torch.equal(gd3, gd0) and torch.equal(go3, go0) and torch.equal(ga3, ga0)
+        # value gradient through LDS planes + partial buffer (fbbev_da_cross_attn_bwd_ws): same sums in another order;
+        # several query chunks per (sample, head) so that the reduction over chunks is exercised
+        import os
+        for chunks in ('1', '3'):
+            os.environ['FBBEV_DA_BWD_CHUNKS'] = chunks
+            try:
+                for hm, vin in ((0, vp), (4, _interleave(vp)), (5, _interleave(vp))):
+                    o_in = f32(offsets).permute(0, 1, 3, 4, 2, 5).contiguous() if hm & 1 else f32(offsets)
+                    gv4, gd4, go4, ga4 = E.da_cross_attn_bwd(vin, ss, ls, f32(pred4), f32(ref_cam), mask, f32(qdepth), o_in,
+                                                             f32(attn), d0, dstep, f32(g), head_minor=hm, head_dim=Dh,
+                                                             lds_planes=True)
+                    if hm & 1:
+                        go4 = go4.permute(0, 1, 4, 2, 3, 5)
+                    gv4 = _deinterleave(gv4) if hm & 4 else gv4
+                    assert not torch.isnan(gv4).any()
+                    assert torch.allclose(gv4, gv0, rtol=1e-5, atol=1e-6) and not gv4[..., Dh:].any()
+                    assert torch.allclose(gd4, gd0, rtol=1e-5, atol=1e-6)
+                    assert torch.allclose(go4, go0, rtol=1e-5, atol=1e-6) and torch.allclose(ga4, ga0, rtol=1e-5, atol=1e-6)
+            finally:
+                del os.environ['FBBEV_DA_BWD_CHUNKS']
 
 
 @pytest.mark.parametrize('B,T1,C,Cout,N', [(1, 3, 16, 16, 64), (2, 2, 32, 16, 100), (1, 4, 16, 32, 17)])
