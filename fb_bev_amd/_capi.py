@@ -60,7 +60,7 @@ SIGNATURES = {
     'fbbev_point_sampling': (c_int, [c_void_p] * 9 + [c_int] * 5 + [c_float, c_float] + [c_void_p] * 4),
     'fbbev_da_cross_attn_fwd': (c_int, [c_void_p] * 9 + [c_int] * 10 + [c_float, c_float, c_int, c_int, c_void_p, c_void_p]),
     'fbbev_da_cross_attn_bwd': (c_int, [c_void_p] * 10 + [c_int] * 10 + [c_float, c_float, c_int, c_int] + [c_void_p] * 5),
-    'fbbev_da_cross_attn_bwd_ws_bytes': (c_size_t, [c_int] * 7),
+    'fbbev_da_cross_attn_bwd_ws_bytes': (c_size_t, [c_int] * 8),
     'fbbev_da_cross_attn_bwd_ws': (c_int, [c_void_p] * 10 + [c_int] * 10 + [c_float, c_float, c_int, c_int] + [c_void_p] * 4 +
                                    [c_void_p, c_size_t, c_void_p]),
     'fbbev_msda_fwd_fused': (c_int, [c_void_p] * 6 + [c_int] * 9 + [c_void_p, c_void_p]),
@@ -433,7 +433,7 @@ def da_cross_attn_bwd(value, spatial_shapes, level_start_index, pred_depth, ref_
     with _on(value):
         # value gradient through LDS planes + a partial buffer when the shape fits (fbbev_da_cross_attn_bwd_ws), else
         # the global-atomic kernel
-        need = lib().fbbev_da_cross_attn_bwd_ws_bytes(B, Ncam, S, M, Dh, Q, HS) if lds_planes else 0
+        need = lib().fbbev_da_cross_attn_bwd_ws_bytes(B, Ncam, S, M, Dh, Q, HS, L * P) if lds_planes else 0
         if need:
             ws = torch.empty(need // 4, dtype=torch.float32, device=value.device)
             _check(lib().fbbev_da_cross_attn_bwd_ws(*args, ws.data_ptr(), need, _stream()), 'fbbev_da_cross_attn_bwd_ws')

@@ -345,15 +345,16 @@ class FusedDACrossAttention(torch.autograd.Function):
         return gv, gd, go, ga, None, None, None, None, None, None, None, None, None
 
 
-def _pad_interleave_rows(w, b, M, Dh, HS):
+def _pad_interleave_rows(w, b, M, Dh, HS, interleave=True):
     """value_proj rows for the fused kernels: each head padded Dh -> HS (multiple of 4) output rows, then the rows of a
     token reordered (head m, chunk k, e) -> (chunk k, head m, e): the 8 head lanes of a query read one contiguous
     M*16-byte piece per load instruction (k_da_cross_attn_fwd_unit, QI).  Same dot products, only the row order of the
     weight matrix changes; differentiable (pad + permute of the parameter)."""
     E = w.shape[1]
-    w = F.pad(w.view(M, Dh, E), (0, 0, 0, HS - Dh)).view(M, HS // 4, 4, E).permute(1, 0, 2, 3).reshape(M * HS, E)
-    b = F.pad(b.view(M, Dh), (0, HS - Dh)).view(M, HS // 4, 4).permute(1, 0, 2).reshape(M * HS)
-    return w.contiguous(), b.contiguous()
+    w, b = F.pad(w.view(M, Dh, E), (0, 0, 0, HS - Dh)), F.pad(b.view(M, Dh), (0, HS - Dh))
+    if interleave:
+        w, b = w.view(M, HS // 4, 4, E).permute(1, 0, 2, 3), b.view(M, HS // 4, 4).permute(1, 0, 2)
+    return w.reshape(M * HS, E).contiguous(), b.reshape(M * HS).contiguous()
 
 
 FUSED_BWD_MAX_HEAD_DIM = 32                 # k_da_cross_attn_bwd: one lane per channel, groups of 16 / 32 lanes
@@ -390,8 +391,12 @@ class DA_SpatialCrossAttention(nn.Module):
         # (_pad_interleave_rows): every 4-channel chunk of a head is 16-byte aligned and the 8 heads' chunks are adjacent.
         # Same dot products for the real rows; the padding rows are zero and ignored by the kernel.
         wt, bs = da.value_proj.weight, da.value_proj.bias
-        if torch.is_grad_enabled() and (wt.requires_grad or bs.requires_grad):
-            w, bb = _pad_interleave_rows(wt, bs, M, Dh, HS)
+        interleave = True
+        if torch.is_grad_enabled() and (wt.requires_grad or bs.requires_grad or value.requires_grad):
+            # training: the backward keeps the value gradient in LDS planes when a head's plane fits (single-level FB-OCC
+            # shapes); otherwise it uses global atomics, whose 10 consecutive channel lanes want head-major rows
+            interleave = _capi.lib().fbbev_da_cross_attn_bwd_ws_bytes(B, ncam, S, M, Dh, Q, HS, da.num_levels * da.num_points) > 0
+            w, bb = _pad_interleave_rows(wt, bs, M, Dh, HS, interleave)
         else:                               # inference: once per weight version
             key = (wt.data_ptr(), wt._version, bs._version, str(wt.device))
             if getattr(self, '_vpad_key', None) != key:
@@ -406,7 +411,7 @@ class DA_SpatialCrossAttention(nn.Module):
             v.contiguous().float(), pred_img_depth.reshape(B * ncam, DC, H0, W0).contiguous().float(),
             so.contiguous().float(), aw.contiguous().float(), spatial_shapes.to(torch.int64).contiguous(),
             level_start_index.to(torch.int64).contiguous(), reference_points_cam.contiguous().float(), mask.contiguous(),
-            bev_query_depth.squeeze(-1).contiguous().float(), self.dbound[0], self.dbound[2], 1 | 4, Dh)
+            bev_query_depth.squeeze(-1).contiguous().float(), self.dbound[0], self.dbound[2], 1 | (4 if interleave else 0), Dh)
 
     # ---- training: vectorised rebatch + composite deformable attention (autograd through the MSDA op)
     def _slots_composite(self, query, value, reference_points_cam, mask, bev_query_depth, pred_img_depth,

@@ -899,30 +899,38 @@ extern "C" int fbbev_da_cross_attn_bwd(const float* value, const int64_t* spatia
 }
 
 // LDS-plane backward (k_da_cross_attn_bwd_tile + k_da_bwd_reduce): needs a caller-owned partial buffer
-struct da_bwd_plan { int chunks, q_per_chunk; size_t lds, ws; };
-static bool da_bwd_tile_plan(int B, int Ncam, int S, int M, int Dh, int Q, int HS, da_bwd_plan* pl) {
-    const size_t plane = (size_t)S * HS * sizeof(float);
-    // four lanes per unit, lane k = channels 4k..4k+3: head dims up to 16 (FB-OCC: 10); >= 2 workgroups per CU
-    if (plane > 64 * 1024 || Dh > 16 || HS % 4 != 0 || HS > 16 || Q <= 0) return false;
-    const int ng = 64;                                                            // queries per workgroup iteration
-    long long want = (1024 + (long long)B * M - 1) / ((long long)B * M);          // ~1024 workgroups (4 per CU)
+struct da_bwd_plan { int chunks, q_per_chunk, threads; size_t lds, ws; };
+static bool da_bwd_tile_plan(int B, int Ncam, int S, int M, int Dh, int Q, int HS, int LP, da_bwd_plan* pl) {
+    const size_t plane = (size_t)S * HS * sizeof(long long);                       // 64-bit fixed-point accumulators
+    // four lanes per unit, lane k = channels 4k..4k+3: head dims up to 16 (FB-OCC: 10); two workgroups per CU
+    if (plane > 72 * 1024 || Dh > 16 || HS % 4 != 0 || HS > 16 || Q <= 0) return false;
+    // two workgroups per CU in one round (512 of them); 512 threads (128 units per iteration, 16 waves per CU) when a
+    // chunk is long enough for a camera to see that many of its queries, else 256
+    long long want = (512 + (long long)B * M - 1) / ((long long)B * M);
     if (const char* e = getenv("FBBEV_DA_BWD_CHUNKS")) { const int v = atoi(e); if (v > 0) want = v; }
     if (want < 1) want = 1;
     if (want > 256) want = 256;
     int qpc = (int)((Q + want - 1) / want);
+    pl->threads = qpc >= 512 ? 512 : 256;
+    if (const char* e = getenv("FBBEV_DA_BWD_THREADS")) { const int v = atoi(e); if (v == 256 || v == 512) pl->threads = v; }
+    const int ng = pl->threads / 4;                                               // queries per workgroup iteration
     qpc = (qpc + ng - 1) / ng * ng;
     pl->q_per_chunk = qpc;
     pl->chunks = (Q + qpc - 1) / qpc;
-    pl->lds = plane + ((size_t)qpc + 4) * sizeof(int);                            // + the camera's hit list and its counter
+    // + the camera's hit list, its counter, the block maximum, and the per-group staging of the weight / offset gradients
+    if (qpc > 65535) return false;                                                // chunk-relative 16-bit query ids
+    pl->lds = plane + (size_t)((qpc + 1) & ~1) * 2 + (size_t)(1 + pl->threads / 64) * sizeof(int) + (size_t)ng * LP * 3 * sizeof(float);
+    if (pl->lds > 80 * 1024) return false;
     pl->ws = (size_t)B * M * pl->chunks * Ncam * S * HS * sizeof(float);
     return true;
 }
 
-extern "C" size_t fbbev_da_cross_attn_bwd_ws_bytes(int B, int Ncam, int S, int M, int Dh, int Q, int head_stride) {
-    if (B <= 0 || Ncam <= 0 || S <= 0 || M <= 0 || Dh <= 0) return 0;
+extern "C" size_t fbbev_da_cross_attn_bwd_ws_bytes(int B, int Ncam, int S, int M, int Dh, int Q, int head_stride,
+                                                   int samples_per_unit) {
+    if (B <= 0 || Ncam <= 0 || S <= 0 || M <= 0 || Dh <= 0 || samples_per_unit <= 0) return 0;
     da_bwd_plan pl;
     const int HS = head_stride == 0 ? Dh : head_stride;
-    if (HS < Dh || !da_bwd_tile_plan(B, Ncam, S, M, Dh, Q, HS, &pl)) return 0;
+    if (HS < Dh || !da_bwd_tile_plan(B, Ncam, S, M, Dh, Q, HS, samples_per_unit, &pl)) return 0;
     return pl.ws;
 }
 
@@ -937,7 +945,7 @@ extern "C" int fbbev_da_cross_attn_bwd_ws(const float* value, const int64_t* spa
         return FBBEV_E_BADARG;
     const int HS = head_stride == 0 ? Dh : head_stride;
     da_bwd_plan pl;
-    if (HS < Dh || Q == 0 || !ws || !aligned16(ws) || !aligned16(grad_value) || !da_bwd_tile_plan(B, Ncam, S, M, Dh, Q, HS, &pl) ||
+    if (HS < Dh || Q == 0 || !ws || !aligned16(ws) || !aligned16(grad_value) || !da_bwd_tile_plan(B, Ncam, S, M, Dh, Q, HS, L * P, &pl) ||
         ws_bytes < pl.ws || (long long)B * M * pl.chunks >= (1ll << 31))
         return fbbev_da_cross_attn_bwd(value, spatial_shapes, level_start_index, pred_depth, ref_cam, mask, qdepth, offsets,
                                        attn, grad_slots, B, Ncam, S, M, Dh, L, Q, P, Za, DC, d0, dstep, head_minor,
@@ -949,9 +957,13 @@ extern "C" int fbbev_da_cross_attn_bwd_ws(const float* value, const int64_t* spa
     fbbev_rt_stream stream = (fbbev_rt_stream)stream_;
     float* part = static_cast<float*>(ws);
     const long long wgs = (long long)B * M * pl.chunks;
-    FBBEV_LAUNCH(k_da_cross_attn_bwd_tile, wgs, 256, pl.lds, stream, value, spatial_shapes, level_start_index,
-                 pred_depth, ref_cam, mask, qdepth, offsets, attn, grad_slots, B, Ncam, S, M, Dh, L, Q, P, Za, DC, d0,
-                 dstep, head_minor & 7, HS, pl.chunks, pl.q_per_chunk, part, grad_pred_depth, grad_offsets, grad_attn);
+#define FBBEV_DA_BWD_TILE(NT_)                                                                                          \
+    FBBEV_LAUNCH(k_da_cross_attn_bwd_tile<NT_>, wgs, NT_, pl.lds, stream, value, spatial_shapes, level_start_index,     \
+                 pred_depth, ref_cam, mask, qdepth, offsets, attn, grad_slots, B, Ncam, S, M, Dh, L, Q, P, Za, DC, d0, \
+                 dstep, head_minor & 7, HS, pl.chunks, pl.q_per_chunk, part, grad_pred_depth, grad_offsets, grad_attn)
+    if (pl.threads == 512) FBBEV_DA_BWD_TILE(512);
+    else FBBEV_DA_BWD_TILE(256);
+#undef FBBEV_DA_BWD_TILE
     const long long n = (long long)B * Ncam * S * M * HS;
     long long rb = (n + 255) / 256;
     if (rb > 65536) rb = 65536;

@@ -362,18 +362,26 @@ k_da_cross_attn_bwd(long long n_units, const float* __restrict__ value, const in
 // k_da_cross_attn_bwd sends every corner of every sample to the value gradient with a global fp32 atomic: at the shipped
 // shapes (Q = 10^4, one 16x44 level) ~110 adds land on each of the 1.6 M gradient floats, across all 8 XCDs -- 1.5 ms at
 // B = 4, bound by the atomic rate.  Here a workgroup owns (sample b, head m, a chunk of consecutive BEV queries) and
-// walks the cameras in order; for each camera the head's gradient plane (S tokens x HS floats, 34 KB at the shipped
-// shape) lives in LDS, the corner adds are LDS atomics, and the finished plane is written with plain 16-byte stores to
-// this workgroup's slice of a partial buffer  part[b][m][chunk][cam][S*HS].  k_da_bwd_reduce then sums the chunks into
-// grad_value in the layout of `value` -- no global atomic touches the value gradient (its sum order over the chunks is
-// fixed; only the LDS adds inside a plane keep the hardware's order).  grad_attn / grad_offsets / grad_pred_depth as in
-// k_da_cross_attn_bwd: a group of GW lanes owns a (b,q,m) unit for every camera (same wave, program order), lane = channel.
+// walks the cameras in order; for each camera the head's gradient plane (S tokens x HS channels) lives in LDS, the corner
+// adds are LDS atomics, and the finished plane is written with plain 16-byte stores to this workgroup's slice of a
+// partial buffer  part[b][m][chunk][cam][S*HS].  k_da_bwd_reduce then sums the chunks into grad_value in the layout of
+// `value` -- no global atomic touches the value gradient.
+// The plane is FIXED POINT: 64-bit integers in units of 2^-30 of the power of two above max|grad_slots| of the chunk.
+// ds_add_f32 retires ~0.8 lanes per ns and CU on gfx950, ds_add_u64 22 (profiles/r02_micro_lds_atomics.jsonl: the fp32
+// LDS atomic is 40x slower than the integer ones), and integer adds commute: the value gradient is bit-reproducible run
+// to run, which neither the fp32-atomic kernels here nor mmcv's col2im are.  A contribution w*g*attn*dw is at most
+// max|g| in magnitude, so it is rounded ONCE to a multiple of 2^-30 of that bound (finer than its own fp32 ulp for
+// everything within 2^-6 of the largest contribution) and the <= q_per_chunk*L*P adds of a plane cannot overflow 63 bits;
+// the plane is converted back with one rounding.  Non-finite upstream gradients turn the chunk's planes into NaN.
+// grad_attn / grad_offsets: plain read-modify-writes of the unit's owner (the same workgroup handles a unit for every
+// camera, phases separated by barriers -> fixed order); grad_pred_depth: fp32 global atomics as in k_da_cross_attn_bwd.
 // Lane mapping: FOUR lanes own a (b,q,m) unit -- lane k its channels 4k..4k+3 (one 16-byte load per corner; with the
 // chunk-major token rows the three chunk lanes of a head read three 16-byte pieces) and its depth anchor z = k (k+4) --
 // so a wave works on 16 queries at once; the queries a camera sees (~28 % of a chunk) are first compacted into an LDS
 // list, so every group of every wave is busy.  (One lane per channel and one query per 16 lanes, the layout of the
 // atomic kernel, left 62 % of the lanes and a third of the groups active: 0.99 ms at the shipped shape, B = 4.)
-__global__ void __launch_bounds__(256)
+template <int NT>        // threads per workgroup: NT/4 units per iteration share one plane
+__global__ void __launch_bounds__(NT)
 k_da_cross_attn_bwd_tile(const float* __restrict__ value, const int64_t* __restrict__ spatial_shapes,
                          const int64_t* __restrict__ level_start, const float* __restrict__ pred_depth,
                          const float* __restrict__ ref_cam, const unsigned char* __restrict__ mask,
@@ -383,13 +391,15 @@ k_da_cross_attn_bwd_tile(const float* __restrict__ value, const int64_t* __restr
                          int HS, int n_chunks, int q_per_chunk, float* __restrict__ part,
                          float* __restrict__ grad_pred_depth, float* __restrict__ grad_offsets,
                          float* __restrict__ grad_attn) {
-    float* plane = fbbev_dyn_lds_f32();                        // [S][HS]
+    long long* plane = reinterpret_cast<long long*>(fbbev_dyn_lds_f32());     // [S][HS] fixed point
     const int plane_n = S * HS;
-    int* hits = reinterpret_cast<int*>(plane + plane_n);       // [q_per_chunk] queries of the chunk the camera sees
-    int* n_hits = hits + q_per_chunk;                          // [1]
+    unsigned short* hits = reinterpret_cast<unsigned short*>(plane + plane_n);   // [q_per_chunk] queries (chunk-relative) the camera sees
+    int* n_hits = reinterpret_cast<int*>(hits + ((q_per_chunk + 1) & ~1));       // [1]
+    float* red = reinterpret_cast<float*>(n_hits + 1);         // [NT/64] block maximum
+    float* stage = red + NT / 64;                              // [NT/4 groups][L*P][3]: a unit's weight / offset gradients of one camera
     const int lane = threadIdx.x & 63;
     const int k = threadIdx.x & 3;                             // channel chunk / anchor lane of the group
-    const int gidx = threadIdx.x >> 2;                         // group in the workgroup: 0..63
+    const int gidx = threadIdx.x >> 2;                         // group in the workgroup: 0..NT/4-1
     const int gbase = lane & ~3;                               // first lane of the group in its wave
     const int chunk = blockIdx.x % n_chunks;
     const int m = (blockIdx.x / n_chunks) % M;
@@ -400,12 +410,40 @@ k_da_cross_attn_bwd_tile(const float* __restrict__ value, const int64_t* __restr
     const int H0 = (int)spatial_shapes[0], W0 = (int)spatial_shapes[1];
     const int lane_off = (head_minor & 4) ? k * (M * 4) + m * 4 : m * HS + 4 * k;   // this lane's 4 channels in a token row
     const bool chunk_live = 4 * k < Dh;                        // HS may hold a chunk of pure padding (Dh = 8, HS = 12)
-    for (int i = threadIdx.x; i < plane_n; i += 256) plane[i] = 0.f;
+    for (int i = threadIdx.x; i < plane_n; i += NT) plane[i] = 0ll;
+    // scale of the fixed-point plane: sc = 2^(30 - ex) with max|grad_slots| < 2^ex over the chunk's units
+    float gmax = 0.f;
+    bool finite = true;
+    for (int i = threadIdx.x; i < nq * Dh; i += NT) {
+        const int qi = i / Dh, c = i - qi * Dh;
+        const float v = fabsf(grad_slots[(((long long)b * Q + q0 + qi) * M + m) * Dh + c]);
+        finite = finite && (v < __builtin_inff());             // false for inf and NaN
+        gmax = fmaxf(gmax, v);
+    }
+    if (!finite) gmax = __builtin_inff();
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, o, 64));
+    if (lane == 0) red[threadIdx.x >> 6] = gmax;
+    __syncthreads();
+    gmax = red[0];
+#pragma unroll
+    for (int w = 1; w < NT / 64; ++w) gmax = fmaxf(gmax, red[w]);
+    const bool poisoned = !(gmax < __builtin_inff());
+    float sc = 0.f, inv_sc = 0.f;
+    if (!poisoned && gmax > 0.f) {
+        unsigned int gb;
+        __builtin_memcpy(&gb, &gmax, 4);
+        int ex = (int)((gb >> 23) & 255u) - 126;               // gmax < 2^ex
+        if (ex < -90) ex = -90;                                 // tiny gradients: keep both scales normal numbers
+        const unsigned int sb = (unsigned int)(127 + 30 - ex) << 23, ib = (unsigned int)(127 - 30 + ex) << 23;
+        __builtin_memcpy(&sc, &sb, 4);
+        __builtin_memcpy(&inv_sc, &ib, 4);
+    }
     for (int cam = 0; cam < Ncam; ++cam) {
         const long long bn = (long long)b * Ncam + cam;
         if (threadIdx.x == 0) *n_hits = 0;
         __syncthreads();
-        for (int i0 = 0; i0 < nq; i0 += 256) {                 // ascending query order inside a wave's 64, waves in any order
+        for (int i0 = 0; i0 < nq; i0 += NT) {                 // ascending query order inside a wave's 64, waves in any order
             const int qi = i0 + threadIdx.x;
             bool hit = false;
             if (qi < nq) {
@@ -416,14 +454,14 @@ k_da_cross_attn_bwd_tile(const float* __restrict__ value, const int64_t* __restr
             int wbase = 0;
             if (lane == 0 && bal) wbase = atomicAdd(n_hits, __popcll(bal));
             wbase = __shfl(wbase, 0, 64);
-            if (hit) hits[wbase + __popcll(bal & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))))] = q0 + qi;
+            if (hit) hits[wbase + __popcll(bal & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))))] = (unsigned short)qi;
         }
         __syncthreads();
         const int nh = *n_hits;
-        for (int it = 0; it < nh; it += 64) {
+        for (int it = 0; it < nh; it += NT / 4) {
             const bool active = it + gidx < nh;
             if (__ballot(active ? 1 : 0) == 0ull) continue;
-            const int q = active ? hits[it + gidx] : q0;
+            const int q = q0 + (active ? (int)hits[it + gidx] : 0);
             const long long bq = (long long)b * Q + q;
             const long long u = bq * M + m;
             const long long base = (((long long)cam * B + b) * Q + q) * Za;
@@ -470,9 +508,8 @@ k_da_cross_attn_bwd_tile(const float* __restrict__ value, const int64_t* __restr
                 const int sh = (int)spatial_shapes[2 * l], sw = (int)spatial_shapes[2 * l + 1];
                 const int ls = (int)level_start[l];
                 const float* vp = value + (bn * S + ls) * row_stride + lane_off;
-                float* pl = plane + ls * HS + 4 * k;
+                long long* pl = plane + ls * HS + 4 * k;
                 for (int p = 0; p < P; ++p, ++lp) {
-                    const long long wo = wo0 + (long long)lp * wo_step, wa = wa0 + (long long)lp * wa_step;
                     const int nlp = lp + 1 < LP ? lp + 1 : lp;
                     const fbbev_v2f o = o_next;
                     const float a = active ? a_next : 0.f;
@@ -504,14 +541,12 @@ k_da_cross_attn_bwd_tile(const float* __restrict__ value, const int64_t* __restr
                         v1 = k1 ? v1 : zero; v2 = k2 ? v2 : zero; v3 = k3 ? v3 : zero; v4 = k4 ? v4 : zero;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const float tgv = g[e] * weight;
-                            // LDS fp32 atomics retire about one LANE per cycle and CU (SQ_WAIT_INST_LDS = 39 % of the wave
-                            // cycles, profiles/r02_pmc_da_bwd_tile.json): padding channels stay out of them
-                            const bool ce = 4 * k + e < Dh;
-                            if (k1 && ce) fbbev_lds_atomic_add_f32(pl + s.o1 * HS + e, s.w1 * tgv);
-                            if (k2 && ce) fbbev_lds_atomic_add_f32(pl + s.o2 * HS + e, s.w2 * tgv);
-                            if (k3 && ce) fbbev_lds_atomic_add_f32(pl + s.o3 * HS + e, s.w3 * tgv);
-                            if (k4 && ce) fbbev_lds_atomic_add_f32(pl + s.o4 * HS + e, s.w4 * tgv);
+                            const float tgv = g[e] * weight * sc;                 // sc is a power of two: exact
+                            const bool ce = 4 * k + e < Dh;                       // padding channels stay out of the atomics
+                            if (k1 && ce) fbbev_lds_atomic_add_i64(pl + s.o1 * HS + e, (long long)__float2int_rn(s.w1 * tgv));
+                            if (k2 && ce) fbbev_lds_atomic_add_i64(pl + s.o2 * HS + e, (long long)__float2int_rn(s.w2 * tgv));
+                            if (k3 && ce) fbbev_lds_atomic_add_i64(pl + s.o3 * HS + e, (long long)__float2int_rn(s.w3 * tgv));
+                            if (k4 && ce) fbbev_lds_atomic_add_i64(pl + s.o4 * HS + e, (long long)__float2int_rn(s.w4 * tgv));
                             dot += g[e] * (s.w1 * v1[e] + s.w2 * v2[e] + s.w3 * v3[e] + s.w4 * v4[e]);
                             gy += g[e] * (-s.hw * v1[e] - s.lw * v2[e] + s.hw * v3[e] + s.lw * v4[e]);
                             gx += g[e] * (-s.hh * v1[e] + s.hh * v2[e] - s.lh * v3[e] + s.lh * v4[e]);
@@ -520,14 +555,25 @@ k_da_cross_attn_bwd_tile(const float* __restrict__ value, const int64_t* __restr
                     dot += __shfl_xor(dot, 1, 64); dot += __shfl_xor(dot, 2, 64);
                     gx += __shfl_xor(gx, 1, 64);   gx += __shfl_xor(gx, 2, 64);
                     gy += __shfl_xor(gy, 1, 64);   gy += __shfl_xor(gy, 2, 64);
-                    // the unit's weight / offset gradients: one add per camera that sees the query (<= Ncam per element).
-                    // Fire-and-forget atomics: a read-modify-write would put a global round trip into every sample of the
-                    // chain (the workgroups of the other cameras' phases are this same workgroup, so there is no race --
-                    // only the latency); the order of the <= Ncam adds is the hardware's.
-                    if (inr && k == 0) fbbev_atomic_add_f32(grad_attn + wa, dwz * dot);
-                    if (inr && k == 1) fbbev_atomic_add_f32(grad_offsets + wo * 2, weight * gx);
-                    if (inr && k == 2) fbbev_atomic_add_f32(grad_offsets + wo * 2 + 1, weight * gy);
+                    // the unit's weight / offset gradients of this camera: parked in LDS, added to global memory after the
+                    // sample loop (a read-modify-write here would put a second global round trip into every sample)
+                    if (k < 3) stage[(gidx * LP + lp) * 3 + k] = !inr ? 0.f : (k == 0 ? dwz * dot : (k == 1 ? weight * gx : weight * gy));
                     if (inr && k == (z & 3)) ddwo[z >> 2] += a * dot;
+                }
+            }
+            // one add per camera that sees the query, in camera order: this workgroup is the unit's only writer and its
+            // camera phases are separated by barriers.  The group's 4 lanes share the L*P samples; (a zero is not added:
+            // the sample was outside the image)
+            (void)__ballot(1);       // the wave's LDS writes above precede these reads (program order of one wave; this
+                                     // makes the CPU emulator's lanes meet here as well)
+            if (active) {
+                for (int j = k; j < LP; j += 4) {
+                    const float* st = stage + (gidx * LP + j) * 3;
+                    const long long wo = wo0 + (long long)j * wo_step, wa = wa0 + (long long)j * wa_step;
+                    const float sa = st[0], sx = st[1], sy = st[2];
+                    if (sa != 0.f) grad_attn[wa] += sa;
+                    if (sx != 0.f) grad_offsets[wo * 2] += sx;
+                    if (sy != 0.f) grad_offsets[wo * 2 + 1] += sy;
                 }
             }
             // dw[z] -> the four corners of the query's bin plane (fbbev_plane_sample), each anchor by its own lane
@@ -548,11 +594,14 @@ k_da_cross_attn_bwd_tile(const float* __restrict__ value, const int64_t* __restr
         __syncthreads();
         // the camera's plane -> this workgroup's slice of the partial buffer; cleared for the next camera on the way
         float* dst = part + ((((long long)b * M + m) * n_chunks + chunk) * Ncam + cam) * (long long)plane_n;
-        for (int i = threadIdx.x * 4; i < plane_n; i += 256 * 4) {
-            const fbbev_v4f t = *reinterpret_cast<const fbbev_v4f*>(plane + i);
+        for (int i = threadIdx.x * 4; i < plane_n; i += NT * 4) {
+            fbbev_v4f t;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                t[e] = poisoned ? __builtin_nanf("") : (float)plane[i + e] * inv_sc;      // one rounding (int64 -> fp32)
+                plane[i + e] = 0ll;
+            }
             *reinterpret_cast<fbbev_v4f*>(dst + i) = t;
-            const fbbev_v4f zero = {0.f, 0.f, 0.f, 0.f};
-            *reinterpret_cast<fbbev_v4f*>(plane + i) = zero;
         }
         __syncthreads();
     }

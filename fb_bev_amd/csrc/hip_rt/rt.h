@@ -56,6 +56,11 @@ __device__ __forceinline__ void fbbev_store4(float* p, fbbev_v4f v) {
 }
 
 __device__ __forceinline__ void fbbev_atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }
+// 64-bit integer add on an LDS word pair (ds_add_u64, no return value): 22 lane-adds per ns and CU on gfx950 where
+// ds_add_f32 manages 0.8 (profiles/r02_micro_lds_atomics.jsonl)
+__device__ __forceinline__ void fbbev_lds_atomic_add_i64(long long* p, long long v) {
+    __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 // fp32 add on an LDS word (ds_add_f32, no return value)
 __device__ __forceinline__ void fbbev_lds_atomic_add_f32(float* p, float v) {
     __builtin_amdgcn_ds_faddf((__attribute__((address_space(3))) float*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP, false);

@@ -311,9 +311,10 @@ int fbbev_da_cross_attn_bwd(const float* value, const int64_t* spatial_shapes, c
  * time in LDS and writes it to its slice of `ws`; a second launch sums the slices into grad_value (written, not
  * accumulated -- no pre-zeroing needed for it; grad_pred_depth / grad_offsets / grad_attn are accumulated as in
  * fbbev_da_cross_attn_bwd and must be pre-zeroed).  ws: fbbev_da_cross_attn_bwd_ws_bytes(...) bytes, 16-byte
- * aligned; returns 0 bytes when the shape does not fit (plane > 64 KiB).  With ws == NULL, too small, or an
+ * aligned; returns 0 bytes when the shape does not fit (64-bit plane + staging > 80 KiB of LDS).  With ws == NULL, too small, or an
  * unsupported shape the call IS fbbev_da_cross_attn_bwd (same results up to the order of the fp32 adds). */
-size_t fbbev_da_cross_attn_bwd_ws_bytes(int B, int Ncam, int S, int M, int Dh, int Q, int head_stride);
+size_t fbbev_da_cross_attn_bwd_ws_bytes(int B, int Ncam, int S, int M, int Dh, int Q, int head_stride,
+                                        int samples_per_unit /* num_levels * num_points */);
 int fbbev_da_cross_attn_bwd_ws(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
                                const float* pred_depth, const float* ref_cam, const uint8_t* mask,
                                const float* qdepth, const float* offsets, const float* attn,

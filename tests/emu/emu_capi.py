@@ -236,7 +236,7 @@ def da_cross_attn_bwd(value, ss, ls, pred_depth, ref_cam, mask, qdepth, offsets,
     args = (p(value), p(ss), p(ls), p(pred_depth), p(ref_cam), p(m8), p(qdepth), p(offsets), p(attn), p(grad_slots), B, Ncam,
             S, M, Dh, L, Q, P, Za, pred_depth.shape[1], d0, dstep, int(head_minor), HS, p(gv), p(gd), p(go), p(ga))
     if lds_planes:
-        need = lib().fbbev_da_cross_attn_bwd_ws_bytes(B, Ncam, S, M, Dh, Q, HS)
+        need = lib().fbbev_da_cross_attn_bwd_ws_bytes(B, Ncam, S, M, Dh, Q, HS, L * P)
         assert need > 0
         ws = torch.full((need // 4,), float('nan'))
         gv.fill_(float('nan'))                       # written, not accumulated

@@ -142,6 +142,7 @@ inline unsigned long long __ballot(int pred) {
     return m;
 }
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+inline int __float2int_rn(float x) { return (int)__builtin_rintf(x); }      // nearest even, as v_cvt_i32 after v_rndne
 inline int __ffsll(long long x) { return __builtin_ffsll(x); }
 inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 inline unsigned int atomicOr(unsigned int* p, unsigned int v) { unsigned int o = *p; *p = o | v; return o; }
@@ -169,6 +170,7 @@ typedef int fbbev_v4i __attribute__((vector_size(16)));
 template <int ST> inline void fbbev_store4(float* p, fbbev_v4f v) { memcpy(p, &v, 16); }
 inline void fbbev_atomic_add_f32(float* p, float v) { *p += v; }
 inline void fbbev_lds_atomic_add_f32(float* p, float v) { *p += v; }
+inline void fbbev_lds_atomic_add_i64(long long* p, long long v) { *p += v; }
 // emulation of v_mfma_f32_16x16x4_f32 with the documented fragment layouts (see csrc/hip_rt/rt.h); every lane of the
 // wave must call it (wave-uniform control flow, as on the hardware)
 inline fbbev_v4f fbbev_mfma_f32_16x16x4(float a, float b, fbbev_v4f c) {

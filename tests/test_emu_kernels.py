@@ -530,8 +530,9 @@ def test_fused_da_cross_attention_backward_emulated():
         # value gradient through LDS planes + partial buffer (fbbev_da_cross_attn_bwd_ws): same sums in another order;
         # several query chunks per (sample, head) so that the reduction over chunks is exercised
         import os
-        for chunks in ('1', '3'):
+        for chunks, threads in (('1', '256'), ('3', '256'), ('2', '512')):
             os.environ['FBBEV_DA_BWD_CHUNKS'] = chunks
+            os.environ['FBBEV_DA_BWD_THREADS'] = threads
             try:
                 for hm, vin in ((0, vp), (4, _interleave(vp)), (5, _interleave(vp))):
                     o_in = f32(offsets).permute(0, 1, 3, 4, 2, 5).contiguous() if hm & 1 else f32(offsets)
@@ -546,7 +547,7 @@ def test_fused_da_cross_attention_backward_emulated():
                     assert torch.allclose(gd4, gd0, rtol=1e-5, atol=1e-6)
                     assert torch.allclose(go4, go0, rtol=1e-5, atol=1e-6) and torch.allclose(ga4, ga0, rtol=1e-5, atol=1e-6)
             finally:
-                del os.environ['FBBEV_DA_BWD_CHUNKS']
+                del os.environ['FBBEV_DA_BWD_CHUNKS'], os.environ['FBBEV_DA_BWD_THREADS']
 
 
 @pytest.mark.parametrize('B,T1,C,Cout,N', [(1, 3, 16, 16, 64), (2, 2, 32, 16, 100), (1, 4, 16, 32, 17)])

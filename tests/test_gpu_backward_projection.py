@@ -127,6 +127,45 @@ def test_training_paths_equal_inference_and_backprop(dev, train_fused):
             assert close(p.grad, P[name].grad, 5e-3), name
 
 
+def test_lds_plane_backward_equals_atomic_backward_and_is_reproducible(dev):
+    """fbbev_da_cross_attn_bwd_ws (fixed-point gradient planes in LDS, partial buffer, fixed-order reduction) against
+    fbbev_da_cross_attn_bwd (fp32 global atomics) at the shipped shape; the value gradient of the former is bit-identical
+    run to run (integer adds commute), which the atomic kernel -- like mmcv's col2im -- is not required to be."""
+    from fb_bev_amd import _capi
+    g = torch.Generator().manual_seed(11)
+    B, Ncam, Q, M, Dh, HS, P, Za, DC, H0, W0 = 2, 6, 2500, 8, 10, 12, 8, 4, 80, 16, 44
+    S_ = H0 * W0
+    value = torch.randn(B * Ncam, S_, M, HS, generator=g)
+    value[..., Dh:] = 0
+    value = value.view(B * Ncam, S_, HS // 4, M, 4).contiguous().view(B * Ncam, S_, M, HS)      # any floats: layout-agnostic
+    pred = torch.rand(B * Ncam, DC, H0, W0, generator=g).softmax(1)
+    ref_cam = torch.rand(Ncam, B, Q, Za, 2, generator=g) * 1.2 - 0.1
+    mask = torch.rand(Ncam, B, Q, Za, generator=g) < 0.15
+    qdepth = torch.rand(Ncam, B, Q, Za, generator=g) * 45 + 1
+    offsets = torch.randn(B, Q, 1, P, M, 2, generator=g) * 1.5                                  # head-minor (B,Q,L,P,M,2)
+    attn = torch.rand(B, Q, M, 1 * P, generator=g).softmax(-1).view(B, Q, M, 1, P)
+    gs = torch.randn(B, Q, M * Dh, generator=g) * 3.0
+    ss = torch.tensor([[H0, W0]]); ls = torch.tensor([0])
+    t = lambda x: x.to(dev).contiguous()  # noqa: E731
+    args = [t(value), t(ss), t(ls), t(pred), t(ref_cam), t(mask), t(qdepth), t(offsets), t(attn), t(gs), 1.0, 0.5, 1 | 4]
+
+    def run(lds):
+        gv, gd, go, ga = (torch.zeros_like(x) for x in (args[0], args[3], args[7], args[8]))
+        _capi.da_cross_attn_bwd(*args, gv, gd, go, ga, head_dim=Dh, lds_planes=lds)
+        torch.cuda.synchronize()
+        return gv, gd, go, ga
+    assert _capi.lib().fbbev_da_cross_attn_bwd_ws_bytes(B, Ncam, S_, M, Dh, Q, HS, P) > 0
+    a, b, c = run(True), run(True), run(False)
+    assert torch.equal(a[0], b[0])                                      # reproducible value gradient
+    assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])          # and the unit-owned ones
+    for x, y in zip(a, c):
+        scale = y.abs().max().item()
+        assert scale > 0 and (x - y).abs().max().item() <= 2e-6 * scale + 1e-7, ((x - y).abs().max().item(), scale)
+    # non-finite upstream gradient: the chunk's planes are NaN, not silently finite
+    args[9] = args[9].clone(); args[9][0, 0, 0] = float('inf')
+    assert torch.isnan(run(True)[0]).any()
+
+
 @pytest.mark.parametrize('E,M,L', [(80, 8, 1), (64, 8, 2)])
 def test_self_attention_fused_inference_equals_composed(dev, E, M, L):
     """MultiScaleDeformableAttention inference (fbbev_msda_fwd_fused: locations built in the kernel, padded value rows)
