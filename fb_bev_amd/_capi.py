@@ -59,6 +59,7 @@ SIGNATURES = {
     'fbbev_msda_fwd': (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_void_p, c_void_p]),
     'fbbev_point_sampling': (c_int, [c_void_p] * 9 + [c_int] * 5 + [c_float, c_float] + [c_void_p] * 4),
     'fbbev_da_cross_attn_fwd': (c_int, [c_void_p] * 9 + [c_int] * 10 + [c_float, c_float, c_int, c_int, c_void_p, c_void_p]),
+    'fbbev_da_cross_attn_fwd_e': (c_int, [c_void_p] * 9 + [c_int] * 10 + [c_float, c_float, c_int, c_int, c_int] + [c_void_p, c_void_p]),
     'fbbev_da_cross_attn_bwd': (c_int, [c_void_p] * 10 + [c_int] * 10 + [c_float, c_float, c_int, c_int] + [c_void_p] * 5),
     'fbbev_da_cross_attn_bwd_ws_bytes': (c_size_t, [c_int] * 8),
     'fbbev_da_cross_attn_bwd_ws': (c_int, [c_void_p] * 10 + [c_int] * 10 + [c_float, c_float, c_int, c_int] + [c_void_p] * 4 +
@@ -402,6 +403,16 @@ def da_cross_attn_fwd(value, spatial_shapes, level_start_index, pred_depth, ref_
     DC = pred_depth.shape[1]
     if mask.dtype == torch.bool:
         mask = mask.view(torch.uint8)
+    if value.dtype != torch.float32:
+        with _on(value):
+            _check(lib().fbbev_da_cross_attn_fwd_e(
+                _dev(value, value.dtype, 'value'), _dev(spatial_shapes, I64, 'spatial_shapes'),
+                _dev(level_start_index, I64, 'level_start_index'), _dev(pred_depth, F32, 'pred_depth'),
+                _dev(ref_cam, F32, 'ref_cam'), _dev(mask, torch.uint8, 'mask'), _dev(qdepth, F32, 'qdepth'),
+                _dev(offsets, F32, 'offsets'), _dev(attn, F32, 'attn'), B, Ncam, S, M, Dh, L, Q, P, Za, DC,
+                float(d0), float(dstep), head_minor, HS, ELEM_TYPE[value.dtype], _dev(slots, F32, 'slots'), _stream()),
+                'fbbev_da_cross_attn_fwd_e')
+        return
     with _on(value):
         _check(lib().fbbev_da_cross_attn_fwd(
             _dev(value, F32, 'value'), _dev(spatial_shapes, I64, 'spatial_shapes'),

@@ -345,15 +345,15 @@ class FusedDACrossAttention(torch.autograd.Function):
         return gv, gd, go, ga, None, None, None, None, None, None, None, None, None
 
 
-def _pad_interleave_rows(w, b, M, Dh, HS, interleave=True):
+def _pad_interleave_rows(w, b, M, Dh, HS, interleave=True, piece=4):
     """value_proj rows for the fused kernels: each head padded Dh -> HS (multiple of 4) output rows, then the rows of a
     token reordered (head m, chunk k, e) -> (chunk k, head m, e): the 8 head lanes of a query read one contiguous
     M*16-byte piece per load instruction (k_da_cross_attn_fwd_unit, QI).  Same dot products, only the row order of the
     weight matrix changes; differentiable (pad + permute of the parameter)."""
     E = w.shape[1]
     w, b = F.pad(w.view(M, Dh, E), (0, 0, 0, HS - Dh)), F.pad(b.view(M, Dh), (0, HS - Dh))
-    if interleave:
-        w, b = w.view(M, HS // 4, 4, E).permute(1, 0, 2, 3), b.view(M, HS // 4, 4).permute(1, 0, 2)
+    if interleave:                       # piece = elements of a (chunk, head) piece: 4 floats or 8 16-bit elements = 16 bytes
+        w, b = w.view(M, HS // piece, piece, E).permute(1, 0, 2, 3), b.view(M, HS // piece, piece).permute(1, 0, 2)
     return w.reshape(M * HS, E).contiguous(), b.reshape(M * HS).contiguous()
 
 
@@ -375,6 +375,9 @@ class DA_SpatialCrossAttention(nn.Module):
         self.output_proj = nn.Linear(embed_dims, embed_dims)
         self.layer_scale = nn.Parameter(layer_scale * torch.ones(embed_dims)) if layer_scale is not None else None
         self.fused = fused
+        # inference option (not part of the reference config): camera tokens (value_proj output) kept in bf16 / fp16 for the
+        # fused sampling kernel -- half the gather bytes, fp32 accumulate; None = fp32 (the reference's precision)
+        self.value_dtype = None
         _xavier(self.output_proj)
 
     # ---- inference: one fused HIP launch (fbbev_da_cross_attn_fwd), no host sync
@@ -392,6 +395,27 @@ class DA_SpatialCrossAttention(nn.Module):
         # Same dot products for the real rows; the padding rows are zero and ignored by the kernel.
         wt, bs = da.value_proj.weight, da.value_proj.bias
         interleave = True
+        grad_mode = torch.is_grad_enabled() and (wt.requires_grad or bs.requires_grad or value.requires_grad or
+                                                 query.requires_grad or pred_img_depth.requires_grad)
+        if self.value_dtype in (torch.bfloat16, torch.float16) and not grad_mode and Dh in (8, 10, 16, 32):
+            # 16-bit tokens: rows chunk-major with 8-element pieces, rounded once after the fp32 projection
+            HS16 = (Dh + 7) // 8 * 8
+            key = (wt.data_ptr(), wt._version, bs._version, str(wt.device), self.value_dtype)
+            if getattr(self, '_vpad16_key', None) != key:
+                with torch.no_grad():
+                    self._vpad16 = _pad_interleave_rows(wt, bs, M, Dh, HS16, True, piece=8)
+                self._vpad16_key = key
+            w, bb = self._vpad16
+            v = F.linear(x, w, bb).to(self.value_dtype).view(B * ncam, S, M, HS16)
+            so, aw = da.project_head_minor(query)
+            DC, H0, W0 = pred_img_depth.shape[2:]
+            slots = torch.empty((B, Q, M * Dh), dtype=torch.float32, device=query.device)
+            _capi.da_cross_attn_fwd(v, spatial_shapes.to(torch.int64).contiguous(), level_start_index.to(torch.int64).contiguous(),
+                                    pred_img_depth.reshape(B * ncam, DC, H0, W0).contiguous().float(),
+                                    reference_points_cam.contiguous().float(), mask.contiguous(),
+                                    bev_query_depth.squeeze(-1).contiguous().float(), so.contiguous().float(),
+                                    aw.contiguous().float(), self.dbound[0], self.dbound[2], slots, head_minor=1 | 4, head_dim=Dh)
+            return slots
         if torch.is_grad_enabled() and (wt.requires_grad or bs.requires_grad or value.requires_grad):
             # training: the backward keeps the value gradient in LDS planes when a head's plane fits (single-level FB-OCC
             # shapes); otherwise it uses global atomics, whose 10 consecutive channel lanes want head-major rows

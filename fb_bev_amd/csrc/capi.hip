@@ -812,6 +812,52 @@ extern "C" int fbbev_msda_bwd(const float* value, const int64_t* spatial_shapes,
 }
 
 // ------------------------------------------------------------------------------ fused DA cross-attention
+// 16-bit token rows (value_elem_type 1 = bf16, 2 = f16): chunk-major rows of 8-element pieces, unit-per-lane kernel only
+extern "C" int fbbev_da_cross_attn_fwd_e(const void* value, const int64_t* spatial_shapes,
+                                         const int64_t* level_start_index, const float* pred_depth,
+                                         const float* ref_cam, const uint8_t* mask, const float* qdepth,
+                                         const float* offsets, const float* attn, int B, int Ncam, int S, int M,
+                                         int Dh, int L, int Q, int P, int Za, int DC, float d0, float dstep,
+                                         int head_minor, int head_stride, int value_elem_type, float* slots,
+                                         fbbev_stream_t stream_) {
+    if (value_elem_type == 0)
+        return fbbev_da_cross_attn_fwd(static_cast<const float*>(value), spatial_shapes, level_start_index, pred_depth, ref_cam,
+                                       mask, qdepth, offsets, attn, B, Ncam, S, M, Dh, L, Q, P, Za, DC, d0, dstep, head_minor,
+                                       head_stride, slots, stream_);
+    if (value_elem_type != 1 && value_elem_type != 2) return FBBEV_E_BADARG;
+    if (B <= 0 || Ncam <= 0 || S <= 0 || M <= 0 || Dh <= 0 || L <= 0 || Q < 0 || P <= 0 || Za <= 0 || DC <= 0)
+        return FBBEV_E_BADARG;
+    if (Za > FBBEV_DA_MAX_ZA || P % Za != 0) return FBBEV_E_UNSUPPORTED;
+    if (dstep == 0.f) return FBBEV_E_BADARG;
+    const long long units = (long long)B * Q * M;
+    if (units == 0) return 0;
+    if (!value || !spatial_shapes || !level_start_index || !pred_depth || !ref_cam || !mask || !qdepth ||
+        !offsets || !attn || !slots) return FBBEV_E_BADARG;
+    const int HS = head_stride;
+    // chunk-major rows of 8-element pieces covering Dh; 32-bit byte offsets; 8-byte aligned offsets / slots
+    if (!(head_minor & 4) || HS % 8 != 0 || HS < (Dh + 7) / 8 * 8 || !aligned16(value) ||
+        (((uintptr_t)offsets | (uintptr_t)slots) & 7) != 0 || (long long)B * Ncam * S * M * HS * 2 >= (1ll << 32) ||
+        !(Dh == 10 || Dh == 8 || Dh == 16 || Dh == 32)) return FBBEV_E_UNSUPPORTED;
+    long long ub = ((units + 255) / 256 + 7) / 8 * 8;
+    if (ub > 65536) ub = 65536;
+    const int LP = L * P;
+    const bool stage = !(head_minor & 2) && LP % 4 == 0 && LP <= 36 && aligned16(attn);
+    const size_t lds = stage ? (size_t)256 * (LP + 1) * sizeof(float) : 0;
+#define FBBEV_DA_UNIT16(DH_, ET_)                                                                                    \
+    FBBEV_LAUNCH((k_da_cross_attn_fwd_unit<DH_, true, true, ET_>), ub, 256, lds, (fbbev_rt_stream)stream_, units, value, \
+                 spatial_shapes, level_start_index, pred_depth, ref_cam, mask, qdepth, offsets, attn, B, Ncam, S, M,  \
+                 L, Q, P, Za, DC, d0, dstep, head_minor & 3, HS, stage ? 1 : 0, slots)
+#define FBBEV_DA_UNIT16_ET(DH_) do { if (value_elem_type == 1) FBBEV_DA_UNIT16(DH_, 1); else FBBEV_DA_UNIT16(DH_, 2); } while (0)
+    if (Dh == 10) FBBEV_DA_UNIT16_ET(10);
+    else if (Dh == 8) FBBEV_DA_UNIT16_ET(8);
+    else if (Dh == 16) FBBEV_DA_UNIT16_ET(16);
+    else FBBEV_DA_UNIT16_ET(32);
+#undef FBBEV_DA_UNIT16_ET
+#undef FBBEV_DA_UNIT16
+    FBBEV_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int fbbev_da_cross_attn_fwd(const float* value, const int64_t* spatial_shapes,
                                        const int64_t* level_start_index, const float* pred_depth,
                                        const float* ref_cam, const uint8_t* mask, const float* qdepth,

@@ -118,9 +118,10 @@ k_da_cross_attn_fwd(long long n, const float* __restrict__ value, const int64_t*
 // WIDE: the head stride HS is a multiple of 4 floats and covers DH rounded up to 4 (the host pads value_proj's output
 // rows, e.g. Dh = 10 -> HS = 12): every head chunk is 16-byte aligned and a corner is read as DHP/4 dwordx4 loads
 // (3 L1 accesses instead of 5 eight-byte ones; the padding floats are loaded and ignored).
-template <int DH, bool WIDE, bool QI>
+// ET: element type of the token rows -- 0 f32; 1 bf16 / 2 f16 (inference option, QI only: [chunk][head][8 elements]).
+template <int DH, bool WIDE, bool QI, int ET = 0>
 __global__ void __launch_bounds__(256)
-k_da_cross_attn_fwd_unit(long long n_units, const float* __restrict__ value, const int64_t* __restrict__ spatial_shapes,
+k_da_cross_attn_fwd_unit(long long n_units, const void* __restrict__ value_, const int64_t* __restrict__ spatial_shapes,
                          const int64_t* __restrict__ level_start, const float* __restrict__ pred_depth,
                          const float* __restrict__ ref_cam, const unsigned char* __restrict__ mask,
                          const float* __restrict__ qdepth, const float* __restrict__ offsets,
@@ -129,10 +130,14 @@ k_da_cross_attn_fwd_unit(long long n_units, const float* __restrict__ value, con
                          float* __restrict__ slots) {
     static_assert(DH % 2 == 0, "eight-byte loads");
     static_assert(!QI || WIDE, "quad-interleaved rows are read with 16-byte loads");
+    static_assert(ET == 0 || QI, "16-bit rows are chunk-major");
+    const float* value = static_cast<const float*>(value_);
+    constexpr int CE = ET == 0 ? 4 : 8;           // elements per (chunk, head) piece: 16 bytes either way
+    constexpr unsigned ESZ = ET == 0 ? 4u : 2u;
     // QI: a camera token's row is stored [chunk k][head m][4 floats] instead of [head m][HS floats]: the 8 head lanes
     // of a query then read ONE contiguous M*16-byte piece per load instruction (one 128-byte line at M = 8) where the
     // head-major row makes every one of the DHP/4 loads touch all of the row's lines.  Same floats, same arithmetic.
-    const int head_off_m = QI ? 4 : HS, chunk_stride = QI ? M * 4 : 4;
+    const int head_off_m = QI ? CE : HS, chunk_stride = QI ? M * CE : 4;
     const int row_stride = M * HS;
     const int H0 = (int)spatial_shapes[0], W0 = (int)spatial_shapes[1];
     const int LP = L * P, LDW = LP + 1;
@@ -195,7 +200,7 @@ k_da_cross_attn_fwd_unit(long long n_units, const float* __restrict__ value, con
             int lp = 0;
             for (int l = 0; l < L; ++l) {
                 const int sh = (int)spatial_shapes[2 * l], sw = (int)spatial_shapes[2 * l + 1];
-                const unsigned lane_off = (unsigned)(((bn * S + level_start[l]) * row_stride + m * head_off_m) * 4);
+                const unsigned lane_off = (unsigned)(((bn * S + level_start[l]) * row_stride + m * head_off_m) * ESZ);
                 for (int p = 0; p < P; ++p, ++lp) {
                     // head-minor (B,Q,L,P,M[,2]): the 8 heads of a query read 64 contiguous bytes per sample; the
                     // (B,Q,M,L,P[,2]) layout strides lanes by L*P*8 bytes and thrashes the vector L1
@@ -212,7 +217,8 @@ k_da_cross_attn_fwd_unit(long long n_units, const float* __restrict__ value, con
                     const float h_im = loc_h * sh - 0.5f, w_im = loc_w * sw - 0.5f;
                     if (h_im > -1.f && w_im > -1.f && h_im < (float)sh && w_im < (float)sw) {
                         const fbbev_bilinear s = fbbev_bilinear_setup(h_im, w_im, sh, sw, row_stride);
-                        fbbev_unit_sample<DH, WIDE ? 4 : 2>(value, lane_off, s, chunk_stride, weight, col);
+                        if constexpr (ET == 0) fbbev_unit_sample<DH, WIDE ? 4 : 2>(value, lane_off, s, chunk_stride, weight, col);
+                        else fbbev_unit_sample16<DH, ET>(value_, lane_off, s, chunk_stride, weight, col);
                     }
                 }
             }

@@ -97,6 +97,46 @@ __device__ __forceinline__ void fbbev_unit_sample(const float* __restrict__ valu
     for (int c = 0; c < DH; ++c) col[c] += (s.w1 * v1[c] + s.w2 * v2[c] + s.w3 * v3[c] + s.w4 * v4[c]) * weight;
 }
 
+// The same sample on 16-bit token rows (ET 1 = bf16, 2 = f16; fp32 accumulate): rows are chunk-major with EIGHT elements
+// per (chunk, head) -- [chunk k][head m][8 x 16 bit] -- so a head's chunk is again one aligned 16-byte load and the 8 head
+// lanes read one 128-byte line per instruction, for half the bytes per corner (Dh = 10: 16 + 4 bytes instead of 40).
+// Elements are widened exactly; the arithmetic after the load is the fp32 kernel's.
+template <int DH, int ET>
+__device__ __forceinline__ void fbbev_unit_sample16(const void* __restrict__ value, unsigned lane_off /* bytes */,
+                                                    const fbbev_bilinear& s, int chunk_stride /* elements */, float weight,
+                                                    float (&col)[DH]) {
+    constexpr int NCH = (DH + 7) / 8;
+    const char* vb = reinterpret_cast<const char*>(value);
+    const bool k1 = s.o1 >= 0, k2 = s.o2 >= 0, k3 = s.o3 >= 0, k4 = s.o4 >= 0;
+    const unsigned b1 = lane_off + (k1 ? (unsigned)s.o1 * 2u : 0u), b2 = lane_off + (k2 ? (unsigned)s.o2 * 2u : 0u);
+    const unsigned b3 = lane_off + (k3 ? (unsigned)s.o3 * 2u : 0u), b4 = lane_off + (k4 ? (unsigned)s.o4 * 2u : 0u);
+    const unsigned cs = (unsigned)chunk_stride * 2u;
+    fbbev_v4u a1[NCH], a2[NCH], a3[NCH], a4[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        a1[k] = *reinterpret_cast<const fbbev_v4u*>(vb + (b1 + k * cs));
+        a2[k] = *reinterpret_cast<const fbbev_v4u*>(vb + (b2 + k * cs));
+        a3[k] = *reinterpret_cast<const fbbev_v4u*>(vb + (b3 + k * cs));
+        a4[k] = *reinterpret_cast<const fbbev_v4u*>(vb + (b4 + k * cs));
+    }
+    auto widen = [](unsigned int word, int half) -> float {
+        if constexpr (ET == 2) return fbbev_f16_bits_to_f32(half ? (word >> 16) : (word & 0xffffu));
+        else {
+            const unsigned int u = half ? (word & 0xffff0000u) : (word << 16);
+            float f;
+            __builtin_memcpy(&f, &u, 4);
+            return f;
+        }
+    };
+#pragma unroll
+    for (int c = 0; c < DH; ++c) {
+        const int k = c >> 3, wd = (c & 7) >> 1, hf = c & 1;
+        const float v1 = k1 ? widen(a1[k][wd], hf) : 0.f, v2 = k2 ? widen(a2[k][wd], hf) : 0.f;
+        const float v3 = k3 ? widen(a3[k][wd], hf) : 0.f, v4 = k4 ? widen(a4[k][wd], hf) : 0.f;
+        col[c] += (s.w1 * v1 + s.w2 * v2 + s.w3 * v3 + s.w4 * v4) * weight;
+    }
+}
+
 __global__ void __launch_bounds__(256)
 k_msda_fwd(long long n, const float* __restrict__ value, const int64_t* __restrict__ spatial_shapes,
            const int64_t* __restrict__ level_start, const float* __restrict__ loc,

@@ -62,6 +62,7 @@ class FBOCC(nn.Module):
         config trains them under mmcv's fp16 hook, cfg :394) -- and with_cp=True|False to override the blocks'
         activation checkpointing (the configs turn it on to fit 16-32 GB parts; 288 GB of HBM does not need it);
         history_dtype='f16' | 'bf16' stores the inference history ring in 16 bits (BASELINE configs[4]);
+        da_value_dtype='bf16' | 'f16' keeps the cross-attention's camera tokens in 16 bits at inference (fp32 accumulate);
         mfma_conv3d / mfma_conv3d_train=True route the voxel encoder + head through fbbev_conv3d_* (mfma_conv3d.py)."""
         super().__init__()
         if frpn is not None or pts_bbox_head is not None:
@@ -78,6 +79,11 @@ class FBOCC(nn.Module):
         fvt = FBViewTransform(forward_projection, backward_projection, readd=readd)
         self.forward_projection = fvt.forward_projection
         self.backward_projection = fvt.backward_projection
+        if ex.get('da_value_dtype') and self.backward_projection is not None:   # 'bf16' | 'f16': 16-bit camera tokens (inference)
+            from .backward_projection import DA_SpatialCrossAttention
+            for mod in self.backward_projection.modules():
+                if isinstance(mod, DA_SpatialCrossAttention):
+                    mod.value_dtype = _dtype(ex['da_value_dtype'])
         fp = fvt.forward_projection
         hist = TemporalHistoryFusion(fp.dx.tolist(), fp.bx.tolist(), single_bev_num_channels=single_bev_num_channels,
                                      history_cat_num=history_cat_num,

@@ -280,7 +280,10 @@ int fbbev_point_sampling(const float* xs, const float* ys, const float* zs, cons
  * sampling_offsets(query) raw, attn (B,Q,M,L,P) = softmax(attention_weights(query)), both computed once
  * per BEV query; d0/dstep = dbound[0]/dbound[2].  head_minor: bit 0 -> offsets is laid out (B,Q,L,P,M,2), bit 1 -> attn
  * is (B,Q,L,P,M) -- what the Linear layers emit when their output rows are permuted; the heads of a query then
- * read contiguous bytes per sample (offsets head-minor is the fast path of the FB-OCC shapes).
+ * read contiguous bytes per sample (offsets head-minor is the fast path of the FB-OCC shapes); bit 2 -> a token's
+ * M*head_stride floats are stored chunk-major, (head_stride/4, M, 4), instead of (M, head_stride): the 8 head lanes of
+ * a query read one contiguous M*16-byte piece per load (needs head_stride % 4 == 0; same for grad_value in the
+ * backward entries).
  * head_stride: floats between two heads inside a value row (0 = Dh, i.e. value is (B*Ncam,S,M,Dh) dense); a value_proj
  * output padded to a multiple of 4 floats per head (Dh = 10 -> 12) makes every head chunk 16-byte aligned and lets the
  * kernel read a corner with 3 dwordx4 loads; the padding floats are ignored (grad_value of the padding stays 0).
@@ -292,6 +295,18 @@ int fbbev_da_cross_attn_fwd(const float* value, const int64_t* spatial_shapes,
                             const float* offsets, const float* attn, int B, int Ncam, int S, int M, int Dh,
                             int L, int Q, int P, int Za, int DC, float d0, float dstep, int head_minor,
                             int head_stride, float* slots, fbbev_stream_t stream);
+
+/* fbbev_da_cross_attn_fwd on 16-bit camera tokens (inference option; fp32 accumulate, every other tensor fp32):
+ * value_elem_type 0 = f32 (== fbbev_da_cross_attn_fwd), 1 = bf16, 2 = f16.  16-bit rows must be chunk-major
+ * (head_minor bit 2) with EIGHT elements per (chunk, head) piece -- a token is (head_stride/8, M, 8) -- and
+ * head_stride a multiple of 8 covering Dh (Dh = 10 -> 16): half the gather bytes of the fp32 rows.  Elements are
+ * widened exactly, so the result equals the fp32 entry on the widened tokens bit for bit. */
+int fbbev_da_cross_attn_fwd_e(const void* value, const int64_t* spatial_shapes,
+                              const int64_t* level_start_index, const float* pred_depth,
+                              const float* ref_cam, const uint8_t* mask, const float* qdepth,
+                              const float* offsets, const float* attn, int B, int Ncam, int S, int M, int Dh,
+                              int L, int Q, int P, int Za, int DC, float d0, float dstep, int head_minor,
+                              int head_stride, int value_elem_type, float* slots, fbbev_stream_t stream);
 
 /* Backward of fbbev_da_cross_attn_fwd in one launch -- replaces the autograd chain of the reference's training step
  * through DA_SpatialCrossAttention / DA_MSDeformableAttention (two MultiScaleDeformableAttnFunction backward launches,

@@ -141,6 +141,12 @@ def da_cross_attn_fwd(value, ss, ls, pred_depth, ref_cam, mask, qdepth, offsets,
     slots = buf[off:off + B * Q * M * Dh].view(B, Q, M * Dh)
     assert (slots.data_ptr() % 8 != 0) == misalign
     m8 = mask.to(torch.uint8).contiguous()
+    if value.dtype != torch.float32:
+        et = {torch.bfloat16: 1, torch.float16: 2}[value.dtype]
+        ok(lib().fbbev_da_cross_attn_fwd_e(p(value), p(ss), p(ls), p(pred_depth), p(ref_cam), p(m8), p(qdepth), p(offsets),
+                                           p(attn), B, Ncam, S, M, Dh, L, Q, P, Za, pred_depth.shape[1], d0, dstep,
+                                           int(head_minor), HS, et, c_void_p(slots.data_ptr()), None))
+        return slots.clone()
     ok(lib().fbbev_da_cross_attn_fwd(p(value), p(ss), p(ls), p(pred_depth), p(ref_cam), p(m8), p(qdepth), p(offsets),
                                      p(attn), B, Ncam, S, M, Dh, L, Q, P, Za, pred_depth.shape[1], d0, dstep,
                                      int(head_minor), HS, c_void_p(slots.data_ptr()), None))

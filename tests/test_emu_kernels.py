@@ -242,6 +242,21 @@ def test_fused_da_cross_attention_emulated():
             a[7] = args[7].permute(0, 1, 3, 4, 2, 5).contiguous() if hm & 1 else args[7]
             assert torch.equal(got, E.da_cross_attn_fwd(*a, head_minor=hm, head_dim=Dh))
             assert torch.equal(got, E.da_cross_attn_fwd(*a, head_minor=hm, head_dim=Dh, misalign=True))
+        # 16-bit tokens (fbbev_da_cross_attn_fwd_e): rows chunk-major with 8-element pieces; the elements are widened
+        # exactly, so the result is the fp32 kernel's on the rounded tokens, bit for bit
+        if Dh in (8, 10, 16, 32):
+            HS16 = (Dh + 7) // 8 * 8
+            for dt in (torch.bfloat16, torch.float16):
+                v16 = torch.full(args[0].shape[:-1] + (HS16,), 3.0e4).to(dt)
+                v16[..., :Dh] = args[0].to(dt)
+                M_ = v16.shape[-2]
+                il = v16.reshape(v16.shape[:-2] + (M_, HS16 // 8, 8)).transpose(-3, -2).contiguous().view(v16.shape)
+                a2 = list(args)
+                a2[0] = args[0].to(dt).float()
+                want = E.da_cross_attn_fwd(*a2)
+                a2[0] = il
+                a2[7] = args[7].permute(0, 1, 3, 4, 2, 5).contiguous()
+                assert torch.equal(E.da_cross_attn_fwd(*a2, head_minor=5, head_dim=Dh), want), dt
 
 
 def test_tokens_from_nchw_emulated():

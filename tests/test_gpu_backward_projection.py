@@ -127,6 +127,31 @@ def test_training_paths_equal_inference_and_backprop(dev, train_fused):
             assert close(p.grad, P[name].grad, 5e-3), name
 
 
+@pytest.mark.parametrize('dt,tol', [(torch.float16, 2e-3), (torch.bfloat16, 1.5e-2)])
+def test_16bit_camera_tokens_vs_fp32_tokens(dev, dt, tol):
+    """DA_SpatialCrossAttention.value_dtype (fbbev_da_cross_attn_fwd_e): camera tokens rounded once to 16 bits, fp32
+    accumulate.  The stated error is against the fp32-token path on the same inputs: max |diff| relative to the output
+    scale (the emulator test pins the kernel itself bit for bit on the rounded tokens)."""
+    from fb_bev_amd.backward_projection import DA_SpatialCrossAttention
+    m, cfg, cam, feats, depth, lss, gcb = _setup(dev, B=2, num_levels=2, bev=20, seed=4)
+    cam_g = [t.to(dev) for t in cam]
+    args = ([f.to(dev) for f in feats], None)
+    kw = dict(lss_bev=lss.to(dev), cam_params=cam_g, pred_img_depth=depth.to(dev))
+    with torch.no_grad():
+        ref = m(*args, **kw)
+        mods = [x for x in m.modules() if isinstance(x, DA_SpatialCrossAttention)]
+        assert mods
+        for x in mods:
+            x.value_dtype = dt
+        got = m(*args, **kw)
+        for x in mods:
+            x.value_dtype = None
+        again = m(*args, **kw)
+    assert torch.equal(again, ref)                       # the option leaves no state behind
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    assert 0 < err < tol, err
+
+
 def test_lds_plane_backward_equals_atomic_backward_and_is_reproducible(dev):
     """fbbev_da_cross_attn_bwd_ws (fixed-point gradient planes in LDS, partial buffer, fixed-order reduction) against
     fbbev_da_cross_attn_bwd (fp32 global atomics) at the shipped shape; the value gradient of the former is bit-identical

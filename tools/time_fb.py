@@ -12,6 +12,7 @@ def main():
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     steps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
     levels = int(sys.argv[4]) if len(sys.argv) > 4 else 1        # BASELINE configs[2]: 4 attention levels
+    vdt = {'f32': None, 'bf16': torch.bfloat16, 'f16': torch.float16}[sys.argv[5] if len(sys.argv) > 5 else 'f32']   # camera-token storage
     dev = torch.device('cuda:0')
     pc = S.CONFIGS[name]
     X, Y, Z = pc.grid_xyz
@@ -20,6 +21,11 @@ def main():
                             grid_config_bevformer=gcb, depth_bound=tuple(pc.grid_config['depth']), downsample=pc.downsample,
                             num_levels=levels)
     m = FBViewTransform(cfg['forward_projection'], cfg['backward_projection']).to(dev).eval()
+    if vdt is not None:
+        from fb_bev_amd.backward_projection import DA_SpatialCrossAttention
+        for mod in m.modules():
+            if isinstance(mod, DA_SpatialCrossAttention):
+                mod.value_dtype = vdt
     cam = [t.to(dev) for t in S.camera_rig(pc, B, seed=0, bda_aug=True)]
     depth, ctx = S.depth_and_context(pc, B, seed=0)
     depth, ctx = depth.to(dev), ctx.to(dev)
@@ -61,7 +67,7 @@ def main():
                 g.replay()
             torch.cuda.synchronize()
             res['ms_' + tag + '_graph'] = (time.perf_counter() - t0) / steps * 1e3
-    print(json.dumps({'config': name, 'B': B, 'levels': levels, 'bev': [Y, X], 'out': list(out.shape), 'ms_fb': dt * 1e3, 'ms_forward_only': dt_f * 1e3,
+    print(json.dumps({'config': name, 'B': B, 'levels': levels, 'camera_tokens': str(vdt or 'f32'), 'bev': [Y, X], 'out': list(out.shape), 'ms_fb': dt * 1e3, 'ms_forward_only': dt_f * 1e3,
                       'samples_per_s_fb': B / dt, **res, 'samples_per_s_fb_graph': B / (res['ms_fb_graph'] * 1e-3)}))
 
 if __name__ == '__main__':
