@@ -10,8 +10,15 @@ Functional restatement (weights passed as a flat dict keyed like the module tree
   DA_SpatialCrossAttention.forward ...... bevformer_utils/spatial_cross_attention_depth.py:85-223
   DA_MSDeformableAttention.forward ...... :464-601, the CUDA branch :579-595 (NOT the :596-598 CPU branch,
                                           which silently drops the depth weighting -- SURVEY H7)
-  mmcv MultiScaleDeformableAttention / FFN / LayerNorm (mmcv-full 1.5.2, external; restated -- parity
-  unpinned against mmcv itself, like the MSDA kernel).
+  mmcv MultiScaleDeformableAttention / FFN / LayerNorm (mmcv-full 1.5.2, external; restated).
+Pins (tests/test_oracle_backward_projection.py, fixtures from tests/golden/make_golden.py):
+  * DA_SpatialCrossAttention rebatch / scatter / count logic: da_sca_stub_inner.npz (real class, stub inner attention);
+  * DA_MSDeformableAttention: da_msda_cpu_branch.npz (real class, CPU branch) and da_msda_cuda_branch.npz (real class
+    driven through its CUDA branch :578-595 on the CPU, the mmcv op answered by oracle.msda_fwd);
+  * mmcv MultiScaleDeformableAttention.forward: mmcv_msda_forward_trt_twin.npz -- the in-tree copy of that forward,
+    multi_scale_deformable_attn_function.py:174-260 (MultiScaleDeformableAttentionTRT), run for real;
+  * the MSDA op itself: tests/test_oracle_msda_ref.py (reference-tree twin of mmcv's bilinear device functions).
+  mmcv's FFN / LayerNorm and the __init__ defaults of its attention class remain restatements.
 The deformable sampling itself uses oracle.msda_grid_sample (F.grid_sample formulation).
 """
 import torch

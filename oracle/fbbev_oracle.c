@@ -13,9 +13,14 @@
  *     im2col / col2im with bilinear sampling, zero padding, align_corners=False)
  *     is restated here and anchored on the reference call sites
  *     backward_projection/bevformer_utils/multi_scale_deformable_attn_function.py:127-133,159-169
- *     and spatial_cross_attention_depth.py:584-595.  PARITY UNPINNED for MSDA:
- *     the reference ships no golden vector at that boundary; the restatement is
- *     cross-checked against F.grid_sample in tests/test_oracle_msda.py.
+ *     and spatial_cross_attention_depth.py:584-595.  mmcv itself ships no vector,
+ *     but the reference tree carries a twin of its two bilinear device functions
+ *     (mmdet3d/ops/ops_dcnv3/src/cuda/dcnv3_im2col_cuda.cuh:32-147): msda_bilinear and
+ *     the corner block of oracle_msda_bwd below reproduce them BIT FOR BIT on
+ *     tests/golden/msda_bilinear_ref.npz (tests/test_oracle_msda_ref.py; generated
+ *     from that header compiled where it lies, `make -C oracle ref_msda`).  What
+ *     remains a restatement of mmcv: the loops over levels / points / heads and
+ *     x = loc*W - 0.5; cross-checked against F.grid_sample in tests/test_oracle_msda.py.
  *
  * Pinned against: the 4-point known-answer fixture of
  *   mmdet3d/ops/bev_pool_v2/bev_pool.py:144-175 (tests/golden/bev_pool_v2_known_answer.json)

@@ -192,6 +192,101 @@ def make_backward_projection_fixtures():
     sd = {k: v.numpy() for k, v in att.state_dict().items()}
     np.savez_compressed(os.path.join(OUT, 'da_msda_cpu_branch.npz'), q=q2.numpy(), v=v2.numpy(), ref=ref2.numpy(),
                         out=out2.numpy(), **{'sd_' + k: v for k, v in sd.items()})
+    # DA_MSDeformableAttention.forward on the reference's CUDA branch (:578-595: depth distribution sampled at every
+    # Z-anchor reference point, dotted with the one-hot query depth, attention weights multiplied without
+    # renormalisation, second MSDA call).  The branch needs `torch.cuda.is_available() and value.is_cuda` and mmcv's
+    # compiled op: here the REAL class runs on the CPU with (1) a tensor subclass that answers is_cuda = True,
+    # (2) torch.cuda.is_available patched for the call, and (3) MultiScaleDeformableAttnFunction_fp32.apply replaced by
+    # the oracle's MSDA forward (itself pinned bit for bit on the reference tree's bilinear functions,
+    # tests/test_oracle_msda_ref.py).  Everything around the op is the reference's own code.
+    class FakeCuda(torch.Tensor):
+        @property
+        def is_cuda(self):
+            return True
+
+    class OracleMSDA:
+        @staticmethod
+        def apply(value, spatial_shapes, level_start_index, loc, w, im2col_step):
+            plain = lambda t: t.as_subclass(torch.Tensor).float().contiguous()  # noqa: E731
+            return O.msda_fwd(plain(value), spatial_shapes, level_start_index, plain(loc), plain(w))
+    sca.MultiScaleDeformableAttnFunction_fp32 = OracleMSDA
+    torch.manual_seed(13)
+    DC3, H3, W3 = 9, 5, 7
+    att3 = sca.DA_MSDeformableAttention(embed_dims=E, num_heads=M, num_levels=L, num_points=P, num_Z_anchors=Za,
+                                        dropout=0.0, batch_first=True)
+    with torch.no_grad():
+        att3.sampling_offsets.weight.normal_(0, 0.3, generator=g)
+        att3.attention_weights.weight.normal_(0, 0.5, generator=g)
+    q3 = torch.randn(3, 20, E, generator=g)
+    v3 = torch.randn(3, 47, E, generator=g)
+    ref3 = torch.rand(3, 20, Za, 2, generator=g) * 1.2 - 0.1            # some anchors outside the image
+    bins3 = torch.randint(0, DC3, (3, 20, Za), generator=g)
+    onehot3 = torch.nn.functional.one_hot(bins3, DC3)                   # what DA_SpatialCrossAttention hands in (:196-199)
+    pred3 = torch.rand(3, H3 * W3, DC3, generator=g).softmax(-1)        # (bs*num_cam, H0*W0, DC), level-0 shape
+    was = torch.cuda.is_available
+    torch.cuda.is_available = lambda: True
+    try:
+        with torch.no_grad():
+            out3 = att3(q3, value=v3.as_subclass(FakeCuda), reference_points=ref3, spatial_shapes=ss2, level_start_index=ls2,
+                        bev_query_depth=onehot3, pred_img_depth=pred3)
+    finally:
+        torch.cuda.is_available = was
+    sd3 = {k: v.numpy() for k, v in att3.state_dict().items()}
+    np.savez_compressed(os.path.join(OUT, 'da_msda_cuda_branch.npz'), q=q3.numpy(), v=v3.numpy(), ref=ref3.numpy(),
+                        bins=bins3.numpy(), pred=pred3.numpy(), out=out3.as_subclass(torch.Tensor).numpy(),
+                        **{'sd_' + k: v for k, v in sd3.items()})
+    # mmcv's MultiScaleDeformableAttention.forward (the BEV self-attention of the encoder layer) is not
+    # in the tree -- but multi_scale_deformable_attn_function.py:174-260 (MultiScaleDeformableAttentionTRT) overrides
+    # forward with a copy of it whose only change is the final op.  The REAL in-tree forward runs here on a stand-in base
+    # class that only creates the four Linear layers (names as in the shipped checkpoints / reference state keys), with
+    # the TRT op replaced by the oracle's MSDA forward.  Cases: self-attention as bevformer_encoder.py:327-341 calls it,
+    # and cross use with value / key_padding_mask / identity / batch_first=False.
+    class _MSDABase(nn.Module):
+        def __init__(self, embed_dims=16, num_heads=4, num_levels=1, num_points=4, im2col_step=64, dropout=0.0,
+                     batch_first=True):
+            super().__init__()
+            self.embed_dims, self.num_heads, self.num_levels, self.num_points = embed_dims, num_heads, num_levels, num_points
+            self.im2col_step, self.batch_first, self.dropout = im2col_step, batch_first, nn.Dropout(dropout)
+            self.sampling_offsets = nn.Linear(embed_dims, num_heads * num_levels * num_points * 2)
+            self.attention_weights = nn.Linear(embed_dims, num_heads * num_levels * num_points)
+            self.value_proj = nn.Linear(embed_dims, embed_dims)
+            self.output_proj = nn.Linear(embed_dims, embed_dims)
+    _mod('mmcv.cnn.bricks.registry', ATTENTION=_Registry())
+    _mod('mmcv.utils', ext_loader=types.SimpleNamespace(load_ext=lambda *a, **k: None))
+    sys.modules['mmcv.ops'].MultiScaleDeformableAttention = _MSDABase
+    _mod('mmdet3d.models.fbbev.custom_ops.multi_scale_deformable_attn',
+         multi_scale_deformable_attn=lambda v, ss, ls, loc, w: O.msda_fwd(v.contiguous(), ss, ls, loc.contiguous(), w.contiguous()))
+    fn = load_ref('refbp.msda_function_real',
+                  'mmdet3d/models/fbbev/view_transformation/backward_projection/bevformer_utils/'
+                  'multi_scale_deformable_attn_function.py')
+    rec = {}
+    torch.manual_seed(21)
+    for tag, kw in (('self', dict(num_levels=1, num_points=4, batch_first=True)),
+                    ('cross', dict(num_levels=2, num_points=3, batch_first=False))):
+        att4 = fn.MultiScaleDeformableAttentionTRT(embed_dims=E, num_heads=M, **kw)
+        with torch.no_grad():
+            att4.sampling_offsets.weight.normal_(0, 0.3, generator=g)
+            att4.attention_weights.weight.normal_(0, 0.5, generator=g)
+        if tag == 'self':
+            ss4 = torch.tensor([[6, 5]]); ls4 = torch.tensor([0])
+            q4 = torch.randn(2, 30, E, generator=g); pos4 = torch.randn(2, 30, E, generator=g)
+            ref4 = torch.rand(2, 30, 1, 2, generator=g)
+            with torch.no_grad():
+                out4 = att4(q4, None, None, None, query_pos=pos4, key_pos=pos4, reference_points=ref4, spatial_shapes=ss4,
+                            level_start_index=ls4)
+            rec.update(self_q=q4, self_pos=pos4, self_ref=ref4, self_out=out4)
+        else:
+            ss4 = torch.tensor([[4, 3], [2, 2]]); ls4 = torch.tensor([0, 12])
+            q4 = torch.randn(11, 2, E, generator=g); v4 = torch.randn(16, 2, E, generator=g)      # (Q,bs,E) / (S,bs,E)
+            idt = torch.randn(11, 2, E, generator=g); pos4 = torch.randn(11, 2, E, generator=g)
+            ref4 = torch.rand(2, 11, 2, 2, generator=g) * 1.2 - 0.1
+            kpm = torch.rand(2, 16, generator=g) < 0.2
+            with torch.no_grad():
+                out4 = att4(q4, None, v4, idt, query_pos=pos4, key_padding_mask=kpm, reference_points=ref4,
+                            spatial_shapes=ss4, level_start_index=ls4)
+            rec.update(cross_q=q4, cross_v=v4, cross_identity=idt, cross_pos=pos4, cross_ref=ref4, cross_kpm=kpm, cross_out=out4)
+        rec.update({f'{tag}_sd_' + k: v for k, v in att4.state_dict().items()})
+    np.savez_compressed(os.path.join(OUT, 'mmcv_msda_forward_trt_twin.npz'), **{k: v.detach().numpy() for k, v in rec.items()})
     print('backward-projection fixtures written')
 
 

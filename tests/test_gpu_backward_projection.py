@@ -1,7 +1,7 @@
 """GPU parity of the backward projection against the CPU oracle
 (oracle/backward_projection_oracle.py, pinned on fixtures from the real reference Python).
-fp32 tolerance 1e-4 on O(1) features (the path is floating point; MSDA itself is 'parity unpinned'
-vs mmcv)."""
+fp32 tolerance 1e-4 on O(1) features (the path is floating point; the MSDA op is pinned on the reference
+tree's twin of mmcv's bilinear functions, tests/test_oracle_msda_ref.py -- see DESIGN.md section 4)."""
 import os
 import sys
 

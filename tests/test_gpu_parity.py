@@ -423,6 +423,26 @@ def test_msda_forward_backward(dev, ci):
         assert torch.allclose(wg.grad, 2.0 * g1, atol=1e-5, rtol=1e-5)
 
 
+def test_msda_kernels_vs_reference_tree_bilinear_vectors(dev):
+    """The HIP kernels against tests/golden/msda_bilinear_ref.npz -- outputs of the reference tree's twin of mmcv's bilinear
+    device functions (ops_dcnv3/src/cuda/dcnv3_im2col_cuda.cuh:32-147; tests/test_oracle_msda_ref.py pins the oracle and the
+    emulated kernels on them bit for bit).  On the GPU the compiler may contract a*b+c, hence a few-ulp tolerance."""
+    import test_oracle_msda_ref as T
+    from fb_bev_amd.ms_deform_attn import MultiScaleDeformableAttnFunction_fp32 as F32
+    for i in range(0, T.N, 2):
+        data, ss, ls, loc, attn, gout, m, c, ch, mask, gi = T._case(i)
+        vg, lg, wg = (t.to(dev).requires_grad_() for t in (data, loc, attn))
+        out = F32.apply(vg, ss.to(dev), ls.to(dev), lg, wg, 64)
+        out.backward(gout.to(dev))
+        tol = lambda x: 4e-6 * abs(float(x)) + 1e-7  # noqa: E731
+        ref_s = float(T.G['sample'][i]) * float(mask)
+        assert abs(out[0, 0, m * ch + c].item() - ref_s) <= tol(ref_s), i
+        assert torch.allclose(vg.grad.cpu(), gi, rtol=4e-6, atol=1e-7), i
+        assert abs(lg.grad[0, 0, m, 0, 0, 0].item() - float(T.G['grad_w'][i])) <= 4 * tol(T.G['grad_w'][i]) + 1e-6, i
+        assert abs(lg.grad[0, 0, m, 0, 0, 1].item() - float(T.G['grad_h'][i])) <= 4 * tol(T.G['grad_h'][i]) + 1e-6, i
+        assert abs(wg.grad[0, 0, m, 0, 0].item() - float(T.G['grad_mask'][i])) <= tol(T.G['grad_mask'][i]), i
+
+
 def test_msda_any_batch_and_im2col_step_ignored(dev):
     """batch 72 with im2col_step 64 fails in mmcv; here any batch works."""
     from test_oracle_msda import make_case
