@@ -152,6 +152,44 @@ def test_16bit_camera_tokens_vs_fp32_tokens(dev, dt, tol):
     assert 0 < err < tol, err
 
 
+@pytest.mark.parametrize('lds_planes', [False, True])
+def test_fused_backward_kernels_within_a_bound_of_fp64_autograd(dev, lds_planes):
+    """A BOUND, not a statistical pass (the module-level test above tolerates 2 % kinked entries): the four gradients of
+    fbbev_da_cross_attn_bwd / _bwd_ws, pushed back to the leaves, against the double-precision autograd of the oracle's
+    loop-for-loop restatement of the reference's training path -- EVERY entry within 1e-4 relative + 5e-5 of the tensor
+    scale.  The comparison is at the kernel boundary (no ReLU / LayerNorm around it), so no kink can flip."""
+    from fb_bev_amd import _capi
+    from da_cases import da_case
+    for seed, kw in ((5, dict(B=1, Q=29, E=16, M=4)),
+                     (6, dict(B=2, Q=17, E=40, M=4, shapes=((4, 6), (2, 3)))),
+                     (7, dict(B=2, Q=333, E=80, M=8, shapes=((16, 44),), DC=20))):      # the shipped head layout
+        args, exp, leaves = da_case(seed, grad=True, **kw)
+        g = torch.randn(exp.shape, generator=torch.Generator().manual_seed(seed), dtype=torch.float64)
+        wrt = [leaves['key'], leaves['pred']] + [leaves['Pm'][k] for k in sorted(leaves['Pm']) if 'output_proj' not in k]
+        ref = torch.autograd.grad(exp, wrt, grad_outputs=g, retain_graph=True, allow_unused=True)
+        value, ss, ls, pred4, ref_cam, mask, qdepth, offsets, attn, d0, dstep = args
+        Dh = value.shape[-1]
+        HS = (Dh + 3) // 4 * 4
+        f32 = lambda t: t.detach().float().contiguous()  # noqa: E731
+        vp = torch.zeros(value.shape[:-1] + (HS,))
+        vp[..., :Dh] = f32(value)
+        t = lambda x: x.to(dev).contiguous()  # noqa: E731
+        a = [t(vp), t(ss), t(ls), t(f32(pred4)), t(f32(ref_cam)), t(mask), t(f32(qdepth)), t(f32(offsets)), t(f32(attn)),
+             t(f32(g)), d0, dstep, 0]
+        gv, gd, go, ga = (torch.zeros_like(x) for x in (a[0], a[3], a[7], a[8]))
+        _capi.da_cross_attn_bwd(*a, gv, gd, go, ga, head_dim=Dh, lds_planes=lds_planes)
+        mine = torch.autograd.grad([value, pred4, offsets, attn], wrt,
+                                   grad_outputs=[gv[..., :Dh].cpu().double(), gd.cpu().double(), go.cpu().double(), ga.cpu().double()],
+                                   retain_graph=True, allow_unused=True)
+        assert not gv[..., Dh:].any()
+        for x, y in zip(mine, ref):
+            if y is None:
+                assert x is None or not x.any()
+                continue
+            bound = 1e-4 * y.abs() + 5e-5 * max(1.0, y.abs().max().item())
+            assert ((x - y).abs() <= bound).all(), ((x - y).abs().max().item(), y.abs().max().item(), seed)
+
+
 def test_lds_plane_backward_equals_atomic_backward_and_is_reproducible(dev):
     """fbbev_da_cross_attn_bwd_ws (fixed-point gradient planes in LDS, partial buffer, fixed-order reduction) against
     fbbev_da_cross_attn_bwd (fp32 global atomics) at the shipped shape; the value gradient of the former is bit-identical
