@@ -1,2 +1,3 @@
-export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_backward_projection.py tests/test_gpu_parity.py -m gpu -q -x -p no:cacheprovider -k "bound or reference_tree or msda or lds_plane or 16bit" 2>&1 | tail -8
+export TMPDIR=/tmp; mkdir -p gpurun_out/s19
+timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline > gpurun_out/s19/bench.json 2> gpurun_out/s19/err.txt; python -c "
+import json;d=json.load(open('gpurun_out/s19/bench.json'));print(d['value'],d['ms_per_step'],d['roofline']['frac']);print(d.get('bf16_storage'))"; tail -3 gpurun_out/s19/err.txt
