@@ -190,10 +190,14 @@ class LSSViewTransformerFunction3D(nn.Module):
             density = n_cams * self.frustum.shape[0] * self.frustum.shape[1] * self.frustum.shape[2] / float(X * Y * Z)
             dense = density >= 1.0
             tv = self._tile_voxels_arg if self._tile_voxels_arg is not None else (64 if dense else _capi.DEFAULT_TILE_VOXELS)
-            if self._tile_voxels_arg is None and self.out_dtype != torch.float32:
+            half = self.out_dtype != torch.float32
+            if self._tile_voxels_arg is None and half and dense:
                 tv *= 2     # 16-bit storage: the kernel's LDS tile is 16-bit too -> twice the voxels per workgroup at the same footprint
+            # sparse grid + 16-bit storage: the SAME 20 KB of LDS hold 128 voxels x ALL channels -- one workgroup per tile, no
+            # second copy of the metadata / gather chain (profiles/r02_sweep_pool_bf16_BL2_B16.jsonl: 0.321 ms vs 0.341 ms for
+            # 256 voxels x 2 channel groups), chunks of 32 tiles per XCD
             fl = self._pool_flags_arg if self._pool_flags_arg is not None else (
-                _capi.pool_flags(csplit=1) if dense else _capi.DEFAULT_POOL_FLAGS)
+                _capi.pool_flags(csplit=1) if dense else (_capi.pool_flags(csplit=1, swz_log2=5) if half else _capi.DEFAULT_POOL_FLAGS))
             self._tiling[n_cams] = (tv, fl)
         return self._tiling[n_cams]
 

@@ -1,3 +1,4 @@
 export TMPDIR=/tmp; mkdir -p gpurun_out/s19
-timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline > gpurun_out/s19/bench.json 2> gpurun_out/s19/err.txt; python -c "
-import json;d=json.load(open('gpurun_out/s19/bench.json'));print(d['value'],d['ms_per_step'],d['roofline']['frac']);print(d.get('bf16_storage'))"; tail -3 gpurun_out/s19/err.txt
+timeout 400 python tools/sweep_pool.py BL2 16 bf16 2>&1 > gpurun_out/s19/sweep_bf16_b.jsonl
+timeout 400 python tools/sweep_pool.py BL2 16 f32 2>&1 > gpurun_out/s19/sweep_f32_b.jsonl
+for f in gpurun_out/s19/sweep_bf16_b.jsonl gpurun_out/s19/sweep_f32_b.jsonl; do echo $f; grep variant $f | awk -F'"ms": ' '{print $2, $1}' | sort -n | head -8; done
