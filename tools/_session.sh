@@ -1,4 +1,2 @@
-export TMPDIR=/tmp; mkdir -p gpurun_out/s19
-timeout 400 python tools/sweep_pool.py BL2 16 bf16 2>&1 > gpurun_out/s19/sweep_bf16_b.jsonl
-timeout 400 python tools/sweep_pool.py BL2 16 f32 2>&1 > gpurun_out/s19/sweep_f32_b.jsonl
-for f in gpurun_out/s19/sweep_bf16_b.jsonl gpurun_out/s19/sweep_f32_b.jsonl; do echo $f; grep variant $f | awk -F'"ms": ' '{print $2, $1}' | sort -n | head -8; done
+export TMPDIR=/tmp
+timeout 1500 python tools/scope_table.py gpurun_out/scope_table.json 2>&1 | tail -30 | cut -c1-220

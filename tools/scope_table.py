@@ -63,6 +63,8 @@ def s1_s2(name, B, n):
         row('S2 rank build only (fbbev_lift_rank_build)', name, B, pct(lambda: vt.build_index_from_cams(*cam), n))
         vc = LSSViewTransformerFunction3D(cfg.grid_config, cfg.input_size, cfg.downsample, accelerate=True).to(DEV)
         row('S2c forward projection, camera-keyed index cache hit', name, B, pct(lambda: vc(cam, ctx, depth), n))
+        vh = LSSViewTransformerFunction3D(cfg.grid_config, cfg.input_size, cfg.downsample, out_dtype=torch.bfloat16).to(DEV)
+        row('S2 forward projection, bf16 volume storage (fp32 in-order sums rounded once)', name, B, pct(lambda: vh(cam, ctx, depth), n))
 
 
 def s3(name, B, levels, n):
@@ -85,6 +87,25 @@ def s3(name, B, levels, n):
     with torch.no_grad():
         row(f'S3 forward + backward projection + re-add ({levels} attention level{"s" if levels > 1 else ""})', name, B,
             pct(lambda: m(cam, ctx, depth, mlvl_feats=mlvl), n))
+        if levels > 1:
+            from fb_bev_amd.backward_projection import DA_SpatialCrossAttention
+            for mod in m.modules():
+                if isinstance(mod, DA_SpatialCrossAttention):
+                    mod.value_dtype = torch.bfloat16
+            row(f'S3 the same with bf16 camera tokens in the cross-attention (fp32 accumulate)', name, B,
+                pct(lambda: m(cam, ctx, depth, mlvl_feats=mlvl), n))
+            return
+    if B == 4 and levels == 1:        # training step of the path alone: forward + backward of FBViewTransform
+        m.train()
+        dg, cg = depth.clone().requires_grad_(), ctx.clone().requires_grad_()
+        w = torch.randn(B, pc.channels, Y, X, Z, device=DEV)
+
+        def step():
+            for p_ in m.parameters():
+                p_.grad = None
+            dg.grad = cg.grad = None
+            (m(cam, cg, dg) * w).sum().backward()
+        row('S3t training step of the path (forward + backward of FBViewTransform, fused DA backward)', name, B, pct(step, n))
 
 
 def s4_s5(quick):

@@ -34,8 +34,8 @@ def main():
     algo = 4 * B * cfg.n_cams * cfg.D * H * W + 4 * B * cfg.n_cams * H * W * C + 4 * (3 * P + 2 * I) + out.numel() * esz
     print(json.dumps({'config': name, 'B': B, 'storage': storage, 'P': P, 'I': I, 'algo_bytes': algo}))
     ref = None
-    tvs = (64, 128) if storage == 'f32' else (128, 256)
-    for tv, cs, wg, lg in itertools.product(tvs, (1, 2), (256,), (3, 4, 5, 6, 7)):
+    tvs = (32, 64, 128) if storage == 'f32' else (64, 128, 256)
+    for tv, cs, wg, lg in itertools.product(tvs, (1, 2), (256, 128), (3, 4, 5, 6)):
         if C % (4 * cs):
             continue
         cc = C // cs
