@@ -263,7 +263,7 @@ class DA_MSDeformableAttention(nn.Module):
         aw = aw.softmax(-1).view(bs, nq, self.num_heads, self.num_levels, self.num_points)
         return so, aw
 
-    def project_head_minor(self, query, softmax=True):
+    def project_head_minor(self, query):
         """`project` with the sampling_offsets rows permuted so that the offsets come out head-minor, (B,Q,L,P,M,2):
         the layout the fused kernel reads with contiguous lanes (same dot product per element, only the row order of
         the weight matrix changes).  The attention weights keep (B,Q,M,L,P): their softmax runs over the last dim."""
@@ -279,8 +279,6 @@ class DA_MSDeformableAttention(nn.Module):
         aw = self.attention_weights(query).view(bs, nq, M, L * P)
         if self.disable_deformable:
             so, aw = so * 0, aw * 0
-        if not softmax:                 # raw logits: the fused kernel runs the softmax on its LDS-staged rows
-            return so, aw.view(bs, nq, M, L, P)
         return so, aw.softmax(-1).view(bs, nq, M, L, P)
 
     def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_padding_mask=None,
@@ -409,16 +407,14 @@ class DA_SpatialCrossAttention(nn.Module):
                 self._vpad16_key = key
             w, bb = self._vpad16
             v = F.linear(x, w, bb).to(self.value_dtype).view(B * ncam, S, M, HS16)
-            fuse_sm = (da.num_levels * da.num_points) % 4 == 0 and da.num_levels * da.num_points <= 36
-            so, aw = da.project_head_minor(query, softmax=not fuse_sm)
+            so, aw = da.project_head_minor(query)
             DC, H0, W0 = pred_img_depth.shape[2:]
             slots = torch.empty((B, Q, M * Dh), dtype=torch.float32, device=query.device)
             _capi.da_cross_attn_fwd(v, spatial_shapes.to(torch.int64).contiguous(), level_start_index.to(torch.int64).contiguous(),
                                     pred_img_depth.reshape(B * ncam, DC, H0, W0).contiguous().float(),
                                     reference_points_cam.contiguous().float(), mask.contiguous(),
                                     bev_query_depth.squeeze(-1).contiguous().float(), so.contiguous().float(),
-                                    aw.contiguous().float(), self.dbound[0], self.dbound[2], slots,
-                                    head_minor=1 | 4 | (8 if fuse_sm else 0), head_dim=Dh)
+                                    aw.contiguous().float(), self.dbound[0], self.dbound[2], slots, head_minor=1 | 4, head_dim=Dh)
             return slots
         if torch.is_grad_enabled() and (wt.requires_grad or bs.requires_grad or value.requires_grad):
             # training: the backward keeps the value gradient in LDS planes when a head's plane fits (single-level FB-OCC
@@ -433,20 +429,6 @@ class DA_SpatialCrossAttention(nn.Module):
                 self._vpad_key = key
             w, bb = self._vpad
         v = F.linear(x, w, bb).view(B * ncam, S, M, HS)           # a token's M*HS floats are (HS/4, M, 4)
-        LP = da.num_levels * da.num_points
-        if not grad_mode and LP % 4 == 0 and LP <= 36 and Dh in (8, 10, 16, 32) and v.numel() * 4 < 2 ** 32:
-            # inference: softmax of the attention logits inside the kernel (its LDS-staged rows), no autograd node
-            so, aw = da.project_head_minor(query, softmax=False)
-            DC, H0, W0 = pred_img_depth.shape[2:]
-            slots = torch.empty((B, Q, M * Dh), dtype=torch.float32, device=query.device)
-            _capi.da_cross_attn_fwd(v.contiguous().float(), spatial_shapes.to(torch.int64).contiguous(),
-                                    level_start_index.to(torch.int64).contiguous(),
-                                    pred_img_depth.reshape(B * ncam, DC, H0, W0).contiguous().float(),
-                                    reference_points_cam.contiguous().float(), mask.contiguous(),
-                                    bev_query_depth.squeeze(-1).contiguous().float(), so.contiguous().float(),
-                                    aw.contiguous().float(), self.dbound[0], self.dbound[2], slots,
-                                    head_minor=1 | (4 if interleave else 0) | 8, head_dim=Dh)
-            return slots
         so, aw = da.project_head_minor(query)
         DC, H0, W0 = pred_img_depth.shape[2:]
         return FusedDACrossAttention.apply(

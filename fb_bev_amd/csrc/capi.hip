@@ -842,12 +842,11 @@ extern "C" int fbbev_da_cross_attn_fwd_e(const void* value, const int64_t* spati
     if (ub > 65536) ub = 65536;
     const int LP = L * P;
     const bool stage = !(head_minor & 2) && LP % 4 == 0 && LP <= 36 && aligned16(attn);
-    if ((head_minor & 8) && !stage) return FBBEV_E_UNSUPPORTED;
     const size_t lds = stage ? (size_t)256 * (LP + 1) * sizeof(float) : 0;
 #define FBBEV_DA_UNIT16(DH_, ET_)                                                                                    \
     FBBEV_LAUNCH((k_da_cross_attn_fwd_unit<DH_, true, true, ET_>), ub, 256, lds, (fbbev_rt_stream)stream_, units, value, \
                  spatial_shapes, level_start_index, pred_depth, ref_cam, mask, qdepth, offsets, attn, B, Ncam, S, M,  \
-                 L, Q, P, Za, DC, d0, dstep, head_minor & 11, HS, stage ? 1 : 0, slots)
+                 L, Q, P, Za, DC, d0, dstep, head_minor & 3, HS, stage ? 1 : 0, slots)
 #define FBBEV_DA_UNIT16_ET(DH_) do { if (value_elem_type == 1) FBBEV_DA_UNIT16(DH_, 1); else FBBEV_DA_UNIT16(DH_, 2); } while (0)
     if (Dh == 10) FBBEV_DA_UNIT16_ET(10);
     else if (Dh == 8) FBBEV_DA_UNIT16_ET(8);
@@ -888,12 +887,11 @@ extern "C" int fbbev_da_cross_attn_fwd(const float* value, const int64_t* spatia
         // attention weights in (B,Q,M,L,P) staged through LDS ([256][L*P+1] floats) when 4 workgroups per CU still fit
         const int LP = L * P;
         const bool stage = !(head_minor & 2) && LP % 4 == 0 && LP <= 36 && aligned16(attn);
-        if ((head_minor & 8) && !stage) return FBBEV_E_UNSUPPORTED;     // in-kernel softmax runs on the staged rows
         const size_t lds = stage ? (size_t)256 * (LP + 1) * sizeof(float) : 0;
 #define FBBEV_DA_UNIT_W(DH_, W_, Q_)                                                                                \
     FBBEV_LAUNCH((k_da_cross_attn_fwd_unit<DH_, W_, Q_>), ub, 256, lds, (fbbev_rt_stream)stream_, units, value,      \
                  spatial_shapes, level_start_index, pred_depth, ref_cam, mask, qdepth, offsets, attn, B, Ncam, S, M, \
-                 L, Q, P, Za, DC, d0, dstep, head_minor & 11, HS, stage ? 1 : 0, slots)
+                 L, Q, P, Za, DC, d0, dstep, head_minor & 3, HS, stage ? 1 : 0, slots)
 #define FBBEV_DA_UNIT(DH_) do { if (qi) FBBEV_DA_UNIT_W(DH_, true, true); else if (wide) FBBEV_DA_UNIT_W(DH_, true, false); \
                                 else FBBEV_DA_UNIT_W(DH_, false, false); } while (0)
         if (Dh == 10) FBBEV_DA_UNIT(10);
@@ -905,7 +903,6 @@ extern "C" int fbbev_da_cross_attn_fwd(const float* value, const int64_t* spatia
         FBBEV_CHECK_LAUNCH();
         return 0;
     }
-    if (head_minor & 8) return FBBEV_E_UNSUPPORTED;                     // raw logits: unit-per-lane kernel only
     long long blocks = (n + 255) / 256;
     if (blocks > 65536) blocks = 65536;
     FBBEV_LAUNCH(k_da_cross_attn_fwd, blocks, 256, 0, (fbbev_rt_stream)stream_, n, value, spatial_shapes,

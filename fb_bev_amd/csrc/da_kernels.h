@@ -163,17 +163,6 @@ k_da_cross_attn_fwd_unit(long long n_units, const void* __restrict__ value_, con
                 d[0] = a[0]; d[1] = a[1]; d[2] = a[2]; d[3] = a[3];
             }
             __syncthreads();
-            if ((head_minor & 8) && unit < n_units) {
-                // `attn` holds the RAW output of the attention_weights Linear: the softmax over the unit's L*P samples
-                // (spatial_cross_attention_depth.py:541-545) runs here on the staged row -- max, exp(x - max), sum, divide,
-                // the steps of torch's softmax -- and saves its launch and a write + read of the (B,Q,M,L,P) tensor
-                float* row = staged + threadIdx.x * LDW;
-                float mx = row[0];
-                for (int i = 1; i < LP; ++i) mx = fmaxf(mx, row[i]);
-                float sum = 0.f;
-                for (int i = 0; i < LP; ++i) { const float e = expf(row[i] - mx); row[i] = e; sum += e; }
-                for (int i = 0; i < LP; ++i) row[i] = row[i] / sum;
-            }
         }
         if (unit >= n_units) continue;
         const float* my_attn = staged + threadIdx.x * LDW;

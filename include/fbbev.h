@@ -283,9 +283,7 @@ int fbbev_point_sampling(const float* xs, const float* ys, const float* zs, cons
  * read contiguous bytes per sample (offsets head-minor is the fast path of the FB-OCC shapes); bit 2 -> a token's
  * M*head_stride floats are stored chunk-major, (head_stride/4, M, 4), instead of (M, head_stride): the 8 head lanes of
  * a query read one contiguous M*16-byte piece per load (needs head_stride % 4 == 0; same for grad_value in the
- * backward entries); bit 3 (forward only) -> attn holds the RAW attention_weights logits in (B,Q,M,L,P) and the softmax
- * over the L*P samples of a (query, head) runs inside the kernel (needs L*P % 4 == 0, L*P <= 36, 16-byte aligned attn;
- * otherwise FBBEV_E_UNSUPPORTED).
+ * backward entries).
  * head_stride: floats between two heads inside a value row (0 = Dh, i.e. value is (B*Ncam,S,M,Dh) dense); a value_proj
  * output padded to a multiple of 4 floats per head (Dh = 10 -> 12) makes every head chunk 16-byte aligned and lets the
  * kernel read a corner with 3 dwordx4 loads; the padding floats are ignored (grad_value of the padding stays 0).
