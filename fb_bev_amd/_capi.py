@@ -61,9 +61,9 @@ SIGNATURES = {
     'fbbev_da_cross_attn_fwd': (c_int, [c_void_p] * 9 + [c_int] * 10 + [c_float, c_float, c_int, c_int, c_void_p, c_void_p]),
     'fbbev_da_cross_attn_fwd_e': (c_int, [c_void_p] * 9 + [c_int] * 10 + [c_float, c_float, c_int, c_int, c_int] + [c_void_p, c_void_p]),
     'fbbev_da_cross_attn_bwd': (c_int, [c_void_p] * 10 + [c_int] * 10 + [c_float, c_float, c_int, c_int] + [c_void_p] * 5),
-    'fbbev_da_cross_attn_bwd_ws_bytes': (c_size_t, [c_int] * 8),
+    'fbbev_da_cross_attn_bwd_ws_bytes': (c_size_t, [c_int] * 9 + [c_void_p]),
     'fbbev_da_cross_attn_bwd_ws': (c_int, [c_void_p] * 10 + [c_int] * 10 + [c_float, c_float, c_int, c_int] + [c_void_p] * 4 +
-                                   [c_void_p, c_size_t, c_void_p]),
+                                   [c_void_p, c_void_p, c_size_t, c_void_p]),
     'fbbev_msda_fwd_fused': (c_int, [c_void_p] * 6 + [c_int] * 9 + [c_void_p, c_void_p]),
     'fbbev_msda_bwd': (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p] * 3 + [c_void_p]),
 }
@@ -422,9 +422,24 @@ def da_cross_attn_fwd(value, spatial_shapes, level_start_index, pred_depth, ref_
             float(d0), float(dstep), head_minor, HS, _dev(slots, F32, 'slots'), _stream()), 'fbbev_da_cross_attn_fwd')
 
 
+def _level_hw(level_hw, L):
+    """host (h, w) pairs -> ctypes int32 array (or None): lets the backward plan LDS token regions without a device read"""
+    if level_hw is None:
+        return None
+    flat = [int(x) for hw in level_hw for x in hw]
+    if len(flat) != 2 * L:
+        raise FbbevError('level_hw must hold num_levels (h, w) pairs')
+    return (c_int32 * len(flat))(*flat)
+
+
+def da_cross_attn_bwd_ws_bytes(B, Ncam, S, M, Dh, Q, HS, L, P, level_hw=None):
+    arr = _level_hw(level_hw, L)
+    return lib().fbbev_da_cross_attn_bwd_ws_bytes(B, Ncam, S, M, Dh, Q, HS, L, P, arr)
+
+
 def da_cross_attn_bwd(value, spatial_shapes, level_start_index, pred_depth, ref_cam, mask, qdepth, offsets, attn,
                       grad_slots, d0, dstep, head_minor, grad_value, grad_pred_depth, grad_offsets, grad_attn, head_dim=None,
-                      lds_planes=True):
+                      lds_planes=True, level_hw=None):
     """Backward of da_cross_attn_fwd; the four grad tensors must be pre-zeroed (accumulated into)."""
     Ncam, B, Q, Za = mask.shape
     _, S, M, HS = value.shape
@@ -444,10 +459,11 @@ def da_cross_attn_bwd(value, spatial_shapes, level_start_index, pred_depth, ref_
     with _on(value):
         # value gradient through LDS planes + a partial buffer when the shape fits (fbbev_da_cross_attn_bwd_ws), else
         # the global-atomic kernel
-        need = lib().fbbev_da_cross_attn_bwd_ws_bytes(B, Ncam, S, M, Dh, Q, HS, L * P) if lds_planes else 0
+        arr = _level_hw(level_hw, L)
+        need = lib().fbbev_da_cross_attn_bwd_ws_bytes(B, Ncam, S, M, Dh, Q, HS, L, P, arr) if lds_planes else 0
         if need:
             ws = torch.empty(need // 4, dtype=torch.float32, device=value.device)
-            _check(lib().fbbev_da_cross_attn_bwd_ws(*args, ws.data_ptr(), need, _stream()), 'fbbev_da_cross_attn_bwd_ws')
+            _check(lib().fbbev_da_cross_attn_bwd_ws(*args, arr, ws.data_ptr(), need, _stream()), 'fbbev_da_cross_attn_bwd_ws')
         else:
             _check(lib().fbbev_da_cross_attn_bwd(*args, _stream()), 'fbbev_da_cross_attn_bwd')
 

@@ -57,8 +57,15 @@ def const_tensor(values, device, dtype=torch.long):
     them from Python lists on every forward is a pageable H2D copy, which also breaks hipGraph capture."""
     key = (repr(values), str(device), dtype)
     if key not in _CONST:
-        _CONST[key] = torch.as_tensor(values, dtype=dtype, device=device)
+        t = torch.as_tensor(values, dtype=dtype, device=device)
+        t._fbbev_host = values          # the Python values ride along: kernels that plan on the host need no device read
+        _CONST[key] = t
     return _CONST[key]
+
+
+def host_values(t):
+    """The Python values a const_tensor was built from (None for any other tensor)."""
+    return getattr(t, '_fbbev_host', None)
 
 
 def inv3x3(m):
@@ -324,7 +331,7 @@ class FusedDACrossAttention(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, value, pred_depth, offsets, attn, spatial_shapes, level_start_index, ref_cam, mask, qdepth,
-                d0, dstep, head_minor, head_dim=None):
+                d0, dstep, head_minor, head_dim=None, level_hw=None):
         B, Q = offsets.shape[0], offsets.shape[1]
         M = value.shape[2]
         Dh = value.shape[3] if head_dim is None else head_dim          # value rows may be head-padded (stride value.shape[3])
@@ -332,17 +339,18 @@ class FusedDACrossAttention(torch.autograd.Function):
         _capi.da_cross_attn_fwd(value, spatial_shapes, level_start_index, pred_depth, ref_cam, mask, qdepth, offsets,
                                 attn, d0, dstep, slots, head_minor=head_minor, head_dim=Dh)
         ctx.save_for_backward(value, pred_depth, offsets, attn, spatial_shapes, level_start_index, ref_cam, mask, qdepth)
-        ctx.consts = (d0, dstep, head_minor, Dh)
+        ctx.consts = (d0, dstep, head_minor, Dh, level_hw)
         return slots
 
     @staticmethod
     def backward(ctx, grad_slots):
         value, pred_depth, offsets, attn, spatial_shapes, level_start_index, ref_cam, mask, qdepth = ctx.saved_tensors
-        d0, dstep, head_minor, Dh = ctx.consts
+        d0, dstep, head_minor, Dh, level_hw = ctx.consts
         gv, gd, go, ga = (torch.zeros_like(t) for t in (value, pred_depth, offsets, attn))
         _capi.da_cross_attn_bwd(value, spatial_shapes, level_start_index, pred_depth, ref_cam, mask, qdepth, offsets,
-                                attn, grad_slots.contiguous().float(), d0, dstep, head_minor, gv, gd, go, ga, head_dim=Dh)
-        return gv, gd, go, ga, None, None, None, None, None, None, None, None, None
+                                attn, grad_slots.contiguous().float(), d0, dstep, head_minor, gv, gd, go, ga, head_dim=Dh,
+                                level_hw=level_hw)
+        return gv, gd, go, ga, None, None, None, None, None, None, None, None, None, None
 
 
 def _pad_interleave_rows(w, b, M, Dh, HS, interleave=True, piece=4):
@@ -419,7 +427,8 @@ class DA_SpatialCrossAttention(nn.Module):
         if torch.is_grad_enabled() and (wt.requires_grad or bs.requires_grad or value.requires_grad):
             # training: the backward keeps the value gradient in LDS planes when a head's plane fits (single-level FB-OCC
             # shapes); otherwise it uses global atomics, whose 10 consecutive channel lanes want head-major rows
-            interleave = _capi.lib().fbbev_da_cross_attn_bwd_ws_bytes(B, ncam, S, M, Dh, Q, HS, da.num_levels * da.num_points) > 0
+            interleave = _capi.da_cross_attn_bwd_ws_bytes(B, ncam, S, M, Dh, Q, HS, da.num_levels, da.num_points,
+                                                          host_values(spatial_shapes)) > 0
             w, bb = _pad_interleave_rows(wt, bs, M, Dh, HS, interleave)
         else:                               # inference: once per weight version
             key = (wt.data_ptr(), wt._version, bs._version, str(wt.device))
@@ -435,7 +444,8 @@ class DA_SpatialCrossAttention(nn.Module):
             v.contiguous().float(), pred_img_depth.reshape(B * ncam, DC, H0, W0).contiguous().float(),
             so.contiguous().float(), aw.contiguous().float(), spatial_shapes.to(torch.int64).contiguous(),
             level_start_index.to(torch.int64).contiguous(), reference_points_cam.contiguous().float(), mask.contiguous(),
-            bev_query_depth.squeeze(-1).contiguous().float(), self.dbound[0], self.dbound[2], 1 | (4 if interleave else 0), Dh)
+            bev_query_depth.squeeze(-1).contiguous().float(), self.dbound[0], self.dbound[2], 1 | (4 if interleave else 0), Dh,
+            host_values(spatial_shapes))
 
     # ---- training: vectorised rebatch + composite deformable attention (autograd through the MSDA op)
     def _slots_composite(self, query, value, reference_points_cam, mask, bev_query_depth, pred_img_depth,

@@ -944,39 +944,86 @@ extern "C" int fbbev_da_cross_attn_bwd(const float* value, const int64_t* spatia
     return 0;
 }
 
-// LDS-plane backward (k_da_cross_attn_bwd_tile + k_da_bwd_reduce): needs a caller-owned partial buffer
-struct da_bwd_plan { int chunks, q_per_chunk, threads; size_t lds, ws; };
-static bool da_bwd_tile_plan(int B, int Ncam, int S, int M, int Dh, int Q, int HS, int LP, da_bwd_plan* pl) {
-    const size_t plane = (size_t)S * HS * sizeof(long long);                       // 64-bit fixed-point accumulators
-    // four lanes per unit, lane k = channels 4k..4k+3: head dims up to 16 (FB-OCC: 10); two workgroups per CU
-    if (plane > 72 * 1024 || Dh > 16 || HS % 4 != 0 || HS > 16 || Q <= 0) return false;
-    // two workgroups per CU in one round (512 of them); 512 threads (128 units per iteration, 16 waves per CU) when a
-    // chunk is long enough for a camera to see that many of its queries, else 256
+// LDS-plane backward (needs a caller-owned partial buffer): k_da_cross_attn_bwd_unit (unit-owned gradients) +
+// k_da_cross_attn_bwd_scatter per token region + k_da_bwd_reduce
+struct da_region { int lvl0, lvl1, tok0, tok1; };
+struct da_bwd_plan { int chunks, q_per_chunk, threads, n_regions; size_t lds, ws; da_region reg[32]; };
+
+// token regions of at most `budget` tokens: whole consecutive levels, or bands of rows of a level larger than the budget
+// (level_hw: HOST array of L (h, w) pairs; without it only the one-region case -- the whole pyramid fits -- is planned)
+static int da_bwd_regions(int L, const int32_t* level_hw, int S, int budget, da_region* out, int cap) {
+    if (!level_hw) {
+        if (S > budget) return 0;
+        out[0] = {0, L, 0, S};
+        return 1;
+    }
+    int n = 0, start = 0;
+    da_region cur = {0, 0, 0, 0};
+    for (int l = 0; l < L; ++l) {
+        const int h = level_hw[2 * l], w = level_hw[2 * l + 1];
+        if (h <= 0 || w <= 0) return 0;
+        const int cnt = h * w;
+        if (cnt > budget) {
+            if (cur.lvl1 > cur.lvl0) { if (n == cap) return 0; out[n++] = cur; }
+            const int rows = budget / w;
+            if (rows < 1) return 0;
+            for (int r = 0; r < h; r += rows) {
+                if (n == cap) return 0;
+                out[n++] = {l, l + 1, start + r * w, start + (r + rows < h ? r + rows : h) * w};
+            }
+            cur = {l + 1, l + 1, start + cnt, start + cnt};
+        } else if (cur.lvl1 > cur.lvl0 && (cur.tok1 - cur.tok0) + cnt > budget) {
+            if (n == cap) return 0;
+            out[n++] = cur;
+            cur = {l, l + 1, start, start + cnt};
+        } else {
+            if (cur.lvl1 == cur.lvl0) cur = {l, l + 1, start, start + cnt};
+            else { cur.lvl1 = l + 1; cur.tok1 = start + cnt; }
+        }
+        start += cnt;
+    }
+    if (cur.lvl1 > cur.lvl0) { if (n == cap) return 0; out[n++] = cur; }
+    return start == S ? n : 0;
+}
+
+static bool da_bwd_tile_plan(int B, int Ncam, int S, int M, int Dh, int Q, int HS, int L, int P, const int32_t* level_hw,
+                             da_bwd_plan* pl) {
+    if (Dh > 16 || HS % 4 != 0 || HS > 16 || Q <= 0) return false;
+    if (P > FBBEV_DA_BWD_MAXP || !(Dh == 10 || Dh == 8 || Dh == 16 || Dh == 4)) return false;
+    int budget = (68 * 1024) / (HS * (int)sizeof(long long)) - 8;                  // tokens per LDS plane (64-bit words, skewed)
+    if (const char* e = getenv("FBBEV_DA_BWD_TOKENS")) { const int v = atoi(e); if (v > 0 && v < budget) budget = v; }   // tests: force bands
+    pl->n_regions = da_bwd_regions(L, level_hw, S, budget, pl->reg, 32);
+    if (pl->n_regions == 0) return false;
+    int max_tok = 0;
+    for (int r = 0; r < pl->n_regions; ++r) max_tok = pl->reg[r].tok1 - pl->reg[r].tok0 > max_tok ? pl->reg[r].tok1 - pl->reg[r].tok0 : max_tok;
+    const size_t plane = (size_t)FBBEV_DA_PLANE_WORDS(max_tok, HS) * sizeof(long long);
+    // two workgroups per CU in one round (512 of them)
     long long want = (512 + (long long)B * M - 1) / ((long long)B * M);
     if (const char* e = getenv("FBBEV_DA_BWD_CHUNKS")) { const int v = atoi(e); if (v > 0) want = v; }
     if (want < 1) want = 1;
     if (want > 256) want = 256;
     int qpc = (int)((Q + want - 1) / want);
+    // one lane per query the camera sees: 512 threads (measured 0.177 vs 0.208 ms at the shipped shape) unless the chunk is short
     pl->threads = qpc >= 512 ? 512 : 256;
     if (const char* e = getenv("FBBEV_DA_BWD_THREADS")) { const int v = atoi(e); if (v == 256 || v == 512) pl->threads = v; }
-    const int ng = pl->threads / 4;                                               // queries per workgroup iteration
+    const int ng = pl->threads;                                                   // queries per workgroup iteration
     qpc = (qpc + ng - 1) / ng * ng;
+    if (qpc > 65535) return false;                                                // chunk-relative 16-bit query ids
     pl->q_per_chunk = qpc;
     pl->chunks = (Q + qpc - 1) / qpc;
-    // + the camera's hit list, its counter, the block maximum, and the per-group staging of the weight / offset gradients
-    if (qpc > 65535) return false;                                                // chunk-relative 16-bit query ids
-    pl->lds = plane + (size_t)((qpc + 1) & ~1) * 2 + (size_t)(1 + pl->threads / 64) * sizeof(int) + (size_t)ng * LP * 3 * sizeof(float);
+    // + the camera's hit list, its counter, the block maximum
+    pl->lds = plane + (size_t)((qpc + 1) & ~1) * 2 + (size_t)(1 + pl->threads / 64) * sizeof(int);
     if (pl->lds > 80 * 1024) return false;
     pl->ws = (size_t)B * M * pl->chunks * Ncam * S * HS * sizeof(float);
     return true;
 }
 
 extern "C" size_t fbbev_da_cross_attn_bwd_ws_bytes(int B, int Ncam, int S, int M, int Dh, int Q, int head_stride,
-                                                   int samples_per_unit) {
-    if (B <= 0 || Ncam <= 0 || S <= 0 || M <= 0 || Dh <= 0 || samples_per_unit <= 0) return 0;
+                                                   int num_levels, int num_points, const int32_t* level_hw_host) {
+    if (B <= 0 || Ncam <= 0 || S <= 0 || M <= 0 || Dh <= 0 || num_levels <= 0 || num_points <= 0) return 0;
     da_bwd_plan pl;
     const int HS = head_stride == 0 ? Dh : head_stride;
-    if (HS < Dh || !da_bwd_tile_plan(B, Ncam, S, M, Dh, Q, HS, samples_per_unit, &pl)) return 0;
+    if (HS < Dh || !da_bwd_tile_plan(B, Ncam, S, M, Dh, Q, HS, num_levels, num_points, level_hw_host, &pl)) return 0;
     return pl.ws;
 }
 
@@ -986,13 +1033,16 @@ extern "C" int fbbev_da_cross_attn_bwd_ws(const float* value, const int64_t* spa
                                           const float* grad_slots, int B, int Ncam, int S, int M, int Dh, int L, int Q,
                                           int P, int Za, int DC, float d0, float dstep, int head_minor, int head_stride,
                                           float* grad_value, float* grad_pred_depth, float* grad_offsets,
-                                          float* grad_attn, void* ws, size_t ws_bytes, fbbev_stream_t stream_) {
+                                          float* grad_attn, const int32_t* level_hw_host, void* ws, size_t ws_bytes,
+                                          fbbev_stream_t stream_) {
     if (B <= 0 || Ncam <= 0 || S <= 0 || M <= 0 || Dh <= 0 || L <= 0 || Q < 0 || P <= 0 || Za <= 0 || DC <= 0)
         return FBBEV_E_BADARG;
     const int HS = head_stride == 0 ? Dh : head_stride;
     da_bwd_plan pl;
-    if (HS < Dh || Q == 0 || !ws || !aligned16(ws) || !aligned16(grad_value) || !da_bwd_tile_plan(B, Ncam, S, M, Dh, Q, HS, L * P, &pl) ||
-        ws_bytes < pl.ws || (long long)B * M * pl.chunks >= (1ll << 31))
+    if (HS < Dh || Q == 0 || !ws || !aligned16(ws) || !aligned16(grad_value) || !aligned16(value) ||
+        !da_bwd_tile_plan(B, Ncam, S, M, Dh, Q, HS, L, P, level_hw_host, &pl) || ws_bytes < pl.ws ||
+        (long long)B * M * pl.chunks >= (1ll << 31) || (long long)B * Ncam * S * M * HS * 4 >= (1ll << 32) ||
+        (((uintptr_t)offsets | (uintptr_t)grad_offsets | (uintptr_t)grad_slots) & 7) != 0)
         return fbbev_da_cross_attn_bwd(value, spatial_shapes, level_start_index, pred_depth, ref_cam, mask, qdepth, offsets,
                                        attn, grad_slots, B, Ncam, S, M, Dh, L, Q, P, Za, DC, d0, dstep, head_minor,
                                        head_stride, grad_value, grad_pred_depth, grad_offsets, grad_attn, stream_);
@@ -1003,13 +1053,45 @@ extern "C" int fbbev_da_cross_attn_bwd_ws(const float* value, const int64_t* spa
     fbbev_rt_stream stream = (fbbev_rt_stream)stream_;
     float* part = static_cast<float*>(ws);
     const long long wgs = (long long)B * M * pl.chunks;
-#define FBBEV_DA_BWD_TILE(NT_)                                                                                          \
-    FBBEV_LAUNCH(k_da_cross_attn_bwd_tile<NT_>, wgs, NT_, pl.lds, stream, value, spatial_shapes, level_start_index,     \
-                 pred_depth, ref_cam, mask, qdepth, offsets, attn, grad_slots, B, Ncam, S, M, Dh, L, Q, P, Za, DC, d0, \
-                 dstep, head_minor & 7, HS, pl.chunks, pl.q_per_chunk, part, grad_pred_depth, grad_offsets, grad_attn)
-    if (pl.threads == 512) FBBEV_DA_BWD_TILE(512);
-    else FBBEV_DA_BWD_TILE(256);
-#undef FBBEV_DA_BWD_TILE
+    {
+        // (A) unit-owned gradients, the forward's launch shape
+        const long long units = (long long)B * Q * M;
+        long long ub = ((units + 255) / 256 + 7) / 8 * 8;
+        if (ub > 65536) ub = 65536;
+        const size_t lds_a = (size_t)256 * (4 * P + 1) * sizeof(float);
+        const bool qi = (head_minor & 4) != 0;
+#define FBBEV_DA_BWD_UNIT(DH_)                                                                                          \
+    do {                                                                                                                \
+        if (qi) FBBEV_LAUNCH((k_da_cross_attn_bwd_unit<DH_, true>), ub, 256, lds_a, stream, units, value, spatial_shapes, \
+                             level_start_index, pred_depth, ref_cam, mask, qdepth, offsets, attn, grad_slots, B, Ncam, S, M, \
+                             L, Q, P, Za, DC, d0, dstep, head_minor & 3, HS, grad_pred_depth, grad_offsets, grad_attn);   \
+        else FBBEV_LAUNCH((k_da_cross_attn_bwd_unit<DH_, false>), ub, 256, lds_a, stream, units, value, spatial_shapes, \
+                          level_start_index, pred_depth, ref_cam, mask, qdepth, offsets, attn, grad_slots, B, Ncam, S, M, \
+                          L, Q, P, Za, DC, d0, dstep, head_minor & 3, HS, grad_pred_depth, grad_offsets, grad_attn);    \
+    } while (0)
+        if (Dh == 10) FBBEV_DA_BWD_UNIT(10);
+        else if (Dh == 8) FBBEV_DA_BWD_UNIT(8);
+        else if (Dh == 4) FBBEV_DA_BWD_UNIT(4);
+        else FBBEV_DA_BWD_UNIT(16);
+#undef FBBEV_DA_BWD_UNIT
+        // (B) value gradient, one launch per token region
+        for (int r = 0; r < pl.n_regions; ++r) {
+            const da_region& rg = pl.reg[r];
+            const size_t lds_b = (size_t)FBBEV_DA_PLANE_WORDS(rg.tok1 - rg.tok0, HS) * sizeof(long long) + (size_t)((pl.q_per_chunk + 1) & ~1) * 2 +
+                                 (size_t)(1 + pl.threads / 64) * sizeof(int);
+#define FBBEV_DA_BWD_SC(NT_, DH_)                                                                                       \
+    FBBEV_LAUNCH((k_da_cross_attn_bwd_scatter<NT_, DH_>), wgs, NT_, lds_b, stream, spatial_shapes, level_start_index,     \
+                 pred_depth, ref_cam, mask, qdepth, offsets, attn, grad_slots, B, Ncam, S, M, L, Q, P, Za, DC, d0, dstep, \
+                 head_minor & 3, HS, pl.chunks, pl.q_per_chunk, rg.lvl0, rg.lvl1, rg.tok0, rg.tok1, part)
+#define FBBEV_DA_BWD_SC_NT(DH_) do { if (pl.threads == 512) FBBEV_DA_BWD_SC(512, DH_); else FBBEV_DA_BWD_SC(256, DH_); } while (0)
+            if (Dh == 10) FBBEV_DA_BWD_SC_NT(10);
+            else if (Dh == 8) FBBEV_DA_BWD_SC_NT(8);
+            else if (Dh == 4) FBBEV_DA_BWD_SC_NT(4);
+            else FBBEV_DA_BWD_SC_NT(16);
+#undef FBBEV_DA_BWD_SC_NT
+#undef FBBEV_DA_BWD_SC
+        }
+    }
     const long long n = (long long)B * Ncam * S * M * HS;
     long long rb = (n + 255) / 256;
     if (rb > 65536) rb = 65536;

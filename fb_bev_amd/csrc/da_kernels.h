@@ -23,6 +23,10 @@
 #include "msda_kernels.h"
 
 #define FBBEV_DA_MAX_ZA 8
+// LDS plane of the fixed-point backward kernels: word index of token t, and words of an n-token plane
+#define FBBEV_DA_PLANE_IDX(t, HS) ((t) * (HS) + ((t) >> 3))
+#define FBBEV_DA_PLANE_WORDS(n, HS) ((n) * (HS) + ((n) >> 3) + 1)
+#define FBBEV_DA_BWD_MAXP 8     // sampling points per level the split backward batches (FB-OCC: 8)
 
 // bilinear sample of ONE plane (H,W) row-major at normalised (x,y), MSDA validity/padding rules
 __device__ __forceinline__ float fbbev_plane_sample(const float* __restrict__ plane, int H, int W, float x,
@@ -364,14 +368,13 @@ k_da_cross_attn_bwd(long long n_units, const float* __restrict__ value, const in
 }
 
 
-// ---------------------------------------------------------------- backward with an LDS-resident value-gradient plane
+// ---------------------------------------------------------------- backward with LDS-resident value-gradient planes
 // k_da_cross_attn_bwd sends every corner of every sample to the value gradient with a global fp32 atomic: at the shipped
 // shapes (Q = 10^4, one 16x44 level) ~110 adds land on each of the 1.6 M gradient floats, across all 8 XCDs -- 1.5 ms at
-// B = 4, bound by the atomic rate.  Here a workgroup owns (sample b, head m, a chunk of consecutive BEV queries) and
-// walks the cameras in order; for each camera the head's gradient plane (S tokens x HS channels) lives in LDS, the corner
-// adds are LDS atomics, and the finished plane is written with plain 16-byte stores to this workgroup's slice of a
-// partial buffer  part[b][m][chunk][cam][S*HS].  k_da_bwd_reduce then sums the chunks into grad_value in the layout of
-// `value` -- no global atomic touches the value gradient.
+// B = 4 (14.2 ms at the configs[2] pyramid), bound by the atomic rate.  The replacement (fbbev_da_cross_attn_bwd_ws) keeps
+// a head's gradient plane in LDS, accumulates with LDS atomics and writes it with plain 16-byte stores to the workgroup's
+// slice of a partial buffer  part[b][m][chunk][cam][S*HS];  k_da_bwd_reduce then sums the chunks into grad_value in the
+// layout of `value` -- no global atomic touches the value gradient.
 // The plane is FIXED POINT: 64-bit integers in units of 2^-30 of the power of two above max|grad_slots| of the chunk.
 // ds_add_f32 retires ~0.8 lanes per ns and CU on gfx950, ds_add_u64 22 (profiles/r02_micro_lds_atomics.jsonl: the fp32
 // LDS atomic is 40x slower than the integer ones), and integer adds commute: the value gradient is bit-reproducible run
@@ -379,51 +382,226 @@ k_da_cross_attn_bwd(long long n_units, const float* __restrict__ value, const in
 // max|g| in magnitude, so it is rounded ONCE to a multiple of 2^-30 of that bound (finer than its own fp32 ulp for
 // everything within 2^-6 of the largest contribution) and the <= q_per_chunk*L*P adds of a plane cannot overflow 63 bits;
 // the plane is converted back with one rounding.  Non-finite upstream gradients turn the chunk's planes into NaN.
-// grad_attn / grad_offsets: plain read-modify-writes of the unit's owner (the same workgroup handles a unit for every
-// camera, phases separated by barriers -> fixed order); grad_pred_depth: fp32 global atomics as in k_da_cross_attn_bwd.
-// Lane mapping: FOUR lanes own a (b,q,m) unit -- lane k its channels 4k..4k+3 (one 16-byte load per corner; with the
-// chunk-major token rows the three chunk lanes of a head read three 16-byte pieces) and its depth anchor z = k (k+4) --
-// so a wave works on 16 queries at once; the queries a camera sees (~28 % of a chunk) are first compacted into an LDS
-// list, so every group of every wave is busy.  (One lane per channel and one query per 16 lanes, the layout of the
-// atomic kernel, left 62 % of the lanes and a third of the groups active: 0.99 ms at the shipped shape, B = 4.)
-template <int NT>        // threads per workgroup: NT/4 units per iteration share one plane
-__global__ void __launch_bounds__(NT)
-k_da_cross_attn_bwd_tile(const float* __restrict__ value, const int64_t* __restrict__ spatial_shapes,
+// History of the design (profiles/r02_da_bwd_variants.jsonl): a first kernel did everything in one loop -- four lanes per
+// unit, value loads, LDS adds, group shuffles, staged read-modify-writes, depth atomics: 0.39 ms at the shipped shape, of
+// which 0.3 ms were the 8.7 M scattered fp32 global atomics of the depth-distribution gradient (8 head workgroups each
+// adding the same corners).  It was replaced by the two kernels below.
+// Split by what the gradients need (the forward kernel moves 100 G samples/s with ONE lane per (b,q,head) unit):
+//   k_da_cross_attn_bwd_unit  (A) the UNIT-OWNED gradients -- attention weights, sampling offsets, depth distribution.
+//       They need the sampled VALUES (value loads, like the forward) but no scatter: the forward's lane mapping, its
+//       chunk-major 16-byte corner loads, its XCD order; a lane owns its unit for every camera, so the per-sample
+//       results are plain read-modify-writes in camera order (deterministic), batched per level through the lane's own
+//       LDS row; the depth-distribution corners keep their fp32 global atomics.
+//   k_da_cross_attn_bwd_scatter (B) the VALUE gradient -- needs NO value loads, only coordinates and weights: a lane owns a
+//       unit (64 compacted hit queries of one head per wave), the head's gradient plane of the launch's token REGION
+//       lives in LDS as 64-bit fixed point (see above), 4 corners x Dh ds_add_u64 per sample; per-region launches
+//       cover pyramids whose whole plane does not fit (a region = whole levels, or a band of rows of one large level;
+//       corners outside the launch's token range are left to the launch that owns them).
+template <int DH>
+__device__ __forceinline__ void fbbev_unit_sample_grad(const float* __restrict__ value, unsigned lane_off, const fbbev_bilinear& s,
+                                                       int chunk_stride, const float (&g)[DH], float& dot, float& gx, float& gy) {
+    constexpr int DHP = (DH + 3) / 4 * 4;
+    const char* vb = reinterpret_cast<const char*>(value);
+    const bool k1 = s.o1 >= 0, k2 = s.o2 >= 0, k3 = s.o3 >= 0, k4 = s.o4 >= 0;
+    const unsigned b1 = lane_off + (k1 ? (unsigned)s.o1 * 4u : 0u), b2 = lane_off + (k2 ? (unsigned)s.o2 * 4u : 0u);
+    const unsigned b3 = lane_off + (k3 ? (unsigned)s.o3 * 4u : 0u), b4 = lane_off + (k4 ? (unsigned)s.o4 * 4u : 0u);
+    const unsigned cs = (unsigned)chunk_stride * 4u;
+    fbbev_v4f a1[DHP / 4], a2[DHP / 4], a3[DHP / 4], a4[DHP / 4];
+#pragma unroll
+    for (int k = 0; k < DHP / 4; ++k) {
+        a1[k] = *reinterpret_cast<const fbbev_v4f*>(vb + (b1 + k * cs));
+        a2[k] = *reinterpret_cast<const fbbev_v4f*>(vb + (b2 + k * cs));
+        a3[k] = *reinterpret_cast<const fbbev_v4f*>(vb + (b3 + k * cs));
+        a4[k] = *reinterpret_cast<const fbbev_v4f*>(vb + (b4 + k * cs));
+    }
+    dot = gx = gy = 0.f;
+#pragma unroll
+    for (int c = 0; c < DH; ++c) {
+        const float v1 = k1 ? a1[c >> 2][c & 3] : 0.f, v2 = k2 ? a2[c >> 2][c & 3] : 0.f;
+        const float v3 = k3 ? a3[c >> 2][c & 3] : 0.f, v4 = k4 ? a4[c >> 2][c & 3] : 0.f;
+        dot += g[c] * (s.w1 * v1 + s.w2 * v2 + s.w3 * v3 + s.w4 * v4);
+        gy += g[c] * (-s.hw * v1 - s.lw * v2 + s.hw * v3 + s.lw * v4);
+        gx += g[c] * (-s.hh * v1 + s.hh * v2 - s.lh * v3 + s.lh * v4);
+    }
+}
+
+template <int DH, bool QI>
+__global__ void __launch_bounds__(256)
+k_da_cross_attn_bwd_unit(long long n_units, const float* __restrict__ value, const int64_t* __restrict__ spatial_shapes,
                          const int64_t* __restrict__ level_start, const float* __restrict__ pred_depth,
                          const float* __restrict__ ref_cam, const unsigned char* __restrict__ mask,
                          const float* __restrict__ qdepth, const float* __restrict__ offsets,
                          const float* __restrict__ attn, const float* __restrict__ grad_slots, int B, int Ncam, int S,
-                         int M, int Dh, int L, int Q, int P, int Za, int DC, float d0, float dstep, int head_minor,
-                         int HS, int n_chunks, int q_per_chunk, float* __restrict__ part,
+                         int M, int L, int Q, int P, int Za, int DC, float d0, float dstep, int head_minor, int HS,
                          float* __restrict__ grad_pred_depth, float* __restrict__ grad_offsets,
                          float* __restrict__ grad_attn) {
-    long long* plane = reinterpret_cast<long long*>(fbbev_dyn_lds_f32());     // [S][HS] fixed point
-    const int plane_n = S * HS;
-    unsigned short* hits = reinterpret_cast<unsigned short*>(plane + plane_n);   // [q_per_chunk] queries (chunk-relative) the camera sees
+    const int head_off_m = QI ? 4 : HS, chunk_stride = QI ? M * 4 : 4;
+    const int row_stride = M * HS;
+    const int H0 = (int)spatial_shapes[0], W0 = (int)spatial_shapes[1];
+    const int LP = L * P, LW = 4 * P + 1;
+    float* row = fbbev_dyn_lds_f32() + threadIdx.x * LW;       // this lane's own row: [P] weights of the level, [3P] results
+    const long long n_wg = (n_units + blockDim.x - 1) / blockDim.x, per_xcd = (n_wg + 7) / 8;
+    for (long long w = blockIdx.x; (w >> 3) < per_xcd; w += gridDim.x) {
+        const long long unit = ((w & 7) * per_xcd + (w >> 3)) * blockDim.x + threadIdx.x;
+        if (unit >= n_units) continue;
+        const int m = (int)(unit % M);
+        const long long bq = unit / M;
+        const int q = (int)(bq % Q);
+        const int b = (int)(bq / Q);
+        int count = 0;
+        for (int cam = 0; cam < Ncam; ++cam) {
+            const long long base = (((long long)cam * B + b) * Q + q) * Za;
+            bool hit = false;
+            for (int z = 0; z < Za; ++z) hit = hit || (mask[base + z] != 0);
+            count += hit ? 1 : 0;
+        }
+        if (count == 0) continue;
+        float g[DH];
+        {
+            const float inv = (float)count;
+            const float* gs = grad_slots + unit * DH;
+#pragma unroll
+            for (int c = 0; c < DH; c += 2) {
+                const fbbev_v2f t = *reinterpret_cast<const fbbev_v2f*>(gs + c);
+                g[c] = t[0] / inv; g[c + 1] = t[1] / inv;
+            }
+        }
+        const long long wo0 = (head_minor & 1) ? bq * LP * M + m : unit * LP, wa0 = (head_minor & 2) ? bq * LP * M + m : unit * LP;
+        const int wo_step = (head_minor & 1) ? M : 1, wa_step = (head_minor & 2) ? M : 1;
+        const fbbev_v2f* op = reinterpret_cast<const fbbev_v2f*>(offsets) + wo0;
+        for (int cam = 0; cam < Ncam; ++cam) {
+            const long long base = (((long long)cam * B + b) * Q + q) * Za;
+            bool hit = false;
+            for (int z = 0; z < Za; ++z) hit = hit || (mask[base + z] != 0);
+            if (!hit) continue;
+            const long long bn = (long long)b * Ncam + cam;
+            float rx[FBBEV_DA_MAX_ZA], ry[FBBEV_DA_MAX_ZA], dw[FBBEV_DA_MAX_ZA], ddw[FBBEV_DA_MAX_ZA];
+            int bin[FBBEV_DA_MAX_ZA];
+            for (int z = 0; z < Za; ++z) {
+                rx[z] = ref_cam[(base + z) * 2];
+                ry[z] = ref_cam[(base + z) * 2 + 1];
+                float fb = floorf(__fdiv_rn(__fsub_rn(qdepth[base + z], d0), dstep));
+                fb = fminf(fmaxf(fb, 0.f), (float)(DC - 1));
+                bin[z] = (int)fb;
+                dw[z] = fbbev_plane_sample(pred_depth + (bn * DC + bin[z]) * (long long)(H0 * W0), H0, W0, rx[z], ry[z]);
+                ddw[z] = 0.f;
+            }
+            fbbev_v2f o_next = op[0];
+            int lp = 0;
+            for (int l = 0; l < L; ++l) {
+                const int sh = (int)spatial_shapes[2 * l], sw = (int)spatial_shapes[2 * l + 1];
+                const unsigned lane_off = (unsigned)(((bn * S + level_start[l]) * row_stride + m * head_off_m) * 4);
+                for (int p = 0; p < P; ++p) row[p] = attn[wa0 + (long long)(lp + p) * wa_step];   // the level's weights
+                for (int p = 0; p < P; ++p, ++lp) {
+                    const fbbev_v2f o = o_next;
+                    o_next = op[(long long)(lp + 1 < LP ? lp + 1 : lp) * wo_step];
+                    const int z = p % Za;
+                    const float loc_w = rx[z] + __fdiv_rn(o[0], (float)sw);
+                    const float loc_h = ry[z] + __fdiv_rn(o[1], (float)sh);
+                    const float a = row[p];
+                    const float weight = a * dw[z];
+                    const float h_im = loc_h * sh - 0.5f, w_im = loc_w * sw - 0.5f;
+                    float ra = 0.f, rgx = 0.f, rgy = 0.f;
+                    if (h_im > -1.f && w_im > -1.f && h_im < (float)sh && w_im < (float)sw) {
+                        const fbbev_bilinear s = fbbev_bilinear_setup(h_im, w_im, sh, sw, row_stride);
+                        float dot, gx, gy;
+                        fbbev_unit_sample_grad<DH>(value, lane_off, s, chunk_stride, g, dot, gx, gy);
+                        ra = dw[z] * dot; rgx = weight * gx; rgy = weight * gy;
+                        ddw[z] += a * dot;
+                    }
+                    row[P + 3 * p] = ra; row[P + 3 * p + 1] = rgx; row[P + 3 * p + 2] = rgy;
+                }
+                // one add per camera that sees the query, in camera order (the lane is the unit's only writer): all loads
+                // of the level first, then the adds (a zero is not added: the sample was outside the image)
+                {
+                    // straight-line code (no branch between the loads and the stores: with conditional stores the compiler
+                    // waited for EVERY earlier store before each next one -- 16 serialised round trips per level): slots
+                    // beyond P repeat slot P-1 (same address, same old value, same sum: an idempotent second store), and
+                    // a sample outside the image adds 0 (x + 0 == x)
+                    float ca[FBBEV_DA_BWD_MAXP];
+                    fbbev_v2f co[FBBEV_DA_BWD_MAXP];
+                    long long ia[FBBEV_DA_BWD_MAXP], io[FBBEV_DA_BWD_MAXP];
+#pragma unroll
+                    for (int p = 0; p < FBBEV_DA_BWD_MAXP; ++p) {
+                        const int pp = p < P ? p : P - 1;
+                        ia[p] = wa0 + (long long)(lp - P + pp) * wa_step;
+                        io[p] = (wo0 + (long long)(lp - P + pp) * wo_step) * 2;
+                        ca[p] = grad_attn[ia[p]];
+                        co[p] = *reinterpret_cast<const fbbev_v2f*>(grad_offsets + io[p]);
+                    }
+#pragma unroll
+                    for (int p = 0; p < FBBEV_DA_BWD_MAXP; ++p) {
+                        const int pp = p < P ? p : P - 1;
+                        ca[p] += row[P + 3 * pp];
+                        co[p][0] += row[P + 3 * pp + 1];
+                        co[p][1] += row[P + 3 * pp + 2];
+                    }
+#pragma unroll
+                    for (int p = 0; p < FBBEV_DA_BWD_MAXP; ++p) {
+                        grad_attn[ia[p]] = ca[p];
+                        *reinterpret_cast<fbbev_v2f*>(grad_offsets + io[p]) = co[p];
+                    }
+                }
+            }
+            // dw[z] -> the four corners of the query's bin plane (fbbev_plane_sample).  The M heads of a query are M adjacent
+            // lanes with the SAME camera set, anchors, bins and corners: their ddw are summed across the lanes first and one
+            // lane issues the atomics -- M x fewer of them (the scattered fp32 global atomics were 0.36 of this kernel's
+            // 0.50 ms at the shipped shape: 8.7 M of them)
+            const bool reduce_heads = M <= 64 && (M & (M - 1)) == 0 && (64 % M) == 0;
+            for (int z = 0; z < Za; ++z) {
+                float dsum = ddw[z];
+                if (reduce_heads)
+                    for (int o = 1; o < M; o <<= 1) dsum += __shfl_xor(dsum, o, 64);
+                if (reduce_heads && m != 0) continue;
+                const float h_im = ry[z] * H0 - 0.5f, w_im = rx[z] * W0 - 0.5f;
+                if (!(h_im > -1.f && w_im > -1.f && h_im < (float)H0 && w_im < (float)W0) || dsum == 0.f) continue;
+                const fbbev_bilinear s = fbbev_bilinear_setup(h_im, w_im, H0, W0, 1);
+                float* gd = grad_pred_depth + (bn * DC + bin[z]) * (long long)(H0 * W0);
+                if (s.o1 >= 0) fbbev_atomic_add_f32(gd + s.o1, s.w1 * dsum);
+                if (s.o2 >= 0) fbbev_atomic_add_f32(gd + s.o2, s.w2 * dsum);
+                if (s.o3 >= 0) fbbev_atomic_add_f32(gd + s.o3, s.w3 * dsum);
+                if (s.o4 >= 0) fbbev_atomic_add_f32(gd + s.o4, s.w4 * dsum);
+            }
+        }
+    }
+}
+
+// (B) value-gradient scatter of one token REGION [tok0, tok1) = levels [lvl0, lvl1) (a band of rows when one level is split
+// over several launches).  Workgroup = (sample b, head m, chunk of consecutive BEV queries); a lane = one query the camera
+// sees (compacted per camera); plane = (tok1 - tok0) x HS 64-bit fixed-point words in LDS; part[b][m][chunk][cam][S*HS] gets
+// the region's slice.  No value loads, no shuffles, no global atomics.
+template <int NT, int DH>
+__global__ void __launch_bounds__(NT)
+k_da_cross_attn_bwd_scatter(const int64_t* __restrict__ spatial_shapes, const int64_t* __restrict__ level_start,
+                            const float* __restrict__ pred_depth, const float* __restrict__ ref_cam,
+                            const unsigned char* __restrict__ mask, const float* __restrict__ qdepth,
+                            const float* __restrict__ offsets, const float* __restrict__ attn,
+                            const float* __restrict__ grad_slots, int B, int Ncam, int S, int M, int L, int Q, int P, int Za,
+                            int DC, float d0, float dstep, int head_minor, int HS, int n_chunks, int q_per_chunk, int lvl0,
+                            int lvl1, int tok0, int tok1, float* __restrict__ part) {
+    // [tok1 - tok0][HS] fixed point, skewed by one word every 8 tokens: a token pitch of HS 64-bit words (24 banks at HS = 12)
+    // repeats its bank every 8 tokens; the skew breaks the period (SQ_LDS_BANK_CONFLICT was 2x the busy cycles) for 1 % more LDS
+    long long* plane = reinterpret_cast<long long*>(fbbev_dyn_lds_f32());
+    const int plane_n = (tok1 - tok0) * HS, plane_w = FBBEV_DA_PLANE_WORDS(tok1 - tok0, HS);
+    unsigned short* hits = reinterpret_cast<unsigned short*>(plane + plane_w);   // [q_per_chunk] chunk-relative queries the camera sees
     int* n_hits = reinterpret_cast<int*>(hits + ((q_per_chunk + 1) & ~1));       // [1]
-    float* red = reinterpret_cast<float*>(n_hits + 1);         // [NT/64] block maximum
-    float* stage = red + NT / 64;                              // [NT/4 groups][L*P][3]: a unit's weight / offset gradients of one camera
+    float* red = reinterpret_cast<float*>(n_hits + 1);                           // [NT/64] block maximum
     const int lane = threadIdx.x & 63;
-    const int k = threadIdx.x & 3;                             // channel chunk / anchor lane of the group
-    const int gidx = threadIdx.x >> 2;                         // group in the workgroup: 0..NT/4-1
-    const int gbase = lane & ~3;                               // first lane of the group in its wave
     const int chunk = blockIdx.x % n_chunks;
     const int m = (blockIdx.x / n_chunks) % M;
     const int b = blockIdx.x / (n_chunks * M);
     const int q0 = chunk * q_per_chunk, q1 = (q0 + q_per_chunk < Q) ? q0 + q_per_chunk : Q;
     const int nq = q1 - q0;
-    const int row_stride = M * HS;
     const int H0 = (int)spatial_shapes[0], W0 = (int)spatial_shapes[1];
-    const int lane_off = (head_minor & 4) ? k * (M * 4) + m * 4 : m * HS + 4 * k;   // this lane's 4 channels in a token row
-    const bool chunk_live = 4 * k < Dh;                        // HS may hold a chunk of pure padding (Dh = 8, HS = 12)
-    for (int i = threadIdx.x; i < plane_n; i += NT) plane[i] = 0ll;
-    // scale of the fixed-point plane: sc = 2^(30 - ex) with max|grad_slots| < 2^ex over the chunk's units
+    const int LP = L * P;
+    for (int i = threadIdx.x; i < plane_w; i += NT) plane[i] = 0ll;
+    // scale of the fixed-point plane: sc = 2^(30 - ex) with max|grad_slots| < 2^ex over the chunk's units (see above)
     float gmax = 0.f;
     bool finite = true;
-    for (int i = threadIdx.x; i < nq * Dh; i += NT) {
-        const int qi = i / Dh, c = i - qi * Dh;
-        const float v = fabsf(grad_slots[(((long long)b * Q + q0 + qi) * M + m) * Dh + c]);
-        finite = finite && (v < __builtin_inff());             // false for inf and NaN
+    for (int i = threadIdx.x; i < nq * DH; i += NT) {
+        const int qi = i / DH, c = i - qi * DH;
+        const float v = fabsf(grad_slots[(((long long)b * Q + q0 + qi) * M + m) * DH + c]);
+        finite = finite && (v < __builtin_inff());
         gmax = fmaxf(gmax, v);
     }
     if (!finite) gmax = __builtin_inff();
@@ -439,8 +617,8 @@ k_da_cross_attn_bwd_tile(const float* __restrict__ value, const int64_t* __restr
     if (!poisoned && gmax > 0.f) {
         unsigned int gb;
         __builtin_memcpy(&gb, &gmax, 4);
-        int ex = (int)((gb >> 23) & 255u) - 126;               // gmax < 2^ex
-        if (ex < -90) ex = -90;                                 // tiny gradients: keep both scales normal numbers
+        int ex = (int)((gb >> 23) & 255u) - 126;
+        if (ex < -90) ex = -90;
         const unsigned int sb = (unsigned int)(127 + 30 - ex) << 23, ib = (unsigned int)(127 - 30 + ex) << 23;
         __builtin_memcpy(&sc, &sb, 4);
         __builtin_memcpy(&inv_sc, &ib, 4);
@@ -449,7 +627,7 @@ k_da_cross_attn_bwd_tile(const float* __restrict__ value, const int64_t* __restr
         const long long bn = (long long)b * Ncam + cam;
         if (threadIdx.x == 0) *n_hits = 0;
         __syncthreads();
-        for (int i0 = 0; i0 < nq; i0 += NT) {                 // ascending query order inside a wave's 64, waves in any order
+        for (int i0 = 0; i0 < nq; i0 += NT) {
             const int qi = i0 + threadIdx.x;
             bool hit = false;
             if (qi < nq) {
@@ -464,148 +642,83 @@ k_da_cross_attn_bwd_tile(const float* __restrict__ value, const int64_t* __restr
         }
         __syncthreads();
         const int nh = *n_hits;
-        for (int it = 0; it < nh; it += NT / 4) {
-            const bool active = it + gidx < nh;
-            if (__ballot(active ? 1 : 0) == 0ull) continue;
-            const int q = q0 + (active ? (int)hits[it + gidx] : 0);
+        for (int it0 = 0; it0 < nh; it0 += NT) {
+            // lane -> hit: a stride of 37 (41 when 37 divides the block) inside each block of NT hits.  Neighbouring BEV
+            // queries sample the same camera tokens: with consecutive hits on consecutive lanes up to 16 lanes of one
+            // ds_add_u64 share an ADDRESS and serialise (1.2 instead of 22 lane-adds per ns, profiles/r02_micro_lds_atomics.jsonl)
+            const int nblk = nh - it0 < NT ? nh - it0 : NT;
+            if ((int)threadIdx.x >= nblk) continue;
+            const int it = it0 + (int)(((unsigned)threadIdx.x * (nblk % 37 == 0 ? 41u : 37u)) % (unsigned)nblk);
+            const int q = q0 + (int)hits[it];
             const long long bq = (long long)b * Q + q;
             const long long u = bq * M + m;
             const long long base = (((long long)cam * B + b) * Q + q) * Za;
-            // number of cameras that see the query: lane k tests cameras k, k+4, ...
             int count = 0;
-            for (int c2 = k; c2 < Ncam; c2 += 4) {
+            for (int c2 = 0; c2 < Ncam; ++c2) {
                 const long long b2 = (((long long)c2 * B + b) * Q + q) * Za;
                 bool h2 = false;
                 for (int z = 0; z < Za; ++z) h2 = h2 || (mask[b2 + z] != 0);
                 count += h2 ? 1 : 0;
             }
-            count += __shfl_xor(count, 1, 64);
-            count += __shfl_xor(count, 2, 64);
             const float inv = (float)(count > 1 ? count : 1);
-            float g[4];
+            float gs[DH];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) g[e] = (active && 4 * k + e < Dh) ? grad_slots[u * Dh + 4 * k + e] / inv : 0.f;
-            // this lane's anchors: z = k and z = k + 4
-            float rxo[2], ryo[2], dwo[2], ddwo[2];
-            int bino[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int z = k + 4 * h;
-                rxo[h] = ryo[h] = dwo[h] = ddwo[h] = 0.f;
-                bino[h] = 0;
-                if (active && z < Za) {
-                    rxo[h] = ref_cam[(base + z) * 2];
-                    ryo[h] = ref_cam[(base + z) * 2 + 1];
-                    float fb = floorf(__fdiv_rn(__fsub_rn(qdepth[base + z], d0), dstep));
-                    fb = fminf(fmaxf(fb, 0.f), (float)(DC - 1));
-                    bino[h] = (int)fb;
-                    dwo[h] = fbbev_plane_sample(pred_depth + (bn * DC + bino[h]) * (long long)(H0 * W0), H0, W0, rxo[h], ryo[h]);
-                }
+            for (int c = 0; c < DH; ++c) gs[c] = grad_slots[u * DH + c] / inv * sc;          // sc is a power of two: exact
+            float rx[FBBEV_DA_MAX_ZA], ry[FBBEV_DA_MAX_ZA], dw[FBBEV_DA_MAX_ZA];
+            for (int z = 0; z < Za; ++z) {
+                rx[z] = ref_cam[(base + z) * 2];
+                ry[z] = ref_cam[(base + z) * 2 + 1];
+                float fb = floorf(__fdiv_rn(__fsub_rn(qdepth[base + z], d0), dstep));
+                fb = fminf(fmaxf(fb, 0.f), (float)(DC - 1));
+                dw[z] = fbbev_plane_sample(pred_depth + (bn * DC + (int)fb) * (long long)(H0 * W0), H0, W0, rx[z], ry[z]);
             }
-            // sample lp of the unit: (B,Q,M,L,P[,2]) -> u*LP + lp, head-minor (B,Q,L,P,M[,2]) -> (bq*LP + lp)*M + m.  The next
-            // sample's offsets / weight are requested before this sample's value loads (one exposed latency per sample).
-            const int LP = L * P;
             const long long wo0 = (head_minor & 1) ? bq * LP * M + m : u * LP, wa0 = (head_minor & 2) ? bq * LP * M + m : u * LP;
             const int wo_step = (head_minor & 1) ? M : 1, wa_step = (head_minor & 2) ? M : 1;
-            fbbev_v2f o_next = *reinterpret_cast<const fbbev_v2f*>(offsets + wo0 * 2);
-            float a_next = attn[wa0];
-            int lp = 0;
-            for (int l = 0; l < L; ++l) {
+            const int lp0 = lvl0 * P, lp1 = lvl1 * P;
+            fbbev_v2f o_next = *reinterpret_cast<const fbbev_v2f*>(offsets + (wo0 + (long long)lp0 * wo_step) * 2);
+            float a_next = attn[wa0 + (long long)lp0 * wa_step];
+            int lp = lp0;
+            for (int l = lvl0; l < lvl1; ++l) {
                 const int sh = (int)spatial_shapes[2 * l], sw = (int)spatial_shapes[2 * l + 1];
                 const int ls = (int)level_start[l];
-                const float* vp = value + (bn * S + ls) * row_stride + lane_off;
-                long long* pl = plane + ls * HS + 4 * k;
                 for (int p = 0; p < P; ++p, ++lp) {
-                    const int nlp = lp + 1 < LP ? lp + 1 : lp;
+                    const int nlp = lp + 1 < lp1 ? lp + 1 : lp;
                     const fbbev_v2f o = o_next;
-                    const float a = active ? a_next : 0.f;
+                    const float a = a_next;
                     o_next = *reinterpret_cast<const fbbev_v2f*>(offsets + (wo0 + (long long)nlp * wo_step) * 2);
                     a_next = attn[wa0 + (long long)nlp * wa_step];
                     const int z = p % Za;
-                    const int src = gbase | (z & 3);
-                    const float rxz = __shfl(z < 4 ? rxo[0] : rxo[1], src, 64);
-                    const float ryz = __shfl(z < 4 ? ryo[0] : ryo[1], src, 64);
-                    const float dwz = __shfl(z < 4 ? dwo[0] : dwo[1], src, 64);
-                    float h_im = -2.f, w_im = -2.f;
-                    if (active) {
-                        const float loc_w = rxz + __fdiv_rn(o[0], (float)sw);
-                        const float loc_h = ryz + __fdiv_rn(o[1], (float)sh);
-                        h_im = loc_h * sh - 0.5f;
-                        w_im = loc_w * sw - 0.5f;
-                    }
-                    const bool inr = active && h_im > -1.f && w_im > -1.f && h_im < (float)sh && w_im < (float)sw;
-                    const float weight = a * dwz;
-                    float dot = 0.f, gx = 0.f, gy = 0.f;
-                    if (inr && chunk_live) {
-                        const fbbev_bilinear s = fbbev_bilinear_setup(h_im, w_im, sh, sw, 1);      // o1..o4 = token indices
-                        const fbbev_v4f zero = {0.f, 0.f, 0.f, 0.f};
-                        const bool k1 = s.o1 >= 0, k2 = s.o2 >= 0, k3 = s.o3 >= 0, k4 = s.o4 >= 0;
-                        fbbev_v4f v1 = *reinterpret_cast<const fbbev_v4f*>(vp + (long long)(k1 ? s.o1 : 0) * row_stride);
-                        fbbev_v4f v2 = *reinterpret_cast<const fbbev_v4f*>(vp + (long long)(k2 ? s.o2 : 0) * row_stride);
-                        fbbev_v4f v3 = *reinterpret_cast<const fbbev_v4f*>(vp + (long long)(k3 ? s.o3 : 0) * row_stride);
-                        fbbev_v4f v4 = *reinterpret_cast<const fbbev_v4f*>(vp + (long long)(k4 ? s.o4 : 0) * row_stride);
-                        v1 = k1 ? v1 : zero; v2 = k2 ? v2 : zero; v3 = k3 ? v3 : zero; v4 = k4 ? v4 : zero;
+                    const float loc_w = rx[z] + __fdiv_rn(o[0], (float)sw);
+                    const float loc_h = ry[z] + __fdiv_rn(o[1], (float)sh);
+                    const float h_im = loc_h * sh - 0.5f, w_im = loc_w * sw - 0.5f;
+                    if (!(h_im > -1.f && w_im > -1.f && h_im < (float)sh && w_im < (float)sw)) continue;
+                    const float weight = a * dw[z];
+                    const fbbev_bilinear s = fbbev_bilinear_setup(h_im, w_im, sh, sw, 1);          // o1..o4 = token indices of the level
+                    const int t1 = ls + s.o1 - tok0, t2 = ls + s.o2 - tok0, t3 = ls + s.o3 - tok0, t4 = ls + s.o4 - tok0;
+                    const int span = tok1 - tok0;
+                    const bool k1 = s.o1 >= 0 && t1 >= 0 && t1 < span, k2 = s.o2 >= 0 && t2 >= 0 && t2 < span;
+                    const bool k3 = s.o3 >= 0 && t3 >= 0 && t3 < span, k4 = s.o4 >= 0 && t4 >= 0 && t4 < span;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float tgv = g[e] * weight * sc;                 // sc is a power of two: exact
-                            const bool ce = 4 * k + e < Dh;                       // padding channels stay out of the atomics
-                            if (k1 && ce) fbbev_lds_atomic_add_i64(pl + s.o1 * HS + e, (long long)__float2int_rn(s.w1 * tgv));
-                            if (k2 && ce) fbbev_lds_atomic_add_i64(pl + s.o2 * HS + e, (long long)__float2int_rn(s.w2 * tgv));
-                            if (k3 && ce) fbbev_lds_atomic_add_i64(pl + s.o3 * HS + e, (long long)__float2int_rn(s.w3 * tgv));
-                            if (k4 && ce) fbbev_lds_atomic_add_i64(pl + s.o4 * HS + e, (long long)__float2int_rn(s.w4 * tgv));
-                            dot += g[e] * (s.w1 * v1[e] + s.w2 * v2[e] + s.w3 * v3[e] + s.w4 * v4[e]);
-                            gy += g[e] * (-s.hw * v1[e] - s.lw * v2[e] + s.hw * v3[e] + s.lw * v4[e]);
-                            gx += g[e] * (-s.hh * v1[e] + s.hh * v2[e] - s.lh * v3[e] + s.lh * v4[e]);
-                        }
+                    for (int c = 0; c < DH; ++c) {
+                        // same product order as the other kernels: w_corner * (g * weight)
+                        const float tgv = gs[c] * weight;
+                        if (k1) fbbev_lds_atomic_add_i64(plane + FBBEV_DA_PLANE_IDX(t1, HS) + c, (long long)__float2int_rn(s.w1 * tgv));
+                        if (k2) fbbev_lds_atomic_add_i64(plane + FBBEV_DA_PLANE_IDX(t2, HS) + c, (long long)__float2int_rn(s.w2 * tgv));
+                        if (k3) fbbev_lds_atomic_add_i64(plane + FBBEV_DA_PLANE_IDX(t3, HS) + c, (long long)__float2int_rn(s.w3 * tgv));
+                        if (k4) fbbev_lds_atomic_add_i64(plane + FBBEV_DA_PLANE_IDX(t4, HS) + c, (long long)__float2int_rn(s.w4 * tgv));
                     }
-                    dot += __shfl_xor(dot, 1, 64); dot += __shfl_xor(dot, 2, 64);
-                    gx += __shfl_xor(gx, 1, 64);   gx += __shfl_xor(gx, 2, 64);
-                    gy += __shfl_xor(gy, 1, 64);   gy += __shfl_xor(gy, 2, 64);
-                    // the unit's weight / offset gradients of this camera: parked in LDS, added to global memory after the
-                    // sample loop (a read-modify-write here would put a second global round trip into every sample)
-                    if (k < 3) stage[(gidx * LP + lp) * 3 + k] = !inr ? 0.f : (k == 0 ? dwz * dot : (k == 1 ? weight * gx : weight * gy));
-                    if (inr && k == (z & 3)) ddwo[z >> 2] += a * dot;
                 }
-            }
-            // one add per camera that sees the query, in camera order: this workgroup is the unit's only writer and its
-            // camera phases are separated by barriers.  The group's 4 lanes share the L*P samples; (a zero is not added:
-            // the sample was outside the image)
-            (void)__ballot(1);       // the wave's LDS writes above precede these reads (program order of one wave; this
-                                     // makes the CPU emulator's lanes meet here as well)
-            if (active) {
-                for (int j = k; j < LP; j += 4) {
-                    const float* st = stage + (gidx * LP + j) * 3;
-                    const long long wo = wo0 + (long long)j * wo_step, wa = wa0 + (long long)j * wa_step;
-                    const float sa = st[0], sx = st[1], sy = st[2];
-                    if (sa != 0.f) grad_attn[wa] += sa;
-                    if (sx != 0.f) grad_offsets[wo * 2] += sx;
-                    if (sy != 0.f) grad_offsets[wo * 2 + 1] += sy;
-                }
-            }
-            // dw[z] -> the four corners of the query's bin plane (fbbev_plane_sample), each anchor by its own lane
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int z = k + 4 * h;
-                if (!active || z >= Za || ddwo[h] == 0.f) continue;
-                const float h_im = ryo[h] * H0 - 0.5f, w_im = rxo[h] * W0 - 0.5f;
-                if (!(h_im > -1.f && w_im > -1.f && h_im < (float)H0 && w_im < (float)W0)) continue;
-                const fbbev_bilinear s = fbbev_bilinear_setup(h_im, w_im, H0, W0, 1);
-                float* gd = grad_pred_depth + (bn * DC + bino[h]) * (long long)(H0 * W0);
-                if (s.o1 >= 0) fbbev_atomic_add_f32(gd + s.o1, s.w1 * ddwo[h]);
-                if (s.o2 >= 0) fbbev_atomic_add_f32(gd + s.o2, s.w2 * ddwo[h]);
-                if (s.o3 >= 0) fbbev_atomic_add_f32(gd + s.o3, s.w3 * ddwo[h]);
-                if (s.o4 >= 0) fbbev_atomic_add_f32(gd + s.o4, s.w4 * ddwo[h]);
             }
         }
         __syncthreads();
-        // the camera's plane -> this workgroup's slice of the partial buffer; cleared for the next camera on the way
-        float* dst = part + ((((long long)b * M + m) * n_chunks + chunk) * Ncam + cam) * (long long)plane_n;
-        for (int i = threadIdx.x * 4; i < plane_n; i += NT * 4) {
+        float* dst = part + ((((long long)b * M + m) * n_chunks + chunk) * Ncam + cam) * (long long)S * HS + (long long)tok0 * HS;
+        for (int i = threadIdx.x * 4; i < plane_n; i += NT * 4) {            // HS % 4 == 0: a group of 4 stays inside one token
+            long long* src = plane + FBBEV_DA_PLANE_IDX(i / HS, HS) + (i % HS);
             fbbev_v4f t;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                t[e] = poisoned ? __builtin_nanf("") : (float)plane[i + e] * inv_sc;      // one rounding (int64 -> fp32)
-                plane[i + e] = 0ll;
+                t[e] = poisoned ? __builtin_nanf("") : (float)src[e] * inv_sc;            // one rounding (int64 -> fp32)
+                src[e] = 0ll;
             }
             *reinterpret_cast<fbbev_v4f*>(dst + i) = t;
         }

@@ -329,14 +329,15 @@ int fbbev_da_cross_attn_bwd(const float* value, const int64_t* spatial_shapes, c
  * aligned; returns 0 bytes when the shape does not fit (64-bit plane + staging > 80 KiB of LDS).  With ws == NULL, too small, or an
  * unsupported shape the call IS fbbev_da_cross_attn_bwd (same results up to the order of the fp32 adds). */
 size_t fbbev_da_cross_attn_bwd_ws_bytes(int B, int Ncam, int S, int M, int Dh, int Q, int head_stride,
-                                        int samples_per_unit /* num_levels * num_points */);
+                                        int num_levels, int num_points, const int32_t* level_hw_host);
 int fbbev_da_cross_attn_bwd_ws(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
                                const float* pred_depth, const float* ref_cam, const uint8_t* mask,
                                const float* qdepth, const float* offsets, const float* attn,
                                const float* grad_slots, int B, int Ncam, int S, int M, int Dh, int L, int Q,
                                int P, int Za, int DC, float d0, float dstep, int head_minor, int head_stride,
                                float* grad_value, float* grad_pred_depth, float* grad_offsets,
-                               float* grad_attn, void* ws, size_t ws_bytes, fbbev_stream_t stream);
+                               float* grad_attn, const int32_t* level_hw_host, void* ws, size_t ws_bytes,
+                               fbbev_stream_t stream);
 
 /* Training backward of the fused lift-splat:  replaces QuickCumsumCuda.backward (bev_pool.py:39-78 --
  * argsort of ranks_feat, mask-built intervals [2 host syncs], the permute().contiguous() of the gradient)

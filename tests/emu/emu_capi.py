@@ -232,7 +232,7 @@ def layernorm(x, weight, bias, eps, residual=None):
 
 
 def da_cross_attn_bwd(value, ss, ls, pred_depth, ref_cam, mask, qdepth, offsets, attn, d0, dstep, grad_slots, head_minor=0,
-                      head_dim=None, lds_planes=False):
+                      head_dim=None, lds_planes=False, level_hw=None):
     Ncam, B, Q, Za = mask.shape
     _, S, M, HS = value.shape
     Dh = HS if head_dim is None else head_dim
@@ -242,11 +242,12 @@ def da_cross_attn_bwd(value, ss, ls, pred_depth, ref_cam, mask, qdepth, offsets,
     args = (p(value), p(ss), p(ls), p(pred_depth), p(ref_cam), p(m8), p(qdepth), p(offsets), p(attn), p(grad_slots), B, Ncam,
             S, M, Dh, L, Q, P, Za, pred_depth.shape[1], d0, dstep, int(head_minor), HS, p(gv), p(gd), p(go), p(ga))
     if lds_planes:
-        need = lib().fbbev_da_cross_attn_bwd_ws_bytes(B, Ncam, S, M, Dh, Q, HS, L * P)
+        arr = _capi._level_hw(level_hw, L)
+        need = lib().fbbev_da_cross_attn_bwd_ws_bytes(B, Ncam, S, M, Dh, Q, HS, L, P, arr)
         assert need > 0
         ws = torch.full((need // 4,), float('nan'))
         gv.fill_(float('nan'))                       # written, not accumulated
-        ok(lib().fbbev_da_cross_attn_bwd_ws(*args, p(ws), need, None))
+        ok(lib().fbbev_da_cross_attn_bwd_ws(*args, arr, p(ws), need, None))
     else:
         ok(lib().fbbev_da_cross_attn_bwd(*args, None))
     return gv, gd, go, ga

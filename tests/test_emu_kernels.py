@@ -503,15 +503,19 @@ def test_fused_da_cross_attention_backward_emulated():
         # value gradient through LDS planes + partial buffer (fbbev_da_cross_attn_bwd_ws): same sums in another order;
         # several query chunks per (sample, head) so that the reduction over chunks is exercised
         import os
-        for chunks, threads in (('1', '256'), ('3', '256'), ('2', '512')):
+        shapes_host = [tuple(int(x) for x in hw) for hw in ss.tolist()]
+        for chunks, threads, tokens in (('1', '256', None), ('3', '256', None), ('2', '512', None),
+                                        ('2', '256', '8')):             # token regions: bands of rows, levels apart
             os.environ['FBBEV_DA_BWD_CHUNKS'] = chunks
             os.environ['FBBEV_DA_BWD_THREADS'] = threads
+            if tokens:
+                os.environ['FBBEV_DA_BWD_TOKENS'] = tokens
             try:
                 for hm, vin in ((0, vp), (4, _interleave(vp)), (5, _interleave(vp))):
                     o_in = f32(offsets).permute(0, 1, 3, 4, 2, 5).contiguous() if hm & 1 else f32(offsets)
                     gv4, gd4, go4, ga4 = E.da_cross_attn_bwd(vin, ss, ls, f32(pred4), f32(ref_cam), mask, f32(qdepth), o_in,
                                                              f32(attn), d0, dstep, f32(g), head_minor=hm, head_dim=Dh,
-                                                             lds_planes=True)
+                                                             lds_planes=True, level_hw=shapes_host)
                     if hm & 1:
                         go4 = go4.permute(0, 1, 4, 2, 3, 5)
                     gv4 = _deinterleave(gv4) if hm & 4 else gv4
@@ -521,6 +525,7 @@ def test_fused_da_cross_attention_backward_emulated():
                     assert torch.allclose(go4, go0, rtol=1e-5, atol=1e-6) and torch.allclose(ga4, ga0, rtol=1e-5, atol=1e-6)
             finally:
                 del os.environ['FBBEV_DA_BWD_CHUNKS'], os.environ['FBBEV_DA_BWD_THREADS']
+                os.environ.pop('FBBEV_DA_BWD_TOKENS', None)
 
 
 @pytest.mark.parametrize('B,T1,C,Cout,N', [(1, 3, 16, 16, 64), (2, 2, 32, 16, 100), (1, 4, 16, 32, 17)])

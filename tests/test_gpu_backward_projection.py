@@ -162,7 +162,8 @@ def test_fused_backward_kernels_within_a_bound_of_fp64_autograd(dev, lds_planes)
     from da_cases import da_case
     for seed, kw in ((5, dict(B=1, Q=29, E=16, M=4)),
                      (6, dict(B=2, Q=17, E=40, M=4, shapes=((4, 6), (2, 3)))),
-                     (7, dict(B=2, Q=333, E=80, M=8, shapes=((16, 44),), DC=20))):      # the shipped head layout
+                     (7, dict(B=2, Q=333, E=80, M=8, shapes=((16, 44),), DC=20)),       # the shipped head layout
+                     (8, dict(B=1, Q=257, E=80, M=8, shapes=((16, 44), (32, 88), (8, 22), (4, 11)), DC=20))):   # configs[2] pyramid: 6 token regions
         args, exp, leaves = da_case(seed, grad=True, **kw)
         g = torch.randn(exp.shape, generator=torch.Generator().manual_seed(seed), dtype=torch.float64)
         wrt = [leaves['key'], leaves['pred']] + [leaves['Pm'][k] for k in sorted(leaves['Pm']) if 'output_proj' not in k]
@@ -177,7 +178,8 @@ def test_fused_backward_kernels_within_a_bound_of_fp64_autograd(dev, lds_planes)
         a = [t(vp), t(ss), t(ls), t(f32(pred4)), t(f32(ref_cam)), t(mask), t(f32(qdepth)), t(f32(offsets)), t(f32(attn)),
              t(f32(g)), d0, dstep, 0]
         gv, gd, go, ga = (torch.zeros_like(x) for x in (a[0], a[3], a[7], a[8]))
-        _capi.da_cross_attn_bwd(*a, gv, gd, go, ga, head_dim=Dh, lds_planes=lds_planes)
+        _capi.da_cross_attn_bwd(*a, gv, gd, go, ga, head_dim=Dh, lds_planes=lds_planes,
+                                level_hw=[tuple(int(x) for x in hw) for hw in ss.tolist()])
         mine = torch.autograd.grad([value, pred4, offsets, attn], wrt,
                                    grad_outputs=[gv[..., :Dh].cpu().double(), gd.cpu().double(), go.cpu().double(), ga.cpu().double()],
                                    retain_graph=True, allow_unused=True)
@@ -217,7 +219,7 @@ def test_lds_plane_backward_equals_atomic_backward_and_is_reproducible(dev):
         _capi.da_cross_attn_bwd(*args, gv, gd, go, ga, head_dim=Dh, lds_planes=lds)
         torch.cuda.synchronize()
         return gv, gd, go, ga
-    assert _capi.lib().fbbev_da_cross_attn_bwd_ws_bytes(B, Ncam, S_, M, Dh, Q, HS, P) > 0
+    assert _capi.da_cross_attn_bwd_ws_bytes(B, Ncam, S_, M, Dh, Q, HS, 1, P) > 0
     a, b, c = run(True), run(True), run(False)
     assert torch.equal(a[0], b[0])                                      # reproducible value gradient
     assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])          # and the unit-owned ones

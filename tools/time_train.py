@@ -11,23 +11,32 @@ from fb_bev_amd.fb_view_transform import FBViewTransform
 def main():
     name = sys.argv[1] if len(sys.argv) > 1 else 'REF'
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    levels = int(sys.argv[3]) if len(sys.argv) > 3 else 1         # 4 = the BASELINE configs[2] pyramid
     dev = torch.device('cuda:0')
     pc = S.CONFIGS[name]
     X, Y, Z = pc.grid_xyz
     gcb = {'x': pc.grid_config['x'], 'y': pc.grid_config['y'], 'z': [-1, 5.4, 1.6]}
     cfg = configs.fbocc_r50(bev_h=Y, bev_w=X, numC_Trans=pc.channels, input_size=pc.input_size, grid_config=pc.grid_config,
-                            grid_config_bevformer=gcb, depth_bound=tuple(pc.grid_config['depth']), downsample=pc.downsample)
+                            grid_config_bevformer=gcb, depth_bound=tuple(pc.grid_config['depth']), downsample=pc.downsample,
+                            num_levels=levels)
     m = FBViewTransform(cfg['forward_projection'], cfg['backward_projection']).to(dev).train()
     cam = [t.to(dev) for t in S.camera_rig(pc, B, seed=0, bda_aug=True)]
     depth, ctx = S.depth_and_context(pc, B, seed=0)
     depth, ctx = depth.to(dev).requires_grad_(), ctx.to(dev).requires_grad_()
     w = torch.randn(B, pc.channels, Y, X, Z, device=dev)
+    mlvl = None
+    if levels > 1:
+        H, W = ctx.shape[-2:]
+        g = torch.Generator().manual_seed(5)
+        shapes = [(H, W), (2 * H, 2 * W), (H // 2, W // 2), (H // 4, W // 4)][:levels]
+        mlvl = [torch.randn(B, pc.n_cams, pc.channels, h, w_, generator=g).to(dev) for h, w_ in shapes]
+        mlvl[0] = ctx
 
     def step():
         for p in m.parameters():
             p.grad = None
         depth.grad = ctx.grad = None
-        out = m(cam, ctx, depth)
+        out = m(cam, ctx, depth, mlvl_feats=mlvl)
         loss = (out * w).sum()
         return out, loss
 
@@ -45,7 +54,7 @@ def main():
         out, loss = step(); loss.backward()
     torch.cuda.synchronize()
     t_fb = (time.perf_counter() - t0) / n
-    print(json.dumps({'config': name, 'B': B, 'ms_forward_train_mode': t_f * 1e3, 'ms_forward_backward': t_fb * 1e3,
+    print(json.dumps({'config': name, 'B': B, 'levels': levels, 'ms_forward_train_mode': t_f * 1e3, 'ms_forward_backward': t_fb * 1e3,
                       'samples_per_s_train_step': B / t_fb}))
 
 
