@@ -321,13 +321,19 @@ int fbbev_da_cross_attn_bwd(const float* value, const int64_t* spatial_shapes, c
                             int head_stride, float* grad_value, float* grad_pred_depth, float* grad_offsets,
                             float* grad_attn, fbbev_stream_t stream);
 
-/* fbbev_da_cross_attn_bwd with the value gradient accumulated in LDS planes instead of global atomics: a workgroup
- * owns (sample, head, chunk of BEV queries), keeps the head's (S x head_stride) gradient plane of one camera at a
- * time in LDS and writes it to its slice of `ws`; a second launch sums the slices into grad_value (written, not
- * accumulated -- no pre-zeroing needed for it; grad_pred_depth / grad_offsets / grad_attn are accumulated as in
- * fbbev_da_cross_attn_bwd and must be pre-zeroed).  ws: fbbev_da_cross_attn_bwd_ws_bytes(...) bytes, 16-byte
- * aligned; returns 0 bytes when the shape does not fit (64-bit plane + staging > 80 KiB of LDS).  With ws == NULL, too small, or an
- * unsupported shape the call IS fbbev_da_cross_attn_bwd (same results up to the order of the fp32 adds). */
+/* fbbev_da_cross_attn_bwd with the value gradient accumulated in LDS planes instead of global atomics, three launches:
+ * (A) the unit-owned gradients (attention weights, sampling offsets, depth distribution) by a kernel with the forward's
+ * lane mapping; (B) the value gradient: a workgroup owns (sample, head, chunk of BEV queries), keeps the head's gradient
+ * plane of one camera at a time in LDS as 64-bit fixed point (bit-reproducible) and writes it to its slice of `ws` -- one
+ * launch per TOKEN REGION when the pyramid's plane does not fit LDS (whole levels, or row bands of a large level);
+ * (C) the slices are summed into grad_value in fixed order (written, not accumulated -- no pre-zeroing needed for it;
+ * grad_pred_depth / grad_offsets / grad_attn are accumulated as in fbbev_da_cross_attn_bwd and must be pre-zeroed).
+ * level_hw_host: HOST array of num_levels (h, w) pairs -- what spatial_shapes holds on the device -- so that the regions
+ * are planned without a device read; NULL plans only the case where the whole pyramid fits one plane (<= 717 tokens at
+ * head_stride 12).  ws: fbbev_da_cross_attn_bwd_ws_bytes(...) bytes, 16-byte aligned; 0 bytes = the plan rejects the shape
+ * (head dims other than 4 / 8 / 10 / 16, more than 8 points per level, head_stride not a multiple of 4 or > 16).  With
+ * ws == NULL, too small, or a rejected shape the call IS fbbev_da_cross_attn_bwd (same results up to the order of the
+ * fp32 adds). */
 size_t fbbev_da_cross_attn_bwd_ws_bytes(int B, int Ncam, int S, int M, int Dh, int Q, int head_stride,
                                         int num_levels, int num_points, const int32_t* level_hw_host);
 int fbbev_da_cross_attn_bwd_ws(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
