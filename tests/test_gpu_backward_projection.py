@@ -152,6 +152,35 @@ def test_16bit_camera_tokens_vs_fp32_tokens(dev, dt, tol):
     assert 0 < err < tol, err
 
 
+def test_graphed_replay_equals_eager_for_new_inputs(dev):
+    """fb_bev_amd.graphed.Graphed: the whole forward + backward projection captured once and replayed with OTHER camera
+    rigs / features / depth than the captured example -- equal to the eager call bit for bit (the index tensors are
+    rebuilt on the device inside the graph)."""
+    from fb_bev_amd import configs, synthetic as S
+    from fb_bev_amd.fb_view_transform import FBViewTransform
+    from fb_bev_amd.graphed import Graphed
+    pc = S.CONFIGS['REF']
+    X, Y, Z = pc.grid_xyz
+    gcb = {'x': pc.grid_config['x'], 'y': pc.grid_config['y'], 'z': [-1, 5.4, 1.6]}
+    cfg = configs.fbocc_r50(bev_h=Y, bev_w=X, numC_Trans=pc.channels, input_size=pc.input_size, grid_config=pc.grid_config,
+                            grid_config_bevformer=gcb, depth_bound=tuple(pc.grid_config['depth']), downsample=pc.downsample)
+    torch.manual_seed(0)
+    m = FBViewTransform(cfg['forward_projection'], cfg['backward_projection']).to(dev).eval()
+
+    def inputs(seed):
+        cam = [t.to(dev) for t in S.camera_rig(pc, 1, seed=seed, bda_aug=True)]
+        depth, ctx = (t.to(dev) for t in S.depth_and_context(pc, 1, seed=seed))
+        return cam, ctx, depth
+    g = Graphed(m, *inputs(0))
+    for seed in (0, 3, 4):
+        cam, ctx, depth = inputs(seed)
+        with torch.no_grad():
+            eager = m(cam, ctx, depth)
+        assert torch.equal(g(cam, ctx, depth), eager), seed
+    with pytest.raises(ValueError):
+        g(cam, ctx[:, :3], depth)
+
+
 @pytest.mark.parametrize('lds_planes', [False, True])
 def test_fused_backward_kernels_within_a_bound_of_fp64_autograd(dev, lds_planes):
     """A BOUND, not a statistical pass (the module-level test above tolerates 2 % kinked entries): the four gradients of

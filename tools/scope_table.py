@@ -87,6 +87,10 @@ def s3(name, B, levels, n):
     with torch.no_grad():
         row(f'S3 forward + backward projection + re-add ({levels} attention level{"s" if levels > 1 else ""})', name, B,
             pct(lambda: m(cam, ctx, depth, mlvl_feats=mlvl), n))
+        from fb_bev_amd.graphed import Graphed
+        g = Graphed(m, cam, ctx, depth, mlvl_feats=mlvl)
+        row(f'S3g the same call replayed from a captured hipGraph (fb_bev_amd.graphed.Graphed)', name, B,
+            pct(lambda: g(cam, ctx, depth, mlvl_feats=mlvl), n))
         if levels > 1:
             from fb_bev_amd.backward_projection import DA_SpatialCrossAttention
             for mod in m.modules():
