@@ -1077,12 +1077,16 @@ extern "C" int fbbev_da_cross_attn_bwd_ws(const float* value, const int64_t* spa
         // (B) value gradient, one launch per token region
         for (int r = 0; r < pl.n_regions; ++r) {
             const da_region& rg = pl.reg[r];
-            const size_t lds_b = (size_t)FBBEV_DA_PLANE_WORDS(rg.tok1 - rg.tok0, HS) * sizeof(long long) + (size_t)((pl.q_per_chunk + 1) & ~1) * 2 +
-                                 (size_t)(1 + pl.threads / 64) * sizeof(int);
+            // small regions (coarse levels): up to 4 copies of the plane inside the LDS budget of the largest region
+            const size_t one = (size_t)FBBEV_DA_PLANE_WORDS(rg.tok1 - rg.tok0, HS) * sizeof(long long);
+            int copies = (int)((size_t)(68 * 1024) / one);
+            copies = copies < 1 ? 1 : (copies > 4 ? 4 : copies);
+            if (const char* e = getenv("FBBEV_DA_BWD_COPIES")) { const int v = atoi(e); if (v >= 1 && v <= copies) copies = v; }
+            const size_t lds_b = one * copies + (size_t)((pl.q_per_chunk + 1) & ~1) * 2 + (size_t)(1 + pl.threads / 64) * sizeof(int);
 #define FBBEV_DA_BWD_SC(NT_, DH_)                                                                                       \
     FBBEV_LAUNCH((k_da_cross_attn_bwd_scatter<NT_, DH_>), wgs, NT_, lds_b, stream, spatial_shapes, level_start_index,     \
                  pred_depth, ref_cam, mask, qdepth, offsets, attn, grad_slots, B, Ncam, S, M, L, Q, P, Za, DC, d0, dstep, \
-                 head_minor & 3, HS, pl.chunks, pl.q_per_chunk, rg.lvl0, rg.lvl1, rg.tok0, rg.tok1, part)
+                 head_minor & 3, HS, pl.chunks, pl.q_per_chunk, rg.lvl0, rg.lvl1, rg.tok0, rg.tok1, copies, part)
 #define FBBEV_DA_BWD_SC_NT(DH_) do { if (pl.threads == 512) FBBEV_DA_BWD_SC(512, DH_); else FBBEV_DA_BWD_SC(256, DH_); } while (0)
             if (Dh == 10) FBBEV_DA_BWD_SC_NT(10);
             else if (Dh == 8) FBBEV_DA_BWD_SC_NT(8);

@@ -578,12 +578,16 @@ k_da_cross_attn_bwd_scatter(const int64_t* __restrict__ spatial_shapes, const in
                             const float* __restrict__ offsets, const float* __restrict__ attn,
                             const float* __restrict__ grad_slots, int B, int Ncam, int S, int M, int L, int Q, int P, int Za,
                             int DC, float d0, float dstep, int head_minor, int HS, int n_chunks, int q_per_chunk, int lvl0,
-                            int lvl1, int tok0, int tok1, float* __restrict__ part) {
+                            int lvl1, int tok0, int tok1, int copies, float* __restrict__ part) {
     // [tok1 - tok0][HS] fixed point, skewed by one word every 8 tokens: a token pitch of HS 64-bit words (24 banks at HS = 12)
     // repeats its bank every 8 tokens; the skew breaks the period (SQ_LDS_BANK_CONFLICT was 2x the busy cycles) for 1 % more LDS
-    long long* plane = reinterpret_cast<long long*>(fbbev_dyn_lds_f32());
+    // `copies` planes when the region is small (the coarse levels of a pyramid: a few hundred tokens that EVERY query of the
+    // chunk samples): lane l adds into copy l % copies, the flush sums the copies -- same-address lanes of one ds_add_u64
+    // serialise (16 lanes per address: 1.2 instead of 22 lane-adds per ns)
+    long long* plane0 = reinterpret_cast<long long*>(fbbev_dyn_lds_f32());
     const int plane_n = (tok1 - tok0) * HS, plane_w = FBBEV_DA_PLANE_WORDS(tok1 - tok0, HS);
-    unsigned short* hits = reinterpret_cast<unsigned short*>(plane + plane_w);   // [q_per_chunk] chunk-relative queries the camera sees
+    long long* plane = plane0 + (threadIdx.x % copies) * plane_w;
+    unsigned short* hits = reinterpret_cast<unsigned short*>(plane0 + copies * plane_w);   // [q_per_chunk] chunk-relative queries the camera sees
     int* n_hits = reinterpret_cast<int*>(hits + ((q_per_chunk + 1) & ~1));       // [1]
     float* red = reinterpret_cast<float*>(n_hits + 1);                           // [NT/64] block maximum
     const int lane = threadIdx.x & 63;
@@ -594,7 +598,7 @@ k_da_cross_attn_bwd_scatter(const int64_t* __restrict__ spatial_shapes, const in
     const int nq = q1 - q0;
     const int H0 = (int)spatial_shapes[0], W0 = (int)spatial_shapes[1];
     const int LP = L * P;
-    for (int i = threadIdx.x; i < plane_w; i += NT) plane[i] = 0ll;
+    for (int i = threadIdx.x; i < copies * plane_w; i += NT) plane0[i] = 0ll;
     // scale of the fixed-point plane: sc = 2^(30 - ex) with max|grad_slots| < 2^ex over the chunk's units (see above)
     float gmax = 0.f;
     bool finite = true;
@@ -713,12 +717,13 @@ k_da_cross_attn_bwd_scatter(const int64_t* __restrict__ spatial_shapes, const in
         __syncthreads();
         float* dst = part + ((((long long)b * M + m) * n_chunks + chunk) * Ncam + cam) * (long long)S * HS + (long long)tok0 * HS;
         for (int i = threadIdx.x * 4; i < plane_n; i += NT * 4) {            // HS % 4 == 0: a group of 4 stays inside one token
-            long long* src = plane + FBBEV_DA_PLANE_IDX(i / HS, HS) + (i % HS);
+            long long* src = plane0 + FBBEV_DA_PLANE_IDX(i / HS, HS) + (i % HS);
             fbbev_v4f t;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                t[e] = poisoned ? __builtin_nanf("") : (float)src[e] * inv_sc;            // one rounding (int64 -> fp32)
-                src[e] = 0ll;
+                long long acc = 0;
+                for (int cp = 0; cp < copies; ++cp) { acc += src[cp * plane_w + e]; src[cp * plane_w + e] = 0ll; }
+                t[e] = poisoned ? __builtin_nanf("") : (float)acc * inv_sc;               // one rounding (int64 -> fp32)
             }
             *reinterpret_cast<fbbev_v4f*>(dst + i) = t;
         }
