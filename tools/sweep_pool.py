@@ -35,7 +35,7 @@ def main():
     print(json.dumps({'config': name, 'B': B, 'storage': storage, 'P': P, 'I': I, 'algo_bytes': algo}))
     ref = None
     tvs = (32, 64, 128) if storage == 'f32' else (64, 128, 256)
-    for tv, cs, wg, lg in itertools.product(tvs, (1, 2), (256, 128), (3, 4, 5, 6)):
+    for tv, cs, wg, lg in itertools.product(tvs, (1, 2), (256, 128), (4, 5, 6)):
         if C % (4 * cs):
             continue
         cc = C // cs
