@@ -112,6 +112,42 @@ def s3(name, B, levels, n):
         row('S3t training step of the path (forward + backward of FBViewTransform, fused DA backward)', name, B, pct(step, n))
 
 
+def s6(n):
+    """BASELINE configs[4] as ONE path: forward projection + backward projection + re-add + 16-frame temporal fusion with
+    the history ring in fp16, 6x512x1408 input (feat 32x88, D=118), 400x400x16 grid, one sample per GPU."""
+    from fb_bev_amd.history_fusion import TemporalHistoryFusion
+    pc = S.CONFIGS['BL5']
+    X, Y, Z = pc.grid_xyz
+    gcb = {'x': pc.grid_config['x'], 'y': pc.grid_config['y'], 'z': [-1, 5.4, 1.6]}
+    cfg = configs.fbocc_r50(bev_h=Y, bev_w=X, numC_Trans=pc.channels, input_size=pc.input_size, grid_config=pc.grid_config,
+                            grid_config_bevformer=gcb, depth_bound=tuple(pc.grid_config['depth']), downsample=pc.downsample)
+    m = FBViewTransform(cfg['forward_projection'], cfg['backward_projection']).to(DEV).eval()
+    dx = [pc.grid_config[a][2] for a in 'xyz']
+    bx = [pc.grid_config[a][0] + pc.grid_config[a][2] / 2 for a in 'xyz']
+    hist = TemporalHistoryFusion(dx, bx, single_bev_num_channels=pc.channels, history_cat_num=16,
+                                 history_dtype=torch.float16).to(DEV).eval()
+    hist.do_history = True
+    cam = [t.to(DEV) for t in S.camera_rig(pc, 1, seed=0, bda_aug=False)]
+    depth, ctx = (t.to(DEV) for t in S.depth_and_context(pc, 1, seed=0))
+    ego = torch.eye(4); ego[0, 3] = 0.8
+    state = {'first': True}
+
+    def frame():
+        bev = m(cam, ctx, depth)
+        out = hist.fuse_history(bev, [dict(sequence_group_idx=0, start_of_sequence=state['first'], curr_to_prev_ego_rt=ego)], cam[5])
+        state['first'] = False
+        return out
+    with torch.no_grad():
+        frame()
+        ms = pct(frame, n, warm=2)
+        vt_ms = pct(lambda: m(cam, ctx, depth), n, warm=1)
+    row('S6 BASELINE configs[4] path: lift-splat + backward projection + re-add + 16-frame history (fp16 ring)', 'BL5 (400x400x16, 6x512x1408)',
+        1, ms, view_transformation_ms_p50=vt_ms[1], history_ring_GB=round(hist.history_bev.numel() * 2 / 2 ** 30, 1),
+        peak_mem_GB=round(torch.cuda.max_memory_allocated() / 2 ** 30, 1))
+    del m, hist
+    torch.cuda.empty_cache()
+
+
 def s4_s5(quick):
     sys.path.insert(0, os.path.join(ROOT, 'tools'))
     import time_full as T
@@ -154,10 +190,16 @@ def main():
     out = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1].endswith('.json') else os.path.join(ROOT, 'gpurun_out', 'scope_table.json')
     quick = 'quick' in sys.argv
     n = 20 if quick else 50
-    for name in ('REF', 'BL2'):
+    only6 = 'only_s6' in sys.argv
+    for name in (() if only6 else ('REF', 'BL2')):
         s1_s2(name, 16, n)
-    s3('REF', 1, 1, n); s3('REF', 4, 1, n); s3('BL2', 4, 4, n)
-    s4_s5(quick)
+    if not only6:
+        s3('REF', 1, 1, n); s3('REF', 4, 1, n); s3('BL2', 4, 4, n)
+    if 'only_s6' in sys.argv:
+        ROWS.clear()
+    s6(8 if quick else 15)
+    if 'only_s6' not in sys.argv:
+        s4_s5(quick)
     json.dump({'device': torch.cuda.get_device_name(0), 'torch': torch.__version__, 'rows': ROWS}, open(out, 'w'), indent=1)
 
 
