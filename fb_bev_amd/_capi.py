@@ -49,6 +49,7 @@ SIGNATURES = {
     'fbbev_layernorm': (c_int, [c_void_p] * 4 + [c_float, c_int64, c_int, c_void_p, c_void_p]),
     'fbbev_history_conv': (c_int, [c_void_p, c_int64] + [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t, c_void_p]),
     'fbbev_history_conv_e': (c_int, [c_void_p, c_int64] + [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    'fbbev_history_conv_bf16': (c_int, [c_void_p, c_int64] + [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     'fbbev_conv3d_ndhwc': (c_int, [c_void_p] * 4 + [c_int] * 14 + [c_void_p, c_void_p]),
     'fbbev_conv2d_nhwc': (c_int, [c_void_p] * 4 + [c_int] * 11 + [c_void_p, c_void_p]),
     'fbbev_conv3d_ndhwc_bf16': (c_int, [c_void_p] * 4 + [c_int] * 15 + [c_void_p, c_void_p]),
@@ -679,19 +680,23 @@ def blend_levels_ndhwc(level0, coarse, wsoft, out):
     return out
 
 
-def history_conv(feats, w1, bias1, w2, bias2, out):
+def history_conv(feats, w1, bias1, w2, bias2, out, compute=torch.float32):
     """feats (B, T1*C, N) f32 / bf16 / f16 whose per-sample block is contiguous; w1 (C,C); bias1 (B*T1, C); w2 (Cout, T1*C);
-    bias2 (Cout); out (B, Cout, N) f32 contiguous -> out = relu(bias2 + sum_t w2_t . relu(w1 . x_t + bias1_t))."""
+    bias2 (Cout); out (B, Cout, N) f32 contiguous -> out = relu(bias2 + sum_t w2_t . relu(w1 . x_t + bias1_t)).
+    compute=torch.bfloat16: both GEMMs on the bf16 MFMA with fp32 accumulation (fbbev_history_conv_bf16)."""
     B, TC, N = feats.shape
     C = w1.shape[0]
     T1 = TC // C
     Cout = w2.shape[0]
     if feats.stride()[1:] != (N, 1) or tuple(out.shape) != (B, Cout, N) or feats.dtype not in ELEM_TYPE:
         raise FbbevError('history_conv: bad feats / out layout')
-    ws = torch.empty((1 + T1) * C * max(C, Cout), dtype=torch.float32, device=feats.device)   # fragment-ordered weights
+    if compute not in (torch.float32, torch.bfloat16):
+        raise FbbevError('history_conv: compute is float32 or bfloat16')
+    ws = torch.empty((1 + T1) * C * max(C, Cout, 96), dtype=torch.float32, device=feats.device)   # fragment-ordered weights
+    name = 'fbbev_history_conv_bf16' if compute == torch.bfloat16 else 'fbbev_history_conv_e'
     with _on(feats):
-        _check(lib().fbbev_history_conv_e(_dev(feats, feats.dtype, 'feats', contiguous=False), feats.stride(0), _dev(w1, F32, 'w1'),
-                                          _dev(bias1, F32, 'bias1'), _dev(w2, F32, 'w2'), _dev(bias2, F32, 'bias2'),
-                                          B, T1, C, Cout, N, _dev(out, F32, 'out'), c_void_p(ws.data_ptr()),
-                                          ws.numel() * 4, ELEM_TYPE[feats.dtype], _stream()), 'fbbev_history_conv_e')
+        _check(getattr(lib(), name)(_dev(feats, feats.dtype, 'feats', contiguous=False), feats.stride(0), _dev(w1, F32, 'w1'),
+                                    _dev(bias1, F32, 'bias1'), _dev(w2, F32, 'w2'), _dev(bias2, F32, 'bias2'),
+                                    B, T1, C, Cout, N, _dev(out, F32, 'out'), c_void_p(ws.data_ptr()),
+                                    ws.numel() * 4, ELEM_TYPE[feats.dtype], _stream()), name)
     return out

@@ -1331,6 +1331,48 @@ extern "C" int fbbev_history_conv_e(const void* feats, long long feats_stride_b,
     return history_conv_launch<2>(feats, feats_stride_b, w1, bias1, w2, bias2, B, T1, C, Cout, N, out, workspace, workspace_bytes, stream);
 }
 
+// bf16-MFMA variant of the two fused convolutions (operands rounded to bf16, fp32 accumulate): C = Cout = 80 or 16
+template <int ET>
+static int history_conv_bf16_launch(const void* feats, long long feats_stride_b, const float* w1, const float* bias1,
+                                    const float* w2, const float* bias2, int B, int T1, int C, int Cout, int N,
+                                    float* out, void* workspace, size_t workspace_bytes, fbbev_rt_stream stream) {
+    const int tiles_per_b = (N + 63) / 64;
+    const long long blocks = (long long)B * tiles_per_b;
+    if (blocks >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
+    const int MT1 = C / 16, MT2 = Cout / 16, KS = (C + 31) / 32;
+    const size_t need = ((size_t)MT1 * KS + (size_t)T1 * MT2 * KS) * 64 * 8 * sizeof(unsigned short);
+    if (!workspace || !aligned16(workspace) || workspace_bytes < need) return FBBEV_E_WORKSPACE;
+    unsigned short* w1f = static_cast<unsigned short*>(workspace);
+    unsigned short* w2f = w1f + (size_t)MT1 * KS * 64 * 8;
+    const int nfrag = (MT1 * KS + T1 * MT2 * KS) * 64;
+    FBBEV_LAUNCH(k_history_weight_fragments_bf16, (nfrag + 255) / 256, 256, 0, stream, w1, w2, MT1, MT2, C, T1, w1f);
+    const size_t lds = (size_t)4 * 16 * (KS * 32 + 8) * sizeof(unsigned short);
+    if (C == 80)
+        FBBEV_LAUNCH((k_history_conv_bf16<5, 5, ET>), blocks, 256, lds, stream, feats, feats_stride_b,
+                     (const unsigned short*)w1f, bias1, (const unsigned short*)w2f, bias2, T1, N, tiles_per_b, out);
+    else
+        FBBEV_LAUNCH((k_history_conv_bf16<1, 1, ET>), blocks, 256, lds, stream, feats, feats_stride_b,
+                     (const unsigned short*)w1f, bias1, (const unsigned short*)w2f, bias2, T1, N, tiles_per_b, out);
+    FBBEV_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int fbbev_history_conv_bf16(const void* feats, long long feats_stride_b, const float* w1, const float* bias1,
+                                       const float* w2, const float* bias2, int B, int T1, int C, int Cout, int N,
+                                       float* out, void* workspace, size_t workspace_bytes, int elem_type,
+                                       fbbev_stream_t stream_) {
+    if (B < 0 || T1 <= 0 || C <= 0 || Cout <= 0 || N < 0 || elem_type < 0 || elem_type > 2) return FBBEV_E_BADARG;
+    if (B == 0 || N == 0) return 0;
+    if (!feats || !w1 || !bias1 || !w2 || !bias2 || !out) return FBBEV_E_BADARG;
+    if (!((C == 80 && Cout == 80) || (C == 16 && Cout == 16))) return FBBEV_E_UNSUPPORTED;
+    if (feats_stride_b == 0) feats_stride_b = (long long)T1 * C * N;
+    if (feats_stride_b < (long long)T1 * C * N) return FBBEV_E_BADARG;
+    fbbev_rt_stream stream = (fbbev_rt_stream)stream_;
+    if (elem_type == 0) return history_conv_bf16_launch<0>(feats, feats_stride_b, w1, bias1, w2, bias2, B, T1, C, Cout, N, out, workspace, workspace_bytes, stream);
+    if (elem_type == 1) return history_conv_bf16_launch<1>(feats, feats_stride_b, w1, bias1, w2, bias2, B, T1, C, Cout, N, out, workspace, workspace_bytes, stream);
+    return history_conv_bf16_launch<2>(feats, feats_stride_b, w1, bias1, w2, bias2, B, T1, C, Cout, N, out, workspace, workspace_bytes, stream);
+}
+
 extern "C" int fbbev_history_conv(const float* feats, long long feats_stride_b, const float* w1, const float* bias1,
                                   const float* w2, const float* bias2, int B, int T1, int C, int Cout, int N,
                                   float* out, void* workspace, size_t workspace_bytes, fbbev_stream_t stream_) {

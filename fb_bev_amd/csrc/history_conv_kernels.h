@@ -187,3 +187,128 @@ k_history_weight_fragments(const float* __restrict__ w1, const float* __restrict
         dst[i] = w2[(long long)(16 * mt + (lane & 15)) * ((long long)T1 * C) + t * C + 4 * kk + (lane >> 4)];
     }
 }
+
+
+// ---------------------------------------------------------------- bf16-MFMA variant (opt-in: compute = bf16)
+// BASELINE configs[4] names fp16 for the 16-frame temporal path; the reference pins these two convolutions to fp32
+// (fbocc.py:279-282 force_fp32).  With the ring stored in 16 bits the fp32-MFMA kernel above is COMPUTE bound: 13-14 ms of
+// the 23 ms frame at 400x400x16 (1.1 TFLOP at ~0.5 of the 157 TFLOP/s fp32-MFMA peak) against 1.2 ms to read the 6.1 GB
+// ring.  This variant runs both GEMMs on v_mfma_f32_16x16x32_bf16 (fp32 accumulate): operands rounded to bf16 -- the
+// folded weights once on the host side of the launch (k_history_weight_fragments_bf16), the frames as stored (bf16 ring:
+// exact; fp32 / fp16 ring: rounded at use), the ReLU'd intermediate when it is parked in LDS.  Biases, accumulators and
+// the output stay fp32.  Channels are padded to a multiple of 32 with zeros (C = 80 -> 3 k-steps).
+// Operand slots: lane (j = lane % 16, g = lane / 16), element e of k-step s stands for channel 32 s + 8 g + e in A and B
+// alike (the instruction only needs the two to agree).
+template <int MT1, int MT2, int ET>
+__global__ void __launch_bounds__(256, 2)
+k_history_conv_bf16(const void* __restrict__ feats, long long fstride_b, const unsigned short* __restrict__ w1f,
+                    const float* __restrict__ bias1, const unsigned short* __restrict__ w2f, const float* __restrict__ bias2,
+                    int T1, int N, int tiles_per_b, float* __restrict__ out) {
+    constexpr int C = 16 * MT1, Cout = 16 * MT2, KS = (C + 31) / 32, CP = KS * 32, PITCH = CP + 8;   // 16-byte aligned rows
+    unsigned short* lds = reinterpret_cast<unsigned short*>(fbbev_dyn_lds_f32());     // [4 waves][16 voxels][PITCH] bf16
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = lane >> 4, j = lane & 15;
+    const int b = blockIdx.x / tiles_per_b, tile = blockIdx.x - b * tiles_per_b;
+    const int n = tile * 64 + wave * 16 + j;
+    const bool inb = n < N;
+    unsigned short* yrow = lds + (wave * 16 + j) * PITCH;
+    for (int c = C + g; c < CP; c += 4) yrow[c] = 0;                       // padding channels of the intermediate
+    const long long xb = (long long)b * fstride_b;
+    fbbev_bf16x8 a1[MT1][KS];
+#pragma unroll
+    for (int mt = 0; mt < MT1; ++mt)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) a1[mt][s] = fbbev_ld_bf16x8(w1f + ((mt * KS + s) * 64 + lane) * 8);
+    fbbev_v4f acc2[MT2];
+#pragma unroll
+    for (int mt = 0; mt < MT2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc2[mt][r] = bias2[16 * mt + 4 * g + r];
+    // X operands stay RAW in registers (the prefetch of frame t+1 must not be followed by a conversion that waits for it)
+    unsigned int bx[KS][8];
+    auto load_x = [&](long long base) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int c = 32 * s + 8 * g + e;
+                bx[s][e] = (inb && c < C) ? fbbev_ld_raw<ET>(feats, base + (long long)c * N + n) : 0u;
+            }
+    };
+    auto x_operand = [&](int s) {
+        fbbev_v4f lo, hi;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { lo[e] = fbbev_widen<ET>(bx[s][e]); hi[e] = fbbev_widen<ET>(bx[s][4 + e]); }
+        return fbbev_cvt_bf16x8(lo, hi);                    // exact for a bf16 ring
+    };
+    load_x(xb);
+    for (int t = 0; t < T1; ++t) {
+        const float* b1 = bias1 + ((long long)b * T1 + t) * C;
+        const unsigned short* w2t = w2f + (long long)t * MT2 * KS * 64 * 8;
+        fbbev_bf16x8 a2[MT2][KS];
+#pragma unroll
+        for (int mt = 0; mt < MT2; ++mt)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) a2[mt][s] = fbbev_ld_bf16x8(w2t + ((mt * KS + s) * 64 + lane) * 8);
+        fbbev_v4f acc1[MT1];
+#pragma unroll
+        for (int mt = 0; mt < MT1; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc1[mt][r] = b1[16 * mt + 4 * g + r];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const fbbev_bf16x8 xo = x_operand(s);
+#pragma unroll
+            for (int mt = 0; mt < MT1; ++mt) acc1[mt] = fbbev_mfma_f32_16x16x32_bf16(a1[mt][s], xo, acc1[mt]);
+        }
+        if (t + 1 < T1) load_x(xb + (long long)(t + 1) * C * N);           // next frame: in flight during GEMM 2
+        fbbev_wave_sync();                                                  // the LDS rows are wave-private
+#pragma unroll
+        for (int mt = 0; mt < MT1; ++mt) {
+            // rows 16 mt + 4 g + r of voxel j = 4 consecutive channels of this lane's voxel row: one 8-byte store
+            const fbbev_v4f y = {fmaxf(acc1[mt][0], 0.f), fmaxf(acc1[mt][1], 0.f), fmaxf(acc1[mt][2], 0.f), fmaxf(acc1[mt][3], 0.f)};
+            const fbbev_bf16x8 pk = fbbev_cvt_bf16x8(y, y);
+            unsigned long long four;
+            __builtin_memcpy(&four, &pk, 8);
+            *reinterpret_cast<unsigned long long*>(yrow + 16 * mt + 4 * g) = four;
+        }
+        fbbev_wave_sync();
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const fbbev_bf16x8 yo = fbbev_ld_bf16x8(yrow + 32 * s + 8 * g);   // channels 32 s + 8 g .. + 7 of voxel j
+#pragma unroll
+            for (int mt = 0; mt < MT2; ++mt) acc2[mt] = fbbev_mfma_f32_16x16x32_bf16(a2[mt][s], yo, acc2[mt]);
+        }
+    }
+    if (inb) {
+        float* ob = out + (long long)b * Cout * N + n;
+#pragma unroll
+        for (int mt = 0; mt < MT2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ob[(long long)(16 * mt + 4 * g + r) * N] = fmaxf(acc2[mt][r], 0.f);
+    }
+}
+
+// Folded weight matrices -> bf16 A operands in fragment order: dst = [ w1f[mt][s][lane][8] | w2f[t][mt][s][lane][8] ],
+// element e of lane = W[16 mt + lane % 16][32 s + 8 (lane / 16) + e] (zero beyond C), rounded to nearest even.
+__global__ void __launch_bounds__(256)
+k_history_weight_fragments_bf16(const float* __restrict__ w1, const float* __restrict__ w2, int MT1, int MT2, int C, int T1,
+                                unsigned short* __restrict__ dst) {
+    const int KS = (C + 31) / 32;
+    const int n1 = MT1 * KS * 64, n2 = MT2 * KS * 64;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;                   // one lane-fragment (8 elements) per thread
+    if (i >= n1 + T1 * n2) return;
+    fbbev_v4f lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+    const int ii = i < n1 ? i : (i - n1) % n2, t = i < n1 ? 0 : (i - n1) / n2;
+    const int lane = ii & 63, s = (ii >> 6) % KS, mt = (ii >> 6) / KS;
+    const float* row = i < n1 ? w1 + (long long)(16 * mt + (lane & 15)) * C
+                              : w2 + (long long)(16 * mt + (lane & 15)) * ((long long)T1 * C) + (long long)t * C;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = 32 * s + 8 * (lane >> 4) + e;
+        const float v = c < C ? row[c] : 0.f;
+        if (e < 4) lo[e] = v; else hi[e - 4] = v;
+    }
+    const fbbev_bf16x8 pk = fbbev_cvt_bf16x8(lo, hi);
+    __builtin_memcpy(dst + (long long)i * 8, &pk, 16);
+}

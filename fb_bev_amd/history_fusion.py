@@ -29,7 +29,8 @@ from .mfma_conv3d import MConv3d      # nn.Conv3d (same parameters / state dict)
 
 class TemporalHistoryFusion(nn.Module):
     def __init__(self, dx, bx, single_bev_num_channels=80, history_cat_num=16, history_cat_conv_out_channels=None,
-                 do_history=True, interpolation_mode='bilinear', history_cam_sweep_freq=0.5, history_dtype=torch.float32):
+                 do_history=True, interpolation_mode='bilinear', history_cam_sweep_freq=0.5, history_dtype=torch.float32,
+                 history_compute=torch.float32):
         super().__init__()
         if interpolation_mode != 'bilinear':
             raise NotImplementedError("only interpolation_mode='bilinear' (trilinear on the voxel grid) is built")
@@ -52,6 +53,10 @@ class TemporalHistoryFusion(nn.Module):
         # convolutions stay fp32 (taps widened exactly, one nearest-even rounding when a frame is stored); the autograd
         # path always keeps fp32.
         self.history_dtype = history_dtype
+        # Arithmetic of the two fused inference convolutions: float32 (the reference, fbocc.py:279-282 force_fp32), or
+        # bfloat16 = both GEMMs on the bf16 MFMA with fp32 accumulation (weights, frames and the ReLU'd intermediate rounded to
+        # bf16; ~1e-2 relative on the fused volume) -- at 400x400x16 the fp32-MFMA kernel is compute bound.
+        self.history_compute = history_compute
         self.reset()
 
     def reset(self):
@@ -188,9 +193,11 @@ class TemporalHistoryFusion(nn.Module):
         bias1 = b1[None, :] + tau * w1[None, :, C]                     # (B*(T+1), C)
         cout = w2.shape[0]
         if self.use_mfma_convs and C % 16 == 0 and cout % 16 == 0 and max(C, cout) <= 128:
-            # both convs in one fp32-MFMA kernel: the (T+1)*C-channel intermediate never leaves the CU
+            # both convs in one MFMA kernel: the (T+1)*C-channel intermediate never leaves the CU
+            compute = self.history_compute if (C == cout and C in (16, 80)) else torch.float32
             out = _capi.history_conv(nxt.view(B, (T + 1) * C, n), w1[:, :C].contiguous(), bias1.contiguous(), w2.contiguous(),
-                                     b2.contiguous(), torch.empty((B, cout, n), dtype=torch.float32, device=curr.device))
+                                     b2.contiguous(), torch.empty((B, cout, n), dtype=torch.float32, device=curr.device),
+                                     compute=compute)
         else:
             y = torch.baddbmm(bias1.unsqueeze(-1), w1[:, :C].unsqueeze(0).expand(B * (T + 1), C, C),
                               nxt.view(B * (T + 1), C, n).float())

@@ -411,6 +411,15 @@ int fbbev_history_conv_e(const void* feats, long long feats_stride_b, const floa
                          const float* w2, const float* bias2, int B, int T1, int C, int Cout, int N, float* out,
                          void* workspace, size_t workspace_bytes, int elem_type, fbbev_stream_t stream);
 
+/* fbbev_history_conv_e with both GEMMs on the bf16 MFMA (v_mfma_f32_16x16x32_bf16, fp32 accumulate): the folded
+ * weights, the frames (exact for a bf16 ring) and the ReLU'd intermediate are rounded to bf16; biases, accumulators
+ * and `out` stay fp32.  Opt-in reduced precision -- the reference pins these convolutions to fp32 (fbocc.py:279-282) while
+ * BASELINE configs[4] names fp16 for the path; at 400x400x16 the fp32-MFMA kernel is compute bound.  C = Cout in {16, 80};
+ * workspace >= (1 + T1) * C * 96 * 2 bytes (bf16 weight fragments), 16-byte aligned. */
+int fbbev_history_conv_bf16(const void* feats, long long feats_stride_b, const float* w1, const float* bias1,
+                            const float* w2, const float* bias2, int B, int T1, int C, int Cout, int N, float* out,
+                            void* workspace, size_t workspace_bytes, int elem_type, fbbev_stream_t stream);
+
 /* Dense 3-D convolution on NDHWC (torch channels_last_3d) f32 activations as an fp32-MFMA implicit GEMM, inference:
  * replaces the eval-mode Conv3d (+ folded BatchNorm) (+ residual) (+ ReLU) groups of CustomResNet3D (resnet3d.py:19-43,
  * 78-102), FPN3D (fpn3d.py:50-70) and OccHead (occupancy_head.py:82-141), which the reference runs in fp32 through the

@@ -253,13 +253,13 @@ def da_cross_attn_bwd(value, ss, ls, pred_depth, ref_cam, mask, qdepth, offsets,
     return gv, gd, go, ga
 
 
-def history_conv(feats, w1, bias1, w2, bias2):
+def history_conv(feats, w1, bias1, w2, bias2, bf16=False):
     B, TC, N = feats.shape
     C, Cout = w1.shape[0], w2.shape[0]
     out = torch.full((B, Cout, N), float('nan'))
-    ws = torch.zeros((1 + TC // C) * C * max(C, Cout))
+    ws = torch.zeros((1 + TC // C) * C * max(C, Cout, 96))
     et = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[feats.dtype]
-    ok(lib().fbbev_history_conv_e(c_void_p(feats.data_ptr()), feats.stride(0), p(w1), p(bias1), p(w2), p(bias2), B, TC // C, C,
+    ok(getattr(lib(), 'fbbev_history_conv_bf16' if bf16 else 'fbbev_history_conv_e')(c_void_p(feats.data_ptr()), feats.stride(0), p(w1), p(bias1), p(w2), p(bias2), B, TC // C, C,
                                   Cout, N, p(out), p(ws), ws.numel() * 4, et, None))
     return out
 

@@ -528,6 +528,32 @@ def test_fused_da_cross_attention_backward_emulated():
                 os.environ.pop('FBBEV_DA_BWD_TOKENS', None)
 
 
+@pytest.mark.parametrize('B,T1,C,N,dt', [(1, 3, 16, 64, torch.float32), (2, 2, 80, 100, torch.bfloat16), (1, 3, 80, 17, torch.float16),
+                                         (1, 17, 80, 64, torch.bfloat16)])
+def test_history_conv_bf16_mfma_emulated(B, T1, C, N, dt):
+    """k_history_conv_bf16 on the emulated v_mfma_f32_16x16x32_bf16 against the same roundings restated in float64: weights and
+    frames to bf16, fp32-exact products, relu(. + b1) rounded to bf16, second GEMM + b2, relu.  A bf16 rounding of the
+    intermediate may land on the other neighbour when the fp32 accumulation order differs in the last bit: bounded, rare."""
+    g = torch.Generator().manual_seed(N + T1)
+    big = (torch.randn(B, T1 * C + 8, N, generator=g)).to(dt)
+    feats = big[:, 8:]
+    w1, w2 = torch.randn(C, C, generator=g) * 0.3, torch.randn(C, T1 * C, generator=g) * 0.2
+    b1, b2 = torch.randn(B * T1, C, generator=g), torch.randn(C, generator=g)
+    got = E.history_conv(feats, w1, b1, w2, b2, bf16=True)
+    r = lambda t: t.bfloat16().double()  # noqa: E731
+    x = r(feats.float()).reshape(B, T1, C, N)
+    y = torch.relu(torch.einsum('oc,btcn->bton', r(w1), x) + b1.view(B, T1, C, 1).double())
+    exp = torch.relu(torch.einsum('oc,bcn->bon', r(w2), r(y.float()).reshape(B, T1 * C, N)) + b2.view(1, C, 1).double())
+    assert not torch.isnan(got).any()
+    err = (got.double() - exp).abs()
+    scale = exp.abs().max().item()
+    assert err.max().item() <= 4e-3 * scale, (err.max().item(), scale)          # a few flipped bf16 neighbours of y at most
+    assert err.mean().item() <= 2e-4 * scale
+    # and the reduced precision itself stays where the docstring says: ~1e-2 of the fp32 kernel's volume
+    ref = E.history_conv(feats, w1, b1, w2, b2)
+    assert (got - ref).abs().max().item() <= 3e-2 * scale
+
+
 @pytest.mark.parametrize('B,T1,C,Cout,N', [(1, 3, 16, 16, 64), (2, 2, 32, 16, 100), (1, 4, 16, 32, 17)])
 def test_history_conv_mfma_emulated(B, T1, C, Cout, N):
     """k_history_conv on the emulated v_mfma_f32_16x16x4_f32: out = relu(b2 + sum_t W2_t relu(W1 x_t + b1_t))."""

@@ -116,6 +116,32 @@ def test_do_history_false_uses_only_the_current_frame(dev):
     assert torch.allclose(outs[0], outs[1], atol=1e-4)      # no state carried over
 
 
+@pytest.mark.parametrize('B,T1,C,N,dt', [(1, 17, 80, 8000, torch.bfloat16), (2, 3, 16, 1000, torch.float32), (1, 17, 80, 4099, torch.float16)])
+def test_history_conv_bf16_mfma_kernel(dev, B, T1, C, N, dt):
+    """fbbev_history_conv_bf16 (v_mfma_f32_16x16x32_bf16, fp32 accumulate) vs float64 with the kernel's roundings restated:
+    weights and frames to bf16, relu(W1 x + b1) to bf16, everything else exact.  What remains is the fp32 accumulation
+    order and the occasional intermediate that rounds to the other bf16 neighbour because of it."""
+    from fb_bev_amd import _capi
+    g = torch.Generator().manual_seed(C + N)
+    feats = torch.randn(B, T1 * C, N, generator=g).to(dt)
+    w1, w2 = torch.randn(C, C, generator=g) * 0.1, torch.randn(C, T1 * C, generator=g) * 0.05
+    b1, b2 = torch.randn(B * T1, C, generator=g) * 0.2, torch.randn(C, generator=g) * 0.2
+    out = torch.full((B, C, N), float('nan'), device=dev)
+    _capi.history_conv(feats.to(dev), w1.to(dev), b1.to(dev), w2.to(dev), b2.to(dev), out, compute=torch.bfloat16)
+    r = lambda t: t.bfloat16().double()  # noqa: E731
+    x = r(feats.float()).view(B, T1, C, N)
+    y = torch.relu(torch.einsum('oc,btcn->bton', r(w1), x) + b1.view(B, T1, C, 1).double())
+    exp = torch.relu(torch.einsum('oc,bcn->bon', r(w2), r(y.float()).reshape(B, T1 * C, N)) + b2.view(1, C, 1).double())
+    assert not torch.isnan(out).any()
+    err = (out.cpu().double() - exp).abs()
+    scale = max(1.0, exp.abs().max().item())
+    assert err.max().item() <= 4e-3 * scale and err.mean().item() <= 2e-4 * scale, (err.max().item(), err.mean().item(), scale)
+    # against the fp32 kernel on the same inputs: the documented ~1e-2 of the volume's peak
+    ref = torch.empty_like(out)
+    _capi.history_conv(feats.to(dev), w1.to(dev), b1.to(dev), w2.to(dev), b2.to(dev), ref)
+    assert (out - ref).abs().max().item() <= 3e-2 * scale
+
+
 @pytest.mark.parametrize('B,T1,C,Cout,N', [(1, 17, 80, 80, 8000), (2, 3, 16, 32, 1000), (1, 2, 128, 128, 77)])
 def test_history_conv_mfma_kernel(dev, B, T1, C, Cout, N):
     """fbbev_history_conv (v_mfma_f32_16x16x4_f32) vs a float64 evaluation of the same two folded convolutions."""

@@ -138,12 +138,17 @@ def s6(n):
         state['first'] = False
         return out
     with torch.no_grad():
-        frame()
-        ms = pct(frame, n, warm=2)
-        vt_ms = pct(lambda: m(cam, ctx, depth), n, warm=1)
-    row('S6 BASELINE configs[4] path: lift-splat + backward projection + re-add + 16-frame history (fp16 ring)', 'BL5 (400x400x16, 6x512x1408)',
-        1, ms, view_transformation_ms_p50=vt_ms[1], history_ring_GB=round(hist.history_bev.numel() * 2 / 2 ** 30, 1),
-        peak_mem_GB=round(torch.cuda.max_memory_allocated() / 2 ** 30, 1))
+        vt_ms = None
+        for comp, label in ((torch.float32, 'fp32 MFMA'), (torch.bfloat16, 'bf16 MFMA (fp32 accumulate)')):
+            hist.history_compute = comp
+            hist.reset(); state['first'] = True
+            frame()
+            ms = pct(frame, n, warm=2)
+            vt_ms = vt_ms or pct(lambda: m(cam, ctx, depth), n, warm=1)
+            row('S6 BASELINE configs[4] path: lift-splat + backward projection + re-add + 16-frame history (fp16 ring)',
+                'BL5 (400x400x16, 6x512x1408)', 1, ms, history_convs=label, view_transformation_ms_p50=vt_ms[1],
+                history_ring_GB=round(hist.history_bev.numel() * 2 / 2 ** 30, 1),
+                peak_mem_GB=round(torch.cuda.max_memory_allocated() / 2 ** 30, 1))
     del m, hist
     torch.cuda.empty_cache()
 

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Temporal history fusion at FB-OCC sizes: fb_bev_amd.TemporalHistoryFusion (HIP warp + folded GEMMs) vs the
 reference's op sequence (fbocc.py:264-319: generate_grid, F.grid_sample, cats, Conv3d+BN+ReLU x2, clone) written in
-plain torch on the same GPU.   python tools/time_history.py [Y X Z] [B] [f32|f16|bf16] [noref]
-(f16 / bf16: the 16-bit history ring of BASELINE configs[4]; noref: skip the torch reference sequence)"""
+plain torch on the same GPU.   python tools/time_history.py [Y X Z] [B] [f32|f16|bf16] [noref] [cbf16]
+(f16 / bf16: the 16-bit history ring of BASELINE configs[4]; noref: skip the torch reference sequence; cbf16: the two
+convolutions on the bf16 MFMA, history_compute=bfloat16)"""
 import json, os, sys
 import torch
 import torch.nn.functional as F
@@ -68,11 +69,13 @@ def main():
     C, T = 80, 16
     dt = {'f32': torch.float32, 'f16': torch.float16, 'bf16': torch.bfloat16}[sys.argv[5] if len(sys.argv) >= 6 else 'f32']
     noref = 'noref' in sys.argv
+    comp = torch.bfloat16 if 'cbf16' in sys.argv else torch.float32
     esz = 4 if dt == torch.float32 else 2
     dev = torch.device('cuda:0')
     torch.manual_seed(0)
     dxv = 80.0 / X
-    m = TemporalHistoryFusion([dxv, dxv, 6.4 / Z], [-40 + dxv / 2, -40 + dxv / 2, -1 + 3.2 / Z], C, T, history_dtype=dt).to(dev).eval()
+    m = TemporalHistoryFusion([dxv, dxv, 6.4 / Z], [-40 + dxv / 2, -40 + dxv / 2, -1 + 3.2 / Z], C, T, history_dtype=dt,
+                              history_compute=comp).to(dev).eval()
     for seq in (m.history_keyframe_time_conv, m.history_keyframe_cat_conv):
         seq[1].running_var.uniform_(0.5, 1.5); seq[1].running_mean.uniform_(-0.2, 0.2)
     ref = TorchReference(m)
@@ -107,12 +110,20 @@ def main():
         from fb_bev_amd import _capi
         hist = m.history_bev; flow = m.rt_flow(ego_dev, bda); dst = torch.empty_like(hist)
         t_warp = timed(lambda i: _capi.history_warp(hist, flow, dst))
+        rel = None
+        if comp != torch.float32:          # same frames through the fp32 convolutions: what the reduced precision costs
+            m.history_compute = torch.float32; m.reset()
+            m.fuse_history(frames[0], metas(True), bda); o2 = m.fuse_history(frames[1], metas(False), bda)
+            m.history_compute = comp; m.reset()
+            m.fuse_history(frames[0], metas(True), bda); o3 = m.fuse_history(frames[1], metas(False), bda)
+            rel = ((o3 - o2).abs().max() / o2.abs().max()).item()
     hist_bytes = B * T * C * Z * Y * X * esz
     print(json.dumps({'grid': [Y, X, Z], 'B': B, 'C': C, 'T': T, 'history_MB': round(hist_bytes / 1e6, 1),
-                      'history_dtype': str(dt).split('.')[-1], 'fused_ms': round(t_hip, 4),
+                      'history_dtype': str(dt).split('.')[-1], 'conv_compute': str(comp).split('.')[-1], 'fused_ms': round(t_hip, 4),
                       'torch_reference_sequence_ms': None if t_ref is None else round(t_ref, 4), 'speedup': None if t_ref is None else round(t_ref / t_hip, 2),
                       'warp_ms': round(t_warp, 4), 'warp_GBps_read_plus_write': round(2 * hist_bytes / t_warp / 1e6, 1),
-                      'max_abs_diff_out': err, 'max_abs_diff_history': herr}))
+                      'max_abs_diff_out': err, 'max_abs_diff_history': herr,
+                      'bf16_convs_vs_fp32_convs_max_rel_to_peak': rel}))
 
 
 if __name__ == '__main__':
