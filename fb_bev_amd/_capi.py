@@ -49,7 +49,9 @@ SIGNATURES = {
     'fbbev_layernorm': (c_int, [c_void_p] * 4 + [c_float, c_int64, c_int, c_void_p, c_void_p]),
     'fbbev_history_conv': (c_int, [c_void_p, c_int64] + [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t, c_void_p]),
     'fbbev_history_conv_e': (c_int, [c_void_p, c_int64] + [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
-    'fbbev_history_conv_bf16': (c_int, [c_void_p, c_int64] + [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    'fbbev_history_conv_bf16': (c_int, [c_void_p, c_int64] + [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
+    'fbbev_history_warp_vm': (c_int, [c_void_p, c_int64, c_void_p] + [c_int] * 6 + [c_void_p, c_int64, c_int, c_void_p]),
+    'fbbev_history_frame_vm': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_int, c_void_p]),
     'fbbev_conv3d_ndhwc': (c_int, [c_void_p] * 4 + [c_int] * 14 + [c_void_p, c_void_p]),
     'fbbev_conv2d_nhwc': (c_int, [c_void_p] * 4 + [c_int] * 11 + [c_void_p, c_void_p]),
     'fbbev_conv3d_ndhwc_bf16': (c_int, [c_void_p] * 4 + [c_int] * 15 + [c_void_p, c_void_p]),
@@ -554,6 +556,38 @@ def history_warp(history, rt_flow, out):
     return out
 
 
+def history_warp_vm(history, rt_flow, out, grid_zyx):
+    """Voxel-major ring: history, out (B,T,N,C) f32 / bf16 / f16 (the same type), N = Z*Y*X with x fastest, the (T,N,C) block
+    of a sample contiguous (batch stride free).  Same taps, weights and roundings as history_warp: the same element bits."""
+    B, T, N, C = history.shape
+    Z, Y, X = grid_zyx
+    if tuple(out.shape) != (B, T, N, C) or N != Z * Y * X:
+        raise FbbevError('history_warp_vm: out must have the shape of history, N = Z*Y*X')
+    if history.dtype not in ELEM_TYPE or out.dtype != history.dtype:
+        raise FbbevError('history / out must both be f32, bf16 or f16')
+    for t, n in ((history, 'history'), (out, 'out')):
+        if t.stride()[1:] != (N * C, C, 1):
+            raise FbbevError(f'{n}: the (T,N,C) block of a sample must be contiguous')
+    with _on(history):
+        _check(lib().fbbev_history_warp_vm(_dev(history, history.dtype, 'history', contiguous=False), history.stride(0),
+                                           _dev(rt_flow, F32, 'rt_flow'), B, T, C, Z, Y, X,
+                                           _dev(out, out.dtype, 'out', contiguous=False), out.stride(0),
+                                           ELEM_TYPE[history.dtype], _stream()), 'fbbev_history_warp_vm')
+    return out
+
+
+def history_frame_vm(curr, out, inner=1):
+    """curr (B,C,N) f32 contiguous planes -> out (B,N,C) f32 / bf16 / f16 rows (batch stride free): one frame slot of a
+    voxel-major ring, rounded once for 16-bit storage.  inner = Z: the planes are (Y,X,Z) volumes, the rows (Z,Y,X)-ordered."""
+    B, C, N = curr.shape
+    if tuple(out.shape) != (B, N, C) or out.stride()[1:] != (C, 1) or out.dtype not in ELEM_TYPE:
+        raise FbbevError('history_frame_vm: out must be (B,N,C) rows')
+    with _on(curr):
+        _check(lib().fbbev_history_frame_vm(_dev(curr, F32, 'curr'), B, C, N, int(inner), _dev(out, out.dtype, 'out', contiguous=False),
+                                            out.stride(0), ELEM_TYPE[out.dtype], _stream()), 'fbbev_history_frame_vm')
+    return out
+
+
 def layernorm(x, weight, bias, eps, residual=None, out=None):
     """LayerNorm over the last dim of a contiguous f32 GPU tensor (C % 4 == 0, C <= 128); out = LN(x [+ residual])."""
     C = x.shape[-1]
@@ -680,23 +714,32 @@ def blend_levels_ndhwc(level0, coarse, wsoft, out):
     return out
 
 
-def history_conv(feats, w1, bias1, w2, bias2, out, compute=torch.float32):
+def history_conv(feats, w1, bias1, w2, bias2, out, compute=torch.float32, voxel_major=False):
     """feats (B, T1*C, N) f32 / bf16 / f16 whose per-sample block is contiguous; w1 (C,C); bias1 (B*T1, C); w2 (Cout, T1*C);
     bias2 (Cout); out (B, Cout, N) f32 contiguous -> out = relu(bias2 + sum_t w2_t . relu(w1 . x_t + bias1_t)).
-    compute=torch.bfloat16: both GEMMs on the bf16 MFMA with fp32 accumulation (fbbev_history_conv_bf16)."""
-    B, TC, N = feats.shape
+    compute=torch.bfloat16: both GEMMs on the bf16 MFMA with fp32 accumulation (fbbev_history_conv_bf16);
+    voxel_major=True (bf16 compute only): feats is (B, T1, N, C), the voxel-major ring."""
     C = w1.shape[0]
-    T1 = TC // C
     Cout = w2.shape[0]
-    if feats.stride()[1:] != (N, 1) or tuple(out.shape) != (B, Cout, N) or feats.dtype not in ELEM_TYPE:
+    if voxel_major:
+        B, T1, N, _ = feats.shape
+        ok = feats.dim() == 4 and feats.shape[3] == C and feats.stride()[1:] == (N * C, C, 1)
+    else:
+        B, TC, N = feats.shape
+        T1 = TC // C
+        ok = feats.stride()[1:] == (N, 1)
+    if not ok or tuple(out.shape) != (B, Cout, N) or feats.dtype not in ELEM_TYPE:
         raise FbbevError('history_conv: bad feats / out layout')
-    if compute not in (torch.float32, torch.bfloat16):
-        raise FbbevError('history_conv: compute is float32 or bfloat16')
+    if compute not in (torch.float32, torch.bfloat16) or (voxel_major and compute != torch.bfloat16):
+        raise FbbevError('history_conv: compute is float32 or bfloat16 (voxel_major: bfloat16)')
     ws = torch.empty((1 + T1) * C * max(C, Cout, 96), dtype=torch.float32, device=feats.device)   # fragment-ordered weights
-    name = 'fbbev_history_conv_bf16' if compute == torch.bfloat16 else 'fbbev_history_conv_e'
+    args = (_dev(feats, feats.dtype, 'feats', contiguous=False), feats.stride(0), _dev(w1, F32, 'w1'),
+            _dev(bias1, F32, 'bias1'), _dev(w2, F32, 'w2'), _dev(bias2, F32, 'bias2'),
+            B, T1, C, Cout, N, _dev(out, F32, 'out'), c_void_p(ws.data_ptr()), ws.numel() * 4)
     with _on(feats):
-        _check(getattr(lib(), name)(_dev(feats, feats.dtype, 'feats', contiguous=False), feats.stride(0), _dev(w1, F32, 'w1'),
-                                    _dev(bias1, F32, 'bias1'), _dev(w2, F32, 'w2'), _dev(bias2, F32, 'bias2'),
-                                    B, T1, C, Cout, N, _dev(out, F32, 'out'), c_void_p(ws.data_ptr()),
-                                    ws.numel() * 4, ELEM_TYPE[feats.dtype], _stream()), name)
+        if compute == torch.bfloat16:
+            _check(lib().fbbev_history_conv_bf16(*args, 1 if voxel_major else 0, ELEM_TYPE[feats.dtype], _stream()),
+                   'fbbev_history_conv_bf16')
+        else:
+            _check(lib().fbbev_history_conv_e(*args, ELEM_TYPE[feats.dtype], _stream()), 'fbbev_history_conv_e')
     return out

@@ -1269,6 +1269,71 @@ extern "C" int fbbev_history_warp(const float* history, long long history_stride
     return fbbev_history_warp_e(history, history_stride_b, rt_flow, B, CH, Z, Y, X, out, out_stride_b, 0, stream_);
 }
 
+// voxel-major ring: frames [T][N][C] per sample (history_kernels.h)
+extern "C" int fbbev_history_warp_vm(const void* history, long long history_stride_b, const float* rt_flow, int B, int T, int C,
+                                     int Z, int Y, int X, void* out, long long out_stride_b, int elem_type,
+                                     fbbev_stream_t stream_) {
+    if (B < 0 || T < 0 || C <= 0 || Z < 2 || Y < 2 || X < 2) return FBBEV_E_BADARG;
+    if (elem_type < 0 || elem_type > 2) return FBBEV_E_BADARG;
+    if (B == 0 || T == 0) return 0;
+    if (!history || !rt_flow || !out) return FBBEV_E_BADARG;
+    const int VE = elem_type == 0 ? 4 : 8;
+    const long long zyx = (long long)Z * Y * X, frame = zyx * C;
+    if (zyx >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
+    if (history_stride_b == 0) history_stride_b = (long long)T * frame;
+    if (out_stride_b == 0) out_stride_b = (long long)T * frame;
+    if (history_stride_b < (long long)T * frame || out_stride_b < (long long)T * frame) return FBBEV_E_BADARG;
+    if (C % VE != 0 || history_stride_b % VE != 0 || out_stride_b % VE != 0 || !aligned16(history) || !aligned16(out))
+        return FBBEV_E_UNSUPPORTED;
+    const int groups = C / VE;
+    const long long items = zyx * groups;
+    const int n_chunks = (int)((items + 255) / 256);
+    constexpr int TU = 2;
+    const int n_tg = (T + TU - 1) / TU;
+    const long long blocks = (long long)B * n_tg * n_chunks;
+    if (blocks >= (1ll << 31) - 8) return FBBEV_E_UNSUPPORTED;
+    const int per_xcd = (int)((blocks + 7) / 8);
+    fbbev_rt_stream stream = (fbbev_rt_stream)stream_;
+    if (elem_type == 0)
+        FBBEV_LAUNCH((k_history_warp_vm<0, TU>), (long long)per_xcd * 8, 256, 0, stream, history, history_stride_b, rt_flow, T, C,
+                     Z, Y, X, groups, n_tg, n_chunks, per_xcd, (int)blocks, out, out_stride_b);
+    else if (elem_type == 1)
+        FBBEV_LAUNCH((k_history_warp_vm<1, TU>), (long long)per_xcd * 8, 256, 0, stream, history, history_stride_b, rt_flow, T, C,
+                     Z, Y, X, groups, n_tg, n_chunks, per_xcd, (int)blocks, out, out_stride_b);
+    else
+        FBBEV_LAUNCH((k_history_warp_vm<2, TU>), (long long)per_xcd * 8, 256, 0, stream, history, history_stride_b, rt_flow, T, C,
+                     Z, Y, X, groups, n_tg, n_chunks, per_xcd, (int)blocks, out, out_stride_b);
+    FBBEV_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int fbbev_history_frame_vm(const float* curr, int B, int C, int N, int inner, void* out, long long out_stride_b,
+                                      int elem_type, fbbev_stream_t stream_) {
+    if (B < 0 || C <= 0 || N < 0 || elem_type < 0 || elem_type > 2) return FBBEV_E_BADARG;
+    if (inner < 1 || N % inner != 0) return FBBEV_E_BADARG;
+    if (B == 0 || N == 0) return 0;
+    if (!curr || !out) return FBBEV_E_BADARG;
+    const int VE = elem_type == 0 ? 4 : 8;
+    if (out_stride_b == 0) out_stride_b = (long long)N * C;
+    if (out_stride_b < (long long)N * C) return FBBEV_E_BADARG;
+    if (C % VE != 0 || C > 512 || out_stride_b % VE != 0 || !aligned16(out)) return FBBEV_E_UNSUPPORTED;
+    const int tiles_per_b = (N + 63) / 64;
+    const long long blocks = (long long)B * tiles_per_b;
+    if (blocks >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
+    const size_t lds = (size_t)C * 65 * sizeof(float);
+    fbbev_rt_stream stream = (fbbev_rt_stream)stream_;
+    if (lds > 64 * 1024) {
+        const void* k = elem_type == 0 ? (const void*)k_history_frame_vm<0> : elem_type == 1 ? (const void*)k_history_frame_vm<1> : (const void*)k_history_frame_vm<2>;
+        const int e = fbbev_rt_allow_dyn_lds(k, lds);
+        if (e) return e;
+    }
+    if (elem_type == 0) FBBEV_LAUNCH(k_history_frame_vm<0>, blocks, 256, lds, stream, curr, C, N, inner, tiles_per_b, out, out_stride_b);
+    else if (elem_type == 1) FBBEV_LAUNCH(k_history_frame_vm<1>, blocks, 256, lds, stream, curr, C, N, inner, tiles_per_b, out, out_stride_b);
+    else FBBEV_LAUNCH(k_history_frame_vm<2>, blocks, 256, lds, stream, curr, C, N, inner, tiles_per_b, out, out_stride_b);
+    FBBEV_CHECK_LAUNCH();
+    return 0;
+}
+
 // ------------------------------------------------------------------------------ LayerNorm over short rows
 extern "C" int fbbev_layernorm(const float* x, const float* residual, const float* weight, const float* bias, float eps,
                                long long rows, int C, float* out, fbbev_stream_t stream_) {
@@ -1332,7 +1397,7 @@ extern "C" int fbbev_history_conv_e(const void* feats, long long feats_stride_b,
 }
 
 // bf16-MFMA variant of the two fused convolutions (operands rounded to bf16, fp32 accumulate): C = Cout = 80 or 16
-template <int ET>
+template <int ET, bool VM>
 static int history_conv_bf16_launch(const void* feats, long long feats_stride_b, const float* w1, const float* bias1,
                                     const float* w2, const float* bias2, int B, int T1, int C, int Cout, int N,
                                     float* out, void* workspace, size_t workspace_bytes, fbbev_rt_stream stream) {
@@ -1348,10 +1413,10 @@ static int history_conv_bf16_launch(const void* feats, long long feats_stride_b,
     FBBEV_LAUNCH(k_history_weight_fragments_bf16, (nfrag + 255) / 256, 256, 0, stream, w1, w2, MT1, MT2, C, T1, w1f);
     const size_t lds = (size_t)4 * 16 * (KS * 32 + 8) * sizeof(unsigned short);
     if (C == 80)
-        FBBEV_LAUNCH((k_history_conv_bf16<5, 5, ET>), blocks, 256, lds, stream, feats, feats_stride_b,
+        FBBEV_LAUNCH((k_history_conv_bf16<5, 5, ET, VM>), blocks, 256, lds, stream, feats, feats_stride_b,
                      (const unsigned short*)w1f, bias1, (const unsigned short*)w2f, bias2, T1, N, tiles_per_b, out);
     else
-        FBBEV_LAUNCH((k_history_conv_bf16<1, 1, ET>), blocks, 256, lds, stream, feats, feats_stride_b,
+        FBBEV_LAUNCH((k_history_conv_bf16<1, 1, ET, VM>), blocks, 256, lds, stream, feats, feats_stride_b,
                      (const unsigned short*)w1f, bias1, (const unsigned short*)w2f, bias2, T1, N, tiles_per_b, out);
     FBBEV_CHECK_LAUNCH();
     return 0;
@@ -1359,18 +1424,21 @@ static int history_conv_bf16_launch(const void* feats, long long feats_stride_b,
 
 extern "C" int fbbev_history_conv_bf16(const void* feats, long long feats_stride_b, const float* w1, const float* bias1,
                                        const float* w2, const float* bias2, int B, int T1, int C, int Cout, int N,
-                                       float* out, void* workspace, size_t workspace_bytes, int elem_type,
+                                       float* out, void* workspace, size_t workspace_bytes, int voxel_major, int elem_type,
                                        fbbev_stream_t stream_) {
     if (B < 0 || T1 <= 0 || C <= 0 || Cout <= 0 || N < 0 || elem_type < 0 || elem_type > 2) return FBBEV_E_BADARG;
+    if (voxel_major != 0 && voxel_major != 1) return FBBEV_E_BADARG;
     if (B == 0 || N == 0) return 0;
     if (!feats || !w1 || !bias1 || !w2 || !bias2 || !out) return FBBEV_E_BADARG;
     if (!((C == 80 && Cout == 80) || (C == 16 && Cout == 16))) return FBBEV_E_UNSUPPORTED;
     if (feats_stride_b == 0) feats_stride_b = (long long)T1 * C * N;
     if (feats_stride_b < (long long)T1 * C * N) return FBBEV_E_BADARG;
+    if (voxel_major && (!aligned16(feats) || feats_stride_b % 8 != 0)) return FBBEV_E_UNSUPPORTED;   // 16-byte row pieces
     fbbev_rt_stream stream = (fbbev_rt_stream)stream_;
-    if (elem_type == 0) return history_conv_bf16_launch<0>(feats, feats_stride_b, w1, bias1, w2, bias2, B, T1, C, Cout, N, out, workspace, workspace_bytes, stream);
-    if (elem_type == 1) return history_conv_bf16_launch<1>(feats, feats_stride_b, w1, bias1, w2, bias2, B, T1, C, Cout, N, out, workspace, workspace_bytes, stream);
-    return history_conv_bf16_launch<2>(feats, feats_stride_b, w1, bias1, w2, bias2, B, T1, C, Cout, N, out, workspace, workspace_bytes, stream);
+#define FBBEV_HCB(ET_, VM_) history_conv_bf16_launch<ET_, VM_>(feats, feats_stride_b, w1, bias1, w2, bias2, B, T1, C, Cout, N, out, workspace, workspace_bytes, stream)
+    if (voxel_major) return elem_type == 0 ? FBBEV_HCB(0, true) : elem_type == 1 ? FBBEV_HCB(1, true) : FBBEV_HCB(2, true);
+    return elem_type == 0 ? FBBEV_HCB(0, false) : elem_type == 1 ? FBBEV_HCB(1, false) : FBBEV_HCB(2, false);
+#undef FBBEV_HCB
 }
 
 extern "C" int fbbev_history_conv(const float* feats, long long feats_stride_b, const float* w1, const float* bias1,

@@ -199,7 +199,9 @@ k_history_weight_fragments(const float* __restrict__ w1, const float* __restrict
 // the output stay fp32.  Channels are padded to a multiple of 32 with zeros (C = 80 -> 3 k-steps).
 // Operand slots: lane (j = lane % 16, g = lane / 16), element e of k-step s stands for channel 32 s + 8 g + e in A and B
 // alike (the instruction only needs the two to agree).
-template <int MT1, int MT2, int ET>
+// VM: the frames are voxel-major ([T1][N][C] per sample, history_kernels.h): a lane's 8 channels of a k-step are one 16-byte
+// row piece (two for an fp32 ring), and for a bf16 ring that piece IS the MFMA operand.
+template <int MT1, int MT2, int ET, bool VM>
 __global__ void __launch_bounds__(256, 2)
 k_history_conv_bf16(const void* __restrict__ feats, long long fstride_b, const unsigned short* __restrict__ w1f,
                     const float* __restrict__ bias1, const unsigned short* __restrict__ w2f, const float* __restrict__ bias2,
@@ -225,21 +227,58 @@ k_history_conv_bf16(const void* __restrict__ feats, long long fstride_b, const u
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc2[mt][r] = bias2[16 * mt + 4 * g + r];
     // X operands stay RAW in registers (the prefetch of frame t+1 must not be followed by a conversion that waits for it)
-    unsigned int bx[KS][8];
+    unsigned int bx[VM ? 1 : KS][VM ? 1 : 8];
+    fbbev_v4u bv[VM ? KS : 1][(VM && ET == 0) ? 2 : 1];
     auto load_x = [&](long long base) {
+        if constexpr (VM) {
+            const fbbev_v4u zero = {0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int s = 0; s < KS; ++s)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int c = 32 * s + 8 * g + e;
-                bx[s][e] = (inb && c < C) ? fbbev_ld_raw<ET>(feats, base + (long long)c * N + n) : 0u;
+            for (int s = 0; s < KS; ++s) {
+                const int c = 32 * s + 8 * g;
+                const bool ok = inb && c < C;                                  // C % 8 == 0: a piece is all in or all out
+                const long long e = ok ? base + (long long)n * C + c : xb;     // clamped address, select below: no branch
+                if constexpr (ET == 0) {
+                    const fbbev_v4u* p4 = reinterpret_cast<const fbbev_v4u*>(static_cast<const float*>(feats) + e);
+                    const fbbev_v4u lo = p4[0], hi = p4[1];
+                    bv[s][0] = ok ? lo : zero;
+                    bv[s][1] = ok ? hi : zero;
+                } else {
+                    const fbbev_v4u q = *reinterpret_cast<const fbbev_v4u*>(static_cast<const unsigned short*>(feats) + e);
+                    bv[s][0] = ok ? q : zero;
+                }
             }
+        } else {
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int c = 32 * s + 8 * g + e;
+                    bx[s][e] = (inb && c < C) ? fbbev_ld_raw<ET>(feats, base + (long long)c * N + n) : 0u;
+                }
+        }
     };
     auto x_operand = [&](int s) {
-        fbbev_v4f lo, hi;
+        if constexpr (VM && ET == 1) {
+            fbbev_bf16x8 r;
+            __builtin_memcpy(&r, &bv[s][0], 16);                // a bf16 ring row piece is the operand
+            return r;
+        } else {
+            fbbev_v4f lo, hi;
+            if constexpr (VM && ET == 0) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { lo[e] = fbbev_widen<ET>(bx[s][e]); hi[e] = fbbev_widen<ET>(bx[s][4 + e]); }
-        return fbbev_cvt_bf16x8(lo, hi);                    // exact for a bf16 ring
+                for (int e = 0; e < 4; ++e) { lo[e] = fbbev_widen<0>(bv[s][0][e]); hi[e] = fbbev_widen<0>(bv[s][1][e]); }
+            } else if constexpr (VM) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    lo[2 * e] = fbbev_widen<ET>(bv[s][0][e] & 0xffffu);     lo[2 * e + 1] = fbbev_widen<ET>(bv[s][0][e] >> 16);
+                    hi[2 * e] = fbbev_widen<ET>(bv[s][0][2 + e] & 0xffffu); hi[2 * e + 1] = fbbev_widen<ET>(bv[s][0][2 + e] >> 16);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { lo[e] = fbbev_widen<ET>(bx[s][e]); hi[e] = fbbev_widen<ET>(bx[s][4 + e]); }
+            }
+            return fbbev_cvt_bf16x8(lo, hi);                    // exact for a bf16 ring
+        }
     };
     load_x(xb);
     for (int t = 0; t < T1; ++t) {

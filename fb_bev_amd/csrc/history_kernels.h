@@ -161,6 +161,143 @@ k_history_warp(const void* __restrict__ hist, long long hist_stride_b, const flo
     }
 }
 
+// ---------------------------------------------------------------- voxel-major ring (opt-in: ring_layout = voxel_major)
+// The reference keeps the history as (B, T*C, Z, Y, X): 80 channel planes per frame, 5 MB apart at 400x400x16.  On that
+// layout every tap of k_history_warp is a 2- or 4-byte gather and the vector L1's access rate is the bound (0.2-0.3 of the
+// HBM peak).  In the voxel-major ring a frame is [voxel][channel] (x fastest over voxels): the C elements of a voxel are
+// contiguous (160 bytes at C = 80 in 16 bits), a tap is a 16-byte load of VE = 8 (16-bit) or 4 (fp32) channels, the taps
+// of x-neighbours are adjacent, and the fused convolutions read their MFMA operands as rows.  A thread owns (voxel, channel
+// group of VE) and TU consecutive frames: 8 TU independent 16-byte loads in flight, 8 fmaf per element in k_history_warp's
+// tap order with k_history_warp's weights -- the elements are the SAME bits as the planar kernel's (tested), only
+// their addresses differ.
+template <int ET>
+__device__ __forceinline__ void fbbev_widen_vec(fbbev_v4u raw, float* f) {      // 16 bytes -> VE floats, exact
+    if constexpr (ET == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) f[e] = fbbev_widen<0>(raw[e]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            f[2 * e] = fbbev_widen<ET>(raw[e] & 0xffffu);
+            f[2 * e + 1] = fbbev_widen<ET>(raw[e] >> 16);
+        }
+    }
+}
+template <int ET>
+__device__ __forceinline__ fbbev_v4u fbbev_narrow_vec(const float* f) {          // VE floats -> 16 bytes, one nearest-even rounding
+    fbbev_v4u r;
+    if constexpr (ET == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { unsigned int u; __builtin_memcpy(&u, &f[e], 4); r[e] = u; }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = fbbev_pack2<ET>(f[2 * e], f[2 * e + 1]);
+    }
+    return r;
+}
+
+// work item = ((b * n_tg) + frame group) * n_chunks + chunk; a chunk = 256 (voxel, channel group) pairs, group fastest
+template <int ET, int TU>
+__global__ void __launch_bounds__(256)
+k_history_warp_vm(const void* __restrict__ hist, long long hist_stride_b, const float* __restrict__ flow, int T, int C,
+                  int Z, int Y, int X, int groups, int n_tg, int n_chunks, int per_xcd, int n_work,
+                  void* __restrict__ out, long long out_stride_b) {
+    constexpr int VE = ET == 0 ? 4 : 8;
+    const int work = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);      // one contiguous eighth per XCD
+    if ((int)(blockIdx.x >> 3) >= per_xcd || work >= n_work) return;
+    const int chunk = work % n_chunks;
+    const int bt = work / n_chunks;
+    const int tg = bt % n_tg, b = bt / n_tg;
+    const int YX = Y * X, ZYX = Z * YX;
+    const long long item = (long long)chunk * 256 + threadIdx.x;
+    if (item >= (long long)ZYX * groups) return;
+    const int v = (int)(item / groups), gq = (int)(item - (long long)v * groups);
+    const int z = v / YX, r = v - z * YX, y = r / X, x = r - y * X;
+    const float* m = flow + b * 16;
+    const float fx = (float)x, fy = (float)y, fz = (float)z;
+    // source coordinate and taps: EXACTLY the expression sequence of k_history_warp
+    float gx = m[0] * fx + m[1] * fy + m[2] * fz + m[3];
+    float gy = m[4] * fx + m[5] * fy + m[6] * fz + m[7];
+    float gz = m[8] * fx + m[9] * fy + m[10] * fz + m[11];
+    gx = gx / (float)(X - 1) * 2.0f - 1.0f;
+    gy = gy / (float)(Y - 1) * 2.0f - 1.0f;
+    gz = gz / (float)(Z - 1) * 2.0f - 1.0f;
+    const float ix = ((gx + 1.f) / 2.f) * (float)(X - 1);
+    const float iy = ((gy + 1.f) / 2.f) * (float)(Y - 1);
+    const float iz = ((gz + 1.f) / 2.f) * (float)(Z - 1);
+    const float x0f = floorf(ix), y0f = floorf(iy), z0f = floorf(iz);
+    const float wx1 = ix - x0f, wy1 = iy - y0f, wz1 = iz - z0f;
+    const float wx0 = (x0f + 1.f) - ix, wy0 = (y0f + 1.f) - iy, wz0 = (z0f + 1.f) - iz;
+    const bool fin = (fabsf(ix) < 1.0e9f) && (fabsf(iy) < 1.0e9f) && (fabsf(iz) < 1.0e9f);
+    const int x0 = fin ? (int)x0f : -2, y0 = fin ? (int)y0f : -2, z0 = fin ? (int)z0f : -2;
+    long long off[8];                                   // element offset of the tap's channel group inside a frame
+    float w[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int cx = x0 + (k & 1), cy = y0 + ((k >> 1) & 1), cz = z0 + (k >> 2);
+        const bool ok = cx >= 0 && cx < X && cy >= 0 && cy < Y && cz >= 0 && cz < Z;
+        const float wk = ((k & 1) ? wx1 : wx0) * (((k >> 1) & 1) ? wy1 : wy0) * ((k >> 2) ? wz1 : wz0);
+        off[k] = (long long)(ok ? (cz * Y + cy) * X + cx : 0) * C + gq * VE;
+        w[k] = ok ? wk : 0.f;
+    }
+    const long long frame = (long long)ZYX * C;
+    const int t0 = tg * TU;
+    const fbbev_v4u* src = reinterpret_cast<const fbbev_v4u*>(hist);       // offsets below are multiples of VE elements = 16 bytes
+    fbbev_v4u* dst = reinterpret_cast<fbbev_v4u*>(out);
+    fbbev_v4u raw[TU][8];
+#pragma unroll
+    for (int u = 0; u < TU; ++u) {
+        const int t = t0 + u < T ? t0 + u : T - 1;                         // clamped: the tail repeats the last frame's loads
+        const long long fo = (long long)b * hist_stride_b + (long long)t * frame;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) raw[u][k] = src[(fo + off[k]) / VE];
+    }
+#pragma unroll
+    for (int u = 0; u < TU; ++u) {
+        if (t0 + u >= T) break;
+        float acc[VE];
+#pragma unroll
+        for (int e = 0; e < VE; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float a[VE];
+            fbbev_widen_vec<ET>(raw[u][k], a);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) acc[e] = fmaf(a[e], w[k], acc[e]);
+        }
+        dst[((long long)b * out_stride_b + (long long)(t0 + u) * frame + (long long)v * C + gq * VE) / VE] = fbbev_narrow_vec<ET>(acc);
+    }
+}
+
+// current frame (B, C, N) fp32 planes -> slot [b][N][C] of a voxel-major ring (one nearest-even rounding for a 16-bit ring).
+// A workgroup turns 64 plane positions: coalesced 256-byte plane reads into an LDS tile [C][65], 16-byte row writes out
+// of it.  inner > 1: the planes are stored (Y, X, Z) like the BEV volume the view transformation hands over (fbocc.py:212
+// permutes it for grid_sample) -- plane position i = (y*X + x)*Z + z lands in row n = z*(Y*X) + (y*X + x); inner = Z.
+template <int ET>
+__global__ void __launch_bounds__(256)
+k_history_frame_vm(const float* __restrict__ curr, int C, int N, int inner, int tiles_per_b, void* __restrict__ out,
+                   long long out_stride_b) {
+    constexpr int VE = ET == 0 ? 4 : 8;
+    float* tile = fbbev_dyn_lds_f32();
+    const int b = blockIdx.x / tiles_per_b, n0 = (blockIdx.x - b * tiles_per_b) * 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* cb = curr + (long long)b * C * N;
+    for (int c = wave; c < C; c += 4) tile[c * 65 + lane] = (n0 + lane < N) ? cb[(long long)c * N + n0 + lane] : 0.f;
+    __syncthreads();
+    const int groups = C / VE, plane = N / inner;
+    fbbev_v4u* dst = reinterpret_cast<fbbev_v4u*>(out);
+    for (int i = threadIdx.x; i < 64 * groups; i += 256) {
+        const int vl = i / groups, gq = i - vl * groups;
+        const int src = n0 + vl;
+        if (src >= N) continue;
+        const int row = inner > 1 ? (src % inner) * plane + src / inner : src;
+        float f[VE];
+#pragma unroll
+        for (int e = 0; e < VE; ++e) f[e] = tile[(gq * VE + e) * 65 + vl];
+        dst[((long long)b * out_stride_b + (long long)row * C + gq * VE) / VE] = fbbev_narrow_vec<ET>(f);
+    }
+}
+
 // ---------------------------------------------------------------- LDS-staged variant (opt-in: FBBEV_HISTORY_WARP=lds)
 // STATUS (round 2, measured): bit-identical to k_history_warp on the GPU, but 3x slower as built (REF 1.05 vs 0.36 ms,
 // 400x400x16 25.6 vs 10.7 ms): with one 1024-thread workgroup per CU the staging loads, the barrier and the taps of a

@@ -30,7 +30,7 @@ from .mfma_conv3d import MConv3d      # nn.Conv3d (same parameters / state dict)
 class TemporalHistoryFusion(nn.Module):
     def __init__(self, dx, bx, single_bev_num_channels=80, history_cat_num=16, history_cat_conv_out_channels=None,
                  do_history=True, interpolation_mode='bilinear', history_cam_sweep_freq=0.5, history_dtype=torch.float32,
-                 history_compute=torch.float32):
+                 history_compute=torch.float32, ring_layout='planar'):
         super().__init__()
         if interpolation_mode != 'bilinear':
             raise NotImplementedError("only interpolation_mode='bilinear' (trilinear on the voxel grid) is built")
@@ -57,6 +57,15 @@ class TemporalHistoryFusion(nn.Module):
         # bfloat16 = both GEMMs on the bf16 MFMA with fp32 accumulation (weights, frames and the ReLU'd intermediate rounded to
         # bf16; ~1e-2 relative on the fused volume) -- at 400x400x16 the fp32-MFMA kernel is compute bound.
         self.history_compute = history_compute
+        # Layout of the inference ring: 'planar' = the reference's (B, T*C, Z, Y, X); 'voxel_major' = (B, T, N, C) frames of
+        # voxel rows (history_kernels.h): a trilinear tap is one 16-byte load of 8 channels instead of 8 scalar gathers from 8
+        # planes, and the convolutions read MFMA operands as rows.  Same element bits as the planar ring.  Taken when the
+        # bf16-MFMA convolutions are (history_compute=bfloat16, C = Cout in {16, 80}); the autograd path stays planar fp32 and
+        # either kind of history is converted when the mode changes.  history_bev is then (B, T, N, C):
+        # history_as_reference() returns the reference's tensor.
+        if ring_layout not in ('planar', 'voxel_major'):
+            raise ValueError("ring_layout is 'planar' or 'voxel_major'")
+        self.ring_layout = ring_layout
         self.reset()
 
     def reset(self):
@@ -65,6 +74,21 @@ class TemporalHistoryFusion(nn.Module):
         self.history_seq_ids = None           # (B,) CPU long
         self.history_forward_augs = None      # (B,4,4) GPU
         self._bufs = None
+        self._grid = None                     # (Z,Y,X) of the last frame
+
+    def _voxel_major(self):
+        C = self.single_bev_num_channels
+        cout = self.history_keyframe_cat_conv[0].weight.shape[0]
+        return (self.ring_layout == 'voxel_major' and self.use_mfma_convs and self.history_compute == torch.bfloat16
+                and C == cout and C in (16, 80))
+
+    def history_as_reference(self):
+        """history_bev in the reference's layout and type: (B, T*C, Z, Y, X) fp32 (fbocc.py:234, :312)."""
+        h = self.history_bev
+        if h is None or h.dim() == 5:
+            return None if h is None else h.float()
+        B, T, N, C = h.shape
+        return h.float().transpose(2, 3).reshape(B, T * C, *self._grid)
 
     # ------------------------------------------------------------------ pieces
     @staticmethod
@@ -96,6 +120,7 @@ class TemporalHistoryFusion(nn.Module):
         dev = curr_bev.device
         curr = curr_bev.permute(0, 1, 4, 2, 3).float()                 # n, c, z, h, w   (:212)
         B, _, Z, Y, X = curr.shape
+        self._grid = (Z, Y, X)
         seq_ids = torch.LongTensor([m['sequence_group_idx'] for m in img_metas])
         start = torch.BoolTensor([bool(m['start_of_sequence']) for m in img_metas])
         fwd = self.forward_augs(bda.float())                           # :220
@@ -117,7 +142,10 @@ class TemporalHistoryFusion(nn.Module):
         self.history_sweep_time = self.history_sweep_time + 1          # :252
         if bool(start.any()):                                          # :253-261 (indices known on the host: no sync)
             for b in torch.nonzero(start).flatten().tolist():
-                self.history_bev[b].view(T, C, Z, Y, X).copy_(curr[b].detach().unsqueeze(0).expand(T, C, Z, Y, X))
+                if self.history_bev.dim() == 4:                        # voxel-major ring: (T, N, C) rows
+                    self.history_bev[b].copy_(curr[b].detach().reshape(C, -1).t().unsqueeze(0).expand(T, Z * Y * X, C))
+                else:
+                    self.history_bev[b].view(T, C, Z, Y, X).copy_(curr[b].detach().unsqueeze(0).expand(T, C, Z, Y, X))
                 self.history_forward_augs[b] = fwd[b]
             self.history_sweep_time[start] = 0
             self.history_seq_ids[start] = seq_ids[start]
@@ -129,8 +157,12 @@ class TemporalHistoryFusion(nn.Module):
             self.history_bev = feats_cat[:, :-C].detach().clone()      # :312
         else:
             with torch.no_grad():
-                out, nxt = self._fuse_infer(curr.detach(), flow, sweep.to(dev, non_blocking=True))
-            self.history_bev = nxt[:, :T * C]                          # view of the buffer just written: no clone
+                if self._voxel_major():
+                    out, nxt = self._fuse_infer_vm(curr_bev.detach().float(), flow, sweep.to(dev, non_blocking=True))
+                    self.history_bev = nxt[:, :T]                      # (B, T, N, C) view of the buffer just written
+                else:
+                    out, nxt = self._fuse_infer(curr.detach(), flow, sweep.to(dev, non_blocking=True))
+                    self.history_bev = nxt[:, :T * C]                  # view of the buffer just written: no clone
         self.history_sweep_time = sweep[:, :-1]                        # :313
         self.history_forward_augs = fwd.clone()                        # :314
         if not self.do_history:                                        # :317-318
@@ -148,11 +180,24 @@ class TemporalHistoryFusion(nn.Module):
             self._bufs = [torch.empty(shape, dtype=self.history_dtype, device=like.device) for _ in range(2)]
         return self._bufs
 
+    def _frame_buffers_vm(self, like, B, N):
+        T, C = self.history_cat_num, self.single_bev_num_channels
+        shape = (B, T + 1, N, C)
+        if (self._bufs is None or tuple(self._bufs[0].shape) != shape or self._bufs[0].device != like.device
+                or self._bufs[0].dtype != self.history_dtype):
+            self._bufs = None                                          # release a planar pair first
+            self._bufs = [torch.empty(shape, dtype=self.history_dtype, device=like.device) for _ in range(2)]
+        return self._bufs
+
     def _new_history(self, curr, train_path):
         T = self.history_cat_num
         if train_path:
             return curr.detach().repeat(1, T, 1, 1, 1)                 # :234
         B, C, Z, Y, X = curr.shape
+        if self._voxel_major():
+            a, _ = self._frame_buffers_vm(curr, B, Z * Y * X)
+            a[:, :T].copy_(curr.detach().reshape(B, 1, C, -1).transpose(2, 3).expand(B, T, Z * Y * X, C))
+            return a[:, :T]
         a, _ = self._frame_buffers(curr, B, Z, Y, X)
         hist = a[:, :T * C]
         hist.view(B, T, C, Z, Y, X).copy_(curr.detach().unsqueeze(1).expand(B, T, C, Z, Y, X))
@@ -162,7 +207,7 @@ class TemporalHistoryFusion(nn.Module):
         """The reference's op sequence (:264-310) on this module's layers; the warp is the HIP kernel."""
         T, C = self.history_cat_num, self.single_bev_num_channels
         B, _, Z, Y, X = curr.shape
-        hist = self.history_bev.float()                                # the autograd path is fp32 (the ring may be 16-bit)
+        hist = self.history_as_reference()                             # the autograd path is planar fp32 (the ring may be neither)
         if hist.stride()[1:] != (Z * Y * X, Y * X, X, 1):
             hist = hist.contiguous()
         sampled = _capi.history_warp(hist, flow, torch.empty((B, T * C, Z, Y, X), dtype=torch.float32, device=curr.device))
@@ -174,12 +219,42 @@ class TemporalHistoryFusion(nn.Module):
         out = self.history_keyframe_cat_conv(f.reshape(B, -1, Z, Y, X))                                      # :308-310
         return out, feats_cat
 
+    def _fuse_infer_vm(self, curr_yxz, flow, sweep):
+        """_fuse_infer on the voxel-major ring; curr_yxz is the (B, C, Y, X, Z) volume as handed over (not permuted)."""
+        T, C = self.history_cat_num, self.single_bev_num_channels
+        B, _, Y, X, Z = curr_yxz.shape
+        n = Z * Y * X
+        hist = self.history_bev
+        if hist.dim() == 5:                                            # planar history (training path, or the mode changed)
+            hist = hist.reshape(B, T, C, n)
+            a, b = self._frame_buffers_vm(curr_yxz, B, n)
+            a[:, :T].copy_(hist.transpose(2, 3))
+            hist, nxt = a[:, :T], b
+        else:
+            a, b = self._frame_buffers_vm(curr_yxz, B, n)
+            if hist.dtype != self.history_dtype:                       # the storage type was changed between frames
+                hist = hist.to(self.history_dtype)
+            nxt = b if hist.data_ptr() == a.data_ptr() else a
+        _capi.history_frame_vm(curr_yxz.contiguous().view(B, C, n), nxt[:, 0], inner=Z)     # slot 0 = current frame (:286)
+        _capi.history_warp_vm(hist, flow, nxt[:, 1:], (Z, Y, X))                            # slots 1..T (:275)
+        w1, b1 = self._folded(self.history_keyframe_time_conv)
+        w2, b2 = self._folded(self.history_keyframe_cat_conv)
+        tau = (sweep * self.history_cam_sweep_freq).reshape(B * (T + 1), 1)
+        bias1 = b1[None, :] + tau * w1[None, :, C]
+        out = _capi.history_conv(nxt, w1[:, :C].contiguous(), bias1.contiguous(), w2.contiguous(), b2.contiguous(),
+                                 torch.empty((B, w2.shape[0], n), dtype=torch.float32, device=curr_yxz.device),
+                                 compute=torch.bfloat16, voxel_major=True)
+        return out.view(B, -1, Z, Y, X), nxt
+
     def _fuse_infer(self, curr, flow, sweep):
         T, C = self.history_cat_num, self.single_bev_num_channels
         B, _, Z, Y, X = curr.shape
         n = Z * Y * X
-        a, b = self._frame_buffers(curr, B, Z, Y, X)
         hist = self.history_bev
+        if hist.dim() == 4:                                            # voxel-major history, planar mode now
+            hist = self.history_as_reference()
+            self._bufs = None
+        a, b = self._frame_buffers(curr, B, Z, Y, X)
         nxt = b if hist.data_ptr() == a.data_ptr() else a              # the buffer the history does NOT live in
         if hist.data_ptr() not in (a.data_ptr(), b.data_ptr()):        # history came from the training path
             a[:, :T * C].copy_(hist)

@@ -415,10 +415,27 @@ int fbbev_history_conv_e(const void* feats, long long feats_stride_b, const floa
  * weights, the frames (exact for a bf16 ring) and the ReLU'd intermediate are rounded to bf16; biases, accumulators
  * and `out` stay fp32.  Opt-in reduced precision -- the reference pins these convolutions to fp32 (fbocc.py:279-282) while
  * BASELINE configs[4] names fp16 for the path; at 400x400x16 the fp32-MFMA kernel is compute bound.  C = Cout in {16, 80};
- * workspace >= (1 + T1) * C * 96 * 2 bytes (bf16 weight fragments), 16-byte aligned. */
+ * workspace >= (1 + T1) * C * 96 * 2 bytes (bf16 weight fragments), 16-byte aligned.  voxel_major = 1: feats is
+ * (B, T1, N, C) (below) instead of (B, T1*C, N). */
 int fbbev_history_conv_bf16(const void* feats, long long feats_stride_b, const float* w1, const float* bias1,
                             const float* w2, const float* bias2, int B, int T1, int C, int Cout, int N, float* out,
-                            void* workspace, size_t workspace_bytes, int elem_type, fbbev_stream_t stream);
+                            void* workspace, size_t workspace_bytes, int voxel_major, int elem_type, fbbev_stream_t stream);
+
+/* ---- voxel-major history ring (opt-in layout of the inference ring; the reference's is (B, T*C, Z, Y, X), fbocc.py:234)
+ * A frame is [voxel n = (z*Y + y)*X + x][channel]: the C elements of a voxel are contiguous, so a trilinear tap is a
+ * 16-byte load of 8 (16-bit) / 4 (fp32) channels instead of one 2- / 4-byte gather per channel plane, and
+ * fbbev_history_conv_bf16(voxel_major = 1) reads its operands as rows.  Element values are bit-identical to the planar
+ * kernels'; only the addresses differ.  C % 8 == 0 (16-bit) or C % 4 == 0 (fp32); strides (elements) likewise; pointers
+ * 16-byte aligned.
+ *   fbbev_history_warp_vm : history (B, T, N, C) -> out (B, T, N, C), F.grid_sample(history, generate_grid(rt_flow)) of
+ *                           fbocc.py:264-275 per frame; strides are per sample, 0 = dense.
+ *   fbbev_history_frame_vm: curr (B, C, N) fp32 planes -> out[b] (N, C): slot 0 of the ring (fbocc.py:286 cat).
+ *                           inner = 1: plane position = row; inner = Z: the planes are (Y, X, Z) volumes as the view
+ *                           transformation returns them (fbocc.py:212 permutes to (Z, Y, X) first), rows are z-major. */
+int fbbev_history_warp_vm(const void* history, long long history_stride_b, const float* rt_flow, int B, int T, int C, int Z,
+                          int Y, int X, void* out, long long out_stride_b, int elem_type, fbbev_stream_t stream);
+int fbbev_history_frame_vm(const float* curr, int B, int C, int N, int inner, void* out, long long out_stride_b,
+                           int elem_type, fbbev_stream_t stream);
 
 /* Dense 3-D convolution on NDHWC (torch channels_last_3d) f32 activations as an fp32-MFMA implicit GEMM, inference:
  * replaces the eval-mode Conv3d (+ folded BatchNorm) (+ residual) (+ ReLU) groups of CustomResNet3D (resnet3d.py:19-43,

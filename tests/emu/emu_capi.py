@@ -253,14 +253,42 @@ def da_cross_attn_bwd(value, ss, ls, pred_depth, ref_cam, mask, qdepth, offsets,
     return gv, gd, go, ga
 
 
-def history_conv(feats, w1, bias1, w2, bias2, bf16=False):
-    B, TC, N = feats.shape
+def history_conv(feats, w1, bias1, w2, bias2, bf16=False, voxel_major=False):
     C, Cout = w1.shape[0], w2.shape[0]
+    if voxel_major:
+        B, T1, N, _ = feats.shape
+    else:
+        B, TC, N = feats.shape
+        T1 = TC // C
     out = torch.full((B, Cout, N), float('nan'))
-    ws = torch.zeros((1 + TC // C) * C * max(C, Cout, 96))
+    ws = torch.zeros((1 + T1) * C * max(C, Cout, 96))
     et = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[feats.dtype]
-    ok(getattr(lib(), 'fbbev_history_conv_bf16' if bf16 else 'fbbev_history_conv_e')(c_void_p(feats.data_ptr()), feats.stride(0), p(w1), p(bias1), p(w2), p(bias2), B, TC // C, C,
-                                  Cout, N, p(out), p(ws), ws.numel() * 4, et, None))
+    args = (c_void_p(feats.data_ptr()), feats.stride(0), p(w1), p(bias1), p(w2), p(bias2), B, T1, C, Cout, N, p(out), p(ws),
+            ws.numel() * 4)
+    if bf16:
+        ok(lib().fbbev_history_conv_bf16(*args, 1 if voxel_major else 0, et, None))
+    else:
+        ok(lib().fbbev_history_conv_e(*args, et, None))
+    return out
+
+
+def history_warp_vm(history, flow, grid_zyx, out=None):
+    B, T, N, C = history.shape
+    Z, Y, X = grid_zyx
+    if out is None:
+        out = torch.full((B, T, N, C), float('nan'), dtype=history.dtype)
+    et = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[history.dtype]
+    ok(lib().fbbev_history_warp_vm(c_void_p(history.data_ptr()), history.stride(0), p(flow), B, T, C, Z, Y, X,
+                                   c_void_p(out.data_ptr()), out.stride(0), et, None))
+    return out
+
+
+def history_frame_vm(curr, dtype, out=None, inner=1):
+    B, C, N = curr.shape
+    if out is None:
+        out = torch.full((B, N, C), float('nan'), dtype=dtype)
+    et = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[dtype]
+    ok(lib().fbbev_history_frame_vm(p(curr), B, C, N, inner, c_void_p(out.data_ptr()), out.stride(0), et, None))
     return out
 
 

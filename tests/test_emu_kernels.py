@@ -735,6 +735,52 @@ def test_history_warp_and_conv_16bit_storage_emulated(dt):
     assert torch.equal(E.history_conv(feats, w1, b1, w2, b2), E.history_conv(feats.float(), w1, b1, w2, b2))
 
 
+@pytest.mark.parametrize('dt', [torch.float32, torch.float16, torch.bfloat16])
+def test_history_voxel_major_ring_equals_planar_kernels_emulated(dt):
+    """The voxel-major ring ([T][N][C] frames): fbbev_history_frame_vm is the rounded transpose of a frame,
+    fbbev_history_warp_vm produces the planar kernel's elements bit for bit (translation, rotation, out-of-grid, NaN flow;
+    padded batch stride; an odd frame count for the two-frames-per-thread loop), and fbbev_history_conv_bf16 reads either
+    layout to the same bits."""
+    g = torch.Generator().manual_seed(11)
+    B, T, C, Z, Y, X = 4, 3, 16, 3, 7, 9
+    N = Z * Y * X
+    planar = (torch.randn(B, T * C, Z, Y, X, generator=g) * 2).to(dt)
+    flow = torch.eye(4)[None].repeat(B, 1, 1)
+    flow[0, :3, 3] = torch.tensor([1.25, -0.5, 0.25])
+    flow[1, :3, :3] = torch.tensor([[0.9, -0.4, 0.0], [0.4, 0.9, 0.0], [0.0, 0.0, 1.0]])
+    flow[2, :3, 3] = torch.tensor([50.0, 0.0, 0.0])                          # leaves the grid: zero padding
+    flow[3, 0, 0] = float('nan')
+    exp = E.history_warp(planar, flow)                                       # (B, T*C, Z, Y, X)
+    big = torch.full((B, T + 1, N, C), float('nan'), dtype=dt)               # ring with a spare slot: padded batch stride
+    big[:, :T] = planar.view(B, T, C, N).transpose(2, 3)
+    out = torch.full((B, T + 1, N, C), float('nan'), dtype=dt)
+    E.history_warp_vm(big[:, :T], flow, (Z, Y, X), out=out[:, 1:])
+    got = out[:, 1:].transpose(2, 3).reshape(B, T * C, Z, Y, X)
+    bits = torch.int32 if dt == torch.float32 else torch.int16
+    assert torch.equal(got.contiguous().view(bits), exp.view(bits))
+    assert torch.isnan(out[:, 0].float()).all()                              # slot 0 untouched
+    # slot 0: the current frame, transposed and rounded once
+    curr = torch.randn(B, C, N, generator=g) * 3
+    curr[0, 0, :4] = torch.tensor([0.0, -0.0, 6.0e-5, 65000.0])
+    E.history_frame_vm(curr, dt, out=out[:, 0])
+    assert torch.equal(out[:, 0].contiguous().view(bits), curr.transpose(1, 2).to(dt).contiguous().view(bits))
+    N2 = 70                                                                   # a partial 64-voxel tile
+    c2 = torch.randn(2, 80, N2, generator=g)
+    assert torch.equal(E.history_frame_vm(c2, dt).view(bits), c2.transpose(1, 2).to(dt).contiguous().view(bits))
+    # a (Y, X, Z) volume -> (Z, Y, X)-ordered rows
+    vol = torch.randn(2, 16, 5, 7, 3, generator=g)                            # B, C, Y, X, Z
+    got = E.history_frame_vm(vol.view(2, 16, -1), dt, inner=3)
+    assert torch.equal(got.view(bits), vol.permute(0, 4, 2, 3, 1).reshape(2, -1, 16).to(dt).contiguous().view(bits))
+    # the convolutions read rows: same bits as from planes
+    for Cc, T1, n in ((16, 3, 70), (80, 2, 33)):
+        feats = torch.randn(2, T1, Cc, n, generator=g).to(dt)
+        w1, w2 = torch.randn(Cc, Cc, generator=g) * 0.3, torch.randn(Cc, T1 * Cc, generator=g) * 0.2
+        b1, b2 = torch.randn(2 * T1, Cc, generator=g), torch.randn(Cc, generator=g)
+        a = E.history_conv(feats.reshape(2, T1 * Cc, n), w1, b1, w2, b2, bf16=True)
+        b = E.history_conv(feats.transpose(2, 3).contiguous(), w1, b1, w2, b2, bf16=True, voxel_major=True)
+        assert not torch.isnan(a).any() and torch.equal(a, b)
+
+
 @pytest.mark.parametrize('dt', [torch.float32, torch.float16])
 def test_history_warp_lds_staged_equals_gather_kernel_emulated(dt, monkeypatch):
     """k_history_warp_lds (a brick's source box staged in LDS) == k_history_warp (8 global gathers per output), bit for bit:

@@ -245,6 +245,53 @@ def test_sequence_with_16bit_history_ring(dev, dt, tol):
     assert worst <= tol
 
 
+@pytest.mark.parametrize('dt', [torch.float16, torch.bfloat16, torch.float32])
+def test_voxel_major_ring_equals_planar_ring(dev, dt):
+    """ring_layout='voxel_major' ((B,T,N,C) rows; 16-byte taps; row-operand convolutions) against the planar ring of the same
+    module configuration (bf16-MFMA convolutions): fused output and stored history bit-identical over a sequence with a
+    restart, ego motion, a flipped bda -- and across a detour through the autograd path, which hands a planar fp32 history
+    back to either ring."""
+    from fb_bev_amd.history_fusion import TemporalHistoryFusion
+    B, C, T, Z, Y, X = 2, 16, 3, 4, 20, 24
+    dx, bx = [0.5, 0.5, 1.0], [-5.75, -4.75, -1.5]
+    torch.manual_seed(3)
+    mods = [TemporalHistoryFusion(dx, bx, single_bev_num_channels=C, history_cat_num=T, history_dtype=dt,
+                                  history_compute=torch.bfloat16, ring_layout=lay).to(dev).eval() for lay in ('planar', 'voxel_major')]
+    with torch.no_grad():
+        for seq in (mods[0].history_keyframe_time_conv, mods[0].history_keyframe_cat_conv):
+            seq[1].running_mean.normal_(0, 0.1); seq[1].running_var.uniform_(0.5, 1.5)
+    mods[1].load_state_dict(mods[0].state_dict())
+    assert mods[1]._voxel_major() and not mods[0]._voxel_major()
+    g = torch.Generator().manual_seed(5)
+    bits = torch.int32 if dt == torch.float32 else torch.int16
+    seqs = [[0, 1], [0, 1], [0, 7], [0, 7], [0, 7], [0, 7]]
+    starts = [[True, True], [False, False], [False, True], [False, False], [False, False], [False, False]]
+    for i in range(6):
+        curr = torch.randn(B, C, Y, X, Z, generator=g).to(dev)
+        ego = torch.eye(4).repeat(B, 1, 1)
+        ego[:, 0, 3] = torch.tensor([0.4 * i, -0.3]); ego[1, :2, :2] = torch.tensor([[0.98, -0.199], [0.199, 0.98]])
+        bda = torch.eye(3).repeat(B, 1, 1)
+        if i >= 3:
+            bda[0, 1, 1] = -1.0
+        metas = [dict(sequence_group_idx=seqs[i][b], start_of_sequence=starts[i][b], curr_to_prev_ego_rt=ego[b]) for b in range(B)]
+        outs = []
+        for m in mods:
+            if i == 4:                                                   # one frame through the autograd path
+                m.train()
+                outs.append(m.fuse_history(curr.clone().requires_grad_(True), metas, bda.to(dev)).detach())
+                m.eval()
+            else:
+                with torch.no_grad():
+                    outs.append(m.fuse_history(curr, metas, bda.to(dev)))
+        assert torch.equal(outs[0], outs[1]), i
+        h0, h1 = mods[0].history_bev, mods[1].history_bev
+        if i != 4:
+            assert h0.shape == (B, T * C, Z, Y, X) and h1.shape == (B, T, Z * Y * X, C) and h1.dtype == dt
+            assert torch.equal(h1.transpose(2, 3).reshape(B, T * C, Z, Y, X).contiguous().view(bits), h0.contiguous().view(bits)), i
+        assert torch.equal(mods[0].history_as_reference(), mods[1].history_as_reference()), i
+    assert outs[0].abs().max().item() > 0
+
+
 def test_baseline_config4_grid_16_frame_fp16_history(dev):
     """BASELINE configs[4] (stress): 400x400x16 grid, C=80, 16-frame history in fp16 = 7 GB per sample ring slot pair
     (13 GB in fp32).  Two frames through TemporalHistoryFusion at that size: (1) sequence start -- every history slot is

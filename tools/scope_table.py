@@ -139,14 +139,15 @@ def s6(n):
         return out
     with torch.no_grad():
         vt_ms = None
-        for comp, label in ((torch.float32, 'fp32 MFMA'), (torch.bfloat16, 'bf16 MFMA (fp32 accumulate)')):
-            hist.history_compute = comp
+        for comp, lay, label in ((torch.float32, 'planar', 'fp32 MFMA'), (torch.bfloat16, 'planar', 'bf16 MFMA (fp32 accumulate)'),
+                                 (torch.bfloat16, 'voxel_major', 'bf16 MFMA (fp32 accumulate)')):
+            hist.history_compute, hist.ring_layout = comp, lay
             hist.reset(); state['first'] = True
             frame()
             ms = pct(frame, n, warm=2)
             vt_ms = vt_ms or pct(lambda: m(cam, ctx, depth), n, warm=1)
             row('S6 BASELINE configs[4] path: lift-splat + backward projection + re-add + 16-frame history (fp16 ring)',
-                'BL5 (400x400x16, 6x512x1408)', 1, ms, history_convs=label, view_transformation_ms_p50=vt_ms[1],
+                'BL5 (400x400x16, 6x512x1408)', 1, ms, history_convs=label, ring_layout=lay, view_transformation_ms_p50=vt_ms[1],
                 history_ring_GB=round(hist.history_bev.numel() * 2 / 2 ** 30, 1),
                 peak_mem_GB=round(torch.cuda.max_memory_allocated() / 2 ** 30, 1))
     del m, hist

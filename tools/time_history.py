@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Temporal history fusion at FB-OCC sizes: fb_bev_amd.TemporalHistoryFusion (HIP warp + folded GEMMs) vs the
 reference's op sequence (fbocc.py:264-319: generate_grid, F.grid_sample, cats, Conv3d+BN+ReLU x2, clone) written in
-plain torch on the same GPU.   python tools/time_history.py [Y X Z] [B] [f32|f16|bf16] [noref] [cbf16]
+plain torch on the same GPU.   python tools/time_history.py [Y X Z] [B] [f32|f16|bf16] [noref] [cbf16] [vm]
 (f16 / bf16: the 16-bit history ring of BASELINE configs[4]; noref: skip the torch reference sequence; cbf16: the two
-convolutions on the bf16 MFMA, history_compute=bfloat16)"""
+convolutions on the bf16 MFMA, history_compute=bfloat16; vm: ring_layout=voxel_major, with cbf16)"""
 import json, os, sys
 import torch
 import torch.nn.functional as F
@@ -70,12 +70,13 @@ def main():
     dt = {'f32': torch.float32, 'f16': torch.float16, 'bf16': torch.bfloat16}[sys.argv[5] if len(sys.argv) >= 6 else 'f32']
     noref = 'noref' in sys.argv
     comp = torch.bfloat16 if 'cbf16' in sys.argv else torch.float32
+    lay = 'voxel_major' if 'vm' in sys.argv else 'planar'
     esz = 4 if dt == torch.float32 else 2
     dev = torch.device('cuda:0')
     torch.manual_seed(0)
     dxv = 80.0 / X
     m = TemporalHistoryFusion([dxv, dxv, 6.4 / Z], [-40 + dxv / 2, -40 + dxv / 2, -1 + 3.2 / Z], C, T, history_dtype=dt,
-                              history_compute=comp).to(dev).eval()
+                              history_compute=comp, ring_layout=lay).to(dev).eval()
     for seq in (m.history_keyframe_time_conv, m.history_keyframe_cat_conv):
         seq[1].running_var.uniform_(0.5, 1.5); seq[1].running_mean.uniform_(-0.2, 0.2)
     ref = TorchReference(m)
@@ -104,12 +105,15 @@ def main():
             r1 = ref.fuse(frames[0], ego_dev, bda, first=True); r1 = ref.fuse(frames[1], ego_dev, bda)
             m.reset(); o1 = m.fuse_history(frames[0], metas(True), bda); o1 = m.fuse_history(frames[1], metas(False), bda)
             err = (o1 - r1).abs().max().item()
-            herr = (m.history_bev.float() - ref.hist).abs().max().item()
+            herr = (m.history_as_reference() - ref.hist).abs().max().item()
             t_ref = timed(lambda i: ref.fuse(frames[i % 3], ego_dev, bda))
         # the warp alone
         from fb_bev_amd import _capi
         hist = m.history_bev; flow = m.rt_flow(ego_dev, bda); dst = torch.empty_like(hist)
-        t_warp = timed(lambda i: _capi.history_warp(hist, flow, dst))
+        if hist.dim() == 4:
+            t_warp = timed(lambda i: _capi.history_warp_vm(hist, flow, dst, (Z, Y, X)))
+        else:
+            t_warp = timed(lambda i: _capi.history_warp(hist, flow, dst))
         rel = None
         if comp != torch.float32:          # same frames through the fp32 convolutions: what the reduced precision costs
             m.history_compute = torch.float32; m.reset()
@@ -119,7 +123,7 @@ def main():
             rel = ((o3 - o2).abs().max() / o2.abs().max()).item()
     hist_bytes = B * T * C * Z * Y * X * esz
     print(json.dumps({'grid': [Y, X, Z], 'B': B, 'C': C, 'T': T, 'history_MB': round(hist_bytes / 1e6, 1),
-                      'history_dtype': str(dt).split('.')[-1], 'conv_compute': str(comp).split('.')[-1], 'fused_ms': round(t_hip, 4),
+                      'history_dtype': str(dt).split('.')[-1], 'conv_compute': str(comp).split('.')[-1], 'ring_layout': lay, 'fused_ms': round(t_hip, 4),
                       'torch_reference_sequence_ms': None if t_ref is None else round(t_ref, 4), 'speedup': None if t_ref is None else round(t_ref / t_hip, 2),
                       'warp_ms': round(t_warp, 4), 'warp_GBps_read_plus_write': round(2 * hist_bytes / t_warp / 1e6, 1),
                       'max_abs_diff_out': err, 'max_abs_diff_history': herr,
