@@ -1286,23 +1286,26 @@ extern "C" int fbbev_history_warp_vm(const void* history, long long history_stri
     if (C % VE != 0 || history_stride_b % VE != 0 || out_stride_b % VE != 0 || !aligned16(history) || !aligned16(out))
         return FBBEV_E_UNSUPPORTED;
     const int groups = C / VE;
-    const long long items = zyx * groups;
-    const int n_chunks = (int)((items + 255) / 256);
+    if (frame * (elem_type == 0 ? 4 : 2) >= (1ll << 32)) return FBBEV_E_UNSUPPORTED;      // 32-bit byte offsets inside a frame
+    const int n_xc = (X * groups + 255) / 256;                   // workgroups per grid row
+    int YB = 256 / Z;                                             // rows per band: a (z, y) slab of ~256 workgroups per x chunk
+    if (YB < 1) YB = 1;
+    if (YB > Y) YB = Y;
+    const int nyb = (Y + YB - 1) / YB;
     constexpr int TU = 2;
-    const int n_tg = (T + TU - 1) / TU;
-    const long long blocks = (long long)B * n_tg * n_chunks;
+    const long long blocks = (long long)B * nyb * n_xc * YB * Z;
     if (blocks >= (1ll << 31) - 8) return FBBEV_E_UNSUPPORTED;
     const int per_xcd = (int)((blocks + 7) / 8);
     fbbev_rt_stream stream = (fbbev_rt_stream)stream_;
     if (elem_type == 0)
         FBBEV_LAUNCH((k_history_warp_vm<0, TU>), (long long)per_xcd * 8, 256, 0, stream, history, history_stride_b, rt_flow, T, C,
-                     Z, Y, X, groups, n_tg, n_chunks, per_xcd, (int)blocks, out, out_stride_b);
+                     Z, Y, X, groups, n_xc, YB, nyb, per_xcd, (int)blocks, out, out_stride_b);
     else if (elem_type == 1)
         FBBEV_LAUNCH((k_history_warp_vm<1, TU>), (long long)per_xcd * 8, 256, 0, stream, history, history_stride_b, rt_flow, T, C,
-                     Z, Y, X, groups, n_tg, n_chunks, per_xcd, (int)blocks, out, out_stride_b);
+                     Z, Y, X, groups, n_xc, YB, nyb, per_xcd, (int)blocks, out, out_stride_b);
     else
         FBBEV_LAUNCH((k_history_warp_vm<2, TU>), (long long)per_xcd * 8, 256, 0, stream, history, history_stride_b, rt_flow, T, C,
-                     Z, Y, X, groups, n_tg, n_chunks, per_xcd, (int)blocks, out, out_stride_b);
+                     Z, Y, X, groups, n_xc, YB, nyb, per_xcd, (int)blocks, out, out_stride_b);
     FBBEV_CHECK_LAUNCH();
     return 0;
 }
@@ -1411,7 +1414,8 @@ static int history_conv_bf16_launch(const void* feats, long long feats_stride_b,
     unsigned short* w2f = w1f + (size_t)MT1 * KS * 64 * 8;
     const int nfrag = (MT1 * KS + T1 * MT2 * KS) * 64;
     FBBEV_LAUNCH(k_history_weight_fragments_bf16, (nfrag + 255) / 256, 256, 0, stream, w1, w2, MT1, MT2, C, T1, w1f);
-    const size_t lds = (size_t)4 * 16 * (KS * 32 + 8) * sizeof(unsigned short);
+    const size_t a2s = (size_t)((MT2 * KS * 64 + 255) / 256) * 256 * 8;                                 // padded staging buffer
+    const size_t lds = (2 * a2s + (size_t)4 * 16 * (KS * 32 + 8)) * sizeof(unsigned short);           // W2_t x 2 + Y rows
     if (C == 80)
         FBBEV_LAUNCH((k_history_conv_bf16<5, 5, ET, VM>), blocks, 256, lds, stream, feats, feats_stride_b,
                      (const unsigned short*)w1f, bias1, (const unsigned short*)w2f, bias2, T1, N, tiles_per_b, out);
@@ -1434,6 +1438,8 @@ extern "C" int fbbev_history_conv_bf16(const void* feats, long long feats_stride
     if (feats_stride_b == 0) feats_stride_b = (long long)T1 * C * N;
     if (feats_stride_b < (long long)T1 * C * N) return FBBEV_E_BADARG;
     if (voxel_major && (!aligned16(feats) || feats_stride_b % 8 != 0)) return FBBEV_E_UNSUPPORTED;   // 16-byte row pieces
+    if (!aligned16(bias1)) return FBBEV_E_UNSUPPORTED;                                              // 16-byte bias loads
+    if (voxel_major && (long long)N * C * (elem_type == 0 ? 4 : 2) >= (1ll << 32)) return FBBEV_E_UNSUPPORTED;   // 32-bit byte offsets in a frame
     fbbev_rt_stream stream = (fbbev_rt_stream)stream_;
 #define FBBEV_HCB(ET_, VM_) history_conv_bf16_launch<ET_, VM_>(feats, feats_stride_b, w1, bias1, w2, bias2, B, T1, C, Cout, N, out, workspace, workspace_bytes, stream)
     if (voxel_major) return elem_type == 0 ? FBBEV_HCB(0, true) : elem_type == 1 ? FBBEV_HCB(1, true) : FBBEV_HCB(2, true);

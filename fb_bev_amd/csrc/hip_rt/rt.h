@@ -74,6 +74,25 @@ __device__ __forceinline__ float fbbev_f16_bits_to_f32(unsigned int h) {
     return (float)x;
 }
 
+// two floats -> one packed pair of 16-bit elements (lo in bits 0..15), round to nearest even, by the conversion
+// instructions (ET 1: bf16, v_cvt_pk_bf16_f32; ET 2: f16, v_cvt_f16_f32 -- half subnormals kept, overflow -> inf).  The same
+// bits as the integer-only fbbev_pack2 (pool_kernels.h) for every non-NaN input (tested on the GPU against it); NaNs come
+// out quiet with the instruction's payload.
+template <int ET>
+__device__ __forceinline__ unsigned int fbbev_cvt_pk16(float lo, float hi) {
+    unsigned int u;
+    if constexpr (ET == 1) {
+        typedef __bf16 pair __attribute__((ext_vector_type(2)));
+        const pair r = {(__bf16)lo, (__bf16)hi};
+        __builtin_memcpy(&u, &r, 4);
+    } else {
+        typedef _Float16 pair __attribute__((ext_vector_type(2)));
+        const pair r = {(_Float16)lo, (_Float16)hi};
+        __builtin_memcpy(&u, &r, 4);
+    }
+    return u;
+}
+
 // v_mfma_f32_16x16x4_f32: D(16x16) = A(16x4) . B(4x16) + C, exact fp32 (a k-ordered fmaf chain per element).
 // A: lane holds A[lane%16][lane/16]; B: lane holds B[lane/16][lane%16]; register r of C/D: row 4*(lane/16)+r, col lane%16.
 __device__ __forceinline__ fbbev_v4f fbbev_mfma_f32_16x16x4(float a, float b, fbbev_v4f c) {

@@ -199,22 +199,37 @@ k_history_weight_fragments(const float* __restrict__ w1, const float* __restrict
 // the output stay fp32.  Channels are padded to a multiple of 32 with zeros (C = 80 -> 3 k-steps).
 // Operand slots: lane (j = lane % 16, g = lane / 16), element e of k-step s stands for channel 32 s + 8 g + e in A and B
 // alike (the instruction only needs the two to agree).
+template <int V> struct fbbev_ic { static constexpr int value = V; };
+
 // VM: the frames are voxel-major ([T1][N][C] per sample, history_kernels.h): a lane's 8 channels of a k-step are one 16-byte
-// row piece (two for an fp32 ring), and for a bf16 ring that piece IS the MFMA operand.
+// row piece (two for an fp32 ring), and for a bf16 ring that piece IS the MFMA operand; three frames of X are kept in
+// flight (12 registers each in 16 bits) -- with 8 waves per CU one frame ahead is 20 KB per CU in flight, 2.5 TB/s at
+// HBM latency.
+// W2_t (15 KB of fragments per frame at C = 80) is the same for the four waves of a workgroup: it is staged through LDS
+// (double-buffered, one barrier per frame: global -> registers before GEMM 1, registers -> LDS after GEMM 2) instead of
+// every wave pulling its own copy through the vector L1 -- 6x the bytes of X itself.
 template <int MT1, int MT2, int ET, bool VM>
 __global__ void __launch_bounds__(256, 2)
 k_history_conv_bf16(const void* __restrict__ feats, long long fstride_b, const unsigned short* __restrict__ w1f,
                     const float* __restrict__ bias1, const unsigned short* __restrict__ w2f, const float* __restrict__ bias2,
                     int T1, int N, int tiles_per_b, float* __restrict__ out) {
     constexpr int C = 16 * MT1, Cout = 16 * MT2, KS = (C + 31) / 32, CP = KS * 32, PITCH = CP + 8;   // 16-byte aligned rows
-    unsigned short* lds = reinterpret_cast<unsigned short*>(fbbev_dyn_lds_f32());     // [4 waves][16 voxels][PITCH] bf16
+    constexpr int A2 = MT2 * KS * 64 * 8;                 // bf16 elements of one frame's W2 fragments
+    constexpr int A2P = (A2 / 8 + 255) / 256;             // 16-byte pieces of them per thread
+    constexpr int A2S = A2P * 256 * 8;                    // elements of a staging buffer (padded: every thread stores A2P pieces)
+    constexpr int PF = VM ? 3 : 1;                        // frames of X in flight
+    constexpr int NV = (VM && ET == 0) ? 2 : 1;
+    unsigned short* lds = reinterpret_cast<unsigned short*>(fbbev_dyn_lds_f32());
+    unsigned short* a2buf = lds;                          // [2][A2S]; then [4 waves][16 voxels][PITCH] bf16
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int g = lane >> 4, j = lane & 15;
     const int b = blockIdx.x / tiles_per_b, tile = blockIdx.x - b * tiles_per_b;
     const int n = tile * 64 + wave * 16 + j;
     const bool inb = n < N;
-    unsigned short* yrow = lds + (wave * 16 + j) * PITCH;
+    unsigned short* yrow = lds + 2 * A2S + (wave * 16 + j) * PITCH;
     for (int c = C + g; c < CP; c += 4) yrow[c] = 0;                       // padding channels of the intermediate
+    for (int i = threadIdx.x; i < A2 / 8; i += 256)                         // W2_0
+        reinterpret_cast<fbbev_v4u*>(a2buf)[i] = reinterpret_cast<const fbbev_v4u*>(w2f)[i];
     const long long xb = (long long)b * fstride_b;
     fbbev_bf16x8 a1[MT1][KS];
 #pragma unroll
@@ -226,26 +241,27 @@ k_history_conv_bf16(const void* __restrict__ feats, long long fstride_b, const u
     for (int mt = 0; mt < MT2; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc2[mt][r] = bias2[16 * mt + 4 * g + r];
-    // X operands stay RAW in registers (the prefetch of frame t+1 must not be followed by a conversion that waits for it)
+    // X operands stay RAW in registers (a prefetch must not be followed by a conversion that waits for it)
     unsigned int bx[VM ? 1 : KS][VM ? 1 : 8];
-    fbbev_v4u bv[VM ? KS : 1][(VM && ET == 0) ? 2 : 1];
-    auto load_x = [&](long long base) {
+    fbbev_v4u bv[VM ? PF : 1][VM ? KS : 1][NV];
+    // unconditional loads from uniform frame base + a 32-bit lane byte offset that is 0 for an out-of-range voxel / padding
+    // piece (selected once, as an offset: a select between addresses becomes a branch around the load); the zero itself is
+    // selected at the point of use -- a select right behind the load would make the prefetch wait for its own data
+    constexpr int ESZ = ET == 0 ? 4 : 2;
+    unsigned int xoff[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int c = 32 * s + 8 * g;
+        xoff[s] = (inb && c < C) ? (unsigned int)(((long long)n * C + c) * ESZ) : 0u;      // C % 8 == 0: a piece is all in or all out
+    }
+    auto load_x = [&](int slot, long long base) {
         if constexpr (VM) {
-            const fbbev_v4u zero = {0u, 0u, 0u, 0u};
+            const char* fb = static_cast<const char*>(feats) + base * ESZ;
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                const int c = 32 * s + 8 * g;
-                const bool ok = inb && c < C;                                  // C % 8 == 0: a piece is all in or all out
-                const long long e = ok ? base + (long long)n * C + c : xb;     // clamped address, select below: no branch
-                if constexpr (ET == 0) {
-                    const fbbev_v4u* p4 = reinterpret_cast<const fbbev_v4u*>(static_cast<const float*>(feats) + e);
-                    const fbbev_v4u lo = p4[0], hi = p4[1];
-                    bv[s][0] = ok ? lo : zero;
-                    bv[s][1] = ok ? hi : zero;
-                } else {
-                    const fbbev_v4u q = *reinterpret_cast<const fbbev_v4u*>(static_cast<const unsigned short*>(feats) + e);
-                    bv[s][0] = ok ? q : zero;
-                }
+                const fbbev_v4u* p4 = reinterpret_cast<const fbbev_v4u*>(fb + xoff[s]);
+                bv[slot][s][0] = p4[0];
+                if constexpr (ET == 0) bv[slot][s][NV - 1] = p4[1];
             }
         } else {
 #pragma unroll
@@ -257,67 +273,103 @@ k_history_conv_bf16(const void* __restrict__ feats, long long fstride_b, const u
                 }
         }
     };
-    auto x_operand = [&](int s) {
+    auto x_operand = [&](int sl, int s) {                       // sl: the slot frame t lives in (compile-time after unrolling)
+        const fbbev_bf16x8 zero8 = fbbev_cvt_bf16x8(fbbev_v4f{0.f, 0.f, 0.f, 0.f}, fbbev_v4f{0.f, 0.f, 0.f, 0.f});
+        const bool ok = inb && 32 * s + 8 * g < C;
         if constexpr (VM && ET == 1) {
             fbbev_bf16x8 r;
-            __builtin_memcpy(&r, &bv[s][0], 16);                // a bf16 ring row piece is the operand
-            return r;
+            __builtin_memcpy(&r, &bv[sl][s][0], 16);             // a bf16 ring row piece is the operand
+            return ok ? r : zero8;
         } else {
             fbbev_v4f lo, hi;
             if constexpr (VM && ET == 0) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { lo[e] = fbbev_widen<0>(bv[s][0][e]); hi[e] = fbbev_widen<0>(bv[s][1][e]); }
+                for (int e = 0; e < 4; ++e) { lo[e] = fbbev_widen<0>(bv[sl][s][0][e]); hi[e] = fbbev_widen<0>(bv[sl][s][NV - 1][e]); }
             } else if constexpr (VM) {
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
-                    lo[2 * e] = fbbev_widen<ET>(bv[s][0][e] & 0xffffu);     lo[2 * e + 1] = fbbev_widen<ET>(bv[s][0][e] >> 16);
-                    hi[2 * e] = fbbev_widen<ET>(bv[s][0][2 + e] & 0xffffu); hi[2 * e + 1] = fbbev_widen<ET>(bv[s][0][2 + e] >> 16);
+                    lo[2 * e] = fbbev_widen<ET>(bv[sl][s][0][e] & 0xffffu);     lo[2 * e + 1] = fbbev_widen<ET>(bv[sl][s][0][e] >> 16);
+                    hi[2 * e] = fbbev_widen<ET>(bv[sl][s][0][2 + e] & 0xffffu); hi[2 * e + 1] = fbbev_widen<ET>(bv[sl][s][0][2 + e] >> 16);
                 }
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { lo[e] = fbbev_widen<ET>(bx[s][e]); hi[e] = fbbev_widen<ET>(bx[s][4 + e]); }
             }
-            return fbbev_cvt_bf16x8(lo, hi);                    // exact for a bf16 ring
+            const fbbev_bf16x8 r = fbbev_cvt_bf16x8(lo, hi);    // exact for a bf16 ring
+            if constexpr (VM) return ok ? r : zero8;
+            else return r;
         }
     };
-    load_x(xb);
-    for (int t = 0; t < T1; ++t) {
+    const long long fsz = (long long)C * N;                     // elements of a frame (either layout)
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+        if (u < T1) load_x(u, xb + (long long)u * fsz);
+    // one frame; SL = the register slot its X lives in.  The slots are a ring indexed at compile time (the frame loop is
+    // unrolled PF times): moving in-flight registers from slot to slot would wait for their loads.
+    auto frame = [&](int t, auto slot_c) {
+        constexpr int SL = decltype(slot_c)::value;
+        __syncthreads();                                        // W2_t is in a2buf[t & 1]; a2buf[(t + 1) & 1] is free again
         const float* b1 = bias1 + ((long long)b * T1 + t) * C;
-        const unsigned short* w2t = w2f + (long long)t * MT2 * KS * 64 * 8;
-        fbbev_bf16x8 a2[MT2][KS];
+        // loads below are unconditional (clamped frame index at the tail): a load under a branch makes the wait counts after
+        // the join assume it was NOT issued, i.e. wait for everything
+        fbbev_v4u wst[A2P];
+        {
+            const fbbev_v4u* wn = reinterpret_cast<const fbbev_v4u*>(w2f + (long long)(t + 1 < T1 ? t + 1 : t) * A2);
 #pragma unroll
-        for (int mt = 0; mt < MT2; ++mt)
+            for (int q = 0; q < A2P; ++q) {
+                const int i = threadIdx.x + 256 * q;
+                wst[q] = wn[i < A2 / 8 ? i : 0];
+            }
+        }
+        fbbev_sched_fence();
+        // bias_1 of the frame: loaded now, added to the finished accumulator (its latency hides behind GEMM 1)
+        fbbev_v4f bia[MT1], acc1[MT1];
 #pragma unroll
-            for (int s = 0; s < KS; ++s) a2[mt][s] = fbbev_ld_bf16x8(w2t + ((mt * KS + s) * 64 + lane) * 8);
-        fbbev_v4f acc1[MT1];
-#pragma unroll
-        for (int mt = 0; mt < MT1; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc1[mt][r] = b1[16 * mt + 4 * g + r];
+        for (int mt = 0; mt < MT1; ++mt) {
+            bia[mt] = *reinterpret_cast<const fbbev_v4f*>(b1 + 16 * mt + 4 * g);
+            acc1[mt] = fbbev_v4f{0.f, 0.f, 0.f, 0.f};
+        }
+        fbbev_sched_fence();                                    // ... and issued BEFORE the X prefetch below (vmcnt is in order)
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            const fbbev_bf16x8 xo = x_operand(s);
+            const fbbev_bf16x8 xo = x_operand(SL, s);
 #pragma unroll
             for (int mt = 0; mt < MT1; ++mt) acc1[mt] = fbbev_mfma_f32_16x16x32_bf16(a1[mt][s], xo, acc1[mt]);
         }
-        if (t + 1 < T1) load_x(xb + (long long)(t + 1) * C * N);           // next frame: in flight during GEMM 2
-        fbbev_wave_sync();                                                  // the LDS rows are wave-private
+        fbbev_sched_fence();
+        load_x(SL, xb + (long long)(t + PF < T1 ? t + PF : T1 - 1) * fsz);  // the slot just consumed takes frame t + PF
+        fbbev_sched_fence();
+        fbbev_wave_sync();                                                  // the Y rows are wave-private
 #pragma unroll
         for (int mt = 0; mt < MT1; ++mt) {
             // rows 16 mt + 4 g + r of voxel j = 4 consecutive channels of this lane's voxel row: one 8-byte store
-            const fbbev_v4f y = {fmaxf(acc1[mt][0], 0.f), fmaxf(acc1[mt][1], 0.f), fmaxf(acc1[mt][2], 0.f), fmaxf(acc1[mt][3], 0.f)};
+            const fbbev_v4f y = {fmaxf(acc1[mt][0] + bia[mt][0], 0.f), fmaxf(acc1[mt][1] + bia[mt][1], 0.f),
+                                 fmaxf(acc1[mt][2] + bia[mt][2], 0.f), fmaxf(acc1[mt][3] + bia[mt][3], 0.f)};
             const fbbev_bf16x8 pk = fbbev_cvt_bf16x8(y, y);
             unsigned long long four;
             __builtin_memcpy(&four, &pk, 8);
             *reinterpret_cast<unsigned long long*>(yrow + 16 * mt + 4 * g) = four;
         }
         fbbev_wave_sync();
+        const unsigned short* a2t = a2buf + (t & 1) * A2S;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const fbbev_bf16x8 yo = fbbev_ld_bf16x8(yrow + 32 * s + 8 * g);   // channels 32 s + 8 g .. + 7 of voxel j
 #pragma unroll
-            for (int mt = 0; mt < MT2; ++mt) acc2[mt] = fbbev_mfma_f32_16x16x32_bf16(a2[mt][s], yo, acc2[mt]);
+            for (int mt = 0; mt < MT2; ++mt)
+                acc2[mt] = fbbev_mfma_f32_16x16x32_bf16(fbbev_ld_bf16x8(a2t + ((mt * KS + s) * 64 + lane) * 8), yo, acc2[mt]);
         }
+        {   // unconditional (a use under a branch lets the compiler sink the loads down to it): the last frame stores a copy
+            // of its own W2 into the idle buffer, the padding pieces take piece 0
+            fbbev_v4u* wd = reinterpret_cast<fbbev_v4u*>(a2buf + ((t + 1) & 1) * A2S);
+#pragma unroll
+            for (int q = 0; q < A2P; ++q) wd[threadIdx.x + 256 * q] = wst[q];
+        }
+    };
+    for (int t = 0; t < T1; t += PF) {
+        frame(t, fbbev_ic<0>{});
+        if constexpr (PF > 1) { if (t + 1 < T1) frame(t + 1, fbbev_ic<(PF > 1 ? 1 : 0)>{}); }
+        if constexpr (PF > 2) { if (t + 2 < T1) frame(t + 2, fbbev_ic<(PF > 2 ? 2 : 0)>{}); }
     }
     if (inb) {
         float* ob = out + (long long)b * Cout * N + n;

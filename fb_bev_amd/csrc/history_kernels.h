@@ -191,28 +191,37 @@ __device__ __forceinline__ fbbev_v4u fbbev_narrow_vec(const float* f) {         
         for (int e = 0; e < 4; ++e) { unsigned int u; __builtin_memcpy(&u, &f[e], 4); r[e] = u; }
     } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) r[e] = fbbev_pack2<ET>(f[2 * e], f[2 * e + 1]);
+        for (int e = 0; e < 4; ++e) r[e] = fbbev_cvt_pk16<ET>(f[2 * e], f[2 * e + 1]);      // rt.h: the conversion instructions
     }
     return r;
 }
 
-// work item = ((b * n_tg) + frame group) * n_chunks + chunk; a chunk = 256 (voxel, channel group) pairs, group fastest
+// A workgroup = 256 (voxel, channel group) pairs of ONE grid row (x, group fastest: 25.6 voxels at C = 80 in 16 bits); a
+// thread walks the T frames of its sample TU at a time (the flow, hence the taps, is the sample's: set up once): uniform
+// frame base + 32-bit lane byte offsets, 8 TU loads in flight.
+// Workgroup order: z fastest, then y inside a band of YB rows, then the x chunk, then the band, then the sample -- the ~256
+// workgroups an XCD runs at a time form a (z, y) slab, so the y+1 and z+1 taps of one workgroup are the x-row of another
+// one in flight on the same L2 (in flattened voxel order the z neighbour is 6250 workgroups away at 400x400 and every tap
+// plane came from HBM again: 2.9x the algorithmic reads, profiles/r02_pmc_history_vm.json).
 template <int ET, int TU>
 __global__ void __launch_bounds__(256)
 k_history_warp_vm(const void* __restrict__ hist, long long hist_stride_b, const float* __restrict__ flow, int T, int C,
-                  int Z, int Y, int X, int groups, int n_tg, int n_chunks, int per_xcd, int n_work,
+                  int Z, int Y, int X, int groups, int n_xc, int YB, int nyb, int per_xcd, int n_work,
                   void* __restrict__ out, long long out_stride_b) {
     constexpr int VE = ET == 0 ? 4 : 8;
-    const int work = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);      // one contiguous eighth per XCD
+    constexpr int ESZ = ET == 0 ? 4 : 2;
+    int work = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);            // one contiguous eighth per XCD
     if ((int)(blockIdx.x >> 3) >= per_xcd || work >= n_work) return;
-    const int chunk = work % n_chunks;
-    const int bt = work / n_chunks;
-    const int tg = bt % n_tg, b = bt / n_tg;
+    const int z = work % Z; work /= Z;
+    const int yl = work % YB; work /= YB;
+    const int xc = work % n_xc; work /= n_xc;
+    const int yb = work % nyb, b = work / nyb;
+    const int y = yb * YB + yl;
+    const int item = xc * 256 + (int)threadIdx.x;
+    const int x = item / groups, gq = item - x * groups;
+    if (y >= Y || x >= X) return;
     const int YX = Y * X, ZYX = Z * YX;
-    const long long item = (long long)chunk * 256 + threadIdx.x;
-    if (item >= (long long)ZYX * groups) return;
-    const int v = (int)(item / groups), gq = (int)(item - (long long)v * groups);
-    const int z = v / YX, r = v - z * YX, y = r / X, x = r - y * X;
+    const int v = (z * Y + y) * X + x;
     const float* m = flow + b * 16;
     const float fx = (float)x, fy = (float)y, fz = (float)z;
     // source coordinate and taps: EXACTLY the expression sequence of k_history_warp
@@ -230,42 +239,44 @@ k_history_warp_vm(const void* __restrict__ hist, long long hist_stride_b, const 
     const float wx0 = (x0f + 1.f) - ix, wy0 = (y0f + 1.f) - iy, wz0 = (z0f + 1.f) - iz;
     const bool fin = (fabsf(ix) < 1.0e9f) && (fabsf(iy) < 1.0e9f) && (fabsf(iz) < 1.0e9f);
     const int x0 = fin ? (int)x0f : -2, y0 = fin ? (int)y0f : -2, z0 = fin ? (int)z0f : -2;
-    long long off[8];                                   // element offset of the tap's channel group inside a frame
+    unsigned int ob[8];                                 // byte offset of the tap's channel group inside a frame (< 4 GiB: checked)
     float w[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int cx = x0 + (k & 1), cy = y0 + ((k >> 1) & 1), cz = z0 + (k >> 2);
         const bool ok = cx >= 0 && cx < X && cy >= 0 && cy < Y && cz >= 0 && cz < Z;
         const float wk = ((k & 1) ? wx1 : wx0) * (((k >> 1) & 1) ? wy1 : wy0) * ((k >> 2) ? wz1 : wz0);
-        off[k] = (long long)(ok ? (cz * Y + cy) * X + cx : 0) * C + gq * VE;
+        const unsigned int tv = ok ? (unsigned int)((cz * Y + cy) * X + cx) : 0u;
+        ob[k] = (tv * (unsigned int)C + (unsigned int)(gq * VE)) * ESZ;
         w[k] = ok ? wk : 0.f;
     }
-    const long long frame = (long long)ZYX * C;
-    const int t0 = tg * TU;
-    const fbbev_v4u* src = reinterpret_cast<const fbbev_v4u*>(hist);       // offsets below are multiples of VE elements = 16 bytes
-    fbbev_v4u* dst = reinterpret_cast<fbbev_v4u*>(out);
-    fbbev_v4u raw[TU][8];
+    const size_t frame_bytes = (size_t)ZYX * C * ESZ;
+    const char* src = static_cast<const char*>(hist) + (size_t)b * hist_stride_b * ESZ;
+    char* dst = static_cast<char*>(out) + (size_t)b * out_stride_b * ESZ + ((size_t)v * C + gq * VE) * ESZ;
+    for (int t0 = 0; t0 < T; t0 += TU) {
+        fbbev_v4u raw[TU][8];
 #pragma unroll
-    for (int u = 0; u < TU; ++u) {
-        const int t = t0 + u < T ? t0 + u : T - 1;                         // clamped: the tail repeats the last frame's loads
-        const long long fo = (long long)b * hist_stride_b + (long long)t * frame;
+        for (int u = 0; u < TU; ++u) {
+            const int t = t0 + u < T ? t0 + u : T - 1;                     // clamped: the tail repeats the last frame's loads
+            const char* fb = src + (size_t)t * frame_bytes;                // uniform
 #pragma unroll
-        for (int k = 0; k < 8; ++k) raw[u][k] = src[(fo + off[k]) / VE];
-    }
-#pragma unroll
-    for (int u = 0; u < TU; ++u) {
-        if (t0 + u >= T) break;
-        float acc[VE];
-#pragma unroll
-        for (int e = 0; e < VE; ++e) acc[e] = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            float a[VE];
-            fbbev_widen_vec<ET>(raw[u][k], a);
-#pragma unroll
-            for (int e = 0; e < VE; ++e) acc[e] = fmaf(a[e], w[k], acc[e]);
+            for (int k = 0; k < 8; ++k) raw[u][k] = *reinterpret_cast<const fbbev_v4u*>(fb + ob[k]);
         }
-        dst[((long long)b * out_stride_b + (long long)(t0 + u) * frame + (long long)v * C + gq * VE) / VE] = fbbev_narrow_vec<ET>(acc);
+#pragma unroll
+        for (int u = 0; u < TU; ++u) {
+            if (t0 + u >= T) break;
+            float acc[VE];
+#pragma unroll
+            for (int e = 0; e < VE; ++e) acc[e] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float a[VE];
+                fbbev_widen_vec<ET>(raw[u][k], a);
+#pragma unroll
+                for (int e = 0; e < VE; ++e) acc[e] = fmaf(a[e], w[k], acc[e]);
+            }
+            *reinterpret_cast<fbbev_v4u*>(dst + (size_t)(t0 + u) * frame_bytes) = fbbev_narrow_vec<ET>(acc);
+        }
     }
 }
 

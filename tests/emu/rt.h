@@ -201,6 +201,11 @@ inline uint16_t fbbev_emu_bf16(float f) {
     return (uint16_t)(u >> 16);
 }
 inline float fbbev_emu_bf16_to_f32(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+inline unsigned int fbbev_f32_to_f16(float f);          // pool_kernels.h: integer-only round to nearest even
+template <int ET> inline unsigned int fbbev_cvt_pk16(float lo, float hi) {
+    if constexpr (ET == 1) return (unsigned int)fbbev_emu_bf16(lo) | ((unsigned int)fbbev_emu_bf16(hi) << 16);
+    else return fbbev_f32_to_f16(lo) | (fbbev_f32_to_f16(hi) << 16);
+}
 inline fbbev_bf16x8 fbbev_cvt_bf16x8(fbbev_v4f lo, fbbev_v4f hi) {
     fbbev_bf16x8 r;
     for (int e = 0; e < 4; ++e) { r.v[e] = fbbev_emu_bf16(lo[e]); r.v[4 + e] = fbbev_emu_bf16(hi[e]); }

@@ -267,7 +267,11 @@ def test_voxel_major_ring_equals_planar_ring(dev, dt):
     seqs = [[0, 1], [0, 1], [0, 7], [0, 7], [0, 7], [0, 7]]
     starts = [[True, True], [False, False], [False, True], [False, False], [False, False], [False, False]]
     for i in range(6):
-        curr = torch.randn(B, C, Y, X, Z, generator=g).to(dev)
+        curr = torch.randn(B, C, Y, X, Z, generator=g)
+        # half subnormals, the largest half, overflow to inf, a tie, values below the smallest subnormal: the ring's hardware
+        # conversions against the planar kernels' integer rounding
+        curr[0, 0, 0, :6, 0] = torch.tensor([6.0e-5, 5.96e-8, 2.0e-8, 65504.0, -1.00048828125, 3.0e-39])
+        curr = curr.to(dev)
         ego = torch.eye(4).repeat(B, 1, 1)
         ego[:, 0, 3] = torch.tensor([0.4 * i, -0.3]); ego[1, :2, :2] = torch.tensor([[0.98, -0.199], [0.199, 0.98]])
         bda = torch.eye(3).repeat(B, 1, 1)
@@ -283,13 +287,21 @@ def test_voxel_major_ring_equals_planar_ring(dev, dt):
             else:
                 with torch.no_grad():
                     outs.append(m.fuse_history(curr, metas, bda.to(dev)))
-        assert torch.equal(outs[0], outs[1]), i
+        assert torch.allclose(outs[0], outs[1], rtol=0, atol=0, equal_nan=True), i
         h0, h1 = mods[0].history_bev, mods[1].history_bev
         if i != 4:
             assert h0.shape == (B, T * C, Z, Y, X) and h1.shape == (B, T, Z * Y * X, C) and h1.dtype == dt
             assert torch.equal(h1.transpose(2, 3).reshape(B, T * C, Z, Y, X).contiguous().view(bits), h0.contiguous().view(bits)), i
-        assert torch.equal(mods[0].history_as_reference(), mods[1].history_as_reference()), i
+        # (an inf tap times a zero weight is NaN in both rings, as in grid_sample)
+        assert torch.allclose(mods[0].history_as_reference(), mods[1].history_as_reference(), rtol=0, atol=0, equal_nan=True), i
     assert outs[0].abs().max().item() > 0
+    # overflow to inf and the ties around the largest half: the slot-0 conversion against torch's (an inf in the ring would
+    # turn the sequence above into NaNs -- inf times a zero tap weight -- in either layout)
+    from fb_bev_amd import _capi
+    vals = torch.tensor([65504.0, 65519.0, 65520.0, 70000.0, -70000.0, 3.4e38, 1.0e-45, -0.0], device=dev)
+    frame = vals.repeat(C * 8).view(1, C, 64).contiguous()
+    rows = _capi.history_frame_vm(frame, torch.empty((1, 64, C), dtype=dt, device=dev))
+    assert torch.equal(rows.view(bits), frame.transpose(1, 2).to(dt).contiguous().view(bits))
 
 
 def test_baseline_config4_grid_16_frame_fp16_history(dev):
