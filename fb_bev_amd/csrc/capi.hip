@@ -1288,7 +1288,10 @@ extern "C" int fbbev_history_warp_vm(const void* history, long long history_stri
     const int groups = C / VE;
     if (frame * (elem_type == 0 ? 4 : 2) >= (1ll << 32)) return FBBEV_E_UNSUPPORTED;      // 32-bit byte offsets inside a frame
     const int n_xc = (X * groups + 255) / 256;                   // workgroups per grid row
-    int YB = 256 / Z;                                             // rows per band: a (z, y) slab of ~256 workgroups per x chunk
+    int YB = 128 / Z;                                             // rows per band: a (z, y) slab of ~128 workgroups per x chunk
+    if (const char* e = getenv("FBBEV_HISTORY_VM_YB")) YB = atoi(e);        // experiment hooks
+    const char* nt_env = getenv("FBBEV_HISTORY_VM_NT");
+    const bool nt = nt_env ? nt_env[0] == '1' : true;
     if (YB < 1) YB = 1;
     if (YB > Y) YB = Y;
     const int nyb = (Y + YB - 1) / YB;
@@ -1297,15 +1300,13 @@ extern "C" int fbbev_history_warp_vm(const void* history, long long history_stri
     if (blocks >= (1ll << 31) - 8) return FBBEV_E_UNSUPPORTED;
     const int per_xcd = (int)((blocks + 7) / 8);
     fbbev_rt_stream stream = (fbbev_rt_stream)stream_;
-    if (elem_type == 0)
-        FBBEV_LAUNCH((k_history_warp_vm<0, TU>), (long long)per_xcd * 8, 256, 0, stream, history, history_stride_b, rt_flow, T, C,
-                     Z, Y, X, groups, n_xc, YB, nyb, per_xcd, (int)blocks, out, out_stride_b);
-    else if (elem_type == 1)
-        FBBEV_LAUNCH((k_history_warp_vm<1, TU>), (long long)per_xcd * 8, 256, 0, stream, history, history_stride_b, rt_flow, T, C,
-                     Z, Y, X, groups, n_xc, YB, nyb, per_xcd, (int)blocks, out, out_stride_b);
-    else
-        FBBEV_LAUNCH((k_history_warp_vm<2, TU>), (long long)per_xcd * 8, 256, 0, stream, history, history_stride_b, rt_flow, T, C,
-                     Z, Y, X, groups, n_xc, YB, nyb, per_xcd, (int)blocks, out, out_stride_b);
+#define FBBEV_HWVM(ET_, ST_)                                                                                                 \
+    FBBEV_LAUNCH((k_history_warp_vm<ET_, TU, ST_>), (long long)per_xcd * 8, 256, 0, stream, history, history_stride_b, rt_flow, \
+                 T, C, Z, Y, X, groups, n_xc, YB, nyb, per_xcd, (int)blocks, out, out_stride_b)
+    if (elem_type == 0) { if (nt) FBBEV_HWVM(0, 1); else FBBEV_HWVM(0, 0); }
+    else if (elem_type == 1) { if (nt) FBBEV_HWVM(1, 1); else FBBEV_HWVM(1, 0); }
+    else { if (nt) FBBEV_HWVM(2, 1); else FBBEV_HWVM(2, 0); }
+#undef FBBEV_HWVM
     FBBEV_CHECK_LAUNCH();
     return 0;
 }

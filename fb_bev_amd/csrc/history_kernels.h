@@ -203,7 +203,7 @@ __device__ __forceinline__ fbbev_v4u fbbev_narrow_vec(const float* f) {         
 // workgroups an XCD runs at a time form a (z, y) slab, so the y+1 and z+1 taps of one workgroup are the x-row of another
 // one in flight on the same L2 (in flattened voxel order the z neighbour is 6250 workgroups away at 400x400 and every tap
 // plane came from HBM again: 2.9x the algorithmic reads, profiles/r02_pmc_history_vm.json).
-template <int ET, int TU>
+template <int ET, int TU, int ST>
 __global__ void __launch_bounds__(256)
 k_history_warp_vm(const void* __restrict__ hist, long long hist_stride_b, const float* __restrict__ flow, int T, int C,
                   int Z, int Y, int X, int groups, int n_xc, int YB, int nyb, int per_xcd, int n_work,
@@ -275,7 +275,11 @@ k_history_warp_vm(const void* __restrict__ hist, long long hist_stride_b, const 
 #pragma unroll
                 for (int e = 0; e < VE; ++e) acc[e] = fmaf(a[e], w[k], acc[e]);
             }
-            *reinterpret_cast<fbbev_v4u*>(dst + (size_t)(t0 + u) * frame_bytes) = fbbev_narrow_vec<ET>(acc);
+            // write-once stream: non-temporal, so the new frames do not push the tap rows of the neighbouring workgroups out of L2
+            const fbbev_v4u pk = fbbev_narrow_vec<ET>(acc);
+            fbbev_v4f pf;
+            __builtin_memcpy(&pf, &pk, 16);
+            fbbev_store4<ST>(reinterpret_cast<float*>(dst + (size_t)(t0 + u) * frame_bytes), pf);
         }
     }
 }

@@ -93,3 +93,115 @@ def test_module_state_logic_on_cpu_with_oracle_standing_in_for_the_hip_calls(mon
             assert torch.equal(m.history_sweep_time, f['sweep_time_after']), (grad, i)
         if not grad:
             assert m.history_bev.data_ptr() in (m._bufs[0].data_ptr(), m._bufs[1].data_ptr())   # a view, not a clone
+
+
+def test_voxel_major_ring_host_logic_on_cpu_with_stubs(monkeypatch):
+    """ring_layout='voxel_major' host logic (ring buffers of (B,T+1,N,C) rows, sequence restarts, the detour through the
+    autograd path and back, history_as_reference) against the planar ring of the same module on CPU: every HIP entry point
+    is replaced FOR THIS TEST ONLY by the oracle warp / a torch evaluation of the two folded convolutions, in the layout
+    the entry point takes (the kernels themselves: tests/test_emu_kernels.py and tests/test_gpu_history.py)."""
+    from fb_bev_amd import _capi
+    from fb_bev_amd.history_fusion import TemporalHistoryFusion
+    B, C, T, Z, Y, X = 2, 16, 3, 3, 6, 7
+    dx, bx = [0.5, 0.5, 1.0], [-1.5, -1.25, -1.0]
+    dxt, bxt = torch.tensor(dx), torch.tensor(bx)
+    calls = {'vm': 0, 'planar': 0}
+
+    def flow_stub(hist_augs, ego, bda, dx3, lower3):
+        return H.rt_flow(hist_augs, H.forward_aug_matrix(bda), ego, dxt, bxt)
+
+    def warp_stub(history, flow, out):
+        calls['planar'] += 1
+        out.copy_(H.warp_history(history.float(), flow))
+        return out
+
+    def warp_vm_stub(history, flow, out, grid_zyx):
+        calls['vm'] += 1
+        b, t, n, c = history.shape
+        planar = history.float().transpose(2, 3).reshape(b, t * c, *grid_zyx)
+        out.copy_(H.warp_history(planar, flow).reshape(b, t, c, n).transpose(2, 3))
+        return out
+
+    def frame_vm_stub(curr, out, inner=1):
+        b, c, n = curr.shape
+        out.copy_(curr.view(b, c, n // inner, inner).permute(0, 3, 2, 1).reshape(b, n, c))
+        return out
+
+    def conv_stub(feats, w1, bias1, w2, bias2, out, compute=torch.float32, voxel_major=False):
+        assert compute == torch.bfloat16
+        if voxel_major:
+            b, t1, n, c = feats.shape
+            x = feats.float().transpose(2, 3)
+        else:
+            b, tc, n = feats.shape
+            c = w1.shape[0]
+            t1 = tc // c
+            x = feats.float().reshape(b, t1, c, n)
+        y = torch.relu(torch.einsum('oc,btcn->bton', w1, x) + bias1.view(b, t1, c, 1))
+        out.copy_(torch.relu(torch.einsum('oc,bcn->bon', w2, y.reshape(b, t1 * c, n)) + bias2.view(1, -1, 1)))
+        return out
+    for name, fn in (('history_flow', flow_stub), ('history_warp', warp_stub), ('history_warp_vm', warp_vm_stub),
+                     ('history_frame_vm', frame_vm_stub), ('history_conv', conv_stub), ('require_gpu', lambda t, n: None)):
+        monkeypatch.setattr(_capi, name, fn)
+    torch.manual_seed(0)
+    mods = [TemporalHistoryFusion(dx, bx, single_bev_num_channels=C, history_cat_num=T, history_compute=torch.bfloat16,
+                                  ring_layout=lay).eval() for lay in ('planar', 'voxel_major')]
+    with torch.no_grad():
+        for seq in (mods[0].history_keyframe_time_conv, mods[0].history_keyframe_cat_conv):
+            seq[1].running_mean.normal_(0, 0.1); seq[1].running_var.uniform_(0.5, 1.5)
+    mods[1].load_state_dict(mods[0].state_dict())
+    g = torch.Generator().manual_seed(1)
+    seqs = [[0, 1], [0, 1], [0, 5], [0, 5], [0, 5], [0, 5]]
+    starts = [[True, True], [False, False], [False, True], [False, False], [False, False], [False, False]]
+    for i in range(6):
+        curr = torch.randn(B, C, Y, X, Z, generator=g)
+        ego = torch.eye(4).repeat(B, 1, 1)
+        ego[:, 0, 3] = torch.tensor([0.3 * i, -0.2])
+        bda = torch.eye(3).repeat(B, 1, 1)
+        if i >= 3:
+            bda[0, 1, 1] = -1.0
+        metas = [dict(sequence_group_idx=seqs[i][b], start_of_sequence=starts[i][b], curr_to_prev_ego_rt=ego[b]) for b in range(B)]
+        outs = []
+        for m in mods:
+            if i == 4:                                       # one frame through the autograd path: a planar fp32 history
+                m.train()
+                outs.append(m.fuse_history(curr.clone().requires_grad_(True), metas, bda).detach())
+                m.eval()
+            else:
+                with torch.no_grad():
+                    outs.append(m.fuse_history(curr, metas, bda))
+        assert torch.allclose(outs[0], outs[1], atol=1e-5), i
+        assert outs[0].shape == (B, C, Y, X, Z)
+        if i != 4:
+            assert mods[1].history_bev.shape == (B, T, Z * Y * X, C) and mods[0].history_bev.shape == (B, T * C, Z, Y, X)
+            assert mods[1].history_bev.data_ptr() in (mods[1]._bufs[0].data_ptr(), mods[1]._bufs[1].data_ptr())
+        assert torch.allclose(mods[0].history_as_reference(), mods[1].history_as_reference(), atol=1e-6), i
+        assert torch.equal(mods[0].history_sweep_time, mods[1].history_sweep_time)
+    assert calls['vm'] == 5 and calls['planar'] == 5 + 2    # five inference frames each; the autograd frame warps planar in both
+    # switching the layout off mid-stream converts the ring back
+    mods[1].ring_layout = 'planar'
+    with torch.no_grad():
+        a, b = (m.fuse_history(curr, metas, bda) for m in mods)
+    assert torch.allclose(a, b, atol=1e-5) and mods[1].history_bev.shape == (B, T * C, Z, Y, X)
+
+
+def test_folded_weights_cache_follows_parameter_updates():
+    """_folded_pair caches the folded conv + eval-BN maps until a parameter or running statistic changes (in place, by
+    load_state_dict, or by replacement)."""
+    from fb_bev_amd.history_fusion import TemporalHistoryFusion
+    m = TemporalHistoryFusion([0.5, 0.5, 1.0], [0.0, 0.0, 0.0], single_bev_num_channels=4, history_cat_num=2).eval()
+    a = m._folded_pair()
+    assert m._folded_pair() is a                              # unchanged: the same tuple
+    w, b = m._folded(m.history_keyframe_time_conv)
+    assert torch.equal(a[0], w[:, :4]) and torch.equal(a[1], w[:, 4]) and torch.equal(a[2], b)
+    with torch.no_grad():
+        m.history_keyframe_cat_conv[1].running_var.mul_(4.0)     # in place
+    c = m._folded_pair()
+    assert c is not a and torch.allclose(c[3], a[3] * (torch.sqrt(torch.tensor(1.0 + 1e-5)) / torch.sqrt(torch.tensor(4.0 + 1e-5))))
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    sd['history_keyframe_time_conv.0.bias'] += 1.0
+    m.load_state_dict(sd)
+    d = m._folded_pair()
+    assert d is not c and not torch.equal(d[2], c[2])
+    m.history_keyframe_time_conv[0].weight = torch.nn.Parameter(m.history_keyframe_time_conv[0].weight.detach() * 2)
+    assert not torch.equal(m._folded_pair()[0], d[0])
