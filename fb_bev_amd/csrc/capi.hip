@@ -1353,7 +1353,7 @@ extern "C" int fbbev_layernorm(const float* x, const float* residual, const floa
     return 0;
 }
 
-template <int ET>
+template <int ET, bool VM = false>
 static int history_conv_launch(const void* feats, long long feats_stride_b, const float* w1, const float* bias1,
                                const float* w2, const float* bias2, int B, int T1, int C, int Cout, int N,
                                float* out, void* workspace, size_t workspace_bytes, fbbev_rt_stream stream) {
@@ -1369,14 +1369,16 @@ static int history_conv_launch(const void* feats, long long feats_stride_b, cons
         float* w1f = static_cast<float*>(workspace);
         float* w2f = w1f + (size_t)MT1 * KS * 64;
         const int nfrag = (MT1 * KS + T1 * MT2 * KS) * 64;
-        FBBEV_LAUNCH(k_history_weight_fragments, (nfrag + 255) / 256, 256, 0, stream, w1, w2, MT1, MT2, KS, T1, w1f);
+        FBBEV_LAUNCH(k_history_weight_fragments, (nfrag + 255) / 256, 256, 0, stream, w1, w2, MT1, MT2, KS, T1, VM ? 1 : 0, w1f);
         if (C == 80)
-            FBBEV_LAUNCH((k_history_conv_t<5, 5, ET>), blocks, 256, lds, stream, feats, feats_stride_b,
+            FBBEV_LAUNCH((k_history_conv_t<5, 5, ET, VM>), blocks, 256, lds, stream, feats, feats_stride_b,
                          (const float*)w1f, bias1, (const float*)w2f, bias2, T1, N, tiles_per_b, out);
         else
-            FBBEV_LAUNCH((k_history_conv_t<1, 1, ET>), blocks, 256, lds, stream, feats, feats_stride_b,
+            FBBEV_LAUNCH((k_history_conv_t<1, 1, ET, VM>), blocks, 256, lds, stream, feats, feats_stride_b,
                          (const float*)w1f, bias1, (const float*)w2f, bias2, T1, N, tiles_per_b, out);
-    } else
+    } else if (VM)
+        return FBBEV_E_UNSUPPORTED;
+    else
         FBBEV_LAUNCH(k_history_conv<ET>, blocks, 256, lds, stream, feats, feats_stride_b, w1, bias1, w2, bias2,
                      T1, C, Cout, N, tiles_per_b, out);
     FBBEV_CHECK_LAUNCH();
@@ -1446,6 +1448,26 @@ extern "C" int fbbev_history_conv_bf16(const void* feats, long long feats_stride
     if (voxel_major) return elem_type == 0 ? FBBEV_HCB(0, true) : elem_type == 1 ? FBBEV_HCB(1, true) : FBBEV_HCB(2, true);
     return elem_type == 0 ? FBBEV_HCB(0, false) : elem_type == 1 ? FBBEV_HCB(1, false) : FBBEV_HCB(2, false);
 #undef FBBEV_HCB
+}
+
+// the fp32-MFMA convolutions on a voxel-major ring (feats (B, T1, N, C)); C = Cout in {16, 80}, workspace required
+extern "C" int fbbev_history_conv_vm(const void* feats, long long feats_stride_b, const float* w1, const float* bias1,
+                                     const float* w2, const float* bias2, int B, int T1, int C, int Cout, int N,
+                                     float* out, void* workspace, size_t workspace_bytes, int elem_type,
+                                     fbbev_stream_t stream_) {
+    if (B < 0 || T1 <= 0 || C <= 0 || Cout <= 0 || N < 0 || elem_type < 0 || elem_type > 2) return FBBEV_E_BADARG;
+    if (B == 0 || N == 0) return 0;
+    if (!feats || !w1 || !bias1 || !w2 || !bias2 || !out) return FBBEV_E_BADARG;
+    if (!((C == 80 && Cout == 80) || (C == 16 && Cout == 16))) return FBBEV_E_UNSUPPORTED;
+    if (!workspace) return FBBEV_E_WORKSPACE;
+    if (feats_stride_b == 0) feats_stride_b = (long long)T1 * C * N;
+    if (feats_stride_b < (long long)T1 * C * N) return FBBEV_E_BADARG;
+    if (!aligned16(feats) || feats_stride_b % 8 != 0) return FBBEV_E_UNSUPPORTED;                      // 8- / 16-byte row pieces
+    if ((long long)N * C * (elem_type == 0 ? 4 : 2) >= (1ll << 32)) return FBBEV_E_UNSUPPORTED;        // 32-bit byte offsets in a frame
+    fbbev_rt_stream stream = (fbbev_rt_stream)stream_;
+    if (elem_type == 0) return history_conv_launch<0, true>(feats, feats_stride_b, w1, bias1, w2, bias2, B, T1, C, Cout, N, out, workspace, workspace_bytes, stream);
+    if (elem_type == 1) return history_conv_launch<1, true>(feats, feats_stride_b, w1, bias1, w2, bias2, B, T1, C, Cout, N, out, workspace, workspace_bytes, stream);
+    return history_conv_launch<2, true>(feats, feats_stride_b, w1, bias1, w2, bias2, B, T1, C, Cout, N, out, workspace, workspace_bytes, stream);
 }
 
 extern "C" int fbbev_history_conv(const float* feats, long long feats_stride_b, const float* w1, const float* bias1,

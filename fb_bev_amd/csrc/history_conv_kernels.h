@@ -96,7 +96,11 @@ k_history_conv(const void* __restrict__ feats, long long fstride_b, const float*
 //   * the X fragments of frame t+1 are fetched while frame t's second GEMM runs (register double buffer).
 // (Streaming the W2 fragments instead of the per-frame burst, to fit two waves per SIMD, measured 1.9x SLOWER on the
 // same box -- 1.77 vs 0.94 ms for the whole fusion step -- and was dropped.)
-template <int MT1, int MT2, int ET>
+// VM: voxel-major frames ([T1][N][C] per sample, history_kernels.h).  K slot kk of lane group g then stands for channel
+// 16 (kk / 4) + 4 g + kk % 4 in GEMM 1 (k_history_weight_fragments arranges W1 the same way): a lane's four channels of a
+// 16-channel block are one 8-byte (16-bit ring) / 16-byte (fp32 ring) row piece.  The fp32 products are the same, their
+// order inside the accumulation chain is permuted: equal to the planar kernel to fp32 rounding, not bit for bit.
+template <int MT1, int MT2, int ET, bool VM = false>
 __global__ void __launch_bounds__(256)
 k_history_conv_t(const void* __restrict__ feats, long long fstride_b, const float* __restrict__ w1f,
                  const float* __restrict__ bias1, const float* __restrict__ w2f, const float* __restrict__ bias2,
@@ -123,8 +127,42 @@ k_history_conv_t(const void* __restrict__ feats, long long fstride_b, const floa
     // X fragments stay RAW (unconverted) in registers: the prefetch of frame t+1 is issued before GEMM 2 of frame t and
     // must not be followed by a conversion that waits for it; the exact widening happens when the MFMA consumes them
     unsigned int bx[KS];
+    constexpr int ESZ = ET == 0 ? 4 : 2;
+    constexpr int PW = ET == 0 ? 4 : 2;                      // dwords of a 4-channel row piece
+    unsigned int xoff[MT1];                                  // VM: lane byte offset of the piece of 16-channel block q (0 when out of range)
 #pragma unroll
-    for (int kk = 0; kk < KS; ++kk) bx[kk] = inb ? fbbev_ld_raw<ET>(feats, xb + (long long)(4 * kk + g) * N + n) : 0u;
+    for (int q = 0; q < MT1; ++q) xoff[q] = inb ? (unsigned int)(((long long)n * C + 16 * q + 4 * g) * ESZ) : 0u;
+    auto load_x = [&](long long base) {                      // base: element offset of the frame
+        if constexpr (VM) {
+            const char* fb = static_cast<const char*>(feats) + base * ESZ;
+#pragma unroll
+            for (int q = 0; q < MT1; ++q) {                  // unconditional loads; the zero of an out-of-range voxel is selected at use
+                const unsigned int* p = reinterpret_cast<const unsigned int*>(fb + xoff[q]);
+                if constexpr (ET == 0) {
+                    const fbbev_v4u v = *reinterpret_cast<const fbbev_v4u*>(p);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bx[4 * q + e] = v[e];
+                } else {
+                    const unsigned long long v = *reinterpret_cast<const unsigned long long*>(p);
+                    bx[4 * q] = (unsigned int)v;             // channels 0,1 of the piece; [4q+1] holds 2,3; the other two slots are unused
+                    bx[4 * q + 1] = (unsigned int)(v >> 32);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) bx[kk] = inb ? fbbev_ld_raw<ET>(feats, base + (long long)(4 * kk + g) * N + n) : 0u;
+        }
+    };
+    auto x_at = [&](int kk) {                                // exact widening at the point of use
+        if constexpr (!VM) return fbbev_widen<ET>(bx[kk]);
+        else if constexpr (ET == 0) return inb ? fbbev_widen<0>(bx[kk]) : 0.f;
+        else {
+            const unsigned int w = bx[4 * (kk >> 2) + ((kk & 3) >> 1)];
+            return inb ? fbbev_widen<ET>((kk & 1) ? (w >> 16) : (w & 0xffffu)) : 0.f;
+        }
+    };
+    (void)PW;
+    load_x(xb);
     for (int t = 0; t < T1; ++t) {
         const float* b1 = bias1 + ((long long)b * T1 + t) * C;
         const float* w2t = w2f + (long long)t * MT2 * KS * 64;
@@ -141,12 +179,9 @@ k_history_conv_t(const void* __restrict__ feats, long long fstride_b, const floa
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
-            for (int mt = 0; mt < MT1; ++mt) acc1[mt] = fbbev_mfma_f32_16x16x4(a1[mt][kk], fbbev_widen<ET>(bx[kk]), acc1[mt]);
-        if (t + 1 < T1) {                                   // next frame's X fragments: in flight during GEMM 2
-            const long long xn = xb + (long long)(t + 1) * C * N;
-#pragma unroll
-            for (int kk = 0; kk < KS; ++kk) bx[kk] = inb ? fbbev_ld_raw<ET>(feats, xn + (long long)(4 * kk + g) * N + n) : 0u;
-        }
+            for (int mt = 0; mt < MT1; ++mt) acc1[mt] = fbbev_mfma_f32_16x16x4(a1[mt][kk], x_at(kk), acc1[mt]);
+        if constexpr (VM) load_x(xb + (long long)(t + 1 < T1 ? t + 1 : t) * C * N);      // unconditional (clamped at the tail)
+        else if (t + 1 < T1) load_x(xb + (long long)(t + 1) * C * N);                    // next frame's X fragments: in flight during GEMM 2
         fbbev_wave_sync();                                  // ylds is wave-private: no workgroup barrier
 #pragma unroll
         for (int mt = 0; mt < MT1; ++mt)
@@ -171,16 +206,18 @@ k_history_conv_t(const void* __restrict__ feats, long long fstride_b, const floa
 
 // Weight matrices -> MFMA A-fragment order, one launch: dst = [ w1f[mt][kk][lane] | w2f[t][mt][kk][lane] ] with
 // fragment element A[16mt + lane%16][4kk + lane/16]; w1 is (16*MT1, C), w2 is (16*MT2, T1*C) and frame t uses columns t*C..
+// vm: W1's K slots follow the voxel-major channel rule of k_history_conv_t<.., VM = true>.
 __global__ void __launch_bounds__(256)
 k_history_weight_fragments(const float* __restrict__ w1, const float* __restrict__ w2, int MT1, int MT2, int KS, int T1,
-                           float* __restrict__ dst) {
+                           int vm, float* __restrict__ dst) {
     const int n1 = MT1 * KS * 64, n2 = MT2 * KS * 64;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n1 + T1 * n2) return;
     const int C = 4 * KS;
     if (i < n1) {
         const int lane = i & 63, kk = (i >> 6) % KS, mt = (i >> 6) / KS;
-        dst[i] = w1[(long long)(16 * mt + (lane & 15)) * C + 4 * kk + (lane >> 4)];
+        const int col = vm ? 16 * (kk >> 2) + 4 * (lane >> 4) + (kk & 3) : 4 * kk + (lane >> 4);
+        dst[i] = w1[(long long)(16 * mt + (lane & 15)) * C + col];
     } else {
         const int r = i - n1, t = r / n2, e = r - t * n2;
         const int lane = e & 63, kk = (e >> 6) % KS, mt = (e >> 6) / KS;

@@ -59,10 +59,11 @@ class TemporalHistoryFusion(nn.Module):
         self.history_compute = history_compute
         # Layout of the inference ring: 'planar' = the reference's (B, T*C, Z, Y, X); 'voxel_major' = (B, T, N, C) frames of
         # voxel rows (history_kernels.h): a trilinear tap is one 16-byte load of 8 channels instead of 8 scalar gathers from 8
-        # planes, and the convolutions read MFMA operands as rows.  Same element bits as the planar ring.  Taken when the
-        # bf16-MFMA convolutions are (history_compute=bfloat16, C = Cout in {16, 80}); the autograd path stays planar fp32 and
-        # either kind of history is converted when the mode changes.  history_bev is then (B, T, N, C):
-        # history_as_reference() returns the reference's tensor.
+        # planes, and the convolutions read MFMA operands as rows.  Same element bits as the planar ring (the fp32
+        # convolutions sum their K in a different order on it: equal to fp32 rounding).  Taken when the register-resident
+        # MFMA convolutions are (C = Cout in {16, 80}); the autograd path stays planar fp32 and either kind of history is
+        # converted when the mode changes.  history_bev is then (B, T, N, C): history_as_reference() returns the reference's
+        # tensor.
         if ring_layout not in ('planar', 'voxel_major'):
             raise ValueError("ring_layout is 'planar' or 'voxel_major'")
         self.ring_layout = ring_layout
@@ -80,8 +81,7 @@ class TemporalHistoryFusion(nn.Module):
     def _voxel_major(self):
         C = self.single_bev_num_channels
         cout = self.history_keyframe_cat_conv[0].weight.shape[0]
-        return (self.ring_layout == 'voxel_major' and self.use_mfma_convs and self.history_compute == torch.bfloat16
-                and C == cout and C in (16, 80))
+        return self.ring_layout == 'voxel_major' and self.use_mfma_convs and C == cout and C in (16, 80)
 
     def history_as_reference(self):
         """history_bev in the reference's layout and type: (B, T*C, Z, Y, X) fp32 (fbocc.py:234, :312)."""
@@ -258,7 +258,7 @@ class TemporalHistoryFusion(nn.Module):
         bias1 = b1[None, :] + tau * wt[None, :]                        # folded bias + scale * W[:, C] * tau, (B*(T+1), C)
         out = _capi.history_conv(nxt, w1, bias1, w2, b2,
                                  torch.empty((B, w2.shape[0], n), dtype=torch.float32, device=curr_yxz.device),
-                                 compute=torch.bfloat16, voxel_major=True)
+                                 compute=self.history_compute, voxel_major=True)
         return out.view(B, -1, Z, Y, X), nxt
 
     def _fuse_infer(self, curr, flow, sweep):

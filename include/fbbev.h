@@ -432,6 +432,12 @@ int fbbev_history_conv_bf16(const void* feats, long long feats_stride_b, const f
  *   fbbev_history_frame_vm: curr (B, C, N) fp32 planes -> out[b] (N, C): slot 0 of the ring (fbocc.py:286 cat).
  *                           inner = 1: plane position = row; inner = Z: the planes are (Y, X, Z) volumes as the view
  *                           transformation returns them (fbocc.py:212 permutes to (Z, Y, X) first), rows are z-major. */
+/* fbbev_history_conv_e (fp32 MFMA, the reference's arithmetic) on a voxel-major ring: feats (B, T1, N, C).  The K order
+ * inside the fp32 accumulation differs from the planar kernel (equal to fp32 rounding).  C = Cout in {16, 80}; workspace
+ * as fbbev_history_conv_e. */
+int fbbev_history_conv_vm(const void* feats, long long feats_stride_b, const float* w1, const float* bias1, const float* w2,
+                          const float* bias2, int B, int T1, int C, int Cout, int N, float* out, void* workspace,
+                          size_t workspace_bytes, int elem_type, fbbev_stream_t stream);
 int fbbev_history_warp_vm(const void* history, long long history_stride_b, const float* rt_flow, int B, int T, int C, int Z,
                           int Y, int X, void* out, long long out_stride_b, int elem_type, fbbev_stream_t stream);
 int fbbev_history_frame_vm(const float* curr, int B, int C, int N, int inner, void* out, long long out_stride_b,

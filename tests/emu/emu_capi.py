@@ -267,6 +267,8 @@ def history_conv(feats, w1, bias1, w2, bias2, bf16=False, voxel_major=False):
             ws.numel() * 4)
     if bf16:
         ok(lib().fbbev_history_conv_bf16(*args, 1 if voxel_major else 0, et, None))
+    elif voxel_major:
+        ok(lib().fbbev_history_conv_vm(*args, et, None))
     else:
         ok(lib().fbbev_history_conv_e(*args, et, None))
     return out

@@ -779,6 +779,14 @@ def test_history_voxel_major_ring_equals_planar_kernels_emulated(dt):
         a = E.history_conv(feats.reshape(2, T1 * Cc, n), w1, b1, w2, b2, bf16=True)
         b = E.history_conv(feats.transpose(2, 3).contiguous(), w1, b1, w2, b2, bf16=True, voxel_major=True)
         assert not torch.isnan(a).any() and torch.equal(a, b)
+        # fp32 MFMA on rows: the same products, K summed in the voxel-major slot order -> equal to fp32 rounding
+        a32 = E.history_conv(feats.reshape(2, T1 * Cc, n), w1, b1, w2, b2)
+        b32 = E.history_conv(feats.transpose(2, 3).contiguous(), w1, b1, w2, b2, voxel_major=True)
+        x = feats.double()
+        y = torch.relu(torch.einsum('oc,btcn->bton', w1.double(), x) + b1.view(2, T1, Cc, 1).double())
+        exp = torch.relu(torch.einsum('oc,bcn->bon', w2.double(), y.reshape(2, T1 * Cc, n)) + b2.view(1, Cc, 1).double())
+        assert not torch.isnan(b32).any()
+        assert torch.allclose(b32.double(), exp, atol=2e-5, rtol=1e-5) and torch.allclose(a32, b32, atol=2e-5, rtol=1e-5)
 
 
 @pytest.mark.parametrize('dt', [torch.float32, torch.float16])

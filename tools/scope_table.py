@@ -139,7 +139,8 @@ def s6(n):
         return out
     with torch.no_grad():
         vt_ms = None
-        for comp, lay, label in ((torch.float32, 'planar', 'fp32 MFMA'), (torch.bfloat16, 'planar', 'bf16 MFMA (fp32 accumulate)'),
+        for comp, lay, label in ((torch.float32, 'planar', 'fp32 MFMA'), (torch.float32, 'voxel_major', 'fp32 MFMA'),
+                                 (torch.bfloat16, 'planar', 'bf16 MFMA (fp32 accumulate)'),
                                  (torch.bfloat16, 'voxel_major', 'bf16 MFMA (fp32 accumulate)')):
             hist.history_compute, hist.ring_layout = comp, lay
             hist.reset(); state['first'] = True

@@ -3,7 +3,7 @@
 reference's op sequence (fbocc.py:264-319: generate_grid, F.grid_sample, cats, Conv3d+BN+ReLU x2, clone) written in
 plain torch on the same GPU.   python tools/time_history.py [Y X Z] [B] [f32|f16|bf16] [noref] [cbf16] [vm]
 (f16 / bf16: the 16-bit history ring of BASELINE configs[4]; noref: skip the torch reference sequence; cbf16: the two
-convolutions on the bf16 MFMA, history_compute=bfloat16; vm: ring_layout=voxel_major, with cbf16)"""
+convolutions on the bf16 MFMA, history_compute=bfloat16; vm: ring_layout=voxel_major)"""
 import json, os, sys
 import torch
 import torch.nn.functional as F
