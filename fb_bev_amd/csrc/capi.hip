@@ -1396,6 +1396,7 @@ extern "C" int fbbev_history_conv_e(const void* feats, long long feats_stride_b,
         return FBBEV_E_UNSUPPORTED;
     if (feats_stride_b == 0) feats_stride_b = (long long)T1 * C * N;
     if (feats_stride_b < (long long)T1 * C * N) return FBBEV_E_BADARG;
+    if (!aligned16(bias1)) return FBBEV_E_UNSUPPORTED;                                  // 16-byte bias loads
     fbbev_rt_stream stream = (fbbev_rt_stream)stream_;
     if (elem_type == 0) return history_conv_launch<0>(feats, feats_stride_b, w1, bias1, w2, bias2, B, T1, C, Cout, N, out, workspace, workspace_bytes, stream);
     if (elem_type == 1) return history_conv_launch<1>(feats, feats_stride_b, w1, bias1, w2, bias2, B, T1, C, Cout, N, out, workspace, workspace_bytes, stream);
@@ -1464,6 +1465,7 @@ extern "C" int fbbev_history_conv_vm(const void* feats, long long feats_stride_b
     if (feats_stride_b < (long long)T1 * C * N) return FBBEV_E_BADARG;
     if (!aligned16(feats) || feats_stride_b % 8 != 0) return FBBEV_E_UNSUPPORTED;                      // 8- / 16-byte row pieces
     if ((long long)N * C * (elem_type == 0 ? 4 : 2) >= (1ll << 32)) return FBBEV_E_UNSUPPORTED;        // 32-bit byte offsets in a frame
+    if (!aligned16(bias1)) return FBBEV_E_UNSUPPORTED;
     fbbev_rt_stream stream = (fbbev_rt_stream)stream_;
     if (elem_type == 0) return history_conv_launch<0, true>(feats, feats_stride_b, w1, bias1, w2, bias2, B, T1, C, Cout, N, out, workspace, workspace_bytes, stream);
     if (elem_type == 1) return history_conv_launch<1, true>(feats, feats_stride_b, w1, bias1, w2, bias2, B, T1, C, Cout, N, out, workspace, workspace_bytes, stream);

@@ -149,12 +149,13 @@ k_history_conv_t(const void* __restrict__ feats, long long fstride_b, const floa
                 }
             }
         } else {
+            const int nc = inb ? n : 0;                      // clamped lane offset: unconditional loads, zero selected at use
 #pragma unroll
-            for (int kk = 0; kk < KS; ++kk) bx[kk] = inb ? fbbev_ld_raw<ET>(feats, base + (long long)(4 * kk + g) * N + n) : 0u;
+            for (int kk = 0; kk < KS; ++kk) bx[kk] = fbbev_ld_raw<ET>(feats, base + (long long)(4 * kk + g) * N + nc);
         }
     };
     auto x_at = [&](int kk) {                                // exact widening at the point of use
-        if constexpr (!VM) return fbbev_widen<ET>(bx[kk]);
+        if constexpr (!VM) return inb ? fbbev_widen<ET>(bx[kk]) : 0.f;
         else if constexpr (ET == 0) return inb ? fbbev_widen<0>(bx[kk]) : 0.f;
         else {
             const unsigned int w = bx[4 * (kk >> 2) + ((kk & 3) >> 1)];
@@ -166,16 +167,18 @@ k_history_conv_t(const void* __restrict__ feats, long long fstride_b, const floa
     for (int t = 0; t < T1; ++t) {
         const float* b1 = bias1 + ((long long)b * T1 + t) * C;
         const float* w2t = w2f + (long long)t * MT2 * KS * 64;
+        // the frame's bias FIRST, the W2_t burst behind it: vmcnt retires in order, so with the bias loads behind the 100
+        // fragment loads GEMM 1 waited for the whole burst every frame (one wave per SIMD: nothing else to run meanwhile)
+        fbbev_v4f acc1[MT1];
+#pragma unroll
+        for (int mt = 0; mt < MT1; ++mt) acc1[mt] = *reinterpret_cast<const fbbev_v4f*>(b1 + 16 * mt + 4 * g);
+        fbbev_sched_fence();
         float a2[MT2][KS];
 #pragma unroll
         for (int mt = 0; mt < MT2; ++mt)
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk) a2[mt][kk] = w2t[(mt * KS + kk) * 64 + lane];
-        fbbev_v4f acc1[MT1];
-#pragma unroll
-        for (int mt = 0; mt < MT1; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc1[mt][r] = b1[16 * mt + 4 * g + r];
+        fbbev_sched_fence();
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
