@@ -254,17 +254,19 @@ k_history_warp_vm(const void* __restrict__ hist, long long hist_stride_b, const 
     const char* src = static_cast<const char*>(hist) + (size_t)b * hist_stride_b * ESZ;
     char* dst = static_cast<char*>(out) + (size_t)b * out_stride_b * ESZ + ((size_t)v * C + gq * VE) * ESZ;
     for (int t0 = 0; t0 < T; t0 += TU) {
+        // straight-line body: the frame index is clamped for the loads AND the stores (an odd tail computes and stores frame
+        // T-1 twice, the same bits) -- with a break in the store loop the compiler split the batch into one frame at a time
         fbbev_v4u raw[TU][8];
+        size_t fo[TU];
 #pragma unroll
         for (int u = 0; u < TU; ++u) {
-            const int t = t0 + u < T ? t0 + u : T - 1;                     // clamped: the tail repeats the last frame's loads
-            const char* fb = src + (size_t)t * frame_bytes;                // uniform
+            fo[u] = (size_t)(t0 + u < T ? t0 + u : T - 1) * frame_bytes;   // uniform
 #pragma unroll
-            for (int k = 0; k < 8; ++k) raw[u][k] = *reinterpret_cast<const fbbev_v4u*>(fb + ob[k]);
+            for (int k = 0; k < 8; ++k) raw[u][k] = *reinterpret_cast<const fbbev_v4u*>(src + fo[u] + ob[k]);
         }
+        fbbev_sched_fence();
 #pragma unroll
         for (int u = 0; u < TU; ++u) {
-            if (t0 + u >= T) break;
             float acc[VE];
 #pragma unroll
             for (int e = 0; e < VE; ++e) acc[e] = 0.f;
@@ -279,7 +281,7 @@ k_history_warp_vm(const void* __restrict__ hist, long long hist_stride_b, const 
             const fbbev_v4u pk = fbbev_narrow_vec<ET>(acc);
             fbbev_v4f pf;
             __builtin_memcpy(&pf, &pk, 16);
-            fbbev_store4<ST>(reinterpret_cast<float*>(dst + (size_t)(t0 + u) * frame_bytes), pf);
+            fbbev_store4<ST>(reinterpret_cast<float*>(dst + fo[u]), pf);
         }
     }
 }
