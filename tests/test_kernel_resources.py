@@ -54,7 +54,7 @@ BUDGETS = {
     r'k_da_cross_attn_bwd_scatter': 96,        # value-gradient scatter: 5 waves / SIMD
     r'k_da_cross_attn_bwd_unitILi10E': 224,    # unit-owned gradients at the shipped head dim: 2 waves / SIMD (48 corner registers in flight)
     r'k_history_warp': 168,
-    r'k_history_conv_tILi5ELi5E': 384,         # register-resident weights: one wave per SIMD by design
+    r'k_history_conv_tILi5ELi5E': 512,         # register-resident weights: one wave per SIMD by design (the whole file)
     r'k_history_warp_vm': 128,                 # voxel-major ring: 4+ waves / SIMD (16 sixteen-byte taps in flight per thread)
     r'k_history_conv_bf16ILi5ELi5E': 256,      # bf16-MFMA variant: two waves per SIMD (the next frame's loads need a partner)
     r'k_conv3d_ndhwc': 256,                    # two waves / SIMD: the ping-pong buffers need a partner wave
