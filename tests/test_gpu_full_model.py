@@ -85,6 +85,35 @@ def test_inference_route_equals_autograd_route_and_formats(dev):
     assert (torch.from_numpy(res[0]['pred_occupancy']).to(dev) == ids[0]).float().mean() > 0.99
 
 
+@pytest.mark.parametrize('execution,tol', [(dict(history_ring='voxel_major'), 1e-4),
+                                           (dict(history_dtype='f16', history_compute='bf16', history_ring='voxel_major'), 5e-2)])
+def test_detector_history_execution_knobs(dev, execution, tol):
+    """The history knobs of the detector's `execution` block through a 3-frame sequence with ego motion: the voxel-major
+    ring alone is the default detector to fp32 rounding (same elements, fp32 convolutions summed in another K order); with
+    the fp16 ring and the bf16-MFMA convolutions the logits stay within the stated reduced-precision band and the predicted
+    classes agree on > 97 % of the voxels."""
+    base = _small_model(dev).eval()
+    m = _small_model(dev, execution).eval()
+    m.load_state_dict(base.state_dict())
+    hist = m._path[1]
+    assert hist._voxel_major()
+    img_inputs, metas, _, _ = _inputs(dev, 2)
+    ego = torch.eye(4); ego[0, 3] = 1.5; ego[1, 3] = -0.7
+    for i in range(3):
+        mt = [dict(d, curr_to_prev_ego_rt=ego) for d in metas(i == 0)]
+        frame = [img_inputs[0] + 0.1 * i] + img_inputs[1:]
+        with torch.no_grad():
+            l0 = base.occupancy_head(base.extract_feat(None, frame, mt)['img_bev_feat'])['output_voxels'][0]
+            l1 = m.occupancy_head(m.extract_feat(None, frame, mt)['img_bev_feat'])['output_voxels'][0]
+        scale = l0.abs().max().item()
+        assert (l0 - l1).abs().max().item() <= tol * scale, (i, (l0 - l1).abs().max().item(), scale)
+        assert (l0.argmax(1) == l1.argmax(1)).float().mean().item() > 0.97
+        assert hist.history_bev.dim() == 4 and hist.history_bev.dtype == hist.history_dtype
+        h0 = base._path[1].history_as_reference()
+        # the stored frames do not depend on the fused output: identical elements, or fp16 roundings of them (one per re-sampling)
+        assert torch.allclose(hist.history_as_reference(), h0, rtol=0, atol=(2e-3 if 'history_dtype' in execution else 0.0) * h0.abs().max().item())
+
+
 def test_losses_on_gpu_equal_cpu_evaluation_and_do_not_sync(dev):
     from fb_bev_amd import occ_loss as L
     g = torch.Generator().manual_seed(0)
