@@ -1289,9 +1289,7 @@ extern "C" int fbbev_history_warp_vm(const void* history, long long history_stri
     if (frame * (elem_type == 0 ? 4 : 2) >= (1ll << 32)) return FBBEV_E_UNSUPPORTED;      // 32-bit byte offsets inside a frame
     const int n_xc = (X * groups + 255) / 256;                   // workgroups per grid row
     int YB = 128 / Z;                                             // rows per band: a (z, y) slab of ~128 workgroups per x chunk
-    if (const char* e = getenv("FBBEV_HISTORY_VM_YB")) YB = atoi(e);        // experiment hooks
-    const char* nt_env = getenv("FBBEV_HISTORY_VM_NT");
-    const bool nt = nt_env ? nt_env[0] == '1' : true;
+    if (const char* e = getenv("FBBEV_HISTORY_VM_YB")) YB = atoi(e);        // tuning knob (profiles/r02_time_history_bf16_voxel_major.jsonl)
     if (YB < 1) YB = 1;
     if (YB > Y) YB = Y;
     const int nyb = (Y + YB - 1) / YB;
@@ -1303,9 +1301,10 @@ extern "C" int fbbev_history_warp_vm(const void* history, long long history_stri
 #define FBBEV_HWVM(ET_, ST_)                                                                                                 \
     FBBEV_LAUNCH((k_history_warp_vm<ET_, TU, ST_>), (long long)per_xcd * 8, 256, 0, stream, history, history_stride_b, rt_flow, \
                  T, C, Z, Y, X, groups, n_xc, YB, nyb, per_xcd, (int)blocks, out, out_stride_b)
-    if (elem_type == 0) { if (nt) FBBEV_HWVM(0, 1); else FBBEV_HWVM(0, 0); }
-    else if (elem_type == 1) { if (nt) FBBEV_HWVM(1, 1); else FBBEV_HWVM(1, 0); }
-    else { if (nt) FBBEV_HWVM(2, 1); else FBBEV_HWVM(2, 0); }
+    // ST = 1: non-temporal ring stores (A/B on one box: 4.0 vs 4.2 ms at 400x400x16, 0.56 vs 0.61 ms at 100x100x8 B=4)
+    if (elem_type == 0) FBBEV_HWVM(0, 1);
+    else if (elem_type == 1) FBBEV_HWVM(1, 1);
+    else FBBEV_HWVM(2, 1);
 #undef FBBEV_HWVM
     FBBEV_CHECK_LAUNCH();
     return 0;
