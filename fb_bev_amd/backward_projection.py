@@ -127,11 +127,14 @@ class FFN(nn.Module):
         self.add_identity = add_identity
         self.embed_dims = embed_dims
 
-    def forward(self, x, identity=None):
+    def forward(self, x, identity=None, _defer_residual=False):
         out = self.layers(x)
         if not self.add_identity:
-            return out
-        return (x if identity is None else identity) + out
+            return (out, None) if _defer_residual else out
+        res = x if identity is None else identity
+        # _defer_residual (BEVFormerEncoderLayer's inference route): hand (branch output, residual) to the following LayerNorm,
+        # whose kernel adds them while it reads the row -- the separate element-wise add pass is skipped
+        return (out, res) if _defer_residual else res + out
 
 
 def _ring_offsets(num_heads):
@@ -170,7 +173,7 @@ class MultiScaleDeformableAttention(nn.Module):
         _xavier(self.output_proj)
 
     def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_padding_mask=None,
-                reference_points=None, spatial_shapes=None, level_start_index=None, **kwargs):
+                reference_points=None, spatial_shapes=None, level_start_index=None, _defer_residual=False, **kwargs):
         if value is None:
             value = query
         if identity is None:
@@ -211,7 +214,7 @@ class MultiScaleDeformableAttention(nn.Module):
             out = self.output_proj(out)
             if not self.batch_first:
                 out = out.permute(1, 0, 2)
-            return out + identity
+            return (out, identity) if _defer_residual else out + identity
         value = self.value_proj(value)
         if key_padding_mask is not None:
             value = value.masked_fill(key_padding_mask[..., None], 0.0)
@@ -227,7 +230,7 @@ class MultiScaleDeformableAttention(nn.Module):
         out = self.output_proj(out)
         if not self.batch_first:
             out = out.permute(1, 0, 2)
-        return self.dropout(out) + identity
+        return (self.dropout(out), identity) if _defer_residual else self.dropout(out) + identity
 
 
 @register
@@ -483,7 +486,8 @@ class DA_SpatialCrossAttention(nn.Module):
 
     def forward(self, query, key, value, residual=None, query_pos=None, key_padding_mask=None, reference_points=None,
                 spatial_shapes=None, reference_points_cam=None, level_start_index=None, flag='encoder',
-                bev_query_depth=None, pred_img_depth=None, bev_mask=None, per_cam_mask_list=None, **kwargs):
+                bev_query_depth=None, pred_img_depth=None, bev_mask=None, per_cam_mask_list=None, _defer_residual=False,
+                **kwargs):
         if key is None:
             key = query
         if value is None:
@@ -505,7 +509,7 @@ class DA_SpatialCrossAttention(nn.Module):
         slots = self.output_proj(slots)
         if self.layer_scale is not None:
             slots = self.layer_scale * slots
-        return self.dropout(slots) + inp_residual
+        return (self.dropout(slots), inp_residual) if _defer_residual else self.dropout(slots) + inp_residual
 
 
 class LayerNorm(nn.LayerNorm):
@@ -513,13 +517,19 @@ class LayerNorm(nn.LayerNorm):
     per 80-float row instead of torch's generic kernel (150 us -> ~25 us on 160k rows).  Same parameters / state_dict;
     with autograd enabled, or for shapes the kernel does not take, it is exactly nn.LayerNorm."""
 
-    def forward(self, x):
+    def kernel_ok(self, x):
         C = x.shape[-1]
-        if (x.is_cuda and x.dtype == torch.float32 and self.elementwise_affine and self.bias is not None and
+        return (x.is_cuda and x.dtype == torch.float32 and self.elementwise_affine and self.bias is not None and
                 len(self.normalized_shape) == 1 and C % 4 == 0 and C <= 128 and x.is_contiguous() and
-                not (torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad))):
-            return _capi.layernorm(x, self.weight, self.bias, self.eps)
-        return super().forward(x)
+                not (torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad)))
+
+    def forward(self, x, residual=None):
+        """LN(x [+ residual]); the kernel adds the residual while it reads the row (the same fp32 sum as a separate add)."""
+        if self.kernel_ok(x) and (residual is None or (residual.shape == x.shape and residual.dtype == x.dtype
+                                                       and residual.is_contiguous() and not
+                                                       (torch.is_grad_enabled() and residual.requires_grad))):
+            return _capi.layernorm(x, self.weight, self.bias, self.eps, residual=residual)
+        return super().forward(x if residual is None else x + residual)
 
 
 @register
@@ -558,29 +568,43 @@ class BEVFormerEncoderLayer(nn.Module):
                 bev_query_depth=None, per_cam_mask_list=None, pred_img_depth=None, key_pos=None, **kwargs):
         ni = ai = fi = 0
         identity = query
-        for layer in self.operation_order:
+        ops = self.operation_order
+        # post-norm inference: a branch followed by 'norm' hands (output, residual) to the LayerNorm kernel, which adds them
+        # while it reads the row (three element-wise passes over the BEV queries less per layer; the same fp32 sums)
+        defer = not self.pre_norm and not torch.is_grad_enabled() and query.is_cuda
+        pending = None
+        for k, layer in enumerate(ops):
+            d = defer and k + 1 < len(ops) and ops[k + 1] == 'norm'
             if layer == 'self_attn':
                 query = self.attentions[ai](
                     query, None, None, identity if self.pre_norm else None, query_pos=bev_pos, key_pos=bev_pos,
                     key_padding_mask=bev_mask, reference_points=ref_2d,
                     spatial_shapes=const_tensor([[bev_h, bev_w]], query.device),
-                    level_start_index=const_tensor([0], query.device))
+                    level_start_index=const_tensor([0], query.device), _defer_residual=d)
                 ai += 1
+                if d:
+                    query, pending = query
                 identity = query
             elif layer == 'norm':
-                query = self.norms[ni](query)
+                query = self.norms[ni](query, pending)
+                pending = None
                 ni += 1
             elif layer == 'cross_attn':
                 query = self.attentions[ai](
                     query, key, value, identity if self.pre_norm else None, query_pos=bev_pos, key_pos=key_pos,
                     reference_points=ref_3d, reference_points_cam=reference_points_cam, spatial_shapes=spatial_shapes,
                     level_start_index=level_start_index, bev_query_depth=bev_query_depth,
-                    pred_img_depth=pred_img_depth, bev_mask=bev_mask, per_cam_mask_list=per_cam_mask_list)
+                    pred_img_depth=pred_img_depth, bev_mask=bev_mask, per_cam_mask_list=per_cam_mask_list,
+                    _defer_residual=d)
                 ai += 1
+                if d:
+                    query, pending = query
                 identity = query
             elif layer == 'ffn':
-                query = self.ffns[fi](query, identity if self.pre_norm else None)
+                query = self.ffns[fi](query, identity if self.pre_norm else None, _defer_residual=d)
                 fi += 1
+                if d:
+                    query, pending = query
         return query
 
 
