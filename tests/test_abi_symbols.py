@@ -78,4 +78,22 @@ def test_invalid_arguments_return_error_codes_without_touching_the_gpu():
     assert lib.fbbev_msda_fwd(P, P, P, P, P, 0, 704, 8, 10, 1, 5, 4, P, NULL) == 0      # empty batch: no-op
     assert lib.fbbev_da_cross_attn_fwd(P, P, P, P, P, P, P, P, P, 1, 6, 704, 8, 10, 1, 100, 8, 16, 80, 2.0, 0.5, 0, 0, P, NULL) == -2  # Za > 8
     assert lib.fbbev_da_cross_attn_fwd(P, P, P, P, P, P, P, P, P, 1, 6, 704, 8, 10, 1, 100, 8, 4, 80, 2.0, 0.0, 0, 0, P, NULL) == -1   # dstep == 0
+    # temporal history fusion: the reference-layout entries and the voxel-major ring
+    P16, P8 = ctypes.c_void_p(0x1000), ctypes.c_void_p(0x1008)     # 16-byte aligned / not
+    assert lib.fbbev_history_warp_e(P, 0, P, 1, 80, 1, 8, 8, P, 0, 0, NULL) == -1          # Z < 2 (the reference divides by Z - 1)
+    assert lib.fbbev_history_warp_e(P, 0, P, 0, 80, 8, 8, 8, P, 0, 0, NULL) == 0           # empty batch: no-op
+    assert lib.fbbev_history_warp_vm(P16, 0, P, 1, 16, 80, 8, 8, 8, P16, 0, 3, NULL) == -1  # elem_type
+    assert lib.fbbev_history_warp_vm(P16, 0, P, 1, 16, 84, 8, 8, 8, P16, 0, 2, NULL) == -2  # C % 8 (16-bit row pieces)
+    assert lib.fbbev_history_warp_vm(P16, 0, P, 1, 16, 80, 8, 8, 8, P8, 0, 2, NULL) == -2   # out not 16-byte aligned
+    assert lib.fbbev_history_warp_vm(P16, 100, P, 1, 16, 80, 8, 8, 8, P16, 0, 2, NULL) == -1    # batch stride < T*N*C
+    assert lib.fbbev_history_warp_vm(P16, 0, P, 1, 0, 80, 8, 8, 8, P16, 0, 2, NULL) == 0    # no frames: no-op
+    assert lib.fbbev_history_frame_vm(P, 1, 80, 512, 3, P16, 0, 2, NULL) == -1              # N % inner
+    assert lib.fbbev_history_frame_vm(P, 1, 82, 512, 1, P16, 0, 2, NULL) == -2              # C % 8
+    assert lib.fbbev_history_conv_bf16(P16, 0, P16, P16, P16, P16, 1, 17, 32, 32, 64, P16, P16, 1 << 20, 0, 1, NULL) == -2   # C in {16, 80}
+    assert lib.fbbev_history_conv_bf16(P16, 0, P16, P16, P16, P16, 1, 17, 80, 80, 64, P16, P16, 16, 0, 1, NULL) == -3        # workspace
+    assert lib.fbbev_history_conv_bf16(P16, 0, P16, P16, P16, P16, 1, 17, 80, 80, 64, P16, P16, 1 << 20, 2, 1, NULL) == -1   # layout flag
+    assert lib.fbbev_history_conv_bf16(P8, 0, P16, P16, P16, P16, 1, 17, 80, 80, 64, P16, P16, 1 << 20, 1, 1, NULL) == -2    # rows not aligned
+    assert lib.fbbev_history_conv_vm(P16, 0, P16, P16, P16, P16, 1, 17, 80, 80, 64, P16, NULL, 0, 1, NULL) == -3             # workspace required
+    assert lib.fbbev_history_conv_vm(P16, 0, P16, P16, P16, P16, 1, 17, 48, 48, 64, P16, P16, 1 << 20, 1, NULL) == -2
+    assert lib.fbbev_history_conv_e(P16, 0, P16, P8, P16, P16, 1, 17, 80, 80, 64, P16, P16, 1 << 20, 1, NULL) == -2          # bias rows are 16-byte loads
     assert lib.fbbev_rank_workspace_bytes(0) == 256 and lib.fbbev_pool_dense_workspace_bytes(0, 1, 1, 1) == 256
