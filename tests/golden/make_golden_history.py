@@ -55,12 +55,15 @@ def rigid(yaw_deg, t):
     return m
 
 
-def main():
+def main(C=4, grid=(4, 10, 12), name='history_fusion_seq4.npz', full=True, seed=0):
+    """full=False: the smaller record of the C = 16 sequence (what the voxel-major / MFMA routes need: inputs, fused output
+    per frame, history state after the last frame) -- grid and sampled volume are pinned by the C = 4 fixture."""
     install_history_stubs()
     ref = MG.load_ref('refdet.fbocc', 'mmdet3d/models/fbbev/detectors/fbocc.py')
     FBOCC = ref.FBOCC
-    torch.manual_seed(0)
-    B, C, T, Z, Y, X = 2, 4, 3, 4, 10, 12
+    torch.manual_seed(seed)
+    B, T = 2, 3
+    Z, Y, X = grid
     det = object.__new__(FBOCC)
     nn.Module.__init__(det)
     # fbocc.py:101-131 (3-D grid => Conv3d); forward_projection only contributes dx / bx (view_transformer.py gen_dx_bx)
@@ -116,15 +119,19 @@ def main():
             out[f'f{i}.ego'] = torch.stack(f['ego']).numpy()
             out[f'f{i}.seq'] = np.array(f['seq']); out[f'f{i}.start'] = np.array(f['start'])
             out[f'f{i}.out'] = res.numpy()
-            out[f'f{i}.grid'] = rec['grid'].numpy()              # (B,Z,Y,X,3) normalised sampling grid
-            out[f'f{i}.sampled'] = rec['sampled'].numpy()        # (B,T*C,Z,Y,X)
-            out[f'f{i}.history_after'] = det.history_bev.clone().numpy()   # clone: the state is mutated in place next frame
+            if full:
+                out[f'f{i}.grid'] = rec['grid'].numpy()              # (B,Z,Y,X,3) normalised sampling grid
+                out[f'f{i}.sampled'] = rec['sampled'].numpy()        # (B,T*C,Z,Y,X)
+            if full or i == len(frames) - 1:
+                out[f'f{i}.history_after'] = det.history_bev.clone().numpy()   # clone: the state is mutated in place next frame
             out[f'f{i}.sweep_time_after'] = det.history_sweep_time.clone().numpy()
             assert rec['kw'] == {'align_corners': True, 'mode': 'bilinear'}
-    path = os.path.join(MG.OUT, 'history_fusion_seq4.npz')
+    path = os.path.join(MG.OUT, name)
     np.savez_compressed(path, **out)
     print('wrote', path, os.path.getsize(path), 'bytes')
 
 
 if __name__ == '__main__':
     main()
+    # C = 16: the channel count the register-resident MFMA convolutions and the voxel-major ring take
+    main(C=16, grid=(3, 8, 9), name='history_fusion_seq4_c16.npz', full=False, seed=1)

@@ -3,15 +3,17 @@
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from oracle import history_oracle as H
 
 G = os.path.join(os.path.dirname(__file__), 'golden', 'history_fusion_seq4.npz')
+G16 = os.path.join(os.path.dirname(__file__), 'golden', 'history_fusion_seq4_c16.npz')     # C = 16: MFMA / voxel-major routes
 
 
-def load():
-    z = np.load(G)
+def load(path=G):
+    z = np.load(path)
     B, C, T, Z, Y, X = (int(v) for v in z['dims'])
     sd = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('w.')}
     return z, (B, C, T, Z, Y, X), sd
@@ -21,7 +23,8 @@ def frames(z):
     i = 0
     while f'f{i}.curr' in z.files:
         yield i, {k: torch.from_numpy(z[f'f{i}.{k}']) for k in
-                  ('curr', 'bda', 'ego', 'seq', 'start', 'out', 'grid', 'sampled', 'history_after', 'sweep_time_after')}
+                  ('curr', 'bda', 'ego', 'seq', 'start', 'out', 'grid', 'sampled', 'history_after', 'sweep_time_after')
+                  if f'f{i}.{k}' in z.files}
         i += 1
 
 
@@ -205,3 +208,77 @@ def test_folded_weights_cache_follows_parameter_updates():
     assert d is not c and not torch.equal(d[2], c[2])
     m.history_keyframe_time_conv[0].weight = torch.nn.Parameter(m.history_keyframe_time_conv[0].weight.detach() * 2)
     assert not torch.equal(m._folded_pair()[0], d[0])
+
+
+def test_oracle_reproduces_reference_sequence_c16():
+    """The C = 16 sequence of the REAL fuse_history (the channel count the MFMA convolutions and the voxel-major ring take)."""
+    z, (B, C, T, Z, Y, X), sd = load(G16)
+    assert C == 16
+    o = H.HistoryFusionOracle(H.weights_from_state_dict(sd), torch.from_numpy(z['dx']), torch.from_numpy(z['bx']), T, C)
+    n = 0
+    for i, f in frames(z):
+        out, _, _ = o.fuse(f['curr'], f['seq'], f['start'].bool(), f['ego'], f['bda'])
+        assert torch.allclose(out, f['out'], atol=2e-4), i
+        assert torch.equal(o.history_sweep_time, f['sweep_time_after']), i
+        if 'history_after' in f:
+            assert torch.allclose(o.history_bev, f['history_after'], atol=1e-4), i
+            n += 1
+    assert n == 1
+
+
+@pytest.mark.parametrize('layout,compute,dt,tol_out,tol_hist', [
+    ('planar', torch.float32, torch.float32, 2e-5, 2e-5),                 # measured 1.3e-6 / 1.1e-6 of the scale
+    ('voxel_major', torch.float32, torch.float32, 2e-5, 2e-5),            # 1.1e-6 / 1.1e-6
+    ('voxel_major', torch.float32, torch.float16, 1e-3, 1.5e-3),          # 2.2e-4 / 3.6e-4
+    ('planar', torch.bfloat16, torch.float32, 1e-2, 2e-5),                # 3.6e-3 / 1.1e-6
+    ('voxel_major', torch.bfloat16, torch.bfloat16, 1e-2, 8e-3),          # 3.3e-3 / 3.9e-3
+])
+def test_product_host_code_on_emulated_kernels_vs_reference_sequence_c16(monkeypatch, layout, compute, dt, tol_out, tol_hist):
+    """fb_bev_amd.history_fusion END TO END on CPU against the fixture of the REAL fuse_history: the module's host code
+    drives the product kernels compiled for the CPU emulator (flow, warp, slot-0 transpose, both fused convolutions --
+    fp32 MFMA / bf16 MFMA, planar / voxel-major ring, fp32 / 16-bit storage), i.e. everything but the GPU itself.
+    Tolerances (relative to the tensor's largest magnitude; measured values next to each case): fp32 routes 2e-5, 16-bit
+    storage a few half-ulps of the frames per re-sampling, bf16 arithmetic 1e-2 of the output scale."""
+    from fb_bev_amd import _capi
+    from fb_bev_amd.history_fusion import TemporalHistoryFusion
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), 'emu'))
+    import emu_capi as E
+    z, (B, C, T, Z, Y, X), sd = load(G16)
+
+    def flow_stub(hist_augs, ego, bda, dx3, lower3):
+        return E.history_flow(hist_augs, ego, bda, dx3, lower3)
+
+    def warp_stub(history, flow, out):
+        return E.history_warp(history, flow, out=out)
+
+    def warp_vm_stub(history, flow, out, grid_zyx):
+        return E.history_warp_vm(history, flow, grid_zyx, out=out)
+
+    def frame_vm_stub(curr, out, inner=1):
+        return E.history_frame_vm(curr, out.dtype, out=out, inner=inner)
+
+    def conv_stub(feats, w1, bias1, w2, bias2, out, compute=torch.float32, voxel_major=False):
+        out.copy_(E.history_conv(feats, w1.contiguous(), bias1.contiguous(), w2.contiguous(), bias2.contiguous(),
+                                 bf16=compute == torch.bfloat16, voxel_major=voxel_major))
+        return out
+    for name, fn in (('history_flow', flow_stub), ('history_warp', warp_stub), ('history_warp_vm', warp_vm_stub),
+                     ('history_frame_vm', frame_vm_stub), ('history_conv', conv_stub), ('require_gpu', lambda t, n: None)):
+        monkeypatch.setattr(_capi, name, fn)
+    m = TemporalHistoryFusion(z['dx'], z['bx'], single_bev_num_channels=C, history_cat_num=T, history_dtype=dt,
+                              history_compute=compute, ring_layout=layout).eval()
+    m.load_state_dict(sd)
+    assert m._voxel_major() == (layout == 'voxel_major')
+    for i, f in frames(z):
+        metas = [dict(sequence_group_idx=int(f['seq'][b]), start_of_sequence=bool(f['start'][b]),
+                      curr_to_prev_ego_rt=f['ego'][b]) for b in range(B)]
+        with torch.no_grad():
+            out = m.fuse_history(f['curr'].clone(), metas, f['bda'])
+        scale = f['out'].abs().max().item()
+        assert (out - f['out']).abs().max().item() <= tol_out * scale, (i, (out - f['out']).abs().max().item(), scale)
+        assert torch.equal(m.history_sweep_time, f['sweep_time_after']), i
+        if 'history_after' in f:
+            h = m.history_as_reference()
+            hs = f['history_after'].abs().max().item()
+            assert (h - f['history_after']).abs().max().item() <= tol_hist * hs, (i, (h - f['history_after']).abs().max().item(), hs)
+    assert m.history_bev.dim() == (4 if layout == 'voxel_major' else 5) and m.history_bev.dtype == dt
