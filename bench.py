@@ -175,7 +175,7 @@ def run_forward(args):
     import torch.distributed as dist
     from fb_bev_amd import _capi
     from fb_bev_amd import synthetic as S
-    from fb_bev_amd.view_transformer import LSSViewTransformerFunction3D, _IndexSet
+    from fb_bev_amd.view_transformer import LSSViewTransformerFunction3D
 
     from fb_bev_amd import shard
     world, rank, local_rank = shard.world()

@@ -10,7 +10,6 @@ The convolutions stay on the vendor library; the losses are the sync-free restat
 """
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 from torch.utils.checkpoint import checkpoint
 
 from . import occ_loss as L

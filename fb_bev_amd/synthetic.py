@@ -8,7 +8,7 @@ N(0,1) context features.  Everything is generated on CPU from a fixed seed so th
 oracle and the GPU path see identical bits.
 """
 import math
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Dict, List, Tuple
 
 import torch

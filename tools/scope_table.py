@@ -12,7 +12,7 @@ JSON this writes (profiles/rNN_scope_table.json).  fp32, synthetic data, p10 / p
   S4  full detector, images -> occupancy ids (shipped config)              B=1: fp32-MFMA convolution route (default), bf16_tiled route
   S5  full training step (forward_train + backward + clip + AdamW)         B=2, B=4 (= BASELINE configs[3] per-GPU batch)
 """
-import json, os, sys, time
+import json, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from fb_bev_amd import _capi, configs, shard, synthetic as S
