@@ -54,7 +54,7 @@ def parse():
     ap.add_argument('--streams', type=int, default=1,
                     help='forward mode, N=1, experiment: after the timed loop, time the same steps once more with consecutive '
                          'batches on this many HIP streams (the rank build of batch i+1 may overlap the pooling of batch i); '
-                         'reported as the extra "pipelined" object, never as `value`.  Measured gain on MI355X: 4-12 %, not '
+                         'reported as the extra "pipelined" object, never as `value`.  Measured gain on MI355X: 4-12 %%, not '
                          'stable (profiles/r02_exp_stream_overlap.jsonl), so off by default')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--mode', choices=['forward', 'train'], default='forward')
