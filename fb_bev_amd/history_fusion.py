@@ -174,7 +174,7 @@ class TemporalHistoryFusion(nn.Module):
         else:
             with torch.no_grad():
                 if self._voxel_major():
-                    out, nxt = self._fuse_infer_vm(curr_bev.detach().float(), flow, sweep.to(dev, non_blocking=True))
+                    out, nxt = self._fuse_infer_vm(curr_bev.detach().float(), curr.detach(), flow, sweep.to(dev, non_blocking=True))
                     self.history_bev = nxt[:, :T]                      # (B, T, N, C) view of the buffer just written
                 else:
                     out, nxt = self._fuse_infer(curr.detach(), flow, sweep.to(dev, non_blocking=True))
@@ -235,8 +235,10 @@ class TemporalHistoryFusion(nn.Module):
         out = self.history_keyframe_cat_conv(f.reshape(B, -1, Z, Y, X))                                      # :308-310
         return out, feats_cat
 
-    def _fuse_infer_vm(self, curr_yxz, flow, sweep):
-        """_fuse_infer on the voxel-major ring; curr_yxz is the (B, C, Y, X, Z) volume as handed over (not permuted)."""
+    def _fuse_infer_vm(self, curr_yxz, curr_zyx, flow, sweep):
+        """_fuse_infer on the voxel-major ring; curr_yxz is the (B, C, Y, X, Z) volume as handed over, curr_zyx the same
+        tensor permuted to (B, C, Z, Y, X) (fbocc.py:212) -- whichever of the two is contiguous feeds the slot-0 transpose
+        (the view transformation returns a (Y, X, Z)-shaped VIEW of a (Z, Y, X) buffer: no copy either way)."""
         T, C = self.history_cat_num, self.single_bev_num_channels
         B, _, Y, X, Z = curr_yxz.shape
         n = Z * Y * X
@@ -251,7 +253,10 @@ class TemporalHistoryFusion(nn.Module):
             if hist.dtype != self.history_dtype:                       # the storage type was changed between frames
                 hist = hist.to(self.history_dtype)
             nxt = b if hist.data_ptr() == a.data_ptr() else a
-        _capi.history_frame_vm(curr_yxz.contiguous().view(B, C, n), nxt[:, 0], inner=Z)     # slot 0 = current frame (:286)
+        if curr_zyx.is_contiguous():                                   # slot 0 = current frame (:286)
+            _capi.history_frame_vm(curr_zyx.view(B, C, n), nxt[:, 0])
+        else:
+            _capi.history_frame_vm(curr_yxz.contiguous().view(B, C, n), nxt[:, 0], inner=Z)
         _capi.history_warp_vm(hist, flow, nxt[:, 1:], (Z, Y, X))                            # slots 1..T (:275)
         w1, wt, b1, w2, b2 = self._folded_pair()
         tau = (sweep * self.history_cam_sweep_freq).reshape(B * (T + 1), 1)

@@ -272,8 +272,12 @@ def test_product_host_code_on_emulated_kernels_vs_reference_sequence_c16(monkeyp
     for i, f in frames(z):
         metas = [dict(sequence_group_idx=int(f['seq'][b]), start_of_sequence=bool(f['start'][b]),
                       curr_to_prev_ego_rt=f['ego'][b]) for b in range(B)]
+        curr = f['curr'].clone()
+        if i % 2 == 1:           # as the view transformation hands it over: a (Y, X, Z)-shaped view of a (Z, Y, X) buffer
+            curr = curr.permute(0, 1, 4, 2, 3).contiguous().permute(0, 1, 3, 4, 2)
+            assert not curr.is_contiguous()
         with torch.no_grad():
-            out = m.fuse_history(f['curr'].clone(), metas, f['bda'])
+            out = m.fuse_history(curr, metas, f['bda'])
         scale = f['out'].abs().max().item()
         assert (out - f['out']).abs().max().item() <= tol_out * scale, (i, (out - f['out']).abs().max().item(), scale)
         assert torch.equal(m.history_sweep_time, f['sweep_time_after']), i
