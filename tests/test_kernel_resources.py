@@ -70,3 +70,46 @@ def test_hot_kernels_keep_their_register_budget(res, pattern):
     assert hits, pattern
     over = {k: n for k, n in hits.items() if n > BUDGETS[pattern]}
     assert not over, over
+
+
+# ---------------------------------------------------------------- memory-operation skeleton of the prefetching kernels
+# (tools/isa_waits.py).  What these guard was found the hard way (history fusion): a select behind a load, a
+# register rotation or a branch around a load put an `s_waitcnt vmcnt(0)` behind the prefetch and the kernel ran 30 %
+# slower with every result unchanged.
+@pytest.fixture(scope='module')
+def skeletons():
+    import isa_waits as IW
+    from fb_bev_amd import build
+    asm = IW.disassemble(build.build())
+    out = {}
+    for m in re.finditer(r'^[0-9a-f]+ <(\S+)>:\n(.*?)(?=\n\n|\Z)', asm, re.S | re.M):
+        if 'k_history' in m.group(1):
+            out[m.group(1)] = IW.skeleton(m.group(2).splitlines())
+    return out
+
+
+@pytest.mark.parametrize('et', [0, 1, 2])
+def test_history_conv_bf16_frame_loop_never_drains_the_load_queue(skeletons, et):
+    """k_history_conv_bf16<5,5,ET,voxel-major>: three frame bodies (the unrolled 3-slot X prefetch), each opened by the one
+    workgroup barrier; inside them the bias and W2 loads are waited for with a non-zero count, i.e. the X rows of the next
+    frames stay in flight."""
+    name = next(k for k in skeletons if f'k_history_conv_bf16ILi5ELi5ELi{et}ELb1E' in k)
+    parts = skeletons[name].split(' | s_barrier | ')
+    assert len(parts) == 4, len(parts)                      # prologue + 3 unrolled frame bodies
+    for body in parts[1:]:
+        assert 'WAIT vmcnt(0)' not in body, body[:300]
+        assert body.count('mfma') >= 2 and 'gload' in body
+
+
+@pytest.mark.parametrize('et', [0, 1, 2])
+def test_history_warp_vm_issues_both_frames_taps_before_the_first_wait(skeletons, et):
+    """k_history_warp_vm<ET,2>: the frame loop issues its 16 sixteen-byte taps (2 frames x 8) back to back, then consumes them
+    in order (first wait = vmcnt(15)) -- with a `break` in the store loop the compiler had split it into 8 + 8."""
+    name = next(k for k in skeletons if f'k_history_warp_vmILi{et}ELi2E' in k)
+    sk = skeletons[name]
+    loop = sk[sk.rindex('sload'):]
+    first_wait = loop.index('WAIT vmcnt(')
+    issued = sum(int(m.group(1) or 1) for m in re.finditer(r'gload(?: x(\d+))?', loop[:first_wait]))
+    assert issued == 16, (issued, loop[:400])
+    assert loop[first_wait:].startswith('WAIT vmcnt(15)')
+    assert 'WAIT vmcnt(0)' not in loop.split('gstore')[0]
