@@ -771,8 +771,14 @@ def test_history_voxel_major_ring_equals_planar_kernels_emulated(dt):
     vol = torch.randn(2, 16, 5, 7, 3, generator=g)                            # B, C, Y, X, Z
     got = E.history_frame_vm(vol.view(2, 16, -1), dt, inner=3)
     assert torch.equal(got.view(bits), vol.permute(0, 4, 2, 3, 1).reshape(2, -1, 16).to(dt).contiguous().view(bits))
-    # the convolutions read rows: same bits as from planes
-    for Cc, T1, n in ((16, 3, 70), (80, 2, 33)):
+    # a single frame (the two-frames-per-thread batch clamps to it), C = 80
+    one = (torch.randn(1, 1, 80, N, generator=g)).to(dt)
+    f1 = torch.eye(4)[None].clone(); f1[0, :3, 3] = torch.tensor([0.5, 0.25, -0.5])
+    got1 = E.history_warp_vm(one.transpose(2, 3).contiguous(), f1, (Z, Y, X))
+    exp1 = E.history_warp(one.reshape(1, 80, Z, Y, X), f1)
+    assert torch.equal(got1.transpose(2, 3).reshape(1, 80, Z, Y, X).contiguous().view(bits), exp1.view(bits))
+    # the convolutions read rows: same bits as from planes (T1 = 1: the 3-slot prefetch ring with a single frame)
+    for Cc, T1, n in ((16, 3, 70), (80, 2, 33), (16, 1, 20), (80, 5, 16)):
         feats = torch.randn(2, T1, Cc, n, generator=g).to(dt)
         w1, w2 = torch.randn(Cc, Cc, generator=g) * 0.3, torch.randn(Cc, T1 * Cc, generator=g) * 0.2
         b1, b2 = torch.randn(2 * T1, Cc, generator=g), torch.randn(Cc, generator=g)
