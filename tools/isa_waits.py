@@ -5,7 +5,8 @@ What it is for: an `s_waitcnt vmcnt(0)` right behind a prefetch, a load that the
 an in-order counter makes an earlier consumer wait for -- the things that cost the history kernels 30 %.
     python tools/isa_waits.py                       one line per kernel: instructions, vmcnt(0) waits
     python tools/isa_waits.py <substr> [<substr>..]  skeletons of the kernels whose mangled name contains every substring
-                                                     (at most 4; --all lifts the cap)"""
+                                                     (at most 4; --all lifts the cap)
+    --lib PATH                                       another HIP binary instead of fb_bev_amd/libfbbev_hip.so"""
 import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LLVM = '/opt/rocm/lib/llvm/bin'
@@ -49,8 +50,14 @@ def skeleton(body):
 
 
 def main():
-    pats = [a for a in sys.argv[1:] if not a.startswith('--')]
-    asm = disassemble()
+    args = sys.argv[1:]
+    lib = None
+    if '--lib' in args:                                     # any HIP binary with a .hip_fatbin section (e.g. tools/micro/*)
+        i = args.index('--lib')
+        lib = args[i + 1]
+        del args[i:i + 2]
+    pats = [a for a in args if not a.startswith('--')]
+    asm = disassemble(lib)
     shown = 0
     for m in re.finditer(r'^[0-9a-f]+ <(\S+)>:\n(.*?)(?=\n\n|\Z)', asm, re.S | re.M):
         name, body = m.group(1), m.group(2).splitlines()

@@ -1,0 +1,186 @@
+// Next-round experiment (lead 7), NOT part of libfbbev_hip.so: does a two-stage issue / consume pipeline of the
+// unit-per-lane bilinear sampler beat the shipped loop (all 12 corner loads of a sample drained before it is blended)?
+// Both kernels below run the product's own sampler arithmetic (msda_kernels.h) on synthetic chunk-major camera-token rows
+// of one level -- a lane owns a (query, head) unit with DH = 10 channels and LP samples around a reference point -- and
+// must produce the same bits; the program checks that, times both and prints one JSON line.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I fb_bev_amd/csrc/hip_rt -I fb_bev_amd/csrc tools/micro/unit_sampler_pipeline.hip \
+//         -o tools/micro/unit_sampler_pipeline && tools/micro/unit_sampler_pipeline [Q] [LP] [lds_kb]
+//   lds_kb: dynamic LDS per 256-thread workgroup, only to cap the occupancy like the product kernels' register budgets do
+//   (48 -> 3 workgroups per CU = 3 waves per SIMD, 72 -> 2)
+//   python tools/isa_waits.py --lib tools/micro/unit_sampler_pipeline k_pipelined     (memory / wait skeleton, no GPU needed)
+#include "rt.h"
+#include "msda_kernels.h"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <vector>
+
+constexpr int DH = 10, M = 8, HS = 12, DHP = 12;          // head dim, heads, padded head stride: rows of M * HS = 96 floats
+
+struct sample_in { float ox, oy, attn; };                   // per (unit, sample): offset in pixels, attention weight
+
+// the shipped loop shape: setup -> 12 loads -> blend, one sample at a time (k_da_cross_attn_fwd_unit / k_msda_fwd_unit)
+__global__ void __launch_bounds__(256)
+k_baseline(const float* __restrict__ value, const float* __restrict__ ref, const sample_in* __restrict__ smp, int units, int LP,
+           int H, int W, float* __restrict__ out) {
+    const int unit = blockIdx.x * blockDim.x + threadIdx.x;
+    if (unit >= units) return;
+    const int q = unit / M, m = unit - q * M;
+    const int row_stride = M * HS, chunk_stride = M * 4;
+    const unsigned lane_off = (unsigned)(m * 4 * 4);
+    const float rx = ref[2 * q], ry = ref[2 * q + 1];
+    float col[DH];
+#pragma unroll
+    for (int c = 0; c < DH; ++c) col[c] = 0.f;
+    const sample_in* sp = smp + unit;                       // [sample][unit]: the lanes of a wave read consecutive records
+    for (int i = 0; i < LP; ++i) {
+        const sample_in s0 = sp[(long long)i * units];
+        const float h_im = (ry + s0.oy / H) * H - 0.5f, w_im = (rx + s0.ox / W) * W - 0.5f;
+        if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
+            const fbbev_bilinear s = fbbev_bilinear_setup(h_im, w_im, H, W, row_stride);
+            fbbev_unit_sample<DH, 4>(value, lane_off, s, chunk_stride, s0.attn, col);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < DH; ++c) out[(long long)unit * DH + c] = col[c];
+}
+
+// issue / consume halves of fbbev_unit_sample<DH, 4>: the SAME arithmetic on the same (unconditional, clamped) corner rows.
+// The third chunk of a head holds channels 8, 9 and two padding floats: it is loaded as 8 bytes -- a 16-byte load leaves two
+// destination registers per corner that nothing reads, the allocator hands them to temporaries, and the write-after-write
+// hazard on an in-flight load becomes an s_waitcnt that drains the pipeline (seen as `vmcnt(1)` in the first build).
+struct pending {
+    fbbev_v4f a1[2], a2[2], a3[2], a4[2];
+    fbbev_v2f t1, t2, t3, t4;
+    float w1, w2, w3, w4, weight;
+    bool k1, k2, k3, k4, live;
+};
+static_assert(DH == 10, "two full chunks + one half chunk");
+
+__device__ __forceinline__ void issue(const float* __restrict__ value, unsigned lane_off, int chunk_stride, int row_stride,
+                                      float h_im, float w_im, int H, int W, float attn, pending& p) {
+    p.live = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
+    // an out-of-range sample still loads (from the level's first token, like a padded corner): no branch around the loads
+    const fbbev_bilinear s = fbbev_bilinear_setup(p.live ? h_im : 0.f, p.live ? w_im : 0.f, H, W, row_stride);
+    p.k1 = s.o1 >= 0; p.k2 = s.o2 >= 0; p.k3 = s.o3 >= 0; p.k4 = s.o4 >= 0;
+    p.w1 = s.w1; p.w2 = s.w2; p.w3 = s.w3; p.w4 = s.w4; p.weight = attn;
+    const char* vb = reinterpret_cast<const char*>(value);
+    const unsigned b1 = lane_off + (p.k1 ? (unsigned)s.o1 * 4u : 0u), b2 = lane_off + (p.k2 ? (unsigned)s.o2 * 4u : 0u);
+    const unsigned b3 = lane_off + (p.k3 ? (unsigned)s.o3 * 4u : 0u), b4 = lane_off + (p.k4 ? (unsigned)s.o4 * 4u : 0u);
+    const unsigned cs = (unsigned)chunk_stride * 4u;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        p.a1[k] = *reinterpret_cast<const fbbev_v4f*>(vb + (b1 + k * cs));
+        p.a2[k] = *reinterpret_cast<const fbbev_v4f*>(vb + (b2 + k * cs));
+        p.a3[k] = *reinterpret_cast<const fbbev_v4f*>(vb + (b3 + k * cs));
+        p.a4[k] = *reinterpret_cast<const fbbev_v4f*>(vb + (b4 + k * cs));
+    }
+    p.t1 = *reinterpret_cast<const fbbev_v2f*>(vb + (b1 + 2 * cs));
+    p.t2 = *reinterpret_cast<const fbbev_v2f*>(vb + (b2 + 2 * cs));
+    p.t3 = *reinterpret_cast<const fbbev_v2f*>(vb + (b3 + 2 * cs));
+    p.t4 = *reinterpret_cast<const fbbev_v2f*>(vb + (b4 + 2 * cs));
+}
+
+__device__ __forceinline__ void consume(const pending& p, float (&col)[DH]) {
+    if (!p.live) return;                                    // pure VALU below: a branch here does not touch the load queue
+#pragma unroll
+    for (int c = 0; c < DH; ++c) {
+        const int k = c >> 2, e = c & 3;
+        const float v1 = p.k1 ? (c < 8 ? p.a1[k & 1][e] : p.t1[e & 1]) : 0.f, v2 = p.k2 ? (c < 8 ? p.a2[k & 1][e] : p.t2[e & 1]) : 0.f;
+        const float v3 = p.k3 ? (c < 8 ? p.a3[k & 1][e] : p.t3[e & 1]) : 0.f, v4 = p.k4 ? (c < 8 ? p.a4[k & 1][e] : p.t4[e & 1]) : 0.f;
+        col[c] += (p.w1 * v1 + p.w2 * v2 + p.w3 * v3 + p.w4 * v4) * p.weight;
+    }
+}
+
+// two register slots indexed at compile time (the loop is unrolled by two: rotating in-flight registers would wait for
+// them); sample i + 1 is issued before sample i is blended
+__global__ void __launch_bounds__(256)
+k_pipelined(const float* __restrict__ value, const float* __restrict__ ref, const sample_in* __restrict__ smp, int units, int LP,
+            int H, int W, float* __restrict__ out) {
+    const int unit = blockIdx.x * blockDim.x + threadIdx.x;
+    if (unit >= units) return;
+    const int q = unit / M, m = unit - q * M;
+    const int row_stride = M * HS, chunk_stride = M * 4;
+    const unsigned lane_off = (unsigned)(m * 4 * 4);
+    const float rx = ref[2 * q], ry = ref[2 * q + 1];
+    float col[DH];
+#pragma unroll
+    for (int c = 0; c < DH; ++c) col[c] = 0.f;
+    const sample_in* sp = smp + unit;
+    // three stages: parameters of sample i + 2 (one 12-byte load, issued FIRST: vmcnt retires in order, so it must be older
+    // than the corner loads it will be waited past), corners of sample i + 1, blend of sample i
+    auto params = [&](int i) { return sp[(long long)(i < LP ? i : LP - 1) * units]; };      // clamped: the tail loads duplicates that are never consumed
+    auto start = [&](const sample_in& s0, pending& p) {
+        const float h_im = (ry + s0.oy / H) * H - 0.5f, w_im = (rx + s0.ox / W) * W - 0.5f;
+        issue(value, lane_off, chunk_stride, row_stride, h_im, w_im, H, W, s0.attn, p);
+    };
+    pending pa, pb;
+    sample_in q0 = params(0), q1 = params(1);
+    start(q0, pa);
+    for (int i = 0; i < LP; i += 2) {
+        q0 = params(i + 2);
+        fbbev_sched_fence();
+        start(q1, pb);                                       // corners of sample i + 1
+        fbbev_sched_fence();
+        consume(pa, col);                                    // sample i
+        q1 = params(i + 3);
+        fbbev_sched_fence();
+        start(q0, pa);                                       // corners of sample i + 2
+        fbbev_sched_fence();
+        if (i + 1 < LP) consume(pb, col);                    // sample i + 1
+    }
+#pragma unroll
+    for (int c = 0; c < DH; ++c) out[(long long)unit * DH + c] = col[c];
+}
+
+static float frand(unsigned& s) { s = s * 1664525u + 1013904223u; return (float)(s >> 8) / 16777216.0f; }
+
+int main(int argc, char** argv) {
+    const int Q = argc > 1 ? atoi(argv[1]) : 160000, LP = argc > 2 ? atoi(argv[2]) : 32;
+    const size_t lds = (size_t)(argc > 3 ? atoi(argv[3]) : 0) * 1024;
+    const int H = 116, W = 200, S = H * W, units = Q * M;
+    std::vector<float> value((size_t)S * M * HS), ref((size_t)Q * 2);
+    std::vector<sample_in> smp((size_t)units * LP);
+    unsigned seed = 12345u;
+    for (auto& v : value) v = frand(seed) - 0.5f;
+    // reference points scan the level like a BEV grid projected into one camera: neighbouring queries sample neighbouring
+    // tokens (with RANDOM reference points the first run of this program was L2-miss bound and showed no difference at any
+    // occupancy: 3.96 vs 4.00 ms, profiles/r02_exp_unit_sampler_pipeline.jsonl)
+    const int side = (int)ceil(sqrt((double)Q));
+    for (int q = 0; q < Q; ++q) { ref[2 * q] = ((q % side) + 0.5f) / side; ref[2 * q + 1] = ((q / side) + 0.5f) / side; }
+    for (auto& s : smp) { s.ox = (frand(seed) - 0.5f) * 12.f; s.oy = (frand(seed) - 0.5f) * 12.f; s.attn = frand(seed) / LP; }
+    float *dv, *dr, *o0, *o1; sample_in* ds;
+    hipMalloc(&dv, value.size() * 4); hipMalloc(&dr, ref.size() * 4); hipMalloc(&ds, smp.size() * sizeof(sample_in));
+    hipMalloc(&o0, (size_t)units * DH * 4); hipMalloc(&o1, (size_t)units * DH * 4);
+    hipMemcpy(dv, value.data(), value.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(dr, ref.data(), ref.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(ds, smp.data(), smp.size() * sizeof(sample_in), hipMemcpyHostToDevice);
+    const int blocks = (units + 255) / 256;
+    if (lds > 64 * 1024) {
+        hipFuncSetAttribute((const void*)k_baseline, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)k_pipelined, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float ms[2] = {0.f, 0.f};
+    for (int which = 0; which < 2; ++which) {
+        for (int it = 0; it < 23; ++it) {
+            if (it == 3) hipEventRecord(e0);
+            if (which == 0) hipLaunchKernelGGL(k_baseline, dim3(blocks), dim3(256), lds, 0, dv, dr, ds, units, LP, H, W, o0);
+            else hipLaunchKernelGGL(k_pipelined, dim3(blocks), dim3(256), lds, 0, dv, dr, ds, units, LP, H, W, o1);
+        }
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms[which], e0, e1);
+        ms[which] /= 20.f;
+    }
+    std::vector<float> h0((size_t)units * DH), h1((size_t)units * DH);
+    hipMemcpy(h0.data(), o0, h0.size() * 4, hipMemcpyDeviceToHost);
+    hipMemcpy(h1.data(), o1, h1.size() * 4, hipMemcpyDeviceToHost);
+    const bool same = memcmp(h0.data(), h1.data(), h0.size() * 4) == 0;
+    double maxd = 0.0, maxv = 0.0;
+    for (size_t i = 0; i < h0.size(); ++i) { const double d = fabs((double)h0[i] - h1[i]); if (d > maxd) maxd = d; if (fabs(h0[i]) > maxv) maxv = fabs(h0[i]); }
+    printf("{\"experiment\": \"unit sampler: one sample at a time vs issue/consume pipeline\", \"Q\": %d, \"LP\": %d, \"level\": [%d, %d], \"lds_kb\": %d, "
+           "\"baseline_ms\": %.4f, \"pipelined_ms\": %.4f, \"bits_equal\": %s, \"max_abs_diff\": %.3g, \"max_abs\": %.3g, \"hip_error\": %d}\n",
+           Q, LP, H, W, (int)(lds / 1024), ms[0], ms[1], same ? "true" : "false", maxd, maxv, (int)hipGetLastError());
+    return maxd <= 1e-5 * maxv ? 0 : 1;        // fp contraction may group the FMAs differently in the two kernels
+}
