@@ -196,7 +196,7 @@ def s4_s5(quick):
 def main():
     out = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1].endswith('.json') else os.path.join(ROOT, 'gpurun_out', 'scope_table.json')
     quick = 'quick' in sys.argv
-    n = 20 if quick else 50
+    n = 20 if quick else 100                 # at least 100 timed iterations (round-2 tables were taken with 50)
     only6 = 'only_s6' in sys.argv
     for name in (() if only6 else ('REF', 'BL2')):
         s1_s2(name, 16, n)
