@@ -120,6 +120,11 @@ __device__ __forceinline__ fbbev_v4f fbbev_mfma_f32_16x16x32_bf16(fbbev_bf16x8 a
 // instruction-scheduling fence: nothing is moved across it (keeps prefetch loads ahead of the MFMA block they overlap)
 __device__ __forceinline__ void fbbev_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 
+// value barrier: the compiler must materialise x here and may not look through it (used where an LDS load followed by a
+// conditional global override of the same variable was if-converted into ONE flat load of a selected pointer)
+__device__ __forceinline__ void fbbev_opaque(int& x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void fbbev_opaque(float& x) { asm volatile("" : "+v"(x)); }
+
 __device__ __forceinline__ void fbbev_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();

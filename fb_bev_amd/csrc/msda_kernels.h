@@ -233,7 +233,9 @@ k_msda_fwd_unit(long long n_units, const float* __restrict__ value, const int64_
                 const fbbev_v2f o = o_next;
                 o_next = op[(long long)(lp + 1 < LP ? lp + 1 : lp) * wo_step];
                 const float loc_w = rx + __fdiv_rn(o[0], (float)sw), loc_h = ry + __fdiv_rn(o[1], (float)sh);
-                const float weight = stage_attn ? my_attn[lp] : attn[unit * LP + lp];
+                float weight;                                   // (uniform branch, LDS read kept an LDS read: see k_da_cross_attn_fwd_unit)
+                if (stage_attn) { weight = my_attn[lp]; fbbev_opaque(weight); }
+                else weight = attn[unit * LP + lp];
                 const float h_im = loc_h * sh - 0.5f, w_im = loc_w * sw - 0.5f;
                 if (!(h_im > -1.f && w_im > -1.f && h_im < (float)sh && w_im < (float)sw)) continue;
                 const fbbev_bilinear s = fbbev_bilinear_setup(h_im, w_im, sh, sw, row_stride);

@@ -203,12 +203,23 @@ __device__ __forceinline__ void fbbev_interval_sum_staged(int c, int s, int len,
     for (int j = 0; j < CPL; ++j) acc[j] = 0.f;
     int k = 0;
     for (; k + U <= len; k += U) {
+        // index pairs: ALWAYS an LDS read (clamped into the staged range), overridden from global memory only by the lanes
+        // whose points lie beyond it (rare: a tile with more than FBBEV_NP_STAGE points).  Written as `idx < N ? lds[idx] :
+        // global[idx]` the compiler selected between the two POINTERS and issued flat_load_dword -- eight flat loads and ~50
+        // VALU instructions of 64-bit address selects per batch (tools/isa_waits.py; flat loads also count on both wait counters)
         int pd[U], pf[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int idx = s + k + u;
-            if (idx < FBBEV_NP_STAGE) { pd[u] = prd_lds[idx]; pf[u] = prf_lds[idx]; }
-            else { pd[u] = rd[p0 + idx]; pf[u] = rf[p0 + idx]; }
+            const int il = idx < FBBEV_NP_STAGE ? idx : FBBEV_NP_STAGE - 1;
+            pd[u] = prd_lds[il]; pf[u] = prf_lds[il];
+        }
+        if (s + k + U > FBBEV_NP_STAGE) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = s + k + u;
+                if (idx >= FBBEV_NP_STAGE) { pd[u] = rd[p0 + idx]; pf[u] = rf[p0 + idx]; }
+            }
         }
         float d[U];
         float f[U][CPL];
@@ -230,9 +241,10 @@ __device__ __forceinline__ void fbbev_interval_sum_staged(int c, int s, int len,
     }
     for (; k < len; ++k) {
         const int idx = s + k;
-        int pd, pf;
-        if (idx < FBBEV_NP_STAGE) { pd = prd_lds[idx]; pf = prf_lds[idx]; }
-        else { pd = rd[p0 + idx]; pf = rf[p0 + idx]; }
+        const int il = idx < FBBEV_NP_STAGE ? idx : FBBEV_NP_STAGE - 1;
+        int pd = prd_lds[il], pf = prf_lds[il];
+        fbbev_opaque(pd); fbbev_opaque(pf);                  // keep these LDS reads (see above): this loop takes the short intervals
+        if (idx >= FBBEV_NP_STAGE) { pd = rd[p0 + idx]; pf = rf[p0 + idx]; }
         const float d0 = depth[pd];
         const float* fp = fbase + (long long)pf * c;
 #pragma unroll

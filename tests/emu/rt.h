@@ -250,3 +250,5 @@ inline float fbbev_f16_bits_to_f32(unsigned int h) {
 }
 inline void fbbev_wave_sync() { emu::wave_barrier(); }
 inline void fbbev_sched_fence() {}
+inline void fbbev_opaque(int&) {}
+inline void fbbev_opaque(float&) {}

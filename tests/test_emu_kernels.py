@@ -102,6 +102,41 @@ def test_pool_dense_matches_oracle(tv, flags):
     assert torch.equal(out, exp)
 
 
+@pytest.mark.parametrize('tv,flags', [(128, 4), (128, 0x24), (256, 0), (128, 0x125)])
+def test_pool_dense_tile_with_more_points_than_the_staged_index_window(tv, flags):
+    """A tile whose points do not fit the FBBEV_NP_STAGE = 512 index pairs staged in LDS: intervals before, ACROSS (in the
+    4-point batches and in the one-point tail) and beyond the window take their indices from LDS / global memory / both.
+    Hand-built index set on a 1 x 8 x 32 grid (two 128-voxel tiles per plane), lengths 1..37; bit-exact vs the oracle."""
+    g = torch.Generator().manual_seed(tv + flags)
+    B, Z, Y, X, C = 1, 2, 8, 32, 16
+    YX = Y * X
+    lens = torch.randint(1, 12, (B * Z * YX,), generator=g)
+    lens[torch.randperm(lens.numel(), generator=g)[:40]] = torch.randint(20, 38, (40,), generator=g)   # long intervals too
+    lens[torch.randperm(lens.numel(), generator=g)[:60]] = 0                                           # and empty voxels
+    ranks = torch.repeat_interleave(torch.arange(B * Z * YX), lens).int()       # sorted voxel rank of every point
+    P = ranks.numel()
+    assert P > 2500                                                              # ~ 700 points per 128-voxel tile
+    n_src = 900
+    rd = torch.randint(0, n_src, (P,), generator=g).int()
+    rf = torch.randint(0, n_src // 4, (P,), generator=g).int()
+    depth = torch.randn(1, 1, 1, 1, n_src, generator=g)
+    feat = torch.randn(1, 1, 1, n_src // 4, C, generator=g)
+    st, ln = O.intervals_from_sorted(ranks)
+    st, ln = st.int().contiguous(), ln.int().contiguous()
+    ir = ranks[st.long()].contiguous()
+    counts = torch.tensor([P, st.numel()], dtype=torch.int32)
+    code, out = E.pool_dense(depth, feat, rd, rf, ir, st, ln, counts, st.numel(), B, C, Z, Y, X, tv, flags)
+    assert code == 0
+    exp = O.bev_pool_v2(depth, feat, rd, rf, ranks, (B, Z, Y, X, C), st, ln, use_fma=True)
+    assert not torch.isnan(out).any()
+    assert torch.equal(out, exp)
+    # the case is what the docstring says: some interval starts inside the window and ends beyond it, in every tile
+    tile = (ranks.long() // YX) * (YX // tv) + (ranks.long() % YX) // tv
+    first = torch.full((int(tile.max()) + 1,), P, dtype=torch.long).scatter_reduce_(0, tile, torch.arange(P), 'amin')
+    rel = st.long() - first[tile[st.long()]]
+    assert ((rel < 512) & (rel + ln.long() > 512)).any() and (rel >= 512).any()
+
+
 def test_pool_dense_rejects_unsupported():
     cfg, vt, coor, depth, feat = _case('TINY', 1)
     rb, rd, rf, st, ln, ir, counts = E.rank_build(coor, *_grid3(vt))

@@ -113,3 +113,19 @@ def test_history_warp_vm_issues_both_frames_taps_before_the_first_wait(skeletons
     assert issued == 16, (issued, loop[:400])
     assert loop[first_wait:].startswith('WAIT vmcnt(15)')
     assert 'WAIT vmcnt(0)' not in loop.split('gstore')[0]
+
+
+def test_no_kernel_uses_flat_memory_instructions():
+    """`cond ? lds[i] : global[j]` is if-converted into a select of the two POINTERS and one flat_load (generic address space):
+    slower than either load, counted on both wait counters, and ~6 VALU instructions of 64-bit address select each.  The
+    staged index reads of the pooling kernels and the staged attention weights of the unit samplers were compiled that way
+    until round 2 (8 flat loads + ~50 VALU per 4-point batch in k_pool_fwd_dense2)."""
+    import isa_waits as IW
+    from fb_bev_amd import build
+    asm = IW.disassemble(build.build())
+    bad = {}
+    for m in re.finditer(r'^[0-9a-f]+ <(\S+)>:\n(.*?)(?=\n\n|\Z)', asm, re.S | re.M):
+        n = sum(1 for line in m.group(2).splitlines() if re.search(r'\bflat_(load|store|atomic)', line))
+        if n:
+            bad[m.group(1)] = n
+    assert not bad, bad
