@@ -216,10 +216,12 @@ k_da_cross_attn_fwd_unit(long long n_units, const void* __restrict__ value_, con
                     const int z = p % Za;
                     const float loc_w = rx[z] + __fdiv_rn(o[0], (float)sw);
                     const float loc_h = ry[z] + __fdiv_rn(o[1], (float)sh);
-                    // uniform branch with the LDS read kept as an LDS read: as `stage_attn ? my_attn[lp] : attn[..]` the two POINTERS
-                    // were selected and one flat_load_dword per sample issued (it counts on both wait counters)
+                    // the staged weight through an explicit LDS pointer: as `stage_attn ? my_attn[lp] : attn[..]` the two
+                    // (generic) POINTERS were selected and one flat_load_dword per sample issued -- generic address space,
+                    // counted on both wait counters.  The value is first needed when the sample is blended, so the ds_read
+                    // overlaps the corner loads.
                     float a;
-                    if (stage_attn) { a = my_attn[lp]; fbbev_opaque(a); }
+                    if (stage_attn) a = fbbev_lds_ld_f32(my_attn + lp);
                     else a = attn[(head_minor & 2) ? (bq * LP + lp) * M + m : unit * LP + lp];
                     const float weight = a * dw[z];
                     const float h_im = loc_h * sh - 0.5f, w_im = loc_w * sw - 0.5f;

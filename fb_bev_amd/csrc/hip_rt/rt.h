@@ -124,6 +124,11 @@ __device__ __forceinline__ void fbbev_sched_fence() { __builtin_amdgcn_sched_bar
 // conditional global override of the same variable was if-converted into ONE flat load of a selected pointer)
 __device__ __forceinline__ void fbbev_opaque(int& x) { asm volatile("" : "+v"(x)); }
 __device__ __forceinline__ void fbbev_opaque(float& x) { asm volatile("" : "+v"(x)); }
+// read of a float that is KNOWN to live in LDS, through an explicit local-address-space pointer: always a ds_read, never
+// merged with a global load of the other arm of a condition
+__device__ __forceinline__ float fbbev_lds_ld_f32(const float* p) {
+    return *(const __attribute__((address_space(3))) float*)p;
+}
 
 __device__ __forceinline__ void fbbev_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

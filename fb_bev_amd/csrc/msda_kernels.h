@@ -234,7 +234,7 @@ k_msda_fwd_unit(long long n_units, const float* __restrict__ value, const int64_
                 o_next = op[(long long)(lp + 1 < LP ? lp + 1 : lp) * wo_step];
                 const float loc_w = rx + __fdiv_rn(o[0], (float)sw), loc_h = ry + __fdiv_rn(o[1], (float)sh);
                 float weight;                                   // (uniform branch, LDS read kept an LDS read: see k_da_cross_attn_fwd_unit)
-                if (stage_attn) { weight = my_attn[lp]; fbbev_opaque(weight); }
+                if (stage_attn) weight = fbbev_lds_ld_f32(my_attn + lp);
                 else weight = attn[unit * LP + lp];
                 const float h_im = loc_h * sh - 0.5f, w_im = loc_w * sw - 0.5f;
                 if (!(h_im > -1.f && w_im > -1.f && h_im < (float)sh && w_im < (float)sw)) continue;

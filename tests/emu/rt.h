@@ -252,3 +252,4 @@ inline void fbbev_wave_sync() { emu::wave_barrier(); }
 inline void fbbev_sched_fence() {}
 inline void fbbev_opaque(int&) {}
 inline void fbbev_opaque(float&) {}
+inline float fbbev_lds_ld_f32(const float* p) { return *p; }
