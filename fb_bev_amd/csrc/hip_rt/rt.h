@@ -129,6 +129,7 @@ __device__ __forceinline__ void fbbev_opaque(float& x) { asm volatile("" : "+v"(
 __device__ __forceinline__ float fbbev_lds_ld_f32(const float* p) {
     return *(const __attribute__((address_space(3))) float*)p;
 }
+__device__ __forceinline__ int fbbev_lds_ld_i32(const int* p) { return *(const __attribute__((address_space(3))) int*)p; }
 
 __device__ __forceinline__ void fbbev_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -242,8 +242,9 @@ __device__ __forceinline__ void fbbev_interval_sum_staged(int c, int s, int len,
     for (; k < len; ++k) {
         const int idx = s + k;
         const int il = idx < FBBEV_NP_STAGE ? idx : FBBEV_NP_STAGE - 1;
-        int pd = prd_lds[il], pf = prf_lds[il];
-        fbbev_opaque(pd); fbbev_opaque(pf);                  // keep these LDS reads (see above): this loop takes the short intervals
+        // explicit LDS-address-space reads (see above; plain `prd_lds[il]` followed by the override was merged into a flat
+        // load again): this loop takes the short intervals, i.e. most of them at 0.4 m voxels
+        int pd = fbbev_lds_ld_i32(prd_lds + il), pf = fbbev_lds_ld_i32(prf_lds + il);
         if (idx >= FBBEV_NP_STAGE) { pd = rd[p0 + idx]; pf = rf[p0 + idx]; }
         const float d0 = depth[pd];
         const float* fp = fbase + (long long)pf * c;

@@ -253,3 +253,4 @@ inline void fbbev_sched_fence() {}
 inline void fbbev_opaque(int&) {}
 inline void fbbev_opaque(float&) {}
 inline float fbbev_lds_ld_f32(const float* p) { return *p; }
+inline int fbbev_lds_ld_i32(const int* p) { return *p; }
