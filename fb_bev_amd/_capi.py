@@ -32,7 +32,7 @@ SIGNATURES = {
     'fbbev_cam_key_words': (c_size_t, [c_int] * 2),
     'fbbev_lift_rank_build_cached': (c_int, [c_void_p] * 10 + [c_int] * 5 + [c_void_p] * 3 + [c_void_p] * 7 +
                                      [c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
-    'fbbev_pool_tile_index_cached': (c_int, [c_void_p] * 3 + [c_int] * 7 + [c_void_p, c_size_t, c_void_p, c_void_p]),
+    'fbbev_pool_tile_index_cached': (c_int, [c_void_p] * 3 + [c_int] * 7 + [c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     'fbbev_pool_dense_workspace_bytes': (c_size_t, [c_int] * 4),
     'fbbev_pool_tile_index': (c_int, [c_void_p] * 3 + [c_int] * 7 + [c_void_p, c_size_t, c_void_p]),
     'fbbev_bev_pool_v2_dense_fwd': (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_void_p, c_int64, c_int64, c_void_p,
@@ -262,7 +262,11 @@ POOL_OUT_BF16, POOL_OUT_F16 = 0x800000, 0x1000000
 
 
 def pool_tile_index(interval_rank, interval_starts, counts, n_intervals_max, B, Z, Y, X, tile_ws,
-                    tile_voxels=64, flags=0, cache_state=None):
+                    tile_voxels=64, flags=0, cache_state=None, table_gate=None):
+    """cache_state + table_gate (int32[2], one per table, initialised to -1): camera-keyed cache, the table is kept only
+    when the index set is unchanged AND this table was built for that build (fbbev_pool_tile_index_cached)."""
+    if (cache_state is None) != (table_gate is None):
+        raise FbbevError('pool_tile_index: cache_state and table_gate go together')
     with _on(interval_rank):
         args = [_dev(interval_rank, I32, 'interval_rank'), _dev(interval_starts, I32, 'interval_starts'),
                 _dev(counts, I32, 'counts'), int(n_intervals_max), B, Z, Y, X, int(tile_voxels), int(flags),
@@ -270,7 +274,8 @@ def pool_tile_index(interval_rank, interval_starts, counts, n_intervals_max, B, 
         if cache_state is None:
             _check(lib().fbbev_pool_tile_index(*args, _stream()), 'fbbev_pool_tile_index')
         else:
-            _check(lib().fbbev_pool_tile_index_cached(*args, _dev(cache_state, I32, 'cache_state'), _stream()),
+            _check(lib().fbbev_pool_tile_index_cached(*args, _dev(cache_state, I32, 'cache_state'),
+                                                      _dev(table_gate, I32, 'table_gate'), _stream()),
                    'fbbev_pool_tile_index_cached')
 
 

@@ -430,11 +430,15 @@ extern "C" int fbbev_pool_tile_index(const int32_t* interval_rank, const int32_t
 extern "C" int fbbev_pool_tile_index_cached(const int32_t* interval_rank, const int32_t* interval_starts,
                                             const int32_t* counts, int n_intervals_max, int B, int Z, int Y,
                                             int X, int tile_voxels, int flags, void* tile_ws, size_t tile_ws_bytes,
-                                            const int32_t* cache_state, fbbev_stream_t stream_) {
-    if (!cache_state) return FBBEV_E_BADARG;
+                                            const int32_t* cache_state, int32_t* table_gate,
+                                            fbbev_stream_t stream_) {
+    if (!cache_state || !table_gate) return FBBEV_E_BADARG;
     if ((flags & FBBEV_POOL_CHANNELS_LAST) && small_tile_shift(tile_voxels)) return FBBEV_E_UNSUPPORTED;
+    // keep THIS table only if the index set is unchanged and the table was built for this very build
+    FBBEV_LAUNCH(k_tile_table_gate, 1, 1, 0, (fbbev_rt_stream)stream_, cache_state, table_gate);
+    FBBEV_CHECK_LAUNCH();
     return pool_tile_index_impl(interval_rank, interval_starts, counts, n_intervals_max, B, Z, Y, X, tile_voxels, flags,
-                                tile_ws, tile_ws_bytes, stream_, cache_state);
+                                tile_ws, tile_ws_bytes, stream_, table_gate + 1);
 }
 
 static int pool_tile_index_impl(const int32_t* interval_rank, const int32_t* interval_starts,
@@ -986,12 +990,30 @@ static int da_bwd_regions(int L, const int32_t* level_hw, int S, int budget, da_
     return start == S ? n : 0;
 }
 
+// Tuning / test overrides of the plan, read ONCE per process (function-local static: thread-safe) -- the Python forward
+// derives the value-row layout from this planner and the backward launches from it, so a variable that changed between
+// the two calls must not be able to make them disagree.  Unset = the measured defaults.
+struct da_bwd_overrides { int tokens, chunks, threads, copies; };
+static da_bwd_overrides da_bwd_read_env() {
+    auto num = [](const char* name) { const char* e = getenv(name); return e ? atoi(e) : 0; };
+    return da_bwd_overrides{num("FBBEV_DA_BWD_TOKENS"), num("FBBEV_DA_BWD_CHUNKS"), num("FBBEV_DA_BWD_THREADS"),
+                            num("FBBEV_DA_BWD_COPIES")};
+}
+#ifdef FBBEV_TEST_OVERRIDES   // CPU emulator build only (tests/emu/rt.h): the tests switch plans inside one process
+static da_bwd_overrides da_bwd_env() { return da_bwd_read_env(); }
+#else
+static const da_bwd_overrides& da_bwd_env() {
+    static const da_bwd_overrides o = da_bwd_read_env();
+    return o;
+}
+#endif
+
 static bool da_bwd_tile_plan(int B, int Ncam, int S, int M, int Dh, int Q, int HS, int L, int P, const int32_t* level_hw,
                              da_bwd_plan* pl) {
     if (Dh > 16 || HS % 4 != 0 || HS > 16 || Q <= 0) return false;
     if (P > FBBEV_DA_BWD_MAXP || !(Dh == 10 || Dh == 8 || Dh == 16 || Dh == 4)) return false;
     int budget = (68 * 1024) / (HS * (int)sizeof(long long)) - 8;                  // tokens per LDS plane (64-bit words, skewed)
-    if (const char* e = getenv("FBBEV_DA_BWD_TOKENS")) { const int v = atoi(e); if (v > 0 && v < budget) budget = v; }   // tests: force bands
+    { const int v = da_bwd_env().tokens; if (v > 0 && v < budget) budget = v; }   // tests: force bands
     pl->n_regions = da_bwd_regions(L, level_hw, S, budget, pl->reg, 32);
     if (pl->n_regions == 0) return false;
     int max_tok = 0;
@@ -999,13 +1021,13 @@ static bool da_bwd_tile_plan(int B, int Ncam, int S, int M, int Dh, int Q, int H
     const size_t plane = (size_t)FBBEV_DA_PLANE_WORDS(max_tok, HS) * sizeof(long long);
     // two workgroups per CU in one round (512 of them)
     long long want = (512 + (long long)B * M - 1) / ((long long)B * M);
-    if (const char* e = getenv("FBBEV_DA_BWD_CHUNKS")) { const int v = atoi(e); if (v > 0) want = v; }
+    { const int v = da_bwd_env().chunks; if (v > 0) want = v; }
     if (want < 1) want = 1;
     if (want > 256) want = 256;
     int qpc = (int)((Q + want - 1) / want);
     // one lane per query the camera sees: 512 threads (measured 0.177 vs 0.208 ms at the shipped shape) unless the chunk is short
     pl->threads = qpc >= 512 ? 512 : 256;
-    if (const char* e = getenv("FBBEV_DA_BWD_THREADS")) { const int v = atoi(e); if (v == 256 || v == 512) pl->threads = v; }
+    { const int v = da_bwd_env().threads; if (v == 256 || v == 512) pl->threads = v; }
     const int ng = pl->threads;                                                   // queries per workgroup iteration
     qpc = (qpc + ng - 1) / ng * ng;
     if (qpc > 65535) return false;                                                // chunk-relative 16-bit query ids
@@ -1074,6 +1096,7 @@ extern "C" int fbbev_da_cross_attn_bwd_ws(const float* value, const int64_t* spa
         else if (Dh == 4) FBBEV_DA_BWD_UNIT(4);
         else FBBEV_DA_BWD_UNIT(16);
 #undef FBBEV_DA_BWD_UNIT
+        FBBEV_CHECK_LAUNCH();
         // (B) value gradient, one launch per token region
         for (int r = 0; r < pl.n_regions; ++r) {
             const da_region& rg = pl.reg[r];
@@ -1081,7 +1104,7 @@ extern "C" int fbbev_da_cross_attn_bwd_ws(const float* value, const int64_t* spa
             const size_t one = (size_t)FBBEV_DA_PLANE_WORDS(rg.tok1 - rg.tok0, HS) * sizeof(long long);
             int copies = (int)((size_t)(68 * 1024) / one);
             copies = copies < 1 ? 1 : (copies > 4 ? 4 : copies);
-            if (const char* e = getenv("FBBEV_DA_BWD_COPIES")) { const int v = atoi(e); if (v >= 1 && v <= copies) copies = v; }
+            { const int v = da_bwd_env().copies; if (v >= 1 && v <= copies) copies = v; }
             const size_t lds_b = one * copies + (size_t)((pl.q_per_chunk + 1) & ~1) * 2 + (size_t)(1 + pl.threads / 64) * sizeof(int);
 #define FBBEV_DA_BWD_SC(NT_, DH_)                                                                                       \
     FBBEV_LAUNCH((k_da_cross_attn_bwd_scatter<NT_, DH_>), wgs, NT_, lds_b, stream, spatial_shapes, level_start_index,     \
@@ -1094,6 +1117,7 @@ extern "C" int fbbev_da_cross_attn_bwd_ws(const float* value, const int64_t* spa
             else FBBEV_DA_BWD_SC_NT(16);
 #undef FBBEV_DA_BWD_SC_NT
 #undef FBBEV_DA_BWD_SC
+            FBBEV_CHECK_LAUNCH();
         }
     }
     const long long n = (long long)B * Ncam * S * M * HS;

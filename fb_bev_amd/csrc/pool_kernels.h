@@ -257,6 +257,15 @@ __device__ __forceinline__ void fbbev_interval_sum_staged(int c, int s, int len,
     }
 }
 
+// gate[0] = build number (cache_state[1]) the tile table was built for, gate[1] = "keep the table" decision of THIS call:
+// the index set is unchanged (cache_state[0] != 0) and the table belongs to that build.  A separate 1-thread launch so
+// that no workgroup of the table kernel can observe the refreshed build number of its own launch.
+__global__ void k_tile_table_gate(const int* __restrict__ cache_state, int* __restrict__ gate) {
+    const int build = cache_state[1];
+    gate[1] = (cache_state[0] != 0 && gate[0] == build) ? 1 : 0;
+    gate[0] = build;
+}
+
 // tile_meta[2*t] = first interval of tile t, tile_meta[2*t+1] = first point of tile t (t in [0,n_tiles])
 __global__ void __launch_bounds__(256)
 k_tile_lower_bound2(int n_tiles, int tiles_per_plane, int YX, int TV,

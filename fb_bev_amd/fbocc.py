@@ -106,6 +106,7 @@ class FBOCC(nn.Module):
         # the default; 'bf16' / 'bf16_tiled' are the faster reduced-precision settings, False = vendor library.
         self.mfma_conv3d = ex.get('mfma_conv3d', True)           # False | True (fp32 MFMA) | 'bf16' | 'bf16_tiled' (bf16 MFMA where Cin % 32 == 0)
         self._runners = None
+        self._runner_tensors = self._runner_key_built = None
         if ex.get('mfma_conv3d_train'):           # opt-in: the autograd route (forward + dgrad + wgrad kernels)
             from .mfma_conv3d import enable_training_route
             for blk in (self.img_bev_encoder_backbone, self.img_bev_encoder_neck, self.occupancy_head,
@@ -137,7 +138,26 @@ class FBOCC(nn.Module):
         self._runners = None                      # folded weights are rebuilt from the current parameters on next use
         return self
 
+    def _apply(self, fn, *args, **kwargs):
+        self._runners = None                      # .to() / .cuda() / .half(): the snapshots point at the old storage
+        return super()._apply(fn, *args, **kwargs)
+
+    def invalidate_folded_weights(self):
+        """Drop the BN-folded weight snapshots of the MFMA convolution runners.  They are keyed on (storage pointer,
+        in-place version) of every parameter / buffer they fold, so load_state_dict(), optimizer steps, .to() and
+        `p.copy_()` are noticed by themselves; a write through `p.data` (some EMA implementations) bumps no version
+        counter -- call this after such a swap."""
+        self._runners = None
+
+    def _runner_key(self):
+        ts = self._runner_tensors
+        return tuple(t.data_ptr() for t in ts), sum(t._version for t in ts)
+
     def _mfma_stacks(self):
+        # the runners snapshot BN-folded weights: rebuild them when any folded tensor was replaced or written in place
+        # (eval -> forward -> load_state_dict / EMA swap -> forward must not run on the old weights; ADVICE r2)
+        if self._runners is not None and self._runner_tensors is not None and self._runner_key() != self._runner_key_built:
+            self._runners = None
         if self._runners is None:
             from . import mfma_conv3d as M
             prec = self.mfma_conv3d if self.mfma_conv3d in ('bf16', 'bf16_tiled') else 'f32'
@@ -156,6 +176,13 @@ class FBOCC(nn.Module):
                 warnings.warn(f'FBOCC: convolution stacks stay on the vendor library ({e})')
                 self.mfma_conv3d = False
                 self._runners = (None, None, None, None)
+            blocks = [self.img_bev_encoder_backbone, self.img_bev_encoder_neck, self.occupancy_head]
+            if img is not None:
+                blocks += [self.img_backbone, self.img_neck]
+            self._runner_tensors = None
+            if any(r is not None for r in self._runners):
+                self._runner_tensors = [t for b in blocks if b is not None for t in list(b.parameters()) + list(b.buffers())]
+                self._runner_key_built = self._runner_key()
         return self._runners
 
     def _use_mfma(self, x):

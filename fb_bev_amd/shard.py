@@ -70,29 +70,47 @@ class GradBuckets:
       pack (`cat`) and no copy-back pass;
     * a post-accumulate-grad hook counts the bucket's parameters; when the last one has its gradient the bucket's
       all-reduce is launched asynchronously on the collective library's own stream, overlapping the rest of backward;
-    * `finish()` launches whatever is still pending (a parameter that received no gradient on this rank contributes
-      its zeros, so every rank always reduces the SAME bucket layout -- no hang when a block is unused on one rank),
-      waits, and scales by 1/world;
+    * collectives of one process group are matched by ISSUE ORDER, so the buckets are launched strictly in index order:
+      bucket i goes out from a hook only once buckets 0..i-1 have gone out, otherwise it waits for `finish()`, which
+      launches whatever is left in index order (a parameter that received no gradient on this rank contributes its
+      zeros).  Every rank therefore issues 0,1,2,... whatever subset of its parameters received gradients -- a block
+      unused on one rank delays that rank's launches, it cannot pair bucket 1 with bucket 2; `prepare_ddp`
+      additionally gives the buckets their own process group so that their issue order is independent of the
+      SyncBN all-reduces interleaved with them during backward;
+    * `finish()` then waits and scales by 1/world;
     * bucket size: a ring all-reduce over xGMI is bound by one ~153 GB/s link whatever the message count, so the
       buckets are few and large (default 64 MB; the 270 MB detector = 5 messages) instead of DDP's 25 MB.
     """
 
-    def __init__(self, params, bucket_bytes=64 << 20, group=None):
+    def __init__(self, params, bucket_bytes=64 << 20, group=None, rebuild=True):
         self.group = group
+        self.bucket_bytes = bucket_bytes
         self.params = [p for p in params if p.requires_grad]
-        order = list(reversed(self.params))
-        self.buckets = []                                   # [flat, [params], pending count, work]
-        cur, size = [], 0
+        self._hooks = []
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # first step: buckets in reverse registration order (~ the order autograd produces gradients); its finish()
+        # re-lays them out in the order the gradients ACTUALLY arrived (rank 0's order, broadcast), because with
+        # strictly ordered launches one late parameter in an early bucket holds back every bucket behind it
+        self._arrival = [] if rebuild else None
+        self._layout(list(reversed(self.params)), keep=False)
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+
+    def _layout(self, order, keep):
+        """Assign every parameter a slice of a flat fp32 bucket (order = bucket fill order); keep=True carries the
+        current gradient values over into the new slices."""
+        buckets, cur, size = [], [], 0
         for p in order:
             n = p.numel() * 4
-            if cur and size + n > bucket_bytes:
-                self.buckets.append(cur)
+            if cur and size + n > self.bucket_bytes:
+                buckets.append(cur)
                 cur, size = [], 0
             cur.append(p)
             size += n
         if cur:
-            self.buckets.append(cur)
+            buckets.append(cur)
+        self.buckets = buckets
         self._flat, self._of, self._ready, self._work = [], {}, [], []
+        self._next = 0                                      # buckets [0, _next) have been launched this step
         for bi, ps in enumerate(self.buckets):
             dev = ps[0].device
             if any(p.device != dev or p.dtype != torch.float32 for p in ps):
@@ -100,15 +118,30 @@ class GradBuckets:
             flat = torch.zeros(sum(p.numel() for p in ps), dtype=torch.float32, device=dev)
             off = 0
             for p in ps:
-                p.grad = flat[off:off + p.numel()].view_as(p)
+                view = flat[off:off + p.numel()].view_as(p)
+                if keep and p.grad is not None:
+                    view.copy_(p.grad)
+                p.grad = view
                 off += p.numel()
                 self._of[p] = bi
             self._flat.append(flat)
             self._ready.append(0)
             self._work.append(None)
-        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.nbytes = sum(f.numel() * 4 for f in self._flat)
+
+    def _rebuild(self):
+        """After the first step: bucket fill order = gradient arrival order of rank 0 (parameters that never arrived go
+        last, in reverse registration order).  One small broadcast; every rank ends with the same layout."""
+        index = {p: i for i, p in enumerate(self.params)}
+        seen = set(self._arrival)
+        ids = [index[p] for p in self._arrival] + [index[p] for p in reversed(self.params) if p not in seen]
+        self._arrival = None
+        if self.world > 1:
+            t = torch.tensor(ids, dtype=torch.int64, device=self._flat[0].device)
+            src = 0 if self.group is None else dist.get_global_rank(self.group, 0)
+            dist.broadcast(t, src=src, group=self.group)
+            ids = t.tolist()
+        self._layout([self.params[i] for i in ids], keep=True)
 
     def _launch(self, bi):
         if self.world > 1 and self._work[bi] is None:
@@ -120,8 +153,12 @@ class GradBuckets:
                 p.grad.data_ptr() >= self._flat[bi].data_ptr() + self._flat[bi].numel() * 4:
             raise RuntimeError('GradBuckets: a .grad was replaced (zero_grad(set_to_none=True)?); use buckets.zero_grad()')
         self._ready[bi] += 1
-        if self._ready[bi] == len(self.buckets[bi]):
-            self._launch(bi)
+        if self._arrival is not None:
+            self._arrival.append(p)
+        # strictly in index order: launch the run of complete buckets that starts at the first unlaunched one
+        while self._next < len(self.buckets) and self._ready[self._next] == len(self.buckets[self._next]):
+            self._launch(self._next)
+            self._next += 1
 
     def zero_grad(self):
         """Zero the flat buckets in place (the .grad views stay attached)."""
@@ -130,14 +167,17 @@ class GradBuckets:
 
     def finish(self):
         """Call after backward(), before clipping / the optimizer step: every gradient is the mean over ranks."""
-        for bi in range(len(self._flat)):
+        for bi in range(self._next, len(self._flat)):
             self._launch(bi)
+        self._next = 0
         for bi, w in enumerate(self._work):
             if w is not None:
                 w.wait()
                 self._flat[bi].div_(self.world)
             self._work[bi] = None
             self._ready[bi] = 0
+        if self._arrival is not None:
+            self._rebuild()
 
     def remove(self):
         for h in self._hooks:
@@ -299,4 +339,11 @@ def prepare_ddp(model, sync_bn=True, bucket_bytes=64 << 20, process_group=None):
     buckets reduced from autograd hooks.  -> (model, GradBuckets); call buckets.zero_grad() / buckets.finish() around
     backward().  Parameters must already be identical on all ranks (same seed or a broadcast checkpoint)."""
     model = convert_sync_batchnorm(model, process_group, sync=sync_bn)
-    return model, GradBuckets([p for p in model.parameters() if p.requires_grad], bucket_bytes, process_group)
+    grad_group = process_group
+    if dist.is_initialized() and dist.get_world_size(process_group) > 1:
+        # the gradient buckets get their OWN communicator: collectives are matched per group by issue order, and the
+        # SyncBN backward all-reduces run on `process_group` in between the hook-launched buckets (collective call:
+        # every rank of the job passes through here)
+        ranks = None if process_group is None else dist.get_process_group_ranks(process_group)
+        grad_group = dist.new_group(ranks=ranks)
+    return model, GradBuckets([p for p in model.parameters() if p.requires_grad], bucket_bytes, grad_group)

@@ -34,7 +34,7 @@ class _IndexSet:
     """Device-resident index tensors of one rank build, padded to the frustum size n; the valid
     prefixes are counts[0]=P points and counts[1]=I intervals (device-side)."""
     __slots__ = ('ranks_bev', 'ranks_depth', 'ranks_feat', 'interval_starts', 'interval_lengths',
-                 'interval_rank', 'counts', 'n', 'cache_state')
+                 'interval_rank', 'counts', 'n', 'cache_state', 'tile_tables')
 
     def __init__(self, n, device):
         def buf():
@@ -44,6 +44,10 @@ class _IndexSet:
         self.interval_starts, self.interval_lengths, self.interval_rank = buf(), buf(), buf()
         self.counts = torch.empty(2, dtype=torch.int32, device=device)   # written by the rank build itself
         self.cache_state = None             # device flag of the camera-keyed cache (None: built unconditionally)
+        # camera-keyed cache only: tile_voxels -> (tile table, gate).  The tables BELONG to this index set (never shared
+        # with the per-call path or another cache entry) and each carries the build number it was built for, so a
+        # cache hit keeps a table only if that very table was built for the current index set.
+        self.tile_tables = None
 
     def exact(self):
         """Trim to exact sizes (ONE host sync: reads the two counts)."""
@@ -73,7 +77,7 @@ class LiftSplat(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, depth, feat, idx, grid_zyx, tile_ws, tile_voxels, pool_flags, out_dtype=torch.float32,
-                ws_cache=None, cache_state=None):
+                ws_cache=None, cache_state=None, table_gate=None):
         depth = depth.contiguous().float()
         # `feat` arrives as the (B,N,H,W,C) permuted view of the NCHW context (view_transformer.py:536); when
         # the underlying tensor is contiguous NCHW the copy is done by the LDS-tiled transpose kernel
@@ -86,7 +90,7 @@ class LiftSplat(torch.autograd.Function):
         Z, Y, X = grid_zyx
         out = torch.empty((B, C, Z, Y, X), dtype=out_dtype, device=depth.device)   # 16-bit: fp32 sums rounded at the store
         _capi.pool_tile_index(idx.interval_rank, idx.interval_starts, idx.counts, idx.n, B, Z, Y, X,
-                              tile_ws, tile_voxels, cache_state=cache_state)
+                              tile_ws, tile_voxels, cache_state=cache_state, table_gate=table_gate)
         _capi.bev_pool_v2_dense_fwd(depth, feat, idx.ranks_depth, idx.ranks_feat, idx.interval_rank,
                                     idx.interval_starts, idx.interval_lengths, B, C, Z, Y, X, out,
                                     tile_ws, tile_voxels, pool_flags)
@@ -114,7 +118,7 @@ class LiftSplat(torch.autograd.Function):
         depth_grad, feat_grad = torch.empty_like(depth), torch.empty_like(feat)
         _capi.bev_pool_v2_dense_bwd(og, depth, feat, idx.ranks_depth, idx.interval_rank, idx.interval_starts,
                                     idx.counts, idx.n, (Z, Y, X), depth_grad, feat_grad, ws)
-        return depth_grad, feat_grad, None, None, None, None, None, None, None, None
+        return depth_grad, feat_grad, None, None, None, None, None, None, None, None, None
 
 
 
@@ -191,6 +195,7 @@ class LSSViewTransformerFunction3D(nn.Module):
             dense = density >= 1.0
             tv = self._tile_voxels_arg if self._tile_voxels_arg is not None else (64 if dense else _capi.DEFAULT_TILE_VOXELS)
             half = self.out_dtype != torch.float32
+            tv32 = tv           # the fp32-LDS tile of this rig (write-once route: its epilogue add keeps an fp32 tile)
             if self._tile_voxels_arg is None and half and dense:
                 tv *= 2     # 16-bit storage: the kernel's LDS tile is 16-bit too -> twice the voxels per workgroup at the same footprint
             # sparse grid + 16-bit storage: the SAME 20 KB of LDS hold 128 voxels x ALL channels -- one workgroup per tile, no
@@ -198,8 +203,8 @@ class LSSViewTransformerFunction3D(nn.Module):
             # 256 voxels x 2 channel groups), chunks of 32 tiles per XCD
             fl = self._pool_flags_arg if self._pool_flags_arg is not None else (
                 _capi.pool_flags(csplit=1) if dense else (_capi.pool_flags(csplit=1, swz_log2=5) if half else _capi.DEFAULT_POOL_FLAGS))
-            self._tiling[n_cams] = (tv, fl)
-        return self._tiling[n_cams]
+            self._tiling[n_cams] = (tv, fl, tv32)
+        return self._tiling[n_cams][:2]
 
     @property
     def tile_voxels(self):
@@ -278,6 +283,8 @@ class LSSViewTransformerFunction3D(nn.Module):
                                          torch.full((_capi.cam_key_words(B, N),), -1, dtype=torch.int32, device=trans.device),
                                          torch.zeros(2, dtype=torch.int32, device=trans.device))
             idx, cam_key, cache_state = self._index_cache[ck]
+            if idx.tile_tables is None:
+                idx.tile_tables = {}
         else:
             idx = _IndexSet(n, trans.device)
         lo, it, gs = self._grid3()
@@ -336,18 +343,33 @@ class LSSViewTransformerFunction3D(nn.Module):
         return bev_feat.permute(0, 1, 3, 4, 2)
 
     def _tile_ws(self, device, B, tile_voxels=None):
+        """Tile table of the per-call path (rebuilt by every call, never trusted across calls)."""
         Z, Y, X = self.grid_zyx
-        key = ('tile_ws', device, B, tile_voxels)     # one table per tile size: a cached (skipped) build keeps it valid
+        key = ('tile_ws', device, B, tile_voxels)
         if key not in self._cache:
             self._cache[key] = torch.empty(_capi.pool_dense_workspace_bytes(B, Z, Y, X), dtype=torch.uint8,
                                            device=device)
         return self._cache[key]
 
+    def _tile_table(self, idx, device, B, tile_voxels):
+        """(tile table, gate) for this index set: a cached set owns one table per tile size, each with its own
+        'built for build number' gate (-1 = never built) -- a table of another tile size, or one the per-call path
+        wrote, can never be mistaken for it; a per-call set uses the module scratch and gate None (always rebuilt)."""
+        if idx.cache_state is None:
+            return self._tile_ws(device, B, tile_voxels), None
+        if tile_voxels not in idx.tile_tables:
+            Z, Y, X = self.grid_zyx
+            idx.tile_tables[tile_voxels] = (
+                torch.empty(_capi.pool_dense_workspace_bytes(B, Z, Y, X), dtype=torch.uint8, device=device),
+                torch.full((2,), -1, dtype=torch.int32, device=device))
+        return idx.tile_tables[tile_voxels]
+
     def lift_splat(self, idx, depth, tran_feat):
         """Fused dense pooling on a prepared index set -> (B,C,Y,X,Z) view of (B,C,Z,Y,X)."""
         feat = tran_feat.permute(0, 1, 3, 4, 2)
-        out = LiftSplat.apply(depth, feat, idx, self.grid_zyx, self._tile_ws(depth.device, depth.shape[0], self.tile_voxels),
-                              self.tile_voxels, self.pool_flags, self.out_dtype, self._ws, idx.cache_state)
+        table, gate = self._tile_table(idx, depth.device, depth.shape[0], self.tile_voxels)
+        out = LiftSplat.apply(depth, feat, idx, self.grid_zyx, table, self.tile_voxels, self.pool_flags, self.out_dtype,
+                              self._ws, idx.cache_state, gate)
         return out.permute(0, 1, 3, 4, 2)
 
     def view_transform_core(self, cam_params, depth, tran_feat):
@@ -382,17 +404,18 @@ class LSSViewTransformerFunction3D(nn.Module):
         feat = _capi.nchw_to_nhwc(context.contiguous().float())
         B = depth.shape[0]
         Z, Y, X = self.grid_zyx
-        tile_ws = self._tile_ws(depth.device, B, self._wo_tile)
+        tile_ws, gate = self._tile_table(idx, depth.device, B, self._wo_tile)
         _capi.pool_tile_index(idx.interval_rank, idx.interval_starts, idx.counts, idx.n, B, Z, Y, X, tile_ws,
-                              self._wo_tile, cache_state=idx.cache_state)
+                              self._wo_tile, cache_state=idx.cache_state, table_gate=gate)
         return idx, depth, feat, tile_ws
 
     @property
     def _wo_tile(self):
         # fbbev_pool_zmean takes tiles of 64..256 voxels; the write-once route adds the refined BEV in the store epilogue,
         # which keeps an fp32 LDS tile: no doubling for 16-bit storage there
-        tv = self.tile_voxels if self.out_dtype == torch.float32 else self.tile_voxels // 2
-        return min(tv, 256)
+        # -> the un-doubled tile of tiling(), clamped into fbbev_pool_zmean's documented 64..256 range
+        self.tiling()
+        return max(64, min(self._tiling[self.n_cams][2], 256))
 
     def pooled_zmean(self, parts):
         """bev_feat.mean(-1) of the lift-splat output, (B,C,Y,X), without materialising the volume (fbbev_pool_zmean)."""

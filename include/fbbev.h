@@ -151,7 +151,10 @@ int fbbev_lift_rank_build(const float* frustum, const float* xs, const float* ys
  * 0xFFFFFFFF): equal -> cache_state[0] = 1 and every kernel of the build returns at once, the index tensors / counts of
  * the previous call stay valid (the caller passes the SAME buffers every time); different -> the key is refreshed,
  * cache_state[0] = 0, cache_state[1] += 1 (number of builds) and the build runs.  No host sync, graph-capturable.
- * fbbev_pool_tile_index_cached is the tile index with the same early-out (cache_state of the build before it). */
+ * fbbev_pool_tile_index_cached is the tile index with the same early-out -- per TABLE: `table_gate` (2 x int32, caller-owned,
+ * one pair per tile table, initialise to -1) remembers the build number (cache_state[1]) the table was built for; the
+ * table is kept only when the index set is unchanged AND this very table was built for it, otherwise it is rebuilt
+ * (a table of another tile size, or one allocated after the last build, is never trusted).  One extra 1-thread launch. */
 size_t fbbev_cam_key_words(int B, int N);
 int fbbev_lift_rank_build_cached(const float* frustum, const float* xs, const float* ys, const float* ds,
                                  const float* rots, const float* trans, const float* intrins,
@@ -164,7 +167,7 @@ int fbbev_lift_rank_build_cached(const float* frustum, const float* xs, const fl
 int fbbev_pool_tile_index_cached(const int32_t* interval_rank, const int32_t* interval_starts,
                                  const int32_t* counts, int n_intervals_max, int B, int Z, int Y, int X,
                                  int tile_voxels, int flags, void* tile_ws, size_t tile_ws_bytes,
-                                 const int32_t* cache_state, fbbev_stream_t stream);
+                                 const int32_t* cache_state, int32_t* table_gate, fbbev_stream_t stream);
 
 /* Fused replacement of  feat.new_zeros + bev_pool_v2_forward + permute(0,4,1,2,3).contiguous()
  *   -- bev_pool.py:24-35,88.  Two launches:

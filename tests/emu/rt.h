@@ -20,6 +20,7 @@
 #include <functional>
 #include <vector>
 
+#define FBBEV_TEST_OVERRIDES 1   /* emulator build: per-call test overrides of launcher plans (capi.hip) */
 #define __global__
 #define __device__
 #define __host__

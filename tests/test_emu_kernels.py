@@ -736,6 +736,63 @@ def test_camera_keyed_cache_skips_and_rebuilds_emulated():
     _assert_index_equal(got4, exp4)
 
 
+def test_cached_tile_table_is_gated_per_table_emulated():
+    """a cache hit may keep a tile table only if THAT table was built for the current index set.
+    Two tables (tile 64 / 128) of one cached set: the table that missed the last rebuild, and a freshly allocated one,
+    are rebuilt on the next hit although cache_state[0] == 1; a table that is current is left untouched."""
+    from ctypes import c_void_p
+    cfg = S.CONFIGS['TINY']
+    cache = {}
+    cam = S.camera_rig(cfg, 2, seed=0, bda_aug=True)
+    got, _ = _lift_vs_oracle('TINY', 2, cache=cache, cam=cam)
+    rb, rd, rf, st, ln, ir, counts = got
+    X, Y, Z = cfg.grid_xyz
+    lib = E.lib()
+    nbytes = lib.fbbev_pool_dense_workspace_bytes(2, Z, Y, X)
+
+    def table():
+        return torch.full((nbytes,), 0x5A, dtype=torch.uint8), torch.full((2,), -1, dtype=torch.int32)
+
+    def build(tbl, gate, tv, state):
+        E.ok(lib.fbbev_pool_tile_index_cached(E.p(ir), E.p(st), E.p(counts), ir.numel(), 2, Z, Y, X, tv, 0, E.p(tbl),
+                                              tbl.numel(), E.p(state), E.p(gate), None))
+
+    def used(tv):                                                # bytes the table kernel writes: (tiles + 1) x 2 ints
+        return (2 * Z * ((Y * X + tv - 1) // tv) + 1) * 8
+
+    def fresh(tv):
+        t = torch.full((nbytes,), 0x5A, dtype=torch.uint8)
+        E.ok(lib.fbbev_pool_tile_index(E.p(ir), E.p(st), E.p(counts), ir.numel(), 2, Z, Y, X, tv, 0, E.p(t), t.numel(), None))
+        return t[:used(tv)]
+
+    state = cache['state']
+    assert state.tolist() == [0, 1]
+    t64, g64 = table()
+    build(t64, g64, 64, state)                                   # build 1 ran: table built, gate remembers build 1
+    assert g64.tolist() == [1, 0] and torch.equal(t64[:used(64)], fresh(64))
+    _lift_vs_oracle('TINY', 2, cache=cache, cam=[t.clone() for t in cam])
+    assert state.tolist() == [1, 1]                              # hit
+    t64.fill_(0x11)
+    build(t64, g64, 64, state)
+    assert g64.tolist() == [1, 1] and int(t64[0]) == 0x11        # current table: kept (not rewritten)
+    t128, g128 = table()                                         # allocated AFTER the build: must not be trusted on a hit
+    build(t128, g128, 128, state)
+    assert g128.tolist() == [1, 0] and torch.equal(t128[:used(128)], fresh(128))
+    # rebuild with another rig through table 128 only; the next hit through table 64 must rebuild table 64
+    cam2 = [t.clone() for t in cam]
+    cam2[5][1] = cam2[5][1] @ torch.tensor([[0., -1., 0.], [1., 0., 0.], [0., 0., 1.]])
+    got2, _ = _lift_vs_oracle('TINY', 2, cache=cache, cam=cam2)
+    rb, rd, rf, st, ln, ir, counts = got2
+    assert state.tolist() == [0, 2]
+    build(t128, g128, 128, state)
+    assert g128.tolist() == [2, 0] and torch.equal(t128[:used(128)], fresh(128))
+    _lift_vs_oracle('TINY', 2, cache=cache, cam=[t.clone() for t in cam2])
+    assert state.tolist() == [1, 2]
+    stale = t64.clone()
+    build(t64, g64, 64, state)                                   # hit, but table 64 belongs to build 1
+    assert g64.tolist() == [2, 0] and torch.equal(t64[:used(64)], fresh(64)) and not torch.equal(t64, stale)
+
+
 # ---------------------------------------------------------------- 16-bit storage of the history ring (BASELINE configs[4])
 @pytest.mark.parametrize('dt', [torch.float16, torch.bfloat16])
 def test_history_warp_and_conv_16bit_storage_emulated(dt):

@@ -66,11 +66,54 @@ def test_detector_mfma_route_equals_vendor_route(dev):
     m = T._small_model(dev, neck_channels=64).eval()          # 64 -> 32 -> 16 channels in the head: multiples of 16
     img_inputs, metas, _, _ = T._inputs(dev, 1)
     with torch.no_grad():
+        m.mfma_conv3d = False                                 # vendor library
         ref = m.predict_occupancy(img_inputs, metas(True), return_raw_occ=True)
+        assert m._runners is None
         m.reset_history()
         m.mfma_conv3d = True
         got = m.predict_occupancy(img_inputs, metas(True), return_raw_occ=True)
+        assert m.mfma_conv3d is True and m._runners[0] is not None       # the hand-written route really ran
     assert torch.allclose(got, ref, atol=1e-4, rtol=1e-3), (got - ref).abs().max()
+
+
+def test_mfma_runners_follow_the_parameters(dev):
+    """the runners snapshot BN-folded weights.  eval() -> forward -> load_state_dict() / in-place
+    parameter update / .to() -> forward must use the NEW weights (the snapshots are keyed on storage pointer + in-place
+    version of every folded tensor)."""
+    import test_gpu_full_model as T
+    img_inputs, metas, _, _ = T._inputs(dev, 1)
+    a = T._small_model(dev, neck_channels=64).eval()
+    b = T._small_model(dev, neck_channels=64).eval()
+    with torch.no_grad():
+        for p in b.parameters():                              # another set of weights
+            p.mul_(1.05)
+        for m_ in b.modules():
+            if isinstance(m_, torch.nn.modules.batchnorm._BatchNorm):
+                m_.running_mean.add_(0.01)
+                m_.running_var.mul_(1.1)
+        out_a = a.predict_occupancy(img_inputs, metas(True), return_raw_occ=True)
+        out_b = b.predict_occupancy(img_inputs, metas(True), return_raw_occ=True)
+        assert a._runners[0] is not None and not torch.allclose(out_a, out_b, atol=1e-3)
+        runners = a._runners
+        a.reset_history()
+        assert torch.equal(a.predict_occupancy(img_inputs, metas(True), return_raw_occ=True), out_a)
+        assert a._runners is runners                          # unchanged parameters: no rebuild
+        a.load_state_dict(b.state_dict())
+        a.reset_history()
+        got = a.predict_occupancy(img_inputs, metas(True), return_raw_occ=True)
+        assert a._runners is not runners
+        assert torch.equal(got, out_b), (got - out_b).abs().max()
+        # an in-place update of one folded buffer (EMA-style copy_) is noticed too
+        runners = a._runners
+        bn = next(m_ for m_ in a.occupancy_head.modules() if isinstance(m_, torch.nn.modules.batchnorm._BatchNorm))
+        bn.running_var.copy_(bn.running_var * 4.0)
+        a.reset_history()
+        got2 = a.predict_occupancy(img_inputs, metas(True), return_raw_occ=True)
+        assert a._runners is not runners and not torch.equal(got2, out_b)
+        a.mfma_conv3d = False
+        a.reset_history()
+        ref2 = a.predict_occupancy(img_inputs, metas(True), return_raw_occ=True)
+        assert torch.allclose(got2, ref2, atol=1e-4, rtol=1e-3), (got2 - ref2).abs().max()
 
 
 def test_blend_levels_vs_torch_interpolate(dev):

@@ -550,6 +550,49 @@ def test_accelerate_is_a_camera_keyed_cache(dev):
     assert vt.ranks_bev.dtype == torch.int32 and vt.interval_starts.numel() > 0 and not vt.initial_flag
 
 
+@pytest.mark.parametrize('out_dtype', [torch.float32, torch.bfloat16])
+def test_cached_tile_tables_survive_mixed_routes(dev, out_dtype):
+    """the tile tables of accelerate=True belong to the cached index set, one per tile size, each
+    gated on the build it was made for.  A fixed validation rig alternating with grad-enabled calls of ANOTHER rig (same
+    B), and the two routes of a 16-bit volume (lift_splat: doubled 16-bit tile; write-once: fp32 tile) interleaved
+    across rebuilds, must always pool with the table of the current index set."""
+    cfg, ovt, cam, _, depth, ctx = _inputs('SMALL', 2, True, dev)
+    rz = torch.tensor([[0., -1., 0.], [1., 0., 0.], [0., 0., 1.]], device=dev)
+    cam_a = [t.to(dev) for t in cam]
+    cam_b = [t.clone() for t in cam_a]
+    cam_b[5][0] = cam_b[5][0] @ rz
+    cam_b[5][1] = cam_b[5][1] @ rz @ rz
+    d, c = depth.to(dev), ctx.to(dev)
+    plain = _vt(cfg, dev, out_dtype=out_dtype)
+    ref_a, ref_b = plain(cam_a, c, d), plain(cam_b, c, d)
+    assert not torch.equal(ref_a, ref_b)
+    vt = _vt(cfg, dev, accelerate=True, out_dtype=out_dtype)
+    with torch.no_grad():
+        assert torch.equal(vt(cam_a, c, d), ref_a)                       # build 1, table of lift_splat's tile
+    # training-style call of another rig, same B: its per-call index set and table must not leak into the cache
+    dg = d.clone().requires_grad_()
+    assert torch.equal(vt(cam_b, c, dg).detach(), ref_b)
+    with torch.no_grad():
+        assert torch.equal(vt(cam_a, c, d), ref_a)                       # hit: cached table still the one of rig a
+        assert vt.index_builds() == 1
+        # the write-once route (another tile size for 16-bit volumes) first used on a HIT: its table is new -> built
+        assert torch.equal(vt.pooled_volume(vt.pooling_inputs(cam_a, c, d)), ref_a)
+        assert vt.index_builds() == 1
+        # rebuild through the write-once route only, then a hit through lift_splat: ITS table is one build behind
+        assert torch.equal(vt.pooled_volume(vt.pooling_inputs(cam_b, c, d)), ref_b)
+        assert vt.index_builds() == 2
+        assert torch.equal(vt(cam_b, c, d), ref_b)
+        assert vt.index_builds() == 2
+        # and the other way round
+        assert torch.equal(vt(cam_a, c, d), ref_a)
+        assert vt.index_builds() == 3
+        assert torch.equal(vt.pooled_volume(vt.pooling_inputs(cam_a, c, d)), ref_a)
+        zm = vt.pooled_zmean(vt.pooling_inputs(cam_a, c, d))
+        assert vt.index_builds() == 3
+    full = _vt(cfg, dev)(cam_a, c, d)                                    # fp32 volume (B,C,Y,X,Z)
+    assert (zm - full.mean(-1)).abs().max().item() <= 1e-5
+
+
 def test_cached_index_build_is_graph_capturable(dev):
     """The camera-key compare + early-out chain contains no host decision: captured once, replayed with the same rig
     (skip) and with a new rig written into the captured input buffers (rebuild)."""

@@ -171,16 +171,22 @@ def _ddp_step_worker(rank, world, port, q):
     buckets._launch = lambda bi: (early.append(bi), launch(bi))[1]
     buckets.zero_grad()
     model.parse_losses(model(return_loss=True, **_detector_batch(grid, C, shard.shard_seed(rank)))).backward()
-    launched_in_backward = len(set(early))
-    buckets.finish()
+    first_step_in_backward = len(set(early))
+    buckets.finish()                                  # also re-lays the buckets out in gradient arrival order
+    # (compared AFTER the re-layout: the averaged gradients were carried over into the new slices; the second step below
+    # sees the detector's history state of the first, so only its rank-to-rank equality is checked)
     err = max(float((p.grad - expect[n]).abs().max() / (expect[n].abs().max() + 1e-6))
               for n, p in model.named_parameters() if p.requires_grad)
     views = all(p.grad.data_ptr() >= buckets._flat[buckets._of[p]].data_ptr() for p in buckets.params)
     # second step with zeroed buckets gives the same gradients (hook / counter state is reset by finish)
     buckets.zero_grad()
+    del early[:]
     model.parse_losses(model(return_loss=True, **_detector_batch(grid, C, shard.shard_seed(rank)))).backward()
+    launched_in_backward, in_order = len(set(early)), early == sorted(early)
     buckets.finish()
-    q.put((rank, err, launched_in_backward, len(buckets.buckets), views, float(sum(p.grad.abs().sum() for p in buckets.params))))
+    views = views and in_order and all(p.grad.data_ptr() >= buckets._flat[buckets._of[p]].data_ptr() for p in buckets.params)
+    q.put((rank, err, launched_in_backward, len(buckets.buckets), views, float(sum(p.grad.abs().sum() for p in buckets.params)),
+           first_step_in_backward))
     torch.distributed.destroy_process_group()
 
 
@@ -188,11 +194,70 @@ def test_two_rank_ddp_training_step_equals_single_process_average():
     """bench.py --mode train on CPU-sized shapes: forward_train + backward of the detector on 2 gloo ranks with the
     hook-launched flat buckets == the average of the two ranks' single-process gradients, for EVERY parameter."""
     res = _run(2, _ddp_step_worker)
-    for rank, err, early, nb, views, _ in res:
+    for rank, err, early, nb, views, _, first in res:
         assert err < 1e-4, (rank, err)
-        assert early >= nb - 1, (early, nb)          # all but (at most) the last bucket went out before backward returned
+        # launches are strictly in bucket order (collectives are matched by issue order); after the first step the
+        # buckets follow the gradient arrival order, so all but (at most) the last went out before backward returned
+        assert early >= nb - 1, (early, nb, first)
         assert views
     assert abs(res[0][5] - res[1][5]) <= 1e-4 * res[0][5]      # both ranks end with the same gradients
+
+
+def _unused_block_worker(rank, world, port, q):
+    _env(rank, world, port)
+    import torch.nn as nn
+    from fb_bev_amd import shard
+    shard.init('gloo')
+    torch.manual_seed(0)
+    # four blocks of DIFFERENT sizes -> four buckets of different lengths (bucket_bytes below one block); block `b`
+    # (the second bucket in reverse registration order) takes no part in rank 1's loss
+    net = nn.ModuleDict(dict(a=nn.Linear(8, 24), b=nn.Linear(8, 40, bias=False), c=nn.Linear(8, 16), d=nn.Linear(8, 56)))
+    # SyncBN collectives in between (their own group: prepare_ddp gives the buckets a separate one)
+    bn = nn.BatchNorm1d(8)
+    bn._fbbev_sync_bn = True
+    net['bn'] = bn
+    model, buckets = shard.prepare_ddp(net, sync_bn=True, bucket_bytes=64)
+    order = []
+    launch = buckets._launch
+    buckets._launch = lambda bi: (order.append(bi), launch(bi))[1]
+    g = torch.Generator().manual_seed(10 + rank)
+    x = torch.randn(6, 8, generator=g)
+
+    def loss_of(m, x, skip_b):
+        h = m['bn'](x)
+        out = m['a'](h).sum() + 2.0 * m['c'](h).sum() + 3.0 * m['d'](h).pow(2).sum()
+        return out if skip_b else out + m['b'](h).sum()
+
+    buckets.zero_grad()
+    loss_of(model, x, skip_b=(rank == 1)).backward()
+    in_backward = list(order)
+    buckets.finish()
+    # expected: both ranks' gradients from un-hooked replicas with global-batch BN statistics == one process on the
+    # concatenated batch with per-sample loss terms (b's term only for rank 0's samples), divided by world
+    torch.manual_seed(0)
+    ref = nn.ModuleDict(dict(a=nn.Linear(8, 24), b=nn.Linear(8, 40, bias=False), c=nn.Linear(8, 16), d=nn.Linear(8, 56)))
+    ref['bn'] = nn.BatchNorm1d(8)
+    xs = [torch.randn(6, 8, generator=torch.Generator().manual_seed(10 + r)) for r in range(world)]
+    h = ref['bn'](torch.cat(xs))
+    tot = ref['a'](h).sum() + 2.0 * ref['c'](h).sum() + 3.0 * ref['d'](h).pow(2).sum() + ref['b'](h[:6]).sum()
+    (tot / world).backward()
+    rp = dict(ref.named_parameters())
+    err = max(float((p.grad - rp[n].grad).abs().max() / (rp[n].grad.abs().max() + 1.0)) for n, p in model.named_parameters())
+    q.put((rank, err, in_backward, list(order), len(buckets.buckets)))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_block_unused_on_one_rank_keeps_launch_order():
+    """collectives of a group are matched by issue order.  With a block that receives no gradient on
+    rank 1 only, rank 1 must not issue bucket 2 before bucket 1 (which would pair buckets of different sizes): launches
+    are strictly 0,1,2,... on every rank -- the incomplete bucket and everything after it wait for finish() -- and
+    the averaged gradients are right, with SyncBN all-reduces interleaved on their own group."""
+    res = _run(2, _unused_block_worker)
+    for rank, err, in_backward, order, nb in res:
+        assert order == list(range(nb)), (rank, order)
+        assert in_backward == list(range(len(in_backward)))
+        assert err < 1e-5, (rank, err)
+    assert len(res[1][2]) < len(res[0][2]) or len(res[0][2]) < res[0][4]    # rank 1 deferred at least the unused bucket
 
 
 def _syncbn_worker(rank, world, port, q):
