@@ -75,16 +75,42 @@ def self_launch(args):
     import socket
     import torch
     have = torch.cuda.device_count()
-    if have < args.gpus:
-        raise SystemExit(f'bench.py --gpus {args.gpus}: only {have} GPU(s) visible on this node')
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
     s.close()
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
-           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    cmd = launch_command(args, have, port)
     sys.stdout.flush()
     os.execv(sys.executable, cmd)
+
+
+def launch_command(args, have, port, argv=None):
+    """argv of the self-launch: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py <the original flags>` -- the command line the driver itself uses for N > 1."""
+    if have < args.gpus:
+        raise SystemExit(f'bench.py --gpus {args.gpus}: only {have} GPU(s) visible on this node')
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv)
+
+
+def check_ranks(args, world, rank, dev, index=None):
+    """The job really is `--gpus` RCCL ranks, one per device: the process group's size (not just the environment) must equal
+    --gpus, and every rank reports the device it is bound to (all-gathered, so rank 0 can print the binding and two ranks
+    on one GPU are refused).  -> (number of ranks in the group, [device index per rank])."""
+    import torch
+    import torch.distributed as dist
+    n = dist.get_world_size() if dist.is_initialized() else 1
+    if n != args.gpus or n != world:
+        raise SystemExit(f'bench.py --gpus {args.gpus}: the process group has {n} rank(s) (WORLD_SIZE={world})')
+    mine = torch.tensor([index if index is not None else (dev.index or 0)], dtype=torch.int64, device=dev)
+    if n == 1:
+        return 1, [int(mine)]
+    got = [torch.zeros_like(mine) for _ in range(n)]
+    dist.all_gather(got, mine)
+    devices = [int(t) for t in got]
+    if len(set(devices)) != n:
+        raise SystemExit(f'bench.py --gpus {args.gpus}: ranks share a device ({devices}); one rank per GPU is required')
+    return n, devices
 
 
 def cpu_baseline(cfg, seconds):
@@ -184,6 +210,7 @@ def run_forward(args):
     dev = torch.device('cuda', local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
     shard.init('nccl', dev)     # backend "nccl" is RCCL on ROCm; used for the fence + max-reduce only
+    ranks, devices = check_ranks(args, world, rank, dev)
 
     cfg = S.CONFIGS[args.config]
     B = args.batch
@@ -353,6 +380,30 @@ def run_forward(args):
         torch.cuda.synchronize(dev)
         fill_ms.append(a.elapsed_time(b))
     fill_gbs = out.numel() * esz / (sorted(fill_ms)[len(fill_ms) // 2] * 1e-3) / 1e9
+    # the kernel's own STORE PATTERN as a floor: the same instantiation, grid, tile walk, XCD order and
+    # `sc1 nt` stores with the gathers compiled out (mode 1: stores alone; mode 2: all but the depth / feature gathers),
+    # timed per launch with HIP events like the real kernel; outside the timed region, results never used
+    floors = {}
+    if args.storage == 'f32':
+        feat_f = _capi.nchw_to_nhwc(ctx)
+        scratch = torch.empty_like(out)
+        for mode, name in ((1, 'store_floor_ms'), (2, 'no_gather_ms')):
+            try:
+                ts = []
+                for it in range(12):
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    _capi.diag_pool_store_floor(depth, feat_f, idx.ranks_depth, idx.ranks_feat, idx.interval_rank,
+                                                idx.interval_starts, idx.interval_lengths, B, C, Z, Y, X, scratch, tile_ws,
+                                                args.tile_voxels, flags, mode)
+                    b.record()
+                    torch.cuda.synchronize(dev)
+                    if it >= 2:
+                        ts.append(a.elapsed_time(b))
+                floors[name] = sum(ts) / len(ts)
+            except _capi.FbbevError:          # another tile / flag set than the default instantiation: no floor reported
+                floors[name] = None
+        del scratch
     P, I = idx.counts.tolist()
     D = cfg.D
     H, W = cfg.feat_hw
@@ -377,6 +428,7 @@ def run_forward(args):
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
             'step_gpu_ms_p10_p50_p90': [pct(0.1), pct(0.5), pct(0.9)],
             'scaling': 'weak', 'vs_baseline': None, 'dtype': args.storage, 'accumulate_dtype': 'f32', 'data': 'synthetic',
+            'rccl_ranks': ranks, 'rank_devices': devices,
             'config': {'workload': f'FB-OCC forward projection, ' + ('BASELINE configs[1] ' if cfg.name == 'BL2' else '') +
                                    f'({cfg.name}): 6x{cfg.input_size[0]}x{cfg.input_size[1]} in, '
                                    f'feat {H}x{W}, D={D}, C={C}, grid {X}x{Y}x{Z}; index tensors rebuilt every step',
@@ -387,7 +439,12 @@ def run_forward(args):
                          'traffic_source': None if traffic is None else f'profiles/pmc_traffic.json[{key}] (rocprofv3 --pmc FETCH_SIZE / '
                                                                        'WRITE_SIZE passes of this command, recorded earlier -- not measured in this run)',
                          'algorithmic_bytes_per_launch': algo_bytes, 'kernel_ms': kern_ms,
-                         'device_fill_GBps': fill_gbs, 'frac_of_device_fill': achieved / fill_gbs if fill_gbs > 0 else None},
+                         'device_fill_GBps': fill_gbs, 'frac_of_device_fill': achieved / fill_gbs if fill_gbs > 0 else None,
+                         'store_floor_ms': floors.get('store_floor_ms'), 'no_gather_ms': floors.get('no_gather_ms'),
+                         'store_floor_over_kernel': (floors['store_floor_ms'] / kern_ms) if floors.get('store_floor_ms') and kern_ms > 0 else None,
+                         'store_floor_what': 'the same k_pool_fwd_dense2 instantiation, grid, tile walk, XCD order and sc1-nt stores with the gathers '
+                                             'compiled out (store_floor_ms: stores alone; no_gather_ms: metadata + index staging + LDS tile + stores), '
+                                             'mean HIP-event time per launch, measured after the timed region'},
         }
         if alt is not None:
             res['bf16_storage'] = alt
@@ -421,6 +478,7 @@ def run_train(args):
     dev = torch.device('cuda', local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
     shard.init('nccl', dev)
+    ranks, devices = check_ranks(args, world, rank, dev)
     B = args.batch if args.batch != 16 else 4          # 16 is the forward mode's default; configs[3] is 4 per GPU
     name = 'fbocc-r50-cbgs_depth_16f_16x4_20e.py'
     cfg = dict(json.load(open(os.path.join(ROOT, 'tests', 'golden', 'fbocc_config_path_blocks.json')))[name]['model'])
@@ -489,6 +547,7 @@ def run_train(args):
                        'parameters': sum(p.numel() for p in params), 'gradient_bytes': buckets.nbytes,
                        'gradient_buckets': len(buckets.buckets), 'bucket_mb': args.bucket_mb, 'sync_bn': bool(args.sync_bn and world > 1),
                        'conv3d_route': args.conv, 'optimizer': 'AdamW lr 2e-4 wd 1e-2, clip 5'},
+            'rccl_ranks': ranks, 'rank_devices': devices,
             'allreduce_exposed_ms': ar_tail_ms, 'loss': float(total.detach()),
         }))
     if world > 1:

@@ -37,6 +37,8 @@ SIGNATURES = {
     'fbbev_pool_tile_index': (c_int, [c_void_p] * 3 + [c_int] * 7 + [c_void_p, c_size_t, c_void_p]),
     'fbbev_bev_pool_v2_dense_fwd': (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_void_p, c_int64, c_int64, c_void_p,
                                             c_size_t, c_int, c_int, c_void_p]),
+    'fbbev_diag_pool_store_floor': (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t, c_int, c_int, c_int,
+                                            c_void_p]),
     'fbbev_bev_pool_v2_dense_fwd_add': (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_void_p, c_int64, c_int64, c_void_p,
                                                 c_size_t, c_int, c_int, c_void_p, c_void_p]),
     'fbbev_pool_zmean': (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
@@ -325,6 +327,21 @@ def bev_pool_v2_dense_fwd(depth, feat, ranks_depth, ranks_feat, interval_rank, i
                 raise FbbevError('addend must be (B,C,Y,X)')
             _check(lib().fbbev_bev_pool_v2_dense_fwd_add(*args, _dev(addend, F32, 'addend'), _stream()),
                    'fbbev_bev_pool_v2_dense_fwd_add')
+
+
+def diag_pool_store_floor(depth, feat, ranks_depth, ranks_feat, interval_rank, interval_starts, interval_lengths, B, C, Z, Y, X,
+                          out, tile_ws, tile_voxels, flags, mode):
+    """Measurement aid (never on the product path): the default fp32 dense-kernel instantiation with its gathers compiled
+    out -- mode 1 the store pattern alone, mode 2 all but the depth / feature gathers.  `out` receives zeros."""
+    if tuple(out.shape) != (B, C, Z, Y, X) or not out.is_contiguous() or out.dtype != F32:
+        raise FbbevError('out must be a contiguous (B,C,Z,Y,X) float32 tensor')
+    with _on(depth):
+        _check(lib().fbbev_diag_pool_store_floor(
+            _dev(depth, F32, 'depth'), _dev(feat, F32, 'feat'), _dev(ranks_depth, I32, 'ranks_depth'),
+            _dev(ranks_feat, I32, 'ranks_feat'), _dev(interval_rank, I32, 'interval_rank'),
+            _dev(interval_starts, I32, 'interval_starts'), _dev(interval_lengths, I32, 'interval_lengths'),
+            B, C, Z, Y, X, _dev(out, F32, 'out'), c_void_p(tile_ws.data_ptr()), tile_ws.numel() * tile_ws.element_size(),
+            int(tile_voxels), int(flags), int(mode), _stream()), 'fbbev_diag_pool_store_floor')
 
 
 def pool_dense_bwd_workspace_bytes(B, N, D, H, W, C, Z, Y, X):

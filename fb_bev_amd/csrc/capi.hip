@@ -672,6 +672,57 @@ extern "C" int fbbev_bev_pool_v2_dense_fwd(const float* depth, const float* feat
                                stream_);
 }
 
+// Measurement aid (bench.py `roofline.store_floor_ms` / `no_gather_ms`): the default fp32 instantiation of the dense kernel
+// (128-voxel tiles, 8 channels per lane, 256 threads, `sc1 nt` stores) with its gathers compiled out -- same grid, tile
+// walk and XCD order as the product launch with these flags.  mode 1: store pattern alone; mode 2: all but the depth /
+// feature gathers.  Writes zeros to `out`.
+extern "C" int fbbev_diag_pool_store_floor(const float* depth, const float* feat, const int32_t* ranks_depth,
+                                           const int32_t* ranks_feat, const int32_t* interval_rank,
+                                           const int32_t* interval_starts, const int32_t* interval_lengths, int B, int C,
+                                           int Z, int Y, int X, float* out, const void* tile_ws, size_t tile_ws_bytes,
+                                           int tile_voxels, int flags, int mode, fbbev_stream_t stream_) {
+    if (B <= 0 || C <= 0 || Z <= 0 || Y <= 0 || X <= 0 || (mode != 1 && mode != 2)) return FBBEV_E_BADARG;
+    if (!depth || !feat || !ranks_depth || !ranks_feat || !interval_rank || !interval_starts || !interval_lengths || !out ||
+        !tile_ws) return FBBEV_E_BADARG;
+    const long long yx = (long long)Y * X;
+    if (pick_tile(tile_voxels) != 128 || tile_voxels != 128 || yx % 4 != 0 || !aligned16(out) ||
+        (flags & (FBBEV_POOL_CHANNELS_LAST | FBBEV_POOL_OUT_BF16 | FBBEV_POOL_OUT_F16)) ||
+        (long long)B * Z * yx >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
+    const int st = (flags & FBBEV_POOL_STORE_MASK) | ((flags >> FBBEV_POOL_STORE_HI_SHIFT) & 1) << 2;
+    int csplit = (flags >> FBBEV_POOL_CSPLIT_SHIFT) & 0xF;
+    if (csplit == 0xF) csplit = 20;
+    if (csplit < 1 || C % (4 * csplit) != 0) csplit = 1;
+    const int CC = C / csplit;
+    if (!(flags & FBBEV_POOL_CPL8) || CC % 8 != 0 || st < 2 || ((flags >> FBBEV_POOL_WG_SHIFT) & 0x3) != 0 || 256 / (CC / 8) < 1)
+        return FBBEV_E_UNSUPPORTED;
+    const int tiles_per_plane = (int)((yx + 127) / 128);
+    const long long n_tiles = (long long)B * Z * tiles_per_plane;
+    if (tile_ws_bytes < (size_t)(n_tiles + 1) * 8) return FBBEV_E_WORKSPACE;
+    dense2_args a;
+    a.n_blocks = n_tiles * csplit;
+    a.lds = ((size_t)CC * (128 + 4) + 3 * (size_t)128 + 2 * FBBEV_NP_STAGE) * sizeof(float);
+    a.stream = (fbbev_rt_stream)stream_; a.C = C; a.Z = Z; a.yx = (int)yx; a.tpp = tiles_per_plane; a.csplit = csplit;
+    a.swizzle = 0;
+    if (flags & FBBEV_POOL_XCD_SWIZZLE) {
+        int lg = (flags >> FBBEV_POOL_SWZ_CHUNK_SHIFT) & 0x1F;
+        if (lg == 0) lg = 6;
+        a.swizzle = lg + 1;
+    }
+    if (a.n_blocks + 8 >= (1ll << 31) || a.lds > 64 * 1024) return FBBEV_E_UNSUPPORTED;
+    a.depth = depth; a.feat = feat; a.rd = ranks_depth; a.rf = ranks_feat; a.irank = interval_rank;
+    a.starts = interval_starts; a.lengths = interval_lengths; a.tile_meta = static_cast<const int*>(tile_ws);
+    a.out = out; a.stride_b = (long long)C * Z * yx; a.stride_c = (long long)Z * yx; a.addend = nullptr;
+    long long grid = a.n_blocks;
+    if (a.swizzle) { const long long g = 8ll << (a.swizzle - 1); grid = (a.n_blocks + g - 1) / g * g; }
+#define FBBEV_DIAG_DENSE(MODE_)                                                                                          \
+    FBBEV_LAUNCH((k_pool_fwd_dense2<128, 8, 4, 256, 0, false, MODE_>), grid, 256, a.lds, a.stream, a.C, a.Z, a.yx, a.tpp,   \
+                 a.csplit, (int)a.n_blocks, a.swizzle, a.stride_b, a.stride_c, a.depth, a.feat, a.rd, a.rf, a.irank,      \
+                 a.starts, a.lengths, a.tile_meta, a.addend, a.out)
+    if (mode == 1) FBBEV_DIAG_DENSE(1); else FBBEV_DIAG_DENSE(2);
+#undef FBBEV_DIAG_DENSE
+    return fbbev_rt_last_error();
+}
+
 extern "C" int fbbev_bev_pool_v2_dense_fwd_add(const float* depth, const float* feat,
                                                const int32_t* ranks_depth, const int32_t* ranks_feat,
                                                const int32_t* interval_rank, const int32_t* interval_starts,

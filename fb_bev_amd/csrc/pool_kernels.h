@@ -341,7 +341,12 @@ __device__ __forceinline__ unsigned int fbbev_pack2(float lo, float hi) {
 // same LDS footprint and keeps the same number of OUTPUT bytes in flight per CU as the fp32 kernel (with an fp32 tile the
 // 16-bit variants were bound by the latency of the dependent-load chain at half the bytes per workgroup: 0.42 of the HBM
 // peak at BASELINE configs[1], profiles/r01_bench_storage_variants.jsonl).
-template <int TV, int CPL, int ST, int NT, int OT, bool T16 = false>
+// DIAG (measurement only, bench.py `roofline.store_floor_ms`): 1 = the kernel's STORE pattern alone -- same grid, tile
+// walk, XCD order and `sc1 nt` 16-byte stores, every tile treated as empty (no metadata, no gathers, no LDS); 2 = everything
+// but the depth / feature gathers and their fmaf chains (tile metadata, interval / point-index staging, LDS tile, barriers,
+// stores).  0 = the product kernel; the diagnostic instantiations write zeros and are reachable only through
+// fbbev_diag_pool_store_floor.
+template <int TV, int CPL, int ST, int NT, int OT, bool T16 = false, int DIAG = 0>
 __global__ void __launch_bounds__(NT)
 k_pool_fwd_dense2(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_blocks, int swizzle,
                   long long out_stride_b, long long out_stride_c,
@@ -382,8 +387,8 @@ k_pool_fwd_dense2(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_b
     const int b = plane / Z, z = plane - b * Z;
     const int v0 = k * TV;
     const int nv = (YX - v0 < TV) ? (YX - v0) : TV;
-    const int i0 = tile_meta[2 * t], p0 = tile_meta[2 * t + 1];
-    const int i1 = tile_meta[2 * t + 2], p1 = tile_meta[2 * t + 3];
+    const int i0 = DIAG == 1 ? 0 : tile_meta[2 * t], p0 = DIAG == 1 ? 0 : tile_meta[2 * t + 1];
+    const int i1 = DIAG == 1 ? 0 : tile_meta[2 * t + 2], p1 = DIAG == 1 ? 0 : tile_meta[2 * t + 3];
     const long long cstride = out_stride_c;      // elements between channels (Z*YX when contiguous)
     const long long oofs = (long long)b * out_stride_b + (long long)z * YX + v0 + (long long)c0 * cstride;
     float* __restrict__ obase = out + oofs;                                         // OT == 0
@@ -447,7 +452,12 @@ k_pool_fwd_dense2(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_b
             for (int i = g; i < ni; i += gpb) {
                 const int v = ivx[i];
                 float acc[CPL];
-                fbbev_interval_sum_staged<CPL, 4>(C, ist[i], iln[i], p0, prd, prf, depth, fbase, rd, rf, acc);
+                if constexpr (DIAG == 2) {
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) acc[j] = 0.f;
+                } else {
+                    fbbev_interval_sum_staged<CPL, 4>(C, ist[i], iln[i], p0, prd, prf, depth, fbase, rd, rf, acc);
+                }
                 if (v >= 0 && v < nv) {
                     if constexpr (T16) {
                         unsigned short* dst = tile16 + (slot * CPL) * LD + v;

@@ -222,6 +222,17 @@ int fbbev_bev_pool_v2_dense_fwd_add(const float* depth, const float* feat, const
                                     const void* tile_ws, size_t tile_ws_bytes, int tile_voxels, int flags,
                                     const float* addend, fbbev_stream_t stream);
 
+/* Measurement aid, not part of the product path (bench.py `roofline.store_floor_ms` / `no_gather_ms`): the default fp32
+ * instantiation of the dense kernel (tile_voxels 128, FBBEV_POOL_CPL8, 256 threads, `sc1 nt` stores; anything else ->
+ * FBBEV_E_UNSUPPORTED) with its gathers compiled out, launched with the grid / tile walk / XCD order the product launch
+ * takes for the same `flags`.  mode 1: the store pattern alone (every tile written as zeros, no metadata); mode 2:
+ * everything except the depth / feature gathers and their fmaf chains.  `out` (B,C,Z,Y,X) f32 contiguous receives zeros. */
+int fbbev_diag_pool_store_floor(const float* depth, const float* feat, const int32_t* ranks_depth,
+                                const int32_t* ranks_feat, const int32_t* interval_rank,
+                                const int32_t* interval_starts, const int32_t* interval_lengths, int B, int C, int Z,
+                                int Y, int X, float* out, const void* tile_ws, size_t tile_ws_bytes, int tile_voxels,
+                                int flags, int mode, fbbev_stream_t stream);
+
 /* ----------------------------------------------------------------------------------------------
  * Boundary 2: mmcv._ext.ms_deform_attn_{forward,backward} (mmcv-full 1.5.2, external to the tree)
  * -------------------------------------------------------------------------------------------- */

@@ -34,7 +34,7 @@ def test_fused_da_kernel_vs_oracle_composite(dev):
         assert torch.allclose(slots.cpu(), exp, atol=1e-4, rtol=1e-4), (seed, (slots.cpu() - exp).abs().max())
 
 
-def _setup(dev, B=2, num_levels=1, bev=20, seed=0):
+def _setup(dev, B=2, num_levels=1, bev=20, seed=0, shapes=None):
     from fb_bev_amd import backward_projection as BP, configs, synthetic as S
     gcb = {'x': [-40, 40, 80.0 / bev], 'y': [-40, 40, 80.0 / bev], 'z': [-1, 5.4, 1.6]}
     cfg = configs.fbocc_r50(num_levels=num_levels, bev_h=bev, bev_w=bev, grid_config_bevformer=gcb)
@@ -50,7 +50,7 @@ def _setup(dev, B=2, num_levels=1, bev=20, seed=0):
     cam = S.camera_rig(pcfg, B, seed=seed, bda_aug=True)
     g = torch.Generator().manual_seed(seed + 5)
     C, DC = 80, 80
-    shapes = [(16, 44), (8, 22), (4, 11), (2, 6)][:num_levels]
+    shapes = list(shapes) if shapes is not None else [(16, 44), (8, 22), (4, 11), (2, 6)][:num_levels]
     feats = [torch.randn(B, 6, C, h, w, generator=g) for h, w in shapes]
     depth = (torch.randn(B, 6, DC, 16, 44, generator=g) * 3).softmax(2)
     lss = torch.randn(B, C, bev, bev, generator=g)
@@ -79,6 +79,28 @@ def test_backward_projection_module_vs_oracle(dev, num_levels):
     bad = (err > 1e-3).any(dim=1).sum().item()
     assert bad <= 3, bad
     assert err.median().item() < 1e-5
+
+
+def test_backward_projection_module_vs_oracle_at_baseline_config2_full_size(dev):
+    """VERDICT r2 (untested sizes): BASELINE configs[2] through the MODULE at its full size -- bev 200x200 (Q = 40 000), the
+    4-level pyramid 16x44 / 32x88 / 8x22 / 4x11 (level 0 = the depth net's level, spatial_cross_attention_depth.py:586),
+    B = 1 -- against oracle/backward_projection_oracle.py (backward_projection.py:84-133, bevformer_encoder.py:250-377).
+    Same bar as the 20x20 test: <= 1e-4-scale agreement, a handful of queries whose borderline in-image mask bit flips
+    between the CPU and GPU fp32 op orders (here out of 40 000 instead of 400)."""
+    bev = 200
+    shapes = [(16, 44), (32, 88), (8, 22), (4, 11)]
+    m, cfg, cam, feats, depth, lss, gcb = _setup(dev, B=1, num_levels=4, bev=bev, shapes=shapes)
+    with torch.no_grad():
+        out = m([f.to(dev) for f in feats], None, lss_bev=lss.to(dev), cam_params=[t.to(dev) for t in cam],
+                pred_img_depth=depth.to(dev))
+    exp = _oracle_out(m, cfg, cam, feats, depth, lss, gcb, bev, 4)
+    assert out.shape == exp.shape == (1, 80, bev, bev)
+    err = (out.cpu() - exp).abs()
+    bad = (err > 1e-3).any(dim=1).sum().item()
+    assert bad <= 12, bad                                        # 0.03 % of the queries (3 of 400 in the small test)
+    ok = ~(err > 1e-3).any(dim=1, keepdim=True).expand_as(err)
+    assert err[ok].max().item() <= 1e-3 and err.median().item() < 1e-5
+    assert (err[ok] > 1e-4).float().mean().item() < 1e-3, (err[ok] > 1e-4).float().mean().item()
 
 
 @pytest.mark.parametrize('train_fused', [True, False])
@@ -192,7 +214,11 @@ def test_fused_backward_kernels_within_a_bound_of_fp64_autograd(dev, lds_planes)
     for seed, kw in ((5, dict(B=1, Q=29, E=16, M=4)),
                      (6, dict(B=2, Q=17, E=40, M=4, shapes=((4, 6), (2, 3)))),
                      (7, dict(B=2, Q=333, E=80, M=8, shapes=((16, 44),), DC=20)),       # the shipped head layout
-                     (8, dict(B=1, Q=257, E=80, M=8, shapes=((16, 44), (32, 88), (8, 22), (4, 11)), DC=20))):   # configs[2] pyramid: 6 token regions
+                     (8, dict(B=1, Q=257, E=80, M=8, shapes=((16, 44), (32, 88), (8, 22), (4, 11)), DC=20)),   # configs[2] pyramid: 6 token regions
+                     # VERDICT r2 (untested sizes): the same bound at Q >= 10 000 -- many query chunks per workgroup plan,
+                     # long per-token accumulation chains in the fixed-point planes
+                     (9, dict(B=1, Q=10000, E=80, M=8, shapes=((16, 44), (32, 88), (8, 22), (4, 11)), DC=20)),
+                     (10, dict(B=1, Q=40000, E=80, M=8, shapes=((16, 44),), DC=20))):          # configs[2]'s Q on the shipped level
         args, exp, leaves = da_case(seed, grad=True, **kw)
         g = torch.randn(exp.shape, generator=torch.Generator().manual_seed(seed), dtype=torch.float64)
         wrt = [leaves['key'], leaves['pred']] + [leaves['Pm'][k] for k in sorted(leaves['Pm']) if 'output_proj' not in k]
