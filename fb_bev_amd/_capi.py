@@ -65,6 +65,7 @@ SIGNATURES = {
     'fbbev_msda_fwd': (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_void_p, c_void_p]),
     'fbbev_point_sampling': (c_int, [c_void_p] * 9 + [c_int] * 5 + [c_float, c_float] + [c_void_p] * 4),
     'fbbev_da_cross_attn_fwd': (c_int, [c_void_p] * 9 + [c_int] * 10 + [c_float, c_float, c_int, c_int, c_void_p, c_void_p]),
+    'fbbev_da_cross_attn_fwd_zt': (c_int, [c_void_p] * 9 + [c_int] * 10 + [c_float, c_float, c_int, c_int, c_void_p, c_void_p]),
     'fbbev_da_cross_attn_fwd_e': (c_int, [c_void_p] * 9 + [c_int] * 10 + [c_float, c_float, c_int, c_int, c_int] + [c_void_p, c_void_p]),
     'fbbev_da_cross_attn_bwd': (c_int, [c_void_p] * 10 + [c_int] * 10 + [c_float, c_float, c_int, c_int] + [c_void_p] * 5),
     'fbbev_da_cross_attn_bwd_ws_bytes': (c_size_t, [c_int] * 9 + [c_void_p]),
@@ -413,10 +414,12 @@ def msda_bwd(value, spatial_shapes, level_start_index, sampling_loc, attn_weight
 
 
 def da_cross_attn_fwd(value, spatial_shapes, level_start_index, pred_depth, ref_cam, mask, qdepth, offsets,
-                      attn, d0, dstep, slots, head_minor=0, head_dim=None):
+                      attn, d0, dstep, slots, head_minor=0, head_dim=None, zero_token=False):
     """value (B*Ncam,S,M,Dh); pred_depth (B*Ncam,DC,H0,W0); ref_cam (Ncam,B,Q,Za,2); mask (Ncam,B,Q,Za) bool;
     qdepth (Ncam,B,Q,Za); offsets (B,Q,M,L,P,2); attn (B,Q,M,L,P); head_minor bit 0: offsets is (B,Q,L,P,M,2),
-    bit 1: attn is (B,Q,L,P,M), bit 2: a value token's M*HS floats are stored (HS/4, M, 4); slots (B,Q,M*Dh)."""
+    bit 1: attn is (B,Q,L,P,M), bit 2: a value token's M*HS floats are stored (HS/4, M, 4); slots (B,Q,M*Dh).
+    zero_token=True (fp32 rows): `value` is the first B*Ncam*S tokens of a buffer that holds one more, all-zero token right
+    behind them (da_value_buffer) -- the pipelined sampler fbbev_da_cross_attn_fwd_zt."""
     Ncam, B, Q, Za = mask.shape
     _, S, M, HS = value.shape                 # HS = head stride; head_dim (<= HS) of them are channels, the rest padding
     Dh = HS if head_dim is None else int(head_dim)
@@ -439,13 +442,27 @@ def da_cross_attn_fwd(value, spatial_shapes, level_start_index, pred_depth, ref_
                 float(d0), float(dstep), head_minor, HS, ELEM_TYPE[value.dtype], _dev(slots, F32, 'slots'), _stream()),
                 'fbbev_da_cross_attn_fwd_e')
         return
+    fn, name = lib().fbbev_da_cross_attn_fwd, 'fbbev_da_cross_attn_fwd'
+    if zero_token:
+        need = (value.storage_offset() + value.numel() + M * HS) * 4
+        if not value.is_contiguous() or value.untyped_storage().nbytes() < need:
+            raise FbbevError('zero_token=True needs the value view of da_value_buffer (one extra token behind the rows)')
+        fn, name = lib().fbbev_da_cross_attn_fwd_zt, 'fbbev_da_cross_attn_fwd_zt'
     with _on(value):
-        _check(lib().fbbev_da_cross_attn_fwd(
+        _check(fn(
             _dev(value, F32, 'value'), _dev(spatial_shapes, I64, 'spatial_shapes'),
             _dev(level_start_index, I64, 'level_start_index'), _dev(pred_depth, F32, 'pred_depth'),
             _dev(ref_cam, F32, 'ref_cam'), _dev(mask, torch.uint8, 'mask'), _dev(qdepth, F32, 'qdepth'),
             _dev(offsets, F32, 'offsets'), _dev(attn, F32, 'attn'), B, Ncam, S, M, Dh, L, Q, P, Za, DC,
-            float(d0), float(dstep), head_minor, HS, _dev(slots, F32, 'slots'), _stream()), 'fbbev_da_cross_attn_fwd')
+            float(d0), float(dstep), head_minor, HS, _dev(slots, F32, 'slots'), _stream()), name)
+
+
+def da_value_buffer(tokens, row_floats, device):
+    """(buffer, rows): `rows` = the (tokens, row_floats) fp32 view the value projection writes into, `buffer` holds one more
+    token behind it, zeroed here (the zero token of fbbev_da_cross_attn_fwd_zt)."""
+    buf = torch.empty((tokens + 1, row_floats), dtype=F32, device=device)
+    buf[tokens].zero_()
+    return buf, buf[:tokens]
 
 
 def _level_hw(level_hw, L):

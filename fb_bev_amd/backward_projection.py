@@ -440,9 +440,24 @@ class DA_SpatialCrossAttention(nn.Module):
                     self._vpad = _pad_interleave_rows(wt, bs, M, Dh, HS)
                 self._vpad_key = key
             w, bb = self._vpad
-        v = F.linear(x, w, bb).view(B * ncam, S, M, HS)           # a token's M*HS floats are (HS/4, M, 4)
         so, aw = da.project_head_minor(query)
         DC, H0, W0 = pred_img_depth.shape[2:]
+        if not grad_mode and x.dtype == torch.float32 and x.is_cuda:
+            # inference: the projection writes into a buffer with one extra all-zero token behind the rows -- the pipelined
+            # sampler (fbbev_da_cross_attn_fwd_zt: two samples in flight per lane) reads it for padded corners and
+            # out-of-image samples instead of branching around their loads
+            _, rows = _capi.da_value_buffer(B * ncam * S, M * HS, x.device)
+            torch.addmm(bb, x.reshape(B * ncam * S, E), w.t(), out=rows)
+            slots = torch.empty((B, Q, M * Dh), dtype=torch.float32, device=query.device)
+            _capi.da_cross_attn_fwd(rows.view(B * ncam, S, M, HS), spatial_shapes.to(torch.int64).contiguous(),
+                                    level_start_index.to(torch.int64).contiguous(),
+                                    pred_img_depth.reshape(B * ncam, DC, H0, W0).contiguous().float(),
+                                    reference_points_cam.contiguous().float(), mask.contiguous(),
+                                    bev_query_depth.squeeze(-1).contiguous().float(), so.contiguous().float(),
+                                    aw.contiguous().float(), self.dbound[0], self.dbound[2], slots,
+                                    head_minor=1 | (4 if interleave else 0), head_dim=Dh, zero_token=True)
+            return slots
+        v = F.linear(x, w, bb).view(B * ncam, S, M, HS)           # a token's M*HS floats are (HS/4, M, 4)
         return FusedDACrossAttention.apply(
             v.contiguous().float(), pred_img_depth.reshape(B * ncam, DC, H0, W0).contiguous().float(),
             so.contiguous().float(), aw.contiguous().float(), spatial_shapes.to(torch.int64).contiguous(),

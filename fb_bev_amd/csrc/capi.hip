@@ -967,6 +967,49 @@ extern "C" int fbbev_da_cross_attn_fwd(const float* value, const int64_t* spatia
     return 0;
 }
 
+// Pipelined forward (k_da_cross_attn_fwd_pipe): the value buffer holds ONE MORE token than B*Ncam*S -- token index
+// B*Ncam*S, M*HS floats, all +0.0f -- which padded corners and out-of-image samples read instead of branching around their
+// loads.  Shapes outside the pipelined kernel's preconditions run fbbev_da_cross_attn_fwd on the same buffer.
+extern "C" int fbbev_da_cross_attn_fwd_zt(const float* value, const int64_t* spatial_shapes,
+                                          const int64_t* level_start_index, const float* pred_depth,
+                                          const float* ref_cam, const uint8_t* mask, const float* qdepth,
+                                          const float* offsets, const float* attn, int B, int Ncam, int S, int M,
+                                          int Dh, int L, int Q, int P, int Za, int DC, float d0, float dstep,
+                                          int head_minor, int head_stride, float* slots, fbbev_stream_t stream_) {
+    if (B <= 0 || Ncam <= 0 || S <= 0 || M <= 0 || Dh <= 0 || L <= 0 || Q < 0 || P <= 0 || Za <= 0 || DC <= 0)
+        return FBBEV_E_BADARG;
+    const int HS = head_stride == 0 ? Dh : head_stride;
+    const int LP = L * P;
+    const long long units = (long long)B * Q * M;
+    const long long tokens = (long long)B * Ncam * S;
+    const bool pipe = value && offsets && attn && slots && units > 0 && dstep != 0.f &&
+                      (head_minor & 7) == (1 | 4) &&                                  // head-minor offsets, (B,Q,M,L,P) attn, chunk-major rows
+                      Za == 4 && P % 4 == 0 && (Dh == 8 || Dh == 10) && HS == (Dh + 3) / 4 * 4 &&
+                      LP % 4 == 0 && LP <= 36 && aligned16(attn) && aligned16(value) &&
+                      (((uintptr_t)offsets | (uintptr_t)slots) & 7) == 0 &&
+                      (tokens + 1) * M * HS * 4 < (1ll << 32);                        // 32-bit byte offsets incl. the zero token
+    static const bool pipe_off = [] { const char* e = getenv("FBBEV_DA_PIPE"); return e && atoi(e) == 0; }();   // A/B timing knob
+    if (!pipe || pipe_off)
+        return fbbev_da_cross_attn_fwd(value, spatial_shapes, level_start_index, pred_depth, ref_cam, mask, qdepth, offsets,
+                                       attn, B, Ncam, S, M, Dh, L, Q, P, Za, DC, d0, dstep, head_minor, head_stride, slots,
+                                       stream_);
+    if (!spatial_shapes || !level_start_index || !pred_depth || !ref_cam || !mask || !qdepth) return FBBEV_E_BADARG;
+    long long ub = ((units + 255) / 256 + 7) / 8 * 8;             // XCD-contiguous order: a multiple of 8 workgroups
+    if (ub > 65536) ub = 65536;
+    const size_t lds = (size_t)256 * (LP + 1) * sizeof(float);
+    const unsigned zero_bytes = (unsigned)(tokens * M * HS * 4);
+#define FBBEV_DA_PIPE(DH_, WPS_)                                                                                     \
+    FBBEV_LAUNCH((k_da_cross_attn_fwd_pipe<DH_, 4, WPS_>), ub, 256, lds, (fbbev_rt_stream)stream_, units, value,         \
+                 spatial_shapes, level_start_index, pred_depth, ref_cam, mask, qdepth, offsets, attn, B, Ncam, S, M, L, \
+                 Q, P, DC, d0, dstep, HS, zero_bytes, slots)
+    static const int wps = [] { const char* e = getenv("FBBEV_DA_PIPE_WPS"); return e ? atoi(e) : 3; }();   // tuning knob, read once
+    if (Dh == 10) { if (wps == 2) FBBEV_DA_PIPE(10, 2); else FBBEV_DA_PIPE(10, 3); }
+    else { if (wps == 2) FBBEV_DA_PIPE(8, 2); else FBBEV_DA_PIPE(8, 3); }
+#undef FBBEV_DA_PIPE
+    FBBEV_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int fbbev_da_cross_attn_bwd(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
                                        const float* pred_depth, const float* ref_cam, const uint8_t* mask,
                                        const float* qdepth, const float* offsets, const float* attn,

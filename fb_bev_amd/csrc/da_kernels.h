@@ -247,6 +247,233 @@ k_da_cross_attn_fwd_unit(long long n_units, const void* __restrict__ value_, con
 }
 
 
+// ---------------------------------------------------------------- pipelined unit-per-lane forward (round 3)
+// The loop above drains every sample's 12 corner loads before it blends them (ISA: `gload x13 | vmcnt(0) | valu x98`), so
+// only the 3 waves per SIMD overlap anything; SQ counters at BASELINE configs[2]: waves parked 42 %, issue-stalled 34 %
+// (profiles/r03_pmc_fb_BL3_B4_before.json).  This variant keeps TWO samples in flight per lane: the corner loads of
+// sample i+1 are issued before sample i is blended (tools/micro/unit_sampler_pipeline.hip on the GPU: 1.35 -> 1.06 ms,
+// profiles/r03_exp_unit_sampler_pipeline.jsonl).  What makes that possible, all visible in the ISA skeleton
+// (tests/test_kernel_resources.py guards it):
+//   * no branch between issue and consume: an out-of-image sample or a zero-padded corner does not skip its loads, it
+//     reads the ZERO TOKEN the host appends to the value buffer (token index B*Ncam*S, all +0.0f) -- the padded corner
+//     then contributes w * 0 exactly as in the reference (no 40 v_cndmask per sample either), an out-of-image sample
+//     gets weight 0;
+//   * two register slots addressed at compile time (the loop is unrolled over the ZA anchors: ZA samples = ZA/2 slot
+//     pairs; the anchor's reference point and depth weight are then static registers instead of a dynamically indexed
+//     array), the look-ahead issue past the last sample is a dummy on the zero token, never a branch;
+//   * the third chunk of a Dh = 10 head (channels 8, 9 + two padding floats) is read as 8 bytes: the two dead floats of a
+//     16-byte load are destination registers the allocator reuses while the load is in flight, and the write-after-write
+//     wait drains the queue; also 160 instead of 192 bytes per sample through the vector L1;
+//   * the offsets of the NEXT group of ZA samples are requested first in a group's body: `vmcnt` retires in order, so they
+//     are older than every corner load issued after them and never waited past.
+// Arithmetic: the blend is the reference's `(w1 v1 + w2 v2 + w3 v3 + w4 v4) * weight` per channel, on channel pairs
+// (v_pk_mul_f32 / v_pk_fma_f32); `offset / size` is evaluated as offset * (1 / size) with the level's reciprocal (one
+// ulp of a sub-pixel offset: the bilinear sample is continuous in it; the unit kernel above keeps the division).
+// Preconditions (launcher): chunk-major fp32 rows (QI), head-minor offsets, attention weights staged through LDS,
+// P % ZA == 0, ZA even, DH in {8, 10}.
+template <int DH>
+struct fbbev_da_pending {
+    static constexpr int NF = DH / 4;                    // full 16-byte chunks of a head
+    fbbev_v4f a1[NF], a2[NF], a3[NF], a4[NF];
+    fbbev_v2f t1, t2, t3, t4;                            // 8-byte tail chunk (DH % 4 == 2)
+    float w1, w2, w3, w4, weight;
+};
+
+template <int DH>
+__device__ __forceinline__ void fbbev_da_issue(const char* __restrict__ vb, unsigned lane_off, unsigned zero_off, unsigned cs,
+                                               int row_stride, float h_im, float w_im, int sh, int sw, float weight,
+                                               bool enable, fbbev_da_pending<DH>& p) {
+    const bool live = enable && h_im > -1.f && w_im > -1.f && h_im < (float)sh && w_im < (float)sw;
+    // an out-of-image sample is set up at (0, 0): finite weights, every corner on the zero token, weight 0
+    const fbbev_bilinear s = fbbev_bilinear_setup(live ? h_im : 0.f, live ? w_im : 0.f, sh, sw, row_stride);
+    p.w1 = s.w1; p.w2 = s.w2; p.w3 = s.w3; p.w4 = s.w4;
+    p.weight = live ? weight : 0.f;
+    const unsigned b1 = (live && s.o1 >= 0) ? lane_off + (unsigned)s.o1 * 4u : zero_off;
+    const unsigned b2 = (live && s.o2 >= 0) ? lane_off + (unsigned)s.o2 * 4u : zero_off;
+    const unsigned b3 = (live && s.o3 >= 0) ? lane_off + (unsigned)s.o3 * 4u : zero_off;
+    const unsigned b4 = (live && s.o4 >= 0) ? lane_off + (unsigned)s.o4 * 4u : zero_off;
+    constexpr int NF = DH / 4;
+#pragma unroll
+    for (int k = 0; k < NF; ++k) {
+        p.a1[k] = *reinterpret_cast<const fbbev_v4f*>(vb + (b1 + k * cs));
+        p.a2[k] = *reinterpret_cast<const fbbev_v4f*>(vb + (b2 + k * cs));
+        p.a3[k] = *reinterpret_cast<const fbbev_v4f*>(vb + (b3 + k * cs));
+        p.a4[k] = *reinterpret_cast<const fbbev_v4f*>(vb + (b4 + k * cs));
+    }
+    if constexpr (DH % 4 == 2) {
+        p.t1 = *reinterpret_cast<const fbbev_v2f*>(vb + (b1 + NF * cs));
+        p.t2 = *reinterpret_cast<const fbbev_v2f*>(vb + (b2 + NF * cs));
+        p.t3 = *reinterpret_cast<const fbbev_v2f*>(vb + (b3 + NF * cs));
+        p.t4 = *reinterpret_cast<const fbbev_v2f*>(vb + (b4 + NF * cs));
+    }
+}
+
+__device__ __forceinline__ fbbev_v2f fbbev_pair(const fbbev_v4f& a, int hi) {
+    fbbev_v2f r;
+    r[0] = a[2 * hi]; r[1] = a[2 * hi + 1];
+    return r;
+}
+
+template <int DH>
+__device__ __forceinline__ void fbbev_da_consume(const fbbev_da_pending<DH>& p, fbbev_v2f (&col)[DH / 2]) {
+    constexpr int NF = DH / 4;
+#pragma unroll
+    for (int k = 0; k < NF; ++k)
+#pragma unroll
+        for (int hi = 0; hi < 2; ++hi) {
+            const fbbev_v2f v1 = fbbev_pair(p.a1[k], hi), v2 = fbbev_pair(p.a2[k], hi);
+            const fbbev_v2f v3 = fbbev_pair(p.a3[k], hi), v4 = fbbev_pair(p.a4[k], hi);
+            col[2 * k + hi] += (p.w1 * v1 + p.w2 * v2 + p.w3 * v3 + p.w4 * v4) * p.weight;
+        }
+    if constexpr (DH % 4 == 2) col[DH / 2 - 1] += (p.w1 * p.t1 + p.w2 * p.t2 + p.w3 * p.t3 + p.w4 * p.t4) * p.weight;
+    // the blend happens HERE, before the next sample's loads are issued (see fbbev_pin)
+#pragma unroll
+    for (int c = 0; c < DH / 2; ++c) fbbev_pin(col[c]);
+}
+
+// WPS: waves per SIMD the register allocation is bounded for (3 -> 168 VGPRs: a dozen values of the per-camera prologue
+// spill, none inside the sample loop; 2 -> the natural 183)
+template <int DH, int ZA, int WPS>
+__global__ void __launch_bounds__(256, WPS)
+k_da_cross_attn_fwd_pipe(long long n_units, const float* __restrict__ value, const int64_t* __restrict__ spatial_shapes,
+                         const int64_t* __restrict__ level_start, const float* __restrict__ pred_depth,
+                         const float* __restrict__ ref_cam, const unsigned char* __restrict__ mask,
+                         const float* __restrict__ qdepth, const float* __restrict__ offsets,
+                         const float* __restrict__ attn, int B, int Ncam, int S, int M, int L, int Q, int P,
+                         int DC, float d0, float dstep, int HS, unsigned zero_token_bytes, float* __restrict__ slots) {
+    static_assert(DH % 2 == 0 && (DH % 4 == 0 || DH % 4 == 2), "channel pairs");
+    static_assert(ZA % 2 == 0 && ZA <= FBBEV_DA_MAX_ZA, "two register slots alternate over the anchors");
+    const char* vb = reinterpret_cast<const char*>(value);
+    const int row_stride = M * HS;                // floats per token
+    const unsigned cs = (unsigned)M * 16u;        // bytes between the chunks of a head (chunk-major rows)
+    const int H0 = (int)spatial_shapes[0], W0 = (int)spatial_shapes[1];
+    const int LP = L * P, LDW = LP + 1, gpl = P / ZA;
+    float* staged = fbbev_dyn_lds_f32();          // [256][LP+1]: the workgroup's attention weights
+    const long long n_wg = (n_units + blockDim.x - 1) / blockDim.x, per_xcd = (n_wg + 7) / 8;
+    for (long long w = blockIdx.x; (w >> 3) < per_xcd; w += gridDim.x) {
+        const long long ubase = ((w & 7) * per_xcd + (w >> 3)) * blockDim.x;          // XCD-contiguous unit order
+        const long long unit = ubase + threadIdx.x;
+        {
+            __syncthreads();
+            const long long rem = n_units - ubase;
+            const int nfl = rem <= 0 ? 0 : (int)(rem < (long long)blockDim.x ? rem : (long long)blockDim.x) * LP;
+            const float* src = attn + ubase * LP;
+            for (int i = threadIdx.x * 4; i < nfl; i += blockDim.x * 4) {
+                const fbbev_v4f a = *reinterpret_cast<const fbbev_v4f*>(src + i);
+                float* d = staged + (i / LP) * LDW + (i % LP);
+                d[0] = a[0]; d[1] = a[1]; d[2] = a[2]; d[3] = a[3];
+            }
+            __syncthreads();
+        }
+        if (unit >= n_units) continue;
+        const float* my_attn = staged + threadIdx.x * LDW;
+        const int m = (int)(unit % M);
+        const long long bq = unit / M;
+        const int q = (int)(bq % Q);
+        const int b = (int)(bq / Q);
+        const unsigned zero_off = zero_token_bytes + (unsigned)m * 16u;
+        fbbev_v2f acc[DH / 2];
+#pragma unroll
+        for (int c = 0; c < DH / 2; ++c) { acc[c][0] = 0.f; acc[c][1] = 0.f; }
+        const fbbev_v2f* op = reinterpret_cast<const fbbev_v2f*>(offsets) + bq * LP * M + m;   // head-minor (B,Q,L,P,M,2)
+        // hit test of all cameras first (independent loads in flight together): a query hits a camera if ANY anchor does
+        unsigned hits = 0u;
+        for (int cam = 0; cam < Ncam; ++cam) {
+            const long long base = (((long long)cam * B + b) * Q + q) * ZA;
+            bool hit = false;
+#pragma unroll
+            for (int z = 0; z < ZA; ++z) hit = hit || (mask[base + z] != 0);
+            hits |= hit ? (1u << cam) : 0u;
+        }
+        int count = 0;
+        for (int cam = 0; cam < Ncam; ++cam) {
+            if (!((hits >> cam) & 1u)) continue;
+            ++count;
+            const long long base = (((long long)cam * B + b) * Q + q) * ZA;
+            const long long bn = (long long)b * Ncam + cam;
+            // offsets of samples 0 and 1: requested before the depth weights are evaluated
+            fbbev_v2f o_a = op[0], o_b = op[M];
+            float rx[ZA], ry[ZA], dw[ZA];
+#pragma unroll
+            for (int z = 0; z < ZA; ++z) {
+                rx[z] = ref_cam[(base + z) * 2];
+                ry[z] = ref_cam[(base + z) * 2 + 1];
+                float fb = floorf(__fdiv_rn(__fsub_rn(qdepth[base + z], d0), dstep));
+                fb = fminf(fmaxf(fb, 0.f), (float)(DC - 1));
+                const int bin = (int)fb;
+                dw[z] = fbbev_plane_sample(pred_depth + (bn * DC + bin) * (long long)(H0 * W0), H0, W0, rx[z], ry[z]);
+            }
+            fbbev_v2f col[DH / 2];
+#pragma unroll
+            for (int c = 0; c < DH / 2; ++c) { col[c][0] = 0.f; col[c][1] = 0.f; }
+            const long long cam_tok = bn * S;
+            // issue-stream state: sizes / reciprocals / this lane's byte offset of the level the NEXT issue samples
+            int sh = H0, sw = W0;
+            float fsh = (float)sh, fsw = (float)sw, rsh = __fdiv_rn(1.f, fsh), rsw = __fdiv_rn(1.f, fsw);
+            unsigned lane_off = (unsigned)(((cam_tok + level_start[0]) * row_stride + m * 4) * 4);
+            fbbev_da_pending<DH> pa, pb;
+            // issue sample lp (anchor z) with the offsets `o`; the offsets of sample lp + 2 -- the next user of the same
+            // register pair -- are requested FIRST: `vmcnt` retires in order, so that small load is older than the corner
+            // loads issued behind it and is complete whenever they are
+            auto start = [&](int lp, int z, bool enable, fbbev_v2f& o, fbbev_da_pending<DH>& slot) {
+                const float loc_w = rx[z] + o[0] * rsw, loc_h = ry[z] + o[1] * rsh;
+                const int nx = lp + 2 < LP ? lp + 2 : LP - 1;          // clamped: past the end a duplicate nobody uses
+                o = op[(long long)nx * M];
+                const float weight = fbbev_lds_ld_f32(my_attn + lp) * dw[z];
+                fbbev_da_issue<DH>(vb, lane_off, zero_off, cs, row_stride, loc_h * fsh - 0.5f, loc_w * fsw - 0.5f, sh, sw,
+                                   weight, enable, slot);
+            };
+            start(0, 0, true, o_a, pa);
+            int g = 0;                             // flat group index = lp / ZA
+            for (int l = 0; l < L; ++l) {
+                // the level after this one (scalar loads, once per level, outside the pipelined loop); the last level looks
+                // ahead into itself and its look-ahead sample is disabled
+                const int ln = l + 1 < L ? l + 1 : l;
+                const int nsh = (int)spatial_shapes[2 * ln], nsw = (int)spatial_shapes[2 * ln + 1];
+                const float nfsh = (float)nsh, nfsw = (float)nsw, nrsh = __fdiv_rn(1.f, nfsh), nrsw = __fdiv_rn(1.f, nfsw);
+                const unsigned nlane_off = (unsigned)(((cam_tok + level_start[ln]) * row_stride + m * 4) * 4);
+                for (int gl = 0; gl < gpl; ++gl, ++g) {
+                    const bool last_of_level = gl + 1 == gpl;
+                    const bool more = !(last_of_level && l + 1 == L);          // a group follows this one
+                    const int gn = more ? g + 1 : g;
+#pragma unroll
+                    for (int z = 0; z < ZA; z += 2) {
+                        start(g * ZA + z + 1, z + 1, true, o_b, pb);   // corners of sample z+1 ...
+                        fbbev_sched_fence();
+                        fbbev_da_consume<DH>(pa, col);                 // ... in flight while sample z is blended
+                        fbbev_sched_fence();
+                        if (z + 2 < ZA) {
+                            start(g * ZA + z + 2, z + 2, true, o_a, pa);
+                        } else {
+                            // look-ahead into the next group: selects, not branches (a branch with memory operations on
+                            // one side makes the wait-count pass assume the worst at the join)
+                            sh = last_of_level ? nsh : sh; sw = last_of_level ? nsw : sw;
+                            fsh = last_of_level ? nfsh : fsh; fsw = last_of_level ? nfsw : fsw;
+                            rsh = last_of_level ? nrsh : rsh; rsw = last_of_level ? nrsw : rsw;
+                            lane_off = last_of_level ? nlane_off : lane_off;
+                            start(gn * ZA, 0, more, o_a, pa);         // past the last sample: a dummy on the zero token
+                        }
+                        fbbev_sched_fence();
+                        fbbev_da_consume<DH>(pb, col);
+                        fbbev_sched_fence();
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < DH / 2; ++c) acc[c] += col[c];
+        }
+        const float inv = (float)(count > 1 ? count : 1);
+        float* dst = slots + unit * DH;
+#pragma unroll
+        for (int c = 0; c < DH / 2; ++c) {
+            fbbev_v2f r;
+            r[0] = acc[c][0] / inv; r[1] = acc[c][1] / inv;
+            *reinterpret_cast<fbbev_v2f*>(dst + 2 * c) = r;
+        }
+    }
+}
+
+
 // ---------------------------------------------------------------- backward of the fused sampling (training path)
 // Replaces the autograd chain of the reference's training step through DA_SpatialCrossAttention /
 // DA_MSDeformableAttention (spatial_cross_attention_depth.py:163-216,513-595 -> two MultiScaleDeformableAttnFunction

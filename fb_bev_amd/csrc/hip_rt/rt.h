@@ -124,6 +124,11 @@ __device__ __forceinline__ void fbbev_sched_fence() { __builtin_amdgcn_sched_bar
 // conditional global override of the same variable was if-converted into ONE flat load of a selected pointer)
 __device__ __forceinline__ void fbbev_opaque(int& x) { asm volatile("" : "+v"(x)); }
 __device__ __forceinline__ void fbbev_opaque(float& x) { asm volatile("" : "+v"(x)); }
+// ordering point for a software pipeline: x must be COMPUTED here, and no memory operation moves across (the "memory"
+// clobber).  __builtin_amdgcn_sched_barrier alone does not do this: it binds the machine scheduler, but pure arithmetic is
+// not chained to it when the selection DAG is linearised -- the blend of sample i floated below the loads of samples
+// i+2 and i+3 (three samples of registers live, 285 VGPRs) until its results were pinned like this.
+__device__ __forceinline__ void fbbev_pin(fbbev_v2f& x) { asm volatile("" : "+v"(x) : : "memory"); }
 // read of a float that is KNOWN to live in LDS, through an explicit local-address-space pointer: always a ds_read, never
 // merged with a global load of the other arm of a condition
 __device__ __forceinline__ float fbbev_lds_ld_f32(const float* p) {

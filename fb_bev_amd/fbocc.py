@@ -92,7 +92,7 @@ class FBOCC(nn.Module):
                                      history_cat_conv_out_channels=history_cat_conv_out_channels, do_history=do_history,
                                      interpolation_mode=interpolation_mode, history_dtype=_dtype(ex.get('history_dtype')),
                                      history_compute=_dtype(ex.get('history_compute')),
-                                     ring_layout=ex.get('history_ring', 'planar'))
+                                     ring_layout=ex.get('history_ring', 'voxel_major'))
         # the reference registers the two fusion convolutions on the detector itself (fbocc.py:111-127): same names here
         self.history_keyframe_time_conv = hist.history_keyframe_time_conv
         self.history_keyframe_cat_conv = hist.history_keyframe_cat_conv

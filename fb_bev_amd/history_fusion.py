@@ -30,7 +30,7 @@ from .mfma_conv3d import MConv3d      # nn.Conv3d (same parameters / state dict)
 class TemporalHistoryFusion(nn.Module):
     def __init__(self, dx, bx, single_bev_num_channels=80, history_cat_num=16, history_cat_conv_out_channels=None,
                  do_history=True, interpolation_mode='bilinear', history_cam_sweep_freq=0.5, history_dtype=torch.float32,
-                 history_compute=torch.float32, ring_layout='planar'):
+                 history_compute=torch.float32, ring_layout='voxel_major'):
         super().__init__()
         if interpolation_mode != 'bilinear':
             raise NotImplementedError("only interpolation_mode='bilinear' (trilinear on the voxel grid) is built")
@@ -61,8 +61,9 @@ class TemporalHistoryFusion(nn.Module):
         # voxel rows (history_kernels.h): a trilinear tap is one 16-byte load of 8 channels instead of 8 scalar gathers from 8
         # planes, and the convolutions read MFMA operands as rows.  Same element bits as the planar ring (the fp32
         # convolutions sum their K in a different order on it: equal to fp32 rounding).  Taken when the register-resident
-        # MFMA convolutions are (C = Cout in {16, 80}); the autograd path stays planar fp32 and either kind of history is
-        # converted when the mode changes.  history_bev is then (B, T, N, C): history_as_reference() returns the reference's
+        # MFMA convolutions are (C = Cout in {16, 80}) -- the DEFAULT since round 3 (measured at BASELINE configs[4]: 21.9 ->
+        # 17.2 ms per frame with the reference's arithmetic); other channel counts, and ring_layout='planar', keep the
+        # reference's layout; the autograd path stays planar fp32 and either kind of history is converted when the mode changes.  history_bev is then (B, T, N, C): history_as_reference() returns the reference's
         # tensor.
         if ring_layout not in ('planar', 'voxel_major'):
             raise ValueError("ring_layout is 'planar' or 'voxel_major'")

@@ -322,6 +322,20 @@ int fbbev_da_cross_attn_fwd_e(const void* value, const int64_t* spatial_shapes,
                               int L, int Q, int P, int Za, int DC, float d0, float dstep, int head_minor,
                               int head_stride, int value_elem_type, float* slots, fbbev_stream_t stream);
 
+/* fbbev_da_cross_attn_fwd on a value buffer that carries ONE EXTRA token: (B*Ncam*S + 1) tokens of M*head_stride floats,
+ * the last one all +0.0f.  The pipelined sampler (two samples in flight per lane, no branch between issuing a sample's
+ * corner loads and blending the previous one) points padded corners and out-of-image samples at that token instead of
+ * skipping their loads; the result is the same sum (a padded corner contributes w * 0, spatial_cross_attention_depth.py:
+ * 593-595 via the zero padding of the op).  Taken for chunk-major fp32 rows (head_minor = 1 | 4), Za = 4, P % 4 == 0,
+ * Dh in {8, 10} with head_stride = Dh rounded up to 4, L*P <= 36; every other shape runs fbbev_da_cross_attn_fwd on the
+ * same buffer.  `offset / size` is evaluated as offset * (1 / size) (one ulp of a sub-pixel offset). */
+int fbbev_da_cross_attn_fwd_zt(const float* value, const int64_t* spatial_shapes,
+                               const int64_t* level_start_index, const float* pred_depth,
+                               const float* ref_cam, const uint8_t* mask, const float* qdepth,
+                               const float* offsets, const float* attn, int B, int Ncam, int S, int M, int Dh,
+                               int L, int Q, int P, int Za, int DC, float d0, float dstep, int head_minor,
+                               int head_stride, float* slots, fbbev_stream_t stream);
+
 /* Backward of fbbev_da_cross_attn_fwd in one launch -- replaces the autograd chain of the reference's training step
  * through DA_SpatialCrossAttention / DA_MSDeformableAttention (two MultiScaleDeformableAttnFunction backward launches,
  * multi_scale_deformable_attn_function.py:137-172, plus the rebatch / one-hot / scatter index ops and their host syncs).

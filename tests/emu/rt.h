@@ -251,6 +251,7 @@ inline float fbbev_f16_bits_to_f32(unsigned int h) {
 }
 inline void fbbev_wave_sync() { emu::wave_barrier(); }
 inline void fbbev_sched_fence() {}
+inline void fbbev_pin(fbbev_v2f&) {}
 inline void fbbev_opaque(int&) {}
 inline void fbbev_opaque(float&) {}
 inline float fbbev_lds_ld_f32(const float* p) { return *p; }

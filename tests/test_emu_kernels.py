@@ -252,6 +252,48 @@ def test_fused_da_cross_attention_emulated():
                 assert torch.equal(E.da_cross_attn_fwd(*a2, head_minor=5, head_dim=Dh), want), dt
 
 
+def test_pipelined_da_cross_attention_emulated():
+    """fbbev_da_cross_attn_fwd_zt -> k_da_cross_attn_fwd_pipe (two samples in flight per lane; padded corners and
+    out-of-image samples read the zero token behind the value rows): against the oracle's composite result and against
+    the one-sample-at-a-time unit kernel on the same inputs.  Not bit-identical by design -- `offset / size` is evaluated as
+    offset * (1 / size) -- but within fp32 rounding of a continuous function.  A zero-token filled with a NON-zero value
+    must change the result exactly when some sample has a padded corner (it does in every case below): proof that the
+    token is what those corners read; shapes outside the pipelined kernel's preconditions fall back to the unit kernel."""
+    cases = ((2, dict(B=1, Q=41, E=40, M=4)),                                          # Dh = 10, 2 levels x 8 points (LP = 16)
+             (4, dict(B=2, Q=300, E=80, M=8, shapes=((16, 44),), P=8, DC=20)),          # the shipped head layout, > 1 workgroup
+             (3, dict(B=2, Q=19, E=16, M=2, shapes=((6, 5), (3, 3), (2, 2)), P=4)),      # Dh = 8, 3 levels x 4 points
+             (6, dict(B=1, Q=37, E=40, M=4, shapes=((5, 7), (9, 6), (3, 4), (2, 2)), P=8)))   # 4 levels: LP = 32
+    for seed, kw in cases:
+        args, exp = _da_case(seed, **kw)
+        Dh = args[0].shape[-1]
+        HS = (Dh + 3) // 4 * 4
+        vp = torch.zeros(args[0].shape[:-1] + (HS,))
+        vp[..., :Dh] = args[0]
+        a = list(args)
+        a[0] = _interleave(vp)
+        a[7] = args[7].permute(0, 1, 3, 4, 2, 5).contiguous()
+        unit = E.da_cross_attn_fwd(*a, head_minor=5, head_dim=Dh)
+        pipe = E.da_cross_attn_fwd(*a, head_minor=5, head_dim=Dh, zero_token=0.0)
+        assert not torch.isnan(pipe).any()
+        assert torch.allclose(pipe, exp, atol=2e-5, rtol=1e-5), (seed, (pipe - exp).abs().max())
+        assert torch.allclose(pipe, unit, atol=2e-6, rtol=1e-5), (seed, (pipe - unit).abs().max())
+        poisoned = E.da_cross_attn_fwd(*a, head_minor=5, head_dim=Dh, zero_token=3.0)
+        assert not torch.equal(poisoned, pipe), seed                                    # the token IS read ...
+        assert torch.isfinite(poisoned).all()
+    # ... and outside the preconditions (here Za = 2; head-major rows) the entry runs the unit kernel: identical bits
+    args, exp = _da_case(7, B=1, Q=23, E=40, M=4, Za=2)
+    Dh = args[0].shape[-1]
+    vp = torch.zeros(args[0].shape[:-1] + (12,)); vp[..., :Dh] = args[0]
+    a = list(args); a[0] = _interleave(vp); a[7] = args[7].permute(0, 1, 3, 4, 2, 5).contiguous()
+    assert torch.equal(E.da_cross_attn_fwd(*a, head_minor=5, head_dim=Dh, zero_token=3.0),
+                       E.da_cross_attn_fwd(*a, head_minor=5, head_dim=Dh))
+    args, exp = _da_case(2, B=1, Q=41, E=40, M=4)
+    vp = torch.zeros(args[0].shape[:-1] + (12,)); vp[..., :10] = args[0]
+    a = list(args); a[0] = vp; a[7] = args[7].permute(0, 1, 3, 4, 2, 5).contiguous()
+    assert torch.equal(E.da_cross_attn_fwd(*a, head_minor=1, head_dim=10, zero_token=3.0),
+                       E.da_cross_attn_fwd(*a, head_minor=1, head_dim=10))
+
+
 def test_tokens_from_nchw_emulated():
     """fbbev_tokens_from_nchw: per-level transposition + cams_embeds into the (bs*num_cam, sum HW, C) token rows ==
     bevformer.py:95-117 (flatten/permute/add, cat) followed by the rebatch permute; and the plain inverse transposition."""

@@ -243,8 +243,12 @@ def test_fused_backward_kernels_within_a_bound_of_fp64_autograd(dev, lds_planes)
             if y is None:
                 assert x is None or not x.any()
                 continue
-            bound = 1e-4 * y.abs() + 5e-5 * max(1.0, y.abs().max().item())
-            assert ((x - y).abs() <= bound).all(), ((x - y).abs().max().item(), y.abs().max().item(), seed)
+            # fp32 accumulation of n contributions per entry carries ~sqrt(n) * 2^-24 of the sum of magnitudes: the atomic
+            # kernel adds every query's contribution to a token in fp32 (arbitrary order), so its bound grows with the
+            # number of queries; the fixed-point planes add exactly and keep the small-case bound at any Q
+            grow = 1.0 if lds_planes else max(1.0, (kw.get('Q', 70) / 25.0) ** 0.5)
+            bound = 1e-4 * y.abs() + 5e-5 * grow * max(1.0, y.abs().max().item())
+            assert ((x - y).abs() <= bound).all(), ((x - y).abs().max().item(), y.abs().max().item(), seed, lds_planes)
 
 
 def test_lds_plane_backward_equals_atomic_backward_and_is_reproducible(dev):

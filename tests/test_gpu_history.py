@@ -213,7 +213,8 @@ def test_config_built_path_end_to_end_at_shipped_size(dev):
             out = hist.fuse_history(bev, metas, cam[5])
             assert out.shape == (B, 80, 100, 100, 8) and torch.isfinite(out).all()
             outs.append(out)
-    assert hist.history_bev.shape == (B, 16 * 80, 8, 100, 100)
+    assert hist._voxel_major() and hist.history_bev.shape == (B, 16, 8 * 100 * 100, 80)     # the default ring: voxel rows
+    assert hist.history_as_reference().shape == (B, 16 * 80, 8, 100, 100)                    # the reference's tensor (fbocc.py:312)
     assert (outs[0] - outs[1]).abs().max().item() > 0
 
 
@@ -307,7 +308,8 @@ def test_voxel_major_ring_equals_planar_ring(dev, dt, comp):
     assert torch.equal(rows.view(bits), frame.transpose(1, 2).to(dt).contiguous().view(bits))
 
 
-def test_baseline_config4_grid_16_frame_fp16_history(dev):
+@pytest.mark.parametrize('layout', ['voxel_major', 'planar'])
+def test_baseline_config4_grid_16_frame_fp16_history(dev, layout):
     """BASELINE configs[4] (stress): 400x400x16 grid, C=80, 16-frame history in fp16 = 7 GB per sample ring slot pair
     (13 GB in fp32).  Two frames through TemporalHistoryFusion at that size: (1) sequence start -- every history slot is
     the current frame, so the fused output of a voxel is a closed form of that voxel's 80 channels: checked against
@@ -317,7 +319,13 @@ def test_baseline_config4_grid_16_frame_fp16_history(dev):
     C, T, Z, Y, X = 80, 16, 16, 400, 400
     dx, bx = [0.2, 0.2, 0.4], [-39.9, -39.9, -0.8]
     torch.manual_seed(0)
-    m = TemporalHistoryFusion(dx, bx, single_bev_num_channels=C, history_cat_num=T, history_dtype=torch.float16).to(dev).eval()
+    m = TemporalHistoryFusion(dx, bx, single_bev_num_channels=C, history_cat_num=T, history_dtype=torch.float16,
+                              ring_layout=layout).to(dev).eval()
+    assert m._voxel_major() == (layout == 'voxel_major')
+
+    def frames():              # the ring as (T, C, Z, Y, X) fp16 frames whatever its layout (a 6.5 GB copy for voxel rows)
+        h = m.history_bev
+        return h.view(T, C, Z, Y, X) if h.dim() == 5 else h[0].transpose(1, 2).reshape(T, C, Z, Y, X)
     with torch.no_grad():
         for seq in (m.history_keyframe_time_conv, m.history_keyframe_cat_conv):
             seq[1].running_mean.normal_(0, 0.1); seq[1].running_var.uniform_(0.5, 1.5)
@@ -328,7 +336,8 @@ def test_baseline_config4_grid_16_frame_fp16_history(dev):
     with torch.no_grad():
         out0 = m.fuse_history(curr, meta(True, torch.eye(4)), bda)
     assert out0.shape == (1, C, Y, X, Z) and m.history_bev.dtype == torch.float16
-    assert m.history_bev.shape == (1, T * C, Z, Y, X) and m.history_bev.numel() * 2 == T * C * Z * Y * X * 2
+    assert m.history_bev.shape == ((1, T * C, Z, Y, X) if layout == 'planar' else (1, T, Z * Y * X, C))
+    assert m.history_bev.numel() * 2 == T * C * Z * Y * X * 2
     # (1) closed form on a voxel subset: all T+1 slots hold fp16(curr), time channel tau_t = 0 at a sequence start
     idx = torch.randint(0, Z * Y * X, (20000,), generator=g, device=dev)
     x16 = curr.permute(0, 1, 4, 2, 3).reshape(C, -1)[:, idx].half().float()      # (C, n) as stored
@@ -340,13 +349,13 @@ def test_baseline_config4_grid_16_frame_fp16_history(dev):
     assert (got - ref).abs().max().item() <= 2e-4 * ref.abs().max().item() + 1e-5
     # (2) one-voxel ego translation along x
     ego = torch.eye(4); ego[0, 3] = dx[0]
-    stored = m.history_bev.clone()                                               # fp16 frames before the second call
+    stored = frames().clone()                                                    # fp16 frames before the second call
     with torch.no_grad():
         out1 = m.fuse_history(curr, meta(False, ego), bda)
     assert torch.isfinite(out1).all()
-    h = m.history_bev.view(T, C, Z, Y, X)
+    h = frames()
     # slot 0 of the new history = the current frame, slot t >= 1 = previous slot t-1 sampled at x+1 (or x-1): find the sign once
-    prev = stored.view(T, C, Z, Y, X)
+    prev = stored
     # (the flow's translation is 1 voxel up to the fp32 rounding of the matrix chain and of coordinates up to 400: a tap
     # weight of ~1e-4 remains on the neighbouring voxel -- O(1e-4) absolute on N(0,1) data -- plus one fp16 rounding)
     close = lambda a, b: bool(torch.allclose(a.float(), b.float(), rtol=2e-3, atol=1e-3))  # noqa: E731
