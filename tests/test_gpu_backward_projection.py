@@ -239,16 +239,21 @@ def test_fused_backward_kernels_within_a_bound_of_fp64_autograd(dev, lds_planes)
                                    grad_outputs=[gv[..., :Dh].cpu().double(), gd.cpu().double(), go.cpu().double(), ga.cpu().double()],
                                    retain_graph=True, allow_unused=True)
         assert not gv[..., Dh:].any()
-        for x, y in zip(mine, ref):
+        names = ['key', 'pred'] + [k for k in sorted(leaves['Pm']) if 'output_proj' not in k]
+        for name, x, y in zip(names, mine, ref):
             if y is None:
                 assert x is None or not x.any()
                 continue
-            # fp32 accumulation of n contributions per entry carries ~sqrt(n) * 2^-24 of the sum of magnitudes: the atomic
-            # kernel adds every query's contribution to a token in fp32 (arbitrary order), so its bound grows with the
-            # number of queries; the fixed-point planes add exactly and keep the small-case bound at any Q
-            grow = 1.0 if lds_planes else max(1.0, (kw.get('Q', 70) / 25.0) ** 0.5)
-            bound = 1e-4 * y.abs() + 5e-5 * grow * max(1.0, y.abs().max().item())
-            assert ((x - y).abs() <= bound).all(), ((x - y).abs().max().item(), y.abs().max().item(), seed, lds_planes)
+            # Every gradient but one keeps the same bound at any Q (measured at Q = 10 000 / 40 000: 2e-6 .. 5e-6 of the
+            # scale for both kernels, profiles/r03_diag_da_bwd_bound.jsonl).  The exception is d/d(sampling offset): the
+            # bilinear sample is only piecewise smooth in its location, so a sample whose fp32 location falls on the other
+            # side of a cell boundary than its fp64 location contributes a DIFFERENT (finite) slope.  Such samples are a
+            # fixed small fraction of the Q * M * L * P * cameras samples, and the leaves sum over all queries: the
+            # deviation grows ~ linearly with Q (1e-6 at Q = 2 500, 5e-4 at 10 000, 2e-2 at 40 000 of the scale) -- the
+            # fp32 reference kernel has the same property.  Allowance: 1e-6 * Q of the scale, for these two leaves only.
+            kink = 1e-6 * kw.get('Q', 70) if 'sampling_offsets' in name and kw.get('Q', 70) >= 5000 else 0.0
+            bound = 1e-4 * y.abs() + (5e-5 + kink) * max(1.0, y.abs().max().item())
+            assert ((x - y).abs() <= bound).all(), (name, (x - y).abs().max().item(), y.abs().max().item(), seed, lds_planes)
 
 
 def test_lds_plane_backward_equals_atomic_backward_and_is_reproducible(dev):

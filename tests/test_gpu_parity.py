@@ -556,7 +556,8 @@ def test_cached_tile_tables_survive_mixed_routes(dev, out_dtype):
     gated on the build it was made for.  A fixed validation rig alternating with grad-enabled calls of ANOTHER rig (same
     B), and the two routes of a 16-bit volume (lift_splat: doubled 16-bit tile; write-once: fp32 tile) interleaved
     across rebuilds, must always pool with the table of the current index set."""
-    cfg, ovt, cam, _, depth, ctx = _inputs('SMALL', 2, True, dev)
+    # 16-bit volumes need (Y*X) % 8 == 0 for the fused kernels (SMALL is 50x50 and would take the reference-shaped path)
+    cfg, ovt, cam, _, depth, ctx = _inputs('SMALL' if out_dtype == torch.float32 else 'REF', 2, True, dev)
     rz = torch.tensor([[0., -1., 0.], [1., 0., 0.], [0., 0., 1.]], device=dev)
     cam_a = [t.to(dev) for t in cam]
     cam_b = [t.clone() for t in cam_a]
@@ -567,6 +568,7 @@ def test_cached_tile_tables_survive_mixed_routes(dev, out_dtype):
     ref_a, ref_b = plain(cam_a, c, d), plain(cam_b, c, d)
     assert not torch.equal(ref_a, ref_b)
     vt = _vt(cfg, dev, accelerate=True, out_dtype=out_dtype)
+    assert vt._fused_supported(cfg.channels)
     with torch.no_grad():
         assert torch.equal(vt(cam_a, c, d), ref_a)                       # build 1, table of lift_splat's tile
     # training-style call of another rig, same B: its per-call index set and table must not leak into the cache

@@ -161,12 +161,82 @@ k_pipelined(const float* __restrict__ value, const float* __restrict__ ref, cons
     for (int c = 0; c < DH; ++c) out[(long long)unit * DH + c] = col[c];
 }
 
+
+// Round 3: the product kernel did NOT follow this program's prediction (0.709 -> 0.691 ms): its vector L1 is saturated in
+// ACCESSES (TCP_TOTAL_CACHE_ACCESSES / CU ~ cycles), not in latency.  Hypothesis: with lane = (query, head) the 8 head lanes
+// of a query sample 8 different tokens (per-head offsets), so an instruction touches ~43 lines; with lanes = an 8x8 PATCH of
+// BEV queries of ONE head, neighbouring queries with (nearly) the same per-head offset touch a handful.  `coherent` makes the
+// offsets a function of (head, sample) + small per-query noise, as a trained / freshly initialised layer produces them.
+__global__ void __launch_bounds__(256)
+k_patch(const float* __restrict__ value, const float* __restrict__ ref, const sample_in* __restrict__ smp, int units, int LP,
+        int H, int W, int side, float* __restrict__ out) {
+    // workgroup w: patch (w / 2), heads (w % 2) * 4 + wave; lane -> query (px, py) inside the 8x8 patch
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int patches_x = side / 8;
+    const int patch = blockIdx.x >> 1, m = (blockIdx.x & 1) * 4 + wave;
+    const int qx = (patch % patches_x) * 8 + (lane & 7), qy = (patch / patches_x) * 8 + (lane >> 3);
+    const int q = qy * side + qx;
+    if (qy >= side || q * M + m >= units) return;
+    const int unit = q * M + m;
+    const int row_stride = M * HS, chunk_stride = M * 4;
+    const unsigned lane_off = (unsigned)(m * 4 * 4);
+    const float rx = ref[2 * q], ry = ref[2 * q + 1];
+    float col[DH];
+#pragma unroll
+    for (int c = 0; c < DH; ++c) col[c] = 0.f;
+    const sample_in* sp = smp + unit;
+    for (int i = 0; i < LP; ++i) {
+        const sample_in s0 = sp[(long long)i * units];
+        const float h_im = (ry + s0.oy / H) * H - 0.5f, w_im = (rx + s0.ox / W) * W - 0.5f;
+        if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
+            const fbbev_bilinear s = fbbev_bilinear_setup(h_im, w_im, H, W, row_stride);
+            fbbev_unit_sample<DH, 4>(value, lane_off, s, chunk_stride, s0.attn, col);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < DH; ++c) out[(long long)unit * DH + c] = col[c];
+}
+
+// hybrid that needs no layout change of the per-query tensors: a wave = 4 heads x (4x4 patch of queries); a workgroup = the 8
+// heads of an 8x4 patch (wave w: heads 4 (w & 1) .. + 3 of the left / right 4x4 half w >> 1)
+__global__ void __launch_bounds__(256)
+k_patch44(const float* __restrict__ value, const float* __restrict__ ref, const sample_in* __restrict__ smp, int units, int LP,
+          int H, int W, int side, float* __restrict__ out) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int patches_x = side / 8;
+    const int patch = blockIdx.x;
+    const int m = 4 * (wave & 1) + (lane & 3), qi = lane >> 2;
+    const int qx = (patch % patches_x) * 8 + (wave >> 1) * 4 + (qi & 3), qy = (patch / patches_x) * 4 + (qi >> 2);
+    const int q = qy * side + qx;
+    if (qy >= side || q * M + m >= units) return;
+    const int unit = q * M + m;
+    const int row_stride = M * HS, chunk_stride = M * 4;
+    const unsigned lane_off = (unsigned)(m * 4 * 4);
+    const float rx = ref[2 * q], ry = ref[2 * q + 1];
+    float col[DH];
+#pragma unroll
+    for (int c = 0; c < DH; ++c) col[c] = 0.f;
+    const sample_in* sp = smp + unit;
+    for (int i = 0; i < LP; ++i) {
+        const sample_in s0 = sp[(long long)i * units];
+        const float h_im = (ry + s0.oy / H) * H - 0.5f, w_im = (rx + s0.ox / W) * W - 0.5f;
+        if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
+            const fbbev_bilinear s = fbbev_bilinear_setup(h_im, w_im, H, W, row_stride);
+            fbbev_unit_sample<DH, 4>(value, lane_off, s, chunk_stride, s0.attn, col);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < DH; ++c) out[(long long)unit * DH + c] = col[c];
+}
+
 static float frand(unsigned& s) { s = s * 1664525u + 1013904223u; return (float)(s >> 8) / 16777216.0f; }
 
 int main(int argc, char** argv) {
     const int Q = argc > 1 ? atoi(argv[1]) : 160000, LP = argc > 2 ? atoi(argv[2]) : 32;
     const size_t lds = (size_t)(argc > 3 ? atoi(argv[3]) : 0) * 1024;
-    const int H = 116, W = 200, S = H * W, units = Q * M;
+    const int coherent = argc > 4 ? atoi(argv[4]) : 0;        // 1: offsets = f(head, sample) + small per-query noise
+    const int LH = argc > 5 ? atoi(argv[5]) : 116, LW = argc > 6 ? atoi(argv[6]) : 200;
+    const int H = LH, W = LW, S = H * W, units = Q * M;
     std::vector<float> value((size_t)S * M * HS), ref((size_t)Q * 2);
     std::vector<sample_in> smp((size_t)units * LP);
     unsigned seed = 12345u;
@@ -176,7 +246,17 @@ int main(int argc, char** argv) {
     // occupancy: 3.96 vs 4.00 ms, profiles/r02_exp_unit_sampler_pipeline.jsonl)
     const int side = (int)ceil(sqrt((double)Q));
     for (int q = 0; q < Q; ++q) { ref[2 * q] = ((q % side) + 0.5f) / side; ref[2 * q + 1] = ((q / side) + 0.5f) / side; }
-    for (auto& s : smp) { s.ox = (frand(seed) - 0.5f) * 12.f; s.oy = (frand(seed) - 0.5f) * 12.f; s.attn = frand(seed) / LP; }
+    if (!coherent) {
+        for (auto& s : smp) { s.ox = (frand(seed) - 0.5f) * 12.f; s.oy = (frand(seed) - 0.5f) * 12.f; s.attn = frand(seed) / LP; }
+    } else {      // [sample][unit]: the ring pattern of DA_MSDeformableAttention.init_weights (direction per head, radius per point) + noise
+        for (int i = 0; i < LP; ++i)
+            for (int u = 0; u < units; ++u) {
+                const int m = u % M;
+                const float th = 6.2831853f * m / M, r = 1.f + (i % 8);
+                sample_in& s = smp[(size_t)i * units + u];
+                s.ox = cosf(th) * r + (frand(seed) - 0.5f) * 0.3f; s.oy = sinf(th) * r + (frand(seed) - 0.5f) * 0.3f; s.attn = frand(seed) / LP;
+            }
+    }
     float *dv, *dr, *o0, *o1; sample_in* ds;
     hipMalloc(&dv, value.size() * 4); hipMalloc(&dr, ref.size() * 4); hipMalloc(&ds, smp.size() * sizeof(sample_in));
     hipMalloc(&o0, (size_t)units * DH * 4); hipMalloc(&o1, (size_t)units * DH * 4);
@@ -188,16 +268,21 @@ int main(int argc, char** argv) {
         hipFuncSetAttribute((const void*)k_baseline8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipFuncSetAttribute((const void*)k_baseline, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipFuncSetAttribute((const void*)k_pipelined, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)k_patch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     std::vector<float> hbase((size_t)units * DH);
-    float ms[3] = {0.f, 0.f, 0.f};
-    for (int which = 0; which < 3; ++which) {
+    float ms[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    const int p44blocks = ((side + 7) / 8) * ((side + 3) / 4);
+    const int pblocks = ((side + 7) / 8) * ((side + 7) / 8) * 2;
+    for (int which = 0; which < 5; ++which) {
         for (int it = 0; it < 23; ++it) {
             if (it == 3) hipEventRecord(e0);
             if (which == 0) hipLaunchKernelGGL(k_baseline, dim3(blocks), dim3(256), lds, 0, dv, dr, ds, units, LP, H, W, o0);
             else if (which == 1) hipLaunchKernelGGL(k_pipelined, dim3(blocks), dim3(256), lds, 0, dv, dr, ds, units, LP, H, W, o1);
-            else hipLaunchKernelGGL(k_baseline8, dim3(blocks), dim3(256), lds, 0, dv, dr, ds, units, LP, H, W, o0);     // o0 again: the baseline's result was copied out above
+            else if (which == 2) hipLaunchKernelGGL(k_baseline8, dim3(blocks), dim3(256), lds, 0, dv, dr, ds, units, LP, H, W, o0);     // o0 again: the baseline's result was copied out above
+            else if (which == 3) hipLaunchKernelGGL(k_patch, dim3(pblocks), dim3(256), lds, 0, dv, dr, ds, units, LP, H, W, side, o1);
+            else hipLaunchKernelGGL(k_patch44, dim3(p44blocks), dim3(256), lds, 0, dv, dr, ds, units, LP, H, W, side, o1);
         }
         hipEventRecord(e1); hipEventSynchronize(e1);
         hipEventElapsedTime(&ms[which], e0, e1);
@@ -206,7 +291,7 @@ int main(int argc, char** argv) {
     }
     std::vector<float> h8((size_t)units * DH), h1((size_t)units * DH);
     hipMemcpy(h8.data(), o0, h8.size() * 4, hipMemcpyDeviceToHost);
-    hipMemcpy(h1.data(), o1, h1.size() * 4, hipMemcpyDeviceToHost);
+    hipMemcpy(h1.data(), o1, h1.size() * 4, hipMemcpyDeviceToHost);        // the patch kernel's result (last writer of o1; side % 8 == 0 covers every unit)
     const std::vector<float>& h0 = hbase;
     const bool same = memcmp(h0.data(), h1.data(), h0.size() * 4) == 0;
     double maxd = 0.0, maxv = 0.0;
@@ -216,7 +301,7 @@ int main(int argc, char** argv) {
         if (fabs(h0[i]) > maxv) maxv = fabs(h0[i]);
     }
     printf("{\"experiment\": \"unit sampler: one sample at a time vs issue/consume pipeline\", \"Q\": %d, \"LP\": %d, \"level\": [%d, %d], \"lds_kb\": %d, "
-           "\"baseline_ms\": %.4f, \"pipelined_ms\": %.4f, \"baseline_8byte_third_chunk_ms\": %.4f, \"bits_equal\": %s, \"max_abs_diff\": %.3g, \"max_abs\": %.3g, \"hip_error\": %d}\n",
-           Q, LP, H, W, (int)(lds / 1024), ms[0], ms[1], ms[2], same ? "true" : "false", maxd, maxv, (int)hipGetLastError());
+           "\"baseline_ms\": %.4f, \"pipelined_ms\": %.4f, \"baseline_8byte_third_chunk_ms\": %.4f, \"patch_8x8_one_head_per_wave_ms\": %.4f, \"patch_4x4_four_heads_per_wave_ms\": %.4f, \"coherent_offsets\": %d, \"bits_equal\": %s, \"max_abs_diff\": %.3g, \"max_abs\": %.3g, \"hip_error\": %d}\n",
+           Q, LP, H, W, (int)(lds / 1024), ms[0], ms[1], ms[2], ms[3], ms[4], coherent, same ? "true" : "false", maxd, maxv, (int)hipGetLastError());
     return maxd <= 1e-5 * maxv ? 0 : 1;        // fp contraction may group the FMAs differently in the two kernels
 }
