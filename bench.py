@@ -63,7 +63,9 @@ def parse():
     ap.add_argument('--bucket-mb', type=int, default=64, help='train mode: gradient bucket size')
     ap.add_argument('--conv', choices=['vendor', 'mfma'], default='mfma',
                     help='train mode: 3-D convolution stacks on the vendor library or on fbbev_conv3d_* (fwd + dgrad + wgrad)')
-    ap.add_argument('--conv-dtype', choices=['f32', 'bf16'], default='f32', help='train mode: compute dtype of the 2-D stacks')
+    ap.add_argument('--conv-dtype', choices=['f32', 'bf16'], default='bf16',
+                    help='train mode: compute dtype of the 2-D stacks (image backbone / neck / depth net), channels-last on the vendor '
+                         'library; default bf16 with fp32 master weights, gradients and every other block fp32 (stated in `dtype`)')
     return ap.parse_args()
 
 
@@ -534,12 +536,26 @@ def run_train(args):
     shard.fence(dev)
     elapsed = shard.max_over_ranks(time.perf_counter() - t0, dev)
     ar_tail_ms = sum(a.elapsed_time(b) for a, b in ar_ev) / max(1, args.steps)
+    if rank == 0 and os.environ.get('FBBEV_TRAIN_PROFILE'):
+        # diagnostics only (after the timed region): per-kernel GPU time of two STEADY-STATE steps -- a rocprofv3 run of
+        # the whole command is dominated by the vendor library's solver search in the first step
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize(dev)
+        evs = sorted(prof.key_averages(), key=lambda e: -e.device_time_total)
+        tot = sum(e.device_time_total for e in evs)
+        json.dump({'steps': 2, 'gpu_ms_per_step': tot / 2e3, 'ms_per_step_wall': 1e3 * elapsed / args.steps,
+                   'kernels': [{'name': e.key[:120], 'calls_per_step': e.count / 2, 'ms_per_step': e.device_time_total / 2e3,
+                                'pct': 100.0 * e.device_time_total / tot} for e in evs[:60]]},
+                  open(os.environ['FBBEV_TRAIN_PROFILE'], 'w'), indent=1)
     if rank == 0:
         print(json.dumps({
             'metric': 'multi-cam samples/sec (FB-OCC R50 training step: forward_train + backward + gradient all-reduce + AdamW)',
             'value': shard.whole_job_rate(B, args.steps, elapsed, world), 'unit': 'samples/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if args.conv_dtype == 'f32' else 'bf16 2-D conv stacks, f32 elsewhere',
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if args.conv_dtype == 'f32' else 'bf16 (2-D convolution stacks: image encoder + depth net, fp32 master weights; view transformation, 3-D stacks, losses, gradients: f32)',
             'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[3]: FB-OCC R50 (fbocc-r50-cbgs_depth_16f_16x4_20e) training step, 6x256x704 in, '
                                    'D=80, 100x100x8 grid, 16-frame history, occupancy + depth losses',

@@ -65,6 +65,7 @@ SIGNATURES = {
     'fbbev_msda_fwd': (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_void_p, c_void_p]),
     'fbbev_point_sampling': (c_int, [c_void_p] * 9 + [c_int] * 5 + [c_float, c_float] + [c_void_p] * 4),
     'fbbev_da_cross_attn_fwd': (c_int, [c_void_p] * 9 + [c_int] * 10 + [c_float, c_float, c_int, c_int, c_void_p, c_void_p]),
+    'fbbev_da_cross_attn_fwd_zt_fuses_softmax': (c_int, [c_int] * 11),
     'fbbev_da_cross_attn_fwd_zt': (c_int, [c_void_p] * 9 + [c_int] * 10 + [c_float, c_float, c_int, c_int, c_void_p, c_void_p]),
     'fbbev_da_cross_attn_fwd_e': (c_int, [c_void_p] * 9 + [c_int] * 10 + [c_float, c_float, c_int, c_int, c_int] + [c_void_p, c_void_p]),
     'fbbev_da_cross_attn_bwd': (c_int, [c_void_p] * 10 + [c_int] * 10 + [c_float, c_float, c_int, c_int] + [c_void_p] * 5),
@@ -262,6 +263,7 @@ DEFAULT_TILE_VOXELS = 128
 
 POOL_CHANNELS_LAST = 0x100000
 POOL_OUT_BF16, POOL_OUT_F16 = 0x800000, 0x1000000
+POOL_SPLIT_LONG = 0x2000000   # tolerance mode: long intervals summed by the whole workgroup (<= 1e-4, not bit-exact)
 
 
 def pool_tile_index(interval_rank, interval_starts, counts, n_intervals_max, B, Z, Y, X, tile_ws,
@@ -293,7 +295,7 @@ def pool_zmean(depth, feat, ranks_depth, ranks_feat, interval_rank, interval_sta
             _dev(ranks_feat, I32, 'ranks_feat'), _dev(interval_rank, I32, 'interval_rank'),
             _dev(interval_starts, I32, 'interval_starts'), _dev(interval_lengths, I32, 'interval_lengths'),
             B, C, Z, Y, X, _dev(out_mean, F32, 'out_mean'), c_void_p(tile_ws.data_ptr()),
-            tile_ws.numel() * tile_ws.element_size(), int(tile_voxels), int(flags) & ~(POOL_OUT_BF16 | POOL_OUT_F16),
+            tile_ws.numel() * tile_ws.element_size(), int(tile_voxels), int(flags) & ~(POOL_OUT_BF16 | POOL_OUT_F16 | POOL_SPLIT_LONG),
             _stream()), 'fbbev_pool_zmean')
     return out_mean
 
@@ -455,6 +457,15 @@ def da_cross_attn_fwd(value, spatial_shapes, level_start_index, pred_depth, ref_
             _dev(ref_cam, F32, 'ref_cam'), _dev(mask, torch.uint8, 'mask'), _dev(qdepth, F32, 'qdepth'),
             _dev(offsets, F32, 'offsets'), _dev(attn, F32, 'attn'), B, Ncam, S, M, Dh, L, Q, P, Za, DC,
             float(d0), float(dstep), head_minor, HS, _dev(slots, F32, 'slots'), _stream()), name)
+
+
+DA_ATTN_LOGITS = 0x10          # head_minor flag of the zero-token entry: `attn` holds raw logits, softmax fused in the kernel
+
+
+def da_fuses_softmax(B, Ncam, S, M, Dh, L, Q, P, Za, head_minor, HS):
+    """True when fbbev_da_cross_attn_fwd_zt takes the pipelined kernel for this shape, i.e. may be handed raw
+    attention logits (head_minor | DA_ATTN_LOGITS)."""
+    return bool(lib().fbbev_da_cross_attn_fwd_zt_fuses_softmax(B, Ncam, S, M, Dh, L, Q, P, Za, int(head_minor), HS))
 
 
 def da_value_buffer(tokens, row_floats, device):

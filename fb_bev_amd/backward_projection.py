@@ -273,7 +273,7 @@ class DA_MSDeformableAttention(nn.Module):
         aw = aw.softmax(-1).view(bs, nq, self.num_heads, self.num_levels, self.num_points)
         return so, aw
 
-    def project_head_minor(self, query):
+    def project_head_minor(self, query, softmax=True):
         """`project` with the sampling_offsets rows permuted so that the offsets come out head-minor, (B,Q,L,P,M,2):
         the layout the fused kernel reads with contiguous lanes (same dot product per element, only the row order of
         the weight matrix changes).  The attention weights keep (B,Q,M,L,P): their softmax runs over the last dim."""
@@ -289,7 +289,8 @@ class DA_MSDeformableAttention(nn.Module):
         aw = self.attention_weights(query).view(bs, nq, M, L * P)
         if self.disable_deformable:
             so, aw = so * 0, aw * 0
-        return so, aw.softmax(-1).view(bs, nq, M, L, P)
+        # softmax=False: raw logits for a kernel that applies the softmax itself (fbbev_da_cross_attn_fwd_zt)
+        return so, (aw.softmax(-1) if softmax else aw).view(bs, nq, M, L, P)
 
     def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_padding_mask=None,
                 reference_points=None, spatial_shapes=None, level_start_index=None, bev_query_depth=None,
@@ -440,9 +441,14 @@ class DA_SpatialCrossAttention(nn.Module):
                     self._vpad = _pad_interleave_rows(wt, bs, M, Dh, HS)
                 self._vpad_key = key
             w, bb = self._vpad
-        so, aw = da.project_head_minor(query)
         DC, H0, W0 = pred_img_depth.shape[2:]
-        if not grad_mode and x.dtype == torch.float32 and x.is_cuda:
+        zt = not grad_mode and x.dtype == torch.float32 and x.is_cuda
+        hm = 1 | (4 if interleave else 0)
+        # the pipelined kernel applies the attention softmax while it stages the weights: hand it the raw logits
+        fuse_sm = zt and not da.disable_deformable and _capi.da_fuses_softmax(
+            B, ncam, S, M, Dh, da.num_levels, Q, da.num_points, reference_points_cam.shape[3], hm, HS)
+        so, aw = da.project_head_minor(query, softmax=not fuse_sm)
+        if zt:
             # inference: the projection writes into a buffer with one extra all-zero token behind the rows -- the pipelined
             # sampler (fbbev_da_cross_attn_fwd_zt: two samples in flight per lane) reads it for padded corners and
             # out-of-image samples instead of branching around their loads
@@ -455,7 +461,7 @@ class DA_SpatialCrossAttention(nn.Module):
                                     reference_points_cam.contiguous().float(), mask.contiguous(),
                                     bev_query_depth.squeeze(-1).contiguous().float(), so.contiguous().float(),
                                     aw.contiguous().float(), self.dbound[0], self.dbound[2], slots,
-                                    head_minor=1 | (4 if interleave else 0), head_dim=Dh, zero_token=True)
+                                    head_minor=hm | (_capi.DA_ATTN_LOGITS if fuse_sm else 0), head_dim=Dh, zero_token=True)
             return slots
         v = F.linear(x, w, bb).view(B * ncam, S, M, HS)           # a token's M*HS floats are (HS/4, M, 4)
         return FusedDACrossAttention.apply(

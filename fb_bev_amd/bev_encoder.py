@@ -53,6 +53,38 @@ def upsample_trilinear(x, size):
     return out.to(x.dtype)
 
 
+def batch_norm_channels_last_3d(bn_forward, x):
+    """Run a batch-norm forward (a callable taking a 2-D (M, C) tensor) on a 5-D tensor that lives in channels_last_3d
+    memory -- what MConv3d / fbbev_conv3d_* produce -- WITHOUT the NCDHW round trip: the (B, D, H, W, C) rows are a
+    contiguous (M, C) matrix, batch norm over dim 0 of it is the same per-channel statistics, and the result goes back as the
+    same permuted view.  The vendor batch norm takes NCDHW only: every conv -> norm -> conv hop of the 3-D stacks cost two
+    full-tensor copies forward and two backward (49 ms of the 303 ms training step, 221 launches,
+    profiles/r03_train_step_kernels_bf16.json)."""
+    B, C, D, H, W = x.shape
+    rows = x.permute(0, 2, 3, 4, 1).reshape(-1, C)                 # a view: no copy
+    with torch.backends.cudnn.flags(enabled=False):                # ATen's channels-last kernels (the vendor path wants NC(D)HW)
+        y = bn_forward(rows)
+    return y.view(B, D, H, W, C).permute(0, 4, 1, 2, 3)
+
+
+def _is_channels_last_3d(x):
+    return x.dim() == 5 and x.is_cuda and not x.is_contiguous() and x.permute(0, 2, 3, 4, 1).is_contiguous()
+
+
+class BatchNorm3d(nn.BatchNorm3d):
+    """nn.BatchNorm3d (same parameters, buffers, state-dict names and arithmetic) that keeps a channels_last_3d activation in
+    its layout instead of converting it to NCDHW and back."""
+
+    def _check_input_dim(self, x):
+        if x.dim() not in (2, 5):
+            raise ValueError(f'expected 5D input (got {x.dim()}D input)')
+
+    def forward(self, x):
+        if _is_channels_last_3d(x):
+            return batch_norm_channels_last_3d(super().forward, x)
+        return super().forward(x)
+
+
 def build_norm(norm_cfg, channels, dims=3):
     """mmcv.cnn.build_norm_layer (external) for the types the FB-OCC configs use -> (state-dict abbreviation, layer).
     SyncBN is built as plain BatchNorm (identical parameters / state names / eval arithmetic) and MARKED
@@ -62,13 +94,13 @@ def build_norm(norm_cfg, channels, dims=3):
     typ = cfg.pop('type')
     requires_grad = cfg.pop('requires_grad', True)
     if typ in ('BN', 'BN1d', 'BN2d', 'BN3d', 'SyncBN'):
-        cls = {1: nn.BatchNorm1d, 2: nn.BatchNorm2d, 3: nn.BatchNorm3d}[dims]
+        cls = {1: nn.BatchNorm1d, 2: nn.BatchNorm2d, 3: BatchNorm3d}[dims]
         if typ == 'BN1d':
             cls = nn.BatchNorm1d
         elif typ == 'BN2d':
             cls = nn.BatchNorm2d
         elif typ == 'BN3d':
-            cls = nn.BatchNorm3d
+            cls = BatchNorm3d
         cfg.setdefault('eps', 1e-5)
         layer, abbr = cls(channels, **cfg), 'bn'
         layer._fbbev_sync_bn = (typ == 'SyncBN')

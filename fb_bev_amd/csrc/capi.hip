@@ -489,15 +489,18 @@ struct dense2_args {
     const float *depth, *feat; const int32_t *rd, *rf, *irank, *starts, *lengths; const int* tile_meta;
     const float* addend = nullptr;   // optional (B,C,Y,X) broadcast-over-z add in the dense2 epilogue
     float* out;
+    bool split = false;              // FBBEV_POOL_SPLIT_LONG: long intervals summed by the whole workgroup (tolerance mode)
 };
 
-template <int TV, int CPL, int ST, int NT, int OT, bool T16 = false>
+#define FBBEV_POOL_SPLIT_LEN 32      // points above which an interval is split over the lane groups in tolerance mode
+template <int TV, int CPL, int ST, int NT, int OT, bool T16 = false, int SPLIT = 0>
 static int launch_dense2(const dense2_args& a) {
     size_t lds = a.lds;
+    if (SPLIT > 0) lds += ((size_t)TV + 4) * sizeof(int) + (size_t)NT * CPL * sizeof(float);   // long-interval list + partial sums
     if (T16)                                   // 16-bit tile [CC][TV + 8] instead of fp32 [CC][TV + 4]
         lds = (size_t)(a.C / a.csplit) * (TV + 8) * 2 + ((size_t)3 * TV + 2 * FBBEV_NP_STAGE) * sizeof(int);
     if (lds > 64 * 1024) {  // > 64 KiB of dynamic LDS must be opted into (160 KiB per CU on gfx950)
-        int e = fbbev_rt_allow_dyn_lds((const void*)k_pool_fwd_dense2<TV, CPL, ST, NT, OT, T16>, lds);
+        int e = fbbev_rt_allow_dyn_lds((const void*)k_pool_fwd_dense2<TV, CPL, ST, NT, OT, T16, 0, SPLIT>, lds);
         if (e) return e;
     }
     long long grid = a.n_blocks;
@@ -505,13 +508,19 @@ static int launch_dense2(const dense2_args& a) {
         const long long g = 8ll << (a.swizzle - 1);
         grid = (a.n_blocks + g - 1) / g * g;
     }
-    FBBEV_LAUNCH((k_pool_fwd_dense2<TV, CPL, ST, NT, OT, T16>), grid, NT, lds, a.stream, a.C, a.Z, a.yx, a.tpp,
+    FBBEV_LAUNCH((k_pool_fwd_dense2<TV, CPL, ST, NT, OT, T16, 0, SPLIT>), grid, NT, lds, a.stream, a.C, a.Z, a.yx, a.tpp,
                  a.csplit, (int)a.n_blocks, a.swizzle, a.stride_b, a.stride_c, a.depth, a.feat, a.rd, a.rf, a.irank, a.starts, a.lengths, a.tile_meta, a.addend, a.out);
     return fbbev_rt_last_error();
 }
 
 template <int TV, int CPL, int ST>
 static int launch_dense2_nt(int nt, int ot, const dense2_args& a) {
+    if (a.split) {                // tolerance mode: fp32 volume, default store policy, 256 threads, 64- / 128-voxel tiles
+        if constexpr (ST == 4 && (TV == 64 || TV == 128)) {
+            if (ot == 0 && nt == 256) return launch_dense2<TV, CPL, 4, 256, 0, false, FBBEV_POOL_SPLIT_LEN>(a);
+        }
+        return FBBEV_E_UNSUPPORTED;
+    }
     if constexpr (ST == 4) {      // 16-bit output storage is built for the default store policy only
         if (ot != 0 && !a.addend && nt == 256)        // no epilogue add: the LDS tile itself is 16-bit (see the kernel)
             return ot == 1 ? launch_dense2<TV, CPL, 4, 256, 1, true>(a) : launch_dense2<TV, CPL, 4, 256, 2, true>(a);
@@ -653,6 +662,7 @@ static int pool_dense_fwd_impl(const float* depth, const float* feat,
     a.depth = depth; a.feat = feat; a.rd = ranks_depth; a.rf = ranks_feat; a.irank = interval_rank;
     a.starts = interval_starts; a.lengths = interval_lengths; a.tile_meta = static_cast<const int*>(tile_ws);
     a.out = out; a.stride_b = out_stride_b; a.stride_c = out_stride_c; a.addend = addend;
+    a.split = (flags & FBBEV_POOL_SPLIT_LONG) != 0;
     if (TV == 64) return cpl8 ? launch_dense2_st<64, 8>(st, nt, ot, a) : launch_dense2_st<64, 4>(st, nt, ot, a);
     if (TV == 128) return cpl8 ? launch_dense2_st<128, 8>(st, nt, ot, a) : launch_dense2_st<128, 4>(st, nt, ot, a);
     if (TV == 256) return cpl8 ? launch_dense2_st<256, 8>(st, nt, ot, a) : launch_dense2_st<256, 4>(st, nt, ot, a);
@@ -967,6 +977,23 @@ extern "C" int fbbev_da_cross_attn_fwd(const float* value, const int64_t* spatia
     return 0;
 }
 
+static bool da_pipe_disabled() {
+    static const bool off = [] { const char* e = getenv("FBBEV_DA_PIPE"); return e && atoi(e) == 0; }();   // A/B timing knob, read once
+    return off;
+}
+static bool da_pipe_shape_ok(int B, int Ncam, int S, int M, int Dh, int L, int Q, int P, int Za, int head_minor, int HS) {
+    const long long tokens = (long long)B * Ncam * S;
+    const int LP = L * P;
+    return (long long)B * Q * M > 0 && (head_minor & 7) == (1 | 4) &&                // head-minor offsets, (B,Q,M,L,P) attn, chunk-major rows
+           Za == 4 && P % 4 == 0 && (Dh == 8 || Dh == 10) && HS == (Dh + 3) / 4 * 4 && LP % 4 == 0 && LP <= 36 &&
+           (tokens + 1) * M * HS * 4 < (1ll << 32);                                  // 32-bit byte offsets incl. the zero token
+}
+extern "C" int fbbev_da_cross_attn_fwd_zt_fuses_softmax(int B, int Ncam, int S, int M, int Dh, int L, int Q, int P, int Za,
+                                                        int head_minor, int head_stride) {
+    if (B <= 0 || Ncam <= 0 || S <= 0 || M <= 0 || Dh <= 0 || L <= 0 || Q <= 0 || P <= 0 || Za <= 0) return 0;
+    return (!da_pipe_disabled() && da_pipe_shape_ok(B, Ncam, S, M, Dh, L, Q, P, Za, head_minor, head_stride == 0 ? Dh : head_stride)) ? 1 : 0;
+}
+
 // Pipelined forward (k_da_cross_attn_fwd_pipe): the value buffer holds ONE MORE token than B*Ncam*S -- token index
 // B*Ncam*S, M*HS floats, all +0.0f -- which padded corners and out-of-image samples read instead of branching around their
 // loads.  Shapes outside the pipelined kernel's preconditions run fbbev_da_cross_attn_fwd on the same buffer.
@@ -982,17 +1009,15 @@ extern "C" int fbbev_da_cross_attn_fwd_zt(const float* value, const int64_t* spa
     const int LP = L * P;
     const long long units = (long long)B * Q * M;
     const long long tokens = (long long)B * Ncam * S;
-    const bool pipe = value && offsets && attn && slots && units > 0 && dstep != 0.f &&
-                      (head_minor & 7) == (1 | 4) &&                                  // head-minor offsets, (B,Q,M,L,P) attn, chunk-major rows
-                      Za == 4 && P % 4 == 0 && (Dh == 8 || Dh == 10) && HS == (Dh + 3) / 4 * 4 &&
-                      LP % 4 == 0 && LP <= 36 && aligned16(attn) && aligned16(value) &&
-                      (((uintptr_t)offsets | (uintptr_t)slots) & 7) == 0 &&
-                      (tokens + 1) * M * HS * 4 < (1ll << 32);                        // 32-bit byte offsets incl. the zero token
-    static const bool pipe_off = [] { const char* e = getenv("FBBEV_DA_PIPE"); return e && atoi(e) == 0; }();   // A/B timing knob
-    if (!pipe || pipe_off)
+    const bool pipe = value && offsets && attn && slots && dstep != 0.f &&
+                      da_pipe_shape_ok(B, Ncam, S, M, Dh, L, Q, P, Za, head_minor, HS) && aligned16(attn) && aligned16(value) &&
+                      (((uintptr_t)offsets | (uintptr_t)slots) & 7) == 0;
+    if (!pipe || da_pipe_disabled()) {
+        if (head_minor & FBBEV_DA_ATTN_LOGITS) return FBBEV_E_UNSUPPORTED;     // only the pipelined kernel fuses the softmax
         return fbbev_da_cross_attn_fwd(value, spatial_shapes, level_start_index, pred_depth, ref_cam, mask, qdepth, offsets,
                                        attn, B, Ncam, S, M, Dh, L, Q, P, Za, DC, d0, dstep, head_minor, head_stride, slots,
                                        stream_);
+    }
     if (!spatial_shapes || !level_start_index || !pred_depth || !ref_cam || !mask || !qdepth) return FBBEV_E_BADARG;
     long long ub = ((units + 255) / 256 + 7) / 8 * 8;             // XCD-contiguous order: a multiple of 8 workgroups
     if (ub > 65536) ub = 65536;
@@ -1001,7 +1026,7 @@ extern "C" int fbbev_da_cross_attn_fwd_zt(const float* value, const int64_t* spa
 #define FBBEV_DA_PIPE(DH_, WPS_)                                                                                     \
     FBBEV_LAUNCH((k_da_cross_attn_fwd_pipe<DH_, 4, WPS_>), ub, 256, lds, (fbbev_rt_stream)stream_, units, value,         \
                  spatial_shapes, level_start_index, pred_depth, ref_cam, mask, qdepth, offsets, attn, B, Ncam, S, M, L, \
-                 Q, P, DC, d0, dstep, HS, zero_bytes, slots)
+                 Q, P, DC, d0, dstep, HS, zero_bytes, (head_minor & FBBEV_DA_ATTN_LOGITS) ? 1 : 0, slots)
     static const int wps = [] { const char* e = getenv("FBBEV_DA_PIPE_WPS"); return e ? atoi(e) : 3; }();   // tuning knob, read once
     if (Dh == 10) { if (wps == 2) FBBEV_DA_PIPE(10, 2); else FBBEV_DA_PIPE(10, 3); }
     else { if (wps == 2) FBBEV_DA_PIPE(8, 2); else FBBEV_DA_PIPE(8, 3); }

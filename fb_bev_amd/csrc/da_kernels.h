@@ -340,7 +340,8 @@ k_da_cross_attn_fwd_pipe(long long n_units, const float* __restrict__ value, con
                          const float* __restrict__ ref_cam, const unsigned char* __restrict__ mask,
                          const float* __restrict__ qdepth, const float* __restrict__ offsets,
                          const float* __restrict__ attn, int B, int Ncam, int S, int M, int L, int Q, int P,
-                         int DC, float d0, float dstep, int HS, unsigned zero_token_bytes, float* __restrict__ slots) {
+                         int DC, float d0, float dstep, int HS, unsigned zero_token_bytes, int attn_logits,
+                         float* __restrict__ slots) {
     static_assert(DH % 2 == 0 && (DH % 4 == 0 || DH % 4 == 2), "channel pairs");
     static_assert(ZA % 2 == 0 && ZA <= FBBEV_DA_MAX_ZA, "two register slots alternate over the anchors");
     const char* vb = reinterpret_cast<const char*>(value);
@@ -366,7 +367,18 @@ k_da_cross_attn_fwd_pipe(long long n_units, const float* __restrict__ value, con
             __syncthreads();
         }
         if (unit >= n_units) continue;
-        const float* my_attn = staged + threadIdx.x * LDW;
+        float* my_attn = staged + threadIdx.x * LDW;
+        if (attn_logits) {
+            // `attn` holds the raw output of the attention_weights Linear: the softmax over the unit's L*P weights
+            // (spatial_cross_attention_depth.py:546-551) runs here on the staged row -- one separate softmax launch and one
+            // write + read of the (B,Q,M,L*P) tensor less; exp(x - max) / sum like ATen's kernel (v_exp_f32 based)
+            float mx = my_attn[0];
+            for (int i = 1; i < LP; ++i) mx = fmaxf(mx, my_attn[i]);
+            float sum = 0.f;
+            for (int i = 0; i < LP; ++i) { const float e = __expf(my_attn[i] - mx); my_attn[i] = e; sum += e; }
+            const float inv_sum = 1.f / sum;
+            for (int i = 0; i < LP; ++i) my_attn[i] *= inv_sum;
+        }
         const int m = (int)(unit % M);
         const long long bq = unit / M;
         const int q = (int)(bq % Q);

@@ -346,7 +346,14 @@ __device__ __forceinline__ unsigned int fbbev_pack2(float lo, float hi) {
 // but the depth / feature gathers and their fmaf chains (tile metadata, interval / point-index staging, LDS tile, barriers,
 // stores).  0 = the product kernel; the diagnostic instantiations write zeros and are reachable only through
 // fbbev_diag_pool_store_floor.
-template <int TV, int CPL, int ST, int NT, int OT, bool T16 = false, int DIAG = 0>
+// SPLIT > 0 (opt-in tolerance mode, FBBEV_POOL_SPLIT_LONG): an interval longer than SPLIT points is summed by ALL lane
+// groups of the workgroup -- group g takes the g-th contiguous chunk of its points (chunk = ceil(len / groups) rounded up to
+// the gather batch), in order, and the partial sums are added in group order: a fixed-shape, run-to-run deterministic
+// reduction that differs from the reference's serial chain (bev_pool_cuda.cu:33-38) only by fp32 reassociation (<= 1e-4 of
+// the sum for the path's sizes: the bar north_star states; tested) -- the default (SPLIT = 0) stays the serial chain, bit
+// for bit.  What it buys: one lane group no longer serialises a 236-point (shipped grid) or 3 894-point (BASELINE
+// configs[0]) interval while the other groups of the tile wait at the barrier.
+template <int TV, int CPL, int ST, int NT, int OT, bool T16 = false, int DIAG = 0, int SPLIT = 0>
 __global__ void __launch_bounds__(NT)
 k_pool_fwd_dense2(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_blocks, int swizzle,
                   long long out_stride_b, long long out_stride_c,
@@ -356,6 +363,7 @@ k_pool_fwd_dense2(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_b
                   const int* __restrict__ lengths, const int* __restrict__ tile_meta,
                   const float* __restrict__ addend, float* __restrict__ out) {
     static_assert(!T16 || OT != 0, "a 16-bit tile only for 16-bit output");
+    static_assert(SPLIT == 0 || (!T16 && DIAG == 0), "tolerance mode: fp32 LDS tile");
     constexpr int LD = T16 ? TV + 8 : TV + 4;  // tile row pitch in ELEMENTS (16-byte aligned rows either way)
     constexpr int Q4 = TV / 4;
     const int CC = C / csplit;                 // channels handled by this block
@@ -367,6 +375,8 @@ k_pool_fwd_dense2(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_b
     int* ivx = iln + TV;                       // [TV] voxel offset inside the tile
     int* prd = ivx + TV;                       // [NP_STAGE]
     int* prf = prd + FBBEV_NP_STAGE;           // [NP_STAGE]
+    int* lng = prf + FBBEV_NP_STAGE;           // SPLIT: [1 + TV] count + list of the tile's long intervals
+    float* part = reinterpret_cast<float*>(lng + TV + 4);   // SPLIT: [groups][CC] partial sums of the interval being split
     const int tid = threadIdx.x;
     int bid = blockIdx.x;
     if (swizzle) {
@@ -429,10 +439,18 @@ k_pool_fwd_dense2(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_b
     const int ni = i1 - i0;
     const int np = p1 - p0;
     const int rank0 = plane * YX + v0;
+    if constexpr (SPLIT > 0) {
+        if (tid == 0) lng[0] = 0;
+        __syncthreads();
+    }
     for (int j = tid; j < ni; j += NT) {
         ist[j] = starts[i0 + j] - p0;
-        iln[j] = lengths[i0 + j];
+        const int len = lengths[i0 + j];
+        iln[j] = len;
         ivx[j] = interval_rank[i0 + j] - rank0;
+        if constexpr (SPLIT > 0) {
+            if (len > SPLIT) lng[1 + atomicAdd(&lng[0], 1)] = j;    // list order is arbitrary: every entry is summed on its own
+        }
     }
     const int nps = np < FBBEV_NP_STAGE ? np : FBBEV_NP_STAGE;
     for (int j = tid; j < nps; j += NT) { prd[j] = rd[p0 + j]; prf[j] = rf[p0 + j]; }
@@ -452,6 +470,9 @@ k_pool_fwd_dense2(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_b
             for (int i = g; i < ni; i += gpb) {
                 const int v = ivx[i];
                 float acc[CPL];
+                if constexpr (SPLIT > 0) {
+                    if (iln[i] > SPLIT) continue;               // summed by the whole workgroup below
+                }
                 if constexpr (DIAG == 2) {
 #pragma unroll
                     for (int j = 0; j < CPL; ++j) acc[j] = 0.f;
@@ -469,6 +490,31 @@ k_pool_fwd_dense2(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_b
                         for (int j = 0; j < CPL; ++j) dst[j * LD] = acc[j];
                     }
                 }
+            }
+        }
+        if constexpr (SPLIT > 0) {
+            const int nl = lng[0];                                   // written before the first barrier: block-uniform
+            const float* fbase = feat + c0 + slot * CPL;
+            for (int q = 0; q < nl; ++q) {
+                const int i = lng[1 + q];
+                const int len = iln[i], s0 = ist[i], v = ivx[i];
+                const int chunk = (((len + gpb - 1) / gpb) + 3) & ~3;   // whole gather batches per group
+                if (g < gpb) {
+                    const int sub = g * chunk;
+                    int sl = len - sub;
+                    sl = sl < 0 ? 0 : (sl > chunk ? chunk : sl);
+                    float acc[CPL];
+                    fbbev_interval_sum_staged<CPL, 4>(C, s0 + sub, sl, p0, prd, prf, depth, fbase, rd, rf, acc);
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) part[g * CC + slot * CPL + j] = acc[j];
+                }
+                __syncthreads();
+                if (tid < CC) {                                      // partial sums in group order: a fixed shape
+                    float sum = part[tid];
+                    for (int gg = 1; gg < gpb; ++gg) sum += part[gg * CC + tid];
+                    if (v >= 0 && v < nv) tile[tid * LD + v] = sum;
+                }
+                __syncthreads();
             }
         }
     }

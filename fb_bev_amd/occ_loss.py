@@ -117,13 +117,32 @@ def lovasz_softmax(probas, labels, ignore=None):
     errors_sorted, perm = torch.sort(errors, dim=1, descending=True)
     fg_sorted = torch.gather(fg, 1, perm)
     gts = fg_sorted.sum(1, keepdim=True)
-    intersection = gts - fg_sorted.cumsum(1)
-    union = gts + (1 - fg_sorted).cumsum(1)
+    # ONE prefix sum instead of the reference's two (lovasz_softmax.py:27-28): cumsum(1 - fg) == (1..N) - cumsum(fg), and
+    # both are sums of 0/1 below 2^24 -- exact integers in fp32, so the values are bit-identical -- evaluated blockwise:
+    # ATen's innermost-dim scan runs a few million-element rows at ~0.4 GB/s-per-row (6.5 ms per call at 200x200x16, B=4)
+    csum = _cumsum_rows(fg_sorted)
+    intersection = gts - csum
+    union = gts + (torch.arange(1, fg_sorted.shape[1] + 1, device=p.device, dtype=csum.dtype)[None] - csum)
     jaccard = 1.0 - intersection / union
     grad = torch.cat([jaccard[:, :1], jaccard[:, 1:] - jaccard[:, :-1]], 1)
     losses = (errors_sorted * grad).sum(1)
     present = gts[:, 0] > 0
     return torch.where(present, losses, torch.zeros_like(losses)).sum() / present.float().sum().clamp(min=1)
+
+
+def _cumsum_rows(x, block=4096):
+    """cumsum along dim 1 of a (rows, N) tensor with long rows as a two-level scan: prefix sums inside blocks of `block`
+    elements (many short rows: the fast case of the scan kernel) + the exclusive prefix of the block totals.  Same additions
+    in another association: exact (hence identical) for integer-valued data below 2^24, fp32 rounding otherwise."""
+    R, N = x.shape
+    if N <= 4 * block:
+        return x.cumsum(1)
+    nb = (N + block - 1) // block
+    pad = nb * block - N
+    xb = (torch.nn.functional.pad(x, (0, pad)) if pad else x).reshape(R, nb, block)
+    inner = xb.cumsum(2)
+    carry = inner[:, :, -1].cumsum(1) - inner[:, :, -1]                  # exclusive prefix of the block totals
+    return (inner + carry[:, :, None]).reshape(R, nb * block)[:, :N]
 
 
 class CustomFocalLoss(torch.nn.Module):

@@ -298,6 +298,9 @@ class SyncBatchNorm(torch.nn.modules.batchnorm._BatchNorm):
     def forward(self, x):
         sync = self.sync and self.training and dist.is_initialized() and dist.get_world_size(self.process_group) > 1
         if not sync:
+            from .bev_encoder import _is_channels_last_3d, batch_norm_channels_last_3d
+            if _is_channels_last_3d(x):                    # keep the convolution kernels' layout (no NCDHW round trip)
+                return batch_norm_channels_last_3d(super().forward, x)
             return super().forward(x)
         out, mean, var, n = _SyncBNFunction.apply(x, self.weight, self.bias, self.eps, self.process_group)
         if self.track_running_stats:

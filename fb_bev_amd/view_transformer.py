@@ -134,7 +134,7 @@ class LSSViewTransformerFunction3D(nn.Module):
 
     def __init__(self, grid_config, input_size, downsample=16, accelerate=False, uniform=False,
                  with_cp=False, extra_relu=False, fused=True, tile_voxels=None, pool_flags=None,
-                 out_dtype=torch.float32):
+                 out_dtype=torch.float32, pool_tolerance=False):
         super().__init__()
         self.uniform = uniform
         self.with_cp = with_cp
@@ -154,6 +154,10 @@ class LSSViewTransformerFunction3D(nn.Module):
         # storage type of the fused path's BEV volume (fp32 sums, rounded once at the store); BASELINE configs[1]
         # names bf16, configs[4] fp16; the reference itself is fp32 (bev_pool.py:16-22)
         self.out_dtype = out_dtype
+        # opt-in tolerance mode of the fused fp32 pooling (FBBEV_POOL_SPLIT_LONG): intervals of more than 32 points are summed by
+        # all lane groups of their workgroup -- deterministic, equal to the reference's serial chain to <= 1e-4 (north_star's
+        # bar for pooled features) instead of bit for bit.  Default False: bit-exact.
+        self.pool_tolerance = bool(pool_tolerance)
         self._tile_voxels_arg, self._pool_flags_arg = tile_voxels, pool_flags
         self._tiling = {}                   # number of cameras -> (tile_voxels, pool_flags)
         self.n_cams = None                  # set by the first call (the camera tensors carry it)
@@ -204,7 +208,10 @@ class LSSViewTransformerFunction3D(nn.Module):
             fl = self._pool_flags_arg if self._pool_flags_arg is not None else (
                 _capi.pool_flags(csplit=1) if dense else (_capi.pool_flags(csplit=1, swz_log2=5) if half else _capi.DEFAULT_POOL_FLAGS))
             self._tiling[n_cams] = (tv, fl, tv32)
-        return self._tiling[n_cams][:2]
+        tv, fl = self._tiling[n_cams][:2]
+        if self.pool_tolerance and self.out_dtype == torch.float32 and tv in (64, 128):
+            fl |= _capi.POOL_SPLIT_LONG
+        return tv, fl
 
     @property
     def tile_voxels(self):

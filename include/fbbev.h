@@ -39,6 +39,12 @@ typedef void* fbbev_stream_t; /* hipStream_t */
 #define FBBEV_POOL_OUT_BF16 0x800000  /* `out` holds bfloat16: fp32 sums rounded once (nearest-even) at the store */
 #define FBBEV_POOL_OUT_F16 0x1000000  /* `out` holds IEEE half; both: (B,C,Z,Y,X) layout only, (Y*X) % 8 == 0 */
 #define FBBEV_POOL_SWZ_CHUNK_SHIFT 12 /* bits 12-16: log2(tiles per chunk) for the swizzle, 0 = default */
+#define FBBEV_POOL_SPLIT_LONG 0x2000000 /* opt-in TOLERANCE mode of fbbev_bev_pool_v2_dense_fwd[_add]: an interval of more than 32
+                                         * points is summed by all lane groups of its workgroup (contiguous chunks in order,
+                                         * partial sums added in group order: deterministic) -- equal to the reference's serial
+                                         * chain (bev_pool_cuda.cu:33-38) up to fp32 reassociation (<= 1e-4, north_star's bar),
+                                         * not bit for bit.  fp32 volume, sc1-nt stores, 256 threads, tile_voxels 64 / 128; the
+                                         * default (flag clear) stays bit-exact */
 
 int fbbev_version(void);
 
@@ -328,7 +334,14 @@ int fbbev_da_cross_attn_fwd_e(const void* value, const int64_t* spatial_shapes,
  * skipping their loads; the result is the same sum (a padded corner contributes w * 0, spatial_cross_attention_depth.py:
  * 593-595 via the zero padding of the op).  Taken for chunk-major fp32 rows (head_minor = 1 | 4), Za = 4, P % 4 == 0,
  * Dh in {8, 10} with head_stride = Dh rounded up to 4, L*P <= 36; every other shape runs fbbev_da_cross_attn_fwd on the
- * same buffer.  `offset / size` is evaluated as offset * (1 / size) (one ulp of a sub-pixel offset). */
+ * same buffer.  `offset / size` is evaluated as offset * (1 / size) (one ulp of a sub-pixel offset).
+ * head_minor | FBBEV_DA_ATTN_LOGITS: `attn` holds the RAW output of the attention_weights Linear and the kernel applies
+ * the softmax over each unit's L*P weights while it stages them (no separate softmax launch, no extra pass over the
+ * tensor); FBBEV_E_UNSUPPORTED when the shape does not take the pipelined kernel -- query fbbev_da_cross_attn_fwd_zt_fuses_softmax
+ * first. */
+#define FBBEV_DA_ATTN_LOGITS 0x10
+int fbbev_da_cross_attn_fwd_zt_fuses_softmax(int B, int Ncam, int S, int M, int Dh, int L, int Q, int P, int Za,
+                                             int head_minor, int head_stride);
 int fbbev_da_cross_attn_fwd_zt(const float* value, const int64_t* spatial_shapes,
                                const int64_t* level_start_index, const float* pred_depth,
                                const float* ref_cam, const uint8_t* mask, const float* qdepth,

@@ -153,6 +153,7 @@ inline float __fsub_rn(float a, float b) { volatile float r = a - b; return r; }
 inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
 inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
 inline float __fdiv_rn(float a, float b) { volatile float r = a / b; return r; }
+inline float __expf(float x) { return expf(x); }   // device fast exp (v_exp_f32 based): the emulator uses libm's
 
 typedef void* fbbev_rt_stream;
 #define FBBEV_LAUNCH(kern, grid, block, lds_bytes, stream, ...) \

@@ -175,6 +175,48 @@ def test_pool_dense_partial_tiles_small_config():
         assert torch.equal(out, exp)
 
 
+def test_pool_dense_tolerance_mode_splits_long_intervals_emulated():
+    """FBBEV_POOL_SPLIT_LONG (0x2000000): intervals of more than 32 points are summed by all lane groups of the workgroup
+    (contiguous chunks, partial sums added in group order).  Hand-made index tensors with interval lengths 1 .. 3 900 (the
+    BASELINE configs[0] maximum is 3 894; more points per tile than the 512 staged indices): the result is within 1e-4
+    relative of the serial chain (the default kernel == the C oracle, bit for bit), identical run to run, and identical
+    to the default wherever no interval is long."""
+    g = torch.Generator().manual_seed(5)
+    B, Z, Y, X, C = 1, 2, 8, 32, 80                       # YX = 256: two 128-voxel tiles (four 64-voxel tiles) per plane
+    N, D, H, W = 2, 6, 8, 16
+    lens = {3: 1, 10: 33, 11: 32, 40: 700, 41: 5, 130: 3900, 200: 64, 255: 2, 256 + 7: 129, 256 + 200: 31}
+    depth = (torch.randn(B, N, D, H, W, generator=g) * 3).softmax(2).contiguous()
+    feat = torch.randn(B, N, H, W, C, generator=g)
+    ir = torch.tensor(sorted(lens), dtype=torch.int32)
+    ln = torch.tensor([lens[int(v)] for v in ir], dtype=torch.int32)
+    st = (torch.cumsum(ln, 0) - ln).int()
+    P = int(ln.sum())
+    rd = torch.randint(0, depth.numel(), (P,), generator=g, dtype=torch.int32)
+    rf = torch.randint(0, B * N * H * W, (P,), generator=g, dtype=torch.int32)
+    rb = torch.repeat_interleave(ir, ln.long()).int()
+    counts = torch.tensor([P, ir.numel()], dtype=torch.int32)
+    exp = O.bev_pool_v2(depth, feat, rd, rf, rb, (B, Z, Y, X, C), st, ln, use_fma=True)
+    for tv, flags in ((128, 0x24424), (64, 0x20414), (64, 0x20404)):        # bench default (csplit 2, 8 ch/lane); dense-grid default; 4 ch/lane
+        code, base = E.pool_dense(depth, feat, rd, rf, ir, st, ln, counts, ir.numel(), B, C, Z, Y, X, tv, flags)
+        assert code == 0 and torch.equal(base, exp)
+        code, tol = E.pool_dense(depth, feat, rd, rf, ir, st, ln, counts, ir.numel(), B, C, Z, Y, X, tv, flags | 0x2000000)
+        assert code == 0 and not torch.isnan(tol).any()
+        code, again = E.pool_dense(depth, feat, rd, rf, ir, st, ln, counts, ir.numel(), B, C, Z, Y, X, tv, flags | 0x2000000)
+        assert torch.equal(tol, again)                                      # deterministic
+        scale = exp.abs().max().item()
+        assert (tol - exp).abs().max().item() <= 1e-4 * scale               # north_star's bar for pooled features
+        assert not torch.equal(tol, exp)                                    # the long intervals really took another order
+        vox = exp.permute(0, 2, 3, 4, 1).reshape(-1, C)
+        tvx = tol.permute(0, 2, 3, 4, 1).reshape(-1, C)
+        short = [int(v) for v in ir if lens[int(v)] <= 32]
+        assert all(torch.equal(vox[v], tvx[v]) for v in short)              # short intervals: the same serial chain
+        empty = torch.ones(vox.shape[0], dtype=torch.bool); empty[ir.long()] = False
+        assert not tvx[empty].any()
+    # outside the mode's instantiations (16-bit volume): refused, not silently ignored
+    code, _ = E.pool_dense(depth, feat, rd, rf, ir, st, ln, counts, ir.numel(), B, C, Z, Y, X, 128, 0x24424 | 0x2000000 | 0x800000)
+    assert code == -4 or code != 0
+
+
 def test_lidar_coor_emulated():
     for name in ('TINY', 'SMALL'):
         cfg = S.CONFIGS[name]
@@ -280,6 +322,12 @@ def test_pipelined_da_cross_attention_emulated():
         poisoned = E.da_cross_attn_fwd(*a, head_minor=5, head_dim=Dh, zero_token=3.0)
         assert not torch.equal(poisoned, pipe), seed                                    # the token IS read ...
         assert torch.isfinite(poisoned).all()
+        # FBBEV_DA_ATTN_LOGITS (0x10): raw attention logits in, softmax over each unit's L*P weights fused into the LDS staging
+        lg = list(a)
+        lg[8] = (args[8].flatten(-2).log() + torch.randn(args[8].shape[:3] + (1,), generator=torch.Generator().manual_seed(seed)) * 3
+                 ).view(args[8].shape).contiguous()                                     # softmax(log p + c) == p
+        fused = E.da_cross_attn_fwd(*lg, head_minor=5 | 0x10, head_dim=Dh, zero_token=0.0)
+        assert torch.allclose(fused, pipe, atol=2e-6, rtol=2e-5), (seed, (fused - pipe).abs().max())
     # ... and outside the preconditions (here Za = 2; head-major rows) the entry runs the unit kernel: identical bits
     args, exp = _da_case(7, B=1, Q=23, E=40, M=4, Za=2)
     Dh = args[0].shape[-1]

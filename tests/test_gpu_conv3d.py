@@ -286,3 +286,35 @@ def test_conv3d_tiled_bf16_kernel_vs_torch_on_rounded_operands(dev, B, dims, Cin
     _capi.conv3d_k3s1_tiled_bf16(M.to_ndhwc(x), M.weight_fragments_bf16(w), b.contiguous(), out, Cout, relu=True)
     assert not torch.isnan(out).any()
     assert torch.allclose(M.to_ncdhw(out).double(), exp, atol=1e-4, rtol=1e-4), (M.to_ncdhw(out).double() - exp).abs().max()
+
+
+def test_channels_last_batch_norm_equals_vendor_batch_norm(dev):
+    """bev_encoder.BatchNorm3d / shard.SyncBatchNorm (per-rank mode) on a channels_last_3d activation -- the layout the
+    fbbev_conv3d_* route produces -- normalise the (M, C) rows in place of the NCDHW round trip: same output, input /
+    parameter gradients and running statistics as nn.BatchNorm3d on the contiguous tensor (train and eval mode), and the
+    result stays channels_last_3d."""
+    import torch.nn as nn
+    from fb_bev_amd import shard
+    from fb_bev_amd.bev_encoder import BatchNorm3d
+    g = torch.Generator().manual_seed(0)
+    x = (torch.randn(2, 32, 4, 10, 12, generator=g) * 2 + 1).to(dev)
+    w = torch.randn(x.shape, generator=g).to(dev)
+    for make in (lambda: BatchNorm3d(32), lambda: shard.SyncBatchNorm(32)):
+        ref, bn = nn.BatchNorm3d(32).to(dev), make().to(dev)
+        with torch.no_grad():
+            for m_ in (ref, bn):
+                m_.weight.copy_(torch.linspace(0.5, 1.5, 32)); m_.bias.copy_(torch.linspace(-1, 1, 32))
+        for mode in (True, False):
+            ref.train(mode); bn.train(mode)
+            a = x.clone().requires_grad_()
+            b = x.clone().contiguous(memory_format=torch.channels_last_3d).requires_grad_()
+            ya, yb = ref(a), bn(b)
+            assert not yb.is_contiguous() and yb.permute(0, 2, 3, 4, 1).is_contiguous()
+            assert torch.allclose(ya, yb, atol=2e-5, rtol=1e-5)
+            (ya * w).sum().backward(); (yb * w).sum().backward()
+            assert torch.allclose(a.grad, b.grad, atol=2e-5, rtol=1e-4)
+            assert torch.allclose(ref.weight.grad, bn.weight.grad, atol=1e-3, rtol=1e-4)
+            assert torch.allclose(ref.bias.grad, bn.bias.grad, atol=1e-3, rtol=1e-4)
+            assert torch.allclose(ref.running_mean, bn.running_mean, atol=1e-6) and torch.allclose(ref.running_var, bn.running_var, atol=1e-5)
+            for m_ in (ref, bn):
+                m_.weight.grad = m_.bias.grad = None

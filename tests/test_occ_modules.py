@@ -133,3 +133,36 @@ def test_resnet50_structure_matches_published_checkpoint_layout():
         c4, c5 = net(torch.randn(1, 3, 64, 96))
     assert c4.shape == (1, 1024, 4, 6) and c5.shape == (1, 2048, 2, 3)
     assert net.layer2[0].conv2.stride == (2, 2) and net.layer2[0].conv1.stride == (1, 1)     # 'pytorch' style
+
+
+def test_lovasz_blockwise_prefix_sum_is_exact():
+    """occ_loss._cumsum_rows (two-level scan of the Lovasz prefix sums) and the single-prefix-sum form of the union:
+    identical values to ATen's cumsum on 0/1 data, and the loss of a long input equals the two-cumsum formulation of
+    lovasz_softmax.py:20-33 bit for bit."""
+    import torch
+    from fb_bev_amd import occ_loss as OL
+    g = torch.Generator().manual_seed(0)
+    x = (torch.rand(5, 100003, generator=g) < 0.3).float()
+    assert torch.equal(OL._cumsum_rows(x), x.cumsum(1))
+    assert torch.equal(OL._cumsum_rows(x[:, :100]), x[:, :100].cumsum(1))
+    C, N = 4, 40000
+    probas = torch.rand(1, C, N, 1, 1, generator=g).softmax(1)
+    labels = torch.randint(0, C + 1, (1, N, 1, 1), generator=g)
+    labels[labels == C] = 255
+    got = OL.lovasz_softmax(probas, labels, ignore=255)
+    # reference formulation, per class (lovasz_softmax.py:20-33,139-160 with classes='present')
+    p = probas.reshape(C, N); lab = labels.reshape(-1); valid = lab != 255
+    losses = []
+    for c in range(C):
+        fg = (lab[valid] == c).float()
+        if fg.sum() == 0:
+            continue
+        err = (fg - p[c][valid]).abs()
+        es, perm = torch.sort(err, 0, descending=True)
+        fs = fg[perm]
+        gts = fs.sum()
+        jac = 1.0 - (gts - fs.cumsum(0)) / (gts + (1 - fs).cumsum(0))
+        jac[1:] = jac[1:] - jac[:-1].clone()
+        losses.append(torch.dot(es, jac))
+    exp = torch.stack(losses).mean()
+    assert abs(float(got) - float(exp)) <= 2e-6 * abs(float(exp))
