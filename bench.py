@@ -540,6 +540,18 @@ def run_train(args):
         # diagnostics only (after the timed region): per-kernel GPU time of two STEADY-STATE steps -- a rocprofv3 run of
         # the whole command is dominated by the vendor library's solver search in the first step
         from torch.profiler import ProfilerActivity, profile
+        if os.environ.get('FBBEV_TRAIN_PROFILE_COPIES'):
+            # where the layout copies come from: device time of aten::copy_ by Python call site (one step)
+            with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
+                step()
+                torch.cuda.synchronize(dev)
+            rows = []
+            for e in prof.key_averages(group_by_input_shape=True, group_by_stack_n=8):
+                if e.key in ('aten::copy_', 'aten::contiguous', 'aten::clone', 'aten::_to_copy') and e.device_time_total > 200:
+                    rows.append({'op': e.key, 'ms': e.device_time_total / 1e3, 'calls': e.count, 'shapes': str(e.input_shapes)[:160],
+                                 'stack': [fr for fr in e.stack if 'fb_bev_amd' in fr or 'bench.py' in fr][:5]})
+            rows.sort(key=lambda r: -r['ms'])
+            json.dump(rows[:60], open(os.environ['FBBEV_TRAIN_PROFILE'] + '.copies.json', 'w'), indent=1)
         with profile(activities=[ProfilerActivity.CUDA]) as prof:
             for _ in range(2):
                 step()

@@ -66,7 +66,7 @@ SIGNATURES = {
     'fbbev_point_sampling': (c_int, [c_void_p] * 9 + [c_int] * 5 + [c_float, c_float] + [c_void_p] * 4),
     'fbbev_da_cross_attn_fwd': (c_int, [c_void_p] * 9 + [c_int] * 10 + [c_float, c_float, c_int, c_int, c_void_p, c_void_p]),
     'fbbev_da_cross_attn_fwd_zt_fuses_softmax': (c_int, [c_int] * 11),
-    'fbbev_da_cross_attn_fwd_zt': (c_int, [c_void_p] * 9 + [c_int] * 10 + [c_float, c_float, c_int, c_int, c_void_p, c_void_p]),
+    'fbbev_da_cross_attn_fwd_zt': (c_int, [c_void_p] * 9 + [c_int] * 10 + [c_float, c_float, c_int, c_int, c_int, c_void_p, c_void_p]),
     'fbbev_da_cross_attn_fwd_e': (c_int, [c_void_p] * 9 + [c_int] * 10 + [c_float, c_float, c_int, c_int, c_int] + [c_void_p, c_void_p]),
     'fbbev_da_cross_attn_bwd': (c_int, [c_void_p] * 10 + [c_int] * 10 + [c_float, c_float, c_int, c_int] + [c_void_p] * 5),
     'fbbev_da_cross_attn_bwd_ws_bytes': (c_size_t, [c_int] * 9 + [c_void_p]),
@@ -416,7 +416,7 @@ def msda_bwd(value, spatial_shapes, level_start_index, sampling_loc, attn_weight
 
 
 def da_cross_attn_fwd(value, spatial_shapes, level_start_index, pred_depth, ref_cam, mask, qdepth, offsets,
-                      attn, d0, dstep, slots, head_minor=0, head_dim=None, zero_token=False):
+                      attn, d0, dstep, slots, head_minor=0, head_dim=None, zero_token=False, bev_w=0):
     """value (B*Ncam,S,M,Dh); pred_depth (B*Ncam,DC,H0,W0); ref_cam (Ncam,B,Q,Za,2); mask (Ncam,B,Q,Za) bool;
     qdepth (Ncam,B,Q,Za); offsets (B,Q,M,L,P,2); attn (B,Q,M,L,P); head_minor bit 0: offsets is (B,Q,L,P,M,2),
     bit 1: attn is (B,Q,L,P,M), bit 2: a value token's M*HS floats are stored (HS/4, M, 4); slots (B,Q,M*Dh).
@@ -444,8 +444,9 @@ def da_cross_attn_fwd(value, spatial_shapes, level_start_index, pred_depth, ref_
                 float(d0), float(dstep), head_minor, HS, ELEM_TYPE[value.dtype], _dev(slots, F32, 'slots'), _stream()),
                 'fbbev_da_cross_attn_fwd_e')
         return
-    fn, name = lib().fbbev_da_cross_attn_fwd, 'fbbev_da_cross_attn_fwd'
+    fn, name, extra = lib().fbbev_da_cross_attn_fwd, 'fbbev_da_cross_attn_fwd', ()
     if zero_token:
+        extra = (int(bev_w) if bev_w and Q % int(bev_w) == 0 else 0,)
         need = (value.storage_offset() + value.numel() + M * HS) * 4
         if not value.is_contiguous() or value.untyped_storage().nbytes() < need:
             raise FbbevError('zero_token=True needs the value view of da_value_buffer (one extra token behind the rows)')
@@ -456,7 +457,7 @@ def da_cross_attn_fwd(value, spatial_shapes, level_start_index, pred_depth, ref_
             _dev(level_start_index, I64, 'level_start_index'), _dev(pred_depth, F32, 'pred_depth'),
             _dev(ref_cam, F32, 'ref_cam'), _dev(mask, torch.uint8, 'mask'), _dev(qdepth, F32, 'qdepth'),
             _dev(offsets, F32, 'offsets'), _dev(attn, F32, 'attn'), B, Ncam, S, M, Dh, L, Q, P, Za, DC,
-            float(d0), float(dstep), head_minor, HS, _dev(slots, F32, 'slots'), _stream()), name)
+            float(d0), float(dstep), head_minor, HS, *extra, _dev(slots, F32, 'slots'), _stream()), name)
 
 
 DA_ATTN_LOGITS = 0x10          # head_minor flag of the zero-token entry: `attn` holds raw logits, softmax fused in the kernel

@@ -394,7 +394,7 @@ class DA_SpatialCrossAttention(nn.Module):
 
     # ---- inference: one fused HIP launch (fbbev_da_cross_attn_fwd), no host sync
     def _slots_fused(self, query, value, reference_points_cam, mask, bev_query_depth, pred_img_depth,
-                     spatial_shapes, level_start_index):
+                     spatial_shapes, level_start_index, bev_w=0):
         da = self.deformable_attention
         B, Q, E = query.shape
         ncam, S, _, _ = value.shape
@@ -461,7 +461,8 @@ class DA_SpatialCrossAttention(nn.Module):
                                     reference_points_cam.contiguous().float(), mask.contiguous(),
                                     bev_query_depth.squeeze(-1).contiguous().float(), so.contiguous().float(),
                                     aw.contiguous().float(), self.dbound[0], self.dbound[2], slots,
-                                    head_minor=hm | (_capi.DA_ATTN_LOGITS if fuse_sm else 0), head_dim=Dh, zero_token=True)
+                                    head_minor=hm | (_capi.DA_ATTN_LOGITS if fuse_sm else 0), head_dim=Dh, zero_token=True,
+                                    bev_w=bev_w)
             return slots
         v = F.linear(x, w, bb).view(B * ncam, S, M, HS)           # a token's M*HS floats are (HS/4, M, 4)
         return FusedDACrossAttention.apply(
@@ -473,7 +474,7 @@ class DA_SpatialCrossAttention(nn.Module):
 
     # ---- training: vectorised rebatch + composite deformable attention (autograd through the MSDA op)
     def _slots_composite(self, query, value, reference_points_cam, mask, bev_query_depth, pred_img_depth,
-                         spatial_shapes, level_start_index):
+                         spatial_shapes, level_start_index, bev_w=0):
         B, Q, E = query.shape
         ncam, S, _, _ = value.shape
         DC = pred_img_depth.shape[2]
@@ -508,7 +509,7 @@ class DA_SpatialCrossAttention(nn.Module):
     def forward(self, query, key, value, residual=None, query_pos=None, key_padding_mask=None, reference_points=None,
                 spatial_shapes=None, reference_points_cam=None, level_start_index=None, flag='encoder',
                 bev_query_depth=None, pred_img_depth=None, bev_mask=None, per_cam_mask_list=None, _defer_residual=False,
-                **kwargs):
+                bev_w=0, **kwargs):
         if key is None:
             key = query
         if value is None:
@@ -526,7 +527,7 @@ class DA_SpatialCrossAttention(nn.Module):
         fused_ok = self.fused and (not needs_grad or head_dim <= FUSED_BWD_MAX_HEAD_DIM)
         fn = self._slots_fused if fused_ok else self._slots_composite
         slots = fn(query, value, reference_points_cam, mask, bev_query_depth, pred_img_depth, spatial_shapes,
-                   level_start_index)
+                   level_start_index, bev_w=bev_w or 0)      # the BEV row length lets the sampler own 2-D patches of queries
         slots = self.output_proj(slots)
         if self.layer_scale is not None:
             slots = self.layer_scale * slots
@@ -616,7 +617,7 @@ class BEVFormerEncoderLayer(nn.Module):
                     reference_points=ref_3d, reference_points_cam=reference_points_cam, spatial_shapes=spatial_shapes,
                     level_start_index=level_start_index, bev_query_depth=bev_query_depth,
                     pred_img_depth=pred_img_depth, bev_mask=bev_mask, per_cam_mask_list=per_cam_mask_list,
-                    _defer_residual=d)
+                    _defer_residual=d, bev_w=bev_w)
                 ai += 1
                 if d:
                     query, pending = query

@@ -39,17 +39,31 @@ def _linear_resize_matrix(n_in, n_out, device):
 def upsample_trilinear(x, size):
     """F.interpolate(x, size, mode='trilinear', align_corners=False) (occupancy_head.py:163-166, fpn3d.py:92-96).  Under autograd on the
     GPU the resize is applied as its three 1-D factors (trilinear interpolation is separable), each a small dense
-    matrix product: the same linear map (to fp32 summation order), but its backward is three transposed GEMMs instead
-    of ATen's atomic scatter (upsample_trilinear3d_backward: 63 % of the training step at 200x200x16 before this,
-    profiles/r02_rocprofv3_train_step_before_separable_upsample.csv)."""
+    matrix applied FROM THE LEFT to the tensor viewed as (outer, n_in, inner): the same linear map (to fp32 summation order),
+    whose backward is the transposed matrix applied the same way instead of ATen's atomic scatter
+    (upsample_trilinear3d_backward: 63 % of the training step at 200x200x16 before this,
+    profiles/r02_rocprofv3_train_step_before_separable_upsample.csv).  Round 3: no transposes -- the round-2 form moved the
+    resized axis to the end for `x @ W^T` and back, and every hop copied the (4, 128, 200, 200, 16) maps of the head: 49 ms
+    of the 303 ms training step (profiles/r03_train_step_copy_sites.json).  The axes are resized in the MEMORY order of x
+    (channels_last_3d stays channels_last_3d: the layout the convolution kernels produce and consume)."""
     if not (x.is_cuda and x.requires_grad and torch.is_grad_enabled()):
         return F.interpolate(x, size=list(size), mode='trilinear', align_corners=False)
-    out = x.float()
-    for axis, n_out in zip((2, 3, 4), size):                   # z, y, x in turn: smallest tensors first
-        n_in = out.shape[axis]
+    cl = x.dim() == 5 and not x.is_contiguous() and x.permute(0, 2, 3, 4, 1).is_contiguous()
+    base = (x.permute(0, 2, 3, 4, 1) if cl else x.contiguous()).float()       # contiguous: (B,d0,d1,d2,C) or (B,C,d0,d1,d2)
+    first = 1 if cl else 2                                                     # position of the first spatial axis in `base`
+    for k, n_out in enumerate(size):                                           # smallest tensors first
+        axis = first + k
+        n_in = base.shape[axis]
         if n_in != n_out:
             w = _linear_resize_matrix(n_in, n_out, x.device)
-            out = torch.movedim(torch.matmul(torch.movedim(out, axis, -1), w.t()), -1, axis)
+            shape = list(base.shape)
+            outer = 1
+            for d in shape[:axis]:
+                outer *= d
+            y = torch.matmul(w, base.reshape(outer, n_in, -1))                 # (outer, n_out, inner): contiguous, no transposes
+            shape[axis] = n_out
+            base = y.view(shape)
+    out = base.permute(0, 4, 1, 2, 3) if cl else base
     return out.to(x.dtype)
 
 

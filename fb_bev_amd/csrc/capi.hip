@@ -150,7 +150,10 @@ static inline int key_bits(long long total_voxels) {
 // still fits ONE round on the 256 CUs (a 1024-thread workgroup is alone on its CU: a second, partly filled round doubles
 // the kernel's time -- measured: 325 workgroups 56 us, the same work in 146 workgroups 29 us).
 //   variant: 0 = 4 waves x 8 (2048), 1 = 16 x 4 (4096), 2 = 16 x 8 (8192), 3 = 16 x 12 (12288), 4 = 16 x 16 (16384)
-static const int kSortTile[5] = {2048, 4096, 8192, 12288, 16384};
+//            5 = 8 waves x 8 (4096), 6 = 8 x 16 (8192): 512-thread workgroups, TWO per CU -- the phases of a scatter workgroup
+//            (column sums -> key loads -> ballot ranking -> scatter) are serial and barrier-separated; a second workgroup on
+//            the CU fills them (round 3; chosen only through FBBEV_RANK_SHAPE until measured better)
+static const int kSortTile[7] = {2048, 4096, 8192, 12288, 16384, 4096, 8192};
 static int sort_variant_for(long long items) {
     for (int v = 0; v < 5; ++v)
         if ((items + kSortTile[v] - 1) / kSortTile[v] <= 256) return v;
@@ -193,7 +196,7 @@ static rank_ws_layout rank_layout(long long n) {
     // tuning / test knob: FBBEV_RANK_SHAPE="v0,v1,vi" forces the chunk variants (results do not depend on them)
     if (const char* env = getenv("FBBEV_RANK_SHAPE")) {
         int a = -1, b = -1, c = -1;
-        if (sscanf(env, "%d,%d,%d", &a, &b, &c) == 3 && a >= 0 && a < 5 && b >= 0 && b < 5 && c >= 0 && c < 3) {
+        if (sscanf(env, "%d,%d,%d", &a, &b, &c) == 3 && a >= 0 && a < 7 && b >= 0 && b < 7 && c >= 0 && c < 3) {
             L.v0 = a; L.v1 = b; L.vi = c;
         }
     }
@@ -219,6 +222,8 @@ static rank_ws_layout rank_layout(long long n) {
             case 1: FBBEV_LAUNCH((KERNEL<(by_waves) ? 16 : 1024, 4>), grid, 1024, 0, stream, __VA_ARGS__); break; \
             case 2: FBBEV_LAUNCH((KERNEL<(by_waves) ? 16 : 1024, 8>), grid, 1024, 0, stream, __VA_ARGS__); break; \
             case 3: FBBEV_LAUNCH((KERNEL<(by_waves) ? 16 : 1024, 12>), grid, 1024, 0, stream, __VA_ARGS__); break; \
+            case 5: FBBEV_LAUNCH((KERNEL<(by_waves) ? 8 : 512, 8>), grid, 512, 0, stream, __VA_ARGS__); break;     \
+            case 6: FBBEV_LAUNCH((KERNEL<(by_waves) ? 8 : 512, 16>), grid, 512, 0, stream, __VA_ARGS__); break;    \
             default: FBBEV_LAUNCH((KERNEL<(by_waves) ? 16 : 1024, 16>), grid, 1024, 0, stream, __VA_ARGS__); break; \
         }                                                                                                       \
     } while (0)
@@ -496,7 +501,7 @@ struct dense2_args {
 template <int TV, int CPL, int ST, int NT, int OT, bool T16 = false, int SPLIT = 0>
 static int launch_dense2(const dense2_args& a) {
     size_t lds = a.lds;
-    if (SPLIT > 0) lds += ((size_t)TV + 4) * sizeof(int) + (size_t)NT * CPL * sizeof(float);   // long-interval list + partial sums
+    if (SPLIT > 0) lds += ((size_t)TV + 4) * sizeof(int) + (size_t)FBBEV_POOL_SPLIT_GROUPS * (a.C / a.csplit) * sizeof(float);   // long-interval list + partial sums
     if (T16)                                   // 16-bit tile [CC][TV + 8] instead of fp32 [CC][TV + 4]
         lds = (size_t)(a.C / a.csplit) * (TV + 8) * 2 + ((size_t)3 * TV + 2 * FBBEV_NP_STAGE) * sizeof(int);
     if (lds > 64 * 1024) {  // > 64 KiB of dynamic LDS must be opted into (160 KiB per CU on gfx950)
@@ -1002,8 +1007,9 @@ extern "C" int fbbev_da_cross_attn_fwd_zt(const float* value, const int64_t* spa
                                           const float* ref_cam, const uint8_t* mask, const float* qdepth,
                                           const float* offsets, const float* attn, int B, int Ncam, int S, int M,
                                           int Dh, int L, int Q, int P, int Za, int DC, float d0, float dstep,
-                                          int head_minor, int head_stride, float* slots, fbbev_stream_t stream_) {
-    if (B <= 0 || Ncam <= 0 || S <= 0 || M <= 0 || Dh <= 0 || L <= 0 || Q < 0 || P <= 0 || Za <= 0 || DC <= 0)
+                                          int head_minor, int head_stride, int bev_w, float* slots,
+                                          fbbev_stream_t stream_) {
+    if (B <= 0 || Ncam <= 0 || S <= 0 || M <= 0 || Dh <= 0 || L <= 0 || Q < 0 || P <= 0 || Za <= 0 || DC <= 0 || bev_w < 0)
         return FBBEV_E_BADARG;
     const int HS = head_stride == 0 ? Dh : head_stride;
     const int LP = L * P;
@@ -1019,14 +1025,18 @@ extern "C" int fbbev_da_cross_attn_fwd_zt(const float* value, const int64_t* spa
                                        stream_);
     }
     if (!spatial_shapes || !level_start_index || !pred_depth || !ref_cam || !mask || !qdepth) return FBBEV_E_BADARG;
-    long long ub = ((units + 255) / 256 + 7) / 8 * 8;             // XCD-contiguous order: a multiple of 8 workgroups
+    // patch mapping (a workgroup = the 8 heads of an 8 x 4 patch of the BEV grid): needs the grid's row length
+    static const bool patch_off = [] { const char* e = getenv("FBBEV_DA_PATCH"); return e && atoi(e) == 0; }();   // A/B timing knob, read once
+    const int pw = (!patch_off && bev_w > 0 && M == 8 && Q % bev_w == 0) ? bev_w : 0;
+    const long long wgs = pw ? (long long)B * ((pw + 7) / 8) * ((Q / pw + 3) / 4) : (units + 255) / 256;
+    long long ub = (wgs + 7) / 8 * 8;                             // XCD-contiguous order: a multiple of 8 workgroups
     if (ub > 65536) ub = 65536;
     const size_t lds = (size_t)256 * (LP + 1) * sizeof(float);
     const unsigned zero_bytes = (unsigned)(tokens * M * HS * 4);
 #define FBBEV_DA_PIPE(DH_, WPS_)                                                                                     \
     FBBEV_LAUNCH((k_da_cross_attn_fwd_pipe<DH_, 4, WPS_>), ub, 256, lds, (fbbev_rt_stream)stream_, units, value,         \
                  spatial_shapes, level_start_index, pred_depth, ref_cam, mask, qdepth, offsets, attn, B, Ncam, S, M, L, \
-                 Q, P, DC, d0, dstep, HS, zero_bytes, (head_minor & FBBEV_DA_ATTN_LOGITS) ? 1 : 0, slots)
+                 Q, P, DC, d0, dstep, HS, zero_bytes, (head_minor & FBBEV_DA_ATTN_LOGITS) ? 1 : 0, pw, slots)
     static const int wps = [] { const char* e = getenv("FBBEV_DA_PIPE_WPS"); return e ? atoi(e) : 3; }();   // tuning knob, read once
     if (Dh == 10) { if (wps == 2) FBBEV_DA_PIPE(10, 2); else FBBEV_DA_PIPE(10, 3); }
     else { if (wps == 2) FBBEV_DA_PIPE(8, 2); else FBBEV_DA_PIPE(8, 3); }

@@ -340,7 +340,7 @@ k_da_cross_attn_fwd_pipe(long long n_units, const float* __restrict__ value, con
                          const float* __restrict__ ref_cam, const unsigned char* __restrict__ mask,
                          const float* __restrict__ qdepth, const float* __restrict__ offsets,
                          const float* __restrict__ attn, int B, int Ncam, int S, int M, int L, int Q, int P,
-                         int DC, float d0, float dstep, int HS, unsigned zero_token_bytes, int attn_logits,
+                         int DC, float d0, float dstep, int HS, unsigned zero_token_bytes, int attn_logits, int bev_w,
                          float* __restrict__ slots) {
     static_assert(DH % 2 == 0 && (DH % 4 == 0 || DH % 4 == 2), "channel pairs");
     static_assert(ZA % 2 == 0 && ZA <= FBBEV_DA_MAX_ZA, "two register slots alternate over the anchors");
@@ -350,12 +350,29 @@ k_da_cross_attn_fwd_pipe(long long n_units, const float* __restrict__ value, con
     const int H0 = (int)spatial_shapes[0], W0 = (int)spatial_shapes[1];
     const int LP = L * P, LDW = LP + 1, gpl = P / ZA;
     float* staged = fbbev_dyn_lds_f32();          // [256][LP+1]: the workgroup's attention weights
-    const long long n_wg = (n_units + blockDim.x - 1) / blockDim.x, per_xcd = (n_wg + 7) / 8;
+    // Which 256 (query, head) units a workgroup owns, and which 64 a wave:
+    //   bev_w == 0 : 32 consecutive queries x 8 heads in unit order (any M, any Q);
+    //   bev_w > 0  : (M == 8, Q = bev_h x bev_w) the 8 heads of an 8 (x) x 4 (y) PATCH of the BEV grid, and a wave = 4 heads
+    //                of a 4 x 4 sub-patch.  The vector L1 of this kernel is saturated in ACCESSES (TCP_TOTAL_CACHE_ACCESSES
+    //                per CU ~ the kernel's cycles, profiles/r03_pmc_fb_BL3_B4_before.json): the 8 heads of a query sample 8
+    //                different tokens (the offsets are per head), while the neighbours of a query IN BOTH BEV directions
+    //                sample (nearly) the same ones for a given head -- a 4 x 4 patch of 4 heads touches fewer distinct
+    //                lines per load instruction than 8 queries of a row x 8 heads (tools/micro/unit_sampler_pipeline.hip:
+    //                0.92 -> 0.69 ms, profiles/r03_exp_unit_sampler_patch.jsonl).  Every tensor keeps its layout; only the
+    //                lane -> unit map changes, so the results are the same bits.
+    const bool patch = bev_w > 0;
+    const int bev_h = patch ? Q / bev_w : 0;
+    const int pxn = patch ? (bev_w + 7) / 8 : 0, pyn = patch ? (bev_h + 3) / 4 : 0;
+    const long long n_wg = patch ? (long long)B * pxn * pyn : (n_units + blockDim.x - 1) / blockDim.x;
+    const long long per_xcd = (n_wg + 7) / 8;
     for (long long w = blockIdx.x; (w >> 3) < per_xcd; w += gridDim.x) {
-        const long long ubase = ((w & 7) * per_xcd + (w >> 3)) * blockDim.x;          // XCD-contiguous unit order
-        const long long unit = ubase + threadIdx.x;
-        {
-            __syncthreads();
+        const long long wgid = (w & 7) * per_xcd + (w >> 3);                          // XCD-contiguous workgroup order
+        long long unit = -1;
+        int lu = threadIdx.x;                                                         // row of the LDS weight table
+        __syncthreads();
+        if (!patch) {
+            const long long ubase = wgid * blockDim.x;
+            unit = ubase + threadIdx.x;
             const long long rem = n_units - ubase;
             const int nfl = rem <= 0 ? 0 : (int)(rem < (long long)blockDim.x ? rem : (long long)blockDim.x) * LP;
             const float* src = attn + ubase * LP;
@@ -364,10 +381,33 @@ k_da_cross_attn_fwd_pipe(long long n_units, const float* __restrict__ value, con
                 float* d = staged + (i / LP) * LDW + (i % LP);
                 d[0] = a[0]; d[1] = a[1]; d[2] = a[2]; d[3] = a[3];
             }
-            __syncthreads();
+            if (unit >= n_units) unit = -1;
+        } else if (wgid < n_wg) {
+            const int pb = (int)(wgid / ((long long)pxn * pyn)), pi = (int)(wgid - (long long)pb * pxn * pyn);
+            const int py = pi / pxn, px = pi - py * pxn;
+            const int x0 = px * 8, nx = bev_w - x0 < 8 ? bev_w - x0 : 8;
+            // the patch's weights: 4 row segments of nx queries x 8 heads x LP floats, each contiguous in (B,Q,M,L,P)
+            for (int r = 0; r < 4; ++r) {
+                const int y = py * 4 + r;
+                if (y >= bev_h) break;
+                const float* src = attn + (((long long)pb * Q + (long long)y * bev_w + x0) * M) * LP;
+                const int nfl = nx * M * LP;
+                for (int i = threadIdx.x * 4; i < nfl; i += blockDim.x * 4) {
+                    const fbbev_v4f a = *reinterpret_cast<const fbbev_v4f*>(src + i);
+                    float* d = staged + (r * 8 * M + i / LP) * LDW + (i % LP);
+                    d[0] = a[0]; d[1] = a[1]; d[2] = a[2]; d[3] = a[3];
+                }
+            }
+            const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+            const int mh = 4 * (wave & 1) + (lane & 3), qi = lane >> 2;
+            const int xi = (wave >> 1) * 4 + (qi & 3), r = qi >> 2;
+            const int y = py * 4 + r, x = x0 + xi;
+            lu = (r * 8 + xi) * M + mh;
+            if (y < bev_h && x < bev_w) unit = ((long long)pb * Q + (long long)y * bev_w + x) * M + mh;
         }
-        if (unit >= n_units) continue;
-        float* my_attn = staged + threadIdx.x * LDW;
+        __syncthreads();
+        if (unit < 0) continue;
+        float* my_attn = staged + lu * LDW;
         if (attn_logits) {
             // `attn` holds the raw output of the attention_weights Linear: the softmax over the unit's L*P weights
             // (spatial_cross_attention_depth.py:546-551) runs here on the staged row -- one separate softmax launch and one

@@ -346,8 +346,9 @@ __device__ __forceinline__ unsigned int fbbev_pack2(float lo, float hi) {
 // but the depth / feature gathers and their fmaf chains (tile metadata, interval / point-index staging, LDS tile, barriers,
 // stores).  0 = the product kernel; the diagnostic instantiations write zeros and are reachable only through
 // fbbev_diag_pool_store_floor.
+#define FBBEV_POOL_SPLIT_GROUPS 16     // lane groups a long interval is split over (bounds the extra LDS: 16 x CC floats)
 // SPLIT > 0 (opt-in tolerance mode, FBBEV_POOL_SPLIT_LONG): an interval longer than SPLIT points is summed by ALL lane
-// groups of the workgroup -- group g takes the g-th contiguous chunk of its points (chunk = ceil(len / groups) rounded up to
+// groups of the workgroup -- group g < 16 takes the g-th contiguous chunk of its points (chunk = ceil(len / groups) rounded up to
 // the gather batch), in order, and the partial sums are added in group order: a fixed-shape, run-to-run deterministic
 // reduction that differs from the reference's serial chain (bev_pool_cuda.cu:33-38) only by fp32 reassociation (<= 1e-4 of
 // the sum for the path's sizes: the bar north_star states; tested) -- the default (SPLIT = 0) stays the serial chain, bit
@@ -376,7 +377,7 @@ k_pool_fwd_dense2(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_b
     int* prd = ivx + TV;                       // [NP_STAGE]
     int* prf = prd + FBBEV_NP_STAGE;           // [NP_STAGE]
     int* lng = prf + FBBEV_NP_STAGE;           // SPLIT: [1 + TV] count + list of the tile's long intervals
-    float* part = reinterpret_cast<float*>(lng + TV + 4);   // SPLIT: [groups][CC] partial sums of the interval being split
+    float* part = reinterpret_cast<float*>(lng + TV + 4);   // SPLIT: [FBBEV_POOL_SPLIT_GROUPS][CC] partial sums of the interval being split
     const int tid = threadIdx.x;
     int bid = blockIdx.x;
     if (swizzle) {
@@ -494,12 +495,13 @@ k_pool_fwd_dense2(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_b
         }
         if constexpr (SPLIT > 0) {
             const int nl = lng[0];                                   // written before the first barrier: block-uniform
+            const int ngs = gpb < FBBEV_POOL_SPLIT_GROUPS ? gpb : FBBEV_POOL_SPLIT_GROUPS;   // lane groups that share an interval
             const float* fbase = feat + c0 + slot * CPL;
             for (int q = 0; q < nl; ++q) {
                 const int i = lng[1 + q];
                 const int len = iln[i], s0 = ist[i], v = ivx[i];
-                const int chunk = (((len + gpb - 1) / gpb) + 3) & ~3;   // whole gather batches per group
-                if (g < gpb) {
+                const int chunk = (((len + ngs - 1) / ngs) + 3) & ~3;   // whole gather batches per group
+                if (g < ngs) {
                     const int sub = g * chunk;
                     int sl = len - sub;
                     sl = sl < 0 ? 0 : (sl > chunk ? chunk : sl);
@@ -511,7 +513,7 @@ k_pool_fwd_dense2(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_b
                 __syncthreads();
                 if (tid < CC) {                                      // partial sums in group order: a fixed shape
                     float sum = part[tid];
-                    for (int gg = 1; gg < gpb; ++gg) sum += part[gg * CC + tid];
+                    for (int gg = 1; gg < ngs; ++gg) sum += part[gg * CC + tid];
                     if (v >= 0 && v < nv) tile[tid * LD + v] = sum;
                 }
                 __syncthreads();

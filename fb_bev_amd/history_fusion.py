@@ -22,6 +22,7 @@ No CPU fallback: the HIP extension must be present and the tensors on the GPU.
 """
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from . import _capi
 from .mfma_conv3d import MConv3d      # nn.Conv3d (same parameters / state dict) that can take the fbbev_conv3d_* autograd route
@@ -48,6 +49,8 @@ class TemporalHistoryFusion(nn.Module):
             MConv3d(C * (T + 1), out_c, kernel_size=1, padding=0, stride=1), nn.SyncBatchNorm(out_c),
             nn.ReLU(inplace=True))
         self.use_mfma_convs = True          # inference: both 1x1x1 convs in one fp32-MFMA kernel when the channels allow
+        self.train_rows = True              # training on a GPU: the two convolutions on voxel rows (_fuse_train_rows); False =
+                                            # the reference's literal op sequence (cat / reshape / Conv3d modules)
         # Storage type of the inference history ring (T+1 frames per sample): float32 (the reference), or float16 / bfloat16
         # -- BASELINE configs[4] names fp16; at 400x400x16 the ring is 13 GB per sample in fp32.  Sampling and the two
         # convolutions stay fp32 (taps widened exactly, one nearest-even rounding when a frame is stored); the autograd
@@ -171,7 +174,8 @@ class TemporalHistoryFusion(nn.Module):
         sweep = torch.cat([torch.zeros(B, 1), self.history_sweep_time], dim=1)    # :279-281, B x (1+T)
         if train_path:
             out, feats_cat = self._fuse_train(curr, flow, sweep.to(dev, non_blocking=True))
-            self.history_bev = feats_cat[:, :-C].detach().clone()      # :312
+            h = feats_cat[:, :-C].detach()                             # :312
+            self.history_bev = h.clone() if feats_cat.requires_grad else h      # (the row path built feats_cat for this alone)
         else:
             with torch.no_grad():
                 if self._voxel_major():
@@ -220,6 +224,35 @@ class TemporalHistoryFusion(nn.Module):
         hist.view(B, T, C, Z, Y, X).copy_(curr.detach().unsqueeze(1).expand(B, T, C, Z, Y, X))
         return hist
 
+    def _fuse_train_rows(self, curr, sampled, sweep):
+        """The two 1x1x1 convolutions of the training path (:288-310) on VOXEL ROWS: the same maps -- conv + batch norm
+        (batch statistics, running buffers updated) + ReLU, twice -- evaluated without the reference's concatenations:
+          * the time channel is a per-(sample, frame) scalar, so the 81 -> 80 convolution is the 80 -> 80 one plus
+            W[:, 80] * tau_t added to its output before the norm (same sum, no (B, 17, 81, Z, Y, X) copy);
+          * the 1360 -> 80 convolution over the frame-concatenated channels is sum_t W2_t y_t, accumulated by T + 1 batched
+            GEMMs on the frames' row blocks (no frame <-> voxel transposition of the 435 MB intermediate).
+        The round-2 path spent 30 ms of the 303 ms training step in those copies (torch's strided transposing copies run at
+        ~150 GB/s on these shapes, profiles/r03_train_step_copy_sites.json).  -> fused (B, Cout, Z, Y, X) view."""
+        T, C = self.history_cat_num, self.single_bev_num_channels
+        B, _, Z, Y, X = curr.shape
+        N = Z * Y * X
+        conv1, bn1 = self.history_keyframe_time_conv[0], self.history_keyframe_time_conv[1]
+        conv2, bn2 = self.history_keyframe_cat_conv[0], self.history_keyframe_cat_conv[1]
+        rows_hist = _capi.transpose_last2(sampled.view(B * T, C, N)).view(B, T, N, C)         # LDS-tiled transpose, no grad
+        rows_curr = curr.reshape(B, 1, C, N).transpose(2, 3)                                  # autograd reaches curr from here
+        x = torch.cat([rows_curr, rows_hist], dim=1)                                          # (B, T+1, N, C)
+        w1 = conv1.weight.flatten(1)                                                          # (C, C + 1)
+        tau = (sweep * self.history_cam_sweep_freq).to(x.dtype)                               # (B, T+1)
+        y = F.linear(x, w1[:, :C]) + (tau[:, :, None, None] * w1[:, C] + conv1.bias)[:, :, None, :].reshape(B, T + 1, 1, C)
+        y = torch.relu_(bn1(y.view(-1, C))).view(B, T + 1, N, C)
+        w2 = conv2.weight.flatten(1)                                                          # (Cout, (T+1) C)
+        cout = w2.shape[0]
+        out = conv2.bias.to(y.dtype).expand(B, N, cout)
+        for t in range(T + 1):                                                                # sum_t y_t W2_t^T
+            out = torch.baddbmm(out, y[:, t], w2[:, t * C:(t + 1) * C].t().unsqueeze(0).expand(B, C, cout))
+        out = torch.relu_(bn2(out.reshape(-1, cout)))
+        return out.view(B, Z, Y, X, cout).permute(0, 4, 1, 2, 3)
+
     def _fuse_train(self, curr, flow, sweep):
         """The reference's op sequence (:264-310) on this module's layers; the warp is the HIP kernel."""
         T, C = self.history_cat_num, self.single_bev_num_channels
@@ -228,6 +261,9 @@ class TemporalHistoryFusion(nn.Module):
         if hist.stride()[1:] != (Z * Y * X, Y * X, X, 1):
             hist = hist.contiguous()
         sampled = _capi.history_warp(hist, flow, torch.empty((B, T * C, Z, Y, X), dtype=torch.float32, device=curr.device))
+        if curr.is_cuda and self.train_rows:
+            out = self._fuse_train_rows(curr, sampled, sweep)
+            return out, torch.cat([curr.detach(), sampled], dim=1)     # the new history = [current, warped frames] (:286, :312)
         feats_cat = torch.cat([curr, sampled], dim=1)                  # :286
         f = feats_cat.reshape(B, T + 1, C, Z, Y, X)
         tchan = (sweep * self.history_cam_sweep_freq)[:, :, None, None, None, None].expand(B, T + 1, 1, Z, Y, X)

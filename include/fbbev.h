@@ -347,7 +347,11 @@ int fbbev_da_cross_attn_fwd_zt(const float* value, const int64_t* spatial_shapes
                                const float* ref_cam, const uint8_t* mask, const float* qdepth,
                                const float* offsets, const float* attn, int B, int Ncam, int S, int M, int Dh,
                                int L, int Q, int P, int Za, int DC, float d0, float dstep, int head_minor,
-                               int head_stride, float* slots, fbbev_stream_t stream);
+                               int head_stride, int bev_w, float* slots, fbbev_stream_t stream);
+/* bev_w: row length of the BEV grid the Q = bev_h * bev_w queries come from (0 = unknown).  With it (and M = 8) a workgroup
+ * owns the 8 heads of an 8 x 4 PATCH of the grid and a wave 4 heads of a 4 x 4 sub-patch instead of 32 / 8 consecutive
+ * queries of a row: neighbours in both BEV directions sample nearly the same camera tokens for a given head, so a load
+ * instruction touches fewer distinct cache lines.  Layouts and results (bit for bit) do not depend on it. */
 
 /* Backward of fbbev_da_cross_attn_fwd in one launch -- replaces the autograd chain of the reference's training step
  * through DA_SpatialCrossAttention / DA_MSDeformableAttention (two MultiScaleDeformableAttnFunction backward launches,

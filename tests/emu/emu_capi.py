@@ -128,7 +128,7 @@ def lidar_coor(xs, ys, ds, cam):
 
 
 def da_cross_attn_fwd(value, ss, ls, pred_depth, ref_cam, mask, qdepth, offsets, attn, d0, dstep, misalign=False,
-                      head_minor=0, head_dim=None, zero_token=None):
+                      head_minor=0, head_dim=None, zero_token=None, bev_w=0):
     """misalign=True: output buffer at a 4-byte (not 8-byte) aligned address => the channel-per-lane kernel runs"""
     Ncam, B, Q, Za = mask.shape
     _, S, M, HS = value.shape
@@ -147,8 +147,9 @@ def da_cross_attn_fwd(value, ss, ls, pred_depth, ref_cam, mask, qdepth, offsets,
                                            p(attn), B, Ncam, S, M, Dh, L, Q, P, Za, pred_depth.shape[1], d0, dstep,
                                            int(head_minor), HS, et, c_void_p(slots.data_ptr()), None))
         return slots.clone()
-    fn = lib().fbbev_da_cross_attn_fwd
+    fn, extra = lib().fbbev_da_cross_attn_fwd, ()
     if zero_token is not None:
+        extra = (int(bev_w),)
         # the pipelined entry: value rows followed by ONE more token; `zero_token` = its fill (0.0 by contract; a test passes
         # another value to prove that padded corners / out-of-image samples really read it)
         buf_v = torch.empty(value.numel() + M * HS)
@@ -158,7 +159,7 @@ def da_cross_attn_fwd(value, ss, ls, pred_depth, ref_cam, mask, qdepth, offsets,
         fn = lib().fbbev_da_cross_attn_fwd_zt
     ok(fn(p(value), p(ss), p(ls), p(pred_depth), p(ref_cam), p(m8), p(qdepth), p(offsets),
           p(attn), B, Ncam, S, M, Dh, L, Q, P, Za, pred_depth.shape[1], d0, dstep,
-          int(head_minor), HS, c_void_p(slots.data_ptr()), None))
+          int(head_minor), HS, *extra, c_void_p(slots.data_ptr()), None))
     return slots.clone()
 
 

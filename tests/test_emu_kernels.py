@@ -328,6 +328,19 @@ def test_pipelined_da_cross_attention_emulated():
                  ).view(args[8].shape).contiguous()                                     # softmax(log p + c) == p
         fused = E.da_cross_attn_fwd(*lg, head_minor=5 | 0x10, head_dim=Dh, zero_token=0.0)
         assert torch.allclose(fused, pipe, atol=2e-6, rtol=2e-5), (seed, (fused - pipe).abs().max())
+    # patch mapping (bev_w given, M = 8): a workgroup = the 8 heads of an 8 x 4 patch of the BEV grid -- the SAME bits as the
+    # linear unit order, for grids that are / are not multiples of the patch (partial patches masked), with fused softmax
+    for seed, (bh, bw) in ((4, (12, 25)), (5, (8, 16)), (6, (5, 7))):
+        args, exp = _da_case(seed, B=2, Q=bh * bw, E=80, M=8, shapes=((16, 44), (8, 22)), P=8, DC=20)
+        vp = torch.zeros(args[0].shape[:-1] + (12,)); vp[..., :10] = args[0]
+        a = list(args); a[0] = _interleave(vp); a[7] = args[7].permute(0, 1, 3, 4, 2, 5).contiguous()
+        lin = E.da_cross_attn_fwd(*a, head_minor=5, head_dim=10, zero_token=0.0)
+        pat = E.da_cross_attn_fwd(*a, head_minor=5, head_dim=10, zero_token=0.0, bev_w=bw)
+        assert torch.equal(lin, pat), (seed, (lin - pat).abs().max())
+        assert torch.allclose(pat, exp, atol=2e-5, rtol=1e-5)
+        lg = list(a); lg[8] = args[8].flatten(-2).log().view(args[8].shape).contiguous()
+        assert torch.equal(E.da_cross_attn_fwd(*lg, head_minor=5 | 0x10, head_dim=10, zero_token=0.0),
+                           E.da_cross_attn_fwd(*lg, head_minor=5 | 0x10, head_dim=10, zero_token=0.0, bev_w=bw))
     # ... and outside the preconditions (here Za = 2; head-major rows) the entry runs the unit kernel: identical bits
     args, exp = _da_case(7, B=1, Q=23, E=40, M=4, Za=2)
     Dh = args[0].shape[-1]
@@ -783,7 +796,7 @@ def _assert_index_equal(got, exp):
     assert torch.equal(st[:I], est) and torch.equal(ln[:I], eln) and torch.equal(ir[:I], erb[est.long()])
 
 
-@pytest.mark.parametrize('shape', ['0,0,0', '1,0,1', '2,1,2', '3,2,1', '4,3,2', '0,4,0'])
+@pytest.mark.parametrize('shape', ['0,0,0', '1,0,1', '2,1,2', '3,2,1', '4,3,2', '0,4,0', '5,6,1', '6,5,2'])
 def test_rank_build_every_chunk_variant_emulated(shape, monkeypatch):
     """Every chunk shape of the sort / interval kernels (thin 256-thread chunks up to 16 waves x 16 rounds) on the SAME
     input: the index tensors do not depend on the shape (FBBEV_RANK_SHAPE = the launcher's tuning knob) and equal the
