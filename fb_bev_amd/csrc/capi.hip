@@ -157,7 +157,9 @@ static const int kSortTile[7] = {2048, 4096, 8192, 12288, 16384, 4096, 8192};
 static int sort_variant_for(long long items) {
     for (int v = 0; v < 5; ++v)
         if ((items + kSortTile[v] - 1) / kSortTile[v] <= 256) return v;
-    return 4;
+    // more than one round of the fattest chunks: 512-thread workgroups of 8192 pairs, two per CU, interleave their phases
+    // (measured at the shipped grid, B = 16, 5.4 M points: 0.262 -> 0.239 ms per build, profiles/r03_time_rank_shapes.jsonl)
+    return 6;
 }
 //   interval kernels: 0 = 4 waves x 4 (1024), 1 = 16 x 4 (4096), 2 = 16 x 8 (8192)
 static const int kIvTile[3] = {1024, 4096, 8192};
@@ -1037,7 +1039,7 @@ extern "C" int fbbev_da_cross_attn_fwd_zt(const float* value, const int64_t* spa
     FBBEV_LAUNCH((k_da_cross_attn_fwd_pipe<DH_, 4, WPS_>), ub, 256, lds, (fbbev_rt_stream)stream_, units, value,         \
                  spatial_shapes, level_start_index, pred_depth, ref_cam, mask, qdepth, offsets, attn, B, Ncam, S, M, L, \
                  Q, P, DC, d0, dstep, HS, zero_bytes, (head_minor & FBBEV_DA_ATTN_LOGITS) ? 1 : 0, pw, slots)
-    static const int wps = [] { const char* e = getenv("FBBEV_DA_PIPE_WPS"); return e ? atoi(e) : 3; }();   // tuning knob, read once
+    static const int wps = [] { const char* e = getenv("FBBEV_DA_PIPE_WPS"); return e ? atoi(e) : 2; }();   // tuning knob, read once (3: 168 registers, spills outside the loop)
     if (Dh == 10) { if (wps == 2) FBBEV_DA_PIPE(10, 2); else FBBEV_DA_PIPE(10, 3); }
     else { if (wps == 2) FBBEV_DA_PIPE(8, 2); else FBBEV_DA_PIPE(8, 3); }
 #undef FBBEV_DA_PIPE

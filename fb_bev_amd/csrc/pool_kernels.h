@@ -346,9 +346,9 @@ __device__ __forceinline__ unsigned int fbbev_pack2(float lo, float hi) {
 // but the depth / feature gathers and their fmaf chains (tile metadata, interval / point-index staging, LDS tile, barriers,
 // stores).  0 = the product kernel; the diagnostic instantiations write zeros and are reachable only through
 // fbbev_diag_pool_store_floor.
-#define FBBEV_POOL_SPLIT_GROUPS 16     // lane groups a long interval is split over (bounds the extra LDS: 16 x CC floats)
+#define FBBEV_POOL_SPLIT_GROUPS 32     // lane groups a long interval is split over (bounds the extra LDS: 32 x CC floats)
 // SPLIT > 0 (opt-in tolerance mode, FBBEV_POOL_SPLIT_LONG): an interval longer than SPLIT points is summed by ALL lane
-// groups of the workgroup -- group g < 16 takes the g-th contiguous chunk of its points (chunk = ceil(len / groups) rounded up to
+// groups of the workgroup -- group g < 32 takes the g-th contiguous chunk of its points (chunk = ceil(len / groups) rounded up to
 // the gather batch), in order, and the partial sums are added in group order: a fixed-shape, run-to-run deterministic
 // reduction that differs from the reference's serial chain (bev_pool_cuda.cu:33-38) only by fp32 reassociation (<= 1e-4 of
 // the sum for the path's sizes: the bar north_star states; tested) -- the default (SPLIT = 0) stays the serial chain, bit

@@ -248,8 +248,10 @@ class TemporalHistoryFusion(nn.Module):
         w2 = conv2.weight.flatten(1)                                                          # (Cout, (T+1) C)
         cout = w2.shape[0]
         out = conv2.bias.to(y.dtype).expand(B, N, cout)
-        for t in range(T + 1):                                                                # sum_t y_t W2_t^T
-            out = torch.baddbmm(out, y[:, t], w2[:, t * C:(t + 1) * C].t().unsqueeze(0).expand(B, C, cout))
+        # unbind, not y[:, t]: the backward of T + 1 separate selects materialises a zero-filled full-size tensor per frame
+        # and adds them up (17 x 435 MB fills + adds: 18 ms per step); unbind's backward is one stack
+        for t, yt in enumerate(y.unbind(1)):                                                  # sum_t y_t W2_t^T
+            out = torch.baddbmm(out, yt, w2[:, t * C:(t + 1) * C].t().unsqueeze(0).expand(B, C, cout))
         out = torch.relu_(bn2(out.reshape(-1, cout)))
         return out.view(B, Z, Y, X, cout).permute(0, 4, 1, 2, 3)
 

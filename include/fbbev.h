@@ -40,7 +40,7 @@ typedef void* fbbev_stream_t; /* hipStream_t */
 #define FBBEV_POOL_OUT_F16 0x1000000  /* `out` holds IEEE half; both: (B,C,Z,Y,X) layout only, (Y*X) % 8 == 0 */
 #define FBBEV_POOL_SWZ_CHUNK_SHIFT 12 /* bits 12-16: log2(tiles per chunk) for the swizzle, 0 = default */
 #define FBBEV_POOL_SPLIT_LONG 0x2000000 /* opt-in TOLERANCE mode of fbbev_bev_pool_v2_dense_fwd[_add]: an interval of more than 32
-                                         * points is summed by all lane groups of its workgroup (contiguous chunks in order,
+                                         * points is summed by up to 32 lane groups of its workgroup (contiguous chunks in order,
                                          * partial sums added in group order: deterministic) -- equal to the reference's serial
                                          * chain (bev_pool_cuda.cu:33-38) up to fp32 reassociation (<= 1e-4, north_star's bar),
                                          * not bit for bit.  fp32 volume, sc1-nt stores, 256 threads, tile_voxels 64 / 128; the
