@@ -183,7 +183,7 @@ static fbbev_fastdiv make_fastdiv(unsigned int d) {
 }
 
 struct rank_ws_layout {
-    size_t keys_a, keys_t, vals_t, matrix, chunk_info, total;
+    size_t keys_a, keys_t, vals_t, matrix, ctot, chunk_info, total;
     int v0, wgs0;          // pass 0 (keys + scatter over all n points)
     int v1, wgs1;          // later passes (over the P kept pairs; P is only known on the device: sized for about n/2,
                            // the grid covers the worst case P = n and surplus workgroups leave at once)
@@ -210,7 +210,12 @@ static rank_ws_layout rank_layout(long long n) {
     L.keys_t = off; off = align_up(off + (size_t)n * 4, 256);
     L.vals_t = off; off = align_up(off + (size_t)n * 4, 256);
     const int rows = L.wgs0 > L.wgs1 ? L.wgs0 : L.wgs1;
-    L.matrix = off; off = align_up(off + (size_t)rows * FBBEV_SORT_MAX_NB * 4, 256);
+    // the segmented (per-sample) sort: at most n / TILE + 256 sample-aligned chunks (<= 256 samples), 2^10 digit columns, + ctot
+    const size_t seg_rows = (size_t)(n / FBBEV_SEG_TILE) + 256 + 1;
+    size_t mbytes = (size_t)rows * FBBEV_SORT_MAX_NB * 4;
+    if (seg_rows * FBBEV_SEG_NB * 4 > mbytes) mbytes = seg_rows * FBBEV_SEG_NB * 4;
+    L.matrix = off; off = align_up(off + mbytes, 256);
+    L.ctot = off; off = align_up(off + seg_rows * 4, 256);
     L.chunk_info = off; off = align_up(off + (size_t)L.wgsi * 8, 256);
     L.total = off;                                         // no per-build state: nothing to clear, no kernel waits for another
     return L;
@@ -234,6 +239,13 @@ extern "C" size_t fbbev_rank_workspace_bytes(int64_t n_points) {
     if (n_points <= 0) return 256;
     return rank_layout(n_points).total;
 }
+
+static int rank_seg_read_env() { const char* e = getenv("FBBEV_RANK_SEG"); return e ? atoi(e) : -1; }
+#ifdef FBBEV_TEST_OVERRIDES   // CPU emulator build: the tests switch modes inside one process
+static int rank_seg_mode() { return rank_seg_read_env(); }
+#else
+static int rank_seg_mode() { static const int m = rank_seg_read_env(); return m; }      // read once per process
+#endif
 
 static int rank_build_impl(const float* coor, const fbbev_cam_ptrs* cams, const float* frustum, int B, int N, int D,
                            int H, int W,
@@ -275,29 +287,77 @@ static int rank_build_impl(const float* coor, const fbbev_cam_ptrs* cams, const 
     plan.rb = (bits + plan.passes - 1) / plan.passes;          // digits as even as possible, <= 8 bits
     if (plan.rb < 4) plan.rb = 4;
     const int rb = plan.rb;
-    if (cams) {
+    // Per-sample (segmented) sort: B V <= 2^24 (the fp32 rank arithmetic is exact, so the keys of sample b lie in [b V, (b+1) V))
+    // and V fits two 10-bit digits -- two passes instead of three, 6 launches instead of 9 (sort_kernels.h).  FBBEV_RANK_SEG=0
+    // keeps the global sort (A/B timing, tests); the index tensors are the same either way.
+    const int seg_mode = rank_seg_mode();                   // -1 auto | 0 never | 2 whenever legal (tests)
+    const long long vps = total_voxels / B;
+    const long long npb = n / B;
+    const int lbits = key_bits(vps);
+    const bool seg_legal = B <= 256 && total_voxels <= (1ll << 24) && lbits <= 2 * FBBEV_SEG_RB;
+    // auto: when it saves a pass AND the launch has the shape the kernels are good at -- enough sample-aligned chunks to fill
+    // the part (>= 96 workgroups) and few chunks per sample (every scatter workgroup sums the <= 64 count rows of its sample).
+    // Measured (profiles/r03_time_rank_seg*.jsonl, whole build, eager): shipped grid B = 16  0.258 -> 0.190 ms, BL2 B = 16
+    // 0.182 -> 0.175 ms, BL2 B = 4  0.133 -> 0.122 ms; it LOSES for one fat sample (BL1 B = 1: 487 chunks per sample,
+    // 0.152 -> 0.258 ms) and for a single small sample (shipped grid B = 1: 42 workgroups), which keep the global sort.
+    const long long seg_cps = (npb + FBBEV_SEG_TILE - 1) / FBBEV_SEG_TILE;
+    const bool seg = seg_legal && seg_mode != 0 &&
+                     (seg_mode == 2 || ((lbits + FBBEV_SEG_RB - 1) / FBBEV_SEG_RB < plan.passes && seg_cps <= 64 && B * seg_cps >= 96));
+    if (seg) {
+        fbbev_seg sg;
+        sg.npb = (int)npb; sg.cps = (int)((npb + FBBEV_SEG_TILE - 1) / FBBEV_SEG_TILE); sg.vps = (unsigned int)vps; sg.nseg = B;
+        const int passes = (lbits + FBBEV_SEG_RB - 1) / FBBEV_SEG_RB;                     // 1 or 2
+        const int srb = (lbits + passes - 1) / passes < 4 ? 4 : (lbits + passes - 1) / passes;
+        const int wgs = B * sg.cps;
+        int* ctot = reinterpret_cast<int*>(ws + L.ctot);
         fbbev_geom_src gs;
-        gs.cam = *cams; gs.frustum = frustum; gs.gp = gp;
-        FBBEV_SORT_DISPATCH(k_keys_hist_geom, L.v0, false, L.wgs0, stream, gs, n, rb, skip, keys_a, matrix);
-    } else {
-        FBBEV_SORT_DISPATCH(k_keys_hist_coor, L.v0, false, L.wgs0, stream, coor, n, n / B, gp, point_depth, depth_thr, rb, keys_a, matrix);
-    }
-    FBBEV_CHECK_LAUNCH();
-    const unsigned int* kin = keys_a;
-    const unsigned int* vin = nullptr;                         // pass 0: value = position = point id
-    for (int p = 0; p < plan.passes; ++p) {
-        const bool to_out = ((plan.passes - 1 - p) % 2) == 0;  // the last pass always writes the outputs
-        unsigned int* ko = to_out ? reinterpret_cast<unsigned int*>(ranks_bev) : keys_t;
-        unsigned int* vo = to_out ? reinterpret_cast<unsigned int*>(ranks_depth) : vals_t;
-        const int v = p == 0 ? L.v0 : L.v1, wgs = p == 0 ? L.wgs0 : L.wgs1;
-        if (p > 0) {                                           // count matrix of this pass (pass 0: written with the keys)
-            FBBEV_SORT_DISPATCH(k_sort_hist, v, false, wgs, stream, kin, (const int*)counts, p * rb, rb, skip, matrix);
-            FBBEV_CHECK_LAUNCH();
-        }
-        FBBEV_SORT_DISPATCH(k_sort_scatter, v, true, wgs, stream, kin, vin, n, (const int*)matrix, p, rb, skip, ko, vo, counts);
+        if (cams) { gs.cam = *cams; gs.frustum = frustum; gs.gp = gp; }
+        else { gs.cam = fbbev_cam_ptrs(); gs.frustum = nullptr; gs.gp = gp; }
+        if (cams) FBBEV_LAUNCH((k_keys_hist_seg<true>), wgs, FBBEV_SEG_NT, 0, stream, gs, (const float*)nullptr, gp, (const float*)nullptr, 0.f,
+                               sg, srb, skip, keys_a, matrix, ctot);
+        else FBBEV_LAUNCH((k_keys_hist_seg<false>), wgs, FBBEV_SEG_NT, 0, stream, gs, coor, gp, point_depth, depth_thr, sg, srb, skip, keys_a,
+                          matrix, ctot);
         FBBEV_CHECK_LAUNCH();
-        kin = ko; vin = vo;
-    }
+        const unsigned int* kin = keys_a;
+        const unsigned int* vin = nullptr;
+        for (int p = 0; p < passes; ++p) {
+            const bool to_out = p == passes - 1;
+            unsigned int* ko = to_out ? reinterpret_cast<unsigned int*>(ranks_bev) : keys_t;
+            unsigned int* vo = to_out ? reinterpret_cast<unsigned int*>(ranks_depth) : vals_t;
+            if (p > 0) {
+                FBBEV_LAUNCH(k_sort_hist_seg, wgs, FBBEV_SEG_NT, 0, stream, kin, (const int*)ctot, sg, p * srb, srb, skip, matrix);
+                FBBEV_CHECK_LAUNCH();
+            }
+            FBBEV_LAUNCH(k_sort_scatter_seg, wgs, FBBEV_SEG_NT, 0, stream, kin, vin, (const int*)matrix, (const int*)ctot, sg, p, srb, skip,
+                         ko, vo, counts);
+            FBBEV_CHECK_LAUNCH();
+            kin = ko; vin = vo;
+        }
+    } else {
+    if (cams) {
+            fbbev_geom_src gs;
+            gs.cam = *cams; gs.frustum = frustum; gs.gp = gp;
+            FBBEV_SORT_DISPATCH(k_keys_hist_geom, L.v0, false, L.wgs0, stream, gs, n, rb, skip, keys_a, matrix);
+        } else {
+            FBBEV_SORT_DISPATCH(k_keys_hist_coor, L.v0, false, L.wgs0, stream, coor, n, n / B, gp, point_depth, depth_thr, rb, keys_a, matrix);
+        }
+        FBBEV_CHECK_LAUNCH();
+        const unsigned int* kin = keys_a;
+        const unsigned int* vin = nullptr;                         // pass 0: value = position = point id
+        for (int p = 0; p < plan.passes; ++p) {
+            const bool to_out = ((plan.passes - 1 - p) % 2) == 0;  // the last pass always writes the outputs
+            unsigned int* ko = to_out ? reinterpret_cast<unsigned int*>(ranks_bev) : keys_t;
+            unsigned int* vo = to_out ? reinterpret_cast<unsigned int*>(ranks_depth) : vals_t;
+            const int v = p == 0 ? L.v0 : L.v1, wgs = p == 0 ? L.wgs0 : L.wgs1;
+            if (p > 0) {                                           // count matrix of this pass (pass 0: written with the keys)
+                FBBEV_SORT_DISPATCH(k_sort_hist, v, false, wgs, stream, kin, (const int*)counts, p * rb, rb, skip, matrix);
+                FBBEV_CHECK_LAUNCH();
+            }
+            FBBEV_SORT_DISPATCH(k_sort_scatter, v, true, wgs, stream, kin, vin, n, (const int*)matrix, p, rb, skip, ko, vo, counts);
+            FBBEV_CHECK_LAUNCH();
+            kin = ko; vin = vo;
+        }
+}
     const unsigned int* keys = reinterpret_cast<const unsigned int*>(ranks_bev);
     const unsigned int* vals = reinterpret_cast<const unsigned int*>(ranks_depth);
     const fbbev_fastdiv div_dhw = make_fastdiv((unsigned int)((long long)D * H * W)), div_hw = make_fastdiv((unsigned int)(H * W));

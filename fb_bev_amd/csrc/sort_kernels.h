@@ -271,6 +271,269 @@ k_sort_scatter(const unsigned int* __restrict__ keys_in, const unsigned int* __r
     }
 }
 
+// ================================================================ per-sample (segmented) sort, round 3
+// The rank of a kept point of sample b lies in [b V, (b+1) V) (V = voxels per sample) whenever B V <= 2^24 -- the fp32 rank
+// arithmetic of the reference is then exact -- and the points arrive in sample order.  Sorting the global keys is therefore B
+// independent sorts of (key - b V) < V: 20 bits at the 200x200x16 grid instead of 24 for 16 samples, i.e. TWO passes of 10-bit
+// digits instead of three of 8 (17 bits = two passes of 9 instead of three of 7 at the shipped grid).  6 launches per build
+// instead of 9: keys + count matrix, scatter 0, count matrix 1, scatter 1, the two interval kernels.  Same stable order, same
+// index tensors, bit for bit (tested against the oracle and against the global sort for every case the suite holds).
+//   * chunks never straddle samples: workgroup w = (sample b = w / cps, chunk c = w % cps) owns points / pairs
+//     [start_b + c T, min(start_b + (c+1) T, end_b)) where [start_b, end_b) is the sample's range in the pass's input order:
+//     b npb .. (b+1) npb for pass 0 (all frustum points), the sample's compacted range for pass 1 -- the prefix sums of
+//     ctot[] (kept points per pass-0 chunk), which every workgroup evaluates itself from the <= B cps words: no extra launch;
+//   * count matrices [B cps][2^rb]; a workgroup only sums the rows of its own sample;
+//   * 512-thread workgroups (8 waves x 16 rounds = 8192 pairs, two per CU): 2^10 digits x 8 waves of running counters are
+//     32 KB of LDS; the per-wave offsets are formed in place.
+#define FBBEV_SEG_RB 10
+#define FBBEV_SEG_NB (1 << FBBEV_SEG_RB)
+#define FBBEV_SEG_WAVES 8
+#define FBBEV_SEG_ROUNDS 16
+#define FBBEV_SEG_NT (FBBEV_SEG_WAVES * 64)
+#define FBBEV_SEG_TILE (FBBEV_SEG_NT * FBBEV_SEG_ROUNDS)
+
+struct fbbev_seg {
+    int npb;              // frustum points per sample (N*D*H*W)
+    int cps;              // chunks per sample = ceil(npb / FBBEV_SEG_TILE)
+    unsigned int vps;     // voxels per sample (Z*Y*X): key of sample b = local key + b * vps
+    int nseg;             // samples
+};
+
+// sums of ctot[0 .. lo) and ctot[0 .. hi) (lo <= hi <= nseg * cps) by the whole workgroup; red: 2 * WAVES ints of LDS
+template <int WAVES>
+__device__ __forceinline__ void fbbev_seg_prefix2(const int* __restrict__ ctot, int lo, int hi, int* red, int& sum_lo, int& sum_hi) {
+    int a = 0, b = 0;
+    for (int i = threadIdx.x; i < hi; i += WAVES * 64) {
+        const int c = ctot[i];
+        b += c;
+        if (i < lo) a += c;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); b += __shfl_down(b, o, 64); }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[2 * wave] = a; red[2 * wave + 1] = b; }
+    __syncthreads();
+    sum_lo = 0; sum_hi = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) { sum_lo += red[2 * w]; sum_hi += red[2 * w + 1]; }
+    __syncthreads();
+}
+
+// keys + pass-0 count matrix + ctot, sample-aligned chunks.  GEOM: keys from the camera geometry, else from `coor`.
+template <bool GEOM>
+__global__ void __launch_bounds__(FBBEV_SEG_NT)
+k_keys_hist_seg(fbbev_geom_src g, const float* __restrict__ coor, fbbev_grid_params gp, const float* __restrict__ depth,
+                float depth_thr, fbbev_seg sg, int rb, const int* __restrict__ skip, unsigned int* __restrict__ keys_out,
+                int* __restrict__ matrix, int* __restrict__ ctot) {
+    if (fbbev_skip(skip)) return;
+    constexpr int NT = FBBEV_SEG_NT, PER = FBBEV_SEG_ROUNDS;
+    __shared__ int cnt[FBBEV_SEG_NB];
+    __shared__ float m[33];
+    __shared__ int tot;
+    const int nb = 1 << rb;
+    const unsigned int dmask = (unsigned int)nb - 1u;
+    for (int d = threadIdx.x; d < nb; d += NT) cnt[d] = 0;
+    if (threadIdx.x == 0) tot = 0;
+    const int b = blockIdx.x / sg.cps, c = blockIdx.x - b * sg.cps;
+    const int base = b * sg.npb + c * FBBEV_SEG_TILE;                       // < 2^30 (launcher)
+    const int lim = (b + 1) * sg.npb;
+    const int end = base + FBBEV_SEG_TILE < lim ? base + FBBEV_SEG_TILE : lim;
+    const unsigned int kbase = (unsigned int)b * sg.vps;
+    int mine = 0;
+    if constexpr (GEOM) {
+        const int dhw = g.cam.D * g.cam.H * g.cam.W;
+        const int cam_lo = base / dhw, cam_hi = (end > base ? end - 1 : base) / dhw;
+        constexpr int G = 4;
+        for (int cam = cam_lo; cam <= cam_hi; ++cam) {
+            __syncthreads();
+            if (threadIdx.x == 0) fbbev_cam_setup(g.cam, cam, m);
+            __syncthreads();
+            const int c0 = cam * dhw;
+            const int lo = base > c0 ? base : c0, hi = end < c0 + dhw ? end : c0 + dhw;
+            for (int r0 = 0; r0 < PER; r0 += G) {
+                unsigned int key[G];
+#pragma unroll
+                for (int r = 0; r < G; ++r) {
+                    const int pid = base + (int)threadIdx.x + (r0 + r) * NT;
+                    key[r] = (pid >= lo && pid < hi) ? fbbev_geom_key(g, m, cam, pid - c0) : FBBEV_DROP_KEY;
+                }
+#pragma unroll
+                for (int r = 0; r < G; ++r) {
+                    const int pid = base + (int)threadIdx.x + (r0 + r) * NT;
+                    if (pid >= lo && pid < hi) {
+                        keys_out[pid] = key[r];
+                        if (key[r] != FBBEV_DROP_KEY) { atomicAdd(&cnt[(key[r] - kbase) & dmask], 1); ++mine; }
+                    }
+                }
+            }
+        }
+    } else {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < PER; ++r) {
+            const int pid = base + (int)threadIdx.x + r * NT;
+            if (pid < end) {
+                unsigned int key = fbbev_rank_key(coor[3 * (long long)pid], coor[3 * (long long)pid + 1], coor[3 * (long long)pid + 2], gp,
+                                                  (float)b, FBBEV_DROP_KEY);
+                if (depth && !(depth[pid] > depth_thr)) key = FBBEV_DROP_KEY;
+                keys_out[pid] = key;
+                if (key != FBBEV_DROP_KEY) { atomicAdd(&cnt[(key - kbase) & dmask], 1); ++mine; }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o, 64);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&tot, mine);
+    __syncthreads();
+    for (int d = threadIdx.x; d < nb; d += NT) matrix[(long long)blockIdx.x * nb + d] = cnt[d];
+    if (threadIdx.x == 0) ctot[blockIdx.x] = tot;
+}
+
+// count matrix of pass 1: chunk (b, c) of the sample's compacted range
+__global__ void __launch_bounds__(FBBEV_SEG_NT)
+k_sort_hist_seg(const unsigned int* __restrict__ keys, const int* __restrict__ ctot, fbbev_seg sg, int shift, int rb,
+                const int* __restrict__ skip, int* __restrict__ matrix) {
+    if (fbbev_skip(skip)) return;
+    constexpr int NT = FBBEV_SEG_NT, PER = FBBEV_SEG_ROUNDS;
+    __shared__ int cnt[FBBEV_SEG_NB];
+    __shared__ int red[2 * FBBEV_SEG_WAVES];
+    const int nb = 1 << rb;
+    const unsigned int dmask = (unsigned int)nb - 1u;
+    const int b = blockIdx.x / sg.cps, c = blockIdx.x - b * sg.cps;
+    for (int d = threadIdx.x; d < nb; d += NT) cnt[d] = 0;
+    int s0, s1;
+    fbbev_seg_prefix2<FBBEV_SEG_WAVES>(ctot, b * sg.cps, (b + 1) * sg.cps, red, s0, s1);     // the sample's pairs: [s0, s1)
+    const long long base = (long long)s0 + (long long)c * FBBEV_SEG_TILE;
+    const unsigned int kbase = (unsigned int)b * sg.vps;
+    if (base < s1) {
+        unsigned int key[PER];
+#pragma unroll
+        for (int r = 0; r < PER; ++r) {
+            const long long idx = base + threadIdx.x + r * NT;
+            key[r] = (idx < s1) ? keys[idx] : FBBEV_DROP_KEY;
+        }
+#pragma unroll
+        for (int r = 0; r < PER; ++r)
+            if (key[r] != FBBEV_DROP_KEY) atomicAdd(&cnt[((key[r] - kbase) >> shift) & dmask], 1);
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < nb; d += NT) matrix[(long long)blockIdx.x * nb + d] = cnt[d];      // zeros for an empty chunk
+}
+
+// one scatter pass of the segmented sort (pass 0 compacts and publishes P; pass 1 reads the compacted pairs)
+__global__ void __launch_bounds__(FBBEV_SEG_NT)
+k_sort_scatter_seg(const unsigned int* __restrict__ keys_in, const unsigned int* __restrict__ vals_in, const int* __restrict__ matrix,
+                   const int* __restrict__ ctot, fbbev_seg sg, int pass, int rb, const int* __restrict__ skip,
+                   unsigned int* __restrict__ keys_out, unsigned int* __restrict__ vals_out, int* __restrict__ counts) {
+    if (fbbev_skip(skip)) return;
+    constexpr int WAVES = FBBEV_SEG_WAVES, ROUNDS = FBBEV_SEG_ROUNDS, NT = FBBEV_SEG_NT, NBM = FBBEV_SEG_NB;
+    __shared__ int cnt[WAVES][NBM];      // per-wave running digit counters, then (in place) each wave's first position of a digit
+    __shared__ int pos0[NBM];            // global position of this chunk's first key of a digit
+    __shared__ int red[2 * WAVES];
+    __shared__ int ldsw[WAVES];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int nb = 1 << rb, shift = pass * rb;
+    const unsigned int dmask = (unsigned int)nb - 1u;
+    const int b = blockIdx.x / sg.cps, c = blockIdx.x - b * sg.cps;
+    const unsigned int kbase = (unsigned int)b * sg.vps;
+    for (int i = tid; i < WAVES * NBM; i += NT) (&cnt[0][0])[i] = 0;
+    // the sample's range in the compacted order (= where its sorted pairs go, and pass 1's input range)
+    int s0, s1;
+    fbbev_seg_prefix2<WAVES>(ctot, b * sg.cps, (b + 1) * sg.cps, red, s0, s1);
+    if (pass == 0 && blockIdx.x == 0) {                  // P = all kept points
+        int p0, pall;
+        fbbev_seg_prefix2<WAVES>(ctot, 0, sg.nseg * sg.cps, red, p0, pall);
+        if (tid == 0) counts[0] = pall;
+    }
+    const long long in0 = pass == 0 ? (long long)b * sg.npb : (long long)s0;                 // the sample's input range
+    const long long in1 = pass == 0 ? (long long)(b + 1) * sg.npb : (long long)s1;
+    const long long chunk0 = in0 + (long long)c * FBBEV_SEG_TILE;
+    if (chunk0 >= in1) return;                            // block-uniform
+    // column sums over the rows of this sample: digit totals and the prefix over its earlier chunks
+    const int row0 = b * sg.cps;
+    for (int d = tid; d < nb; d += NT) {
+        int pre = 0, all = 0;
+        constexpr int U = 8;                              // row loads in flight per thread (the loop is latency bound)
+        const int* col = matrix + (long long)row0 * nb + d;
+        int r = 0;
+        for (; r + U <= sg.cps; r += U) {
+            int v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = col[(long long)(r + u) * nb];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { all += v[u]; if (r + u < c) pre += v[u]; }
+        }
+        for (; r < sg.cps; ++r) {
+            const int v = col[(long long)r * nb];
+            all += v;
+            if (r < c) pre += v;
+        }
+        pos0[d] = pre;
+        cnt[0][d] = all;                                  // parked: scanned below, then cleared again
+    }
+    __syncthreads();
+    // exclusive scan of the digit totals over d (nb <= 2 * NT: two values per thread)
+    {
+        const int d0 = 2 * tid, d1 = 2 * tid + 1;
+        const int a0 = d0 < nb ? cnt[0][d0] : 0, a1 = d1 < nb ? cnt[0][d1] : 0;
+        int total;
+        const int ex = fbbev_block_excl_scan_w<WAVES, false>(a0 + a1, ldsw, &total);
+        __syncthreads();
+        if (d0 < nb) { pos0[d0] += s0 + ex; cnt[0][d0] = 0; }
+        if (d1 < nb) { pos0[d1] += s0 + ex + a0; cnt[0][d1] = 0; }
+    }
+    __syncthreads();
+    const long long chunk = chunk0 + (long long)wave * (64 * ROUNDS);
+    unsigned int k[ROUNDS], v[ROUNDS];
+    int lr[ROUNDS];
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const long long idx = chunk + r * 64 + lane;
+        const bool valid = idx < in1;
+        k[r] = valid ? keys_in[idx] : FBBEV_DROP_KEY;
+        v[r] = valid ? (vals_in ? vals_in[idx] : (unsigned int)idx) : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const bool valid = k[r] != FBBEV_DROP_KEY;
+        lr[r] = -1;
+        const unsigned int d = ((k[r] - kbase) >> shift) & dmask;
+        unsigned long long mm = __ballot(valid ? 1 : 0);
+#pragma unroll
+        for (int bit = 0; bit < FBBEV_SEG_RB; ++bit) {
+            if (bit < rb) {
+                const unsigned long long bb = __ballot((int)((d >> bit) & 1u));
+                mm &= ((d >> bit) & 1u) ? bb : ~bb;
+            }
+        }
+        const int leader = valid ? (__ffsll((long long)mm) - 1) : lane;
+        int prev = 0;
+        if (valid && lane == leader) {
+            prev = cnt[wave][d];
+            cnt[wave][d] = prev + __popcll(mm);
+        }
+        prev = __shfl(prev, leader, 64);
+        if (valid) lr[r] = prev + __popcll(mm & lt);
+    }
+    __syncthreads();
+    for (int d = tid; d < nb; d += NT) {                 // in place: count -> first position of the wave's keys of digit d
+        int run = pos0[d];
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) { const int t = cnt[w][d]; cnt[w][d] = run; run += t; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        if (lr[r] >= 0) {
+            const unsigned int d = ((k[r] - kbase) >> shift) & dmask;
+            const int pos = cnt[wave][d] + lr[r];
+            keys_out[pos] = k[r];
+            vals_out[pos] = v[r];
+        }
+    }
+}
+
 // ---------------------------------------------------------------- camera-parameter key of the cached index set
 // The index tensors depend only on the camera parameters (and on the module's static grid / frustum): SURVEY 8f-2,
 // view_transformer.py:607-611 (`pre_compute`, disabled upstream because nothing invalidates it).  One workgroup compares

@@ -129,6 +129,7 @@ template <class T> inline T shfl_src(T v, int src_lane_or_neg) {
 inline void __syncthreads() { emu::block_barrier(); }
 template <class T> inline T __shfl_xor(T v, int mask, int = 64) { return emu::shfl_src(v, (emu::S().cur & 63) ^ mask); }
 template <class T> inline T __shfl_up(T v, int d, int = 64) { return emu::shfl_src(v, (emu::S().cur & 63) - d); }
+template <class T> inline T __shfl_down(T v, int d, int = 64) { return emu::shfl_src(v, (emu::S().cur & 63) + d); }
 template <class T> inline T __shfl(T v, int src, int = 64) { return emu::shfl_src(v, src & 63); }
 inline unsigned long long __ballot(int pred) {
     emu::State& s = emu::S();

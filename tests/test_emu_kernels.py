@@ -806,6 +806,50 @@ def test_rank_build_every_chunk_variant_emulated(shape, monkeypatch):
     _assert_index_equal(got, exp)
 
 
+@pytest.mark.parametrize('name,B', [('TINY', 2), ('SMALL', 2), ('SMALL', 3), ('REF', 1)])
+def test_segmented_sort_equals_global_sort_and_oracle_emulated(name, B, monkeypatch):
+    """Round 3: the per-sample (segmented) sort -- sample-aligned chunks, digits of (key - b V), two passes of <= 10 bits, 6
+    launches -- against the global 8-bit LSD sort and the oracle: the same index tensors, bit for bit, through BOTH key
+    sources (camera geometry and a materialised coor), partial last chunks and one- and two-pass digit plans included."""
+    monkeypatch.setenv('FBBEV_RANK_SEG', '0')
+    glob_, exp = _lift_vs_oracle(name, B)
+    _assert_index_equal(glob_, exp)
+    monkeypatch.setenv('FBBEV_RANK_SEG', '2')
+    seg, _ = _lift_vs_oracle(name, B)
+    _assert_index_equal(seg, exp)
+    P, I = seg[6].tolist()
+    for a, b_ in zip(seg[:3], glob_[:3]):
+        assert torch.equal(a[:P], b_[:P])
+    for a, b_ in zip(seg[3:6], glob_[3:6]):
+        assert torch.equal(a[:I], b_[:I])
+    # the two-step contract path (keys from coor)
+    cfg, vt, coor, depth, feat = _case(name, B)
+    got = E.rank_build(coor, *_grid3(vt))
+    erb, erd, erf, est, eln = vt.voxel_pooling_prepare_v2(coor)
+    _assert_index_equal(got, (erb, erd, erf, est, eln))
+
+
+def test_segmented_sort_with_depth_filter_and_empty_samples_emulated(monkeypatch):
+    """Data-dependent P (BEVDet-era `depth > 0.01` filter) and a sample without a single kept point: segment ranges of
+    length 0, chunks that return at once, count-matrix rows of zeros."""
+    monkeypatch.setenv('FBBEV_RANK_SEG', '2')
+    cfg, vt, coor, depth, feat = _case('SMALL', 3)
+    coor = coor.clone()
+    coor[1] = 1.0e6                                           # sample 1: every point outside the grid
+    d = depth.clone()
+    d[d < d.median()] = 0.0
+    got = E.rank_build(coor, *_grid3(vt), depth=d, depth_threshold=0.01)
+    monkeypatch.setenv('FBBEV_RANK_SEG', '0')
+    ref = E.rank_build(coor, *_grid3(vt), depth=d, depth_threshold=0.01)
+    P, I = got[6].tolist()
+    assert (P, I) == tuple(ref[6].tolist()) and P > 0
+    for a, b_ in zip(got[:3], ref[:3]):
+        assert torch.equal(a[:P], b_[:P])
+    for a, b_ in zip(got[3:6], ref[3:6]):
+        assert torch.equal(a[:I], b_[:I])
+    assert not ((got[0][:P] >= 20000) & (got[0][:P] < 40000)).any()      # nothing of sample 1 (SMALL: 50x50x8 voxels per sample)
+
+
 def test_rank_build_fat_chunks_at_bench_scale_emulated():
     """n = 0.75 M points (BL2, 3 samples): the launcher itself picks 16-wave chunks for pass 0 and the 1024-thread interval
     kernels -- many full chunks per pass, bit-exact against the oracle on the emulator."""
