@@ -53,6 +53,8 @@ SIGNATURES = {
     'fbbev_history_conv_e': (c_int, [c_void_p, c_int64] + [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     'fbbev_history_conv_bf16': (c_int, [c_void_p, c_int64] + [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
     'fbbev_history_conv_vm': (c_int, [c_void_p, c_int64] + [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    'fbbev_history_fused_vm': (c_int, [c_void_p, c_int64, c_void_p, c_int64] + [c_void_p] * 5 + [c_int] * 7 +
+                               [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     'fbbev_history_warp_vm': (c_int, [c_void_p, c_int64, c_void_p] + [c_int] * 6 + [c_void_p, c_int64, c_int, c_void_p]),
     'fbbev_history_frame_vm': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_int, c_void_p]),
     'fbbev_conv3d_ndhwc': (c_int, [c_void_p] * 4 + [c_int] * 14 + [c_void_p, c_void_p]),
@@ -625,6 +627,31 @@ def history_warp_vm(history, rt_flow, out, grid_zyx):
                                            _dev(rt_flow, F32, 'rt_flow'), B, T, C, Z, Y, X,
                                            _dev(out, out.dtype, 'out', contiguous=False), out.stride(0),
                                            ELEM_TYPE[history.dtype], _stream()), 'fbbev_history_warp_vm')
+    return out
+
+
+def history_fused_vm(history, rt_flow, nxt, grid_zyx, w1, bias1, w2, bias2, out):
+    """Warp + new ring + both convolutions in one launch (fbbev_history_fused_vm): history (B,T,N,C) and nxt (B,T+1,N,C)
+    voxel-major bf16 / f16 rings (nxt[:, 0] = the current frame, already stored), w1 (C,C), bias1 (B*(T+1), C), w2 (Cout,(T+1)C),
+    bias2 (Cout), out (B,Cout,N) f32.  Writes nxt[:, 1:] (== history_warp_vm) and out (== history_conv(nxt, ..., bfloat16))."""
+    B, T, N, C = history.shape
+    Z, Y, X = grid_zyx
+    Cout = w2.shape[0]
+    if tuple(nxt.shape) != (B, T + 1, N, C) or N != Z * Y * X or tuple(out.shape) != (B, Cout, N):
+        raise FbbevError('history_fused_vm: nxt must be (B,T+1,N,C), out (B,Cout,N), N = Z*Y*X')
+    if history.dtype not in (torch.bfloat16, torch.float16) or nxt.dtype != history.dtype:
+        raise FbbevError('history_fused_vm: 16-bit rings of one type')
+    for t, n in ((history, 'history'), (nxt, 'nxt')):
+        if t.stride()[1:] != (N * C, C, 1):
+            raise FbbevError(f'{n}: the (T,N,C) block of a sample must be contiguous')
+    ws = torch.empty((2 + T) * C * max(C, Cout, 96), dtype=torch.float32, device=history.device)   # fragment-ordered weights
+    with _on(history):
+        _check(lib().fbbev_history_fused_vm(
+            _dev(history, history.dtype, 'history', contiguous=False), history.stride(0),
+            _dev(nxt, nxt.dtype, 'nxt', contiguous=False), nxt.stride(0), _dev(rt_flow, F32, 'rt_flow'), _dev(w1, F32, 'w1'),
+            _dev(bias1, F32, 'bias1'), _dev(w2, F32, 'w2'), _dev(bias2, F32, 'bias2'), B, T, C, Cout, Z, Y, X,
+            _dev(out, F32, 'out'), c_void_p(ws.data_ptr()), ws.numel() * 4, ELEM_TYPE[history.dtype], _stream()),
+            'fbbev_history_fused_vm')
     return out
 
 

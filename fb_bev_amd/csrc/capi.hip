@@ -13,6 +13,7 @@
 #include "history_kernels.h"
 #include "norm_kernels.h"
 #include "history_conv_kernels.h"
+#include "history_fused_kernels.h"
 #include "conv3d_kernels.h"
 #include "../../include/fbbev.h"
 
@@ -1513,8 +1514,15 @@ extern "C" int fbbev_history_warp_vm(const void* history, long long history_stri
     if (blocks >= (1ll << 31) - 8) return FBBEV_E_UNSUPPORTED;
     const int per_xcd = (int)((blocks + 7) / 8);
     fbbev_rt_stream stream = (fbbev_rt_stream)stream_;
+    // occupancy experiment knob (round 3, profiles/r03_exp_history_occupancy.jsonl): dynamic LDS the kernel does not use, in KB
+    static const size_t warp_pad = [] { const char* e = getenv("FBBEV_HISTORY_WARP_LDS_PAD_KB"); return e ? (size_t)atoi(e) * 1024 : (size_t)0; }();
+    if (warp_pad > 64 * 1024) {
+        fbbev_rt_allow_dyn_lds((const void*)k_history_warp_vm<0, TU, 1>, warp_pad);
+        fbbev_rt_allow_dyn_lds((const void*)k_history_warp_vm<1, TU, 1>, warp_pad);
+        fbbev_rt_allow_dyn_lds((const void*)k_history_warp_vm<2, TU, 1>, warp_pad);
+    }
 #define FBBEV_HWVM(ET_, ST_)                                                                                                 \
-    FBBEV_LAUNCH((k_history_warp_vm<ET_, TU, ST_>), (long long)per_xcd * 8, 256, 0, stream, history, history_stride_b, rt_flow, \
+    FBBEV_LAUNCH((k_history_warp_vm<ET_, TU, ST_>), (long long)per_xcd * 8, 256, warp_pad, stream, history, history_stride_b, rt_flow, \
                  T, C, Z, Y, X, groups, n_xc, YB, nyb, per_xcd, (int)blocks, out, out_stride_b)
     // ST = 1: non-temporal ring stores (A/B on one box: 4.0 vs 4.2 ms at 400x400x16, 0.56 vs 0.61 ms at 100x100x8 B=4)
     if (elem_type == 0) FBBEV_HWVM(0, 1);
@@ -1633,7 +1641,12 @@ static int history_conv_bf16_launch(const void* feats, long long feats_stride_b,
     const int nfrag = (MT1 * KS + T1 * MT2 * KS) * 64;
     FBBEV_LAUNCH(k_history_weight_fragments_bf16, (nfrag + 255) / 256, 256, 0, stream, w1, w2, MT1, MT2, C, T1, w1f);
     const size_t a2s = (size_t)((MT2 * KS * 64 + 255) / 256) * 256 * 8;                                 // padded staging buffer
-    const size_t lds = (2 * a2s + (size_t)4 * 16 * (KS * 32 + 8)) * sizeof(unsigned short);           // W2_t x 2 + Y rows
+    size_t lds = (2 * a2s + (size_t)4 * 16 * (KS * 32 + 8)) * sizeof(unsigned short);           // W2_t x 2 + Y rows
+    static const size_t conv_pad = [] { const char* e = getenv("FBBEV_HISTORY_CONV_LDS_PAD_KB"); return e ? (size_t)atoi(e) * 1024 : (size_t)0; }();   // occupancy experiment knob
+    if (conv_pad > lds) {
+        lds = conv_pad;
+        if (lds > 64 * 1024) fbbev_rt_allow_dyn_lds((const void*)k_history_conv_bf16<5, 5, ET, VM>, lds);
+    }
     if (C == 80)
         FBBEV_LAUNCH((k_history_conv_bf16<5, 5, ET, VM>), blocks, 256, lds, stream, feats, feats_stride_b,
                      (const unsigned short*)w1f, bias1, (const unsigned short*)w2f, bias2, T1, N, tiles_per_b, out);
@@ -1663,6 +1676,60 @@ extern "C" int fbbev_history_conv_bf16(const void* feats, long long feats_stride
     if (voxel_major) return elem_type == 0 ? FBBEV_HCB(0, true) : elem_type == 1 ? FBBEV_HCB(1, true) : FBBEV_HCB(2, true);
     return elem_type == 0 ? FBBEV_HCB(0, false) : elem_type == 1 ? FBBEV_HCB(1, false) : FBBEV_HCB(2, false);
 #undef FBBEV_HCB
+}
+
+// Warp + new ring + both convolutions in ONE kernel (k_history_fused_bf16): history (B,T,N,C) -> next ring slots 1..T of
+// `next` (B,T+1,N,C) (slot 0 = the current frame, stored by the caller with fbbev_history_frame_vm BEFORE this call) and
+// out (B,Cout,N) = relu(bias2 + sum_t w2_t . relu(w1 . x_t + bias1_t)) over the T+1 frames of `next`, bf16 MFMA.
+extern "C" int fbbev_history_fused_vm(const void* history, long long history_stride_b, void* next, long long next_stride_b,
+                                      const float* rt_flow, const float* w1, const float* bias1, const float* w2,
+                                      const float* bias2, int B, int T, int C, int Cout, int Z, int Y, int X, float* out,
+                                      void* workspace, size_t workspace_bytes, int elem_type, fbbev_stream_t stream_) {
+    if (B < 0 || T <= 0 || C <= 0 || Cout <= 0 || Z <= 0 || Y <= 0 || X <= 0) return FBBEV_E_BADARG;
+    if (B == 0) return 0;
+    if (!history || !next || !rt_flow || !w1 || !bias1 || !w2 || !bias2 || !out) return FBBEV_E_BADARG;
+    if (C != 80 || Cout != 80 || (elem_type != 1 && elem_type != 2) || Z < 2 || Y < 2 || X < 2) return FBBEV_E_UNSUPPORTED;
+    const long long N = (long long)Z * Y * X, frame = N * C;
+    const int T1 = T + 1;
+    if (history_stride_b == 0) history_stride_b = (long long)T * frame;
+    if (next_stride_b == 0) next_stride_b = (long long)T1 * frame;
+    if (history_stride_b < (long long)T * frame || next_stride_b < (long long)T1 * frame) return FBBEV_E_BADARG;
+    if (history_stride_b % 8 != 0 || next_stride_b % 8 != 0 || !aligned16(history) || !aligned16(next) || !aligned16(bias1))
+        return FBBEV_E_UNSUPPORTED;
+    if (frame * 2 >= (1ll << 32) || N >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;              // 32-bit byte offsets inside a frame
+    constexpr int MT = 5, KS = 3;
+    const size_t need = ((size_t)MT * KS + (size_t)T1 * MT * KS) * 64 * 8 * sizeof(unsigned short);
+    if (!workspace || !aligned16(workspace) || workspace_bytes < need) return FBBEV_E_WORKSPACE;
+    fbbev_rt_stream stream = (fbbev_rt_stream)stream_;
+    unsigned short* w1f = static_cast<unsigned short*>(workspace);
+    unsigned short* w2f = w1f + (size_t)MT * KS * 64 * 8;
+    const int nfrag = (MT * KS + T1 * MT * KS) * 64;
+    FBBEV_LAUNCH(k_history_weight_fragments_bf16, (nfrag + 255) / 256, 256, 0, stream, w1, w2, MT, MT, C, T1, w1f);
+    FBBEV_CHECK_LAUNCH();
+    const int n_xc = (X + 63) / 64;                               // 64-voxel tiles per grid row
+    int YB = 128 / Z;                                             // (z, y) slabs per x chunk, as the warp kernel orders its workgroups
+    if (YB < 1) YB = 1;
+    if (YB > Y) YB = Y;
+    const int nyb = (Y + YB - 1) / YB;
+    const long long blocks = (long long)B * nyb * n_xc * YB * Z;
+    if (blocks >= (1ll << 31) - 8) return FBBEV_E_UNSUPPORTED;
+    const int per_xcd = (int)((blocks + 7) / 8);
+    constexpr int A2S = ((MT * KS * 64 + 255) / 256) * 256 * 8;
+    // 4 W2 buffers + the W1 fragments + the Y rows + 4 operand tiles: 137 KB (one 1024-thread workgroup per CU)
+    const size_t lds = ((size_t)4 * A2S + (size_t)MT * KS * 64 * 8 + (size_t)4 * 16 * (KS * 32 + 8) + (size_t)4 * 64 * FBBEV_HF_XP) *
+                       sizeof(unsigned short) + (size_t)4 * 80 * sizeof(float);
+#define FBBEV_HF(ET_)                                                                                                  \
+    do {                                                                                                              \
+        int e_ = fbbev_rt_allow_dyn_lds((const void*)k_history_fused_bf16<ET_>, lds);                                  \
+        if (e_) return e_;                                                                                            \
+        FBBEV_LAUNCH((k_history_fused_bf16<ET_>), (long long)per_xcd * 8, 1024, lds, stream, history, history_stride_b, \
+                     next, next_stride_b, rt_flow, (const unsigned short*)w1f, bias1, (const unsigned short*)w2f, bias2, \
+                     T1, Z, Y, X, n_xc, YB, nyb, per_xcd, (int)blocks, out);                                           \
+    } while (0)
+    if (elem_type == 1) FBBEV_HF(1); else FBBEV_HF(2);
+#undef FBBEV_HF
+    FBBEV_CHECK_LAUNCH();
+    return 0;
 }
 
 // the fp32-MFMA convolutions on a voxel-major ring (feats (B, T1, N, C)); C = Cout in {16, 80}, workspace required

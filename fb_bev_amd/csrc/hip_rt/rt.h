@@ -120,6 +120,24 @@ __device__ __forceinline__ fbbev_v4f fbbev_mfma_f32_16x16x32_bf16(fbbev_bf16x8 a
 // instruction-scheduling fence: nothing is moved across it (keeps prefetch loads ahead of the MFMA block they overlap)
 __device__ __forceinline__ void fbbev_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 
+// ONE correctly rounded fp32 operation that is never fused with a neighbour.  HIP's __fmul_rn / __fadd_rn are plain `x * y` /
+// `x + y` (no OCML_BASIC_ROUNDED_OPERATIONS) and inherit -ffp-contract=fast: after inlining, a product feeding a sum may
+// still become an fma -- or not, depending on the surrounding kernel.  Here the operations are built without the `contract`
+// flag (the pragma is per instruction and survives inlining), so kernels that must agree bit for bit can share a formula.
+__device__ __forceinline__ float fbbev_mul(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ float fbbev_add(float a, float b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+__device__ __forceinline__ float fbbev_sub(float a, float b) {
+#pragma clang fp contract(off)
+    return a - b;
+}
+__device__ __forceinline__ float fbbev_div(float a, float b) { return __fdiv_rn(a, b); }
+
 // value barrier: the compiler must materialise x here and may not look through it (used where an LDS load followed by a
 // conditional global override of the same variable was if-converted into ONE flat load of a selected pointer)
 __device__ __forceinline__ void fbbev_opaque(int& x) { asm volatile("" : "+v"(x)); }

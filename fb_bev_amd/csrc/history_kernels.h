@@ -84,6 +84,42 @@ k_history_flow(const float* __restrict__ hist_augs, const float* __restrict__ eg
 }
 
 // work item = ((b * n_groups) + group) * n_chunks + chunk
+// The 8 trilinear taps of output voxel (x, y, z) under the sample's rt_flow `m` (4x4 row-major): voxel index of each tap in
+// the source frame (0 for a tap outside the grid) and its weight (0 outside).  fbocc.py:205 rt_flow @ (x,y,z,1); :208-209
+// normalise; ATen grid_sampler_unnormalize (align_corners=True) -- the reference's normalise / un-normalise round trip is
+// repeated so that the coordinates carry the same rounding.  Every operation is ONE correctly rounded fp32 operation
+// (fbbev_mul / fbbev_add / fbbev_sub / fbbev_div of rt.h: built without the `contract` flag): the planar kernel, the voxel-major kernel and the fused warp-and-convolution kernel call
+// this one function and therefore blend the same taps with the same weights whatever code surrounds the call -- with plain
+// `a * b + c` the compiler contracts differently from kernel to kernel and the rings differed in the last bit.
+// Tap order tnw,tne,tsw,tse,bnw,bne,bsw,bse: x fastest, then y, then z.  NaN / huge coordinates fail every bounds test =>
+// all weights 0 => output 0 (zero padding).
+__device__ __forceinline__ void fbbev_warp_taps(const float* __restrict__ m, int x, int y, int z, int X, int Y, int Z,
+                                                int (&tv)[8], float (&w)[8]) {
+    const float fx = (float)x, fy = (float)y, fz = (float)z;
+    float gx = fbbev_add(fbbev_add(fbbev_add(fbbev_mul(m[0], fx), fbbev_mul(m[1], fy)), fbbev_mul(m[2], fz)), m[3]);
+    float gy = fbbev_add(fbbev_add(fbbev_add(fbbev_mul(m[4], fx), fbbev_mul(m[5], fy)), fbbev_mul(m[6], fz)), m[7]);
+    float gz = fbbev_add(fbbev_add(fbbev_add(fbbev_mul(m[8], fx), fbbev_mul(m[9], fy)), fbbev_mul(m[10], fz)), m[11]);
+    gx = fbbev_sub(fbbev_mul(fbbev_div(gx, (float)(X - 1)), 2.0f), 1.0f);
+    gy = fbbev_sub(fbbev_mul(fbbev_div(gy, (float)(Y - 1)), 2.0f), 1.0f);
+    gz = fbbev_sub(fbbev_mul(fbbev_div(gz, (float)(Z - 1)), 2.0f), 1.0f);
+    const float ix = fbbev_mul(fbbev_div(fbbev_add(gx, 1.f), 2.f), (float)(X - 1));
+    const float iy = fbbev_mul(fbbev_div(fbbev_add(gy, 1.f), 2.f), (float)(Y - 1));
+    const float iz = fbbev_mul(fbbev_div(fbbev_add(gz, 1.f), 2.f), (float)(Z - 1));
+    const float x0f = floorf(ix), y0f = floorf(iy), z0f = floorf(iz);
+    const float wx1 = fbbev_sub(ix, x0f), wy1 = fbbev_sub(iy, y0f), wz1 = fbbev_sub(iz, z0f);
+    const float wx0 = fbbev_sub(fbbev_add(x0f, 1.f), ix), wy0 = fbbev_sub(fbbev_add(y0f, 1.f), iy), wz0 = fbbev_sub(fbbev_add(z0f, 1.f), iz);
+    const bool fin = (fabsf(ix) < 1.0e9f) && (fabsf(iy) < 1.0e9f) && (fabsf(iz) < 1.0e9f);
+    const int x0 = fin ? (int)x0f : -2, y0 = fin ? (int)y0f : -2, z0 = fin ? (int)z0f : -2;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int cx = x0 + (k & 1), cy = y0 + ((k >> 1) & 1), cz = z0 + (k >> 2);
+        const bool ok = cx >= 0 && cx < X && cy >= 0 && cy < Y && cz >= 0 && cz < Z;
+        const float wk = fbbev_mul(fbbev_mul((k & 1) ? wx1 : wx0, ((k >> 1) & 1) ? wy1 : wy0), (k >> 2) ? wz1 : wz0);
+        tv[k] = ok ? (cz * Y + cy) * X + cx : 0;
+        w[k] = ok ? wk : 0.f;
+    }
+}
+
 template <int ET>
 __global__ void __launch_bounds__(256)
 k_history_warp(const void* __restrict__ hist, long long hist_stride_b, const float* __restrict__ flow, int CH,
@@ -100,34 +136,9 @@ k_history_warp(const void* __restrict__ hist, long long hist_stride_b, const flo
     const int v = chunk * 256 + threadIdx.x;
     if (v >= ZYX) return;
     const int z = v / YX, r = v - z * YX, y = r / X, x = r - y * X;
-    const float* m = flow + b * 16;
-    const float fx = (float)x, fy = (float)y, fz = (float)z;
-    // fbocc.py:205 rt_flow @ (x,y,z,1); :208-209 normalise; ATen grid_sampler_unnormalize (align_corners=True)
-    float gx = m[0] * fx + m[1] * fy + m[2] * fz + m[3];
-    float gy = m[4] * fx + m[5] * fy + m[6] * fz + m[7];
-    float gz = m[8] * fx + m[9] * fy + m[10] * fz + m[11];
-    gx = gx / (float)(X - 1) * 2.0f - 1.0f;
-    gy = gy / (float)(Y - 1) * 2.0f - 1.0f;
-    gz = gz / (float)(Z - 1) * 2.0f - 1.0f;
-    const float ix = ((gx + 1.f) / 2.f) * (float)(X - 1);
-    const float iy = ((gy + 1.f) / 2.f) * (float)(Y - 1);
-    const float iz = ((gz + 1.f) / 2.f) * (float)(Z - 1);
-    // taps; NaN / huge coordinates fail every bounds test below => all weights 0 => output 0 (zero padding)
-    const float x0f = floorf(ix), y0f = floorf(iy), z0f = floorf(iz);
-    const float wx1 = ix - x0f, wy1 = iy - y0f, wz1 = iz - z0f;
-    const float wx0 = (x0f + 1.f) - ix, wy0 = (y0f + 1.f) - iy, wz0 = (z0f + 1.f) - iz;
-    const bool fin = (fabsf(ix) < 1.0e9f) && (fabsf(iy) < 1.0e9f) && (fabsf(iz) < 1.0e9f);
-    const int x0 = fin ? (int)x0f : -2, y0 = fin ? (int)y0f : -2, z0 = fin ? (int)z0f : -2;
     int off[8];
     float w[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {                 // order tnw,tne,tsw,tse,bnw,bne,bsw,bse: x fastest, then y, then z
-        const int cx = x0 + (k & 1), cy = y0 + ((k >> 1) & 1), cz = z0 + (k >> 2);
-        const bool ok = cx >= 0 && cx < X && cy >= 0 && cy < Y && cz >= 0 && cz < Z;
-        const float wk = ((k & 1) ? wx1 : wx0) * (((k >> 1) & 1) ? wy1 : wy0) * ((k >> 2) ? wz1 : wz0);
-        off[k] = ok ? (cz * Y + cy) * X + cx : 0;
-        w[k] = ok ? wk : 0.f;
-    }
+    fbbev_warp_taps(flow + b * 16, x, y, z, X, Y, Z, off, w);
     const int c0 = grp * ch_per_block;
     const int c1 = (c0 + ch_per_block < CH) ? c0 + ch_per_block : CH;
     // element offsets of this workgroup's first channel (16-bit storage: the same offsets, half the bytes)
@@ -196,6 +207,18 @@ __device__ __forceinline__ fbbev_v4u fbbev_narrow_vec(const float* f) {         
     return r;
 }
 
+// Source taps of output voxel (x, y, z) under the sample's rt_flow `m` (4x4 row-major) on a voxel-major frame: byte offset
+// of the channel group starting at channel c0 in each of the 8 trilinear taps (0 for a tap outside the grid) and the tap
+// weights (0 outside).  EXACTLY the expression sequence of k_history_warp (the reference's normalise / un-normalise round
+// trip, fbocc.py:197-203,275), shared by k_history_warp_vm and the fused warp-and-convolution kernel: same taps, same weights.
+__device__ __forceinline__ void fbbev_warp_taps_vm(const float* __restrict__ m, int x, int y, int z, int X, int Y, int Z, int C,
+                                                   int c0, int esz, unsigned int (&ob)[8], float (&w)[8]) {
+    int tv[8];
+    fbbev_warp_taps(m, x, y, z, X, Y, Z, tv, w);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ob[k] = ((unsigned int)tv[k] * (unsigned int)C + (unsigned int)c0) * (unsigned int)esz;
+}
+
 // A workgroup = 256 (voxel, channel group) pairs of ONE grid row (x, group fastest: 25.6 voxels at C = 80 in 16 bits); a
 // thread walks the T frames of its sample TU at a time (the flow, hence the taps, is the sample's: set up once): uniform
 // frame base + 32-bit lane byte offsets, 8 TU loads in flight.
@@ -222,34 +245,9 @@ k_history_warp_vm(const void* __restrict__ hist, long long hist_stride_b, const 
     if (y >= Y || x >= X) return;
     const int YX = Y * X, ZYX = Z * YX;
     const int v = (z * Y + y) * X + x;
-    const float* m = flow + b * 16;
-    const float fx = (float)x, fy = (float)y, fz = (float)z;
-    // source coordinate and taps: EXACTLY the expression sequence of k_history_warp
-    float gx = m[0] * fx + m[1] * fy + m[2] * fz + m[3];
-    float gy = m[4] * fx + m[5] * fy + m[6] * fz + m[7];
-    float gz = m[8] * fx + m[9] * fy + m[10] * fz + m[11];
-    gx = gx / (float)(X - 1) * 2.0f - 1.0f;
-    gy = gy / (float)(Y - 1) * 2.0f - 1.0f;
-    gz = gz / (float)(Z - 1) * 2.0f - 1.0f;
-    const float ix = ((gx + 1.f) / 2.f) * (float)(X - 1);
-    const float iy = ((gy + 1.f) / 2.f) * (float)(Y - 1);
-    const float iz = ((gz + 1.f) / 2.f) * (float)(Z - 1);
-    const float x0f = floorf(ix), y0f = floorf(iy), z0f = floorf(iz);
-    const float wx1 = ix - x0f, wy1 = iy - y0f, wz1 = iz - z0f;
-    const float wx0 = (x0f + 1.f) - ix, wy0 = (y0f + 1.f) - iy, wz0 = (z0f + 1.f) - iz;
-    const bool fin = (fabsf(ix) < 1.0e9f) && (fabsf(iy) < 1.0e9f) && (fabsf(iz) < 1.0e9f);
-    const int x0 = fin ? (int)x0f : -2, y0 = fin ? (int)y0f : -2, z0 = fin ? (int)z0f : -2;
     unsigned int ob[8];                                 // byte offset of the tap's channel group inside a frame (< 4 GiB: checked)
     float w[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int cx = x0 + (k & 1), cy = y0 + ((k >> 1) & 1), cz = z0 + (k >> 2);
-        const bool ok = cx >= 0 && cx < X && cy >= 0 && cy < Y && cz >= 0 && cz < Z;
-        const float wk = ((k & 1) ? wx1 : wx0) * (((k >> 1) & 1) ? wy1 : wy0) * ((k >> 2) ? wz1 : wz0);
-        const unsigned int tv = ok ? (unsigned int)((cz * Y + cy) * X + cx) : 0u;
-        ob[k] = (tv * (unsigned int)C + (unsigned int)(gq * VE)) * ESZ;
-        w[k] = ok ? wk : 0.f;
-    }
+    fbbev_warp_taps_vm(flow + b * 16, x, y, z, X, Y, Z, C, gq * VE, ESZ, ob, w);
     const size_t frame_bytes = (size_t)ZYX * C * ESZ;
     const char* src = static_cast<const char*>(hist) + (size_t)b * hist_stride_b * ESZ;
     char* dst = static_cast<char*>(out) + (size_t)b * out_stride_b * ESZ + ((size_t)v * C + gq * VE) * ESZ;
@@ -350,15 +348,16 @@ k_history_warp_lds(const void* __restrict__ hist, long long hist_stride_b, const
     const float* m = flow + b * 16;
     // source coordinate of an output voxel: EXACTLY the expression sequence of k_history_warp
     auto src = [&](float fx, float fy, float fz, float& ix, float& iy, float& iz) {
-        float gx = m[0] * fx + m[1] * fy + m[2] * fz + m[3];
-        float gy = m[4] * fx + m[5] * fy + m[6] * fz + m[7];
-        float gz = m[8] * fx + m[9] * fy + m[10] * fz + m[11];
-        gx = gx / (float)(X - 1) * 2.0f - 1.0f;
-        gy = gy / (float)(Y - 1) * 2.0f - 1.0f;
-        gz = gz / (float)(Z - 1) * 2.0f - 1.0f;
-        ix = ((gx + 1.f) / 2.f) * (float)(X - 1);
-        iy = ((gy + 1.f) / 2.f) * (float)(Y - 1);
-        iz = ((gz + 1.f) / 2.f) * (float)(Z - 1);
+        // single correctly rounded operations, as fbbev_warp_taps (no contraction: the same coordinates in every kernel)
+        float gx = fbbev_add(fbbev_add(fbbev_add(fbbev_mul(m[0], fx), fbbev_mul(m[1], fy)), fbbev_mul(m[2], fz)), m[3]);
+        float gy = fbbev_add(fbbev_add(fbbev_add(fbbev_mul(m[4], fx), fbbev_mul(m[5], fy)), fbbev_mul(m[6], fz)), m[7]);
+        float gz = fbbev_add(fbbev_add(fbbev_add(fbbev_mul(m[8], fx), fbbev_mul(m[9], fy)), fbbev_mul(m[10], fz)), m[11]);
+        gx = fbbev_sub(fbbev_mul(fbbev_div(gx, (float)(X - 1)), 2.0f), 1.0f);
+        gy = fbbev_sub(fbbev_mul(fbbev_div(gy, (float)(Y - 1)), 2.0f), 1.0f);
+        gz = fbbev_sub(fbbev_mul(fbbev_div(gz, (float)(Z - 1)), 2.0f), 1.0f);
+        ix = fbbev_mul(fbbev_div(fbbev_add(gx, 1.f), 2.f), (float)(X - 1));
+        iy = fbbev_mul(fbbev_div(fbbev_add(gy, 1.f), 2.f), (float)(Y - 1));
+        iz = fbbev_mul(fbbev_div(fbbev_add(gz, 1.f), 2.f), (float)(Z - 1));
     };
     // bounding box of the brick's sources (uniform: every thread evaluates the 8 corners)
     const int X1 = (X0 + TX < X ? X0 + TX : X) - 1, Y1 = (Y0 + TY < Y ? Y0 + TY : Y) - 1, Z1 = (Z0 + BZ < Z ? Z0 + BZ : Z) - 1;
@@ -412,8 +411,8 @@ k_history_warp_lds(const void* __restrict__ hist, long long hist_stride_b, const
         float ix, iy, iz;
         src((float)x, (float)y, (float)z, ix, iy, iz);
         const float x0f = floorf(ix), y0f = floorf(iy), z0f = floorf(iz);
-        const float wx1 = ix - x0f, wy1 = iy - y0f, wz1 = iz - z0f;
-        const float wx0 = (x0f + 1.f) - ix, wy0 = (y0f + 1.f) - iy, wz0 = (z0f + 1.f) - iz;
+        const float wx1 = fbbev_sub(ix, x0f), wy1 = fbbev_sub(iy, y0f), wz1 = fbbev_sub(iz, z0f);
+        const float wx0 = fbbev_sub(fbbev_add(x0f, 1.f), ix), wy0 = fbbev_sub(fbbev_add(y0f, 1.f), iy), wz0 = fbbev_sub(fbbev_add(z0f, 1.f), iz);
         const bool fin = (fabsf(ix) < 1.0e9f) && (fabsf(iy) < 1.0e9f) && (fabsf(iz) < 1.0e9f);
         const int x0 = fin ? (int)x0f : -2, y0 = fin ? (int)y0f : -2, z0 = fin ? (int)z0f : -2;
         const int base = ((z0 - b0[2]) * bys + (y0 - b0[1])) * FBBEV_HW_PITCH + (x0 - b0[0]);
@@ -421,7 +420,7 @@ k_history_warp_lds(const void* __restrict__ hist, long long hist_stride_b, const
         for (int k = 0; k < 8; ++k) {                 // order tnw,tne,tsw,tse,bnw,bne,bsw,bse: x fastest, then y, then z
             const int cx = x0 + (k & 1), cy = y0 + ((k >> 1) & 1), cz = z0 + (k >> 2);
             const bool ok = cx >= 0 && cx < X && cy >= 0 && cy < Y && cz >= 0 && cz < Z;
-            const float wk = ((k & 1) ? wx1 : wx0) * (((k >> 1) & 1) ? wy1 : wy0) * ((k >> 2) ? wz1 : wz0);
+            const float wk = fbbev_mul(fbbev_mul((k & 1) ? wx1 : wx0, ((k >> 1) & 1) ? wy1 : wy0), (k >> 2) ? wz1 : wz0);
             w[v][k] = ok ? wk : 0.f;
             // inside the staged box?  (always, for a valid tap, unless the slack was exceeded)
             const bool inbox = ok && cx >= b0[0] && cx < b0[0] + bxs && cy >= b0[1] && cy < b0[1] + bys &&

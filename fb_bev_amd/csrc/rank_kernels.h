@@ -26,9 +26,9 @@ struct fbbev_grid_params {
 // is the sort key and, above 2^24, decides which voxels collide.
 __device__ __forceinline__ unsigned int fbbev_rank_key(float cx, float cy, float cz, const fbbev_grid_params& gp,
                                                        float bf, unsigned int sentinel) {
-    const float fx = __fdiv_rn(__fsub_rn(cx, gp.lx), gp.ix);
-    const float fy = __fdiv_rn(__fsub_rn(cy, gp.ly), gp.iy);
-    const float fz = __fdiv_rn(__fsub_rn(cz, gp.lz), gp.iz);
+    const float fx = __fdiv_rn(fbbev_sub(cx, gp.lx), gp.ix);
+    const float fy = __fdiv_rn(fbbev_sub(cy, gp.ly), gp.iy);
+    const float fz = __fdiv_rn(fbbev_sub(cz, gp.lz), gp.iz);
     // .long(): truncation toward zero.  |f| >= 2^31 or NaN can never be inside the grid.
     const bool finite = (fx == fx) && (fy == fy) && (fz == fz) && fabsf(fx) < 2.0e9f &&
                         fabsf(fy) < 2.0e9f && fabsf(fz) < 2.0e9f;
@@ -38,10 +38,10 @@ __device__ __forceinline__ unsigned int fbbev_rank_key(float cx, float cy, float
     // kept: integer >= 0 and (float)v < grid_size (long vs 0-dim fp32 tensor compares in fp32)
     const bool kept = finite && vx >= 0 && vy >= 0 && vz >= 0 && (float)vx < gp.gx &&
                       (float)vy < gp.gy && (float)vz < gp.gz;
-    float r = __fmul_rn(bf, gp.f_zyx);
-    r = __fadd_rn(r, __fmul_rn((float)vz, gp.f_yx));
-    const float t = __fadd_rn(__fmul_rn((float)vy, gp.gx), (float)vx);
-    r = __fadd_rn(r, t);
+    float r = fbbev_mul(bf, gp.f_zyx);
+    r = fbbev_add(r, fbbev_mul((float)vz, gp.f_yx));
+    const float t = fbbev_add(fbbev_mul((float)vy, gp.gx), (float)vx);
+    r = fbbev_add(r, t);
     return kept ? (unsigned int)(int)r : sentinel;
 }
 

@@ -49,6 +49,8 @@ class TemporalHistoryFusion(nn.Module):
             MConv3d(C * (T + 1), out_c, kernel_size=1, padding=0, stride=1), nn.SyncBatchNorm(out_c),
             nn.ReLU(inplace=True))
         self.use_mfma_convs = True          # inference: both 1x1x1 convs in one fp32-MFMA kernel when the channels allow
+        self.fused_warp_conv = True         # inference, 16-bit voxel-major ring + bf16 convolutions (C = 80): warp and both
+                                            # convolutions in one kernel (fbbev_history_fused_vm)
         self.train_rows = True              # training on a GPU: the two convolutions on voxel rows (_fuse_train_rows); False =
                                             # the reference's literal op sequence (cat / reshape / Conv3d modules)
         # Storage type of the inference history ring (T+1 frames per sample): float32 (the reference), or float16 / bfloat16
@@ -296,10 +298,16 @@ class TemporalHistoryFusion(nn.Module):
             _capi.history_frame_vm(curr_zyx.view(B, C, n), nxt[:, 0])
         else:
             _capi.history_frame_vm(curr_yxz.contiguous().view(B, C, n), nxt[:, 0], inner=Z)
-        _capi.history_warp_vm(hist, flow, nxt[:, 1:], (Z, Y, X))                            # slots 1..T (:275)
         w1, wt, b1, w2, b2 = self._folded_pair()
         tau = (sweep * self.history_cam_sweep_freq).reshape(B * (T + 1), 1)
         bias1 = b1[None, :] + tau * wt[None, :]                        # folded bias + scale * W[:, C] * tau, (B*(T+1), C)
+        if (self.fused_warp_conv and self.history_compute == torch.bfloat16 and C == 80 and w2.shape[0] == 80
+                and nxt.dtype in (torch.bfloat16, torch.float16) and min(Z, Y, X) >= 2):
+            # one launch: warp into slots 1..T and both convolutions from an LDS tile (the T new frames are not read back)
+            out = _capi.history_fused_vm(hist, flow, nxt, (Z, Y, X), w1, bias1.contiguous(), w2, b2,
+                                         torch.empty((B, 80, n), dtype=torch.float32, device=curr_yxz.device))
+            return out.view(B, -1, Z, Y, X), nxt
+        _capi.history_warp_vm(hist, flow, nxt[:, 1:], (Z, Y, X))                            # slots 1..T (:275)
         out = _capi.history_conv(nxt, w1, bias1, w2, b2,
                                  torch.empty((B, w2.shape[0], n), dtype=torch.float32, device=curr_yxz.device),
                                  compute=self.history_compute, voxel_major=True)

@@ -483,6 +483,19 @@ int fbbev_history_conv_bf16(const void* feats, long long feats_stride_b, const f
 int fbbev_history_conv_vm(const void* feats, long long feats_stride_b, const float* w1, const float* bias1, const float* w2,
                           const float* bias2, int B, int T1, int C, int Cout, int N, float* out, void* workspace,
                           size_t workspace_bytes, int elem_type, fbbev_stream_t stream);
+
+/* Round 3 -- warp, new ring and both convolutions in ONE launch (the "fused warp-and-1x1x1-conv kernel" of SURVEY 8f-1;
+ * fbocc.py:264-310 after the folding described above).  history (B,T,N,C) and `next` (B,T+1,N,C) are voxel-major 16-bit rings
+ * (elem_type 1 = bf16, 2 = f16; C = Cout = 80; strides in elements, 0 = dense).  The caller stores the current frame into
+ * slot 0 of `next` first (fbbev_history_frame_vm); this call writes slots 1..T (frame t+1 = history frame t re-sampled with
+ * rt_flow: the SAME element bits as fbbev_history_warp_vm) and out (B,Cout,N) f32 = the fused volume on the bf16 MFMA with
+ * fp32 accumulation -- the same operands and accumulation order as fbbev_history_conv_bf16 on that ring, without reading the
+ * T new frames back.  workspace: as fbbev_history_conv_bf16.  Other shapes / an fp32 ring: FBBEV_E_UNSUPPORTED (use
+ * fbbev_history_warp_vm + fbbev_history_conv_bf16). */
+int fbbev_history_fused_vm(const void* history, long long history_stride_b, void* next, long long next_stride_b,
+                           const float* rt_flow, const float* w1, const float* bias1, const float* w2,
+                           const float* bias2, int B, int T, int C, int Cout, int Z, int Y, int X, float* out,
+                           void* workspace, size_t workspace_bytes, int elem_type, fbbev_stream_t stream);
 int fbbev_history_warp_vm(const void* history, long long history_stride_b, const float* rt_flow, int B, int T, int C, int Z,
                           int Y, int X, void* out, long long out_stride_b, int elem_type, fbbev_stream_t stream);
 int fbbev_history_frame_vm(const float* curr, int B, int C, int N, int inner, void* out, long long out_stride_b,

@@ -150,6 +150,10 @@ inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 inline unsigned int atomicOr(unsigned int* p, unsigned int v) { unsigned int o = *p; *p = o | v; return o; }
 
 // single correctly-rounded fp32 ops (volatile defeats re-association / contraction)
+inline float fbbev_mul(float a, float b) { volatile float r = a * b; return r; }
+inline float fbbev_add(float a, float b) { volatile float r = a + b; return r; }
+inline float fbbev_sub(float a, float b) { volatile float r = a - b; return r; }
+inline float fbbev_div(float a, float b) { volatile float r = a / b; return r; }
 inline float __fsub_rn(float a, float b) { volatile float r = a - b; return r; }
 inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
 inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }

@@ -974,6 +974,44 @@ def test_history_warp_and_conv_16bit_storage_emulated(dt):
     assert torch.equal(E.history_conv(feats, w1, b1, w2, b2), E.history_conv(feats.float(), w1, b1, w2, b2))
 
 
+@pytest.mark.parametrize('dt', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('producers', ['8', '5'])
+def test_history_fused_warp_and_conv_equals_the_two_kernels_emulated(dt, producers, monkeypatch):
+    """fbbev_history_fused_vm (one launch: producer waves warp the previous ring into the next one and into an LDS operand
+    tile, consumer waves run both bf16-MFMA convolutions from it) against fbbev_history_warp_vm + fbbev_history_conv_bf16 on
+    the same rings: the new ring's slots 1..T and the fused volume are the SAME BITS -- same taps, weights, roundings, operands
+    and accumulation order; only where the operands come from differs.  Grid rows that are not a multiple of the 64-voxel
+    tile, translation / rotation / out-of-grid / NaN flows, padded batch strides, both producer counts."""
+    monkeypatch.setenv('FBBEV_HISTORY_FUSED_PRODUCERS', producers)
+    g = torch.Generator().manual_seed(13)
+    B, T, C, Z, Y, X = 4, 3, 80, 2, 3, 70                                     # X = 70: one full tile + a 6-voxel tile per row
+    N = Z * Y * X
+    hist = torch.full((B, T + 1, N, C), float('nan'), dtype=dt)              # spare slot: padded batch stride
+    hist[:, :T] = (torch.randn(B, T, N, C, generator=g) * 2).to(dt)
+    flow = torch.eye(4)[None].repeat(B, 1, 1)
+    flow[0, :3, 3] = torch.tensor([1.25, -0.5, 0.25])
+    flow[1, :3, :3] = torch.tensor([[0.9, -0.4, 0.0], [0.4, 0.9, 0.0], [0.0, 0.0, 1.0]])
+    flow[2, :3, 3] = torch.tensor([500.0, 0.0, 0.0])                         # leaves the grid: zero padding
+    flow[3, 0, 0] = float('nan')
+    curr = torch.randn(B, C, N, generator=g)
+    w1, w2 = torch.randn(C, C, generator=g) * 0.2, torch.randn(C, (T + 1) * C, generator=g) * 0.1
+    b1, b2 = torch.randn(B * (T + 1), C, generator=g), torch.randn(C, generator=g)
+    # the two-kernel path
+    ref = torch.full((B, T + 1, N, C), float('nan'), dtype=dt)
+    E.history_frame_vm(curr, dt, out=ref[:, 0])
+    E.history_warp_vm(hist[:, :T], flow, (Z, Y, X), out=ref[:, 1:])
+    exp = E.history_conv(ref, w1, b1, w2, b2, bf16=True, voxel_major=True)
+    # the fused kernel
+    nxt = torch.full((B, T + 1, N, C), float('nan'), dtype=dt)
+    E.history_frame_vm(curr, dt, out=nxt[:, 0])
+    code, got = E.history_fused_vm(hist[:, :T], flow, nxt, (Z, Y, X), w1, b1, w2, b2)
+    assert code == 0
+    assert torch.equal(nxt.view(torch.int16), ref.view(torch.int16))         # the ring: identical element bits (NaN flows included)
+    fin = torch.isfinite(exp)
+    assert torch.equal(torch.isfinite(got), fin) and torch.equal(got[fin], exp[fin])
+    assert fin.all()                                                         # a NaN flow samples nothing (zero taps), it does not poison
+
+
 @pytest.mark.parametrize('dt', [torch.float32, torch.float16, torch.bfloat16])
 def test_history_voxel_major_ring_equals_planar_kernels_emulated(dt):
     """The voxel-major ring ([T][N][C] frames): fbbev_history_frame_vm is the rounded transpose of a frame,

@@ -308,6 +308,44 @@ def test_voxel_major_ring_equals_planar_ring(dev, dt, comp):
     assert torch.equal(rows.view(bits), frame.transpose(1, 2).to(dt).contiguous().view(bits))
 
 
+@pytest.mark.parametrize('dt', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('T', [3, 16])
+def test_fused_warp_and_conv_kernel_equals_the_two_kernel_path(dev, dt, T):
+    """fbbev_history_fused_vm (round 3: warp of the previous ring, the new ring and both bf16-MFMA convolutions in ONE launch --
+    producer waves fill an LDS operand tile, consumer waves run the GEMMs from it) against fbbev_history_warp_vm +
+    fbbev_history_conv_bf16 through the module (`fused_warp_conv` on / off) over a sequence with a restart, ego motion and a
+    flipped bda: the stored ring AND the fused volume are the same bits (same taps, weights, roundings, operands and
+    accumulation order).  X = 70: a full 64-voxel tile and a 6-voxel one per grid row."""
+    from fb_bev_amd.history_fusion import TemporalHistoryFusion
+    B, C, Z, Y, X = 2, 80, 4, 12, 70
+    dx, bx = [0.5, 0.5, 1.0], [-17.25, -2.75, -1.5]
+    torch.manual_seed(3)
+    mods = [TemporalHistoryFusion(dx, bx, single_bev_num_channels=C, history_cat_num=T, history_dtype=dt,
+                                  history_compute=torch.bfloat16, ring_layout='voxel_major').to(dev).eval() for _ in range(2)]
+    with torch.no_grad():
+        for seq in (mods[0].history_keyframe_time_conv, mods[0].history_keyframe_cat_conv):
+            seq[1].running_mean.normal_(0, 0.1); seq[1].running_var.uniform_(0.5, 1.5)
+    mods[1].load_state_dict(mods[0].state_dict())
+    mods[0].fused_warp_conv, mods[1].fused_warp_conv = False, True
+    assert all(m._voxel_major() for m in mods)
+    g = torch.Generator().manual_seed(5)
+    starts = [[True, True], [False, False], [False, True], [False, False]]
+    seqs = [[0, 1], [0, 1], [0, 7], [0, 7]]
+    for i in range(4):
+        curr = torch.randn(B, C, Y, X, Z, generator=g).to(dev)
+        ego = torch.eye(4).repeat(B, 1, 1)
+        ego[:, 0, 3] = torch.tensor([0.4 * i, -0.3]); ego[1, :2, :2] = torch.tensor([[0.98, -0.199], [0.199, 0.98]])
+        bda = torch.eye(3).repeat(B, 1, 1)
+        if i >= 2:
+            bda[0, 1, 1] = -1.0
+        metas = [dict(sequence_group_idx=seqs[i][b], start_of_sequence=starts[i][b], curr_to_prev_ego_rt=ego[b]) for b in range(B)]
+        with torch.no_grad():
+            outs = [m.fuse_history(curr, metas, bda.to(dev)) for m in mods]
+        assert torch.equal(outs[0], outs[1]), (i, (outs[0] - outs[1]).abs().max().item())
+        assert torch.equal(mods[0].history_bev.view(torch.int16), mods[1].history_bev.view(torch.int16)), i
+    assert outs[0].abs().max().item() > 0
+
+
 @pytest.mark.parametrize('layout', ['voxel_major', 'planar'])
 def test_baseline_config4_grid_16_frame_fp16_history(dev, layout):
     """BASELINE configs[4] (stress): 400x400x16 grid, C=80, 16-frame history in fp16 = 7 GB per sample ring slot pair

@@ -71,12 +71,14 @@ def main():
     noref = 'noref' in sys.argv
     comp = torch.bfloat16 if 'cbf16' in sys.argv else torch.float32
     lay = 'voxel_major' if 'vm' in sys.argv else 'planar'
+    unfused = 'unfused' in sys.argv       # two-kernel path (warp, then convolutions) instead of fbbev_history_fused_vm
     esz = 4 if dt == torch.float32 else 2
     dev = torch.device('cuda:0')
     torch.manual_seed(0)
     dxv = 80.0 / X
     m = TemporalHistoryFusion([dxv, dxv, 6.4 / Z], [-40 + dxv / 2, -40 + dxv / 2, -1 + 3.2 / Z], C, T, history_dtype=dt,
                               history_compute=comp, ring_layout=lay).to(dev).eval()
+    m.fused_warp_conv = not unfused
     for seq in (m.history_keyframe_time_conv, m.history_keyframe_cat_conv):
         seq[1].running_var.uniform_(0.5, 1.5); seq[1].running_mean.uniform_(-0.2, 0.2)
     ref = TorchReference(m)
@@ -123,7 +125,7 @@ def main():
             rel = ((o3 - o2).abs().max() / o2.abs().max()).item()
     hist_bytes = B * T * C * Z * Y * X * esz
     print(json.dumps({'grid': [Y, X, Z], 'B': B, 'C': C, 'T': T, 'history_MB': round(hist_bytes / 1e6, 1),
-                      'history_dtype': str(dt).split('.')[-1], 'conv_compute': str(comp).split('.')[-1], 'ring_layout': lay, 'fused_ms': round(t_hip, 4),
+                      'history_dtype': str(dt).split('.')[-1], 'conv_compute': str(comp).split('.')[-1], 'ring_layout': lay, 'warp_conv_one_kernel': bool(m.fused_warp_conv and comp == torch.bfloat16 and lay == 'voxel_major' and dt != torch.float32), 'fused_ms': round(t_hip, 4),
                       'torch_reference_sequence_ms': None if t_ref is None else round(t_ref, 4), 'speedup': None if t_ref is None else round(t_ref / t_hip, 2),
                       'warp_ms': round(t_warp, 4), 'warp_GBps_read_plus_write': round(2 * hist_bytes / t_warp / 1e6, 1),
                       'max_abs_diff_out': err, 'max_abs_diff_history': herr,
