@@ -25,6 +25,7 @@ import torch.nn.functional as F
 
 from . import _capi
 from .ms_deform_attn import MultiScaleDeformableAttnFunction_fp32
+from .rows_linear import Linear, linear_rows
 
 REGISTRY = {}
 
@@ -118,10 +119,10 @@ class FFN(nn.Module):
         super().__init__()
         layers, in_ch = [], embed_dims
         for _ in range(num_fcs - 1):
-            layers.append(nn.Sequential(nn.Linear(in_ch, feedforward_channels), nn.ReLU(inplace=True),
+            layers.append(nn.Sequential(Linear(in_ch, feedforward_channels), nn.ReLU(inplace=True),
                                         nn.Dropout(ffn_drop)))
             in_ch = feedforward_channels
-        layers.append(nn.Linear(feedforward_channels, embed_dims))
+        layers.append(Linear(feedforward_channels, embed_dims))
         layers.append(nn.Dropout(ffn_drop))
         self.layers = nn.Sequential(*layers)
         self.add_identity = add_identity
@@ -154,10 +155,10 @@ class MultiScaleDeformableAttention(nn.Module):
         self.embed_dims, self.num_heads, self.num_levels, self.num_points = embed_dims, num_heads, num_levels, num_points
         self.im2col_step, self.batch_first = im2col_step, batch_first
         self.dropout = nn.Dropout(dropout)
-        self.sampling_offsets = nn.Linear(embed_dims, num_heads * num_levels * num_points * 2)
-        self.attention_weights = nn.Linear(embed_dims, num_heads * num_levels * num_points)
-        self.value_proj = nn.Linear(embed_dims, embed_dims)
-        self.output_proj = nn.Linear(embed_dims, embed_dims)
+        self.sampling_offsets = Linear(embed_dims, num_heads * num_levels * num_points * 2)
+        self.attention_weights = Linear(embed_dims, num_heads * num_levels * num_points)
+        self.value_proj = Linear(embed_dims, embed_dims)
+        self.output_proj = Linear(embed_dims, embed_dims)
         self.fused_inference = True
         self.init_weights()
 
@@ -245,9 +246,9 @@ class DA_MSDeformableAttention(nn.Module):
         self.num_Z_anchors, self.im2col_step, self.batch_first = num_Z_anchors, im2col_step, batch_first
         self.disable_deformable = disable_deformable
         self.output_proj = None
-        self.sampling_offsets = nn.Linear(embed_dims, num_heads * num_levels * num_points * 2)
-        self.attention_weights = nn.Linear(embed_dims, num_heads * num_levels * num_points)
-        self.value_proj = nn.Linear(embed_dims, embed_dims)
+        self.sampling_offsets = Linear(embed_dims, num_heads * num_levels * num_points * 2)
+        self.attention_weights = Linear(embed_dims, num_heads * num_levels * num_points)
+        self.value_proj = Linear(embed_dims, embed_dims)
         self.init_weights()
 
     def init_weights(self):
@@ -284,7 +285,7 @@ class DA_MSDeformableAttention(nn.Module):
             o = torch.arange(M * L * P).view(M, L, P).permute(1, 2, 0).reshape(-1)        # new (l,p,m) -> old (m,l,p)
             self._perm_so = (o[:, None] * 2 + torch.arange(2)[None]).reshape(-1).to(query.device)
             self._perm_key = key
-        so = F.linear(query, self.sampling_offsets.weight[self._perm_so], self.sampling_offsets.bias[self._perm_so])
+        so = linear_rows(query, self.sampling_offsets.weight[self._perm_so], self.sampling_offsets.bias[self._perm_so])
         so = so.view(bs, nq, L, P, M, 2)
         aw = self.attention_weights(query).view(bs, nq, M, L * P)
         if self.disable_deformable:
@@ -384,7 +385,7 @@ class DA_SpatialCrossAttention(nn.Module):
         self.pc_range = pc_range
         self.deformable_attention = build(deformable_attention)
         self.embed_dims, self.num_cams, self.dbound, self.batch_first = embed_dims, num_cams, dbound, batch_first
-        self.output_proj = nn.Linear(embed_dims, embed_dims)
+        self.output_proj = Linear(embed_dims, embed_dims)
         self.layer_scale = nn.Parameter(layer_scale * torch.ones(embed_dims)) if layer_scale is not None else None
         self.fused = fused
         # inference option (not part of the reference config): camera tokens (value_proj output) kept in bf16 / fp16 for the
@@ -464,7 +465,7 @@ class DA_SpatialCrossAttention(nn.Module):
                                     head_minor=hm | (_capi.DA_ATTN_LOGITS if fuse_sm else 0), head_dim=Dh, zero_token=True,
                                     bev_w=bev_w)
             return slots
-        v = F.linear(x, w, bb).view(B * ncam, S, M, HS)           # a token's M*HS floats are (HS/4, M, 4)
+        v = linear_rows(x, w, bb).view(B * ncam, S, M, HS)        # a token's M*HS floats are (HS/4, M, 4)
         return FusedDACrossAttention.apply(
             v.contiguous().float(), pred_img_depth.reshape(B * ncam, DC, H0, W0).contiguous().float(),
             so.contiguous().float(), aw.contiguous().float(), spatial_shapes.to(torch.int64).contiguous(),

@@ -110,12 +110,9 @@ k_history_fused_bf16(const void* __restrict__ hist, long long hist_stride_b, voi
                 if (t >= T1) break;                                             // block-uniform
                 // no global load in this loop: W2_t and the bias of frame t were staged by the loader waves a step ahead
                 const float* b1 = b1lds + (t & 3) * C;
-                fbbev_v4f bia[MT1], acc1[MT1];
+                fbbev_v4f acc1[MT1];
 #pragma unroll
-                for (int mt = 0; mt < MT1; ++mt) {
-                    bia[mt] = *reinterpret_cast<const fbbev_v4f*>(b1 + 16 * mt + 4 * g);
-                    acc1[mt] = fbbev_v4f{0.f, 0.f, 0.f, 0.f};
-                }
+                for (int mt = 0; mt < MT1; ++mt) acc1[mt] = fbbev_v4f{0.f, 0.f, 0.f, 0.f};
                 const unsigned short* xrow = xt + (t & 3) * TILE + vl * XP;
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
@@ -129,8 +126,9 @@ k_history_fused_bf16(const void* __restrict__ hist, long long hist_stride_b, voi
                 fbbev_wave_sync();                                              // the Y rows are wave-private
 #pragma unroll
                 for (int mt = 0; mt < MT1; ++mt) {
-                    const fbbev_v4f yv = {fmaxf(acc1[mt][0] + bia[mt][0], 0.f), fmaxf(acc1[mt][1] + bia[mt][1], 0.f),
-                                          fmaxf(acc1[mt][2] + bia[mt][2], 0.f), fmaxf(acc1[mt][3] + bia[mt][3], 0.f)};
+                    const fbbev_v4f bia = *reinterpret_cast<const fbbev_v4f*>(b1 + 16 * mt + 4 * g);          // LDS
+                    const fbbev_v4f yv = {fmaxf(acc1[mt][0] + bia[0], 0.f), fmaxf(acc1[mt][1] + bia[1], 0.f),
+                                          fmaxf(acc1[mt][2] + bia[2], 0.f), fmaxf(acc1[mt][3] + bia[3], 0.f)};
                     const fbbev_bf16x8 pk = fbbev_cvt_bf16x8(yv, yv);
                     unsigned long long four;
                     __builtin_memcpy(&four, &pk, 8);
@@ -170,11 +168,10 @@ k_history_fused_bf16(const void* __restrict__ hist, long long hist_stride_b, voi
         char* dst = static_cast<char*>(nxt) + (size_t)b * nxt_stride_b * 2;
         // frame f of the next ring (f >= 1) = frame f - 1 of the previous ring, re-sampled; frame 0 = the current frame, which
         // fbbev_history_frame_vm has already stored: only its operand pieces are copied into tile 0
-        // issue / finish are split so that the taps of pair p + 1 are issued BEFORE the barrier that ends pair p: the loads read
-        // only the previous ring, and with them in flight the memory system works through the barrier wait and the consumers'
-        // GEMMs instead of idling until every producer wave has come round again (the registers are free once pair p is blended)
-        fbbev_v4u raw[2][8];
-        auto issue_pair = [&](int f0) {                                        // frames f0 (even), f0 + 1
+        // (a build that issued the taps of pair p + 1 BEFORE the barrier ending pair p measured the same 7.1 ms and spilled: the
+        // tap registers are then live across the barrier)
+        auto produce_pair = [&](int f0) {                                      // frames f0 (even), f0 + 1
+            fbbev_v4u raw[2][8];
             const int fa = f0 >= 1 ? f0 - 1 : 0, fb = f0 < T1 - 1 ? f0 : (T1 >= 2 ? T1 - 2 : 0);       // clamped source frames
             const char* sa = src + (size_t)fa * frame_bytes;
             const char* sb = src + (size_t)fb * frame_bytes;
@@ -186,8 +183,7 @@ k_history_fused_bf16(const void* __restrict__ hist, long long hist_stride_b, voi
             }
 #pragma unroll
             for (int q = 0; q < 8; ++q) raw[1][q] = *reinterpret_cast<const fbbev_v4u*>(sb + ob[q]);
-        };
-        auto finish_pair = [&](int f0) {
+            fbbev_sched_fence();
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int f = f0 + h;
@@ -217,7 +213,6 @@ k_history_fused_bf16(const void* __restrict__ hist, long long hist_stride_b, voi
                     *reinterpret_cast<fbbev_v4u*>(xt + (f & 3) * TILE + lofs) = fbbev_hf_operand<ET>(pk);
                 }
             }
-            fbbev_sched_fence();                                               // the next pair's loads stay behind this blend
         };
         // the two waves without items (threads 640..767 of the role) are the LOADERS: W2 fragments and conv-1 bias of a frame
         // pair, global -> registers -> LDS, a step ahead -- the consumers, one wave per SIMD, then never wait on a global load
@@ -225,30 +220,24 @@ k_history_fused_bf16(const void* __restrict__ hist, long long hist_stride_b, voi
         const int ld = item - ITEMS;
         auto stage_pair = [&](int f0) {
             constexpr int R = (A2 / 8 + 127) / 128;                             // 16-byte pieces of one frame per loader thread
-            fbbev_v4u wv[2][R];
-            float bv[2];
-#pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int f = f0 + h < T1 ? f0 + h : T1 - 1;
+                const int f = f0 + h;
+                if (f >= T1) break;
+                fbbev_v4u wv[R];
                 const fbbev_v4u* wn = reinterpret_cast<const fbbev_v4u*>(w2f + (long long)f * A2);
 #pragma unroll
                 for (int q = 0; q < R; ++q) {
                     const int i = ld + 128 * q;
-                    wv[h][q] = wn[i < A2 / 8 ? i : 0];
+                    wv[q] = wn[i < A2 / 8 ? i : 0];
                 }
-                bv[h] = bias1[((long long)b * T1 + f) * C + (ld < C ? ld : 0)];
-            }
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int f = f0 + h;
-                if (f >= T1) break;
+                const float bv = bias1[((long long)b * T1 + f) * C + (ld < C ? ld : 0)];
                 fbbev_v4u* wd = reinterpret_cast<fbbev_v4u*>(a2buf + (f & 3) * A2S);
 #pragma unroll
                 for (int q = 0; q < R; ++q) {
                     const int i = ld + 128 * q;
-                    if (i < A2 / 8) wd[i] = wv[h][q];
+                    if (i < A2 / 8) wd[i] = wv[q];
                 }
-                if (ld < C) b1lds[(f & 3) * C + ld] = bv[h];
+                if (ld < C) b1lds[(f & 3) * C + ld] = bv;
             }
         };
         if (ld >= 0) {
@@ -258,13 +247,10 @@ k_history_fused_bf16(const void* __restrict__ hist, long long hist_stride_b, voi
                 if (st + 1 < steps) stage_pair(2 * (st + 1));
             }
         } else {
-            issue_pair(0);
-            finish_pair(0);
-            if (steps > 1) issue_pair(2);
+            produce_pair(0);
             for (int st = 0; st < steps; ++st) {
                 __syncthreads();
-                if (st + 1 < steps) finish_pair(2 * (st + 1));
-                if (st + 2 < steps) issue_pair(2 * (st + 2));
+                if (st + 1 < steps) produce_pair(2 * (st + 1));
             }
         }
     }

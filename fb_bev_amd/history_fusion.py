@@ -49,8 +49,10 @@ class TemporalHistoryFusion(nn.Module):
             MConv3d(C * (T + 1), out_c, kernel_size=1, padding=0, stride=1), nn.SyncBatchNorm(out_c),
             nn.ReLU(inplace=True))
         self.use_mfma_convs = True          # inference: both 1x1x1 convs in one fp32-MFMA kernel when the channels allow
-        self.fused_warp_conv = True         # inference, 16-bit voxel-major ring + bf16 convolutions (C = 80): warp and both
-                                            # convolutions in one kernel (fbbev_history_fused_vm)
+        self.fused_warp_conv = False        # opt-in.  inference, 16-bit voxel-major ring + bf16 convolutions (C = 80): warp and
+                                            # both convolutions in ONE kernel (fbbev_history_fused_vm).  Bit-identical to the
+                                            # two-kernel path and 2.1 GB less HBM read per step at 400x400x16, but measured
+                                            # SLOWER (6.8 vs 5.6 ms: DESIGN 7, profiles/r03_hist_fused_pmc.json) -- not the default
         self.train_rows = True              # training on a GPU: the two convolutions on voxel rows (_fuse_train_rows); False =
                                             # the reference's literal op sequence (cat / reshape / Conv3d modules)
         # Storage type of the inference history ring (T+1 frames per sample): float32 (the reference), or float16 / bfloat16

@@ -1,0 +1,86 @@
+"""`y = x W^T + b` for the (B*Q, C) row tensors of the backward projection, with a backward built for their shape.
+
+The backward projection applies ~10 small linear layers (80 -> 64 / 80 / 128 / 320 / 512 channels) to 160 000 BEV-query rows
+(BASELINE configs[2]: 200 x 200 queries, B = 4; `spatial_cross_attention_depth.py:533-540`, `transformer.py` FFN).  In
+training, autograd's weight gradient of such a layer is `mm(gy^T, x)` with K = 160 000 and an 80 x 80 ... 512 x 80 result: the
+vendor GEMM runs it as 9-60 output tiles with the whole K loop inside each -- 0.3-0.45 ms per layer for a few GFLOP, 20x
+off the time its 100 MB of operands take to read (profiles/r03_time_train_BL2_B4_L4_sites.json: 4 ms of the 20.6 ms step).
+Here the rows are cut into S slices, the S partial products are one batched GEMM (S x tiles workgroups) and their sum a
+small reduction; the bias gradient is reduced the same way in two stages.  fp32 throughout; the sums are re-associated
+(slice partials), i.e. equal to autograd's within fp32 rounding, which is what the training parity tests allow."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+MIN_ROWS = 16384            # below this autograd's plain GEMM is as good
+SLICE_ROWS = 2048           # rows per partial product
+
+
+def _slices(rows):
+    s = max(1, rows // SLICE_ROWS)
+    return s, rows // s            # S slices of `per` rows; the remainder (< S rows) goes through a plain GEMM
+
+
+def weight_grad(gy, x):
+    """gy (R, O), x (R, I) -> gy^T x (O, I), split along R."""
+    R = gy.shape[0]
+    S, per = _slices(R)
+    main = S * per
+    g3 = gy[:main].view(S, per, gy.shape[1])
+    x3 = x[:main].view(S, per, x.shape[1])
+    gw = torch.bmm(g3.transpose(1, 2), x3).sum(0)
+    if main < R:
+        gw = gw + gy[main:].t() @ x[main:]
+    return gw
+
+
+def bias_grad(gy):
+    """column sums of gy (R, O) as a batched ones-vector GEMM + a small reduction: `gy.sum(0)` runs ATen's strided
+    reduce kernel at ~190 GB/s on these shapes (0.27 ms per layer at R = 160 000)"""
+    R = gy.shape[0]
+    S, per = _slices(R)
+    main = S * per
+    ones = torch.ones((1, 1, per), dtype=gy.dtype, device=gy.device).expand(S, 1, per)
+    gb = torch.bmm(ones, gy[:main].view(S, per, gy.shape[1])).sum((0, 1))
+    if main < R:
+        gb = gb + gy[main:].sum(0)
+    return gb
+
+
+class _RowsLinear(torch.autograd.Function):
+    """x (R, I) 2-D -> (R, O).  2-D on purpose: F.linear of a 3-D tensor returns a VIEW of its GEMM result, and autograd refuses
+    in-place ops (the FFN's ReLU(inplace=True)) on a view created inside a custom Function; `linear_rows` reshapes outside."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return F.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = gy @ w
+        if ctx.needs_input_grad[1]:
+            gw = weight_grad(gy, x)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = bias_grad(gy)
+        return gx, gw, gb
+
+
+def linear_rows(x, w, b=None):
+    """F.linear with the split-K backward when it pays: a GPU tensor of many rows that autograd will differentiate."""
+    rows = x.numel() // max(1, x.shape[-1])
+    if (x.is_cuda and rows >= MIN_ROWS and torch.is_grad_enabled() and x.dtype == torch.float32 and
+            (w.requires_grad or x.requires_grad or (b is not None and b.requires_grad))):
+        return _RowsLinear.apply(x.reshape(rows, x.shape[-1]), w, b).view(*x.shape[:-1], w.shape[0])
+    return F.linear(x, w, b)
+
+
+class Linear(nn.Linear):
+    """nn.Linear (same parameters / state_dict) whose forward goes through `linear_rows`."""
+
+    def forward(self, x):
+        return linear_rows(x, self.weight, self.bias)

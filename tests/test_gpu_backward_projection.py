@@ -403,3 +403,26 @@ def test_write_once_volume_path_equals_reference_composition(dev, name, B):
         assert torch.equal(fp.pooled_volume(parts, addend=addend), vol + addend[..., None])
     assert a.shape == b.shape == (B, pc.channels, Y, X, Z)
     assert (a - b).abs().max().item() < 1e-4
+
+
+@pytest.mark.gpu
+def test_rows_linear_split_k_backward_on_the_gpu():
+    """rows_linear at the configs[2] row count (160 000 x 80 -> 128): the GPU route is taken (custom backward node) and its
+    weight / bias / input gradients equal autograd's plain GEMMs to fp32 rounding."""
+    from fb_bev_amd import rows_linear as RL
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(4, 40000, 80, generator=g).to(dev).requires_grad_()
+    lin = RL.Linear(80, 128).to(dev)
+    gy = torch.randn(4, 40000, 128, generator=g).to(dev)
+    y = lin(x)
+    assert 'RowsLinear' in type(y.grad_fn.next_functions[0][0]).__name__     # y is a view of the custom node's 2-D result
+    y = torch.relu_(y)                       # the FFN's in-place ReLU must be legal on the result
+    y.backward(gy)
+    got = [x.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone()]
+    x.grad = lin.weight.grad = lin.bias.grad = None
+    y2 = torch.relu(torch.nn.functional.linear(x, lin.weight, lin.bias))
+    y2.backward(gy)
+    assert torch.equal(y, y2)
+    for a, r in zip(got, [x.grad, lin.weight.grad, lin.bias.grad]):
+        assert (a - r).abs().max() <= 2e-5 * r.abs().max()

@@ -54,8 +54,23 @@ def main():
         out, loss = step(); loss.backward()
     torch.cuda.synchronize()
     t_fb = (time.perf_counter() - t0) / n
-    print(json.dumps({'config': name, 'B': B, 'levels': levels, 'ms_forward_train_mode': t_f * 1e3, 'ms_forward_backward': t_fb * 1e3,
-                      'samples_per_s_train_step': B / t_fb}))
+    rec = {'config': name, 'B': B, 'levels': levels, 'ms_forward_train_mode': t_f * 1e3, 'ms_forward_backward': t_fb * 1e3,
+           'samples_per_s_train_step': B / t_fb}
+    if 'sites' in sys.argv:
+        # where the torch glue of the step spends device time: ATen ops by Python call site (forward) / by op + shapes (backward
+        # nodes have no Python stack), one step
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
+            out, loss = step(); loss.backward()
+            torch.cuda.synchronize()
+        rows = []
+        for e in prof.key_averages(group_by_input_shape=True, group_by_stack_n=8):
+            if e.self_device_time_total > 100:
+                rows.append({'op': e.key, 'self_ms': e.self_device_time_total / 1e3, 'calls': e.count, 'shapes': str(e.input_shapes)[:200],
+                             'stack': [fr for fr in e.stack if 'fb_bev_amd' in fr][:4]})
+        rows.sort(key=lambda r: -r['self_ms'])
+        rec['op_sites'] = rows[:50]
+    print(json.dumps(rec))
 
 
 if __name__ == '__main__':
