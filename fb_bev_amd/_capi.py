@@ -49,6 +49,8 @@ SIGNATURES = {
     'fbbev_history_warp': (c_int, [c_void_p, c_int64, c_void_p] + [c_int] * 5 + [c_void_p, c_int64, c_void_p]),
     'fbbev_history_warp_e': (c_int, [c_void_p, c_int64, c_void_p] + [c_int] * 5 + [c_void_p, c_int64, c_int, c_void_p]),
     'fbbev_layernorm': (c_int, [c_void_p] * 4 + [c_float, c_int64, c_int, c_void_p, c_void_p]),
+    'fbbev_layernorm_bwd_partials': (c_int, [c_int64]),
+    'fbbev_layernorm_bwd': (c_int, [c_void_p] * 3 + [c_float, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     'fbbev_history_conv': (c_int, [c_void_p, c_int64] + [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t, c_void_p]),
     'fbbev_history_conv_e': (c_int, [c_void_p, c_int64] + [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     'fbbev_history_conv_bf16': (c_int, [c_void_p, c_int64] + [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
@@ -76,6 +78,8 @@ SIGNATURES = {
                                    [c_void_p, c_void_p, c_size_t, c_void_p]),
     'fbbev_msda_fwd_fused': (c_int, [c_void_p] * 6 + [c_int] * 9 + [c_void_p, c_void_p]),
     'fbbev_msda_bwd': (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p] * 3 + [c_void_p]),
+    'fbbev_msda_bwd_ws_bytes': (c_size_t, [c_int] * 7 + [c_void_p]),
+    'fbbev_msda_bwd_ws': (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p] * 3 + [c_void_p, c_void_p, c_size_t, c_void_p]),
 }
 
 _lib = None
@@ -403,18 +407,33 @@ def msda_fwd_fused(value, spatial_shapes, level_start_index, ref_points, offsets
     return out
 
 
+def msda_bwd_ws_bytes(B, S, M, Dh, L, Q, P, level_hw=None):
+    """Scratch bytes of the atomic-free backward (0: not available for this shape / no host level shapes)."""
+    if level_hw is None:
+        return 0
+    return lib().fbbev_msda_bwd_ws_bytes(B, S, M, Dh, L, Q, P, _level_hw(level_hw, L))
+
+
 def msda_bwd(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output,
-             grad_value, grad_sampling_loc, grad_attn_weight):
+             grad_value, grad_sampling_loc, grad_attn_weight, level_hw=None):
+    """grad_sampling_loc / grad_attn_weight pre-zeroed (accumulated into).  With `level_hw` (host (h, w) per level) and a
+    shape the band-binned kernels take, grad_value is WRITTEN (fixed-point LDS planes, bit-reproducible, no pre-zeroing
+    needed); otherwise it is accumulated into with fp32 global atomics and must be pre-zeroed -- callers that pass
+    level_hw check msda_bwd_ws_bytes() to know which."""
     B, S, M, Dh = value.shape
     _, Q, _, L, P, _ = sampling_loc.shape
     with _on(value):
-        _check(lib().fbbev_msda_bwd(
-            _dev(value, F32, 'value'), _dev(spatial_shapes, I64, 'spatial_shapes'),
-            _dev(level_start_index, I64, 'level_start_index'), _dev(sampling_loc, F32, 'sampling_loc'),
-            _dev(attn_weight, F32, 'attn_weight'), _dev(grad_output, F32, 'grad_output'),
-            B, S, M, Dh, L, Q, P, _dev(grad_value, F32, 'grad_value'),
-            _dev(grad_sampling_loc, F32, 'grad_sampling_loc'),
-            _dev(grad_attn_weight, F32, 'grad_attn_weight'), _stream()), 'fbbev_msda_bwd')
+        args = (_dev(value, F32, 'value'), _dev(spatial_shapes, I64, 'spatial_shapes'),
+                _dev(level_start_index, I64, 'level_start_index'), _dev(sampling_loc, F32, 'sampling_loc'),
+                _dev(attn_weight, F32, 'attn_weight'), _dev(grad_output, F32, 'grad_output'),
+                B, S, M, Dh, L, Q, P, _dev(grad_value, F32, 'grad_value'),
+                _dev(grad_sampling_loc, F32, 'grad_sampling_loc'), _dev(grad_attn_weight, F32, 'grad_attn_weight'))
+        need = msda_bwd_ws_bytes(B, S, M, Dh, L, Q, P, level_hw)
+        if need:
+            ws = torch.empty((need + 3) // 4, dtype=torch.int32, device=value.device)
+            _check(lib().fbbev_msda_bwd_ws(*args, _level_hw(level_hw, L), ws.data_ptr(), need, _stream()), 'fbbev_msda_bwd_ws')
+        else:
+            _check(lib().fbbev_msda_bwd(*args, _stream()), 'fbbev_msda_bwd')
 
 
 def da_cross_attn_fwd(value, spatial_shapes, level_start_index, pred_depth, ref_cam, mask, qdepth, offsets,
@@ -678,6 +697,22 @@ def layernorm(x, weight, bias, eps, residual=None, out=None):
                                      _dev(weight, F32, 'weight'), _dev(bias, F32, 'bias'), float(eps), rows, C,
                                      _dev(out, F32, 'out'), _stream()), 'fbbev_layernorm')
     return out
+
+
+def layernorm_bwd(x, grad_out, weight, eps):
+    """Backward of `layernorm` (no residual): returns (grad_x, grad_weight, grad_bias); the parameter gradients are the sum
+    of the kernel's per-workgroup partial rows."""
+    C = x.shape[-1]
+    rows = x.numel() // C
+    n = lib().fbbev_layernorm_bwd_partials(rows)
+    partial = torch.empty((n, 2, C), dtype=F32, device=x.device)
+    grad_x = torch.empty_like(x)
+    with _on(x):
+        _check(lib().fbbev_layernorm_bwd(_dev(x, F32, 'x'), _dev(grad_out, F32, 'grad_out'), _dev(weight, F32, 'weight'),
+                                         float(eps), rows, C, _dev(grad_x, F32, 'grad_x'), _dev(partial, F32, 'partial'),
+                                         _stream()), 'fbbev_layernorm_bwd')
+    gwb = partial.sum(0)
+    return grad_x, gwb[0], gwb[1]
 
 
 def conv3d_ndhwc(x, weight_fragments, bias, out, Cout, ksize=3, stride=1, pad=1, relu=False, residual=None, transposed=False):

@@ -535,24 +535,51 @@ class DA_SpatialCrossAttention(nn.Module):
         return (self.dropout(slots), inp_residual) if _defer_residual else self.dropout(slots) + inp_residual
 
 
-class LayerNorm(nn.LayerNorm):
-    """torch.nn.LayerNorm (= mmcv build_norm_layer('LN')) whose inference forward runs fbbev_layernorm: half a wave64
-    per 80-float row instead of torch's generic kernel (150 us -> ~25 us on 160k rows).  Same parameters / state_dict;
-    with autograd enabled, or for shapes the kernel does not take, it is exactly nn.LayerNorm."""
+class _LayerNormRows(torch.autograd.Function):
+    """fbbev_layernorm / fbbev_layernorm_bwd under autograd (training of the backward projection on a GPU)."""
 
-    def kernel_ok(self, x):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        ctx.save_for_backward(x, weight)
+        ctx.eps = eps
+        return _capi.layernorm(x, weight, bias, eps)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gx, gw, gb = _capi.layernorm_bwd(x, gy.contiguous(), weight, ctx.eps)
+        return (gx if ctx.needs_input_grad[0] else None, gw if ctx.needs_input_grad[1] else None,
+                gb if ctx.needs_input_grad[2] else None, None)
+
+
+class LayerNorm(nn.LayerNorm):
+    """torch.nn.LayerNorm (= mmcv build_norm_layer('LN')) on fbbev_layernorm: half a wave64 per 80-float row instead of
+    torch's generic kernel (150 us -> ~25 us on 160k rows), and under autograd fbbev_layernorm_bwd instead of ATen's three
+    backward kernels (0.47 ms per LayerNorm at 160k rows).  Same parameters / state_dict; for shapes the kernels do not take
+    (and on the CPU) it is exactly nn.LayerNorm."""
+
+    def shape_ok(self, x):
         C = x.shape[-1]
         return (x.is_cuda and x.dtype == torch.float32 and self.elementwise_affine and self.bias is not None and
-                len(self.normalized_shape) == 1 and C % 4 == 0 and C <= 128 and x.is_contiguous() and
-                not (torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad)))
+                len(self.normalized_shape) == 1 and C % 4 == 0 and C <= 128 and x.is_contiguous())
+
+    def wants_grad(self, x):
+        return torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad or self.bias.requires_grad)
+
+    def kernel_ok(self, x):
+        return self.shape_ok(x) and not self.wants_grad(x)
 
     def forward(self, x, residual=None):
-        """LN(x [+ residual]); the kernel adds the residual while it reads the row (the same fp32 sum as a separate add)."""
+        """LN(x [+ residual]); the inference kernel adds the residual while it reads the row (the same fp32 sum as a separate add)."""
         if self.kernel_ok(x) and (residual is None or (residual.shape == x.shape and residual.dtype == x.dtype
                                                        and residual.is_contiguous() and not
                                                        (torch.is_grad_enabled() and residual.requires_grad))):
             return _capi.layernorm(x, self.weight, self.bias, self.eps, residual=residual)
-        return super().forward(x if residual is None else x + residual)
+        if residual is not None:
+            x = x + residual
+        if self.shape_ok(x) and self.wants_grad(x) and x.shape[-1] == self.weight.numel():
+            return _LayerNormRows.apply(x, self.weight, self.bias, self.eps)
+        return super().forward(x)
 
 
 @register

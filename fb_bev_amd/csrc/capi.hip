@@ -14,6 +14,7 @@
 #include "norm_kernels.h"
 #include "history_conv_kernels.h"
 #include "history_fused_kernels.h"
+#include "msda_bwd_kernels.h"
 #include "conv3d_kernels.h"
 #include "../../include/fbbev.h"
 
@@ -944,6 +945,129 @@ extern "C" int fbbev_msda_bwd(const float* value, const int64_t* spatial_shapes,
     return 0;
 }
 
+// Band-binned fixed-point backward (msda_bwd_kernels.h).  level_hw_host: HOST array of L (h, w) pairs -- the band count is a
+// launch dimension.  Plan: tokens per LDS plane from the LDS budget (64 KB: two workgroups per CU; FBBEV_MSDA_BWD_LDS_KB,
+// read once, tunes it), a band = whole rows of one level.
+struct msda_bwd_plan { int budget, n_bands; size_t lds, ws_ranges, ws; };
+static bool msda_bwd_plan_for(int B, int S, int M, int Dh, int L, int Q, int P, const int32_t* level_hw, msda_bwd_plan* pl) {
+    if (!level_hw || !(Dh == 4 || Dh == 8 || Dh == 10 || Dh == 16 || Dh == 32) || Q <= 0) return false;
+    // measured at BASELINE configs[2] (200 x 200 BEV, B = 4): scatter 2.24 / 0.80 / 0.45 ms with 32 / 64 / 128 KB planes -- the
+    // halo of re-evaluated queries per band is what costs, so a band is as tall as LDS allows (one workgroup per CU) ...
+    auto read_kb = [] { const char* e = getenv("FBBEV_MSDA_BWD_LDS_KB"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 150 ? v : 144; };
+#ifdef FBBEV_TEST_OVERRIDES   // CPU emulator build: the tests switch budgets inside one process
+    const int lds_kb = read_kb();
+#else
+    static const int lds_kb = read_kb();          // read once: ws_bytes() and the launch must agree
+#endif
+    int budget = (lds_kb * 1024) / (Dh * (int)sizeof(long long)) - 16;
+    long long nb = 0, tokens = 0;
+    int max_tok = 0, max_w = 1;
+    for (int l = 0; l < L; ++l) max_w = level_hw[2 * l + 1] > max_w ? level_hw[2 * l + 1] : max_w;
+    for (;;) {
+        nb = 0; tokens = 0; max_tok = 0;
+        for (int l = 0; l < L; ++l) {
+            const int h = level_hw[2 * l], w = level_hw[2 * l + 1];
+            if (h <= 0 || w <= 0 || h > 32767 || w > budget) return false;
+            const int rpb = budget / w;
+            nb += (h + rpb - 1) / rpb;
+            tokens += (long long)h * w;
+            const int t = (rpb < h ? rpb : h) * w;
+            max_tok = t > max_tok ? t : max_tok;
+        }
+        // ... unless that leaves CUs idle: shrink the bands until there is a workgroup per CU (small grids / small batches)
+        if ((long long)B * M * nb >= 256 || budget * 3 / 4 < 2 * max_w) break;
+        budget = budget * 3 / 4;
+    }
+    if (tokens != S || nb > 65535 || (long long)B * M * nb >= (1ll << 31)) return false;
+    pl->budget = budget;
+    pl->n_bands = (int)nb;
+    pl->lds = (size_t)FBBEV_DA_PLANE_WORDS(max_tok, Dh) * sizeof(long long);
+    pl->ws_ranges = ((size_t)B * L * Q * sizeof(unsigned int) + 255) / 256 * 256;
+    pl->ws = pl->ws_ranges + (size_t)B * nb * 2 * sizeof(int);
+    return true;
+}
+
+extern "C" size_t fbbev_msda_bwd_ws_bytes(int batch, int spatial_size, int num_heads, int channels, int num_levels,
+                                          int num_query, int num_point, const int32_t* level_hw_host) {
+    msda_bwd_plan pl;
+    if (batch <= 0 || spatial_size <= 0 || num_heads <= 0 || channels <= 0 || num_levels <= 0 || num_point <= 0 ||
+        !msda_bwd_plan_for(batch, spatial_size, num_heads, channels, num_levels, num_query, num_point, level_hw_host, &pl))
+        return 0;
+    return pl.ws;
+}
+
+extern "C" int fbbev_msda_bwd_ws(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                 const float* sampling_loc, const float* attn_weight, const float* grad_output, int batch,
+                                 int spatial_size, int num_heads, int channels, int num_levels, int num_query, int num_point,
+                                 float* grad_value, float* grad_sampling_loc, float* grad_attn_weight,
+                                 const int32_t* level_hw_host, void* ws, size_t ws_bytes, fbbev_stream_t stream_) {
+    if (batch < 0 || spatial_size <= 0 || num_heads <= 0 || channels <= 0 || num_levels <= 0 || num_query < 0 ||
+        num_point <= 0) return FBBEV_E_BADARG;
+    msda_bwd_plan pl;
+    if (batch == 0 || num_query == 0 || !ws ||
+        !msda_bwd_plan_for(batch, spatial_size, num_heads, channels, num_levels, num_query, num_point, level_hw_host, &pl) ||
+        ws_bytes < pl.ws)
+        return fbbev_msda_bwd(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output, batch,
+                              spatial_size, num_heads, channels, num_levels, num_query, num_point, grad_value,
+                              grad_sampling_loc, grad_attn_weight, stream_);
+    if (!value || !spatial_shapes || !level_start_index || !sampling_loc || !attn_weight || !grad_output || !grad_value ||
+        !grad_sampling_loc || !grad_attn_weight) return FBBEV_E_BADARG;
+    fbbev_rt_stream stream = (fbbev_rt_stream)stream_;
+    const int B = batch, S = spatial_size, M = num_heads, Dh = channels, L = num_levels, Q = num_query, P = num_point;
+    unsigned int* ranges = static_cast<unsigned int*>(ws);
+    int* qrange = reinterpret_cast<int*>(static_cast<char*>(ws) + pl.ws_ranges);
+    {
+        const long long n = (long long)B * L * Q;
+        long long blocks = (n + 255) / 256;
+        if (blocks > 65536) blocks = 65536;
+        FBBEV_LAUNCH(k_msda_row_ranges, blocks, 256, 0, stream, n, spatial_shapes, sampling_loc, M, L, Q, P, ranges);
+        FBBEV_CHECK_LAUNCH();
+        FBBEV_LAUNCH(k_msda_band_queries, (long long)B * pl.n_bands, 256, 0, stream, spatial_shapes, level_start_index,
+                     (const unsigned int*)ranges, L, Q, pl.n_bands, pl.budget, qrange);
+        FBBEV_CHECK_LAUNCH();
+    }
+    {
+        // unit-owned gradients: one lane per unit with 8-byte corner loads when the rows allow it, else the atomic kernel's
+        // lane groups without its atomics
+        const long long n_units = (long long)B * Q * M;
+        const bool lane_units = Dh % 2 == 0 && ((uintptr_t)value & 7) == 0 && ((uintptr_t)grad_output & 7) == 0 &&
+                                (n_units + 255) / 256 < (1ll << 31);
+#define FBBEV_MSDA_BWD_UL(DH_)                                                                                        \
+    FBBEV_LAUNCH((k_msda_bwd_unit<DH_>), (n_units + 255) / 256, 256, 0, stream, n_units, value, spatial_shapes,         \
+                 level_start_index, sampling_loc, attn_weight, grad_output, S, M, L, Q, P, grad_sampling_loc, grad_attn_weight)
+#define FBBEV_MSDA_BWD_U(GW)                                                                                          \
+    FBBEV_LAUNCH((k_msda_bwd<GW, false>), (n_units * GW + 255) / 256, 256, 0, stream, n_units, value, spatial_shapes, \
+                 level_start_index, sampling_loc, attn_weight, grad_output, S, M, Dh, L, Q, P, grad_value,             \
+                 grad_sampling_loc, grad_attn_weight)
+        if (lane_units && Dh == 10) FBBEV_MSDA_BWD_UL(10);
+        else if (lane_units && Dh == 8) FBBEV_MSDA_BWD_UL(8);
+        else if (lane_units && Dh == 4) FBBEV_MSDA_BWD_UL(4);
+        else if (lane_units && Dh == 16) FBBEV_MSDA_BWD_UL(16);
+        else if (Dh <= 16) FBBEV_MSDA_BWD_U(16);
+        else FBBEV_MSDA_BWD_U(32);
+#undef FBBEV_MSDA_BWD_U
+#undef FBBEV_MSDA_BWD_UL
+        FBBEV_CHECK_LAUNCH();
+    }
+    const long long wgs = (long long)B * M * pl.n_bands;
+#define FBBEV_MSDA_BWD_SC(DH_)                                                                                        \
+    do {                                                                                                              \
+        int e_ = fbbev_rt_allow_dyn_lds((const void*)k_msda_bwd_scatter<512, DH_>, pl.lds);                            \
+        if (e_) return e_;                                                                                            \
+        FBBEV_LAUNCH((k_msda_bwd_scatter<512, DH_>), wgs, 512, pl.lds, stream, spatial_shapes, level_start_index,      \
+                     sampling_loc, attn_weight, grad_output, (const unsigned int*)ranges, (const int*)qrange, S, M, L,  \
+                     Q, P, pl.n_bands, pl.budget, grad_value);                                                        \
+    } while (0)
+    if (Dh == 10) FBBEV_MSDA_BWD_SC(10);
+    else if (Dh == 8) FBBEV_MSDA_BWD_SC(8);
+    else if (Dh == 4) FBBEV_MSDA_BWD_SC(4);
+    else if (Dh == 16) FBBEV_MSDA_BWD_SC(16);
+    else FBBEV_MSDA_BWD_SC(32);
+#undef FBBEV_MSDA_BWD_SC
+    FBBEV_CHECK_LAUNCH();
+    return 0;
+}
+
 // ------------------------------------------------------------------------------ fused DA cross-attention
 // 16-bit token rows (value_elem_type 1 = bf16, 2 = f16): chunk-major rows of 8-element pieces, unit-per-lane kernel only
 extern "C" int fbbev_da_cross_attn_fwd_e(const void* value, const int64_t* spatial_shapes,
@@ -1185,11 +1309,11 @@ static int da_bwd_regions(int L, const int32_t* level_hw, int S, int budget, da_
 // Tuning / test overrides of the plan, read ONCE per process (function-local static: thread-safe) -- the Python forward
 // derives the value-row layout from this planner and the backward launches from it, so a variable that changed between
 // the two calls must not be able to make them disagree.  Unset = the measured defaults.
-struct da_bwd_overrides { int tokens, chunks, threads, copies; };
+struct da_bwd_overrides { int tokens, chunks, threads, copies, lds_kb; };
 static da_bwd_overrides da_bwd_read_env() {
     auto num = [](const char* name) { const char* e = getenv(name); return e ? atoi(e) : 0; };
     return da_bwd_overrides{num("FBBEV_DA_BWD_TOKENS"), num("FBBEV_DA_BWD_CHUNKS"), num("FBBEV_DA_BWD_THREADS"),
-                            num("FBBEV_DA_BWD_COPIES")};
+                            num("FBBEV_DA_BWD_COPIES"), num("FBBEV_DA_BWD_LDS_KB")};
 }
 #ifdef FBBEV_TEST_OVERRIDES   // CPU emulator build only (tests/emu/rt.h): the tests switch plans inside one process
 static da_bwd_overrides da_bwd_env() { return da_bwd_read_env(); }
@@ -1200,11 +1324,14 @@ static const da_bwd_overrides& da_bwd_env() {
 }
 #endif
 
+// LDS bytes of the fixed-point planes of one workgroup: 68 KB = two workgroups per CU (FBBEV_DA_BWD_LDS_KB tunes it)
+static int da_bwd_plane_kb() { const int v = da_bwd_env().lds_kb; return v >= 8 && v <= 144 ? v : 68; }
+
 static bool da_bwd_tile_plan(int B, int Ncam, int S, int M, int Dh, int Q, int HS, int L, int P, const int32_t* level_hw,
                              da_bwd_plan* pl) {
     if (Dh > 16 || HS % 4 != 0 || HS > 16 || Q <= 0) return false;
     if (P > FBBEV_DA_BWD_MAXP || !(Dh == 10 || Dh == 8 || Dh == 16 || Dh == 4)) return false;
-    int budget = (68 * 1024) / (HS * (int)sizeof(long long)) - 8;                  // tokens per LDS plane (64-bit words, skewed)
+    int budget = (da_bwd_plane_kb() * 1024) / (HS * (int)sizeof(long long)) - 8;   // tokens per LDS plane (64-bit words, skewed)
     { const int v = da_bwd_env().tokens; if (v > 0 && v < budget) budget = v; }   // tests: force bands
     pl->n_regions = da_bwd_regions(L, level_hw, S, budget, pl->reg, 32);
     if (pl->n_regions == 0) return false;
@@ -1227,7 +1354,7 @@ static bool da_bwd_tile_plan(int B, int Ncam, int S, int M, int Dh, int Q, int H
     pl->chunks = (Q + qpc - 1) / qpc;
     // + the camera's hit list, its counter, the block maximum
     pl->lds = plane + (size_t)((qpc + 1) & ~1) * 2 + (size_t)(1 + pl->threads / 64) * sizeof(int);
-    if (pl->lds > 80 * 1024) return false;
+    if (pl->lds > (size_t)(da_bwd_plane_kb() + 12) * 1024) return false;
     pl->ws = (size_t)B * M * pl->chunks * Ncam * S * HS * sizeof(float);
     return true;
 }
@@ -1294,7 +1421,7 @@ extern "C" int fbbev_da_cross_attn_bwd_ws(const float* value, const int64_t* spa
             const da_region& rg = pl.reg[r];
             // small regions (coarse levels): up to 4 copies of the plane inside the LDS budget of the largest region
             const size_t one = (size_t)FBBEV_DA_PLANE_WORDS(rg.tok1 - rg.tok0, HS) * sizeof(long long);
-            int copies = (int)((size_t)(68 * 1024) / one);
+            int copies = (int)((size_t)(da_bwd_plane_kb() * 1024) / one);
             copies = copies < 1 ? 1 : (copies > 4 ? 4 : copies);
             { const int v = da_bwd_env().copies; if (v >= 1 && v <= copies) copies = v; }
             const size_t lds_b = one * copies + (size_t)((pl.q_per_chunk + 1) & ~1) * 2 + (size_t)(1 + pl.threads / 64) * sizeof(int);
@@ -1571,6 +1698,27 @@ extern "C" int fbbev_layernorm(const float* x, const float* residual, const floa
     const long long blocks = (rows + 7) / 8;          // 8 half-waves per 256-thread workgroup
     if (blocks >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
     FBBEV_LAUNCH(k_layernorm_rows, blocks, 256, 0, (fbbev_rt_stream)stream_, x, residual, weight, bias, eps, rows, C, out);
+    FBBEV_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int fbbev_layernorm_bwd_partials(long long rows) {
+    // workgroups of fbbev_layernorm_bwd = rows of its `partial` output: enough to fill the chip, few enough that the
+    // final sum over them stays small
+    long long wgs = (rows + 7) / 8;
+    if (wgs > 2048) wgs = 2048;
+    return (int)(wgs < 1 ? 1 : wgs);
+}
+
+extern "C" int fbbev_layernorm_bwd(const float* x, const float* grad_out, const float* weight, float eps, long long rows,
+                                   int C, float* grad_x, float* partial, fbbev_stream_t stream_) {
+    if (rows < 0 || C <= 0 || !(eps >= 0.f)) return FBBEV_E_BADARG;
+    if (!partial) return FBBEV_E_BADARG;
+    if (rows > 0 && (!x || !grad_out || !weight || !grad_x)) return FBBEV_E_BADARG;
+    if (C % 4 != 0 || C > 128 || !aligned16(x) || !aligned16(grad_out) || !aligned16(weight) || !aligned16(grad_x))
+        return FBBEV_E_UNSUPPORTED;
+    const int wgs = fbbev_layernorm_bwd_partials(rows);
+    FBBEV_LAUNCH(k_layernorm_rows_bwd, wgs, 256, 0, (fbbev_rt_stream)stream_, x, grad_out, weight, eps, rows, C, grad_x, partial);
     FBBEV_CHECK_LAUNCH();
     return 0;
 }

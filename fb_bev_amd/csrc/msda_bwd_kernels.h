@@ -1,0 +1,257 @@
+// msda_bwd_kernels.h -- MultiScaleDeformableAttention backward without floating-point global atomics (round 3).
+//
+// k_msda_bwd (msda_kernels.h) follows ms_deform_attn_cuda_kernel.cuh's col2im: every (sample, channel) adds its four
+// corner products into grad_value with fp32 global atomics -- 205 M of them for the BEV self-attention of BASELINE
+// configs[2] (B = 4, 40 000 queries, 8 heads, 4 points, Dh = 10), 1.48 ms, bound by the L2's read-modify-write rate, and the
+// sum order (hence the low bits) changes from run to run.  Here, as in k_da_cross_attn_bwd_scatter, the value gradient is
+// accumulated in LDS as 64-bit FIXED POINT (integer adds commute: bit-reproducible) -- but a self-attention plane is the
+// whole 200 x 200 BEV, far beyond LDS, and the queries that touch a token are not known in advance.  So the token space is
+// cut into BANDS of rows and the queries are binned by the rows they reach:
+//   k_msda_row_ranges    (b, q, level) -> [first, last] token row any of the M*P samples of that query can touch
+//                        (one row of slack either side: the scatter kernel must never find a corner this pass excluded);
+//   k_msda_band_queries  (b, band) -> [qlo, qhi): the span of query indices whose range meets the band.  For raster-ordered
+//                        BEV queries sampling around themselves that is the band's rows plus a halo; for arbitrary sampling
+//                        it degrades to [0, Q) -- slower, never wrong;
+//   k_msda_bwd_scatter   workgroup = (b, head, band): walks its query span (lane = query), re-evaluates the samples of the
+//                        band's level and adds the corners that fall inside the band into the LDS plane; the band's tokens
+//                        are then written to grad_value ONCE, by this workgroup alone (no partial planes, no reduction pass,
+//                        no pre-zeroed grad_value);
+//   k_msda_bwd<GW,false> the unit-owned gradients (sampling locations, attention weights) -- the old kernel minus its atomics.
+// Fixed point: scale 2^(30 - ex) with max|grad_output| * max(1, max|attn|) < 2^ex over the workgroup's query span; every
+// product is rounded once to that grid (relative 2^-30 of the largest term), the sum is exact, one rounding back to fp32.
+#pragma once
+#include "rt.h"
+#include "msda_kernels.h"
+#include "da_kernels.h"
+
+struct fbbev_msda_band { int level, r0, r1, w, h, ls; };
+
+// band index -> (level, rows [r0, r1)): level l is cut into ceil(h_l / rpb_l) bands of rpb_l = max(1, budget / w_l) rows.
+// The host applies the same rule to count the bands (fbbev_msda_bwd_ws).
+__device__ __forceinline__ fbbev_msda_band fbbev_msda_band_of(int band, int L, const int64_t* __restrict__ ss,
+                                                              const int64_t* __restrict__ lsi, int budget) {
+    fbbev_msda_band r = {-1, 0, 0, 0, 0, 0};
+    for (int l = 0; l < L; ++l) {
+        const int h = (int)ss[2 * l], w = (int)ss[2 * l + 1];
+        int rpb = budget / (w > 0 ? w : 1);
+        rpb = rpb < 1 ? 1 : rpb;
+        const int nb = (h + rpb - 1) / rpb;
+        if (band < nb) {
+            r.level = l; r.r0 = band * rpb; r.r1 = (r.r0 + rpb < h) ? r.r0 + rpb : h; r.w = w; r.h = h; r.ls = (int)lsi[l];
+            return r;
+        }
+        band -= nb;
+    }
+    return r;
+}
+
+// ranges[(b*L + l)*Q + q] = first | last << 16 (first > last: the query has no sample on that level)
+__global__ void __launch_bounds__(256)
+k_msda_row_ranges(long long n, const int64_t* __restrict__ ss, const float* __restrict__ loc, int M, int L, int Q, int P,
+                  unsigned int* __restrict__ ranges) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int q = (int)(i % Q);
+        const long long bl = i / Q;
+        const int l = (int)(bl % L);
+        const long long b = bl / L;
+        const int h = (int)ss[2 * l];
+        int lo = 0x7fff, hi = -1;
+        for (int m = 0; m < M; ++m) {
+            const float* lp = loc + ((((b * Q + q) * M + m) * L + l) * (long long)P) * 2;
+            for (int p = 0; p < P; ++p) {
+                const float h_im = lp[2 * p + 1] * (float)h - 0.5f;
+                if (h_im > -2.f && h_im < (float)h + 1.f) {               // wider than the sampler's own test: slack
+                    const int r = (int)floorf(h_im);
+                    lo = r - 1 < lo ? r - 1 : lo;
+                    hi = r + 2 > hi ? r + 2 : hi;
+                }
+            }
+        }
+        lo = lo < 0 ? 0 : lo;
+        hi = hi > h - 1 ? h - 1 : hi;
+        ranges[i] = hi >= lo ? ((unsigned)lo | ((unsigned)hi << 16)) : 0x00007fffu;
+    }
+}
+
+// qrange[(b*NB + band)*2 + {0, 1}] = [qlo, qhi)
+__global__ void __launch_bounds__(256)
+k_msda_band_queries(const int64_t* __restrict__ ss, const int64_t* __restrict__ lsi, const unsigned int* __restrict__ ranges,
+                    int L, int Q, int NB, int budget, int* __restrict__ qrange) {
+    __shared__ int red[2][4];
+    const int band = blockIdx.x % NB, b = blockIdx.x / NB;
+    const fbbev_msda_band bd = fbbev_msda_band_of(band, L, ss, lsi, budget);
+    int lo = 0x7fffffff, hi = -1;
+    const unsigned int* rr = ranges + ((long long)b * L + bd.level) * Q;
+    for (int q = threadIdx.x; q < Q; q += 256) {
+        const unsigned int v = rr[q];
+        const int first = (int)(v & 0xffffu), last = (int)(v >> 16);
+        if (first <= last && first < bd.r1 && last >= bd.r0) { lo = q < lo ? q : lo; hi = q > hi ? q : hi; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int l2 = __shfl_xor(lo, o, 64), h2 = __shfl_xor(hi, o, 64);
+        lo = l2 < lo ? l2 : lo; hi = h2 > hi ? h2 : hi;
+    }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = lo; red[1][threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) { lo = red[0][w] < lo ? red[0][w] : lo; hi = red[1][w] > hi ? red[1][w] : hi; }
+        qrange[((long long)b * NB + band) * 2] = hi >= 0 ? lo : 0;
+        qrange[((long long)b * NB + band) * 2 + 1] = hi >= 0 ? hi + 1 : 0;
+    }
+}
+
+template <int NT, int DH>
+__global__ void __launch_bounds__(NT)
+k_msda_bwd_scatter(const int64_t* __restrict__ ss, const int64_t* __restrict__ lsi, const float* __restrict__ loc,
+                   const float* __restrict__ attn, const float* __restrict__ grad_out, const unsigned int* __restrict__ ranges,
+                   const int* __restrict__ qrange, int S, int M, int L, int Q, int P, int NB, int budget,
+                   float* __restrict__ grad_value) {
+    long long* plane = reinterpret_cast<long long*>(fbbev_dyn_lds_f32());
+    __shared__ float red[2][NT / 64];
+    const int band = blockIdx.x % NB;
+    const int m = (blockIdx.x / NB) % M;
+    const int b = blockIdx.x / (NB * M);
+    const fbbev_msda_band bd = fbbev_msda_band_of(band, L, ss, lsi, budget);
+    const int ntok = (bd.r1 - bd.r0) * bd.w, tok0 = bd.r0 * bd.w;
+    const int plane_w = FBBEV_DA_PLANE_WORDS(ntok, DH);
+    const int qlo = qrange[((long long)b * NB + band) * 2], qhi = qrange[((long long)b * NB + band) * 2 + 1];
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < plane_w; i += NT) plane[i] = 0ll;
+    // scale of the plane from the largest |grad_output| and |attention weight| of the span
+    float gmax = 0.f, amax = 1.f;
+    bool finite = true;
+    for (int i = threadIdx.x; i < (qhi - qlo) * DH; i += NT) {
+        const int qi = i / DH, c = i - qi * DH;
+        const float v = fabsf(grad_out[(((long long)b * Q + qlo + qi) * M + m) * DH + c]);
+        finite = finite && (v < __builtin_inff());
+        gmax = fmaxf(gmax, v);
+    }
+    for (int i = threadIdx.x; i < (qhi - qlo) * P; i += NT) {
+        const int qi = i / P, p = i - qi * P;
+        const float v = fabsf(attn[((((long long)b * Q + qlo + qi) * M + m) * L + bd.level) * P + p]);
+        finite = finite && (v < __builtin_inff());
+        amax = fmaxf(amax, v);
+    }
+    if (!finite) gmax = __builtin_inff();
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { gmax = fmaxf(gmax, __shfl_xor(gmax, o, 64)); amax = fmaxf(amax, __shfl_xor(amax, o, 64)); }
+    if (lane == 0) { red[0][threadIdx.x >> 6] = gmax; red[1][threadIdx.x >> 6] = amax; }
+    __syncthreads();
+    gmax = red[0][0]; amax = red[1][0];
+#pragma unroll
+    for (int w = 1; w < NT / 64; ++w) { gmax = fmaxf(gmax, red[0][w]); amax = fmaxf(amax, red[1][w]); }
+    gmax = gmax * amax;
+    const bool poisoned = !(gmax < __builtin_inff());
+    float sc = 0.f, inv_sc = 0.f;
+    if (!poisoned && gmax > 0.f) {
+        unsigned int gb;
+        __builtin_memcpy(&gb, &gmax, 4);
+        int ex = (int)((gb >> 23) & 255u) - 126;
+        if (ex < -90) ex = -90;
+        if (ex > 96) ex = 96;
+        const unsigned int sb = (unsigned int)(127 + 30 - ex) << 23, ib = (unsigned int)(127 - 30 + ex) << 23;
+        __builtin_memcpy(&sc, &sb, 4);
+        __builtin_memcpy(&inv_sc, &ib, 4);
+    }
+    const unsigned int* rr = ranges + ((long long)b * L + bd.level) * Q;
+    if (!poisoned && sc > 0.f) {
+        for (int q = qlo + (int)threadIdx.x; q < qhi; q += NT) {
+            const unsigned int v = rr[q];
+            const int first = (int)(v & 0xffffu), last = (int)(v >> 16);
+            if (!(first <= last && first < bd.r1 && last >= bd.r0)) continue;
+            const long long u = ((long long)b * Q + q) * M + m;
+            float gs[DH];
+#pragma unroll
+            for (int c = 0; c < DH; ++c) gs[c] = grad_out[u * DH + c] * sc;          // sc is a power of two: exact
+            const long long wp = (u * L + bd.level) * P;
+            for (int p = 0; p < P; ++p) {
+                const float loc_w = loc[(wp + p) * 2], loc_h = loc[(wp + p) * 2 + 1], weight = attn[wp + p];
+                const float h_im = loc_h * bd.h - 0.5f, w_im = loc_w * bd.w - 0.5f;
+                if (!(h_im > -1.f && w_im > -1.f && h_im < (float)bd.h && w_im < (float)bd.w)) continue;
+                const fbbev_bilinear s = fbbev_bilinear_setup(h_im, w_im, bd.h, bd.w, 1);       // o1..o4 = token index in the level
+                const int t1 = s.o1 - tok0, t2 = s.o2 - tok0, t3 = s.o3 - tok0, t4 = s.o4 - tok0;
+                const bool k1 = s.o1 >= 0 && t1 >= 0 && t1 < ntok, k2 = s.o2 >= 0 && t2 >= 0 && t2 < ntok;
+                const bool k3 = s.o3 >= 0 && t3 >= 0 && t3 < ntok, k4 = s.o4 >= 0 && t4 >= 0 && t4 < ntok;
+#pragma unroll
+                for (int c = 0; c < DH; ++c) {
+                    const float tgv = gs[c] * weight;                                 // the reference's top_grad * attn_weight
+                    if (k1) fbbev_lds_atomic_add_i64(plane + FBBEV_DA_PLANE_IDX(t1, DH) + c, (long long)__float2int_rn(s.w1 * tgv));
+                    if (k2) fbbev_lds_atomic_add_i64(plane + FBBEV_DA_PLANE_IDX(t2, DH) + c, (long long)__float2int_rn(s.w2 * tgv));
+                    if (k3) fbbev_lds_atomic_add_i64(plane + FBBEV_DA_PLANE_IDX(t3, DH) + c, (long long)__float2int_rn(s.w3 * tgv));
+                    if (k4) fbbev_lds_atomic_add_i64(plane + FBBEV_DA_PLANE_IDX(t4, DH) + c, (long long)__float2int_rn(s.w4 * tgv));
+                }
+            }
+        }
+    }
+    __syncthreads();
+    float* dst = grad_value + (((long long)b * S + bd.ls + tok0) * M + m) * DH;
+    for (int i = threadIdx.x; i < ntok * DH; i += NT) {
+        const int t = i / DH, c = i - t * DH;
+        const long long acc = plane[FBBEV_DA_PLANE_IDX(t, DH) + c];
+        dst[(long long)t * M * DH + c] = poisoned ? __builtin_nanf("") : (float)acc * inv_sc;      // one rounding (int64 -> fp32)
+    }
+}
+
+// Unit-owned gradients with ONE LANE PER (b, q, head) UNIT (the forward's unit-per-lane shape): the four corners of a sample
+// are read as DH/2 8-byte loads each (a head's DH floats are 8-byte aligned for even DH) and the three sums stay in the lane --
+// no 16-lane groups with 6 idle lanes at DH = 10, no shuffles.  Same per-channel expressions as k_msda_bwd, channels summed
+// in ascending order (k_msda_bwd sums 16-lane partials: the results agree to fp32 rounding).
+template <int DH>
+__global__ void __launch_bounds__(256)
+k_msda_bwd_unit(long long n_units, const float* __restrict__ value, const int64_t* __restrict__ spatial_shapes,
+                const int64_t* __restrict__ level_start, const float* __restrict__ loc, const float* __restrict__ attn,
+                const float* __restrict__ grad_out, int spatial_size, int M, int L, int Q, int P,
+                float* __restrict__ grad_loc, float* __restrict__ grad_attn) {
+    static_assert(DH % 2 == 0, "8-byte corner loads");
+    const long long unit = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (unit >= n_units) return;
+    const int m = (int)(unit % M);
+    const long long b = unit / M / Q;
+    const int row_stride = M * DH;
+    float top[DH];
+#pragma unroll
+    for (int c = 0; c < DH; c += 2) {
+        const fbbev_v2f t = *reinterpret_cast<const fbbev_v2f*>(grad_out + unit * DH + c);
+        top[c] = t[0]; top[c + 1] = t[1];
+    }
+    long long wp = unit * L * P;
+    for (int l = 0; l < L; ++l) {
+        const int height = (int)spatial_shapes[2 * l], width = (int)spatial_shapes[2 * l + 1];
+        const float* vb = value + (b * spatial_size + level_start[l]) * row_stride + m * DH;
+        for (int p = 0; p < P; ++p, ++wp) {
+            const float loc_w = loc[wp * 2], loc_h = loc[wp * 2 + 1], weight = attn[wp];
+            const float h_im = loc_h * height - 0.5f, w_im = loc_w * width - 0.5f;
+            if (!(h_im > -1.f && w_im > -1.f && h_im < (float)height && w_im < (float)width)) continue;
+            const fbbev_bilinear s = fbbev_bilinear_setup(h_im, w_im, height, width, row_stride);
+            const bool k1 = s.o1 >= 0, k2 = s.o2 >= 0, k3 = s.o3 >= 0, k4 = s.o4 >= 0;
+            const float* p1 = vb + (k1 ? s.o1 : 0);
+            const float* p2 = vb + (k2 ? s.o2 : 0);
+            const float* p3 = vb + (k3 ? s.o3 : 0);
+            const float* p4 = vb + (k4 ? s.o4 : 0);
+            fbbev_v2f a1[DH / 2], a2[DH / 2], a3[DH / 2], a4[DH / 2];
+#pragma unroll
+            for (int k = 0; k < DH / 2; ++k) {                    // unconditional loads (a padded corner reads token 0), zeros selected below
+                a1[k] = *reinterpret_cast<const fbbev_v2f*>(p1 + 2 * k);
+                a2[k] = *reinterpret_cast<const fbbev_v2f*>(p2 + 2 * k);
+                a3[k] = *reinterpret_cast<const fbbev_v2f*>(p3 + 2 * k);
+                a4[k] = *reinterpret_cast<const fbbev_v2f*>(p4 + 2 * k);
+            }
+            float g_w = 0.f, g_x = 0.f, g_y = 0.f;
+#pragma unroll
+            for (int c = 0; c < DH; ++c) {
+                const float v1 = k1 ? a1[c >> 1][c & 1] : 0.f, v2 = k2 ? a2[c >> 1][c & 1] : 0.f;
+                const float v3 = k3 ? a3[c >> 1][c & 1] : 0.f, v4 = k4 ? a4[c >> 1][c & 1] : 0.f;
+                const float tgv = top[c] * weight;
+                const float ghw = -s.hw * v1 - s.lw * v2 + s.hw * v3 + s.lw * v4;
+                const float gww = -s.hh * v1 + s.hh * v2 - s.lh * v3 + s.lh * v4;
+                g_w += top[c] * (s.w1 * v1 + s.w2 * v2 + s.w3 * v3 + s.w4 * v4);
+                g_x += (float)width * gww * tgv;
+                g_y += (float)height * ghw * tgv;
+            }
+            grad_attn[wp] += g_w;
+            grad_loc[wp * 2] += g_x;
+            grad_loc[wp * 2 + 1] += g_y;
+        }
+    }
+}

@@ -255,7 +255,8 @@ __device__ __forceinline__ float fbbev_group_sum(float v) {
     return v;
 }
 
-template <int GW>
+// SCATTER = false: the unit-owned gradients only (grad_value comes from k_msda_bwd_scatter, msda_bwd_kernels.h)
+template <int GW, bool SCATTER = true>
 __global__ void __launch_bounds__(256)
 k_msda_bwd(long long n_units, const float* __restrict__ value,
            const int64_t* __restrict__ spatial_shapes, const int64_t* __restrict__ level_start,
@@ -286,11 +287,12 @@ k_msda_bwd(long long n_units, const float* __restrict__ value,
                     const float tgv = top * weight;
                     const float* vp = value + voff + c;
                     float* gp = grad_value + voff + c;
+                    (void)gp;
                     float ghw = 0.f, gww = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;
-                    if (s.o1 >= 0) { v1 = vp[s.o1]; ghw -= s.hw * v1; gww -= s.hh * v1; fbbev_atomic_add_f32(gp + s.o1, s.w1 * tgv); }
-                    if (s.o2 >= 0) { v2 = vp[s.o2]; ghw -= s.lw * v2; gww += s.hh * v2; fbbev_atomic_add_f32(gp + s.o2, s.w2 * tgv); }
-                    if (s.o3 >= 0) { v3 = vp[s.o3]; ghw += s.hw * v3; gww -= s.lh * v3; fbbev_atomic_add_f32(gp + s.o3, s.w3 * tgv); }
-                    if (s.o4 >= 0) { v4 = vp[s.o4]; ghw += s.lw * v4; gww += s.lh * v4; fbbev_atomic_add_f32(gp + s.o4, s.w4 * tgv); }
+                    if (s.o1 >= 0) { v1 = vp[s.o1]; ghw -= s.hw * v1; gww -= s.hh * v1; if constexpr (SCATTER) fbbev_atomic_add_f32(gp + s.o1, s.w1 * tgv); }
+                    if (s.o2 >= 0) { v2 = vp[s.o2]; ghw -= s.lw * v2; gww += s.hh * v2; if constexpr (SCATTER) fbbev_atomic_add_f32(gp + s.o2, s.w2 * tgv); }
+                    if (s.o3 >= 0) { v3 = vp[s.o3]; ghw += s.hw * v3; gww -= s.lh * v3; if constexpr (SCATTER) fbbev_atomic_add_f32(gp + s.o3, s.w3 * tgv); }
+                    if (s.o4 >= 0) { v4 = vp[s.o4]; ghw += s.lw * v4; gww += s.lh * v4; if constexpr (SCATTER) fbbev_atomic_add_f32(gp + s.o4, s.w4 * tgv); }
                     const float val = s.w1 * v1 + s.w2 * v2 + s.w3 * v3 + s.w4 * v4;
                     g_w += top * val;
                     g_x += (float)width * gww * tgv;

@@ -276,6 +276,23 @@ int fbbev_msda_bwd(const float* value, const int64_t* spatial_shapes,
                    float* grad_value, float* grad_sampling_loc, float* grad_attn_weight,
                    fbbev_stream_t stream);
 
+/* The same backward without floating-point global atomics (bit-reproducible): grad_value is accumulated per (sample, head,
+ * BAND of token rows) in LDS as 64-bit fixed point and every token is written exactly once -- grad_value need NOT be
+ * pre-zeroed; grad_sampling_loc / grad_attn_weight are accumulated into as above.  Queries are binned by the token rows
+ * their samples reach (two small passes over sampling_loc into `ws`), so raster-ordered BEV queries that sample around
+ * themselves cost a halo of re-evaluated samples per band; arbitrary sampling stays correct and gets slower.
+ * level_hw_host: HOST array of num_levels (h, w) pairs (the band count is a launch dimension).  ws: device scratch of
+ * fbbev_msda_bwd_ws_bytes(...) bytes; 0 from that function (channels not in {4,8,10,16,32}, a level wider than a plane,
+ * no host shapes) means this entry forwards to fbbev_msda_bwd -- then grad_value MUST be pre-zeroed, so callers zero it
+ * whenever ws_bytes() returned 0. */
+size_t fbbev_msda_bwd_ws_bytes(int batch, int spatial_size, int num_heads, int channels, int num_levels, int num_query,
+                               int num_point, const int32_t* level_hw_host);
+int fbbev_msda_bwd_ws(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                      const float* sampling_loc, const float* attn_weight, const float* grad_output, int batch,
+                      int spatial_size, int num_heads, int channels, int num_levels, int num_query, int num_point,
+                      float* grad_value, float* grad_sampling_loc, float* grad_attn_weight,
+                      const int32_t* level_hw_host, void* ws, size_t ws_bytes, fbbev_stream_t stream);
+
 /* ----------------------------------------------------------------------------------------------
  * Fused backward-projection sampling (additive)
  * -------------------------------------------------------------------------------------------- */
@@ -439,6 +456,17 @@ int fbbev_history_warp_e(const void* history, long long history_stride_b, const 
  * FBBEV_E_UNSUPPORTED (callers keep torch's kernel).  residual may be NULL; out may alias x. */
 int fbbev_layernorm(const float* x, const float* residual, const float* weight, const float* bias, float eps,
                     long long rows, int C, float* out, fbbev_stream_t stream);
+
+/* Backward of fbbev_layernorm without a residual (training of the backward projection: the `norm` steps of
+ * BEVFormerEncoderLayer under autograd, bevformer_encoder.py:250-377; replaces ATen's native_layer_norm_backward):
+ *   grad_x[row] = inv * (g - mean(g) - xhat * mean(g * xhat)),   g = grad_out[row] * weight, xhat = (x[row] - mean) * inv
+ * and per workgroup w one pair of partial parameter gradients  partial[w][0][C] = sum grad_out * xhat (-> weight),
+ * partial[w][1][C] = sum grad_out (-> bias) over the rows that workgroup walked; the caller sums the
+ * fbbev_layernorm_bwd_partials(rows) partial rows (fixed order: deterministic, no atomics).  mean / inv are recomputed
+ * from x.  Same shape limits and return codes as fbbev_layernorm. */
+int fbbev_layernorm_bwd_partials(long long rows);
+int fbbev_layernorm_bwd(const float* x, const float* grad_out, const float* weight, float eps, long long rows, int C,
+                        float* grad_x, float* partial, fbbev_stream_t stream);
 
 /* The two 1x1x1 convolutions of the temporal fusion in one fp32-MFMA kernel (inference): replaces
  * history_keyframe_time_conv + history_keyframe_cat_conv of FBOCC.fuse_history (fbocc.py:111-127, 289-310) once the

@@ -118,6 +118,23 @@ def msda_bwd(value, ss, ls, loc, w, go):
     return gv, gl, gw
 
 
+def msda_bwd_ws(value, ss, ls, loc, w, go, level_hw):
+    """the band-binned fixed-point backward; grad_value starts as NaN (the kernels must write every token); returns None when
+    the library reports no plan for the shape"""
+    B, S, M, Dh = value.shape
+    _, Q, _, L, P, _ = loc.shape
+    flat = [int(x) for hw in level_hw for x in hw]
+    arr = (ctypes.c_int32 * len(flat))(*flat)
+    need = lib().fbbev_msda_bwd_ws_bytes(B, S, M, Dh, L, Q, P, arr)
+    if not need:
+        return None
+    ws = torch.zeros(need, dtype=torch.uint8)
+    gv, gl, gw = torch.full_like(value, float('nan')), torch.zeros_like(loc), torch.zeros_like(w)
+    ok(lib().fbbev_msda_bwd_ws(p(value), p(ss), p(ls), p(loc), p(w), p(go), B, S, M, Dh, L, Q, P, p(gv), p(gl), p(gw), arr,
+                               p(ws), need, None))
+    return gv, gl, gw
+
+
 def lidar_coor(xs, ys, ds, cam):
     rots, trans, intrins, post_rots, post_trans, bda = cam
     B, N = trans.shape[:2]
@@ -239,6 +256,17 @@ def layernorm(x, weight, bias, eps, residual=None):
     ok(lib().fbbev_layernorm(p(x), p(residual) if residual is not None else None, p(weight), p(bias), eps,
                              x.numel() // C, C, p(out), None))
     return out
+
+
+def layernorm_bwd(x, grad_out, weight, eps):
+    C = x.shape[-1]
+    rows = x.numel() // C
+    n = lib().fbbev_layernorm_bwd_partials(rows)
+    partial = torch.full((n, 2, C), float('nan'))
+    gx = torch.full_like(x, float('nan'))
+    ok(lib().fbbev_layernorm_bwd(p(x), p(grad_out), p(weight), eps, rows, C, p(gx), p(partial), None))
+    s = partial.sum(0)
+    return gx, s[0], s[1]
 
 
 def da_cross_attn_bwd(value, ss, ls, pred_depth, ref_cam, mask, qdepth, offsets, attn, d0, dstep, grad_slots, head_minor=0,

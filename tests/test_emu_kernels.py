@@ -159,6 +159,49 @@ def test_msda_fwd_bwd_emulated():
         assert torch.allclose(gw, egw, atol=1e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize('lds_kb', [0, 8])
+def test_msda_bwd_band_binned_fixed_point_emulated(lds_kb, monkeypatch):
+    """fbbev_msda_bwd_ws (query bins per band of token rows, 64-bit fixed-point LDS planes, every token written once) against
+    the oracle and against the atomic kernel: random sampling all over the levels (query spans = everything), several
+    bands per level with the small LDS budget, Dh = 59 has no plan; and a BEV-like case -- raster-ordered queries sampling
+    around their own cell -- where the spans must be short and the result identical."""
+    from test_oracle_msda import CASES, make_case
+    if lds_kb:
+        monkeypatch.setenv('FBBEV_MSDA_BWD_LDS_KB', str(lds_kb))
+    for case in CASES:
+        value, ss, ls, loc, w = make_case(**case)
+        go = torch.randn(value.shape[0], loc.shape[1], value.shape[2] * value.shape[3], generator=torch.Generator().manual_seed(1))
+        got = E.msda_bwd_ws(value, ss, ls, loc, w, go, case['shapes'])
+        if case['Dh'] == 59:
+            assert got is None
+            continue
+        gv, gl, gw = got
+        egv, egl, egw = O.msda_bwd(value, ss, ls, loc, w, go)
+        assert not torch.isnan(gv).any()
+        assert torch.allclose(gv, egv, atol=1e-5, rtol=1e-5)
+        assert torch.allclose(gl, egl, atol=1e-4, rtol=1e-4)
+        assert torch.allclose(gw, egw, atol=1e-5, rtol=1e-5)
+    # BEV self-attention shape: 24 x 20 cells, queries in raster order, 4 points within +-2.5 cells of the query's cell
+    g = torch.Generator().manual_seed(9)
+    H, W, M, Dh, P, B = 24, 20, 2, 10, 4, 2
+    ss = torch.tensor([[H, W]], dtype=torch.int64); ls = torch.zeros(1, dtype=torch.int64)
+    value = torch.randn(B, H * W, M, Dh, generator=g)
+    ys, xs = torch.meshgrid(torch.arange(H), torch.arange(W), indexing='ij')
+    ref = torch.stack([(xs.flatten() + 0.5) / W, (ys.flatten() + 0.5) / H], -1)               # (Q, 2) as (x, y)
+    off = (torch.rand(B, H * W, M, 1, P, 2, generator=g) - 0.5) * 5.0 / torch.tensor([W, H])
+    loc = (ref[None, :, None, None, None, :] + off).contiguous()
+    w = torch.rand(B, H * W, M, 1, P, generator=g).softmax(-1).contiguous()
+    go = torch.randn(B, H * W, M * Dh, generator=g) * 1e3                                       # a large gradient scale
+    gv, gl, gw = E.msda_bwd_ws(value, ss, ls, loc, w, go, [[H, W]])
+    egv, egl, egw = O.msda_bwd(value, ss, ls, loc, w, go)
+    assert not torch.isnan(gv).any()
+    assert (gv - egv).abs().max() <= 2e-6 * egv.abs().max()
+    assert torch.allclose(gl, egl, atol=1e-1, rtol=1e-4) and torch.allclose(gw, egw, atol=1e-2, rtol=1e-5)
+    # bit-reproducible: a second run gives the same bits (integer sums), and a poisoned gradient poisons only its band span
+    gv2, _, _ = E.msda_bwd_ws(value, ss, ls, loc, w, go, [[H, W]])
+    assert torch.equal(gv, gv2)
+
+
 def test_pool_dense_partial_tiles_small_config():
     """SMALL: 50x50x8 grid (YX=2500 is not a multiple of 64/128), C=20 (5 lanes per interval)."""
     cfg, vt, coor, depth, feat = _case('SMALL', 1)
@@ -583,6 +626,22 @@ def test_layernorm_rows_emulated(rows, C):
     assert torch.allclose(E.layernorm(x, w, b, 1e-5), exp, atol=2e-6, rtol=1e-5)
     exp2 = torch.nn.functional.layer_norm(x + r, (C,), w, b, 1e-5)
     assert torch.allclose(E.layernorm(x, w, b, 1e-5, residual=r), exp2, atol=2e-6, rtol=1e-5)
+
+
+@pytest.mark.parametrize('rows,C', [(37, 80), (8, 128), (5, 4), (3000, 80), (20000, 64)])
+def test_layernorm_rows_backward_emulated(rows, C):
+    """fbbev_layernorm_bwd == autograd of torch's layer_norm: input gradient per row, weight / bias gradients from the summed
+    per-workgroup partial rows (20 000 rows: more rows than row slots, the grid-stride walk; 3 000: a partly filled last round)."""
+    g = torch.Generator().manual_seed(rows)
+    x = (torch.randn(rows, C, generator=g) * 3 + 1.5).requires_grad_()
+    w = torch.randn(C, generator=g).requires_grad_()
+    b = torch.randn(C, generator=g).requires_grad_()
+    gy = torch.randn(rows, C, generator=g)
+    torch.nn.functional.layer_norm(x, (C,), w, b, 1e-5).backward(gy)
+    gx, gw, gb = E.layernorm_bwd(x.detach(), gy, w.detach(), 1e-5)
+    assert torch.allclose(gx, x.grad, atol=3e-6, rtol=2e-5)
+    assert (gw - w.grad).abs().max() <= 2e-5 * w.grad.abs().max().clamp_min(1.0)
+    assert (gb - b.grad).abs().max() <= 2e-5 * b.grad.abs().max().clamp_min(1.0)
 
 
 def test_fused_da_cross_attention_backward_emulated():

@@ -426,3 +426,75 @@ def test_rows_linear_split_k_backward_on_the_gpu():
     assert torch.equal(y, y2)
     for a, r in zip(got, [x.grad, lin.weight.grad, lin.bias.grad]):
         assert (a - r).abs().max() <= 2e-5 * r.abs().max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('rows,C', [(160000, 80), (1000, 128), (37, 64)])
+def test_layernorm_training_route_equals_torch_autograd(rows, C):
+    """backward_projection.LayerNorm with autograd on: fbbev_layernorm + fbbev_layernorm_bwd (custom node) against
+    nn.LayerNorm's own forward / backward -- output, input gradient, weight / bias gradients."""
+    from fb_bev_amd.backward_projection import LayerNorm
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(rows + C)
+    ln = LayerNorm(C).to(dev)
+    ref = torch.nn.LayerNorm(C).to(dev)
+    with torch.no_grad():
+        ln.weight.copy_(torch.randn(C, generator=g)); ln.bias.copy_(torch.randn(C, generator=g))
+    ref.load_state_dict(ln.state_dict())
+    x = (torch.randn(4, rows // 4 if rows % 4 == 0 else rows, C, generator=g) * 2 + 0.5).to(dev)
+    res = torch.randn(x.shape, generator=g).to(dev)
+    gy = torch.randn(x.shape, generator=g).to(dev)
+    for r in (None, res):
+        xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+        ya = ln(xa, residual=r)
+        assert 'LayerNormRows' in type(ya.grad_fn).__name__
+        yb = ref(xb if r is None else xb + r)
+        ya.backward(gy); yb.backward(gy)
+        assert torch.allclose(ya, yb, atol=3e-6, rtol=2e-5)
+        assert torch.allclose(xa.grad, xb.grad, atol=5e-6, rtol=5e-5)
+        for a, b in ((ln.weight.grad, ref.weight.grad), (ln.bias.grad, ref.bias.grad)):
+            assert (a - b).abs().max() <= 3e-5 * b.abs().max().clamp_min(1.0)
+        ln.zero_grad(); ref.zero_grad()
+
+
+@pytest.mark.gpu
+def test_msda_backward_band_binned_route_on_the_gpu():
+    """MultiScaleDeformableAttnFunction_fp32 backward at the configs[2] self-attention shape (200 x 200 BEV, raster queries
+    sampling around their own cell): the atomic-free kernels are taken (grad_value starts uninitialised), equal the fp32
+    global-atomic kernel to rounding, and two runs give the SAME bits (the atomic kernel does not promise that)."""
+    from fb_bev_amd import _capi
+    from fb_bev_amd.backward_projection import const_tensor
+    from fb_bev_amd.ms_deform_attn import MultiScaleDeformableAttnFunction_fp32 as F32
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(11)
+    H = W = 200
+    B, M, Dh, P = 2, 8, 10, 4
+    ss = const_tensor([[H, W]], dev)
+    ls = const_tensor([0], dev)
+    assert _capi.msda_bwd_ws_bytes(B, H * W, M, Dh, 1, H * W, P, [[H, W]]) > 0
+    value = torch.randn(B, H * W, M, Dh, generator=g).to(dev)
+    ys, xs = torch.meshgrid(torch.arange(H), torch.arange(W), indexing='ij')
+    ref = torch.stack([(xs.flatten() + 0.5) / W, (ys.flatten() + 0.5) / H], -1)
+    off = (torch.rand(B, H * W, M, 1, P, 2, generator=g) - 0.5) * 8.0 / torch.tensor([W, H])
+    loc = (ref[None, :, None, None, None, :] + off).contiguous().to(dev)
+    w = torch.rand(B, H * W, M, 1, P, generator=g).softmax(-1).contiguous().to(dev)
+    go = torch.randn(B, H * W, M * Dh, generator=g).to(dev)
+
+    def run(level_hw):
+        gv = torch.full_like(value, float('nan')) if level_hw else torch.zeros_like(value)
+        gl, gw = torch.zeros_like(loc), torch.zeros_like(w)
+        _capi.msda_bwd(value, ss, ls, loc, w, go, gv, gl, gw, level_hw=level_hw)
+        return gv, gl, gw
+    a = run([[H, W]])
+    b = run(None)
+    a2 = run([[H, W]])
+    torch.cuda.synchronize()
+    assert not torch.isnan(a[0]).any()
+    assert (a[0] - b[0]).abs().max() <= 1e-5 * b[0].abs().max()
+    assert torch.allclose(a[1], b[1], atol=1e-4, rtol=1e-4) and torch.allclose(a[2], b[2], atol=1e-5, rtol=1e-5)
+    assert torch.equal(a[0], a2[0])
+    # through the autograd Function: the host level shapes ride on the const tensor
+    v = value.clone().requires_grad_()
+    out = F32.apply(v, ss, ls, loc, w, 64)
+    out.backward(go)
+    assert torch.equal(v.grad, a[0])
