@@ -54,6 +54,7 @@ SIGNATURES = {
     'fbbev_history_conv': (c_int, [c_void_p, c_int64] + [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t, c_void_p]),
     'fbbev_history_conv_e': (c_int, [c_void_p, c_int64] + [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     'fbbev_history_conv_bf16': (c_int, [c_void_p, c_int64] + [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
+    'fbbev_history_conv_bf16x3': (c_int, [c_void_p, c_int64] + [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     'fbbev_history_conv_vm': (c_int, [c_void_p, c_int64] + [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     'fbbev_history_fused_vm': (c_int, [c_void_p, c_int64, c_void_p, c_int64] + [c_void_p] * 5 + [c_int] * 7 +
                                [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
@@ -832,6 +833,7 @@ def history_conv(feats, w1, bias1, w2, bias2, out, compute=torch.float32, voxel_
     """feats (B, T1*C, N) f32 / bf16 / f16 whose per-sample block is contiguous; w1 (C,C); bias1 (B*T1, C); w2 (Cout, T1*C);
     bias2 (Cout); out (B, Cout, N) f32 contiguous -> out = relu(bias2 + sum_t w2_t . relu(w1 . x_t + bias1_t)).
     compute=torch.bfloat16: both GEMMs on the bf16 MFMA with fp32 accumulation (fbbev_history_conv_bf16);
+    compute='bf16x3': the same at fp32-grade precision, operands split into two bf16 terms (fbbev_history_conv_bf16x3);
     voxel_major=True: feats is (B, T1, N, C), the voxel-major ring (C = Cout in {16, 80})."""
     C = w1.shape[0]
     Cout = w2.shape[0]
@@ -844,14 +846,18 @@ def history_conv(feats, w1, bias1, w2, bias2, out, compute=torch.float32, voxel_
         ok = feats.stride()[1:] == (N, 1)
     if not ok or tuple(out.shape) != (B, Cout, N) or feats.dtype not in ELEM_TYPE:
         raise FbbevError('history_conv: bad feats / out layout')
-    if compute not in (torch.float32, torch.bfloat16):
-        raise FbbevError('history_conv: compute is float32 or bfloat16')
+    if compute not in (torch.float32, torch.bfloat16, 'bf16x3'):
+        raise FbbevError("history_conv: compute is float32, bfloat16 or 'bf16x3'")
+    if compute == 'bf16x3' and not (voxel_major and feats.dtype in (torch.bfloat16, torch.float16)):
+        raise FbbevError("history_conv: compute='bf16x3' needs a 16-bit voxel-major ring")
     ws = torch.empty((1 + T1) * C * max(C, Cout, 96), dtype=torch.float32, device=feats.device)   # fragment-ordered weights
     args = (_dev(feats, feats.dtype, 'feats', contiguous=False), feats.stride(0), _dev(w1, F32, 'w1'),
             _dev(bias1, F32, 'bias1'), _dev(w2, F32, 'w2'), _dev(bias2, F32, 'bias2'),
             B, T1, C, Cout, N, _dev(out, F32, 'out'), c_void_p(ws.data_ptr()), ws.numel() * 4)
     with _on(feats):
-        if compute == torch.bfloat16:
+        if compute == 'bf16x3':
+            _check(lib().fbbev_history_conv_bf16x3(*args, ELEM_TYPE[feats.dtype], _stream()), 'fbbev_history_conv_bf16x3')
+        elif compute == torch.bfloat16:
             _check(lib().fbbev_history_conv_bf16(*args, 1 if voxel_major else 0, ELEM_TYPE[feats.dtype], _stream()),
                    'fbbev_history_conv_bf16')
         elif voxel_major:

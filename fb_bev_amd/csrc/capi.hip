@@ -14,6 +14,7 @@
 #include "norm_kernels.h"
 #include "history_conv_kernels.h"
 #include "history_fused_kernels.h"
+#include "history_conv_x3_kernels.h"
 #include "msda_bwd_kernels.h"
 #include "conv3d_kernels.h"
 #include "../../include/fbbev.h"
@@ -1824,6 +1825,48 @@ extern "C" int fbbev_history_conv_bf16(const void* feats, long long feats_stride
     if (voxel_major) return elem_type == 0 ? FBBEV_HCB(0, true) : elem_type == 1 ? FBBEV_HCB(1, true) : FBBEV_HCB(2, true);
     return elem_type == 0 ? FBBEV_HCB(0, false) : elem_type == 1 ? FBBEV_HCB(1, false) : FBBEV_HCB(2, false);
 #undef FBBEV_HCB
+}
+
+// fp32-grade convolutions on the bf16 MFMA (three products per operand pair, history_conv_x3_kernels.h): voxel-major 16-bit ring
+extern "C" int fbbev_history_conv_bf16x3(const void* feats, long long feats_stride_b, const float* w1, const float* bias1,
+                                         const float* w2, const float* bias2, int B, int T1, int C, int Cout, int N,
+                                         float* out, void* workspace, size_t workspace_bytes, int elem_type,
+                                         fbbev_stream_t stream_) {
+    if (B < 0 || T1 <= 0 || C <= 0 || Cout <= 0 || N < 0 || elem_type < 0 || elem_type > 2) return FBBEV_E_BADARG;
+    if (B == 0 || N == 0) return 0;
+    if (!feats || !w1 || !bias1 || !w2 || !bias2 || !out) return FBBEV_E_BADARG;
+    if (!((C == 80 && Cout == 80) || (C == 16 && Cout == 16)) || elem_type == 0) return FBBEV_E_UNSUPPORTED;
+    if (feats_stride_b == 0) feats_stride_b = (long long)T1 * C * N;
+    if (feats_stride_b < (long long)T1 * C * N) return FBBEV_E_BADARG;
+    if (!aligned16(feats) || feats_stride_b % 8 != 0 || !aligned16(bias1)) return FBBEV_E_UNSUPPORTED;
+    if ((long long)N * C * 2 >= (1ll << 32)) return FBBEV_E_UNSUPPORTED;                          // 32-bit byte offsets in a frame
+    const int MT = C / 16, KS = (C + 31) / 32;
+    const size_t part1 = (size_t)MT * KS * 64 * 8, part2 = part1;
+    const size_t need = (2 * part1 + (size_t)T1 * 2 * part2) * sizeof(unsigned short);
+    if (!workspace || !aligned16(workspace) || workspace_bytes < need) return FBBEV_E_WORKSPACE;
+    fbbev_rt_stream stream = (fbbev_rt_stream)stream_;
+    unsigned short* w1x = static_cast<unsigned short*>(workspace);
+    unsigned short* w2x = w1x + 2 * part1;
+    const int nfrag = (MT * KS + T1 * MT * KS) * 64;
+    FBBEV_LAUNCH(k_history_weight_fragments_bf16x3, (nfrag + 255) / 256, 256, 0, stream, w1, w2, MT, MT, C, T1, w1x);
+    FBBEV_CHECK_LAUNCH();
+    const int tiles_per_b = (N + 127) / 128;
+    const long long blocks = (long long)B * tiles_per_b;
+    if (blocks >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
+    const size_t a2s = (size_t)((2 * part2 / 8 + 511) / 512) * 512 * 8;
+    const size_t lds = (2 * a2s + part1 + (size_t)8 * 16 * 2 * (KS * 32 + 8)) * sizeof(unsigned short);
+#define FBBEV_HX3(MT_, ET_)                                                                                            \
+    do {                                                                                                              \
+        int e_ = fbbev_rt_allow_dyn_lds((const void*)k_history_conv_bf16x3<MT_, MT_, ET_>, lds);                        \
+        if (e_) return e_;                                                                                            \
+        FBBEV_LAUNCH((k_history_conv_bf16x3<MT_, MT_, ET_>), blocks, 512, lds, stream, feats, feats_stride_b,           \
+                     (const unsigned short*)w1x, bias1, (const unsigned short*)w2x, bias2, T1, N, tiles_per_b, out);    \
+    } while (0)
+    if (C == 80) { if (elem_type == 1) FBBEV_HX3(5, 1); else FBBEV_HX3(5, 2); }
+    else { if (elem_type == 1) FBBEV_HX3(1, 1); else FBBEV_HX3(1, 2); }
+#undef FBBEV_HX3
+    FBBEV_CHECK_LAUNCH();
+    return 0;
 }
 
 // Warp + new ring + both convolutions in ONE kernel (k_history_fused_bf16): history (B,T,N,C) -> next ring slots 1..T of

@@ -62,7 +62,8 @@ class FBOCC(nn.Module):
         config trains them under mmcv's fp16 hook, cfg :394) -- and with_cp=True|False to override the blocks'
         activation checkpointing (the configs turn it on to fit 16-32 GB parts; 288 GB of HBM does not need it);
         history_dtype='f16' | 'bf16' stores the inference history ring in 16 bits (BASELINE configs[4]);
-        history_compute='bf16' runs the two fused history convolutions on the bf16 MFMA (fp32 accumulate) at inference;
+        history_compute='bf16' runs the two fused history convolutions on the bf16 MFMA (fp32 accumulate) at inference,
+        'bf16x3' the same at fp32-grade precision (split operands; 16-bit voxel-major ring);
         history_ring='voxel_major' keeps the inference ring as (B, T, N, C) voxel rows (16-byte taps, same element bits);
         da_value_dtype='bf16' | 'f16' keeps the cross-attention's camera tokens in 16 bits at inference (fp32 accumulate);
         mfma_conv3d / mfma_conv3d_train=True route the voxel encoder + head through fbbev_conv3d_* (mfma_conv3d.py)."""

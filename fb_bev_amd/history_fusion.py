@@ -62,7 +62,9 @@ class TemporalHistoryFusion(nn.Module):
         self.history_dtype = history_dtype
         # Arithmetic of the two fused inference convolutions: float32 (the reference, fbocc.py:279-282 force_fp32), or
         # bfloat16 = both GEMMs on the bf16 MFMA with fp32 accumulation (weights, frames and the ReLU'd intermediate rounded to
-        # bf16; ~1e-2 relative on the fused volume) -- at 400x400x16 the fp32-MFMA kernel is compute bound.
+        # bf16; ~4e-3 of the output peak) -- at 400x400x16 the fp32-MFMA kernel is compute bound; or
+        # 'bf16x3' = fp32-GRADE results on the bf16 MFMA (every operand split into two bf16 terms, three MFMAs per product:
+        # ~5e-6 of the output peak; 16-bit voxel-major ring, C = Cout in {16, 80} -- anything else runs float32).
         self.history_compute = history_compute
         # Layout of the inference ring: 'planar' = the reference's (B, T*C, Z, Y, X); 'voxel_major' = (B, T, N, C) frames of
         # voxel rows (history_kernels.h): a trilinear tap is one 16-byte load of 8 channels instead of 8 scalar gathers from 8
@@ -310,9 +312,12 @@ class TemporalHistoryFusion(nn.Module):
                                          torch.empty((B, 80, n), dtype=torch.float32, device=curr_yxz.device))
             return out.view(B, -1, Z, Y, X), nxt
         _capi.history_warp_vm(hist, flow, nxt[:, 1:], (Z, Y, X))                            # slots 1..T (:275)
+        compute = self.history_compute
+        if compute == 'bf16x3' and not (nxt.dtype in (torch.bfloat16, torch.float16) and C == w2.shape[0] and C in (16, 80)):
+            compute = torch.float32
         out = _capi.history_conv(nxt, w1, bias1, w2, b2,
                                  torch.empty((B, w2.shape[0], n), dtype=torch.float32, device=curr_yxz.device),
-                                 compute=self.history_compute, voxel_major=True)
+                                 compute=compute, voxel_major=True)
         return out.view(B, -1, Z, Y, X), nxt
 
     def _fuse_infer(self, curr, flow, sweep):
@@ -338,6 +343,8 @@ class TemporalHistoryFusion(nn.Module):
         if self.use_mfma_convs and C % 16 == 0 and cout % 16 == 0 and max(C, cout) <= 128:
             # both convs in one MFMA kernel: the (T+1)*C-channel intermediate never leaves the CU
             compute = self.history_compute if (C == cout and C in (16, 80)) else torch.float32
+            if compute == 'bf16x3':                 # the split-operand kernel reads voxel rows only
+                compute = torch.float32
             out = _capi.history_conv(nxt.view(B, (T + 1) * C, n), w1c, bias1.contiguous(), w2, b2,
                                      torch.empty((B, cout, n), dtype=torch.float32, device=curr.device), compute=compute)
         else:

@@ -291,7 +291,7 @@ def da_cross_attn_bwd(value, ss, ls, pred_depth, ref_cam, mask, qdepth, offsets,
     return gv, gd, go, ga
 
 
-def history_conv(feats, w1, bias1, w2, bias2, bf16=False, voxel_major=False):
+def history_conv(feats, w1, bias1, w2, bias2, bf16=False, voxel_major=False, x3=False):
     C, Cout = w1.shape[0], w2.shape[0]
     if voxel_major:
         B, T1, N, _ = feats.shape
@@ -303,7 +303,9 @@ def history_conv(feats, w1, bias1, w2, bias2, bf16=False, voxel_major=False):
     et = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[feats.dtype]
     args = (c_void_p(feats.data_ptr()), feats.stride(0), p(w1), p(bias1), p(w2), p(bias2), B, T1, C, Cout, N, p(out), p(ws),
             ws.numel() * 4)
-    if bf16:
+    if x3:
+        ok(lib().fbbev_history_conv_bf16x3(*args, et, None))
+    elif bf16:
         ok(lib().fbbev_history_conv_bf16(*args, 1 if voxel_major else 0, et, None))
     elif voxel_major:
         ok(lib().fbbev_history_conv_vm(*args, et, None))

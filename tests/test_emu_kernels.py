@@ -1131,6 +1131,28 @@ def test_history_voxel_major_ring_equals_planar_kernels_emulated(dt):
         assert torch.allclose(b32.double(), exp, atol=2e-5, rtol=1e-5) and torch.allclose(a32, b32, atol=2e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize('dt', [torch.float16, torch.bfloat16])
+def test_history_convs_bf16x3_are_fp32_grade_emulated(dt):
+    """fbbev_history_conv_bf16x3 (operands split into two bf16 terms, three MFMAs per product) on a 16-bit voxel-major ring against
+    the float64 convolutions of the SAME stored frames: < 2e-5 of the output peak (measured 5e-6) -- more than 50x better than the
+    plain bf16 route on the same input (2.6e-3), the fp32-MFMA kernel sits at 2e-7; partial 128-voxel tiles, T1 = 1 (prefetch ring with one frame)."""
+    g = torch.Generator().manual_seed(31)
+    for Cc, T1, n in ((16, 3, 70), (80, 2, 33), (16, 1, 20), (80, 5, 150)):
+        feats = (torch.randn(2, T1, n, Cc, generator=g) * 2).to(dt)
+        w1, w2 = torch.randn(Cc, Cc, generator=g) * 0.3, torch.randn(Cc, T1 * Cc, generator=g) * 0.2
+        b1, b2 = torch.randn(2 * T1, Cc, generator=g), torch.randn(Cc, generator=g)
+        got = E.history_conv(feats, w1, b1, w2, b2, voxel_major=True, x3=True)
+        x = feats.double().transpose(2, 3)                                            # (B, T1, C, n)
+        y = torch.relu(torch.einsum('oc,btcn->bton', w1.double(), x) + b1.view(2, T1, Cc, 1).double())
+        exp = torch.relu(torch.einsum('oc,bcn->bon', w2.double(), y.reshape(2, T1 * Cc, n)) + b2.view(1, Cc, 1).double())
+        peak = exp.abs().max()
+        assert not torch.isnan(got).any()
+        err3 = (got.double() - exp).abs().max() / peak
+        err1 = (E.history_conv(feats, w1, b1, w2, b2, bf16=True, voxel_major=True).double() - exp).abs().max() / peak
+        err32 = (E.history_conv(feats, w1, b1, w2, b2, voxel_major=True).double() - exp).abs().max() / peak
+        assert err3 < 2e-5 and err3 < err1 / 50 and err32 < err3, (Cc, T1, n, float(err3), float(err1), float(err32))
+
+
 @pytest.mark.parametrize('dt', [torch.float32, torch.float16])
 def test_history_warp_lds_staged_equals_gather_kernel_emulated(dt, monkeypatch):
     """k_history_warp_lds (a brick's source box staged in LDS) == k_history_warp (8 global gathers per output), bit for bit:

@@ -346,6 +346,45 @@ def test_fused_warp_and_conv_kernel_equals_the_two_kernel_path(dev, dt, T):
     assert outs[0].abs().max().item() > 0
 
 
+@pytest.mark.parametrize('dt', [torch.float16, torch.bfloat16])
+def test_split_operand_bf16_convolutions_are_fp32_grade(dev, dt):
+    """history_compute='bf16x3' (fbbev_history_conv_bf16x3: every operand split into two bf16 terms, three MFMAs per product)
+    through the module on a 16-bit voxel-major ring, against the fp32-MFMA convolutions on the same ring: the stored ring is the
+    same bits (the convolutions do not touch it), the fused volume within 2e-5 of its peak over a 4-frame sequence with a
+    restart, ego motion and a flipped bda -- and the plain bf16 route on the same frames is > 30x further away.
+    N = 4 * 12 * 70 = 3360 voxels: 26 full 128-voxel tiles and a 32-voxel one."""
+    from fb_bev_amd.history_fusion import TemporalHistoryFusion
+    B, C, Z, Y, X, T = 2, 80, 4, 12, 70, 16
+    dx, bx = [0.5, 0.5, 1.0], [-17.25, -2.75, -1.5]
+    torch.manual_seed(3)
+    mods = [TemporalHistoryFusion(dx, bx, single_bev_num_channels=C, history_cat_num=T, history_dtype=dt,
+                                  history_compute=comp, ring_layout='voxel_major').to(dev).eval()
+            for comp in (torch.float32, 'bf16x3', torch.bfloat16)]
+    with torch.no_grad():
+        for seq in (mods[0].history_keyframe_time_conv, mods[0].history_keyframe_cat_conv):
+            seq[1].running_mean.normal_(0, 0.1); seq[1].running_var.uniform_(0.5, 1.5)
+    for m in mods[1:]:
+        m.load_state_dict(mods[0].state_dict())
+    g = torch.Generator().manual_seed(5)
+    starts = [[True, True], [False, False], [False, True], [False, False]]
+    worst3 = worst1 = 0.0
+    for i in range(4):
+        curr = torch.randn(B, C, Y, X, Z, generator=g).to(dev)
+        ego = torch.eye(4).repeat(B, 1, 1)
+        ego[:, 0, 3] = torch.tensor([0.4 * i, -0.3]); ego[1, :2, :2] = torch.tensor([[0.98, -0.199], [0.199, 0.98]])
+        bda = torch.eye(3).repeat(B, 1, 1)
+        if i >= 2:
+            bda[0, 1, 1] = -1.0
+        metas = [dict(sequence_group_idx=b, start_of_sequence=starts[i][b], curr_to_prev_ego_rt=ego[b]) for b in range(B)]
+        with torch.no_grad():
+            o32, o3, o1 = [m.fuse_history(curr, metas, bda.to(dev)) for m in mods]
+        assert torch.equal(mods[0].history_bev.view(torch.int16), mods[1].history_bev.view(torch.int16)), i
+        peak = o32.abs().max().item()
+        worst3 = max(worst3, (o3 - o32).abs().max().item() / peak)
+        worst1 = max(worst1, (o1 - o32).abs().max().item() / peak)
+    assert worst3 < 2e-5 and worst1 > 30 * worst3, (worst3, worst1)
+
+
 @pytest.mark.parametrize('layout', ['voxel_major', 'planar'])
 def test_baseline_config4_grid_16_frame_fp16_history(dev, layout):
     """BASELINE configs[4] (stress): 400x400x16 grid, C=80, 16-frame history in fp16 = 7 GB per sample ring slot pair

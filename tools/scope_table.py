@@ -141,6 +141,7 @@ def s6(n):
         vt_ms = None
         for comp, lay, label in ((torch.float32, 'planar', 'fp32 MFMA'), (torch.float32, 'voxel_major', 'fp32 MFMA'),
                                  (torch.bfloat16, 'planar', 'bf16 MFMA (fp32 accumulate)'),
+                                 ('bf16x3', 'voxel_major', 'bf16 MFMA x3 (split operands: fp32-grade)'),
                                  (torch.bfloat16, 'voxel_major', 'bf16 MFMA (fp32 accumulate)')):
             hist.history_compute, hist.ring_layout = comp, lay
             hist.reset(); state['first'] = True

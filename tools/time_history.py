@@ -69,7 +69,7 @@ def main():
     C, T = 80, 16
     dt = {'f32': torch.float32, 'f16': torch.float16, 'bf16': torch.bfloat16}[sys.argv[5] if len(sys.argv) >= 6 else 'f32']
     noref = 'noref' in sys.argv
-    comp = torch.bfloat16 if 'cbf16' in sys.argv else torch.float32
+    comp = 'bf16x3' if 'cx3' in sys.argv else torch.bfloat16 if 'cbf16' in sys.argv else torch.float32
     lay = 'voxel_major' if 'vm' in sys.argv else 'planar'
     unfused = 'unfused' in sys.argv       # two-kernel path (warp, then convolutions) instead of fbbev_history_fused_vm
     esz = 4 if dt == torch.float32 else 2
