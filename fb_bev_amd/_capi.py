@@ -49,6 +49,9 @@ SIGNATURES = {
     'fbbev_history_warp': (c_int, [c_void_p, c_int64, c_void_p] + [c_int] * 5 + [c_void_p, c_int64, c_void_p]),
     'fbbev_history_warp_e': (c_int, [c_void_p, c_int64, c_void_p] + [c_int] * 5 + [c_void_p, c_int64, c_int, c_void_p]),
     'fbbev_layernorm': (c_int, [c_void_p] * 4 + [c_float, c_int64, c_int, c_void_p, c_void_p]),
+    'fbbev_rows_linear_x3_fragment_bytes': (c_size_t, [c_int, c_int]),
+    'fbbev_rows_linear_x3_fragments': (c_int, [c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    'fbbev_rows_linear_x3': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
     'fbbev_layernorm_bwd_partials': (c_int, [c_int64]),
     'fbbev_layernorm_bwd': (c_int, [c_void_p] * 3 + [c_float, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     'fbbev_history_conv': (c_int, [c_void_p, c_int64] + [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -697,6 +700,34 @@ def layernorm(x, weight, bias, eps, residual=None, out=None):
         _check(lib().fbbev_layernorm(_dev(x, F32, 'x'), _dev(residual, F32, 'residual') if residual is not None else None,
                                      _dev(weight, F32, 'weight'), _dev(bias, F32, 'bias'), float(eps), rows, C,
                                      _dev(out, F32, 'out'), _stream()), 'fbbev_layernorm')
+    return out
+
+
+def rows_linear_x3_fragments(weight):
+    """W (O, I) f32 -> the split bf16 MFMA fragments of fbbev_rows_linear_x3 (a uint8 buffer; build once per weight version)."""
+    O, I = weight.shape
+    need = lib().fbbev_rows_linear_x3_fragment_bytes(I, O)
+    frag = torch.empty(need, dtype=torch.uint8, device=weight.device)
+    with _on(weight):
+        _check(lib().fbbev_rows_linear_x3_fragments(_dev(weight, F32, 'weight'), I, O, frag.data_ptr(), need, _stream()),
+               'fbbev_rows_linear_x3_fragments')
+    return frag
+
+
+def rows_linear_x3(x, fragments, bias, out_features, relu=False, out=None):
+    """x (R, I) f32 rows (row stride >= I, unit column stride) -> out (R, O) = x W^T + bias (+ ReLU), split-operand bf16 MFMA."""
+    R, I = x.shape
+    if x.stride(1) != 1:
+        raise FbbevError('rows_linear_x3: rows must have unit column stride')
+    if out is None:
+        out = torch.empty((R, out_features), dtype=F32, device=x.device)
+    if out.shape != (R, out_features) or out.stride(1) != 1:
+        raise FbbevError('rows_linear_x3: out must be (rows, out_features) with unit column stride')
+    with _on(x):
+        _check(lib().fbbev_rows_linear_x3(_dev(x, F32, 'x', contiguous=False), x.stride(0), fragments.data_ptr(),
+                                          _dev(bias, F32, 'bias') if bias is not None else None, R, I, out_features,
+                                          1 if relu else 0, _dev(out, F32, 'out', contiguous=False), out.stride(0), _stream()),
+               'fbbev_rows_linear_x3')
     return out
 
 

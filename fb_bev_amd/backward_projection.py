@@ -25,7 +25,7 @@ import torch.nn.functional as F
 
 from . import _capi
 from .ms_deform_attn import MultiScaleDeformableAttnFunction_fp32
-from .rows_linear import Linear, linear_rows
+from .rows_linear import Linear, X3Weights, linear_rows, linear_x3, x3_ok
 
 REGISTRY = {}
 
@@ -129,7 +129,16 @@ class FFN(nn.Module):
         self.embed_dims = embed_dims
 
     def forward(self, x, identity=None, _defer_residual=False):
-        out = self.layers(x)
+        if torch.is_grad_enabled() or self.training:
+            out = self.layers(x)
+        else:
+            # inference: Linear + ReLU blocks as one call each (the ReLU rides in the GEMM's store epilogue; dropout is identity)
+            out = x
+            for layer in self.layers:
+                if isinstance(layer, nn.Sequential) and isinstance(layer[0], Linear) and isinstance(layer[1], nn.ReLU):
+                    out = layer[0](out, relu=True)
+                elif not isinstance(layer, nn.Dropout):
+                    out = layer(out)
         if not self.add_identity:
             return (out, None) if _defer_residual else out
         res = x if identity is None else identity
@@ -203,7 +212,15 @@ class MultiScaleDeformableAttention(nn.Module):
                     self._vpad = _pad_interleave_rows(w, b, self.num_heads, Dh, HS)
                 self._vpad_key = key
             w, b = self._vpad
-            value = F.linear(value, w, b).view(bs, num_value, self.num_heads, HS)   # stored (HS/4, M, 4) per token
+            if x3_ok(value, w.shape[1], w.shape[0]):
+                if not hasattr(self, '_vx3'):
+                    self._vx3 = X3Weights()
+                M_ = self.num_heads
+                value = linear_x3(value, self._vx3.get(self.value_proj.weight, self.value_proj.bias,
+                                                      lambda w_, b_: _pad_interleave_rows(w_, b_, M_, Dh, HS)))
+                value = value.view(bs, num_value, self.num_heads, HS)
+            else:
+                value = F.linear(value, w, b).view(bs, num_value, self.num_heads, HS)   # stored (HS/4, M, 4) per token
             so = self.sampling_offsets(query)
             aw = self.attention_weights(query).view(bs, num_query, self.num_heads, -1).softmax(-1)
             aw = aw.view(bs, num_query, self.num_heads, self.num_levels, self.num_points)
@@ -285,7 +302,11 @@ class DA_MSDeformableAttention(nn.Module):
             o = torch.arange(M * L * P).view(M, L, P).permute(1, 2, 0).reshape(-1)        # new (l,p,m) -> old (m,l,p)
             self._perm_so = (o[:, None] * 2 + torch.arange(2)[None]).reshape(-1).to(query.device)
             self._perm_key = key
-        so = linear_rows(query, self.sampling_offsets.weight[self._perm_so], self.sampling_offsets.bias[self._perm_so])
+        if not hasattr(self, '_so_x3'):
+            self._so_x3 = X3Weights()
+        perm = self._perm_so
+        so = linear_rows(query, self.sampling_offsets.weight, self.sampling_offsets.bias, cache=self._so_x3,
+                         transform=lambda w_, b_: (w_[perm], b_[perm]))
         so = so.view(bs, nq, L, P, M, 2)
         aw = self.attention_weights(query).view(bs, nq, M, L * P)
         if self.disable_deformable:
@@ -454,7 +475,13 @@ class DA_SpatialCrossAttention(nn.Module):
             # sampler (fbbev_da_cross_attn_fwd_zt: two samples in flight per lane) reads it for padded corners and
             # out-of-image samples instead of branching around their loads
             _, rows = _capi.da_value_buffer(B * ncam * S, M * HS, x.device)
-            torch.addmm(bb, x.reshape(B * ncam * S, E), w.t(), out=rows)
+            if x3_ok(x, E, M * HS):
+                if not hasattr(self, '_vx3'):
+                    self._vx3 = X3Weights()
+                linear_x3(x.reshape(B * ncam * S, E),
+                          self._vx3.get(wt, bs, lambda w_, b_: _pad_interleave_rows(w_, b_, M, Dh, HS)), out=rows)
+            else:
+                torch.addmm(bb, x.reshape(B * ncam * S, E), w.t(), out=rows)
             slots = torch.empty((B, Q, M * Dh), dtype=torch.float32, device=query.device)
             _capi.da_cross_attn_fwd(rows.view(B * ncam, S, M, HS), spatial_shapes.to(torch.int64).contiguous(),
                                     level_start_index.to(torch.int64).contiguous(),

@@ -15,6 +15,7 @@
 #include "history_conv_kernels.h"
 #include "history_fused_kernels.h"
 #include "history_conv_x3_kernels.h"
+#include "rows_linear_kernels.h"
 #include "msda_bwd_kernels.h"
 #include "conv3d_kernels.h"
 #include "../../include/fbbev.h"
@@ -1865,6 +1866,57 @@ extern "C" int fbbev_history_conv_bf16x3(const void* feats, long long feats_stri
     if (C == 80) { if (elem_type == 1) FBBEV_HX3(5, 1); else FBBEV_HX3(5, 2); }
     else { if (elem_type == 1) FBBEV_HX3(1, 1); else FBBEV_HX3(1, 2); }
 #undef FBBEV_HX3
+    FBBEV_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------ row-wise linear layers, split-operand bf16 MFMA
+extern "C" size_t fbbev_rows_linear_x3_fragment_bytes(int in_features, int out_features) {
+    if (in_features <= 0 || out_features <= 0) return 0;
+    const size_t n_oc = (size_t)(out_features + 127) / 128, n_kc = (size_t)(in_features + 127) / 128;
+    return n_oc * n_kc * 8 * FBBEV_RL_TILE_ELEMS * sizeof(unsigned short);
+}
+
+extern "C" int fbbev_rows_linear_x3_fragments(const float* weight, int in_features, int out_features, void* fragments,
+                                              size_t fragment_bytes, fbbev_stream_t stream_) {
+    if (in_features <= 0 || out_features <= 0 || !weight || !fragments) return FBBEV_E_BADARG;
+    if (!aligned16(fragments) || fragment_bytes < fbbev_rows_linear_x3_fragment_bytes(in_features, out_features)) return FBBEV_E_WORKSPACE;
+    const int n_oc = (out_features + 127) / 128, n_kc = (in_features + 127) / 128;
+    const long long n = (long long)n_oc * n_kc * 8 * 4 * 64;
+    FBBEV_LAUNCH(k_rows_linear_x3_fragments, (n + 255) / 256, 256, 0, (fbbev_rt_stream)stream_, weight, out_features, in_features,
+                 n_oc, n_kc, static_cast<unsigned short*>(fragments));
+    FBBEV_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int fbbev_rows_linear_x3(const float* x, long long x_row_stride, const void* fragments, const float* bias, long long rows,
+                                    int in_features, int out_features, int relu, float* out, long long out_row_stride,
+                                    fbbev_stream_t stream_) {
+    if (rows < 0 || in_features <= 0 || out_features <= 0) return FBBEV_E_BADARG;
+    if (rows == 0) return 0;
+    if (!x || !fragments || !out) return FBBEV_E_BADARG;
+    if (x_row_stride == 0) x_row_stride = in_features;
+    if (out_row_stride == 0) out_row_stride = out_features;
+    if (x_row_stride < in_features || out_row_stride < out_features) return FBBEV_E_BADARG;
+    if (in_features % 8 != 0 || out_features % 4 != 0 || x_row_stride % 4 != 0 || out_row_stride % 4 != 0 || !aligned16(x) ||
+        !aligned16(out) || !aligned16(fragments) || (bias && !aligned16(bias))) return FBBEV_E_UNSUPPORTED;
+    const int n_oc = (out_features + 127) / 128, n_kc = (in_features + 127) / 128;
+    const long long tiles = (rows + 127) / 128;
+    if (tiles * n_oc >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
+    const int nmt = out_features >= 128 ? 8 : (out_features + 15) / 16;
+    const size_t lds = (size_t)nmt * FBBEV_RL_TILE_ELEMS * sizeof(unsigned short);
+    int e = fbbev_rt_allow_dyn_lds((const void*)k_rows_linear_x3<2>, lds);
+    if (e) return e;
+    // consecutive row tiles per workgroup (fragments staged once) as long as ~4 workgroups per CU remain
+    long long RT = n_kc == 1 ? tiles * n_oc / 1024 : 1;
+    RT = RT < 1 ? 1 : (RT > 8 ? 8 : RT);
+#ifdef FBBEV_TEST_OVERRIDES   // CPU emulator build: lets a small case walk several row tiles per workgroup
+    { const char* e_rt = getenv("FBBEV_ROWS_LINEAR_RT"); if (e_rt && n_kc == 1 && atoi(e_rt) >= 1 && atoi(e_rt) <= 8) RT = atoi(e_rt); }
+#endif
+    const long long groups = (tiles + RT - 1) / RT;
+    FBBEV_LAUNCH((k_rows_linear_x3<2>), groups * n_oc, 256, lds, (fbbev_rt_stream)stream_, x, x_row_stride,
+                 static_cast<const unsigned short*>(fragments), bias, out, out_row_stride, rows, in_features, out_features, relu,
+                 n_kc, n_oc, (int)RT);
     FBBEV_CHECK_LAUNCH();
     return 0;
 }

@@ -1,0 +1,132 @@
+// rows_linear_kernels.h -- y = x W^T + b (+ ReLU) for the (B*Q, C) row tensors of the backward projection, on the bf16 MFMA with
+// SPLIT operands (round 3; the arithmetic of history_conv_x3_kernels.h: v = hi + lo in bf16, three MFMAs per product, fp32
+// accumulate -- ~1e-5 relative, i.e. fp32-grade, against 16x the matrix rate of the fp32 MFMA).
+//
+// Why: at BASELINE configs[2] the encoder applies ~10 linear layers (80 -> 64 ... 512, 512 -> 80) to 160 000 query rows: 0.75 ms
+// of the 2.44 ms forward+backward projection in the vendor library's fp32 GEMMs (87 TFLOP/s on the widest), where the rows
+// themselves (51 MB in, 41-328 MB out) need 20-80 us at HBM speed.  With 3 bf16 MFMAs per product the kernels are bound by
+// their rows, and bias + ReLU ride in the store epilogue (the FFN's ReLU was a separate 328 MB pass).
+//
+// Shape: workgroup = 4 waves x NT 16-row tiles (128 rows at NT = 2) x one 128-wide chunk of the outputs; K is walked in chunks of
+// 128 channels (4 k-steps of 32) whose weight fragments -- hi and lo, prepared once per weight version by
+// k_rows_linear_x3_fragments in the order [out chunk][K chunk][out tile][hi | lo][k-step][lane][8] -- are staged through LDS
+// (8 KB per 16 outputs; 64 KB for a full chunk: two workgroups per CU) and shared by the 4 waves; the rows are read straight
+// into registers (a lane = one row's 8 consecutive channels of a k-step: two float4), split there, never staged.
+#pragma once
+#include "rt.h"
+#include "history_conv_x3_kernels.h"
+
+#define FBBEV_RL_TILE_ELEMS (2 * 4 * 64 * 8)              // bf16 elements of one 16-output tile of one K chunk: [hi|lo][4 k-steps][lane][8]
+
+template <int NT>
+__global__ void __launch_bounds__(256)
+k_rows_linear_x3(const float* __restrict__ x, long long ldx, const unsigned short* __restrict__ wf, const float* __restrict__ bias,
+                 float* __restrict__ out, long long ldo, long long rows, int I, int O, int relu, int n_kc, int n_oc, int RT) {
+    unsigned short* wl = reinterpret_cast<unsigned short*>(fbbev_dyn_lds_f32());          // [nmt][FBBEV_RL_TILE_ELEMS]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = lane >> 4, j = lane & 15;
+    const int oc = (int)(blockIdx.x % n_oc);              // the output chunks of one row tile are neighbours: its rows stay in L2
+    const long long rt0 = (long long)(blockIdx.x / n_oc) * RT;
+    const int o0 = oc * 128;
+    const int nmt = (O - o0 >= 128) ? 8 : (O - o0 + 15) / 16;                             // 16-output tiles of this chunk
+    const fbbev_bf16x8 zero8 = fbbev_cvt_bf16x8(fbbev_v4f{0.f, 0.f, 0.f, 0.f}, fbbev_v4f{0.f, 0.f, 0.f, 0.f});
+    // RT consecutive 128-row tiles per workgroup when the whole K fits one chunk (n_kc == 1: the fragments are staged ONCE and
+    // reused -- with one row tile per workgroup the 64 KB of fragments per 64 KB of output were half the L2 traffic of the
+    // 80 -> 512 layer); RT = 1 otherwise
+    for (int ri = 0; ri < RT; ++ri) {
+        const long long r0 = ((rt0 + ri) * 4 + wave) * (16 * NT);
+        if ((rt0 + ri) * 4 * 16 * NT >= rows) break;                                      // uniform
+        fbbev_v4f acc[8][NT];
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[mt][t] = fbbev_v4f{0.f, 0.f, 0.f, 0.f};
+        for (int kc = 0; kc < n_kc; ++kc) {
+            const int c0 = kc * 128;
+            // the chunk's row pieces first (raw, into registers): they are in flight while the fragments are staged
+            fbbev_v4f raw[4][NT][2];
+            bool okp[4][NT];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int c = c0 + 32 * s + 8 * g;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const long long r = r0 + 16 * t + j;
+                    okp[s][t] = r < rows && c < I;                                        // I % 8 == 0: a piece is all in or all out
+                    const float* p = x + (okp[s][t] ? r * ldx + c : 0);
+                    raw[s][t][0] = *reinterpret_cast<const fbbev_v4f*>(p);
+                    raw[s][t][1] = *reinterpret_cast<const fbbev_v4f*>(p + 4);
+                }
+            }
+            if (n_kc > 1 || ri == 0) {
+                if (kc || ri) __syncthreads();                                            // the previous chunk's fragments are done with
+                const fbbev_v4u* src = reinterpret_cast<const fbbev_v4u*>(wf + ((long long)oc * n_kc + kc) * 8 * FBBEV_RL_TILE_ELEMS);
+                for (int i = threadIdx.x; i < nmt * (FBBEV_RL_TILE_ELEMS / 8); i += 256) reinterpret_cast<fbbev_v4u*>(wl)[i] = src[i];
+                __syncthreads();
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                if (c0 + 32 * s >= I) break;                                              // uniform: no k-step beyond the input width
+                fbbev_bf16x8 xh[NT], xl[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    fbbev_split_bf16x8(raw[s][t][0], raw[s][t][1], xh[t], xl[t]);
+                    xh[t] = okp[s][t] ? xh[t] : zero8;
+                    xl[t] = okp[s][t] ? xl[t] : zero8;
+                }
+#pragma unroll
+                for (int mt = 0; mt < 8; ++mt) {
+                    if (mt >= nmt) break;                                                 // uniform
+                    const fbbev_bf16x8 ah = fbbev_ld_bf16x8(wl + mt * FBBEV_RL_TILE_ELEMS + (s * 64 + lane) * 8);
+                    const fbbev_bf16x8 al = fbbev_ld_bf16x8(wl + mt * FBBEV_RL_TILE_ELEMS + FBBEV_RL_TILE_ELEMS / 2 + (s * 64 + lane) * 8);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        acc[mt][t] = fbbev_mfma_f32_16x16x32_bf16(al, xh[t], acc[mt][t]);
+                        acc[mt][t] = fbbev_mfma_f32_16x16x32_bf16(ah, xl[t], acc[mt][t]);
+                        acc[mt][t] = fbbev_mfma_f32_16x16x32_bf16(ah, xh[t], acc[mt][t]);
+                    }
+                }
+            }
+        }
+        // accumulator register r of tile (mt, t) = output 16 mt + 4 g + r of row j: four consecutive outputs, one 16-byte store
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const long long r = r0 + 16 * t + j;
+            if (r >= rows) continue;
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) {
+                const int o = o0 + 16 * mt + 4 * g;
+                if (mt >= nmt || o >= O) continue;                                        // O % 4 == 0: a group is all in or all out
+                fbbev_v4f v = acc[mt][t];
+                if (bias) v = v + *reinterpret_cast<const fbbev_v4f*>(bias + o);
+                if (relu) v = fbbev_v4f{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+                *reinterpret_cast<fbbev_v4f*>(out + r * ldo + o) = v;
+            }
+        }
+    }
+}
+
+// W (O, I) fp32 row-major -> split bf16 A fragments, order [out chunk][K chunk][out tile][hi | lo][k-step][lane][8]; element e of a
+// lane = W[128 oc + 16 mt + lane % 16][128 kc + 32 s + 8 (lane / 16) + e], zero outside the matrix.
+__global__ void __launch_bounds__(256)
+k_rows_linear_x3_fragments(const float* __restrict__ w, int O, int I, int n_oc, int n_kc, unsigned short* __restrict__ dst) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;               // one lane-fragment per thread
+    const long long n = (long long)n_oc * n_kc * 8 * 4 * 64;
+    if (i >= n) return;
+    const int lane = (int)(i & 63), s = (int)((i >> 6) & 3), mt = (int)((i >> 8) & 7);
+    const long long blk = i >> 11;
+    const int kc = (int)(blk % n_kc), oc = (int)(blk / n_kc);
+    const int o = 128 * oc + 16 * mt + (lane & 15);
+    fbbev_v4f lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = 128 * kc + 32 * s + 8 * (lane >> 4) + e;
+        const float v = (o < O && c < I) ? w[(long long)o * I + c] : 0.f;
+        if (e < 4) lo[e] = v; else hi[e - 4] = v;
+    }
+    fbbev_bf16x8 h8, l8;
+    fbbev_split_bf16x8(lo, hi, h8, l8);
+    unsigned short* base = dst + (blk * 8 + mt) * FBBEV_RL_TILE_ELEMS + (s * 64 + lane) * 8;
+    __builtin_memcpy(base, &h8, 16);
+    __builtin_memcpy(base + FBBEV_RL_TILE_ELEMS / 2, &l8, 16);
+}

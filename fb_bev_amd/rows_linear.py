@@ -8,11 +8,19 @@ off the time its 100 MB of operands take to read (profiles/r03_time_train_BL2_B4
 Here the rows are cut into S slices, the S partial products are one batched GEMM (S x tiles workgroups) and their sum a
 small reduction; the bias gradient is reduced the same way in two stages.  fp32 throughout; the sums are re-associated
 (slice partials), i.e. equal to autograd's within fp32 rounding, which is what the training parity tests allow."""
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import _capi
+
 MIN_ROWS = 16384            # below this autograd's plain GEMM is as good
+# Inference: the split-operand bf16-MFMA kernel (fbbev_rows_linear_x3: ~1e-5 relative to fp32, bias / ReLU in its epilogue)
+# instead of the vendor fp32 GEMM.  FBBEV_ROWS_LINEAR=f32 (or X3 = False) keeps the vendor GEMM.
+X3 = os.environ.get('FBBEV_ROWS_LINEAR', 'x3') != 'f32'
+X3_MIN_ROWS = 2048
 SLICE_ROWS = 2048           # rows per partial product
 
 
@@ -70,17 +78,70 @@ class _RowsLinear(torch.autograd.Function):
         return gx, gw, gb
 
 
-def linear_rows(x, w, b=None):
-    """F.linear with the split-K backward when it pays: a GPU tensor of many rows that autograd will differentiate."""
+class X3Weights:
+    """Split MFMA fragments of a weight matrix, rebuilt when the SOURCE tensors change (data_ptr + _version, as the other
+    folded-weight caches of the package).  `transform(w, b) -> (w', b')` derives the matrix actually applied (row permutation,
+    head padding); it runs under no_grad, once per version.  One instance per call site, owned by the module (never keyed on a
+    temporary: a freed temporary's address can come back with version 0)."""
+
+    def __init__(self):
+        self.key = None
+        self.w = self.b = self.frag = None
+
+    def get(self, w_src, b_src, transform=None):
+        key = (w_src.data_ptr(), w_src._version, None if b_src is None else (b_src.data_ptr(), b_src._version), str(w_src.device))
+        if key != self.key:
+            with torch.no_grad():
+                w, b = (w_src, b_src) if transform is None else transform(w_src, b_src)
+                w = w.detach().float().contiguous()
+                self.w, self.b = w, None if b is None else b.detach().float().contiguous()
+                self.frag = _capi.rows_linear_x3_fragments(w)
+            self.key = key
+        return self
+
+
+def x3_ok(x, in_features, out_features):
+    """the split-operand kernel applies: inference on a GPU, fp32 rows with unit column stride, shapes it takes"""
+    return (X3 and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and in_features % 8 == 0 and
+            out_features % 4 == 0 and x.shape[-1] == in_features and x.numel() // max(1, in_features) >= X3_MIN_ROWS)
+
+
+def linear_x3(x, cache, relu=False, out=None):
+    """x (..., I) -> (..., O) through fbbev_rows_linear_x3 with the fragments of `cache` (an X3Weights after .get())."""
+    I = x.shape[-1]
+    O = cache.w.shape[0]
+    x2 = x.reshape(-1, I)
+    if x2.stride(1) != 1 or x2.stride(0) % 4 != 0 or x2.data_ptr() % 16 != 0:
+        x2 = x2.contiguous()
+    y = _capi.rows_linear_x3(x2, cache.frag, cache.b, O, relu=relu, out=out)
+    return y if out is not None else y.view(*x.shape[:-1], O)
+
+
+def linear_rows(x, w, b=None, cache=None, transform=None, relu=False):
+    """F.linear (+ ReLU) for row tensors.  Inference on a GPU with a `cache` (X3Weights owned by the calling module; `w` / `b` are
+    then the SOURCE parameters and `transform` derives the applied matrix): the split-operand MFMA kernel.  Training on a GPU:
+    the split-K backward when it pays.  Otherwise F.linear."""
+    if cache is not None:
+        O = w.shape[0] if transform is None else None
+        if x3_ok(x, x.shape[-1], O if O is not None else 4):
+            c = cache.get(w, b, transform)
+            if c.w.shape[1] == x.shape[-1] and c.w.shape[0] % 4 == 0:
+                return linear_x3(x, c, relu=relu)
+    if transform is not None:
+        w, b = transform(w, b)
     rows = x.numel() // max(1, x.shape[-1])
     if (x.is_cuda and rows >= MIN_ROWS and torch.is_grad_enabled() and x.dtype == torch.float32 and
             (w.requires_grad or x.requires_grad or (b is not None and b.requires_grad))):
-        return _RowsLinear.apply(x.reshape(rows, x.shape[-1]), w, b).view(*x.shape[:-1], w.shape[0])
-    return F.linear(x, w, b)
+        y = _RowsLinear.apply(x.reshape(rows, x.shape[-1]), w, b).view(*x.shape[:-1], w.shape[0])
+    else:
+        y = F.linear(x, w, b)
+    return torch.relu_(y) if relu else y
 
 
 class Linear(nn.Linear):
     """nn.Linear (same parameters / state_dict) whose forward goes through `linear_rows`."""
 
-    def forward(self, x):
-        return linear_rows(x, self.weight, self.bias)
+    def forward(self, x, relu=False):
+        if not hasattr(self, '_x3'):
+            self._x3 = X3Weights()
+        return linear_rows(x, self.weight, self.bias, cache=self._x3, relu=relu)

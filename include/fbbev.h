@@ -468,6 +468,20 @@ int fbbev_layernorm_bwd_partials(long long rows);
 int fbbev_layernorm_bwd(const float* x, const float* grad_out, const float* weight, float eps, long long rows, int C,
                         float* grad_x, float* partial, fbbev_stream_t stream);
 
+/* Row-wise linear layer  out[r, :] = x[r, :] . W^T + bias (+ ReLU)  for the (B*Q, C) query rows of the backward projection
+ * (inference): replaces the F.linear calls of spatial_cross_attention_depth.py:533-540 (sampling_offsets, attention_weights),
+ * :494-500 (value_proj, output_proj) and the FFN of the encoder layer (mmcv FFN: Linear + ReLU + Linear) -- vendor fp32 GEMMs in
+ * the reference.  Arithmetic: bf16 MFMA with SPLIT operands (v = hi + lo, three MFMAs per product, fp32 accumulation): ~1e-5
+ * relative to the fp32 result.  Two steps: fbbev_rows_linear_x3_fragments turns W (out_features, in_features) row-major fp32
+ * into split MFMA fragments (once per weight version; fbbev_rows_linear_x3_fragment_bytes bytes, 16-byte aligned), then
+ * fbbev_rows_linear_x3 per call.  Row strides in floats (0 = dense).  in_features % 8 == 0, out_features % 4 == 0, strides % 4 == 0,
+ * 16-byte aligned pointers, else FBBEV_E_UNSUPPORTED (callers keep the vendor GEMM).  bias may be NULL. */
+size_t fbbev_rows_linear_x3_fragment_bytes(int in_features, int out_features);
+int fbbev_rows_linear_x3_fragments(const float* weight, int in_features, int out_features, void* fragments, size_t fragment_bytes,
+                                   fbbev_stream_t stream);
+int fbbev_rows_linear_x3(const float* x, long long x_row_stride, const void* fragments, const float* bias, long long rows,
+                         int in_features, int out_features, int relu, float* out, long long out_row_stride, fbbev_stream_t stream);
+
 /* The two 1x1x1 convolutions of the temporal fusion in one fp32-MFMA kernel (inference): replaces
  * history_keyframe_time_conv + history_keyframe_cat_conv of FBOCC.fuse_history (fbocc.py:111-127, 289-310) once the
  * eval-mode batch norms are folded into the weights and the time channel into a per-frame bias:

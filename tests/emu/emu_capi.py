@@ -258,6 +258,21 @@ def layernorm(x, weight, bias, eps, residual=None):
     return out
 
 
+def rows_linear_x3(x, weight, bias, relu=False, out=None):
+    O, I = weight.shape
+    need = lib().fbbev_rows_linear_x3_fragment_bytes(I, O)
+    frag = torch.zeros(need + 16, dtype=torch.uint8)
+    off = (-frag.data_ptr()) % 16
+    fp = c_void_p(frag.data_ptr() + off)
+    ok(lib().fbbev_rows_linear_x3_fragments(p(weight), I, O, fp, need, None))
+    R = x.shape[0]
+    if out is None:
+        out = torch.full((R, O), float('nan'))
+    code = lib().fbbev_rows_linear_x3(c_void_p(x.data_ptr()), x.stride(0), fp, p(bias) if bias is not None else None, R, I, O,
+                                      1 if relu else 0, c_void_p(out.data_ptr()), out.stride(0), None)
+    return code, out
+
+
 def layernorm_bwd(x, grad_out, weight, eps):
     C = x.shape[-1]
     rows = x.numel() // C

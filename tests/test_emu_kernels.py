@@ -628,6 +628,53 @@ def test_layernorm_rows_emulated(rows, C):
     assert torch.allclose(E.layernorm(x, w, b, 1e-5, residual=r), exp2, atol=2e-6, rtol=1e-5)
 
 
+@pytest.mark.parametrize('R,I,O,relu', [(300, 80, 128, False), (130, 80, 64, False), (257, 80, 96, False), (129, 80, 512, True),
+                                        (200, 512, 80, False), (64, 80, 320, True), (50, 8, 4, False), (1, 264, 132, True)])
+def test_rows_linear_split_operand_emulated(R, I, O, relu):
+    """fbbev_rows_linear_x3 (x W^T + b [+ ReLU], split-operand bf16 MFMA) against float64: < 2e-5 of the output peak for the
+    backward projection's layer shapes (80 -> 64 / 96 / 128 / 320 / 512, 512 -> 80: four K chunks), partial row tiles, partial output
+    chunks (132 = 128 + 4), an input width that is not a multiple of 32, no bias, strided rows in and out."""
+    g = torch.Generator().manual_seed(R + I + O)
+    xs = torch.randn(R, I + 8, generator=g) * 2
+    x = xs[:, :I]                                                      # row stride I + 8
+    w = torch.randn(O, I, generator=g) * 0.2
+    b = torch.randn(O, generator=g) if O != 64 else None
+    outs = torch.full((R, O + 4), float('nan'))
+    code, got = E.rows_linear_x3(x, w, b, relu=relu, out=outs[:, :O])
+    assert code == 0
+    exp = x.double() @ w.double().t() + (b.double() if b is not None else 0)
+    if relu:
+        exp = exp.relu()
+    assert not torch.isnan(got).any() and torch.isnan(outs[:, O:]).all()          # nothing written beyond the output columns
+    assert (got.double() - exp).abs().max() <= 2e-5 * exp.abs().max()
+    # plain bf16 operands would be ~100x further away
+    xb, wb = x.bfloat16().double(), w.bfloat16().double()
+    e1 = xb @ wb.t() + (b.double() if b is not None else 0)
+    if relu:
+        e1 = e1.relu()
+    assert (got.double() - exp).abs().max() * 30 < (e1 - exp).abs().max()
+
+
+def test_rows_linear_several_row_tiles_per_workgroup_emulated(monkeypatch):
+    """the n_kc == 1 shape with RT = 3 row tiles per workgroup (fragments staged once): 5 tiles of 128 rows -> groups of 3 + 2,
+    a partial last tile, two output chunks; same result as one tile per workgroup, bit for bit."""
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(5 * 128 - 37, 80, generator=g)
+    w, b = torch.randn(160, 80, generator=g) * 0.2, torch.randn(160, generator=g)
+    code, one = E.rows_linear_x3(x, w, b, relu=True)
+    monkeypatch.setenv('FBBEV_ROWS_LINEAR_RT', '3')
+    code3, three = E.rows_linear_x3(x, w, b, relu=True)
+    assert code == 0 and code3 == 0 and not torch.isnan(three).any()
+    assert torch.equal(one, three)
+
+
+def test_rows_linear_split_operand_rejects_unsupported_shapes():
+    x = torch.randn(10, 12); w = torch.randn(8, 12)
+    assert E.rows_linear_x3(x, w, None)[0] == -2                       # in_features % 8 != 0
+    x = torch.randn(10, 16); w = torch.randn(6, 16)
+    assert E.rows_linear_x3(x, w, None)[0] == -2                       # out_features % 4 != 0
+
+
 @pytest.mark.parametrize('rows,C', [(37, 80), (8, 128), (5, 4), (3000, 80), (20000, 64)])
 def test_layernorm_rows_backward_emulated(rows, C):
     """fbbev_layernorm_bwd == autograd of torch's layer_norm: input gradient per row, weight / bias gradients from the summed
