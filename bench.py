@@ -56,6 +56,12 @@ def parse():
                          'batches on this many HIP streams (the rank build of batch i+1 may overlap the pooling of batch i); '
                          'reported as the extra "pipelined" object, never as `value`.  Measured gain on MI355X: 4-12 %%, not '
                          'stable (profiles/r02_exp_stream_overlap.jsonl), so off by default')
+    ap.add_argument('--launch', choices=['auto', 'graph', 'eager'], default='auto',
+                    help='forward mode: how the ~10 short launches of the index build (geometry, ranking, NCHW->NHWC, tile index) '
+                         'reach the GPU in every step: replayed from ONE captured hipGraph (the step then needs 2 host launches '
+                         'and stays GPU-bound on a slow or busy host CPU; ~1 %% slower than eager launches on a fast one) or launched '
+                         'one by one; auto (default) = whichever ran the warm-up steps faster.  The pooling kernel is always '
+                         'launched eagerly between the HIP events that time it')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--mode', choices=['forward', 'train'], default='forward')
     ap.add_argument('--sync-bn', action='store_true', help="train mode: cross-rank statistics for the config's SyncBN layers "
@@ -234,18 +240,44 @@ def run_forward(args):
     sev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
            for _ in range(args.steps)]       # whole-step GPU time, for the p10 / p50 / p90 spread
 
-    def step(i=None):
-        if i is not None:
-            sev[i][0].record()
+    def prep():
         idx = vt.build_index_from_cams(*cam)                        # fbbev_lift_rank_build: geometry + ranking, device counts
         feat = _capi.nchw_to_nhwc(ctx)                              # (B,N,H,W,C), the copy of bev_pool.py:18
         _capi.pool_tile_index(idx.interval_rank, idx.interval_starts, idx.counts, idx.n, B, Z, Y, X,
                               tile_ws, args.tile_voxels)
+        return idx, feat
+
+    def pool(idx, feat, dst):
+        _capi.bev_pool_v2_dense_fwd(depth, feat, idx.ranks_depth, idx.ranks_feat, idx.interval_rank,
+                                    idx.interval_starts, idx.interval_lengths, B, C, Z, Y, X, dst, tile_ws,
+                                    args.tile_voxels, flags)
+
+    graph = None
+    if args.launch in ('graph', 'auto'):
+        # The index build is ~10 launches of 5-45 us each: issued one by one they cost the host 0.2-1.2 ms per step depending
+        # on the box's CPU -- more than the 0.7 ms the GPU needs on a slow or busy host.  Captured once, replayed per step:
+        # the SAME kernels on the same buffers (indices still rebuilt from the camera tensors every step, device-side counts,
+        # no host sync anywhere), one host launch.
+        side = torch.cuda.Stream(dev)
+        with torch.cuda.stream(side):
+            prep()
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            g_idx, g_feat = prep()
+        torch.cuda.synchronize(dev)
+
+    def step(i=None):
+        if i is not None:
+            sev[i][0].record()
+        if graph is not None:
+            graph.replay()
+            idx, feat = g_idx, g_feat
+        else:
+            idx, feat = prep()
         if i is not None:
             ev[i][0].record()
-        _capi.bev_pool_v2_dense_fwd(depth, feat, idx.ranks_depth, idx.ranks_feat, idx.interval_rank,
-                                    idx.interval_starts, idx.interval_lengths, B, C, Z, Y, X, out, tile_ws,
-                                    args.tile_voxels, flags)
+        pool(idx, feat, out)
         if i is not None:
             ev[i][1].record()
             sev[i][1].record()
@@ -254,8 +286,25 @@ def run_forward(args):
     def fence():
         shard.fence(dev)
 
-    for _ in range(args.warmup):
-        idx = step()
+    launch_probe = None
+    if args.launch == 'auto':
+        # warm-up doubles as the probe: W steps launched eagerly, W steps with the index build replayed from the graph, each
+        # block wall-clocked between fences; the timed region uses the faster one (every rank decides from the max over ranks)
+        captured, rates = graph, {}
+        for mode in ('eager', 'graph'):
+            graph = captured if mode == 'graph' else None
+            step(); fence()
+            tw = time.perf_counter()
+            for _ in range(max(1, args.warmup)):
+                step()
+            fence()
+            rates[mode] = shard.max_over_ranks(time.perf_counter() - tw, dev) / max(1, args.warmup)
+        graph = captured if rates['graph'] <= rates['eager'] else None
+        launch_probe = {'eager_ms_per_step': 1e3 * rates['eager'], 'graph_ms_per_step': 1e3 * rates['graph'],
+                        'chosen': 'graph' if graph is not None else 'eager'}
+    else:
+        for _ in range(args.warmup):
+            idx = step()
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -263,6 +312,16 @@ def run_forward(args):
     fence()
     elapsed = time.perf_counter() - t0
     elapsed = shard.max_over_ranks(elapsed, dev)
+
+    # the graph-replayed step must produce what the eagerly launched step produces: one eager step into a second volume
+    graph_equal = None
+    if graph is not None:
+        ei, ef = prep()
+        chk = torch.empty_like(out)
+        pool(ei, ef, chk)
+        fence()
+        graph_equal = bool(torch.equal(chk, out))
+        del chk, ei, ef
 
     # Extra leg (reported beside `value`, never as it): the same K steps with the volume STORED in bf16 -- the storage
     # dtype BASELINE configs[1] names; the per-voxel sums stay the fp32 in-order fmaf chains, rounded once at the store.
@@ -431,6 +490,10 @@ def run_forward(args):
             'step_gpu_ms_p10_p50_p90': [pct(0.1), pct(0.5), pct(0.9)],
             'scaling': 'weak', 'vs_baseline': None, 'dtype': args.storage, 'accumulate_dtype': 'f32', 'data': 'synthetic',
             'rccl_ranks': ranks, 'rank_devices': devices,
+            'launch': ('index build (geometry + ranking + NCHW->NHWC + tile index: ~10 short kernels) replayed from one captured hipGraph '
+                       'per step, pooling kernel launched eagerly between the HIP events that time it' if graph is not None else
+                       'every kernel launched one by one from the host'),
+            'graph_step_equals_eager_step': graph_equal, 'launch_probe': launch_probe,
             'config': {'workload': f'FB-OCC forward projection, ' + ('BASELINE configs[1] ' if cfg.name == 'BL2' else '') +
                                    f'({cfg.name}): 6x{cfg.input_size[0]}x{cfg.input_size[1]} in, '
                                    f'feat {H}x{W}, D={D}, C={C}, grid {X}x{Y}x{Z}; index tensors rebuilt every step',
