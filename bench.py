@@ -252,7 +252,7 @@ def run_forward(args):
                                     idx.interval_starts, idx.interval_lengths, B, C, Z, Y, X, dst, tile_ws,
                                     args.tile_voxels, flags)
 
-    graph = None
+    graph, graph_error = None, None
     if args.launch in ('graph', 'auto'):
         # The index build is ~10 launches of 5-45 us each: issued one by one they cost the host 0.2-1.2 ms per step depending
         # on the box's CPU -- more than the 0.7 ms the GPU needs on a slow or busy host.  Captured once, replayed per step:
@@ -262,10 +262,17 @@ def run_forward(args):
         with torch.cuda.stream(side):
             prep()
         torch.cuda.synchronize(dev)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=side):
-            g_idx, g_feat = prep()
-        torch.cuda.synchronize(dev)
+        try:
+            graph = torch.cuda.CUDAGraph()
+            # thread_local: the RCCL watchdog thread of the process group may query events while this thread captures
+            with torch.cuda.graph(graph, stream=side, capture_error_mode='thread_local'):
+                g_idx, g_feat = prep()
+            torch.cuda.synchronize(dev)
+        except Exception as e:                                      # capture refused: the eager step is always available
+            if args.launch == 'graph':
+                raise
+            graph, graph_error = None, f'{type(e).__name__}: {e}'[:200]
+            torch.cuda.synchronize(dev)
 
     def step(i=None):
         if i is not None:
@@ -287,7 +294,7 @@ def run_forward(args):
         shard.fence(dev)
 
     launch_probe = None
-    if args.launch == 'auto':
+    if args.launch == 'auto' and graph is not None:
         # warm-up doubles as the probe: W steps launched eagerly, W steps with the index build replayed from the graph, each
         # block wall-clocked between fences; the timed region uses the faster one (every rank decides from the max over ranks)
         captured, rates = graph, {}
@@ -493,7 +500,7 @@ def run_forward(args):
             'launch': ('index build (geometry + ranking + NCHW->NHWC + tile index: ~10 short kernels) replayed from one captured hipGraph '
                        'per step, pooling kernel launched eagerly between the HIP events that time it' if graph is not None else
                        'every kernel launched one by one from the host'),
-            'graph_step_equals_eager_step': graph_equal, 'launch_probe': launch_probe,
+            'graph_step_equals_eager_step': graph_equal, 'launch_probe': launch_probe, 'graph_capture_error': graph_error,
             'config': {'workload': f'FB-OCC forward projection, ' + ('BASELINE configs[1] ' if cfg.name == 'BL2' else '') +
                                    f'({cfg.name}): 6x{cfg.input_size[0]}x{cfg.input_size[1]} in, '
                                    f'feat {H}x{W}, D={D}, C={C}, grid {X}x{Y}x{Z}; index tensors rebuilt every step',
