@@ -498,3 +498,39 @@ def test_msda_backward_band_binned_route_on_the_gpu():
     out = F32.apply(v, ss, ls, loc, w, 64)
     out.backward(go)
     assert torch.equal(v.grad, a[0])
+
+
+@pytest.mark.gpu
+def test_rows_linear_inference_route_and_its_weight_cache():
+    """rows_linear.Linear without autograd on a GPU: the split-operand MFMA kernel (fbbev_rows_linear_x3) within 2e-5 of the
+    fp32 GEMM, ReLU in the epilogue, and NO stale fragments: an in-place weight update, a storage swap and load_state_dict are
+    each followed by the new weights' result."""
+    from fb_bev_amd import rows_linear as RL
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(21)
+    lin = RL.Linear(80, 128).to(dev)
+    x = torch.randn(4, 10000, 80, generator=g).to(dev)
+
+    def check(relu=False):
+        with torch.no_grad():
+            y = lin(x, relu=relu)
+            ref = torch.nn.functional.linear(x.double(), lin.weight.double(), lin.bias.double())
+            ref = ref.relu() if relu else ref
+        assert (y.double() - ref).abs().max() <= 2e-5 * ref.abs().max()
+        return y
+    assert not RL.x3_ok(x, 80, 128)                         # autograd on: the vendor GEMM / split-K route
+    with torch.no_grad():
+        assert RL.x3_ok(x, 80, 128)                         # inference: the split-operand kernel
+    y0 = check()
+    check(relu=True)
+    with torch.no_grad():
+        lin.weight.mul_(-0.5)                               # in-place (optimizer step)
+    y1 = check()
+    assert not torch.allclose(y0, y1)
+    lin.weight.data = torch.randn(128, 80, generator=g).to(dev) * 0.1          # storage swap
+    check()
+    other = torch.nn.Linear(80, 128).to(dev)
+    lin.load_state_dict(other.state_dict())
+    y3 = check()
+    with torch.no_grad():
+        assert (y3 - other(x)).abs().max() <= 2e-5 * y3.abs().max()

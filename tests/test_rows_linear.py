@@ -51,3 +51,32 @@ def test_module_keeps_linear_state_dict_and_cpu_route():
     y = m(x)
     assert y.grad_fn is not None and 'RowsLinear' not in type(y.grad_fn).__name__     # CPU: autograd's own linear
     assert torch.equal(y, ref(x))
+
+
+def test_x3_fragment_cache_follows_the_source_parameters(monkeypatch):
+    """X3Weights rebuilds its fragments when -- and only when -- a SOURCE tensor changes: in-place update (_version), storage
+    swap (data_ptr), a different bias; the transform (row permutation) is applied to what is cached.  (The fragment builder
+    is a GPU kernel: replaced by a counter here.)"""
+    calls = []
+    monkeypatch.setattr(RL._capi, 'rows_linear_x3_fragments', lambda w: calls.append(w.clone()) or calls[-1])
+    w = torch.nn.Parameter(torch.randn(8, 16))
+    b = torch.nn.Parameter(torch.randn(8))
+    perm = torch.tensor([7, 6, 5, 4, 3, 2, 1, 0])
+    c = RL.X3Weights()
+    c.get(w, b, lambda w_, b_: (w_[perm], b_[perm]))
+    assert len(calls) == 1 and torch.equal(c.w, w.detach()[perm]) and torch.equal(c.b, b.detach()[perm])
+    c.get(w, b, lambda w_, b_: (w_[perm], b_[perm]))
+    assert len(calls) == 1                                            # unchanged sources: cached
+    with torch.no_grad():
+        w.mul_(2.0)                                                   # optimizer-style in-place update
+    c.get(w, b, lambda w_, b_: (w_[perm], b_[perm]))
+    assert len(calls) == 2 and torch.equal(c.w, w.detach()[perm])
+    w.data = torch.randn(8, 16)                                       # storage swap (load_state_dict(assign=True), EMA): version unchanged
+    c.get(w, b, lambda w_, b_: (w_[perm], b_[perm]))
+    assert len(calls) == 3 and torch.equal(c.w, w.detach()[perm])
+    with torch.no_grad():
+        b.add_(1.0)
+    c.get(w, b, lambda w_, b_: (w_[perm], b_[perm]))
+    assert len(calls) == 4 and torch.equal(c.b, b.detach()[perm])
+    c.get(w, None)                                                    # no bias, no transform
+    assert len(calls) == 5 and c.b is None and torch.equal(c.w, w.detach())
