@@ -22,6 +22,7 @@ SIGNATURES = {
     'fbbev_lidar_coor': (c_int, [c_void_p] * 9 + [c_int] * 5 + [c_void_p, c_void_p]),
     'fbbev_nchw_to_nhwc': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'fbbev_tokens_from_nchw': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_void_p, c_int, c_void_p]),
+    'fbbev_tokens_from_nchw_pos': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_void_p, c_void_p]),
     'fbbev_rank_workspace_bytes': (c_size_t, [c_int64]),
     'fbbev_rank_build': (c_int, [c_void_p] + [c_int] * 5 + [c_void_p] * 3 + [c_void_p] * 7 +
                          [c_void_p, c_size_t, c_void_p]),
@@ -52,6 +53,8 @@ SIGNATURES = {
     'fbbev_rows_linear_x3_fragment_bytes': (c_size_t, [c_int, c_int]),
     'fbbev_rows_linear_x3_fragments': (c_int, [c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     'fbbev_rows_linear_x3': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
+    'fbbev_rows_linear_x3_add': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
+                                         c_void_p, c_int64, c_void_p]),
     'fbbev_layernorm_bwd_partials': (c_int, [c_int64]),
     'fbbev_layernorm_bwd': (c_int, [c_void_p] * 3 + [c_float, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     'fbbev_history_conv': (c_int, [c_void_p, c_int64] + [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -572,15 +575,22 @@ def nchw_to_nhwc(context):
     return feat
 
 
-def tokens_from_nchw(x, out, out_offset=0, bias=None):
-    """x (n_images, C, HW) f32 contiguous -> out[img, out_offset/C + p, c] = x[img, c, p] (+ bias[img % rows, c]);
-    out (n_images, S, C) contiguous with S >= HW rows per image; out_offset in floats."""
+def tokens_from_nchw(x, out, out_offset=0, bias=None, pos_bias=None):
+    """x (n_images, C, HW) f32 contiguous -> out[img, out_offset/C + p, c] = x[img, c, p] (+ bias[img % rows, c]) or, with
+    pos_bias (HW, C), + pos_bias[p, c]; out (n_images, S, C) contiguous with S >= HW rows per image; out_offset in floats."""
     n, C, HW = x.shape
     if out.shape[0] != n or out.shape[-1] != C or not out.is_contiguous():
         raise FbbevError('tokens_from_nchw: out must be (n_images, S, C) contiguous')
     stride = out.stride(0)
     if out_offset + C * HW > stride:
         raise FbbevError('tokens_from_nchw: level does not fit the token rows')
+    if pos_bias is not None:
+        if bias is not None or tuple(pos_bias.shape) != (HW, C):
+            raise FbbevError('tokens_from_nchw: pos_bias is (HW, C) and excludes bias')
+        with _on(x):
+            _check(lib().fbbev_tokens_from_nchw_pos(_dev(x, F32, 'x'), _dev(out, F32, 'out'), n, C, HW, stride, int(out_offset),
+                                                    _dev(pos_bias, F32, 'pos_bias'), _stream()), 'fbbev_tokens_from_nchw_pos')
+        return out
     with _on(x):
         _check(lib().fbbev_tokens_from_nchw(
             _dev(x, F32, 'x'), _dev(out, F32, 'out'), n, C, HW, stride, int(out_offset),
@@ -714,8 +724,9 @@ def rows_linear_x3_fragments(weight):
     return frag
 
 
-def rows_linear_x3(x, fragments, bias, out_features, relu=False, out=None):
-    """x (R, I) f32 rows (row stride >= I, unit column stride) -> out (R, O) = x W^T + bias (+ ReLU), split-operand bf16 MFMA."""
+def rows_linear_x3(x, fragments, bias, out_features, relu=False, out=None, addend=None):
+    """x (R, I) f32 rows (row stride >= I, unit column stride) -> out (R, O) = x W^T + bias (+ ReLU), split-operand bf16 MFMA.
+    addend (P, I): the rows are x[r] + addend[r % P] (R % P == 0)."""
     R, I = x.shape
     if x.stride(1) != 1:
         raise FbbevError('rows_linear_x3: rows must have unit column stride')
@@ -723,11 +734,20 @@ def rows_linear_x3(x, fragments, bias, out_features, relu=False, out=None):
         out = torch.empty((R, out_features), dtype=F32, device=x.device)
     if out.shape != (R, out_features) or out.stride(1) != 1:
         raise FbbevError('rows_linear_x3: out must be (rows, out_features) with unit column stride')
+    b = _dev(bias, F32, 'bias') if bias is not None else None
     with _on(x):
-        _check(lib().fbbev_rows_linear_x3(_dev(x, F32, 'x', contiguous=False), x.stride(0), fragments.data_ptr(),
-                                          _dev(bias, F32, 'bias') if bias is not None else None, R, I, out_features,
-                                          1 if relu else 0, _dev(out, F32, 'out', contiguous=False), out.stride(0), _stream()),
-               'fbbev_rows_linear_x3')
+        if addend is None:
+            _check(lib().fbbev_rows_linear_x3(_dev(x, F32, 'x', contiguous=False), x.stride(0), fragments.data_ptr(), b, R, I,
+                                              out_features, 1 if relu else 0, _dev(out, F32, 'out', contiguous=False),
+                                              out.stride(0), _stream()), 'fbbev_rows_linear_x3')
+        else:
+            if addend.dim() != 2 or addend.shape[1] != I or addend.stride(1) != 1 or R % addend.shape[0] != 0:
+                raise FbbevError('rows_linear_x3: addend must be (P, in_features) rows with rows % P == 0')
+            _check(lib().fbbev_rows_linear_x3_add(_dev(x, F32, 'x', contiguous=False), x.stride(0),
+                                                  _dev(addend, F32, 'addend', contiguous=False), addend.stride(0), addend.shape[0],
+                                                  fragments.data_ptr(), b, R, I, out_features, 1 if relu else 0,
+                                                  _dev(out, F32, 'out', contiguous=False), out.stride(0), _stream()),
+                   'fbbev_rows_linear_x3_add')
     return out
 
 

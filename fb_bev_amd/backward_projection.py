@@ -188,8 +188,14 @@ class MultiScaleDeformableAttention(nn.Module):
             value = query
         if identity is None:
             identity = query
+        pos = None
         if query_pos is not None:
-            query = query + query_pos
+            # inference (batch_first rows): the two projections add the positional rows while they load the query rows
+            if (self.batch_first and self.fused_inference and not torch.is_grad_enabled() and key_padding_mask is None and
+                    x3_ok(query, query.shape[-1], 4)):
+                pos = query_pos
+            else:
+                query = query + query_pos
         if not self.batch_first:
             query, value = query.permute(1, 0, 2), value.permute(1, 0, 2)
         bs, num_query, _ = query.shape
@@ -221,8 +227,8 @@ class MultiScaleDeformableAttention(nn.Module):
                 value = value.view(bs, num_value, self.num_heads, HS)
             else:
                 value = F.linear(value, w, b).view(bs, num_value, self.num_heads, HS)   # stored (HS/4, M, 4) per token
-            so = self.sampling_offsets(query)
-            aw = self.attention_weights(query).view(bs, num_query, self.num_heads, -1).softmax(-1)
+            so = self.sampling_offsets(query, addend=pos)
+            aw = self.attention_weights(query, addend=pos).view(bs, num_query, self.num_heads, -1).softmax(-1)
             aw = aw.view(bs, num_query, self.num_heads, self.num_levels, self.num_points)
             out = torch.empty(bs, num_query, self.embed_dims, dtype=torch.float32, device=query.device)
             ref = reference_points.expand(bs, num_query, self.num_levels, 2).contiguous()
@@ -233,6 +239,8 @@ class MultiScaleDeformableAttention(nn.Module):
             if not self.batch_first:
                 out = out.permute(1, 0, 2)
             return (out, identity) if _defer_residual else out + identity
+        if pos is not None:                                  # the fused branch was not taken after all
+            query = query + pos
         value = self.value_proj(value)
         if key_padding_mask is not None:
             value = value.masked_fill(key_padding_mask[..., None], 0.0)
@@ -291,7 +299,7 @@ class DA_MSDeformableAttention(nn.Module):
         aw = aw.softmax(-1).view(bs, nq, self.num_heads, self.num_levels, self.num_points)
         return so, aw
 
-    def project_head_minor(self, query, softmax=True):
+    def project_head_minor(self, query, softmax=True, addend=None):
         """`project` with the sampling_offsets rows permuted so that the offsets come out head-minor, (B,Q,L,P,M,2):
         the layout the fused kernel reads with contiguous lanes (same dot product per element, only the row order of
         the weight matrix changes).  The attention weights keep (B,Q,M,L,P): their softmax runs over the last dim."""
@@ -305,10 +313,11 @@ class DA_MSDeformableAttention(nn.Module):
         if not hasattr(self, '_so_x3'):
             self._so_x3 = X3Weights()
         perm = self._perm_so
+        # addend: the positional encoding the caller would otherwise have added to `query` in a pass of its own
         so = linear_rows(query, self.sampling_offsets.weight, self.sampling_offsets.bias, cache=self._so_x3,
-                         transform=lambda w_, b_: (w_[perm], b_[perm]))
+                         transform=lambda w_, b_: (w_[perm], b_[perm]), addend=addend)
         so = so.view(bs, nq, L, P, M, 2)
-        aw = self.attention_weights(query).view(bs, nq, M, L * P)
+        aw = self.attention_weights(query, addend=addend).view(bs, nq, M, L * P)
         if self.disable_deformable:
             so, aw = so * 0, aw * 0
         # softmax=False: raw logits for a kernel that applies the softmax itself (fbbev_da_cross_attn_fwd_zt)
@@ -416,7 +425,7 @@ class DA_SpatialCrossAttention(nn.Module):
 
     # ---- inference: one fused HIP launch (fbbev_da_cross_attn_fwd), no host sync
     def _slots_fused(self, query, value, reference_points_cam, mask, bev_query_depth, pred_img_depth,
-                     spatial_shapes, level_start_index, bev_w=0):
+                     spatial_shapes, level_start_index, bev_w=0, query_pos=None):
         da = self.deformable_attention
         B, Q, E = query.shape
         ncam, S, _, _ = value.shape
@@ -441,7 +450,7 @@ class DA_SpatialCrossAttention(nn.Module):
                 self._vpad16_key = key
             w, bb = self._vpad16
             v = F.linear(x, w, bb).to(self.value_dtype).view(B * ncam, S, M, HS16)
-            so, aw = da.project_head_minor(query)
+            so, aw = da.project_head_minor(query, addend=query_pos)
             DC, H0, W0 = pred_img_depth.shape[2:]
             slots = torch.empty((B, Q, M * Dh), dtype=torch.float32, device=query.device)
             _capi.da_cross_attn_fwd(v, spatial_shapes.to(torch.int64).contiguous(), level_start_index.to(torch.int64).contiguous(),
@@ -469,7 +478,7 @@ class DA_SpatialCrossAttention(nn.Module):
         # the pipelined kernel applies the attention softmax while it stages the weights: hand it the raw logits
         fuse_sm = zt and not da.disable_deformable and _capi.da_fuses_softmax(
             B, ncam, S, M, Dh, da.num_levels, Q, da.num_points, reference_points_cam.shape[3], hm, HS)
-        so, aw = da.project_head_minor(query, softmax=not fuse_sm)
+        so, aw = da.project_head_minor(query, softmax=not fuse_sm, addend=query_pos)
         if zt:
             # inference: the projection writes into a buffer with one extra all-zero token behind the rows -- the pipelined
             # sampler (fbbev_da_cross_attn_fwd_zt: two samples in flight per lane) reads it for padded corners and
@@ -543,7 +552,11 @@ class DA_SpatialCrossAttention(nn.Module):
         if value is None:
             value = key
         inp_residual = query if residual is None else residual
-        if query_pos is not None:
+        # inference on the fused route: `query + query_pos` is only consumed by the two projections of the sampler, whose
+        # kernel adds the positional rows while it loads the query rows -- no pass of its own
+        fold_pos = (query_pos is not None and self.fused and not torch.is_grad_enabled() and
+                    x3_ok(query, query.shape[-1], 4))
+        if query_pos is not None and not fold_pos:
             query = query + query_pos
         mask = per_cam_mask_list
         if bev_mask is not None:
@@ -554,8 +567,11 @@ class DA_SpatialCrossAttention(nn.Module):
         head_dim = self.embed_dims // self.deformable_attention.num_heads
         fused_ok = self.fused and (not needs_grad or head_dim <= FUSED_BWD_MAX_HEAD_DIM)
         fn = self._slots_fused if fused_ok else self._slots_composite
+        if fold_pos and fn != self._slots_fused:             # (cannot happen without autograd; kept for safety)
+            query, fold_pos = query + query_pos, False
+        kw = dict(query_pos=query_pos) if fold_pos else {}
         slots = fn(query, value, reference_points_cam, mask, bev_query_depth, pred_img_depth, spatial_shapes,
-                   level_start_index, bev_w=bev_w or 0)      # the BEV row length lets the sampler own 2-D patches of queries
+                   level_start_index, bev_w=bev_w or 0, **kw)  # the BEV row length lets the sampler own 2-D patches of queries
         slots = self.output_proj(slots)
         if self.layer_scale is not None:
             slots = self.layer_scale * slots
@@ -865,12 +881,11 @@ class BackwardProjection(nn.Module):
                 not (torch.is_grad_enabled() and (lss_bev.requires_grad or self.bev_embedding.weight.requires_grad)))
         if lss_bev is not None:
             if fast:                                                                    # LDS-tiled transposition kernel
+                # + bev_embedding in the same pass: the same single fp32 add per element as below
                 tok = _capi.tokens_from_nchw(lss_bev.reshape(bs, lss_bev.shape[1], -1).contiguous(),
                                              torch.empty((bs, self.bev_h * self.bev_w, lss_bev.shape[1]),
                                                          dtype=torch.float32, device=lss_bev.device),
-                                             0, None)
-                # + bev_embedding: the same single fp32 add per element as below
-                tok.add_(self.bev_embedding.weight.detach().unsqueeze(0))
+                                             0, None, pos_bias=self.bev_embedding.weight.detach().float().contiguous())
                 bev_queries = tok.permute(1, 0, 2)
             else:
                 tok = lss_bev.flatten(2).transpose(1, 2).contiguous()                   # (bs,Q,C): the one transposition

@@ -108,9 +108,9 @@ extern "C" int fbbev_nchw_to_nhwc(const float* in, float* out, int n_images, int
     return fbbev_tokens_from_nchw(in, out, n_images, C, HW, (long long)C * HW, 0, nullptr, 0, stream_);
 }
 
-extern "C" int fbbev_tokens_from_nchw(const float* in, float* out, int n_images, int C, int HW,
-                                      long long out_image_stride, long long out_offset, const float* bias,
-                                      int bias_rows, fbbev_stream_t stream_) {
+static int tokens_from_nchw_impl(const float* in, float* out, int n_images, int C, int HW, long long out_image_stride,
+                                 long long out_offset, const float* bias, int bias_rows, const float* pos_bias,
+                                 fbbev_stream_t stream_) {
     if (n_images < 0 || C <= 0 || HW <= 0 || out_offset < 0 || out_image_stride < (long long)C * HW) return FBBEV_E_BADARG;
     if (bias && bias_rows <= 0) return FBBEV_E_BADARG;
     if (n_images == 0) return 0;
@@ -119,9 +119,23 @@ extern "C" int fbbev_tokens_from_nchw(const float* in, float* out, int n_images,
     const long long blocks = (long long)n_images * tc * th;
     if (blocks >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
     FBBEV_LAUNCH(k_nchw_to_nhwc, blocks, 256, 0, (fbbev_rt_stream)stream_, in, out, C, HW, tc, th, out_image_stride,
-                 out_offset, bias, bias ? bias_rows : 1);
+                 out_offset, bias, bias ? bias_rows : 1, pos_bias);
     FBBEV_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int fbbev_tokens_from_nchw(const float* in, float* out, int n_images, int C, int HW,
+                                      long long out_image_stride, long long out_offset, const float* bias,
+                                      int bias_rows, fbbev_stream_t stream_) {
+    return tokens_from_nchw_impl(in, out, n_images, C, HW, out_image_stride, out_offset, bias, bias_rows, nullptr, stream_);
+}
+
+// out[img, p, c] = in[img, c, p] + pos_bias[p, c]: the BEV queries of the backward projection (backward_projection.py:96-99:
+// lss_bev flattened to tokens + the learned bev_embedding) in one transposing pass
+extern "C" int fbbev_tokens_from_nchw_pos(const float* in, float* out, int n_images, int C, int HW, long long out_image_stride,
+                                          long long out_offset, const float* pos_bias, fbbev_stream_t stream_) {
+    if (!pos_bias) return FBBEV_E_BADARG;
+    return tokens_from_nchw_impl(in, out, n_images, C, HW, out_image_stride, out_offset, nullptr, 0, pos_bias, stream_);
 }
 
 extern "C" int fbbev_point_sampling(const float* xs, const float* ys, const float* zs, const float* rots,
@@ -1889,9 +1903,32 @@ extern "C" int fbbev_rows_linear_x3_fragments(const float* weight, int in_featur
     return 0;
 }
 
+static int rows_linear_x3_impl(const float* x, long long x_row_stride, const void* fragments, const float* bias, long long rows,
+                               int in_features, int out_features, int relu, float* out, long long out_row_stride,
+                               const float* addend, long long addend_row_stride, long long addend_period, fbbev_stream_t stream_);
+
 extern "C" int fbbev_rows_linear_x3(const float* x, long long x_row_stride, const void* fragments, const float* bias, long long rows,
                                     int in_features, int out_features, int relu, float* out, long long out_row_stride,
                                     fbbev_stream_t stream_) {
+    return rows_linear_x3_impl(x, x_row_stride, fragments, bias, rows, in_features, out_features, relu, out, out_row_stride, nullptr,
+                               0, 1, stream_);
+}
+
+extern "C" int fbbev_rows_linear_x3_add(const float* x, long long x_row_stride, const float* addend, long long addend_row_stride,
+                                        long long addend_period, const void* fragments, const float* bias, long long rows,
+                                        int in_features, int out_features, int relu, float* out, long long out_row_stride,
+                                        fbbev_stream_t stream_) {
+    if (!addend || addend_period <= 0) return FBBEV_E_BADARG;
+    if (addend_row_stride == 0) addend_row_stride = in_features;
+    if (addend_row_stride < in_features) return FBBEV_E_BADARG;
+    if (addend_row_stride % 4 != 0 || !aligned16(addend)) return FBBEV_E_UNSUPPORTED;
+    return rows_linear_x3_impl(x, x_row_stride, fragments, bias, rows, in_features, out_features, relu, out, out_row_stride, addend,
+                               addend_row_stride, addend_period, stream_);
+}
+
+static int rows_linear_x3_impl(const float* x, long long x_row_stride, const void* fragments, const float* bias, long long rows,
+                               int in_features, int out_features, int relu, float* out, long long out_row_stride,
+                               const float* addend, long long addend_row_stride, long long addend_period, fbbev_stream_t stream_) {
     if (rows < 0 || in_features <= 0 || out_features <= 0) return FBBEV_E_BADARG;
     if (rows == 0) return 0;
     if (!x || !fragments || !out) return FBBEV_E_BADARG;
@@ -1916,7 +1953,7 @@ extern "C" int fbbev_rows_linear_x3(const float* x, long long x_row_stride, cons
     const long long groups = (tiles + RT - 1) / RT;
     FBBEV_LAUNCH((k_rows_linear_x3<2>), groups * n_oc, 256, lds, (fbbev_rt_stream)stream_, x, x_row_stride,
                  static_cast<const unsigned short*>(fragments), bias, out, out_row_stride, rows, in_features, out_features, relu,
-                 n_kc, n_oc, (int)RT);
+                 n_kc, n_oc, (int)RT, addend, addend_row_stride, addend_period);
     FBBEV_CHECK_LAUNCH();
     return 0;
 }

@@ -147,7 +147,8 @@ k_point_sampling(const float* __restrict__ xs, const float* __restrict__ ys, con
 // out + img*out_image_stride + out_offset, with bias[(img % bias_rows)*C + c] added when bias != nullptr.
 __global__ void __launch_bounds__(256)
 k_nchw_to_nhwc(const float* __restrict__ in, float* __restrict__ out, int C, int HW, int tiles_c, int tiles_hw,
-               long long out_image_stride, long long out_offset, const float* __restrict__ bias, int bias_rows) {
+               long long out_image_stride, long long out_offset, const float* __restrict__ bias, int bias_rows,
+               const float* __restrict__ pos_bias) {
     __shared__ float tile[32][33];
     const int t = blockIdx.x;
     const int img = t / (tiles_c * tiles_hw), r = t - img * (tiles_c * tiles_hw);
@@ -162,6 +163,14 @@ k_nchw_to_nhwc(const float* __restrict__ in, float* __restrict__ out, int C, int
     }
     __syncthreads();
     const int cb = tc * 32 + lx;
+    if (pos_bias != nullptr) {                      // + a per-position row (HW, C), the same for every image: the learned BEV embedding
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int p = th * 32 + ly + 8 * k;
+            if (cb < C && p < HW) dst[(long long)p * C + cb] = tile[lx][ly + 8 * k] + pos_bias[(long long)p * C + cb];
+        }
+        return;
+    }
     if (bias == nullptr) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {

@@ -11,7 +11,9 @@
 // 128 channels (4 k-steps of 32) whose weight fragments -- hi and lo, prepared once per weight version by
 // k_rows_linear_x3_fragments in the order [out chunk][K chunk][out tile][hi | lo][k-step][lane][8] -- are staged through LDS
 // (8 KB per 16 outputs; 64 KB for a full chunk: two workgroups per CU) and shared by the 4 waves; the rows are read straight
-// into registers (a lane = one row's 8 consecutive channels of a k-step: two float4), split there, never staged.
+// into registers (a lane = one row's 8 consecutive channels of a k-step: two float4), split there, never staged.  Optional
+// `addend` (rows repeating with a period: the positional encoding of the BEV queries) is added to the row piece in fp32 first --
+// the `query + query_pos` pass of the attention modules folded into the projections that consume it.
 #pragma once
 #include "rt.h"
 #include "history_conv_x3_kernels.h"
@@ -21,7 +23,8 @@
 template <int NT>
 __global__ void __launch_bounds__(256)
 k_rows_linear_x3(const float* __restrict__ x, long long ldx, const unsigned short* __restrict__ wf, const float* __restrict__ bias,
-                 float* __restrict__ out, long long ldo, long long rows, int I, int O, int relu, int n_kc, int n_oc, int RT) {
+                 float* __restrict__ out, long long ldo, long long rows, int I, int O, int relu, int n_kc, int n_oc, int RT,
+                 const float* __restrict__ addend, long long ld_add, long long add_period) {
     unsigned short* wl = reinterpret_cast<unsigned short*>(fbbev_dyn_lds_f32());          // [nmt][FBBEV_RL_TILE_ELEMS]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int g = lane >> 4, j = lane & 15;
@@ -41,6 +44,9 @@ k_rows_linear_x3(const float* __restrict__ x, long long ldx, const unsigned shor
         for (int mt = 0; mt < 8; ++mt)
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[mt][t] = fbbev_v4f{0.f, 0.f, 0.f, 0.f};
+        long long ra[NT];                                                                 // row of the addend (x + addend[row % period])
+#pragma unroll
+        for (int t = 0; t < NT; ++t) ra[t] = addend ? (r0 + 16 * t + j) % add_period : 0;
         for (int kc = 0; kc < n_kc; ++kc) {
             const int c0 = kc * 128;
             // the chunk's row pieces first (raw, into registers): they are in flight while the fragments are staged
@@ -56,6 +62,11 @@ k_rows_linear_x3(const float* __restrict__ x, long long ldx, const unsigned shor
                     const float* p = x + (okp[s][t] ? r * ldx + c : 0);
                     raw[s][t][0] = *reinterpret_cast<const fbbev_v4f*>(p);
                     raw[s][t][1] = *reinterpret_cast<const fbbev_v4f*>(p + 4);
+                    if (addend) {                                                         // uniform: x + addend[row % period] (query + query_pos)
+                        const float* q = addend + (okp[s][t] ? ra[t] * ld_add + c : 0);
+                        raw[s][t][0] = raw[s][t][0] + *reinterpret_cast<const fbbev_v4f*>(q);
+                        raw[s][t][1] = raw[s][t][1] + *reinterpret_cast<const fbbev_v4f*>(q + 4);
+                    }
                 }
             }
             if (n_kc > 1 || ri == 0) {

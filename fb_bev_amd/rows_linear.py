@@ -21,6 +21,8 @@ MIN_ROWS = 16384            # below this autograd's plain GEMM is as good
 # instead of the vendor fp32 GEMM.  FBBEV_ROWS_LINEAR=f32 (or X3 = False) keeps the vendor GEMM.
 X3 = os.environ.get('FBBEV_ROWS_LINEAR', 'x3') != 'f32'
 X3_MIN_ROWS = 2048
+# fold `query + query_pos` into the projections' row loads (fbbev_rows_linear_x3_add); FBBEV_ROWS_LINEAR_FOLD=0: a pass of its own
+FOLD_ADDEND = os.environ.get('FBBEV_ROWS_LINEAR_FOLD', '1') != '0'
 SLICE_ROWS = 2048           # rows per partial product
 
 
@@ -106,27 +108,53 @@ def x3_ok(x, in_features, out_features):
             out_features % 4 == 0 and x.shape[-1] == in_features and x.numel() // max(1, in_features) >= X3_MIN_ROWS)
 
 
-def linear_x3(x, cache, relu=False, out=None):
-    """x (..., I) -> (..., O) through fbbev_rows_linear_x3 with the fragments of `cache` (an X3Weights after .get())."""
+def _addend_rows(addend, x):
+    """(P, I) rows of a positional addend for fbbev_rows_linear_x3_add: a (bs, Q, I) tensor that is the SAME (Q, I) table for
+    every sample (a stride-0 expand, how the encoder hands over `query_pos`) repeats with period Q; anything else is taken row by
+    row.  None if the kernel cannot read it as it is."""
+    I = x.shape[-1]
+    if addend.shape[-1] != I or addend.dtype != torch.float32 or not addend.is_cuda:
+        return None
+    if addend.dim() == 3 and addend.shape[0] > 1 and addend.stride(0) == 0:
+        a = addend[0]
+    elif addend.shape == x.shape and addend.is_contiguous():
+        a = addend.reshape(-1, I)
+    else:
+        return None
+    rows = x.numel() // I
+    if a.stride(1) != 1 or a.stride(0) % 4 != 0 or a.data_ptr() % 16 != 0 or rows % a.shape[0] != 0:
+        return None
+    return a
+
+
+def linear_x3(x, cache, relu=False, out=None, addend=None):
+    """x (..., I) [+ addend] -> (..., O) through fbbev_rows_linear_x3 with the fragments of `cache` (an X3Weights after .get())."""
     I = x.shape[-1]
     O = cache.w.shape[0]
+    a = None
+    if addend is not None:
+        a = _addend_rows(addend, x) if FOLD_ADDEND else None
+        if a is None:
+            x = x + addend
     x2 = x.reshape(-1, I)
     if x2.stride(1) != 1 or x2.stride(0) % 4 != 0 or x2.data_ptr() % 16 != 0:
         x2 = x2.contiguous()
-    y = _capi.rows_linear_x3(x2, cache.frag, cache.b, O, relu=relu, out=out)
+    y = _capi.rows_linear_x3(x2, cache.frag, cache.b, O, relu=relu, out=out, addend=a)
     return y if out is not None else y.view(*x.shape[:-1], O)
 
 
-def linear_rows(x, w, b=None, cache=None, transform=None, relu=False):
-    """F.linear (+ ReLU) for row tensors.  Inference on a GPU with a `cache` (X3Weights owned by the calling module; `w` / `b` are
-    then the SOURCE parameters and `transform` derives the applied matrix): the split-operand MFMA kernel.  Training on a GPU:
-    the split-K backward when it pays.  Otherwise F.linear."""
+def linear_rows(x, w, b=None, cache=None, transform=None, relu=False, addend=None):
+    """F.linear (+ ReLU) of x [+ addend] for row tensors.  Inference on a GPU with a `cache` (X3Weights owned by the calling module;
+    `w` / `b` are then the SOURCE parameters and `transform` derives the applied matrix): the split-operand MFMA kernel, which
+    also folds the addend (query_pos) into its row loads.  Training on a GPU: the split-K backward when it pays.  Otherwise F.linear."""
     if cache is not None:
         O = w.shape[0] if transform is None else None
         if x3_ok(x, x.shape[-1], O if O is not None else 4):
             c = cache.get(w, b, transform)
             if c.w.shape[1] == x.shape[-1] and c.w.shape[0] % 4 == 0:
-                return linear_x3(x, c, relu=relu)
+                return linear_x3(x, c, relu=relu, addend=addend)
+    if addend is not None:
+        x = x + addend
     if transform is not None:
         w, b = transform(w, b)
     rows = x.numel() // max(1, x.shape[-1])
@@ -141,7 +169,7 @@ def linear_rows(x, w, b=None, cache=None, transform=None, relu=False):
 class Linear(nn.Linear):
     """nn.Linear (same parameters / state_dict) whose forward goes through `linear_rows`."""
 
-    def forward(self, x, relu=False):
+    def forward(self, x, relu=False, addend=None):
         if not hasattr(self, '_x3'):
             self._x3 = X3Weights()
-        return linear_rows(x, self.weight, self.bias, cache=self._x3, relu=relu)
+        return linear_rows(x, self.weight, self.bias, cache=self._x3, relu=relu, addend=addend)

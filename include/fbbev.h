@@ -106,6 +106,11 @@ int fbbev_nchw_to_nhwc(const float* in, float* out, int n_images, int C, int HW,
 int fbbev_tokens_from_nchw(const float* in, float* out, int n_images, int C, int HW,
                            long long out_image_stride, long long out_offset, const float* bias,
                            int bias_rows, fbbev_stream_t stream);
+/* The same transposition with a per-POSITION row added:  out[img, p, c] = in[img, c, p] + pos_bias[p, c]  (pos_bias (HW, C), the
+ * same for every image): the BEV queries of the backward projection -- `lss_bev.flatten(2).permute(2, 0, 1)` + the learned
+ * `bev_embedding` (backward_projection.py:96-99) -- in one pass. */
+int fbbev_tokens_from_nchw_pos(const float* in, float* out, int n_images, int C, int HW, long long out_image_stride,
+                               long long out_offset, const float* pos_bias, fbbev_stream_t stream);
 
 /* Replaces LSSViewTransformerFunction3D.voxel_pooling_prepare_v2
  *   -- fbbev/view_transformation/forward_projection/view_transformer.py:547-605
@@ -481,6 +486,13 @@ int fbbev_rows_linear_x3_fragments(const float* weight, int in_features, int out
                                    fbbev_stream_t stream);
 int fbbev_rows_linear_x3(const float* x, long long x_row_stride, const void* fragments, const float* bias, long long rows,
                          int in_features, int out_features, int relu, float* out, long long out_row_stride, fbbev_stream_t stream);
+/* The same with  x[r, :] + addend[r % addend_period, :]  as the row (one fp32 add per element before the product): the
+ * `query = query + query_pos` pass of the attention modules (spatial_cross_attention_depth.py:122-123, mmcv
+ * MultiScaleDeformableAttention.forward) folded into the projections that consume the sum.  addend: (addend_period,
+ * in_features) rows, stride in floats (0 = dense). */
+int fbbev_rows_linear_x3_add(const float* x, long long x_row_stride, const float* addend, long long addend_row_stride,
+                             long long addend_period, const void* fragments, const float* bias, long long rows, int in_features,
+                             int out_features, int relu, float* out, long long out_row_stride, fbbev_stream_t stream);
 
 /* The two 1x1x1 convolutions of the temporal fusion in one fp32-MFMA kernel (inference): replaces
  * history_keyframe_time_conv + history_keyframe_cat_conv of FBOCC.fuse_history (fbocc.py:111-127, 289-310) once the

@@ -258,7 +258,7 @@ def layernorm(x, weight, bias, eps, residual=None):
     return out
 
 
-def rows_linear_x3(x, weight, bias, relu=False, out=None):
+def rows_linear_x3(x, weight, bias, relu=False, out=None, addend=None):
     O, I = weight.shape
     need = lib().fbbev_rows_linear_x3_fragment_bytes(I, O)
     frag = torch.zeros(need + 16, dtype=torch.uint8)
@@ -268,8 +268,14 @@ def rows_linear_x3(x, weight, bias, relu=False, out=None):
     R = x.shape[0]
     if out is None:
         out = torch.full((R, O), float('nan'))
-    code = lib().fbbev_rows_linear_x3(c_void_p(x.data_ptr()), x.stride(0), fp, p(bias) if bias is not None else None, R, I, O,
-                                      1 if relu else 0, c_void_p(out.data_ptr()), out.stride(0), None)
+    b = p(bias) if bias is not None else None
+    if addend is None:
+        code = lib().fbbev_rows_linear_x3(c_void_p(x.data_ptr()), x.stride(0), fp, b, R, I, O, 1 if relu else 0,
+                                          c_void_p(out.data_ptr()), out.stride(0), None)
+    else:
+        code = lib().fbbev_rows_linear_x3_add(c_void_p(x.data_ptr()), x.stride(0), c_void_p(addend.data_ptr()), addend.stride(0),
+                                              addend.shape[0], fp, b, R, I, O, 1 if relu else 0, c_void_p(out.data_ptr()),
+                                              out.stride(0), None)
     return code, out
 
 
@@ -363,8 +369,11 @@ def history_frame_vm(curr, dtype, out=None, inner=1):
     return out
 
 
-def tokens_from_nchw(x, out, out_offset=0, bias=None):
+def tokens_from_nchw(x, out, out_offset=0, bias=None, pos_bias=None):
     n, C, HW = x.shape
+    if pos_bias is not None:
+        ok(lib().fbbev_tokens_from_nchw_pos(p(x), p(out), n, C, HW, out.stride(0), out_offset, p(pos_bias), None))
+        return out
     ok(lib().fbbev_tokens_from_nchw(p(x), p(out), n, C, HW, out.stride(0), out_offset, None if bias is None else p(bias),
                                     0 if bias is None else bias.shape[0], None))
     return out

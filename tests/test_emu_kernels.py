@@ -418,6 +418,10 @@ def test_tokens_from_nchw_emulated():
     x = torch.randn(2, 37, 50, generator=g)
     out = E.tokens_from_nchw(x, torch.full((2, 50, 37), float('nan')))
     assert torch.equal(out, x.transpose(1, 2).contiguous())
+    # per-position row added in the same pass (the BEV queries: lss_bev tokens + bev_embedding)
+    pos = torch.randn(50, 37, generator=g)
+    out = E.tokens_from_nchw(x, torch.full((2, 50, 37), float('nan')), pos_bias=pos)
+    assert torch.equal(out, x.transpose(1, 2) + pos[None])
 
 
 def test_point_sampling_emulated():
@@ -666,6 +670,21 @@ def test_rows_linear_several_row_tiles_per_workgroup_emulated(monkeypatch):
     code3, three = E.rows_linear_x3(x, w, b, relu=True)
     assert code == 0 and code3 == 0 and not torch.isnan(three).any()
     assert torch.equal(one, three)
+
+
+def test_rows_linear_with_periodic_addend_emulated():
+    """fbbev_rows_linear_x3_add: rows = x[r] + addend[r % P] (the query + query_pos of the attention modules folded into the
+    projection), bit-identical to the plain entry on the pre-added rows; 3 samples of 150 queries, a partial last row tile."""
+    g = torch.Generator().manual_seed(5)
+    Q, B, I, O = 150, 3, 80, 96
+    x = torch.randn(B * Q, I, generator=g)
+    pos = torch.randn(Q, I, generator=g)
+    w, b = torch.randn(O, I, generator=g) * 0.2, torch.randn(O, generator=g)
+    code, fused = E.rows_linear_x3(x, w, b, addend=pos)
+    summed = (x.view(B, Q, I) + pos[None]).reshape(B * Q, I).contiguous()
+    code2, plain = E.rows_linear_x3(summed, w, b)
+    assert code == 0 and code2 == 0 and not torch.isnan(fused).any()
+    assert torch.equal(fused, plain)
 
 
 def test_rows_linear_split_operand_rejects_unsupported_shapes():
