@@ -1283,7 +1283,7 @@ extern "C" int fbbev_da_cross_attn_bwd(const float* value, const int64_t* spatia
 // LDS-plane backward (needs a caller-owned partial buffer): k_da_cross_attn_bwd_unit (unit-owned gradients) +
 // k_da_cross_attn_bwd_scatter per token region + k_da_bwd_reduce
 struct da_region { int lvl0, lvl1, tok0, tok1; };
-struct da_bwd_plan { int chunks, q_per_chunk, threads, n_regions; size_t lds, ws; da_region reg[32]; };
+struct da_bwd_plan { int chunks, q_per_chunk, threads, n_regions, info_stride; size_t lds, ws, ws_part; da_region reg[32]; };
 
 // token regions of at most `budget` tokens: whole consecutive levels, or bands of rows of a level larger than the budget
 // (level_hw: HOST array of L (h, w) pairs; without it only the one-region case -- the whole pyramid fits -- is planned)
@@ -1325,11 +1325,12 @@ static int da_bwd_regions(int L, const int32_t* level_hw, int S, int budget, da_
 // Tuning / test overrides of the plan, read ONCE per process (function-local static: thread-safe) -- the Python forward
 // derives the value-row layout from this planner and the backward launches from it, so a variable that changed between
 // the two calls must not be able to make them disagree.  Unset = the measured defaults.
-struct da_bwd_overrides { int tokens, chunks, threads, copies, lds_kb; };
+struct da_bwd_overrides { int tokens, chunks, threads, copies, lds_kb, prepass; };
 static da_bwd_overrides da_bwd_read_env() {
     auto num = [](const char* name) { const char* e = getenv(name); return e ? atoi(e) : 0; };
     return da_bwd_overrides{num("FBBEV_DA_BWD_TOKENS"), num("FBBEV_DA_BWD_CHUNKS"), num("FBBEV_DA_BWD_THREADS"),
-                            num("FBBEV_DA_BWD_COPIES"), num("FBBEV_DA_BWD_LDS_KB")};
+                            num("FBBEV_DA_BWD_COPIES"), num("FBBEV_DA_BWD_LDS_KB"),
+                            getenv("FBBEV_DA_BWD_PREPASS") ? num("FBBEV_DA_BWD_PREPASS") : -1};
 }
 #ifdef FBBEV_TEST_OVERRIDES   // CPU emulator build only (tests/emu/rt.h): the tests switch plans inside one process
 static da_bwd_overrides da_bwd_env() { return da_bwd_read_env(); }
@@ -1371,7 +1372,16 @@ static bool da_bwd_tile_plan(int B, int Ncam, int S, int M, int Dh, int Q, int H
     // + the camera's hit list, its counter, the block maximum
     pl->lds = plane + (size_t)((qpc + 1) & ~1) * 2 + (size_t)(1 + pl->threads / 64) * sizeof(int);
     if (pl->lds > (size_t)(da_bwd_plane_kb() + 12) * 1024) return false;
-    pl->ws = (size_t)B * M * pl->chunks * Ncam * S * HS * sizeof(float);
+    pl->ws_part = ((size_t)B * M * pl->chunks * Ncam * S * HS * sizeof(float) + 255) / 256 * 256;
+    // pre-pass (k_da_bwd_hitinfo; FBBEV_DA_BWD_PREPASS=0 turns it off): per (b, camera, query) the camera count and the Za depth
+    // weights, behind the partials -- worth it when several region launches would each recompute them (configs[2] pyramid:
+    // scatter 2.43 -> 2.22 ms, profiles/r03_exp_da_bwd_prepass.jsonl)
+    pl->info_stride = 0;
+    pl->ws = pl->ws_part;
+    if (da_bwd_env().prepass != 0 && pl->n_regions > 1) {
+        pl->info_stride = 8;                                        // 1 + Za <= 8 floats (Za is checked at the launch)
+        pl->ws += (size_t)B * Ncam * Q * pl->info_stride * sizeof(float);
+    }
     return true;
 }
 
@@ -1410,6 +1420,14 @@ extern "C" int fbbev_da_cross_attn_bwd_ws(const float* value, const int64_t* spa
     fbbev_rt_stream stream = (fbbev_rt_stream)stream_;
     float* part = static_cast<float*>(ws);
     const long long wgs = (long long)B * M * pl.chunks;
+    const float* info = nullptr;
+    if (pl.info_stride > 0 && 1 + Za <= pl.info_stride) {
+        float* info_w = reinterpret_cast<float*>(static_cast<char*>(ws) + pl.ws_part);
+        FBBEV_LAUNCH(k_da_bwd_hitinfo, ((long long)B * Q + 255) / 256, 256, 0, stream, spatial_shapes, pred_depth, ref_cam, mask,
+                     qdepth, B, Ncam, Q, Za, DC, d0, dstep, pl.info_stride, info_w);
+        FBBEV_CHECK_LAUNCH();
+        info = info_w;
+    }
     {
         // (A) unit-owned gradients, the forward's launch shape
         const long long units = (long long)B * Q * M;
@@ -1444,7 +1462,8 @@ extern "C" int fbbev_da_cross_attn_bwd_ws(const float* value, const int64_t* spa
 #define FBBEV_DA_BWD_SC(NT_, DH_)                                                                                       \
     FBBEV_LAUNCH((k_da_cross_attn_bwd_scatter<NT_, DH_>), wgs, NT_, lds_b, stream, spatial_shapes, level_start_index,     \
                  pred_depth, ref_cam, mask, qdepth, offsets, attn, grad_slots, B, Ncam, S, M, L, Q, P, Za, DC, d0, dstep, \
-                 head_minor & 3, HS, pl.chunks, pl.q_per_chunk, rg.lvl0, rg.lvl1, rg.tok0, rg.tok1, copies, part)
+                 head_minor & 3, HS, pl.chunks, pl.q_per_chunk, rg.lvl0, rg.lvl1, rg.tok0, rg.tok1, copies, part, info,  \
+                 pl.info_stride)
 #define FBBEV_DA_BWD_SC_NT(DH_) do { if (pl.threads == 512) FBBEV_DA_BWD_SC(512, DH_); else FBBEV_DA_BWD_SC(256, DH_); } while (0)
             if (Dh == 10) FBBEV_DA_BWD_SC_NT(10);
             else if (Dh == 8) FBBEV_DA_BWD_SC_NT(8);

@@ -767,12 +767,26 @@ def test_fused_da_cross_attention_backward_emulated():
         # several query chunks per (sample, head) so that the reduction over chunks is exercised
         import os
         shapes_host = [tuple(int(x) for x in hw) for hw in ss.tolist()]
-        for chunks, threads, tokens in (('1', '256', None), ('3', '256', None), ('2', '512', None),
-                                        ('2', '256', '8')):             # token regions: bands of rows, levels apart
+        for chunks, threads, tokens, prepass in (('1', '256', None, None), ('3', '256', None, None), ('2', '512', None, None),
+                                                 ('2', '256', '8', '0'),         # token regions: bands of rows, levels apart
+                                                 ('2', '256', '8', '1')):        # + the per-(camera, query) pre-pass (the default)
             os.environ['FBBEV_DA_BWD_CHUNKS'] = chunks
             os.environ['FBBEV_DA_BWD_THREADS'] = threads
             if tokens:
                 os.environ['FBBEV_DA_BWD_TOKENS'] = tokens
+            if prepass == '0':
+                os.environ['FBBEV_DA_BWD_PREPASS'] = '0'
+            if prepass == '1':
+                import ctypes
+                flat = [int(x) for hw in shapes_host for x in hw]
+                harr = (ctypes.c_int32 * len(flat))(*flat)
+                Ncam_, B_, Q_, _ = mask.shape
+                wsb = lambda: E.lib().fbbev_da_cross_attn_bwd_ws_bytes(B_, Ncam_, vp.shape[1], vp.shape[2], Dh, Q_, HS, len(shapes_host),  # noqa: E731
+                                                                       attn.shape[-1], harr)
+                os.environ['FBBEV_DA_BWD_PREPASS'] = '0'
+                plain = wsb()
+                os.environ['FBBEV_DA_BWD_PREPASS'] = prepass
+                assert wsb() > plain > 0                                 # the pre-pass is planned (its table sits behind the partials)
             try:
                 for hm, vin in ((0, vp), (4, _interleave(vp)), (5, _interleave(vp))):
                     o_in = f32(offsets).permute(0, 1, 3, 4, 2, 5).contiguous() if hm & 1 else f32(offsets)
@@ -789,6 +803,7 @@ def test_fused_da_cross_attention_backward_emulated():
             finally:
                 del os.environ['FBBEV_DA_BWD_CHUNKS'], os.environ['FBBEV_DA_BWD_THREADS']
                 os.environ.pop('FBBEV_DA_BWD_TOKENS', None)
+                os.environ.pop('FBBEV_DA_BWD_PREPASS', None)
 
 
 @pytest.mark.parametrize('B,T1,C,N,dt', [(1, 3, 16, 64, torch.float32), (2, 2, 80, 100, torch.bfloat16), (1, 3, 80, 17, torch.float16),
