@@ -552,8 +552,8 @@ def run_train(args):
     shard.init('nccl', dev)
     ranks, devices = check_ranks(args, world, rank, dev)
     B = args.batch if args.batch != 16 else 4          # 16 is the forward mode's default; configs[3] is 4 per GPU
-    name = 'fbocc-r50-cbgs_depth_16f_16x4_20e.py'
-    cfg = dict(json.load(open(os.path.join(ROOT, 'tests', 'golden', 'fbocc_config_path_blocks.json')))[name]['model'])
+    from fb_bev_amd import configs
+    cfg = configs.model_block(configs.SHIPPED)          # package data: the shipped config's unchanged `model` block
     cfg.pop('type')
     ex = dict(with_cp=False, mfma_conv3d_train=(args.conv == 'mfma'))
     if args.conv_dtype == 'bf16':

@@ -438,8 +438,11 @@ class DA_SpatialCrossAttention(nn.Module):
         # Same dot products for the real rows; the padding rows are zero and ignored by the kernel.
         wt, bs = da.value_proj.weight, da.value_proj.bias
         interleave = True
-        grad_mode = torch.is_grad_enabled() and (wt.requires_grad or bs.requires_grad or value.requires_grad or
-                                                 query.requires_grad or pred_img_depth.requires_grad)
+        # every parameter of the deformable attention counts: with only sampling_offsets / attention_weights
+        # trainable the zero-token inference branch below would hand back slots without an autograd node
+        grad_mode = torch.is_grad_enabled() and (value.requires_grad or query.requires_grad or pred_img_depth.requires_grad or
+                                                 (query_pos is not None and query_pos.requires_grad) or
+                                                 any(p.requires_grad for p in da.parameters()))
         if self.value_dtype in (torch.bfloat16, torch.float16) and not grad_mode and Dh in (8, 10, 16, 32):
             # 16-bit tokens: rows chunk-major with 8-element pieces, rounded once after the fp32 projection
             HS16 = (Dh + 7) // 8 * 8
@@ -582,15 +585,17 @@ class _LayerNormRows(torch.autograd.Function):
     """fbbev_layernorm / fbbev_layernorm_bwd under autograd (training of the backward projection on a GPU)."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
     def forward(ctx, x, weight, bias, eps):
         ctx.save_for_backward(x, weight)
         ctx.eps = eps
         return _capi.layernorm(x, weight, bias, eps)
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
     def backward(ctx, gy):
         x, weight = ctx.saved_tensors
-        gx, gw, gb = _capi.layernorm_bwd(x, gy.contiguous(), weight, ctx.eps)
+        gx, gw, gb = _capi.layernorm_bwd(x, gy.float().contiguous(), weight, ctx.eps)
         return (gx if ctx.needs_input_grad[0] else None, gw if ctx.needs_input_grad[1] else None,
                 gb if ctx.needs_input_grad[2] else None, None)
 

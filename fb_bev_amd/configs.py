@@ -3,6 +3,8 @@
 path can be built without mmcv's Config loader.  Values are configuration data of the reference; the
 `type=` strings are the registry names preserved by fb_bev_amd."""
 import copy
+import json
+import os
 
 
 def fbocc_r50(num_levels=1, bev_h=100, bev_w=100, numC_Trans=80, input_size=(256, 704),
@@ -41,3 +43,38 @@ def fbocc_r50(num_levels=1, bev_h=100, bev_w=100, numC_Trans=80, input_size=(256
     return copy.deepcopy(dict(forward_projection=forward_projection, backward_projection=backward_projection,
                               grid_config=grid_config, grid_config_bevformer=grid_config_bevformer,
                               data_config=data_config, depth_bound=list(depth_bound)))
+
+
+# ---- the whole `model` block of the shipped detector configs, as package data --------------------------------------------------
+# bench.py --mode train / tools build the full FBOCC from it on a box without /root/reference.  The JSON is what
+# `fb_bev_amd.config.load_config` returns for occupancy_configs/fb_occ/*.py (`model` key), written by `extract_model_blocks`
+# (run in the build container: `python -m fb_bev_amd.configs /root/reference`); tests/test_config_loading.py checks it against
+# the live reference configs when the tree is mounted, and against the test fixture otherwise.
+DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data', 'fbocc_model_blocks.json')
+SHIPPED = 'fbocc-r50-cbgs_depth_16f_16x4_20e.py'
+
+
+def model_block(name=SHIPPED):
+    """The unchanged `model` dict of a shipped FB-OCC config (type FBOCC / FBOCCTRT), by config file name."""
+    with open(DATA) as f:
+        blocks = json.load(f)
+    if name not in blocks:
+        raise KeyError(f'{name!r} is not a shipped FB-OCC config ({sorted(blocks)})')
+    return copy.deepcopy(blocks[name])
+
+
+def extract_model_blocks(reference_root, dst=DATA):
+    import glob
+    from .config import load_config
+    out = {}
+    for path in sorted(glob.glob(os.path.join(reference_root, 'occupancy_configs', 'fb_occ', '*.py'))):
+        out[os.path.basename(path)] = load_config(path)['model']
+    os.makedirs(os.path.dirname(dst), exist_ok=True)
+    with open(dst, 'w') as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    return out
+
+
+if __name__ == '__main__':
+    import sys
+    print(sorted(extract_model_blocks(sys.argv[1] if len(sys.argv) > 1 else '/root/reference')))

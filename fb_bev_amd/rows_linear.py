@@ -62,14 +62,17 @@ class _RowsLinear(torch.autograd.Function):
     in-place ops (the FFN's ReLU(inplace=True)) on a view created inside a custom Function; `linear_rows` reshapes outside."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)     # autocast-safe (ADVICE r3): fp32 in, fp32 GEMM,
+    def forward(ctx, x, w, b):                                              # autocast off inside forward AND backward
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
         return F.linear(x, w, b)
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
+        gy = gy.float()
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gx = gy @ w

@@ -88,10 +88,12 @@ class GradBuckets:
         self.params = [p for p in params if p.requires_grad]
         self._hooks = []
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._hold = False
         # first step: buckets in reverse registration order (~ the order autograd produces gradients); its finish()
         # re-lays them out in the order the gradients ACTUALLY arrived (rank 0's order, broadcast), because with
         # strictly ordered launches one late parameter in an early bucket holds back every bucket behind it
         self._arrival = [] if rebuild else None
+        self._seen = set()                 # parameters whose gradient arrived since the last finish()
         self._layout(list(reversed(self.params)), keep=False)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
 
@@ -152,6 +154,17 @@ class GradBuckets:
         if p.grad.data_ptr() < self._flat[bi].data_ptr() or \
                 p.grad.data_ptr() >= self._flat[bi].data_ptr() + self._flat[bi].numel() * 4:
             raise RuntimeError('GradBuckets: a .grad was replaced (zero_grad(set_to_none=True)?); use buckets.zero_grad()')
+        if self._hold:
+            return                         # non-final pass of a gradient accumulation: summed into the bucket, not counted
+        if p in self._seen:
+            # a second backward() before finish() without no_sync(): counting the parameter twice would leave duplicate slots
+            # in the re-laid-out buckets and a ready count no bucket ever reaches; and a bucket that already went
+            # out must not be accumulated into while its all-reduce is in flight
+            if self._work[bi] is not None:
+                raise RuntimeError('GradBuckets: a gradient arrived again after its bucket was all-reduced; call finish() '
+                                   'after every backward(), or accumulate under `with buckets.no_sync():`')
+            return
+        self._seen.add(p)
         self._ready[bi] += 1
         if self._arrival is not None:
             self._arrival.append(p)
@@ -159,6 +172,20 @@ class GradBuckets:
         while self._next < len(self.buckets) and self._ready[self._next] == len(self.buckets[self._next]):
             self._launch(self._next)
             self._next += 1
+
+    def no_sync(self):
+        """Context for the non-final backward passes of gradient accumulation: gradients accumulate into the flat buckets,
+        nothing is launched; the next backward() outside the context launches, or finish() does."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            self._hold = True
+            try:
+                yield
+            finally:
+                self._hold = False
+        return ctx()
 
     def zero_grad(self):
         """Zero the flat buckets in place (the .grad views stay attached)."""
@@ -170,6 +197,7 @@ class GradBuckets:
         for bi in range(self._next, len(self._flat)):
             self._launch(bi)
         self._next = 0
+        self._seen.clear()
         for bi, w in enumerate(self._work):
             if w is not None:
                 w.wait()

@@ -60,3 +60,17 @@ def test_base_merge_semantics(tmp_path):
     (tmp_path / 'child.py').write_text("_base_ = ['./base.py']\na = dict(y=dict(q=5), z=7)\nc = dict(_delete_=True, k=1)\n")
     cfg = C.load_config(str(tmp_path / 'child.py'))
     assert cfg == {'a': {'x': 1, 'y': {'p': 1, 'q': 5}, 'z': 7}, 'b': 3, 'c': {'k': 1}}
+
+
+def test_package_model_blocks_equal_the_reference_configs():
+    """bench.py --mode train and the tools build the detector from fb_bev_amd/data/fbocc_model_blocks.json
+    (fb_bev_amd.configs.model_block): it is the `model` block of the shipped configs -- the same as the test fixture's copy, and
+    as the live reference configs when the tree is mounted."""
+    from fb_bev_amd import configs
+    fixture = json.load(open(G))
+    for name, info in fixture.items():
+        assert configs.model_block(name) == info['model']
+    for path in LIVE:
+        assert json.loads(json.dumps(C.load_config(path)['model'])) == configs.model_block(os.path.basename(path))
+    with pytest.raises(KeyError):
+        configs.model_block('nope.py')

@@ -317,3 +317,54 @@ def test_two_rank_sync_batchnorm_equals_full_batch_statistics():
         assert kinds == ['Conv3d', 'SyncBatchNorm', 'ReLU', 'Conv3d', 'BatchNorm3d', 'SyncBatchNorm'], kinds
         assert e_dx < 2e-4 and e_dw < 2e-4, (rank, e_dx, e_dw)
         assert e_rm < 1e-5 and e_rv < 1e-5 and nbt == 1
+
+
+def _accum_worker(rank, world, port, q):
+    _env(rank, world, port)
+    import torch.nn as nn
+    from fb_bev_amd import shard
+    shard.init('gloo')
+    torch.manual_seed(0)
+    net = nn.Sequential(nn.Linear(6, 5), nn.ReLU(), nn.Linear(5, 4), nn.ReLU(), nn.Linear(4, 3))
+    gb = shard.GradBuckets(net.parameters(), bucket_bytes=64)          # several small buckets
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(world, 2, 3, 6, generator=g)                       # (rank, micro-batch, rows, features)
+    # reference: mean over ranks of the SUM over the two micro-batches
+    ref = [torch.zeros_like(p) for p in net.parameters()]
+    for r in range(world):
+        for mb in range(2):
+            gs = torch.autograd.grad(net(x[r, mb]).square().sum(), list(net.parameters()))
+            for a, b in zip(ref, gs):
+                a += b / world
+    errs, layouts = [], []
+    for step in range(3):                                              # step 0 re-lays the buckets out, 1-2 run on that layout
+        gb.zero_grad()
+        with gb.no_sync():
+            net(x[rank, 0]).square().sum().backward()
+        net(x[rank, 1]).square().sum().backward()
+        gb.finish()
+        errs.append(max(float((p.grad - a).abs().max()) for p, a in zip(net.parameters(), ref)))
+        layouts.append([len(b) for b in gb.buckets])
+    n_slots = sum(layouts[-1])
+    # a second un-fenced backward after the buckets went out must be refused, not silently raced
+    gb.zero_grad()
+    net(x[rank, 0]).square().sum().backward()
+    refused = False
+    if world > 1:
+        try:
+            net(x[rank, 1]).square().sum().backward()
+        except RuntimeError as e:
+            refused = 'no_sync' in str(e)
+    gb.finish()
+    q.put((rank, errs, n_slots, len(list(net.parameters())), refused))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_gradient_accumulation_no_sync_and_no_duplicate_slots():
+    """a parameter whose hook fires twice before finish() must not get two slots in the re-laid-out buckets; the
+    supported form of accumulation is `with buckets.no_sync():` for the non-final passes; a second un-fenced backward after
+    the all-reduces went out raises."""
+    for rank, errs, n_slots, n_params, refused in _run(2, _accum_worker):
+        assert n_slots == n_params, (n_slots, n_params)
+        assert max(errs) < 1e-5, errs
+        assert refused

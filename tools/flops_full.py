@@ -16,8 +16,8 @@ from fb_bev_amd.fbocc import FBOCC  # noqa: E402
 
 
 def main():
-    cfg = dict(json.load(open(os.path.join(ROOT, 'tests', 'golden', 'fbocc_config_path_blocks.json')))
-               ['fbocc-r50-cbgs_depth_16f_16x4_20e.py']['model'])
+    from fb_bev_amd import configs
+    cfg = configs.model_block()
     cfg.pop('type')
     torch.manual_seed(0)
     m = FBOCC(**cfg, execution=dict(with_cp=False)).eval()

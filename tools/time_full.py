@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Scopes S4 / S5 of SURVEY 8d on one GPU: the whole FB-OCC detector built from the shipped config block
-(tests/golden/fbocc_config_path_blocks.json, extracted from occupancy_configs/fb_occ/fbocc-r50-cbgs_depth_16f_16x4_20e.py)
+(fb_bev_amd/data/fbocc_model_blocks.json, extracted from occupancy_configs/fb_occ/fbocc-r50-cbgs_depth_16f_16x4_20e.py)
 with random-init weights and synthetic inputs of SURVEY Appendix B.
 
     python tools/time_full.py infer B [f32|bf16] [mfma]   S4: images -> occupancy class ids (device), per-stage split;
@@ -25,8 +25,8 @@ from fb_bev_amd.fbocc import FBOCC  # noqa: E402
 
 
 def build(dtype, with_cp=False, mfma=False, mfma_train=False):
-    cfg = dict(json.load(open(os.path.join(ROOT, 'tests', 'golden', 'fbocc_config_path_blocks.json')))
-               ['fbocc-r50-cbgs_depth_16f_16x4_20e.py']['model'])
+    from fb_bev_amd import configs
+    cfg = configs.model_block()
     cfg.pop('type')
     ex = dict(with_cp=with_cp, mfma_conv3d=mfma, mfma_conv3d_train=mfma_train)     # mfma: False | True | 'bf16'
     if dtype == 'bf16':

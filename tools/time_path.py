@@ -12,8 +12,8 @@ def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     bf16 = len(sys.argv) > 2 and sys.argv[2] == 'bf16'
     dev = torch.device('cuda:0')
-    blocks = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'fbocc_config_path_blocks.json')))
-    model = blocks['fbocc-r50-cbgs_depth_16f_16x4_20e.py']['path_blocks']
+    from fb_bev_amd import configs
+    model = C.path_blocks(configs.model_block())
     torch.manual_seed(0)
     depth_net = C.build_depth_net(model, compute_dtype=torch.bfloat16 if bf16 else torch.float32).to(dev).eval()
     fvt, hist = C.build_view_transformation(model)
