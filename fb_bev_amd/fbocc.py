@@ -63,7 +63,8 @@ class FBOCC(nn.Module):
         activation checkpointing (the configs turn it on to fit 16-32 GB parts; 288 GB of HBM does not need it);
         history_dtype='f16' | 'bf16' stores the inference history ring in 16 bits (BASELINE configs[4]);
         history_compute='bf16' runs the two fused history convolutions on the bf16 MFMA (fp32 accumulate) at inference,
-        'bf16x3' the same at fp32-grade precision (split operands; 16-bit voxel-major ring);
+        'bf16x3' the same with split operands (three MFMAs per product: 6.5e-6 of the output peak against the fp32 convolutions;
+        16-bit voxel-major ring), 'f32' the reference's arithmetic; default 'auto' = 'bf16x3' for a 16-bit ring, 'f32' otherwise;
         history_ring='voxel_major' keeps the inference ring as (B, T, N, C) voxel rows (16-byte taps, same element bits);
         da_value_dtype='bf16' | 'f16' keeps the cross-attention's camera tokens in 16 bits at inference (fp32 accumulate);
         mfma_conv3d / mfma_conv3d_train=True route the voxel encoder + head through fbbev_conv3d_* (mfma_conv3d.py)."""
@@ -92,7 +93,7 @@ class FBOCC(nn.Module):
                                      history_cat_num=history_cat_num,
                                      history_cat_conv_out_channels=history_cat_conv_out_channels, do_history=do_history,
                                      interpolation_mode=interpolation_mode, history_dtype=_dtype(ex.get('history_dtype')),
-                                     history_compute=_dtype(ex.get('history_compute')),
+                                     history_compute=_dtype(ex['history_compute']) if ex.get('history_compute') else 'auto',
                                      ring_layout=ex.get('history_ring', 'voxel_major'))
         # the reference registers the two fusion convolutions on the detector itself (fbocc.py:111-127): same names here
         self.history_keyframe_time_conv = hist.history_keyframe_time_conv

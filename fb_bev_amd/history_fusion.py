@@ -31,7 +31,7 @@ from .mfma_conv3d import MConv3d      # nn.Conv3d (same parameters / state dict)
 class TemporalHistoryFusion(nn.Module):
     def __init__(self, dx, bx, single_bev_num_channels=80, history_cat_num=16, history_cat_conv_out_channels=None,
                  do_history=True, interpolation_mode='bilinear', history_cam_sweep_freq=0.5, history_dtype=torch.float32,
-                 history_compute=torch.float32, ring_layout='voxel_major'):
+                 history_compute='auto', ring_layout='voxel_major'):
         super().__init__()
         if interpolation_mode != 'bilinear':
             raise NotImplementedError("only interpolation_mode='bilinear' (trilinear on the voxel grid) is built")
@@ -64,7 +64,12 @@ class TemporalHistoryFusion(nn.Module):
         # bfloat16 = both GEMMs on the bf16 MFMA with fp32 accumulation (weights, frames and the ReLU'd intermediate rounded to
         # bf16; ~4e-3 of the output peak) -- at 400x400x16 the fp32-MFMA kernel is compute bound; or
         # 'bf16x3' = fp32-GRADE results on the bf16 MFMA (every operand split into two bf16 terms, three MFMAs per product:
-        # ~5e-6 of the output peak; 16-bit voxel-major ring, C = Cout in {16, 80} -- anything else runs float32).
+        # ~5e-6 of the output peak; 16-bit voxel-major ring, C = Cout in {16, 80} -- anything else runs float32); or
+        # 'auto' (the DEFAULT since round 4) = 'bf16x3' for a 16-bit ring, float32 for an fp32 ring: with a 16-bit ring the
+        # frames already carry a 2^-11 (fp16) / 2^-8 (bf16) storage rounding, against which the split-operand products' 6.5e-6 of
+        # the output peak (measured on an MI355X against the fp32 convolutions, tests/test_gpu_history.py) is noise -- and the
+        # fp32-MFMA kernel is the compute-bound 10.5 ms of the 14.7 ms configs[4] step (profiles/r03_scope_s6_variants.json).
+        # torch.float32 stays selectable and is bit-for-bit the reference's arithmetic on the stored frames.
         self.history_compute = history_compute
         # Layout of the inference ring: 'planar' = the reference's (B, T*C, Z, Y, X); 'voxel_major' = (B, T, N, C) frames of
         # voxel rows (history_kernels.h): a trilinear tap is one 16-byte load of 8 channels instead of 8 scalar gathers from 8
@@ -313,6 +318,8 @@ class TemporalHistoryFusion(nn.Module):
             return out.view(B, -1, Z, Y, X), nxt
         _capi.history_warp_vm(hist, flow, nxt[:, 1:], (Z, Y, X))                            # slots 1..T (:275)
         compute = self.history_compute
+        if compute == 'auto':
+            compute = 'bf16x3' if nxt.dtype in (torch.bfloat16, torch.float16) else torch.float32
         if compute == 'bf16x3' and not (nxt.dtype in (torch.bfloat16, torch.float16) and C == w2.shape[0] and C in (16, 80)):
             compute = torch.float32
         out = _capi.history_conv(nxt, w1, bias1, w2, b2,
@@ -343,7 +350,7 @@ class TemporalHistoryFusion(nn.Module):
         if self.use_mfma_convs and C % 16 == 0 and cout % 16 == 0 and max(C, cout) <= 128:
             # both convs in one MFMA kernel: the (T+1)*C-channel intermediate never leaves the CU
             compute = self.history_compute if (C == cout and C in (16, 80)) else torch.float32
-            if compute == 'bf16x3':                 # the split-operand kernel reads voxel rows only
+            if compute in ('bf16x3', 'auto'):       # the split-operand kernel reads voxel rows only
                 compute = torch.float32
             out = _capi.history_conv(nxt.view(B, (T + 1) * C, n), w1c, bias1.contiguous(), w2, b2,
                                      torch.empty((B, cout, n), dtype=torch.float32, device=curr.device), compute=compute)
