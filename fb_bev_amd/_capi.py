@@ -55,6 +55,11 @@ SIGNATURES = {
     'fbbev_rows_linear_x3': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
     'fbbev_rows_linear_x3_add': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
                                          c_void_p, c_int64, c_void_p]),
+    'fbbev_rows_linear_x3_planes': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'fbbev_da_cross_attn_fused_supported': (c_int, [c_int] * 10),
+    'fbbev_da_cross_attn_fused': (c_int, [c_void_p] * 8 + [c_int64, c_void_p, c_int64, c_int64] + [c_void_p] * 4 + [c_int] * 10 +
+                                  [c_float, c_float, c_int, c_int, c_void_p, c_void_p]),
+    'fbbev_rows_to_head_planes': (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
     'fbbev_layernorm_bwd_partials': (c_int, [c_int64]),
     'fbbev_layernorm_bwd': (c_int, [c_void_p] * 3 + [c_float, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     'fbbev_history_conv': (c_int, [c_void_p, c_int64] + [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -749,6 +754,72 @@ def rows_linear_x3(x, fragments, bias, out_features, relu=False, out=None, adden
                                                   _dev(out, F32, 'out', contiguous=False), out.stride(0), _stream()),
                    'fbbev_rows_linear_x3_add')
     return out
+
+
+def rows_linear_x3_planes(x, fragments, bias, tokens_per_image, heads, head_dim, out=None):
+    """x (R, I) f32 rows of camera tokens (R = images * tokens_per_image) -> head planes (images, heads, tokens_per_image, head_dim)
+    = value_proj written in the layout fbbev_da_cross_attn_fused samples (fbbev_rows_linear_x3_planes)."""
+    R, I = x.shape
+    if x.stride(1) != 1 or R % tokens_per_image != 0:
+        raise FbbevError('rows_linear_x3_planes: rows must have unit column stride and cover whole images')
+    shape = (R // tokens_per_image, heads, tokens_per_image, head_dim)
+    if out is None:
+        out = torch.empty(shape, dtype=F32, device=x.device)
+    if tuple(out.shape) != shape or not out.is_contiguous():
+        raise FbbevError('rows_linear_x3_planes: out must be contiguous (images, heads, tokens, head_dim)')
+    b = _dev(bias, F32, 'bias') if bias is not None else None
+    with _on(x):
+        _check(lib().fbbev_rows_linear_x3_planes(_dev(x, F32, 'x', contiguous=False), x.stride(0), fragments.data_ptr(), b, R, I,
+                                                 heads * head_dim, tokens_per_image, head_dim, _dev(out, F32, 'out'), _stream()),
+               'fbbev_rows_linear_x3_planes')
+    return out
+
+
+def rows_to_head_planes(rows, tokens_per_image, heads, head_dim):
+    """(images * tokens_per_image, heads * head_dim) row-major camera tokens -> (images, heads, tokens_per_image, head_dim)"""
+    R = rows.shape[0]
+    out = torch.empty((R // tokens_per_image, heads, tokens_per_image, head_dim), dtype=F32, device=rows.device)
+    with _on(rows):
+        _check(lib().fbbev_rows_to_head_planes(_dev(rows, F32, 'rows'), R, tokens_per_image, heads, head_dim, _dev(out, F32, 'out'),
+                                               _stream()), 'fbbev_rows_to_head_planes')
+    return out
+
+
+def da_cross_attn_fused_supported(B, Ncam, S, M, Dh, L, Q, P, Za, bev_w):
+    return bool(lib().fbbev_da_cross_attn_fused_supported(B, Ncam, S, M, Dh, L, Q, P, Za, int(bev_w)))
+
+
+def da_cross_attn_fused(planes, spatial_shapes, level_start_index, pred_depth, ref_cam, mask, qdepth, query, addend,
+                        offsets_fragments, offsets_bias, attn_fragments, attn_bias, num_points, d0, dstep, bev_w, min_level_width,
+                        slots):
+    """fbbev_da_cross_attn_fused: planes (B*Ncam, M, S, Dh) head-plane camera tokens; query (B, Q, E) rows [+ addend (P_, E) rows with
+    B*Q % P_ == 0, e.g. the (Q, E) positional table]; fragments / biases of sampling_offsets and attention_weights in the module's
+    row order (rows_linear_x3_fragments); slots (B, Q, E) written.  min_level_width: host value of the narrowest level's width."""
+    Ncam, B, Q, Za = mask.shape
+    BN, M, S, Dh = planes.shape
+    E = M * Dh
+    L = spatial_shapes.shape[0]
+    DC = pred_depth.shape[1]
+    if tuple(query.shape) != (B, Q, E) or query.stride(2) != 1 or query.stride(0) != Q * query.stride(1):
+        raise FbbevError('da_cross_attn_fused: query must be (B, Q, E) rows with one row stride')
+    if tuple(slots.shape) != (B, Q, E) or not slots.is_contiguous():
+        raise FbbevError('da_cross_attn_fused: slots must be contiguous (B, Q, M*Dh)')
+    if mask.dtype == torch.bool:
+        mask = mask.view(torch.uint8)
+    a_ptr, a_ld, a_per = None, 0, 1
+    if addend is not None:
+        if addend.dim() != 2 or addend.shape[1] != E or addend.stride(1) != 1 or (B * Q) % addend.shape[0] != 0:
+            raise FbbevError('da_cross_attn_fused: addend must be (P, E) rows with B*Q % P == 0')
+        a_ptr, a_ld, a_per = _dev(addend, F32, 'addend', contiguous=False), addend.stride(0), addend.shape[0]
+    with _on(planes):
+        _check(lib().fbbev_da_cross_attn_fused(
+            _dev(planes, F32, 'planes'), _dev(spatial_shapes, I64, 'spatial_shapes'), _dev(level_start_index, I64, 'level_start_index'),
+            _dev(pred_depth, F32, 'pred_depth'), _dev(ref_cam, F32, 'ref_cam'), _dev(mask, torch.uint8, 'mask'),
+            _dev(qdepth, F32, 'qdepth'), _dev(query, F32, 'query', contiguous=False), query.stride(1), a_ptr, a_ld, a_per,
+            offsets_fragments.data_ptr(), _dev(offsets_bias, F32, 'offsets_bias'), attn_fragments.data_ptr(),
+            _dev(attn_bias, F32, 'attn_bias'), B, Ncam, S, M, Dh, L, Q, int(num_points), Za, DC, float(d0), float(dstep), int(bev_w),
+            int(min_level_width), _dev(slots, F32, 'slots'), _stream()), 'fbbev_da_cross_attn_fused')
+    return slots
 
 
 def layernorm_bwd(x, grad_out, weight, eps):

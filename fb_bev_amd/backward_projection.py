@@ -25,6 +25,7 @@ import torch.nn.functional as F
 
 from . import _capi
 from .ms_deform_attn import MultiScaleDeformableAttnFunction_fp32
+from . import rows_linear as _RL
 from .rows_linear import Linear, X3Weights, linear_rows, linear_x3, x3_ok
 
 REGISTRY = {}
@@ -481,6 +482,11 @@ class DA_SpatialCrossAttention(nn.Module):
         # the pipelined kernel applies the attention softmax while it stages the weights: hand it the raw logits
         fuse_sm = zt and not da.disable_deformable and _capi.da_fuses_softmax(
             B, ncam, S, M, Dh, da.num_levels, Q, da.num_points, reference_points_cam.shape[3], hm, HS)
+        if zt and not da.disable_deformable:
+            slots = self._slots_one_kernel(da, x, query, query_pos, reference_points_cam, mask, bev_query_depth, pred_img_depth,
+                                           spatial_shapes, level_start_index, bev_w)
+            if slots is not None:
+                return slots
         so, aw = da.project_head_minor(query, softmax=not fuse_sm, addend=query_pos)
         if zt:
             # inference: the projection writes into a buffer with one extra all-zero token behind the rows -- the pipelined
@@ -511,6 +517,42 @@ class DA_SpatialCrossAttention(nn.Module):
             level_start_index.to(torch.int64).contiguous(), reference_points_cam.contiguous().float(), mask.contiguous(),
             bev_query_depth.squeeze(-1).contiguous().float(), self.dbound[0], self.dbound[2], 1 | (4 if interleave else 0), Dh,
             host_values(spatial_shapes))
+
+    # ---- inference default since round 4: query rows -> slots in ONE kernel (fbbev_da_cross_attn_fused, da_fused_kernels.h)
+    def _slots_one_kernel(self, da, x, query, query_pos, reference_points_cam, mask, bev_query_depth, pred_img_depth,
+                          spatial_shapes, level_start_index, bev_w):
+        """value_proj writes the camera tokens as head planes (fbbev_rows_linear_x3_planes); the sampling_offsets / attention_weights
+        projections, the softmax and the sampling run inside one kernel from the query rows (+ positional rows): no offsets /
+        weights tensors (492 MB written and re-read at BASELINE configs[2], B = 4).  None when the shape is not the kernel's
+        (M = 8, Dh in {8, 10}, 8 points, 4 anchors, levels >= 2 tokens wide, a BEV grid) or FBBEV_ROWS_LINEAR=f32 asks for the
+        vendor fp32 GEMMs: the caller falls through to the projection kernels + the pipelined sampler."""
+        B, Q, E = query.shape
+        BN, S, _ = x.shape
+        ncam = BN // B
+        M, L, P = da.num_heads, da.num_levels, da.num_points
+        Dh = E // M
+        hw = host_values(spatial_shapes)
+        if (not _RL.X3 or hw is None or min(int(w) for _, w in hw) < 2 or E % 8 != 0 or not query.is_contiguous() or
+                not _capi.da_cross_attn_fused_supported(B, ncam, S, M, Dh, L, Q, P, reference_points_cam.shape[3], bev_w or 0)):
+            return None
+        if not hasattr(self, '_vx3p'):
+            self._vx3p, da._so_x3p, da._aw_x3p = X3Weights(), X3Weights(), X3Weights()
+        vp = self._vx3p.get(da.value_proj.weight, da.value_proj.bias)
+        planes = _capi.rows_linear_x3_planes(x.reshape(BN * S, E), vp.frag, vp.b, S, M, Dh)
+        so = da._so_x3p.get(da.sampling_offsets.weight, da.sampling_offsets.bias)
+        aw = da._aw_x3p.get(da.attention_weights.weight, da.attention_weights.bias)
+        addend = None
+        if query_pos is not None:
+            addend = _RL._addend_rows(query_pos, query) if _RL.FOLD_ADDEND else None
+            if addend is None:
+                query = query + query_pos
+        DC, H0, W0 = pred_img_depth.shape[2:]
+        slots = torch.empty((B, Q, E), dtype=torch.float32, device=query.device)
+        return _capi.da_cross_attn_fused(
+            planes, spatial_shapes.to(torch.int64).contiguous(), level_start_index.to(torch.int64).contiguous(),
+            pred_img_depth.reshape(BN, DC, H0, W0).contiguous().float(), reference_points_cam.contiguous().float(), mask.contiguous(),
+            bev_query_depth.squeeze(-1).contiguous().float(), query, addend, so.frag, so.b, aw.frag, aw.b, P, self.dbound[0],
+            self.dbound[2], bev_w, min(int(w) for _, w in hw), slots)
 
     # ---- training: vectorised rebatch + composite deformable attention (autograd through the MSDA op)
     def _slots_composite(self, query, value, reference_points_cam, mask, bev_query_depth, pred_img_depth,

@@ -16,6 +16,7 @@
 #include "history_fused_kernels.h"
 #include "history_conv_x3_kernels.h"
 #include "rows_linear_kernels.h"
+#include "da_fused_kernels.h"
 #include "msda_bwd_kernels.h"
 #include "conv3d_kernels.h"
 #include "../../include/fbbev.h"
@@ -1248,6 +1249,75 @@ extern "C" int fbbev_da_cross_attn_fwd_zt(const float* value, const int64_t* spa
     return 0;
 }
 
+// ---- fbbev_da_cross_attn_fused: query rows -> slots in one kernel (da_fused_kernels.h)
+static bool da_fused_shape_ok(int B, int Ncam, int S, int M, int Dh, int L, int Q, int P, int Za, int bev_w) {
+    if (M != 8 || (Dh != 10 && Dh != 8) || P != FBBEV_DAF_P || Za != FBBEV_DAF_ZA || L < 1 || bev_w <= 0 || Q % bev_w != 0) return false;
+    if (fbbev_daf_lds_bytes(M * Dh, M, Ncam, L * P) > 160 * 1024) return false;
+    return (long long)S * Dh * 4 < (1ll << 31);                                      // 32-bit byte offsets inside a head plane
+}
+extern "C" int fbbev_da_cross_attn_fused_supported(int B, int Ncam, int S, int M, int Dh, int L, int Q, int P, int Za, int bev_w) {
+    if (B <= 0 || Ncam <= 0 || S <= 0 || M <= 0 || Dh <= 0 || L <= 0 || Q <= 0 || P <= 0 || Za <= 0) return 0;
+    static const bool off = [] { const char* e = getenv("FBBEV_DA_FUSED"); return e && atoi(e) == 0; }();   // A/B timing knob, read once
+    return (!off && da_fused_shape_ok(B, Ncam, S, M, Dh, L, Q, P, Za, bev_w)) ? 1 : 0;
+}
+extern "C" int fbbev_da_cross_attn_fused(const float* planes, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                         const float* pred_depth, const float* ref_cam, const uint8_t* mask, const float* qdepth,
+                                         const float* query, long long query_row_stride, const float* addend,
+                                         long long addend_row_stride, long long addend_period, const void* offsets_fragments,
+                                         const float* offsets_bias, const void* attn_fragments, const float* attn_bias, int B,
+                                         int Ncam, int S, int M, int Dh, int L, int Q, int P, int Za, int DC, float d0, float dstep,
+                                         int bev_w, int min_level_width, float* slots, fbbev_stream_t stream_) {
+    if (B <= 0 || Ncam <= 0 || S <= 0 || M <= 0 || Dh <= 0 || L <= 0 || Q < 0 || P <= 0 || Za <= 0 || DC <= 0 || bev_w < 0)
+        return FBBEV_E_BADARG;
+    if (Q == 0) return 0;
+    if (!planes || !spatial_shapes || !level_start_index || !pred_depth || !ref_cam || !mask || !qdepth || !query ||
+        !offsets_fragments || !offsets_bias || !attn_fragments || !attn_bias || !slots || dstep == 0.f) return FBBEV_E_BADARG;
+    const int E = M * Dh;
+    if (query_row_stride == 0) query_row_stride = E;
+    if (query_row_stride < E) return FBBEV_E_BADARG;
+    if (addend) {
+        if (addend_period <= 0) return FBBEV_E_BADARG;
+        if (addend_row_stride == 0) addend_row_stride = E;
+        if (addend_row_stride < E) return FBBEV_E_BADARG;
+    } else { addend_row_stride = 0; addend_period = 1; }
+    // min_level_width: the caller's host-side knowledge of the narrowest level (the x-corner runs are clamped into a row of at
+    // least two tokens); the shapes themselves stay on the device
+    if (!da_fused_shape_ok(B, Ncam, S, M, Dh, L, Q, P, Za, bev_w) || min_level_width < 2) return FBBEV_E_UNSUPPORTED;
+    if (query_row_stride % 4 != 0 || addend_row_stride % 4 != 0 || !aligned16(query) || (addend && !aligned16(addend)) ||
+        !aligned16(offsets_fragments) || !aligned16(attn_fragments) || ((uintptr_t)planes & 7) != 0 || ((uintptr_t)slots & 7) != 0)
+        return FBBEV_E_UNSUPPORTED;
+    const long long wgs = (long long)B * ((bev_w + 7) / 8) * ((Q / bev_w + 7) / 8);
+    const long long grid = (wgs + 7) / 8 * 8;
+    if (grid >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
+    const size_t lds = fbbev_daf_lds_bytes(E, M, Ncam, L * P);
+#define FBBEV_DA_FUSED(DH_)                                                                                            \
+    do {                                                                                                               \
+        int e = fbbev_rt_allow_dyn_lds((const void*)k_da_cross_attn_fused<DH_, 8>, lds);                              \
+        if (e) return e;                                                                                               \
+        FBBEV_LAUNCH((k_da_cross_attn_fused<DH_, 8>), grid, 512, lds, (fbbev_rt_stream)stream_, planes, spatial_shapes, \
+                     level_start_index, pred_depth, ref_cam, mask, qdepth, query, query_row_stride, addend,           \
+                     addend_row_stride, addend_period, static_cast<const unsigned short*>(offsets_fragments),         \
+                     offsets_bias, static_cast<const unsigned short*>(attn_fragments), attn_bias, B, Ncam, S, L, Q,    \
+                     bev_w, DC, d0, dstep, slots);                                                                     \
+    } while (0)
+    if (Dh == 10) FBBEV_DA_FUSED(10); else FBBEV_DA_FUSED(8);
+#undef FBBEV_DA_FUSED
+    FBBEV_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int fbbev_rows_to_head_planes(const float* rows, long long n_rows, int tokens_per_image, int M, int Dh, float* planes,
+                                         fbbev_stream_t stream_) {
+    if (n_rows < 0 || tokens_per_image <= 0 || M <= 0 || Dh <= 0) return FBBEV_E_BADARG;
+    if (n_rows == 0) return 0;
+    if (!rows || !planes || n_rows % tokens_per_image != 0) return FBBEV_E_BADARG;
+    const long long n = n_rows * M * Dh;
+    if ((n + 255) / 256 >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
+    FBBEV_LAUNCH(k_rows_to_head_planes, (n + 255) / 256, 256, 0, (fbbev_rt_stream)stream_, rows, n_rows, tokens_per_image, M, Dh, planes);
+    FBBEV_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int fbbev_da_cross_attn_bwd(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
                                        const float* pred_depth, const float* ref_cam, const uint8_t* mask,
                                        const float* qdepth, const float* offsets, const float* attn,
@@ -1924,7 +1994,8 @@ extern "C" int fbbev_rows_linear_x3_fragments(const float* weight, int in_featur
 
 static int rows_linear_x3_impl(const float* x, long long x_row_stride, const void* fragments, const float* bias, long long rows,
                                int in_features, int out_features, int relu, float* out, long long out_row_stride,
-                               const float* addend, long long addend_row_stride, long long addend_period, fbbev_stream_t stream_);
+                               const float* addend, long long addend_row_stride, long long addend_period, fbbev_stream_t stream_,
+                               int plane_S = 0, int plane_TS = 0);
 
 extern "C" int fbbev_rows_linear_x3(const float* x, long long x_row_stride, const void* fragments, const float* bias, long long rows,
                                     int in_features, int out_features, int relu, float* out, long long out_row_stride,
@@ -1947,7 +2018,8 @@ extern "C" int fbbev_rows_linear_x3_add(const float* x, long long x_row_stride, 
 
 static int rows_linear_x3_impl(const float* x, long long x_row_stride, const void* fragments, const float* bias, long long rows,
                                int in_features, int out_features, int relu, float* out, long long out_row_stride,
-                               const float* addend, long long addend_row_stride, long long addend_period, fbbev_stream_t stream_) {
+                               const float* addend, long long addend_row_stride, long long addend_period, fbbev_stream_t stream_,
+                               int plane_S, int plane_TS) {
     if (rows < 0 || in_features <= 0 || out_features <= 0) return FBBEV_E_BADARG;
     if (rows == 0) return 0;
     if (!x || !fragments || !out) return FBBEV_E_BADARG;
@@ -1972,9 +2044,21 @@ static int rows_linear_x3_impl(const float* x, long long x_row_stride, const voi
     const long long groups = (tiles + RT - 1) / RT;
     FBBEV_LAUNCH((k_rows_linear_x3<2>), groups * n_oc, 256, lds, (fbbev_rt_stream)stream_, x, x_row_stride,
                  static_cast<const unsigned short*>(fragments), bias, out, out_row_stride, rows, in_features, out_features, relu,
-                 n_kc, n_oc, (int)RT, addend, addend_row_stride, addend_period);
+                 n_kc, n_oc, (int)RT, addend, addend_row_stride, addend_period, plane_S, plane_TS);
     FBBEV_CHECK_LAUNCH();
     return 0;
+}
+
+// y = x W^T + b written as HEAD PLANES: rows = (B*Ncam) x S tokens, out_features = M * head_dim (module order (head, channel));
+// out (B*Ncam, M, S, head_dim) -- the camera-token layout of fbbev_da_cross_attn_fused (value_proj of the cross-attention).
+extern "C" int fbbev_rows_linear_x3_planes(const float* x, long long x_row_stride, const void* fragments, const float* bias,
+                                           long long rows, int in_features, int out_features, int tokens_per_image, int head_dim,
+                                           float* out, fbbev_stream_t stream_) {
+    if (tokens_per_image <= 0 || head_dim <= 0 || out_features <= 0) return FBBEV_E_BADARG;
+    if (head_dim % 2 != 0 || out_features % head_dim != 0 || rows % tokens_per_image != 0) return FBBEV_E_UNSUPPORTED;
+    if (out && ((uintptr_t)out & 7) != 0) return FBBEV_E_UNSUPPORTED;
+    return rows_linear_x3_impl(x, x_row_stride, fragments, bias, rows, in_features, out_features, 0, out, 0, nullptr, 0, 1, stream_,
+                               tokens_per_image, head_dim);
 }
 
 // Warp + new ring + both convolutions in ONE kernel (k_history_fused_bf16): history (B,T,N,C) -> next ring slots 1..T of

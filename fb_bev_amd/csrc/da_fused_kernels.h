@@ -1,0 +1,352 @@
+// da_fused_kernels.h -- depth-aware spatial cross-attention, inference, ONE kernel from the BEV query rows to the slots
+// (round 4; SURVEY 8b names it `fbbev_da_cross_attn_fused`).  Replaces k_rows_linear_x3 (sampling_offsets) + k_rows_linear_x3
+// (attention_weights) + the softmax + k_da_cross_attn_fwd_pipe, i.e. spatial_cross_attention_depth.py:533-595 and :136-223.
+//
+// What was wrong with the three-kernel form at BASELINE configs[2] (B = 4, 200 x 200 queries, 4 levels; profiles/r03_*):
+//   * the two projections wrote offsets (B,Q,8,4,8,2) + weights (B,Q,8,4,8) = 492 MB which the sampler read back: 0.26 ms of store
+//     streams + the re-read;
+//   * the sampler was bound by vector-L1 ACCESSES (456 M per launch, ~43 lines per load instruction): with token rows
+//     [token][chunk][head][4 floats] a (token, head) piece is 16 bytes inside a 384-byte row, so two lanes share a line only when
+//     they sample the SAME token.
+// What this kernel does instead:
+//   * HEAD-PLANE tokens: value_proj writes (B*Ncam, M, S, DH) -- the tokens of one head contiguous, DH floats each (40 bytes at
+//     DH = 10, no padding).  The two x-corners of a bilinear sample are ONE 2*DH-float run (5 sixteen-byte loads instead of 6
+//     scattered pieces), and lanes that sample neighbouring tokens of the same head share 128-byte lines;
+//   * a WAVE owns ONE head of an 8 x 8 patch of BEV queries (a workgroup = the M heads of the patch): all 64 lanes read the
+//     same head plane around the same image region -- tools/micro/plane_sampler.hip: 0.56 -> 0.34 ms per 41 M samples against
+//     the row layout (profiles/r04_exp_plane_sampler.jsonl);
+//   * the projections run INSIDE the workgroup on the bf16 MFMA with split operands (the arithmetic of k_rows_linear_x3:
+//     v = hi + lo, three MFMAs per product, ~1e-5 relative): the 64 query rows (+ positional rows) are split once into LDS
+//     fragments; each wave computes the logits of its head (L*P outputs -> softmax in LDS) and, level by level, the 2*P offsets
+//     of its head, straight into a wave-private LDS tile -- nothing per-query ever goes to HBM, and the weight fragments
+//     (2 x 123 KB in all, 6-12 KB per wave and step) stream from L2;
+//   * the camera hit test / reference points / depth weights are per (query, camera), not per head: computed ONCE per
+//     workgroup into LDS instead of once per head lane (8x fewer depth-plane samples).
+// Loop order: level outer (its offsets live in 16 registers), camera inner (uniform loop over the cameras some lane of the
+// wave hits), P samples per (level, camera) with two samples in flight per lane.  The reference sums per camera first
+// (levels, points), then over cameras; here one accumulator takes (level, camera, point) order: equal up to fp32
+// re-association (tests: <= 1e-4 against the oracle composite, observed ~1e-6).
+// Padded corners: their WEIGHT is zeroed and the run is clamped into the row (w * 0 of the reference becomes 0 * v: the same
+// +-0 contribution for finite tokens); an out-of-image or non-hit sample loads the level's first tokens with weight 0.
+// Preconditions (launcher): M <= 8 waves, E = M*DH, DH in {8, 10}, P == 8, Za == 4, every level at least 2 tokens wide,
+// Q = bev_h x bev_w, LDS budget (see fbbev_daf_lds_bytes).
+#pragma once
+#include "rt.h"
+#include "da_kernels.h"
+#include "rows_linear_kernels.h"
+
+#define FBBEV_DAF_QC 13          // floats of a (camera, query) record: rx[4] ry[4] dw[4] hit
+#define FBBEV_DAF_OS 20          // floats per query of a wave's offsets tile (16 used; 20 makes the 16-byte row reads conflict free)
+#define FBBEV_DAF_P 8            // sampling points per level
+#define FBBEV_DAF_ZA 4           // Z anchors per pillar
+
+// LDS carve-up (bytes): x fragments | (camera, query) records | per-wave attention rows | per-wave offset tiles
+__host__ __device__ inline size_t fbbev_daf_xf_bytes(int E) { return (size_t)4 * ((E + 31) / 32) * 2 * 64 * 16; }
+__host__ __device__ inline size_t fbbev_daf_lds_bytes(int E, int M, int Ncam, int LP) {
+    return fbbev_daf_xf_bytes(E) + (size_t)Ncam * 64 * FBBEV_DAF_QC * 4 + (size_t)M * 64 * (LP + 1) * 4 + (size_t)M * 64 * FBBEV_DAF_OS * 4;
+}
+
+template <int DH>
+struct fbbev_daf_pending {
+    static constexpr int NV = (2 * DH) / 4;
+    fbbev_v4f a[NV], b[NV];            // the two row runs: tokens (x, x+1) of rows y0 and y1
+    float w00, w01, w10, w11, weight;
+};
+
+// run `k` float of slot `slot` (0 / 1) of a run
+template <int DH>
+__device__ __forceinline__ fbbev_v2f fbbev_daf_pair(const fbbev_v4f (&r)[(2 * DH) / 4], int slot, int c) {
+    const int i = slot * DH + c;
+    fbbev_v2f v;
+    v[0] = r[i >> 2][i & 3]; v[1] = r[(i + 1) >> 2][(i + 1) & 3];
+    return v;
+}
+
+template <int DH>
+__device__ __forceinline__ void fbbev_daf_issue(const char* __restrict__ plane, int level_off /* floats */, float h_im, float w_im,
+                                                int sh, int sw, float weight, bool enable, fbbev_daf_pending<DH>& p) {
+    const bool live = enable && h_im > -1.f && w_im > -1.f && h_im < (float)sh && w_im < (float)sw;
+    const float h = live ? h_im : 0.f, w = live ? w_im : 0.f;
+    const int h_low = (int)floorf(h), w_low = (int)floorf(w);
+    const float lh = h - (float)h_low, lw = w - (float)w_low, hh = 1.f - lh, hw = 1.f - lw;
+    // x: the run covers tokens (xb, xb + 1), clamped into the row; at the left edge the only valid corner (x = 0, the HIGH
+    // corner) sits in slot 0, at the right edge (x = W - 1, the LOW corner) in slot 1
+    const bool left = w_low < 0, right = w_low >= sw - 1;
+    const int xb = left ? 0 : (right ? sw - 2 : w_low);
+    const float sx0 = left ? lw : (right ? 0.f : hw), sx1 = left ? 0.f : (right ? hw : lw);
+    // y: an invalid row reads the valid one again (the same lines) with weight 0
+    const bool top = h_low < 0, bottom = h_low >= sh - 1;
+    const int y0 = top ? 0 : h_low, y1 = bottom ? h_low : h_low + 1;
+    const float sy0 = top ? 0.f : hh, sy1 = bottom ? 0.f : lh;
+    p.w00 = sy0 * sx0; p.w01 = sy0 * sx1; p.w10 = sy1 * sx0; p.w11 = sy1 * sx1;
+    p.weight = live ? weight : 0.f;
+    const unsigned o0 = (unsigned)(level_off + (y0 * sw + xb) * DH) * 4u, o1 = (unsigned)(level_off + (y1 * sw + xb) * DH) * 4u;
+    constexpr int NV = (2 * DH) / 4;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {          // DH = 10: 8-byte aligned 16-byte loads (global memory takes dword-aligned b128)
+        fbbev_v4f t0, t1;
+        __builtin_memcpy(&t0, plane + o0 + 16 * k, 16);
+        __builtin_memcpy(&t1, plane + o1 + 16 * k, 16);
+        p.a[k] = t0; p.b[k] = t1;
+    }
+}
+
+template <int DH>
+__device__ __forceinline__ void fbbev_daf_consume(const fbbev_daf_pending<DH>& p, fbbev_v2f (&col)[DH / 2]) {
+#pragma unroll
+    for (int c = 0; c < DH; c += 2) {
+        const fbbev_v2f v00 = fbbev_daf_pair<DH>(p.a, 0, c), v01 = fbbev_daf_pair<DH>(p.a, 1, c);
+        const fbbev_v2f v10 = fbbev_daf_pair<DH>(p.b, 0, c), v11 = fbbev_daf_pair<DH>(p.b, 1, c);
+        col[c / 2] += (p.w00 * v00 + p.w01 * v01 + p.w10 * v10 + p.w11 * v11) * p.weight;
+    }
+#pragma unroll
+    for (int c = 0; c < DH / 2; ++c) fbbev_pin(col[c]);
+}
+
+// one 16-output tile of a split-operand projection of the workgroup's 64 query rows: acc[rt] (row tile rt = queries 16 rt ..
+// 16 rt + 15) = W[16 T .. 16 T + 15][:] . x^T, lane (g, j) holds outputs 16 T + 4 g + r (r = 0..3) of query 16 rt + j
+template <int KS>
+__device__ __forceinline__ void fbbev_daf_project(const unsigned short* __restrict__ wf, int T, const unsigned short* __restrict__ xf,
+                                                  int lane, fbbev_v4f (&acc)[4]) {
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) acc[rt] = fbbev_v4f{0.f, 0.f, 0.f, 0.f};
+    const unsigned short* wt = wf + (long long)T * FBBEV_RL_TILE_ELEMS;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const fbbev_bf16x8 ah = fbbev_ld_bf16x8(wt + (s * 64 + lane) * 8);
+        const fbbev_bf16x8 al = fbbev_ld_bf16x8(wt + FBBEV_RL_TILE_ELEMS / 2 + (s * 64 + lane) * 8);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+            const fbbev_bf16x8 xh = fbbev_ld_bf16x8(xf + (((rt * KS + s) * 2 + 0) * 64 + lane) * 8);
+            const fbbev_bf16x8 xl = fbbev_ld_bf16x8(xf + (((rt * KS + s) * 2 + 1) * 64 + lane) * 8);
+            acc[rt] = fbbev_mfma_f32_16x16x32_bf16(al, xh, acc[rt]);
+            acc[rt] = fbbev_mfma_f32_16x16x32_bf16(ah, xl, acc[rt]);
+            acc[rt] = fbbev_mfma_f32_16x16x32_bf16(ah, xh, acc[rt]);
+        }
+    }
+}
+
+// One bilinear sample of a (H, W >= 2) plane at normalised (x, y) as four CLAMPED corner offsets + weights: a padded corner keeps a
+// valid address and gets weight 0, a sample outside the image gets four zero weights (fbbev_plane_sample's value: the reference's
+// w * 0 for a padded corner becomes 0 * v), so the caller can issue all loads unconditionally.
+__device__ __forceinline__ void fbbev_daf_plane_corners(float x, float y, int H, int W, int (&off)[4], float (&wgt)[4]) {
+    const float h_im = y * H - 0.5f, w_im = x * W - 0.5f;
+    const bool live = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
+    const float h = live ? h_im : 0.f, w = live ? w_im : 0.f;
+    const int h_low = (int)floorf(h), w_low = (int)floorf(w);
+    const float lh = h - (float)h_low, lw = w - (float)w_low, hh = 1.f - lh, hw = 1.f - lw;
+    const bool left = w_low < 0, right = w_low >= W - 1, top = h_low < 0, bottom = h_low >= H - 1;
+    const int xa = left ? 0 : w_low, xb = right ? w_low : w_low + 1;       // (low, high) x corners, clamped
+    const int ya = top ? 0 : h_low, yb = bottom ? h_low : h_low + 1;
+    const float s = live ? 1.f : 0.f;
+    off[0] = ya * W + xa; off[1] = ya * W + xb; off[2] = yb * W + xa; off[3] = yb * W + xb;
+    wgt[0] = (top || left) ? 0.f : s * hh * hw; wgt[1] = (top || right) ? 0.f : s * hh * lw;
+    wgt[2] = (bottom || left) ? 0.f : s * lh * hw; wgt[3] = (bottom || right) ? 0.f : s * lh * lw;
+}
+
+// planes (B*Ncam, M, S, DH); pred_depth (B*Ncam, DC, H0, W0); ref_cam (Ncam,B,Q,Za,2); mask (Ncam,B,Q,Za) u8; qdepth (Ncam,B,Q,Za);
+// query (B*Q rows, ldq floats apart, E used) [+ addend rows: row (b*Q + q) % add_period]; so_frag / aw_frag: split bf16 fragments of
+// sampling_offsets.weight (M*L*P*2, E) / attention_weights.weight (M*L*P, E) in the order of k_rows_linear_x3_fragments, rows in
+// the MODULE's order ((m, l, p, xy) / (m, l, p)); so_bias / aw_bias fp32; slots (B, Q, M*DH).  blockDim = 64 * M.
+template <int DH, int MH>
+__global__ void __launch_bounds__(64 * MH)
+k_da_cross_attn_fused(const float* __restrict__ planes, const int64_t* __restrict__ spatial_shapes,
+                      const int64_t* __restrict__ level_start, const float* __restrict__ pred_depth,
+                      const float* __restrict__ ref_cam, const unsigned char* __restrict__ mask,
+                      const float* __restrict__ qdepth, const float* __restrict__ query, long long ldq,
+                      const float* __restrict__ addend, long long ld_add, long long add_period,
+                      const unsigned short* __restrict__ so_frag, const float* __restrict__ so_bias,
+                      const unsigned short* __restrict__ aw_frag, const float* __restrict__ aw_bias,
+                      int B, int Ncam, int S, int L, int Q, int bev_w, int DC, float d0, float dstep, float* __restrict__ slots) {
+    constexpr int E = MH * DH, KS = (E + 31) / 32, P = FBBEV_DAF_P, ZA = FBBEV_DAF_ZA, NT = 64 * MH;
+    static_assert((2 * DH) % 4 == 0 && DH % 2 == 0 && E % 8 == 0, "runs of whole 16-byte pieces, channel pairs");
+    const int LP = L * P, LDW = LP + 1;
+    unsigned char* lds = reinterpret_cast<unsigned char*>(fbbev_dyn_lds_f32());
+    unsigned short* xf = reinterpret_cast<unsigned short*>(lds);                            // [4][KS][hi|lo][64][8] bf16
+    float* qc = reinterpret_cast<float*>(lds + fbbev_daf_xf_bytes(E));                      // [Ncam][64][QC]
+    float* attn_all = qc + (size_t)Ncam * 64 * FBBEV_DAF_QC;                                // [MH][64][LP + 1]
+    float* off_all = attn_all + (size_t)MH * 64 * LDW;                                      // [MH][64][OS]
+    const int H0 = (int)spatial_shapes[0], W0 = (int)spatial_shapes[1];
+    const int bev_h = Q / bev_w;
+    const int pxn = (bev_w + 7) / 8, pyn = (bev_h + 7) / 8;
+    const long long n_wg = (long long)B * pxn * pyn, per_xcd = (n_wg + 7) / 8;
+    const long long wgid = (long long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);       // XCD-contiguous patch order
+    if (wgid >= n_wg) return;                                                               // uniform
+    const int b = (int)(wgid / ((long long)pxn * pyn)), pi = (int)(wgid - (long long)b * pxn * pyn);
+    const int py = pi / pxn, px = pi - py * pxn;
+    const int x0 = px * 8, y0 = py * 8;
+    // ---------------- phase A (whole workgroup): the patch's query rows as split MFMA fragments, its (camera, query) records
+    for (int i = threadIdx.x; i < 4 * KS * 64; i += NT) {
+        const int rt = i / (KS * 64), s = (i >> 6) % KS, ln = i & 63;
+        const int g = ln >> 4, j = ln & 15, ql = 16 * rt + j, c = 32 * s + 8 * g;
+        const int qy = y0 + (ql >> 3), qx = x0 + (ql & 7);
+        fbbev_v4f lo4 = {0.f, 0.f, 0.f, 0.f}, hi4 = {0.f, 0.f, 0.f, 0.f};
+        if (c < E && qy < bev_h && qx < bev_w) {
+            const long long row = (long long)b * Q + (long long)qy * bev_w + qx;
+            const float* src = query + row * ldq + c;
+            lo4 = *reinterpret_cast<const fbbev_v4f*>(src); hi4 = *reinterpret_cast<const fbbev_v4f*>(src + 4);
+            if (addend) {
+                const float* a = addend + (row % add_period) * ld_add + c;
+                lo4 = lo4 + *reinterpret_cast<const fbbev_v4f*>(a); hi4 = hi4 + *reinterpret_cast<const fbbev_v4f*>(a + 4);
+            }
+        }
+        fbbev_bf16x8 h8, l8;
+        fbbev_split_bf16x8(lo4, hi4, h8, l8);
+        __builtin_memcpy(xf + (((rt * KS + s) * 2 + 0) * 64 + ln) * 8, &h8, 16);
+        __builtin_memcpy(xf + (((rt * KS + s) * 2 + 1) * 64 + ln) * 8, &l8, 16);
+    }
+    for (int i = threadIdx.x; i < Ncam * 64; i += NT) {
+        // every load of a record is issued before any is used (a camera nobody hits costs the same few loads): out-of-grid
+        // lanes read query 0 of the sample, a non-hit record's depth weights are computed and never used
+        const int cam = i >> 6, ql = i & 63;
+        const int qy = y0 + (ql >> 3), qx = x0 + (ql & 7);
+        const bool inb = qy < bev_h && qx < bev_w;
+        float* rec = qc + (size_t)i * FBBEV_DAF_QC;
+        const long long base = (((long long)cam * B + b) * Q + (inb ? (long long)qy * bev_w + qx : 0)) * ZA;
+        unsigned int mask4;
+        __builtin_memcpy(&mask4, mask + base, 4);                                       // ZA = 4 mask bytes
+        const fbbev_v4f r01 = *reinterpret_cast<const fbbev_v4f*>(ref_cam + base * 2);  // (x0, y0, x1, y1)
+        const fbbev_v4f r23 = *reinterpret_cast<const fbbev_v4f*>(ref_cam + base * 2 + 4);
+        const fbbev_v4f qd = *reinterpret_cast<const fbbev_v4f*>(qdepth + base);
+        const long long bn = (long long)b * Ncam + cam;
+        float rx[ZA], ry[ZA], wgt[ZA][4], val[ZA][4];
+#pragma unroll
+        for (int z = 0; z < ZA; ++z) {
+            rx[z] = z < 2 ? r01[2 * z] : r23[2 * z - 4]; ry[z] = z < 2 ? r01[2 * z + 1] : r23[2 * z - 3];
+            float fb = floorf(__fdiv_rn(__fsub_rn(qd[z], d0), dstep));
+            fb = fminf(fmaxf(fb, 0.f), (float)(DC - 1));
+            const float* plane = pred_depth + (bn * DC + (int)fb) * (long long)(H0 * W0);
+            int off[4];
+            fbbev_daf_plane_corners(rx[z], ry[z], H0, W0, off, wgt[z]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) val[z][k] = plane[off[k]];
+        }
+#pragma unroll
+        for (int z = 0; z < ZA; ++z) {
+            rec[z] = rx[z]; rec[ZA + z] = ry[z];
+            rec[2 * ZA + z] = wgt[z][0] * val[z][0] + wgt[z][1] * val[z][1] + wgt[z][2] * val[z][2] + wgt[z][3] * val[z][3];
+        }
+        rec[3 * ZA] = (inb && mask4 != 0u) ? 1.f : 0.f;
+    }
+    __syncthreads();
+    // ---------------- phase B (per wave = head m, no workgroup barrier below)
+    const int m = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int g = lane >> 4, j = lane & 15;
+    float* attn_w = attn_all + (size_t)m * 64 * LDW;
+    float* off_w = off_all + (size_t)m * 64 * FBBEV_DAF_OS;
+    fbbev_v4f pacc[4];
+    // logits of head m: rows [m*LP, (m+1)*LP) of attention_weights -> + bias -> this wave's attention rows
+    {
+        const int o_lo = m * LP, o_hi = o_lo + LP;
+        for (int T = o_lo / 16; T * 16 < o_hi; ++T) {
+            fbbev_daf_project<KS>(aw_frag, T, xf, lane, pacc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = 16 * T + 4 * g + r;
+                if (o >= o_lo && o < o_hi) {
+                    const float bias = aw_bias[o];
+#pragma unroll
+                    for (int rt = 0; rt < 4; ++rt) attn_w[(16 * rt + j) * LDW + (o - o_lo)] = pacc[rt][r] + bias;
+                }
+            }
+        }
+    }
+    fbbev_wave_sync();
+    float* my_attn = attn_w + lane * LDW;
+    {   // softmax over the unit's L*P logits (spatial_cross_attention_depth.py:546-551): exp(x - max) / sum, as ATen's kernel
+        float mx = my_attn[0];
+        for (int i = 1; i < LP; ++i) mx = fmaxf(mx, my_attn[i]);
+        float sum = 0.f;
+        for (int i = 0; i < LP; ++i) { const float e = __expf(my_attn[i] - mx); my_attn[i] = e; sum += e; }
+        const float inv_sum = 1.f / sum;
+        for (int i = 0; i < LP; ++i) my_attn[i] *= inv_sum;
+    }
+    const int qy = y0 + (lane >> 3), qx = x0 + (lane & 7);
+    const bool valid = qy < bev_h && qx < bev_w;
+    const long long bq = (long long)b * Q + (long long)qy * bev_w + qx;
+    const float* my_qc = qc + (size_t)lane * FBBEV_DAF_QC;
+    int count = 0;
+    for (int cam = 0; cam < Ncam; ++cam) count += (fbbev_lds_ld_f32(my_qc + (size_t)cam * 64 * FBBEV_DAF_QC + 3 * ZA) != 0.f) ? 1 : 0;
+    fbbev_v2f acc[DH / 2];
+#pragma unroll
+    for (int c = 0; c < DH / 2; ++c) { acc[c][0] = 0.f; acc[c][1] = 0.f; }
+    const char* pb = reinterpret_cast<const char*>(planes);
+    for (int l = 0; l < L; ++l) {
+        // the 2*P offsets of (head m, level l): rows ((m*L + l)*P + p)*2 + xy of sampling_offsets = ONE 16-output tile
+        const int T = m * L + l;
+        fbbev_daf_project<KS>(so_frag, T, xf, lane, pacc);
+        {
+            fbbev_v4f bias4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bias4[r] = so_bias[16 * T + 4 * g + r];
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+                const fbbev_v4f v = pacc[rt] + bias4;
+                __builtin_memcpy(off_w + (16 * rt + j) * FBBEV_DAF_OS + 4 * g, &v, 16);
+            }
+        }
+        fbbev_wave_sync();
+        fbbev_v4f o4[4];                         // this lane's offsets: o4[p / 2] = (x_p, y_p, x_{p+1}, y_{p+1})
+#pragma unroll
+        for (int k = 0; k < 4; ++k) __builtin_memcpy(&o4[k], off_w + lane * FBBEV_DAF_OS + 4 * k, 16);
+        fbbev_wave_sync();                       // every lane holds its offsets before the tile is overwritten
+        const int sh = (int)spatial_shapes[2 * l], sw = (int)spatial_shapes[2 * l + 1];
+        const float fsh = (float)sh, fsw = (float)sw;
+        const int lvl_off = (int)level_start[l] * DH;
+        for (int cam = 0; cam < Ncam; ++cam) {
+            const float* rec = my_qc + (size_t)cam * 64 * FBBEV_DAF_QC;
+            const bool hit = valid && fbbev_lds_ld_f32(rec + 3 * ZA) != 0.f;
+            if (__ballot(hit) == 0ull) continue;                                           // uniform: nobody in the wave hits
+            float rx[ZA], ry[ZA], dw[ZA];
+#pragma unroll
+            for (int z = 0; z < ZA; ++z) {
+                rx[z] = fbbev_lds_ld_f32(rec + z); ry[z] = fbbev_lds_ld_f32(rec + ZA + z); dw[z] = fbbev_lds_ld_f32(rec + 2 * ZA + z);
+            }
+            const char* plane = pb + (((long long)b * Ncam + cam) * MH + m) * (long long)S * DH * 4;   // wave-uniform base
+            fbbev_daf_pending<DH> pa, pq;
+            auto start = [&](int p, fbbev_daf_pending<DH>& slot) {
+                const int z = p % ZA;
+                const float ox = o4[p >> 1][2 * (p & 1)], oy = o4[p >> 1][2 * (p & 1) + 1];
+                const float loc_w = rx[z] + __fdiv_rn(ox, fsw), loc_h = ry[z] + __fdiv_rn(oy, fsh);
+                const float weight = fbbev_lds_ld_f32(my_attn + l * P + p) * dw[z];
+                fbbev_daf_issue<DH>(plane, lvl_off, loc_h * fsh - 0.5f, loc_w * fsw - 0.5f, sh, sw, weight, hit, slot);
+            };
+            start(0, pa);
+#pragma unroll
+            for (int p = 0; p < P; p += 2) {
+                start(p + 1, pq);
+                fbbev_sched_fence();
+                fbbev_daf_consume<DH>(pa, acc);
+                fbbev_sched_fence();
+                if (p + 2 < P) start(p + 2, pa);
+                fbbev_sched_fence();
+                fbbev_daf_consume<DH>(pq, acc);
+                fbbev_sched_fence();
+            }
+        }
+    }
+    if (!valid) return;
+    const float inv = (float)(count > 1 ? count : 1);
+    float* dst = slots + bq * E + m * DH;
+#pragma unroll
+    for (int c = 0; c < DH / 2; ++c) {
+        fbbev_v2f r;
+        r[0] = acc[c][0] / inv; r[1] = acc[c][1] / inv;
+        *reinterpret_cast<fbbev_v2f*>(dst + 2 * c) = r;
+    }
+}
+
+// value_proj rows (B*Ncam*S, M*DH) -> head planes (B*Ncam, M, S, DH): standalone re-layout for callers that hold row-major
+// tokens (tests; the product's projection writes planes directly, k_rows_linear_x3 `plane_S`)
+__global__ void __launch_bounds__(256)
+k_rows_to_head_planes(const float* __restrict__ rows, long long n_rows, int S, int M, int DH, float* __restrict__ planes) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long n = n_rows * M * DH;
+    if (i >= n) return;
+    const int c = (int)(i % DH);
+    const long long t = i / DH;
+    const int m = (int)(t % M);
+    const long long r = t / M;
+    const long long bn = r / S, tok = r - bn * S;
+    planes[((bn * M + m) * S + tok) * DH + c] = rows[i];
+}

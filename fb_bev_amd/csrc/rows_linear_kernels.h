@@ -24,7 +24,7 @@ template <int NT>
 __global__ void __launch_bounds__(256)
 k_rows_linear_x3(const float* __restrict__ x, long long ldx, const unsigned short* __restrict__ wf, const float* __restrict__ bias,
                  float* __restrict__ out, long long ldo, long long rows, int I, int O, int relu, int n_kc, int n_oc, int RT,
-                 const float* __restrict__ addend, long long ld_add, long long add_period) {
+                 const float* __restrict__ addend, long long ld_add, long long add_period, int plane_S, int plane_TS) {
     unsigned short* wl = reinterpret_cast<unsigned short*>(fbbev_dyn_lds_f32());          // [nmt][FBBEV_RL_TILE_ELEMS]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int g = lane >> 4, j = lane & 15;
@@ -111,6 +111,21 @@ k_rows_linear_x3(const float* __restrict__ x, long long ldx, const unsigned shor
                 fbbev_v4f v = acc[mt][t];
                 if (bias) v = v + *reinterpret_cast<const fbbev_v4f*>(bias + o);
                 if (relu) v = fbbev_v4f{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+                if (plane_S > 0) {
+                    // head-plane output (da_fused_kernels.h): rows are (sample-camera bn, token) pairs, outputs (head, channel);
+                    // element (r, o) goes to out[((bn * M + o / TS) * S + token) * TS + o % TS], M = O / TS.  TS is even, so a
+                    // channel pair never straddles two heads: two 8-byte stores
+                    const long long bn = r / plane_S, tok = r - bn * plane_S;
+                    const int Mh = O / plane_TS;
+#pragma unroll
+                    for (int e = 0; e < 4; e += 2) {
+                        const int hd = (o + e) / plane_TS, ch = (o + e) - hd * plane_TS;
+                        fbbev_v2f pr;
+                        pr[0] = v[e]; pr[1] = v[e + 1];
+                        *reinterpret_cast<fbbev_v2f*>(out + ((bn * Mh + hd) * plane_S + tok) * plane_TS + ch) = pr;
+                    }
+                    continue;
+                }
                 *reinterpret_cast<fbbev_v4f*>(out + r * ldo + o) = v;
             }
         }

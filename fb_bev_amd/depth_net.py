@@ -62,7 +62,11 @@ class ASPP(nn.Module):
 
     def forward(self, x):
         branches = [self.aspp1(x), self.aspp2(x), self.aspp3(x), self.aspp4(x)]
-        pooled = F.interpolate(self.global_avg_pool(x), size=x.shape[2:], mode='bilinear', align_corners=True)
+        # depth_net.py:167-168: F.interpolate(1x1 -> HxW, bilinear, align_corners=True).  With a 1x1 source every output pixel has
+        # source index 0 and interpolation weight (1, 0): the value itself, bit for bit -- a broadcast.  ATen's generic
+        # upsample kernel took 2.0 ms of the 5.2 ms bf16 depth net at B = 4 x 6 images (38 % of its GPU time,
+        # profiles/r04_pmc_mfma.json); its backward is the same sum over pixels that expand's backward is.
+        pooled = self.global_avg_pool(x).expand(-1, -1, x.shape[2], x.shape[3])
         return self.dropout(self.relu(self.bn1(self.conv1(torch.cat(branches + [pooled], dim=1)))))
 
 

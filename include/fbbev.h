@@ -375,6 +375,32 @@ int fbbev_da_cross_attn_fwd_zt(const float* value, const int64_t* spatial_shapes
  * queries of a row: neighbours in both BEV directions sample nearly the same camera tokens for a given head, so a load
  * instruction touches fewer distinct cache lines.  Layouts and results (bit for bit) do not depend on it. */
 
+/* The whole inference cross-attention sampling in ONE kernel, from the BEV query rows to the slots (SURVEY 8b:
+ * `fbbev_da_cross_attn_fused`; replaces spatial_cross_attention_depth.py:533-595 + :136-223, i.e. the sampling_offsets and
+ * attention_weights Linears, the softmax, both MSDA launches, the rebatch / scatter loops).  Differences to
+ * fbbev_da_cross_attn_fwd_zt:
+ *   - `planes`: camera tokens (the value_proj output) as HEAD PLANES, (B*Ncam, M, S, Dh) fp32, no padding -- written by
+ *     fbbev_rows_linear_x3_planes (or fbbev_rows_to_head_planes from row-major tokens);
+ *   - no offsets / attn tensors: `query` (B*Q rows of E = M*Dh floats, query_row_stride apart) [+ `addend` rows with period
+ *     addend_period: the positional encoding] is projected inside the kernel with the split-operand bf16 MFMA arithmetic of
+ *     fbbev_rows_linear_x3 (~1e-5 relative) from `offsets_fragments` / `attn_fragments` = fbbev_rows_linear_x3_fragments of
+ *     sampling_offsets.weight (M*L*P*2, E) / attention_weights.weight (M*L*P, E) in the MODULE's row order, + fp32 biases;
+ *   - a workgroup = the M heads of an 8 x 8 patch of the BEV grid (Q = bev_h x bev_w, bev_w required), a wave = one head.
+ * Supported: M = 8, Dh in {8, 10}, P = 8, Za = 4, every level >= 2 tokens wide (`min_level_width`: the caller's host-side
+ * value), LDS budget (fbbev_da_cross_attn_fused_supported); FBBEV_E_UNSUPPORTED otherwise.  Result: the reference's sum in
+ * (level, camera, point) order -- equal to fbbev_da_cross_attn_fwd up to fp32 re-association and the projection arithmetic. */
+int fbbev_da_cross_attn_fused_supported(int B, int Ncam, int S, int M, int Dh, int L, int Q, int P, int Za, int bev_w);
+int fbbev_da_cross_attn_fused(const float* planes, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                              const float* pred_depth, const float* ref_cam, const uint8_t* mask, const float* qdepth,
+                              const float* query, long long query_row_stride, const float* addend,
+                              long long addend_row_stride, long long addend_period, const void* offsets_fragments,
+                              const float* offsets_bias, const void* attn_fragments, const float* attn_bias, int B,
+                              int Ncam, int S, int M, int Dh, int L, int Q, int P, int Za, int DC, float d0, float dstep,
+                              int bev_w, int min_level_width, float* slots, fbbev_stream_t stream);
+/* row-major camera tokens (n_rows = B*Ncam*S rows of M*Dh floats, module order (head, channel)) -> head planes (B*Ncam, M, S, Dh) */
+int fbbev_rows_to_head_planes(const float* rows, long long n_rows, int tokens_per_image, int M, int Dh, float* planes,
+                              fbbev_stream_t stream);
+
 /* Backward of fbbev_da_cross_attn_fwd in one launch -- replaces the autograd chain of the reference's training step
  * through DA_SpatialCrossAttention / DA_MSDeformableAttention (two MultiScaleDeformableAttnFunction backward launches,
  * multi_scale_deformable_attn_function.py:137-172, plus the rebatch / one-hot / scatter index ops and their host syncs).
@@ -493,6 +519,12 @@ int fbbev_rows_linear_x3(const float* x, long long x_row_stride, const void* fra
 int fbbev_rows_linear_x3_add(const float* x, long long x_row_stride, const float* addend, long long addend_row_stride,
                              long long addend_period, const void* fragments, const float* bias, long long rows, int in_features,
                              int out_features, int relu, float* out, long long out_row_stride, fbbev_stream_t stream);
+/* fbbev_rows_linear_x3 with the result written as HEAD PLANES: rows = (B*Ncam) x tokens_per_image camera tokens, out_features =
+ * M * head_dim in the module's (head, channel) order, out (B*Ncam, M, tokens_per_image, head_dim) -- the value_proj of the
+ * cross-attention feeding fbbev_da_cross_attn_fused (spatial_cross_attention_depth.py:522-530). */
+int fbbev_rows_linear_x3_planes(const float* x, long long x_row_stride, const void* fragments, const float* bias,
+                                long long rows, int in_features, int out_features, int tokens_per_image, int head_dim,
+                                float* out, fbbev_stream_t stream);
 
 /* The two 1x1x1 convolutions of the temporal fusion in one fp32-MFMA kernel (inference): replaces
  * history_keyframe_time_conv + history_keyframe_cat_conv of FBOCC.fuse_history (fbocc.py:111-127, 289-310) once the

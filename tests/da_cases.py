@@ -3,7 +3,7 @@ and the GPU bound test of the fused backward (tests/test_gpu_backward_projection
 import torch
 
 
-def da_case(seed=0, B=2, N=6, Q=70, Za=4, E=16, M=4, shapes=((5, 7), (3, 4)), P=8, DC=12, grad=False):
+def da_case(seed=0, B=2, N=6, Q=70, Za=4, E=16, M=4, shapes=((5, 7), (3, 4)), P=8, DC=12, grad=False, extras=False):
     """Random DA cross-attention case + the oracle's composite result (slots before output_proj)."""
     from oracle import backward_projection_oracle as BO
     g = torch.Generator().manual_seed(seed)
@@ -45,4 +45,6 @@ def da_case(seed=0, B=2, N=6, Q=70, Za=4, E=16, M=4, shapes=((5, 7), (3, 4)), P=
             qdepth.squeeze(-1).contiguous(), offsets, attn, dbound[0], dbound[2])
     if grad:
         return args, exp, dict(Pm=Pm, key=key, pred=pred)
+    if extras:      # what the one-kernel entry (fbbev_da_cross_attn_fused) consumes instead of offsets / attn
+        return args, exp, dict(Pm=Pm, query=query, qpos=qpos, key=key)
     return args, exp

@@ -279,6 +279,50 @@ def rows_linear_x3(x, weight, bias, relu=False, out=None, addend=None):
     return code, out
 
 
+def _fragments(weight):
+    O, I = weight.shape
+    need = lib().fbbev_rows_linear_x3_fragment_bytes(I, O)
+    frag = torch.zeros(need + 16, dtype=torch.uint8)
+    off = (-frag.data_ptr()) % 16
+    fp = c_void_p(frag.data_ptr() + off)
+    ok(lib().fbbev_rows_linear_x3_fragments(p(weight), I, O, fp, need, None))
+    return frag, fp
+
+
+def rows_linear_x3_planes(x, weight, bias, tokens_per_image, heads, head_dim):
+    frag, fp = _fragments(weight)
+    R, I = x.shape
+    out = torch.full((R // tokens_per_image, heads, tokens_per_image, head_dim), float('nan'))
+    code = lib().fbbev_rows_linear_x3_planes(c_void_p(x.data_ptr()), x.stride(0), fp, p(bias) if bias is not None else None, R, I,
+                                             heads * head_dim, tokens_per_image, head_dim, p(out), None)
+    return code, out
+
+
+def rows_to_head_planes(rows, tokens_per_image, heads, head_dim):
+    R = rows.shape[0]
+    out = torch.full((R // tokens_per_image, heads, tokens_per_image, head_dim), float('nan'))
+    ok(lib().fbbev_rows_to_head_planes(p(rows), R, tokens_per_image, heads, head_dim, p(out), None))
+    return out
+
+
+def da_cross_attn_fused(planes, ss, ls, pred_depth, ref_cam, mask, qdepth, query, addend, w_so, b_so, w_aw, b_aw, P, d0, dstep, bev_w,
+                        min_level_width=None):
+    Ncam, B, Q, Za = mask.shape
+    BN, M, S, Dh = planes.shape
+    L = ss.shape[0]
+    f_so, p_so = _fragments(w_so)
+    f_aw, p_aw = _fragments(w_aw)
+    slots = torch.full((B, Q, M * Dh), float('nan'))
+    m8 = mask.to(torch.uint8).contiguous()
+    if min_level_width is None:
+        min_level_width = int(ss[:, 1].min())
+    a = (c_void_p(addend.data_ptr()), addend.stride(0), addend.shape[0]) if addend is not None else (None, 0, 1)
+    code = lib().fbbev_da_cross_attn_fused(p(planes), p(ss), p(ls), p(pred_depth), p(ref_cam), p(m8), p(qdepth), p(query),
+                                           query.stride(1), *a, p_so, p(b_so), p_aw, p(b_aw), B, Ncam, S, M, Dh, L, Q, P, Za,
+                                           pred_depth.shape[1], d0, dstep, bev_w, min_level_width, p(slots), None)
+    return code, slots
+
+
 def layernorm_bwd(x, grad_out, weight, eps):
     C = x.shape[-1]
     rows = x.numel() // C

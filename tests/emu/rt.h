@@ -261,4 +261,5 @@ inline void fbbev_pin(fbbev_v2f&) {}
 inline void fbbev_opaque(int&) {}
 inline void fbbev_opaque(float&) {}
 inline float fbbev_lds_ld_f32(const float* p) { return *p; }
+inline int __builtin_amdgcn_readfirstlane(int v) { return v; }    // wave-uniform by construction where the kernels use it
 inline int fbbev_lds_ld_i32(const int* p) { return *p; }

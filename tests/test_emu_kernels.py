@@ -1264,3 +1264,68 @@ def test_history_warp_lds_staged_equals_gather_kernel_emulated(dt, monkeypatch):
     E.history_warp(hist, flow, big[:, 3:])
     assert torch.equal(big[:, 3:].contiguous().view(torch.int16 if dt == torch.float16 else torch.int32),
                        ref.view(torch.int16 if dt == torch.float16 else torch.int32)) and torch.isnan(big[:, :3].float()).all()
+
+
+def test_fused_da_cross_attention_emulated():
+    """fbbev_da_cross_attn_fused -> k_da_cross_attn_fused (round 4): query rows -> slots in one kernel -- the sampling_offsets /
+    attention_weights projections on the split-operand bf16 MFMA inside the workgroup, softmax in LDS, head-plane camera tokens,
+    a wave = one head of an 8 x 8 patch of BEV queries -- against the oracle's composite (spatial_cross_attention_depth.py:136-223,
+    513-595) and against the unit kernel fed with fp32 projections.  Grids that are / are not multiples of the patch, 1 / 2 / 4
+    levels, a level only two tokens wide, with and without the positional addend; fbbev_rows_linear_x3_planes writes the same
+    planes as the row-major projection re-laid out; unsupported shapes are refused."""
+    cases = ((21, dict(B=1, Q=8 * 8, shapes=((6, 9),)), 8),                                  # one full patch, one level
+             (22, dict(B=2, Q=5 * 11, shapes=((16, 44), (8, 22))), 11),                       # partial patches in x and y
+             (23, dict(B=1, Q=9 * 8, shapes=((5, 7), (9, 6), (3, 4), (2, 2))), 8))            # 4 levels (LP = 32), a 2-wide level
+    for seed, kw, bev_w in cases:
+        args, exp, ex = _da_case(seed, E=80, M=8, P=8, DC=20, extras=True, **kw)
+        value, ss, ls, pred, ref_cam, mask, qdepth, offsets, attn, d0, dstep = args
+        BN, S_, M, Dh = value.shape
+        Pm = ex['Pm']
+        pre = 'a.deformable_attention.'
+        planes = E.rows_to_head_planes(value.reshape(BN * S_, M * Dh).contiguous(), S_, M, Dh)
+        assert torch.equal(planes, value.permute(0, 2, 1, 3))
+        # value_proj straight into planes (split-operand arithmetic: ~1e-5 relative)
+        key = ex['key']                                                               # (N, S, B, E)
+        x = key.permute(2, 0, 1, 3).reshape(BN * S_, M * Dh).contiguous()
+        code, vp = E.rows_linear_x3_planes(x, Pm[pre + 'value_proj.weight'].contiguous(), Pm[pre + 'value_proj.bias'].contiguous(), S_, M, Dh)
+        assert code == 0 and not torch.isnan(vp).any()
+        assert torch.allclose(vp, planes, atol=2e-5 * planes.abs().max().item(), rtol=0)
+        unit = E.da_cross_attn_fwd(*args)                                             # fp32 projections, unit kernel
+        for with_pos in (True, False):
+            q = (ex['query'] if with_pos else ex['query'] + ex['qpos']).contiguous()
+            B, Q = q.shape[:2]
+            add = None
+            if with_pos:      # per-row addend (period B*Q): the general form; a (Q, E) table repeats with period Q
+                add = ex['qpos'].reshape(B * Q, -1).contiguous()
+            code, slots = E.da_cross_attn_fused(planes, ss, ls, pred, ref_cam, mask, qdepth, q, add,
+                                                Pm[pre + 'sampling_offsets.weight'].contiguous(), Pm[pre + 'sampling_offsets.bias'].contiguous(),
+                                                Pm[pre + 'attention_weights.weight'].contiguous(), Pm[pre + 'attention_weights.bias'].contiguous(),
+                                                8, d0, dstep, bev_w)
+            assert code == 0, code
+            assert not torch.isnan(slots).any(), seed
+            scale = exp.abs().max().item()
+            assert (slots - exp).abs().max().item() <= 1e-4 * max(scale, 1.0), (seed, with_pos, (slots - exp).abs().max().item(), scale)
+            assert (slots - unit).abs().max().item() <= 1e-4 * max(scale, 1.0), (seed, (slots - unit).abs().max().item())
+    # a (Q, E) positional table shared by the samples: period Q
+    args, exp, ex = _da_case(24, B=2, Q=4 * 8, E=80, M=8, P=8, DC=20, shapes=((6, 9),), extras=True)
+    value, ss, ls, pred, ref_cam, mask, qdepth, offsets, attn, d0, dstep = args
+    Pm, pre = ex['Pm'], 'a.deformable_attention.'
+    planes = value.permute(0, 2, 1, 3).contiguous()
+    table = ex['qpos'][0].contiguous()                                                 # one table for both samples
+    q2 = (ex['query'] + ex['qpos'] - table[None]).contiguous()                        # q2 + table == query + qpos
+    code, slots = E.da_cross_attn_fused(planes, ss, ls, pred, ref_cam, mask, qdepth, q2, table,
+                                        Pm[pre + 'sampling_offsets.weight'].contiguous(), Pm[pre + 'sampling_offsets.bias'].contiguous(),
+                                        Pm[pre + 'attention_weights.weight'].contiguous(), Pm[pre + 'attention_weights.bias'].contiguous(),
+                                        8, d0, dstep, 8)
+    assert code == 0 and (slots - exp).abs().max().item() <= 1e-4 * max(exp.abs().max().item(), 1.0)
+    # refused: a 1-token-wide level, P != 8
+    code, _ = E.da_cross_attn_fused(planes, ss, ls, pred, ref_cam, mask, qdepth, q2, table,
+                                    Pm[pre + 'sampling_offsets.weight'].contiguous(), Pm[pre + 'sampling_offsets.bias'].contiguous(),
+                                    Pm[pre + 'attention_weights.weight'].contiguous(), Pm[pre + 'attention_weights.bias'].contiguous(),
+                                    8, d0, dstep, 8, min_level_width=1)
+    assert code == -3 or code < 0
+    code, _ = E.da_cross_attn_fused(planes, ss, ls, pred, ref_cam, mask, qdepth, q2, table,
+                                    Pm[pre + 'sampling_offsets.weight'].contiguous(), Pm[pre + 'sampling_offsets.bias'].contiguous(),
+                                    Pm[pre + 'attention_weights.weight'].contiguous(), Pm[pre + 'attention_weights.bias'].contiguous(),
+                                    4, d0, dstep, 8)
+    assert code < 0

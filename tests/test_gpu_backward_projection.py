@@ -10,8 +10,12 @@ import torch
 
 pytestmark = pytest.mark.gpu
 # full-size BackwardProjection test: the bars (set from the observed values, see the test)
-BP_FULL_BAD_QUERIES = 12
-BP_FULL_FRAC_1E4 = 1e-3
+# observed on an MI355X (profiles/r04_gpu_tests_observed.txt): 0 of 40 000 queries beyond 1e-3, max|err| 7.5e-5 among the rest, no
+# element beyond 1e-4, median 4.4e-6 at an output scale of 4.8.  Bars = 2x observed; the query allowance stays above zero because
+# an in-image mask bit that flips between the CPU and GPU op orders is a property of the rig, not of the kernels.
+BP_FULL_BAD_QUERIES = 4
+BP_FULL_MAX_ERR = 1.5e-4
+BP_FULL_FRAC_1E4 = 1e-5
 sys.path.insert(0, os.path.dirname(__file__))
 
 
@@ -93,6 +97,42 @@ def test_default_pipelined_da_kernel_vs_oracle_composite(dev, case):
     assert torch.isfinite(slots).all() and not torch.equal(slots, results['patch'])
 
 
+@pytest.mark.parametrize('case', ['shipped', 'bl3_pyramid', 'partial_patches'])
+def test_one_kernel_da_cross_attention_vs_oracle_composite(dev, case):
+    """fbbev_da_cross_attn_fused (round 4, the inference default): query rows -> slots in one kernel -- in-kernel sampling_offsets /
+    attention_weights projections (split-operand bf16 MFMA), softmax in LDS, head-plane camera tokens written by
+    fbbev_rows_linear_x3_planes -- called as DA_SpatialCrossAttention._slots_one_kernel calls it, at the shipped shape
+    (Q = 100 x 100, one 16x44 level, 80 bins), the BASELINE configs[2] pyramid and a grid that is no multiple of the 8 x 8 patch:
+    <= 1e-4 of the output scale against the oracle's composite (spatial_cross_attention_depth.py:136-223, 513-595)."""
+    from da_cases import da_case
+    from fb_bev_amd import _capi
+    kw, bev_w = dict(shipped=(dict(B=2, Q=10000, shapes=((16, 44),), DC=80), 100),
+                     bl3_pyramid=(dict(B=1, Q=10000, shapes=((32, 88), (16, 44), (8, 22), (4, 11)), DC=59), 100),
+                     partial_patches=(dict(B=2, Q=37 * 21, shapes=((16, 44), (8, 22)), DC=30), 21))[case]
+    args, exp, ex = da_case(12, E=80, M=8, P=8, extras=True, **kw)
+    value, ss, ls, pred, ref_cam, mask, qdepth, offsets, attn, d0, dstep = args
+    BN, S_, M, Dh = value.shape
+    Pm, pre = ex['Pm'], 'a.deformable_attention.'
+    g = lambda t: t.to(dev).contiguous()  # noqa: E731
+    assert _capi.da_cross_attn_fused_supported(ex['query'].shape[0], 6, S_, M, Dh, len(kw['shapes']), kw['Q'], 8, 4, bev_w)
+    frag = {n: _capi.rows_linear_x3_fragments(g(Pm[pre + n + '.weight'])) for n in ('value_proj', 'sampling_offsets', 'attention_weights')}
+    x = g(ex['key'].permute(2, 0, 1, 3).reshape(BN * S_, M * Dh))
+    planes = _capi.rows_linear_x3_planes(x, frag['value_proj'], g(Pm[pre + 'value_proj.bias']), S_, M, Dh)
+    exact = _capi.rows_to_head_planes(g(value.reshape(BN * S_, M * Dh)), S_, M, Dh)
+    assert torch.equal(exact.cpu(), value.permute(0, 2, 1, 3))
+    assert (planes - exact).abs().max().item() <= 2e-5 * exact.abs().max().item()         # split-operand arithmetic
+    scale = max(exp.abs().max().item(), 1.0)
+    for tag, q, add in (('table', ex['query'], ex['qpos'].reshape(-1, M * Dh)), ('no addend', ex['query'] + ex['qpos'], None)):
+        slots = torch.full(exp.shape, float('nan'), device=dev)
+        _capi.da_cross_attn_fused(planes, g(ss), g(ls), g(pred), g(ref_cam), g(mask), g(qdepth), g(q), None if add is None else g(add),
+                                  frag['sampling_offsets'], g(Pm[pre + 'sampling_offsets.bias']), frag['attention_weights'],
+                                  g(Pm[pre + 'attention_weights.bias']), 8, d0, dstep, bev_w, min(w for _, w in kw['shapes']), slots)
+        assert not torch.isnan(slots).any(), tag
+        err = (slots.cpu() - exp).abs().max().item()
+        print(f'one-kernel DA [{case} / {tag}]: max|err| vs oracle composite = {err:.3e} (output scale {scale:.2f})')
+        assert err <= 1e-4 * scale, (tag, err)
+
+
 def _setup(dev, B=2, num_levels=1, bev=20, seed=0, shapes=None):
     from fb_bev_amd import backward_projection as BP, configs, synthetic as S
     gcb = {'x': [-40, 40, 80.0 / bev], 'y': [-40, 40, 80.0 / bev], 'z': [-1, 5.4, 1.6]}
@@ -144,8 +184,8 @@ def test_backward_projection_module_vs_oracle_at_baseline_config2_full_size(dev)
     """VERDICT r2 (untested sizes): BASELINE configs[2] through the MODULE at its full size -- bev 200x200 (Q = 40 000), the
     4-level pyramid 16x44 / 32x88 / 8x22 / 4x11 (level 0 = the depth net's level, spatial_cross_attention_depth.py:586),
     B = 1 -- against oracle/backward_projection_oracle.py (backward_projection.py:84-133, bevformer_encoder.py:250-377).
-    Same bar as the 20x20 test: <= 1e-4-scale agreement, a handful of queries whose borderline in-image mask bit flips
-    between the CPU and GPU fp32 op orders (here out of 40 000 instead of 400)."""
+    Bar: <= 1.5e-4 absolute on every element (output scale 4.8; observed 7.5e-5) except at most 4 queries whose borderline
+    in-image mask bit flips between the CPU and GPU fp32 op orders (observed: none of 40 000); the statistics are printed."""
     bev = 200
     shapes = [(16, 44), (32, 88), (8, 22), (4, 11)]
     m, cfg, cam, feats, depth, lss, gcb = _setup(dev, B=1, num_levels=4, bev=bev, shapes=shapes)
@@ -163,8 +203,8 @@ def test_backward_projection_module_vs_oracle_at_baseline_config2_full_size(dev)
           f'output scale = {exp.abs().max().item():.3f}')
     # the bars are 2x what this test printed on an MI355X (profiles/r04_gpu_tests_observed.txt), not round numbers
     assert bad <= BP_FULL_BAD_QUERIES, bad
-    assert err[ok].max().item() <= 1e-3 and err.median().item() < 1e-5
-    assert frac4 < BP_FULL_FRAC_1E4, frac4
+    assert err[ok].max().item() <= BP_FULL_MAX_ERR and err.median().item() < 1e-5
+    assert frac4 <= BP_FULL_FRAC_1E4, frac4
 
 
 @pytest.mark.parametrize('train_fused', [True, False])
