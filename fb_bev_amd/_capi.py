@@ -60,6 +60,9 @@ SIGNATURES = {
     'fbbev_da_cross_attn_fused': (c_int, [c_void_p] * 8 + [c_int64, c_void_p, c_int64, c_int64] + [c_void_p] * 4 + [c_int] * 10 +
                                   [c_float, c_float, c_int, c_int, c_void_p, c_void_p]),
     'fbbev_rows_to_head_planes': (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'fbbev_msda_self_fused_supported': (c_int, [c_int] * 8),
+    'fbbev_msda_self_fused': (c_int, [c_void_p] * 3 + [c_int64, c_void_p, c_int64, c_int64] + [c_void_p] * 4 + [c_int] * 10 +
+                              [c_void_p, c_void_p]),
     'fbbev_layernorm_bwd_partials': (c_int, [c_int64]),
     'fbbev_layernorm_bwd': (c_int, [c_void_p] * 3 + [c_float, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     'fbbev_history_conv': (c_int, [c_void_p, c_int64] + [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -820,6 +823,37 @@ def da_cross_attn_fused(planes, spatial_shapes, level_start_index, pred_depth, r
             _dev(attn_bias, F32, 'attn_bias'), B, Ncam, S, M, Dh, L, Q, int(num_points), Za, DC, float(d0), float(dstep), int(bev_w),
             int(min_level_width), _dev(slots, F32, 'slots'), _stream()), 'fbbev_da_cross_attn_fused')
     return slots
+
+
+def msda_self_fused_supported(B, S, M, Dh, L, Q, P, bev_w):
+    return bool(lib().fbbev_msda_self_fused_supported(B, S, M, Dh, L, Q, P, int(bev_w)))
+
+
+def msda_self_fused(planes, reference_points, query, addend, offsets_fragments, offsets_bias, attn_fragments, attn_bias, num_points,
+                    bev_w, level_hw, out):
+    """fbbev_msda_self_fused: planes (B, M, S, Dh) head-plane value tokens; reference_points (B, Q, 1, 2); query (B, Q, E) rows
+    [+ addend (P_, E) rows]; fragments / biases of sampling_offsets and attention_weights in the module's row order; out (B, Q, E)."""
+    B, M, S, Dh = planes.shape
+    Q = query.shape[1]
+    E = M * Dh
+    if tuple(query.shape) != (B, Q, E) or query.stride(2) != 1 or query.stride(0) != Q * query.stride(1):
+        raise FbbevError('msda_self_fused: query must be (B, Q, E) rows with one row stride')
+    if tuple(out.shape) != (B, Q, E) or not out.is_contiguous():
+        raise FbbevError('msda_self_fused: out must be contiguous (B, Q, M*Dh)')
+    if tuple(reference_points.shape) != (B, Q, 1, 2):
+        raise FbbevError('msda_self_fused: reference_points must be (B, Q, 1, 2)')
+    a_ptr, a_ld, a_per = None, 0, 1
+    if addend is not None:
+        if addend.dim() != 2 or addend.shape[1] != E or addend.stride(1) != 1 or (B * Q) % addend.shape[0] != 0:
+            raise FbbevError('msda_self_fused: addend must be (P, E) rows with B*Q % P == 0')
+        a_ptr, a_ld, a_per = _dev(addend, F32, 'addend', contiguous=False), addend.stride(0), addend.shape[0]
+    with _on(planes):
+        _check(lib().fbbev_msda_self_fused(
+            _dev(planes, F32, 'planes'), _dev(reference_points, F32, 'reference_points'), _dev(query, F32, 'query', contiguous=False),
+            query.stride(1), a_ptr, a_ld, a_per, offsets_fragments.data_ptr(), _dev(offsets_bias, F32, 'offsets_bias'),
+            attn_fragments.data_ptr(), _dev(attn_bias, F32, 'attn_bias'), B, S, M, Dh, 1, Q, int(num_points), int(bev_w),
+            int(level_hw[0]), int(level_hw[1]), _dev(out, F32, 'out'), _stream()), 'fbbev_msda_self_fused')
+    return out
 
 
 def layernorm_bwd(x, grad_out, weight, eps):

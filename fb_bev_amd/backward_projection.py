@@ -210,6 +210,36 @@ class MultiScaleDeformableAttention(nn.Module):
             # inference: fbbev_msda_fwd_fused builds `reference_points + offsets / (W,H)` per sample inside the kernel
             # (the reference spends two elementwise passes on that tensor) and reads head-padded value rows with
             # aligned 16-byte loads (value_proj rows padded once, like DA_MSDeformableAttention)
+            hw = host_values(spatial_shapes)
+            if (_RL.X3 and self.batch_first and hw is not None and len(hw) == 1 and num_query == hw[0][0] * hw[0][1]
+                    and num_value == num_query and hw[0][1] >= 2
+                    and tuple(reference_points.shape[1:]) == (num_query, 1, 2) and self.embed_dims % 8 == 0
+                    and _capi.msda_self_fused_supported(bs, num_value, self.num_heads, Dh, self.num_levels, num_query,
+                                                        self.num_points, hw[0][1])):
+                # round 4: query rows -> attention output in ONE kernel (fbbev_msda_self_fused): value_proj writes head planes,
+                # the sampling_offsets / attention_weights projections and the softmax run inside the sampler's workgroups
+                if not hasattr(self, '_vx3p'):
+                    self._vx3p, self._so_x3p, self._aw_x3p = X3Weights(), X3Weights(), X3Weights()
+                same = value is query
+                if not query.is_contiguous():             # the encoder's first layer hands a (Q, B, C) tensor permuted to (B, Q, C)
+                    query = query.contiguous()
+                value = query if same else value.contiguous()
+                vp = self._vx3p.get(self.value_proj.weight, self.value_proj.bias)
+                planes = _capi.rows_linear_x3_planes(value.reshape(bs * num_value, self.embed_dims), vp.frag, vp.b, num_value,
+                                                     self.num_heads, Dh)
+                so_c = self._so_x3p.get(self.sampling_offsets.weight, self.sampling_offsets.bias)
+                aw_c = self._aw_x3p.get(self.attention_weights.weight, self.attention_weights.bias)
+                q_in, add = query, None
+                if pos is not None:
+                    add = _RL._addend_rows(pos, query) if _RL.FOLD_ADDEND else None
+                    if add is None:
+                        q_in = query + pos
+                out = torch.empty(bs, num_query, self.embed_dims, dtype=torch.float32, device=query.device)
+                ref = reference_points.expand(bs, num_query, 1, 2).contiguous()
+                _capi.msda_self_fused(planes, ref, q_in, add, so_c.frag, so_c.b, aw_c.frag, aw_c.b, self.num_points, hw[0][1],
+                                      hw[0], out)
+                out = self.output_proj(out)
+                return (out, identity) if _defer_residual else out + identity
             HS = (Dh + 3) // 4 * 4
             w, b = self.value_proj.weight, self.value_proj.bias
             # data_ptr: a storage swap (param.data = ..., load_state_dict(assign=True), EMA) does not bump _version

@@ -1290,18 +1290,70 @@ extern "C" int fbbev_da_cross_attn_fused(const float* planes, const int64_t* spa
     const long long grid = (wgs + 7) / 8 * 8;
     if (grid >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
     const size_t lds = fbbev_daf_lds_bytes(E, M, Ncam, L * P);
-#define FBBEV_DA_FUSED(DH_)                                                                                            \
+#define FBBEV_DA_FUSED(DH_, NP_)                                                                                       \
     do {                                                                                                               \
-        int e = fbbev_rt_allow_dyn_lds((const void*)k_da_cross_attn_fused<DH_, 8>, lds);                              \
+        int e = fbbev_rt_allow_dyn_lds((const void*)k_da_cross_attn_fused<DH_, 8, NP_>, lds);                         \
         if (e) return e;                                                                                               \
-        FBBEV_LAUNCH((k_da_cross_attn_fused<DH_, 8>), grid, 512, lds, (fbbev_rt_stream)stream_, planes, spatial_shapes, \
+        FBBEV_LAUNCH((k_da_cross_attn_fused<DH_, 8, NP_>), grid, 512, lds, (fbbev_rt_stream)stream_, planes, spatial_shapes, \
                      level_start_index, pred_depth, ref_cam, mask, qdepth, query, query_row_stride, addend,           \
                      addend_row_stride, addend_period, static_cast<const unsigned short*>(offsets_fragments),         \
                      offsets_bias, static_cast<const unsigned short*>(attn_fragments), attn_bias, B, Ncam, S, L, Q,    \
                      bev_w, DC, d0, dstep, slots);                                                                     \
     } while (0)
-    if (Dh == 10) FBBEV_DA_FUSED(10); else FBBEV_DA_FUSED(8);
+    static const int np = [] { const char* e = getenv("FBBEV_DA_FUSED_NP"); return e ? atoi(e) : 2; }();   // samples in flight per lane (tuning knob, read once)
+    if (Dh == 10) { if (np == 3) FBBEV_DA_FUSED(10, 3); else if (np == 4) FBBEV_DA_FUSED(10, 4); else FBBEV_DA_FUSED(10, 2); }
+    else { if (np == 3) FBBEV_DA_FUSED(8, 3); else FBBEV_DA_FUSED(8, 2); }
 #undef FBBEV_DA_FUSED
+    FBBEV_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- fbbev_msda_self_fused: BEV self-attention, query rows -> attention output in one kernel (da_fused_kernels.h)
+extern "C" int fbbev_msda_self_fused_supported(int B, int S, int M, int Dh, int L, int Q, int P, int bev_w) {
+    if (B <= 0 || S <= 0 || M <= 0 || Dh <= 0 || L <= 0 || Q <= 0 || P <= 0) return 0;
+    static const bool off = [] { const char* e = getenv("FBBEV_MSDA_FUSED"); return e && atoi(e) == 0; }();   // A/B timing knob, read once
+    return (!off && M == 8 && (Dh == 10 || Dh == 8) && L == 1 && P == FBBEV_MSF_P && bev_w > 0 && Q % bev_w == 0 &&
+            (long long)S * Dh * 4 < (1ll << 31)) ? 1 : 0;
+}
+extern "C" int fbbev_msda_self_fused(const float* planes, const float* reference_points, const float* query,
+                                     long long query_row_stride, const float* addend, long long addend_row_stride,
+                                     long long addend_period, const void* offsets_fragments, const float* offsets_bias,
+                                     const void* attn_fragments, const float* attn_bias, int B, int S, int M, int Dh, int L, int Q,
+                                     int P, int bev_w, int level_h, int level_w, float* out, fbbev_stream_t stream_) {
+    if (B <= 0 || S <= 0 || M <= 0 || Dh <= 0 || L <= 0 || Q < 0 || P <= 0 || bev_w < 0 || level_h <= 0 || level_w <= 0)
+        return FBBEV_E_BADARG;
+    if (Q == 0) return 0;
+    if (!planes || !reference_points || !query || !offsets_fragments || !offsets_bias || !attn_fragments || !attn_bias || !out)
+        return FBBEV_E_BADARG;
+    if ((long long)level_h * level_w != S) return FBBEV_E_BADARG;
+    const int E = M * Dh;
+    if (query_row_stride == 0) query_row_stride = E;
+    if (query_row_stride < E) return FBBEV_E_BADARG;
+    if (addend) {
+        if (addend_period <= 0) return FBBEV_E_BADARG;
+        if (addend_row_stride == 0) addend_row_stride = E;
+        if (addend_row_stride < E) return FBBEV_E_BADARG;
+    } else { addend_row_stride = 0; addend_period = 1; }
+    if (!(M == 8 && (Dh == 10 || Dh == 8) && L == 1 && P == FBBEV_MSF_P && bev_w > 0 && Q % bev_w == 0) || level_w < 2 ||
+        (long long)S * Dh * 4 >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
+    if (query_row_stride % 4 != 0 || addend_row_stride % 4 != 0 || !aligned16(query) || (addend && !aligned16(addend)) ||
+        !aligned16(offsets_fragments) || !aligned16(attn_fragments) || ((uintptr_t)planes & 7) != 0 || ((uintptr_t)out & 7) != 0 ||
+        ((uintptr_t)reference_points & 7) != 0) return FBBEV_E_UNSUPPORTED;
+    const long long wgs = (long long)B * ((bev_w + 7) / 8) * ((Q / bev_w + 7) / 8);
+    const long long grid = (wgs + 7) / 8 * 8;
+    if (grid >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
+    const size_t lds = fbbev_msf_lds_bytes(E, M);
+#define FBBEV_MSDA_SELF(DH_)                                                                                            \
+    do {                                                                                                               \
+        int e = fbbev_rt_allow_dyn_lds((const void*)k_msda_self_fused<DH_, 8>, lds);                                  \
+        if (e) return e;                                                                                               \
+        FBBEV_LAUNCH((k_msda_self_fused<DH_, 8>), grid, 512, lds, (fbbev_rt_stream)stream_, planes, reference_points,  \
+                     query, query_row_stride, addend, addend_row_stride, addend_period,                                \
+                     static_cast<const unsigned short*>(offsets_fragments), offsets_bias,                              \
+                     static_cast<const unsigned short*>(attn_fragments), attn_bias, B, Q, bev_w, S, level_h, level_w, out); \
+    } while (0)
+    if (Dh == 10) FBBEV_MSDA_SELF(10); else FBBEV_MSDA_SELF(8);
+#undef FBBEV_MSDA_SELF
     FBBEV_CHECK_LAUNCH();
     return 0;
 }

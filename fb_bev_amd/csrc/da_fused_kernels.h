@@ -148,7 +148,7 @@ __device__ __forceinline__ void fbbev_daf_plane_corners(float x, float y, int H,
 // query (B*Q rows, ldq floats apart, E used) [+ addend rows: row (b*Q + q) % add_period]; so_frag / aw_frag: split bf16 fragments of
 // sampling_offsets.weight (M*L*P*2, E) / attention_weights.weight (M*L*P, E) in the order of k_rows_linear_x3_fragments, rows in
 // the MODULE's order ((m, l, p, xy) / (m, l, p)); so_bias / aw_bias fp32; slots (B, Q, M*DH).  blockDim = 64 * M.
-template <int DH, int MH>
+template <int DH, int MH, int NP>
 __global__ void __launch_bounds__(64 * MH)
 k_da_cross_attn_fused(const float* __restrict__ planes, const int64_t* __restrict__ spatial_shapes,
                       const int64_t* __restrict__ level_start, const float* __restrict__ pred_depth,
@@ -160,6 +160,7 @@ k_da_cross_attn_fused(const float* __restrict__ planes, const int64_t* __restric
                       int B, int Ncam, int S, int L, int Q, int bev_w, int DC, float d0, float dstep, float* __restrict__ slots) {
     constexpr int E = MH * DH, KS = (E + 31) / 32, P = FBBEV_DAF_P, ZA = FBBEV_DAF_ZA, NT = 64 * MH;
     static_assert((2 * DH) % 4 == 0 && DH % 2 == 0 && E % 8 == 0, "runs of whole 16-byte pieces, channel pairs");
+    static_assert(NP >= 2 && NP <= FBBEV_DAF_P, "samples in flight per lane");
     const int LP = L * P, LDW = LP + 1;
     unsigned char* lds = reinterpret_cast<unsigned char*>(fbbev_dyn_lds_f32());
     unsigned short* xf = reinterpret_cast<unsigned short*>(lds);                            // [4][KS][hi|lo][64][8] bf16
@@ -303,7 +304,9 @@ k_da_cross_attn_fused(const float* __restrict__ planes, const int64_t* __restric
                 rx[z] = fbbev_lds_ld_f32(rec + z); ry[z] = fbbev_lds_ld_f32(rec + ZA + z); dw[z] = fbbev_lds_ld_f32(rec + 2 * ZA + z);
             }
             const char* plane = pb + (((long long)b * Ncam + cam) * MH + m) * (long long)S * DH * 4;   // wave-uniform base
-            fbbev_daf_pending<DH> pa, pq;
+            // NP samples in flight per lane: sample p + NP - 1 is issued before sample p is blended (register slots addressed
+            // at compile time: the P samples are unrolled)
+            fbbev_daf_pending<DH> pend[NP];
             auto start = [&](int p, fbbev_daf_pending<DH>& slot) {
                 const int z = p % ZA;
                 const float ox = o4[p >> 1][2 * (p & 1)], oy = o4[p >> 1][2 * (p & 1) + 1];
@@ -311,16 +314,13 @@ k_da_cross_attn_fused(const float* __restrict__ planes, const int64_t* __restric
                 const float weight = fbbev_lds_ld_f32(my_attn + l * P + p) * dw[z];
                 fbbev_daf_issue<DH>(plane, lvl_off, loc_h * fsh - 0.5f, loc_w * fsw - 0.5f, sh, sw, weight, hit, slot);
             };
-            start(0, pa);
 #pragma unroll
-            for (int p = 0; p < P; p += 2) {
-                start(p + 1, pq);
+            for (int p = 0; p < NP - 1; ++p) start(p, pend[p]);
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                if (p + NP - 1 < P) start(p + NP - 1, pend[(p + NP - 1) % NP]);
                 fbbev_sched_fence();
-                fbbev_daf_consume<DH>(pa, acc);
-                fbbev_sched_fence();
-                if (p + 2 < P) start(p + 2, pa);
-                fbbev_sched_fence();
-                fbbev_daf_consume<DH>(pq, acc);
+                fbbev_daf_consume<DH>(pend[p % NP], acc);
                 fbbev_sched_fence();
             }
         }
@@ -349,4 +349,132 @@ k_rows_to_head_planes(const float* __restrict__ rows, long long n_rows, int S, i
     const long long r = t / M;
     const long long bn = r / S, tok = r - bn * S;
     planes[((bn * M + m) * S + tok) * DH + c] = rows[i];
+}
+
+// ---------------------------------------------------------------- BEV self-attention, inference, one kernel (round 4)
+// mmcv MultiScaleDeformableAttention.forward as the encoder layer uses it (bevformer_encoder.py:327-341; one level = the BEV grid
+// itself, 4 points, value = the query tokens): the same construction as k_da_cross_attn_fused -- value_proj writes head planes
+// (B, M, S, DH); a workgroup = the MH heads of an 8 x 8 patch of BEV queries, a wave = one head; the sampling_offsets (80 -> 64)
+// and attention_weights (80 -> 32) projections run on the split-operand bf16 MFMA from the patch's query rows (+ positional
+// rows) in LDS; softmax over the head's 4 logits in registers; `loc = ref + offset / (W, H)` and the bilinear samples as in
+// k_msda_fwd_unit.  Replaces two k_rows_linear_x3 launches, the softmax launch and k_msda_fwd_unit, and the (B,Q,8,1,4,2) /
+// (B,Q,8,1,4) tensors between them.  One level, P = 4 (mmcv's defaults, the only form the FB-OCC configs use).
+// Rows of the weight matrices in the MODULE's order: offsets ((m*P + p)*2 + xy), logits (m*P + p).
+#define FBBEV_MSF_P 4
+__host__ __device__ inline size_t fbbev_msf_lds_bytes(int E, int M) { return fbbev_daf_xf_bytes(E) + (size_t)M * 64 * FBBEV_DAF_OS * 4; }
+
+template <int DH, int MH>
+__global__ void __launch_bounds__(64 * MH)
+k_msda_self_fused(const float* __restrict__ planes, const float* __restrict__ ref, const float* __restrict__ query, long long ldq,
+                  const float* __restrict__ addend, long long ld_add, long long add_period,
+                  const unsigned short* __restrict__ so_frag, const float* __restrict__ so_bias,
+                  const unsigned short* __restrict__ aw_frag, const float* __restrict__ aw_bias,
+                  int B, int Q, int bev_w, int S, int H, int W, float* __restrict__ out) {
+    constexpr int E = MH * DH, KS = (E + 31) / 32, P = FBBEV_MSF_P, NT = 64 * MH;
+    static_assert(MH == 8, "a 16-output tile = the offsets of two heads / the logits of four");
+    unsigned char* lds = reinterpret_cast<unsigned char*>(fbbev_dyn_lds_f32());
+    unsigned short* xf = reinterpret_cast<unsigned short*>(lds);
+    float* tiles = reinterpret_cast<float*>(lds + fbbev_daf_xf_bytes(E));                   // [MH][64][OS]
+    const int bev_h = Q / bev_w;
+    const int pxn = (bev_w + 7) / 8, pyn = (bev_h + 7) / 8;
+    const long long n_wg = (long long)B * pxn * pyn, per_xcd = (n_wg + 7) / 8;
+    const long long wgid = (long long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (wgid >= n_wg) return;
+    const int b = (int)(wgid / ((long long)pxn * pyn)), pi = (int)(wgid - (long long)b * pxn * pyn);
+    const int py = pi / pxn, px = pi - py * pxn;
+    const int x0 = px * 8, y0 = py * 8;
+    for (int i = threadIdx.x; i < 4 * KS * 64; i += NT) {
+        const int rt = i / (KS * 64), s = (i >> 6) % KS, ln = i & 63;
+        const int g = ln >> 4, j = ln & 15, ql = 16 * rt + j, c = 32 * s + 8 * g;
+        const int qy = y0 + (ql >> 3), qx = x0 + (ql & 7);
+        fbbev_v4f lo4 = {0.f, 0.f, 0.f, 0.f}, hi4 = {0.f, 0.f, 0.f, 0.f};
+        if (c < E && qy < bev_h && qx < bev_w) {
+            const long long row = (long long)b * Q + (long long)qy * bev_w + qx;
+            const float* src = query + row * ldq + c;
+            lo4 = *reinterpret_cast<const fbbev_v4f*>(src); hi4 = *reinterpret_cast<const fbbev_v4f*>(src + 4);
+            if (addend) {
+                const float* a = addend + (row % add_period) * ld_add + c;
+                lo4 = lo4 + *reinterpret_cast<const fbbev_v4f*>(a); hi4 = hi4 + *reinterpret_cast<const fbbev_v4f*>(a + 4);
+            }
+        }
+        fbbev_bf16x8 h8, l8;
+        fbbev_split_bf16x8(lo4, hi4, h8, l8);
+        __builtin_memcpy(xf + (((rt * KS + s) * 2 + 0) * 64 + ln) * 8, &h8, 16);
+        __builtin_memcpy(xf + (((rt * KS + s) * 2 + 1) * 64 + ln) * 8, &l8, 16);
+    }
+    __syncthreads();
+    const int m = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int g = lane >> 4, j = lane & 15;
+    float* tile = tiles + (size_t)m * 64 * FBBEV_DAF_OS;
+    const int qy = y0 + (lane >> 3), qx = x0 + (lane & 7);
+    const bool valid = qy < bev_h && qx < bev_w;
+    const long long bq = (long long)b * Q + (valid ? (long long)qy * bev_w + qx : 0);
+    const fbbev_v2f rxy = *reinterpret_cast<const fbbev_v2f*>(ref + bq * 2);                // requested before the projections
+    fbbev_v4f pacc[4];
+    {   // offsets: tile m / 2 holds heads (m & ~1, m | 1); this head's 8 outputs are 4g + r with g / 2 == m & 1
+        const int T = m >> 1;
+        fbbev_daf_project<KS>(so_frag, T, xf, lane, pacc);
+        if ((g >> 1) == (m & 1)) {
+            fbbev_v4f bias4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bias4[r] = so_bias[16 * T + 4 * g + r];
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+                const fbbev_v4f v = pacc[rt] + bias4;
+                __builtin_memcpy(tile + (16 * rt + j) * FBBEV_DAF_OS + 4 * (g & 1), &v, 16);
+            }
+        }
+    }
+    {   // logits: tile m / 4 holds four heads; this head's P = 4 outputs are 4g + r with g == m & 3
+        const int T = m >> 2;
+        fbbev_daf_project<KS>(aw_frag, T, xf, lane, pacc);
+        if (g == (m & 3)) {
+            fbbev_v4f bias4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bias4[r] = aw_bias[16 * T + 4 * g + r];
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+                const fbbev_v4f v = pacc[rt] + bias4;
+                __builtin_memcpy(tile + (16 * rt + j) * FBBEV_DAF_OS + 8, &v, 16);
+            }
+        }
+    }
+    fbbev_wave_sync();
+    fbbev_v4f o4[2], lg;
+    __builtin_memcpy(&o4[0], tile + lane * FBBEV_DAF_OS, 16);
+    __builtin_memcpy(&o4[1], tile + lane * FBBEV_DAF_OS + 4, 16);
+    __builtin_memcpy(&lg, tile + lane * FBBEV_DAF_OS + 8, 16);
+    float wts[P];
+    {
+        const float mx = fmaxf(fmaxf(lg[0], lg[1]), fmaxf(lg[2], lg[3]));
+        float sum = 0.f;
+#pragma unroll
+        for (int p = 0; p < P; ++p) { wts[p] = __expf(lg[p] - mx); sum += wts[p]; }
+        const float inv_sum = 1.f / sum;
+#pragma unroll
+        for (int p = 0; p < P; ++p) wts[p] *= inv_sum;
+    }
+    const float fsh = (float)H, fsw = (float)W;
+    const char* plane = reinterpret_cast<const char*>(planes) + ((long long)b * MH + m) * (long long)S * DH * 4;
+    fbbev_v2f acc[DH / 2];
+#pragma unroll
+    for (int c = 0; c < DH / 2; ++c) { acc[c][0] = 0.f; acc[c][1] = 0.f; }
+    fbbev_daf_pending<DH> pend[2];
+    auto start = [&](int p, fbbev_daf_pending<DH>& slot) {
+        const float ox = o4[p >> 1][2 * (p & 1)], oy = o4[p >> 1][2 * (p & 1) + 1];
+        const float loc_w = rxy[0] + __fdiv_rn(ox, fsw), loc_h = rxy[1] + __fdiv_rn(oy, fsh);
+        fbbev_daf_issue<DH>(plane, 0, loc_h * fsh - 0.5f, loc_w * fsw - 0.5f, H, W, wts[p], valid, slot);
+    };
+    start(0, pend[0]);
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        if (p + 1 < P) start(p + 1, pend[(p + 1) & 1]);
+        fbbev_sched_fence();
+        fbbev_daf_consume<DH>(pend[p & 1], acc);
+        fbbev_sched_fence();
+    }
+    if (!valid) return;
+    float* dst = out + bq * E + m * DH;
+#pragma unroll
+    for (int c = 0; c < DH / 2; ++c) *reinterpret_cast<fbbev_v2f*>(dst + 2 * c) = acc[c];
 }

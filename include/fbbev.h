@@ -397,6 +397,20 @@ int fbbev_da_cross_attn_fused(const float* planes, const int64_t* spatial_shapes
                               const float* offsets_bias, const void* attn_fragments, const float* attn_bias, int B,
                               int Ncam, int S, int M, int Dh, int L, int Q, int P, int Za, int DC, float d0, float dstep,
                               int bev_w, int min_level_width, float* slots, fbbev_stream_t stream);
+/* The BEV self-attention of the encoder layer in ONE kernel, from the query rows to the attention output (before output_proj):
+ * mmcv MultiScaleDeformableAttention.forward as bevformer_encoder.py:327-341 calls it -- sampling_offsets / attention_weights
+ * Linears (split-operand bf16 MFMA inside the kernel, fragments of the MODULE-ordered weights), softmax over the head's points,
+ * `loc = ref + offset / (W, H)`, the bilinear samples of ms_deform_attn_forward.  `planes`: the value_proj output as head planes
+ * (B, M, S, Dh) with S = level_h * level_w value tokens per sample (fbbev_rows_linear_x3_planes, tokens_per_image = S);
+ * reference_points (B, Q, 1, 2) normalised (x, y); query (+ addend rows, period addend_period) as fbbev_da_cross_attn_fused;
+ * out (B, Q, M*Dh).  Supported: M = 8, Dh in {8, 10}, ONE level, P = 4 (mmcv's defaults = the FB-OCC configs), Q = a bev_h x
+ * bev_w grid, level_w >= 2; FBBEV_E_UNSUPPORTED otherwise (callers fall back to fbbev_msda_fwd_fused). */
+int fbbev_msda_self_fused_supported(int B, int S, int M, int Dh, int L, int Q, int P, int bev_w);
+int fbbev_msda_self_fused(const float* planes, const float* reference_points, const float* query, long long query_row_stride,
+                          const float* addend, long long addend_row_stride, long long addend_period,
+                          const void* offsets_fragments, const float* offsets_bias, const void* attn_fragments,
+                          const float* attn_bias, int B, int S, int M, int Dh, int L, int Q, int P, int bev_w, int level_h,
+                          int level_w, float* out, fbbev_stream_t stream);
 /* row-major camera tokens (n_rows = B*Ncam*S rows of M*Dh floats, module order (head, channel)) -> head planes (B*Ncam, M, S, Dh) */
 int fbbev_rows_to_head_planes(const float* rows, long long n_rows, int tokens_per_image, int M, int Dh, float* planes,
                               fbbev_stream_t stream);

@@ -1329,3 +1329,39 @@ def test_fused_da_cross_attention_emulated():
                                     Pm[pre + 'attention_weights.weight'].contiguous(), Pm[pre + 'attention_weights.bias'].contiguous(),
                                     4, d0, dstep, 8)
     assert code < 0
+
+
+@pytest.mark.parametrize('B,bh,bw,with_pos', [(1, 8, 8, True), (2, 5, 11, True), (1, 9, 16, False)])
+def test_fused_bev_self_attention_emulated(B, bh, bw, with_pos):
+    """fbbev_msda_self_fused -> k_msda_self_fused: mmcv MultiScaleDeformableAttention.forward as the encoder layer calls it
+    (one level = the BEV grid, 4 points, value = the query tokens) from the query rows in one kernel.  Against fbbev_msda_fwd on
+    the location tensor / softmaxed weights torch builds in fp32 (the in-kernel projections are split-operand bf16: ~1e-5
+    relative), full and partial 8 x 8 patches, with the positional rows as addend or pre-added."""
+    import torch.nn.functional as F
+    M, Dh, P = 8, 10, 4
+    Em, Q = M * Dh, bh * bw
+    g = torch.Generator().manual_seed(Q + B)
+    query = torch.randn(B, Q, Em, generator=g)
+    pos = torch.randn(Q, Em, generator=g) * 0.5
+    w_v, b_v = torch.randn(Em, Em, generator=g) * 0.2, torch.randn(Em, generator=g) * 0.1
+    w_so, b_so = torch.randn(M * P * 2, Em, generator=g) * 0.15, torch.randn(M * P * 2, generator=g) * 2.0
+    w_aw, b_aw = torch.randn(M * P, Em, generator=g) * 0.2, torch.randn(M * P, generator=g)
+    xs, ys = (torch.arange(bw) + 0.5) / bw, (torch.arange(bh) + 0.5) / bh
+    ref = torch.stack([xs[None].expand(bh, bw), ys[:, None].expand(bh, bw)], -1).reshape(1, Q, 1, 2).expand(B, Q, 1, 2).contiguous()
+    ss, ls = torch.tensor([[bh, bw]]), torch.tensor([0])
+    value = F.linear(query, w_v, b_v).view(B, Q, M, Dh).contiguous()              # value = the tokens WITHOUT the positional rows
+    qp = query + pos[None]
+    so = F.linear(qp, w_so, b_so).view(B, Q, M, 1, P, 2)
+    aw = F.linear(qp, w_aw, b_aw).view(B, Q, M, P).softmax(-1).view(B, Q, M, 1, P).contiguous()
+    norm = torch.stack([ss[..., 1], ss[..., 0]], -1)
+    loc = (ref[:, :, None, :, None, :] + so / norm[None, None, None, :, None, :]).contiguous()
+    base = E.msda_fwd(value, ss, ls, loc, aw)
+    planes = value.permute(0, 2, 1, 3).contiguous()
+    q_in, add = (query.contiguous(), pos.contiguous()) if with_pos else (qp.contiguous(), None)
+    code, out = E.msda_self_fused(planes, ref, q_in, add, w_so, b_so, w_aw, b_aw, P, bw, (bh, bw))
+    assert code == 0 and not torch.isnan(out).any()
+    scale = max(base.abs().max().item(), 1.0)
+    assert (out - base).abs().max().item() <= 1e-4 * scale, ((out - base).abs().max().item(), scale)
+    # refused: two levels, 8 points
+    code, _ = E.msda_self_fused(planes, ref, q_in, add, w_so, b_so, w_aw, b_aw, 8, bw, (bh, bw))
+    assert code < 0
