@@ -259,6 +259,7 @@ extern "C" size_t fbbev_rank_workspace_bytes(int64_t n_points) {
     return rank_layout(n_points).total;
 }
 
+static int rank_probe() { static const int v = [] { const char* e = getenv("FBBEV_RANK_PROBE"); return e ? atoi(e) : 0; }(); return v; }   // timing probes of k_sort_scatter_seg (results are WRONG when set)
 static int rank_seg_read_env() { const char* e = getenv("FBBEV_RANK_SEG"); return e ? atoi(e) : -1; }
 #ifdef FBBEV_TEST_OVERRIDES   // CPU emulator build: the tests switch modes inside one process
 static int rank_seg_mode() { return rank_seg_read_env(); }
@@ -339,16 +340,25 @@ static int rank_build_impl(const float* coor, const fbbev_cam_ptrs* cams, const 
         FBBEV_CHECK_LAUNCH();
         const unsigned int* kin = keys_a;
         const unsigned int* vin = nullptr;
+        static const int pairs = [] { const char* e = getenv("FBBEV_RANK_PAIRS"); return e ? atoi(e) : 1; }();   // A/B knob, read once
         for (int p = 0; p < passes; ++p) {
             const bool to_out = p == passes - 1;
+            // the intermediate (pass 0 -> pass 1) lives in keys_t | vals_t, which are adjacent: as ONE array of (key, value) pairs
+            const int pm = pairs ? ((p > 0 ? 1 : 0) | (to_out ? 0 : 2)) : 0;
             unsigned int* ko = to_out ? reinterpret_cast<unsigned int*>(ranks_bev) : keys_t;
             unsigned int* vo = to_out ? reinterpret_cast<unsigned int*>(ranks_depth) : vals_t;
             if (p > 0) {
-                FBBEV_LAUNCH(k_sort_hist_seg, wgs, FBBEV_SEG_NT, 0, stream, kin, (const int*)ctot, sg, p * srb, srb, skip, matrix);
+                FBBEV_LAUNCH(k_sort_hist_seg, wgs, FBBEV_SEG_NT, 0, stream, kin, (const int*)ctot, sg, p * srb, srb, skip, matrix,
+                             (pm & 1) ? 2 : 1);
                 FBBEV_CHECK_LAUNCH();
             }
-            FBBEV_LAUNCH(k_sort_scatter_seg, wgs, FBBEV_SEG_NT, 0, stream, kin, vin, (const int*)matrix, (const int*)ctot, sg, p, srb, skip,
-                         ko, vo, counts);
+            static const int swz = [] { const char* e = getenv("FBBEV_RANK_XCD_SWIZZLE"); return e ? atoi(e) : 1; }();   // A/B knob, read once
+            // XCD-contiguous chunk order when every XCD then owns whole samples' worth of chunks (B >= 8): measured 0.174 -> 0.156 ms
+            // per build at BL2 B = 16, 0.192 -> 0.184 at the shipped grid B = 16; with few samples the round-robin order is faster
+            // (BL2 B = 4: 0.123 vs 0.129) -- profiles/r04_time_rank_swizzle.jsonl
+            const int sw = (swz && B >= 8) ? 1 : 0;
+            FBBEV_LAUNCH(k_sort_scatter_seg, sw ? (wgs + 7) / 8 * 8 : wgs, FBBEV_SEG_NT, 0, stream, kin, vin, (const int*)matrix,
+                         (const int*)ctot, sg, p, srb, skip, ko, vo, counts, sw, rank_probe(), pm);
             FBBEV_CHECK_LAUNCH();
             kin = ko; vin = vo;
         }
@@ -372,7 +382,11 @@ static int rank_build_impl(const float* coor, const fbbev_cam_ptrs* cams, const 
                 FBBEV_SORT_DISPATCH(k_sort_hist, v, false, wgs, stream, kin, (const int*)counts, p * rb, rb, skip, matrix);
                 FBBEV_CHECK_LAUNCH();
             }
-            FBBEV_SORT_DISPATCH(k_sort_scatter, v, true, wgs, stream, kin, vin, n, (const int*)matrix, p, rb, skip, ko, vo, counts);
+            static const int swz = [] { const char* e = getenv("FBBEV_RANK_XCD_SWIZZLE"); return e ? atoi(e) : 1; }();   // A/B knob, read once
+            // pass 0 only: later passes size their grid for n but run on the P kept pairs -- a contiguous split would idle XCDs
+            const bool sw = swz == 2 && p == 0;       // off by default: measured slower for the global sort (BL1 B = 1: 0.151 -> 0.156 ms)
+            FBBEV_SORT_DISPATCH(k_sort_scatter, v, true, sw ? (wgs + 7) / 8 * 8 : wgs, stream, kin, vin, n, (const int*)matrix, p, rb, skip,
+                                ko, vo, counts, sw ? wgs : 0);
             FBBEV_CHECK_LAUNCH();
             kin = ko; vin = vo;
         }

@@ -163,7 +163,7 @@ template <int WAVES, int ROUNDS>
 __global__ void __launch_bounds__(WAVES * 64)
 k_sort_scatter(const unsigned int* __restrict__ keys_in, const unsigned int* __restrict__ vals_in, long long n_host,
                const int* __restrict__ matrix, int pass, int rb, const int* __restrict__ skip,
-               unsigned int* __restrict__ keys_out, unsigned int* __restrict__ vals_out, int* __restrict__ counts) {
+               unsigned int* __restrict__ keys_out, unsigned int* __restrict__ vals_out, int* __restrict__ counts, int swz_chunks) {
     if (fbbev_skip(skip)) return;
     constexpr int NT = WAVES * 64;
     constexpr int TILE = NT * ROUNDS;
@@ -175,7 +175,12 @@ k_sort_scatter(const unsigned int* __restrict__ keys_in, const unsigned int* __r
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nb = 1 << rb, shift = pass * rb;
     const unsigned int dmask = (unsigned int)nb - 1u;
-    const int wg = blockIdx.x;
+    // swz_chunks > 0 (grid = 8 * ceil(swz_chunks / 8)): XCD-contiguous chunk order, see k_sort_scatter_seg
+    int wg = (int)blockIdx.x;
+    if (swz_chunks > 0) {
+        wg = (int)(blockIdx.x & 7) * ((swz_chunks + 7) >> 3) + (int)(blockIdx.x >> 3);
+        if (wg >= swz_chunks) return;                     // block-uniform
+    }
     const long long n = (pass == 0) ? n_host : (long long)counts[0];
     const long long chunk0 = (long long)wg * TILE;
     if (chunk0 >= n) {
@@ -343,7 +348,7 @@ k_keys_hist_seg(fbbev_geom_src g, const float* __restrict__ coor, fbbev_grid_par
     if constexpr (GEOM) {
         const int dhw = g.cam.D * g.cam.H * g.cam.W;
         const int cam_lo = base / dhw, cam_hi = (end > base ? end - 1 : base) / dhw;
-        constexpr int G = 4;
+        constexpr int G = 8;                              // points in flight per thread (table loads of 8 points overlap; was 4)
         for (int cam = cam_lo; cam <= cam_hi; ++cam) {
             __syncthreads();
             if (threadIdx.x == 0) fbbev_cam_setup(g.cam, cam, m);
@@ -392,7 +397,7 @@ k_keys_hist_seg(fbbev_geom_src g, const float* __restrict__ coor, fbbev_grid_par
 // count matrix of pass 1: chunk (b, c) of the sample's compacted range
 __global__ void __launch_bounds__(FBBEV_SEG_NT)
 k_sort_hist_seg(const unsigned int* __restrict__ keys, const int* __restrict__ ctot, fbbev_seg sg, int shift, int rb,
-                const int* __restrict__ skip, int* __restrict__ matrix) {
+                const int* __restrict__ skip, int* __restrict__ matrix, int key_stride) {
     if (fbbev_skip(skip)) return;
     constexpr int NT = FBBEV_SEG_NT, PER = FBBEV_SEG_ROUNDS;
     __shared__ int cnt[FBBEV_SEG_NB];
@@ -410,7 +415,7 @@ k_sort_hist_seg(const unsigned int* __restrict__ keys, const int* __restrict__ c
 #pragma unroll
         for (int r = 0; r < PER; ++r) {
             const long long idx = base + threadIdx.x + r * NT;
-            key[r] = (idx < s1) ? keys[idx] : FBBEV_DROP_KEY;
+            key[r] = (idx < s1) ? keys[idx * key_stride] : FBBEV_DROP_KEY;          // key_stride 2: (key, value) pairs
         }
 #pragma unroll
         for (int r = 0; r < PER; ++r)
@@ -424,9 +429,20 @@ k_sort_hist_seg(const unsigned int* __restrict__ keys, const int* __restrict__ c
 __global__ void __launch_bounds__(FBBEV_SEG_NT)
 k_sort_scatter_seg(const unsigned int* __restrict__ keys_in, const unsigned int* __restrict__ vals_in, const int* __restrict__ matrix,
                    const int* __restrict__ ctot, fbbev_seg sg, int pass, int rb, const int* __restrict__ skip,
-                   unsigned int* __restrict__ keys_out, unsigned int* __restrict__ vals_out, int* __restrict__ counts) {
+                   unsigned int* __restrict__ keys_out, unsigned int* __restrict__ vals_out, int* __restrict__ counts, int xcd_swizzle, int probe, int pair_mode) {
     if (fbbev_skip(skip)) return;
     constexpr int WAVES = FBBEV_SEG_WAVES, ROUNDS = FBBEV_SEG_ROUNDS, NT = FBBEV_SEG_NT, NBM = FBBEV_SEG_NB;
+    // chunk id of this workgroup.  xcd_swizzle (grid = 8 * ceil(chunks / 8)): workgroups are dealt to the 8 XCDs round-robin, so
+    // hardware id w runs on XCD w % 8; with chunk = (w % 8) * ceil(chunks / 8) + w / 8 an XCD owns a CONTIGUOUS range of chunks
+    // = whole samples.  The scatter writes 4-byte words to 2^rb digit regions; the chunks of one sample fill each region in chunk
+    // order, so their partial lines meet in ONE L2 and leave it as full lines -- dealt round-robin, every XCD's L2 wrote its own
+    // byte-masked fragment of every line (the passes were bound by those partial writes, not by their 30 MB of traffic).
+    int chunk_id = (int)blockIdx.x;
+    if (xcd_swizzle) {
+        const int total = sg.nseg * sg.cps, per_xcd = (total + 7) >> 3;
+        chunk_id = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+        if (chunk_id >= total) return;                    // block-uniform
+    }
     __shared__ int cnt[WAVES][NBM];      // per-wave running digit counters, then (in place) each wave's first position of a digit
     __shared__ int pos0[NBM];            // global position of this chunk's first key of a digit
     __shared__ int red[2 * WAVES];
@@ -434,13 +450,13 @@ k_sort_scatter_seg(const unsigned int* __restrict__ keys_in, const unsigned int*
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nb = 1 << rb, shift = pass * rb;
     const unsigned int dmask = (unsigned int)nb - 1u;
-    const int b = blockIdx.x / sg.cps, c = blockIdx.x - b * sg.cps;
+    const int b = chunk_id / sg.cps, c = chunk_id - b * sg.cps;
     const unsigned int kbase = (unsigned int)b * sg.vps;
     for (int i = tid; i < WAVES * NBM; i += NT) (&cnt[0][0])[i] = 0;
     // the sample's range in the compacted order (= where its sorted pairs go, and pass 1's input range)
     int s0, s1;
     fbbev_seg_prefix2<WAVES>(ctot, b * sg.cps, (b + 1) * sg.cps, red, s0, s1);
-    if (pass == 0 && blockIdx.x == 0) {                  // P = all kept points
+    if (pass == 0 && chunk_id == 0) {                    // P = all kept points
         int p0, pall;
         fbbev_seg_prefix2<WAVES>(ctot, 0, sg.nseg * sg.cps, red, p0, pall);
         if (tid == 0) counts[0] = pall;
@@ -453,20 +469,15 @@ k_sort_scatter_seg(const unsigned int* __restrict__ keys_in, const unsigned int*
     const int row0 = b * sg.cps;
     for (int d = tid; d < nb; d += NT) {
         int pre = 0, all = 0;
-        constexpr int U = 8;                              // row loads in flight per thread (the loop is latency bound)
+        constexpr int U = 16;                             // row loads in flight per thread: the loop is latency bound; masked batches
+                                                          // (no one-at-a-time remainder: cps = 31 used to take 3 batches of 8 + 7 serial loads)
         const int* col = matrix + (long long)row0 * nb + d;
-        int r = 0;
-        for (; r + U <= sg.cps; r += U) {
+        for (int r = 0; r < sg.cps; r += U) {
             int v[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) v[u] = col[(long long)(r + u) * nb];
+            for (int u = 0; u < U; ++u) v[u] = col[(long long)(r + u < sg.cps ? r + u : sg.cps - 1) * nb];     // unconditional (clamped) loads
 #pragma unroll
-            for (int u = 0; u < U; ++u) { all += v[u]; if (r + u < c) pre += v[u]; }
-        }
-        for (; r < sg.cps; ++r) {
-            const int v = col[(long long)r * nb];
-            all += v;
-            if (r < c) pre += v;
+            for (int u = 0; u < U; ++u) { if (r + u < sg.cps) all += v[u]; if (r + u < c) pre += v[u]; }
         }
         pos0[d] = pre;
         cnt[0][d] = all;                                  // parked: scanned below, then cleared again
@@ -483,6 +494,7 @@ k_sort_scatter_seg(const unsigned int* __restrict__ keys_in, const unsigned int*
         if (d1 < nb) { pos0[d1] += s0 + ex + a0; cnt[0][d1] = 0; }
     }
     __syncthreads();
+    if (probe == 3) return;                               // (timing probe: prologue only)
     const long long chunk = chunk0 + (long long)wave * (64 * ROUNDS);
     unsigned int k[ROUNDS], v[ROUNDS];
     int lr[ROUNDS];
@@ -491,9 +503,16 @@ k_sort_scatter_seg(const unsigned int* __restrict__ keys_in, const unsigned int*
     for (int r = 0; r < ROUNDS; ++r) {
         const long long idx = chunk + r * 64 + lane;
         const bool valid = idx < in1;
-        k[r] = valid ? keys_in[idx] : FBBEV_DROP_KEY;
-        v[r] = valid ? (vals_in ? vals_in[idx] : (unsigned int)idx) : 0u;
+        if (pair_mode & 1) {                               // uniform: the intermediate array holds (key, value) pairs
+            uint2 kv = make_uint2(FBBEV_DROP_KEY, 0u);
+            if (valid) kv = reinterpret_cast<const uint2*>(keys_in)[idx];
+            k[r] = kv.x; v[r] = kv.y;
+        } else {
+            k[r] = valid ? keys_in[idx] : FBBEV_DROP_KEY;
+            v[r] = valid ? (vals_in ? vals_in[idx] : (unsigned int)idx) : 0u;
+        }
     }
+    if (probe == 2) { unsigned int x = 0; for (int r = 0; r < ROUNDS; ++r) x ^= k[r] ^ v[r]; if (x == 0x12345u) keys_out[0] = x; return; }   // (probe: + pair loads)
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
         const bool valid = k[r] != FBBEV_DROP_KEY;
@@ -523,13 +542,16 @@ k_sort_scatter_seg(const unsigned int* __restrict__ keys_in, const unsigned int*
         for (int w = 0; w < WAVES; ++w) { const int t = cnt[w][d]; cnt[w][d] = run; run += t; }
     }
     __syncthreads();
+    if (probe == 1) { int x = 0; for (int r = 0; r < ROUNDS; ++r) x ^= lr[r] + cnt[wave][((k[r] - kbase) >> shift) & dmask]; if (x == 0x7654321) keys_out[0] = x; return; }   // (probe: + ranking, no stores)
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
         if (lr[r] >= 0) {
             const unsigned int d = ((k[r] - kbase) >> shift) & dmask;
             const int pos = cnt[wave][d] + lr[r];
-            keys_out[pos] = k[r];
-            vals_out[pos] = v[r];
+            // pair_mode & 2: ONE 8-byte store per pair into the intermediate array instead of two 4-byte stores into two arrays
+            // (the scattered stores are a third of the pass: profiles/r04_rank_scatter_probes.txt)
+            if (pair_mode & 2) reinterpret_cast<uint2*>(keys_out)[pos] = make_uint2(k[r], v[r]);
+            else { keys_out[pos] = k[r]; vals_out[pos] = v[r]; }
         }
     }
 }

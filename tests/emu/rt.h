@@ -32,6 +32,8 @@ struct dim3 { unsigned x, y, z; };
 struct float4 { float x, y, z, w; } __attribute__((aligned(16)));
 struct int2 { int x, y; } __attribute__((aligned(8)));
 inline int2 make_int2(int x, int y) { int2 r; r.x = x; r.y = y; return r; }
+struct uint2 { unsigned int x, y; } __attribute__((aligned(8)));
+inline uint2 make_uint2(unsigned int x, unsigned int y) { uint2 r; r.x = x; r.y = y; return r; }
 
 namespace emu {
 struct Fiber { ucontext_t ctx; bool done; };
