@@ -284,6 +284,7 @@ DEFAULT_TILE_VOXELS = 128
 
 POOL_CHANNELS_LAST = 0x100000
 POOL_OUT_BF16, POOL_OUT_F16 = 0x800000, 0x1000000
+POOL_PIPE = 0x4000000         # a workgroup walks a run of tiles with the next tile's staging loads in flight (dense grids; same bits)
 POOL_SPLIT_LONG = 0x2000000   # tolerance mode: long intervals summed by the whole workgroup (<= 1e-4, not bit-exact)
 
 
@@ -316,7 +317,7 @@ def pool_zmean(depth, feat, ranks_depth, ranks_feat, interval_rank, interval_sta
             _dev(ranks_feat, I32, 'ranks_feat'), _dev(interval_rank, I32, 'interval_rank'),
             _dev(interval_starts, I32, 'interval_starts'), _dev(interval_lengths, I32, 'interval_lengths'),
             B, C, Z, Y, X, _dev(out_mean, F32, 'out_mean'), c_void_p(tile_ws.data_ptr()),
-            tile_ws.numel() * tile_ws.element_size(), int(tile_voxels), int(flags) & ~(POOL_OUT_BF16 | POOL_OUT_F16 | POOL_SPLIT_LONG),
+            tile_ws.numel() * tile_ws.element_size(), int(tile_voxels), int(flags) & ~(POOL_OUT_BF16 | POOL_OUT_F16 | POOL_SPLIT_LONG | POOL_PIPE),
             _stream()), 'fbbev_pool_zmean')
     return out_mean
 

@@ -763,6 +763,37 @@ static int pool_dense_fwd_impl(const float* depth, const float* feat,
     a.starts = interval_starts; a.lengths = interval_lengths; a.tile_meta = static_cast<const int*>(tile_ws);
     a.out = out; a.stride_b = out_stride_b; a.stride_c = out_stride_c; a.addend = addend;
     a.split = (flags & FBBEV_POOL_SPLIT_LONG) != 0;
+    if ((flags & FBBEV_POOL_PIPE) && ot == 0 && !a.split && nt == 256 && st >= 2 && (TV == 64 || TV == 128 || TV == 256)) {
+        // tiles per workgroup: enough to amortise the pipeline's fill, few enough to keep >= ~8 workgroups per CU's worth of runs
+#ifdef FBBEV_TEST_OVERRIDES   // CPU emulator build: the tests switch the run length inside one process
+        const int tpw_env = [] { const char* e = getenv("FBBEV_POOL_PIPE_TPW"); return e ? atoi(e) : 0; }();
+#else
+        static const int tpw_env = [] { const char* e = getenv("FBBEV_POOL_PIPE_TPW"); return e ? atoi(e) : 0; }();   // tuning knob, read once
+#endif
+        int tpw = tpw_env > 0 ? (tpw_env > 64 ? 64 : tpw_env) : 4;
+        if (tpw_env <= 0) while (tpw > 1 && (n_tiles / tpw) * csplit < 2048) tpw >>= 1;
+        const long long groups = (n_tiles + tpw - 1) / tpw;
+        a.n_blocks = groups * csplit;
+        a.lds = ((size_t)CC * (TV + 4) + 2 * (3 * (size_t)TV + 2 * FBBEV_NP_STAGE)) * sizeof(float);
+        if (a.lds > 160 * 1024) return FBBEV_E_UNSUPPORTED;
+        long long grid = a.n_blocks;
+        if (a.swizzle) {
+            const long long g = 8ll << (a.swizzle - 1);
+            grid = (a.n_blocks + g - 1) / g * g;
+        }
+#define FBBEV_POOL_PIPE_LAUNCH(TV_, CPL_)                                                                                  \
+        do {                                                                                                               \
+            if (a.lds > 64 * 1024) { int e = fbbev_rt_allow_dyn_lds((const void*)k_pool_fwd_dense_pipe<TV_, CPL_, 4, 256>, a.lds); if (e) return e; } \
+            FBBEV_LAUNCH((k_pool_fwd_dense_pipe<TV_, CPL_, 4, 256>), grid, 256, a.lds, a.stream, a.C, a.Z, a.yx, a.tpp, a.csplit, \
+                         (int)a.n_blocks, a.swizzle, tpw, (int)n_tiles, a.stride_b, a.stride_c, a.depth, a.feat, a.rd, a.rf,    \
+                         a.irank, a.starts, a.lengths, a.tile_meta, a.addend, a.out);                                      \
+        } while (0)
+        if (TV == 64) { if (cpl8) FBBEV_POOL_PIPE_LAUNCH(64, 8); else FBBEV_POOL_PIPE_LAUNCH(64, 4); }
+        else if (TV == 128) { if (cpl8) FBBEV_POOL_PIPE_LAUNCH(128, 8); else FBBEV_POOL_PIPE_LAUNCH(128, 4); }
+        else { if (cpl8) FBBEV_POOL_PIPE_LAUNCH(256, 8); else FBBEV_POOL_PIPE_LAUNCH(256, 4); }
+#undef FBBEV_POOL_PIPE_LAUNCH
+        return fbbev_rt_last_error();
+    }
     if (TV == 64) return cpl8 ? launch_dense2_st<64, 8>(st, nt, ot, a) : launch_dense2_st<64, 4>(st, nt, ot, a);
     if (TV == 128) return cpl8 ? launch_dense2_st<128, 8>(st, nt, ot, a) : launch_dense2_st<128, 4>(st, nt, ot, a);
     if (TV == 256) return cpl8 ? launch_dense2_st<256, 8>(st, nt, ot, a) : launch_dense2_st<256, 4>(st, nt, ot, a);

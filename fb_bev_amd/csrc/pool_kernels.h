@@ -558,6 +558,147 @@ k_pool_fwd_dense2(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_b
     }
 }
 
+// ================================================================ dense forward, software-pipelined over a run of tiles (round 4)
+// k_pool_fwd_dense2 walks a five-level dependent chain per tile -- tile table -> interval metadata / point indices -> (barrier)
+// -> depth / feature gathers -> (barrier) -> stores -- with nothing of the next tile in flight: at the shipped grid (100x100x8,
+// 68 % of the voxels occupied, ~87 intervals x 4 points per 128-voxel tile) the waves are parked 61 % of the time and the
+// kernel reaches 0.35 of the HBM peak where the sparse BASELINE configs[1] grid reaches 0.76 (profiles/r03_scope_table.json,
+// r02_pmc_forward_REF_B16.json).  Here a workgroup owns `tpw` CONSECUTIVE tiles of one channel group and double-buffers the
+// staging arrays: while tile t's gathers run, the interval metadata and the first FBBEV_NP_STAGE point indices of tile t + 1
+// are already in flight (registers -> the other LDS buffer after the store phase), and its tile-table words were fetched
+// one tile earlier still.  The store phase re-zeroes exactly the tile elements the same thread just read, so the LDS tile
+// needs no separate clear and the loop keeps two barriers per tile.  Same per-interval fmaf chains (fbbev_interval_sum_staged)
+// => the same bits as k_pool_fwd_dense2; fp32 volume, optional re-add epilogue.
+template <int TV, int CPL, int ST, int NT>
+__global__ void __launch_bounds__(NT)
+k_pool_fwd_dense_pipe(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_blocks, int swizzle, int tpw, int n_tiles,
+                      long long out_stride_b, long long out_stride_c,
+                      const float* __restrict__ depth, const float* __restrict__ feat,
+                      const int* __restrict__ rd, const int* __restrict__ rf,
+                      const int* __restrict__ interval_rank, const int* __restrict__ starts,
+                      const int* __restrict__ lengths, const int* __restrict__ tile_meta,
+                      const float* __restrict__ addend, float* __restrict__ out) {
+    constexpr int LD = TV + 4, Q4 = TV / 4;
+    constexpr int STG = 3 * TV + 2 * FBBEV_NP_STAGE;                       // ints of one staging buffer
+    constexpr int IPT = (TV + NT - 1) / NT, PPT = (FBBEV_NP_STAGE + NT - 1) / NT;
+    const int CC = C / csplit;
+    float* tile = fbbev_dyn_lds_f32();                                      // [CC][LD]
+    int* stg = reinterpret_cast<int*>(tile + CC * LD);                      // [2][STG]: ist | iln | ivx | prd | prf
+    const int tid = threadIdx.x;
+    int bid = blockIdx.x;
+    if (swizzle) {                                                          // as k_pool_fwd_dense2, on runs of tiles
+        const int sh = swizzle - 1;
+        const int xcd = bid & 7, j = bid >> 3;
+        bid = ((((j >> sh) << 3) + xcd) << sh) + (j & ((1 << sh) - 1));
+    }
+    if (bid >= n_blocks) return;
+    const int grp = bid / csplit, half = bid - grp * csplit;
+    const int c0 = half * CC;
+    const int t0 = grp * tpw, t1 = t0 + tpw < n_tiles ? t0 + tpw : n_tiles;
+    const long long cstride = out_stride_c;
+    const int n4 = CC * Q4;
+    // the tile table words of tiles t (a), t + 1 (b), t + 2 (c): (first interval, first point); entry n_tiles closes the table
+    int ia = tile_meta[2 * t0], pa = tile_meta[2 * t0 + 1];
+    int ib = tile_meta[2 * (t0 + 1)], pb = tile_meta[2 * (t0 + 1) + 1];
+    int r_st[IPT], r_ln[IPT], r_vx[IPT], r_rd[PPT], r_rf[PPT];
+    auto issue = [&](int i0, int p0, int i1, int p1) {                      // staging loads of one tile into registers
+        const int ni = i1 - i0, np = p1 - p0;
+#pragma unroll
+        for (int q = 0; q < IPT; ++q) {
+            const int j = tid + q * NT;
+            const int jj = i0 + (j < ni ? j : 0);                           // clamped: lanes beyond the tile load a duplicate
+            r_st[q] = starts[jj]; r_ln[q] = lengths[jj]; r_vx[q] = interval_rank[jj];
+        }
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            const int j = tid + q * NT;
+            const int jj = p0 + (j < np ? j : 0);
+            r_rd[q] = rd[jj]; r_rf[q] = rf[jj];
+        }
+    };
+    auto commit = [&](int buf, int i0, int p0, int i1, int p1, int rank0) {  // registers -> staging buffer `buf`
+        int* ist = stg + buf * STG;
+        int *iln = ist + TV, *ivx = iln + TV, *prd = ivx + TV, *prf = prd + FBBEV_NP_STAGE;
+        const int ni = i1 - i0, np = p1 - p0;
+#pragma unroll
+        for (int q = 0; q < IPT; ++q) {
+            const int j = tid + q * NT;
+            if (j < ni) { ist[j] = r_st[q] - p0; iln[j] = r_ln[q]; ivx[j] = r_vx[q] - rank0; }
+        }
+        const int nps = np < FBBEV_NP_STAGE ? np : FBBEV_NP_STAGE;
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            const int j = tid + q * NT;
+            if (j < nps) { prd[j] = r_rd[q]; prf[j] = r_rf[q]; }
+        }
+    };
+    auto rank_of = [&](int t) { const int plane = t / tiles_per_plane; return plane * YX + (t - plane * tiles_per_plane) * TV; };
+    if (ib > ia) issue(ia, pa, ib, pb);
+    for (int idx = tid; idx < CC * LD; idx += NT) tile[idx] = 0.f;          // once: the store phase re-zeroes what it reads
+    if (ib > ia) commit(0, ia, pa, ib, pb, rank_of(t0));
+    for (int t = t0; t < t1; ++t) {
+        const int cur = (t - t0) & 1;
+        const bool has_next = t + 1 < t1;
+        // table words of tile t + 2's start = tile t + 1's end (clamped to the closing entry)
+        const int tn = t + 2 <= n_tiles ? t + 2 : n_tiles;
+        const int ic = tile_meta[2 * tn], pc = tile_meta[2 * tn + 1];
+        const bool next_full = has_next && ic > ib;
+        if (next_full) issue(ib, pb, ic, pc);                               // in flight under this tile's gathers
+        const int plane = t / tiles_per_plane, k = t - plane * tiles_per_plane;
+        const int b = plane / Z, z = plane - b * Z;
+        const int v0 = k * TV;
+        const int nv = (YX - v0 < TV) ? (YX - v0) : TV;
+        const int ni = ib - ia;
+        const long long oofs = (long long)b * out_stride_b + (long long)z * YX + v0 + (long long)c0 * cstride;
+        float* __restrict__ obase = out + oofs;
+        const float* __restrict__ ab = addend ? addend + ((long long)b * C + c0) * YX + v0 : nullptr;
+        if (ni == 0) {                                                      // block-uniform: an empty tile is zeros (+ addend)
+            fbbev_v4f zero; zero[0] = zero[1] = zero[2] = zero[3] = 0.f;
+            for (int idx = tid; idx < n4; idx += NT) {
+                const int c = idx / Q4, j = (idx - c * Q4) * 4;
+                if (j < nv) fbbev_store4<ST>(obase + c * cstride + j,
+                                             ab ? *reinterpret_cast<const fbbev_v4f*>(ab + (long long)c * YX + j) : zero);
+            }
+        } else {
+            const int* ist = stg + cur * STG;
+            const int *iln = ist + TV, *ivx = iln + TV, *prd = ivx + TV, *prf = prd + FBBEV_NP_STAGE;
+            __syncthreads();                                                // staging(cur) committed, tile zeroed
+            {
+                const int lpi = CC / CPL;
+                const int gpb = NT / lpi;
+                const int g = tid / lpi, slot = tid - g * lpi;
+                if (g < gpb) {
+                    const float* fbase = feat + c0 + slot * CPL;
+                    for (int i = g; i < ni; i += gpb) {
+                        const int v = ivx[i];
+                        float acc[CPL];
+                        fbbev_interval_sum_staged<CPL, 4>(C, ist[i], iln[i], pa, prd, prf, depth, fbase, rd, rf, acc);
+                        if (v >= 0 && v < nv) {
+                            float* dst = tile + (slot * CPL) * LD + v;
+#pragma unroll
+                            for (int j = 0; j < CPL; ++j) dst[j * LD] = acc[j];
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            for (int idx = tid; idx < n4; idx += NT) {
+                const int c = idx / Q4, j = (idx - c * Q4) * 4;
+                float* tp = tile + c * LD + j;
+                fbbev_v4f val = *reinterpret_cast<const fbbev_v4f*>(tp);
+                fbbev_v4f zero; zero[0] = zero[1] = zero[2] = zero[3] = 0.f;
+                *reinterpret_cast<fbbev_v4f*>(tp) = zero;                   // the next tile starts from a clear tile
+                if (j < nv) {
+                    if (ab) val += *reinterpret_cast<const fbbev_v4f*>(ab + (long long)c * YX + j);
+                    fbbev_store4<ST>(obase + c * cstride + j, val);
+                }
+            }
+        }
+        if (next_full) commit(cur ^ 1, ib, pb, ic, pc, rank_of(t + 1));     // buffer cur ^ 1 was last read before this tile's barriers
+        ia = ib; pa = pb; ib = ic; pb = pc;
+    }
+}
+
 // ================================================================ Z-mean of the pooled volume without the volume
 // lss_bev = bev_feat.mean(-1) (fbocc.py:359: the backward projection's input) computed straight from the index
 // tensors: a workgroup owns TV consecutive (y,x) voxels x CC channels and walks the Z planes in ascending order,

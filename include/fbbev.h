@@ -39,6 +39,9 @@ typedef void* fbbev_stream_t; /* hipStream_t */
 #define FBBEV_POOL_OUT_BF16 0x800000  /* `out` holds bfloat16: fp32 sums rounded once (nearest-even) at the store */
 #define FBBEV_POOL_OUT_F16 0x1000000  /* `out` holds IEEE half; both: (B,C,Z,Y,X) layout only, (Y*X) % 8 == 0 */
 #define FBBEV_POOL_SWZ_CHUNK_SHIFT 12 /* bits 12-16: log2(tiles per chunk) for the swizzle, 0 = default */
+#define FBBEV_POOL_PIPE 0x4000000 /* fbbev_bev_pool_v2_dense_fwd[_add], fp32 volume, 64- / 128- / 256-voxel tiles: a workgroup walks a run
+                                   * of consecutive tiles and keeps the NEXT tile's interval metadata / point indices in flight under the
+                                   * current tile's gathers (k_pool_fwd_dense_pipe) -- the same bits; pays on dense grids (shipped config) */
 #define FBBEV_POOL_SPLIT_LONG 0x2000000 /* opt-in TOLERANCE mode of fbbev_bev_pool_v2_dense_fwd[_add]: an interval of more than 32
                                          * points is summed by up to 32 lane groups of its workgroup (contiguous chunks in order,
                                          * partial sums added in group order: deterministic) -- equal to the reference's serial

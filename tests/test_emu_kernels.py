@@ -1365,3 +1365,35 @@ def test_fused_bev_self_attention_emulated(B, bh, bw, with_pos):
     # refused: two levels, 8 points
     code, _ = E.msda_self_fused(planes, ref, q_in, add, w_so, b_so, w_aw, b_aw, 8, bw, (bh, bw))
     assert code < 0
+
+
+def test_pool_dense_pipelined_over_tile_runs_emulated():
+    """FBBEV_POOL_PIPE (0x4000000) -> k_pool_fwd_dense_pipe: a workgroup walks a run of consecutive tiles, the next tile's interval
+    metadata / point indices in flight under the current tile's gathers, the LDS tile re-zeroed by the store phase.  The same bits
+    as the one-tile-per-workgroup kernel (== the C oracle) for runs that contain empty tiles, partial last tiles (YX no multiple of
+    the tile), plane boundaries inside a run, more points per tile than the staged indices, 1 / 2 / 4 tiles per workgroup, and with
+    the re-add epilogue."""
+    import os
+    vt = O.ViewTransformerOracle(S.CONFIGS['SMALL'].grid_config, S.CONFIGS['SMALL'].input_size, S.CONFIGS['SMALL'].downsample)
+    cfg = S.CONFIGS['SMALL']
+    B = 2
+    cam = S.camera_rig(cfg, B, seed=1, bda_aug=True)
+    depth, ctx = S.depth_and_context(cfg, B, seed=1)
+    coor = vt.get_lidar_coor(*cam).contiguous()
+    rb, rd, rf, st, ln = vt.voxel_pooling_prepare_v2(coor)
+    Bz, Z, Y, X, C = vt.bev_feat_shape(B, cfg.channels)
+    feat = ctx.permute(0, 1, 3, 4, 2).contiguous()
+    ir = rb[st.long()].contiguous()
+    counts = torch.tensor([rb.numel(), st.numel()], dtype=torch.int32)
+    exp = O.bev_pool_v2(depth, feat, rd, rf, rb, (B, Z, Y, X, C), st, ln, use_fma=True)
+    for tv, flags in ((64, 0x20414), (128, 0x24424), (64, 0x20404)):
+        code, base = E.pool_dense(depth, feat, rd, rf, ir, st, ln, counts, st.numel(), B, C, Z, Y, X, tv, flags)
+        assert code == 0 and torch.equal(base, exp)
+        for tpw in ('1', '2', '4'):
+            os.environ['FBBEV_POOL_PIPE_TPW'] = tpw
+            try:
+                code, out = E.pool_dense(depth, feat, rd, rf, ir, st, ln, counts, st.numel(), B, C, Z, Y, X, tv, flags | 0x4000000)
+            finally:
+                del os.environ['FBBEV_POOL_PIPE_TPW']
+            assert code == 0 and not torch.isnan(out).any()
+            assert torch.equal(out, exp), (tv, hex(flags), tpw, (out - exp).abs().max())
