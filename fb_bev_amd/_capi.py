@@ -55,6 +55,8 @@ SIGNATURES = {
     'fbbev_rows_linear_x3': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
     'fbbev_rows_linear_x3_add': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
                                          c_void_p, c_int64, c_void_p]),
+    'fbbev_rows_linear_x3_ln': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p,
+                                        c_float, c_void_p, c_int64, c_void_p]),
     'fbbev_rows_linear_x3_planes': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'fbbev_da_cross_attn_fused_supported': (c_int, [c_int] * 10),
     'fbbev_da_cross_attn_fused': (c_int, [c_void_p] * 8 + [c_int64, c_void_p, c_int64, c_int64] + [c_void_p] * 4 + [c_int] * 10 +
@@ -757,6 +759,23 @@ def rows_linear_x3(x, fragments, bias, out_features, relu=False, out=None, adden
                                                   fragments.data_ptr(), b, R, I, out_features, 1 if relu else 0,
                                                   _dev(out, F32, 'out', contiguous=False), out.stride(0), _stream()),
                    'fbbev_rows_linear_x3_add')
+    return out
+
+
+def rows_linear_x3_ln(x, fragments, bias, out_features, residual, ln_weight, ln_bias, eps, out=None):
+    """LayerNorm(x W^T + bias [+ residual]) in one kernel (fbbev_rows_linear_x3_ln); x (R, I), residual (R, O) rows, out (R, O)."""
+    R, I = x.shape
+    if x.stride(1) != 1 or (residual is not None and (tuple(residual.shape) != (R, out_features) or residual.stride(1) != 1)):
+        raise FbbevError('rows_linear_x3_ln: rows must have unit column stride; residual must be (rows, out_features)')
+    if out is None:
+        out = torch.empty((R, out_features), dtype=F32, device=x.device)
+    b = _dev(bias, F32, 'bias') if bias is not None else None
+    with _on(x):
+        _check(lib().fbbev_rows_linear_x3_ln(
+            _dev(x, F32, 'x', contiguous=False), x.stride(0), fragments.data_ptr(), b, R, I, out_features,
+            _dev(residual, F32, 'residual', contiguous=False) if residual is not None else None,
+            residual.stride(0) if residual is not None else 0, _dev(ln_weight, F32, 'ln_weight'), _dev(ln_bias, F32, 'ln_bias'),
+            float(eps), _dev(out, F32, 'out', contiguous=False), out.stride(0), _stream()), 'fbbev_rows_linear_x3_ln')
     return out
 
 

@@ -259,7 +259,6 @@ extern "C" size_t fbbev_rank_workspace_bytes(int64_t n_points) {
     return rank_layout(n_points).total;
 }
 
-static int rank_probe() { static const int v = [] { const char* e = getenv("FBBEV_RANK_PROBE"); return e ? atoi(e) : 0; }(); return v; }   // timing probes of k_sort_scatter_seg (results are WRONG when set)
 static int rank_seg_read_env() { const char* e = getenv("FBBEV_RANK_SEG"); return e ? atoi(e) : -1; }
 #ifdef FBBEV_TEST_OVERRIDES   // CPU emulator build: the tests switch modes inside one process
 static int rank_seg_mode() { return rank_seg_read_env(); }
@@ -358,7 +357,7 @@ static int rank_build_impl(const float* coor, const fbbev_cam_ptrs* cams, const 
             // (BL2 B = 4: 0.123 vs 0.129) -- profiles/r04_time_rank_swizzle.jsonl
             const int sw = (swz && B >= 8) ? 1 : 0;
             FBBEV_LAUNCH(k_sort_scatter_seg, sw ? (wgs + 7) / 8 * 8 : wgs, FBBEV_SEG_NT, 0, stream, kin, vin, (const int*)matrix,
-                         (const int*)ctot, sg, p, srb, skip, ko, vo, counts, sw, rank_probe(), pm);
+                         (const int*)ctot, sg, p, srb, skip, ko, vo, counts, sw, pm);
             FBBEV_CHECK_LAUNCH();
             kin = ko; vin = vo;
         }
@@ -2092,7 +2091,8 @@ extern "C" int fbbev_rows_linear_x3_fragments(const float* weight, int in_featur
 static int rows_linear_x3_impl(const float* x, long long x_row_stride, const void* fragments, const float* bias, long long rows,
                                int in_features, int out_features, int relu, float* out, long long out_row_stride,
                                const float* addend, long long addend_row_stride, long long addend_period, fbbev_stream_t stream_,
-                               int plane_S = 0, int plane_TS = 0);
+                               int plane_S = 0, int plane_TS = 0, const float* res = nullptr, long long ld_res = 0,
+                               const float* ln_w = nullptr, const float* ln_b = nullptr, float ln_eps = 0.f);
 
 extern "C" int fbbev_rows_linear_x3(const float* x, long long x_row_stride, const void* fragments, const float* bias, long long rows,
                                     int in_features, int out_features, int relu, float* out, long long out_row_stride,
@@ -2116,7 +2116,8 @@ extern "C" int fbbev_rows_linear_x3_add(const float* x, long long x_row_stride, 
 static int rows_linear_x3_impl(const float* x, long long x_row_stride, const void* fragments, const float* bias, long long rows,
                                int in_features, int out_features, int relu, float* out, long long out_row_stride,
                                const float* addend, long long addend_row_stride, long long addend_period, fbbev_stream_t stream_,
-                               int plane_S, int plane_TS) {
+                               int plane_S, int plane_TS, const float* res, long long ld_res, const float* ln_w, const float* ln_b,
+                               float ln_eps) {
     if (rows < 0 || in_features <= 0 || out_features <= 0) return FBBEV_E_BADARG;
     if (rows == 0) return 0;
     if (!x || !fragments || !out) return FBBEV_E_BADARG;
@@ -2141,9 +2142,29 @@ static int rows_linear_x3_impl(const float* x, long long x_row_stride, const voi
     const long long groups = (tiles + RT - 1) / RT;
     FBBEV_LAUNCH((k_rows_linear_x3<2>), groups * n_oc, 256, lds, (fbbev_rt_stream)stream_, x, x_row_stride,
                  static_cast<const unsigned short*>(fragments), bias, out, out_row_stride, rows, in_features, out_features, relu,
-                 n_kc, n_oc, (int)RT, addend, addend_row_stride, addend_period, plane_S, plane_TS);
+                 n_kc, n_oc, (int)RT, addend, addend_row_stride, addend_period, plane_S, plane_TS, res, ld_res, ln_w, ln_b, ln_eps);
     FBBEV_CHECK_LAUNCH();
     return 0;
+}
+
+// out = LayerNorm(x W^T + b [+ residual]) over the out_features outputs of a row, weight / bias / eps of torch.nn.LayerNorm: the
+// `output_proj -> + residual -> norm` tail of the encoder layer's attention blocks and of its FFN (bevformer_encoder.py:250-377
+// with operation_order (attn, norm, ...)) as ONE kernel -- the LayerNorm rides in the GEMM's store epilogue.  out_features <= 128
+// (a workgroup must hold whole output rows).
+extern "C" int fbbev_rows_linear_x3_ln(const float* x, long long x_row_stride, const void* fragments, const float* bias, long long rows,
+                                       int in_features, int out_features, const float* residual, long long residual_row_stride,
+                                       const float* ln_weight, const float* ln_bias, float ln_eps, float* out,
+                                       long long out_row_stride, fbbev_stream_t stream_) {
+    if (!ln_weight || !ln_bias || out_features <= 0) return FBBEV_E_BADARG;
+    if (out_features > 128) return FBBEV_E_UNSUPPORTED;
+    if (residual) {
+        if (residual_row_stride == 0) residual_row_stride = out_features;
+        if (residual_row_stride < out_features) return FBBEV_E_BADARG;
+        if (residual_row_stride % 4 != 0 || !aligned16(residual)) return FBBEV_E_UNSUPPORTED;
+    }
+    if (!aligned16(ln_weight) || !aligned16(ln_bias)) return FBBEV_E_UNSUPPORTED;
+    return rows_linear_x3_impl(x, x_row_stride, fragments, bias, rows, in_features, out_features, 0, out, out_row_stride, nullptr, 0, 1,
+                               stream_, 0, 0, residual, residual_row_stride, ln_weight, ln_bias, ln_eps);
 }
 
 // y = x W^T + b written as HEAD PLANES: rows = (B*Ncam) x S tokens, out_features = M * head_dim (module order (head, channel));

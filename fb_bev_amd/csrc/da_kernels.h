@@ -267,8 +267,8 @@ k_da_cross_attn_fwd_unit(long long n_units, const void* __restrict__ value_, con
 //   * the offsets of the NEXT group of ZA samples are requested first in a group's body: `vmcnt` retires in order, so they
 //     are older than every corner load issued after them and never waited past.
 // Arithmetic: the blend is the reference's `(w1 v1 + w2 v2 + w3 v3 + w4 v4) * weight` per channel, on channel pairs
-// (v_pk_mul_f32 / v_pk_fma_f32); `offset / size` is evaluated as offset * (1 / size) with the level's reciprocal (one
-// ulp of a sub-pixel offset: the bilinear sample is continuous in it; the unit kernel above keeps the division).
+// (v_pk_mul_f32 / v_pk_fma_f32); `offset / size` is the correctly rounded division of the unit kernel and the backward kernels
+// (round 3 used offset * (1 / size): one ulp of a sub-pixel offset, but inference and training forward then disagreed in bits).
 // Preconditions (launcher): chunk-major fp32 rows (QI), head-minor offsets, attention weights staged through LDS,
 // P % ZA == 0, ZA even, DH in {8, 10}.
 template <int DH>
@@ -461,14 +461,14 @@ k_da_cross_attn_fwd_pipe(long long n_units, const float* __restrict__ value, con
             const long long cam_tok = bn * S;
             // issue-stream state: sizes / reciprocals / this lane's byte offset of the level the NEXT issue samples
             int sh = H0, sw = W0;
-            float fsh = (float)sh, fsw = (float)sw, rsh = __fdiv_rn(1.f, fsh), rsw = __fdiv_rn(1.f, fsw);
+            float fsh = (float)sh, fsw = (float)sw;
             unsigned lane_off = (unsigned)(((cam_tok + level_start[0]) * row_stride + m * 4) * 4);
             fbbev_da_pending<DH> pa, pb;
             // issue sample lp (anchor z) with the offsets `o`; the offsets of sample lp + 2 -- the next user of the same
             // register pair -- are requested FIRST: `vmcnt` retires in order, so that small load is older than the corner
             // loads issued behind it and is complete whenever they are
             auto start = [&](int lp, int z, bool enable, fbbev_v2f& o, fbbev_da_pending<DH>& slot) {
-                const float loc_w = rx[z] + o[0] * rsw, loc_h = ry[z] + o[1] * rsh;
+                const float loc_w = rx[z] + __fdiv_rn(o[0], fsw), loc_h = ry[z] + __fdiv_rn(o[1], fsh);   // the division of every other DA kernel
                 const int nx = lp + 2 < LP ? lp + 2 : LP - 1;          // clamped: past the end a duplicate nobody uses
                 o = op[(long long)nx * M];
                 const float weight = fbbev_lds_ld_f32(my_attn + lp) * dw[z];
@@ -482,7 +482,7 @@ k_da_cross_attn_fwd_pipe(long long n_units, const float* __restrict__ value, con
                 // ahead into itself and its look-ahead sample is disabled
                 const int ln = l + 1 < L ? l + 1 : l;
                 const int nsh = (int)spatial_shapes[2 * ln], nsw = (int)spatial_shapes[2 * ln + 1];
-                const float nfsh = (float)nsh, nfsw = (float)nsw, nrsh = __fdiv_rn(1.f, nfsh), nrsw = __fdiv_rn(1.f, nfsw);
+                const float nfsh = (float)nsh, nfsw = (float)nsw;
                 const unsigned nlane_off = (unsigned)(((cam_tok + level_start[ln]) * row_stride + m * 4) * 4);
                 for (int gl = 0; gl < gpl; ++gl, ++g) {
                     const bool last_of_level = gl + 1 == gpl;
@@ -501,7 +501,6 @@ k_da_cross_attn_fwd_pipe(long long n_units, const float* __restrict__ value, con
                             // one side makes the wait-count pass assume the worst at the join)
                             sh = last_of_level ? nsh : sh; sw = last_of_level ? nsw : sw;
                             fsh = last_of_level ? nfsh : fsh; fsw = last_of_level ? nfsw : fsw;
-                            rsh = last_of_level ? nrsh : rsh; rsw = last_of_level ? nrsw : rsw;
                             lane_off = last_of_level ? nlane_off : lane_off;
                             start(gn * ZA, 0, more, o_a, pa);         // past the last sample: a dummy on the zero token
                         }

@@ -24,7 +24,8 @@ template <int NT>
 __global__ void __launch_bounds__(256)
 k_rows_linear_x3(const float* __restrict__ x, long long ldx, const unsigned short* __restrict__ wf, const float* __restrict__ bias,
                  float* __restrict__ out, long long ldo, long long rows, int I, int O, int relu, int n_kc, int n_oc, int RT,
-                 const float* __restrict__ addend, long long ld_add, long long add_period, int plane_S, int plane_TS) {
+                 const float* __restrict__ addend, long long ld_add, long long add_period, int plane_S, int plane_TS,
+                 const float* __restrict__ res, long long ld_res, const float* __restrict__ ln_w, const float* __restrict__ ln_b, float ln_eps) {
     unsigned short* wl = reinterpret_cast<unsigned short*>(fbbev_dyn_lds_f32());          // [nmt][FBBEV_RL_TILE_ELEMS]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int g = lane >> 4, j = lane & 15;
@@ -98,6 +99,57 @@ k_rows_linear_x3(const float* __restrict__ x, long long ldx, const unsigned shor
                     }
                 }
             }
+        }
+        if (ln_w) {
+            // LayerNorm epilogue (n_oc == 1: the workgroup holds whole output rows): out = LN(x W^T + b + res) -- the `output_proj
+            // + residual + norm` tail of an attention block / the FFN (bevformer_encoder.py:250-377) in the GEMM's store epilogue
+            // instead of a k_layernorm_rows launch that re-reads the rows.  Two-pass statistics as k_layernorm_rows (mean, then
+            // the biased variance of the deviations); a row's O values live in the 4 lanes (g = 0..3, same j) of its row tile:
+            // two xor-shuffles per reduction.
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const long long r = r0 + 16 * t + j;
+                const bool live = r < rows;
+                fbbev_v4f v[8];
+                float s = 0.f;
+#pragma unroll
+                for (int mt = 0; mt < 8; ++mt) {
+                    const int o = 16 * mt + 4 * g;
+                    const bool ok = mt < nmt && o < O;
+                    v[mt] = fbbev_v4f{0.f, 0.f, 0.f, 0.f};
+                    if (ok) {
+                        v[mt] = acc[mt][t];
+                        if (bias) v[mt] = v[mt] + *reinterpret_cast<const fbbev_v4f*>(bias + o);
+                        if (res && live) v[mt] = v[mt] + *reinterpret_cast<const fbbev_v4f*>(res + r * ld_res + o);
+                        s += (v[mt][0] + v[mt][1]) + (v[mt][2] + v[mt][3]);
+                    }
+                }
+                s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+                const float mean = s / (float)O;
+                float q = 0.f;
+#pragma unroll
+                for (int mt = 0; mt < 8; ++mt) {
+                    const int o = 16 * mt + 4 * g;
+                    if (mt < nmt && o < O) {
+                        v[mt] = v[mt] - fbbev_v4f{mean, mean, mean, mean};
+                        q += (v[mt][0] * v[mt][0] + v[mt][1] * v[mt][1]) + (v[mt][2] * v[mt][2] + v[mt][3] * v[mt][3]);
+                    }
+                }
+                q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+                const float inv = 1.0f / sqrtf(q / (float)O + ln_eps);
+#pragma unroll
+                for (int mt = 0; mt < 8; ++mt) {
+                    const int o = 16 * mt + 4 * g;
+                    if (mt < nmt && o < O && live) {
+                        const fbbev_v4f w4 = *reinterpret_cast<const fbbev_v4f*>(ln_w + o), b4 = *reinterpret_cast<const fbbev_v4f*>(ln_b + o);
+                        fbbev_v4f y;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) y[e] = v[mt][e] * inv * w4[e] + b4[e];
+                        *reinterpret_cast<fbbev_v4f*>(out + r * ldo + o) = y;
+                    }
+                }
+            }
+            continue;
         }
         // accumulator register r of tile (mt, t) = output 16 mt + 4 g + r of row j: four consecutive outputs, one 16-byte store
 #pragma unroll

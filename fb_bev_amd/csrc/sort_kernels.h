@@ -429,7 +429,7 @@ k_sort_hist_seg(const unsigned int* __restrict__ keys, const int* __restrict__ c
 __global__ void __launch_bounds__(FBBEV_SEG_NT)
 k_sort_scatter_seg(const unsigned int* __restrict__ keys_in, const unsigned int* __restrict__ vals_in, const int* __restrict__ matrix,
                    const int* __restrict__ ctot, fbbev_seg sg, int pass, int rb, const int* __restrict__ skip,
-                   unsigned int* __restrict__ keys_out, unsigned int* __restrict__ vals_out, int* __restrict__ counts, int xcd_swizzle, int probe, int pair_mode) {
+                   unsigned int* __restrict__ keys_out, unsigned int* __restrict__ vals_out, int* __restrict__ counts, int xcd_swizzle, int pair_mode) {
     if (fbbev_skip(skip)) return;
     constexpr int WAVES = FBBEV_SEG_WAVES, ROUNDS = FBBEV_SEG_ROUNDS, NT = FBBEV_SEG_NT, NBM = FBBEV_SEG_NB;
     // chunk id of this workgroup.  xcd_swizzle (grid = 8 * ceil(chunks / 8)): workgroups are dealt to the 8 XCDs round-robin, so
@@ -469,7 +469,7 @@ k_sort_scatter_seg(const unsigned int* __restrict__ keys_in, const unsigned int*
     const int row0 = b * sg.cps;
     for (int d = tid; d < nb; d += NT) {
         int pre = 0, all = 0;
-        constexpr int U = 16;                             // row loads in flight per thread: the loop is latency bound; masked batches
+        constexpr int U = 8;                              // row loads in flight per thread: the loop is latency bound; masked batches
                                                           // (no one-at-a-time remainder: cps = 31 used to take 3 batches of 8 + 7 serial loads)
         const int* col = matrix + (long long)row0 * nb + d;
         for (int r = 0; r < sg.cps; r += U) {
@@ -494,7 +494,6 @@ k_sort_scatter_seg(const unsigned int* __restrict__ keys_in, const unsigned int*
         if (d1 < nb) { pos0[d1] += s0 + ex + a0; cnt[0][d1] = 0; }
     }
     __syncthreads();
-    if (probe == 3) return;                               // (timing probe: prologue only)
     const long long chunk = chunk0 + (long long)wave * (64 * ROUNDS);
     unsigned int k[ROUNDS], v[ROUNDS];
     int lr[ROUNDS];
@@ -512,7 +511,6 @@ k_sort_scatter_seg(const unsigned int* __restrict__ keys_in, const unsigned int*
             v[r] = valid ? (vals_in ? vals_in[idx] : (unsigned int)idx) : 0u;
         }
     }
-    if (probe == 2) { unsigned int x = 0; for (int r = 0; r < ROUNDS; ++r) x ^= k[r] ^ v[r]; if (x == 0x12345u) keys_out[0] = x; return; }   // (probe: + pair loads)
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
         const bool valid = k[r] != FBBEV_DROP_KEY;
@@ -542,7 +540,6 @@ k_sort_scatter_seg(const unsigned int* __restrict__ keys_in, const unsigned int*
         for (int w = 0; w < WAVES; ++w) { const int t = cnt[w][d]; cnt[w][d] = run; run += t; }
     }
     __syncthreads();
-    if (probe == 1) { int x = 0; for (int r = 0; r < ROUNDS; ++r) x ^= lr[r] + cnt[wave][((k[r] - kbase) >> shift) & dmask]; if (x == 0x7654321) keys_out[0] = x; return; }   // (probe: + ranking, no stores)
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
         if (lr[r] >= 0) {

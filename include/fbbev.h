@@ -536,6 +536,14 @@ int fbbev_rows_linear_x3(const float* x, long long x_row_stride, const void* fra
 int fbbev_rows_linear_x3_add(const float* x, long long x_row_stride, const float* addend, long long addend_row_stride,
                              long long addend_period, const void* fragments, const float* bias, long long rows, int in_features,
                              int out_features, int relu, float* out, long long out_row_stride, fbbev_stream_t stream);
+/* out = LayerNorm(x W^T + b [+ residual]) -- torch.nn.LayerNorm over the out_features outputs of a row (two-pass statistics,
+ * biased variance, eps inside the square root) in the store epilogue of fbbev_rows_linear_x3: the `output_proj -> + residual ->
+ * norm` tail of the encoder layer's attention blocks and FFN (bevformer_encoder.py:250-377) without a separate LayerNorm pass.
+ * out_features <= 128; residual rows optional (stride in floats, 0 = dense). */
+int fbbev_rows_linear_x3_ln(const float* x, long long x_row_stride, const void* fragments, const float* bias, long long rows,
+                            int in_features, int out_features, const float* residual, long long residual_row_stride,
+                            const float* ln_weight, const float* ln_bias, float ln_eps, float* out, long long out_row_stride,
+                            fbbev_stream_t stream);
 /* fbbev_rows_linear_x3 with the result written as HEAD PLANES: rows = (B*Ncam) x tokens_per_image camera tokens, out_features =
  * M * head_dim in the module's (head, channel) order, out (B*Ncam, M, tokens_per_image, head_dim) -- the value_proj of the
  * cross-attention feeding fbbev_da_cross_attn_fused (spatial_cross_attention_depth.py:522-530). */

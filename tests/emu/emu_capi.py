@@ -289,6 +289,18 @@ def _fragments(weight):
     return frag, fp
 
 
+def rows_linear_x3_ln(x, weight, bias, residual, ln_w, ln_b, eps):
+    frag, fp = _fragments(weight)
+    R, I = x.shape
+    O = weight.shape[0]
+    out = torch.full((R, O), float('nan'))
+    code = lib().fbbev_rows_linear_x3_ln(c_void_p(x.data_ptr()), x.stride(0), fp, p(bias) if bias is not None else None, R, I, O,
+                                         c_void_p(residual.data_ptr()) if residual is not None else None,
+                                         residual.stride(0) if residual is not None else 0, p(ln_w), p(ln_b), eps,
+                                         c_void_p(out.data_ptr()), out.stride(0), None)
+    return code, out
+
+
 def rows_linear_x3_planes(x, weight, bias, tokens_per_image, heads, head_dim):
     frag, fp = _fragments(weight)
     R, I = x.shape
