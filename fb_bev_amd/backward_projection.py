@@ -65,6 +65,9 @@ def const_tensor(values, device, dtype=torch.long):
     return _CONST[key]
 
 
+_NORMED = object()       # 'residual' slot of a deferred branch result whose following LayerNorm already ran inside the branch's last GEMM
+
+
 def host_values(t):
     """The Python values a const_tensor was built from (None for any other tensor)."""
     return getattr(t, '_fbbev_host', None)
@@ -129,16 +132,21 @@ class FFN(nn.Module):
         self.add_identity = add_identity
         self.embed_dims = embed_dims
 
-    def forward(self, x, identity=None, _defer_residual=False):
+    def forward(self, x, identity=None, _defer_residual=False, _norm=None):
         if torch.is_grad_enabled() or self.training:
             out = self.layers(x)
         else:
             # inference: Linear + ReLU blocks as one call each (the ReLU rides in the GEMM's store epilogue; dropout is identity)
             out = x
-            for layer in self.layers:
+            real = [l for l in self.layers if not isinstance(l, nn.Dropout)]
+            for layer in real:
                 if isinstance(layer, nn.Sequential) and isinstance(layer[0], Linear) and isinstance(layer[1], nn.ReLU):
                     out = layer[0](out, relu=True)
-                elif not isinstance(layer, nn.Dropout):
+                elif (layer is real[-1] and _norm is not None and _defer_residual and self.add_identity and isinstance(layer, Linear)):
+                    # the last Linear + residual + the layer's following LayerNorm in one kernel (fbbev_rows_linear_x3_ln)
+                    res = x if identity is None else identity
+                    return layer(out, ln=(res.contiguous(), _norm)), _NORMED
+                else:
                     out = layer(out)
         if not self.add_identity:
             return (out, None) if _defer_residual else out
@@ -184,7 +192,7 @@ class MultiScaleDeformableAttention(nn.Module):
         _xavier(self.output_proj)
 
     def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_padding_mask=None,
-                reference_points=None, spatial_shapes=None, level_start_index=None, _defer_residual=False, **kwargs):
+                reference_points=None, spatial_shapes=None, level_start_index=None, _defer_residual=False, _norm=None, **kwargs):
         if value is None:
             value = query
         if identity is None:
@@ -238,6 +246,8 @@ class MultiScaleDeformableAttention(nn.Module):
                 ref = reference_points.expand(bs, num_query, 1, 2).contiguous()
                 _capi.msda_self_fused(planes, ref, q_in, add, so_c.frag, so_c.b, aw_c.frag, aw_c.b, self.num_points, hw[0][1],
                                       hw[0], out)
+                if _norm is not None and _defer_residual:     # output_proj + residual + the following LayerNorm: one kernel
+                    return self.output_proj(out, ln=(identity.contiguous(), _norm)), _NORMED
                 out = self.output_proj(out)
                 return (out, identity) if _defer_residual else out + identity
             HS = (Dh + 3) // 4 * 4
@@ -431,6 +441,8 @@ def _pad_interleave_rows(w, b, M, Dh, HS, interleave=True, piece=4):
     return w.reshape(M * HS, E).contiguous(), b.reshape(M * HS).contiguous()
 
 
+import os as _os
+FUSE_OUT_NORM = _os.environ.get('FBBEV_FUSE_OUT_NORM', '1') != '0'     # output_proj / FFN tail + residual + LayerNorm in one kernel (A/B knob)
 FUSED_BWD_MAX_HEAD_DIM = 32                 # k_da_cross_attn_bwd: one lane per channel, groups of 16 / 32 lanes
 
 
@@ -621,7 +633,7 @@ class DA_SpatialCrossAttention(nn.Module):
     def forward(self, query, key, value, residual=None, query_pos=None, key_padding_mask=None, reference_points=None,
                 spatial_shapes=None, reference_points_cam=None, level_start_index=None, flag='encoder',
                 bev_query_depth=None, pred_img_depth=None, bev_mask=None, per_cam_mask_list=None, _defer_residual=False,
-                bev_w=0, **kwargs):
+                bev_w=0, _norm=None, **kwargs):
         if key is None:
             key = query
         if value is None:
@@ -647,6 +659,10 @@ class DA_SpatialCrossAttention(nn.Module):
         kw = dict(query_pos=query_pos) if fold_pos else {}
         slots = fn(query, value, reference_points_cam, mask, bev_query_depth, pred_img_depth, spatial_shapes,
                    level_start_index, bev_w=bev_w or 0, **kw)  # the BEV row length lets the sampler own 2-D patches of queries
+        if (_norm is not None and _defer_residual and self.layer_scale is None and not torch.is_grad_enabled()
+                and not (self.training and self.dropout.p > 0)):
+            # output_proj + residual + the layer's following LayerNorm in one kernel (fbbev_rows_linear_x3_ln)
+            return self.output_proj(slots, ln=(inp_residual.contiguous(), _norm)), _NORMED
         slots = self.output_proj(slots)
         if self.layer_scale is not None:
             slots = self.layer_scale * slots
@@ -745,18 +761,20 @@ class BEVFormerEncoderLayer(nn.Module):
         pending = None
         for k, layer in enumerate(ops):
             d = defer and k + 1 < len(ops) and ops[k + 1] == 'norm'
+            nk = dict(_norm=self.norms[ni]) if d and FUSE_OUT_NORM else {}      # the branch may run its following norm itself
             if layer == 'self_attn':
                 query = self.attentions[ai](
                     query, None, None, identity if self.pre_norm else None, query_pos=bev_pos, key_pos=bev_pos,
                     key_padding_mask=bev_mask, reference_points=ref_2d,
                     spatial_shapes=const_tensor([[bev_h, bev_w]], query.device),
-                    level_start_index=const_tensor([0], query.device), _defer_residual=d)
+                    level_start_index=const_tensor([0], query.device), _defer_residual=d, **nk)
                 ai += 1
                 if d:
                     query, pending = query
                 identity = query
             elif layer == 'norm':
-                query = self.norms[ni](query, pending)
+                if pending is not _NORMED:                    # _NORMED: norm ni already ran in the previous branch's last GEMM
+                    query = self.norms[ni](query, pending)
                 pending = None
                 ni += 1
             elif layer == 'cross_attn':
@@ -765,13 +783,13 @@ class BEVFormerEncoderLayer(nn.Module):
                     reference_points=ref_3d, reference_points_cam=reference_points_cam, spatial_shapes=spatial_shapes,
                     level_start_index=level_start_index, bev_query_depth=bev_query_depth,
                     pred_img_depth=pred_img_depth, bev_mask=bev_mask, per_cam_mask_list=per_cam_mask_list,
-                    _defer_residual=d, bev_w=bev_w)
+                    _defer_residual=d, bev_w=bev_w, **nk)
                 ai += 1
                 if d:
                     query, pending = query
                 identity = query
             elif layer == 'ffn':
-                query = self.ffns[fi](query, identity if self.pre_norm else None, _defer_residual=d)
+                query = self.ffns[fi](query, identity if self.pre_norm else None, _defer_residual=d, **nk)
                 fi += 1
                 if d:
                     query, pending = query

@@ -2131,7 +2131,7 @@ static int rows_linear_x3_impl(const float* x, long long x_row_stride, const voi
     if (tiles * n_oc >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
     const int nmt = out_features >= 128 ? 8 : (out_features + 15) / 16;
     const size_t lds = (size_t)nmt * FBBEV_RL_TILE_ELEMS * sizeof(unsigned short);
-    int e = fbbev_rt_allow_dyn_lds((const void*)k_rows_linear_x3<2>, lds);
+    int e = ln_w ? fbbev_rt_allow_dyn_lds((const void*)k_rows_linear_x3<2, true>, lds) : fbbev_rt_allow_dyn_lds((const void*)k_rows_linear_x3<2, false>, lds);
     if (e) return e;
     // consecutive row tiles per workgroup (fragments staged once) as long as ~4 workgroups per CU remain
     long long RT = n_kc == 1 ? tiles * n_oc / 1024 : 1;
@@ -2140,9 +2140,16 @@ static int rows_linear_x3_impl(const float* x, long long x_row_stride, const voi
     { const char* e_rt = getenv("FBBEV_ROWS_LINEAR_RT"); if (e_rt && n_kc == 1 && atoi(e_rt) >= 1 && atoi(e_rt) <= 8) RT = atoi(e_rt); }
 #endif
     const long long groups = (tiles + RT - 1) / RT;
-    FBBEV_LAUNCH((k_rows_linear_x3<2>), groups * n_oc, 256, lds, (fbbev_rt_stream)stream_, x, x_row_stride,
-                 static_cast<const unsigned short*>(fragments), bias, out, out_row_stride, rows, in_features, out_features, relu,
-                 n_kc, n_oc, (int)RT, addend, addend_row_stride, addend_period, plane_S, plane_TS, res, ld_res, ln_w, ln_b, ln_eps);
+    if (ln_w) {
+        if (n_oc != 1) return FBBEV_E_UNSUPPORTED;
+        FBBEV_LAUNCH((k_rows_linear_x3<2, true>), groups * n_oc, 256, lds, (fbbev_rt_stream)stream_, x, x_row_stride,
+                     static_cast<const unsigned short*>(fragments), bias, out, out_row_stride, rows, in_features, out_features, relu,
+                     n_kc, n_oc, (int)RT, addend, addend_row_stride, addend_period, plane_S, plane_TS, res, ld_res, ln_w, ln_b, ln_eps);
+    } else {
+        FBBEV_LAUNCH((k_rows_linear_x3<2, false>), groups * n_oc, 256, lds, (fbbev_rt_stream)stream_, x, x_row_stride,
+                     static_cast<const unsigned short*>(fragments), bias, out, out_row_stride, rows, in_features, out_features, relu,
+                     n_kc, n_oc, (int)RT, addend, addend_row_stride, addend_period, plane_S, plane_TS, res, ld_res, ln_w, ln_b, ln_eps);
+    }
     FBBEV_CHECK_LAUNCH();
     return 0;
 }

@@ -20,7 +20,7 @@
 
 #define FBBEV_RL_TILE_ELEMS (2 * 4 * 64 * 8)              // bf16 elements of one 16-output tile of one K chunk: [hi|lo][4 k-steps][lane][8]
 
-template <int NT>
+template <int NT, bool LN>
 __global__ void __launch_bounds__(256)
 k_rows_linear_x3(const float* __restrict__ x, long long ldx, const unsigned short* __restrict__ wf, const float* __restrict__ bias,
                  float* __restrict__ out, long long ldo, long long rows, int I, int O, int relu, int n_kc, int n_oc, int RT,
@@ -100,8 +100,9 @@ k_rows_linear_x3(const float* __restrict__ x, long long ldx, const unsigned shor
                 }
             }
         }
-        if (ln_w) {
-            // LayerNorm epilogue (n_oc == 1: the workgroup holds whole output rows): out = LN(x W^T + b + res) -- the `output_proj
+        if constexpr (LN) {
+            // LayerNorm epilogue (its own instantiation: in the common kernel its 8 extra vectors per row tile cost the 240-register
+            // budget -- 336 registers = one wave per SIMD for EVERY launch).  n_oc == 1: the workgroup holds whole output rows): out = LN(x W^T + b + res) -- the `output_proj
             // + residual + norm` tail of an attention block / the FFN (bevformer_encoder.py:250-377) in the GEMM's store epilogue
             // instead of a k_layernorm_rows launch that re-reads the rows.  Two-pass statistics as k_layernorm_rows (mean, then
             // the biased variance of the deviations); a row's O values live in the 4 lanes (g = 0..3, same j) of its row tile:

@@ -130,10 +130,33 @@ def _addend_rows(addend, x):
     return a
 
 
-def linear_x3(x, cache, relu=False, out=None, addend=None):
-    """x (..., I) [+ addend] -> (..., O) through fbbev_rows_linear_x3 with the fragments of `cache` (an X3Weights after .get())."""
+def ln_fusable(norm, residual, x, out_features):
+    """fbbev_rows_linear_x3_ln applies: `norm` is a one-dimensional affine LayerNorm over the out_features outputs (fp32, on the GPU),
+    the residual (if any) has the output's shape with dense rows, out_features <= 128."""
+    w, b = getattr(norm, 'weight', None), getattr(norm, 'bias', None)
+    if (w is None or b is None or tuple(getattr(norm, 'normalized_shape', ())) != (out_features,) or out_features > 128 or
+            w.dtype != torch.float32 or not w.is_cuda):
+        return False
+    if residual is not None and (residual.shape[:-1] != x.shape[:-1] or residual.shape[-1] != out_features or
+                                 residual.dtype != torch.float32 or not residual.is_contiguous()):
+        return False
+    return True
+
+
+def linear_x3(x, cache, relu=False, out=None, addend=None, ln=None):
+    """x (..., I) [+ addend] -> (..., O) through fbbev_rows_linear_x3 with the fragments of `cache` (an X3Weights after .get()).
+    ln = (residual or None, LayerNorm module): LayerNorm(x W^T + b + residual) in the same kernel (fbbev_rows_linear_x3_ln)."""
     I = x.shape[-1]
     O = cache.w.shape[0]
+    if ln is not None:
+        assert not relu and out is None and addend is None
+        res, norm = ln
+        x2 = x.reshape(-1, I)
+        if x2.stride(1) != 1 or x2.stride(0) % 4 != 0 or x2.data_ptr() % 16 != 0:
+            x2 = x2.contiguous()
+        y = _capi.rows_linear_x3_ln(x2, cache.frag, cache.b, O, None if res is None else res.reshape(-1, O), norm.weight, norm.bias,
+                                    norm.eps)
+        return y.view(*x.shape[:-1], O)
     a = None
     if addend is not None:
         a = _addend_rows(addend, x) if FOLD_ADDEND else None
@@ -146,7 +169,7 @@ def linear_x3(x, cache, relu=False, out=None, addend=None):
     return y if out is not None else y.view(*x.shape[:-1], O)
 
 
-def linear_rows(x, w, b=None, cache=None, transform=None, relu=False, addend=None):
+def linear_rows(x, w, b=None, cache=None, transform=None, relu=False, addend=None, ln=None):
     """F.linear (+ ReLU) of x [+ addend] for row tensors.  Inference on a GPU with a `cache` (X3Weights owned by the calling module;
     `w` / `b` are then the SOURCE parameters and `transform` derives the applied matrix): the split-operand MFMA kernel, which
     also folds the addend (query_pos) into its row loads.  Training on a GPU: the split-K backward when it pays.  Otherwise F.linear."""
@@ -155,7 +178,10 @@ def linear_rows(x, w, b=None, cache=None, transform=None, relu=False, addend=Non
         if x3_ok(x, x.shape[-1], O if O is not None else 4):
             c = cache.get(w, b, transform)
             if c.w.shape[1] == x.shape[-1] and c.w.shape[0] % 4 == 0:
-                return linear_x3(x, c, relu=relu, addend=addend)
+                if ln is not None and ln_fusable(ln[1], ln[0], x, c.w.shape[0]) and not relu and addend is None:
+                    return linear_x3(x, c, ln=ln)
+                y = linear_x3(x, c, relu=relu, addend=addend)
+                return y if ln is None else ln[1](y, ln[0])
     if addend is not None:
         x = x + addend
     if transform is not None:
@@ -166,13 +192,15 @@ def linear_rows(x, w, b=None, cache=None, transform=None, relu=False, addend=Non
         y = _RowsLinear.apply(x.reshape(rows, x.shape[-1]), w, b).view(*x.shape[:-1], w.shape[0])
     else:
         y = F.linear(x, w, b)
-    return torch.relu_(y) if relu else y
+    y = torch.relu_(y) if relu else y
+    return y if ln is None else ln[1](y, ln[0])
 
 
 class Linear(nn.Linear):
     """nn.Linear (same parameters / state_dict) whose forward goes through `linear_rows`."""
 
-    def forward(self, x, relu=False, addend=None):
+    def forward(self, x, relu=False, addend=None, ln=None):
+        """ln = (residual or None, LayerNorm): returns norm(linear(x) + residual) -- one kernel on the inference route"""
         if not hasattr(self, '_x3'):
             self._x3 = X3Weights()
-        return linear_rows(x, self.weight, self.bias, cache=self._x3, relu=relu, addend=addend)
+        return linear_rows(x, self.weight, self.bias, cache=self._x3, relu=relu, addend=addend, ln=ln)

@@ -1397,3 +1397,24 @@ def test_pool_dense_pipelined_over_tile_runs_emulated():
                 del os.environ['FBBEV_POOL_PIPE_TPW']
             assert code == 0 and not torch.isnan(out).any()
             assert torch.equal(out, exp), (tv, hex(flags), tpw, (out - exp).abs().max())
+
+
+@pytest.mark.parametrize('rows,I,O,with_res', [(200, 80, 80, True), (130, 320, 80, True), (70, 80, 64, False), (33, 16, 20, True)])
+def test_rows_linear_layernorm_epilogue_emulated(rows, I, O, with_res):
+    """fbbev_rows_linear_x3_ln: LayerNorm(x W^T + b [+ residual]) in the GEMM's store epilogue == torch's layer_norm of the fp32
+    linear (+ residual) within the split-operand arithmetic (~1e-5 relative), rows that do not fill the last tile, an output width
+    that is no multiple of 16, K in three chunks (the FFN's 320 -> 80)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(rows + O)
+    x = torch.randn(rows, I, generator=g)
+    w = torch.randn(O, I, generator=g) / I ** 0.5
+    b = torch.randn(O, generator=g) * 0.3
+    res = torch.randn(rows, O, generator=g) if with_res else None
+    lw, lb = torch.rand(O, generator=g) + 0.5, torch.randn(O, generator=g) * 0.2
+    code, out = E.rows_linear_x3_ln(x, w, b, res, lw, lb, 1e-5)
+    assert code == 0 and not torch.isnan(out).any()
+    y = F.linear(x, w, b)
+    ref = F.layer_norm(y + res if with_res else y, (O,), lw, lb, 1e-5)
+    assert (out - ref).abs().max().item() <= 5e-5 * max(1.0, ref.abs().max().item()), (out - ref).abs().max().item()
+    code, _ = E.rows_linear_x3_ln(x, torch.randn(256, I, generator=g), None, None, torch.ones(256), torch.zeros(256), 1e-5)
+    assert code < 0                                                       # wider than one workgroup's output rows: refused

@@ -71,6 +71,10 @@ BUDGETS = {
     r'k_conv3d_wgrad_ndhwc': 256,
     r'k_conv3d_k3_tile_bf16': 256,             # 8 waves per workgroup (4 MFMA + 4 loader): two per SIMD
     r'k_msda_fwd_unitILi10E': 136,
+    r'k_rows_linear_x3ILi2E': 256,             # two waves / SIMD; round 4: an epilogue added to the COMMON kernel took it to 336 registers
+                                               # (one wave / SIMD) and every row-wise linear layer of the encoder slowed down: 1.62 -> 1.76 ms
+    r'k_da_cross_attn_fusedILi10ELi8ELi2E': 256,   # 8 waves per workgroup, one workgroup per CU: two waves / SIMD
+    r'k_msda_self_fusedILi10E': 256,
 }
 
 
