@@ -2088,6 +2088,7 @@ extern "C" int fbbev_rows_linear_x3_fragments(const float* weight, int in_featur
     return 0;
 }
 
+static bool rows_linear_nt1() { static const bool v = [] { const char* e = getenv("FBBEV_ROWS_LINEAR_NT"); return e && atoi(e) == 1; }(); return v; }   // tuning knob, read once
 static int rows_linear_x3_impl(const float* x, long long x_row_stride, const void* fragments, const float* bias, long long rows,
                                int in_features, int out_features, int relu, float* out, long long out_row_stride,
                                const float* addend, long long addend_row_stride, long long addend_period, fbbev_stream_t stream_,
@@ -2145,6 +2146,16 @@ static int rows_linear_x3_impl(const float* x, long long x_row_stride, const voi
         FBBEV_LAUNCH((k_rows_linear_x3<2, true>), groups * n_oc, 256, lds, (fbbev_rt_stream)stream_, x, x_row_stride,
                      static_cast<const unsigned short*>(fragments), bias, out, out_row_stride, rows, in_features, out_features, relu,
                      n_kc, n_oc, (int)RT, addend, addend_row_stride, addend_period, plane_S, plane_TS, res, ld_res, ln_w, ln_b, ln_eps);
+    } else if (rows_linear_nt1() && n_kc == 1) {
+        // 16 rows per wave (64 per workgroup): half the accumulators / row pieces in registers -> more waves per SIMD
+        const long long tiles1 = (rows + 63) / 64;
+        long long RT1 = tiles1 * n_oc / 2048;
+        RT1 = RT1 < 1 ? 1 : (RT1 > 8 ? 8 : RT1);
+        e = fbbev_rt_allow_dyn_lds((const void*)k_rows_linear_x3<1, false>, lds);
+        if (e) return e;
+        FBBEV_LAUNCH((k_rows_linear_x3<1, false>), (tiles1 + RT1 - 1) / RT1 * n_oc, 256, lds, (fbbev_rt_stream)stream_, x, x_row_stride,
+                     static_cast<const unsigned short*>(fragments), bias, out, out_row_stride, rows, in_features, out_features, relu,
+                     n_kc, n_oc, (int)RT1, addend, addend_row_stride, addend_period, plane_S, plane_TS, res, ld_res, ln_w, ln_b, ln_eps);
     } else {
         FBBEV_LAUNCH((k_rows_linear_x3<2, false>), groups * n_oc, 256, lds, (fbbev_rt_stream)stream_, x, x_row_stride,
                      static_cast<const unsigned short*>(fragments), bias, out, out_row_stride, rows, in_features, out_features, relu,

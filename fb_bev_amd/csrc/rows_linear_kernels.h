@@ -21,7 +21,7 @@
 #define FBBEV_RL_TILE_ELEMS (2 * 4 * 64 * 8)              // bf16 elements of one 16-output tile of one K chunk: [hi|lo][4 k-steps][lane][8]
 
 template <int NT, bool LN>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, NT == 1 ? 3 : 2)
 k_rows_linear_x3(const float* __restrict__ x, long long ldx, const unsigned short* __restrict__ wf, const float* __restrict__ bias,
                  float* __restrict__ out, long long ldo, long long rows, int I, int O, int relu, int n_kc, int n_oc, int RT,
                  const float* __restrict__ addend, long long ld_add, long long add_period, int plane_S, int plane_TS,
