@@ -57,6 +57,8 @@ SIGNATURES = {
                                          c_void_p, c_int64, c_void_p]),
     'fbbev_rows_linear_x3_ln': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p,
                                         c_float, c_void_p, c_int64, c_void_p]),
+    'fbbev_rows_ffn_x3': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int64,
+                                  c_void_p, c_void_p, c_float, c_void_p, c_int64, c_void_p]),
     'fbbev_rows_linear_x3_planes': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'fbbev_da_cross_attn_fused_supported': (c_int, [c_int] * 10),
     'fbbev_da_cross_attn_fused': (c_int, [c_void_p] * 8 + [c_int64, c_void_p, c_int64, c_int64] + [c_void_p] * 4 + [c_int] * 10 +
@@ -776,6 +778,24 @@ def rows_linear_x3_ln(x, fragments, bias, out_features, residual, ln_weight, ln_
             _dev(residual, F32, 'residual', contiguous=False) if residual is not None else None,
             residual.stride(0) if residual is not None else 0, _dev(ln_weight, F32, 'ln_weight'), _dev(ln_bias, F32, 'ln_bias'),
             float(eps), _dev(out, F32, 'out', contiguous=False), out.stride(0), _stream()), 'fbbev_rows_linear_x3_ln')
+    return out
+
+
+def rows_ffn_x3(x, w1_fragments, b1, w2_fragments, b2, hidden, out_features, residual=None, ln_weight=None, ln_bias=None, eps=1e-5):
+    """[LayerNorm](W2 relu(W1 x + b1) + b2 [+ residual]) in one kernel (fbbev_rows_ffn_x3); x (R, I) rows, out (R, O)."""
+    R, I = x.shape
+    if x.stride(1) != 1 or (residual is not None and (tuple(residual.shape) != (R, out_features) or residual.stride(1) != 1)):
+        raise FbbevError('rows_ffn_x3: rows must have unit column stride; residual must be (rows, out_features)')
+    out = torch.empty((R, out_features), dtype=F32, device=x.device)
+    with _on(x):
+        _check(lib().fbbev_rows_ffn_x3(
+            _dev(x, F32, 'x', contiguous=False), x.stride(0), w1_fragments.data_ptr(), _dev(b1, F32, 'b1'), w2_fragments.data_ptr(),
+            _dev(b2, F32, 'b2'), R, I, int(hidden), int(out_features),
+            _dev(residual, F32, 'residual', contiguous=False) if residual is not None else None,
+            residual.stride(0) if residual is not None else 0,
+            _dev(ln_weight, F32, 'ln_weight') if ln_weight is not None else None,
+            _dev(ln_bias, F32, 'ln_bias') if ln_bias is not None else None, float(eps), _dev(out, F32, 'out'), out.stride(0), _stream()),
+            'fbbev_rows_ffn_x3')
     return out
 
 

@@ -132,13 +132,52 @@ class FFN(nn.Module):
         self.add_identity = add_identity
         self.embed_dims = embed_dims
 
+    def _one_kernel(self, x, identity, defer, norm, real):
+        """inference, the encoder's shape (Linear + ReLU, Linear; in <= 96, hidden % 64 == 0, out <= 80): both GEMMs, the ReLU, the
+        residual and -- when the layer hands it over -- the following LayerNorm in ONE kernel (fbbev_rows_ffn_x3): the hidden rows stay
+        in LDS.  None when the shape / route does not apply."""
+        if not (FUSE_FFN and len(real) == 2 and isinstance(real[0], nn.Sequential) and isinstance(real[0][0], Linear)
+                and isinstance(real[0][1], nn.ReLU) and isinstance(real[1], Linear)):
+            return None
+        l1, l2 = real[0][0], real[1]
+        I, H, O = l1.in_features, l1.out_features, l2.out_features
+        if not (x3_ok(x, I, H) and I <= 96 and H % 64 == 0 and O <= 80 and O % 4 == 0 and l1.bias is not None and l2.bias is not None
+                and x.is_contiguous()):
+            return None
+        res = None
+        if self.add_identity:
+            res = (x if identity is None else identity)
+            if res.dtype != torch.float32 or res.shape[:-1] != x.shape[:-1] or res.shape[-1] != O:
+                return None
+            res = res.contiguous().reshape(-1, O)
+        fuse_norm = defer and norm is not None and self.add_identity and _RL.ln_fusable(norm, None, x, O)
+        if defer and not fuse_norm and self.add_identity:
+            res_arg, tail = None, (x if identity is None else identity)      # the caller's LayerNorm adds the residual itself
+        else:
+            res_arg, tail = res, None
+        for lin in (l1, l2):
+            if not hasattr(lin, '_x3'):
+                lin._x3 = X3Weights()
+        c1, c2 = l1._x3.get(l1.weight, l1.bias), l2._x3.get(l2.weight, l2.bias)
+        y = _capi.rows_ffn_x3(x.reshape(-1, I), c1.frag, c1.b, c2.frag, c2.b, H, O, residual=res_arg,
+                              ln_weight=norm.weight if fuse_norm else None, ln_bias=norm.bias if fuse_norm else None,
+                              eps=norm.eps if fuse_norm else 1e-5).view(*x.shape[:-1], O)
+        if fuse_norm:
+            return y, _NORMED
+        if defer:
+            return y, tail
+        return y
+
     def forward(self, x, identity=None, _defer_residual=False, _norm=None):
         if torch.is_grad_enabled() or self.training:
             out = self.layers(x)
         else:
+            real = [l for l in self.layers if not isinstance(l, nn.Dropout)]
+            one = self._one_kernel(x, identity, _defer_residual, _norm, real)
+            if one is not None:
+                return one
             # inference: Linear + ReLU blocks as one call each (the ReLU rides in the GEMM's store epilogue; dropout is identity)
             out = x
-            real = [l for l in self.layers if not isinstance(l, nn.Dropout)]
             for layer in real:
                 if isinstance(layer, nn.Sequential) and isinstance(layer[0], Linear) and isinstance(layer[1], nn.ReLU):
                     out = layer[0](out, relu=True)
@@ -442,6 +481,7 @@ def _pad_interleave_rows(w, b, M, Dh, HS, interleave=True, piece=4):
 
 
 import os as _os
+FUSE_FFN = _os.environ.get('FBBEV_FUSE_FFN', '1') != '0'               # the FFN pair as one kernel (fbbev_rows_ffn_x3; A/B knob)
 FUSE_OUT_NORM = _os.environ.get('FBBEV_FUSE_OUT_NORM', '1') != '0'     # output_proj / FFN tail + residual + LayerNorm in one kernel (A/B knob)
 FUSED_BWD_MAX_HEAD_DIM = 32                 # k_da_cross_attn_bwd: one lane per channel, groups of 16 / 32 lanes
 

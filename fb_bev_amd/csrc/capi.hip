@@ -2197,6 +2197,54 @@ extern "C" int fbbev_rows_linear_x3_planes(const float* x, long long x_row_strid
                                tokens_per_image, head_dim);
 }
 
+// The FFN pair of the encoder layer in one kernel: out = [LayerNorm](W2 relu(W1 x + b1) + b2 [+ residual]) -- mmcv FFN
+// (bevformer_encoder.py:250-377 with ffn_cfgs: Linear + ReLU, Linear, add_identity) and, when ln_weight is given, the layer's
+// following LayerNorm.  w1_fragments / w2_fragments = fbbev_rows_linear_x3_fragments of W1 (hidden, in) / W2 (out, hidden).
+// Supported: in_features <= 96, hidden % 64 == 0, out_features <= 80 (the FB-OCC shape 80 -> 320 -> 80); FBBEV_E_UNSUPPORTED otherwise.
+extern "C" int fbbev_rows_ffn_x3(const float* x, long long x_row_stride, const void* w1_fragments, const float* b1,
+                                 const void* w2_fragments, const float* b2, long long rows, int in_features, int hidden,
+                                 int out_features, const float* residual, long long residual_row_stride, const float* ln_weight,
+                                 const float* ln_bias, float ln_eps, float* out, long long out_row_stride, fbbev_stream_t stream_) {
+    if (rows < 0 || in_features <= 0 || hidden <= 0 || out_features <= 0) return FBBEV_E_BADARG;
+    if (rows == 0) return 0;
+    if (!x || !w1_fragments || !b1 || !w2_fragments || !b2 || !out || (ln_weight && !ln_bias)) return FBBEV_E_BADARG;
+    if (x_row_stride == 0) x_row_stride = in_features;
+    if (out_row_stride == 0) out_row_stride = out_features;
+    if (x_row_stride < in_features || out_row_stride < out_features) return FBBEV_E_BADARG;
+    if (residual) {
+        if (residual_row_stride == 0) residual_row_stride = out_features;
+        if (residual_row_stride < out_features) return FBBEV_E_BADARG;
+    }
+    if (in_features > 96 || in_features % 8 != 0 || hidden % FBBEV_FFN_HC != 0 || out_features > 80 || out_features % 4 != 0 ||
+        x_row_stride % 4 != 0 || out_row_stride % 4 != 0 || !aligned16(x) || !aligned16(out) || !aligned16(w1_fragments) ||
+        !aligned16(w2_fragments) || !aligned16(b1) || !aligned16(b2) || (residual && (residual_row_stride % 4 != 0 || !aligned16(residual))) ||
+        (ln_weight && (!aligned16(ln_weight) || !aligned16(ln_bias)))) return FBBEV_E_UNSUPPORTED;
+    const long long wgs = (rows + 127) / 128;
+    if (wgs >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
+    // hidden units per chunk: 32 (three workgroups per CU) measured 1.480 vs 1.508 ms for 64 in the S3 scope (profiles/r04_time_fb_ffn_hc.jsonl)
+#ifdef FBBEV_TEST_OVERRIDES   // CPU emulator build: the tests switch the chunk inside one process
+    const int hc = [] { const char* e = getenv("FBBEV_FFN_HC"); return e ? atoi(e) : 32; }();
+#else
+    static const int hc = [] { const char* e = getenv("FBBEV_FFN_HC"); return e ? atoi(e) : 32; }();   // tuning knob, read once
+#endif
+    const int n_kc2 = (hidden + 127) / 128;
+#define FBBEV_FFN(LN_, HC_)                                                                                              \
+    do {                                                                                                               \
+        const size_t lds = (size_t)fbbev_ffn_lds_bytes<3, 5, HC_>();                                                   \
+        int e = fbbev_rt_allow_dyn_lds((const void*)k_rows_ffn_x3<3, 5, LN_, HC_>, lds);                               \
+        if (e) return e;                                                                                               \
+        FBBEV_LAUNCH((k_rows_ffn_x3<3, 5, LN_, HC_>), wgs, 256, lds, (fbbev_rt_stream)stream_, x, x_row_stride,          \
+                     static_cast<const unsigned short*>(w1_fragments), b1, static_cast<const unsigned short*>(w2_fragments), b2,  \
+                     out, out_row_stride, rows, in_features, hidden, out_features, n_kc2, residual, residual_row_stride,     \
+                     ln_weight, ln_bias, ln_eps);                                                                      \
+    } while (0)
+    if (hc == 64) { if (ln_weight) FBBEV_FFN(true, 64); else FBBEV_FFN(false, 64); }
+    else { if (ln_weight) FBBEV_FFN(true, 32); else FBBEV_FFN(false, 32); }
+#undef FBBEV_FFN
+    FBBEV_CHECK_LAUNCH();
+    return 0;
+}
+
 // Warp + new ring + both convolutions in ONE kernel (k_history_fused_bf16): history (B,T,N,C) -> next ring slots 1..T of
 // `next` (B,T+1,N,C) (slot 0 = the current frame, stored by the caller with fbbev_history_frame_vm BEFORE this call) and
 // out (B,Cout,N) = relu(bias2 + sum_t w2_t . relu(w1 . x_t + bias1_t)) over the T+1 frames of `next`, bf16 MFMA.

@@ -209,3 +209,179 @@ k_rows_linear_x3_fragments(const float* __restrict__ w, int O, int I, int n_oc, 
     __builtin_memcpy(base, &h8, 16);
     __builtin_memcpy(base + FBBEV_RL_TILE_ELEMS / 2, &l8, 16);
 }
+
+// ---------------------------------------------------------------- the FFN pair in one kernel (round 4)
+// mmcv FFN of the encoder layer (bevformer_encoder.py:250-377, cfg ffn_cfgs: Linear(80 -> 320) + ReLU, Linear(320 -> 80), + identity,
+// then the layer's LayerNorm): y = [LN](x + W2 relu(W1 x + b1) + b2).  As two k_rows_linear_x3 launches the 320-wide hidden rows
+// were written and re-read (205 MB each way at 160 000 rows).  Here a wave keeps its 32 rows' x fragments and output accumulators
+// in registers and walks the hidden units in chunks of 64: GEMM 1 (4 tiles x KS1 k-steps) -> + b1, ReLU -> split into bf16 hi / lo
+// and dropped into a wave-private LDS buffer ALREADY in B-fragment order (the accumulator register of lane (g, j) for hidden unit
+// 16 mt + 4 g + r of row j is element 4 (g & 1) + r of fragment lane (2 (mt & 1) + g / 2, j) of k-step mt / 2) -> GEMM 2 (MT2 tiles x
+// 2 k-steps) accumulates into the outputs.  The chunk's weight fragments (W1: 24 KB, W2: 20 KB, split operands) are staged through
+// LDS once per workgroup and chunk.  Same split-operand arithmetic as k_rows_linear_x3 (three MFMAs per product) for both GEMMs.
+// LDS: 24 + 20 + 4 x 8 KB = 76 KB -> two workgroups per CU.
+#define FBBEV_FFN_HC 64                                    // hidden units the launcher requires the width to be a multiple of
+// HC = hidden units per chunk: 64 (4 tiles = 2 k-steps of GEMM 2, 76 KB of LDS: two workgroups per CU) or 32 (2 tiles = 1 k-step,
+// 38 KB: three workgroups per CU at the kernel's 164 registers -- twice the barriers, 1.5x the waves to hide them behind)
+template <int KS1, int MT2, int HC>
+__host__ __device__ constexpr int fbbev_ffn_lds_bytes() { return ((HC / 16) * 2 * KS1 + MT2 * 2 * (HC / 32)) * 1024 + 4 * 2 * (HC / 32) * 2 * 1024; }
+
+template <int KS1, int MT2, bool LN, int HC>
+__global__ void __launch_bounds__(256, HC == 32 ? 3 : 2)
+k_rows_ffn_x3(const float* __restrict__ x, long long ldx, const unsigned short* __restrict__ w1f, const float* __restrict__ b1,
+              const unsigned short* __restrict__ w2f, const float* __restrict__ b2, float* __restrict__ out, long long ldo,
+              long long rows, int I, int H, int O, int n_kc2, const float* __restrict__ res, long long ld_res,
+              const float* __restrict__ ln_w, const float* __restrict__ ln_b, float ln_eps) {
+    constexpr int NT = 2, T1 = HC / 16, S2 = HC / 32;
+    unsigned short* w1s = reinterpret_cast<unsigned short*>(fbbev_dyn_lds_f32());          // [T1][hi|lo][KS1][64][8]
+    unsigned short* w2s = w1s + T1 * 2 * KS1 * 512;                                        // [MT2][hi|lo][S2][64][8]
+    unsigned short* hb = w2s + MT2 * 2 * S2 * 512 + (threadIdx.x >> 6) * (NT * S2 * 2 * 512);   // this wave's [t][s2][hi|lo][64][8]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = lane >> 4, j = lane & 15;
+    const long long r0 = ((long long)blockIdx.x * 4 + wave) * (16 * NT);
+    // this wave's rows as split B fragments, once
+    fbbev_bf16x8 xh[KS1][NT], xl[KS1][NT];
+    {
+        const fbbev_bf16x8 zero8 = fbbev_cvt_bf16x8(fbbev_v4f{0.f, 0.f, 0.f, 0.f}, fbbev_v4f{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+        for (int s = 0; s < KS1; ++s) {
+            const int c = 32 * s + 8 * g;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const long long r = r0 + 16 * t + j;
+                const bool ok = r < rows && c < I;
+                const float* p = x + (ok ? r * ldx + c : 0);
+                const fbbev_v4f a0 = *reinterpret_cast<const fbbev_v4f*>(p), a1 = *reinterpret_cast<const fbbev_v4f*>(p + 4);
+                fbbev_split_bf16x8(a0, a1, xh[s][t], xl[s][t]);
+                xh[s][t] = ok ? xh[s][t] : zero8;
+                xl[s][t] = ok ? xl[s][t] : zero8;
+            }
+        }
+    }
+    fbbev_v4f acc2[MT2][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT2; ++mt)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc2[mt][t] = fbbev_v4f{0.f, 0.f, 0.f, 0.f};
+    const int n_chunks = H / HC;
+    for (int c = 0; c < n_chunks; ++c) {
+        if (c) __syncthreads();                                                             // the previous chunk's weights are done with
+        // W1 tiles 4c .. 4c+3 (k-steps 0..KS1-1 of their single K chunk), W2 tiles 0..MT2-1 at hidden units [64c, 64c + 64) = k-steps
+        // 2 (c & 1), 2 (c & 1) + 1 of K chunk c / 2; 16-byte pieces, [hi | lo] kept apart as in the fragment arrays
+        for (int i = threadIdx.x; i < T1 * 2 * KS1 * 64; i += 256) {
+            const int ln = i & 63, s = (i >> 6) % KS1, h = (i / (64 * KS1)) & 1, mt = i / (64 * KS1 * 2);
+            const unsigned short* src = w1f + (long long)(T1 * c + mt) * FBBEV_RL_TILE_ELEMS + h * (FBBEV_RL_TILE_ELEMS / 2) + (s * 64 + ln) * 8;
+            reinterpret_cast<fbbev_v4u*>(w1s)[i] = *reinterpret_cast<const fbbev_v4u*>(src);
+        }
+        const int u0 = c * HC, kc2 = u0 >> 7, ks2 = (u0 & 127) >> 5;                        // K chunk / first k-step of the hidden chunk in W2's fragments
+        for (int i = threadIdx.x; i < MT2 * 2 * S2 * 64; i += 256) {
+            const int ln = i & 63, s = (i >> 6) % S2, h = (i / (64 * S2)) & 1, mt = i / (64 * S2 * 2);
+            const unsigned short* src = w2f + ((long long)kc2 * 8 + mt) * FBBEV_RL_TILE_ELEMS + h * (FBBEV_RL_TILE_ELEMS / 2) +
+                                        ((ks2 + s) * 64 + ln) * 8;
+            reinterpret_cast<fbbev_v4u*>(w2s)[i] = *reinterpret_cast<const fbbev_v4u*>(src);
+        }
+        __syncthreads();
+        // GEMM 1 + bias + ReLU -> hidden fragments of this wave
+#pragma unroll
+        for (int mt = 0; mt < T1; ++mt) {
+            fbbev_v4f acc1[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc1[t] = fbbev_v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KS1; ++s) {
+                const fbbev_bf16x8 ah = fbbev_ld_bf16x8(w1s + (((mt * 2 + 0) * KS1 + s) * 64 + lane) * 8);
+                const fbbev_bf16x8 al = fbbev_ld_bf16x8(w1s + (((mt * 2 + 1) * KS1 + s) * 64 + lane) * 8);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    acc1[t] = fbbev_mfma_f32_16x16x32_bf16(al, xh[s][t], acc1[t]);
+                    acc1[t] = fbbev_mfma_f32_16x16x32_bf16(ah, xl[s][t], acc1[t]);
+                    acc1[t] = fbbev_mfma_f32_16x16x32_bf16(ah, xh[s][t], acc1[t]);
+                }
+            }
+            const fbbev_v4f bias4 = *reinterpret_cast<const fbbev_v4f*>(b1 + HC * c + 16 * mt + 4 * g);
+            const int s2 = mt >> 1, gl = 2 * (mt & 1) + (g >> 1), e0 = 4 * (g & 1);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                fbbev_v4f v = acc1[t] + bias4;
+                v = fbbev_v4f{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+                // hi = bf16(v), lo = bf16(v - hi): the split of fbbev_split_bf16x8 on four values
+                fbbev_bf16x8 h8, l8;
+                fbbev_split_bf16x8(v, fbbev_v4f{0.f, 0.f, 0.f, 0.f}, h8, l8);
+                unsigned short* dh = hb + ((((t * S2 + s2) * 2 + 0) * 64 + gl * 16 + j) * 8 + e0);
+                unsigned short* dl = hb + ((((t * S2 + s2) * 2 + 1) * 64 + gl * 16 + j) * 8 + e0);
+                __builtin_memcpy(dh, &h8, 8);                                             // the first four elements
+                __builtin_memcpy(dl, &l8, 8);
+            }
+        }
+        fbbev_wave_sync();
+        // GEMM 2: outputs += W2[:, chunk] . hidden
+#pragma unroll
+        for (int s2 = 0; s2 < S2; ++s2) {
+            fbbev_bf16x8 hh[NT], hl[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                hh[t] = fbbev_ld_bf16x8(hb + (((t * S2 + s2) * 2 + 0) * 64 + lane) * 8);
+                hl[t] = fbbev_ld_bf16x8(hb + (((t * S2 + s2) * 2 + 1) * 64 + lane) * 8);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT2; ++mt) {
+                const fbbev_bf16x8 ah = fbbev_ld_bf16x8(w2s + (((mt * 2 + 0) * S2 + s2) * 64 + lane) * 8);
+                const fbbev_bf16x8 al = fbbev_ld_bf16x8(w2s + (((mt * 2 + 1) * S2 + s2) * 64 + lane) * 8);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    acc2[mt][t] = fbbev_mfma_f32_16x16x32_bf16(al, hh[t], acc2[mt][t]);
+                    acc2[mt][t] = fbbev_mfma_f32_16x16x32_bf16(ah, hl[t], acc2[mt][t]);
+                    acc2[mt][t] = fbbev_mfma_f32_16x16x32_bf16(ah, hh[t], acc2[mt][t]);
+                }
+            }
+        }
+        fbbev_wave_sync();                                                                  // this wave's hidden fragments are read
+    }
+    // epilogue: + b2 (+ residual -> LayerNorm), as k_rows_linear_x3
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const long long r = r0 + 16 * t + j;
+        const bool live = r < rows;
+        fbbev_v4f v[MT2];
+        float s = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT2; ++mt) {
+            const int o = 16 * mt + 4 * g;
+            v[mt] = fbbev_v4f{0.f, 0.f, 0.f, 0.f};
+            if (o < O) {
+                v[mt] = acc2[mt][t] + *reinterpret_cast<const fbbev_v4f*>(b2 + o);
+                if (res && live) v[mt] = v[mt] + *reinterpret_cast<const fbbev_v4f*>(res + r * ld_res + o);
+                s += (v[mt][0] + v[mt][1]) + (v[mt][2] + v[mt][3]);
+            }
+        }
+        if constexpr (LN) {
+            s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+            const float mean = s / (float)O;
+            float q = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MT2; ++mt) {
+                if (16 * mt + 4 * g < O) {
+                    v[mt] = v[mt] - fbbev_v4f{mean, mean, mean, mean};
+                    q += (v[mt][0] * v[mt][0] + v[mt][1] * v[mt][1]) + (v[mt][2] * v[mt][2] + v[mt][3] * v[mt][3]);
+                }
+            }
+            q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+            const float inv = 1.0f / sqrtf(q / (float)O + ln_eps);
+#pragma unroll
+            for (int mt = 0; mt < MT2; ++mt) {
+                const int o = 16 * mt + 4 * g;
+                if (o < O) {
+                    const fbbev_v4f w4 = *reinterpret_cast<const fbbev_v4f*>(ln_w + o), b4 = *reinterpret_cast<const fbbev_v4f*>(ln_b + o);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[mt][e] = v[mt][e] * inv * w4[e] + b4[e];
+                }
+            }
+        }
+        if (!live) continue;
+#pragma unroll
+        for (int mt = 0; mt < MT2; ++mt) {
+            const int o = 16 * mt + 4 * g;
+            if (o < O) *reinterpret_cast<fbbev_v4f*>(out + r * ldo + o) = v[mt];
+        }
+    }
+}

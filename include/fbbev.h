@@ -544,6 +544,15 @@ int fbbev_rows_linear_x3_ln(const float* x, long long x_row_stride, const void* 
                             int in_features, int out_features, const float* residual, long long residual_row_stride,
                             const float* ln_weight, const float* ln_bias, float ln_eps, float* out, long long out_row_stride,
                             fbbev_stream_t stream);
+/* The FFN pair of the encoder layer in ONE kernel: out = [LayerNorm](W2 relu(W1 x + b1) + b2 [+ residual]) -- mmcv FFN as the encoder
+ * layer configures it (Linear + ReLU, Linear, add_identity; bevformer_encoder.py:250-377) and, with ln_weight, the layer's following
+ * LayerNorm.  The hidden rows never leave the CU (as two launches they are written and re-read: 205 MB each way at 160 000 rows).
+ * Fragments: fbbev_rows_linear_x3_fragments of W1 (hidden, in_features) / W2 (out_features, hidden); the split-operand arithmetic
+ * of fbbev_rows_linear_x3 in both GEMMs.  in_features <= 96, hidden % 64 == 0, out_features <= 80. */
+int fbbev_rows_ffn_x3(const float* x, long long x_row_stride, const void* w1_fragments, const float* b1, const void* w2_fragments,
+                      const float* b2, long long rows, int in_features, int hidden, int out_features, const float* residual,
+                      long long residual_row_stride, const float* ln_weight, const float* ln_bias, float ln_eps, float* out,
+                      long long out_row_stride, fbbev_stream_t stream);
 /* fbbev_rows_linear_x3 with the result written as HEAD PLANES: rows = (B*Ncam) x tokens_per_image camera tokens, out_features =
  * M * head_dim in the module's (head, channel) order, out (B*Ncam, M, tokens_per_image, head_dim) -- the value_proj of the
  * cross-attention feeding fbbev_da_cross_attn_fused (spatial_cross_attention_depth.py:522-530). */

@@ -301,6 +301,19 @@ def rows_linear_x3_ln(x, weight, bias, residual, ln_w, ln_b, eps):
     return code, out
 
 
+def rows_ffn_x3(x, w1, b1, w2, b2, residual=None, ln_w=None, ln_b=None, eps=1e-5):
+    f1, p1 = _fragments(w1)
+    f2, p2 = _fragments(w2)
+    R, I = x.shape
+    H, O = w1.shape[0], w2.shape[0]
+    out = torch.full((R, O), float('nan'))
+    code = lib().fbbev_rows_ffn_x3(c_void_p(x.data_ptr()), x.stride(0), p1, p(b1), p2, p(b2), R, I, H, O,
+                                   c_void_p(residual.data_ptr()) if residual is not None else None,
+                                   residual.stride(0) if residual is not None else 0, p(ln_w) if ln_w is not None else None,
+                                   p(ln_b) if ln_b is not None else None, eps, p(out), out.stride(0), None)
+    return code, out
+
+
 def rows_linear_x3_planes(x, weight, bias, tokens_per_image, heads, head_dim):
     frag, fp = _fragments(weight)
     R, I = x.shape

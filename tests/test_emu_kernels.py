@@ -1418,3 +1418,31 @@ def test_rows_linear_layernorm_epilogue_emulated(rows, I, O, with_res):
     assert (out - ref).abs().max().item() <= 5e-5 * max(1.0, ref.abs().max().item()), (out - ref).abs().max().item()
     code, _ = E.rows_linear_x3_ln(x, torch.randn(256, I, generator=g), None, None, torch.ones(256), torch.zeros(256), 1e-5)
     assert code < 0                                                       # wider than one workgroup's output rows: refused
+
+
+@pytest.mark.parametrize('rows,I,H,O,ln,with_res', [(200, 80, 320, 80, True, True), (70, 80, 64, 80, False, True), (33, 64, 128, 48, True, False)])
+def test_rows_ffn_one_kernel_emulated(rows, I, H, O, ln, with_res):
+    """fbbev_rows_ffn_x3: [LayerNorm](W2 relu(W1 x + b1) + b2 [+ residual]) with the hidden rows kept in LDS fragments == the fp32
+    composition in torch within the split-operand arithmetic; rows that do not fill the last tile, one / several hidden chunks."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(rows + H)
+    x = torch.randn(rows, I, generator=g)
+    w1, b1 = torch.randn(H, I, generator=g) / I ** 0.5, torch.randn(H, generator=g) * 0.3
+    w2, b2 = torch.randn(O, H, generator=g) / H ** 0.5, torch.randn(O, generator=g) * 0.3
+    res = torch.randn(rows, O, generator=g) if with_res else None
+    lw, lb = (torch.rand(O, generator=g) + 0.5, torch.randn(O, generator=g) * 0.2) if ln else (None, None)
+    y = F.linear(torch.relu(F.linear(x, w1, b1)), w2, b2)
+    if with_res:
+        y = y + res
+    ref = F.layer_norm(y, (O,), lw, lb, 1e-5) if ln else y
+    import os
+    for hc in ('32', '64'):                                                # hidden units per chunk: both instantiations
+        os.environ['FBBEV_FFN_HC'] = hc
+        try:
+            code, out = E.rows_ffn_x3(x, w1, b1, w2, b2, res, lw, lb, 1e-5)
+        finally:
+            del os.environ['FBBEV_FFN_HC']
+        assert code == 0 and not torch.isnan(out).any()
+        assert (out - ref).abs().max().item() <= 5e-5 * max(1.0, ref.abs().max().item()), (hc, (out - ref).abs().max().item())
+    code, _ = E.rows_ffn_x3(x, torch.randn(100, I, generator=g), torch.zeros(100), torch.randn(O, 100, generator=g), b2)
+    assert code < 0                                                        # hidden width no multiple of 64: refused
