@@ -21,6 +21,7 @@ SIGNATURES = {
     'fbbev_bev_pool_v2_bwd': (c_int, [c_int, c_int] + [c_void_p] * 10 + [c_void_p]),
     'fbbev_lidar_coor': (c_int, [c_void_p] * 9 + [c_int] * 5 + [c_void_p, c_void_p]),
     'fbbev_nchw_to_nhwc': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'fbbev_tokens_from_nchw_levels': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
     'fbbev_tokens_from_nchw': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_void_p, c_int, c_void_p]),
     'fbbev_tokens_from_nchw_pos': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_void_p, c_void_p]),
     'fbbev_rank_workspace_bytes': (c_size_t, [c_int64]),
@@ -609,6 +610,22 @@ def tokens_from_nchw(x, out, out_offset=0, bias=None, pos_bias=None):
             _dev(x, F32, 'x'), _dev(out, F32, 'out'), n, C, HW, stride, int(out_offset),
             None if bias is None else _dev(bias, F32, 'bias'), 0 if bias is None else bias.shape[0], _stream()),
             'fbbev_tokens_from_nchw')
+    return out
+
+
+def tokens_from_nchw_levels(levels, out, bias=None):
+    """levels: list of (n_images, C, HW_l) f32 contiguous tensors (<= 8) -> out (n_images, sum HW_l, C) contiguous, level l at rows
+    [start_l, start_l + HW_l); + bias[img % rows, c] when given.  ONE launch for the whole pyramid (fbbev_tokens_from_nchw_levels)."""
+    n, C = levels[0].shape[:2]
+    hws = [int(t.shape[2]) for t in levels]
+    if any(t.shape[0] != n or t.shape[1] != C for t in levels) or tuple(out.shape) != (n, sum(hws), C) or not out.is_contiguous():
+        raise FbbevError('tokens_from_nchw_levels: levels are (n_images, C, HW_l); out is (n_images, sum HW_l, C) contiguous')
+    ptrs = (c_void_p * len(levels))(*[_dev(t, F32, 'level').value for t in levels])
+    hw = (c_int32 * len(levels))(*hws)
+    with _on(out):
+        _check(lib().fbbev_tokens_from_nchw_levels(ptrs, hw, len(levels), _dev(out, F32, 'out'), n, C,
+                                                   None if bias is None else _dev(bias, F32, 'bias'),
+                                                   0 if bias is None else bias.shape[0], _stream()), 'fbbev_tokens_from_nchw_levels')
     return out
 
 

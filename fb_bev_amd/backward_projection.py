@@ -959,10 +959,14 @@ class BEVFormer(nn.Module):
             rows = torch.empty((bs * ncam, S, c), dtype=torch.float32, device=f0.device)
             ce = self.cams_embeds.detach().to(torch.float32)
             ce = (ce if self.use_cams_embeds else ce * 0).contiguous()
-            start = 0
-            for feat, (h, w) in zip(mlvl_feats, shapes):
-                _capi.tokens_from_nchw(feat.reshape(bs * ncam, c, h * w).contiguous(), rows, start * c, ce)
-                start += h * w
+            if 1 < len(mlvl_feats) <= 8:       # the whole pyramid in one launch
+                _capi.tokens_from_nchw_levels([f.reshape(bs * ncam, c, h * w).contiguous() for f, (h, w) in zip(mlvl_feats, shapes)],
+                                              rows, ce)
+            else:
+                start = 0
+                for feat, (h, w) in zip(mlvl_feats, shapes):
+                    _capi.tokens_from_nchw(feat.reshape(bs * ncam, c, h * w).contiguous(), rows, start * c, ce)
+                    start += h * w
             feat_flatten = rows.view(bs, ncam, S, c).permute(1, 0, 2, 3)            # (num_cam, bs, sum HW, C)
         else:
             feats = []

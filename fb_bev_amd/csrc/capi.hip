@@ -131,6 +131,32 @@ extern "C" int fbbev_tokens_from_nchw(const float* in, float* out, int n_images,
     return tokens_from_nchw_impl(in, out, n_images, C, HW, out_image_stride, out_offset, bias, bias_rows, nullptr, stream_);
 }
 
+// every level of the camera-token pyramid in one launch: level l = in[l] (n_images, C, hw[l]) -> rows [start_l, start_l + hw[l]) of
+// every image's (sum hw, C) token block in `out`, start_l = hw[0] + .. + hw[l-1]; + bias[(img % bias_rows), c] when bias is given
+extern "C" int fbbev_tokens_from_nchw_levels(const float* const* in, const int32_t* hw, int n_levels, float* out, int n_images, int C,
+                                             const float* bias, int bias_rows, fbbev_stream_t stream_) {
+    if (n_levels <= 0 || n_levels > 8 || n_images < 0 || C <= 0 || !in || !hw) return FBBEV_E_BADARG;
+    if (bias && bias_rows <= 0) return FBBEV_E_BADARG;
+    if (n_images == 0) return 0;
+    if (!out) return FBBEV_E_BADARG;
+    fbbev_token_levels lv;
+    const int tc = (C + 31) / 32;
+    long long start = 0, blocks = 0;
+    for (int l = 0; l < 8; ++l) { lv.in[l] = nullptr; lv.out_off[l] = 0; lv.hw[l] = 1; lv.blk0[l] = 0; }
+    for (int l = 0; l < n_levels; ++l) {
+        if (hw[l] <= 0 || !in[l]) return FBBEV_E_BADARG;
+        lv.in[l] = in[l]; lv.hw[l] = hw[l]; lv.out_off[l] = start * C; lv.blk0[l] = (int)blocks;
+        start += hw[l];
+        blocks += (long long)n_images * tc * ((hw[l] + 31) / 32);
+        if (blocks >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
+    }
+    lv.blk0[n_levels] = (int)blocks;
+    lv.n = n_levels;
+    FBBEV_LAUNCH(k_nchw_to_nhwc_levels, blocks, 256, 0, (fbbev_rt_stream)stream_, lv, out, C, tc, start * C, bias, bias ? bias_rows : 1);
+    FBBEV_CHECK_LAUNCH();
+    return 0;
+}
+
 // out[img, p, c] = in[img, c, p] + pos_bias[p, c]: the BEV queries of the backward projection (backward_projection.py:96-99:
 // lss_bev flattened to tokens + the learned bev_embedding) in one transposing pass
 extern "C" int fbbev_tokens_from_nchw_pos(const float* in, float* out, int n_images, int C, int HW, long long out_image_stride,

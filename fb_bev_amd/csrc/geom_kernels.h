@@ -82,6 +82,45 @@ k_lidar_coor(fbbev_cam_ptrs g, int chunks, float* __restrict__ coor) {
     }
 }
 
+// All levels of the camera-token pyramid in ONE launch (round 4): bevformer.py:95-117 runs the flatten / permute / + cams_embeds per
+// level and concatenates; one k_nchw_to_nhwc launch per level cost ~13 us each for a few hundred tokens (latency of a nearly empty
+// launch), four per forward.  Blocks [blk0[l], blk0[l+1]) transpose level l (n_images x C x hw[l]) into rows out_off[l] .. of every
+// image's token block; bias row (img % bias_rows) is added (cams_embeds).
+struct fbbev_token_levels {
+    const float* in[8];
+    long long out_off[8];       // float offset of the level's first token inside an image's block (level_start * C)
+    int hw[8];
+    int blk0[9];
+    int n;
+};
+__global__ void __launch_bounds__(256)
+k_nchw_to_nhwc_levels(fbbev_token_levels lv, float* __restrict__ out, int C, int tiles_c, long long out_image_stride,
+                      const float* __restrict__ bias, int bias_rows) {
+    __shared__ float tile[32][33];
+    int l = 0;
+    while (l + 1 < lv.n && (int)blockIdx.x >= lv.blk0[l + 1]) ++l;
+    const int HW = lv.hw[l], tiles_hw = (HW + 31) / 32;
+    const int t = (int)blockIdx.x - lv.blk0[l];
+    const int img = t / (tiles_c * tiles_hw), r = t - img * (tiles_c * tiles_hw);
+    const int tc = r / tiles_hw, th = r - tc * tiles_hw;
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    const float* src = lv.in[l] + (long long)img * C * HW;
+    float* dst = out + (long long)img * out_image_stride + lv.out_off[l];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = tc * 32 + ly + 8 * k, p = th * 32 + lx;
+        tile[ly + 8 * k][lx] = (c < C && p < HW) ? src[(long long)c * HW + p] : 0.f;
+    }
+    __syncthreads();
+    const int cb = tc * 32 + lx;
+    const float add = (bias != nullptr && cb < C) ? bias[(long long)(img % bias_rows) * C + cb] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int p = th * 32 + ly + 8 * k;
+        if (cb < C && p < HW) dst[(long long)p * C + cb] = tile[lx][ly + 8 * k] + add;
+    }
+}
+
 // ---------------------------------------------------------------- BEV voxel centres -> image points
 // Replaces bevformer_encoder.point_sampling
 // (fbbev/view_transformation/backward_projection/bevformer_utils/bevformer_encoder.py:91-120): three

@@ -114,6 +114,11 @@ int fbbev_tokens_from_nchw(const float* in, float* out, int n_images, int C, int
  * `bev_embedding` (backward_projection.py:96-99) -- in one pass. */
 int fbbev_tokens_from_nchw_pos(const float* in, float* out, int n_images, int C, int HW, long long out_image_stride,
                                long long out_offset, const float* pos_bias, fbbev_stream_t stream);
+/* fbbev_tokens_from_nchw for EVERY level of the camera-token pyramid in one launch (bevformer.py:95-117: per-level flatten / permute /
+ * + cams_embeds, then torch.cat): in[l] is level l as (n_images, C, hw[l]) (HOST array of device pointers, n_levels <= 8); out is
+ * (n_images, sum hw, C); bias as above. */
+int fbbev_tokens_from_nchw_levels(const float* const* in, const int32_t* hw, int n_levels, float* out, int n_images, int C,
+                                  const float* bias, int bias_rows, fbbev_stream_t stream);
 
 /* Replaces LSSViewTransformerFunction3D.voxel_pooling_prepare_v2
  *   -- fbbev/view_transformation/forward_projection/view_transformer.py:547-605

@@ -180,6 +180,17 @@ def da_cross_attn_fwd(value, ss, ls, pred_depth, ref_cam, mask, qdepth, offsets,
     return slots.clone()
 
 
+def tokens_from_nchw_levels(levels, bias=None):
+    n, C = levels[0].shape[:2]
+    hws = [int(t.shape[2]) for t in levels]
+    out = torch.full((n, sum(hws), C), float('nan'))
+    ptrs = (c_void_p * len(levels))(*[t.data_ptr() for t in levels])
+    hw = (ctypes.c_int32 * len(levels))(*hws)
+    code = lib().fbbev_tokens_from_nchw_levels(ptrs, hw, len(levels), p(out), n, C, p(bias) if bias is not None else None,
+                                               bias.shape[0] if bias is not None else 0, None)
+    return code, out
+
+
 def point_sampling(xs, ys, zs, cam, ogfH, ogfW):
     rots, trans, intrins, post_rots, post_trans, bda = cam
     B, N = trans.shape[:2]

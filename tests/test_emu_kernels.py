@@ -1446,3 +1446,19 @@ def test_rows_ffn_one_kernel_emulated(rows, I, H, O, ln, with_res):
         assert (out - ref).abs().max().item() <= 5e-5 * max(1.0, ref.abs().max().item()), (hc, (out - ref).abs().max().item())
     code, _ = E.rows_ffn_x3(x, torch.randn(100, I, generator=g), torch.zeros(100), torch.randn(O, 100, generator=g), b2)
     assert code < 0                                                        # hidden width no multiple of 64: refused
+
+
+def test_token_pyramid_in_one_launch_emulated():
+    """fbbev_tokens_from_nchw_levels == the per-level flatten(3).permute + cams_embeds + cat of bevformer.py:95-117 (bit-exact), for
+    level sizes that are / are not multiples of the 32-wide transpose tile and a channel count that is not."""
+    g = torch.Generator().manual_seed(7)
+    n, C = 6, 80
+    shapes = [(5, 9), (8, 4), (1, 3), (2, 2)]
+    levels = [torch.randn(n, C, h * w, generator=g) for h, w in shapes]
+    bias = torch.randn(3, C, generator=g)
+    code, out = E.tokens_from_nchw_levels(levels, bias)
+    assert code == 0
+    exp = torch.cat([t.permute(0, 2, 1) for t in levels], 1) + bias[torch.arange(n) % 3][:, None, :]
+    assert torch.equal(out, exp)
+    code, out = E.tokens_from_nchw_levels(levels[:2], None)
+    assert code == 0 and torch.equal(out, torch.cat([t.permute(0, 2, 1) for t in levels[:2]], 1))
