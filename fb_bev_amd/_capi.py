@@ -43,6 +43,8 @@ SIGNATURES = {
                                             c_void_p]),
     'fbbev_bev_pool_v2_dense_fwd_add': (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_void_p, c_int64, c_int64, c_void_p,
                                                 c_size_t, c_int, c_int, c_void_p, c_void_p]),
+    'fbbev_pool_zmean_split': (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_void_p, c_size_t,
+                                       c_void_p]),
     'fbbev_pool_zmean': (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
     'fbbev_pool_dense_bwd_workspace_bytes': (c_size_t, [c_int] * 9),
     'fbbev_bev_pool_v2_dense_bwd': (c_int, [c_void_p, c_int64, c_int64] + [c_void_p] * 6 + [c_int] * 10 +
@@ -312,10 +314,24 @@ def pool_tile_index(interval_rank, interval_starts, counts, n_intervals_max, B, 
 
 
 def pool_zmean(depth, feat, ranks_depth, ranks_feat, interval_rank, interval_starts, interval_lengths, B, C, Z, Y, X,
-               out_mean, tile_ws, tile_voxels=64, flags=DEFAULT_POOL_FLAGS):
-    """out_mean (B,C,Y,X) f32 contiguous = mean over z of the pooled sums (tile index of the same tile_voxels in tile_ws)."""
+               out_mean, tile_ws, tile_voxels=64, flags=DEFAULT_POOL_FLAGS, z_groups=1, partial=None):
+    """out_mean (B,C,Y,X) f32 contiguous = mean over z of the pooled sums (tile index of the same tile_voxels in tile_ws).
+    z_groups > 1: the planes of a tile go to z_groups workgroups (fbbev_pool_zmean_split); partial = f32 buffer of >= z_groups * out numel."""
     if tuple(out_mean.shape) != (B, C, Y, X):
         raise FbbevError('out_mean must be (B,C,Y,X)')
+    fl = int(flags) & ~(POOL_OUT_BF16 | POOL_OUT_F16 | POOL_SPLIT_LONG | POOL_PIPE)
+    if z_groups > 1:
+        if partial is None or partial.dtype != F32 or partial.numel() < z_groups * out_mean.numel():
+            raise FbbevError('pool_zmean: z_groups > 1 needs a float32 partial buffer of z_groups * B*C*Y*X elements')
+        with _on(depth):
+            _check(lib().fbbev_pool_zmean_split(
+                _dev(depth, F32, 'depth'), _dev(feat, F32, 'feat'), _dev(ranks_depth, I32, 'ranks_depth'),
+                _dev(ranks_feat, I32, 'ranks_feat'), _dev(interval_rank, I32, 'interval_rank'),
+                _dev(interval_starts, I32, 'interval_starts'), _dev(interval_lengths, I32, 'interval_lengths'),
+                B, C, Z, Y, X, _dev(out_mean, F32, 'out_mean'), c_void_p(tile_ws.data_ptr()),
+                tile_ws.numel() * tile_ws.element_size(), int(tile_voxels), fl, int(z_groups), c_void_p(partial.data_ptr()),
+                partial.numel() * 4, _stream()), 'fbbev_pool_zmean_split')
+        return out_mean
     with _on(depth):
         _check(lib().fbbev_pool_zmean(
             _dev(depth, F32, 'depth'), _dev(feat, F32, 'feat'), _dev(ranks_depth, I32, 'ranks_depth'),

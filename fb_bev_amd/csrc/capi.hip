@@ -902,11 +902,42 @@ extern "C" int fbbev_bev_pool_v2_dense_fwd_add(const float* depth, const float* 
                                stream_);
 }
 
+static int pool_zmean_impl(const float* depth, const float* feat, const int32_t* ranks_depth,
+                           const int32_t* ranks_feat, const int32_t* interval_rank,
+                           const int32_t* interval_starts, const int32_t* interval_lengths, int B, int C, int Z,
+                           int Y, int X, float* out_mean, const void* tile_ws, size_t tile_ws_bytes,
+                           int tile_voxels, int flags, int z_groups, float* partial, size_t partial_bytes, fbbev_stream_t stream_);
+
 extern "C" int fbbev_pool_zmean(const float* depth, const float* feat, const int32_t* ranks_depth,
                                 const int32_t* ranks_feat, const int32_t* interval_rank,
                                 const int32_t* interval_starts, const int32_t* interval_lengths, int B, int C, int Z,
                                 int Y, int X, float* out_mean, const void* tile_ws, size_t tile_ws_bytes,
                                 int tile_voxels, int flags, fbbev_stream_t stream_) {
+    return pool_zmean_impl(depth, feat, ranks_depth, ranks_feat, interval_rank, interval_starts, interval_lengths, B, C, Z, Y, X,
+                           out_mean, tile_ws, tile_ws_bytes, tile_voxels, flags, 1, nullptr, 0, stream_);
+}
+
+// fbbev_pool_zmean with the Z planes of a tile dealt to z_groups workgroups (each walks ceil(Z / z_groups) planes) and a caller-owned
+// partial buffer of z_groups * B*C*Y*X floats; a second small kernel adds the groups in order and divides by Z.  For grids with few
+// tiles (the shipped 100x100x8 grid): the single pass is one Z-plane latency chain per workgroup.
+extern "C" int fbbev_pool_zmean_split(const float* depth, const float* feat, const int32_t* ranks_depth,
+                                      const int32_t* ranks_feat, const int32_t* interval_rank,
+                                      const int32_t* interval_starts, const int32_t* interval_lengths, int B, int C, int Z,
+                                      int Y, int X, float* out_mean, const void* tile_ws, size_t tile_ws_bytes,
+                                      int tile_voxels, int flags, int z_groups, void* partial_ws, size_t partial_ws_bytes,
+                                      fbbev_stream_t stream_) {
+    if (z_groups < 1 || z_groups > 64) return FBBEV_E_BADARG;
+    if (z_groups > 1 && (!partial_ws || !aligned16(partial_ws))) return FBBEV_E_BADARG;
+    return pool_zmean_impl(depth, feat, ranks_depth, ranks_feat, interval_rank, interval_starts, interval_lengths, B, C, Z, Y, X,
+                           out_mean, tile_ws, tile_ws_bytes, tile_voxels, flags, z_groups, static_cast<float*>(partial_ws),
+                           partial_ws_bytes, stream_);
+}
+
+static int pool_zmean_impl(const float* depth, const float* feat, const int32_t* ranks_depth,
+                           const int32_t* ranks_feat, const int32_t* interval_rank,
+                           const int32_t* interval_starts, const int32_t* interval_lengths, int B, int C, int Z,
+                           int Y, int X, float* out_mean, const void* tile_ws, size_t tile_ws_bytes,
+                           int tile_voxels, int flags, int z_groups, float* partial, size_t partial_bytes, fbbev_stream_t stream_) {
     if (B <= 0 || C <= 0 || Z <= 0 || Y <= 0 || X <= 0) return FBBEV_E_BADARG;
     if (!depth || !feat || !ranks_depth || !ranks_feat || !interval_rank || !interval_starts || !interval_lengths ||
         !out_mean || !tile_ws) return FBBEV_E_BADARG;
@@ -928,16 +959,25 @@ extern "C" int fbbev_pool_zmean(const float* depth, const float* feat, const int
     const size_t lds = ((size_t)CC * (TV + 4) + 3 * (size_t)TV + 2 * FBBEV_NP_STAGE) * sizeof(float);
     if (lds > 64 * 1024) return FBBEV_E_UNSUPPORTED;
     const long long blocks = (long long)B * tiles_per_plane * csplit;
+    if (z_groups > Z) z_groups = Z;
+    const long long n_out = (long long)B * C * yx;
+    if (z_groups > 1 && partial_bytes < (size_t)z_groups * n_out * sizeof(float)) return FBBEV_E_WORKSPACE;
+    if (blocks * z_groups >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
     const int* meta = static_cast<const int*>(tile_ws);
 #define FBBEV_ZMEAN(TV_, CPL_)                                                                                       \
-    FBBEV_LAUNCH((k_pool_zmean<TV_, CPL_, 256>), blocks, 256, lds, (fbbev_rt_stream)stream_, C, Z, (int)yx,           \
+    FBBEV_LAUNCH((k_pool_zmean<TV_, CPL_, 256>), blocks * z_groups, 256, lds, (fbbev_rt_stream)stream_, C, Z, (int)yx, \
                  tiles_per_plane, csplit, (int)blocks, depth, feat, ranks_depth, ranks_feat, interval_rank,          \
-                 interval_starts, interval_lengths, meta, out_mean)
+                 interval_starts, interval_lengths, meta, out_mean, z_groups, partial)
     if (TV == 64) { if (cpl8) FBBEV_ZMEAN(64, 8); else FBBEV_ZMEAN(64, 4); }
     else if (TV == 128) { if (cpl8) FBBEV_ZMEAN(128, 8); else FBBEV_ZMEAN(128, 4); }
     else { if (cpl8) FBBEV_ZMEAN(256, 8); else FBBEV_ZMEAN(256, 4); }
 #undef FBBEV_ZMEAN
     FBBEV_CHECK_LAUNCH();
+    if (z_groups > 1) {
+        FBBEV_LAUNCH(k_pool_zmean_reduce, (n_out / 4 + 255) / 256, 256, 0, (fbbev_rt_stream)stream_, (const float*)partial, n_out,
+                     z_groups, (float)Z, out_mean);
+        FBBEV_CHECK_LAUNCH();
+    }
     return 0;
 }
 

@@ -699,6 +699,8 @@ k_pool_fwd_dense_pipe(int C, int Z, int YX, int tiles_per_plane, int csplit, int
     }
 }
 
+__host__ __device__ inline long long gridDim_stride(int n_blocks, int csplit, int tiles_per_plane) { return n_blocks / (csplit * tiles_per_plane); }   // = B
+
 // ================================================================ Z-mean of the pooled volume without the volume
 // lss_bev = bev_feat.mean(-1) (fbocc.py:359: the backward projection's input) computed straight from the index
 // tensors: a workgroup owns TV consecutive (y,x) voxels x CC channels and walks the Z planes in ascending order,
@@ -712,7 +714,13 @@ k_pool_zmean(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_blocks
              const float* __restrict__ depth, const float* __restrict__ feat,
              const int* __restrict__ rd, const int* __restrict__ rf,
              const int* __restrict__ interval_rank, const int* __restrict__ starts,
-             const int* __restrict__ lengths, const int* __restrict__ tile_meta, float* __restrict__ out) {
+             const int* __restrict__ lengths, const int* __restrict__ tile_meta, float* __restrict__ out, int z_groups,
+             float* __restrict__ partial) {
+    // z_groups > 1 (round 4): the Z planes of a tile are walked ONE AFTER THE OTHER (two barriers and two dependent memory round
+    // trips per plane), so with few tiles -- the shipped grid at B = 1 has 157 -- the launch is one 8-plane latency chain per CU and
+    // was the largest kernel of the shipped-shape forward+backward projection (106 us).  Then workgroup (tile, zg) takes the planes
+    // [zg * ceil(Z / z_groups), ...) and writes its raw sums to partial[zg][b][c][y][x]; k_pool_zmean_reduce adds the groups in
+    // order and divides by Z.  (z_groups == 1: the original single pass; the association of the z sum differs between the two.)
     constexpr int LD = TV + 4;
     constexpr int Q4 = TV / 4;
     const int CC = C / csplit;
@@ -723,15 +731,18 @@ k_pool_zmean(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_blocks
     int* prd = ivx + TV;
     int* prf = prd + FBBEV_NP_STAGE;
     const int tid = threadIdx.x;
-    const int bid = blockIdx.x;
-    if (bid >= n_blocks) return;
+    const int bid0 = blockIdx.x;
+    if (bid0 >= n_blocks * z_groups) return;
+    const int zg = bid0 / n_blocks, bid = bid0 - zg * n_blocks;
     const int tk = bid / csplit, half = bid - tk * csplit;      // tk = b * tiles_per_plane + k
     const int c0 = half * CC;
     const int b = tk / tiles_per_plane, k = tk - b * tiles_per_plane;
     const int v0 = k * TV;
     const int nv = (YX - v0 < TV) ? (YX - v0) : TV;
+    const int zper = (Z + z_groups - 1) / z_groups;
+    const int z_lo = zg * zper, z_hi = z_lo + zper < Z ? z_lo + zper : Z;
     for (int idx = tid; idx < CC * LD; idx += NT) tile[idx] = 0.f;
-    for (int z = 0; z < Z; ++z) {
+    for (int z = z_lo; z < z_hi; ++z) {
         const int plane = b * Z + z;
         const int t = plane * tiles_per_plane + k;
         const int i0 = tile_meta[2 * t], p0 = tile_meta[2 * t + 1];
@@ -766,8 +777,9 @@ k_pool_zmean(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_blocks
         }
     }
     __syncthreads();
-    const float zf = (float)Z;
-    float* __restrict__ ob = out + ((long long)b * C + c0) * YX + v0;
+    const float zf = z_groups > 1 ? 1.f : (float)Z;
+    float* __restrict__ ob = (z_groups > 1 ? partial + (long long)zg * gridDim_stride(n_blocks, csplit, tiles_per_plane) * C * YX : out) +
+                             ((long long)b * C + c0) * YX + v0;
     for (int idx = tid; idx < CC * Q4; idx += NT) {
         const int c = idx / Q4, j = (idx - c * Q4) * 4;
         if (j < nv) {
@@ -776,6 +788,17 @@ k_pool_zmean(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_blocks
             *reinterpret_cast<fbbev_v4f*>(ob + (long long)c * YX + j) = val;
         }
     }
+}
+
+// out[i] = (partial[0][i] + partial[1][i] + ... in group order) / Z over n = B*C*Y*X floats (n % 4 == 0)
+__global__ void __launch_bounds__(256)
+k_pool_zmean_reduce(const float* __restrict__ partial, long long n, int z_groups, float zf, float* __restrict__ out) {
+    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    fbbev_v4f acc = *reinterpret_cast<const fbbev_v4f*>(partial + i);
+    for (int g = 1; g < z_groups; ++g) acc += *reinterpret_cast<const fbbev_v4f*>(partial + (long long)g * n + i);
+    acc[0] /= zf; acc[1] /= zf; acc[2] /= zf; acc[3] /= zf;
+    *reinterpret_cast<fbbev_v4f*>(out + i) = acc;
 }
 
 // ================================================================ fused dense forward, channels-last

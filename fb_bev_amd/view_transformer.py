@@ -122,6 +122,11 @@ class LiftSplat(torch.autograd.Function):
 
 
 
+import os as _os
+_ZMEAN_CSPLIT = int(_os.environ.get('FBBEV_ZMEAN_CSPLIT', '0'))      # tuning knob: channel groups of the Z-mean kernel
+_ZMEAN_ZGROUPS = int(_os.environ.get('FBBEV_ZMEAN_ZGROUPS', '0'))    # tuning knob: workgroups the Z planes of a tile are dealt to (0 = heuristic)
+
+
 class LSSViewTransformerFunction3D(nn.Module):
     """Lift-Splat view transformer with a 3-D (X,Y,Z) voxel grid -- view_transformer.py:315-663.
 
@@ -430,8 +435,32 @@ class LSSViewTransformerFunction3D(nn.Module):
         B, C = depth.shape[0], feat.shape[-1]
         Z, Y, X = self.grid_zyx
         out = torch.empty((B, C, Y, X), dtype=torch.float32, device=depth.device)
+        flags = self.pool_flags
+        if _ZMEAN_CSPLIT:
+            flags = (flags & ~0xF0) | ((_ZMEAN_CSPLIT & 0xF) << 4)
+        self._C_hint = C
+        zg = _ZMEAN_ZGROUPS if _ZMEAN_ZGROUPS else self._zmean_z_groups(B, Z, Y * X)
+        partial = None
+        if zg > 1:
+            key = (zg, out.numel(), depth.device)
+            if getattr(self, '_zmean_partial_key', None) != key:
+                self._zmean_partial = torch.empty(zg * out.numel(), dtype=torch.float32, device=depth.device)
+                self._zmean_partial_key = key
+            partial = self._zmean_partial
         return _capi.pool_zmean(depth, feat, idx.ranks_depth, idx.ranks_feat, idx.interval_rank, idx.interval_starts,
-                                idx.interval_lengths, B, C, Z, Y, X, out, tile_ws, self._wo_tile, self.pool_flags)
+                                idx.interval_lengths, B, C, Z, Y, X, out, tile_ws, self._wo_tile, flags, z_groups=zg, partial=partial)
+
+    def _zmean_z_groups(self, B, Z, YX):
+        """fbbev_pool_zmean walks the Z planes of a tile one after the other (two barriers + two dependent round trips per plane): with
+        few tiles -- the shipped grid at B = 1 has 157 -- the launch is one Z-plane latency chain per CU (106 us, the largest kernel
+        of the shipped-shape S3).  Then every plane gets its own workgroup and a small reduce kernel adds the partial sums; with
+        many tiles (BASELINE configs[2]: 1 252 at B = 4) the partial buffer would cost more than the chains."""
+        # measured (profiles/r04_zmean_zsplit.jsonl, r04_zmean_zgroups.jsonl): shipped grid B = 1: S3 0.416 -> 0.366 ms, B = 4: 0.567 ->
+        # 0.543 ms with one workgroup per plane; BASELINE configs[2] grid B = 1 (313 tiles, 205 MB of partial sums): 0.568 -> 0.64 ms,
+        # shipped grid B = 16 (2 512 tiles): 1.38 -> 1.47 ms -- so: few tiles AND a partial buffer of at most 128 MB
+        tiles = B * ((YX + self._wo_tile - 1) // self._wo_tile)
+        partial_bytes = Z * B * self._C_hint * YX * 4 if getattr(self, '_C_hint', None) else 0
+        return Z if (tiles <= 1024 and partial_bytes <= (128 << 20)) else 1
 
     def pooled_volume(self, parts, addend=None):
         """The (B,C,Y,X,Z) view of the volume, written once; addend (B,C,Y,X) is added broadcast over z in the store."""

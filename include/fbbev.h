@@ -234,6 +234,15 @@ int fbbev_pool_zmean(const float* depth, const float* feat, const int32_t* ranks
                      const int32_t* interval_rank, const int32_t* interval_starts, const int32_t* interval_lengths,
                      int B, int C, int Z, int Y, int X, float* out_mean, const void* tile_ws, size_t tile_ws_bytes,
                      int tile_voxels, int flags, fbbev_stream_t stream);
+/* fbbev_pool_zmean with the Z planes of a tile dealt to z_groups workgroups (each walks ceil(Z / z_groups) planes) + a caller-owned
+ * partial buffer of z_groups * B*C*Y*X floats; a second small kernel adds the groups in order and divides by Z.  For grids with
+ * few tiles (the shipped 100x100x8 grid at small batch), where the single pass is one Z-plane latency chain per workgroup.  The
+ * association of the z sum differs from the single pass (fp32 rounding); z_groups = 1 is fbbev_pool_zmean. */
+int fbbev_pool_zmean_split(const float* depth, const float* feat, const int32_t* ranks_depth, const int32_t* ranks_feat,
+                           const int32_t* interval_rank, const int32_t* interval_starts, const int32_t* interval_lengths,
+                           int B, int C, int Z, int Y, int X, float* out_mean, const void* tile_ws, size_t tile_ws_bytes,
+                           int tile_voxels, int flags, int z_groups, void* partial_ws, size_t partial_ws_bytes,
+                           fbbev_stream_t stream);
 int fbbev_bev_pool_v2_dense_fwd_add(const float* depth, const float* feat, const int32_t* ranks_depth,
                                     const int32_t* ranks_feat, const int32_t* interval_rank,
                                     const int32_t* interval_starts, const int32_t* interval_lengths, int B, int C,

@@ -62,10 +62,17 @@ def pool_bwd(out_grad, depth_grad, feat_grad, depth, feat, rd, rf, rb, st, ln):
                                    p(rf), p(rb), p(st), p(ln), p(depth_grad), p(feat_grad), None))
 
 
-def pool_zmean(depth, feat, rd, rf, ir, st, ln, counts, n_max, B, C, Z, Y, X, tile_voxels, flags=0):
+def pool_zmean(depth, feat, rd, rf, ir, st, ln, counts, n_max, B, C, Z, Y, X, tile_voxels, flags=0, z_groups=1):
     out = torch.full((B, C, Y, X), float('nan'))
     ws = torch.zeros(lib().fbbev_pool_dense_workspace_bytes(B, Z, Y, X), dtype=torch.uint8)
     ok(lib().fbbev_pool_tile_index(p(ir), p(st), p(counts), n_max, B, Z, Y, X, tile_voxels, flags, p(ws), ws.numel(), None))
+    if z_groups > 1:
+        partial = torch.full((z_groups * out.numel() + 4,), float('nan'))
+        off = (-partial.data_ptr() // 4) % 4
+        code = lib().fbbev_pool_zmean_split(p(depth), p(feat), p(rd), p(rf), p(ir), p(st), p(ln), B, C, Z, Y, X, p(out), p(ws),
+                                            ws.numel(), tile_voxels, flags, z_groups, c_void_p(partial.data_ptr() + 4 * off),
+                                            z_groups * out.numel() * 4, None)
+        return code, out
     code = lib().fbbev_pool_zmean(p(depth), p(feat), p(rd), p(rf), p(ir), p(st), p(ln), B, C, Z, Y, X, p(out), p(ws),
                                   ws.numel(), tile_voxels, flags, None)
     return code, out

@@ -862,6 +862,11 @@ def test_pool_zmean_and_add_epilogue_emulated(name, tv, flags):
     assert code == 0 and not torch.isnan(mean).any()
     assert torch.allclose(mean, vol.mean(2), atol=1e-6, rtol=1e-5)
     assert torch.allclose(mean, vol.double().sum(2).float() / Z, atol=1e-6, rtol=1e-5)
+    # fbbev_pool_zmean_split: the planes of a tile dealt to 2 / 3 / Z workgroups + the ordered reduce (another association of the z sum)
+    for zg in (2, 3, Z):
+        code, m2 = E.pool_zmean(depth, feat, rd, rf, ir, st, ln, counts, st.numel(), B, C, Z, Y, X, tv, flags, z_groups=zg)
+        assert code == 0 and not torch.isnan(m2).any(), zg
+        assert torch.allclose(m2, vol.double().sum(2).float() / Z, atol=1e-6, rtol=1e-5), zg
     addend = torch.randn(B, C, Y, X, generator=torch.Generator().manual_seed(3))
     code, out = E.pool_dense(depth, feat, rd, rf, ir, st, ln, counts, st.numel(), B, C, Z, Y, X, tv, flags, addend=addend)
     assert code == 0
