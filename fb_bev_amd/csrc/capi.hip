@@ -1617,13 +1617,168 @@ static bool da_bwd_tile_plan(int B, int Ncam, int S, int M, int Dh, int Q, int H
     return true;
 }
 
+// ---- output-owned planes (k_da_bwd_scatter_owned; FBBEV_DA_BWD_OWNED=0 restores the chunked scatter above)
+struct da_own_plan { fbbev_da_bwd_region_tab tab; int threads, info_stride; size_t lds, off_list, off_count, off_gmax, ws; };
+// FBBEV_DA_BWD_OWNED: 1 = whenever the shape is supported, 0 = never, unset = when the launch has at least one workgroup per CU
+// (the shipped single-level shape at B = 4 has 192 (sample, camera, head) planes: the chunked scatter's 512 workgroups win there)
+static int da_bwd_owned_mode() {
+#ifdef FBBEV_TEST_OVERRIDES
+    const char* e = getenv("FBBEV_DA_BWD_OWNED"); return e ? (atoi(e) != 0 ? 1 : 0) : -1;
+#else
+    static const int mode = [] { const char* e = getenv("FBBEV_DA_BWD_OWNED"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+    return mode;
+#endif
+}
+// LDS bytes of an owned plane: 136 KB = one 512-thread workgroup per CU; fewer, larger regions beat two workgroups per CU
+// (configs[2] pyramid: 1.06 ms at 136 KB / 512 threads, 1.38 ms at 68 KB / 256, 2.18 ms at 68 KB / 512, 3.47 ms at 34 KB)
+static int da_own_plane_kb() { const int v = da_bwd_env().lds_kb; return v >= 8 && v <= 144 ? v : 136; }
+static bool da_own_plan_make(int B, int Ncam, int S, int M, int Dh, int Q, int HS, int L, int P, int Za, const int32_t* level_hw,
+                             da_own_plan* pl) {
+    const int mode = da_bwd_owned_mode();
+    if (mode == 0) return false;
+    if (Dh > 16 || HS % 4 != 0 || HS > 16 || Q <= 0 || P > FBBEV_DA_BWD_MAXP || !(Dh == 10 || Dh == 8 || Dh == 16 || Dh == 4)) return false;
+    pl->info_stride = 8;
+    if (1 + Za > pl->info_stride || Za > FBBEV_DA_MAX_ZA) return false;
+    const size_t budget_bytes = (size_t)da_own_plane_kb() * 1024;
+    int budget = (int)(budget_bytes / (HS * sizeof(long long))) - 8;             // tokens per LDS plane (64-bit words, skewed)
+    { const int v = da_bwd_env().tokens; if (v > 0 && v < budget) budget = v; }   // tests: force bands
+    // one region per level (a level larger than the budget: bands of rows), so that every level gets the copies its size allows
+    da_region reg[24];
+    int n = 0;
+    if (!level_hw) {
+        if (S > budget) return false;
+        reg[n++] = {0, L, 0, S};
+    } else {
+        int start = 0;
+        for (int l = 0; l < L; ++l) {
+            const int h = level_hw[2 * l], w = level_hw[2 * l + 1];
+            if (h <= 0 || w <= 0) return false;
+            const int cnt = h * w, rows = cnt > budget ? budget / w : h;
+            if (rows < 1) return false;
+            for (int r = 0; r < h; r += rows) {
+                if (n == 24) return false;
+                reg[n++] = {l, l + 1, start + r * w, start + (r + rows < h ? r + rows : h) * w};
+            }
+            start += cnt;
+        }
+        if (start != S) return false;
+    }
+    // small regions first in the launch order: their adds collide most, they run longest
+    for (int i = 1; i < n; ++i)
+        for (int j = i; j > 0 && reg[j].tok1 - reg[j].tok0 < reg[j - 1].tok1 - reg[j - 1].tok0; --j) { const da_region t = reg[j]; reg[j] = reg[j - 1]; reg[j - 1] = t; }
+    size_t lds = 0;
+    pl->tab.n = n;
+    pl->tab.perm = 0u;
+    for (int i = 0; i < n; ++i) {
+        // lane -> hit permutation (spreads neighbouring queries over the waves) for whole levels only: in a BAND of rows it costs
+        // more than it saves -- consecutive hits sample neighbouring rows, so whole waves skip the corners outside the band (-5 %)
+        const bool band = level_hw && (reg[i].tok1 - reg[i].tok0) != level_hw[2 * reg[i].lvl0] * level_hw[2 * reg[i].lvl0 + 1];
+        if (!band) pl->tab.perm |= 1u << i;
+        const size_t one = (size_t)FBBEV_DA_PLANE_WORDS(reg[i].tok1 - reg[i].tok0, HS) * sizeof(long long);
+        int copies = (int)(budget_bytes / one);
+        copies = copies < 1 ? 1 : (copies > 16 ? 16 : copies);
+        { const int v = da_bwd_env().copies; if (v >= 1 && v < copies) copies = v; }
+        pl->tab.lvl0[i] = reg[i].lvl0; pl->tab.lvl1[i] = reg[i].lvl1; pl->tab.tok0[i] = reg[i].tok0; pl->tab.tok1[i] = reg[i].tok1;
+        pl->tab.copies[i] = copies;
+        lds = one * copies > lds ? one * copies : lds;
+    }
+    if (lds > budget_bytes + 12 * 1024) return false;
+    pl->lds = lds;
+    pl->threads = 512;
+    { const int v = da_bwd_env().threads; if (v == 256 || v == 512) pl->threads = v; }
+    if ((long long)n * B * Ncam * M >= (1ll << 31) || (long long)B * Ncam * Q >= (1ll << 31)) return false;
+    if (mode < 0 && (long long)n * B * Ncam * M < 256) return false;              // too few planes to fill the chip: chunked scatter
+    pl->off_list = align_up((size_t)B * Ncam * Q * pl->info_stride * sizeof(float), 256);
+    pl->off_count = pl->off_list + align_up((size_t)B * Ncam * Q * sizeof(int), 256);
+    pl->off_gmax = pl->off_count + align_up((size_t)B * Ncam * sizeof(int), 256);
+    pl->ws = pl->off_gmax + 256;
+    return true;
+}
+
 extern "C" size_t fbbev_da_cross_attn_bwd_ws_bytes(int B, int Ncam, int S, int M, int Dh, int Q, int head_stride,
                                                    int num_levels, int num_points, const int32_t* level_hw_host) {
     if (B <= 0 || Ncam <= 0 || S <= 0 || M <= 0 || Dh <= 0 || num_levels <= 0 || num_points <= 0) return 0;
     da_bwd_plan pl;
     const int HS = head_stride == 0 ? Dh : head_stride;
-    if (HS < Dh || !da_bwd_tile_plan(B, Ncam, S, M, Dh, Q, HS, num_levels, num_points, level_hw_host, &pl)) return 0;
+    if (HS < Dh) return 0;
+    da_own_plan op;       // Za is not an argument here: the table stride covers Za <= 7, the launch checks it
+    if (da_own_plan_make(B, Ncam, S, M, Dh, Q, HS, num_levels, num_points, 1, level_hw_host, &op)) return op.ws;
+    if (!da_bwd_tile_plan(B, Ncam, S, M, Dh, Q, HS, num_levels, num_points, level_hw_host, &pl)) return 0;
     return pl.ws;
+}
+
+// (A) of both LDS-plane backward routes: unit-owned gradients (offsets / attention / depth distribution), the forward's launch shape
+static int da_bwd_unit_launch(fbbev_rt_stream stream, const float* value, const int64_t* spatial_shapes,
+                              const int64_t* level_start_index, const float* pred_depth, const float* ref_cam, const uint8_t* mask,
+                              const float* qdepth, const float* offsets, const float* attn, const float* grad_slots, int B,
+                              int Ncam, int S, int M, int Dh, int L, int Q, int P, int Za, int DC, float d0, float dstep,
+                              int head_minor, int HS, float* grad_pred_depth, float* grad_offsets, float* grad_attn,
+                              unsigned int* gmax_bits) {
+    // (A) unit-owned gradients, the forward's launch shape
+    const long long units = (long long)B * Q * M;
+    long long ub = ((units + 255) / 256 + 7) / 8 * 8;
+    if (ub > 65536) ub = 65536;
+    const size_t lds_a = (size_t)256 * (4 * P + 1) * sizeof(float);
+    const bool qi = (head_minor & 4) != 0;
+#define FBBEV_DA_BWD_UNIT(DH_)                                                                                          \
+    do {                                                                                                                \
+    if (qi) FBBEV_LAUNCH((k_da_cross_attn_bwd_unit<DH_, true>), ub, 256, lds_a, stream, units, value, spatial_shapes, \
+                         level_start_index, pred_depth, ref_cam, mask, qdepth, offsets, attn, grad_slots, B, Ncam, S, M, \
+                         L, Q, P, Za, DC, d0, dstep, head_minor & 3, HS, grad_pred_depth, grad_offsets, grad_attn, gmax_bits); \
+    else FBBEV_LAUNCH((k_da_cross_attn_bwd_unit<DH_, false>), ub, 256, lds_a, stream, units, value, spatial_shapes, \
+                      level_start_index, pred_depth, ref_cam, mask, qdepth, offsets, attn, grad_slots, B, Ncam, S, M, \
+                      L, Q, P, Za, DC, d0, dstep, head_minor & 3, HS, grad_pred_depth, grad_offsets, grad_attn, gmax_bits); \
+    } while (0)
+    if (Dh == 10) FBBEV_DA_BWD_UNIT(10);
+    else if (Dh == 8) FBBEV_DA_BWD_UNIT(8);
+    else if (Dh == 4) FBBEV_DA_BWD_UNIT(4);
+    else FBBEV_DA_BWD_UNIT(16);
+#undef FBBEV_DA_BWD_UNIT
+    FBBEV_CHECK_LAUNCH();
+    return 0;
+}
+
+// output-owned route: unit gradients, then init + hit lists + ONE scatter launch over every token region
+static int da_bwd_owned_launch(const da_own_plan& op, fbbev_rt_stream stream, const float* value, const int64_t* spatial_shapes,
+                               const int64_t* level_start_index, const float* pred_depth, const float* ref_cam, const uint8_t* mask,
+                               const float* qdepth, const float* offsets, const float* attn, const float* grad_slots, int B,
+                               int Ncam, int S, int M, int Dh, int L, int Q, int P, int Za, int DC, float d0, float dstep,
+                               int head_minor, int HS, float* grad_value, float* grad_pred_depth, float* grad_offsets,
+                               float* grad_attn, void* ws) {
+    char* w = static_cast<char*>(ws);
+    float* info = reinterpret_cast<float*>(w);
+    int* hit_list = reinterpret_cast<int*>(w + op.off_list);
+    int* hit_count = reinterpret_cast<int*>(w + op.off_count);
+    unsigned int* gmax_bits = reinterpret_cast<unsigned int*>(w + op.off_gmax);
+    FBBEV_LAUNCH(k_da_bwd_init, 1, 256, 0, stream, B * Ncam, hit_count, 1, gmax_bits);
+    FBBEV_CHECK_LAUNCH();
+    int e = da_bwd_unit_launch(stream, value, spatial_shapes, level_start_index, pred_depth, ref_cam, mask, qdepth, offsets, attn,
+                               grad_slots, B, Ncam, S, M, Dh, L, Q, P, Za, DC, d0, dstep, head_minor, HS, grad_pred_depth,
+                               grad_offsets, grad_attn, gmax_bits);
+    if (e) return e;
+    FBBEV_LAUNCH(k_da_bwd_hitlist, (long long)B * ((Q + 255) / 256), 256, 0, stream, spatial_shapes, pred_depth, ref_cam, mask,
+                 qdepth, B, Ncam, Q, Za, DC, d0, dstep, op.info_stride, info, hit_list, hit_count);
+    FBBEV_CHECK_LAUNCH();
+    const fbbev_da_bwd_region_tab& tab = op.tab;
+    const long long wgs = (long long)tab.n * B * Ncam * M;
+#define FBBEV_DA_OWN(NT_, DH_)                                                                                          \
+    do {                                                                                                                \
+        e = fbbev_rt_allow_dyn_lds((const void*)k_da_bwd_scatter_owned<NT_, DH_>, op.lds);                              \
+        if (e) return e;                                                                                                \
+        FBBEV_LAUNCH((k_da_bwd_scatter_owned<NT_, DH_>), wgs, NT_, op.lds, stream, spatial_shapes, level_start_index,   \
+                     ref_cam, offsets, attn, grad_slots, B, Ncam, S, M, L, Q, P, Za, head_minor & 3, HS, tab,            \
+                     (const float*)info, op.info_stride, (const int*)hit_list, (const int*)hit_count,                    \
+                     (const unsigned int*)gmax_bits, (head_minor & 4) ? 1 : 0, grad_value);                              \
+    } while (0)
+#define FBBEV_DA_OWN_NT(DH_) do { if (op.threads == 512) FBBEV_DA_OWN(512, DH_); else FBBEV_DA_OWN(256, DH_); } while (0)
+    if (Dh == 10) FBBEV_DA_OWN_NT(10);
+    else if (Dh == 8) FBBEV_DA_OWN_NT(8);
+    else if (Dh == 4) FBBEV_DA_OWN_NT(4);
+    else FBBEV_DA_OWN_NT(16);
+#undef FBBEV_DA_OWN_NT
+#undef FBBEV_DA_OWN
+    FBBEV_CHECK_LAUNCH();
+    return 0;
 }
 
 extern "C" int fbbev_da_cross_attn_bwd_ws(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
@@ -1637,6 +1792,17 @@ extern "C" int fbbev_da_cross_attn_bwd_ws(const float* value, const int64_t* spa
     if (B <= 0 || Ncam <= 0 || S <= 0 || M <= 0 || Dh <= 0 || L <= 0 || Q < 0 || P <= 0 || Za <= 0 || DC <= 0)
         return FBBEV_E_BADARG;
     const int HS = head_stride == 0 ? Dh : head_stride;
+    {
+        da_own_plan op;
+        if (HS >= Dh && Q > 0 && ws && aligned16(ws) && aligned16(grad_value) && value && spatial_shapes && level_start_index &&
+            pred_depth && ref_cam && mask && qdepth && offsets && attn && grad_slots && grad_value && grad_pred_depth &&
+            grad_offsets && grad_attn && dstep != 0.f && P % Za == 0 &&
+            (((uintptr_t)offsets | (uintptr_t)grad_offsets | (uintptr_t)grad_slots) & 7) == 0 &&
+            da_own_plan_make(B, Ncam, S, M, Dh, Q, HS, L, P, Za, level_hw_host, &op) && ws_bytes >= op.ws)
+            return da_bwd_owned_launch(op, (fbbev_rt_stream)stream_, value, spatial_shapes, level_start_index, pred_depth, ref_cam,
+                                       mask, qdepth, offsets, attn, grad_slots, B, Ncam, S, M, Dh, L, Q, P, Za, DC, d0, dstep,
+                                       head_minor, HS, grad_value, grad_pred_depth, grad_offsets, grad_attn, ws);
+    }
     da_bwd_plan pl;
     if (HS < Dh || Q == 0 || !ws || !aligned16(ws) || !aligned16(grad_value) || !aligned16(value) ||
         !da_bwd_tile_plan(B, Ncam, S, M, Dh, Q, HS, L, P, level_hw_host, &pl) || ws_bytes < pl.ws ||
@@ -1661,27 +1827,12 @@ extern "C" int fbbev_da_cross_attn_bwd_ws(const float* value, const int64_t* spa
         info = info_w;
     }
     {
-        // (A) unit-owned gradients, the forward's launch shape
-        const long long units = (long long)B * Q * M;
-        long long ub = ((units + 255) / 256 + 7) / 8 * 8;
-        if (ub > 65536) ub = 65536;
-        const size_t lds_a = (size_t)256 * (4 * P + 1) * sizeof(float);
-        const bool qi = (head_minor & 4) != 0;
-#define FBBEV_DA_BWD_UNIT(DH_)                                                                                          \
-    do {                                                                                                                \
-        if (qi) FBBEV_LAUNCH((k_da_cross_attn_bwd_unit<DH_, true>), ub, 256, lds_a, stream, units, value, spatial_shapes, \
-                             level_start_index, pred_depth, ref_cam, mask, qdepth, offsets, attn, grad_slots, B, Ncam, S, M, \
-                             L, Q, P, Za, DC, d0, dstep, head_minor & 3, HS, grad_pred_depth, grad_offsets, grad_attn);   \
-        else FBBEV_LAUNCH((k_da_cross_attn_bwd_unit<DH_, false>), ub, 256, lds_a, stream, units, value, spatial_shapes, \
-                          level_start_index, pred_depth, ref_cam, mask, qdepth, offsets, attn, grad_slots, B, Ncam, S, M, \
-                          L, Q, P, Za, DC, d0, dstep, head_minor & 3, HS, grad_pred_depth, grad_offsets, grad_attn);    \
-    } while (0)
-        if (Dh == 10) FBBEV_DA_BWD_UNIT(10);
-        else if (Dh == 8) FBBEV_DA_BWD_UNIT(8);
-        else if (Dh == 4) FBBEV_DA_BWD_UNIT(4);
-        else FBBEV_DA_BWD_UNIT(16);
-#undef FBBEV_DA_BWD_UNIT
-        FBBEV_CHECK_LAUNCH();
+        {
+            const int e = da_bwd_unit_launch(stream, value, spatial_shapes, level_start_index, pred_depth, ref_cam, mask, qdepth, offsets,
+                                             attn, grad_slots, B, Ncam, S, M, Dh, L, Q, P, Za, DC, d0, dstep, head_minor, HS,
+                                             grad_pred_depth, grad_offsets, grad_attn, nullptr);
+            if (e) return e;
+        }
         // (B) value gradient, one launch per token region
         for (int r = 0; r < pl.n_regions; ++r) {
             const da_region& rg = pl.reg[r];

@@ -26,6 +26,19 @@
 // LDS plane of the fixed-point backward kernels: word index of token t, and words of an n-token plane
 #define FBBEV_DA_PLANE_IDX(t, HS) ((t) * (HS) + ((t) >> 3))
 #define FBBEV_DA_PLANE_WORDS(n, HS) ((n) * (HS) + ((n) >> 3) + 1)
+
+// One bilinear corner of a sample into a fixed-point LDS plane: DH adds of floor(w * tg[c] + 0.5) at dst[c], inside ONE divergent region.
+template <int DH>
+__device__ __forceinline__ void fbbev_lds_corner_add(bool live, long long* dst, float w, const float (&tg)[DH]) {
+    if (!live) return;
+    static_assert(DH % 2 == 0, "channel pairs");
+#pragma unroll
+    for (int c = 0; c < DH; c += 2) {
+        const fbbev_v2f pr = fbbev_v2f{tg[c], tg[c + 1]} * w;                        // v_pk_mul_f32: two channels per instruction
+        fbbev_lds_atomic_add_i64(dst + c, (long long)fbbev_cvt_rpi(pr[0]));
+        fbbev_lds_atomic_add_i64(dst + c + 1, (long long)fbbev_cvt_rpi(pr[1]));
+    }
+}
 #define FBBEV_DA_BWD_MAXP 8     // sampling points per level the split backward batches (FB-OCC: 8)
 
 // bilinear sample of ONE plane (H,W) row-major at normalised (x,y), MSDA validity/padding rules
@@ -718,7 +731,11 @@ k_da_cross_attn_bwd_unit(long long n_units, const float* __restrict__ value, con
                          const float* __restrict__ attn, const float* __restrict__ grad_slots, int B, int Ncam, int S,
                          int M, int L, int Q, int P, int Za, int DC, float d0, float dstep, int head_minor, int HS,
                          float* __restrict__ grad_pred_depth, float* __restrict__ grad_offsets,
-                         float* __restrict__ grad_attn) {
+                         float* __restrict__ grad_attn, unsigned int* __restrict__ gmax_bits) {
+    // gmax_bits (may be null): max |grad_slots| of the call, folded here because this kernel reads every gradient row anyway --
+    // the fixed-point scale of k_da_bwd_scatter_owned (bits of a non-negative float order like the float; non-finite -> inf)
+    float gm_lane = 0.f;
+    bool fin_lane = true;
     const int head_off_m = QI ? 4 : HS, chunk_stride = QI ? M * 4 : 4;
     const int row_stride = M * HS;
     const int H0 = (int)spatial_shapes[0], W0 = (int)spatial_shapes[1];
@@ -732,6 +749,16 @@ k_da_cross_attn_bwd_unit(long long n_units, const float* __restrict__ value, con
         const long long bq = unit / M;
         const int q = (int)(bq % Q);
         const int b = (int)(bq / Q);
+        if (gmax_bits) {
+            const float* gs = grad_slots + unit * DH;
+#pragma unroll
+            for (int c = 0; c < DH; c += 2) {
+                const fbbev_v2f t = *reinterpret_cast<const fbbev_v2f*>(gs + c);
+                const float a0 = fabsf(t[0]), a1 = fabsf(t[1]);
+                fin_lane = fin_lane && (a0 < __builtin_inff()) && (a1 < __builtin_inff());
+                gm_lane = fmaxf(gm_lane, fmaxf(a0, a1));
+            }
+        }
         int count = 0;
         for (int cam = 0; cam < Ncam; ++cam) {
             const long long base = (((long long)cam * B + b) * Q + q) * Za;
@@ -847,6 +874,14 @@ k_da_cross_attn_bwd_unit(long long n_units, const float* __restrict__ value, con
                 if (s.o4 >= 0) fbbev_atomic_add_f32(gd + s.o4, s.w4 * dsum);
             }
         }
+    }
+    if (gmax_bits) {                                                    // every lane is back here: one atomic per wave
+        if (!fin_lane) gm_lane = __builtin_inff();
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) gm_lane = fmaxf(gm_lane, __shfl_xor(gm_lane, o, 64));
+        unsigned int gb;
+        __builtin_memcpy(&gb, &gm_lane, 4);
+        if ((threadIdx.x & 63) == 0 && gb != 0u) atomicMax(gmax_bits, gb);
     }
 }
 
@@ -1040,15 +1075,17 @@ k_da_cross_attn_bwd_scatter(const int64_t* __restrict__ spatial_shapes, const in
                     const int span = tok1 - tok0;
                     const bool k1 = s.o1 >= 0 && t1 >= 0 && t1 < span, k2 = s.o2 >= 0 && t2 >= 0 && t2 < span;
                     const bool k3 = s.o3 >= 0 && t3 >= 0 && t3 < span, k4 = s.o4 >= 0 && t4 >= 0 && t4 < span;
+                    // corner outer, channel inner: ONE divergent region per corner instead of one per (corner, channel) -- the
+                    // 40 predicated adds of a sample were 40 exec-mask diamonds (~600 instructions per sample, 33 M scalar
+                    // instructions per launch, profiles/r04_diag_da_bwd_regions.json).  Same product order as the other
+                    // kernels: w_corner * (g * weight); integer adds commute, so the plane is bit-identical.
+                    float tg[DH];
 #pragma unroll
-                    for (int c = 0; c < DH; ++c) {
-                        // same product order as the other kernels: w_corner * (g * weight)
-                        const float tgv = gs[c] * weight;
-                        if (k1) fbbev_lds_atomic_add_i64(plane + FBBEV_DA_PLANE_IDX(t1, HS) + c, (long long)__float2int_rn(s.w1 * tgv));
-                        if (k2) fbbev_lds_atomic_add_i64(plane + FBBEV_DA_PLANE_IDX(t2, HS) + c, (long long)__float2int_rn(s.w2 * tgv));
-                        if (k3) fbbev_lds_atomic_add_i64(plane + FBBEV_DA_PLANE_IDX(t3, HS) + c, (long long)__float2int_rn(s.w3 * tgv));
-                        if (k4) fbbev_lds_atomic_add_i64(plane + FBBEV_DA_PLANE_IDX(t4, HS) + c, (long long)__float2int_rn(s.w4 * tgv));
-                    }
+                    for (int c = 0; c < DH; ++c) tg[c] = gs[c] * weight;
+                    fbbev_lds_corner_add<DH>(k1, plane + FBBEV_DA_PLANE_IDX(t1, HS), s.w1, tg);
+                    fbbev_lds_corner_add<DH>(k2, plane + FBBEV_DA_PLANE_IDX(t2, HS), s.w2, tg);
+                    fbbev_lds_corner_add<DH>(k3, plane + FBBEV_DA_PLANE_IDX(t3, HS), s.w3, tg);
+                    fbbev_lds_corner_add<DH>(k4, plane + FBBEV_DA_PLANE_IDX(t4, HS), s.w4, tg);
                 }
             }
         }
@@ -1088,5 +1125,193 @@ k_da_bwd_reduce(const float* __restrict__ part, int B, int Ncam, int S, int M, i
         for (int k = 0; k < n_chunks; ++k) acc += src[(long long)k * Ncam * plane_n];
         const long long row = (((long long)b * Ncam + cam) * S + sidx) * (long long)(M * HS);
         grad_value[row + (interleaved ? (c >> 2) * (M * 4) + m * 4 + (c & 3) : m * HS + c)] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Round 4: value-gradient scatter with OUTPUT-OWNED planes.  The chunked scatter above gives a workgroup a chunk of queries
+// and walks the cameras (a barrier-bracketed compaction + a mostly empty tail iteration + a 34 KB flush per camera, one launch
+// per token region, 551 MB of per-chunk partial planes and a reduction at the configs[2] pyramid: 2.4 ms, waves parked 63 %,
+// profiles/r04_diag_da_bwd_regions.json -- halving its instruction count changed nothing).  Here a workgroup OWNS the plane of
+// one (sample, camera, head, token region) and walks the camera's whole hit list: one long uniform loop, no per-camera
+// barriers, no partial planes, no reduction (integer adds commute, so any list order gives the same bits), every region of the
+// pyramid in ONE launch, and small regions (coarse levels) keep up to 16 copies of their plane against same-address adds.
+//   k_da_bwd_init      zero the per-(sample, camera) hit counters and the |gradient| maximum (k_da_cross_attn_bwd_unit folds
+//                      max |grad_slots| of the call into it: the planes' fixed-point scale)
+//   k_da_bwd_hitlist   per (sample, query): camera count / depth weights (the table of k_da_bwd_hitinfo), append the query to the
+//                      list of every camera that sees it
+//   k_da_bwd_scatter_owned
+struct fbbev_da_bwd_region_tab { int n; unsigned int perm; int lvl0[24], lvl1[24], tok0[24], tok1[24], copies[24]; };
+
+__global__ void __launch_bounds__(256)
+k_da_bwd_init(int n_count, int* __restrict__ hit_count, int n_max, unsigned int* __restrict__ gmax_bits) {
+    for (int i = threadIdx.x; i < n_count; i += 256) hit_count[i] = 0;
+    for (int i = threadIdx.x; i < n_max; i += 256) gmax_bits[i] = 0u;
+}
+
+// grid B * ceil(Q / 256): a wave never straddles two samples, so one ballot + one counter add per (wave, camera)
+__global__ void __launch_bounds__(256)
+k_da_bwd_hitlist(const int64_t* __restrict__ spatial_shapes, const float* __restrict__ pred_depth,
+                 const float* __restrict__ ref_cam, const unsigned char* __restrict__ mask, const float* __restrict__ qdepth,
+                 int B, int Ncam, int Q, int Za, int DC, float d0, float dstep, int IS, float* __restrict__ info,
+                 int* __restrict__ hit_list, int* __restrict__ hit_count) {
+    const int bps = (Q + 255) / 256;                                      // blocks per sample
+    const int b = blockIdx.x / bps, lane = threadIdx.x & 63;
+    const int qb = (blockIdx.x - b * bps) * 256, q = qb + (int)threadIdx.x;
+    const bool live = q < Q;
+    const int H0 = (int)spatial_shapes[0], W0 = (int)spatial_shapes[1];
+    int count = 0;
+    if (live) {
+        for (int c2 = 0; c2 < Ncam; ++c2) {
+            const long long b2 = (((long long)c2 * B + b) * Q + q) * Za;
+            bool h2 = false;
+            for (int z = 0; z < Za; ++z) h2 = h2 || (mask[b2 + z] != 0);
+            count += h2 ? 1 : 0;
+        }
+    }
+    for (int cam = 0; cam < Ncam; ++cam) {
+        const long long bn = (long long)b * Ncam + cam;
+        bool hit = false;
+        if (live) {
+            const long long base = (((long long)cam * B + b) * Q + q) * Za;
+            for (int z = 0; z < Za; ++z) hit = hit || (mask[base + z] != 0);
+            float* dst = info + (bn * Q + q) * IS;
+            dst[0] = hit ? (float)(count > 1 ? count : 1) : 0.f;
+            if (hit) {
+                for (int z = 0; z < Za; ++z) {
+                    const float rx = ref_cam[(base + z) * 2], ry = ref_cam[(base + z) * 2 + 1];
+                    float fb = floorf(__fdiv_rn(__fsub_rn(qdepth[base + z], d0), dstep));
+                    fb = fminf(fmaxf(fb, 0.f), (float)(DC - 1));
+                    dst[1 + z] = fbbev_plane_sample(pred_depth + (bn * DC + (int)fb) * (long long)(H0 * W0), H0, W0, rx, ry);
+                }
+            }
+        }
+        const unsigned long long bal = __ballot(hit ? 1 : 0);
+        int wbase = 0;
+        if (lane == 0 && bal) wbase = atomicAdd(hit_count + bn, __popcll(bal));
+        wbase = __shfl(wbase, 0, 64);
+        if (hit) hit_list[bn * Q + wbase + __popcll(bal & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))))] = q;
+    }
+}
+
+// One workgroup = (token region r, sample b, camera cam, head m).  blockIdx -> (r, b, cam, m): the workgroups of one
+// (sample, camera) -- which share the hit list, the table, the reference points and the gradient rows -- sit on one XCD when the
+// number of (sample, camera) pairs divides by 8.  grad_value gets the region's tokens of head m directly.
+template <int NT, int DH>
+__global__ void __launch_bounds__(NT)
+k_da_bwd_scatter_owned(const int64_t* __restrict__ spatial_shapes, const int64_t* __restrict__ level_start,
+                       const float* __restrict__ ref_cam, const float* __restrict__ offsets, const float* __restrict__ attn,
+                       const float* __restrict__ grad_slots, int B, int Ncam, int S, int M, int L, int Q, int P, int Za,
+                       int head_minor, int HS, fbbev_da_bwd_region_tab tab, const float* __restrict__ info, int IS,
+                       const int* __restrict__ hit_list, const int* __restrict__ hit_count,
+                       const unsigned int* __restrict__ gmax_bits, int interleaved, float* __restrict__ grad_value) {
+    const int pairs = B * Ncam;
+    int r, pair, m;
+    if (pairs % 8 == 0) {
+        const int ppx = pairs / 8, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        pair = xcd * ppx + slot % ppx;
+        const int rest = slot / ppx;
+        m = rest % M;
+        r = rest / M;
+    } else {
+        pair = blockIdx.x % pairs;
+        const int rest = blockIdx.x / pairs;
+        m = rest % M;
+        r = rest / M;
+    }
+    const int b = pair / Ncam, cam = pair - b * Ncam;
+    const int lvl0 = tab.lvl0[r], lvl1 = tab.lvl1[r], tok0 = tab.tok0[r], tok1 = tab.tok1[r], copies = tab.copies[r];
+    long long* plane0 = reinterpret_cast<long long*>(fbbev_dyn_lds_f32());
+    const int span = tok1 - tok0, plane_n = span * HS, plane_w = FBBEV_DA_PLANE_WORDS(span, HS);
+    long long* plane = plane0 + (threadIdx.x % copies) * plane_w;
+    for (int i = threadIdx.x; i < copies * plane_w; i += NT) plane0[i] = 0ll;
+    // scale of the fixed-point plane: sc = 2^(30 - ex) with max |grad_slots| of the CALL < 2^ex (every addend is
+    // |corner weight * attention * depth weight / cameras| <= 1 times a gradient: below 2^30; a token takes < 2^33 of them)
+    const unsigned int gb = gmax_bits[0];
+    const bool poisoned = gb >= 0x7f800000u;
+    float sc = 0.f, inv_sc = 0.f;
+    if (!poisoned && gb != 0u) {
+        int ex = (int)((gb >> 23) & 255u) - 126;
+        if (ex < -90) ex = -90;
+        const unsigned int sb = (unsigned int)(127 + 30 - ex) << 23, ib = (unsigned int)(127 - 30 + ex) << 23;
+        __builtin_memcpy(&sc, &sb, 4);
+        __builtin_memcpy(&inv_sc, &ib, 4);
+    }
+    const long long bn = (long long)b * Ncam + cam;
+    const int nh = (poisoned || sc == 0.f) ? 0 : hit_count[bn];
+    const int* list = hit_list + bn * Q;
+    const int LP = L * P;
+    const bool perm = (tab.perm >> r) & 1;
+    __syncthreads();
+    for (int it0 = 0; it0 < nh; it0 += NT) {
+        // lane -> hit: a stride of 37 (41 when 37 divides the block) inside each block of NT hits -- neighbouring queries sample
+        // the same tokens, consecutive hits on consecutive lanes would share addresses inside one ds_add_u64
+        const int nblk = nh - it0 < NT ? nh - it0 : NT;
+        if ((int)threadIdx.x >= nblk) continue;
+        const int it = it0 + (perm ? (int)(((unsigned)threadIdx.x * (nblk % 37 == 0 ? 41u : 37u)) % (unsigned)nblk) : (int)threadIdx.x);
+        const int q = list[it];
+        const long long bq = (long long)b * Q + q;
+        const long long u = bq * M + m;
+        const long long base = (((long long)cam * B + b) * Q + q) * Za;
+        const float* ip = info + (bn * Q + q) * IS;
+        const float inv = ip[0];
+        float rx[FBBEV_DA_MAX_ZA], ry[FBBEV_DA_MAX_ZA], dw[FBBEV_DA_MAX_ZA];
+        for (int z = 0; z < Za; ++z) {
+            rx[z] = ref_cam[(base + z) * 2];
+            ry[z] = ref_cam[(base + z) * 2 + 1];
+            dw[z] = ip[1 + z];
+        }
+        float gs[DH];
+#pragma unroll
+        for (int c = 0; c < DH; ++c) gs[c] = grad_slots[u * DH + c] / inv * sc;          // sc is a power of two: exact
+        const long long wo0 = (head_minor & 1) ? bq * LP * M + m : u * LP, wa0 = (head_minor & 2) ? bq * LP * M + m : u * LP;
+        const int wo_step = (head_minor & 1) ? M : 1, wa_step = (head_minor & 2) ? M : 1;
+        const int lp0 = lvl0 * P, lp1 = lvl1 * P;
+        fbbev_v2f o_next = *reinterpret_cast<const fbbev_v2f*>(offsets + (wo0 + (long long)lp0 * wo_step) * 2);
+        float a_next = attn[wa0 + (long long)lp0 * wa_step];
+        int lp = lp0;
+        for (int l = lvl0; l < lvl1; ++l) {
+            const int sh = (int)spatial_shapes[2 * l], sw = (int)spatial_shapes[2 * l + 1];
+            const int ls = (int)level_start[l];
+            for (int p = 0; p < P; ++p, ++lp) {
+                const int nlp = lp + 1 < lp1 ? lp + 1 : lp;
+                const fbbev_v2f o = o_next;
+                const float a = a_next;
+                o_next = *reinterpret_cast<const fbbev_v2f*>(offsets + (wo0 + (long long)nlp * wo_step) * 2);
+                a_next = attn[wa0 + (long long)nlp * wa_step];
+                const int z = p % Za;
+                const float loc_w = rx[z] + __fdiv_rn(o[0], (float)sw);
+                const float loc_h = ry[z] + __fdiv_rn(o[1], (float)sh);
+                const float h_im = loc_h * sh - 0.5f, w_im = loc_w * sw - 0.5f;
+                if (!(h_im > -1.f && w_im > -1.f && h_im < (float)sh && w_im < (float)sw)) continue;
+                const float weight = a * dw[z];
+                const fbbev_bilinear s = fbbev_bilinear_setup(h_im, w_im, sh, sw, 1);          // o1..o4 = token indices of the level
+                const int t1 = ls + s.o1 - tok0, t2 = ls + s.o2 - tok0, t3 = ls + s.o3 - tok0, t4 = ls + s.o4 - tok0;
+                const bool k1 = s.o1 >= 0 && t1 >= 0 && t1 < span, k2 = s.o2 >= 0 && t2 >= 0 && t2 < span;
+                const bool k3 = s.o3 >= 0 && t3 >= 0 && t3 < span, k4 = s.o4 >= 0 && t4 >= 0 && t4 < span;
+                float tg[DH];
+#pragma unroll
+                for (int c = 0; c < DH; ++c) tg[c] = gs[c] * weight;                // w_corner * (g * weight): the order of the other kernels
+                fbbev_lds_corner_add<DH>(k1, plane + FBBEV_DA_PLANE_IDX(t1, HS), s.w1, tg);
+                fbbev_lds_corner_add<DH>(k2, plane + FBBEV_DA_PLANE_IDX(t2, HS), s.w2, tg);
+                fbbev_lds_corner_add<DH>(k3, plane + FBBEV_DA_PLANE_IDX(t3, HS), s.w3, tg);
+                fbbev_lds_corner_add<DH>(k4, plane + FBBEV_DA_PLANE_IDX(t4, HS), s.w4, tg);
+            }
+        }
+    }
+    __syncthreads();
+    const int MHS = M * HS;
+    float* dst = grad_value + (bn * S + tok0) * (long long)MHS;
+    for (int i = threadIdx.x * 4; i < plane_n; i += NT * 4) {            // HS % 4 == 0: a group of 4 stays inside one token
+        const int t = i / HS, c = i - t * HS;
+        const long long* src = plane0 + FBBEV_DA_PLANE_IDX(t, HS) + c;
+        fbbev_v4f v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            long long acc = 0;
+            for (int cp = 0; cp < copies; ++cp) acc += src[cp * plane_w + e];
+            v[e] = poisoned ? __builtin_nanf("") : (float)acc * inv_sc;                   // one rounding (int64 -> fp32)
+        }
+        *reinterpret_cast<fbbev_v4f*>(dst + (long long)t * MHS + (interleaved ? (c >> 2) * (M * 4) + m * 4 : m * HS + c)) = v;
     }
 }

@@ -61,6 +61,13 @@ __device__ __forceinline__ void fbbev_atomic_add_f32(float* p, float v) { unsafe
 __device__ __forceinline__ void fbbev_lds_atomic_add_i64(long long* p, long long v) {
     __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+// float -> int32, floor(x + 0.5) in ONE instruction (v_cvt_rpi_i32_f32; __float2int_rn is v_rndne_f32 + v_cvt_i32_f32 and differs
+// from it only on exact .5 ties).  The fixed-point LDS planes convert 40 addends per sample with it.
+__device__ __forceinline__ int fbbev_cvt_rpi(float x) {
+    int r;
+    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
 // fp32 add on an LDS word (ds_add_f32, no return value)
 __device__ __forceinline__ void fbbev_lds_atomic_add_f32(float* p, float v) {
     __builtin_amdgcn_ds_faddf((__attribute__((address_space(3))) float*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP, false);

@@ -173,14 +173,14 @@ k_msda_bwd_scatter(const int64_t* __restrict__ ss, const int64_t* __restrict__ l
                 const int t1 = s.o1 - tok0, t2 = s.o2 - tok0, t3 = s.o3 - tok0, t4 = s.o4 - tok0;
                 const bool k1 = s.o1 >= 0 && t1 >= 0 && t1 < ntok, k2 = s.o2 >= 0 && t2 >= 0 && t2 < ntok;
                 const bool k3 = s.o3 >= 0 && t3 >= 0 && t3 < ntok, k4 = s.o4 >= 0 && t4 >= 0 && t4 < ntok;
+                float tg[DH];                                                         // the reference's top_grad * attn_weight
 #pragma unroll
-                for (int c = 0; c < DH; ++c) {
-                    const float tgv = gs[c] * weight;                                 // the reference's top_grad * attn_weight
-                    if (k1) fbbev_lds_atomic_add_i64(plane + FBBEV_DA_PLANE_IDX(t1, DH) + c, (long long)__float2int_rn(s.w1 * tgv));
-                    if (k2) fbbev_lds_atomic_add_i64(plane + FBBEV_DA_PLANE_IDX(t2, DH) + c, (long long)__float2int_rn(s.w2 * tgv));
-                    if (k3) fbbev_lds_atomic_add_i64(plane + FBBEV_DA_PLANE_IDX(t3, DH) + c, (long long)__float2int_rn(s.w3 * tgv));
-                    if (k4) fbbev_lds_atomic_add_i64(plane + FBBEV_DA_PLANE_IDX(t4, DH) + c, (long long)__float2int_rn(s.w4 * tgv));
-                }
+                for (int c = 0; c < DH; ++c) tg[c] = gs[c] * weight;
+                // corner outer, channel inner: one divergent region per corner (see k_da_cross_attn_bwd_scatter)
+                fbbev_lds_corner_add<DH>(k1, plane + FBBEV_DA_PLANE_IDX(t1, DH), s.w1, tg);
+                fbbev_lds_corner_add<DH>(k2, plane + FBBEV_DA_PLANE_IDX(t2, DH), s.w2, tg);
+                fbbev_lds_corner_add<DH>(k3, plane + FBBEV_DA_PLANE_IDX(t3, DH), s.w3, tg);
+                fbbev_lds_corner_add<DH>(k4, plane + FBBEV_DA_PLANE_IDX(t4, DH), s.w4, tg);
             }
         }
     }

@@ -149,6 +149,7 @@ inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __float2int_rn(float x) { return (int)__builtin_rintf(x); }      // nearest even, as v_cvt_i32 after v_rndne
 inline int __ffsll(long long x) { return __builtin_ffsll(x); }
 inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
+inline unsigned int atomicMax(unsigned int* p, unsigned int v) { unsigned int o = *p; if (v > o) *p = v; return o; }
 inline unsigned int atomicOr(unsigned int* p, unsigned int v) { unsigned int o = *p; *p = o | v; return o; }
 
 // single correctly-rounded fp32 ops (volatile defeats re-association / contraction)
@@ -180,6 +181,10 @@ template <int ST> inline void fbbev_store4(float* p, fbbev_v4f v) { memcpy(p, &v
 inline void fbbev_atomic_add_f32(float* p, float v) { *p += v; }
 inline void fbbev_lds_atomic_add_f32(float* p, float v) { *p += v; }
 inline void fbbev_lds_atomic_add_i64(long long* p, long long v) { *p += v; }
+inline int fbbev_cvt_rpi(float x) {                       // v_cvt_rpi_i32_f32: floor(x + 0.5), saturating
+    const double r = __builtin_floor((double)x + 0.5);
+    return r >= 2147483647.0 ? 2147483647 : (r <= -2147483648.0 ? (int)(-2147483647 - 1) : (int)r);
+}
 // emulation of v_mfma_f32_16x16x4_f32 with the documented fragment layouts (see csrc/hip_rt/rt.h); every lane of the
 // wave must call it (wave-uniform control flow, as on the hardware)
 inline fbbev_v4f fbbev_mfma_f32_16x16x4(float a, float b, fbbev_v4f c) {

@@ -767,15 +767,36 @@ def test_fused_da_cross_attention_backward_emulated():
         # several query chunks per (sample, head) so that the reduction over chunks is exercised
         import os
         shapes_host = [tuple(int(x) for x in hw) for hw in ss.tolist()]
-        for chunks, threads, tokens, prepass in (('1', '256', None, None), ('3', '256', None, None), ('2', '512', None, None),
+        # two routes: output-owned planes (the default since round 4: hit lists, one launch over all regions, no partials) and the
+        # chunked scatter (FBBEV_DA_BWD_OWNED=0: query chunks, partial planes, a reduction)
+        for chunks, threads, tokens, prepass in (('own', '256', None, None), ('own', '512', None, None), ('own', '256', '8', None),
+                                                 ('own1', '256', '8', None),     # owned planes, bands of rows, a single copy
+                                                 ('1', '256', None, None), ('3', '256', None, None), ('2', '512', None, None),
                                                  ('2', '256', '8', '0'),         # token regions: bands of rows, levels apart
                                                  ('2', '256', '8', '1')):        # + the per-(camera, query) pre-pass (the default)
-            os.environ['FBBEV_DA_BWD_CHUNKS'] = chunks
+            owned = chunks.startswith('own')
+            os.environ['FBBEV_DA_BWD_OWNED'] = '1' if owned else '0'
+            if chunks == 'own1':
+                os.environ['FBBEV_DA_BWD_COPIES'] = '1'
+            os.environ['FBBEV_DA_BWD_CHUNKS'] = '1' if owned else chunks
             os.environ['FBBEV_DA_BWD_THREADS'] = threads
             if tokens:
                 os.environ['FBBEV_DA_BWD_TOKENS'] = tokens
             if prepass == '0':
                 os.environ['FBBEV_DA_BWD_PREPASS'] = '0'
+            if chunks == 'own':          # the owned route is planned (its workspace = table + hit lists, not partial planes)
+                import ctypes
+                flat = [int(x) for hw in shapes_host for x in hw]
+                harr = (ctypes.c_int32 * len(flat))(*flat)
+                Ncam_, B_, Q_, _ = mask.shape
+                sizes = []
+                for flag in ('1', '0'):
+                    os.environ['FBBEV_DA_BWD_OWNED'] = flag
+                    sizes.append(E.lib().fbbev_da_cross_attn_bwd_ws_bytes(B_, Ncam_, vp.shape[1], vp.shape[2], Dh, Q_, HS,
+                                                                          len(shapes_host), attn.shape[-1], harr))
+                os.environ['FBBEV_DA_BWD_OWNED'] = '1'
+                table = B_ * Ncam_ * Q_ * 8 * 4
+                assert table < sizes[0] <= table + B_ * Ncam_ * Q_ * 4 + 4 * 256 and sizes[1] > 0 and sizes[0] != sizes[1]
             if prepass == '1':
                 import ctypes
                 flat = [int(x) for hw in shapes_host for x in hw]
@@ -804,6 +825,8 @@ def test_fused_da_cross_attention_backward_emulated():
                 del os.environ['FBBEV_DA_BWD_CHUNKS'], os.environ['FBBEV_DA_BWD_THREADS']
                 os.environ.pop('FBBEV_DA_BWD_TOKENS', None)
                 os.environ.pop('FBBEV_DA_BWD_PREPASS', None)
+                os.environ.pop('FBBEV_DA_BWD_OWNED', None)
+                os.environ.pop('FBBEV_DA_BWD_COPIES', None)
 
 
 @pytest.mark.parametrize('B,T1,C,N,dt', [(1, 3, 16, 64, torch.float32), (2, 2, 80, 100, torch.bfloat16), (1, 3, 80, 17, torch.float16),

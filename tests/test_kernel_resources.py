@@ -61,7 +61,8 @@ BUDGETS = {
     r'k_da_cross_attn_fwd_unitILi10E': 168,
     r'k_da_cross_attn_fwd_pipeILi10ELi4ELi2E': 200,   # pipelined sampler, the default build: 2 waves / SIMD x 2 samples in flight per lane    # the shipped head dim: 3 waves / SIMD (12 corner loads of a sample in flight)
     r'k_da_cross_attn_bwdILi': 128,            # the global-atomic backward: 4 waves / SIMD
-    r'k_da_cross_attn_bwd_scatter': 96,        # value-gradient scatter: 5 waves / SIMD
+    r'k_da_cross_attn_bwd_scatterILi\d+ELi10E': 96,   # chunked value-gradient scatter at the shipped head dim: 5 waves / SIMD
+    r'k_da_bwd_scatter_ownedILi\d+ELi10E': 96,        # output-owned scatter (round 4)
     r'k_da_cross_attn_bwd_unitILi10E': 224,    # unit-owned gradients at the shipped head dim: 2 waves / SIMD (48 corner registers in flight)
     r'k_history_warp': 168,
     r'k_history_conv_tILi5ELi5E': 512,         # register-resident weights: one wave per SIMD by design (the whole file)
