@@ -570,8 +570,8 @@ def da_cross_attn_bwd(value, spatial_shapes, level_start_index, pred_depth, ref_
             _dev(grad_value, F32, 'grad_value'), _dev(grad_pred_depth, F32, 'grad_pred_depth'),
             _dev(grad_offsets, F32, 'grad_offsets'), _dev(grad_attn, F32, 'grad_attn'))
     with _on(value):
-        # value gradient through LDS planes + a partial buffer when the shape fits (fbbev_da_cross_attn_bwd_ws), else
-        # the global-atomic kernel
+        # value gradient through fixed-point LDS planes when the shape fits (fbbev_da_cross_attn_bwd_ws: output-owned planes + hit
+        # lists, or query chunks + partial planes for small launches), else the global-atomic kernel
         arr = _level_hw(level_hw, L)
         need = lib().fbbev_da_cross_attn_bwd_ws_bytes(B, Ncam, S, M, Dh, Q, HS, L, P, arr) if lds_planes else 0
         if need:

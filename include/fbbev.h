@@ -457,7 +457,14 @@ int fbbev_da_cross_attn_bwd(const float* value, const int64_t* spatial_shapes, c
  * head_stride 12).  ws: fbbev_da_cross_attn_bwd_ws_bytes(...) bytes, 16-byte aligned; 0 bytes = the plan rejects the shape
  * (head dims other than 4 / 8 / 10 / 16, more than 8 points per level, head_stride not a multiple of 4 or > 16).  With
  * ws == NULL, too small, or a rejected shape the call IS fbbev_da_cross_attn_bwd (same results up to the order of the
- * fp32 adds). */
+ * fp32 adds).
+ * Round 4, OUTPUT-OWNED planes: when the launch has at least one workgroup per CU (token regions x B x Ncam x M >= 256;
+ * FBBEV_DA_BWD_OWNED=1 / 0 forces / forbids it) step (B) is instead: per-(sample, camera) hit lists + the (camera, query)
+ * table in `ws` (k_da_bwd_hitlist), then ONE launch in which a workgroup owns the plane of one (sample, camera, head,
+ * token region), walks the camera's hit list and writes its tokens of grad_value directly -- no partial planes, no step
+ * (C); `ws` shrinks from the partial planes (551 MB at the configs[2] pyramid) to table + lists (35 MB).  The fixed-point
+ * scale is then the call's max |grad_slots| (folded by kernel (A)): a non-finite upstream gradient makes the whole
+ * grad_value NaN.  Same bits run to run; configs[2] pyramid, B = 4: 2.39 -> 1.18 ms. */
 size_t fbbev_da_cross_attn_bwd_ws_bytes(int B, int Ncam, int S, int M, int Dh, int Q, int head_stride,
                                         int num_levels, int num_points, const int32_t* level_hw_host);
 int fbbev_da_cross_attn_bwd_ws(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
