@@ -1362,7 +1362,7 @@ extern "C" int fbbev_da_cross_attn_fwd_zt(const float* value, const int64_t* spa
 // ---- fbbev_da_cross_attn_fused: query rows -> slots in one kernel (da_fused_kernels.h)
 static bool da_fused_shape_ok(int B, int Ncam, int S, int M, int Dh, int L, int Q, int P, int Za, int bev_w) {
     if (M != 8 || (Dh != 10 && Dh != 8) || P != FBBEV_DAF_P || Za != FBBEV_DAF_ZA || L < 1 || bev_w <= 0 || Q % bev_w != 0) return false;
-    if (fbbev_daf_lds_bytes(M * Dh, M, Ncam, L * P) > 160 * 1024) return false;
+    if (L > FBBEV_DAF_MAXL || fbbev_daf_lds_bytes(M * Dh, 8, Ncam) > 160 * 1024) return false;
     return (long long)S * Dh * 4 < (1ll << 31);                                      // 32-bit byte offsets inside a head plane
 }
 extern "C" int fbbev_da_cross_attn_fused_supported(int B, int Ncam, int S, int M, int Dh, int L, int Q, int P, int Za, int bev_w) {
@@ -1396,23 +1396,36 @@ extern "C" int fbbev_da_cross_attn_fused(const float* planes, const int64_t* spa
     if (query_row_stride % 4 != 0 || addend_row_stride % 4 != 0 || !aligned16(query) || (addend && !aligned16(addend)) ||
         !aligned16(offsets_fragments) || !aligned16(attn_fragments) || ((uintptr_t)planes & 7) != 0 || ((uintptr_t)slots & 7) != 0)
         return FBBEV_E_UNSUPPORTED;
-    const long long wgs = (long long)B * ((bev_w + 7) / 8) * ((Q / bev_w + 7) / 8);
+    // heads per workgroup: 4 = two 256-thread workgroups per patch and per CU (one's prologue + projections under the other's
+    // samples), 8 = one 512-thread workgroup per patch (FBBEV_DA_FUSED_HW, read once)
+    auto read_hw = [] { const char* e = getenv("FBBEV_DA_FUSED_HW"); const int v = e ? atoi(e) : 4; return v == 8 ? 8 : 4; };
+#ifdef FBBEV_TEST_OVERRIDES   // CPU emulator build: the tests run both forms inside one process
+    const int hw = read_hw();
+#else
+    static const int hw = read_hw();
+#endif
+    const long long wgs = (long long)B * ((bev_w + 7) / 8) * ((Q / bev_w + 7) / 8) * (8 / hw);
     const long long grid = (wgs + 7) / 8 * 8;
     if (grid >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
-    const size_t lds = fbbev_daf_lds_bytes(E, M, Ncam, L * P);
-#define FBBEV_DA_FUSED(DH_, NP_)                                                                                       \
+    const size_t lds = fbbev_daf_lds_bytes(E, hw, Ncam);
+#define FBBEV_DA_FUSED(DH_, NP_, HW_)                                                                                  \
     do {                                                                                                               \
-        int e = fbbev_rt_allow_dyn_lds((const void*)k_da_cross_attn_fused<DH_, 8, NP_>, lds);                         \
+        int e = fbbev_rt_allow_dyn_lds((const void*)k_da_cross_attn_fused<DH_, 8, NP_, HW_>, lds);                    \
         if (e) return e;                                                                                               \
-        FBBEV_LAUNCH((k_da_cross_attn_fused<DH_, 8, NP_>), grid, 512, lds, (fbbev_rt_stream)stream_, planes, spatial_shapes, \
+        FBBEV_LAUNCH((k_da_cross_attn_fused<DH_, 8, NP_, HW_>), grid, 64 * HW_, lds, (fbbev_rt_stream)stream_, planes, spatial_shapes, \
                      level_start_index, pred_depth, ref_cam, mask, qdepth, query, query_row_stride, addend,           \
                      addend_row_stride, addend_period, static_cast<const unsigned short*>(offsets_fragments),         \
                      offsets_bias, static_cast<const unsigned short*>(attn_fragments), attn_bias, B, Ncam, S, L, Q,    \
                      bev_w, DC, d0, dstep, slots);                                                                     \
     } while (0)
     static const int np = [] { const char* e = getenv("FBBEV_DA_FUSED_NP"); return e ? atoi(e) : 2; }();   // samples in flight per lane (tuning knob, read once)
-    if (Dh == 10) { if (np == 3) FBBEV_DA_FUSED(10, 3); else if (np == 4) FBBEV_DA_FUSED(10, 4); else FBBEV_DA_FUSED(10, 2); }
-    else { if (np == 3) FBBEV_DA_FUSED(8, 3); else FBBEV_DA_FUSED(8, 2); }
+    if (hw == 8) {
+        if (Dh == 10) { if (np == 3) FBBEV_DA_FUSED(10, 3, 8); else FBBEV_DA_FUSED(10, 2, 8); }
+        else { if (np == 3) FBBEV_DA_FUSED(8, 3, 8); else FBBEV_DA_FUSED(8, 2, 8); }
+    } else {
+        if (Dh == 10) { if (np == 3) FBBEV_DA_FUSED(10, 3, 4); else FBBEV_DA_FUSED(10, 2, 4); }
+        else { if (np == 3) FBBEV_DA_FUSED(8, 3, 4); else FBBEV_DA_FUSED(8, 2, 4); }
+    }
 #undef FBBEV_DA_FUSED
     FBBEV_CHECK_LAUNCH();
     return 0;

@@ -40,10 +40,12 @@
 #define FBBEV_DAF_P 8            // sampling points per level
 #define FBBEV_DAF_ZA 4           // Z anchors per pillar
 
-// LDS carve-up (bytes): x fragments | (camera, query) records | per-wave attention rows | per-wave offset tiles
+#define FBBEV_DAF_MAXL 4         // levels whose attention weights a lane keeps in registers (8 each)
+
+// LDS carve-up (bytes): x fragments | (camera, query) records | per-wave transposition tiles (HW = heads = waves of a workgroup)
 __host__ __device__ inline size_t fbbev_daf_xf_bytes(int E) { return (size_t)4 * ((E + 31) / 32) * 2 * 64 * 16; }
-__host__ __device__ inline size_t fbbev_daf_lds_bytes(int E, int M, int Ncam, int LP) {
-    return fbbev_daf_xf_bytes(E) + (size_t)Ncam * 64 * FBBEV_DAF_QC * 4 + (size_t)M * 64 * (LP + 1) * 4 + (size_t)M * 64 * FBBEV_DAF_OS * 4;
+__host__ __device__ inline size_t fbbev_daf_lds_bytes(int E, int HW, int Ncam) {
+    return fbbev_daf_xf_bytes(E) + (size_t)Ncam * 64 * FBBEV_DAF_QC * 4 + (size_t)HW * 64 * FBBEV_DAF_OS * 4;
 }
 
 template <int DH>
@@ -148,8 +150,8 @@ __device__ __forceinline__ void fbbev_daf_plane_corners(float x, float y, int H,
 // query (B*Q rows, ldq floats apart, E used) [+ addend rows: row (b*Q + q) % add_period]; so_frag / aw_frag: split bf16 fragments of
 // sampling_offsets.weight (M*L*P*2, E) / attention_weights.weight (M*L*P, E) in the order of k_rows_linear_x3_fragments, rows in
 // the MODULE's order ((m, l, p, xy) / (m, l, p)); so_bias / aw_bias fp32; slots (B, Q, M*DH).  blockDim = 64 * M.
-template <int DH, int MH, int NP>
-__global__ void __launch_bounds__(64 * MH)
+template <int DH, int MH, int NP, int HW>
+__global__ void __launch_bounds__(64 * HW)
 k_da_cross_attn_fused(const float* __restrict__ planes, const int64_t* __restrict__ spatial_shapes,
                       const int64_t* __restrict__ level_start, const float* __restrict__ pred_depth,
                       const float* __restrict__ ref_cam, const unsigned char* __restrict__ mask,
@@ -158,21 +160,24 @@ k_da_cross_attn_fused(const float* __restrict__ planes, const int64_t* __restric
                       const unsigned short* __restrict__ so_frag, const float* __restrict__ so_bias,
                       const unsigned short* __restrict__ aw_frag, const float* __restrict__ aw_bias,
                       int B, int Ncam, int S, int L, int Q, int bev_w, int DC, float d0, float dstep, float* __restrict__ slots) {
-    constexpr int E = MH * DH, KS = (E + 31) / 32, P = FBBEV_DAF_P, ZA = FBBEV_DAF_ZA, NT = 64 * MH;
+    constexpr int E = MH * DH, KS = (E + 31) / 32, P = FBBEV_DAF_P, ZA = FBBEV_DAF_ZA, NT = 64 * HW, PARTS = MH / HW;
     static_assert((2 * DH) % 4 == 0 && DH % 2 == 0 && E % 8 == 0, "runs of whole 16-byte pieces, channel pairs");
     static_assert(NP >= 2 && NP <= FBBEV_DAF_P, "samples in flight per lane");
-    const int LP = L * P, LDW = LP + 1;
+    static_assert(MH % HW == 0 && P == 8, "a workgroup takes HW of the MH heads; a level's 8 logits are half an MFMA tile");
     unsigned char* lds = reinterpret_cast<unsigned char*>(fbbev_dyn_lds_f32());
     unsigned short* xf = reinterpret_cast<unsigned short*>(lds);                            // [4][KS][hi|lo][64][8] bf16
     float* qc = reinterpret_cast<float*>(lds + fbbev_daf_xf_bytes(E));                      // [Ncam][64][QC]
-    float* attn_all = qc + (size_t)Ncam * 64 * FBBEV_DAF_QC;                                // [MH][64][LP + 1]
-    float* off_all = attn_all + (size_t)MH * 64 * LDW;                                      // [MH][64][OS]
+    float* off_all = qc + (size_t)Ncam * 64 * FBBEV_DAF_QC;                                 // [HW][64][OS]
     const int H0 = (int)spatial_shapes[0], W0 = (int)spatial_shapes[1];
     const int bev_h = Q / bev_w;
     const int pxn = (bev_w + 7) / 8, pyn = (bev_h + 7) / 8;
-    const long long n_wg = (long long)B * pxn * pyn, per_xcd = (n_wg + 7) / 8;
-    const long long wgid = (long long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);       // XCD-contiguous patch order
-    if (wgid >= n_wg) return;                                                               // uniform
+    const long long n_wg = (long long)B * pxn * pyn * PARTS, per_xcd = (n_wg + 7) / 8;
+    const long long wgid_ = (long long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);      // XCD-contiguous patch order
+    if (wgid_ >= n_wg) return;                                                              // uniform
+    // PARTS workgroups share a patch (HW heads each: their own copy of phase A, so that one's prologue runs under the other's
+    // samples on the same CU); consecutive ids = the same XCD
+    const long long wgid = wgid_ / PARTS;
+    const int part = (int)(wgid_ - wgid * PARTS);
     const int b = (int)(wgid / ((long long)pxn * pyn)), pi = (int)(wgid - (long long)b * pxn * pyn);
     const int py = pi / pxn, px = pi - py * pxn;
     const int x0 = px * 8, y0 = py * 8;
@@ -231,36 +236,60 @@ k_da_cross_attn_fused(const float* __restrict__ planes, const int64_t* __restric
     }
     __syncthreads();
     // ---------------- phase B (per wave = head m, no workgroup barrier below)
-    const int m = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int m = part * HW + wv;
     const int g = lane >> 4, j = lane & 15;
-    float* attn_w = attn_all + (size_t)m * 64 * LDW;
-    float* off_w = off_all + (size_t)m * 64 * FBBEV_DAF_OS;
+    float* off_w = off_all + (size_t)wv * 64 * FBBEV_DAF_OS;
     fbbev_v4f pacc[4];
-    // logits of head m: rows [m*LP, (m+1)*LP) of attention_weights -> + bias -> this wave's attention rows
+    // logits of head m: the 8 logits of (head m, level l) are rows (m*L + l)*8 .. +7 of attention_weights = HALF of one
+    // 16-output tile; the tile goes through the wave's transposition tile (the path of the offsets below) and the lane keeps
+    // its 8 values in registers: lg[l][p], levels taken last to first while the rows shift up, so lg[0] is level 0
+    float lg[FBBEV_DAF_MAXL][P];
+#pragma unroll
+    for (int k = 0; k < FBBEV_DAF_MAXL; ++k)
+#pragma unroll
+        for (int p = 0; p < P; ++p) lg[k][p] = 0.f;
     {
-        const int o_lo = m * LP, o_hi = o_lo + LP;
-        for (int T = o_lo / 16; T * 16 < o_hi; ++T) {
-            fbbev_daf_project<KS>(aw_frag, T, xf, lane, pacc);
+        int t_have = -1;
+        for (int l = L - 1; l >= 0; --l) {
+            const int G = m * L + l, T = G >> 1, h8 = (G & 1) * 8;
+            if (T != t_have) {                                                              // uniform
+                fbbev_daf_project<KS>(aw_frag, T, xf, lane, pacc);
+                t_have = T;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int o = 16 * T + 4 * g + r;
-                if (o >= o_lo && o < o_hi) {
-                    const float bias = aw_bias[o];
-#pragma unroll
-                    for (int rt = 0; rt < 4; ++rt) attn_w[(16 * rt + j) * LDW + (o - o_lo)] = pacc[rt][r] + bias;
-                }
+                for (int rt = 0; rt < 4; ++rt) __builtin_memcpy(off_w + (16 * rt + j) * FBBEV_DAF_OS + 4 * g, &pacc[rt], 16);
+                fbbev_wave_sync();
             }
+            fbbev_v4f c0, c1;
+            __builtin_memcpy(&c0, off_w + lane * FBBEV_DAF_OS + h8, 16);
+            __builtin_memcpy(&c1, off_w + lane * FBBEV_DAF_OS + h8 + 4, 16);
+            if (l == 0 || ((m * L + l - 1) >> 1) != T) fbbev_wave_sync();                   // the next level overwrites the tile
+#pragma unroll
+            for (int k = FBBEV_DAF_MAXL - 1; k > 0; --k)
+#pragma unroll
+                for (int p = 0; p < P; ++p) lg[k][p] = lg[k - 1][p];
+#pragma unroll
+            for (int p = 0; p < P; ++p) lg[0][p] = (p < 4 ? c0[p] : c1[p - 4]) + aw_bias[G * P + p];
         }
     }
-    fbbev_wave_sync();
-    float* my_attn = attn_w + lane * LDW;
     {   // softmax over the unit's L*P logits (spatial_cross_attention_depth.py:546-551): exp(x - max) / sum, as ATen's kernel
-        float mx = my_attn[0];
-        for (int i = 1; i < LP; ++i) mx = fmaxf(mx, my_attn[i]);
+        float mx = lg[0][0];
+#pragma unroll
+        for (int k = 0; k < FBBEV_DAF_MAXL; ++k)
+            if (k < L)
+#pragma unroll
+                for (int p = 0; p < P; ++p) mx = fmaxf(mx, lg[k][p]);
         float sum = 0.f;
-        for (int i = 0; i < LP; ++i) { const float e = __expf(my_attn[i] - mx); my_attn[i] = e; sum += e; }
+#pragma unroll
+        for (int k = 0; k < FBBEV_DAF_MAXL; ++k)
+            if (k < L)
+#pragma unroll
+                for (int p = 0; p < P; ++p) { lg[k][p] = __expf(lg[k][p] - mx); sum += lg[k][p]; }
         const float inv_sum = 1.f / sum;
-        for (int i = 0; i < LP; ++i) my_attn[i] *= inv_sum;
+#pragma unroll
+        for (int k = 0; k < FBBEV_DAF_MAXL; ++k)
+#pragma unroll
+            for (int p = 0; p < P; ++p) lg[k][p] *= inv_sum;
     }
     const int qy = y0 + (lane >> 3), qx = x0 + (lane & 7);
     const bool valid = qy < bev_h && qx < bev_w;
@@ -311,7 +340,7 @@ k_da_cross_attn_fused(const float* __restrict__ planes, const int64_t* __restric
                 const int z = p % ZA;
                 const float ox = o4[p >> 1][2 * (p & 1)], oy = o4[p >> 1][2 * (p & 1) + 1];
                 const float loc_w = rx[z] + __fdiv_rn(ox, fsw), loc_h = ry[z] + __fdiv_rn(oy, fsh);
-                const float weight = fbbev_lds_ld_f32(my_attn + l * P + p) * dw[z];
+                const float weight = lg[0][p] * dw[z];
                 fbbev_daf_issue<DH>(plane, lvl_off, loc_h * fsh - 0.5f, loc_w * fsw - 0.5f, sh, sw, weight, hit, slot);
             };
 #pragma unroll
@@ -324,6 +353,10 @@ k_da_cross_attn_fused(const float* __restrict__ planes, const int64_t* __restric
                 fbbev_sched_fence();
             }
         }
+#pragma unroll
+        for (int k = 0; k + 1 < FBBEV_DAF_MAXL; ++k)                   // the next level's weights move to row 0
+#pragma unroll
+            for (int p = 0; p < P; ++p) lg[k][p] = lg[k + 1][p];
     }
     if (!valid) return;
     const float inv = (float)(count > 1 ? count : 1);

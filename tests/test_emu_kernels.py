@@ -1294,7 +1294,7 @@ def test_history_warp_lds_staged_equals_gather_kernel_emulated(dt, monkeypatch):
                        ref.view(torch.int16 if dt == torch.float16 else torch.int32)) and torch.isnan(big[:, :3].float()).all()
 
 
-def test_fused_da_cross_attention_emulated():
+def test_one_kernel_da_cross_attention_emulated():
     """fbbev_da_cross_attn_fused -> k_da_cross_attn_fused (round 4): query rows -> slots in one kernel -- the sampling_offsets /
     attention_weights projections on the split-operand bf16 MFMA inside the workgroup, softmax in LDS, head-plane camera tokens,
     a wave = one head of an 8 x 8 patch of BEV queries -- against the oracle's composite (spatial_cross_attention_depth.py:136-223,
@@ -1303,7 +1303,9 @@ def test_fused_da_cross_attention_emulated():
     planes as the row-major projection re-laid out; unsupported shapes are refused."""
     cases = ((21, dict(B=1, Q=8 * 8, shapes=((6, 9),)), 8),                                  # one full patch, one level
              (22, dict(B=2, Q=5 * 11, shapes=((16, 44), (8, 22))), 11),                       # partial patches in x and y
-             (23, dict(B=1, Q=9 * 8, shapes=((5, 7), (9, 6), (3, 4), (2, 2))), 8))            # 4 levels (LP = 32), a 2-wide level
+             (23, dict(B=1, Q=9 * 8, shapes=((5, 7), (9, 6), (3, 4), (2, 2))), 8),            # 4 levels (LP = 32), a 2-wide level
+             (25, dict(B=1, Q=8 * 8, shapes=((5, 7), (4, 6), (3, 4))), 8))                    # 3 levels: a head's logits straddle MFMA tiles
+    import os
     for seed, kw, bev_w in cases:
         args, exp, ex = _da_case(seed, E=80, M=8, P=8, DC=20, extras=True, **kw)
         value, ss, ls, pred, ref_cam, mask, qdepth, offsets, attn, d0, dstep = args
@@ -1325,11 +1327,19 @@ def test_fused_da_cross_attention_emulated():
             add = None
             if with_pos:      # per-row addend (period B*Q): the general form; a (Q, E) table repeats with period Q
                 add = ex['qpos'].reshape(B * Q, -1).contiguous()
-            code, slots = E.da_cross_attn_fused(planes, ss, ls, pred, ref_cam, mask, qdepth, q, add,
-                                                Pm[pre + 'sampling_offsets.weight'].contiguous(), Pm[pre + 'sampling_offsets.bias'].contiguous(),
-                                                Pm[pre + 'attention_weights.weight'].contiguous(), Pm[pre + 'attention_weights.bias'].contiguous(),
-                                                8, d0, dstep, bev_w)
-            assert code == 0, code
+            both = []
+            for hw in ('8', '4'):      # heads per workgroup: one 512-thread workgroup per patch / two 256-thread ones (the default)
+                os.environ['FBBEV_DA_FUSED_HW'] = hw
+                try:
+                    code, slots = E.da_cross_attn_fused(planes, ss, ls, pred, ref_cam, mask, qdepth, q, add,
+                                                        Pm[pre + 'sampling_offsets.weight'].contiguous(), Pm[pre + 'sampling_offsets.bias'].contiguous(),
+                                                        Pm[pre + 'attention_weights.weight'].contiguous(), Pm[pre + 'attention_weights.bias'].contiguous(),
+                                                        8, d0, dstep, bev_w)
+                finally:
+                    del os.environ['FBBEV_DA_FUSED_HW']
+                assert code == 0, code
+                both.append(slots)
+            assert torch.equal(both[0], both[1]), seed                        # the same per-wave arithmetic: the same bits
             assert not torch.isnan(slots).any(), seed
             scale = exp.abs().max().item()
             assert (slots - exp).abs().max().item() <= 1e-4 * max(scale, 1.0), (seed, with_pos, (slots - exp).abs().max().item(), scale)
