@@ -56,6 +56,26 @@ def main():
     t_fb = (time.perf_counter() - t0) / n
     rec = {'config': name, 'B': B, 'levels': levels, 'ms_forward_train_mode': t_f * 1e3, 'ms_forward_backward': t_fb * 1e3,
            'samples_per_s_train_step': B / t_fb}
+    # the same step with the upstream gradient HANDED OVER (out.backward(g), g in out's own memory layout) instead of produced by
+    # the harness's synthetic loss: (out * w).sum() costs a multiply, a reduction and their backward over the whole volume, and
+    # a contiguous w makes autograd re-lay the gradient out -- none of which is the path
+    g_direct = torch.empty_strided(out.shape, out.stride(), dtype=out.dtype, device=dev).copy_(w)
+
+    def step_direct():
+        for p in m.parameters():
+            p.grad = None
+        depth.grad = ctx.grad = None
+        o = m(cam, ctx, depth, mlvl_feats=mlvl)
+        o.backward(g_direct)
+    for _ in range(3):
+        step_direct()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step_direct()
+    torch.cuda.synchronize()
+    rec['ms_forward_backward_gradient_handed_over'] = (time.perf_counter() - t0) / n * 1e3
+    rec['out_stride'] = list(out.stride())
     if 'sites' in sys.argv:
         # where the torch glue of the step spends device time: ATen ops by Python call site (forward) / by op + shapes (backward
         # nodes have no Python stack), one step
