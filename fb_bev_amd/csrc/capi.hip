@@ -1698,7 +1698,7 @@ static bool da_own_plan_make(int B, int Ncam, int S, int M, int Dh, int Q, int H
     if (lds > budget_bytes + 12 * 1024) return false;
     pl->lds = lds;
     pl->threads = 512;
-    { const int v = da_bwd_env().threads; if (v == 256 || v == 512 || v == 1024) pl->threads = v; }
+    { const int v = da_bwd_env().threads; if (v == 256 || v == 512) pl->threads = v; }
     if ((long long)n * B * Ncam * M >= (1ll << 31) || (long long)B * Ncam * Q >= (1ll << 31)) return false;
     if (mode < 0 && (long long)n * B * Ncam * M < 256) return false;              // too few planes to fill the chip: chunked scatter
     pl->off_list = align_up((size_t)B * Ncam * Q * pl->info_stride * sizeof(float), 256);
@@ -1783,7 +1783,7 @@ static int da_bwd_owned_launch(const da_own_plan& op, fbbev_rt_stream stream, co
                      (const float*)info, op.info_stride, (const int*)hit_list, (const int*)hit_count,                    \
                      (const unsigned int*)gmax_bits, (head_minor & 4) ? 1 : 0, grad_value);                              \
     } while (0)
-#define FBBEV_DA_OWN_NT(DH_) do { if (op.threads == 1024) FBBEV_DA_OWN(1024, DH_); else if (op.threads == 512) FBBEV_DA_OWN(512, DH_); else FBBEV_DA_OWN(256, DH_); } while (0)
+#define FBBEV_DA_OWN_NT(DH_) do { if (op.threads == 512) FBBEV_DA_OWN(512, DH_); else FBBEV_DA_OWN(256, DH_); } while (0)   /* 1024 threads measured slower */
     if (Dh == 10) FBBEV_DA_OWN_NT(10);
     else if (Dh == 8) FBBEV_DA_OWN_NT(8);
     else if (Dh == 4) FBBEV_DA_OWN_NT(4);

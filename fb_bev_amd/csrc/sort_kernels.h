@@ -443,7 +443,7 @@ k_sort_scatter_seg(const unsigned int* __restrict__ keys_in, const unsigned int*
         chunk_id = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
         if (chunk_id >= total) return;                    // block-uniform
     }
-    __shared__ int cnt[WAVES][NBM];      // per-wave running digit counters, then (in place) each wave's first position of a digit
+    __shared__ __attribute__((aligned(16))) int cnt[WAVES][NBM];      // per-wave running digit counters, then (in place) each wave's first position of a digit
     __shared__ int pos0[NBM];            // global position of this chunk's first key of a digit
     __shared__ int red[2 * WAVES];
     __shared__ int ldsw[WAVES];
@@ -452,7 +452,6 @@ k_sort_scatter_seg(const unsigned int* __restrict__ keys_in, const unsigned int*
     const unsigned int dmask = (unsigned int)nb - 1u;
     const int b = chunk_id / sg.cps, c = chunk_id - b * sg.cps;
     const unsigned int kbase = (unsigned int)b * sg.vps;
-    for (int i = tid; i < WAVES * NBM; i += NT) (&cnt[0][0])[i] = 0;
     // the sample's range in the compacted order (= where its sorted pairs go, and pass 1's input range)
     int s0, s1;
     fbbev_seg_prefix2<WAVES>(ctot, b * sg.cps, (b + 1) * sg.cps, red, s0, s1);
@@ -465,35 +464,8 @@ k_sort_scatter_seg(const unsigned int* __restrict__ keys_in, const unsigned int*
     const long long in1 = pass == 0 ? (long long)(b + 1) * sg.npb : (long long)s1;
     const long long chunk0 = in0 + (long long)c * FBBEV_SEG_TILE;
     if (chunk0 >= in1) return;                            // block-uniform
-    // column sums over the rows of this sample: digit totals and the prefix over its earlier chunks
-    const int row0 = b * sg.cps;
-    for (int d = tid; d < nb; d += NT) {
-        int pre = 0, all = 0;
-        constexpr int U = 8;                              // row loads in flight per thread: the loop is latency bound; masked batches
-                                                          // (no one-at-a-time remainder: cps = 31 used to take 3 batches of 8 + 7 serial loads)
-        const int* col = matrix + (long long)row0 * nb + d;
-        for (int r = 0; r < sg.cps; r += U) {
-            int v[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) v[u] = col[(long long)(r + u < sg.cps ? r + u : sg.cps - 1) * nb];     // unconditional (clamped) loads
-#pragma unroll
-            for (int u = 0; u < U; ++u) { if (r + u < sg.cps) all += v[u]; if (r + u < c) pre += v[u]; }
-        }
-        pos0[d] = pre;
-        cnt[0][d] = all;                                  // parked: scanned below, then cleared again
-    }
-    __syncthreads();
-    // exclusive scan of the digit totals over d (nb <= 2 * NT: two values per thread)
-    {
-        const int d0 = 2 * tid, d1 = 2 * tid + 1;
-        const int a0 = d0 < nb ? cnt[0][d0] : 0, a1 = d1 < nb ? cnt[0][d1] : 0;
-        int total;
-        const int ex = fbbev_block_excl_scan_w<WAVES, false>(a0 + a1, ldsw, &total);
-        __syncthreads();
-        if (d0 < nb) { pos0[d0] += s0 + ex; cnt[0][d0] = 0; }
-        if (d1 < nb) { pos0[d1] += s0 + ex + a0; cnt[0][d1] = 0; }
-    }
-    __syncthreads();
+    // the wave's pairs are requested FIRST: their round trip runs under the column sums below (round 4; the prologue used to
+    // be 10.7 of the pass's 35 us with the loads behind it, profiles/r04_rank_scatter_probes.txt)
     const long long chunk = chunk0 + (long long)wave * (64 * ROUNDS);
     unsigned int k[ROUNDS], v[ROUNDS];
     int lr[ROUNDS];
@@ -511,6 +483,49 @@ k_sort_scatter_seg(const unsigned int* __restrict__ keys_in, const unsigned int*
             v[r] = valid ? (vals_in ? vals_in[idx] : (unsigned int)idx) : 0u;
         }
     }
+    // column sums over the rows of this sample: digit totals and the prefix over its earlier chunks.  A thread takes FOUR
+    // adjacent digits (16-byte loads) of every second row: 2 x nb / 4 threads, ceil(cps / 2) loads each in batches of 8 (two
+    // round trips at cps = 31 where one digit pair per thread took eight); the two row groups meet in LDS (rows 1..4 of cnt,
+    // cleared again below)
+    const int row0 = b * sg.cps;
+    {
+        const int nq = nb >> 2;                            // nb >= 4
+        const int quad = tid % nq, rg = tid / nq;          // rg < 2 works
+        fbbev_v4i pre = {0, 0, 0, 0}, all = {0, 0, 0, 0};
+        if (rg < 2) {
+            constexpr int U = 8;
+            const int* col = matrix + (long long)row0 * nb + 4 * quad;
+            for (int r = rg; r < sg.cps; r += 2 * U) {
+                fbbev_v4i t[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int rr = r + 2 * u < sg.cps ? r + 2 * u : sg.cps - 1;          // unconditional (clamped) loads
+                    __builtin_memcpy(&t[u], col + (long long)rr * nb, 16);               // 16-byte aligned: nb % 4 == 0
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (r + 2 * u < sg.cps) all += t[u];
+                    if (r + 2 * u < c) pre += t[u];
+                }
+            }
+            __builtin_memcpy(&cnt[1 + rg][4 * quad], &pre, 16);
+            __builtin_memcpy(&cnt[3 + rg][4 * quad], &all, 16);
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the digit totals over d (nb <= 2 * NT: two values per thread)
+    {
+        const int d0 = 2 * tid, d1 = 2 * tid + 1;
+        const int a0 = d0 < nb ? cnt[3][d0] + cnt[4][d0] : 0, a1 = d1 < nb ? cnt[3][d1] + cnt[4][d1] : 0;
+        const int p0 = d0 < nb ? cnt[1][d0] + cnt[2][d0] : 0, p1 = d1 < nb ? cnt[1][d1] + cnt[2][d1] : 0;
+        int total;
+        const int ex = fbbev_block_excl_scan_w<WAVES, false>(a0 + a1, ldsw, &total);
+        if (d0 < nb) pos0[d0] = p0 + s0 + ex;
+        if (d1 < nb) pos0[d1] = p1 + s0 + ex + a0;
+    }
+    __syncthreads();                                      // every partial has been read
+    for (int i = tid; i < WAVES * NBM; i += NT) (&cnt[0][0])[i] = 0;
+    __syncthreads();
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
         const bool valid = k[r] != FBBEV_DROP_KEY;
