@@ -98,6 +98,8 @@ SIGNATURES = {
     'fbbev_da_cross_attn_bwd_ws_bytes': (c_size_t, [c_int] * 9 + [c_void_p]),
     'fbbev_da_cross_attn_bwd_ws': (c_int, [c_void_p] * 10 + [c_int] * 10 + [c_float, c_float, c_int, c_int] + [c_void_p] * 4 +
                                    [c_void_p, c_void_p, c_size_t, c_void_p]),
+    'fbbev_da_cross_attn_bwd_ws_grid': (c_int, [c_void_p] * 10 + [c_int] * 10 + [c_float, c_float, c_int, c_int] + [c_void_p] * 4 +
+                                        [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     'fbbev_msda_fwd_fused': (c_int, [c_void_p] * 6 + [c_int] * 9 + [c_void_p, c_void_p]),
     'fbbev_msda_bwd': (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p] * 3 + [c_void_p]),
     'fbbev_msda_bwd_ws_bytes': (c_size_t, [c_int] * 7 + [c_void_p]),
@@ -552,8 +554,9 @@ def da_cross_attn_bwd_ws_bytes(B, Ncam, S, M, Dh, Q, HS, L, P, level_hw=None):
 
 def da_cross_attn_bwd(value, spatial_shapes, level_start_index, pred_depth, ref_cam, mask, qdepth, offsets, attn,
                       grad_slots, d0, dstep, head_minor, grad_value, grad_pred_depth, grad_offsets, grad_attn, head_dim=None,
-                      lds_planes=True, level_hw=None):
-    """Backward of da_cross_attn_fwd; the four grad tensors must be pre-zeroed (accumulated into)."""
+                      lds_planes=True, level_hw=None, bev_w=0):
+    """Backward of da_cross_attn_fwd; the four grad tensors must be pre-zeroed (accumulated into).  bev_w: width of the BEV grid
+    the Q queries form (0 = a plain list): lets the unit-gradient kernel take 8 x 8 patches of it."""
     Ncam, B, Q, Za = mask.shape
     _, S, M, HS = value.shape
     Dh = HS if head_dim is None else int(head_dim)
@@ -576,7 +579,8 @@ def da_cross_attn_bwd(value, spatial_shapes, level_start_index, pred_depth, ref_
         need = lib().fbbev_da_cross_attn_bwd_ws_bytes(B, Ncam, S, M, Dh, Q, HS, L, P, arr) if lds_planes else 0
         if need:
             ws = torch.empty(need // 4, dtype=torch.float32, device=value.device)
-            _check(lib().fbbev_da_cross_attn_bwd_ws(*args, arr, ws.data_ptr(), need, _stream()), 'fbbev_da_cross_attn_bwd_ws')
+            _check(lib().fbbev_da_cross_attn_bwd_ws_grid(*args, arr, ws.data_ptr(), need, int(bev_w or 0), _stream()),
+                   'fbbev_da_cross_attn_bwd_ws_grid')
         else:
             _check(lib().fbbev_da_cross_attn_bwd(*args, _stream()), 'fbbev_da_cross_attn_bwd')
 

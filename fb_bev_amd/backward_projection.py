@@ -446,7 +446,7 @@ class FusedDACrossAttention(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, value, pred_depth, offsets, attn, spatial_shapes, level_start_index, ref_cam, mask, qdepth,
-                d0, dstep, head_minor, head_dim=None, level_hw=None):
+                d0, dstep, head_minor, head_dim=None, level_hw=None, bev_w=0):
         B, Q = offsets.shape[0], offsets.shape[1]
         M = value.shape[2]
         Dh = value.shape[3] if head_dim is None else head_dim          # value rows may be head-padded (stride value.shape[3])
@@ -454,18 +454,18 @@ class FusedDACrossAttention(torch.autograd.Function):
         _capi.da_cross_attn_fwd(value, spatial_shapes, level_start_index, pred_depth, ref_cam, mask, qdepth, offsets,
                                 attn, d0, dstep, slots, head_minor=head_minor, head_dim=Dh)
         ctx.save_for_backward(value, pred_depth, offsets, attn, spatial_shapes, level_start_index, ref_cam, mask, qdepth)
-        ctx.consts = (d0, dstep, head_minor, Dh, level_hw)
+        ctx.consts = (d0, dstep, head_minor, Dh, level_hw, int(bev_w or 0))
         return slots
 
     @staticmethod
     def backward(ctx, grad_slots):
         value, pred_depth, offsets, attn, spatial_shapes, level_start_index, ref_cam, mask, qdepth = ctx.saved_tensors
-        d0, dstep, head_minor, Dh, level_hw = ctx.consts
+        d0, dstep, head_minor, Dh, level_hw, bev_w = ctx.consts
         gv, gd, go, ga = (torch.zeros_like(t) for t in (value, pred_depth, offsets, attn))
         _capi.da_cross_attn_bwd(value, spatial_shapes, level_start_index, pred_depth, ref_cam, mask, qdepth, offsets,
                                 attn, grad_slots.contiguous().float(), d0, dstep, head_minor, gv, gd, go, ga, head_dim=Dh,
-                                level_hw=level_hw)
-        return gv, gd, go, ga, None, None, None, None, None, None, None, None, None, None
+                                level_hw=level_hw, bev_w=bev_w)       # the BEV row length: the unit gradients take 8 x 8 query patches
+        return gv, gd, go, ga, None, None, None, None, None, None, None, None, None, None, None
 
 
 def _pad_interleave_rows(w, b, M, Dh, HS, interleave=True, piece=4):
@@ -598,7 +598,7 @@ class DA_SpatialCrossAttention(nn.Module):
             so.contiguous().float(), aw.contiguous().float(), spatial_shapes.to(torch.int64).contiguous(),
             level_start_index.to(torch.int64).contiguous(), reference_points_cam.contiguous().float(), mask.contiguous(),
             bev_query_depth.squeeze(-1).contiguous().float(), self.dbound[0], self.dbound[2], 1 | (4 if interleave else 0), Dh,
-            host_values(spatial_shapes))
+            host_values(spatial_shapes), bev_w or 0)
 
     # ---- inference default since round 4: query rows -> slots in ONE kernel (fbbev_da_cross_attn_fused, da_fused_kernels.h)
     def _slots_one_kernel(self, da, x, query, query_pos, reference_points_cam, mask, bev_query_depth, pred_img_depth,

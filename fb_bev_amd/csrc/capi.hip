@@ -17,6 +17,7 @@
 #include "history_conv_x3_kernels.h"
 #include "rows_linear_kernels.h"
 #include "da_fused_kernels.h"
+#include "da_bwd_planes_kernels.h"
 #include "msda_bwd_kernels.h"
 #include "conv3d_kernels.h"
 #include "../../include/fbbev.h"
@@ -1631,7 +1632,7 @@ static bool da_bwd_tile_plan(int B, int Ncam, int S, int M, int Dh, int Q, int H
 }
 
 // ---- output-owned planes (k_da_bwd_scatter_owned; FBBEV_DA_BWD_OWNED=0 restores the chunked scatter above)
-struct da_own_plan { fbbev_da_bwd_region_tab tab; int threads, info_stride; size_t lds, off_list, off_count, off_gmax, ws; };
+struct da_own_plan { fbbev_da_bwd_region_tab tab; int threads, info_stride, unit_planes; size_t lds, off_list, off_count, off_gmax, off_planes, ws; };
 // FBBEV_DA_BWD_OWNED: 1 = whenever the shape is supported, 0 = never, unset = when the launch has at least one workgroup per CU
 // (the shipped single-level shape at B = 4 has 192 (sample, camera, head) planes: the chunked scatter's 512 workgroups win there)
 static int da_bwd_owned_mode() {
@@ -1705,6 +1706,24 @@ static bool da_own_plan_make(int B, int Ncam, int S, int M, int Dh, int Q, int H
     pl->off_count = pl->off_list + align_up((size_t)B * Ncam * Q * sizeof(int), 256);
     pl->off_gmax = pl->off_count + align_up((size_t)B * Ncam * sizeof(int), 256);
     pl->ws = pl->off_gmax + 256;
+    // unit gradients on head planes (k_da_bwd_unit_planes, da_bwd_planes_kernels.h; FBBEV_DA_BWD_UNIT_PLANES=0 keeps the row kernel):
+    // M = 8, Dh in {8, 10}, 8 points, 4 anchors, every level at least 2 tokens wide; the planes sit behind the hit lists
+    pl->unit_planes = 0;
+    pl->off_planes = pl->ws;
+    {
+#ifdef FBBEV_TEST_OVERRIDES
+        const char* e = getenv("FBBEV_DA_BWD_UNIT_PLANES"); const bool on = !(e && atoi(e) == 0);
+#else
+        static const bool on = [] { const char* e = getenv("FBBEV_DA_BWD_UNIT_PLANES"); return !(e && atoi(e) == 0); }();
+#endif
+        bool wide = level_hw != nullptr;
+        for (int l = 0; wide && l < L; ++l) wide = level_hw[2 * l + 1] >= 2;
+        if (on && wide && M == 8 && (Dh == 10 || Dh == 8) && P == FBBEV_DAF_P && (long long)S * Dh * 4 < (1ll << 31) &&
+            fbbev_dbp_lds_bytes(M, Ncam) <= 156 * 1024) {
+            pl->unit_planes = 1;
+            pl->ws += align_up((size_t)B * Ncam * M * S * Dh * sizeof(float), 256);
+        }
+    }
     return true;
 }
 
@@ -1757,7 +1776,7 @@ static int da_bwd_owned_launch(const da_own_plan& op, fbbev_rt_stream stream, co
                                const float* qdepth, const float* offsets, const float* attn, const float* grad_slots, int B,
                                int Ncam, int S, int M, int Dh, int L, int Q, int P, int Za, int DC, float d0, float dstep,
                                int head_minor, int HS, float* grad_value, float* grad_pred_depth, float* grad_offsets,
-                               float* grad_attn, void* ws) {
+                               float* grad_attn, void* ws, int bev_w) {
     char* w = static_cast<char*>(ws);
     float* info = reinterpret_cast<float*>(w);
     int* hit_list = reinterpret_cast<int*>(w + op.off_list);
@@ -1765,10 +1784,36 @@ static int da_bwd_owned_launch(const da_own_plan& op, fbbev_rt_stream stream, co
     unsigned int* gmax_bits = reinterpret_cast<unsigned int*>(w + op.off_gmax);
     FBBEV_LAUNCH(k_da_bwd_init, 1, 256, 0, stream, B * Ncam, hit_count, 1, gmax_bits);
     FBBEV_CHECK_LAUNCH();
-    int e = da_bwd_unit_launch(stream, value, spatial_shapes, level_start_index, pred_depth, ref_cam, mask, qdepth, offsets, attn,
+    int e = 0;
+    if (op.unit_planes && Za == FBBEV_DAF_ZA) {
+        // camera tokens as head planes, then the unit gradients with the forward's (head, patch) mapping
+        float* planes = reinterpret_cast<float*>(w + op.off_planes);
+        const long long n_el = (long long)B * Ncam * S * M * Dh;
+        FBBEV_LAUNCH(k_value_rows_to_head_planes, (n_el + 255) / 256, 256, 0, stream, value, (long long)B * Ncam * S, S, M, Dh, HS,
+                     (head_minor & 4) ? 1 : 0, planes);
+        FBBEV_CHECK_LAUNCH();
+        const int gw = (bev_w > 0 && Q % bev_w == 0) ? bev_w : 0;
+        const long long wgs_u = gw > 0 ? (long long)B * ((gw + 7) / 8) * ((Q / gw + 7) / 8) : (long long)B * ((Q + 63) / 64);
+        const long long grid_u = (wgs_u + 7) / 8 * 8;
+        const size_t lds_u = fbbev_dbp_lds_bytes(M, Ncam);
+        if (grid_u >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
+#define FBBEV_DA_UNIT_PLANES(DH_)                                                                                     \
+    do {                                                                                                               \
+        e = fbbev_rt_allow_dyn_lds((const void*)k_da_bwd_unit_planes<DH_, 8>, lds_u);                                  \
+        if (e) return e;                                                                                               \
+        FBBEV_LAUNCH((k_da_bwd_unit_planes<DH_, 8>), grid_u, 512, lds_u, stream, (const float*)planes, spatial_shapes,  \
+                     level_start_index, pred_depth, ref_cam, mask, qdepth, offsets, attn, grad_slots, B, Ncam, S, L, Q, \
+                     gw, DC, d0, dstep, head_minor & 3, grad_pred_depth, grad_offsets, grad_attn, gmax_bits);           \
+    } while (0)
+        if (Dh == 10) FBBEV_DA_UNIT_PLANES(10); else FBBEV_DA_UNIT_PLANES(8);
+#undef FBBEV_DA_UNIT_PLANES
+        FBBEV_CHECK_LAUNCH();
+    } else {
+        e = da_bwd_unit_launch(stream, value, spatial_shapes, level_start_index, pred_depth, ref_cam, mask, qdepth, offsets, attn,
                                grad_slots, B, Ncam, S, M, Dh, L, Q, P, Za, DC, d0, dstep, head_minor, HS, grad_pred_depth,
                                grad_offsets, grad_attn, gmax_bits);
-    if (e) return e;
+        if (e) return e;
+    }
     FBBEV_LAUNCH(k_da_bwd_hitlist, (long long)B * ((Q + 255) / 256), 256, 0, stream, spatial_shapes, pred_depth, ref_cam, mask,
                  qdepth, B, Ncam, Q, Za, DC, d0, dstep, op.info_stride, info, hit_list, hit_count);
     FBBEV_CHECK_LAUNCH();
@@ -1794,15 +1839,15 @@ static int da_bwd_owned_launch(const da_own_plan& op, fbbev_rt_stream stream, co
     return 0;
 }
 
-extern "C" int fbbev_da_cross_attn_bwd_ws(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+static int da_cross_attn_bwd_ws_impl(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
                                           const float* pred_depth, const float* ref_cam, const uint8_t* mask,
                                           const float* qdepth, const float* offsets, const float* attn,
                                           const float* grad_slots, int B, int Ncam, int S, int M, int Dh, int L, int Q,
                                           int P, int Za, int DC, float d0, float dstep, int head_minor, int head_stride,
                                           float* grad_value, float* grad_pred_depth, float* grad_offsets,
                                           float* grad_attn, const int32_t* level_hw_host, void* ws, size_t ws_bytes,
-                                          fbbev_stream_t stream_) {
-    if (B <= 0 || Ncam <= 0 || S <= 0 || M <= 0 || Dh <= 0 || L <= 0 || Q < 0 || P <= 0 || Za <= 0 || DC <= 0)
+                                          fbbev_stream_t stream_, int bev_w) {
+    if (B <= 0 || Ncam <= 0 || S <= 0 || M <= 0 || Dh <= 0 || L <= 0 || Q < 0 || P <= 0 || Za <= 0 || DC <= 0 || bev_w < 0)
         return FBBEV_E_BADARG;
     const int HS = head_stride == 0 ? Dh : head_stride;
     {
@@ -1814,7 +1859,7 @@ extern "C" int fbbev_da_cross_attn_bwd_ws(const float* value, const int64_t* spa
             da_own_plan_make(B, Ncam, S, M, Dh, Q, HS, L, P, Za, level_hw_host, &op) && ws_bytes >= op.ws)
             return da_bwd_owned_launch(op, (fbbev_rt_stream)stream_, value, spatial_shapes, level_start_index, pred_depth, ref_cam,
                                        mask, qdepth, offsets, attn, grad_slots, B, Ncam, S, M, Dh, L, Q, P, Za, DC, d0, dstep,
-                                       head_minor, HS, grad_value, grad_pred_depth, grad_offsets, grad_attn, ws);
+                                       head_minor, HS, grad_value, grad_pred_depth, grad_offsets, grad_attn, ws, bev_w);
     }
     da_bwd_plan pl;
     if (HS < Dh || Q == 0 || !ws || !aligned16(ws) || !aligned16(grad_value) || !aligned16(value) ||
@@ -1877,6 +1922,34 @@ extern "C" int fbbev_da_cross_attn_bwd_ws(const float* value, const int64_t* spa
                  grad_value);
     FBBEV_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int fbbev_da_cross_attn_bwd_ws(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                          const float* pred_depth, const float* ref_cam, const uint8_t* mask,
+                                          const float* qdepth, const float* offsets, const float* attn,
+                                          const float* grad_slots, int B, int Ncam, int S, int M, int Dh, int L, int Q,
+                                          int P, int Za, int DC, float d0, float dstep, int head_minor, int head_stride,
+                                          float* grad_value, float* grad_pred_depth, float* grad_offsets,
+                                          float* grad_attn, const int32_t* level_hw_host, void* ws, size_t ws_bytes,
+                                          fbbev_stream_t stream_) {
+    return da_cross_attn_bwd_ws_impl(value, spatial_shapes, level_start_index, pred_depth, ref_cam, mask, qdepth, offsets, attn,
+                                     grad_slots, B, Ncam, S, M, Dh, L, Q, P, Za, DC, d0, dstep, head_minor, head_stride,
+                                     grad_value, grad_pred_depth, grad_offsets, grad_attn, level_hw_host, ws, ws_bytes, stream_, 0);
+}
+// ... with the BEV grid's width: the queries are a (Q / bev_w) x bev_w grid, so the unit gradients take 8 x 8 patches of it
+// (k_da_bwd_unit_planes; bev_w = 0 or not a divisor of Q: runs of 64 consecutive queries)
+extern "C" int fbbev_da_cross_attn_bwd_ws_grid(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                               const float* pred_depth, const float* ref_cam, const uint8_t* mask,
+                                               const float* qdepth, const float* offsets, const float* attn,
+                                               const float* grad_slots, int B, int Ncam, int S, int M, int Dh, int L, int Q,
+                                               int P, int Za, int DC, float d0, float dstep, int head_minor, int head_stride,
+                                               float* grad_value, float* grad_pred_depth, float* grad_offsets,
+                                               float* grad_attn, const int32_t* level_hw_host, void* ws, size_t ws_bytes,
+                                               int bev_w, fbbev_stream_t stream_) {
+    return da_cross_attn_bwd_ws_impl(value, spatial_shapes, level_start_index, pred_depth, ref_cam, mask, qdepth, offsets, attn,
+                                     grad_slots, B, Ncam, S, M, Dh, L, Q, P, Za, DC, d0, dstep, head_minor, head_stride,
+                                     grad_value, grad_pred_depth, grad_offsets, grad_attn, level_hw_host, ws, ws_bytes, stream_,
+                                     bev_w);
 }
 
 // ---------------------------------------------------------------- fused lift-splat backward (training)

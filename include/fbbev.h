@@ -475,6 +475,20 @@ int fbbev_da_cross_attn_bwd_ws(const float* value, const int64_t* spatial_shapes
                                float* grad_value, float* grad_pred_depth, float* grad_offsets,
                                float* grad_attn, const int32_t* level_hw_host, void* ws, size_t ws_bytes,
                                fbbev_stream_t stream);
+/* fbbev_da_cross_attn_bwd_ws for queries that form a (Q / bev_w) x bev_w BEV grid (bevformer_encoder.py:91-120: the reference's
+ * queries always do).  Round 4: on the output-owned route the unit gradients (step A) run on HEAD PLANES with the forward's mapping
+ * (k_da_bwd_unit_planes: the camera tokens are re-laid out as (B*Ncam, M, S, Dh) planes in `ws`, a workgroup = the 8 heads of an
+ * 8 x 8 patch of queries, a wave = one head) when M = 8, Dh in {8, 10}, 8 points, 4 anchors, levels >= 2 tokens wide
+ * (FBBEV_DA_BWD_UNIT_PLANES=0 keeps k_da_cross_attn_bwd_unit).  bev_w = 0 (or not a divisor of Q): patches of 64 consecutive
+ * queries -- what fbbev_da_cross_attn_bwd_ws does. */
+int fbbev_da_cross_attn_bwd_ws_grid(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                               const float* pred_depth, const float* ref_cam, const uint8_t* mask,
+                               const float* qdepth, const float* offsets, const float* attn,
+                               const float* grad_slots, int B, int Ncam, int S, int M, int Dh, int L, int Q,
+                               int P, int Za, int DC, float d0, float dstep, int head_minor, int head_stride,
+                               float* grad_value, float* grad_pred_depth, float* grad_offsets,
+                               float* grad_attn, const int32_t* level_hw_host, void* ws, size_t ws_bytes, int bev_w,
+                               fbbev_stream_t stream);
 
 /* Training backward of the fused lift-splat:  replaces QuickCumsumCuda.backward (bev_pool.py:39-78 --
  * argsort of ranks_feat, mask-built intervals [2 host syncs], the permute().contiguous() of the gradient)

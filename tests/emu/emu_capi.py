@@ -390,7 +390,7 @@ def layernorm_bwd(x, grad_out, weight, eps):
 
 
 def da_cross_attn_bwd(value, ss, ls, pred_depth, ref_cam, mask, qdepth, offsets, attn, d0, dstep, grad_slots, head_minor=0,
-                      head_dim=None, lds_planes=False, level_hw=None):
+                      head_dim=None, lds_planes=False, level_hw=None, bev_w=0):
     Ncam, B, Q, Za = mask.shape
     _, S, M, HS = value.shape
     Dh = HS if head_dim is None else head_dim
@@ -405,7 +405,10 @@ def da_cross_attn_bwd(value, ss, ls, pred_depth, ref_cam, mask, qdepth, offsets,
         assert need > 0
         ws = torch.full((need // 4,), float('nan'))
         gv.fill_(float('nan'))                       # written, not accumulated
-        ok(lib().fbbev_da_cross_attn_bwd_ws(*args, arr, p(ws), need, None))
+        if bev_w:
+            ok(lib().fbbev_da_cross_attn_bwd_ws_grid(*args, arr, p(ws), need, int(bev_w), None))
+        else:
+            ok(lib().fbbev_da_cross_attn_bwd_ws(*args, arr, p(ws), need, None))
     else:
         ok(lib().fbbev_da_cross_attn_bwd(*args, None))
     return gv, gd, go, ga

@@ -829,6 +829,54 @@ def test_fused_da_cross_attention_backward_emulated():
                 os.environ.pop('FBBEV_DA_BWD_COPIES', None)
 
 
+def test_da_backward_unit_gradients_on_head_planes_emulated():
+    """k_da_bwd_unit_planes (round 4: the unit gradients of the DA backward with the forward's mapping -- head planes, a wave = one
+    head of a patch of 64 queries) against k_da_cross_attn_bwd_unit on the same inputs: d/d offsets, d/d attention, d/d depth
+    distribution equal up to fp32 re-association, the value gradient (whose fixed-point scale both kernels fold) bit for bit.
+    8 x 8 patches of a grid that is not a multiple of the patch, runs of 64 consecutive queries, 2 / 4 levels with a 2-wide
+    level, plain and chunk-major token rows."""
+    import os
+    cases = ((31, dict(B=2, Q=5 * 11, shapes=((16, 44), (8, 22))), 11),
+             (32, dict(B=1, Q=9 * 8, shapes=((5, 7), (9, 6), (3, 4), (2, 2))), 8),
+             (33, dict(B=1, Q=70, shapes=((6, 9),)), 0))
+    for seed, kw, bev_w in cases:
+        args, exp = _da_case(seed, E=80, M=8, P=8, DC=20, **kw)
+        value, ss, ls, pred, ref_cam, mask, qdepth, offsets, attn, d0, dstep = args
+        g = torch.randn(exp.shape, generator=torch.Generator().manual_seed(seed))
+        shapes_host = [tuple(int(x) for x in hw) for hw in ss.tolist()]
+        Dh = value.shape[-1]
+        vp = torch.zeros(value.shape[:-1] + (12,)); vp[..., :Dh] = value
+        for hm, vin in ((0, vp), (5, _interleave(vp))):
+            o_in = offsets.permute(0, 1, 3, 4, 2, 5).contiguous() if hm & 1 else offsets
+            got = {}
+            for planes in ('0', '1'):
+                os.environ['FBBEV_DA_BWD_OWNED'] = '1'
+                os.environ['FBBEV_DA_BWD_UNIT_PLANES'] = planes
+                try:
+                    got[planes] = E.da_cross_attn_bwd(vin, ss, ls, pred, ref_cam, mask, qdepth, o_in, attn, d0, dstep, g, head_minor=hm,
+                                                      head_dim=Dh, lds_planes=True, level_hw=shapes_host, bev_w=bev_w)
+                finally:
+                    del os.environ['FBBEV_DA_BWD_OWNED'], os.environ['FBBEV_DA_BWD_UNIT_PLANES']
+            if hm == 0:       # the planes route is planned: its workspace holds the (B*Ncam, M, S, Dh) planes behind the hit lists
+                import ctypes
+                flat = [int(x) for hw in shapes_host for x in hw]
+                harr = (ctypes.c_int32 * len(flat))(*flat)
+                Ncam_, B_, Q_, _ = mask.shape
+                sizes = {}
+                for planes in ('0', '1'):
+                    os.environ['FBBEV_DA_BWD_OWNED'] = '1'
+                    os.environ['FBBEV_DA_BWD_UNIT_PLANES'] = planes
+                    sizes[planes] = E.lib().fbbev_da_cross_attn_bwd_ws_bytes(B_, Ncam_, vp.shape[1], 8, Dh, Q_, 12, len(shapes_host), 8, harr)
+                    del os.environ['FBBEV_DA_BWD_OWNED'], os.environ['FBBEV_DA_BWD_UNIT_PLANES']
+                plane_bytes = B_ * Ncam_ * 8 * vp.shape[1] * Dh * 4
+                assert plane_bytes <= sizes['1'] - sizes['0'] < plane_bytes + 256, (sizes, plane_bytes)
+            assert torch.equal(got['0'][0], got['1'][0]), (seed, hm)                      # value gradient: same scale, same bits
+            for name, x, y in zip(('pred', 'offsets', 'attn'), got['1'][1:], got['0'][1:]):
+                assert not torch.isnan(x).any()
+                scale = y.abs().max().item()
+                assert scale > 0 and (x - y).abs().max().item() <= 2e-6 * scale + 1e-7, (seed, hm, name, (x - y).abs().max().item(), scale)
+
+
 @pytest.mark.parametrize('B,T1,C,N,dt', [(1, 3, 16, 64, torch.float32), (2, 2, 80, 100, torch.bfloat16), (1, 3, 80, 17, torch.float16),
                                          (1, 17, 80, 64, torch.bfloat16)])
 def test_history_conv_bf16_mfma_emulated(B, T1, C, N, dt):

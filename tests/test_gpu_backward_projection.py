@@ -481,15 +481,21 @@ def test_output_owned_plane_backward_at_a_pyramid(dev):
     # the owned route is planned: its workspace is the (camera, query) table + the hit lists, not partial planes
     table, lists = B * Ncam * Q * 8 * 4, B * Ncam * Q * 4
     need = _capi.da_cross_attn_bwd_ws_bytes(B, Ncam, S_, M, Dh, Q, HS, L, P, level_hw=shapes)
-    assert table + lists <= need <= table + lists + 4 * 256, (need, table, lists)
+    planes = B * Ncam * M * S_ * Dh * 4                               # + the camera tokens as head planes for the unit gradients
+    assert table + lists + planes <= need <= table + lists + planes + 5 * 256, (need, table, lists, planes)
 
-    def run(lds):
+    def run(lds, bev_w=0):
         gv = torch.full_like(args[0], float('nan')) if lds else torch.zeros_like(args[0])      # the owned planes write every word
         gd, go, ga = (torch.zeros_like(x) for x in (args[3], args[7], args[8]))
-        _capi.da_cross_attn_bwd(*args, gv, gd, go, ga, head_dim=Dh, lds_planes=lds, level_hw=shapes if lds else None)
+        _capi.da_cross_attn_bwd(*args, gv, gd, go, ga, head_dim=Dh, lds_planes=lds, level_hw=shapes if lds else None, bev_w=bev_w)
         torch.cuda.synchronize()
         return gv, gd, go, ga
     a, b, c = run(True), run(True), run(False)
+    # the unit gradients run on head planes here (k_da_bwd_unit_planes: M = 8, Dh = 10, 8 points, 4 anchors); with the BEV grid's
+    # width they take 8 x 8 patches of the 50 x 100 queries instead of runs of 64: the same sums per unit in the same order
+    d = run(True, bev_w=100)
+    assert torch.equal(a[0], d[0]) and torch.equal(a[2], d[2]) and torch.equal(a[3], d[3])
+    assert (a[1] - d[1]).abs().max().item() <= 2e-6 * a[1].abs().max().item()                # fp32 atomics into the depth planes
     assert not torch.isnan(a[0]).any() and not a[0].view(B * Ncam, S_, HS // 4, M, 4)[:, :, 2, :, 2:].any()   # padding channels stay 0
     assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
     for i, (x, y) in enumerate(zip(a, c)):

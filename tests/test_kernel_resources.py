@@ -76,6 +76,7 @@ BUDGETS = {
                                                # (one wave / SIMD) and every row-wise linear layer of the encoder slowed down: 1.62 -> 1.76 ms
     r'k_da_cross_attn_fusedILi10ELi8ELi2E': 256,   # 8 waves per workgroup, one workgroup per CU: two waves / SIMD
     r'k_msda_self_fusedILi10E': 256,
+    r'k_da_bwd_unit_planesILi10E': 256,            # 512-thread workgroups: two waves / SIMD, two samples (80 registers) in flight
 }
 
 
