@@ -13,7 +13,7 @@
 // same cameras and the level loop may hold barriers).  The per-unit tensors are touched by the workgroup TOGETHER: a lane's
 // offsets / attention / gradient words lie 2 KB from its neighbour's (lane = query), but the 64 queries x 8 heads x 8 points of a
 // level are whole contiguous runs -- they are staged through two LDS tiles with coalesced loads, the level's gradients go back
-// through the same tiles and are added to grad_offsets / grad_attn with coalesced read-modify-writes (the first form of this
+// through the same tiles and are stored to grad_offsets / grad_attn with coalesced writes (the first form of this
 // kernel let every lane touch its own words: 1.72 ms against the row kernel's 1.31).  Cameras add in ascending order.
 // A padded corner keeps a valid address and gets weight AND slope 0; a sample outside the image contributes nothing.
 #pragma once
@@ -213,11 +213,12 @@ k_da_bwd_unit_planes(const float* __restrict__ planes, const int64_t* __restrict
             const long long ia = ((head_minor & 2) ? ubq * LP * MH + h : uu * LP) + (long long)(l * P + p) * ((head_minor & 2) ? MH : 1);
             float* so = off_s + ql * FBBEV_DBP_OQ + (p * MH + h) * 2;
             float* sa = att_s + ql * FBBEV_DBP_AQ + h * P + p;
-            if (write_back) {                                           // the level's gradients: added by their only writer
-                fbbev_v2f t = *reinterpret_cast<const fbbev_v2f*>(grad_offsets + io);
-                t[0] += so[0]; t[1] += so[1];
-                *reinterpret_cast<fbbev_v2f*>(grad_offsets + io) = t;
-                grad_attn[ia] += gat_s[ql * FBBEV_DBP_AQ + h * P + p];
+            if (write_back) {
+                // the level's gradients, STORED: the entry's contract is "accumulated into caller-zeroed tensors", every word of a
+                // valid query has exactly this one writer per call (a unit no camera sees stores its zeros), so a store is the
+                // accumulation -- without reading 492 MB of zeros back at the configs[2] pyramid
+                *reinterpret_cast<fbbev_v2f*>(grad_offsets + io) = fbbev_v2f{so[0], so[1]};
+                grad_attn[ia] = gat_s[ql * FBBEV_DBP_AQ + h * P + p];
             }
             if (load) {
                 const fbbev_v2f t = *reinterpret_cast<const fbbev_v2f*>(offsets + io);
