@@ -104,6 +104,9 @@ SIGNATURES = {
     'fbbev_msda_bwd': (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p] * 3 + [c_void_p]),
     'fbbev_msda_bwd_ws_bytes': (c_size_t, [c_int] * 7 + [c_void_p]),
     'fbbev_msda_bwd_ws': (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p] * 3 + [c_void_p, c_void_p, c_size_t, c_void_p]),
+    'fbbev_value_rows_to_head_planes': (c_int, [c_void_p, c_int64] + [c_int] * 5 + [c_void_p, c_void_p]),
+    'fbbev_da_cross_attn_fwd_planes_supported': (c_int, [c_int] * 9),
+    'fbbev_da_cross_attn_fwd_planes': (c_int, [c_void_p] * 9 + [c_int] * 10 + [c_float, c_float, c_int, c_int, c_int] + [c_void_p, c_void_p]),
 }
 
 _lib = None
@@ -863,6 +866,39 @@ def rows_to_head_planes(rows, tokens_per_image, heads, head_dim):
         _check(lib().fbbev_rows_to_head_planes(_dev(rows, F32, 'rows'), R, tokens_per_image, heads, head_dim, _dev(out, F32, 'out'),
                                                _stream()), 'fbbev_rows_to_head_planes')
     return out
+
+
+def value_rows_to_head_planes(value, head_dim=None, interleaved=False):
+    """(B*Ncam, S, M, HS) value rows (head m at m*HS, or chunk-major (HS/4, M, 4) when `interleaved`) -> (B*Ncam, M, S, Dh) planes"""
+    BN, S, M, HS = value.shape
+    Dh = HS if head_dim is None else int(head_dim)
+    out = torch.empty((BN, M, S, Dh), dtype=F32, device=value.device)
+    with _on(value):
+        _check(lib().fbbev_value_rows_to_head_planes(_dev(value, F32, 'value'), BN * S, S, M, Dh, HS, 1 if interleaved else 0,
+                                                     _dev(out, F32, 'planes'), _stream()), 'fbbev_value_rows_to_head_planes')
+    return out
+
+
+def da_cross_attn_fwd_planes_supported(B, Ncam, S, M, Dh, L, Q, P, Za):
+    return bool(lib().fbbev_da_cross_attn_fwd_planes_supported(B, Ncam, S, M, Dh, L, Q, P, Za))
+
+
+def da_cross_attn_fwd_planes(planes, spatial_shapes, level_start_index, pred_depth, ref_cam, mask, qdepth, offsets, attn, d0, dstep,
+                             slots, head_minor=0, bev_w=0, min_level_width=2):
+    """fbbev_da_cross_attn_fwd_planes: the training forward on head planes (offsets / softmaxed weights handed in)."""
+    Ncam, B, Q, Za = mask.shape
+    BN, M, S, Dh = planes.shape
+    head_minor = int(head_minor)
+    L, P = (attn.shape[2], attn.shape[3]) if head_minor & 2 else (attn.shape[3], attn.shape[4])
+    if mask.dtype == torch.bool:
+        mask = mask.view(torch.uint8)
+    with _on(planes):
+        _check(lib().fbbev_da_cross_attn_fwd_planes(
+            _dev(planes, F32, 'planes'), _dev(spatial_shapes, I64, 'spatial_shapes'), _dev(level_start_index, I64, 'level_start_index'),
+            _dev(pred_depth, F32, 'pred_depth'), _dev(ref_cam, F32, 'ref_cam'), _dev(mask, torch.uint8, 'mask'),
+            _dev(qdepth, F32, 'qdepth'), _dev(offsets, F32, 'offsets'), _dev(attn, F32, 'attn'), B, Ncam, S, M, Dh, L, Q, P, Za,
+            pred_depth.shape[1], float(d0), float(dstep), head_minor & 3, int(bev_w or 0), int(min_level_width),
+            _dev(slots, F32, 'slots'), _stream()), 'fbbev_da_cross_attn_fwd_planes')
 
 
 def da_cross_attn_fused_supported(B, Ncam, S, M, Dh, L, Q, P, Za, bev_w):

@@ -451,8 +451,19 @@ class FusedDACrossAttention(torch.autograd.Function):
         M = value.shape[2]
         Dh = value.shape[3] if head_dim is None else head_dim          # value rows may be head-padded (stride value.shape[3])
         slots = torch.empty((B, Q, M * Dh), dtype=torch.float32, device=value.device)
-        _capi.da_cross_attn_fwd(value, spatial_shapes, level_start_index, pred_depth, ref_cam, mask, qdepth, offsets,
-                                attn, d0, dstep, slots, head_minor=head_minor, head_dim=Dh)
+        Ncam, Za = mask.shape[0], mask.shape[3]
+        L, P = (attn.shape[2], attn.shape[3]) if head_minor & 2 else (attn.shape[3], attn.shape[4])
+        if (value.is_cuda and level_hw is not None and min(int(w) for _, w in level_hw) >= 2 and
+                _capi.da_cross_attn_fwd_planes_supported(B, Ncam, value.shape[1], M, Dh, L, Q, P, Za)):
+            # round 4: the sampler's mapping for the training forward too -- tokens as head planes, a wave = one head of an
+            # 8 x 8 patch of queries (k_da_fwd_planes); the row kernel stays for every other shape
+            planes = _capi.value_rows_to_head_planes(value, head_dim=Dh, interleaved=bool(head_minor & 4))
+            _capi.da_cross_attn_fwd_planes(planes, spatial_shapes, level_start_index, pred_depth, ref_cam, mask, qdepth, offsets, attn,
+                                           d0, dstep, slots, head_minor=head_minor, bev_w=bev_w,
+                                           min_level_width=min(int(w) for _, w in level_hw))
+        else:
+            _capi.da_cross_attn_fwd(value, spatial_shapes, level_start_index, pred_depth, ref_cam, mask, qdepth, offsets,
+                                    attn, d0, dstep, slots, head_minor=head_minor, head_dim=Dh)
         ctx.save_for_backward(value, pred_depth, offsets, attn, spatial_shapes, level_start_index, ref_cam, mask, qdepth)
         ctx.consts = (d0, dstep, head_minor, Dh, level_hw, int(bev_w or 0))
         return slots

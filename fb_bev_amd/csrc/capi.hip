@@ -1432,6 +1432,58 @@ extern "C" int fbbev_da_cross_attn_fused(const float* planes, const int64_t* spa
     return 0;
 }
 
+// ---- training forward on head planes (da_bwd_planes_kernels.h): offsets / softmaxed weights from memory, tokens as planes
+extern "C" int fbbev_value_rows_to_head_planes(const float* value, long long n_tokens, int S, int M, int Dh, int head_stride,
+                                               int interleaved, float* planes, fbbev_stream_t stream_) {
+    if (n_tokens < 0 || S <= 0 || M <= 0 || Dh <= 0 || n_tokens % S != 0) return FBBEV_E_BADARG;
+    if (n_tokens == 0) return 0;
+    const int HS = head_stride == 0 ? Dh : head_stride;
+    if (!value || !planes || HS < Dh || (interleaved && HS % 4 != 0)) return FBBEV_E_BADARG;
+    const long long n_el = n_tokens * M * Dh;
+    if ((n_el + 255) / 256 >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
+    FBBEV_LAUNCH(k_value_rows_to_head_planes, (n_el + 255) / 256, 256, 0, (fbbev_rt_stream)stream_, value, n_tokens, S, M, Dh, HS,
+                 interleaved ? 1 : 0, planes);
+    FBBEV_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int fbbev_da_cross_attn_fwd_planes_supported(int B, int Ncam, int S, int M, int Dh, int L, int Q, int P, int Za) {
+    if (B <= 0 || Ncam <= 0 || S <= 0 || M <= 0 || Dh <= 0 || L <= 0 || Q <= 0 || P <= 0 || Za <= 0) return 0;
+    static const bool off = [] { const char* e = getenv("FBBEV_DA_FWD_PLANES"); return e && atoi(e) == 0; }();   // A/B timing knob, read once
+    return (!off && M == 8 && (Dh == 10 || Dh == 8) && P == FBBEV_DAF_P && Za == FBBEV_DAF_ZA && (long long)S * Dh * 4 < (1ll << 31) &&
+            fbbev_dfp_lds_bytes(Ncam) <= 156 * 1024) ? 1 : 0;
+}
+extern "C" int fbbev_da_cross_attn_fwd_planes(const float* planes, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                              const float* pred_depth, const float* ref_cam, const uint8_t* mask, const float* qdepth,
+                                              const float* offsets, const float* attn, int B, int Ncam, int S, int M, int Dh, int L,
+                                              int Q, int P, int Za, int DC, float d0, float dstep, int head_minor, int bev_w,
+                                              int min_level_width, float* slots, fbbev_stream_t stream_) {
+    if (B <= 0 || Ncam <= 0 || S <= 0 || M <= 0 || Dh <= 0 || L <= 0 || Q < 0 || P <= 0 || Za <= 0 || DC <= 0 || bev_w < 0)
+        return FBBEV_E_BADARG;
+    if (Q == 0) return 0;
+    if (!planes || !spatial_shapes || !level_start_index || !pred_depth || !ref_cam || !mask || !qdepth || !offsets || !attn ||
+        !slots || dstep == 0.f) return FBBEV_E_BADARG;
+    if (!fbbev_da_cross_attn_fwd_planes_supported(B, Ncam, S, M, Dh, L, Q, P, Za) || min_level_width < 2 ||
+        ((uintptr_t)planes & 7) != 0 || ((uintptr_t)slots & 7) != 0 || ((uintptr_t)offsets & 7) != 0 || !aligned16(ref_cam) ||
+        !aligned16(qdepth) || ((uintptr_t)mask & 3) != 0) return FBBEV_E_UNSUPPORTED;
+    const int gw = (bev_w > 0 && Q % bev_w == 0) ? bev_w : 0;
+    const long long wgs = gw > 0 ? (long long)B * ((gw + 7) / 8) * ((Q / gw + 7) / 8) : (long long)B * ((Q + 63) / 64);
+    const long long grid = (wgs + 7) / 8 * 8;
+    if (grid >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
+    const size_t lds = fbbev_dfp_lds_bytes(Ncam);
+#define FBBEV_DA_FWD_PLANES(DH_)                                                                                       \
+    do {                                                                                                               \
+        int e = fbbev_rt_allow_dyn_lds((const void*)k_da_fwd_planes<DH_, 8>, lds);                                     \
+        if (e) return e;                                                                                               \
+        FBBEV_LAUNCH((k_da_fwd_planes<DH_, 8>), grid, 512, lds, (fbbev_rt_stream)stream_, planes, spatial_shapes,       \
+                     level_start_index, pred_depth, ref_cam, mask, qdepth, offsets, attn, B, Ncam, S, L, Q, gw, DC, d0,  \
+                     dstep, head_minor & 3, slots);                                                                    \
+    } while (0)
+    if (Dh == 10) FBBEV_DA_FWD_PLANES(10); else FBBEV_DA_FWD_PLANES(8);
+#undef FBBEV_DA_FWD_PLANES
+    FBBEV_CHECK_LAUNCH();
+    return 0;
+}
+
 // ---- fbbev_msda_self_fused: BEV self-attention, query rows -> attention output in one kernel (da_fused_kernels.h)
 extern "C" int fbbev_msda_self_fused_supported(int B, int S, int M, int Dh, int L, int Q, int P, int bev_w) {
     if (B <= 0 || S <= 0 || M <= 0 || Dh <= 0 || L <= 0 || Q <= 0 || P <= 0) return 0;

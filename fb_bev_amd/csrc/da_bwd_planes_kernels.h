@@ -310,3 +310,146 @@ k_da_bwd_unit_planes(const float* __restrict__ planes, const int64_t* __restrict
         }
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+__host__ __device__ inline size_t fbbev_dfp_lds_bytes(int Ncam) {
+    return (size_t)Ncam * 64 * FBBEV_DBP_QC * 4 + (size_t)64 * FBBEV_DBP_OQ * 4 + (size_t)64 * FBBEV_DBP_AQ * 4;
+}
+
+// The TRAINING forward on head planes: projected offsets / softmaxed weights come from memory (autograd owns the projections),
+// everything else is k_da_cross_attn_fused's sampler -- records once per workgroup, wave = head, lane = query of the patch, two
+// samples in flight -- with the level's unit words staged through the LDS tiles of k_da_bwd_unit_planes.  Replaces
+// k_da_cross_attn_fwd_unit (0.71 ms at the configs[2] pyramid) when autograd is on.  slots (B, Q, MH*DH), written.
+template <int DH, int MH>
+__global__ void __launch_bounds__(64 * MH)
+k_da_fwd_planes(const float* __restrict__ planes, const int64_t* __restrict__ spatial_shapes, const int64_t* __restrict__ level_start,
+                const float* __restrict__ pred_depth, const float* __restrict__ ref_cam, const unsigned char* __restrict__ mask,
+                const float* __restrict__ qdepth, const float* __restrict__ offsets, const float* __restrict__ attn, int B, int Ncam,
+                int S, int L, int Q, int bev_w, int DC, float d0, float dstep, int head_minor, float* __restrict__ slots) {
+    constexpr int P = FBBEV_DAF_P, ZA = FBBEV_DAF_ZA, NT = 64 * MH;
+    static_assert(MH == 8, "the staging tiles hold 8 heads");
+    float* qc = fbbev_dyn_lds_f32();                                                        // [Ncam][64][QC]
+    float* off_s = qc + (size_t)Ncam * 64 * FBBEV_DBP_QC;                                   // [64][OQ]: (p, m, xy) of a query
+    float* att_s = off_s + 64 * FBBEV_DBP_OQ;                                               // [64][AQ]: (m, p) of a query
+    const int H0 = (int)spatial_shapes[0], W0 = (int)spatial_shapes[1];
+    const int gw = bev_w > 0 ? bev_w : Q, gh = Q / gw, plog = bev_w > 0 ? 3 : 6, pw = 1 << plog, ph = 64 >> plog;
+    const int pxn = (gw + pw - 1) / pw, pyn = (gh + ph - 1) / ph;
+    const long long n_wg = (long long)B * pxn * pyn, per_xcd = (n_wg + 7) / 8;
+    const long long wgid = (long long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);       // XCD-contiguous patch order
+    if (wgid >= n_wg) return;                                                               // uniform
+    const int b = (int)(wgid / ((long long)pxn * pyn)), pi = (int)(wgid - (long long)b * pxn * pyn);
+    const int py = pi / pxn, px = pi - py * pxn;
+    const int x0 = px * pw, y0 = py * ph;
+    for (int i = threadIdx.x; i < Ncam * 64; i += NT) {                                     // the records of k_da_cross_attn_fused
+        const int cam = i >> 6, ql = i & 63;
+        const int qy = y0 + (ql >> plog), qx = x0 + (ql & (pw - 1));
+        const bool inb = qy < gh && qx < gw;
+        float* rec = qc + (size_t)i * FBBEV_DBP_QC;
+        const long long base = (((long long)cam * B + b) * Q + (inb ? (long long)qy * gw + qx : 0)) * ZA;
+        unsigned int mask4;
+        __builtin_memcpy(&mask4, mask + base, 4);
+        const fbbev_v4f r01 = *reinterpret_cast<const fbbev_v4f*>(ref_cam + base * 2);
+        const fbbev_v4f r23 = *reinterpret_cast<const fbbev_v4f*>(ref_cam + base * 2 + 4);
+        const fbbev_v4f qd = *reinterpret_cast<const fbbev_v4f*>(qdepth + base);
+        const long long bn = (long long)b * Ncam + cam;
+        float rx[ZA], ry[ZA], wgt[ZA][4], val[ZA][4];
+#pragma unroll
+        for (int z = 0; z < ZA; ++z) {
+            rx[z] = z < 2 ? r01[2 * z] : r23[2 * z - 4]; ry[z] = z < 2 ? r01[2 * z + 1] : r23[2 * z - 3];
+            float fb = floorf(__fdiv_rn(__fsub_rn(qd[z], d0), dstep));
+            fb = fminf(fmaxf(fb, 0.f), (float)(DC - 1));
+            const float* plane = pred_depth + (bn * DC + (int)fb) * (long long)(H0 * W0);
+            int off[4];
+            fbbev_daf_plane_corners(rx[z], ry[z], H0, W0, off, wgt[z]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) val[z][k] = plane[off[k]];
+        }
+#pragma unroll
+        for (int z = 0; z < ZA; ++z) {
+            rec[z] = rx[z]; rec[ZA + z] = ry[z];
+            rec[2 * ZA + z] = wgt[z][0] * val[z][0] + wgt[z][1] * val[z][1] + wgt[z][2] * val[z][2] + wgt[z][3] * val[z][3];
+        }
+        rec[3 * ZA] = (inb && mask4 != 0u) ? 1.f : 0.f;
+    }
+    const int m = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int qy = y0 + (lane >> plog), qx = x0 + (lane & (pw - 1));
+    const bool valid = qy < gh && qx < gw;
+    const long long bq = (long long)b * Q + (valid ? (long long)qy * gw + qx : 0);
+    const float* my_qc = qc + (size_t)lane * FBBEV_DBP_QC;
+    const int LP = L * P;
+    auto unit_words = [&](int l) {                            // coalesced: item i = (query, point, head) in the head-minor layouts' order
+        for (int i = threadIdx.x; i < 64 * P * MH; i += NT) {
+            const int ql = i / (P * MH), r = i - ql * (P * MH), p = r / MH, h = r - p * MH;
+            const int uy = y0 + (ql >> plog), ux = x0 + (ql & (pw - 1));
+            if (!(uy < gh && ux < gw)) continue;
+            const long long ubq = (long long)b * Q + (long long)uy * gw + ux, uu = ubq * MH + h;
+            const long long io = (((head_minor & 1) ? ubq * LP * MH + h : uu * LP) + (long long)(l * P + p) * ((head_minor & 1) ? MH : 1)) * 2;
+            const long long ia = ((head_minor & 2) ? ubq * LP * MH + h : uu * LP) + (long long)(l * P + p) * ((head_minor & 2) ? MH : 1);
+            const fbbev_v2f t = *reinterpret_cast<const fbbev_v2f*>(offsets + io);
+            float* so = off_s + ql * FBBEV_DBP_OQ + (p * MH + h) * 2;
+            so[0] = t[0]; so[1] = t[1];
+            att_s[ql * FBBEV_DBP_AQ + h * P + p] = attn[ia];
+        }
+    };
+    unit_words(0);
+    __syncthreads();                                                                        // records + level 0
+    int count = 0;
+    for (int cam = 0; cam < Ncam; ++cam) count += (fbbev_lds_ld_f32(my_qc + (size_t)cam * 64 * FBBEV_DBP_QC + 3 * ZA) != 0.f) ? 1 : 0;
+    fbbev_v2f acc[DH / 2];
+#pragma unroll
+    for (int c = 0; c < DH / 2; ++c) { acc[c][0] = 0.f; acc[c][1] = 0.f; }
+    const float* my_off = off_s + lane * FBBEV_DBP_OQ + m * 2;
+    const float* my_att = att_s + lane * FBBEV_DBP_AQ + m * P;
+    const char* pb = reinterpret_cast<const char*>(planes);
+    for (int l = 0; l < L; ++l) {
+        const int sh = (int)spatial_shapes[2 * l], sw = (int)spatial_shapes[2 * l + 1];
+        const float fsh = (float)sh, fsw = (float)sw;
+        const int lvl_off = (int)level_start[l] * DH;
+        fbbev_v2f o[P];
+        float a[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            o[p][0] = fbbev_lds_ld_f32(my_off + p * MH * 2); o[p][1] = fbbev_lds_ld_f32(my_off + p * MH * 2 + 1);
+            a[p] = fbbev_lds_ld_f32(my_att + p);
+        }
+        if (l + 1 < L) {                                                                    // the next level's words arrive under this level's samples
+            __syncthreads();
+            unit_words(l + 1);
+        }
+        for (int cam = 0; cam < Ncam; ++cam) {
+            const float* rec = my_qc + (size_t)cam * 64 * FBBEV_DBP_QC;
+            const bool hit = valid && fbbev_lds_ld_f32(rec + 3 * ZA) != 0.f;
+            if (__ballot(hit) == 0ull) continue;
+            float rx[ZA], ry[ZA], dw[ZA];
+#pragma unroll
+            for (int z = 0; z < ZA; ++z) {
+                rx[z] = fbbev_lds_ld_f32(rec + z); ry[z] = fbbev_lds_ld_f32(rec + ZA + z); dw[z] = fbbev_lds_ld_f32(rec + 2 * ZA + z);
+            }
+            const char* plane = pb + (((long long)b * Ncam + cam) * MH + m) * (long long)S * DH * 4;
+            fbbev_daf_pending<DH> pend[2];
+            auto start = [&](int p, fbbev_daf_pending<DH>& slot) {
+                const int z = p % ZA;
+                const float loc_w = rx[z] + __fdiv_rn(o[p][0], fsw), loc_h = ry[z] + __fdiv_rn(o[p][1], fsh);
+                fbbev_daf_issue<DH>(plane, lvl_off, loc_h * fsh - 0.5f, loc_w * fsw - 0.5f, sh, sw, a[p] * dw[z], hit, slot);
+            };
+            start(0, pend[0]);
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                if (p + 1 < P) start(p + 1, pend[(p + 1) & 1]);
+                fbbev_sched_fence();
+                fbbev_daf_consume<DH>(pend[p & 1], acc);
+                fbbev_sched_fence();
+            }
+        }
+        __syncthreads();                                                                    // the next level's words are in the tiles
+    }
+    if (!valid) return;
+    const float inv = (float)(count > 1 ? count : 1);
+    float* dst = slots + bq * (MH * DH) + m * DH;
+#pragma unroll
+    for (int c = 0; c < DH / 2; ++c) {
+        fbbev_v2f r;
+        r[0] = acc[c][0] / inv; r[1] = acc[c][1] / inv;
+        *reinterpret_cast<fbbev_v2f*>(dst + 2 * c) = r;
+    }
+}

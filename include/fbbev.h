@@ -475,6 +475,22 @@ int fbbev_da_cross_attn_bwd_ws(const float* value, const int64_t* spatial_shapes
                                float* grad_value, float* grad_pred_depth, float* grad_offsets,
                                float* grad_attn, const int32_t* level_hw_host, void* ws, size_t ws_bytes,
                                fbbev_stream_t stream);
+/* The TRAINING forward of the DA cross-attention on head planes (round 4; k_da_fwd_planes): what fbbev_da_cross_attn_fwd computes
+ * (spatial_cross_attention_depth.py:136-223, 513-595 with projected offsets and softmaxed weights handed in, as autograd owns the
+ * two Linears), with the camera tokens as (B*Ncam, M, S, Dh) planes -- fbbev_value_rows_to_head_planes re-lays the value rows
+ * (plain, or chunk-major when `interleaved`) out -- and the one-kernel sampler's mapping: a workgroup = the 8 heads of an 8 x 8
+ * patch of a bev_w-wide query grid (bev_w = 0: 64 consecutive queries), a wave = one head.  offsets / attn in the layouts of
+ * fbbev_da_cross_attn_fwd (head_minor bits 0 / 1).  M = 8, Dh in {8, 10}, 8 points, 4 anchors, every level >= 2 tokens wide
+ * (min_level_width: the caller's host-side knowledge); otherwise FBBEV_E_UNSUPPORTED.  slots (B, Q, M*Dh) is written. */
+int fbbev_value_rows_to_head_planes(const float* value, long long n_tokens, int S, int M, int Dh, int head_stride, int interleaved,
+                                    float* planes, fbbev_stream_t stream);
+int fbbev_da_cross_attn_fwd_planes_supported(int B, int Ncam, int S, int M, int Dh, int L, int Q, int P, int Za);
+int fbbev_da_cross_attn_fwd_planes(const float* planes, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                   const float* pred_depth, const float* ref_cam, const uint8_t* mask, const float* qdepth,
+                                   const float* offsets, const float* attn, int B, int Ncam, int S, int M, int Dh, int L, int Q,
+                                   int P, int Za, int DC, float d0, float dstep, int head_minor, int bev_w, int min_level_width,
+                                   float* slots, fbbev_stream_t stream);
+
 /* fbbev_da_cross_attn_bwd_ws for queries that form a (Q / bev_w) x bev_w BEV grid (bevformer_encoder.py:91-120: the reference's
  * queries always do).  Round 4: on the output-owned route the unit gradients (step A) run on HEAD PLANES with the forward's mapping
  * (k_da_bwd_unit_planes: the camera tokens are re-laid out as (B*Ncam, M, S, Dh) planes in `ws`, a workgroup = the 8 heads of an

@@ -389,6 +389,23 @@ def layernorm_bwd(x, grad_out, weight, eps):
     return gx, s[0], s[1]
 
 
+def da_cross_attn_fwd_planes(value, ss, ls, pred_depth, ref_cam, mask, qdepth, offsets, attn, d0, dstep, head_minor=0, head_dim=None,
+                             bev_w=0, min_level_width=2):
+    """value rows -> head planes (fbbev_value_rows_to_head_planes) -> fbbev_da_cross_attn_fwd_planes; returns (code, slots)"""
+    Ncam, B, Q, Za = mask.shape
+    BN, S, M, HS = value.shape
+    Dh = HS if head_dim is None else head_dim
+    L, P = (attn.shape[2], attn.shape[3]) if head_minor & 2 else (attn.shape[3], attn.shape[4])
+    planes = torch.full((BN, M, S, Dh), float('nan'))
+    ok(lib().fbbev_value_rows_to_head_planes(p(value), BN * S, S, M, Dh, HS, 1 if head_minor & 4 else 0, p(planes), None))
+    slots = torch.full((B, Q, M * Dh), float('nan'))
+    m8 = mask.to(torch.uint8).contiguous()
+    code = lib().fbbev_da_cross_attn_fwd_planes(p(planes), p(ss), p(ls), p(pred_depth), p(ref_cam), p(m8), p(qdepth), p(offsets), p(attn),
+                                                B, Ncam, S, M, Dh, L, Q, P, Za, pred_depth.shape[1], d0, dstep, int(head_minor) & 3,
+                                                int(bev_w), int(min_level_width), p(slots), None)
+    return code, slots, planes
+
+
 def da_cross_attn_bwd(value, ss, ls, pred_depth, ref_cam, mask, qdepth, offsets, attn, d0, dstep, grad_slots, head_minor=0,
                       head_dim=None, lds_planes=False, level_hw=None, bev_w=0):
     Ncam, B, Q, Za = mask.shape

@@ -857,6 +857,12 @@ def test_da_backward_unit_gradients_on_head_planes_emulated():
                                                       head_dim=Dh, lds_planes=True, level_hw=shapes_host, bev_w=bev_w)
                 finally:
                     del os.environ['FBBEV_DA_BWD_OWNED'], os.environ['FBBEV_DA_BWD_UNIT_PLANES']
+            # the training forward on the same planes (k_da_fwd_planes) against the unit kernel / the oracle composite
+            code, slots, planes = E.da_cross_attn_fwd_planes(vin, ss, ls, pred, ref_cam, mask, qdepth, o_in, attn, d0, dstep, head_minor=hm,
+                                                             head_dim=Dh, bev_w=bev_w)
+            assert code == 0 and torch.equal(planes, value.permute(0, 2, 1, 3))
+            assert not torch.isnan(slots).any()
+            assert torch.allclose(slots, exp, atol=2e-5, rtol=1e-5), (seed, hm, (slots - exp).abs().max())
             if hm == 0:       # the planes route is planned: its workspace holds the (B*Ncam, M, S, Dh) planes behind the hit lists
                 import ctypes
                 flat = [int(x) for hw in shapes_host for x in hw]

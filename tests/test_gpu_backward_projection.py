@@ -478,6 +478,17 @@ def test_output_owned_plane_backward_at_a_pyramid(dev):
     ls = torch.cat([ss.new_zeros(1), (ss[:, 0] * ss[:, 1]).cumsum(0)[:-1]])
     t = lambda x: x.to(dev).contiguous()  # noqa: E731
     args = [t(value), t(ss), t(ls), t(pred), t(ref_cam), t(mask), t(qdepth), t(offsets), t(attn), t(gs), 1.0, 0.5, 1 | 4]
+    # the training forward on head planes (k_da_fwd_planes) against the row kernel: same samples, another summation order
+    assert _capi.da_cross_attn_fwd_planes_supported(B, Ncam, S_, M, Dh, L, Q, P, Za)
+    planes = _capi.value_rows_to_head_planes(args[0], head_dim=Dh, interleaved=True)
+    assert torch.equal(planes.cpu(), value.view(B * Ncam, S_, HS // 4, M, 4).permute(0, 3, 1, 2, 4).reshape(B * Ncam, M, S_, HS)[..., :Dh])
+    s_rows = torch.full((B, Q, M * Dh), float('nan'), device=dev)
+    _capi.da_cross_attn_fwd(*args[:9], 1.0, 0.5, s_rows, head_minor=1 | 4, head_dim=Dh)
+    for bw in (0, 100):
+        s_pl = torch.full((B, Q, M * Dh), float('nan'), device=dev)
+        _capi.da_cross_attn_fwd_planes(planes, *args[1:9], 1.0, 0.5, s_pl, head_minor=1 | 4, bev_w=bw, min_level_width=22)
+        err = (s_pl - s_rows).abs().max().item()
+        assert not torch.isnan(s_pl).any() and err <= 1e-5 * max(1.0, s_rows.abs().max().item()), (bw, err)
     # the owned route is planned: its workspace is the (camera, query) table + the hit lists, not partial planes
     table, lists = B * Ncam * Q * 8 * 4, B * Ncam * Q * 4
     need = _capi.da_cross_attn_bwd_ws_bytes(B, Ncam, S_, M, Dh, Q, HS, L, P, level_hw=shapes)
