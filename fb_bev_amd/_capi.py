@@ -104,6 +104,7 @@ SIGNATURES = {
     'fbbev_msda_bwd': (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p] * 3 + [c_void_p]),
     'fbbev_msda_bwd_ws_bytes': (c_size_t, [c_int] * 7 + [c_void_p]),
     'fbbev_msda_bwd_ws': (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p] * 3 + [c_void_p, c_void_p, c_size_t, c_void_p]),
+    'fbbev_volume_zreduce': (c_int, [c_void_p, c_int64, c_int, c_int64, c_float, c_void_p, c_void_p]),
     'fbbev_value_rows_to_head_planes': (c_int, [c_void_p, c_int64] + [c_int] * 5 + [c_void_p, c_void_p]),
     'fbbev_da_cross_attn_fwd_planes_supported': (c_int, [c_int] * 9),
     'fbbev_da_cross_attn_fwd_planes': (c_int, [c_void_p] * 9 + [c_int] * 10 + [c_float, c_float, c_int, c_int, c_int] + [c_void_p, c_void_p]),
@@ -865,6 +866,22 @@ def rows_to_head_planes(rows, tokens_per_image, heads, head_dim):
     with _on(rows):
         _check(lib().fbbev_rows_to_head_planes(_dev(rows, F32, 'rows'), R, tokens_per_image, heads, head_dim, _dev(out, F32, 'out'),
                                                _stream()), 'fbbev_rows_to_head_planes')
+    return out
+
+
+def volume_zreduce_supported(vol_view):
+    """vol_view: (B, C, Y, X, Z) VIEW of a (B, C, Z, Y, X)-contiguous fp32 CUDA volume with Y*X % 4 == 0?"""
+    return (vol_view.is_cuda and vol_view.dtype == F32 and vol_view.dim() == 5 and vol_view.permute(0, 1, 4, 2, 3).is_contiguous() and
+            (vol_view.shape[2] * vol_view.shape[3]) % 4 == 0 and vol_view.data_ptr() % 16 == 0)
+
+
+def volume_zreduce(vol_view, divisor):
+    """(B, C, Y, X) = sum over Z of the (B, C, Y, X, Z) view / divisor (fbbev_volume_zreduce)."""
+    B, C, Y, X, Z = vol_view.shape
+    out = torch.empty((B, C, Y, X), dtype=F32, device=vol_view.device)
+    with _on(vol_view):
+        _check(lib().fbbev_volume_zreduce(vol_view.data_ptr(), B * C, Z, Y * X, float(divisor), _dev(out, F32, 'out'), _stream()),
+               'fbbev_volume_zreduce')
     return out
 
 

@@ -1432,6 +1432,20 @@ extern "C" int fbbev_da_cross_attn_fused(const float* planes, const int64_t* spa
     return 0;
 }
 
+// ---- Z-mean / Z-sum of a materialised (B*C, Z, Y*X) volume (training path; k_volume_zreduce)
+extern "C" int fbbev_volume_zreduce(const float* volume, long long n_bc, int Z, long long YX, float divisor, float* out,
+                                    fbbev_stream_t stream_) {
+    if (n_bc < 0 || Z <= 0 || YX <= 0 || divisor == 0.f) return FBBEV_E_BADARG;
+    if (n_bc == 0) return 0;
+    if (!volume || !out) return FBBEV_E_BADARG;
+    if (YX % 4 != 0 || !aligned16(volume) || !aligned16(out)) return FBBEV_E_UNSUPPORTED;
+    const long long items = n_bc * (YX / 4);
+    if ((items + 255) / 256 >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
+    FBBEV_LAUNCH(k_volume_zreduce, (items + 255) / 256, 256, 0, (fbbev_rt_stream)stream_, volume, n_bc, Z, YX, divisor, out);
+    FBBEV_CHECK_LAUNCH();
+    return 0;
+}
+
 // ---- training forward on head planes (da_bwd_planes_kernels.h): offsets / softmaxed weights from memory, tokens as planes
 extern "C" int fbbev_value_rows_to_head_planes(const float* value, long long n_tokens, int S, int M, int Dh, int head_stride,
                                                int interleaved, float* planes, fbbev_stream_t stream_) {

@@ -801,6 +801,21 @@ k_pool_zmean_reduce(const float* __restrict__ partial, long long n, int z_groups
     *reinterpret_cast<fbbev_v4f*>(out + i) = acc;
 }
 
+// out[bc][i] = (vol[bc][0][i] + vol[bc][1][i] + ... in z order) / divisor over a (B*C, Z, Y*X) volume: the Z-mean of the training
+// path (fbocc.py:359 on a materialised volume) and the Z-sum its re-add's backward needs (fbocc.py:365-366), as one HBM-bound
+// pass -- the ATen reductions over the strided last dimension of the (B,C,Y,X,Z) VIEW ran at 0.9 TB/s.  YX % 4 == 0.
+__global__ void __launch_bounds__(256)
+k_volume_zreduce(const float* __restrict__ vol, long long n_bc, int Z, long long YX, float divisor, float* __restrict__ out) {
+    const long long q = YX >> 2, i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_bc * q) return;
+    const long long bc = i / q, j = (i - bc * q) * 4;
+    const float* src = vol + bc * (long long)Z * YX + j;
+    fbbev_v4f acc = *reinterpret_cast<const fbbev_v4f*>(src);
+    for (int z = 1; z < Z; ++z) acc += *reinterpret_cast<const fbbev_v4f*>(src + (long long)z * YX);
+    acc[0] /= divisor; acc[1] /= divisor; acc[2] /= divisor; acc[3] /= divisor;
+    *reinterpret_cast<fbbev_v4f*>(out + bc * YX + j) = acc;
+}
+
 // ================================================================ fused dense forward, channels-last
 // out (B,Z,Y,X,C) -- the reference op's own output layout (QuickCumsumCuda.forward, bev_pool.py:24-38) --
 // but with EVERY voxel row written exactly once (zeros for empty voxels): replaces new_zeros + kernel.

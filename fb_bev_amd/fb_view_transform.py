@@ -5,8 +5,37 @@ produces (`context`, `depth`) plus `cam_params = img_inputs[1:7]`."""
 import torch
 import torch.nn as nn
 
+from . import _capi
 from . import backward_projection as BP
 from .view_transformer import LSSViewTransformerFunction3D
+
+
+class _ZMean(torch.autograd.Function):
+    """bev_feat.mean(-1) of the (B,C,Y,X,Z) view of a (B,C,Z,Y,X) volume (fbocc.py:359) as one HBM-bound pass."""
+
+    @staticmethod
+    def forward(ctx, vol):
+        ctx.Z = vol.shape[-1]
+        return _capi.volume_zreduce(vol, vol.shape[-1])
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g / ctx.Z)[..., None].expand(*g.shape, ctx.Z)
+
+
+class _ReAdd(torch.autograd.Function):
+    """refined[..., None] + bev_feat (fbocc.py:365-366); the backward's Z-sum for `refined` is one HBM-bound pass instead of an
+    ATen reduction over the strided last dimension (0.93 -> 0.2 ms at the configs[2] grid, B = 4)."""
+
+    @staticmethod
+    def forward(ctx, refined, vol):
+        return refined[..., None] + vol
+
+    @staticmethod
+    def backward(ctx, g):
+        if _capi.volume_zreduce_supported(g):
+            return _capi.volume_zreduce(g, 1.0), g
+        return g.sum(-1), g
 
 
 class FBViewTransform(nn.Module):
@@ -39,6 +68,9 @@ class FBViewTransform(nn.Module):
         bev_feat = fp(cam_params, context, depth)                                 # (B,C,Y,X,Z)   fbocc.py:344-345
         if self.backward_projection is None:
             return bev_feat
-        refined = self.backward_projection(feats, img_metas, lss_bev=bev_feat.mean(-1), cam_params=cam_params,
-                                           bev_mask=bev_mask, gt_bboxes_3d=None, pred_img_depth=depth)   # :357-363
-        return refined[..., None] + bev_feat if self.readd else refined           # :365-368
+        fast = _capi.volume_zreduce_supported(bev_feat)                           # training: the volume exists; one pass per reduction
+        refined = self.backward_projection(feats, img_metas, lss_bev=_ZMean.apply(bev_feat) if fast else bev_feat.mean(-1),
+                                           cam_params=cam_params, bev_mask=bev_mask, gt_bboxes_3d=None, pred_img_depth=depth)   # :357-363
+        if not self.readd:
+            return refined
+        return _ReAdd.apply(refined, bev_feat) if fast and refined.dtype == bev_feat.dtype else refined[..., None] + bev_feat   # :365-368

@@ -475,6 +475,11 @@ int fbbev_da_cross_attn_bwd_ws(const float* value, const int64_t* spatial_shapes
                                float* grad_value, float* grad_pred_depth, float* grad_offsets,
                                float* grad_attn, const int32_t* level_hw_host, void* ws, size_t ws_bytes,
                                fbbev_stream_t stream);
+/* out[bc][i] = (sum over z of volume[bc][z][i]) / divisor for a materialised (B*C, Z, Y*X) fp32 volume: the training path's
+ * `bev_feat.mean(-1)` (fbocc.py:359; divisor = Z) and the Z-sum that the backward of the re-add `refined[..., None] + bev_feat`
+ * (fbocc.py:365-366) sends to the refined BEV (divisor = 1), one HBM-bound pass each.  YX % 4 == 0, 16-byte aligned. */
+int fbbev_volume_zreduce(const float* volume, long long n_bc, int Z, long long YX, float divisor, float* out, fbbev_stream_t stream);
+
 /* The TRAINING forward of the DA cross-attention on head planes (round 4; k_da_fwd_planes): what fbbev_da_cross_attn_fwd computes
  * (spatial_cross_attention_depth.py:136-223, 513-595 with projected offsets and softmaxed weights handed in, as autograd owns the
  * two Linears), with the camera tokens as (B*Ncam, M, S, Dh) planes -- fbbev_value_rows_to_head_planes re-lays the value rows

@@ -749,3 +749,32 @@ def test_pool_tolerance_mode_on_gpu(dev, name, B):
     short[long_vox] = False
     assert torch.equal(flat_g[short], flat_e[short])                    # short intervals and empty voxels: the same bits
     assert not torch.equal(flat_g[long_vox], flat_e[long_vox])          # long intervals: another (deterministic) order
+
+
+@pytest.mark.gpu
+def test_volume_zreduce_and_the_training_path_functions_match_torch():
+    """fbbev_volume_zreduce (Z-mean / Z-sum of a materialised volume through its (B,C,Y,X,Z) view) and the two autograd functions
+    the training path builds on it (fb_view_transform._ZMean / _ReAdd) against the ATen expressions they replace
+    (fbocc.py:359, 365-366), values and gradients."""
+    from fb_bev_amd import _capi
+    from fb_bev_amd.fb_view_transform import _ReAdd, _ZMean
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(5)
+    vol = torch.randn(2, 5, 8, 12, 20, generator=g).to(dev)                       # (B, C, Z, Y, X) memory
+    view = vol.permute(0, 1, 3, 4, 2)                                             # the module's (B, C, Y, X, Z) view
+    assert _capi.volume_zreduce_supported(view) and not _capi.volume_zreduce_supported(view.contiguous())
+    assert torch.allclose(_capi.volume_zreduce(view, 8), view.mean(-1), rtol=1e-6, atol=1e-6)
+    assert torch.allclose(_capi.volume_zreduce(view, 1.0), view.sum(-1), rtol=1e-6, atol=1e-5)
+    w = torch.randn(view.shape, generator=g).to(dev)
+    ref = torch.randn(2, 5, 12, 20, generator=g).to(dev)
+    outs = []
+    for fast in (True, False):
+        v = vol.clone().requires_grad_()
+        r = ref.clone().requires_grad_()
+        vv = v.permute(0, 1, 3, 4, 2)
+        zm = _ZMean.apply(vv) if fast else vv.mean(-1)
+        out = _ReAdd.apply(r * zm, vv) if fast else (r * zm)[..., None] + vv
+        (out * w).sum().backward()
+        outs.append((out.detach(), v.grad, r.grad))
+    for a, b in zip(*outs):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-5)
