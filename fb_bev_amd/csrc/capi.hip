@@ -1851,7 +1851,8 @@ static int da_bwd_owned_launch(const da_own_plan& op, fbbev_rt_stream stream, co
     FBBEV_LAUNCH(k_da_bwd_init, 1, 256, 0, stream, B * Ncam, hit_count, 1, gmax_bits);
     FBBEV_CHECK_LAUNCH();
     int e = 0;
-    if (op.unit_planes && Za == FBBEV_DAF_ZA) {
+    // (the plane kernel reads a record's 4 mask bytes / 8 reference floats / 4 depths as whole words: alignment of the geometry inputs)
+    if (op.unit_planes && Za == FBBEV_DAF_ZA && aligned16(ref_cam) && aligned16(qdepth) && ((uintptr_t)mask & 3) == 0) {
         // camera tokens as head planes, then the unit gradients with the forward's (head, patch) mapping
         float* planes = reinterpret_cast<float*>(w + op.off_planes);
         const long long n_el = (long long)B * Ncam * S * M * Dh;
