@@ -105,6 +105,8 @@ SIGNATURES = {
     'fbbev_msda_bwd_ws_bytes': (c_size_t, [c_int] * 7 + [c_void_p]),
     'fbbev_msda_bwd_ws': (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p] * 3 + [c_void_p, c_void_p, c_size_t, c_void_p]),
     'fbbev_volume_zreduce': (c_int, [c_void_p, c_int64, c_int, c_int64, c_float, c_void_p, c_void_p]),
+    'fbbev_volume_zreduce_inner': (c_int, [c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p]),
+    'fbbev_volume_z_to_front': (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p]),
     'fbbev_value_rows_to_head_planes': (c_int, [c_void_p, c_int64] + [c_int] * 5 + [c_void_p, c_void_p]),
     'fbbev_da_cross_attn_fwd_planes_supported': (c_int, [c_int] * 9),
     'fbbev_da_cross_attn_fwd_planes': (c_int, [c_void_p] * 9 + [c_int] * 10 + [c_float, c_float, c_int, c_int, c_int] + [c_void_p, c_void_p]),
@@ -882,6 +884,30 @@ def volume_zreduce(vol_view, divisor):
     with _on(vol_view):
         _check(lib().fbbev_volume_zreduce(vol_view.data_ptr(), B * C, Z, Y * X, float(divisor), _dev(out, F32, 'out'), _stream()),
                'fbbev_volume_zreduce')
+    return out
+
+
+def volume_zlast_supported(t):
+    """t: a CONTIGUOUS (B, C, Y, X, Z) fp32 CUDA tensor with Z % 4 == 0 (a gradient handed over in the module's output shape)?"""
+    return t.is_cuda and t.dtype == F32 and t.dim() == 5 and t.is_contiguous() and t.shape[-1] % 4 == 0 and t.data_ptr() % 16 == 0
+
+
+def volume_zreduce_inner(t, divisor):
+    """(B, C, Y, X) = sum over the innermost Z of a contiguous (B, C, Y, X, Z) tensor / divisor"""
+    B, C, Y, X, Z = t.shape
+    out = torch.empty((B, C, Y, X), dtype=F32, device=t.device)
+    with _on(t):
+        _check(lib().fbbev_volume_zreduce_inner(t.data_ptr(), B * C * Y * X, Z, float(divisor), _dev(out, F32, 'out'), _stream()),
+               'fbbev_volume_zreduce_inner')
+    return out
+
+
+def volume_z_to_front(t):
+    """contiguous (B, C, Y, X, Z) -> contiguous (B, C, Z, Y, X), the same elements"""
+    B, C, Y, X, Z = t.shape
+    out = torch.empty((B, C, Z, Y, X), dtype=F32, device=t.device)
+    with _on(t):
+        _check(lib().fbbev_volume_z_to_front(t.data_ptr(), B * C, Z, Y * X, _dev(out, F32, 'out'), _stream()), 'fbbev_volume_z_to_front')
     return out
 
 

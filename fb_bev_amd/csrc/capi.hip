@@ -1446,6 +1446,26 @@ extern "C" int fbbev_volume_zreduce(const float* volume, long long n_bc, int Z, 
     return 0;
 }
 
+extern "C" int fbbev_volume_zreduce_inner(const float* volume, long long n_pillars, int Z, float divisor, float* out,
+                                          fbbev_stream_t stream_) {
+    if (n_pillars < 0 || Z <= 0 || divisor == 0.f) return FBBEV_E_BADARG;
+    if (n_pillars == 0) return 0;
+    if (!volume || !out) return FBBEV_E_BADARG;
+    if (Z % 4 != 0 || !aligned16(volume) || (n_pillars + 255) / 256 >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
+    FBBEV_LAUNCH(k_volume_zreduce_inner, (n_pillars + 255) / 256, 256, 0, (fbbev_rt_stream)stream_, volume, n_pillars, Z, divisor, out);
+    FBBEV_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int fbbev_volume_z_to_front(const float* src, long long n_bc, int Z, long long YX, float* dst, fbbev_stream_t stream_) {
+    if (n_bc < 0 || Z <= 0 || YX <= 0) return FBBEV_E_BADARG;
+    if (n_bc == 0) return 0;
+    if (!src || !dst || src == dst) return FBBEV_E_BADARG;
+    if (Z % 4 != 0 || !aligned16(src) || (n_bc * YX + 255) / 256 >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
+    FBBEV_LAUNCH(k_volume_z_to_front, (n_bc * YX + 255) / 256, 256, 0, (fbbev_rt_stream)stream_, src, n_bc, Z, YX, dst);
+    FBBEV_CHECK_LAUNCH();
+    return 0;
+}
+
 // ---- training forward on head planes (da_bwd_planes_kernels.h): offsets / softmaxed weights from memory, tokens as planes
 extern "C" int fbbev_value_rows_to_head_planes(const float* value, long long n_tokens, int S, int M, int Dh, int head_stride,
                                                int interleaved, float* planes, fbbev_stream_t stream_) {

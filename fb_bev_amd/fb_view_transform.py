@@ -33,8 +33,10 @@ class _ReAdd(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        if _capi.volume_zreduce_supported(g):
+        if _capi.volume_zreduce_supported(g):          # the gradient has the volume's own memory layout
             return _capi.volume_zreduce(g, 1.0), g
+        if _capi.volume_zlast_supported(g):            # ... or is contiguous in the output's (B,C,Y,X,Z) shape
+            return _capi.volume_zreduce_inner(g, 1.0), g
         return g.sum(-1), g
 
 

@@ -113,7 +113,11 @@ class LiftSplat(torch.autograd.Function):
         sb, sc = og.stride(0), og.stride(1)
         if (og.dtype != torch.float32 or og.stride()[2:] != (Y * X, X, 1) or sc < Z * Y * X or sb < C * sc or sc % 4
                 or sb % 4 or og.data_ptr() % 16):
-            og = og.contiguous().float()
+            zl = og.permute(0, 1, 3, 4, 2)                        # the module hands the volume out as a (B,C,Y,X,Z) view
+            if _capi.volume_zlast_supported(zl):                  # a gradient contiguous in THAT shape: one coalesced re-layout
+                og = _capi.volume_z_to_front(zl)
+            else:
+                og = og.contiguous().float()
         ws = ctx.ws_cache.bwd_workspace(depth.device, _capi.pool_dense_bwd_workspace_bytes(B, N, D, H, W, C, Z, Y, X))
         depth_grad, feat_grad = torch.empty_like(depth), torch.empty_like(feat)
         _capi.bev_pool_v2_dense_bwd(og, depth, feat, idx.ranks_depth, idx.interval_rank, idx.interval_starts,

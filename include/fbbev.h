@@ -480,6 +480,12 @@ int fbbev_da_cross_attn_bwd_ws(const float* value, const int64_t* spatial_shapes
  * (fbocc.py:365-366) sends to the refined BEV (divisor = 1), one HBM-bound pass each.  YX % 4 == 0, 16-byte aligned. */
 int fbbev_volume_zreduce(const float* volume, long long n_bc, int Z, long long YX, float divisor, float* out, fbbev_stream_t stream);
 
+/* The same for a Z-INNERMOST volume (B*C*Y*X pillars of Z contiguous floats): an upstream gradient that arrives contiguous in the
+ * module's (B,C,Y,X,Z) output shape; and its re-layout (B*C, Y*X, Z) -> (B*C, Z, Y*X) for the pooling backward (the `.contiguous()`
+ * autograd would otherwise run as a strided ATen copy).  Z % 4 == 0, 16-byte aligned, src != dst. */
+int fbbev_volume_zreduce_inner(const float* volume, long long n_pillars, int Z, float divisor, float* out, fbbev_stream_t stream);
+int fbbev_volume_z_to_front(const float* src, long long n_bc, int Z, long long YX, float* dst, fbbev_stream_t stream);
+
 /* The TRAINING forward of the DA cross-attention on head planes (round 4; k_da_fwd_planes): what fbbev_da_cross_attn_fwd computes
  * (spatial_cross_attention_depth.py:136-223, 513-595 with projected offsets and softmaxed weights handed in, as autograd owns the
  * two Linears), with the camera tokens as (B*Ncam, M, S, Dh) planes -- fbbev_value_rows_to_head_planes re-lays the value rows

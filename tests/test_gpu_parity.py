@@ -765,6 +765,11 @@ def test_volume_zreduce_and_the_training_path_functions_match_torch():
     assert _capi.volume_zreduce_supported(view) and not _capi.volume_zreduce_supported(view.contiguous())
     assert torch.allclose(_capi.volume_zreduce(view, 8), view.mean(-1), rtol=1e-6, atol=1e-6)
     assert torch.allclose(_capi.volume_zreduce(view, 1.0), view.sum(-1), rtol=1e-6, atol=1e-5)
+    # a gradient that arrives CONTIGUOUS in the output's (B,C,Y,X,Z) shape: Z-innermost reduction and the re-layout for the pooling backward
+    zl = view.contiguous()
+    assert _capi.volume_zlast_supported(zl) and not _capi.volume_zlast_supported(view)
+    assert torch.allclose(_capi.volume_zreduce_inner(zl, 1.0), zl.sum(-1), rtol=1e-6, atol=1e-5)
+    assert torch.equal(_capi.volume_z_to_front(zl), vol)
     w = torch.randn(view.shape, generator=g).to(dev)
     ref = torch.randn(2, 5, 12, 20, generator=g).to(dev)
     outs = []
