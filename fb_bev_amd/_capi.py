@@ -49,6 +49,8 @@ SIGNATURES = {
     'fbbev_pool_dense_bwd_workspace_bytes': (c_size_t, [c_int] * 9),
     'fbbev_bev_pool_v2_dense_bwd': (c_int, [c_void_p, c_int64, c_int64] + [c_void_p] * 6 + [c_int] * 10 +
                                     [c_void_p] * 3 + [c_size_t, c_void_p]),
+    'fbbev_bev_pool_v2_dense_bwd_z': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_float] + [c_void_p] * 6 + [c_int] * 10 +
+                                    [c_void_p] * 3 + [c_size_t, c_void_p]),
     'fbbev_history_flow': (c_int, [c_void_p] * 5 + [c_int, c_void_p, c_void_p]),
     'fbbev_history_warp': (c_int, [c_void_p, c_int64, c_void_p] + [c_int] * 5 + [c_void_p, c_int64, c_void_p]),
     'fbbev_history_warp_e': (c_int, [c_void_p, c_int64, c_void_p] + [c_int] * 5 + [c_void_p, c_int64, c_int, c_void_p]),
@@ -403,9 +405,10 @@ def pool_dense_bwd_workspace_bytes(B, N, D, H, W, C, Z, Y, X):
 
 
 def bev_pool_v2_dense_bwd(out_grad, depth, feat, ranks_depth, interval_rank, interval_starts, counts,
-                          n_intervals_max, grid_zyx, depth_grad, feat_grad, workspace):
+                          n_intervals_max, grid_zyx, depth_grad, feat_grad, workspace, zgrad=None, zscale=0.0):
     """Sync-free backward of the fused lift-splat.  out_grad: (B,C,Z,Y,X) f32 with a contiguous (Z,Y,X)
-    block; depth (B,N,D,H,W); feat (B,N,H,W,C); depth_grad / feat_grad: same shapes, written completely."""
+    block; depth (B,N,D,H,W); feat (B,N,H,W,C); depth_grad / feat_grad: same shapes, written completely.
+    zgrad (B,C,Y,X), optional: added to every z plane of out_grad scaled by zscale (the Z-mean's backward, folded in)."""
     B, N, D, H, W = depth.shape
     C = feat.shape[-1]
     Z, Y, X = grid_zyx
@@ -413,6 +416,19 @@ def bev_pool_v2_dense_bwd(out_grad, depth, feat, ranks_depth, interval_rank, int
         raise FbbevError('out_grad must be a (B,C,Z,Y,X) tensor with a contiguous (Z,Y,X) block')
     if tuple(feat.shape) != (B, N, H, W, C) or depth_grad.shape != depth.shape or feat_grad.shape != feat.shape:
         raise FbbevError('depth/feat/grad shapes do not match')
+    if zgrad is not None:
+        if tuple(zgrad.shape) != (B, C, Y, X):
+            raise FbbevError('zgrad must be (B,C,Y,X)')
+        with _on(depth):
+            _check(lib().fbbev_bev_pool_v2_dense_bwd_z(
+                _dev(out_grad, F32, 'out_grad', contiguous=False), out_grad.stride(0), out_grad.stride(1),
+                _dev(zgrad, F32, 'zgrad'), float(zscale), _dev(depth, F32, 'depth'), _dev(feat, F32, 'feat'),
+                _dev(ranks_depth, I32, 'ranks_depth'), _dev(interval_rank, I32, 'interval_rank'),
+                _dev(interval_starts, I32, 'interval_starts'), _dev(counts, I32, 'counts'), int(n_intervals_max),
+                B, N, D, H, W, C, Z, Y, X, _dev(depth_grad, F32, 'depth_grad'), _dev(feat_grad, F32, 'feat_grad'),
+                c_void_p(workspace.data_ptr()), workspace.numel() * workspace.element_size(), _stream()),
+                'fbbev_bev_pool_v2_dense_bwd_z')
+        return
     with _on(depth):
         _check(lib().fbbev_bev_pool_v2_dense_bwd(
             _dev(out_grad, F32, 'out_grad', contiguous=False), out_grad.stride(0), out_grad.stride(1),

@@ -2060,13 +2060,14 @@ extern "C" size_t fbbev_pool_dense_bwd_workspace_bytes(int B, int N, int D, int 
     return pool_bwd_layout(B, N, D, H, W, C, Z, Y, X).total;
 }
 
-extern "C" int fbbev_bev_pool_v2_dense_bwd(const float* out_grad, long long og_stride_b, long long og_stride_c,
-                                           const float* depth, const float* feat, const int32_t* ranks_depth,
-                                           const int32_t* interval_rank, const int32_t* interval_starts,
-                                           const int32_t* counts, int n_intervals_max, int B, int N, int D,
-                                           int H, int W, int C, int Z, int Y, int X, float* depth_grad,
-                                           float* feat_grad, void* workspace, size_t workspace_bytes,
-                                           fbbev_stream_t stream_) {
+static int pool_dense_bwd_impl(const float* out_grad, long long og_stride_b, long long og_stride_c,
+                               const float* depth, const float* feat, const int32_t* ranks_depth,
+                               const int32_t* interval_rank, const int32_t* interval_starts,
+                               const int32_t* counts, int n_intervals_max, int B, int N, int D,
+                               int H, int W, int C, int Z, int Y, int X, float* depth_grad,
+                               float* feat_grad, void* workspace, size_t workspace_bytes,
+                               fbbev_stream_t stream_, const float* zgrad, float zscale) {
+    if (zgrad && !aligned16(zgrad)) return FBBEV_E_UNSUPPORTED;
     if (B <= 0 || N <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0 || Z <= 0 || Y <= 0 || X <= 0 || n_intervals_max < 0)
         return FBBEV_E_BADARG;
     if (!out_grad || !depth || !feat || !ranks_depth || !interval_rank || !interval_starts || !counts ||
@@ -2105,7 +2106,7 @@ extern "C" int fbbev_bev_pool_v2_dense_bwd(const float* out_grad, long long og_s
         if (e) return e;
     }
     FBBEV_LAUNCH(k_pool_bwd_rows<128>, l.n_tiles, 256, lds, stream, C, Z, (int)yx, l.tpp, og_stride_b, og_stride_c,
-                 out_grad, interval_rank, meta, rows);
+                 out_grad, interval_rank, meta, rows, zgrad, zscale);
     FBBEV_CHECK_LAUNCH();
     const long long n_pixels = (long long)B * N * H * W;
     const long long blocks = (n_pixels + 7) / 8;      // 8 half-waves per 256-thread workgroup
@@ -2119,6 +2120,30 @@ extern "C" int fbbev_bev_pool_v2_dense_bwd(const float* out_grad, long long og_s
         return FBBEV_E_UNSUPPORTED;
     FBBEV_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int fbbev_bev_pool_v2_dense_bwd(const float* out_grad, long long og_stride_b, long long og_stride_c,
+                                           const float* depth, const float* feat, const int32_t* ranks_depth,
+                                           const int32_t* interval_rank, const int32_t* interval_starts,
+                                           const int32_t* counts, int n_intervals_max, int B, int N, int D,
+                                           int H, int W, int C, int Z, int Y, int X, float* depth_grad,
+                                           float* feat_grad, void* workspace, size_t workspace_bytes,
+                                           fbbev_stream_t stream_) {
+    return pool_dense_bwd_impl(out_grad, og_stride_b, og_stride_c, depth, feat, ranks_depth, interval_rank, interval_starts, counts,
+                               n_intervals_max, B, N, D, H, W, C, Z, Y, X, depth_grad, feat_grad, workspace, workspace_bytes, stream_,
+                               nullptr, 0.f);
+}
+// ... with a second gradient (B, C, Y, X) that every z plane receives, scaled by zscale: out_grad_eff = out_grad + zscale * zgrad[..., None]
+extern "C" int fbbev_bev_pool_v2_dense_bwd_z(const float* out_grad, long long og_stride_b, long long og_stride_c,
+                                             const float* zgrad, float zscale, const float* depth, const float* feat,
+                                             const int32_t* ranks_depth, const int32_t* interval_rank,
+                                             const int32_t* interval_starts, const int32_t* counts, int n_intervals_max, int B,
+                                             int N, int D, int H, int W, int C, int Z, int Y, int X, float* depth_grad,
+                                             float* feat_grad, void* workspace, size_t workspace_bytes, fbbev_stream_t stream_) {
+    if (!zgrad) return FBBEV_E_BADARG;
+    return pool_dense_bwd_impl(out_grad, og_stride_b, og_stride_c, depth, feat, ranks_depth, interval_rank, interval_starts, counts,
+                               n_intervals_max, B, N, D, H, W, C, Z, Y, X, depth_grad, feat_grad, workspace, workspace_bytes, stream_,
+                               zgrad, zscale);
 }
 
 // ------------------------------------------------------------------------------ temporal history alignment

@@ -45,7 +45,10 @@ template <int TV>
 __global__ void __launch_bounds__(256)
 k_pool_bwd_rows(int C, int Z, int YX, int tiles_per_plane, long long stride_b, long long stride_c,
                 const float* __restrict__ out_grad, const int* __restrict__ interval_rank,
-                const int* __restrict__ tile_meta, float* __restrict__ rows) {
+                const int* __restrict__ tile_meta, float* __restrict__ rows, const float* __restrict__ zgrad, float zscale) {
+    // zgrad (B, C, Y*X), may be null: a gradient every z plane receives on top of out_grad, scaled -- the backward of the
+    // training path's Z-mean (fbocc.py:359: d mean / d voxel = 1 / Z) folded into this read instead of an expand + add over
+    // the whole volume
     constexpr int LD = TV + 4;
     constexpr int Q4 = TV / 4;
     float* tile = fbbev_dyn_lds_f32();            // [C][LD]
@@ -60,9 +63,11 @@ k_pool_bwd_rows(int C, int Z, int YX, int tiles_per_plane, long long stride_b, l
     const int n4 = C * Q4;
     for (int idx = tid; idx < n4; idx += 256) {
         const int c = idx / Q4, j = (idx - c * Q4) * 4;
-        if (j < nv)
-            *reinterpret_cast<fbbev_v4f*>(tile + c * LD + j) =
-                *reinterpret_cast<const fbbev_v4f*>(base + (long long)c * stride_c + j);
+        if (j < nv) {
+            fbbev_v4f v = *reinterpret_cast<const fbbev_v4f*>(base + (long long)c * stride_c + j);
+            if (zgrad) v += *reinterpret_cast<const fbbev_v4f*>(zgrad + ((long long)b * C + c) * YX + v0 + j) * zscale;
+            *reinterpret_cast<fbbev_v4f*>(tile + c * LD + j) = v;
+        }
     }
     __syncthreads();
     const int rank0 = plane * YX + v0;

@@ -77,7 +77,7 @@ class LiftSplat(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, depth, feat, idx, grid_zyx, tile_ws, tile_voxels, pool_flags, out_dtype=torch.float32,
-                ws_cache=None, cache_state=None, table_gate=None):
+                ws_cache=None, cache_state=None, table_gate=None, with_zmean=False):
         depth = depth.contiguous().float()
         # `feat` arrives as the (B,N,H,W,C) permuted view of the NCHW context (view_transformer.py:536); when
         # the underlying tensor is contiguous NCHW the copy is done by the LDS-tiled transpose kernel
@@ -98,10 +98,17 @@ class LiftSplat(torch.autograd.Function):
         ctx.ws_cache = ws_cache if ws_cache is not None else _WorkspaceCache()
         ctx.grid_zyx = (Z, Y, X)
         ctx.save_for_backward(depth, feat)
+        ctx.set_materialize_grads(False)                               # an unused output's gradient arrives as None, not as zeros
+        if with_zmean:
+            # second output: the volume's Z-mean (fbocc.py:359), one HBM-bound pass over the fresh volume; its gradient comes
+            # back as `zmean_grad` and is folded into the pooling backward's read of out_grad (no expand + add over the volume)
+            ctx.with_zmean = True
+            return out, _capi.volume_zreduce(out.permute(0, 1, 3, 4, 2), Z)
+        ctx.with_zmean = False
         return out
 
     @staticmethod
-    def backward(ctx, out_grad):
+    def backward(ctx, out_grad, zmean_grad=None):
         """Sync-free: the frustum structure is the feature-pixel index (no argsort of ranks_feat, no mask-built
         intervals, no permuted copy of the gradient) -- fbbev_bev_pool_v2_dense_bwd."""
         depth, feat = ctx.saved_tensors
@@ -110,6 +117,10 @@ class LiftSplat(torch.autograd.Function):
         B, N, D, H, W = depth.shape
         C = feat.shape[-1]
         og = out_grad
+        if og is None and (not ctx.with_zmean or zmean_grad is None):
+            return (None,) * 12
+        if og is None:                                                # only the Z-mean was used downstream
+            og = torch.zeros((B, C, Z, Y, X), dtype=torch.float32, device=depth.device)
         sb, sc = og.stride(0), og.stride(1)
         if (og.dtype != torch.float32 or og.stride()[2:] != (Y * X, X, 1) or sc < Z * Y * X or sb < C * sc or sc % 4
                 or sb % 4 or og.data_ptr() % 16):
@@ -120,9 +131,12 @@ class LiftSplat(torch.autograd.Function):
                 og = og.contiguous().float()
         ws = ctx.ws_cache.bwd_workspace(depth.device, _capi.pool_dense_bwd_workspace_bytes(B, N, D, H, W, C, Z, Y, X))
         depth_grad, feat_grad = torch.empty_like(depth), torch.empty_like(feat)
+        zg = None
+        if ctx.with_zmean and zmean_grad is not None:
+            zg = zmean_grad.contiguous().float()
         _capi.bev_pool_v2_dense_bwd(og, depth, feat, idx.ranks_depth, idx.interval_rank, idx.interval_starts,
-                                    idx.counts, idx.n, (Z, Y, X), depth_grad, feat_grad, ws)
-        return depth_grad, feat_grad, None, None, None, None, None, None, None, None, None
+                                    idx.counts, idx.n, (Z, Y, X), depth_grad, feat_grad, ws, zgrad=zg, zscale=1.0 / Z)
+        return depth_grad, feat_grad, None, None, None, None, None, None, None, None, None, None
 
 
 
@@ -380,13 +394,24 @@ class LSSViewTransformerFunction3D(nn.Module):
                 torch.full((2,), -1, dtype=torch.int32, device=device))
         return idx.tile_tables[tile_voxels]
 
-    def lift_splat(self, idx, depth, tran_feat):
-        """Fused dense pooling on a prepared index set -> (B,C,Y,X,Z) view of (B,C,Z,Y,X)."""
+    def lift_splat(self, idx, depth, tran_feat, with_zmean=False):
+        """Fused dense pooling on a prepared index set -> (B,C,Y,X,Z) view of (B,C,Z,Y,X) [, its Z-mean (B,C,Y,X)]."""
         feat = tran_feat.permute(0, 1, 3, 4, 2)
         table, gate = self._tile_table(idx, depth.device, depth.shape[0], self.tile_voxels)
         out = LiftSplat.apply(depth, feat, idx, self.grid_zyx, table, self.tile_voxels, self.pool_flags, self.out_dtype,
-                              self._ws, idx.cache_state, gate)
+                              self._ws, idx.cache_state, gate, with_zmean)
+        if with_zmean:
+            return out[0].permute(0, 1, 3, 4, 2), out[1]
         return out.permute(0, 1, 3, 4, 2)
+
+    def forward_with_zmean(self, cam_params, context, depth):
+        """(volume view (B,C,Y,X,Z), its Z-mean (B,C,Y,X)) as ONE differentiable op, or None when the fused fp32 route does
+        not apply (the caller then takes forward() and `.mean(-1)`)."""
+        Z, Y, X = self.grid_zyx
+        if (not self.fused or self.extra_relu or self.out_dtype != torch.float32 or not context.is_cuda or
+                not self._fused_supported(context.shape[2]) or (Y * X) % 4 != 0):
+            return None
+        return self.lift_splat(self._index_for(cam_params, depth, context), depth, context, with_zmean=True)
 
     def view_transform_core(self, cam_params, depth, tran_feat):
         """view_transformer.py:613-635."""

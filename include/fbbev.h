@@ -536,6 +536,16 @@ int fbbev_bev_pool_v2_dense_bwd(const float* out_grad, long long og_stride_b, lo
                                 const int32_t* counts, int n_intervals_max, int B, int N, int D, int H, int W,
                                 int C, int Z, int Y, int X, float* depth_grad, float* feat_grad,
                                 void* workspace, size_t workspace_bytes, fbbev_stream_t stream);
+/* fbbev_bev_pool_v2_dense_bwd with a second upstream gradient zgrad (B, C, Y, X) that EVERY z plane receives, scaled:
+ * out_grad_eff[b,c,z,y,x] = out_grad[b,c,z,y,x] + zscale * zgrad[b,c,y,x] -- the backward of `bev_feat.mean(-1)` (fbocc.py:359:
+ * zscale = 1 / Z) folded into the gradient read instead of an expand + add over the whole volume. */
+int fbbev_bev_pool_v2_dense_bwd_z(const float* out_grad, long long og_stride_b, long long og_stride_c, const float* zgrad,
+                                  float zscale, const float* depth, const float* feat, const int32_t* ranks_depth,
+                                  const int32_t* interval_rank, const int32_t* interval_starts, const int32_t* counts,
+                                  int n_intervals_max, int B, int N, int D, int H, int W, int C, int Z, int Y, int X,
+                                  float* depth_grad, float* feat_grad, void* workspace, size_t workspace_bytes,
+                                  fbbev_stream_t stream);
+
 
 /* Temporal history alignment -- replaces FBOCC.generate_grid + the 5-D F.grid_sample of FBOCC.fuse_history
  *   -- mmdet3d/models/fbbev/detectors/fbocc.py:169-205 and :264-275.
