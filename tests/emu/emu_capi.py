@@ -93,7 +93,7 @@ def pool_dense(depth, feat, rd, rf, ir, st, ln, counts, n_max, B, C, Z, Y, X, ti
     return code, out
 
 
-def pool_dense_bwd(out_grad, depth, feat, rd, ir, st, counts, n_max, grid_zyx, poison=True):
+def pool_dense_bwd(out_grad, depth, feat, rd, ir, st, counts, n_max, grid_zyx, poison=True, zgrad=None, zscale=0.0):
     """out_grad (B,C,Z,Y,X) (may have padded batch/channel strides) -> depth_grad, feat_grad"""
     B, N, D, H, W = depth.shape
     C = feat.shape[-1]
@@ -102,6 +102,11 @@ def pool_dense_bwd(out_grad, depth, feat, rd, ir, st, counts, n_max, grid_zyx, p
     fg = torch.full_like(feat, float('nan'))
     ws = torch.zeros(lib().fbbev_pool_dense_bwd_workspace_bytes(B, N, D, H, W, C, Z, Y, X), dtype=torch.uint8)
     assert out_grad.stride()[2:] == (Y * X, X, 1)
+    if zgrad is not None:      # + a (B,C,Y,X) gradient every z plane receives (fbbev_bev_pool_v2_dense_bwd_z)
+        code = lib().fbbev_bev_pool_v2_dense_bwd_z(c_void_p(out_grad.data_ptr()), out_grad.stride(0), out_grad.stride(1), p(zgrad),
+                                                   float(zscale), p(depth), p(feat), p(rd), p(ir), p(st), p(counts), n_max,
+                                                   B, N, D, H, W, C, Z, Y, X, p(dg), p(fg), p(ws), ws.numel(), None)
+        return code, dg, fg
     code = lib().fbbev_bev_pool_v2_dense_bwd(c_void_p(out_grad.data_ptr()), out_grad.stride(0), out_grad.stride(1),
                                              p(depth), p(feat), p(rd), p(ir), p(st), p(counts), n_max,
                                              B, N, D, H, W, C, Z, Y, X, p(dg), p(fg), p(ws), ws.numel(), None)

@@ -511,6 +511,12 @@ def test_pool_dense_bwd_emulated(name, B, padded):
     kept = torch.zeros(depth.numel(), dtype=torch.bool)
     kept[erd.long()] = True
     assert torch.equal(dg.flatten()[~kept], torch.zeros((~kept).sum()))
+    # fbbev_bev_pool_v2_dense_bwd_z: a (B,C,Y,X) gradient added to every z plane inside the gradient read (the Z-mean's backward)
+    # == the plain backward of out_grad + zscale * zgrad[:, :, None], bit for bit
+    zg = torch.randn((B, C, Y, X), generator=g)
+    code, dg2, fg2 = E.pool_dense_bwd(og, depth, feat, rd, ir, st, counts, st.numel(), (Z, Y, X), zgrad=zg, zscale=1.0 / Z)
+    code3, dg3, fg3 = E.pool_dense_bwd((og + (zg * (1.0 / Z))[:, :, None]).contiguous(), depth, feat, rd, ir, st, counts, st.numel(), (Z, Y, X))
+    assert code == 0 and code3 == 0 and torch.equal(dg2, dg3) and torch.equal(fg2, fg3)
 
 
 def test_pool_dense_bwd_empty_index_writes_zeros():
