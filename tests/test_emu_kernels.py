@@ -1560,3 +1560,29 @@ def test_token_pyramid_in_one_launch_emulated():
     assert torch.equal(out, exp)
     code, out = E.tokens_from_nchw_levels(levels[:2], None)
     assert code == 0 and torch.equal(out, torch.cat([t.permute(0, 2, 1) for t in levels[:2]], 1))
+
+
+def test_volume_z_reductions_emulated():
+    """fbbev_volume_zreduce / _inner / fbbev_volume_z_to_front (the training path's Z-mean, the re-add's backward Z-sum, the re-layout
+    of a (Y,X,Z)-contiguous gradient) against torch on the CPU emulator; refused shapes."""
+    import ctypes
+    g = torch.Generator().manual_seed(9)
+    B, C, Z, Y, X = 2, 3, 8, 5, 12
+    vol = torch.randn(B, C, Z, Y, X, generator=g)
+    L = E.lib()
+    out = torch.full((B, C, Y, X), float('nan'))
+    assert L.fbbev_volume_zreduce(E.p(vol), B * C, Z, Y * X, ctypes.c_float(Z), E.p(out), None) == 0
+    assert torch.allclose(out, vol.mean(2), rtol=1e-6, atol=1e-6)
+    zl = vol.permute(0, 1, 3, 4, 2).contiguous()                                # (B, C, Y, X, Z) memory
+    out2 = torch.full((B, C, Y, X), float('nan'))
+    assert L.fbbev_volume_zreduce_inner(E.p(zl), B * C * Y * X, Z, ctypes.c_float(1.0), E.p(out2), None) == 0
+    assert torch.allclose(out2, vol.sum(2), rtol=1e-6, atol=1e-5)
+    back = torch.full((B, C, Z, Y, X), float('nan'))
+    assert L.fbbev_volume_z_to_front(E.p(zl), B * C, Z, Y * X, E.p(back), None) == 0
+    assert torch.equal(back, vol)
+    # Y*X not a multiple of 4 / Z not a multiple of 4: refused, nothing written
+    odd = torch.randn(1, 1, 6, 3, 3, generator=g)
+    o = torch.full((1, 1, 3, 3), float('nan'))
+    assert L.fbbev_volume_zreduce(E.p(odd), 1, 6, 9, ctypes.c_float(6.0), E.p(o), None) < 0 and torch.isnan(o).all()
+    assert L.fbbev_volume_zreduce_inner(E.p(odd), 9, 6, ctypes.c_float(1.0), E.p(o), None) < 0
+    assert L.fbbev_volume_z_to_front(E.p(odd), 1, 6, 9, E.p(torch.empty(1, 1, 6, 3, 3)), None) < 0
