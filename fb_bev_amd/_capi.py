@@ -72,6 +72,8 @@ SIGNATURES = {
     'fbbev_msda_self_fused_supported': (c_int, [c_int] * 8),
     'fbbev_msda_self_fused': (c_int, [c_void_p] * 3 + [c_int64, c_void_p, c_int64, c_int64] + [c_void_p] * 4 + [c_int] * 10 +
                               [c_void_p, c_void_p]),
+    'fbbev_msda_self_fused_ln': (c_int, [c_void_p] * 3 + [c_int64, c_void_p, c_int64, c_int64] + [c_void_p] * 4 +
+                                 [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_float] + [c_int] * 10 + [c_void_p, c_void_p]),
     'fbbev_layernorm_bwd_partials': (c_int, [c_int64]),
     'fbbev_layernorm_bwd': (c_int, [c_void_p] * 3 + [c_float, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     'fbbev_history_conv': (c_int, [c_void_p, c_int64] + [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -1002,9 +1004,11 @@ def msda_self_fused_supported(B, S, M, Dh, L, Q, P, bev_w):
 
 
 def msda_self_fused(planes, reference_points, query, addend, offsets_fragments, offsets_bias, attn_fragments, attn_bias, num_points,
-                    bev_w, level_hw, out):
+                    bev_w, level_hw, out, out_proj=None):
     """fbbev_msda_self_fused: planes (B, M, S, Dh) head-plane value tokens; reference_points (B, Q, 1, 2); query (B, Q, E) rows
-    [+ addend (P_, E) rows]; fragments / biases of sampling_offsets and attention_weights in the module's row order; out (B, Q, E)."""
+    [+ addend (P_, E) rows]; fragments / biases of sampling_offsets and attention_weights in the module's row order; out (B, Q, E).
+    out_proj = (fragments, bias, residual (B, Q, E) or None, ln_weight, ln_bias, eps): the block's tail in the same workgroups
+    (fbbev_msda_self_fused_ln): out = LayerNorm(output_proj(attention) + residual)."""
     B, M, S, Dh = planes.shape
     Q = query.shape[1]
     E = M * Dh
@@ -1019,6 +1023,19 @@ def msda_self_fused(planes, reference_points, query, addend, offsets_fragments, 
         if addend.dim() != 2 or addend.shape[1] != E or addend.stride(1) != 1 or (B * Q) % addend.shape[0] != 0:
             raise FbbevError('msda_self_fused: addend must be (P, E) rows with B*Q % P == 0')
         a_ptr, a_ld, a_per = _dev(addend, F32, 'addend', contiguous=False), addend.stride(0), addend.shape[0]
+    if out_proj is not None:
+        wf, wb, res, lnw, lnb, eps = out_proj
+        if res is not None and (tuple(res.shape) != (B, Q, E) or not res.is_contiguous()):
+            raise FbbevError('msda_self_fused: residual must be contiguous (B, Q, E)')
+        with _on(planes):
+            _check(lib().fbbev_msda_self_fused_ln(
+                _dev(planes, F32, 'planes'), _dev(reference_points, F32, 'reference_points'), _dev(query, F32, 'query', contiguous=False),
+                query.stride(1), a_ptr, a_ld, a_per, offsets_fragments.data_ptr(), _dev(offsets_bias, F32, 'offsets_bias'),
+                attn_fragments.data_ptr(), _dev(attn_bias, F32, 'attn_bias'), wf.data_ptr(), _dev(wb, F32, 'out_bias'),
+                None if res is None else _dev(res, F32, 'residual'), E, _dev(lnw, F32, 'ln_weight'), _dev(lnb, F32, 'ln_bias'),
+                float(eps), B, S, M, Dh, 1, Q, int(num_points), int(bev_w), int(level_hw[0]), int(level_hw[1]), _dev(out, F32, 'out'),
+                _stream()), 'fbbev_msda_self_fused_ln')
+        return out
     with _on(planes):
         _check(lib().fbbev_msda_self_fused(
             _dev(planes, F32, 'planes'), _dev(reference_points, F32, 'reference_points'), _dev(query, F32, 'query', contiguous=False),

@@ -283,6 +283,16 @@ class MultiScaleDeformableAttention(nn.Module):
                         q_in = query + pos
                 out = torch.empty(bs, num_query, self.embed_dims, dtype=torch.float32, device=query.device)
                 ref = reference_points.expand(bs, num_query, 1, 2).contiguous()
+                if (_norm is not None and _defer_residual and FUSE_ATTN_TAIL and self.embed_dims % 16 == 0
+                        and _RL.ln_fusable(_norm, identity.contiguous(), out, self.embed_dims)):
+                    # output_proj + residual + the following LayerNorm inside the attention kernel's workgroups (fbbev_msda_self_fused_ln):
+                    # the attention output never leaves the CU
+                    if not hasattr(self.output_proj, '_x3'):
+                        self.output_proj._x3 = X3Weights()
+                    oc = self.output_proj._x3.get(self.output_proj.weight, self.output_proj.bias)
+                    _capi.msda_self_fused(planes, ref, q_in, add, so_c.frag, so_c.b, aw_c.frag, aw_c.b, self.num_points, hw[0][1],
+                                          hw[0], out, out_proj=(oc.frag, oc.b, identity.contiguous(), _norm.weight, _norm.bias, _norm.eps))
+                    return out, _NORMED
                 _capi.msda_self_fused(planes, ref, q_in, add, so_c.frag, so_c.b, aw_c.frag, aw_c.b, self.num_points, hw[0][1],
                                       hw[0], out)
                 if _norm is not None and _defer_residual:     # output_proj + residual + the following LayerNorm: one kernel
@@ -494,6 +504,7 @@ def _pad_interleave_rows(w, b, M, Dh, HS, interleave=True, piece=4):
 import os as _os
 FUSE_FFN = _os.environ.get('FBBEV_FUSE_FFN', '1') != '0'               # the FFN pair as one kernel (fbbev_rows_ffn_x3; A/B knob)
 FUSE_OUT_NORM = _os.environ.get('FBBEV_FUSE_OUT_NORM', '1') != '0'     # output_proj / FFN tail + residual + LayerNorm in one kernel (A/B knob)
+FUSE_ATTN_TAIL = _os.environ.get('FBBEV_FUSE_ATTN_TAIL', '1') != '0'   # ... inside the attention kernel's own workgroups (A/B knob)
 FUSED_BWD_MAX_HEAD_DIM = 32                 # k_da_cross_attn_bwd: one lane per channel, groups of 16 / 32 lanes
 
 

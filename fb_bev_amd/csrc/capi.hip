@@ -1525,11 +1525,12 @@ extern "C" int fbbev_msda_self_fused_supported(int B, int S, int M, int Dh, int 
     return (!off && M == 8 && (Dh == 10 || Dh == 8) && L == 1 && P == FBBEV_MSF_P && bev_w > 0 && Q % bev_w == 0 &&
             (long long)S * Dh * 4 < (1ll << 31)) ? 1 : 0;
 }
-extern "C" int fbbev_msda_self_fused(const float* planes, const float* reference_points, const float* query,
-                                     long long query_row_stride, const float* addend, long long addend_row_stride,
-                                     long long addend_period, const void* offsets_fragments, const float* offsets_bias,
-                                     const void* attn_fragments, const float* attn_bias, int B, int S, int M, int Dh, int L, int Q,
-                                     int P, int bev_w, int level_h, int level_w, float* out, fbbev_stream_t stream_) {
+static int msda_self_fused_impl(const float* planes, const float* reference_points, const float* query,
+                                long long query_row_stride, const float* addend, long long addend_row_stride,
+                                long long addend_period, const void* offsets_fragments, const float* offsets_bias,
+                                const void* attn_fragments, const float* attn_bias, int B, int S, int M, int Dh, int L, int Q,
+                                int P, int bev_w, int level_h, int level_w, float* out, fbbev_stream_t stream_,
+                                fbbev_daf_outproj op) {
     if (B <= 0 || S <= 0 || M <= 0 || Dh <= 0 || L <= 0 || Q < 0 || P <= 0 || bev_w < 0 || level_h <= 0 || level_w <= 0)
         return FBBEV_E_BADARG;
     if (Q == 0) return 0;
@@ -1553,19 +1554,51 @@ extern "C" int fbbev_msda_self_fused(const float* planes, const float* reference
     const long long grid = (wgs + 7) / 8 * 8;
     if (grid >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
     const size_t lds = fbbev_msf_lds_bytes(E, M);
-#define FBBEV_MSDA_SELF(DH_)                                                                                            \
+#define FBBEV_MSDA_SELF(DH_) do { if (op.w_frag) FBBEV_MSDA_SELF2(DH_, true); else FBBEV_MSDA_SELF2(DH_, false); } while (0)
+#define FBBEV_MSDA_SELF2(DH_, OP_)                                                                                      \
     do {                                                                                                               \
-        int e = fbbev_rt_allow_dyn_lds((const void*)k_msda_self_fused<DH_, 8>, lds);                                  \
+        int e = fbbev_rt_allow_dyn_lds((const void*)k_msda_self_fused<DH_, 8, OP_>, lds);                             \
         if (e) return e;                                                                                               \
-        FBBEV_LAUNCH((k_msda_self_fused<DH_, 8>), grid, 512, lds, (fbbev_rt_stream)stream_, planes, reference_points,  \
+        FBBEV_LAUNCH((k_msda_self_fused<DH_, 8, OP_>), grid, 512, lds, (fbbev_rt_stream)stream_, planes, reference_points,  \
                      query, query_row_stride, addend, addend_row_stride, addend_period,                                \
                      static_cast<const unsigned short*>(offsets_fragments), offsets_bias,                              \
-                     static_cast<const unsigned short*>(attn_fragments), attn_bias, B, Q, bev_w, S, level_h, level_w, out); \
+                     static_cast<const unsigned short*>(attn_fragments), attn_bias, B, Q, bev_w, S, level_h, level_w, out, op); \
     } while (0)
     if (Dh == 10) FBBEV_MSDA_SELF(10); else FBBEV_MSDA_SELF(8);
 #undef FBBEV_MSDA_SELF
+#undef FBBEV_MSDA_SELF2
     FBBEV_CHECK_LAUNCH();
     return 0;
+}
+extern "C" int fbbev_msda_self_fused(const float* planes, const float* reference_points, const float* query,
+                                     long long query_row_stride, const float* addend, long long addend_row_stride,
+                                     long long addend_period, const void* offsets_fragments, const float* offsets_bias,
+                                     const void* attn_fragments, const float* attn_bias, int B, int S, int M, int Dh, int L, int Q,
+                                     int P, int bev_w, int level_h, int level_w, float* out, fbbev_stream_t stream_) {
+    return msda_self_fused_impl(planes, reference_points, query, query_row_stride, addend, addend_row_stride, addend_period,
+                                offsets_fragments, offsets_bias, attn_fragments, attn_bias, B, S, M, Dh, L, Q, P, bev_w, level_h,
+                                level_w, out, stream_, fbbev_daf_outproj{nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0.f});
+}
+// ... followed, inside the same workgroups, by output_proj + residual + LayerNorm: out = LN(W_o attention + b_o + residual)
+extern "C" int fbbev_msda_self_fused_ln(const float* planes, const float* reference_points, const float* query,
+                                        long long query_row_stride, const float* addend, long long addend_row_stride,
+                                        long long addend_period, const void* offsets_fragments, const float* offsets_bias,
+                                        const void* attn_fragments, const float* attn_bias, const void* out_fragments,
+                                        const float* out_bias, const float* residual, long long residual_row_stride,
+                                        const float* ln_weight, const float* ln_bias, float ln_eps, int B, int S, int M, int Dh,
+                                        int L, int Q, int P, int bev_w, int level_h, int level_w, float* out,
+                                        fbbev_stream_t stream_) {
+    if (!out_fragments || !out_bias || !ln_weight || !ln_bias || !(ln_eps >= 0.f) || M <= 0 || Dh <= 0) return FBBEV_E_BADARG;
+    const int E = M * Dh;
+    if (residual && residual_row_stride == 0) residual_row_stride = E;
+    if (residual && residual_row_stride < E) return FBBEV_E_BADARG;
+    if (E % 16 != 0 || !aligned16(out_fragments) || !aligned16(out_bias) || !aligned16(ln_weight) || !aligned16(ln_bias) ||
+        !aligned16(out) || (residual && (!aligned16(residual) || residual_row_stride % 4 != 0))) return FBBEV_E_UNSUPPORTED;
+    return msda_self_fused_impl(planes, reference_points, query, query_row_stride, addend, addend_row_stride, addend_period,
+                                offsets_fragments, offsets_bias, attn_fragments, attn_bias, B, S, M, Dh, L, Q, P, bev_w, level_h,
+                                level_w, out, stream_,
+                                fbbev_daf_outproj{static_cast<const unsigned short*>(out_fragments), out_bias, residual,
+                                                  residual_row_stride, ln_weight, ln_bias, ln_eps});
 }
 
 extern "C" int fbbev_rows_to_head_planes(const float* rows, long long n_rows, int tokens_per_image, int M, int Dh, float* planes,

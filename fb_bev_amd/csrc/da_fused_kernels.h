@@ -146,6 +146,102 @@ __device__ __forceinline__ void fbbev_daf_plane_corners(float x, float y, int H,
     wgt[2] = (bottom || left) ? 0.f : s * lh * hw; wgt[3] = (bottom || right) ? 0.f : s * lh * lw;
 }
 
+// ---------------------------------------------------------------- output projection + residual + LayerNorm in the workgroup
+// The attention output of a patch never leaves the CU: every wave drops its head's DH channels of the 64 queries into the
+// workgroup's x-fragment buffer (split bf16, the B-operand layout of fbbev_daf_project -- the query fragments are no longer
+// needed), then wave rt (rt = 0..3) takes the 16 queries of row tile rt through `output_proj` (O = 16 MT outputs, the
+// three-MFMA split-operand arithmetic of k_rows_linear_x3), adds bias + residual and applies the layer's LayerNorm exactly as
+// k_rows_linear_x3<., true>'s epilogue does (two-pass statistics; a row's outputs live in the 4 lanes g = 0..3 of lane j).
+// Replaces a k_rows_linear_x3_ln launch and the write + read of the (B, Q, E) attention output between the two kernels.
+struct fbbev_daf_outproj {
+    const unsigned short* w_frag;      // output_proj.weight as split bf16 fragments (k_rows_linear_x3_fragments); null = no epilogue
+    const float* bias;                 // (O)
+    const float* res;                  // residual rows (B*Q, ld_res), may be null
+    long long ld_res;
+    const float* ln_w;                 // LayerNorm weight / bias (O)
+    const float* ln_b;
+    float eps;
+};
+
+template <int DH, int KS>
+__device__ __forceinline__ void fbbev_daf_put_channels(unsigned short* __restrict__ xf, int m, int lane, const fbbev_v2f (&acc)[DH / 2]) {
+    static_assert(DH <= 16, "two groups of eight");
+    const int rt = lane >> 4, j = lane & 15;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {                      // eight channels at a time (registers: the sampler's budget is the kernel's)
+        if (8 * h >= DH) break;
+        float v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = 8 * h + c < DH ? acc[(8 * h + c) >> 1][c & 1] : 0.f;
+        fbbev_bf16x8 h8, l8;
+        fbbev_split_bf16x8(fbbev_v4f{v[0], v[1], v[2], v[3]}, fbbev_v4f{v[4], v[5], v[6], v[7]}, h8, l8);
+        unsigned short hs[8], ls[8];
+        __builtin_memcpy(hs, &h8, 16);
+        __builtin_memcpy(ls, &l8, 16);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            if (8 * h + c >= DH) break;
+            const int ch = m * DH + 8 * h + c, s = ch >> 5, g = (ch & 31) >> 3, e = ch & 7;            // uniform over the wave
+            unsigned short* dst = xf + (((rt * KS + s) * 2) * 64 + g * 16 + j) * 8 + e;
+            dst[0] = hs[c];
+            dst[64 * 8] = ls[c];
+        }
+    }
+}
+
+// rows 16 rt .. 16 rt + 15 of the patch (row of lane (g, j): `row`, `live`): out[row][:O] = LN(W x + b + res[row])
+template <int KS, int MT>
+__device__ __forceinline__ void fbbev_daf_outproj_ln(const fbbev_daf_outproj& op, const unsigned short* __restrict__ xf, int rt, int lane,
+                                                     long long row, bool live, float* __restrict__ out, long long ldo) {
+    constexpr int O = 16 * MT;
+    const int g = lane >> 4;
+    fbbev_v4f v[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) v[mt] = fbbev_v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const fbbev_bf16x8 xh = fbbev_ld_bf16x8(xf + (((rt * KS + s) * 2 + 0) * 64 + lane) * 8);
+        const fbbev_bf16x8 xl = fbbev_ld_bf16x8(xf + (((rt * KS + s) * 2 + 1) * 64 + lane) * 8);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const unsigned short* wt = op.w_frag + (long long)mt * FBBEV_RL_TILE_ELEMS;
+            const fbbev_bf16x8 ah = fbbev_ld_bf16x8(wt + (s * 64 + lane) * 8);
+            const fbbev_bf16x8 al = fbbev_ld_bf16x8(wt + FBBEV_RL_TILE_ELEMS / 2 + (s * 64 + lane) * 8);
+            v[mt] = fbbev_mfma_f32_16x16x32_bf16(al, xh, v[mt]);
+            v[mt] = fbbev_mfma_f32_16x16x32_bf16(ah, xl, v[mt]);
+            v[mt] = fbbev_mfma_f32_16x16x32_bf16(ah, xh, v[mt]);
+        }
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int o = 16 * mt + 4 * g;
+        v[mt] = v[mt] + *reinterpret_cast<const fbbev_v4f*>(op.bias + o);
+        if (op.res && live) v[mt] = v[mt] + *reinterpret_cast<const fbbev_v4f*>(op.res + row * op.ld_res + o);
+        sum += (v[mt][0] + v[mt][1]) + (v[mt][2] + v[mt][3]);
+    }
+    sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
+    const float mean = sum / (float)O;
+    float q = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        v[mt] = v[mt] - fbbev_v4f{mean, mean, mean, mean};
+        q += (v[mt][0] * v[mt][0] + v[mt][1] * v[mt][1]) + (v[mt][2] * v[mt][2] + v[mt][3] * v[mt][3]);
+    }
+    q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+    const float inv = 1.0f / sqrtf(q / (float)O + op.eps);
+    if (!live) return;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int o = 16 * mt + 4 * g;
+        const fbbev_v4f w4 = *reinterpret_cast<const fbbev_v4f*>(op.ln_w + o), b4 = *reinterpret_cast<const fbbev_v4f*>(op.ln_b + o);
+        fbbev_v4f y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = v[mt][e] * inv * w4[e] + b4[e];
+        *reinterpret_cast<fbbev_v4f*>(out + row * ldo + o) = y;
+    }
+}
+
 // planes (B*Ncam, M, S, DH); pred_depth (B*Ncam, DC, H0, W0); ref_cam (Ncam,B,Q,Za,2); mask (Ncam,B,Q,Za) u8; qdepth (Ncam,B,Q,Za);
 // query (B*Q rows, ldq floats apart, E used) [+ addend rows: row (b*Q + q) % add_period]; so_frag / aw_frag: split bf16 fragments of
 // sampling_offsets.weight (M*L*P*2, E) / attention_weights.weight (M*L*P, E) in the order of k_rows_linear_x3_fragments, rows in
@@ -396,14 +492,15 @@ k_rows_to_head_planes(const float* __restrict__ rows, long long n_rows, int S, i
 #define FBBEV_MSF_P 4
 __host__ __device__ inline size_t fbbev_msf_lds_bytes(int E, int M) { return fbbev_daf_xf_bytes(E) + (size_t)M * 64 * FBBEV_DAF_OS * 4; }
 
-template <int DH, int MH>
-__global__ void __launch_bounds__(64 * MH)
+template <int DH, int MH, bool OP>
+__global__ void __launch_bounds__(64 * MH, 4)      // 4 waves per SIMD = two workgroups per CU (65 KB of LDS each): 128 registers
 k_msda_self_fused(const float* __restrict__ planes, const float* __restrict__ ref, const float* __restrict__ query, long long ldq,
                   const float* __restrict__ addend, long long ld_add, long long add_period,
                   const unsigned short* __restrict__ so_frag, const float* __restrict__ so_bias,
                   const unsigned short* __restrict__ aw_frag, const float* __restrict__ aw_bias,
-                  int B, int Q, int bev_w, int S, int H, int W, float* __restrict__ out) {
+                  int B, int Q, int bev_w, int S, int H, int W, float* __restrict__ out, fbbev_daf_outproj op) {
     constexpr int E = MH * DH, KS = (E + 31) / 32, P = FBBEV_MSF_P, NT = 64 * MH;
+    static_assert(E % 16 == 0, "output_proj epilogue: whole 16-output tiles");
     static_assert(MH == 8, "a 16-output tile = the offsets of two heads / the logits of four");
     unsigned char* lds = reinterpret_cast<unsigned char*>(fbbev_dyn_lds_f32());
     unsigned short* xf = reinterpret_cast<unsigned short*>(lds);
@@ -506,8 +603,20 @@ k_msda_self_fused(const float* __restrict__ planes, const float* __restrict__ re
         fbbev_daf_consume<DH>(pend[p & 1], acc);
         fbbev_sched_fence();
     }
-    if (!valid) return;
-    float* dst = out + bq * E + m * DH;
+    if constexpr (OP) {                                                 // output_proj + residual + LayerNorm in the workgroup (its own instantiation)
+        __syncthreads();                                                // every wave is done with the query fragments
+        fbbev_daf_put_channels<DH, KS>(xf, m, lane, acc);
+        __syncthreads();
+        if (m < 4) {
+            const int ql = 16 * m + (lane & 15);
+            const int ry = y0 + (ql >> 3), rx = x0 + (ql & 7);
+            const bool live = ry < bev_h && rx < bev_w;
+            fbbev_daf_outproj_ln<KS, E / 16>(op, xf, m, lane, (long long)b * Q + (live ? (long long)ry * bev_w + rx : 0), live, out, E);
+        }
+    } else {
+        if (!valid) return;
+        float* dst = out + bq * E + m * DH;
 #pragma unroll
-    for (int c = 0; c < DH / 2; ++c) *reinterpret_cast<fbbev_v2f*>(dst + 2 * c) = acc[c];
+        for (int c = 0; c < DH / 2; ++c) *reinterpret_cast<fbbev_v2f*>(dst + 2 * c) = acc[c];
+    }
 }

@@ -428,6 +428,18 @@ int fbbev_msda_self_fused(const float* planes, const float* reference_points, co
                           const void* offsets_fragments, const float* offsets_bias, const void* attn_fragments,
                           const float* attn_bias, int B, int S, int M, int Dh, int L, int Q, int P, int bev_w, int level_h,
                           int level_w, float* out, fbbev_stream_t stream);
+/* fbbev_msda_self_fused followed, inside the same workgroups, by the attention block's tail: out = LayerNorm(output_proj(attention)
+ * + residual) (bevformer_encoder.py:250-377, operation_order (self_attn, norm, ...)).  out_fragments: output_proj.weight as split bf16
+ * fragments (fbbev_rows_linear_x3_fragments); residual rows (B*Q, residual_row_stride) or NULL.  Same arithmetic as
+ * fbbev_rows_linear_x3_ln on the attention output (three-MFMA split operands, two-pass LayerNorm statistics); M*Dh % 16 == 0. */
+int fbbev_msda_self_fused_ln(const float* planes, const float* reference_points, const float* query, long long query_row_stride,
+                             const float* addend, long long addend_row_stride, long long addend_period,
+                             const void* offsets_fragments, const float* offsets_bias, const void* attn_fragments,
+                             const float* attn_bias, const void* out_fragments, const float* out_bias, const float* residual,
+                             long long residual_row_stride, const float* ln_weight, const float* ln_bias, float ln_eps, int B, int S,
+                             int M, int Dh, int L, int Q, int P, int bev_w, int level_h, int level_w, float* out,
+                             fbbev_stream_t stream);
+
 /* row-major camera tokens (n_rows = B*Ncam*S rows of M*Dh floats, module order (head, channel)) -> head planes (B*Ncam, M, S, Dh) */
 int fbbev_rows_to_head_planes(const float* rows, long long n_rows, int tokens_per_image, int M, int Dh, float* planes,
                               fbbev_stream_t stream);

@@ -371,13 +371,21 @@ def da_cross_attn_fused(planes, ss, ls, pred_depth, ref_cam, mask, qdepth, query
     return code, slots
 
 
-def msda_self_fused(planes, ref, query, addend, w_so, b_so, w_aw, b_aw, P, bev_w, level_hw):
+def msda_self_fused(planes, ref, query, addend, w_so, b_so, w_aw, b_aw, P, bev_w, level_hw, out_proj=None):
+    """out_proj = (weight, bias, residual or None, ln_weight, ln_bias, eps): fbbev_msda_self_fused_ln"""
     B, M, S, Dh = planes.shape
     Q = query.shape[1]
     f_so, p_so = _fragments(w_so)
     f_aw, p_aw = _fragments(w_aw)
     out = torch.full((B, Q, M * Dh), float('nan'))
     a = (c_void_p(addend.data_ptr()), addend.stride(0), addend.shape[0]) if addend is not None else (None, 0, 1)
+    if out_proj is not None:
+        wo, bo, res, lnw, lnb, eps = out_proj
+        f_o, p_o = _fragments(wo)
+        code = lib().fbbev_msda_self_fused_ln(p(planes), p(ref), p(query), query.stride(1), *a, p_so, p(b_so), p_aw, p(b_aw), p_o, p(bo),
+                                              None if res is None else p(res), M * Dh, p(lnw), p(lnb), eps, B, S, M, Dh, 1, Q, P, bev_w,
+                                              level_hw[0], level_hw[1], p(out), None)
+        return code, out
     code = lib().fbbev_msda_self_fused(p(planes), p(ref), p(query), query.stride(1), *a, p_so, p(b_so), p_aw, p(b_aw), B, S, M, Dh,
                                        1, Q, P, bev_w, level_hw[0], level_hw[1], p(out), None)
     return code, out

@@ -1463,6 +1463,16 @@ def test_fused_bev_self_attention_emulated(B, bh, bw, with_pos):
     # refused: two levels, 8 points
     code, _ = E.msda_self_fused(planes, ref, q_in, add, w_so, b_so, w_aw, b_aw, 8, bw, (bh, bw))
     assert code < 0
+    # fbbev_msda_self_fused_ln: the block's tail in the same workgroups -- LayerNorm(output_proj(attention) + residual) -- against the
+    # fp32 expression on the one-kernel attention output (split-operand output_proj: ~1e-5 relative), with and without a residual
+    w_o, b_o = torch.randn(Em, Em, generator=g) * 0.2, torch.randn(Em, generator=g) * 0.1
+    lnw, lnb = torch.rand(Em, generator=g) + 0.5, torch.randn(Em, generator=g) * 0.1
+    for res in (query.contiguous(), None):
+        code, y = E.msda_self_fused(planes, ref, q_in, add, w_so, b_so, w_aw, b_aw, P, bw, (bh, bw), out_proj=(w_o, b_o, res, lnw, lnb, 1e-5))
+        assert code == 0 and not torch.isnan(y).any()
+        pre = F.linear(out, w_o, b_o) + (res if res is not None else 0)
+        want = F.layer_norm(pre, (Em,), lnw, lnb, 1e-5)
+        assert (y - want).abs().max().item() <= 2e-4, (y - want).abs().max().item()
 
 
 def test_pool_dense_pipelined_over_tile_runs_emulated():
