@@ -1770,8 +1770,8 @@ static bool da_own_plan_make(int B, int Ncam, int S, int M, int Dh, int Q, int H
     const int mode = da_bwd_owned_mode();
     if (mode == 0) return false;
     if (Dh > 16 || HS % 4 != 0 || HS > 16 || Q <= 0 || P > FBBEV_DA_BWD_MAXP || !(Dh == 10 || Dh == 8 || Dh == 16 || Dh == 4)) return false;
-    pl->info_stride = 8;
-    if (1 + Za > pl->info_stride || Za > FBBEV_DA_MAX_ZA) return false;
+    pl->info_stride = 0;
+    if (Za > FBBEV_DA_HIT_ZA) return false;                             // a hit record holds 4 anchors
     const size_t budget_bytes = (size_t)da_own_plane_kb() * 1024;
     int budget = (int)(budget_bytes / (HS * sizeof(long long))) - 8;             // tokens per LDS plane (64-bit words, skewed)
     { const int v = da_bwd_env().tokens; if (v > 0 && v < budget) budget = v; }   // tests: force bands
@@ -1822,8 +1822,8 @@ static bool da_own_plan_make(int B, int Ncam, int S, int M, int Dh, int Q, int H
     { const int v = da_bwd_env().threads; if (v == 256 || v == 512) pl->threads = v; }
     if ((long long)n * B * Ncam * M >= (1ll << 31) || (long long)B * Ncam * Q >= (1ll << 31)) return false;
     if (mode < 0 && (long long)n * B * Ncam * M < 256) return false;              // too few planes to fill the chip: chunked scatter
-    pl->off_list = align_up((size_t)B * Ncam * Q * pl->info_stride * sizeof(float), 256);
-    pl->off_count = pl->off_list + align_up((size_t)B * Ncam * Q * sizeof(int), 256);
+    pl->off_list = 0;                                                  // hit records [B*Ncam][Q][16 floats] at the start of ws
+    pl->off_count = align_up((size_t)B * Ncam * Q * FBBEV_DA_HIT_REC * sizeof(float), 256);
     pl->off_gmax = pl->off_count + align_up((size_t)B * Ncam * sizeof(int), 256);
     pl->ws = pl->off_gmax + 256;
     // unit gradients on head planes (k_da_bwd_unit_planes, da_bwd_planes_kernels.h; FBBEV_DA_BWD_UNIT_PLANES=0 keeps the row kernel):
@@ -1898,8 +1898,7 @@ static int da_bwd_owned_launch(const da_own_plan& op, fbbev_rt_stream stream, co
                                int head_minor, int HS, float* grad_value, float* grad_pred_depth, float* grad_offsets,
                                float* grad_attn, void* ws, int bev_w) {
     char* w = static_cast<char*>(ws);
-    float* info = reinterpret_cast<float*>(w);
-    int* hit_list = reinterpret_cast<int*>(w + op.off_list);
+    float* hit_rec = reinterpret_cast<float*>(w + op.off_list);
     int* hit_count = reinterpret_cast<int*>(w + op.off_count);
     unsigned int* gmax_bits = reinterpret_cast<unsigned int*>(w + op.off_gmax);
     FBBEV_LAUNCH(k_da_bwd_init, 1, 256, 0, stream, B * Ncam, hit_count, 1, gmax_bits);
@@ -1936,7 +1935,7 @@ static int da_bwd_owned_launch(const da_own_plan& op, fbbev_rt_stream stream, co
         if (e) return e;
     }
     FBBEV_LAUNCH(k_da_bwd_hitlist, (long long)B * ((Q + 255) / 256), 256, 0, stream, spatial_shapes, pred_depth, ref_cam, mask,
-                 qdepth, B, Ncam, Q, Za, DC, d0, dstep, op.info_stride, info, hit_list, hit_count);
+                 qdepth, B, Ncam, Q, Za, DC, d0, dstep, hit_rec, hit_count);
     FBBEV_CHECK_LAUNCH();
     const fbbev_da_bwd_region_tab& tab = op.tab;
     const long long wgs = (long long)tab.n * B * Ncam * M;
@@ -1946,7 +1945,7 @@ static int da_bwd_owned_launch(const da_own_plan& op, fbbev_rt_stream stream, co
         if (e) return e;                                                                                                \
         FBBEV_LAUNCH((k_da_bwd_scatter_owned<NT_, DH_>), wgs, NT_, op.lds, stream, spatial_shapes, level_start_index,   \
                      ref_cam, offsets, attn, grad_slots, B, Ncam, S, M, L, Q, P, Za, head_minor & 3, HS, tab,            \
-                     (const float*)info, op.info_stride, (const int*)hit_list, (const int*)hit_count,                    \
+                     (const float*)hit_rec, (const int*)hit_count,                                                       \
                      (const unsigned int*)gmax_bits, (head_minor & 4) ? 1 : 0, grad_value);                              \
     } while (0)
 #define FBBEV_DA_OWN_NT(DH_) do { if (op.threads == 512) FBBEV_DA_OWN(512, DH_); else FBBEV_DA_OWN(256, DH_); } while (0)   /* 1024 threads measured slower */

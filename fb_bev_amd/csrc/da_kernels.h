@@ -1141,6 +1141,8 @@ k_da_bwd_reduce(const float* __restrict__ part, int B, int Ncam, int S, int M, i
 //   k_da_bwd_hitlist   per (sample, query): camera count / depth weights (the table of k_da_bwd_hitinfo), append the query to the
 //                      list of every camera that sees it
 //   k_da_bwd_scatter_owned
+#define FBBEV_DA_HIT_ZA 4                                   // anchors a hit record holds
+#define FBBEV_DA_HIT_REC (2 + 3 * FBBEV_DA_HIT_ZA + 2)        // floats per record (64 bytes): q, cameras, dw[4], rx[4], ry[4], pad
 struct fbbev_da_bwd_region_tab { int n; unsigned int perm; int lvl0[24], lvl1[24], tok0[24], tok1[24], copies[24]; };
 
 __global__ void __launch_bounds__(256)
@@ -1153,8 +1155,8 @@ k_da_bwd_init(int n_count, int* __restrict__ hit_count, int n_max, unsigned int*
 __global__ void __launch_bounds__(256)
 k_da_bwd_hitlist(const int64_t* __restrict__ spatial_shapes, const float* __restrict__ pred_depth,
                  const float* __restrict__ ref_cam, const unsigned char* __restrict__ mask, const float* __restrict__ qdepth,
-                 int B, int Ncam, int Q, int Za, int DC, float d0, float dstep, int IS, float* __restrict__ info,
-                 int* __restrict__ hit_list, int* __restrict__ hit_count) {
+                 int B, int Ncam, int Q, int Za, int DC, float d0, float dstep, float* __restrict__ hit_rec,
+                 int* __restrict__ hit_count) {
     const int bps = (Q + 255) / 256;                                      // blocks per sample
     const int b = blockIdx.x / bps, lane = threadIdx.x & 63;
     const int qb = (blockIdx.x - b * bps) * 256, q = qb + (int)threadIdx.x;
@@ -1172,17 +1174,21 @@ k_da_bwd_hitlist(const int64_t* __restrict__ spatial_shapes, const float* __rest
     for (int cam = 0; cam < Ncam; ++cam) {
         const long long bn = (long long)b * Ncam + cam;
         bool hit = false;
+        float rec[FBBEV_DA_HIT_REC];
         if (live) {
             const long long base = (((long long)cam * B + b) * Q + q) * Za;
             for (int z = 0; z < Za; ++z) hit = hit || (mask[base + z] != 0);
-            float* dst = info + (bn * Q + q) * IS;
-            dst[0] = hit ? (float)(count > 1 ? count : 1) : 0.f;
             if (hit) {
+                __builtin_memcpy(&rec[0], &q, 4);
+                rec[1] = (float)(count > 1 ? count : 1);
+                for (int z = 0; z < FBBEV_DA_HIT_ZA; ++z) { rec[2 + z] = 0.f; rec[2 + FBBEV_DA_HIT_ZA + z] = 0.f; rec[2 + 2 * FBBEV_DA_HIT_ZA + z] = 0.f; }
                 for (int z = 0; z < Za; ++z) {
                     const float rx = ref_cam[(base + z) * 2], ry = ref_cam[(base + z) * 2 + 1];
                     float fb = floorf(__fdiv_rn(__fsub_rn(qdepth[base + z], d0), dstep));
                     fb = fminf(fmaxf(fb, 0.f), (float)(DC - 1));
-                    dst[1 + z] = fbbev_plane_sample(pred_depth + (bn * DC + (int)fb) * (long long)(H0 * W0), H0, W0, rx, ry);
+                    rec[2 + z] = fbbev_plane_sample(pred_depth + (bn * DC + (int)fb) * (long long)(H0 * W0), H0, W0, rx, ry);
+                    rec[2 + FBBEV_DA_HIT_ZA + z] = rx;
+                    rec[2 + 2 * FBBEV_DA_HIT_ZA + z] = ry;
                 }
             }
         }
@@ -1190,7 +1196,13 @@ k_da_bwd_hitlist(const int64_t* __restrict__ spatial_shapes, const float* __rest
         int wbase = 0;
         if (lane == 0 && bal) wbase = atomicAdd(hit_count + bn, __popcll(bal));
         wbase = __shfl(wbase, 0, 64);
-        if (hit) hit_list[bn * Q + wbase + __popcll(bal & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))))] = q;
+        if (hit) {
+            // the hit's record in LIST order: {query, cameras that see it, depth weight / reference x / y of the anchors} -- the scatter
+            // reads its hits as consecutive 64-byte records instead of chasing list -> query -> table / reference rows
+            float* dst = hit_rec + (bn * Q + wbase + __popcll(bal & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))))) * FBBEV_DA_HIT_REC;
+#pragma unroll
+            for (int k = 0; k < FBBEV_DA_HIT_REC; k += 4) *reinterpret_cast<fbbev_v4f*>(dst + k) = fbbev_v4f{rec[k], rec[k + 1], rec[k + 2], rec[k + 3]};
+        }
     }
 }
 
@@ -1202,8 +1214,8 @@ __global__ void __launch_bounds__(NT)
 k_da_bwd_scatter_owned(const int64_t* __restrict__ spatial_shapes, const int64_t* __restrict__ level_start,
                        const float* __restrict__ ref_cam, const float* __restrict__ offsets, const float* __restrict__ attn,
                        const float* __restrict__ grad_slots, int B, int Ncam, int S, int M, int L, int Q, int P, int Za,
-                       int head_minor, int HS, fbbev_da_bwd_region_tab tab, const float* __restrict__ info, int IS,
-                       const int* __restrict__ hit_list, const int* __restrict__ hit_count,
+                       int head_minor, int HS, fbbev_da_bwd_region_tab tab, const float* __restrict__ hit_rec,
+                       const int* __restrict__ hit_count,
                        const unsigned int* __restrict__ gmax_bits, int interleaved, float* __restrict__ grad_value) {
     const int pairs = B * Ncam;
     int r, pair, m;
@@ -1239,7 +1251,7 @@ k_da_bwd_scatter_owned(const int64_t* __restrict__ spatial_shapes, const int64_t
     }
     const long long bn = (long long)b * Ncam + cam;
     const int nh = (poisoned || sc == 0.f) ? 0 : hit_count[bn];
-    const int* list = hit_list + bn * Q;
+    const float* list = hit_rec + bn * (long long)Q * FBBEV_DA_HIT_REC;
     const int LP = L * P;
     const bool perm = (tab.perm >> r) & 1;
     __syncthreads();
@@ -1249,17 +1261,24 @@ k_da_bwd_scatter_owned(const int64_t* __restrict__ spatial_shapes, const int64_t
         const int nblk = nh - it0 < NT ? nh - it0 : NT;
         if ((int)threadIdx.x >= nblk) continue;
         const int it = it0 + (perm ? (int)(((unsigned)threadIdx.x * (nblk % 37 == 0 ? 41u : 37u)) % (unsigned)nblk) : (int)threadIdx.x);
-        const int q = list[it];
+        const float* rp = list + (long long)it * FBBEV_DA_HIT_REC;       // 64 bytes, 16-byte aligned
+        const fbbev_v4f r0 = *reinterpret_cast<const fbbev_v4f*>(rp), r1 = *reinterpret_cast<const fbbev_v4f*>(rp + 4);
+        const fbbev_v4f r2 = *reinterpret_cast<const fbbev_v4f*>(rp + 8), r3 = *reinterpret_cast<const fbbev_v4f*>(rp + 12);
+        const float q_bits = r0[0];
+        int q;
+        __builtin_memcpy(&q, &q_bits, 4);
+        const float inv = r0[1];
         const long long bq = (long long)b * Q + q;
         const long long u = bq * M + m;
-        const long long base = (((long long)cam * B + b) * Q + q) * Za;
-        const float* ip = info + (bn * Q + q) * IS;
-        const float inv = ip[0];
         float rx[FBBEV_DA_MAX_ZA], ry[FBBEV_DA_MAX_ZA], dw[FBBEV_DA_MAX_ZA];
-        for (int z = 0; z < Za; ++z) {
-            rx[z] = ref_cam[(base + z) * 2];
-            ry[z] = ref_cam[(base + z) * 2 + 1];
-            dw[z] = ip[1 + z];
+        {
+            const float rec[16] = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3], r2[0], r2[1], r2[2], r2[3], r3[0], r3[1], r3[2], r3[3]};
+#pragma unroll
+            for (int z = 0; z < FBBEV_DA_MAX_ZA; ++z) {
+                dw[z] = z < FBBEV_DA_HIT_ZA ? rec[2 + z] : 0.f;
+                rx[z] = z < FBBEV_DA_HIT_ZA ? rec[2 + FBBEV_DA_HIT_ZA + z] : 0.f;
+                ry[z] = z < FBBEV_DA_HIT_ZA ? rec[2 + 2 * FBBEV_DA_HIT_ZA + z] : 0.f;
+            }
         }
         float gs[DH];
 #pragma unroll

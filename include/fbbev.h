@@ -471,10 +471,10 @@ int fbbev_da_cross_attn_bwd(const float* value, const int64_t* spatial_shapes, c
  * ws == NULL, too small, or a rejected shape the call IS fbbev_da_cross_attn_bwd (same results up to the order of the
  * fp32 adds).
  * Round 4, OUTPUT-OWNED planes: when the launch has at least one workgroup per CU (token regions x B x Ncam x M >= 256;
- * FBBEV_DA_BWD_OWNED=1 / 0 forces / forbids it) step (B) is instead: per-(sample, camera) hit lists + the (camera, query)
- * table in `ws` (k_da_bwd_hitlist), then ONE launch in which a workgroup owns the plane of one (sample, camera, head,
+ * FBBEV_DA_BWD_OWNED=1 / 0 forces / forbids it) step (B) is instead: per-(sample, camera) lists of hit RECORDS (query, camera count,
+ * depth weights, reference points: 64 bytes, in list order) in `ws` (k_da_bwd_hitlist), then ONE launch in which a workgroup owns the plane of one (sample, camera, head,
  * token region), walks the camera's hit list and writes its tokens of grad_value directly -- no partial planes, no step
- * (C); `ws` shrinks from the partial planes (551 MB at the configs[2] pyramid) to table + lists (35 MB).  The fixed-point
+ * (C); `ws` shrinks from the partial planes (551 MB at the configs[2] pyramid) to the hit records (64 bytes per (camera, query): 61 MB).  The fixed-point
  * scale is then the call's max |grad_slots| (folded by kernel (A)): a non-finite upstream gradient makes the whole
  * grad_value NaN.  Same bits run to run; configs[2] pyramid, B = 4: 2.39 -> 1.18 ms. */
 size_t fbbev_da_cross_attn_bwd_ws_bytes(int B, int Ncam, int S, int M, int Dh, int Q, int head_stride,

@@ -801,8 +801,8 @@ def test_fused_da_cross_attention_backward_emulated():
                     sizes.append(E.lib().fbbev_da_cross_attn_bwd_ws_bytes(B_, Ncam_, vp.shape[1], vp.shape[2], Dh, Q_, HS,
                                                                           len(shapes_host), attn.shape[-1], harr))
                 os.environ['FBBEV_DA_BWD_OWNED'] = '1'
-                table = B_ * Ncam_ * Q_ * 8 * 4
-                assert table < sizes[0] <= table + B_ * Ncam_ * Q_ * 4 + 4 * 256 and sizes[1] > 0 and sizes[0] != sizes[1]
+                records = B_ * Ncam_ * Q_ * 16 * 4                       # 64-byte hit records in list order
+                assert records <= sizes[0] <= records + 4 * 256 + B_ * Ncam_ * vp.shape[1] * vp.shape[2] * Dh * 4 + 256 and sizes[1] > 0 and sizes[0] != sizes[1]
             if prepass == '1':
                 import ctypes
                 flat = [int(x) for hw in shapes_host for x in hw]

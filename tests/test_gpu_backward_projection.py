@@ -489,11 +489,11 @@ def test_output_owned_plane_backward_at_a_pyramid(dev):
         _capi.da_cross_attn_fwd_planes(planes, *args[1:9], 1.0, 0.5, s_pl, head_minor=1 | 4, bev_w=bw, min_level_width=22)
         err = (s_pl - s_rows).abs().max().item()
         assert not torch.isnan(s_pl).any() and err <= 1e-5 * max(1.0, s_rows.abs().max().item()), (bw, err)
-    # the owned route is planned: its workspace is the (camera, query) table + the hit lists, not partial planes
-    table, lists = B * Ncam * Q * 8 * 4, B * Ncam * Q * 4
+    # the owned route is planned: its workspace is the hit records (+ the planes), not partial planes
+    records = B * Ncam * Q * 16 * 4                                   # 64-byte hit records in list order
     need = _capi.da_cross_attn_bwd_ws_bytes(B, Ncam, S_, M, Dh, Q, HS, L, P, level_hw=shapes)
     planes = B * Ncam * M * S_ * Dh * 4                               # + the camera tokens as head planes for the unit gradients
-    assert table + lists + planes <= need <= table + lists + planes + 5 * 256, (need, table, lists, planes)
+    assert records + planes <= need <= records + planes + 5 * 256, (need, records, planes)
 
     def run(lds, bev_w=0):
         gv = torch.full_like(args[0], float('nan')) if lds else torch.zeros_like(args[0])      # the owned planes write every word
