@@ -1181,7 +1181,7 @@ k_da_bwd_hitlist(const int64_t* __restrict__ spatial_shapes, const float* __rest
             if (hit) {
                 __builtin_memcpy(&rec[0], &q, 4);
                 rec[1] = (float)(count > 1 ? count : 1);
-                for (int z = 0; z < FBBEV_DA_HIT_ZA; ++z) { rec[2 + z] = 0.f; rec[2 + FBBEV_DA_HIT_ZA + z] = 0.f; rec[2 + 2 * FBBEV_DA_HIT_ZA + z] = 0.f; }
+                for (int k = 2; k < FBBEV_DA_HIT_REC; ++k) rec[k] = 0.f;        // anchors beyond Za and the two pad words
                 for (int z = 0; z < Za; ++z) {
                     const float rx = ref_cam[(base + z) * 2], ry = ref_cam[(base + z) * 2 + 1];
                     float fb = floorf(__fdiv_rn(__fsub_rn(qdepth[base + z], d0), dstep));
