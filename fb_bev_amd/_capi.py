@@ -68,6 +68,9 @@ SIGNATURES = {
     'fbbev_da_cross_attn_fused_supported': (c_int, [c_int] * 10),
     'fbbev_da_cross_attn_fused': (c_int, [c_void_p] * 8 + [c_int64, c_void_p, c_int64, c_int64] + [c_void_p] * 4 + [c_int] * 10 +
                                   [c_float, c_float, c_int, c_int, c_void_p, c_void_p]),
+    'fbbev_da_cross_attn_fused_ln': (c_int, [c_void_p] * 8 + [c_int64, c_void_p, c_int64, c_int64] + [c_void_p] * 4 +
+                                     [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_float] + [c_int] * 10 +
+                                     [c_float, c_float, c_int, c_int, c_void_p, c_void_p]),
     'fbbev_rows_to_head_planes': (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
     'fbbev_msda_self_fused_supported': (c_int, [c_int] * 8),
     'fbbev_msda_self_fused': (c_int, [c_void_p] * 3 + [c_int64, c_void_p, c_int64, c_int64] + [c_void_p] * 4 + [c_int] * 10 +
@@ -968,7 +971,7 @@ def da_cross_attn_fused_supported(B, Ncam, S, M, Dh, L, Q, P, Za, bev_w):
 
 def da_cross_attn_fused(planes, spatial_shapes, level_start_index, pred_depth, ref_cam, mask, qdepth, query, addend,
                         offsets_fragments, offsets_bias, attn_fragments, attn_bias, num_points, d0, dstep, bev_w, min_level_width,
-                        slots):
+                        slots, out_proj=None):
     """fbbev_da_cross_attn_fused: planes (B*Ncam, M, S, Dh) head-plane camera tokens; query (B, Q, E) rows [+ addend (P_, E) rows with
     B*Q % P_ == 0, e.g. the (Q, E) positional table]; fragments / biases of sampling_offsets and attention_weights in the module's
     row order (rows_linear_x3_fragments); slots (B, Q, E) written.  min_level_width: host value of the narrowest level's width."""
@@ -988,6 +991,21 @@ def da_cross_attn_fused(planes, spatial_shapes, level_start_index, pred_depth, r
         if addend.dim() != 2 or addend.shape[1] != E or addend.stride(1) != 1 or (B * Q) % addend.shape[0] != 0:
             raise FbbevError('da_cross_attn_fused: addend must be (P, E) rows with B*Q % P == 0')
         a_ptr, a_ld, a_per = _dev(addend, F32, 'addend', contiguous=False), addend.stride(0), addend.shape[0]
+    if out_proj is not None:      # (fragments, bias, residual (B, Q, E) or None, ln_weight, ln_bias, eps): the block's tail in the same workgroups
+        wf, wb, res, lnw, lnb, eps = out_proj
+        if res is not None and (tuple(res.shape) != (B, Q, E) or not res.is_contiguous()):
+            raise FbbevError('da_cross_attn_fused: residual must be contiguous (B, Q, E)')
+        with _on(planes):
+            _check(lib().fbbev_da_cross_attn_fused_ln(
+                _dev(planes, F32, 'planes'), _dev(spatial_shapes, I64, 'spatial_shapes'), _dev(level_start_index, I64, 'level_start_index'),
+                _dev(pred_depth, F32, 'pred_depth'), _dev(ref_cam, F32, 'ref_cam'), _dev(mask, torch.uint8, 'mask'),
+                _dev(qdepth, F32, 'qdepth'), _dev(query, F32, 'query', contiguous=False), query.stride(1), a_ptr, a_ld, a_per,
+                offsets_fragments.data_ptr(), _dev(offsets_bias, F32, 'offsets_bias'), attn_fragments.data_ptr(),
+                _dev(attn_bias, F32, 'attn_bias'), wf.data_ptr(), _dev(wb, F32, 'out_bias'),
+                None if res is None else _dev(res, F32, 'residual'), E, _dev(lnw, F32, 'ln_weight'), _dev(lnb, F32, 'ln_bias'), float(eps),
+                B, Ncam, S, M, Dh, L, Q, int(num_points), Za, DC, float(d0), float(dstep), int(bev_w), int(min_level_width),
+                _dev(slots, F32, 'out'), _stream()), 'fbbev_da_cross_attn_fused_ln')
+        return slots
     with _on(planes):
         _check(lib().fbbev_da_cross_attn_fused(
             _dev(planes, F32, 'planes'), _dev(spatial_shapes, I64, 'spatial_shapes'), _dev(level_start_index, I64, 'level_start_index'),

@@ -505,6 +505,7 @@ import os as _os
 FUSE_FFN = _os.environ.get('FBBEV_FUSE_FFN', '1') != '0'               # the FFN pair as one kernel (fbbev_rows_ffn_x3; A/B knob)
 FUSE_OUT_NORM = _os.environ.get('FBBEV_FUSE_OUT_NORM', '1') != '0'     # output_proj / FFN tail + residual + LayerNorm in one kernel (A/B knob)
 FUSE_ATTN_TAIL = _os.environ.get('FBBEV_FUSE_ATTN_TAIL', '1') != '0'   # ... inside the attention kernel's own workgroups (A/B knob)
+FUSE_ATTN_TAIL_DA = _os.environ.get('FBBEV_FUSE_ATTN_TAIL_DA', '0') != '0'   # the same for the cross-attention (needs its 8-heads-per-workgroup form)
 FUSED_BWD_MAX_HEAD_DIM = 32                 # k_da_cross_attn_bwd: one lane per channel, groups of 16 / 32 lanes
 
 
@@ -530,7 +531,7 @@ class DA_SpatialCrossAttention(nn.Module):
 
     # ---- inference: one fused HIP launch (fbbev_da_cross_attn_fwd), no host sync
     def _slots_fused(self, query, value, reference_points_cam, mask, bev_query_depth, pred_img_depth,
-                     spatial_shapes, level_start_index, bev_w=0, query_pos=None):
+                     spatial_shapes, level_start_index, bev_w=0, query_pos=None, _tail=None):
         da = self.deformable_attention
         B, Q, E = query.shape
         ncam, S, _, _ = value.shape
@@ -588,7 +589,7 @@ class DA_SpatialCrossAttention(nn.Module):
             B, ncam, S, M, Dh, da.num_levels, Q, da.num_points, reference_points_cam.shape[3], hm, HS)
         if zt and not da.disable_deformable:
             slots = self._slots_one_kernel(da, x, query, query_pos, reference_points_cam, mask, bev_query_depth, pred_img_depth,
-                                           spatial_shapes, level_start_index, bev_w)
+                                           spatial_shapes, level_start_index, bev_w, _tail=_tail)
             if slots is not None:
                 return slots
         so, aw = da.project_head_minor(query, softmax=not fuse_sm, addend=query_pos)
@@ -624,7 +625,7 @@ class DA_SpatialCrossAttention(nn.Module):
 
     # ---- inference default since round 4: query rows -> slots in ONE kernel (fbbev_da_cross_attn_fused, da_fused_kernels.h)
     def _slots_one_kernel(self, da, x, query, query_pos, reference_points_cam, mask, bev_query_depth, pred_img_depth,
-                          spatial_shapes, level_start_index, bev_w):
+                          spatial_shapes, level_start_index, bev_w, _tail=None):
         """value_proj writes the camera tokens as head planes (fbbev_rows_linear_x3_planes); the sampling_offsets / attention_weights
         projections, the softmax and the sampling run inside one kernel from the query rows (+ positional rows): no offsets /
         weights tensors (492 MB written and re-read at BASELINE configs[2], B = 4).  None when the shape is not the kernel's
@@ -656,7 +657,14 @@ class DA_SpatialCrossAttention(nn.Module):
             planes, spatial_shapes.to(torch.int64).contiguous(), level_start_index.to(torch.int64).contiguous(),
             pred_img_depth.reshape(BN, DC, H0, W0).contiguous().float(), reference_points_cam.contiguous().float(), mask.contiguous(),
             bev_query_depth.squeeze(-1).contiguous().float(), query, addend, so.frag, so.b, aw.frag, aw.b, P, self.dbound[0],
-            self.dbound[2], bev_w, min(int(w) for _, w in hw), slots)
+            self.dbound[2], bev_w, min(int(w) for _, w in hw), slots, out_proj=self._take_tail(_tail))
+
+    @staticmethod
+    def _take_tail(tail):
+        if tail is None:
+            return None
+        tail['done'] = True
+        return tail['spec']
 
     # ---- training: vectorised rebatch + composite deformable attention (autograd through the MSDA op)
     def _slots_composite(self, query, value, reference_points_cam, mask, bev_query_depth, pred_img_depth,
@@ -719,10 +727,22 @@ class DA_SpatialCrossAttention(nn.Module):
         if fold_pos and fn != self._slots_fused:             # (cannot happen without autograd; kept for safety)
             query, fold_pos = query + query_pos, False
         kw = dict(query_pos=query_pos) if fold_pos else {}
+        tail_ok = (_norm is not None and _defer_residual and self.layer_scale is None and not torch.is_grad_enabled()
+                   and not (self.training and self.dropout.p > 0))
+        tail = None
+        if (tail_ok and FUSE_ATTN_TAIL_DA and fn == self._slots_fused and self.embed_dims % 16 == 0
+                and _RL.ln_fusable(_norm, inp_residual.contiguous(), query, self.embed_dims)):
+            # output_proj + residual + LayerNorm inside the sampler's (8-head) workgroups: fbbev_da_cross_attn_fused_ln (opt-in)
+            if not hasattr(self.output_proj, '_x3'):
+                self.output_proj._x3 = X3Weights()
+            oc = self.output_proj._x3.get(self.output_proj.weight, self.output_proj.bias)
+            tail = {'spec': (oc.frag, oc.b, inp_residual.contiguous(), _norm.weight, _norm.bias, _norm.eps), 'done': False}
+            kw['_tail'] = tail
         slots = fn(query, value, reference_points_cam, mask, bev_query_depth, pred_img_depth, spatial_shapes,
                    level_start_index, bev_w=bev_w or 0, **kw)  # the BEV row length lets the sampler own 2-D patches of queries
-        if (_norm is not None and _defer_residual and self.layer_scale is None and not torch.is_grad_enabled()
-                and not (self.training and self.dropout.p > 0)):
+        if tail is not None and tail['done']:
+            return slots, _NORMED
+        if tail_ok:
             # output_proj + residual + the layer's following LayerNorm in one kernel (fbbev_rows_linear_x3_ln)
             return self.output_proj(slots, ln=(inp_residual.contiguous(), _norm)), _NORMED
         slots = self.output_proj(slots)

@@ -1371,13 +1371,13 @@ extern "C" int fbbev_da_cross_attn_fused_supported(int B, int Ncam, int S, int M
     static const bool off = [] { const char* e = getenv("FBBEV_DA_FUSED"); return e && atoi(e) == 0; }();   // A/B timing knob, read once
     return (!off && da_fused_shape_ok(B, Ncam, S, M, Dh, L, Q, P, Za, bev_w)) ? 1 : 0;
 }
-extern "C" int fbbev_da_cross_attn_fused(const float* planes, const int64_t* spatial_shapes, const int64_t* level_start_index,
-                                         const float* pred_depth, const float* ref_cam, const uint8_t* mask, const float* qdepth,
-                                         const float* query, long long query_row_stride, const float* addend,
-                                         long long addend_row_stride, long long addend_period, const void* offsets_fragments,
-                                         const float* offsets_bias, const void* attn_fragments, const float* attn_bias, int B,
-                                         int Ncam, int S, int M, int Dh, int L, int Q, int P, int Za, int DC, float d0, float dstep,
-                                         int bev_w, int min_level_width, float* slots, fbbev_stream_t stream_) {
+static int da_cross_attn_fused_impl(const float* planes, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                    const float* pred_depth, const float* ref_cam, const uint8_t* mask, const float* qdepth,
+                                    const float* query, long long query_row_stride, const float* addend,
+                                    long long addend_row_stride, long long addend_period, const void* offsets_fragments,
+                                    const float* offsets_bias, const void* attn_fragments, const float* attn_bias, int B,
+                                    int Ncam, int S, int M, int Dh, int L, int Q, int P, int Za, int DC, float d0, float dstep,
+                                    int bev_w, int min_level_width, float* slots, fbbev_stream_t stream_, fbbev_daf_outproj op) {
     if (B <= 0 || Ncam <= 0 || S <= 0 || M <= 0 || Dh <= 0 || L <= 0 || Q < 0 || P <= 0 || Za <= 0 || DC <= 0 || bev_w < 0)
         return FBBEV_E_BADARG;
     if (Q == 0) return 0;
@@ -1401,26 +1401,30 @@ extern "C" int fbbev_da_cross_attn_fused(const float* planes, const int64_t* spa
     // samples), 8 = one 512-thread workgroup per patch (FBBEV_DA_FUSED_HW, read once)
     auto read_hw = [] { const char* e = getenv("FBBEV_DA_FUSED_HW"); const int v = e ? atoi(e) : 4; return v == 8 ? 8 : 4; };
 #ifdef FBBEV_TEST_OVERRIDES   // CPU emulator build: the tests run both forms inside one process
-    const int hw = read_hw();
+    const int hw_env = read_hw();
 #else
-    static const int hw = read_hw();
+    static const int hw_env = read_hw();
 #endif
+    const int hw = op.w_frag ? 8 : hw_env;                  // the output_proj + LayerNorm tail needs all 8 heads of a query in one workgroup
     const long long wgs = (long long)B * ((bev_w + 7) / 8) * ((Q / bev_w + 7) / 8) * (8 / hw);
     const long long grid = (wgs + 7) / 8 * 8;
     if (grid >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
     const size_t lds = fbbev_daf_lds_bytes(E, hw, Ncam);
-#define FBBEV_DA_FUSED(DH_, NP_, HW_)                                                                                  \
+#define FBBEV_DA_FUSED(DH_, NP_, HW_) FBBEV_DA_FUSED2(DH_, NP_, HW_, false)
+#define FBBEV_DA_FUSED2(DH_, NP_, HW_, OP_)                                                                            \
     do {                                                                                                               \
-        int e = fbbev_rt_allow_dyn_lds((const void*)k_da_cross_attn_fused<DH_, 8, NP_, HW_>, lds);                    \
+        int e = fbbev_rt_allow_dyn_lds((const void*)k_da_cross_attn_fused<DH_, 8, NP_, HW_, OP_>, lds);               \
         if (e) return e;                                                                                               \
-        FBBEV_LAUNCH((k_da_cross_attn_fused<DH_, 8, NP_, HW_>), grid, 64 * HW_, lds, (fbbev_rt_stream)stream_, planes, spatial_shapes, \
+        FBBEV_LAUNCH((k_da_cross_attn_fused<DH_, 8, NP_, HW_, OP_>), grid, 64 * HW_, lds, (fbbev_rt_stream)stream_, planes, spatial_shapes, \
                      level_start_index, pred_depth, ref_cam, mask, qdepth, query, query_row_stride, addend,           \
                      addend_row_stride, addend_period, static_cast<const unsigned short*>(offsets_fragments),         \
                      offsets_bias, static_cast<const unsigned short*>(attn_fragments), attn_bias, B, Ncam, S, L, Q,    \
-                     bev_w, DC, d0, dstep, slots);                                                                     \
+                     bev_w, DC, d0, dstep, slots, op);                                                                 \
     } while (0)
     static const int np = [] { const char* e = getenv("FBBEV_DA_FUSED_NP"); return e ? atoi(e) : 2; }();   // samples in flight per lane (tuning knob, read once)
-    if (hw == 8) {
+    if (op.w_frag) {
+        if (Dh == 10) FBBEV_DA_FUSED2(10, 2, 8, true); else FBBEV_DA_FUSED2(8, 2, 8, true);
+    } else if (hw == 8) {
         if (Dh == 10) { if (np == 3) FBBEV_DA_FUSED(10, 3, 8); else FBBEV_DA_FUSED(10, 2, 8); }
         else { if (np == 3) FBBEV_DA_FUSED(8, 3, 8); else FBBEV_DA_FUSED(8, 2, 8); }
     } else {
@@ -1428,8 +1432,45 @@ extern "C" int fbbev_da_cross_attn_fused(const float* planes, const int64_t* spa
         else { if (np == 3) FBBEV_DA_FUSED(8, 3, 4); else FBBEV_DA_FUSED(8, 2, 4); }
     }
 #undef FBBEV_DA_FUSED
+#undef FBBEV_DA_FUSED2
     FBBEV_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int fbbev_da_cross_attn_fused(const float* planes, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                         const float* pred_depth, const float* ref_cam, const uint8_t* mask, const float* qdepth,
+                                         const float* query, long long query_row_stride, const float* addend,
+                                         long long addend_row_stride, long long addend_period, const void* offsets_fragments,
+                                         const float* offsets_bias, const void* attn_fragments, const float* attn_bias, int B,
+                                         int Ncam, int S, int M, int Dh, int L, int Q, int P, int Za, int DC, float d0, float dstep,
+                                         int bev_w, int min_level_width, float* slots, fbbev_stream_t stream_) {
+    return da_cross_attn_fused_impl(planes, spatial_shapes, level_start_index, pred_depth, ref_cam, mask, qdepth, query,
+                                    query_row_stride, addend, addend_row_stride, addend_period, offsets_fragments, offsets_bias,
+                                    attn_fragments, attn_bias, B, Ncam, S, M, Dh, L, Q, P, Za, DC, d0, dstep, bev_w, min_level_width,
+                                    slots, stream_, fbbev_daf_outproj{nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0.f});
+}
+// ... followed, inside the same workgroups (8 heads per workgroup), by output_proj + residual + LayerNorm: out rows instead of slots
+extern "C" int fbbev_da_cross_attn_fused_ln(const float* planes, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                            const float* pred_depth, const float* ref_cam, const uint8_t* mask, const float* qdepth,
+                                            const float* query, long long query_row_stride, const float* addend,
+                                            long long addend_row_stride, long long addend_period, const void* offsets_fragments,
+                                            const float* offsets_bias, const void* attn_fragments, const float* attn_bias,
+                                            const void* out_fragments, const float* out_bias, const float* residual,
+                                            long long residual_row_stride, const float* ln_weight, const float* ln_bias, float ln_eps,
+                                            int B, int Ncam, int S, int M, int Dh, int L, int Q, int P, int Za, int DC, float d0,
+                                            float dstep, int bev_w, int min_level_width, float* out, fbbev_stream_t stream_) {
+    if (!out_fragments || !out_bias || !ln_weight || !ln_bias || !(ln_eps >= 0.f) || M <= 0 || Dh <= 0) return FBBEV_E_BADARG;
+    const int E = M * Dh;
+    if (residual && residual_row_stride == 0) residual_row_stride = E;
+    if (residual && residual_row_stride < E) return FBBEV_E_BADARG;
+    if (E % 16 != 0 || !aligned16(out_fragments) || !aligned16(out_bias) || !aligned16(ln_weight) || !aligned16(ln_bias) ||
+        !aligned16(out) || (residual && (!aligned16(residual) || residual_row_stride % 4 != 0))) return FBBEV_E_UNSUPPORTED;
+    return da_cross_attn_fused_impl(planes, spatial_shapes, level_start_index, pred_depth, ref_cam, mask, qdepth, query,
+                                    query_row_stride, addend, addend_row_stride, addend_period, offsets_fragments, offsets_bias,
+                                    attn_fragments, attn_bias, B, Ncam, S, M, Dh, L, Q, P, Za, DC, d0, dstep, bev_w, min_level_width,
+                                    out, stream_,
+                                    fbbev_daf_outproj{static_cast<const unsigned short*>(out_fragments), out_bias, residual,
+                                                      residual_row_stride, ln_weight, ln_bias, ln_eps});
 }
 
 // ---- Z-mean / Z-sum of a materialised (B*C, Z, Y*X) volume (training path; k_volume_zreduce)

@@ -246,7 +246,7 @@ __device__ __forceinline__ void fbbev_daf_outproj_ln(const fbbev_daf_outproj& op
 // query (B*Q rows, ldq floats apart, E used) [+ addend rows: row (b*Q + q) % add_period]; so_frag / aw_frag: split bf16 fragments of
 // sampling_offsets.weight (M*L*P*2, E) / attention_weights.weight (M*L*P, E) in the order of k_rows_linear_x3_fragments, rows in
 // the MODULE's order ((m, l, p, xy) / (m, l, p)); so_bias / aw_bias fp32; slots (B, Q, M*DH).  blockDim = 64 * M.
-template <int DH, int MH, int NP, int HW>
+template <int DH, int MH, int NP, int HW, bool OP = false>
 __global__ void __launch_bounds__(64 * HW)
 k_da_cross_attn_fused(const float* __restrict__ planes, const int64_t* __restrict__ spatial_shapes,
                       const int64_t* __restrict__ level_start, const float* __restrict__ pred_depth,
@@ -255,8 +255,10 @@ k_da_cross_attn_fused(const float* __restrict__ planes, const int64_t* __restric
                       const float* __restrict__ addend, long long ld_add, long long add_period,
                       const unsigned short* __restrict__ so_frag, const float* __restrict__ so_bias,
                       const unsigned short* __restrict__ aw_frag, const float* __restrict__ aw_bias,
-                      int B, int Ncam, int S, int L, int Q, int bev_w, int DC, float d0, float dstep, float* __restrict__ slots) {
+                      int B, int Ncam, int S, int L, int Q, int bev_w, int DC, float d0, float dstep, float* __restrict__ slots,
+                      fbbev_daf_outproj op) {
     constexpr int E = MH * DH, KS = (E + 31) / 32, P = FBBEV_DAF_P, ZA = FBBEV_DAF_ZA, NT = 64 * HW, PARTS = MH / HW;
+    static_assert(!OP || (HW == MH && E % 16 == 0), "the output_proj + LayerNorm tail needs all heads of a query in one workgroup");
     static_assert((2 * DH) % 4 == 0 && DH % 2 == 0 && E % 8 == 0, "runs of whole 16-byte pieces, channel pairs");
     static_assert(NP >= 2 && NP <= FBBEV_DAF_P, "samples in flight per lane");
     static_assert(MH % HW == 0 && P == 8, "a workgroup takes HW of the MH heads; a level's 8 logits are half an MFMA tile");
@@ -454,14 +456,29 @@ k_da_cross_attn_fused(const float* __restrict__ planes, const int64_t* __restric
 #pragma unroll
             for (int p = 0; p < P; ++p) lg[k][p] = lg[k + 1][p];
     }
-    if (!valid) return;
     const float inv = (float)(count > 1 ? count : 1);
-    float* dst = slots + bq * E + m * DH;
+    if constexpr (OP) {
+        // the block's tail in the workgroup (see fbbev_daf_outproj): slots -> output_proj + residual + LayerNorm, rows to `slots`
 #pragma unroll
-    for (int c = 0; c < DH / 2; ++c) {
-        fbbev_v2f r;
-        r[0] = acc[c][0] / inv; r[1] = acc[c][1] / inv;
-        *reinterpret_cast<fbbev_v2f*>(dst + 2 * c) = r;
+        for (int c = 0; c < DH / 2; ++c) { acc[c][0] = acc[c][0] / inv; acc[c][1] = acc[c][1] / inv; }
+        __syncthreads();                                                // every wave is done with the query fragments
+        fbbev_daf_put_channels<DH, KS>(xf, m, lane, acc);
+        __syncthreads();
+        if (wv < 4) {
+            const int ql = 16 * wv + (lane & 15);
+            const int ry = y0 + (ql >> 3), rx = x0 + (ql & 7);
+            const bool live = ry < bev_h && rx < bev_w;
+            fbbev_daf_outproj_ln<KS, E / 16>(op, xf, wv, lane, (long long)b * Q + (live ? (long long)ry * bev_w + rx : 0), live, slots, E);
+        }
+    } else {
+        if (!valid) return;
+        float* dst = slots + bq * E + m * DH;
+#pragma unroll
+        for (int c = 0; c < DH / 2; ++c) {
+            fbbev_v2f r;
+            r[0] = acc[c][0] / inv; r[1] = acc[c][1] / inv;
+            *reinterpret_cast<fbbev_v2f*>(dst + 2 * c) = r;
+        }
     }
 }
 

@@ -414,6 +414,18 @@ int fbbev_da_cross_attn_fused(const float* planes, const int64_t* spatial_shapes
                               const float* offsets_bias, const void* attn_fragments, const float* attn_bias, int B,
                               int Ncam, int S, int M, int Dh, int L, int Q, int P, int Za, int DC, float d0, float dstep,
                               int bev_w, int min_level_width, float* slots, fbbev_stream_t stream);
+/* fbbev_da_cross_attn_fused followed, inside the same workgroups (all 8 heads of a patch in one 512-thread workgroup), by the block's
+ * tail: out = LayerNorm(output_proj(slots) + residual) (spatial_cross_attention_depth.py:223-226 + the layer's norm).  The arguments of
+ * fbbev_msda_self_fused_ln; M*Dh % 16 == 0. */
+int fbbev_da_cross_attn_fused_ln(const float* planes, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                 const float* pred_depth, const float* ref_cam, const uint8_t* mask, const float* qdepth,
+                                 const float* query, long long query_row_stride, const float* addend, long long addend_row_stride,
+                                 long long addend_period, const void* offsets_fragments, const float* offsets_bias,
+                                 const void* attn_fragments, const float* attn_bias, const void* out_fragments, const float* out_bias,
+                                 const float* residual, long long residual_row_stride, const float* ln_weight, const float* ln_bias,
+                                 float ln_eps, int B, int Ncam, int S, int M, int Dh, int L, int Q, int P, int Za, int DC, float d0,
+                                 float dstep, int bev_w, int min_level_width, float* out, fbbev_stream_t stream);
+
 /* The BEV self-attention of the encoder layer in ONE kernel, from the query rows to the attention output (before output_proj):
  * mmcv MultiScaleDeformableAttention.forward as bevformer_encoder.py:327-341 calls it -- sampling_offsets / attention_weights
  * Linears (split-operand bf16 MFMA inside the kernel, fragments of the MODULE-ordered weights), softmax over the head's points,

@@ -354,7 +354,7 @@ def rows_to_head_planes(rows, tokens_per_image, heads, head_dim):
 
 
 def da_cross_attn_fused(planes, ss, ls, pred_depth, ref_cam, mask, qdepth, query, addend, w_so, b_so, w_aw, b_aw, P, d0, dstep, bev_w,
-                        min_level_width=None):
+                        min_level_width=None, out_proj=None):
     Ncam, B, Q, Za = mask.shape
     BN, M, S, Dh = planes.shape
     L = ss.shape[0]
@@ -365,6 +365,14 @@ def da_cross_attn_fused(planes, ss, ls, pred_depth, ref_cam, mask, qdepth, query
     if min_level_width is None:
         min_level_width = int(ss[:, 1].min())
     a = (c_void_p(addend.data_ptr()), addend.stride(0), addend.shape[0]) if addend is not None else (None, 0, 1)
+    if out_proj is not None:      # (weight, bias, residual or None, ln_weight, ln_bias, eps): fbbev_da_cross_attn_fused_ln
+        wo, bo, res, lnw, lnb, eps = out_proj
+        f_o, p_o = _fragments(wo)
+        code = lib().fbbev_da_cross_attn_fused_ln(p(planes), p(ss), p(ls), p(pred_depth), p(ref_cam), p(m8), p(qdepth), p(query),
+                                                  query.stride(1), *a, p_so, p(b_so), p_aw, p(b_aw), p_o, p(bo),
+                                                  None if res is None else p(res), M * Dh, p(lnw), p(lnb), eps, B, Ncam, S, M, Dh, L, Q, P,
+                                                  Za, pred_depth.shape[1], d0, dstep, bev_w, min_level_width, p(slots), None)
+        return code, slots
     code = lib().fbbev_da_cross_attn_fused(p(planes), p(ss), p(ls), p(pred_depth), p(ref_cam), p(m8), p(qdepth), p(query),
                                            query.stride(1), *a, p_so, p(b_so), p_aw, p(b_aw), B, Ncam, S, M, Dh, L, Q, P, Za,
                                            pred_depth.shape[1], d0, dstep, bev_w, min_level_width, p(slots), None)

@@ -1401,6 +1401,20 @@ def test_one_kernel_da_cross_attention_emulated():
                 both.append(slots)
             assert torch.equal(both[0], both[1]), seed                        # the same per-wave arithmetic: the same bits
             assert not torch.isnan(slots).any(), seed
+            if with_pos:      # fbbev_da_cross_attn_fused_ln: LayerNorm(output_proj(slots) + residual) in the same (8-head) workgroups
+                import torch.nn.functional as F
+                gg = torch.Generator().manual_seed(seed)
+                Em = slots.shape[-1]
+                w_o, b_o = torch.randn(Em, Em, generator=gg) * 0.2, torch.randn(Em, generator=gg) * 0.1
+                lnw, lnb = torch.rand(Em, generator=gg) + 0.5, torch.randn(Em, generator=gg) * 0.1
+                res = ex['query'].contiguous()
+                code, y = E.da_cross_attn_fused(planes, ss, ls, pred, ref_cam, mask, qdepth, q, add,
+                                                Pm[pre + 'sampling_offsets.weight'].contiguous(), Pm[pre + 'sampling_offsets.bias'].contiguous(),
+                                                Pm[pre + 'attention_weights.weight'].contiguous(), Pm[pre + 'attention_weights.bias'].contiguous(),
+                                                8, d0, dstep, bev_w, out_proj=(w_o, b_o, res, lnw, lnb, 1e-5))
+                assert code == 0 and not torch.isnan(y).any()
+                want = F.layer_norm(F.linear(slots, w_o, b_o) + res, (Em,), lnw, lnb, 1e-5)
+                assert (y - want).abs().max().item() <= 2e-4, (seed, (y - want).abs().max().item())
             scale = exp.abs().max().item()
             assert (slots - exp).abs().max().item() <= 1e-4 * max(scale, 1.0), (seed, with_pos, (slots - exp).abs().max().item(), scale)
             assert (slots - unit).abs().max().item() <= 1e-4 * max(scale, 1.0), (seed, (slots - unit).abs().max().item())
