@@ -1610,3 +1610,35 @@ def test_volume_z_reductions_emulated():
     assert L.fbbev_volume_zreduce(E.p(odd), 1, 6, 9, ctypes.c_float(6.0), E.p(o), None) < 0 and torch.isnan(o).all()
     assert L.fbbev_volume_zreduce_inner(E.p(odd), 9, 6, ctypes.c_float(1.0), E.p(o), None) < 0
     assert L.fbbev_volume_z_to_front(E.p(odd), 1, 6, 9, E.p(torch.empty(1, 1, 6, 3, 3)), None) < 0
+
+
+def test_owned_plane_scatter_xcd_mapping_emulated():
+    """k_da_bwd_scatter_owned decodes blockIdx -> (region, sample, camera, head) in two ways: plainly, and -- when the number of
+    (sample, camera) pairs divides by 8 -- so that the workgroups of one pair share an XCD.  The second form is the one the configs[2]
+    training shape (B = 4, 6 cameras: 24 pairs) takes; 2 samples x 4 cameras = 8 pairs here.  Owned route (bands + whole levels, 1 and several copies) against the
+    chunked route on the same inputs: the same value gradient up to the planes' scales, every word written."""
+    import os
+    args, exp = _da_case(41, B=2, N=4, Q=37, E=80, M=8, P=8, DC=12, shapes=((6, 9), (3, 4)))
+    value, ss, ls, pred, ref_cam, mask, qdepth, offsets, attn, d0, dstep = args
+    g = torch.randn(exp.shape, generator=torch.Generator().manual_seed(41))
+    shapes_host = [tuple(int(x) for x in hw) for hw in ss.tolist()]
+    Dh = value.shape[-1]
+    vp = torch.zeros(value.shape[:-1] + (12,)); vp[..., :Dh] = value
+    got = {}
+    for route, tokens in (('1', None), ('1', '20'), ('0', None)):
+        os.environ['FBBEV_DA_BWD_OWNED'] = route
+        os.environ['FBBEV_DA_BWD_CHUNKS'] = '2'
+        os.environ['FBBEV_DA_BWD_THREADS'] = '256'
+        if tokens:
+            os.environ['FBBEV_DA_BWD_TOKENS'] = tokens
+        try:
+            got[(route, tokens)] = E.da_cross_attn_bwd(vp, ss, ls, pred, ref_cam, mask, qdepth, offsets, attn, d0, dstep, g, head_minor=0,
+                                                       head_dim=Dh, lds_planes=True, level_hw=shapes_host)
+        finally:
+            for k in ('FBBEV_DA_BWD_OWNED', 'FBBEV_DA_BWD_CHUNKS', 'FBBEV_DA_BWD_THREADS', 'FBBEV_DA_BWD_TOKENS'):
+                os.environ.pop(k, None)
+    base = got[('0', None)]
+    for key in (('1', None), ('1', '20')):
+        for x, y in zip(got[key], base):
+            assert not torch.isnan(x).any()
+            assert torch.allclose(x, y, rtol=1e-5, atol=1e-6), (key, (x - y).abs().max())
