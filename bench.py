@@ -63,6 +63,9 @@ def parse():
                          'one by one; auto (default) = whichever ran the warm-up steps faster.  The pooling kernel is always '
                          'launched eagerly between the HIP events that time it')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
+    ap.add_argument('--no-fb-projection', action='store_true',
+                    help='forward mode, N=1: skip the extra `fb_projection` leg (BASELINE configs[2]: forward + backward projection)')
+    ap.add_argument('--fb-steps', type=int, default=50, help='timed steps of the fb_projection leg')
     ap.add_argument('--mode', choices=['forward', 'train'], default='forward')
     ap.add_argument('--sync-bn', action='store_true', help="train mode: cross-rank statistics for the config's SyncBN layers "
                     '(SURVEY 8e: off for the headline, the delta is reported separately)')
@@ -202,6 +205,198 @@ def cpu_baseline_c(cfg, seconds):
     return {'value': n / dt, 'unit': 'samples/s', 'cores': int(os.environ.get('OMP_NUM_THREADS', os.cpu_count() or 1)),
             'kind': 'port', 'sample': f'{n} x 1-sample {cfg.name} passes in {dt:.1f}s; pooling = loop-exact C oracle with OpenMP over '
                                       f'intervals, geometry + ranking = torch CPU ops on {torch.get_num_threads()} threads'}
+
+
+def cpu_baseline_fb(pc, levels, state, gcb, dbound, mlvl_shapes, seconds):
+    """CPU baseline of the forward + backward projection scope (S3 of SURVEY 8d, BASELINE configs[2]): the oracle restatement
+    on this host's cores, one sample per pass -- forward projection (torch CPU ops: geometry, argsort ranking, index_add
+    pooling), Z-mean, oracle/backward_projection_oracle.py (BackwardProjection.forward restated: self-attention, depth-aware
+    deformable cross-attention with its per-camera rebatch loops, FFN, LayerNorms) and the re-add."""
+    import torch
+    from fb_bev_amd import synthetic as S
+    from oracle import backward_projection_oracle as BO, oracle as O
+    ncpu = os.cpu_count() or 1
+    torch.set_num_threads(min(32, ncpu))
+    ovt = O.ViewTransformerOracle(pc.grid_config, pc.input_size, pc.downsample)
+    cam = S.camera_rig(pc, 1, seed=0, bda_aug=True)
+    depth, ctx = S.depth_and_context(pc, 1, seed=0)
+    g = torch.Generator().manual_seed(5)
+    feats = [torch.randn(1, pc.n_cams, pc.channels, h, w, generator=g) for h, w in mlvl_shapes]
+    feats[0] = ctx
+    X, Y, Z = pc.grid_xyz
+    shape = ovt.bev_feat_shape(1, pc.channels)
+
+    def one():
+        rb, rd, rf, st, ln = ovt.voxel_pooling_prepare_v2(ovt.get_lidar_coor(*cam))
+        vol = O.bev_pool_v2_torch(depth, ctx.permute(0, 1, 3, 4, 2).contiguous(), rd, rf, rb, shape).permute(0, 1, 3, 4, 2)
+        refined = BO.backward_projection(state, feats, vol.mean(-1), cam, depth, Y, X, gcb, pc.input_size, dbound,
+                                         inverse=O.inv3x3_closed_form)
+        return refined[..., None] + vol
+    one()
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        one()
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds or n >= 50:
+            break
+    return {'value': n / dt, 'unit': 'samples/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'{n} x 1-sample passes of the same scope in {dt:.1f}s on {torch.get_num_threads()} of {ncpu} hw threads: oracle forward '
+                      f'projection (torch CPU ops) + Z-mean + oracle/backward_projection_oracle.py ({levels} levels, {Y}x{X} queries) + re-add'}
+
+
+def fb_projection_leg(dev, steps, warmup, cpu_seconds, with_cpu=True):
+    """BASELINE configs[2] on one GPU, reported beside `value` (never as it): forward projection + backward projection (BEV
+    self-attention, depth-aware multi-scale deformable cross-attention over 6 cameras x 4 levels, FFN) + re-add for B = 4 samples
+    of 200 x 200 BEV queries -- scope S3 of SURVEY 8d, the reference's tools/analysis_tools/benchmark_view_transformer.py:64-134
+    protocol (indices rebuilt every step, nothing cached across steps except per-shape constants).  `ms_per_step` is the wall
+    time of K back-to-back steps between device synchronisations; p10/p50/p90 and the DA kernel time are HIP events on the
+    launch stream."""
+    import torch
+    from fb_bev_amd import _capi, configs, synthetic as S
+    from fb_bev_amd.fb_view_transform import FBViewTransform
+    from fb_bev_amd.graphed import Graphed
+
+    def build(name, B, levels):
+        pc = S.CONFIGS[name]
+        X, Y, Z = pc.grid_xyz
+        gcb = {'x': pc.grid_config['x'], 'y': pc.grid_config['y'], 'z': [-1, 5.4, 1.6]}
+        cfg = configs.fbocc_r50(bev_h=Y, bev_w=X, numC_Trans=pc.channels, input_size=pc.input_size, grid_config=pc.grid_config,
+                                grid_config_bevformer=gcb, depth_bound=tuple(pc.grid_config['depth']), downsample=pc.downsample,
+                                num_levels=levels)
+        torch.manual_seed(0)
+        m = FBViewTransform(cfg['forward_projection'], cfg['backward_projection'])
+        with torch.no_grad():      # the reference init zeroes these heads: offsets / weights would not depend on the queries
+            for n_, p_ in m.named_parameters():
+                if 'sampling_offsets.weight' in n_ or 'attention_weights.weight' in n_:
+                    p_.normal_(0, 0.05)
+        m = m.to(dev).eval()
+        cam = [t.to(dev) for t in S.camera_rig(pc, B, seed=0, bda_aug=True)]
+        depth, ctx = (t.to(dev) for t in S.depth_and_context(pc, B, seed=0))
+        H, W = ctx.shape[-2:]
+        shapes = [(H, W), (2 * H, 2 * W), (H // 2, W // 2), (H // 4, W // 4)][:levels]     # level 0 = the depth net's level
+        g = torch.Generator().manual_seed(5)
+        mlvl = [torch.randn(B, pc.n_cams, pc.channels, h, w, generator=g).to(dev) for h, w in shapes]
+        mlvl[0] = ctx
+        return pc, cfg, gcb, m, cam, depth, ctx, mlvl, shapes
+
+    B, levels = 4, 4
+    pc, cfg, gcb, m, cam, depth, ctx, mlvl, shapes = build('BL2', B, levels)
+    X, Y, Z = pc.grid_xyz
+    Q, E, ncam = X * Y, pc.channels, pc.n_cams
+    da_ev = []
+    real_da = _capi.da_cross_attn_fused
+
+    def timed_da(*a, **k):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = real_da(*a, **k)
+        e1.record()
+        da_ev.append((e0, e1))
+        return r
+
+    out = {}
+    with torch.no_grad():
+        for _ in range(max(3, warmup)):
+            m(cam, ctx, depth, mlvl_feats=mlvl)
+        torch.cuda.synchronize(dev)
+        sev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        _capi.da_cross_attn_fused = timed_da
+        try:
+            t0 = time.perf_counter()
+            for i in range(steps):
+                sev[i][0].record()
+                res = m(cam, ctx, depth, mlvl_feats=mlvl)
+                sev[i][1].record()
+            torch.cuda.synchronize(dev)
+            elapsed = time.perf_counter() - t0
+        finally:
+            _capi.da_cross_attn_fused = real_da
+        step_ms = sorted(a.elapsed_time(b) for a, b in sev)
+        pct = lambda q: step_ms[min(len(step_ms) - 1, int(q * len(step_ms)))]  # noqa: E731
+        da_ms = sum(a.elapsed_time(b) for a, b in da_ev) / len(da_ev) if da_ev else None
+        # launches of one step (for the launch-count x 5 us floor SURVEY 8d prescribes for the attention part)
+        launches = None
+        try:
+            from torch.profiler import ProfilerActivity, profile
+            with profile(activities=[ProfilerActivity.CUDA]) as prof:
+                m(cam, ctx, depth, mlvl_feats=mlvl)
+                torch.cuda.synchronize(dev)
+            launches = sum(e.count for e in prof.key_averages() if e.device_time_total > 0)
+        except Exception:
+            launches = None
+        # the same call replayed from a captured hipGraph
+        graph_ms = None
+        try:
+            gr = Graphed(m, cam, ctx, depth, mlvl_feats=mlvl)
+            gr(cam, ctx, depth, mlvl_feats=mlvl)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(steps):
+                gr(cam, ctx, depth, mlvl_feats=mlvl)
+            torch.cuda.synchronize(dev)
+            graph_ms = 1e3 * (time.perf_counter() - t1) / steps
+            del gr
+        except Exception as e:
+            graph_ms = f'{type(e).__name__}: {e}'[:160]
+        S_tok = sum(h * w for h, w in shapes)
+        Za = 4
+        DC, Hd, Wd = depth.shape[2], depth.shape[3], depth.shape[4]
+        parts = {'slots_written': 4 * B * Q * E, 'query_rows_read': 4 * B * Q * E + 4 * Q * E,
+                 'reference_points_mask_depth_records': ncam * B * Q * Za * (8 + 1 + 4),
+                 'camera_token_head_planes': 4 * B * ncam * S_tok * E, 'depth_distribution': 4 * B * ncam * DC * Hd * Wd}
+        algo = sum(parts.values())
+        ms = 1e3 * elapsed / steps
+        out = {
+            'what': 'BASELINE configs[2] (scope S3 of SURVEY 8d): forward projection + backward projection + re-add, 1 x MI355X',
+            'value': B * steps / elapsed, 'unit': 'samples/s', 'ms_per_step': ms, 'steps': steps,
+            'step_gpu_ms_p10_p50_p90': [pct(0.1), pct(0.5), pct(0.9)], 'dtype': 'f32', 'data': 'synthetic',
+            'hipgraph_replay_ms_per_step': graph_ms,
+            'config': {'workload': f'FB-OCC forward + backward projection, BASELINE configs[2]: 6x{pc.input_size[0]}x{pc.input_size[1]} in, D={DC}, C={E}, '
+                                   f'grid {X}x{Y}x{Z}, {Y}x{X} BEV queries, {levels} attention levels '
+                                   f'{"/".join(f"{h}x{w}" for h, w in shapes)}, 8 points, 4 Z anchors, 1 encoder layer; indices rebuilt every step',
+                       'samples_per_gpu': B},
+            'roofline': {'kernel': 'k_da_cross_attn_fused', 'bound': 'hbm', 'achieved': (algo / (da_ms * 1e-3) / 1e9) if da_ms else None,
+                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': (algo / (da_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if da_ms else None,
+                         'traffic': None, 'algorithmic_bytes_per_launch': algo, 'algorithmic_bytes_parts': parts, 'kernel_ms': da_ms,
+                         'note': 'the sampler is bound by vector-L1 accesses / latency, not by HBM (SURVEY 8d: working set < L2); the HBM '
+                                 'fraction is reported because the contract asks for it, the launch floor below is the second yardstick'},
+            'launch_floor': {'launches_per_step': launches, 'us_per_launch': 5.0,
+                             'floor_ms': None if launches is None else launches * 5e-3,
+                             'step_over_floor': None if not launches else ms / (launches * 5e-3)},
+        }
+        del m, mlvl, res
+        # the shipped shape (100 x 100 queries, one 16x44 level, D = 80), B = 1, replayed from a captured hipGraph
+        try:
+            pc1, _, _, m1, cam1, depth1, ctx1, _, _ = build('REF', 1, 1)
+            for _ in range(3):
+                m1(cam1, ctx1, depth1)
+            g1 = Graphed(m1, cam1, ctx1, depth1)
+            g1(cam1, ctx1, depth1)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(steps):
+                g1(cam1, ctx1, depth1)
+            torch.cuda.synchronize(dev)
+            gms = 1e3 * (time.perf_counter() - t1) / steps
+            t1 = time.perf_counter()
+            for _ in range(steps):
+                m1(cam1, ctx1, depth1)
+            torch.cuda.synchronize(dev)
+            ems = 1e3 * (time.perf_counter() - t1) / steps
+            out['shipped_shape'] = {'workload': 'shipped fbocc-r50 shape: 100x100 queries, one 16x44 level, D=80, grid 100x100x8, B=1',
+                                    'hipgraph_replay_ms_per_step': gms, 'eager_ms_per_step': ems, 'samples_per_s_graph': 1e3 / gms}
+            del g1, m1
+        except Exception as e:
+            out['shipped_shape'] = {'error': f'{type(e).__name__}: {e}'[:200]}
+    if with_cpu:
+        pcb, cfgb, gcbb, mb, *_ = build('BL2', 1, levels)
+        state = {k: v.detach().cpu() for k, v in mb.backward_projection.state_dict().items()}
+        del mb
+        out['cpu_baseline'] = cpu_baseline_fb(pcb, levels, state, gcbb, cfgb['depth_bound'], shapes, cpu_seconds)
+        out['gpu_over_cpu'] = out['value'] / out['cpu_baseline']['value']
+    return out
 
 
 def run_forward(args):
@@ -488,6 +683,15 @@ def run_forward(args):
         except Exception:
             traffic = None
 
+    # Extra leg (beside `value`, never as it): BASELINE configs[2] -- the backward-projection half of the path on this GPU
+    fb = None
+    if world == 1 and rank == 0 and not args.no_fb_projection and cfg.name == 'BL2':
+        del out
+        try:
+            fb = fb_projection_leg(dev, args.fb_steps, args.warmup, min(10.0, args.cpu_seconds), with_cpu=not args.no_cpu_baseline)
+        except Exception as e:                    # the headline line is printed regardless; the leg reports its own failure
+            fb = {'error': f'{type(e).__name__}: {e}'[:300]}
+
     if rank == 0:
         total = B * world * args.steps
         res = {
@@ -520,6 +724,8 @@ def run_forward(args):
         }
         if alt is not None:
             res['bf16_storage'] = alt
+        if fb is not None:
+            res['fb_projection'] = fb
         if piped is not None:
             res['pipelined'] = piped
         if world == 1 and not args.no_cpu_baseline:

@@ -35,6 +35,10 @@ SIGNATURES = {
     'fbbev_lift_rank_build_cached': (c_int, [c_void_p] * 10 + [c_int] * 5 + [c_void_p] * 3 + [c_void_p] * 7 +
                                      [c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     'fbbev_pool_tile_index_cached': (c_int, [c_void_p] * 3 + [c_int] * 7 + [c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    'fbbev_lift_splat_fused_ws_bytes': (c_size_t, [c_int] * 9),
+    'fbbev_lift_splat_fused_ws_offsets': (c_int, [c_int] * 9 + [c_void_p]),
+    'fbbev_lift_splat_fused': (c_int, [c_void_p] * 12 + [c_int] * 6 + [c_void_p] * 3 + [c_int] * 3 + [c_void_p, c_int64, c_int64, c_int,
+                                       c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     'fbbev_pool_dense_workspace_bytes': (c_size_t, [c_int] * 4),
     'fbbev_pool_tile_index': (c_int, [c_void_p] * 3 + [c_int] * 7 + [c_void_p, c_size_t, c_void_p]),
     'fbbev_bev_pool_v2_dense_fwd': (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_void_p, c_int64, c_int64, c_void_p,
@@ -280,6 +284,56 @@ def lift_rank_build(xs, ys, ds, rots, trans, intrins, post_rots, post_trans, bda
 
 def cam_key_words(B, N):
     return int(lib().fbbev_cam_key_words(int(B), int(N)))
+
+
+def lift_splat_fused_ws_bytes(B, N, D, H, W, C, Z, Y, X):
+    return int(lib().fbbev_lift_splat_fused_ws_bytes(B, N, D, H, W, C, Z, Y, X))
+
+
+def lift_splat_fused_ws_views(workspace, B, N, D, H, W, C, Z, Y, X):
+    """The index tensors fbbev_lift_splat_fused left in `workspace` (uint8), as int32 views of the padded arrays + counts + the NHWC
+    feature rows: dict(ranks_bev, ranks_depth, ranks_feat, interval_starts, interval_lengths, interval_rank, counts, feat)."""
+    off = (ctypes.c_size_t * 8)()
+    _check(lib().fbbev_lift_splat_fused_ws_offsets(B, N, D, H, W, C, Z, Y, X, ctypes.cast(off, c_void_p)), 'fbbev_lift_splat_fused_ws_offsets')
+    n = B * N * D * H * W
+    names = ('ranks_bev', 'ranks_depth', 'ranks_feat', 'interval_starts', 'interval_lengths', 'interval_rank')
+    out = {k: workspace[off[i]:off[i] + 4 * n].view(torch.int32) for i, k in enumerate(names)}
+    out['counts'] = workspace[off[6]:off[6] + 8].view(torch.int32)
+    out['feat'] = workspace[off[7]:off[7] + 4 * B * N * H * W * C].view(torch.float32).view(B, N, H, W, C)
+    return out
+
+
+def lift_splat_fused(xs, ys, ds, rots, trans, intrins, post_rots, post_trans, bda, depth, context, lower3, interval3, grid_size3,
+                     grid_zyx, out, workspace, tile_voxels=128, flags=None, frustum=None, cam_key=None, cache_state=None):
+    """fbbev_lift_splat_fused: camera tensors + depth (B,N,D,H,W) + context (B,N,C,H,W) -> out (B,C,Z,Y,X) f32 / bf16 / f16 in ONE
+    C call (geometry, ranking, NCHW->NHWC, tile index, dense pooling on the current stream).  workspace: uint8 tensor of
+    lift_splat_fused_ws_bytes(...).  cam_key (int32[cam_key_words], -1) + cache_state (int32[4] = [0, 0, -1, -1]): camera-keyed cache."""
+    B, N, D, H, W = depth.shape
+    C = context.shape[2]
+    Z, Y, X = grid_zyx
+    if tuple(context.shape) != (B, N, C, H, W) or (ds.numel(), ys.numel(), xs.numel()) != (D, H, W):
+        raise FbbevError('lift_splat_fused: depth (B,N,D,H,W), context (B,N,C,H,W), frustum axes (W), (H), (D)')
+    if tuple(out.shape) != (B, C, Z, Y, X) or out.stride()[2:] != (Y * X, X, 1) or out.dtype not in (F32, torch.bfloat16, torch.float16):
+        raise FbbevError('lift_splat_fused: out must be a (B,C,Z,Y,X) f32 / bf16 / f16 tensor with a contiguous (Z,Y,X) block')
+    fl = (DEFAULT_POOL_FLAGS if flags is None else int(flags)) & ~(POOL_OUT_BF16 | POOL_OUT_F16 | POOL_CHANNELS_LAST)
+    fl |= {F32: 0, torch.bfloat16: POOL_OUT_BF16, torch.float16: POOL_OUT_F16}[out.dtype]
+    if (cam_key is None) != (cache_state is None):
+        raise FbbevError('lift_splat_fused: cam_key and cache_state go together')
+    if cam_key is not None and (cam_key.numel() < cam_key_words(B, N) or cache_state.numel() < 4):
+        raise FbbevError('lift_splat_fused: cam_key / cache_state too small (cache_state: 4 x int32)')
+    arr = ctypes.c_float * 3
+    lo, it, gs = arr(*lower3), arr(*interval3), arr(*grid_size3)
+    with _on(depth):
+        _check(lib().fbbev_lift_splat_fused(
+            _dev(frustum, F32, 'frustum') if frustum is not None else c_void_p(0), _dev(xs, F32, 'xs'), _dev(ys, F32, 'ys'),
+            _dev(ds, F32, 'ds'), _dev(rots, F32, 'rots'), _dev(trans, F32, 'trans'), _dev(intrins, F32, 'intrins'),
+            _dev(post_rots, F32, 'post_rots'), _dev(post_trans, F32, 'post_trans'), _dev(bda, F32, 'bda'), _dev(depth, F32, 'depth'),
+            _dev(context, F32, 'context'), B, N, D, H, W, C, ctypes.cast(lo, c_void_p), ctypes.cast(it, c_void_p),
+            ctypes.cast(gs, c_void_p), Z, Y, X, c_void_p(out.data_ptr()), out.stride(0), out.stride(1), int(tile_voxels), fl,
+            c_void_p(workspace.data_ptr()), workspace.numel() * workspace.element_size(),
+            _dev(cam_key, I32, 'cam_key') if cam_key is not None else c_void_p(0),
+            _dev(cache_state, I32, 'cache_state') if cache_state is not None else c_void_p(0), _stream()), 'fbbev_lift_splat_fused')
+    return out
 
 
 def pool_dense_workspace_bytes(B, Z, Y, X):

@@ -1,12 +1,12 @@
 """Host-side mirror of mmdet3d/ops/bev_pool_v2/bev_pool.py (QuickCumsumCuda :11-80,
-bev_pool_v2 :83-89): same names, argument meaning and autograd contract (gradients for `depth`
+bev_pool_v2 :83-89, TRTBEVPoolv2 :92-141): same names, argument meaning and autograd contract (gradients for `depth`
 and `feat` only), running on the HIP kernels of libfbbev_hip.so.
 """
 import torch
 
 from . import bev_pool_v2_ext
 
-__all__ = ['bev_pool_v2', 'QuickCumsumCuda', 'intervals_over']
+__all__ = ['bev_pool_v2', 'QuickCumsumCuda', 'TRTBEVPoolv2', 'intervals_over']
 
 
 def intervals_over(sorted_keys):

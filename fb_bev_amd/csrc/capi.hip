@@ -903,6 +903,83 @@ extern "C" int fbbev_bev_pool_v2_dense_fwd_add(const float* depth, const float* 
                                stream_);
 }
 
+// ------------------------------------------------------------------------------ lift-splat in ONE entry
+// Workspace layout of fbbev_lift_splat_fused (all blocks 256-byte aligned): the seven padded index tensors + counts the build
+// writes, the NHWC feature rows, the tile table, the ranking workspace.
+struct lift_splat_layout {
+    size_t ranks_bev, ranks_depth, ranks_feat, interval_starts, interval_lengths, interval_rank, counts, feat, tile, rank, total;
+    size_t tile_bytes, rank_bytes;
+};
+static bool lift_splat_plan(int B, int N, int D, int H, int W, int C, int Z, int Y, int X, lift_splat_layout& L) {
+    if (B <= 0 || N <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0 || Z <= 0 || Y <= 0 || X <= 0) return false;
+    const long long n = (long long)B * N * D * H * W;
+    if (n >= (1ll << 31)) return false;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off = align_up(off + bytes, 256); return o; };
+    L.ranks_bev = take((size_t)n * 4); L.ranks_depth = take((size_t)n * 4); L.ranks_feat = take((size_t)n * 4);
+    L.interval_starts = take((size_t)n * 4); L.interval_lengths = take((size_t)n * 4); L.interval_rank = take((size_t)n * 4);
+    L.counts = take(16);
+    L.feat = take((size_t)B * N * H * W * C * 4);
+    L.tile_bytes = fbbev_pool_dense_workspace_bytes(B, Z, Y, X);
+    L.tile = take(L.tile_bytes);
+    L.rank_bytes = fbbev_rank_workspace_bytes(n);
+    L.rank = take(L.rank_bytes);
+    L.total = off;
+    return true;
+}
+
+extern "C" size_t fbbev_lift_splat_fused_ws_bytes(int B, int N, int D, int H, int W, int C, int Z, int Y, int X) {
+    lift_splat_layout L;
+    return lift_splat_plan(B, N, D, H, W, C, Z, Y, X, L) ? L.total : 0;
+}
+
+extern "C" int fbbev_lift_splat_fused_ws_offsets(int B, int N, int D, int H, int W, int C, int Z, int Y, int X, size_t* offsets8) {
+    lift_splat_layout L;
+    if (!offsets8 || !lift_splat_plan(B, N, D, H, W, C, Z, Y, X, L)) return FBBEV_E_BADARG;
+    offsets8[0] = L.ranks_bev; offsets8[1] = L.ranks_depth; offsets8[2] = L.ranks_feat; offsets8[3] = L.interval_starts;
+    offsets8[4] = L.interval_lengths; offsets8[5] = L.interval_rank; offsets8[6] = L.counts; offsets8[7] = L.feat;
+    return 0;
+}
+
+extern "C" int fbbev_lift_splat_fused(const float* frustum, const float* xs, const float* ys, const float* ds, const float* rots,
+                                      const float* trans, const float* intrins, const float* post_rots, const float* post_trans,
+                                      const float* bda, const float* depth, const float* context, int B, int N, int D, int H,
+                                      int W, int C, const float* lower3, const float* interval3, const float* grid_size3, int Z,
+                                      int Y, int X, void* out, long long out_stride_b, long long out_stride_c, int tile_voxels,
+                                      int flags, void* workspace, size_t workspace_bytes, uint32_t* cam_key, int32_t* cache_state,
+                                      fbbev_stream_t stream_) {
+    lift_splat_layout L;
+    if (!depth || !context || !out || !workspace) return FBBEV_E_BADARG;
+    if (!lift_splat_plan(B, N, D, H, W, C, Z, Y, X, L)) return FBBEV_E_BADARG;
+    if ((cam_key == nullptr) != (cache_state == nullptr)) return FBBEV_E_BADARG;
+    if (workspace_bytes < L.total) return FBBEV_E_WORKSPACE;
+    if (!aligned16(workspace)) return FBBEV_E_UNSUPPORTED;
+    char* ws = static_cast<char*>(workspace);
+    auto i32 = [&](size_t o) { return reinterpret_cast<int32_t*>(ws + o); };
+    const long long n = (long long)B * N * D * H * W;
+    // view_transformer.py:458-498 + :547-605: geometry + voxel ranking, device-side counts (cache_state[0] = 1 on a key hit)
+    int rc = lift_rank_build_impl(frustum, xs, ys, ds, rots, trans, intrins, post_rots, post_trans, bda, B, N, D, H, W, lower3,
+                                  interval3, grid_size3, i32(L.ranks_bev), i32(L.ranks_depth), i32(L.ranks_feat),
+                                  i32(L.interval_starts), i32(L.interval_lengths), i32(L.interval_rank), i32(L.counts),
+                                  ws + L.rank, L.rank_bytes, (fbbev_rt_stream)stream_, cam_key, cache_state);
+    if (rc) return rc;
+    // :536 / bev_pool.py:18: feat.permute(0,1,3,4,2).contiguous()
+    float* feat = reinterpret_cast<float*>(ws + L.feat);
+    rc = fbbev_nchw_to_nhwc(context, feat, B * N, C, H * W, stream_);
+    if (rc) return rc;
+    // bev_pool.py:24-35,88: new_zeros + kernel + permute().contiguous() as tile index + one dense pass
+    if (cache_state)
+        rc = fbbev_pool_tile_index_cached(i32(L.interval_rank), i32(L.interval_starts), i32(L.counts), (int)n, B, Z, Y, X,
+                                          tile_voxels, flags, ws + L.tile, L.tile_bytes, cache_state, cache_state + 2, stream_);
+    else
+        rc = pool_tile_index_impl(i32(L.interval_rank), i32(L.interval_starts), i32(L.counts), (int)n, B, Z, Y, X, tile_voxels,
+                                  flags, ws + L.tile, L.tile_bytes, stream_, nullptr);
+    if (rc) return rc;
+    return pool_dense_fwd_impl(depth, feat, i32(L.ranks_depth), i32(L.ranks_feat), i32(L.interval_rank), i32(L.interval_starts),
+                               i32(L.interval_lengths), B, C, Z, Y, X, static_cast<float*>(out), out_stride_b, out_stride_c,
+                               ws + L.tile, L.tile_bytes, tile_voxels, flags, nullptr, stream_);
+}
+
 static int pool_zmean_impl(const float* depth, const float* feat, const int32_t* ranks_depth,
                            const int32_t* ranks_feat, const int32_t* interval_rank,
                            const int32_t* interval_starts, const int32_t* interval_lengths, int B, int C, int Z,

@@ -489,7 +489,8 @@ class LSSViewTransformerFunction3D(nn.Module):
         # shipped grid B = 16 (2 512 tiles): 1.38 -> 1.47 ms -- so: few tiles AND a partial buffer of at most 128 MB
         tiles = B * ((YX + self._wo_tile - 1) // self._wo_tile)
         partial_bytes = Z * B * self._C_hint * YX * 4 if getattr(self, '_C_hint', None) else 0
-        return Z if (tiles <= 1024 and partial_bytes <= (128 << 20)) else 1
+        # fbbev_pool_zmean_split takes at most 64 Z groups (include/fbbev.h): taller grids keep the single pass
+        return Z if (tiles <= 1024 and partial_bytes <= (128 << 20) and Z <= 64) else 1
 
     def pooled_volume(self, parts, addend=None):
         """The (B,C,Y,X,Z) view of the volume, written once; addend (B,C,Y,X) is added broadcast over z in the store."""

@@ -250,6 +250,30 @@ int fbbev_bev_pool_v2_dense_fwd_add(const float* depth, const float* feat, const
                                     const void* tile_ws, size_t tile_ws_bytes, int tile_voxels, int flags,
                                     const float* addend, fbbev_stream_t stream);
 
+/* The forward projection as ONE entry (SURVEY 8b `fbbev_lift_splat_fused`).  Replaces, in
+ *   fbbev/view_transformation/forward_projection/view_transformer.py:521-545 (voxel_pooling_v2) + :613-635 (view_transform_core),
+ * get_lidar_coor (:458-498) -> voxel_pooling_prepare_v2 (:547-605) -> feat.permute(0,1,3,4,2) (:536) -> bev_pool_v2 (bev_pool.py:83-89:
+ * new_zeros + bev_pool_v2_forward + permute().contiguous()), i.e. exactly the sequence
+ *   fbbev_lift_rank_build[_cached] -> fbbev_nchw_to_nhwc -> fbbev_pool_tile_index[_cached] -> fbbev_bev_pool_v2_dense_fwd
+ * on the caller's stream, bit-identical to issuing the four calls (tests/test_gpu_parity.py), no host sync, graph-capturable.
+ * depth (B,N,D,H,W) f32, context (B,N,C,H,W) f32 (the depth net's two outputs, NCHW as it leaves them); camera tensors, frustum
+ * axes and grid triples as fbbev_lift_rank_build; out / strides / tile_voxels / flags as fbbev_bev_pool_v2_dense_fwd (the storage
+ * flags select a 16-bit `out`).  workspace: fbbev_lift_splat_fused_ws_bytes(...) bytes, 16-byte aligned, caller-owned; it holds the
+ * index tensors of the call, which a backward pass (fbbev_bev_pool_v2_dense_bwd) or a second consumer (fbbev_pool_zmean) reads at
+ * the byte offsets fbbev_lift_splat_fused_ws_offsets reports: [ranks_bev, ranks_depth, ranks_feat, interval_starts,
+ * interval_lengths, interval_rank, counts (int32 [P, I]), feat rows (B,N,H,W,C) f32].
+ * cam_key / cache_state: both NULL = indices rebuilt every call (the reference's own setting, :628); both given = the camera-keyed
+ * cache of fbbev_lift_rank_build_cached with the SAME workspace passed every call: cam_key fbbev_cam_key_words(B,N) uint32
+ * initialised to 0xFFFFFFFF, cache_state FOUR int32 initialised to {0, 0, -1, -1} (hit flag, build count, tile-table gate pair). */
+size_t fbbev_lift_splat_fused_ws_bytes(int B, int N, int D, int H, int W, int C, int Z, int Y, int X);
+int fbbev_lift_splat_fused_ws_offsets(int B, int N, int D, int H, int W, int C, int Z, int Y, int X, size_t* offsets8);
+int fbbev_lift_splat_fused(const float* frustum, const float* xs, const float* ys, const float* ds, const float* rots,
+                           const float* trans, const float* intrins, const float* post_rots, const float* post_trans,
+                           const float* bda, const float* depth, const float* context, int B, int N, int D, int H, int W, int C,
+                           const float* lower3, const float* interval3, const float* grid_size3, int Z, int Y, int X, void* out,
+                           long long out_stride_b, long long out_stride_c, int tile_voxels, int flags, void* workspace,
+                           size_t workspace_bytes, uint32_t* cam_key, int32_t* cache_state, fbbev_stream_t stream);
+
 /* Measurement aid, not part of the product path (bench.py `roofline.store_floor_ms` / `no_gather_ms`): the default fp32
  * instantiation of the dense kernel (tile_voxels 128, FBBEV_POOL_CPL8, 256 threads, `sc1 nt` stores; anything else ->
  * FBBEV_E_UNSUPPORTED) with its gathers compiled out, launched with the grid / tile walk / XCD order the product launch

@@ -46,6 +46,34 @@ def main():
     path = os.path.join(MG.OUT, 'bevdet_view_transformer_small.npz')
     np.savez_compressed(path, **out)
     print('wrote', path, os.path.getsize(path), 'bytes')
+    make_trt_pool_fixture(sys.modules['mmdet3d.ops.bev_pool_v2.bev_pool'])
+
+
+def make_trt_pool_fixture(ref_pool):
+    """The REAL TRTBEVPoolv2.forward (ops/bev_pool_v2/bev_pool.py:118-141; imported at module scope by fbocc.py:12 and
+    detectors/bevdet.py:6) on a Z = 1 grid: depth (n, d, h, w), feat, the index tensors of a single sample ->
+    (1, out_height, out_width, C).  The extension under it is the C oracle (install_stubs)."""
+    from fb_bev_amd import synthetic as S
+    from oracle import oracle as O
+    grid = {'x': [-8, 8, 1.0], 'y': [-6, 6, 1.0], 'z': [-10, 10, 20.0], 'depth': [1.0, 9.0, 1.0]}       # X=16, Y=12, Z=1
+    pc = S.PathConfig(name='trt', input_size=(64, 96), downsample=16, grid_config=grid, channels=8)
+    n, C = 6, 8
+    H, W = pc.feat_hw
+    D = pc.D
+    cam = S.camera_rig(pc, 1, seed=2, bda_aug=True)
+    ovt = O.ViewTransformerOracle(grid, pc.input_size, pc.downsample)
+    rb, rd, rf, st, ln = ovt.voxel_pooling_prepare_v2(ovt.get_lidar_coor(*cam).contiguous())
+    g = torch.Generator().manual_seed(3)
+    depth = (torch.randn(n, D, H, W, generator=g) * 2).softmax(1).contiguous()
+    # bev_pool.py:132 `feat.view(1, n, feat.shape[3], h, w)`: dim 3 of the argument is taken as the channel count and its MEMORY is
+    # read in (n, C, h, w) order -- reproduced literally: a contiguous tensor shaped (n, h, w, C)
+    feat_arg = torch.randn(n, H, W, C, generator=g).contiguous()
+    out = ref_pool.TRTBEVPoolv2.forward(None, depth, feat_arg, rd, rf, rb, st, ln, 12, 16)
+    path = os.path.join(MG.OUT, 'trt_bev_pool_v2_small.npz')
+    np.savez_compressed(path, depth=depth.numpy(), feat=feat_arg.numpy(), ranks_depth=rd.numpy(), ranks_feat=rf.numpy(),
+                        ranks_bev=rb.numpy(), interval_starts=st.numpy(), interval_lengths=ln.numpy(), out=out.numpy(),
+                        out_hw=np.array([12, 16]))
+    print('TRTBEVPoolv2', tuple(out.shape), 'wrote', path, os.path.getsize(path), 'bytes')
 
 
 if __name__ == '__main__':

@@ -77,3 +77,22 @@ def test_onnx_symbolic_emits_the_reference_node():
     assert name == 'mmdeploy::bev_pool_v2'
     assert inputs == ('depth', 'feat', 'rd', 'rf', 'rb', 'starts', 'lengths')
     assert attrs == {'out_height_i': 200, 'out_width_i': 100}
+
+
+def test_trt_bev_pool_v2_forward_equals_the_real_class_fixture(monkeypatch):
+    """TRTBEVPoolv2.forward (ops/bev_pool_v2/bev_pool.py:118-141) against a fixture of the REAL class
+    (tests/golden/make_golden_bevdet.py): the host logic of fb_bev_amd.bev_pool.TRTBEVPoolv2 with the extension call served by the
+    emulated kernel (the GPU twin of this test is tests/test_gpu_bevdet.py)."""
+    from fb_bev_amd import bev_pool, bev_pool_v2_ext
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'trt_bev_pool_v2_small.npz'))
+
+    def fwd(depth, feat, out, rd, rf, rb, lengths, starts):
+        E.pool_fwd(depth, feat, out, rd, rf, rb, starts, lengths)
+    monkeypatch.setattr(bev_pool_v2_ext, 'bev_pool_v2_forward', fwd)
+    t = {k: torch.from_numpy(z[k]) for k in z.files}
+    oh, ow = z['out_hw'].tolist()
+    out = bev_pool.TRTBEVPoolv2.forward(None, t['depth'], t['feat'], t['ranks_depth'], t['ranks_feat'], t['ranks_bev'],
+                                        t['interval_starts'], t['interval_lengths'], oh, ow)
+    assert out.shape == t['out'].shape == (1, oh, ow, t['feat'].shape[3])
+    assert torch.equal(out, t['out'])                      # the same in-order fmaf chain as the oracle that served the real class
+    assert 'TRTBEVPoolv2' in bev_pool.__all__

@@ -472,6 +472,67 @@ def test_fused_geometry_rank_build_equals_two_step(name, B):
             assert torch.equal(a[:n], b[:n])
 
 
+@pytest.mark.parametrize('name,B,tv,flags', [('TINY', 2, 64, 0), ('SMALL', 1, 128, 0x24424), ('TINY', 2, 64, 0x800414)])
+def test_lift_splat_fused_one_entry_equals_the_four_calls_emulated(name, B, tv, flags):
+    """fbbev_lift_splat_fused (view_transformer.py:521-545 as ONE C entry) == fbbev_lift_rank_build -> fbbev_nchw_to_nhwc ->
+    fbbev_pool_tile_index -> fbbev_bev_pool_v2_dense_fwd bit for bit, == the C oracle on the same coor; the index tensors it
+    leaves in its workspace are the ones the four calls produce; the camera-keyed form keeps them on a hit and rebuilds on a
+    changed rig; bf16 storage; short / misaligned workspace refused."""
+    import ctypes
+    cfg = S.CONFIGS[name]
+    vt = O.ViewTransformerOracle(cfg.grid_config, cfg.input_size, cfg.downsample)
+    cam = S.camera_rig(cfg, B, seed=0, bda_aug=True)
+    depth, ctx = S.depth_and_context(cfg, B, seed=0)
+    xs = vt.frustum[0, 0, :, 0].contiguous(); ys = vt.frustum[0, :, 0, 1].contiguous(); ds = vt.frustum[:, 0, 0, 2].contiguous()
+    _, Z, Y, X, C = vt.bev_feat_shape(B, cfg.channels)
+    N, D, (H, W) = cfg.n_cams, cfg.D, cfg.feat_hw
+    L = E.lib()
+    rb, rd, rf, st, ln, ir, counts = E.lift_rank_build(xs, ys, ds, cam, *_grid3(vt))
+    feat = E.nchw_to_nhwc(ctx)
+    code, four = E.pool_dense(depth, feat, rd, rf, ir, st, ln, counts, st.numel(), B, C, Z, Y, X, tv, flags & ~0x800000)
+    assert code == 0
+    exp = O.bev_pool_v2(depth, feat, *[t[:counts[0]] for t in (rd, rf, rb)], (B, Z, Y, X, C), st[:counts[1]], ln[:counts[1]], use_fma=True)
+    assert torch.equal(four, exp)
+    dims = (B, N, D, H, W, C, Z, Y, X)
+    need = L.fbbev_lift_splat_fused_ws_bytes(*dims)
+    assert need > 0 and L.fbbev_lift_splat_fused_ws_bytes(0, N, D, H, W, C, Z, Y, X) == 0
+    ws = torch.full((need,), 0xA5, dtype=torch.uint8)
+    arr = ctypes.c_float * 3
+    lo, it, gs = (arr(*v) for v in _grid3(vt))
+    bf16 = bool(flags & 0x800000)
+    out = torch.full((B, C, Z, Y, X), float('nan'), dtype=torch.bfloat16 if bf16 else torch.float32)
+
+    def call(cam_, ws_, key=None, state=None, nbytes=None):
+        rots, trans, intrins, post_rots, post_trans, bda = cam_
+        return L.fbbev_lift_splat_fused(None, E.p(xs), E.p(ys), E.p(ds), E.p(rots), E.p(trans), E.p(intrins), E.p(post_rots), E.p(post_trans),
+                                        E.p(bda), E.p(depth), E.p(ctx), B, N, D, H, W, C, ctypes.cast(lo, ctypes.c_void_p),
+                                        ctypes.cast(it, ctypes.c_void_p), ctypes.cast(gs, ctypes.c_void_p), Z, Y, X, E.p(out), 0, 0, tv, flags,
+                                        ctypes.c_void_p(ws_.data_ptr()), ws_.numel() if nbytes is None else nbytes,
+                                        None if key is None else E.p(key), None if state is None else E.p(state), None)
+    assert call(cam, ws) == 0 and not torch.isnan(out.float()).any()
+    assert torch.equal(out, four.to(out.dtype))                           # 16-bit storage = the fp32 sums rounded once
+    off = (ctypes.c_size_t * 8)()
+    assert L.fbbev_lift_splat_fused_ws_offsets(*dims, ctypes.cast(off, ctypes.c_void_p)) == 0
+    P, I = ws[off[6]:off[6] + 8].view(torch.int32).tolist()
+    assert [P, I] == counts.tolist()
+    for k, (ref, n) in enumerate(((rb, P), (rd, P), (rf, P), (st, I), (ln, I), (ir, I))):
+        assert torch.equal(ws[off[k]:off[k] + 4 * n].view(torch.int32), ref[:n]), k
+    assert torch.equal(ws[off[7]:off[7] + 4 * feat.numel()].view(torch.float32), feat.reshape(-1))
+    # camera-keyed cache: first call builds, second (same rig) keeps the workspace's index tensors, a changed rig rebuilds
+    key = torch.full((L.fbbev_cam_key_words(B, N),), -1, dtype=torch.int32)
+    state = torch.tensor([0, 0, -1, -1], dtype=torch.int32)
+    ws2 = torch.full((need,), 0x5A, dtype=torch.uint8)
+    for want_hit, want_builds, cam_ in ((0, 1, cam), (1, 1, cam), (0, 2, S.camera_rig(cfg, B, seed=3, bda_aug=True)), (0, 3, cam)):
+        out.fill_(float('nan'))
+        assert call(cam_, ws2, key, state) == 0
+        assert state[:2].tolist() == [want_hit, want_builds] and not torch.isnan(out.float()).any()
+        if cam_ is cam:
+            assert torch.equal(out, four.to(out.dtype))
+    # refused: workspace too small / one of the cache pointers missing
+    assert call(cam, ws, nbytes=need - 256) == -4 or call(cam, ws, nbytes=need - 256) < 0
+    assert call(cam, ws2, key, None) < 0
+
+
 def test_nchw_to_nhwc_emulated():
     for shape in ((2, 3, 8, 4, 6), (1, 2, 80, 5, 7), (1, 1, 33, 3, 11)):
         x = torch.randn(shape, generator=torch.Generator().manual_seed(0))

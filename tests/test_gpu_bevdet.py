@@ -31,3 +31,17 @@ def test_module_equals_reference_fixture_and_backpropagates(name):
     bev, _ = m(inp)
     bev.square().sum().backward()
     assert inp[0].grad is not None and torch.isfinite(inp[0].grad).all() and m.depth_net.weight.grad.abs().sum() > 0
+
+
+def test_trt_bev_pool_v2_forward_equals_the_real_class_fixture():
+    """fb_bev_amd.bev_pool.TRTBEVPoolv2.forward on the HIP op == the REAL TRTBEVPoolv2.forward (ops/bev_pool_v2/bev_pool.py:118-141;
+    fixture of tests/golden/make_golden_bevdet.py, the extension under the real class served by the C oracle): bit for bit."""
+    from fb_bev_amd.bev_pool import TRTBEVPoolv2
+    dev = torch.device('cuda:0')
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'trt_bev_pool_v2_small.npz'))
+    t = {k: torch.from_numpy(z[k]).to(dev) for k in z.files if k != 'out_hw'}
+    oh, ow = z['out_hw'].tolist()
+    out = TRTBEVPoolv2.apply(t['depth'], t['feat'], t['ranks_depth'], t['ranks_feat'], t['ranks_bev'], t['interval_starts'],
+                             t['interval_lengths'], oh, ow)
+    assert out.shape == (1, oh, ow, t['feat'].shape[3])
+    assert torch.equal(out.cpu(), torch.from_numpy(z['out']))

@@ -186,6 +186,57 @@ def test_nchw_to_nhwc_kernel(dev):
         assert torch.equal(_capi.nchw_to_nhwc(x), x.permute(0, 1, 3, 4, 2).contiguous())
 
 
+@pytest.mark.parametrize('name,B,dt', [('SMALL', 2, torch.float32), ('REF', 2, torch.float32), ('BL2', 4, torch.float32), ('BL2', 2, torch.bfloat16),
+                                       ('BL5', 1, torch.float16)])
+def test_lift_splat_fused_one_entry_equals_the_four_call_sequence(dev, name, B, dt):
+    """fbbev_lift_splat_fused (view_transformer.py:521-545 + :613-635 as ONE C entry) == the sequence
+    fbbev_lift_rank_build -> fbbev_nchw_to_nhwc -> fbbev_pool_tile_index -> fbbev_bev_pool_v2_dense_fwd bit for bit (fp32 and 16-bit
+    storage), == the C oracle on the same coor for the fp32 volume, index tensors in the workspace == the oracle's, and the
+    camera-keyed form (hit / changed rig) reproduces the same volume."""
+    from fb_bev_amd import _capi
+    O = _oracle()
+    cfg, ovt, cam, _, depth, ctx = _inputs(name, B, True, dev)
+    vt = _vt(cfg, dev, out_dtype=dt)
+    tv, flags = vt.tiling(cfg.n_cams)
+    cam_g = [t.to(dev) for t in cam]
+    d_g, c_g = depth.to(dev), ctx.to(dev)
+    Z, Y, X = vt.grid_zyx
+    C = cfg.channels
+    four = vt(cam_g, c_g, d_g).permute(0, 1, 4, 2, 3)                       # the module's own 4-call route, (B,C,Z,Y,X)
+    N, D, (H, W) = cfg.n_cams, cfg.D, cfg.feat_hw
+    dims = (B, N, D, H, W, C, Z, Y, X)
+    ws = torch.full((_capi.lift_splat_fused_ws_bytes(*dims),), 0xA5, dtype=torch.uint8, device=dev)
+    xs, ys, ds = vt._axes(dev)
+    lo, it, gs = vt._grid3()
+    out = torch.full((B, C, Z, Y, X), float('nan'), dtype=dt, device=dev)
+    _capi.lift_splat_fused(xs, ys, ds, *cam_g, d_g, c_g, lo, it, gs, (Z, Y, X), out, ws, tile_voxels=tv, flags=flags)
+    assert not torch.isnan(out.float()).any()
+    assert torch.equal(out, four)
+    views = _capi.lift_splat_fused_ws_views(ws, *dims)
+    P, I = views['counts'].tolist()
+    coor = vt.get_lidar_coor(*cam_g).cpu()                                    # contract pinned at the ranking input
+    exp_idx = ovt.voxel_pooling_prepare_v2(coor)
+    for k, e, n in zip(('ranks_bev', 'ranks_depth', 'ranks_feat', 'interval_starts', 'interval_lengths'), exp_idx, (P, P, P, I, I)):
+        assert n == e.numel() and torch.equal(views[k][:n].cpu(), e), k
+    if dt == torch.float32:
+        rb, rd, rf, st, ln = exp_idx
+        exp = O.bev_pool_v2(depth, ctx.permute(0, 1, 3, 4, 2).contiguous(), rd, rf, rb, ovt.bev_feat_shape(B, C), st, ln)
+        assert torch.equal(out.cpu(), exp)
+    key = torch.full((_capi.cam_key_words(B, N),), -1, dtype=torch.int32, device=dev)
+    state = torch.tensor([0, 0, -1, -1], dtype=torch.int32, device=dev)
+    ws2 = torch.full_like(ws, 0x5A)
+    cam_b = [t.to(dev) for t in S.camera_rig(cfg, B, seed=9, bda_aug=True)]
+    for want, cams in (([0, 1], cam_g), ([1, 1], cam_g), ([0, 2], cam_b), ([0, 3], cam_g)):
+        out.fill_(float('nan'))
+        _capi.lift_splat_fused(xs, ys, ds, *cams, d_g, c_g, lo, it, gs, (Z, Y, X), out, ws2, tile_voxels=tv, flags=flags, cam_key=key,
+                               cache_state=state)
+        assert state[:2].tolist() == want and not torch.isnan(out.float()).any()
+        if cams is cam_g:
+            assert torch.equal(out, four)
+    with pytest.raises(_capi.FbbevError):
+        _capi.lift_splat_fused(xs, ys, ds, *cam_g, d_g, c_g, lo, it, gs, (Z, Y, X), out, ws[:ws.numel() - 512], tile_voxels=tv, flags=flags)
+
+
 # ------------------------------------------------------------------ pooling forward
 CASES = [('TINY', 2, True), ('SMALL', 2, True), ('REF', 1, False), ('BL2', 2, True), ('BL1', 1, False)]
 
