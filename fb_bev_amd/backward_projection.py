@@ -104,10 +104,24 @@ class CustormLearnedPositionalEncoding(nn.Module):
         nn.init.uniform_(self.col_embed.weight)
         self.num_feats = num_feats
 
-    def forward(self, bs, h, w, device):
+    def _table(self, h, w, device):
         x_embed = self.col_embed(torch.arange(w, device=device))
         y_embed = self.row_embed(torch.arange(h, device=device))
-        pos = torch.cat((x_embed.unsqueeze(0).repeat(h, 1, 1), y_embed.unsqueeze(1).repeat(1, w, 1)), dim=-1)
+        return torch.cat((x_embed.unsqueeze(0).repeat(h, 1, 1), y_embed.unsqueeze(1).repeat(1, w, 1)), dim=-1)
+
+    def forward(self, bs, h, w, device):
+        rw, cw = self.row_embed.weight, self.col_embed.weight
+        if torch.is_grad_enabled() and (rw.requires_grad or cw.requires_grad):
+            pos = self._table(h, w, device)
+        else:
+            # inference: the (h, w, C) table is a per-shape constant of the two embedding tables -- built once per weight version
+            # (data_ptr + _version, as the other folded-weight caches) instead of seven ATen launches per step
+            key = (h, w, str(device), rw.data_ptr(), rw._version, cw.data_ptr(), cw._version)
+            if getattr(self, '_pos_key', None) != key:
+                with torch.no_grad():
+                    self._pos = self._table(h, w, device).contiguous()
+                self._pos_key = key
+            pos = self._pos
         # (bs,C,h,w) like the reference (positional_encoding.py:57-60) but as a broadcast VIEW of the token-major
         # (h,w,C) table instead of `.repeat`: flattened and permuted back to (bs,Q,C) by the encoder it is again
         # contiguous rows, so `query + query_pos` runs vectorised and nothing is copied
@@ -282,7 +296,10 @@ class MultiScaleDeformableAttention(nn.Module):
                     if add is None:
                         q_in = query + pos
                 out = torch.empty(bs, num_query, self.embed_dims, dtype=torch.float32, device=query.device)
-                ref = reference_points.expand(bs, num_query, 1, 2).contiguous()
+                rk = (reference_points.data_ptr(), reference_points._version, tuple(reference_points.shape), bs, str(query.device))
+                if getattr(self, '_ref_key', None) != rk:      # the encoder's cached 2-D grid: one contiguous copy per shape
+                    self._ref, self._ref_src, self._ref_key = reference_points.expand(bs, num_query, 1, 2).contiguous(), reference_points, rk
+                ref = self._ref
                 if (_norm is not None and _defer_residual and FUSE_ATTN_TAIL and self.embed_dims % 16 == 0
                         and _RL.ln_fusable(_norm, identity.contiguous(), out, self.embed_dims)):
                     # output_proj + residual + the following LayerNorm inside the attention kernel's workgroups (fbbev_msda_self_fused_ln):
@@ -999,8 +1016,11 @@ class BEVFormer(nn.Module):
             bs, ncam, c = f0.shape[:3]
             S = sum(h * w for h, w in shapes)
             rows = torch.empty((bs * ncam, S, c), dtype=torch.float32, device=f0.device)
-            ce = self.cams_embeds.detach().to(torch.float32)
-            ce = (ce if self.use_cams_embeds else ce * 0).contiguous()
+            ck = (self.cams_embeds.data_ptr(), self.cams_embeds._version, str(f0.device), self.use_cams_embeds)
+            if getattr(self, '_ce_key', None) != ck:       # per-weight-version constant (the reference adds `cams_embeds * 0` when unused)
+                ce = self.cams_embeds.detach().to(torch.float32)
+                self._ce, self._ce_key = (ce if self.use_cams_embeds else ce * 0).contiguous(), ck
+            ce = self._ce
             if 1 < len(mlvl_feats) <= 8:       # the whole pyramid in one launch
                 _capi.tokens_from_nchw_levels([f.reshape(bs * ncam, c, h * w).contiguous() for f, (h, w) in zip(mlvl_feats, shapes)],
                                               rows, ce)

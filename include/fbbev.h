@@ -236,8 +236,9 @@ int fbbev_pool_zmean(const float* depth, const float* feat, const int32_t* ranks
                      int tile_voxels, int flags, fbbev_stream_t stream);
 /* fbbev_pool_zmean with the Z planes of a tile dealt to z_groups workgroups (each walks ceil(Z / z_groups) planes) + a caller-owned
  * partial buffer of z_groups * B*C*Y*X floats; a second small kernel adds the groups in order and divides by Z.  For grids with
- * few tiles (the shipped 100x100x8 grid at small batch), where the single pass is one Z-plane latency chain per workgroup.  The
- * association of the z sum differs from the single pass (fp32 rounding); z_groups = 1 is fbbev_pool_zmean. */
+ * few tiles (the shipped 100x100x8 grid at small batch), where the single pass is one Z-plane latency chain per workgroup.
+ * z_groups = Z (one plane per group) gives the single pass's bits (both add the per-plane sums of a pillar in z order); 1 < z_groups
+ * < Z is another association of the z sum (fp32 rounding); z_groups = 1 is fbbev_pool_zmean. */
 int fbbev_pool_zmean_split(const float* depth, const float* feat, const int32_t* ranks_depth, const int32_t* ranks_feat,
                            const int32_t* interval_rank, const int32_t* interval_starts, const int32_t* interval_lengths,
                            int B, int C, int Z, int Y, int X, float* out_mean, const void* tile_ws, size_t tile_ws_bytes,

@@ -193,10 +193,10 @@ def test_token_pyramid_in_one_launch_bit_exact(dev, images, C, shapes):
 @pytest.mark.parametrize('name,B', [('REF', 1), ('REF', 4), ('BL2', 1), ('SMALL', 2)])
 def test_pool_zmean_split_equals_single_pass_and_oracle_volume_mean(dev, name, B):
     """fbbev_pool_zmean_split (every Z plane of a pixel tile its own workgroup + ordered reduce; FBViewTransform's default for
-    grids with few tiles, fbocc.py:359) against fbbev_pool_zmean (one fmaf chain through all planes of a pillar; the split form sums
-    per-plane chains in Z order: another association of the same fp32 sum, include/fbbev.h) -- <= 1e-6 of the volume scale apart,
-    bit-identical run to run -- and both within 1e-5 of the volume scale of the mean over Z of the ORACLE's pooled volume
-    (oracle/fbbev_oracle.c, the reference kernel's fmaf chain per voxel)."""
+    grids with few tiles, fbocc.py:359) against fbbev_pool_zmean: with one plane per group (z_groups = Z, the module's choice) the
+    SAME BITS -- both add the per-plane fmaf chains of a pillar to a running sum in Z order --, with several planes per group another
+    association of that sum (<= 1e-6 of the volume scale apart); bit-identical run to run; and both within 1e-5 of the volume scale
+    of the mean over Z of the ORACLE's pooled volume (oracle/fbbev_oracle.c, the reference kernel's fmaf chain per voxel)."""
     from fb_bev_amd import _capi, synthetic as S
     from fb_bev_amd.view_transformer import LSSViewTransformerFunction3D
     from oracle import oracle as O
@@ -236,7 +236,7 @@ def test_pool_zmean_split_equals_single_pass_and_oracle_volume_mean(dev, name, B
         err = (split.cpu().double() - exp).abs().max().item()
         _say(f'fbbev_pool_zmean_split [{name} B={B}, z_groups {zg} of Z={Z}]: max|split - single pass| = {d:.3e}, max|err| vs mean_z(oracle '
              f'volume) = {err:.3e} (single pass {err1:.3e}; volume scale {scale:.2f})')
-        assert d <= 1e-6 * scale and err <= 1e-5 * scale, (zg, d, err)
+        assert err <= 1e-5 * scale and (d == 0.0 if zg == Z else d <= 1e-6 * scale), (zg, d, err)      # one plane per group: the same bits
     # the module's own route (split form for grids with <= 1 024 tiles) stays inside the same bar
     assert (vt.pooled_zmean(parts).cpu().double() - exp).abs().max().item() <= 1e-5 * scale
 
