@@ -536,11 +536,14 @@ def run_forward(args):
         tws16 = v16._tile_ws(dev, B, tv16)
         out16 = torch.empty((B, C, Z, Y, X), dtype=torch.bfloat16, device=dev)
         ev16 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        ft16 = None
 
         def step16(i=None):
             ix = v16.build_index_from_cams(*cam)
             ft = _capi.nchw_to_nhwc(ctx)
             _capi.pool_tile_index(ix.interval_rank, ix.interval_starts, ix.counts, ix.n, B, Z, Y, X, tws16, tv16)
+            nonlocal ft16
+            ft16 = ft
             if i is not None:
                 ev16[i][0].record()
             _capi.bev_pool_v2_dense_fwd(depth, ft, ix.ranks_depth, ix.ranks_feat, ix.interval_rank, ix.interval_starts,
@@ -561,10 +564,32 @@ def run_forward(args):
         ab16 = 4 * B * cfg.n_cams * cfg.D * cfg.feat_hw[0] * cfg.feat_hw[1] + 4 * B * cfg.n_cams * cfg.feat_hw[0] * cfg.feat_hw[1] * C + \
             4 * (3 * P16 + 2 * I16) + 2 * B * Z * Y * X * C
         same = torch.equal(out16, out.to(torch.bfloat16))           # == the fp32 volume rounded once
+        # the bf16 instantiation's own floors: stores alone / all but the gathers / all but the stores
+        fl16_ms = {}
+        scratch16 = torch.empty_like(out16)
+        for mode, name in ((1, 'store_floor_ms'), (2, 'no_gather_ms'), (3, 'no_store_ms')):
+            try:
+                ts = []
+                for it in range(12):
+                    a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a_.record()
+                    _capi.diag_pool_store_floor(depth, ft16, ix16.ranks_depth, ix16.ranks_feat,
+                                                ix16.interval_rank, ix16.interval_starts, ix16.interval_lengths, B, C, Z, Y, X,
+                                                scratch16, tws16, tv16, fl16, mode)
+                    b_.record()
+                    torch.cuda.synchronize(dev)
+                    if it >= 2:
+                        ts.append(a_.elapsed_time(b_))
+                fl16_ms[name] = sum(ts) / len(ts)
+            except _capi.FbbevError:
+                fl16_ms[name] = None
+        del scratch16
         alt = {'volume_storage': 'bf16', 'accumulate_dtype': 'f32', 'value': B * args.steps / t16, 'unit': 'samples/s',
                'ms_per_step': 1e3 * t16 / args.steps, 'tile_voxels': tv16, 'kernel_ms': k16,
                'algorithmic_bytes_per_launch': ab16, 'roofline_frac': ab16 / (k16 * 1e-3) / 1e9 / HBM_PEAK_GBS if k16 > 0 else None,
-               'equals_fp32_volume_rounded_once': bool(same)}
+               'equals_fp32_volume_rounded_once': bool(same), 'store_floor_ms': fl16_ms.get('store_floor_ms'),
+               'no_gather_ms': fl16_ms.get('no_gather_ms'), 'no_store_ms': fl16_ms.get('no_store_ms'),
+               'store_floor_over_kernel': (fl16_ms['store_floor_ms'] / k16) if fl16_ms.get('store_floor_ms') and k16 > 0 else None}
         del out16, tws16, v16
 
     # Extra leg (reported beside `value`, not as it): consecutive batches on alternating HIP streams, each with its own index
@@ -650,7 +675,7 @@ def run_forward(args):
     if args.storage == 'f32':
         feat_f = _capi.nchw_to_nhwc(ctx)
         scratch = torch.empty_like(out)
-        for mode, name in ((1, 'store_floor_ms'), (2, 'no_gather_ms')):
+        for mode, name in ((1, 'store_floor_ms'), (2, 'no_gather_ms'), (3, 'no_store_ms')):
             try:
                 ts = []
                 for it in range(12):
@@ -717,9 +742,10 @@ def run_forward(args):
                          'algorithmic_bytes_per_launch': algo_bytes, 'kernel_ms': kern_ms,
                          'device_fill_GBps': fill_gbs, 'frac_of_device_fill': achieved / fill_gbs if fill_gbs > 0 else None,
                          'store_floor_ms': floors.get('store_floor_ms'), 'no_gather_ms': floors.get('no_gather_ms'),
+                         'no_store_ms': floors.get('no_store_ms'),
                          'store_floor_over_kernel': (floors['store_floor_ms'] / kern_ms) if floors.get('store_floor_ms') and kern_ms > 0 else None,
                          'store_floor_what': 'the same k_pool_fwd_dense2 instantiation, grid, tile walk, XCD order and sc1-nt stores with the gathers '
-                                             'compiled out (store_floor_ms: stores alone; no_gather_ms: metadata + index staging + LDS tile + stores), '
+                                             'compiled out (store_floor_ms: stores alone; no_gather_ms: metadata + index staging + LDS tile + stores; no_store_ms: everything but the stores), '
                                              'mean HIP-event time per launch, measured after the timed region'},
         }
         if alt is not None:

@@ -68,6 +68,8 @@ SIGNATURES = {
                                         c_float, c_void_p, c_int64, c_void_p]),
     'fbbev_rows_ffn_x3': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int64,
                                   c_void_p, c_void_p, c_float, c_void_p, c_int64, c_void_p]),
+    'fbbev_rows_tail_ffn_x3': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_void_p]),
     'fbbev_rows_linear_x3_planes': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'fbbev_da_cross_attn_fused_supported': (c_int, [c_int] * 10),
     'fbbev_da_cross_attn_fused': (c_int, [c_void_p] * 8 + [c_int64, c_void_p, c_int64, c_int64] + [c_void_p] * 4 + [c_int] * 10 +
@@ -107,6 +109,7 @@ SIGNATURES = {
     'fbbev_da_cross_attn_fwd_e': (c_int, [c_void_p] * 9 + [c_int] * 10 + [c_float, c_float, c_int, c_int, c_int] + [c_void_p, c_void_p]),
     'fbbev_da_cross_attn_bwd': (c_int, [c_void_p] * 10 + [c_int] * 10 + [c_float, c_float, c_int, c_int] + [c_void_p] * 5),
     'fbbev_da_cross_attn_bwd_ws_bytes': (c_size_t, [c_int] * 9 + [c_void_p]),
+    'fbbev_da_cross_attn_bwd_ws_bytes_za': (c_size_t, [c_int] * 10 + [c_void_p]),
     'fbbev_da_cross_attn_bwd_ws': (c_int, [c_void_p] * 10 + [c_int] * 10 + [c_float, c_float, c_int, c_int] + [c_void_p] * 4 +
                                    [c_void_p, c_void_p, c_size_t, c_void_p]),
     'fbbev_da_cross_attn_bwd_ws_grid': (c_int, [c_void_p] * 10 + [c_int] * 10 + [c_float, c_float, c_int, c_int] + [c_void_p] * 4 +
@@ -446,16 +449,18 @@ def bev_pool_v2_dense_fwd(depth, feat, ranks_depth, ranks_feat, interval_rank, i
 
 def diag_pool_store_floor(depth, feat, ranks_depth, ranks_feat, interval_rank, interval_starts, interval_lengths, B, C, Z, Y, X,
                           out, tile_ws, tile_voxels, flags, mode):
-    """Measurement aid (never on the product path): the default fp32 dense-kernel instantiation with its gathers compiled
-    out -- mode 1 the store pattern alone, mode 2 all but the depth / feature gathers.  `out` receives zeros."""
-    if tuple(out.shape) != (B, C, Z, Y, X) or not out.is_contiguous() or out.dtype != F32:
-        raise FbbevError('out must be a contiguous (B,C,Z,Y,X) float32 tensor')
+    """Measurement aid (never on the product path): the default fp32 (or, for a bfloat16 `out`, bf16-storage) dense-kernel
+    instantiation with parts compiled out -- mode 1 the store pattern alone, mode 2 all but the depth / feature gathers, mode 3 all
+    but the stores.  `out` receives zeros (mode 3: untouched)."""
+    if tuple(out.shape) != (B, C, Z, Y, X) or not out.is_contiguous() or out.dtype not in (F32, torch.bfloat16):
+        raise FbbevError('out must be a contiguous (B,C,Z,Y,X) float32 / bfloat16 tensor')
+    flags = (int(flags) & ~(POOL_OUT_BF16 | POOL_OUT_F16)) | (POOL_OUT_BF16 if out.dtype == torch.bfloat16 else 0)
     with _on(depth):
         _check(lib().fbbev_diag_pool_store_floor(
             _dev(depth, F32, 'depth'), _dev(feat, F32, 'feat'), _dev(ranks_depth, I32, 'ranks_depth'),
             _dev(ranks_feat, I32, 'ranks_feat'), _dev(interval_rank, I32, 'interval_rank'),
             _dev(interval_starts, I32, 'interval_starts'), _dev(interval_lengths, I32, 'interval_lengths'),
-            B, C, Z, Y, X, _dev(out, F32, 'out'), c_void_p(tile_ws.data_ptr()), tile_ws.numel() * tile_ws.element_size(),
+            B, C, Z, Y, X, c_void_p(out.data_ptr()), c_void_p(tile_ws.data_ptr()), tile_ws.numel() * tile_ws.element_size(),
             int(tile_voxels), int(flags), int(mode), _stream()), 'fbbev_diag_pool_store_floor')
 
 
@@ -628,8 +633,11 @@ def _level_hw(level_hw, L):
     return (c_int32 * len(flat))(*flat)
 
 
-def da_cross_attn_bwd_ws_bytes(B, Ncam, S, M, Dh, Q, HS, L, P, level_hw=None):
+def da_cross_attn_bwd_ws_bytes(B, Ncam, S, M, Dh, Q, HS, L, P, level_hw=None, Za=None):
+    """Za given: the size of the route a launch with that many Z anchors takes; None: the maximum over both LDS-plane routes."""
     arr = _level_hw(level_hw, L)
+    if Za is not None:
+        return lib().fbbev_da_cross_attn_bwd_ws_bytes_za(B, Ncam, S, M, Dh, Q, HS, L, P, int(Za), arr)
     return lib().fbbev_da_cross_attn_bwd_ws_bytes(B, Ncam, S, M, Dh, Q, HS, L, P, arr)
 
 
@@ -657,8 +665,10 @@ def da_cross_attn_bwd(value, spatial_shapes, level_start_index, pred_depth, ref_
         # value gradient through fixed-point LDS planes when the shape fits (fbbev_da_cross_attn_bwd_ws: output-owned planes + hit
         # lists, or query chunks + partial planes for small launches), else the global-atomic kernel
         arr = _level_hw(level_hw, L)
-        need = lib().fbbev_da_cross_attn_bwd_ws_bytes(B, Ncam, S, M, Dh, Q, HS, L, P, arr) if lds_planes else 0
+        need = lib().fbbev_da_cross_attn_bwd_ws_bytes_za(B, Ncam, S, M, Dh, Q, HS, L, P, Za, arr) if lds_planes else 0
         if need:
+            if any(t.data_ptr() % 8 for t in (offsets, grad_offsets, grad_slots)):       # the owned route's alignment: size for both
+                need = max(need, lib().fbbev_da_cross_attn_bwd_ws_bytes(B, Ncam, S, M, Dh, Q, HS, L, P, arr))
             ws = torch.empty(need // 4, dtype=torch.float32, device=value.device)
             _check(lib().fbbev_da_cross_attn_bwd_ws_grid(*args, arr, ws.data_ptr(), need, int(bev_w or 0), _stream()),
                    'fbbev_da_cross_attn_bwd_ws_grid')
@@ -914,6 +924,31 @@ def rows_ffn_x3(x, w1_fragments, b1, w2_fragments, b2, hidden, out_features, res
             _dev(ln_weight, F32, 'ln_weight') if ln_weight is not None else None,
             _dev(ln_bias, F32, 'ln_bias') if ln_bias is not None else None, float(eps), _dev(out, F32, 'out'), out.stride(0), _stream()),
             'fbbev_rows_ffn_x3')
+    return out
+
+
+def rows_tail_ffn_x3_supported(x, residual0, embed, hidden):
+    """shapes / alignment fbbev_rows_tail_ffn_x3 takes (probe the pointers too, a storage-offset view takes the fallback)"""
+    def ok(t):
+        return (t.is_cuda and t.dtype == F32 and t.dim() == 2 and t.shape[1] == embed and t.stride(1) == 1 and t.stride(0) % 4 == 0 and
+                t.data_ptr() % 16 == 0)
+    return embed % 16 == 0 and embed <= 80 and hidden % 64 == 0 and ok(x) and (residual0 is None or (ok(residual0) and residual0.shape == x.shape))
+
+
+def rows_tail_ffn_x3(x, w0_fragments, b0, residual0, ln0_weight, ln0_bias, ln0_eps, w1_fragments, b1, w2_fragments, b2, hidden,
+                     ln1_weight, ln1_bias, ln1_eps):
+    """LayerNorm1(y1 + W2 relu(W1 y1 + b1) + b2) with y1 = LayerNorm0(x W0^T + b0 [+ residual0]) in one kernel
+    (fbbev_rows_tail_ffn_x3): x (R, E) attention slots, residual0 (R, E) rows; out (R, E)."""
+    R, E = x.shape
+    out = torch.empty((R, E), dtype=F32, device=x.device)
+    with _on(x):
+        _check(lib().fbbev_rows_tail_ffn_x3(
+            _dev(x, F32, 'x', contiguous=False), x.stride(0), w0_fragments.data_ptr(), _dev(b0, F32, 'b0'),
+            _dev(residual0, F32, 'residual0', contiguous=False) if residual0 is not None else None,
+            residual0.stride(0) if residual0 is not None else 0, _dev(ln0_weight, F32, 'ln0_weight'), _dev(ln0_bias, F32, 'ln0_bias'),
+            float(ln0_eps), w1_fragments.data_ptr(), _dev(b1, F32, 'b1'), w2_fragments.data_ptr(), _dev(b2, F32, 'b2'), R, E, int(hidden),
+            _dev(ln1_weight, F32, 'ln1_weight'), _dev(ln1_bias, F32, 'ln1_bias'), float(ln1_eps), _dev(out, F32, 'out'), out.stride(0),
+            _stream()), 'fbbev_rows_tail_ffn_x3')
     return out
 
 

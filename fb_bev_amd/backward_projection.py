@@ -156,7 +156,7 @@ class FFN(nn.Module):
         l1, l2 = real[0][0], real[1]
         I, H, O = l1.in_features, l1.out_features, l2.out_features
         if not (x3_ok(x, I, H) and I <= 96 and H % 64 == 0 and O <= 80 and O % 4 == 0 and l1.bias is not None and l2.bias is not None
-                and x.is_contiguous()):
+                and x.is_contiguous() and x.data_ptr() % 16 == 0):     # a misaligned view takes the two-GEMM fallback
             return None
         res = None
         if self.add_identity:
@@ -164,6 +164,8 @@ class FFN(nn.Module):
             if res.dtype != torch.float32 or res.shape[:-1] != x.shape[:-1] or res.shape[-1] != O:
                 return None
             res = res.contiguous().reshape(-1, O)
+            if res.data_ptr() % 16 != 0:
+                return None
         fuse_norm = defer and norm is not None and self.add_identity and _RL.ln_fusable(norm, None, x, O)
         if defer and not fuse_norm and self.add_identity:
             res_arg, tail = None, (x if identity is None else identity)      # the caller's LayerNorm adds the residual itself
@@ -181,6 +183,22 @@ class FFN(nn.Module):
         if defer:
             return y, tail
         return y
+
+    def fused_tail_spec(self, E):
+        """(W1 fragments, W2 fragments, hidden width) when this FFN is the shape fbbev_rows_tail_ffn_x3 runs behind an attention
+        block's tail -- Linear(E, H) + ReLU, Linear(H, E), add_identity, H % 64 == 0, E % 16 == 0, E <= 80 -- else None."""
+        real = [l for l in self.layers if not isinstance(l, nn.Dropout)]
+        if not (FUSE_TAIL_FFN and FUSE_FFN and self.add_identity and len(real) == 2 and isinstance(real[0], nn.Sequential)
+                and isinstance(real[0][0], Linear) and isinstance(real[0][1], nn.ReLU) and isinstance(real[1], Linear)):
+            return None
+        l1, l2 = real[0][0], real[1]
+        if (l1.in_features != E or l2.out_features != E or l2.in_features != l1.out_features or l1.out_features % 64 != 0 or
+                E % 16 != 0 or E > 80 or l1.bias is None or l2.bias is None or not l1.weight.is_cuda):
+            return None
+        for lin in (l1, l2):
+            if not hasattr(lin, '_x3'):
+                lin._x3 = X3Weights()
+        return l1._x3.get(l1.weight, l1.bias), l2._x3.get(l2.weight, l2.bias), l1.out_features
 
     def forward(self, x, identity=None, _defer_residual=False, _norm=None):
         if torch.is_grad_enabled() or self.training:
@@ -481,7 +499,9 @@ class FusedDACrossAttention(torch.autograd.Function):
         Ncam, Za = mask.shape[0], mask.shape[3]
         L, P = (attn.shape[2], attn.shape[3]) if head_minor & 2 else (attn.shape[3], attn.shape[4])
         if (value.is_cuda and level_hw is not None and min(int(w) for _, w in level_hw) >= 2 and
-                _capi.da_cross_attn_fwd_planes_supported(B, Ncam, value.shape[1], M, Dh, L, Q, P, Za)):
+                _capi.da_cross_attn_fwd_planes_supported(B, Ncam, value.shape[1], M, Dh, L, Q, P, Za) and
+                # the entry wants 16-byte aligned records / 4-byte aligned mask words; a storage-offset view takes the row kernel
+                ref_cam.data_ptr() % 16 == 0 and qdepth.data_ptr() % 16 == 0 and mask.data_ptr() % 4 == 0):
             # round 4: the sampler's mapping for the training forward too -- tokens as head planes, a wave = one head of an
             # 8 x 8 patch of queries (k_da_fwd_planes); the row kernel stays for every other shape
             planes = _capi.value_rows_to_head_planes(value, head_dim=Dh, interleaved=bool(head_minor & 4))
@@ -520,6 +540,7 @@ def _pad_interleave_rows(w, b, M, Dh, HS, interleave=True, piece=4):
 
 import os as _os
 FUSE_FFN = _os.environ.get('FBBEV_FUSE_FFN', '1') != '0'               # the FFN pair as one kernel (fbbev_rows_ffn_x3; A/B knob)
+FUSE_TAIL_FFN = _os.environ.get('FBBEV_FUSE_TAIL_FFN', '1') != '0'   # cross-attention tail + FFN block as one kernel (fbbev_rows_tail_ffn_x3; A/B knob)
 FUSE_OUT_NORM = _os.environ.get('FBBEV_FUSE_OUT_NORM', '1') != '0'     # output_proj / FFN tail + residual + LayerNorm in one kernel (A/B knob)
 FUSE_ATTN_TAIL = _os.environ.get('FBBEV_FUSE_ATTN_TAIL', '1') != '0'   # ... inside the attention kernel's own workgroups (A/B knob)
 FUSE_ATTN_TAIL_DA = _os.environ.get('FBBEV_FUSE_ATTN_TAIL_DA', '0') != '0'   # the same for the cross-attention (needs its 8-heads-per-workgroup form)
@@ -720,7 +741,7 @@ class DA_SpatialCrossAttention(nn.Module):
     def forward(self, query, key, value, residual=None, query_pos=None, key_padding_mask=None, reference_points=None,
                 spatial_shapes=None, reference_points_cam=None, level_start_index=None, flag='encoder',
                 bev_query_depth=None, pred_img_depth=None, bev_mask=None, per_cam_mask_list=None, _defer_residual=False,
-                bev_w=0, _norm=None, **kwargs):
+                bev_w=0, _norm=None, _ffn_tail=None, **kwargs):
         if key is None:
             key = query
         if value is None:
@@ -759,6 +780,23 @@ class DA_SpatialCrossAttention(nn.Module):
                    level_start_index, bev_w=bev_w or 0, **kw)  # the BEV row length lets the sampler own 2-D patches of queries
         if tail is not None and tail['done']:
             return slots, _NORMED
+        if tail_ok and _ffn_tail is not None and _RL.X3 and slots.is_cuda and slots.dtype == torch.float32:
+            # round 5: output_proj + residual + norm AND the layer's FFN + residual + norm in ONE kernel (fbbev_rows_tail_ffn_x3):
+            # the block's output rows stay in the wave's registers between the two
+            E = self.embed_dims
+            res = inp_residual.contiguous()
+            c1, c2, H = _ffn_tail['spec']
+            n1 = _ffn_tail['norm1']
+            s2, r2 = slots.reshape(-1, E), res.reshape(-1, E)
+            if (_RL.ln_fusable(_norm, res, slots, E) and _RL.ln_fusable(n1, None, slots, E) and self.output_proj.bias is not None
+                    and _capi.rows_tail_ffn_x3_supported(s2, r2, E, H)):
+                if not hasattr(self.output_proj, '_x3'):
+                    self.output_proj._x3 = X3Weights()
+                oc = self.output_proj._x3.get(self.output_proj.weight, self.output_proj.bias)
+                out = _capi.rows_tail_ffn_x3(s2, oc.frag, oc.b, r2, _norm.weight, _norm.bias, _norm.eps, c1.frag, c1.b, c2.frag, c2.b, H,
+                                             n1.weight, n1.bias, n1.eps)
+                _ffn_tail['done'] = True
+                return out.view(slots.shape), _NORMED
         if tail_ok:
             # output_proj + residual + the layer's following LayerNorm in one kernel (fbbev_rows_linear_x3_ln)
             return self.output_proj(slots, ln=(inp_residual.contiguous(), _norm)), _NORMED
@@ -858,7 +896,11 @@ class BEVFormerEncoderLayer(nn.Module):
         # while it reads the row (three element-wise passes over the BEV queries less per layer; the same fp32 sums)
         defer = not self.pre_norm and not torch.is_grad_enabled() and query.is_cuda
         pending = None
+        skip = 0
         for k, layer in enumerate(ops):
+            if skip:                                      # ops a previous branch already ran inside its own kernel
+                skip -= 1
+                continue
             d = defer and k + 1 < len(ops) and ops[k + 1] == 'norm'
             nk = dict(_norm=self.norms[ni]) if d and FUSE_OUT_NORM else {}      # the branch may run its following norm itself
             if layer == 'self_attn':
@@ -877,6 +919,13 @@ class BEVFormerEncoderLayer(nn.Module):
                 pending = None
                 ni += 1
             elif layer == 'cross_attn':
+                ft = None
+                if nk and FUSE_TAIL_FFN and ops[k + 1:k + 4] == ('norm', 'ffn', 'norm') and fi < len(self.ffns):
+                    # the block's tail and the following FFN block as one row kernel when the attention module can hand over its slots
+                    spec = self.ffns[fi].fused_tail_spec(self.embed_dims) if hasattr(self.ffns[fi], 'fused_tail_spec') else None
+                    if spec is not None:
+                        ft = dict(spec=spec, norm1=self.norms[ni + 1], done=False)
+                        nk = dict(nk, _ffn_tail=ft)
                 query = self.attentions[ai](
                     query, key, value, identity if self.pre_norm else None, query_pos=bev_pos, key_pos=key_pos,
                     reference_points=ref_3d, reference_points_cam=reference_points_cam, spatial_shapes=spatial_shapes,
@@ -887,6 +936,10 @@ class BEVFormerEncoderLayer(nn.Module):
                 if d:
                     query, pending = query
                 identity = query
+                if ft is not None and ft['done']:         # 'norm', 'ffn', 'norm' ran inside the attention block's tail kernel
+                    skip, pending = 3, None
+                    ni += 2
+                    fi += 1
             elif layer == 'ffn':
                 query = self.ffns[fi](query, identity if self.pre_norm else None, _defer_residual=d, **nk)
                 fi += 1

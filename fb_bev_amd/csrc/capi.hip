@@ -848,13 +848,13 @@ extern "C" int fbbev_diag_pool_store_floor(const float* depth, const float* feat
                                            const int32_t* interval_starts, const int32_t* interval_lengths, int B, int C,
                                            int Z, int Y, int X, float* out, const void* tile_ws, size_t tile_ws_bytes,
                                            int tile_voxels, int flags, int mode, fbbev_stream_t stream_) {
-    if (B <= 0 || C <= 0 || Z <= 0 || Y <= 0 || X <= 0 || (mode != 1 && mode != 2)) return FBBEV_E_BADARG;
+    if (B <= 0 || C <= 0 || Z <= 0 || Y <= 0 || X <= 0 || mode < 1 || mode > 3) return FBBEV_E_BADARG;
     if (!depth || !feat || !ranks_depth || !ranks_feat || !interval_rank || !interval_starts || !interval_lengths || !out ||
         !tile_ws) return FBBEV_E_BADARG;
     const long long yx = (long long)Y * X;
-    if (pick_tile(tile_voxels) != 128 || tile_voxels != 128 || yx % 4 != 0 || !aligned16(out) ||
-        (flags & (FBBEV_POOL_CHANNELS_LAST | FBBEV_POOL_OUT_BF16 | FBBEV_POOL_OUT_F16)) ||
-        (long long)B * Z * yx >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
+    const bool bf16 = (flags & FBBEV_POOL_OUT_BF16) != 0;          // round 5: the 16-bit-tile instantiation of the bf16-storage leg
+    if (pick_tile(tile_voxels) != 128 || tile_voxels != 128 || yx % (bf16 ? 8 : 4) != 0 || !aligned16(out) ||
+        (flags & (FBBEV_POOL_CHANNELS_LAST | FBBEV_POOL_OUT_F16)) || (long long)B * Z * yx >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
     const int st = (flags & FBBEV_POOL_STORE_MASK) | ((flags >> FBBEV_POOL_STORE_HI_SHIFT) & 1) << 2;
     int csplit = (flags >> FBBEV_POOL_CSPLIT_SHIFT) & 0xF;
     if (csplit == 0xF) csplit = 20;
@@ -867,7 +867,8 @@ extern "C" int fbbev_diag_pool_store_floor(const float* depth, const float* feat
     if (tile_ws_bytes < (size_t)(n_tiles + 1) * 8) return FBBEV_E_WORKSPACE;
     dense2_args a;
     a.n_blocks = n_tiles * csplit;
-    a.lds = ((size_t)CC * (128 + 4) + 3 * (size_t)128 + 2 * FBBEV_NP_STAGE) * sizeof(float);
+    a.lds = bf16 ? (size_t)CC * (128 + 8) * 2 + ((size_t)3 * 128 + 2 * FBBEV_NP_STAGE) * sizeof(int)
+                 : ((size_t)CC * (128 + 4) + 3 * (size_t)128 + 2 * FBBEV_NP_STAGE) * sizeof(float);
     a.stream = (fbbev_rt_stream)stream_; a.C = C; a.Z = Z; a.yx = (int)yx; a.tpp = tiles_per_plane; a.csplit = csplit;
     a.swizzle = 0;
     if (flags & FBBEV_POOL_XCD_SWIZZLE) {
@@ -881,11 +882,12 @@ extern "C" int fbbev_diag_pool_store_floor(const float* depth, const float* feat
     a.out = out; a.stride_b = (long long)C * Z * yx; a.stride_c = (long long)Z * yx; a.addend = nullptr;
     long long grid = a.n_blocks;
     if (a.swizzle) { const long long g = 8ll << (a.swizzle - 1); grid = (a.n_blocks + g - 1) / g * g; }
-#define FBBEV_DIAG_DENSE(MODE_)                                                                                          \
-    FBBEV_LAUNCH((k_pool_fwd_dense2<128, 8, 4, 256, 0, false, MODE_>), grid, 256, a.lds, a.stream, a.C, a.Z, a.yx, a.tpp,   \
+#define FBBEV_DIAG_DENSE(OT_, T16_, MODE_)                                                                               \
+    FBBEV_LAUNCH((k_pool_fwd_dense2<128, 8, 4, 256, OT_, T16_, MODE_>), grid, 256, a.lds, a.stream, a.C, a.Z, a.yx, a.tpp, \
                  a.csplit, (int)a.n_blocks, a.swizzle, a.stride_b, a.stride_c, a.depth, a.feat, a.rd, a.rf, a.irank,      \
                  a.starts, a.lengths, a.tile_meta, a.addend, a.out)
-    if (mode == 1) FBBEV_DIAG_DENSE(1); else FBBEV_DIAG_DENSE(2);
+    if (bf16) { if (mode == 1) FBBEV_DIAG_DENSE(1, true, 1); else if (mode == 2) FBBEV_DIAG_DENSE(1, true, 2); else FBBEV_DIAG_DENSE(1, true, 3); }
+    else { if (mode == 1) FBBEV_DIAG_DENSE(0, false, 1); else if (mode == 2) FBBEV_DIAG_DENSE(0, false, 2); else FBBEV_DIAG_DENSE(0, false, 3); }
 #undef FBBEV_DIAG_DENSE
     return fbbev_rt_last_error();
 }
@@ -1042,6 +1044,28 @@ static int pool_zmean_impl(const float* depth, const float* feat, const int32_t*
     if (z_groups > 1 && partial_bytes < (size_t)z_groups * n_out * sizeof(float)) return FBBEV_E_WORKSPACE;
     if (blocks * z_groups >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
     const int* meta = static_cast<const int*>(tile_ws);
+    // round 5: the column form (every plane's metadata at once, a lane group per pixel; the same bits) when the column's slot table
+    // fits -- OPT-IN (FBBEV_ZMEAN_COL=1): built to cut the Z dependent round-trip chains of the plane walk, measured SLOWER at the
+    // BASELINE configs[2] grid, B = 4 (135.7 vs 103.9 us, S3 1.395 vs 1.360 ms: profiles/r05_exp_zmean_col.md -- 54 KB of LDS = 2
+    // workgroups per CU instead of 5, and a lane group's pixels are a serial chain of their own)
+#ifdef FBBEV_TEST_OVERRIDES
+    const bool col_on = [] { const char* e = getenv("FBBEV_ZMEAN_COL"); return e && atoi(e) != 0; }();
+#else
+    static const bool col_on = [] { const char* e = getenv("FBBEV_ZMEAN_COL"); return e && atoi(e) != 0; }();   // read once
+#endif
+    const size_t lds_col = fbbev_zmean_col_lds_bytes(CC, TV, Z);
+    if (col_on && z_groups == 1 && Z <= 64 && lds_col <= 64 * 1024) {
+#define FBBEV_ZMEAN_COL(TV_, CPL_)                                                                                   \
+    FBBEV_LAUNCH((k_pool_zmean_col<TV_, CPL_, 256>), blocks, 256, lds_col, (fbbev_rt_stream)stream_, C, Z, (int)yx,   \
+                 tiles_per_plane, csplit, (int)blocks, depth, feat, ranks_depth, ranks_feat, interval_rank,          \
+                 interval_starts, interval_lengths, meta, out_mean)
+        if (TV == 64) { if (cpl8) FBBEV_ZMEAN_COL(64, 8); else FBBEV_ZMEAN_COL(64, 4); }
+        else if (TV == 128) { if (cpl8) FBBEV_ZMEAN_COL(128, 8); else FBBEV_ZMEAN_COL(128, 4); }
+        else { if (cpl8) FBBEV_ZMEAN_COL(256, 8); else FBBEV_ZMEAN_COL(256, 4); }
+#undef FBBEV_ZMEAN_COL
+        FBBEV_CHECK_LAUNCH();
+        return 0;
+    }
 #define FBBEV_ZMEAN(TV_, CPL_)                                                                                       \
     FBBEV_LAUNCH((k_pool_zmean<TV_, CPL_, 256>), blocks * z_groups, 256, lds, (fbbev_rt_stream)stream_, C, Z, (int)yx, \
                  tiles_per_plane, csplit, (int)blocks, depth, feat, ranks_depth, ranks_feat, interval_rank,          \
@@ -1486,7 +1510,16 @@ static int da_cross_attn_fused_impl(const float* planes, const int64_t* spatial_
     const long long wgs = (long long)B * ((bev_w + 7) / 8) * ((Q / bev_w + 7) / 8) * (8 / hw);
     const long long grid = (wgs + 7) / 8 * 8;
     if (grid >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
-    const size_t lds = fbbev_daf_lds_bytes(E, hw, Ncam);
+    // round 5: floats of a wave's LDS staging region for coarse levels (the 8 x 22 level of BASELINE configs[2] at Dh = 10: 1 760);
+    // a level that fits is sampled from LDS instead of through the vector L1.  FBBEV_DA_FUSED_STAGE=0 turns it off (A/B knob)
+    auto read_stage = [] { const char* e = getenv("FBBEV_DA_FUSED_STAGE"); const int v = e ? atoi(e) : 1760; return v < 0 ? 0 : (v > 8192 ? 8192 : v); };
+#ifdef FBBEV_TEST_OVERRIDES
+    const int stage_floats = read_stage();
+#else
+    static const int stage_floats = read_stage();
+#endif
+    const size_t lds = fbbev_daf_lds_bytes(E, hw, Ncam, stage_floats);
+    if (lds > 160 * 1024) return FBBEV_E_UNSUPPORTED;
 #define FBBEV_DA_FUSED(DH_, NP_, HW_) FBBEV_DA_FUSED2(DH_, NP_, HW_, false)
 #define FBBEV_DA_FUSED2(DH_, NP_, HW_, OP_)                                                                            \
     do {                                                                                                               \
@@ -1496,17 +1529,16 @@ static int da_cross_attn_fused_impl(const float* planes, const int64_t* spatial_
                      level_start_index, pred_depth, ref_cam, mask, qdepth, query, query_row_stride, addend,           \
                      addend_row_stride, addend_period, static_cast<const unsigned short*>(offsets_fragments),         \
                      offsets_bias, static_cast<const unsigned short*>(attn_fragments), attn_bias, B, Ncam, S, L, Q,    \
-                     bev_w, DC, d0, dstep, slots, op);                                                                 \
+                     bev_w, DC, d0, dstep, slots, op, stage_floats);                                                   \
     } while (0)
-    static const int np = [] { const char* e = getenv("FBBEV_DA_FUSED_NP"); return e ? atoi(e) : 2; }();   // samples in flight per lane (tuning knob, read once)
+    // (three samples in flight per lane -- FBBEV_DA_FUSED_NP=3 in round 4 -- measured no gain and, with the staged levels' second
+    // sample loop, no longer fits the register file: the instantiations are gone, two in flight is the form)
     if (op.w_frag) {
         if (Dh == 10) FBBEV_DA_FUSED2(10, 2, 8, true); else FBBEV_DA_FUSED2(8, 2, 8, true);
     } else if (hw == 8) {
-        if (Dh == 10) { if (np == 3) FBBEV_DA_FUSED(10, 3, 8); else FBBEV_DA_FUSED(10, 2, 8); }
-        else { if (np == 3) FBBEV_DA_FUSED(8, 3, 8); else FBBEV_DA_FUSED(8, 2, 8); }
+        if (Dh == 10) FBBEV_DA_FUSED(10, 2, 8); else FBBEV_DA_FUSED(8, 2, 8);
     } else {
-        if (Dh == 10) { if (np == 3) FBBEV_DA_FUSED(10, 3, 4); else FBBEV_DA_FUSED(10, 2, 4); }
-        else { if (np == 3) FBBEV_DA_FUSED(8, 3, 4); else FBBEV_DA_FUSED(8, 2, 4); }
+        if (Dh == 10) FBBEV_DA_FUSED(10, 2, 4); else FBBEV_DA_FUSED(8, 2, 4);
     }
 #undef FBBEV_DA_FUSED
 #undef FBBEV_DA_FUSED2
@@ -1971,10 +2003,27 @@ extern "C" size_t fbbev_da_cross_attn_bwd_ws_bytes(int B, int Ncam, int S, int M
     da_bwd_plan pl;
     const int HS = head_stride == 0 ? Dh : head_stride;
     if (HS < Dh) return 0;
-    da_own_plan op;       // Za is not an argument here: the table stride covers Za <= 7, the launch checks it
-    if (da_own_plan_make(B, Ncam, S, M, Dh, Q, HS, num_levels, num_points, 1, level_hw_host, &op)) return op.ws;
-    if (!da_bwd_tile_plan(B, Ncam, S, M, Dh, Q, HS, num_levels, num_points, level_hw_host, &pl)) return 0;
-    return pl.ws;
+    // Za is not an argument here (the owned plan needs Za <= 4 and word-aligned records, which only the launch can check): the
+    // size covers BOTH routes, so a launch whose owned plan fails still finds room for the chunked LDS planes instead of falling
+    // back to global atomics
+    da_own_plan op;
+    const size_t own = da_own_plan_make(B, Ncam, S, M, Dh, Q, HS, num_levels, num_points, 1, level_hw_host, &op) ? op.ws : 0;
+    const size_t tile = da_bwd_tile_plan(B, Ncam, S, M, Dh, Q, HS, num_levels, num_points, level_hw_host, &pl) ? pl.ws : 0;
+    return own > tile ? own : tile;
+}
+
+// The same query with the number of Z anchors the launch will see: exactly the size of the route that launch takes (owned planes
+// when their plan holds for this Za, the chunked planes otherwise) instead of the maximum over both.
+extern "C" size_t fbbev_da_cross_attn_bwd_ws_bytes_za(int B, int Ncam, int S, int M, int Dh, int Q, int head_stride, int num_levels,
+                                                      int num_points, int num_z_anchors, const int32_t* level_hw_host) {
+    if (B <= 0 || Ncam <= 0 || S <= 0 || M <= 0 || Dh <= 0 || num_levels <= 0 || num_points <= 0 || num_z_anchors <= 0) return 0;
+    const int HS = head_stride == 0 ? Dh : head_stride;
+    if (HS < Dh) return 0;
+    da_own_plan op;
+    if (num_points % num_z_anchors == 0 &&
+        da_own_plan_make(B, Ncam, S, M, Dh, Q, HS, num_levels, num_points, num_z_anchors, level_hw_host, &op)) return op.ws;
+    da_bwd_plan pl;
+    return da_bwd_tile_plan(B, Ncam, S, M, Dh, Q, HS, num_levels, num_points, level_hw_host, &pl) ? pl.ws : 0;
 }
 
 // (A) of both LDS-plane backward routes: unit-owned gradients (offsets / attention / depth distribution), the forward's launch shape
@@ -2802,11 +2851,60 @@ extern "C" int fbbev_rows_ffn_x3(const float* x, long long x_row_stride, const v
         FBBEV_LAUNCH((k_rows_ffn_x3<3, 5, LN_, HC_>), wgs, 256, lds, (fbbev_rt_stream)stream_, x, x_row_stride,          \
                      static_cast<const unsigned short*>(w1_fragments), b1, static_cast<const unsigned short*>(w2_fragments), b2,  \
                      out, out_row_stride, rows, in_features, hidden, out_features, n_kc2, residual, residual_row_stride,     \
-                     ln_weight, ln_bias, ln_eps);                                                                      \
+                     ln_weight, ln_bias, ln_eps, fbbev_ffn_pre{});                                                     \
     } while (0)
     if (hc == 64) { if (ln_weight) FBBEV_FFN(true, 64); else FBBEV_FFN(false, 64); }
     else { if (ln_weight) FBBEV_FFN(true, 32); else FBBEV_FFN(false, 32); }
 #undef FBBEV_FFN
+    FBBEV_CHECK_LAUNCH();
+    return 0;
+}
+
+// The cross-attention block's tail AND the FFN block of the encoder layer in one kernel (round 5):
+//   y1  = LayerNorm0(x W0^T + b0 + residual0)                 output_proj + residual + norm   (bevformer_encoder.py:250-377, ops 'cross_attn', 'norm')
+//   out = LayerNorm1(y1 + W2 relu(W1 y1 + b1) + b2)           mmcv FFN (add_identity) + norm  (ops 'ffn', 'norm')
+// x (rows, E) = the attention slots, residual0 (rows, E) = the block's input rows.  Supported: E in {16, 32, 48, 64, 80}, hidden % 64 == 0.
+extern "C" int fbbev_rows_tail_ffn_x3(const float* x, long long x_row_stride, const void* w0_fragments, const float* b0,
+                                      const float* residual0, long long residual0_row_stride, const float* ln0_weight,
+                                      const float* ln0_bias, float ln0_eps, const void* w1_fragments, const float* b1,
+                                      const void* w2_fragments, const float* b2, long long rows, int embed, int hidden,
+                                      const float* ln1_weight, const float* ln1_bias, float ln1_eps, float* out,
+                                      long long out_row_stride, fbbev_stream_t stream_) {
+    if (rows < 0 || embed <= 0 || hidden <= 0) return FBBEV_E_BADARG;
+    if (rows == 0) return 0;
+    if (!x || !w0_fragments || !b0 || !ln0_weight || !ln0_bias || !w1_fragments || !b1 || !w2_fragments || !b2 || !ln1_weight ||
+        !ln1_bias || !out) return FBBEV_E_BADARG;
+    if (x_row_stride == 0) x_row_stride = embed;
+    if (out_row_stride == 0) out_row_stride = embed;
+    if (residual0 && residual0_row_stride == 0) residual0_row_stride = embed;
+    if (x_row_stride < embed || out_row_stride < embed || (residual0 && residual0_row_stride < embed)) return FBBEV_E_BADARG;
+    if (embed > 80 || embed % 16 != 0 || hidden % FBBEV_FFN_HC != 0 || x_row_stride % 4 != 0 || out_row_stride % 4 != 0 ||
+        !aligned16(x) || !aligned16(out) || !aligned16(w0_fragments) || !aligned16(w1_fragments) || !aligned16(w2_fragments) ||
+        !aligned16(b0) || !aligned16(b1) || !aligned16(b2) || !aligned16(ln0_weight) || !aligned16(ln0_bias) || !aligned16(ln1_weight) ||
+        !aligned16(ln1_bias) || (residual0 && (residual0_row_stride % 4 != 0 || !aligned16(residual0)))) return FBBEV_E_UNSUPPORTED;
+    const long long wgs = (rows + 127) / 128;
+    if (wgs >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
+#ifdef FBBEV_TEST_OVERRIDES
+    const int hc = [] { const char* e = getenv("FBBEV_TAIL_FFN_HC"); return e ? atoi(e) : 32; }();
+#else
+    static const int hc = [] { const char* e = getenv("FBBEV_TAIL_FFN_HC"); return e ? atoi(e) : 32; }();   // tuning knob, read once
+#endif
+    const int n_kc2 = (hidden + 127) / 128;
+    fbbev_ffn_pre pre;
+    pre.w0f = static_cast<const unsigned short*>(w0_fragments); pre.b0 = b0; pre.res0 = residual0; pre.ld_res0 = residual0_row_stride;
+    pre.ln0_w = ln0_weight; pre.ln0_b = ln0_bias; pre.eps0 = ln0_eps;
+#define FBBEV_TFFN(HC_)                                                                                                \
+    do {                                                                                                              \
+        const size_t lds = (size_t)fbbev_ffn_pre_lds_bytes<3, 5, HC_>();                                               \
+        int e = fbbev_rt_allow_dyn_lds((const void*)k_rows_ffn_x3<3, 5, true, HC_, true>, lds);                        \
+        if (e) return e;                                                                                              \
+        FBBEV_LAUNCH((k_rows_ffn_x3<3, 5, true, HC_, true>), wgs, 256, lds, (fbbev_rt_stream)stream_, x, x_row_stride,   \
+                     static_cast<const unsigned short*>(w1_fragments), b1, static_cast<const unsigned short*>(w2_fragments), b2, \
+                     out, out_row_stride, rows, embed, hidden, embed, n_kc2, (const float*)nullptr, (long long)0, ln1_weight,  \
+                     ln1_bias, ln1_eps, pre);                                                                         \
+    } while (0)
+    if (hc == 64) FBBEV_TFFN(64); else FBBEV_TFFN(32);
+#undef FBBEV_TFFN
     FBBEV_CHECK_LAUNCH();
     return 0;
 }

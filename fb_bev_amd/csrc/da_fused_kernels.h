@@ -44,8 +44,14 @@
 
 // LDS carve-up (bytes): x fragments | (camera, query) records | per-wave transposition tiles (HW = heads = waves of a workgroup)
 __host__ __device__ inline size_t fbbev_daf_xf_bytes(int E) { return (size_t)4 * ((E + 31) / 32) * 2 * 64 * 16; }
-__host__ __device__ inline size_t fbbev_daf_lds_bytes(int E, int HW, int Ncam) {
-    return fbbev_daf_xf_bytes(E) + (size_t)Ncam * 64 * FBBEV_DAF_QC * 4 + (size_t)HW * 64 * FBBEV_DAF_OS * 4;
+// stage_floats > 0 (round 5): a wave's transposition tile doubles as the staging buffer of a COARSE level's head plane (see the
+// kernel): the per-wave region grows to max(tile, stage_floats) floats
+__host__ __device__ inline int fbbev_daf_wave_region(int stage_floats) {
+    const int t = 64 * FBBEV_DAF_OS;
+    return (((stage_floats > t ? stage_floats : t) + 3) / 4) * 4;
+}
+__host__ __device__ inline size_t fbbev_daf_lds_bytes(int E, int HW, int Ncam, int stage_floats = 0) {
+    return fbbev_daf_xf_bytes(E) + (size_t)Ncam * 64 * FBBEV_DAF_QC * 4 + (size_t)HW * fbbev_daf_wave_region(stage_floats) * 4;
 }
 
 template <int DH>
@@ -64,7 +70,7 @@ __device__ __forceinline__ fbbev_v2f fbbev_daf_pair(const fbbev_v4f (&r)[(2 * DH
     return v;
 }
 
-template <int DH>
+template <int DH, bool LDS = false>
 __device__ __forceinline__ void fbbev_daf_issue(const char* __restrict__ plane, int level_off /* floats */, float h_im, float w_im,
                                                 int sh, int sw, float weight, bool enable, fbbev_daf_pending<DH>& p) {
     const bool live = enable && h_im > -1.f && w_im > -1.f && h_im < (float)sh && w_im < (float)sw;
@@ -86,10 +92,15 @@ __device__ __forceinline__ void fbbev_daf_issue(const char* __restrict__ plane, 
     constexpr int NV = (2 * DH) / 4;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {          // DH = 10: 8-byte aligned 16-byte loads (global memory takes dword-aligned b128)
-        fbbev_v4f t0, t1;
-        __builtin_memcpy(&t0, plane + o0 + 16 * k, 16);
-        __builtin_memcpy(&t1, plane + o1 + 16 * k, 16);
-        p.a[k] = t0; p.b[k] = t1;
+        if constexpr (LDS) {                // the level's plane staged in LDS: no vector-L1 access at all
+            p.a[k] = fbbev_lds_ld_v4f_a8(reinterpret_cast<const float*>(plane + o0 + 16 * k));
+            p.b[k] = fbbev_lds_ld_v4f_a8(reinterpret_cast<const float*>(plane + o1 + 16 * k));
+        } else {
+            fbbev_v4f t0, t1;
+            __builtin_memcpy(&t0, plane + o0 + 16 * k, 16);
+            __builtin_memcpy(&t1, plane + o1 + 16 * k, 16);
+            p.a[k] = t0; p.b[k] = t1;
+        }
     }
 }
 
@@ -256,7 +267,7 @@ k_da_cross_attn_fused(const float* __restrict__ planes, const int64_t* __restric
                       const unsigned short* __restrict__ so_frag, const float* __restrict__ so_bias,
                       const unsigned short* __restrict__ aw_frag, const float* __restrict__ aw_bias,
                       int B, int Ncam, int S, int L, int Q, int bev_w, int DC, float d0, float dstep, float* __restrict__ slots,
-                      fbbev_daf_outproj op) {
+                      fbbev_daf_outproj op, int stage_floats) {
     constexpr int E = MH * DH, KS = (E + 31) / 32, P = FBBEV_DAF_P, ZA = FBBEV_DAF_ZA, NT = 64 * HW, PARTS = MH / HW;
     static_assert(!OP || (HW == MH && E % 16 == 0), "the output_proj + LayerNorm tail needs all heads of a query in one workgroup");
     static_assert((2 * DH) % 4 == 0 && DH % 2 == 0 && E % 8 == 0, "runs of whole 16-byte pieces, channel pairs");
@@ -337,7 +348,7 @@ k_da_cross_attn_fused(const float* __restrict__ planes, const int64_t* __restric
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int m = part * HW + wv;
     const int g = lane >> 4, j = lane & 15;
-    float* off_w = off_all + (size_t)wv * 64 * FBBEV_DAF_OS;
+    float* off_w = off_all + (size_t)wv * fbbev_daf_wave_region(stage_floats);
     fbbev_v4f pacc[4];
     // logits of head m: the 8 logits of (head m, level l) are rows (m*L + l)*8 .. +7 of attention_weights = HALF of one
     // 16-output tile; the tile goes through the wave's transposition tile (the path of the offsets below) and the lane keeps
@@ -421,6 +432,12 @@ k_da_cross_attn_fused(const float* __restrict__ planes, const int64_t* __restric
         const int sh = (int)spatial_shapes[2 * l], sw = (int)spatial_shapes[2 * l + 1];
         const float fsh = (float)sh, fsw = (float)sw;
         const int lvl_off = (int)level_start[l] * DH;
+        // round 5: a level whose head plane fits the wave's staging region (the transposition tile, free between two projections,
+        // + the launcher's extra bytes: 8 x 22 and 4 x 11 tokens at BASELINE configs[2]) is copied into LDS once per hit camera and
+        // sampled from there: ds_read instead of ~22 vector-L1 line accesses per load instruction -- the counter that bounds
+        // this kernel (TCP_TOTAL_CACHE_ACCESSES: 195 M per launch, 0.71 per CU-cycle; profiles/r04_pmc_fb_BL3_B4_final.json)
+        const int lvl_n = sh * sw * DH;                                                      // floats of the level's plane
+        const bool staged = lvl_n <= stage_floats;                                           // uniform
         for (int cam = 0; cam < Ncam; ++cam) {
             const float* rec = my_qc + (size_t)cam * 64 * FBBEV_DAF_QC;
             const bool hit = valid && fbbev_lds_ld_f32(rec + 3 * ZA) != 0.f;
@@ -434,6 +451,34 @@ k_da_cross_attn_fused(const float* __restrict__ planes, const int64_t* __restric
             // NP samples in flight per lane: sample p + NP - 1 is issued before sample p is blended (register slots addressed
             // at compile time: the P samples are unrolled)
             fbbev_daf_pending<DH> pend[NP];
+            if (staged) {
+                const float* src = reinterpret_cast<const float*>(plane) + lvl_off;
+                if ((lvl_n & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {      // uniform
+                    for (int i = lane * 4; i < lvl_n; i += 256) *reinterpret_cast<fbbev_v4f*>(off_w + i) = *reinterpret_cast<const fbbev_v4f*>(src + i);
+                } else {                                                                     // DH is even: 8-byte pieces
+                    for (int i = lane * 2; i < lvl_n; i += 128) *reinterpret_cast<fbbev_v2f*>(off_w + i) = *reinterpret_cast<const fbbev_v2f*>(src + i);
+                }
+                fbbev_wave_sync();
+                const char* lplane = reinterpret_cast<const char*>(off_w);
+                auto start = [&](int p, fbbev_daf_pending<DH>& slot) {
+                    const int z = p % ZA;
+                    const float ox = o4[p >> 1][2 * (p & 1)], oy = o4[p >> 1][2 * (p & 1) + 1];
+                    const float loc_w = rx[z] + __fdiv_rn(ox, fsw), loc_h = ry[z] + __fdiv_rn(oy, fsh);
+                    const float weight = lg[0][p] * dw[z];
+                    fbbev_daf_issue<DH, true>(lplane, 0, loc_h * fsh - 0.5f, loc_w * fsw - 0.5f, sh, sw, weight, hit, slot);
+                };
+#pragma unroll
+                for (int p = 0; p < NP - 1; ++p) start(p, pend[p]);
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    if (p + NP - 1 < P) start(p + NP - 1, pend[(p + NP - 1) % NP]);
+                    fbbev_sched_fence();
+                    fbbev_daf_consume<DH>(pend[p % NP], acc);
+                    fbbev_sched_fence();
+                }
+                fbbev_wave_sync();                                                          // sampled before the next copy / projection overwrites it
+                continue;
+            }
             auto start = [&](int p, fbbev_daf_pending<DH>& slot) {
                 const int z = p % ZA;
                 const float ox = o4[p >> 1][2 * (p & 1)], oy = o4[p >> 1][2 * (p & 1) + 1];

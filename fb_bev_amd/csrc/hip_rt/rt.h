@@ -160,6 +160,12 @@ __device__ __forceinline__ float fbbev_lds_ld_f32(const float* p) {
     return *(const __attribute__((address_space(3))) float*)p;
 }
 __device__ __forceinline__ int fbbev_lds_ld_i32(const int* p) { return *(const __attribute__((address_space(3))) int*)p; }
+// 16 bytes at an 8-byte aligned LDS address (two ds_read_b64 / one ds_read2_b64: head-plane tokens of 10 floats are 8-byte aligned)
+__device__ __forceinline__ fbbev_v4f fbbev_lds_ld_v4f_a8(const float* p) {
+    const __attribute__((address_space(3))) fbbev_v2f* q = (const __attribute__((address_space(3))) fbbev_v2f*)p;
+    const fbbev_v2f a = q[0], b = q[1];
+    return fbbev_v4f{a[0], a[1], b[0], b[1]};
+}
 
 __device__ __forceinline__ void fbbev_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

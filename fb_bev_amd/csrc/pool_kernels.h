@@ -344,7 +344,8 @@ __device__ __forceinline__ unsigned int fbbev_pack2(float lo, float hi) {
 // DIAG (measurement only, bench.py `roofline.store_floor_ms`): 1 = the kernel's STORE pattern alone -- same grid, tile
 // walk, XCD order and `sc1 nt` 16-byte stores, every tile treated as empty (no metadata, no gathers, no LDS); 2 = everything
 // but the depth / feature gathers and their fmaf chains (tile metadata, interval / point-index staging, LDS tile, barriers,
-// stores).  0 = the product kernel; the diagnostic instantiations write zeros and are reachable only through
+// stores); 3 = everything but the stores (metadata, staging, gathers, fmaf chains, LDS tile: what the stores have to hide).
+// 0 = the product kernel; the diagnostic instantiations write zeros (3: nothing) and are reachable only through
 // fbbev_diag_pool_store_floor.
 #define FBBEV_POOL_SPLIT_GROUPS 32     // lane groups a long interval is split over (bounds the extra LDS: 32 x CC floats)
 // SPLIT > 0 (opt-in tolerance mode, FBBEV_POOL_SPLIT_LONG): an interval longer than SPLIT points is summed by ALL lane
@@ -411,6 +412,7 @@ k_pool_fwd_dense2(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_b
     const float* __restrict__ ab = addend ? addend + ((long long)b * C + c0) * YX + v0 : nullptr;
 
     if (i0 == i1) {
+        if constexpr (DIAG == 3) return;                     // gathers alone: an empty tile has none
         fbbev_v4f zero; zero[0] = zero[1] = zero[2] = zero[3] = 0.f;
         if constexpr (OT == 0) {
             for (int idx = tid; idx < n4; idx += NT) {
@@ -521,6 +523,7 @@ k_pool_fwd_dense2(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_b
         }
     }
     __syncthreads();
+    if constexpr (DIAG == 3) return;                         // (the LDS tile writes keep the gathers alive)
 
     if constexpr (OT == 0) {
         for (int idx = tid; idx < n4; idx += NT) {
@@ -780,6 +783,194 @@ k_pool_zmean(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_blocks
     const float zf = z_groups > 1 ? 1.f : (float)Z;
     float* __restrict__ ob = (z_groups > 1 ? partial + (long long)zg * gridDim_stride(n_blocks, csplit, tiles_per_plane) * C * YX : out) +
                              ((long long)b * C + c0) * YX + v0;
+    for (int idx = tid; idx < CC * Q4; idx += NT) {
+        const int c = idx / Q4, j = (idx - c * Q4) * 4;
+        if (j < nv) {
+            fbbev_v4f val = *reinterpret_cast<const fbbev_v4f*>(tile + c * LD + j);
+            val[0] /= zf; val[1] /= zf; val[2] /= zf; val[3] /= zf;
+            *reinterpret_cast<fbbev_v4f*>(ob + (long long)c * YX + j) = val;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- the same Z-mean, a pixel COLUMN at a time (round 5)
+// k_pool_zmean walks the Z planes of its tile one after the other: per plane a dependent chain tile metadata -> interval metadata /
+// point indices -> barrier -> gathers -> barrier, i.e. ~4 memory round trips and 2 barriers times Z (BASELINE configs[2] grid, B = 4:
+// 104 us for 100 MB, waves parked 82 %).  Here the metadata of ALL planes of the tile is fetched at once (Z <= 64 lanes), the
+// intervals of the whole column are scattered into a dense (plane, pixel) slot table in LDS and the point indices of the whole
+// column are staged in one flattened pass; then a lane group OWNS a pixel and walks its Z voxels in ascending order, adding each
+// voxel's in-order fmaf chain to the pixel's running sum -- the summation order of k_pool_zmean (identical bits), 5 barriers and ~3
+// dependent round trips before the gathers instead of ~4 Z.
+#define FBBEV_ZC_CAP 1024                              // point-index pairs of a column staged in LDS (the rest is read from global memory)
+__host__ __device__ inline size_t fbbev_zmean_col_lds_bytes(int CC, int TV, int Z) {
+    return ((size_t)CC * (TV + 4) + 2 * (size_t)Z * TV + 2 * FBBEV_ZC_CAP + 6 * (size_t)(Z + 1)) * 4;
+}
+
+template <int CPL, int U>
+__device__ __forceinline__ void fbbev_interval_sum_staged_n(int c, int s, int len, int p0, const int* __restrict__ prd_lds,
+                                                            const int* __restrict__ prf_lds, int n_staged,
+                                                            const float* __restrict__ depth, const float* __restrict__ fbase,
+                                                            const int* __restrict__ rd, const int* __restrict__ rf, float (&acc)[CPL]) {
+    // fbbev_interval_sum_staged with a run-time number of staged pairs (n_staged >= 0; 0 = everything from global memory)
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) acc[j] = 0.f;
+    const int last = n_staged > 0 ? n_staged - 1 : 0;
+    int k = 0;
+    for (; k + U <= len; k += U) {
+        int pd[U], pf[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = s + k + u;
+            const int il = idx < n_staged ? idx : last;
+            pd[u] = fbbev_lds_ld_i32(prd_lds + il); pf[u] = fbbev_lds_ld_i32(prf_lds + il);
+        }
+        if (s + k + U > n_staged) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = s + k + u;
+                if (idx >= n_staged) { pd[u] = rd[p0 + idx]; pf[u] = rf[p0 + idx]; }
+            }
+        }
+        float d[U];
+        float f[U][CPL];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            d[u] = depth[pd[u]];
+            const float* fp = fbase + (long long)pf[u] * c;
+#pragma unroll
+            for (int q = 0; q < CPL / 4; ++q) {
+                const fbbev_v4f t = *reinterpret_cast<const fbbev_v4f*>(fp + 4 * q);
+                f[u][4 * q] = t[0]; f[u][4 * q + 1] = t[1]; f[u][4 * q + 2] = t[2]; f[u][4 * q + 3] = t[3];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc[j] = fmaf(f[u][j], d[u], acc[j]);
+        }
+    }
+    for (; k < len; ++k) {
+        const int idx = s + k;
+        const int il = idx < n_staged ? idx : last;
+        int pd = fbbev_lds_ld_i32(prd_lds + il), pf = fbbev_lds_ld_i32(prf_lds + il);
+        if (idx >= n_staged) { pd = rd[p0 + idx]; pf = rf[p0 + idx]; }
+        const float d0 = depth[pd];
+        const float* fp = fbase + (long long)pf * c;
+#pragma unroll
+        for (int q = 0; q < CPL / 4; ++q) {
+            const fbbev_v4f t = *reinterpret_cast<const fbbev_v4f*>(fp + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[4 * q + e] = fmaf(t[e], d0, acc[4 * q + e]);
+        }
+    }
+}
+
+template <int TV, int CPL, int NT>
+__global__ void __launch_bounds__(NT)
+k_pool_zmean_col(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_blocks,
+                 const float* __restrict__ depth, const float* __restrict__ feat,
+                 const int* __restrict__ rd, const int* __restrict__ rf,
+                 const int* __restrict__ interval_rank, const int* __restrict__ starts,
+                 const int* __restrict__ lengths, const int* __restrict__ tile_meta, float* __restrict__ out) {
+    constexpr int LD = TV + 4, Q4 = TV / 4;
+    const int CC = C / csplit;
+    float* tile = fbbev_dyn_lds_f32();                           // [CC][LD] running sums of the column's pixels
+    int* slot_s = reinterpret_cast<int*>(tile + CC * LD);        // [Z][TV] first point of the voxel's interval
+    int* slot_l = slot_s + Z * TV;                               // [Z][TV] its length, 0 = empty voxel
+    int* prd = slot_l + Z * TV;                                  // [CAP] staged point indices of the column, plane after plane
+    int* prf = prd + FBBEV_ZC_CAP;
+    int* zi0 = prf + FBBEV_ZC_CAP;                               // per plane: first interval | first point | exclusive prefixes of the
+    int* zp0 = zi0 + (Z + 1);                                    // interval / point counts ([Z] = totals)
+    int* zib = zp0 + (Z + 1);
+    int* zpb = zib + (Z + 1);
+    int* zni = zpb + (Z + 1);
+    int* znp = zni + (Z + 1);
+    const int tid = threadIdx.x;
+    const int bid = blockIdx.x;
+    if (bid >= n_blocks) return;
+    const int tk = bid / csplit, half = bid - tk * csplit;       // tk = b * tiles_per_plane + k
+    const int c0 = half * CC;
+    const int b = tk / tiles_per_plane, k = tk - b * tiles_per_plane;
+    const int v0 = k * TV;
+    const int nv = (YX - v0 < TV) ? (YX - v0) : TV;
+    // P0: tile metadata of every plane (one lane per plane), cleared sums and slots
+    if (tid < Z) {
+        const int t = (b * Z + tid) * tiles_per_plane + k;
+        const int i0 = tile_meta[2 * t], p0 = tile_meta[2 * t + 1], i1 = tile_meta[2 * t + 2], p1 = tile_meta[2 * t + 3];
+        zi0[tid] = i0; zp0[tid] = p0; zni[tid] = i1 - i0; znp[tid] = p1 - p0;
+    }
+    for (int idx = tid; idx < CC * LD; idx += NT) tile[idx] = 0.f;
+    for (int idx = tid; idx < Z * TV; idx += NT) slot_l[idx] = 0;
+    __syncthreads();
+    // P1: exclusive prefixes over the planes (lane z sums the counts below it: Z <= 64 reads, all lanes in parallel)
+    if (tid <= Z) {
+        int a = 0;
+        for (int z = 0; z < tid; ++z) a += zni[z];
+        zib[tid] = a;
+    } else if (tid >= 128 && tid - 128 <= Z) {                   // (Z <= 64 < 128 <= NT - 65: another wave, the same moment)
+        int a = 0;
+        for (int z = 0; z < tid - 128; ++z) a += znp[z];
+        zpb[tid - 128] = a;
+    }
+    __syncthreads();
+    // P2: every interval of the column into its (plane, pixel) slot; the column's point indices into the staging arrays
+    {
+        const int ti = zib[Z];
+        for (int f = tid; f < ti; f += NT) {
+            int lo = 0, hi = Z - 1;                              // the plane of flattened interval f: last z with zib[z] <= f
+            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (zib[mid] <= f) lo = mid; else hi = mid - 1; }
+            const int i = zi0[lo] + (f - zib[lo]);
+            const int v = interval_rank[i] - ((b * Z + lo) * YX + v0);
+            const int st = starts[i], ln = lengths[i];
+            if (v >= 0 && v < nv) { slot_s[lo * TV + v] = st; slot_l[lo * TV + v] = ln; }
+        }
+        int tp = zpb[Z];
+        if (tp > FBBEV_ZC_CAP) tp = FBBEV_ZC_CAP;
+        for (int f = tid; f < tp; f += NT) {
+            int lo = 0, hi = Z - 1;
+            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (zpb[mid] <= f) lo = mid; else hi = mid - 1; }
+            const int p = zp0[lo] + (f - zpb[lo]);
+            prd[f] = rd[p]; prf[f] = rf[p];
+        }
+    }
+    __syncthreads();
+    // P3: a lane group owns a pixel and walks its voxels in ascending z (the order of k_pool_zmean: the same bits)
+    {
+        const int lpi = CC / CPL;
+        const int gpb = NT / lpi;
+        const int g = tid / lpi, slot = tid - g * lpi;
+        if (g < gpb) {
+            const float* fbase = feat + c0 + slot * CPL;
+            for (int v = g; v < nv; v += gpb) {
+                float sum[CPL];
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) sum[j] = 0.f;
+                bool any = false;
+                for (int z = 0; z < Z; ++z) {
+                    const int len = fbbev_lds_ld_i32(slot_l + z * TV + v);
+                    if (len == 0) continue;
+                    const int p0 = zp0[z], pb = zpb[z];
+                    int nst = FBBEV_ZC_CAP - pb;
+                    const int np = znp[z];
+                    nst = nst < 0 ? 0 : (nst > np ? np : nst);
+                    float acc[CPL];
+                    fbbev_interval_sum_staged_n<CPL, 4>(C, fbbev_lds_ld_i32(slot_s + z * TV + v) - p0, len, p0, prd + (nst > 0 ? pb : 0),
+                                                        prf + (nst > 0 ? pb : 0), nst, depth, fbase, rd, rf, acc);
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) sum[j] += acc[j];
+                    any = true;
+                }
+                if (any) {
+                    float* dst = tile + (slot * CPL) * LD + v;
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) dst[j * LD] = sum[j];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const float zf = (float)Z;
+    float* __restrict__ ob = out + ((long long)b * C + c0) * YX + v0;
     for (int idx = tid; idx < CC * Q4; idx += NT) {
         const int c = idx / Q4, j = (idx - c * Q4) * 4;
         if (j < nv) {

@@ -226,16 +226,38 @@ k_rows_linear_x3_fragments(const float* __restrict__ w, int O, int I, int n_oc, 
 template <int KS1, int MT2, int HC>
 __host__ __device__ constexpr int fbbev_ffn_lds_bytes() { return ((HC / 16) * 2 * KS1 + MT2 * 2 * (HC / 32)) * 1024 + 4 * 2 * (HC / 32) * 2 * 1024; }
 
-template <int KS1, int MT2, bool LN, int HC>
-__global__ void __launch_bounds__(256, HC == 32 ? 3 : 2)
+// The attention block's tail in FRONT of the FFN pair (round 5, `PRE`): y1 = LayerNorm0(x0 W0^T + b0 + res0) -- `output_proj` +
+// residual + the layer's norm after the cross-attention, bevformer_encoder.py:250-377 -- computed by the same wave for its 32 rows,
+// kept in registers as the FFN's residual and re-laid out through the wave's hidden-fragment buffer into the B fragments of GEMM 1.
+// Replaces a k_rows_linear_x3<., true> launch and the write + re-read of the (rows, E) tensor between the two kernels.
+struct fbbev_ffn_pre {
+    const unsigned short* w0f;         // output_proj.weight (E, E) as split bf16 fragments (k_rows_linear_x3_fragments)
+    const float* b0;                   // (E)
+    const float* res0;                 // residual rows (rows, ld_res0), may be null
+    long long ld_res0;
+    const float* ln0_w;                // LayerNorm0 weight / bias (E)
+    const float* ln0_b;
+    float eps0;
+};
+// weight region = max(W1 chunk + W2 chunk, the MT2 x KS1 fragments of W0) KB + the four waves' hidden-fragment buffers
+template <int KS1, int MT2, int HC>
+__host__ __device__ constexpr int fbbev_ffn_pre_wregion_kb() {
+    return ((HC / 16) * 2 * KS1 + MT2 * 2 * (HC / 32)) > MT2 * 2 * KS1 ? ((HC / 16) * 2 * KS1 + MT2 * 2 * (HC / 32)) : MT2 * 2 * KS1;
+}
+template <int KS1, int MT2, int HC>
+__host__ __device__ constexpr int fbbev_ffn_pre_lds_bytes() { return fbbev_ffn_pre_wregion_kb<KS1, MT2, HC>() * 1024 + 4 * 2 * (HC / 32) * 2 * 1024; }
+
+template <int KS1, int MT2, bool LN, int HC, bool PRE = false>
+__global__ void __launch_bounds__(256, (HC == 32 && !PRE) ? 3 : 2)
 k_rows_ffn_x3(const float* __restrict__ x, long long ldx, const unsigned short* __restrict__ w1f, const float* __restrict__ b1,
               const unsigned short* __restrict__ w2f, const float* __restrict__ b2, float* __restrict__ out, long long ldo,
               long long rows, int I, int H, int O, int n_kc2, const float* __restrict__ res, long long ld_res,
-              const float* __restrict__ ln_w, const float* __restrict__ ln_b, float ln_eps) {
+              const float* __restrict__ ln_w, const float* __restrict__ ln_b, float ln_eps, fbbev_ffn_pre pre) {
     constexpr int NT = 2, T1 = HC / 16, S2 = HC / 32;
+    constexpr int WREGION = PRE ? fbbev_ffn_pre_wregion_kb<KS1, MT2, HC>() * 512 : (T1 * 2 * KS1 + MT2 * 2 * S2) * 512;   // bf16 elements
     unsigned short* w1s = reinterpret_cast<unsigned short*>(fbbev_dyn_lds_f32());          // [T1][hi|lo][KS1][64][8]
     unsigned short* w2s = w1s + T1 * 2 * KS1 * 512;                                        // [MT2][hi|lo][S2][64][8]
-    unsigned short* hb = w2s + MT2 * 2 * S2 * 512 + (threadIdx.x >> 6) * (NT * S2 * 2 * 512);   // this wave's [t][s2][hi|lo][64][8]
+    unsigned short* hb = w1s + WREGION + (threadIdx.x >> 6) * (NT * S2 * 2 * 512);         // this wave's [t][s2][hi|lo][64][8]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int g = lane >> 4, j = lane & 15;
     const long long r0 = ((long long)blockIdx.x * 4 + wave) * (16 * NT);
@@ -258,6 +280,102 @@ k_rows_ffn_x3(const float* __restrict__ x, long long ldx, const unsigned short* 
             }
         }
     }
+    fbbev_v4f y1[PRE ? MT2 : 1][NT];                                                        // PRE: LayerNorm0's output = the FFN's residual
+    if constexpr (PRE) {
+        // W0's fragments (tiles 0..MT2-1, k-steps 0..KS1-1 of its single K chunk) through the weight region, shared by the 4 waves
+        for (int i = threadIdx.x; i < MT2 * 2 * KS1 * 64; i += 256) {
+            const int ln = i & 63, s = (i >> 6) % KS1, h = (i / (64 * KS1)) & 1, mt = i / (64 * KS1 * 2);
+            const unsigned short* src = pre.w0f + (long long)mt * FBBEV_RL_TILE_ELEMS + h * (FBBEV_RL_TILE_ELEMS / 2) + (s * 64 + ln) * 8;
+            reinterpret_cast<fbbev_v4u*>(w1s)[i] = *reinterpret_cast<const fbbev_v4u*>(src);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < MT2; ++mt)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) y1[mt][t] = fbbev_v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS1; ++s) {
+#pragma unroll
+            for (int mt = 0; mt < MT2; ++mt) {
+                const fbbev_bf16x8 ah = fbbev_ld_bf16x8(w1s + (((mt * 2 + 0) * KS1 + s) * 64 + lane) * 8);
+                const fbbev_bf16x8 al = fbbev_ld_bf16x8(w1s + (((mt * 2 + 1) * KS1 + s) * 64 + lane) * 8);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    y1[mt][t] = fbbev_mfma_f32_16x16x32_bf16(al, xh[s][t], y1[mt][t]);
+                    y1[mt][t] = fbbev_mfma_f32_16x16x32_bf16(ah, xl[s][t], y1[mt][t]);
+                    y1[mt][t] = fbbev_mfma_f32_16x16x32_bf16(ah, xh[s][t], y1[mt][t]);
+                }
+            }
+        }
+        // + b0 + res0 -> LayerNorm0 (two-pass statistics, as k_rows_linear_x3<., true>); the FFN's input width I == W0's output width
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const long long r = r0 + 16 * t + j;
+            const bool live = r < rows;
+            float sm = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MT2; ++mt) {
+                const int o = 16 * mt + 4 * g;
+                if (o < I) {
+                    y1[mt][t] = y1[mt][t] + *reinterpret_cast<const fbbev_v4f*>(pre.b0 + o);
+                    if (pre.res0 && live) y1[mt][t] = y1[mt][t] + *reinterpret_cast<const fbbev_v4f*>(pre.res0 + r * pre.ld_res0 + o);
+                    sm += (y1[mt][t][0] + y1[mt][t][1]) + (y1[mt][t][2] + y1[mt][t][3]);
+                } else {
+                    y1[mt][t] = fbbev_v4f{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            sm += __shfl_xor(sm, 16, 64); sm += __shfl_xor(sm, 32, 64);
+            const float mean = sm / (float)I;
+            float q = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MT2; ++mt) {
+                if (16 * mt + 4 * g < I) {
+                    y1[mt][t] = y1[mt][t] - fbbev_v4f{mean, mean, mean, mean};
+                    q += (y1[mt][t][0] * y1[mt][t][0] + y1[mt][t][1] * y1[mt][t][1]) + (y1[mt][t][2] * y1[mt][t][2] + y1[mt][t][3] * y1[mt][t][3]);
+                }
+            }
+            q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+            const float inv = 1.0f / sqrtf(q / (float)I + pre.eps0);
+#pragma unroll
+            for (int mt = 0; mt < MT2; ++mt) {
+                const int o = 16 * mt + 4 * g;
+                if (o < I) {
+                    const fbbev_v4f w4 = *reinterpret_cast<const fbbev_v4f*>(pre.ln0_w + o), b4 = *reinterpret_cast<const fbbev_v4f*>(pre.ln0_b + o);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) y1[mt][t][e] = y1[mt][t][e] * inv * w4[e] + b4[e];
+                }
+            }
+        }
+        // accumulator layout -> B fragments of GEMM 1, one k-step (= two 16-output tiles) at a time through the wave's hidden buffer:
+        // output 16 mt + 4 g + r of row j is element 4 (g & 1) + r of fragment lane (2 (mt & 1) + g / 2, j) of k-step mt / 2
+        const fbbev_bf16x8 zero8 = fbbev_cvt_bf16x8(fbbev_v4f{0.f, 0.f, 0.f, 0.f}, fbbev_v4f{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+        for (int s = 0; s < KS1; ++s) {
+#pragma unroll
+            for (int hm = 0; hm < 2; ++hm) {
+                const int mt = 2 * s + hm;
+                if (mt >= MT2) break;
+                const int gl = 2 * hm + (g >> 1), e0 = 4 * (g & 1);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    fbbev_bf16x8 h8, l8;
+                    fbbev_split_bf16x8(y1[mt][t], fbbev_v4f{0.f, 0.f, 0.f, 0.f}, h8, l8);
+                    __builtin_memcpy(hb + (((t * S2 * 2 + 0) * 64 + gl * 16 + j) * 8 + e0), &h8, 8);
+                    __builtin_memcpy(hb + (((t * S2 * 2 + 1) * 64 + gl * 16 + j) * 8 + e0), &l8, 8);
+                }
+            }
+            fbbev_wave_sync();
+            const bool okc = 32 * s + 8 * g < I;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                xh[s][t] = fbbev_ld_bf16x8(hb + ((t * S2 * 2 + 0) * 64 + lane) * 8);
+                xl[s][t] = fbbev_ld_bf16x8(hb + ((t * S2 * 2 + 1) * 64 + lane) * 8);
+                xh[s][t] = okc ? xh[s][t] : zero8;
+                xl[s][t] = okc ? xl[s][t] : zero8;
+            }
+            fbbev_wave_sync();                                                              // read before the next k-step overwrites
+        }
+    }
     fbbev_v4f acc2[MT2][NT];
 #pragma unroll
     for (int mt = 0; mt < MT2; ++mt)
@@ -265,7 +383,7 @@ k_rows_ffn_x3(const float* __restrict__ x, long long ldx, const unsigned short* 
         for (int t = 0; t < NT; ++t) acc2[mt][t] = fbbev_v4f{0.f, 0.f, 0.f, 0.f};
     const int n_chunks = H / HC;
     for (int c = 0; c < n_chunks; ++c) {
-        if (c) __syncthreads();                                                             // the previous chunk's weights are done with
+        if (c || PRE) __syncthreads();                                                      // the previous chunk's weights (PRE: W0's) are done with
         // W1 tiles 4c .. 4c+3 (k-steps 0..KS1-1 of their single K chunk), W2 tiles 0..MT2-1 at hidden units [64c, 64c + 64) = k-steps
         // 2 (c & 1), 2 (c & 1) + 1 of K chunk c / 2; 16-byte pieces, [hi | lo] kept apart as in the fragment arrays
         for (int i = threadIdx.x; i < T1 * 2 * KS1 * 64; i += 256) {
@@ -350,7 +468,8 @@ k_rows_ffn_x3(const float* __restrict__ x, long long ldx, const unsigned short* 
             v[mt] = fbbev_v4f{0.f, 0.f, 0.f, 0.f};
             if (o < O) {
                 v[mt] = acc2[mt][t] + *reinterpret_cast<const fbbev_v4f*>(b2 + o);
-                if (res && live) v[mt] = v[mt] + *reinterpret_cast<const fbbev_v4f*>(res + r * ld_res + o);
+                if constexpr (PRE) v[mt] = v[mt] + y1[mt][t];                                // add_identity: the FFN's own input
+                else if (res && live) v[mt] = v[mt] + *reinterpret_cast<const fbbev_v4f*>(res + r * ld_res + o);
                 s += (v[mt][0] + v[mt][1]) + (v[mt][2] + v[mt][3]);
             }
         }

@@ -138,8 +138,8 @@ def ln_fusable(norm, residual, x, out_features):
             w.dtype != torch.float32 or not w.is_cuda):
         return False
     if residual is not None and (residual.shape[:-1] != x.shape[:-1] or residual.shape[-1] != out_features or
-                                 residual.dtype != torch.float32 or not residual.is_contiguous()):
-        return False
+                                 residual.dtype != torch.float32 or not residual.is_contiguous() or residual.data_ptr() % 16 != 0):
+        return False           # (a storage-offset residual takes the separate LayerNorm: ADVICE r4)
     return True
 
 

@@ -279,7 +279,10 @@ int fbbev_lift_splat_fused(const float* frustum, const float* xs, const float* y
  * instantiation of the dense kernel (tile_voxels 128, FBBEV_POOL_CPL8, 256 threads, `sc1 nt` stores; anything else ->
  * FBBEV_E_UNSUPPORTED) with its gathers compiled out, launched with the grid / tile walk / XCD order the product launch
  * takes for the same `flags`.  mode 1: the store pattern alone (every tile written as zeros, no metadata); mode 2:
- * everything except the depth / feature gathers and their fmaf chains.  `out` (B,C,Z,Y,X) f32 contiguous receives zeros. */
+ * everything except the depth / feature gathers and their fmaf chains; mode 3 (round 5): everything except the stores (what
+ * the store stream has to hide; `out` untouched).  `out` (B,C,Z,Y,X) f32 contiguous receives zeros.  With FBBEV_POOL_OUT_BF16
+ * in `flags` (round 5) the same three modes of the bf16-storage leg's instantiation (16-bit LDS tile, 128 voxels; `out` then
+ * points to 16-bit elements). */
 int fbbev_diag_pool_store_floor(const float* depth, const float* feat, const int32_t* ranks_depth,
                                 const int32_t* ranks_feat, const int32_t* interval_rank,
                                 const int32_t* interval_starts, const int32_t* interval_lengths, int B, int C, int Z,
@@ -516,6 +519,11 @@ int fbbev_da_cross_attn_bwd(const float* value, const int64_t* spatial_shapes, c
  * grad_value NaN.  Same bits run to run; configs[2] pyramid, B = 4: 2.39 -> 1.18 ms. */
 size_t fbbev_da_cross_attn_bwd_ws_bytes(int B, int Ncam, int S, int M, int Dh, int Q, int head_stride,
                                         int num_levels, int num_points, const int32_t* level_hw_host);
+/* fbbev_da_cross_attn_bwd_ws_bytes covers BOTH LDS-plane routes (the launch picks one from arguments the query does not see: the
+ * number of Z anchors, pointer alignment), i.e. the maximum of their sizes.  With the anchor count the launch will pass, this
+ * query returns the size of the route that launch takes (61 MB instead of 551 MB at the configs[2] pyramid). */
+size_t fbbev_da_cross_attn_bwd_ws_bytes_za(int B, int Ncam, int S, int M, int Dh, int Q, int head_stride, int num_levels,
+                                           int num_points, int num_z_anchors, const int32_t* level_hw_host);
 int fbbev_da_cross_attn_bwd_ws(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
                                const float* pred_depth, const float* ref_cam, const uint8_t* mask,
                                const float* qdepth, const float* offsets, const float* attn,
@@ -674,6 +682,20 @@ int fbbev_rows_ffn_x3(const float* x, long long x_row_stride, const void* w1_fra
                       const float* b2, long long rows, int in_features, int hidden, int out_features, const float* residual,
                       long long residual_row_stride, const float* ln_weight, const float* ln_bias, float ln_eps, float* out,
                       long long out_row_stride, fbbev_stream_t stream);
+/* The cross-attention block's tail AND the FFN block of the encoder layer in ONE kernel (round 5) -- bevformer_encoder.py:250-377 with
+ * operation_order (..., 'cross_attn', 'norm', 'ffn', 'norm'):
+ *   y1  = LayerNorm0(x W0^T + b0 + residual0)        DA_SpatialCrossAttention's output_proj + `+ inp_residual`
+ *                                                    (spatial_cross_attention_depth.py:222-223) + the layer's norm
+ *   out = LayerNorm1(y1 + W2 relu(W1 y1 + b1) + b2)  mmcv FFN (add_identity) + the layer's last norm
+ * x (rows, embed) = the attention slots, residual0 = the block's input rows (optional).  y1 stays in the wave's registers (it is the
+ * FFN's residual) and is re-laid out through LDS into GEMM 1's operand fragments: replaces fbbev_rows_linear_x3_ln +
+ * fbbev_rows_ffn_x3 and the (rows, embed) tensor between them.  Fragments of W0 (embed, embed), W1 (hidden, embed), W2 (embed,
+ * hidden) from fbbev_rows_linear_x3_fragments.  embed % 16 == 0, embed <= 80, hidden % 64 == 0. */
+int fbbev_rows_tail_ffn_x3(const float* x, long long x_row_stride, const void* w0_fragments, const float* b0,
+                           const float* residual0, long long residual0_row_stride, const float* ln0_weight, const float* ln0_bias,
+                           float ln0_eps, const void* w1_fragments, const float* b1, const void* w2_fragments, const float* b2,
+                           long long rows, int embed, int hidden, const float* ln1_weight, const float* ln1_bias, float ln1_eps,
+                           float* out, long long out_row_stride, fbbev_stream_t stream);
 /* fbbev_rows_linear_x3 with the result written as HEAD PLANES: rows = (B*Ncam) x tokens_per_image camera tokens, out_features =
  * M * head_dim in the module's (head, channel) order, out (B*Ncam, M, tokens_per_image, head_dim) -- the value_proj of the
  * cross-attention feeding fbbev_da_cross_attn_fused (spatial_cross_attention_depth.py:522-530). */

@@ -859,11 +859,17 @@ def test_fused_da_cross_attention_backward_emulated():
                 sizes = []
                 for flag in ('1', '0'):
                     os.environ['FBBEV_DA_BWD_OWNED'] = flag
-                    sizes.append(E.lib().fbbev_da_cross_attn_bwd_ws_bytes(B_, Ncam_, vp.shape[1], vp.shape[2], Dh, Q_, HS,
-                                                                          len(shapes_host), attn.shape[-1], harr))
+                    sizes.append(E.lib().fbbev_da_cross_attn_bwd_ws_bytes_za(B_, Ncam_, vp.shape[1], vp.shape[2], Dh, Q_, HS,
+                                                                             len(shapes_host), attn.shape[-1], mask.shape[3], harr))
                 os.environ['FBBEV_DA_BWD_OWNED'] = '1'
                 records = B_ * Ncam_ * Q_ * 16 * 4                       # 64-byte hit records in list order
                 assert records <= sizes[0] <= records + 4 * 256 + B_ * Ncam_ * vp.shape[1] * vp.shape[2] * Dh * 4 + 256 and sizes[1] > 0 and sizes[0] != sizes[1]
+                # the query without the anchor count covers BOTH routes (a launch whose owned plan fails must still find
+                # room for the chunked planes); more anchors than a hit record holds -> the chunked route's size
+                both = E.lib().fbbev_da_cross_attn_bwd_ws_bytes(B_, Ncam_, vp.shape[1], vp.shape[2], Dh, Q_, HS, len(shapes_host), attn.shape[-1], harr)
+                assert both == max(sizes)
+                assert E.lib().fbbev_da_cross_attn_bwd_ws_bytes_za(B_, Ncam_, vp.shape[1], vp.shape[2], Dh, Q_, HS, len(shapes_host),
+                                                                   attn.shape[-1], 8, harr) == sizes[1]
             if prepass == '1':
                 import ctypes
                 flat = [int(x) for hw in shapes_host for x in hw]
@@ -939,7 +945,7 @@ def test_da_backward_unit_gradients_on_head_planes_emulated():
                 for planes in ('0', '1'):
                     os.environ['FBBEV_DA_BWD_OWNED'] = '1'
                     os.environ['FBBEV_DA_BWD_UNIT_PLANES'] = planes
-                    sizes[planes] = E.lib().fbbev_da_cross_attn_bwd_ws_bytes(B_, Ncam_, vp.shape[1], 8, Dh, Q_, 12, len(shapes_host), 8, harr)
+                    sizes[planes] = E.lib().fbbev_da_cross_attn_bwd_ws_bytes_za(B_, Ncam_, vp.shape[1], 8, Dh, Q_, 12, len(shapes_host), 8, mask.shape[3], harr)
                     del os.environ['FBBEV_DA_BWD_OWNED'], os.environ['FBBEV_DA_BWD_UNIT_PLANES']
                 plane_bytes = B_ * Ncam_ * 8 * vp.shape[1] * Dh * 4
                 assert plane_bytes <= sizes['1'] - sizes['0'] < plane_bytes + 256, (sizes, plane_bytes)
@@ -1006,11 +1012,22 @@ def test_pool_zmean_and_add_epilogue_emulated(name, tv, flags):
     assert code == 0 and not torch.isnan(mean).any()
     assert torch.allclose(mean, vol.mean(2), atol=1e-6, rtol=1e-5)
     assert torch.allclose(mean, vol.double().sum(2).float() / Z, atol=1e-6, rtol=1e-5)
+    # round 5: the COLUMN form of the same entry (k_pool_zmean_col, FBBEV_ZMEAN_COL=1: all planes' metadata at once, a lane group
+    # per pixel; opt-in, measured slower) -- the bits of the plane-after-plane walk; SMALL columns hold more points than the staging cap
+    import os
+    os.environ['FBBEV_ZMEAN_COL'] = '1'
+    try:
+        code, col = E.pool_zmean(depth, feat, rd, rf, ir, st, ln, counts, st.numel(), B, C, Z, Y, X, tv, flags)
+    finally:
+        del os.environ['FBBEV_ZMEAN_COL']
+    assert code == 0 and torch.equal(mean, col)
     # fbbev_pool_zmean_split: the planes of a tile dealt to 2 / 3 / Z workgroups + the ordered reduce (another association of the z sum)
     for zg in (2, 3, Z):
         code, m2 = E.pool_zmean(depth, feat, rd, rf, ir, st, ln, counts, st.numel(), B, C, Z, Y, X, tv, flags, z_groups=zg)
         assert code == 0 and not torch.isnan(m2).any(), zg
         assert torch.allclose(m2, vol.double().sum(2).float() / Z, atol=1e-6, rtol=1e-5), zg
+        if zg == Z:
+            assert torch.equal(m2, mean)                             # one plane per group: the single pass's bits
     addend = torch.randn(B, C, Y, X, generator=torch.Generator().manual_seed(3))
     code, out = E.pool_dense(depth, feat, rd, rf, ir, st, ln, counts, st.numel(), B, C, Z, Y, X, tv, flags, addend=addend)
     assert code == 0
@@ -1629,6 +1646,45 @@ def test_rows_ffn_one_kernel_emulated(rows, I, H, O, ln, with_res):
         assert (out - ref).abs().max().item() <= 5e-5 * max(1.0, ref.abs().max().item()), (hc, (out - ref).abs().max().item())
     code, _ = E.rows_ffn_x3(x, torch.randn(100, I, generator=g), torch.zeros(100), torch.randn(O, 100, generator=g), b2)
     assert code < 0                                                        # hidden width no multiple of 64: refused
+
+
+@pytest.mark.parametrize('rows,Em,H,with_res', [(200, 80, 320, True), (70, 80, 64, True), (33, 64, 128, False), (130, 16, 64, True)])
+def test_rows_tail_ffn_one_kernel_emulated(rows, Em, H, with_res):
+    """fbbev_rows_tail_ffn_x3: LayerNorm1(y1 + W2 relu(W1 y1 + b1) + b2) with y1 = LayerNorm0(x W0^T + b0 [+ res0]) -- the
+    cross-attention block's tail and the FFN block of the encoder layer (bevformer_encoder.py:250-377) in one kernel, y1 kept in
+    registers and re-laid out through LDS -- against the fp32 composition in torch, and against the two kernels it replaces
+    (fbbev_rows_linear_x3_ln -> fbbev_rows_ffn_x3: the same split-operand arithmetic per GEMM); rows that do not fill the last
+    tile, E = 16 / 64 / 80 (one to three k-steps, a half-empty last k-step), both hidden-chunk sizes; refused shapes."""
+    import os
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(rows + H + Em)
+    x = torch.randn(rows, Em, generator=g)
+    w0, b0 = torch.randn(Em, Em, generator=g) / Em ** 0.5, torch.randn(Em, generator=g) * 0.3
+    res0 = torch.randn(rows, Em, generator=g) if with_res else None
+    l0w, l0b = torch.rand(Em, generator=g) + 0.5, torch.randn(Em, generator=g) * 0.2
+    w1, b1 = torch.randn(H, Em, generator=g) / Em ** 0.5, torch.randn(H, generator=g) * 0.3
+    w2, b2 = torch.randn(Em, H, generator=g) / H ** 0.5, torch.randn(Em, generator=g) * 0.3
+    l1w, l1b = torch.rand(Em, generator=g) + 0.5, torch.randn(Em, generator=g) * 0.2
+    y0 = F.linear(x, w0, b0)
+    y1 = F.layer_norm(y0 + res0 if with_res else y0, (Em,), l0w, l0b, 1e-5)
+    ref = F.layer_norm(y1 + F.linear(torch.relu(F.linear(y1, w1, b1)), w2, b2), (Em,), l1w, l1b, 1e-6)
+    code, t1 = E.rows_linear_x3_ln(x, w0, b0, res0, l0w, l0b, 1e-5)
+    assert code == 0
+    code, two = E.rows_ffn_x3(t1, w1, b1, w2, b2, residual=t1, ln_w=l1w, ln_b=l1b, eps=1e-6)
+    assert code == 0
+    for hc in ('32', '64'):
+        os.environ['FBBEV_TAIL_FFN_HC'] = hc
+        try:
+            code, out = E.rows_tail_ffn_x3(x, w0, b0, res0, l0w, l0b, 1e-5, w1, b1, w2, b2, l1w, l1b, 1e-6)
+        finally:
+            del os.environ['FBBEV_TAIL_FFN_HC']
+        assert code == 0 and not torch.isnan(out).any()
+        assert (out - ref).abs().max().item() <= 5e-5 * max(1.0, ref.abs().max().item()), (hc, (out - ref).abs().max().item())
+        assert (out - two).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item()), (hc, (out - two).abs().max().item())
+    code, _ = E.rows_tail_ffn_x3(x[:, :Em - 8].contiguous(), w0[:Em - 8, :Em - 8].contiguous(), b0[:Em - 8].contiguous(), None, l0w[:Em - 8].contiguous(),
+                                  l0b[:Em - 8].contiguous(), 1e-5, w1[:, :Em - 8].contiguous(), b1, w2[:Em - 8].contiguous(), b2[:Em - 8].contiguous(),
+                                  l1w[:Em - 8].contiguous(), l1b[:Em - 8].contiguous(), 1e-6)
+    assert code < 0                                                        # embed no multiple of 16: refused
 
 
 def test_token_pyramid_in_one_launch_emulated():

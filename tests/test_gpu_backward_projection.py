@@ -491,7 +491,8 @@ def test_output_owned_plane_backward_at_a_pyramid(dev):
         assert not torch.isnan(s_pl).any() and err <= 1e-5 * max(1.0, s_rows.abs().max().item()), (bw, err)
     # the owned route is planned: its workspace is the hit records (+ the planes), not partial planes
     records = B * Ncam * Q * 16 * 4                                   # 64-byte hit records in list order
-    need = _capi.da_cross_attn_bwd_ws_bytes(B, Ncam, S_, M, Dh, Q, HS, L, P, level_hw=shapes)
+    need = _capi.da_cross_attn_bwd_ws_bytes(B, Ncam, S_, M, Dh, Q, HS, L, P, level_hw=shapes, Za=mask.shape[3])
+    assert _capi.da_cross_attn_bwd_ws_bytes(B, Ncam, S_, M, Dh, Q, HS, L, P, level_hw=shapes) >= need      # without Za: covers both routes
     planes = B * Ncam * M * S_ * Dh * 4                               # + the camera tokens as head planes for the unit gradients
     assert records + planes <= need <= records + planes + 5 * 256, (need, records, planes)
 

@@ -168,6 +168,72 @@ def test_linear_layernorm_epilogue_vs_fp64(dev, rows, I, O, with_res):
     assert err <= 2e-5 * scale, err
 
 
+@pytest.mark.parametrize('rows,E,H,with_res', [(160000, 80, 320, True), (40000, 80, 320, False), (1037, 64, 128, True)])
+def test_attention_tail_plus_ffn_one_kernel_vs_fp64(dev, rows, E, H, with_res):
+    """fbbev_rows_tail_ffn_x3 (round 5: output_proj + residual + norm of the cross-attention block AND the FFN block + norm,
+    bevformer_encoder.py:250-377, one kernel) as DA_SpatialCrossAttention.forward calls it, at the encoder's row count for BASELINE
+    configs[2] B = 4: <= 2e-5 of the output scale against the fp64 composition, and <= 1e-5 of it against the two kernels it
+    replaces (fbbev_rows_linear_x3_ln -> fbbev_rows_ffn_x3)."""
+    from fb_bev_amd import _capi
+    g = torch.Generator().manual_seed(rows + H + E)
+    x = torch.randn(rows, E, generator=g)
+    w0, b0 = torch.randn(E, E, generator=g) / E ** 0.5, torch.randn(E, generator=g) * 0.3
+    res0 = torch.randn(rows, E, generator=g) if with_res else None
+    l0w, l0b = torch.rand(E, generator=g) + 0.5, torch.randn(E, generator=g) * 0.2
+    w1, b1 = torch.randn(H, E, generator=g) / E ** 0.5, torch.randn(H, generator=g) * 0.3
+    w2, b2 = torch.randn(E, H, generator=g) / H ** 0.5, torch.randn(E, generator=g) * 0.3
+    l1w, l1b = torch.rand(E, generator=g) + 0.5, torch.randn(E, generator=g) * 0.2
+    d = lambda t: None if t is None else t.double()  # noqa: E731
+    y0 = F.linear(d(x), d(w0), d(b0))
+    y1 = F.layer_norm(y0 + d(res0) if with_res else y0, (E,), d(l0w), d(l0b), 1e-5)
+    ref = F.layer_norm(y1 + F.linear(torch.relu(F.linear(y1, d(w1), d(b1))), d(w2), d(b2)), (E,), d(l1w), d(l1b), 1e-5)
+    gg = lambda t: None if t is None else t.to(dev).contiguous()  # noqa: E731
+    f0, f1, f2 = (_capi.rows_linear_x3_fragments(gg(w)) for w in (w0, w1, w2))
+    xg, rg = gg(x), gg(res0)
+    assert _capi.rows_tail_ffn_x3_supported(xg, rg, E, H)
+    out = _capi.rows_tail_ffn_x3(xg, f0, gg(b0), rg, gg(l0w), gg(l0b), 1e-5, f1, gg(b1), f2, gg(b2), H, gg(l1w), gg(l1b), 1e-5)
+    assert not torch.isnan(out).any()
+    t1 = _capi.rows_linear_x3_ln(xg, f0, gg(b0), E, rg, gg(l0w), gg(l0b), 1e-5)
+    two = _capi.rows_ffn_x3(t1, f1, gg(b1), f2, gg(b2), H, E, residual=t1, ln_weight=gg(l1w), ln_bias=gg(l1b), eps=1e-5)
+    scale = max(1.0, ref.abs().max().item())
+    err = (out.cpu().double() - ref).abs().max().item()
+    dlt = (out - two).abs().max().item()
+    _say(f'fbbev_rows_tail_ffn_x3 [{rows} rows, E={E}, H={H}, residual={with_res}]: max|err| vs fp64 = {err:.3e}, vs the two kernels it '
+         f'replaces = {dlt:.3e} (scale {scale:.2f})')
+    assert err <= 2e-5 * scale and dlt <= 1e-5 * scale, (err, dlt)
+    assert not _capi.rows_tail_ffn_x3_supported(xg[:, :E - 8], None, E - 8, H)          # embed no multiple of 16
+    assert not _capi.rows_tail_ffn_x3_supported(xg.view(-1)[2:2 + (rows - 1) * E].view(rows - 1, E), None, E, H)   # misaligned view (ADVICE r4)
+
+
+def test_encoder_layer_with_and_without_the_fused_tail_ffn_route(dev):
+    """BackwardProjection through the module with the cross-attention tail + FFN as one kernel (default) and as the two round-4 kernels
+    (FBBEV_FUSE_TAIL_FFN=0): the same output within the split-operand arithmetic (1e-5 of scale), and the default route really runs
+    fbbev_rows_tail_ffn_x3."""
+    from fb_bev_amd import _capi, backward_projection as BP
+    from test_gpu_backward_projection import _setup
+    m, cfg, cam, feats, depth, lss, gcb = _setup(dev, B=2, num_levels=4, bev=40, shapes=[(16, 44), (32, 88), (8, 22), (4, 11)])
+    args = ([f.to(dev) for f in feats], None)
+    kw = dict(lss_bev=lss.to(dev), cam_params=[t.to(dev) for t in cam], pred_img_depth=depth.to(dev))
+    calls = []
+    real = _capi.rows_tail_ffn_x3
+    _capi.rows_tail_ffn_x3 = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            one = m(*args, **kw)
+            assert calls, 'the default inference route did not take fbbev_rows_tail_ffn_x3'
+            BP.FUSE_TAIL_FFN = False
+            n = len(calls)
+            two = m(*args, **kw)
+            assert len(calls) == n
+    finally:
+        BP.FUSE_TAIL_FFN = True
+        _capi.rows_tail_ffn_x3 = real
+    scale = max(1.0, two.abs().max().item())
+    dlt = (one - two).abs().max().item()
+    _say(f'BackwardProjection, tail + FFN as one kernel vs two: max|diff| = {dlt:.3e} (scale {scale:.2f})')
+    assert dlt <= 1e-5 * scale
+
+
 # ------------------------------------------------------------------ camera-token pyramid in one launch
 @pytest.mark.parametrize('images,C,shapes', [(24, 80, ((16, 44), (32, 88), (8, 22), (4, 11))), (6, 80, ((16, 44),)), (5, 33, ((5, 9), (8, 4), (1, 3), (2, 2)))])
 def test_token_pyramid_in_one_launch_bit_exact(dev, images, C, shapes):
