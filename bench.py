@@ -708,6 +708,26 @@ def run_forward(args):
         except Exception:
             traffic = None
 
+    # Extra leg (beside `value`, never as it): the same step with the camera-keyed index cache (the reference's
+    # `pre_compute` / `init_acceleration_v2`, view_transformer.py:500-519,607-611, disabled upstream): the six camera tensors are
+    # compared on the device every step, the index build returns at once on a hit -- what a deployment with a fixed rig runs
+    cached = None
+    if world == 1 and rank == 0 and args.storage == 'f32':
+        with torch.no_grad():
+            vc = LSSViewTransformerFunction3D(cfg.grid_config, cfg.input_size, cfg.downsample, accelerate=True).to(dev)
+            for _ in range(max(3, args.warmup)):
+                oc = vc(cam, ctx, depth)
+            fence()
+            tc = time.perf_counter()
+            for _ in range(args.steps):
+                oc = vc(cam, ctx, depth)
+            fence()
+            tc = time.perf_counter() - tc
+            cached = {'what': 'forward projection with the camera-keyed index cache hit every step (rank build skipped on the device)',
+                      'value': B * args.steps / tc, 'unit': 'samples/s', 'ms_per_step': 1e3 * tc / args.steps,
+                      'volume_equals_uncached': bool(torch.equal(oc.permute(0, 1, 4, 2, 3), out))}
+            del oc, vc
+
     # Extra leg (beside `value`, never as it): BASELINE configs[2] -- the backward-projection half of the path on this GPU
     fb = None
     if world == 1 and rank == 0 and not args.no_fb_projection and cfg.name == 'BL2':
@@ -750,6 +770,8 @@ def run_forward(args):
         }
         if alt is not None:
             res['bf16_storage'] = alt
+        if cached is not None:
+            res['index_cache'] = cached
         if fb is not None:
             res['fb_projection'] = fb
         if piped is not None:
