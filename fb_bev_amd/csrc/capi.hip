@@ -1975,7 +1975,7 @@ static bool da_own_plan_make(int B, int Ncam, int S, int M, int Dh, int Q, int H
     pl->off_list = 0;                                                  // hit records [B*Ncam][Q][16 floats] at the start of ws
     pl->off_count = align_up((size_t)B * Ncam * Q * FBBEV_DA_HIT_REC * sizeof(float), 256);
     pl->off_gmax = pl->off_count + align_up((size_t)B * Ncam * sizeof(int), 256);
-    pl->ws = pl->off_gmax + 256;
+    pl->ws = pl->off_gmax + align_up((size_t)B * sizeof(unsigned int), 256);          // one fixed-point scale per sample
     // unit gradients on head planes (k_da_bwd_unit_planes, da_bwd_planes_kernels.h; FBBEV_DA_BWD_UNIT_PLANES=0 keeps the row kernel):
     // M = 8, Dh in {8, 10}, 8 points, 4 anchors, every level at least 2 tokens wide; the planes sit behind the hit lists
     pl->unit_planes = 0;
@@ -2068,7 +2068,7 @@ static int da_bwd_owned_launch(const da_own_plan& op, fbbev_rt_stream stream, co
     float* hit_rec = reinterpret_cast<float*>(w + op.off_list);
     int* hit_count = reinterpret_cast<int*>(w + op.off_count);
     unsigned int* gmax_bits = reinterpret_cast<unsigned int*>(w + op.off_gmax);
-    FBBEV_LAUNCH(k_da_bwd_init, 1, 256, 0, stream, B * Ncam, hit_count, 1, gmax_bits);
+    FBBEV_LAUNCH(k_da_bwd_init, 1, 256, 0, stream, B * Ncam, hit_count, B, gmax_bits);
     FBBEV_CHECK_LAUNCH();
     int e = 0;
     // (the plane kernel reads a record's 4 mask bytes / 8 reference floats / 4 depths as whole words: alignment of the geometry inputs)

@@ -190,13 +190,13 @@ k_da_bwd_unit_planes(const float* __restrict__ planes, const int64_t* __restrict
             gm = fmaxf(gm, fmaxf(a0, a1));
             g[c][0] = t[0] / inv; g[c][1] = t[1] / inv;
         }
-        if (gmax_bits) {                                                                // the call's max |gradient| (see k_da_bwd_scatter_owned)
+        if (gmax_bits) {                                                                // the sample's max |gradient| (see k_da_bwd_scatter_owned)
             if (!fin) gm = __builtin_inff();
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) gm = fmaxf(gm, __shfl_xor(gm, o, 64));
             unsigned int gb;
             __builtin_memcpy(&gb, &gm, 4);
-            if (lane == 0 && gb != 0u) atomicMax(gmax_bits, gb);
+            if (lane == 0 && gb != 0u) atomicMax(gmax_bits + b, gb);                       // per SAMPLE (round 5): a workgroup = one sample's patch
         }
     }
     const int LP = L * P;

@@ -736,6 +736,13 @@ k_da_cross_attn_bwd_unit(long long n_units, const float* __restrict__ value, con
     // the fixed-point scale of k_da_bwd_scatter_owned (bits of a non-negative float order like the float; non-finite -> inf)
     float gm_lane = 0.f;
     bool fin_lane = true;
+    int gm_b = -1;                                             // the sample the running maximum belongs to (round 5: one scale per sample)
+    auto flush_gmax = [&](int bb, float gm, bool fin) {
+        if (!fin) gm = __builtin_inff();
+        unsigned int gb;
+        __builtin_memcpy(&gb, &gm, 4);
+        if (gb != 0u) atomicMax(gmax_bits + bb, gb);
+    };
     const int head_off_m = QI ? 4 : HS, chunk_stride = QI ? M * 4 : 4;
     const int row_stride = M * HS;
     const int H0 = (int)spatial_shapes[0], W0 = (int)spatial_shapes[1];
@@ -750,6 +757,10 @@ k_da_cross_attn_bwd_unit(long long n_units, const float* __restrict__ value, con
         const int q = (int)(bq % Q);
         const int b = (int)(bq / Q);
         if (gmax_bits) {
+            if (b != gm_b) {                                   // a lane's units come in ascending order: a new sample at most B times
+                if (gm_b >= 0) flush_gmax(gm_b, gm_lane, fin_lane);
+                gm_b = b; gm_lane = 0.f; fin_lane = true;
+            }
             const float* gs = grad_slots + unit * DH;
 #pragma unroll
             for (int c = 0; c < DH; c += 2) {
@@ -875,13 +886,23 @@ k_da_cross_attn_bwd_unit(long long n_units, const float* __restrict__ value, con
             }
         }
     }
-    if (gmax_bits) {                                                    // every lane is back here: one atomic per wave
-        if (!fin_lane) gm_lane = __builtin_inff();
+    if (gmax_bits) {                                                    // every lane is back here
+        // one atomic per wave when its lanes ended in the same sample (the rule; a wave that straddles two samples: one per lane)
+        int lo = gm_b < 0 ? 0x7fffffff : gm_b, hi = gm_b;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) gm_lane = fmaxf(gm_lane, __shfl_xor(gm_lane, o, 64));
-        unsigned int gb;
-        __builtin_memcpy(&gb, &gm_lane, 4);
-        if ((threadIdx.x & 63) == 0 && gb != 0u) atomicMax(gmax_bits, gb);
+        for (int o = 32; o > 0; o >>= 1) {
+            const int l2 = __shfl_xor(lo, o, 64), h2 = __shfl_xor(hi, o, 64);
+            lo = l2 < lo ? l2 : lo; hi = h2 > hi ? h2 : hi;
+        }
+        if (hi >= 0 && lo == hi) {
+            if (!fin_lane) gm_lane = __builtin_inff();
+            if (gm_b < 0) gm_lane = 0.f;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) gm_lane = fmaxf(gm_lane, __shfl_xor(gm_lane, o, 64));
+            if ((threadIdx.x & 63) == 0) flush_gmax(hi, gm_lane, true);
+        } else if (gm_b >= 0) {
+            flush_gmax(gm_b, gm_lane, fin_lane);
+        }
     }
 }
 
@@ -1237,10 +1258,10 @@ k_da_bwd_scatter_owned(const int64_t* __restrict__ spatial_shapes, const int64_t
     const int span = tok1 - tok0, plane_n = span * HS, plane_w = FBBEV_DA_PLANE_WORDS(span, HS);
     long long* plane = plane0 + (threadIdx.x % copies) * plane_w;
     for (int i = threadIdx.x; i < copies * plane_w; i += NT) plane0[i] = 0ll;
-    // scale of the fixed-point plane: sc = 2^(30 - ex) with max |grad_slots| of the CALL < 2^ex (every addend is
+    // scale of the fixed-point plane: sc = 2^(30 - ex) with max |grad_slots| of the SAMPLE < 2^ex (every addend is
     // |corner weight * attention * depth weight / cameras| <= 1 times a gradient: below 2^30; a token takes < 2^33 of them)
-    const unsigned int gb = gmax_bits[0];
-    const bool poisoned = gb >= 0x7f800000u;
+    const unsigned int gb = gmax_bits[b];                      // round 5: the scale of THIS sample's planes (one outlier
+    const bool poisoned = gb >= 0x7f800000u;                   // gradient no longer sets the quantum of every other sample)
     float sc = 0.f, inv_sc = 0.f;
     if (!poisoned && gb != 0u) {
         int ex = (int)((gb >> 23) & 255u) - 126;

@@ -515,8 +515,10 @@ int fbbev_da_cross_attn_bwd(const float* value, const int64_t* spatial_shapes, c
  * depth weights, reference points: 64 bytes, in list order) in `ws` (k_da_bwd_hitlist), then ONE launch in which a workgroup owns the plane of one (sample, camera, head,
  * token region), walks the camera's hit list and writes its tokens of grad_value directly -- no partial planes, no step
  * (C); `ws` shrinks from the partial planes (551 MB at the configs[2] pyramid) to the hit records (64 bytes per (camera, query): 61 MB).  The fixed-point
- * scale is then the call's max |grad_slots| (folded by kernel (A)): a non-finite upstream gradient makes the whole
- * grad_value NaN.  Same bits run to run; configs[2] pyramid, B = 4: 2.39 -> 1.18 ms. */
+ * scale is then the SAMPLE's max |grad_slots| (folded by kernel (A); round 5: per sample, round 4: per call): every addend
+ * of a sample is quantised to 2^-30 of that maximum, i.e. contributions below ~1e-9 of the sample's largest upstream gradient
+ * round to zero (an outlier -- AMP loss scaling -- costs resolution in its own sample only); a non-finite upstream gradient
+ * makes that sample's grad_value NaN.  Same bits run to run; configs[2] pyramid, B = 4: 2.39 -> 1.18 ms. */
 size_t fbbev_da_cross_attn_bwd_ws_bytes(int B, int Ncam, int S, int M, int Dh, int Q, int head_stride,
                                         int num_levels, int num_points, const int32_t* level_hw_host);
 /* fbbev_da_cross_attn_bwd_ws_bytes covers BOTH LDS-plane routes (the launch picks one from arguments the query does not see: the
