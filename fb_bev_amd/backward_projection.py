@@ -65,6 +65,28 @@ def const_tensor(values, device, dtype=torch.long):
     return _CONST[key]
 
 
+# ---- inference prefetch (round 5): the part of the backward projection that does not depend on the lift-splat's Z-mean -- camera-token
+# rows, their value projection as head planes, BEV -> image point sampling -- computed on a SIDE stream while the forward projection's
+# latency-bound ranking chain and Z-mean run on the main one (FBViewTransform.forward); consumed by the forward that follows when it
+# is called with the same input tensors.  FBBEV_BP_PREFETCH=0 turns it off (A/B knob); never active during hipGraph capture.
+import os as _os0
+PREFETCH = _os0.environ.get('FBBEV_BP_PREFETCH', '1') != '0'
+PREFETCH_MIN_QUERIES = int(_os0.environ.get('FBBEV_BP_PREFETCH_MIN_QUERIES', '120000'))
+
+
+class _Prefetch:
+    def __init__(self):
+        self.rows = self.rows_key = self.sampling = self.sampling_key = self.event = None
+        self.planes = {}                  # id(cross-attention module) -> (data_ptr of the rows, head planes)
+
+
+_PRE = None                               # set by BackwardProjection.forward around its transformer call
+
+
+def _tkey(ts):
+    return tuple((t.data_ptr(), tuple(t.shape), t._version) for t in ts)
+
+
 _NORMED = object()       # 'residual' slot of a deferred branch result whose following LayerNorm already ran inside the branch's last GEMM
 
 
@@ -680,8 +702,11 @@ class DA_SpatialCrossAttention(nn.Module):
             return None
         if not hasattr(self, '_vx3p'):
             self._vx3p, da._so_x3p, da._aw_x3p = X3Weights(), X3Weights(), X3Weights()
-        vp = self._vx3p.get(da.value_proj.weight, da.value_proj.bias)
-        planes = _capi.rows_linear_x3_planes(x.reshape(BN * S, E), vp.frag, vp.b, S, M, Dh)
+        pre = _PRE.planes.get(id(self)) if _PRE is not None else None
+        if pre is not None and pre[0] == (x.data_ptr(), BN, S, E):      # projected on the side stream by BackwardProjection.prefetch
+            planes = pre[1]
+        else:
+            planes = self._value_planes(x.reshape(BN * S, E), S)
         so = da._so_x3p.get(da.sampling_offsets.weight, da.sampling_offsets.bias)
         aw = da._aw_x3p.get(da.attention_weights.weight, da.attention_weights.bias)
         addend = None
@@ -696,6 +721,14 @@ class DA_SpatialCrossAttention(nn.Module):
             pred_img_depth.reshape(BN, DC, H0, W0).contiguous().float(), reference_points_cam.contiguous().float(), mask.contiguous(),
             bev_query_depth.squeeze(-1).contiguous().float(), query, addend, so.frag, so.b, aw.frag, aw.b, P, self.dbound[0],
             self.dbound[2], bev_w, min(int(w) for _, w in hw), slots, out_proj=self._take_tail(_tail))
+
+    def _value_planes(self, x2d, S):
+        """value_proj of the camera-token rows (images * S, E) written as head planes (images, M, S, Dh)"""
+        da = self.deformable_attention
+        if not hasattr(self, '_vx3p'):
+            self._vx3p, da._so_x3p, da._aw_x3p = X3Weights(), X3Weights(), X3Weights()
+        vp = self._vx3p.get(da.value_proj.weight, da.value_proj.bias)
+        return _capi.rows_linear_x3_planes(x2d, vp.frag, vp.b, S, da.num_heads, self.embed_dims // da.num_heads)
 
     @staticmethod
     def _take_tail(tail):
@@ -1016,8 +1049,11 @@ class bevformer_encoder(nn.Module):
                                           dtype=bev_query.dtype))
             self._ref_cache_key = ck
         ref_3d, ref_2d = self._ref_cache
-        ref_3d, ref_cam, per_cam_mask_list, bev_query_depth = self.point_sampling(
-            ref_3d, self.pc_range, kwargs.get('img_metas'), cam_params=cam_params, gt_bboxes_3d=gt_bboxes_3d)
+        if _PRE is not None and _PRE.sampling is not None and _PRE.sampling_key == _tkey(cam_params):
+            ref_cam, per_cam_mask_list, bev_query_depth = _PRE.sampling          # sampled on the side stream (prefetch)
+        else:
+            ref_3d, ref_cam, per_cam_mask_list, bev_query_depth = self.point_sampling(
+                ref_3d, self.pc_range, kwargs.get('img_metas'), cam_params=cam_params, gt_bboxes_3d=gt_bboxes_3d)
         bev_query = bev_query.permute(1, 0, 2)
         bev_pos = bev_pos.permute(1, 0, 2)
         output, inter = bev_query, []
@@ -1054,34 +1090,48 @@ class BEVFormer(nn.Module):
                 m.init_weights()
         nn.init.normal_(self.cams_embeds)
 
+    def _tokens_fusable(self, mlvl_feats):
+        f0 = mlvl_feats[0]
+        needs_grad = torch.is_grad_enabled() and (self.cams_embeds.requires_grad or any(f.requires_grad for f in mlvl_feats))
+        return (self.fused_tokens and f0.is_cuda and f0.dtype == torch.float32 and not needs_grad and f0.shape[1] == self.num_cams
+                and all(f.shape[:3] == f0.shape[:3] for f in mlvl_feats))
+
+    def _token_rows(self, mlvl_feats, shapes):
+        """(bs * num_cam, sum HW, C) camera-token rows: feat.flatten(3).permute + cams_embeds + cat + the rebatch permute of the
+        reference (bevformer.py:95-117, spatial_cross_attention_depth.py:151) in one transposing launch"""
+        f0 = mlvl_feats[0]
+        bs, ncam, c = f0.shape[:3]
+        S = sum(h * w for h, w in shapes)
+        rows = torch.empty((bs * ncam, S, c), dtype=torch.float32, device=f0.device)
+        ck = (self.cams_embeds.data_ptr(), self.cams_embeds._version, str(f0.device), self.use_cams_embeds)
+        if getattr(self, '_ce_key', None) != ck:       # per-weight-version constant (the reference adds `cams_embeds * 0` when unused)
+            ce = self.cams_embeds.detach().to(torch.float32)
+            self._ce, self._ce_key = (ce if self.use_cams_embeds else ce * 0).contiguous(), ck
+        ce = self._ce
+        if 1 < len(mlvl_feats) <= 8:       # the whole pyramid in one launch
+            _capi.tokens_from_nchw_levels([f.reshape(bs * ncam, c, h * w).contiguous() for f, (h, w) in zip(mlvl_feats, shapes)], rows, ce)
+        else:
+            start = 0
+            for feat, (h, w) in zip(mlvl_feats, shapes):
+                _capi.tokens_from_nchw(feat.reshape(bs * ncam, c, h * w).contiguous(), rows, start * c, ce)
+                start += h * w
+        return rows
+
     def forward(self, mlvl_feats, bev_queries, bev_h, bev_w, bev_pos=None, cam_params=None, gt_bboxes_3d=None,
                 pred_img_depth=None, prev_bev=None, bev_mask=None, **kwargs):
         bev_pos = bev_pos.flatten(2).permute(2, 0, 1)
         shapes = [tuple(feat.shape[-2:]) for feat in mlvl_feats]
         f0 = mlvl_feats[0]
-        needs_grad = torch.is_grad_enabled() and (self.cams_embeds.requires_grad or any(f.requires_grad for f in mlvl_feats))
-        if (self.fused_tokens and f0.is_cuda and f0.dtype == torch.float32 and not needs_grad and f0.shape[1] == self.num_cams
-                and all(f.shape[:3] == f0.shape[:3] for f in mlvl_feats)):
+        if self._tokens_fusable(mlvl_feats):
             # inference: one transposing pass per level (fbbev_tokens_from_nchw) writes feat + cams_embeds straight into the
             # (bs*num_cam, sum HW, C) token rows the cross-attention's value projection reads -- the flatten/permute/add,
             # the cat and the rebatch permute of the reference (three copies of the camera features) in one.  What the
             # encoder receives is the reference's (num_cam, sum HW, bs, C) tensor as a VIEW of those rows.
             bs, ncam, c = f0.shape[:3]
             S = sum(h * w for h, w in shapes)
-            rows = torch.empty((bs * ncam, S, c), dtype=torch.float32, device=f0.device)
-            ck = (self.cams_embeds.data_ptr(), self.cams_embeds._version, str(f0.device), self.use_cams_embeds)
-            if getattr(self, '_ce_key', None) != ck:       # per-weight-version constant (the reference adds `cams_embeds * 0` when unused)
-                ce = self.cams_embeds.detach().to(torch.float32)
-                self._ce, self._ce_key = (ce if self.use_cams_embeds else ce * 0).contiguous(), ck
-            ce = self._ce
-            if 1 < len(mlvl_feats) <= 8:       # the whole pyramid in one launch
-                _capi.tokens_from_nchw_levels([f.reshape(bs * ncam, c, h * w).contiguous() for f, (h, w) in zip(mlvl_feats, shapes)],
-                                              rows, ce)
-            else:
-                start = 0
-                for feat, (h, w) in zip(mlvl_feats, shapes):
-                    _capi.tokens_from_nchw(feat.reshape(bs * ncam, c, h * w).contiguous(), rows, start * c, ce)
-                    start += h * w
+            rows = _PRE.rows if (_PRE is not None and _PRE.rows is not None and _PRE.rows_key == _tkey(mlvl_feats)) else None
+            if rows is None:
+                rows = self._token_rows(mlvl_feats, shapes)
             feat_flatten = rows.view(bs, ncam, S, c).permute(1, 0, 2, 3)            # (num_cam, bs, sum HW, C)
         else:
             feats = []
@@ -1125,8 +1175,67 @@ class BackwardProjection(nn.Module):
     def init_weights(self):
         self.transformer.init_weights()
 
+    def prefetch(self, mlvl_feats, cam_params):
+        """Inference: start everything of the backward projection that does not need `lss_bev` -- the camera-token rows, their value
+        projection as head planes (first encoder layer), the BEV -> image point sampling -- on a side stream, so that it runs under the
+        caller's latency-bound ranking / Z-mean kernels.  Returns a handle for `forward(..., _pre=handle)` (same input tensors), or
+        None when the route does not apply (autograd, hipGraph capture, CPU, FBBEV_BP_PREFETCH=0)."""
+        f0 = mlvl_feats[0]
+        tr = self.transformer
+        if (not PREFETCH or torch.is_grad_enabled() or not f0.is_cuda or cam_params is None or not isinstance(tr, BEVFormer)
+                or torch.cuda.is_current_stream_capturing() or not tr._tokens_fusable(mlvl_feats)):
+            return None
+        # measured (profiles/r05_time_fb_prefetch.jsonl): -18 us at BASELINE configs[2] B = 4 (160 000 queries: the step is GPU-bound),
+        # but +80-95 us at the shipped shape B = 1 / 4 and at configs[2] B = 1, where the eager step is bound by the host's launches and
+        # the stream switch + event cost host time: only for large launches (a captured hipGraph never takes this route)
+        if f0.shape[0] * self.bev_h * self.bev_w < PREFETCH_MIN_QUERIES:
+            return None
+        main = torch.cuda.current_stream(f0.device)
+        if getattr(self, '_side_dev', None) != f0.device:
+            self._side, self._side_dev = torch.cuda.Stream(f0.device), f0.device
+        side = self._side
+        side.wait_stream(main)                                   # the inputs were produced on the caller's stream
+        pre = _Prefetch()
+        keep = []
+        with torch.cuda.stream(side):
+            shapes = [tuple(f.shape[-2:]) for f in mlvl_feats]
+            rows = tr._token_rows(mlvl_feats, shapes)
+            pre.rows, pre.rows_key = rows, _tkey(mlvl_feats)
+            keep.append(rows)
+            enc = tr.encoder
+            BN, S, E = rows.shape
+            bs = f0.shape[0]
+            if _RL.X3 and E % 8 == 0 and min(w for _, w in shapes) >= 2:
+                za = enc._axes(f0.device)[2].numel()
+                for att in enc.layers[0].attentions:
+                    if isinstance(att, DA_SpatialCrossAttention) and att.value_dtype is None and att.fused:
+                        da = att.deformable_attention
+                        if (not da.disable_deformable and E == att.embed_dims and _capi.da_cross_attn_fused_supported(
+                                bs, BN // bs, S, da.num_heads, E // da.num_heads, da.num_levels, self.bev_h * self.bev_w,
+                                da.num_points, za, self.bev_w)):
+                            planes = att._value_planes(rows.reshape(BN * S, E), S)
+                            pre.planes[id(att)] = ((rows.data_ptr(), BN, S, E), planes)
+                            keep.append(planes)
+            _, ref_cam, mask, qd = enc.point_sampling(None, enc.pc_range, None, cam_params=cam_params)
+            pre.sampling, pre.sampling_key = (ref_cam, mask, qd), _tkey(cam_params)
+            keep += [ref_cam, mask, qd]
+            pre.event = torch.cuda.Event()
+            pre.event.record(side)
+        for t in keep:
+            t.record_stream(main)                                # allocated on the side stream, consumed on the caller's
+        return pre
+
     def forward(self, mlvl_feats, img_metas, lss_bev=None, gt_bboxes_3d=None, cam_params=None, pred_img_depth=None,
-                bev_mask=None):
+                bev_mask=None, _pre=None):
+        global _PRE
+        if _pre is not None:
+            torch.cuda.current_stream(mlvl_feats[0].device).wait_event(_pre.event)
+            _PRE = _pre
+            try:
+                return self.forward(mlvl_feats, img_metas, lss_bev=lss_bev, gt_bboxes_3d=gt_bboxes_3d, cam_params=cam_params,
+                                    pred_img_depth=pred_img_depth, bev_mask=bev_mask)
+            finally:
+                _PRE = None
         bs = mlvl_feats[0].shape[0]
         dtype = mlvl_feats[0].dtype
         # (Q,bs,C) as backward_projection.py:96-99 -- built batch-major so that the encoder's permute(1,0,2) yields

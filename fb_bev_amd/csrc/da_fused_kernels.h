@@ -258,7 +258,7 @@ __device__ __forceinline__ void fbbev_daf_outproj_ln(const fbbev_daf_outproj& op
 // sampling_offsets.weight (M*L*P*2, E) / attention_weights.weight (M*L*P, E) in the order of k_rows_linear_x3_fragments, rows in
 // the MODULE's order ((m, l, p, xy) / (m, l, p)); so_bias / aw_bias fp32; slots (B, Q, M*DH).  blockDim = 64 * M.
 template <int DH, int MH, int NP, int HW, bool OP = false>
-__global__ void __launch_bounds__(64 * HW)
+__global__ void __launch_bounds__(64 * HW, 2)     // two waves per SIMD (HW = 4: two workgroups per CU; HW = 8: one): at most 256 registers
 k_da_cross_attn_fused(const float* __restrict__ planes, const int64_t* __restrict__ spatial_shapes,
                       const int64_t* __restrict__ level_start, const float* __restrict__ pred_depth,
                       const float* __restrict__ ref_cam, const unsigned char* __restrict__ mask,
@@ -411,6 +411,33 @@ k_da_cross_attn_fused(const float* __restrict__ planes, const int64_t* __restric
     for (int c = 0; c < DH / 2; ++c) { acc[c][0] = 0.f; acc[c][1] = 0.f; }
     const char* pb = reinterpret_cast<const char*>(planes);
     for (int l = 0; l < L; ++l) {
+        // a staged level (see below): the copy of its plane for the FIRST hit camera is requested here, into registers that are
+        // free during the projection (the sample slots are dead), and lands under the MFMAs instead of in front of the samples
+        const int sh = (int)spatial_shapes[2 * l], sw = (int)spatial_shapes[2 * l + 1];
+        const int lvl_off = (int)level_start[l] * DH;
+        const int lvl_n = sh * sw * DH;                                                      // floats of the level's plane
+        const bool staged = lvl_n <= stage_floats;                                           // uniform
+        constexpr int PRE_N = 7;                                                             // 16-byte pieces per lane held ahead (7 x 256 floats >= 1 760)
+        fbbev_v4f pre[PRE_N];
+        int cam0 = -1;
+        bool pre_ok = false;
+        if (staged) {
+            for (int cam = 0; cam < Ncam && cam0 < 0; ++cam) {
+                const bool hit = valid && fbbev_lds_ld_f32(my_qc + (size_t)cam * 64 * FBBEV_DAF_QC + 3 * ZA) != 0.f;
+                if (__ballot(hit) != 0ull) cam0 = cam;
+            }
+            if (cam0 >= 0) {
+                const float* src = reinterpret_cast<const float*>(pb + (((long long)b * Ncam + cam0) * MH + m) * (long long)S * DH * 4) + lvl_off;
+                pre_ok = (lvl_n & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0 && lvl_n <= PRE_N * 256;   // uniform
+                if (pre_ok) {
+#pragma unroll
+                    for (int k = 0; k < PRE_N; ++k) {
+                        const int i = lane * 4 + 256 * k;
+                        pre[k] = *reinterpret_cast<const fbbev_v4f*>(src + (i < lvl_n ? i : 0));
+                    }
+                }
+            }
+        }
         // the 2*P offsets of (head m, level l): rows ((m*L + l)*P + p)*2 + xy of sampling_offsets = ONE 16-output tile
         const int T = m * L + l;
         fbbev_daf_project<KS>(so_frag, T, xf, lane, pacc);
@@ -429,15 +456,11 @@ k_da_cross_attn_fused(const float* __restrict__ planes, const int64_t* __restric
 #pragma unroll
         for (int k = 0; k < 4; ++k) __builtin_memcpy(&o4[k], off_w + lane * FBBEV_DAF_OS + 4 * k, 16);
         fbbev_wave_sync();                       // every lane holds its offsets before the tile is overwritten
-        const int sh = (int)spatial_shapes[2 * l], sw = (int)spatial_shapes[2 * l + 1];
         const float fsh = (float)sh, fsw = (float)sw;
-        const int lvl_off = (int)level_start[l] * DH;
         // round 5: a level whose head plane fits the wave's staging region (the transposition tile, free between two projections,
         // + the launcher's extra bytes: 8 x 22 and 4 x 11 tokens at BASELINE configs[2]) is copied into LDS once per hit camera and
         // sampled from there: ds_read instead of ~22 vector-L1 line accesses per load instruction -- the counter that bounds
         // this kernel (TCP_TOTAL_CACHE_ACCESSES: 195 M per launch, 0.71 per CU-cycle; profiles/r04_pmc_fb_BL3_B4_final.json)
-        const int lvl_n = sh * sw * DH;                                                      // floats of the level's plane
-        const bool staged = lvl_n <= stage_floats;                                           // uniform
         for (int cam = 0; cam < Ncam; ++cam) {
             const float* rec = my_qc + (size_t)cam * 64 * FBBEV_DAF_QC;
             const bool hit = valid && fbbev_lds_ld_f32(rec + 3 * ZA) != 0.f;
@@ -453,7 +476,13 @@ k_da_cross_attn_fused(const float* __restrict__ planes, const int64_t* __restric
             fbbev_daf_pending<DH> pend[NP];
             if (staged) {
                 const float* src = reinterpret_cast<const float*>(plane) + lvl_off;
-                if ((lvl_n & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {      // uniform
+                if (cam == cam0 && pre_ok) {                                                 // requested before the projection
+#pragma unroll
+                    for (int k = 0; k < PRE_N; ++k) {
+                        const int i = lane * 4 + 256 * k;
+                        if (i < lvl_n) *reinterpret_cast<fbbev_v4f*>(off_w + i) = pre[k];
+                    }
+                } else if ((lvl_n & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {      // uniform
                     for (int i = lane * 4; i < lvl_n; i += 256) *reinterpret_cast<fbbev_v4f*>(off_w + i) = *reinterpret_cast<const fbbev_v4f*>(src + i);
                 } else {                                                                     // DH is even: 8-byte pieces
                     for (int i = lane * 2; i < lvl_n; i += 128) *reinterpret_cast<fbbev_v2f*>(off_w + i) = *reinterpret_cast<const fbbev_v2f*>(src + i);

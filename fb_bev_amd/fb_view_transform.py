@@ -66,10 +66,15 @@ class FBViewTransform(nn.Module):
             # inference: the volume is written ONCE.  The reference writes it (bev_pool_v2), reads it for the Z-mean
             # (fbocc.py:359) and reads + re-writes it for the re-add (:365-366); here the Z-mean comes straight from the
             # index tensors and the refined BEV is added in the store epilogue of the one dense pooling pass.
+            # round 5: what the backward projection can do without the Z-mean (camera-token rows, their value planes, point sampling:
+            # ~90 us at BASELINE configs[2]) starts on a side stream and runs under the ranking chain + Z-mean below, whose
+            # latency-bound kernels leave most of the chip idle
+            pre = self.backward_projection.prefetch(feats, cam_params) if hasattr(self.backward_projection, 'prefetch') else None
             parts = fp.pooling_inputs(cam_params, context, depth)
             lss_mean = fp.pooled_zmean(parts)
+            kw = {} if pre is None else {'_pre': pre}
             refined = self.backward_projection(feats, img_metas, lss_bev=lss_mean, cam_params=cam_params, bev_mask=bev_mask,
-                                               gt_bboxes_3d=None, pred_img_depth=depth)
+                                               gt_bboxes_3d=None, pred_img_depth=depth, **kw)
             return fp.pooled_volume(parts, addend=refined)
         both = fp.forward_with_zmean(cam_params, context, depth) if (self.backward_projection is not None and needs_grad and _ONE_OP) else None
         if both is not None:

@@ -234,6 +234,58 @@ def test_encoder_layer_with_and_without_the_fused_tail_ffn_route(dev):
     assert dlt <= 1e-5 * scale
 
 
+def test_side_stream_prefetch_of_the_backward_projection_changes_no_bit(dev):
+    """FBViewTransform (inference) starts the Z-mean-independent part of the backward projection -- camera-token rows, their value
+    planes, the BEV -> image point sampling -- on a side stream under the forward projection's ranking chain (round 5,
+    BackwardProjection.prefetch).  Same kernels, same inputs: the output is bit-identical to the single-stream order
+    (FBBEV_BP_PREFETCH=0), every one of 20 back-to-back calls with changing inputs (a missed stream dependency would show as a
+    stale or half-written buffer), and the prefetch really is consumed."""
+    from fb_bev_amd import backward_projection as BP, configs, synthetic as S
+    from fb_bev_amd.fb_view_transform import FBViewTransform
+    pc = S.CONFIGS['BL2']
+    X, Y, Z = pc.grid_xyz
+    gcb = {'x': pc.grid_config['x'], 'y': pc.grid_config['y'], 'z': [-1, 5.4, 1.6]}
+    cfg = configs.fbocc_r50(bev_h=Y, bev_w=X, numC_Trans=pc.channels, input_size=pc.input_size, grid_config=pc.grid_config,
+                            grid_config_bevformer=gcb, depth_bound=tuple(pc.grid_config['depth']), downsample=pc.downsample, num_levels=4)
+    torch.manual_seed(0)
+    m = FBViewTransform(cfg['forward_projection'], cfg['backward_projection'])
+    with torch.no_grad():
+        for n_, p_ in m.named_parameters():
+            if 'sampling_offsets.weight' in n_ or 'attention_weights.weight' in n_:
+                p_.normal_(0, 0.05)
+    m = m.to(dev).eval()
+    B = 2
+    H, W = pc.feat_hw
+    shapes = [(H, W), (2 * H, 2 * W), (H // 2, W // 2), (H // 4, W // 4)]
+    used = []
+    real = BP.BackwardProjection.prefetch
+
+    def spy(self, *a, **k):
+        r = real(self, *a, **k)
+        used.append(r is not None and bool(r.planes) and r.rows is not None and r.sampling is not None)
+        return r
+    BP.BackwardProjection.prefetch = spy
+    min_q, BP.PREFETCH_MIN_QUERIES = BP.PREFETCH_MIN_QUERIES, 0          # (the module only takes the route for >= 120 000 queries)
+    try:
+        with torch.no_grad():
+            for it in range(20):
+                cam = [t.to(dev) for t in S.camera_rig(pc, B, seed=it, bda_aug=True)]
+                depth, ctx = (t.to(dev) for t in S.depth_and_context(pc, B, seed=it))
+                g = torch.Generator().manual_seed(100 + it)
+                mlvl = [ctx] + [torch.randn(B, pc.n_cams, pc.channels, h, w, generator=g).to(dev) for h, w in shapes[1:]]
+                BP.PREFETCH = True
+                a = m(cam, ctx, depth, mlvl_feats=mlvl)
+                BP.PREFETCH = False
+                b = m(cam, ctx, depth, mlvl_feats=mlvl)
+                assert torch.equal(a, b), (it, (a - b).abs().max().item())
+    finally:
+        BP.PREFETCH = True
+        BP.PREFETCH_MIN_QUERIES = min_q
+        BP.BackwardProjection.prefetch = real
+    assert used.count(True) == 20, used
+    _say('BackwardProjection.prefetch on a side stream: 20 / 20 calls bit-identical to the single-stream order')
+
+
 # ------------------------------------------------------------------ camera-token pyramid in one launch
 @pytest.mark.parametrize('images,C,shapes', [(24, 80, ((16, 44), (32, 88), (8, 22), (4, 11))), (6, 80, ((16, 44),)), (5, 33, ((5, 9), (8, 4), (1, 3), (2, 2)))])
 def test_token_pyramid_in_one_launch_bit_exact(dev, images, C, shapes):
