@@ -364,6 +364,7 @@ DEFAULT_TILE_VOXELS = 128
 POOL_CHANNELS_LAST = 0x100000
 POOL_OUT_BF16, POOL_OUT_F16 = 0x800000, 0x1000000
 POOL_PIPE = 0x4000000         # a workgroup walks a run of tiles with the next tile's staging loads in flight (dense grids; same bits)
+POOL_GATHER8 = 0x8000000      # eight points per gather batch (experiment knob for dense grids; same bits)
 POOL_SPLIT_LONG = 0x2000000   # tolerance mode: long intervals summed by the whole workgroup (<= 1e-4, not bit-exact)
 
 

@@ -616,17 +616,18 @@ struct dense2_args {
     const float* addend = nullptr;   // optional (B,C,Y,X) broadcast-over-z add in the dense2 epilogue
     float* out;
     bool split = false;              // FBBEV_POOL_SPLIT_LONG: long intervals summed by the whole workgroup (tolerance mode)
+    bool gather8 = false;            // FBBEV_POOL_GATHER8: eight points per gather batch (experiment knob, same bits)
 };
 
 #define FBBEV_POOL_SPLIT_LEN 32      // points above which an interval is split over the lane groups in tolerance mode
-template <int TV, int CPL, int ST, int NT, int OT, bool T16 = false, int SPLIT = 0>
+template <int TV, int CPL, int ST, int NT, int OT, bool T16 = false, int SPLIT = 0, int GU = 4>
 static int launch_dense2(const dense2_args& a) {
     size_t lds = a.lds;
     if (SPLIT > 0) lds += ((size_t)TV + 4) * sizeof(int) + (size_t)FBBEV_POOL_SPLIT_GROUPS * (a.C / a.csplit) * sizeof(float);   // long-interval list + partial sums
     if (T16)                                   // 16-bit tile [CC][TV + 8] instead of fp32 [CC][TV + 4]
         lds = (size_t)(a.C / a.csplit) * (TV + 8) * 2 + ((size_t)3 * TV + 2 * FBBEV_NP_STAGE) * sizeof(int);
     if (lds > 64 * 1024) {  // > 64 KiB of dynamic LDS must be opted into (160 KiB per CU on gfx950)
-        int e = fbbev_rt_allow_dyn_lds((const void*)k_pool_fwd_dense2<TV, CPL, ST, NT, OT, T16, 0, SPLIT>, lds);
+        int e = fbbev_rt_allow_dyn_lds((const void*)k_pool_fwd_dense2<TV, CPL, ST, NT, OT, T16, 0, SPLIT, GU>, lds);
         if (e) return e;
     }
     long long grid = a.n_blocks;
@@ -634,7 +635,7 @@ static int launch_dense2(const dense2_args& a) {
         const long long g = 8ll << (a.swizzle - 1);
         grid = (a.n_blocks + g - 1) / g * g;
     }
-    FBBEV_LAUNCH((k_pool_fwd_dense2<TV, CPL, ST, NT, OT, T16, 0, SPLIT>), grid, NT, lds, a.stream, a.C, a.Z, a.yx, a.tpp,
+    FBBEV_LAUNCH((k_pool_fwd_dense2<TV, CPL, ST, NT, OT, T16, 0, SPLIT, GU>), grid, NT, lds, a.stream, a.C, a.Z, a.yx, a.tpp,
                  a.csplit, (int)a.n_blocks, a.swizzle, a.stride_b, a.stride_c, a.depth, a.feat, a.rd, a.rf, a.irank, a.starts, a.lengths, a.tile_meta, a.addend, a.out);
     return fbbev_rt_last_error();
 }
@@ -644,6 +645,12 @@ static int launch_dense2_nt(int nt, int ot, const dense2_args& a) {
     if (a.split) {                // tolerance mode: fp32 volume, default store policy, 256 threads, 64- / 128-voxel tiles
         if constexpr (ST == 4 && (TV == 64 || TV == 128)) {
             if (ot == 0 && nt == 256) return launch_dense2<TV, CPL, 4, 256, 0, false, FBBEV_POOL_SPLIT_LEN>(a);
+        }
+        return FBBEV_E_UNSUPPORTED;
+    }
+    if (a.gather8) {              // experiment knob: fp32 volume, default store policy, 256 threads, 64- / 128-voxel tiles
+        if constexpr (ST == 4 && (TV == 64 || TV == 128)) {
+            if (ot == 0 && nt == 256) return launch_dense2<TV, CPL, 4, 256, 0, false, 0, 8>(a);
         }
         return FBBEV_E_UNSUPPORTED;
     }
@@ -789,6 +796,7 @@ static int pool_dense_fwd_impl(const float* depth, const float* feat,
     a.starts = interval_starts; a.lengths = interval_lengths; a.tile_meta = static_cast<const int*>(tile_ws);
     a.out = out; a.stride_b = out_stride_b; a.stride_c = out_stride_c; a.addend = addend;
     a.split = (flags & FBBEV_POOL_SPLIT_LONG) != 0;
+    a.gather8 = (flags & FBBEV_POOL_GATHER8) != 0 && !a.split;
     if ((flags & FBBEV_POOL_PIPE) && ot == 0 && !a.split && nt == 256 && st >= 2 && (TV == 64 || TV == 128 || TV == 256)) {
         // tiles per workgroup: enough to amortise the pipeline's fill, few enough to keep >= ~8 workgroups per CU's worth of runs
 #ifdef FBBEV_TEST_OVERRIDES   // CPU emulator build: the tests switch the run length inside one process
@@ -1520,6 +1528,8 @@ static int da_cross_attn_fused_impl(const float* planes, const int64_t* spatial_
 #endif
     const size_t lds = fbbev_daf_lds_bytes(E, hw, Ncam, stage_floats);
     if (lds > 160 * 1024) return FBBEV_E_UNSUPPORTED;
+    static const bool pre_off = [] { const char* e = getenv("FBBEV_DA_FUSED_PRE"); return e && atoi(e) == 0; }();   // A/B knob, read once
+    const int stage_arg = stage_floats | (pre_off ? 0x40000000 : 0);
 #define FBBEV_DA_FUSED(DH_, NP_, HW_) FBBEV_DA_FUSED2(DH_, NP_, HW_, false)
 #define FBBEV_DA_FUSED2(DH_, NP_, HW_, OP_)                                                                            \
     do {                                                                                                               \
@@ -1529,7 +1539,7 @@ static int da_cross_attn_fused_impl(const float* planes, const int64_t* spatial_
                      level_start_index, pred_depth, ref_cam, mask, qdepth, query, query_row_stride, addend,           \
                      addend_row_stride, addend_period, static_cast<const unsigned short*>(offsets_fragments),         \
                      offsets_bias, static_cast<const unsigned short*>(attn_fragments), attn_bias, B, Ncam, S, L, Q,    \
-                     bev_w, DC, d0, dstep, slots, op, stage_floats);                                                   \
+                     bev_w, DC, d0, dstep, slots, op, stage_arg);                                                      \
     } while (0)
     // (three samples in flight per lane -- FBBEV_DA_FUSED_NP=3 in round 4 -- measured no gain and, with the staged levels' second
     // sample loop, no longer fits the register file: the instantiations are gone, two in flight is the form)

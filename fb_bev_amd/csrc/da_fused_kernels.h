@@ -269,6 +269,8 @@ k_da_cross_attn_fused(const float* __restrict__ planes, const int64_t* __restric
                       int B, int Ncam, int S, int L, int Q, int bev_w, int DC, float d0, float dstep, float* __restrict__ slots,
                       fbbev_daf_outproj op, int stage_floats) {
     constexpr int E = MH * DH, KS = (E + 31) / 32, P = FBBEV_DAF_P, ZA = FBBEV_DAF_ZA, NT = 64 * HW, PARTS = MH / HW;
+    const bool pre_copy = (stage_floats & 0x40000000) == 0;     // A/B bit of the launcher: the first staged copy ahead of the projection
+    stage_floats &= 0x3fffffff;
     static_assert(!OP || (HW == MH && E % 16 == 0), "the output_proj + LayerNorm tail needs all heads of a query in one workgroup");
     static_assert((2 * DH) % 4 == 0 && DH % 2 == 0 && E % 8 == 0, "runs of whole 16-byte pieces, channel pairs");
     static_assert(NP >= 2 && NP <= FBBEV_DAF_P, "samples in flight per lane");
@@ -421,7 +423,7 @@ k_da_cross_attn_fused(const float* __restrict__ planes, const int64_t* __restric
         fbbev_v4f pre[PRE_N];
         int cam0 = -1;
         bool pre_ok = false;
-        if (staged) {
+        if (staged && pre_copy) {
             for (int cam = 0; cam < Ncam && cam0 < 0; ++cam) {
                 const bool hit = valid && fbbev_lds_ld_f32(my_qc + (size_t)cam * 64 * FBBEV_DAF_QC + 3 * ZA) != 0.f;
                 if (__ballot(hit) != 0ull) cam0 = cam;

