@@ -36,6 +36,24 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
+class no_gc:
+    """Timed regions run with the cyclic garbage collector paused (collected first, re-enabled after): a full collection of a
+    process that has imported torch takes 30-80 ms, and one of them landing inside a 30-step loop of 0.45 ms steps tripled a
+    leg's ms_per_step (tools/diag_bf16_leg.py + tools/diag_bf16_leg_trace.sh: the GPU time line shows the kernels at their usual
+    durations and ONE idle gap of 31-80 ms between two steps).  Nothing is skipped: reference-counted frees are unaffected."""
+
+    def __enter__(self):
+        import gc
+        gc.collect()
+        self.was = gc.isenabled()
+        gc.disable()
+
+    def __exit__(self, *a):
+        import gc
+        if self.was:
+            gc.enable()
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -305,13 +323,14 @@ def fb_projection_leg(dev, steps, warmup, cpu_seconds, with_cpu=True):
         sev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
         _capi.da_cross_attn_fused = timed_da
         try:
-            t0 = time.perf_counter()
-            for i in range(steps):
-                sev[i][0].record()
-                res = m(cam, ctx, depth, mlvl_feats=mlvl)
-                sev[i][1].record()
-            torch.cuda.synchronize(dev)
-            elapsed = time.perf_counter() - t0
+            with no_gc():
+                t0 = time.perf_counter()
+                for i in range(steps):
+                    sev[i][0].record()
+                    res = m(cam, ctx, depth, mlvl_feats=mlvl)
+                    sev[i][1].record()
+                torch.cuda.synchronize(dev)
+                elapsed = time.perf_counter() - t0
         finally:
             _capi.da_cross_attn_fused = real_da
         step_ms = sorted(a.elapsed_time(b) for a, b in sev)
@@ -509,11 +528,12 @@ def run_forward(args):
         for _ in range(args.warmup):
             idx = step()
     fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        idx = step(i)
-    fence()
-    elapsed = time.perf_counter() - t0
+    with no_gc():
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            idx = step(i)
+        fence()
+        elapsed = time.perf_counter() - t0
     elapsed = shard.max_over_ranks(elapsed, dev)
 
     # the graph-replayed step must produce what the eagerly launched step produces: one eager step into a second volume
@@ -537,14 +557,11 @@ def run_forward(args):
         tws16 = v16._tile_ws(dev, B, tv16)
         out16 = torch.empty((B, C, Z, Y, X), dtype=torch.bfloat16, device=dev)
         ev16 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-        ft16 = None
 
         def step16(i=None):
             ix = v16.build_index_from_cams(*cam)
             ft = _capi.nchw_to_nhwc(ctx)
             _capi.pool_tile_index(ix.interval_rank, ix.interval_starts, ix.counts, ix.n, B, Z, Y, X, tws16, tv16)
-            nonlocal ft16
-            ft16 = ft
             if i is not None:
                 ev16[i][0].record()
             _capi.bev_pool_v2_dense_fwd(depth, ft, ix.ranks_depth, ix.ranks_feat, ix.interval_rank, ix.interval_starts,
@@ -555,11 +572,12 @@ def run_forward(args):
         for _ in range(args.warmup):
             step16()
         fence()
-        t16 = time.perf_counter()
-        for i in range(args.steps):
-            ix16 = step16(i)
-        fence()
-        t16 = time.perf_counter() - t16
+        with no_gc():
+            t16 = time.perf_counter()
+            for i in range(args.steps):
+                ix16 = step16(i)
+            fence()
+            t16 = time.perf_counter() - t16
         k16 = sum(a.elapsed_time(b) for a, b in ev16) / max(1, args.steps)
         P16, I16 = ix16.counts.tolist()
         ab16 = 4 * B * cfg.n_cams * cfg.D * cfg.feat_hw[0] * cfg.feat_hw[1] + 4 * B * cfg.n_cams * cfg.feat_hw[0] * cfg.feat_hw[1] * C + \
@@ -567,6 +585,7 @@ def run_forward(args):
         same = torch.equal(out16, out.to(torch.bfloat16))           # == the fp32 volume rounded once
         # the bf16 instantiation's own floors: stores alone / all but the gathers / all but the stores
         fl16_ms = {}
+        ft16 = _capi.nchw_to_nhwc(ctx)
         scratch16 = torch.empty_like(out16)
         for mode, name in ((1, 'store_floor_ms'), (2, 'no_gather_ms'), (3, 'no_store_ms')):
             try:
@@ -584,7 +603,7 @@ def run_forward(args):
                 fl16_ms[name] = sum(ts) / len(ts)
             except _capi.FbbevError:
                 fl16_ms[name] = None
-        del scratch16
+        del scratch16, ft16
         alt = {'volume_storage': 'bf16', 'accumulate_dtype': 'f32', 'value': B * args.steps / t16, 'unit': 'samples/s',
                'ms_per_step': 1e3 * t16 / args.steps, 'tile_voxels': tv16, 'kernel_ms': k16,
                'algorithmic_bytes_per_launch': ab16, 'roofline_frac': ab16 / (k16 * 1e-3) / 1e9 / HBM_PEAK_GBS if k16 > 0 else None,
@@ -719,14 +738,19 @@ def run_forward(args):
             for _ in range(max(3, args.warmup)):
                 oc = vc(cam, ctx, depth)
             fence()
-            tc = time.perf_counter()
-            for _ in range(args.steps):
-                oc = vc(cam, ctx, depth)
+            with no_gc():
+                tc = time.perf_counter()
+                for _ in range(args.steps):
+                    oc = vc(cam, ctx, depth)
+                fence()
+                tc = time.perf_counter() - tc
+            ei, ef = prep()                                              # (the fill-rate loop above zeroed `out`: one fresh uncached step)
+            pool(ei, ef, out)
             fence()
-            tc = time.perf_counter() - tc
             cached = {'what': 'forward projection with the camera-keyed index cache hit every step (rank build skipped on the device)',
                       'value': B * args.steps / tc, 'unit': 'samples/s', 'ms_per_step': 1e3 * tc / args.steps,
                       'volume_equals_uncached': bool(torch.equal(oc.permute(0, 1, 4, 2, 3), out))}
+            del ei, ef
             del oc, vc
 
     # Extra leg (beside `value`, never as it): BASELINE configs[2] -- the backward-projection half of the path on this GPU
@@ -751,6 +775,7 @@ def run_forward(args):
                        'per step, pooling kernel launched eagerly between the HIP events that time it' if graph is not None else
                        'every kernel launched one by one from the host'),
             'graph_step_equals_eager_step': graph_equal, 'launch_probe': launch_probe, 'graph_capture_error': graph_error,
+            'timed_regions': 'cyclic garbage collector paused (collected before, re-enabled after); barrier + device synchronisation on both sides',
             'config': {'workload': f'FB-OCC forward projection, ' + ('BASELINE configs[1] ' if cfg.name == 'BL2' else '') +
                                    f'({cfg.name}): 6x{cfg.input_size[0]}x{cfg.input_size[1]} in, '
                                    f'feat {H}x{W}, D={D}, C={C}, grid {X}x{Y}x{Z}; index tensors rebuilt every step',
@@ -861,11 +886,13 @@ def run_train(args):
         for _ in range(max(0, warmup - 1)):
             total = step()
         shard.fence(dev)
-        t0 = time.perf_counter()
-        for i in range(steps):
-            total = step(i)
-        shard.fence(dev)
-        return shard.max_over_ranks(time.perf_counter() - t0, dev), total
+        with no_gc():
+            t0 = time.perf_counter()
+            for i in range(steps):
+                total = step(i)
+            shard.fence(dev)
+            dt = time.perf_counter() - t0
+        return shard.max_over_ranks(dt, dev), total
 
     model, buckets, opt = build(args.conv_dtype)
     params = buckets.params

@@ -1044,7 +1044,7 @@ static int pool_zmean_impl(const float* depth, const float* feat, const int32_t*
     const int CC = C / csplit;
     const bool cpl8 = (flags & FBBEV_POOL_CPL8) && (CC % 8 == 0);
     if (256 / (CC / (cpl8 ? 8 : 4)) < 1) return FBBEV_E_UNSUPPORTED;
-    const size_t lds = ((size_t)CC * (TV + 4) + 3 * (size_t)TV + 2 * FBBEV_NP_STAGE + 4 * (size_t)Z) * sizeof(float);   // + the planes' tile metadata
+    const size_t lds = ((size_t)CC * (TV + 4) + 3 * (size_t)TV + 2 * FBBEV_NP_STAGE) * sizeof(float);
     if (lds > 64 * 1024) return FBBEV_E_UNSUPPORTED;
     const long long blocks = (long long)B * tiles_per_plane * csplit;
     if (z_groups > Z) z_groups = Z;

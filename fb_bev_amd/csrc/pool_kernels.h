@@ -812,19 +812,11 @@ k_pool_zmean(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_blocks
     const int zper = (Z + z_groups - 1) / z_groups;
     const int z_lo = zg * zper, z_hi = z_lo + zper < Z ? z_lo + zper : Z;
     for (int idx = tid; idx < CC * LD; idx += NT) tile[idx] = 0.f;
-    // round 5: the tile metadata of EVERY plane this workgroup walks is fetched up front (one lane per plane) -- one dependent
-    // memory round trip in front of the walk instead of one per plane
-    int* zmeta = prf + FBBEV_NP_STAGE;         // [4 * (z_hi - z_lo)]
-    for (int zz = z_lo + tid; zz < z_hi; zz += NT) {
-        const int t = (b * Z + zz) * tiles_per_plane + k;
-        int* m4 = zmeta + 4 * (zz - z_lo);
-        m4[0] = tile_meta[2 * t]; m4[1] = tile_meta[2 * t + 1]; m4[2] = tile_meta[2 * t + 2]; m4[3] = tile_meta[2 * t + 3];
-    }
-    __syncthreads();
     for (int z = z_lo; z < z_hi; ++z) {
         const int plane = b * Z + z;
-        const int* m4 = zmeta + 4 * (z - z_lo);
-        const int i0 = m4[0], p0 = m4[1], i1 = m4[2], p1 = m4[3];
+        const int t = plane * tiles_per_plane + k;
+        const int i0 = tile_meta[2 * t], p0 = tile_meta[2 * t + 1];
+        const int i1 = tile_meta[2 * t + 2], p1 = tile_meta[2 * t + 3];
         if (i0 == i1) continue;                 // block-uniform
         const int ni = i1 - i0, np = p1 - p0;
         const int rank0 = plane * YX + v0;

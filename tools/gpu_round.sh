@@ -11,11 +11,11 @@ if [ "$MODE" != "quick" ]; then
   timeout 300 python bench.py --steps 30 --warmup 5 --storage bf16 --no-cpu-baseline > $OUT/bench_bf16.json 2>> $OUT/bench.err; cut -c1-300 $OUT/bench_bf16.json
   cd /tmp
   rm -rf $OUT/prof_stats $OUT/prof_fetch $OUT/prof_write
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -- python $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-alt-storage > $OUT/prof_stats.log 2>&1; echo "rocprof stats rc=$?" | tee -a $OUT/box.txt
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -- python $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-alt-storage --no-fb-projection > $OUT/prof_stats.log 2>&1; echo "rocprof stats rc=$?" | tee -a $OUT/box.txt
   timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/prof_fetch -- python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-alt-storage --no-fb-projection > $OUT/prof_fetch.log 2>&1; echo "rocprof fetch rc=$?" | tee -a $OUT/box.txt
   timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/prof_write -- python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-alt-storage --no-fb-projection > $OUT/prof_write.log 2>&1; echo "rocprof write rc=$?" | tee -a $OUT/box.txt
   cd $REPO
-  python tools/pmc_to_json.py $OUT BL2_B16_tv128
+  python tools/pmc_to_json.py $OUT BL2_B16_tv128 "k_pool_fwd_dense2<128, 8, 4, 256, 0, false, 0, 0"
   find $OUT -name "*.csv" -size +20M -delete
 fi
 echo "== done $(date)" >> $OUT/box.txt
