@@ -71,7 +71,10 @@ SIGNATURES = {
     'fbbev_rows_tail_ffn_x3': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_void_p]),
     'fbbev_rows_linear_x3_planes': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'fbbev_rows_linear_x3_planes_e': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'fbbev_da_cross_attn_fused_supported': (c_int, [c_int] * 10),
+    'fbbev_da_cross_attn_fused_e': (c_int, [c_void_p, c_int] + [c_void_p] * 7 + [c_int64, c_void_p, c_int64, c_int64] + [c_void_p] * 4 + [c_int] * 10 +
+                                    [c_float, c_float, c_int, c_int, c_void_p, c_void_p]),
     'fbbev_da_cross_attn_fused': (c_int, [c_void_p] * 8 + [c_int64, c_void_p, c_int64, c_int64] + [c_void_p] * 4 + [c_int] * 10 +
                                   [c_float, c_float, c_int, c_int, c_void_p, c_void_p]),
     'fbbev_da_cross_attn_fused_ln': (c_int, [c_void_p] * 8 + [c_int64, c_void_p, c_int64, c_int64] + [c_void_p] * 4 +
@@ -953,18 +956,27 @@ def rows_tail_ffn_x3(x, w0_fragments, b0, residual0, ln0_weight, ln0_bias, ln0_e
     return out
 
 
-def rows_linear_x3_planes(x, fragments, bias, tokens_per_image, heads, head_dim, out=None):
+def rows_linear_x3_planes(x, fragments, bias, tokens_per_image, heads, head_dim, out=None, dtype=None):
     """x (R, I) f32 rows of camera tokens (R = images * tokens_per_image) -> head planes (images, heads, tokens_per_image, head_dim)
-    = value_proj written in the layout fbbev_da_cross_attn_fused samples (fbbev_rows_linear_x3_planes)."""
+    = value_proj written in the layout fbbev_da_cross_attn_fused samples (fbbev_rows_linear_x3_planes).  dtype bfloat16 / float16:
+    the planes stored in 16 bits (fbbev_rows_linear_x3_planes_e: the fp32 result rounded once)."""
     R, I = x.shape
     if x.stride(1) != 1 or R % tokens_per_image != 0:
         raise FbbevError('rows_linear_x3_planes: rows must have unit column stride and cover whole images')
     shape = (R // tokens_per_image, heads, tokens_per_image, head_dim)
+    dt = F32 if dtype is None else dtype
     if out is None:
-        out = torch.empty(shape, dtype=F32, device=x.device)
-    if tuple(out.shape) != shape or not out.is_contiguous():
-        raise FbbevError('rows_linear_x3_planes: out must be contiguous (images, heads, tokens, head_dim)')
+        out = torch.empty(shape, dtype=dt, device=x.device)
+    if tuple(out.shape) != shape or not out.is_contiguous() or out.dtype not in (F32, torch.bfloat16, torch.float16):
+        raise FbbevError('rows_linear_x3_planes: out must be contiguous (images, heads, tokens, head_dim), f32 / bf16 / f16')
     b = _dev(bias, F32, 'bias') if bias is not None else None
+    if out.dtype != F32:
+        with _on(x):
+            _check(lib().fbbev_rows_linear_x3_planes_e(_dev(x, F32, 'x', contiguous=False), x.stride(0), fragments.data_ptr(), b, R, I,
+                                                       heads * head_dim, tokens_per_image, head_dim,
+                                                       1 if out.dtype == torch.bfloat16 else 2, c_void_p(out.data_ptr()), _stream()),
+                   'fbbev_rows_linear_x3_planes_e')
+        return out
     with _on(x):
         _check(lib().fbbev_rows_linear_x3_planes(_dev(x, F32, 'x', contiguous=False), x.stride(0), fragments.data_ptr(), b, R, I,
                                                  heads * head_dim, tokens_per_image, head_dim, _dev(out, F32, 'out'), _stream()),
@@ -1095,6 +1107,18 @@ def da_cross_attn_fused(planes, spatial_shapes, level_start_index, pred_depth, r
                 None if res is None else _dev(res, F32, 'residual'), E, _dev(lnw, F32, 'ln_weight'), _dev(lnb, F32, 'ln_bias'), float(eps),
                 B, Ncam, S, M, Dh, L, Q, int(num_points), Za, DC, float(d0), float(dstep), int(bev_w), int(min_level_width),
                 _dev(slots, F32, 'out'), _stream()), 'fbbev_da_cross_attn_fused_ln')
+        return slots
+    if planes.dtype in (torch.bfloat16, torch.float16):       # 16-bit camera tokens (storage option; products and sums stay fp32)
+        if not planes.is_cuda or not planes.is_contiguous():
+            raise FbbevError('da_cross_attn_fused: 16-bit planes must be contiguous GPU tensors')
+        with _on(planes):
+            _check(lib().fbbev_da_cross_attn_fused_e(
+                c_void_p(planes.data_ptr()), 1 if planes.dtype == torch.bfloat16 else 2, _dev(spatial_shapes, I64, 'spatial_shapes'),
+                _dev(level_start_index, I64, 'level_start_index'), _dev(pred_depth, F32, 'pred_depth'), _dev(ref_cam, F32, 'ref_cam'),
+                _dev(mask, torch.uint8, 'mask'), _dev(qdepth, F32, 'qdepth'), _dev(query, F32, 'query', contiguous=False), query.stride(1),
+                a_ptr, a_ld, a_per, offsets_fragments.data_ptr(), _dev(offsets_bias, F32, 'offsets_bias'), attn_fragments.data_ptr(),
+                _dev(attn_bias, F32, 'attn_bias'), B, Ncam, S, M, Dh, L, Q, int(num_points), Za, DC, float(d0), float(dstep), int(bev_w),
+                int(min_level_width), _dev(slots, F32, 'slots'), _stream()), 'fbbev_da_cross_attn_fused_e')
         return slots
     with _on(planes):
         _check(lib().fbbev_da_cross_attn_fused(

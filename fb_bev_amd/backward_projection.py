@@ -563,6 +563,7 @@ def _pad_interleave_rows(w, b, M, Dh, HS, interleave=True, piece=4):
 import os as _os
 FUSE_FFN = _os.environ.get('FBBEV_FUSE_FFN', '1') != '0'               # the FFN pair as one kernel (fbbev_rows_ffn_x3; A/B knob)
 FUSE_TAIL_FFN = _os.environ.get('FBBEV_FUSE_TAIL_FFN', '1') != '0'   # cross-attention tail + FFN block as one kernel (fbbev_rows_tail_ffn_x3; A/B knob)
+PLANES_16BIT = _os.environ.get('FBBEV_DA_16BIT_PLANES', '1') != '0'   # 16-bit camera tokens as head planes on the one-kernel sampler (A/B knob; 0: round-3 kernels)
 FUSE_OUT_NORM = _os.environ.get('FBBEV_FUSE_OUT_NORM', '1') != '0'     # output_proj / FFN tail + residual + LayerNorm in one kernel (A/B knob)
 FUSE_ATTN_TAIL = _os.environ.get('FBBEV_FUSE_ATTN_TAIL', '1') != '0'   # ... inside the attention kernel's own workgroups (A/B knob)
 FUSE_ATTN_TAIL_DA = _os.environ.get('FBBEV_FUSE_ATTN_TAIL_DA', '0') != '0'   # the same for the cross-attention (needs its 8-heads-per-workgroup form)
@@ -609,6 +610,15 @@ class DA_SpatialCrossAttention(nn.Module):
         grad_mode = torch.is_grad_enabled() and (value.requires_grad or query.requires_grad or pred_img_depth.requires_grad or
                                                  (query_pos is not None and query_pos.requires_grad) or
                                                  any(p.requires_grad for p in da.parameters()))
+        if (PLANES_16BIT and self.value_dtype in (torch.bfloat16, torch.float16) and not grad_mode and not da.disable_deformable and
+                x.dtype == torch.float32 and x.is_cuda):
+            # round 5: 16-bit camera tokens on the one-kernel route too -- value_proj writes bf16 / fp16 HEAD PLANES
+            # (fbbev_rows_linear_x3_planes_e), the sampler reads them (fbbev_da_cross_attn_fused_e): half the gather bytes of the
+            # default, fp32 products and sums.  None (unsupported shape): the round-3 kernels below
+            slots = self._slots_one_kernel(da, x, query, query_pos, reference_points_cam, mask, bev_query_depth, pred_img_depth,
+                                           spatial_shapes, level_start_index, bev_w, plane_dtype=self.value_dtype)
+            if slots is not None:
+                return slots
         if self.value_dtype in (torch.bfloat16, torch.float16) and not grad_mode and Dh in (8, 10, 16, 32):
             # 16-bit tokens: rows chunk-major with 8-element pieces, rounded once after the fp32 projection
             HS16 = (Dh + 7) // 8 * 8
@@ -685,7 +695,7 @@ class DA_SpatialCrossAttention(nn.Module):
 
     # ---- inference default since round 4: query rows -> slots in ONE kernel (fbbev_da_cross_attn_fused, da_fused_kernels.h)
     def _slots_one_kernel(self, da, x, query, query_pos, reference_points_cam, mask, bev_query_depth, pred_img_depth,
-                          spatial_shapes, level_start_index, bev_w, _tail=None):
+                          spatial_shapes, level_start_index, bev_w, _tail=None, plane_dtype=None):
         """value_proj writes the camera tokens as head planes (fbbev_rows_linear_x3_planes); the sampling_offsets / attention_weights
         projections, the softmax and the sampling run inside one kernel from the query rows (+ positional rows): no offsets /
         weights tensors (492 MB written and re-read at BASELINE configs[2], B = 4).  None when the shape is not the kernel's
@@ -702,11 +712,13 @@ class DA_SpatialCrossAttention(nn.Module):
             return None
         if not hasattr(self, '_vx3p'):
             self._vx3p, da._so_x3p, da._aw_x3p = X3Weights(), X3Weights(), X3Weights()
-        pre = _PRE.planes.get(id(self)) if _PRE is not None else None
+        pre = _PRE.planes.get(id(self)) if (_PRE is not None and plane_dtype is None) else None
         if pre is not None and pre[0] == (x.data_ptr(), BN, S, E):      # projected on the side stream by BackwardProjection.prefetch
             planes = pre[1]
         else:
-            planes = self._value_planes(x.reshape(BN * S, E), S)
+            planes = self._value_planes(x.reshape(BN * S, E), S, plane_dtype)
+        if plane_dtype is not None:
+            _tail = None                                                  # (the block tail inside the sampler is an fp32-plane route)
         so = da._so_x3p.get(da.sampling_offsets.weight, da.sampling_offsets.bias)
         aw = da._aw_x3p.get(da.attention_weights.weight, da.attention_weights.bias)
         addend = None
@@ -722,13 +734,14 @@ class DA_SpatialCrossAttention(nn.Module):
             bev_query_depth.squeeze(-1).contiguous().float(), query, addend, so.frag, so.b, aw.frag, aw.b, P, self.dbound[0],
             self.dbound[2], bev_w, min(int(w) for _, w in hw), slots, out_proj=self._take_tail(_tail))
 
-    def _value_planes(self, x2d, S):
-        """value_proj of the camera-token rows (images * S, E) written as head planes (images, M, S, Dh)"""
+    def _value_planes(self, x2d, S, dtype=None):
+        """value_proj of the camera-token rows (images * S, E) written as head planes (images, M, S, Dh); dtype bf16 / fp16: stored
+        in 16 bits (the fp32 projection rounded once)"""
         da = self.deformable_attention
         if not hasattr(self, '_vx3p'):
             self._vx3p, da._so_x3p, da._aw_x3p = X3Weights(), X3Weights(), X3Weights()
         vp = self._vx3p.get(da.value_proj.weight, da.value_proj.bias)
-        return _capi.rows_linear_x3_planes(x2d, vp.frag, vp.b, S, da.num_heads, self.embed_dims // da.num_heads)
+        return _capi.rows_linear_x3_planes(x2d, vp.frag, vp.b, S, da.num_heads, self.embed_dims // da.num_heads, dtype=dtype)
 
     @staticmethod
     def _take_tail(tail):

@@ -1473,7 +1473,7 @@ extern "C" int fbbev_da_cross_attn_fwd_zt(const float* value, const int64_t* spa
 static bool da_fused_shape_ok(int B, int Ncam, int S, int M, int Dh, int L, int Q, int P, int Za, int bev_w) {
     if (M != 8 || (Dh != 10 && Dh != 8) || P != FBBEV_DAF_P || Za != FBBEV_DAF_ZA || L < 1 || bev_w <= 0 || Q % bev_w != 0) return false;
     if (L > FBBEV_DAF_MAXL || fbbev_daf_lds_bytes(M * Dh, 8, Ncam) > 160 * 1024) return false;
-    return (long long)S * Dh * 4 < (1ll << 31);                                      // 32-bit byte offsets inside a head plane
+    return (long long)S * Dh * 4 < (1ll << 31) && S < (1 << 24);                     // 32-bit byte offsets inside a head plane, 24-bit token indices
 }
 extern "C" int fbbev_da_cross_attn_fused_supported(int B, int Ncam, int S, int M, int Dh, int L, int Q, int P, int Za, int bev_w) {
     if (B <= 0 || Ncam <= 0 || S <= 0 || M <= 0 || Dh <= 0 || L <= 0 || Q <= 0 || P <= 0 || Za <= 0) return 0;
@@ -1486,9 +1486,11 @@ static int da_cross_attn_fused_impl(const float* planes, const int64_t* spatial_
                                     long long addend_row_stride, long long addend_period, const void* offsets_fragments,
                                     const float* offsets_bias, const void* attn_fragments, const float* attn_bias, int B,
                                     int Ncam, int S, int M, int Dh, int L, int Q, int P, int Za, int DC, float d0, float dstep,
-                                    int bev_w, int min_level_width, float* slots, fbbev_stream_t stream_, fbbev_daf_outproj op) {
-    if (B <= 0 || Ncam <= 0 || S <= 0 || M <= 0 || Dh <= 0 || L <= 0 || Q < 0 || P <= 0 || Za <= 0 || DC <= 0 || bev_w < 0)
-        return FBBEV_E_BADARG;
+                                    int bev_w, int min_level_width, float* slots, fbbev_stream_t stream_, fbbev_daf_outproj op,
+                                    int elem_type = 0) {
+    if (B <= 0 || Ncam <= 0 || S <= 0 || M <= 0 || Dh <= 0 || L <= 0 || Q < 0 || P <= 0 || Za <= 0 || DC <= 0 || bev_w < 0 ||
+        elem_type < 0 || elem_type > 2) return FBBEV_E_BADARG;
+    if (elem_type != 0 && op.w_frag) return FBBEV_E_UNSUPPORTED;          // 16-bit planes: the plain sampler only
     if (Q == 0) return 0;
     if (!planes || !spatial_shapes || !level_start_index || !pred_depth || !ref_cam || !mask || !qdepth || !query ||
         !offsets_fragments || !offsets_bias || !attn_fragments || !attn_bias || !slots || dstep == 0.f) return FBBEV_E_BADARG;
@@ -1504,7 +1506,8 @@ static int da_cross_attn_fused_impl(const float* planes, const int64_t* spatial_
     // least two tokens); the shapes themselves stay on the device
     if (!da_fused_shape_ok(B, Ncam, S, M, Dh, L, Q, P, Za, bev_w) || min_level_width < 2) return FBBEV_E_UNSUPPORTED;
     if (query_row_stride % 4 != 0 || addend_row_stride % 4 != 0 || !aligned16(query) || (addend && !aligned16(addend)) ||
-        !aligned16(offsets_fragments) || !aligned16(attn_fragments) || ((uintptr_t)planes & 7) != 0 || ((uintptr_t)slots & 7) != 0)
+        !aligned16(offsets_fragments) || !aligned16(attn_fragments) || !aligned16(offsets_bias) || ((uintptr_t)planes & 7) != 0 ||
+        ((uintptr_t)slots & 7) != 0)
         return FBBEV_E_UNSUPPORTED;
     // heads per workgroup: 4 = two 256-thread workgroups per patch and per CU (one's prologue + projections under the other's
     // samples), 8 = one 512-thread workgroup per patch (FBBEV_DA_FUSED_HW, read once)
@@ -1514,7 +1517,7 @@ static int da_cross_attn_fused_impl(const float* planes, const int64_t* spatial_
 #else
     static const int hw_env = read_hw();
 #endif
-    const int hw = op.w_frag ? 8 : hw_env;                  // the output_proj + LayerNorm tail needs all 8 heads of a query in one workgroup
+    const int hw = op.w_frag ? 8 : (elem_type ? 4 : hw_env); // the output_proj + LayerNorm tail needs all 8 heads of a query in one workgroup
     const long long wgs = (long long)B * ((bev_w + 7) / 8) * ((Q / bev_w + 7) / 8) * (8 / hw);
     const long long grid = (wgs + 7) / 8 * 8;
     if (grid >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
@@ -1529,13 +1532,15 @@ static int da_cross_attn_fused_impl(const float* planes, const int64_t* spatial_
     const size_t lds = fbbev_daf_lds_bytes(E, hw, Ncam, stage_floats);
     if (lds > 160 * 1024) return FBBEV_E_UNSUPPORTED;
     static const bool pre_off = [] { const char* e = getenv("FBBEV_DA_FUSED_PRE"); return e && atoi(e) == 0; }();   // A/B knob, read once
-    const int stage_arg = stage_floats | (pre_off ? 0x40000000 : 0);
-#define FBBEV_DA_FUSED(DH_, NP_, HW_) FBBEV_DA_FUSED2(DH_, NP_, HW_, false)
-#define FBBEV_DA_FUSED2(DH_, NP_, HW_, OP_)                                                                            \
+    static const int diag = [] { const char* e = getenv("FBBEV_DA_FUSED_DIAG"); return e ? (atoi(e) & 63) : 0; }();   // timing diagnostics (wrong results), read once
+    const int stage_arg = stage_floats | (pre_off ? 0x40000000 : 0) | (diag << 24);
+#define FBBEV_DA_FUSED(DH_, NP_, HW_) FBBEV_DA_FUSED3(DH_, NP_, HW_, false, 0)
+#define FBBEV_DA_FUSED2(DH_, NP_, HW_, OP_) FBBEV_DA_FUSED3(DH_, NP_, HW_, OP_, 0)
+#define FBBEV_DA_FUSED3(DH_, NP_, HW_, OP_, ET_)                                                                       \
     do {                                                                                                               \
-        int e = fbbev_rt_allow_dyn_lds((const void*)k_da_cross_attn_fused<DH_, 8, NP_, HW_, OP_>, lds);               \
+        int e = fbbev_rt_allow_dyn_lds((const void*)k_da_cross_attn_fused<DH_, 8, NP_, HW_, OP_, ET_>, lds);          \
         if (e) return e;                                                                                               \
-        FBBEV_LAUNCH((k_da_cross_attn_fused<DH_, 8, NP_, HW_, OP_>), grid, 64 * HW_, lds, (fbbev_rt_stream)stream_, planes, spatial_shapes, \
+        FBBEV_LAUNCH((k_da_cross_attn_fused<DH_, 8, NP_, HW_, OP_, ET_>), grid, 64 * HW_, lds, (fbbev_rt_stream)stream_, planes, spatial_shapes, \
                      level_start_index, pred_depth, ref_cam, mask, qdepth, query, query_row_stride, addend,           \
                      addend_row_stride, addend_period, static_cast<const unsigned short*>(offsets_fragments),         \
                      offsets_bias, static_cast<const unsigned short*>(attn_fragments), attn_bias, B, Ncam, S, L, Q,    \
@@ -1543,15 +1548,29 @@ static int da_cross_attn_fused_impl(const float* planes, const int64_t* spatial_
     } while (0)
     // (three samples in flight per lane -- FBBEV_DA_FUSED_NP=3 in round 4 -- measured no gain and, with the staged levels' second
     // sample loop, no longer fits the register file: the instantiations are gone, two in flight is the form)
-    if (op.w_frag) {
+    // (round 5, 16-bit planes: three / four samples in flight per lane -- 234 registers / 256 with 5 spills -- measured 401.3 / 405.1 us
+    // against 402.1 us with two at BASELINE configs[2]: the sampler is not waiting for its gathers; profiles/r05_exp_da_fused_where.md)
+    if (elem_type == 1) {              // round 5: camera tokens stored as bf16 / fp16 head planes (fp32 products and sums)
+        if (Dh == 10) FBBEV_DA_FUSED3(10, 2, 4, false, 1); else FBBEV_DA_FUSED3(8, 2, 4, false, 1);
+    } else if (elem_type == 2) {
+        if (Dh == 10) FBBEV_DA_FUSED3(10, 2, 4, false, 2); else FBBEV_DA_FUSED3(8, 2, 4, false, 2);
+    } else if (op.w_frag) {
         if (Dh == 10) FBBEV_DA_FUSED2(10, 2, 8, true); else FBBEV_DA_FUSED2(8, 2, 8, true);
     } else if (hw == 8) {
         if (Dh == 10) FBBEV_DA_FUSED(10, 2, 8); else FBBEV_DA_FUSED(8, 2, 8);
+    } else if (diag && Dh == 10) {     // FBBEV_DA_FUSED_DIAG: the instantiation with the timing-diagnostic bits (wrong results by design)
+        int e = fbbev_rt_allow_dyn_lds((const void*)k_da_cross_attn_fused<10, 8, 2, 4, false, 0, true>, lds);
+        if (e) return e;
+        FBBEV_LAUNCH((k_da_cross_attn_fused<10, 8, 2, 4, false, 0, true>), grid, 256, lds, (fbbev_rt_stream)stream_, planes, spatial_shapes,
+                     level_start_index, pred_depth, ref_cam, mask, qdepth, query, query_row_stride, addend, addend_row_stride, addend_period,
+                     static_cast<const unsigned short*>(offsets_fragments), offsets_bias, static_cast<const unsigned short*>(attn_fragments),
+                     attn_bias, B, Ncam, S, L, Q, bev_w, DC, d0, dstep, slots, op, stage_arg);
     } else {
         if (Dh == 10) FBBEV_DA_FUSED(10, 2, 4); else FBBEV_DA_FUSED(8, 2, 4);
     }
 #undef FBBEV_DA_FUSED
 #undef FBBEV_DA_FUSED2
+#undef FBBEV_DA_FUSED3
     FBBEV_CHECK_LAUNCH();
     return 0;
 }
@@ -1567,6 +1586,20 @@ extern "C" int fbbev_da_cross_attn_fused(const float* planes, const int64_t* spa
                                     query_row_stride, addend, addend_row_stride, addend_period, offsets_fragments, offsets_bias,
                                     attn_fragments, attn_bias, B, Ncam, S, M, Dh, L, Q, P, Za, DC, d0, dstep, bev_w, min_level_width,
                                     slots, stream_, fbbev_daf_outproj{nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0.f});
+}
+// The same kernel on 16-bit head planes (elem_type 1 bf16, 2 fp16; 0 = the entry above): the camera-token STORAGE option of the
+// cross-attention (fbbev_rows_linear_x3_planes_e writes them); every product and sum stays fp32.
+extern "C" int fbbev_da_cross_attn_fused_e(const void* planes, int elem_type, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                         const float* pred_depth, const float* ref_cam, const uint8_t* mask, const float* qdepth,
+                                         const float* query, long long query_row_stride, const float* addend,
+                                         long long addend_row_stride, long long addend_period, const void* offsets_fragments,
+                                         const float* offsets_bias, const void* attn_fragments, const float* attn_bias, int B,
+                                         int Ncam, int S, int M, int Dh, int L, int Q, int P, int Za, int DC, float d0, float dstep,
+                                         int bev_w, int min_level_width, float* slots, fbbev_stream_t stream_) {
+    return da_cross_attn_fused_impl(static_cast<const float*>(planes), spatial_shapes, level_start_index, pred_depth, ref_cam, mask, qdepth,
+                                    query, query_row_stride, addend, addend_row_stride, addend_period, offsets_fragments, offsets_bias,
+                                    attn_fragments, attn_bias, B, Ncam, S, M, Dh, L, Q, P, Za, DC, d0, dstep, bev_w, min_level_width,
+                                    slots, stream_, fbbev_daf_outproj{nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0.f}, elem_type);
 }
 // ... followed, inside the same workgroups (8 heads per workgroup), by output_proj + residual + LayerNorm: out rows instead of slots
 extern "C" int fbbev_da_cross_attn_fused_ln(const float* planes, const int64_t* spatial_shapes, const int64_t* level_start_index,
@@ -2820,6 +2853,19 @@ extern "C" int fbbev_rows_linear_x3_planes(const float* x, long long x_row_strid
     if (out && ((uintptr_t)out & 7) != 0) return FBBEV_E_UNSUPPORTED;
     return rows_linear_x3_impl(x, x_row_stride, fragments, bias, rows, in_features, out_features, 0, out, 0, nullptr, 0, 1, stream_,
                                tokens_per_image, head_dim);
+}
+
+// The same projection with the planes STORED in 16 bits (elem_type 1 bf16, 2 fp16; 0 = fbbev_rows_linear_x3_planes): the fp32 result
+// rounded once -- the camera-token storage option of the cross-attention (DA_SpatialCrossAttention.value_dtype) on head planes.
+extern "C" int fbbev_rows_linear_x3_planes_e(const float* x, long long x_row_stride, const void* fragments, const float* bias,
+                                             long long rows, int in_features, int out_features, int tokens_per_image, int head_dim,
+                                             int elem_type, void* out, fbbev_stream_t stream_) {
+    if (tokens_per_image <= 0 || head_dim <= 0 || out_features <= 0 || elem_type < 0 || elem_type > 2) return FBBEV_E_BADARG;
+    if (head_dim % 2 != 0 || out_features % head_dim != 0 || rows % tokens_per_image != 0 || head_dim > 0xffff) return FBBEV_E_UNSUPPORTED;
+    if (out && ((uintptr_t)out & (elem_type ? 3 : 7)) != 0) return FBBEV_E_UNSUPPORTED;
+    if (out && !aligned16(out)) return FBBEV_E_UNSUPPORTED;
+    return rows_linear_x3_impl(x, x_row_stride, fragments, bias, rows, in_features, out_features, 0, static_cast<float*>(out), 0, nullptr, 0,
+                               1, stream_, tokens_per_image, head_dim | (elem_type << 16));
 }
 
 // The FFN pair of the encoder layer in one kernel: out = [LayerNorm](W2 relu(W1 x + b1) + b2 [+ residual]) -- mmcv FFN

@@ -54,10 +54,13 @@ __host__ __device__ inline size_t fbbev_daf_lds_bytes(int E, int HW, int Ncam, i
     return fbbev_daf_xf_bytes(E) + (size_t)Ncam * 64 * FBBEV_DAF_QC * 4 + (size_t)HW * fbbev_daf_wave_region(stage_floats) * 4;
 }
 
-template <int DH>
+// ET: element type of the head planes -- 0 fp32 (the default: the reference's precision), 1 bf16, 2 fp16 (round 5: the camera-token
+// STORAGE option on head planes; every product and sum stays fp32).  A 16-bit run of two tokens is 2 DH halves = DH 32-bit words.
+template <int DH, int ET = 0>
 struct fbbev_daf_pending {
     static constexpr int NV = (2 * DH) / 4;
-    fbbev_v4f a[NV], b[NV];            // the two row runs: tokens (x, x+1) of rows y0 and y1
+    fbbev_v4f a[ET == 0 ? NV : 1], b[ET == 0 ? NV : 1];   // fp32: the two row runs, tokens (x, x+1) of rows y0 and y1
+    unsigned int ra[ET == 0 ? 1 : DH], rb[ET == 0 ? 1 : DH];   // 16-bit: the same runs as raw words (two channels each)
     float w00, w01, w10, w11, weight;
 };
 
@@ -69,10 +72,23 @@ __device__ __forceinline__ fbbev_v2f fbbev_daf_pair(const fbbev_v4f (&r)[(2 * DH
     v[0] = r[i >> 2][i & 3]; v[1] = r[(i + 1) >> 2][(i + 1) & 3];
     return v;
 }
+template <int ET>
+__device__ __forceinline__ float fbbev_daf_widen(unsigned int h) {          // 16 bits -> fp32, exact (1 bf16, 2 fp16)
+    if constexpr (ET == 2) return fbbev_f16_bits_to_f32(h);
+    else { const unsigned int u = h << 16; float f; __builtin_memcpy(&f, &u, 4); return f; }
+}
+// channels (c, c + 1) of token `slot` of a raw 16-bit run, widened exactly
+template <int DH, int ET>
+__device__ __forceinline__ fbbev_v2f fbbev_daf_pair16(const unsigned int (&r)[DH], int slot, int c) {
+    const unsigned int w = r[slot * (DH / 2) + (c >> 1)];
+    fbbev_v2f v;
+    v[0] = fbbev_daf_widen<ET>(w & 0xffffu); v[1] = fbbev_daf_widen<ET>(w >> 16);
+    return v;
+}
 
-template <int DH, bool LDS = false>
-__device__ __forceinline__ void fbbev_daf_issue(const char* __restrict__ plane, int level_off /* floats */, float h_im, float w_im,
-                                                int sh, int sw, float weight, bool enable, fbbev_daf_pending<DH>& p) {
+template <int DH, bool LDS = false, int ET = 0>
+__device__ __forceinline__ void fbbev_daf_issue(const char* __restrict__ plane, int level_off /* elements */, float h_im, float w_im,
+                                                int sh, int sw, float weight, bool enable, fbbev_daf_pending<DH, ET>& p) {
     const bool live = enable && h_im > -1.f && w_im > -1.f && h_im < (float)sh && w_im < (float)sw;
     const float h = live ? h_im : 0.f, w = live ? w_im : 0.f;
     const int h_low = (int)floorf(h), w_low = (int)floorf(w);
@@ -88,28 +104,66 @@ __device__ __forceinline__ void fbbev_daf_issue(const char* __restrict__ plane, 
     const float sy0 = top ? 0.f : hh, sy1 = bottom ? 0.f : lh;
     p.w00 = sy0 * sx0; p.w01 = sy0 * sx1; p.w10 = sy1 * sx0; p.w11 = sy1 * sx1;
     p.weight = live ? weight : 0.f;
-    const unsigned o0 = (unsigned)(level_off + (y0 * sw + xb) * DH) * 4u, o1 = (unsigned)(level_off + (y1 * sw + xb) * DH) * 4u;
-    constexpr int NV = (2 * DH) / 4;
+    constexpr unsigned ESZ = ET == 0 ? 4u : 2u;
+    // byte offsets of the two runs inside the head plane: token index < S < 2^24 (the launcher checks), 24-bit multiplies (full rate)
+    const unsigned o0 = fbbev_mad_u24_vks<DH * ESZ>(fbbev_mad_u24_vsv((unsigned)y0, (unsigned)sw, (unsigned)xb), (unsigned)level_off * ESZ);
+    const unsigned o1 = fbbev_mad_u24_vks<DH * ESZ>(fbbev_mad_u24_vsv((unsigned)y1, (unsigned)sw, (unsigned)xb), (unsigned)level_off * ESZ);
+    if constexpr (ET == 0) {
+        constexpr int NV = (2 * DH) / 4;
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {          // DH = 10: 8-byte aligned 16-byte loads (global memory takes dword-aligned b128)
-        if constexpr (LDS) {                // the level's plane staged in LDS: no vector-L1 access at all
-            p.a[k] = fbbev_lds_ld_v4f_a8(reinterpret_cast<const float*>(plane + o0 + 16 * k));
-            p.b[k] = fbbev_lds_ld_v4f_a8(reinterpret_cast<const float*>(plane + o1 + 16 * k));
-        } else {
-            fbbev_v4f t0, t1;
-            __builtin_memcpy(&t0, plane + o0 + 16 * k, 16);
-            __builtin_memcpy(&t1, plane + o1 + 16 * k, 16);
-            p.a[k] = t0; p.b[k] = t1;
+        for (int k = 0; k < NV; ++k) {          // DH = 10: 8-byte aligned 16-byte loads (global memory takes dword-aligned b128)
+            if constexpr (LDS) {                // the level's plane staged in LDS: no vector-L1 access at all
+                p.a[k] = fbbev_lds_ld_v4f_a8(reinterpret_cast<const float*>(plane + o0 + 16 * k));
+                p.b[k] = fbbev_lds_ld_v4f_a8(reinterpret_cast<const float*>(plane + o1 + 16 * k));
+            } else {
+                fbbev_v4f t0, t1;
+                __builtin_memcpy(&t0, plane + o0 + 16 * k, 16);
+                __builtin_memcpy(&t1, plane + o1 + 16 * k, 16);
+                p.a[k] = t0; p.b[k] = t1;
+            }
+        }
+    } else {                                    // 16-bit tokens: DH words per run, 4-byte aligned (a token is 2 DH bytes)
+#pragma unroll
+        for (int k = 0; k < (LDS ? DH : 0); k += 2) {
+            if constexpr (LDS) {
+                p.ra[k] = (unsigned int)fbbev_lds_ld_i32(reinterpret_cast<const int*>(plane + o0 + 4 * k));
+                p.ra[k + 1] = (unsigned int)fbbev_lds_ld_i32(reinterpret_cast<const int*>(plane + o0 + 4 * k + 4));
+                p.rb[k] = (unsigned int)fbbev_lds_ld_i32(reinterpret_cast<const int*>(plane + o1 + 4 * k));
+                p.rb[k + 1] = (unsigned int)fbbev_lds_ld_i32(reinterpret_cast<const int*>(plane + o1 + 4 * k + 4));
+            }
+        }
+        if constexpr (!LDS) {                   // global: DH = 10 -> b128, b128, b64 per row at a dword-aligned address (3 loads, fp32: 5)
+            constexpr int N4 = DH / 4 * 4;
+#pragma unroll
+            for (int k = 0; k < N4; k += 4) {
+                unsigned int t0[4], t1[4];
+                __builtin_memcpy(t0, plane + o0 + 4 * k, 16);
+                __builtin_memcpy(t1, plane + o1 + 4 * k, 16);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { p.ra[k + i] = t0[i]; p.rb[k + i] = t1[i]; }
+            }
+            if constexpr (N4 < DH) {
+                unsigned int t0[2], t1[2];
+                __builtin_memcpy(t0, plane + o0 + 4 * N4, 8);
+                __builtin_memcpy(t1, plane + o1 + 4 * N4, 8);
+                p.ra[N4] = t0[0]; p.ra[N4 + 1] = t0[1]; p.rb[N4] = t1[0]; p.rb[N4 + 1] = t1[1];
+            }
         }
     }
 }
 
-template <int DH>
-__device__ __forceinline__ void fbbev_daf_consume(const fbbev_daf_pending<DH>& p, fbbev_v2f (&col)[DH / 2]) {
+template <int DH, int ET = 0>
+__device__ __forceinline__ void fbbev_daf_consume(const fbbev_daf_pending<DH, ET>& p, fbbev_v2f (&col)[DH / 2]) {
 #pragma unroll
     for (int c = 0; c < DH; c += 2) {
-        const fbbev_v2f v00 = fbbev_daf_pair<DH>(p.a, 0, c), v01 = fbbev_daf_pair<DH>(p.a, 1, c);
-        const fbbev_v2f v10 = fbbev_daf_pair<DH>(p.b, 0, c), v11 = fbbev_daf_pair<DH>(p.b, 1, c);
+        fbbev_v2f v00, v01, v10, v11;
+        if constexpr (ET == 0) {
+            v00 = fbbev_daf_pair<DH>(p.a, 0, c); v01 = fbbev_daf_pair<DH>(p.a, 1, c);
+            v10 = fbbev_daf_pair<DH>(p.b, 0, c); v11 = fbbev_daf_pair<DH>(p.b, 1, c);
+        } else {
+            v00 = fbbev_daf_pair16<DH, ET>(p.ra, 0, c); v01 = fbbev_daf_pair16<DH, ET>(p.ra, 1, c);
+            v10 = fbbev_daf_pair16<DH, ET>(p.rb, 0, c); v11 = fbbev_daf_pair16<DH, ET>(p.rb, 1, c);
+        }
         col[c / 2] += (p.w00 * v00 + p.w01 * v01 + p.w10 * v10 + p.w11 * v11) * p.weight;
     }
 #pragma unroll
@@ -118,25 +172,42 @@ __device__ __forceinline__ void fbbev_daf_consume(const fbbev_daf_pending<DH>& p
 
 // one 16-output tile of a split-operand projection of the workgroup's 64 query rows: acc[rt] (row tile rt = queries 16 rt ..
 // 16 rt + 15) = W[16 T .. 16 T + 15][:] . x^T, lane (g, j) holds outputs 16 T + 4 g + r (r = 0..3) of query 16 rt + j
+// (two steps: the tile's six weight fragments are REQUESTED first -- fbbev_daf_wload, 24 registers that are free while no sample is
+// in flight -- so that the caller can put its other loads behind them and the MFMAs wait for one round trip only)
 template <int KS>
-__device__ __forceinline__ void fbbev_daf_project(const unsigned short* __restrict__ wf, int T, const unsigned short* __restrict__ xf,
-                                                  int lane, fbbev_v4f (&acc)[4]) {
-#pragma unroll
-    for (int rt = 0; rt < 4; ++rt) acc[rt] = fbbev_v4f{0.f, 0.f, 0.f, 0.f};
+struct fbbev_daf_wtile { fbbev_bf16x8 h[KS], l[KS]; };
+template <int KS>
+__device__ __forceinline__ void fbbev_daf_wload(const unsigned short* __restrict__ wf, int T, int lane, fbbev_daf_wtile<KS>& w) {
     const unsigned short* wt = wf + (long long)T * FBBEV_RL_TILE_ELEMS;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-        const fbbev_bf16x8 ah = fbbev_ld_bf16x8(wt + (s * 64 + lane) * 8);
-        const fbbev_bf16x8 al = fbbev_ld_bf16x8(wt + FBBEV_RL_TILE_ELEMS / 2 + (s * 64 + lane) * 8);
+        w.h[s] = fbbev_ld_bf16x8(wt + (s * 64 + lane) * 8);
+        w.l[s] = fbbev_ld_bf16x8(wt + FBBEV_RL_TILE_ELEMS / 2 + (s * 64 + lane) * 8);
+    }
+}
+template <int KS>
+__device__ __forceinline__ void fbbev_daf_project_w(const fbbev_daf_wtile<KS>& w, const unsigned short* __restrict__ xf, int lane,
+                                                    fbbev_v4f (&acc)[4]) {
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) acc[rt] = fbbev_v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) {
             const fbbev_bf16x8 xh = fbbev_ld_bf16x8(xf + (((rt * KS + s) * 2 + 0) * 64 + lane) * 8);
             const fbbev_bf16x8 xl = fbbev_ld_bf16x8(xf + (((rt * KS + s) * 2 + 1) * 64 + lane) * 8);
-            acc[rt] = fbbev_mfma_f32_16x16x32_bf16(al, xh, acc[rt]);
-            acc[rt] = fbbev_mfma_f32_16x16x32_bf16(ah, xl, acc[rt]);
-            acc[rt] = fbbev_mfma_f32_16x16x32_bf16(ah, xh, acc[rt]);
+            acc[rt] = fbbev_mfma_f32_16x16x32_bf16(w.l[s], xh, acc[rt]);
+            acc[rt] = fbbev_mfma_f32_16x16x32_bf16(w.h[s], xl, acc[rt]);
+            acc[rt] = fbbev_mfma_f32_16x16x32_bf16(w.h[s], xh, acc[rt]);
         }
     }
+}
+template <int KS>
+__device__ __forceinline__ void fbbev_daf_project(const unsigned short* __restrict__ wf, int T, const unsigned short* __restrict__ xf,
+                                                  int lane, fbbev_v4f (&acc)[4]) {
+    fbbev_daf_wtile<KS> w;
+    fbbev_daf_wload<KS>(wf, T, lane, w);
+    fbbev_daf_project_w<KS>(w, xf, lane, acc);
 }
 
 // One bilinear sample of a (H, W >= 2) plane at normalised (x, y) as four CLAMPED corner offsets + weights: a padded corner keeps a
@@ -257,9 +328,9 @@ __device__ __forceinline__ void fbbev_daf_outproj_ln(const fbbev_daf_outproj& op
 // query (B*Q rows, ldq floats apart, E used) [+ addend rows: row (b*Q + q) % add_period]; so_frag / aw_frag: split bf16 fragments of
 // sampling_offsets.weight (M*L*P*2, E) / attention_weights.weight (M*L*P, E) in the order of k_rows_linear_x3_fragments, rows in
 // the MODULE's order ((m, l, p, xy) / (m, l, p)); so_bias / aw_bias fp32; slots (B, Q, M*DH).  blockDim = 64 * M.
-template <int DH, int MH, int NP, int HW, bool OP = false>
+template <int DH, int MH, int NP, int HW, bool OP = false, int ET = 0, bool DG = false>
 __global__ void __launch_bounds__(64 * HW, 2)     // two waves per SIMD (HW = 4: two workgroups per CU; HW = 8: one): at most 256 registers
-k_da_cross_attn_fused(const float* __restrict__ planes, const int64_t* __restrict__ spatial_shapes,
+k_da_cross_attn_fused(const float* __restrict__ planes /* ET != 0: 16-bit elements behind the pointer */, const int64_t* __restrict__ spatial_shapes,
                       const int64_t* __restrict__ level_start, const float* __restrict__ pred_depth,
                       const float* __restrict__ ref_cam, const unsigned char* __restrict__ mask,
                       const float* __restrict__ qdepth, const float* __restrict__ query, long long ldq,
@@ -270,7 +341,13 @@ k_da_cross_attn_fused(const float* __restrict__ planes, const int64_t* __restric
                       fbbev_daf_outproj op, int stage_floats) {
     constexpr int E = MH * DH, KS = (E + 31) / 32, P = FBBEV_DAF_P, ZA = FBBEV_DAF_ZA, NT = 64 * HW, PARTS = MH / HW;
     const bool pre_copy = (stage_floats & 0x40000000) == 0;     // A/B bit of the launcher: the first staged copy ahead of the projection
-    stage_floats &= 0x3fffffff;
+    // timing diagnostics of the launcher (FBBEV_DA_FUSED_DIAG, results are WRONG): 1 = no samples at all (phase A + projections +
+    // softmax remain), 2 = every sample reads token 0 of its level (the instruction stream without the gather's divergence)
+    // 4 = no (camera, query) records (nothing hits), 8 = no projections (MFMA tiles skipped)
+    // (DG: the diagnostic instantiation -- the bits cost registers; the product kernels compile them out)
+    // exit points (diag >> 4): 1 = return behind phase A, 2 = behind the softmax, 3 = no final store
+    const int diag = DG ? ((stage_floats >> 24) & 63) : 0;
+    stage_floats &= 0x00ffffff;
     static_assert(!OP || (HW == MH && E % 16 == 0), "the output_proj + LayerNorm tail needs all heads of a query in one workgroup");
     static_assert((2 * DH) % 4 == 0 && DH % 2 == 0 && E % 8 == 0, "runs of whole 16-byte pieces, channel pairs");
     static_assert(NP >= 2 && NP <= FBBEV_DAF_P, "samples in flight per lane");
@@ -293,6 +370,17 @@ k_da_cross_attn_fused(const float* __restrict__ planes, const int64_t* __restric
     const int py = pi / pxn, px = pi - py * pxn;
     const int x0 = px * 8, y0 = py * 8;
     // ---------------- phase A (whole workgroup): the patch's query rows as split MFMA fragments, its (camera, query) records
+    // hit flags first (one round trip, under the query rows' loads below): a record of a camera the query does not see -- three of
+    // four at six surround cameras -- is never computed (round 5; before, every record paid its 16 depth loads and ~300 VALU)
+    for (int i = threadIdx.x; i < ((diag & 4) ? 0 : Ncam * 64); i += NT) {
+        const int cam = i >> 6, ql = i & 63;
+        const int qy = y0 + (ql >> 3), qx = x0 + (ql & 7);
+        const bool inb = qy < bev_h && qx < bev_w;
+        const long long base = (((long long)cam * B + b) * Q + (inb ? (long long)qy * bev_w + qx : 0)) * ZA;
+        unsigned int mask4;
+        __builtin_memcpy(&mask4, mask + base, 4);                                       // ZA = 4 mask bytes
+        qc[(size_t)i * FBBEV_DAF_QC + 3 * ZA] = (inb && mask4 != 0u) ? 1.f : 0.f;
+    }
     for (int i = threadIdx.x; i < 4 * KS * 64; i += NT) {
         const int rt = i / (KS * 64), s = (i >> 6) % KS, ln = i & 63;
         const int g = ln >> 4, j = ln & 15, ql = 16 * rt + j, c = 32 * s + 8 * g;
@@ -312,16 +400,14 @@ k_da_cross_attn_fused(const float* __restrict__ planes, const int64_t* __restric
         __builtin_memcpy(xf + (((rt * KS + s) * 2 + 0) * 64 + ln) * 8, &h8, 16);
         __builtin_memcpy(xf + (((rt * KS + s) * 2 + 1) * 64 + ln) * 8, &l8, 16);
     }
-    for (int i = threadIdx.x; i < Ncam * 64; i += NT) {
-        // every load of a record is issued before any is used (a camera nobody hits costs the same few loads): out-of-grid
-        // lanes read query 0 of the sample, a non-hit record's depth weights are computed and never used
+    for (int i = threadIdx.x; i < ((diag & 4) ? 0 : Ncam * 64); i += NT) {
+        // every load of a hit record is issued before any is used; a non-hit record keeps only its flag (phase B reads the other
+        // fields of such a record only into selects that discard them)
         const int cam = i >> 6, ql = i & 63;
         const int qy = y0 + (ql >> 3), qx = x0 + (ql & 7);
-        const bool inb = qy < bev_h && qx < bev_w;
         float* rec = qc + (size_t)i * FBBEV_DAF_QC;
-        const long long base = (((long long)cam * B + b) * Q + (inb ? (long long)qy * bev_w + qx : 0)) * ZA;
-        unsigned int mask4;
-        __builtin_memcpy(&mask4, mask + base, 4);                                       // ZA = 4 mask bytes
+        if (fbbev_lds_ld_f32(rec + 3 * ZA) == 0.f) continue;                            // (this thread's own flag: no barrier needed)
+        const long long base = (((long long)cam * B + b) * Q + (long long)qy * bev_w + qx) * ZA;
         const fbbev_v4f r01 = *reinterpret_cast<const fbbev_v4f*>(ref_cam + base * 2);  // (x0, y0, x1, y1)
         const fbbev_v4f r23 = *reinterpret_cast<const fbbev_v4f*>(ref_cam + base * 2 + 4);
         const fbbev_v4f qd = *reinterpret_cast<const fbbev_v4f*>(qdepth + base);
@@ -343,15 +429,18 @@ k_da_cross_attn_fused(const float* __restrict__ planes, const int64_t* __restric
             rec[z] = rx[z]; rec[ZA + z] = ry[z];
             rec[2 * ZA + z] = wgt[z][0] * val[z][0] + wgt[z][1] * val[z][1] + wgt[z][2] * val[z][2] + wgt[z][3] * val[z][3];
         }
-        rec[3 * ZA] = (inb && mask4 != 0u) ? 1.f : 0.f;
     }
     __syncthreads();
+    if ((diag >> 4) == 1) return;
     // ---------------- phase B (per wave = head m, no workgroup barrier below)
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int m = part * HW + wv;
     const int g = lane >> 4, j = lane & 15;
     float* off_w = off_all + (size_t)wv * fbbev_daf_wave_region(stage_floats);
     fbbev_v4f pacc[4];
+    if (diag & 8)
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) pacc[rt] = fbbev_v4f{0.f, 0.f, 0.f, 0.f};
     // logits of head m: the 8 logits of (head m, level l) are rows (m*L + l)*8 .. +7 of attention_weights = HALF of one
     // 16-output tile; the tile goes through the wave's transposition tile (the path of the offsets below) and the lane keeps
     // its 8 values in registers: lg[l][p], levels taken last to first while the rows shift up, so lg[0] is level 0
@@ -362,10 +451,17 @@ k_da_cross_attn_fused(const float* __restrict__ planes, const int64_t* __restric
         for (int p = 0; p < P; ++p) lg[k][p] = 0.f;
     {
         int t_have = -1;
+        // (the weight fragments of the NEXT logits tile are requested before the MFMAs of the current one)
+        const int T_lo = (m * L) >> 1;
+        fbbev_daf_wtile<KS> wcur, wnxt;
+        fbbev_daf_wload<KS>(aw_frag, (m * L + L - 1) >> 1, lane, wcur);
+        wnxt = wcur;
         for (int l = L - 1; l >= 0; --l) {
             const int G = m * L + l, T = G >> 1, h8 = (G & 1) * 8;
             if (T != t_have) {                                                              // uniform
-                fbbev_daf_project<KS>(aw_frag, T, xf, lane, pacc);
+                if (T - 1 >= T_lo) fbbev_daf_wload<KS>(aw_frag, T - 1, lane, wnxt);
+                if (!(diag & 8)) fbbev_daf_project_w<KS>(wcur, xf, lane, pacc);
+                wcur = wnxt;
                 t_have = T;
 #pragma unroll
                 for (int rt = 0; rt < 4; ++rt) __builtin_memcpy(off_w + (16 * rt + j) * FBBEV_DAF_OS + 4 * g, &pacc[rt], 16);
@@ -402,6 +498,7 @@ k_da_cross_attn_fused(const float* __restrict__ planes, const int64_t* __restric
 #pragma unroll
             for (int p = 0; p < P; ++p) lg[k][p] *= inv_sum;
     }
+    if ((diag >> 4) == 2) { if (lg[0][0] + lg[1][1] + lg[2][2] + lg[3][3] == 123.f) slots[0] = 0.f; return; }
     const int qy = y0 + (lane >> 3), qx = x0 + (lane & 7);
     const bool valid = qy < bev_h && qx < bev_w;
     const long long bq = (long long)b * Q + (long long)qy * bev_w + qx;
@@ -415,21 +512,28 @@ k_da_cross_attn_fused(const float* __restrict__ planes, const int64_t* __restric
     for (int l = 0; l < L; ++l) {
         // a staged level (see below): the copy of its plane for the FIRST hit camera is requested here, into registers that are
         // free during the projection (the sample slots are dead), and lands under the MFMAs instead of in front of the samples
+        constexpr int ESZ = ET == 0 ? 4 : 2;
         const int sh = (int)spatial_shapes[2 * l], sw = (int)spatial_shapes[2 * l + 1];
-        const int lvl_off = (int)level_start[l] * DH;
-        const int lvl_n = sh * sw * DH;                                                      // floats of the level's plane
+        const int lvl_off = (int)level_start[l] * DH;                                        // elements
+        const int lvl_n = sh * sw * DH * ESZ / 4;                                            // 4-byte words of the level's plane (DH even)
         const bool staged = lvl_n <= stage_floats;                                           // uniform
-        constexpr int PRE_N = 7;                                                             // 16-byte pieces per lane held ahead (7 x 256 floats >= 1 760)
+        // the 2*P offsets of (head m, level l): rows ((m*L + l)*P + p)*2 + xy of sampling_offsets = ONE 16-output tile.  Its weight
+        // fragments and bias are requested before anything else of the level (in-order vmcnt: the MFMAs wait for these only)
+        const int T = m * L + l;
+        fbbev_daf_wtile<KS> wso;
+        if (!(diag & 8)) fbbev_daf_wload<KS>(so_frag, T, lane, wso);
+        const fbbev_v4f bias4 = *reinterpret_cast<const fbbev_v4f*>(so_bias + 16 * T + 4 * g);
+        constexpr int PRE_N = ET == 0 ? 7 : 4;                                               // 16-byte pieces per lane held ahead (7 x 256 words >= 1 760)
         fbbev_v4f pre[PRE_N];
         int cam0 = -1;
         bool pre_ok = false;
-        if (staged && pre_copy) {
+        if (!OP && staged && pre_copy) {       // (the tail instantiation has no registers to spare for the held pieces)
             for (int cam = 0; cam < Ncam && cam0 < 0; ++cam) {
                 const bool hit = valid && fbbev_lds_ld_f32(my_qc + (size_t)cam * 64 * FBBEV_DAF_QC + 3 * ZA) != 0.f;
                 if (__ballot(hit) != 0ull) cam0 = cam;
             }
             if (cam0 >= 0) {
-                const float* src = reinterpret_cast<const float*>(pb + (((long long)b * Ncam + cam0) * MH + m) * (long long)S * DH * 4) + lvl_off;
+                const float* src = reinterpret_cast<const float*>(pb + ((((long long)b * Ncam + cam0) * MH + m) * (long long)S + level_start[l]) * DH * ESZ);
                 pre_ok = (lvl_n & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0 && lvl_n <= PRE_N * 256;   // uniform
                 if (pre_ok) {
 #pragma unroll
@@ -440,13 +544,8 @@ k_da_cross_attn_fused(const float* __restrict__ planes, const int64_t* __restric
                 }
             }
         }
-        // the 2*P offsets of (head m, level l): rows ((m*L + l)*P + p)*2 + xy of sampling_offsets = ONE 16-output tile
-        const int T = m * L + l;
-        fbbev_daf_project<KS>(so_frag, T, xf, lane, pacc);
+        if (!(diag & 8)) fbbev_daf_project_w<KS>(wso, xf, lane, pacc);
         {
-            fbbev_v4f bias4;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) bias4[r] = so_bias[16 * T + 4 * g + r];
 #pragma unroll
             for (int rt = 0; rt < 4; ++rt) {
                 const fbbev_v4f v = pacc[rt] + bias4;
@@ -466,18 +565,18 @@ k_da_cross_attn_fused(const float* __restrict__ planes, const int64_t* __restric
         for (int cam = 0; cam < Ncam; ++cam) {
             const float* rec = my_qc + (size_t)cam * 64 * FBBEV_DAF_QC;
             const bool hit = valid && fbbev_lds_ld_f32(rec + 3 * ZA) != 0.f;
-            if (__ballot(hit) == 0ull) continue;                                           // uniform: nobody in the wave hits
+            if (__ballot(hit) == 0ull || (diag & 1)) continue;                             // uniform: nobody in the wave hits
             float rx[ZA], ry[ZA], dw[ZA];
 #pragma unroll
             for (int z = 0; z < ZA; ++z) {
                 rx[z] = fbbev_lds_ld_f32(rec + z); ry[z] = fbbev_lds_ld_f32(rec + ZA + z); dw[z] = fbbev_lds_ld_f32(rec + 2 * ZA + z);
             }
-            const char* plane = pb + (((long long)b * Ncam + cam) * MH + m) * (long long)S * DH * 4;   // wave-uniform base
+            const char* plane = pb + (((long long)b * Ncam + cam) * MH + m) * (long long)S * DH * ESZ;   // wave-uniform base
             // NP samples in flight per lane: sample p + NP - 1 is issued before sample p is blended (register slots addressed
             // at compile time: the P samples are unrolled)
-            fbbev_daf_pending<DH> pend[NP];
+            fbbev_daf_pending<DH, ET> pend[NP];
             if (staged) {
-                const float* src = reinterpret_cast<const float*>(plane) + lvl_off;
+                const float* src = reinterpret_cast<const float*>(plane + (long long)lvl_off * ESZ);
                 if (cam == cam0 && pre_ok) {                                                 // requested before the projection
 #pragma unroll
                     for (int k = 0; k < PRE_N; ++k) {
@@ -486,17 +585,17 @@ k_da_cross_attn_fused(const float* __restrict__ planes, const int64_t* __restric
                     }
                 } else if ((lvl_n & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {      // uniform
                     for (int i = lane * 4; i < lvl_n; i += 256) *reinterpret_cast<fbbev_v4f*>(off_w + i) = *reinterpret_cast<const fbbev_v4f*>(src + i);
-                } else {                                                                     // DH is even: 8-byte pieces
-                    for (int i = lane * 2; i < lvl_n; i += 128) *reinterpret_cast<fbbev_v2f*>(off_w + i) = *reinterpret_cast<const fbbev_v2f*>(src + i);
+                } else {                                                                     // DH is even: whole 4-byte words
+                    for (int i = lane; i < lvl_n; i += 64) off_w[i] = src[i];
                 }
                 fbbev_wave_sync();
                 const char* lplane = reinterpret_cast<const char*>(off_w);
-                auto start = [&](int p, fbbev_daf_pending<DH>& slot) {
+                auto start = [&](int p, fbbev_daf_pending<DH, ET>& slot) {
                     const int z = p % ZA;
                     const float ox = o4[p >> 1][2 * (p & 1)], oy = o4[p >> 1][2 * (p & 1) + 1];
                     const float loc_w = rx[z] + __fdiv_rn(ox, fsw), loc_h = ry[z] + __fdiv_rn(oy, fsh);
                     const float weight = lg[0][p] * dw[z];
-                    fbbev_daf_issue<DH, true>(lplane, 0, loc_h * fsh - 0.5f, loc_w * fsw - 0.5f, sh, sw, weight, hit, slot);
+                    fbbev_daf_issue<DH, true, ET>(lplane, 0, loc_h * fsh - 0.5f, loc_w * fsw - 0.5f, sh, sw, weight, hit && !(diag & 2), slot);
                 };
 #pragma unroll
                 for (int p = 0; p < NP - 1; ++p) start(p, pend[p]);
@@ -504,18 +603,18 @@ k_da_cross_attn_fused(const float* __restrict__ planes, const int64_t* __restric
                 for (int p = 0; p < P; ++p) {
                     if (p + NP - 1 < P) start(p + NP - 1, pend[(p + NP - 1) % NP]);
                     fbbev_sched_fence();
-                    fbbev_daf_consume<DH>(pend[p % NP], acc);
+                    fbbev_daf_consume<DH, ET>(pend[p % NP], acc);
                     fbbev_sched_fence();
                 }
                 fbbev_wave_sync();                                                          // sampled before the next copy / projection overwrites it
                 continue;
             }
-            auto start = [&](int p, fbbev_daf_pending<DH>& slot) {
+            auto start = [&](int p, fbbev_daf_pending<DH, ET>& slot) {
                 const int z = p % ZA;
                 const float ox = o4[p >> 1][2 * (p & 1)], oy = o4[p >> 1][2 * (p & 1) + 1];
                 const float loc_w = rx[z] + __fdiv_rn(ox, fsw), loc_h = ry[z] + __fdiv_rn(oy, fsh);
                 const float weight = lg[0][p] * dw[z];
-                fbbev_daf_issue<DH>(plane, lvl_off, loc_h * fsh - 0.5f, loc_w * fsw - 0.5f, sh, sw, weight, hit, slot);
+                fbbev_daf_issue<DH, false, ET>(plane, lvl_off, loc_h * fsh - 0.5f, loc_w * fsw - 0.5f, sh, sw, weight, hit && !(diag & 2), slot);
             };
 #pragma unroll
             for (int p = 0; p < NP - 1; ++p) start(p, pend[p]);
@@ -523,7 +622,7 @@ k_da_cross_attn_fused(const float* __restrict__ planes, const int64_t* __restric
             for (int p = 0; p < P; ++p) {
                 if (p + NP - 1 < P) start(p + NP - 1, pend[(p + NP - 1) % NP]);
                 fbbev_sched_fence();
-                fbbev_daf_consume<DH>(pend[p % NP], acc);
+                fbbev_daf_consume<DH, ET>(pend[p % NP], acc);
                 fbbev_sched_fence();
             }
         }
@@ -548,6 +647,7 @@ k_da_cross_attn_fused(const float* __restrict__ planes, const int64_t* __restric
         }
     } else {
         if (!valid) return;
+        if ((diag >> 4) == 3 && acc[0][0] != 123.f) return;
         float* dst = slots + bq * E + m * DH;
 #pragma unroll
         for (int c = 0; c < DH / 2; ++c) {

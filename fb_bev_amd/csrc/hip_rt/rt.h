@@ -161,6 +161,21 @@ __device__ __forceinline__ float fbbev_lds_ld_f32(const float* p) {
 }
 __device__ __forceinline__ int fbbev_lds_ld_i32(const int* p) { return *(const __attribute__((address_space(3))) int*)p; }
 // 16 bytes at an 8-byte aligned LDS address (two ds_read_b64 / one ds_read2_b64: head-plane tokens of 10 floats are 8-byte aligned)
+// a * b + c with a, b < 2^24 as ONE full-rate v_mad_u32_u24 (the compiler turns the mul24 builtins back into the quarter-rate
+// v_mad_u64_u32 / v_mul_lo_u32 when it cannot prove the ranges).  _vsv: b wave-uniform (SGPR); _vks: b a compile-time inline
+// constant (<= 64), c wave-uniform
+__device__ __forceinline__ unsigned int fbbev_mad_u24_vsv(unsigned int a, unsigned int b_uniform, unsigned int c) {
+    unsigned int r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b_uniform), "v"(c));
+    return r;
+}
+template <unsigned int K>
+__device__ __forceinline__ unsigned int fbbev_mad_u24_vks(unsigned int a, unsigned int c_uniform) {
+    static_assert(K <= 64, "inline constant");
+    unsigned int r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "n"(K), "s"(c_uniform));
+    return r;
+}
 __device__ __forceinline__ fbbev_v4f fbbev_lds_ld_v4f_a8(const float* p) {
     const __attribute__((address_space(3))) fbbev_v2f* q = (const __attribute__((address_space(3))) fbbev_v2f*)p;
     const fbbev_v2f a = q[0], b = q[1];

@@ -167,15 +167,23 @@ k_rows_linear_x3(const float* __restrict__ x, long long ldx, const unsigned shor
                 if (plane_S > 0) {
                     // head-plane output (da_fused_kernels.h): rows are (sample-camera bn, token) pairs, outputs (head, channel);
                     // element (r, o) goes to out[((bn * M + o / TS) * S + token) * TS + o % TS], M = O / TS.  TS is even, so a
-                    // channel pair never straddles two heads: two 8-byte stores
+                    // channel pair never straddles two heads: two 8-byte stores.  Bits 16.. of plane_TS (round 5): 16-bit planes
+                    // (1 bf16, 2 fp16; one nearest-even rounding of the fp32 result) -- a channel pair is one 4-byte store
+                    const int TS = plane_TS & 0xffff, pet = plane_TS >> 16;
                     const long long bn = r / plane_S, tok = r - bn * plane_S;
-                    const int Mh = O / plane_TS;
+                    const int Mh = O / TS;
 #pragma unroll
                     for (int e = 0; e < 4; e += 2) {
-                        const int hd = (o + e) / plane_TS, ch = (o + e) - hd * plane_TS;
-                        fbbev_v2f pr;
-                        pr[0] = v[e]; pr[1] = v[e + 1];
-                        *reinterpret_cast<fbbev_v2f*>(out + ((bn * Mh + hd) * plane_S + tok) * plane_TS + ch) = pr;
+                        const int hd = (o + e) / TS, ch = (o + e) - hd * TS;
+                        const long long at = ((bn * Mh + hd) * plane_S + tok) * TS + ch;
+                        if (pet) {
+                            const unsigned int pk = pet == 1 ? fbbev_cvt_pk16<1>(v[e], v[e + 1]) : fbbev_cvt_pk16<2>(v[e], v[e + 1]);
+                            *reinterpret_cast<unsigned int*>(reinterpret_cast<unsigned short*>(out) + at) = pk;
+                        } else {
+                            fbbev_v2f pr;
+                            pr[0] = v[e]; pr[1] = v[e + 1];
+                            *reinterpret_cast<fbbev_v2f*>(out + at) = pr;
+                        }
                     }
                     continue;
                 }

@@ -444,6 +444,16 @@ int fbbev_da_cross_attn_fused(const float* planes, const int64_t* spatial_shapes
                               const float* offsets_bias, const void* attn_fragments, const float* attn_bias, int B,
                               int Ncam, int S, int M, int Dh, int L, int Q, int P, int Za, int DC, float d0, float dstep,
                               int bev_w, int min_level_width, float* slots, fbbev_stream_t stream);
+/* fbbev_da_cross_attn_fused on 16-bit head planes (round 5): elem_type 1 = bf16, 2 = fp16 (0 = the entry above), the planes written
+ * by fbbev_rows_linear_x3_planes_e.  The reference keeps the camera tokens in fp32; this is the storage option of
+ * DA_SpatialCrossAttention.value_dtype on the one-kernel route (half the gather bytes; tokens rounded once, products / sums fp32). */
+int fbbev_da_cross_attn_fused_e(const void* planes, int elem_type, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                              const float* pred_depth, const float* ref_cam, const uint8_t* mask, const float* qdepth,
+                              const float* query, long long query_row_stride, const float* addend,
+                              long long addend_row_stride, long long addend_period, const void* offsets_fragments,
+                              const float* offsets_bias, const void* attn_fragments, const float* attn_bias, int B,
+                              int Ncam, int S, int M, int Dh, int L, int Q, int P, int Za, int DC, float d0, float dstep,
+                              int bev_w, int min_level_width, float* slots, fbbev_stream_t stream);
 /* fbbev_da_cross_attn_fused followed, inside the same workgroups (all 8 heads of a patch in one 512-thread workgroup), by the block's
  * tail: out = LayerNorm(output_proj(slots) + residual) (spatial_cross_attention_depth.py:223-226 + the layer's norm).  The arguments of
  * fbbev_msda_self_fused_ln; M*Dh % 16 == 0. */
@@ -706,6 +716,10 @@ int fbbev_rows_tail_ffn_x3(const float* x, long long x_row_stride, const void* w
 int fbbev_rows_linear_x3_planes(const float* x, long long x_row_stride, const void* fragments, const float* bias,
                                 long long rows, int in_features, int out_features, int tokens_per_image, int head_dim,
                                 float* out, fbbev_stream_t stream);
+/* The same projection with the planes stored in 16 bits (elem_type 1 bf16, 2 fp16, 0 = fp32): one nearest-even rounding of the fp32 result. */
+int fbbev_rows_linear_x3_planes_e(const float* x, long long x_row_stride, const void* fragments, const float* bias, long long rows,
+                                  int in_features, int out_features, int tokens_per_image, int head_dim, int elem_type, void* out,
+                                  fbbev_stream_t stream);
 
 /* The two 1x1x1 convolutions of the temporal fusion in one fp32-MFMA kernel (inference): replaces
  * history_keyframe_time_conv + history_keyframe_cat_conv of FBOCC.fuse_history (fbocc.py:111-127, 289-310) once the

@@ -351,9 +351,15 @@ def rows_tail_ffn_x3(x, w0, b0, res0, ln0_w, ln0_b, eps0, w1, b1, w2, b2, ln1_w,
     return code, out
 
 
-def rows_linear_x3_planes(x, weight, bias, tokens_per_image, heads, head_dim):
+def rows_linear_x3_planes(x, weight, bias, tokens_per_image, heads, head_dim, dtype=None):
     frag, fp = _fragments(weight)
     R, I = x.shape
+    if dtype is not None:                  # 16-bit planes: fbbev_rows_linear_x3_planes_e
+        out = torch.zeros((R // tokens_per_image, heads, tokens_per_image, head_dim), dtype=dtype)
+        code = lib().fbbev_rows_linear_x3_planes_e(c_void_p(x.data_ptr()), x.stride(0), fp, p(bias) if bias is not None else None, R, I,
+                                                   heads * head_dim, tokens_per_image, head_dim, 1 if dtype == torch.bfloat16 else 2,
+                                                   p(out), None)
+        return code, out
     out = torch.full((R // tokens_per_image, heads, tokens_per_image, head_dim), float('nan'))
     code = lib().fbbev_rows_linear_x3_planes(c_void_p(x.data_ptr()), x.stride(0), fp, p(bias) if bias is not None else None, R, I,
                                              heads * head_dim, tokens_per_image, head_dim, p(out), None)
@@ -386,6 +392,11 @@ def da_cross_attn_fused(planes, ss, ls, pred_depth, ref_cam, mask, qdepth, query
                                                   query.stride(1), *a, p_so, p(b_so), p_aw, p(b_aw), p_o, p(bo),
                                                   None if res is None else p(res), M * Dh, p(lnw), p(lnb), eps, B, Ncam, S, M, Dh, L, Q, P,
                                                   Za, pred_depth.shape[1], d0, dstep, bev_w, min_level_width, p(slots), None)
+        return code, slots
+    if planes.dtype in (torch.bfloat16, torch.float16):      # fbbev_da_cross_attn_fused_e: 16-bit head planes
+        code = lib().fbbev_da_cross_attn_fused_e(p(planes), 1 if planes.dtype == torch.bfloat16 else 2, p(ss), p(ls), p(pred_depth), p(ref_cam),
+                                                 p(m8), p(qdepth), p(query), query.stride(1), *a, p_so, p(b_so), p_aw, p(b_aw), B, Ncam, S, M,
+                                                 Dh, L, Q, P, Za, pred_depth.shape[1], d0, dstep, bev_w, min_level_width, p(slots), None)
         return code, slots
     code = lib().fbbev_da_cross_attn_fused(p(planes), p(ss), p(ls), p(pred_depth), p(ref_cam), p(m8), p(qdepth), p(query),
                                            query.stride(1), *a, p_so, p(b_so), p_aw, p(b_aw), B, Ncam, S, M, Dh, L, Q, P, Za,

@@ -1521,6 +1521,38 @@ def test_one_kernel_da_cross_attention_emulated():
     assert code < 0
 
 
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16])
+def test_one_kernel_da_cross_attention_on_16bit_head_planes_emulated(dt):
+    """Round 5: fbbev_rows_linear_x3_planes_e writes the value projection as bf16 / fp16 head planes (== the fp32 planes rounded once)
+    and fbbev_da_cross_attn_fused_e samples them -- staged levels from LDS, the others from global memory -- with fp32 products
+    and sums: EXACTLY the fp32 kernel's result on the widened planes (widening is exact, the arithmetic is the same sequence), and
+    within the storage rounding of the fp32-token result (DA_SpatialCrossAttention.value_dtype; the reference keeps fp32)."""
+    for seed, kw, bev_w in ((31, dict(B=2, Q=5 * 11, shapes=((16, 44), (8, 22))), 11),
+                            (32, dict(B=1, Q=9 * 8, shapes=((5, 7), (9, 6), (3, 4), (2, 2))), 8)):
+        args, exp, ex = _da_case(seed, E=80, M=8, P=8, DC=20, extras=True, **kw)
+        value, ss, ls, pred, ref_cam, mask, qdepth, offsets, attn, d0, dstep = args
+        BN, S_, M, Dh = value.shape
+        Pm, pre = ex['Pm'], 'a.deformable_attention.'
+        x = ex['key'].permute(2, 0, 1, 3).reshape(BN * S_, M * Dh).contiguous()
+        w_v, b_v = Pm[pre + 'value_proj.weight'].contiguous(), Pm[pre + 'value_proj.bias'].contiguous()
+        code, p32 = E.rows_linear_x3_planes(x, w_v, b_v, S_, M, Dh)
+        assert code == 0
+        code, p16 = E.rows_linear_x3_planes(x, w_v, b_v, S_, M, Dh, dtype=dt)
+        assert code == 0 and torch.equal(p16, p32.to(dt))                        # the fp32 projection rounded once (nearest even)
+        q, add = ex['query'].contiguous(), ex['qpos'].reshape(-1, M * Dh).contiguous()
+        w = [Pm[pre + n].contiguous() for n in ('sampling_offsets.weight', 'sampling_offsets.bias', 'attention_weights.weight',
+                                                'attention_weights.bias')]
+        code, s16 = E.da_cross_attn_fused(p16, ss, ls, pred, ref_cam, mask, qdepth, q, add, *w, 8, d0, dstep, bev_w)
+        assert code == 0 and not torch.isnan(s16).any()
+        code, swide = E.da_cross_attn_fused(p16.float().contiguous(), ss, ls, pred, ref_cam, mask, qdepth, q, add, *w, 8, d0, dstep, bev_w)
+        assert code == 0 and torch.equal(s16, swide)
+        code, s32 = E.da_cross_attn_fused(p32, ss, ls, pred, ref_cam, mask, qdepth, q, add, *w, 8, d0, dstep, bev_w)
+        tol = (2e-2 if dt == torch.bfloat16 else 3e-3) * max(1.0, s32.abs().max().item())
+        assert (s16 - s32).abs().max().item() <= tol, (s16 - s32).abs().max().item()
+    code, _ = E.lib().fbbev_rows_linear_x3_planes_e(None, 0, None, None, 0, 80, 80, 10, 10, 3, None, None), None
+    assert code < 0                                                               # unknown element type
+
+
 @pytest.mark.parametrize('B,bh,bw,with_pos', [(1, 8, 8, True), (2, 5, 11, True), (1, 9, 16, False)])
 def test_fused_bev_self_attention_emulated(B, bh, bw, with_pos):
     """fbbev_msda_self_fused -> k_msda_self_fused: mmcv MultiScaleDeformableAttention.forward as the encoder layer calls it

@@ -310,9 +310,12 @@ def test_row_functions_survive_autocast(dev):
 
 @pytest.mark.parametrize('dt,tol', [(torch.float16, 2e-3), (torch.bfloat16, 1.5e-2)])
 def test_16bit_camera_tokens_vs_fp32_tokens(dev, dt, tol):
-    """DA_SpatialCrossAttention.value_dtype (fbbev_da_cross_attn_fwd_e): camera tokens rounded once to 16 bits, fp32
-    accumulate.  The stated error is against the fp32-token path on the same inputs: max |diff| relative to the output
-    scale (the emulator test pins the kernel itself bit for bit on the rounded tokens)."""
+    """DA_SpatialCrossAttention.value_dtype: camera tokens rounded once to 16 bits, fp32 accumulate -- on the one-kernel route
+    (16-bit head planes, fbbev_da_cross_attn_fused_e; round 5) and, with FBBEV_DA_16BIT_PLANES=0, on the round-3 kernels
+    (fbbev_da_cross_attn_fwd_e).  The stated error is against the fp32-token path on the same inputs: max |diff| relative to the
+    output scale (the emulator tests pin the kernels themselves bit for bit on the rounded tokens); the two 16-bit routes read the
+    same rounded tokens and differ by the fp32 association only."""
+    from fb_bev_amd import backward_projection as BP
     from fb_bev_amd.backward_projection import DA_SpatialCrossAttention
     m, cfg, cam, feats, depth, lss, gcb = _setup(dev, B=2, num_levels=2, bev=20, seed=4)
     cam_g = [t.to(dev) for t in cam]
@@ -324,13 +327,27 @@ def test_16bit_camera_tokens_vs_fp32_tokens(dev, dt, tol):
         assert mods
         for x in mods:
             x.value_dtype = dt
-        got = m(*args, **kw)
+        seen, orig = [], BP._capi.da_cross_attn_fused
+        BP._capi.da_cross_attn_fused = lambda planes, *a, **k: (seen.append(planes.dtype), orig(planes, *a, **k))[1]
+        keep = BP.PLANES_16BIT
+        try:
+            got = m(*args, **kw)
+            assert seen and all(d == dt for d in seen), seen      # the one-kernel sampler ran, on 16-bit head planes
+            del seen[:]
+            BP.PLANES_16BIT = False
+            got_r3 = m(*args, **kw)
+            assert not seen
+        finally:
+            BP.PLANES_16BIT, BP._capi.da_cross_attn_fused = keep, orig
         for x in mods:
             x.value_dtype = None
         again = m(*args, **kw)
     assert torch.equal(again, ref)                       # the option leaves no state behind
-    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    scale = ref.abs().max().item()
+    err = (got - ref).abs().max().item() / scale
     assert 0 < err < tol, err
+    assert 0 < (got_r3 - ref).abs().max().item() / scale < tol
+    assert (got - got_r3).abs().max().item() / scale < 1e-4
 
 
 def test_graphed_replay_equals_eager_for_new_inputs(dev):

@@ -286,6 +286,37 @@ def test_side_stream_prefetch_of_the_backward_projection_changes_no_bit(dev):
     _say('BackwardProjection.prefetch on a side stream: 20 / 20 calls bit-identical to the single-stream order')
 
 
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16])
+def test_one_kernel_da_cross_attention_on_16bit_head_planes(dev, dt):
+    """Round 5: the camera-token storage option (DA_SpatialCrossAttention.value_dtype) on the one-kernel route: value_proj writes bf16 /
+    fp16 head planes (fbbev_rows_linear_x3_planes_e == the fp32 planes rounded once), fbbev_da_cross_attn_fused_e samples them with
+    fp32 products and sums: EXACTLY the fp32 kernel's slots on the widened planes (Q = 100 x 100, the configs[2] pyramid), and within
+    the storage rounding of the oracle composite on fp32 tokens (the reference keeps fp32: an option, not the default)."""
+    from da_cases import da_case
+    from fb_bev_amd import _capi
+    args, exp, ex = da_case(12, E=80, M=8, P=8, extras=True, B=1, Q=10000, shapes=((32, 88), (16, 44), (8, 22), (4, 11)), DC=59)
+    value, ss, ls, pred, ref_cam, mask, qdepth, offsets, attn, d0, dstep = args
+    BN, S_, M, Dh = value.shape
+    Pm, pre = ex['Pm'], 'a.deformable_attention.'
+    g = lambda t: t.to(dev).contiguous()  # noqa: E731
+    frag = {n: _capi.rows_linear_x3_fragments(g(Pm[pre + n + '.weight'])) for n in ('value_proj', 'sampling_offsets', 'attention_weights')}
+    x = g(ex['key'].permute(2, 0, 1, 3).reshape(BN * S_, M * Dh))
+    p32 = _capi.rows_linear_x3_planes(x, frag['value_proj'], g(Pm[pre + 'value_proj.bias']), S_, M, Dh)
+    p16 = _capi.rows_linear_x3_planes(x, frag['value_proj'], g(Pm[pre + 'value_proj.bias']), S_, M, Dh, dtype=dt)
+    assert p16.dtype == dt and torch.equal(p16, p32.to(dt))
+    common = (g(ss), g(ls), g(pred), g(ref_cam), g(mask), g(qdepth), g(ex['query']), g(ex['qpos'].reshape(-1, M * Dh)),
+              frag['sampling_offsets'], g(Pm[pre + 'sampling_offsets.bias']), frag['attention_weights'], g(Pm[pre + 'attention_weights.bias']),
+              8, d0, dstep, 100, 11)
+    s16 = _capi.da_cross_attn_fused(p16, *common, torch.full(exp.shape, float('nan'), device=dev))
+    swide = _capi.da_cross_attn_fused(p16.float().contiguous(), *common, torch.full(exp.shape, float('nan'), device=dev))
+    assert not torch.isnan(s16).any() and torch.equal(s16, swide)
+    err = (s16.cpu() - exp).abs().max().item()
+    scale = max(exp.abs().max().item(), 1.0)
+    _say(f'fbbev_da_cross_attn_fused_e [{str(dt)[6:]} head planes]: == the fp32 kernel on the widened planes bit for bit; max|err| vs the oracle '
+         f'composite on fp32 tokens = {err:.3e} (scale {scale:.2f}: storage rounding)')
+    assert err <= (1.5e-2 if dt == torch.bfloat16 else 2e-3) * scale
+
+
 # ------------------------------------------------------------------ camera-token pyramid in one launch
 @pytest.mark.parametrize('images,C,shapes', [(24, 80, ((16, 44), (32, 88), (8, 22), (4, 11))), (6, 80, ((16, 44),)), (5, 33, ((5, 9), (8, 4), (1, 3), (2, 2)))])
 def test_token_pyramid_in_one_launch_bit_exact(dev, images, C, shapes):
