@@ -1471,7 +1471,7 @@ extern "C" int fbbev_da_cross_attn_fwd_zt(const float* value, const int64_t* spa
 
 // ---- fbbev_da_cross_attn_fused: query rows -> slots in one kernel (da_fused_kernels.h)
 static bool da_fused_shape_ok(int B, int Ncam, int S, int M, int Dh, int L, int Q, int P, int Za, int bev_w) {
-    if (M != 8 || (Dh != 10 && Dh != 8) || P != FBBEV_DAF_P || Za != FBBEV_DAF_ZA || L < 1 || bev_w <= 0 || Q % bev_w != 0) return false;
+    if (M != 8 || (Dh != 10 && Dh != 8) || P != FBBEV_DAF_P || Za != FBBEV_DAF_ZA || L < 1 || bev_w <= 0 || Q % bev_w != 0 || Ncam > 32) return false;
     if (L > FBBEV_DAF_MAXL || fbbev_daf_lds_bytes(M * Dh, 8, Ncam) > 160 * 1024) return false;
     return (long long)S * Dh * 4 < (1ll << 31) && S < (1 << 24);                     // 32-bit byte offsets inside a head plane, 24-bit token indices
 }

@@ -503,8 +503,16 @@ k_da_cross_attn_fused(const float* __restrict__ planes /* ET != 0: 16-bit elemen
     const bool valid = qy < bev_h && qx < bev_w;
     const long long bq = (long long)b * Q + (long long)qy * bev_w + qx;
     const float* my_qc = qc + (size_t)lane * FBBEV_DAF_QC;
-    int count = 0;
-    for (int cam = 0; cam < Ncam; ++cam) count += (fbbev_lds_ld_f32(my_qc + (size_t)cam * 64 * FBBEV_DAF_QC + 3 * ZA) != 0.f) ? 1 : 0;
+    // the lane's hit flags as a bit mask and the cameras ANY lane of the wave hits (uniform), read once: the level loop below walks
+    // the set bits instead of reading a flag + ballot per (level, camera)  (Ncam <= 32: the launcher checks)
+    unsigned hitmask = 0u;
+    for (int cam = 0; cam < Ncam; ++cam)
+        hitmask |= (fbbev_lds_ld_f32(my_qc + (size_t)cam * 64 * FBBEV_DAF_QC + 3 * ZA) != 0.f) ? (1u << cam) : 0u;
+    const int count = __builtin_popcount(hitmask);
+    unsigned wave_cams_ = 0u;
+    for (int cam = 0; cam < Ncam; ++cam)
+        if (__ballot((hitmask >> cam) & 1u) != 0ull) wave_cams_ |= 1u << cam;
+    const unsigned wave_cams = (unsigned)__builtin_amdgcn_readfirstlane((int)wave_cams_);
     fbbev_v2f acc[DH / 2];
 #pragma unroll
     for (int c = 0; c < DH / 2; ++c) { acc[c][0] = 0.f; acc[c][1] = 0.f; }
@@ -528,10 +536,7 @@ k_da_cross_attn_fused(const float* __restrict__ planes /* ET != 0: 16-bit elemen
         int cam0 = -1;
         bool pre_ok = false;
         if (!OP && staged && pre_copy) {       // (the tail instantiation has no registers to spare for the held pieces)
-            for (int cam = 0; cam < Ncam && cam0 < 0; ++cam) {
-                const bool hit = valid && fbbev_lds_ld_f32(my_qc + (size_t)cam * 64 * FBBEV_DAF_QC + 3 * ZA) != 0.f;
-                if (__ballot(hit) != 0ull) cam0 = cam;
-            }
+            if (wave_cams != 0u) cam0 = __builtin_ctz(wave_cams);
             if (cam0 >= 0) {
                 const float* src = reinterpret_cast<const float*>(pb + ((((long long)b * Ncam + cam0) * MH + m) * (long long)S + level_start[l]) * DH * ESZ);
                 pre_ok = (lvl_n & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0 && lvl_n <= PRE_N * 256;   // uniform
@@ -562,10 +567,10 @@ k_da_cross_attn_fused(const float* __restrict__ planes /* ET != 0: 16-bit elemen
         // + the launcher's extra bytes: 8 x 22 and 4 x 11 tokens at BASELINE configs[2]) is copied into LDS once per hit camera and
         // sampled from there: ds_read instead of ~22 vector-L1 line accesses per load instruction -- the counter that bounds
         // this kernel (TCP_TOTAL_CACHE_ACCESSES: 195 M per launch, 0.71 per CU-cycle; profiles/r04_pmc_fb_BL3_B4_final.json)
-        for (int cam = 0; cam < Ncam; ++cam) {
+        for (unsigned rem = (diag & 1) ? 0u : wave_cams; rem != 0u; rem &= rem - 1u) {       // uniform: the cameras somebody in the wave hits
+            const int cam = __builtin_ctz(rem);
             const float* rec = my_qc + (size_t)cam * 64 * FBBEV_DAF_QC;
-            const bool hit = valid && fbbev_lds_ld_f32(rec + 3 * ZA) != 0.f;
-            if (__ballot(hit) == 0ull || (diag & 1)) continue;                             // uniform: nobody in the wave hits
+            const bool hit = ((hitmask >> cam) & 1u) != 0u;
             float rx[ZA], ry[ZA], dw[ZA];
 #pragma unroll
             for (int z = 0; z < ZA; ++z) {
