@@ -2940,11 +2940,6 @@ extern "C" int fbbev_rows_tail_ffn_x3(const float* x, long long x_row_stride, co
         !aligned16(ln1_bias) || (residual0 && (residual0_row_stride % 4 != 0 || !aligned16(residual0)))) return FBBEV_E_UNSUPPORTED;
     const long long wgs = (rows + 127) / 128;
     if (wgs >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
-#ifdef FBBEV_TEST_OVERRIDES
-    const int hc = [] { const char* e = getenv("FBBEV_TAIL_FFN_HC"); return e ? atoi(e) : 32; }();
-#else
-    static const int hc = [] { const char* e = getenv("FBBEV_TAIL_FFN_HC"); return e ? atoi(e) : 32; }();   // tuning knob, read once
-#endif
     const int n_kc2 = (hidden + 127) / 128;
     fbbev_ffn_pre pre;
     pre.w0f = static_cast<const unsigned short*>(w0_fragments); pre.b0 = b0; pre.res0 = residual0; pre.ld_res0 = residual0_row_stride;
@@ -2959,7 +2954,7 @@ extern "C" int fbbev_rows_tail_ffn_x3(const float* x, long long x_row_stride, co
                      out, out_row_stride, rows, embed, hidden, embed, n_kc2, (const float*)nullptr, (long long)0, ln1_weight,  \
                      ln1_bias, ln1_eps, pre);                                                                         \
     } while (0)
-    if (hc == 64) FBBEV_TFFN(64); else FBBEV_TFFN(32);
+    FBBEV_TFFN(32);      // (hidden chunks of 64 -- FBBEV_TAIL_FFN_HC=64 until round 5 -- measured no gain: 1.392 vs 1.392 ms S3; gone)
 #undef FBBEV_TFFN
     FBBEV_CHECK_LAUNCH();
     return 0;

@@ -20,6 +20,20 @@
 
 #define FBBEV_RL_TILE_ELEMS (2 * 4 * 64 * 8)              // bf16 elements of one 16-output tile of one K chunk: [hi|lo][4 k-steps][lane][8]
 
+// global -> LDS copy of n 16-byte pieces by a 256-thread workgroup, U pieces per thread REQUESTED before the first is stored: one
+// round trip per batch (round 5: written as `for (i = tid; i < n; i += 256) dst[i] = src[i]` the compiler keeps a loop of load,
+// s_waitcnt vmcnt(0), store -- n / 256 round trips in a row, 16 for a full 128-output chunk; profiles/r05_exp_weight_staging.md)
+template <int U>
+__device__ __forceinline__ void fbbev_stage_v4u(fbbev_v4u* __restrict__ dst, const fbbev_v4u* __restrict__ src, int n) {
+    for (int i0 = threadIdx.x; i0 < n; i0 += 256 * U) {
+        fbbev_v4u t[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const int i = i0 + 256 * u; t[u] = src[i < n ? i : i0]; }     // (clamped: unconditional loads)
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const int i = i0 + 256 * u; if (i < n) dst[i] = t[u]; }
+    }
+}
+
 template <int NT, bool LN>
 __global__ void __launch_bounds__(256, NT == 1 ? 3 : 2)
 k_rows_linear_x3(const float* __restrict__ x, long long ldx, const unsigned short* __restrict__ wf, const float* __restrict__ bias,
@@ -73,7 +87,7 @@ k_rows_linear_x3(const float* __restrict__ x, long long ldx, const unsigned shor
             if (n_kc > 1 || ri == 0) {
                 if (kc || ri) __syncthreads();                                            // the previous chunk's fragments are done with
                 const fbbev_v4u* src = reinterpret_cast<const fbbev_v4u*>(wf + ((long long)oc * n_kc + kc) * 8 * FBBEV_RL_TILE_ELEMS);
-                for (int i = threadIdx.x; i < nmt * (FBBEV_RL_TILE_ELEMS / 8); i += 256) reinterpret_cast<fbbev_v4u*>(wl)[i] = src[i];
+                fbbev_stage_v4u<(NT == 1 ? 2 : 4)>(reinterpret_cast<fbbev_v4u*>(wl), src, nmt * (FBBEV_RL_TILE_ELEMS / 8));
                 __syncthreads();
             }
 #pragma unroll
@@ -107,11 +121,19 @@ k_rows_linear_x3(const float* __restrict__ x, long long ldx, const unsigned shor
             // instead of a k_layernorm_rows launch that re-reads the rows.  Two-pass statistics as k_layernorm_rows (mean, then
             // the biased variance of the deviations); a row's O values live in the 4 lanes (g = 0..3, same j) of its row tile:
             // two xor-shuffles per reduction.
+            // (round 5: the bias / residual / LayerNorm pieces of a row tile are REQUESTED together, unconditionally, at clamped
+            // addresses -- under their `if`s every piece was its own load, s_waitcnt vmcnt(0), use: up to 32 round trips in a row)
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const long long r = r0 + 16 * t + j;
                 const bool live = r < rows;
-                fbbev_v4f v[8];
+                fbbev_v4f v[8], pb[8], pr[8];
+#pragma unroll
+                for (int mt = 0; mt < 8; ++mt) {
+                    const int o = 16 * mt + 4 * g, oc_ = (mt < nmt && o < O) ? o : 0;
+                    pb[mt] = bias ? *reinterpret_cast<const fbbev_v4f*>(bias + oc_) : fbbev_v4f{0.f, 0.f, 0.f, 0.f};
+                    pr[mt] = res ? *reinterpret_cast<const fbbev_v4f*>(res + (live ? r : 0) * ld_res + oc_) : fbbev_v4f{0.f, 0.f, 0.f, 0.f};
+                }
                 float s = 0.f;
 #pragma unroll
                 for (int mt = 0; mt < 8; ++mt) {
@@ -120,8 +142,8 @@ k_rows_linear_x3(const float* __restrict__ x, long long ldx, const unsigned shor
                     v[mt] = fbbev_v4f{0.f, 0.f, 0.f, 0.f};
                     if (ok) {
                         v[mt] = acc[mt][t];
-                        if (bias) v[mt] = v[mt] + *reinterpret_cast<const fbbev_v4f*>(bias + o);
-                        if (res && live) v[mt] = v[mt] + *reinterpret_cast<const fbbev_v4f*>(res + r * ld_res + o);
+                        if (bias) v[mt] = v[mt] + pb[mt];
+                        if (res && live) v[mt] = v[mt] + pr[mt];
                         s += (v[mt][0] + v[mt][1]) + (v[mt][2] + v[mt][3]);
                     }
                 }
@@ -139,10 +161,16 @@ k_rows_linear_x3(const float* __restrict__ x, long long ldx, const unsigned shor
                 q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
                 const float inv = 1.0f / sqrtf(q / (float)O + ln_eps);
 #pragma unroll
+                for (int mt = 0; mt < 8; ++mt) {                                           // (pb / pr are free: the LayerNorm pieces take their place)
+                    const int o = 16 * mt + 4 * g, oc_ = (mt < nmt && o < O) ? o : 0;
+                    pb[mt] = *reinterpret_cast<const fbbev_v4f*>(ln_w + oc_);
+                    pr[mt] = *reinterpret_cast<const fbbev_v4f*>(ln_b + oc_);
+                }
+#pragma unroll
                 for (int mt = 0; mt < 8; ++mt) {
                     const int o = 16 * mt + 4 * g;
                     if (mt < nmt && o < O && live) {
-                        const fbbev_v4f w4 = *reinterpret_cast<const fbbev_v4f*>(ln_w + o), b4 = *reinterpret_cast<const fbbev_v4f*>(ln_b + o);
+                        const fbbev_v4f w4 = pb[mt], b4 = pr[mt];
                         fbbev_v4f y;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) y[e] = v[mt][e] * inv * w4[e] + b4[e];
@@ -153,6 +181,14 @@ k_rows_linear_x3(const float* __restrict__ x, long long ldx, const unsigned shor
             continue;
         }
         // accumulator register r of tile (mt, t) = output 16 mt + 4 g + r of row j: four consecutive outputs, one 16-byte store
+        fbbev_v4f pbias[NT >= 2 ? 8 : 1];                                                 // (requested together: see the LayerNorm epilogue;
+        if constexpr (NT >= 2) {                                                          //  the 168-register NT = 1 build has no room for them)
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) {
+                const int o = o0 + 16 * mt + 4 * g;
+                pbias[mt] = bias ? *reinterpret_cast<const fbbev_v4f*>(bias + ((mt < nmt && o < O) ? o : 0)) : fbbev_v4f{0.f, 0.f, 0.f, 0.f};
+            }
+        }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const long long r = r0 + 16 * t + j;
@@ -162,7 +198,8 @@ k_rows_linear_x3(const float* __restrict__ x, long long ldx, const unsigned shor
                 const int o = o0 + 16 * mt + 4 * g;
                 if (mt >= nmt || o >= O) continue;                                        // O % 4 == 0: a group is all in or all out
                 fbbev_v4f v = acc[mt][t];
-                if (bias) v = v + *reinterpret_cast<const fbbev_v4f*>(bias + o);
+                if constexpr (NT >= 2) { if (bias) v = v + pbias[mt]; }
+                else if (bias) v = v + *reinterpret_cast<const fbbev_v4f*>(bias + o);
                 if (relu) v = fbbev_v4f{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
                 if (plane_S > 0) {
                     // head-plane output (da_fused_kernels.h): rows are (sample-camera bn, token) pairs, outputs (head, channel);
@@ -288,15 +325,67 @@ k_rows_ffn_x3(const float* __restrict__ x, long long ldx, const unsigned short* 
             }
         }
     }
+    // a chunk's weight fragments: W1 tiles T1 c .. T1 c + T1 - 1 (k-steps 0..KS1-1 of their single K chunk), W2 tiles 0..MT2-1 at hidden
+    // units [HC c, HC c + HC) = k-steps ks2 .. of K chunk kc2; 16-byte pieces, [hi | lo] kept apart as in the fragment arrays.  Round 5:
+    // `request` puts every piece of the chunk in flight (registers), `commit` stores them to LDS -- one round trip per chunk instead of
+    // one per piece, and with PRE (two waves per SIMD: 256 registers) the NEXT chunk is requested before the current chunk's GEMMs
+    constexpr int N1 = T1 * 2 * KS1 * 64, N2 = MT2 * 2 * S2 * 64, I1 = (N1 + 255) / 256, I2 = (N2 + 255) / 256;
+    static_assert(N1 >= 256 && N2 >= 256, "clamped loads");
+    constexpr bool PF = PRE && HC == 32;                                                    // (HC = 64 holds 44 registers of pieces: no room across its GEMMs)
+    fbbev_v4u st1[I1], st2[I2];
+    auto request = [&](int c) {
+#pragma unroll
+        for (int k = 0; k < I1; ++k) {
+            const int i_ = (int)threadIdx.x + 256 * k, i = i_ < N1 ? i_ : (int)threadIdx.x;
+            const int ln = i & 63, s = (i >> 6) % KS1, h = (i / (64 * KS1)) & 1, mt = i / (64 * KS1 * 2);
+            st1[k] = *reinterpret_cast<const fbbev_v4u*>(w1f + (long long)(T1 * c + mt) * FBBEV_RL_TILE_ELEMS + h * (FBBEV_RL_TILE_ELEMS / 2) + (s * 64 + ln) * 8);
+        }
+        const int u0 = c * HC, kc2 = u0 >> 7, ks2 = (u0 & 127) >> 5;                        // K chunk / first k-step of the hidden chunk in W2's fragments
+#pragma unroll
+        for (int k = 0; k < I2; ++k) {
+            const int i_ = (int)threadIdx.x + 256 * k, i = i_ < N2 ? i_ : (int)threadIdx.x;
+            const int ln = i & 63, s = (i >> 6) % S2, h = (i / (64 * S2)) & 1, mt = i / (64 * S2 * 2);
+            st2[k] = *reinterpret_cast<const fbbev_v4u*>(w2f + ((long long)kc2 * 8 + mt) * FBBEV_RL_TILE_ELEMS + h * (FBBEV_RL_TILE_ELEMS / 2) + ((ks2 + s) * 64 + ln) * 8);
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int k = 0; k < I1; ++k) { const int i = (int)threadIdx.x + 256 * k; if (i < N1) reinterpret_cast<fbbev_v4u*>(w1s)[i] = st1[k]; }
+#pragma unroll
+        for (int k = 0; k < I2; ++k) { const int i = (int)threadIdx.x + 256 * k; if (i < N2) reinterpret_cast<fbbev_v4u*>(w2s)[i] = st2[k]; }
+    };
     fbbev_v4f y1[PRE ? MT2 : 1][NT];                                                        // PRE: LayerNorm0's output = the FFN's residual
     if constexpr (PRE) {
         // W0's fragments (tiles 0..MT2-1, k-steps 0..KS1-1 of its single K chunk) through the weight region, shared by the 4 waves
-        for (int i = threadIdx.x; i < MT2 * 2 * KS1 * 64; i += 256) {
-            const int ln = i & 63, s = (i >> 6) % KS1, h = (i / (64 * KS1)) & 1, mt = i / (64 * KS1 * 2);
-            const unsigned short* src = pre.w0f + (long long)mt * FBBEV_RL_TILE_ELEMS + h * (FBBEV_RL_TILE_ELEMS / 2) + (s * 64 + ln) * 8;
-            reinterpret_cast<fbbev_v4u*>(w1s)[i] = *reinterpret_cast<const fbbev_v4u*>(src);
+        {   // (all pieces requested before the first is stored: one round trip, see fbbev_stage_v4u)
+            constexpr int N0 = MT2 * 2 * KS1 * 64, I0 = (N0 + 255) / 256;
+            static_assert(N0 >= 256, "clamped loads");
+            fbbev_v4u st0[I0];
+#pragma unroll
+            for (int k = 0; k < I0; ++k) {
+                const int i_ = (int)threadIdx.x + 256 * k, i = i_ < N0 ? i_ : (int)threadIdx.x;
+                const int ln = i & 63, s = (i >> 6) % KS1, h = (i / (64 * KS1)) & 1, mt = i / (64 * KS1 * 2);
+                st0[k] = *reinterpret_cast<const fbbev_v4u*>(pre.w0f + (long long)mt * FBBEV_RL_TILE_ELEMS + h * (FBBEV_RL_TILE_ELEMS / 2) + (s * 64 + ln) * 8);
+            }
+#pragma unroll
+            for (int k = 0; k < I0; ++k) {
+                const int i = (int)threadIdx.x + 256 * k;
+                if (i < N0) reinterpret_cast<fbbev_v4u*>(w1s)[i] = st0[k];
+            }
         }
         __syncthreads();
+        // bias and residual pieces of LayerNorm0's input: requested here, unconditionally (clamped), they arrive under GEMM 0
+        fbbev_v4f pb0[MT2], pr0[MT2][NT];
+#pragma unroll
+        for (int mt = 0; mt < MT2; ++mt) {
+            const int o = 16 * mt + 4 * g, oc_ = o < I ? o : 0;
+            pb0[mt] = *reinterpret_cast<const fbbev_v4f*>(pre.b0 + oc_);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const long long r = r0 + 16 * t + j;
+                pr0[mt][t] = pre.res0 ? *reinterpret_cast<const fbbev_v4f*>(pre.res0 + (r < rows ? r : 0) * pre.ld_res0 + oc_) : fbbev_v4f{0.f, 0.f, 0.f, 0.f};
+            }
+        }
 #pragma unroll
         for (int mt = 0; mt < MT2; ++mt)
 #pragma unroll
@@ -316,6 +405,13 @@ k_rows_ffn_x3(const float* __restrict__ x, long long ldx, const unsigned short* 
             }
         }
         // + b0 + res0 -> LayerNorm0 (two-pass statistics, as k_rows_linear_x3<., true>); the FFN's input width I == W0's output width
+        fbbev_v4f pw0[MT2], pq0[MT2];                                                       // LayerNorm0's weight / bias pieces, requested together
+#pragma unroll
+        for (int mt = 0; mt < MT2; ++mt) {
+            const int o = 16 * mt + 4 * g, oc_ = o < I ? o : 0;
+            pw0[mt] = *reinterpret_cast<const fbbev_v4f*>(pre.ln0_w + oc_);
+            pq0[mt] = *reinterpret_cast<const fbbev_v4f*>(pre.ln0_b + oc_);
+        }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const long long r = r0 + 16 * t + j;
@@ -325,8 +421,8 @@ k_rows_ffn_x3(const float* __restrict__ x, long long ldx, const unsigned short* 
             for (int mt = 0; mt < MT2; ++mt) {
                 const int o = 16 * mt + 4 * g;
                 if (o < I) {
-                    y1[mt][t] = y1[mt][t] + *reinterpret_cast<const fbbev_v4f*>(pre.b0 + o);
-                    if (pre.res0 && live) y1[mt][t] = y1[mt][t] + *reinterpret_cast<const fbbev_v4f*>(pre.res0 + r * pre.ld_res0 + o);
+                    y1[mt][t] = y1[mt][t] + pb0[mt];
+                    if (pre.res0 && live) y1[mt][t] = y1[mt][t] + pr0[mt][t];
                     sm += (y1[mt][t][0] + y1[mt][t][1]) + (y1[mt][t][2] + y1[mt][t][3]);
                 } else {
                     y1[mt][t] = fbbev_v4f{0.f, 0.f, 0.f, 0.f};
@@ -348,7 +444,7 @@ k_rows_ffn_x3(const float* __restrict__ x, long long ldx, const unsigned short* 
             for (int mt = 0; mt < MT2; ++mt) {
                 const int o = 16 * mt + 4 * g;
                 if (o < I) {
-                    const fbbev_v4f w4 = *reinterpret_cast<const fbbev_v4f*>(pre.ln0_w + o), b4 = *reinterpret_cast<const fbbev_v4f*>(pre.ln0_b + o);
+                    const fbbev_v4f w4 = pw0[mt], b4 = pq0[mt];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) y1[mt][t][e] = y1[mt][t][e] * inv * w4[e] + b4[e];
                 }
@@ -384,6 +480,7 @@ k_rows_ffn_x3(const float* __restrict__ x, long long ldx, const unsigned short* 
             fbbev_wave_sync();                                                              // read before the next k-step overwrites
         }
     }
+    if constexpr (PF) request(0);
     fbbev_v4f acc2[MT2][NT];
 #pragma unroll
     for (int mt = 0; mt < MT2; ++mt)
@@ -391,22 +488,11 @@ k_rows_ffn_x3(const float* __restrict__ x, long long ldx, const unsigned short* 
         for (int t = 0; t < NT; ++t) acc2[mt][t] = fbbev_v4f{0.f, 0.f, 0.f, 0.f};
     const int n_chunks = H / HC;
     for (int c = 0; c < n_chunks; ++c) {
+        if (!PF) request(c);                                                                // (PF: in flight since the previous chunk's GEMMs / the PRE block)
         if (c || PRE) __syncthreads();                                                      // the previous chunk's weights (PRE: W0's) are done with
-        // W1 tiles 4c .. 4c+3 (k-steps 0..KS1-1 of their single K chunk), W2 tiles 0..MT2-1 at hidden units [64c, 64c + 64) = k-steps
-        // 2 (c & 1), 2 (c & 1) + 1 of K chunk c / 2; 16-byte pieces, [hi | lo] kept apart as in the fragment arrays
-        for (int i = threadIdx.x; i < T1 * 2 * KS1 * 64; i += 256) {
-            const int ln = i & 63, s = (i >> 6) % KS1, h = (i / (64 * KS1)) & 1, mt = i / (64 * KS1 * 2);
-            const unsigned short* src = w1f + (long long)(T1 * c + mt) * FBBEV_RL_TILE_ELEMS + h * (FBBEV_RL_TILE_ELEMS / 2) + (s * 64 + ln) * 8;
-            reinterpret_cast<fbbev_v4u*>(w1s)[i] = *reinterpret_cast<const fbbev_v4u*>(src);
-        }
-        const int u0 = c * HC, kc2 = u0 >> 7, ks2 = (u0 & 127) >> 5;                        // K chunk / first k-step of the hidden chunk in W2's fragments
-        for (int i = threadIdx.x; i < MT2 * 2 * S2 * 64; i += 256) {
-            const int ln = i & 63, s = (i >> 6) % S2, h = (i / (64 * S2)) & 1, mt = i / (64 * S2 * 2);
-            const unsigned short* src = w2f + ((long long)kc2 * 8 + mt) * FBBEV_RL_TILE_ELEMS + h * (FBBEV_RL_TILE_ELEMS / 2) +
-                                        ((ks2 + s) * 64 + ln) * 8;
-            reinterpret_cast<fbbev_v4u*>(w2s)[i] = *reinterpret_cast<const fbbev_v4u*>(src);
-        }
+        commit();
         __syncthreads();
+        if (PF && c + 1 < n_chunks) request(c + 1);
         // GEMM 1 + bias + ReLU -> hidden fragments of this wave
 #pragma unroll
         for (int mt = 0; mt < T1; ++mt) {
@@ -463,7 +549,21 @@ k_rows_ffn_x3(const float* __restrict__ x, long long ldx, const unsigned short* 
         }
         fbbev_wave_sync();                                                                  // this wave's hidden fragments are read
     }
-    // epilogue: + b2 (+ residual -> LayerNorm), as k_rows_linear_x3
+    // epilogue: + b2 (+ residual -> LayerNorm), as k_rows_linear_x3; its parameter / residual pieces requested together (clamped)
+    fbbev_v4f pb2[MT2], pw[LN ? MT2 : 1], pq[LN ? MT2 : 1], pres[PRE ? 1 : MT2][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT2; ++mt) {
+        const int o = 16 * mt + 4 * g, oc_ = o < O ? o : 0;
+        pb2[mt] = *reinterpret_cast<const fbbev_v4f*>(b2 + oc_);
+        if constexpr (LN) { pw[mt] = *reinterpret_cast<const fbbev_v4f*>(ln_w + oc_); pq[mt] = *reinterpret_cast<const fbbev_v4f*>(ln_b + oc_); }
+        if constexpr (!PRE) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const long long r = r0 + 16 * t + j;
+                pres[mt][t] = res ? *reinterpret_cast<const fbbev_v4f*>(res + (r < rows ? r : 0) * ld_res + oc_) : fbbev_v4f{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const long long r = r0 + 16 * t + j;
@@ -475,9 +575,9 @@ k_rows_ffn_x3(const float* __restrict__ x, long long ldx, const unsigned short* 
             const int o = 16 * mt + 4 * g;
             v[mt] = fbbev_v4f{0.f, 0.f, 0.f, 0.f};
             if (o < O) {
-                v[mt] = acc2[mt][t] + *reinterpret_cast<const fbbev_v4f*>(b2 + o);
+                v[mt] = acc2[mt][t] + pb2[mt];
                 if constexpr (PRE) v[mt] = v[mt] + y1[mt][t];                                // add_identity: the FFN's own input
-                else if (res && live) v[mt] = v[mt] + *reinterpret_cast<const fbbev_v4f*>(res + r * ld_res + o);
+                else if (res && live) v[mt] = v[mt] + pres[mt][t];
                 s += (v[mt][0] + v[mt][1]) + (v[mt][2] + v[mt][3]);
             }
         }
@@ -498,7 +598,7 @@ k_rows_ffn_x3(const float* __restrict__ x, long long ldx, const unsigned short* 
             for (int mt = 0; mt < MT2; ++mt) {
                 const int o = 16 * mt + 4 * g;
                 if (o < O) {
-                    const fbbev_v4f w4 = *reinterpret_cast<const fbbev_v4f*>(ln_w + o), b4 = *reinterpret_cast<const fbbev_v4f*>(ln_b + o);
+                    const fbbev_v4f w4 = pw[mt], b4 = pq[mt];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[mt][e] = v[mt][e] * inv * w4[e] + b4[e];
                 }

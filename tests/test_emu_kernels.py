@@ -1731,12 +1731,8 @@ def test_rows_tail_ffn_one_kernel_emulated(rows, Em, H, with_res):
     assert code == 0
     code, two = E.rows_ffn_x3(t1, w1, b1, w2, b2, residual=t1, ln_w=l1w, ln_b=l1b, eps=1e-6)
     assert code == 0
-    for hc in ('32', '64'):
-        os.environ['FBBEV_TAIL_FFN_HC'] = hc
-        try:
-            code, out = E.rows_tail_ffn_x3(x, w0, b0, res0, l0w, l0b, 1e-5, w1, b1, w2, b2, l1w, l1b, 1e-6)
-        finally:
-            del os.environ['FBBEV_TAIL_FFN_HC']
+    for hc in ('32',):        # (the 64-unit chunk form of the tail kernel measured no gain and left with round 5's register-held staging)
+        code, out = E.rows_tail_ffn_x3(x, w0, b0, res0, l0w, l0b, 1e-5, w1, b1, w2, b2, l1w, l1b, 1e-6)
         assert code == 0 and not torch.isnan(out).any()
         assert (out - ref).abs().max().item() <= 5e-5 * max(1.0, ref.abs().max().item()), (hc, (out - ref).abs().max().item())
         assert (out - two).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item()), (hc, (out - two).abs().max().item())
