@@ -2901,7 +2901,7 @@ extern "C" int fbbev_rows_ffn_x3(const float* x, long long x_row_stride, const v
     const int n_kc2 = (hidden + 127) / 128;
 #define FBBEV_FFN(LN_, HC_)                                                                                              \
     do {                                                                                                               \
-        const size_t lds = (size_t)fbbev_ffn_lds_bytes<3, 5, HC_>();                                                   \
+        const size_t lds = (size_t)fbbev_ffn_lds_bytes<3, 5, HC_>() + (size_t)hidden * 4; /* + b1 */                                                 \
         int e = fbbev_rt_allow_dyn_lds((const void*)k_rows_ffn_x3<3, 5, LN_, HC_>, lds);                               \
         if (e) return e;                                                                                               \
         FBBEV_LAUNCH((k_rows_ffn_x3<3, 5, LN_, HC_>), wgs, 256, lds, (fbbev_rt_stream)stream_, x, x_row_stride,          \
@@ -2946,7 +2946,7 @@ extern "C" int fbbev_rows_tail_ffn_x3(const float* x, long long x_row_stride, co
     pre.ln0_w = ln0_weight; pre.ln0_b = ln0_bias; pre.eps0 = ln0_eps;
 #define FBBEV_TFFN(HC_)                                                                                                \
     do {                                                                                                              \
-        const size_t lds = (size_t)fbbev_ffn_pre_lds_bytes<3, 5, HC_>();                                               \
+        const size_t lds = (size_t)fbbev_ffn_pre_lds_bytes<3, 5, HC_>() + (size_t)hidden * 4; /* + b1 */                                             \
         int e = fbbev_rt_allow_dyn_lds((const void*)k_rows_ffn_x3<3, 5, true, HC_, true>, lds);                        \
         if (e) return e;                                                                                              \
         FBBEV_LAUNCH((k_rows_ffn_x3<3, 5, true, HC_, true>), wgs, 256, lds, (fbbev_rt_stream)stream_, x, x_row_stride,   \

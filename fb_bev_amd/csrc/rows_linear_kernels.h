@@ -303,6 +303,12 @@ k_rows_ffn_x3(const float* __restrict__ x, long long ldx, const unsigned short* 
     unsigned short* w1s = reinterpret_cast<unsigned short*>(fbbev_dyn_lds_f32());          // [T1][hi|lo][KS1][64][8]
     unsigned short* w2s = w1s + T1 * 2 * KS1 * 512;                                        // [MT2][hi|lo][S2][64][8]
     unsigned short* hb = w1s + WREGION + (threadIdx.x >> 6) * (NT * S2 * 2 * 512);         // this wave's [t][s2][hi|lo][64][8]
+    // b1 (H floats) behind the four waves' buffers (round 5; the launcher adds H * 4 bytes): a chunk's bias pieces come by ds_read --
+    // as global loads they sat BEHIND the next chunk's prefetch in the in-order vmcnt and every GEMM 1 waited for that round trip
+    float* b1s = reinterpret_cast<float*>(w1s + WREGION + 4 * (NT * S2 * 2 * 512));
+    float b1r[4];                                                                           // (requested here, stored behind the rows' loads)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int i = (int)threadIdx.x + 256 * u; b1r[u] = b1[i < H ? i : 0]; }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int g = lane >> 4, j = lane & 15;
     const long long r0 = ((long long)blockIdx.x * 4 + wave) * (16 * NT);
@@ -354,6 +360,10 @@ k_rows_ffn_x3(const float* __restrict__ x, long long ldx, const unsigned short* 
 #pragma unroll
         for (int k = 0; k < I2; ++k) { const int i = (int)threadIdx.x + 256 * k; if (i < N2) reinterpret_cast<fbbev_v4u*>(w2s)[i] = st2[k]; }
     };
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int i = (int)threadIdx.x + 256 * u; if (i < H) b1s[i] = b1r[u]; }
+    for (int i = (int)threadIdx.x + 1024; i < H; i += 256) b1s[i] = b1[i];                  // (H > 1024: not an FB-OCC width); visible behind the
+                                                                                            // __syncthreads that precedes the first GEMM 1
     fbbev_v4f y1[PRE ? MT2 : 1][NT];                                                        // PRE: LayerNorm0's output = the FFN's residual
     if constexpr (PRE) {
         // W0's fragments (tiles 0..MT2-1, k-steps 0..KS1-1 of its single K chunk) through the weight region, shared by the 4 waves
@@ -491,8 +501,8 @@ k_rows_ffn_x3(const float* __restrict__ x, long long ldx, const unsigned short* 
         if (!PF) request(c);                                                                // (PF: in flight since the previous chunk's GEMMs / the PRE block)
         if (c || PRE) __syncthreads();                                                      // the previous chunk's weights (PRE: W0's) are done with
         commit();
+        if (PF && c + 1 < n_chunks) request(c + 1);                                         // (the pieces' registers are free again)
         __syncthreads();
-        if (PF && c + 1 < n_chunks) request(c + 1);
         // GEMM 1 + bias + ReLU -> hidden fragments of this wave
 #pragma unroll
         for (int mt = 0; mt < T1; ++mt) {
@@ -510,7 +520,7 @@ k_rows_ffn_x3(const float* __restrict__ x, long long ldx, const unsigned short* 
                     acc1[t] = fbbev_mfma_f32_16x16x32_bf16(ah, xh[s][t], acc1[t]);
                 }
             }
-            const fbbev_v4f bias4 = *reinterpret_cast<const fbbev_v4f*>(b1 + HC * c + 16 * mt + 4 * g);
+            const fbbev_v4f bias4 = *reinterpret_cast<const fbbev_v4f*>(b1s + HC * c + 16 * mt + 4 * g);
             const int s2 = mt >> 1, gl = 2 * (mt & 1) + (g >> 1), e0 = 4 * (g & 1);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
