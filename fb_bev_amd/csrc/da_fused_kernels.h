@@ -324,6 +324,47 @@ __device__ __forceinline__ void fbbev_daf_outproj_ln(const fbbev_daf_outproj& op
     }
 }
 
+// the 64 query rows (+ positional rows) of an 8 x 8 patch as split bf16 B fragments in LDS: [4 row tiles][KS][hi|lo][64][8].  Every
+// piece of the workgroup is REQUESTED before the first is split and stored (round 5: as a `for (i = tid; ...; i += NT)` loop the
+// compiler waited for each iteration's loads before the next iteration's were issued -- three round trips to the query rows in a row
+// at 256 threads)
+template <int E, int KS, int NT>
+__device__ __forceinline__ void fbbev_daf_query_fragments(unsigned short* __restrict__ xf, const float* __restrict__ query, long long ldq,
+                                                          const float* __restrict__ addend, long long ld_add, long long add_period,
+                                                          int b, int Q, int bev_w, int bev_h, int x0, int y0) {
+    constexpr int N = 4 * KS * 64, NI = (N + NT - 1) / NT;
+    fbbev_v4f q4[NI][2], a4[NI][2];
+    bool ok[NI];
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+        const int i = (int)threadIdx.x + NT * k;
+        const int rt = i / (KS * 64), s = (i >> 6) % KS, ln = i & 63;
+        const int g = ln >> 4, j = ln & 15, ql = 16 * rt + j, c = 32 * s + 8 * g;
+        const int qy = y0 + (ql >> 3), qx = x0 + (ql & 7);
+        ok[k] = i < N && c < E && qy < bev_h && qx < bev_w;
+        const long long row = ok[k] ? (long long)b * Q + (long long)qy * bev_w + qx : (long long)b * Q;      // (clamped: unconditional loads)
+        const float* src = query + row * ldq + (ok[k] ? c : 0);
+        q4[k][0] = *reinterpret_cast<const fbbev_v4f*>(src); q4[k][1] = *reinterpret_cast<const fbbev_v4f*>(src + 4);
+        if (addend) {                                                                       // uniform
+            const float* a = addend + (row % add_period) * ld_add + (ok[k] ? c : 0);
+            a4[k][0] = *reinterpret_cast<const fbbev_v4f*>(a); a4[k][1] = *reinterpret_cast<const fbbev_v4f*>(a + 4);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+        const int i = (int)threadIdx.x + NT * k;
+        if (i >= N) break;
+        const int rt = i / (KS * 64), s = (i >> 6) % KS, ln = i & 63;
+        fbbev_v4f lo4 = q4[k][0], hi4 = q4[k][1];
+        if (addend) { lo4 = lo4 + a4[k][0]; hi4 = hi4 + a4[k][1]; }
+        if (!ok[k]) { lo4 = fbbev_v4f{0.f, 0.f, 0.f, 0.f}; hi4 = fbbev_v4f{0.f, 0.f, 0.f, 0.f}; }
+        fbbev_bf16x8 h8, l8;
+        fbbev_split_bf16x8(lo4, hi4, h8, l8);
+        __builtin_memcpy(xf + (((rt * KS + s) * 2 + 0) * 64 + ln) * 8, &h8, 16);
+        __builtin_memcpy(xf + (((rt * KS + s) * 2 + 1) * 64 + ln) * 8, &l8, 16);
+    }
+}
+
 // planes (B*Ncam, M, S, DH); pred_depth (B*Ncam, DC, H0, W0); ref_cam (Ncam,B,Q,Za,2); mask (Ncam,B,Q,Za) u8; qdepth (Ncam,B,Q,Za);
 // query (B*Q rows, ldq floats apart, E used) [+ addend rows: row (b*Q + q) % add_period]; so_frag / aw_frag: split bf16 fragments of
 // sampling_offsets.weight (M*L*P*2, E) / attention_weights.weight (M*L*P, E) in the order of k_rows_linear_x3_fragments, rows in
@@ -372,34 +413,23 @@ k_da_cross_attn_fused(const float* __restrict__ planes /* ET != 0: 16-bit elemen
     // ---------------- phase A (whole workgroup): the patch's query rows as split MFMA fragments, its (camera, query) records
     // hit flags first (one round trip, under the query rows' loads below): a record of a camera the query does not see -- three of
     // four at six surround cameras -- is never computed (round 5; before, every record paid its 16 depth loads and ~300 VALU)
-    for (int i = threadIdx.x; i < ((diag & 4) ? 0 : Ncam * 64); i += NT) {
-        const int cam = i >> 6, ql = i & 63;
-        const int qy = y0 + (ql >> 3), qx = x0 + (ql & 7);
-        const bool inb = qy < bev_h && qx < bev_w;
-        const long long base = (((long long)cam * B + b) * Q + (inb ? (long long)qy * bev_w + qx : 0)) * ZA;
-        unsigned int mask4;
-        __builtin_memcpy(&mask4, mask + base, 4);                                       // ZA = 4 mask bytes
-        qc[(size_t)i * FBBEV_DAF_QC + 3 * ZA] = (inb && mask4 != 0u) ? 1.f : 0.f;
-    }
-    for (int i = threadIdx.x; i < 4 * KS * 64; i += NT) {
-        const int rt = i / (KS * 64), s = (i >> 6) % KS, ln = i & 63;
-        const int g = ln >> 4, j = ln & 15, ql = 16 * rt + j, c = 32 * s + 8 * g;
-        const int qy = y0 + (ql >> 3), qx = x0 + (ql & 7);
-        fbbev_v4f lo4 = {0.f, 0.f, 0.f, 0.f}, hi4 = {0.f, 0.f, 0.f, 0.f};
-        if (c < E && qy < bev_h && qx < bev_w) {
-            const long long row = (long long)b * Q + (long long)qy * bev_w + qx;
-            const float* src = query + row * ldq + c;
-            lo4 = *reinterpret_cast<const fbbev_v4f*>(src); hi4 = *reinterpret_cast<const fbbev_v4f*>(src + 4);
-            if (addend) {
-                const float* a = addend + (row % add_period) * ld_add + c;
-                lo4 = lo4 + *reinterpret_cast<const fbbev_v4f*>(a); hi4 = hi4 + *reinterpret_cast<const fbbev_v4f*>(a + 4);
-            }
+    for (int i0 = threadIdx.x; i0 < ((diag & 4) ? 0 : Ncam * 64); i0 += 2 * NT) {           // (two records' masks per round trip)
+        unsigned int mask4[2];
+        bool inb[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = i0 + NT * u < Ncam * 64 ? i0 + NT * u : i0;
+            const int cam = i >> 6, ql = i & 63;
+            const int qy = y0 + (ql >> 3), qx = x0 + (ql & 7);
+            inb[u] = qy < bev_h && qx < bev_w;
+            const long long base = (((long long)cam * B + b) * Q + (inb[u] ? (long long)qy * bev_w + qx : 0)) * ZA;
+            __builtin_memcpy(&mask4[u], mask + base, 4);                                // ZA = 4 mask bytes
         }
-        fbbev_bf16x8 h8, l8;
-        fbbev_split_bf16x8(lo4, hi4, h8, l8);
-        __builtin_memcpy(xf + (((rt * KS + s) * 2 + 0) * 64 + ln) * 8, &h8, 16);
-        __builtin_memcpy(xf + (((rt * KS + s) * 2 + 1) * 64 + ln) * 8, &l8, 16);
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (i0 + NT * u < Ncam * 64) qc[(size_t)(i0 + NT * u) * FBBEV_DAF_QC + 3 * ZA] = (inb[u] && mask4[u] != 0u) ? 1.f : 0.f;
     }
+    fbbev_daf_query_fragments<E, KS, NT>(xf, query, ldq, addend, ld_add, add_period, b, Q, bev_w, bev_h, x0, y0);
     for (int i = threadIdx.x; i < ((diag & 4) ? 0 : Ncam * 64); i += NT) {
         // every load of a hit record is issued before any is used; a non-hit record keeps only its flag (phase B reads the other
         // fields of such a record only into selects that discard them)
@@ -711,8 +741,8 @@ k_msda_self_fused(const float* __restrict__ planes, const float* __restrict__ re
     const int b = (int)(wgid / ((long long)pxn * pyn)), pi = (int)(wgid - (long long)b * pxn * pyn);
     const int py = pi / pxn, px = pi - py * pxn;
     const int x0 = px * 8, y0 = py * 8;
-    for (int i = threadIdx.x; i < 4 * KS * 64; i += NT) {
-        const int rt = i / (KS * 64), s = (i >> 6) % KS, ln = i & 63;
+    for (int i = threadIdx.x; i < 4 * KS * 64; i += NT) {                                   // (the batched form, fbbev_daf_query_fragments, costs this
+        const int rt = i / (KS * 64), s = (i >> 6) % KS, ln = i & 63;                       //  128-register kernel two spilled values and 2 us)
         const int g = ln >> 4, j = ln & 15, ql = 16 * rt + j, c = 32 * s + 8 * g;
         const int qy = y0 + (ql >> 3), qx = x0 + (ql & 7);
         fbbev_v4f lo4 = {0.f, 0.f, 0.f, 0.f}, hi4 = {0.f, 0.f, 0.f, 0.f};
