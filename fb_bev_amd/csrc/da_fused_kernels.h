@@ -277,7 +277,15 @@ __device__ __forceinline__ void fbbev_daf_outproj_ln(const fbbev_daf_outproj& op
                                                      long long row, bool live, float* __restrict__ out, long long ldo) {
     constexpr int O = 16 * MT;
     const int g = lane >> 4;
-    fbbev_v4f v[MT];
+    // bias and residual pieces requested ahead of the MFMAs, unconditionally (`row` is valid for a dead lane too): behind their `if`
+    // every piece was its own round trip at the tail of the workgroup (round 5)
+    fbbev_v4f v[MT], pb[MT], pr[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) pb[mt] = *reinterpret_cast<const fbbev_v4f*>(op.bias + 16 * mt + 4 * g);
+    if (op.res) {                                                       // uniform
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) pr[mt] = fbbev_gld_v4f(op.res + row * op.ld_res + 16 * mt + 4 * g);
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) v[mt] = fbbev_v4f{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -297,9 +305,8 @@ __device__ __forceinline__ void fbbev_daf_outproj_ln(const fbbev_daf_outproj& op
     float sum = 0.f;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        const int o = 16 * mt + 4 * g;
-        v[mt] = v[mt] + *reinterpret_cast<const fbbev_v4f*>(op.bias + o);
-        if (op.res && live) v[mt] = v[mt] + *reinterpret_cast<const fbbev_v4f*>(op.res + row * op.ld_res + o);
+        v[mt] = v[mt] + pb[mt];
+        if (op.res && live) v[mt] = v[mt] + pr[mt];
         sum += (v[mt][0] + v[mt][1]) + (v[mt][2] + v[mt][3]);
     }
     sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
@@ -314,9 +321,15 @@ __device__ __forceinline__ void fbbev_daf_outproj_ln(const fbbev_daf_outproj& op
     const float inv = 1.0f / sqrtf(q / (float)O + op.eps);
     if (!live) return;
 #pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {                                   // (pb / pr are free: the LayerNorm pieces, requested together)
+        const int o = 16 * mt + 4 * g;
+        pb[mt] = *reinterpret_cast<const fbbev_v4f*>(op.ln_w + o);
+        pr[mt] = *reinterpret_cast<const fbbev_v4f*>(op.ln_b + o);
+    }
+#pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int o = 16 * mt + 4 * g;
-        const fbbev_v4f w4 = *reinterpret_cast<const fbbev_v4f*>(op.ln_w + o), b4 = *reinterpret_cast<const fbbev_v4f*>(op.ln_b + o);
+        const fbbev_v4f w4 = pb[mt], b4 = pr[mt];
         fbbev_v4f y;
 #pragma unroll
         for (int e = 0; e < 4; ++e) y[e] = v[mt][e] * inv * w4[e] + b4[e];

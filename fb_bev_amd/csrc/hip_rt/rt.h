@@ -159,6 +159,8 @@ __device__ __forceinline__ void fbbev_pin(fbbev_v2f& x) { asm volatile("" : "+v"
 __device__ __forceinline__ float fbbev_lds_ld_f32(const float* p) {
     return *(const __attribute__((address_space(3))) float*)p;
 }
+// a 16-byte load through a pointer the compiler cannot trace to a kernel argument (a nullable member of a by-value struct): global, not flat
+__device__ __forceinline__ fbbev_v4f fbbev_gld_v4f(const float* p) { return *(const __attribute__((address_space(1))) fbbev_v4f*)p; }
 __device__ __forceinline__ int fbbev_lds_ld_i32(const int* p) { return *(const __attribute__((address_space(3))) int*)p; }
 // 16 bytes at an 8-byte aligned LDS address (two ds_read_b64 / one ds_read2_b64: head-plane tokens of 10 floats are 8-byte aligned)
 // a * b + c with a, b < 2^24 as ONE full-rate v_mad_u32_u24 (the compiler turns the mul24 builtins back into the quarter-rate

@@ -273,4 +273,5 @@ inline int fbbev_lds_ld_i32(const int* p) { return *p; }
 inline unsigned int fbbev_mad_u24_vsv(unsigned int a, unsigned int b, unsigned int c) { return (unsigned int)((unsigned long long)(a & 0xffffffu) * (b & 0xffffffu)) + c; }
 template <unsigned int K>
 inline unsigned int fbbev_mad_u24_vks(unsigned int a, unsigned int c) { return (unsigned int)((unsigned long long)(a & 0xffffffu) * K) + c; }
+inline fbbev_v4f fbbev_gld_v4f(const float* p) { return *reinterpret_cast<const fbbev_v4f*>(p); }
 inline fbbev_v4f fbbev_lds_ld_v4f_a8(const float* p) { return fbbev_v4f{p[0], p[1], p[2], p[3]}; }
