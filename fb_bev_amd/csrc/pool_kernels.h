@@ -821,13 +821,21 @@ k_pool_zmean(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_blocks
         const int ni = i1 - i0, np = p1 - p0;
         const int rank0 = plane * YX + v0;
         __syncthreads();                        // previous plane's gathers are done with the staging buffers / tile init
-        for (int j = tid; j < ni; j += NT) {
+        const int nps = np < FBBEV_NP_STAGE ? np : FBBEV_NP_STAGE;
+        {   // round 5: a thread's first interval record AND its first point-index pair are requested together (clamped, unconditional):
+            // as two loops the second one's loads waited for the first one's round trip -- one of the ~5 per plane this kernel is made of
+            const int ji = tid < ni ? tid : 0, jp = tid < nps ? tid : 0;           // ni >= 1 here; np >= 1 with it
+            const int a = starts[i0 + ji], l = lengths[i0 + ji], r = interval_rank[i0 + ji];
+            const int d = rd[p0 + jp], f = rf[p0 + jp];
+            if (tid < ni) { ist[tid] = a - p0; iln[tid] = l; ivx[tid] = r - rank0; }
+            if (tid < nps) { prd[tid] = d; prf[tid] = f; }
+        }
+        for (int j = tid + NT; j < ni; j += NT) {
             ist[j] = starts[i0 + j] - p0;
             iln[j] = lengths[i0 + j];
             ivx[j] = interval_rank[i0 + j] - rank0;
         }
-        const int nps = np < FBBEV_NP_STAGE ? np : FBBEV_NP_STAGE;
-        for (int j = tid; j < nps; j += NT) { prd[j] = rd[p0 + j]; prf[j] = rf[p0 + j]; }
+        for (int j = tid + NT; j < nps; j += NT) { prd[j] = rd[p0 + j]; prf[j] = rf[p0 + j]; }
         __syncthreads();
         const int lpi = CC / CPL;
         const int gpb = NT / lpi;
