@@ -812,47 +812,67 @@ k_pool_zmean(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_blocks
     const int zper = (Z + z_groups - 1) / z_groups;
     const int z_lo = zg * zper, z_hi = z_lo + zper < Z ? z_lo + zper : Z;
     for (int idx = tid; idx < CC * LD; idx += NT) tile[idx] = 0.f;
+    // Round 5: the plane walk as a two-stage pipeline.  A plane costs a chain tile metadata -> interval records / point pairs -> barrier
+    // -> gathers; the metadata of plane z + 2 (scalar loads) and the records of plane z + 1 (five registers per thread: its first interval
+    // record and point-index pair) are requested BEFORE the gathers of plane z and land under them.  Same staging contents, same gather
+    // order: identical bits.
+    auto load_meta = [&](int z, int (&m)[4]) {
+        const long long t = (long long)(b * Z + z) * tiles_per_plane + k;
+        m[0] = tile_meta[2 * t]; m[1] = tile_meta[2 * t + 1]; m[2] = tile_meta[2 * t + 2]; m[3] = tile_meta[2 * t + 3];
+    };
+    int sa = 0, sl = 0, sr = 0, sd = 0, sf = 0;                   // the staged-ahead record / pair of the NEXT plane to be committed
+    auto request = [&](const int (&m)[4]) {                      // (clamped, unconditional loads: one round trip)
+        const int ni = m[2] - m[0], np = m[3] - m[1];
+        if (ni == 0) return;                                     // block-uniform
+        const int nps = np < FBBEV_NP_STAGE ? np : FBBEV_NP_STAGE;
+        const int ji = tid < ni ? tid : 0, jp = tid < nps ? tid : 0;
+        sa = starts[m[0] + ji]; sl = lengths[m[0] + ji]; sr = interval_rank[m[0] + ji];
+        sd = rd[m[1] + jp]; sf = rf[m[1] + jp];
+    };
+    int m0[4] = {0, 0, 0, 0}, m1[4] = {0, 0, 0, 0}, m2[4] = {0, 0, 0, 0};
+    if (z_lo < z_hi) load_meta(z_lo, m0);
+    if (z_lo + 1 < z_hi) load_meta(z_lo + 1, m1);
+    request(m0);
     for (int z = z_lo; z < z_hi; ++z) {
+        if (z + 2 < z_hi) load_meta(z + 2, m2);
         const int plane = b * Z + z;
-        const int t = plane * tiles_per_plane + k;
-        const int i0 = tile_meta[2 * t], p0 = tile_meta[2 * t + 1];
-        const int i1 = tile_meta[2 * t + 2], p1 = tile_meta[2 * t + 3];
-        if (i0 == i1) continue;                 // block-uniform
+        const int i0 = m0[0], p0 = m0[1], i1 = m0[2], p1 = m0[3];
         const int ni = i1 - i0, np = p1 - p0;
         const int rank0 = plane * YX + v0;
-        __syncthreads();                        // previous plane's gathers are done with the staging buffers / tile init
         const int nps = np < FBBEV_NP_STAGE ? np : FBBEV_NP_STAGE;
-        {   // round 5: a thread's first interval record AND its first point-index pair are requested together (clamped, unconditional):
-            // as two loops the second one's loads waited for the first one's round trip -- one of the ~5 per plane this kernel is made of
-            const int ji = tid < ni ? tid : 0, jp = tid < nps ? tid : 0;           // ni >= 1 here; np >= 1 with it
-            const int a = starts[i0 + ji], l = lengths[i0 + ji], r = interval_rank[i0 + ji];
-            const int d = rd[p0 + jp], f = rf[p0 + jp];
-            if (tid < ni) { ist[tid] = a - p0; iln[tid] = l; ivx[tid] = r - rank0; }
-            if (tid < nps) { prd[tid] = d; prf[tid] = f; }
+        if (ni != 0) {                          // block-uniform
+            __syncthreads();                    // previous plane's gathers are done with the staging buffers / tile init
+            if (tid < ni) { ist[tid] = sa - p0; iln[tid] = sl; ivx[tid] = sr - rank0; }
+            if (tid < nps) { prd[tid] = sd; prf[tid] = sf; }
+            for (int j = tid + NT; j < ni; j += NT) {
+                ist[j] = starts[i0 + j] - p0;
+                iln[j] = lengths[i0 + j];
+                ivx[j] = interval_rank[i0 + j] - rank0;
+            }
+            for (int j = tid + NT; j < nps; j += NT) { prd[j] = rd[p0 + j]; prf[j] = rf[p0 + j]; }
+            __syncthreads();
         }
-        for (int j = tid + NT; j < ni; j += NT) {
-            ist[j] = starts[i0 + j] - p0;
-            iln[j] = lengths[i0 + j];
-            ivx[j] = interval_rank[i0 + j] - rank0;
-        }
-        for (int j = tid + NT; j < nps; j += NT) { prd[j] = rd[p0 + j]; prf[j] = rf[p0 + j]; }
-        __syncthreads();
-        const int lpi = CC / CPL;
-        const int gpb = NT / lpi;
-        const int g = tid / lpi, slot = tid - g * lpi;
-        if (g < gpb) {
-            const float* fbase = feat + c0 + slot * CPL;
-            for (int i = g; i < ni; i += gpb) {          // a voxel appears in at most one interval of a plane:
-                const int v = ivx[i];                    // its LDS cell is owned by one lane group per plane
-                float acc[CPL];
-                fbbev_interval_sum_staged<CPL, 4>(C, ist[i], iln[i], p0, prd, prf, depth, fbase, rd, rf, acc);
-                if (v >= 0 && v < nv) {
-                    float* dst = tile + (slot * CPL) * LD + v;
+        if (z + 1 < z_hi) request(m1);          // lands under this plane's gathers
+        if (ni != 0) {
+            const int lpi = CC / CPL;
+            const int gpb = NT / lpi;
+            const int g = tid / lpi, slot = tid - g * lpi;
+            if (g < gpb) {
+                const float* fbase = feat + c0 + slot * CPL;
+                for (int i = g; i < ni; i += gpb) {          // a voxel appears in at most one interval of a plane:
+                    const int v = ivx[i];                    // its LDS cell is owned by one lane group per plane
+                    float acc[CPL];
+                    fbbev_interval_sum_staged<CPL, 4>(C, ist[i], iln[i], p0, prd, prf, depth, fbase, rd, rf, acc);
+                    if (v >= 0 && v < nv) {
+                        float* dst = tile + (slot * CPL) * LD + v;
 #pragma unroll
-                    for (int j = 0; j < CPL; ++j) dst[j * LD] += acc[j];
+                        for (int j = 0; j < CPL; ++j) dst[j * LD] += acc[j];
+                    }
                 }
             }
         }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { m0[q] = m1[q]; m1[q] = m2[q]; }
     }
     __syncthreads();
     const float zf = z_groups > 1 ? 1.f : (float)Z;
