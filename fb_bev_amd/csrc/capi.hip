@@ -175,11 +175,13 @@ extern "C" int fbbev_point_sampling(const float* xs, const float* ys, const floa
     if (!xs || !ys || !zs || !rots || !trans || !intrins || !post_rots || !post_trans || !bda || !ref_cam ||
         !mask || !qdepth) return FBBEV_E_BADARG;
     const long long npts = (long long)Y * X * Za;
-    const long long chunks = (npts + 255) / 256;
-    if (chunks * B * N >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
+    int ppt = 8;                                            // points per thread: the most that leaves >= 1024 workgroups
+    while (ppt > 1 && (npts + 256 * ppt - 1) / (256 * ppt) * B * N < 1024) ppt >>= 1;
+    const long long chunks = (npts + 256 * ppt - 1) / (256 * ppt);
+    if (chunks * B * N >= (1ll << 31) || ((uintptr_t)ref_cam & 7) != 0) return FBBEV_E_UNSUPPORTED;
     FBBEV_LAUNCH(k_point_sampling, chunks * B * N, 256, 0, (fbbev_rt_stream)stream_, xs, ys, zs, rots, trans,
                  intrins, post_rots, post_trans, bda, B, N, Y, X, Za, ogfH, ogfW, (int)chunks, ref_cam, mask,
-                 qdepth);
+                 qdepth, ppt);
     FBBEV_CHECK_LAUNCH();
     return 0;
 }

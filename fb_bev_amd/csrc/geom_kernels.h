@@ -136,7 +136,7 @@ k_point_sampling(const float* __restrict__ xs, const float* __restrict__ ys, con
                  const float* __restrict__ intrins, const float* __restrict__ post_rots,
                  const float* __restrict__ post_trans, const float* __restrict__ bda, int B, int N, int Y, int X,
                  int Za, float ogfH, float ogfW, int chunks, float* __restrict__ ref_cam,
-                 unsigned char* __restrict__ mask, float* __restrict__ qdepth) {
+                 unsigned char* __restrict__ mask, float* __restrict__ qdepth, int ppt) {
     __shared__ float m[9 + 9 + 9 + 3 + 3];  // inv(bda), inv(rots*inv(K)), post_rots, trans, post_trans
     const int cam_b = blockIdx.x / chunks, chunk = blockIdx.x - cam_b * chunks;   // cam_b = b*N + n
     const int b = cam_b / N, n = cam_b - b * N;
@@ -152,8 +152,11 @@ k_point_sampling(const float* __restrict__ xs, const float* __restrict__ ys, con
     __syncthreads();
     const float eps = 1e-5f;
     const int npts = Y * X * Za;
-    const int i = chunk * 256 + threadIdx.x;
-    if (i < npts) {
+    // round 5: `ppt` points per thread (the launcher's choice: as many as keep >= 1024 workgroups).  The per-camera algebra above is one
+    // thread's serial work behind its own loads -- with one point per thread it was most of a workgroup's life (33 us for 45 MB at configs[2])
+    for (int k = 0; k < ppt; ++k) {
+        const int i = (chunk * ppt + k) * 256 + (int)threadIdx.x;
+        if (i >= npts) break;
         const int z = i % Za, x = (i / Za) % X, y = i / (Za * X);
         const float px = xs[x], py = ys[y], pz = zs[z];
         float qx = m[0] * px + m[1] * py + m[2] * pz - m[27];
@@ -170,8 +173,7 @@ k_point_sampling(const float* __restrict__ xs, const float* __restrict__ ys, con
         const float u = ux / ogfW, v = uy / ogfH;
         const bool ok = (uz > eps) && (u > eps) && (u < (1.0f - eps)) && (v > eps) && (v < (1.0f - eps));
         const long long o = ((long long)(n * B + b)) * npts + i;   // (N,B,Q=Y*X,Za)
-        ref_cam[o * 2] = u;
-        ref_cam[o * 2 + 1] = v;
+        *reinterpret_cast<fbbev_v2f*>(ref_cam + o * 2) = fbbev_v2f{u, v};
         mask[o] = ok ? 1 : 0;
         qdepth[o] = uz;
     }

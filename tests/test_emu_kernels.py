@@ -1679,7 +1679,8 @@ def test_rows_linear_layernorm_epilogue_emulated(rows, I, O, with_res):
     assert code < 0                                                       # wider than one workgroup's output rows: refused
 
 
-@pytest.mark.parametrize('rows,I,H,O,ln,with_res', [(200, 80, 320, 80, True, True), (70, 80, 64, 80, False, True), (33, 64, 128, 48, True, False)])
+@pytest.mark.parametrize('rows,I,H,O,ln,with_res', [(200, 80, 320, 80, True, True), (70, 80, 64, 80, False, True), (33, 64, 128, 48, True, False),
+                                                    (40, 80, 1088, 80, True, True)])      # H > 1024: b1's LDS copy takes its tail loop
 def test_rows_ffn_one_kernel_emulated(rows, I, H, O, ln, with_res):
     """fbbev_rows_ffn_x3: [LayerNorm](W2 relu(W1 x + b1) + b2 [+ residual]) with the hidden rows kept in LDS fragments == the fp32
     composition in torch within the split-operand arithmetic; rows that do not fill the last tile, one / several hidden chunks."""
@@ -1707,7 +1708,7 @@ def test_rows_ffn_one_kernel_emulated(rows, I, H, O, ln, with_res):
     assert code < 0                                                        # hidden width no multiple of 64: refused
 
 
-@pytest.mark.parametrize('rows,Em,H,with_res', [(200, 80, 320, True), (70, 80, 64, True), (33, 64, 128, False), (130, 16, 64, True)])
+@pytest.mark.parametrize('rows,Em,H,with_res', [(200, 80, 320, True), (70, 80, 64, True), (33, 64, 128, False), (130, 16, 64, True), (40, 80, 1088, True)])
 def test_rows_tail_ffn_one_kernel_emulated(rows, Em, H, with_res):
     """fbbev_rows_tail_ffn_x3: LayerNorm1(y1 + W2 relu(W1 y1 + b1) + b2) with y1 = LayerNorm0(x W0^T + b0 [+ res0]) -- the
     cross-attention block's tail and the FFN block of the encoder layer (bevformer_encoder.py:250-377) in one kernel, y1 kept in
