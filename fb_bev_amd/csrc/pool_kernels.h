@@ -457,10 +457,22 @@ k_pool_fwd_dense2(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_b
     }
     if (bid >= n_blocks) return;
     // tile-major: the csplit channel groups of a tile are adjacent workgroups (index / feat reads shared through L2)
-    const int t = bid / csplit;
-    const int half = bid - t * csplit;
+    const int t_ = bid / csplit;
+    const int half = bid - t_ * csplit;
     const int c0 = half * CC;
-    const int plane = t / tiles_per_plane, k = t - plane * tiles_per_plane;
+    // tile order.  Plain: plane-major (consecutive workgroups = consecutive 128-voxel runs of one plane).  With an addend (round 5): the Z
+    // planes of a BEV tile are CONSECUTIVE workgroups -- they all add the same (C, TV) piece of the (B, C, Y, X) addend, which then comes
+    // from the XCD's L2 most of the time instead of being re-read from far memory for every plane.  Every tile still writes its own runs.
+    int plane, k;
+    if (addend != nullptr) {                                                         // uniform
+        const int per_b = tiles_per_plane * Z;
+        const int bb = t_ / per_b, r = t_ - bb * per_b;
+        k = r / Z;
+        plane = bb * Z + (r - k * Z);
+    } else {
+        plane = t_ / tiles_per_plane; k = t_ - plane * tiles_per_plane;
+    }
+    const int t = plane * tiles_per_plane + k;                                      // index of the tile in tile_meta (the interval build's order)
     const int b = plane / Z, z = plane - b * Z;
     const int v0 = k * TV;
     const int nv = (YX - v0 < TV) ? (YX - v0) : TV;
@@ -480,10 +492,31 @@ k_pool_fwd_dense2(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_b
         if constexpr (DIAG == 3) return;                     // gathers alone: an empty tile has none
         fbbev_v4f zero; zero[0] = zero[1] = zero[2] = zero[3] = 0.f;
         if constexpr (OT == 0) {
-            for (int idx = tid; idx < n4; idx += NT) {
-                const int c = idx / Q4, j = (idx - c * Q4) * 4;
-                if (j < nv) fbbev_store4<ST>(obase + c * cstride + j,
-                                             ab ? *reinterpret_cast<const fbbev_v4f*>(ab + (long long)c * YX + j) : zero);
+            if (ab) {                                                                // uniform
+                // round 5: the addend pieces of a batch are REQUESTED before the first is stored (one load, wait, store per piece before).
+                // Requesting them at the top of the kernel, next to the tile metadata, costs the PLAIN kernel 8 registers and 3 % (0.766 ->
+                // 0.741 of the HBM peak): not done
+                constexpr int NB = 5;
+                for (int idx0 = tid; idx0 < n4; idx0 += NT * NB) {
+                    fbbev_v4f av[NB];
+#pragma unroll
+                    for (int u = 0; u < NB; ++u) {
+                        const int idx = idx0 + NT * u < n4 ? idx0 + NT * u : idx0;
+                        const int c = idx / Q4, j = (idx - c * Q4) * 4;
+                        av[u] = *reinterpret_cast<const fbbev_v4f*>(ab + (long long)c * YX + (j < nv ? j : 0));
+                    }
+#pragma unroll
+                    for (int u = 0; u < NB; ++u) {
+                        const int idx = idx0 + NT * u;
+                        const int c = idx / Q4, j = (idx - c * Q4) * 4;
+                        if (idx < n4 && j < nv) fbbev_store4<ST>(obase + c * cstride + j, av[u]);
+                    }
+                }
+            } else {
+                for (int idx = tid; idx < n4; idx += NT) {
+                    const int c = idx / Q4, j = (idx - c * Q4) * 4;
+                    if (j < nv) fbbev_store4<ST>(obase + c * cstride + j, zero);
+                }
             }
         } else {
             for (int idx = tid; idx < CC * Q8; idx += NT) {
@@ -593,12 +626,31 @@ k_pool_fwd_dense2(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_b
     if constexpr (DIAG == 3) return;                         // (the LDS tile writes keep the gathers alive)
 
     if constexpr (OT == 0) {
-        for (int idx = tid; idx < n4; idx += NT) {
-            const int c = idx / Q4, j = (idx - c * Q4) * 4;
-            if (j < nv) {
-                fbbev_v4f val = *reinterpret_cast<const fbbev_v4f*>(tile + c * LD + j);
-                if (ab) val += *reinterpret_cast<const fbbev_v4f*>(ab + (long long)c * YX + j);
-                fbbev_store4<ST>(obase + c * cstride + j, val);
+        if (ab) {                                                                    // uniform; batches as in the empty-tile branch
+            constexpr int NB = 5;
+            for (int idx0 = tid; idx0 < n4; idx0 += NT * NB) {
+                fbbev_v4f av[NB];
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const int idx = idx0 + NT * u < n4 ? idx0 + NT * u : idx0;
+                    const int c = idx / Q4, j = (idx - c * Q4) * 4;
+                    av[u] = *reinterpret_cast<const fbbev_v4f*>(ab + (long long)c * YX + (j < nv ? j : 0));
+                }
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const int idx = idx0 + NT * u;
+                    const int c = idx / Q4, j = (idx - c * Q4) * 4;
+                    if (idx < n4 && j < nv) {
+                        fbbev_v4f val = *reinterpret_cast<const fbbev_v4f*>(tile + c * LD + j);
+                        val += av[u];
+                        fbbev_store4<ST>(obase + c * cstride + j, val);
+                    }
+                }
+            }
+        } else {
+            for (int idx = tid; idx < n4; idx += NT) {
+                const int c = idx / Q4, j = (idx - c * Q4) * 4;
+                if (j < nv) fbbev_store4<ST>(obase + c * cstride + j, *reinterpret_cast<const fbbev_v4f*>(tile + c * LD + j));
             }
         }
     } else if constexpr (T16) {
