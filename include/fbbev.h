@@ -353,7 +353,8 @@ int fbbev_msda_bwd_ws(const float* value, const int64_t* spatial_shapes, const i
  *   -- bevformer_utils/bevformer_encoder.py:91-120 (3 batched inverses + 3 broadcast matmuls).
  * xs (X), ys (Y), zs (Za): voxel-centre axes of get_reference_points '3d' (:66-75); camera tensors as in
  * fbbev_lidar_coor; ogfH/ogfW = data_config['input_size'].  Outputs: ref_cam (N,B,Y*X,Za,2) normalised
- * pixel coordinates, mask (N,B,Y*X,Za) bool, qdepth (N,B,Y*X,Za) camera-frame depth. */
+ * pixel coordinates, mask (N,B,Y*X,Za) bool, qdepth (N,B,Y*X,Za) camera-frame depth.  ref_cam 8-byte aligned (a point's (u, v) is
+ * one store), FBBEV_E_UNSUPPORTED otherwise. */
 int fbbev_point_sampling(const float* xs, const float* ys, const float* zs, const float* rots,
                          const float* trans, const float* intrins, const float* post_rots,
                          const float* post_trans, const float* bda, int B, int N, int Y, int X, int Za,
@@ -434,7 +435,9 @@ int fbbev_da_cross_attn_fwd_zt(const float* value, const int64_t* spatial_shapes
  *     sampling_offsets.weight (M*L*P*2, E) / attention_weights.weight (M*L*P, E) in the MODULE's row order, + fp32 biases;
  *   - a workgroup = the M heads of an 8 x 8 patch of the BEV grid (Q = bev_h x bev_w, bev_w required), a wave = one head.
  * Supported: M = 8, Dh in {8, 10}, P = 8, Za = 4, every level >= 2 tokens wide (`min_level_width`: the caller's host-side
- * value), LDS budget (fbbev_da_cross_attn_fused_supported); FBBEV_E_UNSUPPORTED otherwise.  Result: the reference's sum in
+ * value), Ncam <= 32 (a lane's hit flags are a bit mask), S < 2^24 tokens per image (24-bit offset multiplies), LDS budget
+ * (fbbev_da_cross_attn_fused_supported); query / addend rows, fragments and offsets_bias 16-byte aligned, planes / slots 8-byte;
+ * FBBEV_E_UNSUPPORTED otherwise.  Result: the reference's sum in
  * (level, camera, point) order -- equal to fbbev_da_cross_attn_fwd up to fp32 re-association and the projection arithmetic. */
 int fbbev_da_cross_attn_fused_supported(int B, int Ncam, int S, int M, int Dh, int L, int Q, int P, int Za, int bev_w);
 int fbbev_da_cross_attn_fused(const float* planes, const int64_t* spatial_shapes, const int64_t* level_start_index,
