@@ -163,6 +163,8 @@ __device__ __forceinline__ float fbbev_lds_ld_f32(const float* p) {
 __device__ __forceinline__ fbbev_v4f fbbev_gld_v4f(const float* p) { return *(const __attribute__((address_space(1))) fbbev_v4f*)p; }
 __device__ __forceinline__ int fbbev_lds_ld_i32(const int* p) { return *(const __attribute__((address_space(3))) int*)p; }
 // 16 bytes at an 8-byte aligned LDS address (two ds_read_b64 / one ds_read2_b64: head-plane tokens of 10 floats are 8-byte aligned)
+// high 32 bits of a 32 x 32-bit product (division by a run-time constant through its reciprocal)
+__device__ __forceinline__ unsigned int fbbev_umulhi(unsigned int a, unsigned int b) { return __umulhi(a, b); }
 // a * b + c with a, b < 2^24 as ONE full-rate v_mad_u32_u24 (the compiler turns the mul24 builtins back into the quarter-rate
 // v_mad_u64_u32 / v_mul_lo_u32 when it cannot prove the ranges).  _vsv: b wave-uniform (SGPR); _vks: b a compile-time inline
 // constant (<= 64), c wave-uniform

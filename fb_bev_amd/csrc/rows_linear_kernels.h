@@ -181,6 +181,22 @@ k_rows_linear_x3(const float* __restrict__ x, long long ldx, const unsigned shor
             continue;
         }
         // accumulator register r of tile (mt, t) = output 16 mt + 4 g + r of row j: four consecutive outputs, one 16-byte store
+        // head-plane output: a row's part of the element index ((bn * M) * S + token) * TS, the stride between two heads S * TS, 2^32 / TS
+        long long row_at[NT];
+        long long head_stride = 0;
+        unsigned int ts_rcp = 0;
+        if (plane_S > 0) {                                                                // uniform
+            const int TS = plane_TS & 0xffff;
+            const int Mh = O / TS;
+            head_stride = (long long)plane_S * TS;
+            ts_rcp = 0xffffffffu / (unsigned int)TS + 1u;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const long long r = r0 + 16 * t + j;
+                const long long bn = r / plane_S, tok = r - bn * plane_S;
+                row_at[t] = (bn * Mh * plane_S + tok) * TS;
+            }
+        }
         fbbev_v4f pbias[NT >= 2 ? 8 : 1];                                                 // (requested together: see the LayerNorm epilogue;
         if constexpr (NT >= 2) {                                                          //  the 168-register NT = 1 build has no room for them)
 #pragma unroll
@@ -206,13 +222,13 @@ k_rows_linear_x3(const float* __restrict__ x, long long ldx, const unsigned shor
                     // element (r, o) goes to out[((bn * M + o / TS) * S + token) * TS + o % TS], M = O / TS.  TS is even, so a
                     // channel pair never straddles two heads: two 8-byte stores.  Bits 16.. of plane_TS (round 5): 16-bit planes
                     // (1 bf16, 2 fp16; one nearest-even rounding of the fp32 result) -- a channel pair is one 4-byte store
+                    // (round 5: the divisions by TS go through its reciprocal -- exact for o < 2^16 -- and the row's part of the address is
+                    // formed once per row: as written first, ~50 integer instructions per 8-byte store made this epilogue longer than the GEMM)
                     const int TS = plane_TS & 0xffff, pet = plane_TS >> 16;
-                    const long long bn = r / plane_S, tok = r - bn * plane_S;
-                    const int Mh = O / TS;
 #pragma unroll
                     for (int e = 0; e < 4; e += 2) {
-                        const int hd = (o + e) / TS, ch = (o + e) - hd * TS;
-                        const long long at = ((bn * Mh + hd) * plane_S + tok) * TS + ch;
+                        const unsigned int hd = fbbev_umulhi((unsigned int)(o + e), ts_rcp), ch = (unsigned int)(o + e) - hd * (unsigned int)TS;
+                        const long long at = row_at[t] + (long long)hd * head_stride + ch;
                         if (pet) {
                             const unsigned int pk = pet == 1 ? fbbev_cvt_pk16<1>(v[e], v[e + 1]) : fbbev_cvt_pk16<2>(v[e], v[e + 1]);
                             *reinterpret_cast<unsigned int*>(reinterpret_cast<unsigned short*>(out) + at) = pk;

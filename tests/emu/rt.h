@@ -270,6 +270,7 @@ inline void fbbev_opaque(float&) {}
 inline float fbbev_lds_ld_f32(const float* p) { return *p; }
 inline int __builtin_amdgcn_readfirstlane(int v) { return v; }    // wave-uniform by construction where the kernels use it
 inline int fbbev_lds_ld_i32(const int* p) { return *p; }
+inline unsigned int fbbev_umulhi(unsigned int a, unsigned int b) { return (unsigned int)(((unsigned long long)a * b) >> 32); }
 inline unsigned int fbbev_mad_u24_vsv(unsigned int a, unsigned int b, unsigned int c) { return (unsigned int)((unsigned long long)(a & 0xffffffu) * (b & 0xffffffu)) + c; }
 template <unsigned int K>
 inline unsigned int fbbev_mad_u24_vks(unsigned int a, unsigned int c) { return (unsigned int)((unsigned long long)(a & 0xffffffu) * K) + c; }
