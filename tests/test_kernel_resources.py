@@ -173,3 +173,17 @@ def test_no_kernel_uses_flat_memory_instructions():
         if n:
             bad[m.group(1)] = n
     assert not bad, bad
+
+
+def test_row_kernels_stage_their_weights_in_batches():
+    """Round 5 (profiles/r05_exp_weight_staging.md): a global -> LDS copy written as a plain loop compiles to load, s_waitcnt vmcnt(0),
+    store per piece -- one memory round trip per iteration; the tail + FFN kernel spent two thirds of its time in 55 of them.  The
+    staging now requests a batch into registers first: in the default (PRE) instantiation only the two loops of the rare wide-hidden
+    path (H > 1024) may still wait for a single load, and k_rows_linear_x3's staging loop carries batches of at least three loads."""
+    import isa_chains
+    from fb_bev_amd import build
+    c = isa_chains.chains(build.build())
+    pre = [v for k, v in c.items() if 'k_rows_ffn_x3ILi3ELi5ELb1ELi32ELb1E' in k]
+    assert pre and len(pre[0]) <= 2 and all(lds <= 1 for _, _, lds in pre[0]), pre
+    lin = [v for k, v in c.items() if 'k_rows_linear_x3ILi2ELb0E' in k]
+    assert lin and all(loads >= 3 or lds <= 1 for _, loads, lds in lin[0]), lin
