@@ -100,6 +100,8 @@ class X3Weights:
                 w, b = (w_src, b_src) if transform is None else transform(w_src, b_src)
                 w = w.detach().float().contiguous()
                 self.w, self.b = w, None if b is None else b.detach().float().contiguous()
+                if self.b is not None and self.b.data_ptr() % 16 != 0:      # a view into a flat parameter buffer: the kernels read the
+                    self.b = self.b.clone()                                  # bias in 16-byte pieces (round 5), a private copy is aligned
                 self.frag = _capi.rows_linear_x3_fragments(w)
             self.key = key
         return self
