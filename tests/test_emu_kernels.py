@@ -1442,7 +1442,9 @@ def test_one_kernel_da_cross_attention_emulated():
     cases = ((21, dict(B=1, Q=8 * 8, shapes=((6, 9),)), 8),                                  # one full patch, one level
              (22, dict(B=2, Q=5 * 11, shapes=((16, 44), (8, 22))), 11),                       # partial patches in x and y
              (23, dict(B=1, Q=9 * 8, shapes=((5, 7), (9, 6), (3, 4), (2, 2))), 8),            # 4 levels (LP = 32), a 2-wide level
-             (25, dict(B=1, Q=8 * 8, shapes=((5, 7), (4, 6), (3, 4))), 8))                    # 3 levels: a head's logits straddle MFMA tiles
+             (25, dict(B=1, Q=8 * 8, shapes=((5, 7), (4, 6), (3, 4))), 8),                    # 3 levels: a head's logits straddle MFMA tiles
+             (26, dict(B=1, N=3, Q=8 * 8, shapes=((6, 9), (3, 4))), 8),                       # fewer records than threads: the hit-flag batches' clamps
+             (27, dict(B=2, N=9, Q=5 * 11, shapes=((6, 9), (3, 4))), 11))                     # nine cameras: hit masks beyond a byte, 2.25 flag batches
     import os
     for seed, kw, bev_w in cases:
         args, exp, ex = _da_case(seed, E=80, M=8, P=8, DC=20, extras=True, **kw)
