@@ -1534,7 +1534,12 @@ static int da_cross_attn_fused_impl(const float* planes, const int64_t* spatial_
     const size_t lds = fbbev_daf_lds_bytes(E, hw, Ncam, stage_floats);
     if (lds > 160 * 1024) return FBBEV_E_UNSUPPORTED;
     static const bool pre_off = [] { const char* e = getenv("FBBEV_DA_FUSED_PRE"); return e && atoi(e) == 0; }();   // A/B knob, read once
-    static const int diag = [] { const char* e = getenv("FBBEV_DA_FUSED_DIAG"); return e ? (atoi(e) & 63) : 0; }();   // timing diagnostics (wrong results), read once
+    static const int diag = [] {                                                         // timing diagnostics (wrong results), read once
+        const char* e = getenv("FBBEV_DA_FUSED_DIAG");
+        const int v = e ? (atoi(e) & 63) : 0;
+        if (v) fprintf(stderr, "libfbbev_hip: FBBEV_DA_FUSED_DIAG=%d -- fbbev_da_cross_attn_fused runs its timing-diagnostic build: RESULTS ARE WRONG BY DESIGN\n", v);
+        return v;
+    }();
     const int stage_arg = stage_floats | (pre_off ? 0x40000000 : 0) | (diag << 24);
 #define FBBEV_DA_FUSED(DH_, NP_, HW_) FBBEV_DA_FUSED3(DH_, NP_, HW_, false, 0)
 #define FBBEV_DA_FUSED2(DH_, NP_, HW_, OP_) FBBEV_DA_FUSED3(DH_, NP_, HW_, OP_, 0)
