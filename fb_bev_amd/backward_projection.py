@@ -168,6 +168,10 @@ class FFN(nn.Module):
         self.add_identity = add_identity
         self.embed_dims = embed_dims
 
+    def _has_live_dropout(self):
+        """some Dropout of this FFN has p > 0 (it acts whenever the module is in training mode, grad or no grad)"""
+        return any(isinstance(l, nn.Dropout) and l.p > 0 for l in self.layers.modules())
+
     def _one_kernel(self, x, identity, defer, norm, real):
         """inference, the encoder's shape (Linear + ReLU, Linear; in <= 96, hidden % 64 == 0, out <= 80): both GEMMs, the ReLU, the
         residual and -- when the layer hands it over -- the following LayerNorm in ONE kernel (fbbev_rows_ffn_x3): the hidden rows stay
@@ -209,6 +213,9 @@ class FFN(nn.Module):
     def fused_tail_spec(self, E):
         """(W1 fragments, W2 fragments, hidden width) when this FFN is the shape fbbev_rows_tail_ffn_x3 runs behind an attention
         block's tail -- Linear(E, H) + ReLU, Linear(H, E), add_identity, H % 64 == 0, E % 16 == 0, E <= 80 -- else None."""
+        if self.training and self._has_live_dropout():
+            # ADVICE r5: train() + no_grad() with ffn_drop > 0 must keep the Dropout layers (FFN.forward keeps `self.layers` then)
+            return None
         real = [l for l in self.layers if not isinstance(l, nn.Dropout)]
         if not (FUSE_TAIL_FFN and FUSE_FFN and self.add_identity and len(real) == 2 and isinstance(real[0], nn.Sequential)
                 and isinstance(real[0][0], Linear) and isinstance(real[0][1], nn.ReLU) and isinstance(real[1], Linear)):
@@ -935,6 +942,16 @@ class BEVFormerEncoderLayer(nn.Module):
     def forward(self, query, key=None, value=None, bev_pos=None, ref_2d=None, ref_3d=None, bev_h=None, bev_w=None,
                 reference_points_cam=None, spatial_shapes=None, level_start_index=None, bev_mask=None,
                 bev_query_depth=None, per_cam_mask_list=None, pred_img_depth=None, key_pos=None, **kwargs):
+        if torch.is_grad_enabled() and query.is_cuda and value is not None and value.dim() == 4 and pred_img_depth is not None:
+            # training (round 6): the whole layer as ONE autograd node on the inference kernels (train_path.EncoderLayerFn)
+            from . import train_path as TP
+            ncam, S_, bs_, E_ = value.shape
+            rows = value.permute(2, 0, 1, 3).reshape(bs_ * ncam, S_, E_)
+            if (TP.TRAIN_FUSED and rows.is_contiguous() and reference_points_cam is not None and bev_pos is not None and
+                    TP.layer_supported(self, query, bev_pos, rows, pred_img_depth, reference_points_cam, spatial_shapes, bev_h, bev_w,
+                                       bev_mask)):
+                return TP.run_layer(self, query, bev_pos, rows, pred_img_depth, ref_2d, reference_points_cam, per_cam_mask_list,
+                                    bev_query_depth, spatial_shapes, level_start_index, bev_h, bev_w)
         ni = ai = fi = 0
         identity = query
         ops = self.operation_order
@@ -1109,6 +1126,12 @@ class BEVFormer(nn.Module):
         return (self.fused_tokens and f0.is_cuda and f0.dtype == torch.float32 and not needs_grad and f0.shape[1] == self.num_cams
                 and all(f.shape[:3] == f0.shape[:3] for f in mlvl_feats))
 
+    def _tokens_trainable(self, mlvl_feats):
+        from . import train_path as TP
+        f0 = mlvl_feats[0]
+        return (TP.TRAIN_FUSED and torch.is_grad_enabled() and self.fused_tokens and f0.is_cuda and f0.dtype == torch.float32 and
+                f0.shape[1] == self.num_cams and all(f.shape[:3] == f0.shape[:3] and f.dtype == torch.float32 for f in mlvl_feats))
+
     def _token_rows(self, mlvl_feats, shapes):
         """(bs * num_cam, sum HW, C) camera-token rows: feat.flatten(3).permute + cams_embeds + cat + the rebatch permute of the
         reference (bevformer.py:95-117, spatial_cross_attention_depth.py:151) in one transposing launch"""
@@ -1146,6 +1169,13 @@ class BEVFormer(nn.Module):
             if rows is None:
                 rows = self._token_rows(mlvl_feats, shapes)
             feat_flatten = rows.view(bs, ncam, S, c).permute(1, 0, 2, 3)            # (num_cam, bs, sum HW, C)
+        elif self._tokens_trainable(mlvl_feats):
+            # training (round 6): the same one-launch token rows as a differentiable op (train_path.TokenRows)
+            from . import train_path as TP
+            bs, ncam, c = f0.shape[:3]
+            S = sum(h * w for h, w in shapes)
+            rows = TP.TokenRows.apply(self.cams_embeds, self.use_cams_embeds, *mlvl_feats)
+            feat_flatten = rows.view(bs, ncam, S, c).permute(1, 0, 2, 3)
         else:
             feats = []
             for feat in mlvl_feats:
@@ -1255,8 +1285,13 @@ class BackwardProjection(nn.Module):
         # contiguous (bs,Q,C) tokens (the Linear layers then take them without a copy); same sums element for element
         fast = (lss_bev is not None and lss_bev.is_cuda and lss_bev.dtype == torch.float32 and
                 not (torch.is_grad_enabled() and (lss_bev.requires_grad or self.bev_embedding.weight.requires_grad)))
+        from . import train_path as TP
+        train_fast = (not fast and TP.TRAIN_FUSED and torch.is_grad_enabled() and lss_bev is not None and lss_bev.is_cuda and
+                      lss_bev.dtype == torch.float32 and dtype == torch.float32)
         if lss_bev is not None:
-            if fast:                                                                    # LDS-tiled transposition kernel
+            if train_fast:                                     # the same transposing pass, differentiable (train_path.BevQueries)
+                bev_queries = TP.BevQueries.apply(lss_bev, self.bev_embedding.weight).permute(1, 0, 2)
+            elif fast:                                                                  # LDS-tiled transposition kernel
                 # + bev_embedding in the same pass: the same single fp32 add per element as below
                 tok = _capi.tokens_from_nchw(lss_bev.reshape(bs, lss_bev.shape[1], -1).contiguous(),
                                              torch.empty((bs, self.bev_h * self.bev_w, lss_bev.shape[1]),
@@ -1277,4 +1312,6 @@ class BackwardProjection(nn.Module):
                                pred_img_depth=pred_img_depth, prev_bev=None, bev_mask=bev_mask)
         if fast and bev.is_contiguous() and not bev.requires_grad:
             return _capi.transpose_last2(bev).view(bs, -1, self.bev_h, self.bev_w)
+        if train_fast and bev.is_cuda and bev.dtype == torch.float32 and bev.dim() == 3:
+            return TP.RowsToNCHW.apply(bev, self.bev_h, self.bev_w)
         return bev.permute(0, 2, 1).view(bs, -1, self.bev_h, self.bev_w).contiguous()

@@ -7,6 +7,7 @@ import torch.nn as nn
 
 from . import _capi
 from . import backward_projection as BP
+from . import train_path as TP
 from .view_transformer import LSSViewTransformerFunction3D
 
 
@@ -76,6 +77,16 @@ class FBViewTransform(nn.Module):
             refined = self.backward_projection(feats, img_metas, lss_bev=lss_mean, cam_params=cam_params, bev_mask=bev_mask,
                                                gt_bboxes_3d=None, pred_img_depth=depth, **kw)
             return fp.pooled_volume(parts, addend=refined)
+        if (self.write_once and self.backward_projection is not None and self.readd and needs_grad and TP.TRAIN_FUSED and
+                TP.write_once_supported(fp, context) and depth.dtype == torch.float32):
+            # training (round 6): the volume is written once here too -- Z-mean from the index tensors, the refined BEV added in the
+            # pooling store, ONE pooling backward with the mean's gradient folded in (train_path.WriteOnce)
+            parts = fp.pooling_inputs(cam_params, context, depth)
+            shared = {'defer': True}
+            lss_mean = TP.WriteOnce.ZMean.apply(context, depth, fp, parts, shared)
+            refined = self.backward_projection(feats, img_metas, lss_bev=lss_mean, cam_params=cam_params, bev_mask=bev_mask,
+                                               gt_bboxes_3d=None, pred_img_depth=depth)
+            return TP.WriteOnce.PoolAdd.apply(context, depth, refined, fp, parts, shared)
         both = fp.forward_with_zmean(cam_params, context, depth) if (self.backward_projection is not None and needs_grad and _ONE_OP) else None
         if both is not None:
             # training: the volume and its Z-mean leave the lift-splat as ONE differentiable op -- the mean's gradient is folded
