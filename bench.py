@@ -84,6 +84,8 @@ def parse():
     ap.add_argument('--no-fb-projection', action='store_true',
                     help='forward mode, N=1: skip the extra `fb_projection` leg (BASELINE configs[2]: forward + backward projection)')
     ap.add_argument('--fb-steps', type=int, default=50, help='timed steps of the fb_projection leg')
+    ap.add_argument('--no-fb-train', action='store_true',
+                    help='forward mode, N=1: skip the extra `fb_projection_train` leg (forward + backward of the path at configs[2] shapes)')
     ap.add_argument('--mode', choices=['forward', 'train'], default='forward')
     ap.add_argument('--sync-bn', action='store_true', help="train mode: cross-rank statistics for the config's SyncBN layers "
                     '(SURVEY 8e: off for the headline, the delta is reported separately)')
@@ -360,6 +362,26 @@ def fb_projection_leg(dev, steps, warmup, cpu_seconds, with_cpu=True):
             del gr
         except Exception as e:
             graph_ms = f'{type(e).__name__}: {e}'[:160]
+        # A/B: the same step with every row-wise layer on the vendor fp32 GEMM (FBBEV_ROWS_LINEAR=f32; this also
+        # takes the round-3 attention kernels, whose projections are separate GEMMs)
+        f32_ms = None
+        try:
+            from fb_bev_amd import rows_linear as _RLmod
+            was = _RLmod.X3
+            _RLmod.X3 = False
+            try:
+                for _ in range(3):
+                    m(cam, ctx, depth, mlvl_feats=mlvl)
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                for _ in range(steps):
+                    m(cam, ctx, depth, mlvl_feats=mlvl)
+                torch.cuda.synchronize(dev)
+                f32_ms = 1e3 * (time.perf_counter() - t1) / steps
+            finally:
+                _RLmod.X3 = was
+        except Exception as e:
+            f32_ms = f'{type(e).__name__}: {e}'[:160]
         S_tok = sum(h * w for h, w in shapes)
         Za = 4
         DC, Hd, Wd = depth.shape[2], depth.shape[3], depth.shape[4]
@@ -371,8 +393,9 @@ def fb_projection_leg(dev, steps, warmup, cpu_seconds, with_cpu=True):
         out = {
             'what': 'BASELINE configs[2] (scope S3 of SURVEY 8d): forward projection + backward projection + re-add, 1 x MI355X',
             'value': B * steps / elapsed, 'unit': 'samples/s', 'ms_per_step': ms, 'steps': steps,
-            'step_gpu_ms_p10_p50_p90': [pct(0.1), pct(0.5), pct(0.9)], 'dtype': 'f32', 'data': 'synthetic',
-            'hipgraph_replay_ms_per_step': graph_ms,
+            'step_gpu_ms_p10_p50_p90': [pct(0.1), pct(0.5), pct(0.9)],
+            'dtype': 'f32 storage/accumulate, bf16x3 split products in the row-wise layers (fp32-grade, ~1e-5 relative; FBBEV_ROWS_LINEAR=f32: vendor fp32 GEMMs)',
+            'data': 'synthetic', 'hipgraph_replay_ms_per_step': graph_ms, 'fp32_gemm_route_ms': f32_ms,
             'config': {'workload': f'FB-OCC forward + backward projection, BASELINE configs[2]: 6x{pc.input_size[0]}x{pc.input_size[1]} in, D={DC}, C={E}, '
                                    f'grid {X}x{Y}x{Z}, {Y}x{X} BEV queries, {levels} attention levels '
                                    f'{"/".join(f"{h}x{w}" for h, w in shapes)}, 8 points, 4 Z anchors, 1 encoder layer; indices rebuilt every step',
@@ -415,6 +438,159 @@ def fb_projection_leg(dev, steps, warmup, cpu_seconds, with_cpu=True):
         state = {k: v.detach().cpu() for k, v in mb.backward_projection.state_dict().items()}
         del mb
         out['cpu_baseline'] = cpu_baseline_fb(pcb, levels, state, gcbb, cfgb['depth_bound'], shapes, cpu_seconds)
+        out['gpu_over_cpu'] = out['value'] / out['cpu_baseline']['value']
+    return out
+
+
+def cpu_baseline_fb_train(pc, levels, state, gcb, dbound, mlvl_shapes, seconds):
+    """CPU baseline of the path's TRAINING step (BASELINE configs[2] / [3] scope): the oracle restatement of cpu_baseline_fb under
+    torch CPU autograd, one sample per pass -- forward as there, then backward from an upstream gradient in the output's shape to
+    depth, context, the pyramid levels and every parameter of the backward projection."""
+    import torch
+    from fb_bev_amd import synthetic as S
+    from oracle import backward_projection_oracle as BO, oracle as O
+    ncpu = os.cpu_count() or 1
+    torch.set_num_threads(min(32, ncpu))
+    ovt = O.ViewTransformerOracle(pc.grid_config, pc.input_size, pc.downsample)
+    cam = S.camera_rig(pc, 1, seed=0, bda_aug=True)
+    depth0, ctx0 = S.depth_and_context(pc, 1, seed=0)
+    g = torch.Generator().manual_seed(5)
+    feats0 = [torch.randn(1, pc.n_cams, pc.channels, h, w, generator=g) for h, w in mlvl_shapes]
+    X, Y, Z = pc.grid_xyz
+    shape = ovt.bev_feat_shape(1, pc.channels)
+    gout = torch.randn(1, pc.channels, Y, X, Z, generator=torch.Generator().manual_seed(11))
+
+    def one():
+        P = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in state.items()}
+        depth, ctx = depth0.clone().requires_grad_(), ctx0.clone().requires_grad_()
+        feats = [ctx] + [f.clone().requires_grad_() for f in feats0[1:]]
+        with torch.no_grad():
+            rb, rd, rf, st, ln = ovt.voxel_pooling_prepare_v2(ovt.get_lidar_coor(*cam))
+        vol = O.bev_pool_v2_torch(depth, ctx.permute(0, 1, 3, 4, 2).contiguous(), rd, rf, rb, shape).permute(0, 1, 3, 4, 2)
+        refined = BO.backward_projection(P, feats, vol.mean(-1), cam, depth, Y, X, gcb, pc.input_size, dbound,
+                                         inverse=O.inv3x3_closed_form)
+        (refined[..., None] + vol).backward(gout)
+        return depth.grad
+    one()
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        one()
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds or n >= 50:
+            break
+    return {'value': n / dt, 'unit': 'samples/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'{n} x 1-sample forward+backward passes of the same scope in {dt:.1f}s on {torch.get_num_threads()} of {ncpu} hw threads: '
+                      f'the oracle (forward projection by torch CPU ops, oracle/backward_projection_oracle.py, {levels} levels, {Y}x{X} '
+                      f'queries, re-add) under torch CPU autograd'}
+
+
+def fb_projection_train_leg(dev, steps, warmup, cpu_seconds, with_cpu=True):
+    """The path's TRAINING step on one GPU, reported beside `value` (never as it): forward + backward of FBViewTransform (forward
+    projection, Z-mean, backward projection with both deformable attentions, FFN, LayerNorms, re-add) at BASELINE configs[2] shapes,
+    B = 4 -- the per-GPU share of configs[3]'s batch 32 on 8 GPUs -- with the upstream gradient handed over in the output's own layout
+    (what the voxel encoder's backward gives the path).  Gradients of depth, context, every pyramid level and every parameter are
+    produced; nothing is cached across steps.  Reference: bev_pool.py:40-80, bev_pool_cuda.cu:64-118,
+    multi_scale_deformable_attn_function.py:137-172, bevformer_encoder.py:206-377 under autograd.  `ms_per_step` = wall time of K
+    back-to-back steps between device synchronisations; p10/p50/p90 are HIP events on the launch stream; the DA backward (hit lists +
+    unit gradients + output-owned value-gradient planes) is bracketed by HIP events, its kernels split by a one-step roctracer profile."""
+    import torch
+    from fb_bev_amd import _capi, synthetic as S, train_path as TP
+    B, levels = 4, 4
+    d = S.fb_path_step('BL2', B, levels, dev)
+    pc, step, shapes = d['pc'], d['step'], d['shapes']
+    X, Y, Z = pc.grid_xyz
+    Q, E, ncam = X * Y, pc.channels, pc.n_cams
+    for _ in range(max(3, warmup)):
+        step()
+    torch.cuda.synchronize(dev)
+    da_ev = []
+    real = _capi.da_cross_attn_bwd
+
+    def timed(*a, **k):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = real(*a, **k)
+        e1.record()
+        da_ev.append((e0, e1))
+        return r
+    sev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    _capi.da_cross_attn_bwd = timed
+    try:
+        with no_gc():
+            t0 = time.perf_counter()
+            for i in range(steps):
+                sev[i][0].record()
+                step()
+                sev[i][1].record()
+            torch.cuda.synchronize(dev)
+            elapsed = time.perf_counter() - t0
+    finally:
+        _capi.da_cross_attn_bwd = real
+    step_ms = sorted(a.elapsed_time(b) for a, b in sev)
+    pct = lambda q: step_ms[min(len(step_ms) - 1, int(q * len(step_ms)))]  # noqa: E731
+    da_ms = sum(a.elapsed_time(b) for a, b in da_ev) / len(da_ev) if da_ev else None
+    # forward only (autograd graph recorded), same inputs
+    m, cam, ctx, depth, mlvl = d['model'], d['cam'], d['ctx'], d['depth'], d['mlvl']
+    torch.cuda.synchronize(dev)
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        o = m(cam, ctx, depth, mlvl_feats=mlvl)
+    torch.cuda.synchronize(dev)
+    fwd_ms = 1e3 * (time.perf_counter() - t1) / steps
+    del o
+    kernels, launches = {}, None
+    try:
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            step()
+            torch.cuda.synchronize(dev)
+        ka = [e for e in prof.key_averages() if e.device_time_total > 0]
+        launches = sum(e.count for e in ka)
+        for e in ka:
+            for key in ('k_da_bwd_scatter_owned', 'k_da_bwd_unit_planes', 'k_da_bwd_hitlist', 'k_msda_bwd_scatter', 'k_msda_bwd_unit',
+                        'k_da_cross_attn_fused', 'k_rows_linear_x3', 'k_rows_wgrad_x3', 'k_pool_bwd_rows', 'Cijk_'):
+                if key in e.key:
+                    kernels[key] = kernels.get(key, 0.0) + e.device_time_total / 1e3
+    except Exception:
+        pass
+    S_tok = sum(h * w for h, w in shapes)
+    L, P, M, HS = levels, 8, 8, 12
+    # algorithmic bytes of k_da_bwd_scatter_owned (DESIGN 3.3): hit records (64 B per (camera, query) hit slot), the upstream slot
+    # gradient, the offsets / attention words of every unit, the value gradient written once
+    parts = {'hit_records': ncam * B * Q * 64, 'grad_slots_read': 4 * B * Q * E, 'offsets_read': 4 * B * Q * M * L * P * 2,
+             'attention_read': 4 * B * Q * M * L * P, 'grad_value_written': 4 * B * ncam * S_tok * M * HS}
+    algo = sum(parts.values())
+    sc_ms = kernels.get('k_da_bwd_scatter_owned')
+    ms = 1e3 * elapsed / steps
+    out = {
+        'what': 'training step of the PATH (forward + backward of the forward-backward view transformation) at BASELINE configs[2] shapes, '
+                'B = 4 = the per-GPU share of configs[3]; upstream gradient handed over in the output layout; 1 x MI355X',
+        'value': B * steps / elapsed, 'unit': 'samples/s', 'ms_per_step': ms, 'steps': steps,
+        'step_gpu_ms_p10_p50_p90': [pct(0.1), pct(0.5), pct(0.9)], 'forward_ms_train_mode': fwd_ms,
+        'dtype': 'f32 storage/accumulate, bf16x3 split products in the row-wise layers (fp32-grade, ~1e-5 relative)', 'data': 'synthetic',
+        'route': 'one autograd node per encoder layer on the inference kernels (FBBEV_TRAIN_FUSED)' if TP.TRAIN_FUSED else 'composite autograd (FBBEV_TRAIN_FUSED=0)',
+        'config': {'workload': f'FB-OCC forward-backward view transformation, training step: 6x{pc.input_size[0]}x{pc.input_size[1]} in, '
+                               f'D={depth.shape[2]}, C={E}, grid {X}x{Y}x{Z}, {Y}x{X} BEV queries, {levels} attention levels '
+                               f'{"/".join(f"{h}x{w}" for h, w in shapes)}, 8 points, 4 Z anchors, 1 encoder layer; indices rebuilt every step; '
+                               f'gradients for depth, context, all pyramid levels and all parameters',
+                   'samples_per_gpu': B},
+        'da_backward_ms_hip_events': da_ms, 'kernel_ms_one_step_profile': kernels, 'launches_per_step': launches,
+        'roofline': {'kernel': 'k_da_bwd_scatter_owned', 'bound': 'hbm', 'achieved': (algo / (sc_ms * 1e-3) / 1e9) if sc_ms else None,
+                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': (algo / (sc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if sc_ms else None,
+                     'traffic': None, 'algorithmic_bytes_per_launch': algo, 'algorithmic_bytes_parts': parts, 'kernel_ms': sc_ms,
+                     'note': 'the value-gradient scatter is bound by its 64-bit LDS atomics (one ds_add_u64 per channel and corner) and '
+                             'the hit-list walk, not by HBM: counters in profiles/r06_*pmc_train*.json, DESIGN 3.3'},
+    }
+    del d, m, step
+    torch.cuda.empty_cache()
+    if with_cpu:
+        db = S.fb_path_step('BL2', 1, levels, dev, train=False)
+        state = {k: v.detach().cpu() for k, v in db['model'].backward_projection.state_dict().items()}
+        cfgb, gcbb, pcb = db['cfg'], db['gcb'], db['pc']
+        del db
+        out['cpu_baseline'] = cpu_baseline_fb_train(pcb, levels, state, gcbb, cfgb['depth_bound'], shapes, cpu_seconds)
         out['gpu_over_cpu'] = out['value'] / out['cpu_baseline']['value']
     return out
 
@@ -762,6 +938,17 @@ def run_forward(args):
         except Exception as e:                    # the headline line is printed regardless; the leg reports its own failure
             fb = {'error': f'{type(e).__name__}: {e}'[:300]}
 
+    # Extra leg (beside `value`, never as it): the path's TRAINING step (forward + backward) at the same shapes -- VERDICT r5 item 1
+    fbt = None
+    if world == 1 and rank == 0 and not args.no_fb_projection and not args.no_fb_train and cfg.name == 'BL2':
+        try:
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            fbt = fb_projection_train_leg(dev, min(args.fb_steps, 30), args.warmup, min(10.0, args.cpu_seconds), with_cpu=not args.no_cpu_baseline)
+        except Exception as e:
+            fbt = {'error': f'{type(e).__name__}: {e}'[:300]}
+
     if rank == 0:
         total = B * world * args.steps
         res = {
@@ -800,6 +987,8 @@ def run_forward(args):
             res['index_cache'] = cached
         if fb is not None:
             res['fb_projection'] = fb
+        if fbt is not None:
+            res['fb_projection_train'] = fbt
         if piped is not None:
             res['pipelined'] = piped
         if world == 1 and not args.no_cpu_baseline:

@@ -114,3 +114,58 @@ def depth_and_context(cfg: PathConfig, batch: int, seed: int = 0):
     g2 = torch.Generator().manual_seed(seed + 1)
     context = torch.randn(batch, cfg.n_cams, cfg.channels, H, W, generator=g2)
     return depth.contiguous(), context.contiguous()
+
+
+# ------------------------------------------------------------------------------------------------ the path's training step (round 6)
+PYRAMID = lambda H, W: [(H, W), (2 * H, 2 * W), (H // 2, W // 2), (H // 4, W // 4)]     # noqa: E731  level 0 = the depth net's level
+
+
+def fb_path_step(name, B, levels, dev, seed=0, feat_grad=True, train=True):
+    """FBViewTransform (forward projection + backward projection + re-add, fbocc.py:344-366) at a named workload with seeded inputs,
+    and `step()` = one forward + backward with the upstream gradient HANDED OVER in the output's own memory layout (what the voxel
+    encoder's backward gives the path in training; bench.py `fb_projection_train`, tools/train_path.py).  The sampling_offsets /
+    attention_weights heads are randomised (the reference init zeroes them: offsets / weights would not depend on the queries).
+    -> dict(pc, model, cam, depth, ctx, mlvl, step, leaves, names, gout)"""
+    from . import configs
+    from .fb_view_transform import FBViewTransform
+    pc = CONFIGS[name]
+    X, Y, Z = pc.grid_xyz
+    gcb = {'x': pc.grid_config['x'], 'y': pc.grid_config['y'], 'z': [-1, 5.4, 1.6]}
+    cfg = configs.fbocc_r50(bev_h=Y, bev_w=X, numC_Trans=pc.channels, input_size=pc.input_size, grid_config=pc.grid_config,
+                            grid_config_bevformer=gcb, depth_bound=tuple(pc.grid_config['depth']), downsample=pc.downsample,
+                            num_levels=levels)
+    torch.manual_seed(seed)
+    m = FBViewTransform(cfg['forward_projection'], cfg['backward_projection'])
+    with torch.no_grad():
+        for n_, p_ in m.named_parameters():
+            if 'sampling_offsets.weight' in n_ or 'attention_weights.weight' in n_:
+                p_.normal_(0, 0.05)
+    m = m.to(dev)
+    m = m.train() if train else m.eval()
+    cam = [t.to(dev) for t in camera_rig(pc, B, seed=0, bda_aug=True)]
+    depth, ctx = depth_and_context(pc, B, seed=0)
+    depth, ctx = depth.to(dev).requires_grad_(train), ctx.to(dev).requires_grad_(train)
+    mlvl, shapes = None, [tuple(ctx.shape[-2:])]
+    if levels > 1:
+        H, W = ctx.shape[-2:]
+        g = torch.Generator().manual_seed(5)
+        shapes = PYRAMID(H, W)[:levels]
+        mlvl = [torch.randn(B, pc.n_cams, pc.channels, h, w_, generator=g).to(dev).requires_grad_(train and feat_grad) for h, w_ in shapes]
+        mlvl[0] = ctx
+    with torch.no_grad():
+        out = m(cam, ctx, depth, mlvl_feats=mlvl)
+    w = torch.randn(B, pc.channels, Y, X, Z, generator=torch.Generator().manual_seed(11)).to(dev)
+    gout = torch.empty_strided(out.shape, out.stride(), dtype=out.dtype, device=dev).copy_(w)       # the output's own layout
+    del out, w
+    named = list(m.named_parameters())
+    leaves = [p for _, p in named] + [depth, ctx] + (list(mlvl[1:]) if mlvl else [])
+    names = [n for n, _ in named] + ['depth', 'ctx'] + [f'mlvl{i}' for i in range(1, len(mlvl or []))]
+
+    def step():
+        for t in leaves:
+            t.grad = None
+        o = m(cam, ctx, depth, mlvl_feats=mlvl)
+        o.backward(gout)
+        return o
+    return dict(pc=pc, cfg=cfg, gcb=gcb, model=m, cam=cam, depth=depth, ctx=ctx, mlvl=mlvl, shapes=shapes, step=step, leaves=leaves,
+                names=names, gout=gout)

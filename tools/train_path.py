@@ -16,54 +16,19 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from fb_bev_amd import configs, synthetic as S                      # noqa: E402
-from fb_bev_amd.fb_view_transform import FBViewTransform            # noqa: E402
+from fb_bev_amd import synthetic as S                               # noqa: E402
 
 
 def build(name, B, levels, dev, seed=0, feat_grad=True):
-    pc = S.CONFIGS[name]
-    X, Y, Z = pc.grid_xyz
-    gcb = {'x': pc.grid_config['x'], 'y': pc.grid_config['y'], 'z': [-1, 5.4, 1.6]}
-    cfg = configs.fbocc_r50(bev_h=Y, bev_w=X, numC_Trans=pc.channels, input_size=pc.input_size, grid_config=pc.grid_config,
-                            grid_config_bevformer=gcb, depth_bound=tuple(pc.grid_config['depth']), downsample=pc.downsample,
-                            num_levels=levels)
-    torch.manual_seed(seed)
-    m = FBViewTransform(cfg['forward_projection'], cfg['backward_projection'])
-    with torch.no_grad():      # the reference init zeroes these heads: offsets / weights would not depend on the queries
-        for n_, p_ in m.named_parameters():
-            if 'sampling_offsets.weight' in n_ or 'attention_weights.weight' in n_:
-                p_.normal_(0, 0.05)
-    m = m.to(dev).train()
-    cam = [t.to(dev) for t in S.camera_rig(pc, B, seed=0, bda_aug=True)]
-    depth, ctx = S.depth_and_context(pc, B, seed=0)
-    depth, ctx = depth.to(dev).requires_grad_(), ctx.to(dev).requires_grad_()
-    mlvl = None
-    if levels > 1:
-        H, W = ctx.shape[-2:]
-        g = torch.Generator().manual_seed(5)
-        shapes = [(H, W), (2 * H, 2 * W), (H // 2, W // 2), (H // 4, W // 4)][:levels]
-        mlvl = [torch.randn(B, pc.n_cams, pc.channels, h, w_, generator=g).to(dev).requires_grad_(feat_grad) for h, w_ in shapes]
-        mlvl[0] = ctx
-    return pc, m, cam, depth, ctx, mlvl
+    d = S.fb_path_step(name, B, levels, dev, seed=seed, feat_grad=feat_grad)
+    build.last = d
+    return d['pc'], d['model'], d['cam'], d['depth'], d['ctx'], d['mlvl']
 
 
 def make_step(m, cam, depth, ctx, mlvl, dev, pc, B):
-    X, Y, Z = pc.grid_xyz
-    with torch.no_grad():
-        out = m(cam, ctx, depth, mlvl_feats=mlvl)
-    g = torch.Generator().manual_seed(11)
-    w = torch.randn(B, pc.channels, Y, X, Z, generator=g).to(dev)
-    gout = torch.empty_strided(out.shape, out.stride(), dtype=out.dtype, device=dev).copy_(w)   # the output's own layout
-    del out, w
-    leaves = [p for p in m.parameters()] + [depth, ctx] + ([t for t in mlvl[1:]] if mlvl else [])
-
-    def step():
-        for t in leaves:
-            t.grad = None
-        o = m(cam, ctx, depth, mlvl_feats=mlvl)
-        o.backward(gout)
-        return o
-    return step, leaves, gout
+    d = build.last
+    assert d['model'] is m
+    return d['step'], d['leaves'], d['gout']
 
 
 def main():
