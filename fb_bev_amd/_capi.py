@@ -86,6 +86,8 @@ SIGNATURES = {
                               [c_void_p, c_void_p]),
     'fbbev_msda_self_fused_ln': (c_int, [c_void_p] * 3 + [c_int64, c_void_p, c_int64, c_int64] + [c_void_p] * 4 +
                                  [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_float] + [c_int] * 10 + [c_void_p, c_void_p]),
+    'fbbev_rows_wgrad_x3_ws_bytes': (c_size_t, [c_int64, c_int, c_int]),
+    'fbbev_rows_wgrad_x3': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'fbbev_layernorm_bwd_partials': (c_int, [c_int64]),
     'fbbev_layernorm_bwd': (c_int, [c_void_p] * 3 + [c_float, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     'fbbev_history_conv': (c_int, [c_void_p, c_int64] + [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -1191,6 +1193,33 @@ def layernorm_bwd(x, grad_out, weight, eps):
                                          _stream()), 'fbbev_layernorm_bwd')
     gwb = partial.sum(0)
     return grad_x, gwb[0], gwb[1]
+
+
+def rows_wgrad_x3(grad_out, x, bias=True):
+    """grad_out (R, O), x (R, I) f32 rows (unit column stride) -> (grad_weight (O, I), grad_bias (O) or None): fbbev_rows_wgrad_x3,
+    split-operand MFMA over the rows, fixed-order reduction of the per-workgroup partial results (bit-stable)."""
+    R, O = grad_out.shape
+    I = x.shape[1]
+    if x.shape[0] != R or grad_out.stride(1) != 1 or x.stride(1) != 1:
+        raise FbbevError('rows_wgrad_x3: grad_out (R, O) and x (R, I) rows with unit column stride')
+    need = lib().fbbev_rows_wgrad_x3_ws_bytes(R, I, O)
+    if need == 0:
+        raise FbbevError('rows_wgrad_x3: unsupported shape')
+    ws = torch.empty(need // 4, dtype=F32, device=x.device)
+    gw = torch.empty((O, I), dtype=F32, device=x.device)
+    gb = torch.empty((O,), dtype=F32, device=x.device) if bias else None
+    with _on(x):
+        _check(lib().fbbev_rows_wgrad_x3(_dev(grad_out, F32, 'grad_out', contiguous=False), grad_out.stride(0),
+                                         _dev(x, F32, 'x', contiguous=False), x.stride(0), R, I, O, _dev(gw, F32, 'grad_weight'),
+                                         _dev(gb, F32, 'grad_bias') if gb is not None else None, c_void_p(ws.data_ptr()), need, _stream()),
+               'fbbev_rows_wgrad_x3')
+    return gw, gb
+
+
+def rows_wgrad_x3_supported(grad_out, x):
+    return (grad_out.is_cuda and grad_out.dtype == F32 and x.dtype == F32 and grad_out.dim() == 2 and x.dim() == 2 and
+            grad_out.stride(1) == 1 and x.stride(1) == 1 and grad_out.stride(0) % 4 == 0 and x.stride(0) % 4 == 0 and
+            grad_out.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 and grad_out.shape[1] % 4 == 0 and x.shape[1] % 4 == 0)
 
 
 def conv3d_ndhwc(x, weight_fragments, bias, out, Cout, ksize=3, stride=1, pad=1, relu=False, residual=None, transposed=False):

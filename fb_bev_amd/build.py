@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libfbbev_hip.so')
-SOURCES = ['capi.hip']
+SOURCES = ['capi.hip', 'capi_train.hip']      # two translation units: the training-path entries recompile in seconds
 def _headers():
     """every header the translation unit can include: a header-only edit must trigger a rebuild (a hard-coded list
     here once went stale and a measurement was taken on an old binary)"""

@@ -22,14 +22,7 @@
 #include "conv3d_kernels.h"
 #include "../../include/fbbev.h"
 
-#define FBBEV_CHECK_LAUNCH()                      \
-    do {                                          \
-        int e_ = fbbev_rt_last_error();           \
-        if (e_ != 0) return e_;                   \
-    } while (0)
-
-static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
-static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+#include "capi_common.h"
 
 extern "C" int fbbev_version(void) { return 100; }
 
@@ -3237,3 +3230,9 @@ extern "C" int fbbev_blend_levels_ndhwc(const float* level0, const float* const*
     FBBEV_CHECK_LAUNCH();
     return 0;
 }
+
+// the training-path entries live in their own translation unit (capi_train.hip: a header-only edit there recompiles in seconds); the
+// CPU emulator build (tests/emu) is ONE translation unit and takes them from here
+#ifdef FBBEV_TEST_OVERRIDES
+#include "capi_train.hip"
+#endif

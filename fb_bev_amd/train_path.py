@@ -24,6 +24,7 @@ from . import rows_linear as _RL
 from .rows_linear import X3Weights
 
 TRAIN_FUSED = os.environ.get('FBBEV_TRAIN_FUSED', '1') != '0'
+WGRAD_X3 = os.environ.get('FBBEV_TRAIN_WGRAD', '1') != '0'
 ORDER = ('self_attn', 'norm', 'cross_attn', 'norm', 'ffn', 'norm')
 
 
@@ -305,12 +306,18 @@ class EncoderLayerFn(torch.autograd.Function):
         G = {}                                        # name -> [grad weight, grad bias]
 
         def wgrad(name, gy, x, post=None):
+            # grad_weight = gy^T x and grad_bias = column sums of gy in one split-K MFMA kernel + a fixed-order reduction
+            # (fbbev_rows_wgrad_x3); FBBEV_TRAIN_WGRAD=0: the split-K batched vendor GEMMs of rows_linear.py (A/B knob)
             gw = gb = None
-            if need[name][0]:
-                gw = _RL.weight_grad(gy, x)
-                gw = post(gw) if post is not None else gw
-            if need[name][1]:
-                gb = _RL.bias_grad(gy)
+            if WGRAD_X3 and need[name][0] and _capi.rows_wgrad_x3_supported(gy, x):
+                gw, gb = _capi.rows_wgrad_x3(gy, x, bias=need[name][1])
+            else:
+                if need[name][0]:
+                    gw = _RL.weight_grad(gy, x)
+                if need[name][1]:
+                    gb = _RL.bias_grad(gy)
+            if gw is not None and post is not None:
+                gw = post(gw)
             G[name] = [gw, gb]
 
         def ln_bwd(name, x, gy, w):

@@ -662,6 +662,19 @@ int fbbev_layernorm_bwd_partials(long long rows);
 int fbbev_layernorm_bwd(const float* x, const float* grad_out, const float* weight, float eps, long long rows, int C,
                         float* grad_x, float* partial, fbbev_stream_t stream);
 
+/* Weight and bias gradient of a row-wise linear layer y = x W^T + b (training of the backward projection: autograd's
+ * `grad_out.t().mm(x)` / `grad_out.sum(0)` behind every nn.Linear of bevformer_encoder.py:206-377 and
+ * spatial_cross_attention_depth.py:432-436,464 -- vendor fp32 GEMMs + ATen reductions in the reference):
+ *   grad_weight (out_features, in_features) = grad_out^T x,   grad_bias (out_features) = column sums of grad_out (NULL: skipped)
+ * for grad_out (rows, out_features) and x (rows, in_features), row strides in floats (0 = dense).  Arithmetic: the split-operand bf16
+ * MFMA of fbbev_rows_linear_x3 (~1e-5 relative), rows split over workgroups, partial results summed in a FIXED order (bit-identical
+ * run to run, no atomics) through `workspace` (fbbev_rows_wgrad_x3_ws_bytes bytes, 16-byte aligned).  in_features % 4 == 0,
+ * out_features % 4 == 0, strides % 4 == 0, 16-byte aligned pointers, else FBBEV_E_UNSUPPORTED (ws_bytes returns 0). */
+size_t fbbev_rows_wgrad_x3_ws_bytes(long long rows, int in_features, int out_features);
+int fbbev_rows_wgrad_x3(const float* grad_out, long long ld_grad, const float* x, long long ldx, long long rows, int in_features,
+                        int out_features, float* grad_weight, float* grad_bias, void* workspace, size_t workspace_bytes,
+                        fbbev_stream_t stream);
+
 /* Row-wise linear layer  out[r, :] = x[r, :] . W^T + bias (+ ReLU)  for the (B*Q, C) query rows of the backward projection
  * (inference): replaces the F.linear calls of spatial_cross_attention_depth.py:533-540 (sampling_offsets, attention_weights),
  * :494-500 (value_proj, output_proj) and the FFN of the encoder layer (mmcv FFN: Linear + ReLU + Linear) -- vendor fp32 GEMMs in

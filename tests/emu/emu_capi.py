@@ -632,3 +632,17 @@ def conv3d_k3s1_tiled_bf16(x, wfb, bias, Cout, relu=False, residual=None):
     code = lib().fbbev_conv3d_k3s1_tiled_bf16(p(x), c_void_p(wfb.data_ptr()), p(bias), p(residual) if residual is not None else None,
                                               B, D, H, W, Cin, Cout, 1 if relu else 0, p(out), None)
     return code, out
+
+
+def rows_wgrad_x3(grad_out, x, with_bias=True):
+    """fbbev_rows_wgrad_x3 on CPU tensors (row strides taken from the views) -> (code, grad_weight, grad_bias)"""
+    R, O = grad_out.shape
+    I = x.shape[1]
+    need = lib().fbbev_rows_wgrad_x3_ws_bytes(R, I, O)
+    ws = torch.full((need // 4 + 4,), float('nan'))
+    off = ((-ws.data_ptr()) % 16) // 4
+    gw = torch.full((O, I), float('nan'))
+    gb = torch.full((O,), float('nan')) if with_bias else None
+    code = lib().fbbev_rows_wgrad_x3(c_void_p(grad_out.data_ptr()), grad_out.stride(0), c_void_p(x.data_ptr()), x.stride(0), R, I, O,
+                                     p(gw), p(gb) if gb is not None else None, c_void_p(ws.data_ptr() + 4 * off), need, None)
+    return code, gw, gb

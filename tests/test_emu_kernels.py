@@ -754,6 +754,37 @@ def test_rows_linear_with_periodic_addend_emulated():
     assert torch.equal(fused, plain)
 
 
+@pytest.mark.parametrize('R,I,O', [(300, 80, 80), (1000, 80, 512), (77, 80, 96), (257, 320, 80), (64, 80, 32), (33, 8, 4), (40, 132, 260)])
+def test_rows_wgrad_split_operand_emulated(R, I, O, monkeypatch):
+    """fbbev_rows_wgrad_x3 (grad_weight = grad_out^T x, grad_bias = column sums: autograd's backward of nn.Linear) against float64 for
+    the backward projection's layer shapes (80 x 80, 512 x 80, 96 x 80, the FFN's 80 x 320 with three input chunks), row counts that
+    are not multiples of the 32-row step, widths that are not multiples of a 16-column tile, strided rows, three K splits (the last one
+    partial); a second run is bit-identical, and the bias gradient can be skipped."""
+    g = torch.Generator().manual_seed(R * 7 + I + O)
+    gys = torch.randn(R, O + 4, generator=g)
+    xs = torch.randn(R, I + 8, generator=g) * 2
+    gy, x = gys[:, :O], xs[:, :I]
+    monkeypatch.setenv('FBBEV_WGRAD_SPLITS', '3')
+    code, gw, gb = E.rows_wgrad_x3(gy, x)
+    assert code == 0 and not torch.isnan(gw).any() and not torch.isnan(gb).any()
+    ew, eb = gy.double().t() @ x.double(), gy.double().sum(0)
+    assert (gw.double() - ew).abs().max() <= 2e-5 * ew.abs().max()
+    assert (gb.double() - eb).abs().max() <= 1e-5 * max(eb.abs().max().item(), 1.0)
+    # plain bf16 operands would be far away
+    e1 = gy.bfloat16().double().t() @ x.bfloat16().double()
+    assert (gw.double() - ew).abs().max() * 30 < (e1 - ew).abs().max()
+    code2, gw2, gb2 = E.rows_wgrad_x3(gy, x)
+    assert code2 == 0 and torch.equal(gw, gw2) and torch.equal(gb, gb2)
+    code3, gw3, gb3 = E.rows_wgrad_x3(gy, x, with_bias=False)
+    assert code3 == 0 and gb3 is None and torch.equal(gw, gw3)
+
+
+def test_rows_wgrad_rejects_unsupported_shapes():
+    assert E.lib().fbbev_rows_wgrad_x3_ws_bytes(100, 6, 8) == 0            # in_features % 4 != 0
+    assert E.lib().fbbev_rows_wgrad_x3_ws_bytes(100, 8, 6) == 0
+    assert E.lib().fbbev_rows_wgrad_x3_ws_bytes(100, 80, 80) > 0
+
+
 def test_rows_linear_split_operand_rejects_unsupported_shapes():
     x = torch.randn(10, 12); w = torch.randn(8, 12)
     assert E.rows_linear_x3(x, w, None)[0] == -2                       # in_features % 8 != 0
