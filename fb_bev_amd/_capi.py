@@ -87,7 +87,12 @@ SIGNATURES = {
     'fbbev_msda_self_fused_ln': (c_int, [c_void_p] * 3 + [c_int64, c_void_p, c_int64, c_int64] + [c_void_p] * 4 +
                                  [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_float] + [c_int] * 10 + [c_void_p, c_void_p]),
     'fbbev_rows_wgrad_x3_ws_bytes': (c_size_t, [c_int64, c_int, c_int]),
-    'fbbev_rows_wgrad_x3': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'fbbev_rows_wgrad_x3': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p,
+                                    c_void_p, c_size_t, c_void_p]),
+    'fbbev_rows_linear_x3_train': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
+                                           c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
+    'fbbev_sum_leading': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p]),
+    'fbbev_sum_partials': (c_int, [c_void_p, c_int, c_int64, c_void_p, c_void_p]),
     'fbbev_layernorm_bwd_partials': (c_int, [c_int64]),
     'fbbev_layernorm_bwd': (c_int, [c_void_p] * 3 + [c_float, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     'fbbev_history_conv': (c_int, [c_void_p, c_int64] + [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -1191,11 +1196,50 @@ def layernorm_bwd(x, grad_out, weight, eps):
         _check(lib().fbbev_layernorm_bwd(_dev(x, F32, 'x'), _dev(grad_out, F32, 'grad_out'), _dev(weight, F32, 'weight'),
                                          float(eps), rows, C, _dev(grad_x, F32, 'grad_x'), _dev(partial, F32, 'partial'),
                                          _stream()), 'fbbev_layernorm_bwd')
-    gwb = partial.sum(0)
+    gwb = torch.empty((2, C), dtype=F32, device=x.device)
+    with _on(x):          # fixed-order sum of the partial rows (ATen's dim-0 reduction of this shape is one latency chain per column)
+        _check(lib().fbbev_sum_partials(_dev(partial, F32, 'partial'), n, 2 * C, _dev(gwb, F32, 'out'), _stream()), 'fbbev_sum_partials')
     return grad_x, gwb[0], gwb[1]
 
 
-def rows_wgrad_x3(grad_out, x, bias=True):
+def rows_linear_x3_train(x, fragments, bias, out_features, relu=False, addend=None, residual=None, mask=None, out=None):
+    """fbbev_rows_linear_x3_train: out = ((x [+ addend[r % P]]) W^T + bias) [ReLU]) * [mask > 0] + residual; residual may be `out`."""
+    R, I = x.shape
+    if x.stride(1) != 1:
+        raise FbbevError('rows_linear_x3_train: rows must have unit column stride')
+    if out is None:
+        out = torch.empty((R, out_features), dtype=F32, device=x.device)
+    for t, nm in ((residual, 'residual'), (mask, 'mask'), (out, 'out')):
+        if t is not None and (tuple(t.shape) != (R, out_features) or t.stride(1) != 1):
+            raise FbbevError(f'rows_linear_x3_train: {nm} must be (rows, out_features) with unit column stride')
+    a_ptr, a_ld, a_per = None, 0, 1
+    if addend is not None:
+        if addend.dim() != 2 or addend.shape[1] != I or addend.stride(1) != 1 or R % addend.shape[0] != 0:
+            raise FbbevError('rows_linear_x3_train: addend must be (P, in_features) rows with rows % P == 0')
+        a_ptr, a_ld, a_per = _dev(addend, F32, 'addend', contiguous=False), addend.stride(0), addend.shape[0]
+    with _on(x):
+        _check(lib().fbbev_rows_linear_x3_train(
+            _dev(x, F32, 'x', contiguous=False), x.stride(0), a_ptr, a_ld, a_per, fragments.data_ptr(),
+            _dev(bias, F32, 'bias') if bias is not None else None, R, I, out_features, 1 if relu else 0,
+            _dev(residual, F32, 'residual', contiguous=False) if residual is not None else None,
+            residual.stride(0) if residual is not None else 0, _dev(mask, F32, 'mask', contiguous=False) if mask is not None else None,
+            mask.stride(0) if mask is not None else 0, _dev(out, F32, 'out', contiguous=False), out.stride(0), _stream()),
+            'fbbev_rows_linear_x3_train')
+    return out
+
+
+def sum_leading(x, x2=None):
+    """(B, ...) f32 contiguous [+ x2 of the same shape] -> sum over the leading dimension, ascending b (fbbev_sum_leading)"""
+    B = x.shape[0]
+    N = x.numel() // B
+    out = torch.empty(x.shape[1:], dtype=F32, device=x.device)
+    with _on(x):
+        _check(lib().fbbev_sum_leading(_dev(x, F32, 'x'), _dev(x2, F32, 'x2') if x2 is not None else None, B, N, _dev(out, F32, 'out'),
+                                       _stream()), 'fbbev_sum_leading')
+    return out
+
+
+def rows_wgrad_x3(grad_out, x, bias=True, addend=None):
     """grad_out (R, O), x (R, I) f32 rows (unit column stride) -> (grad_weight (O, I), grad_bias (O) or None): fbbev_rows_wgrad_x3,
     split-operand MFMA over the rows, fixed-order reduction of the per-workgroup partial results (bit-stable)."""
     R, O = grad_out.shape
@@ -1208,9 +1252,14 @@ def rows_wgrad_x3(grad_out, x, bias=True):
     ws = torch.empty(need // 4, dtype=F32, device=x.device)
     gw = torch.empty((O, I), dtype=F32, device=x.device)
     gb = torch.empty((O,), dtype=F32, device=x.device) if bias else None
+    a_ptr, a_ld, a_per = None, 0, 1
+    if addend is not None:      # the layer's input rows were x[r] + addend[r % P]
+        if addend.dim() != 2 or addend.shape[1] != I or addend.stride(1) != 1 or R % addend.shape[0] != 0:
+            raise FbbevError('rows_wgrad_x3: addend must be (P, in_features) rows with rows % P == 0')
+        a_ptr, a_ld, a_per = _dev(addend, F32, 'addend', contiguous=False), addend.stride(0), addend.shape[0]
     with _on(x):
         _check(lib().fbbev_rows_wgrad_x3(_dev(grad_out, F32, 'grad_out', contiguous=False), grad_out.stride(0),
-                                         _dev(x, F32, 'x', contiguous=False), x.stride(0), R, I, O, _dev(gw, F32, 'grad_weight'),
+                                         _dev(x, F32, 'x', contiguous=False), x.stride(0), a_ptr, a_ld, a_per, R, I, O, _dev(gw, F32, 'grad_weight'),
                                          _dev(gb, F32, 'grad_bias') if gb is not None else None, c_void_p(ws.data_ptr()), need, _stream()),
                'fbbev_rows_wgrad_x3')
     return gw, gb

@@ -2751,7 +2751,8 @@ static int rows_linear_x3_impl(const float* x, long long x_row_stride, const voi
                                int in_features, int out_features, int relu, float* out, long long out_row_stride,
                                const float* addend, long long addend_row_stride, long long addend_period, fbbev_stream_t stream_,
                                int plane_S = 0, int plane_TS = 0, const float* res = nullptr, long long ld_res = 0,
-                               const float* ln_w = nullptr, const float* ln_b = nullptr, float ln_eps = 0.f);
+                               const float* ln_w = nullptr, const float* ln_b = nullptr, float ln_eps = 0.f,
+                               const float* mask = nullptr, long long ld_mask = 0, bool train_epi = false);
 
 extern "C" int fbbev_rows_linear_x3(const float* x, long long x_row_stride, const void* fragments, const float* bias, long long rows,
                                     int in_features, int out_features, int relu, float* out, long long out_row_stride,
@@ -2776,7 +2777,7 @@ static int rows_linear_x3_impl(const float* x, long long x_row_stride, const voi
                                int in_features, int out_features, int relu, float* out, long long out_row_stride,
                                const float* addend, long long addend_row_stride, long long addend_period, fbbev_stream_t stream_,
                                int plane_S, int plane_TS, const float* res, long long ld_res, const float* ln_w, const float* ln_b,
-                               float ln_eps) {
+                               float ln_eps, const float* mask, long long ld_mask, bool train_epi) {
     if (rows < 0 || in_features <= 0 || out_features <= 0) return FBBEV_E_BADARG;
     if (rows == 0) return 0;
     if (!x || !fragments || !out) return FBBEV_E_BADARG;
@@ -2799,11 +2800,19 @@ static int rows_linear_x3_impl(const float* x, long long x_row_stride, const voi
     { const char* e_rt = getenv("FBBEV_ROWS_LINEAR_RT"); if (e_rt && n_kc == 1 && atoi(e_rt) >= 1 && atoi(e_rt) <= 8) RT = atoi(e_rt); }
 #endif
     const long long groups = (tiles + RT - 1) / RT;
-    if (ln_w) {
+    if (train_epi) {
+        e = fbbev_rt_allow_dyn_lds((const void*)k_rows_linear_x3<2, false, 1>, lds);
+        if (e) return e;
+        FBBEV_LAUNCH((k_rows_linear_x3<2, false, 1>), groups * n_oc, 256, lds, (fbbev_rt_stream)stream_, x, x_row_stride,
+                     static_cast<const unsigned short*>(fragments), bias, out, out_row_stride, rows, in_features, out_features, relu,
+                     n_kc, n_oc, (int)RT, addend, addend_row_stride, addend_period, 0, 0, res, ld_res, (const float*)nullptr,
+                     (const float*)nullptr, 0.f, mask, ld_mask);
+    } else if (ln_w) {
         if (n_oc != 1) return FBBEV_E_UNSUPPORTED;
         FBBEV_LAUNCH((k_rows_linear_x3<2, true>), groups * n_oc, 256, lds, (fbbev_rt_stream)stream_, x, x_row_stride,
                      static_cast<const unsigned short*>(fragments), bias, out, out_row_stride, rows, in_features, out_features, relu,
-                     n_kc, n_oc, (int)RT, addend, addend_row_stride, addend_period, plane_S, plane_TS, res, ld_res, ln_w, ln_b, ln_eps);
+                     n_kc, n_oc, (int)RT, addend, addend_row_stride, addend_period, plane_S, plane_TS, res, ld_res, ln_w, ln_b, ln_eps,
+                     (const float*)nullptr, 0ll);
     } else if (rows_linear_nt1() && n_kc == 1) {
         // 16 rows per wave (64 per workgroup): half the accumulators / row pieces in registers -> more waves per SIMD
         const long long tiles1 = (rows + 63) / 64;
@@ -2813,14 +2822,47 @@ static int rows_linear_x3_impl(const float* x, long long x_row_stride, const voi
         if (e) return e;
         FBBEV_LAUNCH((k_rows_linear_x3<1, false>), (tiles1 + RT1 - 1) / RT1 * n_oc, 256, lds, (fbbev_rt_stream)stream_, x, x_row_stride,
                      static_cast<const unsigned short*>(fragments), bias, out, out_row_stride, rows, in_features, out_features, relu,
-                     n_kc, n_oc, (int)RT1, addend, addend_row_stride, addend_period, plane_S, plane_TS, res, ld_res, ln_w, ln_b, ln_eps);
+                     n_kc, n_oc, (int)RT1, addend, addend_row_stride, addend_period, plane_S, plane_TS, res, ld_res, ln_w, ln_b, ln_eps,
+                     (const float*)nullptr, 0ll);
     } else {
         FBBEV_LAUNCH((k_rows_linear_x3<2, false>), groups * n_oc, 256, lds, (fbbev_rt_stream)stream_, x, x_row_stride,
                      static_cast<const unsigned short*>(fragments), bias, out, out_row_stride, rows, in_features, out_features, relu,
-                     n_kc, n_oc, (int)RT, addend, addend_row_stride, addend_period, plane_S, plane_TS, res, ld_res, ln_w, ln_b, ln_eps);
+                     n_kc, n_oc, (int)RT, addend, addend_row_stride, addend_period, plane_S, plane_TS, res, ld_res, ln_w, ln_b, ln_eps,
+                     (const float*)nullptr, 0ll);
     }
     FBBEV_CHECK_LAUNCH();
     return 0;
+}
+
+// training epilogue (round 6): out = ((x W^T + b) [ReLU]) * [mask > 0] + residual -- the forward recomputations and dgrads of the
+// encoder layer's backward with their neighbouring element-wise passes (residual adds, ReLU's threshold_backward, gradient sums)
+extern "C" int fbbev_rows_linear_x3_train(const float* x, long long x_row_stride, const float* addend, long long addend_row_stride,
+                                          long long addend_period, const void* fragments, const float* bias, long long rows,
+                                          int in_features, int out_features, int relu, const float* residual, long long residual_row_stride,
+                                          const float* mask, long long mask_row_stride, float* out, long long out_row_stride,
+                                          fbbev_stream_t stream_) {
+    if (out_features <= 0 || in_features <= 0) return FBBEV_E_BADARG;
+    if (addend) {
+        if (addend_period <= 0) return FBBEV_E_BADARG;
+        if (addend_row_stride == 0) addend_row_stride = in_features;
+        if (addend_row_stride < in_features) return FBBEV_E_BADARG;
+        if (addend_row_stride % 4 != 0 || !aligned16(addend)) return FBBEV_E_UNSUPPORTED;
+    } else {
+        addend_period = 1;
+    }
+    if (residual) {
+        if (residual_row_stride == 0) residual_row_stride = out_features;
+        if (residual_row_stride < out_features) return FBBEV_E_BADARG;
+        if (residual_row_stride % 4 != 0 || !aligned16(residual)) return FBBEV_E_UNSUPPORTED;
+    }
+    if (mask) {
+        if (mask_row_stride == 0) mask_row_stride = out_features;
+        if (mask_row_stride < out_features) return FBBEV_E_BADARG;
+        if (mask_row_stride % 4 != 0 || !aligned16(mask)) return FBBEV_E_UNSUPPORTED;
+    }
+    return rows_linear_x3_impl(x, x_row_stride, fragments, bias, rows, in_features, out_features, relu, out, out_row_stride, addend,
+                               addend_row_stride, addend_period, stream_, 0, 0, residual, residual_row_stride, nullptr, nullptr, 0.f,
+                               mask, mask_row_stride, true);
 }
 
 // out = LayerNorm(x W^T + b [+ residual]) over the out_features outputs of a row, weight / bias / eps of torch.nn.LayerNorm: the

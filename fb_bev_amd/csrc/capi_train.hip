@@ -8,7 +8,7 @@
 #include "../../include/fbbev.h"
 
 // ------------------------------------------------------------------------------ weight / bias gradient of a row-wise linear layer
-struct wgrad_plan { int nti, n_oc, n_ic, ksteps, kps, n_split; size_t part_w, part_b, total; };
+struct wgrad_plan { int nti, n_oc, n_ic, ksteps, kps, n_split, amt; size_t part_w, part_b, total; };
 
 static bool wgrad_plan_make(long long rows, int I, int O, wgrad_plan* p) {
     if (rows <= 0 || I <= 0 || O <= 0 || I % 4 != 0 || O % 4 != 0) return false;
@@ -19,6 +19,8 @@ static bool wgrad_plan_make(long long rows, int I, int O, wgrad_plan* p) {
     p->n_ic = (I + 16 * p->nti - 1) / (16 * p->nti);
     p->ksteps = (int)ks;
     // enough workgroups to fill the chip twice, few enough partial results that the fixed-order reduction stays small
+    p->amt = O >= 128 ? 8 : (O + 15) / 16;
+    // (768 workgroups for the narrow layers -- three per CU at their 41 KB of LDS -- measured slower than 256: 48.8 -> 54.8 us at 80 x 80)
     long long want = 512 / ((long long)p->n_oc * p->n_ic);
     static const int env_split = [] { const char* e = getenv("FBBEV_WGRAD_SPLITS"); return e ? atoi(e) : 0; }();   // tuning knob
     if (env_split > 0) want = env_split;
@@ -38,9 +40,10 @@ extern "C" size_t fbbev_rows_wgrad_x3_ws_bytes(long long rows, int in_features, 
     return wgrad_plan_make(rows, in_features, out_features, &p) ? p.total : 0;
 }
 
-extern "C" int fbbev_rows_wgrad_x3(const float* grad_out, long long ld_grad, const float* x, long long ldx, long long rows,
-                                   int in_features, int out_features, float* grad_weight, float* grad_bias, void* workspace,
-                                   size_t workspace_bytes, fbbev_stream_t stream_) {
+extern "C" int fbbev_rows_wgrad_x3(const float* grad_out, long long ld_grad, const float* x, long long ldx, const float* x_addend,
+                                   long long addend_row_stride, long long addend_period, long long rows, int in_features,
+                                   int out_features, float* grad_weight, float* grad_bias, void* workspace, size_t workspace_bytes,
+                                   fbbev_stream_t stream_) {
     const int I = in_features, O = out_features;
     if (rows < 0 || I <= 0 || O <= 0) return FBBEV_E_BADARG;
     if (!grad_weight) return FBBEV_E_BADARG;
@@ -54,6 +57,14 @@ extern "C" int fbbev_rows_wgrad_x3(const float* grad_out, long long ld_grad, con
     if (ld_grad == 0) ld_grad = O;
     if (ldx == 0) ldx = I;
     if (ld_grad < O || ldx < I) return FBBEV_E_BADARG;
+    if (x_addend) {
+        if (addend_period <= 0 || addend_period >= (1ll << 31)) return FBBEV_E_BADARG;
+        if (addend_row_stride == 0) addend_row_stride = I;
+        if (addend_row_stride < I) return FBBEV_E_BADARG;
+        if (addend_row_stride % 4 != 0 || !aligned16(x_addend)) return FBBEV_E_UNSUPPORTED;
+    } else {
+        addend_period = 1;
+    }
     wgrad_plan p;
     if (!wgrad_plan_make(rows, I, O, &p) || ld_grad % 4 != 0 || ldx % 4 != 0 || !aligned16(grad_out) || !aligned16(x))
         return FBBEV_E_UNSUPPORTED;
@@ -62,22 +73,49 @@ extern "C" int fbbev_rows_wgrad_x3(const float* grad_out, long long ld_grad, con
     float* part_b = grad_bias ? reinterpret_cast<float*>(static_cast<char*>(workspace) + p.part_b) : nullptr;
     const long long wgs = (long long)p.n_split * p.n_oc * p.n_ic;
     if (wgs >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
-    const size_t lds = (size_t)2 * (8 + p.nti) * FBBEV_WG_TILE_DW * 4;
-    if (p.nti == 5) {
-        FBBEV_LAUNCH(k_rows_wgrad_x3<5>, wgs, 256, lds, stream, grad_out, ld_grad, x, ldx, rows, O, I, p.n_oc, p.n_ic, p.ksteps,
-                     p.kps, part_w, part_b);
-    } else {
-        if (lds > 64 * 1024) {
-            const int e = fbbev_rt_allow_dyn_lds((const void*)k_rows_wgrad_x3<8>, lds);
-            if (e) return e;
-        }
-        FBBEV_LAUNCH(k_rows_wgrad_x3<8>, wgs, 256, lds, stream, grad_out, ld_grad, x, ldx, rows, O, I, p.n_oc, p.n_ic, p.ksteps,
-                     p.kps, part_w, part_b);
-    }
+    const size_t lds = (size_t)2 * (p.amt + p.nti) * FBBEV_WG_TILE_DW * 4;
+#define FBBEV_WGRAD_LAUNCH(NTI_, ADD_)                                                                                            \
+    do {                                                                                                                          \
+        if (lds > 64 * 1024) {                                                                                                    \
+            const int e_ = fbbev_rt_allow_dyn_lds((const void*)k_rows_wgrad_x3<NTI_, ADD_>, lds);                                  \
+            if (e_) return e_;                                                                                                    \
+        }                                                                                                                         \
+        FBBEV_LAUNCH((k_rows_wgrad_x3<NTI_, ADD_>), wgs, 256, lds, stream, grad_out, ld_grad, x, ldx, x_addend, addend_row_stride, \
+                     (int)addend_period, rows, O, I, p.n_oc, p.n_ic, p.ksteps, p.kps, p.amt, part_w, part_b);                             \
+    } while (0)
+    if (p.nti == 5) { if (x_addend) FBBEV_WGRAD_LAUNCH(5, true); else FBBEV_WGRAD_LAUNCH(5, false); }
+    else { if (x_addend) FBBEV_WGRAD_LAUNCH(8, true); else FBBEV_WGRAD_LAUNCH(8, false); }
+#undef FBBEV_WGRAD_LAUNCH
     FBBEV_CHECK_LAUNCH();
     const long long OI = (long long)O * I, total = OI + (grad_bias ? O : 0);
-    FBBEV_LAUNCH(k_rows_wgrad_reduce<0>, (total + 31) / 32, 256, 0, stream, (const float*)part_w, (const float*)part_b, p.n_split, OI,
+    FBBEV_LAUNCH(k_rows_wgrad_reduce<8>, (total + 31) / 32, 256, 0, stream, (const float*)part_w, (const float*)part_b, p.n_split, OI,
                  O, grad_weight, grad_bias);
+    FBBEV_CHECK_LAUNCH();
+    return 0;
+}
+
+// out (N) = sum over the leading dimension of x (B, N) [+ x2 (B, N)], ascending b
+extern "C" int fbbev_sum_leading(const float* x, const float* x2, int B, long long N, float* out, fbbev_stream_t stream_) {
+    if (B <= 0 || N < 0) return FBBEV_E_BADARG;
+    if (N == 0) return 0;
+    if (!x || !out) return FBBEV_E_BADARG;
+    if (N % 4 != 0 || !aligned16(x) || !aligned16(out) || (x2 && !aligned16(x2))) return FBBEV_E_UNSUPPORTED;
+    const long long n4 = N / 4;
+    if ((n4 + 255) / 256 >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
+    FBBEV_LAUNCH(k_sum_leading<0>, (n4 + 255) / 256, 256, 0, (fbbev_rt_stream)stream_, x, x2, B, n4, reinterpret_cast<fbbev_v4f*>(out));
+    FBBEV_CHECK_LAUNCH();
+    return 0;
+}
+
+// out (len) = sum over the n rows of part (n, len), fixed association (32 lanes each adding every 32nd row in ascending order, lane sums
+// added in lane order): the per-workgroup partial parameter gradients of fbbev_layernorm_bwd -- ATen's reduction over the leading
+// dimension of a (2048, 160) tensor is one latency chain per column (79 us per LayerNorm at 160 000 rows)
+extern "C" int fbbev_sum_partials(const float* part, int n, long long len, float* out, fbbev_stream_t stream_) {
+    if (n <= 0 || len < 0) return FBBEV_E_BADARG;
+    if (len == 0) return 0;
+    if (!part || !out) return FBBEV_E_BADARG;
+    FBBEV_LAUNCH(k_rows_wgrad_reduce<32>, (len + 31) / 32, 1024, 0, (fbbev_rt_stream)stream_, part, (const float*)nullptr, n, len, 0, out,
+                 (float*)nullptr);
     FBBEV_CHECK_LAUNCH();
     return 0;
 }

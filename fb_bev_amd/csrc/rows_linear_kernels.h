@@ -34,12 +34,18 @@ __device__ __forceinline__ void fbbev_stage_v4u(fbbev_v4u* __restrict__ dst, con
     }
 }
 
-template <int NT, bool LN>
+// EPI = 1 (round 6, the training path's instantiation -- its own, so that the inference kernels keep their register budgets):
+// out = ((x W^T + b) [ReLU]) * [mask > 0] + res, with `mask` (rows, O) the saved forward activation of a ReLU whose backward this
+// product is (`threshold_backward` folded into the dgrad's store) and `res` (rows, O) a residual / running gradient sum; `res == out`
+// is allowed (an element is read, then written, by one thread, and the stored value depends on the loaded one) -- the element-wise
+// passes between the GEMMs of a backward
+template <int NT, bool LN, int EPI = 0>
 __global__ void __launch_bounds__(256, NT == 1 ? 3 : 2)
 k_rows_linear_x3(const float* __restrict__ x, long long ldx, const unsigned short* __restrict__ wf, const float* __restrict__ bias,
                  float* __restrict__ out, long long ldo, long long rows, int I, int O, int relu, int n_kc, int n_oc, int RT,
                  const float* __restrict__ addend, long long ld_add, long long add_period, int plane_S, int plane_TS,
-                 const float* __restrict__ res, long long ld_res, const float* __restrict__ ln_w, const float* __restrict__ ln_b, float ln_eps) {
+                 const float* __restrict__ res, long long ld_res, const float* __restrict__ ln_w, const float* __restrict__ ln_b, float ln_eps,
+                 const float* __restrict__ mask = nullptr, long long ld_mask = 0) {
     unsigned short* wl = reinterpret_cast<unsigned short*>(fbbev_dyn_lds_f32());          // [nmt][FBBEV_RL_TILE_ELEMS]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int g = lane >> 4, j = lane & 15;
@@ -196,6 +202,37 @@ k_rows_linear_x3(const float* __restrict__ x, long long ldx, const unsigned shor
                 const long long bn = r / plane_S, tok = r - bn * plane_S;
                 row_at[t] = (bn * Mh * plane_S + tok) * TS;
             }
+        }
+        if constexpr (EPI == 1) {
+            // training epilogue: the residual / mask pieces of four output tiles are requested together (clamped, unconditional)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const long long r = r0 + 16 * t + j;
+                const bool live = r < rows;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    fbbev_v4f pr[4], pm[4], pb[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int mt = 4 * half + q, o = o0 + 16 * mt + 4 * g;
+                        const bool ok = live && mt < nmt && o < O;
+                        pb[q] = bias ? *reinterpret_cast<const fbbev_v4f*>(bias + ((mt < nmt && o < O) ? o : 0)) : fbbev_v4f{0.f, 0.f, 0.f, 0.f};
+                        pr[q] = res ? *reinterpret_cast<const fbbev_v4f*>(res + (ok ? r * ld_res + o : 0)) : fbbev_v4f{0.f, 0.f, 0.f, 0.f};
+                        pm[q] = mask ? *reinterpret_cast<const fbbev_v4f*>(mask + (ok ? r * ld_mask + o : 0)) : fbbev_v4f{1.f, 1.f, 1.f, 1.f};
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int mt = 4 * half + q, o = o0 + 16 * mt + 4 * g;
+                        if (!(live && mt < nmt && o < O)) continue;
+                        fbbev_v4f v = acc[mt][t] + pb[q];
+                        if (relu) v = fbbev_v4f{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = (pm[q][e] > 0.f ? v[e] : 0.f) + pr[q][e];
+                        *reinterpret_cast<fbbev_v4f*>(out + r * ldo + o) = v;
+                    }
+                }
+            }
+            continue;
         }
         fbbev_v4f pbias[NT >= 2 ? 8 : 1];                                                 // (requested together: see the LayerNorm epilogue;
         if constexpr (NT >= 2) {                                                          //  the 168-register NT = 1 build has no room for them)

@@ -39,12 +39,16 @@ __device__ __forceinline__ fbbev_bf16x8 fbbev_wg_frag(const unsigned int* p) {  
 // grid = n_split * n_oc * n_ic workgroups of 256 threads; workgroup (split, oc, ic) accumulates output rows [128 oc, 128 oc + 128) x
 // input columns [16 NTI ic, 16 NTI (ic + 1)) over the 32-row steps [split * kps, (split + 1) * kps) and writes
 // part_w[split][o][i] (dense (O, I) per split); the ic == 0 workgroups also write part_b[split][o] when part_b is given.
-template <int NTI>
+// addend (period, I), optional: the layer's input rows were x[r] + addend[r % period] (query + query_pos, never materialised).
+template <int NTI, bool ADD>
 __global__ void __launch_bounds__(256, 2)
-k_rows_wgrad_x3(const float* __restrict__ gy, long long ldg, const float* __restrict__ x, long long ldx, long long rows, int O, int I,
-                int n_oc, int n_ic, int ksteps, int kps, float* __restrict__ part_w, float* __restrict__ part_b) {
-    constexpr int XQ = 4 * NTI, BUF = (8 + NTI) * FBBEV_WG_TILE_DW;
-    unsigned int* lds = reinterpret_cast<unsigned int*>(fbbev_dyn_lds_f32());               // [2][8 + NTI tiles][TILE_DW]
+k_rows_wgrad_x3(const float* __restrict__ gy, long long ldg, const float* __restrict__ x, long long ldx,
+                const float* __restrict__ addend, long long ld_add, int add_period, long long rows, int O, int I,
+                int n_oc, int n_ic, int ksteps, int kps, int amt, float* __restrict__ part_w, float* __restrict__ part_b) {
+    constexpr int XQ = 4 * NTI;
+    // amt = 16-column tiles of grad_out a workgroup stages (min(8, O / 16 rounded up)): a narrow layer takes less LDS -> three workgroups per CU
+    const int BUF = (amt + NTI) * FBBEV_WG_TILE_DW;
+    unsigned int* lds = reinterpret_cast<unsigned int*>(fbbev_dyn_lds_f32());               // [2][amt + NTI tiles][TILE_DW]
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63, g = lane >> 4, j = lane & 15;
     int bid = blockIdx.x;
     const int ic = bid % n_ic; bid /= n_ic;
@@ -64,8 +68,18 @@ k_rows_wgrad_x3(const float* __restrict__ gy, long long ldg, const float* __rest
         xcq[u] = it % XQ; xrp[u] = it / XQ;                                                 // x: 16 row pairs x XQ column quads
         xcol[u] = xrp[u] < 16 && i0 + 4 * xcq[u] < I;
     }
-    fbbev_v4f ga[2][2], xa[2][2];
+    // a step's pieces stay RAW in registers from `request` to `commit` (round-6 lesson, as in rows_linear_kernels.h: a select or
+    // an add on a loaded value right behind its load put an s_waitcnt vmcnt(0) after every piece -- four round trips per step in
+    // front of the MFMAs instead of one behind them); out-of-range pieces load a clamped address and are zeroed at commit
+    fbbev_v4f ga[2][2], xa[2][2], va[ADD ? 2 : 1][2];
     const fbbev_v4f zero4 = {0.f, 0.f, 0.f, 0.f};
+    // row of the addend for this thread's x rows: (row % period), carried from step to step (steps are requested in ascending order)
+    int ra[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) ra[u][h] = ADD ? (int)(((long long)ks0 * 32 + 2 * xrp[u] + h) % add_period) : 0;
+    const int step_mod = ADD ? 32 % add_period : 0;
     auto request = [&](int ks) {
         const long long r0 = (long long)ks * 32;
 #pragma unroll
@@ -74,35 +88,45 @@ k_rows_wgrad_x3(const float* __restrict__ gy, long long ldg, const float* __rest
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const bool okg = gcol && rg + h < rows, okx = xcol[u] && rx + h < rows;
-                const fbbev_v4f vg = *reinterpret_cast<const fbbev_v4f*>(gy + (okg ? (rg + h) * ldg + o0 + 4 * gcq : 0));
-                const fbbev_v4f vx = *reinterpret_cast<const fbbev_v4f*>(x + (okx ? (rx + h) * ldx + i0 + 4 * xcq[u] : 0));
-                ga[u][h] = okg ? vg : zero4;
-                xa[u][h] = okx ? vx : zero4;
+                ga[u][h] = *reinterpret_cast<const fbbev_v4f*>(gy + (okg ? (rg + h) * ldg + o0 + 4 * gcq : 0));
+                xa[u][h] = *reinterpret_cast<const fbbev_v4f*>(x + (okx ? (rx + h) * ldx + i0 + 4 * xcq[u] : 0));
+                if constexpr (ADD) {
+                    va[u][h] = *reinterpret_cast<const fbbev_v4f*>(addend + (okx ? (long long)ra[u][h] * ld_add + i0 + 4 * xcq[u] : 0));
+                    ra[u][h] += step_mod;
+                    if (ra[u][h] >= add_period) ra[u][h] -= add_period;
+                }
             }
         }
     };
     float bsum[4] = {0.f, 0.f, 0.f, 0.f};
-    auto commit = [&](unsigned int* buf) {
+    auto commit = [&](unsigned int* buf, int ks) {
+        const long long r0 = (long long)ks * 32;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            {
+            if ((gcq >> 2) < amt) {
                 const int rp = grp0 + 8 * u;
+                const long long rg = r0 + 2 * rp;
+                const fbbev_v4f a = (gcol && rg < rows) ? ga[u][0] : zero4, b = (gcol && rg + 1 < rows) ? ga[u][1] : zero4;
                 unsigned int* dst = buf + (gcq >> 2) * FBBEV_WG_TILE_DW + ((rp >> 2) * 16 + 4 * (gcq & 3)) * 4 + (rp & 3);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     unsigned int hi, lo;
-                    fbbev_wg_split_pair(ga[u][0][k], ga[u][1][k], hi, lo);
+                    fbbev_wg_split_pair(a[k], b[k], hi, lo);
                     dst[4 * k] = hi; dst[4 * k + 256] = lo;
-                    bsum[k] += ga[u][0][k] + ga[u][1][k];
+                    bsum[k] += a[k] + b[k];
                 }
             }
             if (xrp[u] < 16) {
                 const int rp = xrp[u];
-                unsigned int* dst = buf + (8 + (xcq[u] >> 2)) * FBBEV_WG_TILE_DW + ((rp >> 2) * 16 + 4 * (xcq[u] & 3)) * 4 + (rp & 3);
+                const long long rx = r0 + 2 * rp;
+                fbbev_v4f a = xa[u][0], b = xa[u][1];
+                if constexpr (ADD) { a = a + va[u][0]; b = b + va[u][1]; }
+                a = (xcol[u] && rx < rows) ? a : zero4; b = (xcol[u] && rx + 1 < rows) ? b : zero4;
+                unsigned int* dst = buf + (amt + (xcq[u] >> 2)) * FBBEV_WG_TILE_DW + ((rp >> 2) * 16 + 4 * (xcq[u] & 3)) * 4 + (rp & 3);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     unsigned int hi, lo;
-                    fbbev_wg_split_pair(xa[u][0][k], xa[u][1][k], hi, lo);
+                    fbbev_wg_split_pair(a[k], b[k], hi, lo);
                     dst[4 * k] = hi; dst[4 * k + 256] = lo;
                 }
             }
@@ -115,7 +139,7 @@ k_rows_wgrad_x3(const float* __restrict__ gy, long long ldg, const float* __rest
         for (int nt = 0; nt < NTI; ++nt) acc[ml][nt] = zero4;
     if (ks0 < ks1) {
         request(ks0);
-        commit(lds);
+        commit(lds, ks0);
     }
     __syncthreads();
     for (int ks = ks0; ks < ks1; ++ks) {
@@ -123,6 +147,7 @@ k_rows_wgrad_x3(const float* __restrict__ gy, long long ldg, const float* __rest
         unsigned int* nxt = lds + (((ks - ks0) & 1) ^ 1) * BUF;
         const bool more = ks + 1 < ks1;                                                     // uniform
         if (more) request(ks + 1);
+        fbbev_sched_fence();                                                                // the requests stay ahead of the MFMAs
         fbbev_bf16x8 ah[2], al[2];
 #pragma unroll
         for (int ml = 0; ml < 2; ++ml) {
@@ -132,7 +157,7 @@ k_rows_wgrad_x3(const float* __restrict__ gy, long long ldg, const float* __rest
 #pragma unroll
         for (int nt = 0; nt < NTI; ++nt) {
             if (i0 + 16 * nt >= I) break;                                                   // uniform
-            const unsigned int* base = cur + (8 + nt) * FBBEV_WG_TILE_DW + lane * 4;
+            const unsigned int* base = cur + (amt + nt) * FBBEV_WG_TILE_DW + lane * 4;
             const fbbev_bf16x8 bh = fbbev_wg_frag(base), bl = fbbev_wg_frag(base + 256);
 #pragma unroll
             for (int ml = 0; ml < 2; ++ml) {
@@ -142,7 +167,8 @@ k_rows_wgrad_x3(const float* __restrict__ gy, long long ldg, const float* __rest
                 acc[ml][nt] = fbbev_mfma_f32_16x16x32_bf16(ah[ml], bh, acc[ml][nt]);
             }
         }
-        if (more) commit(nxt);
+        fbbev_sched_fence();
+        if (more) commit(nxt, ks + 1);
         __syncthreads();
     }
     // accumulator register r of tile (ml, nt) = gW[o0 + 16 (2 wave + ml) + 4 g + r][i0 + 16 nt + j]
@@ -175,13 +201,13 @@ k_rows_wgrad_x3(const float* __restrict__ gy, long long ldg, const float* __rest
     }
 }
 
-// gw[idx] = sum over the splits of part_w[split][idx] (idx < OI), gb[o] likewise from part_b: a workgroup = 32 outputs x 8 split lanes,
-// each lane adds its splits in ascending order, the 8 lane sums are added in lane order -- one fixed association for every launch
-template <int UNUSED>
-__global__ void __launch_bounds__(256)
+// gw[idx] = sum over the splits of part_w[split][idx] (idx < OI), gb[o] likewise from part_b: a workgroup = 32 outputs x LANES split lanes,
+// each lane adds its splits in ascending order, the lane sums are added in lane order -- one fixed association for every launch
+template <int LANES>
+__global__ void __launch_bounds__(32 * LANES)
 k_rows_wgrad_reduce(const float* __restrict__ part_w, const float* __restrict__ part_b, int n_split, long long OI, int O,
                     float* __restrict__ gw, float* __restrict__ gb) {
-    __shared__ float red[8][32];
+    __shared__ float red[LANES][32];
     const int ii = threadIdx.x & 31, sl = threadIdx.x >> 5;
     const long long idx = (long long)blockIdx.x * 32 + ii;
     const long long total = OI + (gb ? O : 0);
@@ -189,14 +215,29 @@ k_rows_wgrad_reduce(const float* __restrict__ part_w, const float* __restrict__ 
     if (idx < total) {
         const float* src = idx < OI ? part_w + idx : part_b + (idx - OI);
         const long long stride = idx < OI ? OI : (long long)O;
-        for (int sp = sl; sp < n_split; sp += 8) s += src[(long long)sp * stride];
+        for (int sp = sl; sp < n_split; sp += LANES) s += src[(long long)sp * stride];
     }
     red[sl][ii] = s;
     __syncthreads();
     if (sl == 0 && idx < total) {
         float r = 0.f;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) r += red[q][ii];
+        for (int q = 0; q < LANES; ++q) r += red[q][ii];
         if (idx < OI) gw[idx] = r; else gb[idx - OI] = r;
     }
+}
+
+// out[n] = sum over b < B of x[b][n] (ascending b): the batch sum behind a parameter that every sample shares (the positional table
+// under `query + query_pos`, the BEV embedding) -- ATen's reduction over the leading dimension runs at ~0.6 TB/s on (4, 3.2 M)
+template <int UNUSED>
+__global__ void __launch_bounds__(256)
+k_sum_leading(const float* __restrict__ x, const float* __restrict__ x2, int B, long long N4, fbbev_v4f* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N4) return;
+    fbbev_v4f s = {0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < B; ++b) {
+        s = s + reinterpret_cast<const fbbev_v4f*>(x)[(long long)b * N4 + i];
+        if (x2) s = s + reinterpret_cast<const fbbev_v4f*>(x2)[(long long)b * N4 + i];
+    }
+    out[i] = s;
 }

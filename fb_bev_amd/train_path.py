@@ -185,8 +185,10 @@ def _t(w_, b_):
     return w_.t().contiguous(), None
 
 
-def _lin(x2d, c, relu=False, addend=None, out=None):
-    return _capi.rows_linear_x3(x2d, c.frag, c.b, c.w.shape[0], relu=relu, addend=addend, out=out)
+def _lin(x2d, c, relu=False, addend=None, out=None, res=None, mask=None):
+    if res is None and mask is None:
+        return _capi.rows_linear_x3(x2d, c.frag, c.b, c.w.shape[0], relu=relu, addend=addend, out=out)
+    return _capi.rows_linear_x3_train(x2d, c.frag, c.b, c.w.shape[0], relu=relu, addend=addend, residual=res, mask=mask, out=out)
 
 
 def layer_supported(layer, query, bev_pos, value_rows, pred_depth, reference_points_cam, spatial_shapes, bev_h, bev_w, bev_mask):
@@ -305,13 +307,16 @@ class EncoderLayerFn(torch.autograd.Function):
         dev = q.device
         G = {}                                        # name -> [grad weight, grad bias]
 
-        def wgrad(name, gy, x, post=None):
+        def wgrad(name, gy, x, post=None, addend=None):
             # grad_weight = gy^T x and grad_bias = column sums of gy in one split-K MFMA kernel + a fixed-order reduction
             # (fbbev_rows_wgrad_x3); FBBEV_TRAIN_WGRAD=0: the split-K batched vendor GEMMs of rows_linear.py (A/B knob)
             gw = gb = None
             if WGRAD_X3 and need[name][0] and _capi.rows_wgrad_x3_supported(gy, x):
-                gw, gb = _capi.rows_wgrad_x3(gy, x, bias=need[name][1])
+                gw, gb = _capi.rows_wgrad_x3(gy, x, bias=need[name][1], addend=addend)
             else:
+                if addend is not None:
+                    x = (x.view(-1, *addend.shape) + addend).view(x.shape)
+
                 if need[name][0]:
                     gw = _RL.weight_grad(gy, x)
                 if need[name][1]:
@@ -328,21 +333,19 @@ class EncoderLayerFn(torch.autograd.Function):
         g_y2 = g_y2.contiguous().view(R, E)
         q2, y0_2, s2 = q.view(R, E), y0.view(R, E), slots.view(R, E)
         # ================================================================ FFN block (recompute y1, hidden, pre-norm sum)
+        # (every residual add, the ReLU's threshold_backward and the gradient sums ride in the GEMMs' store epilogues:
+        #  fbbev_rows_linear_x3_train)
         co, c1, c2 = _frag(layer, 'co', *p['co']), _frag(layer, 'f1', *p['f1']), _frag(layer, 'f2', *p['f2'])
-        x1 = _lin(s2, co)
-        x1.add_(y0_2)                                                                    # output_proj(slots) + residual
+        x1 = _lin(s2, co, res=y0_2)                                                      # output_proj(slots) + residual
         y1 = _capi.layernorm(x1, p['n1'][0], p['n1'][1], layer.norms[1].eps)
         h = _lin(y1, c1, relu=True)
-        x2 = _lin(h, c2)
-        x2.add_(y1)
+        x2 = _lin(h, c2, res=y1)
         g_x2 = ln_bwd('n2', x2, g_y2, p['n2'][0])
         del x2
-        g_h = _lin(g_x2, _frag(layer, 'f2t', p['f2'][0], None, _t))
-        g_h = torch.where(h > 0, g_h, torch.zeros((), dtype=g_h.dtype, device=dev))
+        g_h = _lin(g_x2, _frag(layer, 'f2t', p['f2'][0], None, _t), mask=h)              # (g_x2 W2) * [h > 0]
         wgrad('f2', g_x2, h)
         del h
-        g_y1 = _lin(g_h, _frag(layer, 'f1t', p['f1'][0], None, _t))
-        g_y1.add_(g_x2)
+        g_y1 = _lin(g_h, _frag(layer, 'f1t', p['f1'][0], None, _t), res=g_x2)
         wgrad('f1', g_h, y1)
         del g_h, g_x2, y1
         # ================================================================ cross-attention tail
@@ -350,16 +353,13 @@ class EncoderLayerFn(torch.autograd.Function):
         del x1, g_y1
         g_slots = _lin(g_x1, _frag(layer, 'cot', p['co'][0], None, _t))
         wgrad('co', g_x1, s2)
-        g_y0 = g_x1                                                                      # the residual branch
         # ================================================================ depth-aware deformable cross-attention
         L, P = da.num_levels, da.num_points
         BN, S, _ = rows.shape
-        ncam = BN // B
         HS = (Dh + 3) // 4 * 4
         hw = geo['hw']
         perm = _so_perm(da, M, L, P, dev)
-        inv = torch.empty_like(perm)
-        inv[perm] = torch.arange(perm.numel(), device=dev)
+        inv = _so_perm_inv(da, perm)
         cso = _frag(layer, 'cso_hm', p['cso'][0], p['cso'][1], lambda w_, b_: (w_[perm], b_[perm]))
         caw = _frag(layer, 'caw', *p['caw'])
         so = _lin(y0_2, cso, addend=pos)                                                  # (R, L*P*M*2) head-minor offsets
@@ -377,17 +377,15 @@ class EncoderLayerFn(torch.autograd.Function):
         del v, so, g_slots
         g_lg = torch._softmax_backward_data(g_aw, aw, -1, torch.float32).view(R, M * L * P)
         del g_aw, aw
-        qp = y0_2 + pos.repeat(B, 1) if (need['cso'][0] or need['caw'][0]) else None       # the projections' input rows
-        g_qp = _lin(g_so, _frag(layer, 'cso_hm_t', p['cso'][0], None, lambda w_, b_: (w_[perm].t().contiguous(), None)))
-        g_qp.add_(_lin(g_lg, _frag(layer, 'cawt', p['caw'][0], None, _t)))
-        wgrad('cso', g_so, qp, post=lambda gw: gw[inv])
+        g_qp_c = _lin(g_so, _frag(layer, 'cso_hm_t', p['cso'][0], None, lambda w_, b_: (w_[perm].t().contiguous(), None)))
+        _lin(g_lg, _frag(layer, 'cawt', p['caw'][0], None, _t), res=g_qp_c, out=g_qp_c)   # d / d (y0 + pos), both heads
+        wgrad('cso', g_so, y0_2, post=lambda gw: gw[inv], addend=pos)
         if G['cso'][1] is not None:
             G['cso'][1] = G['cso'][1][inv]
-        wgrad('caw', g_lg, qp)
-        del g_so, g_lg, qp
-        g_pos = g_qp.view(B, Q, E).sum(0)
-        g_y0 = g_y0 + g_qp
-        del g_qp
+        wgrad('caw', g_lg, y0_2, addend=pos)
+        del g_so, g_lg
+        g_y0 = g_x1 + g_qp_c                                                               # residual branch + the projections' input
+        del g_x1
         g_rows = None
         g_v2 = g_v.view(BN * S, M * HS)
         if ctx.needs_input_grad[4]:
@@ -406,46 +404,88 @@ class EncoderLayerFn(torch.autograd.Function):
         _capi.msda_self_fused(planes_s, geo['ref2d'], q, pos, cso.frag, cso.b, caw.frag, caw.b, sa.num_points, geo['bev_w'],
                               (geo['bev_h'], geo['bev_w']), a)
         a2 = a.view(R, E)
-        x0 = _lin(a2, _frag(layer, 'so', *p['so']))
-        x0.add_(q2)
-        g_x0 = ln_bwd('n0', x0, g_y0.contiguous(), p['n0'][0])
+        x0 = _lin(a2, _frag(layer, 'so', *p['so']), res=q2)
+        g_x0 = ln_bwd('n0', x0, g_y0, p['n0'][0])
         del x0, g_y0
         g_a = _lin(g_x0, _frag(layer, 'sot', p['so'][0], None, _t))
         wgrad('so', g_x0, a2)
         del a, a2
         # ================================================================ BEV self-attention (mmcv MultiScaleDeformableAttention)
+        # sampling locations = reference point + offsets / (W, H) (multi_scale_deform_attn: offset_normalizer): the division lives in
+        # a derived weight matrix, the reference point arrives as the GEMM's residual -- no element-wise pass; the offsets' gradient is
+        # then the locations' gradient, and the weight gradient is rescaled row-wise at the end
         Ps = sa.num_points
         bh, bw = geo['bev_h'], geo['bev_w']
-        so = _lin(q2, cso, addend=pos)                                                     # (R, M*1*Ps*2)
-        from .backward_projection import const_tensor
-        norm = const_tensor([float(bw), float(bh)], dev, torch.float32)
-        loc = (geo['ref2d'].view(B, Q, 1, 1, 1, 2) + so.view(B, Q, M, 1, Ps, 2) / norm).contiguous()
+        nrm = _offset_normalizer(layer, M, Ps, bw, bh, dev)                                # (M*Ps*2): (W, H, W, H, ...)
+        csn = _frag(layer, 'sso_n', p['sso'][0], p['sso'][1], lambda w_, b_: (w_ / nrm[:, None], b_ / nrm))
+        loc = _lin(q2, csn, addend=pos, res=_ref_rows(layer, geo['ref2d'], M * Ps)).view(B, Q, M, 1, Ps, 2)
         aw = _lin(q2, caw, addend=pos).view(R, M, Ps).softmax(-1)
         v = _lin(q2, _frag(layer, 'sv', *p['sv'])).view(B, Q, M, Dh)
         g_v = torch.empty_like(v)
         g_loc, g_aw = torch.zeros_like(loc), torch.zeros_like(aw)
         _capi.msda_bwd(v, geo['ss_self'], geo['ls_self'], loc, aw.view(B, Q, M, 1, Ps), g_a.view(B, Q, E), g_v, g_loc,
                        g_aw.view(B, Q, M, 1, Ps), level_hw=[(bh, bw)])
-        del v, loc, so, g_a
-        g_so = (g_loc / norm).view(R, M * Ps * 2)
+        del v, loc, g_a
+        g_loc = g_loc.view(R, M * Ps * 2)
         g_lg = torch._softmax_backward_data(g_aw, aw, -1, torch.float32).view(R, M * Ps)
-        del g_loc, g_aw, aw
-        qp = q2 + pos.repeat(B, 1) if (need['sso'][0] or need['saw'][0]) else None
-        g_qp = _lin(g_so, _frag(layer, 'ssot', p['sso'][0], None, _t))
-        g_qp.add_(_lin(g_lg, _frag(layer, 'sawt', p['saw'][0], None, _t)))
-        wgrad('sso', g_so, qp)
-        wgrad('saw', g_lg, qp)
-        del g_so, g_lg, qp
-        g_pos = g_pos + g_qp.view(B, Q, E).sum(0)
+        del g_aw, aw
+        g_qp_s = _lin(g_loc, _frag(layer, 'sso_n_t', p['sso'][0], None, lambda w_, b_: ((w_ / nrm[:, None]).t().contiguous(), None)))
+        _lin(g_lg, _frag(layer, 'sawt', p['saw'][0], None, _t), res=g_qp_s, out=g_qp_s)
+        wgrad('sso', g_loc, q2, post=lambda gw: gw / nrm[:, None], addend=pos)
+        if G['sso'][1] is not None:
+            G['sso'][1] = G['sso'][1] / nrm
+        wgrad('saw', g_lg, q2, addend=pos)
+        del g_loc, g_lg
+        g_pos = _capi.sum_leading(g_qp_c.view(B, Q, E), g_qp_s.view(B, Q, E)) if ctx.needs_input_grad[3] else None
+        del g_qp_c
         g_v2 = g_v.view(R, E)
-        g_q = _lin(g_v2, _frag(layer, 'svt', p['sv'][0], None, _t))
-        g_q.add_(g_x0).add_(g_qp)
+        g_q = _lin(g_v2, _frag(layer, 'svt', p['sv'][0], None, _t), res=g_x0)
+        g_q.add_(g_qp_s)
         wgrad('sv', g_v2, q2)
         flat = []
         for n in NAMES:
             flat += G[n]
         return (None, None, g_q.view(B, Q, E) if ctx.needs_input_grad[2] else None, g_pos if ctx.needs_input_grad[3] else None,
                 g_rows, g_d if ctx.needs_input_grad[5] else None, *flat)
+
+
+def _pos_table(bev_pos, Q, E):
+    """the (Q, E) positional table behind `bev_pos`.  The encoder hands over a (bs, Q, E) stride-0 expand of it
+    (positional_encoding.py:57-60); indexing that view would make autograd materialise a zero (bs, Q, E) gradient, copy one sample
+    into it and sum the batch away again (0.3 ms at 160 000 queries) -- the view's base IS the table, taken when the layouts agree"""
+    if bev_pos.dim() == 2:
+        return bev_pos
+    base = bev_pos._base
+    if (base is not None and bev_pos.stride(0) == 0 and bev_pos.stride(1) == E and bev_pos.stride(2) == 1 and base.numel() == Q * E and
+            base.is_contiguous() and base.data_ptr() == bev_pos.data_ptr() and base.shape[-1] == E):
+        return base.view(Q, E)
+    return bev_pos[0]
+
+
+def _so_perm_inv(da, perm):
+    if getattr(da, '_train_perm_inv_of', None) is not perm:
+        inv = torch.empty_like(perm)
+        inv[perm] = torch.arange(perm.numel(), device=perm.device)
+        da._train_perm_inv, da._train_perm_inv_of = inv, perm
+    return da._train_perm_inv
+
+
+def _offset_normalizer(layer, M, Ps, bw, bh, dev):
+    key = (M, Ps, bw, bh, str(dev))
+    if getattr(layer, '_train_nrm_key', None) != key:
+        layer._train_nrm = torch.tensor([float(bw), float(bh)], dtype=torch.float32).repeat(M * Ps).to(dev)
+        layer._train_nrm_key = key
+    return layer._train_nrm
+
+
+def _ref_rows(layer, ref2d, reps):
+    """(B, Q, 1, 2) reference points -> (B*Q, reps*2) rows (x, y, x, y, ...): the additive part of every sampling location of a query"""
+    key = (ref2d.data_ptr(), ref2d._version, tuple(ref2d.shape), reps)
+    if getattr(layer, '_train_ref_rows_key', None) != key:
+        B, Q = ref2d.shape[:2]
+        layer._train_ref_rows = ref2d.reshape(B * Q, 1, 2).expand(B * Q, reps, 2).reshape(B * Q, reps * 2).contiguous()
+        layer._train_ref_rows_key = key
+    return layer._train_ref_rows
 
 
 def _so_perm(da, M, L, P, dev):
@@ -473,6 +513,6 @@ def run_layer(layer, query, bev_pos, value_rows, pred_depth, ref_2d, ref_cam, ma
                qdepth=qdepth.squeeze(-1).contiguous().float(), ss=spatial_shapes.to(torch.int64).contiguous(),
                ls=level_start_index.to(torch.int64).contiguous(), hw=hw, min_w=min(w for _, w in hw), bev_h=bev_h, bev_w=bev_w,
                ss_self=BP.const_tensor([[bev_h, bev_w]], dev), ls_self=BP.const_tensor([0], dev))
-    pos = bev_pos[0] if bev_pos.dim() == 3 else bev_pos
+    pos = _pos_table(bev_pos, Q, E)
     depth4 = pred_depth.reshape(-1, DC, H0, W0)
     return EncoderLayerFn.apply(layer, geo, query, pos, value_rows, depth4, *layer_params(layer))

@@ -666,14 +666,33 @@ int fbbev_layernorm_bwd(const float* x, const float* grad_out, const float* weig
  * `grad_out.t().mm(x)` / `grad_out.sum(0)` behind every nn.Linear of bevformer_encoder.py:206-377 and
  * spatial_cross_attention_depth.py:432-436,464 -- vendor fp32 GEMMs + ATen reductions in the reference):
  *   grad_weight (out_features, in_features) = grad_out^T x,   grad_bias (out_features) = column sums of grad_out (NULL: skipped)
- * for grad_out (rows, out_features) and x (rows, in_features), row strides in floats (0 = dense).  Arithmetic: the split-operand bf16
+ * for grad_out (rows, out_features) and x (rows, in_features), row strides in floats (0 = dense); x_addend (period, in_features),
+ * optional: the layer's input rows were x[r] + x_addend[r % period] (query + query_pos, never materialised).  Arithmetic: the split-operand bf16
  * MFMA of fbbev_rows_linear_x3 (~1e-5 relative), rows split over workgroups, partial results summed in a FIXED order (bit-identical
  * run to run, no atomics) through `workspace` (fbbev_rows_wgrad_x3_ws_bytes bytes, 16-byte aligned).  in_features % 4 == 0,
  * out_features % 4 == 0, strides % 4 == 0, 16-byte aligned pointers, else FBBEV_E_UNSUPPORTED (ws_bytes returns 0). */
 size_t fbbev_rows_wgrad_x3_ws_bytes(long long rows, int in_features, int out_features);
-int fbbev_rows_wgrad_x3(const float* grad_out, long long ld_grad, const float* x, long long ldx, long long rows, int in_features,
-                        int out_features, float* grad_weight, float* grad_bias, void* workspace, size_t workspace_bytes,
-                        fbbev_stream_t stream);
+int fbbev_rows_wgrad_x3(const float* grad_out, long long ld_grad, const float* x, long long ldx, const float* x_addend,
+                        long long addend_row_stride, long long addend_period, long long rows, int in_features, int out_features,
+                        float* grad_weight, float* grad_bias, void* workspace, size_t workspace_bytes, fbbev_stream_t stream);
+
+/* Training epilogue of fbbev_rows_linear_x3 (same arithmetic, shapes and return codes):
+ *   out = ((x [+ addend[r % period]]) W^T + bias) [ReLU]) * [mask > 0] + residual
+ * mask (rows, out_features), optional: the saved output of a ReLU whose backward this product is (ATen threshold_backward folded
+ * into the dgrad's store); residual (rows, out_features), optional, MAY be `out` itself (a running sum of gradients): the forward
+ * recomputations and dgrads of the encoder layer's backward (bevformer_encoder.py:250-377 under autograd) without their
+ * neighbouring element-wise passes. */
+int fbbev_rows_linear_x3_train(const float* x, long long x_row_stride, const float* addend, long long addend_row_stride,
+                               long long addend_period, const void* fragments, const float* bias, long long rows, int in_features,
+                               int out_features, int relu, const float* residual, long long residual_row_stride, const float* mask,
+                               long long mask_row_stride, float* out, long long out_row_stride, fbbev_stream_t stream);
+
+/* out (N) = sum over b of x (B, N) [+ x2 (B, N)], ascending b, N % 4 == 0: the batch sum behind a parameter every sample shares
+ * (autograd's sum-to-size of `query + query_pos`, backward_projection.py:96-99 `lss_bev + bev_embedding`). */
+int fbbev_sum_leading(const float* x, const float* x2, int B, long long N, float* out, fbbev_stream_t stream);
+/* out (len) = sum over the n rows of part (n, len) in a fixed association: the per-workgroup partial parameter gradients of
+ * fbbev_layernorm_bwd (n = fbbev_layernorm_bwd_partials(rows), len = 2 C). */
+int fbbev_sum_partials(const float* part, int n, long long len, float* out, fbbev_stream_t stream);
 
 /* Row-wise linear layer  out[r, :] = x[r, :] . W^T + bias (+ ReLU)  for the (B*Q, C) query rows of the backward projection
  * (inference): replaces the F.linear calls of spatial_cross_attention_depth.py:533-540 (sampling_offsets, attention_weights),

@@ -634,7 +634,7 @@ def conv3d_k3s1_tiled_bf16(x, wfb, bias, Cout, relu=False, residual=None):
     return code, out
 
 
-def rows_wgrad_x3(grad_out, x, with_bias=True):
+def rows_wgrad_x3(grad_out, x, with_bias=True, addend=None):
     """fbbev_rows_wgrad_x3 on CPU tensors (row strides taken from the views) -> (code, grad_weight, grad_bias)"""
     R, O = grad_out.shape
     I = x.shape[1]
@@ -643,6 +643,36 @@ def rows_wgrad_x3(grad_out, x, with_bias=True):
     off = ((-ws.data_ptr()) % 16) // 4
     gw = torch.full((O, I), float('nan'))
     gb = torch.full((O,), float('nan')) if with_bias else None
-    code = lib().fbbev_rows_wgrad_x3(c_void_p(grad_out.data_ptr()), grad_out.stride(0), c_void_p(x.data_ptr()), x.stride(0), R, I, O,
+    code = lib().fbbev_rows_wgrad_x3(c_void_p(grad_out.data_ptr()), grad_out.stride(0), c_void_p(x.data_ptr()), x.stride(0),
+                                     None if addend is None else c_void_p(addend.data_ptr()), 0 if addend is None else addend.stride(0),
+                                     1 if addend is None else addend.shape[0], R, I, O,
                                      p(gw), p(gb) if gb is not None else None, c_void_p(ws.data_ptr() + 4 * off), need, None)
     return code, gw, gb
+
+
+def rows_linear_x3_train(x, weight, bias, relu=False, addend=None, residual=None, mask=None, out=None):
+    frag, fp = _fragments(weight)
+    R, I = x.shape
+    O = weight.shape[0]
+    if out is None:
+        out = torch.full((R, O), float('nan'))
+    code = lib().fbbev_rows_linear_x3_train(
+        c_void_p(x.data_ptr()), x.stride(0), None if addend is None else c_void_p(addend.data_ptr()),
+        0 if addend is None else addend.stride(0), 1 if addend is None else addend.shape[0], fp, p(bias) if bias is not None else None,
+        R, I, O, 1 if relu else 0, None if residual is None else c_void_p(residual.data_ptr()), 0 if residual is None else residual.stride(0),
+        None if mask is None else c_void_p(mask.data_ptr()), 0 if mask is None else mask.stride(0), c_void_p(out.data_ptr()), out.stride(0), None)
+    return code, out
+
+
+def sum_leading(x, x2=None):
+    B = x.shape[0]
+    out = torch.full(x.shape[1:], float('nan'))
+    code = lib().fbbev_sum_leading(p(x), p(x2) if x2 is not None else None, B, x.numel() // B, p(out), None)
+    return code, out
+
+
+def sum_partials(part):
+    n, ln = part.shape[0], part.numel() // part.shape[0]
+    out = torch.full((ln,), float('nan'))
+    code = lib().fbbev_sum_partials(p(part), n, ln, p(out), None)
+    return code, out

@@ -779,6 +779,57 @@ def test_rows_wgrad_split_operand_emulated(R, I, O, monkeypatch):
     assert code3 == 0 and gb3 is None and torch.equal(gw, gw3)
 
 
+def test_rows_wgrad_with_periodic_addend_emulated():
+    """x_addend: the layer's input was x[r] + addend[r % P] -- equal to the plain entry on the pre-added rows, bit for bit"""
+    g = torch.Generator().manual_seed(3)
+    Q, B, I, O = 75, 3, 80, 64
+    x, pos, gy = torch.randn(B * Q, I, generator=g), torch.randn(Q, I, generator=g), torch.randn(B * Q, O, generator=g)
+    c1, w1, b1 = E.rows_wgrad_x3(gy, x, addend=pos)
+    c2, w2, b2 = E.rows_wgrad_x3(gy, (x.view(B, Q, I) + pos[None]).reshape(B * Q, I).contiguous())
+    assert c1 == 0 and c2 == 0 and torch.equal(w1, w2) and torch.equal(b1, b2)
+
+
+def test_rows_linear_training_epilogue_emulated():
+    """fbbev_rows_linear_x3_train: ((x [+ addend]) W^T + b) [ReLU]) * [mask > 0] + residual against the plain entry + the torch
+    expressions (bit for bit: the same accumulators, one fp32 add), in place on the residual, partial tiles, two output chunks."""
+    g = torch.Generator().manual_seed(8)
+    R, I, O = 150, 80, 160
+    x, w, b = torch.randn(R, I, generator=g), torch.randn(O, I, generator=g) * 0.2, torch.randn(O, generator=g)
+    res, mask = torch.randn(R, O, generator=g), torch.randn(R, O, generator=g)
+    c0, plain = E.rows_linear_x3(x, w, b)
+    assert c0 == 0
+    c1, got = E.rows_linear_x3_train(x, w, b, residual=res, mask=mask)
+    assert c1 == 0 and torch.equal(got, torch.where(mask > 0, plain, torch.zeros(())) + res)
+    acc = res.clone()
+    c2, got2 = E.rows_linear_x3_train(x, w, b, residual=acc, out=acc)          # running sum, in place
+    assert c2 == 0 and got2 is acc and torch.equal(acc, plain + res)
+    c3, got3 = E.rows_linear_x3_train(x, w, None, relu=True)
+    c4, plain3 = E.rows_linear_x3(x, w, None, relu=True)
+    assert c3 == 0 and c4 == 0 and torch.equal(got3, plain3)
+    pos = torch.randn(50, I, generator=g)
+    c5, got5 = E.rows_linear_x3_train(x, w, b, addend=pos, residual=res)
+    c6, plain5 = E.rows_linear_x3(x, w, b, addend=pos)
+    assert c5 == 0 and c6 == 0 and torch.equal(got5, plain5 + res)
+
+
+def test_sum_leading_emulated():
+    g = torch.Generator().manual_seed(4)
+    x, y = torch.randn(3, 50, 8, generator=g), torch.randn(3, 50, 8, generator=g)
+    c, s = E.sum_leading(x)
+    assert c == 0 and torch.equal(s, x[0] + x[1] + x[2])
+    c, s2 = E.sum_leading(x, y)
+    assert c == 0 and torch.equal(s2, ((x[0] + y[0]) + x[1] + y[1]) + x[2] + y[2])
+
+
+def test_sum_partials_emulated():
+    g = torch.Generator().manual_seed(6)
+    part = torch.randn(100, 2, 20, generator=g)
+    c, s = E.sum_partials(part)
+    assert c == 0 and (s.view(2, 20).double() - part.double().sum(0)).abs().max() < 1e-5
+    c2, s2 = E.sum_partials(part)
+    assert torch.equal(s, s2)
+
+
 def test_rows_wgrad_rejects_unsupported_shapes():
     assert E.lib().fbbev_rows_wgrad_x3_ws_bytes(100, 6, 8) == 0            # in_features % 4 != 0
     assert E.lib().fbbev_rows_wgrad_x3_ws_bytes(100, 8, 6) == 0
