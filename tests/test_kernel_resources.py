@@ -50,7 +50,9 @@ def test_no_kernel_uses_scratch_or_spills(res):
     # the split DA backward kernels (~30 kernel arguments each) park more of their loop-invariant scalars there: one VGPR's worth
     # (round 5: the per-sample fixed-point scale added one more loop-carried value to k_da_cross_attn_bwd_unit: 65 parked scalars)
     # (k_rows_linear_x3: 23 kernel arguments; round 5's batched staging / epilogue loads park two more: 26)
-    lim = lambda k: 72 if ('k_da_cross_attn_bwd_' in k or 'k_da_cross_attn_fwd_pipe' in k) else (32 if 'k_rows_linear_x3I' in k else 24)  # noqa: E731
+    # (round 6: the training-epilogue instantiation <2, false, 1> has two more pointer arguments and their strides: 40)
+    lim = lambda k: 72 if ('k_da_cross_attn_bwd_' in k or 'k_da_cross_attn_fwd_pipe' in k) else (  # noqa: E731
+        48 if 'k_rows_linear_x3ILi2ELb0ELi1E' in k else (32 if 'k_rows_linear_x3I' in k else 24))
     over = {k: v.get('sgpr_spills', 0) for k, v in res.items() if v.get('sgpr_spills', 0) > lim(k)}
     assert not over, over
 

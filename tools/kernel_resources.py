@@ -23,9 +23,17 @@ def kernel_resources(lib=None):
     with tempfile.TemporaryDirectory() as tmp:
         fat, co = os.path.join(tmp, 'fat.bin'), os.path.join(tmp, 'k.co')
         subprocess.check_call(['objcopy', '-O', 'binary', '--only-section=.hip_fatbin', lib, fat])
-        subprocess.check_call([os.path.join(LLVM, 'clang-offload-bundler'), '--unbundle', '--type=o', '--input=' + fat,
-                               '--targets=hipv4-amdgcn-amd-amdhsa--gfx950', '--output=' + co])
-        notes = subprocess.check_output([os.path.join(LLVM, 'llvm-readelf'), '--notes', co], text=True)
+        # one offload bundle per translation unit of the library (capi.hip, capi_train.hip), back to back in the section
+        blob, magic = open(fat, 'rb').read(), b'__CLANG_OFFLOAD_BUNDLE__'
+        starts = [m.start() for m in re.finditer(re.escape(magic), blob)]
+        notes = ''
+        for k, st in enumerate(starts):
+            part = os.path.join(tmp, f'fat{k}.bin')
+            with open(part, 'wb') as f:
+                f.write(blob[st:starts[k + 1] if k + 1 < len(starts) else len(blob)])
+            subprocess.check_call([os.path.join(LLVM, 'clang-offload-bundler'), '--unbundle', '--type=o', '--input=' + part,
+                                   '--targets=hipv4-amdgcn-amd-amdhsa--gfx950', '--output=' + co])
+            notes += subprocess.check_output([os.path.join(LLVM, 'llvm-readelf'), '--notes', co], text=True) + '\n'
     keys = {'.vgpr_count': 'vgpr', '.agpr_count': 'agpr', '.sgpr_count': 'sgpr', '.group_segment_fixed_size': 'lds',
             '.private_segment_fixed_size': 'scratch', '.vgpr_spill_count': 'vgpr_spills', '.sgpr_spill_count': 'sgpr_spills',
             '.max_flat_workgroup_size': 'max_wg'}
