@@ -14,8 +14,8 @@ pytestmark = pytest.mark.gpu
 # element beyond 1e-4, median 4.4e-6 at an output scale of 4.8.  Bars = 2x observed; the query allowance stays above zero because
 # an in-image mask bit that flips between the CPU and GPU op orders is a property of the rig, not of the kernels.
 BP_FULL_BAD_QUERIES = 4
-BP_FULL_MAX_ERR = 1.5e-4
-BP_FULL_FRAC_1E4 = 1e-5
+BP_FULL_MAX_ERR = 1e-4          # round 6: north_star's own bar (observed 7.5e-5), not 2x observed
+BP_FULL_FRAC_1E4 = 0.0
 sys.path.insert(0, os.path.dirname(__file__))
 
 
@@ -184,7 +184,7 @@ def test_backward_projection_module_vs_oracle_at_baseline_config2_full_size(dev)
     """VERDICT r2 (untested sizes): BASELINE configs[2] through the MODULE at its full size -- bev 200x200 (Q = 40 000), the
     4-level pyramid 16x44 / 32x88 / 8x22 / 4x11 (level 0 = the depth net's level, spatial_cross_attention_depth.py:586),
     B = 1 -- against oracle/backward_projection_oracle.py (backward_projection.py:84-133, bevformer_encoder.py:250-377).
-    Bar: <= 1.5e-4 absolute on every element (output scale 4.8; observed 7.5e-5) except at most 4 queries whose borderline
+    Bar: <= 1e-4 absolute on every element (north_star's bar; output scale 4.8; observed 7.5e-5) except at most 4 queries whose borderline
     in-image mask bit flips between the CPU and GPU fp32 op orders (observed: none of 40 000); the statistics are printed."""
     bev = 200
     shapes = [(16, 44), (32, 88), (8, 22), (4, 11)]
