@@ -692,6 +692,37 @@ def reference_same_gpu_leg(dev, cfg, B, cam, depth, ctx, vt, idx, steps=10):
             's1_equals_s2_volume_within_1e-4': close}
 
 
+def device_identity(dev):
+    """Which physical GPU this process drives, for the reader of a driver-side utilisation sample (VERDICT r5 hygiene: BENCH_r05's
+    `gpu_busy` read 0 % on card0 while the kernel traces prove the work ran): marketing name, PCI bus id, the sysfs card that carries
+    that bus id and its gpu_busy_percent read WHILE warm-up steps are queued (0 here too would mean the sampler, not the run)."""
+    import glob
+    import torch
+    out = {}
+    try:
+        pr = torch.cuda.get_device_properties(dev)
+        out['name'] = pr.name
+        out['compute_units'] = getattr(pr, 'multi_processor_count', None)
+        dom, bus, devid = getattr(pr, 'pci_domain_id', None), getattr(pr, 'pci_bus_id', None), getattr(pr, 'pci_device_id', None)
+        if bus is not None:
+            out['pci_bus_id'] = f'{dom or 0:04x}:{bus:02x}:{devid or 0:02x}.0'
+        for card in sorted(glob.glob('/sys/class/drm/card[0-9]*')):
+            try:
+                addr = os.path.basename(os.path.realpath(os.path.join(card, 'device')))
+            except OSError:
+                continue
+            if out.get('pci_bus_id') and addr.lower() == out['pci_bus_id'].lower():
+                out['sysfs_card'] = os.path.basename(card)
+                try:
+                    out['gpu_busy_percent_during_warmup'] = int(open(os.path.join(card, 'device', 'gpu_busy_percent')).read().strip())
+                except (OSError, ValueError):
+                    pass
+        out['visible_devices_env'] = {k: os.environ[k] for k in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES') if k in os.environ}
+    except Exception as e:
+        out['error'] = f'{type(e).__name__}: {e}'[:160]
+    return out
+
+
 def run_forward(args):
     import torch
     import torch.distributed as dist
@@ -801,6 +832,12 @@ def run_forward(args):
         for _ in range(args.warmup):
             idx = step()
     fence()
+    dev_id = None
+    if rank == 0:                               # outside the timed region: queue a burst of steps and read the card's own busy counter under it
+        for _ in range(20):
+            step()
+        dev_id = device_identity(dev)
+        fence()
     with no_gc():
         t0 = time.perf_counter()
         for i in range(args.steps):
@@ -1081,7 +1118,7 @@ def run_forward(args):
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
             'step_gpu_ms_p10_p50_p90': [pct(0.1), pct(0.5), pct(0.9)],
             'scaling': 'weak', 'vs_baseline': None, 'dtype': args.storage, 'accumulate_dtype': 'f32', 'data': 'synthetic',
-            'rccl_ranks': ranks, 'rank_devices': devices,
+            'rccl_ranks': ranks, 'rank_devices': devices, 'device': dev_id,
             'launch': ('index build (geometry + ranking + NCHW->NHWC + tile index: ~10 short kernels) replayed from one captured hipGraph '
                        'per step, pooling kernel launched eagerly between the HIP events that time it' if graph is not None else
                        'every kernel launched one by one from the host'),

@@ -93,6 +93,8 @@ SIGNATURES = {
                                            c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
     'fbbev_sum_leading': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p]),
     'fbbev_sum_partials': (c_int, [c_void_p, c_int, c_int64, c_void_p, c_void_p]),
+    'fbbev_diag_fill': (c_int, [c_void_p, c_int64, c_int, c_void_p]),
+    'fbbev_touch': (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     'fbbev_layernorm_bwd_partials': (c_int, [c_int64]),
     'fbbev_layernorm_bwd': (c_int, [c_void_p] * 3 + [c_float, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     'fbbev_history_conv': (c_int, [c_void_p, c_int64] + [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -1200,6 +1202,17 @@ def layernorm_bwd(x, grad_out, weight, eps):
     with _on(x):          # fixed-order sum of the partial rows (ATen's dim-0 reduction of this shape is one latency chain per column)
         _check(lib().fbbev_sum_partials(_dev(partial, F32, 'partial'), n, 2 * C, _dev(gwb, F32, 'out'), _stream()), 'fbbev_sum_partials')
     return grad_x, gwb[0], gwb[1]
+
+
+def touch(*tensors):
+    """fbbev_touch: read up to 8 device tensors once (a read-ahead of a later kernel's gather sources); values unused"""
+    ts = [t for t in tensors if t is not None and t.numel() > 0][:8]
+    if not ts:
+        return
+    ptrs = (c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    nbytes = (c_size_t * len(ts))(*[t.numel() * t.element_size() for t in ts])
+    with _on(ts[0]):
+        _check(lib().fbbev_touch(ptrs, nbytes, len(ts), _stream()), 'fbbev_touch')
 
 
 def rows_linear_x3_train(x, fragments, bias, out_features, relu=False, addend=None, residual=None, mask=None, out=None):

@@ -1524,7 +1524,11 @@ static int da_cross_attn_fused_impl(const float* planes, const int64_t* spatial_
 #else
     static const int stage_floats = read_stage();
 #endif
-    const size_t lds = fbbev_daf_lds_bytes(E, hw, Ncam, stage_floats);
+    // (fbbev_da_cross_attn_fused_supported budgets LDS WITHOUT the staging region -- a launch whose staged layout does not
+    // fit (8 heads per workgroup with ~25+ cameras) runs unstaged instead of failing after the probe said yes)
+    int stage_eff = stage_floats;
+    if (fbbev_daf_lds_bytes(E, hw, Ncam, stage_eff) > 160 * 1024) stage_eff = 0;
+    const size_t lds = fbbev_daf_lds_bytes(E, hw, Ncam, stage_eff);
     if (lds > 160 * 1024) return FBBEV_E_UNSUPPORTED;
     static const bool pre_off = [] { const char* e = getenv("FBBEV_DA_FUSED_PRE"); return e && atoi(e) == 0; }();   // A/B knob, read once
     static const int diag = [] {                                                         // timing diagnostics (wrong results), read once
@@ -1533,7 +1537,7 @@ static int da_cross_attn_fused_impl(const float* planes, const int64_t* spatial_
         if (v) fprintf(stderr, "libfbbev_hip: FBBEV_DA_FUSED_DIAG=%d -- fbbev_da_cross_attn_fused runs its timing-diagnostic build: RESULTS ARE WRONG BY DESIGN\n", v);
         return v;
     }();
-    const int stage_arg = stage_floats | (pre_off ? 0x40000000 : 0) | (diag << 24);
+    const int stage_arg = stage_eff | (pre_off ? 0x40000000 : 0) | (diag << 24);
 #define FBBEV_DA_FUSED(DH_, NP_, HW_) FBBEV_DA_FUSED3(DH_, NP_, HW_, false, 0)
 #define FBBEV_DA_FUSED2(DH_, NP_, HW_, OP_) FBBEV_DA_FUSED3(DH_, NP_, HW_, OP_, 0)
 #define FBBEV_DA_FUSED3(DH_, NP_, HW_, OP_, ET_)                                                                       \
@@ -2891,7 +2895,10 @@ extern "C" int fbbev_rows_linear_x3_planes(const float* x, long long x_row_strid
                                            long long rows, int in_features, int out_features, int tokens_per_image, int head_dim,
                                            float* out, fbbev_stream_t stream_) {
     if (tokens_per_image <= 0 || head_dim <= 0 || out_features <= 0) return FBBEV_E_BADARG;
-    if (head_dim % 2 != 0 || out_features % head_dim != 0 || rows % tokens_per_image != 0) return FBBEV_E_UNSUPPORTED;
+    // (the head-plane epilogue divides by head_dim through a 32-bit reciprocal, exact for outputs < 2^16, and packs the element
+    // type above bit 16 of its head-width argument)
+    if (head_dim % 2 != 0 || out_features % head_dim != 0 || rows % tokens_per_image != 0 || head_dim > 0xffff || out_features > 0xffff)
+        return FBBEV_E_UNSUPPORTED;
     if (out && ((uintptr_t)out & 7) != 0) return FBBEV_E_UNSUPPORTED;
     return rows_linear_x3_impl(x, x_row_stride, fragments, bias, rows, in_features, out_features, 0, out, 0, nullptr, 0, 1, stream_,
                                tokens_per_image, head_dim);
@@ -2903,7 +2910,8 @@ extern "C" int fbbev_rows_linear_x3_planes_e(const float* x, long long x_row_str
                                              long long rows, int in_features, int out_features, int tokens_per_image, int head_dim,
                                              int elem_type, void* out, fbbev_stream_t stream_) {
     if (tokens_per_image <= 0 || head_dim <= 0 || out_features <= 0 || elem_type < 0 || elem_type > 2) return FBBEV_E_BADARG;
-    if (head_dim % 2 != 0 || out_features % head_dim != 0 || rows % tokens_per_image != 0 || head_dim > 0xffff) return FBBEV_E_UNSUPPORTED;
+    if (head_dim % 2 != 0 || out_features % head_dim != 0 || rows % tokens_per_image != 0 || head_dim > 0xffff || out_features > 0xffff)
+        return FBBEV_E_UNSUPPORTED;
     if (out && ((uintptr_t)out & (elem_type ? 3 : 7)) != 0) return FBBEV_E_UNSUPPORTED;
     if (out && !aligned16(out)) return FBBEV_E_UNSUPPORTED;
     return rows_linear_x3_impl(x, x_row_stride, fragments, bias, rows, in_features, out_features, 0, static_cast<float*>(out), 0, nullptr, 0,

@@ -119,3 +119,74 @@ extern "C" int fbbev_sum_partials(const float* part, int n, long long len, float
     FBBEV_CHECK_LAUNCH();
     return 0;
 }
+
+// diagnostics (tools/dbg_store_policy.py): fill n floats with 16-byte stores of cache policy `policy` (fbbev_store4: 0 plain, 1 nt, 2 sc1,
+// 3 sc0 sc1, 4 sc1 nt, 5 sc0 nt, 6 sc0 sc1 nt, 7 sc0) -- what a kernel's stores leave behind for the NEXT kernel's store stream
+template <int ST>
+__global__ void __launch_bounds__(256)
+k_diag_fill(float* __restrict__ p, long long n4, float v) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256)
+        fbbev_store4<ST>(p + 4 * i, fbbev_v4f{v, v, v, v});
+}
+extern "C" int fbbev_diag_fill(float* p, long long n, int policy, fbbev_stream_t stream_) {
+    if (!p || n < 0 || n % 4 != 0 || policy < 0 || policy > 7 || !aligned16(p)) return FBBEV_E_BADARG;
+    if (n == 0) return 0;
+    const long long n4 = n / 4;
+    long long blocks = (n4 + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    fbbev_rt_stream stream = (fbbev_rt_stream)stream_;
+    switch (policy) {
+    case 0: FBBEV_LAUNCH(k_diag_fill<0>, blocks, 256, 0, stream, p, n4, 1.f); break;
+    case 1: FBBEV_LAUNCH(k_diag_fill<1>, blocks, 256, 0, stream, p, n4, 1.f); break;
+    case 2: FBBEV_LAUNCH(k_diag_fill<2>, blocks, 256, 0, stream, p, n4, 1.f); break;
+    case 3: FBBEV_LAUNCH(k_diag_fill<3>, blocks, 256, 0, stream, p, n4, 1.f); break;
+    case 4: FBBEV_LAUNCH(k_diag_fill<4>, blocks, 256, 0, stream, p, n4, 1.f); break;
+    case 5: FBBEV_LAUNCH(k_diag_fill<5>, blocks, 256, 0, stream, p, n4, 1.f); break;
+    case 6: FBBEV_LAUNCH(k_diag_fill<6>, blocks, 256, 0, stream, p, n4, 1.f); break;
+    default: FBBEV_LAUNCH(k_diag_fill<7>, blocks, 256, 0, stream, p, n4, 1.f); break;
+    }
+    FBBEV_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------ read-ahead of a kernel's gather sources
+// The dense pooling kernel at the END of the forward-backward step gathers through index tensors, depth and feature rows that were
+// written ~1 ms and ~0.7 GB of intermediate traffic earlier: they have left the 256 MB memory-side cache, and the kernel's dependent
+// gather chains run at HBM latency (tools/dbg_pool_in_step.py: 260 us cold, 176 us with the ~30 MB of sources read once right before).
+// fbbev_touch reads up to 8 spans with 16-byte loads and discards them: the lines are back in the memory-side cache (and the L2s) when
+// the gathers start.
+struct fbbev_touch_spans { const char* p[8]; unsigned long long n16[8]; };
+template <int UNUSED>
+__global__ void __launch_bounds__(256)
+k_touch(fbbev_touch_spans sp, int n) {
+    fbbev_v4u acc = {0u, 0u, 0u, 0u};
+    for (int k = 0; k < n; ++k) {
+        const fbbev_v4u* q = reinterpret_cast<const fbbev_v4u*>(sp.p[k]);
+        for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < sp.n16[k]; i += (unsigned long long)gridDim.x * 256) {
+            const fbbev_v4u v = q[i];
+            acc[0] |= v[0]; acc[1] |= v[1]; acc[2] |= v[2]; acc[3] |= v[3];
+        }
+    }
+    fbbev_opaque_u32(acc[0] | acc[1] | acc[2] | acc[3]);                                 // the loads are used; nothing is stored
+}
+extern "C" int fbbev_touch(const void* const* spans, const size_t* bytes, int n, fbbev_stream_t stream_) {
+    if (n < 0 || n > 8 || (n > 0 && (!spans || !bytes))) return FBBEV_E_BADARG;
+    fbbev_touch_spans sp;
+    unsigned long long total = 0;
+    int m = 0;
+    for (int k = 0; k < n; ++k) {
+        if (!spans[k] || bytes[k] < 16) continue;
+        const uintptr_t a = (reinterpret_cast<uintptr_t>(spans[k]) + 15u) & ~(uintptr_t)15u;      // whole 16-byte pieces inside the span
+        const size_t skip = a - reinterpret_cast<uintptr_t>(spans[k]);
+        sp.p[m] = reinterpret_cast<const char*>(a);
+        sp.n16[m] = (bytes[k] - skip) / 16;
+        total += sp.n16[m];
+        ++m;
+    }
+    if (m == 0 || total == 0) return 0;
+    unsigned long long blocks = (total + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    FBBEV_LAUNCH(k_touch<0>, blocks, 256, 0, (fbbev_rt_stream)stream_, sp, m);
+    FBBEV_CHECK_LAUNCH();
+    return 0;
+}

@@ -333,7 +333,7 @@ __device__ __forceinline__ void fbbev_daf_outproj_ln(const fbbev_daf_outproj& op
         fbbev_v4f y;
 #pragma unroll
         for (int e = 0; e < 4; ++e) y[e] = v[mt][e] * inv * w4[e] + b4[e];
-        *reinterpret_cast<fbbev_v4f*>(out + row * ldo + o) = y;
+        fbbev_st(reinterpret_cast<fbbev_v4f*>(out + row * ldo + o), y);
     }
 }
 
@@ -701,7 +701,7 @@ k_da_cross_attn_fused(const float* __restrict__ planes /* ET != 0: 16-bit elemen
         for (int c = 0; c < DH / 2; ++c) {
             fbbev_v2f r;
             r[0] = acc[c][0] / inv; r[1] = acc[c][1] / inv;
-            *reinterpret_cast<fbbev_v2f*>(dst + 2 * c) = r;
+            fbbev_st(reinterpret_cast<fbbev_v2f*>(dst + 2 * c), r);
         }
     }
 }
@@ -858,6 +858,6 @@ k_msda_self_fused(const float* __restrict__ planes, const float* __restrict__ re
         if (!valid) return;
         float* dst = out + bq * E + m * DH;
 #pragma unroll
-        for (int c = 0; c < DH / 2; ++c) *reinterpret_cast<fbbev_v2f*>(dst + 2 * c) = acc[c];
+        for (int c = 0; c < DH / 2; ++c) fbbev_st(reinterpret_cast<fbbev_v2f*>(dst + 2 * c), acc[c]);
     }
 }

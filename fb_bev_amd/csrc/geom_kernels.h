@@ -117,7 +117,7 @@ k_nchw_to_nhwc_levels(fbbev_token_levels lv, float* __restrict__ out, int C, int
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int p = th * 32 + ly + 8 * k;
-        if (cb < C && p < HW) dst[(long long)p * C + cb] = tile[lx][ly + 8 * k] + add;
+        if (cb < C && p < HW) fbbev_st(dst + (long long)p * C + cb, tile[lx][ly + 8 * k] + add);
     }
 }
 
@@ -173,9 +173,9 @@ k_point_sampling(const float* __restrict__ xs, const float* __restrict__ ys, con
         const float u = ux / ogfW, v = uy / ogfH;
         const bool ok = (uz > eps) && (u > eps) && (u < (1.0f - eps)) && (v > eps) && (v < (1.0f - eps));
         const long long o = ((long long)(n * B + b)) * npts + i;   // (N,B,Q=Y*X,Za)
-        *reinterpret_cast<fbbev_v2f*>(ref_cam + o * 2) = fbbev_v2f{u, v};
-        mask[o] = ok ? 1 : 0;
-        qdepth[o] = uz;
+        fbbev_st(reinterpret_cast<fbbev_v2f*>(ref_cam + o * 2), fbbev_v2f{u, v});
+        fbbev_st(mask + o, (unsigned char)(ok ? 1 : 0));
+        fbbev_st(qdepth + o, uz);
     }
 }
 
@@ -208,7 +208,7 @@ k_nchw_to_nhwc(const float* __restrict__ in, float* __restrict__ out, int C, int
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int p = th * 32 + ly + 8 * k;
-            if (cb < C && p < HW) dst[(long long)p * C + cb] = tile[lx][ly + 8 * k] + pos_bias[(long long)p * C + cb];
+            if (cb < C && p < HW) fbbev_st(dst + (long long)p * C + cb, tile[lx][ly + 8 * k] + pos_bias[(long long)p * C + cb]);
         }
         return;
     }
@@ -216,7 +216,7 @@ k_nchw_to_nhwc(const float* __restrict__ in, float* __restrict__ out, int C, int
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int p = th * 32 + ly + 8 * k;
-            if (cb < C && p < HW) dst[(long long)p * C + cb] = tile[lx][ly + 8 * k];
+            if (cb < C && p < HW) fbbev_st(dst + (long long)p * C + cb, tile[lx][ly + 8 * k]);
         }
         return;
     }
@@ -224,6 +224,6 @@ k_nchw_to_nhwc(const float* __restrict__ in, float* __restrict__ out, int C, int
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int p = th * 32 + ly + 8 * k;
-        if (cb < C && p < HW) dst[(long long)p * C + cb] = tile[lx][ly + 8 * k] + add;
+        if (cb < C && p < HW) fbbev_st(dst + (long long)p * C + cb, tile[lx][ly + 8 * k] + add);
     }
 }

@@ -55,6 +55,23 @@ __device__ __forceinline__ void fbbev_store4(float* p, fbbev_v4f v) {
     }
 }
 
+// Stores of the backward projection's INTERMEDIATE tensors (token rows, head planes, attention outputs, the refined BEV).  Round 6
+// (tools/dbg_store_policy.py, profiles/r06_exp_store_policy.md): a kernel that writes with plain stores parks its lines dirty in the 256 MB
+// memory-side cache, and the NEXT streaming kernel pays for their write-back (the dense pooling kernel: 166 us behind 512 MB of `nt`
+// stores, 287 us behind the same bytes stored plain).  FBBEV_STREAM_STORES=1 (build flag) makes these stores non-temporal: the
+// latency-bound attention kernels write through while HBM is idle.  Values are unaffected.
+#ifndef FBBEV_STREAM_STORES
+#define FBBEV_STREAM_STORES 0
+#endif
+template <typename T>
+__device__ __forceinline__ void fbbev_st(T* p, T v) {
+#if FBBEV_STREAM_STORES
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
 __device__ __forceinline__ void fbbev_atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }
 // 64-bit integer add on an LDS word pair (ds_add_u64, no return value): 22 lane-adds per ns and CU on gfx950 where
 // ds_add_f32 manages 0.8 (profiles/r02_micro_lds_atomics.jsonl)
@@ -147,6 +164,7 @@ __device__ __forceinline__ float fbbev_div(float a, float b) { return __fdiv_rn(
 
 // value barrier: the compiler must materialise x here and may not look through it (used where an LDS load followed by a
 // conditional global override of the same variable was if-converted into ONE flat load of a selected pointer)
+__device__ __forceinline__ void fbbev_opaque_u32(unsigned int x) { asm volatile("" : : "v"(x)); }
 __device__ __forceinline__ void fbbev_opaque(int& x) { asm volatile("" : "+v"(x)); }
 __device__ __forceinline__ void fbbev_opaque(float& x) { asm volatile("" : "+v"(x)); }
 // ordering point for a software pipeline: x must be COMPUTED here, and no memory operation moves across (the "memory"

@@ -935,7 +935,7 @@ k_pool_zmean(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_blocks
         if (j < nv) {
             fbbev_v4f val = *reinterpret_cast<const fbbev_v4f*>(tile + c * LD + j);
             val[0] /= zf; val[1] /= zf; val[2] /= zf; val[3] /= zf;
-            *reinterpret_cast<fbbev_v4f*>(ob + (long long)c * YX + j) = val;
+            fbbev_st(reinterpret_cast<fbbev_v4f*>(ob + (long long)c * YX + j), val);
         }
     }
 }
@@ -1123,7 +1123,7 @@ k_pool_zmean_col(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_bl
         if (j < nv) {
             fbbev_v4f val = *reinterpret_cast<const fbbev_v4f*>(tile + c * LD + j);
             val[0] /= zf; val[1] /= zf; val[2] /= zf; val[3] /= zf;
-            *reinterpret_cast<fbbev_v4f*>(ob + (long long)c * YX + j) = val;
+            fbbev_st(reinterpret_cast<fbbev_v4f*>(ob + (long long)c * YX + j), val);
         }
     }
 }
@@ -1136,7 +1136,7 @@ k_pool_zmean_reduce(const float* __restrict__ partial, long long n, int z_groups
     fbbev_v4f acc = *reinterpret_cast<const fbbev_v4f*>(partial + i);
     for (int g = 1; g < z_groups; ++g) acc += *reinterpret_cast<const fbbev_v4f*>(partial + (long long)g * n + i);
     acc[0] /= zf; acc[1] /= zf; acc[2] /= zf; acc[3] /= zf;
-    *reinterpret_cast<fbbev_v4f*>(out + i) = acc;
+    fbbev_st(reinterpret_cast<fbbev_v4f*>(out + i), acc);
 }
 
 // out[bc][i] = (vol[bc][0][i] + vol[bc][1][i] + ... in z order) / divisor over a (B*C, Z, Y*X) volume: the Z-mean of the training

@@ -180,7 +180,7 @@ k_rows_linear_x3(const float* __restrict__ x, long long ldx, const unsigned shor
                         fbbev_v4f y;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) y[e] = v[mt][e] * inv * w4[e] + b4[e];
-                        *reinterpret_cast<fbbev_v4f*>(out + r * ldo + o) = y;
+                        fbbev_st(reinterpret_cast<fbbev_v4f*>(out + r * ldo + o), y);
                     }
                 }
             }
@@ -228,7 +228,7 @@ k_rows_linear_x3(const float* __restrict__ x, long long ldx, const unsigned shor
                         if (relu) v = fbbev_v4f{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = (pm[q][e] > 0.f ? v[e] : 0.f) + pr[q][e];
-                        *reinterpret_cast<fbbev_v4f*>(out + r * ldo + o) = v;
+                        fbbev_st(reinterpret_cast<fbbev_v4f*>(out + r * ldo + o), v);
                     }
                 }
             }
@@ -268,16 +268,16 @@ k_rows_linear_x3(const float* __restrict__ x, long long ldx, const unsigned shor
                         const long long at = row_at[t] + (long long)hd * head_stride + ch;
                         if (pet) {
                             const unsigned int pk = pet == 1 ? fbbev_cvt_pk16<1>(v[e], v[e + 1]) : fbbev_cvt_pk16<2>(v[e], v[e + 1]);
-                            *reinterpret_cast<unsigned int*>(reinterpret_cast<unsigned short*>(out) + at) = pk;
+                            fbbev_st(reinterpret_cast<unsigned int*>(reinterpret_cast<unsigned short*>(out) + at), pk);
                         } else {
                             fbbev_v2f pr;
                             pr[0] = v[e]; pr[1] = v[e + 1];
-                            *reinterpret_cast<fbbev_v2f*>(out + at) = pr;
+                            fbbev_st(reinterpret_cast<fbbev_v2f*>(out + at), pr);
                         }
                     }
                     continue;
                 }
-                *reinterpret_cast<fbbev_v4f*>(out + r * ldo + o) = v;
+                fbbev_st(reinterpret_cast<fbbev_v4f*>(out + r * ldo + o), v);
             }
         }
     }
@@ -671,7 +671,7 @@ k_rows_ffn_x3(const float* __restrict__ x, long long ldx, const unsigned short* 
 #pragma unroll
         for (int mt = 0; mt < MT2; ++mt) {
             const int o = 16 * mt + 4 * g;
-            if (o < O) *reinterpret_cast<fbbev_v4f*>(out + r * ldo + o) = v[mt];
+            if (o < O) fbbev_st(reinterpret_cast<fbbev_v4f*>(out + r * ldo + o), v[mt]);
         }
     }
 }

@@ -137,8 +137,8 @@ def ln_fusable(norm, residual, x, out_features):
     the residual (if any) has the output's shape with dense rows, out_features <= 128."""
     w, b = getattr(norm, 'weight', None), getattr(norm, 'bias', None)
     if (w is None or b is None or tuple(getattr(norm, 'normalized_shape', ())) != (out_features,) or out_features > 128 or
-            w.dtype != torch.float32 or not w.is_cuda):
-        return False
+            w.dtype != torch.float32 or not w.is_cuda or w.data_ptr() % 16 != 0 or b.data_ptr() % 16 != 0):
+        return False           # (ADVICE r5: LayerNorm parameters that are views into a flat buffer may be misaligned -> the two-kernel path)
     if residual is not None and (residual.shape[:-1] != x.shape[:-1] or residual.shape[-1] != out_features or
                                  residual.dtype != torch.float32 or not residual.is_contiguous() or residual.data_ptr() % 16 != 0):
         return False           # (a storage-offset residual takes the separate LayerNorm: ADVICE r4)

@@ -141,6 +141,8 @@ class LiftSplat(torch.autograd.Function):
 
 
 import os as _os
+POOL_READ_AHEAD = _os.environ.get('FBBEV_POOL_READ_AHEAD', '1') != '0'   # A/B knob: read the final pooling's gather sources once before it
+POOL_READ_AHEAD_MIN_QUERIES = int(_os.environ.get('FBBEV_POOL_READ_AHEAD_MIN_QUERIES', '120000'))
 _ZMEAN_CSPLIT = int(_os.environ.get('FBBEV_ZMEAN_CSPLIT', '0'))      # tuning knob: channel groups of the Z-mean kernel
 _ZMEAN_ZGROUPS = int(_os.environ.get('FBBEV_ZMEAN_ZGROUPS', '0'))    # tuning knob: workgroups the Z planes of a tile are dealt to (0 = heuristic)
 
@@ -498,6 +500,13 @@ class LSSViewTransformerFunction3D(nn.Module):
         B, C = depth.shape[0], feat.shape[-1]
         Z, Y, X = self.grid_zyx
         out = torch.empty((B, C, Z, Y, X), dtype=self.out_dtype, device=depth.device)
+        if addend is not None and POOL_READ_AHEAD and B * Y * X >= POOL_READ_AHEAD_MIN_QUERIES:
+            # round 6: this call comes ~1 ms and ~0.7 GB of intermediate traffic after `parts` was built -- the kernel's gather sources
+            # have left the memory-side cache and its dependent gather chains would run at HBM latency (tools/dbg_pool_in_step.py:
+            # 260 -> 176 us at BASELINE configs[2], B = 4): read the ~30 MB once, right before.  S3 1.169 -> 1.077 ms there; at B = 1 and at
+            # the shipped grid (<= 40 000 queries: the step's intermediates fit the 256 MB cache, and the eager step is host-bound) the extra
+            # launch costs 4-40 us: only for large steps (profiles/r06_exp_pool_read_ahead.md)
+            _capi.touch(idx.ranks_depth, idx.ranks_feat, idx.interval_rank, idx.interval_starts, idx.interval_lengths, depth, feat, tile_ws)
         _capi.bev_pool_v2_dense_fwd(depth, feat, idx.ranks_depth, idx.ranks_feat, idx.interval_rank, idx.interval_starts,
                                     idx.interval_lengths, B, C, Z, Y, X, out, tile_ws, self._wo_tile, self.pool_flags,
                                     addend=None if addend is None else addend.contiguous().float())

@@ -690,6 +690,15 @@ int fbbev_rows_linear_x3_train(const float* x, long long x_row_stride, const flo
 /* out (N) = sum over b of x (B, N) [+ x2 (B, N)], ascending b, N % 4 == 0: the batch sum behind a parameter every sample shares
  * (autograd's sum-to-size of `query + query_pos`, backward_projection.py:96-99 `lss_bev + bev_embedding`). */
 int fbbev_sum_leading(const float* x, const float* x2, int B, long long N, float* out, fbbev_stream_t stream);
+/* Read-ahead of a kernel's gather sources: reads up to 8 spans (pointer, bytes) once with 16-byte loads and discards the data, so that
+ * the lines are back in the memory-side cache when a later kernel's dependent gathers start (the dense pooling at the end of the
+ * forward-backward step: its index tensors, depth and feature rows were written ~0.7 GB of intermediate traffic earlier).  Values
+ * are never used; no effect on results. */
+int fbbev_touch(const void* const* spans, const size_t* bytes, int n, fbbev_stream_t stream);
+
+/* Diagnostics: fill n floats (n % 4 == 0) with 16-byte stores of one cache policy (0 plain, 1 nt, 2 sc1, 3 sc0 sc1, 4 sc1 nt, 5 sc0 nt,
+ * 6 sc0 sc1 nt, 7 sc0): measures what a kernel's stores leave behind for the next kernel's store stream (tools/dbg_store_policy.py). */
+int fbbev_diag_fill(float* p, long long n, int policy, fbbev_stream_t stream);
 /* out (len) = sum over the n rows of part (n, len) in a fixed association: the per-workgroup partial parameter gradients of
  * fbbev_layernorm_bwd (n = fbbev_layernorm_bwd_partials(rows), len = 2 C). */
 int fbbev_sum_partials(const float* part, int n, long long len, float* out, fbbev_stream_t stream);
@@ -747,7 +756,8 @@ int fbbev_rows_tail_ffn_x3(const float* x, long long x_row_stride, const void* w
                            float* out, long long out_row_stride, fbbev_stream_t stream);
 /* fbbev_rows_linear_x3 with the result written as HEAD PLANES: rows = (B*Ncam) x tokens_per_image camera tokens, out_features =
  * M * head_dim in the module's (head, channel) order, out (B*Ncam, M, tokens_per_image, head_dim) -- the value_proj of the
- * cross-attention feeding fbbev_da_cross_attn_fused (spatial_cross_attention_depth.py:522-530). */
+ * cross-attention feeding fbbev_da_cross_attn_fused (spatial_cross_attention_depth.py:522-530).  head_dim even, <= 65535 and
+ * out_features <= 65535 (the epilogue's index arithmetic), else FBBEV_E_UNSUPPORTED. */
 int fbbev_rows_linear_x3_planes(const float* x, long long x_row_stride, const void* fragments, const float* bias,
                                 long long rows, int in_features, int out_features, int tokens_per_image, int head_dim,
                                 float* out, fbbev_stream_t stream);

@@ -178,6 +178,7 @@ typedef float fbbev_v2f __attribute__((vector_size(8)));
 typedef unsigned int fbbev_v4u __attribute__((vector_size(16)));
 typedef int fbbev_v4i __attribute__((vector_size(16)));
 template <int ST> inline void fbbev_store4(float* p, fbbev_v4f v) { memcpy(p, &v, 16); }
+template <typename T> inline void fbbev_st(T* p, T v) { *p = v; }
 inline void fbbev_atomic_add_f32(float* p, float v) { *p += v; }
 inline void fbbev_lds_atomic_add_f32(float* p, float v) { *p += v; }
 inline void fbbev_lds_atomic_add_i64(long long* p, long long v) { *p += v; }
@@ -276,3 +277,4 @@ template <unsigned int K>
 inline unsigned int fbbev_mad_u24_vks(unsigned int a, unsigned int c) { return (unsigned int)((unsigned long long)(a & 0xffffffu) * K) + c; }
 inline fbbev_v4f fbbev_gld_v4f(const float* p) { return *reinterpret_cast<const fbbev_v4f*>(p); }
 inline fbbev_v4f fbbev_lds_ld_v4f_a8(const float* p) { return fbbev_v4f{p[0], p[1], p[2], p[3]}; }
+inline void fbbev_opaque_u32(unsigned int x) { volatile unsigned int sink = x; (void)sink; }

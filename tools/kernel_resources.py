@@ -60,6 +60,9 @@ def kernel_resources(lib=None):
 
 
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1].startswith('-'):
+        raise SystemExit(f'{sys.argv[1]!r} looks like an option; this tool takes one optional OUTPUT PATH (a past `--all` / `--help` call '
+                         'left files of those names in the repo root)')
     res = kernel_resources()
     if len(sys.argv) > 1:
         json.dump(res, open(sys.argv[1], 'w'), indent=0, sort_keys=True)
