@@ -126,6 +126,9 @@ SIGNATURES = {
                                    [c_void_p, c_void_p, c_size_t, c_void_p]),
     'fbbev_da_cross_attn_bwd_ws_grid': (c_int, [c_void_p] * 10 + [c_int] * 10 + [c_float, c_float, c_int, c_int] + [c_void_p] * 4 +
                                         [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    'fbbev_da_cross_attn_bwd_planes': (c_int, [c_void_p] * 10 + [c_int] * 10 + [c_float, c_float, c_int, c_int] + [c_void_p] * 4 +
+                                       [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    'fbbev_da_cross_attn_bwd_planes_supported': (c_int, [c_int] * 10 + [c_void_p, c_int]),
     'fbbev_msda_fwd_fused': (c_int, [c_void_p] * 6 + [c_int] * 9 + [c_void_p, c_void_p]),
     'fbbev_msda_bwd': (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p] * 3 + [c_void_p]),
     'fbbev_msda_bwd_ws_bytes': (c_size_t, [c_int] * 7 + [c_void_p]),
@@ -687,6 +690,36 @@ def da_cross_attn_bwd(value, spatial_shapes, level_start_index, pred_depth, ref_
                    'fbbev_da_cross_attn_bwd_ws_grid')
         else:
             _check(lib().fbbev_da_cross_attn_bwd(*args, _stream()), 'fbbev_da_cross_attn_bwd')
+
+
+def da_cross_attn_bwd_planes_supported(B, Ncam, S, M, Dh, L, Q, P, Za, HS, level_hw, bev_w):
+    if level_hw is None or not bev_w:
+        return False
+    return bool(lib().fbbev_da_cross_attn_bwd_planes_supported(B, Ncam, S, M, Dh, L, Q, P, Za, HS, _level_hw(level_hw, L), int(bev_w)))
+
+
+def da_cross_attn_bwd_planes(planes, spatial_shapes, level_start_index, pred_depth, ref_cam, mask, qdepth, offsets, attn, grad_slots,
+                             d0, dstep, head_minor, HS, grad_value, grad_pred_depth, grad_offsets, grad_attn, level_hw, bev_w):
+    """fbbev_da_cross_attn_bwd_planes: the DA backward on the forward's head planes; grad_value (B*Ncam, S, M, HS), grad_offsets and
+    grad_attn are written in full (torch.empty is enough), grad_pred_depth must be zeroed."""
+    Ncam, B, Q, Za = mask.shape
+    BN, M, S, Dh = planes.shape
+    head_minor = int(head_minor)
+    L, P = (attn.shape[2], attn.shape[3]) if head_minor & 2 else (attn.shape[3], attn.shape[4])
+    DC = pred_depth.shape[1]
+    if mask.dtype == torch.bool:
+        mask = mask.view(torch.uint8)
+    arr = _level_hw(level_hw, L)
+    need = lib().fbbev_da_cross_attn_bwd_ws_bytes_za(B, Ncam, S, M, Dh, Q, HS, L, P, Za, arr)
+    ws = torch.empty(max(need, 16) // 4, dtype=F32, device=planes.device)
+    with _on(planes):
+        _check(lib().fbbev_da_cross_attn_bwd_planes(
+            _dev(planes, F32, 'planes'), _dev(spatial_shapes, I64, 'spatial_shapes'), _dev(level_start_index, I64, 'level_start_index'),
+            _dev(pred_depth, F32, 'pred_depth'), _dev(ref_cam, F32, 'ref_cam'), _dev(mask, torch.uint8, 'mask'), _dev(qdepth, F32, 'qdepth'),
+            _dev(offsets, F32, 'offsets'), _dev(attn, F32, 'attn'), _dev(grad_slots, F32, 'grad_slots'), B, Ncam, S, M, Dh, L, Q, P, Za,
+            DC, float(d0), float(dstep), head_minor, int(HS), _dev(grad_value, F32, 'grad_value'),
+            _dev(grad_pred_depth, F32, 'grad_pred_depth'), _dev(grad_offsets, F32, 'grad_offsets'), _dev(grad_attn, F32, 'grad_attn'),
+            arr, ws.data_ptr(), need, int(bev_w), _stream()), 'fbbev_da_cross_attn_bwd_planes')
 
 
 def point_sampling(xs, ys, zs, rots, trans, intrins, post_rots, post_trans, bda, ogfH, ogfW, ref_cam, mask, qdepth):

@@ -2110,7 +2110,7 @@ static int da_bwd_owned_launch(const da_own_plan& op, fbbev_rt_stream stream, co
                                const float* qdepth, const float* offsets, const float* attn, const float* grad_slots, int B,
                                int Ncam, int S, int M, int Dh, int L, int Q, int P, int Za, int DC, float d0, float dstep,
                                int head_minor, int HS, float* grad_value, float* grad_pred_depth, float* grad_offsets,
-                               float* grad_attn, void* ws, int bev_w) {
+                               float* grad_attn, void* ws, int bev_w, const float* planes_in = nullptr) {
     char* w = static_cast<char*>(ws);
     float* hit_rec = reinterpret_cast<float*>(w + op.off_list);
     int* hit_count = reinterpret_cast<int*>(w + op.off_count);
@@ -2121,11 +2121,15 @@ static int da_bwd_owned_launch(const da_own_plan& op, fbbev_rt_stream stream, co
     // (the plane kernel reads a record's 4 mask bytes / 8 reference floats / 4 depths as whole words: alignment of the geometry inputs)
     if (op.unit_planes && Za == FBBEV_DAF_ZA && aligned16(ref_cam) && aligned16(qdepth) && ((uintptr_t)mask & 3) == 0) {
         // camera tokens as head planes, then the unit gradients with the forward's (head, patch) mapping
-        float* planes = reinterpret_cast<float*>(w + op.off_planes);
-        const long long n_el = (long long)B * Ncam * S * M * Dh;
-        FBBEV_LAUNCH(k_value_rows_to_head_planes, (n_el + 255) / 256, 256, 0, stream, value, (long long)B * Ncam * S, S, M, Dh, HS,
-                     (head_minor & 4) ? 1 : 0, planes);
-        FBBEV_CHECK_LAUNCH();
+        const float* planes = planes_in;
+        if (!planes) {                                                 // (round 6: the training forward's own head planes may be handed in)
+            float* pl_w = reinterpret_cast<float*>(w + op.off_planes);
+            const long long n_el = (long long)B * Ncam * S * M * Dh;
+            FBBEV_LAUNCH(k_value_rows_to_head_planes, (n_el + 255) / 256, 256, 0, stream, value, (long long)B * Ncam * S, S, M, Dh, HS,
+                         (head_minor & 4) ? 1 : 0, pl_w);
+            FBBEV_CHECK_LAUNCH();
+            planes = pl_w;
+        }
         const int gw = (bev_w > 0 && Q % bev_w == 0) ? bev_w : 0;
         const long long wgs_u = gw > 0 ? (long long)B * ((gw + 7) / 8) * ((Q / gw + 7) / 8) : (long long)B * ((Q + 63) / 64);
         const long long grid_u = (wgs_u + 7) / 8 * 8;
@@ -2284,6 +2288,45 @@ extern "C" int fbbev_da_cross_attn_bwd_ws_grid(const float* value, const int64_t
                                      grad_slots, B, Ncam, S, M, Dh, L, Q, P, Za, DC, d0, dstep, head_minor, head_stride,
                                      grad_value, grad_pred_depth, grad_offsets, grad_attn, level_hw_host, ws, ws_bytes, stream_,
                                      bev_w);
+}
+
+// Round 6: the backward of fbbev_da_cross_attn_fused for the training step that runs the one-kernel forward -- the camera tokens arrive as
+// the HEAD PLANES the forward sampled (fbbev_rows_linear_x3_planes: no row copy of them exists), and on this route every output but
+// grad_pred_depth is WRITTEN in full (grad_value by the plane owners incl. the padding channels, grad_offsets / grad_attn by the
+// unit kernel for every query of the grid): the caller zeroes only grad_pred_depth.  Needs the output-owned plane route with the
+// unit gradients on head planes (M = 8, Dh in {8, 10}, 8 points, 4 anchors, levels >= 2 wide, >= 256 planes) and queries on a
+// bev_w-wide grid; FBBEV_E_UNSUPPORTED otherwise (the caller keeps fbbev_da_cross_attn_bwd_ws_grid on row tokens).
+extern "C" int fbbev_da_cross_attn_bwd_planes_supported(int B, int Ncam, int S, int M, int Dh, int L, int Q, int P, int Za, int head_stride,
+                                                        const int32_t* level_hw_host, int bev_w) {
+    if (B <= 0 || Ncam <= 0 || S <= 0 || M <= 0 || Dh <= 0 || L <= 0 || Q <= 0 || P <= 0 || Za <= 0 || bev_w <= 0 || Q % bev_w != 0) return 0;
+    const int HS = head_stride == 0 ? Dh : head_stride;
+    da_own_plan op;
+    if (HS < Dh || P % Za != 0 || Za != FBBEV_DAF_ZA || !da_own_plan_make(B, Ncam, S, M, Dh, Q, HS, L, P, Za, level_hw_host, &op)) return 0;
+    return op.unit_planes ? 1 : 0;
+}
+extern "C" int fbbev_da_cross_attn_bwd_planes(const float* planes, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                              const float* pred_depth, const float* ref_cam, const uint8_t* mask,
+                                              const float* qdepth, const float* offsets, const float* attn, const float* grad_slots,
+                                              int B, int Ncam, int S, int M, int Dh, int L, int Q, int P, int Za, int DC, float d0,
+                                              float dstep, int head_minor, int head_stride, float* grad_value, float* grad_pred_depth,
+                                              float* grad_offsets, float* grad_attn, const int32_t* level_hw_host, void* ws,
+                                              size_t ws_bytes, int bev_w, fbbev_stream_t stream_) {
+    if (B <= 0 || Ncam <= 0 || S <= 0 || M <= 0 || Dh <= 0 || L <= 0 || Q <= 0 || P <= 0 || Za <= 0 || DC <= 0 || bev_w <= 0)
+        return FBBEV_E_BADARG;
+    if (!planes || !spatial_shapes || !level_start_index || !pred_depth || !ref_cam || !mask || !qdepth || !offsets || !attn ||
+        !grad_slots || !grad_value || !grad_pred_depth || !grad_offsets || !grad_attn || !ws) return FBBEV_E_BADARG;
+    if (dstep == 0.f) return FBBEV_E_BADARG;
+    const int HS = head_stride == 0 ? Dh : head_stride;
+    da_own_plan op;
+    if (HS < Dh || P % Za != 0 || Za != FBBEV_DAF_ZA || Q % bev_w != 0 ||
+        !da_own_plan_make(B, Ncam, S, M, Dh, Q, HS, L, P, Za, level_hw_host, &op) || !op.unit_planes) return FBBEV_E_UNSUPPORTED;
+    if (!aligned16(ws) || !aligned16(grad_value) || !aligned16(ref_cam) || !aligned16(qdepth) || ((uintptr_t)mask & 3) != 0 ||
+        ((uintptr_t)planes & 7) != 0 || (((uintptr_t)offsets | (uintptr_t)grad_offsets | (uintptr_t)grad_slots) & 7) != 0)
+        return FBBEV_E_UNSUPPORTED;
+    if (ws_bytes < op.ws) return FBBEV_E_WORKSPACE;
+    return da_bwd_owned_launch(op, (fbbev_rt_stream)stream_, nullptr, spatial_shapes, level_start_index, pred_depth, ref_cam, mask, qdepth,
+                               offsets, attn, grad_slots, B, Ncam, S, M, Dh, L, Q, P, Za, DC, d0, dstep, head_minor, HS, grad_value,
+                               grad_pred_depth, grad_offsets, grad_attn, ws, bev_w, planes);
 }
 
 // ---------------------------------------------------------------- fused lift-splat backward (training)

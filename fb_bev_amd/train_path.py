@@ -25,6 +25,7 @@ from .rows_linear import X3Weights
 
 TRAIN_FUSED = os.environ.get('FBBEV_TRAIN_FUSED', '1') != '0'
 WGRAD_X3 = os.environ.get('FBBEV_TRAIN_WGRAD', '1') != '0'
+DA_BWD_PLANES = os.environ.get('FBBEV_TRAIN_DA_PLANES', '1') != '0'    # A/B knob: the DA backward on the forward's head planes, outputs written in full
 ORDER = ('self_attn', 'norm', 'cross_attn', 'norm', 'ffn', 'norm')
 
 
@@ -290,13 +291,13 @@ class EncoderLayerFn(torch.autograd.Function):
         y2 = _capi.rows_tail_ffn_x3(slots.view(B * Q, E), co.frag, co.b, y0.view(B * Q, E), n1w, n1b, layer.norms[1].eps,
                                     c1.frag, c1.b, c2.frag, c2.b, H, n2w, n2b, layer.norms[2].eps).view(B, Q, E)
         ctx.layer, ctx.geo = layer, geo
-        ctx.save_for_backward(q, pos, rows, depth, y0, slots, planes_s, *params)
+        ctx.save_for_backward(q, pos, rows, depth, y0, slots, planes_s, planes_c, *params)
         return y2
 
     @staticmethod
     def backward(ctx, g_y2):
         layer, geo = ctx.layer, ctx.geo
-        q, pos, rows, depth, y0, slots, planes_s, *params = ctx.saved_tensors
+        q, pos, rows, depth, y0, slots, planes_s, planes_c, *params = ctx.saved_tensors
         p = dict(zip(NAMES, zip(params[0::2], params[1::2])))
         need = dict(zip(NAMES, zip(ctx.needs_input_grad[6::2], ctx.needs_input_grad[7::2])))
         sa, ca = layer.attentions
@@ -367,14 +368,27 @@ class EncoderLayerFn(torch.autograd.Function):
         from .backward_projection import _pad_interleave_rows
         cv = _frag(layer, 'cv_rows', p['cv'][0], p['cv'][1], lambda w_, b_: _pad_interleave_rows(w_, b_, M, Dh, HS, True))
         rows2 = rows.reshape(BN * S, E)
-        v = _lin(rows2, cv).view(BN, S, M, HS)
-        g_v, g_d = torch.zeros_like(v), torch.zeros_like(depth)
-        g_so, g_aw = torch.zeros_like(so), torch.zeros_like(aw)
-        _capi.da_cross_attn_bwd(v, geo['ss'], geo['ls'], depth, geo['ref_cam'], geo['mask'], geo['qdepth'],
-                                so.view(B, Q, L, P, M, 2), aw.view(B, Q, M, L, P), g_slots.view(B, Q, E), ca.dbound[0], ca.dbound[2],
-                                1 | 4, g_v, g_d, g_so.view(B, Q, L, P, M, 2), g_aw.view(B, Q, M, L, P), head_dim=Dh, level_hw=hw,
-                                bev_w=geo['bev_w'])
-        del v, so, g_slots
+        g_d = torch.zeros_like(depth)
+        Za = geo['mask'].shape[3]
+        if DA_BWD_PLANES and _capi.da_cross_attn_bwd_planes_supported(B, BN // B, S, M, Dh, L, Q, P, Za, HS, hw, geo['bev_w']):
+            # the forward's own head planes go straight to the gradient kernels, which WRITE the three large outputs in full: no row copy
+            # of the camera tokens, no 0.5 GB of zero fills (fbbev_da_cross_attn_bwd_planes)
+            g_v = torch.empty((BN, S, M, HS), dtype=torch.float32, device=dev)
+            g_so, g_aw = torch.empty_like(so), torch.empty_like(aw)
+            _capi.da_cross_attn_bwd_planes(planes_c, geo['ss'], geo['ls'], depth, geo['ref_cam'], geo['mask'], geo['qdepth'],
+                                           so.view(B, Q, L, P, M, 2), aw.view(B, Q, M, L, P), g_slots.view(B, Q, E), ca.dbound[0],
+                                           ca.dbound[2], 1 | 4, HS, g_v, g_d, g_so.view(B, Q, L, P, M, 2), g_aw.view(B, Q, M, L, P), hw,
+                                           geo['bev_w'])
+        else:
+            v = _lin(rows2, cv).view(BN, S, M, HS)
+            g_v = torch.zeros_like(v)
+            g_so, g_aw = torch.zeros_like(so), torch.zeros_like(aw)
+            _capi.da_cross_attn_bwd(v, geo['ss'], geo['ls'], depth, geo['ref_cam'], geo['mask'], geo['qdepth'],
+                                    so.view(B, Q, L, P, M, 2), aw.view(B, Q, M, L, P), g_slots.view(B, Q, E), ca.dbound[0], ca.dbound[2],
+                                    1 | 4, g_v, g_d, g_so.view(B, Q, L, P, M, 2), g_aw.view(B, Q, M, L, P), head_dim=Dh, level_hw=hw,
+                                    bev_w=geo['bev_w'])
+            del v
+        del so, g_slots
         g_lg = torch._softmax_backward_data(g_aw, aw, -1, torch.float32).view(R, M * L * P)
         del g_aw, aw
         g_qp_c = _lin(g_so, _frag(layer, 'cso_hm_t', p['cso'][0], None, lambda w_, b_: (w_[perm].t().contiguous(), None)))

@@ -591,6 +591,23 @@ int fbbev_da_cross_attn_bwd_ws_grid(const float* value, const int64_t* spatial_s
                                float* grad_attn, const int32_t* level_hw_host, void* ws, size_t ws_bytes, int bev_w,
                                fbbev_stream_t stream);
 
+/* Backward of fbbev_da_cross_attn_fused for a training step that ran the one-kernel forward (round 6): the camera tokens arrive as
+ * the HEAD PLANES (B*Ncam, M, S, Dh) the forward sampled (fbbev_rows_linear_x3_planes), offsets (B,Q,L,P,M,2) / attn as for
+ * fbbev_da_cross_attn_bwd_ws_grid (head_minor bits 0 / 1), grad_value in the row layout of that entry (head_stride, head_minor bit 2).
+ * On this route grad_value, grad_offsets and grad_attn are WRITTEN in full (no pre-zeroing); grad_pred_depth is accumulated into with
+ * fp32 atomics and must be zeroed by the caller.  Workspace: fbbev_da_cross_attn_bwd_ws_bytes_za.  Applies when
+ * fbbev_da_cross_attn_bwd_planes_supported returns 1 (the output-owned plane route with unit gradients on head planes: M = 8,
+ * Dh in {8, 10}, 8 points, 4 anchors, levels >= 2 tokens wide, >= 256 planes, queries on a bev_w-wide grid); else FBBEV_E_UNSUPPORTED.
+ * Reference: autograd through spatial_cross_attention_depth.py:136-223,513-595 and mmcv ms_deform_attn_backward. */
+int fbbev_da_cross_attn_bwd_planes_supported(int B, int Ncam, int S, int M, int Dh, int L, int Q, int P, int Za, int head_stride,
+                                             const int32_t* level_hw_host, int bev_w);
+int fbbev_da_cross_attn_bwd_planes(const float* planes, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                   const float* pred_depth, const float* ref_cam, const uint8_t* mask, const float* qdepth,
+                                   const float* offsets, const float* attn, const float* grad_slots, int B, int Ncam, int S, int M,
+                                   int Dh, int L, int Q, int P, int Za, int DC, float d0, float dstep, int head_minor, int head_stride,
+                                   float* grad_value, float* grad_pred_depth, float* grad_offsets, float* grad_attn,
+                                   const int32_t* level_hw_host, void* ws, size_t ws_bytes, int bev_w, fbbev_stream_t stream);
+
 /* Training backward of the fused lift-splat:  replaces QuickCumsumCuda.backward (bev_pool.py:39-78 --
  * argsort of ranks_feat, mask-built intervals [2 host syncs], the permute().contiguous() of the gradient)
  * and bev_pool_v2_backward / bev_pool_v2_grad_kernel (src/bev_pool_cuda.cu:52-100,128-135).

@@ -121,3 +121,29 @@ def test_one_node_route_with_frozen_projections(dev, monkeypatch):
         res[fused] = {n: (None if p.grad is None else p.grad.clone()) for n, p in m.named_parameters()}
     _compare(res[True], res[False], 'frozen projections')
     assert sum(1 for a in res[True].values() if a is not None and a.abs().max() > 0) >= 4
+
+
+def test_da_backward_on_the_forwards_head_planes_equals_the_row_entry(dev, monkeypatch):
+    """fbbev_da_cross_attn_bwd_planes (the forward's head planes handed in; grad_value / grad_offsets / grad_attn allocated with
+    torch.empty and WRITTEN in full) against fbbev_da_cross_attn_bwd_ws_grid on row tokens with zero-filled outputs, through the whole
+    training step at the BASELINE configs[2] pyramid: every gradient bit-identical except the depth distribution's (fp32 atomics in
+    both).  Unwritten words of the uninitialised outputs would show up as differences; the step is run twice per route."""
+    import train_path as T
+    from fb_bev_amd import train_path as TP
+    res = {}
+    for planes in (False, True):
+        monkeypatch.setattr(TP, 'TRAIN_FUSED', True)
+        monkeypatch.setattr(TP, 'DA_BWD_PLANES', planes)
+        pc, m, cam, depth, ctx, mlvl = T.build('BL2', 1, 4, dev)
+        step, leaves, gout = T.make_step(m, cam, depth, ctx, mlvl, dev, pc, 1)
+        junk = torch.full((64 << 20,), float('nan'), device=dev)       # poison the allocator's free blocks
+        del junk
+        step()
+        step()
+        names = [n for n, _ in m.named_parameters()] + ['depth', 'ctx'] + [f'mlvl{i}' for i in range(1, len(mlvl))]
+        res[planes] = {n: (None if t.grad is None else t.grad.clone()) for n, t in zip(names, leaves)}
+    diff = [n for n, a in res[True].items() if a is not None and n != 'depth' and 'embed' not in n and not torch.equal(a, res[False][n])]
+    assert all(torch.isfinite(a).all() for a in res[True].values() if a is not None)
+    assert not diff, diff
+    d = (res[True]['depth'] - res[False]['depth']).abs().max().item() / res[False]['depth'].abs().max().item()
+    assert d < 1e-5, d
