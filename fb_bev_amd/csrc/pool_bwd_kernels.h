@@ -61,25 +61,53 @@ k_pool_bwd_rows(int C, int Z, int YX, int tiles_per_plane, long long stride_b, l
     const int nv = (YX - v0 < TV) ? (YX - v0) : TV;
     const float* __restrict__ base = out_grad + (long long)b * stride_b + (long long)z * YX + v0;
     const int n4 = C * Q4;
-    for (int idx = tid; idx < n4; idx += 256) {
-        const int c = idx / Q4, j = (idx - c * Q4) * 4;
-        if (j < nv) {
-            fbbev_v4f v = *reinterpret_cast<const fbbev_v4f*>(base + (long long)c * stride_c + j);
-            if (zgrad) v += *reinterpret_cast<const fbbev_v4f*>(zgrad + ((long long)b * C + c) * YX + v0 + j) * zscale;
-            *reinterpret_cast<fbbev_v4f*>(tile + c * LD + j) = v;
+    // round 6: the tile's pieces are REQUESTED in batches of U before the first is used (written as one load-add-store per iteration
+    // the loop compiled to load, s_waitcnt vmcnt(0), ds_write: ten round trips in a row per workgroup at C = 80 -- the pattern
+    // tools/isa_waits.py found in the row kernels in round 5; 0.25 ms for an 0.8 GB read at BASELINE configs[2], B = 4)
+    constexpr int U = 5;
+    for (int idx0 = tid; idx0 < n4; idx0 += 256 * U) {
+        fbbev_v4f v[U], zg[U];
+        int cc[U], jj[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx_ = idx0 + 256 * u, idx = idx_ < n4 ? idx_ : idx0;
+            cc[u] = idx / Q4; jj[u] = (idx - cc[u] * Q4) * 4;
+            ok[u] = idx_ < n4 && jj[u] < nv;
+            const int jl = jj[u] < nv ? jj[u] : 0;                                  // (clamped: unconditional loads)
+            v[u] = *reinterpret_cast<const fbbev_v4f*>(base + (long long)cc[u] * stride_c + jl);
+            if (zgrad) zg[u] = *reinterpret_cast<const fbbev_v4f*>(zgrad + ((long long)b * C + cc[u]) * YX + v0 + jl);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!ok[u]) continue;
+            fbbev_v4f w = v[u];
+            if (zgrad) w += zg[u] * zscale;
+            *reinterpret_cast<fbbev_v4f*>(tile + cc[u] * LD + jj[u]) = w;
         }
     }
     __syncthreads();
     const int rank0 = plane * YX + v0;
     const int C4 = C >> 2;
     const int work = (i1 - i0) * C4;
-    for (int idx = tid; idx < work; idx += 256) {
-        const int ii = idx / C4, c4 = idx - ii * C4;
-        const int tv = interval_rank[i0 + ii] - rank0;
-        const float* col = tile + (4 * c4) * LD + tv;
-        fbbev_v4f r;
-        r[0] = col[0]; r[1] = col[LD]; r[2] = col[2 * LD]; r[3] = col[3 * LD];
-        *reinterpret_cast<fbbev_v4f*>(rows + (long long)(i0 + ii) * C + 4 * c4) = r;
+    constexpr int U2 = 4;
+    for (int idx0 = tid; idx0 < work; idx0 += 256 * U2) {
+        int tvs[U2];
+#pragma unroll
+        for (int u = 0; u < U2; ++u) {                     // the intervals' voxel ranks first: one round trip per batch
+            const int idx_ = idx0 + 256 * u, idx = idx_ < work ? idx_ : idx0;
+            tvs[u] = interval_rank[i0 + idx / C4] - rank0;
+        }
+#pragma unroll
+        for (int u = 0; u < U2; ++u) {
+            const int idx = idx0 + 256 * u;
+            if (idx >= work) continue;
+            const int ii = idx / C4, c4 = idx - ii * C4;
+            const float* col = tile + (4 * c4) * LD + tvs[u];
+            fbbev_v4f r;
+            r[0] = col[0]; r[1] = col[LD]; r[2] = col[2 * LD]; r[3] = col[3 * LD];
+            *reinterpret_cast<fbbev_v4f*>(rows + (long long)(i0 + ii) * C + 4 * c4) = r;
+        }
     }
 }
 

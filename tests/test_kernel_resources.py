@@ -63,7 +63,7 @@ BUDGETS = {
     r'k_pool_zmeanILi': 80,             # five 27 KB workgroups per CU = 5 waves / SIMD (102 registers would do); round 5's two-stage plane
                                         # pipeline holds 5 + 12 values ahead: 72 -> 78 (the opt-in column form k_pool_zmean_col has its own, larger footprint)
     r'k_pool_bwd_pixel': 96,
-    r'k_pool_bwd_rows': 32,
+    r'k_pool_bwd_rows': 96,                # round 6: ten pieces of the gradient tile in flight per thread (LDS, 42 KB per workgroup, bounds the occupancy at 3 waves / SIMD: 168 would do)
     r'k_sort_scatterILi4E': 64,           # thin chunks: 8 waves / SIMD
     r'k_sort_scatterILi16E': 128,         # 1024-thread workgroups (4 waves / SIMD is one workgroup: 128 registers each)
     r'k_sort_hist': 64,
