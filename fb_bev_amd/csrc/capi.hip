@@ -1263,6 +1263,7 @@ extern "C" int fbbev_msda_bwd_ws(const float* value, const int64_t* spatial_shap
         // lane groups without its atomics
         const long long n_units = (long long)B * Q * M;
         const bool lane_units = Dh % 2 == 0 && ((uintptr_t)value & 7) == 0 && ((uintptr_t)grad_output & 7) == 0 &&
+                                ((uintptr_t)sampling_loc & 7) == 0 && ((uintptr_t)grad_sampling_loc & 7) == 0 &&      // 8-byte location / gradient pairs (round 6)
                                 (n_units + 255) / 256 < (1ll << 31);
 #define FBBEV_MSDA_BWD_UL(DH_)                                                                                        \
     FBBEV_LAUNCH((k_msda_bwd_unit<DH_>), (n_units + 255) / 256, 256, 0, stream, n_units, value, spatial_shapes,         \

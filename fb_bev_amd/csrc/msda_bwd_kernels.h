@@ -58,12 +58,18 @@ k_msda_row_ranges(long long n, const int64_t* __restrict__ ss, const float* __re
         int lo = 0x7fff, hi = -1;
         for (int m = 0; m < M; ++m) {
             const float* lp = loc + ((((b * Q + q) * M + m) * L + l) * (long long)P) * 2;
-            for (int p = 0; p < P; ++p) {
-                const float h_im = lp[2 * p + 1] * (float)h - 0.5f;
-                if (h_im > -2.f && h_im < (float)h + 1.f) {               // wider than the sampler's own test: slack
-                    const int r = (int)floorf(h_im);
-                    lo = r - 1 < lo ? r - 1 : lo;
-                    hi = r + 2 > hi ? r + 2 : hi;
+            for (int p0 = 0; p0 < P; p0 += 4) {                               // (round 6: four row coordinates requested together)
+                float ly[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ly[e] = lp[2 * (p0 + e < P ? p0 + e : p0) + 1];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float h_im = ly[e] * (float)h - 0.5f;
+                    if (p0 + e < P && h_im > -2.f && h_im < (float)h + 1.f) {   // wider than the sampler's own test: slack
+                        const int r = (int)floorf(h_im);
+                        lo = r - 1 < lo ? r - 1 : lo;
+                        hi = r + 2 > hi ? r + 2 : hi;
+                    }
                 }
             }
         }
@@ -82,10 +88,17 @@ k_msda_band_queries(const int64_t* __restrict__ ss, const int64_t* __restrict__ 
     const fbbev_msda_band bd = fbbev_msda_band_of(band, L, ss, lsi, budget);
     int lo = 0x7fffffff, hi = -1;
     const unsigned int* rr = ranges + ((long long)b * L + bd.level) * Q;
-    for (int q = threadIdx.x; q < Q; q += 256) {
-        const unsigned int v = rr[q];
-        const int first = (int)(v & 0xffffu), last = (int)(v >> 16);
-        if (first <= last && first < bd.r1 && last >= bd.r0) { lo = q < lo ? q : lo; hi = q > hi ? q : hi; }
+    constexpr int U = 8;                                   // (round 6: eight range words in flight per thread; one per iteration was 156 round trips at Q = 40 000)
+    for (int q0 = threadIdx.x; q0 < Q; q0 += 256 * U) {
+        unsigned int vv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) vv[u] = rr[q0 + 256 * u < Q ? q0 + 256 * u : q0];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int q = q0 + 256 * u;
+            const int first = (int)(vv[u] & 0xffffu), last = (int)(vv[u] >> 16);
+            if (q < Q && first <= last && first < bd.r1 && last >= bd.r0) { lo = q < lo ? q : lo; hi = q > hi ? q : hi; }
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -121,17 +134,25 @@ k_msda_bwd_scatter(const int64_t* __restrict__ ss, const int64_t* __restrict__ l
     // scale of the plane from the largest |grad_output| and |attention weight| of the span
     float gmax = 0.f, amax = 1.f;
     bool finite = true;
-    for (int i = threadIdx.x; i < (qhi - qlo) * DH; i += NT) {
-        const int qi = i / DH, c = i - qi * DH;
-        const float v = fabsf(grad_out[(((long long)b * Q + qlo + qi) * M + m) * DH + c]);
-        finite = finite && (v < __builtin_inff());
-        gmax = fmaxf(gmax, v);
-    }
-    for (int i = threadIdx.x; i < (qhi - qlo) * P; i += NT) {
-        const int qi = i / P, p = i - qi * P;
-        const float v = fabsf(attn[((((long long)b * Q + qlo + qi) * M + m) * L + bd.level) * P + p]);
-        finite = finite && (v < __builtin_inff());
-        amax = fmaxf(amax, v);
+    // (round 6: one thread per query of the span, its DH gradient floats and P weights requested together -- as two element-wise loops
+    // of one load per iteration the scan was ~90 dependent round trips per workgroup, most of the kernel's time)
+    for (int q0 = qlo; q0 < qhi; q0 += NT) {
+        const int q_ = q0 + (int)threadIdx.x, q = q_ < qhi ? q_ : qhi - 1;
+        const long long u = ((long long)b * Q + q) * M + m;
+        float gv[DH], av[4];
+#pragma unroll
+        for (int c = 0; c < DH; ++c) gv[c] = grad_out[u * DH + c];
+        const long long wp = (u * L + bd.level) * P;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) av[e] = attn[wp + (e < P ? e : 0)];
+        float am = 0.f;
+        for (int e = 4; e < P; ++e) am = fmaxf(am, fabsf(attn[wp + e]));                 // (P > 4: not an FB-OCC shape)
+#pragma unroll
+        for (int c = 0; c < DH; ++c) { const float v = fabsf(gv[c]); finite = finite && (v < __builtin_inff()); gmax = fmaxf(gmax, v); }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) am = fmaxf(am, fabsf(av[e]));
+        finite = finite && (am < __builtin_inff());
+        amax = fmaxf(amax, am);
     }
     if (!finite) gmax = __builtin_inff();
 #pragma unroll
@@ -156,17 +177,37 @@ k_msda_bwd_scatter(const int64_t* __restrict__ ss, const int64_t* __restrict__ l
     }
     const unsigned int* rr = ranges + ((long long)b * L + bd.level) * Q;
     if (!poisoned && sc > 0.f) {
-        for (int q = qlo + (int)threadIdx.x; q < qhi; q += NT) {
+        // round 6: a query's words -- row range, upstream gradient, the level's locations and weights -- are requested together
+        // (clamped, unconditional) before any is used: as written first (range -> gradient -> per point location / weight) every query
+        // cost 2 + P dependent round trips in front of its LDS adds
+        constexpr int PB = 4;
+        for (int q0 = qlo; q0 < qhi; q0 += NT) {
+            const int q_ = q0 + (int)threadIdx.x, q = q_ < qhi ? q_ : qhi - 1;
             const unsigned int v = rr[q];
-            const int first = (int)(v & 0xffffu), last = (int)(v >> 16);
-            if (!(first <= last && first < bd.r1 && last >= bd.r0)) continue;
             const long long u = ((long long)b * Q + q) * M + m;
+            const long long wp = (u * L + bd.level) * P;
             float gs[DH];
 #pragma unroll
-            for (int c = 0; c < DH; ++c) gs[c] = grad_out[u * DH + c] * sc;          // sc is a power of two: exact
-            const long long wp = (u * L + bd.level) * P;
+            for (int c = 0; c < DH; ++c) gs[c] = grad_out[u * DH + c];
+            float lw[PB], lh[PB], wt[PB];
+#pragma unroll
+            for (int e = 0; e < PB; ++e) {
+                const int pp = e < P ? e : 0;
+                lw[e] = loc[(wp + pp) * 2]; lh[e] = loc[(wp + pp) * 2 + 1]; wt[e] = attn[wp + pp];
+            }
+            const int first = (int)(v & 0xffffu), last = (int)(v >> 16);
+            if (q_ >= qhi || !(first <= last && first < bd.r1 && last >= bd.r0)) continue;
+#pragma unroll
+            for (int c = 0; c < DH; ++c) gs[c] = gs[c] * sc;                              // sc is a power of two: exact
             for (int p = 0; p < P; ++p) {
-                const float loc_w = loc[(wp + p) * 2], loc_h = loc[(wp + p) * 2 + 1], weight = attn[wp + p];
+                float loc_w, loc_h, weight;
+                if (p < PB) {                                                               // (compile-time after unrolling for P <= 4)
+                    loc_w = p == 0 ? lw[0] : p == 1 ? lw[1] : p == 2 ? lw[2] : lw[3];
+                    loc_h = p == 0 ? lh[0] : p == 1 ? lh[1] : p == 2 ? lh[2] : lh[3];
+                    weight = p == 0 ? wt[0] : p == 1 ? wt[1] : p == 2 ? wt[2] : wt[3];
+                } else {
+                    loc_w = loc[(wp + p) * 2]; loc_h = loc[(wp + p) * 2 + 1]; weight = attn[wp + p];
+                }
                 const float h_im = loc_h * bd.h - 0.5f, w_im = loc_w * bd.w - 0.5f;
                 if (!(h_im > -1.f && w_im > -1.f && h_im < (float)bd.h && w_im < (float)bd.w)) continue;
                 const fbbev_bilinear s = fbbev_bilinear_setup(h_im, w_im, bd.h, bd.w, 1);       // o1..o4 = token index in the level
@@ -215,43 +256,79 @@ k_msda_bwd_unit(long long n_units, const float* __restrict__ value, const int64_
         const fbbev_v2f t = *reinterpret_cast<const fbbev_v2f*>(grad_out + unit * DH + c);
         top[c] = t[0]; top[c + 1] = t[1];
     }
-    long long wp = unit * L * P;
+    // round 6: the unit's words of up to four points (location, weight, the gradients accumulated so far) are requested together, then
+    // the corner runs of two samples at a time -- as one point per iteration (location -> corner addresses -> corners -> read-add-write
+    // of the gradients) the loop was three dependent round trips per point (0.29 ms for the BEV self-attention of BASELINE configs[2]);
+    // the same expressions in the same order: identical bits
+    constexpr int PB = 4;
+    const long long wp0 = unit * L * P;
     for (int l = 0; l < L; ++l) {
         const int height = (int)spatial_shapes[2 * l], width = (int)spatial_shapes[2 * l + 1];
         const float* vb = value + (b * spatial_size + level_start[l]) * row_stride + m * DH;
-        for (int p = 0; p < P; ++p, ++wp) {
-            const float loc_w = loc[wp * 2], loc_h = loc[wp * 2 + 1], weight = attn[wp];
-            const float h_im = loc_h * height - 0.5f, w_im = loc_w * width - 0.5f;
-            if (!(h_im > -1.f && w_im > -1.f && h_im < (float)height && w_im < (float)width)) continue;
-            const fbbev_bilinear s = fbbev_bilinear_setup(h_im, w_im, height, width, row_stride);
-            const bool k1 = s.o1 >= 0, k2 = s.o2 >= 0, k3 = s.o3 >= 0, k4 = s.o4 >= 0;
-            const float* p1 = vb + (k1 ? s.o1 : 0);
-            const float* p2 = vb + (k2 ? s.o2 : 0);
-            const float* p3 = vb + (k3 ? s.o3 : 0);
-            const float* p4 = vb + (k4 ? s.o4 : 0);
-            fbbev_v2f a1[DH / 2], a2[DH / 2], a3[DH / 2], a4[DH / 2];
+        for (int p0 = 0; p0 < P; p0 += PB) {
+            fbbev_v2f lc[PB], gl[PB];
+            float wt[PB], ga[PB];
 #pragma unroll
-            for (int k = 0; k < DH / 2; ++k) {                    // unconditional loads (a padded corner reads token 0), zeros selected below
-                a1[k] = *reinterpret_cast<const fbbev_v2f*>(p1 + 2 * k);
-                a2[k] = *reinterpret_cast<const fbbev_v2f*>(p2 + 2 * k);
-                a3[k] = *reinterpret_cast<const fbbev_v2f*>(p3 + 2 * k);
-                a4[k] = *reinterpret_cast<const fbbev_v2f*>(p4 + 2 * k);
+            for (int u = 0; u < PB; ++u) {
+                const long long wp = wp0 + (long long)l * P + (p0 + u < P ? p0 + u : p0);          // (clamped: unconditional loads)
+                lc[u] = *reinterpret_cast<const fbbev_v2f*>(loc + wp * 2);
+                gl[u] = *reinterpret_cast<const fbbev_v2f*>(grad_loc + wp * 2);
+                wt[u] = attn[wp];
+                ga[u] = grad_attn[wp];
             }
-            float g_w = 0.f, g_x = 0.f, g_y = 0.f;
+            float rw[PB], rx[PB], ry[PB];
 #pragma unroll
-            for (int c = 0; c < DH; ++c) {
-                const float v1 = k1 ? a1[c >> 1][c & 1] : 0.f, v2 = k2 ? a2[c >> 1][c & 1] : 0.f;
-                const float v3 = k3 ? a3[c >> 1][c & 1] : 0.f, v4 = k4 ? a4[c >> 1][c & 1] : 0.f;
-                const float tgv = top[c] * weight;
-                const float ghw = -s.hw * v1 - s.lw * v2 + s.hw * v3 + s.lw * v4;
-                const float gww = -s.hh * v1 + s.hh * v2 - s.lh * v3 + s.lh * v4;
-                g_w += top[c] * (s.w1 * v1 + s.w2 * v2 + s.w3 * v3 + s.w4 * v4);
-                g_x += (float)width * gww * tgv;
-                g_y += (float)height * ghw * tgv;
+            for (int u0 = 0; u0 < PB; u0 += 2) {
+                fbbev_bilinear s[2];
+                bool live[2], k1[2], k2[2], k3[2], k4[2];
+                fbbev_v2f a1[2][DH / 2], a2[2][DH / 2], a3[2][DH / 2], a4[2][DH / 2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int u = u0 + e;
+                    const float h_im = lc[u][1] * height - 0.5f, w_im = lc[u][0] * width - 0.5f;
+                    live[e] = p0 + u < P && h_im > -1.f && w_im > -1.f && h_im < (float)height && w_im < (float)width;
+                    s[e] = fbbev_bilinear_setup(live[e] ? h_im : 0.f, live[e] ? w_im : 0.f, height, width, row_stride);
+                    k1[e] = live[e] && s[e].o1 >= 0; k2[e] = live[e] && s[e].o2 >= 0; k3[e] = live[e] && s[e].o3 >= 0; k4[e] = live[e] && s[e].o4 >= 0;
+                    const float* p1 = vb + (k1[e] ? s[e].o1 : 0);
+                    const float* p2 = vb + (k2[e] ? s[e].o2 : 0);
+                    const float* p3 = vb + (k3[e] ? s[e].o3 : 0);
+                    const float* p4 = vb + (k4[e] ? s[e].o4 : 0);
+#pragma unroll
+                    for (int k = 0; k < DH / 2; ++k) {            // unconditional loads (a padded corner reads token 0), zeros selected below
+                        a1[e][k] = *reinterpret_cast<const fbbev_v2f*>(p1 + 2 * k);
+                        a2[e][k] = *reinterpret_cast<const fbbev_v2f*>(p2 + 2 * k);
+                        a3[e][k] = *reinterpret_cast<const fbbev_v2f*>(p3 + 2 * k);
+                        a4[e][k] = *reinterpret_cast<const fbbev_v2f*>(p4 + 2 * k);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int u = u0 + e;
+                    const float weight = wt[u];
+                    float g_w = 0.f, g_x = 0.f, g_y = 0.f;
+#pragma unroll
+                    for (int c = 0; c < DH; ++c) {
+                        const float v1 = k1[e] ? a1[e][c >> 1][c & 1] : 0.f, v2 = k2[e] ? a2[e][c >> 1][c & 1] : 0.f;
+                        const float v3 = k3[e] ? a3[e][c >> 1][c & 1] : 0.f, v4 = k4[e] ? a4[e][c >> 1][c & 1] : 0.f;
+                        const float tgv = top[c] * weight;
+                        const float ghw = -s[e].hw * v1 - s[e].lw * v2 + s[e].hw * v3 + s[e].lw * v4;
+                        const float gww = -s[e].hh * v1 + s[e].hh * v2 - s[e].lh * v3 + s[e].lh * v4;
+                        g_w += top[c] * (s[e].w1 * v1 + s[e].w2 * v2 + s[e].w3 * v3 + s[e].w4 * v4);
+                        g_x += (float)width * gww * tgv;
+                        g_y += (float)height * ghw * tgv;
+                    }
+                    rw[u] = g_w; rx[u] = g_x; ry[u] = g_y;
+                    if (!live[e]) { rw[u] = 0.f; rx[u] = 0.f; ry[u] = 0.f; }
+                }
             }
-            grad_attn[wp] += g_w;
-            grad_loc[wp * 2] += g_x;
-            grad_loc[wp * 2 + 1] += g_y;
+#pragma unroll
+            for (int u = 0; u < PB; ++u) {
+                if (p0 + u >= P) break;
+                const long long wp = wp0 + (long long)l * P + p0 + u;
+                // (a sample outside the image contributed nothing before either: the words keep their values)
+                grad_attn[wp] = ga[u] + rw[u];
+                *reinterpret_cast<fbbev_v2f*>(grad_loc + wp * 2) = fbbev_v2f{gl[u][0] + rx[u], gl[u][1] + ry[u]};
+            }
         }
     }
 }
