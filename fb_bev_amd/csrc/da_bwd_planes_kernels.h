@@ -202,36 +202,56 @@ k_da_bwd_unit_planes(const float* __restrict__ planes, const int64_t* __restrict
     const int LP = L * P;
     const char* pb = reinterpret_cast<const char*>(planes);
     for (int i = threadIdx.x; i < MH * Ncam * 64 * ZA; i += NT) dd[i] = 0.f;
-    // cooperative pass over a level's unit words: item i = (query ql, point p, head h) in the order of the head-minor layouts
-    auto unit_words = [&](int l, bool write_back, bool load) {
-        for (int i = threadIdx.x; i < 64 * P * MH; i += NT) {
+    // cooperative pass over a level's unit words: item i = (query ql, point p, head h) in the order of the head-minor layouts.
+    // Round 6: ONE pass per level boundary -- the next level's words are REQUESTED first (all of a thread's items, clamped addresses),
+    // the finished level's gradients go back from the tiles while they are in flight, then the loaded words take the gradients'
+    // slots (an item's slots are touched by this thread only: no barrier in between).  As three loops of load / wait / LDS write per
+    // item the staging was 8 dependent round trips per level and two more barriers (tools/isa_chains.py: (47, 2, 2), (71, 2, 2)).
+    constexpr int NI = (64 * P * MH + NT - 1) / NT;
+    auto unit_words = [&](int l_back, int l_load) {          // -1: nothing to write back / to load
+        fbbev_v2f ot[NI];
+        float at[NI];
+        long long io_b[NI], ia_b[NI];
+        bool ok[NI];
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            const int i = (int)threadIdx.x + k * NT;
             const int ql = i / (P * MH), r = i - ql * (P * MH), p = r / MH, h = r - p * MH;
             const int uy = y0 + (ql >> plog), ux = x0 + (ql & (pw - 1));
-            if (!(uy < gh && ux < gw)) continue;
-            const long long ubq = (long long)b * Q + (long long)uy * gw + ux, uu = ubq * MH + h;
-            const long long io = (((head_minor & 1) ? ubq * LP * MH + h : uu * LP) + (long long)(l * P + p) * ((head_minor & 1) ? MH : 1)) * 2;
-            const long long ia = ((head_minor & 2) ? ubq * LP * MH + h : uu * LP) + (long long)(l * P + p) * ((head_minor & 2) ? MH : 1);
+            ok[k] = i < 64 * P * MH && uy < gh && ux < gw;
+            const long long ubq = (long long)b * Q + (ok[k] ? (long long)uy * gw + ux : 0), uu = ubq * MH + h;
+            const long long rowo = (head_minor & 1) ? ubq * LP * MH + h : uu * LP, rowa = (head_minor & 2) ? ubq * LP * MH + h : uu * LP;
+            const long long so_ = (head_minor & 1) ? MH : 1, sa_ = (head_minor & 2) ? MH : 1;
+            io_b[k] = (rowo + (long long)((l_back < 0 ? 0 : l_back) * P + p) * so_) * 2;
+            ia_b[k] = rowa + (long long)((l_back < 0 ? 0 : l_back) * P + p) * sa_;
+            if (l_load >= 0) {
+                const long long io = (rowo + (long long)(l_load * P + p) * so_) * 2, ia = rowa + (long long)(l_load * P + p) * sa_;
+                ot[k] = *reinterpret_cast<const fbbev_v2f*>(offsets + io);
+                at[k] = attn[ia];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            const int i = (int)threadIdx.x + k * NT;
+            const int ql = i / (P * MH), r = i - ql * (P * MH), p = r / MH, h = r - p * MH;
             float* so = off_s + ql * FBBEV_DBP_OQ + (p * MH + h) * 2;
             float* sa = att_s + ql * FBBEV_DBP_AQ + h * P + p;
-            if (write_back) {
+            if (!ok[k]) continue;
+            if (l_back >= 0) {
                 // the level's gradients, STORED: the entry's contract is "accumulated into caller-zeroed tensors", every word of a
                 // valid query has exactly this one writer per call (a unit no camera sees stores its zeros), so a store is the
                 // accumulation -- without reading 492 MB of zeros back at the configs[2] pyramid
-                *reinterpret_cast<fbbev_v2f*>(grad_offsets + io) = fbbev_v2f{so[0], so[1]};
-                grad_attn[ia] = gat_s[ql * FBBEV_DBP_AQ + h * P + p];
+                *reinterpret_cast<fbbev_v2f*>(grad_offsets + io_b[k]) = fbbev_v2f{so[0], so[1]};
+                grad_attn[ia_b[k]] = gat_s[ql * FBBEV_DBP_AQ + h * P + p];
             }
-            if (load) {
-                const fbbev_v2f t = *reinterpret_cast<const fbbev_v2f*>(offsets + io);
-                so[0] = t[0]; so[1] = t[1];
-                sa[0] = attn[ia];
-            }
+            if (l_load >= 0) { so[0] = ot[k][0]; so[1] = ot[k][1]; sa[0] = at[k]; }
         }
     };
     float* my_off = off_s + lane * FBBEV_DBP_OQ + m * 2;                // + p * MH * 2
     float* my_att = att_s + lane * FBBEV_DBP_AQ + m * P;               // + p
     float* my_gat = gat_s + lane * FBBEV_DBP_AQ + m * P;
     float* my_dd = dd + (((size_t)m * Ncam) * 64 + lane) * ZA;          // + cam * 64 * ZA + z
-    unit_words(0, false, true);
+    unit_words(-1, 0);
     __syncthreads();
     for (int l = 0; l < L; ++l) {
         const int sh = (int)spatial_shapes[2 * l], sw = (int)spatial_shapes[2 * l + 1];
@@ -277,12 +297,8 @@ k_da_bwd_unit_planes(const float* __restrict__ planes, const int64_t* __restrict
             }
         }
         __syncthreads();                                               // the tiles now hold the level's gradients
-        unit_words(l, true, false);
-        if (l + 1 < L) {
-            __syncthreads();
-            unit_words(l + 1, false, true);
-            __syncthreads();
-        }
+        unit_words(l, l + 1 < L ? l + 1 : -1);
+        if (l + 1 < L) __syncthreads();
     }
     __syncthreads();
     // d / d depth weight: summed over the heads in head order, wave z pushes anchor z of the 64 queries to the four taps of the
