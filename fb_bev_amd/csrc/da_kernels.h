@@ -1276,15 +1276,38 @@ k_da_bwd_scatter_owned(const int64_t* __restrict__ spatial_shapes, const int64_t
     const int LP = L * P;
     const bool perm = (tab.perm >> r) & 1;
     __syncthreads();
-    for (int it0 = 0; it0 < nh; it0 += NT) {
+    // Round 6: the hit walk was a chain of ~2 + P dependent round trips per hit (record -> gradient row -> one point's offset / weight
+    // at a time, each behind the previous point's adds): "a pass over the hit lists costs ~200 us whatever fraction of its corners is
+    // live" (round 4) was this latency, not the LDS adds.  Now the NEXT block's record is requested before the current hit is worked
+    // on, and a hit's gradient row and the offsets / weights of up to eight points are requested together: two round trips per hit,
+    // one of them hidden.  Same expressions, same order of adds per lane.
+    constexpr int PB = 8;
+    auto hit_index = [&](int it0) {
         // lane -> hit: a stride of 37 (41 when 37 divides the block) inside each block of NT hits -- neighbouring queries sample
         // the same tokens, consecutive hits on consecutive lanes would share addresses inside one ds_add_u64
         const int nblk = nh - it0 < NT ? nh - it0 : NT;
-        if ((int)threadIdx.x >= nblk) continue;
-        const int it = it0 + (perm ? (int)(((unsigned)threadIdx.x * (nblk % 37 == 0 ? 41u : 37u)) % (unsigned)nblk) : (int)threadIdx.x);
-        const float* rp = list + (long long)it * FBBEV_DA_HIT_REC;       // 64 bytes, 16-byte aligned
-        const fbbev_v4f r0 = *reinterpret_cast<const fbbev_v4f*>(rp), r1 = *reinterpret_cast<const fbbev_v4f*>(rp + 4);
-        const fbbev_v4f r2 = *reinterpret_cast<const fbbev_v4f*>(rp + 8), r3 = *reinterpret_cast<const fbbev_v4f*>(rp + 12);
+        if ((int)threadIdx.x >= nblk) return -1;
+        return it0 + (perm ? (int)(((unsigned)threadIdx.x * (nblk % 37 == 0 ? 41u : 37u)) % (unsigned)nblk) : (int)threadIdx.x);
+    };
+    fbbev_v4f n0 = {0.f, 0.f, 0.f, 0.f}, n1 = n0, n2 = n0, n3 = n0;
+    {
+        const int it = nh > 0 ? hit_index(0) : -1;
+        const float* rp = list + (long long)(it < 0 ? 0 : it) * FBBEV_DA_HIT_REC;       // 64 bytes, 16-byte aligned
+        if (nh > 0) {
+            n0 = *reinterpret_cast<const fbbev_v4f*>(rp); n1 = *reinterpret_cast<const fbbev_v4f*>(rp + 4);
+            n2 = *reinterpret_cast<const fbbev_v4f*>(rp + 8); n3 = *reinterpret_cast<const fbbev_v4f*>(rp + 12);
+        }
+    }
+    for (int it0 = 0; it0 < nh; it0 += NT) {
+        const bool mine = hit_index(it0) >= 0;
+        const fbbev_v4f r0 = n0, r1 = n1, r2 = n2, r3 = n3;
+        if (it0 + NT < nh) {                                                 // uniform: the next block's record of this lane
+            const int itn = hit_index(it0 + NT);
+            const float* rp = list + (long long)(itn < 0 ? 0 : itn) * FBBEV_DA_HIT_REC;
+            n0 = *reinterpret_cast<const fbbev_v4f*>(rp); n1 = *reinterpret_cast<const fbbev_v4f*>(rp + 4);
+            n2 = *reinterpret_cast<const fbbev_v4f*>(rp + 8); n3 = *reinterpret_cast<const fbbev_v4f*>(rp + 12);
+        }
+        if (!mine) continue;
         const float q_bits = r0[0];
         int q;
         __builtin_memcpy(&q, &q_bits, 4);
@@ -1301,41 +1324,53 @@ k_da_bwd_scatter_owned(const int64_t* __restrict__ spatial_shapes, const int64_t
                 ry[z] = z < FBBEV_DA_HIT_ZA ? rec[2 + 2 * FBBEV_DA_HIT_ZA + z] : 0.f;
             }
         }
-        float gs[DH];
-#pragma unroll
-        for (int c = 0; c < DH; ++c) gs[c] = grad_slots[u * DH + c] / inv * sc;          // sc is a power of two: exact
         const long long wo0 = (head_minor & 1) ? bq * LP * M + m : u * LP, wa0 = (head_minor & 2) ? bq * LP * M + m : u * LP;
         const int wo_step = (head_minor & 1) ? M : 1, wa_step = (head_minor & 2) ? M : 1;
-        const int lp0 = lvl0 * P, lp1 = lvl1 * P;
-        fbbev_v2f o_next = *reinterpret_cast<const fbbev_v2f*>(offsets + (wo0 + (long long)lp0 * wo_step) * 2);
-        float a_next = attn[wa0 + (long long)lp0 * wa_step];
-        int lp = lp0;
+        float gs[DH];
+#pragma unroll
+        for (int c = 0; c < DH; ++c) gs[c] = grad_slots[u * DH + c];                     // (raw: scaled below, behind the batch's requests)
+        bool scaled = false;
         for (int l = lvl0; l < lvl1; ++l) {
             const int sh = (int)spatial_shapes[2 * l], sw = (int)spatial_shapes[2 * l + 1];
             const int ls = (int)level_start[l];
-            for (int p = 0; p < P; ++p, ++lp) {
-                const int nlp = lp + 1 < lp1 ? lp + 1 : lp;
-                const fbbev_v2f o = o_next;
-                const float a = a_next;
-                o_next = *reinterpret_cast<const fbbev_v2f*>(offsets + (wo0 + (long long)nlp * wo_step) * 2);
-                a_next = attn[wa0 + (long long)nlp * wa_step];
-                const int z = p % Za;
-                const float loc_w = rx[z] + __fdiv_rn(o[0], (float)sw);
-                const float loc_h = ry[z] + __fdiv_rn(o[1], (float)sh);
-                const float h_im = loc_h * sh - 0.5f, w_im = loc_w * sw - 0.5f;
-                if (!(h_im > -1.f && w_im > -1.f && h_im < (float)sh && w_im < (float)sw)) continue;
-                const float weight = a * dw[z];
-                const fbbev_bilinear s = fbbev_bilinear_setup(h_im, w_im, sh, sw, 1);          // o1..o4 = token indices of the level
-                const int t1 = ls + s.o1 - tok0, t2 = ls + s.o2 - tok0, t3 = ls + s.o3 - tok0, t4 = ls + s.o4 - tok0;
-                const bool k1 = s.o1 >= 0 && t1 >= 0 && t1 < span, k2 = s.o2 >= 0 && t2 >= 0 && t2 < span;
-                const bool k3 = s.o3 >= 0 && t3 >= 0 && t3 < span, k4 = s.o4 >= 0 && t4 >= 0 && t4 < span;
-                float tg[DH];
+            for (int p0 = 0; p0 < P; p0 += PB) {
+                fbbev_v2f ob[PB];
+                float ab[PB];
 #pragma unroll
-                for (int c = 0; c < DH; ++c) tg[c] = gs[c] * weight;                // w_corner * (g * weight): the order of the other kernels
-                fbbev_lds_corner_add<DH>(k1, plane + FBBEV_DA_PLANE_IDX(t1, HS), s.w1, tg);
-                fbbev_lds_corner_add<DH>(k2, plane + FBBEV_DA_PLANE_IDX(t2, HS), s.w2, tg);
-                fbbev_lds_corner_add<DH>(k3, plane + FBBEV_DA_PLANE_IDX(t3, HS), s.w3, tg);
-                fbbev_lds_corner_add<DH>(k4, plane + FBBEV_DA_PLANE_IDX(t4, HS), s.w4, tg);
+                for (int e = 0; e < PB; ++e) {
+                    const long long lp = (long long)l * P + (p0 + e < P ? p0 + e : p0);       // (clamped: unconditional loads)
+                    ob[e] = *reinterpret_cast<const fbbev_v2f*>(offsets + (wo0 + lp * wo_step) * 2);
+                    ab[e] = attn[wa0 + lp * wa_step];
+                }
+                if (!scaled) {
+#pragma unroll
+                    for (int c = 0; c < DH; ++c) gs[c] = gs[c] / inv * sc;                // sc is a power of two: exact
+                    scaled = true;
+                }
+#pragma unroll
+                for (int e = 0; e < PB; ++e) {
+                    const int p = p0 + e;
+                    if (p >= P) break;
+                    const fbbev_v2f o = ob[e];
+                    const float a = ab[e];
+                    const int z = p % Za;
+                    const float loc_w = rx[z] + __fdiv_rn(o[0], (float)sw);
+                    const float loc_h = ry[z] + __fdiv_rn(o[1], (float)sh);
+                    const float h_im = loc_h * sh - 0.5f, w_im = loc_w * sw - 0.5f;
+                    if (!(h_im > -1.f && w_im > -1.f && h_im < (float)sh && w_im < (float)sw)) continue;
+                    const float weight = a * dw[z];
+                    const fbbev_bilinear s = fbbev_bilinear_setup(h_im, w_im, sh, sw, 1);          // o1..o4 = token indices of the level
+                    const int t1 = ls + s.o1 - tok0, t2 = ls + s.o2 - tok0, t3 = ls + s.o3 - tok0, t4 = ls + s.o4 - tok0;
+                    const bool k1 = s.o1 >= 0 && t1 >= 0 && t1 < span, k2 = s.o2 >= 0 && t2 >= 0 && t2 < span;
+                    const bool k3 = s.o3 >= 0 && t3 >= 0 && t3 < span, k4 = s.o4 >= 0 && t4 >= 0 && t4 < span;
+                    float tg[DH];
+#pragma unroll
+                    for (int c = 0; c < DH; ++c) tg[c] = gs[c] * weight;                // w_corner * (g * weight): the order of the other kernels
+                    fbbev_lds_corner_add<DH>(k1, plane + FBBEV_DA_PLANE_IDX(t1, HS), s.w1, tg);
+                    fbbev_lds_corner_add<DH>(k2, plane + FBBEV_DA_PLANE_IDX(t2, HS), s.w2, tg);
+                    fbbev_lds_corner_add<DH>(k3, plane + FBBEV_DA_PLANE_IDX(t3, HS), s.w3, tg);
+                    fbbev_lds_corner_add<DH>(k4, plane + FBBEV_DA_PLANE_IDX(t4, HS), s.w4, tg);
+                }
             }
         }
     }
