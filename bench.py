@@ -509,17 +509,20 @@ def fb_projection_train_leg(dev, steps, warmup, cpu_seconds, with_cpu=True):
         step()
     torch.cuda.synchronize(dev)
     da_ev = []
-    real = _capi.da_cross_attn_bwd
+    reals = {n: getattr(_capi, n) for n in ('da_cross_attn_bwd', 'da_cross_attn_bwd_planes')}     # whichever entry the route takes
 
-    def timed(*a, **k):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        r = real(*a, **k)
-        e1.record()
-        da_ev.append((e0, e1))
-        return r
+    def timed_of(real):
+        def timed(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = real(*a, **k)
+            e1.record()
+            da_ev.append((e0, e1))
+            return r
+        return timed
     sev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-    _capi.da_cross_attn_bwd = timed
+    for n, f in reals.items():
+        setattr(_capi, n, timed_of(f))
     try:
         with no_gc():
             t0 = time.perf_counter()
@@ -530,7 +533,8 @@ def fb_projection_train_leg(dev, steps, warmup, cpu_seconds, with_cpu=True):
             torch.cuda.synchronize(dev)
             elapsed = time.perf_counter() - t0
     finally:
-        _capi.da_cross_attn_bwd = real
+        for n, f in reals.items():
+            setattr(_capi, n, f)
     step_ms = sorted(a.elapsed_time(b) for a, b in sev)
     pct = lambda q: step_ms[min(len(step_ms) - 1, int(q * len(step_ms)))]  # noqa: E731
     da_ms = sum(a.elapsed_time(b) for a, b in da_ev) / len(da_ev) if da_ev else None

@@ -95,6 +95,8 @@ SIGNATURES = {
     'fbbev_sum_partials': (c_int, [c_void_p, c_int, c_int64, c_void_p, c_void_p]),
     'fbbev_diag_fill': (c_int, [c_void_p, c_int64, c_int, c_void_p]),
     'fbbev_touch': (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
+    'fbbev_softmax_groups': (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    'fbbev_softmax_groups_bwd': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     'fbbev_layernorm_bwd_partials': (c_int, [c_int64]),
     'fbbev_layernorm_bwd': (c_int, [c_void_p] * 3 + [c_float, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     'fbbev_history_conv': (c_int, [c_void_p, c_int64] + [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -1235,6 +1237,23 @@ def layernorm_bwd(x, grad_out, weight, eps):
     with _on(x):          # fixed-order sum of the partial rows (ATen's dim-0 reduction of this shape is one latency chain per column)
         _check(lib().fbbev_sum_partials(_dev(partial, F32, 'partial'), n, 2 * C, _dev(gwb, F32, 'out'), _stream()), 'fbbev_sum_partials')
     return grad_x, gwb[0], gwb[1]
+
+
+def softmax_groups(x, group, out=None):
+    """softmax over groups of `group` consecutive floats of a contiguous f32 tensor (fbbev_softmax_groups); out may be x"""
+    out = torch.empty_like(x) if out is None else out
+    with _on(x):
+        _check(lib().fbbev_softmax_groups(_dev(x, F32, 'x'), x.numel() // group, int(group), _dev(out, F32, 'out'), _stream()), 'fbbev_softmax_groups')
+    return out
+
+
+def softmax_groups_bwd(y, grad_y, group, out=None):
+    """grad_x = y * (grad_y - sum over the group of y * grad_y) (fbbev_softmax_groups_bwd); out may be grad_y"""
+    out = torch.empty_like(grad_y) if out is None else out
+    with _on(y):
+        _check(lib().fbbev_softmax_groups_bwd(_dev(y, F32, 'y'), _dev(grad_y, F32, 'grad_y'), y.numel() // group, int(group),
+                                              _dev(out, F32, 'out'), _stream()), 'fbbev_softmax_groups_bwd')
+    return out
 
 
 def touch(*tensors):

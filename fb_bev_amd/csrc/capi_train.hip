@@ -190,3 +190,31 @@ extern "C" int fbbev_touch(const void* const* spans, const size_t* bytes, int n,
     FBBEV_CHECK_LAUNCH();
     return 0;
 }
+
+// softmax over groups of `group` consecutive floats and its backward (the attention weights of the deformable attentions, training)
+template <bool BWD>
+static int softmax_groups_launch(const float* a, const float* b, long long n_groups, int group, float* out, fbbev_stream_t stream_) {
+    if (n_groups < 0 || group <= 0) return FBBEV_E_BADARG;
+    if (n_groups == 0) return 0;
+    if (!a || !out || (BWD && !b)) return FBBEV_E_BADARG;
+    if (!(group == 4 || group == 8 || group == 16 || group == 32) || !aligned16(a) || !aligned16(out) || (b && !aligned16(b)))
+        return FBBEV_E_UNSUPPORTED;
+    const long long n4 = n_groups * (group / 4), blocks = (n4 + 255) / 256;
+    if (blocks >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
+    fbbev_rt_stream stream = (fbbev_rt_stream)stream_;
+    switch (group) {
+    case 4: FBBEV_LAUNCH((k_softmax_groups<4, BWD>), blocks, 256, 0, stream, a, b, n4, out); break;
+    case 8: FBBEV_LAUNCH((k_softmax_groups<8, BWD>), blocks, 256, 0, stream, a, b, n4, out); break;
+    case 16: FBBEV_LAUNCH((k_softmax_groups<16, BWD>), blocks, 256, 0, stream, a, b, n4, out); break;
+    default: FBBEV_LAUNCH((k_softmax_groups<32, BWD>), blocks, 256, 0, stream, a, b, n4, out); break;
+    }
+    FBBEV_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int fbbev_softmax_groups(const float* x, long long n_groups, int group, float* y, fbbev_stream_t stream_) {
+    return softmax_groups_launch<false>(x, nullptr, n_groups, group, y, stream_);
+}
+extern "C" int fbbev_softmax_groups_bwd(const float* y, const float* grad_y, long long n_groups, int group, float* grad_x,
+                                        fbbev_stream_t stream_) {
+    return softmax_groups_launch<true>(y, grad_y, n_groups, group, grad_x, stream_);
+}

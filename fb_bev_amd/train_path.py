@@ -364,7 +364,7 @@ class EncoderLayerFn(torch.autograd.Function):
         cso = _frag(layer, 'cso_hm', p['cso'][0], p['cso'][1], lambda w_, b_: (w_[perm], b_[perm]))
         caw = _frag(layer, 'caw', *p['caw'])
         so = _lin(y0_2, cso, addend=pos)                                                  # (R, L*P*M*2) head-minor offsets
-        aw = _lin(y0_2, caw, addend=pos).view(R, M, L * P).softmax(-1)
+        aw = _softmax(_lin(y0_2, caw, addend=pos), L * P).view(R, M, L * P)
         from .backward_projection import _pad_interleave_rows
         cv = _frag(layer, 'cv_rows', p['cv'][0], p['cv'][1], lambda w_, b_: _pad_interleave_rows(w_, b_, M, Dh, HS, True))
         rows2 = rows.reshape(BN * S, E)
@@ -389,7 +389,7 @@ class EncoderLayerFn(torch.autograd.Function):
                                     bev_w=geo['bev_w'])
             del v
         del so, g_slots
-        g_lg = torch._softmax_backward_data(g_aw, aw, -1, torch.float32).view(R, M * L * P)
+        g_lg = _softmax_bwd(aw, g_aw, L * P).view(R, M * L * P)
         del g_aw, aw
         g_qp_c = _lin(g_so, _frag(layer, 'cso_hm_t', p['cso'][0], None, lambda w_, b_: (w_[perm].t().contiguous(), None)))
         _lin(g_lg, _frag(layer, 'cawt', p['caw'][0], None, _t), res=g_qp_c, out=g_qp_c)   # d / d (y0 + pos), both heads
@@ -433,7 +433,7 @@ class EncoderLayerFn(torch.autograd.Function):
         nrm = _offset_normalizer(layer, M, Ps, bw, bh, dev)                                # (M*Ps*2): (W, H, W, H, ...)
         csn = _frag(layer, 'sso_n', p['sso'][0], p['sso'][1], lambda w_, b_: (w_ / nrm[:, None], b_ / nrm))
         loc = _lin(q2, csn, addend=pos, res=_ref_rows(layer, geo['ref2d'], M * Ps)).view(B, Q, M, 1, Ps, 2)
-        aw = _lin(q2, caw, addend=pos).view(R, M, Ps).softmax(-1)
+        aw = _softmax(_lin(q2, caw, addend=pos), Ps).view(R, M, Ps)
         v = _lin(q2, _frag(layer, 'sv', *p['sv'])).view(B, Q, M, Dh)
         g_v = torch.empty_like(v)
         g_loc, g_aw = torch.zeros_like(loc), torch.zeros_like(aw)
@@ -441,7 +441,7 @@ class EncoderLayerFn(torch.autograd.Function):
                        g_aw.view(B, Q, M, 1, Ps), level_hw=[(bh, bw)])
         del v, loc, g_a
         g_loc = g_loc.view(R, M * Ps * 2)
-        g_lg = torch._softmax_backward_data(g_aw, aw, -1, torch.float32).view(R, M * Ps)
+        g_lg = _softmax_bwd(aw, g_aw, Ps).view(R, M * Ps)
         del g_aw, aw
         g_qp_s = _lin(g_loc, _frag(layer, 'sso_n_t', p['sso'][0], None, lambda w_, b_: ((w_ / nrm[:, None]).t().contiguous(), None)))
         _lin(g_lg, _frag(layer, 'sawt', p['saw'][0], None, _t), res=g_qp_s, out=g_qp_s)
@@ -461,6 +461,19 @@ class EncoderLayerFn(torch.autograd.Function):
             flat += G[n]
         return (None, None, g_q.view(B, Q, E) if ctx.needs_input_grad[2] else None, g_pos if ctx.needs_input_grad[3] else None,
                 g_rows, g_d if ctx.needs_input_grad[5] else None, *flat)
+
+
+def _softmax(x, group):
+    """softmax over groups of `group` logits, in place (fbbev_softmax_groups); ATen for group sizes the kernel does not take"""
+    if group in (4, 8, 16, 32):
+        return _capi.softmax_groups(x, group, out=x)
+    return x.view(-1, group).softmax(-1).view(x.shape)
+
+
+def _softmax_bwd(y, gy, group):
+    if group in (4, 8, 16, 32):
+        return _capi.softmax_groups_bwd(y.reshape(-1), gy.reshape(-1), group, out=gy.reshape(-1))
+    return torch._softmax_backward_data(gy.view(-1, group), y.view(-1, group), -1, torch.float32)
 
 
 def _pos_table(bev_pos, Q, E):

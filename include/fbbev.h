@@ -707,6 +707,12 @@ int fbbev_rows_linear_x3_train(const float* x, long long x_row_stride, const flo
 /* out (N) = sum over b of x (B, N) [+ x2 (B, N)], ascending b, N % 4 == 0: the batch sum behind a parameter every sample shares
  * (autograd's sum-to-size of `query + query_pos`, backward_projection.py:96-99 `lss_bev + bev_embedding`). */
 int fbbev_sum_leading(const float* x, const float* x2, int B, long long N, float* out, fbbev_stream_t stream);
+/* softmax over groups of `group` consecutive floats (4, 8, 16 or 32: the num_levels * num_points attention logits of one (query,
+ * head), spatial_cross_attention_depth.py:541-546 / mmcv MultiScaleDeformableAttention) and its backward
+ * grad_x = y * (grad_y - sum(y * grad_y)); grad_x may be grad_y.  16-byte aligned pointers, else FBBEV_E_UNSUPPORTED. */
+int fbbev_softmax_groups(const float* x, long long n_groups, int group, float* y, fbbev_stream_t stream);
+int fbbev_softmax_groups_bwd(const float* y, const float* grad_y, long long n_groups, int group, float* grad_x, fbbev_stream_t stream);
+
 /* Read-ahead of a kernel's gather sources: reads up to 8 spans (pointer, bytes) once with 16-byte loads and discards the data, so that
  * the lines are back in the memory-side cache when a later kernel's dependent gathers start (the dense pooling at the end of the
  * forward-backward step: its index tensors, depth and feature rows were written ~0.7 GB of intermediate traffic earlier).  Values

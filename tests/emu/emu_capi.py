@@ -676,3 +676,13 @@ def sum_partials(part):
     out = torch.full((ln,), float('nan'))
     code = lib().fbbev_sum_partials(p(part), n, ln, p(out), None)
     return code, out
+
+
+def softmax_groups(x, group):
+    out = torch.full_like(x, float('nan'))
+    return lib().fbbev_softmax_groups(p(x), x.numel() // group, group, p(out), None), out
+
+
+def softmax_groups_bwd(y, gy, group):
+    out = torch.full_like(y, float('nan'))
+    return lib().fbbev_softmax_groups_bwd(p(y), p(gy), y.numel() // group, group, p(out), None), out

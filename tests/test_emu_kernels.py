@@ -830,6 +830,21 @@ def test_sum_partials_emulated():
     assert torch.equal(s, s2)
 
 
+@pytest.mark.parametrize('group', [4, 8, 16, 32])
+def test_softmax_groups_forward_and_backward_emulated(group):
+    g = torch.Generator().manual_seed(group)
+    x = torch.randn(37, 8, group, generator=g) * 3
+    gy = torch.randn(37, 8, group, generator=g)
+    c, y = E.softmax_groups(x, group)
+    exp = x.double().softmax(-1)
+    assert c == 0 and (y.double() - exp).abs().max() < 3e-7
+    c, gx = E.softmax_groups_bwd(y, gy, group)
+    yd = y.double()
+    ex = yd * (gy.double() - (yd * gy.double()).sum(-1, keepdim=True))
+    assert c == 0 and (gx.double() - ex).abs().max() < 1e-6
+    assert E.lib().fbbev_softmax_groups(E.p(x), 10, 12, E.p(y), None) == -2
+
+
 def test_rows_wgrad_rejects_unsupported_shapes():
     assert E.lib().fbbev_rows_wgrad_x3_ws_bytes(100, 6, 8) == 0            # in_features % 4 != 0
     assert E.lib().fbbev_rows_wgrad_x3_ws_bytes(100, 8, 6) == 0
