@@ -74,3 +74,27 @@ def test_head_minor_projection_is_a_row_permutation_of_the_reference_projection(
     assert so2.shape == (2, 37, 4, 8, 8, 2) and aw2.shape == aw.shape
     assert torch.allclose(so2, so.permute(0, 1, 3, 4, 2, 5), atol=1e-6)
     assert torch.allclose(aw2, aw, atol=1e-6)
+
+
+def test_fused_tail_is_refused_while_the_ffn_has_a_live_dropout():
+    """the cross-attention tail + FFN one-kernel route (fbbev_rows_tail_ffn_x3) has no dropout; FB-OCC variants
+    with ffn_dropout > 0 under model.train() + torch.no_grad() must keep the FFN's own Dropout layers -- fused_tail_spec answers None
+    then, as FFN.forward itself keeps `self.layers`.  In eval() mode, or with p = 0 in train() mode, the route stays available
+    (the spec itself needs GPU weights: only the gate is checked here)."""
+    import torch
+    from fb_bev_amd import backward_projection as BP
+    ffn = BP.FFN(embed_dims=80, feedforward_channels=320, ffn_drop=0.1)
+    ffn.train()
+    assert ffn._has_live_dropout() and ffn.fused_tail_spec(80) is None
+    ffn0 = BP.FFN(embed_dims=80, feedforward_channels=320, ffn_drop=0.0)
+    ffn0.train()
+    assert not ffn0._has_live_dropout()
+    # the training route's gate refuses a layer with a live dropout as well
+    from fb_bev_amd import configs, train_path as TP
+    cfg = configs.fbocc_r50(bev_h=16, bev_w=16)
+    cfg['backward_projection']['transformer']['encoder']['transformerlayers']['ffn_dropout'] = 0.1
+    m = BP.build(cfg['backward_projection']).train()
+    layer = m.transformer.encoder.layers[0]
+    assert layer.ffns[0]._has_live_dropout()
+    q = torch.zeros(1, 256, 80)
+    assert not TP.layer_supported(layer, q, q, torch.zeros(6, 704, 80), None, torch.zeros(6, 1, 256, 4, 2), None, 16, 16, None)
