@@ -1470,7 +1470,8 @@ def history_conv(feats, w1, bias1, w2, bias2, out, compute=torch.float32, voxel_
         raise FbbevError("history_conv: compute is float32, bfloat16 or 'bf16x3'")
     if compute == 'bf16x3' and not (voxel_major and feats.dtype in (torch.bfloat16, torch.float16)):
         raise FbbevError("history_conv: compute='bf16x3' needs a 16-bit voxel-major ring")
-    ws = torch.empty((1 + T1) * C * max(C, Cout, 96), dtype=torch.float32, device=feats.device)   # fragment-ordered weights
+    # fragment-ordered weights (+ the scaled biases of the split-operand route)
+    ws = torch.empty((1 + T1) * C * max(C, Cout, 96) + B * T1 * C, dtype=torch.float32, device=feats.device)
     args = (_dev(feats, feats.dtype, 'feats', contiguous=False), feats.stride(0), _dev(w1, F32, 'w1'),
             _dev(bias1, F32, 'bias1'), _dev(w2, F32, 'w2'), _dev(bias2, F32, 'bias2'),
             B, T1, C, Cout, N, _dev(out, F32, 'out'), c_void_p(ws.data_ptr()), ws.numel() * 4)

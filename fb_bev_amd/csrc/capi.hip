@@ -2748,28 +2748,38 @@ extern "C" int fbbev_history_conv_bf16x3(const void* feats, long long feats_stri
     if ((long long)N * C * 2 >= (1ll << 32)) return FBBEV_E_UNSUPPORTED;                          // 32-bit byte offsets in a frame
     const int MT = C / 16, KS = (C + 31) / 32;
     const size_t part1 = (size_t)MT * KS * 64 * 8, part2 = part1;
-    const size_t need = (2 * part1 + (size_t)T1 * 2 * part2) * sizeof(unsigned short);
+    const size_t wbytes = (2 * part1 + (size_t)T1 * 2 * part2) * sizeof(unsigned short);
+    const size_t need = wbytes + (size_t)B * T1 * C * sizeof(float);
     if (!workspace || !aligned16(workspace) || workspace_bytes < need) return FBBEV_E_WORKSPACE;
     fbbev_rt_stream stream = (fbbev_rt_stream)stream_;
     unsigned short* w1x = static_cast<unsigned short*>(workspace);
     unsigned short* w2x = w1x + 2 * part1;
-    const int nfrag = (MT * KS + T1 * MT * KS) * 64;
-    FBBEV_LAUNCH(k_history_weight_fragments_bf16x3, (nfrag + 255) / 256, 256, 0, stream, w1, w2, MT, MT, C, T1, w1x);
+    float* biasx = reinterpret_cast<float*>(static_cast<char*>(workspace) + wbytes);
+    const long long nprep = (long long)(MT * KS + T1 * MT * KS) * 64 + (long long)B * T1 * C;
+    if (nprep >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
+    if (elem_type == 1)
+        FBBEV_LAUNCH(k_history_weight_fragments_bf16x3<1>, (nprep + 255) / 256, 256, 0, stream, w1, w2, bias1, MT, MT, C, T1, B * T1, w1x, biasx);
+    else
+        FBBEV_LAUNCH(k_history_weight_fragments_bf16x3<2>, (nprep + 255) / 256, 256, 0, stream, w1, w2, bias1, MT, MT, C, T1, B * T1, w1x, biasx);
     FBBEV_CHECK_LAUNCH();
-    const int tiles_per_b = (N + 127) / 128;
+    const int tile_voxels = 128 * FBBEV_HX3_NV;
+    const int tiles_per_b = (N + tile_voxels - 1) / tile_voxels;
     const long long blocks = (long long)B * tiles_per_b;
     if (blocks >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
-    const size_t a2s = (size_t)((2 * part2 / 8 + 511) / 512) * 512 * 8;
-    const size_t lds = (2 * a2s + part1 + (size_t)8 * 16 * 2 * (KS * 32 + 8)) * sizeof(unsigned short);
-#define FBBEV_HX3(MT_, ET_)                                                                                            \
+    const size_t a2s = (size_t)((2 * part2 / 8 + C / 4 + 511) / 512) * 512 * 8;
+    const size_t lds = (2 * a2s + 2 * part1) * sizeof(unsigned short);
+#define FBBEV_HX3(MT_, ET_, PF_)                                                                                       \
     do {                                                                                                              \
-        int e_ = fbbev_rt_allow_dyn_lds((const void*)k_history_conv_bf16x3<MT_, MT_, ET_>, lds);                        \
+        int e_ = fbbev_rt_allow_dyn_lds((const void*)k_history_conv_bf16x3<MT_, MT_, ET_, PF_>, lds);                   \
         if (e_) return e_;                                                                                            \
-        FBBEV_LAUNCH((k_history_conv_bf16x3<MT_, MT_, ET_>), blocks, 512, lds, stream, feats, feats_stride_b,           \
-                     (const unsigned short*)w1x, bias1, (const unsigned short*)w2x, bias2, T1, N, tiles_per_b, out);    \
+        FBBEV_LAUNCH((k_history_conv_bf16x3<MT_, MT_, ET_, PF_>), blocks, 512, lds, stream, feats, feats_stride_b,      \
+                     (const unsigned short*)w1x, (const float*)biasx, (const unsigned short*)w2x, bias2, T1, N,       \
+                     tiles_per_b, out);                                                                               \
     } while (0)
-    if (C == 80) { if (elem_type == 1) FBBEV_HX3(5, 1); else FBBEV_HX3(5, 2); }
-    else { if (elem_type == 1) FBBEV_HX3(1, 1); else FBBEV_HX3(1, 2); }
+#define FBBEV_HX3P(MT_, ET_) FBBEV_HX3(MT_, ET_, 2)      /* two frames of X in flight: three spill (256 registers at 2 waves / SIMD) */
+    if (C == 80) { if (elem_type == 1) FBBEV_HX3P(5, 1); else FBBEV_HX3P(5, 2); }
+    else { if (elem_type == 1) FBBEV_HX3P(1, 1); else FBBEV_HX3P(1, 2); }
+#undef FBBEV_HX3P
 #undef FBBEV_HX3
     FBBEV_CHECK_LAUNCH();
     return 0;

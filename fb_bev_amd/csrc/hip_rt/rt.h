@@ -138,6 +138,15 @@ __device__ __forceinline__ fbbev_bf16x8 fbbev_ld_bf16x8(const void* p) { return 
 __device__ __forceinline__ fbbev_v4f fbbev_mfma_f32_16x16x32_bf16(fbbev_bf16x8 a, fbbev_bf16x8 b, fbbev_v4f c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
+// v_mfma_f32_16x16x32_f16: the same shape and slot rule with IEEE binary16 operands (8 halves = 16 raw bytes per lane), fp32
+// accumulation: a product of two halves is exact in fp32 (11 x 11 mantissa bits).
+__device__ __forceinline__ fbbev_v4f fbbev_mfma_f32_16x16x32_f16(fbbev_v4u a, fbbev_v4u b, fbbev_v4f c) {
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    h8 ha, hb;
+    __builtin_memcpy(&ha, &a, 16);
+    __builtin_memcpy(&hb, &b, 16);
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(ha, hb, c, 0, 0, 0);
+}
 
 // wave-level ordering point for a wave-PRIVATE LDS region: the 64 lanes run in lockstep and the LDS queue of a wave is
 // in order, so only the compiler has to be kept from moving LDS accesses across it (no s_barrier, no other wave waits)

@@ -1,19 +1,31 @@
-// history_conv_x3_kernels.h -- the two folded 1x1x1 convolutions of the temporal fusion at fp32-GRADE precision on the bf16
-// MFMA ("bf16 x 3", round 3).
+// history_conv_x3_kernels.h -- the two folded 1x1x1 convolutions of the temporal fusion at fp32-GRADE precision on the 16-bit
+// MFMAs (split operands; round 3, rebuilt in round 6).
 //
 // The exact route (k_history_conv_t: v_mfma_f32_16x16x4_f32) is compute bound: 10.5 ms of the 16.6 ms BASELINE configs[4] step.
 // The bf16 route (k_history_conv_bf16) is 5x faster but rounds weights, frames and the intermediate to 8 mantissa bits (~4e-3
-// of the output peak).  Here every operand is split into TWO bf16 terms, v = hi + lo with hi = bf16(v), lo = bf16(v - hi)
-// (16 mantissa bits), and a product is three MFMAs:  a.b ~= a_hi.b_hi + a_lo.b_hi + a_hi.b_lo  (the dropped lo.lo term and the
-// split's own remainder are both ~2^-17 relative), fp32 accumulation as before:
-//   * an fp16 ring element has 11 mantissa bits: its split is EXACT; a bf16 ring element is its own hi (two MFMAs);
-//   * the folded weights are split once per launch (k_history_weight_fragments_bf16x3), the ReLU'd intermediate when it is
-//     parked in LDS (two rows per voxel: hi and lo).
+// of the output peak).  Here no operand loses more than ~2^-17 of itself:
+//   * convolution 1 (x_t -> y_t, C x C): the ring element IS the MFMA operand -- an fp16 ring goes through
+//     v_mfma_f32_16x16x32_f16 untouched, a bf16 ring through v_mfma_f32_16x16x32_bf16 -- and the folded weight is split into two
+//     16-bit terms of that type, W = hi + lo (22 / 16 mantissa bits): TWO MFMAs per product, no conversion of the frames at all.
+//     For the fp16 form a weight row is scaled by a power of two S_c so that its largest entry sits at 2^11 (hi and lo stay
+//     normal halves whatever the layer's scale); the bias of that row is scaled with it, and column c of W2 by 1 / S_c --
+//     all exact -- so the kernel never multiplies by a scale: y'_c = relu(acc + S_c b_c) = S_c y_c.
+//   * convolution 2 (y_t -> out, Cout x T1 C): y' (fp32) and W2' are split into two bf16 terms each, a product is three MFMAs
+//     a_hi.b_hi + a_lo.b_hi + a_hi.b_lo (the dropped lo.lo term and the split's own remainder are ~2^-17 relative).
 // Error against the fp32 convolutions of the same stored frames: ~1e-5 of the output peak (tests) -- three decimal digits
-// better than the TF32 arithmetic PyTorch's cuDNN convolutions use by default on the reference's own hardware, at ~3x the
-// bf16 kernel's MFMA work instead of the fp32 MFMA's 16x.
-// Shape: voxel-major 16-bit ring only.  512 threads = 8 waves x 16 voxels per workgroup so that the LDS-staged weights (W2 hi + lo,
-// 30 KB per frame, double buffered; W1 lo 15 KB; W1 hi stays in registers) are shared by 128 voxels: 132 KB, one workgroup per CU.
+// better than the TF32 arithmetic PyTorch's cuDNN convolutions use by default on the reference's own hardware.
+//
+// Round 6 layout (the round-3 kernel spent a frame as: 45 LDS fragment reads each waited for by the MFMA behind it,
+// ~225 VALU operations converting frames and re-packing y through LDS, and 90 MFMAs per 16 voxels -- 8 850 cycles per frame per CU
+// where the MFMAs need 2 900):
+//   * a wave owns NV = 2 tiles of 16 voxels: an A fragment read from LDS feeds 2 x (2 or 3) MFMAs, and the fragments of one K step
+//     (all output tiles, hi and lo) are requested together, ahead of the MFMAs that use them;
+//   * y never goes through LDS: with the weights as the A operand a lane ends convolution 1 holding channels 16 mt + 4 (lane/16) +
+//     r of voxel lane%16, and the K order of an MFMA is free as long as A and B agree -- W2's fragments are laid out so that K
+//     slot (lane/16, e) of step s stands for channel 16 (2 s + e/4) + 4 (lane/16) + e%4: the B operand of step s is the pair of
+//     accumulator tiles 2 s, 2 s + 1 of the same lane, split in registers;
+//   * the frame's bias rides in the LDS block of W2_t (one staging stream, double buffered, one barrier per frame).
+// Shape: voxel-major 16-bit ring only.  512 threads = 8 waves x 32 voxels per workgroup; LDS: W2 block 2 x 32 KB + W1 30 KB.
 #pragma once
 #include "rt.h"
 #include "history_kernels.h"
@@ -21,136 +33,183 @@
 
 #include "x3_split.h"
 
-template <int MT1, int MT2, int ET>
+#define FBBEV_HX3_NV 2                                    // 16-voxel tiles per wave
+
+template <int ET>
+__device__ __forceinline__ fbbev_v4f fbbev_mfma_16x16x32_raw(fbbev_v4u a, fbbev_v4u b, fbbev_v4f c) {
+    if constexpr (ET == 2) return fbbev_mfma_f32_16x16x32_f16(a, b, c);
+    else {
+        fbbev_bf16x8 xa, xb;
+        __builtin_memcpy(&xa, &a, 16);
+        __builtin_memcpy(&xb, &b, 16);
+        return fbbev_mfma_f32_16x16x32_bf16(xa, xb, c);
+    }
+}
+
+template <int MT1, int MT2, int ET, int PF>
 __global__ void __launch_bounds__(512)
 k_history_conv_bf16x3(const void* __restrict__ feats, long long fstride_b, const unsigned short* __restrict__ w1x,
-                      const float* __restrict__ bias1, const unsigned short* __restrict__ w2x, const float* __restrict__ bias2,
+                      const float* __restrict__ biasx, const unsigned short* __restrict__ w2x, const float* __restrict__ bias2,
                       int T1, int N, int tiles_per_b, float* __restrict__ out) {
     static_assert(ET == 1 || ET == 2, "16-bit voxel-major ring");
-    constexpr int C = 16 * MT1, Cout = 16 * MT2, KS = (C + 31) / 32, CP = KS * 32, PITCH = CP + 8;
-    constexpr int A1 = MT1 * KS * 64 * 8;                 // bf16 elements of one W1 part (hi or lo)
-    constexpr int A2 = MT2 * KS * 64 * 8;                 // ... of one W2 part of one frame; a frame's block is [hi | lo]
-    constexpr int A2P = (2 * A2 / 8 + 511) / 512;         // 16-byte pieces of a frame's block per thread
+    constexpr int NV = FBBEV_HX3_NV;
+    constexpr int C = 16 * MT1, Cout = 16 * MT2, KS = (C + 31) / 32;
+    constexpr int A1 = MT1 * KS * 64 * 8;                 // 16-bit elements of one W1 part (hi or lo)
+    constexpr int A2 = MT2 * KS * 64 * 8;                 // ... of one W2 part of one frame; a frame's block is [hi | lo | bias]
+    constexpr int NW2 = 2 * A2 / 8, NBI = C / 4;          // 16-byte pieces of a frame's block: weights, then the C bias floats
+    constexpr int NP = NW2 + NBI, A2P = (NP + 511) / 512;
     constexpr int A2S = A2P * 512 * 8;                    // elements of a staging buffer
-    constexpr int PF = 3;                                 // frames of X in flight
+    constexpr int NW1 = 2 * A1 / 8, IW1 = (NW1 + 511) / 512;
     unsigned short* lds = reinterpret_cast<unsigned short*>(fbbev_dyn_lds_f32());
     unsigned short* a2buf = lds;                          // [2][A2S]
-    unsigned short* a1lo = lds + 2 * A2S;                 // [A1]
+    unsigned short* w1buf = lds + 2 * A2S;                // [hi A1 | lo A1]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int g = lane >> 4, j = lane & 15;
     const int b = blockIdx.x / tiles_per_b, tile = blockIdx.x - b * tiles_per_b;
-    const int n = tile * 128 + wave * 16 + j;
-    const bool inb = n < N;
-    unsigned short* yh = a1lo + A1 + ((wave * 16 + j) * 2) * PITCH;      // this voxel's hi row; the lo row follows it
-    unsigned short* yl = yh + PITCH;
-    for (int c = C + g; c < CP; c += 4) { yh[c] = 0; yl[c] = 0; }        // padding channels of the intermediate
-    for (int i = threadIdx.x; i < 2 * A2 / 8; i += 512)                   // W2_0 (hi | lo)
-        reinterpret_cast<fbbev_v4u*>(a2buf)[i] = reinterpret_cast<const fbbev_v4u*>(w2x)[i];
-    for (int i = threadIdx.x; i < A1 / 8; i += 512)                       // W1 lo
-        reinterpret_cast<fbbev_v4u*>(a1lo)[i] = reinterpret_cast<const fbbev_v4u*>(w1x + A1)[i];
+    int n[NV];
+    bool inb[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        n[v] = tile * (128 * NV) + (wave * NV + v) * 16 + j;
+        inb[v] = n[v] < N;
+    }
+    // a frame's block: piece i < NW2 of W2_t, then the frame's (scaled) bias
+    auto block_piece = [&](int t, int q) -> fbbev_v4u {
+        const int i = (int)threadIdx.x + 512 * q;
+        const fbbev_v4u* wsrc = reinterpret_cast<const fbbev_v4u*>(w2x + (long long)t * 2 * A2);
+        const fbbev_v4u* bsrc = reinterpret_cast<const fbbev_v4u*>(biasx + ((long long)b * T1 + t) * C);
+        if (512 * (q + 1) <= NW2) return wsrc[i];                                      // the whole round is weights
+        const fbbev_v4u* src = i < NW2 ? wsrc + i : bsrc + (i - NW2 < NBI ? i - NW2 : 0);
+        return *src;
+    };
+    {   // block 0 and W1 (hi | lo): every piece REQUESTED before the first is stored
+        fbbev_v4u ta[A2P], tb[IW1];
+#pragma unroll
+        for (int q = 0; q < A2P; ++q) ta[q] = block_piece(0, q);
+#pragma unroll
+        for (int k = 0; k < IW1; ++k) { const int i = (int)threadIdx.x + 512 * k; tb[k] = reinterpret_cast<const fbbev_v4u*>(w1x)[i < NW1 ? i : 0]; }
+#pragma unroll
+        for (int q = 0; q < A2P; ++q) reinterpret_cast<fbbev_v4u*>(a2buf)[threadIdx.x + 512 * q] = ta[q];
+#pragma unroll
+        for (int k = 0; k < IW1; ++k) { const int i = (int)threadIdx.x + 512 * k; if (i < NW1) reinterpret_cast<fbbev_v4u*>(w1buf)[i] = tb[k]; }
+    }
     const long long xb = (long long)b * fstride_b;
-    fbbev_bf16x8 a1[MT1][KS];
-#pragma unroll
-    for (int mt = 0; mt < MT1; ++mt)
-#pragma unroll
-        for (int s = 0; s < KS; ++s) a1[mt][s] = fbbev_ld_bf16x8(w1x + ((mt * KS + s) * 64 + lane) * 8);
-    fbbev_v4f acc2[MT2];
+    fbbev_v4f acc2[NV][MT2];
 #pragma unroll
     for (int mt = 0; mt < MT2; ++mt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc2[mt][r] = bias2[16 * mt + 4 * g + r];
-    fbbev_v4u bv[PF][KS];                                   // X stays RAW in registers until it is used
-    unsigned int xoff[KS];
+        for (int r = 0; r < 4; ++r) {
+            const float bz = bias2[16 * mt + 4 * g + r];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        const int c = 32 * s + 8 * g;
-        xoff[s] = (inb && c < C) ? (unsigned int)(((long long)n * C + c) * 2) : 0u;
-    }
+            for (int v = 0; v < NV; ++v) acc2[v][mt][r] = bz;
+        }
+    fbbev_v4u bv[PF][NV][KS];                               // X stays RAW in registers: it is the B operand as loaded
+    unsigned int xoff[NV][KS];
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int c = 32 * s + 8 * g;
+            xoff[v][s] = (inb[v] && c < C) ? (unsigned int)(((long long)n[v] * C + c) * 2) : 0u;
+        }
     auto load_x = [&](int slot, long long base) {
         const char* fb = static_cast<const char*>(feats) + base * 2;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) bv[slot][s] = *reinterpret_cast<const fbbev_v4u*>(fb + xoff[s]);
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) bv[slot][v][s] = *reinterpret_cast<const fbbev_v4u*>(fb + xoff[v][s]);
     };
     const long long fsz = (long long)C * N;
 #pragma unroll
     for (int u = 0; u < PF; ++u)
         if (u < T1) load_x(u, xb + (long long)u * fsz);
-    const fbbev_bf16x8 zero8 = fbbev_cvt_bf16x8(fbbev_v4f{0.f, 0.f, 0.f, 0.f}, fbbev_v4f{0.f, 0.f, 0.f, 0.f});
+    const fbbev_v4u zero4 = {0u, 0u, 0u, 0u};
+    const fbbev_v4f zero4f = {0.f, 0.f, 0.f, 0.f};
     auto frame = [&](int t, auto slot_c) {
         constexpr int SL = decltype(slot_c)::value;
-        __syncthreads();                                        // W2_t is in a2buf[t & 1]; a2buf[(t + 1) & 1] is free again
-        const float* b1 = bias1 + ((long long)b * T1 + t) * C;
-        fbbev_v4u wst[A2P];
-        {
-            const fbbev_v4u* wn = reinterpret_cast<const fbbev_v4u*>(w2x + (long long)(t + 1 < T1 ? t + 1 : t) * 2 * A2);
+        __syncthreads();                                        // block t is in a2buf[t & 1]; a2buf[(t + 1) & 1] is free again
+        const unsigned short* a2t = a2buf + (t & 1) * A2S;
+        fbbev_v4f acc1[NV][MT1];
 #pragma unroll
-            for (int q = 0; q < A2P; ++q) {
-                const int i = threadIdx.x + 512 * q;
-                wst[q] = wn[i < 2 * A2 / 8 ? i : 0];
-            }
-        }
-        fbbev_sched_fence();
-        fbbev_v4f bia[MT1], acc1[MT1];
+        for (int v = 0; v < NV; ++v)
 #pragma unroll
-        for (int mt = 0; mt < MT1; ++mt) {
-            bia[mt] = *reinterpret_cast<const fbbev_v4f*>(b1 + 16 * mt + 4 * g);
-            acc1[mt] = fbbev_v4f{0.f, 0.f, 0.f, 0.f};
-        }
-        fbbev_sched_fence();
+            for (int mt = 0; mt < MT1; ++mt) acc1[v][mt] = zero4f;
+        // ---- convolution 1: W1 (hi, lo) . x_t, the K step's fragments requested together
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            const bool ok = inb && 32 * s + 8 * g < C;
-            fbbev_bf16x8 xh, xl = zero8;
-            if constexpr (ET == 1) {
-                __builtin_memcpy(&xh, &bv[SL][s], 16);           // a bf16 ring piece is its own hi term
-            } else {
-                fbbev_v4f lo4, hi4;
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    lo4[2 * e] = fbbev_widen<ET>(bv[SL][s][e] & 0xffffu);     lo4[2 * e + 1] = fbbev_widen<ET>(bv[SL][s][e] >> 16);
-                    hi4[2 * e] = fbbev_widen<ET>(bv[SL][s][2 + e] & 0xffffu); hi4[2 * e + 1] = fbbev_widen<ET>(bv[SL][s][2 + e] >> 16);
-                }
-                fbbev_split_bf16x8(lo4, hi4, xh, xl);            // exact: 11 mantissa bits = 8 + 3
-                xl = ok ? xl : zero8;
-            }
-            xh = ok ? xh : zero8;
+            fbbev_v4u ah[MT1], al[MT1], xr[NV];
 #pragma unroll
             for (int mt = 0; mt < MT1; ++mt) {
-                const fbbev_bf16x8 al = fbbev_ld_bf16x8(a1lo + ((mt * KS + s) * 64 + lane) * 8);
-                acc1[mt] = fbbev_mfma_f32_16x16x32_bf16(al, xh, acc1[mt]);
-                if constexpr (ET != 1) acc1[mt] = fbbev_mfma_f32_16x16x32_bf16(a1[mt][s], xl, acc1[mt]);
-                acc1[mt] = fbbev_mfma_f32_16x16x32_bf16(a1[mt][s], xh, acc1[mt]);
+                ah[mt] = *reinterpret_cast<const fbbev_v4u*>(w1buf + ((mt * KS + s) * 64 + lane) * 8);
+                al[mt] = *reinterpret_cast<const fbbev_v4u*>(w1buf + A1 + ((mt * KS + s) * 64 + lane) * 8);
             }
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                xr[v] = bv[SL][v][s];
+                if (32 * s + 32 > C) xr[v] = (32 * s + 8 * g < C) ? xr[v] : zero4;      // K padding: 0 x (another voxel's bits) must stay 0
+            }
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+#pragma unroll
+                for (int mt = 0; mt < MT1; ++mt) acc1[v][mt] = fbbev_mfma_16x16x32_raw<ET>(al[mt], xr[v], acc1[v][mt]);
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+#pragma unroll
+                for (int mt = 0; mt < MT1; ++mt) acc1[v][mt] = fbbev_mfma_16x16x32_raw<ET>(ah[mt], xr[v], acc1[v][mt]);
         }
         fbbev_sched_fence();
+        // the next block and the next frames of X: requested here, under the epilogue and convolution 2
+        fbbev_v4u wst[A2P];
+        {
+            const int tn = t + 1 < T1 ? t + 1 : t;
+#pragma unroll
+            for (int q = 0; q < A2P; ++q) wst[q] = block_piece(tn, q);
+        }
         load_x(SL, xb + (long long)(t + PF < T1 ? t + PF : T1 - 1) * fsz);
         fbbev_sched_fence();
-        fbbev_wave_sync();                                                  // the Y rows are wave-private
+        // ---- y' = relu(acc + bias'), split into bf16 hi / lo in the K order of W2's fragments: step s = tiles 2 s, 2 s + 1
+        fbbev_bf16x8 yh[NV][KS], yl[NV][KS];
+        {
+            const float* bt = reinterpret_cast<const float*>(a2t + 2 * A2);
+            fbbev_v4f bia[MT1];
 #pragma unroll
-        for (int mt = 0; mt < MT1; ++mt) {
-            const fbbev_v4f y = {fmaxf(acc1[mt][0] + bia[mt][0], 0.f), fmaxf(acc1[mt][1] + bia[mt][1], 0.f),
-                                 fmaxf(acc1[mt][2] + bia[mt][2], 0.f), fmaxf(acc1[mt][3] + bia[mt][3], 0.f)};
-            fbbev_bf16x8 h8, l8;
-            fbbev_split_bf16x8(y, y, h8, l8);
-            unsigned long long fh, fl;
-            __builtin_memcpy(&fh, &h8, 8);
-            __builtin_memcpy(&fl, &l8, 8);
-            *reinterpret_cast<unsigned long long*>(yh + 16 * mt + 4 * g) = fh;
-            *reinterpret_cast<unsigned long long*>(yl + 16 * mt + 4 * g) = fl;
+            for (int mt = 0; mt < MT1; ++mt) bia[mt] = *reinterpret_cast<const fbbev_v4f*>(bt + 16 * mt + 4 * g);
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    fbbev_v4f y0, y1 = zero4f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) y0[r] = fmaxf(acc1[v][2 * s][r] + bia[2 * s][r], 0.f);
+                    if (2 * s + 1 < MT1) {
+                        const int m1 = 2 * s + 1 < MT1 ? 2 * s + 1 : 0;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) y1[r] = fmaxf(acc1[v][m1][r] + bia[m1][r], 0.f);
+                    }
+                    fbbev_split_bf16x8(y0, y1, yh[v][s], yl[v][s]);
+                }
         }
-        fbbev_wave_sync();
-        const unsigned short* a2t = a2buf + (t & 1) * A2S;
+        // ---- convolution 2: acc2 += W2'_t . y'
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            const fbbev_bf16x8 yho = fbbev_ld_bf16x8(yh + 32 * s + 8 * g), ylo = fbbev_ld_bf16x8(yl + 32 * s + 8 * g);
+            fbbev_bf16x8 ah[MT2], al[MT2];
 #pragma unroll
             for (int mt = 0; mt < MT2; ++mt) {
-                const fbbev_bf16x8 ah = fbbev_ld_bf16x8(a2t + ((mt * KS + s) * 64 + lane) * 8);
-                const fbbev_bf16x8 al = fbbev_ld_bf16x8(a2t + A2 + ((mt * KS + s) * 64 + lane) * 8);
-                acc2[mt] = fbbev_mfma_f32_16x16x32_bf16(al, yho, acc2[mt]);
-                acc2[mt] = fbbev_mfma_f32_16x16x32_bf16(ah, ylo, acc2[mt]);
-                acc2[mt] = fbbev_mfma_f32_16x16x32_bf16(ah, yho, acc2[mt]);
+                ah[mt] = fbbev_ld_bf16x8(a2t + ((mt * KS + s) * 64 + lane) * 8);
+                al[mt] = fbbev_ld_bf16x8(a2t + A2 + ((mt * KS + s) * 64 + lane) * 8);
             }
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+#pragma unroll
+                for (int mt = 0; mt < MT2; ++mt) acc2[v][mt] = fbbev_mfma_f32_16x16x32_bf16(al[mt], yh[v][s], acc2[v][mt]);
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+#pragma unroll
+                for (int mt = 0; mt < MT2; ++mt) acc2[v][mt] = fbbev_mfma_f32_16x16x32_bf16(ah[mt], yl[v][s], acc2[v][mt]);
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+#pragma unroll
+                for (int mt = 0; mt < MT2; ++mt) acc2[v][mt] = fbbev_mfma_f32_16x16x32_bf16(ah[mt], yh[v][s], acc2[v][mt]);
         }
         {
             fbbev_v4u* wd = reinterpret_cast<fbbev_v4u*>(a2buf + ((t + 1) & 1) * A2S);
@@ -160,42 +219,94 @@ k_history_conv_bf16x3(const void* __restrict__ feats, long long fstride_b, const
     };
     for (int t = 0; t < T1; t += PF) {
         frame(t, fbbev_ic<0>{});
-        if (t + 1 < T1) frame(t + 1, fbbev_ic<1>{});
-        if (t + 2 < T1) frame(t + 2, fbbev_ic<2>{});
+        if constexpr (PF > 1) { if (t + 1 < T1) frame(t + 1, fbbev_ic<(PF > 1 ? 1 : 0)>{}); }
+        if constexpr (PF > 2) { if (t + 2 < T1) frame(t + 2, fbbev_ic<(PF > 2 ? 2 : 0)>{}); }
     }
-    if (inb) {
-        float* ob = out + (long long)b * Cout * N + n;
 #pragma unroll
-        for (int mt = 0; mt < MT2; ++mt)
+    for (int v = 0; v < NV; ++v)
+        if (inb[v]) {
+            float* ob = out + (long long)b * Cout * N + n[v];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ob[(long long)(16 * mt + 4 * g + r) * N] = fmaxf(acc2[mt][r], 0.f);
-    }
+            for (int mt = 0; mt < MT2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ob[(long long)(16 * mt + 4 * g + r) * N] = fmaxf(acc2[v][mt][r], 0.f);
+        }
 }
 
-// Folded weights -> split bf16 A operands in fragment order: dst = [ w1 hi | w1 lo | per frame t: w2_t hi | w2_t lo ], a part =
-// [mt][s][lane][8], element e of a lane = W[16 mt + lane % 16][32 s + 8 (lane / 16) + e] (zero beyond C).
+// Row scale of convolution 1 (fp16 form): the power of two that puts the row's largest |w| in [2^11, 2^12) -- as float bits, with
+// its reciprocal; 1 for a zero row or one outside 2^+-30 (nothing to gain there, and S y must stay far from the fp32 range's ends).
+__device__ __forceinline__ void fbbev_hx3_row_scale(float rowmax, float& s, float& inv) {
+    unsigned int u;
+    __builtin_memcpy(&u, &rowmax, 4);
+    const int eb = (int)((u >> 23) & 0xffu);
+    unsigned int su = 0x3f800000u, iu = 0x3f800000u;
+    if (eb >= 97 && eb <= 157) { su = (unsigned int)(265 - eb) << 23; iu = (unsigned int)(eb - 11) << 23; }
+    __builtin_memcpy(&s, &su, 4);
+    __builtin_memcpy(&inv, &iu, 4);
+}
+
+// Folded weights -> split 16-bit A operands in fragment order, and the biases of convolution 1 in its rows' scale:
+//   dst  = [ w1 hi | w1 lo | per frame t: w2_t hi | w2_t lo ], a part = [mt][s][lane][8];
+//   W1 (ET 2: halves of S_row w, ET 1: bf16 of w): element e of a lane = W1[16 mt + lane % 16][32 s + 8 (lane / 16) + e];
+//   W2 (bf16 of w / S_c): element e = W2_t[16 mt + lane % 16][c], c = 16 (2 s + e / 4) + 4 (lane / 16) + e % 4 -- the channels a lane
+//   of k_history_conv_bf16x3 holds after convolution 1 (zero beyond C);
+//   bias_dst[bt][c] = S_c bias1[bt][c].
+template <int ET>
 __global__ void __launch_bounds__(256)
-k_history_weight_fragments_bf16x3(const float* __restrict__ w1, const float* __restrict__ w2, int MT1, int MT2, int C, int T1,
-                                  unsigned short* __restrict__ dst) {
+k_history_weight_fragments_bf16x3(const float* __restrict__ w1, const float* __restrict__ w2, const float* __restrict__ bias1,
+                                  int MT1, int MT2, int C, int T1, int BT, unsigned short* __restrict__ dst,
+                                  float* __restrict__ bias_dst) {
+    __shared__ float sc[256], isc[256];
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float m = 0.f, s = 1.f, inv = 1.f;
+        if constexpr (ET == 2) {
+            for (int k = 0; k < C; ++k) m = fmaxf(m, fabsf(w1[(long long)c * C + k]));
+            fbbev_hx3_row_scale(m, s, inv);
+        }
+        sc[c] = s; isc[c] = inv;
+    }
+    __syncthreads();
     const int KS = (C + 31) / 32;
     const int n1 = MT1 * KS * 64, n2 = MT2 * KS * 64;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;                   // one lane-fragment (8 elements, both parts) per thread
-    if (i >= n1 + T1 * n2) return;
+    if (i >= n1 + T1 * n2) {
+        const int k = i - (n1 + T1 * n2);                                  // then one bias per thread
+        if (k < BT * C) bias_dst[k] = bias1[k] * sc[k % C];
+        return;
+    }
     fbbev_v4f lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
     const int ii = i < n1 ? i : (i - n1) % n2, t = i < n1 ? 0 : (i - n1) / n2;
     const int lane = ii & 63, s = (ii >> 6) % KS, mt = (ii >> 6) / KS;
-    const float* row = i < n1 ? w1 + (long long)(16 * mt + (lane & 15)) * C
-                              : w2 + (long long)(16 * mt + (lane & 15)) * ((long long)T1 * C) + (long long)t * C;
+    const int row = 16 * mt + (lane & 15), g = lane >> 4;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const int c = 32 * s + 8 * (lane >> 4) + e;
-        const float v = c < C ? row[c] : 0.f;
+        float v = 0.f;
+        if (i < n1) {
+            const int c = 32 * s + 8 * g + e;
+            if (c < C) v = w1[(long long)row * C + c] * sc[row];
+        } else {
+            const int c = 16 * (2 * s + (e >> 2)) + 4 * g + (e & 3);
+            if (c < C) v = w2[(long long)row * ((long long)T1 * C) + (long long)t * C + c] * isc[c];
+        }
         if (e < 4) lo[e] = v; else hi[e - 4] = v;
+    }
+    unsigned short* ph = i < n1 ? dst + (long long)ii * 8 : dst + 2ll * n1 * 8 + ((long long)t * 2 * n2 + ii) * 8;
+    unsigned short* pl = ph + (long long)(i < n1 ? n1 : n2) * 8;
+    if (ET == 2 && i < n1) {                                               // two halves: hi = f16(v), lo = f16(v - hi)
+        fbbev_v4u h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float a = e < 2 ? lo[2 * e] : hi[2 * e - 4], c = e < 2 ? lo[2 * e + 1] : hi[2 * e - 3];
+            h[e] = fbbev_cvt_pk16<2>(a, c);
+            const float ra = a - fbbev_f16_bits_to_f32(h[e] & 0xffffu), rc = c - fbbev_f16_bits_to_f32(h[e] >> 16);
+            l[e] = fbbev_cvt_pk16<2>(ra, rc);
+        }
+        __builtin_memcpy(ph, &h, 16);
+        __builtin_memcpy(pl, &l, 16);
+        return;
     }
     fbbev_bf16x8 h8, l8;
     fbbev_split_bf16x8(lo, hi, h8, l8);
-    unsigned short* ph = i < n1 ? dst + (long long)ii * 8 : dst + 2ll * n1 * 8 + ((long long)t * 2 * n2 + ii) * 8;
-    unsigned short* pl = ph + (long long)(i < n1 ? n1 : n2) * 8;
     __builtin_memcpy(ph, &h8, 16);
     __builtin_memcpy(pl, &l8, 16);
 }

@@ -815,11 +815,13 @@ int fbbev_history_conv_bf16(const void* feats, long long feats_stride_b, const f
                             const float* w2, const float* bias2, int B, int T1, int C, int Cout, int N, float* out,
                             void* workspace, size_t workspace_bytes, int voxel_major, int elem_type, fbbev_stream_t stream);
 
-/* The same two convolutions at fp32-GRADE precision on the bf16 MFMA: every operand split into two bf16 terms (hi + lo, 16
- * mantissa bits), three MFMAs per product, fp32 accumulation -- ~1e-5 of the output peak against the fp32 convolutions
- * (an fp16 ring element splits exactly; the reference's own convolutions run TF32 by default on its hardware).  Voxel-major
- * 16-bit ring only (feats (B, T1, N, C), elem_type FBBEV_ELEM_BF16 / FBBEV_ELEM_F16), C = Cout in {16, 80};
- * workspace >= (2 + 2 T1) * (C/16) * ceil(C/32) * 512 * 2 bytes, 16-byte aligned. */
+/* The same two convolutions at fp32-GRADE precision on the 16-bit MFMAs, operands split into two 16-bit terms (hi + lo), fp32
+ * accumulation -- ~1e-5 of the output peak against the fp32 convolutions (the reference's own convolutions run TF32 by default
+ * on its hardware).  Convolution 1 takes the ring element as stored (f16 MFMA for an fp16 ring, bf16 MFMA for a bf16 ring) with
+ * the weight split in two terms of that type: two MFMAs per product; convolution 2 splits the fp32 intermediate and its weights
+ * into two bf16 terms each: three MFMAs per product.  Voxel-major 16-bit ring only (feats (B, T1, N, C), elem_type
+ * FBBEV_ELEM_BF16 / FBBEV_ELEM_F16), C = Cout in {16, 80};
+ * workspace >= (2 + 2 T1) * (C/16) * ceil(C/32) * 512 * 2 + B * T1 * C * 4 bytes, 16-byte aligned. */
 int fbbev_history_conv_bf16x3(const void* feats, long long feats_stride_b, const float* w1, const float* bias1,
                               const float* w2, const float* bias2, int B, int T1, int C, int Cout, int N, float* out,
                               void* workspace, size_t workspace_bytes, int elem_type, fbbev_stream_t stream);

@@ -485,7 +485,7 @@ def history_conv(feats, w1, bias1, w2, bias2, bf16=False, voxel_major=False, x3=
         B, TC, N = feats.shape
         T1 = TC // C
     out = torch.full((B, Cout, N), float('nan'))
-    ws = torch.zeros((1 + T1) * C * max(C, Cout, 96))
+    ws = torch.zeros((1 + T1) * C * max(C, Cout, 96) + B * T1 * C)
     et = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[feats.dtype]
     args = (c_void_p(feats.data_ptr()), feats.stride(0), p(w1), p(bias1), p(w2), p(bias2), B, T1, C, Cout, N, p(out), p(ws),
             ws.numel() * 4)

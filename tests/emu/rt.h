@@ -263,6 +263,25 @@ inline float fbbev_f16_bits_to_f32(unsigned int h) {
     __builtin_memcpy(&f, &u, 4);
     return f;
 }
+// emulation of v_mfma_f32_16x16x32_f16 (raw halves; same slot rule and k-ordered fp32 chain as the bf16 form above)
+inline fbbev_v4f fbbev_mfma_f32_16x16x32_f16(fbbev_v4u a, fbbev_v4u b, fbbev_v4f c) {
+    emu::State& s = emu::S();
+    const int w = s.cur >> 6, lane = s.cur & 63;
+    static thread_local fbbev_v4u A[16][64], B[16][64];
+    A[w][lane] = a; B[w][lane] = b;
+    emu::wave_barrier();
+    const int g = lane >> 4, j = lane & 15;
+    fbbev_v4f d = c;
+    auto half = [](const fbbev_v4u& v, int e) { return fbbev_f16_bits_to_f32((v[e >> 1] >> (16 * (e & 1))) & 0xffffu); };
+    for (int r = 0; r < 4; ++r) {
+        float acc = c[r];
+        for (int gg = 0; gg < 4; ++gg)
+            for (int e = 0; e < 8; ++e) acc += half(A[w][gg * 16 + 4 * g + r], e) * half(B[w][gg * 16 + j], e);
+        d[r] = acc;
+    }
+    emu::wave_barrier();
+    return d;
+}
 inline void fbbev_wave_sync() { emu::wave_barrier(); }
 inline void fbbev_sched_fence() {}
 inline void fbbev_pin(fbbev_v2f&) {}

@@ -51,7 +51,8 @@ def test_no_kernel_uses_scratch_or_spills(res):
     # (round 5: the per-sample fixed-point scale added one more loop-carried value to k_da_cross_attn_bwd_unit: 65 parked scalars)
     # (k_rows_linear_x3: 23 kernel arguments; round 5's batched staging / epilogue loads park two more: 26)
     # (round 6: the training-epilogue instantiation <2, false, 1> has two more pointer arguments and their strides: 40)
-    lim = lambda k: 72 if ('k_da_cross_attn_bwd_' in k or 'k_da_cross_attn_fwd_pipe' in k) else (  # noqa: E731
+    # (round 6: k_da_bwd_scatter_owned keeps the next hit's record and a point batch's words requested across its walk: 51 parked)
+    lim = lambda k: 72 if ('k_da_cross_attn_bwd_' in k or 'k_da_cross_attn_fwd_pipe' in k or 'k_da_bwd_scatter_owned' in k) else (  # noqa: E731
         48 if 'k_rows_linear_x3ILi2ELb0ELi1E' in k else (32 if 'k_rows_linear_x3I' in k else 24))
     over = {k: v.get('sgpr_spills', 0) for k, v in res.items() if v.get('sgpr_spills', 0) > lim(k)}
     assert not over, over
@@ -73,7 +74,7 @@ BUDGETS = {
     r'k_da_cross_attn_fwd_pipeILi10ELi4ELi2E': 200,   # pipelined sampler, the default build: 2 waves / SIMD x 2 samples in flight per lane    # the shipped head dim: 3 waves / SIMD (12 corner loads of a sample in flight)
     r'k_da_cross_attn_bwdILi': 128,            # the global-atomic backward: 4 waves / SIMD
     r'k_da_cross_attn_bwd_scatterILi\d+ELi10E': 96,   # chunked value-gradient scatter at the shipped head dim: 5 waves / SIMD
-    r'k_da_bwd_scatter_ownedILi\d+ELi10E': 96,        # output-owned scatter (round 4)
+    r'k_da_bwd_scatter_ownedILi\d+ELi10E': 112,       # output-owned scatter (round 4); round 6 keeps the next record + a point batch in flight (96 -> 111: its LDS planes already hold it to 4 waves / SIMD)
     r'k_da_cross_attn_bwd_unitILi10E': 224,    # unit-owned gradients at the shipped head dim: 2 waves / SIMD (48 corner registers in flight)
     r'k_history_warp': 168,
     r'k_history_conv_tILi5ELi5E': 512,         # register-resident weights: one wave per SIMD by design (the whole file)
