@@ -2520,9 +2520,10 @@ extern "C" int fbbev_history_warp(const float* history, long long history_stride
 }
 
 // voxel-major ring: frames [T][N][C] per sample (history_kernels.h)
-extern "C" int fbbev_history_warp_vm(const void* history, long long history_stride_b, const float* rt_flow, int B, int T, int C,
-                                     int Z, int Y, int X, void* out, long long out_stride_b, int elem_type,
-                                     fbbev_stream_t stream_) {
+struct fbbev_warp_vm_plan { int groups, n_xc, YB, nyb; };
+
+static int history_warp_vm_plan(const void* history, long long& history_stride_b, const float* rt_flow, int B, int T, int C,
+                                int Z, int Y, int X, void* out, long long& out_stride_b, int elem_type, fbbev_warp_vm_plan& pl) {
     if (B < 0 || T < 0 || C <= 0 || Z < 2 || Y < 2 || X < 2) return FBBEV_E_BADARG;
     if (elem_type < 0 || elem_type > 2) return FBBEV_E_BADARG;
     if (B == 0 || T == 0) return 0;
@@ -2535,36 +2536,60 @@ extern "C" int fbbev_history_warp_vm(const void* history, long long history_stri
     if (history_stride_b < (long long)T * frame || out_stride_b < (long long)T * frame) return FBBEV_E_BADARG;
     if (C % VE != 0 || history_stride_b % VE != 0 || out_stride_b % VE != 0 || !aligned16(history) || !aligned16(out))
         return FBBEV_E_UNSUPPORTED;
-    const int groups = C / VE;
+    pl.groups = C / VE;
     if (frame * (elem_type == 0 ? 4 : 2) >= (1ll << 32)) return FBBEV_E_UNSUPPORTED;      // 32-bit byte offsets inside a frame
-    const int n_xc = (X * groups + 255) / 256;                   // workgroups per grid row
+    pl.n_xc = (X * pl.groups + 255) / 256;                        // workgroups per grid row
     int YB = 128 / Z;                                             // rows per band: a (z, y) slab of ~128 workgroups per x chunk
     if (const char* e = getenv("FBBEV_HISTORY_VM_YB")) YB = atoi(e);        // tuning knob (profiles/r02_time_history_bf16_voxel_major.jsonl)
     if (YB < 1) YB = 1;
     if (YB > Y) YB = Y;
-    const int nyb = (Y + YB - 1) / YB;
+    pl.YB = YB;
+    pl.nyb = (Y + YB - 1) / YB;
+    return 0;
+}
+
+// the bands yb0 .. yb0 + nyb_c - 1 of every sample (all of them: the whole warp)
+static int history_warp_vm_bands(const void* history, long long history_stride_b, const float* rt_flow, int B, int T, int C,
+                                 int Z, int Y, int X, void* out, long long out_stride_b, int elem_type,
+                                 const fbbev_warp_vm_plan& pl, int yb0, int nyb_c, fbbev_rt_stream stream) {
     constexpr int TU = 2;
-    const long long blocks = (long long)B * nyb * n_xc * YB * Z;
+    const int groups = pl.groups, n_xc = pl.n_xc, YB = pl.YB;
+    const long long blocks = (long long)B * nyb_c * n_xc * YB * Z;
     if (blocks >= (1ll << 31) - 8) return FBBEV_E_UNSUPPORTED;
+    if (blocks == 0) return 0;
     const int per_xcd = (int)((blocks + 7) / 8);
-    fbbev_rt_stream stream = (fbbev_rt_stream)stream_;
     // occupancy experiment knob (round 3, profiles/r03_exp_history_occupancy.jsonl): dynamic LDS the kernel does not use, in KB
     static const size_t warp_pad = [] { const char* e = getenv("FBBEV_HISTORY_WARP_LDS_PAD_KB"); return e ? (size_t)atoi(e) * 1024 : (size_t)0; }();
     if (warp_pad > 64 * 1024) {
         fbbev_rt_allow_dyn_lds((const void*)k_history_warp_vm<0, TU, 1>, warp_pad);
         fbbev_rt_allow_dyn_lds((const void*)k_history_warp_vm<1, TU, 1>, warp_pad);
         fbbev_rt_allow_dyn_lds((const void*)k_history_warp_vm<2, TU, 1>, warp_pad);
+        fbbev_rt_allow_dyn_lds((const void*)k_history_warp_vm<2, 4, 1>, warp_pad);
     }
-#define FBBEV_HWVM(ET_, ST_)                                                                                                 \
-    FBBEV_LAUNCH((k_history_warp_vm<ET_, TU, ST_>), (long long)per_xcd * 8, 256, warp_pad, stream, history, history_stride_b, rt_flow, \
-                 T, C, Z, Y, X, groups, n_xc, YB, nyb, per_xcd, (int)blocks, out, out_stride_b)
+#define FBBEV_HWVM(ET_, TU_, ST_)                                                                                            \
+    FBBEV_LAUNCH((k_history_warp_vm<ET_, TU_, ST_>), (long long)per_xcd * 8, 256, warp_pad, stream, history, history_stride_b, rt_flow, \
+                 T, C, Z, Y, X, groups, n_xc, YB, nyb_c, per_xcd, (int)blocks, out, out_stride_b, yb0)
     // ST = 1: non-temporal ring stores (A/B on one box: 4.0 vs 4.2 ms at 400x400x16, 0.56 vs 0.61 ms at 100x100x8 B=4)
-    if (elem_type == 0) FBBEV_HWVM(0, 1);
-    else if (elem_type == 1) FBBEV_HWVM(1, 1);
-    else FBBEV_HWVM(2, 1);
+    // fp16 ring: four frames (32 taps) in flight per thread -- the widening rides in the multiply (v_fma_mix_f32), which left the
+    // registers for it (round 6: 3.45 -> 3.33 ms at 400x400x16); FBBEV_HISTORY_VM_TU=2 restores two
+    static const int tu2 = [] { const char* e = getenv("FBBEV_HISTORY_VM_TU"); return e && atoi(e) == 2 ? 1 : 0; }();
+    if (elem_type == 0) FBBEV_HWVM(0, TU, 1);
+    else if (elem_type == 1) FBBEV_HWVM(1, TU, 1);
+    else if (tu2) FBBEV_HWVM(2, TU, 1);
+    else FBBEV_HWVM(2, 4, 1);
 #undef FBBEV_HWVM
     FBBEV_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int fbbev_history_warp_vm(const void* history, long long history_stride_b, const float* rt_flow, int B, int T, int C,
+                                     int Z, int Y, int X, void* out, long long out_stride_b, int elem_type,
+                                     fbbev_stream_t stream_) {
+    fbbev_warp_vm_plan pl{};
+    const int e = history_warp_vm_plan(history, history_stride_b, rt_flow, B, T, C, Z, Y, X, out, out_stride_b, elem_type, pl);
+    if (e || B == 0 || T == 0) return e;
+    return history_warp_vm_bands(history, history_stride_b, rt_flow, B, T, C, Z, Y, X, out, out_stride_b, elem_type, pl, 0, pl.nyb,
+                                 (fbbev_rt_stream)stream_);
 }
 
 extern "C" int fbbev_history_frame_vm(const float* curr, int B, int C, int N, int inner, void* out, long long out_stride_b,
@@ -2733,11 +2758,12 @@ extern "C" int fbbev_history_conv_bf16(const void* feats, long long feats_stride
 #undef FBBEV_HCB
 }
 
-// fp32-grade convolutions on the bf16 MFMA (three products per operand pair, history_conv_x3_kernels.h): voxel-major 16-bit ring
-extern "C" int fbbev_history_conv_bf16x3(const void* feats, long long feats_stride_b, const float* w1, const float* bias1,
-                                         const float* w2, const float* bias2, int B, int T1, int C, int Cout, int N,
-                                         float* out, void* workspace, size_t workspace_bytes, int elem_type,
-                                         fbbev_stream_t stream_) {
+// fp32-grade convolutions on the 16-bit MFMAs (split operands, history_conv_x3_kernels.h): voxel-major 16-bit ring
+struct fbbev_conv_x3_plan { unsigned short* w1x; unsigned short* w2x; float* biasx; size_t pieces, part1; };
+
+static int history_conv_x3_prepare(const void* feats, long long& feats_stride_b, const float* w1, const float* bias1, const float* w2,
+                                   const float* bias2, int B, int T1, int C, int Cout, int N, float* out, void* workspace,
+                                   size_t workspace_bytes, int elem_type, fbbev_rt_stream stream, fbbev_conv_x3_plan& pl) {
     if (B < 0 || T1 <= 0 || C <= 0 || Cout <= 0 || N < 0 || elem_type < 0 || elem_type > 2) return FBBEV_E_BADARG;
     if (B == 0 || N == 0) return 0;
     if (!feats || !w1 || !bias1 || !w2 || !bias2 || !out) return FBBEV_E_BADARG;
@@ -2751,37 +2777,139 @@ extern "C" int fbbev_history_conv_bf16x3(const void* feats, long long feats_stri
     const size_t wbytes = (2 * part1 + (size_t)T1 * 2 * part2) * sizeof(unsigned short);
     const size_t need = wbytes + (size_t)B * T1 * C * sizeof(float);
     if (!workspace || !aligned16(workspace) || workspace_bytes < need) return FBBEV_E_WORKSPACE;
-    fbbev_rt_stream stream = (fbbev_rt_stream)stream_;
-    unsigned short* w1x = static_cast<unsigned short*>(workspace);
-    unsigned short* w2x = w1x + 2 * part1;
-    float* biasx = reinterpret_cast<float*>(static_cast<char*>(workspace) + wbytes);
+    pl.w1x = static_cast<unsigned short*>(workspace);
+    pl.w2x = pl.w1x + 2 * part1;
+    pl.biasx = reinterpret_cast<float*>(static_cast<char*>(workspace) + wbytes);
     const long long nprep = (long long)(MT * KS + T1 * MT * KS) * 64 + (long long)B * T1 * C;
     if (nprep >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
     if (elem_type == 1)
-        FBBEV_LAUNCH(k_history_weight_fragments_bf16x3<1>, (nprep + 255) / 256, 256, 0, stream, w1, w2, bias1, MT, MT, C, T1, B * T1, w1x, biasx);
+        FBBEV_LAUNCH(k_history_weight_fragments_bf16x3<1>, (nprep + 255) / 256, 256, 0, stream, w1, w2, bias1, MT, MT, C, T1, B * T1, pl.w1x, pl.biasx);
     else
-        FBBEV_LAUNCH(k_history_weight_fragments_bf16x3<2>, (nprep + 255) / 256, 256, 0, stream, w1, w2, bias1, MT, MT, C, T1, B * T1, w1x, biasx);
+        FBBEV_LAUNCH(k_history_weight_fragments_bf16x3<2>, (nprep + 255) / 256, 256, 0, stream, w1, w2, bias1, MT, MT, C, T1, B * T1, pl.w1x, pl.biasx);
     FBBEV_CHECK_LAUNCH();
-    const int tile_voxels = 128 * FBBEV_HX3_NV;
-    const int tiles_per_b = (N + tile_voxels - 1) / tile_voxels;
+    pl.pieces = 2 * part2 / 8 + C / 4;
+    pl.part1 = part1;
+    return 0;
+}
+
+// n_seg segments of seg_len voxels, seg_stride apart from voxel seg0 on, in every sample (one segment of N voxels: the whole volume)
+static int history_conv_x3_segments(const void* feats, long long feats_stride_b, const float* bias2, int B, int T1, int C, int N,
+                                    float* out, int elem_type, const fbbev_conv_x3_plan& pl, int seg0, int seg_stride, int seg_len,
+                                    int n_seg, int nw, fbbev_rt_stream stream) {
+    if (seg_len <= 0 || n_seg <= 0) return 0;
+    const int nt = 64 * nw;                                       // nw = 8: a workgroup fills a CU's registers; 4: half of them (the pipelined step)
+    const int tile_voxels = 16 * nw * FBBEV_HX3_NV;
+    const int tiles_per_seg = (seg_len + tile_voxels - 1) / tile_voxels;
+    const long long tiles_per_b = (long long)tiles_per_seg * n_seg;
     const long long blocks = (long long)B * tiles_per_b;
     if (blocks >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
-    const size_t a2s = (size_t)((2 * part2 / 8 + C / 4 + 511) / 512) * 512 * 8;
-    const size_t lds = (2 * a2s + 2 * part1) * sizeof(unsigned short);
-#define FBBEV_HX3(MT_, ET_, PF_)                                                                                       \
+    // one frame per workgroup barrier (FPB = 2, four W2 buffers: measured 2 % slower, profiles/r06_exp_history_step.md)
+    const size_t lds = ((size_t)2 * ((pl.pieces + nt - 1) / nt) * nt * 8 + 2 * pl.part1) * sizeof(unsigned short);
+#define FBBEV_HX3(MT_, ET_, PF_, NW_, FPB_)                                                                            \
     do {                                                                                                              \
-        int e_ = fbbev_rt_allow_dyn_lds((const void*)k_history_conv_bf16x3<MT_, MT_, ET_, PF_>, lds);                   \
+        int e_ = fbbev_rt_allow_dyn_lds((const void*)k_history_conv_bf16x3<MT_, MT_, ET_, PF_, NW_, FPB_>, lds);        \
         if (e_) return e_;                                                                                            \
-        FBBEV_LAUNCH((k_history_conv_bf16x3<MT_, MT_, ET_, PF_>), blocks, 512, lds, stream, feats, feats_stride_b,      \
-                     (const unsigned short*)w1x, (const float*)biasx, (const unsigned short*)w2x, bias2, T1, N,       \
-                     tiles_per_b, out);                                                                               \
+        FBBEV_LAUNCH((k_history_conv_bf16x3<MT_, MT_, ET_, PF_, NW_, FPB_>), blocks, 64 * NW_, lds, stream, feats, feats_stride_b, \
+                     (const unsigned short*)pl.w1x, (const float*)pl.biasx, (const unsigned short*)pl.w2x, bias2, T1, N, \
+                     (int)tiles_per_b, out, seg0, seg_stride, seg_len, tiles_per_seg);                                 \
     } while (0)
-#define FBBEV_HX3P(MT_, ET_) FBBEV_HX3(MT_, ET_, 2)      /* two frames of X in flight: three spill (256 registers at 2 waves / SIMD) */
+    /* two frames of X in flight: three spill (256 registers at 2 waves / SIMD) */
+#define FBBEV_HX3P(MT_, ET_) do { if (nw == 4) FBBEV_HX3(MT_, ET_, 2, 4, 1); else FBBEV_HX3(MT_, ET_, 2, 8, 1); } while (0)
     if (C == 80) { if (elem_type == 1) FBBEV_HX3P(5, 1); else FBBEV_HX3P(5, 2); }
     else { if (elem_type == 1) FBBEV_HX3P(1, 1); else FBBEV_HX3P(1, 2); }
 #undef FBBEV_HX3P
 #undef FBBEV_HX3
     FBBEV_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int fbbev_history_conv_bf16x3(const void* feats, long long feats_stride_b, const float* w1, const float* bias1,
+                                         const float* w2, const float* bias2, int B, int T1, int C, int Cout, int N,
+                                         float* out, void* workspace, size_t workspace_bytes, int elem_type,
+                                         fbbev_stream_t stream_) {
+    fbbev_conv_x3_plan pl{};
+    fbbev_rt_stream stream = (fbbev_rt_stream)stream_;
+    const int e = history_conv_x3_prepare(feats, feats_stride_b, w1, bias1, w2, bias2, B, T1, C, Cout, N, out, workspace,
+                                          workspace_bytes, elem_type, stream, pl);
+    if (e || B <= 0 || N <= 0) return e;
+    static const int nw = [] { const char* e = getenv("FBBEV_HX3_WAVES"); return e && atoi(e) == 4 ? 4 : 8; }();     // tuning: 256-thread workgroups
+    return history_conv_x3_segments(feats, feats_stride_b, bias2, B, T1, C, N, out, elem_type, pl, 0, 0, N, 1, nw, stream);
+}
+
+// One history step on a 16-bit voxel-major ring as a two-stream pipeline: the warp of a band of grid rows into next[:, 1:] on the
+// caller's stream, the split-operand convolutions of the band before it on a second stream -- a bandwidth-bound gather kernel and
+// an MFMA-bound one that leave each other's resource idle when they run back to back.  next[:, 0] must hold the current frame.
+// The same kernels, operands and results as fbbev_history_warp_vm + fbbev_history_conv_bf16x3, bit for bit.
+struct fbbev_side_stream { fbbev_rt_stream stream; fbbev_rt_event ev[2 + 64]; bool ok; };
+
+static fbbev_side_stream* history_side_stream() {
+    static fbbev_side_stream table[16];
+    static bool made[16];
+    const int d = fbbev_rt_device();
+    if (d < 0 || d >= 16) return nullptr;
+    if (!made[d]) {
+        made[d] = true;
+        // the convolutions' stream outranks the caller's: their 256-thread workgroups (one per CU: LDS) are placed first and the warp's
+        // waves fill the registers that are left -- at equal priority the warp's small workgroups refill every CU before a
+        // convolution workgroup fits (profiles/r06_exp_history_pipeline.md).  FBBEV_HISTORY_STEP_PRIORITY=0: equal priorities
+        const char* pe = getenv("FBBEV_HISTORY_STEP_PRIORITY");
+        table[d].ok = fbbev_rt_stream_create(&table[d].stream, pe && atoi(pe) == 0 ? 0 : 1) == 0;
+        for (int i = 0; i < 2 + 64 && table[d].ok; ++i) table[d].ok = fbbev_rt_event_create(&table[d].ev[i]) == 0;
+    }
+    return table[d].ok ? &table[d] : nullptr;
+}
+
+extern "C" int fbbev_history_step_x3_vm(const void* history, long long history_stride_b, void* next, long long next_stride_b,
+                                        const float* rt_flow, const float* w1, const float* bias1, const float* w2,
+                                        const float* bias2, int B, int T, int C, int Cout, int Z, int Y, int X, float* out,
+                                        void* workspace, size_t workspace_bytes, int elem_type, int chunks,
+                                        fbbev_stream_t stream_) {
+    if (B < 0 || T <= 0 || C <= 0 || Cout <= 0 || Z <= 0 || Y <= 0 || X <= 0 || chunks < 0 || chunks > 64) return FBBEV_E_BADARG;
+    if (B == 0) return 0;
+    if (!history || !next || !rt_flow || !w1 || !bias1 || !w2 || !bias2 || !out) return FBBEV_E_BADARG;
+    if (elem_type != 1 && elem_type != 2) return FBBEV_E_UNSUPPORTED;
+    const long long N = (long long)Z * Y * X, frame = N * C;
+    if (N >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;
+    const int T1 = T + 1;
+    if (next_stride_b == 0) next_stride_b = (long long)T1 * frame;
+    if (next_stride_b < (long long)T1 * frame) return FBBEV_E_BADARG;
+    const int esz = 2;
+    void* warped = static_cast<char*>(next) + frame * esz;                                       // next[:, 1:]
+    fbbev_warp_vm_plan wp{};
+    long long hs = history_stride_b, ns = next_stride_b;
+    int e = history_warp_vm_plan(history, hs, rt_flow, B, T, C, Z, Y, X, warped, ns, elem_type, wp);
+    if (e) return e;
+    fbbev_rt_stream stream = (fbbev_rt_stream)stream_;
+    fbbev_conv_x3_plan cp{};
+    long long fs = next_stride_b;
+    e = history_conv_x3_prepare(next, fs, w1, bias1, w2, bias2, B, T1, C, Cout, (int)N, out, workspace, workspace_bytes, elem_type, stream, cp);
+    if (e) return e;
+    if (chunks == 0) chunks = 10;
+    // the convolutions of the pipeline in 256-thread workgroups: half a CU's registers, so that warp waves share the CU with them
+    static const int step_nw = [] { const char* e = getenv("FBBEV_HISTORY_STEP_WAVES"); return e && atoi(e) == 8 ? 8 : 4; }();
+    if (chunks > wp.nyb) chunks = wp.nyb;
+    fbbev_side_stream* side = chunks > 1 ? history_side_stream() : nullptr;
+    if (!side) {                                                                                  // one chunk: the two kernels back to back
+        e = history_warp_vm_bands(history, hs, rt_flow, B, T, C, Z, Y, X, warped, ns, elem_type, wp, 0, wp.nyb, stream);
+        if (e) return e;
+        return history_conv_x3_segments(next, fs, bias2, B, T1, C, (int)N, out, elem_type, cp, 0, 0, (int)N, 1, 8, stream);
+    }
+#define FBBEV_RT(x) do { const int e_ = (x); if (e_) return e_; } while (0)
+    FBBEV_RT(fbbev_rt_event_record(side->ev[0], stream));
+    FBBEV_RT(fbbev_rt_stream_wait(side->stream, side->ev[0]));
+    for (int i = 0; i < chunks; ++i) {
+        const int yb0 = (int)((long long)wp.nyb * i / chunks), yb1 = (int)((long long)wp.nyb * (i + 1) / chunks);
+        e = history_warp_vm_bands(history, hs, rt_flow, B, T, C, Z, Y, X, warped, ns, elem_type, wp, yb0, yb1 - yb0, stream);
+        if (e) return e;
+        FBBEV_RT(fbbev_rt_event_record(side->ev[2 + i], stream));
+        FBBEV_RT(fbbev_rt_stream_wait(side->stream, side->ev[2 + i]));
+        const int y0 = yb0 * wp.YB, y1 = yb1 * wp.YB < Y ? yb1 * wp.YB : Y;
+        e = history_conv_x3_segments(next, fs, bias2, B, T1, C, (int)N, out, elem_type, cp, y0 * X, Y * X, (y1 - y0) * X, Z, step_nw, side->stream);
+        if (e) return e;
+    }
+    FBBEV_RT(fbbev_rt_event_record(side->ev[1], side->stream));
+    FBBEV_RT(fbbev_rt_stream_wait(stream, side->ev[1]));
+#undef FBBEV_RT
     return 0;
 }
 

@@ -17,6 +17,20 @@ static inline int fbbev_rt_memset_async(void* p, int byte, size_t n, fbbev_rt_st
     return (int)hipMemsetAsync(p, byte, n, s);
 }
 
+// a second stream of the calling thread's device and the events that order work across the two (the pipelined history step)
+typedef hipEvent_t fbbev_rt_event;
+static inline int fbbev_rt_device() { int d = 0; return hipGetDevice(&d) == hipSuccess ? d : -1; }
+// high = 1: the device's highest stream priority (its workgroups are dispatched ahead of the caller's stream's when both wait for a CU)
+static inline int fbbev_rt_stream_create(fbbev_rt_stream* s, int high) {
+    int least = 0, greatest = 0;
+    if (high && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
+        return (int)hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest);
+    return (int)hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+}
+static inline int fbbev_rt_event_create(fbbev_rt_event* e) { return (int)hipEventCreateWithFlags(e, hipEventDisableTiming); }
+static inline int fbbev_rt_event_record(fbbev_rt_event e, fbbev_rt_stream s) { return (int)hipEventRecord(e, s); }
+static inline int fbbev_rt_stream_wait(fbbev_rt_stream s, fbbev_rt_event e) { return (int)hipStreamWaitEvent(s, e, 0); }
+
 static inline int fbbev_rt_allow_dyn_lds(const void* kern, size_t bytes) {
     return (int)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
@@ -146,6 +160,16 @@ __device__ __forceinline__ fbbev_v4f fbbev_mfma_f32_16x16x32_f16(fbbev_v4u a, fb
     __builtin_memcpy(&ha, &a, 16);
     __builtin_memcpy(&hb, &b, 16);
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(ha, hb, c, 0, 0, 0);
+}
+
+// fmaf(half, w, acc) with the half taken straight from a packed pair (v_fma_mix_f32: the widening is part of the instruction -- the
+// same value as v_cvt_f32_f16 + v_fma_f32, one issue slot instead of two).  HI = 0: bits 0..15, HI = 1: bits 16..31.
+template <int HI>
+__device__ __forceinline__ float fbbev_fma_f16(unsigned int pair, float w, float acc) {
+    float d;
+    if constexpr (HI == 0) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(pair), "v"(w), "v"(acc));
+    else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(pair), "v"(w), "v"(acc));
+    return d;
 }
 
 // wave-level ordering point for a wave-PRIVATE LDS region: the 64 lanes run in lockstep and the LDS queue of a wave is

@@ -46,52 +46,63 @@ __device__ __forceinline__ fbbev_v4f fbbev_mfma_16x16x32_raw(fbbev_v4u a, fbbev_
     }
 }
 
-template <int MT1, int MT2, int ET, int PF>
-__global__ void __launch_bounds__(512)
+template <int MT1, int MT2, int ET, int PF, int NW, int FPB>
+__global__ void __launch_bounds__(64 * NW, 2)
 k_history_conv_bf16x3(const void* __restrict__ feats, long long fstride_b, const unsigned short* __restrict__ w1x,
                       const float* __restrict__ biasx, const unsigned short* __restrict__ w2x, const float* __restrict__ bias2,
-                      int T1, int N, int tiles_per_b, float* __restrict__ out) {
+                      int T1, int N, int tiles_per_b, float* __restrict__ out, int seg0, int seg_stride, int seg_len,
+                      int tiles_per_seg) {
     static_assert(ET == 1 || ET == 2, "16-bit voxel-major ring");
-    constexpr int NV = FBBEV_HX3_NV;
+    constexpr int NV = FBBEV_HX3_NV, NT = 64 * NW;          // NW waves of NV x 16 voxels (8: one workgroup fills a CU's registers; 4: half of them)
     constexpr int C = 16 * MT1, Cout = 16 * MT2, KS = (C + 31) / 32;
     constexpr int A1 = MT1 * KS * 64 * 8;                 // 16-bit elements of one W1 part (hi or lo)
     constexpr int A2 = MT2 * KS * 64 * 8;                 // ... of one W2 part of one frame; a frame's block is [hi | lo | bias]
     constexpr int NW2 = 2 * A2 / 8, NBI = C / 4;          // 16-byte pieces of a frame's block: weights, then the C bias floats
-    constexpr int NP = NW2 + NBI, A2P = (NP + 511) / 512;
-    constexpr int A2S = A2P * 512 * 8;                    // elements of a staging buffer
-    constexpr int NW1 = 2 * A1 / 8, IW1 = (NW1 + 511) / 512;
+    constexpr int NP = NW2 + NBI, A2P = (NP + NT - 1) / NT;
+    constexpr int A2S = A2P * NT * 8;                     // elements of a staging buffer
+    constexpr int NW1 = 2 * A1 / 8, IW1 = (NW1 + NT - 1) / NT;
     unsigned short* lds = reinterpret_cast<unsigned short*>(fbbev_dyn_lds_f32());
-    unsigned short* a2buf = lds;                          // [2][A2S]
-    unsigned short* w1buf = lds + 2 * A2S;                // [hi A1 | lo A1]
+    // FPB frames per barrier: block t lives in buffer t % (2 FPB); the block staged during frame t is block t + FPB
+    constexpr int NB = 2 * FPB;
+    unsigned short* a2buf = lds;                          // [NB][A2S]
+    unsigned short* w1buf = lds + NB * A2S;               // [hi A1 | lo A1]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int g = lane >> 4, j = lane & 15;
     const int b = blockIdx.x / tiles_per_b, tile = blockIdx.x - b * tiles_per_b;
+    // the launch covers tiles_per_b / tiles_per_seg segments of seg_len voxels, seg_stride apart from seg0 on: the whole sample
+    // (one segment of N voxels) or, for one chunk of the pipelined step, the rows of a y range in every z plane
+    const int seg = tile / tiles_per_seg, ti = tile - seg * tiles_per_seg;
     int n[NV];
     bool inb[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-        n[v] = tile * (128 * NV) + (wave * NV + v) * 16 + j;
-        inb[v] = n[v] < N;
+        const int nl = ti * (16 * NW * NV) + (wave * NV + v) * 16 + j;
+        inb[v] = nl < seg_len;
+        n[v] = seg0 + seg * seg_stride + nl;
     }
     // a frame's block: piece i < NW2 of W2_t, then the frame's (scaled) bias
     auto block_piece = [&](int t, int q) -> fbbev_v4u {
-        const int i = (int)threadIdx.x + 512 * q;
+        const int i = (int)threadIdx.x + NT * q;
         const fbbev_v4u* wsrc = reinterpret_cast<const fbbev_v4u*>(w2x + (long long)t * 2 * A2);
         const fbbev_v4u* bsrc = reinterpret_cast<const fbbev_v4u*>(biasx + ((long long)b * T1 + t) * C);
-        if (512 * (q + 1) <= NW2) return wsrc[i];                                      // the whole round is weights
+        if (NT * (q + 1) <= NW2) return wsrc[i];                                      // the whole round is weights
         const fbbev_v4u* src = i < NW2 ? wsrc + i : bsrc + (i - NW2 < NBI ? i - NW2 : 0);
         return *src;
     };
     {   // block 0 and W1 (hi | lo): every piece REQUESTED before the first is stored
-        fbbev_v4u ta[A2P], tb[IW1];
+        fbbev_v4u ta[FPB][A2P], tb[IW1];
 #pragma unroll
-        for (int q = 0; q < A2P; ++q) ta[q] = block_piece(0, q);
+        for (int f = 0; f < FPB; ++f)
 #pragma unroll
-        for (int k = 0; k < IW1; ++k) { const int i = (int)threadIdx.x + 512 * k; tb[k] = reinterpret_cast<const fbbev_v4u*>(w1x)[i < NW1 ? i : 0]; }
+            for (int q = 0; q < A2P; ++q) ta[f][q] = block_piece(f < T1 ? f : T1 - 1, q);
 #pragma unroll
-        for (int q = 0; q < A2P; ++q) reinterpret_cast<fbbev_v4u*>(a2buf)[threadIdx.x + 512 * q] = ta[q];
+        for (int k = 0; k < IW1; ++k) { const int i = (int)threadIdx.x + NT * k; tb[k] = reinterpret_cast<const fbbev_v4u*>(w1x)[i < NW1 ? i : 0]; }
 #pragma unroll
-        for (int k = 0; k < IW1; ++k) { const int i = (int)threadIdx.x + 512 * k; if (i < NW1) reinterpret_cast<fbbev_v4u*>(w1buf)[i] = tb[k]; }
+        for (int f = 0; f < FPB; ++f)
+#pragma unroll
+            for (int q = 0; q < A2P; ++q) reinterpret_cast<fbbev_v4u*>(a2buf + f * A2S)[threadIdx.x + NT * q] = ta[f][q];
+#pragma unroll
+        for (int k = 0; k < IW1; ++k) { const int i = (int)threadIdx.x + NT * k; if (i < NW1) reinterpret_cast<fbbev_v4u*>(w1buf)[i] = tb[k]; }
     }
     const long long xb = (long long)b * fstride_b;
     fbbev_v4f acc2[NV][MT2];
@@ -127,13 +138,18 @@ k_history_conv_bf16x3(const void* __restrict__ feats, long long fstride_b, const
     const fbbev_v4f zero4f = {0.f, 0.f, 0.f, 0.f};
     auto frame = [&](int t, auto slot_c) {
         constexpr int SL = decltype(slot_c)::value;
-        __syncthreads();                                        // block t is in a2buf[t & 1]; a2buf[(t + 1) & 1] is free again
-        const unsigned short* a2t = a2buf + (t & 1) * A2S;
-        fbbev_v4f acc1[NV][MT1];
+        if (t % FPB == 0) __syncthreads();                      // blocks t .. t + FPB - 1 are in place; the FPB buffers before them are free again
+        const unsigned short* a2t = a2buf + (t % NB) * A2S;
+        fbbev_v4f acc1[NV][MT1];                                // starts at the frame's bias: it is the C operand of the first MFMA
+        {
+            const float* bt = reinterpret_cast<const float*>(a2t + 2 * A2);
 #pragma unroll
-        for (int v = 0; v < NV; ++v)
+            for (int mt = 0; mt < MT1; ++mt) {
+                const fbbev_v4f bia = *reinterpret_cast<const fbbev_v4f*>(bt + 16 * mt + 4 * g);
 #pragma unroll
-            for (int mt = 0; mt < MT1; ++mt) acc1[v][mt] = zero4f;
+                for (int v = 0; v < NV; ++v) acc1[v][mt] = bia;
+            }
+        }
         // ---- convolution 1: W1 (hi, lo) . x_t, the K step's fragments requested together
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
@@ -161,34 +177,28 @@ k_history_conv_bf16x3(const void* __restrict__ feats, long long fstride_b, const
         // the next block and the next frames of X: requested here, under the epilogue and convolution 2
         fbbev_v4u wst[A2P];
         {
-            const int tn = t + 1 < T1 ? t + 1 : t;
+            const int tn = t + FPB < T1 ? t + FPB : T1 - 1;
 #pragma unroll
             for (int q = 0; q < A2P; ++q) wst[q] = block_piece(tn, q);
         }
         load_x(SL, xb + (long long)(t + PF < T1 ? t + PF : T1 - 1) * fsz);
         fbbev_sched_fence();
-        // ---- y' = relu(acc + bias'), split into bf16 hi / lo in the K order of W2's fragments: step s = tiles 2 s, 2 s + 1
+        // ---- y' = relu(acc) (the bias is in it), split into bf16 hi / lo in the K order of W2's fragments: step s = tiles 2 s, 2 s + 1
         fbbev_bf16x8 yh[NV][KS], yl[NV][KS];
-        {
-            const float* bt = reinterpret_cast<const float*>(a2t + 2 * A2);
-            fbbev_v4f bia[MT1];
 #pragma unroll
-            for (int mt = 0; mt < MT1; ++mt) bia[mt] = *reinterpret_cast<const fbbev_v4f*>(bt + 16 * mt + 4 * g);
+        for (int v = 0; v < NV; ++v)
 #pragma unroll
-            for (int v = 0; v < NV; ++v)
+            for (int s = 0; s < KS; ++s) {
+                fbbev_v4f y0, y1 = zero4f;
 #pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    fbbev_v4f y0, y1 = zero4f;
+                for (int r = 0; r < 4; ++r) y0[r] = fmaxf(acc1[v][2 * s][r], 0.f);
+                if (2 * s + 1 < MT1) {
+                    const int m1 = 2 * s + 1 < MT1 ? 2 * s + 1 : 0;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) y0[r] = fmaxf(acc1[v][2 * s][r] + bia[2 * s][r], 0.f);
-                    if (2 * s + 1 < MT1) {
-                        const int m1 = 2 * s + 1 < MT1 ? 2 * s + 1 : 0;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) y1[r] = fmaxf(acc1[v][m1][r] + bia[m1][r], 0.f);
-                    }
-                    fbbev_split_bf16x8(y0, y1, yh[v][s], yl[v][s]);
+                    for (int r = 0; r < 4; ++r) y1[r] = fmaxf(acc1[v][m1][r], 0.f);
                 }
-        }
+                fbbev_split_bf16x8(y0, y1, yh[v][s], yl[v][s]);
+            }
         // ---- convolution 2: acc2 += W2'_t . y'
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
@@ -212,9 +222,9 @@ k_history_conv_bf16x3(const void* __restrict__ feats, long long fstride_b, const
                 for (int mt = 0; mt < MT2; ++mt) acc2[v][mt] = fbbev_mfma_f32_16x16x32_bf16(ah[mt], yh[v][s], acc2[v][mt]);
         }
         {
-            fbbev_v4u* wd = reinterpret_cast<fbbev_v4u*>(a2buf + ((t + 1) & 1) * A2S);
+            fbbev_v4u* wd = reinterpret_cast<fbbev_v4u*>(a2buf + ((t + FPB) % NB) * A2S);
 #pragma unroll
-            for (int q = 0; q < A2P; ++q) wd[threadIdx.x + 512 * q] = wst[q];
+            for (int q = 0; q < A2P; ++q) wd[threadIdx.x + NT * q] = wst[q];
         }
     };
     for (int t = 0; t < T1; t += PF) {

@@ -230,7 +230,7 @@ template <int ET, int TU, int ST>
 __global__ void __launch_bounds__(256)
 k_history_warp_vm(const void* __restrict__ hist, long long hist_stride_b, const float* __restrict__ flow, int T, int C,
                   int Z, int Y, int X, int groups, int n_xc, int YB, int nyb, int per_xcd, int n_work,
-                  void* __restrict__ out, long long out_stride_b) {
+                  void* __restrict__ out, long long out_stride_b, int yb0) {
     constexpr int VE = ET == 0 ? 4 : 8;
     constexpr int ESZ = ET == 0 ? 4 : 2;
     int work = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);            // one contiguous eighth per XCD
@@ -238,7 +238,7 @@ k_history_warp_vm(const void* __restrict__ hist, long long hist_stride_b, const 
     const int z = work % Z; work /= Z;
     const int yl = work % YB; work /= YB;
     const int xc = work % n_xc; work /= n_xc;
-    const int yb = work % nyb, b = work / nyb;
+    const int yb = yb0 + work % nyb, b = work / nyb;    // the launch covers the bands yb0 .. yb0 + nyb - 1 (all of them, or one chunk of the pipelined step)
     const int y = yb * YB + yl;
     const int item = xc * 256 + (int)threadIdx.x;
     const int x = item / groups, gq = item - x * groups;
@@ -270,10 +270,18 @@ k_history_warp_vm(const void* __restrict__ hist, long long hist_stride_b, const 
             for (int e = 0; e < VE; ++e) acc[e] = 0.f;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                float a[VE];
-                fbbev_widen_vec<ET>(raw[u][k], a);
+                if constexpr (ET == 2) {                 // the half is widened by the multiply itself (same value, half the issue slots)
 #pragma unroll
-                for (int e = 0; e < VE; ++e) acc[e] = fmaf(a[e], w[k], acc[e]);
+                    for (int e = 0; e < 4; ++e) {
+                        acc[2 * e] = fbbev_fma_f16<0>(raw[u][k][e], w[k], acc[2 * e]);
+                        acc[2 * e + 1] = fbbev_fma_f16<1>(raw[u][k][e], w[k], acc[2 * e + 1]);
+                    }
+                } else {
+                    float a[VE];
+                    fbbev_widen_vec<ET>(raw[u][k], a);
+#pragma unroll
+                    for (int e = 0; e < VE; ++e) acc[e] = fmaf(a[e], w[k], acc[e]);
+                }
             }
             // write-once stream: non-temporal, so the new frames do not push the tap rows of the neighbouring workgroups out of L2
             const fbbev_v4u pk = fbbev_narrow_vec<ET>(acc);

@@ -826,6 +826,18 @@ int fbbev_history_conv_bf16x3(const void* feats, long long feats_stride_b, const
                               const float* w2, const float* bias2, int B, int T1, int C, int Cout, int N, float* out,
                               void* workspace, size_t workspace_bytes, int elem_type, fbbev_stream_t stream);
 
+/* One history step on a 16-bit voxel-major ring (the reference's fuse_history, fbocc.py:264-319, after the current frame was put
+ * into next[:, 0] by fbbev_history_frame_vm): fbbev_history_warp_vm of history (B, T, N, C) into next[:, 1:] and
+ * fbbev_history_conv_bf16x3 of next (B, T+1, N, C) into out (B, Cout, N) -- as a pipeline over `chunks` bands of grid rows (0: the
+ * default, 10; 1: the two kernels back to back): the warp of a band runs on `stream`, the convolutions of the band before it
+ * on a second stream of the device that the library keeps, joined back into `stream` before the call returns control of it.
+ * The gather kernel is bound by memory, the convolutions by the MFMA: side by side each uses what the other leaves idle.  Same
+ * kernels, operands and result bits as the two calls.  Shapes, element types and workspace: as fbbev_history_conv_bf16x3. */
+int fbbev_history_step_x3_vm(const void* history, long long history_stride_b, void* next, long long next_stride_b,
+                             const float* rt_flow, const float* w1, const float* bias1, const float* w2, const float* bias2,
+                             int B, int T, int C, int Cout, int Z, int Y, int X, float* out, void* workspace,
+                             size_t workspace_bytes, int elem_type, int chunks, fbbev_stream_t stream);
+
 /* ---- voxel-major history ring (opt-in layout of the inference ring; the reference's is (B, T*C, Z, Y, X), fbocc.py:234)
  * A frame is [voxel n = (z*Y + y)*X + x][channel]: the C elements of a voxel are contiguous, so a trilinear tap is a
  * 16-byte load of 8 (16-bit) / 4 (fp32) channels instead of one 2- / 4-byte gather per channel plane, and

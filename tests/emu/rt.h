@@ -167,6 +167,12 @@ typedef void* fbbev_rt_stream;
 #define FBBEV_LAUNCH(kern, grid, block, lds_bytes, stream, ...) \
     emu::launch((unsigned)(grid), (unsigned)(block), (size_t)(lds_bytes), [=]() { kern(__VA_ARGS__); })
 static inline int fbbev_rt_last_error() { return 0; }
+typedef int fbbev_rt_event;                                  // launches are synchronous here: streams and events are no-ops
+static inline int fbbev_rt_device() { return 0; }
+static inline int fbbev_rt_stream_create(fbbev_rt_stream* s, int) { *s = nullptr; return 0; }
+static inline int fbbev_rt_event_create(fbbev_rt_event* e) { *e = 0; return 0; }
+static inline int fbbev_rt_event_record(fbbev_rt_event, fbbev_rt_stream) { return 0; }
+static inline int fbbev_rt_stream_wait(fbbev_rt_stream, fbbev_rt_event) { return 0; }
 static inline int fbbev_rt_allow_dyn_lds(const void*, size_t) { return 0; }
 static inline int fbbev_rt_memset_async(void* p, int byte, size_t n, fbbev_rt_stream) { memset(p, byte, n); return 0; }
 inline float* fbbev_dyn_lds_f32() {
@@ -281,6 +287,9 @@ inline fbbev_v4f fbbev_mfma_f32_16x16x32_f16(fbbev_v4u a, fbbev_v4u b, fbbev_v4f
     }
     emu::wave_barrier();
     return d;
+}
+template <int HI> inline float fbbev_fma_f16(unsigned int pair, float w, float acc) {
+    return __builtin_fmaf(fbbev_f16_bits_to_f32((pair >> (16 * HI)) & 0xffffu), w, acc);
 }
 inline void fbbev_wave_sync() { emu::wave_barrier(); }
 inline void fbbev_sched_fence() {}

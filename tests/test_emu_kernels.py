@@ -1415,6 +1415,42 @@ def test_history_fused_warp_and_conv_equals_the_two_kernels_emulated(dt, produce
     assert fin.all()                                                         # a NaN flow samples nothing (zero taps), it does not poison
 
 
+@pytest.mark.parametrize('dt', [torch.float16, torch.bfloat16])
+def test_history_step_in_row_bands_equals_the_two_calls_emulated(dt):
+    """fbbev_history_step_x3_vm (warp and split-operand convolutions launched band of rows by band of rows: the chunks of the
+    two-stream pipeline) against fbbev_history_warp_vm + fbbev_history_conv_bf16x3 over the whole volume: the ring and the fused
+    volume are the SAME BITS for 1 chunk (back to back), 2, and more chunks than bands; bands whose row segments are not a
+    multiple of the 256-voxel tile, a padded batch stride, translation / rotation / out-of-grid flows."""
+    g = torch.Generator().manual_seed(17)
+    B, T, C, Z, Y, X = 3, 2, 80, 2, 5, 37                                     # YB = 64 rows per band -> clamped to Y; see FBBEV_HISTORY_VM_YB below
+    N = Z * Y * X
+    hist = torch.full((B, T + 1, N, C), float('nan'), dtype=dt)              # spare slot: padded batch stride
+    hist[:, :T] = (torch.randn(B, T, N, C, generator=g) * 2).to(dt)
+    flow = torch.eye(4)[None].repeat(B, 1, 1)
+    flow[0, :3, 3] = torch.tensor([1.25, -0.5, 0.25])
+    flow[1, :3, :3] = torch.tensor([[0.9, -0.4, 0.0], [0.4, 0.9, 0.0], [0.0, 0.0, 1.0]])
+    flow[2, :3, 3] = torch.tensor([500.0, 0.0, 0.0])
+    curr = torch.randn(B, C, N, generator=g)
+    w1, w2 = torch.randn(C, C, generator=g) * 0.2, torch.randn(C, (T + 1) * C, generator=g) * 0.1
+    b1, b2 = torch.randn(B * (T + 1), C, generator=g), torch.randn(C, generator=g)
+    ref = torch.full((B, T + 1, N, C), float('nan'), dtype=dt)
+    E.history_frame_vm(curr, dt, out=ref[:, 0])
+    E.history_warp_vm(hist[:, :T], flow, (Z, Y, X), out=ref[:, 1:])
+    exp = E.history_conv(ref, w1, b1, w2, b2, voxel_major=True, x3=True)
+    assert torch.isfinite(exp).all()
+    import os
+    os.environ['FBBEV_HISTORY_VM_YB'] = '2'                                  # 3 bands of rows: 2 + 2 + 1
+    try:
+        for chunks in (1, 2, 0, 64):
+            nxt = torch.full((B, T + 1, N, C), float('nan'), dtype=dt)
+            E.history_frame_vm(curr, dt, out=nxt[:, 0])
+            got = E.history_step_x3_vm(hist[:, :T], flow, nxt, (Z, Y, X), w1, b1, w2, b2, chunks=chunks)
+            assert torch.equal(nxt.view(torch.int16), ref.view(torch.int16)), chunks
+            assert torch.equal(got, exp), chunks
+    finally:
+        del os.environ['FBBEV_HISTORY_VM_YB']
+
+
 @pytest.mark.parametrize('dt', [torch.float32, torch.float16, torch.bfloat16])
 def test_history_voxel_major_ring_equals_planar_kernels_emulated(dt):
     """The voxel-major ring ([T][N][C] frames): fbbev_history_frame_vm is the rounded transpose of a frame,
