@@ -103,6 +103,7 @@ SIGNATURES = {
     'fbbev_history_conv_e': (c_int, [c_void_p, c_int64] + [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     'fbbev_history_conv_bf16': (c_int, [c_void_p, c_int64] + [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
     'fbbev_history_conv_bf16x3': (c_int, [c_void_p, c_int64] + [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    'fbbev_history_fused_x3_vm': (c_int, [c_void_p, c_int64, c_void_p, c_int64] + [c_void_p] * 5 + [c_int] * 7 + [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     'fbbev_history_step_x3_vm': (c_int, [c_void_p, c_int64, c_void_p, c_int64] + [c_void_p] * 5 + [c_int] * 7 + [c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
     'fbbev_history_conv_vm': (c_int, [c_void_p, c_int64] + [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     'fbbev_history_fused_vm': (c_int, [c_void_p, c_int64, c_void_p, c_int64] + [c_void_p] * 5 + [c_int] * 7 +
@@ -1447,6 +1448,28 @@ def blend_levels_ndhwc(level0, coarse, wsoft, out):
             _dev(level0, F32, 'level0'), ctypes.cast(ptrs, c_void_p) if n else None, ctypes.cast(dims, c_void_p) if n else None,
             n, _dev(wsoft, F32, 'wsoft'), int(wsoft.shape[4]), B, D, H, W, C, _dev(out, F32, 'out'), _stream()),
             'fbbev_blend_levels_ndhwc')
+    return out
+
+
+def history_fused_x3_vm(history, flow, nxt, grid_zyx, w1, bias1, w2, bias2, out):
+    """fbbev_history_fused_x3_vm: warp + new ring + both split-operand convolutions in ONE launch.  history (B, T, N, C) and
+    nxt (B, T+1, N, C) 16-bit voxel-major rings (nxt[:, 0] = the current frame, already stored), C = Cout = 80; writes nxt[:, 1:]
+    (== history_warp_vm) and out (B, Cout, N) f32 (== history_conv(nxt, ..., compute='bf16x3'))."""
+    Z, Y, X = grid_zyx
+    B, T, N, C = history.shape
+    Cout = w2.shape[0]
+    if (tuple(nxt.shape) != (B, T + 1, N, C) or nxt.dtype != history.dtype or history.dtype not in (torch.bfloat16, torch.float16)
+            or N != Z * Y * X or history.stride()[1:] != (N * C, C, 1) or nxt.stride()[1:] != (N * C, C, 1)
+            or tuple(out.shape) != (B, Cout, N)):
+        raise FbbevError('history_fused_x3_vm: bad history / next / out layout')
+    ws = torch.empty((2 + T) * C * max(C, Cout, 96) + B * (T + 1) * C + 16, dtype=torch.float32, device=history.device)
+    with _on(history):
+        _check(lib().fbbev_history_fused_x3_vm(
+            _dev(history, history.dtype, 'history', contiguous=False), history.stride(0),
+            _dev(nxt, nxt.dtype, 'next', contiguous=False), nxt.stride(0), _dev(flow, F32, 'rt_flow'), _dev(w1, F32, 'w1'),
+            _dev(bias1, F32, 'bias1'), _dev(w2, F32, 'w2'), _dev(bias2, F32, 'bias2'), B, T, C, Cout, Z, Y, X,
+            _dev(out, F32, 'out'), c_void_p(ws.data_ptr()), ws.numel() * 4, ELEM_TYPE[history.dtype], _stream()),
+            'fbbev_history_fused_x3_vm')
     return out
 
 

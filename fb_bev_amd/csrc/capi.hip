@@ -15,6 +15,7 @@
 #include "history_conv_kernels.h"
 #include "history_fused_kernels.h"
 #include "history_conv_x3_kernels.h"
+#include "history_fused_x3_kernels.h"
 #include "rows_linear_kernels.h"
 #include "da_fused_kernels.h"
 #include "da_bwd_planes_kernels.h"
@@ -2834,6 +2835,51 @@ extern "C" int fbbev_history_conv_bf16x3(const void* feats, long long feats_stri
     if (e || B <= 0 || N <= 0) return e;
     static const int nw = [] { const char* e = getenv("FBBEV_HX3_WAVES"); return e && atoi(e) == 4 ? 4 : 8; }();     // tuning: 256-thread workgroups
     return history_conv_x3_segments(feats, feats_stride_b, bias2, B, T1, C, N, out, elem_type, pl, 0, 0, N, 1, nw, stream);
+}
+
+// One history step on a 16-bit voxel-major ring as ONE kernel (history_fused_x3_kernels.h): every MFMA wave warps its own operands.
+// next[:, 0] must hold the current frame; writes next[:, 1:] (== fbbev_history_warp_vm) and out (== fbbev_history_conv_bf16x3).
+extern "C" int fbbev_history_fused_x3_vm(const void* history, long long history_stride_b, void* next, long long next_stride_b,
+                                         const float* rt_flow, const float* w1, const float* bias1, const float* w2,
+                                         const float* bias2, int B, int T, int C, int Cout, int Z, int Y, int X, float* out,
+                                         void* workspace, size_t workspace_bytes, int elem_type, fbbev_stream_t stream_) {
+    if (B < 0 || T <= 0 || C <= 0 || Cout <= 0 || Z <= 0 || Y <= 0 || X <= 0) return FBBEV_E_BADARG;
+    if (B == 0) return 0;
+    if (!history || !next || !rt_flow || !w1 || !bias1 || !w2 || !bias2 || !out) return FBBEV_E_BADARG;
+    if (C != 80 || Cout != 80 || (elem_type != 1 && elem_type != 2) || Z < 2 || Y < 2 || X < 2) return FBBEV_E_UNSUPPORTED;
+    const long long N = (long long)Z * Y * X, frame = N * C;
+    const int T1 = T + 1;
+    if (history_stride_b == 0) history_stride_b = (long long)T * frame;
+    if (next_stride_b == 0) next_stride_b = (long long)T1 * frame;
+    if (history_stride_b < (long long)T * frame || next_stride_b < (long long)T1 * frame) return FBBEV_E_BADARG;
+    if (history_stride_b % 8 != 0 || next_stride_b % 8 != 0 || !aligned16(history) || !aligned16(next)) return FBBEV_E_UNSUPPORTED;
+    if (frame * 2 >= (1ll << 32) || N >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;              // 32-bit byte offsets inside a frame
+    fbbev_rt_stream stream = (fbbev_rt_stream)stream_;
+    fbbev_conv_x3_plan cp{};
+    long long fs = next_stride_b;
+    if (workspace_bytes < 64) return FBBEV_E_WORKSPACE;
+    int e = history_conv_x3_prepare(next, fs, w1, bias1, w2, bias2, B, T1, C, Cout, (int)N, out, workspace, workspace_bytes - 64, elem_type, stream, cp);
+    if (e) return e;
+    void* dump = static_cast<char*>(workspace) + ((workspace_bytes - 64) & ~(size_t)15);       // 16 bytes nobody reads (the tail of the workspace)
+    const int n_xt = (X + 15) / 16, n_yt = (Y + 7) / 8;           // bricks of 16 x 8 voxels of one z plane, z fastest
+    const long long blocks = (long long)B * n_yt * n_xt * Z;
+    if (blocks >= (1ll << 31) - 8) return FBBEV_E_UNSUPPORTED;
+    const int per_xcd = (int)((blocks + 7) / 8);
+    // two W2 / bias blocks + W1 (hi | lo) + two operand tiles [128 voxels][FBBEV_HFX_PITCH] + the voxel table [128][16 dwords]: 154 KB
+    const size_t lds = ((size_t)2 * ((cp.pieces + 511) / 512) * 512 * 8 + 2 * cp.part1 + (size_t)2 * 128 * FBBEV_HFX_PITCH) * sizeof(unsigned short) +
+                       (size_t)128 * 16 * sizeof(unsigned int);
+#define FBBEV_HFX(ET_)                                                                                                 \
+    do {                                                                                                              \
+        int e_ = fbbev_rt_allow_dyn_lds((const void*)k_history_fused_x3<ET_>, lds);                                    \
+        if (e_) return e_;                                                                                            \
+        FBBEV_LAUNCH((k_history_fused_x3<ET_>), (long long)per_xcd * 8, 512, lds, stream, history, history_stride_b,   \
+                     next, next_stride_b, rt_flow, (const unsigned short*)cp.w1x, (const float*)cp.biasx,             \
+                     (const unsigned short*)cp.w2x, bias2, T1, Z, Y, X, n_xt, n_yt, per_xcd, (int)blocks, out, dump);  \
+    } while (0)
+    if (elem_type == 1) FBBEV_HFX(1); else FBBEV_HFX(2);
+#undef FBBEV_HFX
+    FBBEV_CHECK_LAUNCH();
+    return 0;
 }
 
 // One history step on a 16-bit voxel-major ring as a two-stream pipeline: the warp of a band of grid rows into next[:, 1:] on the

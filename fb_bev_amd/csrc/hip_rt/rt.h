@@ -172,10 +172,25 @@ __device__ __forceinline__ float fbbev_fma_f16(unsigned int pair, float w, float
     return d;
 }
 
+// 16 bytes per lane straight from global memory into LDS (global_load_lds_dwordx4): lane l's bytes land at lds_wave_base + 16 l
+// (the base is wave-uniform).  Counted by vmcnt like any load; fbbev_wait_loads() before the barrier that publishes the data.
+__device__ __forceinline__ void fbbev_lds_dma16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ void fbbev_wait_loads() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// ... for everything but the N youngest loads / stores of the wave (vmcnt retires in issue order)
+template <int N> __device__ __forceinline__ void fbbev_wait_loads_but() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
+
 // wave-level ordering point for a wave-PRIVATE LDS region: the 64 lanes run in lockstep and the LDS queue of a wave is
 // in order, so only the compiler has to be kept from moving LDS accesses across it (no s_barrier, no other wave waits)
 // instruction-scheduling fence: nothing is moved across it (keeps prefetch loads ahead of the MFMA block they overlap)
 __device__ __forceinline__ void fbbev_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+// instruction-order hint inside a scheduling region: the next N instructions of a kind (MFMA / LDS read) form a group, groups are
+// issued in the order they are declared -- spells out "five fragment reads ahead of the MFMA that consumes them" where the
+// compiler on its own issues each read right in front of its MFMA and waits for it (history_fused_x3_kernels.h)
+#define FBBEV_SCHED_MFMA(N) __builtin_amdgcn_sched_group_barrier(0x008, N, 0)
+#define FBBEV_SCHED_LDS_READ(N) __builtin_amdgcn_sched_group_barrier(0x100, N, 0)
 
 // ONE correctly rounded fp32 operation that is never fused with a neighbour.  HIP's __fmul_rn / __fadd_rn are plain `x * y` /
 // `x + y` (no OCML_BASIC_ROUNDED_OPERATIONS) and inherit -ffp-contract=fast: after inlining, a product feeding a sum may

@@ -150,28 +150,41 @@ k_history_conv_bf16x3(const void* __restrict__ feats, long long fstride_b, const
                 for (int v = 0; v < NV; ++v) acc1[v][mt] = bia;
             }
         }
-        // ---- convolution 1: W1 (hi, lo) . x_t, the K step's fragments requested together
+        // ---- convolution 1: W1 (lo, hi) . x_t
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            fbbev_v4u ah[MT1], al[MT1], xr[NV];
-#pragma unroll
-            for (int mt = 0; mt < MT1; ++mt) {
-                ah[mt] = *reinterpret_cast<const fbbev_v4u*>(w1buf + ((mt * KS + s) * 64 + lane) * 8);
-                al[mt] = *reinterpret_cast<const fbbev_v4u*>(w1buf + A1 + ((mt * KS + s) * 64 + lane) * 8);
-            }
+            fbbev_v4u af[MT1], xr[NV];
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 xr[v] = bv[SL][v][s];
                 if (32 * s + 32 > C) xr[v] = (32 * s + 8 * g < C) ? xr[v] : zero4;      // K padding: 0 x (another voxel's bits) must stay 0
             }
 #pragma unroll
-            for (int v = 0; v < NV; ++v)
-#pragma unroll
-                for (int mt = 0; mt < MT1; ++mt) acc1[v][mt] = fbbev_mfma_16x16x32_raw<ET>(al[mt], xr[v], acc1[v][mt]);
+            for (int mt = 0; mt < MT1; ++mt) af[mt] = *reinterpret_cast<const fbbev_v4u*>(w1buf + A1 + ((mt * KS + s) * 64 + lane) * 8);
 #pragma unroll
             for (int v = 0; v < NV; ++v)
 #pragma unroll
-                for (int mt = 0; mt < MT1; ++mt) acc1[v][mt] = fbbev_mfma_16x16x32_raw<ET>(ah[mt], xr[v], acc1[v][mt]);
+                for (int mt = 0; mt < MT1; ++mt) acc1[v][mt] = fbbev_mfma_16x16x32_raw<ET>(af[mt], xr[v], acc1[v][mt]);
+#pragma unroll
+            for (int mt = 0; mt < MT1; ++mt) af[mt] = *reinterpret_cast<const fbbev_v4u*>(w1buf + ((mt * KS + s) * 64 + lane) * 8);
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+#pragma unroll
+                for (int mt = 0; mt < MT1; ++mt) acc1[v][mt] = fbbev_mfma_16x16x32_raw<ET>(af[mt], xr[v], acc1[v][mt]);
+        }
+        // issue order of the fragment reads and MFMAs above (the compiler on its own issues a read right in front of its MFMA and waits
+        // for it): a fragment set (MT1 reads) is requested while the last MFMAs of the set before it issue -- one read behind each, into
+        // the registers that MFMA just consumed.  The region's first MT1 LDS reads are the bias.
+        if constexpr (NV == 2) {
+            FBBEV_SCHED_LDS_READ(2 * MT1);
+#pragma unroll
+            for (int q = 0; q < 2 * KS; ++q) {
+                FBBEV_SCHED_MFMA(MT1);                                                             // tile 0
+                if (q + 1 < 2 * KS) {
+#pragma unroll
+                    for (int i = 0; i < MT1; ++i) { FBBEV_SCHED_MFMA(1); FBBEV_SCHED_LDS_READ(1); }  // tile 1: the set's last use
+                } else FBBEV_SCHED_MFMA(MT1);
+            }
         }
         fbbev_sched_fence();
         // the next block and the next frames of X: requested here, under the epilogue and convolution 2
@@ -202,24 +215,38 @@ k_history_conv_bf16x3(const void* __restrict__ feats, long long fstride_b, const
         // ---- convolution 2: acc2 += W2'_t . y'
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            fbbev_bf16x8 ah[MT2], al[MT2];
+            fbbev_bf16x8 af[MT2];
 #pragma unroll
-            for (int mt = 0; mt < MT2; ++mt) {
-                ah[mt] = fbbev_ld_bf16x8(a2t + ((mt * KS + s) * 64 + lane) * 8);
-                al[mt] = fbbev_ld_bf16x8(a2t + A2 + ((mt * KS + s) * 64 + lane) * 8);
+            for (int mt = 0; mt < MT2; ++mt) af[mt] = fbbev_ld_bf16x8(a2t + A2 + ((mt * KS + s) * 64 + lane) * 8);
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+#pragma unroll
+                for (int mt = 0; mt < MT2; ++mt) acc2[v][mt] = fbbev_mfma_f32_16x16x32_bf16(af[mt], yh[v][s], acc2[v][mt]);
+#pragma unroll
+            for (int mt = 0; mt < MT2; ++mt) af[mt] = fbbev_ld_bf16x8(a2t + ((mt * KS + s) * 64 + lane) * 8);
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+#pragma unroll
+                for (int mt = 0; mt < MT2; ++mt) acc2[v][mt] = fbbev_mfma_f32_16x16x32_bf16(af[mt], yl[v][s], acc2[v][mt]);
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+#pragma unroll
+                for (int mt = 0; mt < MT2; ++mt) acc2[v][mt] = fbbev_mfma_f32_16x16x32_bf16(af[mt], yh[v][s], acc2[v][mt]);
+        }
+        // issue order (as above): per K step the lo set feeds 2 x MT2 MFMAs, the hi set 4 x MT2
+        if constexpr (NV == 2) {
+            FBBEV_SCHED_LDS_READ(MT2);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                FBBEV_SCHED_MFMA(MT2);
+#pragma unroll
+                for (int i = 0; i < MT2; ++i) { FBBEV_SCHED_MFMA(1); FBBEV_SCHED_LDS_READ(1); }      // lo . yh, tile 1; the hi set behind it
+                FBBEV_SCHED_MFMA(3 * MT2);
+                if (s + 1 < KS) {
+#pragma unroll
+                    for (int i = 0; i < MT2; ++i) { FBBEV_SCHED_MFMA(1); FBBEV_SCHED_LDS_READ(1); }  // hi . yh, tile 1; the next step's lo set
+                } else FBBEV_SCHED_MFMA(MT2);
             }
-#pragma unroll
-            for (int v = 0; v < NV; ++v)
-#pragma unroll
-                for (int mt = 0; mt < MT2; ++mt) acc2[v][mt] = fbbev_mfma_f32_16x16x32_bf16(al[mt], yh[v][s], acc2[v][mt]);
-#pragma unroll
-            for (int v = 0; v < NV; ++v)
-#pragma unroll
-                for (int mt = 0; mt < MT2; ++mt) acc2[v][mt] = fbbev_mfma_f32_16x16x32_bf16(ah[mt], yl[v][s], acc2[v][mt]);
-#pragma unroll
-            for (int v = 0; v < NV; ++v)
-#pragma unroll
-                for (int mt = 0; mt < MT2; ++mt) acc2[v][mt] = fbbev_mfma_f32_16x16x32_bf16(ah[mt], yh[v][s], acc2[v][mt]);
         }
         {
             fbbev_v4u* wd = reinterpret_cast<fbbev_v4u*>(a2buf + ((t + FPB) % NB) * A2S);

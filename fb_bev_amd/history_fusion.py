@@ -49,6 +49,8 @@ class TemporalHistoryFusion(nn.Module):
             MConv3d(C * (T + 1), out_c, kernel_size=1, padding=0, stride=1), nn.SyncBatchNorm(out_c),
             nn.ReLU(inplace=True))
         self.use_mfma_convs = True          # inference: both 1x1x1 convs in one fp32-MFMA kernel when the channels allow
+        self.fused_x3 = False               # 16-bit voxel-major ring, split-operand convolutions, C = 80: the whole step in one kernel
+                                            # (fbbev_history_fused_x3_vm)
         self.pipelined_step = False         # opt-in: the warp of a band of rows and the split-operand convolutions of the band before it on
         self.pipelined_step_chunks = 0      # two streams (fbbev_history_step_x3_vm).  Same bits; measured NOT faster (the convolutions' workgroups
                                             # starve while warp workgroups wait for CUs: profiles/r06_exp_history_step.md)
@@ -324,6 +326,12 @@ class TemporalHistoryFusion(nn.Module):
             compute = 'bf16x3' if nxt.dtype in (torch.bfloat16, torch.float16) else torch.float32
         if compute == 'bf16x3' and not (nxt.dtype in (torch.bfloat16, torch.float16) and C == w2.shape[0] and C in (16, 80)):
             compute = torch.float32
+        if (compute == 'bf16x3' and self.fused_x3 and C == 80 and w2.shape[0] == 80 and min(Z, Y, X) >= 2
+                and hist.stride()[1:] == (n * C, C, 1)):
+            # ONE launch: every MFMA wave warps its own operands (same ring and volume bits as the two kernels below)
+            out = _capi.history_fused_x3_vm(hist, flow, nxt, (Z, Y, X), w1, bias1.contiguous(), w2, b2,
+                                            torch.empty((B, 80, n), dtype=torch.float32, device=curr_yxz.device))
+            return out.view(B, -1, Z, Y, X), nxt
         if compute == 'bf16x3' and self.pipelined_step and min(Z, Y, X) >= 2 and hist.stride()[1:] == (n * C, C, 1):
             # warp and convolutions band of rows by band of rows on two streams (same kernels, same bits: fbbev_history_step_x3_vm)
             out = _capi.history_step_x3_vm(hist, flow, nxt, (Z, Y, X), w1, bias1.contiguous(), w2, b2,

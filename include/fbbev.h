@@ -838,6 +838,16 @@ int fbbev_history_step_x3_vm(const void* history, long long history_stride_b, vo
                              int B, int T, int C, int Cout, int Z, int Y, int X, float* out, void* workspace,
                              size_t workspace_bytes, int elem_type, int chunks, fbbev_stream_t stream);
 
+/* The same step as ONE kernel (history_fused_x3_kernels.h): every MFMA wave blends the 8 trilinear taps of its own operands --
+ * fbbev_history_warp_vm's taps, weights, order and rounding -- stores them to next[:, 1:] and feeds them to the split-operand
+ * convolutions of fbbev_history_conv_bf16x3; the T warped frames are not read back.  next[:, 0] must hold the current frame.  The
+ * ring and `out` are the same bits as the two calls.  C = Cout = 80, FBBEV_ELEM_BF16 / FBBEV_ELEM_F16, Z, Y, X >= 2; other shapes
+ * FBBEV_E_UNSUPPORTED (use the two calls).  workspace: as fbbev_history_conv_bf16x3 with T1 = T + 1, plus 64 bytes. */
+int fbbev_history_fused_x3_vm(const void* history, long long history_stride_b, void* next, long long next_stride_b,
+                              const float* rt_flow, const float* w1, const float* bias1, const float* w2, const float* bias2,
+                              int B, int T, int C, int Cout, int Z, int Y, int X, float* out, void* workspace,
+                              size_t workspace_bytes, int elem_type, fbbev_stream_t stream);
+
 /* ---- voxel-major history ring (opt-in layout of the inference ring; the reference's is (B, T*C, Z, Y, X), fbocc.py:234)
  * A frame is [voxel n = (z*Y + y)*X + x][channel]: the C elements of a voxel are contiguous, so a trilinear tap is a
  * 16-byte load of 8 (16-bit) / 4 (fp32) channels instead of one 2- / 4-byte gather per channel plane, and

@@ -511,6 +511,20 @@ def history_warp_vm(history, flow, grid_zyx, out=None):
     return out
 
 
+def history_fused_x3_vm(history, flow, nxt, grid_zyx, w1, bias1, w2, bias2):
+    """fbbev_history_fused_x3_vm: writes nxt[:, 1:] and returns (code, out (B, Cout, N)); nxt[:, 0] must hold the current frame."""
+    B, T, N, C = history.shape
+    Z, Y, X = grid_zyx
+    Cout = w2.shape[0]
+    out = torch.full((B, Cout, N), float('nan'))
+    ws = torch.zeros((2 + T) * C * max(C, Cout, 96) + B * (T + 1) * C + 16)
+    et = {torch.bfloat16: 1, torch.float16: 2}[history.dtype]
+    code = lib().fbbev_history_fused_x3_vm(c_void_p(history.data_ptr()), history.stride(0), c_void_p(nxt.data_ptr()), nxt.stride(0),
+                                           p(flow), p(w1), p(bias1), p(w2), p(bias2), B, T, C, Cout, Z, Y, X, p(out), p(ws),
+                                           ws.numel() * 4, et, None)
+    return code, out
+
+
 def history_step_x3_vm(history, flow, nxt, grid_zyx, w1, bias1, w2, bias2, chunks=0):
     """fbbev_history_step_x3_vm: writes nxt[:, 1:] and returns out (B, Cout, N); nxt[:, 0] must hold the current frame."""
     B, T, N, C = history.shape

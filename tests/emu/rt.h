@@ -288,11 +288,18 @@ inline fbbev_v4f fbbev_mfma_f32_16x16x32_f16(fbbev_v4u a, fbbev_v4u b, fbbev_v4f
     emu::wave_barrier();
     return d;
 }
+inline void fbbev_lds_dma16(const void* gsrc, void* lds_wave_base) {
+    memcpy(static_cast<char*>(lds_wave_base) + 16 * (emu::S().cur & 63), gsrc, 16);
+}
+inline void fbbev_wait_loads() {}
+template <int N> inline void fbbev_wait_loads_but() {}
 template <int HI> inline float fbbev_fma_f16(unsigned int pair, float w, float acc) {
     return __builtin_fmaf(fbbev_f16_bits_to_f32((pair >> (16 * HI)) & 0xffffu), w, acc);
 }
 inline void fbbev_wave_sync() { emu::wave_barrier(); }
 inline void fbbev_sched_fence() {}
+#define FBBEV_SCHED_MFMA(N) ((void)0)
+#define FBBEV_SCHED_LDS_READ(N) ((void)0)
 inline void fbbev_pin(fbbev_v2f&) {}
 inline void fbbev_opaque(int&) {}
 inline void fbbev_opaque(float&) {}

@@ -1416,6 +1416,38 @@ def test_history_fused_warp_and_conv_equals_the_two_kernels_emulated(dt, produce
 
 
 @pytest.mark.parametrize('dt', [torch.float16, torch.bfloat16])
+def test_history_fused_x3_equals_the_two_kernels_emulated(dt):
+    """fbbev_history_fused_x3_vm (one launch: every MFMA wave blends the taps of its own operands, stores them to the next ring
+    and runs both split-operand convolutions on them) against fbbev_history_warp_vm + fbbev_history_conv_bf16x3 on the same
+    rings: slots 1..T of the new ring and the fused volume are the SAME BITS.  Bricks that overhang the grid in x (70 = 4 x 16 + 6)
+    and y (11 = 8 + 3), translation / rotation / out-of-grid / NaN flows, a padded batch stride, -0.0 in the current frame."""
+    g = torch.Generator().manual_seed(23)
+    B, T, C, Z, Y, X = 4, 3, 80, 2, 11, 70
+    N = Z * Y * X
+    hist = torch.full((B, T + 1, N, C), float('nan'), dtype=dt)              # spare slot: padded batch stride
+    hist[:, :T] = (torch.randn(B, T, N, C, generator=g) * 2).to(dt)
+    flow = torch.eye(4)[None].repeat(B, 1, 1)
+    flow[0, :3, 3] = torch.tensor([1.25, -0.5, 0.25])
+    flow[1, :3, :3] = torch.tensor([[0.9, -0.4, 0.0], [0.4, 0.9, 0.0], [0.0, 0.0, 1.0]])
+    flow[2, :3, 3] = torch.tensor([500.0, 0.0, 0.0])                         # leaves the grid: zero padding
+    flow[3, 0, 0] = float('nan')
+    curr = torch.randn(B, C, N, generator=g)
+    curr[0, :, :5] = -0.0
+    w1, w2 = torch.randn(C, C, generator=g) * 0.2, torch.randn(C, (T + 1) * C, generator=g) * 0.1
+    b1, b2 = torch.randn(B * (T + 1), C, generator=g), torch.randn(C, generator=g)
+    ref = torch.full((B, T + 1, N, C), float('nan'), dtype=dt)
+    E.history_frame_vm(curr, dt, out=ref[:, 0])
+    E.history_warp_vm(hist[:, :T], flow, (Z, Y, X), out=ref[:, 1:])
+    exp = E.history_conv(ref, w1, b1, w2, b2, voxel_major=True, x3=True)
+    nxt = torch.full((B, T + 1, N, C), float('nan'), dtype=dt)
+    E.history_frame_vm(curr, dt, out=nxt[:, 0])
+    code, got = E.history_fused_x3_vm(hist[:, :T], flow, nxt, (Z, Y, X), w1, b1, w2, b2)
+    assert code == 0
+    assert torch.equal(nxt.view(torch.int16), ref.view(torch.int16))         # the ring: identical element bits (NaN flows included)
+    assert torch.isfinite(exp).all() and torch.equal(got, exp)
+
+
+@pytest.mark.parametrize('dt', [torch.float16, torch.bfloat16])
 def test_history_step_in_row_bands_equals_the_two_calls_emulated(dt):
     """fbbev_history_step_x3_vm (warp and split-operand convolutions launched band of rows by band of rows: the chunks of the
     two-stream pipeline) against fbbev_history_warp_vm + fbbev_history_conv_bf16x3 over the whole volume: the ring and the fused

@@ -347,6 +347,42 @@ def test_fused_warp_and_conv_kernel_equals_the_two_kernel_path(dev, dt, T):
 
 
 @pytest.mark.parametrize('dt', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('T', [3, 16])
+def test_one_kernel_and_pipelined_steps_equal_the_two_split_operand_kernels(dev, dt, T):
+    """fbbev_history_fused_x3_vm (one launch: a brick's items blended in memory order, stored to the next ring and fed to both
+    split-operand convolutions through an LDS tile) and fbbev_history_step_x3_vm (the two kernels launched band of rows by band on
+    two streams) against fbbev_history_warp_vm + fbbev_history_conv_bf16x3: slots 1..T of the new ring and the fused volume are the
+    SAME BITS.  Bricks that overhang the grid in x (70 = 4 x 16 + 6) and y (21 = 2 x 8 + 5), translation / rotation / out-of-grid
+    flows, T = 16 (the detector's ring) and T = 3."""
+    from fb_bev_amd import _capi
+    g = torch.Generator().manual_seed(29)
+    B, C, Z, Y, X = 3, 80, 4, 21, 70
+    N = Z * Y * X
+    hist = (torch.randn(B, T, N, C, generator=g) * 2).to(dt).to(dev)
+    flow = torch.eye(4)[None].repeat(B, 1, 1)
+    flow[0, :3, 3] = torch.tensor([1.25, -0.5, 0.25])
+    flow[1, :3, :3] = torch.tensor([[0.9, -0.4, 0.0], [0.4, 0.9, 0.0], [0.0, 0.0, 1.0]])
+    flow[2, :3, 3] = torch.tensor([500.0, 0.0, 0.0])
+    flow = flow.to(dev)
+    curr = torch.randn(B, C, N, generator=g).to(dev)
+    w1, w2 = (torch.randn(C, C, generator=g) * 0.2).to(dev), (torch.randn(C, (T + 1) * C, generator=g) * 0.1).to(dev)
+    b1, b2 = torch.randn(B * (T + 1), C, generator=g).to(dev), torch.randn(C, generator=g).to(dev)
+    ref = torch.zeros(B, T + 1, N, C, dtype=dt, device=dev)
+    _capi.history_frame_vm(curr, ref[:, 0])
+    _capi.history_warp_vm(hist, flow, ref[:, 1:], (Z, Y, X))
+    exp = _capi.history_conv(ref, w1, b1, w2, b2, torch.empty(B, C, N, device=dev), compute='bf16x3', voxel_major=True)
+    assert torch.isfinite(exp).all() and exp.abs().max().item() > 0
+    for name, step in (('one kernel', lambda n, o: _capi.history_fused_x3_vm(hist, flow, n, (Z, Y, X), w1, b1, w2, b2, o)),
+                       ('pipelined', lambda n, o: _capi.history_step_x3_vm(hist, flow, n, (Z, Y, X), w1, b1, w2, b2, o, chunks=3))):
+        nxt = torch.full((B, T + 1, N, C), float('nan'), dtype=dt, device=dev)
+        _capi.history_frame_vm(curr, nxt[:, 0])
+        got = step(nxt, torch.full((B, C, N), float('nan'), device=dev))
+        torch.cuda.synchronize()
+        assert torch.equal(nxt.view(torch.int16), ref.view(torch.int16)), name
+        assert torch.equal(got, exp), name
+
+
+@pytest.mark.parametrize('dt', [torch.float16, torch.bfloat16])
 def test_split_operand_bf16_convolutions_are_fp32_grade(dev, dt):
     """history_compute='bf16x3' (fbbev_history_conv_bf16x3: every operand split into two bf16 terms, three MFMAs per product)
     through the module on a 16-bit voxel-major ring, against the fp32-MFMA convolutions on the same ring: the stored ring is the

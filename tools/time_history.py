@@ -79,6 +79,8 @@ def main():
     m = TemporalHistoryFusion([dxv, dxv, 6.4 / Z], [-40 + dxv / 2, -40 + dxv / 2, -1 + 3.2 / Z], C, T, history_dtype=dt,
                               history_compute=comp, ring_layout=lay).to(dev).eval()
     m.fused_warp_conv = not unfused
+    if hasattr(m, 'fused_x3'):
+        m.fused_x3 = os.environ.get('HIST_FUSED_X3', '1' if m.fused_x3 else '0') == '1'
     m.pipelined_step = os.environ.get('HIST_PIPE', '0') == '1'            # two-stream step (fbbev_history_step_x3_vm)
     m.pipelined_step_chunks = int(os.environ.get('HIST_CHUNKS', '0'))
     for seq in (m.history_keyframe_time_conv, m.history_keyframe_cat_conv):
@@ -127,7 +129,7 @@ def main():
             rel = ((o3 - o2).abs().max() / o2.abs().max()).item()
     hist_bytes = B * T * C * Z * Y * X * esz
     print(json.dumps({'grid': [Y, X, Z], 'B': B, 'C': C, 'T': T, 'history_MB': round(hist_bytes / 1e6, 1),
-                      'history_dtype': str(dt).split('.')[-1], 'conv_compute': str(comp).split('.')[-1], 'ring_layout': lay, 'pipelined_step': bool(m.pipelined_step), 'chunks': m.pipelined_step_chunks, 'warp_conv_one_kernel': bool(m.fused_warp_conv and comp == torch.bfloat16 and lay == 'voxel_major' and dt != torch.float32), 'fused_ms': round(t_hip, 4),
+                      'history_dtype': str(dt).split('.')[-1], 'conv_compute': str(comp).split('.')[-1], 'ring_layout': lay, 'fused_x3': bool(getattr(m, 'fused_x3', False)), 'pipelined_step': bool(m.pipelined_step), 'chunks': m.pipelined_step_chunks, 'warp_conv_one_kernel': bool(m.fused_warp_conv and comp == torch.bfloat16 and lay == 'voxel_major' and dt != torch.float32), 'fused_ms': round(t_hip, 4),
                       'torch_reference_sequence_ms': None if t_ref is None else round(t_ref, 4), 'speedup': None if t_ref is None else round(t_ref / t_hip, 2),
                       'warp_ms': round(t_warp, 4), 'warp_GBps_read_plus_write': round(2 * hist_bytes / t_warp / 1e6, 1),
                       'max_abs_diff_out': err, 'max_abs_diff_history': herr,
