@@ -32,6 +32,9 @@ if [ "$MODE" != "quick" ]; then
   bash tools/pmc_passes.sh r06/train_path -- python tools/train_path.py BL2 4 4 --profile-steps 3 > $OUT/pmc_train.log 2>&1
   bash tools/pmc_mfma.sh r06/fb_BL3_B4 -- python tools/time_fb.py BL2 4 5 4 > $OUT/pmc_mfma_fb.log 2>&1
   bash tools/pmc_mfma.sh r06/train_path -- python tools/train_path.py BL2 4 4 --profile-steps 3 > $OUT/pmc_mfma_train.log 2>&1
+  bash tools/pmc_mfma.sh r06/hist -- python tools/time_history.py 400 400 16 1 f16 noref cx3 vm > $OUT/pmc_mfma_hist.log 2>&1
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_hist -- python $REPO/tools/time_history.py 400 400 16 1 f16 noref cx3 vm > $OUT/prof_hist.log 2>&1 ); f=$(find $OUT/prof_hist -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/rocprofv3_prof_hist.csv
+  for i in 1 2; do python tools/time_history.py 400 400 16 1 f16 noref cx3 vm >> $OUT/time_history_x3_vm.jsonl 2>/dev/null; done
   timeout 1500 python tools/scope_table.py $OUT/scope_table.json > $OUT/scope_table.log 2>&1; echo "scope table rc=$?" | tee -a $OUT/box.txt
 fi
 find $OUT -name "*.csv" -size +20M -delete

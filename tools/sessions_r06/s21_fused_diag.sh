@@ -1,4 +1,5 @@
 #!/bin/bash
+# (the FBBEV_HFX_DIAG builds this script timed were removed again after the session: results in profiles/r06_exp_history_step.md)
 # round 6, session 21: where the one-kernel history step spends its time -- diagnostic builds that leave one part out (wrong results)
 REPO=$(pwd); OUT=$REPO/gpurun_out/s21; mkdir -p $OUT; export TMPDIR=/tmp
 P='import json,sys; d=json.loads(sys.stdin.read()); print(sys.argv[1], "step_ms", d["fused_ms"], "warp_ms", d["warp_ms"])'
