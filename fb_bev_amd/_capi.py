@@ -70,6 +70,8 @@ SIGNATURES = {
                                   c_void_p, c_void_p, c_float, c_void_p, c_int64, c_void_p]),
     'fbbev_rows_tail_ffn_x3': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_void_p]),
+    'fbbev_rows_tail_ffn_x3_planes': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
+                                              c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_float, c_int64, c_void_p, c_void_p]),
     'fbbev_rows_linear_x3_planes': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'fbbev_rows_linear_x3_planes_e': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'fbbev_da_cross_attn_fused_supported': (c_int, [c_int] * 10),
@@ -986,10 +988,25 @@ def rows_tail_ffn_x3_supported(x, residual0, embed, hidden):
 
 
 def rows_tail_ffn_x3(x, w0_fragments, b0, residual0, ln0_weight, ln0_bias, ln0_eps, w1_fragments, b1, w2_fragments, b2, hidden,
-                     ln1_weight, ln1_bias, ln1_eps):
+                     ln1_weight, ln1_bias, ln1_eps, tokens_per_image=None):
     """LayerNorm1(y1 + W2 relu(W1 y1 + b1) + b2) with y1 = LayerNorm0(x W0^T + b0 [+ residual0]) in one kernel
-    (fbbev_rows_tail_ffn_x3): x (R, E) attention slots, residual0 (R, E) rows; out (R, E)."""
+    (fbbev_rows_tail_ffn_x3): x (R, E) attention slots, residual0 (R, E) rows; out (R, E).  tokens_per_image = S: out is written
+    as planes (R / S, E, S) instead (fbbev_rows_tail_ffn_x3_planes: the same values, the (B, C, Y, X) layout of the refined BEV)."""
     R, E = x.shape
+    if tokens_per_image:
+        S = int(tokens_per_image)
+        if R % S:
+            raise FbbevError('rows_tail_ffn_x3: rows must cover whole images')
+        out = torch.empty((R // S, E, S), dtype=F32, device=x.device)
+        with _on(x):
+            _check(lib().fbbev_rows_tail_ffn_x3_planes(
+                _dev(x, F32, 'x', contiguous=False), x.stride(0), w0_fragments.data_ptr(), _dev(b0, F32, 'b0'),
+                _dev(residual0, F32, 'residual0', contiguous=False) if residual0 is not None else None,
+                residual0.stride(0) if residual0 is not None else 0, _dev(ln0_weight, F32, 'ln0_weight'), _dev(ln0_bias, F32, 'ln0_bias'),
+                float(ln0_eps), w1_fragments.data_ptr(), _dev(b1, F32, 'b1'), w2_fragments.data_ptr(), _dev(b2, F32, 'b2'), R, E, int(hidden),
+                _dev(ln1_weight, F32, 'ln1_weight'), _dev(ln1_bias, F32, 'ln1_bias'), float(ln1_eps), S, _dev(out, F32, 'out'), _stream()),
+                'fbbev_rows_tail_ffn_x3_planes')
+        return out
     out = torch.empty((R, E), dtype=F32, device=x.device)
     with _on(x):
         _check(lib().fbbev_rows_tail_ffn_x3(

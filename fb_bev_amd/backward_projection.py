@@ -87,6 +87,9 @@ def _tkey(ts):
     return tuple((t.data_ptr(), tuple(t.shape), t._version) for t in ts)
 
 
+_OUT_PLANES = None        # inference: {'tokens': Y * X, 'last': bool, 'got': bool} while BackwardProjection.forward runs its transformer -- the LAST
+#                           layer's tail + FFN kernel may then write the refined BEV as (B, C, Y, X) planes itself (fbbev_rows_tail_ffn_x3_planes)
+OUT_PLANES = _os0.environ.get('FBBEV_BP_OUT_PLANES', '1') != '0'    # A/B knob
 _NORMED = object()       # 'residual' slot of a deferred branch result whose following LayerNorm already ran inside the branch's last GEMM
 
 
@@ -846,6 +849,13 @@ class DA_SpatialCrossAttention(nn.Module):
                 if not hasattr(self.output_proj, '_x3'):
                     self.output_proj._x3 = X3Weights()
                 oc = self.output_proj._x3.get(self.output_proj.weight, self.output_proj.bias)
+                planes = _ffn_tail.get('planes')
+                if planes and s2.shape[0] % planes == 0 and _OUT_PLANES is not None:
+                    out = _capi.rows_tail_ffn_x3(s2, oc.frag, oc.b, r2, _norm.weight, _norm.bias, _norm.eps, c1.frag, c1.b, c2.frag, c2.b, H,
+                                                 n1.weight, n1.bias, n1.eps, tokens_per_image=planes)
+                    _ffn_tail['done'] = True
+                    _OUT_PLANES['got'] = True
+                    return out, _NORMED                         # (B, C, Y * X): BackwardProjection.forward views it as (B, C, Y, X)
                 out = _capi.rows_tail_ffn_x3(s2, oc.frag, oc.b, r2, _norm.weight, _norm.bias, _norm.eps, c1.frag, c1.b, c2.frag, c2.b, H,
                                              n1.weight, n1.bias, n1.eps)
                 _ffn_tail['done'] = True
@@ -988,6 +998,8 @@ class BEVFormerEncoderLayer(nn.Module):
                     spec = self.ffns[fi].fused_tail_spec(self.embed_dims) if hasattr(self.ffns[fi], 'fused_tail_spec') else None
                     if spec is not None:
                         ft = dict(spec=spec, norm1=self.norms[ni + 1], done=False)
+                        if _OUT_PLANES is not None and _OUT_PLANES['last'] and k + 4 == len(ops):
+                            ft['planes'] = _OUT_PLANES['tokens']      # the layer ends with this kernel: it may write (B, C, Y, X)
                         nk = dict(nk, _ffn_tail=ft)
                 query = self.attentions[ai](
                     query, key, value, identity if self.pre_norm else None, query_pos=bev_pos, key_pos=key_pos,
@@ -1087,7 +1099,9 @@ class bevformer_encoder(nn.Module):
         bev_query = bev_query.permute(1, 0, 2)
         bev_pos = bev_pos.permute(1, 0, 2)
         output, inter = bev_query, []
-        for layer in self.layers:
+        for li, layer in enumerate(self.layers):
+            if _OUT_PLANES is not None:
+                _OUT_PLANES['last'] = li == len(self.layers) - 1 and not self.return_intermediate
             output = layer(bev_query, key, value, bev_pos=bev_pos, ref_2d=ref_2d, ref_3d=ref_3d, bev_h=bev_h,
                            bev_w=bev_w, spatial_shapes=spatial_shapes, level_start_index=level_start_index,
                            reference_points_cam=ref_cam, per_cam_mask_list=per_cam_mask_list, bev_mask=bev_mask,
@@ -1306,10 +1320,18 @@ class BackwardProjection(nn.Module):
         if bev_mask is not None:
             bev_mask = bev_mask.reshape(bs, -1)
         bev_pos = self.positional_encoding(bs, self.bev_h, self.bev_w, bev_queries.device).to(dtype)
-        bev = self.transformer(mlvl_feats, bev_queries, self.bev_h, self.bev_w,
-                               grid_length=(self.real_h / self.bev_h, self.real_w / self.bev_w), bev_pos=bev_pos,
-                               img_metas=img_metas, cam_params=cam_params, gt_bboxes_3d=gt_bboxes_3d,
-                               pred_img_depth=pred_img_depth, prev_bev=None, bev_mask=bev_mask)
+        global _OUT_PLANES
+        ctx = dict(tokens=self.bev_h * self.bev_w, last=False, got=False) if (fast and OUT_PLANES and not torch.is_grad_enabled()) else None
+        _OUT_PLANES = ctx
+        try:
+            bev = self.transformer(mlvl_feats, bev_queries, self.bev_h, self.bev_w,
+                                   grid_length=(self.real_h / self.bev_h, self.real_w / self.bev_w), bev_pos=bev_pos,
+                                   img_metas=img_metas, cam_params=cam_params, gt_bboxes_3d=gt_bboxes_3d,
+                                   pred_img_depth=pred_img_depth, prev_bev=None, bev_mask=bev_mask)
+        finally:
+            _OUT_PLANES = None
+        if ctx is not None and ctx['got']:                     # the last layer's kernel wrote (bs, C, Y * X) itself
+            return bev.view(bs, -1, self.bev_h, self.bev_w)
         if fast and bev.is_contiguous() and not bev.requires_grad:
             return _capi.transpose_last2(bev).view(bs, -1, self.bev_h, self.bev_w)
         if train_fast and bev.is_cuda and bev.dtype == torch.float32 and bev.dim() == 3:

@@ -3198,14 +3198,19 @@ extern "C" int fbbev_rows_ffn_x3(const float* x, long long x_row_stride, const v
 //   y1  = LayerNorm0(x W0^T + b0 + residual0)                 output_proj + residual + norm   (bevformer_encoder.py:250-377, ops 'cross_attn', 'norm')
 //   out = LayerNorm1(y1 + W2 relu(W1 y1 + b1) + b2)           mmcv FFN (add_identity) + norm  (ops 'ffn', 'norm')
 // x (rows, E) = the attention slots, residual0 (rows, E) = the block's input rows.  Supported: E in {16, 32, 48, 64, 80}, hidden % 64 == 0.
-extern "C" int fbbev_rows_tail_ffn_x3(const float* x, long long x_row_stride, const void* w0_fragments, const float* b0,
-                                      const float* residual0, long long residual0_row_stride, const float* ln0_weight,
-                                      const float* ln0_bias, float ln0_eps, const void* w1_fragments, const float* b1,
-                                      const void* w2_fragments, const float* b2, long long rows, int embed, int hidden,
-                                      const float* ln1_weight, const float* ln1_bias, float ln1_eps, float* out,
-                                      long long out_row_stride, fbbev_stream_t stream_) {
-    if (rows < 0 || embed <= 0 || hidden <= 0) return FBBEV_E_BADARG;
+static int rows_tail_ffn_x3_impl(const float* x, long long x_row_stride, const void* w0_fragments, const float* b0,
+                                 const float* residual0, long long residual0_row_stride, const float* ln0_weight,
+                                 const float* ln0_bias, float ln0_eps, const void* w1_fragments, const float* b1,
+                                 const void* w2_fragments, const float* b2, long long rows, int embed, int hidden,
+                                 const float* ln1_weight, const float* ln1_bias, float ln1_eps, float* out,
+                                 long long out_row_stride, long long tokens_per_image, fbbev_stream_t stream_) {
+    if (rows < 0 || embed <= 0 || hidden <= 0 || tokens_per_image < 0) return FBBEV_E_BADARG;
     if (rows == 0) return 0;
+    if (tokens_per_image > 0) {                            // planes: out (rows / S, embed, S); the kernel takes S as a negative row stride
+        if (rows % tokens_per_image != 0) return FBBEV_E_BADARG;
+        if (rows >= (1ll << 31) || tokens_per_image >= (1ll << 31)) return FBBEV_E_UNSUPPORTED;      // 32-bit row arithmetic in the store
+        out_row_stride = embed;                            // (passes the checks below)
+    }
     if (!x || !w0_fragments || !b0 || !ln0_weight || !ln0_bias || !w1_fragments || !b1 || !w2_fragments || !b2 || !ln1_weight ||
         !ln1_bias || !out) return FBBEV_E_BADARG;
     if (x_row_stride == 0) x_row_stride = embed;
@@ -3229,13 +3234,39 @@ extern "C" int fbbev_rows_tail_ffn_x3(const float* x, long long x_row_stride, co
         if (e) return e;                                                                                              \
         FBBEV_LAUNCH((k_rows_ffn_x3<3, 5, true, HC_, true>), wgs, 256, lds, (fbbev_rt_stream)stream_, x, x_row_stride,   \
                      static_cast<const unsigned short*>(w1_fragments), b1, static_cast<const unsigned short*>(w2_fragments), b2, \
-                     out, out_row_stride, rows, embed, hidden, embed, n_kc2, (const float*)nullptr, (long long)0, ln1_weight,  \
+                     out, ldo, rows, embed, hidden, embed, n_kc2, (const float*)nullptr, (long long)0, ln1_weight,             \
                      ln1_bias, ln1_eps, pre);                                                                         \
     } while (0)
+    const long long ldo = tokens_per_image > 0 ? -tokens_per_image : out_row_stride;
     FBBEV_TFFN(32);      // (hidden chunks of 64 -- FBBEV_TAIL_FFN_HC=64 until round 5 -- measured no gain: 1.392 vs 1.392 ms S3; gone)
 #undef FBBEV_TFFN
     FBBEV_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int fbbev_rows_tail_ffn_x3(const float* x, long long x_row_stride, const void* w0_fragments, const float* b0,
+                                      const float* residual0, long long residual0_row_stride, const float* ln0_weight,
+                                      const float* ln0_bias, float ln0_eps, const void* w1_fragments, const float* b1,
+                                      const void* w2_fragments, const float* b2, long long rows, int embed, int hidden,
+                                      const float* ln1_weight, const float* ln1_bias, float ln1_eps, float* out,
+                                      long long out_row_stride, fbbev_stream_t stream_) {
+    return rows_tail_ffn_x3_impl(x, x_row_stride, w0_fragments, b0, residual0, residual0_row_stride, ln0_weight, ln0_bias, ln0_eps,
+                                 w1_fragments, b1, w2_fragments, b2, rows, embed, hidden, ln1_weight, ln1_bias, ln1_eps, out,
+                                 out_row_stride, 0, stream_);
+}
+
+// The same with the result written as planes: out (rows / tokens_per_image, embed, tokens_per_image) -- the (B, C, Y, X) refined BEV
+// the final pooling re-adds (backward_projection.py:129: permute + view + contiguous), without the transposing pass behind the layer.
+extern "C" int fbbev_rows_tail_ffn_x3_planes(const float* x, long long x_row_stride, const void* w0_fragments, const float* b0,
+                                             const float* residual0, long long residual0_row_stride, const float* ln0_weight,
+                                             const float* ln0_bias, float ln0_eps, const void* w1_fragments, const float* b1,
+                                             const void* w2_fragments, const float* b2, long long rows, int embed, int hidden,
+                                             const float* ln1_weight, const float* ln1_bias, float ln1_eps,
+                                             long long tokens_per_image, float* out, fbbev_stream_t stream_) {
+    if (tokens_per_image <= 0) return FBBEV_E_BADARG;
+    return rows_tail_ffn_x3_impl(x, x_row_stride, w0_fragments, b0, residual0, residual0_row_stride, ln0_weight, ln0_bias, ln0_eps,
+                                 w1_fragments, b1, w2_fragments, b2, rows, embed, hidden, ln1_weight, ln1_bias, ln1_eps, out, 0,
+                                 tokens_per_image, stream_);
 }
 
 // Warp + new ring + both convolutions in ONE kernel (k_history_fused_bf16): history (B,T,N,C) -> next ring slots 1..T of

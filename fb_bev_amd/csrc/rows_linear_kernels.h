@@ -668,6 +668,22 @@ k_rows_ffn_x3(const float* __restrict__ x, long long ldx, const unsigned short* 
             }
         }
         if (!live) continue;
+        if (ldo < 0) {
+            // planes (round 6): out is (rows / S, O, S) with S = -ldo rows per image -- the (B, C, Y, X) tensor the next consumer takes
+            // (the re-add epilogue of the final pooling), written here instead of rows + a transposing pass.  The 16 lanes of a
+            // row tile hold 16 consecutive rows of one feature: 64-byte runs.
+            const unsigned int S = (unsigned int)(-ldo), ru = (unsigned int)r, bn = ru / S, tok = ru - bn * S;   // rows < 2^31: checked
+            float* ob = out + (size_t)bn * O * S + tok;
+#pragma unroll
+            for (int mt = 0; mt < MT2; ++mt) {
+                const int o = 16 * mt + 4 * g;
+                if (o < O) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) fbbev_st(ob + (size_t)(o + e) * S, v[mt][e]);
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int mt = 0; mt < MT2; ++mt) {
             const int o = 16 * mt + 4 * g;

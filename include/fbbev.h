@@ -777,6 +777,15 @@ int fbbev_rows_tail_ffn_x3(const float* x, long long x_row_stride, const void* w
                            float ln0_eps, const void* w1_fragments, const float* b1, const void* w2_fragments, const float* b2,
                            long long rows, int embed, int hidden, const float* ln1_weight, const float* ln1_bias, float ln1_eps,
                            float* out, long long out_row_stride, fbbev_stream_t stream);
+/* The same with the result written as PLANES: rows = images x tokens_per_image, out (images, embed, tokens_per_image) -- the
+ * (B, C, Y, X) tensor BackwardProjection returns (backward_projection.py:129: permute + view + contiguous of the encoder's rows),
+ * stored by the layer's last kernel instead of rows + a transposing pass; same values.  rows % tokens_per_image == 0. */
+int fbbev_rows_tail_ffn_x3_planes(const float* x, long long x_row_stride, const void* w0_fragments, const float* b0,
+                                  const float* residual0, long long residual0_row_stride, const float* ln0_weight,
+                                  const float* ln0_bias, float ln0_eps, const void* w1_fragments, const float* b1,
+                                  const void* w2_fragments, const float* b2, long long rows, int embed, int hidden,
+                                  const float* ln1_weight, const float* ln1_bias, float ln1_eps, long long tokens_per_image,
+                                  float* out, fbbev_stream_t stream);
 /* fbbev_rows_linear_x3 with the result written as HEAD PLANES: rows = (B*Ncam) x tokens_per_image camera tokens, out_features =
  * M * head_dim in the module's (head, channel) order, out (B*Ncam, M, tokens_per_image, head_dim) -- the value_proj of the
  * cross-attention feeding fbbev_da_cross_attn_fused (spatial_cross_attention_depth.py:522-530).  head_dim even, <= 65535 and

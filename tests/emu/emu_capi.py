@@ -337,12 +337,19 @@ def rows_ffn_x3(x, w1, b1, w2, b2, residual=None, ln_w=None, ln_b=None, eps=1e-5
     return code, out
 
 
-def rows_tail_ffn_x3(x, w0, b0, res0, ln0_w, ln0_b, eps0, w1, b1, w2, b2, ln1_w, ln1_b, eps1):
+def rows_tail_ffn_x3(x, w0, b0, res0, ln0_w, ln0_b, eps0, w1, b1, w2, b2, ln1_w, ln1_b, eps1, tokens_per_image=None):
     f0, p0 = _fragments(w0)
     f1, p1 = _fragments(w1)
     f2, p2 = _fragments(w2)
     R, E = x.shape
     H = w1.shape[0]
+    if tokens_per_image:
+        out = torch.full((R // tokens_per_image, E, tokens_per_image), float('nan'))
+        code = lib().fbbev_rows_tail_ffn_x3_planes(c_void_p(x.data_ptr()), x.stride(0), p0, p(b0),
+                                                   c_void_p(res0.data_ptr()) if res0 is not None else None,
+                                                   res0.stride(0) if res0 is not None else 0, p(ln0_w), p(ln0_b), eps0, p1, p(b1), p2, p(b2),
+                                                   R, E, H, p(ln1_w), p(ln1_b), eps1, tokens_per_image, p(out), None)
+        return code, out
     out = torch.full((R, E), float('nan'))
     code = lib().fbbev_rows_tail_ffn_x3(c_void_p(x.data_ptr()), x.stride(0), p0, p(b0),
                                         c_void_p(res0.data_ptr()) if res0 is not None else None, res0.stride(0) if res0 is not None else 0,

@@ -1904,6 +1904,12 @@ def test_rows_tail_ffn_one_kernel_emulated(rows, Em, H, with_res):
         assert code == 0 and not torch.isnan(out).any()
         assert (out - ref).abs().max().item() <= 5e-5 * max(1.0, ref.abs().max().item()), (hc, (out - ref).abs().max().item())
         assert (out - two).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item()), (hc, (out - two).abs().max().item())
+    # planes output (fbbev_rows_tail_ffn_x3_planes): the same bits, (images, E, tokens) instead of rows
+    S = {200: 50, 70: 35, 33: 11, 130: 65, 40: 40}[rows]
+    code, pl = E.rows_tail_ffn_x3(x, w0, b0, res0, l0w, l0b, 1e-5, w1, b1, w2, b2, l1w, l1b, 1e-6, tokens_per_image=S)
+    assert code == 0 and torch.equal(pl, out.view(rows // S, S, Em).transpose(1, 2))
+    code, _ = E.rows_tail_ffn_x3(x, w0, b0, res0, l0w, l0b, 1e-5, w1, b1, w2, b2, l1w, l1b, 1e-6, tokens_per_image=rows - 1 if rows > 1 else 2)
+    assert code < 0                                                        # rows do not cover whole images
     code, _ = E.rows_tail_ffn_x3(x[:, :Em - 8].contiguous(), w0[:Em - 8, :Em - 8].contiguous(), b0[:Em - 8].contiguous(), None, l0w[:Em - 8].contiguous(),
                                   l0b[:Em - 8].contiguous(), 1e-5, w1[:, :Em - 8].contiguous(), b1, w2[:Em - 8].contiguous(), b2[:Em - 8].contiguous(),
                                   l1w[:Em - 8].contiguous(), l1b[:Em - 8].contiguous(), 1e-6)

@@ -163,6 +163,27 @@ def _oracle_out(m, cfg, cam, feats, depth, lss, gcb, bev, num_levels):
                                   inverse=O.inv3x3_closed_form)
 
 
+def test_last_layer_writes_the_refined_bev_as_planes_itself(dev, monkeypatch):
+    """Inference: the last encoder layer's tail + FFN kernel stores the refined BEV as (B, C, Y, X) (fbbev_rows_tail_ffn_x3_planes) instead
+    of rows + the transposing pass of backward_projection.py:129 -- the SAME BITS as that route (FBBEV_BP_OUT_PLANES=0), and the
+    route is actually taken (no transposing launch left behind the encoder)."""
+    from fb_bev_amd import backward_projection as BP, _capi
+    m, cfg, cam, feats, depth, lss, gcb = _setup(dev, num_levels=4, bev=20)
+    args = dict(lss_bev=lss.to(dev), cam_params=[t.to(dev) for t in cam], pred_img_depth=depth.to(dev))
+    calls = []
+    real = _capi.transpose_last2
+    monkeypatch.setattr(_capi, 'transpose_last2', lambda x: (calls.append(1), real(x))[1])
+    with torch.no_grad():
+        monkeypatch.setattr(BP, 'OUT_PLANES', False)
+        rows_route = m([f.to(dev) for f in feats], None, **args)
+        n_rows = len(calls)
+        monkeypatch.setattr(BP, 'OUT_PLANES', True)
+        planes_route = m([f.to(dev) for f in feats], None, **args)
+    assert n_rows == 1 and len(calls) == 1                       # the planes route made no transposing call
+    assert planes_route.shape == rows_route.shape and planes_route.is_contiguous()
+    assert torch.equal(planes_route, rows_route)
+
+
 @pytest.mark.parametrize('num_levels', [1, 4])
 def test_backward_projection_module_vs_oracle(dev, num_levels):
     bev = 20
