@@ -50,6 +50,7 @@ SIGNATURES = {
     'fbbev_pool_zmean_split': (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_void_p, c_size_t,
                                        c_void_p]),
     'fbbev_pool_zmean': (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
+    'fbbev_pool_zmean_rows': (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
     'fbbev_pool_dense_bwd_workspace_bytes': (c_size_t, [c_int] * 9),
     'fbbev_bev_pool_v2_dense_bwd': (c_int, [c_void_p, c_int64, c_int64] + [c_void_p] * 6 + [c_int] * 10 +
                                     [c_void_p] * 3 + [c_size_t, c_void_p]),
@@ -435,6 +436,25 @@ def pool_zmean(depth, feat, ranks_depth, ranks_feat, interval_rank, interval_sta
             tile_ws.numel() * tile_ws.element_size(), int(tile_voxels), int(flags) & ~(POOL_OUT_BF16 | POOL_OUT_F16 | POOL_SPLIT_LONG | POOL_PIPE),
             _stream()), 'fbbev_pool_zmean')
     return out_mean
+
+
+def pool_zmean_rows(depth, feat, ranks_depth, ranks_feat, interval_rank, interval_starts, interval_lengths, B, C, Z, Y, X,
+                    out_rows, tile_ws, tile_voxels=64, flags=DEFAULT_POOL_FLAGS, row_bias=None):
+    """out_rows (B, Y*X, C) f32 contiguous = mean over z of the pooled sums + row_bias (Y*X, C): the Z-mean written as the backward
+    projection's query rows (fbbev_pool_zmean_rows; single pass)."""
+    if tuple(out_rows.shape) != (B, Y * X, C) or not out_rows.is_contiguous():
+        raise FbbevError('out_rows must be (B, Y*X, C) contiguous')
+    if row_bias is not None and (tuple(row_bias.shape) != (Y * X, C) or not row_bias.is_contiguous()):
+        raise FbbevError('row_bias must be (Y*X, C) contiguous')
+    with _on(depth):
+        _check(lib().fbbev_pool_zmean_rows(
+            _dev(depth, F32, 'depth'), _dev(feat, F32, 'feat'), _dev(ranks_depth, I32, 'ranks_depth'),
+            _dev(ranks_feat, I32, 'ranks_feat'), _dev(interval_rank, I32, 'interval_rank'),
+            _dev(interval_starts, I32, 'interval_starts'), _dev(interval_lengths, I32, 'interval_lengths'),
+            B, C, Z, Y, X, _dev(row_bias, F32, 'row_bias') if row_bias is not None else None, _dev(out_rows, F32, 'out_rows'),
+            c_void_p(tile_ws.data_ptr()), tile_ws.numel() * tile_ws.element_size(), int(tile_voxels),
+            int(flags) & ~(POOL_OUT_BF16 | POOL_OUT_F16 | POOL_SPLIT_LONG | POOL_PIPE), _stream()), 'fbbev_pool_zmean_rows')
+    return out_rows
 
 
 def bev_pool_v2_dense_fwd(depth, feat, ranks_depth, ranks_feat, interval_rank, interval_starts,

@@ -1282,19 +1282,34 @@ class BackwardProjection(nn.Module):
             t.record_stream(main)                                # allocated on the side stream, consumed on the caller's
         return pre
 
+    def query_row_bias(self, channels, grid_zyx):
+        """bev_embedding as the (Y*X, C) row bias of fbbev_pool_zmean_rows, or None when the queries cannot be handed over as rows
+        (grad mode, another grid / width than the module's)."""
+        w = self.bev_embedding.weight
+        if (torch.is_grad_enabled() and w.requires_grad) or not w.is_cuda or w.dtype != torch.float32:
+            return None
+        if tuple(w.shape) != (self.bev_h * self.bev_w, channels) or (grid_zyx[1], grid_zyx[2]) != (self.bev_h, self.bev_w):
+            return None
+        return w.detach().contiguous()
+
     def forward(self, mlvl_feats, img_metas, lss_bev=None, gt_bboxes_3d=None, cam_params=None, pred_img_depth=None,
-                bev_mask=None, _pre=None):
+                bev_mask=None, _pre=None, lss_rows=None):
+        """lss_rows (inference): the queries as rows (bs, Y*X, C) ALREADY carrying bev_embedding (fbbev_pool_zmean_rows) instead of
+        lss_bev (bs, C, Y, X)."""
         global _PRE
         if _pre is not None:
             torch.cuda.current_stream(mlvl_feats[0].device).wait_event(_pre.event)
             _PRE = _pre
             try:
                 return self.forward(mlvl_feats, img_metas, lss_bev=lss_bev, gt_bboxes_3d=gt_bboxes_3d, cam_params=cam_params,
-                                    pred_img_depth=pred_img_depth, bev_mask=bev_mask)
+                                    pred_img_depth=pred_img_depth, bev_mask=bev_mask, lss_rows=lss_rows)
             finally:
                 _PRE = None
         bs = mlvl_feats[0].shape[0]
         dtype = mlvl_feats[0].dtype
+        if lss_rows is not None:
+            assert lss_bev is None and lss_rows.is_cuda and lss_rows.dtype == torch.float32 and not torch.is_grad_enabled()
+            lss_bev = lss_rows                                  # (takes the `fast` route below; used only for its device / dtype / grad state)
         # (Q,bs,C) as backward_projection.py:96-99 -- built batch-major so that the encoder's permute(1,0,2) yields
         # contiguous (bs,Q,C) tokens (the Linear layers then take them without a copy); same sums element for element
         fast = (lss_bev is not None and lss_bev.is_cuda and lss_bev.dtype == torch.float32 and
@@ -1305,6 +1320,8 @@ class BackwardProjection(nn.Module):
         if lss_bev is not None:
             if train_fast:                                     # the same transposing pass, differentiable (train_path.BevQueries)
                 bev_queries = TP.BevQueries.apply(lss_bev, self.bev_embedding.weight).permute(1, 0, 2)
+            elif lss_rows is not None:                                                  # rows + bev_embedding straight from the Z-mean
+                bev_queries = lss_rows.permute(1, 0, 2)
             elif fast:                                                                  # LDS-tiled transposition kernel
                 # + bev_embedding in the same pass: the same single fp32 add per element as below
                 tok = _capi.tokens_from_nchw(lss_bev.reshape(bs, lss_bev.shape[1], -1).contiguous(),

@@ -990,7 +990,8 @@ static int pool_zmean_impl(const float* depth, const float* feat, const int32_t*
                            const int32_t* ranks_feat, const int32_t* interval_rank,
                            const int32_t* interval_starts, const int32_t* interval_lengths, int B, int C, int Z,
                            int Y, int X, float* out_mean, const void* tile_ws, size_t tile_ws_bytes,
-                           int tile_voxels, int flags, int z_groups, float* partial, size_t partial_bytes, fbbev_stream_t stream_);
+                           int tile_voxels, int flags, int z_groups, float* partial, size_t partial_bytes, fbbev_stream_t stream_,
+                           int rows_out = 0, const float* row_bias = nullptr);
 
 extern "C" int fbbev_pool_zmean(const float* depth, const float* feat, const int32_t* ranks_depth,
                                 const int32_t* ranks_feat, const int32_t* interval_rank,
@@ -1021,8 +1022,10 @@ static int pool_zmean_impl(const float* depth, const float* feat, const int32_t*
                            const int32_t* ranks_feat, const int32_t* interval_rank,
                            const int32_t* interval_starts, const int32_t* interval_lengths, int B, int C, int Z,
                            int Y, int X, float* out_mean, const void* tile_ws, size_t tile_ws_bytes,
-                           int tile_voxels, int flags, int z_groups, float* partial, size_t partial_bytes, fbbev_stream_t stream_) {
+                           int tile_voxels, int flags, int z_groups, float* partial, size_t partial_bytes, fbbev_stream_t stream_,
+                           int rows_out, const float* row_bias) {
     if (B <= 0 || C <= 0 || Z <= 0 || Y <= 0 || X <= 0) return FBBEV_E_BADARG;
+    if (rows_out && (z_groups != 1 || (row_bias && !aligned16(row_bias)))) return FBBEV_E_UNSUPPORTED;
     if (!depth || !feat || !ranks_depth || !ranks_feat || !interval_rank || !interval_starts || !interval_lengths ||
         !out_mean || !tile_ws) return FBBEV_E_BADARG;
     const long long yx = (long long)Y * X;
@@ -1058,7 +1061,7 @@ static int pool_zmean_impl(const float* depth, const float* feat, const int32_t*
     static const bool col_on = [] { const char* e = getenv("FBBEV_ZMEAN_COL"); return e && atoi(e) != 0; }();   // read once
 #endif
     const size_t lds_col = fbbev_zmean_col_lds_bytes(CC, TV, Z);
-    if (col_on && z_groups == 1 && Z <= 64 && lds_col <= 64 * 1024) {
+    if (col_on && !rows_out && z_groups == 1 && Z <= 64 && lds_col <= 64 * 1024) {
 #define FBBEV_ZMEAN_COL(TV_, CPL_)                                                                                   \
     FBBEV_LAUNCH((k_pool_zmean_col<TV_, CPL_, 256>), blocks, 256, lds_col, (fbbev_rt_stream)stream_, C, Z, (int)yx,   \
                  tiles_per_plane, csplit, (int)blocks, depth, feat, ranks_depth, ranks_feat, interval_rank,          \
@@ -1073,7 +1076,7 @@ static int pool_zmean_impl(const float* depth, const float* feat, const int32_t*
 #define FBBEV_ZMEAN(TV_, CPL_)                                                                                       \
     FBBEV_LAUNCH((k_pool_zmean<TV_, CPL_, 256>), blocks * z_groups, 256, lds, (fbbev_rt_stream)stream_, C, Z, (int)yx, \
                  tiles_per_plane, csplit, (int)blocks, depth, feat, ranks_depth, ranks_feat, interval_rank,          \
-                 interval_starts, interval_lengths, meta, out_mean, z_groups, partial)
+                 interval_starts, interval_lengths, meta, out_mean, z_groups, partial, rows_out, row_bias)
     if (TV == 64) { if (cpl8) FBBEV_ZMEAN(64, 8); else FBBEV_ZMEAN(64, 4); }
     else if (TV == 128) { if (cpl8) FBBEV_ZMEAN(128, 8); else FBBEV_ZMEAN(128, 4); }
     else { if (cpl8) FBBEV_ZMEAN(256, 8); else FBBEV_ZMEAN(256, 4); }
@@ -1085,6 +1088,18 @@ static int pool_zmean_impl(const float* depth, const float* feat, const int32_t*
         FBBEV_CHECK_LAUNCH();
     }
     return 0;
+}
+
+// fbbev_pool_zmean with the result written as the backward projection's QUERY ROWS: out_rows (B, Y*X, C) = mean + row_bias (Y*X, C)
+// (bev_embedding; may be null) -- backward_projection.py:96-99's flatten + permute + `+ bev_embedding` done by the Z-mean's store
+// instead of a transposing pass over (B, C, Y, X).  Single pass only (no Z groups).
+extern "C" int fbbev_pool_zmean_rows(const float* depth, const float* feat, const int32_t* ranks_depth, const int32_t* ranks_feat,
+                                     const int32_t* interval_rank, const int32_t* interval_starts,
+                                     const int32_t* interval_lengths, int B, int C, int Z, int Y, int X, const float* row_bias,
+                                     float* out_rows, const void* tile_ws, size_t tile_ws_bytes, int tile_voxels, int flags,
+                                     fbbev_stream_t stream_) {
+    return pool_zmean_impl(depth, feat, ranks_depth, ranks_feat, interval_rank, interval_starts, interval_lengths, B, C, Z, Y, X,
+                           out_rows, tile_ws, tile_ws_bytes, tile_voxels, flags, 1, nullptr, 0, stream_, 1, row_bias);
 }
 
 // ------------------------------------------------------------------------------ MSDeformAttn

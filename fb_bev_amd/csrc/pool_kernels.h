@@ -837,7 +837,7 @@ k_pool_zmean(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_blocks
              const int* __restrict__ rd, const int* __restrict__ rf,
              const int* __restrict__ interval_rank, const int* __restrict__ starts,
              const int* __restrict__ lengths, const int* __restrict__ tile_meta, float* __restrict__ out, int z_groups,
-             float* __restrict__ partial) {
+             float* __restrict__ partial, int rows_out, const float* __restrict__ row_bias) {
     // z_groups > 1 (round 4): the Z planes of a tile are walked ONE AFTER THE OTHER (two barriers and two dependent memory round
     // trips per plane), so with few tiles -- the shipped grid at B = 1 has 157 -- the launch is one 8-plane latency chain per CU and
     // was the largest kernel of the shipped-shape forward+backward projection (106 us).  Then workgroup (tile, zg) takes the planes
@@ -927,6 +927,27 @@ k_pool_zmean(int C, int Z, int YX, int tiles_per_plane, int csplit, int n_blocks
         for (int q = 0; q < 4; ++q) { m0[q] = m1[q]; m1[q] = m2[q]; }
     }
     __syncthreads();
+    if (rows_out) {
+        // round 6 (z_groups == 1): out is (B, Y*X, C) ROWS -- the backward projection's query layout -- plus row_bias (Y*X, C) when given
+        // (its bev_embedding: the same single fp32 add as the transposing pass that used to follow, fbbev_tokens_from_nchw): mean / Z + bias
+        const float zr = (float)Z;
+        const int cq_n = CC / 4;
+        float* __restrict__ orow = out + ((long long)b * YX + v0) * C + c0;
+        const float* __restrict__ brow = row_bias ? row_bias + (long long)v0 * C + c0 : nullptr;
+        for (int idx = tid; idx < nv * cq_n; idx += NT) {
+            const int v = idx / cq_n, cq = idx - v * cq_n;
+            fbbev_v4f val;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) val[e] = tile[(4 * cq + e) * LD + v] / zr;
+            if (brow) {
+                const fbbev_v4f bb = *reinterpret_cast<const fbbev_v4f*>(brow + (long long)v * C + 4 * cq);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) val[e] = fbbev_add(val[e], bb[e]);
+            }
+            fbbev_st(reinterpret_cast<fbbev_v4f*>(orow + (long long)v * C + 4 * cq), val);
+        }
+        return;
+    }
     const float zf = z_groups > 1 ? 1.f : (float)Z;
     float* __restrict__ ob = (z_groups > 1 ? partial + (long long)zg * gridDim_stride(n_blocks, csplit, tiles_per_plane) * C * YX : out) +
                              ((long long)b * C + c0) * YX + v0;

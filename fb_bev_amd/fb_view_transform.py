@@ -12,6 +12,7 @@ from .view_transformer import LSSViewTransformerFunction3D
 
 
 import os as _os
+ZMEAN_ROWS = _os.environ.get('FBBEV_ZMEAN_ROWS', '1') != '0'     # A/B knob (round 6): inference, the Z-mean written as query rows + bev_embedding
 _ONE_OP = _os.environ.get('FBBEV_LSS_ZMEAN', '1') != '0'      # A/B knob: volume + Z-mean as one differentiable op (training)
 
 
@@ -72,10 +73,20 @@ class FBViewTransform(nn.Module):
             # latency-bound kernels leave most of the chip idle
             pre = self.backward_projection.prefetch(feats, cam_params) if hasattr(self.backward_projection, 'prefetch') else None
             parts = fp.pooling_inputs(cam_params, context, depth)
-            lss_mean = fp.pooled_zmean(parts)
             kw = {} if pre is None else {'_pre': pre}
-            refined = self.backward_projection(feats, img_metas, lss_bev=lss_mean, cam_params=cam_params, bev_mask=bev_mask,
-                                               gt_bboxes_3d=None, pred_img_depth=depth, **kw)
+            bp = self.backward_projection
+            rows = None
+            if ZMEAN_ROWS and hasattr(bp, 'query_row_bias') and context.dtype == torch.float32:
+                # round 6: the Z-mean leaves its kernel as the backward projection's query rows (+ bev_embedding): no transposing pass
+                bias = bp.query_row_bias(context.shape[2], fp.grid_zyx)
+                rows = fp.pooled_zmean_rows(parts, bias) if bias is not None else None
+            if rows is not None:
+                refined = bp(feats, img_metas, lss_rows=rows, cam_params=cam_params, bev_mask=bev_mask, gt_bboxes_3d=None,
+                             pred_img_depth=depth, **kw)
+            else:
+                lss_mean = fp.pooled_zmean(parts)
+                refined = bp(feats, img_metas, lss_bev=lss_mean, cam_params=cam_params, bev_mask=bev_mask,
+                             gt_bboxes_3d=None, pred_img_depth=depth, **kw)
             return fp.pooled_volume(parts, addend=refined)
         if (self.write_once and self.backward_projection is not None and self.readd and needs_grad and TP.TRAIN_FUSED and
                 TP.write_once_supported(fp, context) and depth.dtype == torch.float32):

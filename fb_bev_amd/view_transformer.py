@@ -481,6 +481,22 @@ class LSSViewTransformerFunction3D(nn.Module):
         return _capi.pool_zmean(depth, feat, idx.ranks_depth, idx.ranks_feat, idx.interval_rank, idx.interval_starts,
                                 idx.interval_lengths, B, C, Z, Y, X, out, tile_ws, self._wo_tile, flags, z_groups=zg, partial=partial)
 
+    def pooled_zmean_rows(self, parts, row_bias):
+        """The same mean as the backward projection's query rows (B, Y*X, C) + row_bias (Y*X, C) (fbbev_pool_zmean_rows), or None when the
+        launch would be split into Z groups (few tiles: pooled_zmean + the transposing pass then)."""
+        idx, depth, feat, tile_ws = parts
+        B, C = depth.shape[0], feat.shape[-1]
+        Z, Y, X = self.grid_zyx
+        self._C_hint = C
+        if (_ZMEAN_ZGROUPS if _ZMEAN_ZGROUPS else self._zmean_z_groups(B, Z, Y * X)) != 1:
+            return None
+        flags = self.pool_flags
+        if _ZMEAN_CSPLIT:
+            flags = (flags & ~0xF0) | ((_ZMEAN_CSPLIT & 0xF) << 4)
+        out = torch.empty((B, Y * X, C), dtype=torch.float32, device=depth.device)
+        return _capi.pool_zmean_rows(depth, feat, idx.ranks_depth, idx.ranks_feat, idx.interval_rank, idx.interval_starts,
+                                     idx.interval_lengths, B, C, Z, Y, X, out, tile_ws, self._wo_tile, flags, row_bias=row_bias)
+
     def _zmean_z_groups(self, B, Z, YX):
         """fbbev_pool_zmean walks the Z planes of a tile one after the other (two barriers + two dependent round trips per plane): with
         few tiles -- the shipped grid at B = 1 has 157 -- the launch is one Z-plane latency chain per CU (106 us, the largest kernel

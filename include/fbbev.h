@@ -236,6 +236,14 @@ int fbbev_pool_zmean(const float* depth, const float* feat, const int32_t* ranks
                      const int32_t* interval_rank, const int32_t* interval_starts, const int32_t* interval_lengths,
                      int B, int C, int Z, int Y, int X, float* out_mean, const void* tile_ws, size_t tile_ws_bytes,
                      int tile_voxels, int flags, fbbev_stream_t stream);
+/* fbbev_pool_zmean with the result written as the backward projection's QUERY ROWS: out_rows (B, Y*X, C) = mean over z + row_bias
+ * (Y*X, C) (the module's bev_embedding; NULL: none) -- backward_projection.py:96-99's flatten(2).permute + `+ bev_embedding` done by
+ * the Z-mean's store instead of a transposing pass over (B, C, Y, X); the same values (one fp32 add per element).  Single pass
+ * only (the z_groups form keeps the planes layout). */
+int fbbev_pool_zmean_rows(const float* depth, const float* feat, const int32_t* ranks_depth, const int32_t* ranks_feat,
+                          const int32_t* interval_rank, const int32_t* interval_starts, const int32_t* interval_lengths, int B,
+                          int C, int Z, int Y, int X, const float* row_bias, float* out_rows, const void* tile_ws,
+                          size_t tile_ws_bytes, int tile_voxels, int flags, fbbev_stream_t stream);
 /* fbbev_pool_zmean with the Z planes of a tile dealt to z_groups workgroups (each walks ceil(Z / z_groups) planes) + a caller-owned
  * partial buffer of z_groups * B*C*Y*X floats; a second small kernel adds the groups in order and divides by Z.  For grids with
  * few tiles (the shipped 100x100x8 grid at small batch), where the single pass is one Z-plane latency chain per workgroup.

@@ -78,6 +78,15 @@ def pool_zmean(depth, feat, rd, rf, ir, st, ln, counts, n_max, B, C, Z, Y, X, ti
     return code, out
 
 
+def pool_zmean_rows(depth, feat, rd, rf, ir, st, ln, counts, n_max, B, C, Z, Y, X, tile_voxels, flags=0, row_bias=None):
+    out = torch.full((B, Y * X, C), float('nan'))
+    ws = torch.zeros(lib().fbbev_pool_dense_workspace_bytes(B, Z, Y, X), dtype=torch.uint8)
+    ok(lib().fbbev_pool_tile_index(p(ir), p(st), p(counts), n_max, B, Z, Y, X, tile_voxels, flags, p(ws), ws.numel(), None))
+    code = lib().fbbev_pool_zmean_rows(p(depth), p(feat), p(rd), p(rf), p(ir), p(st), p(ln), B, C, Z, Y, X,
+                                       p(row_bias) if row_bias is not None else None, p(out), p(ws), ws.numel(), tile_voxels, flags, None)
+    return code, out
+
+
 def pool_dense(depth, feat, rd, rf, ir, st, ln, counts, n_max, B, C, Z, Y, X, tile_voxels, flags=0, addend=None):
     cl = bool(flags & 0x100000)
     dt = torch.bfloat16 if flags & 0x800000 else (torch.float16 if flags & 0x1000000 else torch.float32)

@@ -1125,6 +1125,13 @@ def test_pool_zmean_and_add_epilogue_emulated(name, tv, flags):
         assert torch.allclose(m2, vol.double().sum(2).float() / Z, atol=1e-6, rtol=1e-5), zg
         if zg == Z:
             assert torch.equal(m2, mean)                             # one plane per group: the single pass's bits
+    # round 6: fbbev_pool_zmean_rows -- the mean written as the backward projection's query rows (B, Y*X, C) + a (Y*X, C) row bias
+    # (bev_embedding): the bits of the planes form transposed, + one fp32 add
+    emb = torch.randn(Y * X, C, generator=torch.Generator().manual_seed(5))
+    code, rows = E.pool_zmean_rows(depth, feat, rd, rf, ir, st, ln, counts, st.numel(), B, C, Z, Y, X, tv, flags)
+    assert code == 0 and torch.equal(rows, mean.flatten(2).transpose(1, 2))
+    code, rows = E.pool_zmean_rows(depth, feat, rd, rf, ir, st, ln, counts, st.numel(), B, C, Z, Y, X, tv, flags, row_bias=emb)
+    assert code == 0 and torch.equal(rows, mean.flatten(2).transpose(1, 2) + emb[None])
     addend = torch.randn(B, C, Y, X, generator=torch.Generator().manual_seed(3))
     code, out = E.pool_dense(depth, feat, rd, rf, ir, st, ln, counts, st.numel(), B, C, Z, Y, X, tv, flags, addend=addend)
     assert code == 0

@@ -678,6 +678,23 @@ def test_write_once_volume_path_equals_reference_composition(dev, name, B):
         assert torch.equal(fp.pooled_volume(parts, addend=addend), vol + addend[..., None])
     assert a.shape == b.shape == (B, pc.channels, Y, X, Z)
     assert (a - b).abs().max().item() < 1e-4
+    # round 6: the Z-mean handed over as query rows + bev_embedding (fbbev_pool_zmean_rows: no transposing pass in front of the encoder)
+    # and the refined BEV written as planes by the last layer's kernel (no transposing pass behind it): the SAME BITS as with both
+    # passes -- where the single-pass Z-mean is what the module runs (many tiles); with Z groups the rows form declines (None)
+    from fb_bev_amd import fb_view_transform as FV, backward_projection as BPm
+    with torch.no_grad():
+        m.write_once = True
+        rows = fp.pooled_zmean_rows(parts, m.backward_projection.query_row_bias(pc.channels, fp.grid_zyx))
+        if rows is not None:
+            emb = m.backward_projection.bev_embedding.weight
+            assert torch.equal(rows, fp.pooled_zmean(parts).flatten(2).transpose(1, 2) + emb[None])
+        old = (FV.ZMEAN_ROWS, BPm.OUT_PLANES)
+        try:
+            FV.ZMEAN_ROWS, BPm.OUT_PLANES = False, False
+            c = m(cam, ctx, depth)
+        finally:
+            FV.ZMEAN_ROWS, BPm.OUT_PLANES = old
+    assert torch.equal(a, c)
 
 
 @pytest.mark.gpu
