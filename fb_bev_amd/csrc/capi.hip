@@ -2,6 +2,7 @@
 // launch geometry, workspace carving.  No torch, no host synchronisation, caller's stream.
 #include <stdio.h>
 #include <stdlib.h>
+#include <mutex>
 #include "rt.h"
 #include "pool_kernels.h"
 #include "pool_bwd_kernels.h"
@@ -2908,11 +2909,13 @@ static fbbev_side_stream* history_side_stream() {
     static bool made[16];
     const int d = fbbev_rt_device();
     if (d < 0 || d >= 16) return nullptr;
+    static std::mutex mu;                                    // (first use from two host threads; the stream and its events are per DEVICE:
+    std::lock_guard<std::mutex> lock(mu);                    //  callers serialise their calls per device, as with any stream-ordered workspace)
     if (!made[d]) {
         made[d] = true;
-        // the convolutions' stream outranks the caller's: their 256-thread workgroups (one per CU: LDS) are placed first and the warp's
-        // waves fill the registers that are left -- at equal priority the warp's small workgroups refill every CU before a
-        // convolution workgroup fits (profiles/r06_exp_history_pipeline.md).  FBBEV_HISTORY_STEP_PRIORITY=0: equal priorities
+        // the convolutions' stream is created at the device's highest priority: built to let their workgroups in ahead of the thousands
+        // of queued warp workgroups -- measured: no effect on the dispatch (profiles/r06_exp_history_step.md).
+        // FBBEV_HISTORY_STEP_PRIORITY=0: equal priorities
         const char* pe = getenv("FBBEV_HISTORY_STEP_PRIORITY");
         table[d].ok = fbbev_rt_stream_create(&table[d].stream, pe && atoi(pe) == 0 ? 0 : 1) == 0;
         for (int i = 0; i < 2 + 64 && table[d].ok; ++i) table[d].ok = fbbev_rt_event_create(&table[d].ev[i]) == 0;

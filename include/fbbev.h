@@ -849,7 +849,8 @@ int fbbev_history_conv_bf16x3(const void* feats, long long feats_stride_b, const
  * default, 10; 1: the two kernels back to back): the warp of a band runs on `stream`, the convolutions of the band before it
  * on a second stream of the device that the library keeps, joined back into `stream` before the call returns control of it.
  * The gather kernel is bound by memory, the convolutions by the MFMA: side by side each uses what the other leaves idle.  Same
- * kernels, operands and result bits as the two calls.  Shapes, element types and workspace: as fbbev_history_conv_bf16x3. */
+ * kernels, operands and result bits as the two calls.  Shapes, element types and workspace: as fbbev_history_conv_bf16x3.  The second
+ * stream and its events are per DEVICE: one call at a time per device.  Measured NOT faster than the two calls. */
 int fbbev_history_step_x3_vm(const void* history, long long history_stride_b, void* next, long long next_stride_b,
                              const float* rt_flow, const float* w1, const float* bias1, const float* w2, const float* bias2,
                              int B, int T, int C, int Cout, int Z, int Y, int X, float* out, void* workspace,
