@@ -3050,6 +3050,44 @@ static int rows_linear_x3_impl(const float* x, long long x_row_stride, const voi
     { const char* e_rt = getenv("FBBEV_ROWS_LINEAR_RT"); if (e_rt && n_kc == 1 && atoi(e_rt) >= 1 && atoi(e_rt) <= 8) RT = atoi(e_rt); }
 #endif
     const long long groups = (tiles + RT - 1) / RT;
+    // round 6: the persistent form (k_rows_linear_x3p: fragments staged once per workgroup, the next tile's rows in flight under the
+    // MFMAs, fragment reads under the MFMAs of the tile before) for one K chunk, no addend, no LayerNorm tail.  Same bits.
+    // FBBEV_ROWS_LINEAR_P=0: off (A/B knob)
+#ifdef FBBEV_TEST_OVERRIDES
+    const bool persist = [] { const char* e_ = getenv("FBBEV_ROWS_LINEAR_P"); return !(e_ && atoi(e_) == 0); }();
+#else
+    static const bool persist = [] { const char* e_ = getenv("FBBEV_ROWS_LINEAR_P"); return !(e_ && atoi(e_) == 0); }();
+#endif
+    // (the training epilogue at 8 output tiles x 4 k-steps -- 96 < I <= 128 and O > 80: no layer of the model -- would spill: old kernel)
+    if (persist && n_kc == 1 && !ln_w && !addend && !(rows_linear_nt1() && !train_epi) &&
+        !(train_epi && out_features > 80 && in_features > 96)) {
+        const int nmtp = out_features <= 80 ? 5 : 8, ksp = in_features <= 96 ? 3 : 4;
+        long long n_slots = 512 / n_oc;
+#ifdef FBBEV_TEST_OVERRIDES   // CPU emulator build: lets a small case walk several row tiles per workgroup
+        { const char* e_sl = getenv("FBBEV_ROWS_LINEAR_SLOTS"); if (e_sl && atoi(e_sl) >= 1) n_slots = atoi(e_sl); }
+#endif
+        if (n_slots < 1) n_slots = 1;
+        if (n_slots > tiles) n_slots = tiles;
+        const size_t ldsp = (size_t)nmtp * FBBEV_RL_TILE_ELEMS * sizeof(unsigned short) + (size_t)16 * nmtp * sizeof(float);
+#define FBBEV_RLP(NMT_, KS_, EPI_)                                                                                      \
+    do {                                                                                                              \
+        e = fbbev_rt_allow_dyn_lds((const void*)k_rows_linear_x3p<NMT_, KS_, EPI_>, ldsp);                              \
+        if (e) return e;                                                                                              \
+        FBBEV_LAUNCH((k_rows_linear_x3p<NMT_, KS_, EPI_>), n_slots * n_oc, 256, ldsp, (fbbev_rt_stream)stream_, x, x_row_stride, \
+                     static_cast<const unsigned short*>(fragments), bias, out, out_row_stride, rows, in_features, out_features, relu, \
+                     n_oc, (int)n_slots, plane_S, plane_TS, res, ld_res, mask, ld_mask);                              \
+    } while (0)
+        if (train_epi) {
+            if (nmtp == 5) { if (ksp == 3) FBBEV_RLP(5, 3, 1); else FBBEV_RLP(5, 4, 1); }
+            else FBBEV_RLP(8, 3, 1);
+        } else {
+            if (nmtp == 5) { if (ksp == 3) FBBEV_RLP(5, 3, 0); else FBBEV_RLP(5, 4, 0); }
+            else { if (ksp == 3) FBBEV_RLP(8, 3, 0); else FBBEV_RLP(8, 4, 0); }
+        }
+#undef FBBEV_RLP
+        FBBEV_CHECK_LAUNCH();
+        return 0;
+    }
     if (train_epi) {
         e = fbbev_rt_allow_dyn_lds((const void*)k_rows_linear_x3<2, false, 1>, lds);
         if (e) return e;

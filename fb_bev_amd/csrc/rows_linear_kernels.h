@@ -283,6 +283,168 @@ k_rows_linear_x3(const float* __restrict__ x, long long ldx, const unsigned shor
     }
 }
 
+// ---------------------------------------------------------------- the same product, PERSISTENT over row tiles (round 6)
+// k_rows_linear_x3 runs at ~3 TB/s of rows in + out at every shape and every row-tile knob (profiles/r06_exp_rows_linear.md), where a
+// copy with the same lane -> address pattern reaches 6 (tools/micro/row_access_bench.hip): a workgroup's tile is one serial chain --
+// row pieces, fragment staging (two round trips + barrier), 90-144 MFMAs each behind its own LDS read, bias round trip, stores --
+// with a second workgroup per CU as the only overlap.  Here, for one K chunk (I <= 128) and plain / head-plane output:
+//   * a workgroup stays on its output chunk and walks every n_slots-th row tile: fragments and bias are staged ONCE (bias in LDS);
+//   * the NEXT tile's row pieces are requested right after the current ones were split: in flight under the MFMAs and the stores;
+//   * the fragment reads of an output tile are issued under the MFMAs of the tile before it (issue-order hints);
+//   * NMT (output tiles of a chunk) and KS (k-steps) are compile-time: the MFMA phase is straight-line code.
+// Same fragments, same product / accumulation order per element as k_rows_linear_x3: identical bits.
+template <int NMT, int KS, int EPI>
+__global__ void __launch_bounds__(256, 2)
+k_rows_linear_x3p(const float* __restrict__ x, long long ldx, const unsigned short* __restrict__ wf, const float* __restrict__ bias,
+                  float* __restrict__ out, long long ldo, long long rows, int I, int O, int relu, int n_oc, int n_slots,
+                  int plane_S, int plane_TS, const float* __restrict__ res, long long ld_res, const float* __restrict__ mask,
+                  long long ld_mask) {
+    constexpr int NT = 2;
+    unsigned short* wl = reinterpret_cast<unsigned short*>(fbbev_dyn_lds_f32());          // [NMT][FBBEV_RL_TILE_ELEMS]
+    float* bl = reinterpret_cast<float*>(wl + NMT * FBBEV_RL_TILE_ELEMS);                // [16 NMT]: the chunk's bias (zeros: none / beyond O)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = lane >> 4, j = lane & 15;
+    const int oc = (int)(blockIdx.x % n_oc);              // the output chunks of one row tile are neighbours: its rows stay in L2
+    const long long slot = blockIdx.x / n_oc;
+    const int o0 = oc * 128;
+    const long long tiles = (rows + 127) / 128;
+    if (slot >= tiles) return;                                                            // uniform
+    const fbbev_bf16x8 zero8 = fbbev_cvt_bf16x8(fbbev_v4f{0.f, 0.f, 0.f, 0.f}, fbbev_v4f{0.f, 0.f, 0.f, 0.f});
+    fbbev_v4f raw[KS][NT][2];
+    auto request = [&](long long rt) {                                                    // a tile's row pieces, raw (clamped, unconditional)
+        const long long r0 = (rt * 4 + wave) * (16 * NT);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int c = 32 * s + 8 * g;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const long long r = r0 + 16 * t + j;
+                const float* p = x + ((r < rows && c < I) ? r * ldx + c : 0);
+                raw[s][t][0] = *reinterpret_cast<const fbbev_v4f*>(p);
+                raw[s][t][1] = *reinterpret_cast<const fbbev_v4f*>(p + 4);
+            }
+        }
+    };
+    request(slot);
+    {
+        const fbbev_v4u* src = reinterpret_cast<const fbbev_v4u*>(wf + (long long)oc * 8 * FBBEV_RL_TILE_ELEMS);      // n_kc == 1
+        fbbev_stage_v4u<4>(reinterpret_cast<fbbev_v4u*>(wl), src, NMT * (FBBEV_RL_TILE_ELEMS / 8));
+        for (int i = threadIdx.x; i < 16 * NMT; i += 256) bl[i] = (bias && o0 + i < O) ? bias[o0 + i] : 0.f;
+    }
+    __syncthreads();
+    // head-plane output (as k_rows_linear_x3): the stride between two heads S * TS, 2^32 / TS
+    long long head_stride = 0;
+    unsigned int ts_rcp = 0;
+    const int TS = plane_TS & 0xffff, pet = plane_TS >> 16;
+    if (plane_S > 0) {
+        head_stride = (long long)plane_S * TS;
+        ts_rcp = 0xffffffffu / (unsigned int)TS + 1u;
+    }
+    for (long long rt = slot; rt < tiles; rt += n_slots) {
+        const long long r0 = (rt * 4 + wave) * (16 * NT);
+        fbbev_bf16x8 xh[KS][NT], xl[KS][NT];
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const bool ok = r0 + 16 * t + j < rows && 32 * s + 8 * g < I;             // I % 8 == 0: a piece is all in or all out
+                fbbev_split_bf16x8(raw[s][t][0], raw[s][t][1], xh[s][t], xl[s][t]);
+                xh[s][t] = ok ? xh[s][t] : zero8;
+                xl[s][t] = ok ? xl[s][t] : zero8;
+            }
+        fbbev_sched_fence();
+        request(rt + n_slots < tiles ? rt + n_slots : rt);                                // the next tile (the last one again: unused)
+        fbbev_sched_fence();
+        fbbev_v4f acc[NMT][NT];
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[mt][t] = fbbev_v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int mt = 0; mt < NMT; ++mt) {
+                const fbbev_bf16x8 ah = fbbev_ld_bf16x8(wl + mt * FBBEV_RL_TILE_ELEMS + (s * 64 + lane) * 8);
+                const fbbev_bf16x8 al = fbbev_ld_bf16x8(wl + mt * FBBEV_RL_TILE_ELEMS + FBBEV_RL_TILE_ELEMS / 2 + (s * 64 + lane) * 8);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    acc[mt][t] = fbbev_mfma_f32_16x16x32_bf16(al, xh[s][t], acc[mt][t]);
+                    acc[mt][t] = fbbev_mfma_f32_16x16x32_bf16(ah, xl[s][t], acc[mt][t]);
+                    acc[mt][t] = fbbev_mfma_f32_16x16x32_bf16(ah, xh[s][t], acc[mt][t]);
+                }
+            }
+        // issue order: the two fragment reads of output tile (s, mt + 1) under the six MFMAs of tile (s, mt)
+        FBBEV_SCHED_LDS_READ(2);
+#pragma unroll
+        for (int i = 0; i < KS * NMT - 1; ++i) { FBBEV_SCHED_MFMA(3); FBBEV_SCHED_LDS_READ(1); FBBEV_SCHED_MFMA(3); FBBEV_SCHED_LDS_READ(1); }
+        FBBEV_SCHED_MFMA(6);
+        fbbev_sched_fence();
+        // epilogue: accumulator register r of tile (mt, t) = output 16 mt + 4 g + r of row j
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const long long r = r0 + 16 * t + j;
+            const bool live = r < rows;
+            long long row_at = 0;
+            if (plane_S > 0) {
+                const long long bn = r / plane_S, tok = r - bn * plane_S;
+                row_at = (bn * (O / TS) * plane_S + tok) * TS;
+            }
+            if constexpr (EPI == 1) {
+                // training epilogue: the residual / mask pieces of four output tiles are requested together (clamped, unconditional)
+#pragma unroll
+                for (int m0 = 0; m0 < NMT; m0 += 4) {
+                    fbbev_v4f pr[4], pm[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int mt = m0 + q < NMT ? m0 + q : NMT - 1, o = o0 + 16 * mt + 4 * g;
+                        const bool ok = live && o < O;
+                        pr[q] = res ? *reinterpret_cast<const fbbev_v4f*>(res + (ok ? r * ld_res + o : 0)) : fbbev_v4f{0.f, 0.f, 0.f, 0.f};
+                        pm[q] = mask ? *reinterpret_cast<const fbbev_v4f*>(mask + (ok ? r * ld_mask + o : 0)) : fbbev_v4f{1.f, 1.f, 1.f, 1.f};
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (m0 + q >= NMT) continue;
+                        const int mt = m0 + q < NMT ? m0 + q : NMT - 1, o = o0 + 16 * mt + 4 * g;
+                        if (!(live && o < O)) continue;
+                        fbbev_v4f v = acc[mt][t] + *reinterpret_cast<const fbbev_v4f*>(bl + 16 * mt + 4 * g);
+                        if (relu) v = fbbev_v4f{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = (pm[q][e] > 0.f ? v[e] : 0.f) + pr[q][e];
+                        fbbev_st(reinterpret_cast<fbbev_v4f*>(out + r * ldo + o), v);
+                    }
+                }
+                continue;
+            }
+            if (!live) continue;
+#pragma unroll
+            for (int mt = 0; mt < NMT; ++mt) {
+                const int o = o0 + 16 * mt + 4 * g;
+                if (o >= O) continue;                                                     // O % 4 == 0: a group is all in or all out
+                fbbev_v4f v = acc[mt][t];
+                if (bias) v = v + *reinterpret_cast<const fbbev_v4f*>(bl + 16 * mt + 4 * g);   // (uniform; no `+ 0`: -0 stays -0 as in k_rows_linear_x3)
+                if (relu) v = fbbev_v4f{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+                if (plane_S > 0) {
+#pragma unroll
+                    for (int e = 0; e < 4; e += 2) {
+                        const unsigned int hd = fbbev_umulhi((unsigned int)(o + e), ts_rcp), ch = (unsigned int)(o + e) - hd * (unsigned int)TS;
+                        const long long at = row_at + (long long)hd * head_stride + ch;
+                        if (pet) {
+                            const unsigned int pk = pet == 1 ? fbbev_cvt_pk16<1>(v[e], v[e + 1]) : fbbev_cvt_pk16<2>(v[e], v[e + 1]);
+                            fbbev_st(reinterpret_cast<unsigned int*>(reinterpret_cast<unsigned short*>(out) + at), pk);
+                        } else {
+                            fbbev_v2f pr;
+                            pr[0] = v[e]; pr[1] = v[e + 1];
+                            fbbev_st(reinterpret_cast<fbbev_v2f*>(out + at), pr);
+                        }
+                    }
+                    continue;
+                }
+                fbbev_st(reinterpret_cast<fbbev_v4f*>(out + r * ldo + o), v);
+            }
+        }
+    }
+}
+
 // W (O, I) fp32 row-major -> split bf16 A fragments, order [out chunk][K chunk][out tile][hi | lo][k-step][lane][8]; element e of a
 // lane = W[128 oc + 16 mt + lane % 16][128 kc + 32 s + 8 (lane / 16) + e], zero outside the matrix.
 __global__ void __launch_bounds__(256)

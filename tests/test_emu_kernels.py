@@ -739,6 +739,42 @@ def test_rows_linear_several_row_tiles_per_workgroup_emulated(monkeypatch):
     assert torch.equal(one, three)
 
 
+@pytest.mark.parametrize('R,I,O,relu,slots', [(5 * 128 - 37, 80, 160, True, 2), (300, 80, 80, False, 1), (130, 64, 64, True, 3),
+                                              (257, 128, 96, False, 2), (129, 80, 512, True, 1), (700, 96, 80, False, 2)])
+def test_rows_linear_persistent_form_equals_the_tile_per_workgroup_form_emulated(R, I, O, relu, slots, monkeypatch):
+    """k_rows_linear_x3p (round 6: a workgroup stays on its output chunk and walks every n_slots-th row tile -- fragments and bias staged
+    once, the next tile's rows requested under the MFMAs, compile-time tile counts) against k_rows_linear_x3 (FBBEV_ROWS_LINEAR_P=0):
+    the SAME BITS, plain rows and head planes (fp32 / 16-bit), with and without bias, the training epilogue (residual / mask), partial
+    last tiles, 1-3 tiles per workgroup, one to four output chunks, K of 2-4 steps."""
+    g = torch.Generator().manual_seed(R + I + O)
+    x = torch.randn(R, I, generator=g) * 2
+    w = torch.randn(O, I, generator=g) * 0.2
+    b = torch.randn(O, generator=g) if O != 64 else None
+    res, msk = torch.randn(R, O, generator=g), torch.randn(R, O, generator=g)
+
+    def run():
+        outs = {}
+        code, outs['rows'] = E.rows_linear_x3(x, w, b, relu=relu)
+        assert code == 0
+        code, outs['train'] = E.rows_linear_x3_train(x, w, b, relu=relu, residual=res, mask=msk)
+        assert code == 0
+        if O % 8 == 0 and R % 5 == 0 and O <= 128:
+            for dt in (None, torch.bfloat16):
+                code, outs[f'planes{dt}'] = E.rows_linear_x3_planes(x, w, b, R // 5, 8, O // 8, dtype=dt)
+                assert code == 0
+        return outs
+
+    monkeypatch.setenv('FBBEV_ROWS_LINEAR_P', '0')
+    old = run()
+    monkeypatch.setenv('FBBEV_ROWS_LINEAR_P', '1')
+    monkeypatch.setenv('FBBEV_ROWS_LINEAR_SLOTS', str(slots))
+    new = run()
+    for k in old:
+        a, c = old[k], new[k]
+        assert not torch.isnan(c.float()).any(), k
+        assert torch.equal(a.view(torch.int16) if a.dtype != torch.float32 else a, c.view(torch.int16) if c.dtype != torch.float32 else c), k
+
+
 def test_rows_linear_with_periodic_addend_emulated():
     """fbbev_rows_linear_x3_add: rows = x[r] + addend[r % P] (the query + query_pos of the attention modules folded into the
     projection), bit-identical to the plain entry on the pre-added rows; 3 samples of 150 queries, a partial last row tile."""
