@@ -632,7 +632,15 @@ k_da_cross_attn_fused(const float* __restrict__ planes /* ET != 0: 16-bit elemen
                         if (i < lvl_n) *reinterpret_cast<fbbev_v4f*>(off_w + i) = pre[k];
                     }
                 } else if ((lvl_n & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {      // uniform
-                    for (int i = lane * 4; i < lvl_n; i += 256) *reinterpret_cast<fbbev_v4f*>(off_w + i) = *reinterpret_cast<const fbbev_v4f*>(src + i);
+                    // round 6: the plane's 16-byte pieces are REQUESTED PRE_N at a time before the first is stored (one load, wait, LDS
+                    // store per iteration before: up to 7 dependent round trips per camera and staged level)
+                    for (int i0 = lane * 4; i0 < lvl_n; i0 += 256 * PRE_N) {
+                        fbbev_v4f t[PRE_N];
+#pragma unroll
+                        for (int k = 0; k < PRE_N; ++k) { const int i = i0 + 256 * k; t[k] = *reinterpret_cast<const fbbev_v4f*>(src + (i < lvl_n ? i : i0)); }
+#pragma unroll
+                        for (int k = 0; k < PRE_N; ++k) { const int i = i0 + 256 * k; if (i < lvl_n) *reinterpret_cast<fbbev_v4f*>(off_w + i) = t[k]; }
+                    }
                 } else {                                                                     // DH is even: whole 4-byte words
                     for (int i = lane; i < lvl_n; i += 64) off_w[i] = src[i];
                 }
